@@ -1,0 +1,76 @@
+"""Seeded synthetic count matrices for parity tests and `bench.py`.
+
+Poisson-lognormal counts with `C` planted clusters, tuned to a target sparsity, with the
+`preprocess` invariants of the reference enforced (scLENS.jl:160-162: every cell expresses
+>= 200 genes (scaled down for tiny matrices), every gene is seen in >= 15 cells), so that
+`TGC > 0` (scLENS.jl:678) and every per-gene std is > 0 (scLENS.jl:683).
+"""
+from __future__ import annotations
+
+import numpy as np
+import scipy.sparse as sp
+
+
+def _rates(M, C, rng, marker_frac=0.05, marker_sd=1.0):
+    beta0 = np.clip(rng.normal(-1.5, 1.5, size=M), -6.0, 3.0)
+    delta = np.zeros((C, M))
+    for c in range(C):
+        mk = rng.random(M) < marker_frac
+        delta[c, mk] = rng.normal(0.0, marker_sd, size=int(mk.sum()))
+    return beta0, delta
+
+
+def _sparsity_for_offset(beta0, off, lib_sigma=0.3):
+    # E[P(x = 0)] ignoring the marker shifts and library-size spread (good enough for tuning)
+    return float(np.mean(np.exp(-np.exp(beta0 + off))))
+
+
+def synth_counts(N: int, M: int, seed: int, C: int = 8, sparsity: float = 0.90,
+                 min_genes_per_cell: int | None = None, min_cells_per_gene: int | None = None,
+                 chunk_rows: int = 4096, marker_frac: float = 0.05, marker_sd: float = 1.0) -> sp.csc_matrix:
+    """Return an N x M CSC float32 matrix of integer counts (cells x genes)."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    beta0, delta = _rates(M, C, rng, marker_frac, marker_sd)
+    lo, hi = -8.0, 8.0
+    for _ in range(60):  # bisection on a global log-rate offset
+        mid = 0.5 * (lo + hi)
+        if _sparsity_for_offset(beta0, mid) > sparsity:
+            lo = mid
+        else:
+            hi = mid
+    beta0 = beta0 + 0.5 * (lo + hi)
+    labels = np.arange(N) % C
+    rng.shuffle(labels)
+    lib = rng.lognormal(0.0, 0.3, size=N)
+    rows, cols, vals = [], [], []
+    for r0 in range(0, N, chunk_rows):
+        r1 = min(N, r0 + chunk_rows)
+        lam = lib[r0:r1, None] * np.exp(beta0[None, :] + delta[labels[r0:r1]])
+        x = rng.poisson(lam).astype(np.float32)
+        i, j = np.nonzero(x)
+        rows.append((i + r0).astype(np.int64))
+        cols.append(j.astype(np.int64))
+        vals.append(x[i, j])
+    X = sp.csc_matrix((np.concatenate(vals), (np.concatenate(rows), np.concatenate(cols))),
+                      shape=(N, M), dtype=np.float32)
+    # enforce the QC invariants by planting single counts where needed (deterministic given seed)
+    mg = min(200, max(2, M // 20)) if min_genes_per_cell is None else min_genes_per_cell
+    mc = min(15, max(2, N // 20)) if min_cells_per_gene is None else min_cells_per_gene
+    X = X.tolil()
+    csr_nnz = np.diff(X.tocsr().indptr)
+    for i in np.flatnonzero(csr_nnz < mg):
+        need = mg - csr_nnz[i]
+        zero_cols = np.setdiff1d(np.arange(M), np.asarray(X.rows[i]))
+        X[i, rng.choice(zero_cols, size=need, replace=False)] = 1.0
+    X = X.tocsc()
+    col_nnz = np.diff(X.indptr)
+    if np.any(col_nnz < mc):
+        X = X.tolil()
+        Xc = X.tocsc()
+        for j in np.flatnonzero(col_nnz < mc):
+            present = Xc.indices[Xc.indptr[j]:Xc.indptr[j + 1]]
+            zero_rows = np.setdiff1d(np.arange(N), present)
+            X[rng.choice(zero_rows, size=mc - len(present), replace=False), j] = 1.0
+        X = X.tocsc()
+    X.sort_indices()
+    return X.astype(np.float32)
