@@ -1,0 +1,141 @@
+/* sclens_hip.h -- C ABI of libsclens_hip.so: the MI355X (gfx950) replacement for the device side of
+ * scLENS.sclens() (reference: Mathbiomed/scLENS v2.0.1, src/scLENS.jl).
+ *
+ * The reference dispatches on a string kwarg `device` inside five functions and three inline sites
+ * (scLENS.jl:332, :363, :375, :489, :526, :505, :558-561, :813-816); every GPU call there uploads a
+ * host matrix, runs one cuBLAS/cuSOLVER routine and downloads the result. This library offers
+ *   (A) the same five operations with the same host-array semantics (drop-in per call site), and
+ *   (B) a session that keeps the count matrix, the scaled matrices, the Gram matrix and the
+ *       eigenvectors resident in HBM for the whole sclens() call (what a `device_="hip"` branch of
+ *       sclens() would call; see INTEGRATION.md for the Julia ccall shim).
+ *
+ * Conventions: plain pointers and sizes, no C++/torch types. Host matrices are COLUMN-MAJOR (Julia
+ * layout) unless stated. Sparse input is CSC with 0-BASED int64 column pointers and int32 row indices
+ * (Julia's SparseMatrixCSC{Float32,UInt32} minus one, scLENS.jl:103-117). All functions return 0 on
+ * success or an SCLENS_ERR_* code and never throw; sclens_hip_last_error() gives the message.
+ * Blocking calls; one host thread per context. The caller owns every host buffer; the library owns
+ * device memory behind the opaque handles.
+ */
+#ifndef SCLENS_HIP_H
+#define SCLENS_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SCLENS_OK 0
+#define SCLENS_ERR_ARG 1       /* bad argument */
+#define SCLENS_ERR_NO_DEVICE 2 /* no HIP device / device init failed (shim falls back to "cpu") */
+#define SCLENS_ERR_OOM 3       /* device out of memory (reference: catch -> CPU, scLENS.jl:504-508) */
+#define SCLENS_ERR_HIP 4       /* other HIP runtime error */
+#define SCLENS_ERR_NOCONV 5    /* eigensolver did not converge */
+#define SCLENS_ERR_NAN 6       /* NaN eigenvalue (reference: redo in Float64 on CPU, scLENS.jl:379-381) */
+#define SCLENS_ERR_STATE 7     /* session call out of order */
+
+typedef struct sclens_hip_ctx sclens_hip_ctx;
+typedef struct sclens_hip_session sclens_hip_session;
+
+/* ---------------------------------------------------------------- context ---------------------- */
+int sclens_hip_create(sclens_hip_ctx** ctx, int device_id);
+void sclens_hip_destroy(sclens_hip_ctx* ctx);
+const char* sclens_hip_last_error(const sclens_hip_ctx* ctx);
+const char* sclens_hip_version(void);
+/* per-stage HIP-event timing ("scale","gram","sytrd","stebz","stein","ormtr","corr","recover") */
+int sclens_hip_set_timing(sclens_hip_ctx* ctx, int enabled);
+int sclens_hip_get_timing(sclens_hip_ctx* ctx, const char* stage, double* total_ms, int64_t* calls);
+int sclens_hip_reset_timing(sclens_hip_ctx* ctx);
+/* raw stream handle (hipStream_t) so a host framework can order its own work after ours */
+void* sclens_hip_stream(sclens_hip_ctx* ctx);
+
+/* ---------------------------------------------------------------- (A) per-call drop-ins -------- */
+/* _wishart_matrix(X; device, dims)  (scLENS.jl:332-361): X is N x M; dims=2 -> X'X / M (M x M),
+ * dims=1 -> XX' / M (N x N). Both divide by size(X,2). Y is caller-allocated. */
+int sclens_hip_wishart_matrix_f32(sclens_hip_ctx* ctx, const float* X, int64_t N, int64_t M, int dims, float* Y);
+/* _get_eigen(Y; device)  (scLENS.jl:375-387): all eigenvalues ascending in L[n], eigenvectors as the
+ * columns of V (n x n). Returns SCLENS_ERR_NAN if an eigenvalue is NaN. */
+int sclens_hip_get_eigen_f32(sclens_hip_ctx* ctx, const float* Y, int64_t n, float* L, float* V);
+/* corr_mat(X, Y; device)  (scLENS.jl:363-373): out = X' * Y, X is n x p, Y is n x q, out is p x q. */
+int sclens_hip_corr_mat_f32(sclens_hip_ctx* ctx, const float* X, int64_t n, int64_t p, const float* Y, int64_t q,
+                            float* out);
+/* get_eigvec(X; device)  (scLENS.jl:489-524): X is N x M scaled data. nL[r] positive eigenvalues
+ * descending, nV is N x r (cell-side eigenvectors, unit columns). On input *r = capacity in columns
+ * (min(N,M) always suffices); on output the number of positive eigenvalues. keep_top > 0 limits the
+ * eigenvectors to the first keep_top columns (what the caller consumes, scLENS.jl:776). */
+int sclens_hip_get_eigvec_f32(sclens_hip_ctx* ctx, const float* X, int64_t N, int64_t M, int64_t keep_top,
+                              float* nL, float* nV, int64_t* r);
+
+/* ---------------------------------------------------------------- host statistics (no GPU) ----- */
+/* _mp_calculation(L, Lr)  (scLENS.jl:424-459). L_mp_mask[n] gets 1 where b_minus < L < b_plus. */
+int sclens_mp_calculation(const double* L, int64_t n, const double* Lr, int64_t nr, double* b_plus, double* b_minus,
+                          uint8_t* L_mp_mask);
+/* _tw(L, L_mp)  (scLENS.jl:461-467): lambda_c, gamma, p, sigma. n_all = length(L). */
+int sclens_tw(int64_t n_all, const double* L_mp, int64_t n_mp, double* lambda_c, double* gamma, double* p,
+              double* sigma);
+/* mp_check(test_L)  (scLENS.jl:469-487) */
+int sclens_mp_check(const double* L_mp, int64_t n_mp, double p_val, double* ks_static, int* pass);
+/* robustness statistics from b_ (k x npairs, row-major)  (scLENS.jl:797-806): Tukey fence, median, std */
+int sclens_robust_scores(const double* b, int64_t k, int64_t npairs, double* m_score, double* sd_score);
+/* expected max |N(0,1/n)| over n draws, the quantity scLENS.jl:709-712 estimates with 5000 trials */
+double sclens_noise_baseline_exact(int64_t n);
+
+/* ---------------------------------------------------------------- (B) device-resident session -- */
+/* Count matrix (what df2sparr(inp_df) returns, scLENS.jl:662) + the zero-candidate list
+ * (z_idx1, z_idx2 of scLENS.jl:668-673, 0-based, disjoint from the stored entries, unique). */
+int sclens_hip_session_create(sclens_hip_ctx* ctx, int64_t N, int64_t M, const int64_t* colptr, const int32_t* rowval,
+                              const float* nzval, int64_t n_cand, const uint32_t* z_idx1, const uint32_t* z_idx2,
+                              sclens_hip_session** out);
+void sclens_hip_session_destroy(sclens_hip_session* s);
+
+/* First half of get_sigev (scLENS.jl:526-537, :569-576): eigenvalues (ascending, length min(N,M)) of the
+ * Gram matrix of the scaled data (L) and of the scaled null matrix X_r (Lr; CSC, same shape).
+ * rec_* receive rec_vals (scLENS.jl:676-696); any of them may be NULL. */
+int sclens_hip_session_spectrum(sclens_hip_session* s, const int64_t* r_colptr, const int32_t* r_rowval,
+                                const float* r_nzval, double* L, double* Lr, double* rec_tgc, double* rec_mat2_mean,
+                                double* rec_mat2_std, double* rec_norm_tgc, double* rec_cent);
+/* Second half (scLENS.jl:541-558, :580-590): cell-side eigenvectors of the k largest eigenvalues,
+ * descending; nV is N x k (may be NULL: they also stay on the device for the later steps). */
+int sclens_hip_session_signal_vectors(sclens_hip_session* s, int64_t k, float* nV);
+
+/* Vr2 of scLENS.jl:717-721: eigenbasis of the binarised pattern. L_bin[min(N,M)] ascending; *r = number of
+ * positive eigenvalues (columns of Vr2, kept on the device). */
+int sclens_hip_session_binary_basis(sclens_hip_session* s, double* L_bin, int64_t* r);
+/* One iteration of the sparsity search (scLENS.jl:731-747): sample = indices into the candidate list
+ * (0-based, distinct); n_2 as at scLENS.jl:722. d5 = the five smallest values of d_arr, ascending. */
+int sclens_hip_session_search_step(sclens_hip_session* s, const uint32_t* sample, int64_t m, int64_t n_2, double* d5,
+                                   int64_t* r_it);
+/* One member of the perturbation ensemble (scLENS.jl:772-777): keeps the first min(min_pc, r) cell-side
+ * eigenvectors in device slot t; nL_top[min_pc] their eigenvalues (descending); *ncols their number. */
+int sclens_hip_session_perturb(sclens_hip_session* s, int64_t t, const uint32_t* sample, int64_t m, int64_t min_pc,
+                               double* nL_top, int64_t* ncols);
+/* Download slot t (N x ncols, column-major) -- for tests and for callers that score on the host. */
+int sclens_hip_session_get_perturbed(sclens_hip_session* s, int64_t t, float* nV_t);
+/* Robustness matching (scLENS.jl:788-795) over slots 0..P-1: a_b is k x P (0-based column picks,
+ * column-major), b is k x P(P-1)/2 ROW-major (pair order i<j as at :792). */
+int sclens_hip_session_robustness(sclens_hip_session* s, int64_t P, int32_t* a_b, double* b);
+/* gene_basis (scLENS.jl:813-818): (nL^-1/2 .* nV') * scaled_X / sqrt(M), written as out[q*M + j]
+ * (k rows of M genes). */
+int sclens_hip_session_gene_basis(sclens_hip_session* s, const double* nL, float* out);
+
+/* ---------------------------------------------------------------- device-level entry points ---- */
+/* Used by the repository's own tests and bench.py (device pointers, row-major; see csrc/common.h). */
+int sclens_hip_dev_gemm_f32(sclens_hip_ctx* ctx, const float* P, const float* Q, float* C, int64_t M, int64_t N,
+                            int64_t K, int64_t ldp, int64_t ldq, int64_t ldc, float alpha, float beta, int q_kcontig,
+                            int lower, uint32_t* colabsmax);
+int sclens_hip_dev_gram_f32(sclens_hip_ctx* ctx, const float* B, int64_t n, int64_t K, int64_t ldb, float divisor,
+                            float* A, int64_t lda);
+int sclens_hip_dev_sytrd_f32(sclens_hip_ctx* ctx, float* A, int64_t n, int64_t lda, double* d, double* e, float* tau);
+int sclens_hip_dev_stebz_f64(sclens_hip_ctx* ctx, const double* d, const double* e, int64_t n, double* w);
+int sclens_hip_dev_eigh_f32(sclens_hip_ctx* ctx, float* A, int64_t n, int64_t lda, double* w, int64_t vec_lo,
+                            int64_t vec_hi, float* Zt, int64_t ldz);
+void* sclens_hip_dev_malloc(sclens_hip_ctx* ctx, int64_t bytes);
+void sclens_hip_dev_free(sclens_hip_ctx* ctx, void* p);
+int sclens_hip_dev_memcpy(sclens_hip_ctx* ctx, void* dst, const void* src, int64_t bytes, int kind /*1 H2D, 2 D2H, 3 D2D*/);
+int sclens_hip_dev_memset(sclens_hip_ctx* ctx, void* dst, int value, int64_t bytes);
+int sclens_hip_dev_sync(sclens_hip_ctx* ctx);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SCLENS_HIP_H */

@@ -1,0 +1,159 @@
+"""ctypes binding of libsclens_hip.so (include/sclens_hip.h). Fails loudly: there is no CPU fallback.
+
+The shared library is built in-tree by `__graft_entry__.build()` / `make -C sclens_amd/csrc`.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libsclens_hip.so")
+
+ERR_NAMES = {1: "ARG", 2: "NO_DEVICE", 3: "OOM", 4: "HIP", 5: "NOCONV", 6: "NAN", 7: "STATE"}
+
+c_f32p = C.POINTER(C.c_float)
+c_f64p = C.POINTER(C.c_double)
+c_i64p = C.POINTER(C.c_int64)
+c_i32p = C.POINTER(C.c_int32)
+c_u32p = C.POINTER(C.c_uint32)
+c_u8p = C.POINTER(C.c_uint8)
+vp = C.c_void_p
+i64 = C.c_int64
+
+# name -> (restype, argtypes); every symbol declared in include/sclens_hip.h
+SIGNATURES = {
+    "sclens_hip_create": (C.c_int, [C.POINTER(vp), C.c_int]),
+    "sclens_hip_destroy": (None, [vp]),
+    "sclens_hip_last_error": (C.c_char_p, [vp]),
+    "sclens_hip_version": (C.c_char_p, []),
+    "sclens_hip_set_timing": (C.c_int, [vp, C.c_int]),
+    "sclens_hip_get_timing": (C.c_int, [vp, C.c_char_p, c_f64p, c_i64p]),
+    "sclens_hip_reset_timing": (C.c_int, [vp]),
+    "sclens_hip_stream": (vp, [vp]),
+    "sclens_hip_wishart_matrix_f32": (C.c_int, [vp, c_f32p, i64, i64, C.c_int, c_f32p]),
+    "sclens_hip_get_eigen_f32": (C.c_int, [vp, c_f32p, i64, c_f32p, c_f32p]),
+    "sclens_hip_corr_mat_f32": (C.c_int, [vp, c_f32p, i64, i64, c_f32p, i64, c_f32p]),
+    "sclens_hip_get_eigvec_f32": (C.c_int, [vp, c_f32p, i64, i64, i64, c_f32p, c_f32p, c_i64p]),
+    "sclens_mp_calculation": (C.c_int, [c_f64p, i64, c_f64p, i64, c_f64p, c_f64p, c_u8p]),
+    "sclens_tw": (C.c_int, [i64, c_f64p, i64, c_f64p, c_f64p, c_f64p, c_f64p]),
+    "sclens_mp_check": (C.c_int, [c_f64p, i64, C.c_double, c_f64p, C.POINTER(C.c_int)]),
+    "sclens_robust_scores": (C.c_int, [c_f64p, i64, i64, c_f64p, c_f64p]),
+    "sclens_noise_baseline_exact": (C.c_double, [i64]),
+    "sclens_hip_session_create": (C.c_int, [vp, i64, i64, c_i64p, c_i32p, c_f32p, i64, c_u32p, c_u32p, C.POINTER(vp)]),
+    "sclens_hip_session_destroy": (None, [vp]),
+    "sclens_hip_session_spectrum": (C.c_int, [vp, c_i64p, c_i32p, c_f32p, c_f64p, c_f64p, c_f64p, c_f64p, c_f64p, c_f64p, c_f64p]),
+    "sclens_hip_session_signal_vectors": (C.c_int, [vp, i64, c_f32p]),
+    "sclens_hip_session_binary_basis": (C.c_int, [vp, c_f64p, c_i64p]),
+    "sclens_hip_session_search_step": (C.c_int, [vp, c_u32p, i64, i64, c_f64p, c_i64p]),
+    "sclens_hip_session_perturb": (C.c_int, [vp, i64, c_u32p, i64, i64, c_f64p, c_i64p]),
+    "sclens_hip_session_get_perturbed": (C.c_int, [vp, i64, c_f32p]),
+    "sclens_hip_session_robustness": (C.c_int, [vp, i64, c_i32p, c_f64p]),
+    "sclens_hip_session_gene_basis": (C.c_int, [vp, c_f64p, c_f32p]),
+    "sclens_hip_dev_gemm_f32": (C.c_int, [vp, vp, vp, vp, i64, i64, i64, i64, i64, i64, C.c_float, C.c_float, C.c_int, C.c_int, vp]),
+    "sclens_hip_dev_gram_f32": (C.c_int, [vp, vp, i64, i64, i64, C.c_float, vp, i64]),
+    "sclens_hip_dev_sytrd_f32": (C.c_int, [vp, vp, i64, i64, vp, vp, vp]),
+    "sclens_hip_dev_stebz_f64": (C.c_int, [vp, vp, vp, i64, vp]),
+    "sclens_hip_dev_eigh_f32": (C.c_int, [vp, vp, i64, i64, vp, i64, i64, vp, i64]),
+    "sclens_hip_dev_malloc": (vp, [vp, i64]),
+    "sclens_hip_dev_free": (None, [vp, vp]),
+    "sclens_hip_dev_memcpy": (C.c_int, [vp, vp, vp, i64, C.c_int]),
+    "sclens_hip_dev_memset": (C.c_int, [vp, vp, C.c_int, i64]),
+    "sclens_hip_dev_sync": (C.c_int, [vp]),
+}
+
+_lib = None
+
+
+class SclensHipError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"libsclens_hip: SCLENS_ERR_{ERR_NAMES.get(code, code)}: {msg}")
+        self.code = code
+
+
+def load():
+    """Load the shared library (no GPU needed for loading or for the host statistics)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(or `make -C sclens_amd/csrc`). sclens_amd has no CPU fallback."
+        )
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the symbol is not exported
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def ptr(a: np.ndarray, ctype):
+    return a.ctypes.data_as(C.POINTER(ctype))
+
+
+class Context:
+    """Owns one sclens_hip_ctx (one GPU, one stream)."""
+
+    def __init__(self, device: int = 0):
+        self.lib = load()
+        h = vp()
+        rc = self.lib.sclens_hip_create(C.byref(h), int(device))
+        if rc != 0:
+            raise SclensHipError(rc, "sclens_hip_create failed (no usable HIP device?)")
+        self.h = h
+
+    def check(self, rc):
+        if rc != 0:
+            raise SclensHipError(rc, self.lib.sclens_hip_last_error(self.h).decode())
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.sclens_hip_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- timing
+    def set_timing(self, on: bool):
+        self.check(self.lib.sclens_hip_set_timing(self.h, int(on)))
+
+    def reset_timing(self):
+        self.check(self.lib.sclens_hip_reset_timing(self.h))
+
+    def timing(self, stage: str):
+        ms, calls = C.c_double(0), C.c_int64(0)
+        self.check(self.lib.sclens_hip_get_timing(self.h, stage.encode(), C.byref(ms), C.byref(calls)))
+        return ms.value, calls.value
+
+    # ---- raw device memory helpers (tests / bench)
+    def malloc(self, nbytes: int):
+        p = self.lib.sclens_hip_dev_malloc(self.h, int(nbytes))
+        if not p:
+            raise SclensHipError(3, "dev_malloc")
+        return p
+
+    def free(self, p):
+        self.lib.sclens_hip_dev_free(self.h, p)
+
+    def h2d(self, dst, arr: np.ndarray):
+        arr = np.ascontiguousarray(arr)
+        self.check(self.lib.sclens_hip_dev_memcpy(self.h, dst, arr.ctypes.data, arr.nbytes, 1))
+
+    def d2h(self, arr: np.ndarray, src):
+        assert arr.flags.c_contiguous
+        self.check(self.lib.sclens_hip_dev_memcpy(self.h, arr.ctypes.data, src, arr.nbytes, 2))
+
+    def memset(self, dst, value, nbytes):
+        self.check(self.lib.sclens_hip_dev_memset(self.h, dst, int(value), int(nbytes)))
+
+    def sync(self):
+        self.check(self.lib.sclens_hip_dev_sync(self.h))

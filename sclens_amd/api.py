@@ -1,0 +1,434 @@
+"""Host-side mirror of the reference's operator interface for the sclens() hot path, over the C ABI.
+
+Julia is not available in the build image, so this Python module plays the role of the thin Julia shim
+(`julia/scLENS_hip.jl`): same function names, argument meaning and error behaviour as
+`/root/reference/src/scLENS.jl`, every heavy operation forwarded to libsclens_hip.so. There is no CPU
+fallback here and nothing in this file imports `oracle/`.
+
+  _wishart_matrix, corr_mat, _get_eigen, get_eigvec      scLENS.jl:332-387, :489-524 (per-call drop-ins)
+  _mp_calculation, _tw, mp_check                          scLENS.jl:424-487 (host statistics, C++)
+  sclens                                                  scLENS.jl:649-832 (device-resident session)
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+import time
+from dataclasses import dataclass, field
+from typing import Callable, Dict, List, Optional
+
+import numpy as np
+import scipy.sparse as sp
+
+from . import _lib
+from ._lib import Context, SclensHipError, ptr
+
+_default_ctx: Optional[Context] = None
+
+
+def default_context(device: int = 0) -> Context:
+    global _default_ctx
+    if _default_ctx is None:
+        _default_ctx = Context(device)
+    return _default_ctx
+
+
+def _f32_colmajor(X) -> np.ndarray:
+    return np.asfortranarray(np.asarray(X, dtype=np.float32))
+
+
+# ----------------------------------------------------------------------------- per-call drop-ins
+def _wishart_matrix(X, device="gpu", dims=1, ctx: Optional[Context] = None) -> np.ndarray:
+    """scLENS.jl:332-361. Unknown device strings return None like the reference (SURVEY 8a defect 5)."""
+    if device != "gpu":
+        return None
+    ctx = ctx or default_context()
+    Xf = _f32_colmajor(X)
+    N, M = Xf.shape
+    n = M if dims == 2 else N
+    Y = np.empty((n, n), dtype=np.float32, order="F")
+    ctx.check(ctx.lib.sclens_hip_wishart_matrix_f32(ctx.h, ptr(Xf, C.c_float), N, M, int(dims), ptr(Y, C.c_float)))
+    return Y
+
+
+def corr_mat(X, Y, device="gpu", ctx: Optional[Context] = None) -> np.ndarray:
+    """scLENS.jl:363-373: X' * Y."""
+    if device != "gpu":
+        return None
+    ctx = ctx or default_context()
+    Xf, Yf = _f32_colmajor(X), _f32_colmajor(Y)
+    n, p = Xf.shape
+    q = Yf.shape[1]
+    out = np.empty((p, q), dtype=np.float32, order="F")
+    ctx.check(ctx.lib.sclens_hip_corr_mat_f32(ctx.h, ptr(Xf, C.c_float), n, p, ptr(Yf, C.c_float), q, ptr(out, C.c_float)))
+    return out
+
+
+def _get_eigen(Y, device="gpu", ctx: Optional[Context] = None):
+    """scLENS.jl:375-387: (values ascending, vectors as columns)."""
+    if device != "gpu":
+        return None
+    ctx = ctx or default_context()
+    Yf = _f32_colmajor(Y)
+    n = Yf.shape[0]
+    L = np.empty(n, dtype=np.float32)
+    V = np.empty((n, n), dtype=np.float32, order="F")
+    ctx.check(ctx.lib.sclens_hip_get_eigen_f32(ctx.h, ptr(Yf, C.c_float), n, ptr(L, C.c_float), ptr(V, C.c_float)))
+    return L, V
+
+
+def get_eigvec(X, device="gpu", keep_top: int = 0, ctx: Optional[Context] = None):
+    """scLENS.jl:489-524: (nL descending, N x r cell-side unit eigenvectors)."""
+    if device != "gpu":
+        return None
+    ctx = ctx or default_context()
+    Xf = _f32_colmajor(X)
+    N, M = Xf.shape
+    n = min(N, M)
+    nL = np.empty(n, dtype=np.float32)
+    ncol = n if keep_top <= 0 else min(keep_top, n)
+    nV = np.empty((N, ncol), dtype=np.float32, order="F")
+    r = C.c_int64(n)
+    ctx.check(ctx.lib.sclens_hip_get_eigvec_f32(ctx.h, ptr(Xf, C.c_float), N, M, int(keep_top), ptr(nL, C.c_float),
+                                                ptr(nV, C.c_float), C.byref(r)))
+    rr = r.value
+    return nL[:rr], nV[:, : min(rr, ncol)]
+
+
+# ----------------------------------------------------------------------------- host statistics
+def _mp_calculation(L, Lr):
+    """scLENS.jl:424-459 -> (L_mp, b_plus, b_minus)."""
+    lib = _lib.load()
+    L = np.ascontiguousarray(L, dtype=np.float64)
+    Lr = np.ascontiguousarray(Lr, dtype=np.float64)
+    mask = np.zeros(L.size, dtype=np.uint8)
+    bp, bm = C.c_double(0), C.c_double(0)
+    rc = lib.sclens_mp_calculation(ptr(L, C.c_double), L.size, ptr(Lr, C.c_double), Lr.size, C.byref(bp), C.byref(bm),
+                                   ptr(mask, C.c_uint8))
+    if rc:
+        raise SclensHipError(rc, "sclens_mp_calculation")
+    return L[mask.astype(bool)], bp.value, bm.value
+
+
+def _tw(L, L_mp):
+    """scLENS.jl:461-467 -> (lambda_c, gamma, p, sigma)."""
+    lib = _lib.load()
+    L_mp = np.ascontiguousarray(L_mp, dtype=np.float64)
+    out = [C.c_double(0) for _ in range(4)]
+    rc = lib.sclens_tw(len(L), ptr(L_mp, C.c_double), L_mp.size, *[C.byref(o) for o in out])
+    if rc:
+        raise SclensHipError(rc, "sclens_tw")
+    return tuple(o.value for o in out)
+
+
+def mp_check(test_L, p_val=0.05):
+    """scLENS.jl:469-487."""
+    lib = _lib.load()
+    t = np.ascontiguousarray(test_L, dtype=np.float64)
+    ks, ok = C.c_double(0), C.c_int(0)
+    rc = lib.sclens_mp_check(ptr(t, C.c_double), t.size, float(p_val), C.byref(ks), C.byref(ok))
+    if rc:
+        raise SclensHipError(rc, "sclens_mp_check")
+    return {"ks_static": ks.value, "pass": bool(ok.value)}
+
+
+def _robust_scores(b_):
+    lib = _lib.load()
+    b = np.ascontiguousarray(b_, dtype=np.float64)
+    k, npairs = b.shape
+    m = np.empty(k)
+    sd = np.empty(k)
+    rc = lib.sclens_robust_scores(ptr(b, C.c_double), k, npairs, ptr(m, C.c_double), ptr(sd, C.c_double))
+    if rc:
+        raise SclensHipError(rc, "sclens_robust_scores")
+    return m, sd
+
+
+# ----------------------------------------------------------------------------- random draws (host)
+@dataclass
+class Draws:
+    """The five random draws of one sclens() call (scLENS.jl:669, :701, :711, :731, :772), 0-based.
+
+    Julia's global RNG stream cannot be reproduced outside Julia; results are statistically equivalent.
+    Tests inject the same Draws into the oracle and into this path.
+    """
+
+    z_idx1: np.ndarray
+    z_idx2: np.ndarray
+    X_r: sp.csc_matrix
+    p_th: float
+    sampler: Callable[[str, int, int, int], np.ndarray] = None
+
+
+def _csc_f32(X) -> sp.csc_matrix:
+    X = sp.csc_matrix(X, dtype=np.float32)
+    X.eliminate_zeros()
+    X.sort_indices()
+    return X
+
+
+def draw_zero_candidates(X: sp.csc_matrix, rng: np.random.Generator):
+    """scLENS.jl:668-673: nnz uniform (i,j) pairs minus the stored set, first-occurrence order."""
+    N, M = X.shape
+    nnz = X.nnz
+    key = rng.integers(0, N, size=nnz, dtype=np.int64) + rng.integers(0, M, size=nnz, dtype=np.int64) * N
+    _, first = np.unique(key, return_index=True)
+    first.sort()
+    key = key[first]
+    nzkey = X.indices.astype(np.int64) + np.repeat(np.arange(M, dtype=np.int64), np.diff(X.indptr)) * N
+    key = key[~np.isin(key, nzkey, assume_unique=False)]
+    return (key % N).astype(np.uint32), (key // N).astype(np.uint32)
+
+
+def draw_null_matrix(X: sp.csc_matrix, rng: np.random.Generator) -> sp.csc_matrix:
+    """random_nz(pre_df, rmix=true) (scLENS.jl:261-289, :239-248), intent as in SURVEY 8a defect 4:
+    stored values shuffled globally; every gene keeps its number of entries at uniformly drawn distinct cells."""
+    N, M = X.shape
+    vals = rng.permutation(X.data)
+    rows = np.empty_like(X.indices)
+    ip = X.indptr
+    for j in range(M):
+        c = ip[j + 1] - ip[j]
+        if c:
+            rows[ip[j]: ip[j + 1]] = np.sort(rng.choice(N, size=c, replace=False))
+    return sp.csc_matrix((vals, rows, ip.copy()), shape=(N, M), dtype=np.float32)
+
+
+def draw_noise_baseline(n: int, rng: np.random.Generator, trials: int = 5000) -> float:
+    """scLENS.jl:709-712."""
+    acc = 0.0
+    sd = math.sqrt(1.0 / n)
+    chunk = max(1, int(2e7 // n))
+    done = 0
+    while done < trials:
+        t = min(chunk, trials - done)
+        acc += float(np.abs(rng.standard_normal((t, n))).max(axis=1).sum()) * sd
+        done += t
+    return acc / trials
+
+
+def make_draws(X, seed: int, p_th_trials: int = 5000) -> Draws:
+    X = _csc_f32(X)
+    rng = np.random.default_rng(seed)
+    z1, z2 = draw_zero_candidates(X, rng)
+    Xr = draw_null_matrix(X, rng)
+    p_th = draw_noise_baseline(min(X.shape), rng, p_th_trials)
+
+    def sampler(kind, it, population, m):
+        r = np.random.default_rng([seed, 1 if kind == "search" else 2, it])
+        return r.choice(population, size=m, replace=False)
+
+    return Draws(z1, z2, Xr, p_th, sampler)
+
+
+# ----------------------------------------------------------------------------- session wrapper
+class Session:
+    """Device-resident state of one sclens() call (include/sclens_hip.h, part B)."""
+
+    def __init__(self, ctx: Context, X: sp.csc_matrix, z1: np.ndarray, z2: np.ndarray):
+        self.ctx = ctx
+        self.N, self.M = X.shape
+        self.n = min(X.shape)
+        colptr = np.ascontiguousarray(X.indptr, dtype=np.int64)
+        rowval = np.ascontiguousarray(X.indices, dtype=np.int32)
+        nzval = np.ascontiguousarray(X.data, dtype=np.float32)
+        z1 = np.ascontiguousarray(z1, dtype=np.uint32)
+        z2 = np.ascontiguousarray(z2, dtype=np.uint32)
+        self.ncand = int(z1.size)
+        h = C.c_void_p()
+        ctx.check(ctx.lib.sclens_hip_session_create(ctx.h, self.N, self.M, ptr(colptr, C.c_int64), ptr(rowval, C.c_int32),
+                                                    ptr(nzval, C.c_float), self.ncand, ptr(z1, C.c_uint32),
+                                                    ptr(z2, C.c_uint32), C.byref(h)))
+        self.h = h
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.ctx.lib.sclens_hip_session_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def spectrum(self, X_r: sp.csc_matrix):
+        X_r = _csc_f32(X_r)
+        cp = np.ascontiguousarray(X_r.indptr, dtype=np.int64)
+        rv = np.ascontiguousarray(X_r.indices, dtype=np.int32)
+        nz = np.ascontiguousarray(X_r.data, dtype=np.float32)
+        L = np.empty(self.n)
+        Lr = np.empty(self.n)
+        rec = {"TGC": np.empty(self.N), "mat2_mean": np.empty(self.M), "mat2_std": np.empty(self.M),
+               "norm_tgc": np.empty(self.N), "cent_": np.empty(self.M)}
+        self.ctx.check(self.ctx.lib.sclens_hip_session_spectrum(
+            self.h, ptr(cp, C.c_int64), ptr(rv, C.c_int32), ptr(nz, C.c_float), ptr(L, C.c_double), ptr(Lr, C.c_double),
+            ptr(rec["TGC"], C.c_double), ptr(rec["mat2_mean"], C.c_double), ptr(rec["mat2_std"], C.c_double),
+            ptr(rec["norm_tgc"], C.c_double), ptr(rec["cent_"], C.c_double)))
+        return L, Lr, rec
+
+    def signal_vectors(self, k: int) -> np.ndarray:
+        nV = np.empty((self.N, k), dtype=np.float32, order="F")
+        self.ctx.check(self.ctx.lib.sclens_hip_session_signal_vectors(self.h, int(k), ptr(nV, C.c_float)))
+        return nV
+
+    def binary_basis(self):
+        L = np.empty(self.n)
+        r = C.c_int64(0)
+        self.ctx.check(self.ctx.lib.sclens_hip_session_binary_basis(self.h, ptr(L, C.c_double), C.byref(r)))
+        return L, r.value
+
+    def search_step(self, sample: np.ndarray, n_2: int):
+        s = np.ascontiguousarray(sample, dtype=np.uint32)
+        d5 = np.empty(5)
+        r = C.c_int64(0)
+        self.ctx.check(self.ctx.lib.sclens_hip_session_search_step(self.h, ptr(s, C.c_uint32), s.size, int(n_2),
+                                                                   ptr(d5, C.c_double), C.byref(r)))
+        return d5, r.value
+
+    def perturb(self, t: int, sample: np.ndarray, min_pc: int):
+        s = np.ascontiguousarray(sample, dtype=np.uint32)
+        nL = np.empty(min_pc)
+        c = C.c_int64(0)
+        self.ctx.check(self.ctx.lib.sclens_hip_session_perturb(self.h, int(t), ptr(s, C.c_uint32), s.size, int(min_pc),
+                                                               ptr(nL, C.c_double), C.byref(c)))
+        return nL[: c.value], c.value
+
+    def get_perturbed(self, t: int, ncols: int) -> np.ndarray:
+        out = np.empty((self.N, ncols), dtype=np.float32, order="F")
+        self.ctx.check(self.ctx.lib.sclens_hip_session_get_perturbed(self.h, int(t), ptr(out, C.c_float)))
+        return out
+
+    def robustness(self, k: int, P: int):
+        a_b = np.empty((k, P), dtype=np.int32, order="F")
+        b = np.empty((k, P * (P - 1) // 2), dtype=np.float64)
+        self.ctx.check(self.ctx.lib.sclens_hip_session_robustness(self.h, int(P), ptr(a_b, C.c_int32), ptr(b, C.c_double)))
+        return a_b, b
+
+    def gene_basis(self, nL: np.ndarray) -> np.ndarray:
+        nL = np.ascontiguousarray(nL, dtype=np.float64)
+        out = np.empty((nL.size, self.M), dtype=np.float32)
+        self.ctx.check(self.ctx.lib.sclens_hip_session_gene_basis(self.h, ptr(nL, C.c_double), ptr(out, C.c_float)))
+        return out
+
+
+# ----------------------------------------------------------------------------- driver
+def _extract(inp):
+    """df2sparr(inp_df) (scLENS.jl:662, :90-120) for a DataFrame with a leading `cell` column, a scipy sparse
+    matrix or a dense array (cells x genes)."""
+    cell_id = gene_id = None
+    try:
+        import pandas as pd
+
+        if isinstance(inp, pd.DataFrame):
+            cell_id = inp.iloc[:, 0].astype(str).to_numpy()
+            gene_id = np.asarray(inp.columns[1:])
+            inp = inp.iloc[:, 1:].to_numpy(dtype=np.float32)
+    except ImportError:
+        pass
+    X = _csc_f32(inp)
+    if cell_id is None:
+        cell_id = np.arange(X.shape[0]).astype(str)
+        gene_id = np.arange(X.shape[1]).astype(str)
+    return X, cell_id, gene_id
+
+
+def sclens(inp_df, device_="gpu", th=60, p_step=0.001, n_perturb=20, centering="mean", draws: Optional[Draws] = None,
+           seed: Optional[int] = None, ctx: Optional[Context] = None, max_search_iters: Optional[int] = None,
+           keep_intermediates: bool = False, verbose: bool = False) -> Dict[str, object]:
+    """scLENS.sclens (scLENS.jl:649-832) on one MI355X.
+
+    Same keyword arguments as the reference. `draws`/`seed` expose the randomness the reference takes from
+    Julia's global RNG; `max_search_iters` is a test-only cap of the sparsity search.
+    """
+    if device_ != "gpu":
+        raise NotImplementedError("sclens_amd implements the device path only; use the reference for device_='cpu'")
+    if centering != "mean":
+        raise NotImplementedError("centering='median' is outside the hot path of this build (SURVEY 8f-4)")
+    ctx = ctx or default_context()
+    t_all = time.perf_counter()
+    X_, cell_id, gene_id = _extract(inp_df)  # :662
+    N, M = X_.shape
+    if draws is None:
+        draws = make_draws(X_, seed if seed is not None else int(time.time_ns() % (2**31)))
+    z1, z2 = draws.z_idx1, draws.z_idx2
+    ses = Session(ctx, X_, z1, z2)
+    try:
+        # ---- get_sigev (:704): spectra of data and null, MP fit, TW threshold (host), signal vectors
+        L, Lr, rec_vals = ses.spectrum(draws.X_r)
+        L_mp, _, b_min = _mp_calculation(L, Lr[:-1])  # Lr[1:end-1] (:537, :576)
+        lambda_c = _tw(L, L_mp)[0]
+        sel = L > lambda_c
+        k = int(sel.sum())
+        if verbose:
+            print(f"(Using hip) number of signal ev: {k}")
+        nL = L[sel][::-1].copy()  # descending
+        nV = ses.signal_vectors(k)
+        mpC = mp_check(L_mp)  # :706
+        p_th = draws.p_th  # :709-712
+
+        # ---- sparsity search (:715-762)
+        p_ = 0.999
+        _, r_vr2 = ses.binary_basis()  # Vr2 (:717-721)
+        n_2 = int(round(r_vr2 / 2))  # :722
+        tank = np.zeros((5, 0))
+        it = 0
+        trace = []
+        while True:
+            nnzidx = int(round((1 - p_) * M * N))  # :726
+            if len(z1) < nnzidx:
+                p_ += p_step
+                break
+            idx = draws.sampler("search", it, len(z1), nnzidx)  # :731
+            d5, _r = ses.search_step(idx, n_2)  # :733-747
+            tank = np.hstack([tank, d5[:, None]])
+            ppj = tank[1, :] if tank.shape[1] < 5 else tank[1, -5:]
+            trace.append((p_, d5.copy()))
+            it += 1
+            if verbose:
+                print(ppj[-1])
+            if (np.sum(ppj < p_th) > 4) or (p_ < 0.9) or (max_search_iters is not None and it >= max_search_iters):
+                p_ += 4 * p_step
+                break
+            p_ -= p_step
+        if verbose:
+            print(f"Selected perturb sparisty: {p_}")
+
+        # ---- perturbation ensemble (:767-778)
+        min_s = k
+        min_pc = int(math.ceil(min_s * 1.5))
+        m_pert = int(round((1 - p_) * M * N))
+        nL_set, ncols = [], []
+        if min_s > 0:
+            for t in range(n_perturb):
+                idx = draws.sampler("perturb", t, len(z1), m_pert)
+                tl, c = ses.perturb(t, idx, min_pc)
+                nL_set.append(tl)
+                ncols.append(c)
+
+        res: Dict[str, object] = {"L": L, "L_mp": L_mp, "λ": lambda_c, "lambda_c": lambda_c, "cell_id": cell_id,
+                                  "p_": p_, "p_th": p_th, "n_search": it, "search_trace": trace}
+        if min_s == 0:  # :780-784
+            res["wall_s"] = time.perf_counter() - t_all
+            return res
+        # ---- robustness (:786-807)
+        th_ = math.cos(math.radians(th))
+        a_b, b_ = ses.robustness(k, n_perturb)
+        m_score, sd_score = _robust_scores(b_)
+        rob_score = m_score
+        sig_id = np.flatnonzero(rob_score > th_)
+        # ---- reconstruction (:809-830)
+        Xout0 = nV * np.sqrt(nL)[None, :].astype(np.float32)
+        Xout1 = nV[:, sig_id] * np.sqrt(nL[sig_id])[None, :].astype(np.float32)
+        gmat = ses.gene_basis(nL)
+        res.update({"pca": Xout0, "pca_n1": Xout1, "sig_id": sig_id,
+                    "robustness_scores": {"b_": b_, "rob_score": rob_score, "m_scores": m_score, "sd_scores": sd_score,
+                                          "a_b": a_b},
+                    "signal_evec": nV, "signal_ev": nL, "gene_id": gene_id, "gene_basis": gmat, "pass": mpC["pass"],
+                    "ks_static": mpC["ks_static"], "rec_vals": rec_vals, "nL_set": nL_set, "min_pc": min_pc})
+        if keep_intermediates:
+            res["nV_set"] = [ses.get_perturbed(t, ncols[t]) for t in range(n_perturb)]
+        res["wall_s"] = time.perf_counter() - t_all
+        return res
+    finally:
+        ses.close()

@@ -1,0 +1,236 @@
+// extern "C" surface of libsclens_hip.so (see include/sclens_hip.h). Thin: argument checks + forwarding.
+#include "common.h"
+#include "pattern.h"
+
+namespace scl {
+struct Session;
+int session_create(Ctx*, int64_t, int64_t, const int64_t*, const int32_t*, const float*, int64_t, const uint32_t*,
+                   const uint32_t*, Session**);
+void session_destroy(Session*);
+int session_spectrum(Session*, const int64_t*, const int32_t*, const float*, double*, double*, ScaleVecs*);
+int session_signal_vectors(Session*, int64_t, float*);
+int session_binary_basis(Session*, double*, int64_t*);
+int session_search_step(Session*, const uint32_t*, int64_t, int64_t, double*, int64_t*);
+int session_perturb(Session*, int64_t, const uint32_t*, int64_t, int64_t, double*, int64_t*);
+int session_get_perturbed(Session*, int64_t, float*);
+int session_robustness(Session*, int64_t, int32_t*, double*);
+int session_gene_basis(Session*, const double*, float*);
+int wishart_host(Ctx*, const float*, int64_t, int64_t, int, float*);
+int get_eigen_host(Ctx*, const float*, int64_t, float*, float*);
+int corr_mat_host(Ctx*, const float*, int64_t, int64_t, const float*, int64_t, float*);
+int get_eigvec_host(Ctx*, const float*, int64_t, int64_t, int64_t, float*, float*, int64_t*);
+Ctx* session_ctx(Session* s);
+}  // namespace scl
+
+using scl::Ctx;
+
+struct sclens_hip_ctx { Ctx c; };
+struct sclens_hip_session { scl::Session* s; sclens_hip_ctx* ctx; std::vector<double> scratch; };
+
+extern "C" {
+
+const char* sclens_hip_version(void) { return "sclens_hip 0.1 (gfx950)"; }
+
+int sclens_hip_create(sclens_hip_ctx** out, int device_id) {
+  if (!out) return SCLENS_ERR_ARG;
+  *out = nullptr;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || device_id < 0 || device_id >= ndev) return SCLENS_ERR_NO_DEVICE;
+  if (hipSetDevice(device_id) != hipSuccess) return SCLENS_ERR_NO_DEVICE;
+  sclens_hip_ctx* h = new sclens_hip_ctx();
+  h->c.device = device_id;
+  if (hipStreamCreateWithFlags(&h->c.stream, hipStreamNonBlocking) != hipSuccess ||
+      hipEventCreate(&h->c.ev0) != hipSuccess || hipEventCreate(&h->c.ev1) != hipSuccess) {
+    delete h;
+    return SCLENS_ERR_NO_DEVICE;
+  }
+  *out = h;
+  return SCLENS_OK;
+}
+
+void sclens_hip_destroy(sclens_hip_ctx* h) {
+  if (!h) return;
+  hipSetDevice(h->c.device);
+  h->c.release_all();
+  if (h->c.ev0) hipEventDestroy(h->c.ev0);
+  if (h->c.ev1) hipEventDestroy(h->c.ev1);
+  if (h->c.stream) hipStreamDestroy(h->c.stream);
+  delete h;
+}
+
+const char* sclens_hip_last_error(const sclens_hip_ctx* h) { return h ? h->c.err.c_str() : "null context"; }
+void* sclens_hip_stream(sclens_hip_ctx* h) { return h ? (void*)h->c.stream : nullptr; }
+
+int sclens_hip_set_timing(sclens_hip_ctx* h, int enabled) {
+  if (!h) return SCLENS_ERR_ARG;
+  h->c.timing = enabled != 0;
+  return SCLENS_OK;
+}
+int sclens_hip_reset_timing(sclens_hip_ctx* h) {
+  if (!h) return SCLENS_ERR_ARG;
+  h->c.t_ms.clear();
+  h->c.t_calls.clear();
+  return SCLENS_OK;
+}
+int sclens_hip_get_timing(sclens_hip_ctx* h, const char* stage, double* total_ms, int64_t* calls) {
+  if (!h || !stage) return SCLENS_ERR_ARG;
+  auto it = h->c.t_ms.find(stage);
+  if (total_ms) *total_ms = (it == h->c.t_ms.end()) ? 0.0 : it->second;
+  if (calls) *calls = (it == h->c.t_ms.end()) ? 0 : (int64_t)h->c.t_calls[stage];
+  return SCLENS_OK;
+}
+
+#define CTX_GUARD(h) \
+  if (!(h)) return SCLENS_ERR_ARG; \
+  hipSetDevice((h)->c.device)
+
+int sclens_hip_wishart_matrix_f32(sclens_hip_ctx* h, const float* X, int64_t N, int64_t M, int dims, float* Y) {
+  CTX_GUARD(h);
+  return scl::wishart_host(&h->c, X, N, M, dims, Y);
+}
+int sclens_hip_get_eigen_f32(sclens_hip_ctx* h, const float* Y, int64_t n, float* L, float* V) {
+  CTX_GUARD(h);
+  return scl::get_eigen_host(&h->c, Y, n, L, V);
+}
+int sclens_hip_corr_mat_f32(sclens_hip_ctx* h, const float* X, int64_t n, int64_t p, const float* Y, int64_t q, float* out) {
+  CTX_GUARD(h);
+  return scl::corr_mat_host(&h->c, X, n, p, Y, q, out);
+}
+int sclens_hip_get_eigvec_f32(sclens_hip_ctx* h, const float* X, int64_t N, int64_t M, int64_t keep_top, float* nL,
+                              float* nV, int64_t* r) {
+  CTX_GUARD(h);
+  return scl::get_eigvec_host(&h->c, X, N, M, keep_top, nL, nV, r);
+}
+
+int sclens_hip_session_create(sclens_hip_ctx* h, int64_t N, int64_t M, const int64_t* colptr, const int32_t* rowval,
+                              const float* nzval, int64_t n_cand, const uint32_t* z1, const uint32_t* z2,
+                              sclens_hip_session** out) {
+  CTX_GUARD(h);
+  if (!out) return SCLENS_ERR_ARG;
+  scl::Session* s = nullptr;
+  int rc = scl::session_create(&h->c, N, M, colptr, rowval, nzval, n_cand, z1, z2, &s);
+  if (rc != SCLENS_OK) return rc;
+  sclens_hip_session* w = new sclens_hip_session();
+  w->s = s;
+  w->ctx = h;
+  *out = w;
+  return SCLENS_OK;
+}
+void sclens_hip_session_destroy(sclens_hip_session* w) {
+  if (!w) return;
+  hipSetDevice(w->ctx->c.device);
+  scl::session_destroy(w->s);
+  delete w;
+}
+#define SES_GUARD(w) \
+  if (!(w) || !(w)->s) return SCLENS_ERR_ARG; \
+  hipSetDevice((w)->ctx->c.device)
+
+int sclens_hip_session_spectrum(sclens_hip_session* w, const int64_t* rc, const int32_t* rr, const float* rv, double* L,
+                                double* Lr, double* rec_tgc, double* rec_mean, double* rec_std, double* rec_norm,
+                                double* rec_cent) {
+  SES_GUARD(w);
+  // scale_to_dense copies all five vectors or none: route missing ones to scratch
+  scl::ScaleVecs k{rec_tgc, rec_mean, rec_std, rec_norm, rec_cent};
+  bool any = rec_tgc || rec_mean || rec_std || rec_norm || rec_cent;
+  if (any && !(rec_tgc && rec_mean && rec_std && rec_norm && rec_cent))
+    return w->ctx->c.fail(SCLENS_ERR_ARG, "spectrum: pass all rec_* buffers or none");
+  return scl::session_spectrum(w->s, rc, rr, rv, L, Lr, any ? &k : nullptr);
+}
+int sclens_hip_session_signal_vectors(sclens_hip_session* w, int64_t k, float* nV) {
+  SES_GUARD(w);
+  return scl::session_signal_vectors(w->s, k, nV);
+}
+int sclens_hip_session_binary_basis(sclens_hip_session* w, double* L_bin, int64_t* r) {
+  SES_GUARD(w);
+  return scl::session_binary_basis(w->s, L_bin, r);
+}
+int sclens_hip_session_search_step(sclens_hip_session* w, const uint32_t* sample, int64_t m, int64_t n_2, double* d5,
+                                   int64_t* r_it) {
+  SES_GUARD(w);
+  if (!d5 || (m > 0 && !sample)) return SCLENS_ERR_ARG;
+  return scl::session_search_step(w->s, sample, m, n_2, d5, r_it);
+}
+int sclens_hip_session_perturb(sclens_hip_session* w, int64_t t, const uint32_t* sample, int64_t m, int64_t min_pc,
+                               double* nL_top, int64_t* ncols) {
+  SES_GUARD(w);
+  if (!nL_top || (m > 0 && !sample)) return SCLENS_ERR_ARG;
+  return scl::session_perturb(w->s, t, sample, m, min_pc, nL_top, ncols);
+}
+int sclens_hip_session_get_perturbed(sclens_hip_session* w, int64_t t, float* out) {
+  SES_GUARD(w);
+  if (!out) return SCLENS_ERR_ARG;
+  return scl::session_get_perturbed(w->s, t, out);
+}
+int sclens_hip_session_robustness(sclens_hip_session* w, int64_t P, int32_t* a_b, double* b) {
+  SES_GUARD(w);
+  if (!a_b || !b) return SCLENS_ERR_ARG;
+  return scl::session_robustness(w->s, P, a_b, b);
+}
+int sclens_hip_session_gene_basis(sclens_hip_session* w, const double* nL, float* out) {
+  SES_GUARD(w);
+  if (!nL || !out) return SCLENS_ERR_ARG;
+  return scl::session_gene_basis(w->s, nL, out);
+}
+
+// ---- device-level entry points
+int sclens_hip_dev_gemm_f32(sclens_hip_ctx* h, const float* P, const float* Q, float* C, int64_t M, int64_t N, int64_t K,
+                            int64_t ldp, int64_t ldq, int64_t ldc, float alpha, float beta, int q_kcontig, int lower,
+                            uint32_t* colabsmax) {
+  CTX_GUARD(h);
+  scl::GemmArgs g{P, Q, C, M, N, K, ldp, ldq, ldc, alpha, beta, q_kcontig, lower, colabsmax};
+  return scl::gemm_f32(&h->c, g);
+}
+int sclens_hip_dev_gram_f32(sclens_hip_ctx* h, const float* B, int64_t n, int64_t K, int64_t ldb, float divisor, float* A,
+                            int64_t lda) {
+  CTX_GUARD(h);
+  return scl::gram_f32(&h->c, B, n, K, ldb, divisor, A, lda);
+}
+int sclens_hip_dev_sytrd_f32(sclens_hip_ctx* h, float* A, int64_t n, int64_t lda, double* d, double* e, float* tau) {
+  CTX_GUARD(h);
+  return scl::sytrd_f32(&h->c, A, n, lda, d, e, tau);
+}
+int sclens_hip_dev_stebz_f64(sclens_hip_ctx* h, const double* d, const double* e, int64_t n, double* w) {
+  CTX_GUARD(h);
+  return scl::stebz_f64(&h->c, d, e, n, w);
+}
+int sclens_hip_dev_eigh_f32(sclens_hip_ctx* h, float* A, int64_t n, int64_t lda, double* w, int64_t vec_lo, int64_t vec_hi,
+                            float* Zt, int64_t ldz) {
+  CTX_GUARD(h);
+  return scl::eigh_f32(&h->c, A, n, lda, w, vec_lo, vec_hi, Zt, ldz);
+}
+void* sclens_hip_dev_malloc(sclens_hip_ctx* h, int64_t bytes) {
+  if (!h || bytes < 0) return nullptr;
+  hipSetDevice(h->c.device);
+  void* p = nullptr;
+  if (hipMalloc(&p, bytes > 0 ? (size_t)bytes : 16) != hipSuccess) {
+    h->c.fail(SCLENS_ERR_OOM, "dev_malloc failed");
+    return nullptr;
+  }
+  return p;
+}
+void sclens_hip_dev_free(sclens_hip_ctx* h, void* p) {
+  if (!h || !p) return;
+  hipSetDevice(h->c.device);
+  hipStreamSynchronize(h->c.stream);
+  hipFree(p);
+}
+int sclens_hip_dev_memcpy(sclens_hip_ctx* h, void* dst, const void* src, int64_t bytes, int kind) {
+  CTX_GUARD(h);
+  hipMemcpyKind k = kind == 1 ? hipMemcpyHostToDevice : (kind == 2 ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice);
+  SCL_HIP(&h->c, hipMemcpyAsync(dst, src, (size_t)bytes, k, h->c.stream));
+  SCL_HIP(&h->c, hipStreamSynchronize(h->c.stream));
+  return SCLENS_OK;
+}
+int sclens_hip_dev_memset(sclens_hip_ctx* h, void* dst, int value, int64_t bytes) {
+  CTX_GUARD(h);
+  SCL_HIP(&h->c, hipMemsetAsync(dst, value, (size_t)bytes, h->c.stream));
+  return SCLENS_OK;
+}
+int sclens_hip_dev_sync(sclens_hip_ctx* h) {
+  CTX_GUARD(h);
+  SCL_HIP(&h->c, hipStreamSynchronize(h->c.stream));
+  return SCLENS_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,134 @@
+// Internal declarations shared by the HIP/C++ translation units of libsclens_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/sclens_hip.h"
+
+namespace scl {
+
+struct Ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  std::string err;
+  // grow-only named device workspaces (freed at destroy); avoids hipMalloc inside hot loops
+  std::map<std::string, std::pair<void*, size_t>> ws;
+  // per-stage timing (ms) accumulated when timing is enabled
+  bool timing = false;
+  std::map<std::string, double> t_ms;
+  std::map<std::string, long> t_calls;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+
+  int fail(int code, const std::string& msg) {
+    err = msg;
+    return code;
+  }
+  // returns nullptr on OOM (err set)
+  void* workspace(const std::string& name, size_t bytes);
+  void release(const std::string& name);
+  void release_all();
+};
+
+#define SCL_HIP(ctx, expr)                                                                       \
+  do {                                                                                           \
+    hipError_t e__ = (expr);                                                                     \
+    if (e__ != hipSuccess) {                                                                     \
+      return (ctx)->fail(e__ == hipErrorOutOfMemory ? SCLENS_ERR_OOM : SCLENS_ERR_HIP,           \
+                         std::string(#expr) + ": " + hipGetErrorString(e__) + " (" + __FILE__ +  \
+                             ":" + std::to_string(__LINE__) + ")");                              \
+    }                                                                                            \
+  } while (0)
+
+#define SCL_TRY(expr)                 \
+  do {                                \
+    int rc__ = (expr);                \
+    if (rc__ != SCLENS_OK) return rc__; \
+  } while (0)
+
+#define SCL_WS(ctx, var, type, name, count)                                                     \
+  type* var = static_cast<type*>((ctx)->workspace((name), sizeof(type) * (size_t)(count)));     \
+  if (!(var) && (count) > 0) return SCLENS_ERR_OOM
+
+struct StageTimer {  // HIP-event timing of one stage on ctx->stream (only when ctx->timing)
+  Ctx* c;
+  const char* name;
+  StageTimer(Ctx* ctx, const char* n) : c(ctx), name(n) {
+    if (c->timing) hipEventRecord(c->ev0, c->stream);
+  }
+  ~StageTimer() {
+    if (c->timing) {
+      hipEventRecord(c->ev1, c->stream);
+      hipEventSynchronize(c->ev1);
+      float ms = 0;
+      hipEventElapsedTime(&ms, c->ev0, c->ev1);
+      c->t_ms[name] += ms;
+      c->t_calls[name] += 1;
+    }
+  }
+};
+
+static inline int64_t round_up(int64_t x, int64_t m) { return (x + m - 1) / m * m; }
+
+// ------------------------------------------------------------------ GEMM (gemm.hip)
+// C[M x N] (ldc) = alpha * P[M x K] * op(Q) + beta * C, everything row-major fp32.
+//   P is [M][K] with K contiguous (ldp).
+//   q_kcontig = 1: Q is [N][K] with K contiguous (ldq)   ("NT":  C = P * Q^T)
+//   q_kcontig = 0: Q is [K][N] with N contiguous (ldq)   ("NN":  C = P * Q)
+//   lower = 1: M == N, only tiles on/below the diagonal are computed and every value is also
+//              written to its mirrored position (exactly symmetric result).
+//   colabsmax != nullptr: C is not written; colabsmax[n] = max(colabsmax[n], max_m |alpha*acc|)
+//              (caller zero-fills colabsmax; values are float bit patterns of non-negative floats).
+struct GemmArgs {
+  const float* P;
+  const float* Q;
+  float* C;
+  int64_t M, N, K;
+  int64_t ldp, ldq, ldc;
+  float alpha, beta;
+  int q_kcontig;
+  int lower;
+  unsigned* colabsmax;
+};
+int gemm_f32(Ctx* ctx, const GemmArgs& a);
+
+// ------------------------------------------------------------------ eigensolver (tridiag.hip, trieig.hip)
+// Symmetric eigensolver on a device-resident n x n fp32 matrix A (row-major, lda, FULL storage,
+// exactly symmetric). A is destroyed (holds the Householder reflectors afterwards).
+//   w64[n]      : all eigenvalues ascending (fp64, of the fp32-tridiagonalised matrix)
+//   vec_lo/hi   : eigenvectors for ascending indices [vec_lo, vec_hi) are written to
+//                 Zt[(idx - vec_lo) * ldz + i], i.e. one eigenvector per ROW (fp32).
+int eigh_f32(Ctx* ctx, float* A, int64_t n, int64_t lda, double* w64_dev, int64_t vec_lo,
+             int64_t vec_hi, float* Zt, int64_t ldz);
+
+// the same in two phases (values first, vectors of a range chosen afterwards); state lives in ctx workspaces
+int eig_values(Ctx* ctx, float* A, int64_t n, int64_t lda, double* w64_dev);
+int eig_vectors(Ctx* ctx, const float* A, int64_t n, int64_t lda, const double* w64_dev, int64_t vec_lo,
+                int64_t vec_hi, float* Zt, int64_t ldz);
+
+// pieces (exposed for unit tests through the C ABI)
+int sytrd_f32(Ctx* ctx, float* A, int64_t n, int64_t lda, double* d_dev, double* e_dev,
+              float* tau_dev);
+int stebz_f64(Ctx* ctx, const double* d_dev, const double* e_dev, int64_t n, double* w_dev);
+int stein_f64(Ctx* ctx, const double* d_dev, const double* e_dev, int64_t n, const double* w_dev,
+              int64_t lo, int64_t hi, float* Zt, int64_t ldz);
+int ormtr_f32(Ctx* ctx, const float* A, int64_t n, int64_t lda, const float* tau_dev, float* Zt,
+              int64_t m, int64_t ldz);
+
+// ------------------------------------------------------------------ small device helpers (util.hip)
+int fill_f32(Ctx* ctx, float* p, int64_t n, float v);
+int normalize_rows_f32(Ctx* ctx, float* A, int64_t rows, int64_t cols, int64_t ld);
+int scale_rows_f32(Ctx* ctx, float* A, int64_t rows, int64_t cols, int64_t ld, const float* s);
+// out[c*ldo + r] = in[r*ldi + c]
+int transpose_f32(Ctx* ctx, const float* in, int64_t rows, int64_t cols, int64_t ldi, float* out, int64_t ldo);
+// out row q = in row (rows-1-q)
+int reverse_rows_f32(Ctx* ctx, const float* in, int64_t rows, int64_t cols, int64_t ldi, float* out, int64_t ldo);
+// A (n x n, lda, zero padded) = B B^T / divisor for B [n x K] row-major (ldb), exactly symmetric
+int gram_f32(Ctx* ctx, const float* B, int64_t n, int64_t K, int64_t ldb, float divisor, float* A, int64_t lda);
+
+}  // namespace scl

@@ -1,0 +1,48 @@
+// Sparse pattern shared by every matrix of one sclens() call: stored counts UNION zero candidates
+// (scLENS.jl:664-673), held on the device as a CSC view plus a CSR view of the same slots.
+#pragma once
+#include "common.h"
+
+namespace scl {
+
+struct PatternDev {
+  int64_t N = 0, M = 0, nU = 0, ncand = 0;
+  const int64_t* colptr = nullptr;   // [M+1]  CSC: per column the stored counts (rows ascending), then candidates
+  const int32_t* row = nullptr;      // [nU]
+  const int64_t* rowptr = nullptr;   // [N+1]  CSR view (columns ascending inside a row)
+  const int64_t* csr2csc = nullptr;  // [nU]   CSC slot of each CSR slot
+  const int32_t* csrcol = nullptr;   // [nU]
+  const int64_t* cand_pos = nullptr; // [ncand] CSC slot of candidate t
+};
+
+struct PatternOwner {  // owns the device arrays of a PatternDev
+  PatternDev dev;
+  float* base_val = nullptr;  // [nU] stored counts, 0 in candidate slots
+  std::vector<void*> allocs;
+};
+
+// Build on the host (O(nU)) and upload. Indices are 0-based. z1/z2 may be null when ncand == 0.
+int pattern_build(Ctx* ctx, int64_t N, int64_t M, const int64_t* colptr, const int32_t* rowval, const float* nzval,
+                  int64_t ncand, const uint32_t* z1, const uint32_t* z2, PatternOwner* out);
+void pattern_free(PatternOwner* p);
+
+struct ScaleVecs {  // host destinations for rec_vals (scLENS.jl:676-696); all fp64
+  double* tgc;        // [N]
+  double* mat2_mean;  // [M]
+  double* mat2_std;   // [M]
+  double* norm_tgc;   // [N]
+  double* cent;       // [M]
+};
+
+// Dense scaled matrix from a value array over the pattern.
+//   f32path = 1 : closure path logn_scale(pre_scale(x)) (Float32 proj_l/log1p/std)
+//   f32path = 0 : inline Float64 path of the data matrix (scLENS.jl:676-696)
+//   cells_major = 1 : B[i*ldb + j] (N rows of M genes); 0 : B[j*ldb + i] (M rows of N cells)
+int scale_to_dense(Ctx* ctx, const PatternDev& p, const float* val, int f32path, int cells_major, float* B,
+                   int64_t ldb, ScaleVecs* keep);
+
+// val = (binary ? pattern-of-counts : counts), then 1 at the candidate slots idx_dev[0..m)
+int make_values(Ctx* ctx, const PatternDev& p, const float* base_val, int binary, const uint32_t* idx_dev, int64_t m,
+                float* out);
+
+}  // namespace scl

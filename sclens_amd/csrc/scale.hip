@@ -1,0 +1,306 @@
+// Normalisation of a sparse count matrix into the dense, scaled fp32 matrix the Gram kernel consumes.
+// Device restatement of `logn_scale(pre_scale(x))` (scLENS.jl:650-652 -> proj_l :607, log1p,
+// zscore_with_l2 :596-605, scaled_gdata "cent" :300-305) and of its inline Float64 twin for the
+// data matrix (scLENS.jl:676-696, which also yields rec_vals). The reference densifies on the host
+// with 2-3 N x M Float64 temporaries; here all statistics are O(nnz) passes over a fixed sparse
+// pattern (CSC + CSR views of the same entries) and the dense matrix is written exactly once:
+//     X_ij = s_i (Z_ij - mu_j) - cent_j ,   Z_ij = log1p(x_ij / TGC_i) / std_j ,  s_i = mean(l)/l_i
+// (the identity of scLENS.jl:601-603 / :688-690 for l_i). Statistics are accumulated in fp64 in a
+// fixed order (deterministic); the dense output is fp32.
+//
+// The pattern is the union of the stored counts and the zero-candidate positions (scLENS.jl:668-673);
+// a perturbed matrix (scLENS.jl:735, :774) is just another value array over the same pattern, so a
+// perturbation costs one scatter of ones instead of a sparse(...) rebuild.
+#include "common.h"
+#include "pattern.h"
+
+namespace scl {
+
+__device__ __forceinline__ double wsum(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+
+// ---- K1: row sums (CSR view), one wave per row ---------------------------------------------------
+__global__ __launch_bounds__(256) void k_row_sums(PatternDev p, const float* __restrict__ val,
+                                                  double* __restrict__ tgc) {
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (row >= p.N) return;
+  double s = 0.0;
+  for (int64_t q = p.rowptr[row] + lane; q < p.rowptr[row + 1]; q += 64) s += (double)val[p.csr2csc[q]];
+  s = wsum(s);
+  if (lane == 0) tgc[row] = s;
+}
+
+// ---- K2: lg = log1p(x / TGC_row) per stored entry (CSC order) + column mean/std -------------------
+// f32path = 1: the closure path (Float32 proj_l + log1p, Float32 std)
+__global__ __launch_bounds__(256) void k_col_stats(PatternDev p, const float* __restrict__ val,
+                                                   const double* __restrict__ tgc, int f32path,
+                                                   double* __restrict__ lg, double* __restrict__ mean,
+                                                   double* __restrict__ stdv, double* __restrict__ mu) {
+  const int64_t col = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (col >= p.M) return;
+  const int64_t b = p.colptr[col], e = p.colptr[col + 1];
+  double s = 0.0;
+  for (int64_t q = b + lane; q < e; q += 64) {
+    const float v = val[q];
+    double l = 0.0;
+    if (v != 0.f) {
+      const int64_t r = p.row[q];
+      if (f32path) {
+        const float inv = 1.0f / (float)tgc[r];
+        l = (double)log1pf(inv * v);
+      } else {
+        l = log1p((double)v / tgc[r]);
+      }
+    }
+    lg[q] = l;
+    s += l;
+  }
+  s = wsum(s);
+  const double m = s / (double)p.N;
+  double s2 = 0.0;
+  for (int64_t q = b + lane; q < e; q += 64) {
+    const double dlt = lg[q] - m;  // written by this lane above
+    s2 += dlt * dlt;
+  }
+  s2 = wsum(s2);
+  s2 += (double)(p.N - (e - b)) * m * m;  // implicit zeros
+  double sd = sqrt(s2 / (double)(p.N - 1));
+  if (f32path) sd = (double)(float)sd;
+  if (lane == 0) {
+    mean[col] = f32path ? (double)(float)m : m;
+    stdv[col] = sd;
+    mu[col] = (s / sd) / (double)p.N;  // mean of the std-scaled column
+  }
+}
+
+// ---- deterministic reductions of a vector: out[0] = sum(f(v)) ---------------------------------------
+// mode 0: sum v^2, mode 1: sum v, mode 2: sum 1/v
+__global__ __launch_bounds__(1024) void k_reduce(const double* __restrict__ v, int64_t n, int mode,
+                                                 double* __restrict__ out) {
+  __shared__ double sw[16];
+  double s = 0.0;
+  for (int64_t i = threadIdx.x; i < n; i += 1024) {
+    const double x = v[i];
+    s += (mode == 0) ? x * x : (mode == 1 ? x : 1.0 / x);
+  }
+  s = wsum(s);
+  if ((threadIdx.x & 63) == 0) sw[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double t = 0.0;
+    for (int w = 0; w < 16; ++w) t += sw[w];
+    out[0] = t;
+  }
+}
+
+// ---- K3: row L2 norms of the centred row (CSR view) ------------------------------------------------
+__global__ __launch_bounds__(256) void k_row_norms(PatternDev p, const double* __restrict__ lg,
+                                                   const double* __restrict__ stdv, const double* __restrict__ mu,
+                                                   const double* __restrict__ mu2sum, double* __restrict__ l2) {
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (row >= p.N) return;
+  double zz = 0.0, zm = 0.0;
+  for (int64_t q = p.rowptr[row] + lane; q < p.rowptr[row + 1]; q += 64) {
+    const int64_t pos = p.csr2csc[q];
+    const int64_t c = p.csrcol[q];
+    const double z = lg[pos] / stdv[c];
+    zz += z * z;
+    zm += z * mu[c];
+  }
+  zz = wsum(zz);
+  zm = wsum(zm);
+  if (lane == 0) l2[row] = sqrt(zz - 2.0 * zm + mu2sum[0]);
+}
+
+// s_i = mean(l) / l_i
+__global__ void k_row_scale(const double* __restrict__ l2, int64_t N, const double* __restrict__ lsum,
+                            double* __restrict__ srow) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < N) srow[i] = (lsum[0] / (double)N) / l2[i];
+}
+
+// ---- K4: cent_j = mean_i s_i (Z_ij - mu_j) (CSC view) ----------------------------------------------
+__global__ __launch_bounds__(256) void k_col_cent(PatternDev p, const double* __restrict__ lg,
+                                                  const double* __restrict__ stdv, const double* __restrict__ mu,
+                                                  const double* __restrict__ srow, const double* __restrict__ ssum,
+                                                  double* __restrict__ cent) {
+  const int64_t col = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (col >= p.M) return;
+  double s = 0.0;
+  for (int64_t q = p.colptr[col] + lane; q < p.colptr[col + 1]; q += 64) s += srow[p.row[q]] * lg[q];
+  s = wsum(s);
+  if (lane == 0) cent[col] = (s / stdv[col] - mu[col] * ssum[0]) / (double)p.N;
+}
+
+// ---- K5: dense write. cells_major = 1: B[i][j] (ld over genes); 0: B[j][i] (ld over cells) ---------
+__global__ __launch_bounds__(256) void k_dense_fill(int64_t N, int64_t M, int cells_major,
+                                                    const double* __restrict__ srow, const double* __restrict__ mu,
+                                                    const double* __restrict__ cent, float* __restrict__ B,
+                                                    int64_t ldb) {
+  // grid.y = B row, grid.x over the contiguous dimension
+  const int64_t r = blockIdx.y;
+  const int64_t c = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
+  const int64_t nc = cells_major ? M : N;
+  if (c >= nc) return;
+  float out[4];
+  if (cells_major) {
+    const double s = srow[r];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) out[e] = (c + e < nc) ? (float)(-s * mu[c + e] - cent[c + e]) : 0.f;
+  } else {
+    const double m = mu[r], ce = cent[r];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) out[e] = (c + e < nc) ? (float)(-srow[c + e] * m - ce) : 0.f;
+  }
+  float* dst = B + r * ldb + c;
+  if (c + 3 < ldb) {
+    *reinterpret_cast<float4*>(dst) = make_float4(out[0], out[1], out[2], out[3]);
+  } else {
+    for (int e = 0; e < 4 && c + e < ldb; ++e) dst[e] = out[e];
+  }
+}
+
+__global__ __launch_bounds__(256) void k_dense_scatter(PatternDev p, int cells_major, const float* __restrict__ val,
+                                                       const double* __restrict__ lg, const double* __restrict__ stdv,
+                                                       const double* __restrict__ mu, const double* __restrict__ cent,
+                                                       const double* __restrict__ srow, float* __restrict__ B,
+                                                       int64_t ldb) {
+  const int64_t col = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (col >= p.M) return;
+  const double isd = 1.0 / stdv[col], m = mu[col], ce = cent[col];
+  for (int64_t q = p.colptr[col] + lane; q < p.colptr[col + 1]; q += 64) {
+    if (val[q] == 0.f) continue;
+    const int64_t r = p.row[q];
+    const float x = (float)(srow[r] * (lg[q] * isd - m) - ce);
+    if (cells_major) B[r * ldb + col] = x;
+    else B[col * ldb + r] = x;
+  }
+}
+
+int scale_to_dense(Ctx* ctx, const PatternDev& p, const float* val, int f32path, int cells_major, float* B,
+                   int64_t ldb, ScaleVecs* keep) {
+  StageTimer tm(ctx, "scale");
+  const int64_t N = p.N, M = p.M;
+  SCL_WS(ctx, tgc, double, "sc.tgc", N);
+  SCL_WS(ctx, lg, double, "sc.lg", p.nU);
+  SCL_WS(ctx, mean, double, "sc.mean", M);
+  SCL_WS(ctx, stdv, double, "sc.std", M);
+  SCL_WS(ctx, mu, double, "sc.mu", M);
+  SCL_WS(ctx, l2, double, "sc.l2", N);
+  SCL_WS(ctx, srow, double, "sc.srow", N);
+  SCL_WS(ctx, cent, double, "sc.cent", M);
+  SCL_WS(ctx, red, double, "sc.red", 8);
+  hipStream_t st = ctx->stream;
+  hipLaunchKernelGGL(k_row_sums, dim3((unsigned)((N + 3) / 4)), dim3(256), 0, st, p, val, tgc);
+  hipLaunchKernelGGL(k_col_stats, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, st, p, val, tgc, f32path, lg, mean,
+                     stdv, mu);
+  hipLaunchKernelGGL(k_reduce, dim3(1), dim3(1024), 0, st, mu, M, 0, red + 0);  // ||mu||^2
+  hipLaunchKernelGGL(k_row_norms, dim3((unsigned)((N + 3) / 4)), dim3(256), 0, st, p, lg, stdv, mu, red + 0, l2);
+  hipLaunchKernelGGL(k_reduce, dim3(1), dim3(1024), 0, st, l2, N, 1, red + 1);  // sum l
+  hipLaunchKernelGGL(k_row_scale, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, st, l2, N, red + 1, srow);
+  hipLaunchKernelGGL(k_reduce, dim3(1), dim3(1024), 0, st, srow, N, 1, red + 2);  // sum s
+  hipLaunchKernelGGL(k_col_cent, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, st, p, lg, stdv, mu, srow, red + 2,
+                     cent);
+  const int64_t nr = cells_major ? N : M, nc = cells_major ? M : N;
+  if (nr > 65535LL * 65535LL) return ctx->fail(SCLENS_ERR_ARG, "scale_to_dense: too many rows");
+  // grid.y is limited to 65535: loop over row slabs
+  for (int64_t r0 = 0; r0 < nr; r0 += 65535) {
+    const int64_t rows = (nr - r0 < 65535) ? nr - r0 : 65535;
+    hipLaunchKernelGGL(k_dense_fill, dim3((unsigned)((nc + 1023) / 1024), (unsigned)rows), dim3(256), 0, st, N, M,
+                       cells_major, cells_major ? srow + r0 : srow, cells_major ? mu : mu + r0,
+                       cells_major ? cent : cent + r0, B + r0 * ldb, ldb);
+  }
+  hipLaunchKernelGGL(k_dense_scatter, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, st, p, cells_major, val, lg, stdv,
+                     mu, cent, srow, B, ldb);
+  SCL_HIP(ctx, hipGetLastError());
+  if (keep) {  // rec_vals of the data matrix (scLENS.jl:676-696) -> host
+    SCL_HIP(ctx, hipMemcpyAsync(keep->tgc, tgc, sizeof(double) * N, hipMemcpyDeviceToHost, st));
+    SCL_HIP(ctx, hipMemcpyAsync(keep->mat2_mean, mean, sizeof(double) * M, hipMemcpyDeviceToHost, st));
+    SCL_HIP(ctx, hipMemcpyAsync(keep->mat2_std, stdv, sizeof(double) * M, hipMemcpyDeviceToHost, st));
+    SCL_HIP(ctx, hipMemcpyAsync(keep->norm_tgc, l2, sizeof(double) * N, hipMemcpyDeviceToHost, st));
+    SCL_HIP(ctx, hipMemcpyAsync(keep->cent, cent, sizeof(double) * M, hipMemcpyDeviceToHost, st));
+    SCL_HIP(ctx, hipStreamSynchronize(st));
+  }
+  return SCLENS_OK;
+}
+
+// ---- value arrays over the pattern ------------------------------------------------------------------
+// out[q] = binary ? (base[q] != 0) : base[q]     (candidate slots have base 0)
+__global__ void k_val_init(const float* __restrict__ base, int64_t nU, int binary, float* __restrict__ out) {
+  const int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (q < nU) {
+    const float b = base[q];
+    out[q] = binary ? (b != 0.f ? 1.f : 0.f) : b;
+  }
+}
+// out[cand_pos[idx[t]]] = 1
+__global__ void k_val_set_ones(const uint32_t* __restrict__ idx, int64_t m, const int64_t* __restrict__ cand_pos,
+                               float* __restrict__ out) {
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t < m) out[cand_pos[idx[t]]] = 1.f;
+}
+
+int make_values(Ctx* ctx, const PatternDev& p, const float* base_val, int binary, const uint32_t* idx_dev, int64_t m,
+                float* out) {
+  hipLaunchKernelGGL(k_val_init, dim3((unsigned)((p.nU + 255) / 256)), dim3(256), 0, ctx->stream, base_val, p.nU,
+                     binary, out);
+  if (m > 0)
+    hipLaunchKernelGGL(k_val_set_ones, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, ctx->stream, idx_dev, m,
+                       p.cand_pos, out);
+  SCL_HIP(ctx, hipGetLastError());
+  return SCLENS_OK;
+}
+
+// ---- small helpers ----------------------------------------------------------------------------------
+__global__ void k_fill(float* p, int64_t n, float v) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) p[i] = v;
+}
+int fill_f32(Ctx* ctx, float* p, int64_t n, float v) {
+  if (n <= 0) return SCLENS_OK;
+  hipLaunchKernelGGL(k_fill, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, p, n, v);
+  SCL_HIP(ctx, hipGetLastError());
+  return SCLENS_OK;
+}
+
+__global__ __launch_bounds__(256) void k_normalize_rows(float* A, int64_t rows, int64_t cols, int64_t ld) {
+  __shared__ double sw[4];
+  const int64_t r = blockIdx.x;
+  float* a = A + r * ld;
+  double s = 0.0;
+  for (int64_t c = threadIdx.x; c < cols; c += 256) s += (double)a[c] * (double)a[c];
+  s = wsum(s);
+  if ((threadIdx.x & 63) == 0) sw[threadIdx.x >> 6] = s;
+  __syncthreads();
+  const double inv = 1.0 / sqrt(sw[0] + sw[1] + sw[2] + sw[3]);
+  for (int64_t c = threadIdx.x; c < cols; c += 256) a[c] = (float)((double)a[c] * inv);
+}
+int normalize_rows_f32(Ctx* ctx, float* A, int64_t rows, int64_t cols, int64_t ld) {
+  if (rows <= 0) return SCLENS_OK;
+  hipLaunchKernelGGL(k_normalize_rows, dim3((unsigned)rows), dim3(256), 0, ctx->stream, A, rows, cols, ld);
+  SCL_HIP(ctx, hipGetLastError());
+  return SCLENS_OK;
+}
+
+__global__ void k_scale_rows(float* A, int64_t rows, int64_t cols, int64_t ld, const float* s) {
+  const int64_t r = blockIdx.y;
+  const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (c < cols) A[r * ld + c] *= s[r];
+}
+int scale_rows_f32(Ctx* ctx, float* A, int64_t rows, int64_t cols, int64_t ld, const float* s) {
+  if (rows <= 0) return SCLENS_OK;
+  hipLaunchKernelGGL(k_scale_rows, dim3((unsigned)((cols + 255) / 256), (unsigned)rows), dim3(256), 0, ctx->stream,
+                     A, rows, cols, ld, s);
+  SCL_HIP(ctx, hipGetLastError());
+  return SCLENS_OK;
+}
+
+}  // namespace scl

@@ -1,0 +1,668 @@
+// Context, pattern builder, the device-resident session behind sclens() and the per-call drop-ins.
+// Reference call sites: sclens scLENS.jl:649-832, get_sigev :526-594, get_eigvec :489-524,
+// _wishart_matrix :332-361, _get_eigen :375-387, corr_mat :363-373.
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+
+#include "common.h"
+#include "pattern.h"
+
+namespace scl {
+
+// ------------------------------------------------------------------------------------------------ ctx
+void* Ctx::workspace(const std::string& name, size_t bytes) {
+  auto it = ws.find(name);
+  if (it != ws.end() && it->second.second >= bytes) return it->second.first;
+  if (it != ws.end()) {
+    hipStreamSynchronize(stream);
+    hipFree(it->second.first);
+    ws.erase(it);
+  }
+  if (bytes == 0) bytes = 16;
+  void* p = nullptr;
+  hipError_t e = hipMalloc(&p, bytes);
+  if (e != hipSuccess) {
+    fail(SCLENS_ERR_OOM, "hipMalloc(" + name + ", " + std::to_string(bytes) + " B): " + hipGetErrorString(e));
+    return nullptr;
+  }
+  ws[name] = {p, bytes};
+  return p;
+}
+void Ctx::release(const std::string& name) {
+  auto it = ws.find(name);
+  if (it != ws.end()) {
+    hipStreamSynchronize(stream);
+    hipFree(it->second.first);
+    ws.erase(it);
+  }
+}
+void Ctx::release_all() {
+  if (stream) hipStreamSynchronize(stream);
+  for (auto& kv : ws) hipFree(kv.second.first);
+  ws.clear();
+}
+
+// ------------------------------------------------------------------------------------------------ utils
+__global__ __launch_bounds__(256) void k_transpose(const float* __restrict__ in, int64_t rows, int64_t cols,
+                                                   int64_t ldi, float* __restrict__ out, int64_t ldo) {
+  __shared__ float tile[32][33];
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  const int64_t c0 = (int64_t)blockIdx.x * 32, r0 = (int64_t)blockIdx.y * 32;
+  for (int r = ty; r < 32; r += 8)
+    tile[r][tx] = (r0 + r < rows && c0 + tx < cols) ? in[(r0 + r) * ldi + c0 + tx] : 0.f;
+  __syncthreads();
+  for (int r = ty; r < 32; r += 8)
+    if (c0 + r < cols && r0 + tx < rows) out[(c0 + r) * ldo + r0 + tx] = tile[tx][r];
+}
+int transpose_f32(Ctx* ctx, const float* in, int64_t rows, int64_t cols, int64_t ldi, float* out, int64_t ldo) {
+  if (rows <= 0 || cols <= 0) return SCLENS_OK;
+  const int64_t gy = (rows + 31) / 32;
+  if (gy > 65535) {
+    // slab the row dimension
+    for (int64_t r0 = 0; r0 < rows; r0 += 65535LL * 32) {
+      const int64_t rr = std::min<int64_t>(rows - r0, 65535LL * 32);
+      hipLaunchKernelGGL(k_transpose, dim3((unsigned)((cols + 31) / 32), (unsigned)((rr + 31) / 32)), dim3(256), 0,
+                         ctx->stream, in + r0 * ldi, rr, cols, ldi, out + r0, ldo);
+    }
+  } else {
+    hipLaunchKernelGGL(k_transpose, dim3((unsigned)((cols + 31) / 32), (unsigned)gy), dim3(256), 0, ctx->stream, in,
+                       rows, cols, ldi, out, ldo);
+  }
+  SCL_HIP(ctx, hipGetLastError());
+  return SCLENS_OK;
+}
+__global__ void k_reverse_rows(const float* __restrict__ in, int64_t rows, int64_t cols, int64_t ldi,
+                               float* __restrict__ out, int64_t ldo) {
+  const int64_t q = blockIdx.y;
+  const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (c < cols) out[q * ldo + c] = in[(rows - 1 - q) * ldi + c];
+}
+int reverse_rows_f32(Ctx* ctx, const float* in, int64_t rows, int64_t cols, int64_t ldi, float* out, int64_t ldo) {
+  if (rows <= 0 || cols <= 0) return SCLENS_OK;
+  hipLaunchKernelGGL(k_reverse_rows, dim3((unsigned)((cols + 255) / 256), (unsigned)rows), dim3(256), 0, ctx->stream,
+                     in, rows, cols, ldi, out, ldo);
+  SCL_HIP(ctx, hipGetLastError());
+  return SCLENS_OK;
+}
+
+int gram_f32(Ctx* ctx, const float* B, int64_t n, int64_t K, int64_t ldb, float divisor, float* A, int64_t lda) {
+  StageTimer tm(ctx, "gram");
+  SCL_HIP(ctx, hipMemsetAsync(A, 0, sizeof(float) * (size_t)n * lda, ctx->stream));
+  GemmArgs g{};
+  g.P = B; g.Q = B; g.C = A;
+  g.M = n; g.N = n; g.K = K;
+  g.ldp = ldb; g.ldq = ldb; g.ldc = lda;
+  g.alpha = 1.0f / divisor; g.beta = 0.f;
+  g.q_kcontig = 1; g.lower = 1; g.colabsmax = nullptr;
+  return gemm_f32(ctx, g);
+}
+
+// ------------------------------------------------------------------------------------------------ pattern
+template <typename T>
+static int upload(Ctx* ctx, PatternOwner* o, const std::vector<T>& h, const T** dev) {
+  void* p = nullptr;
+  const size_t bytes = std::max<size_t>(16, h.size() * sizeof(T));
+  hipError_t e = hipMalloc(&p, bytes);
+  if (e != hipSuccess) return ctx->fail(SCLENS_ERR_OOM, std::string("pattern upload: ") + hipGetErrorString(e));
+  o->allocs.push_back(p);
+  if (!h.empty()) SCL_HIP(ctx, hipMemcpy(p, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice));
+  *dev = static_cast<const T*>(p);
+  return SCLENS_OK;
+}
+
+int pattern_build(Ctx* ctx, int64_t N, int64_t M, const int64_t* colptr, const int32_t* rowval, const float* nzval,
+                  int64_t ncand, const uint32_t* z1, const uint32_t* z2, PatternOwner* out) {
+  if (N <= 0 || M <= 0 || !colptr || (colptr[M] > 0 && (!rowval || !nzval)) || (ncand > 0 && (!z1 || !z2)))
+    return ctx->fail(SCLENS_ERR_ARG, "pattern_build: bad arguments");
+  const int64_t nnz = colptr[M];
+  const int64_t nU = nnz + ncand;
+  std::vector<int64_t> ucol(M + 1, 0);
+  for (int64_t j = 0; j < M; ++j) ucol[j + 1] = colptr[j + 1] - colptr[j];
+  for (int64_t t = 0; t < ncand; ++t) {
+    if (z2[t] >= (uint64_t)M || z1[t] >= (uint64_t)N) return ctx->fail(SCLENS_ERR_ARG, "candidate index out of range");
+    ucol[z2[t] + 1] += 1;
+  }
+  for (int64_t j = 0; j < M; ++j) ucol[j + 1] += ucol[j];
+  std::vector<int32_t> urow(nU);
+  std::vector<float> uval(nU, 0.f);
+  std::vector<int64_t> cpos(ncand);
+  std::vector<int64_t> cur(M);
+  for (int64_t j = 0; j < M; ++j) {
+    int64_t q = ucol[j];
+    for (int64_t s = colptr[j]; s < colptr[j + 1]; ++s, ++q) {
+      if (rowval[s] < 0 || rowval[s] >= N) return ctx->fail(SCLENS_ERR_ARG, "row index out of range");
+      urow[q] = rowval[s];
+      uval[q] = nzval[s];
+    }
+    cur[j] = q;
+  }
+  for (int64_t t = 0; t < ncand; ++t) {
+    const int64_t q = cur[z2[t]]++;
+    urow[q] = (int32_t)z1[t];
+    cpos[t] = q;
+  }
+  // CSR view
+  std::vector<int64_t> rptr(N + 1, 0);
+  for (int64_t q = 0; q < nU; ++q) rptr[urow[q] + 1] += 1;
+  for (int64_t i = 0; i < N; ++i) rptr[i + 1] += rptr[i];
+  std::vector<int64_t> c2c(nU);
+  std::vector<int32_t> ccol(nU);
+  {
+    std::vector<int64_t> rc(rptr.begin(), rptr.end() - 1);
+    for (int64_t j = 0; j < M; ++j)
+      for (int64_t q = ucol[j]; q < ucol[j + 1]; ++q) {
+        const int64_t s = rc[urow[q]]++;
+        c2c[s] = q;
+        ccol[s] = (int32_t)j;
+      }
+  }
+  out->dev.N = N; out->dev.M = M; out->dev.nU = nU; out->dev.ncand = ncand;
+  SCL_TRY(upload(ctx, out, ucol, &out->dev.colptr));
+  SCL_TRY(upload(ctx, out, urow, &out->dev.row));
+  SCL_TRY(upload(ctx, out, rptr, &out->dev.rowptr));
+  SCL_TRY(upload(ctx, out, c2c, &out->dev.csr2csc));
+  SCL_TRY(upload(ctx, out, ccol, &out->dev.csrcol));
+  SCL_TRY(upload(ctx, out, cpos, &out->dev.cand_pos));
+  const float* bv = nullptr;
+  SCL_TRY(upload(ctx, out, uval, &bv));
+  out->base_val = const_cast<float*>(bv);
+  return SCLENS_OK;
+}
+void pattern_free(PatternOwner* p) {
+  for (void* q : p->allocs) hipFree(q);
+  p->allocs.clear();
+  p->dev = PatternDev();
+  p->base_val = nullptr;
+}
+
+// ------------------------------------------------------------------------------------------------ session
+struct Session {
+  Ctx* ctx = nullptr;
+  int64_t N = 0, M = 0, n = 0, K = 0;
+  int cells_major = 1;  // N <= M: rows of B are cells (Gram over genes); else rows are genes
+  PatternOwner pat;
+  float* val = nullptr;       // [nU] working value array
+  float* Bmain = nullptr;     // scaled data matrix, [n][ldb]
+  float* Btmp = nullptr;      // scaled null / binary / perturbed matrix
+  int64_t ldb = 0;
+  float* A = nullptr;         // [n][lda] Gram / reflectors
+  int64_t lda = 0;
+  double* w64 = nullptr;      // [n] eigenvalues (device)
+  std::vector<double> w_host;
+  float* Zt = nullptr;        // eigenvector rows [cap][ldz]
+  int64_t ldz = 0, zcap = 0;
+  float* Vr2t = nullptr;      // [r][ldz]
+  int64_t r_vr2 = 0;
+  float* nVt = nullptr;       // signal vectors, cell side, descending, [k][ldn]
+  int64_t k = 0, ldn = 0;
+  std::vector<float*> ens;    // slot t: [ncols][ldn], descending
+  std::vector<int64_t> ens_cols;
+  uint32_t* idx_dev = nullptr;
+  int64_t idx_cap = 0;
+  bool have_spectrum = false;
+  std::vector<void*> allocs;
+
+  int dmalloc(void** p, size_t bytes) {
+    hipError_t e = hipMalloc(p, std::max<size_t>(bytes, 16));
+    if (e != hipSuccess) return ctx->fail(SCLENS_ERR_OOM, std::string("session hipMalloc: ") + hipGetErrorString(e));
+    allocs.push_back(*p);
+    return SCLENS_OK;
+  }
+  int ensure_zt(int64_t rows) {
+    if (rows <= zcap) return SCLENS_OK;
+    float* p = static_cast<float*>(ctx->workspace("ses.Zt", sizeof(float) * (size_t)rows * ldz));
+    if (!p) return SCLENS_ERR_OOM;
+    Zt = p;
+    zcap = rows;
+    return SCLENS_OK;
+  }
+  int upload_idx(const uint32_t* h, int64_t m) {
+    if (m > idx_cap) {
+      uint32_t* p = static_cast<uint32_t*>(ctx->workspace("ses.idx", sizeof(uint32_t) * (size_t)m));
+      if (!p) return SCLENS_ERR_OOM;
+      idx_dev = p;
+      idx_cap = m;
+    }
+    if (m > 0) SCL_HIP(ctx, hipMemcpyAsync(idx_dev, h, sizeof(uint32_t) * (size_t)m, hipMemcpyHostToDevice, ctx->stream));
+    return SCLENS_OK;
+  }
+  int fetch_w() {
+    w_host.resize(n);
+    SCL_HIP(ctx, hipMemcpyAsync(w_host.data(), w64, sizeof(double) * n, hipMemcpyDeviceToHost, ctx->stream));
+    SCL_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    for (double v : w_host)
+      if (v != v) return ctx->fail(SCLENS_ERR_NAN, "NaN eigenvalue");
+    return SCLENS_OK;
+  }
+  int64_t count_positive() const {
+    int64_t r = 0;
+    for (double v : w_host) r += (v > 0.0) ? 1 : 0;  // L .> 0 (scLENS.jl:495, :515)
+    return r;
+  }
+};
+
+int session_create(Ctx* ctx, int64_t N, int64_t M, const int64_t* colptr, const int32_t* rowval, const float* nzval,
+                   int64_t ncand, const uint32_t* z1, const uint32_t* z2, Session** out) {
+  Session* s = new Session();
+  s->ctx = ctx;
+  s->N = N; s->M = M;
+  s->n = std::min(N, M); s->K = std::max(N, M);
+  s->cells_major = (N <= M) ? 1 : 0;
+  int rc = pattern_build(ctx, N, M, colptr, rowval, nzval, ncand, z1, z2, &s->pat);
+  if (rc != SCLENS_OK) { delete s; return rc; }
+  s->ldb = round_up(s->K, 32);
+  s->lda = round_up(s->n, 32);
+  s->ldz = round_up(s->n, 32);
+  s->ldn = round_up(N, 32);
+  auto fail = [&](int code) { pattern_free(&s->pat); for (void* p : s->allocs) hipFree(p); delete s; return code; };
+  if ((rc = s->dmalloc((void**)&s->val, sizeof(float) * s->pat.dev.nU)) != SCLENS_OK) return fail(rc);
+  if ((rc = s->dmalloc((void**)&s->Bmain, sizeof(float) * (size_t)s->n * s->ldb)) != SCLENS_OK) return fail(rc);
+  if ((rc = s->dmalloc((void**)&s->Btmp, sizeof(float) * (size_t)s->n * s->ldb)) != SCLENS_OK) return fail(rc);
+  if ((rc = s->dmalloc((void**)&s->A, sizeof(float) * (size_t)s->n * s->lda)) != SCLENS_OK) return fail(rc);
+  if ((rc = s->dmalloc((void**)&s->w64, sizeof(double) * s->n)) != SCLENS_OK) return fail(rc);
+  *out = s;
+  return SCLENS_OK;
+}
+
+void session_destroy(Session* s) {
+  if (!s) return;
+  hipStreamSynchronize(s->ctx->stream);
+  pattern_free(&s->pat);
+  for (void* p : s->allocs) hipFree(p);
+  delete s;
+}
+
+// scaled dense matrix of `val` -> B, Gram -> A, eigenvalues -> w64/w_host
+static int decompose(Session* s, const PatternDev& p, const float* val, int f32path, float* B, float divisor,
+                     ScaleVecs* keep) {
+  SCL_TRY(scale_to_dense(s->ctx, p, val, f32path, s->cells_major, B, s->ldb, keep));
+  SCL_TRY(gram_f32(s->ctx, B, s->n, s->K, s->ldb, divisor, s->A, s->lda));
+  SCL_TRY(eig_values(s->ctx, s->A, s->n, s->lda, s->w64));
+  return s->fetch_w();
+}
+
+int session_spectrum(Session* s, const int64_t* rc_, const int32_t* rr_, const float* rv_, double* L, double* Lr,
+                     ScaleVecs* keep) {
+  Ctx* ctx = s->ctx;
+  // null matrix X_r (scLENS.jl:701, :704): closure path, eigenvalues only (:532, :572)
+  if (rc_) {
+    PatternOwner pr;
+    SCL_TRY(pattern_build(ctx, s->N, s->M, rc_, rr_, rv_, 0, nullptr, nullptr, &pr));
+    float* valr = static_cast<float*>(ctx->workspace("ses.valr", sizeof(float) * (size_t)pr.dev.nU));
+    int rc = valr ? SCLENS_OK : SCLENS_ERR_OOM;
+    if (rc == SCLENS_OK) rc = make_values(ctx, pr.dev, pr.base_val, 0, nullptr, 0, valr);
+    if (rc == SCLENS_OK) rc = decompose(s, pr.dev, valr, 1, s->Btmp, (float)s->M, nullptr);
+    hipStreamSynchronize(ctx->stream);
+    pattern_free(&pr);
+    SCL_TRY(rc);
+    if (Lr) std::copy(s->w_host.begin(), s->w_host.end(), Lr);
+  }
+  // data matrix: inline Float64 path with rec_vals (scLENS.jl:676-696); divisor size(X,2) = M
+  SCL_TRY(make_values(ctx, s->pat.dev, s->pat.base_val, 0, nullptr, 0, s->val));
+  SCL_TRY(decompose(s, s->pat.dev, s->val, 0, s->Bmain, (float)s->M, keep));
+  if (L) std::copy(s->w_host.begin(), s->w_host.end(), L);
+  s->have_spectrum = true;
+  return SCLENS_OK;
+}
+
+// rows of Zt (ascending eigen-index, gene- or cell-side, `cnt` rows) -> cell-side unit vectors,
+// descending, in dst[cnt][ldn]. For N > M: normalize(X * v) (scLENS.jl:503-508, :556-558; the
+// Lambda^-1/2 factor is positive and drops out of the normalisation).
+static int to_cell_side(Session* s, const float* B, int64_t cnt, float* dst) {
+  Ctx* ctx = s->ctx;
+  if (s->cells_major) return reverse_rows_f32(ctx, s->Zt, cnt, s->N, s->ldz, dst, s->ldn);
+  StageTimer tm(ctx, "recover");
+  float* tmp = static_cast<float*>(ctx->workspace("ses.rec", sizeof(float) * (size_t)cnt * s->ldn));
+  if (!tmp) return SCLENS_ERR_OOM;
+  GemmArgs g{};
+  g.P = s->Zt; g.Q = B; g.C = tmp;
+  g.M = cnt; g.N = s->N; g.K = s->M;
+  g.ldp = s->ldz; g.ldq = s->ldb; g.ldc = s->ldn;
+  g.alpha = 1.f; g.beta = 0.f; g.q_kcontig = 0; g.lower = 0; g.colabsmax = nullptr;
+  SCL_TRY(gemm_f32(ctx, g));
+  SCL_TRY(normalize_rows_f32(ctx, tmp, cnt, s->N, s->ldn));
+  return reverse_rows_f32(ctx, tmp, cnt, s->N, s->ldn, dst, s->ldn);
+}
+
+int session_signal_vectors(Session* s, int64_t k, float* nV) {
+  Ctx* ctx = s->ctx;
+  if (!s->have_spectrum) return ctx->fail(SCLENS_ERR_STATE, "signal_vectors: call spectrum first");
+  if (k < 0 || k > s->n) return ctx->fail(SCLENS_ERR_ARG, "signal_vectors: bad k");
+  s->k = k;
+  if (k == 0) return SCLENS_OK;
+  SCL_TRY(s->ensure_zt(k));
+  SCL_TRY(eig_vectors(ctx, s->A, s->n, s->lda, s->w64, s->n - k, s->n, s->Zt, s->ldz));
+  {
+    float* p = static_cast<float*>(ctx->workspace("ses.nVt", sizeof(float) * (size_t)k * s->ldn));
+    if (!p) return SCLENS_ERR_OOM;
+    s->nVt = p;
+  }
+  SCL_TRY(to_cell_side(s, s->Bmain, k, s->nVt));
+  if (nV) {
+    SCL_HIP(ctx, hipMemcpy2DAsync(nV, sizeof(float) * s->N, s->nVt, sizeof(float) * s->ldn, sizeof(float) * s->N, k,
+                                  hipMemcpyDeviceToHost, ctx->stream));
+    SCL_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  }
+  s->have_spectrum = false;  // reflectors are overwritten by the next decomposition
+  return SCLENS_OK;
+}
+
+int session_binary_basis(Session* s, double* L_bin, int64_t* r_out) {
+  Ctx* ctx = s->ctx;
+  SCL_TRY(make_values(ctx, s->pat.dev, s->pat.base_val, 1, nullptr, 0, s->val));
+  // get_eigvec(scaled', ...) for N > M / get_eigvec(scaled) otherwise: n x n Gram, divisor = K (Appendix A8)
+  SCL_TRY(decompose(s, s->pat.dev, s->val, 1, s->Btmp, (float)s->K, nullptr));
+  if (L_bin) std::copy(s->w_host.begin(), s->w_host.end(), L_bin);
+  const int64_t r = s->count_positive();
+  s->r_vr2 = r;
+  if (r_out) *r_out = r;
+  if (r == 0) return SCLENS_OK;
+  SCL_TRY(s->ensure_zt(r));
+  SCL_TRY(eig_vectors(ctx, s->A, s->n, s->lda, s->w64, s->n - r, s->n, s->Zt, s->ldz));
+  float* v = static_cast<float*>(ctx->workspace("ses.Vr2t", sizeof(float) * (size_t)r * s->ldz));
+  if (!v) return SCLENS_ERR_OOM;
+  s->Vr2t = v;
+  SCL_HIP(ctx, hipMemcpyAsync(v, s->Zt, sizeof(float) * (size_t)r * s->ldz, hipMemcpyDeviceToDevice, ctx->stream));
+  return SCLENS_OK;
+}
+
+int session_search_step(Session* s, const uint32_t* sample, int64_t m, int64_t n_2, double* d5, int64_t* r_it) {
+  Ctx* ctx = s->ctx;
+  if (!s->Vr2t) return ctx->fail(SCLENS_ERR_STATE, "search_step: call binary_basis first");
+  if (m < 0 || m > s->pat.dev.ncand) return ctx->fail(SCLENS_ERR_ARG, "search_step: bad sample size");
+  SCL_TRY(s->upload_idx(sample, m));
+  SCL_TRY(make_values(ctx, s->pat.dev, s->pat.base_val, 1, s->idx_dev, m, s->val));
+  SCL_TRY(decompose(s, s->pat.dev, s->val, 1, s->Btmp, (float)s->K, nullptr));
+  const int64_t r = s->count_positive();
+  if (r_it) *r_it = r;
+  // nV_2[:, end-n_2:end] (scLENS.jl:742): the n_2+1 smallest positive eigenvalues
+  int64_t cnt = std::min<int64_t>(n_2 + 1, r);
+  if (cnt < 5) return ctx->fail(SCLENS_ERR_ARG, "search_step: fewer than 5 columns to compare");
+  const int64_t lo = s->n - r;
+  SCL_TRY(s->ensure_zt(cnt));
+  SCL_TRY(eig_vectors(ctx, s->A, s->n, s->lda, s->w64, lo, lo + cnt, s->Zt, s->ldz));
+  unsigned* cmax = static_cast<unsigned*>(ctx->workspace("ses.cmax", sizeof(unsigned) * (size_t)cnt));
+  if (!cmax) return SCLENS_ERR_OOM;
+  {
+    StageTimer tm(ctx, "corr");
+    SCL_HIP(ctx, hipMemsetAsync(cmax, 0, sizeof(unsigned) * (size_t)cnt, ctx->stream));
+    GemmArgs g{};  // |Vr2' * nV_2| column maxima (scLENS.jl:742), never materialised
+    g.P = s->Vr2t; g.Q = s->Zt; g.C = nullptr;
+    g.M = s->r_vr2; g.N = cnt; g.K = s->n;
+    g.ldp = s->ldz; g.ldq = s->ldz; g.ldc = 0;
+    g.alpha = 1.f; g.beta = 0.f; g.q_kcontig = 1; g.lower = 0; g.colabsmax = cmax;
+    SCL_TRY(gemm_f32(ctx, g));
+  }
+  std::vector<float> d(cnt);
+  SCL_HIP(ctx, hipMemcpyAsync(d.data(), cmax, sizeof(float) * (size_t)cnt, hipMemcpyDeviceToHost, ctx->stream));
+  SCL_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  std::partial_sort(d.begin(), d.begin() + 5, d.end());
+  for (int i = 0; i < 5; ++i) d5[i] = (double)d[i];
+  return SCLENS_OK;
+}
+
+int session_perturb(Session* s, int64_t t, const uint32_t* sample, int64_t m, int64_t min_pc, double* nL_top,
+                    int64_t* ncols) {
+  Ctx* ctx = s->ctx;
+  if (t < 0 || min_pc <= 0) return ctx->fail(SCLENS_ERR_ARG, "perturb: bad slot / min_pc");
+  if (m < 0 || m > s->pat.dev.ncand) return ctx->fail(SCLENS_ERR_ARG, "perturb: bad sample size");
+  SCL_TRY(s->upload_idx(sample, m));
+  SCL_TRY(make_values(ctx, s->pat.dev, s->pat.base_val, 0, s->idx_dev, m, s->val));
+  SCL_TRY(decompose(s, s->pat.dev, s->val, 1, s->Btmp, (float)s->M, nullptr));
+  const int64_t r = s->count_positive();
+  const int64_t c = std::min<int64_t>(min_pc, r);
+  if (ncols) *ncols = c;
+  for (int64_t q = 0; q < min_pc; ++q) nL_top[q] = (q < c) ? s->w_host[s->n - 1 - q] : 0.0;
+  if ((int64_t)s->ens.size() <= t) { s->ens.resize(t + 1, nullptr); s->ens_cols.resize(t + 1, 0); }
+  s->ens_cols[t] = c;
+  if (c == 0) return SCLENS_OK;
+  SCL_TRY(s->ensure_zt(c));
+  SCL_TRY(eig_vectors(ctx, s->A, s->n, s->lda, s->w64, s->n - c, s->n, s->Zt, s->ldz));
+  float* slot = static_cast<float*>(ctx->workspace("ses.ens" + std::to_string(t), sizeof(float) * (size_t)min_pc * s->ldn));
+  if (!slot) return SCLENS_ERR_OOM;
+  s->ens[t] = slot;
+  return to_cell_side(s, s->Btmp, c, slot);
+}
+
+int session_get_perturbed(Session* s, int64_t t, float* out) {
+  Ctx* ctx = s->ctx;
+  if (t < 0 || t >= (int64_t)s->ens.size() || !s->ens[t]) return ctx->fail(SCLENS_ERR_ARG, "get_perturbed: empty slot");
+  SCL_HIP(ctx, hipMemcpy2DAsync(out, sizeof(float) * s->N, s->ens[t], sizeof(float) * s->ldn, sizeof(float) * s->N,
+                                s->ens_cols[t], hipMemcpyDeviceToHost, ctx->stream));
+  SCL_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return SCLENS_OK;
+}
+
+__global__ void k_gather_rows(const float* __restrict__ src, int64_t lds, const int32_t* __restrict__ pick, int64_t cols,
+                              float* __restrict__ dst, int64_t ldd) {
+  const int64_t q = blockIdx.y;
+  const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (c < cols) dst[q * ldd + c] = src[(int64_t)pick[q] * lds + c];
+}
+
+int session_robustness(Session* s, int64_t P, int32_t* a_b, double* b) {
+  Ctx* ctx = s->ctx;
+  const int64_t k = s->k;
+  if (k <= 0 || !s->nVt) return ctx->fail(SCLENS_ERR_STATE, "robustness: no signal vectors");
+  if (P < 1 || (int64_t)s->ens.size() < P) return ctx->fail(SCLENS_ERR_STATE, "robustness: ensemble incomplete");
+  int64_t cmax = 0;
+  for (int64_t t = 0; t < P; ++t) {
+    if (!s->ens[t] || s->ens_cols[t] <= 0) return ctx->fail(SCLENS_ERR_STATE, "robustness: empty ensemble slot");
+    cmax = std::max(cmax, s->ens_cols[t]);
+  }
+  // a_b[:, t] = argmax_c |nV' * nV_set[t]| per signal (scLENS.jl:788)
+  float* C1 = static_cast<float*>(ctx->workspace("ses.C1", sizeof(float) * (size_t)k * cmax));
+  float* sub = static_cast<float*>(ctx->workspace("ses.sub", sizeof(float) * (size_t)P * k * s->ldn));
+  int32_t* pick = static_cast<int32_t*>(ctx->workspace("ses.pick", sizeof(int32_t) * (size_t)k));
+  if (!C1 || !sub || !pick) return SCLENS_ERR_OOM;
+  std::vector<float> hC((size_t)k * cmax);
+  std::vector<int32_t> hp(k);
+  for (int64_t t = 0; t < P; ++t) {
+    const int64_t c = s->ens_cols[t];
+    GemmArgs g{};
+    g.P = s->nVt; g.Q = s->ens[t]; g.C = C1;
+    g.M = k; g.N = c; g.K = s->N;
+    g.ldp = s->ldn; g.ldq = s->ldn; g.ldc = cmax;
+    g.alpha = 1.f; g.beta = 0.f; g.q_kcontig = 1; g.lower = 0; g.colabsmax = nullptr;
+    SCL_TRY(gemm_f32(ctx, g));
+    SCL_HIP(ctx, hipMemcpyAsync(hC.data(), C1, sizeof(float) * (size_t)k * cmax, hipMemcpyDeviceToHost, ctx->stream));
+    SCL_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    for (int64_t i = 0; i < k; ++i) {
+      int32_t best = 0;
+      float bv = -1.f;
+      for (int64_t j = 0; j < c; ++j) {
+        const float v = std::fabs(hC[i * cmax + j]);
+        if (v > bv) { bv = v; best = (int32_t)j; }  // first maximum (Appendix A25)
+      }
+      hp[i] = best;
+      a_b[i + t * k] = best;
+    }
+    SCL_HIP(ctx, hipMemcpyAsync(pick, hp.data(), sizeof(int32_t) * k, hipMemcpyHostToDevice, ctx->stream));
+    hipLaunchKernelGGL(k_gather_rows, dim3((unsigned)((s->N + 255) / 256), (unsigned)k), dim3(256), 0, ctx->stream,
+                       s->ens[t], s->ldn, pick, s->N, sub + (size_t)t * k * s->ldn, s->ldn);
+    SCL_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  }
+  // all pairwise |sub_i' sub_j| at once: G = Sub Sub^T ((P k) x (P k)), then row maxima per block (:792-795)
+  const int64_t PK = P * k;
+  float* G = static_cast<float*>(ctx->workspace("ses.G2", sizeof(float) * (size_t)PK * PK));
+  if (!G) return SCLENS_ERR_OOM;
+  {
+    GemmArgs g{};
+    g.P = sub; g.Q = sub; g.C = G;
+    g.M = PK; g.N = PK; g.K = s->N;
+    g.ldp = s->ldn; g.ldq = s->ldn; g.ldc = PK;
+    g.alpha = 1.f; g.beta = 0.f; g.q_kcontig = 1; g.lower = 1; g.colabsmax = nullptr;
+    SCL_TRY(gemm_f32(ctx, g));
+  }
+  std::vector<float> hG((size_t)PK * PK);
+  SCL_HIP(ctx, hipMemcpyAsync(hG.data(), G, sizeof(float) * (size_t)PK * PK, hipMemcpyDeviceToHost, ctx->stream));
+  SCL_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  const int64_t npairs = P * (P - 1) / 2;
+  int64_t col = 0;
+  for (int64_t i = 0; i < P; ++i)
+    for (int64_t j = i + 1; j < P; ++j, ++col)
+      for (int64_t a = 0; a < k; ++a) {
+        float mx = 0.f;
+        for (int64_t c = 0; c < k; ++c) mx = std::max(mx, std::fabs(hG[(size_t)(i * k + a) * PK + (j * k + c)]));
+        b[a * npairs + col] = (double)mx;
+      }
+  return SCLENS_OK;
+}
+
+int session_gene_basis(Session* s, const double* nL, float* out) {
+  Ctx* ctx = s->ctx;
+  const int64_t k = s->k;
+  if (k <= 0 || !s->nVt) return ctx->fail(SCLENS_ERR_STATE, "gene_basis: no signal vectors");
+  float* G = static_cast<float*>(ctx->workspace("ses.gb", sizeof(float) * (size_t)k * round_up(s->M, 32)));
+  float* sc = static_cast<float*>(ctx->workspace("ses.gbs", sizeof(float) * (size_t)k));
+  if (!G || !sc) return SCLENS_ERR_OOM;
+  const int64_t ldg = round_up(s->M, 32);
+  GemmArgs g{};
+  g.P = s->nVt; g.Q = s->Bmain; g.C = G;
+  g.M = k; g.N = s->M; g.K = s->N;
+  g.ldp = s->ldn; g.ldq = s->ldb; g.ldc = ldg;
+  g.alpha = 1.f; g.beta = 0.f; g.lower = 0; g.colabsmax = nullptr;
+  g.q_kcontig = s->cells_major ? 0 : 1;  // Bmain is [N][M] (NN) or [M][N] (NT)
+  SCL_TRY(gemm_f32(ctx, g));
+  std::vector<float> hs(k);
+  for (int64_t q = 0; q < k; ++q) hs[q] = (float)(1.0 / std::sqrt(nL[q]) / std::sqrt((double)s->M));
+  SCL_HIP(ctx, hipMemcpyAsync(sc, hs.data(), sizeof(float) * k, hipMemcpyHostToDevice, ctx->stream));
+  SCL_TRY(scale_rows_f32(ctx, G, k, s->M, ldg, sc));
+  SCL_HIP(ctx, hipMemcpy2DAsync(out, sizeof(float) * s->M, G, sizeof(float) * ldg, sizeof(float) * s->M, k,
+                                hipMemcpyDeviceToHost, ctx->stream));
+  SCL_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return SCLENS_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ drop-ins (A)
+static int upload_padded(Ctx* ctx, const float* h, int64_t rows, int64_t cols, float* d, int64_t ld) {
+  SCL_HIP(ctx, hipMemsetAsync(d, 0, sizeof(float) * (size_t)rows * ld, ctx->stream));
+  SCL_HIP(ctx, hipMemcpy2DAsync(d, sizeof(float) * ld, h, sizeof(float) * cols, sizeof(float) * cols, rows,
+                                hipMemcpyHostToDevice, ctx->stream));
+  return SCLENS_OK;
+}
+static int download_packed(Ctx* ctx, const float* d, int64_t rows, int64_t cols, int64_t ld, float* h) {
+  SCL_HIP(ctx, hipMemcpy2DAsync(h, sizeof(float) * cols, d, sizeof(float) * ld, sizeof(float) * cols, rows,
+                                hipMemcpyDeviceToHost, ctx->stream));
+  SCL_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return SCLENS_OK;
+}
+
+int wishart_host(Ctx* ctx, const float* X, int64_t N, int64_t M, int dims, float* Y) {
+  if (!X || !Y || N <= 0 || M <= 0 || (dims != 1 && dims != 2)) return ctx->fail(SCLENS_ERR_ARG, "wishart: bad arguments");
+  // column-major N x M == row-major [M][N]
+  const int64_t ldx = round_up(N, 32);
+  SCL_WS(ctx, dX, float, "w.X", M * ldx);
+  SCL_TRY(upload_padded(ctx, X, M, N, dX, ldx));
+  if (dims == 2) {  // X'X / M : rows = genes, K = N
+    const int64_t lda = round_up(M, 32);
+    SCL_WS(ctx, dA, float, "w.A", M * lda);
+    SCL_TRY(gram_f32(ctx, dX, M, N, ldx, (float)M, dA, lda));
+    return download_packed(ctx, dA, M, M, lda, Y);
+  }
+  const int64_t ldt = round_up(M, 32), lda = round_up(N, 32);
+  SCL_WS(ctx, dT, float, "w.T", N * ldt);
+  SCL_WS(ctx, dA, float, "w.A", N * lda);
+  SCL_HIP(ctx, hipMemsetAsync(dT, 0, sizeof(float) * (size_t)N * ldt, ctx->stream));
+  SCL_TRY(transpose_f32(ctx, dX, M, N, ldx, dT, ldt));
+  SCL_TRY(gram_f32(ctx, dT, N, M, ldt, (float)M, dA, lda));  // XX' / size(X,2)
+  return download_packed(ctx, dA, N, N, lda, Y);
+}
+
+int get_eigen_host(Ctx* ctx, const float* Y, int64_t n, float* L, float* V) {
+  if (!Y || !L || n <= 0) return ctx->fail(SCLENS_ERR_ARG, "get_eigen: bad arguments");
+  const int64_t lda = round_up(n, 32);
+  SCL_WS(ctx, dA, float, "e.A", n * lda);
+  SCL_WS(ctx, dw, double, "e.w", n);
+  SCL_TRY(upload_padded(ctx, Y, n, n, dA, lda));
+  float* dZ = nullptr;
+  if (V) {
+    dZ = static_cast<float*>(ctx->workspace("e.Z", sizeof(float) * (size_t)n * lda));
+    if (!dZ) return SCLENS_ERR_OOM;
+  }
+  SCL_TRY(eigh_f32(ctx, dA, n, lda, dw, 0, V ? n : 0, dZ, lda));
+  std::vector<double> w(n);
+  SCL_HIP(ctx, hipMemcpyAsync(w.data(), dw, sizeof(double) * n, hipMemcpyDeviceToHost, ctx->stream));
+  SCL_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  for (int64_t i = 0; i < n; ++i) {
+    if (w[i] != w[i]) return ctx->fail(SCLENS_ERR_NAN, "get_eigen: NaN eigenvalue");
+    L[i] = (float)w[i];
+  }
+  if (V) return download_packed(ctx, dZ, n, n, lda, V);  // row k = eigenvector k == column k in column-major
+  return SCLENS_OK;
+}
+
+int corr_mat_host(Ctx* ctx, const float* X, int64_t n, int64_t p, const float* Yv, int64_t q, float* out) {
+  if (!X || !Yv || !out || n <= 0 || p <= 0 || q <= 0) return ctx->fail(SCLENS_ERR_ARG, "corr_mat: bad arguments");
+  const int64_t ld = round_up(n, 32), ldc = round_up(p, 32);
+  SCL_WS(ctx, dX, float, "c.X", p * ld);
+  SCL_WS(ctx, dY, float, "c.Y", q * ld);
+  SCL_WS(ctx, dC, float, "c.C", q * ldc);
+  SCL_TRY(upload_padded(ctx, X, p, n, dX, ld));
+  SCL_TRY(upload_padded(ctx, Yv, q, n, dY, ld));
+  GemmArgs g{};  // column-major p x q == row-major [q][p] = Y' X
+  g.P = dY; g.Q = dX; g.C = dC;
+  g.M = q; g.N = p; g.K = n;
+  g.ldp = ld; g.ldq = ld; g.ldc = ldc;
+  g.alpha = 1.f; g.beta = 0.f; g.q_kcontig = 1; g.lower = 0; g.colabsmax = nullptr;
+  SCL_TRY(gemm_f32(ctx, g));
+  return download_packed(ctx, dC, q, p, ldc, out);
+}
+
+int get_eigvec_host(Ctx* ctx, const float* X, int64_t N, int64_t M, int64_t keep_top, float* nL, float* nV, int64_t* r) {
+  if (!X || !nL || !r || N <= 0 || M <= 0) return ctx->fail(SCLENS_ERR_ARG, "get_eigvec: bad arguments");
+  const int64_t n = std::min(N, M), K = std::max(N, M);
+  const int64_t cap = *r;
+  const int64_t ldx = round_up(N, 32);
+  SCL_WS(ctx, dX, float, "w.X", M * ldx);  // [M][N]
+  SCL_TRY(upload_padded(ctx, X, M, N, dX, ldx));
+  const float* B = dX;
+  int64_t ldb = ldx;
+  if (N <= M) {  // need [N][M]
+    const int64_t ldt = round_up(M, 32);
+    SCL_WS(ctx, dT, float, "w.T", N * ldt);
+    SCL_HIP(ctx, hipMemsetAsync(dT, 0, sizeof(float) * (size_t)N * ldt, ctx->stream));
+    SCL_TRY(transpose_f32(ctx, dX, M, N, ldx, dT, ldt));
+    B = dT;
+    ldb = ldt;
+  }
+  const int64_t lda = round_up(n, 32);
+  SCL_WS(ctx, dA, float, "w.A", n * lda);
+  SCL_WS(ctx, dw, double, "e.w", n);
+  SCL_TRY(gram_f32(ctx, B, n, K, ldb, (float)M, dA, lda));
+  SCL_TRY(eig_values(ctx, dA, n, lda, dw));
+  std::vector<double> w(n);
+  SCL_HIP(ctx, hipMemcpyAsync(w.data(), dw, sizeof(double) * n, hipMemcpyDeviceToHost, ctx->stream));
+  SCL_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  int64_t rp = 0;
+  for (double v : w) {
+    if (v != v) return ctx->fail(SCLENS_ERR_NAN, "get_eigvec: NaN eigenvalue");
+    rp += (v > 0.0) ? 1 : 0;
+  }
+  *r = rp;
+  if (rp > cap) return ctx->fail(SCLENS_ERR_ARG, "get_eigvec: output capacity too small");
+  for (int64_t c = 0; c < rp; ++c) nL[c] = (float)w[n - 1 - c];
+  int64_t nv = (keep_top > 0) ? std::min(keep_top, rp) : rp;
+  if (!nV || nv == 0) return SCLENS_OK;
+  SCL_WS(ctx, dZ, float, "e.Z", nv * lda);
+  SCL_TRY(eig_vectors(ctx, dA, n, lda, dw, n - nv, n, dZ, lda));
+  const int64_t ldn = round_up(N, 32);
+  SCL_WS(ctx, dO, float, "w.O", nv * ldn);
+  if (N > M) {
+    SCL_WS(ctx, dR, float, "w.R", nv * ldn);
+    GemmArgs g{};
+    g.P = dZ; g.Q = dX; g.C = dR;
+    g.M = nv; g.N = N; g.K = M;
+    g.ldp = lda; g.ldq = ldx; g.ldc = ldn;
+    g.alpha = 1.f; g.beta = 0.f; g.q_kcontig = 0; g.lower = 0; g.colabsmax = nullptr;
+    SCL_TRY(gemm_f32(ctx, g));
+    SCL_TRY(normalize_rows_f32(ctx, dR, nv, N, ldn));
+    SCL_TRY(reverse_rows_f32(ctx, dR, nv, N, ldn, dO, ldn));
+  } else {
+    SCL_TRY(reverse_rows_f32(ctx, dZ, nv, N, lda, dO, ldn));
+  }
+  return download_packed(ctx, dO, nv, N, ldn, nV);
+}
+
+}  // namespace scl

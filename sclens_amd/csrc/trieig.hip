@@ -1,0 +1,446 @@
+// Symmetric tridiagonal eigenproblem (fp64) + back-transformation (fp32 MFMA), device-resident.
+// Second and third phase of the replacement for the reference's `_get_eigen` (scLENS.jl:375-387).
+//
+//  * stebz_f64 : all eigenvalues by Sturm-count bisection, one thread per eigenvalue (ascending index;
+//                the reference's eigen()/syevd! also return ascending order).
+//  * stein_f64 : eigenvectors of selected indices by inverse iteration with a partially pivoted LU of
+//                T - lambda I (the dlagtf/dlagts/dstein scheme, restated from the published LAPACK
+//                algorithm), one thread per eigenvector, workspaces laid out [row][vector] so every
+//                access is coalesced. fp64 keeps eps/gap small enough that no re-orthogonalisation
+//                is needed for the simple spectra of this path (near-degenerate pairs are counted
+//                and reported).
+//  * ormtr_f32 : Z <- Q Z with Q = H_0 H_1 ... from sytrd_f32, as block reflectors (I - V T V^T)
+//                applied with three fp32 MFMA GEMMs per panel; T comes from the V^T v products that
+//                the tridiagonalisation already formed (no extra pass over V).
+#include "common.h"
+
+namespace scl {
+
+constexpr int NB = 128;  // must match tridiag.hip
+constexpr double EPS64 = 2.220446049250313e-16;
+constexpr double SFMIN64 = 2.2250738585072014e-308;
+
+// info[0]=gl, [1]=gu, [2]=pivmin, [3]=onenrm, [4]=tnorm(max abs entry)
+__global__ __launch_bounds__(1024) void tri_bounds(const double* __restrict__ d, const double* __restrict__ e,
+                                                   int64_t n, double* __restrict__ e2, double* __restrict__ info) {
+  __shared__ double s_lo[16], s_hi[16], s_e2[16], s_one[16], s_tn[16];
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  double lo = 1e300, hi = -1e300, me2 = 0.0, one = 0.0, tn = 0.0;
+  for (int64_t i = tid; i < n; i += 1024) {
+    const double el = (i > 0) ? fabs(e[i - 1]) : 0.0, er = (i < n - 1) ? fabs(e[i]) : 0.0;
+    const double di = d[i];
+    lo = fmin(lo, di - el - er);
+    hi = fmax(hi, di + el + er);
+    one = fmax(one, fabs(di) + el + er);
+    tn = fmax(tn, fmax(fabs(di), er));
+    if (i < n - 1) {
+      const double q = e[i] * e[i];
+      e2[i] = q;
+      me2 = fmax(me2, q);
+    }
+  }
+  for (int o = 32; o > 0; o >>= 1) {
+    lo = fmin(lo, __shfl_xor(lo, o));
+    hi = fmax(hi, __shfl_xor(hi, o));
+    me2 = fmax(me2, __shfl_xor(me2, o));
+    one = fmax(one, __shfl_xor(one, o));
+    tn = fmax(tn, __shfl_xor(tn, o));
+  }
+  if (lane == 0) { s_lo[wid] = lo; s_hi[wid] = hi; s_e2[wid] = me2; s_one[wid] = one; s_tn[wid] = tn; }
+  __syncthreads();
+  if (tid == 0) {
+    for (int w = 1; w < 16; ++w) {
+      lo = fmin(lo, s_lo[w]); hi = fmax(hi, s_hi[w]); me2 = fmax(me2, s_e2[w]);
+      one = fmax(one, s_one[w]); tn = fmax(tn, s_tn[w]);
+    }
+    const double pivmin = SFMIN64 * fmax(1.0, me2);
+    const double bn = fmax(fabs(lo), fabs(hi));
+    info[0] = lo - 2.0 * bn * EPS64 * (double)n - 2.0 * pivmin;
+    info[1] = hi + 2.0 * bn * EPS64 * (double)n + 2.0 * pivmin;
+    info[2] = pivmin;
+    info[3] = one;
+    info[4] = tn;
+  }
+}
+
+// One thread per eigenvalue index k: bisection on the Sturm count (#eigenvalues < x).
+__global__ __launch_bounds__(64) void tri_bisect(const double* __restrict__ d, const double* __restrict__ e2,
+                                                 int64_t n, const double* __restrict__ info,
+                                                 double* __restrict__ w) {
+  const int64_t k = (int64_t)blockIdx.x * 64 + threadIdx.x;
+  double lo = info[0], hi = info[1];
+  const double pivmin = info[2], atol = EPS64 * info[4];
+  const bool live = k < n;
+  for (int it = 0; it < 80; ++it) {
+    const bool done = (hi - lo) <= 2.0 * EPS64 * fmax(fabs(lo), fabs(hi)) + atol;
+    if (__all(done || !live)) break;
+    const double mid = 0.5 * (lo + hi);
+    double q = d[0] - mid;
+    if (fabs(q) < pivmin) q = -pivmin;
+    int64_t cnt = (q < 0.0) ? 1 : 0;
+    for (int64_t i = 1; i < n; ++i) {
+      q = d[i] - mid - e2[i - 1] / q;
+      if (fabs(q) < pivmin) q = -pivmin;
+      cnt += (q < 0.0) ? 1 : 0;
+    }
+    if (!done) {
+      if (cnt > k) hi = mid; else lo = mid;
+    }
+  }
+  if (live) w[k] = 0.5 * (lo + hi);
+}
+
+__device__ __forceinline__ double hash_uniform(uint64_t a, uint64_t b) {  // deterministic U(-1,1)
+  uint64_t z = a * 0x9E3779B97F4A7C15ull + b * 0xBF58476D1CE4E5B9ull + 0x94D049BB133111EBull;
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  z ^= z >> 31;
+  return (double)(z >> 11) * (2.0 / 9007199254740992.0) - 1.0;
+}
+
+// Inverse iteration, one thread per eigenvector t (eigenvalue index lo + t0 + t).
+// Workspaces are [n][B] (row i, vector t): element (i,t) at i*B + t.
+__global__ __launch_bounds__(64) void tri_stein(const double* __restrict__ d, const double* __restrict__ e,
+                                                int64_t n, const double* __restrict__ w, int64_t idx0,
+                                                int64_t count, int64_t B, const double* __restrict__ info,
+                                                double* __restrict__ wa, double* __restrict__ wb,
+                                                double* __restrict__ wc, double* __restrict__ wd,
+                                                unsigned char* __restrict__ win, double* __restrict__ wx,
+                                                int* __restrict__ fail_count) {
+  const int64_t t = (int64_t)blockIdx.x * 64 + threadIdx.x;
+  if (t >= count) return;
+  const int64_t gi = idx0 + t;
+  double lam = w[gi];
+  const double onenrm = info[3];
+  // separate numerically coincident shifts a little (dstein's PERTOL idea, index-local form)
+  if (gi > 0) {
+    const double prev = w[gi - 1];
+    const double pertol = 10.0 * fabs(EPS64 * lam);
+    if (lam - prev < pertol) lam = prev + pertol;
+  }
+#define AT(arr, i) arr[(i) * B + t]
+  if (n == 1) {
+    AT(wx, 0) = 1.0;
+    return;
+  }
+  // ---- dlagtf: LU of T - lam I with partial pivoting. a=diag, b=super, c=sub(multipliers), d2=2nd super
+  double ak = d[0] - lam;
+  double bk = e[0];
+  double scale1 = fabs(ak) + fabs(bk);
+  for (int64_t k = 0; k < n - 1; ++k) {
+    double ak1 = d[k + 1] - lam;
+    const double ck = e[k];
+    const double bk1 = (k < n - 2) ? e[k + 1] : 0.0;
+    double scale2 = fabs(ck) + fabs(ak1);
+    if (k < n - 2) scale2 += fabs(bk1);
+    const double piv1 = (ak == 0.0) ? 0.0 : fabs(ak) / scale1;
+    double a_out, b_out, c_out, d_out = 0.0, b_next = bk1;
+    unsigned char in_k;
+    if (ck == 0.0) {
+      in_k = 0; a_out = ak; b_out = bk; c_out = ck;
+    } else {
+      const double piv2 = fabs(ck) / scale2;
+      if (piv2 <= piv1) {
+        in_k = 0;
+        c_out = ck / ak;
+        ak1 -= c_out * bk;
+        a_out = ak; b_out = bk;
+      } else {
+        in_k = 1;
+        const double mult = ak / ck;
+        a_out = ck;
+        const double temp = ak1;
+        ak1 = bk - mult * temp;
+        if (k < n - 2) { d_out = bk1; b_next = -mult * d_out; }
+        b_out = temp;
+        c_out = mult;
+      }
+    }
+    scale1 = scale2;
+    AT(wa, k) = a_out; AT(wb, k) = b_out; AT(wc, k) = c_out; AT(win, k) = in_k;
+    if (k < n - 2) AT(wd, k) = d_out;
+    ak = ak1;
+    bk = b_next;
+  }
+  AT(wa, n - 1) = ak;
+  const double a_last = ak;
+  // dlagts tolerance (computed on first call when TOL <= 0)
+  double tol = 0.0;
+  for (int64_t k = 0; k < n; ++k) {
+    tol = fmax(tol, fabs(AT(wa, k)));
+    if (k < n - 1) tol = fmax(tol, fabs(AT(wb, k)));
+    if (k < n - 2) tol = fmax(tol, fabs(AT(wd, k)));
+  }
+  tol *= EPS64;
+  if (tol == 0.0) tol = EPS64;
+  // ---- start vector
+  for (int64_t i = 0; i < n; ++i) AT(wx, i) = hash_uniform((uint64_t)gi, (uint64_t)i);
+  const double dtpcrt = sqrt(0.1 / (double)n);
+  const double bignum = 1.0 / SFMIN64;
+  int nrmchk = 0, its = 0;
+  bool failed = false;
+  while (true) {
+    ++its;
+    if (its > 8) { failed = true; break; }
+    double xmax = 0.0;
+    for (int64_t i = 0; i < n; ++i) xmax = fmax(xmax, fabs(AT(wx, i)));
+    const double scl = (double)n * onenrm * fmax(EPS64, fabs(a_last)) / xmax;
+    // forward: y = L^-1 P (scl * x)
+    double yprev = AT(wx, 0) * scl;
+    for (int64_t k = 1; k < n; ++k) {
+      const double yk = AT(wx, k) * scl;
+      const double ck = AT(wc, k - 1);
+      double ynew;
+      if (AT(win, k - 1) == 0) {
+        ynew = yk - ck * yprev;
+        AT(wx, k - 1) = yprev;
+      } else {
+        AT(wx, k - 1) = yk;
+        ynew = yprev - ck * yk;
+      }
+      yprev = ynew;
+    }
+    AT(wx, n - 1) = yprev;
+    // backward with pivot perturbation
+    double y1 = 0.0, y2 = 0.0;  // y[k+1], y[k+2]
+    double nrm = 0.0;
+    for (int64_t k = n - 1; k >= 0; --k) {
+      double temp = AT(wx, k);
+      if (k <= n - 2) temp -= AT(wb, k) * y1;
+      if (k <= n - 3) temp -= AT(wd, k) * y2;
+      double akk = AT(wa, k);
+      double pert = copysign(tol, akk);
+      while (true) {
+        const double absak = fabs(akk);
+        if (absak < 1.0) {
+          if (absak < SFMIN64) {
+            if (absak == 0.0 || fabs(temp) * SFMIN64 > absak) { akk += pert; pert *= 2.0; continue; }
+            temp *= bignum; akk *= bignum;
+          } else if (fabs(temp) > absak * bignum) { akk += pert; pert *= 2.0; continue; }
+        }
+        break;
+      }
+      const double yk = temp / akk;
+      AT(wx, k) = yk;
+      nrm = fmax(nrm, fabs(yk));
+      y2 = y1; y1 = yk;
+    }
+    if (nrm < dtpcrt) continue;
+    ++nrmchk;
+    if (nrmchk < 3) continue;
+    break;
+  }
+  double s2 = 0.0;
+  for (int64_t i = 0; i < n; ++i) { const double v = AT(wx, i); s2 += v * v; }
+  const double inv = 1.0 / sqrt(s2);
+  for (int64_t i = 0; i < n; ++i) AT(wx, i) *= inv;
+  if (failed) atomicAdd(fail_count, 1);
+#undef AT
+}
+
+// wx [n][B] fp64 -> Zt rows (t0 + t) fp32: Zt[(t0+t)*ldz + i]
+__global__ __launch_bounds__(256) void tri_transpose_out(const double* __restrict__ wx, int64_t n, int64_t count,
+                                                         int64_t B, float* __restrict__ Zt, int64_t ldz,
+                                                         int64_t t0) {
+  __shared__ float tile[32][33];
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+  const int64_t tb = (int64_t)blockIdx.x * 32, ib = (int64_t)blockIdx.y * 32;
+  for (int r = ty; r < 32; r += 8) {
+    const int64_t i = ib + r, t = tb + tx;
+    tile[r][tx] = (i < n && t < count) ? (float)wx[i * B + t] : 0.f;
+  }
+  __syncthreads();
+  for (int r = ty; r < 32; r += 8) {
+    const int64_t t = tb + r, i = ib + tx;
+    if (t < count && i < n) Zt[(t0 + t) * ldz + i] = tile[tx][r];
+  }
+}
+
+int stebz_f64(Ctx* ctx, const double* d_dev, const double* e_dev, int64_t n, double* w_dev) {
+  StageTimer tm(ctx, "stebz");
+  SCL_WS(ctx, e2, double, "tri.e2", n + 1);
+  SCL_WS(ctx, info, double, "tri.info", 8);
+  hipLaunchKernelGGL(tri_bounds, dim3(1), dim3(1024), 0, ctx->stream, d_dev, e_dev, n, e2, info);
+  hipLaunchKernelGGL(tri_bisect, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, ctx->stream, d_dev, e2, n, info,
+                     w_dev);
+  SCL_HIP(ctx, hipGetLastError());
+  return SCLENS_OK;
+}
+
+int stein_f64(Ctx* ctx, const double* d_dev, const double* e_dev, int64_t n, const double* w_dev, int64_t lo,
+              int64_t hi, float* Zt, int64_t ldz) {
+  const int64_t m = hi - lo;
+  if (m <= 0) return SCLENS_OK;
+  StageTimer tm(ctx, "stein");
+  double* info = static_cast<double*>(ctx->workspace("tri.info", 8 * sizeof(double)));  // filled by stebz_f64
+  if (!info) return SCLENS_ERR_OOM;
+  // batch so that the six [n][B] workspaces stay below ~6 GiB
+  int64_t B = (int64_t)(6.0e9 / (41.0 * (double)n));
+  B = B / 64 * 64;
+  if (B < 64) B = 64;
+  if (B > round_up(m, 64)) B = round_up(m, 64);
+  SCL_WS(ctx, wa, double, "stein.a", n * B);
+  SCL_WS(ctx, wb, double, "stein.b", n * B);
+  SCL_WS(ctx, wc, double, "stein.c", n * B);
+  SCL_WS(ctx, wd, double, "stein.d", n * B);
+  SCL_WS(ctx, wx, double, "stein.x", n * B);
+  SCL_WS(ctx, win, unsigned char, "stein.in", n * B);
+  SCL_WS(ctx, failc, int, "stein.fail", 4);
+  SCL_HIP(ctx, hipMemsetAsync(failc, 0, sizeof(int), ctx->stream));
+  for (int64_t t0 = 0; t0 < m; t0 += B) {
+    const int64_t cnt = (m - t0 < B) ? m - t0 : B;
+    hipLaunchKernelGGL(tri_stein, dim3((unsigned)((cnt + 63) / 64)), dim3(64), 0, ctx->stream, d_dev, e_dev, n,
+                       w_dev, lo + t0, cnt, B, info, wa, wb, wc, wd, win, wx, failc);
+    hipLaunchKernelGGL(tri_transpose_out, dim3((unsigned)((cnt + 31) / 32), (unsigned)((n + 31) / 32)), dim3(256),
+                       0, ctx->stream, wx, n, cnt, B, Zt, ldz, t0);
+  }
+  SCL_HIP(ctx, hipGetLastError());
+  return SCLENS_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Block-reflector T factors for all panels at once (forward, columnwise; LAPACK dlarft recurrence):
+//   T[c][c] = tau_c,  T[0:c, c] = -tau_c * T[0:c, 0:c] * G[0:c, c],  G[cc][c] = V[:,cc]^T V[:,c] = Gst[p+c][cc]
+// Trep[pnl] is [NB][S*NB] with Trep[r][s*NB + k] = T[r][k] (S copies, see the split-K use in ormtr_f32).
+__global__ __launch_bounds__(NB) void build_T(const float* __restrict__ Gst, const float* __restrict__ tau,
+                                              int64_t nref, float* __restrict__ Trep, int S) {
+  __shared__ float T[NB][NB + 1];
+  __shared__ float g[NB];
+  const int64_t p = (int64_t)blockIdx.x * NB;
+  const int k = (int)((nref - p < NB) ? nref - p : NB);
+  const int tid = threadIdx.x;
+  for (int c = 0; c < NB; ++c) T[tid][c] = 0.f;
+  __syncthreads();
+  for (int c = 0; c < k; ++c) {
+    const float tc = tau[p + c];
+    if (tid < c) g[tid] = Gst[(p + c) * NB + tid];
+    __syncthreads();
+    if (tid < c) {
+      float s = 0.f;
+      for (int q = tid; q < c; ++q) s += T[tid][q] * g[q];  // T upper triangular: T[tid][q] = 0 for q < tid
+      T[tid][c] = -tc * s;
+    }
+    if (tid == c) T[c][c] = tc;
+    __syncthreads();
+  }
+  float* out = Trep + (int64_t)blockIdx.x * NB * ((int64_t)S * NB);
+  for (int r = 0; r < NB; ++r)
+    for (int s = 0; s < S; ++s) out[(int64_t)r * S * NB + s * NB + tid] = T[r][tid];
+}
+
+// Clean reflector panel: Vp[c][i] = v_{p+c}[i] (0 for i <= p+c, 1 at i = p+c+1), rows c >= k are zero.
+__global__ __launch_bounds__(256) void build_Vp(const float* __restrict__ A, int64_t n, int64_t lda, int64_t p,
+                                                int k, int64_t k_al, float* __restrict__ Vp, int64_t ldvp) {
+  const int c = blockIdx.y;
+  const int64_t i = k_al + (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  float v = 0.f;
+  if (c < k) {
+    const int64_t j = p + c;
+    if (i == j + 1) v = 1.f;
+    else if (i > j + 1) v = A[j * lda + i];
+  }
+  Vp[(int64_t)c * ldvp + i] = v;
+}
+
+int ormtr_f32(Ctx* ctx, const float* A, int64_t n, int64_t lda, const float* tau_dev, float* Zt, int64_t m,
+              int64_t ldz) {
+  if (m <= 0 || n <= 1) return SCLENS_OK;
+  if (ldz % 4 != 0 || (reinterpret_cast<uintptr_t>(Zt) & 15u))
+    return ctx->fail(SCLENS_ERR_ARG, "ormtr_f32: Zt must be 16-byte aligned with ldz a multiple of 4");
+  StageTimer tm(ctx, "ormtr");
+  const int64_t nref = n - 1;  // reflectors j = 0 .. n-2 (the last ones have tau = 0)
+  const int64_t npanel = (nref + NB - 1) / NB;
+  float* Gst = static_cast<float*>(ctx->workspace("trd.Gst", sizeof(float) * n * NB));
+  if (!Gst) return SCLENS_ERR_OOM;
+  // split-K factor of the skinny first GEMM (m x NB output): fill the chip
+  const int64_t tiles_m = (m + 127) / 128;
+  int S = (int)((512 + tiles_m - 1) / tiles_m);
+  if (S < 1) S = 1;
+  if (S > 16) S = 16;
+  const int64_t ldvp = round_up(n, 4);
+  SCL_WS(ctx, Trep, float, "orm.Trep", npanel * NB * (int64_t)S * NB);
+  SCL_WS(ctx, Vp, float, "orm.Vp", NB * ldvp);
+  SCL_WS(ctx, W1, float, "orm.W1", m * (int64_t)S * NB);
+  SCL_WS(ctx, W2, float, "orm.W2", m * NB);
+  hipLaunchKernelGGL(build_T, dim3((unsigned)npanel), dim3(NB), 0, ctx->stream, Gst, tau_dev, nref, Trep, S);
+  for (int64_t pi = npanel - 1; pi >= 0; --pi) {
+    const int64_t p = pi * NB;
+    const int k = (int)((nref - p < NB) ? nref - p : NB);
+    const int64_t k_al = (p + 1) & ~(int64_t)15;
+    const int64_t Kr = n - k_al;
+    hipLaunchKernelGGL(build_Vp, dim3((unsigned)((Kr + 255) / 256), NB), dim3(256), 0, ctx->stream, A, n, lda, p, k,
+                       k_al, Vp, ldvp);
+    // W1[m][S][NB] : split-K partials of Zt[:, k_al:] * Vp[:, k_al:]^T
+    const int64_t kc = round_up((Kr + S - 1) / S, 16);
+    for (int s = 0; s < S; ++s) {
+      const int64_t ks = s * kc;
+      GemmArgs g{};
+      g.M = m; g.N = NB; g.ldp = ldz; g.ldq = ldvp; g.ldc = (int64_t)S * NB;
+      g.alpha = 1.f; g.beta = 0.f; g.q_kcontig = 1; g.lower = 0; g.colabsmax = nullptr;
+      g.C = W1 + s * NB;
+      if (ks >= Kr) {  // empty slice: zero partial
+        g.K = 0;
+        g.P = Zt + k_al; g.Q = Vp + k_al;
+      } else {
+        g.K = (Kr - ks < kc) ? Kr - ks : kc;
+        g.P = Zt + k_al + ks; g.Q = Vp + k_al + ks;
+      }
+      SCL_TRY(gemm_f32(ctx, g));
+    }
+    {  // W2 = (sum_s W1_s) * T^T   (NT with the S-fold replicated T)
+      GemmArgs g{};
+      g.P = W1; g.Q = Trep + pi * NB * ((int64_t)S * NB); g.C = W2;
+      g.M = m; g.N = NB; g.K = (int64_t)S * NB;
+      g.ldp = (int64_t)S * NB; g.ldq = (int64_t)S * NB; g.ldc = NB;
+      g.alpha = 1.f; g.beta = 0.f; g.q_kcontig = 1; g.lower = 0; g.colabsmax = nullptr;
+      SCL_TRY(gemm_f32(ctx, g));
+    }
+    {  // Zt[:, k_al:] -= W2 * Vp[:, k_al:]
+      GemmArgs g{};
+      g.P = W2; g.Q = Vp + k_al; g.C = Zt + k_al;
+      g.M = m; g.N = Kr; g.K = NB;
+      g.ldp = NB; g.ldq = ldvp; g.ldc = ldz;
+      g.alpha = -1.f; g.beta = 1.f; g.q_kcontig = 0; g.lower = 0; g.colabsmax = nullptr;
+      SCL_TRY(gemm_f32(ctx, g));
+    }
+  }
+  SCL_HIP(ctx, hipGetLastError());
+  return SCLENS_OK;
+}
+
+__global__ void cvt_f64_to_f32(const double* __restrict__ in, float* __restrict__ out, int64_t n) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = (float)in[i];
+}
+
+int eig_values(Ctx* ctx, float* A, int64_t n, int64_t lda, double* w64_dev) {
+  if (n <= 0) return SCLENS_OK;
+  SCL_WS(ctx, d, double, "eig.d", n);
+  SCL_WS(ctx, e, double, "eig.e", n);
+  SCL_WS(ctx, tau, float, "eig.tau", n);
+  SCL_TRY(sytrd_f32(ctx, A, n, lda, d, e, tau));
+  SCL_TRY(stebz_f64(ctx, d, e, n, w64_dev));
+  return SCLENS_OK;
+}
+
+int eig_vectors(Ctx* ctx, const float* A, int64_t n, int64_t lda, const double* w64_dev, int64_t vec_lo,
+                int64_t vec_hi, float* Zt, int64_t ldz) {
+  if (vec_hi <= vec_lo) return SCLENS_OK;
+  if (vec_lo < 0 || vec_hi > n || !Zt) return ctx->fail(SCLENS_ERR_ARG, "eig_vectors: bad eigenvector range");
+  SCL_WS(ctx, d, double, "eig.d", n);
+  SCL_WS(ctx, e, double, "eig.e", n);
+  SCL_WS(ctx, tau, float, "eig.tau", n);
+  SCL_TRY(stein_f64(ctx, d, e, n, w64_dev, vec_lo, vec_hi, Zt, ldz));
+  SCL_TRY(ormtr_f32(ctx, A, n, lda, tau, Zt, vec_hi - vec_lo, ldz));
+  return SCLENS_OK;
+}
+
+int eigh_f32(Ctx* ctx, float* A, int64_t n, int64_t lda, double* w64_dev, int64_t vec_lo, int64_t vec_hi,
+             float* Zt, int64_t ldz) {
+  SCL_TRY(eig_values(ctx, A, n, lda, w64_dev));
+  SCL_TRY(eig_vectors(ctx, A, n, lda, w64_dev, vec_lo, vec_hi, Zt, ldz));
+  return SCLENS_OK;
+}
+
+}  // namespace scl

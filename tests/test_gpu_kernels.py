@@ -1,0 +1,115 @@
+"""-m gpu: kernel-level parity of the HIP building blocks against NumPy/SciPy float64, through the C ABI."""
+import numpy as np
+import pytest
+import scipy.linalg as sla
+
+from devutil import DevArray, pad_rows, rup
+
+pytestmark = pytest.mark.gpu
+
+
+def _gemm(ctx, P, Q, C0, alpha, beta, q_kcontig, lower=0, absmax=False):
+    M, K = P.shape
+    N = Q.shape[0] if q_kcontig else Q.shape[1]
+    ldp, ldq, ldc = rup(P.shape[1], 4), rup(Q.shape[1], 4), rup(N, 4)
+    dP, dQ = DevArray(ctx, pad_rows(P, ldp)), DevArray(ctx, pad_rows(Q, ldq))
+    dC = DevArray(ctx, pad_rows(C0, ldc))
+    dmax = DevArray(ctx, nbytes=4 * N) if absmax else None
+    ctx.check(ctx.lib.sclens_hip_dev_gemm_f32(ctx.h, dP.p, dQ.p, dC.p, M, N, K, ldp, ldq, ldc, alpha, beta, q_kcontig, lower,
+                                              dmax.p if absmax else None))
+    ctx.sync()
+    out = dmax.get((N,), np.float32) if absmax else dC.get((M, ldc), np.float32)[:, :N]
+    for d in (dP, dQ, dC, dmax):
+        if d is not None:
+            d.free()
+    return out
+
+
+@pytest.mark.parametrize("M,N,K", [(128, 128, 16), (130, 257, 33), (64, 300, 1000), (1000, 77, 515), (5, 5, 3)])
+def test_gemm_nt_nn(ctx, M, N, K):
+    rng = np.random.default_rng(M * 7 + N)
+    P = rng.standard_normal((M, K)).astype(np.float32)
+    Qn = rng.standard_normal((N, K)).astype(np.float32)
+    C0 = rng.standard_normal((M, N)).astype(np.float32)
+    ref = 0.5 * (P.astype(np.float64) @ Qn.T.astype(np.float64)) + 2.0 * C0
+    out = _gemm(ctx, P, Qn, C0, 0.5, 2.0, 1)
+    tol = 2e-6 * np.sqrt(K) * np.abs(ref).max() + 1e-5
+    assert np.abs(out - ref).max() < tol
+    out2 = _gemm(ctx, P, np.ascontiguousarray(Qn.T), C0, 0.5, 2.0, 0)
+    assert np.abs(out2 - ref).max() < tol
+
+
+def test_gemm_asymmetric_identity(ctx):
+    # A = I with an asymmetric B catches a transposed C write
+    n = 96
+    B = np.arange(n * n, dtype=np.float32).reshape(n, n) / 100.0
+    out = _gemm(ctx, np.eye(n, dtype=np.float32), np.ascontiguousarray(B.T), np.zeros((n, n), np.float32), 1.0, 0.0, 1)
+    assert np.array_equal(out, B)
+
+
+@pytest.mark.parametrize("n,K", [(200, 64), (333, 257)])
+def test_gemm_lower_mirror_and_absmax(ctx, n, K):
+    rng = np.random.default_rng(n)
+    P = rng.standard_normal((n, K)).astype(np.float32)
+    Q = rng.standard_normal((n, K)).astype(np.float32)
+    C0 = rng.standard_normal((n, n)).astype(np.float32)
+    C0 = (C0 + C0.T) / 2
+    # symmetric rank-2K style update: P Q^T + Q P^T via [P|Q][Q|P]^T
+    PQ, QP = np.hstack([P, Q]), np.hstack([Q, P])
+    ref = C0 - (PQ.astype(np.float64) @ QP.T.astype(np.float64))
+    out = _gemm(ctx, PQ, QP, C0, -1.0, 1.0, 1, lower=1)
+    assert np.array_equal(out, out.T), "lower+mirror must give an exactly symmetric matrix"
+    assert np.abs(out - ref).max() < 1e-4 * np.abs(ref).max()
+    am = _gemm(ctx, P, Q, np.zeros((n, n), np.float32), 1.0, 0.0, 1, absmax=True)
+    refm = np.abs(P.astype(np.float64) @ Q.T.astype(np.float64)).max(axis=0)
+    assert np.abs(am - refm).max() < 1e-4 * refm.max()
+
+
+def _sym(n, seed, K=None):
+    rng = np.random.default_rng(seed)
+    K = K or 2 * n
+    B = rng.standard_normal((n, K))
+    B -= B.mean(axis=0, keepdims=True)  # exact null vector like the centred matrices of the path
+    return (B @ B.T / K).astype(np.float32)
+
+
+@pytest.mark.parametrize("n", [3, 64, 129, 300, 1000])
+def test_sytrd_stebz_eigenvalues(ctx, n):
+    A = _sym(n, n)
+    lda = rup(n, 32)
+    dA = DevArray(ctx, pad_rows(A, lda))
+    dd, de, dt, dw = (DevArray(ctx, nbytes=8 * n) for _ in range(4))
+    ctx.check(ctx.lib.sclens_hip_dev_sytrd_f32(ctx.h, dA.p, n, lda, dd.p, de.p, dt.p))
+    ctx.check(ctx.lib.sclens_hip_dev_stebz_f64(ctx.h, dd.p, de.p, n, dw.p))
+    ctx.sync()
+    d, e, w = dd.get((n,), np.float64), de.get((n,), np.float64), dw.get((n,), np.float64)
+    ref = np.linalg.eigvalsh(A.astype(np.float64))
+    # bisection is exact (fp64) for the tridiagonal it was given
+    wt = sla.eigvalsh_tridiagonal(d, e[: n - 1]) if n > 1 else d
+    assert np.abs(w - wt).max() < 1e-12 * max(1.0, np.abs(wt).max())
+    # the fp32 reduction is backward stable: eigenvalue error ~ sqrt(n) eps32 ||A||
+    assert np.abs(w - ref).max() < 4e-7 * np.sqrt(n) * np.abs(ref).max() + 1e-7
+    for x in (dA, dd, de, dt, dw):
+        x.free()
+
+
+@pytest.mark.parametrize("n,lo,hi", [(64, 0, 64), (300, 0, 300), (300, 290, 300), (515, 100, 360), (1000, 0, 1000)])
+def test_eigh_vectors(ctx, n, lo, hi):
+    A = _sym(n, 1000 + n)
+    lda = rup(n, 32)
+    m = hi - lo
+    dA = DevArray(ctx, pad_rows(A, lda))
+    dw = DevArray(ctx, nbytes=8 * n)
+    dZ = DevArray(ctx, nbytes=4 * m * lda)
+    ctx.check(ctx.lib.sclens_hip_dev_eigh_f32(ctx.h, dA.p, n, lda, dw.p, lo, hi, dZ.p, lda))
+    ctx.sync()
+    w = dw.get((n,), np.float64)
+    Z = dZ.get((m, lda), np.float32)[:, :n].astype(np.float64)  # rows = eigenvectors
+    A64 = A.astype(np.float64)
+    nrm = np.abs(np.linalg.eigvalsh(A64)).max()
+    resid = np.abs(Z @ A64 - w[lo:hi, None] * Z).max()
+    orth = np.abs(Z @ Z.T - np.eye(m)).max()
+    assert resid < 2e-5 * nrm * np.sqrt(n / 64 + 1), resid
+    assert orth < 2e-5 * np.sqrt(n / 64 + 1), orth
+    for x in (dA, dw, dZ):
+        x.free()
