@@ -1,0 +1,198 @@
+#!/usr/bin/env python3
+"""bench.py -- sclens() wall-clock and cells*genes/s on synthetic count matrices (BASELINE.json metric).
+
+One "step" = one complete sclens() call (scLENS.jl:649-832: normalisation, data/null/binary decompositions,
+MP/TW thresholding, sparsity search, 20-member perturbation ensemble, robustness scoring, gene basis) on a
+seeded synthetic cells x genes count matrix that is already resident in host CSC form; every random draw of the
+call is generated inside the timed region. Default workload = BASELINE.json configs[1] (10 000 x 20 000).
+
+  python bench.py --gpus N --steps K --warmup W        (N > 1: launched by torch.distributed.run, one rank per GPU)
+
+Prints ONE JSON line on rank 0 (contract in the task statement) with two extra objects:
+  roofline     : dominant kernel `trd_colB` (HBM-bound symmetric matrix-vector product of the tridiagonalisation),
+                 algorithmic bytes = 4 (n-j-1)^2 per launch, durations from HIP events recorded on the
+                 library's stream around every launch of one extra tridiagonalisation at the workload's n.
+  cpu_baseline : the oracle (float64 NumPy/SciPy port of the reference CPU path) timed on the host cores on a
+                 bounded sample, stage-extrapolated to the workload (see `sample`).
+"""
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+
+CONFIGS = {  # name -> (N cells, M genes, index in BASELINE.json configs)
+    "tiny": (600, 900, 0),
+    "cfg2": (10000, 20000, 1),
+    "cfg3": (50000, 30000, 2),
+    "cfg4": (100000, 30000, 3),
+}
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def roofline_probe(ctx, n):
+    """One tridiagonalisation of a random symmetric n x n matrix with every trd_colB launch HIP-event timed."""
+    import ctypes as C
+
+    rng = np.random.default_rng(5)
+    lda = (n + 31) // 32 * 32
+    K = 256
+    B = rng.standard_normal((n, K)).astype(np.float32)
+    dB = ctx.malloc(B.nbytes)
+    ctx.h2d(dB, B)
+    dA = ctx.malloc(4 * n * lda)
+    dd, de, dt = ctx.malloc(8 * n), ctx.malloc(8 * n), ctx.malloc(8 * n)
+    ctx.check(ctx.lib.sclens_hip_dev_gram_f32(ctx.h, dB, n, K, K, float(K), dA, lda))
+    ctx.check(ctx.lib.sclens_hip_symv_profile(ctx.h, 1))
+    ctx.check(ctx.lib.sclens_hip_dev_sytrd_f32(ctx.h, dA, n, lda, dd, de, dt))
+    launches, ms, nbytes = C.c_int64(0), C.c_double(0), C.c_double(0)
+    ctx.check(ctx.lib.sclens_hip_symv_profile_read(ctx.h, C.byref(launches), C.byref(ms), C.byref(nbytes)))
+    ctx.check(ctx.lib.sclens_hip_symv_profile(ctx.h, 0))
+    for p in (dB, dA, dd, de, dt):
+        ctx.free(p)
+    gbs = nbytes.value / (ms.value * 1e-3) / 1e9
+    return {"bound": "hbm", "kernel": "trd_colB", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": None, "launches": launches.value,
+            "avg_launch_us": round(ms.value * 1e3 / max(1, launches.value), 2),
+            "algorithmic_bytes_per_launch_avg": round(nbytes.value / max(1, launches.value), 1), "n": n}
+
+
+def cpu_baseline(N, M, n_search, n_perturb):
+    """Oracle (port of the reference CPU path) on the host cores: every stage timed once on a bounded sample and
+    scaled to the workload by its complexity, times the call counts observed in the GPU run."""
+    from oracle import sclens_oracle as O  # checker / baseline only
+    from sclens_amd.synth import synth_counts
+
+    n, K = min(N, M), max(N, M)
+    ns = min(n, 2000)
+    Ns, Ms = (ns, int(ns * M / N)) if N <= M else (int(ns * N / M), ns)
+    Xs = synth_counts(Ns, Ms, seed=11)
+    t0 = time.perf_counter()
+    S = O.logn_scale(O.pre_scale(Xs))
+    t_scale = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    Y = O.wishart_matrix(S, 2 if Ns > Ms else 1)
+    t_gram = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    O.get_eigen(Y)
+    t_eig = time.perf_counter() - t0
+    calls = 3 + n_search + n_perturb
+    f3 = (n / ns) ** 3
+    T = calls * (t_scale * (N * M) / (Ns * Ms) + t_gram * (n * n * K) / (ns * ns * max(Ns, Ms)) + t_eig * f3)
+    T += n_search * t_gram * (n ** 3) / (ns * ns * max(Ns, Ms))  # corr_mat (scLENS.jl:742): ~n^3 flop per iteration
+    cores = os.cpu_count() or 1
+    try:  # threads the BLAS/LAPACK behind NumPy/SciPy actually uses
+        from threadpoolctl import threadpool_info
+
+        cores = max([int(i.get("num_threads", 1)) for i in threadpool_info()] or [cores])
+    except Exception:
+        pass
+    return {"value": round(N * M / T, 1), "unit": "cells*genes/s", "cores": cores, "kind": "port",
+            "wall_s_extrapolated": round(T, 1),
+            "sample": (f"oracle normalise+Gram+dsyevr timed once at {Ns}x{Ms} ({t_scale:.2f}s, {t_gram:.2f}s, {t_eig:.2f}s), "
+                       f"scaled by NM, n^2K and n^3 to {N}x{M}, times {calls} decompositions (S={n_search}, P={n_perturb}) "
+                       f"+ {n_search} corr GEMMs; BLAS threads = {cores} (host has {os.cpu_count()} cores)")}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=1)
+    ap.add_argument("--warmup", type=int, default=0)
+    ap.add_argument("--config", default="cfg2", choices=list(CONFIGS))
+    ap.add_argument("--n-perturb", type=int, default=20)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--backend", default="nccl")
+    ap.add_argument("--verbose", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    import torch
+
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (torch.cuda.is_available() is False); there is no CPU fallback")
+    if args.backend != "nccl":  # gloo test mode: several ranks may share one GPU
+        local_rank = min(local_rank, torch.cuda.device_count() - 1)
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        import torch.distributed as dist
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend=args.backend, rank=rank, world_size=world,
+                                device_id=dev if args.backend == "nccl" else None)
+    from sclens_amd import api
+    from sclens_amd._lib import Context
+    from sclens_amd.shard import Shard
+    from sclens_amd.synth import synth_counts
+
+    ctx = Context(local_rank)
+    shard = Shard(rank, world, dev if (world > 1 and args.backend == "nccl") else None)
+    N, M, cfg_index = CONFIGS[args.config]
+    t0 = time.perf_counter()
+    X = synth_counts(N, M, seed=20240427 + cfg_index)  # PCG64(20240427 + config_index)
+    t_synth = time.perf_counter() - t0
+
+    def one_step(step):
+        draws = api.make_draws(X, seed=1000 + step)  # R1-R3 inside the timed region; R4/R5 inside sclens()
+        return api.sclens(X, draws=draws, ctx=ctx, n_perturb=args.n_perturb, shard=shard, verbose=args.verbose and rank == 0)
+
+    def fence():
+        shard.barrier()
+        torch.cuda.synchronize()
+        ctx.sync()
+
+    res = None
+    for w in range(args.warmup):
+        res = one_step(-1 - w)
+    fence()
+    t0 = time.perf_counter()
+    for s in range(args.steps):
+        res = one_step(s)
+    fence()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        import torch.distributed as dist
+
+        tt = torch.tensor([dt], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+
+    if rank == 0:
+        ms_per_step = dt / max(1, args.steps) * 1e3
+        out = {
+            "metric": "sclens() cells*genes/s (wall-clock of one full sclens() call)", "value": round(N * M * args.steps / dt, 1),
+            "unit": "cells*genes/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(ms_per_step, 1), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"{args.config}: synthetic Poisson-lognormal counts {N} cells x {M} genes, sparsity "
+                                   f"{1 - X.nnz / (N * M):.3f}, full sclens() incl. sparsity search and {args.n_perturb}-member "
+                                   f"perturbation ensemble", "N": N, "M": M, "nnz": int(X.nnz), "n_perturb": args.n_perturb,
+                       "parallelism": ("single GPU" if world == 1 else f"search rounds of {world} + ensemble t%{world}, 1 RCCL all-gather")},
+            "sclens_wall_s": round(dt / max(1, args.steps), 3),
+            "observed": {"signals": int(len(res.get("signal_ev", []))), "robust_signals": int(len(res.get("sig_id", []))),
+                         "search_iters": int(res["n_search"]), "p_": res["p_"], "synth_s": round(t_synth, 1)},
+        }
+        if not args.no_roofline:
+            out["roofline"] = roofline_probe(ctx, min(N, M))
+        if not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(N, M, int(res["n_search"]), args.n_perturb)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        import torch.distributed as dist
+
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -46,6 +46,12 @@ const char* sclens_hip_version(void);
 int sclens_hip_set_timing(sclens_hip_ctx* ctx, int enabled);
 int sclens_hip_get_timing(sclens_hip_ctx* ctx, const char* stage, double* total_ms, int64_t* calls);
 int sclens_hip_reset_timing(sclens_hip_ctx* ctx);
+/* Per-launch HIP-event timing of the dominant kernel (trd_colB, the HBM-bound symmetric matrix-vector product of
+ * the tridiagonalisation). enable=1 starts recording; sclens_hip_symv_profile_read() synchronises, returns the
+ * number of recorded launches, the sum of their durations and of their algorithmic bytes (4 (n-j-1)^2 each), and
+ * clears the record. */
+int sclens_hip_symv_profile(sclens_hip_ctx* ctx, int enable);
+int sclens_hip_symv_profile_read(sclens_hip_ctx* ctx, int64_t* launches, double* total_ms, double* total_bytes);
 /* raw stream handle (hipStream_t) so a host framework can order its own work after ours */
 void* sclens_hip_stream(sclens_hip_ctx* ctx);
 
@@ -111,6 +117,12 @@ int sclens_hip_session_perturb(sclens_hip_session* s, int64_t t, const uint32_t*
                                double* nL_top, int64_t* ncols);
 /* Download slot t (N x ncols, column-major) -- for tests and for callers that score on the host. */
 int sclens_hip_session_get_perturbed(sclens_hip_session* s, int64_t t, float* nV_t);
+/* Multi-GPU ensemble sharding: copy slot t to / from a contiguous device buffer of min_pc x ldn floats
+ * (ldn = N rounded up to 32; sclens_hip_session_slot_ld). The buffer may belong to the host framework (e.g. a torch
+ * tensor that RCCL all-gathers). */
+int64_t sclens_hip_session_slot_ld(sclens_hip_session* s);
+int sclens_hip_session_export_slot(sclens_hip_session* s, int64_t t, int64_t min_pc, void* dst_dev);
+int sclens_hip_session_import_slot(sclens_hip_session* s, int64_t t, int64_t min_pc, int64_t ncols, const void* src_dev);
 /* Robustness matching (scLENS.jl:788-795) over slots 0..P-1: a_b is k x P (0-based column picks,
  * column-major), b is k x P(P-1)/2 ROW-major (pair order i<j as at :792). */
 int sclens_hip_session_robustness(sclens_hip_session* s, int64_t P, int32_t* a_b, double* b);

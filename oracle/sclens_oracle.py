@@ -248,14 +248,22 @@ def _normalize_cols(A: np.ndarray) -> np.ndarray:
     return A / np.linalg.norm(A, axis=0, keepdims=True)
 
 
-def get_eigvec(X: np.ndarray) -> Tuple[np.ndarray, np.ndarray]:
-    """get_eigvec (scLENS.jl:489-524), CPU branch; the catch expression (:507) is used for N > M."""
+# Positive filter `L .> 0` (scLENS.jl:495, :515). Reference oddity (SURVEY 8a defect 6): for N <= M the centred
+# matrix has one structurally zero eigenvalue whose computed value is +-1e-17 by rounding luck, so the reference
+# keeps or drops that eigenvector at random (and with it one ~0 entry of d_arr at :742). NULL_TOL = 0 restates the
+# reference literally; the HIP path (and the parity tests, via null_tol=NULL_DROP) always drop it.
+NULL_DROP = 1e-9
+
+
+def get_eigvec(X: np.ndarray, null_tol: float = 0.0) -> Tuple[np.ndarray, np.ndarray]:
+    """get_eigvec (scLENS.jl:489-524), CPU branch; the catch expression (:507) is used for N > M.
+    `null_tol`: eigenvalues <= null_tol * max(L) count as non-positive (0 = the reference's `L .> 0`)."""
     N, M = X.shape
     if N > M:
         L, V = get_eigen(wishart_matrix(X, 2))
     else:
         L, V = get_eigen(wishart_matrix(X, 1))
-    pos = L > 0
+    pos = L > (null_tol * L.max() if null_tol > 0 else 0.0)
     L, V = L[pos], V[:, pos]
     order = np.argsort(-L, kind="stable")  # sortperm(L, rev=true) (Appendix A15)
     nL, nVs = L[order], V[:, order]
@@ -428,11 +436,13 @@ def sclens(
     n_perturb: int = 20,
     max_search_iters: Optional[int] = None,
     keep_intermediates: bool = False,
+    null_tol: float = 0.0,
 ) -> Dict[str, object]:
     """sclens(inp_df; device_="cpu", centering="mean") (scLENS.jl:649-832).
 
     `X` is the cells x genes count matrix (what `df2sparr(inp_df)` returns, :662).
     `max_search_iters` is a test-only cap on the sparsity-search loop (None = reference behaviour).
+    `null_tol`: see NULL_DROP above (0 = literal reference behaviour).
     """
     X_ = _as_csc_f32(X)
     N, M = X_.shape
@@ -451,7 +461,7 @@ def sclens(
     p_ = 0.999
     binary = sp.csc_matrix((np.ones_like(nz_val), (nz_row, nz_col)), shape=(N, M), dtype=np.float32)
     sb = logn_scale(pre_scale(binary))
-    Vr2 = get_eigvec(sb.T if N > M else sb)[1]  # :717-721
+    Vr2 = get_eigvec(sb.T if N > M else sb, null_tol)[1]  # :717-721
     n_2 = int(round(Vr2.shape[1] / 2))  # round half to even (Appendix A17)
     tank = np.zeros((5, 0))
     it = 0
@@ -464,7 +474,7 @@ def sclens(
         idx = draws.sample("search", it, len(z1), nnzidx)
         pert = _with_ones(N, M, nz_row, nz_col, nz_val, z1, z2, idx, binary=True)
         sp_ = logn_scale(pre_scale(pert))
-        nV_2 = get_eigvec(sp_.T if N > M else sp_)[1]  # :733-739
+        nV_2 = get_eigvec(sp_.T if N > M else sp_, null_tol)[1]  # :733-739
         C = corr_mat(Vr2, nV_2[:, nV_2.shape[1] - n_2 - 1 :])  # end-n_2:end -> n_2+1 columns (A17)
         d_arr = np.nanmax(np.abs(C), axis=0)  # :742 (A18)
         tmp_A = np.sort(d_arr)
@@ -485,7 +495,7 @@ def sclens(
     for t in range(n_perturb):
         idx = draws.sample("perturb", t, len(z1), m_pert)
         tmp_X = _with_ones(N, M, nz_row, nz_col, nz_val, z1, z2, idx, binary=False)
-        tL, tV = get_eigvec(logn_scale(pre_scale(tmp_X)))
+        tL, tV = get_eigvec(logn_scale(pre_scale(tmp_X)), null_tol)
         c = min(min_pc, tV.shape[1])
         nV_set.append(tV[:, :c])
         nL_set.append(tL[:c])

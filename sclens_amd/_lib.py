@@ -33,6 +33,11 @@ SIGNATURES = {
     "sclens_hip_get_timing": (C.c_int, [vp, C.c_char_p, c_f64p, c_i64p]),
     "sclens_hip_reset_timing": (C.c_int, [vp]),
     "sclens_hip_stream": (vp, [vp]),
+    "sclens_hip_symv_profile": (C.c_int, [vp, C.c_int]),
+    "sclens_hip_symv_profile_read": (C.c_int, [vp, c_i64p, c_f64p, c_f64p]),
+    "sclens_hip_session_slot_ld": (i64, [vp]),
+    "sclens_hip_session_export_slot": (C.c_int, [vp, i64, i64, vp]),
+    "sclens_hip_session_import_slot": (C.c_int, [vp, i64, i64, i64, vp]),
     "sclens_hip_wishart_matrix_f32": (C.c_int, [vp, c_f32p, i64, i64, C.c_int, c_f32p]),
     "sclens_hip_get_eigen_f32": (C.c_int, [vp, c_f32p, i64, c_f32p, c_f32p]),
     "sclens_hip_corr_mat_f32": (C.c_int, [vp, c_f32p, i64, i64, c_f32p, i64, c_f32p]),
@@ -106,6 +111,7 @@ class Context:
         if rc != 0:
             raise SclensHipError(rc, "sclens_hip_create failed (no usable HIP device?)")
         self.h = h
+        self.device = int(device)
 
     def check(self, rc):
         if rc != 0:

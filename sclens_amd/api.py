@@ -22,6 +22,7 @@ import scipy.sparse as sp
 
 from . import _lib
 from ._lib import Context, SclensHipError, ptr
+from .shard import Shard, consume_search_round, owned_perturbations, search_schedule
 
 _default_ctx: Optional[Context] = None
 
@@ -299,6 +300,16 @@ class Session:
         self.ctx.check(self.ctx.lib.sclens_hip_session_get_perturbed(self.h, int(t), ptr(out, C.c_float)))
         return out
 
+    def slot_ld(self) -> int:
+        return int(self.ctx.lib.sclens_hip_session_slot_ld(self.h))
+
+    def export_slot(self, t: int, min_pc: int, dst_dev_ptr: int):
+        self.ctx.check(self.ctx.lib.sclens_hip_session_export_slot(self.h, int(t), int(min_pc), C.c_void_p(dst_dev_ptr)))
+
+    def import_slot(self, t: int, min_pc: int, ncols: int, src_dev_ptr: int):
+        self.ctx.check(self.ctx.lib.sclens_hip_session_import_slot(self.h, int(t), int(min_pc), int(ncols),
+                                                                   C.c_void_p(src_dev_ptr)))
+
     def robustness(self, k: int, P: int):
         a_b = np.empty((k, P), dtype=np.int32, order="F")
         b = np.empty((k, P * (P - 1) // 2), dtype=np.float64)
@@ -313,6 +324,34 @@ class Session:
 
 
 # ----------------------------------------------------------------------------- driver
+def _exchange_ensemble(ses: "Session", shard: Shard, n_perturb: int, min_pc: int, nL_set, ncols):
+    """The single gather of the ensemble: all-gather the owned N x min_pc blocks (+ their
+    eigenvalues and column counts) over RCCL; every rank then holds all slots (rank 0 scores them)."""
+    import torch
+
+    ld = ses.slot_ld()
+    per = (n_perturb + shard.world - 1) // shard.world
+    dev = shard.device if shard.device is not None else torch.device("cuda", ses.ctx.device)
+    blocks = torch.zeros((per, min_pc, ld), dtype=torch.float32, device=dev)
+    meta = np.zeros((per, min_pc + 1))
+    mine = owned_perturbations(shard.rank, shard.world, n_perturb)
+    for q, t in enumerate(mine):
+        ses.export_slot(t, min_pc, blocks[q].data_ptr())
+        meta[q, 0] = ncols[t]
+        meta[q, 1: 1 + len(nL_set[t])] = nL_set[t]
+    torch.cuda.synchronize()
+    allb = shard.allgather_blocks(blocks)
+    allm = shard.allgather_small(meta)
+    torch.cuda.synchronize()
+    for r in range(shard.world):
+        for q, t in enumerate(owned_perturbations(r, shard.world, n_perturb)):
+            c = int(allm[r, q, 0])
+            ncols[t] = c
+            nL_set[t] = allm[r, q, 1: 1 + c].copy()
+            if r != shard.rank:
+                ses.import_slot(t, min_pc, c, allb[r, q].data_ptr())
+
+
 def _extract(inp):
     """df2sparr(inp_df) (scLENS.jl:662, :90-120) for a DataFrame with a leading `cell` column, a scipy sparse
     matrix or a dense array (cells x genes)."""
@@ -335,7 +374,7 @@ def _extract(inp):
 
 def sclens(inp_df, device_="gpu", th=60, p_step=0.001, n_perturb=20, centering="mean", draws: Optional[Draws] = None,
            seed: Optional[int] = None, ctx: Optional[Context] = None, max_search_iters: Optional[int] = None,
-           keep_intermediates: bool = False, verbose: bool = False) -> Dict[str, object]:
+           keep_intermediates: bool = False, verbose: bool = False, shard: Optional[Shard] = None) -> Dict[str, object]:
     """scLENS.sclens (scLENS.jl:649-832) on one MI355X.
 
     Same keyword arguments as the reference. `draws`/`seed` expose the randomness the reference takes from
@@ -346,6 +385,7 @@ def sclens(inp_df, device_="gpu", th=60, p_step=0.001, n_perturb=20, centering="
     if centering != "mean":
         raise NotImplementedError("centering='median' is outside the hot path of this build (SURVEY 8f-4)")
     ctx = ctx or default_context()
+    shard = shard or Shard()
     t_all = time.perf_counter()
     X_, cell_id, gene_id = _extract(inp_df)  # :662
     N, M = X_.shape
@@ -366,45 +406,43 @@ def sclens(inp_df, device_="gpu", th=60, p_step=0.001, n_perturb=20, centering="
         nV = ses.signal_vectors(k)
         mpC = mp_check(L_mp)  # :706
         p_th = draws.p_th  # :709-712
-
-        # ---- sparsity search (:715-762)
-        p_ = 0.999
+        # ---- sparsity search (:715-762); `shard.world` consecutive p_ values are evaluated per round
         _, r_vr2 = ses.binary_basis()  # Vr2 (:717-721)
         n_2 = int(round(r_vr2 / 2))  # :722
+        p_list = search_schedule(p_step)
         tank = np.zeros((5, 0))
         it = 0
-        trace = []
-        while True:
-            nnzidx = int(round((1 - p_) * M * N))  # :726
-            if len(z1) < nnzidx:
-                p_ += p_step
-                break
-            idx = draws.sampler("search", it, len(z1), nnzidx)  # :731
-            d5, _r = ses.search_step(idx, n_2)  # :733-747
-            tank = np.hstack([tank, d5[:, None]])
-            ppj = tank[1, :] if tank.shape[1] < 5 else tank[1, -5:]
-            trace.append((p_, d5.copy()))
-            it += 1
-            if verbose:
-                print(ppj[-1])
-            if (np.sum(ppj < p_th) > 4) or (p_ < 0.9) or (max_search_iters is not None and it >= max_search_iters):
-                p_ += 4 * p_step
-                break
-            p_ -= p_step
+        p_ = None
+        while p_ is None:
+            my_it = it + shard.rank
+            mine = np.full(6, np.nan)
+            nnzidx = int(round((1 - p_list[my_it]) * M * N))  # :726
+            if len(z1) >= nnzidx:
+                idx = draws.sampler("search", my_it, len(z1), nnzidx)  # :731
+                d5, _r = ses.search_step(idx, n_2)  # :733-747
+                mine[:5], mine[5] = d5, 1.0
+            allr = shard.allgather_small(mine)
+            results = [allr[q, :5] if allr[q, 5] == 1.0 else None for q in range(shard.world)]
+            tank, used, stopped, p_fin = consume_search_round(tank, results, p_list, it, p_th, p_step, max_search_iters)
+            it += used
+            if stopped:
+                p_ = p_fin
+        trace = [(p_list[q], tank[:, q].copy()) for q in range(tank.shape[1])]
         if verbose:
             print(f"Selected perturb sparisty: {p_}")
 
-        # ---- perturbation ensemble (:767-778)
+        # ---- perturbation ensemble (:767-778): member t runs on rank t % world
         min_s = k
         min_pc = int(math.ceil(min_s * 1.5))
         m_pert = int(round((1 - p_) * M * N))
-        nL_set, ncols = [], []
+        nL_set = [None] * n_perturb
+        ncols = [0] * n_perturb
         if min_s > 0:
-            for t in range(n_perturb):
+            for t in owned_perturbations(shard.rank, shard.world, n_perturb):
                 idx = draws.sampler("perturb", t, len(z1), m_pert)
-                tl, c = ses.perturb(t, idx, min_pc)
-                nL_set.append(tl)
-                ncols.append(c)
+                nL_set[t], ncols[t] = ses.perturb(t, idx, min_pc)
+            if shard.world > 1:
+                _exchange_ensemble(ses, shard, n_perturb, min_pc, nL_set, ncols)
 
         res: Dict[str, object] = {"L": L, "L_mp": L_mp, "λ": lambda_c, "lambda_c": lambda_c, "cell_id": cell_id,
                                   "p_": p_, "p_th": p_th, "n_search": it, "search_trace": trace}

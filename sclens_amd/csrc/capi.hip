@@ -15,6 +15,9 @@ int session_perturb(Session*, int64_t, const uint32_t*, int64_t, int64_t, double
 int session_get_perturbed(Session*, int64_t, float*);
 int session_robustness(Session*, int64_t, int32_t*, double*);
 int session_gene_basis(Session*, const double*, float*);
+int64_t session_slot_ld(Session*);
+int session_export_slot(Session*, int64_t, int64_t, void*);
+int session_import_slot(Session*, int64_t, int64_t, int64_t, const void*);
 int wishart_host(Ctx*, const float*, int64_t, int64_t, int, float*);
 int get_eigen_host(Ctx*, const float*, int64_t, float*, float*);
 int corr_mat_host(Ctx*, const float*, int64_t, int64_t, const float*, int64_t, float*);
@@ -54,6 +57,7 @@ void sclens_hip_destroy(sclens_hip_ctx* h) {
   h->c.release_all();
   if (h->c.ev0) hipEventDestroy(h->c.ev0);
   if (h->c.ev1) hipEventDestroy(h->c.ev1);
+  for (hipEvent_t e : h->c.prof_ev) hipEventDestroy(e);
   if (h->c.stream) hipStreamDestroy(h->c.stream);
   delete h;
 }
@@ -171,6 +175,40 @@ int sclens_hip_session_gene_basis(sclens_hip_session* w, const double* nL, float
   SES_GUARD(w);
   if (!nL || !out) return SCLENS_ERR_ARG;
   return scl::session_gene_basis(w->s, nL, out);
+}
+
+int64_t sclens_hip_session_slot_ld(sclens_hip_session* w) { return (w && w->s) ? scl::session_slot_ld(w->s) : -1; }
+int sclens_hip_session_export_slot(sclens_hip_session* w, int64_t t, int64_t min_pc, void* dst) {
+  SES_GUARD(w);
+  return scl::session_export_slot(w->s, t, min_pc, dst);
+}
+int sclens_hip_session_import_slot(sclens_hip_session* w, int64_t t, int64_t min_pc, int64_t ncols, const void* src) {
+  SES_GUARD(w);
+  return scl::session_import_slot(w->s, t, min_pc, ncols, src);
+}
+
+int sclens_hip_symv_profile(sclens_hip_ctx* h, int enable) {
+  CTX_GUARD(h);
+  h->c.prof_symv = enable != 0;
+  h->c.prof_used = 0;
+  h->c.prof_bytes = 0.0;
+  return SCLENS_OK;
+}
+int sclens_hip_symv_profile_read(sclens_hip_ctx* h, int64_t* launches, double* total_ms, double* total_bytes) {
+  CTX_GUARD(h);
+  SCL_HIP(&h->c, hipStreamSynchronize(h->c.stream));
+  double ms = 0.0;
+  for (size_t q = 0; q + 1 < h->c.prof_used; q += 2) {
+    float t = 0.f;
+    SCL_HIP(&h->c, hipEventElapsedTime(&t, h->c.prof_ev[q], h->c.prof_ev[q + 1]));
+    ms += (double)t;
+  }
+  if (launches) *launches = (int64_t)(h->c.prof_used / 2);
+  if (total_ms) *total_ms = ms;
+  if (total_bytes) *total_bytes = h->c.prof_bytes;
+  h->c.prof_used = 0;
+  h->c.prof_bytes = 0.0;
+  return SCLENS_OK;
 }
 
 // ---- device-level entry points

@@ -24,6 +24,11 @@ struct Ctx {
   std::map<std::string, double> t_ms;
   std::map<std::string, long> t_calls;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  // optional per-launch HIP-event timing of the dominant kernel (trd_colB): bench.py's roofline leg
+  bool prof_symv = false;
+  std::vector<hipEvent_t> prof_ev;   // pairs (start, stop) recorded on `stream`
+  size_t prof_used = 0;
+  double prof_bytes = 0.0;           // algorithmic bytes of the recorded launches
 
   int fail(int code, const std::string& msg) {
     err = msg;

@@ -176,6 +176,18 @@ void pattern_free(PatternOwner* p) {
   p->base_val = nullptr;
 }
 
+// `L .> 0` (scLENS.jl:495, :515) with a rounding floor. For N <= M the centred matrix has one structurally
+// zero eigenvalue; in fp32 it comes out as +-(1e-8..1e-6) * lambda_max, and the reference keeps or drops that
+// eigenvector by the sign of its rounding error (SURVEY 8a defect 6). Here it is always dropped: positive means
+// lambda > 8 * eps32 * sqrt(n) * lambda_max (measured null |lambda| / lambda_max: 5e-7 at n = 10k).
+static int64_t count_positive_tol(const std::vector<double>& w) {
+  if (w.empty()) return 0;
+  const double tol = 8.0 * 5.96e-8 * std::sqrt((double)w.size()) * std::max(0.0, w.back());
+  int64_t r = 0;
+  for (double v : w) r += (v > tol) ? 1 : 0;
+  return r;
+}
+
 // ------------------------------------------------------------------------------------------------ session
 struct Session {
   Ctx* ctx = nullptr;
@@ -235,11 +247,7 @@ struct Session {
       if (v != v) return ctx->fail(SCLENS_ERR_NAN, "NaN eigenvalue");
     return SCLENS_OK;
   }
-  int64_t count_positive() const {
-    int64_t r = 0;
-    for (double v : w_host) r += (v > 0.0) ? 1 : 0;  // L .> 0 (scLENS.jl:495, :515)
-    return r;
-  }
+  int64_t count_positive() const { return count_positive_tol(w_host); }
 };
 
 int session_create(Ctx* ctx, int64_t N, int64_t M, const int64_t* colptr, const int32_t* rowval, const float* nzval,
@@ -430,6 +438,27 @@ int session_get_perturbed(Session* s, int64_t t, float* out) {
   if (t < 0 || t >= (int64_t)s->ens.size() || !s->ens[t]) return ctx->fail(SCLENS_ERR_ARG, "get_perturbed: empty slot");
   SCL_HIP(ctx, hipMemcpy2DAsync(out, sizeof(float) * s->N, s->ens[t], sizeof(float) * s->ldn, sizeof(float) * s->N,
                                 s->ens_cols[t], hipMemcpyDeviceToHost, ctx->stream));
+  SCL_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return SCLENS_OK;
+}
+
+int64_t session_slot_ld(Session* s) { return s->ldn; }
+int session_export_slot(Session* s, int64_t t, int64_t min_pc, void* dst) {
+  Ctx* ctx = s->ctx;
+  if (t < 0 || t >= (int64_t)s->ens.size() || !s->ens[t] || !dst) return ctx->fail(SCLENS_ERR_ARG, "export_slot: empty slot");
+  SCL_HIP(ctx, hipMemcpyAsync(dst, s->ens[t], sizeof(float) * (size_t)min_pc * s->ldn, hipMemcpyDeviceToDevice, ctx->stream));
+  SCL_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return SCLENS_OK;
+}
+int session_import_slot(Session* s, int64_t t, int64_t min_pc, int64_t ncols, const void* src) {
+  Ctx* ctx = s->ctx;
+  if (t < 0 || min_pc <= 0 || ncols < 0 || ncols > min_pc || !src) return ctx->fail(SCLENS_ERR_ARG, "import_slot: bad arguments");
+  if ((int64_t)s->ens.size() <= t) { s->ens.resize(t + 1, nullptr); s->ens_cols.resize(t + 1, 0); }
+  float* slot = static_cast<float*>(ctx->workspace("ses.ens" + std::to_string(t), sizeof(float) * (size_t)min_pc * s->ldn));
+  if (!slot) return SCLENS_ERR_OOM;
+  s->ens[t] = slot;
+  s->ens_cols[t] = ncols;
+  SCL_HIP(ctx, hipMemcpyAsync(slot, src, sizeof(float) * (size_t)min_pc * s->ldn, hipMemcpyDeviceToDevice, ctx->stream));
   SCL_HIP(ctx, hipStreamSynchronize(ctx->stream));
   return SCLENS_OK;
 }
@@ -635,11 +664,9 @@ int get_eigvec_host(Ctx* ctx, const float* X, int64_t N, int64_t M, int64_t keep
   std::vector<double> w(n);
   SCL_HIP(ctx, hipMemcpyAsync(w.data(), dw, sizeof(double) * n, hipMemcpyDeviceToHost, ctx->stream));
   SCL_HIP(ctx, hipStreamSynchronize(ctx->stream));
-  int64_t rp = 0;
-  for (double v : w) {
+  for (double v : w)
     if (v != v) return ctx->fail(SCLENS_ERR_NAN, "get_eigvec: NaN eigenvalue");
-    rp += (v > 0.0) ? 1 : 0;
-  }
+  const int64_t rp = count_positive_tol(w);
   *r = rp;
   if (rp > cap) return ctx->fail(SCLENS_ERR_ARG, "get_eigvec: output capacity too small");
   for (int64_t c = 0; c < rp; ++c) nL[c] = (float)w[n - 1 - c];

@@ -295,7 +295,23 @@ int sytrd_f32(Ctx* ctx, float* A, int64_t n, int64_t lda, double* d_dev, double*
       hipLaunchKernelGGL(trd_colA, dim3(na), dim3(256), 0, ctx->stream, a, j, c, nbB_prev);
       if (j == n - 1) break;
       const int nbB = (int)((n - (j + 1) + ROWS_B - 1) / ROWS_B);
+      if (ctx->prof_symv) {
+        if (ctx->prof_used + 2 > ctx->prof_ev.size()) {
+          for (int q = 0; q < 2; ++q) {
+            hipEvent_t ev;
+            SCL_HIP(ctx, hipEventCreate(&ev));
+            ctx->prof_ev.push_back(ev);
+          }
+        }
+        SCL_HIP(ctx, hipEventRecord(ctx->prof_ev[ctx->prof_used], ctx->stream));
+      }
       hipLaunchKernelGGL(trd_colB, dim3(nbB), dim3(512), 0, ctx->stream, a, j, c, na);
+      if (ctx->prof_symv) {
+        SCL_HIP(ctx, hipEventRecord(ctx->prof_ev[ctx->prof_used + 1], ctx->stream));
+        ctx->prof_used += 2;
+        const double nt = (double)(n - j - 1);
+        ctx->prof_bytes += 4.0 * nt * nt;  // the trailing matrix, once (sum_j 4 (n-j)^2)
+      }
       nbB_prev = nbB;
     }
     if (pe < n) {

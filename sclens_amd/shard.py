@@ -1,0 +1,96 @@
+"""Multi-GPU sharding of one sclens() call: one process per GPU, torch.distributed (RCCL on ROCm) for the few
+exchanges the path needs.
+
+  * sparsity search (scLENS.jl:725-761): sequential early-exit loop, but each p_ evaluation is independent given
+    its sample -> evaluate `world` consecutive p_ values per round, all-gather the five numbers each produces,
+    consume them in order with the reference's stop rule (same decision sequence as the serial loop).
+  * perturbation ensemble (scLENS.jl:771-778): member t runs on rank t % world; one gather of the N x min_pc
+    eigenvector blocks to rank 0 at the end, which then scores robustness.
+The data/null/binary decompositions are replicated on every rank (3 of ~3+S+P; noted in DESIGN.md).
+"""
+from __future__ import annotations
+
+from typing import Callable, List, Sequence
+
+import numpy as np
+
+
+class Shard:
+    """rank/world + the two collectives. `world == 1` needs no torch."""
+
+    def __init__(self, rank: int = 0, world: int = 1, device=None):
+        self.rank, self.world, self.device = rank, world, device
+
+    # -- small host arrays (search statistics): fixed-shape float64 all-gather
+    def allgather_small(self, arr: np.ndarray) -> np.ndarray:
+        arr = np.ascontiguousarray(arr, dtype=np.float64)
+        if self.world == 1:
+            return arr[None]
+        import torch
+        import torch.distributed as dist
+
+        t = torch.from_numpy(arr.copy())
+        if self.device is not None:
+            t = t.to(self.device)
+        out = [torch.empty_like(t) for _ in range(self.world)]
+        dist.all_gather(out, t)
+        return np.stack([o.cpu().numpy() for o in out])
+
+    # -- ensemble blocks: every rank contributes `per_rank` equally sized tensors (padded), all ranks receive all
+    def allgather_blocks(self, local):
+        """local: tensor [per_rank, ...] (same shape on every rank) -> tensor [world, per_rank, ...]."""
+        import torch
+
+        if self.world == 1:
+            return local[None]
+        import torch.distributed as dist
+
+        if self.device is None:  # gloo (tests): stage through host memory
+            h = local.detach().cpu().contiguous()
+            outs = [torch.empty_like(h) for _ in range(self.world)]
+            dist.all_gather(outs, h)
+            return torch.stack(outs).to(local.device)
+        out = torch.empty((self.world,) + tuple(local.shape), dtype=local.dtype, device=local.device)
+        dist.all_gather_into_tensor(out.view(-1), local.contiguous().view(-1))
+        return out
+
+    def barrier(self):
+        if self.world > 1:
+            import torch.distributed as dist
+
+            dist.barrier()
+
+
+def owner_of_perturbation(t: int, world: int) -> int:
+    return t % world
+
+
+def owned_perturbations(rank: int, world: int, n_perturb: int) -> List[int]:
+    return [t for t in range(n_perturb) if owner_of_perturbation(t, world) == rank]
+
+
+def search_schedule(p_step: float, max_iters: int = 200) -> List[float]:
+    """p_ of iteration it, produced by the same repeated `p_ -= p_step` as the reference (Appendix A21)."""
+    p = 0.999
+    out = []
+    for _ in range(max_iters):
+        out.append(p)
+        p -= p_step
+    return out
+
+
+def consume_search_round(tank: np.ndarray, results: Sequence[np.ndarray], p_list: Sequence[float], it0: int,
+                         p_th: float, p_step: float, max_search_iters=None):
+    """Apply the stop rule of scLENS.jl:747-760 to the results of iterations it0, it0+1, ... in order.
+    results[i] = d5 of iteration it0+i, or None if that iteration hit the early exit of :727-730.
+    Returns (tank, n_consumed, stopped, p_final_or_None)."""
+    for i, d5 in enumerate(results):
+        it = it0 + i
+        p_ = p_list[it]
+        if d5 is None:  # fewer candidates than requested (:727-730)
+            return tank, i, True, p_ + p_step
+        tank = np.hstack([tank, np.asarray(d5, dtype=np.float64)[:, None]])
+        ppj = tank[1, :] if tank.shape[1] < 5 else tank[1, -5:]
+        if (np.sum(ppj < p_th) > 4) or (p_ < 0.9) or (max_search_iters is not None and it + 1 >= max_search_iters):
+            return tank, i + 1, True, p_ + 4 * p_step
+    return tank, len(results), False, None

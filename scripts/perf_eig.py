@@ -1,0 +1,37 @@
+"""Stage timings of the device eigensolver + Gram at a given size (GPU box). Usage: perf_eig.py n [K] [mvec]"""
+import sys, time, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+import numpy as np
+from sclens_amd._lib import Context
+from devutil import DevArray, rup
+
+n = int(sys.argv[1]); K = int(sys.argv[2]) if len(sys.argv) > 2 else 2 * n
+mvec = int(sys.argv[3]) if len(sys.argv) > 3 else n
+ctx = Context(0)
+rng = np.random.default_rng(0)
+B = rng.standard_normal((n, K)).astype(np.float32)
+B -= B.mean(axis=0, keepdims=True)
+ldb = rup(K, 32); lda = rup(n, 32)
+Bp = np.zeros((n, ldb), np.float32); Bp[:, :K] = B
+dB = DevArray(ctx, Bp); dA = DevArray(ctx, nbytes=4 * n * lda); dw = DevArray(ctx, nbytes=8 * n)
+dZ = DevArray(ctx, nbytes=4 * max(mvec, 1) * lda)
+ctx.set_timing(True)
+for rep in range(2):
+    ctx.reset_timing()
+    t0 = time.perf_counter()
+    ctx.check(ctx.lib.sclens_hip_dev_gram_f32(ctx.h, dB.p, n, K, ldb, float(K), dA.p, lda))
+    ctx.check(ctx.lib.sclens_hip_dev_eigh_f32(ctx.h, dA.p, n, lda, dw.p, n - mvec, n, dZ.p, lda))
+    ctx.sync()
+    wall = time.perf_counter() - t0
+    out = {s: ctx.timing(s) for s in ("gram", "sytrd", "stebz", "stein", "ormtr")}
+    print(f"n={n} K={K} mvec={mvec} rep={rep} wall={wall:.3f}s", {k: round(v[0], 2) for k, v in out.items()})
+w = dw.get((n,), np.float64)
+print("gram TF/s (full 2n^2K):", 2 * n * n * K / (out["gram"][0] * 1e-3) / 1e12)
+print("sytrd algorithmic GB/s (4/3 n^3 * 4B / 2... full-matrix symv reads 4/3 n^3 B):", (4 / 3 * n**3) / (out["sytrd"][0] * 1e-3) / 1e9)
+print("null eig / max eig:", w[0] / w[-1], " second:", w[1] / w[-1])
+if n <= 4000:
+    ref = np.linalg.eigvalsh((B.astype(np.float64) @ B.T.astype(np.float64)) / K)
+    print("max eig err rel:", np.abs(w - ref).max() / ref.max())
+    Z = dZ.get((mvec, lda), np.float32)[:, :n].astype(np.float64)
+    print("orth:", np.abs(Z @ Z.T - np.eye(mvec)).max())

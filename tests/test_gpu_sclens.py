@@ -47,11 +47,10 @@ def test_dropin_wishart_eigen_corr(ctx, N, M):
 def test_dropin_get_eigvec(ctx, N, M):
     X = synth_counts(N, M, seed=3, C=4, marker_frac=0.3, marker_sd=1.5)
     S = O.logn_scale(O.pre_scale(X))
-    nL_ref, nV_ref = O.get_eigvec(S)
+    nL_ref, nV_ref = O.get_eigvec(S, O.NULL_DROP)
     nL, nV = api.get_eigvec(S.astype(np.float32), keep_top=6, ctx=ctx)
-    r = min(len(nL), len(nL_ref))
-    assert abs(len(nL) - len(nL_ref)) <= 1  # sign of the rounding of the exact null eigenvalue (SURVEY 8a defect 6)
-    assert np.abs(nL[: r - 1] - nL_ref[: r - 1]).max() < 2e-4 * nL_ref[0]
+    assert len(nL) == len(nL_ref)  # structural null eigenvalue dropped on both sides (SURVEY 8a defect 6)
+    assert np.abs(nL - nL_ref).max() < 2e-4 * nL_ref[0]
     assert nV.shape == (N, 6)
     assert np.all(_abs_cos(nV[:, :3], nV_ref[:, :3]) > 1 - 2e-3)
     assert np.abs(np.linalg.norm(nV, axis=0) - 1).max() < 1e-4
@@ -69,7 +68,7 @@ def run_pair(request, ctx):
     X = synth_counts(c["N"], c["M"], seed=c["seed"], C=5, marker_frac=0.2, marker_sd=1.5)
     d = api.make_draws(X, seed=c["draws_seed"], p_th_trials=300)
     od = O.Draws(d.z_idx1, d.z_idx2, d.X_r, d.p_th, d.sampler)
-    ref = O.sclens(X, od, n_perturb=6, keep_intermediates=True)
+    ref = O.sclens(X, od, n_perturb=6, keep_intermediates=True, null_tol=O.NULL_DROP)
     res = api.sclens(X, draws=d, n_perturb=6, ctx=ctx, keep_intermediates=True)
     return X, ref, res
 
