@@ -1,0 +1,124 @@
+"""CPU: host-side product code (C++ statistics through the C ABI, draw generators, sharding logic) against the oracle."""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import sclens_oracle as O
+from sclens_amd import api
+from sclens_amd.shard import consume_search_round, owned_perturbations, search_schedule
+from sclens_amd.synth import synth_counts
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def test_cpp_statistics_match_golden_and_oracle():
+    g = np.load(os.path.join(GOLD, "mp_known_answers.npz"))
+    for name in ("white", "spiked"):
+        L, Lr, exp = g[name + "_L"], g[name + "_Lr"], g[name + "_expect"]
+        L_mp, bp, bm = api._mp_calculation(L, Lr[:-1])
+        lam, gamma, p, sigma = api._tw(L, L_mp)
+        chk = api.mp_check(L_mp)
+        got = np.array([len(L_mp), bp, bm, lam, gamma, p, sigma, chk["ks_static"], float(chk["pass"]), float(np.sum(L > lam))])
+        assert np.allclose(got, exp, rtol=1e-11)
+
+
+def test_cpp_mp_calculation_empty_selection_runs_to_max_iter():
+    # Appendix A12: a null spectrum whose edges select nothing -> NaN parameters -> loop ends at max_iter, empty L_mp
+    L = np.linspace(5.0, 6.0, 50)
+    Lr = np.linspace(0.1, 0.2, 49)
+    a, _, _ = api._mp_calculation(L, Lr)
+    b, _, _ = O.mp_calculation(L, Lr)
+    assert len(a) == len(b) == 0
+
+
+def test_cpp_robust_scores_match_oracle():
+    rng = np.random.default_rng(1)
+    k, P = 6, 20
+    nV = np.linalg.qr(rng.standard_normal((200, k)))[0]
+    nV_set = [np.linalg.qr(nV + 0.3 * rng.standard_normal((200, k)))[0] for _ in range(P)]
+    rob = O.robustness(nV, nV_set)
+    m, sd = api._robust_scores(rob["b_"])
+    assert np.allclose(m, rob["rob_score"], rtol=1e-12)
+    assert np.allclose(sd, rob["sd_scores"], rtol=1e-10)
+    # heavy-tailed rows exercise the Tukey fence
+    b = rng.random((4, 190))
+    b[:, :5] = 0.0
+    rows = []
+    for s in range(4):
+        row = b[s]
+        q1, q3 = np.quantile(row, 0.25), np.quantile(row, 0.75)
+        f = row[(q1 - 1.5 * (q3 - q1) <= row) & (row <= q3 + 1.5 * (q3 - q1))]
+        rows.append(np.median(f))
+    assert np.allclose(api._robust_scores(b)[0], rows)
+
+
+def test_noise_baseline_exact_is_the_expectation_the_reference_samples():
+    lib = api._lib.load()
+    for n in (300, 5000):
+        mc = O.noise_baseline(n, np.random.default_rng(0), trials=3000)
+        ex = lib.sclens_noise_baseline_exact(n)
+        assert abs(mc - ex) < 4 * 0.4 / np.sqrt(2 * np.log(n)) / np.sqrt(n) / np.sqrt(3000) + 1e-4
+
+
+def test_draw_generators_contract():
+    X = api._csc_f32(synth_counts(70, 110, seed=3, C=3))
+    rng = np.random.default_rng(0)
+    z1, z2 = api.draw_zero_candidates(X, rng)
+    assert np.all(X[z1.astype(int), z2.astype(int)] == 0)
+    assert len(np.unique(z1.astype(np.int64) + z2.astype(np.int64) * 70)) == len(z1)
+    Xr = api.draw_null_matrix(X, rng)
+    assert np.array_equal(np.diff(Xr.indptr), np.diff(X.indptr))
+    assert np.array_equal(np.sort(Xr.data), np.sort(X.data))
+    d = api.make_draws(X, seed=5, p_th_trials=50)
+    a = d.sampler("search", 3, len(d.z_idx1), 40)
+    assert len(np.unique(a)) == 40 and np.array_equal(a, d.sampler("search", 3, len(d.z_idx1), 40))
+
+
+def test_sclens_refuses_cpu_and_median_paths():
+    X = synth_counts(60, 90, seed=2, C=3)
+    with pytest.raises(NotImplementedError):
+        api.sclens(X, device_="cpu")
+    with pytest.raises(NotImplementedError):
+        api.sclens(X, centering="median")
+
+
+def _serial_search(d_list, p_th, p_step):
+    """The reference's loop (scLENS.jl:725-761) over a pre-computed list of d5 results."""
+    p_ = 0.999
+    tank = np.zeros((5, 0))
+    it = 0
+    while True:
+        tank = np.hstack([tank, d_list[it][:, None]])
+        ppj = tank[1, :] if tank.shape[1] < 5 else tank[1, -5:]
+        it += 1
+        if (np.sum(ppj < p_th) > 4) or (p_ < 0.9):
+            p_ += 4 * p_step
+            break
+        p_ -= p_step
+    return p_, it
+
+
+@pytest.mark.parametrize("world", [1, 2, 3, 8])
+def test_speculative_search_rounds_reproduce_the_serial_decisions(world):
+    rng = np.random.default_rng(world)
+    p_step, p_th = 0.001, 0.2
+    d_list = [np.sort(rng.random(5) * (0.5 - 0.012 * i) + 0.05) for i in range(150)]
+    p_ref, it_ref = _serial_search(d_list, p_th, p_step)
+    p_list = search_schedule(p_step)
+    tank, it, p_ = np.zeros((5, 0)), 0, None
+    while p_ is None:
+        results = [d_list[it + r] for r in range(world)]
+        tank, used, stopped, p_fin = consume_search_round(tank, results, p_list, it, p_th, p_step)
+        it += used
+        if stopped:
+            p_ = p_fin
+    assert (p_, it) == (p_ref, it_ref)
+    assert tank.shape[1] == it_ref
+
+
+def test_ensemble_ownership_is_a_partition():
+    for world in (1, 2, 4, 8):
+        owned = [owned_perturbations(r, world, 20) for r in range(world)]
+        assert sorted(sum(owned, [])) == list(range(20))
+        assert max(map(len, owned)) == -(-20 // world)

@@ -1,0 +1,114 @@
+"""CPU: the oracle against its committed golden vectors, plus the invariants the reference's arithmetic implies
+(normalisation invariants, Gram spectrum identities, MP fixed point). PARITY UNPINNED (see oracle header)."""
+import os
+
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+from oracle import sclens_oracle as O
+from sclens_amd.synth import synth_counts
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def load_case(name):
+    g = np.load(os.path.join(GOLD, name + ".npz"))
+    X = sp.csc_matrix((g["data"], g["indices"], g["indptr"]), shape=(int(g["N"]), int(g["M"])))
+    Xr = sp.csc_matrix((g["xr_data"], g["xr_indices"], g["xr_indptr"]), shape=X.shape)
+    so, po = np.cumsum(np.r_[0, g["search_len"]]), np.cumsum(np.r_[0, g["pert_len"]])
+
+    def sampler(kind, it, population, m):
+        if kind == "search":
+            idx = g["search_idx"][so[it]: so[it + 1]]
+        else:
+            idx = g["pert_idx"][po[it]: po[it + 1]]
+        assert len(idx) == m
+        return idx.astype(np.int64)
+
+    return g, X, Xr, sampler
+
+
+def test_normalisation_invariants():
+    X = synth_counts(120, 200, seed=5, C=3, marker_frac=0.2, marker_sd=1.2)
+    dense, rec = O.zscore_with_l2(O.pre_scale(X))
+    rn = np.linalg.norm(dense, axis=1)
+    assert np.allclose(rn, rn.mean(), rtol=1e-10)  # every row has the same L2 norm (scLENS.jl:604)
+    S = O.logn_scale(O.pre_scale(X))
+    assert np.abs(S.mean(axis=0)).max() < 1e-12  # column means 0 after :305
+    S2, rec2 = O.scale_main(X)
+    assert np.abs(S2.mean(axis=0)).max() < 1e-12
+    assert np.allclose(rec2["TGC"], np.asarray(X.sum(axis=1)).ravel())
+    # the sparse l2 identity of :603 equals the direct norm of the centred row
+    Z = O.pre_scale(X).astype(np.float64).toarray() / rec["mat2_std"][None, :]
+    assert np.allclose(rec["norm_tgc"], np.linalg.norm(Z - Z.mean(axis=0, keepdims=True), axis=1), rtol=1e-9)
+
+
+def test_gram_spectrum_identities():
+    rng = np.random.default_rng(0)
+    X = rng.standard_normal((40, 70))
+    Y1, Y2 = O.wishart_matrix(X, 1), O.wishart_matrix(X, 2)
+    assert np.allclose(Y1, Y1.T) and np.allclose(Y2, Y2.T)
+    l1, l2 = np.linalg.eigvalsh(Y1), np.linalg.eigvalsh(Y2)
+    assert l1.min() > -1e-12
+    assert np.allclose(l1, l2[-40:], atol=1e-10)  # XX'/M and X'X/M share the non-zero spectrum
+    L, V = O.get_eigen(Y1)
+    assert np.all(np.diff(L) >= 0)
+
+
+def test_mp_known_answers():
+    g = np.load(os.path.join(GOLD, "mp_known_answers.npz"))
+    for name in ("white", "spiked"):
+        L, Lr, exp = g[name + "_L"], g[name + "_Lr"], g[name + "_expect"]
+        L_mp, bp, bm = O.mp_calculation(L, Lr[:-1])
+        lam, gamma, p, sigma = O.tw(L, L_mp)
+        chk = O.mp_check(L_mp)
+        got = np.array([len(L_mp), bp, bm, lam, gamma, p, sigma, chk["ks_static"], float(chk["pass"]), float(np.sum(L > lam))])
+        assert np.allclose(got, exp, rtol=1e-12, atol=0)
+    assert g["white_expect"][-1] == 0  # pure noise: no signal above the TW-shifted edge
+    assert g["spiked_expect"][-1] >= 3  # the three planted spikes are found
+    # fixed point of the bulk fit: re-running from its own edges does not move them
+    L, Lr = g["spiked_L"], g["spiked_Lr"]
+    L_mp, bp, bm = O.mp_calculation(L, Lr[:-1])
+    par = O.mp_parameters(L_mp)
+    assert (1 - par["b_plus"] / bp) ** 2 <= 1e-6
+
+
+@pytest.mark.parametrize("name", ["synth_300x500", "synth_600x250"])
+def test_oracle_matches_golden(name):
+    g, X, Xr, sampler = load_case(name)
+    d = O.Draws(g["z1"], g["z2"], Xr, float(g["p_th"]), sampler)
+    res = O.sclens(X, d, n_perturb=len(g["pert_len"]), null_tol=O.NULL_DROP)
+    assert np.allclose(res["L"], g["L"], rtol=1e-9, atol=1e-12)
+    assert len(res["L_mp"]) == int(g["n_L_mp"])
+    assert np.isclose(res["lambda_c"], float(g["lambda_c"]), rtol=1e-10)
+    assert res["n_search"] == int(g["n_search"]) and res["p_"] == float(g["p_"])
+    assert np.allclose(np.array([a for _, a in res["search_trace"]]), g["search_trace"], atol=1e-8)
+    assert np.array_equal(res["sig_id"], g["sig_id"])
+    assert np.array_equal(res["robustness_scores"]["a_b"], g["a_b"])
+    assert np.allclose(res["robustness_scores"]["b_"], g["b_"], atol=1e-8)
+
+
+def test_null_policy_only_changes_the_structural_zero():
+    """NULL_DROP vs the literal `L .> 0` differ by at most the one structurally zero eigenvalue (SURVEY 8a defect 6)."""
+    X = synth_counts(80, 130, seed=9, C=3, marker_frac=0.2, marker_sd=1.2)
+    S = O.logn_scale(O.pre_scale(X))
+    a, _ = O.get_eigvec(S, 0.0)
+    b, _ = O.get_eigvec(S, O.NULL_DROP)
+    assert len(a) - len(b) in (0, 1)
+    assert np.allclose(a[: len(b)], b)
+    if len(a) > len(b):
+        assert a[-1] < 1e-9 * a[0]
+
+
+def test_random_nz_keeps_column_counts_and_values():
+    X = synth_counts(60, 90, seed=2, C=3)
+    Xr = O.random_nz(X, np.random.default_rng(3))
+    assert Xr.shape == X.shape
+    assert np.array_equal(np.diff(Xr.indptr), np.diff(X.indptr))
+    assert np.array_equal(np.sort(Xr.data), np.sort(X.data))
+    z1, z2 = O.zero_candidates(X, np.random.default_rng(4))
+    assert len(z1) == len(z2) > 0
+    assert np.all(X[z1.astype(int), z2.astype(int)] == 0)
+    key = z1.astype(np.int64) + z2.astype(np.int64) * X.shape[0]
+    assert len(np.unique(key)) == len(key)
