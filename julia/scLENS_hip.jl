@@ -1,0 +1,135 @@
+# scLENS_hip.jl -- thin `ccall` shim that puts libsclens_hip.so behind scLENS.sclens(pre_df; device_="hip").
+#
+# NOT EXECUTED in the build image (no `julia` binary there or on the GPU box): kept deliberately thin, every call is a
+# 1:1 binding of include/sclens_hip.h; the same C ABI is exercised by sclens_amd/api.py (ctypes) and the test-suite.
+# Reference: Mathbiomed/scLENS v2.0.1, src/scLENS.jl. Include after `using scLENS`:
+#     include("scLENS_hip.jl");  res = scLENS.sclens(pre_df; device_="hip")
+module ScLENSHip
+
+using SparseArrays, Random, StatsBase, Distributions, DataFrames
+import scLENS
+
+const LIB = get(ENV, "SCLENS_HIP_LIB", joinpath(@__DIR__, "..", "sclens_amd", "libsclens_hip.so"))
+
+struct HipError <: Exception
+    code::Cint
+    msg::String
+end
+check(ctx, rc) = rc == 0 ? nothing : throw(HipError(rc, unsafe_string(ccall((:sclens_hip_last_error, LIB), Cstring, (Ptr{Cvoid},), ctx))))
+
+function with_ctx(f, device::Integer=0)
+    h = Ref{Ptr{Cvoid}}(C_NULL)
+    rc = ccall((:sclens_hip_create, LIB), Cint, (Ref{Ptr{Cvoid}}, Cint), h, device)
+    rc == 0 || throw(HipError(rc, "sclens_hip_create"))
+    try
+        return f(h[])
+    finally
+        ccall((:sclens_hip_destroy, LIB), Cvoid, (Ptr{Cvoid},), h[])
+    end
+end
+
+# ---- (A) per-call drop-ins: what `device == "hip"` would do inside the five reference functions -------------------
+function _wishart_matrix(ctx, X::Matrix{Float32}; dims=1)                      # scLENS.jl:332-361
+    N, M = size(X); n = dims == 2 ? M : N
+    Y = Matrix{Float32}(undef, n, n)
+    GC.@preserve X Y check(ctx, ccall((:sclens_hip_wishart_matrix_f32, LIB), Cint,
+        (Ptr{Cvoid}, Ptr{Float32}, Int64, Int64, Cint, Ptr{Float32}), ctx, X, N, M, dims, Y))
+    Y
+end
+function _get_eigen(ctx, Y::Matrix{Float32})                                  # scLENS.jl:375-387
+    n = size(Y, 1); L = Vector{Float32}(undef, n); V = Matrix{Float32}(undef, n, n)
+    rc = GC.@preserve Y L V ccall((:sclens_hip_get_eigen_f32, LIB), Cint,
+        (Ptr{Cvoid}, Ptr{Float32}, Int64, Ptr{Float32}, Ptr{Float32}), ctx, Y, n, L, V)
+    rc == 6 && return scLENS._get_eigen(Float64.(Y); device="cpu")           # NaN -> Float64 CPU redo (:379-381)
+    check(ctx, rc); (L, V)
+end
+function corr_mat(ctx, X::Matrix{Float32}, Y::Matrix{Float32})               # scLENS.jl:363-373
+    n, p = size(X); q = size(Y, 2); out = Matrix{Float32}(undef, p, q)
+    GC.@preserve X Y out check(ctx, ccall((:sclens_hip_corr_mat_f32, LIB), Cint,
+        (Ptr{Cvoid}, Ptr{Float32}, Int64, Int64, Ptr{Float32}, Int64, Ptr{Float32}), ctx, X, n, p, Y, q, out))
+    out
+end
+
+# ---- (B) device-resident sclens() --------------------------------------------------------------------------------
+csc0(X::SparseMatrixCSC) = (Int64.(X.colptr) .- 1, Int32.(X.rowval) .- Int32(1), Float32.(X.nzval))
+
+function sclens_hip(inp_df; th=60, p_step=0.001, n_perturb=20, device=0)
+    X_ = scLENS.df2sparr(inp_df)                                              # :662
+    N, M = size(X_); nm = min(N, M)
+    nz_row, nz_col, nz_val = findnz(X_)
+    # R1 zero candidates (:668-673), 0-based for the ABI
+    sample_idx = [(i, j) for (i, j) in zip(rand(UInt32(1):UInt32(N), length(nz_val)), rand(UInt32(1):UInt32(M), length(nz_val)))]
+    nzz_ = setdiff(sample_idx, [(i, j) for (i, j) in zip(nz_row, nz_col)])
+    z1 = UInt32[s[1] - 1 for s in nzz_]; z2 = UInt32[s[2] - 1 for s in nzz_]
+    X_r = scLENS.df2sparr(scLENS.random_nz(inp_df, rmix=true))                # R2 (:701)
+    cp, rv, nz = csc0(X_); rcp, rrv, rnz = csc0(X_r)
+    with_ctx(device) do ctx
+        ses = Ref{Ptr{Cvoid}}(C_NULL)
+        GC.@preserve cp rv nz z1 z2 check(ctx, ccall((:sclens_hip_session_create, LIB), Cint,
+            (Ptr{Cvoid}, Int64, Int64, Ptr{Int64}, Ptr{Int32}, Ptr{Float32}, Int64, Ptr{UInt32}, Ptr{UInt32}, Ref{Ptr{Cvoid}}),
+            ctx, N, M, cp, rv, nz, length(z1), z1, z2, ses))
+        s = ses[]
+        try
+            L = Vector{Float64}(undef, nm); Lr = similar(L)
+            rec = Dict("TGC" => zeros(N), "mat2_mean" => zeros(M), "mat2_std" => zeros(M), "norm_tgc" => zeros(N), "cent_" => zeros(M))
+            GC.@preserve rcp rrv rnz L Lr rec check(ctx, ccall((:sclens_hip_session_spectrum, LIB), Cint,
+                (Ptr{Cvoid}, Ptr{Int64}, Ptr{Int32}, Ptr{Float32}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}),
+                s, rcp, rrv, rnz, L, Lr, rec["TGC"], rec["mat2_mean"], rec["mat2_std"], rec["norm_tgc"], rec["cent_"]))
+            L_mp, _, b_min = scLENS._mp_calculation(L, Lr[1:end-1])           # host statistics stay in Julia (:537-538)
+            lambda_c, _ = scLENS._tw(L, L_mp)
+            k = sum(L .> lambda_c); nL = reverse(L[L .> lambda_c])
+            nV = Matrix{Float32}(undef, N, k)
+            GC.@preserve nV check(ctx, ccall((:sclens_hip_session_signal_vectors, LIB), Cint, (Ptr{Cvoid}, Int64, Ptr{Float32}), s, k, nV))
+            mpC_ = scLENS.mp_check(L_mp)
+            p_th = mean([maximum(abs.(rand(Normal(0, sqrt(1 / nm)), nm))) for _ = 1:5000])   # R3 (:709-712)
+            r = Ref{Int64}(0)
+            check(ctx, ccall((:sclens_hip_session_binary_basis, LIB), Cint, (Ptr{Cvoid}, Ptr{Float64}, Ref{Int64}), s, C_NULL, r))
+            n_2 = round(Int, r[] / 2)                                         # :722
+            p_ = 0.999; tank_ = zeros(5, 0); d5 = zeros(5); rit = Ref{Int64}(0)
+            while true                                                       # :725-761
+                nnzidx = Int(round((1 - p_) * M * N))
+                if length(z1) < nnzidx; p_ += p_step; break; end
+                sple = UInt32.(sample(UInt32(1):UInt32(length(z1)), nnzidx, replace=false) .- 1)   # R4
+                GC.@preserve sple d5 check(ctx, ccall((:sclens_hip_session_search_step, LIB), Cint,
+                    (Ptr{Cvoid}, Ptr{UInt32}, Int64, Int64, Ptr{Float64}, Ref{Int64}), s, sple, nnzidx, n_2, d5, rit))
+                tank_ = hcat(tank_, d5)
+                ppj_ = size(tank_, 2) < 5 ? tank_[2, :] : tank_[2, end-4:end]
+                if (sum(ppj_ .< p_th) > 4) | (p_ < 0.9); p_ += 4p_step; break; end
+                p_ -= p_step
+            end
+            min_s = k; min_pc = Int(ceil(min_s * 1.5))
+            iszero(min_s) && return Dict(:L => L, :L_mp => L_mp, :λ => lambda_c, :cell_id => string.(inp_df.cell))   # :780-784
+            nLt = zeros(min_pc); nc = Ref{Int64}(0)
+            for t in 1:n_perturb                                             # :771-778
+                sple = UInt32.(sample(UInt32(1):UInt32(length(z1)), Int(round((1 - p_) * M * N)), replace=false) .- 1)   # R5
+                GC.@preserve sple nLt check(ctx, ccall((:sclens_hip_session_perturb, LIB), Cint,
+                    (Ptr{Cvoid}, Int64, Ptr{UInt32}, Int64, Int64, Ptr{Float64}, Ref{Int64}), s, t - 1, sple, length(sple), min_pc, nLt, nc))
+            end
+            npairs = div(n_perturb * (n_perturb - 1), 2)
+            a_b = Matrix{Int32}(undef, k, n_perturb); bt = Matrix{Float64}(undef, npairs, k)   # row-major k x npairs
+            GC.@preserve a_b bt check(ctx, ccall((:sclens_hip_session_robustness, LIB), Cint, (Ptr{Cvoid}, Int64, Ptr{Int32}, Ptr{Float64}), s, n_perturb, a_b, bt))
+            b_ = permutedims(bt)
+            q1 = mapslices(x -> quantile(x, 0.25), b_, dims=2)[:]; q3 = mapslices(x -> quantile(x, 0.75), b_, dims=2)[:]
+            iq = mapslices(iqr, b_, dims=2)[:]
+            filt = [b_[i, :][q1[i]-1.5*iq[i].<=b_[i, :].<=q3[i]+1.5*iq[i]] for i = 1:k]
+            m_score = median.(filt); sd_score = std.(filt)
+            sig_id = findall(m_score .> cos(deg2rad(th)))
+            gt = Matrix{Float32}(undef, M, k)                                 # k rows of M genes, row-major
+            GC.@preserve nL gt check(ctx, ccall((:sclens_hip_session_gene_basis, LIB), Cint, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float32}), s, Float64.(nL), gt))
+            df_X0 = DataFrame(nV .* (sqrt.(nL))', :auto); insertcols!(df_X0, 1, :cell => inp_df.cell)
+            df_X1 = DataFrame(nV[:, sig_id] .* sqrt.(nL[sig_id])', :auto); insertcols!(df_X1, 1, :cell => inp_df.cell)
+            return Dict(:pca => df_X0, :pca_n1 => df_X1, :sig_id => sig_id, :L => L, :L_mp => L_mp, :λ => lambda_c,
+                :robustness_scores => Dict(:b_ => b_, :rob_score => m_score, :m_scores => m_score, :sd_scores => sd_score),
+                :signal_evec => nV, :signal_ev => nL, :cell_id => inp_df.cell, :gene_id => names(inp_df)[2:end],
+                :gene_basis => permutedims(gt), :pass => mpC_[:pass], :rec_vals => rec)   # keys of :826-829
+        finally
+            ccall((:sclens_hip_session_destroy, LIB), Cvoid, (Ptr{Cvoid},), s)
+        end
+    end
+end
+
+end # module
+
+# One-line hook a maintainer adds at the top of scLENS.sclens (src/scLENS.jl:649):
+#     device_ == "hip" && return ScLENSHip.sclens_hip(inp_df; th=th, p_step=p_step, n_perturb=n_perturb)
+# On HipError code 2 (no device) or 3 (OOM) fall back to device_="cpu", mirroring example.jl:9-14 and :504-508.
