@@ -143,7 +143,7 @@ def main():
     t_synth = time.perf_counter() - t0
 
     def one_step(step):
-        draws = api.make_draws(X, seed=1000 + step)  # R1-R3 inside the timed region; R4/R5 inside sclens()
+        draws = api.make_draws_native(X, seed=1000 + step)  # R1-R3 inside the timed region; R4/R5 on the device inside sclens()
         return api.sclens(X, draws=draws, ctx=ctx, n_perturb=args.n_perturb, shard=shard, verbose=args.verbose and rank == 0)
 
     def fence():

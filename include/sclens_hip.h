@@ -86,6 +86,19 @@ int sclens_robust_scores(const double* b, int64_t k, int64_t npairs, double* m_s
 /* expected max |N(0,1/n)| over n draws, the quantity scLENS.jl:709-712 estimates with 5000 trials */
 double sclens_noise_baseline_exact(int64_t n);
 
+/* ---------------------------------------------------------------- random draws (host, no GPU) -- */
+/* R1, scLENS.jl:668-673: nnz uniform (i,j) draws minus the stored entries, de-duplicated in first-occurrence order.
+ * z1/z2 need capacity nnz; *count receives the number of candidates. 0-based. */
+int sclens_draw_zero_candidates(int64_t N, int64_t M, const int64_t* colptr, const int32_t* rowval, uint64_t seed,
+                                uint32_t* z_idx1, uint32_t* z_idx2, int64_t* count);
+/* R2, scLENS.jl:701 (random_nz, rmix=true): stored values shuffled globally, each gene keeps its number of entries at
+ * uniformly drawn distinct cells (rows ascending). Same colptr as the input. */
+int sclens_draw_null_matrix(int64_t N, int64_t M, const int64_t* colptr, const float* nzval, uint64_t seed,
+                            int32_t* out_rowval, float* out_nzval);
+/* R4/R5, scLENS.jl:731, :772: m distinct indices of [0, len) -- the same keyed permutation the *_seeded session calls
+ * evaluate on the device, so host and device samples are identical for equal (len, m, seed). */
+int sclens_sample_without_replacement(uint64_t len, int64_t m, uint64_t seed, uint32_t* out);
+
 /* ---------------------------------------------------------------- (B) device-resident session -- */
 /* Count matrix (what df2sparr(inp_df) returns, scLENS.jl:662) + the zero-candidate list
  * (z_idx1, z_idx2 of scLENS.jl:668-673, 0-based, disjoint from the stored entries, unique). */
@@ -111,6 +124,11 @@ int sclens_hip_session_binary_basis(sclens_hip_session* s, double* L_bin, int64_
  * (0-based, distinct); n_2 as at scLENS.jl:722. d5 = the five smallest values of d_arr, ascending. */
 int sclens_hip_session_search_step(sclens_hip_session* s, const uint32_t* sample, int64_t m, int64_t n_2, double* d5,
                                    int64_t* r_it);
+/* The same with the sample drawn on the device: indices sclens_sample_without_replacement(n_cand, m, seed). */
+int sclens_hip_session_search_step_seeded(sclens_hip_session* s, uint64_t seed, int64_t m, int64_t n_2, double* d5,
+                                          int64_t* r_it);
+int sclens_hip_session_perturb_seeded(sclens_hip_session* s, int64_t t, uint64_t seed, int64_t m, int64_t min_pc,
+                                      double* nL_top, int64_t* ncols);
 /* One member of the perturbation ensemble (scLENS.jl:772-777): keeps the first min(min_pc, r) cell-side
  * eigenvectors in device slot t; nL_top[min_pc] their eigenvalues (descending); *ncols their number. */
 int sclens_hip_session_perturb(sclens_hip_session* s, int64_t t, const uint32_t* sample, int64_t m, int64_t min_pc,

@@ -47,6 +47,11 @@ SIGNATURES = {
     "sclens_mp_check": (C.c_int, [c_f64p, i64, C.c_double, c_f64p, C.POINTER(C.c_int)]),
     "sclens_robust_scores": (C.c_int, [c_f64p, i64, i64, c_f64p, c_f64p]),
     "sclens_noise_baseline_exact": (C.c_double, [i64]),
+    "sclens_draw_zero_candidates": (C.c_int, [i64, i64, c_i64p, c_i32p, C.c_uint64, c_u32p, c_u32p, c_i64p]),
+    "sclens_draw_null_matrix": (C.c_int, [i64, i64, c_i64p, c_f32p, C.c_uint64, c_i32p, c_f32p]),
+    "sclens_sample_without_replacement": (C.c_int, [C.c_uint64, i64, C.c_uint64, c_u32p]),
+    "sclens_hip_session_search_step_seeded": (C.c_int, [vp, C.c_uint64, i64, i64, c_f64p, c_i64p]),
+    "sclens_hip_session_perturb_seeded": (C.c_int, [vp, i64, C.c_uint64, i64, i64, c_f64p, c_i64p]),
     "sclens_hip_session_create": (C.c_int, [vp, i64, i64, c_i64p, c_i32p, c_f32p, i64, c_u32p, c_u32p, C.POINTER(vp)]),
     "sclens_hip_session_destroy": (None, [vp]),
     "sclens_hip_session_spectrum": (C.c_int, [vp, c_i64p, c_i32p, c_f32p, c_f64p, c_f64p, c_f64p, c_f64p, c_f64p, c_f64p, c_f64p]),

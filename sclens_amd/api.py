@@ -158,7 +158,29 @@ class Draws:
     z_idx2: np.ndarray
     X_r: sp.csc_matrix
     p_th: float
-    sampler: Callable[[str, int, int, int], np.ndarray] = None
+    # R4/R5: (kind, iteration, population, m) -> index vector; None = draw on the device from `sample_seed`
+    sampler: Optional[Callable[[str, int, int, int], np.ndarray]] = None
+    sample_seed: int = 0
+
+
+_M64 = (1 << 64) - 1
+
+
+def sample_seed_for(base_seed: int, kind: str, it: int) -> int:
+    """Seed of the keyed permutation used for the sample of (kind, iteration)."""
+    k = 1 if kind == "search" else 2
+    return (base_seed * 0x9E3779B97F4A7C15 + k * 0x632BE59BD9B4E019 + (it + 1) * 0xD1B54A32D192ED03) & _M64
+
+
+def sample_indices(population: int, m: int, seed: int) -> np.ndarray:
+    """m distinct indices of [0, population): the host evaluation of the permutation the device uses
+    (sclens_sample_without_replacement)."""
+    lib = _lib.load()
+    out = np.empty(m, dtype=np.uint32)
+    rc = lib.sclens_sample_without_replacement(int(population), int(m), int(seed) & _M64, ptr(out, C.c_uint32))
+    if rc:
+        raise SclensHipError(rc, "sclens_sample_without_replacement")
+    return out
 
 
 def _csc_f32(X) -> sp.csc_matrix:
@@ -206,6 +228,38 @@ def draw_noise_baseline(n: int, rng: np.random.Generator, trials: int = 5000) ->
         acc += float(np.abs(rng.standard_normal((t, n))).max(axis=1).sum()) * sd
         done += t
     return acc / trials
+
+
+def make_draws_native(X, seed: int, host_sampler: bool = False) -> Draws:
+    """All draws from the library's own generators (C++ on the host for R1/R2, the exact expectation for R3 --
+    the quantity scLENS.jl:709-712 estimates with 5000 Monte-Carlo trials -- and the device-side keyed permutation
+    for R4/R5). `host_sampler=True` materialises the identical R4/R5 index vectors on the host instead."""
+    lib = _lib.load()
+    X = _csc_f32(X)
+    N, M = X.shape
+    cp = np.ascontiguousarray(X.indptr, dtype=np.int64)
+    rv = np.ascontiguousarray(X.indices, dtype=np.int32)
+    nz = np.ascontiguousarray(X.data, dtype=np.float32)
+    z1 = np.empty(X.nnz, dtype=np.uint32)
+    z2 = np.empty(X.nnz, dtype=np.uint32)
+    cnt = C.c_int64(0)
+    rc = lib.sclens_draw_zero_candidates(N, M, ptr(cp, C.c_int64), ptr(rv, C.c_int32), int(seed) & _M64, ptr(z1, C.c_uint32),
+                                         ptr(z2, C.c_uint32), C.byref(cnt))
+    if rc:
+        raise SclensHipError(rc, "sclens_draw_zero_candidates")
+    z1, z2 = z1[: cnt.value].copy(), z2[: cnt.value].copy()
+    rrow = np.empty(X.nnz, dtype=np.int32)
+    rval = np.empty(X.nnz, dtype=np.float32)
+    rc = lib.sclens_draw_null_matrix(N, M, ptr(cp, C.c_int64), ptr(nz, C.c_float), (int(seed) + 1) & _M64, ptr(rrow, C.c_int32),
+                                     ptr(rval, C.c_float))
+    if rc:
+        raise SclensHipError(rc, "sclens_draw_null_matrix")
+    Xr = sp.csc_matrix((rval, rrow, cp.copy()), shape=(N, M), dtype=np.float32)
+    p_th = float(lib.sclens_noise_baseline_exact(min(N, M)))
+    d = Draws(z1, z2, Xr, p_th, None, int(seed))
+    if host_sampler:
+        d.sampler = lambda kind, it, population, m: sample_indices(population, m, sample_seed_for(int(seed), kind, it))
+    return d
 
 
 def make_draws(X, seed: int, p_th_trials: int = 5000) -> Draws:
@@ -286,6 +340,20 @@ class Session:
         self.ctx.check(self.ctx.lib.sclens_hip_session_search_step(self.h, ptr(s, C.c_uint32), s.size, int(n_2),
                                                                    ptr(d5, C.c_double), C.byref(r)))
         return d5, r.value
+
+    def search_step_seeded(self, seed: int, m: int, n_2: int):
+        d5 = np.empty(5)
+        r = C.c_int64(0)
+        self.ctx.check(self.ctx.lib.sclens_hip_session_search_step_seeded(self.h, int(seed) & _M64, int(m), int(n_2),
+                                                                          ptr(d5, C.c_double), C.byref(r)))
+        return d5, r.value
+
+    def perturb_seeded(self, t: int, seed: int, m: int, min_pc: int):
+        nL = np.empty(min_pc)
+        c = C.c_int64(0)
+        self.ctx.check(self.ctx.lib.sclens_hip_session_perturb_seeded(self.h, int(t), int(seed) & _M64, int(m), int(min_pc),
+                                                                      ptr(nL, C.c_double), C.byref(c)))
+        return nL[: c.value], c.value
 
     def perturb(self, t: int, sample: np.ndarray, min_pc: int):
         s = np.ascontiguousarray(sample, dtype=np.uint32)
@@ -390,7 +458,7 @@ def sclens(inp_df, device_="gpu", th=60, p_step=0.001, n_perturb=20, centering="
     X_, cell_id, gene_id = _extract(inp_df)  # :662
     N, M = X_.shape
     if draws is None:
-        draws = make_draws(X_, seed if seed is not None else int(time.time_ns() % (2**31)))
+        draws = make_draws_native(X_, seed if seed is not None else int(time.time_ns() % (2**31)))
     z1, z2 = draws.z_idx1, draws.z_idx2
     ses = Session(ctx, X_, z1, z2)
     try:
@@ -418,8 +486,11 @@ def sclens(inp_df, device_="gpu", th=60, p_step=0.001, n_perturb=20, centering="
             mine = np.full(6, np.nan)
             nnzidx = int(round((1 - p_list[my_it]) * M * N))  # :726
             if len(z1) >= nnzidx:
-                idx = draws.sampler("search", my_it, len(z1), nnzidx)  # :731
-                d5, _r = ses.search_step(idx, n_2)  # :733-747
+                if draws.sampler is not None:
+                    idx = draws.sampler("search", my_it, len(z1), nnzidx)  # :731
+                    d5, _r = ses.search_step(idx, n_2)  # :733-747
+                else:
+                    d5, _r = ses.search_step_seeded(sample_seed_for(draws.sample_seed, "search", my_it), nnzidx, n_2)
                 mine[:5], mine[5] = d5, 1.0
             allr = shard.allgather_small(mine)
             results = [allr[q, :5] if allr[q, 5] == 1.0 else None for q in range(shard.world)]
@@ -439,8 +510,11 @@ def sclens(inp_df, device_="gpu", th=60, p_step=0.001, n_perturb=20, centering="
         ncols = [0] * n_perturb
         if min_s > 0:
             for t in owned_perturbations(shard.rank, shard.world, n_perturb):
-                idx = draws.sampler("perturb", t, len(z1), m_pert)
-                nL_set[t], ncols[t] = ses.perturb(t, idx, min_pc)
+                if draws.sampler is not None:
+                    idx = draws.sampler("perturb", t, len(z1), m_pert)
+                    nL_set[t], ncols[t] = ses.perturb(t, idx, min_pc)
+                else:
+                    nL_set[t], ncols[t] = ses.perturb_seeded(t, sample_seed_for(draws.sample_seed, "perturb", t), m_pert, min_pc)
             if shard.world > 1:
                 _exchange_ensemble(ses, shard, n_perturb, min_pc, nL_set, ncols)
 

@@ -13,6 +13,8 @@ int session_binary_basis(Session*, double*, int64_t*);
 int session_search_step(Session*, const uint32_t*, int64_t, int64_t, double*, int64_t*);
 int session_perturb(Session*, int64_t, const uint32_t*, int64_t, int64_t, double*, int64_t*);
 int session_get_perturbed(Session*, int64_t, float*);
+int session_search_step_seeded(Session*, uint64_t, int64_t, int64_t, double*, int64_t*);
+int session_perturb_seeded(Session*, int64_t, uint64_t, int64_t, int64_t, double*, int64_t*);
 int session_robustness(Session*, int64_t, int32_t*, double*);
 int session_gene_basis(Session*, const double*, float*);
 int64_t session_slot_ld(Session*);
@@ -160,6 +162,18 @@ int sclens_hip_session_perturb(sclens_hip_session* w, int64_t t, const uint32_t*
   SES_GUARD(w);
   if (!nL_top || (m > 0 && !sample)) return SCLENS_ERR_ARG;
   return scl::session_perturb(w->s, t, sample, m, min_pc, nL_top, ncols);
+}
+int sclens_hip_session_search_step_seeded(sclens_hip_session* w, uint64_t seed, int64_t m, int64_t n_2, double* d5,
+                                          int64_t* r_it) {
+  SES_GUARD(w);
+  if (!d5) return SCLENS_ERR_ARG;
+  return scl::session_search_step_seeded(w->s, seed, m, n_2, d5, r_it);
+}
+int sclens_hip_session_perturb_seeded(sclens_hip_session* w, int64_t t, uint64_t seed, int64_t m, int64_t min_pc,
+                                      double* nL_top, int64_t* ncols) {
+  SES_GUARD(w);
+  if (!nL_top) return SCLENS_ERR_ARG;
+  return scl::session_perturb_seeded(w->s, t, seed, m, min_pc, nL_top, ncols);
 }
 int sclens_hip_session_get_perturbed(sclens_hip_session* w, int64_t t, float* out) {
   SES_GUARD(w);

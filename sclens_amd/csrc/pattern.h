@@ -44,5 +44,8 @@ int scale_to_dense(Ctx* ctx, const PatternDev& p, const float* val, int f32path,
 // val = (binary ? pattern-of-counts : counts), then 1 at the candidate slots idx_dev[0..m)
 int make_values(Ctx* ctx, const PatternDev& p, const float* base_val, int binary, const uint32_t* idx_dev, int64_t m,
                 float* out);
+// the same with idx = the first m values of the keyed Feistel permutation of [0, ncand) (rng.h), evaluated on the device
+int make_values_seeded(Ctx* ctx, const PatternDev& p, const float* base_val, int binary, uint64_t seed, int64_t m,
+                       float* out);
 
 }  // namespace scl

@@ -1,0 +1,62 @@
+// Counter-based randomness shared by host (rng.cpp) and device (scale.hip): a keyed bijection of [0, len) built from a
+// balanced Feistel network with cycle walking. Evaluating it at t = 0..m-1 yields m distinct, uniformly scattered
+// indices -- a sample without replacement (scLENS.jl:731, :772: `sample(1:len, m, replace=false)`) that needs no
+// memory, no host round trip, and is identical on host and device.
+#pragma once
+#include <cstdint>
+
+#if defined(__HIPCC__)
+#define SCL_HD __host__ __device__
+#else
+#define SCL_HD
+#endif
+
+namespace scl {
+
+SCL_HD inline uint32_t mix32(uint32_t x) {  // murmur3 finaliser
+  x ^= x >> 16; x *= 0x85EBCA6Bu; x ^= x >> 13; x *= 0xC2B2AE35u; x ^= x >> 16;
+  return x;
+}
+SCL_HD inline uint64_t splitmix64(uint64_t& s) {
+  uint64_t z = (s += 0x9E3779B97F4A7C15ull);
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  return z ^ (z >> 31);
+}
+
+struct FeistelPerm {
+  uint64_t len;
+  uint32_t half_bits, half_mask;
+  uint32_t key[6];
+};
+
+inline FeistelPerm feistel_make(uint64_t len, uint64_t seed) {
+  FeistelPerm p;
+  p.len = len;
+  uint32_t bits = 2;
+  while ((1ull << bits) < len) ++bits;
+  if (bits & 1u) ++bits;
+  p.half_bits = bits / 2;
+  p.half_mask = (1u << p.half_bits) - 1u;
+  uint64_t s = seed ^ 0xD1B54A32D192ED03ull;
+  for (int i = 0; i < 6; ++i) p.key[i] = (uint32_t)(splitmix64(s) >> 16);
+  return p;
+}
+
+SCL_HD inline uint64_t feistel_apply(const FeistelPerm& p, uint64_t t) {
+  uint64_t x = t;
+  do {  // cycle walking: the domain 2^(2*half_bits) is < 4*len, so <= 4 expected iterations
+    uint32_t L = (uint32_t)(x >> p.half_bits) & p.half_mask, R = (uint32_t)x & p.half_mask;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+      const uint32_t F = mix32(R * 0x9E3779B1u + p.key[i]) & p.half_mask;
+      const uint32_t nl = R;
+      R = L ^ F;
+      L = nl;
+    }
+    x = ((uint64_t)L << p.half_bits) | R;
+  } while (x >= p.len);
+  return x;
+}
+
+}  // namespace scl

@@ -13,6 +13,7 @@
 // perturbation costs one scatter of ones instead of a sparse(...) rebuild.
 #include "common.h"
 #include "pattern.h"
+#include "rng.h"
 
 namespace scl {
 
@@ -255,6 +256,26 @@ int make_values(Ctx* ctx, const PatternDev& p, const float* base_val, int binary
   if (m > 0)
     hipLaunchKernelGGL(k_val_set_ones, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, ctx->stream, idx_dev, m,
                        p.cand_pos, out);
+  SCL_HIP(ctx, hipGetLastError());
+  return SCLENS_OK;
+}
+
+__global__ void k_val_set_ones_feistel(FeistelPerm perm, int64_t m, const int64_t* __restrict__ cand_pos,
+                                       float* __restrict__ out) {
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t < m) out[cand_pos[feistel_apply(perm, (uint64_t)t)]] = 1.f;
+}
+
+int make_values_seeded(Ctx* ctx, const PatternDev& p, const float* base_val, int binary, uint64_t seed, int64_t m,
+                       float* out) {
+  if (m < 0 || m > p.ncand) return ctx->fail(SCLENS_ERR_ARG, "make_values_seeded: bad sample size");
+  hipLaunchKernelGGL(k_val_init, dim3((unsigned)((p.nU + 255) / 256)), dim3(256), 0, ctx->stream, base_val, p.nU,
+                     binary, out);
+  if (m > 0) {
+    const FeistelPerm perm = feistel_make((uint64_t)p.ncand, seed);
+    hipLaunchKernelGGL(k_val_set_ones_feistel, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, ctx->stream, perm, m,
+                       p.cand_pos, out);
+  }
   SCL_HIP(ctx, hipGetLastError());
   return SCLENS_OK;
 }

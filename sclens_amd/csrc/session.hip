@@ -375,12 +375,23 @@ int session_binary_basis(Session* s, double* L_bin, int64_t* r_out) {
   return SCLENS_OK;
 }
 
+static int search_core(Session* s, int64_t n_2, double* d5, int64_t* r_it);
 int session_search_step(Session* s, const uint32_t* sample, int64_t m, int64_t n_2, double* d5, int64_t* r_it) {
   Ctx* ctx = s->ctx;
   if (!s->Vr2t) return ctx->fail(SCLENS_ERR_STATE, "search_step: call binary_basis first");
   if (m < 0 || m > s->pat.dev.ncand) return ctx->fail(SCLENS_ERR_ARG, "search_step: bad sample size");
   SCL_TRY(s->upload_idx(sample, m));
   SCL_TRY(make_values(ctx, s->pat.dev, s->pat.base_val, 1, s->idx_dev, m, s->val));
+  return search_core(s, n_2, d5, r_it);
+}
+int session_search_step_seeded(Session* s, uint64_t seed, int64_t m, int64_t n_2, double* d5, int64_t* r_it) {
+  Ctx* ctx = s->ctx;
+  if (!s->Vr2t) return ctx->fail(SCLENS_ERR_STATE, "search_step: call binary_basis first");
+  SCL_TRY(make_values_seeded(ctx, s->pat.dev, s->pat.base_val, 1, seed, m, s->val));
+  return search_core(s, n_2, d5, r_it);
+}
+static int search_core(Session* s, int64_t n_2, double* d5, int64_t* r_it) {
+  Ctx* ctx = s->ctx;
   SCL_TRY(decompose(s, s->pat.dev, s->val, 1, s->Btmp, (float)s->K, nullptr));
   const int64_t r = s->count_positive();
   if (r_it) *r_it = r;
@@ -410,6 +421,7 @@ int session_search_step(Session* s, const uint32_t* sample, int64_t m, int64_t n
   return SCLENS_OK;
 }
 
+static int perturb_core(Session* s, int64_t t, int64_t min_pc, double* nL_top, int64_t* ncols);
 int session_perturb(Session* s, int64_t t, const uint32_t* sample, int64_t m, int64_t min_pc, double* nL_top,
                     int64_t* ncols) {
   Ctx* ctx = s->ctx;
@@ -417,6 +429,17 @@ int session_perturb(Session* s, int64_t t, const uint32_t* sample, int64_t m, in
   if (m < 0 || m > s->pat.dev.ncand) return ctx->fail(SCLENS_ERR_ARG, "perturb: bad sample size");
   SCL_TRY(s->upload_idx(sample, m));
   SCL_TRY(make_values(ctx, s->pat.dev, s->pat.base_val, 0, s->idx_dev, m, s->val));
+  return perturb_core(s, t, min_pc, nL_top, ncols);
+}
+int session_perturb_seeded(Session* s, int64_t t, uint64_t seed, int64_t m, int64_t min_pc, double* nL_top,
+                           int64_t* ncols) {
+  Ctx* ctx = s->ctx;
+  if (t < 0 || min_pc <= 0) return ctx->fail(SCLENS_ERR_ARG, "perturb: bad slot / min_pc");
+  SCL_TRY(make_values_seeded(ctx, s->pat.dev, s->pat.base_val, 0, seed, m, s->val));
+  return perturb_core(s, t, min_pc, nL_top, ncols);
+}
+static int perturb_core(Session* s, int64_t t, int64_t min_pc, double* nL_top, int64_t* ncols) {
+  Ctx* ctx = s->ctx;
   SCL_TRY(decompose(s, s->pat.dev, s->val, 1, s->Btmp, (float)s->M, nullptr));
   const int64_t r = s->count_positive();
   const int64_t c = std::min<int64_t>(min_pc, r);

@@ -2,45 +2,54 @@
 // Replaces the first phase of the reference's `_get_eigen` (scLENS.jl:375-387), which there is
 // cuSOLVER `syevd!` (GPU) / LAPACK `dsyevr` (CPU) on a host matrix.
 //
-// Blocked (panel width NB) right-looking reduction A = Q T Q^T with the trailing matrix kept in
-// FULL symmetric storage. Three kernels per column, no host synchronisation:
-//   trd_colA : x = column j updated by the panel's reflectors (thread = row x column-group, all loads
-//              issued at once), finalisation of the previous W column, per-block partial sums of
-//              ||x||^2, V^T x, W^T x                                                   (small, many blocks)
+// Blocked (panel width NB) right-looking reduction A = Q T Q^T; the trailing matrix is kept in full
+// symmetric storage but the matrix-vector product reads only its LOWER half. Three kernels per column,
+// no host synchronisation, every reduction in a fixed order (no float atomics: bitwise reproducible):
+//   trd_colA : (1) finishes the previous column: u = A v is assembled from the partial buffers of trd_colB,
+//              w = tau (u - V (W^T v) - W (V^T v)) - 1/2 tau (w^T v) v is written as W[:, c-1];
+//              (2) x = column j of A updated by the panel's reflectors; (3) per-block partial sums of
+//              ||x||^2, V^T x, W^T x. Thread = (row, column group); all global loads are issued up front.
 //   trd_colR : one block: fixed-order reduction of those partials, Householder scalars (fp64),
-//              V^T v and W^T v                                                         (tiny)
-//   trd_colB : v = x*scale on the fly, u = A_trail * v -- the HBM-bound symmetric matrix-vector product,
-//              the dominant kernel of the whole sclens() path -- 4 rows per wave, 16 rows per block so a
-//              launch has n'/16 >> 256 blocks; then w' = tau (u - V (W^T v) - W (V^T v)) and partial w'^T v
-// and per panel one finalize/transposition kernel + one rank-2*NB symmetric MFMA update
-// (gemm_f32, lower+mirror so the matrix stays exactly symmetric).
-// All reductions run in a fixed order (no float atomics): results are bitwise reproducible.
+//              V^T v, W^T v and their dot product.
+//   trd_colB : the HBM-bound symmetric matrix-vector product u = A_trail v, v = x*scale formed on the fly --
+//              the dominant kernel of the whole sclens() path. Work unit = (strip of 32 rows) x (segment of
+//              1024 columns) of the lower trapezoid; each of the 4 waves owns one 256-column chunk for all 32
+//              rows, so its transposed contribution (u_c += A[r][c] v_r) is complete in registers and is stored
+//              once (colpart[strip][c]); row dot products are reduced across the waves in LDS (rowpart[seg][r]).
+//              Each matrix element of the lower half is read exactly once: 2 n'^2 B per column instead of 4 n'^2.
+// Per panel: one transposition kernel + one rank-2*NB symmetric MFMA update (gemm_f32, lower+mirror).
 // V^T v of each column is kept (Gst) so the block-reflector T factors need no extra pass over V.
 #include "common.h"
 
 namespace scl {
 
-constexpr int NB = 128;       // panel width (also the block-reflector width of the back-transform)
-constexpr int RPB_A = 256;    // rows per block in trd_colA (x 4 column groups = 1024 threads)
-constexpr int ROWS_B = 16;    // rows per block in trd_colB (4 waves x 4 rows)
+constexpr int NB = 128;        // panel width (also the block-reflector width of the back-transform)
+constexpr int RPB_A = 128;     // rows per block in trd_colA (x 8 column groups = 1024 threads)
+constexpr int NG_A = 8;        // column groups in trd_colA
+constexpr int RS = 32;         // strip height of trd_colB
+constexpr int SEG = 1024;      // segment width of trd_colB (4 waves x 256 columns)
 constexpr int PA_LD = 2 * NB + 1;
-constexpr int CI_LD = 2 * NB + 4;  // colinfo: [0]=tau [1]=scale, [4..4+NB) = V^T v, [4+NB..4+2NB) = W^T v
+// colinfo: [0]=tau [1]=scale [2]=(V^T v).(W^T v), [4..4+NB) = V^T v, [4+NB..4+2NB) = W^T v
+constexpr int CI_LD = 2 * NB + 4;
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 struct TrdArgs {
-  float* A;        // n x n, row-major, lda (multiple of 4, padding finite/zero)
+  float* A;         // n x n, row-major, lda (multiple of 4, padding finite/zero)
   int64_t n, lda;
-  float* VWt;      // [2*NB][ldv]: rows 0..NB-1 = V columns, NB..2NB-1 = W columns (each contiguous over matrix rows)
+  float* VWt;       // [2*NB][ldv]: rows 0..NB-1 = V columns, NB..2NB-1 = W columns (each contiguous over matrix rows)
   int64_t ldv;
-  float* x;        // [ldv] current column
-  double* partA;   // [na][PA_LD]
-  double* partB;   // [nblkB]
-  float* colinfo;  // [CI_LD]
-  double* d;       // [n]
-  double* e;       // [n]
-  float* tau;      // [n]
-  float* Gst;      // [n][NB]: Gst[j][cc] = V[:,cc]^T v_j for cc < c(j)
+  float* x;         // [ldv] current column
+  double* partA;    // [PA_LD][na_ld]  (partial sums of trd_colA, one column per block)
+  int64_t na_ld;
+  double* partB;    // [nstrips * nsegmax] partial u^T v per trd_colB block (0 for idle blocks)
+  float* colinfo;   // [CI_LD]
+  float* rowpart;   // [nsegmax][ldv]   row-dot partials of trd_colB, indexed by absolute row
+  float* colpart;   // [nstripmax][ldv] transposed partials of trd_colB, indexed by absolute column
+  double* d;        // [n]
+  double* e;        // [n]
+  float* tau;       // [n]
+  float* Gst;       // [n][NB]: Gst[j][cc] = V[:,cc]^T v_j for cc < c(j)
 };
 
 __device__ __forceinline__ double wave_sum(double v) {
@@ -54,127 +63,239 @@ __device__ __forceinline__ float wave_sumf(float v) {
   return v;
 }
 
-// ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(1024) void trd_colA(TrdArgs a, int64_t j, int c, int nbB_prev) {
-  __shared__ float Vj[NB], Wj[NB];
-  __shared__ float a_s[RPB_A];
-  __shared__ float part_s[4][RPB_A];
-  __shared__ double red[16];
-  __shared__ float alpha2_s;
-  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-  const int r = tid & (RPB_A - 1), g = tid >> 8;  // row within the block, column group (cc = g mod 4)
+// geometry of trd_colB for the column that produced the partial buffers (rows/cols >= jj+1)
+__device__ __forceinline__ int nseg_of_strip(int64_t jj, int64_t s, int64_t n) {
+  const int64_t c_al = (jj + 1) & ~(int64_t)3;
+  int64_t cend = (jj + 1) + (s + 1) * RS;  // exclusive end of the strip's diagonal block
+  if (cend > n) cend = n;
+  return (int)((cend - c_al + SEG - 1) / SEG);
+}
+
+// u_i = sum_g rowpart[g][i] + sum_{s > strip(i)} colpart[s][i]  over the share (part, nparts) of the terms
+__device__ __forceinline__ float gather_u(const TrdArgs& a, int64_t jj, int64_t i, int part, int nparts) {
   const int64_t n = a.n, ldv = a.ldv;
-
-  // alpha2 = -1/2 tau_{j-1} (w'^T v) from the previous column's kernel-B partials (fixed order)
-  if (c > 0) {
-    double s = 0.0;
-    for (int b = tid; b < nbB_prev; b += 1024) s += a.partB[b];
-    s = wave_sum(s);
-    if (lane == 0) red[wid] = s;
-    __syncthreads();
-    if (tid == 0) {
-      double t = 0.0;
-      for (int w = 0; w < 16; ++w) t += red[w];
-      alpha2_s = (float)(-0.5 * (double)a.tau[j - 1] * t);
+  const int64_t si = (i - (jj + 1)) / RS;
+  const int64_t nstrip = (n - (jj + 1) + RS - 1) / RS;
+  const int nseg = nseg_of_strip(jj, si, n);
+  float acc = 0.f;
+  // both lists are walked in a fixed order; 16 independent loads in flight
+  for (int g0 = part; g0 < nseg; g0 += 16 * nparts) {
+    float t[16];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+      const int g = g0 + u * nparts;
+      t[u] = (g < nseg) ? a.rowpart[(int64_t)g * ldv + i] : 0.f;
     }
+#pragma unroll
+    for (int u = 0; u < 16; ++u) acc += t[u];
   }
-  // row j of V and W (W[j][c-1] needs its finalisation: w' + alpha2 * v, with v_j = V[j][c-1])
-  __syncthreads();
-  const float alpha2 = (c > 0) ? alpha2_s : 0.f;
-  if (tid < c) {
-    const float vj = a.VWt[(int64_t)tid * ldv + j];
-    float wj = a.VWt[(int64_t)(NB + tid) * ldv + j];
-    if (tid == c - 1) wj += alpha2 * vj;
-    Vj[tid] = vj;
-    Wj[tid] = wj;
+  for (int64_t s0 = si + 1 + part; s0 < nstrip; s0 += 16 * nparts) {
+    float t[16];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+      const int64_t s = s0 + (int64_t)u * nparts;
+      t[u] = (s < nstrip) ? a.colpart[s * ldv + i] : 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < 16; ++u) acc += t[u];
   }
-  __syncthreads();
+  return acc;
+}
 
+// ------------------------------------------------------------------------------------------------
+// mode 0: full column step for column j (panel-local index c).  mode 1: only finish W[:, c-1] for rows >= j
+// (panel end: c = NB, j = pe).
+__global__ __launch_bounds__(1024) void trd_colA(TrdArgs a, int64_t j, int c, int nbB_prev, int mode) {
+  __shared__ float Vj[NB], Wj[NB], tVp[NB], tWp[NB];
+  __shared__ float a_s[RPB_A];
+  __shared__ float part_s[NG_A][RPB_A], part2_s[NG_A][RPB_A], upart_s[NG_A][RPB_A];
+  __shared__ double red[16];
+  __shared__ float redf[16];
+  __shared__ float alpha2_s, wj_s;
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int r = tid & (RPB_A - 1), g = tid >> 7;  // row within the block, column group (cc = g mod NG_A)
+  const int64_t n = a.n, ldv = a.ldv;
+  const int cp = c - 1;  // previous panel column (the one whose W is finished here); valid when c > 0
   const int64_t i_lo = j + (int64_t)blockIdx.x * RPB_A;
   const int64_t i = i_lo + r;
   const bool live = i < n;
-  // ---- phase 1: thread (row r, group g) accumulates its columns cc = g, g+4, ... ; all loads up front
-  float p = 0.f;
-  if (live && c > 0) {
-    float vv[NB / 4], ww[NB / 4];
-#pragma unroll
-    for (int q = 0; q < NB / 4; ++q) {
-      const int cc = g + 4 * q;
-      const bool ok = cc < c;
-      vv[q] = ok ? a.VWt[(int64_t)cc * ldv + i] : 0.f;
-      ww[q] = ok ? a.VWt[(int64_t)(NB + cc) * ldv + i] : 0.f;
+
+  // ---------------- all independent global loads first
+  double pb = 0.0;
+  if (c > 0)
+    for (int b = tid; b < nbB_prev; b += 1024) pb += a.partB[b];
+  float vj = 0.f, wj = 0.f, tvp = 0.f, twp = 0.f;
+  if (tid < c) {
+    vj = a.VWt[(int64_t)tid * ldv + j];
+    if (tid < cp) {
+      wj = a.VWt[(int64_t)(NB + tid) * ldv + j];
+      tvp = a.colinfo[4 + tid];
+      twp = a.colinfo[4 + NB + tid];
     }
+  }
+  const float tau_p = (c > 0) ? a.colinfo[0] : 0.f;
+  const float dotvw_p = (c > 0) ? a.colinfo[2] : 0.f;
+  float vv[NB / NG_A], ww[NB / NG_A];
 #pragma unroll
-    for (int q = 0; q < NB / 4; ++q) {
-      const int cc = g + 4 * q;
-      if (cc < c) {
-        float wv = ww[q];
-        if (cc == c - 1) {  // finalise W[:, c-1]; entry j stays raw (every block re-derives W[j][c-1] from it)
-          wv += alpha2 * vv[q];
-          if (i != j) a.VWt[(int64_t)(NB + cc) * ldv + i] = wv;
-        }
-        p += vv[q] * Wj[cc] + wv * Vj[cc];
+  for (int q = 0; q < NB / NG_A; ++q) {
+    const int cc = g + NG_A * q;
+    vv[q] = (live && cc < c) ? a.VWt[(int64_t)cc * ldv + i] : 0.f;
+    ww[q] = (live && cc < cp) ? a.VWt[(int64_t)(NB + cc) * ldv + i] : 0.f;
+  }
+  const float arow = (live && g == 0 && mode == 0) ? a.A[j * a.lda + i] : 0.f;
+  float up = 0.f, uj = 0.f;
+  if (c > 0) {
+    if (live) up = gather_u(a, j - 1, i, g, NG_A);
+    uj = gather_u(a, j - 1, j, tid, 1024);  // row j's u, spread over the whole block
+  }
+
+  // ---------------- alpha2 (fixed-order block reduction), row j of V/W incl. the finished W[j][c-1]
+  if (c > 0) {
+    pb = wave_sum(pb);
+    uj = wave_sumf(uj);
+    if (lane == 0) { red[wid] = pb; redf[wid] = uj; }
+    if (tid < c) { Vj[tid] = vj; Wj[tid] = wj; tVp[tid] = tvp; tWp[tid] = twp; }
+    __syncthreads();
+    if (wid == 0) {  // wave 0: p2 of row j = sum_{cc<cp} V[j][cc] tWp[cc] + W[j][cc] tVp[cc]
+      float p2 = 0.f;
+      for (int cc = lane; cc < cp; cc += 64) p2 += Vj[cc] * tWp[cc] + Wj[cc] * tVp[cc];
+      p2 = wave_sumf(p2);
+      if (lane == 0) {
+        double utv = 0.0;
+        float ujs = 0.f;
+        for (int w = 0; w < 16; ++w) { utv += red[w]; ujs += redf[w]; }
+        const double wtv = (double)tau_p * (utv - 2.0 * (double)dotvw_p);
+        const float alpha2 = (float)(-0.5 * (double)tau_p * wtv);
+        alpha2_s = alpha2;
+        wj_s = tau_p * (ujs - p2) + alpha2 * Vj[cp];  // W[j][c-1]
+      }
+    }
+    __syncthreads();
+    if (tid == 0) Wj[cp] = wj_s;
+    __syncthreads();
+  }
+  const float alpha2 = (c > 0) ? alpha2_s : 0.f;
+
+  // ---------------- per (row, group): partial p1 (x update) and p2 (W finish) over cc < c-1
+  float p1 = 0.f, p2 = 0.f;
+  if (live && c > 0) {
+#pragma unroll
+    for (int q = 0; q < NB / NG_A; ++q) {
+      const int cc = g + NG_A * q;
+      if (cc < cp) {
+        p1 += vv[q] * Wj[cc] + ww[q] * Vj[cc];
+        p2 += vv[q] * tWp[cc] + ww[q] * tVp[cc];
       }
     }
   }
-  part_s[g][r] = p;
+  part_s[g][r] = p1;
+  part2_s[g][r] = p2;
+  upart_s[g][r] = up;
+  // V[i][c-1] lives in group (c-1) % NG_A, slot (c-1) / NG_A: publish it for group 0
+  __shared__ float vlast_s[RPB_A];
+  if (c > 0 && g == (cp % NG_A)) {
+    float vl = 0.f;
+#pragma unroll
+    for (int q = 0; q < NB / NG_A; ++q)
+      if (q == (cp / NG_A)) vl = vv[q];
+    vlast_s[r] = vl;
+  }
   __syncthreads();
   if (g == 0) {
     float av = 0.f;
     if (live) {
-      av = a.A[j * a.lda + i] - (part_s[0][r] + part_s[1][r] + part_s[2][r] + part_s[3][r]);
-      a.x[i] = av;
-      if (i == j && j == n - 1) a.d[j] = (double)av;  // last diagonal entry (no kernel B for it)
+      float p1t = 0.f;
+      if (c > 0) {
+        float u = 0.f, p2t = 0.f, p1s = 0.f;
+#pragma unroll
+        for (int gg = 0; gg < NG_A; ++gg) { u += upart_s[gg][r]; p2t += part2_s[gg][r]; p1s += part_s[gg][r]; }
+        const float vl = vlast_s[r];
+        const float w = tau_p * (u - p2t) + alpha2 * vl;
+        a.VWt[(int64_t)(NB + cp) * ldv + i] = w;  // finished W[i][c-1] (row j included: nobody re-reads it raw)
+        p1t = p1s + vl * Wj[cp] + w * Vj[cp];
+      }
+      if (mode == 0) {
+        av = arow - p1t;
+        a.x[i] = av;
+        if (i == j && j == n - 1) a.d[j] = (double)av;  // last diagonal entry (no kernel B for it)
+      }
     }
-    a_s[r] = (live && i >= j + 2) ? av : 0.f;
+    a_s[r] = (live && mode == 0 && i >= j + 2) ? av : 0.f;
   }
+  if (mode != 0) return;
   __syncthreads();
-  // ---- phase 2: one wave per panel column: partial V^T x, W^T x, ||x||^2 over this block's rows (i >= j+2)
-  double* pa = a.partA + (int64_t)blockIdx.x * PA_LD;
+  // ---------------- partial V^T x, W^T x, ||x||^2 over this block's rows (i >= j+2); sums s = wid + 16*q
+  double* pa = a.partA + blockIdx.x;  // partA[row * na_ld + block]
+  const int64_t na_ld = a.na_ld;
   const int64_t nrow = (i_lo + RPB_A <= n) ? RPB_A : (n - i_lo);
-  for (int s = wid; s < 2 * c + 1; s += 16) {
-    double acc = 0.0;
-    if (s == 2 * c) {
+  const int nsum = 2 * c + 1;
+#pragma unroll 1
+  for (int q0 = 0; q0 < 18; q0 += 9) {
+    if (wid + 16 * q0 >= nsum) break;
+    float t[9][RPB_A / 64];
 #pragma unroll
-      for (int q = 0; q < RPB_A / 64; ++q) acc += (double)a_s[lane + 64 * q] * (double)a_s[lane + 64 * q];
-      acc = wave_sum(acc);
-      if (lane == 0) pa[2 * NB] = acc;
-    } else {
+    for (int qq = 0; qq < 9; ++qq) {
+      const int s = wid + 16 * (q0 + qq);
       const int row = (s < c) ? s : NB + (s - c);
-      const float* vp = a.VWt + (int64_t)row * ldv + i_lo;
-      float t[RPB_A / 64];
+      const bool in = s < 2 * c;
+      const float* vp = a.VWt + (int64_t)(in ? row : 0) * ldv + i_lo;
 #pragma unroll
-      for (int q = 0; q < RPB_A / 64; ++q) t[q] = (lane + 64 * q < nrow) ? vp[lane + 64 * q] : 0.f;
+      for (int q = 0; q < RPB_A / 64; ++q) t[qq][q] = (in && lane + 64 * q < nrow) ? vp[lane + 64 * q] : 0.f;
+    }
+    float xs[RPB_A / 64];
 #pragma unroll
-      for (int q = 0; q < RPB_A / 64; ++q) acc += (double)t[q] * (double)a_s[lane + 64 * q];
-      acc = wave_sum(acc);
-      if (lane == 0) pa[row] = acc;
+    for (int q = 0; q < RPB_A / 64; ++q) xs[q] = a_s[lane + 64 * q];
+#pragma unroll
+    for (int qq = 0; qq < 9; ++qq) {
+      const int s = wid + 16 * (q0 + qq);
+      if (s < nsum) {  // wave-uniform
+        double acc = 0.0;
+        if (s == 2 * c) {
+#pragma unroll
+          for (int q = 0; q < RPB_A / 64; ++q) acc += (double)xs[q] * (double)xs[q];
+        } else {
+#pragma unroll
+          for (int q = 0; q < RPB_A / 64; ++q) acc += (double)t[qq][q] * (double)xs[q];
+        }
+        acc = wave_sum(acc);
+        const int row = (s < c) ? s : (s < 2 * c ? NB + (s - c) : 2 * NB);
+        if (lane == 0) pa[(int64_t)row * na_ld] = acc;
+      }
     }
   }
 }
 
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(512) void trd_colR(TrdArgs a, int64_t j, int c, int na) {
+__global__ __launch_bounds__(1024) void trd_colR(TrdArgs a, int64_t j, int c, int na) {
   __shared__ double sums[2 * NB + 1];
   __shared__ float sc_scale;
+  __shared__ float prod[NB];
   const int tid = threadIdx.x;
   const int64_t ldv = a.ldv;
-  if (tid < 2 * c + 1) {
-    const int row = (tid < c) ? tid : (tid < 2 * c ? NB + (tid - c) : 2 * NB);
-    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
-    int b = 0;
-    for (; b + 4 <= na; b += 4) {  // fixed order; 4 independent loads in flight
-      s0 += a.partA[(int64_t)(b + 0) * PA_LD + row];
-      s1 += a.partA[(int64_t)(b + 1) * PA_LD + row];
-      s2 += a.partA[(int64_t)(b + 2) * PA_LD + row];
-      s3 += a.partA[(int64_t)(b + 3) * PA_LD + row];
+  // independent loads first
+  const float vrow = (tid < c) ? a.VWt[(int64_t)tid * ldv + (j + 1)] : 0.f;
+  const float wrow = (tid < c) ? a.VWt[(int64_t)(NB + tid) * ldv + (j + 1)] : 0.f;
+  const float xa = a.x[j + 1], xd = a.x[j];
+  {  // 4 lanes per sum (2c+1 <= 255 sums): lane q adds blocks q, q+4, ... (16 loads in flight), then a fixed 2-step tree
+    const int sidx = tid >> 2, q4 = tid & 3;
+    const bool on = sidx < 2 * c + 1;
+    const int row = (sidx < c) ? sidx : (sidx < 2 * c ? NB + (sidx - c) : 2 * NB);
+    const double* pr = a.partA + (int64_t)(on ? row : 0) * a.na_ld;
+    double acc = 0.0;
+    for (int b0 = q4; b0 < na; b0 += 64) {
+      double t[16];
+#pragma unroll
+      for (int u = 0; u < 16; ++u) t[u] = (on && b0 + 4 * u < na) ? pr[b0 + 4 * u] : 0.0;
+#pragma unroll
+      for (int u = 0; u < 16; ++u) acc += t[u];
     }
-    for (; b < na; ++b) s0 += a.partA[(int64_t)b * PA_LD + row];
-    sums[row] = (s0 + s1) + (s2 + s3);
+    acc += __shfl_xor(acc, 1);
+    acc += __shfl_xor(acc, 2);
+    if (on && q4 == 0) sums[row] = acc;
   }
   __syncthreads();
   if (tid == 0) {
-    const double alpha = (double)a.x[j + 1];
+    const double alpha = (double)xa;
     const double xn2 = sums[2 * NB];
     double beta, tau, scale;
     if (xn2 == 0.0) {
@@ -187,159 +308,178 @@ __global__ __launch_bounds__(512) void trd_colR(TrdArgs a, int64_t j, int c, int
     sc_scale = (float)scale;
     a.colinfo[0] = (float)tau;
     a.colinfo[1] = (float)scale;
-    a.d[j] = (double)a.x[j];
+    a.d[j] = (double)xd;
     a.e[j] = beta;
     a.tau[j] = (float)tau;
   }
   __syncthreads();
+  float pr = 0.f;
   if (tid < c) {
     const float scale = sc_scale;
-    const float g = (float)(sums[tid] * (double)scale) + a.VWt[(int64_t)tid * ldv + (j + 1)];
-    a.colinfo[4 + tid] = g;
-    a.colinfo[4 + NB + tid] = (float)(sums[NB + tid] * (double)scale) + a.VWt[(int64_t)(NB + tid) * ldv + (j + 1)];
-    a.Gst[j * NB + tid] = g;
+    const float gv = (float)(sums[tid] * (double)scale) + vrow;
+    const float gw = (float)(sums[NB + tid] * (double)scale) + wrow;
+    a.colinfo[4 + tid] = gv;
+    a.colinfo[4 + NB + tid] = gw;
+    a.Gst[j * NB + tid] = gv;
+    pr = gv * gw;
+  }
+  if (tid < NB) prod[tid] = pr;
+  __syncthreads();
+  if (tid == 0) {
+    float s = 0.f;
+    for (int q = 0; q < c; ++q) s += prod[q];  // fixed order
+    a.colinfo[2] = s;
   }
 }
 
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void trd_colB(TrdArgs a, int64_t j, int c) {
-  __shared__ float tVv[NB], tWv[NB];
-  __shared__ float us[ROWS_B];
-  __shared__ float corr_s[16][ROWS_B + 1];
+// 32 values per lane -> sums over the 64 lanes; lane l ends with the total of value index vidx(l) in v[0].
+__device__ __forceinline__ float reduce32_over_wave(float (&v)[32], int lane) {
+#pragma unroll
+  for (int k = 0; k < 16; ++k) {  // offset 32: lanes < 32 keep 0..15, lanes >= 32 keep 16..31
+    const bool hi = lane & 32;
+    const float send = hi ? v[k] : v[k + 16];
+    const float keep = hi ? v[k + 16] : v[k];
+    v[k] = keep + __shfl_xor(send, 32);
+  }
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    const bool hi = lane & 16;
+    const float send = hi ? v[k] : v[k + 8];
+    const float keep = hi ? v[k + 8] : v[k];
+    v[k] = keep + __shfl_xor(send, 16);
+  }
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const bool hi = lane & 8;
+    const float send = hi ? v[k] : v[k + 4];
+    const float keep = hi ? v[k + 4] : v[k];
+    v[k] = keep + __shfl_xor(send, 8);
+  }
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    const bool hi = lane & 4;
+    const float send = hi ? v[k] : v[k + 2];
+    const float keep = hi ? v[k + 2] : v[k];
+    v[k] = keep + __shfl_xor(send, 4);
+  }
+  {
+    const bool hi = lane & 2;
+    const float send = hi ? v[0] : v[1];
+    const float keep = hi ? v[1] : v[0];
+    v[0] = keep + __shfl_xor(send, 2);
+  }
+  v[0] += __shfl_xor(v[0], 1);
+  return v[0];
+}
+// value index held by `lane` after reduce32_over_wave
+__device__ __forceinline__ int reduce32_index(int lane) {
+  return ((lane >> 5) & 1) * 16 + ((lane >> 4) & 1) * 8 + ((lane >> 3) & 1) * 4 + ((lane >> 2) & 1) * 2 + ((lane >> 1) & 1);
+}
+
+__global__ __launch_bounds__(256) void trd_colB(TrdArgs a, int64_t j, int c, int nsegmax) {
+  __shared__ float rowred[4][RS];
+  __shared__ double utv_s[4];
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int64_t n = a.n, ldv = a.ldv, lda = a.lda;
-  const float tau = a.colinfo[0], scale = a.colinfo[1];
-  if (tid < c) {
-    tVv[tid] = a.colinfo[4 + tid];
-    tWv[tid] = a.colinfo[4 + NB + tid];
-  }
-
-  // ---- symv: 4 rows per wave, all columns >= j+1 (aligned down to 4; v = 0 left of j+1), 2 chunks in flight
-  const int64_t rb = (j + 1) + (int64_t)blockIdx.x * ROWS_B;
-  const int64_t r0 = rb + wid * 4;
+  const int64_t s = blockIdx.x;                 // strip
+  const int seg = blockIdx.y;                   // segment
+  const int64_t rb = (j + 1) + s * RS;          // first row of the strip
   const int64_t c_al = (j + 1) & ~(int64_t)3;
-  const float* rp[4];
-  bool ok[4];
-#pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    ok[r] = (r0 + r) < n;
-    rp[r] = a.A + (ok[r] ? (r0 + r) : (n - 1)) * lda;
+  const int64_t cend = (rb + RS < n) ? rb + RS : n;  // columns < cend belong to this strip's trapezoid
+  const int bidx = (int)(s * nsegmax + seg);
+  const int64_t cseg = c_al + (int64_t)seg * SEG;
+  if (cseg >= cend) {                           // idle unit
+    if (tid == 0) a.partB[bidx] = 0.0;
+    return;
   }
-  float acc[4] = {0.f, 0.f, 0.f, 0.f};
-  auto vfrom = [&](const f32x4& xv, int64_t col) {
-    f32x4 v;
+  const float scale = a.colinfo[1];
+  const int64_t col = cseg + wid * 256 + 4 * lane;  // this lane's 4 columns
+  const bool colok = col < n && col < cend;
+  // v for the 4 columns (row-dot use) and the transposed mask (columns strictly left of the strip)
+  f32x4 vc = {0.f, 0.f, 0.f, 0.f};
+  float tmask[4] = {0.f, 0.f, 0.f, 0.f};
+  if (colok) {
+    const f32x4 xv = *reinterpret_cast<const f32x4*>(a.x + col);  // x is zero-padded past n
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       const int64_t idx = col + e;
-      v[e] = (idx == j + 1) ? 1.f : ((idx > j + 1 && idx < n) ? xv[e] * scale : 0.f);
-    }
-    return v;
-  };
-  int64_t col = c_al + 4 * lane;
-  for (; col + 256 < n; col += 512) {
-    const f32x4 x0 = *reinterpret_cast<const f32x4*>(a.x + col);
-    const f32x4 x1 = *reinterpret_cast<const f32x4*>(a.x + col + 256);
-    f32x4 a0[4], a1[4];
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      a0[r] = *reinterpret_cast<const f32x4*>(rp[r] + col);
-      a1[r] = *reinterpret_cast<const f32x4*>(rp[r] + col + 256);
-    }
-    const f32x4 v0 = vfrom(x0, col), v1 = vfrom(x1, col + 256);
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      acc[r] += a0[r][0] * v0[0] + a0[r][1] * v0[1] + a0[r][2] * v0[2] + a0[r][3] * v0[3];
-      acc[r] += a1[r][0] * v1[0] + a1[r][1] * v1[1] + a1[r][2] * v1[2] + a1[r][3] * v1[3];
+      const float v = (idx == j + 1) ? 1.f : ((idx > j + 1 && idx < n) ? xv[e] * scale : 0.f);
+      vc[e] = (idx < cend) ? v : 0.f;
+      tmask[e] = (idx < rb && idx >= j + 1) ? 1.f : 0.f;
     }
   }
-  if (col < n) {
-    const f32x4 x0 = *reinterpret_cast<const f32x4*>(a.x + col);  // x is zero-padded past n
-    f32x4 a0[4];
+  float racc[RS];
+  f32x4 cacc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int r = 0; r < 4; ++r) a0[r] = *reinterpret_cast<const f32x4*>(rp[r] + col);
-    const f32x4 v0 = vfrom(x0, col);
+  for (int q = 0; q < RS; ++q) racc[q] = 0.f;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) acc[r] += a0[r][0] * v0[0] + a0[r][1] * v0[1] + a0[r][2] * v0[2] + a0[r][3] * v0[3];
-  }
+  for (int pass = 0; pass < 2; ++pass) {
+    f32x4 av[16];
+    float vr[16];
 #pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    const float s = wave_sumf(acc[r]);
-    if (lane == 0) us[wid * 4 + r] = ok[r] ? s : 0.f;
-  }
-  __syncthreads();  // us, tVv, tWv visible
-  // ---- corrections  u_i -= V[i,:] . (W^T v) + W[i,:] . (V^T v): 16 rows x 16 column groups
-  {
-    const int rr = tid & 15, g = tid >> 4;
-    const int64_t i = rb + rr;
-    float p = 0.f;
-    if (i < n) {
-      float vv[NB / 16], ww[NB / 16];
-#pragma unroll
-      for (int q = 0; q < NB / 16; ++q) {
-        const int cc = g + 16 * q;
-        const bool in = cc < c;
-        vv[q] = in ? a.VWt[(int64_t)cc * ldv + i] : 0.f;
-        ww[q] = in ? a.VWt[(int64_t)(NB + cc) * ldv + i] : 0.f;
-      }
-#pragma unroll
-      for (int q = 0; q < NB / 16; ++q) {
-        const int cc = g + 16 * q;
-        if (cc < c) p += vv[q] * tWv[cc] + ww[q] * tVv[cc];
-      }
+    for (int q = 0; q < 16; ++q) {
+      const int64_t row = rb + pass * 16 + q;
+      const bool rok = row < n;
+      av[q] = (rok && colok) ? *reinterpret_cast<const f32x4*>(a.A + row * lda + col) : f32x4{0.f, 0.f, 0.f, 0.f};
+      const float xr = rok ? a.x[row] : 0.f;  // wave-uniform
+      vr[q] = (row == j + 1) ? 1.f : xr * scale;
+      if (!rok) vr[q] = 0.f;
     }
-    corr_s[g][rr] = p;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      racc[pass * 16 + q] += av[q][0] * vc[0] + av[q][1] * vc[1] + av[q][2] * vc[2] + av[q][3] * vc[3];
+      cacc[0] += av[q][0] * vr[q];
+      cacc[1] += av[q][1] * vr[q];
+      cacc[2] += av[q][2] * vr[q];
+      cacc[3] += av[q][3] * vr[q];
+    }
   }
+  // transposed contribution of this (strip, chunk): complete, stored once; masked outside [j+1, rb)
+#pragma unroll
+  for (int e = 0; e < 4; ++e) cacc[e] *= tmask[e];
+  if (col < n) *reinterpret_cast<f32x4*>(a.colpart + s * ldv + col) = cacc;
+  // partial u^T v of this unit: v_col * cacc (transposed part) ...
+  double utv = (double)(cacc[0] * vc[0]) + (double)(cacc[1] * vc[1]) + (double)(cacc[2] * vc[2]) + (double)(cacc[3] * vc[3]);
+  utv = wave_sum(utv);
+  // row dots: reduce the 32 per-lane values over the wave, then over the 4 waves
+  const float rsum = reduce32_over_wave(racc, lane);
+  if ((lane & 1) == 0) rowred[wid][reduce32_index(lane)] = rsum;
+  if (lane == 0) utv_s[wid] = utv;
   __syncthreads();
-  if (tid < 64) {  // wave 0
-    const int64_t i = rb + tid;
-    double wv = 0.0;
-    if (tid < ROWS_B && i < n) {
-      float u = us[tid];
-#pragma unroll
-      for (int g = 0; g < 16; ++g) u -= corr_s[g][tid];
-      const float vi = (i == j + 1) ? 1.f : a.x[i] * scale;
-      const float w = tau * u;
-      a.VWt[(int64_t)(NB + c) * ldv + i] = w;
-      a.VWt[(int64_t)c * ldv + i] = vi;
-      a.A[j * lda + i] = vi;  // reflector j lives in row j, right of the diagonal
-      wv = (double)w * (double)vi;
+  if (tid < 64) {
+    double t = 0.0;
+    if (tid < RS) {
+      const int64_t row = rb + tid;
+      const float rs = (rowred[0][tid] + rowred[1][tid]) + (rowred[2][tid] + rowred[3][tid]);
+      if (row < n) {
+        a.rowpart[(int64_t)seg * ldv + row] = rs;
+        const float vrow = (row == j + 1) ? 1.f : a.x[row] * scale;
+        t = (double)rs * (double)vrow;  // ... + v_row * rowdot (row part)
+        if (seg == 0) {                 // publish v once per row: panel column c and reflector storage
+          a.VWt[(int64_t)c * ldv + row] = vrow;
+          a.A[j * lda + row] = vrow;    // reflector j lives in row j, right of the diagonal
+        }
+      }
     }
-    wv = wave_sum(wv);
-    if (tid == 0) a.partB[blockIdx.x] = wv;
+    t = wave_sum(t);
+    if (tid == 0) a.partB[bidx] = t + ((utv_s[0] + utv_s[1]) + (utv_s[2] + utv_s[3]));
   }
 }
 
 // ------------------------------------------------------------------------------------------------
-// Panel end: finalise the last W column and write row-major VW = [V|W], WV = [W|V] for rows >= pe.
-__global__ __launch_bounds__(256) void trd_panel_finish(TrdArgs a, int64_t pe, int nbB_prev, float* VW,
-                                                       float* WV) {
+// Panel end: write row-major VW = [V|W], WV = [W|V] for rows >= pe (W is already finished by trd_colA mode 1).
+__global__ __launch_bounds__(256) void trd_panel_finish(TrdArgs a, int64_t pe, float* VW, float* WV) {
   __shared__ float tile[2 * NB][33];
-  __shared__ double red[4];
-  __shared__ float alpha2_s;
-  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-  double s = 0.0;
-  for (int b = tid; b < nbB_prev; b += 256) s += a.partB[b];
-  s = wave_sum(s);
-  if (lane == 0) red[wid] = s;
-  __syncthreads();
-  if (tid == 0) alpha2_s = (float)(-0.5 * (double)a.tau[pe - 1] * (red[0] + red[1] + red[2] + red[3]));
-  __syncthreads();
-  const float alpha2 = alpha2_s;
+  const int tid = threadIdx.x;
   const int64_t i0 = pe + (int64_t)blockIdx.x * 32;
-  // read 2NB x 32 (coalesced over matrix rows)
-  for (int idx = tid; idx < 2 * NB * 32; idx += 256) {
+  for (int idx = tid; idx < 2 * NB * 32; idx += 256) {  // read 2NB x 32 (coalesced over matrix rows)
     const int row = idx >> 5, r = idx & 31;
     const int64_t i = i0 + r;
-    float v = 0.f;
-    if (i < a.n) {
-      v = a.VWt[(int64_t)row * a.ldv + i];
-      if (row == 2 * NB - 1) v += alpha2 * a.VWt[(int64_t)(NB - 1) * a.ldv + i];
-    }
-    tile[row][r] = v;
+    tile[row][r] = (i < a.n) ? a.VWt[(int64_t)row * a.ldv + i] : 0.f;
   }
   __syncthreads();
-  // write 32 x 2NB (coalesced over panel columns); VW/WV row index is relative to pe
-  for (int idx = tid; idx < 32 * 2 * NB; idx += 256) {
+  for (int idx = tid; idx < 32 * 2 * NB; idx += 256) {  // write 32 x 2NB (coalesced over panel columns)
     const int r = idx / (2 * NB), col = idx % (2 * NB);
     const int64_t i = i0 + r;
     if (i < a.n) {
@@ -356,12 +496,15 @@ int sytrd_f32(Ctx* ctx, float* A, int64_t n, int64_t lda, double* d_dev, double*
     return ctx->fail(SCLENS_ERR_ARG, "sytrd_f32: A must be 16-byte aligned with lda a multiple of 4");
   StageTimer tm(ctx, "sytrd");
   const int64_t ldv = round_up(n, 64) + 512;
+  const int64_t nstripMax = (n + RS - 1) / RS + 1, nsegMax = (n + SEG - 1) / SEG + 2;
   SCL_WS(ctx, VWt, float, "trd.VWt", 2 * NB * ldv);
   SCL_WS(ctx, x, float, "trd.x", ldv);
-  const int64_t naMax = (n + RPB_A - 1) / RPB_A + 1, nbMax = (n + ROWS_B - 1) / ROWS_B + 1;
+  const int64_t naMax = round_up((n + RPB_A - 1) / RPB_A + 1, 64);
   SCL_WS(ctx, partA, double, "trd.partA", naMax * PA_LD);
-  SCL_WS(ctx, partB, double, "trd.partB", nbMax);
+  SCL_WS(ctx, partB, double, "trd.partB", nstripMax * nsegMax);
   SCL_WS(ctx, colinfo, float, "trd.colinfo", CI_LD);
+  SCL_WS(ctx, rowpart, float, "trd.rowpart", nsegMax * ldv);
+  SCL_WS(ctx, colpart, float, "trd.colpart", nstripMax * ldv);
   SCL_WS(ctx, Gst, float, "trd.Gst", n * NB);
   SCL_WS(ctx, VW, float, "trd.VW", n * 2 * NB);
   SCL_WS(ctx, WV, float, "trd.WV", n * 2 * NB);
@@ -369,7 +512,8 @@ int sytrd_f32(Ctx* ctx, float* A, int64_t n, int64_t lda, double* d_dev, double*
   SCL_HIP(ctx, hipMemsetAsync(Gst, 0, sizeof(float) * n * NB, ctx->stream));
   SCL_HIP(ctx, hipMemsetAsync(tau_dev, 0, sizeof(float) * n, ctx->stream));
   SCL_HIP(ctx, hipMemsetAsync(e_dev, 0, sizeof(double) * n, ctx->stream));
-  TrdArgs a{A, n, lda, VWt, ldv, x, partA, partB, colinfo, d_dev, e_dev, tau_dev, Gst};
+  SCL_HIP(ctx, hipMemsetAsync(colinfo, 0, sizeof(float) * CI_LD, ctx->stream));
+  TrdArgs a{A, n, lda, VWt, ldv, x, partA, naMax, partB, colinfo, rowpart, colpart, d_dev, e_dev, tau_dev, Gst};
   int nbB_prev = 0;
   for (int64_t p = 0; p < n; p += NB) {
     const int64_t pe = (p + NB < n) ? p + NB : n;
@@ -377,10 +521,13 @@ int sytrd_f32(Ctx* ctx, float* A, int64_t n, int64_t lda, double* d_dev, double*
     for (int64_t j = p; j < pe; ++j) {
       const int c = (int)(j - p);
       const int na = (int)((n - j + RPB_A - 1) / RPB_A);
-      hipLaunchKernelGGL(trd_colA, dim3(na), dim3(1024), 0, ctx->stream, a, j, c, nbB_prev);
+      hipLaunchKernelGGL(trd_colA, dim3(na), dim3(1024), 0, ctx->stream, a, j, c, nbB_prev, 0);
       if (j == n - 1) break;
-      hipLaunchKernelGGL(trd_colR, dim3(1), dim3(512), 0, ctx->stream, a, j, c, na);
-      const int nbB = (int)((n - (j + 1) + ROWS_B - 1) / ROWS_B);
+      hipLaunchKernelGGL(trd_colR, dim3(1), dim3(1024), 0, ctx->stream, a, j, c, na);
+      const int64_t nt = n - (j + 1);
+      const int nstrip = (int)((nt + RS - 1) / RS);
+      const int64_t c_al = (j + 1) & ~(int64_t)3;
+      const int nsegmax = (int)((n - c_al + SEG - 1) / SEG);
       if (ctx->prof_symv) {
         if (ctx->prof_used + 2 > ctx->prof_ev.size()) {
           for (int q = 0; q < 2; ++q) {
@@ -391,19 +538,19 @@ int sytrd_f32(Ctx* ctx, float* A, int64_t n, int64_t lda, double* d_dev, double*
         }
         SCL_HIP(ctx, hipEventRecord(ctx->prof_ev[ctx->prof_used], ctx->stream));
       }
-      hipLaunchKernelGGL(trd_colB, dim3(nbB), dim3(256), 0, ctx->stream, a, j, c);
+      hipLaunchKernelGGL(trd_colB, dim3(nstrip, nsegmax), dim3(256), 0, ctx->stream, a, j, c, nsegmax);
       if (ctx->prof_symv) {
         SCL_HIP(ctx, hipEventRecord(ctx->prof_ev[ctx->prof_used + 1], ctx->stream));
         ctx->prof_used += 2;
-        const double nt = (double)(n - j - 1);
-        ctx->prof_bytes += 4.0 * nt * nt;  // the trailing matrix, once (sum_j 4 (n-j)^2)
+        ctx->prof_bytes += 4.0 * (double)nt * (double)nt;  // the trailing matrix, once (sum_j 4 (n-j)^2)
       }
-      nbB_prev = nbB;
+      nbB_prev = nstrip * nsegmax;
     }
     if (pe < n) {
       const int64_t nt = n - pe;
-      hipLaunchKernelGGL(trd_panel_finish, dim3((unsigned)((nt + 31) / 32)), dim3(256), 0, ctx->stream, a,
-                         pe, nbB_prev, VW, WV);
+      const int na = (int)((nt + RPB_A - 1) / RPB_A);
+      hipLaunchKernelGGL(trd_colA, dim3(na), dim3(1024), 0, ctx->stream, a, pe, (int)NB, nbB_prev, 1);  // finish W[:, NB-1]
+      hipLaunchKernelGGL(trd_panel_finish, dim3((unsigned)((nt + 31) / 32)), dim3(256), 0, ctx->stream, a, pe, VW, WV);
       GemmArgs g{};
       g.P = VW; g.Q = WV; g.C = A + pe * lda + pe;
       g.M = nt; g.N = nt; g.K = 2 * NB;

@@ -117,3 +117,31 @@ def test_sclens_robustness(run_pair):
         k = len(ref["signal_ev"])
         assert np.all(_abs_cos(a[:, :k], b[:, :k]) > 1 - 3e-3)
         assert np.allclose(res["nL_set"][t], ref["nL_set"][t], rtol=3e-4)
+
+
+def test_device_sampler_equals_host_sampler(ctx):
+    """*_seeded session calls draw the sample on the device with the same keyed permutation the host function
+    evaluates: both routes must give bit-identical results."""
+    X = synth_counts(300, 500, seed=1, C=5, marker_frac=0.2, marker_sd=1.5)
+    d_dev = api.make_draws_native(X, seed=21)
+    d_host = api.make_draws_native(X, seed=21, host_sampler=True)
+    a = api.sclens(X, draws=d_dev, n_perturb=4, ctx=ctx, max_search_iters=6)
+    b = api.sclens(X, draws=d_host, n_perturb=4, ctx=ctx, max_search_iters=6)
+    assert a["p_"] == b["p_"] and a["n_search"] == b["n_search"]
+    for (p1, t1), (p2, t2) in zip(a["search_trace"], b["search_trace"]):
+        assert np.array_equal(t1, t2)
+    assert np.array_equal(a["robustness_scores"]["b_"], b["robustness_scores"]["b_"])
+    assert np.array_equal(a["L"], b["L"])  # the whole path is bitwise reproducible
+
+
+def test_native_draws_agree_with_oracle(ctx):
+    """End-to-end with the library's own draw generators (what bench.py times), oracle fed the identical draws."""
+    X = synth_counts(600, 250, seed=2, C=4, marker_frac=0.2, marker_sd=1.5)
+    d = api.make_draws_native(X, seed=5, host_sampler=True)
+    od = O.Draws(d.z_idx1, d.z_idx2, d.X_r, d.p_th, d.sampler)
+    ref = O.sclens(X, od, n_perturb=5, null_tol=O.NULL_DROP)
+    res = api.sclens(X, draws=api.make_draws_native(X, seed=5), n_perturb=5, ctx=ctx)
+    assert len(res["signal_ev"]) == len(ref["signal_ev"])
+    assert res["p_"] == ref["p_"] and res["n_search"] == ref["n_search"]
+    assert np.array_equal(res["sig_id"], ref["sig_id"])
+    assert np.abs(res["robustness_scores"]["rob_score"] - ref["robustness_scores"]["rob_score"]).max() < 3e-3

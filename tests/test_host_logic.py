@@ -122,3 +122,38 @@ def test_ensemble_ownership_is_a_partition():
         owned = [owned_perturbations(r, world, 20) for r in range(world)]
         assert sorted(sum(owned, [])) == list(range(20))
         assert max(map(len, owned)) == -(-20 // world)
+
+
+def test_native_draw_generators_contract():
+    X = api._csc_f32(synth_counts(90, 140, seed=4, C=3))
+    d = api.make_draws_native(X, seed=3, host_sampler=True)
+    z1, z2 = d.z_idx1, d.z_idx2
+    assert 0 < len(z1) <= X.nnz
+    assert np.all(X[z1.astype(int), z2.astype(int)] == 0)  # disjoint from the stored entries (setdiff, scLENS.jl:671)
+    assert len(np.unique(z1.astype(np.int64) + z2.astype(np.int64) * 90)) == len(z1)  # unique
+    # about nnz * sparsity candidates survive
+    assert abs(len(z1) / X.nnz - (1 - X.nnz / (90 * 140))) < 0.1  # minus ~nnz/(2NM) duplicate draws
+    Xr = d.X_r
+    assert np.array_equal(np.diff(Xr.indptr), np.diff(X.indptr))
+    assert np.array_equal(np.sort(Xr.data), np.sort(X.data))
+    for j in range(140):
+        rows = Xr.indices[Xr.indptr[j]: Xr.indptr[j + 1]]
+        assert len(np.unique(rows)) == len(rows) and (len(rows) == 0 or rows.max() < 90)
+    assert np.array_equal(api.make_draws_native(X, seed=3).z_idx1, z1)  # deterministic
+    assert not np.array_equal(api.make_draws_native(X, seed=4).z_idx1[:50], z1[:50])
+
+
+def test_keyed_permutation_sampler():
+    for population, m in ((1000, 1000), (12345, 400), (17, 5), (1 << 20, 5000)):
+        idx = api.sample_indices(population, m, seed=99)
+        assert idx.max() < population and len(np.unique(idx)) == m  # distinct = without replacement
+        assert np.array_equal(idx, api.sample_indices(population, m, seed=99))
+        assert not np.array_equal(idx, api.sample_indices(population, m, seed=100))
+    # uniformity: chi-square of 10 equal bins over many seeds
+    counts = np.zeros(10)
+    for s in range(200):
+        idx = api.sample_indices(5000, 50, seed=s)
+        counts += np.bincount(idx // 500, minlength=10)
+    exp = counts.sum() / 10
+    assert ((counts - exp) ** 2 / exp).sum() < 30  # chi2(9) 99.9 % quantile is 27.9
+    assert api.sample_seed_for(1, "search", 0) != api.sample_seed_for(1, "perturb", 0)
