@@ -63,31 +63,44 @@ __global__ __launch_bounds__(1024) void tri_bounds(const double* __restrict__ d,
   }
 }
 
-// One thread per eigenvalue index k: bisection on the Sturm count (#eigenvalues < x).
+// Eight lanes per eigenvalue index k: 9-section on the Sturm count (#eigenvalues < x). Each sweep shrinks the
+// bracket 9x (18 sweeps to full fp64 resolution instead of 57 bisection sweeps); the n-step recurrence is the
+// latency chain, so trading 8x more lanes for 3x fewer sweeps is what a mostly idle chip wants.
 __global__ __launch_bounds__(64) void tri_bisect(const double* __restrict__ d, const double* __restrict__ e2,
                                                  int64_t n, const double* __restrict__ info,
                                                  double* __restrict__ w) {
-  const int64_t k = (int64_t)blockIdx.x * 64 + threadIdx.x;
+  const int q = threadIdx.x & 7;
+  const int64_t k = (int64_t)blockIdx.x * 8 + (threadIdx.x >> 3);
   double lo = info[0], hi = info[1];
   const double pivmin = info[2], atol = EPS64 * info[4];
   const bool live = k < n;
-  for (int it = 0; it < 80; ++it) {
+  for (int it = 0; it < 40; ++it) {
     const bool done = (hi - lo) <= 2.0 * EPS64 * fmax(fabs(lo), fabs(hi)) + atol;
     if (__all(done || !live)) break;
-    const double mid = 0.5 * (lo + hi);
-    double q = d[0] - mid;
-    if (fabs(q) < pivmin) q = -pivmin;
-    int64_t cnt = (q < 0.0) ? 1 : 0;
+    const double step = (hi - lo) / 9.0;
+    const double xq = lo + (double)(q + 1) * step;
+    double p = d[0] - xq;
+    if (fabs(p) < pivmin) p = -pivmin;
+    int64_t cnt = (p < 0.0) ? 1 : 0;
     for (int64_t i = 1; i < n; ++i) {
-      q = d[i] - mid - e2[i - 1] / q;
-      if (fabs(q) < pivmin) q = -pivmin;
-      cnt += (q < 0.0) ? 1 : 0;
+      p = d[i] - xq - e2[i - 1] / p;
+      if (fabs(p) < pivmin) p = -pivmin;
+      cnt += (p < 0.0) ? 1 : 0;
     }
+    // m = number of probe points of this group with count <= k (eigenvalue k is not below them)
+    int below = (cnt <= k) ? 1 : 0;
+    int m = below;
+    m += __shfl_xor(m, 1);
+    m += __shfl_xor(m, 2);
+    m += __shfl_xor(m, 4);
     if (!done) {
-      if (cnt > k) hi = mid; else lo = mid;
+      const double nlo = (m == 0) ? lo : lo + (double)m * step;
+      const double nhi = (m == 8) ? hi : lo + (double)(m + 1) * step;
+      lo = nlo;
+      hi = nhi;
     }
   }
-  if (live) w[k] = 0.5 * (lo + hi);
+  if (live && q == 0) w[k] = 0.5 * (lo + hi);
 }
 
 __device__ __forceinline__ double hash_uniform(uint64_t a, uint64_t b) {  // deterministic U(-1,1)
@@ -98,15 +111,16 @@ __device__ __forceinline__ double hash_uniform(uint64_t a, uint64_t b) {  // det
   return (double)(z >> 11) * (2.0 / 9007199254740992.0) - 1.0;
 }
 
-// Inverse iteration, one thread per eigenvector t (eigenvalue index lo + t0 + t).
-// Workspaces are [n][B] (row i, vector t): element (i,t) at i*B + t.
+// Inverse iteration, one thread per eigenvector t (eigenvalue index idx0 + t).
+// Workspaces are [n][B] (row i, vector t): element (i,t) at i*B + t, so every access is coalesced across threads.
+// The recurrences are sequential in i; loads of the next four steps are issued together to hide memory latency.
 __global__ __launch_bounds__(64) void tri_stein(const double* __restrict__ d, const double* __restrict__ e,
                                                 int64_t n, const double* __restrict__ w, int64_t idx0,
                                                 int64_t count, int64_t B, const double* __restrict__ info,
                                                 double* __restrict__ wa, double* __restrict__ wb,
                                                 double* __restrict__ wc, double* __restrict__ wd,
                                                 unsigned char* __restrict__ win, double* __restrict__ wx,
-                                                int* __restrict__ fail_count) {
+                                                double* __restrict__ inv_norm, int* __restrict__ fail_count) {
   const int64_t t = (int64_t)blockIdx.x * 64 + threadIdx.x;
   if (t >= count) return;
   const int64_t gi = idx0 + t;
@@ -121,12 +135,14 @@ __global__ __launch_bounds__(64) void tri_stein(const double* __restrict__ d, co
 #define AT(arr, i) arr[(i) * B + t]
   if (n == 1) {
     AT(wx, 0) = 1.0;
+    inv_norm[t] = 1.0;
     return;
   }
   // ---- dlagtf: LU of T - lam I with partial pivoting. a=diag, b=super, c=sub(multipliers), d2=2nd super
   double ak = d[0] - lam;
   double bk = e[0];
   double scale1 = fabs(ak) + fabs(bk);
+  double tol = 0.0;  // dlagts tolerance: eps * max |a|,|b|,|d2| of the factors
   for (int64_t k = 0; k < n - 1; ++k) {
     double ak1 = d[k + 1] - lam;
     const double ck = e[k];
@@ -159,36 +175,53 @@ __global__ __launch_bounds__(64) void tri_stein(const double* __restrict__ d, co
     scale1 = scale2;
     AT(wa, k) = a_out; AT(wb, k) = b_out; AT(wc, k) = c_out; AT(win, k) = in_k;
     if (k < n - 2) AT(wd, k) = d_out;
+    tol = fmax(tol, fmax(fabs(a_out), fmax(fabs(b_out), fabs(d_out))));
     ak = ak1;
     bk = b_next;
   }
   AT(wa, n - 1) = ak;
   const double a_last = ak;
-  // dlagts tolerance (computed on first call when TOL <= 0)
-  double tol = 0.0;
-  for (int64_t k = 0; k < n; ++k) {
-    tol = fmax(tol, fabs(AT(wa, k)));
-    if (k < n - 1) tol = fmax(tol, fabs(AT(wb, k)));
-    if (k < n - 2) tol = fmax(tol, fabs(AT(wd, k)));
-  }
-  tol *= EPS64;
+  tol = fmax(tol, fabs(a_last)) * EPS64;
   if (tol == 0.0) tol = EPS64;
-  // ---- start vector
-  for (int64_t i = 0; i < n; ++i) AT(wx, i) = hash_uniform((uint64_t)gi, (uint64_t)i);
   const double dtpcrt = sqrt(0.1 / (double)n);
   const double bignum = 1.0 / SFMIN64;
   int nrmchk = 0, its = 0;
   bool failed = false;
+  double xmax = 1.0;  // the start vector is uniform(-1,1), generated on the fly in the first forward sweep
+  double s2 = 1.0;
   while (true) {
     ++its;
     if (its > 8) { failed = true; break; }
-    double xmax = 0.0;
-    for (int64_t i = 0; i < n; ++i) xmax = fmax(xmax, fabs(AT(wx, i)));
+    const bool first = (its == 1);
     const double scl = (double)n * onenrm * fmax(EPS64, fabs(a_last)) / xmax;
-    // forward: y = L^-1 P (scl * x)
-    double yprev = AT(wx, 0) * scl;
-    for (int64_t k = 1; k < n; ++k) {
-      const double yk = AT(wx, k) * scl;
+    // ---- forward: y = L^-1 P (scl * x)
+    double yprev = (first ? hash_uniform((uint64_t)gi, 0) : AT(wx, 0)) * scl;
+    int64_t k = 1;
+    for (; k + 4 <= n; k += 4) {
+      double xk[4], ck[4];
+      unsigned char ik[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        xk[u] = first ? hash_uniform((uint64_t)gi, (uint64_t)(k + u)) : AT(wx, k + u);
+        ck[u] = AT(wc, k + u - 1);
+        ik[u] = AT(win, k + u - 1);
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const double yk = xk[u] * scl;
+        double ynew;
+        if (ik[u] == 0) {
+          ynew = yk - ck[u] * yprev;
+          AT(wx, k + u - 1) = yprev;
+        } else {
+          AT(wx, k + u - 1) = yk;
+          ynew = yprev - ck[u] * yk;
+        }
+        yprev = ynew;
+      }
+    }
+    for (; k < n; ++k) {
+      const double yk = (first ? hash_uniform((uint64_t)gi, (uint64_t)k) : AT(wx, k)) * scl;
       const double ck = AT(wc, k - 1);
       double ynew;
       if (AT(win, k - 1) == 0) {
@@ -201,14 +234,12 @@ __global__ __launch_bounds__(64) void tri_stein(const double* __restrict__ d, co
       yprev = ynew;
     }
     AT(wx, n - 1) = yprev;
-    // backward with pivot perturbation
-    double y1 = 0.0, y2 = 0.0;  // y[k+1], y[k+2]
-    double nrm = 0.0;
-    for (int64_t k = n - 1; k >= 0; --k) {
-      double temp = AT(wx, k);
-      if (k <= n - 2) temp -= AT(wb, k) * y1;
-      if (k <= n - 3) temp -= AT(wd, k) * y2;
-      double akk = AT(wa, k);
+    // ---- backward with pivot perturbation (dlagts job = -1); tracks max |y| and sum y^2
+    double y1 = 0.0, y2 = 0.0, nrm = 0.0;
+    s2 = 0.0;
+    auto solve_one = [&](int64_t kk, double xv, double av, double bv, double dv) {
+      double temp = xv - bv * y1 - dv * y2;
+      double akk = av;
       double pert = copysign(tol, akk);
       while (true) {
         const double absak = fabs(akk);
@@ -221,33 +252,47 @@ __global__ __launch_bounds__(64) void tri_stein(const double* __restrict__ d, co
         break;
       }
       const double yk = temp / akk;
-      AT(wx, k) = yk;
+      AT(wx, kk) = yk;
       nrm = fmax(nrm, fabs(yk));
+      s2 += yk * yk;
       y2 = y1; y1 = yk;
+    };
+    int64_t kb = n - 1;
+    // the top two rows have no b / d2 entries: handle them singly, then blocks of four
+    for (; kb >= n - 2 && kb >= 0; --kb)
+      solve_one(kb, AT(wx, kb), AT(wa, kb), (kb <= n - 2) ? AT(wb, kb) : 0.0, 0.0);
+    for (; kb >= 3; kb -= 4) {
+      double xv[4], av[4], bv[4], dv[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        xv[u] = AT(wx, kb - u); av[u] = AT(wa, kb - u); bv[u] = AT(wb, kb - u); dv[u] = AT(wd, kb - u);
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) solve_one(kb - u, xv[u], av[u], bv[u], dv[u]);
     }
+    for (; kb >= 0; --kb) solve_one(kb, AT(wx, kb), AT(wa, kb), AT(wb, kb), AT(wd, kb));
+    xmax = nrm;
     if (nrm < dtpcrt) continue;
     ++nrmchk;
     if (nrmchk < 3) continue;
     break;
   }
-  double s2 = 0.0;
-  for (int64_t i = 0; i < n; ++i) { const double v = AT(wx, i); s2 += v * v; }
-  const double inv = 1.0 / sqrt(s2);
-  for (int64_t i = 0; i < n; ++i) AT(wx, i) *= inv;
+  inv_norm[t] = 1.0 / sqrt(s2);
   if (failed) atomicAdd(fail_count, 1);
 #undef AT
 }
 
-// wx [n][B] fp64 -> Zt rows (t0 + t) fp32: Zt[(t0+t)*ldz + i]
-__global__ __launch_bounds__(256) void tri_transpose_out(const double* __restrict__ wx, int64_t n, int64_t count,
-                                                         int64_t B, float* __restrict__ Zt, int64_t ldz,
-                                                         int64_t t0) {
+// wx [n][B] fp64 (unnormalised) * inv_norm[t] -> Zt rows (t0 + t) fp32: Zt[(t0+t)*ldz + i]
+__global__ __launch_bounds__(256) void tri_transpose_out(const double* __restrict__ wx, const double* __restrict__ inv_norm,
+                                                         int64_t n, int64_t count, int64_t B, float* __restrict__ Zt,
+                                                         int64_t ldz, int64_t t0) {
   __shared__ float tile[32][33];
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
   const int64_t tb = (int64_t)blockIdx.x * 32, ib = (int64_t)blockIdx.y * 32;
+  const double sc = (tb + tx < count) ? inv_norm[tb + tx] : 0.0;
   for (int r = ty; r < 32; r += 8) {
     const int64_t i = ib + r, t = tb + tx;
-    tile[r][tx] = (i < n && t < count) ? (float)wx[i * B + t] : 0.f;
+    tile[r][tx] = (i < n && t < count) ? (float)(wx[i * B + t] * sc) : 0.f;
   }
   __syncthreads();
   for (int r = ty; r < 32; r += 8) {
@@ -261,7 +306,7 @@ int stebz_f64(Ctx* ctx, const double* d_dev, const double* e_dev, int64_t n, dou
   SCL_WS(ctx, e2, double, "tri.e2", n + 1);
   SCL_WS(ctx, info, double, "tri.info", 8);
   hipLaunchKernelGGL(tri_bounds, dim3(1), dim3(1024), 0, ctx->stream, d_dev, e_dev, n, e2, info);
-  hipLaunchKernelGGL(tri_bisect, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, ctx->stream, d_dev, e2, n, info,
+  hipLaunchKernelGGL(tri_bisect, dim3((unsigned)((n + 7) / 8)), dim3(64), 0, ctx->stream, d_dev, e2, n, info,
                      w_dev);
   SCL_HIP(ctx, hipGetLastError());
   return SCLENS_OK;
@@ -286,13 +331,14 @@ int stein_f64(Ctx* ctx, const double* d_dev, const double* e_dev, int64_t n, con
   SCL_WS(ctx, wx, double, "stein.x", n * B);
   SCL_WS(ctx, win, unsigned char, "stein.in", n * B);
   SCL_WS(ctx, failc, int, "stein.fail", 4);
+  SCL_WS(ctx, invn, double, "stein.invn", B);
   SCL_HIP(ctx, hipMemsetAsync(failc, 0, sizeof(int), ctx->stream));
   for (int64_t t0 = 0; t0 < m; t0 += B) {
     const int64_t cnt = (m - t0 < B) ? m - t0 : B;
     hipLaunchKernelGGL(tri_stein, dim3((unsigned)((cnt + 63) / 64)), dim3(64), 0, ctx->stream, d_dev, e_dev, n,
-                       w_dev, lo + t0, cnt, B, info, wa, wb, wc, wd, win, wx, failc);
+                       w_dev, lo + t0, cnt, B, info, wa, wb, wc, wd, win, wx, invn, failc);
     hipLaunchKernelGGL(tri_transpose_out, dim3((unsigned)((cnt + 31) / 32), (unsigned)((n + 31) / 32)), dim3(256),
-                       0, ctx->stream, wx, n, cnt, B, Zt, ldz, t0);
+                       0, ctx->stream, wx, invn, n, cnt, B, Zt, ldz, t0);
   }
   SCL_HIP(ctx, hipGetLastError());
   return SCLENS_OK;
