@@ -10,8 +10,9 @@ call is generated inside the timed region. Default workload = BASELINE.json conf
 
 Prints ONE JSON line on rank 0 (contract in the task statement) with two extra objects:
   roofline     : dominant kernel `trd_colB` (HBM-bound symmetric matrix-vector product of the tridiagonalisation),
-                 algorithmic bytes = 4 (n-j-1)^2 per launch, durations from HIP events recorded on the
-                 library's stream around every launch of one extra tridiagonalisation at the workload's n.
+                 algorithmic bytes = the lower triangle of the symmetric trailing matrix, 2 n'(n'+1) B with n' = n-j-1,
+                 per launch (half of SURVEY 8(d)'s full-read figure 4 n'^2, which is also reported), durations from
+                 HIP events recorded on the library's stream around every launch of one extra tridiagonalisation.
   cpu_baseline : the oracle (float64 NumPy/SciPy port of the reference CPU path) timed on the host cores on a
                  bounded sample, stage-extrapolated to the workload (see `sample`).
 """
@@ -60,7 +61,8 @@ def roofline_probe(ctx, n):
     return {"bound": "hbm", "kernel": "trd_colB", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": None, "launches": launches.value,
             "avg_launch_us": round(ms.value * 1e3 / max(1, launches.value), 2),
-            "algorithmic_bytes_per_launch_avg": round(nbytes.value / max(1, launches.value), 1), "n": n}
+            "algorithmic_bytes_per_launch_avg": round(nbytes.value / max(1, launches.value), 1), "n": n,
+            "achieved_vs_full_read_4n2": round(2 * gbs, 1)}
 
 
 def cpu_baseline(N, M, n_search, n_perturb):
@@ -111,6 +113,7 @@ def main():
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--backend", default="nccl")
     ap.add_argument("--verbose", action="store_true")
+    ap.add_argument("--stage-timing", action="store_true", help="per-stage HIP-event totals on stderr (adds syncs)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -151,6 +154,8 @@ def main():
         torch.cuda.synchronize()
         ctx.sync()
 
+    if args.stage_timing:
+        ctx.set_timing(True)
     res = None
     for w in range(args.warmup):
         res = one_step(-1 - w)
@@ -167,6 +172,9 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
 
+    if args.stage_timing and rank == 0:
+        st = {k: ctx.timing(k) for k in ("scale", "gram", "sytrd", "stebz", "stein", "ormtr", "chefsi", "corr", "recover")}
+        print("stage totals (ms, calls):", {k: (round(v[0], 1), v[1]) for k, v in st.items()}, "wall_s", round(dt, 2), file=sys.stderr)
     if rank == 0:
         ms_per_step = dt / max(1, args.steps) * 1e3
         out = {
@@ -180,7 +188,8 @@ def main():
                        "parallelism": ("single GPU" if world == 1 else f"search rounds of {world} + ensemble t%{world}, 1 RCCL all-gather")},
             "sclens_wall_s": round(dt / max(1, args.steps), 3),
             "observed": {"signals": int(len(res.get("signal_ev", []))), "robust_signals": int(len(res.get("sig_id", []))),
-                         "search_iters": int(res["n_search"]), "p_": res["p_"], "synth_s": round(t_synth, 1)},
+                         "search_iters": int(res["n_search"]), "p_": res["p_"], "synth_s": round(t_synth, 1),
+                         "ensemble_partial_eig": {"used": int(res["partial_eig"][0]), "fallback_to_full": int(res["partial_eig"][1])}},
         }
         if not args.no_roofline:
             out["roofline"] = roofline_probe(ctx, min(N, M))

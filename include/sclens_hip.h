@@ -42,13 +42,14 @@ int sclens_hip_create(sclens_hip_ctx** ctx, int device_id);
 void sclens_hip_destroy(sclens_hip_ctx* ctx);
 const char* sclens_hip_last_error(const sclens_hip_ctx* ctx);
 const char* sclens_hip_version(void);
-/* per-stage HIP-event timing ("scale","gram","sytrd","stebz","stein","ormtr","corr","recover") */
+/* per-stage HIP-event timing ("scale","gram","sytrd","stebz","stein","ormtr","chefsi","corr","recover") */
 int sclens_hip_set_timing(sclens_hip_ctx* ctx, int enabled);
 int sclens_hip_get_timing(sclens_hip_ctx* ctx, const char* stage, double* total_ms, int64_t* calls);
 int sclens_hip_reset_timing(sclens_hip_ctx* ctx);
 /* Per-launch HIP-event timing of the dominant kernel (trd_colB, the HBM-bound symmetric matrix-vector product of
  * the tridiagonalisation). enable=1 starts recording; sclens_hip_symv_profile_read() synchronises, returns the
- * number of recorded launches, the sum of their durations and of their algorithmic bytes (4 (n-j-1)^2 each), and
+ * number of recorded launches, the sum of their durations and of their algorithmic bytes (the lower triangle of the
+ * symmetric trailing matrix, 2 n'(n'+1) with n' = n-j-1, each), and
  * clears the record. */
 int sclens_hip_symv_profile(sclens_hip_ctx* ctx, int enable);
 int sclens_hip_symv_profile_read(sclens_hip_ctx* ctx, int64_t* launches, double* total_ms, double* total_bytes);
@@ -135,6 +136,11 @@ int sclens_hip_session_perturb(sclens_hip_session* s, int64_t t, const uint32_t*
                                double* nL_top, int64_t* ncols);
 /* Download slot t (N x ncols, column-major) -- for tests and for callers that score on the host. */
 int sclens_hip_session_get_perturbed(sclens_hip_session* s, int64_t t, float* nV_t);
+/* Options / counters. set: "chefsi" (1 = ensemble members use the leading-eigenpair subspace iteration seeded with the
+ * data matrix's eigenvectors, falling back to the full solver if it does not converge; 0 = always the full solver).
+ * get: "chefsi", "chefsi_used", "chefsi_fallback". */
+int sclens_hip_session_set_int(sclens_hip_session* s, const char* name, int64_t value);
+int sclens_hip_session_get_int(sclens_hip_session* s, const char* name, int64_t* value);
 /* Multi-GPU ensemble sharding: copy slot t to / from a contiguous device buffer of min_pc x ldn floats
  * (ldn = N rounded up to 32; sclens_hip_session_slot_ld). The buffer may belong to the host framework (e.g. a torch
  * tensor that RCCL all-gathers). */

@@ -35,6 +35,8 @@ SIGNATURES = {
     "sclens_hip_stream": (vp, [vp]),
     "sclens_hip_symv_profile": (C.c_int, [vp, C.c_int]),
     "sclens_hip_symv_profile_read": (C.c_int, [vp, c_i64p, c_f64p, c_f64p]),
+    "sclens_hip_session_set_int": (C.c_int, [vp, C.c_char_p, i64]),
+    "sclens_hip_session_get_int": (C.c_int, [vp, C.c_char_p, c_i64p]),
     "sclens_hip_session_slot_ld": (i64, [vp]),
     "sclens_hip_session_export_slot": (C.c_int, [vp, i64, i64, vp]),
     "sclens_hip_session_import_slot": (C.c_int, [vp, i64, i64, i64, vp]),

@@ -368,6 +368,14 @@ class Session:
         self.ctx.check(self.ctx.lib.sclens_hip_session_get_perturbed(self.h, int(t), ptr(out, C.c_float)))
         return out
 
+    def set_int(self, name: str, value: int):
+        self.ctx.check(self.ctx.lib.sclens_hip_session_set_int(self.h, name.encode(), int(value)))
+
+    def get_int(self, name: str) -> int:
+        v = C.c_int64(0)
+        self.ctx.check(self.ctx.lib.sclens_hip_session_get_int(self.h, name.encode(), C.byref(v)))
+        return v.value
+
     def slot_ld(self) -> int:
         return int(self.ctx.lib.sclens_hip_session_slot_ld(self.h))
 
@@ -442,7 +450,8 @@ def _extract(inp):
 
 def sclens(inp_df, device_="gpu", th=60, p_step=0.001, n_perturb=20, centering="mean", draws: Optional[Draws] = None,
            seed: Optional[int] = None, ctx: Optional[Context] = None, max_search_iters: Optional[int] = None,
-           keep_intermediates: bool = False, verbose: bool = False, shard: Optional[Shard] = None) -> Dict[str, object]:
+           keep_intermediates: bool = False, verbose: bool = False, shard: Optional[Shard] = None,
+           partial_eig: bool = True) -> Dict[str, object]:
     """scLENS.sclens (scLENS.jl:649-832) on one MI355X.
 
     Same keyword arguments as the reference. `draws`/`seed` expose the randomness the reference takes from
@@ -461,6 +470,7 @@ def sclens(inp_df, device_="gpu", th=60, p_step=0.001, n_perturb=20, centering="
         draws = make_draws_native(X_, seed if seed is not None else int(time.time_ns() % (2**31)))
     z1, z2 = draws.z_idx1, draws.z_idx2
     ses = Session(ctx, X_, z1, z2)
+    ses.set_int("chefsi", 1 if partial_eig else 0)
     try:
         # ---- get_sigev (:704): spectra of data and null, MP fit, TW threshold (host), signal vectors
         L, Lr, rec_vals = ses.spectrum(draws.X_r)
@@ -519,7 +529,8 @@ def sclens(inp_df, device_="gpu", th=60, p_step=0.001, n_perturb=20, centering="
                 _exchange_ensemble(ses, shard, n_perturb, min_pc, nL_set, ncols)
 
         res: Dict[str, object] = {"L": L, "L_mp": L_mp, "λ": lambda_c, "lambda_c": lambda_c, "cell_id": cell_id,
-                                  "p_": p_, "p_th": p_th, "n_search": it, "search_trace": trace}
+                                  "p_": p_, "p_th": p_th, "n_search": it, "search_trace": trace,
+                                  "partial_eig": (ses.get_int("chefsi_used"), ses.get_int("chefsi_fallback"))}
         if min_s == 0:  # :780-784
             res["wall_s"] = time.perf_counter() - t_all
             return res

@@ -17,6 +17,8 @@ int session_search_step_seeded(Session*, uint64_t, int64_t, int64_t, double*, in
 int session_perturb_seeded(Session*, int64_t, uint64_t, int64_t, int64_t, double*, int64_t*);
 int session_robustness(Session*, int64_t, int32_t*, double*);
 int session_gene_basis(Session*, const double*, float*);
+int session_set_int(Session*, const char*, int64_t);
+int session_get_int(Session*, const char*, int64_t*);
 int64_t session_slot_ld(Session*);
 int session_export_slot(Session*, int64_t, int64_t, void*);
 int session_import_slot(Session*, int64_t, int64_t, int64_t, const void*);
@@ -191,6 +193,15 @@ int sclens_hip_session_gene_basis(sclens_hip_session* w, const double* nL, float
   return scl::session_gene_basis(w->s, nL, out);
 }
 
+int sclens_hip_session_set_int(sclens_hip_session* w, const char* name, int64_t value) {
+  SES_GUARD(w);
+  return scl::session_set_int(w->s, name, value);
+}
+int sclens_hip_session_get_int(sclens_hip_session* w, const char* name, int64_t* value) {
+  SES_GUARD(w);
+  if (!value) return SCLENS_ERR_ARG;
+  return scl::session_get_int(w->s, name, value);
+}
 int64_t sclens_hip_session_slot_ld(sclens_hip_session* w) { return (w && w->s) ? scl::session_slot_ld(w->s) : -1; }
 int sclens_hip_session_export_slot(sclens_hip_session* w, int64_t t, int64_t min_pc, void* dst) {
   SES_GUARD(w);

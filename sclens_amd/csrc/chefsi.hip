@@ -1,0 +1,297 @@
+// Leading eigenpairs by Chebyshev-filtered subspace iteration (CheFSI) with Rayleigh-Ritz, device-resident.
+//
+// Used for the members of the perturbation ensemble (scLENS.jl:771-778): the reference runs a FULL
+// eigendecomposition per member (get_eigvec, :489-524) and keeps the first min_pc = ceil(1.5 k) columns (:776).
+// Here only those are computed: the block is seeded with the leading eigenvectors of the unperturbed data matrix
+// (already known from get_sigev), every sweep is `degree` block products with the Gram matrix (fp32 MFMA GEMM,
+// split-K so the 400 MB - 3.6 GB matrix is streamed exactly once per product by >= 256 blocks) and one b x b
+// Rayleigh-Ritz problem solved on the host in fp64 (Cholesky + cyclic Jacobi). If the residuals do not reach the
+// tolerance the caller falls back to the full solver, so correctness never depends on convergence here.
+#include <algorithm>
+#include <cmath>
+#include <vector>
+
+#include "common.h"
+
+namespace scl {
+
+// out = a1 * (sum_s part[s] - cc * cur) - a2 * prev      (elementwise over rows x cols; prev may be null when a2 == 0)
+__global__ __launch_bounds__(256) void k_cheb_step(const float* __restrict__ part, int S, int64_t slab,
+                                                   const float* __restrict__ cur, const float* __restrict__ prev,
+                                                   float* __restrict__ out, int64_t rows, int64_t cols, int64_t ld,
+                                                   float a1, float cc, float a2) {
+  const int64_t r = blockIdx.y;
+  const int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (c >= cols) return;
+  const int64_t o = r * ld + c;
+  float s = 0.f;
+  for (int q = 0; q < S; ++q) s += part[(int64_t)q * slab + o];  // fixed order
+  float v = a1 * (s - cc * cur[o]);
+  if (a2 != 0.f) v -= a2 * prev[o];
+  out[o] = v;
+}
+
+// out[i] = sum_s part[s*slab + i]
+__global__ void k_sum_slabs(const float* __restrict__ part, int S, int64_t slab, float* __restrict__ out, int64_t cnt) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= cnt) return;
+  float s = 0.f;
+  for (int q = 0; q < S; ++q) s += part[(int64_t)q * slab + i];
+  out[i] = s;
+}
+
+// res[r] = || Y[r,:] - theta[r] X[r,:] ||_2
+__global__ __launch_bounds__(256) void k_resid_rows(const float* __restrict__ Y, const float* __restrict__ X,
+                                                    const float* __restrict__ theta, int64_t cols, int64_t ld,
+                                                    float* __restrict__ res) {
+  __shared__ double sw[4];
+  const int64_t r = blockIdx.x;
+  const float th = theta[r];
+  double s = 0.0;
+  for (int64_t c = threadIdx.x; c < cols; c += 256) {
+    const double dlt = (double)Y[r * ld + c] - (double)th * (double)X[r * ld + c];
+    s += dlt * dlt;
+  }
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+  if ((threadIdx.x & 63) == 0) sw[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) res[r] = (float)sqrt(sw[0] + sw[1] + sw[2] + sw[3]);
+}
+
+namespace {
+
+// ---- small dense fp64 helpers on the host (b <= 128) ---------------------------------------------------------
+bool cholesky_lower(std::vector<double>& G, int b) {  // in place, row-major; returns false if not SPD
+  for (int j = 0; j < b; ++j) {
+    double dsum = G[j * b + j];
+    for (int k = 0; k < j; ++k) dsum -= G[j * b + k] * G[j * b + k];
+    if (!(dsum > 0.0)) return false;
+    const double l = std::sqrt(dsum);
+    G[j * b + j] = l;
+    for (int i = j + 1; i < b; ++i) {
+      double s = G[i * b + j];
+      for (int k = 0; k < j; ++k) s -= G[i * b + k] * G[j * b + k];
+      G[i * b + j] = s / l;
+    }
+    for (int i = 0; i < j; ++i) G[i * b + j] = 0.0;
+  }
+  return true;
+}
+void invert_lower(const std::vector<double>& L, std::vector<double>& Li, int b) {  // Li = L^-1 (lower)
+  Li.assign((size_t)b * b, 0.0);
+  for (int j = 0; j < b; ++j) {
+    Li[j * b + j] = 1.0 / L[j * b + j];
+    for (int i = j + 1; i < b; ++i) {
+      double s = 0.0;
+      for (int k = j; k < i; ++k) s += L[i * b + k] * Li[k * b + j];
+      Li[i * b + j] = -s / L[i * b + i];
+    }
+  }
+}
+// cyclic Jacobi: C (symmetric, row-major) -> eigenvalues ev, eigenvectors as the COLUMNS of U
+void jacobi_eig(std::vector<double> C, int b, std::vector<double>& ev, std::vector<double>& U) {
+  U.assign((size_t)b * b, 0.0);
+  for (int i = 0; i < b; ++i) U[i * b + i] = 1.0;
+  for (int sweep = 0; sweep < 60; ++sweep) {
+    double off = 0.0, dia = 0.0;
+    for (int i = 0; i < b; ++i)
+      for (int j = 0; j < b; ++j) (i == j ? dia : off) += C[i * b + j] * C[i * b + j];
+    if (off <= 1e-30 * dia) break;
+    for (int p = 0; p < b - 1; ++p)
+      for (int q = p + 1; q < b; ++q) {
+        const double apq = C[p * b + q];
+        if (std::fabs(apq) < 1e-300) continue;
+        const double tau = (C[q * b + q] - C[p * b + p]) / (2.0 * apq);
+        const double t = (tau >= 0 ? 1.0 : -1.0) / (std::fabs(tau) + std::sqrt(1.0 + tau * tau));
+        const double cs = 1.0 / std::sqrt(1.0 + t * t), sn = t * cs;
+        for (int k = 0; k < b; ++k) {  // columns p, q
+          const double ckp = C[k * b + p], ckq = C[k * b + q];
+          C[k * b + p] = cs * ckp - sn * ckq;
+          C[k * b + q] = sn * ckp + cs * ckq;
+        }
+        for (int k = 0; k < b; ++k) {  // rows p, q
+          const double cpk = C[p * b + k], cqk = C[q * b + k];
+          C[p * b + k] = cs * cpk - sn * cqk;
+          C[q * b + k] = sn * cpk + cs * cqk;
+        }
+        for (int k = 0; k < b; ++k) {
+          const double ukp = U[k * b + p], ukq = U[k * b + q];
+          U[k * b + p] = cs * ukp - sn * ukq;
+          U[k * b + q] = sn * ukp + cs * ukq;
+        }
+      }
+  }
+  ev.resize(b);
+  for (int i = 0; i < b; ++i) ev[i] = C[i * b + i];
+}
+
+}  // namespace
+
+int topk_chefsi(Ctx* ctx, const float* A, int64_t n, int64_t lda, int m, int b, const float* X0t, int64_t ldx,
+                const double* theta0, double* w_desc, float* Zt, int64_t ldz, int* converged, int* iters) {
+  *converged = 0;
+  if (iters) *iters = 0;
+  if (m <= 0 || b < m || b > 128 || b > n) return ctx->fail(SCLENS_ERR_ARG, "topk_chefsi: bad block sizes");
+  StageTimer tm(ctx, "chefsi");
+  hipStream_t st = ctx->stream;
+  const int64_t ld = round_up(n, 32);
+  // split-K so that one block product launches >= ~320 blocks
+  const int64_t tiles_n = (n + 127) / 128;
+  int S = (int)((320 + tiles_n - 1) / tiles_n);
+  S = std::max(1, std::min(S, 8));
+  const int64_t slab = (int64_t)b * ld;
+  SCL_WS(ctx, X, float, "che.X", slab);
+  SCL_WS(ctx, Y1, float, "che.Y1", slab);
+  SCL_WS(ctx, Y2, float, "che.Y2", slab);
+  SCL_WS(ctx, AX, float, "che.AX", slab);
+  SCL_WS(ctx, part, float, "che.part", (int64_t)S * slab);
+  const int SG = 32;  // split-K of the two b x b products
+  SCL_WS(ctx, gpart, float, "che.gpart", (int64_t)SG * b * b);
+  SCL_WS(ctx, GH, float, "che.GH", 2 * b * b);
+  SCL_WS(ctx, Wd, float, "che.W", b * b);
+  SCL_WS(ctx, thd, float, "che.theta", b);
+  SCL_WS(ctx, resd, float, "che.res", b);
+  SCL_HIP(ctx, hipMemsetAsync(X, 0, sizeof(float) * slab, st));
+  SCL_HIP(ctx, hipMemcpy2DAsync(X, sizeof(float) * ld, X0t, sizeof(float) * ldx, sizeof(float) * n, b,
+                                hipMemcpyDeviceToDevice, st));
+  SCL_HIP(ctx, hipMemsetAsync(Y1, 0, sizeof(float) * slab, st));
+  SCL_HIP(ctx, hipMemsetAsync(Y2, 0, sizeof(float) * slab, st));
+
+  auto block_product = [&](const float* V) -> int {  // part[s] = V * A (slice s of the contraction)
+    GemmArgs g{};
+    g.P = V; g.Q = A; g.C = part;
+    g.M = b; g.N = n; g.K = n;
+    g.ldp = ld; g.ldq = lda; g.ldc = ld;
+    g.alpha = 1.f; g.beta = 0.f; g.q_kcontig = 1; g.lower = 0; g.colabsmax = nullptr;  // A symmetric: rows are K-contiguous
+    g.splits = S; g.k_chunk = round_up((n + S - 1) / S, 16); g.c_split_off = slab;
+    return gemm_f32(ctx, g);
+  };
+  auto small_product = [&](const float* P, const float* Q, float* out) -> int {  // out[b x b] = P Q^T
+    GemmArgs g{};
+    g.P = P; g.Q = Q; g.C = gpart;
+    g.M = b; g.N = b; g.K = n;
+    g.ldp = ld; g.ldq = ld; g.ldc = b;
+    g.alpha = 1.f; g.beta = 0.f; g.q_kcontig = 1; g.lower = 0; g.colabsmax = nullptr;
+    g.splits = SG; g.k_chunk = round_up((n + SG - 1) / SG, 16); g.c_split_off = (int64_t)b * b;
+    SCL_TRY(gemm_f32(ctx, g));
+    hipLaunchKernelGGL(k_sum_slabs, dim3((unsigned)((b * b + 255) / 256)), dim3(256), 0, st, gpart, SG, (int64_t)b * b,
+                       out, (int64_t)b * b);
+    return SCLENS_OK;
+  };
+  const dim3 egrid((unsigned)((n + 255) / 256), (unsigned)b);
+
+  float *B0 = X, *B1 = Y1, *B2 = Y2;  // B0 = current basis, B1/B2 = scratch
+  std::vector<double> theta(theta0, theta0 + b);
+  std::vector<float> hGH(2 * (size_t)b * b), hW((size_t)b * b), hth(b), hres(b);
+  std::vector<double> G((size_t)b * b), H((size_t)b * b), Li, Cm((size_t)b * b), T1((size_t)b * b), ev, U;
+  const int max_degree = 16, max_outer = 40;
+  const double tol_rel = 1e-3;
+  for (int outer = 0; outer < max_outer; ++outer) {
+    // ---- Chebyshev filter of `degree`: damp [0, theta_b], normalise at theta_1
+    const double lo = 0.0, cut = std::max(theta[b - 1], 1e-12 * theta[0]);
+    const double e = 0.5 * (cut - lo), c = 0.5 * (cut + lo);
+    const double sigma1 = e / (theta[0] - c);
+    double sigma = sigma1;
+    // The filter scales Ritz direction q by T_d(x_q), x_q = (theta_q - c)/e. Between two re-orthogonalisations the
+    // spread T_d(x_1) / T_d(1) must stay far below 1/eps32, or the rows collapse onto the leading eigenvectors.
+    int degree = 2;
+    {
+      const double ach = std::acosh(std::max(1.0 + 1e-9, (theta[0] - c) / e));
+      while (degree < max_degree && std::cosh((degree + 1) * ach) <= 1e5) ++degree;
+    }
+    float *xprev = B0, *xcur = B1, *xnext = B2;
+    SCL_TRY(block_product(B0));
+    hipLaunchKernelGGL(k_cheb_step, egrid, dim3(256), 0, st, part, S, slab, B0, (const float*)nullptr, xcur, (int64_t)b, n, ld,
+                       (float)(sigma1 / e), (float)c, 0.f);
+    for (int i = 2; i <= degree; ++i) {
+      const double sn = 1.0 / (2.0 / sigma1 - sigma);
+      SCL_TRY(block_product(xcur));
+      hipLaunchKernelGGL(k_cheb_step, egrid, dim3(256), 0, st, part, S, slab, xcur, xprev, xnext, (int64_t)b, n, ld,
+                         (float)(2.0 * sn / e), (float)c, (float)(sigma * sn));
+      float* t = xprev; xprev = xcur; xcur = xnext; xnext = t;
+      sigma = sn;
+    }
+    // ---- Rayleigh-Ritz on span(xcur): rows rescaled to unit length first, G = V V^T, H = V (A V)^T
+    SCL_TRY(normalize_rows_f32(ctx, xcur, b, n, ld));
+    SCL_TRY(block_product(xcur));
+    hipLaunchKernelGGL(k_sum_slabs, dim3((unsigned)((slab + 255) / 256)), dim3(256), 0, st, part, S, slab, AX, slab);
+    SCL_TRY(small_product(xcur, xcur, GH));
+    SCL_TRY(small_product(xcur, AX, GH + b * b));
+    SCL_HIP(ctx, hipMemcpyAsync(hGH.data(), GH, sizeof(float) * 2 * b * b, hipMemcpyDeviceToHost, st));
+    SCL_HIP(ctx, hipStreamSynchronize(st));
+    for (int i = 0; i < b; ++i)
+      for (int j = 0; j < b; ++j) {
+        G[i * b + j] = 0.5 * ((double)hGH[i * b + j] + (double)hGH[j * b + i]);
+        H[i * b + j] = 0.5 * ((double)hGH[b * b + i * b + j] + (double)hGH[b * b + j * b + i]);
+      }
+    if (!cholesky_lower(G, b)) {  // numerically rank deficient block -> let the caller fall back
+      if (getenv("SCLENS_HIP_DEBUG")) fprintf(stderr, "[chefsi] outer %d: Gram of the block not SPD\n", outer);
+      break;
+    }
+    invert_lower(G, Li, b);
+    // Cm = Li H Li^T
+    for (int i = 0; i < b; ++i)
+      for (int j = 0; j < b; ++j) {
+        double s = 0.0;
+        for (int k = 0; k <= i; ++k) s += Li[i * b + k] * H[k * b + j];
+        T1[i * b + j] = s;
+      }
+    for (int i = 0; i < b; ++i)
+      for (int j = 0; j < b; ++j) {
+        double s = 0.0;
+        for (int k = 0; k <= j; ++k) s += T1[i * b + k] * Li[j * b + k];
+        Cm[i * b + j] = s;
+      }
+    jacobi_eig(Cm, b, ev, U);
+    std::vector<int> ord(b);
+    for (int i = 0; i < b; ++i) ord[i] = i;
+    std::sort(ord.begin(), ord.end(), [&](int x, int y) { return ev[x] > ev[y]; });
+    // new rows = W V with W = U^T Li (rows ordered by descending Ritz value)
+    for (int r = 0; r < b; ++r) {
+      const int col = ord[r];
+      theta[r] = ev[col];
+      hth[r] = (float)ev[col];
+      for (int j = 0; j < b; ++j) {
+        double s = 0.0;
+        for (int k = j; k < b; ++k) s += U[k * b + col] * Li[k * b + j];
+        hW[r * b + j] = (float)s;
+      }
+    }
+    SCL_HIP(ctx, hipMemcpyAsync(Wd, hW.data(), sizeof(float) * b * b, hipMemcpyHostToDevice, st));
+    SCL_HIP(ctx, hipMemcpyAsync(thd, hth.data(), sizeof(float) * b, hipMemcpyHostToDevice, st));
+    {  // new basis = W V -> xnext ; W (A V) -> xprev ; residuals
+      GemmArgs g{};
+      g.P = Wd; g.Q = xcur; g.C = xnext;
+      g.M = b; g.N = n; g.K = b;
+      g.ldp = b; g.ldq = ld; g.ldc = ld;
+      g.alpha = 1.f; g.beta = 0.f; g.q_kcontig = 0; g.lower = 0; g.colabsmax = nullptr;
+      SCL_TRY(gemm_f32(ctx, g));
+      g.Q = AX; g.C = xprev;
+      SCL_TRY(gemm_f32(ctx, g));
+      hipLaunchKernelGGL(k_resid_rows, dim3((unsigned)b), dim3(256), 0, st, xprev, xnext, thd, n, ld, resd);
+      B0 = xnext; B1 = xprev; B2 = xcur;
+    }
+    SCL_HIP(ctx, hipMemcpyAsync(hres.data(), resd, sizeof(float) * b, hipMemcpyDeviceToHost, st));
+    SCL_HIP(ctx, hipStreamSynchronize(st));
+    if (iters) *iters = outer + 1;
+    if (getenv("SCLENS_HIP_DEBUG")) {
+      fprintf(stderr, "[chefsi] outer %d deg %d cut %.4g theta:", outer, degree, cut);
+      for (int q = 0; q < std::min(b, 14); ++q) fprintf(stderr, " %.5g", theta[q]);
+      fprintf(stderr, " ... %.5g | res/theta:", theta[b - 1]);
+      for (int q = 0; q < std::min(m, 14); ++q) fprintf(stderr, " %.2e", hres[q] / std::fabs(theta[q]));
+      fprintf(stderr, "\n");
+    }
+    bool ok = true;
+    for (int q = 0; q < m; ++q) ok = ok && ((double)hres[q] <= tol_rel * std::fabs(theta[q]));
+    if (ok && outer >= 1) { *converged = 1; break; }
+  }
+  SCL_HIP(ctx, hipGetLastError());
+  if (!*converged) return SCLENS_OK;
+  for (int q = 0; q < m; ++q) w_desc[q] = theta[q];
+  SCL_HIP(ctx, hipMemcpy2DAsync(Zt, sizeof(float) * ldz, B0, sizeof(float) * ld, sizeof(float) * n, m,
+                                hipMemcpyDeviceToDevice, st));
+  SCL_TRY(normalize_rows_f32(ctx, Zt, m, n, ldz));
+  return SCLENS_OK;
+}
+
+}  // namespace scl

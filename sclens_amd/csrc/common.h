@@ -99,6 +99,12 @@ struct GemmArgs {
   int q_kcontig;
   int lower;
   unsigned* colabsmax;
+  // split-K inside one launch (grid.y = splits): slice s covers K range [s*k_chunk, min(K, (s+1)*k_chunk)) and
+  // writes its own output C + s*c_split_off (partials are summed by the consumer in a fixed order).
+  // splits <= 1 means a plain GEMM. k_chunk must be a multiple of 16.
+  int splits = 1;
+  int64_t k_chunk = 0;
+  int64_t c_split_off = 0;
 };
 int gemm_f32(Ctx* ctx, const GemmArgs& a);
 
@@ -124,6 +130,14 @@ int stein_f64(Ctx* ctx, const double* d_dev, const double* e_dev, int64_t n, con
               int64_t lo, int64_t hi, float* Zt, int64_t ldz);
 int ormtr_f32(Ctx* ctx, const float* A, int64_t n, int64_t lda, const float* tau_dev, float* Zt,
               int64_t m, int64_t ldz);
+
+// ------------------------------------------------------------------ partial eigensolver (chefsi.hip)
+// Top-m eigenpairs of a symmetric PSD matrix A (n x n fp32, row-major, lda; NOT modified) by Chebyshev-filtered
+// subspace iteration with Rayleigh-Ritz, started from X0t (b rows of n: approximate leading eigenvectors) and
+// theta0[b] (their eigenvalue estimates, descending). On success (*converged = 1) w_desc[m] (host) holds the m largest
+// eigenvalues (descending) and Zt rows 0..m-1 (device, ldz) the unit eigenvectors in the same order.
+int topk_chefsi(Ctx* ctx, const float* A, int64_t n, int64_t lda, int m, int b, const float* X0t, int64_t ldx,
+                const double* theta0, double* w_desc, float* Zt, int64_t ldz, int* converged, int* iters);
 
 // ------------------------------------------------------------------ small device helpers (util.hip)
 int fill_f32(Ctx* ctx, float* p, int64_t n, float v);

@@ -57,6 +57,14 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs a, int tiles_n) {
     tj = (int)(t % (unsigned)tiles_n);
   }
   const int64_t m0 = (int64_t)ti * BM, n0 = (int64_t)tj * BN;
+  if (a.splits > 1) {  // this block's K slice and private output (grid.y = slice)
+    const int64_t koff = (int64_t)blockIdx.y * a.k_chunk;
+    const int64_t kleft = a.K - koff;
+    a.K = kleft < 0 ? 0 : (kleft < a.k_chunk ? kleft : a.k_chunk);
+    a.P += koff;
+    a.Q += QKC ? koff : koff * a.ldq;
+    a.C += (int64_t)blockIdx.y * a.c_split_off;
+  }
 
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int wm = wid >> 1, wn = wid & 1, l31 = lane & 31, h = lane >> 5;
@@ -174,7 +182,9 @@ int gemm_f32(Ctx* ctx, const GemmArgs& a) {
   if (ntiles > 0x7fffffffLL) return ctx->fail(SCLENS_ERR_ARG, "gemm_f32: too many tiles");
   const bool vec = ((reinterpret_cast<uintptr_t>(a.P) | reinterpret_cast<uintptr_t>(a.Q)) & 15u) == 0 &&
                    (a.ldp % 4 == 0) && (a.ldq % 4 == 0);
-  dim3 grid((unsigned)ntiles), block(256);
+  if (a.splits > 1 && (a.k_chunk <= 0 || a.k_chunk % 16 != 0 || a.colabsmax || a.beta != 0.f))
+    return ctx->fail(SCLENS_ERR_ARG, "gemm_f32: bad split-K arguments");
+  dim3 grid((unsigned)ntiles, (unsigned)(a.splits > 1 ? a.splits : 1)), block(256);
   if (a.q_kcontig) {
     if (vec)
       hipLaunchKernelGGL((gemm_kernel<true, true>), grid, block, 0, ctx->stream, a, (int)tn);

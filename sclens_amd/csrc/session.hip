@@ -206,6 +206,11 @@ struct Session {
   int64_t ldz = 0, zcap = 0;
   float* Vr2t = nullptr;      // [r][ldz]
   int64_t r_vr2 = 0;
+  float* Z0t = nullptr;       // leading b0 eigenvectors of the data Gram matrix (descending), seed of the CheFSI block
+  std::vector<double> theta0; // their eigenvalues (descending)
+  int64_t b0 = 0;
+  int use_chefsi = 1;
+  int64_t chefsi_used = 0, chefsi_fallback = 0;
   float* nVt = nullptr;       // signal vectors, cell side, descending, [k][ldn]
   int64_t k = 0, ldn = 0;
   std::vector<float*> ens;    // slot t: [ncols][ldn], descending
@@ -317,20 +322,30 @@ int session_spectrum(Session* s, const int64_t* rc_, const int32_t* rr_, const f
 // rows of Zt (ascending eigen-index, gene- or cell-side, `cnt` rows) -> cell-side unit vectors,
 // descending, in dst[cnt][ldn]. For N > M: normalize(X * v) (scLENS.jl:503-508, :556-558; the
 // Lambda^-1/2 factor is positive and drops out of the normalisation).
-static int to_cell_side(Session* s, const float* B, int64_t cnt, float* dst) {
+static int copy_rows_f32(Ctx* ctx, const float* src, int64_t rows, int64_t cols, int64_t lds, float* dst, int64_t ldd) {
+  SCL_HIP(ctx, hipMemcpy2DAsync(dst, sizeof(float) * ldd, src, sizeof(float) * lds, sizeof(float) * cols, rows,
+                                hipMemcpyDeviceToDevice, ctx->stream));
+  return SCLENS_OK;
+}
+static int to_cell_side(Session* s, const float* B, int64_t cnt, float* dst, bool desc_input = false,
+                        const float* src = nullptr) {
   Ctx* ctx = s->ctx;
-  if (s->cells_major) return reverse_rows_f32(ctx, s->Zt, cnt, s->N, s->ldz, dst, s->ldn);
+  if (!src) src = s->Zt;
+  if (s->cells_major)
+    return desc_input ? copy_rows_f32(ctx, src, cnt, s->N, s->ldz, dst, s->ldn)
+                      : reverse_rows_f32(ctx, src, cnt, s->N, s->ldz, dst, s->ldn);
   StageTimer tm(ctx, "recover");
   float* tmp = static_cast<float*>(ctx->workspace("ses.rec", sizeof(float) * (size_t)cnt * s->ldn));
   if (!tmp) return SCLENS_ERR_OOM;
   GemmArgs g{};
-  g.P = s->Zt; g.Q = B; g.C = tmp;
+  g.P = src; g.Q = B; g.C = tmp;
   g.M = cnt; g.N = s->N; g.K = s->M;
   g.ldp = s->ldz; g.ldq = s->ldb; g.ldc = s->ldn;
   g.alpha = 1.f; g.beta = 0.f; g.q_kcontig = 0; g.lower = 0; g.colabsmax = nullptr;
   SCL_TRY(gemm_f32(ctx, g));
   SCL_TRY(normalize_rows_f32(ctx, tmp, cnt, s->N, s->ldn));
-  return reverse_rows_f32(ctx, tmp, cnt, s->N, s->ldn, dst, s->ldn);
+  return desc_input ? copy_rows_f32(ctx, tmp, cnt, s->N, s->ldn, dst, s->ldn)
+                    : reverse_rows_f32(ctx, tmp, cnt, s->N, s->ldn, dst, s->ldn);
 }
 
 int session_signal_vectors(Session* s, int64_t k, float* nV) {
@@ -339,14 +354,29 @@ int session_signal_vectors(Session* s, int64_t k, float* nV) {
   if (k < 0 || k > s->n) return ctx->fail(SCLENS_ERR_ARG, "signal_vectors: bad k");
   s->k = k;
   if (k == 0) return SCLENS_OK;
-  SCL_TRY(s->ensure_zt(k));
-  SCL_TRY(eig_vectors(ctx, s->A, s->n, s->lda, s->w64, s->n - k, s->n, s->Zt, s->ldz));
+  // besides the k signal vectors keep the leading b0 eigenvectors of the data matrix: they seed the subspace
+  // iteration of the ensemble members (min_pc = ceil(1.5 k) wanted + a guard band)
+  const int64_t min_pc = (3 * k + 1) / 2;
+  int64_t b0 = round_up(min_pc + 16, 32);
+  if (b0 > 128 || b0 > s->n / 2) b0 = 0;  // too wide for the small-block solver: ensemble uses the full solver
+  const int64_t nv = std::max(k, b0);
+  SCL_TRY(s->ensure_zt(nv));
+  SCL_TRY(eig_vectors(ctx, s->A, s->n, s->lda, s->w64, s->n - nv, s->n, s->Zt, s->ldz));
+  s->b0 = b0;
+  if (b0 > 0) {
+    float* z0 = static_cast<float*>(ctx->workspace("ses.Z0t", sizeof(float) * (size_t)b0 * s->ldz));
+    if (!z0) return SCLENS_ERR_OOM;
+    s->Z0t = z0;
+    SCL_TRY(reverse_rows_f32(ctx, s->Zt + (nv - b0) * s->ldz, b0, s->n, s->ldz, z0, s->ldz));
+    s->theta0.resize(b0);
+    for (int64_t q = 0; q < b0; ++q) s->theta0[q] = s->w_host[s->n - 1 - q];
+  }
   {
     float* p = static_cast<float*>(ctx->workspace("ses.nVt", sizeof(float) * (size_t)k * s->ldn));
     if (!p) return SCLENS_ERR_OOM;
     s->nVt = p;
   }
-  SCL_TRY(to_cell_side(s, s->Bmain, k, s->nVt));
+  SCL_TRY(to_cell_side(s, s->Bmain, k, s->nVt, false, s->Zt + (nv - k) * s->ldz));  // top-k rows (ascending)
   if (nV) {
     SCL_HIP(ctx, hipMemcpy2DAsync(nV, sizeof(float) * s->N, s->nVt, sizeof(float) * s->ldn, sizeof(float) * s->N, k,
                                   hipMemcpyDeviceToHost, ctx->stream));
@@ -440,20 +470,54 @@ int session_perturb_seeded(Session* s, int64_t t, uint64_t seed, int64_t m, int6
 }
 static int perturb_core(Session* s, int64_t t, int64_t min_pc, double* nL_top, int64_t* ncols) {
   Ctx* ctx = s->ctx;
-  SCL_TRY(decompose(s, s->pat.dev, s->val, 1, s->Btmp, (float)s->M, nullptr));
+  if ((int64_t)s->ens.size() <= t) { s->ens.resize(t + 1, nullptr); s->ens_cols.resize(t + 1, 0); }
+  float* slot = static_cast<float*>(ctx->workspace("ses.ens" + std::to_string(t), sizeof(float) * (size_t)min_pc * s->ldn));
+  if (!slot) return SCLENS_ERR_OOM;
+  s->ens[t] = slot;
+  // get_eigvec(logn_scale(pre_scale(tmp_X))) (scLENS.jl:775): closure path, divisor size(X,2) = M
+  SCL_TRY(scale_to_dense(ctx, s->pat.dev, s->val, 1, s->cells_major, s->Btmp, s->ldb, nullptr));
+  SCL_TRY(gram_f32(ctx, s->Btmp, s->n, s->K, s->ldb, (float)s->M, s->A, s->lda));
+  // only the first min_pc eigenpairs are consumed (:776): subspace iteration seeded with the data matrix's vectors
+  if (s->use_chefsi && s->b0 >= min_pc + 8 && s->Z0t) {
+    SCL_TRY(s->ensure_zt(min_pc));
+    std::vector<double> wd(min_pc);
+    int conv = 0, its = 0;
+    SCL_TRY(topk_chefsi(ctx, s->A, s->n, s->lda, (int)min_pc, (int)s->b0, s->Z0t, s->ldz, s->theta0.data(), wd.data(), s->Zt,
+                        s->ldz, &conv, &its));
+    const double tol = 8.0 * 5.96e-8 * std::sqrt((double)s->n) * std::max(0.0, wd.empty() ? 0.0 : wd[0]);
+    if (conv && wd[min_pc - 1] > tol) {  // all min_pc eigenvalues positive: c = min(min_pc, r) = min_pc
+      s->chefsi_used += 1;
+      s->ens_cols[t] = min_pc;
+      if (ncols) *ncols = min_pc;
+      for (int64_t q = 0; q < min_pc; ++q) nL_top[q] = wd[q];
+      return to_cell_side(s, s->Btmp, min_pc, slot, /*desc_input=*/true);
+    }
+    s->chefsi_fallback += 1;
+  }
+  SCL_TRY(eig_values(ctx, s->A, s->n, s->lda, s->w64));
+  SCL_TRY(s->fetch_w());
   const int64_t r = s->count_positive();
   const int64_t c = std::min<int64_t>(min_pc, r);
   if (ncols) *ncols = c;
   for (int64_t q = 0; q < min_pc; ++q) nL_top[q] = (q < c) ? s->w_host[s->n - 1 - q] : 0.0;
-  if ((int64_t)s->ens.size() <= t) { s->ens.resize(t + 1, nullptr); s->ens_cols.resize(t + 1, 0); }
   s->ens_cols[t] = c;
   if (c == 0) return SCLENS_OK;
   SCL_TRY(s->ensure_zt(c));
   SCL_TRY(eig_vectors(ctx, s->A, s->n, s->lda, s->w64, s->n - c, s->n, s->Zt, s->ldz));
-  float* slot = static_cast<float*>(ctx->workspace("ses.ens" + std::to_string(t), sizeof(float) * (size_t)min_pc * s->ldn));
-  if (!slot) return SCLENS_ERR_OOM;
-  s->ens[t] = slot;
   return to_cell_side(s, s->Btmp, c, slot);
+}
+
+int session_set_int(Session* s, const char* name, int64_t value) {
+  const std::string k(name ? name : "");
+  if (k == "chefsi") { s->use_chefsi = value != 0; return SCLENS_OK; }
+  return s->ctx->fail(SCLENS_ERR_ARG, "session_set_int: unknown option " + k);
+}
+int session_get_int(Session* s, const char* name, int64_t* value) {
+  const std::string k(name ? name : "");
+  if (k == "chefsi_used") { *value = s->chefsi_used; return SCLENS_OK; }
+  if (k == "chefsi_fallback") { *value = s->chefsi_fallback; return SCLENS_OK; }
+  if (k == "chefsi") { *value = s->use_chefsi; return SCLENS_OK; }
+  return s->ctx->fail(SCLENS_ERR_ARG, "session_get_int: unknown option " + k);
 }
 
 int session_get_perturbed(Session* s, int64_t t, float* out) {

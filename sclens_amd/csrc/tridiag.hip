@@ -542,7 +542,7 @@ int sytrd_f32(Ctx* ctx, float* A, int64_t n, int64_t lda, double* d_dev, double*
       if (ctx->prof_symv) {
         SCL_HIP(ctx, hipEventRecord(ctx->prof_ev[ctx->prof_used + 1], ctx->stream));
         ctx->prof_used += 2;
-        ctx->prof_bytes += 4.0 * (double)nt * (double)nt;  // the trailing matrix, once (sum_j 4 (n-j)^2)
+        ctx->prof_bytes += 2.0 * (double)nt * (double)(nt + 1);  // unique bytes of the symmetric trailing matrix (lower half)
       }
       nbB_prev = nstrip * nsegmax;
     }

@@ -417,21 +417,14 @@ int ormtr_f32(Ctx* ctx, const float* A, int64_t n, int64_t lda, const float* tau
     const int64_t Kr = n - k_al;
     hipLaunchKernelGGL(build_Vp, dim3((unsigned)((Kr + 255) / 256), NB), dim3(256), 0, ctx->stream, A, n, lda, p, k,
                        k_al, Vp, ldvp);
-    // W1[m][S][NB] : split-K partials of Zt[:, k_al:] * Vp[:, k_al:]^T
-    const int64_t kc = round_up((Kr + S - 1) / S, 16);
-    for (int s = 0; s < S; ++s) {
-      const int64_t ks = s * kc;
+    // W1[m][S][NB] : split-K partials of Zt[:, k_al:] * Vp[:, k_al:]^T, one launch (grid.y = slice)
+    {
       GemmArgs g{};
-      g.M = m; g.N = NB; g.ldp = ldz; g.ldq = ldvp; g.ldc = (int64_t)S * NB;
+      g.P = Zt + k_al; g.Q = Vp + k_al; g.C = W1;
+      g.M = m; g.N = NB; g.K = Kr;
+      g.ldp = ldz; g.ldq = ldvp; g.ldc = (int64_t)S * NB;
       g.alpha = 1.f; g.beta = 0.f; g.q_kcontig = 1; g.lower = 0; g.colabsmax = nullptr;
-      g.C = W1 + s * NB;
-      if (ks >= Kr) {  // empty slice: zero partial
-        g.K = 0;
-        g.P = Zt + k_al; g.Q = Vp + k_al;
-      } else {
-        g.K = (Kr - ks < kc) ? Kr - ks : kc;
-        g.P = Zt + k_al + ks; g.Q = Vp + k_al + ks;
-      }
+      g.splits = S; g.k_chunk = round_up((Kr + S - 1) / S, 16); g.c_split_off = NB;
       SCL_TRY(gemm_f32(ctx, g));
     }
     {  // W2 = (sum_s W1_s) * T^T   (NT with the S-fold replicated T)

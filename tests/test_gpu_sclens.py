@@ -145,3 +145,22 @@ def test_native_draws_agree_with_oracle(ctx):
     assert res["p_"] == ref["p_"] and res["n_search"] == ref["n_search"]
     assert np.array_equal(res["sig_id"], ref["sig_id"])
     assert np.abs(res["robustness_scores"]["rob_score"] - ref["robustness_scores"]["rob_score"]).max() < 3e-3
+
+
+@pytest.mark.parametrize("N,M", [(300, 500), (600, 250)])
+def test_partial_eigensolver_matches_full_solver(ctx, N, M):
+    """Ensemble members via the leading-eigenpair subspace iteration vs the full eigensolver: same decisions,
+    eigenvalues to 3e-4, signal eigenvectors to |cos| >= 1 - 3e-3."""
+    X = synth_counts(N, M, seed=1, C=5, marker_frac=0.2, marker_sd=1.5)
+    d = api.make_draws_native(X, seed=9)
+    a = api.sclens(X, draws=d, n_perturb=5, ctx=ctx, keep_intermediates=True, max_search_iters=6, partial_eig=True)
+    b = api.sclens(X, draws=d, n_perturb=5, ctx=ctx, keep_intermediates=True, max_search_iters=6, partial_eig=False)
+    assert a["partial_eig"][0] == 5 and a["partial_eig"][1] == 0, a["partial_eig"]  # used, no fallback
+    assert b["partial_eig"] == (0, 0)
+    k = len(b["signal_ev"])
+    for t in range(5):
+        assert np.allclose(a["nL_set"][t], b["nL_set"][t], rtol=3e-4)
+        assert np.all(_abs_cos(a["nV_set"][t][:, :k], b["nV_set"][t][:, :k]) > 1 - 3e-3)
+    assert np.array_equal(a["robustness_scores"]["a_b"], b["robustness_scores"]["a_b"])
+    assert np.abs(a["robustness_scores"]["rob_score"] - b["robustness_scores"]["rob_score"]).max() < 3e-3
+    assert np.array_equal(a["sig_id"], b["sig_id"])
