@@ -112,6 +112,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--backend", default="nccl")
+    ap.add_argument("--streams", type=int, default=2, help="concurrent decompositions per GPU (worker sessions on own HIP streams)")
     ap.add_argument("--verbose", action="store_true")
     ap.add_argument("--stage-timing", action="store_true", help="per-stage HIP-event totals on stderr (adds syncs)")
     args = ap.parse_args()
@@ -147,7 +148,8 @@ def main():
 
     def one_step(step):
         draws = api.make_draws_native(X, seed=1000 + step)  # R1-R3 inside the timed region; R4/R5 on the device inside sclens()
-        return api.sclens(X, draws=draws, ctx=ctx, n_perturb=args.n_perturb, shard=shard, verbose=args.verbose and rank == 0)
+        return api.sclens(X, draws=draws, ctx=ctx, n_perturb=args.n_perturb, shard=shard, streams=args.streams,
+                          verbose=args.verbose and rank == 0)
 
     def fence():
         shard.barrier()
@@ -185,7 +187,8 @@ def main():
             "config": {"workload": f"{args.config}: synthetic Poisson-lognormal counts {N} cells x {M} genes, sparsity "
                                    f"{1 - X.nnz / (N * M):.3f}, full sclens() incl. sparsity search and {args.n_perturb}-member "
                                    f"perturbation ensemble", "N": N, "M": M, "nnz": int(X.nnz), "n_perturb": args.n_perturb,
-                       "parallelism": ("single GPU" if world == 1 else f"search rounds of {world} + ensemble t%{world}, 1 RCCL all-gather")},
+                       "parallelism": (f"single GPU, {args.streams} concurrent decompositions (HIP streams)" if world == 1 else
+                                       f"search rounds of {world}x{args.streams} + ensemble t%{world}, 1 RCCL all-gather")},
             "sclens_wall_s": round(dt / max(1, args.steps), 3),
             "observed": {"signals": int(len(res.get("signal_ev", []))), "robust_signals": int(len(res.get("sig_id", []))),
                          "search_iters": int(res["n_search"]), "p_": res["p_"], "synth_s": round(t_synth, 1),

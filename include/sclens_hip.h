@@ -107,6 +107,10 @@ int sclens_hip_session_create(sclens_hip_ctx* ctx, int64_t N, int64_t M, const i
                               const float* nzval, int64_t n_cand, const uint32_t* z_idx1, const uint32_t* z_idx2,
                               sclens_hip_session** out);
 void sclens_hip_session_destroy(sclens_hip_session* s);
+/* A worker session on another context of the SAME device (its own stream and scratch) sharing the read-only device data
+ * of `src` (pattern, Vr2, seed block). Valid calls on it: search_step*, perturb*, export_slot. Create it after
+ * binary_basis; destroy it before `src`. Lets two independent decompositions overlap on one GPU (one host thread each). */
+int sclens_hip_session_clone(sclens_hip_ctx* ctx2, sclens_hip_session* src, sclens_hip_session** out);
 
 /* First half of get_sigev (scLENS.jl:526-537, :569-576): eigenvalues (ascending, length min(N,M)) of the
  * Gram matrix of the scaled data (L) and of the scaled null matrix X_r (Lr; CSC, same shape).

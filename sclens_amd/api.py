@@ -14,6 +14,7 @@ from __future__ import annotations
 import ctypes as C
 import math
 import time
+from concurrent.futures import ThreadPoolExecutor
 from dataclasses import dataclass, field
 from typing import Callable, Dict, List, Optional
 
@@ -307,6 +308,15 @@ class Session:
         except Exception:
             pass
 
+    def clone(self, ctx2: Context) -> "Session":
+        """Worker session on another context (stream) of the same GPU, sharing the read-only device data."""
+        w = Session.__new__(Session)
+        w.ctx, w.N, w.M, w.n, w.ncand = ctx2, self.N, self.M, self.n, self.ncand
+        h = C.c_void_p()
+        ctx2.check(ctx2.lib.sclens_hip_session_clone(ctx2.h, self.h, C.byref(h)))
+        w.h = h
+        return w
+
     def spectrum(self, X_r: sp.csc_matrix):
         X_r = _csc_f32(X_r)
         cp = np.ascontiguousarray(X_r.indptr, dtype=np.int64)
@@ -451,7 +461,7 @@ def _extract(inp):
 def sclens(inp_df, device_="gpu", th=60, p_step=0.001, n_perturb=20, centering="mean", draws: Optional[Draws] = None,
            seed: Optional[int] = None, ctx: Optional[Context] = None, max_search_iters: Optional[int] = None,
            keep_intermediates: bool = False, verbose: bool = False, shard: Optional[Shard] = None,
-           partial_eig: bool = True) -> Dict[str, object]:
+           partial_eig: bool = True, streams: int = 1) -> Dict[str, object]:
     """scLENS.sclens (scLENS.jl:649-832) on one MI355X.
 
     Same keyword arguments as the reference. `draws`/`seed` expose the randomness the reference takes from
@@ -488,49 +498,98 @@ def sclens(inp_df, device_="gpu", th=60, p_step=0.001, n_perturb=20, centering="
         _, r_vr2 = ses.binary_basis()  # Vr2 (:717-721)
         n_2 = int(round(r_vr2 / 2))  # :722
         p_list = search_schedule(p_step)
+        # local workers: `streams` sessions on this GPU (own stream + scratch each, shared read-only data), one host
+        # thread per session (ctypes releases the GIL), so independent decompositions overlap on the device
+        workers = [ses]
+        wctx = []
+        for _ in range(max(1, int(streams)) - 1):
+            c2 = Context(ctx.device)
+            wctx.append(c2)
+            workers.append(ses.clone(c2))
+        W = len(workers)
+        pool = ThreadPoolExecutor(max_workers=W) if W > 1 else None
+
+        def run_all(jobs):
+            """jobs: list of (worker_index, callable) -> results in order."""
+            if pool is None:
+                return [f() for _, f in jobs]
+            futs = [pool.submit(f) for _, f in jobs]
+            return [f.result() for f in futs]
+
+        def search_job(wk, my_it):
+            def f():
+                nnzidx = int(round((1 - p_list[my_it]) * M * N))  # :726
+                out = np.full(6, np.nan)
+                if len(z1) >= nnzidx:
+                    if draws.sampler is not None:
+                        idx = draws.sampler("search", my_it, len(z1), nnzidx)  # :731
+                        d5, _r = workers[wk].search_step(idx, n_2)  # :733-747
+                    else:
+                        d5, _r = workers[wk].search_step_seeded(sample_seed_for(draws.sample_seed, "search", my_it), nnzidx, n_2)
+                    out[:5], out[5] = d5, 1.0
+                return out
+            return f
+
         tank = np.zeros((5, 0))
         it = 0
         p_ = None
-        while p_ is None:
-            my_it = it + shard.rank
-            mine = np.full(6, np.nan)
-            nnzidx = int(round((1 - p_list[my_it]) * M * N))  # :726
-            if len(z1) >= nnzidx:
-                if draws.sampler is not None:
-                    idx = draws.sampler("search", my_it, len(z1), nnzidx)  # :731
-                    d5, _r = ses.search_step(idx, n_2)  # :733-747
-                else:
-                    d5, _r = ses.search_step_seeded(sample_seed_for(draws.sample_seed, "search", my_it), nnzidx, n_2)
-                mine[:5], mine[5] = d5, 1.0
-            allr = shard.allgather_small(mine)
-            results = [allr[q, :5] if allr[q, 5] == 1.0 else None for q in range(shard.world)]
-            tank, used, stopped, p_fin = consume_search_round(tank, results, p_list, it, p_th, p_step, max_search_iters)
-            it += used
-            if stopped:
-                p_ = p_fin
-        trace = [(p_list[q], tank[:, q].copy()) for q in range(tank.shape[1])]
-        if verbose:
-            print(f"Selected perturb sparisty: {p_}")
+        try:
+            while p_ is None:
+                base = it + shard.rank * W
+                mine = np.stack(run_all([(w, search_job(w, base + w)) for w in range(W)]))  # W x 6
+                allr = shard.allgather_small(mine).reshape(shard.world * W, 6)
+                results = [allr[q, :5] if allr[q, 5] == 1.0 else None for q in range(shard.world * W)]
+                tank, used, stopped, p_fin = consume_search_round(tank, results, p_list, it, p_th, p_step, max_search_iters)
+                it += used
+                if stopped:
+                    p_ = p_fin
+            trace = [(p_list[q], tank[:, q].copy()) for q in range(tank.shape[1])]
+            if verbose:
+                print(f"Selected perturb sparisty: {p_}")
 
-        # ---- perturbation ensemble (:767-778): member t runs on rank t % world
-        min_s = k
-        min_pc = int(math.ceil(min_s * 1.5))
-        m_pert = int(round((1 - p_) * M * N))
-        nL_set = [None] * n_perturb
-        ncols = [0] * n_perturb
-        if min_s > 0:
-            for t in owned_perturbations(shard.rank, shard.world, n_perturb):
-                if draws.sampler is not None:
-                    idx = draws.sampler("perturb", t, len(z1), m_pert)
-                    nL_set[t], ncols[t] = ses.perturb(t, idx, min_pc)
-                else:
-                    nL_set[t], ncols[t] = ses.perturb_seeded(t, sample_seed_for(draws.sample_seed, "perturb", t), m_pert, min_pc)
-            if shard.world > 1:
-                _exchange_ensemble(ses, shard, n_perturb, min_pc, nL_set, ncols)
+            # ---- perturbation ensemble (:767-778): member t runs on rank t % world, local worker round-robin
+            min_s = k
+            min_pc = int(math.ceil(min_s * 1.5))
+            m_pert = int(round((1 - p_) * M * N))
+            nL_set = [None] * n_perturb
+            ncols = [0] * n_perturb
+            if min_s > 0:
+                mine_t = owned_perturbations(shard.rank, shard.world, n_perturb)
+
+                def pert_job(wk, t):
+                    def f():
+                        if draws.sampler is not None:
+                            idx = draws.sampler("perturb", t, len(z1), m_pert)
+                            return workers[wk].perturb(t, idx, min_pc)
+                        return workers[wk].perturb_seeded(t, sample_seed_for(draws.sample_seed, "perturb", t), m_pert, min_pc)
+                    return f
+
+                for q0 in range(0, len(mine_t), W):
+                    chunk = mine_t[q0: q0 + W]
+                    outs = run_all([(w, pert_job(w, t)) for w, t in enumerate(chunk)])
+                    for w, t in enumerate(chunk):
+                        nL_set[t], ncols[t] = outs[w]
+                        if w > 0:  # move the slot from the worker session into the main session (device-to-device)
+                            buf = ctx.malloc(4 * min_pc * ses.slot_ld())
+                            try:
+                                workers[w].export_slot(t, min_pc, buf)
+                                ses.import_slot(t, min_pc, ncols[t], buf)
+                            finally:
+                                ctx.free(buf)
+                if shard.world > 1:
+                    _exchange_ensemble(ses, shard, n_perturb, min_pc, nL_set, ncols)
+            pe_counts = (sum(w.get_int("chefsi_used") for w in workers), sum(w.get_int("chefsi_fallback") for w in workers))
+        finally:
+            if pool is not None:
+                pool.shutdown(wait=True)
+            for w in workers[1:]:
+                w.close()
+            for c2 in wctx:
+                c2.close()
 
         res: Dict[str, object] = {"L": L, "L_mp": L_mp, "λ": lambda_c, "lambda_c": lambda_c, "cell_id": cell_id,
                                   "p_": p_, "p_th": p_th, "n_search": it, "search_trace": trace,
-                                  "partial_eig": (ses.get_int("chefsi_used"), ses.get_int("chefsi_fallback"))}
+                                  "partial_eig": pe_counts}
         if min_s == 0:  # :780-784
             res["wall_s"] = time.perf_counter() - t_all
             return res

@@ -7,6 +7,7 @@ struct Session;
 int session_create(Ctx*, int64_t, int64_t, const int64_t*, const int32_t*, const float*, int64_t, const uint32_t*,
                    const uint32_t*, Session**);
 void session_destroy(Session*);
+int session_clone(Ctx*, Session*, Session**);
 int session_spectrum(Session*, const int64_t*, const int32_t*, const float*, double*, double*, ScaleVecs*);
 int session_signal_vectors(Session*, int64_t, float*);
 int session_binary_basis(Session*, double*, int64_t*);
@@ -117,6 +118,19 @@ int sclens_hip_session_create(sclens_hip_ctx* h, int64_t N, int64_t M, const int
   if (!out) return SCLENS_ERR_ARG;
   scl::Session* s = nullptr;
   int rc = scl::session_create(&h->c, N, M, colptr, rowval, nzval, n_cand, z1, z2, &s);
+  if (rc != SCLENS_OK) return rc;
+  sclens_hip_session* w = new sclens_hip_session();
+  w->s = s;
+  w->ctx = h;
+  *out = w;
+  return SCLENS_OK;
+}
+int sclens_hip_session_clone(sclens_hip_ctx* h, sclens_hip_session* src, sclens_hip_session** out) {
+  CTX_GUARD(h);
+  if (!src || !src->s || !out) return SCLENS_ERR_ARG;
+  if (h->c.device != src->ctx->c.device) return h->c.fail(SCLENS_ERR_ARG, "session_clone: contexts must share the device");
+  scl::Session* s = nullptr;
+  int rc = scl::session_clone(&h->c, src->s, &s);
   if (rc != SCLENS_OK) return rc;
   sclens_hip_session* w = new sclens_hip_session();
   w->s = s;

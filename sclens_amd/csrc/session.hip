@@ -278,6 +278,31 @@ int session_create(Ctx* ctx, int64_t N, int64_t M, const int64_t* colptr, const 
   return SCLENS_OK;
 }
 
+// A second session on another context (= another stream of the same GPU) that shares the read-only device data of
+// `src` (sparse pattern, Vr2, CheFSI seed block) and owns its scratch: independent search iterations / ensemble members
+// can then run concurrently, the latency-bound column kernels of one decomposition overlapping the bandwidth-bound
+// kernel of the other. The clone must be destroyed before `src`.
+int session_clone(Ctx* ctx2, Session* src, Session** out) {
+  Session* s = new Session();
+  s->ctx = ctx2;
+  s->N = src->N; s->M = src->M; s->n = src->n; s->K = src->K;
+  s->cells_major = src->cells_major;
+  s->pat.dev = src->pat.dev;            // shared, not owned (allocs stays empty)
+  s->pat.base_val = src->pat.base_val;
+  s->ldb = src->ldb; s->lda = src->lda; s->ldz = src->ldz; s->ldn = src->ldn;
+  s->Vr2t = src->Vr2t; s->r_vr2 = src->r_vr2;
+  s->Z0t = src->Z0t; s->theta0 = src->theta0; s->b0 = src->b0; s->use_chefsi = src->use_chefsi;
+  s->k = src->k;
+  int rc;
+  auto fail = [&](int code) { for (void* p : s->allocs) hipFree(p); delete s; return code; };
+  if ((rc = s->dmalloc((void**)&s->val, sizeof(float) * s->pat.dev.nU)) != SCLENS_OK) return fail(rc);
+  if ((rc = s->dmalloc((void**)&s->Btmp, sizeof(float) * (size_t)s->n * s->ldb)) != SCLENS_OK) return fail(rc);
+  if ((rc = s->dmalloc((void**)&s->A, sizeof(float) * (size_t)s->n * s->lda)) != SCLENS_OK) return fail(rc);
+  if ((rc = s->dmalloc((void**)&s->w64, sizeof(double) * s->n)) != SCLENS_OK) return fail(rc);
+  *out = s;
+  return SCLENS_OK;
+}
+
 void session_destroy(Session* s) {
   if (!s) return;
   hipStreamSynchronize(s->ctx->stream);

@@ -164,3 +164,19 @@ def test_partial_eigensolver_matches_full_solver(ctx, N, M):
     assert np.array_equal(a["robustness_scores"]["a_b"], b["robustness_scores"]["a_b"])
     assert np.abs(a["robustness_scores"]["rob_score"] - b["robustness_scores"]["rob_score"]).max() < 3e-3
     assert np.array_equal(a["sig_id"], b["sig_id"])
+
+
+def test_two_streams_give_identical_results(ctx):
+    """streams=2 (two worker sessions on separate HIP streams, speculative search rounds of 2) must reproduce the
+    serial run bit for bit: same samples per iteration, deterministic kernels, results consumed in order."""
+    X = synth_counts(300, 500, seed=1, C=5, marker_frac=0.2, marker_sd=1.5)
+    d = api.make_draws_native(X, seed=13)
+    a = api.sclens(X, draws=d, n_perturb=5, ctx=ctx, streams=1)
+    b = api.sclens(X, draws=d, n_perturb=5, ctx=ctx, streams=2)
+    assert a["p_"] == b["p_"] and a["n_search"] == b["n_search"]
+    for (p1, t1), (p2, t2) in zip(a["search_trace"], b["search_trace"]):
+        assert p1 == p2 and np.array_equal(t1, t2)
+    assert np.array_equal(a["robustness_scores"]["b_"], b["robustness_scores"]["b_"])
+    assert np.array_equal(a["sig_id"], b["sig_id"])
+    for t in range(5):
+        assert np.array_equal(a["nL_set"][t], b["nL_set"][t])
