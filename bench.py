@@ -112,7 +112,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--backend", default="nccl")
-    ap.add_argument("--streams", type=int, default=2, help="concurrent decompositions per GPU (worker sessions on own HIP streams)")
+    ap.add_argument("--streams", type=int, default=3, help="concurrent decompositions per GPU (worker sessions on own HIP streams)")
     ap.add_argument("--verbose", action="store_true")
     ap.add_argument("--stage-timing", action="store_true", help="per-stage HIP-event totals on stderr (adds syncs)")
     args = ap.parse_args()

@@ -108,8 +108,8 @@ int sclens_hip_session_create(sclens_hip_ctx* ctx, int64_t N, int64_t M, const i
                               sclens_hip_session** out);
 void sclens_hip_session_destroy(sclens_hip_session* s);
 /* A worker session on another context of the SAME device (its own stream and scratch) sharing the read-only device data
- * of `src` (pattern, Vr2, seed block). Valid calls on it: search_step*, perturb*, export_slot. Create it after
- * binary_basis; destroy it before `src`. Lets two independent decompositions overlap on one GPU (one host thread each). */
+ * of `src` (pattern, and Vr2 / seed block if already computed; see sclens_hip_session_adopt). Valid calls on it:
+ * null_spectrum, binary_basis, search_step*, perturb*, export_slot. Destroy it before `src`. Lets two independent decompositions overlap on one GPU (one host thread each). */
 int sclens_hip_session_clone(sclens_hip_ctx* ctx2, sclens_hip_session* src, sclens_hip_session** out);
 
 /* First half of get_sigev (scLENS.jl:526-537, :569-576): eigenvalues (ascending, length min(N,M)) of the
@@ -118,6 +118,15 @@ int sclens_hip_session_clone(sclens_hip_ctx* ctx2, sclens_hip_session* src, scle
 int sclens_hip_session_spectrum(sclens_hip_session* s, const int64_t* r_colptr, const int32_t* r_rowval,
                                 const float* r_nzval, double* L, double* Lr, double* rec_tgc, double* rec_mat2_mean,
                                 double* rec_mat2_std, double* rec_norm_tgc, double* rec_cent);
+/* The two halves of session_spectrum as separate calls, so that the null matrix can be decomposed by a worker session
+ * (sclens_hip_session_clone) while the main session decomposes the data matrix. */
+int sclens_hip_session_null_spectrum(sclens_hip_session* s, const int64_t* r_colptr, const int32_t* r_rowval,
+                                     const float* r_nzval, double* Lr);
+int sclens_hip_session_data_spectrum(sclens_hip_session* s, double* L, double* rec_tgc, double* rec_mat2_mean,
+                                     double* rec_mat2_std, double* rec_norm_tgc, double* rec_cent);
+/* Share read-only device results between sessions of one GPU: what = 1 Vr2 (after binary_basis on src), 2 the seed
+ * block of the partial eigensolver (after signal_vectors on src), 3 both. `src` must outlive `dst`'s use of them. */
+int sclens_hip_session_adopt(sclens_hip_session* dst, sclens_hip_session* src, int what);
 /* Second half (scLENS.jl:541-558, :580-590): cell-side eigenvectors of the k largest eigenvalues,
  * descending; nV is N x k (may be NULL: they also stay on the device for the later steps). */
 int sclens_hip_session_signal_vectors(sclens_hip_session* s, int64_t k, float* nV);

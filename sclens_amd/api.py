@@ -332,6 +332,28 @@ class Session:
             ptr(rec["norm_tgc"], C.c_double), ptr(rec["cent_"], C.c_double)))
         return L, Lr, rec
 
+    def null_spectrum(self, X_r: sp.csc_matrix) -> np.ndarray:
+        X_r = _csc_f32(X_r)
+        cp = np.ascontiguousarray(X_r.indptr, dtype=np.int64)
+        rv = np.ascontiguousarray(X_r.indices, dtype=np.int32)
+        nz = np.ascontiguousarray(X_r.data, dtype=np.float32)
+        Lr = np.empty(self.n)
+        self.ctx.check(self.ctx.lib.sclens_hip_session_null_spectrum(self.h, ptr(cp, C.c_int64), ptr(rv, C.c_int32),
+                                                                     ptr(nz, C.c_float), ptr(Lr, C.c_double)))
+        return Lr
+
+    def data_spectrum(self):
+        L = np.empty(self.n)
+        rec = {"TGC": np.empty(self.N), "mat2_mean": np.empty(self.M), "mat2_std": np.empty(self.M),
+               "norm_tgc": np.empty(self.N), "cent_": np.empty(self.M)}
+        self.ctx.check(self.ctx.lib.sclens_hip_session_data_spectrum(
+            self.h, ptr(L, C.c_double), ptr(rec["TGC"], C.c_double), ptr(rec["mat2_mean"], C.c_double),
+            ptr(rec["mat2_std"], C.c_double), ptr(rec["norm_tgc"], C.c_double), ptr(rec["cent_"], C.c_double)))
+        return L, rec
+
+    def adopt(self, src: "Session", what: int):
+        self.ctx.check(self.ctx.lib.sclens_hip_session_adopt(self.h, src.h, int(what)))
+
     def signal_vectors(self, k: int) -> np.ndarray:
         nV = np.empty((self.N, k), dtype=np.float32, order="F")
         self.ctx.check(self.ctx.lib.sclens_hip_session_signal_vectors(self.h, int(k), ptr(nV, C.c_float)))
@@ -482,22 +504,6 @@ def sclens(inp_df, device_="gpu", th=60, p_step=0.001, n_perturb=20, centering="
     ses = Session(ctx, X_, z1, z2)
     ses.set_int("chefsi", 1 if partial_eig else 0)
     try:
-        # ---- get_sigev (:704): spectra of data and null, MP fit, TW threshold (host), signal vectors
-        L, Lr, rec_vals = ses.spectrum(draws.X_r)
-        L_mp, _, b_min = _mp_calculation(L, Lr[:-1])  # Lr[1:end-1] (:537, :576)
-        lambda_c = _tw(L, L_mp)[0]
-        sel = L > lambda_c
-        k = int(sel.sum())
-        if verbose:
-            print(f"(Using hip) number of signal ev: {k}")
-        nL = L[sel][::-1].copy()  # descending
-        nV = ses.signal_vectors(k)
-        mpC = mp_check(L_mp)  # :706
-        p_th = draws.p_th  # :709-712
-        # ---- sparsity search (:715-762); `shard.world` consecutive p_ values are evaluated per round
-        _, r_vr2 = ses.binary_basis()  # Vr2 (:717-721)
-        n_2 = int(round(r_vr2 / 2))  # :722
-        p_list = search_schedule(p_step)
         # local workers: `streams` sessions on this GPU (own stream + scratch each, shared read-only data), one host
         # thread per session (ctypes releases the GIL), so independent decompositions overlap on the device
         workers = [ses]
@@ -510,11 +516,54 @@ def sclens(inp_df, device_="gpu", th=60, p_step=0.001, n_perturb=20, centering="
         pool = ThreadPoolExecutor(max_workers=W) if W > 1 else None
 
         def run_all(jobs):
-            """jobs: list of (worker_index, callable) -> results in order."""
+            """jobs: list of (worker_index, callable) -> results in job order. Jobs of one worker run sequentially in
+            one thread (a session is single-threaded); different workers run concurrently."""
             if pool is None:
                 return [f() for _, f in jobs]
-            futs = [pool.submit(f) for _, f in jobs]
-            return [f.result() for f in futs]
+            out = [None] * len(jobs)
+            by_worker = {}
+            for pos, (wk, f) in enumerate(jobs):
+                by_worker.setdefault(wk, []).append((pos, f))
+
+            def run_group(group):
+                for pos, f in group:
+                    out[pos] = f()
+
+            futs = [pool.submit(run_group, g) for g in by_worker.values()]
+            for f in futs:
+                f.result()
+            return out
+
+        # ---- get_sigev (:704) and Vr2 (:717-721): the data, null and binarised matrices are independent decompositions
+        if W == 1:  # serial order of the reference: null and data spectra, signal vectors, then Vr2
+            w_bin = ses
+            Lr = ses.null_spectrum(draws.X_r)
+            L, rec_vals = ses.data_spectrum()
+            r_vr2 = None
+        else:  # the main session keeps the data matrix's reflectors for signal_vectors; workers take the other two
+            w_null, w_bin = workers[1], workers[2 if W >= 3 else 1]
+            (L, rec_vals), Lr, (_, r_vr2) = run_all([(0, ses.data_spectrum), (1, lambda: w_null.null_spectrum(draws.X_r)),
+                                                     (2 if W >= 3 else 1, w_bin.binary_basis)])
+        L_mp, _, b_min = _mp_calculation(L, Lr[:-1])  # Lr[1:end-1] (:537, :576)
+        lambda_c = _tw(L, L_mp)[0]
+        sel = L > lambda_c
+        k = int(sel.sum())
+        if verbose:
+            print(f"(Using hip) number of signal ev: {k}")
+        nL = L[sel][::-1].copy()  # descending
+        nV = ses.signal_vectors(k)
+        if r_vr2 is None:
+            _, r_vr2 = ses.binary_basis()
+        for w in workers:  # share Vr2 (from w_bin) and the seed block of the partial eigensolver (from ses)
+            if w is not w_bin:
+                w.adopt(w_bin, 1)
+            if w is not ses:
+                w.adopt(ses, 2)
+        mpC = mp_check(L_mp)  # :706
+        p_th = draws.p_th  # :709-712
+        # ---- sparsity search (:715-762); world x W consecutive p_ values are evaluated per round
+        n_2 = int(round(r_vr2 / 2))  # :722
+        p_list = search_schedule(p_step)
 
         def search_job(wk, my_it):
             def f():

@@ -9,6 +9,9 @@ int session_create(Ctx*, int64_t, int64_t, const int64_t*, const int32_t*, const
 void session_destroy(Session*);
 int session_clone(Ctx*, Session*, Session**);
 int session_spectrum(Session*, const int64_t*, const int32_t*, const float*, double*, double*, ScaleVecs*);
+int session_null_spectrum(Session*, const int64_t*, const int32_t*, const float*, double*);
+int session_data_spectrum(Session*, double*, ScaleVecs*);
+int session_adopt(Session*, Session*, int);
 int session_signal_vectors(Session*, int64_t, float*);
 int session_binary_basis(Session*, double*, int64_t*);
 int session_search_step(Session*, const uint32_t*, int64_t, int64_t, double*, int64_t*);
@@ -158,6 +161,26 @@ int sclens_hip_session_spectrum(sclens_hip_session* w, const int64_t* rc, const 
   if (any && !(rec_tgc && rec_mean && rec_std && rec_norm && rec_cent))
     return w->ctx->c.fail(SCLENS_ERR_ARG, "spectrum: pass all rec_* buffers or none");
   return scl::session_spectrum(w->s, rc, rr, rv, L, Lr, any ? &k : nullptr);
+}
+int sclens_hip_session_null_spectrum(sclens_hip_session* w, const int64_t* rc, const int32_t* rr, const float* rv,
+                                     double* Lr) {
+  SES_GUARD(w);
+  if (!rc || !rr || !rv) return SCLENS_ERR_ARG;
+  return scl::session_null_spectrum(w->s, rc, rr, rv, Lr);
+}
+int sclens_hip_session_data_spectrum(sclens_hip_session* w, double* L, double* rec_tgc, double* rec_mean, double* rec_std,
+                                     double* rec_norm, double* rec_cent) {
+  SES_GUARD(w);
+  scl::ScaleVecs k{rec_tgc, rec_mean, rec_std, rec_norm, rec_cent};
+  bool any = rec_tgc || rec_mean || rec_std || rec_norm || rec_cent;
+  if (any && !(rec_tgc && rec_mean && rec_std && rec_norm && rec_cent))
+    return w->ctx->c.fail(SCLENS_ERR_ARG, "data_spectrum: pass all rec_* buffers or none");
+  return scl::session_data_spectrum(w->s, L, any ? &k : nullptr);
+}
+int sclens_hip_session_adopt(sclens_hip_session* dst, sclens_hip_session* src, int what) {
+  SES_GUARD(dst);
+  if (!src || !src->s) return SCLENS_ERR_ARG;
+  return scl::session_adopt(dst->s, src->s, what);
 }
 int sclens_hip_session_signal_vectors(sclens_hip_session* w, int64_t k, float* nV) {
   SES_GUARD(w);

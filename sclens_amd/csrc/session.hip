@@ -320,27 +320,43 @@ static int decompose(Session* s, const PatternDev& p, const float* val, int f32p
   return s->fetch_w();
 }
 
-int session_spectrum(Session* s, const int64_t* rc_, const int32_t* rr_, const float* rv_, double* L, double* Lr,
-                     ScaleVecs* keep) {
+// null matrix X_r (scLENS.jl:701, :704): closure path, eigenvalues only (:532, :572)
+int session_null_spectrum(Session* s, const int64_t* rc_, const int32_t* rr_, const float* rv_, double* Lr) {
   Ctx* ctx = s->ctx;
-  // null matrix X_r (scLENS.jl:701, :704): closure path, eigenvalues only (:532, :572)
-  if (rc_) {
-    PatternOwner pr;
-    SCL_TRY(pattern_build(ctx, s->N, s->M, rc_, rr_, rv_, 0, nullptr, nullptr, &pr));
-    float* valr = static_cast<float*>(ctx->workspace("ses.valr", sizeof(float) * (size_t)pr.dev.nU));
-    int rc = valr ? SCLENS_OK : SCLENS_ERR_OOM;
-    if (rc == SCLENS_OK) rc = make_values(ctx, pr.dev, pr.base_val, 0, nullptr, 0, valr);
-    if (rc == SCLENS_OK) rc = decompose(s, pr.dev, valr, 1, s->Btmp, (float)s->M, nullptr);
-    hipStreamSynchronize(ctx->stream);
-    pattern_free(&pr);
-    SCL_TRY(rc);
-    if (Lr) std::copy(s->w_host.begin(), s->w_host.end(), Lr);
-  }
-  // data matrix: inline Float64 path with rec_vals (scLENS.jl:676-696); divisor size(X,2) = M
+  PatternOwner pr;
+  SCL_TRY(pattern_build(ctx, s->N, s->M, rc_, rr_, rv_, 0, nullptr, nullptr, &pr));
+  float* valr = static_cast<float*>(ctx->workspace("ses.valr", sizeof(float) * (size_t)pr.dev.nU));
+  int rc = valr ? SCLENS_OK : SCLENS_ERR_OOM;
+  if (rc == SCLENS_OK) rc = make_values(ctx, pr.dev, pr.base_val, 0, nullptr, 0, valr);
+  if (rc == SCLENS_OK) rc = decompose(s, pr.dev, valr, 1, s->Btmp, (float)s->M, nullptr);
+  hipStreamSynchronize(ctx->stream);
+  pattern_free(&pr);
+  SCL_TRY(rc);
+  if (Lr) std::copy(s->w_host.begin(), s->w_host.end(), Lr);
+  return SCLENS_OK;
+}
+
+// data matrix: inline Float64 path with rec_vals (scLENS.jl:676-696); divisor size(X,2) = M
+int session_data_spectrum(Session* s, double* L, ScaleVecs* keep) {
+  Ctx* ctx = s->ctx;
+  if (!s->Bmain) return ctx->fail(SCLENS_ERR_STATE, "data_spectrum: not available on a worker session");
   SCL_TRY(make_values(ctx, s->pat.dev, s->pat.base_val, 0, nullptr, 0, s->val));
   SCL_TRY(decompose(s, s->pat.dev, s->val, 0, s->Bmain, (float)s->M, keep));
   if (L) std::copy(s->w_host.begin(), s->w_host.end(), L);
   s->have_spectrum = true;
+  return SCLENS_OK;
+}
+
+int session_spectrum(Session* s, const int64_t* rc_, const int32_t* rr_, const float* rv_, double* L, double* Lr,
+                     ScaleVecs* keep) {
+  if (rc_) SCL_TRY(session_null_spectrum(s, rc_, rr_, rv_, Lr));
+  return session_data_spectrum(s, L, keep);
+}
+
+// copy the shared read-only results of `src` (Vr2 and/or the seed block of the partial eigensolver) into `dst`
+int session_adopt(Session* dst, Session* src, int what) {
+  if (what & 1) { dst->Vr2t = src->Vr2t; dst->r_vr2 = src->r_vr2; }
+  if (what & 2) { dst->Z0t = src->Z0t; dst->theta0 = src->theta0; dst->b0 = src->b0; dst->k = src->k; }
   return SCLENS_OK;
 }
 
