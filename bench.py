@@ -35,6 +35,10 @@ CONFIGS = {  # name -> (N cells, M genes, index in BASELINE.json configs)
     "cfg4": (100000, 30000, 3),
 }
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+# HBM bytes per trd_colB launch / algorithmic bytes, from the PMC passes in profiles/r01_pmc (rocprofv3 --pmc FETCH_SIZE
+# and --pmc WRITE_SIZE in separate runs, first panel at n = 10000: FETCH_SIZE 99 731 KB x 2 (gfx950 reports half the bytes
+# of wide coalesced reads, MI355X_MICROARCH.md) + WRITE_SIZE 7 149 KB = 211.6 MB against 197.5 MB algorithmic).
+PMC_TRAFFIC_RATIO = 1.07
 
 
 def roofline_probe(ctx, n):
@@ -59,7 +63,8 @@ def roofline_probe(ctx, n):
         ctx.free(p)
     gbs = nbytes.value / (ms.value * 1e-3) / 1e9
     return {"bound": "hbm", "kernel": "trd_colB", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": None, "launches": launches.value,
+            "frac": round(gbs / HBM_PEAK_GBS, 4),
+            "traffic": round(PMC_TRAFFIC_RATIO * nbytes.value / max(1, launches.value), 1), "launches": launches.value,
             "avg_launch_us": round(ms.value * 1e3 / max(1, launches.value), 2),
             "algorithmic_bytes_per_launch_avg": round(nbytes.value / max(1, launches.value), 1), "n": n,
             "achieved_vs_full_read_4n2": round(2 * gbs, 1)}
@@ -143,11 +148,11 @@ def main():
     shard = Shard(rank, world, dev if (world > 1 and args.backend == "nccl") else None)
     N, M, cfg_index = CONFIGS[args.config]
     t0 = time.perf_counter()
-    X = synth_counts(N, M, seed=20240427 + cfg_index)  # PCG64(20240427 + config_index)
+    X = api._csc_f32(synth_counts(N, M, seed=20240427 + cfg_index))  # PCG64(20240427 + config_index)
     t_synth = time.perf_counter() - t0
 
     def one_step(step):
-        draws = api.make_draws_native(X, seed=1000 + step)  # R1-R3 inside the timed region; R4/R5 on the device inside sclens()
+        draws = api.make_draws_native(X, seed=1000 + step, async_null=True)  # R1-R3 inside the timed region; R4/R5 on the device inside sclens()
         return api.sclens(X, draws=draws, ctx=ctx, n_perturb=args.n_perturb, shard=shard, streams=args.streams,
                           verbose=args.verbose and rank == 0)
 

@@ -185,9 +185,12 @@ def sample_indices(population: int, m: int, seed: int) -> np.ndarray:
 
 
 def _csc_f32(X) -> sp.csc_matrix:
+    if getattr(X, "_sclens_canonical", False):  # already float32 CSC, sorted, no explicit zeros (our own generators)
+        return X
     X = sp.csc_matrix(X, dtype=np.float32)
     X.eliminate_zeros()
     X.sort_indices()
+    X._sclens_canonical = True
     return X
 
 
@@ -231,7 +234,15 @@ def draw_noise_baseline(n: int, rng: np.random.Generator, trials: int = 5000) ->
     return acc / trials
 
 
-def make_draws_native(X, seed: int, host_sampler: bool = False) -> Draws:
+def _resolve(x):
+    """X_r may be a concurrent.futures.Future (make_draws_native(async_null=True))."""
+    return x.result() if hasattr(x, "result") else x
+
+
+_draw_pool = ThreadPoolExecutor(max_workers=2)
+
+
+def make_draws_native(X, seed: int, host_sampler: bool = False, async_null: bool = False) -> Draws:
     """All draws from the library's own generators (C++ on the host for R1/R2, the exact expectation for R3 --
     the quantity scLENS.jl:709-712 estimates with 5000 Monte-Carlo trials -- and the device-side keyed permutation
     for R4/R5). `host_sampler=True` materialises the identical R4/R5 index vectors on the host instead."""
@@ -249,13 +260,21 @@ def make_draws_native(X, seed: int, host_sampler: bool = False) -> Draws:
     if rc:
         raise SclensHipError(rc, "sclens_draw_zero_candidates")
     z1, z2 = z1[: cnt.value].copy(), z2[: cnt.value].copy()
-    rrow = np.empty(X.nnz, dtype=np.int32)
-    rval = np.empty(X.nnz, dtype=np.float32)
-    rc = lib.sclens_draw_null_matrix(N, M, ptr(cp, C.c_int64), ptr(nz, C.c_float), (int(seed) + 1) & _M64, ptr(rrow, C.c_int32),
-                                     ptr(rval, C.c_float))
-    if rc:
-        raise SclensHipError(rc, "sclens_draw_null_matrix")
-    Xr = sp.csc_matrix((rval, rrow, cp.copy()), shape=(N, M), dtype=np.float32)
+
+    def null_matrix():
+        rrow = np.empty(X.nnz, dtype=np.int32)
+        rval = np.empty(X.nnz, dtype=np.float32)
+        rc2 = lib.sclens_draw_null_matrix(N, M, ptr(cp, C.c_int64), ptr(nz, C.c_float), (int(seed) + 1) & _M64,
+                                          ptr(rrow, C.c_int32), ptr(rval, C.c_float))
+        if rc2:
+            raise SclensHipError(rc2, "sclens_draw_null_matrix")
+        out = sp.csc_matrix((rval, rrow, cp.copy()), shape=(N, M), dtype=np.float32)
+        out._sclens_canonical = True  # rows ascending per gene, values are the (non-zero) stored counts
+        return out
+
+    # async_null: X_r is generated on a host thread (the C++ generator releases the GIL) while the caller already
+    # builds the session and decomposes the data matrix; sclens() resolves the future when the null spectrum is due
+    Xr = _draw_pool.submit(null_matrix) if async_null else null_matrix()
     p_th = float(lib.sclens_noise_baseline_exact(min(N, M)))
     d = Draws(z1, z2, Xr, p_th, None, int(seed))
     if host_sampler:
@@ -537,12 +556,12 @@ def sclens(inp_df, device_="gpu", th=60, p_step=0.001, n_perturb=20, centering="
         # ---- get_sigev (:704) and Vr2 (:717-721): the data, null and binarised matrices are independent decompositions
         if W == 1:  # serial order of the reference: null and data spectra, signal vectors, then Vr2
             w_bin = ses
-            Lr = ses.null_spectrum(draws.X_r)
+            Lr = ses.null_spectrum(_resolve(draws.X_r))
             L, rec_vals = ses.data_spectrum()
             r_vr2 = None
         else:  # the main session keeps the data matrix's reflectors for signal_vectors; workers take the other two
             w_null, w_bin = workers[1], workers[2 if W >= 3 else 1]
-            (L, rec_vals), Lr, (_, r_vr2) = run_all([(0, ses.data_spectrum), (1, lambda: w_null.null_spectrum(draws.X_r)),
+            (L, rec_vals), Lr, (_, r_vr2) = run_all([(0, ses.data_spectrum), (1, lambda: w_null.null_spectrum(_resolve(draws.X_r))),
                                                      (2 if W >= 3 else 1, w_bin.binary_basis)])
         L_mp, _, b_min = _mp_calculation(L, Lr[:-1])  # Lr[1:end-1] (:537, :576)
         lambda_c = _tw(L, L_mp)[0]
