@@ -127,7 +127,7 @@ void jacobi_eig(std::vector<double> C, int b, std::vector<double>& ev, std::vect
 
 }  // namespace
 
-int topk_chefsi(Ctx* ctx, const float* A, int64_t n, int64_t lda, int m, int b, const float* X0t, int64_t ldx,
+int topk_chefsi(Ctx* ctx, const float* A, int64_t n, int64_t lda, int m, int m_strict, int b, const float* X0t, int64_t ldx,
                 const double* theta0, double* w_desc, float* Zt, int64_t ldz, int* converged, int* iters) {
   *converged = 0;
   if (iters) *iters = 0;
@@ -184,8 +184,11 @@ int topk_chefsi(Ctx* ctx, const float* A, int64_t n, int64_t lda, int m, int b, 
   std::vector<double> theta(theta0, theta0 + b);
   std::vector<float> hGH(2 * (size_t)b * b), hW((size_t)b * b), hth(b), hres(b);
   std::vector<double> G((size_t)b * b), H((size_t)b * b), Li, Cm((size_t)b * b), T1((size_t)b * b), ev, U;
-  const int max_degree = 16, max_outer = 40;
-  const double tol_rel = 1e-3;
+  const int max_degree = 16, max_outer = 24;
+  // residual targets: the first m_strict pairs (the signals, whose eigenvectors are consumed) 1e-3 * theta; the
+  // remaining ones up to m only feed eigenvalues and the matching argmax: 3e-3 * theta (Ritz value error ~ res^2 / gap
+  // to the spectrum outside the block, well below the 3e-4 relative tolerance of the parity tests)
+  const double tol_rel = 1e-3, tol_rel_tail = 3e-3;
   for (int outer = 0; outer < max_outer; ++outer) {
     // ---- Chebyshev filter of `degree`: damp [0, theta_b], normalise at theta_1
     const double lo = 0.0, cut = std::max(theta[b - 1], 1e-12 * theta[0]);
@@ -282,7 +285,7 @@ int topk_chefsi(Ctx* ctx, const float* A, int64_t n, int64_t lda, int m, int b, 
       fprintf(stderr, "\n");
     }
     bool ok = true;
-    for (int q = 0; q < m; ++q) ok = ok && ((double)hres[q] <= tol_rel * std::fabs(theta[q]));
+    for (int q = 0; q < m; ++q) ok = ok && ((double)hres[q] <= (q < m_strict ? tol_rel : tol_rel_tail) * std::fabs(theta[q]));
     if (ok && outer >= 1) { *converged = 1; break; }
   }
   SCL_HIP(ctx, hipGetLastError());

@@ -134,9 +134,9 @@ int ormtr_f32(Ctx* ctx, const float* A, int64_t n, int64_t lda, const float* tau
 // ------------------------------------------------------------------ partial eigensolver (chefsi.hip)
 // Top-m eigenpairs of a symmetric PSD matrix A (n x n fp32, row-major, lda; NOT modified) by Chebyshev-filtered
 // subspace iteration with Rayleigh-Ritz, started from X0t (b rows of n: approximate leading eigenvectors) and
-// theta0[b] (their eigenvalue estimates, descending). On success (*converged = 1) w_desc[m] (host) holds the m largest
+// theta0[b] (their eigenvalue estimates, descending); the first m_strict pairs get the tight residual target. On success (*converged = 1) w_desc[m] (host) holds the m largest
 // eigenvalues (descending) and Zt rows 0..m-1 (device, ldz) the unit eigenvectors in the same order.
-int topk_chefsi(Ctx* ctx, const float* A, int64_t n, int64_t lda, int m, int b, const float* X0t, int64_t ldx,
+int topk_chefsi(Ctx* ctx, const float* A, int64_t n, int64_t lda, int m, int m_strict, int b, const float* X0t, int64_t ldx,
                 const double* theta0, double* w_desc, float* Zt, int64_t ldz, int* converged, int* iters);
 
 // ------------------------------------------------------------------ small device helpers (util.hip)

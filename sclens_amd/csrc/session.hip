@@ -523,7 +523,8 @@ static int perturb_core(Session* s, int64_t t, int64_t min_pc, double* nL_top, i
     SCL_TRY(s->ensure_zt(min_pc));
     std::vector<double> wd(min_pc);
     int conv = 0, its = 0;
-    SCL_TRY(topk_chefsi(ctx, s->A, s->n, s->lda, (int)min_pc, (int)s->b0, s->Z0t, s->ldz, s->theta0.data(), wd.data(), s->Zt,
+    SCL_TRY(topk_chefsi(ctx, s->A, s->n, s->lda, (int)min_pc, (int)std::min<int64_t>(s->k, min_pc), (int)s->b0, s->Z0t, s->ldz,
+                        s->theta0.data(), wd.data(), s->Zt,
                         s->ldz, &conv, &its));
     const double tol = 8.0 * 5.96e-8 * std::sqrt((double)s->n) * std::max(0.0, wd.empty() ? 0.0 : wd[0]);
     if (conv && wd[min_pc - 1] > tol) {  // all min_pc eigenvalues positive: c = min(min_pc, r) = min_pc
