@@ -11,8 +11,8 @@ call is generated inside the timed region. Default workload = BASELINE.json conf
 Prints ONE JSON line on rank 0 (contract in the task statement) with two extra objects:
   roofline     : dominant kernel `trd_colB` (HBM-bound symmetric matrix-vector product of the tridiagonalisation),
                  algorithmic bytes = the lower triangle of the symmetric trailing matrix, 2 n'(n'+1) B with n' = n-j-1,
-                 per launch (half of SURVEY 8(d)'s full-read figure 4 n'^2, which is also reported), durations from
-                 HIP events recorded on the library's stream around every launch of one extra tridiagonalisation.
+                 per launch (half of SURVEY 8(d)'s full-read figure 4 n'^2, which is also reported); duration = one
+                 HIP-event pair on the library's stream around all n-1 launches of one tridiagonalisation, back to back.
   cpu_baseline : the oracle (float64 NumPy/SciPy port of the reference CPU path) timed on the host cores on a
                  bounded sample, stage-extrapolated to the workload (see `sample`).
 """
@@ -42,25 +42,13 @@ PMC_TRAFFIC_RATIO = 1.07
 
 
 def roofline_probe(ctx, n):
-    """One tridiagonalisation of a random symmetric n x n matrix with every trd_colB launch HIP-event timed."""
+    """Every trd_colB launch of one tridiagonalisation of order n (same grids / arguments as the real reduction), back
+    to back on the library's stream between one pair of HIP events (sclens_hip_symv_probe)."""
     import ctypes as C
 
-    rng = np.random.default_rng(5)
-    lda = (n + 31) // 32 * 32
-    K = 256
-    B = rng.standard_normal((n, K)).astype(np.float32)
-    dB = ctx.malloc(B.nbytes)
-    ctx.h2d(dB, B)
-    dA = ctx.malloc(4 * n * lda)
-    dd, de, dt = ctx.malloc(8 * n), ctx.malloc(8 * n), ctx.malloc(8 * n)
-    ctx.check(ctx.lib.sclens_hip_dev_gram_f32(ctx.h, dB, n, K, K, float(K), dA, lda))
-    ctx.check(ctx.lib.sclens_hip_symv_profile(ctx.h, 1))
-    ctx.check(ctx.lib.sclens_hip_dev_sytrd_f32(ctx.h, dA, n, lda, dd, de, dt))
     launches, ms, nbytes = C.c_int64(0), C.c_double(0), C.c_double(0)
-    ctx.check(ctx.lib.sclens_hip_symv_profile_read(ctx.h, C.byref(launches), C.byref(ms), C.byref(nbytes)))
-    ctx.check(ctx.lib.sclens_hip_symv_profile(ctx.h, 0))
-    for p in (dB, dA, dd, de, dt):
-        ctx.free(p)
+    ctx.check(ctx.lib.sclens_hip_symv_probe(ctx.h, n, C.byref(launches), C.byref(ms), C.byref(nbytes)))  # warm-up
+    ctx.check(ctx.lib.sclens_hip_symv_probe(ctx.h, n, C.byref(launches), C.byref(ms), C.byref(nbytes)))
     gbs = nbytes.value / (ms.value * 1e-3) / 1e9
     return {"bound": "hbm", "kernel": "trd_colB", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(gbs / HBM_PEAK_GBS, 4),

@@ -53,6 +53,9 @@ int sclens_hip_reset_timing(sclens_hip_ctx* ctx);
  * clears the record. */
 int sclens_hip_symv_profile(sclens_hip_ctx* ctx, int enable);
 int sclens_hip_symv_profile_read(sclens_hip_ctx* ctx, int64_t* launches, double* total_ms, double* total_bytes);
+/* Roofline probe: all n-1 trd_colB launches of one tridiagonalisation of order n, back to back between one pair of HIP
+ * events on the context's stream (synthetic finite data; same grids and arguments as the real reduction). */
+int sclens_hip_symv_probe(sclens_hip_ctx* ctx, int64_t n, int64_t* launches, double* total_ms, double* total_bytes);
 /* raw stream handle (hipStream_t) so a host framework can order its own work after ours */
 void* sclens_hip_stream(sclens_hip_ctx* ctx);
 

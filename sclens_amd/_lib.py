@@ -33,6 +33,7 @@ SIGNATURES = {
     "sclens_hip_get_timing": (C.c_int, [vp, C.c_char_p, c_f64p, c_i64p]),
     "sclens_hip_reset_timing": (C.c_int, [vp]),
     "sclens_hip_stream": (vp, [vp]),
+    "sclens_hip_symv_probe": (C.c_int, [vp, i64, c_i64p, c_f64p, c_f64p]),
     "sclens_hip_symv_profile": (C.c_int, [vp, C.c_int]),
     "sclens_hip_symv_profile_read": (C.c_int, [vp, c_i64p, c_f64p, c_f64p]),
     "sclens_hip_session_set_int": (C.c_int, [vp, C.c_char_p, i64]),

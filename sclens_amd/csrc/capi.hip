@@ -249,6 +249,11 @@ int sclens_hip_session_import_slot(sclens_hip_session* w, int64_t t, int64_t min
   return scl::session_import_slot(w->s, t, min_pc, ncols, src);
 }
 
+int sclens_hip_symv_probe(sclens_hip_ctx* h, int64_t n, int64_t* launches, double* total_ms, double* total_bytes) {
+  CTX_GUARD(h);
+  if (!launches || !total_ms || !total_bytes) return SCLENS_ERR_ARG;
+  return scl::symv_probe(&h->c, n, launches, total_ms, total_bytes);
+}
 int sclens_hip_symv_profile(sclens_hip_ctx* h, int enable) {
   CTX_GUARD(h);
   h->c.prof_symv = enable != 0;

@@ -100,7 +100,9 @@ void jacobi_eig(std::vector<double> C, int b, std::vector<double>& ev, std::vect
     for (int p = 0; p < b - 1; ++p)
       for (int q = p + 1; q < b; ++q) {
         const double apq = C[p * b + q];
-        if (std::fabs(apq) < 1e-300) continue;
+        // threshold Jacobi: after the first Rayleigh-Ritz step the projected matrix is nearly diagonal (the block rows
+        // are Ritz vectors), so almost every rotation is skipped
+        if (std::fabs(apq) <= 1e-17 * std::sqrt(std::fabs(C[p * b + p] * C[q * b + q])) || std::fabs(apq) < 1e-300) continue;
         const double tau = (C[q * b + q] - C[p * b + p]) / (2.0 * apq);
         const double t = (tau >= 0 ? 1.0 : -1.0) / (std::fabs(tau) + std::sqrt(1.0 + tau * tau));
         const double cs = 1.0 / std::sqrt(1.0 + t * t), sn = t * cs;
@@ -184,11 +186,11 @@ int topk_chefsi(Ctx* ctx, const float* A, int64_t n, int64_t lda, int m, int m_s
   std::vector<double> theta(theta0, theta0 + b);
   std::vector<float> hGH(2 * (size_t)b * b), hW((size_t)b * b), hth(b), hres(b);
   std::vector<double> G((size_t)b * b), H((size_t)b * b), Li, Cm((size_t)b * b), T1((size_t)b * b), ev, U;
-  const int max_degree = 16, max_outer = 24;
+  const int max_degree = 16, max_outer = 32;
   // residual targets: the first m_strict pairs (the signals, whose eigenvectors are consumed) 1e-3 * theta; the
   // remaining ones up to m only feed eigenvalues and the matching argmax: 3e-3 * theta (Ritz value error ~ res^2 / gap
   // to the spectrum outside the block, well below the 3e-4 relative tolerance of the parity tests)
-  const double tol_rel = 1e-3, tol_rel_tail = 3e-3;
+  const double tol_rel = 1e-3, tol_rel_tail = 5e-3;
   for (int outer = 0; outer < max_outer; ++outer) {
     // ---- Chebyshev filter of `degree`: damp [0, theta_b], normalise at theta_1
     const double lo = 0.0, cut = std::max(theta[b - 1], 1e-12 * theta[0]);

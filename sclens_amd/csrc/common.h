@@ -131,6 +131,8 @@ int stein_f64(Ctx* ctx, const double* d_dev, const double* e_dev, int64_t n, con
 int ormtr_f32(Ctx* ctx, const float* A, int64_t n, int64_t lda, const float* tau_dev, float* Zt,
               int64_t m, int64_t ldz);
 
+int symv_probe(Ctx* ctx, int64_t n, int64_t* launches, double* total_ms, double* total_bytes);
+
 // ------------------------------------------------------------------ partial eigensolver (chefsi.hip)
 // Top-m eigenpairs of a symmetric PSD matrix A (n x n fp32, row-major, lda; NOT modified) by Chebyshev-filtered
 // subspace iteration with Rayleigh-Ritz, started from X0t (b rows of n: approximate leading eigenvectors) and

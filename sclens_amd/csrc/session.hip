@@ -398,7 +398,7 @@ int session_signal_vectors(Session* s, int64_t k, float* nV) {
   // besides the k signal vectors keep the leading b0 eigenvectors of the data matrix: they seed the subspace
   // iteration of the ensemble members (min_pc = ceil(1.5 k) wanted + a guard band)
   const int64_t min_pc = (3 * k + 1) / 2;
-  int64_t b0 = round_up(min_pc + 16, 32);
+  int64_t b0 = round_up(min_pc + 40, 32);  // guard band: the block product streams the matrix once whatever b <= 128 is
   if (b0 > 128 || b0 > s->n / 2) b0 = 0;  // too wide for the small-block solver: ensemble uses the full solver
   const int64_t nv = std::max(k, b0);
   SCL_TRY(s->ensure_zt(nv));

@@ -27,7 +27,8 @@ constexpr int NB = 128;        // panel width (also the block-reflector width of
 constexpr int RPB_A = 128;     // rows per block in trd_colA (x 8 column groups = 1024 threads)
 constexpr int NG_A = 8;        // column groups in trd_colA
 constexpr int RS = 32;         // strip height of trd_colB
-constexpr int SEG = 1024;      // segment width of trd_colB (4 waves x 256 columns)
+constexpr int CH = 1;          // 256-column chunks per wave in trd_colB
+constexpr int SEG = 1024 * CH; // segment width of trd_colB (4 waves x CH x 256 columns)
 constexpr int PR = 16;         // rows loaded per pass in trd_colB (registers vs. loads in flight)
 constexpr int PA_LD = 2 * NB + 1;
 // colinfo: [0]=tau [1]=scale [2]=(V^T v).(W^T v), [4..4+NB) = V^T v, [4+NB..4+2NB) = W^T v
@@ -395,53 +396,58 @@ __global__ __launch_bounds__(256) void trd_colB(TrdArgs a, int64_t j, int c, int
     return;
   }
   const float scale = a.colinfo[1];
-  const int64_t col = cseg + wid * 256 + 4 * lane;  // this lane's 4 columns
-  const bool colok = col < n && col < cend;
-  // v for the 4 columns (row-dot use) and the transposed mask (columns strictly left of the strip)
-  f32x4 vc = {0.f, 0.f, 0.f, 0.f};
-  float tmask[4] = {0.f, 0.f, 0.f, 0.f};
-  if (colok) {
-    const f32x4 xv = *reinterpret_cast<const f32x4*>(a.x + col);  // x is zero-padded past n
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      const int64_t idx = col + e;
-      const float v = (idx == j + 1) ? 1.f : ((idx > j + 1 && idx < n) ? xv[e] * scale : 0.f);
-      vc[e] = (idx < cend) ? v : 0.f;
-      tmask[e] = (idx < rb && idx >= j + 1) ? 1.f : 0.f;
-    }
-  }
   float racc[RS];
-  f32x4 cacc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
   for (int q = 0; q < RS; ++q) racc[q] = 0.f;
+  double utv = 0.0;
+#pragma unroll 1
+  for (int ch = 0; ch < CH; ++ch) {
+    const int64_t col = cseg + (int64_t)(ch * 4 + wid) * 256 + 4 * lane;  // this lane's 4 columns of chunk ch
+    if (cseg + (int64_t)(ch * 4) * 256 >= cend) break;  // whole chunk row of the block is outside the trapezoid
+    const bool colok = col < n && col < cend;
+    // v for the 4 columns (row-dot use) and the transposed mask (columns strictly left of the strip)
+    f32x4 vc = {0.f, 0.f, 0.f, 0.f};
+    float tmask[4] = {0.f, 0.f, 0.f, 0.f};
+    if (colok) {
+      const f32x4 xv = *reinterpret_cast<const f32x4*>(a.x + col);  // x is zero-padded past n
 #pragma unroll
-  for (int pass = 0; pass < RS / PR; ++pass) {
-    f32x4 av[PR];
-    float vr[PR];
-#pragma unroll
-    for (int q = 0; q < PR; ++q) {
-      const int64_t row = rb + pass * PR + q;
-      const bool rok = row < n;
-      av[q] = (rok && colok) ? *reinterpret_cast<const f32x4*>(a.A + row * lda + col) : f32x4{0.f, 0.f, 0.f, 0.f};
-      const float xr = rok ? a.x[row] : 0.f;  // wave-uniform
-      vr[q] = (row == j + 1) ? 1.f : xr * scale;
-      if (!rok) vr[q] = 0.f;
+      for (int e = 0; e < 4; ++e) {
+        const int64_t idx = col + e;
+        const float v = (idx == j + 1) ? 1.f : ((idx > j + 1 && idx < n) ? xv[e] * scale : 0.f);
+        vc[e] = (idx < cend) ? v : 0.f;
+        tmask[e] = (idx < rb && idx >= j + 1) ? 1.f : 0.f;
+      }
     }
+    f32x4 cacc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int q = 0; q < PR; ++q) {
-      racc[pass * PR + q] += av[q][0] * vc[0] + av[q][1] * vc[1] + av[q][2] * vc[2] + av[q][3] * vc[3];
-      cacc[0] += av[q][0] * vr[q];
-      cacc[1] += av[q][1] * vr[q];
-      cacc[2] += av[q][2] * vr[q];
-      cacc[3] += av[q][3] * vr[q];
+    for (int pass = 0; pass < RS / PR; ++pass) {
+      f32x4 av[PR];
+      float vr[PR];
+#pragma unroll
+      for (int q = 0; q < PR; ++q) {
+        const int64_t row = rb + pass * PR + q;
+        const bool rok = row < n;
+        av[q] = (rok && colok) ? *reinterpret_cast<const f32x4*>(a.A + row * lda + col) : f32x4{0.f, 0.f, 0.f, 0.f};
+        const float xr = rok ? a.x[row] : 0.f;  // wave-uniform
+        vr[q] = (row == j + 1) ? 1.f : xr * scale;
+        if (!rok) vr[q] = 0.f;
+      }
+#pragma unroll
+      for (int q = 0; q < PR; ++q) {
+        racc[pass * PR + q] += av[q][0] * vc[0] + av[q][1] * vc[1] + av[q][2] * vc[2] + av[q][3] * vc[3];
+        cacc[0] += av[q][0] * vr[q];
+        cacc[1] += av[q][1] * vr[q];
+        cacc[2] += av[q][2] * vr[q];
+        cacc[3] += av[q][3] * vr[q];
+      }
     }
+    // transposed contribution of this (strip, chunk): complete, stored once; masked outside [j+1, rb)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) cacc[e] *= tmask[e];
+    if (col < n) *reinterpret_cast<f32x4*>(a.colpart + s * ldv + col) = cacc;
+    // partial u^T v of this unit: v_col * cacc (transposed part) ...
+    utv += (double)(cacc[0] * vc[0]) + (double)(cacc[1] * vc[1]) + (double)(cacc[2] * vc[2]) + (double)(cacc[3] * vc[3]);
   }
-  // transposed contribution of this (strip, chunk): complete, stored once; masked outside [j+1, rb)
-#pragma unroll
-  for (int e = 0; e < 4; ++e) cacc[e] *= tmask[e];
-  if (col < n) *reinterpret_cast<f32x4*>(a.colpart + s * ldv + col) = cacc;
-  // partial u^T v of this unit: v_col * cacc (transposed part) ...
-  double utv = (double)(cacc[0] * vc[0]) + (double)(cacc[1] * vc[1]) + (double)(cacc[2] * vc[2]) + (double)(cacc[3] * vc[3]);
   utv = wave_sum(utv);
   // row dots: reduce the 32 per-lane values over the wave, then over the 4 waves
   const float rsum = reduce32_over_wave(racc, lane);
@@ -564,6 +570,50 @@ int sytrd_f32(Ctx* ctx, float* A, int64_t n, int64_t lda, double* d_dev, double*
     }
   }
   SCL_HIP(ctx, hipGetLastError());
+  return SCLENS_OK;
+}
+
+// Roofline probe for bench.py: every trd_colB launch of one tridiagonalisation of order n (j = 0 .. n-2, same grids and
+// arguments as sytrd_f32), back to back on ctx->stream between ONE pair of HIP events, on synthetic finite data. Reports
+// the launches, the elapsed time and the algorithmic bytes (lower triangle of each trailing matrix, 2 n'(n'+1)).
+int symv_probe(Ctx* ctx, int64_t n, int64_t* launches, double* total_ms, double* total_bytes) {
+  if (n < 2) return ctx->fail(SCLENS_ERR_ARG, "symv_probe: n < 2");
+  const int64_t lda = round_up(n, 32), ldv = round_up(n, 64) + 512;
+  const int64_t nstripMax = (n + RS - 1) / RS + 1, nsegMax = (n + SEG - 1) / SEG + 2;
+  SCL_WS(ctx, A, float, "probe.A", n * lda);
+  SCL_WS(ctx, VWt, float, "trd.VWt", 2 * NB * ldv);
+  SCL_WS(ctx, x, float, "trd.x", ldv);
+  SCL_WS(ctx, partB, double, "trd.partB", nstripMax * nsegMax);
+  SCL_WS(ctx, colinfo, float, "trd.colinfo", CI_LD);
+  SCL_WS(ctx, rowpart, float, "trd.rowpart", nsegMax * ldv);
+  SCL_WS(ctx, colpart, float, "trd.colpart", nstripMax * ldv);
+  SCL_HIP(ctx, hipMemsetAsync(A, 0x3c, sizeof(float) * n * lda, ctx->stream));      // 0x3c3c3c3c = 0.0115 (finite)
+  SCL_HIP(ctx, hipMemsetAsync(x, 0x3c, sizeof(float) * ldv, ctx->stream));
+  SCL_HIP(ctx, hipMemsetAsync(colinfo, 0x3c, sizeof(float) * CI_LD, ctx->stream));
+  TrdArgs a{A, n, lda, VWt, ldv, x, nullptr, 0, partB, colinfo, rowpart, colpart, nullptr, nullptr, nullptr, nullptr};
+  hipEvent_t e0, e1;
+  SCL_HIP(ctx, hipEventCreate(&e0));
+  SCL_HIP(ctx, hipEventCreate(&e1));
+  double bytes = 0.0;
+  SCL_HIP(ctx, hipEventRecord(e0, ctx->stream));
+  for (int64_t j = 0; j + 1 < n; ++j) {
+    const int64_t nt = n - (j + 1);
+    const int nstrip = (int)((nt + RS - 1) / RS);
+    const int64_t c_al = (j + 1) & ~(int64_t)3;
+    const int nsegmax = (int)((n - c_al + SEG - 1) / SEG);
+    hipLaunchKernelGGL(trd_colB, dim3(nstrip, nsegmax), dim3(256), 0, ctx->stream, a, j, (int)(j % NB), nsegmax);
+    bytes += 2.0 * (double)nt * (double)(nt + 1);
+  }
+  SCL_HIP(ctx, hipEventRecord(e1, ctx->stream));
+  SCL_HIP(ctx, hipEventSynchronize(e1));
+  float ms = 0.f;
+  SCL_HIP(ctx, hipEventElapsedTime(&ms, e0, e1));
+  hipEventDestroy(e0);
+  hipEventDestroy(e1);
+  SCL_HIP(ctx, hipGetLastError());
+  *launches = n - 1;
+  *total_ms = (double)ms;
+  *total_bytes = bytes;
   return SCLENS_OK;
 }
 
