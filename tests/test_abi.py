@@ -47,3 +47,17 @@ def test_product_path_never_imports_the_oracle():
             if f.endswith((".py", ".hip", ".cpp", ".h")):
                 txt = open(os.path.join(dirpath, f)).read()
                 assert "import oracle" not in txt and "from oracle" not in txt, f
+
+
+def test_julia_shim_binds_only_declared_symbols():
+    """julia/scLENS_hip.jl cannot be executed here (no julia): at least every symbol it ccall's must be declared in the
+    header and exported by the library, with the library path it expects."""
+    src = open(os.path.join(ROOT, "julia", "scLENS_hip.jl")).read()
+    used = sorted(set(re.findall(r"\(:(sclens_[a-z0-9_]+),\s*LIB\)", src)))
+    assert len(used) >= 10
+    declared = set(_declared())
+    lib = _lib.load()
+    for n in used:
+        assert n in declared, f"{n} used by the Julia shim but not declared in include/sclens_hip.h"
+        assert hasattr(lib, n)
+    assert "libsclens_hip.so" in src
