@@ -76,6 +76,13 @@ int sclens_hip_corr_mat_f32(sclens_hip_ctx* ctx, const float* X, int64_t n, int6
 int sclens_hip_get_eigvec_f32(sclens_hip_ctx* ctx, const float* X, int64_t N, int64_t M, int64_t keep_top,
                               float* nL, float* nV, int64_t* r);
 
+/* get_denoised_df(inp_obj; device_)  (scLENS.jl:889-931): pca_n1 is N x n_sig, gene_basis_sig =
+ * gene_basis[sig_id,:] as n_sig rows of M genes (row-major, what sclens_hip_session_gene_basis writes), the five vectors
+ * are rec_vals. out is N x M (cells x genes), the denoised count means (the DataFrame body of :927). */
+int sclens_hip_get_denoised_f32(sclens_hip_ctx* ctx, const float* pca_n1, int64_t N, int64_t n_sig, const float* gene_basis_sig,
+                                int64_t M, const double* tgc, const double* mat2_mean, const double* mat2_std,
+                                const double* norm_tgc, const double* cent, float* out);
+
 /* ---------------------------------------------------------------- host statistics (no GPU) ----- */
 /* _mp_calculation(L, Lr)  (scLENS.jl:424-459). L_mp_mask[n] gets 1 where b_minus < L < b_plus. */
 int sclens_mp_calculation(const double* L, int64_t n, const double* Lr, int64_t nr, double* b_plus, double* b_minus,

@@ -50,6 +50,18 @@ function corr_mat(ctx, X::Matrix{Float32}, Y::Matrix{Float32})               # s
     out
 end
 
+function get_denoised_df(ctx, inp_obj)                                        # scLENS.jl:889-931 (body of the DataFrame)
+    g = permutedims(Matrix{Float32}(inp_obj[:gene_basis][inp_obj[:sig_id], :]))   # M x s column-major = s rows of M genes
+    X0 = Matrix{Float32}(inp_obj[:pca_n1][!, 2:end]); N, s = size(X0); M = size(g, 1)
+    rv = inp_obj[:rec_vals]; out = Matrix{Float32}(undef, N, M)
+    v(k) = Vector{Float64}(vec(rv[k]))
+    tgc, m2m, m2s, ntg, cen = v("TGC"), v("mat2_mean"), v("mat2_std"), v("norm_tgc"), v("cent_")
+    GC.@preserve g X0 out tgc m2m m2s ntg cen check(ctx, ccall((:sclens_hip_get_denoised_f32, LIB), Cint,
+        (Ptr{Cvoid}, Ptr{Float32}, Int64, Int64, Ptr{Float32}, Int64, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float32}),
+        ctx, X0, N, s, g, M, tgc, m2m, m2s, ntg, cen, out))
+    out
+end
+
 # ---- (B) device-resident sclens() --------------------------------------------------------------------------------
 csc0(X::SparseMatrixCSC) = (Int64.(X.colptr) .- 1, Int32.(X.rowval) .- Int32(1), Float32.(X.nzval))
 

@@ -519,6 +519,23 @@ def sclens(
     return res
 
 
+def get_denoised(res: Dict[str, object]) -> np.ndarray:
+    """get_denoised_df (scLENS.jl:889-931), CPU branch: returns the N x M matrix `rcov_mean` (:926)."""
+    g_mat = np.asarray(res["gene_basis"])[np.asarray(res["sig_id"]), :]
+    Xout0 = np.asarray(res["pca_n1"], dtype=np.float32).astype(np.float64)  # Matrix{Float32}(pca_n1) (:891)
+    M = np.asarray(res["gene_basis"]).shape[1]
+    d_mean = (Xout0 @ g_mat) * math.sqrt(M)
+    rv = res["rec_vals"]
+    norm_tgc = np.ravel(rv["norm_tgc"])
+    r1 = d_mean + np.ravel(rv["cent_"])[None, :]
+    r2 = r1 * (norm_tgc / norm_tgc.mean())[:, None]
+    r3 = r2 * np.ravel(rv["mat2_std"])[None, :] + np.ravel(rv["mat2_mean"])[None, :]
+    r4 = np.exp(r3) - 1.0
+    r4[r4 < 0] = 0.0
+    r4 /= r4.sum(axis=1, keepdims=True)
+    return r4 * np.ravel(rv["TGC"]).mean()
+
+
 # --------------------------------------------------------------------------------------
 # QC used only to build fixtures from the bundled datasets (scLENS.jl:160-236, defaults)
 # --------------------------------------------------------------------------------------

@@ -45,6 +45,7 @@ SIGNATURES = {
     "sclens_hip_get_eigen_f32": (C.c_int, [vp, c_f32p, i64, c_f32p, c_f32p]),
     "sclens_hip_corr_mat_f32": (C.c_int, [vp, c_f32p, i64, i64, c_f32p, i64, c_f32p]),
     "sclens_hip_get_eigvec_f32": (C.c_int, [vp, c_f32p, i64, i64, i64, c_f32p, c_f32p, c_i64p]),
+    "sclens_hip_get_denoised_f32": (C.c_int, [vp, c_f32p, i64, i64, c_f32p, i64, c_f64p, c_f64p, c_f64p, c_f64p, c_f64p, c_f32p]),
     "sclens_mp_calculation": (C.c_int, [c_f64p, i64, c_f64p, i64, c_f64p, c_f64p, c_u8p]),
     "sclens_tw": (C.c_int, [i64, c_f64p, i64, c_f64p, c_f64p, c_f64p, c_f64p]),
     "sclens_mp_check": (C.c_int, [c_f64p, i64, C.c_double, c_f64p, C.POINTER(C.c_int)]),

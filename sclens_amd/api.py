@@ -97,6 +97,29 @@ def get_eigvec(X, device="gpu", keep_top: int = 0, ctx: Optional[Context] = None
     return nL[:rr], nV[:, : min(rr, ncol)]
 
 
+def get_denoised_df(inp_obj: Dict[str, object], device_="gpu", ctx: Optional[Context] = None) -> np.ndarray:
+    """scLENS.jl:889-931: denoised count means from the robust signals of an sclens() result (N x M array; the
+    reference wraps it in a DataFrame with `gene_id` columns and a `cell` column)."""
+    if device_ != "gpu":
+        raise NotImplementedError("sclens_amd implements the device path only")
+    ctx = ctx or default_context()
+    sig = np.asarray(inp_obj["sig_id"], dtype=np.int64)
+    if sig.size == 0:
+        raise ValueError("no robust signal to reconstruct from")
+    g_mat = np.ascontiguousarray(np.asarray(inp_obj["gene_basis"], dtype=np.float32)[sig, :])
+    Xout0 = np.asfortranarray(np.asarray(inp_obj["pca_n1"], dtype=np.float32))
+    N, s_ = Xout0.shape
+    M = g_mat.shape[1]
+    rv = inp_obj["rec_vals"]
+    vec = {k: np.ascontiguousarray(np.ravel(rv[k]), dtype=np.float64) for k in ("TGC", "mat2_mean", "mat2_std", "norm_tgc", "cent_")}
+    out = np.empty((N, M), dtype=np.float32, order="F")
+    ctx.check(ctx.lib.sclens_hip_get_denoised_f32(ctx.h, ptr(Xout0, C.c_float), N, s_, ptr(g_mat, C.c_float), M,
+                                                  ptr(vec["TGC"], C.c_double), ptr(vec["mat2_mean"], C.c_double),
+                                                  ptr(vec["mat2_std"], C.c_double), ptr(vec["norm_tgc"], C.c_double),
+                                                  ptr(vec["cent_"], C.c_double), ptr(out, C.c_float)))
+    return out
+
+
 # ----------------------------------------------------------------------------- host statistics
 def _mp_calculation(L, Lr):
     """scLENS.jl:424-459 -> (L_mp, b_plus, b_minus)."""

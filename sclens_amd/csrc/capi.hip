@@ -31,6 +31,8 @@ int get_eigen_host(Ctx*, const float*, int64_t, float*, float*);
 int corr_mat_host(Ctx*, const float*, int64_t, int64_t, const float*, int64_t, float*);
 int get_eigvec_host(Ctx*, const float*, int64_t, int64_t, int64_t, float*, float*, int64_t*);
 Ctx* session_ctx(Session* s);
+int denoise_host(Ctx*, const float*, int64_t, int64_t, const float*, int64_t, const double*, const double*, const double*,
+                 const double*, const double*, float*);
 }  // namespace scl
 
 using scl::Ctx;
@@ -112,6 +114,13 @@ int sclens_hip_get_eigvec_f32(sclens_hip_ctx* h, const float* X, int64_t N, int6
                               float* nV, int64_t* r) {
   CTX_GUARD(h);
   return scl::get_eigvec_host(&h->c, X, N, M, keep_top, nL, nV, r);
+}
+
+int sclens_hip_get_denoised_f32(sclens_hip_ctx* h, const float* pca_n1, int64_t N, int64_t n_sig, const float* gene_basis_sig,
+                                int64_t M, const double* tgc, const double* mat2_mean, const double* mat2_std,
+                                const double* norm_tgc, const double* cent, float* out) {
+  CTX_GUARD(h);
+  return scl::denoise_host(&h->c, pca_n1, N, n_sig, gene_basis_sig, M, tgc, mat2_mean, mat2_std, norm_tgc, cent, out);
 }
 
 int sclens_hip_session_create(sclens_hip_ctx* h, int64_t N, int64_t M, const int64_t* colptr, const int32_t* rowval,

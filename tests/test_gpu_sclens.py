@@ -182,3 +182,18 @@ def test_two_streams_give_identical_results(ctx):
     assert np.array_equal(a["sig_id"], b["sig_id"])
     for t in range(5):
         assert np.array_equal(a["nL_set"][t], b["nL_set"][t])
+
+
+def test_get_denoised_df(run_pair, ctx):
+    """the denoised reconstruction (scLENS.jl:889-931) on the device vs the oracle, both from the oracle's
+    sclens() result (so the comparison isolates this function)."""
+    X, ref, res = run_pair
+    want = O.get_denoised(ref)
+    got = api.get_denoised_df({"sig_id": ref["sig_id"], "gene_basis": ref["gene_basis"], "pca_n1": ref["pca_n1"],
+                               "rec_vals": ref["rec_vals"]}, ctx=ctx)
+    assert got.shape == want.shape
+    assert np.abs(got - want).max() < 2e-4 * want.max()
+    assert np.allclose(got.sum(axis=1), np.ravel(ref["rec_vals"]["TGC"]).mean(), rtol=1e-4)
+    # and end to end from the device result (eigenvector signs cancel in pca_n1 * gene_basis)
+    got2 = api.get_denoised_df(res, ctx=ctx)
+    assert np.abs(got2 - want).max() < 2e-2 * want.max()
