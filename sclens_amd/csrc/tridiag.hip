@@ -29,7 +29,7 @@ constexpr int NG_A = 8;        // column groups in trd_colA
 constexpr int RS = 32;         // strip height of trd_colB
 constexpr int CH = 1;          // 256-column chunks per wave in trd_colB
 constexpr int SEG = 1024 * CH; // segment width of trd_colB (4 waves x CH x 256 columns)
-constexpr int PR = 16;         // rows loaded per pass in trd_colB (registers vs. loads in flight)
+constexpr int PR = 8;          // rows loaded per pass in trd_colB (registers vs. loads in flight)
 constexpr int PA_LD = 2 * NB + 1;
 // colinfo: [0]=tau [1]=scale [2]=(V^T v).(W^T v), [4..4+NB) = V^T v, [4+NB..4+2NB) = W^T v
 constexpr int CI_LD = 2 * NB + 4;
@@ -379,7 +379,7 @@ __device__ __forceinline__ int reduce32_index(int lane) {
   return ((lane >> 5) & 1) * 16 + ((lane >> 4) & 1) * 8 + ((lane >> 3) & 1) * 4 + ((lane >> 2) & 1) * 2 + ((lane >> 1) & 1);
 }
 
-__global__ __launch_bounds__(256) void trd_colB(TrdArgs a, int64_t j, int c, int nsegmax) {
+__global__ __launch_bounds__(256, 3) void trd_colB(TrdArgs a, int64_t j, int c, int nsegmax) {
   __shared__ float rowred[4][RS];
   __shared__ double utv_s[4];
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -440,6 +440,7 @@ __global__ __launch_bounds__(256) void trd_colB(TrdArgs a, int64_t j, int c, int
         cacc[2] += av[q][2] * vr[q];
         cacc[3] += av[q][3] * vr[q];
       }
+      // __builtin_amdgcn_sched_barrier(0);  // keep the next pass's loads below this pass's FMAs: registers are reused
     }
     // transposed contribution of this (strip, chunk): complete, stored once; masked outside [j+1, rb)
 #pragma unroll
