@@ -12,6 +12,10 @@
 //  * ormtr_f32 : Z <- Q Z with Q = H_0 H_1 ... from sytrd_f32, as block reflectors (I - V T V^T)
 //                applied with three fp32 MFMA GEMMs per panel; T comes from the V^T v products that
 //                the tridiagonalisation already formed (no extra pass over V).
+#include <algorithm>
+#include <cmath>
+#include <vector>
+
 #include "common.h"
 
 namespace scl {
@@ -453,6 +457,35 @@ __global__ void cvt_f64_to_f32(const double* __restrict__ in, float* __restrict_
   if (i < n) out[i] = (float)in[i];
 }
 
+// Modified Gram-Schmidt over `cnt` consecutive rows of Zt (one block). Inverse iteration runs every eigenvector
+// independently; for eigenvalues that coincide to fp32 resolution it returns independent but not orthogonal vectors of the
+// shared eigenspace, so those (rare, small) clusters are orthonormalised afterwards, like LAPACK's dstein does inside.
+__global__ __launch_bounds__(256) void k_mgs_rows(float* __restrict__ Zt, int64_t ldz, int64_t n, int64_t r0, int cnt) {
+  __shared__ double sw[4];
+  __shared__ double bc;
+  for (int i = 0; i < cnt; ++i) {
+    float* ri = Zt + (r0 + i) * ldz;
+    for (int j = 0; j <= i; ++j) {  // j < i: project out row j; j == i: normalise
+      const float* rj = Zt + (r0 + j) * ldz;
+      double s = 0.0;
+      for (int64_t c = threadIdx.x; c < n; c += 256) s += (double)ri[c] * (double)rj[c];
+      for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+      if ((threadIdx.x & 63) == 0) sw[threadIdx.x >> 6] = s;
+      __syncthreads();
+      if (threadIdx.x == 0) bc = (sw[0] + sw[1]) + (sw[2] + sw[3]);
+      __syncthreads();
+      const double dot = bc;
+      if (j < i) {
+        for (int64_t c = threadIdx.x; c < n; c += 256) ri[c] = (float)((double)ri[c] - dot * (double)rj[c]);
+      } else {
+        const double inv = 1.0 / sqrt(dot);
+        for (int64_t c = threadIdx.x; c < n; c += 256) ri[c] = (float)((double)ri[c] * inv);
+      }
+      __syncthreads();
+    }
+  }
+}
+
 int eig_values(Ctx* ctx, float* A, int64_t n, int64_t lda, double* w64_dev) {
   if (n <= 0) return SCLENS_OK;
   SCL_WS(ctx, d, double, "eig.d", n);
@@ -472,6 +505,27 @@ int eig_vectors(Ctx* ctx, const float* A, int64_t n, int64_t lda, const double* 
   SCL_WS(ctx, tau, float, "eig.tau", n);
   SCL_TRY(stein_f64(ctx, d, e, n, w64_dev, vec_lo, vec_hi, Zt, ldz));
   SCL_TRY(ormtr_f32(ctx, A, n, lda, tau, Zt, vec_hi - vec_lo, ldz));
+  // clusters of eigenvalues that coincide to fp32 resolution: orthonormalise their vectors
+  const int64_t m = vec_hi - vec_lo;
+  if (m > 1) {
+    std::vector<double> w(m);
+    SCL_HIP(ctx, hipMemcpyAsync(w.data(), w64_dev + vec_lo, sizeof(double) * m, hipMemcpyDeviceToHost, ctx->stream));
+    SCL_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    double wmax = 0.0;
+    for (double v : w) wmax = std::max(wmax, std::fabs(v));
+    const double tol = 2.4e-7 * wmax;
+    int64_t i = 0;
+    while (i + 1 < m) {
+      int64_t jn = i;
+      while (jn + 1 < m && w[jn + 1] - w[jn] <= tol) ++jn;
+      if (jn > i) {
+        hipLaunchKernelGGL(k_mgs_rows, dim3(1), dim3(256), 0, ctx->stream, Zt, ldz, n, i, (int)(jn - i + 1));
+        ctx->t_calls["degenerate_clusters"] += 1;
+      }
+      i = jn + 1;
+    }
+    SCL_HIP(ctx, hipGetLastError());
+  }
   return SCLENS_OK;
 }
 

@@ -113,3 +113,27 @@ def test_eigh_vectors(ctx, n, lo, hi):
     assert orth < 2e-5 * np.sqrt(n / 64 + 1), orth
     for x in (dA, dw, dZ):
         x.free()
+
+
+def test_eigh_repeated_eigenvalues_are_orthonormalised(ctx):
+    """Exactly repeated eigenvalues (two identical diagonal blocks): inverse iteration alone would return non-orthogonal
+    vectors inside each 2-dimensional eigenspace; the cluster Gram-Schmidt pass must restore orthonormality."""
+    h = 150
+    B = _sym(h, 5)
+    A = np.zeros((2 * h, 2 * h), np.float32)
+    A[:h, :h] = B
+    A[h:, h:] = B
+    n = 2 * h
+    lda = rup(n, 32)
+    dA = DevArray(ctx, pad_rows(A, lda))
+    dw = DevArray(ctx, nbytes=8 * n)
+    dZ = DevArray(ctx, nbytes=4 * n * lda)
+    ctx.check(ctx.lib.sclens_hip_dev_eigh_f32(ctx.h, dA.p, n, lda, dw.p, 0, n, dZ.p, lda))
+    ctx.sync()
+    w = dw.get((n,), np.float64)
+    Z = dZ.get((n, lda), np.float32)[:, :n].astype(np.float64)
+    assert np.abs(w[0::2] - w[1::2]).max() < 1e-5 * w.max()  # every eigenvalue twice
+    assert np.abs(Z @ Z.T - np.eye(n)).max() < 5e-5
+    assert np.abs(Z @ A.astype(np.float64) - w[:, None] * Z).max() < 5e-5 * w.max()
+    for x in (dA, dw, dZ):
+        x.free()
