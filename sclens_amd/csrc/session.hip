@@ -4,6 +4,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstring>
+#include <thread>
 
 #include "common.h"
 #include "pattern.h"
@@ -127,22 +128,38 @@ int pattern_build(Ctx* ctx, int64_t N, int64_t M, const int64_t* colptr, const i
   std::vector<int32_t> urow(nU);
   std::vector<float> uval(nU, 0.f);
   std::vector<int64_t> cpos(ncand);
-  std::vector<int64_t> cur(M);
-  for (int64_t j = 0; j < M; ++j) {
-    int64_t q = ucol[j];
-    for (int64_t s = colptr[j]; s < colptr[j + 1]; ++s, ++q) {
-      if (rowval[s] < 0 || rowval[s] >= N) return ctx->fail(SCLENS_ERR_ARG, "row index out of range");
-      urow[q] = rowval[s];
-      uval[q] = nzval[s];
+  // candidate cursors per column (sequential: candidate order inside a column is the order of the list)
+  {
+    std::vector<int64_t> cur(M);
+    for (int64_t j = 0; j < M; ++j) cur[j] = ucol[j] + (colptr[j + 1] - colptr[j]);
+    for (int64_t t = 0; t < ncand; ++t) cpos[t] = cur[z2[t]]++;
+  }
+  const int T = (int)std::max<int64_t>(1, std::min<int64_t>(8, nU / 2000000 + 1));  // host threads
+  std::vector<int> bad(T, 0);
+  auto run = [&](auto&& fn) {
+    std::vector<std::thread> th;
+    for (int t = 1; t < T; ++t) th.emplace_back(fn, t);
+    fn(0);
+    for (auto& x : th) x.join();
+  };
+  // CSC fill: stored counts (by column range) and candidates (by list range)
+  run([&](int t) {
+    const int64_t j0 = M * t / T, j1 = M * (t + 1) / T;
+    for (int64_t j = j0; j < j1; ++j) {
+      int64_t q = ucol[j];
+      for (int64_t s = colptr[j]; s < colptr[j + 1]; ++s, ++q) {
+        if (rowval[s] < 0 || rowval[s] >= N) { bad[t] = 1; return; }
+        urow[q] = rowval[s];
+        uval[q] = nzval[s];
+      }
     }
-    cur[j] = q;
-  }
-  for (int64_t t = 0; t < ncand; ++t) {
-    const int64_t q = cur[z2[t]]++;
-    urow[q] = (int32_t)z1[t];
-    cpos[t] = q;
-  }
-  // CSR view
+    const int64_t t0 = ncand * t / T, t1 = ncand * (t + 1) / T;
+    for (int64_t c = t0; c < t1; ++c) urow[cpos[c]] = (int32_t)z1[c];
+  });
+  for (int b : bad)
+    if (b) return ctx->fail(SCLENS_ERR_ARG, "row index out of range");
+  // CSR view: thread t owns the row range [r0, r1): it scans every slot but only places its own rows, so the
+  // order inside a row (ascending column, slot order inside a column) does not depend on the thread count
   std::vector<int64_t> rptr(N + 1, 0);
   for (int64_t q = 0; q < nU; ++q) rptr[urow[q] + 1] += 1;
   for (int64_t i = 0; i < N; ++i) rptr[i + 1] += rptr[i];
@@ -150,12 +167,17 @@ int pattern_build(Ctx* ctx, int64_t N, int64_t M, const int64_t* colptr, const i
   std::vector<int32_t> ccol(nU);
   {
     std::vector<int64_t> rc(rptr.begin(), rptr.end() - 1);
-    for (int64_t j = 0; j < M; ++j)
-      for (int64_t q = ucol[j]; q < ucol[j + 1]; ++q) {
-        const int64_t s = rc[urow[q]]++;
-        c2c[s] = q;
-        ccol[s] = (int32_t)j;
-      }
+    run([&](int t) {
+      const int32_t r0 = (int32_t)(N * t / T), r1 = (int32_t)(N * (t + 1) / T);
+      for (int64_t j = 0; j < M; ++j)
+        for (int64_t q = ucol[j]; q < ucol[j + 1]; ++q) {
+          const int32_t r = urow[q];
+          if (r < r0 || r >= r1) continue;
+          const int64_t s = rc[r]++;
+          c2c[s] = q;
+          ccol[s] = (int32_t)j;
+        }
+    });
   }
   out->dev.N = N; out->dev.M = M; out->dev.nU = nU; out->dev.ncand = ncand;
   SCL_TRY(upload(ctx, out, ucol, &out->dev.colptr));
