@@ -140,7 +140,9 @@ def main():
     t_synth = time.perf_counter() - t0
 
     def one_step(step):
-        draws = api.make_draws_native(X, seed=1000 + step, async_null=True)  # R1-R3 inside the timed region; R4/R5 on the device inside sclens()
+        t_d = time.perf_counter()
+        draws = api.make_draws_native(X, seed=1000 + step, async_null=True)
+        one_step.draws_s = time.perf_counter() - t_d  # R1-R3 inside the timed region; R4/R5 on the device inside sclens()
         return api.sclens(X, draws=draws, ctx=ctx, n_perturb=args.n_perturb, shard=shard, streams=args.streams,
                           verbose=args.verbose and rank == 0)
 
@@ -185,7 +187,8 @@ def main():
             "sclens_wall_s": round(dt / max(1, args.steps), 3),
             "observed": {"signals": int(len(res.get("signal_ev", []))), "robust_signals": int(len(res.get("sig_id", []))),
                          "search_iters": int(res["n_search"]), "p_": res["p_"], "synth_s": round(t_synth, 1),
-                         "ensemble_partial_eig": {"used": int(res["partial_eig"][0]), "fallback_to_full": int(res["partial_eig"][1])}},
+                         "ensemble_partial_eig": {"used": int(res["partial_eig"][0]), "fallback_to_full": int(res["partial_eig"][1])},
+                         "phase_s_rank0_last_step": dict({"draws_host": round(one_step.draws_s, 4)}, **res.get("phase_s", {}))},
         }
         if not args.no_roofline:
             out["roofline"] = roofline_probe(ctx, min(N, M))

@@ -543,8 +543,18 @@ def sclens(inp_df, device_="gpu", th=60, p_step=0.001, n_perturb=20, centering="
     if draws is None:
         draws = make_draws_native(X_, seed if seed is not None else int(time.time_ns() % (2**31)))
     z1, z2 = draws.z_idx1, draws.z_idx2
+    phase = {}
+    t_ph = time.perf_counter()
+
+    def lap(name):
+        nonlocal t_ph
+        now = time.perf_counter()
+        phase[name] = phase.get(name, 0.0) + (now - t_ph)
+        t_ph = now
+
     ses = Session(ctx, X_, z1, z2)
     ses.set_int("chefsi", 1 if partial_eig else 0)
+    lap("session_create")
     try:
         # local workers: `streams` sessions on this GPU (own stream + scratch each, shared read-only data), one host
         # thread per session (ctypes releases the GIL), so independent decompositions overlap on the device
@@ -603,6 +613,7 @@ def sclens(inp_df, device_="gpu", th=60, p_step=0.001, n_perturb=20, centering="
                 w.adopt(ses, 2)
         mpC = mp_check(L_mp)  # :706
         p_th = draws.p_th  # :709-712
+        lap("spectra_signal_vectors_vr2")
         # ---- sparsity search (:715-762); world x W consecutive p_ values are evaluated per round
         n_2 = int(round(r_vr2 / 2))  # :722
         p_list = search_schedule(p_step)
@@ -637,6 +648,7 @@ def sclens(inp_df, device_="gpu", th=60, p_step=0.001, n_perturb=20, centering="
             trace = [(p_list[q], tank[:, q].copy()) for q in range(tank.shape[1])]
             if verbose:
                 print(f"Selected perturb sparisty: {p_}")
+            lap("sparsity_search")
 
             # ---- perturbation ensemble (:767-778): member t runs on rank t % world, local worker round-robin
             min_s = k
@@ -670,6 +682,7 @@ def sclens(inp_df, device_="gpu", th=60, p_step=0.001, n_perturb=20, centering="
                 if shard.world > 1:
                     _exchange_ensemble(ses, shard, n_perturb, min_pc, nL_set, ncols)
             pe_counts = (sum(w.get_int("chefsi_used") for w in workers), sum(w.get_int("chefsi_fallback") for w in workers))
+            lap("perturbation_ensemble")
         finally:
             if pool is not None:
                 pool.shutdown(wait=True)
@@ -701,6 +714,8 @@ def sclens(inp_df, device_="gpu", th=60, p_step=0.001, n_perturb=20, centering="
                     "ks_static": mpC["ks_static"], "rec_vals": rec_vals, "nL_set": nL_set, "min_pc": min_pc})
         if keep_intermediates:
             res["nV_set"] = [ses.get_perturbed(t, ncols[t]) for t in range(n_perturb)]
+        lap("robustness_gene_basis")
+        res["phase_s"] = {k_: round(v_, 4) for k_, v_ in phase.items()}
         res["wall_s"] = time.perf_counter() - t_all
         return res
     finally:
