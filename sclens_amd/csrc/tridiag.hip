@@ -9,8 +9,8 @@
 //              w = tau (u - V (W^T v) - W (V^T v)) - 1/2 tau (w^T v) v is written as W[:, c-1];
 //              (2) x = column j of A updated by the panel's reflectors; (3) per-block partial sums of
 //              ||x||^2, V^T x, W^T x. Thread = (row, column group); all global loads are issued up front.
-//   trd_colR : one block: fixed-order reduction of those partials, Householder scalars (fp64),
-//              V^T v, W^T v and their dot product.
+//   trd_colR : one wave: ||x||^2 from those partials, Householder scalars in fp64. (V^T v, W^T v and their dot
+//              product are reduced redundantly in the prologue of the NEXT trd_colA, off the critical path of trd_colB.)
 //   trd_colB : the HBM-bound symmetric matrix-vector product u = A_trail v, v = x*scale formed on the fly --
 //              the dominant kernel of the whole sclens() path. Work unit = (strip of 32 rows) x (segment of
 //              1024 columns) of the lower trapezoid; each of the 4 waves owns one 256-column chunk for all 32
@@ -42,7 +42,7 @@ struct TrdArgs {
   float* VWt;       // [2*NB][ldv]: rows 0..NB-1 = V columns, NB..2NB-1 = W columns (each contiguous over matrix rows)
   int64_t ldv;
   float* x;         // [ldv] current column
-  double* partA;    // [PA_LD][na_ld]  (partial sums of trd_colA, one column per block)
+  double* partA;    // [2][PA_LD][na_ld]  partial sums of trd_colA (one column per block), ping-pong by column parity
   int64_t na_ld;
   double* partB;    // [nstrips * nsegmax] partial u^T v per trd_colB block (0 for idle blocks)
   float* colinfo;   // [CI_LD]
@@ -105,15 +105,62 @@ __device__ __forceinline__ float gather_u(const TrdArgs& a, int64_t jj, int64_t 
 }
 
 // ------------------------------------------------------------------------------------------------
+// 32 values per lane -> sums over the 64 lanes; lane l ends with the total of value index vidx(l) in v[0].
+__device__ __forceinline__ float reduce32_over_wave(float (&v)[32], int lane) {
+#pragma unroll
+  for (int k = 0; k < 16; ++k) {  // offset 32: lanes < 32 keep 0..15, lanes >= 32 keep 16..31
+    const bool hi = lane & 32;
+    const float send = hi ? v[k] : v[k + 16];
+    const float keep = hi ? v[k + 16] : v[k];
+    v[k] = keep + __shfl_xor(send, 32);
+  }
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    const bool hi = lane & 16;
+    const float send = hi ? v[k] : v[k + 8];
+    const float keep = hi ? v[k + 8] : v[k];
+    v[k] = keep + __shfl_xor(send, 16);
+  }
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const bool hi = lane & 8;
+    const float send = hi ? v[k] : v[k + 4];
+    const float keep = hi ? v[k + 4] : v[k];
+    v[k] = keep + __shfl_xor(send, 8);
+  }
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    const bool hi = lane & 4;
+    const float send = hi ? v[k] : v[k + 2];
+    const float keep = hi ? v[k + 2] : v[k];
+    v[k] = keep + __shfl_xor(send, 4);
+  }
+  {
+    const bool hi = lane & 2;
+    const float send = hi ? v[0] : v[1];
+    const float keep = hi ? v[1] : v[0];
+    v[0] = keep + __shfl_xor(send, 2);
+  }
+  v[0] += __shfl_xor(v[0], 1);
+  return v[0];
+}
+// value index held by `lane` after reduce32_over_wave
+__device__ __forceinline__ int reduce32_index(int lane) {
+  return ((lane >> 5) & 1) * 16 + ((lane >> 4) & 1) * 8 + ((lane >> 3) & 1) * 4 + ((lane >> 2) & 1) * 2 + ((lane >> 1) & 1);
+}
+
+// ------------------------------------------------------------------------------------------------
 // mode 0: full column step for column j (panel-local index c).  mode 1: only finish W[:, c-1] for rows >= j
 // (panel end: c = NB, j = pe).
-__global__ __launch_bounds__(1024) void trd_colA(TrdArgs a, int64_t j, int c, int nbB_prev, int mode) {
+__global__ __launch_bounds__(1024) void trd_colA(TrdArgs a, int64_t j, int c, int nbB_prev, int na_prev, int mode) {
   __shared__ float Vj[NB], Wj[NB], tVp[NB], tWp[NB];
   __shared__ float a_s[RPB_A];
   __shared__ float part_s[NG_A][RPB_A], part2_s[NG_A][RPB_A], upart_s[NG_A][RPB_A];
   __shared__ double red[16];
   __shared__ float redf[16];
   __shared__ float alpha2_s, wj_s;
+  __shared__ double psums_s[2 * NB];
+  __shared__ float prod_s[NB];
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int r = tid & (RPB_A - 1), g = tid >> 7;  // row within the block, column group (cc = g mod NG_A)
   const int64_t n = a.n, ldv = a.ldv;
@@ -126,17 +173,30 @@ __global__ __launch_bounds__(1024) void trd_colA(TrdArgs a, int64_t j, int c, in
   double pb = 0.0;
   if (c > 0)
     for (int b = tid; b < nbB_prev; b += 1024) pb += a.partB[b];
-  float vj = 0.f, wj = 0.f, tvp = 0.f, twp = 0.f;
+  float vj = 0.f, wj = 0.f;
   if (tid < c) {
     vj = a.VWt[(int64_t)tid * ldv + j];
-    if (tid < cp) {
-      wj = a.VWt[(int64_t)(NB + tid) * ldv + j];
-      tvp = a.colinfo[4 + tid];
-      twp = a.colinfo[4 + NB + tid];
-    }
+    if (tid < cp) wj = a.VWt[(int64_t)(NB + tid) * ldv + j];
   }
   const float tau_p = (c > 0) ? a.colinfo[0] : 0.f;
-  const float dotvw_p = (c > 0) ? a.colinfo[2] : 0.f;
+  const float scale_p = (c > 0) ? a.colinfo[1] : 0.f;
+  // partial sums V^T x, W^T x of the previous column (its trd_colA wrote them): 4 lanes per sum, fixed-order tree
+  double psum = 0.0;
+  if (c > 0) {
+    const int sidx = tid >> 2, q4 = tid & 3;
+    const bool on = sidx < 2 * cp;
+    const int row = (sidx < cp) ? sidx : NB + (sidx - cp);
+    const double* pr = a.partA + (int64_t)((j - 1) & 1) * PA_LD * a.na_ld + (int64_t)(on ? row : 0) * a.na_ld;
+    for (int b0 = q4; b0 < na_prev; b0 += 64) {
+      double t[16];
+#pragma unroll
+      for (int u = 0; u < 16; ++u) t[u] = (on && b0 + 4 * u < na_prev) ? pr[b0 + 4 * u] : 0.0;
+#pragma unroll
+      for (int u = 0; u < 16; ++u) psum += t[u];
+    }
+    psum += __shfl_xor(psum, 1);
+    psum += __shfl_xor(psum, 2);
+  }
   float vv[NB / NG_A], ww[NB / NG_A];
 #pragma unroll
   for (int q = 0; q < NB / NG_A; ++q) {
@@ -156,7 +216,20 @@ __global__ __launch_bounds__(1024) void trd_colA(TrdArgs a, int64_t j, int c, in
     pb = wave_sum(pb);
     uj = wave_sumf(uj);
     if (lane == 0) { red[wid] = pb; redf[wid] = uj; }
-    if (tid < c) { Vj[tid] = vj; Wj[tid] = wj; tVp[tid] = tvp; tWp[tid] = twp; }
+    if (tid < c) { Vj[tid] = vj; Wj[tid] = wj; }
+    {  // publish the reduced sums: sum index sidx -> psums_s
+      const int sidx = tid >> 2;
+      if ((tid & 3) == 0 && sidx < 2 * cp) psums_s[sidx] = psum;
+    }
+    __syncthreads();
+    if (tid < cp) {  // V^T v and W^T v of the previous column: scale * (V^T x) + V[j][:]  (v = x*scale, v_{j} = 1)
+      const float gv = (float)(psums_s[tid] * (double)scale_p) + Vj[tid];
+      const float gw = (float)(psums_s[cp + tid] * (double)scale_p) + Wj[tid];
+      tVp[tid] = gv;
+      tWp[tid] = gw;
+      prod_s[tid] = gv * gw;
+      if (blockIdx.x == 0) a.Gst[(j - 1) * NB + tid] = gv;
+    }
     __syncthreads();
     if (wid == 0) {  // wave 0: p2 of row j = sum_{cc<cp} V[j][cc] tWp[cc] + W[j][cc] tVp[cc]
       float p2 = 0.f;
@@ -166,6 +239,8 @@ __global__ __launch_bounds__(1024) void trd_colA(TrdArgs a, int64_t j, int c, in
         double utv = 0.0;
         float ujs = 0.f;
         for (int w = 0; w < 16; ++w) { utv += red[w]; ujs += redf[w]; }
+        float dotvw_p = 0.f;
+        for (int q = 0; q < cp; ++q) dotvw_p += prod_s[q];  // fixed order
         const double wtv = (double)tau_p * (utv - 2.0 * (double)dotvw_p);
         const float alpha2 = (float)(-0.5 * (double)tau_p * wtv);
         alpha2_s = alpha2;
@@ -227,156 +302,76 @@ __global__ __launch_bounds__(1024) void trd_colA(TrdArgs a, int64_t j, int c, in
   if (mode != 0) return;
   __syncthreads();
   // ---------------- partial V^T x, W^T x, ||x||^2 over this block's rows (i >= j+2); sums s = wid + 16*q
-  double* pa = a.partA + blockIdx.x;  // partA[row * na_ld + block]
+  double* pa = a.partA + (int64_t)(j & 1) * PA_LD * a.na_ld + blockIdx.x;  // partA[j&1][row * na_ld + block]
   const int64_t na_ld = a.na_ld;
   const int64_t nrow = (i_lo + RPB_A <= n) ? RPB_A : (n - i_lo);
+  // all loads of the wave issued at once, fp32 products over this block's 128 rows, one 32-value halving tree over the
+  // wave (32 shuffles instead of 17 x 6 double shuffles), fp64 only across blocks
   const int nsum = 2 * c + 1;
-#pragma unroll 1
-  for (int q0 = 0; q0 < 18; q0 += 9) {
-    if (wid + 16 * q0 >= nsum) break;
-    float t[9][RPB_A / 64];
+  {
+    float vals[32];
+    float xs[RPB_A / 64];
 #pragma unroll
-    for (int qq = 0; qq < 9; ++qq) {
-      const int s = wid + 16 * (q0 + qq);
-      const int row = (s < c) ? s : NB + (s - c);
-      const bool in = s < 2 * c;
+    for (int q = 0; q < RPB_A / 64; ++q) xs[q] = a_s[lane + 64 * q];
+    float t[17][RPB_A / 64];
+#pragma unroll
+    for (int qq = 0; qq < 17; ++qq) {
+      const int sidx = wid + 16 * qq;
+      const int row = (sidx < c) ? sidx : NB + (sidx - c);
+      const bool in = sidx < 2 * c;
       const float* vp = a.VWt + (int64_t)(in ? row : 0) * ldv + i_lo;
 #pragma unroll
       for (int q = 0; q < RPB_A / 64; ++q) t[qq][q] = (in && lane + 64 * q < nrow) ? vp[lane + 64 * q] : 0.f;
     }
-    float xs[RPB_A / 64];
 #pragma unroll
-    for (int q = 0; q < RPB_A / 64; ++q) xs[q] = a_s[lane + 64 * q];
+    for (int qq = 0; qq < 32; ++qq) vals[qq] = 0.f;
 #pragma unroll
-    for (int qq = 0; qq < 9; ++qq) {
-      const int s = wid + 16 * (q0 + qq);
-      if (s < nsum) {  // wave-uniform
-        double acc = 0.0;
-        if (s == 2 * c) {
+    for (int qq = 0; qq < 17; ++qq) {
+      const int sidx = wid + 16 * qq;
+      float acc = 0.f;
+      if (sidx == 2 * c) {
 #pragma unroll
-          for (int q = 0; q < RPB_A / 64; ++q) acc += (double)xs[q] * (double)xs[q];
-        } else {
+        for (int q = 0; q < RPB_A / 64; ++q) acc += xs[q] * xs[q];
+      } else {
 #pragma unroll
-          for (int q = 0; q < RPB_A / 64; ++q) acc += (double)t[qq][q] * (double)xs[q];
-        }
-        acc = wave_sum(acc);
-        const int row = (s < c) ? s : (s < 2 * c ? NB + (s - c) : 2 * NB);
-        if (lane == 0) pa[(int64_t)row * na_ld] = acc;
+        for (int q = 0; q < RPB_A / 64; ++q) acc += t[qq][q] * xs[q];
       }
+      vals[qq] = acc;
+    }
+    const float tot = reduce32_over_wave(vals, lane);
+    const int qq = reduce32_index(lane);
+    const int sidx = wid + 16 * qq;
+    if ((lane & 1) == 0 && qq < 17 && sidx < nsum) {
+      const int row = (sidx < c) ? sidx : (sidx < 2 * c ? NB + (sidx - c) : 2 * NB);
+      pa[(int64_t)row * na_ld] = (double)tot;
     }
   }
 }
 
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(1024) void trd_colR(TrdArgs a, int64_t j, int c, int na) {
-  __shared__ double sums[2 * NB + 1];
-  __shared__ float sc_scale;
-  __shared__ float prod[NB];
-  const int tid = threadIdx.x;
-  const int64_t ldv = a.ldv;
-  // independent loads first
-  const float vrow = (tid < c) ? a.VWt[(int64_t)tid * ldv + (j + 1)] : 0.f;
-  const float wrow = (tid < c) ? a.VWt[(int64_t)(NB + tid) * ldv + (j + 1)] : 0.f;
-  const float xa = a.x[j + 1], xd = a.x[j];
-  {  // 4 lanes per sum (2c+1 <= 255 sums): lane q adds blocks q, q+4, ... (16 loads in flight), then a fixed 2-step tree
-    const int sidx = tid >> 2, q4 = tid & 3;
-    const bool on = sidx < 2 * c + 1;
-    const int row = (sidx < c) ? sidx : (sidx < 2 * c ? NB + (sidx - c) : 2 * NB);
-    const double* pr = a.partA + (int64_t)(on ? row : 0) * a.na_ld;
-    double acc = 0.0;
-    for (int b0 = q4; b0 < na; b0 += 64) {
-      double t[16];
-#pragma unroll
-      for (int u = 0; u < 16; ++u) t[u] = (on && b0 + 4 * u < na) ? pr[b0 + 4 * u] : 0.0;
-#pragma unroll
-      for (int u = 0; u < 16; ++u) acc += t[u];
-    }
-    acc += __shfl_xor(acc, 1);
-    acc += __shfl_xor(acc, 2);
-    if (on && q4 == 0) sums[row] = acc;
-  }
-  __syncthreads();
-  if (tid == 0) {
-    const double alpha = (double)xa;
-    const double xn2 = sums[2 * NB];
-    double beta, tau, scale;
-    if (xn2 == 0.0) {
-      beta = alpha; tau = 0.0; scale = 0.0;
+// One wave: ||x||^2 from the per-block partials of trd_colA (fixed order), Householder scalars in fp64.
+__global__ __launch_bounds__(64) void trd_colR(TrdArgs a, int64_t j, int na) {
+  const int lane = threadIdx.x;
+  const double* pn = a.partA + (int64_t)(j & 1) * PA_LD * a.na_ld + (int64_t)(2 * NB) * a.na_ld;
+  double sx = 0.0;
+  for (int b = lane; b < na; b += 64) sx += pn[b];
+  sx = wave_sum(sx);
+  if (lane == 0) {
+    const double alpha = (double)a.x[j + 1];
+    double beta, tau, sc;
+    if (sx == 0.0) {
+      beta = alpha; tau = 0.0; sc = 0.0;
     } else {
-      beta = -copysign(sqrt(alpha * alpha + xn2), alpha);
+      beta = -copysign(sqrt(alpha * alpha + sx), alpha);
       tau = (beta - alpha) / beta;
-      scale = 1.0 / (alpha - beta);
+      sc = 1.0 / (alpha - beta);
     }
-    sc_scale = (float)scale;
     a.colinfo[0] = (float)tau;
-    a.colinfo[1] = (float)scale;
-    a.d[j] = (double)xd;
+    a.colinfo[1] = (float)sc;
+    a.d[j] = (double)a.x[j];
     a.e[j] = beta;
     a.tau[j] = (float)tau;
   }
-  __syncthreads();
-  float pr = 0.f;
-  if (tid < c) {
-    const float scale = sc_scale;
-    const float gv = (float)(sums[tid] * (double)scale) + vrow;
-    const float gw = (float)(sums[NB + tid] * (double)scale) + wrow;
-    a.colinfo[4 + tid] = gv;
-    a.colinfo[4 + NB + tid] = gw;
-    a.Gst[j * NB + tid] = gv;
-    pr = gv * gw;
-  }
-  if (tid < NB) prod[tid] = pr;
-  __syncthreads();
-  if (tid == 0) {
-    float s = 0.f;
-    for (int q = 0; q < c; ++q) s += prod[q];  // fixed order
-    a.colinfo[2] = s;
-  }
-}
-
-// ------------------------------------------------------------------------------------------------
-// 32 values per lane -> sums over the 64 lanes; lane l ends with the total of value index vidx(l) in v[0].
-__device__ __forceinline__ float reduce32_over_wave(float (&v)[32], int lane) {
-#pragma unroll
-  for (int k = 0; k < 16; ++k) {  // offset 32: lanes < 32 keep 0..15, lanes >= 32 keep 16..31
-    const bool hi = lane & 32;
-    const float send = hi ? v[k] : v[k + 16];
-    const float keep = hi ? v[k + 16] : v[k];
-    v[k] = keep + __shfl_xor(send, 32);
-  }
-#pragma unroll
-  for (int k = 0; k < 8; ++k) {
-    const bool hi = lane & 16;
-    const float send = hi ? v[k] : v[k + 8];
-    const float keep = hi ? v[k + 8] : v[k];
-    v[k] = keep + __shfl_xor(send, 16);
-  }
-#pragma unroll
-  for (int k = 0; k < 4; ++k) {
-    const bool hi = lane & 8;
-    const float send = hi ? v[k] : v[k + 4];
-    const float keep = hi ? v[k + 4] : v[k];
-    v[k] = keep + __shfl_xor(send, 8);
-  }
-#pragma unroll
-  for (int k = 0; k < 2; ++k) {
-    const bool hi = lane & 4;
-    const float send = hi ? v[k] : v[k + 2];
-    const float keep = hi ? v[k + 2] : v[k];
-    v[k] = keep + __shfl_xor(send, 4);
-  }
-  {
-    const bool hi = lane & 2;
-    const float send = hi ? v[0] : v[1];
-    const float keep = hi ? v[1] : v[0];
-    v[0] = keep + __shfl_xor(send, 2);
-  }
-  v[0] += __shfl_xor(v[0], 1);
-  return v[0];
-}
-// value index held by `lane` after reduce32_over_wave
-__device__ __forceinline__ int reduce32_index(int lane) {
-  return ((lane >> 5) & 1) * 16 + ((lane >> 4) & 1) * 8 + ((lane >> 3) & 1) * 4 + ((lane >> 2) & 1) * 2 + ((lane >> 1) & 1);
 }
 
 __global__ __launch_bounds__(256, 3) void trd_colB(TrdArgs a, int64_t j, int c, int nsegmax) {
@@ -508,7 +503,7 @@ int sytrd_f32(Ctx* ctx, float* A, int64_t n, int64_t lda, double* d_dev, double*
   SCL_WS(ctx, VWt, float, "trd.VWt", 2 * NB * ldv);
   SCL_WS(ctx, x, float, "trd.x", ldv);
   const int64_t naMax = round_up((n + RPB_A - 1) / RPB_A + 1, 64);
-  SCL_WS(ctx, partA, double, "trd.partA", naMax * PA_LD);
+  SCL_WS(ctx, partA, double, "trd.partA", 2 * naMax * PA_LD);
   SCL_WS(ctx, partB, double, "trd.partB", nstripMax * nsegMax);
   SCL_WS(ctx, colinfo, float, "trd.colinfo", CI_LD);
   SCL_WS(ctx, rowpart, float, "trd.rowpart", nsegMax * ldv);
@@ -522,7 +517,7 @@ int sytrd_f32(Ctx* ctx, float* A, int64_t n, int64_t lda, double* d_dev, double*
   SCL_HIP(ctx, hipMemsetAsync(e_dev, 0, sizeof(double) * n, ctx->stream));
   SCL_HIP(ctx, hipMemsetAsync(colinfo, 0, sizeof(float) * CI_LD, ctx->stream));
   TrdArgs a{A, n, lda, VWt, ldv, x, partA, naMax, partB, colinfo, rowpart, colpart, d_dev, e_dev, tau_dev, Gst};
-  int nbB_prev = 0;
+  int nbB_prev = 0, na_prev = 0;
   // profiling hook only (PMC passes serialise every dispatch): stop after this many columns; results are then meaningless
   const char* maxc_env = getenv("SCLENS_HIP_SYTRD_MAXCOLS");
   const int64_t maxcols = maxc_env ? atoll(maxc_env) : n;
@@ -532,9 +527,10 @@ int sytrd_f32(Ctx* ctx, float* A, int64_t n, int64_t lda, double* d_dev, double*
     for (int64_t j = p; j < pe; ++j) {
       const int c = (int)(j - p);
       const int na = (int)((n - j + RPB_A - 1) / RPB_A);
-      hipLaunchKernelGGL(trd_colA, dim3(na), dim3(1024), 0, ctx->stream, a, j, c, nbB_prev, 0);
+      hipLaunchKernelGGL(trd_colA, dim3(na), dim3(1024), 0, ctx->stream, a, j, c, nbB_prev, na_prev, 0);
+      na_prev = na;
       if (j == n - 1) break;
-      hipLaunchKernelGGL(trd_colR, dim3(1), dim3(1024), 0, ctx->stream, a, j, c, na);
+      hipLaunchKernelGGL(trd_colR, dim3(1), dim3(64), 0, ctx->stream, a, j, na);
       const int64_t nt = n - (j + 1);
       const int nstrip = (int)((nt + RS - 1) / RS);
       const int64_t c_al = (j + 1) & ~(int64_t)3;
@@ -560,7 +556,7 @@ int sytrd_f32(Ctx* ctx, float* A, int64_t n, int64_t lda, double* d_dev, double*
     if (pe < n) {
       const int64_t nt = n - pe;
       const int na = (int)((nt + RPB_A - 1) / RPB_A);
-      hipLaunchKernelGGL(trd_colA, dim3(na), dim3(1024), 0, ctx->stream, a, pe, (int)NB, nbB_prev, 1);  // finish W[:, NB-1]
+      hipLaunchKernelGGL(trd_colA, dim3(na), dim3(1024), 0, ctx->stream, a, pe, (int)NB, nbB_prev, na_prev, 1);  // finish W[:, NB-1]
       hipLaunchKernelGGL(trd_panel_finish, dim3((unsigned)((nt + 31) / 32)), dim3(256), 0, ctx->stream, a, pe, VW, WV);
       GemmArgs g{};
       g.P = VW; g.Q = WV; g.C = A + pe * lda + pe;
@@ -591,7 +587,13 @@ int symv_probe(Ctx* ctx, int64_t n, int64_t* launches, double* total_ms, double*
   SCL_HIP(ctx, hipMemsetAsync(A, 0x3c, sizeof(float) * n * lda, ctx->stream));      // 0x3c3c3c3c = 0.0115 (finite)
   SCL_HIP(ctx, hipMemsetAsync(x, 0x3c, sizeof(float) * ldv, ctx->stream));
   SCL_HIP(ctx, hipMemsetAsync(colinfo, 0x3c, sizeof(float) * CI_LD, ctx->stream));
-  TrdArgs a{A, n, lda, VWt, ldv, x, nullptr, 0, partB, colinfo, rowpart, colpart, nullptr, nullptr, nullptr, nullptr};
+  const int64_t naMax = round_up((n + RPB_A - 1) / RPB_A + 1, 64);
+  SCL_WS(ctx, partA, double, "trd.partA", 2 * naMax * PA_LD);
+  SCL_WS(ctx, dd, double, "probe.d", n);
+  SCL_WS(ctx, de, double, "probe.e", n);
+  SCL_WS(ctx, dt, float, "probe.tau", n);
+  SCL_HIP(ctx, hipMemsetAsync(partA, 0x3c, sizeof(double) * 2 * naMax * PA_LD, ctx->stream));  // small positive finite doubles
+  TrdArgs a{A, n, lda, VWt, ldv, x, partA, naMax, partB, colinfo, rowpart, colpart, dd, de, dt, nullptr};
   hipEvent_t e0, e1;
   SCL_HIP(ctx, hipEventCreate(&e0));
   SCL_HIP(ctx, hipEventCreate(&e1));
