@@ -15,8 +15,8 @@ import ctypes as C
 import math
 import time
 from concurrent.futures import ThreadPoolExecutor
-from dataclasses import dataclass, field
-from typing import Callable, Dict, List, Optional
+from dataclasses import dataclass
+from typing import Callable, Dict, Optional
 
 import numpy as np
 import scipy.sparse as sp

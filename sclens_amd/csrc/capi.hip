@@ -30,7 +30,6 @@ int wishart_host(Ctx*, const float*, int64_t, int64_t, int, float*);
 int get_eigen_host(Ctx*, const float*, int64_t, float*, float*);
 int corr_mat_host(Ctx*, const float*, int64_t, int64_t, const float*, int64_t, float*);
 int get_eigvec_host(Ctx*, const float*, int64_t, int64_t, int64_t, float*, float*, int64_t*);
-Ctx* session_ctx(Session* s);
 int denoise_host(Ctx*, const float*, int64_t, int64_t, const float*, int64_t, const double*, const double*, const double*,
                  const double*, const double*, float*);
 }  // namespace scl

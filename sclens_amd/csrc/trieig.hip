@@ -452,11 +452,6 @@ int ormtr_f32(Ctx* ctx, const float* A, int64_t n, int64_t lda, const float* tau
   return SCLENS_OK;
 }
 
-__global__ void cvt_f64_to_f32(const double* __restrict__ in, float* __restrict__ out, int64_t n) {
-  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) out[i] = (float)in[i];
-}
-
 // Modified Gram-Schmidt over `cnt` consecutive rows of Zt (one block). Inverse iteration runs every eigenvector
 // independently; for eigenvalues that coincide to fp32 resolution it returns independent but not orthogonal vectors of the
 // shared eigenspace, so those (rare, small) clusters are orthonormalised afterwards, like LAPACK's dstein does inside.

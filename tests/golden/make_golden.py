@@ -23,13 +23,6 @@ from oracle import sclens_oracle as O  # noqa: E402
 from sclens_amd.synth import synth_counts  # noqa: E402
 
 
-class RecordingDraws:
-    """numpy-seeded draws whose R4/R5 samples are recorded so the fixture is self-contained."""
-
-    def __init__(self, X, seed, p_th_trials=2000):
-        self.d = O.make_draws(X, seed, p_th_trials)
-
-
 def run_case(name, X, seed, n_perturb):
     d = O.make_draws(X, seed, 2000)
     res = O.sclens(X, d, n_perturb=n_perturb, keep_intermediates=True, null_tol=O.NULL_DROP)
