@@ -3,15 +3,17 @@
 // cuSOLVER `syevd!` (GPU) / LAPACK `dsyevr` (CPU) on a host matrix.
 //
 // Blocked (panel width NB) right-looking reduction A = Q T Q^T; the trailing matrix is kept in full
-// symmetric storage but the matrix-vector product reads only its LOWER half. Three kernels per column,
+// symmetric storage but the matrix-vector product reads only its LOWER half. Two kernels per column,
 // no host synchronisation, every reduction in a fixed order (no float atomics: bitwise reproducible):
 //   trd_colA : (1) finishes the previous column: u = A v is assembled from the partial buffers of trd_colB,
 //              w = tau (u - V (W^T v) - W (V^T v)) - 1/2 tau (w^T v) v is written as W[:, c-1];
 //              (2) x = column j of A updated by the panel's reflectors; (3) per-block partial sums of
 //              ||x||^2, V^T x, W^T x. Thread = (row, column group); all global loads are issued up front.
-//   trd_colR : one wave: ||x||^2 from those partials, Householder scalars in fp64. (V^T v, W^T v and their dot
-//              product are reduced redundantly in the prologue of the NEXT trd_colA, off the critical path of trd_colB.)
-//   trd_colB : the HBM-bound symmetric matrix-vector product u = A_trail v, v = x*scale formed on the fly --
+//   (the Householder scalars need ||x||^2 = a grid-wide reduction; the matrix-vector product does not wait for it: it
+//    runs on the UN-normalised column, u = a1 + scale * A x~, and the next trd_colA applies `scale`. One spare block of
+//    trd_colB's grid reduces the norm partials and writes beta / tau / scale; V^T v, W^T v are reduced in the prologue of
+//    the next trd_colA. Two launches per column.)
+//   trd_colB : the HBM-bound symmetric matrix-vector product S = A_trail x~ (x~ = the column without its first entry) --
 //              the dominant kernel of the whole sclens() path. Work unit = (strip of 32 rows) x (segment of
 //              1024 columns) of the lower trapezoid; each of the 4 waves owns one 256-column chunk for all 32
 //              rows, so its transposed contribution (u_c += A[r][c] v_r) is complete in registers and is stored
@@ -174,10 +176,12 @@ __global__ __launch_bounds__(1024) void trd_colA(TrdArgs a, int64_t j, int c, in
   if (c > 0)
     for (int b = tid; b < nbB_prev; b += 1024) pb += a.partB[b];
   float vj = 0.f, wj = 0.f;
-  if (tid < c) {
+  if (tid < cp) {  // columns < c-1 of V and W are final; column c-1 is completed below (V[j][c-1] = v_j = 1)
     vj = a.VWt[(int64_t)tid * ldv + j];
-    if (tid < cp) wj = a.VWt[(int64_t)(NB + tid) * ldv + j];
+    wj = a.VWt[(int64_t)(NB + tid) * ldv + j];
   }
+  if (tid == cp) vj = 1.f;
+  const float ajj = (c > 0) ? a.A[j * a.lda + j] : 0.f;  // a1_j: first column of the previous trailing matrix, row j
   const float tau_p = (c > 0) ? a.colinfo[0] : 0.f;
   const float scale_p = (c > 0) ? a.colinfo[1] : 0.f;
   // partial sums V^T x, W^T x of the previous column (its trd_colA wrote them): 4 lanes per sum, fixed-order tree
@@ -201,10 +205,12 @@ __global__ __launch_bounds__(1024) void trd_colA(TrdArgs a, int64_t j, int c, in
 #pragma unroll
   for (int q = 0; q < NB / NG_A; ++q) {
     const int cc = g + NG_A * q;
-    vv[q] = (live && cc < c) ? a.VWt[(int64_t)cc * ldv + i] : 0.f;
+    vv[q] = (live && cc < cp) ? a.VWt[(int64_t)cc * ldv + i] : 0.f;
     ww[q] = (live && cc < cp) ? a.VWt[(int64_t)(NB + cc) * ldv + i] : 0.f;
   }
-  const float arow = (live && g == 0 && mode == 0) ? a.A[j * a.lda + i] : 0.f;
+  // row j of A: the column being reduced now AND a1 = first column of the previous trailing matrix (u = a1 + scale S)
+  const float arow = (live && g == 0) ? a.A[j * a.lda + i] : 0.f;
+  const float xold = (live && g == 0 && c > 0) ? a.x[i] : 0.f;  // previous column's x (v = x*scale, v_j = 1)
   float up = 0.f, uj = 0.f;
   if (c > 0) {
     if (live) up = gather_u(a, j - 1, i, g, NG_A);
@@ -241,10 +247,15 @@ __global__ __launch_bounds__(1024) void trd_colA(TrdArgs a, int64_t j, int c, in
         for (int w = 0; w < 16; ++w) { utv += red[w]; ujs += redf[w]; }
         float dotvw_p = 0.f;
         for (int q = 0; q < cp; ++q) dotvw_p += prod_s[q];  // fixed order
-        const double wtv = (double)tau_p * (utv - 2.0 * (double)dotvw_p);
+        // u = a1 + scale S with S = A x~ from trd_colB (x~ = x without its first entry):
+        //   u^T v = A[j][j] + 2 scale S_j + scale^2 (x~^T S)          (a1^T x~ = S_j by symmetry)
+        const double sp = (double)scale_p;
+        const double utv_full = (double)ajj + 2.0 * sp * (double)ujs + sp * sp * utv;
+        const double wtv = (double)tau_p * (utv_full - 2.0 * (double)dotvw_p);
         const float alpha2 = (float)(-0.5 * (double)tau_p * wtv);
         alpha2_s = alpha2;
-        wj_s = tau_p * (ujs - p2) + alpha2 * Vj[cp];  // W[j][c-1]
+        const float u_j = ajj + scale_p * ujs;
+        wj_s = tau_p * (u_j - p2) + alpha2;  // W[j][c-1]  (v_j = 1)
       }
     }
     __syncthreads();
@@ -268,15 +279,6 @@ __global__ __launch_bounds__(1024) void trd_colA(TrdArgs a, int64_t j, int c, in
   part_s[g][r] = p1;
   part2_s[g][r] = p2;
   upart_s[g][r] = up;
-  // V[i][c-1] lives in group (c-1) % NG_A, slot (c-1) / NG_A: publish it for group 0
-  __shared__ float vlast_s[RPB_A];
-  if (c > 0 && g == (cp % NG_A)) {
-    float vl = 0.f;
-#pragma unroll
-    for (int q = 0; q < NB / NG_A; ++q)
-      if (q == (cp / NG_A)) vl = vv[q];
-    vlast_s[r] = vl;
-  }
   __syncthreads();
   if (g == 0) {
     float av = 0.f;
@@ -286,9 +288,11 @@ __global__ __launch_bounds__(1024) void trd_colA(TrdArgs a, int64_t j, int c, in
         float u = 0.f, p2t = 0.f, p1s = 0.f;
 #pragma unroll
         for (int gg = 0; gg < NG_A; ++gg) { u += upart_s[gg][r]; p2t += part2_s[gg][r]; p1s += part_s[gg][r]; }
-        const float vl = vlast_s[r];
-        const float w = tau_p * (u - p2t) + alpha2 * vl;
+        const float vl = (i == j) ? 1.f : xold * scale_p;  // v of the previous column
+        const float w = tau_p * ((arow + scale_p * u) - p2t) + alpha2 * vl;
         a.VWt[(int64_t)(NB + cp) * ldv + i] = w;  // finished W[i][c-1] (row j included: nobody re-reads it raw)
+        a.VWt[(int64_t)cp * ldv + i] = vl;        // V[i][c-1]
+        a.A[(j - 1) * a.lda + i] = vl;            // reflector j-1 lives in row j-1, right of the diagonal
         p1t = p1s + vl * Wj[cp] + w * Vj[cp];
       }
       if (mode == 0) {
@@ -348,33 +352,7 @@ __global__ __launch_bounds__(1024) void trd_colA(TrdArgs a, int64_t j, int c, in
   }
 }
 
-// ------------------------------------------------------------------------------------------------
-// One wave: ||x||^2 from the per-block partials of trd_colA (fixed order), Householder scalars in fp64.
-__global__ __launch_bounds__(64) void trd_colR(TrdArgs a, int64_t j, int na) {
-  const int lane = threadIdx.x;
-  const double* pn = a.partA + (int64_t)(j & 1) * PA_LD * a.na_ld + (int64_t)(2 * NB) * a.na_ld;
-  double sx = 0.0;
-  for (int b = lane; b < na; b += 64) sx += pn[b];
-  sx = wave_sum(sx);
-  if (lane == 0) {
-    const double alpha = (double)a.x[j + 1];
-    double beta, tau, sc;
-    if (sx == 0.0) {
-      beta = alpha; tau = 0.0; sc = 0.0;
-    } else {
-      beta = -copysign(sqrt(alpha * alpha + sx), alpha);
-      tau = (beta - alpha) / beta;
-      sc = 1.0 / (alpha - beta);
-    }
-    a.colinfo[0] = (float)tau;
-    a.colinfo[1] = (float)sc;
-    a.d[j] = (double)a.x[j];
-    a.e[j] = beta;
-    a.tau[j] = (float)tau;
-  }
-}
-
-__global__ __launch_bounds__(256, 3) void trd_colB(TrdArgs a, int64_t j, int c, int nsegmax) {
+__global__ __launch_bounds__(256, 3) void trd_colB(TrdArgs a, int64_t j, int c, int nsegmax, int na) {
   __shared__ float rowred[4][RS];
   __shared__ double utv_s[4];
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -384,13 +362,37 @@ __global__ __launch_bounds__(256, 3) void trd_colB(TrdArgs a, int64_t j, int c, 
   const int64_t rb = (j + 1) + s * RS;          // first row of the strip
   const int64_t c_al = (j + 1) & ~(int64_t)3;
   const int64_t cend = (rb + RS < n) ? rb + RS : n;  // columns < cend belong to this strip's trapezoid
+  if (seg == nsegmax) {  // spare grid row: one wave of block (0, nsegmax) computes the Householder scalars
+    if (s == 0 && wid == 0) {
+      const double* pn = a.partA + (int64_t)(j & 1) * PA_LD * a.na_ld + (int64_t)(2 * NB) * a.na_ld;
+      double sx = 0.0;
+      for (int b = lane; b < na; b += 64) sx += pn[b];
+      sx = wave_sum(sx);
+      if (lane == 0) {
+        const double alpha = (double)a.x[j + 1];
+        double beta, tau, sc;
+        if (sx == 0.0) {
+          beta = alpha; tau = 0.0; sc = 0.0;
+        } else {
+          beta = -copysign(sqrt(alpha * alpha + sx), alpha);
+          tau = (beta - alpha) / beta;
+          sc = 1.0 / (alpha - beta);
+        }
+        a.colinfo[0] = (float)tau;
+        a.colinfo[1] = (float)sc;
+        a.d[j] = (double)a.x[j];
+        a.e[j] = beta;
+        a.tau[j] = (float)tau;
+      }
+    }
+    return;
+  }
   const int bidx = (int)(s * nsegmax + seg);
   const int64_t cseg = c_al + (int64_t)seg * SEG;
   if (cseg >= cend) {                           // idle unit
     if (tid == 0) a.partB[bidx] = 0.0;
     return;
   }
-  const float scale = a.colinfo[1];
   float racc[RS];
 #pragma unroll
   for (int q = 0; q < RS; ++q) racc[q] = 0.f;
@@ -408,7 +410,7 @@ __global__ __launch_bounds__(256, 3) void trd_colB(TrdArgs a, int64_t j, int c, 
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         const int64_t idx = col + e;
-        const float v = (idx == j + 1) ? 1.f : ((idx > j + 1 && idx < n) ? xv[e] * scale : 0.f);
+        const float v = (idx > j + 1 && idx < n) ? xv[e] : 0.f;  // x~: the column without its first entry
         vc[e] = (idx < cend) ? v : 0.f;
         tmask[e] = (idx < rb && idx >= j + 1) ? 1.f : 0.f;
       }
@@ -423,9 +425,7 @@ __global__ __launch_bounds__(256, 3) void trd_colB(TrdArgs a, int64_t j, int c, 
         const int64_t row = rb + pass * PR + q;
         const bool rok = row < n;
         av[q] = (rok && colok) ? *reinterpret_cast<const f32x4*>(a.A + row * lda + col) : f32x4{0.f, 0.f, 0.f, 0.f};
-        const float xr = rok ? a.x[row] : 0.f;  // wave-uniform
-        vr[q] = (row == j + 1) ? 1.f : xr * scale;
-        if (!rok) vr[q] = 0.f;
+        vr[q] = (rok && row > j + 1) ? a.x[row] : 0.f;  // wave-uniform
       }
 #pragma unroll
       for (int q = 0; q < PR; ++q) {
@@ -457,12 +457,8 @@ __global__ __launch_bounds__(256, 3) void trd_colB(TrdArgs a, int64_t j, int c, 
       const float rs = (rowred[0][tid] + rowred[1][tid]) + (rowred[2][tid] + rowred[3][tid]);
       if (row < n) {
         a.rowpart[(int64_t)seg * ldv + row] = rs;
-        const float vrow = (row == j + 1) ? 1.f : a.x[row] * scale;
-        t = (double)rs * (double)vrow;  // ... + v_row * rowdot (row part)
-        if (seg == 0) {                 // publish v once per row: panel column c and reflector storage
-          a.VWt[(int64_t)c * ldv + row] = vrow;
-          a.A[j * lda + row] = vrow;    // reflector j lives in row j, right of the diagonal
-        }
+        const float xrow = (row > j + 1) ? a.x[row] : 0.f;
+        t = (double)rs * (double)xrow;  // ... + x~_row * rowdot (row part)
       }
     }
     t = wave_sum(t);
@@ -530,7 +526,6 @@ int sytrd_f32(Ctx* ctx, float* A, int64_t n, int64_t lda, double* d_dev, double*
       hipLaunchKernelGGL(trd_colA, dim3(na), dim3(1024), 0, ctx->stream, a, j, c, nbB_prev, na_prev, 0);
       na_prev = na;
       if (j == n - 1) break;
-      hipLaunchKernelGGL(trd_colR, dim3(1), dim3(64), 0, ctx->stream, a, j, na);
       const int64_t nt = n - (j + 1);
       const int nstrip = (int)((nt + RS - 1) / RS);
       const int64_t c_al = (j + 1) & ~(int64_t)3;
@@ -545,7 +540,7 @@ int sytrd_f32(Ctx* ctx, float* A, int64_t n, int64_t lda, double* d_dev, double*
         }
         SCL_HIP(ctx, hipEventRecord(ctx->prof_ev[ctx->prof_used], ctx->stream));
       }
-      hipLaunchKernelGGL(trd_colB, dim3(nstrip, nsegmax), dim3(256), 0, ctx->stream, a, j, c, nsegmax);
+      hipLaunchKernelGGL(trd_colB, dim3(nstrip, nsegmax + 1), dim3(256), 0, ctx->stream, a, j, c, nsegmax, na);
       if (ctx->prof_symv) {
         SCL_HIP(ctx, hipEventRecord(ctx->prof_ev[ctx->prof_used + 1], ctx->stream));
         ctx->prof_used += 2;
@@ -604,7 +599,8 @@ int symv_probe(Ctx* ctx, int64_t n, int64_t* launches, double* total_ms, double*
     const int nstrip = (int)((nt + RS - 1) / RS);
     const int64_t c_al = (j + 1) & ~(int64_t)3;
     const int nsegmax = (int)((n - c_al + SEG - 1) / SEG);
-    hipLaunchKernelGGL(trd_colB, dim3(nstrip, nsegmax), dim3(256), 0, ctx->stream, a, j, (int)(j % NB), nsegmax);
+    hipLaunchKernelGGL(trd_colB, dim3(nstrip, nsegmax + 1), dim3(256), 0, ctx->stream, a, j, (int)(j % NB), nsegmax,
+                       (int)((n - j + RPB_A - 1) / RPB_A));
     bytes += 2.0 * (double)nt * (double)(nt + 1);
   }
   SCL_HIP(ctx, hipEventRecord(e1, ctx->stream));
