@@ -31,7 +31,7 @@ constexpr int NG_A = 8;        // column groups in trd_colA
 constexpr int RS = 32;         // strip height of trd_colB
 constexpr int CH = 1;          // 256-column chunks per wave in trd_colB
 constexpr int SEG = 1024 * CH; // segment width of trd_colB (4 waves x CH x 256 columns)
-constexpr int PR = 8;          // rows loaded per pass in trd_colB (registers vs. loads in flight)
+constexpr int PR = 16;         // rows loaded per pass in trd_colB (registers vs. loads in flight)
 constexpr int PA_LD = 2 * NB + 1;
 // colinfo: [0]=tau [1]=scale [2]=(V^T v).(W^T v), [4..4+NB) = V^T v, [4+NB..4+2NB) = W^T v
 constexpr int CI_LD = 2 * NB + 4;
