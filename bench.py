@@ -105,6 +105,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--backend", default="nccl")
+    ap.add_argument("--batch", action="store_true", help="merge the column steps of concurrent tridiagonalisations into shared launches (opt-in)")
     ap.add_argument("--streams", type=int, default=3, help="concurrent decompositions per GPU (worker sessions on own HIP streams)")
     ap.add_argument("--verbose", action="store_true")
     ap.add_argument("--stage-timing", action="store_true", help="per-stage HIP-event totals on stderr (adds syncs)")
@@ -144,7 +145,7 @@ def main():
         draws = api.make_draws_native(X, seed=1000 + step, async_null=True)
         one_step.draws_s = time.perf_counter() - t_d  # R1-R3 inside the timed region; R4/R5 on the device inside sclens()
         return api.sclens(X, draws=draws, ctx=ctx, n_perturb=args.n_perturb, shard=shard, streams=args.streams,
-                          verbose=args.verbose and rank == 0)
+                          batch=args.batch, verbose=args.verbose and rank == 0)
 
     def fence():
         shard.barrier()

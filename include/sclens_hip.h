@@ -59,6 +59,20 @@ int sclens_hip_symv_probe(sclens_hip_ctx* ctx, int64_t n, int64_t* launches, dou
 /* raw stream handle (hipStream_t) so a host framework can order its own work after ours */
 void* sclens_hip_stream(sclens_hip_ctx* ctx);
 
+/* Lock-step batching of concurrent eigendecompositions. The reference runs its 3 + S + P decompositions one after the
+ * other (scLENS.jl:704, :717-721, :735-745); here independent ones run on several contexts (one host thread + one HIP
+ * stream each), and the contexts attached to one batch group merge the column steps of their tridiagonalisations into
+ * shared launches (each matrix keeps exactly the arithmetic of a solo run: bitwise identical results).
+ * Protocol per round: sclens_hip_batch_expect(group, m), then m threads each run ONE decomposition on m different
+ * attached contexts; a thread whose job fails before its decomposition calls sclens_hip_batch_leave. count <= 1 (or no
+ * call) = unbatched. A participant that never arrives fails the round with SCLENS_ERR_STATE after 600 s. */
+typedef struct sclens_hip_batch sclens_hip_batch;
+sclens_hip_batch* sclens_hip_batch_create(void);
+void sclens_hip_batch_destroy(sclens_hip_batch* group);
+int sclens_hip_batch_expect(sclens_hip_batch* group, int count);
+int sclens_hip_batch_leave(sclens_hip_batch* group);
+int sclens_hip_set_batch(sclens_hip_ctx* ctx, sclens_hip_batch* group); /* group = NULL detaches */
+
 /* ---------------------------------------------------------------- (A) per-call drop-ins -------- */
 /* _wishart_matrix(X; device, dims)  (scLENS.jl:332-361): X is N x M; dims=2 -> X'X / M (M x M),
  * dims=1 -> XX' / M (N x N). Both divide by size(X,2). Y is caller-allocated. */

@@ -33,6 +33,11 @@ SIGNATURES = {
     "sclens_hip_get_timing": (C.c_int, [vp, C.c_char_p, c_f64p, c_i64p]),
     "sclens_hip_reset_timing": (C.c_int, [vp]),
     "sclens_hip_stream": (vp, [vp]),
+    "sclens_hip_batch_create": (vp, []),
+    "sclens_hip_batch_destroy": (None, [vp]),
+    "sclens_hip_batch_expect": (C.c_int, [vp, C.c_int]),
+    "sclens_hip_batch_leave": (C.c_int, [vp]),
+    "sclens_hip_set_batch": (C.c_int, [vp, vp]),
     "sclens_hip_symv_probe": (C.c_int, [vp, i64, c_i64p, c_f64p, c_f64p]),
     "sclens_hip_symv_profile": (C.c_int, [vp, C.c_int]),
     "sclens_hip_symv_profile_read": (C.c_int, [vp, c_i64p, c_f64p, c_f64p]),
@@ -114,6 +119,25 @@ def ptr(a: np.ndarray, ctype):
     return a.ctypes.data_as(C.POINTER(ctype))
 
 
+class BatchGroup:
+    """sclens_hip_batch: contexts attached to one group merge the column steps of concurrent tridiagonalisations."""
+
+    def __init__(self):
+        self.lib = load()
+        self.h = vp(self.lib.sclens_hip_batch_create())
+
+    def expect(self, count: int):
+        self.lib.sclens_hip_batch_expect(self.h, int(count))
+
+    def leave(self):
+        self.lib.sclens_hip_batch_leave(self.h)
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.sclens_hip_batch_destroy(self.h)
+            self.h = None
+
+
 class Context:
     """Owns one sclens_hip_ctx (one GPU, one stream)."""
 
@@ -140,6 +164,9 @@ class Context:
             self.close()
         except Exception:
             pass
+
+    def set_batch(self, group: "Optional[BatchGroup]"):
+        self.check(self.lib.sclens_hip_set_batch(self.h, group.h if group is not None else None))
 
     # ---- timing
     def set_timing(self, on: bool):

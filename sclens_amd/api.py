@@ -22,7 +22,7 @@ import numpy as np
 import scipy.sparse as sp
 
 from . import _lib
-from ._lib import Context, SclensHipError, ptr
+from ._lib import BatchGroup, Context, SclensHipError, ptr
 from .shard import Shard, consume_search_round, owned_perturbations, search_schedule
 
 _default_ctx: Optional[Context] = None
@@ -525,7 +525,7 @@ def _extract(inp):
 def sclens(inp_df, device_="gpu", th=60, p_step=0.001, n_perturb=20, centering="mean", draws: Optional[Draws] = None,
            seed: Optional[int] = None, ctx: Optional[Context] = None, max_search_iters: Optional[int] = None,
            keep_intermediates: bool = False, verbose: bool = False, shard: Optional[Shard] = None,
-           partial_eig: bool = True, streams: int = 1) -> Dict[str, object]:
+           partial_eig: bool = True, streams: int = 1, batch: bool = False) -> Dict[str, object]:
     """scLENS.sclens (scLENS.jl:649-832) on one MI355X.
 
     Same keyword arguments as the reference. `draws`/`seed` expose the randomness the reference takes from
@@ -566,20 +566,36 @@ def sclens(inp_df, device_="gpu", th=60, p_step=0.001, n_perturb=20, centering="
             workers.append(ses.clone(c2))
         W = len(workers)
         pool = ThreadPoolExecutor(max_workers=W) if W > 1 else None
+        # batch=True: concurrent decompositions of one round advance their tridiagonalisations in shared launches (bitwise
+        # the same results as solo runs). Opt-in: measured on MI355X it only pays with >= 6 streams at n <= ~3000
+        # (17.8 vs 22.8 ms per matrix); at 3 streams independent streams overlap better at every n.
+        group = BatchGroup() if (W > 1 and batch) else None
+        if group is not None:
+            for c_ in [ctx] + wctx:
+                c_.set_batch(group)
 
-        def run_all(jobs):
+        def run_all(jobs, lockstep=False):
             """jobs: list of (worker_index, callable) -> results in job order. Jobs of one worker run sequentially in
-            one thread (a session is single-threaded); different workers run concurrently."""
+            one thread (a session is single-threaded); different workers run concurrently. `lockstep`: every job runs
+            exactly one full decomposition (or calls group.leave()), so the round can be batched."""
             if pool is None:
                 return [f() for _, f in jobs]
             out = [None] * len(jobs)
             by_worker = {}
             for pos, (wk, f) in enumerate(jobs):
                 by_worker.setdefault(wk, []).append((pos, f))
+            batched = group is not None and lockstep and len(by_worker) == len(jobs) and len(jobs) > 1
+            if group is not None:
+                group.expect(len(jobs) if batched else 0)
 
-            def run_group(group):
-                for pos, f in group:
-                    out[pos] = f()
+            def run_group(grp):
+                for pos, f in grp:
+                    try:
+                        out[pos] = f()
+                    except BaseException:
+                        if batched:
+                            group.leave()  # no-op once this job's decomposition has been through the round
+                        raise
 
             futs = [pool.submit(run_group, g) for g in by_worker.values()]
             for f in futs:
@@ -595,7 +611,7 @@ def sclens(inp_df, device_="gpu", th=60, p_step=0.001, n_perturb=20, centering="
         else:  # the main session keeps the data matrix's reflectors for signal_vectors; workers take the other two
             w_null, w_bin = workers[1], workers[2 if W >= 3 else 1]
             (L, rec_vals), Lr, (_, r_vr2) = run_all([(0, ses.data_spectrum), (1, lambda: w_null.null_spectrum(_resolve(draws.X_r))),
-                                                     (2 if W >= 3 else 1, w_bin.binary_basis)])
+                                                     (2 if W >= 3 else 1, w_bin.binary_basis)], lockstep=True)
         L_mp, _, b_min = _mp_calculation(L, Lr[:-1])  # Lr[1:end-1] (:537, :576)
         lambda_c = _tw(L, L_mp)[0]
         sel = L > lambda_c
@@ -629,6 +645,8 @@ def sclens(inp_df, device_="gpu", th=60, p_step=0.001, n_perturb=20, centering="
                     else:
                         d5, _r = workers[wk].search_step_seeded(sample_seed_for(draws.sample_seed, "search", my_it), nnzidx, n_2)
                     out[:5], out[5] = d5, 1.0
+                elif group is not None:
+                    group.leave()  # no decomposition in this job
                 return out
             return f
 
@@ -638,7 +656,7 @@ def sclens(inp_df, device_="gpu", th=60, p_step=0.001, n_perturb=20, centering="
         try:
             while p_ is None:
                 base = it + shard.rank * W
-                mine = np.stack(run_all([(w, search_job(w, base + w)) for w in range(W)]))  # W x 6
+                mine = np.stack(run_all([(w, search_job(w, base + w)) for w in range(W)], lockstep=True))  # W x 6
                 allr = shard.allgather_small(mine).reshape(shard.world * W, 6)
                 results = [allr[q, :5] if allr[q, 5] == 1.0 else None for q in range(shard.world * W)]
                 tank, used, stopped, p_fin = consume_search_round(tank, results, p_list, it, p_th, p_step, max_search_iters)
@@ -690,6 +708,9 @@ def sclens(inp_df, device_="gpu", th=60, p_step=0.001, n_perturb=20, centering="
                 w.close()
             for c2 in wctx:
                 c2.close()
+            if group is not None:
+                ctx.set_batch(None)
+                group.close()
 
         res: Dict[str, object] = {"L": L, "L_mp": L_mp, "λ": lambda_c, "lambda_c": lambda_c, "cell_id": cell_id,
                                   "p_": p_, "p_th": p_th, "n_search": it, "search_trace": trace,

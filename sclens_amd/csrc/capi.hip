@@ -74,6 +74,24 @@ void sclens_hip_destroy(sclens_hip_ctx* h) {
 const char* sclens_hip_last_error(const sclens_hip_ctx* h) { return h ? h->c.err.c_str() : "null context"; }
 void* sclens_hip_stream(sclens_hip_ctx* h) { return h ? (void*)h->c.stream : nullptr; }
 
+sclens_hip_batch* sclens_hip_batch_create(void) { return reinterpret_cast<sclens_hip_batch*>(scl::batch_create()); }
+void sclens_hip_batch_destroy(sclens_hip_batch* g) { scl::batch_destroy(reinterpret_cast<scl::BatchGroup*>(g)); }
+int sclens_hip_batch_expect(sclens_hip_batch* g, int count) {
+  if (!g) return SCLENS_ERR_ARG;
+  scl::batch_expect(reinterpret_cast<scl::BatchGroup*>(g), count);
+  return SCLENS_OK;
+}
+int sclens_hip_batch_leave(sclens_hip_batch* g) {
+  if (!g) return SCLENS_ERR_ARG;
+  scl::batch_leave(reinterpret_cast<scl::BatchGroup*>(g));
+  return SCLENS_OK;
+}
+int sclens_hip_set_batch(sclens_hip_ctx* h, sclens_hip_batch* g) {
+  if (!h) return SCLENS_ERR_ARG;
+  h->c.batch = reinterpret_cast<scl::BatchGroup*>(g);
+  return SCLENS_OK;
+}
+
 int sclens_hip_set_timing(sclens_hip_ctx* h, int enabled) {
   if (!h) return SCLENS_ERR_ARG;
   h->c.timing = enabled != 0;

@@ -29,6 +29,8 @@ struct Ctx {
   std::vector<hipEvent_t> prof_ev;   // pairs (start, stop) recorded on `stream`
   size_t prof_used = 0;
   double prof_bytes = 0.0;           // algorithmic bytes of the recorded launches
+  // lock-step batching of tridiagonalisations that run concurrently on several contexts (tridiag.hip); not owned
+  struct BatchGroup* batch = nullptr;
 
   int fail(int code, const std::string& msg) {
     err = msg;
@@ -131,6 +133,10 @@ int stein_f64(Ctx* ctx, const double* d_dev, const double* e_dev, int64_t n, con
 int ormtr_f32(Ctx* ctx, const float* A, int64_t n, int64_t lda, const float* tau_dev, float* Zt,
               int64_t m, int64_t ldz);
 
+BatchGroup* batch_create();
+void batch_destroy(BatchGroup* g);
+void batch_expect(BatchGroup* g, int count);
+void batch_leave(BatchGroup* g);
 int symv_probe(Ctx* ctx, int64_t n, int64_t* launches, double* total_ms, double* total_bytes);
 
 // ------------------------------------------------------------------ partial eigensolver (chefsi.hip)

@@ -23,6 +23,10 @@
 // V^T v of each column is kept (Gst) so the block-reflector T factors need no extra pass over V.
 #include "common.h"
 
+#include <chrono>
+#include <condition_variable>
+#include <mutex>
+
 namespace scl {
 
 constexpr int NB = 128;        // panel width (also the block-reflector width of the back-transform)
@@ -54,6 +58,17 @@ struct TrdArgs {
   double* e;        // [n]
   float* tau;       // [n]
   float* Gst;       // [n][NB]: Gst[j][cc] = V[:,cc]^T v_j for cc < c(j)
+  float* VW;        // [n][2NB] row-major [V|W] of the finished panel (operands of the rank-2NB update)
+  float* WV;        // [n][2NB] row-major [W|V]
+};
+
+// Several independent matrices of the same order advance in lock-step: blockIdx.z selects the member. A column step of
+// ONE matrix cannot fill the chip (trd_colA is a latency chain over ~n/128 blocks), so concurrent decompositions
+// (sparsity-search evaluations, data | null | binarised matrix) share their launches. Each member's arithmetic is
+// exactly that of a solo run (same blocks, same reduction orders): results are bitwise identical.
+constexpr int TRD_MAXB = 8;
+struct TrdBatch {
+  TrdArgs a[TRD_MAXB];
 };
 
 __device__ __forceinline__ double wave_sum(double v) {
@@ -154,7 +169,8 @@ __device__ __forceinline__ int reduce32_index(int lane) {
 // ------------------------------------------------------------------------------------------------
 // mode 0: full column step for column j (panel-local index c).  mode 1: only finish W[:, c-1] for rows >= j
 // (panel end: c = NB, j = pe).
-__global__ __launch_bounds__(1024) void trd_colA(TrdArgs a, int64_t j, int c, int nbB_prev, int na_prev, int mode) {
+__global__ __launch_bounds__(1024) void trd_colA(TrdBatch bt, int64_t j, int c, int nbB_prev, int na_prev, int mode) {
+  const TrdArgs a = bt.a[blockIdx.z];
   __shared__ float Vj[NB], Wj[NB], tVp[NB], tWp[NB];
   __shared__ float a_s[RPB_A];
   __shared__ float part_s[NG_A][RPB_A], part2_s[NG_A][RPB_A], upart_s[NG_A][RPB_A];
@@ -352,7 +368,8 @@ __global__ __launch_bounds__(1024) void trd_colA(TrdArgs a, int64_t j, int c, in
   }
 }
 
-__global__ __launch_bounds__(256, 3) void trd_colB(TrdArgs a, int64_t j, int c, int nsegmax, int na) {
+__global__ __launch_bounds__(256, 3) void trd_colB(TrdBatch bt, int64_t j, int c, int nsegmax, int na) {
+  const TrdArgs a = bt.a[blockIdx.z];
   __shared__ float rowred[4][RS];
   __shared__ double utv_s[4];
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -468,7 +485,10 @@ __global__ __launch_bounds__(256, 3) void trd_colB(TrdArgs a, int64_t j, int c, 
 
 // ------------------------------------------------------------------------------------------------
 // Panel end: write row-major VW = [V|W], WV = [W|V] for rows >= pe (W is already finished by trd_colA mode 1).
-__global__ __launch_bounds__(256) void trd_panel_finish(TrdArgs a, int64_t pe, float* VW, float* WV) {
+__global__ __launch_bounds__(256) void trd_panel_finish(TrdBatch bt, int64_t pe) {
+  const TrdArgs a = bt.a[blockIdx.z];
+  float* __restrict__ VW = a.VW;
+  float* __restrict__ WV = a.WV;
   __shared__ float tile[2 * NB][33];
   const int tid = threadIdx.x;
   const int64_t i0 = pe + (int64_t)blockIdx.x * 32;
@@ -489,11 +509,13 @@ __global__ __launch_bounds__(256) void trd_panel_finish(TrdArgs a, int64_t pe, f
   }
 }
 
-int sytrd_f32(Ctx* ctx, float* A, int64_t n, int64_t lda, double* d_dev, double* e_dev, float* tau_dev) {
-  if (n <= 0) return SCLENS_OK;
-  if (lda % 4 != 0 || lda < n || (reinterpret_cast<uintptr_t>(A) & 15u))
-    return ctx->fail(SCLENS_ERR_ARG, "sytrd_f32: A must be 16-byte aligned with lda a multiple of 4");
-  StageTimer tm(ctx, "sytrd");
+struct TrdJob {
+  Ctx* ctx;
+  TrdArgs a;
+};
+
+// workspaces + initial state of one member, enqueued on its own stream
+static int sytrd_setup(Ctx* ctx, float* A, int64_t n, int64_t lda, double* d_dev, double* e_dev, float* tau_dev, TrdJob* job) {
   const int64_t ldv = round_up(n, 64) + 512;
   const int64_t nstripMax = (n + RS - 1) / RS + 1, nsegMax = (n + SEG - 1) / SEG + 2;
   SCL_WS(ctx, VWt, float, "trd.VWt", 2 * NB * ldv);
@@ -512,25 +534,35 @@ int sytrd_f32(Ctx* ctx, float* A, int64_t n, int64_t lda, double* d_dev, double*
   SCL_HIP(ctx, hipMemsetAsync(tau_dev, 0, sizeof(float) * n, ctx->stream));
   SCL_HIP(ctx, hipMemsetAsync(e_dev, 0, sizeof(double) * n, ctx->stream));
   SCL_HIP(ctx, hipMemsetAsync(colinfo, 0, sizeof(float) * CI_LD, ctx->stream));
-  TrdArgs a{A, n, lda, VWt, ldv, x, partA, naMax, partB, colinfo, rowpart, colpart, d_dev, e_dev, tau_dev, Gst};
+  job->ctx = ctx;
+  job->a = TrdArgs{A, n, lda, VWt, ldv, x, partA, naMax, partB, colinfo, rowpart, colpart, d_dev, e_dev, tau_dev, Gst, VW, WV};
+  return SCLENS_OK;
+}
+
+// the column loop for nb members of equal order, every launch on lead->stream
+static int sytrd_run(Ctx* ctx, const TrdJob* jobs, int nb) {
+  TrdBatch bt{};
+  for (int b = 0; b < nb; ++b) bt.a[b] = jobs[b].a;
+  const int64_t n = bt.a[0].n, ldv = bt.a[0].ldv;
+  const bool prof = ctx->prof_symv && nb == 1;
   int nbB_prev = 0, na_prev = 0;
   // profiling hook only (PMC passes serialise every dispatch): stop after this many columns; results are then meaningless
   const char* maxc_env = getenv("SCLENS_HIP_SYTRD_MAXCOLS");
   const int64_t maxcols = maxc_env ? atoll(maxc_env) : n;
   for (int64_t p = 0; p < n && p < maxcols; p += NB) {
     const int64_t pe = (p + NB < n) ? p + NB : n;
-    SCL_HIP(ctx, hipMemsetAsync(VWt, 0, sizeof(float) * 2 * NB * ldv, ctx->stream));
+    for (int b = 0; b < nb; ++b) SCL_HIP(ctx, hipMemsetAsync(bt.a[b].VWt, 0, sizeof(float) * 2 * NB * ldv, ctx->stream));
     for (int64_t j = p; j < pe; ++j) {
       const int c = (int)(j - p);
       const int na = (int)((n - j + RPB_A - 1) / RPB_A);
-      hipLaunchKernelGGL(trd_colA, dim3(na), dim3(1024), 0, ctx->stream, a, j, c, nbB_prev, na_prev, 0);
+      hipLaunchKernelGGL(trd_colA, dim3(na, 1, nb), dim3(1024), 0, ctx->stream, bt, j, c, nbB_prev, na_prev, 0);
       na_prev = na;
       if (j == n - 1) break;
       const int64_t nt = n - (j + 1);
       const int nstrip = (int)((nt + RS - 1) / RS);
       const int64_t c_al = (j + 1) & ~(int64_t)3;
       const int nsegmax = (int)((n - c_al + SEG - 1) / SEG);
-      if (ctx->prof_symv) {
+      if (prof) {
         if (ctx->prof_used + 2 > ctx->prof_ev.size()) {
           for (int q = 0; q < 2; ++q) {
             hipEvent_t ev;
@@ -540,8 +572,8 @@ int sytrd_f32(Ctx* ctx, float* A, int64_t n, int64_t lda, double* d_dev, double*
         }
         SCL_HIP(ctx, hipEventRecord(ctx->prof_ev[ctx->prof_used], ctx->stream));
       }
-      hipLaunchKernelGGL(trd_colB, dim3(nstrip, nsegmax + 1), dim3(256), 0, ctx->stream, a, j, c, nsegmax, na);
-      if (ctx->prof_symv) {
+      hipLaunchKernelGGL(trd_colB, dim3(nstrip, nsegmax + 1, nb), dim3(256), 0, ctx->stream, bt, j, c, nsegmax, na);
+      if (prof) {
         SCL_HIP(ctx, hipEventRecord(ctx->prof_ev[ctx->prof_used + 1], ctx->stream));
         ctx->prof_used += 2;
         ctx->prof_bytes += 2.0 * (double)nt * (double)(nt + 1);  // unique bytes of the symmetric trailing matrix (lower half)
@@ -551,18 +583,134 @@ int sytrd_f32(Ctx* ctx, float* A, int64_t n, int64_t lda, double* d_dev, double*
     if (pe < n) {
       const int64_t nt = n - pe;
       const int na = (int)((nt + RPB_A - 1) / RPB_A);
-      hipLaunchKernelGGL(trd_colA, dim3(na), dim3(1024), 0, ctx->stream, a, pe, (int)NB, nbB_prev, na_prev, 1);  // finish W[:, NB-1]
-      hipLaunchKernelGGL(trd_panel_finish, dim3((unsigned)((nt + 31) / 32)), dim3(256), 0, ctx->stream, a, pe, VW, WV);
-      GemmArgs g{};
-      g.P = VW; g.Q = WV; g.C = A + pe * lda + pe;
-      g.M = nt; g.N = nt; g.K = 2 * NB;
-      g.ldp = 2 * NB; g.ldq = 2 * NB; g.ldc = lda;
-      g.alpha = -1.f; g.beta = 1.f; g.q_kcontig = 1; g.lower = 1; g.colabsmax = nullptr;
-      SCL_TRY(gemm_f32(ctx, g));
+      hipLaunchKernelGGL(trd_colA, dim3(na, 1, nb), dim3(1024), 0, ctx->stream, bt, pe, (int)NB, nbB_prev, na_prev, 1);  // finish W[:, NB-1]
+      hipLaunchKernelGGL(trd_panel_finish, dim3((unsigned)((nt + 31) / 32), 1, nb), dim3(256), 0, ctx->stream, bt, pe);
+      for (int b = 0; b < nb; ++b) {
+        GemmArgs g{};
+        g.P = bt.a[b].VW; g.Q = bt.a[b].WV; g.C = bt.a[b].A + pe * bt.a[b].lda + pe;
+        g.M = nt; g.N = nt; g.K = 2 * NB;
+        g.ldp = 2 * NB; g.ldq = 2 * NB; g.ldc = bt.a[b].lda;
+        g.alpha = -1.f; g.beta = 1.f; g.q_kcontig = 1; g.lower = 1; g.colabsmax = nullptr;
+        SCL_TRY(gemm_f32(ctx, g));
+      }
     }
   }
   SCL_HIP(ctx, hipGetLastError());
   return SCLENS_OK;
+}
+
+// ---- rendezvous of concurrent decompositions (one host thread + one stream each) into batched launches -------------
+struct BatchGroup {
+  std::mutex mu;
+  std::condition_variable cv;
+  int expected = 0;             // participants of the current round (set by batch_expect; <= 1: no batching)
+  bool promote = false;         // a participant left: a waiter must take the lead
+  uint64_t generation = 0;
+  std::vector<TrdJob> jobs;     // arrived so far
+  std::vector<hipEvent_t> ready;
+  hipEvent_t done = nullptr;
+  int last_rc = SCLENS_OK;
+  std::string last_err;
+};
+
+BatchGroup* batch_create() { return new BatchGroup(); }
+void batch_destroy(BatchGroup* g) {
+  if (!g) return;
+  for (hipEvent_t e : g->ready) hipEventDestroy(e);
+  if (g->done) hipEventDestroy(g->done);
+  delete g;
+}
+void batch_expect(BatchGroup* g, int count) {
+  std::lock_guard<std::mutex> lk(g->mu);
+  g->expected = count > TRD_MAXB ? 0 : count;  // more members than one launch holds: run unbatched
+  g->promote = false;
+}
+void batch_leave(BatchGroup* g) {  // a participant of this round will not arrive (it failed before its tridiagonalisation)
+  std::lock_guard<std::mutex> lk(g->mu);
+  if (g->expected <= 0) return;
+  g->expected -= 1;
+  if (!g->jobs.empty() && (int)g->jobs.size() >= g->expected) {
+    g->promote = true;
+    g->cv.notify_all();
+  }
+}
+
+// called with g->mu held by the thread that completes the round
+static int batch_lead(BatchGroup* g, Ctx* ctx) {
+  std::vector<TrdJob> jobs;
+  jobs.swap(g->jobs);
+  g->expected = 0;
+  g->promote = false;
+  int rc = SCLENS_OK;
+  auto hip_ok = [&](hipError_t e, const char* what) {
+    if (e != hipSuccess && rc == SCLENS_OK) rc = ctx->fail(SCLENS_ERR_HIP, std::string(what) + ": " + hipGetErrorString(e));
+  };
+  for (size_t i = 0; i < jobs.size(); ++i)
+    if (jobs[i].ctx != ctx) hip_ok(hipStreamWaitEvent(ctx->stream, g->ready[i], 0), "hipStreamWaitEvent");
+  bool same = true;
+  for (const TrdJob& jb : jobs) same = same && jb.a.n == jobs[0].a.n && jb.a.ldv == jobs[0].a.ldv;
+  if (rc == SCLENS_OK) {
+    if (same) {
+      rc = sytrd_run(ctx, jobs.data(), (int)jobs.size());
+    } else {
+      for (size_t i = 0; i < jobs.size() && rc == SCLENS_OK; ++i) rc = sytrd_run(ctx, &jobs[i], 1);
+    }
+  }
+  if (!g->done) hip_ok(hipEventCreateWithFlags(&g->done, hipEventDisableTiming), "hipEventCreate");
+  if (g->done) {
+    hip_ok(hipEventRecord(g->done, ctx->stream), "hipEventRecord");
+    for (const TrdJob& jb : jobs)
+      if (jb.ctx != ctx) hip_ok(hipStreamWaitEvent(jb.ctx->stream, g->done, 0), "hipStreamWaitEvent");
+  }
+  g->last_rc = rc;
+  g->last_err = ctx->err;
+  g->generation += 1;
+  g->cv.notify_all();
+  return rc;
+}
+
+static int batch_join(BatchGroup* g, Ctx* ctx, const TrdJob& job) {
+  std::unique_lock<std::mutex> lk(g->mu);
+  if (g->expected <= 1) {
+    lk.unlock();
+    return sytrd_run(ctx, &job, 1);
+  }
+  const size_t idx = g->jobs.size();
+  while (g->ready.size() <= idx) {
+    hipEvent_t ev;
+    SCL_HIP(ctx, hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+    g->ready.push_back(ev);
+  }
+  SCL_HIP(ctx, hipEventRecord(g->ready[idx], ctx->stream));
+  g->jobs.push_back(job);
+  if ((int)g->jobs.size() >= g->expected) return batch_lead(g, ctx);
+  const uint64_t gen = g->generation;
+  while (g->generation == gen) {
+    if (g->promote) return batch_lead(g, ctx);
+    if (g->cv.wait_for(lk, std::chrono::seconds(600)) == std::cv_status::timeout && g->generation == gen && !g->promote) {
+      // fail the whole round loudly: every waiter returns this error
+      g->jobs.clear();
+      g->expected = 0;
+      g->last_rc = ctx->fail(SCLENS_ERR_STATE, "sytrd_f32: batched tridiagonalisation: a participant of the round never arrived");
+      g->last_err = ctx->err;
+      g->generation += 1;
+      g->cv.notify_all();
+      return g->last_rc;
+    }
+  }
+  if (g->last_rc != SCLENS_OK) ctx->err = g->last_err;
+  return g->last_rc;
+}
+
+int sytrd_f32(Ctx* ctx, float* A, int64_t n, int64_t lda, double* d_dev, double* e_dev, float* tau_dev) {
+  if (n <= 0) return SCLENS_OK;
+  if (lda % 4 != 0 || lda < n || (reinterpret_cast<uintptr_t>(A) & 15u))
+    return ctx->fail(SCLENS_ERR_ARG, "sytrd_f32: A must be 16-byte aligned with lda a multiple of 4");
+  StageTimer tm(ctx, "sytrd");
+  TrdJob job;
+  SCL_TRY(sytrd_setup(ctx, A, n, lda, d_dev, e_dev, tau_dev, &job));
+  if (ctx->batch) return batch_join(ctx->batch, ctx, job);
+  return sytrd_run(ctx, &job, 1);
 }
 
 // Roofline probe for bench.py: every trd_colB launch of one tridiagonalisation of order n (j = 0 .. n-2, same grids and
@@ -588,7 +736,8 @@ int symv_probe(Ctx* ctx, int64_t n, int64_t* launches, double* total_ms, double*
   SCL_WS(ctx, de, double, "probe.e", n);
   SCL_WS(ctx, dt, float, "probe.tau", n);
   SCL_HIP(ctx, hipMemsetAsync(partA, 0x3c, sizeof(double) * 2 * naMax * PA_LD, ctx->stream));  // small positive finite doubles
-  TrdArgs a{A, n, lda, VWt, ldv, x, partA, naMax, partB, colinfo, rowpart, colpart, dd, de, dt, nullptr};
+  TrdBatch a{};
+  a.a[0] = TrdArgs{A, n, lda, VWt, ldv, x, partA, naMax, partB, colinfo, rowpart, colpart, dd, de, dt, nullptr, nullptr, nullptr};
   hipEvent_t e0, e1;
   SCL_HIP(ctx, hipEventCreate(&e0));
   SCL_HIP(ctx, hipEventCreate(&e1));
