@@ -83,6 +83,15 @@ int sclens_hip_get_eigen_f32(sclens_hip_ctx* ctx, const float* Y, int64_t n, flo
 /* corr_mat(X, Y; device)  (scLENS.jl:363-373): out = X' * Y, X is n x p, Y is n x q, out is p x q. */
 int sclens_hip_corr_mat_f32(sclens_hip_ctx* ctx, const float* X, int64_t n, int64_t p, const float* Y, int64_t q,
                             float* out);
+/* logn_scale(pre_scale(x))  (scLENS.jl:650-654: proj_l :607 -> log1p -> zscore_with_l2 :596-605 -> scaled_gdata "cent"
+ * :300-305 for centering="mean"; scaled_gdata "median" :291-298 -> norm_l :608 for centering="median") and, with
+ * f32path = 0 and the five rec_* vectors, the inline Float64 twin of the data matrix (scLENS.jl:676-696).
+ * Input: N x M counts as 0-based CSC (colptr[M+1], rowval, nzval). centering: 0 mean, 1 median. f32path: 1 = the closure
+ * (Float32 proj_l / log1p / std), 0 = the inline Float64 statistics. out: dense N x M, column-major, fp32.
+ * rec_*: all five (TGC[N], mat2_mean[M], mat2_std[M], norm_tgc[N], cent_[M]) or all NULL; must be NULL for median. */
+int sclens_hip_scale_csc_f32(sclens_hip_ctx* ctx, int64_t N, int64_t M, const int64_t* colptr, const int32_t* rowval,
+                             const float* nzval, int centering, int f32path, float* out, double* rec_tgc,
+                             double* rec_mat2_mean, double* rec_mat2_std, double* rec_norm_tgc, double* rec_cent);
 /* get_eigvec(X; device)  (scLENS.jl:489-524): X is N x M scaled data. nL[r] positive eigenvalues
  * descending, nV is N x r (cell-side eigenvectors, unit columns). On input *r = capacity in columns
  * (min(N,M) always suffices); on output the number of positive eigenvalues. keep_top > 0 limits the

@@ -65,7 +65,7 @@ end
 # ---- (B) device-resident sclens() --------------------------------------------------------------------------------
 csc0(X::SparseMatrixCSC) = (Int64.(X.colptr) .- 1, Int32.(X.rowval) .- Int32(1), Float32.(X.nzval))
 
-function sclens_hip(inp_df; th=60, p_step=0.001, n_perturb=20, device=0)
+function sclens_hip(inp_df; th=60, p_step=0.001, n_perturb=20, centering="mean", device=0)
     X_ = scLENS.df2sparr(inp_df)                                              # :662
     N, M = size(X_); nm = min(N, M)
     nz_row, nz_col, nz_val = findnz(X_)
@@ -82,11 +82,15 @@ function sclens_hip(inp_df; th=60, p_step=0.001, n_perturb=20, device=0)
             ctx, N, M, cp, rv, nz, length(z1), z1, z2, ses))
         s = ses[]
         try
+            median_ = centering == "median"                                  # :653-654; rec_vals stays empty there (:697-698)
+            check(ctx, ccall((:sclens_hip_session_set_int, LIB), Cint, (Ptr{Cvoid}, Cstring, Int64), s, "centering", median_ ? 1 : 0))
             L = Vector{Float64}(undef, nm); Lr = similar(L)
-            rec = Dict("TGC" => zeros(N), "mat2_mean" => zeros(M), "mat2_std" => zeros(M), "norm_tgc" => zeros(N), "cent_" => zeros(M))
+            rec = median_ ? Dict{String,Vector{Float64}}() :
+                  Dict("TGC" => zeros(N), "mat2_mean" => zeros(M), "mat2_std" => zeros(M), "norm_tgc" => zeros(N), "cent_" => zeros(M))
+            recp(k) = median_ ? Ptr{Float64}(C_NULL) : pointer(rec[k])
             GC.@preserve rcp rrv rnz L Lr rec check(ctx, ccall((:sclens_hip_session_spectrum, LIB), Cint,
                 (Ptr{Cvoid}, Ptr{Int64}, Ptr{Int32}, Ptr{Float32}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}),
-                s, rcp, rrv, rnz, L, Lr, rec["TGC"], rec["mat2_mean"], rec["mat2_std"], rec["norm_tgc"], rec["cent_"]))
+                s, rcp, rrv, rnz, L, Lr, recp("TGC"), recp("mat2_mean"), recp("mat2_std"), recp("norm_tgc"), recp("cent_")))
             L_mp, _, b_min = scLENS._mp_calculation(L, Lr[1:end-1])           # host statistics stay in Julia (:537-538)
             lambda_c, _ = scLENS._tw(L, L_mp)
             k = sum(L .> lambda_c); nL = reverse(L[L .> lambda_c])

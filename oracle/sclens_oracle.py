@@ -106,6 +106,29 @@ def logn_scale(Y: sp.csc_matrix) -> np.ndarray:
     return dense - dense.mean(axis=0, keepdims=True)
 
 
+def scaled_gdata_median(Xd: np.ndarray) -> np.ndarray:
+    """scaled_gdata(X, position_="median") on a dense Float32 matrix (scLENS.jl:291-298 dense branch, :306, :328):
+    per gene (x - median) / std, median and corrected std over all N cells, everything Float32."""
+    Xd = np.asarray(Xd, dtype=np.float32)
+    med = np.median(Xd, axis=0).astype(np.float32)  # mapslices(median, X, dims=1); even N: middle(a, b)
+    sd = Xd.std(axis=0, ddof=1, dtype=np.float32)
+    return (Xd - med[None, :]) / sd[None, :]
+
+
+def norm_l(x: np.ndarray) -> np.ndarray:
+    """norm_l, dense branch (scLENS.jl:608): every row scaled to the mean row L2 norm."""
+    l2 = np.sqrt((x * x).sum(axis=1, dtype=x.dtype))
+    return x / l2[:, None] * l2.mean(dtype=x.dtype)
+
+
+def logn_scale_median(Y: sp.csc_matrix) -> np.ndarray:
+    """`logn_scale` for centering="median" (scLENS.jl:653-654): norm_l(scaled_gdata(Matrix{Float32}(x), "median")).
+    The reference stays Float32 from here through LAPACK (ssyevr); the oracle returns the Float32-scaled matrix
+    promoted to float64 so that the Gram matrix and the eigendecomposition are the accurate ones."""
+    dense = np.asarray(Y.todense(), dtype=np.float32)
+    return norm_l(scaled_gdata_median(dense)).astype(np.float64)
+
+
 def scale_main(X: sp.csc_matrix) -> Tuple[np.ndarray, dict]:
     """Inline Float64 normalisation of the data matrix with rec_vals (scLENS.jl:676-696)."""
     X = _as_csc_f32(X)
@@ -437,8 +460,9 @@ def sclens(
     max_search_iters: Optional[int] = None,
     keep_intermediates: bool = False,
     null_tol: float = 0.0,
+    centering: str = "mean",
 ) -> Dict[str, object]:
-    """sclens(inp_df; device_="cpu", centering="mean") (scLENS.jl:649-832).
+    """sclens(inp_df; device_="cpu", centering="mean" | "median") (scLENS.jl:649-832).
 
     `X` is the cells x genes count matrix (what `df2sparr(inp_df)` returns, :662).
     `max_search_iters` is a test-only cap on the sparsity-search loop (None = reference behaviour).
@@ -451,8 +475,15 @@ def sclens(
     nz_row, nz_col, nz_val = coo.row[order].astype(np.int64), coo.col[order].astype(np.int64), coo.data[order]
     z1, z2 = draws.z_idx1, draws.z_idx2
 
-    scaled_X, rec_vals = scale_main(X_)  # :676-696
-    Xr_scaled = logn_scale(pre_scale(draws.X_r))  # :704
+    if centering == "mean":
+        ls = logn_scale  # :651-652
+        scaled_X, rec_vals = scale_main(X_)  # :676-696
+    elif centering == "median":
+        ls = logn_scale_median  # :653-654
+        scaled_X, rec_vals = ls(pre_scale(X_)), {}  # :697-698 (rec_vals stays empty)
+    else:
+        raise ValueError("centering must be 'mean' or 'median' (the reference's third scaling :655-657 is not restated)")
+    Xr_scaled = ls(pre_scale(draws.X_r))  # :704
     nL, nV, L, L_mp, lambda_c, _ = get_sigev(scaled_X, Xr_scaled)  # :704
     mpC = mp_check(L_mp)  # :706
     p_th = draws.p_th  # :709-712
@@ -460,7 +491,7 @@ def sclens(
     # ---- sparsity search (:715-762) ----
     p_ = 0.999
     binary = sp.csc_matrix((np.ones_like(nz_val), (nz_row, nz_col)), shape=(N, M), dtype=np.float32)
-    sb = logn_scale(pre_scale(binary))
+    sb = ls(pre_scale(binary))
     Vr2 = get_eigvec(sb.T if N > M else sb, null_tol)[1]  # :717-721
     n_2 = int(round(Vr2.shape[1] / 2))  # round half to even (Appendix A17)
     tank = np.zeros((5, 0))
@@ -473,7 +504,7 @@ def sclens(
             break
         idx = draws.sample("search", it, len(z1), nnzidx)
         pert = _with_ones(N, M, nz_row, nz_col, nz_val, z1, z2, idx, binary=True)
-        sp_ = logn_scale(pre_scale(pert))
+        sp_ = ls(pre_scale(pert))
         nV_2 = get_eigvec(sp_.T if N > M else sp_, null_tol)[1]  # :733-739
         C = corr_mat(Vr2, nV_2[:, nV_2.shape[1] - n_2 - 1 :])  # end-n_2:end -> n_2+1 columns (A17)
         d_arr = np.nanmax(np.abs(C), axis=0)  # :742 (A18)
@@ -495,7 +526,7 @@ def sclens(
     for t in range(n_perturb):
         idx = draws.sample("perturb", t, len(z1), m_pert)
         tmp_X = _with_ones(N, M, nz_row, nz_col, nz_val, z1, z2, idx, binary=False)
-        tL, tV = get_eigvec(logn_scale(pre_scale(tmp_X)), null_tol)
+        tL, tV = get_eigvec(ls(pre_scale(tmp_X)), null_tol)
         c = min(min_pc, tV.shape[1])
         nV_set.append(tV[:, :c])
         nL_set.append(tL[:c])

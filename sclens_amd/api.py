@@ -97,6 +97,35 @@ def get_eigvec(X, device="gpu", keep_top: int = 0, ctx: Optional[Context] = None
     return nL[:rr], nV[:, : min(rr, ncol)]
 
 
+def logn_scale(X, centering: str = "mean", inline_f64: bool = False, device="gpu", ctx: Optional[Context] = None):
+    """`logn_scale(pre_scale(x))` of scLENS.jl:650-654 (centering "mean" or "median") on the device: counts (N x M, any
+    scipy-sparse / dense) -> dense scaled N x M float32. `inline_f64=True` is the inline Float64 twin of the data matrix
+    (:676-696) and also returns rec_vals."""
+    if device != "gpu":
+        return None
+    if centering not in ("mean", "median"):
+        raise NotImplementedError(f"centering={centering!r}")
+    if inline_f64 and centering != "mean":
+        raise ValueError("the inline Float64 path with rec_vals exists for centering='mean' only (scLENS.jl:676-698)")
+    ctx = ctx or default_context()
+    Xc = _csc_f32(X)
+    N, M = Xc.shape
+    colptr = np.ascontiguousarray(Xc.indptr, dtype=np.int64)
+    rowval = np.ascontiguousarray(Xc.indices, dtype=np.int32)
+    nzval = np.ascontiguousarray(Xc.data, dtype=np.float32)
+    out = np.empty((N, M), dtype=np.float32, order="F")
+    if inline_f64:
+        rec = {"TGC": np.empty(N), "mat2_mean": np.empty(M), "mat2_std": np.empty(M), "norm_tgc": np.empty(N),
+               "cent_": np.empty(M)}
+        recp = [ptr(rec[k], C.c_double) for k in ("TGC", "mat2_mean", "mat2_std", "norm_tgc", "cent_")]
+    else:
+        rec, recp = None, [None] * 5
+    ctx.check(ctx.lib.sclens_hip_scale_csc_f32(ctx.h, N, M, ptr(colptr, C.c_int64), ptr(rowval, C.c_int32),
+                                               ptr(nzval, C.c_float), 1 if centering == "median" else 0,
+                                               0 if inline_f64 else 1, ptr(out, C.c_float), *recp))
+    return (out, rec) if inline_f64 else out
+
+
 def get_denoised_df(inp_obj: Dict[str, object], device_="gpu", ctx: Optional[Context] = None) -> np.ndarray:
     """scLENS.jl:889-931: denoised count means from the robust signals of an sclens() result (N x M array; the
     reference wraps it in a DataFrame with `gene_id` columns and a `cell` column)."""
@@ -384,8 +413,11 @@ class Session:
                                                                      ptr(nz, C.c_float), ptr(Lr, C.c_double)))
         return Lr
 
-    def data_spectrum(self):
+    def data_spectrum(self, with_rec_vals: bool = True):
         L = np.empty(self.n)
+        if not with_rec_vals:  # centering="median": the reference's rec_vals Dict stays empty (scLENS.jl:697-698)
+            self.ctx.check(self.ctx.lib.sclens_hip_session_data_spectrum(self.h, ptr(L, C.c_double), None, None, None, None, None))
+            return L, {}
         rec = {"TGC": np.empty(self.N), "mat2_mean": np.empty(self.M), "mat2_std": np.empty(self.M),
                "norm_tgc": np.empty(self.N), "cent_": np.empty(self.M)}
         self.ctx.check(self.ctx.lib.sclens_hip_session_data_spectrum(
@@ -533,8 +565,10 @@ def sclens(inp_df, device_="gpu", th=60, p_step=0.001, n_perturb=20, centering="
     """
     if device_ != "gpu":
         raise NotImplementedError("sclens_amd implements the device path only; use the reference for device_='cpu'")
-    if centering != "mean":
-        raise NotImplementedError("centering='median' is outside the hot path of this build (SURVEY 8f-4)")
+    if centering not in ("mean", "median"):
+        # the reference prints a warning and runs a third, undocumented scaling (scLENS.jl:655-657); not restated
+        raise NotImplementedError(f"centering={centering!r}: only 'mean' and 'median' are implemented")
+    median = centering == "median"
     ctx = ctx or default_context()
     shard = shard or Shard()
     t_all = time.perf_counter()
@@ -554,6 +588,7 @@ def sclens(inp_df, device_="gpu", th=60, p_step=0.001, n_perturb=20, centering="
 
     ses = Session(ctx, X_, z1, z2)
     ses.set_int("chefsi", 1 if partial_eig else 0)
+    ses.set_int("centering", 1 if median else 0)
     lap("session_create")
     try:
         # local workers: `streams` sessions on this GPU (own stream + scratch each, shared read-only data), one host
@@ -606,11 +641,11 @@ def sclens(inp_df, device_="gpu", th=60, p_step=0.001, n_perturb=20, centering="
         if W == 1:  # serial order of the reference: null and data spectra, signal vectors, then Vr2
             w_bin = ses
             Lr = ses.null_spectrum(_resolve(draws.X_r))
-            L, rec_vals = ses.data_spectrum()
+            L, rec_vals = ses.data_spectrum(not median)
             r_vr2 = None
         else:  # the main session keeps the data matrix's reflectors for signal_vectors; workers take the other two
             w_null, w_bin = workers[1], workers[2 if W >= 3 else 1]
-            (L, rec_vals), Lr, (_, r_vr2) = run_all([(0, ses.data_spectrum), (1, lambda: w_null.null_spectrum(_resolve(draws.X_r))),
+            (L, rec_vals), Lr, (_, r_vr2) = run_all([(0, lambda: ses.data_spectrum(not median)), (1, lambda: w_null.null_spectrum(_resolve(draws.X_r))),
                                                      (2 if W >= 3 else 1, w_bin.binary_basis)], lockstep=True)
         L_mp, _, b_min = _mp_calculation(L, Lr[:-1])  # Lr[1:end-1] (:537, :576)
         lambda_c = _tw(L, L_mp)[0]

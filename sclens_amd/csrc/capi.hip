@@ -30,6 +30,7 @@ int wishart_host(Ctx*, const float*, int64_t, int64_t, int, float*);
 int get_eigen_host(Ctx*, const float*, int64_t, float*, float*);
 int corr_mat_host(Ctx*, const float*, int64_t, int64_t, const float*, int64_t, float*);
 int get_eigvec_host(Ctx*, const float*, int64_t, int64_t, int64_t, float*, float*, int64_t*);
+int scale_csc_host(Ctx*, int64_t, int64_t, const int64_t*, const int32_t*, const float*, int, int, float*, ScaleVecs*);
 int denoise_host(Ctx*, const float*, int64_t, int64_t, const float*, int64_t, const double*, const double*, const double*,
                  const double*, const double*, float*);
 }  // namespace scl
@@ -126,6 +127,16 @@ int sclens_hip_get_eigen_f32(sclens_hip_ctx* h, const float* Y, int64_t n, float
 int sclens_hip_corr_mat_f32(sclens_hip_ctx* h, const float* X, int64_t n, int64_t p, const float* Y, int64_t q, float* out) {
   CTX_GUARD(h);
   return scl::corr_mat_host(&h->c, X, n, p, Y, q, out);
+}
+int sclens_hip_scale_csc_f32(sclens_hip_ctx* h, int64_t N, int64_t M, const int64_t* colptr, const int32_t* rowval,
+                             const float* nzval, int centering, int f32path, float* out, double* rec_tgc, double* rec_mean,
+                             double* rec_std, double* rec_norm, double* rec_cent) {
+  CTX_GUARD(h);
+  scl::ScaleVecs k{rec_tgc, rec_mean, rec_std, rec_norm, rec_cent};
+  const bool any = rec_tgc || rec_mean || rec_std || rec_norm || rec_cent;
+  if (any && !(rec_tgc && rec_mean && rec_std && rec_norm && rec_cent))
+    return h->c.fail(SCLENS_ERR_ARG, "scale_csc: pass all rec_* buffers or none");
+  return scl::scale_csc_host(&h->c, N, M, colptr, rowval, nzval, centering, f32path, out, any ? &k : nullptr);
 }
 int sclens_hip_get_eigvec_f32(sclens_hip_ctx* h, const float* X, int64_t N, int64_t M, int64_t keep_top, float* nL,
                               float* nV, int64_t* r) {

@@ -37,9 +37,10 @@ struct ScaleVecs {  // host destinations for rec_vals (scLENS.jl:676-696); all f
 // Dense scaled matrix from a value array over the pattern.
 //   f32path = 1 : closure path logn_scale(pre_scale(x)) (Float32 proj_l/log1p/std)
 //   f32path = 0 : inline Float64 path of the data matrix (scLENS.jl:676-696)
+//   centering = 0 : mean (zscore_with_l2 + final centring), 1 : median (scLENS.jl:653-654; no rec_vals there)
 //   cells_major = 1 : B[i*ldb + j] (N rows of M genes); 0 : B[j*ldb + i] (M rows of N cells)
-int scale_to_dense(Ctx* ctx, const PatternDev& p, const float* val, int f32path, int cells_major, float* B,
-                   int64_t ldb, ScaleVecs* keep);
+int scale_to_dense(Ctx* ctx, const PatternDev& p, const float* val, int f32path, int centering, int cells_major,
+                   float* B, int64_t ldb, ScaleVecs* keep);
 
 // val = (binary ? pattern-of-counts : counts), then 1 at the candidate slots idx_dev[0..m)
 int make_values(Ctx* ctx, const PatternDev& p, const float* base_val, int binary, const uint32_t* idx_dev, int64_t m,

@@ -5,7 +5,8 @@
 // with 2-3 N x M Float64 temporaries; here all statistics are O(nnz) passes over a fixed sparse
 // pattern (CSC + CSR views of the same entries) and the dense matrix is written exactly once:
 //     X_ij = s_i (Z_ij - mu_j) - cent_j ,   Z_ij = log1p(x_ij / TGC_i) / std_j ,  s_i = mean(l)/l_i
-// (the identity of scLENS.jl:601-603 / :688-690 for l_i). Statistics are accumulated in fp64 in a
+// (the identity of scLENS.jl:601-603 / :688-690 for l_i). centering="median" (scLENS.jl:653-654: scaled_gdata "median"
+// then norm_l :608) is the same expression with mu_j = median_j / std_j and cent = 0. Statistics are accumulated in fp64 in a
 // fixed order (deterministic); the dense output is fp32.
 //
 // The pattern is the union of the stored counts and the zero-candidate positions (scLENS.jl:668-673);
@@ -77,6 +78,74 @@ __global__ __launch_bounds__(256) void k_col_stats(PatternDev p, const float* __
     stdv[col] = sd;
     mu[col] = (s / sd) / (double)p.N;  // mean of the std-scaled column
   }
+}
+
+// ---- median centring (scLENS.jl:653-654 -> scaled_gdata(position_="median") :291-298, :328) ----------------------
+// mu_j := median_i(lg_ij) / std_j over ALL N cells (the reference densifies first, so implicit zeros count). One block
+// per gene. Sorted column = (N - nz) zeros, then the nz positives ascending: genes whose positives do not reach the
+// middle have median 0 (the usual case at 90 % sparsity); for the others the one or two middle order statistics are
+// found exactly by an MSB-first radix select on the bit pattern of the positive values (8 bits per pass, histogram in
+// LDS with integer atomics: order-independent, deterministic). Even N: mean of the two middle values (`middle`).
+__device__ __forceinline__ double radix_select_pos(const double* __restrict__ v, int64_t len, int64_t k, int* hist,
+                                                   unsigned long long* sh) {
+  // k-th smallest (0-based) among the entries v[0..len) that are > 0
+  unsigned long long prefix = 0ull, mask = 0ull;
+  for (int pass = 7; pass >= 0; --pass) {
+    for (int b = threadIdx.x; b < 256; b += blockDim.x) hist[b] = 0;
+    __syncthreads();
+    for (int64_t q = threadIdx.x; q < len; q += blockDim.x) {
+      const double x = v[q];
+      if (x > 0.0) {
+        const unsigned long long key = (unsigned long long)__double_as_longlong(x);
+        if ((key & mask) == prefix) atomicAdd(&hist[(int)((key >> (8 * pass)) & 255ull)], 1);
+      }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      int64_t cum = 0;
+      int b = 0;
+      for (; b < 255; ++b) {
+        if (cum + hist[b] > k) break;
+        cum += hist[b];
+      }
+      sh[0] = (unsigned long long)b;
+      sh[1] = (unsigned long long)(k - cum);
+    }
+    __syncthreads();
+    prefix |= sh[0] << (8 * pass);
+    mask |= 255ull << (8 * pass);
+    k = (int64_t)sh[1];
+    __syncthreads();
+  }
+  return __longlong_as_double((long long)prefix);
+}
+
+__global__ __launch_bounds__(256) void k_col_median(PatternDev p, const double* __restrict__ lg,
+                                                    const double* __restrict__ stdv, int f32path,
+                                                    double* __restrict__ mu) {
+  __shared__ int hist[256];
+  __shared__ unsigned long long sh[2];
+  __shared__ int64_t cnt_s[4];
+  const int64_t col = blockIdx.x;
+  const int64_t b = p.colptr[col], len = p.colptr[col + 1] - b;
+  int64_t nzl = 0;
+  for (int64_t q = threadIdx.x; q < len; q += 256) nzl += lg[b + q] > 0.0 ? 1 : 0;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) nzl += __shfl_xor(nzl, o);
+  if ((threadIdx.x & 63) == 0) cnt_s[threadIdx.x >> 6] = nzl;
+  __syncthreads();
+  const int64_t nz = cnt_s[0] + cnt_s[1] + cnt_s[2] + cnt_s[3];
+  const int64_t zeros = p.N - nz;
+  const int64_t r2 = p.N / 2, r1 = (p.N & 1) ? r2 : r2 - 1;  // 0-based ranks of the middle element(s)
+  double med = 0.0;
+  if (r2 >= zeros) {  // block-uniform branch
+    const double v2 = radix_select_pos(lg + b, len, r2 - zeros, hist, sh);
+    double v1 = v2;
+    if (r1 != r2) v1 = (r1 >= zeros) ? radix_select_pos(lg + b, len, r1 - zeros, hist, sh) : 0.0;
+    med = f32path ? (double)((float)v1 * 0.5f + (float)v2 * 0.5f) : 0.5 * v1 + 0.5 * v2;
+    if (r1 == r2) med = v2;
+  }
+  if (threadIdx.x == 0) mu[col] = med / stdv[col];
 }
 
 // ---- deterministic reductions of a vector: out[0] = sum(f(v)) ---------------------------------------
@@ -186,8 +255,8 @@ __global__ __launch_bounds__(256) void k_dense_scatter(PatternDev p, int cells_m
   }
 }
 
-int scale_to_dense(Ctx* ctx, const PatternDev& p, const float* val, int f32path, int cells_major, float* B,
-                   int64_t ldb, ScaleVecs* keep) {
+int scale_to_dense(Ctx* ctx, const PatternDev& p, const float* val, int f32path, int centering, int cells_major,
+                   float* B, int64_t ldb, ScaleVecs* keep) {
   StageTimer tm(ctx, "scale");
   const int64_t N = p.N, M = p.M;
   SCL_WS(ctx, tgc, double, "sc.tgc", N);
@@ -203,13 +272,19 @@ int scale_to_dense(Ctx* ctx, const PatternDev& p, const float* val, int f32path,
   hipLaunchKernelGGL(k_row_sums, dim3((unsigned)((N + 3) / 4)), dim3(256), 0, st, p, val, tgc);
   hipLaunchKernelGGL(k_col_stats, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, st, p, val, tgc, f32path, lg, mean,
                      stdv, mu);
+  if (centering == 1)  // median centring: the column offset is the median instead of the mean
+    hipLaunchKernelGGL(k_col_median, dim3((unsigned)M), dim3(256), 0, st, p, lg, stdv, f32path, mu);
   hipLaunchKernelGGL(k_reduce, dim3(1), dim3(1024), 0, st, mu, M, 0, red + 0);  // ||mu||^2
   hipLaunchKernelGGL(k_row_norms, dim3((unsigned)((N + 3) / 4)), dim3(256), 0, st, p, lg, stdv, mu, red + 0, l2);
   hipLaunchKernelGGL(k_reduce, dim3(1), dim3(1024), 0, st, l2, N, 1, red + 1);  // sum l
   hipLaunchKernelGGL(k_row_scale, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, st, l2, N, red + 1, srow);
   hipLaunchKernelGGL(k_reduce, dim3(1), dim3(1024), 0, st, srow, N, 1, red + 2);  // sum s
-  hipLaunchKernelGGL(k_col_cent, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, st, p, lg, stdv, mu, srow, red + 2,
-                     cent);
+  if (centering == 1) {  // norm_l(scaled_gdata(.,"median")) has no final centring (scLENS.jl:654)
+    SCL_HIP(ctx, hipMemsetAsync(cent, 0, sizeof(double) * M, st));
+  } else {
+    hipLaunchKernelGGL(k_col_cent, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, st, p, lg, stdv, mu, srow, red + 2,
+                       cent);
+  }
   const int64_t nr = cells_major ? N : M, nc = cells_major ? M : N;
   if (nr > 65535LL * 65535LL) return ctx->fail(SCLENS_ERR_ARG, "scale_to_dense: too many rows");
   // grid.y is limited to 65535: loop over row slabs

@@ -232,6 +232,7 @@ struct Session {
   std::vector<double> theta0; // their eigenvalues (descending)
   int64_t b0 = 0;
   int use_chefsi = 1;
+  int centering = 0;  // 0 mean, 1 median (scLENS.jl:651-654)
   int64_t chefsi_used = 0, chefsi_fallback = 0;
   float* nVt = nullptr;       // signal vectors, cell side, descending, [k][ldn]
   int64_t k = 0, ldn = 0;
@@ -309,6 +310,7 @@ int session_clone(Ctx* ctx2, Session* src, Session** out) {
   s->ctx = ctx2;
   s->N = src->N; s->M = src->M; s->n = src->n; s->K = src->K;
   s->cells_major = src->cells_major;
+  s->centering = src->centering;
   s->pat.dev = src->pat.dev;            // shared, not owned (allocs stays empty)
   s->pat.base_val = src->pat.base_val;
   s->ldb = src->ldb; s->lda = src->lda; s->ldz = src->ldz; s->ldn = src->ldn;
@@ -336,7 +338,8 @@ void session_destroy(Session* s) {
 // scaled dense matrix of `val` -> B, Gram -> A, eigenvalues -> w64/w_host
 static int decompose(Session* s, const PatternDev& p, const float* val, int f32path, float* B, float divisor,
                      ScaleVecs* keep) {
-  SCL_TRY(scale_to_dense(s->ctx, p, val, f32path, s->cells_major, B, s->ldb, keep));
+  SCL_TRY(scale_to_dense(s->ctx, p, val, s->centering ? 1 : f32path, s->centering, s->cells_major, B, s->ldb,
+                         s->centering ? nullptr : keep));
   SCL_TRY(gram_f32(s->ctx, B, s->n, s->K, s->ldb, divisor, s->A, s->lda));
   SCL_TRY(eig_values(s->ctx, s->A, s->n, s->lda, s->w64));
   return s->fetch_w();
@@ -362,6 +365,8 @@ int session_null_spectrum(Session* s, const int64_t* rc_, const int32_t* rr_, co
 int session_data_spectrum(Session* s, double* L, ScaleVecs* keep) {
   Ctx* ctx = s->ctx;
   if (!s->Bmain) return ctx->fail(SCLENS_ERR_STATE, "data_spectrum: not available on a worker session");
+  if (s->centering && keep)
+    return ctx->fail(SCLENS_ERR_ARG, "data_spectrum: centering=median has no rec_vals (scLENS.jl:697-698), pass NULL");
   SCL_TRY(make_values(ctx, s->pat.dev, s->pat.base_val, 0, nullptr, 0, s->val));
   SCL_TRY(decompose(s, s->pat.dev, s->val, 0, s->Bmain, (float)s->M, keep));
   if (L) std::copy(s->w_host.begin(), s->w_host.end(), L);
@@ -538,7 +543,7 @@ static int perturb_core(Session* s, int64_t t, int64_t min_pc, double* nL_top, i
   if (!slot) return SCLENS_ERR_OOM;
   s->ens[t] = slot;
   // get_eigvec(logn_scale(pre_scale(tmp_X))) (scLENS.jl:775): closure path, divisor size(X,2) = M
-  SCL_TRY(scale_to_dense(ctx, s->pat.dev, s->val, 1, s->cells_major, s->Btmp, s->ldb, nullptr));
+  SCL_TRY(scale_to_dense(ctx, s->pat.dev, s->val, 1, s->centering, s->cells_major, s->Btmp, s->ldb, nullptr));
   SCL_TRY(gram_f32(ctx, s->Btmp, s->n, s->K, s->ldb, (float)s->M, s->A, s->lda));
   // only the first min_pc eigenpairs are consumed (:776): subspace iteration seeded with the data matrix's vectors
   if (s->use_chefsi && s->b0 >= min_pc + 8 && s->Z0t) {
@@ -574,6 +579,12 @@ static int perturb_core(Session* s, int64_t t, int64_t min_pc, double* nL_top, i
 int session_set_int(Session* s, const char* name, int64_t value) {
   const std::string k(name ? name : "");
   if (k == "chefsi") { s->use_chefsi = value != 0; return SCLENS_OK; }
+  if (k == "centering") {  // 0 = "mean", 1 = "median" (scLENS.jl:651-654); set before the first decomposition
+    if (value != 0 && value != 1) return s->ctx->fail(SCLENS_ERR_ARG, "session_set_int: centering must be 0 or 1");
+    if (s->have_spectrum) return s->ctx->fail(SCLENS_ERR_STATE, "session_set_int: centering is fixed once the data spectrum exists");
+    s->centering = (int)value;
+    return SCLENS_OK;
+  }
   return s->ctx->fail(SCLENS_ERR_ARG, "session_set_int: unknown option " + k);
 }
 int session_get_int(Session* s, const char* name, int64_t* value) {
@@ -581,6 +592,7 @@ int session_get_int(Session* s, const char* name, int64_t* value) {
   if (k == "chefsi_used") { *value = s->chefsi_used; return SCLENS_OK; }
   if (k == "chefsi_fallback") { *value = s->chefsi_fallback; return SCLENS_OK; }
   if (k == "chefsi") { *value = s->use_chefsi; return SCLENS_OK; }
+  if (k == "centering") { *value = s->centering; return SCLENS_OK; }
   return s->ctx->fail(SCLENS_ERR_ARG, "session_get_int: unknown option " + k);
 }
 
@@ -788,6 +800,27 @@ int corr_mat_host(Ctx* ctx, const float* X, int64_t n, int64_t p, const float* Y
   g.alpha = 1.f; g.beta = 0.f; g.q_kcontig = 1; g.lower = 0; g.colabsmax = nullptr;
   SCL_TRY(gemm_f32(ctx, g));
   return download_packed(ctx, dC, q, p, ldc, out);
+}
+
+// logn_scale(pre_scale(x)) (scLENS.jl:650-654) / the inline twin of the data matrix (:676-696) as a per-call drop-in:
+// host CSC in, dense column-major N x M fp32 out.
+int scale_csc_host(Ctx* ctx, int64_t N, int64_t M, const int64_t* colptr, const int32_t* rowval, const float* nzval,
+                   int centering, int f32path, float* out, ScaleVecs* keep) {
+  if (!colptr || !rowval || !nzval || !out || N <= 0 || M <= 0) return ctx->fail(SCLENS_ERR_ARG, "scale_csc: bad arguments");
+  if (centering != 0 && centering != 1) return ctx->fail(SCLENS_ERR_ARG, "scale_csc: centering must be 0 (mean) or 1 (median)");
+  if (centering == 1 && keep) return ctx->fail(SCLENS_ERR_ARG, "scale_csc: centering=median has no rec_vals");
+  PatternOwner pr;
+  SCL_TRY(pattern_build(ctx, N, M, colptr, rowval, nzval, 0, nullptr, nullptr, &pr));
+  const int64_t ldb = round_up(N, 32);
+  float* val = static_cast<float*>(ctx->workspace("w.scval", sizeof(float) * (size_t)pr.dev.nU));
+  float* B = static_cast<float*>(ctx->workspace("w.scB", sizeof(float) * (size_t)M * ldb));
+  int rc = (val && B) ? SCLENS_OK : SCLENS_ERR_OOM;
+  if (rc == SCLENS_OK) rc = make_values(ctx, pr.dev, pr.base_val, 0, nullptr, 0, val);
+  if (rc == SCLENS_OK) rc = scale_to_dense(ctx, pr.dev, val, centering ? 1 : f32path, centering, /*cells_major=*/0, B, ldb, keep);
+  if (rc == SCLENS_OK) rc = download_packed(ctx, B, M, N, ldb, out);
+  hipStreamSynchronize(ctx->stream);
+  pattern_free(&pr);
+  return rc;
 }
 
 int get_eigvec_host(Ctx* ctx, const float* X, int64_t N, int64_t M, int64_t keep_top, float* nL, float* nV, int64_t* r) {

@@ -6,7 +6,7 @@ oracle's own outputs: they guard the oracle against regressions and give the HIP
 Each fixture stores the INPUT count matrix (CSC), every injected random draw, and the expected outputs. Eigenvectors
 are stored as |V| column signs removed by the consumer (sign-invariant comparisons only).
 
-    python tests/golden/make_golden.py
+    python tests/golden/make_golden.py [fixture names ...]
 """
 import gzip
 import os
@@ -23,9 +23,9 @@ from oracle import sclens_oracle as O  # noqa: E402
 from sclens_amd.synth import synth_counts  # noqa: E402
 
 
-def run_case(name, X, seed, n_perturb):
+def run_case(name, X, seed, n_perturb, centering="mean"):
     d = O.make_draws(X, seed, 2000)
-    res = O.sclens(X, d, n_perturb=n_perturb, keep_intermediates=True, null_tol=O.NULL_DROP)
+    res = O.sclens(X, d, n_perturb=n_perturb, keep_intermediates=True, null_tol=O.NULL_DROP, centering=centering)
     search = [idx for kind, it, idx in d.log if kind == "search"]
     pert = [idx for kind, it, idx in d.log if kind == "perturb"]
     X = sp.csc_matrix(X)
@@ -41,10 +41,12 @@ def run_case(name, X, seed, n_perturb):
         signal_evec=res["signal_evec"].astype(np.float32), p_=np.float64(res["p_"]), n_search=np.int64(res["n_search"]),
         search_trace=np.array([a for _, a in res["search_trace"]]), a_b=rob["a_b"], b_=rob["b_"], rob_score=rob["rob_score"],
         sig_id=res["sig_id"], nL_set=np.array(res["nL_set"]), mp_pass=np.bool_(res["pass"]), ks_static=np.float64(res["ks_static"]),
-        gene_basis=res["gene_basis"].astype(np.float32),
-        rec_TGC=res["rec_vals"]["TGC"], rec_mat2_mean=res["rec_vals"]["mat2_mean"], rec_mat2_std=res["rec_vals"]["mat2_std"],
-        rec_norm_tgc=res["rec_vals"]["norm_tgc"], rec_cent=res["rec_vals"]["cent_"],
+        gene_basis=res["gene_basis"].astype(np.float32), centering=np.str_(centering),
     )
+    if centering == "mean":  # centering="median" leaves rec_vals empty (scLENS.jl:697-698)
+        out.update(rec_TGC=res["rec_vals"]["TGC"], rec_mat2_mean=res["rec_vals"]["mat2_mean"],
+                   rec_mat2_std=res["rec_vals"]["mat2_std"], rec_norm_tgc=res["rec_vals"]["norm_tgc"],
+                   rec_cent=res["rec_vals"]["cent_"])
     path = os.path.join(HERE, name + ".npz")
     np.savez_compressed(path, **out)
     print(name, X.shape, "k =", len(res["signal_ev"]), "sig_id =", res["sig_id"], "S =", res["n_search"], "p_ =", res["p_"],
@@ -76,12 +78,31 @@ def known_answer_spectra():
     np.savez_compressed(os.path.join(HERE, "mp_known_answers.npz"), **out)
 
 
+def median_case_matrix(N, M):
+    """synthetic counts in which a tenth of the genes is expressed in most cells (non-zero medians)"""
+    X = synth_counts(N, M, seed=1, C=5, marker_frac=0.2, marker_sd=1.5).toarray()
+    rng = np.random.default_rng(11)
+    dg = rng.choice(M, size=M // 10, replace=False)
+    X[:, dg] += rng.poisson(2.0, size=(N, len(dg))).astype(X.dtype)
+    return sp.csc_matrix(X)
+
+
 def main():
-    run_case("synth_300x500", synth_counts(300, 500, seed=1, C=5, marker_frac=0.2, marker_sd=1.5), seed=7, n_perturb=6)
-    run_case("synth_600x250", synth_counts(600, 250, seed=1, C=5, marker_frac=0.2, marker_sd=1.5), seed=7, n_perturb=6)
-    known_answer_spectra()
+    only = set(sys.argv[1:])  # optional: names of the fixtures to (re)generate; default all
+
+    def want(name):
+        return not only or name in only
+
+    if want("synth_300x500"):
+        run_case("synth_300x500", synth_counts(300, 500, seed=1, C=5, marker_frac=0.2, marker_sd=1.5), seed=7, n_perturb=6)
+    if want("synth_600x250"):
+        run_case("synth_600x250", synth_counts(600, 250, seed=1, C=5, marker_frac=0.2, marker_sd=1.5), seed=7, n_perturb=6)
+    if want("synth_300x500_median"):
+        run_case("synth_300x500_median", median_case_matrix(300, 500), seed=7, n_perturb=5, centering="median")
+    if want("mp_known_answers"):
+        known_answer_spectra()
     ref = "/root/reference/data/Real_Zheng_data/z_data_785.csv.gz"
-    if os.path.exists(ref):
+    if want("zheng_785") and os.path.exists(ref):
         import pandas as pd
 
         df = pd.read_csv(ref)

@@ -205,3 +205,59 @@ def test_get_denoised_df(run_pair, ctx):
     # and end to end from the device result (eigenvector signs cancel in pca_n1 * gene_basis)
     got2 = api.get_denoised_df(res, ctx=ctx)
     assert np.abs(got2 - want).max() < 2e-2 * want.max()
+
+
+@pytest.mark.parametrize("N,M,dense_frac", [(151, 260, 0.0), (300, 500, 0.1), (420, 130, 0.3), (64, 40, 0.6)])
+def test_logn_scale_dropin_mean_and_median(ctx, N, M, dense_frac):
+    """sclens_hip_scale_csc_f32 (logn_scale(pre_scale(x)), scLENS.jl:650-654) against the oracle for both centrings;
+    `dense_frac` of the genes are expressed in most cells, so their medians are non-zero (odd and even N, so one and
+    two middle order statistics), and the inline Float64 twin returns the reference's rec_vals."""
+    X = synth_counts(N, M, seed=N + M, C=4, marker_frac=0.3, marker_sd=1.5).toarray()
+    rng = np.random.default_rng(5)
+    dense_genes = rng.choice(M, size=int(dense_frac * M), replace=False)
+    X[:, dense_genes] += rng.poisson(3.0, size=(N, len(dense_genes))).astype(X.dtype)
+    Xs = O._as_csc_f32(X)
+    want = O.logn_scale(O.pre_scale(Xs))
+    got = api.logn_scale(Xs, "mean", ctx=ctx)
+    assert got.shape == want.shape and got.dtype == np.float32
+    assert np.abs(got - want).max() < 2e-5 * np.abs(want).max()
+    want_m = O.logn_scale_median(O.pre_scale(Xs))
+    got_m = api.logn_scale(Xs, "median", ctx=ctx)
+    assert np.abs(got_m - want_m).max() < 2e-5 * np.abs(want_m).max()
+    if dense_frac > 0:
+        med = np.median(np.asarray(O.pre_scale(Xs).todense()), axis=0)
+        assert (med > 0).sum() >= len(dense_genes) // 2  # the radix-select branch was exercised
+    want_i, rec = O.scale_main(Xs)
+    got_i, rec_d = api.logn_scale(Xs, "mean", inline_f64=True, ctx=ctx)
+    assert np.abs(got_i - want_i).max() < 2e-6 * np.abs(want_i).max()
+    for key in ("TGC", "mat2_mean", "mat2_std", "norm_tgc", "cent_"):
+        assert np.allclose(np.ravel(rec_d[key]), np.ravel(rec[key]), rtol=1e-9, atol=1e-12), key
+
+
+@pytest.mark.parametrize("N,M", [(300, 500), (600, 250)])
+def test_sclens_median_centering(ctx, N, M):
+    """centering="median" (scLENS.jl:653-654) end to end against the oracle on the same draws."""
+    X = synth_counts(N, M, seed=1, C=5, marker_frac=0.2, marker_sd=1.5).toarray()
+    rng = np.random.default_rng(11)
+    dg = rng.choice(M, size=M // 10, replace=False)
+    X[:, dg] += rng.poisson(2.0, size=(N, len(dg))).astype(X.dtype)  # genes with non-zero medians
+    d = api.make_draws(X, seed=7, p_th_trials=300)
+    od = O.Draws(d.z_idx1, d.z_idx2, d.X_r, d.p_th, d.sampler)
+    ref = O.sclens(X, od, n_perturb=5, keep_intermediates=True, null_tol=O.NULL_DROP, centering="median")
+    res = api.sclens(X, draws=d, n_perturb=5, ctx=ctx, keep_intermediates=True, centering="median", streams=2)
+    assert res["rec_vals"] == {} and ref["rec_vals"] == {}
+    assert np.abs(res["L"] - ref["L"]).max() < 2e-4 * ref["L"].max()
+    assert abs(res["lambda_c"] - ref["lambda_c"]) < 2e-4 * ref["lambda_c"]
+    k = len(ref["signal_ev"])
+    assert len(res["signal_ev"]) == k > 0
+    assert np.allclose(res["signal_ev"], ref["signal_ev"], rtol=2e-4)
+    assert np.all(_abs_cos(res["signal_evec"], ref["signal_evec"]) > 1 - 2e-3)
+    assert res["n_search"] == ref["n_search"] and res["p_"] == ref["p_"]
+    for (p1, d1), (p2, d2) in zip(res["search_trace"], ref["search_trace"]):
+        assert p1 == p2 and np.abs(d1 - d2).max() < 3e-3
+    rr, ro = res["robustness_scores"], ref["robustness_scores"]
+    assert np.array_equal(rr["a_b"], ro["a_b"])
+    assert np.abs(rr["rob_score"] - ro["rob_score"]).max() < 3e-3
+    assert np.array_equal(res["sig_id"], ref["sig_id"])
+    with pytest.raises(NotImplementedError):
+        api.sclens(X, draws=d, ctx=ctx, centering="mode")

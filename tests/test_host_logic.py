@@ -75,12 +75,15 @@ def test_draw_generators_contract():
     assert len(np.unique(a)) == 40 and np.array_equal(a, d.sampler("search", 3, len(d.z_idx1), 40))
 
 
-def test_sclens_refuses_cpu_and_median_paths():
+def test_sclens_refuses_cpu_and_unknown_centering():
+    """No CPU fallback inside the package; the reference's undocumented third scaling (scLENS.jl:655-657) is not restated."""
     X = synth_counts(60, 90, seed=2, C=3)
     with pytest.raises(NotImplementedError):
         api.sclens(X, device_="cpu")
     with pytest.raises(NotImplementedError):
-        api.sclens(X, centering="median")
+        api.sclens(X, centering="mode")
+    with pytest.raises(NotImplementedError):
+        api.logn_scale(X, centering="mode")
 
 
 def _serial_search(d_list, p_th, p_step):

@@ -74,11 +74,12 @@ def test_mp_known_answers():
     assert (1 - par["b_plus"] / bp) ** 2 <= 1e-6
 
 
-@pytest.mark.parametrize("name", ["synth_300x500", "synth_600x250"])
+@pytest.mark.parametrize("name", ["synth_300x500", "synth_600x250", "synth_300x500_median"])
 def test_oracle_matches_golden(name):
     g, X, Xr, sampler = load_case(name)
     d = O.Draws(g["z1"], g["z2"], Xr, float(g["p_th"]), sampler)
-    res = O.sclens(X, d, n_perturb=len(g["pert_len"]), null_tol=O.NULL_DROP)
+    centering = str(g["centering"]) if "centering" in g else "mean"
+    res = O.sclens(X, d, n_perturb=len(g["pert_len"]), null_tol=O.NULL_DROP, centering=centering)
     assert np.allclose(res["L"], g["L"], rtol=1e-9, atol=1e-12)
     assert len(res["L_mp"]) == int(g["n_L_mp"])
     assert np.isclose(res["lambda_c"], float(g["lambda_c"]), rtol=1e-10)
