@@ -83,6 +83,23 @@ int sclens_hip_get_eigen_f32(sclens_hip_ctx* ctx, const float* Y, int64_t n, flo
 /* corr_mat(X, Y; device)  (scLENS.jl:363-373): out = X' * Y, X is n x p, Y is n x q, out is p x q. */
 int sclens_hip_corr_mat_f32(sclens_hip_ctx* ctx, const float* X, int64_t n, int64_t p, const float* Y, int64_t q,
                             float* out);
+/* preprocess(tmp_df; min_tp_c, min_tp_g, max_tp_c, max_tp_g, min_genes_per_cell, max_genes_per_cell, min_cells_per_gene,
+ * mito_percent, ribo_percent)  (scLENS.jl:160-236), the QC filter that precedes sclens(), on a raw count
+ * matrix given as 0-based CSC (N cells x M genes). is_mito / is_ribo: per-gene flags (the reference's regexes
+ * r"^(?i)mt-." / r"^(?i)RP[SL]." evaluated by the caller on the gene names; NULL = none). Call 1 computes the masks:
+ * keep_cell[N] (fc_idx), gene_order[0..*n_genes) = original indices of the kept genes in OUTPUT order (all-zero genes
+ * dropped, sorted by mean count ascending, ties in original order), and the sizes of the filtered matrix.
+ * *n_cells == 0 or *n_genes == 0 is the reference's "no high quality cells and genes" (returns nothing).
+ * Call 2 writes the filtered matrix (n_cells x n_genes CSC, cells renumbered in order) into caller-allocated arrays
+ * out_colptr[n_genes+1], out_rowval[nnz_out], out_nzval[nnz_out]; SCLENS_ERR_STATE without a preceding call 1. */
+int sclens_hip_preprocess_csc(sclens_hip_ctx* ctx, int64_t N, int64_t M, const int64_t* colptr, const int32_t* rowval,
+                              const float* nzval, const uint8_t* is_mito, const uint8_t* is_ribo, double min_tp_c,
+                              double min_tp_g, double max_tp_c, double max_tp_g, int64_t min_genes_per_cell,
+                              int64_t max_genes_per_cell, int64_t min_cells_per_gene, double mito_percent,
+                              double ribo_percent, uint8_t* keep_cell, int64_t* gene_order, int64_t* n_cells,
+                              int64_t* n_genes, int64_t* nnz_out);
+int sclens_hip_preprocess_gather(sclens_hip_ctx* ctx, int64_t* out_colptr, int32_t* out_rowval, float* out_nzval);
+
 /* logn_scale(pre_scale(x))  (scLENS.jl:650-654: proj_l :607 -> log1p -> zscore_with_l2 :596-605 -> scaled_gdata "cent"
  * :300-305 for centering="mean"; scaled_gdata "median" :291-298 -> norm_l :608 for centering="median") and, with
  * f32path = 0 and the five rec_* vectors, the inline Float64 twin of the data matrix (scLENS.jl:676-696).

@@ -28,6 +28,8 @@ function with_ctx(f, device::Integer=0)
     end
 end
 
+csc0(X::SparseMatrixCSC) = (Int64.(X.colptr) .- 1, Int32.(X.rowval) .- Int32(1), Float32.(X.nzval))
+
 # ---- (A) per-call drop-ins: what `device == "hip"` would do inside the five reference functions -------------------
 function _wishart_matrix(ctx, X::Matrix{Float32}; dims=1)                      # scLENS.jl:332-361
     N, M = size(X); n = dims == 2 ? M : N
@@ -62,9 +64,40 @@ function get_denoised_df(ctx, inp_obj)                                        # 
     out
 end
 
-# ---- (B) device-resident sclens() --------------------------------------------------------------------------------
-csc0(X::SparseMatrixCSC) = (Int64.(X.colptr) .- 1, Int32.(X.rowval) .- Int32(1), Float32.(X.nzval))
+# logn_scale(pre_scale(x)) (scLENS.jl:650-654) as one call: sparse counts in, dense scaled matrix out
+function logn_scale(ctx, X::SparseMatrixCSC; centering="mean")
+    N, M = size(X); cp, rv, nz = csc0(X); out = Matrix{Float32}(undef, N, M)
+    GC.@preserve cp rv nz out check(ctx, ccall((:sclens_hip_scale_csc_f32, LIB), Cint,
+        (Ptr{Cvoid}, Int64, Int64, Ptr{Int64}, Ptr{Int32}, Ptr{Float32}, Cint, Cint, Ptr{Float32}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}),
+        ctx, N, M, cp, rv, nz, centering == "median" ? 1 : 0, 1, out, C_NULL, C_NULL, C_NULL, C_NULL, C_NULL))
+    out
+end
 
+# preprocess(tmp_df; ...) (scLENS.jl:160-236): QC masks, gene order and the filtered matrix from the device
+function preprocess_hip(tmp_df; min_tp_c=0, min_tp_g=0, max_tp_c=Inf, max_tp_g=Inf, min_genes_per_cell=200,
+                        max_genes_per_cell=0, min_cells_per_gene=15, mito_percent=5., ribo_percent=0., device=0)
+    gene_name = names(tmp_df)[2:end]
+    X = SparseMatrixCSC{Float32,Int64}(scLENS.df2sparr(tmp_df)); N, M = size(X); cp, rv, nz = csc0(X)
+    mito = UInt8.(occursin.(r"^(?i)mt-.", gene_name)); ribo = UInt8.(occursin.(r"^(?i)RP[SL].", gene_name))
+    keep = zeros(UInt8, N); order = zeros(Int64, M); nc = Ref{Int64}(0); ng = Ref{Int64}(0); nnz_ = Ref{Int64}(0)
+    fin(x) = isinf(x) ? floatmax(Float64) : Float64(x)
+    with_ctx(device) do ctx
+        GC.@preserve cp rv nz mito ribo keep order check(ctx, ccall((:sclens_hip_preprocess_csc, LIB), Cint,
+            (Ptr{Cvoid}, Int64, Int64, Ptr{Int64}, Ptr{Int32}, Ptr{Float32}, Ptr{UInt8}, Ptr{UInt8}, Float64, Float64, Float64, Float64,
+             Int64, Int64, Int64, Float64, Float64, Ptr{UInt8}, Ptr{Int64}, Ref{Int64}, Ref{Int64}, Ref{Int64}),
+            ctx, N, M, cp, rv, nz, mito, ribo, fin(min_tp_c), fin(min_tp_g), fin(max_tp_c), fin(max_tp_g), min_genes_per_cell,
+            max_genes_per_cell, min_cells_per_gene, mito_percent, ribo_percent, keep, order, nc, ng, nnz_))
+        (nc[] == 0 || ng[] == 0) && (println("There is no high quality cells and genes"); return nothing)
+        ocp = Vector{Int64}(undef, ng[] + 1); orv = Vector{Int32}(undef, nnz_[]); onz = Vector{Float32}(undef, nnz_[])
+        GC.@preserve ocp orv onz check(ctx, ccall((:sclens_hip_preprocess_gather, LIB), Cint,
+            (Ptr{Cvoid}, Ptr{Int64}, Ptr{Int32}, Ptr{Float32}), ctx, ocp, orv, onz))
+        o_df = DataFrame(SparseMatrixCSC(nc[], ng[], ocp .+ 1, Int64.(orv) .+ 1, onz), gene_name[order[1:ng[]] .+ 1])
+        insertcols!(o_df, 1, :cell => tmp_df.cell[keep .== 1])
+        o_df
+    end
+end
+
+# ---- (B) device-resident sclens() --------------------------------------------------------------------------------
 function sclens_hip(inp_df; th=60, p_step=0.001, n_perturb=20, centering="mean", device=0)
     X_ = scLENS.df2sparr(inp_df)                                              # :662
     N, M = size(X_); nm = min(N, M)

@@ -572,24 +572,36 @@ def get_denoised(res: Dict[str, object]) -> np.ndarray:
 # --------------------------------------------------------------------------------------
 
 
-def preprocess_counts(X: np.ndarray, gene_names: Sequence[str]):
-    """preprocess() with default arguments on a dense count matrix (scLENS.jl:160-236).
-    Out of the hot path; here only so fixtures start from the same QC'd matrix."""
+def preprocess_counts(X, gene_names: Sequence[str], min_tp_c=0, min_tp_g=0, max_tp_c=np.inf, max_tp_g=np.inf,
+                      min_genes_per_cell=200, max_genes_per_cell=0, min_cells_per_gene=15, mito_percent=5.0,
+                      ribo_percent=0.0):
+    """preprocess(tmp_df; ...) on a cells x genes count matrix (scLENS.jl:160-236), same keyword arguments and defaults.
+    Returns (filtered matrix with genes sorted by mean count, their names, indices of the kept cells) or None
+    ("There is no high quality cells and genes", :233). The step before the hot path; also used so that
+    fixtures start from the same QC'd matrix as `example.jl`."""
     import re
 
-    X = np.asarray(X, dtype=np.float32)
+    X = np.asarray(X.todense() if sp.issparse(X) else X, dtype=np.float32)
     names = np.asarray(gene_names)
-    n_cell_counts = (X != 0).sum(axis=0)
-    gsum = X.sum(axis=0)
-    fg = (gsum > 0) & (gsum < np.inf) & (n_cell_counts >= 15)
+    n_cell_counts = (X != 0).sum(axis=0)  # :181
+    gsum = X.sum(axis=0, dtype=np.float32)
+    fg = (gsum > min_tp_g) & (gsum < max_tp_g) & (n_cell_counts >= min_cells_per_gene)  # :183-186
     n_gene_counts = (X != 0).sum(axis=1)
-    csum = X.sum(axis=1)
-    mito = np.array([bool(re.match(r"(?i)^mt-.", g)) for g in names])
-    b4 = (X[:, mito].sum(axis=1) / csum) < 0.05
-    fc = (csum > 0) & (csum < np.inf) & (n_gene_counts >= 200) & b4
+    csum = X.sum(axis=1, dtype=np.float32)
+    mito = np.array([bool(re.match(r"(?i)^mt-.", g)) for g in names])  # :194
+    ribo = np.array([bool(re.match(r"(?i)^RP[SL].", g)) for g in names])  # :195
+    with np.errstate(invalid="ignore", divide="ignore"):  # Float32 ratio compared in Float64 (Julia promotion)
+        b4 = np.ones(len(csum), bool) if mito_percent == 0 else \
+            (X[:, mito].sum(axis=1, dtype=np.float32) / csum).astype(np.float64) < mito_percent / 100
+        b5 = np.ones(len(csum), bool) if ribo_percent == 0 else \
+            (X[:, ribo].sum(axis=1, dtype=np.float32) / csum).astype(np.float64) < ribo_percent / 100
+    b6 = np.ones(len(csum), bool) if max_genes_per_cell == 0 else n_gene_counts < max_genes_per_cell
+    fc = (csum > min_tp_c) & (csum < max_tp_c) & (n_gene_counts >= min_genes_per_cell) & b4 & b5 & b6  # :215
+    if not (fc.any() and fg.any()):
+        return None
     oo = X[fc][:, fg]
-    nn = oo.sum(axis=0) != 0
+    nn = oo.sum(axis=0, dtype=np.float32) != 0  # :219
     oo = oo[:, nn]
     g = names[fg][nn]
-    s = np.argsort(oo.mean(axis=0), kind="stable")
-    return oo[:, s], g[s], np.flatnonzero(fc)
+    s_idx = np.argsort(oo.mean(axis=0, dtype=np.float32), kind="stable")  # :223
+    return oo[:, s_idx], g[s_idx], np.flatnonzero(fc)

@@ -18,8 +18,8 @@ c_f32p = C.POINTER(C.c_float)
 c_f64p = C.POINTER(C.c_double)
 c_i64p = C.POINTER(C.c_int64)
 c_i32p = C.POINTER(C.c_int32)
-c_u32p = C.POINTER(C.c_uint32)
 c_u8p = C.POINTER(C.c_uint8)
+c_u32p = C.POINTER(C.c_uint32)
 vp = C.c_void_p
 i64 = C.c_int64
 
@@ -49,6 +49,10 @@ SIGNATURES = {
     "sclens_hip_wishart_matrix_f32": (C.c_int, [vp, c_f32p, i64, i64, C.c_int, c_f32p]),
     "sclens_hip_get_eigen_f32": (C.c_int, [vp, c_f32p, i64, c_f32p, c_f32p]),
     "sclens_hip_corr_mat_f32": (C.c_int, [vp, c_f32p, i64, i64, c_f32p, i64, c_f32p]),
+    "sclens_hip_preprocess_csc": (C.c_int, [vp, i64, i64, c_i64p, c_i32p, c_f32p, c_u8p, c_u8p, C.c_double, C.c_double, C.c_double,
+                                            C.c_double, i64, i64, i64, C.c_double, C.c_double, c_u8p, c_i64p, c_i64p, c_i64p,
+                                            c_i64p]),
+    "sclens_hip_preprocess_gather": (C.c_int, [vp, c_i64p, c_i32p, c_f32p]),
     "sclens_hip_scale_csc_f32": (C.c_int, [vp, i64, i64, c_i64p, c_i32p, c_f32p, C.c_int, C.c_int, c_f32p, c_f64p, c_f64p, c_f64p,
                                            c_f64p, c_f64p]),
     "sclens_hip_get_eigvec_f32": (C.c_int, [vp, c_f32p, i64, i64, i64, c_f32p, c_f32p, c_i64p]),

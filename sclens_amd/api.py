@@ -97,6 +97,47 @@ def get_eigvec(X, device="gpu", keep_top: int = 0, ctx: Optional[Context] = None
     return nL[:rr], nV[:, : min(rr, ncol)]
 
 
+def preprocess(X, gene_names, cell_names=None, min_tp_c=0, min_tp_g=0, max_tp_c=np.inf, max_tp_g=np.inf,
+               min_genes_per_cell=200, max_genes_per_cell=0, min_cells_per_gene=15, mito_percent=5.0, ribo_percent=0.0,
+               ctx: Optional[Context] = None):
+    """scLENS.preprocess (scLENS.jl:160-236) on the device: QC-filter a raw cells x genes count matrix. Same keyword
+    arguments and defaults as the reference. Returns (filtered CSC float32 with genes sorted by mean count, gene names,
+    cell names or indices) or None when no cell or gene passes (the reference prints a message and returns nothing)."""
+    import re
+
+    ctx = ctx or default_context()
+    Xc = _csc_f32(X)
+    N, M = Xc.shape
+    names = np.asarray(gene_names)
+    if len(names) != M:
+        raise ValueError("gene_names must have one entry per column")
+    is_mito = np.array([bool(re.match(r"(?i)^mt-.", str(g))) for g in names], dtype=np.uint8)  # :194
+    is_ribo = np.array([bool(re.match(r"(?i)^RP[SL].", str(g))) for g in names], dtype=np.uint8)  # :195
+    colptr = np.ascontiguousarray(Xc.indptr, dtype=np.int64)
+    rowval = np.ascontiguousarray(Xc.indices, dtype=np.int32)
+    nzval = np.ascontiguousarray(Xc.data, dtype=np.float32)
+    keep_cell = np.zeros(N, dtype=np.uint8)
+    order = np.zeros(M, dtype=np.int64)
+    nc, ng, nnz = C.c_int64(0), C.c_int64(0), C.c_int64(0)
+    big = 1.7976931348623157e308  # Inf thresholds cross the C ABI as finite doubles compare the same way
+    ctx.check(ctx.lib.sclens_hip_preprocess_csc(
+        ctx.h, N, M, ptr(colptr, C.c_int64), ptr(rowval, C.c_int32), ptr(nzval, C.c_float), ptr(is_mito, C.c_uint8),
+        ptr(is_ribo, C.c_uint8), float(min_tp_c), float(min_tp_g), float(min(max_tp_c, big)), float(min(max_tp_g, big)),
+        int(min_genes_per_cell), int(max_genes_per_cell), int(min_cells_per_gene), float(mito_percent), float(ribo_percent),
+        ptr(keep_cell, C.c_uint8), ptr(order, C.c_int64), C.byref(nc), C.byref(ng), C.byref(nnz)))
+    if nc.value == 0 or ng.value == 0:
+        return None
+    out_colptr = np.empty(ng.value + 1, dtype=np.int64)
+    out_row = np.empty(nnz.value, dtype=np.int32)
+    out_val = np.empty(nnz.value, dtype=np.float32)
+    ctx.check(ctx.lib.sclens_hip_preprocess_gather(ctx.h, ptr(out_colptr, C.c_int64), ptr(out_row, C.c_int32),
+                                                   ptr(out_val, C.c_float)))
+    Xo = sp.csc_matrix((out_val, out_row, out_colptr), shape=(nc.value, ng.value))
+    Xo._sclens_canonical = True  # sorted rows, no explicit zeros, float32
+    cells = np.flatnonzero(keep_cell)
+    return Xo, names[order[: ng.value]], (np.asarray(cell_names)[cells] if cell_names is not None else cells)
+
+
 def logn_scale(X, centering: str = "mean", inline_f64: bool = False, device="gpu", ctx: Optional[Context] = None):
     """`logn_scale(pre_scale(x))` of scLENS.jl:650-654 (centering "mean" or "median") on the device: counts (N x M, any
     scipy-sparse / dense) -> dense scaled N x M float32. `inline_f64=True` is the inline Float64 twin of the data matrix

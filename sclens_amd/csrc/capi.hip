@@ -128,6 +128,22 @@ int sclens_hip_corr_mat_f32(sclens_hip_ctx* h, const float* X, int64_t n, int64_
   CTX_GUARD(h);
   return scl::corr_mat_host(&h->c, X, n, p, Y, q, out);
 }
+int sclens_hip_preprocess_csc(sclens_hip_ctx* h, int64_t N, int64_t M, const int64_t* colptr, const int32_t* rowval,
+                              const float* nzval, const uint8_t* is_mito, const uint8_t* is_ribo, double min_tp_c,
+                              double min_tp_g, double max_tp_c, double max_tp_g, int64_t min_genes_per_cell,
+                              int64_t max_genes_per_cell, int64_t min_cells_per_gene, double mito_percent,
+                              double ribo_percent, uint8_t* keep_cell, int64_t* gene_order, int64_t* n_cells,
+                              int64_t* n_genes, int64_t* nnz_out) {
+  CTX_GUARD(h);
+  const scl::PpParams P{min_tp_c, min_tp_g, max_tp_c, max_tp_g, min_genes_per_cell, max_genes_per_cell, min_cells_per_gene,
+                        mito_percent, ribo_percent};
+  return scl::preprocess_stats(&h->c, N, M, colptr, rowval, nzval, is_mito, is_ribo, P, keep_cell, gene_order, n_cells,
+                               n_genes, nnz_out);
+}
+int sclens_hip_preprocess_gather(sclens_hip_ctx* h, int64_t* out_colptr, int32_t* out_rowval, float* out_nzval) {
+  CTX_GUARD(h);
+  return scl::preprocess_gather(&h->c, out_colptr, out_rowval, out_nzval);
+}
 int sclens_hip_scale_csc_f32(sclens_hip_ctx* h, int64_t N, int64_t M, const int64_t* colptr, const int32_t* rowval,
                              const float* nzval, int centering, int f32path, float* out, double* rec_tgc, double* rec_mean,
                              double* rec_std, double* rec_norm, double* rec_cent) {

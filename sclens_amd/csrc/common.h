@@ -29,6 +29,11 @@ struct Ctx {
   std::vector<hipEvent_t> prof_ev;   // pairs (start, stop) recorded on `stream`
   size_t prof_used = 0;
   double prof_bytes = 0.0;           // algorithmic bytes of the recorded launches
+  // state between the two calls of the QC filter (preprocess.hip)
+  struct PpState {
+    bool valid = false;
+    int64_t N = 0, M = 0, n_cells = 0, n_genes = 0, nnz_out = 0;
+  } pp;
   // lock-step batching of tridiagonalisations that run concurrently on several contexts (tridiag.hip); not owned
   struct BatchGroup* batch = nullptr;
 
@@ -133,6 +138,15 @@ int stein_f64(Ctx* ctx, const double* d_dev, const double* e_dev, int64_t n, con
 int ormtr_f32(Ctx* ctx, const float* A, int64_t n, int64_t lda, const float* tau_dev, float* Zt,
               int64_t m, int64_t ldz);
 
+struct PpParams {  // keyword arguments of preprocess (scLENS.jl:160-162)
+  double min_tp_c, min_tp_g, max_tp_c, max_tp_g;
+  int64_t min_genes_per_cell, max_genes_per_cell, min_cells_per_gene;
+  double mito_percent, ribo_percent;
+};
+int preprocess_stats(Ctx* ctx, int64_t N, int64_t M, const int64_t* colptr, const int32_t* rowval, const float* nzval,
+                     const uint8_t* is_mito, const uint8_t* is_ribo, const PpParams& P, uint8_t* keep_cell,
+                     int64_t* gene_order, int64_t* n_cells, int64_t* n_genes, int64_t* nnz_out);
+int preprocess_gather(Ctx* ctx, int64_t* out_colptr, int32_t* out_rowval, float* out_nzval);
 BatchGroup* batch_create();
 void batch_destroy(BatchGroup* g);
 void batch_expect(BatchGroup* g, int count);

@@ -113,3 +113,26 @@ def test_random_nz_keeps_column_counts_and_values():
     assert np.all(X[z1.astype(int), z2.astype(int)] == 0)
     key = z1.astype(np.int64) + z2.astype(np.int64) * X.shape[0]
     assert len(np.unique(key)) == len(key)
+
+
+def test_preprocess_counts_hand_case():
+    """preprocess (scLENS.jl:160-236) on a matrix small enough to filter by hand."""
+    #            g0  MT-a g2  g3  RPS1
+    X = np.array([[1, 0, 2, 0, 1],   # c0: 3 genes, total 4, mito 0 %, ribo 25 %
+                  [3, 4, 1, 0, 0],   # c1: 3 genes, total 8, mito 50 %           -> dropped by mito_percent=30
+                  [0, 0, 0, 0, 0],   # c2: empty                                 -> dropped (total > 0 fails)
+                  [2, 1, 0, 0, 5],   # c3: 3 genes, total 8, mito 12.5 %
+                  [1, 0, 1, 0, 0]],  # c4: 2 genes                               -> dropped by min_genes_per_cell=3
+                 dtype=np.float32)
+    names = ["g0", "MT-a", "g2", "g3", "RPS1"]
+    out = O.preprocess_counts(X, names, min_genes_per_cell=3, min_cells_per_gene=2, mito_percent=30.0)
+    Xf, genes, cells = out
+    assert list(cells) == [0, 3]
+    # genes kept on the FULL matrix: g0 (4 cells), MT-a (2), g2 (3), RPS1 (2); g3 never expressed. Over the kept cells:
+    # means g0 1.5, MT-a 0.5, g2 1.0, RPS1 3.0 -> ascending order MT-a, g2, g0, RPS1
+    assert list(genes) == ["MT-a", "g2", "g0", "RPS1"]
+    assert np.array_equal(Xf, np.array([[0, 2, 1, 1], [1, 0, 2, 5]], dtype=np.float32))
+    assert O.preprocess_counts(X, names) is None  # defaults (>= 200 genes per cell): nothing passes
+    # ribosomal filter (:204-208): c0 has 25 % ribosomal counts, c3 62.5 %
+    out = O.preprocess_counts(X, names, min_genes_per_cell=3, min_cells_per_gene=2, mito_percent=30.0, ribo_percent=30.0)
+    assert list(out[2]) == [0]
