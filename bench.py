@@ -142,7 +142,7 @@ def main():
 
     def one_step(step):
         t_d = time.perf_counter()
-        draws = api.make_draws_native(X, seed=1000 + step, async_null=True)
+        draws = api.make_draws_native(X, seed=1000 + step, async_null=True, async_candidates=True)
         one_step.draws_s = time.perf_counter() - t_d  # R1-R3 inside the timed region; R4/R5 on the device inside sclens()
         return api.sclens(X, draws=draws, ctx=ctx, n_perturb=args.n_perturb, shard=shard, streams=args.streams,
                           batch=args.batch, verbose=args.verbose and rank == 0)

@@ -162,6 +162,19 @@ void sclens_hip_session_destroy(sclens_hip_session* s);
  * null_spectrum, binary_basis, search_step*, perturb*, export_slot. Destroy it before `src`. Lets two independent decompositions overlap on one GPU (one host thread each). */
 int sclens_hip_session_clone(sclens_hip_ctx* ctx2, sclens_hip_session* src, sclens_hip_session** out);
 
+/* Late candidate attachment. The data / null / binarised decompositions (scLENS.jl:676-721) do not involve the zero
+ * candidates, so a session may be created with n_cand = 0 and start them at once, while the host still draws the
+ * candidates (:668-673) and merges them into the sparse pattern: sclens_hip_pattern_create builds the union pattern
+ * (counts + candidates; host work + one upload on `ctx`'s stream, any context of the device, thread-safe w.r.t. work on
+ * other contexts); sclens_hip_session_set_pattern hands it to the idle owner session (which takes ownership: the handle
+ * is empty afterwards and only needs sclens_hip_pattern_destroy); worker clones then call session_adopt(what = 4). */
+typedef struct sclens_hip_pattern sclens_hip_pattern;
+int sclens_hip_pattern_create(sclens_hip_ctx* ctx, int64_t N, int64_t M, const int64_t* colptr, const int32_t* rowval,
+                              const float* nzval, int64_t n_cand, const uint32_t* z_idx1, const uint32_t* z_idx2,
+                              sclens_hip_pattern** out);
+void sclens_hip_pattern_destroy(sclens_hip_pattern* p);
+int sclens_hip_session_set_pattern(sclens_hip_session* s, sclens_hip_pattern* p);
+
 /* First half of get_sigev (scLENS.jl:526-537, :569-576): eigenvalues (ascending, length min(N,M)) of the
  * Gram matrix of the scaled data (L) and of the scaled null matrix X_r (Lr; CSC, same shape).
  * rec_* receive rec_vals (scLENS.jl:676-696); any of them may be NULL. */
@@ -175,7 +188,8 @@ int sclens_hip_session_null_spectrum(sclens_hip_session* s, const int64_t* r_col
 int sclens_hip_session_data_spectrum(sclens_hip_session* s, double* L, double* rec_tgc, double* rec_mat2_mean,
                                      double* rec_mat2_std, double* rec_norm_tgc, double* rec_cent);
 /* Share read-only device results between sessions of one GPU: what = 1 Vr2 (after binary_basis on src), 2 the seed
- * block of the partial eigensolver (after signal_vectors on src), 3 both. `src` must outlive `dst`'s use of them. */
+ * block of the partial eigensolver (after signal_vectors on src), 4 the sparse pattern (after set_pattern on src);
+ * flags may be or-ed. `src` must outlive `dst`'s use of them. */
 int sclens_hip_session_adopt(sclens_hip_session* dst, sclens_hip_session* src, int what);
 /* Second half (scLENS.jl:541-558, :580-590): cell-side eigenvectors of the k largest eigenvalues,
  * descending; nV is N x k (may be NULL: they also stay on the device for the later steps). */

@@ -335,7 +335,18 @@ def _resolve(x):
 _draw_pool = ThreadPoolExecutor(max_workers=2)
 
 
-def make_draws_native(X, seed: int, host_sampler: bool = False, async_null: bool = False) -> Draws:
+class _FutureItem:
+    """item `i` of a future's tuple result, resolved by `_resolve`"""
+
+    def __init__(self, fut, i):
+        self.fut, self.i = fut, i
+
+    def result(self):
+        return self.fut.result()[self.i]
+
+
+def make_draws_native(X, seed: int, host_sampler: bool = False, async_null: bool = False,
+                      async_candidates: bool = False) -> Draws:
     """All draws from the library's own generators (C++ on the host for R1/R2, the exact expectation for R3 --
     the quantity scLENS.jl:709-712 estimates with 5000 Monte-Carlo trials -- and the device-side keyed permutation
     for R4/R5). `host_sampler=True` materialises the identical R4/R5 index vectors on the host instead."""
@@ -345,14 +356,24 @@ def make_draws_native(X, seed: int, host_sampler: bool = False, async_null: bool
     cp = np.ascontiguousarray(X.indptr, dtype=np.int64)
     rv = np.ascontiguousarray(X.indices, dtype=np.int32)
     nz = np.ascontiguousarray(X.data, dtype=np.float32)
-    z1 = np.empty(X.nnz, dtype=np.uint32)
-    z2 = np.empty(X.nnz, dtype=np.uint32)
-    cnt = C.c_int64(0)
-    rc = lib.sclens_draw_zero_candidates(N, M, ptr(cp, C.c_int64), ptr(rv, C.c_int32), int(seed) & _M64, ptr(z1, C.c_uint32),
-                                         ptr(z2, C.c_uint32), C.byref(cnt))
-    if rc:
-        raise SclensHipError(rc, "sclens_draw_zero_candidates")
-    z1, z2 = z1[: cnt.value].copy(), z2[: cnt.value].copy()
+
+    def candidates():
+        z1 = np.empty(X.nnz, dtype=np.uint32)
+        z2 = np.empty(X.nnz, dtype=np.uint32)
+        cnt = C.c_int64(0)
+        rc = lib.sclens_draw_zero_candidates(N, M, ptr(cp, C.c_int64), ptr(rv, C.c_int32), int(seed) & _M64,
+                                             ptr(z1, C.c_uint32), ptr(z2, C.c_uint32), C.byref(cnt))
+        if rc:
+            raise SclensHipError(rc, "sclens_draw_zero_candidates")
+        return z1[: cnt.value].copy(), z2[: cnt.value].copy()
+
+    # async_candidates: the candidate list is only needed once the sparsity search starts (sclens() attaches it to the
+    # session after the first three decompositions), so it can be drawn on a host thread meanwhile
+    if async_candidates:
+        zf = _draw_pool.submit(candidates)
+        z1, z2 = _FutureItem(zf, 0), _FutureItem(zf, 1)
+    else:
+        z1, z2 = candidates()
 
     def null_matrix():
         rrow = np.empty(X.nnz, dtype=np.int32)
@@ -390,18 +411,48 @@ def make_draws(X, seed: int, p_th_trials: int = 5000) -> Draws:
 
 
 # ----------------------------------------------------------------------------- session wrapper
+class Pattern:
+    """sclens_hip_pattern: the sparse pattern counts + zero candidates, built (host) and uploaded on `ctx`'s stream."""
+
+    def __init__(self, ctx: Context, X: sp.csc_matrix, z1: np.ndarray, z2: np.ndarray):
+        self.ctx = ctx
+        colptr = np.ascontiguousarray(X.indptr, dtype=np.int64)
+        rowval = np.ascontiguousarray(X.indices, dtype=np.int32)
+        nzval = np.ascontiguousarray(X.data, dtype=np.float32)
+        z1 = np.ascontiguousarray(z1, dtype=np.uint32)
+        z2 = np.ascontiguousarray(z2, dtype=np.uint32)
+        self.ncand = int(z1.size)
+        h = C.c_void_p()
+        ctx.check(ctx.lib.sclens_hip_pattern_create(ctx.h, X.shape[0], X.shape[1], ptr(colptr, C.c_int64),
+                                                    ptr(rowval, C.c_int32), ptr(nzval, C.c_float), self.ncand,
+                                                    ptr(z1, C.c_uint32), ptr(z2, C.c_uint32), C.byref(h)))
+        self.h = h
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.ctx.lib.sclens_hip_pattern_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 class Session:
     """Device-resident state of one sclens() call (include/sclens_hip.h, part B)."""
 
-    def __init__(self, ctx: Context, X: sp.csc_matrix, z1: np.ndarray, z2: np.ndarray):
+    def __init__(self, ctx: Context, X: sp.csc_matrix, z1: Optional[np.ndarray] = None, z2: Optional[np.ndarray] = None):
+        """z1/z2 = None: counts only; the candidates are attached later with set_pattern (see Pattern)."""
         self.ctx = ctx
         self.N, self.M = X.shape
         self.n = min(X.shape)
         colptr = np.ascontiguousarray(X.indptr, dtype=np.int64)
         rowval = np.ascontiguousarray(X.indices, dtype=np.int32)
         nzval = np.ascontiguousarray(X.data, dtype=np.float32)
-        z1 = np.ascontiguousarray(z1, dtype=np.uint32)
-        z2 = np.ascontiguousarray(z2, dtype=np.uint32)
+        z1 = np.ascontiguousarray(z1 if z1 is not None else [], dtype=np.uint32)
+        z2 = np.ascontiguousarray(z2 if z2 is not None else [], dtype=np.uint32)
         self.ncand = int(z1.size)
         h = C.c_void_p()
         ctx.check(ctx.lib.sclens_hip_session_create(ctx.h, self.N, self.M, ptr(colptr, C.c_int64), ptr(rowval, C.c_int32),
@@ -419,6 +470,11 @@ class Session:
             self.close()
         except Exception:
             pass
+
+    def set_pattern(self, pat: "Pattern"):
+        """Attach the union pattern (counts + zero candidates) built by `Pattern`; the session must be idle."""
+        self.ctx.check(self.ctx.lib.sclens_hip_session_set_pattern(self.h, pat.h))
+        self.ncand = pat.ncand
 
     def clone(self, ctx2: Context) -> "Session":
         """Worker session on another context (stream) of the same GPU, sharing the read-only device data."""
@@ -617,7 +673,6 @@ def sclens(inp_df, device_="gpu", th=60, p_step=0.001, n_perturb=20, centering="
     N, M = X_.shape
     if draws is None:
         draws = make_draws_native(X_, seed if seed is not None else int(time.time_ns() % (2**31)))
-    z1, z2 = draws.z_idx1, draws.z_idx2
     phase = {}
     t_ph = time.perf_counter()
 
@@ -627,10 +682,22 @@ def sclens(inp_df, device_="gpu", th=60, p_step=0.001, n_perturb=20, centering="
         phase[name] = phase.get(name, 0.0) + (now - t_ph)
         t_ph = now
 
-    ses = Session(ctx, X_, z1, z2)
+    # The session starts with the counts only: the data / null / binarised decompositions (:676-721) do not involve the
+    # zero candidates. Meanwhile a host thread resolves the candidate draw (:668-673) and builds + uploads the union
+    # pattern on an auxiliary context; it is attached before the sparsity search.
+    ses = Session(ctx, X_)
     ses.set_int("chefsi", 1 if partial_eig else 0)
     ses.set_int("centering", 1 if median else 0)
     lap("session_create")
+    aux_ctx = Context(ctx.device)
+    aux_pool = ThreadPoolExecutor(max_workers=1)
+
+    def build_pattern():
+        z1_, z2_ = _resolve(draws.z_idx1), _resolve(draws.z_idx2)
+        return Pattern(aux_ctx, X_, z1_, z2_), z1_, z2_
+
+    pat_future = aux_pool.submit(build_pattern)
+    pat = None
     try:
         # local workers: `streams` sessions on this GPU (own stream + scratch each, shared read-only data), one host
         # thread per session (ctypes releases the GIL), so independent decompositions overlap on the device
@@ -698,14 +765,18 @@ def sclens(inp_df, device_="gpu", th=60, p_step=0.001, n_perturb=20, centering="
         nV = ses.signal_vectors(k)
         if r_vr2 is None:
             _, r_vr2 = ses.binary_basis()
-        for w in workers:  # share Vr2 (from w_bin) and the seed block of the partial eigensolver (from ses)
+        lap("spectra_signal_vectors_vr2")
+        pat, z1, z2 = pat_future.result()
+        ses.set_pattern(pat)
+        for w in workers:  # share Vr2 (from w_bin), the seed block of the partial eigensolver and the pattern (from ses)
             if w is not w_bin:
                 w.adopt(w_bin, 1)
             if w is not ses:
-                w.adopt(ses, 2)
+                w.adopt(ses, 2 | 4)
+                w.ncand = ses.ncand
         mpC = mp_check(L_mp)  # :706
         p_th = draws.p_th  # :709-712
-        lap("spectra_signal_vectors_vr2")
+        lap("attach_candidates")
         # ---- sparsity search (:715-762); world x W consecutive p_ values are evaluated per round
         n_2 = int(round(r_vr2 / 2))  # :722
         p_list = search_schedule(p_step)
@@ -816,4 +887,13 @@ def sclens(inp_df, device_="gpu", th=60, p_step=0.001, n_perturb=20, centering="
         res["wall_s"] = time.perf_counter() - t_all
         return res
     finally:
+        try:
+            if pat is None:  # failed before the pattern was attached: let the builder finish, then drop its result
+                pat = pat_future.result()[0]
+        except Exception:
+            pat = None
+        aux_pool.shutdown(wait=True)
         ses.close()
+        if pat is not None:
+            pat.close()
+        aux_ctx.close()

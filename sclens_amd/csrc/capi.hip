@@ -12,6 +12,10 @@ int session_spectrum(Session*, const int64_t*, const int32_t*, const float*, dou
 int session_null_spectrum(Session*, const int64_t*, const int32_t*, const float*, double*);
 int session_data_spectrum(Session*, double*, ScaleVecs*);
 int session_adopt(Session*, Session*, int);
+int pattern_create(Ctx*, int64_t, int64_t, const int64_t*, const int32_t*, const float*, int64_t, const uint32_t*,
+                   const uint32_t*, PatternOwner**);
+void pattern_destroy(PatternOwner*);
+int session_set_pattern(Session*, PatternOwner*);
 int session_signal_vectors(Session*, int64_t, float*);
 int session_binary_basis(Session*, double*, int64_t*);
 int session_search_step(Session*, const uint32_t*, int64_t, int64_t, double*, int64_t*);
@@ -229,6 +233,22 @@ int sclens_hip_session_data_spectrum(sclens_hip_session* w, double* L, double* r
   if (any && !(rec_tgc && rec_mean && rec_std && rec_norm && rec_cent))
     return w->ctx->c.fail(SCLENS_ERR_ARG, "data_spectrum: pass all rec_* buffers or none");
   return scl::session_data_spectrum(w->s, L, any ? &k : nullptr);
+}
+int sclens_hip_pattern_create(sclens_hip_ctx* h, int64_t N, int64_t M, const int64_t* colptr, const int32_t* rowval,
+                              const float* nzval, int64_t n_cand, const uint32_t* z1, const uint32_t* z2,
+                              sclens_hip_pattern** out) {
+  CTX_GUARD(h);
+  if (!out) return SCLENS_ERR_ARG;
+  scl::PatternOwner* p = nullptr;
+  const int rc = scl::pattern_create(&h->c, N, M, colptr, rowval, nzval, n_cand, z1, z2, &p);
+  if (rc == SCLENS_OK) *out = reinterpret_cast<sclens_hip_pattern*>(p);
+  return rc;
+}
+void sclens_hip_pattern_destroy(sclens_hip_pattern* p) { scl::pattern_destroy(reinterpret_cast<scl::PatternOwner*>(p)); }
+int sclens_hip_session_set_pattern(sclens_hip_session* w, sclens_hip_pattern* p) {
+  SES_GUARD(w);
+  if (!p) return SCLENS_ERR_ARG;
+  return scl::session_set_pattern(w->s, reinterpret_cast<scl::PatternOwner*>(p));
 }
 int sclens_hip_session_adopt(sclens_hip_session* dst, sclens_hip_session* src, int what) {
   SES_GUARD(dst);

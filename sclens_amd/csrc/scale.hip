@@ -317,11 +317,11 @@ __global__ void k_val_init(const float* __restrict__ base, int64_t nU, int binar
     out[q] = binary ? (b != 0.f ? 1.f : 0.f) : b;
   }
 }
-// out[cand_pos[idx[t]]] = 1
+// out[cand_pos[idx[t]]] = 1 (indices >= ncand are ignored rather than dereferenced)
 __global__ void k_val_set_ones(const uint32_t* __restrict__ idx, int64_t m, const int64_t* __restrict__ cand_pos,
-                               float* __restrict__ out) {
+                               int64_t ncand, float* __restrict__ out) {
   const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (t < m) out[cand_pos[idx[t]]] = 1.f;
+  if (t < m && (int64_t)idx[t] < ncand) out[cand_pos[idx[t]]] = 1.f;
 }
 
 int make_values(Ctx* ctx, const PatternDev& p, const float* base_val, int binary, const uint32_t* idx_dev, int64_t m,
@@ -330,7 +330,7 @@ int make_values(Ctx* ctx, const PatternDev& p, const float* base_val, int binary
                      binary, out);
   if (m > 0)
     hipLaunchKernelGGL(k_val_set_ones, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, ctx->stream, idx_dev, m,
-                       p.cand_pos, out);
+                       p.cand_pos, p.ncand, out);
   SCL_HIP(ctx, hipGetLastError());
   return SCLENS_OK;
 }

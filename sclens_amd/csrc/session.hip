@@ -107,7 +107,9 @@ static int upload(Ctx* ctx, PatternOwner* o, const std::vector<T>& h, const T** 
   hipError_t e = hipMalloc(&p, bytes);
   if (e != hipSuccess) return ctx->fail(SCLENS_ERR_OOM, std::string("pattern upload: ") + hipGetErrorString(e));
   o->allocs.push_back(p);
-  if (!h.empty()) SCL_HIP(ctx, hipMemcpy(p, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice));
+  // on the context's own stream (pattern_build synchronises it before the host vectors die): a pattern may be built
+  // on an auxiliary context while other contexts run decompositions, and must not serialise with them
+  if (!h.empty()) SCL_HIP(ctx, hipMemcpyAsync(p, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice, ctx->stream));
   *dev = static_cast<const T*>(p);
   return SCLENS_OK;
 }
@@ -189,6 +191,7 @@ int pattern_build(Ctx* ctx, int64_t N, int64_t M, const int64_t* colptr, const i
   const float* bv = nullptr;
   SCL_TRY(upload(ctx, out, uval, &bv));
   out->base_val = const_cast<float*>(bv);
+  SCL_HIP(ctx, hipStreamSynchronize(ctx->stream));
   return SCLENS_OK;
 }
 void pattern_free(PatternOwner* p) {
@@ -301,6 +304,24 @@ int session_create(Ctx* ctx, int64_t N, int64_t M, const int64_t* colptr, const 
   return SCLENS_OK;
 }
 
+int pattern_create(Ctx* ctx, int64_t N, int64_t M, const int64_t* colptr, const int32_t* rowval, const float* nzval,
+                   int64_t ncand, const uint32_t* z1, const uint32_t* z2, PatternOwner** out) {
+  PatternOwner* p = new PatternOwner();
+  const int rc = pattern_build(ctx, N, M, colptr, rowval, nzval, ncand, z1, z2, p);
+  if (rc != SCLENS_OK) {
+    pattern_free(p);
+    delete p;
+    return rc;
+  }
+  *out = p;
+  return SCLENS_OK;
+}
+void pattern_destroy(PatternOwner* p) {
+  if (!p) return;
+  pattern_free(p);
+  delete p;
+}
+
 // A second session on another context (= another stream of the same GPU) that shares the read-only device data of
 // `src` (sparse pattern, Vr2, CheFSI seed block) and owns its scratch: independent search iterations / ensemble members
 // can then run concurrently, the latency-bound column kernels of one decomposition overlapping the bandwidth-bound
@@ -381,7 +402,42 @@ int session_spectrum(Session* s, const int64_t* rc_, const int32_t* rr_, const f
 }
 
 // copy the shared read-only results of `src` (Vr2 and/or the seed block of the partial eigensolver) into `dst`
+// (re)allocate the working value array for the session's current pattern
+static int session_realloc_val(Session* s) {
+  if (s->val) {
+    auto it = std::find(s->allocs.begin(), s->allocs.end(), (void*)s->val);
+    if (it != s->allocs.end()) s->allocs.erase(it);
+    hipFree(s->val);
+    s->val = nullptr;
+  }
+  return s->dmalloc((void**)&s->val, sizeof(float) * (size_t)s->pat.dev.nU);
+}
+
+// Hand a pattern built by pattern_create (counts + zero candidates) to an idle owner session that was created without
+// candidates. The session takes ownership; *p is left empty. Worker clones refresh their view with adopt(what = 4).
+int session_set_pattern(Session* s, PatternOwner* p) {
+  Ctx* ctx = s->ctx;
+  if (!p || p->allocs.empty()) return ctx->fail(SCLENS_ERR_ARG, "set_pattern: empty pattern");
+  if (p->dev.N != s->N || p->dev.M != s->M) return ctx->fail(SCLENS_ERR_ARG, "set_pattern: pattern has different dimensions");
+  if (s->pat.allocs.empty()) return ctx->fail(SCLENS_ERR_STATE, "set_pattern: not available on a worker session (adopt it instead)");
+  SCL_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  pattern_free(&s->pat);
+  s->pat.dev = p->dev;
+  s->pat.base_val = p->base_val;
+  s->pat.allocs.swap(p->allocs);
+  p->dev = PatternDev();
+  p->base_val = nullptr;
+  return session_realloc_val(s);
+}
+
 int session_adopt(Session* dst, Session* src, int what) {
+  if (what & 4) {  // the (new) sparse pattern of src; dst must be a clone (it never owns a pattern)
+    if (!dst->pat.allocs.empty()) return dst->ctx->fail(SCLENS_ERR_STATE, "adopt: only a worker session can adopt a pattern");
+    SCL_HIP(dst->ctx, hipStreamSynchronize(dst->ctx->stream));
+    dst->pat.dev = src->pat.dev;
+    dst->pat.base_val = src->pat.base_val;
+    SCL_TRY(session_realloc_val(dst));
+  }
   if (what & 1) { dst->Vr2t = src->Vr2t; dst->r_vr2 = src->r_vr2; }
   if (what & 2) { dst->Z0t = src->Z0t; dst->theta0 = src->theta0; dst->b0 = src->b0; dst->k = src->k; }
   return SCLENS_OK;

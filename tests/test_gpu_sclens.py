@@ -261,3 +261,47 @@ def test_sclens_median_centering(ctx, N, M):
     assert np.array_equal(res["sig_id"], ref["sig_id"])
     with pytest.raises(NotImplementedError):
         api.sclens(X, draws=d, ctx=ctx, centering="mode")
+
+
+def test_late_candidate_attachment_equals_upfront_session(ctx):
+    """A session created from the counts alone, with the union pattern (counts + zero candidates) attached after the
+    first decompositions (sclens_hip_pattern_create / _session_set_pattern / adopt(4)), must give bit-identical search
+    and ensemble results to a session that was created with the candidates."""
+    from sclens_amd._lib import Context
+
+    X = api._csc_f32(synth_counts(260, 410, seed=4, C=4, marker_frac=0.2, marker_sd=1.5))
+    d = api.make_draws_native(X, seed=17, host_sampler=True)
+    z1, z2 = d.z_idx1, d.z_idx2
+    N, M = X.shape
+    m = int(round(0.004 * N * M))
+    idx = d.sampler("search", 0, len(z1), m)
+
+    def run(late):
+        ses = api.Session(ctx, X) if late else api.Session(ctx, X, z1, z2)
+        c2 = Context(ctx.device)
+        w = ses.clone(c2)
+        try:
+            L, _ = ses.data_spectrum()
+            _, r = w.binary_basis()
+            ses.signal_vectors(3)
+            if late:
+                with pytest.raises(api.SclensHipError):  # no candidates yet: the sample is out of range
+                    w.search_step(idx, int(round(r / 2)))
+                pat = api.Pattern(c2, X, z1, z2)
+                ses.set_pattern(pat)
+                pat.close()  # ownership has moved to the session
+                w.adopt(ses, 4)
+            ses.adopt(w, 1)
+            d5a, _ = w.search_step(idx, int(round(r / 2)))
+            d5b, _ = ses.search_step_seeded(123, m, int(round(r / 2)))
+            nLp, nc = ses.perturb(0, idx, 4)
+            V = ses.get_perturbed(0, nc)
+            return L, d5a, d5b, nLp, V
+        finally:
+            w.close()
+            c2.close()
+            ses.close()
+
+    a, b = run(False), run(True)
+    for x, y in zip(a, b):
+        assert np.array_equal(x, y)
