@@ -305,3 +305,27 @@ def test_late_candidate_attachment_equals_upfront_session(ctx):
     a, b = run(False), run(True)
     for x, y in zip(a, b):
         assert np.array_equal(x, y)
+
+
+def test_midsize_parity_native_draws(ctx):
+    """A size with ten reduction panels and multi-work-unit symv launches (n = 1200) against the oracle, library draws
+    (what bench.py times), three concurrent streams: decisions exact, spectra and scores within the fp32 tolerances."""
+    X = synth_counts(1200, 2400, seed=3, C=6, marker_frac=0.1, marker_sd=1.2)
+    d = api.make_draws_native(X, seed=31, host_sampler=True)
+    od = O.Draws(d.z_idx1, d.z_idx2, d.X_r, d.p_th, d.sampler)
+    ref = O.sclens(X, od, n_perturb=6, null_tol=O.NULL_DROP, keep_intermediates=True)
+    res = api.sclens(X, draws=api.make_draws_native(X, seed=31, async_null=True, async_candidates=True), n_perturb=6, ctx=ctx,
+                     streams=3, keep_intermediates=True)
+    assert np.abs(res["L"] - ref["L"]).max() < 2e-4 * ref["L"].max()
+    k = len(ref["signal_ev"])
+    assert len(res["signal_ev"]) == k > 0
+    assert np.allclose(res["signal_ev"], ref["signal_ev"], rtol=2e-4)
+    assert res["n_search"] == ref["n_search"] and res["p_"] == ref["p_"]
+    for (p1, d1), (p2, d2) in zip(res["search_trace"], ref["search_trace"]):
+        assert p1 == p2 and np.abs(d1 - d2).max() < 3e-3
+    gaps = np.minimum(np.abs(np.diff(ref["signal_ev"], prepend=np.inf)), np.abs(np.diff(ref["signal_ev"], append=ref["lambda_c"])))
+    sep = gaps > 0.02 * ref["signal_ev"]
+    assert np.all(_abs_cos(res["signal_evec"], ref["signal_evec"])[sep] > 1 - 2e-3)
+    assert np.array_equal(res["sig_id"], ref["sig_id"])
+    assert np.abs(res["robustness_scores"]["rob_score"] - ref["robustness_scores"]["rob_score"]).max() < 5e-3
+    assert res["partial_eig"][0] + res["partial_eig"][1] == 6
