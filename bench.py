@@ -65,7 +65,7 @@ def cpu_baseline(N, M, n_search, n_perturb):
     from sclens_amd.synth import synth_counts
 
     n, K = min(N, M), max(N, M)
-    ns = min(n, 2000)
+    ns = min(n, 4000)  # ~10-20 s of CPU work on the box's host cores; n^3 extrapolation factor <= 16 at cfg2
     Ns, Ms = (ns, int(ns * M / N)) if N <= M else (int(ns * N / M), ns)
     Xs = synth_counts(Ns, Ms, seed=11)
     t0 = time.perf_counter()
