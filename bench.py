@@ -30,6 +30,7 @@ import numpy as np  # noqa: E402
 
 CONFIGS = {  # name -> (N cells, M genes, index in BASELINE.json configs)
     "tiny": (600, 900, 0),
+    "tiny_gt": (900, 400, 0),  # cells > genes, for --row-shard smoke runs
     "cfg2": (10000, 20000, 1),
     "cfg3": (50000, 30000, 2),
     "cfg4": (100000, 30000, 3),
@@ -106,6 +107,9 @@ def main():
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--backend", default="nccl")
     ap.add_argument("--batch", action="store_true", help="merge the column steps of concurrent tridiagonalisations into shared launches (opt-in)")
+    ap.add_argument("--row-shard", action="store_true",
+                    help="cells > genes configs on N > 1 GPUs: every rank holds a block of cells, partial Gram matrices are "
+                         "all-reduced (SURVEY 8e-iii, sclens_amd/atlas.py) instead of distributing whole decompositions")
     ap.add_argument("--streams", type=int, default=3, help="concurrent decompositions per GPU (worker sessions on own HIP streams)")
     ap.add_argument("--verbose", action="store_true")
     ap.add_argument("--stage-timing", action="store_true", help="per-stage HIP-event totals on stderr (adds syncs)")
@@ -140,10 +144,20 @@ def main():
     X = api._csc_f32(synth_counts(N, M, seed=20240427 + cfg_index))  # PCG64(20240427 + config_index)
     t_synth = time.perf_counter() - t0
 
+    row_shard = args.row_shard and N > M
+    if row_shard:
+        from sclens_amd import atlas
+
+        r0, r1 = atlas.row_block(rank, world, N)
+        X_rows = api._csc_f32(X.tocsr()[r0:r1].tocsc())
+
     def one_step(step):
         t_d = time.perf_counter()
-        draws = api.make_draws_native(X, seed=1000 + step, async_null=True, async_candidates=True)
+        draws = api.make_draws_native(X, seed=1000 + step, async_null=True, async_candidates=not row_shard)
         one_step.draws_s = time.perf_counter() - t_d  # R1-R3 inside the timed region; R4/R5 on the device inside sclens()
+        if row_shard:  # global draws (identical on every rank), local cells
+            return atlas.sclens_row_sharded(X_rows, r0, N, draws, shard, n_perturb=args.n_perturb, ctx=ctx, gather=False,
+                                            verbose=args.verbose)
         return api.sclens(X, draws=draws, ctx=ctx, n_perturb=args.n_perturb, shard=shard, streams=args.streams,
                           batch=args.batch, verbose=args.verbose and rank == 0)
 
@@ -183,7 +197,9 @@ def main():
             "config": {"workload": f"{args.config}: synthetic Poisson-lognormal counts {N} cells x {M} genes, sparsity "
                                    f"{1 - X.nnz / (N * M):.3f}, full sclens() incl. sparsity search and {args.n_perturb}-member "
                                    f"perturbation ensemble", "N": N, "M": M, "nnz": int(X.nnz), "n_perturb": args.n_perturb,
-                       "parallelism": (f"single GPU, {args.streams} concurrent decompositions (HIP streams)" if world == 1 else
+                       "parallelism": (f"cells row-sharded over {world} ranks: per decomposition 4 small all-reduces + one "
+                                       f"all-reduce of the {M}x{M} fp32 partial Gram matrix, eigen-solver replicated" if row_shard
+                                       else f"single GPU, {args.streams} concurrent decompositions (HIP streams)" if world == 1 else
                                        f"search rounds of {world}x{args.streams} + ensemble t%{world}, 1 RCCL all-gather")},
             "sclens_wall_s": round(dt / max(1, args.steps), 3),
             "observed": {"signals": int(len(res.get("signal_ev", []))), "robust_signals": int(len(res.get("sig_id", []))),

@@ -151,6 +151,9 @@ int sclens_draw_null_matrix(int64_t N, int64_t M, const int64_t* colptr, const f
 int sclens_sample_without_replacement(uint64_t len, int64_t m, uint64_t seed, uint32_t* out);
 
 /* ---------------------------------------------------------------- (B) device-resident session -- */
+/* all-reduce supplied by the host for row-sharded sessions (see sclens_hip_session_create_sharded) */
+typedef int (*sclens_hip_allreduce_fn)(void* user, void* dev_ptr, int64_t count, int dtype /*0 fp64, 1 fp32*/);
+
 /* Count matrix (what df2sparr(inp_df) returns, scLENS.jl:662) + the zero-candidate list
  * (z_idx1, z_idx2 of scLENS.jl:668-673, 0-based, disjoint from the stored entries, unique). */
 int sclens_hip_session_create(sclens_hip_ctx* ctx, int64_t N, int64_t M, const int64_t* colptr, const int32_t* rowval,
@@ -161,6 +164,24 @@ void sclens_hip_session_destroy(sclens_hip_session* s);
  * of `src` (pattern, and Vr2 / seed block if already computed; see sclens_hip_session_adopt). Valid calls on it:
  * null_spectrum, binary_basis, search_step*, perturb*, export_slot. Destroy it before `src`. Lets two independent decompositions overlap on one GPU (one host thread each). */
 int sclens_hip_session_clone(sclens_hip_ctx* ctx2, sclens_hip_session* src, sclens_hip_session** out);
+
+/* Row-sharded session for the atlas configuration (cells > genes, so the Gram matrix X'X is a sum over
+ * cells): this process holds the cells [row0, row0 + N_local) of an N_global x M count matrix (colptr / rowval / nzval:
+ * the LOCAL cells, row indices 0 .. N_local-1; z_idx1: GLOBAL cell indices of the whole candidate list, identical on
+ * every rank). `allreduce` sums a device buffer over all ranks in place (RCCL via torch.distributed in the Python host;
+ * any equivalent); the library calls it, on the calling thread and with its stream synchronised, where the path has a
+ * real exchange: three O(M) fp64 vectors + one scalar inside each normalisation (column mean / variance / centring,
+ * mean row norm), the M x M fp32 partial Gram matrix of each decomposition (scLENS.jl:332-361), the norms of the
+ * recovered cell-side vectors (:503-508), and the small k x min_pc / (P k)^2 / k x M products of the robustness scoring
+ * (:788-795) and the gene basis (:813-818). The eigendecompositions run replicated on identical inputs. Every session
+ * call must be made by all ranks in the same order. Outputs on the gene side are identical on every rank; signal_vectors,
+ * get_perturbed, rec_tgc, rec_norm_tgc cover the local cells. Mean centring only; no late candidate attachment.
+ * A worker clone needs its own exchange channel: sclens_hip_session_set_reducer. */
+int sclens_hip_session_create_sharded(sclens_hip_ctx* ctx, int64_t N_global, int64_t row0, int64_t N_local, int64_t M,
+                                      const int64_t* colptr, const int32_t* rowval, const float* nzval, int64_t n_cand,
+                                      const uint32_t* z_idx1, const uint32_t* z_idx2, sclens_hip_allreduce_fn allreduce,
+                                      void* user, sclens_hip_session** out);
+int sclens_hip_session_set_reducer(sclens_hip_session* s, sclens_hip_allreduce_fn allreduce, void* user);
 
 /* Late candidate attachment. The data / null / binarised decompositions (scLENS.jl:676-721) do not involve the zero
  * candidates, so a session may be created with n_cand = 0 and start them at once, while the host still draws the

@@ -21,6 +21,8 @@ c_i32p = C.POINTER(C.c_int32)
 c_u8p = C.POINTER(C.c_uint8)
 c_u32p = C.POINTER(C.c_uint32)
 vp = C.c_void_p
+# int allreduce(void* user, void* dev_ptr, int64_t count, int dtype): see sclens_hip_session_create_sharded
+ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_int)
 i64 = C.c_int64
 
 # name -> (restype, argtypes); every symbol declared in include/sclens_hip.h
@@ -53,6 +55,9 @@ SIGNATURES = {
                                             C.c_double, i64, i64, i64, C.c_double, C.c_double, c_u8p, c_i64p, c_i64p, c_i64p,
                                             c_i64p]),
     "sclens_hip_preprocess_gather": (C.c_int, [vp, c_i64p, c_i32p, c_f32p]),
+    "sclens_hip_session_create_sharded": (C.c_int, [vp, i64, i64, i64, i64, c_i64p, c_i32p, c_f32p, i64, c_u32p, c_u32p, ALLREDUCE_FN,
+                                                    vp, C.POINTER(vp)]),
+    "sclens_hip_session_set_reducer": (C.c_int, [vp, ALLREDUCE_FN, vp]),
     "sclens_hip_pattern_create": (C.c_int, [vp, i64, i64, c_i64p, c_i32p, c_f32p, i64, c_u32p, c_u32p, C.POINTER(vp)]),
     "sclens_hip_pattern_destroy": (None, [vp]),
     "sclens_hip_session_set_pattern": (C.c_int, [vp, vp]),

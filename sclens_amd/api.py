@@ -460,6 +460,31 @@ class Session:
                                                     ptr(z2, C.c_uint32), C.byref(h)))
         self.h = h
 
+    @classmethod
+    def create_sharded(cls, ctx: Context, X_local: sp.csc_matrix, row0: int, N_global: int, z1: np.ndarray, z2: np.ndarray,
+                       reducer) -> "Session":
+        """Row-sharded session (sclens_hip_session_create_sharded): `X_local` = the cells [row0, row0 + N_local) of an
+        N_global x M matrix, z1 = GLOBAL cell indices of the whole candidate list, `reducer` = an `_lib.ALLREDUCE_FN`
+        object (kept alive by the session)."""
+        s = cls.__new__(cls)
+        s.ctx = ctx
+        s.N, s.M = X_local.shape
+        s.n = s.M
+        s._reducer = reducer
+        colptr = np.ascontiguousarray(X_local.indptr, dtype=np.int64)
+        rowval = np.ascontiguousarray(X_local.indices, dtype=np.int32)
+        nzval = np.ascontiguousarray(X_local.data, dtype=np.float32)
+        z1 = np.ascontiguousarray(z1, dtype=np.uint32)
+        z2 = np.ascontiguousarray(z2, dtype=np.uint32)
+        s.ncand = int(z1.size)
+        h = C.c_void_p()
+        ctx.check(ctx.lib.sclens_hip_session_create_sharded(ctx.h, int(N_global), int(row0), s.N, s.M, ptr(colptr, C.c_int64),
+                                                            ptr(rowval, C.c_int32), ptr(nzval, C.c_float), s.ncand,
+                                                            ptr(z1, C.c_uint32), ptr(z2, C.c_uint32), reducer, None,
+                                                            C.byref(h)))
+        s.h = h
+        return s
+
     def close(self):
         if getattr(self, "h", None):
             self.ctx.lib.sclens_hip_session_destroy(self.h)

@@ -1,0 +1,148 @@
+"""Row-sharded sclens() for the atlas configuration: cells > genes, every rank holds a contiguous block of
+cells. The Gram matrix X'X (genes x genes) is a sum over cells, so each decomposition is: local normalisation statistics
+(three O(M) all-reduces + one scalar), local partial Gram matrix, one all-reduce of 4 M^2 bytes, then the eigen-solver
+replicated on identical inputs; the recovery GEMM X_g V is row-local. All ranks run the same control flow (the serial loop of
+scLENS.jl:715-778); the library calls back into `Shard.allreduce_dev` wherever the path has a real exchange.
+
+Memory is what this mode scales (the sparse pattern, the dense scaled matrix and the cell-side vectors are divided by the
+number of ranks), not the eigen-solver time; for cells <= genes, or when the matrix fits one GPU, use api.sclens(shard=...)
+which distributes independent decompositions instead.
+"""
+from __future__ import annotations
+
+import math
+import time
+import traceback
+from typing import Dict, Optional
+
+import numpy as np
+import scipy.sparse as sp
+
+from . import _lib
+from .api import (Context, Draws, Session, _csc_f32, _mp_calculation, _resolve, _robust_scores, _tw, default_context,
+                  mp_check, sample_seed_for)
+from .shard import Shard, consume_search_round, search_schedule
+
+
+def row_block(rank: int, world: int, N: int):
+    """cells [row0, row1) of rank `rank`: contiguous, sizes differing by at most one"""
+    base, rem = divmod(N, world)
+    row0 = rank * base + min(rank, rem)
+    return row0, row0 + base + (1 if rank < rem else 0)
+
+
+def make_reducer(shard: Shard, ctx: Context):
+    """the `sclens_hip_allreduce_fn` the library calls: sum a device buffer over all ranks in place"""
+
+    def cb(_user, dev_ptr, count, dtype):
+        try:
+            shard.allreduce_dev(ctx, dev_ptr, count, dtype)
+            return 0
+        except Exception:  # never let an exception cross the C ABI
+            traceback.print_exc()
+            return 1
+
+    return _lib.ALLREDUCE_FN(cb)
+
+
+def _gather_rows(shard: Shard, local: np.ndarray, N_global: int) -> np.ndarray:
+    """stack the ranks' row blocks (rows = cells) into the full array on every rank"""
+    if shard.world == 1:
+        return local
+    per = (N_global + shard.world - 1) // shard.world
+    pad = np.zeros((per,) + local.shape[1:], dtype=np.float64)
+    pad[: local.shape[0]] = local
+    allp = shard.allgather_small(pad)
+    parts = []
+    for r in range(shard.world):
+        a, b = row_block(r, shard.world, N_global)
+        parts.append(allp[r, : b - a])
+    return np.concatenate(parts, axis=0).astype(local.dtype)
+
+
+def sclens_row_sharded(X_local, row0: int, N_global: int, draws: Draws, shard: Shard, th=60, p_step=0.001, n_perturb=20,
+                       ctx: Optional[Context] = None, max_search_iters: Optional[int] = None, gather: bool = True,
+                       verbose: bool = False) -> Dict[str, object]:
+    """scLENS.sclens (scLENS.jl:649-832) with the cells divided over the ranks of `shard`.
+
+    X_local: this rank's cells (N_local x M, N_global > M). draws: the GLOBAL draws, identical on every rank (z_idx1 =
+    global cell indices; X_r = the whole null matrix, of which this rank takes its rows; sampler / sample_seed index the
+    global candidate list). Returns the reference's result keys; with `gather` the cell-side arrays cover all cells."""
+    ctx = ctx or default_context()
+    t_all = time.perf_counter()
+    X_local = _csc_f32(X_local)
+    N_local, M = X_local.shape
+    if N_global <= M:
+        raise ValueError("row sharding needs cells > genes; use api.sclens(shard=...) otherwise")
+    z1, z2 = _resolve(draws.z_idx1), _resolve(draws.z_idx2)
+    Xr = _resolve(draws.X_r)
+    Xr_local = _csc_f32(sp.csc_matrix(Xr.tocsr()[row0: row0 + N_local])) if Xr.shape[0] == N_global else _csc_f32(Xr)
+    reducer = make_reducer(shard, ctx)
+    ses = Session.create_sharded(ctx, X_local, row0, N_global, z1, z2, reducer)
+    try:
+        Lr = shard.agree(ses.null_spectrum(Xr_local))  # :704
+        L, rec_vals = ses.data_spectrum()
+        L = shard.agree(L)
+        L_mp, _, _ = _mp_calculation(L, Lr[:-1])
+        lambda_c = _tw(L, L_mp)[0]
+        sel = L > lambda_c
+        k = int(sel.sum())
+        if verbose and shard.rank == 0:
+            print(f"(Using hip, {shard.world} row blocks) number of signal ev: {k}")
+        nL = L[sel][::-1].copy()
+        nV_local = ses.signal_vectors(k)
+        _, r_vr2 = ses.binary_basis()  # :717-721
+        mpC = mp_check(L_mp)
+        p_th = draws.p_th
+        n_2 = int(round(r_vr2 / 2))
+        p_list = search_schedule(p_step)
+        tank = np.zeros((5, 0))
+        it, p_ = 0, None
+        while p_ is None:  # :725-761, one evaluation at a time, all ranks together
+            nnzidx = int(round((1 - p_list[it]) * M * N_global))
+            d5 = None
+            if len(z1) >= nnzidx:
+                if draws.sampler is not None:
+                    d5, _ = ses.search_step(draws.sampler("search", it, len(z1), nnzidx), n_2)
+                else:
+                    d5, _ = ses.search_step_seeded(sample_seed_for(draws.sample_seed, "search", it), nnzidx, n_2)
+                d5 = shard.agree(d5)
+            tank, used, stopped, p_fin = consume_search_round(tank, [d5], p_list, it, p_th, p_step, max_search_iters)
+            it += used
+            if stopped:
+                p_ = p_fin
+        trace = [(p_list[q], tank[:, q].copy()) for q in range(tank.shape[1])]
+        min_pc = int(math.ceil(k * 1.5))
+        m_pert = int(round((1 - p_) * M * N_global))
+        nL_set, ncols = [None] * n_perturb, [0] * n_perturb
+        res: Dict[str, object] = {"L": L, "L_mp": L_mp, "λ": lambda_c, "lambda_c": lambda_c, "p_": p_, "p_th": p_th,
+                                  "n_search": it, "search_trace": trace, "row_block": (row0, row0 + N_local)}
+        if k == 0:  # :780-784
+            res["partial_eig"] = (0, 0)
+            res["wall_s"] = time.perf_counter() - t_all
+            return res
+        for t in range(n_perturb):  # :767-778
+            if draws.sampler is not None:
+                nL_set[t], ncols[t] = ses.perturb(t, draws.sampler("perturb", t, len(z1), m_pert), min_pc)
+            else:
+                nL_set[t], ncols[t] = ses.perturb_seeded(t, sample_seed_for(draws.sample_seed, "perturb", t), m_pert, min_pc)
+        a_b, b_ = ses.robustness(k, n_perturb)  # :786-807; the small products are summed over the ranks inside
+        b_ = shard.agree(b_)
+        m_score, sd_score = _robust_scores(b_)
+        sig_id = np.flatnonzero(m_score > math.cos(math.radians(th)))
+        gmat = ses.gene_basis(nL)
+        nV = _gather_rows(shard, nV_local, N_global) if gather else nV_local
+        if gather:
+            for key in ("TGC", "norm_tgc"):
+                rec_vals[key] = _gather_rows(shard, np.ravel(rec_vals[key])[:, None], N_global)[:, 0]
+        res.update({"pca": nV * np.sqrt(nL)[None, :].astype(np.float32),
+                    "pca_n1": nV[:, sig_id] * np.sqrt(nL[sig_id])[None, :].astype(np.float32), "sig_id": sig_id,
+                    "robustness_scores": {"b_": b_, "rob_score": m_score, "m_scores": m_score, "sd_scores": sd_score,
+                                          "a_b": a_b},
+                    "signal_evec": nV, "signal_ev": nL, "gene_basis": gmat, "pass": mpC["pass"],
+                    "ks_static": mpC["ks_static"], "rec_vals": rec_vals, "nL_set": nL_set, "min_pc": min_pc,
+                    "partial_eig": (ses.get_int("chefsi_used"), ses.get_int("chefsi_fallback"))})
+        res["wall_s"] = time.perf_counter() - t_all
+        return res
+    finally:
+        ses.close()

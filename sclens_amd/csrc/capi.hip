@@ -6,6 +6,9 @@ namespace scl {
 struct Session;
 int session_create(Ctx*, int64_t, int64_t, const int64_t*, const int32_t*, const float*, int64_t, const uint32_t*,
                    const uint32_t*, Session**);
+int session_create_sharded(Ctx*, int64_t, int64_t, int64_t, int64_t, const int64_t*, const int32_t*, const float*, int64_t,
+                           const uint32_t*, const uint32_t*, sclens_hip_allreduce_fn, void*, Session**);
+int session_set_reducer(Session*, sclens_hip_allreduce_fn, void*);
 void session_destroy(Session*);
 int session_clone(Ctx*, Session*, Session**);
 int session_spectrum(Session*, const int64_t*, const int32_t*, const float*, double*, double*, ScaleVecs*);
@@ -185,6 +188,22 @@ int sclens_hip_session_create(sclens_hip_ctx* h, int64_t N, int64_t M, const int
   *out = w;
   return SCLENS_OK;
 }
+int sclens_hip_session_create_sharded(sclens_hip_ctx* h, int64_t N_global, int64_t row0, int64_t N_local, int64_t M,
+                                      const int64_t* colptr, const int32_t* rowval, const float* nzval, int64_t n_cand,
+                                      const uint32_t* z1, const uint32_t* z2, sclens_hip_allreduce_fn allreduce, void* user,
+                                      sclens_hip_session** out) {
+  CTX_GUARD(h);
+  if (!out) return SCLENS_ERR_ARG;
+  scl::Session* s = nullptr;
+  int rc = scl::session_create_sharded(&h->c, N_global, row0, N_local, M, colptr, rowval, nzval, n_cand, z1, z2, allreduce,
+                                       user, &s);
+  if (rc != SCLENS_OK) return rc;
+  sclens_hip_session* w = new sclens_hip_session();
+  w->s = s;
+  w->ctx = h;
+  *out = w;
+  return SCLENS_OK;
+}
 int sclens_hip_session_clone(sclens_hip_ctx* h, sclens_hip_session* src, sclens_hip_session** out) {
   CTX_GUARD(h);
   if (!src || !src->s || !out) return SCLENS_ERR_ARG;
@@ -208,6 +227,10 @@ void sclens_hip_session_destroy(sclens_hip_session* w) {
   if (!(w) || !(w)->s) return SCLENS_ERR_ARG; \
   hipSetDevice((w)->ctx->c.device)
 
+int sclens_hip_session_set_reducer(sclens_hip_session* w, sclens_hip_allreduce_fn allreduce, void* user) {
+  SES_GUARD(w);
+  return scl::session_set_reducer(w->s, allreduce, user);
+}
 int sclens_hip_session_spectrum(sclens_hip_session* w, const int64_t* rc, const int32_t* rr, const float* rv, double* L,
                                 double* Lr, double* rec_tgc, double* rec_mean, double* rec_std, double* rec_norm,
                                 double* rec_cent) {

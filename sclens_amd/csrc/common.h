@@ -165,6 +165,8 @@ int topk_chefsi(Ctx* ctx, const float* A, int64_t n, int64_t lda, int m, int m_s
 int fill_f32(Ctx* ctx, float* p, int64_t n, float v);
 int normalize_rows_f32(Ctx* ctx, float* A, int64_t rows, int64_t cols, int64_t ld);
 int scale_rows_f32(Ctx* ctx, float* A, int64_t rows, int64_t cols, int64_t ld, const float* s);
+int row_sqnorms_f32(Ctx* ctx, const float* A, int64_t rows, int64_t cols, int64_t ld, double* out);
+int scale_rows_rsqrt_f32(Ctx* ctx, float* A, int64_t rows, int64_t cols, int64_t ld, const double* sq);
 // out[c*ldo + r] = in[r*ldi + c]
 int transpose_f32(Ctx* ctx, const float* in, int64_t rows, int64_t cols, int64_t ldi, float* out, int64_t ldo);
 // out row q = in row (rows-1-q)

@@ -12,7 +12,7 @@ struct PatternDev {
   const int64_t* rowptr = nullptr;   // [N+1]  CSR view (columns ascending inside a row)
   const int64_t* csr2csc = nullptr;  // [nU]   CSC slot of each CSR slot
   const int32_t* csrcol = nullptr;   // [nU]
-  const int64_t* cand_pos = nullptr; // [ncand] CSC slot of candidate t
+  const int64_t* cand_pos = nullptr; // [ncand] CSC slot of candidate t (-1: not in this session's cells, row-sharded mode)
 };
 
 struct PatternOwner {  // owns the device arrays of a PatternDev
@@ -22,9 +22,28 @@ struct PatternOwner {  // owns the device arrays of a PatternDev
 };
 
 // Build on the host (O(nU)) and upload. Indices are 0-based. z1/z2 may be null when ncand == 0.
+// row0 / N_global: row-sharded session, z1 holds GLOBAL cell indices of which [row0, row0 + N) are local (N_global = 0: N).
 int pattern_build(Ctx* ctx, int64_t N, int64_t M, const int64_t* colptr, const int32_t* rowval, const float* nzval,
-                  int64_t ncand, const uint32_t* z1, const uint32_t* z2, PatternOwner* out);
+                  int64_t ncand, const uint32_t* z1, const uint32_t* z2, PatternOwner* out, int64_t row0 = 0,
+                  int64_t N_global = 0);
 void pattern_free(PatternOwner* p);
+
+// Row-sharded session: the all-reduce the host supplies. dtype 0 = fp64, 1 = fp32; sum over all ranks, in
+// place, on a device buffer; called from the thread that made the session call, after the session's stream has been
+// synchronised, and must return only when the buffer holds the result.
+struct ShardReduce {
+  int64_t N_global = 0, row0 = 0;
+  sclens_hip_allreduce_fn fn = nullptr;
+  void* user = nullptr;
+  bool on() const { return fn != nullptr; }
+  int sum(Ctx* ctx, void* dev, int64_t count, int dtype) const {
+    if (!fn) return SCLENS_OK;
+    hipError_t e = hipStreamSynchronize(ctx->stream);
+    if (e != hipSuccess) return ctx->fail(SCLENS_ERR_HIP, std::string("allreduce: ") + hipGetErrorString(e));
+    const int rc = fn(user, dev, count, dtype);
+    return rc == 0 ? SCLENS_OK : ctx->fail(SCLENS_ERR_HIP, "allreduce callback failed with code " + std::to_string(rc));
+  }
+};
 
 struct ScaleVecs {  // host destinations for rec_vals (scLENS.jl:676-696); all fp64
   double* tgc;        // [N]
@@ -41,6 +60,10 @@ struct ScaleVecs {  // host destinations for rec_vals (scLENS.jl:676-696); all f
 //   cells_major = 1 : B[i*ldb + j] (N rows of M genes); 0 : B[j*ldb + i] (M rows of N cells)
 int scale_to_dense(Ctx* ctx, const PatternDev& p, const float* val, int f32path, int centering, int cells_major,
                    float* B, int64_t ldb, ScaleVecs* keep);
+
+// the same for a session that holds p.N of sh.N_global cells (N > M layout: B[j][i_local]); mean centring only
+int scale_to_dense_sharded(Ctx* ctx, const PatternDev& p, const float* val, int f32path, float* B, int64_t ldb,
+                           ScaleVecs* keep, const ShardReduce& sh);
 
 // val = (binary ? pattern-of-counts : counts), then 1 at the candidate slots idx_dev[0..m)
 int make_values(Ctx* ctx, const PatternDev& p, const float* base_val, int binary, const uint32_t* idx_dev, int64_t m,

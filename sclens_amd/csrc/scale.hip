@@ -308,6 +308,140 @@ int scale_to_dense(Ctx* ctx, const PatternDev& p, const float* val, int f32path,
   return SCLENS_OK;
 }
 
+// ---- row-sharded variant (atlas configuration): this process holds N_local of the N_global cells -------
+// Per-cell quantities (TGC, l_i, s_i) are local; the statistics that span all cells are formed as local partial sums, summed
+// over the ranks by the caller-supplied all-reduce (ShardReduce; RCCL through torch.distributed, or gloo in the tests)
+// and finished identically on every rank: three all-reduces of O(M) doubles and one scalar per normalisation.
+__global__ __launch_bounds__(256) void k_sh_col_sum(PatternDev p, const float* __restrict__ val,
+                                                    const double* __restrict__ tgc, int f32path, double* __restrict__ lg,
+                                                    double* __restrict__ sum_cnt, int64_t M) {
+  const int64_t col = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (col >= M) return;
+  const int64_t b = p.colptr[col], e = p.colptr[col + 1];
+  double s = 0.0;
+  for (int64_t q = b + lane; q < e; q += 64) {
+    const float v = val[q];
+    double l = 0.0;
+    if (v != 0.f) {
+      const int64_t r = p.row[q];
+      if (f32path) {
+        const float inv = 1.0f / (float)tgc[r];
+        l = (double)log1pf(inv * v);
+      } else {
+        l = log1p((double)v / tgc[r]);
+      }
+    }
+    lg[q] = l;
+    s += l;
+  }
+  s = wsum(s);
+  if (lane == 0) {
+    sum_cnt[col] = s;
+    sum_cnt[M + col] = (double)(e - b);  // local slots of the column (exact in fp64)
+  }
+}
+__global__ __launch_bounds__(256) void k_sh_col_var(PatternDev p, const double* __restrict__ lg,
+                                                    const double* __restrict__ sum_cnt, double n_global,
+                                                    double* __restrict__ s2out, int64_t M) {
+  const int64_t col = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (col >= M) return;
+  const double m = sum_cnt[col] / n_global;
+  double s2 = 0.0;
+  for (int64_t q = p.colptr[col] + lane; q < p.colptr[col + 1]; q += 64) {
+    const double dlt = lg[q] - m;
+    s2 += dlt * dlt;
+  }
+  s2 = wsum(s2);
+  if (lane == 0) s2out[col] = s2;
+}
+__global__ void k_sh_col_fin(const double* __restrict__ sum_cnt, const double* __restrict__ s2, double n_global, int f32path,
+                             int64_t M, double* __restrict__ mean, double* __restrict__ stdv, double* __restrict__ mu) {
+  const int64_t col = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (col >= M) return;
+  const double s = sum_cnt[col], m = s / n_global;
+  const double tot = s2[col] + (n_global - sum_cnt[M + col]) * m * m;  // implicit zeros of all ranks
+  double sd = sqrt(tot / (n_global - 1.0));
+  if (f32path) sd = (double)(float)sd;
+  mean[col] = f32path ? (double)(float)m : m;
+  stdv[col] = sd;
+  mu[col] = (s / sd) / n_global;
+}
+__global__ void k_sh_row_scale(const double* __restrict__ l2, int64_t n_local, double n_global,
+                               const double* __restrict__ lsum, double* __restrict__ srow) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n_local) srow[i] = (lsum[0] / n_global) / l2[i];
+}
+__global__ __launch_bounds__(256) void k_sh_col_cent_part(PatternDev p, const double* __restrict__ lg,
+                                                          const double* __restrict__ srow, double* __restrict__ part,
+                                                          int64_t M) {
+  const int64_t col = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (col >= M) return;
+  double s = 0.0;
+  for (int64_t q = p.colptr[col] + lane; q < p.colptr[col + 1]; q += 64) s += srow[p.row[q]] * lg[q];
+  s = wsum(s);
+  if (lane == 0) part[col] = s;
+}
+__global__ void k_sh_col_cent_fin(const double* __restrict__ part, const double* __restrict__ stdv,
+                                  const double* __restrict__ mu, double n_global, int64_t M, double* __restrict__ cent) {
+  const int64_t col = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (col < M) cent[col] = (part[col] / stdv[col] - mu[col] * part[M]) / n_global;  // part[M] = sum of s over all cells
+}
+
+int scale_to_dense_sharded(Ctx* ctx, const PatternDev& p, const float* val, int f32path, float* B, int64_t ldb,
+                           ScaleVecs* keep, const ShardReduce& sh) {
+  StageTimer tm(ctx, "scale");
+  const int64_t N = p.N, M = p.M;  // N = local cells
+  const double ng = (double)sh.N_global;
+  SCL_WS(ctx, tgc, double, "sc.tgc", N);
+  SCL_WS(ctx, lg, double, "sc.lg", p.nU);
+  SCL_WS(ctx, mean, double, "sc.mean", M);
+  SCL_WS(ctx, stdv, double, "sc.std", M);
+  SCL_WS(ctx, mu, double, "sc.mu", M);
+  SCL_WS(ctx, l2, double, "sc.l2", N);
+  SCL_WS(ctx, srow, double, "sc.srow", N);
+  SCL_WS(ctx, cent, double, "sc.cent", M);
+  SCL_WS(ctx, red, double, "sc.red", 8);
+  SCL_WS(ctx, part, double, "sc.part", 2 * M + 8);
+  SCL_WS(ctx, s2, double, "sc.s2", M);
+  hipStream_t st = ctx->stream;
+  const unsigned gc4 = (unsigned)((M + 3) / 4), gcm = (unsigned)((M + 255) / 256);
+  hipLaunchKernelGGL(k_row_sums, dim3((unsigned)((N + 3) / 4)), dim3(256), 0, st, p, val, tgc);  // all genes are local
+  hipLaunchKernelGGL(k_sh_col_sum, dim3(gc4), dim3(256), 0, st, p, val, tgc, f32path, lg, part, M);
+  SCL_TRY(sh.sum(ctx, part, 2 * M, 0));
+  hipLaunchKernelGGL(k_sh_col_var, dim3(gc4), dim3(256), 0, st, p, lg, part, ng, s2, M);
+  SCL_TRY(sh.sum(ctx, s2, M, 0));
+  hipLaunchKernelGGL(k_sh_col_fin, dim3(gcm), dim3(256), 0, st, part, s2, ng, f32path, M, mean, stdv, mu);
+  hipLaunchKernelGGL(k_reduce, dim3(1), dim3(1024), 0, st, mu, M, 0, red + 0);  // ||mu||^2 (replicated)
+  hipLaunchKernelGGL(k_row_norms, dim3((unsigned)((N + 3) / 4)), dim3(256), 0, st, p, lg, stdv, mu, red + 0, l2);
+  hipLaunchKernelGGL(k_reduce, dim3(1), dim3(1024), 0, st, l2, N, 1, red + 1);  // local sum of l
+  SCL_TRY(sh.sum(ctx, red + 1, 1, 0));
+  hipLaunchKernelGGL(k_sh_row_scale, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, st, l2, N, ng, red + 1, srow);
+  hipLaunchKernelGGL(k_sh_col_cent_part, dim3(gc4), dim3(256), 0, st, p, lg, srow, part, M);
+  hipLaunchKernelGGL(k_reduce, dim3(1), dim3(1024), 0, st, srow, N, 1, part + M);  // local sum of s, appended
+  SCL_TRY(sh.sum(ctx, part, M + 1, 0));
+  hipLaunchKernelGGL(k_sh_col_cent_fin, dim3(gcm), dim3(256), 0, st, part, stdv, mu, ng, M, cent);
+  if (M > 65535LL * 65535LL) return ctx->fail(SCLENS_ERR_ARG, "scale_to_dense: too many rows");
+  for (int64_t r0 = 0; r0 < M; r0 += 65535) {  // genes-major: B[j][i_local]
+    const int64_t rows = (M - r0 < 65535) ? M - r0 : 65535;
+    hipLaunchKernelGGL(k_dense_fill, dim3((unsigned)((N + 1023) / 1024), (unsigned)rows), dim3(256), 0, st, N, M, 0, srow,
+                       mu + r0, cent + r0, B + r0 * ldb, ldb);
+  }
+  hipLaunchKernelGGL(k_dense_scatter, dim3(gc4), dim3(256), 0, st, p, 0, val, lg, stdv, mu, cent, srow, B, ldb);
+  SCL_HIP(ctx, hipGetLastError());
+  if (keep) {
+    SCL_HIP(ctx, hipMemcpyAsync(keep->tgc, tgc, sizeof(double) * N, hipMemcpyDeviceToHost, st));
+    SCL_HIP(ctx, hipMemcpyAsync(keep->mat2_mean, mean, sizeof(double) * M, hipMemcpyDeviceToHost, st));
+    SCL_HIP(ctx, hipMemcpyAsync(keep->mat2_std, stdv, sizeof(double) * M, hipMemcpyDeviceToHost, st));
+    SCL_HIP(ctx, hipMemcpyAsync(keep->norm_tgc, l2, sizeof(double) * N, hipMemcpyDeviceToHost, st));
+    SCL_HIP(ctx, hipMemcpyAsync(keep->cent, cent, sizeof(double) * M, hipMemcpyDeviceToHost, st));
+    SCL_HIP(ctx, hipStreamSynchronize(st));
+  }
+  return SCLENS_OK;
+}
+
 // ---- value arrays over the pattern ------------------------------------------------------------------
 // out[q] = binary ? (base[q] != 0) : base[q]     (candidate slots have base 0)
 __global__ void k_val_init(const float* __restrict__ base, int64_t nU, int binary, float* __restrict__ out) {
@@ -321,7 +455,10 @@ __global__ void k_val_init(const float* __restrict__ base, int64_t nU, int binar
 __global__ void k_val_set_ones(const uint32_t* __restrict__ idx, int64_t m, const int64_t* __restrict__ cand_pos,
                                int64_t ncand, float* __restrict__ out) {
   const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (t < m && (int64_t)idx[t] < ncand) out[cand_pos[idx[t]]] = 1.f;
+  if (t < m && (int64_t)idx[t] < ncand) {
+    const int64_t pos = cand_pos[idx[t]];
+    if (pos >= 0) out[pos] = 1.f;  // -1: the candidate's cell belongs to another rank (row-sharded session)
+  }
 }
 
 int make_values(Ctx* ctx, const PatternDev& p, const float* base_val, int binary, const uint32_t* idx_dev, int64_t m,
@@ -338,7 +475,10 @@ int make_values(Ctx* ctx, const PatternDev& p, const float* base_val, int binary
 __global__ void k_val_set_ones_feistel(FeistelPerm perm, int64_t m, const int64_t* __restrict__ cand_pos,
                                        float* __restrict__ out) {
   const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (t < m) out[cand_pos[feistel_apply(perm, (uint64_t)t)]] = 1.f;
+  if (t < m) {
+    const int64_t pos = cand_pos[feistel_apply(perm, (uint64_t)t)];
+    if (pos >= 0) out[pos] = 1.f;
+  }
 }
 
 int make_values_seeded(Ctx* ctx, const PatternDev& p, const float* base_val, int binary, uint64_t seed, int64_t m,
@@ -382,6 +522,37 @@ __global__ __launch_bounds__(256) void k_normalize_rows(float* A, int64_t rows, 
 int normalize_rows_f32(Ctx* ctx, float* A, int64_t rows, int64_t cols, int64_t ld) {
   if (rows <= 0) return SCLENS_OK;
   hipLaunchKernelGGL(k_normalize_rows, dim3((unsigned)rows), dim3(256), 0, ctx->stream, A, rows, cols, ld);
+  SCL_HIP(ctx, hipGetLastError());
+  return SCLENS_OK;
+}
+
+// squared row norms (fp64) and the matching rescale: normalize_rows_f32 in two halves, so that a row-sharded session can
+// sum the squared norms over the ranks in between
+__global__ __launch_bounds__(256) void k_row_sqnorms(const float* A, int64_t cols, int64_t ld, double* out) {
+  __shared__ double sw[4];
+  const float* a = A + (int64_t)blockIdx.x * ld;
+  double s = 0.0;
+  for (int64_t c = threadIdx.x; c < cols; c += 256) s += (double)a[c] * (double)a[c];
+  s = wsum(s);
+  if ((threadIdx.x & 63) == 0) sw[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) out[blockIdx.x] = (sw[0] + sw[1]) + (sw[2] + sw[3]);
+}
+__global__ void k_scale_rows_rsqrt(float* A, int64_t cols, int64_t ld, const double* sq) {
+  const int64_t r = blockIdx.y;
+  const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (c < cols) A[r * ld + c] = (float)((double)A[r * ld + c] / sqrt(sq[r]));
+}
+int row_sqnorms_f32(Ctx* ctx, const float* A, int64_t rows, int64_t cols, int64_t ld, double* out) {
+  if (rows <= 0) return SCLENS_OK;
+  hipLaunchKernelGGL(k_row_sqnorms, dim3((unsigned)rows), dim3(256), 0, ctx->stream, A, cols, ld, out);
+  SCL_HIP(ctx, hipGetLastError());
+  return SCLENS_OK;
+}
+int scale_rows_rsqrt_f32(Ctx* ctx, float* A, int64_t rows, int64_t cols, int64_t ld, const double* sq) {
+  if (rows <= 0) return SCLENS_OK;
+  hipLaunchKernelGGL(k_scale_rows_rsqrt, dim3((unsigned)((cols + 255) / 256), (unsigned)rows), dim3(256), 0, ctx->stream, A,
+                     cols, ld, sq);
   SCL_HIP(ctx, hipGetLastError());
   return SCLENS_OK;
 }

@@ -115,17 +115,25 @@ static int upload(Ctx* ctx, PatternOwner* o, const std::vector<T>& h, const T** 
 }
 
 int pattern_build(Ctx* ctx, int64_t N, int64_t M, const int64_t* colptr, const int32_t* rowval, const float* nzval,
-                  int64_t ncand, const uint32_t* z1, const uint32_t* z2, PatternOwner* out) {
+                  int64_t ncand, const uint32_t* z1, const uint32_t* z2, PatternOwner* out, int64_t row0, int64_t N_global) {
   if (N <= 0 || M <= 0 || !colptr || (colptr[M] > 0 && (!rowval || !nzval)) || (ncand > 0 && (!z1 || !z2)))
     return ctx->fail(SCLENS_ERR_ARG, "pattern_build: bad arguments");
+  if (N_global <= 0) N_global = N;
+  if (row0 < 0 || row0 + N > N_global) return ctx->fail(SCLENS_ERR_ARG, "pattern_build: bad row range");
   const int64_t nnz = colptr[M];
-  const int64_t nU = nnz + ncand;
+  // candidates whose cell lies in [row0, row0 + N) are local; the others keep their list index with slot -1
+  auto local = [&](int64_t t) { return (int64_t)z1[t] >= row0 && (int64_t)z1[t] < row0 + N; };
   std::vector<int64_t> ucol(M + 1, 0);
   for (int64_t j = 0; j < M; ++j) ucol[j + 1] = colptr[j + 1] - colptr[j];
+  int64_t ncl = 0;
   for (int64_t t = 0; t < ncand; ++t) {
-    if (z2[t] >= (uint64_t)M || z1[t] >= (uint64_t)N) return ctx->fail(SCLENS_ERR_ARG, "candidate index out of range");
-    ucol[z2[t] + 1] += 1;
+    if (z2[t] >= (uint64_t)M || z1[t] >= (uint64_t)N_global) return ctx->fail(SCLENS_ERR_ARG, "candidate index out of range");
+    if (local(t)) {
+      ucol[z2[t] + 1] += 1;
+      ncl += 1;
+    }
   }
+  const int64_t nU = nnz + ncl;
   for (int64_t j = 0; j < M; ++j) ucol[j + 1] += ucol[j];
   std::vector<int32_t> urow(nU);
   std::vector<float> uval(nU, 0.f);
@@ -134,7 +142,7 @@ int pattern_build(Ctx* ctx, int64_t N, int64_t M, const int64_t* colptr, const i
   {
     std::vector<int64_t> cur(M);
     for (int64_t j = 0; j < M; ++j) cur[j] = ucol[j] + (colptr[j + 1] - colptr[j]);
-    for (int64_t t = 0; t < ncand; ++t) cpos[t] = cur[z2[t]]++;
+    for (int64_t t = 0; t < ncand; ++t) cpos[t] = local(t) ? cur[z2[t]]++ : -1;
   }
   const int T = (int)std::max<int64_t>(1, std::min<int64_t>(8, nU / 2000000 + 1));  // host threads
   std::vector<int> bad(T, 0);
@@ -156,7 +164,8 @@ int pattern_build(Ctx* ctx, int64_t N, int64_t M, const int64_t* colptr, const i
       }
     }
     const int64_t t0 = ncand * t / T, t1 = ncand * (t + 1) / T;
-    for (int64_t c = t0; c < t1; ++c) urow[cpos[c]] = (int32_t)z1[c];
+    for (int64_t c = t0; c < t1; ++c)
+      if (cpos[c] >= 0) urow[cpos[c]] = (int32_t)((int64_t)z1[c] - row0);
   });
   for (int b : bad)
     if (b) return ctx->fail(SCLENS_ERR_ARG, "row index out of range");
@@ -236,6 +245,10 @@ struct Session {
   int64_t b0 = 0;
   int use_chefsi = 1;
   int centering = 0;  // 0 mean, 1 median (scLENS.jl:651-654)
+  // row-sharded session: N = local cells, K = local contraction length, Kdiv = the reference's divisor
+  // size(X', 2) = number of ALL cells; sh.fn sums partial results over the ranks
+  ShardReduce sh;
+  int64_t Kdiv = 0;
   int64_t chefsi_used = 0, chefsi_fallback = 0;
   float* nVt = nullptr;       // signal vectors, cell side, descending, [k][ldn]
   int64_t k = 0, ldn = 0;
@@ -287,6 +300,7 @@ int session_create(Ctx* ctx, int64_t N, int64_t M, const int64_t* colptr, const 
   s->ctx = ctx;
   s->N = N; s->M = M;
   s->n = std::min(N, M); s->K = std::max(N, M);
+  s->Kdiv = s->K;
   s->cells_major = (N <= M) ? 1 : 0;
   int rc = pattern_build(ctx, N, M, colptr, rowval, nzval, ncand, z1, z2, &s->pat);
   if (rc != SCLENS_OK) { delete s; return rc; }
@@ -322,6 +336,45 @@ void pattern_destroy(PatternOwner* p) {
   delete p;
 }
 
+// Row-sharded session: this process holds the cells [row0, row0 + N_local) of an N_global x M matrix,
+// N_global > M (the Gram matrix is genes x genes, a sum over cells). colptr/rowval/nzval describe the LOCAL cells (row
+// indices 0 .. N_local-1); z1 holds GLOBAL cell indices. Every session call must then be made by all ranks in the same
+// order; results that live on the gene side (spectra, search statistics, scores, gene basis) come out identical on every
+// rank, cell-side outputs (signal vectors, ensemble slots, TGC / norm_tgc) cover the local cells.
+int session_create_sharded(Ctx* ctx, int64_t N_global, int64_t row0, int64_t N_local, int64_t M, const int64_t* colptr,
+                           const int32_t* rowval, const float* nzval, int64_t ncand, const uint32_t* z1, const uint32_t* z2,
+                           sclens_hip_allreduce_fn fn, void* user, Session** out) {
+  if (!fn) return ctx->fail(SCLENS_ERR_ARG, "session_create_sharded: an all-reduce function is required");
+  if (N_global <= M) return ctx->fail(SCLENS_ERR_ARG, "session_create_sharded: only the cells > genes layout shards by cells");
+  if (N_local <= 0 || row0 < 0 || row0 + N_local > N_global) return ctx->fail(SCLENS_ERR_ARG, "session_create_sharded: bad cell range");
+  Session* s = new Session();
+  s->ctx = ctx;
+  s->N = N_local; s->M = M;
+  s->n = M; s->K = N_local; s->Kdiv = N_global;
+  s->cells_major = 0;
+  s->sh.N_global = N_global; s->sh.row0 = row0; s->sh.fn = fn; s->sh.user = user;
+  int rc = pattern_build(ctx, N_local, M, colptr, rowval, nzval, ncand, z1, z2, &s->pat, row0, N_global);
+  if (rc != SCLENS_OK) { delete s; return rc; }
+  s->ldb = round_up(s->K, 32);
+  s->lda = round_up(s->n, 32);
+  s->ldz = round_up(s->n, 32);
+  s->ldn = round_up(N_local, 32);
+  auto fail = [&](int code) { pattern_free(&s->pat); for (void* p : s->allocs) hipFree(p); delete s; return code; };
+  if ((rc = s->dmalloc((void**)&s->val, sizeof(float) * s->pat.dev.nU)) != SCLENS_OK) return fail(rc);
+  if ((rc = s->dmalloc((void**)&s->Bmain, sizeof(float) * (size_t)s->n * s->ldb)) != SCLENS_OK) return fail(rc);
+  if ((rc = s->dmalloc((void**)&s->Btmp, sizeof(float) * (size_t)s->n * s->ldb)) != SCLENS_OK) return fail(rc);
+  if ((rc = s->dmalloc((void**)&s->A, sizeof(float) * (size_t)s->n * s->lda)) != SCLENS_OK) return fail(rc);
+  if ((rc = s->dmalloc((void**)&s->w64, sizeof(double) * s->n)) != SCLENS_OK) return fail(rc);
+  *out = s;
+  return SCLENS_OK;
+}
+int session_set_reducer(Session* s, sclens_hip_allreduce_fn fn, void* user) {
+  if (!s->sh.on() || !fn) return s->ctx->fail(SCLENS_ERR_STATE, "set_reducer: not a row-sharded session");
+  s->sh.fn = fn;
+  s->sh.user = user;
+  return SCLENS_OK;
+}
+
 // A second session on another context (= another stream of the same GPU) that shares the read-only device data of
 // `src` (sparse pattern, Vr2, CheFSI seed block) and owns its scratch: independent search iterations / ensemble members
 // can then run concurrently, the latency-bound column kernels of one decomposition overlapping the bandwidth-bound
@@ -330,6 +383,8 @@ int session_clone(Ctx* ctx2, Session* src, Session** out) {
   Session* s = new Session();
   s->ctx = ctx2;
   s->N = src->N; s->M = src->M; s->n = src->n; s->K = src->K;
+  s->Kdiv = src->Kdiv;
+  s->sh = src->sh;  // same cells; the worker gets its own reducer channel through session_set_reducer
   s->cells_major = src->cells_major;
   s->centering = src->centering;
   s->pat.dev = src->pat.dev;            // shared, not owned (allocs stays empty)
@@ -359,9 +414,15 @@ void session_destroy(Session* s) {
 // scaled dense matrix of `val` -> B, Gram -> A, eigenvalues -> w64/w_host
 static int decompose(Session* s, const PatternDev& p, const float* val, int f32path, float* B, float divisor,
                      ScaleVecs* keep) {
-  SCL_TRY(scale_to_dense(s->ctx, p, val, s->centering ? 1 : f32path, s->centering, s->cells_major, B, s->ldb,
-                         s->centering ? nullptr : keep));
-  SCL_TRY(gram_f32(s->ctx, B, s->n, s->K, s->ldb, divisor, s->A, s->lda));
+  if (s->sh.on()) {  // partial statistics and a partial Gram matrix over this rank's cells, summed over the ranks
+    SCL_TRY(scale_to_dense_sharded(s->ctx, p, val, f32path, B, s->ldb, keep, s->sh));
+    SCL_TRY(gram_f32(s->ctx, B, s->n, s->K, s->ldb, divisor, s->A, s->lda));
+    SCL_TRY(s->sh.sum(s->ctx, s->A, s->n * s->lda, 1));
+  } else {
+    SCL_TRY(scale_to_dense(s->ctx, p, val, s->centering ? 1 : f32path, s->centering, s->cells_major, B, s->ldb,
+                           s->centering ? nullptr : keep));
+    SCL_TRY(gram_f32(s->ctx, B, s->n, s->K, s->ldb, divisor, s->A, s->lda));
+  }
   SCL_TRY(eig_values(s->ctx, s->A, s->n, s->lda, s->w64));
   return s->fetch_w();
 }
@@ -370,7 +431,7 @@ static int decompose(Session* s, const PatternDev& p, const float* val, int f32p
 int session_null_spectrum(Session* s, const int64_t* rc_, const int32_t* rr_, const float* rv_, double* Lr) {
   Ctx* ctx = s->ctx;
   PatternOwner pr;
-  SCL_TRY(pattern_build(ctx, s->N, s->M, rc_, rr_, rv_, 0, nullptr, nullptr, &pr));
+  SCL_TRY(pattern_build(ctx, s->N, s->M, rc_, rr_, rv_, 0, nullptr, nullptr, &pr));  // sharded: this rank's cells of X_r
   float* valr = static_cast<float*>(ctx->workspace("ses.valr", sizeof(float) * (size_t)pr.dev.nU));
   int rc = valr ? SCLENS_OK : SCLENS_ERR_OOM;
   if (rc == SCLENS_OK) rc = make_values(ctx, pr.dev, pr.base_val, 0, nullptr, 0, valr);
@@ -420,6 +481,7 @@ int session_set_pattern(Session* s, PatternOwner* p) {
   if (!p || p->allocs.empty()) return ctx->fail(SCLENS_ERR_ARG, "set_pattern: empty pattern");
   if (p->dev.N != s->N || p->dev.M != s->M) return ctx->fail(SCLENS_ERR_ARG, "set_pattern: pattern has different dimensions");
   if (s->pat.allocs.empty()) return ctx->fail(SCLENS_ERR_STATE, "set_pattern: not available on a worker session (adopt it instead)");
+  if (s->sh.on()) return ctx->fail(SCLENS_ERR_STATE, "set_pattern: a row-sharded session takes its candidates at creation");
   SCL_HIP(ctx, hipStreamSynchronize(ctx->stream));
   pattern_free(&s->pat);
   s->pat.dev = p->dev;
@@ -467,7 +529,15 @@ static int to_cell_side(Session* s, const float* B, int64_t cnt, float* dst, boo
   g.ldp = s->ldz; g.ldq = s->ldb; g.ldc = s->ldn;
   g.alpha = 1.f; g.beta = 0.f; g.q_kcontig = 0; g.lower = 0; g.colabsmax = nullptr;
   SCL_TRY(gemm_f32(ctx, g));
-  SCL_TRY(normalize_rows_f32(ctx, tmp, cnt, s->N, s->ldn));
+  if (s->sh.on()) {  // the recovery GEMM is row-local; only the vector norms span all cells
+    double* nrm = static_cast<double*>(ctx->workspace("ses.recn", sizeof(double) * (size_t)cnt));
+    if (!nrm) return SCLENS_ERR_OOM;
+    SCL_TRY(row_sqnorms_f32(ctx, tmp, cnt, s->N, s->ldn, nrm));
+    SCL_TRY(s->sh.sum(ctx, nrm, cnt, 0));
+    SCL_TRY(scale_rows_rsqrt_f32(ctx, tmp, cnt, s->N, s->ldn, nrm));
+  } else {
+    SCL_TRY(normalize_rows_f32(ctx, tmp, cnt, s->N, s->ldn));
+  }
   return desc_input ? copy_rows_f32(ctx, tmp, cnt, s->N, s->ldn, dst, s->ldn)
                     : reverse_rows_f32(ctx, tmp, cnt, s->N, s->ldn, dst, s->ldn);
 }
@@ -514,7 +584,7 @@ int session_binary_basis(Session* s, double* L_bin, int64_t* r_out) {
   Ctx* ctx = s->ctx;
   SCL_TRY(make_values(ctx, s->pat.dev, s->pat.base_val, 1, nullptr, 0, s->val));
   // get_eigvec(scaled', ...) for N > M / get_eigvec(scaled) otherwise: n x n Gram, divisor = K (Appendix A8)
-  SCL_TRY(decompose(s, s->pat.dev, s->val, 1, s->Btmp, (float)s->K, nullptr));
+  SCL_TRY(decompose(s, s->pat.dev, s->val, 1, s->Btmp, (float)s->Kdiv, nullptr));
   if (L_bin) std::copy(s->w_host.begin(), s->w_host.end(), L_bin);
   const int64_t r = s->count_positive();
   s->r_vr2 = r;
@@ -546,7 +616,7 @@ int session_search_step_seeded(Session* s, uint64_t seed, int64_t m, int64_t n_2
 }
 static int search_core(Session* s, int64_t n_2, double* d5, int64_t* r_it) {
   Ctx* ctx = s->ctx;
-  SCL_TRY(decompose(s, s->pat.dev, s->val, 1, s->Btmp, (float)s->K, nullptr));
+  SCL_TRY(decompose(s, s->pat.dev, s->val, 1, s->Btmp, (float)s->Kdiv, nullptr));
   const int64_t r = s->count_positive();
   if (r_it) *r_it = r;
   // nV_2[:, end-n_2:end] (scLENS.jl:742): the n_2+1 smallest positive eigenvalues
@@ -599,8 +669,14 @@ static int perturb_core(Session* s, int64_t t, int64_t min_pc, double* nL_top, i
   if (!slot) return SCLENS_ERR_OOM;
   s->ens[t] = slot;
   // get_eigvec(logn_scale(pre_scale(tmp_X))) (scLENS.jl:775): closure path, divisor size(X,2) = M
-  SCL_TRY(scale_to_dense(ctx, s->pat.dev, s->val, 1, s->centering, s->cells_major, s->Btmp, s->ldb, nullptr));
-  SCL_TRY(gram_f32(ctx, s->Btmp, s->n, s->K, s->ldb, (float)s->M, s->A, s->lda));
+  if (s->sh.on()) {
+    SCL_TRY(scale_to_dense_sharded(ctx, s->pat.dev, s->val, 1, s->Btmp, s->ldb, nullptr, s->sh));
+    SCL_TRY(gram_f32(ctx, s->Btmp, s->n, s->K, s->ldb, (float)s->M, s->A, s->lda));
+    SCL_TRY(s->sh.sum(ctx, s->A, s->n * s->lda, 1));
+  } else {
+    SCL_TRY(scale_to_dense(ctx, s->pat.dev, s->val, 1, s->centering, s->cells_major, s->Btmp, s->ldb, nullptr));
+    SCL_TRY(gram_f32(ctx, s->Btmp, s->n, s->K, s->ldb, (float)s->M, s->A, s->lda));
+  }
   // only the first min_pc eigenpairs are consumed (:776): subspace iteration seeded with the data matrix's vectors
   if (s->use_chefsi && s->b0 >= min_pc + 8 && s->Z0t) {
     SCL_TRY(s->ensure_zt(min_pc));
@@ -637,6 +713,7 @@ int session_set_int(Session* s, const char* name, int64_t value) {
   if (k == "chefsi") { s->use_chefsi = value != 0; return SCLENS_OK; }
   if (k == "centering") {  // 0 = "mean", 1 = "median" (scLENS.jl:651-654); set before the first decomposition
     if (value != 0 && value != 1) return s->ctx->fail(SCLENS_ERR_ARG, "session_set_int: centering must be 0 or 1");
+    if (value == 1 && s->sh.on()) return s->ctx->fail(SCLENS_ERR_ARG, "session_set_int: a row-sharded session supports mean centring only");
     if (s->have_spectrum) return s->ctx->fail(SCLENS_ERR_STATE, "session_set_int: centering is fixed once the data spectrum exists");
     s->centering = (int)value;
     return SCLENS_OK;
@@ -714,6 +791,7 @@ int session_robustness(Session* s, int64_t P, int32_t* a_b, double* b) {
     g.ldp = s->ldn; g.ldq = s->ldn; g.ldc = cmax;
     g.alpha = 1.f; g.beta = 0.f; g.q_kcontig = 1; g.lower = 0; g.colabsmax = nullptr;
     SCL_TRY(gemm_f32(ctx, g));
+    SCL_TRY(s->sh.sum(ctx, C1, k * cmax, 1));  // contraction over cells: partial on a row-sharded session
     SCL_HIP(ctx, hipMemcpyAsync(hC.data(), C1, sizeof(float) * (size_t)k * cmax, hipMemcpyDeviceToHost, ctx->stream));
     SCL_HIP(ctx, hipStreamSynchronize(ctx->stream));
     for (int64_t i = 0; i < k; ++i) {
@@ -742,6 +820,7 @@ int session_robustness(Session* s, int64_t P, int32_t* a_b, double* b) {
     g.ldp = s->ldn; g.ldq = s->ldn; g.ldc = PK;
     g.alpha = 1.f; g.beta = 0.f; g.q_kcontig = 1; g.lower = 1; g.colabsmax = nullptr;
     SCL_TRY(gemm_f32(ctx, g));
+    SCL_TRY(s->sh.sum(ctx, G, PK * PK, 1));
   }
   std::vector<float> hG((size_t)PK * PK);
   SCL_HIP(ctx, hipMemcpyAsync(hG.data(), G, sizeof(float) * (size_t)PK * PK, hipMemcpyDeviceToHost, ctx->stream));
@@ -773,6 +852,7 @@ int session_gene_basis(Session* s, const double* nL, float* out) {
   g.alpha = 1.f; g.beta = 0.f; g.lower = 0; g.colabsmax = nullptr;
   g.q_kcontig = s->cells_major ? 0 : 1;  // Bmain is [N][M] (NN) or [M][N] (NT)
   SCL_TRY(gemm_f32(ctx, g));
+  SCL_TRY(s->sh.sum(ctx, G, k * ldg, 1));
   std::vector<float> hs(k);
   for (int64_t q = 0; q < k; ++q) hs[q] = (float)(1.0 / std::sqrt(nL[q]) / std::sqrt((double)s->M));
   SCL_HIP(ctx, hipMemcpyAsync(sc, hs.data(), sizeof(float) * k, hipMemcpyHostToDevice, ctx->stream));

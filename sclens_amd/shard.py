@@ -54,6 +54,36 @@ class Shard:
         dist.all_gather_into_tensor(out.view(-1), local.contiguous().view(-1))
         return out
 
+    # -- in-place sum of a raw device buffer over the ranks (row-sharded sessions)
+    def allreduce_dev(self, ctx, dev_ptr: int, count: int, dtype: int):
+        """dtype 0 = float64, 1 = float32. RCCL when the process group has a device (backend nccl): the buffer is wrapped as
+        a torch tensor without a copy; otherwise (gloo, tests) it is staged through host memory."""
+        if self.world == 1 or count == 0:
+            return
+        import torch
+        import torch.distributed as dist
+
+        np_t = np.float64 if dtype == 0 else np.float32
+        if self.device is None:
+            h = np.empty(int(count), dtype=np_t)
+            ctx.d2h(h, dev_ptr)
+            t = torch.from_numpy(h)
+            dist.all_reduce(t)
+            ctx.h2d(dev_ptr, h)
+            return
+
+        class _Raw:  # zero-copy view of library-owned device memory
+            __cuda_array_interface__ = {"shape": (int(count),), "typestr": "<f8" if dtype == 0 else "<f4",
+                                        "data": (int(dev_ptr), False), "version": 3}
+
+        t = torch.as_tensor(_Raw(), device=self.device)
+        dist.all_reduce(t)
+        torch.cuda.synchronize(self.device)
+
+    def agree(self, arr: np.ndarray) -> np.ndarray:
+        """rank 0's copy of a small host array on every rank (decisions must not diverge by a rounding bit)"""
+        return self.allgather_small(arr)[0]
+
     def barrier(self):
         if self.world > 1:
             import torch.distributed as dist

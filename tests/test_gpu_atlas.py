@@ -1,0 +1,149 @@
+"""-m gpu: the row-sharded session (sclens_hip_session_create_sharded + sclens_amd/atlas.py) against the
+unsharded path on the same matrix and draws. The ranks are simulated inside this process: one context + one session + one
+host thread per row block, and a thread-based exchange object with the interface of sclens_amd.shard.Shard (the real
+collectives are torch.distributed all-reduces; tests/shard_rows_worker.py runs the same comparison under torchrun/gloo)."""
+import threading
+
+import numpy as np
+import pytest
+
+from sclens_amd import api, atlas
+from sclens_amd._lib import Context
+from sclens_amd.synth import synth_counts
+
+pytestmark = pytest.mark.gpu
+
+
+class ThreadShard:
+    """rank `rank` of `world` threads of this process; collectives by a barrier and shared slots"""
+
+    class Group:
+        def __init__(self, world):
+            self.world = world
+            self.bar = threading.Barrier(world, timeout=300)
+            self.slots = [None] * world
+            self.nreduce = 0
+            self.bytes = 0
+
+    def __init__(self, group, rank):
+        self.g, self.rank, self.world, self.device = group, rank, group.world, None
+
+    def _exchange(self, value):
+        self.g.slots[self.rank] = value
+        self.g.bar.wait()
+        out = list(self.g.slots)
+        self.g.bar.wait()
+        return out
+
+    def allgather_small(self, arr):
+        return np.stack(self._exchange(np.ascontiguousarray(arr, dtype=np.float64).copy()))
+
+    def agree(self, arr):
+        return self.allgather_small(arr)[0]
+
+    def allreduce_dev(self, ctx, dev_ptr, count, dtype):
+        h = np.empty(int(count), dtype=np.float64 if dtype == 0 else np.float32)
+        ctx.d2h(h, dev_ptr)
+        parts = self._exchange(h)
+        tot = parts[0].copy()
+        for p in parts[1:]:  # same order on every rank: identical bits everywhere
+            tot += p
+        ctx.h2d(dev_ptr, tot)
+        if self.rank == 0:
+            self.g.nreduce += 1
+            self.g.bytes += tot.nbytes
+
+    def barrier(self):
+        self.g.bar.wait()
+
+
+def _run_blocks(X, d, world, device, **kw):
+    N = X.shape[0]
+    group = ThreadShard.Group(world)
+    Xr = X.tocsr()
+    out, err = [None] * world, [None] * world
+
+    def work(r):
+        c = Context(device)
+        try:
+            a, b = atlas.row_block(r, world, N)
+            out[r] = atlas.sclens_row_sharded(Xr[a:b].tocsc(), a, N, d, ThreadShard(group, r), ctx=c, **kw)
+        except BaseException as e:  # noqa: BLE001 - reported by the main thread
+            err[r] = e
+            group.bar.abort()
+        finally:
+            c.close()
+
+    th = [threading.Thread(target=work, args=(r,)) for r in range(world)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    for e in err:
+        if e is not None and not isinstance(e, threading.BrokenBarrierError):
+            raise e
+    for e in err:
+        if e is not None:
+            raise e
+    return out, group
+
+
+def _cos(U, V):
+    return np.abs(np.sum(U.astype(np.float64) * V.astype(np.float64), axis=0))
+
+
+def _compare(res, ref):
+    assert np.abs(res["L"] - ref["L"]).max() < 2e-5 * ref["L"].max()
+    assert abs(res["lambda_c"] - ref["lambda_c"]) < 2e-5 * ref["lambda_c"]
+    k = len(ref["signal_ev"])
+    assert len(res["signal_ev"]) == k > 0
+    assert np.allclose(res["signal_ev"], ref["signal_ev"], rtol=5e-5)
+    assert res["n_search"] == ref["n_search"] and res["p_"] == ref["p_"]
+    for (p1, d1), (p2, d2) in zip(res["search_trace"], ref["search_trace"]):
+        assert p1 == p2 and np.abs(d1 - d2).max() < 2e-3
+    assert np.all(_cos(res["signal_evec"], ref["signal_evec"]) > 1 - 1e-3)
+    assert np.array_equal(res["robustness_scores"]["a_b"], ref["robustness_scores"]["a_b"])
+    assert np.abs(res["robustness_scores"]["rob_score"] - ref["robustness_scores"]["rob_score"]).max() < 3e-3
+    assert np.array_equal(res["sig_id"], ref["sig_id"])
+    s = np.sign(np.sum(res["signal_evec"] * ref["signal_evec"], axis=0))
+    assert np.abs(res["gene_basis"] * s[:, None] - ref["gene_basis"]).max() < 5e-3 * np.abs(ref["gene_basis"]).max()
+    for key in ("TGC", "mat2_mean", "mat2_std", "norm_tgc", "cent_"):
+        assert np.allclose(np.ravel(res["rec_vals"][key]), np.ravel(ref["rec_vals"][key]), rtol=1e-9, atol=1e-12), key
+
+
+@pytest.mark.parametrize("world", [1, 2, 3])
+def test_row_sharded_blocks_match_unsharded(ctx, world):
+    N, M = 600, 250
+    X = api._csc_f32(synth_counts(N, M, seed=1, C=5, marker_frac=0.2, marker_sd=1.5))
+    d = api.make_draws_native(X, seed=23, host_sampler=True)
+    ref = api.sclens(X, draws=d, n_perturb=5, ctx=ctx)
+    outs, group = _run_blocks(X, d, world, ctx.device, n_perturb=5)
+    for r, res in enumerate(outs):
+        _compare(res, ref)
+        assert res["row_block"] == atlas.row_block(r, world, N)
+    # gene-side results are bitwise the same on every rank (the eigen-solver ran replicated on identical inputs)
+    for res in outs[1:]:
+        assert np.array_equal(res["L"], outs[0]["L"]) and np.array_equal(res["gene_basis"], outs[0]["gene_basis"])
+        assert np.array_equal(res["robustness_scores"]["b_"], outs[0]["robustness_scores"]["b_"])
+    if world > 1:
+        S, P = ref["n_search"], 5
+        # the exchange is what SURVEY 8e-iii lists: per decomposition 4 small all-reduces + one M x M fp32 Gram matrix
+        assert group.nreduce >= (3 + S + P) * 5
+        assert group.bytes >= (3 + S + P) * 4 * M * M
+
+
+def test_row_sharded_device_sampler_and_errors(ctx):
+    N, M = 520, 200
+    X = api._csc_f32(synth_counts(N, M, seed=3, C=4, marker_frac=0.2, marker_sd=1.5))
+    d = api.make_draws_native(X, seed=5)  # R4/R5 on the device: keyed permutation over the GLOBAL candidate list
+    ref = api.sclens(X, draws=d, n_perturb=4, ctx=ctx, max_search_iters=6)
+    outs, _ = _run_blocks(X, d, 2, ctx.device, n_perturb=4, max_search_iters=6)
+    _compare(outs[0], ref)
+    # cells <= genes does not shard by cells; a reducer is mandatory
+    with pytest.raises(ValueError):
+        atlas.sclens_row_sharded(X.T.tocsc()[:100], 0, M, d, ThreadShard(ThreadShard.Group(1), 0), ctx=ctx)
+    import ctypes as C
+    h = C.c_void_p()
+    rc = ctx.lib.sclens_hip_session_create_sharded(ctx.h, N, 0, N // 2, M, None, None, None, 0, None, None,
+                                                   C.cast(None, api._lib.ALLREDUCE_FN), None, C.byref(h))
+    assert rc == 1

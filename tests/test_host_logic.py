@@ -160,3 +160,15 @@ def test_keyed_permutation_sampler():
     exp = counts.sum() / 10
     assert ((counts - exp) ** 2 / exp).sum() < 30  # chi2(9) 99.9 % quantile is 27.9
     assert api.sample_seed_for(1, "search", 0) != api.sample_seed_for(1, "perturb", 0)
+
+
+def test_row_blocks_partition_the_cells():
+    """atlas.row_block: contiguous, disjoint, covering, sizes within one of each other."""
+    from sclens_amd import atlas
+
+    for N, world in ((10, 3), (601, 2), (1000000, 8), (7, 7)):
+        blocks = [atlas.row_block(r, world, N) for r in range(world)]
+        assert blocks[0][0] == 0 and blocks[-1][1] == N
+        assert all(blocks[r][1] == blocks[r + 1][0] for r in range(world - 1))
+        sizes = [b - a for a, b in blocks]
+        assert max(sizes) - min(sizes) <= 1 and min(sizes) >= 1
