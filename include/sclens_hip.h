@@ -212,6 +212,13 @@ int sclens_hip_session_data_spectrum(sclens_hip_session* s, double* L, double* r
  * block of the partial eigensolver (after signal_vectors on src), 4 the sparse pattern (after set_pattern on src);
  * flags may be or-ed. `src` must outlive `dst`'s use of them. */
 int sclens_hip_session_adopt(sclens_hip_session* dst, sclens_hip_session* src, int what);
+/* The same between GPUs: device buffers of Vr2 (what = 1) and of the seed block of the partial eigensolver (what = 2: its
+ * b0 rows, their eigenvalues theta0[b0] and the signal count k), for a host that spreads the data / null / binarised
+ * decompositions (scLENS.jl:704, :717-721) over ranks and broadcasts the results (RCCL on *dev_ptr: rows x *ld floats).
+ * rows = 0: owner side, query (theta0 is filled); rows > 0: receiver side, allocate for `rows` rows and record k / theta0
+ * before the broadcast lands. For the seed block *dev_ptr may come back NULL (*rows_out = 0): no seed, full solver. */
+int sclens_hip_session_shared_buffer(sclens_hip_session* s, int what, int64_t rows, int64_t k, double* theta0,
+                                     void** dev_ptr, int64_t* rows_out, int64_t* k_out, int64_t* ld);
 /* Second half (scLENS.jl:541-558, :580-590): cell-side eigenvectors of the k largest eigenvalues,
  * descending; nV is N x k (may be NULL: they also stay on the device for the later steps). */
 int sclens_hip_session_signal_vectors(sclens_hip_session* s, int64_t k, float* nV);

@@ -6,6 +6,7 @@ from __future__ import annotations
 
 import ctypes as C
 import os
+import sys
 
 import numpy as np
 
@@ -58,6 +59,7 @@ SIGNATURES = {
     "sclens_hip_session_create_sharded": (C.c_int, [vp, i64, i64, i64, i64, c_i64p, c_i32p, c_f32p, i64, c_u32p, c_u32p, ALLREDUCE_FN,
                                                     vp, C.POINTER(vp)]),
     "sclens_hip_session_set_reducer": (C.c_int, [vp, ALLREDUCE_FN, vp]),
+    "sclens_hip_session_shared_buffer": (C.c_int, [vp, C.c_int, i64, i64, c_f64p, C.POINTER(vp), c_i64p, c_i64p, c_i64p]),
     "sclens_hip_pattern_create": (C.c_int, [vp, i64, i64, c_i64p, c_i32p, c_f32p, i64, c_u32p, c_u32p, C.POINTER(vp)]),
     "sclens_hip_pattern_destroy": (None, [vp]),
     "sclens_hip_session_set_pattern": (C.c_int, [vp, vp]),
@@ -157,6 +159,14 @@ class Context:
 
     def __init__(self, device: int = 0):
         self.lib = load()
+        # PyTorch-ROCm wheels bundle their own HIP runtime next to the system one this library links: both can live in one
+        # process, but only if torch's is initialised first (measured: the other order leaves torch with "No HIP GPUs").
+        # A process that has imported torch (the multi-GPU hosts do, for torch.distributed) gets that order here.
+        if "torch" in sys.modules:
+            try:
+                sys.modules["torch"].cuda.is_available()
+            except Exception:
+                pass
         h = vp()
         rc = self.lib.sclens_hip_create(C.byref(h), int(device))
         if rc != 0:

@@ -496,6 +496,20 @@ class Session:
         except Exception:
             pass
 
+    def shared_buffer(self, what: int, rows: int = 0, k: int = 0, theta0: Optional[np.ndarray] = None):
+        """(device pointer, rows, theta0) of Vr2 (what = 1) or of the seed block (what = 2); rows > 0 allocates on a receiver."""
+        p, r_out, k_out, ld = C.c_void_p(), C.c_int64(0), C.c_int64(0), C.c_int64(0)
+        th = np.zeros(max(int(rows), 128))
+        if theta0 is not None:
+            th[: len(theta0)] = theta0
+        self.ctx.check(self.ctx.lib.sclens_hip_session_shared_buffer(self.h, int(what), int(rows), int(k), ptr(th, C.c_double),
+                                                                     C.byref(p), C.byref(r_out), C.byref(k_out), C.byref(ld)))
+        self._ldz = ld.value
+        return p.value, r_out.value, th[: r_out.value].copy()
+
+    def ldz(self) -> int:
+        return (self.n + 31) // 32 * 32
+
     def set_pattern(self, pat: "Pattern"):
         """Attach the union pattern (counts + zero candidates) built by `Pattern`; the session must be idle."""
         self.ctx.check(self.ctx.lib.sclens_hip_session_set_pattern(self.h, pat.h))
@@ -679,7 +693,7 @@ def _extract(inp):
 def sclens(inp_df, device_="gpu", th=60, p_step=0.001, n_perturb=20, centering="mean", draws: Optional[Draws] = None,
            seed: Optional[int] = None, ctx: Optional[Context] = None, max_search_iters: Optional[int] = None,
            keep_intermediates: bool = False, verbose: bool = False, shard: Optional[Shard] = None,
-           partial_eig: bool = True, streams: int = 1, batch: bool = False) -> Dict[str, object]:
+           partial_eig: bool = True, streams: int = 1, batch: bool = False, spread_initial: bool = True) -> Dict[str, object]:
     """scLENS.sclens (scLENS.jl:649-832) on one MI355X.
 
     Same keyword arguments as the reference. `draws`/`seed` expose the randomness the reference takes from
@@ -771,7 +785,28 @@ def sclens(inp_df, device_="gpu", th=60, p_step=0.001, n_perturb=20, centering="
             return out
 
         # ---- get_sigev (:704) and Vr2 (:717-721): the data, null and binarised matrices are independent decompositions
-        if W == 1:  # serial order of the reference: null and data spectra, signal vectors, then Vr2
+        spread = shard.world > 1 and spread_initial
+        if spread:
+            # one decomposition per rank (rank 0 data, rank 1 null, rank 2 -- or 1 -- binarised), each running alone on its
+            # GPU instead of three sharing every GPU; spectra go over the wire as host arrays, Vr2 and the seed block of the
+            # partial eigensolver as device-to-device broadcasts (RCCL)
+            r_null, r_bin = 1, (2 if shard.world >= 3 else 1)
+            free = workers[1:] if shard.rank == 0 else workers  # sessions for the null / binarised matrix on this rank
+            jobs, w_bin = [], ses
+            if shard.rank == 0:
+                jobs.append((0, lambda: ("data", ses.data_spectrum(not median))))
+            if shard.rank == r_null:
+                w_null = free[0]
+                jobs.append((workers.index(w_null), lambda: ("null", w_null.null_spectrum(_resolve(draws.X_r)))))
+            if shard.rank == r_bin:
+                w_bin = free[1] if (shard.rank == r_null and len(free) > 1) else free[0]
+                jobs.append((workers.index(w_bin), lambda: ("bin", w_bin.binary_basis())))
+            got = dict(run_all(jobs)) if jobs else {}
+            L, rec_vals = got.get("data", (np.zeros(ses.n), {}))
+            L = shard.bcast_host(L, 0)
+            Lr = shard.bcast_host(got.get("null", np.zeros(ses.n)), r_null)
+            r_vr2 = int(shard.bcast_host(np.array([float(got["bin"][1]) if "bin" in got else 0.0]), r_bin)[0])
+        elif W == 1:  # serial order of the reference: null and data spectra, signal vectors, then Vr2
             w_bin = ses
             Lr = ses.null_spectrum(_resolve(draws.X_r))
             L, rec_vals = ses.data_spectrum(not median)
@@ -787,9 +822,28 @@ def sclens(inp_df, device_="gpu", th=60, p_step=0.001, n_perturb=20, centering="
         if verbose:
             print(f"(Using hip) number of signal ev: {k}")
         nL = L[sel][::-1].copy()  # descending
-        nV = ses.signal_vectors(k)
+        nV = ses.signal_vectors(k) if (not spread or shard.rank == 0) else None
         if r_vr2 is None:
             _, r_vr2 = ses.binary_basis()
+        if spread:
+            # seed block of the partial eigensolver: rank 0 -> all (b0 rows of ldz floats + their eigenvalues)
+            meta = np.zeros(130)
+            if shard.rank == 0:
+                ptr0, b0_, th0 = ses.shared_buffer(2)
+                meta[0] = b0_
+                meta[1: 1 + b0_] = th0
+            meta = shard.bcast_host(meta, 0)
+            b0_ = int(meta[0])
+            if b0_ > 0:
+                if shard.rank != 0:
+                    ptr0, _, _ = ses.shared_buffer(2, rows=b0_, k=k, theta0=meta[1: 1 + b0_])
+                shard.bcast_dev(ctx, ptr0, b0_ * ses.ldz(), 0)
+            # Vr2: the rank that decomposed the binarised matrix -> all
+            if r_vr2 > 0:
+                holder = w_bin if shard.rank == r_bin else ses
+                ptr1, _, _ = holder.shared_buffer(1, rows=0 if shard.rank == r_bin else r_vr2)
+                shard.bcast_dev(ctx, ptr1, r_vr2 * ses.ldz(), r_bin)
+                w_bin = holder
         lap("spectra_signal_vectors_vr2")
         pat, z1, z2 = pat_future.result()
         ses.set_pattern(pat)
@@ -888,6 +942,9 @@ def sclens(inp_df, device_="gpu", th=60, p_step=0.001, n_perturb=20, centering="
                                   "p_": p_, "p_th": p_th, "n_search": it, "search_trace": trace,
                                   "partial_eig": pe_counts}
         if min_s == 0:  # :780-784
+            res["wall_s"] = time.perf_counter() - t_all
+            return res
+        if spread and shard.rank != 0:  # the signal vectors and the scaled data matrix live on rank 0, which scores
             res["wall_s"] = time.perf_counter() - t_all
             return res
         # ---- robustness (:786-807)

@@ -9,6 +9,7 @@ int session_create(Ctx*, int64_t, int64_t, const int64_t*, const int32_t*, const
 int session_create_sharded(Ctx*, int64_t, int64_t, int64_t, int64_t, const int64_t*, const int32_t*, const float*, int64_t,
                            const uint32_t*, const uint32_t*, sclens_hip_allreduce_fn, void*, Session**);
 int session_set_reducer(Session*, sclens_hip_allreduce_fn, void*);
+int session_shared_buffer(Session*, int, int64_t, int64_t, double*, void**, int64_t*, int64_t*, int64_t*);
 void session_destroy(Session*);
 int session_clone(Ctx*, Session*, Session**);
 int session_spectrum(Session*, const int64_t*, const int32_t*, const float*, double*, double*, ScaleVecs*);
@@ -272,6 +273,11 @@ int sclens_hip_session_set_pattern(sclens_hip_session* w, sclens_hip_pattern* p)
   SES_GUARD(w);
   if (!p) return SCLENS_ERR_ARG;
   return scl::session_set_pattern(w->s, reinterpret_cast<scl::PatternOwner*>(p));
+}
+int sclens_hip_session_shared_buffer(sclens_hip_session* w, int what, int64_t rows, int64_t k, double* theta0, void** dev_ptr,
+                                     int64_t* rows_out, int64_t* k_out, int64_t* ld) {
+  SES_GUARD(w);
+  return scl::session_shared_buffer(w->s, what, rows, k, theta0, dev_ptr, rows_out, k_out, ld);
 }
 int sclens_hip_session_adopt(sclens_hip_session* dst, sclens_hip_session* src, int what) {
   SES_GUARD(dst);

@@ -708,6 +708,46 @@ static int perturb_core(Session* s, int64_t t, int64_t min_pc, double* nL_top, i
   return to_cell_side(s, s->Btmp, c, slot);
 }
 
+// Device buffers of the two read-only results that other ranks need when the first three decompositions are spread
+// over the ranks (api.sclens with world > 1): Vr2 (what = 1; rows = positive eigenvalues of the binarised matrix) and the
+// seed block of the partial eigensolver (what = 2; rows = b0, with its eigenvalues theta0 and the signal count k).
+// rows > 0: receiver side, (re)allocate for `rows` rows and record the metadata; rows == 0: owner side, query.
+int session_shared_buffer(Session* s, int what, int64_t rows, int64_t k, double* theta0, void** ptr, int64_t* rows_out,
+                          int64_t* k_out, int64_t* ld) {
+  Ctx* ctx = s->ctx;
+  if (what != 1 && what != 2) return ctx->fail(SCLENS_ERR_ARG, "shared_buffer: what must be 1 (Vr2) or 2 (seed block)");
+  if (rows < 0 || rows > s->n) return ctx->fail(SCLENS_ERR_ARG, "shared_buffer: bad row count");
+  SCL_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  if (what == 1) {
+    if (rows > 0) {
+      float* v = static_cast<float*>(ctx->workspace("ses.Vr2t", sizeof(float) * (size_t)rows * s->ldz));
+      if (!v) return SCLENS_ERR_OOM;
+      s->Vr2t = v;
+      s->r_vr2 = rows;
+    }
+    if (!s->Vr2t) return ctx->fail(SCLENS_ERR_STATE, "shared_buffer: no Vr2 on this session");
+    if (ptr) *ptr = s->Vr2t;
+    if (rows_out) *rows_out = s->r_vr2;
+  } else {
+    if (rows > 0) {
+      if (!theta0 || k < 0) return ctx->fail(SCLENS_ERR_ARG, "shared_buffer: the seed block needs k and theta0");
+      float* z0 = static_cast<float*>(ctx->workspace("ses.Z0t", sizeof(float) * (size_t)rows * s->ldz));
+      if (!z0) return SCLENS_ERR_OOM;
+      s->Z0t = z0;
+      s->b0 = rows;
+      s->k = k;
+      s->theta0.assign(theta0, theta0 + rows);
+    } else if (s->Z0t && theta0) {
+      std::copy(s->theta0.begin(), s->theta0.end(), theta0);
+    }
+    if (ptr) *ptr = s->Z0t;  // may be null: the data matrix gave no usable seed block (b0 = 0)
+    if (rows_out) *rows_out = s->Z0t ? s->b0 : 0;
+    if (k_out) *k_out = s->k;
+  }
+  if (ld) *ld = s->ldz;
+  return SCLENS_OK;
+}
+
 int session_set_int(Session* s, const char* name, int64_t value) {
   const std::string k(name ? name : "");
   if (k == "chefsi") { s->use_chefsi = value != 0; return SCLENS_OK; }

@@ -80,6 +80,46 @@ class Shard:
         dist.all_reduce(t)
         torch.cuda.synchronize(self.device)
 
+    # -- one-to-all copies for the spread initial phase (api.sclens, world > 1)
+    def bcast_host(self, arr: np.ndarray, src: int) -> np.ndarray:
+        """float64 host array of the same shape on every rank; returns rank `src`'s content"""
+        arr = np.ascontiguousarray(arr, dtype=np.float64)
+        if self.world == 1:
+            return arr
+        import torch
+        import torch.distributed as dist
+
+        t = torch.from_numpy(arr.copy())
+        if self.device is not None:
+            t = t.to(self.device)
+        dist.broadcast(t, src=src)
+        return t.cpu().numpy()
+
+    def bcast_dev(self, ctx, dev_ptr: int, count_f32: int, src: int):
+        """`count_f32` floats at a raw device pointer (allocated on every rank), from rank `src` to all, in place"""
+        if self.world == 1 or count_f32 == 0:
+            return
+        import torch
+        import torch.distributed as dist
+
+        if self.device is None:  # gloo (tests): through host memory
+            h = np.empty(int(count_f32), dtype=np.float32)
+            if self.rank == src:
+                ctx.d2h(h, dev_ptr)
+            t = torch.from_numpy(h)
+            dist.broadcast(t, src=src)
+            if self.rank != src:
+                ctx.h2d(dev_ptr, h)
+            return
+
+        class _Raw:
+            __cuda_array_interface__ = {"shape": (int(count_f32),), "typestr": "<f4", "data": (int(dev_ptr), False),
+                                        "version": 3}
+
+        t = torch.as_tensor(_Raw(), device=self.device)
+        dist.broadcast(t, src=src)
+        torch.cuda.synchronize(self.device)
+
     def agree(self, arr: np.ndarray) -> np.ndarray:
         """rank 0's copy of a small host array on every rank (decisions must not diverge by a rounding bit)"""
         return self.allgather_small(arr)[0]

@@ -14,6 +14,12 @@ def pytest_configure(config):
 
 @pytest.fixture(scope="session")
 def ctx():
+    # some -m gpu tests hand torch CUDA tensors to the library (ensemble exchange): PyTorch's bundled HIP runtime has to be
+    # initialised before the library's; Context() does that when torch is already imported
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     from sclens_amd._lib import Context
 
     c = Context(0)

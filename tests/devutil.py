@@ -1,5 +1,6 @@
 """Helpers for the -m gpu tests: move numpy arrays through the C ABI's raw device entry points."""
 import ctypes as C
+import threading
 
 import numpy as np
 
@@ -39,3 +40,63 @@ def pad_rows(a, ld):
 
 def rup(x, m):
     return (x + m - 1) // m * m
+
+
+class ThreadShard:
+    """rank `rank` of `world` threads of this process; collectives by a barrier and shared slots"""
+
+    class Group:
+        def __init__(self, world):
+            self.world = world
+            self.bar = threading.Barrier(world, timeout=300)
+            self.slots = [None] * world
+            self.nreduce = 0
+            self.bytes = 0
+
+    def __init__(self, group, rank):
+        self.g, self.rank, self.world, self.device = group, rank, group.world, None
+
+    def _exchange(self, value):
+        self.g.slots[self.rank] = value
+        self.g.bar.wait()
+        out = list(self.g.slots)
+        self.g.bar.wait()
+        return out
+
+    def allgather_small(self, arr):
+        return np.stack(self._exchange(np.ascontiguousarray(arr, dtype=np.float64).copy()))
+
+    def agree(self, arr):
+        return self.allgather_small(arr)[0]
+
+    def allreduce_dev(self, ctx, dev_ptr, count, dtype):
+        h = np.empty(int(count), dtype=np.float64 if dtype == 0 else np.float32)
+        ctx.d2h(h, dev_ptr)
+        parts = self._exchange(h)
+        tot = parts[0].copy()
+        for p in parts[1:]:  # same order on every rank: identical bits everywhere
+            tot += p
+        ctx.h2d(dev_ptr, tot)
+        if self.rank == 0:
+            self.g.nreduce += 1
+            self.g.bytes += tot.nbytes
+
+    def barrier(self):
+        self.g.bar.wait()
+
+    def bcast_host(self, arr, src):
+        return self.allgather_small(arr)[src]
+
+    def bcast_dev(self, ctx, dev_ptr, count_f32, src):
+        h = np.empty(int(count_f32), dtype=np.float32)
+        if self.rank == src:
+            ctx.d2h(h, dev_ptr)
+        got = self._exchange(h if self.rank == src else None)[src]
+        if self.rank != src:
+            ctx.h2d(dev_ptr, got)
+
+    def allgather_blocks(self, local):
+        import torch
+
+        return torch.stack([t.to(local.device) for t in self._exchange(local.detach().clone())])
+

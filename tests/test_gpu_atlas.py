@@ -7,54 +7,12 @@ import threading
 import numpy as np
 import pytest
 
+from devutil import ThreadShard
 from sclens_amd import api, atlas
 from sclens_amd._lib import Context
 from sclens_amd.synth import synth_counts
 
 pytestmark = pytest.mark.gpu
-
-
-class ThreadShard:
-    """rank `rank` of `world` threads of this process; collectives by a barrier and shared slots"""
-
-    class Group:
-        def __init__(self, world):
-            self.world = world
-            self.bar = threading.Barrier(world, timeout=300)
-            self.slots = [None] * world
-            self.nreduce = 0
-            self.bytes = 0
-
-    def __init__(self, group, rank):
-        self.g, self.rank, self.world, self.device = group, rank, group.world, None
-
-    def _exchange(self, value):
-        self.g.slots[self.rank] = value
-        self.g.bar.wait()
-        out = list(self.g.slots)
-        self.g.bar.wait()
-        return out
-
-    def allgather_small(self, arr):
-        return np.stack(self._exchange(np.ascontiguousarray(arr, dtype=np.float64).copy()))
-
-    def agree(self, arr):
-        return self.allgather_small(arr)[0]
-
-    def allreduce_dev(self, ctx, dev_ptr, count, dtype):
-        h = np.empty(int(count), dtype=np.float64 if dtype == 0 else np.float32)
-        ctx.d2h(h, dev_ptr)
-        parts = self._exchange(h)
-        tot = parts[0].copy()
-        for p in parts[1:]:  # same order on every rank: identical bits everywhere
-            tot += p
-        ctx.h2d(dev_ptr, tot)
-        if self.rank == 0:
-            self.g.nreduce += 1
-            self.g.bytes += tot.nbytes
-
-    def barrier(self):
-        self.g.bar.wait()
 
 
 def _run_blocks(X, d, world, device, **kw):

@@ -329,3 +329,53 @@ def test_midsize_parity_native_draws(ctx):
     assert np.array_equal(res["sig_id"], ref["sig_id"])
     assert np.abs(res["robustness_scores"]["rob_score"] - ref["robustness_scores"]["rob_score"]).max() < 5e-3
     assert res["partial_eig"][0] + res["partial_eig"][1] == 6
+
+
+@pytest.mark.parametrize("world,streams", [(2, 2), (3, 1), (4, 2)])
+def test_multi_rank_sclens_equals_single_rank(ctx, world, streams):
+    """api.sclens(shard=...) with `world` ranks simulated as threads of this process (one context each; collectives by
+    devutil.ThreadShard): the data / null / binarised decompositions are spread over the ranks and their results
+    broadcast, search rounds of world x streams evaluations, ensemble members t % world. Rank 0's result must equal the
+    single-rank run bit for bit (same kernels on the same inputs; results consumed in iteration order)."""
+    import threading
+
+    from devutil import ThreadShard
+    from sclens_amd._lib import Context
+
+    X = api._csc_f32(synth_counts(300, 500, seed=1, C=5, marker_frac=0.2, marker_sd=1.5))
+    d = api.make_draws_native(X, seed=13)
+    ref = api.sclens(X, draws=d, n_perturb=6, ctx=ctx, streams=streams)
+    group = ThreadShard.Group(world)
+    out, err = [None] * world, [None] * world
+
+    def work(r):
+        c = Context(ctx.device)
+        try:
+            out[r] = api.sclens(X, draws=d, n_perturb=6, ctx=c, streams=streams, shard=ThreadShard(group, r))
+        except BaseException as e:  # noqa: BLE001
+            err[r] = e
+            group.bar.abort()
+        finally:
+            c.close()
+
+    th = [threading.Thread(target=work, args=(r,)) for r in range(world)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    for e in err:
+        if e is not None and not isinstance(e, threading.BrokenBarrierError):
+            raise e
+    assert all(e is None for e in err)
+    res = out[0]
+    assert np.array_equal(res["L"], ref["L"]) and res["p_"] == ref["p_"] and res["n_search"] == ref["n_search"]
+    for (p1, t1), (p2, t2) in zip(res["search_trace"], ref["search_trace"]):
+        assert p1 == p2 and np.array_equal(t1, t2)
+    assert np.array_equal(res["signal_evec"], ref["signal_evec"])
+    assert np.array_equal(res["robustness_scores"]["b_"], ref["robustness_scores"]["b_"])
+    assert np.array_equal(res["sig_id"], ref["sig_id"])
+    assert np.array_equal(res["gene_basis"], ref["gene_basis"])
+    for t in range(6):
+        assert np.array_equal(res["nL_set"][t], ref["nL_set"][t])
+    for r in range(1, world):  # the other ranks return the shared part of the result
+        assert np.array_equal(out[r]["L"], ref["L"]) and out[r]["p_"] == ref["p_"] and "pca" not in out[r]
