@@ -15,6 +15,16 @@ from typing import Callable, List, Sequence
 import numpy as np
 
 
+def raw_device_tensor(dev_ptr: int, count: int, typestr: str, device):
+    """zero-copy torch view of `count` elements of library-owned device memory (`__cuda_array_interface__`)"""
+    import torch
+
+    class _Raw:
+        __cuda_array_interface__ = {"shape": (int(count),), "typestr": typestr, "data": (int(dev_ptr), False), "version": 3}
+
+    return torch.as_tensor(_Raw(), device=device)
+
+
 class Shard:
     """rank/world + the two collectives. `world == 1` needs no torch."""
 
@@ -55,10 +65,11 @@ class Shard:
         return out
 
     # -- in-place sum of a raw device buffer over the ranks (row-sharded sessions)
-    def allreduce_dev(self, ctx, dev_ptr: int, count: int, dtype: int):
+    def allreduce_dev(self, ctx, dev_ptr: int, count: int, dtype: int, _force: bool = False):
         """dtype 0 = float64, 1 = float32. RCCL when the process group has a device (backend nccl): the buffer is wrapped as
-        a torch tensor without a copy; otherwise (gloo, tests) it is staged through host memory."""
-        if self.world == 1 or count == 0:
+        a torch tensor without a copy; otherwise (gloo, tests) it is staged through host memory. `_force`: run the
+        collective even in a one-rank group (tests of the RCCL branch on a single GPU)."""
+        if (self.world == 1 and not _force) or count == 0:
             return
         import torch
         import torch.distributed as dist
@@ -72,11 +83,7 @@ class Shard:
             ctx.h2d(dev_ptr, h)
             return
 
-        class _Raw:  # zero-copy view of library-owned device memory
-            __cuda_array_interface__ = {"shape": (int(count),), "typestr": "<f8" if dtype == 0 else "<f4",
-                                        "data": (int(dev_ptr), False), "version": 3}
-
-        t = torch.as_tensor(_Raw(), device=self.device)
+        t = raw_device_tensor(dev_ptr, count, "<f8" if dtype == 0 else "<f4", self.device)
         dist.all_reduce(t)
         torch.cuda.synchronize(self.device)
 
@@ -95,9 +102,9 @@ class Shard:
         dist.broadcast(t, src=src)
         return t.cpu().numpy()
 
-    def bcast_dev(self, ctx, dev_ptr: int, count_f32: int, src: int):
+    def bcast_dev(self, ctx, dev_ptr: int, count_f32: int, src: int, _force: bool = False):
         """`count_f32` floats at a raw device pointer (allocated on every rank), from rank `src` to all, in place"""
-        if self.world == 1 or count_f32 == 0:
+        if (self.world == 1 and not _force) or count_f32 == 0:
             return
         import torch
         import torch.distributed as dist
@@ -112,11 +119,7 @@ class Shard:
                 ctx.h2d(dev_ptr, h)
             return
 
-        class _Raw:
-            __cuda_array_interface__ = {"shape": (int(count_f32),), "typestr": "<f4", "data": (int(dev_ptr), False),
-                                        "version": 3}
-
-        t = torch.as_tensor(_Raw(), device=self.device)
+        t = raw_device_tensor(dev_ptr, count_f32, "<f4", self.device)
         dist.broadcast(t, src=src)
         torch.cuda.synchronize(self.device)
 

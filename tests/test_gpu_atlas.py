@@ -105,3 +105,50 @@ def test_row_sharded_device_sampler_and_errors(ctx):
     rc = ctx.lib.sclens_hip_session_create_sharded(ctx.h, N, 0, N // 2, M, None, None, None, 0, None, None,
                                                    C.cast(None, api._lib.ALLREDUCE_FN), None, C.byref(h))
     assert rc == 1
+
+
+def test_rccl_branch_on_a_one_rank_group(ctx):
+    """The `nccl` (= RCCL) branches of Shard.allreduce_dev / bcast_dev / allgather_blocks cannot meet a second rank on a
+    one-GPU box, but everything else about them can be checked in a one-rank group: the zero-copy torch view of
+    library-owned device memory (`__cuda_array_interface__` on PyTorch-ROCm), an RCCL collective running on that view,
+    and the result landing in the library's buffer."""
+    import os
+
+    import torch
+    import torch.distributed as dist
+
+    from devutil import DevArray
+    from sclens_amd.shard import Shard, raw_device_tensor
+
+    dev = torch.device("cuda", ctx.device)
+    x64 = np.arange(1000, dtype=np.float64) * 0.5 - 3.0
+    x32 = np.linspace(-1, 1, 777).astype(np.float32)
+    d64, d32 = DevArray(ctx, x64), DevArray(ctx, x32)
+    # the view aliases the library's memory: a torch write is visible through the C ABI
+    t = raw_device_tensor(d32.p, x32.size, "<f4", dev)
+    assert t.dtype == torch.float32 and t.is_cuda and np.array_equal(t.cpu().numpy(), x32)
+    t.mul_(2.0)
+    torch.cuda.synchronize()
+    assert np.array_equal(d32.get(x32.shape, np.float32), 2 * x32)
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29591")
+    created = not dist.is_initialized()
+    if created:
+        dist.init_process_group(backend="nccl", rank=0, world_size=1, device_id=dev)
+    try:
+        sh = Shard(0, 1, dev)
+        sh.allreduce_dev(ctx, d64.p, x64.size, 0, _force=True)  # sum over one rank: unchanged, but through RCCL
+        sh.allreduce_dev(ctx, d32.p, x32.size, 1, _force=True)
+        sh.bcast_dev(ctx, d32.p, x32.size, 0, _force=True)
+        assert np.array_equal(d64.get(x64.shape, np.float64), x64)
+        assert np.array_equal(d32.get(x32.shape, np.float32), 2 * x32)
+        sh.world = 1
+        blocks = torch.arange(24, dtype=torch.float32, device=dev).reshape(2, 3, 4)
+        out = torch.empty((1,) + tuple(blocks.shape), dtype=blocks.dtype, device=dev)
+        dist.all_gather_into_tensor(out.view(-1), blocks.contiguous().view(-1))  # what allgather_blocks issues
+        assert torch.equal(out[0], blocks)
+    finally:
+        if created:
+            dist.destroy_process_group()
+        d64.free()
+        d32.free()
