@@ -393,6 +393,10 @@ int sclens_hip_dev_gram_f32(sclens_hip_ctx* h, const float* B, int64_t n, int64_
   CTX_GUARD(h);
   return scl::gram_f32(&h->c, B, n, K, ldb, divisor, A, lda);
 }
+int sclens_hip_dev_sy2sb_f32(sclens_hip_ctx* h, float* A, int64_t n, int64_t lda, float* T, int* breakdown) {
+  CTX_GUARD(h);
+  return scl::sy2sb_f32(&h->c, A, n, lda, T, breakdown);
+}
 int sclens_hip_dev_sytrd_f32(sclens_hip_ctx* h, float* A, int64_t n, int64_t lda, double* d, double* e, float* tau) {
   CTX_GUARD(h);
   return scl::sytrd_f32(&h->c, A, n, lda, d, e, tau);

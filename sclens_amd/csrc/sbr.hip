@@ -1,0 +1,377 @@
+// Two-stage tridiagonalisation, stage 1: dense symmetric -> symmetric band of half-width SB, on the matrix cores.
+// (Work in progress towards replacing the one-stage reduction of tridiag.hip, whose symmetric matrix-vector product streams
+// the trailing matrix once per column -- 2/3 n^3 bytes -- see DESIGN.md section 7. Not selected by eig_values yet.)
+//
+// Replaces, together with the later stages, the first phase of `_get_eigen` (scLENS.jl:375-387 -> cuSOLVER ssyevd / LAPACK
+// dsyevr in the reference).
+//
+// Panel p reduces the columns [p SB, (p+1) SB) below the band: P = A[r0:, c0:c0+SB] (n' x SB, r0 = c0 + SB) is factored
+// P = Q R by a Cholesky QR whose Gram matrix and triangular algebra are fp64 (fp32 data: orthogonality ~ eps64 cond(P)^2 +
+// eps32, so one pass is enough up to cond ~ 1e4; a non-positive pivot raises the breakdown flag and the caller falls back
+// to the one-stage solver), the Householder representation Q D = (I - V T V')[:, :SB] is reconstructed from the thin Q
+// by the sign-modified LU of its top block (Ballard, Demmel, Grigori, Jacquelin, Knight, Nguyen: "Reconstructing
+// Householder vectors from tall-skinny QR", 2015): only SB x SB work is sequential, the rest is one n' x SB triangular
+// product. The trailing matrix then gets the two-sided update A22 <- A22 - V Z' - Z V' with W = A22 V, Y = W T,
+// Z = Y - 1/2 V (T' V' Y): one skinny MFMA product (split over K inside one launch) and one rank-2SB symmetric MFMA
+// update per panel, the same gemm_kernel as everywhere else.
+// Storage: V_p is kept in the UPPER part of A (rows c0..c0+SB-1, columns r0..n-1: contiguous over the long dimension, the
+// layout every GEMM here wants), the band in the LOWER part, T_p in a side array. The matrix order must be a multiple of
+// SB (the caller pads with a decoupled diagonal block). All reductions run in a fixed order: bitwise reproducible.
+#include "common.h"
+
+namespace scl {
+
+constexpr int SB = 64;
+
+// ---- partial cross products of two 64-row blocks: part[wg][i][j] = sum_{k in chunk wg} X[i][k] * Y[j][k]  (fp64) ------
+__global__ __launch_bounds__(256) void sbr_cross_part(const float* __restrict__ X, int64_t ldx, const float* __restrict__ Y,
+                                                      int64_t ldy, int64_t len, double* __restrict__ part) {
+  __shared__ float xs[SB][33], ys[SB][33];
+  const int tid = threadIdx.x, ti = tid >> 4, tj = tid & 15;
+  const bool same = (X == Y);
+  double acc[4][4];
+#pragma unroll
+  for (int u = 0; u < 4; ++u)
+#pragma unroll
+    for (int v = 0; v < 4; ++v) acc[u][v] = 0.0;
+  const int64_t k0 = (int64_t)blockIdx.x * 256;
+  const int64_t kend = (k0 + 256 < len) ? k0 + 256 : len;
+  for (int64_t kc = k0; kc < kend; kc += 32) {
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const int idx = tid + 256 * q, r = idx >> 5, c = idx & 31;
+      const int64_t k = kc + c;
+      xs[r][c] = (k < kend) ? X[(int64_t)r * ldx + k] : 0.f;
+      if (!same) ys[r][c] = (k < kend) ? Y[(int64_t)r * ldy + k] : 0.f;
+    }
+    __syncthreads();
+#pragma unroll 4
+    for (int c = 0; c < 32; ++c) {
+      double a[4], b[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) a[u] = (double)xs[4 * ti + u][c];
+#pragma unroll
+      for (int v = 0; v < 4; ++v) b[v] = (double)(same ? xs[4 * tj + v][c] : ys[4 * tj + v][c]);
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int v = 0; v < 4; ++v) acc[u][v] += a[u] * b[v];
+    }
+    __syncthreads();
+  }
+  double* out = part + (int64_t)blockIdx.x * SB * SB;
+#pragma unroll
+  for (int u = 0; u < 4; ++u)
+#pragma unroll
+    for (int v = 0; v < 4; ++v) out[(4 * ti + u) * SB + 4 * tj + v] = acc[u][v];
+}
+
+// ---- the SB x SB algebra of one panel, one wave, fp64 in LDS -----------------------------------------------------------
+// in : part[nparts][SB][SB] (Gram partials of the panel), Ptop = transposed top block of the panel
+//      (Ptop[j * ldp + i] = P[i][j], i, j < SB)
+// out: Mout = R^-1 D U'^-1 (V2 = P2 * Mout), V1 (unit lower, row-major fp32), T (upper, row-major fp32),
+//      Rh = D R (upper, fp32), flag != 0 on breakdown
+struct SbrSmall {
+  double* M;     // [SB][SB]
+  float* V1;     // [SB][SB]
+  float* T;      // [SB][SB]
+  float* Rh;     // [SB][SB]
+  int* flag;
+};
+
+__device__ __forceinline__ double& at(double* m, int r, int c) { return m[r * SB + c]; }
+
+__global__ __launch_bounds__(64) void sbr_panel_small(const double* __restrict__ part, int nparts,
+                                                      const float* __restrict__ Ptop, int64_t ldp, SbrSmall o) {
+  extern __shared__ double lds[];
+  double* A = lds;                 // G -> R (upper) -> U'^-1
+  double* B = lds + SB * SB;       // R^-1 -> T
+  double* Cm = lds + 2 * SB * SB;  // Q_top -> LU (V1 strictly below, U' on/above the diagonal)
+  double* Dm = lds + 3 * SB * SB;  // M
+  __shared__ double dsign[SB];
+  __shared__ int bad;
+  const int l = threadIdx.x;  // lane = row index in most loops
+  if (l == 0) bad = 0;
+  // G = sum of the partials in a fixed order
+  for (int c = 0; c < SB; ++c) {
+    double s = 0.0;
+    for (int p = 0; p < nparts; ++p) s += part[(int64_t)p * SB * SB + l * SB + c];
+    at(A, l, c) = s;
+  }
+  __syncthreads();
+  // Cholesky G = R' R, R upper, stored in the upper triangle of A (row l of R is owned by lane l)
+  for (int j = 0; j < SB; ++j) {
+    // column update of row j: R[j][c] = (G[j][c] - sum_{k<j} R[k][j] R[k][c]) / R[j][j]; lane c handles column c >= j
+    double s = 0.0;
+    if (l >= j) {
+      s = at(A, j, l);
+      for (int k = 0; k < j; ++k) s -= at(A, k, j) * at(A, k, l);
+    }
+    __syncthreads();
+    double djj = __shfl(s, j);
+    if (!(djj > 0.0)) {
+      if (l == 0) bad = 1;
+      djj = 1.0;
+    }
+    const double rjj = sqrt(djj);
+    if (l == j) at(A, j, j) = rjj;
+    if (l > j) at(A, j, l) = s / rjj;
+    __syncthreads();
+  }
+  // B = R^-1 (upper): column l by back substitution, lane l owns column l:  R * x = e_l
+  for (int r = SB - 1; r >= 0; --r) {
+    double x = 0.0;
+    if (r <= l) {
+      double s = (r == l) ? 1.0 : 0.0;
+      for (int k = r + 1; k <= l; ++k) s -= at(A, r, k) * at(B, k, l);
+      x = s / at(A, r, r);
+    }
+    at(B, r, l) = x;  // rows below the diagonal: 0
+  }
+  __syncthreads();
+  // Cm = Q_top = P_top * R^-1 : row l
+  for (int c = 0; c < SB; ++c) {
+    double s = 0.0;
+    for (int k = 0; k <= c; ++k) s += (double)Ptop[(int64_t)k * ldp + l] * at(B, k, c);
+    at(Cm, l, c) = s;
+  }
+  __syncthreads();
+  // sign-modified LU of (Q D - E): lane l owns row l
+  for (int j = 0; j < SB; ++j) {
+    const double qjj = at(Cm, j, j);
+    const double dj = (qjj >= 0.0) ? -1.0 : 1.0;  // D_j = -sgn(q_jj)
+    const double piv = dj * qjj - 1.0;            // = -|q_jj| - 1
+    __syncthreads();
+    if (l == j) {
+      dsign[j] = dj;
+      at(Cm, j, j) = piv;
+    }
+    if (l > j) {
+      const double lij = dj * at(Cm, l, j) / piv;
+      at(Cm, l, j) = lij;
+      for (int c = j + 1; c < SB; ++c) at(Cm, l, c) -= lij * at(Cm, j, c);
+    }
+    __syncthreads();
+  }
+  // U'[j][c] = D_c * q~[j][c] for c > j (diagonal already holds the pivot)
+  for (int c = l + 1; c < SB; ++c) at(Cm, l, c) *= dsign[c];
+  // Rh = D R
+  for (int c = 0; c < SB; ++c) o.Rh[l * SB + c] = (c >= l) ? (float)(dsign[l] * at(A, l, c)) : 0.f;
+  // V1 (unit lower)
+  for (int c = 0; c < SB; ++c) o.V1[l * SB + c] = (c < l) ? (float)at(Cm, l, c) : (c == l ? 1.f : 0.f);
+  __syncthreads();
+  // A = U'^-1 (upper), column l by back substitution
+  for (int r = SB - 1; r >= 0; --r) {
+    double x = 0.0;
+    if (r <= l) {
+      double s = (r == l) ? 1.0 : 0.0;
+      for (int k = r + 1; k <= l; ++k) s -= at(Cm, r, k) * at(A, k, l);
+      x = s / at(Cm, r, r);
+    }
+    at(A, r, l) = x;
+  }
+  __syncthreads();
+  // Dm = M = R^-1 D U'^-1 : row l (upper triangular)
+  for (int c = 0; c < SB; ++c) {
+    double s = 0.0;
+    for (int k = l; k <= c; ++k) s += at(B, l, k) * dsign[k] * at(A, k, c);
+    at(Dm, l, c) = s;
+  }
+  __syncthreads();
+  for (int c = 0; c < SB; ++c) o.M[l * SB + c] = at(Dm, l, c);
+  // T = -U' V1^-T : row l of T by forward substitution over the columns (V1^T is unit upper)
+  for (int c = 0; c < SB; ++c) {
+    double s = -((c >= l) ? at(Cm, l, c) : 0.0);
+    for (int k = 0; k < c; ++k) s -= at(B, l, k) * ((k > c) ? 0.0 : at(Cm, c, k));  // V1[c][k], k < c
+    at(B, l, c) = s;  // row l of B is only read by lane l from here on
+  }
+  for (int c = 0; c < SB; ++c) o.T[l * SB + c] = (c >= l) ? (float)at(B, l, c) : 0.f;
+  if (l == 0 && bad) atomicExch(o.flag, 1);
+}
+
+// ---- "right multiplication" of a 64-row block by a 64 x 64 matrix, one thread per long-dimension position -------------
+//   out[j][r] = sum_i in[i][r] * Mat[i][j]                      (mode 0)
+//   mode 1: V of a panel. in = out = the panel in its transposed storage; positions r < SB take V1 (and the lower-part
+//           band block of the panel receives Rh), positions r >= SB get P2 * Mat
+//   mode 2: in = the sum of `nslab` split-K slabs (slab stride `slab`), Mat = T  ->  Y = W T, also stores W's sum? no: only Y
+//   mode 3: Z = Y - V * Sh (in = V, Mat = Sh = 1/2 T'V'Y, acc = Y); also writes the row-major [V|Z] / [Z|V] operands
+struct SbrMul {
+  const float* in;
+  int64_t ldi;
+  const double* Mat;   // [SB][SB] fp64, row-major
+  float* out;
+  int64_t ldo;
+  int64_t len;
+  int mode;
+  // mode 1
+  const float* V1;
+  const float* Rh;
+  float* band;         // &A[r0][c0]: lower-part block of the panel (stride lda)
+  int64_t lda;
+  // mode 2
+  int nslab;
+  int64_t slab;
+  // mode 3
+  const float* Y;
+  int64_t ldy;
+  float* VW;           // [len][2 SB]
+  float* WV;
+};
+
+__global__ __launch_bounds__(256) void sbr_rightmul(SbrMul a) {
+  __shared__ double Ms[SB][SB];
+  for (int idx = threadIdx.x; idx < SB * SB; idx += 256) Ms[idx >> 6][idx & 63] = a.Mat[idx];
+  __syncthreads();
+  const int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (r >= a.len) return;
+  if (a.mode == 1 && r < SB) {
+    // top block: V1 row r, and the band block of the panel: row r of Rh (upper triangular)
+    for (int j = 0; j < SB; ++j) {
+      a.out[(int64_t)j * a.ldo + r] = a.V1[r * SB + j];
+      a.band[r * a.lda + j] = a.Rh[r * SB + j];
+    }
+    return;
+  }
+  float x[SB];  // every loop over x is fully unrolled: the array lives in registers
+  if (a.mode == 2) {
+#pragma unroll
+    for (int i = 0; i < SB; ++i) {
+      float s = 0.f;
+      for (int q = 0; q < a.nslab; ++q) s += a.in[(int64_t)q * a.slab + (int64_t)i * a.ldi + r];  // fixed order
+      x[i] = s;
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < SB; ++i) x[i] = a.in[(int64_t)i * a.ldi + r];
+  }
+  float* vw = nullptr;
+  float* wv = nullptr;
+  if (a.mode == 3) {
+    vw = a.VW + r * (2 * SB);
+    wv = a.WV + r * (2 * SB);
+#pragma unroll
+    for (int i = 0; i < SB; ++i) {
+      vw[i] = x[i];
+      wv[SB + i] = x[i];
+    }
+  }
+#pragma unroll 1
+  for (int j = 0; j < SB; ++j) {
+    double s = 0.0;
+#pragma unroll
+    for (int i = 0; i < SB; ++i) s += (double)x[i] * Ms[i][j];
+    if (a.mode == 3) {
+      const float zz = a.Y[(int64_t)j * a.ldy + r] - (float)s;
+      vw[SB + j] = zz;
+      wv[j] = zz;
+    } else {
+      a.out[(int64_t)j * a.ldo + r] = (float)s;
+    }
+  }
+}
+
+__global__ void sbr_cvt64(const float* __restrict__ in, double* __restrict__ out, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = (double)in[i];
+}
+
+// Sh = 1/2 T' (V'Y), V'Y = sum of the cross partials in a fixed order; one wave, lane = row
+__global__ __launch_bounds__(64) void sbr_small_s(const double* __restrict__ part, int nparts, const float* __restrict__ T,
+                                                  double* __restrict__ Sh) {
+  __shared__ double G[SB][SB];
+  const int l = threadIdx.x;
+  for (int c = 0; c < SB; ++c) {
+    double s = 0.0;
+    for (int p = 0; p < nparts; ++p) s += part[(int64_t)p * SB * SB + l * SB + c];
+    G[l][c] = s;
+  }
+  __syncthreads();
+  for (int c = 0; c < SB; ++c) {  // (T' G)[l][c] = sum_k T[k][l] G[k][c], T upper: k <= l
+    double s = 0.0;
+    for (int k = 0; k <= l; ++k) s += (double)T[k * SB + l] * G[k][c];
+    Sh[l * SB + c] = 0.5 * s;
+  }
+}
+
+// ---- host driver ------------------------------------------------------------------------------------------------------
+// A: n x n fp32 row-major, full symmetric storage, n a multiple of SB. On return: lower band (|i - j| <= SB) = the band
+// matrix, upper part = the panel reflectors V_p, Tall[p][SB][SB] = their T factors. *breakdown (host) != 0: a panel was
+// numerically rank deficient for the Cholesky QR -- the result must not be used.
+int sy2sb_f32(Ctx* ctx, float* A, int64_t n, int64_t lda, float* Tall, int* breakdown) {
+  if (n % SB != 0 || n < SB) return ctx->fail(SCLENS_ERR_ARG, "sy2sb_f32: the order must be a positive multiple of 64");
+  if (lda % 4 != 0 || lda < n || (reinterpret_cast<uintptr_t>(A) & 15u))
+    return ctx->fail(SCLENS_ERR_ARG, "sy2sb_f32: A must be 16-byte aligned with lda a multiple of 4");
+  StageTimer tm(ctx, "sy2sb");
+  const int64_t npan = n / SB - 1;  // the last diagonal block needs no reduction
+  const int64_t ldw = round_up(n, 64);
+  const int64_t maxparts = (n + 255) / 256 + 1;
+  const int S = 8;  // K-slices of the skinny product W = A22 V
+  SCL_WS(ctx, part, double, "sbr.part", maxparts * SB * SB);
+  SCL_WS(ctx, Mat, double, "sbr.M", 2 * SB * SB);   // M | Sh
+  SCL_WS(ctx, V1, float, "sbr.V1", 2 * SB * SB);    // V1 | Rh
+  SCL_WS(ctx, Wp, float, "sbr.Wp", (int64_t)S * SB * ldw);
+  SCL_WS(ctx, Yt, float, "sbr.Yt", SB * ldw);
+  SCL_WS(ctx, VW, float, "sbr.VW", n * 2 * SB);
+  SCL_WS(ctx, WV, float, "sbr.WV", n * 2 * SB);
+  SCL_WS(ctx, flag, int, "sbr.flag", 4);
+  hipStream_t st = ctx->stream;
+  SCL_HIP(ctx, hipMemsetAsync(flag, 0, sizeof(int) * 4, st));
+  static bool attr_set = false;
+  if (!attr_set) {
+    SCL_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(sbr_panel_small),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, 4 * SB * SB * (int)sizeof(double)));
+    attr_set = true;
+  }
+  for (int64_t p = 0; p < npan; ++p) {
+    const int64_t c0 = p * SB, r0 = c0 + SB, np = n - r0;
+    float* Pt = A + c0 * lda + r0;  // transposed panel: Pt[j][i] = A[c0 + j][r0 + i] = P[i][j] (symmetric storage)
+    float* Tp = Tall + p * SB * SB;
+    const int nparts = (int)((np + 255) / 256);
+    hipLaunchKernelGGL(sbr_cross_part, dim3(nparts), dim3(256), 0, st, Pt, lda, Pt, lda, np, part);
+    SbrSmall sm{Mat, V1, Tp, V1 + SB * SB, flag};
+    hipLaunchKernelGGL(sbr_panel_small, dim3(1), dim3(64), 4 * SB * SB * sizeof(double), st, part, nparts, Pt, lda, sm);
+    SbrMul mv{};
+    mv.in = Pt; mv.ldi = lda; mv.Mat = Mat; mv.out = Pt; mv.ldo = lda; mv.len = np; mv.mode = 1;
+    mv.V1 = V1; mv.Rh = V1 + SB * SB; mv.band = A + r0 * lda + c0; mv.lda = lda;
+    hipLaunchKernelGGL(sbr_rightmul, dim3((unsigned)((np + 255) / 256)), dim3(256), 0, st, mv);
+    // W' (SB x n') = V' A22, K = n' split into S slices inside one launch
+    float* A22 = A + r0 * lda + r0;
+    {
+      GemmArgs g{};
+      g.P = Pt; g.Q = A22; g.C = Wp;
+      g.M = SB; g.N = np; g.K = np;
+      g.ldp = lda; g.ldq = lda; g.ldc = ldw;
+      g.alpha = 1.f; g.beta = 0.f; g.q_kcontig = 0; g.lower = 0; g.colabsmax = nullptr;
+      g.splits = S; g.k_chunk = round_up((np + S - 1) / S, 16); g.c_split_off = (int64_t)SB * ldw;
+      SCL_TRY(gemm_f32(ctx, g));
+    }
+    SbrMul my{};  // Y' = T' W'
+    my.in = Wp; my.ldi = ldw; my.Mat = Mat + SB * SB; my.out = Yt; my.ldo = ldw; my.len = np; my.mode = 2;
+    my.nslab = S; my.slab = (int64_t)SB * ldw;
+    // sbr_rightmul takes its matrix in fp64: Mat + SB*SB holds T for this launch, then Sh
+    hipLaunchKernelGGL(sbr_cvt64, dim3(16), dim3(256), 0, st, Tp, Mat + SB * SB, SB * SB);
+    hipLaunchKernelGGL(sbr_rightmul, dim3((unsigned)((np + 255) / 256)), dim3(256), 0, st, my);
+    hipLaunchKernelGGL(sbr_cross_part, dim3(nparts), dim3(256), 0, st, Pt, lda, Yt, ldw, np, part);
+    hipLaunchKernelGGL(sbr_small_s, dim3(1), dim3(64), 0, st, part, nparts, Tp, Mat + SB * SB);
+    SbrMul mz{};  // Z = Y - V Sh, and the row-major operands of the rank-2SB update
+    mz.in = Pt; mz.ldi = lda; mz.Mat = Mat + SB * SB; mz.len = np; mz.mode = 3;
+    mz.Y = Yt; mz.ldy = ldw; mz.VW = VW; mz.WV = WV;
+    hipLaunchKernelGGL(sbr_rightmul, dim3((unsigned)((np + 255) / 256)), dim3(256), 0, st, mz);
+    {
+      GemmArgs g{};
+      g.P = VW; g.Q = WV; g.C = A22;
+      g.M = np; g.N = np; g.K = 2 * SB;
+      g.ldp = 2 * SB; g.ldq = 2 * SB; g.ldc = lda;
+      g.alpha = -1.f; g.beta = 1.f; g.q_kcontig = 1; g.lower = 1; g.colabsmax = nullptr;
+      SCL_TRY(gemm_f32(ctx, g));
+    }
+  }
+  SCL_HIP(ctx, hipGetLastError());
+  if (breakdown) {
+    SCL_HIP(ctx, hipMemcpyAsync(breakdown, flag, sizeof(int), hipMemcpyDeviceToHost, st));
+    SCL_HIP(ctx, hipStreamSynchronize(st));
+  }
+  return SCLENS_OK;
+}
+
+}  // namespace scl

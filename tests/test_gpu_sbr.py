@@ -1,0 +1,82 @@
+"""-m gpu: building blocks of the two-stage tridiagonalisation (sbr.hip, work in progress; the one-stage solver is what
+eig_values uses). Stage 1: dense symmetric -> band of half-width 64."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from devutil import DevArray, pad_rows, rup
+
+pytestmark = pytest.mark.gpu
+SB = 64
+
+
+def _sym_psd(n, seed, K=None):
+    rng = np.random.default_rng(seed)
+    K = K or 2 * n
+    B = rng.standard_normal((n, K)).astype(np.float32)
+    B -= B.mean(axis=0, keepdims=True)  # one structurally zero eigenvalue, like the centred data
+    return (B @ B.T / K).astype(np.float32)
+
+
+def _run_sy2sb(ctx, A):
+    n = A.shape[0]
+    lda = rup(n, 32)
+    dA = DevArray(ctx, pad_rows(A, lda))
+    npan = n // SB - 1
+    dT = DevArray(ctx, nbytes=4 * max(1, npan) * SB * SB)
+    bd = C.c_int(-1)
+    ctx.check(ctx.lib.sclens_hip_dev_sy2sb_f32(ctx.h, dA.p, n, lda, dT.p, C.byref(bd)))
+    out = dA.get((n, lda), np.float32)[:, :n].astype(np.float64)
+    T = dT.get((max(1, npan), SB, SB), np.float32).astype(np.float64)
+    dA.free()
+    dT.free()
+    return out, T, bd.value
+
+
+def _band_of(out):
+    n = out.shape[0]
+    i, j = np.indices((n, n))
+    low = np.where((i - j >= 0) & (i - j <= SB), out, 0.0)
+    return low + np.tril(low, -1).T
+
+
+@pytest.mark.parametrize("n", [128, 320, 1024, 2048])
+def test_sy2sb_band_has_the_same_spectrum(ctx, n):
+    A = _sym_psd(n, n)
+    out, T, bd = _run_sy2sb(ctx, A)
+    assert bd == 0
+    Bm = _band_of(out)
+    ref = np.linalg.eigvalsh(A.astype(np.float64))
+    got = np.linalg.eigvalsh(Bm)
+    assert np.abs(got - ref).max() < 4e-7 * np.sqrt(n) * ref.max() + 1e-7
+
+
+@pytest.mark.parametrize("n", [128, 256, 448])
+def test_sy2sb_reflectors_reproduce_the_band(ctx, n):
+    """Q1 = H_0 H_1 ... with H_p = I - V_p T_p V_p' (V_p from the upper part of the output) satisfies Q1' A Q1 = band."""
+    A = _sym_psd(n, 7 * n)
+    out, T, bd = _run_sy2sb(ctx, A)
+    assert bd == 0
+    Q = np.eye(n)
+    for p in range(n // SB - 1):
+        c0, r0 = p * SB, (p + 1) * SB
+        V = out[c0:c0 + SB, r0:].T  # (n - r0) x SB, unit lower trapezoidal
+        assert np.allclose(np.diag(V[:SB]), 1.0) and np.abs(np.triu(V[:SB], 1)).max() == 0
+        H = np.eye(n)
+        H[r0:, r0:] -= V @ T[p] @ V.T
+        assert np.abs(H.T @ H - np.eye(n)).max() < 5e-6  # orthogonal to fp32 accuracy
+        Q = Q @ H
+    Bm = _band_of(out)
+    A64 = A.astype(np.float64)
+    assert np.abs(Q.T @ A64 @ Q - Bm).max() < 2e-5 * np.abs(A64).max() * np.sqrt(n / 64)
+
+
+def test_sy2sb_rank_deficient_panel_raises_the_flag(ctx):
+    n = 256
+    A = np.zeros((n, n), dtype=np.float32)
+    A[:8, :8] = _sym_psd(8, 1)
+    _, _, bd = _run_sy2sb(ctx, A)
+    assert bd == 1
+    rc = ctx.lib.sclens_hip_dev_sy2sb_f32(ctx.h, None, 100, 128, None, None)
+    assert rc == 1  # order not a multiple of 64
