@@ -81,112 +81,140 @@ struct SbrSmall {
 
 __device__ __forceinline__ double& at(double* m, int r, int c) { return m[r * SB + c]; }
 
-__global__ __launch_bounds__(64) void sbr_panel_small(const double* __restrict__ part, int nparts,
-                                                      const float* __restrict__ Ptop, int64_t ldp, SbrSmall o) {
+// 64 x 64 fp64 helpers in LDS for one workgroup of 256 threads (thread = 4 x 4 output block of a product)
+// C = A * B
+__device__ __forceinline__ void mm64(double* C, const double* A, const double* B) {
+  const int ti = threadIdx.x >> 4, tj = threadIdx.x & 15;
+  double acc[4][4];
+#pragma unroll
+  for (int u = 0; u < 4; ++u)
+#pragma unroll
+    for (int v = 0; v < 4; ++v) acc[u][v] = 0.0;
+  for (int k = 0; k < SB; ++k) {
+    double a[4], b[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) a[u] = A[(4 * ti + u) * SB + k];
+#pragma unroll
+    for (int v = 0; v < 4; ++v) b[v] = B[k * SB + 4 * tj + v];
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+      for (int v = 0; v < 4; ++v) acc[u][v] += a[u] * b[v];
+  }
+#pragma unroll
+  for (int u = 0; u < 4; ++u)
+#pragma unroll
+    for (int v = 0; v < 4; ++v) C[(4 * ti + u) * SB + 4 * tj + v] = acc[u][v];
+  __syncthreads();
+}
+// X = R^-1 for an upper triangular R (X upper): rows from the bottom, row j = (e_j - R[j][j+1:] X[j+1:][:]) / R[j][j];
+// thread (c = tid & 63, q = tid >> 6) sums its quarter of the k range, the four quarters are combined in a fixed order
+__device__ __forceinline__ void trinv_upper(double* X, const double* R, double* red /*[4][SB]*/) {
+  const int c = threadIdx.x & 63, q = threadIdx.x >> 6;
+  for (int j = SB - 1; j >= 0; --j) {
+    double s = 0.0;
+    for (int k = j + 1 + q; k <= c; k += 4) s += R[j * SB + k] * X[k * SB + c];  // X[k][c] = 0 for k > c
+    red[q * SB + c] = s;
+    __syncthreads();
+    if (q == 0) {
+      const double tot = (red[c] + red[SB + c]) + (red[2 * SB + c] + red[3 * SB + c]);
+      X[j * SB + c] = (c < j) ? 0.0 : (((c == j) ? 1.0 : 0.0) - tot) / R[j * SB + j];
+    }
+    __syncthreads();
+  }
+}
+
+__global__ __launch_bounds__(256) void sbr_panel_small(const double* __restrict__ part, int nparts,
+                                                       const float* __restrict__ Ptop, int64_t ldp, SbrSmall o) {
   extern __shared__ double lds[];
-  double* A = lds;                 // G -> R (upper) -> U'^-1
-  double* B = lds + SB * SB;       // R^-1 -> T
-  double* Cm = lds + 2 * SB * SB;  // Q_top -> LU (V1 strictly below, U' on/above the diagonal)
-  double* Dm = lds + 3 * SB * SB;  // M
+  double* A = lds;                 // G -> R (upper)            -> U'^-1
+  double* B = lds + SB * SB;       // R^-1                      -> T
+  double* Cm = lds + 2 * SB * SB;  // P_top -> (later) M
+  double* Dm = lds + 3 * SB * SB;  // Q_top -> LU (V1 strictly below, U' on/above the diagonal)
+  __shared__ double red[4 * SB];
   __shared__ double dsign[SB];
+  __shared__ double piv_s;
   __shared__ int bad;
-  const int l = threadIdx.x;  // lane = row index in most loops
-  if (l == 0) bad = 0;
-  // G = sum of the partials in a fixed order
-  for (int c = 0; c < SB; ++c) {
+  const int tid = threadIdx.x;
+  if (tid == 0) bad = 0;
+  // G = sum of the partials in a fixed order; P_top (P_top[i][j] = Ptop[j * ldp + i])
+  for (int idx = tid; idx < SB * SB; idx += 256) {
     double s = 0.0;
-    for (int p = 0; p < nparts; ++p) s += part[(int64_t)p * SB * SB + l * SB + c];
-    at(A, l, c) = s;
+    for (int p = 0; p < nparts; ++p) s += part[(int64_t)p * SB * SB + idx];
+    A[idx] = s;
+    const int j = idx >> 6, i = idx & 63;  // coalesced over i
+    Cm[i * SB + j] = (double)Ptop[(int64_t)j * ldp + i];
   }
   __syncthreads();
-  // Cholesky G = R' R, R upper, stored in the upper triangle of A (row l of R is owned by lane l)
+  // Cholesky G = R' R (right-looking): row j of R, then the rank-one update of the trailing block
   for (int j = 0; j < SB; ++j) {
-    // column update of row j: R[j][c] = (G[j][c] - sum_{k<j} R[k][j] R[k][c]) / R[j][j]; lane c handles column c >= j
-    double s = 0.0;
-    if (l >= j) {
-      s = at(A, j, l);
-      for (int k = 0; k < j; ++k) s -= at(A, k, j) * at(A, k, l);
+    if (tid == 0) {
+      double d = A[j * SB + j];
+      if (!(d > 0.0)) {
+        bad = 1;
+        d = 1.0;
+      }
+      piv_s = sqrt(d);
     }
     __syncthreads();
-    double djj = __shfl(s, j);
-    if (!(djj > 0.0)) {
-      if (l == 0) bad = 1;
-      djj = 1.0;
+    const double rjj = piv_s;
+    if (tid >= j && tid < SB) A[j * SB + tid] = (tid == j) ? rjj : A[j * SB + tid] / rjj;
+    __syncthreads();
+    for (int idx = tid; idx < SB * SB; idx += 256) {
+      const int i = idx >> 6, c = idx & 63;
+      if (i > j && c >= i) A[idx] -= A[j * SB + i] * A[j * SB + c];
     }
-    const double rjj = sqrt(djj);
-    if (l == j) at(A, j, j) = rjj;
-    if (l > j) at(A, j, l) = s / rjj;
     __syncthreads();
   }
-  // B = R^-1 (upper): column l by back substitution, lane l owns column l:  R * x = e_l
-  for (int r = SB - 1; r >= 0; --r) {
-    double x = 0.0;
-    if (r <= l) {
-      double s = (r == l) ? 1.0 : 0.0;
-      for (int k = r + 1; k <= l; ++k) s -= at(A, r, k) * at(B, k, l);
-      x = s / at(A, r, r);
-    }
-    at(B, r, l) = x;  // rows below the diagonal: 0
-  }
+  for (int idx = tid; idx < SB * SB; idx += 256)
+    if ((idx >> 6) > (idx & 63)) A[idx] = 0.0;  // strictly lower part of R
   __syncthreads();
-  // Cm = Q_top = P_top * R^-1 : row l
-  for (int c = 0; c < SB; ++c) {
-    double s = 0.0;
-    for (int k = 0; k <= c; ++k) s += (double)Ptop[(int64_t)k * ldp + l] * at(B, k, c);
-    at(Cm, l, c) = s;
-  }
-  __syncthreads();
-  // sign-modified LU of (Q D - E): lane l owns row l
+  trinv_upper(B, A, red);
+  mm64(Dm, Cm, B);  // Q_top = P_top R^-1
+  // sign-modified LU of (Q D - E), right-looking
   for (int j = 0; j < SB; ++j) {
-    const double qjj = at(Cm, j, j);
-    const double dj = (qjj >= 0.0) ? -1.0 : 1.0;  // D_j = -sgn(q_jj)
-    const double piv = dj * qjj - 1.0;            // = -|q_jj| - 1
-    __syncthreads();
-    if (l == j) {
+    if (tid == 0) {
+      const double qjj = Dm[j * SB + j];
+      const double dj = (qjj >= 0.0) ? -1.0 : 1.0;  // D_j = -sgn(q_jj)
       dsign[j] = dj;
-      at(Cm, j, j) = piv;
-    }
-    if (l > j) {
-      const double lij = dj * at(Cm, l, j) / piv;
-      at(Cm, l, j) = lij;
-      for (int c = j + 1; c < SB; ++c) at(Cm, l, c) -= lij * at(Cm, j, c);
+      piv_s = dj * qjj - 1.0;  // = -|q_jj| - 1
     }
     __syncthreads();
-  }
-  // U'[j][c] = D_c * q~[j][c] for c > j (diagonal already holds the pivot)
-  for (int c = l + 1; c < SB; ++c) at(Cm, l, c) *= dsign[c];
-  // Rh = D R
-  for (int c = 0; c < SB; ++c) o.Rh[l * SB + c] = (c >= l) ? (float)(dsign[l] * at(A, l, c)) : 0.f;
-  // V1 (unit lower)
-  for (int c = 0; c < SB; ++c) o.V1[l * SB + c] = (c < l) ? (float)at(Cm, l, c) : (c == l ? 1.f : 0.f);
-  __syncthreads();
-  // A = U'^-1 (upper), column l by back substitution
-  for (int r = SB - 1; r >= 0; --r) {
-    double x = 0.0;
-    if (r <= l) {
-      double s = (r == l) ? 1.0 : 0.0;
-      for (int k = r + 1; k <= l; ++k) s -= at(Cm, r, k) * at(A, k, l);
-      x = s / at(Cm, r, r);
+    const double piv = piv_s, dj = dsign[j];
+    if (tid > j && tid < SB) Dm[tid * SB + j] = dj * Dm[tid * SB + j] / piv;  // L[i][j]
+    __syncthreads();
+    for (int idx = tid; idx < SB * SB; idx += 256) {
+      const int i = idx >> 6, c = idx & 63;
+      if (i > j && c > j) Dm[idx] -= Dm[i * SB + j] * Dm[j * SB + c];
     }
-    at(A, r, l) = x;
+    if (tid == 0) Dm[j * SB + j] = piv;
+    __syncthreads();
+  }
+  // outputs that need R and the raw LU: Rh = D R, V1 (unit lower); U'[j][c] = D_c q~[j][c] above the diagonal
+  for (int idx = tid; idx < SB * SB; idx += 256) {
+    const int r = idx >> 6, c = idx & 63;
+    o.Rh[idx] = (c >= r) ? (float)(dsign[r] * A[idx]) : 0.f;
+    o.V1[idx] = (c < r) ? (float)Dm[idx] : (c == r ? 1.f : 0.f);
   }
   __syncthreads();
-  // Dm = M = R^-1 D U'^-1 : row l (upper triangular)
-  for (int c = 0; c < SB; ++c) {
-    double s = 0.0;
-    for (int k = l; k <= c; ++k) s += at(B, l, k) * dsign[k] * at(A, k, c);
-    at(Dm, l, c) = s;
+  // A = U' (upper, with the column signs), Cm = V1^T (unit upper)
+  for (int idx = tid; idx < SB * SB; idx += 256) {
+    const int r = idx >> 6, c = idx & 63;
+    A[idx] = (c > r) ? dsign[c] * Dm[idx] : (c == r ? Dm[idx] : 0.0);
+    Cm[idx] = (c > r) ? Dm[c * SB + r] : (c == r ? 1.0 : 0.0);
   }
   __syncthreads();
-  for (int c = 0; c < SB; ++c) o.M[l * SB + c] = at(Dm, l, c);
-  // T = -U' V1^-T : row l of T by forward substitution over the columns (V1^T is unit upper)
-  for (int c = 0; c < SB; ++c) {
-    double s = -((c >= l) ? at(Cm, l, c) : 0.0);
-    for (int k = 0; k < c; ++k) s -= at(B, l, k) * ((k > c) ? 0.0 : at(Cm, c, k));  // V1[c][k], k < c
-    at(B, l, c) = s;  // row l of B is only read by lane l from here on
-  }
-  for (int c = 0; c < SB; ++c) o.T[l * SB + c] = (c >= l) ? (float)at(B, l, c) : 0.f;
-  if (l == 0 && bad) atomicExch(o.flag, 1);
+  // T = -U' V1^-T = -U' (V1^T)^-1
+  trinv_upper(Dm, Cm, red);  // Dm = (V1^T)^-1
+  mm64(Cm, A, Dm);           // Cm = U' (V1^T)^-1
+  for (int idx = tid; idx < SB * SB; idx += 256) o.T[idx] = ((idx & 63) >= (idx >> 6)) ? (float)(-Cm[idx]) : 0.f;
+  // M = R^-1 D U'^-1
+  trinv_upper(Dm, A, red);  // Dm = U'^-1
+  for (int idx = tid; idx < SB * SB; idx += 256) B[idx] *= dsign[idx & 63];  // R^-1 D (scale the columns)
+  __syncthreads();
+  mm64(Cm, B, Dm);
+  for (int idx = tid; idx < SB * SB; idx += 256) o.M[idx] = Cm[idx];
+  if (tid == 0 && bad) atomicExch(o.flag, 1);
 }
 
 // ---- "right multiplication" of a 64-row block by a 64 x 64 matrix, one thread per long-dimension position -------------
@@ -329,7 +357,7 @@ int sy2sb_f32(Ctx* ctx, float* A, int64_t n, int64_t lda, float* Tall, int* brea
     const int nparts = (int)((np + 255) / 256);
     hipLaunchKernelGGL(sbr_cross_part, dim3(nparts), dim3(256), 0, st, Pt, lda, Pt, lda, np, part);
     SbrSmall sm{Mat, V1, Tp, V1 + SB * SB, flag};
-    hipLaunchKernelGGL(sbr_panel_small, dim3(1), dim3(64), 4 * SB * SB * sizeof(double), st, part, nparts, Pt, lda, sm);
+    hipLaunchKernelGGL(sbr_panel_small, dim3(1), dim3(256), 4 * SB * SB * sizeof(double), st, part, nparts, Pt, lda, sm);
     SbrMul mv{};
     mv.in = Pt; mv.ldi = lda; mv.Mat = Mat; mv.out = Pt; mv.ldo = lda; mv.len = np; mv.mode = 1;
     mv.V1 = V1; mv.Rh = V1 + SB * SB; mv.band = A + r0 * lda + c0; mv.lda = lda;
