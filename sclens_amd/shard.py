@@ -28,8 +28,30 @@ def raw_device_tensor(dev_ptr: int, count: int, typestr: str, device):
 class Shard:
     """rank/world + the two collectives. `world == 1` needs no torch."""
 
-    def __init__(self, rank: int = 0, world: int = 1, device=None):
-        self.rank, self.world, self.device = rank, world, device
+    def __init__(self, rank: int = 0, world: int = 1, device=None, zero_copy: bool = False):
+        """device: the torch device of this rank when the process group is RCCL (`nccl`), None for gloo.
+        zero_copy: hand RCCL a view of the library's own device buffers instead of a torch-allocated staging tensor.
+        Off by default: the PyTorch-ROCm wheel and libsclens_hip.so carry two instances of the HIP runtime, and memory
+        allocated by one is a foreign pointer to the other; device-to-device copies between the two work (measured),
+        RCCL on a foreign buffer across GPUs could not be tested on a one-GPU box, so the collectives only ever see
+        torch-allocated memory (one extra copy each way: 0.3 ms for the 0.4 GB Vr2 broadcast at cfg2)."""
+        self.rank, self.world, self.device, self.zero_copy = rank, world, device, zero_copy
+
+    def _dev_tensor(self, ctx, dev_ptr: int, count: int, dtype: int):
+        """(tensor RCCL operates on, copy-back function)"""
+        import torch
+
+        if self.zero_copy:
+            return raw_device_tensor(dev_ptr, count, "<f8" if dtype == 0 else "<f4", self.device), (lambda: None)
+        t = torch.empty(int(count), dtype=torch.float64 if dtype == 0 else torch.float32, device=self.device)
+        nbytes = int(count) * (8 if dtype == 0 else 4)
+        ctx.check(ctx.lib.sclens_hip_dev_memcpy(ctx.h, t.data_ptr(), dev_ptr, nbytes, 3))  # synchronous on the library's stream
+
+        def back():
+            torch.cuda.synchronize(self.device)
+            ctx.check(ctx.lib.sclens_hip_dev_memcpy(ctx.h, dev_ptr, t.data_ptr(), nbytes, 3))
+
+        return t, back
 
     # -- small host arrays (search statistics): fixed-shape float64 all-gather
     def allgather_small(self, arr: np.ndarray) -> np.ndarray:
@@ -83,9 +105,10 @@ class Shard:
             ctx.h2d(dev_ptr, h)
             return
 
-        t = raw_device_tensor(dev_ptr, count, "<f8" if dtype == 0 else "<f4", self.device)
+        t, back = self._dev_tensor(ctx, dev_ptr, count, dtype)
         dist.all_reduce(t)
         torch.cuda.synchronize(self.device)
+        back()
 
     # -- one-to-all copies for the spread initial phase (api.sclens, world > 1)
     def bcast_host(self, arr: np.ndarray, src: int) -> np.ndarray:
@@ -119,9 +142,11 @@ class Shard:
                 ctx.h2d(dev_ptr, h)
             return
 
-        t = raw_device_tensor(dev_ptr, count_f32, "<f4", self.device)
+        t, back = self._dev_tensor(ctx, dev_ptr, count_f32, 1)
         dist.broadcast(t, src=src)
         torch.cuda.synchronize(self.device)
+        if self.rank != src or _force:
+            back()
 
     def agree(self, arr: np.ndarray) -> np.ndarray:
         """rank 0's copy of a small host array on every rank (decisions must not diverge by a rounding bit)"""

@@ -136,12 +136,13 @@ def test_rccl_branch_on_a_one_rank_group(ctx):
     if created:
         dist.init_process_group(backend="nccl", rank=0, world_size=1, device_id=dev)
     try:
-        sh = Shard(0, 1, dev)
-        sh.allreduce_dev(ctx, d64.p, x64.size, 0, _force=True)  # sum over one rank: unchanged, but through RCCL
-        sh.allreduce_dev(ctx, d32.p, x32.size, 1, _force=True)
-        sh.bcast_dev(ctx, d32.p, x32.size, 0, _force=True)
-        assert np.array_equal(d64.get(x64.shape, np.float64), x64)
-        assert np.array_equal(d32.get(x32.shape, np.float32), 2 * x32)
+        for zero_copy in (False, True):  # staging tensor (default) and the view of the library's own buffer
+            sh = Shard(0, 1, dev, zero_copy=zero_copy)
+            sh.allreduce_dev(ctx, d64.p, x64.size, 0, _force=True)  # sum over one rank: unchanged, but through RCCL
+            sh.allreduce_dev(ctx, d32.p, x32.size, 1, _force=True)
+            sh.bcast_dev(ctx, d32.p, x32.size, 0, _force=True)
+            assert np.array_equal(d64.get(x64.shape, np.float64), x64)
+            assert np.array_equal(d32.get(x32.shape, np.float32), 2 * x32)
         sh.world = 1
         blocks = torch.arange(24, dtype=torch.float32, device=dev).reshape(2, 3, 4)
         out = torch.empty((1,) + tuple(blocks.shape), dtype=blocks.dtype, device=dev)
