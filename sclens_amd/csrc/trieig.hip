@@ -28,11 +28,15 @@ constexpr double SFMIN64 = 2.2250738585072014e-308;
 __global__ __launch_bounds__(1024) void tri_bounds(const double* __restrict__ d, const double* __restrict__ e,
                                                    int64_t n, double* __restrict__ e2, double* __restrict__ info) {
   __shared__ double s_lo[16], s_hi[16], s_e2[16], s_one[16], s_tn[16];
+  __shared__ int s_nan;
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  if (tid == 0) s_nan = 0;
+  __syncthreads();
   double lo = 1e300, hi = -1e300, me2 = 0.0, one = 0.0, tn = 0.0;
   for (int64_t i = tid; i < n; i += 1024) {
     const double el = (i > 0) ? fabs(e[i - 1]) : 0.0, er = (i < n - 1) ? fabs(e[i]) : 0.0;
     const double di = d[i];
+    if (!(fabs(di) + er < 1e300)) s_nan = 1;  // NaN / Inf in the tridiagonal: fmin / fmax below would hide it
     lo = fmin(lo, di - el - er);
     hi = fmax(hi, di + el + er);
     one = fmax(one, fabs(di) + el + er);
@@ -64,6 +68,7 @@ __global__ __launch_bounds__(1024) void tri_bounds(const double* __restrict__ d,
     info[2] = pivmin;
     info[3] = one;
     info[4] = tn;
+    info[5] = s_nan ? 1.0 : 0.0;  // -> every eigenvalue is reported as NaN (the check of scLENS.jl:379 then fires)
   }
 }
 
@@ -78,6 +83,10 @@ __global__ __launch_bounds__(64) void tri_bisect(const double* __restrict__ d, c
   double lo = info[0], hi = info[1];
   const double pivmin = info[2], atol = EPS64 * info[4];
   const bool live = k < n;
+  if (info[5] != 0.0) {  // non-finite input (block-uniform)
+    if (live && q == 0) w[k] = __longlong_as_double(0x7ff8000000000000LL);
+    return;
+  }
   for (int it = 0; it < 40; ++it) {
     const bool done = (hi - lo) <= 2.0 * EPS64 * fmax(fabs(lo), fabs(hi)) + atol;
     if (__all(done || !live)) break;
