@@ -397,6 +397,10 @@ int sclens_hip_dev_sy2sb_f32(sclens_hip_ctx* h, float* A, int64_t n, int64_t lda
   CTX_GUARD(h);
   return scl::sy2sb_f32(&h->c, A, n, lda, T, breakdown);
 }
+int sclens_hip_dev_sb2st_f32(sclens_hip_ctx* h, const float* A, int64_t n, int64_t lda, double* d, double* e) {
+  CTX_GUARD(h);
+  return scl::sb2st_f32(&h->c, A, n, lda, d, e);
+}
 int sclens_hip_dev_sytrd_f32(sclens_hip_ctx* h, float* A, int64_t n, int64_t lda, double* d, double* e, float* tau) {
   CTX_GUARD(h);
   return scl::sytrd_f32(&h->c, A, n, lda, d, e, tau);

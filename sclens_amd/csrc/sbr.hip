@@ -17,6 +17,8 @@
 // Storage: V_p is kept in the UPPER part of A (rows c0..c0+SB-1, columns r0..n-1: contiguous over the long dimension, the
 // layout every GEMM here wants), the band in the LOWER part, T_p in a side array. The matrix order must be a multiple of
 // SB (the caller pads with a decoupled diagonal block). All reductions run in a fixed order: bitwise reproducible.
+#include <algorithm>
+
 #include "common.h"
 
 namespace scl {
@@ -399,6 +401,196 @@ int sy2sb_f32(Ctx* ctx, float* A, int64_t n, int64_t lda, float* Tall, int* brea
     SCL_HIP(ctx, hipMemcpyAsync(breakdown, flag, sizeof(int), hipMemcpyDeviceToHost, st));
     SCL_HIP(ctx, hipStreamSynchronize(st));
   }
+  return SCLENS_OK;
+}
+
+
+// ======================================================================================================================
+// Stage 2: symmetric band (half-width SB) -> tridiagonal by bulge chasing. (Work in progress like stage 1: eigenvalues
+// only so far -- the reflectors are stored for the second back-transformation, which does not exist yet.)
+// Sweep s annihilates column s below the sub-diagonal with a reflector on rows s+1 .. s+SB and chases the bulge it creates
+// down the band: task k of the sweep (rows r_k = s + 1 + k SB ...) right-applies the previous reflector to the
+// off-diagonal block B_k, takes a new reflector from its first column, left-applies it, and applies it two-sidedly to the
+// diagonal block D_k (Schwarz / Lang). Sweep s may run task k as soon as sweep s-1 has finished task k+1, so ~n/(2 SB)
+// sweeps are in flight: one persistent kernel, sweep s on workgroup s mod G (all G resident), per-sweep progress counters
+// with agent-scope release / acquire. Blocks live in LDS (2 x 64 x 64 floats); the band is packed as Bd[column][row - column]
+// with room for the bulge (row - column <= 2 SB).
+constexpr int LDB2 = 2 * SB + 4;  // floats per column of the packed band
+
+__global__ void sbr_pack_band(const float* __restrict__ A, int64_t n, int64_t lda, float* __restrict__ Bd) {
+  const int64_t j = blockIdx.x;
+  for (int r = threadIdx.x; r < LDB2; r += blockDim.x)
+    Bd[j * LDB2 + r] = (r <= SB && j + r < n) ? A[(j + r) * lda + j] : 0.f;
+}
+
+__device__ __forceinline__ int sbr_tasks_of(int64_t s, int64_t n) { return (int)((n - s - 1 + SB - 1) / SB); }
+
+__global__ __launch_bounds__(256) void sbr_chase(float* __restrict__ Bd, int64_t n, float* __restrict__ V2, int64_t ldv2,
+                                                 float* __restrict__ TAU2, int64_t ldt, int* __restrict__ done) {
+  __shared__ float D[SB][SB + 1], B[SB][SB + 1];
+  __shared__ float v[SB], vp[SB], y[SB], w[SB];
+  __shared__ float sc[4];  // tau, beta, alpha2, tau_prev
+  const int tid = threadIdx.x, lane4 = tid & 3, row4 = tid >> 2;  // 4 threads per row for the matrix-vector products
+  for (int64_t s = blockIdx.x; s + 2 < n; s += gridDim.x) {
+    const int K = sbr_tasks_of(s, n);
+    const int Kprev = (s > 0) ? sbr_tasks_of(s - 1, n) : 0;
+    for (int k = 0; k < K; ++k) {
+      if (s > 0) {  // wait for sweep s-1 to be two tasks ahead (or finished)
+        const int need = (k + 2 < Kprev) ? k + 2 : Kprev;
+        while (__hip_atomic_load(&done[s - 1], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < need) __builtin_amdgcn_s_sleep(2);
+      }
+      __syncthreads();
+      const int64_t rk = s + 1 + (int64_t)k * SB;
+      const int L = (int)((n - rk < SB) ? n - rk : SB);
+      // ---- load D (full symmetric image) and B
+      for (int idx = tid; idx < SB * SB; idx += 256) {
+        const int j = idx >> 6, i = idx & 63;  // coalesced over i (the row offset inside a packed column)
+        float dv = 0.f;
+        if (i < L && j < L) dv = (i >= j) ? Bd[(rk + j) * LDB2 + (i - j)] : Bd[(rk + i) * LDB2 + (j - i)];
+        D[i][j] = dv;
+        float bv = 0.f;
+        if (k > 0 && i < L) bv = Bd[(rk - SB + j) * LDB2 + (SB + i - j)];
+        B[i][j] = bv;
+      }
+      if (tid < SB) {
+        if (k == 0) y[tid] = (tid < L) ? Bd[s * LDB2 + 1 + tid] : 0.f;  // column s below the diagonal
+      }
+      __syncthreads();
+      if (k > 0) {
+        // ---- B <- B H_prev :  yv = B vp ; B -= tau_prev yv vp'
+        float part = 0.f;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) part += B[row4][lane4 * 16 + q] * vp[lane4 * 16 + q];
+        part += __shfl_xor(part, 1);
+        part += __shfl_xor(part, 2);
+        if (lane4 == 0) w[row4] = part;
+        __syncthreads();
+        const float tp = sc[3];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) B[row4][lane4 * 16 + q] -= tp * w[row4] * vp[lane4 * 16 + q];
+        __syncthreads();
+        if (tid < SB) y[tid] = B[tid][0];
+        __syncthreads();
+      }
+      // ---- reflector from x = y[0..L)
+      if (tid < 64) {
+        const float xi = (tid >= 1 && tid < L) ? y[tid] : 0.f;
+        double sg = (double)xi * (double)xi;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) sg += __shfl_xor(sg, o);
+        const float alpha = y[0];
+        float tau = 0.f, beta = alpha, scale = 0.f;
+        if (sg > 0.0) {
+          const double nrm = sqrt((double)alpha * (double)alpha + sg);
+          beta = (float)((alpha >= 0.f) ? -nrm : nrm);
+          tau = (beta - alpha) / beta;
+          scale = 1.f / (alpha - beta);
+        }
+        v[tid] = (tid == 0) ? 1.f : xi * scale;
+        if (tid == 0) {
+          sc[0] = tau;
+          sc[1] = beta;
+        }
+      }
+      __syncthreads();
+      const float tau = sc[0], beta = sc[1];
+      if (k > 0) {
+        // ---- B <- H B (columns 1..): z = v' B ; B -= tau v z'   (thread: column row4, quarter of the rows)
+        float part = 0.f;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) part += v[lane4 * 16 + q] * B[lane4 * 16 + q][row4];
+        part += __shfl_xor(part, 1);
+        part += __shfl_xor(part, 2);
+        if (lane4 == 0) w[row4] = part;
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+          const int i = lane4 * 16 + q;
+          B[i][row4] = (row4 == 0) ? (i == 0 ? beta : 0.f) : B[i][row4] - tau * v[i] * w[row4];
+        }
+        __syncthreads();
+        for (int idx = tid; idx < SB * SB; idx += 256) {
+          const int j = idx >> 6, i = idx & 63;
+          if (i < L) Bd[(rk - SB + j) * LDB2 + (SB + i - j)] = B[i][j];
+        }
+      } else if (tid < L) {
+        Bd[s * LDB2 + 1 + tid] = (tid == 0) ? beta : 0.f;
+      }
+      // ---- D <- H D H :  w = tau D v ; a2 = -1/2 tau v'w ; w += a2 v ; D -= v w' + w v'
+      {
+        float part = 0.f;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) part += D[row4][lane4 * 16 + q] * v[lane4 * 16 + q];
+        part += __shfl_xor(part, 1);
+        part += __shfl_xor(part, 2);
+        __syncthreads();  // w is free again (the B update above has consumed it)
+        if (lane4 == 0) w[row4] = tau * part;
+        __syncthreads();
+        if (tid < 64) {
+          float t = v[tid] * w[tid];
+#pragma unroll
+          for (int o = 32; o > 0; o >>= 1) t += __shfl_xor(t, o);
+          if (tid == 0) sc[2] = -0.5f * tau * t;
+        }
+        __syncthreads();
+        if (tid < SB) w[tid] += sc[2] * v[tid];
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+          const int j = lane4 * 16 + q;
+          D[row4][j] -= v[row4] * w[j] + w[row4] * v[j];
+        }
+        __syncthreads();
+        for (int idx = tid; idx < SB * SB; idx += 256) {
+          const int j = idx >> 6, i = idx & 63;
+          if (i >= j && i < L) Bd[(rk + j) * LDB2 + (i - j)] = D[i][j];
+        }
+      }
+      if (tid < SB) {
+        if (tid < L) V2[s * ldv2 + rk + tid] = v[tid];
+        vp[tid] = v[tid];
+        if (tid == 0) {
+          TAU2[s * ldt + k] = tau;
+          sc[3] = tau;
+        }
+      }
+      __threadfence();
+      __syncthreads();
+      if (tid == 0) __hip_atomic_store(&done[s], k + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+}
+
+__global__ void sbr_band_diag(const float* __restrict__ Bd, int64_t n, double* __restrict__ d, double* __restrict__ e) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) {
+    d[i] = (double)Bd[i * LDB2];
+    e[i] = (i + 1 < n) ? (double)Bd[i * LDB2 + 1] : 0.0;
+  }
+}
+
+// A: the output of sy2sb_f32 (lower band valid). d, e (fp64, device) receive the tridiagonal matrix.
+int sb2st_f32(Ctx* ctx, const float* A, int64_t n, int64_t lda, double* d_dev, double* e_dev) {
+  if (n % SB != 0 || n < SB) return ctx->fail(SCLENS_ERR_ARG, "sb2st_f32: the order must be a positive multiple of 64");
+  StageTimer tm(ctx, "sb2st");
+  const int64_t ldv2 = round_up(n, 64), ldt = n / SB + 2;
+  SCL_WS(ctx, Bd, float, "sbr.Bd", n * LDB2);
+  SCL_WS(ctx, V2, float, "sbr.V2", n * ldv2);
+  SCL_WS(ctx, TAU2, float, "sbr.TAU2", n * ldt);
+  SCL_WS(ctx, done, int, "sbr.done", n);
+  hipStream_t st = ctx->stream;
+  SCL_HIP(ctx, hipMemsetAsync(done, 0, sizeof(int) * n, st));
+  SCL_HIP(ctx, hipMemsetAsync(TAU2, 0, sizeof(float) * n * ldt, st));
+  hipLaunchKernelGGL(sbr_pack_band, dim3((unsigned)n), dim3(128), 0, st, A, n, lda, Bd);
+  // every workgroup must be resident (a sweep spins on its predecessor): one per CU is always safe
+  int dev = 0, cus = 0;
+  SCL_HIP(ctx, hipGetDevice(&dev));
+  SCL_HIP(ctx, hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+  int G = (int)std::min<int64_t>(cus > 0 ? cus : 64, n / (2 * SB) + 1);
+  if (G < 1) G = 1;
+  hipLaunchKernelGGL(sbr_chase, dim3(G), dim3(256), 0, st, Bd, n, V2, ldv2, TAU2, ldt, done);
+  hipLaunchKernelGGL(sbr_band_diag, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, Bd, n, d_dev, e_dev);
+  SCL_HIP(ctx, hipGetLastError());
   return SCLENS_OK;
 }
 

@@ -80,3 +80,27 @@ def test_sy2sb_rank_deficient_panel_raises_the_flag(ctx):
     assert bd == 1
     rc = ctx.lib.sclens_hip_dev_sy2sb_f32(ctx.h, None, 100, 128, None, None)
     assert rc == 1  # order not a multiple of 64
+
+
+@pytest.mark.parametrize("n", [128, 192, 576, 2048])
+def test_two_stage_tridiagonal_has_the_same_spectrum(ctx, n):
+    """sy2sb + sb2st (bulge chasing in one persistent kernel, sweeps pipelined through progress counters): the tridiagonal
+    matrix has the spectrum of A; the off-band part of the packed band is annihilated."""
+    import scipy.linalg as sla
+
+    A = _sym_psd(n, 3 * n + 1)
+    lda = rup(n, 32)
+    dA = DevArray(ctx, pad_rows(A, lda))
+    dT = DevArray(ctx, nbytes=4 * max(1, n // SB - 1) * SB * SB)
+    dd, de = DevArray(ctx, nbytes=8 * n), DevArray(ctx, nbytes=8 * n)
+    bd = C.c_int(-1)
+    ctx.check(ctx.lib.sclens_hip_dev_sy2sb_f32(ctx.h, dA.p, n, lda, dT.p, C.byref(bd)))
+    assert bd.value == 0
+    ctx.check(ctx.lib.sclens_hip_dev_sb2st_f32(ctx.h, dA.p, n, lda, dd.p, de.p))
+    ctx.sync()
+    d, e = dd.get((n,), np.float64), de.get((n,), np.float64)
+    for x in (dA, dT, dd, de):
+        x.free()
+    ref = np.linalg.eigvalsh(A.astype(np.float64))
+    got = sla.eigvalsh_tridiagonal(d, e[: n - 1])
+    assert np.abs(got - ref).max() < 6e-7 * np.sqrt(n) * ref.max() + 1e-7
