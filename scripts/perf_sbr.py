@@ -22,6 +22,7 @@ src = DevArray(ctx, A0)
 dA = DevArray(ctx, A0)
 dT = DevArray(ctx, nbytes=4 * (n // 64) * 64 * 64)
 bd = C.c_int(0)
+dd, de = DevArray(ctx, nbytes=8 * n), DevArray(ctx, nbytes=8 * n)
 ctx.set_timing(True)
 for rep in range(3):
     ctx.check(ctx.lib.sclens_hip_dev_memcpy(ctx.h, dA.p, src.p, 4 * n * lda, 3))
@@ -29,4 +30,8 @@ for rep in range(3):
     t0 = time.perf_counter()
     ctx.check(ctx.lib.sclens_hip_dev_sy2sb_f32(ctx.h, dA.p, n, lda, dT.p, C.byref(bd)))
     ctx.sync()
-    print(f"n={n} sy2sb wall {1e3 * (time.perf_counter() - t0):.1f} ms breakdown={bd.value}", flush=True)
+    t1 = time.perf_counter()
+    ctx.check(ctx.lib.sclens_hip_dev_sb2st_f32(ctx.h, dA.p, n, lda, dd.p, de.p))
+    ctx.sync()
+    t2 = time.perf_counter()
+    print(f"n={n} sy2sb {1e3 * (t1 - t0):.1f} ms  sb2st {1e3 * (t2 - t1):.1f} ms  breakdown={bd.value}", flush=True)
