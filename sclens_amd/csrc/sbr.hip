@@ -346,12 +346,9 @@ int sy2sb_f32(Ctx* ctx, float* A, int64_t n, int64_t lda, float* Tall, int* brea
   SCL_WS(ctx, flag, int, "sbr.flag", 4);
   hipStream_t st = ctx->stream;
   SCL_HIP(ctx, hipMemsetAsync(flag, 0, sizeof(int) * 4, st));
-  static bool attr_set = false;
-  if (!attr_set) {
-    SCL_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(sbr_panel_small),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, 4 * SB * SB * (int)sizeof(double)));
-    attr_set = true;
-  }
+  // 128 KB of dynamic LDS for the panel algebra (above the 64 KB default; idempotent, cheap)
+  SCL_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(sbr_panel_small),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, 4 * SB * SB * (int)sizeof(double)));
   for (int64_t p = 0; p < npan; ++p) {
     const int64_t c0 = p * SB, r0 = c0 + SB, np = n - r0;
     float* Pt = A + c0 * lda + r0;  // transposed panel: Pt[j][i] = A[c0 + j][r0 + i] = P[i][j] (symmetric storage)
