@@ -269,6 +269,9 @@ int sclens_hip_dev_gram_f32(sclens_hip_ctx* ctx, const float* B, int64_t n, int6
 /* stage 1 of the two-stage reduction (work in progress, see sbr.hip): dense symmetric -> band of half-width 64; n must be a
  * multiple of 64. Lower band of A = the band matrix, upper part = panel reflectors, T[(n/64-1)][64][64] their factors. */
 int sclens_hip_dev_sy2sb_f32(sclens_hip_ctx* ctx, float* A, int64_t n, int64_t lda, float* T, int* breakdown);
+/* first back-transformation: the m rows of Zt (length n, leading dimension ldz) are multiplied by Q1 of sy2sb (A, T) */
+int sclens_hip_dev_sbr_apply_q1_f32(sclens_hip_ctx* ctx, const float* A, int64_t n, int64_t lda, const float* T, float* Zt,
+                                    int64_t m, int64_t ldz);
 /* stage 2 (work in progress): band (output of sy2sb) -> tridiagonal d[n], e[n] (fp64, device) by bulge chasing */
 int sclens_hip_dev_sb2st_f32(sclens_hip_ctx* ctx, const float* A, int64_t n, int64_t lda, double* d, double* e);
 int sclens_hip_dev_sytrd_f32(sclens_hip_ctx* ctx, float* A, int64_t n, int64_t lda, double* d, double* e, float* tau);

@@ -402,6 +402,70 @@ int sy2sb_f32(Ctx* ctx, float* A, int64_t n, int64_t lda, float* Tall, int* brea
 }
 
 
+// ---- first back-transformation: rows of Zt (eigenvectors of the band matrix) -> eigenvectors of A --------------------
+// z_A = H_0 (H_1 (... H_{P-1} z_B)), H_p = I - V_p T_p V_p' on the coordinates >= r0_p. In row form, per panel from the
+// last to the first:  Zt[:, r0:] -= ((Zt[:, r0:] V) T') V'  -- three GEMMs, the first one split over K in one launch and
+// summed by the second through an S-fold replicated T (the scheme of ormtr_f32).
+__global__ void sbr_rep_t(const float* __restrict__ Tall, int64_t npan, int S, float* __restrict__ Trep) {
+  // Trep[p][j][s * SB + i] = T_p[j][i]
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t per = (int64_t)SB * S * SB;
+  if (idx >= npan * per) return;
+  const int64_t p = idx / per, rem = idx % per;
+  const int j = (int)(rem / (S * SB)), c = (int)(rem % (S * SB)), i = c % SB;
+  Trep[idx] = Tall[p * SB * SB + j * SB + i];
+}
+
+int sbr_apply_q1(Ctx* ctx, const float* A, int64_t n, int64_t lda, const float* Tall, float* Zt, int64_t m, int64_t ldz) {
+  if (m <= 0) return SCLENS_OK;
+  if (n % SB != 0) return ctx->fail(SCLENS_ERR_ARG, "sbr_apply_q1: the order must be a multiple of 64");
+  StageTimer tm(ctx, "sbr_q1");
+  const int64_t npan = n / SB - 1;
+  if (npan <= 0) return SCLENS_OK;
+  const int64_t tiles_m = (m + 127) / 128;
+  int S = (int)((512 + tiles_m - 1) / tiles_m);
+  if (S < 1) S = 1;
+  if (S > 16) S = 16;
+  SCL_WS(ctx, Trep, float, "sbr.Trep", npan * SB * (int64_t)S * SB);
+  SCL_WS(ctx, W1, float, "sbr.W1", m * (int64_t)S * SB);
+  SCL_WS(ctx, W2, float, "sbr.W2", m * SB);
+  {
+    const int64_t tot = npan * SB * (int64_t)S * SB;
+    hipLaunchKernelGGL(sbr_rep_t, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, ctx->stream, Tall, npan, S, Trep);
+  }
+  for (int64_t p = npan - 1; p >= 0; --p) {
+    const int64_t c0 = p * SB, r0 = c0 + SB, np = n - r0;
+    const float* Vt = A + c0 * lda + r0;  // [SB][np], row stride lda
+    {
+      GemmArgs g{};
+      g.P = Zt + r0; g.Q = Vt; g.C = W1;
+      g.M = m; g.N = SB; g.K = np;
+      g.ldp = ldz; g.ldq = lda; g.ldc = (int64_t)S * SB;
+      g.alpha = 1.f; g.beta = 0.f; g.q_kcontig = 1; g.lower = 0; g.colabsmax = nullptr;
+      g.splits = S; g.k_chunk = round_up((np + S - 1) / S, 16); g.c_split_off = SB;
+      SCL_TRY(gemm_f32(ctx, g));
+    }
+    {
+      GemmArgs g{};
+      g.P = W1; g.Q = Trep + p * SB * ((int64_t)S * SB); g.C = W2;
+      g.M = m; g.N = SB; g.K = (int64_t)S * SB;
+      g.ldp = (int64_t)S * SB; g.ldq = (int64_t)S * SB; g.ldc = SB;
+      g.alpha = 1.f; g.beta = 0.f; g.q_kcontig = 1; g.lower = 0; g.colabsmax = nullptr;
+      SCL_TRY(gemm_f32(ctx, g));
+    }
+    {
+      GemmArgs g{};
+      g.P = W2; g.Q = Vt; g.C = Zt + r0;
+      g.M = m; g.N = np; g.K = SB;
+      g.ldp = SB; g.ldq = lda; g.ldc = ldz;
+      g.alpha = -1.f; g.beta = 1.f; g.q_kcontig = 0; g.lower = 0; g.colabsmax = nullptr;
+      SCL_TRY(gemm_f32(ctx, g));
+    }
+  }
+  SCL_HIP(ctx, hipGetLastError());
+  return SCLENS_OK;
+}
+
 // ======================================================================================================================
 // Stage 2: symmetric band (half-width SB) -> tridiagonal by bulge chasing. (Work in progress like stage 1: eigenvalues
 // only so far -- the reflectors are stored for the second back-transformation, which does not exist yet.)

@@ -104,3 +104,30 @@ def test_two_stage_tridiagonal_has_the_same_spectrum(ctx, n):
     ref = np.linalg.eigvalsh(A.astype(np.float64))
     got = sla.eigvalsh_tridiagonal(d, e[: n - 1])
     assert np.abs(got - ref).max() < 6e-7 * np.sqrt(n) * ref.max() + 1e-7
+
+
+@pytest.mark.parametrize("n,m", [(256, 256), (448, 100), (1024, 37)])
+def test_first_back_transformation(ctx, n, m):
+    """Eigenvectors of the band matrix (host, float64) multiplied by Q1 on the device are eigenvectors of A."""
+    A = _sym_psd(n, 5 * n + 2)
+    lda = rup(n, 32)
+    dA = DevArray(ctx, pad_rows(A, lda))
+    npan = n // SB - 1
+    dT = DevArray(ctx, nbytes=4 * max(1, npan) * SB * SB)
+    bd = C.c_int(-1)
+    ctx.check(ctx.lib.sclens_hip_dev_sy2sb_f32(ctx.h, dA.p, n, lda, dT.p, C.byref(bd)))
+    out = dA.get((n, lda), np.float32)[:, :n].astype(np.float64)
+    wB, ZB = np.linalg.eigh(_band_of(out))
+    sel = np.linspace(0, n - 1, m).astype(int)
+    Zt = np.zeros((m, lda), dtype=np.float32)
+    Zt[:, :n] = ZB[:, sel].T
+    dZ = DevArray(ctx, Zt)
+    ctx.check(ctx.lib.sclens_hip_dev_sbr_apply_q1_f32(ctx.h, dA.p, n, lda, dT.p, dZ.p, m, lda))
+    ctx.sync()
+    Z = dZ.get((m, lda), np.float32)[:, :n].astype(np.float64)
+    for x in (dA, dT, dZ):
+        x.free()
+    A64 = A.astype(np.float64)
+    nrm = np.abs(wB).max()
+    assert np.abs(Z @ A64 - wB[sel, None] * Z).max() < 3e-5 * nrm
+    assert np.abs(np.linalg.norm(Z, axis=1) - 1).max() < 1e-4
