@@ -272,6 +272,8 @@ int sclens_hip_dev_sy2sb_f32(sclens_hip_ctx* ctx, float* A, int64_t n, int64_t l
 /* first back-transformation: the m rows of Zt (length n, leading dimension ldz) are multiplied by Q1 of sy2sb (A, T) */
 int sclens_hip_dev_sbr_apply_q1_f32(sclens_hip_ctx* ctx, const float* A, int64_t n, int64_t lda, const float* T, float* Zt,
                                     int64_t m, int64_t ldz);
+/* second back-transformation: the m rows of Zt are multiplied by Q2 of the preceding sb2st on this context */
+int sclens_hip_dev_sbr_apply_q2_f32(sclens_hip_ctx* ctx, int64_t n, float* Zt, int64_t m, int64_t ldz);
 /* stage 2 (work in progress): band (output of sy2sb) -> tridiagonal d[n], e[n] (fp64, device) by bulge chasing */
 int sclens_hip_dev_sb2st_f32(sclens_hip_ctx* ctx, const float* A, int64_t n, int64_t lda, double* d, double* e);
 int sclens_hip_dev_sytrd_f32(sclens_hip_ctx* ctx, float* A, int64_t n, int64_t lda, double* d, double* e, float* tau);

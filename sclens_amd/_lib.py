@@ -95,6 +95,7 @@ SIGNATURES = {
     "sclens_hip_dev_gram_f32": (C.c_int, [vp, vp, i64, i64, i64, C.c_float, vp, i64]),
     "sclens_hip_dev_sy2sb_f32": (C.c_int, [vp, vp, i64, i64, vp, C.POINTER(C.c_int)]),
     "sclens_hip_dev_sbr_apply_q1_f32": (C.c_int, [vp, vp, i64, i64, vp, vp, i64, i64]),
+    "sclens_hip_dev_sbr_apply_q2_f32": (C.c_int, [vp, i64, vp, i64, i64]),
     "sclens_hip_dev_sb2st_f32": (C.c_int, [vp, vp, i64, i64, vp, vp]),
     "sclens_hip_dev_sytrd_f32": (C.c_int, [vp, vp, i64, i64, vp, vp, vp]),
     "sclens_hip_dev_stebz_f64": (C.c_int, [vp, vp, vp, i64, vp]),

@@ -402,6 +402,10 @@ int sclens_hip_dev_sbr_apply_q1_f32(sclens_hip_ctx* h, const float* A, int64_t n
   CTX_GUARD(h);
   return scl::sbr_apply_q1(&h->c, A, n, lda, T, Zt, m, ldz);
 }
+int sclens_hip_dev_sbr_apply_q2_f32(sclens_hip_ctx* h, int64_t n, float* Zt, int64_t m, int64_t ldz) {
+  CTX_GUARD(h);
+  return scl::sbr_apply_q2(&h->c, n, Zt, m, ldz);
+}
 int sclens_hip_dev_sb2st_f32(sclens_hip_ctx* h, const float* A, int64_t n, int64_t lda, double* d, double* e) {
   CTX_GUARD(h);
   return scl::sb2st_f32(&h->c, A, n, lda, d, e);

@@ -149,6 +149,7 @@ int preprocess_stats(Ctx* ctx, int64_t N, int64_t M, const int64_t* colptr, cons
 int preprocess_gather(Ctx* ctx, int64_t* out_colptr, int32_t* out_rowval, float* out_nzval);
 int sy2sb_f32(Ctx* ctx, float* A, int64_t n, int64_t lda, float* Tall, int* breakdown);
 int sbr_apply_q1(Ctx* ctx, const float* A, int64_t n, int64_t lda, const float* Tall, float* Zt, int64_t m, int64_t ldz);
+int sbr_apply_q2(Ctx* ctx, int64_t n, float* Zt, int64_t m, int64_t ldz);
 int sb2st_f32(Ctx* ctx, const float* A, int64_t n, int64_t lda, double* d_dev, double* e_dev);
 BatchGroup* batch_create();
 void batch_destroy(BatchGroup* g);

@@ -655,4 +655,62 @@ int sb2st_f32(Ctx* ctx, const float* A, int64_t n, int64_t lda, double* d_dev, d
   return SCLENS_OK;
 }
 
+
+// ---- second back-transformation, reference version: rows of Zt (eigenvectors of the tridiagonal matrix) -> eigenvectors
+// of the band matrix. z_B = Q2 z_T with Q2 = prod_{s ascending} prod_k H_{s,k}: the reflectors are applied in the reverse
+// order of their creation, sweep by sweep (the tasks of one sweep act on disjoint coordinates). One workgroup keeps
+// `VT` whole vectors in LDS and streams all reflectors: every workgroup reads all of V2, so this version is only meant
+// for tests and small orders; the blocked version (groups of consecutive sweeps as WY blocks) replaces it.
+__global__ __launch_bounds__(256) void sbr_q2_simple(const float* __restrict__ V2, int64_t ldv2, const float* __restrict__ TAU2,
+                                                     int64_t ldt, int64_t n, float* __restrict__ Zt, int64_t m, int64_t ldz,
+                                                     int VT) {
+  extern __shared__ float zs[];  // [VT][n]
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int64_t v0 = (int64_t)blockIdx.x * VT;
+  const int nv = (int)((m - v0 < VT) ? m - v0 : VT);
+  for (int q = 0; q < nv; ++q)
+    for (int64_t c = tid; c < n; c += 256) zs[(int64_t)q * n + c] = Zt[(v0 + q) * ldz + c];
+  __syncthreads();
+  for (int64_t s = n - 3; s >= 0; --s) {
+    const int K = sbr_tasks_of(s, n);
+    for (int k = wv; k < K; k += 4) {
+      const int64_t rk = s + 1 + (int64_t)k * SB;
+      const int L = (int)((n - rk < SB) ? n - rk : SB);
+      const float tau = TAU2[s * ldt + k];
+      if (tau == 0.f) continue;  // wave-uniform
+      const float vi = (lane < L) ? V2[s * ldv2 + rk + lane] : 0.f;
+      for (int q = 0; q < nv; ++q) {
+        float* z = zs + (int64_t)q * n + rk;
+        const float zi = (lane < L) ? z[lane] : 0.f;
+        float dot = vi * zi;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) dot += __shfl_xor(dot, o);
+        if (lane < L) z[lane] = zi - tau * dot * vi;
+      }
+    }
+    __syncthreads();
+  }
+  for (int q = 0; q < nv; ++q)
+    for (int64_t c = tid; c < n; c += 256) Zt[(v0 + q) * ldz + c] = zs[(int64_t)q * n + c];
+}
+
+int sbr_apply_q2(Ctx* ctx, int64_t n, float* Zt, int64_t m, int64_t ldz) {
+  if (m <= 0) return SCLENS_OK;
+  StageTimer tm(ctx, "sbr_q2");
+  const int64_t ldv2 = round_up(n, 64), ldt = n / SB + 2;
+  const float* V2 = static_cast<const float*>(ctx->ws.count("sbr.V2") ? ctx->ws.at("sbr.V2").first : nullptr);
+  const float* TAU2 = static_cast<const float*>(ctx->ws.count("sbr.TAU2") ? ctx->ws.at("sbr.TAU2").first : nullptr);
+  if (!V2 || !TAU2) return ctx->fail(SCLENS_ERR_STATE, "sbr_apply_q2: no reflectors of a preceding sb2st_f32 on this context");
+  int VT = (int)((150 * 1024) / (4 * n));
+  if (VT > 8) VT = 8;
+  if (VT < 1) return ctx->fail(SCLENS_ERR_ARG, "sbr_apply_q2 (reference version): order too large for one vector in LDS");
+  const size_t lds = sizeof(float) * (size_t)VT * (size_t)n;
+  SCL_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(sbr_q2_simple), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   (int)lds));
+  hipLaunchKernelGGL(sbr_q2_simple, dim3((unsigned)((m + VT - 1) / VT)), dim3(256), lds, ctx->stream, V2, ldv2, TAU2, ldt, n, Zt,
+                     m, ldz, VT);
+  SCL_HIP(ctx, hipGetLastError());
+  return SCLENS_OK;
+}
+
 }  // namespace scl

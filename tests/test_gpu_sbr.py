@@ -131,3 +131,35 @@ def test_first_back_transformation(ctx, n, m):
     nrm = np.abs(wB).max()
     assert np.abs(Z @ A64 - wB[sel, None] * Z).max() < 3e-5 * nrm
     assert np.abs(np.linalg.norm(Z, axis=1) - 1).max() < 1e-4
+
+
+@pytest.mark.parametrize("n,m", [(128, 128), (320, 64), (1024, 50)])
+def test_two_stage_eigenvectors(ctx, n, m):
+    """Eigenvectors of the tridiagonal matrix (host, float64) through both back-transformations are eigenvectors of A."""
+    import scipy.linalg as sla
+
+    A = _sym_psd(n, 11 * n + 3)
+    lda = rup(n, 32)
+    dA = DevArray(ctx, pad_rows(A, lda))
+    dT = DevArray(ctx, nbytes=4 * max(1, n // SB - 1) * SB * SB)
+    dd, de = DevArray(ctx, nbytes=8 * n), DevArray(ctx, nbytes=8 * n)
+    bd = C.c_int(-1)
+    ctx.check(ctx.lib.sclens_hip_dev_sy2sb_f32(ctx.h, dA.p, n, lda, dT.p, C.byref(bd)))
+    ctx.check(ctx.lib.sclens_hip_dev_sb2st_f32(ctx.h, dA.p, n, lda, dd.p, de.p))
+    ctx.sync()
+    d, e = dd.get((n,), np.float64), de.get((n,), np.float64)
+    w, ZT = sla.eigh_tridiagonal(d, e[: n - 1])
+    sel = np.linspace(0, n - 1, m).astype(int)
+    Zt = np.zeros((m, lda), dtype=np.float32)
+    Zt[:, :n] = ZT[:, sel].T
+    dZ = DevArray(ctx, Zt)
+    ctx.check(ctx.lib.sclens_hip_dev_sbr_apply_q2_f32(ctx.h, n, dZ.p, m, lda))
+    ctx.check(ctx.lib.sclens_hip_dev_sbr_apply_q1_f32(ctx.h, dA.p, n, lda, dT.p, dZ.p, m, lda))
+    ctx.sync()
+    Z = dZ.get((m, lda), np.float32)[:, :n].astype(np.float64)
+    for x in (dA, dT, dd, de, dZ):
+        x.free()
+    A64 = A.astype(np.float64)
+    nrm = np.abs(w).max()
+    assert np.abs(Z @ A64 - w[sel, None] * Z).max() < 5e-5 * nrm
+    assert np.abs(Z @ Z.T - np.eye(m)).max() < 2e-4
