@@ -35,6 +35,7 @@ SIGNATURES = {
     "sclens_hip_set_timing": (C.c_int, [vp, C.c_int]),
     "sclens_hip_get_timing": (C.c_int, [vp, C.c_char_p, c_f64p, c_i64p]),
     "sclens_hip_reset_timing": (C.c_int, [vp]),
+    "sclens_hip_set_option": (C.c_int, [vp, C.c_char_p, i64]),
     "sclens_hip_stream": (vp, [vp]),
     "sclens_hip_batch_create": (vp, []),
     "sclens_hip_batch_destroy": (None, [vp]),
@@ -192,6 +193,9 @@ class Context:
             self.close()
         except Exception:
             pass
+
+    def set_option(self, name: str, value: int):
+        self.check(self.lib.sclens_hip_set_option(self.h, name.encode(), int(value)))
 
     def set_batch(self, group: "Optional[BatchGroup]"):
         self.check(self.lib.sclens_hip_set_batch(self.h, group.h if group is not None else None))

@@ -34,6 +34,10 @@ struct Ctx {
     bool valid = false;
     int64_t N = 0, M = 0, n_cells = 0, n_genes = 0, nnz_out = 0;
   } pp;
+  // eigen-solver selection: 0 = one-stage reduction (tridiag.hip), 1 = two-stage (sbr.hip) with fall-back to one-stage;
+  // set from SCLENS_HIP_TWO_STAGE at creation. last_two_stage: which path holds the state eig_vectors continues from.
+  int two_stage = 0;
+  bool last_two_stage = false;
   // lock-step batching of tridiagonalisations that run concurrently on several contexts (tridiag.hip); not owned
   struct BatchGroup* batch = nullptr;
 
@@ -150,6 +154,8 @@ int preprocess_gather(Ctx* ctx, int64_t* out_colptr, int32_t* out_rowval, float*
 int sy2sb_f32(Ctx* ctx, float* A, int64_t n, int64_t lda, float* Tall, int* breakdown);
 int sbr_apply_q1(Ctx* ctx, const float* A, int64_t n, int64_t lda, const float* Tall, float* Zt, int64_t m, int64_t ldz);
 int sbr_apply_q2(Ctx* ctx, int64_t n, float* Zt, int64_t m, int64_t ldz);
+int eig_values_two_stage(Ctx* ctx, const float* A, int64_t n, int64_t lda, double* w64_dev, int* used);
+int eig_vectors_two_stage(Ctx* ctx, int64_t n, int64_t vec_lo, int64_t vec_hi, float* Zt, int64_t ldz);
 int sb2st_f32(Ctx* ctx, const float* A, int64_t n, int64_t lda, double* d_dev, double* e_dev);
 BatchGroup* batch_create();
 void batch_destroy(BatchGroup* g);

@@ -219,6 +219,73 @@ __global__ __launch_bounds__(256) void sbr_panel_small(const double* __restrict_
   if (tid == 0 && bad) atomicExch(o.flag, 1);
 }
 
+// ---- the last panel (n' = SB rows, some of which may be the zero rows of the padding: rank deficient, so no Cholesky QR):
+// plain Householder QR of the SB x SB block in LDS, one wave, fp64. Same outputs as sbr_panel_small (M is not needed).
+__global__ __launch_bounds__(64) void sbr_panel_house(const float* __restrict__ Ptop, int64_t ldp, SbrSmall o) {
+  __shared__ double P[SB][SB + 1], T[SB][SB + 1];
+  __shared__ double tau_s[SB];
+  const int l = threadIdx.x;  // lane = row
+  for (int c = 0; c < SB; ++c) {
+    P[l][c] = (double)Ptop[(int64_t)c * ldp + l];
+    T[l][c] = 0.0;
+  }
+  __syncthreads();
+  for (int j = 0; j < SB; ++j) {
+    // reflector from P[j:, j]
+    double xi = (l > j) ? P[l][j] : 0.0;
+    double sg = xi * xi;
+#pragma unroll
+    for (int o2 = 32; o2 > 0; o2 >>= 1) sg += __shfl_xor(sg, o2);
+    const double alpha = P[j][j];
+    double tau = 0.0, beta = alpha, scale = 0.0;
+    if (sg > 0.0) {
+      const double nrm = sqrt(alpha * alpha + sg);
+      beta = (alpha >= 0.0) ? -nrm : nrm;
+      tau = (beta - alpha) / beta;
+      scale = 1.0 / (alpha - beta);
+    }
+    const double vl = (l == j) ? 1.0 : (l > j ? xi * scale : 0.0);
+    __syncthreads();
+    // apply H_j = I - tau v v' to the columns c > j; column j becomes (.., beta, 0, ..)
+    for (int c = j + 1; c < SB; ++c) {
+      double t = vl * P[l][c];
+#pragma unroll
+      for (int o2 = 32; o2 > 0; o2 >>= 1) t += __shfl_xor(t, o2);
+      P[l][c] -= tau * vl * t;
+    }
+    if (l == j) P[j][j] = beta;
+    if (l > j) P[l][j] = vl;  // V below the diagonal
+    if (l == 0) tau_s[j] = tau;
+    __syncthreads();
+  }
+  // T (forward, columnwise): T[j][j] = tau_j, T[0:j, j] = -tau_j T[0:j, 0:j] (V[:, 0:j]' v_j)
+  for (int j = 0; j < SB; ++j) {
+    const double tj = tau_s[j];
+    // g_i = V[:, i]' v_j for i < j  (lane i): v_j = (0.., 1 at j, P[r][j] for r > j), V[r][i] = (r == i ? 1 : r > i ? P[r][i] : 0)
+    double g = 0.0;
+    if (l < j) {
+      g = P[j][l];  // r = j: V[j][l] * 1   (j > l)
+      for (int r = j + 1; r < SB; ++r) g += P[r][l] * P[r][j];
+    }
+    __syncthreads();
+    if (l < j) T[l][SB] = g;  // scratch column
+    __syncthreads();
+    if (l < j) {
+      double acc = 0.0;
+      for (int i = l; i < j; ++i) acc += T[l][i] * T[i][SB];
+      T[l][j] = -tj * acc;
+    }
+    if (l == j) T[j][j] = tj;
+    __syncthreads();
+  }
+  for (int c = 0; c < SB; ++c) {
+    o.Rh[l * SB + c] = (c >= l) ? (float)P[l][c] : 0.f;
+    o.V1[l * SB + c] = (c < l) ? (float)P[l][c] : (c == l ? 1.f : 0.f);
+    o.T[l * SB + c] = (c >= l) ? (float)T[l][c] : 0.f;
+    o.M[l * SB + c] = 0.0;
+  }
+}
+
 // ---- "right multiplication" of a 64-row block by a 64 x 64 matrix, one thread per long-dimension position -------------
 //   out[j][r] = sum_i in[i][r] * Mat[i][j]                      (mode 0)
 //   mode 1: V of a panel. in = out = the panel in its transposed storage; positions r < SB take V1 (and the lower-part
@@ -356,7 +423,10 @@ int sy2sb_f32(Ctx* ctx, float* A, int64_t n, int64_t lda, float* Tall, int* brea
     const int nparts = (int)((np + 255) / 256);
     hipLaunchKernelGGL(sbr_cross_part, dim3(nparts), dim3(256), 0, st, Pt, lda, Pt, lda, np, part);
     SbrSmall sm{Mat, V1, Tp, V1 + SB * SB, flag};
-    hipLaunchKernelGGL(sbr_panel_small, dim3(1), dim3(256), 4 * SB * SB * sizeof(double), st, part, nparts, Pt, lda, sm);
+    if (np == SB)  // last panel: may contain the zero rows of the padding
+      hipLaunchKernelGGL(sbr_panel_house, dim3(1), dim3(64), 0, st, Pt, lda, sm);
+    else
+      hipLaunchKernelGGL(sbr_panel_small, dim3(1), dim3(256), 4 * SB * SB * sizeof(double), st, part, nparts, Pt, lda, sm);
     SbrMul mv{};
     mv.in = Pt; mv.ldi = lda; mv.Mat = Mat; mv.out = Pt; mv.ldo = lda; mv.len = np; mv.mode = 1;
     mv.V1 = V1; mv.Rh = V1 + SB * SB; mv.band = A + r0 * lda + c0; mv.lda = lda;
@@ -709,6 +779,101 @@ int sbr_apply_q2(Ctx* ctx, int64_t n, float* Zt, int64_t m, int64_t ldz) {
                                    (int)lds));
   hipLaunchKernelGGL(sbr_q2_simple, dim3((unsigned)((m + VT - 1) / VT)), dim3(256), lds, ctx->stream, V2, ldv2, TAU2, ldt, n, Zt,
                      m, ldz, VT);
+  SCL_HIP(ctx, hipGetLastError());
+  return SCLENS_OK;
+}
+
+
+// ---- the two-stage eigen-solver behind eig_values / eig_vectors (selected by Ctx::two_stage) ----------------------------
+// Orders that are not multiples of SB are embedded in a padded copy: [A 0; 0 diag(sentinel)] with the sentinel above
+// the Gershgorin bound of A, so that the true eigenvalues are the first n of the padded spectrum; the pad block is exactly
+// decoupled (its reflector components stay zero), so it does not touch the accuracy of the rest. A itself is not modified.
+__global__ __launch_bounds__(256) void sbr_row_abs_max(const float* __restrict__ A, int64_t n, int64_t lda,
+                                                       unsigned* __restrict__ out) {
+  __shared__ float sw[4];
+  const float* a = A + (int64_t)blockIdx.x * lda;
+  float s = 0.f;
+  for (int64_t c = threadIdx.x; c < n; c += 256) s += fabsf(a[c]);
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+  if ((threadIdx.x & 63) == 0) sw[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) atomicMax(out, __float_as_uint((sw[0] + sw[1]) + (sw[2] + sw[3])));  // non-negative floats order as uints
+}
+__global__ void sbr_pad_copy(const float* __restrict__ A, int64_t n, int64_t lda, float* __restrict__ Ap, int64_t np,
+                             int64_t ldp, const unsigned* __restrict__ bound, int64_t row0) {
+  const int64_t r = row0 + blockIdx.y;
+  const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= ldp) return;
+  float v = 0.f;
+  if (r < n && c < n) v = A[r * lda + c];
+  else if (r == c && r < np) v = 2.f * __uint_as_float(*bound) + 1.f + (float)(r - n);  // decoupled sentinels, distinct
+  Ap[r * ldp + c] = v;
+}
+__global__ void sbr_copy_f64(const double* __restrict__ in, double* __restrict__ out, int64_t n) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = in[i];
+}
+
+// returns SCLENS_OK with *used = 1, or *used = 0 when the caller must take the one-stage path (order too small, or a
+// panel broke down in the Cholesky QR)
+int eig_values_two_stage(Ctx* ctx, const float* A, int64_t n, int64_t lda, double* w64_dev, int* used) {
+  *used = 0;
+  const int64_t np = round_up(n, SB);
+  if (np < 2 * SB || np > 38000) return SCLENS_OK;  // 38000: the reference second back-transformation keeps a vector in LDS
+  const int64_t ldp = np;
+  SCL_WS(ctx, Ap, float, "sbr.Ap", np * ldp);
+  SCL_WS(ctx, Tall, float, "sbr.Tall", (np / SB) * SB * SB);
+  SCL_WS(ctx, d, double, "sbr.d", np);
+  SCL_WS(ctx, e, double, "sbr.e", np);
+  SCL_WS(ctx, wp, double, "sbr.w", np);
+  SCL_WS(ctx, bound, unsigned, "sbr.bound", 4);
+  hipStream_t st = ctx->stream;
+  SCL_HIP(ctx, hipMemsetAsync(bound, 0, sizeof(unsigned) * 4, st));
+  hipLaunchKernelGGL(sbr_row_abs_max, dim3((unsigned)n), dim3(256), 0, st, A, n, lda, bound);
+  for (int64_t r0 = 0; r0 < np; r0 += 65535) {
+    const int64_t rows = (np - r0 < 65535) ? np - r0 : 65535;
+    hipLaunchKernelGGL(sbr_pad_copy, dim3((unsigned)((ldp + 255) / 256), (unsigned)rows), dim3(256), 0, st, A, n, lda,
+                       Ap, np, ldp, bound, r0);
+  }
+  int breakdown = 0;
+  SCL_TRY(sy2sb_f32(ctx, Ap, np, ldp, Tall, &breakdown));
+  if (breakdown) return SCLENS_OK;
+  SCL_TRY(sb2st_f32(ctx, Ap, np, ldp, d, e));
+  SCL_TRY(stebz_f64(ctx, d, e, np, wp));
+  hipLaunchKernelGGL(sbr_copy_f64, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, wp, w64_dev, n);
+  SCL_HIP(ctx, hipGetLastError());
+  *used = 1;
+  return SCLENS_OK;
+}
+
+__global__ void sbr_unpad_rows(const float* __restrict__ Zp, int64_t ldzp, int64_t n, float* __restrict__ Zt, int64_t ldz) {
+  const int64_t r = blockIdx.y;
+  const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (c < n) Zt[r * ldz + c] = Zp[r * ldzp + c];
+}
+
+// eigenvectors vec_lo .. vec_hi-1 (ascending eigen-index) of the matrix of the preceding eig_values_two_stage call
+int eig_vectors_two_stage(Ctx* ctx, int64_t n, int64_t vec_lo, int64_t vec_hi, float* Zt, int64_t ldz) {
+  const int64_t m = vec_hi - vec_lo;
+  if (m <= 0) return SCLENS_OK;
+  const int64_t np = round_up(n, SB), ldp = np;
+  auto ws = [&](const char* name) -> void* { return ctx->ws.count(name) ? ctx->ws.at(name).first : nullptr; };
+  float* Ap = static_cast<float*>(ws("sbr.Ap"));
+  float* Tall = static_cast<float*>(ws("sbr.Tall"));
+  double* d = static_cast<double*>(ws("sbr.d"));
+  double* e = static_cast<double*>(ws("sbr.e"));
+  double* wp = static_cast<double*>(ws("sbr.w"));
+  if (!Ap || !Tall || !d || !e || !wp) return ctx->fail(SCLENS_ERR_STATE, "eig_vectors_two_stage: no preceding eig_values_two_stage");
+  SCL_WS(ctx, Zp, float, "sbr.Zp", m * ldp);
+  SCL_TRY(stein_f64(ctx, d, e, np, wp, vec_lo, vec_hi, Zp, ldp));
+  SCL_TRY(sbr_apply_q2(ctx, np, Zp, m, ldp));
+  SCL_TRY(sbr_apply_q1(ctx, Ap, np, ldp, Tall, Zp, m, ldp));
+  for (int64_t r0 = 0; r0 < m; r0 += 65535) {
+    const int64_t rows = (m - r0 < 65535) ? m - r0 : 65535;
+    hipLaunchKernelGGL(sbr_unpad_rows, dim3((unsigned)((n + 255) / 256), (unsigned)rows), dim3(256), 0, ctx->stream,
+                       Zp + r0 * ldp, ldp, n, Zt + r0 * ldz, ldz);
+  }
   SCL_HIP(ctx, hipGetLastError());
   return SCLENS_OK;
 }

@@ -492,6 +492,15 @@ __global__ __launch_bounds__(256) void k_mgs_rows(float* __restrict__ Zt, int64_
 
 int eig_values(Ctx* ctx, float* A, int64_t n, int64_t lda, double* w64_dev) {
   if (n <= 0) return SCLENS_OK;
+  ctx->last_two_stage = false;
+  if (ctx->two_stage) {
+    int used = 0;
+    SCL_TRY(eig_values_two_stage(ctx, A, n, lda, w64_dev, &used));
+    if (used) {
+      ctx->last_two_stage = true;
+      return SCLENS_OK;
+    }
+  }
   SCL_WS(ctx, d, double, "eig.d", n);
   SCL_WS(ctx, e, double, "eig.e", n);
   SCL_WS(ctx, tau, float, "eig.tau", n);
@@ -504,11 +513,15 @@ int eig_vectors(Ctx* ctx, const float* A, int64_t n, int64_t lda, const double* 
                 int64_t vec_hi, float* Zt, int64_t ldz) {
   if (vec_hi <= vec_lo) return SCLENS_OK;
   if (vec_lo < 0 || vec_hi > n || !Zt) return ctx->fail(SCLENS_ERR_ARG, "eig_vectors: bad eigenvector range");
-  SCL_WS(ctx, d, double, "eig.d", n);
-  SCL_WS(ctx, e, double, "eig.e", n);
-  SCL_WS(ctx, tau, float, "eig.tau", n);
-  SCL_TRY(stein_f64(ctx, d, e, n, w64_dev, vec_lo, vec_hi, Zt, ldz));
-  SCL_TRY(ormtr_f32(ctx, A, n, lda, tau, Zt, vec_hi - vec_lo, ldz));
+  if (ctx->last_two_stage) {
+    SCL_TRY(eig_vectors_two_stage(ctx, n, vec_lo, vec_hi, Zt, ldz));
+  } else {
+    SCL_WS(ctx, d, double, "eig.d", n);
+    SCL_WS(ctx, e, double, "eig.e", n);
+    SCL_WS(ctx, tau, float, "eig.tau", n);
+    SCL_TRY(stein_f64(ctx, d, e, n, w64_dev, vec_lo, vec_hi, Zt, ldz));
+    SCL_TRY(ormtr_f32(ctx, A, n, lda, tau, Zt, vec_hi - vec_lo, ldz));
+  }
   // clusters of eigenvalues that coincide to fp32 resolution: orthonormalise their vectors
   const int64_t m = vec_hi - vec_lo;
   if (m > 1) {

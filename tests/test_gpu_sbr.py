@@ -163,3 +163,59 @@ def test_two_stage_eigenvectors(ctx, n, m):
     nrm = np.abs(w).max()
     assert np.abs(Z @ A64 - w[sel, None] * Z).max() < 5e-5 * nrm
     assert np.abs(Z @ Z.T - np.eye(m)).max() < 2e-4
+
+
+@pytest.mark.parametrize("n,lo,hi", [(300, 0, 300), (515, 100, 360), (1000, 990, 1000), (2048, 0, 1025), (100, 0, 100)])
+def test_two_stage_solver_behind_eigh(ctx, n, lo, hi):
+    """sclens_hip_dev_eigh_f32 with the context option "two_stage": orders that are not multiples of 64 go through the
+    padded copy (decoupled sentinel block), n = 100 is below the threshold and silently takes the one-stage path."""
+    from sclens_amd._lib import Context
+
+    c2 = Context(ctx.device)
+    c2.set_option("two_stage", 1)
+    try:
+        A = _sym_psd(n, 1000 + n)
+        lda = rup(n, 32)
+        m = hi - lo
+        dA = DevArray(c2, pad_rows(A, lda))
+        dw = DevArray(c2, nbytes=8 * n)
+        dZ = DevArray(c2, nbytes=4 * m * lda)
+        c2.check(c2.lib.sclens_hip_dev_eigh_f32(c2.h, dA.p, n, lda, dw.p, lo, hi, dZ.p, lda))
+        c2.sync()
+        w = dw.get((n,), np.float64)
+        Z = dZ.get((m, lda), np.float32)[:, :n].astype(np.float64)
+        if n >= 128:  # the two-stage path works on a copy: A is untouched
+            assert np.array_equal(dA.get((n, lda), np.float32)[:, :n], A)
+        for x in (dA, dw, dZ):
+            x.free()
+        A64 = A.astype(np.float64)
+        ref = np.linalg.eigvalsh(A64)
+        assert np.abs(w - ref).max() < 6e-7 * np.sqrt(n) * ref.max() + 1e-7
+        assert np.abs(Z @ A64 - w[lo:hi, None] * Z).max() < 5e-5 * ref.max() * np.sqrt(n / 64 + 1)
+        assert np.abs(Z @ Z.T - np.eye(m)).max() < 3e-4
+    finally:
+        c2.close()
+
+
+def test_sclens_with_the_two_stage_solver(ctx, monkeypatch):
+    """The whole path with SCLENS_HIP_TWO_STAGE=1 (every context created inside sclens() picks it up): same decisions as
+    the default solver, spectra and scores within the fp32 tolerances."""
+    from sclens_amd import api
+    from sclens_amd._lib import Context
+    from sclens_amd.synth import synth_counts
+
+    X = synth_counts(300, 500, seed=1, C=5, marker_frac=0.2, marker_sd=1.5)
+    d = api.make_draws_native(X, seed=19)
+    ref = api.sclens(X, draws=d, n_perturb=5, ctx=ctx, streams=2)
+    monkeypatch.setenv("SCLENS_HIP_TWO_STAGE", "1")
+    c2 = Context(ctx.device)
+    try:
+        res = api.sclens(X, draws=d, n_perturb=5, ctx=c2, streams=2)
+    finally:
+        c2.close()
+    assert np.abs(res["L"] - ref["L"]).max() < 2e-5 * ref["L"].max()
+    assert len(res["signal_ev"]) == len(ref["signal_ev"]) and res["p_"] == ref["p_"] and res["n_search"] == ref["n_search"]
+    for (p1, t1), (p2, t2) in zip(res["search_trace"], ref["search_trace"]):
+        assert p1 == p2 and np.abs(t1 - t2).max() < 2e-3
+    assert np.array_equal(res["sig_id"], ref["sig_id"])
+    assert np.abs(res["robustness_scores"]["rob_score"] - ref["robustness_scores"]["rob_score"]).max() < 3e-3
