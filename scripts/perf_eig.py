@@ -24,7 +24,7 @@ for rep in range(2):
     ctx.check(ctx.lib.sclens_hip_dev_eigh_f32(ctx.h, dA.p, n, lda, dw.p, n - mvec, n, dZ.p, lda))
     ctx.sync()
     wall = time.perf_counter() - t0
-    out = {s: ctx.timing(s) for s in ("gram", "sytrd", "stebz", "stein", "ormtr")}
+    out = {s: ctx.timing(s) for s in ("gram", "sytrd", "sy2sb", "sb2st", "stebz", "stein", "ormtr", "sbr_q2", "sbr_q1")}
     print(f"n={n} K={K} mvec={mvec} rep={rep} wall={wall:.3f}s", {k: round(v[0], 2) for k, v in out.items()})
 w = dw.get((n,), np.float64)
 print("gram TF/s (full 2n^2K):", 2 * n * n * K / (out["gram"][0] * 1e-3) / 1e12)
