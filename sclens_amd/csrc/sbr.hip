@@ -1,6 +1,6 @@
 // Two-stage tridiagonalisation, stage 1: dense symmetric -> symmetric band of half-width SB, on the matrix cores.
-// (Work in progress towards replacing the one-stage reduction of tridiag.hip, whose symmetric matrix-vector product streams
-// the trailing matrix once per column -- 2/3 n^3 bytes -- see DESIGN.md section 7. Not selected by eig_values yet.)
+// (An experimental alternative to the one-stage reduction of tridiag.hip, whose symmetric matrix-vector product streams the
+// trailing matrix once per column -- 2/3 n^3 bytes; selected per context by the option "two_stage")
 //
 // Replaces, together with the later stages, the first phase of `_get_eigen` (scLENS.jl:375-387 -> cuSOLVER ssyevd / LAPACK
 // dsyevr in the reference).
@@ -764,6 +764,155 @@ __global__ __launch_bounds__(256) void sbr_q2_simple(const float* __restrict__ V
     for (int64_t c = tid; c < n; c += 256) Zt[(v0 + q) * ldz + c] = zs[(int64_t)q * n + c];
 }
 
+// ---- second back-transformation, blocked: WY groups on the matrix cores -----------------------------------------------------
+// Group (blk, k) = the reflectors (s, k) of the QW consecutive sweeps s = QW blk + c, c < QW: in the window of rows
+// R0 = QW blk + 1 + SB k .. R0 + SB + QW - 2 they form a parallelogram Vg (column c occupies the rows c .. c + L_c - 1);
+// H_S H_{S+1} ... = I - Vg Tg Vg' with the forward columnwise T factor. Row form: zw <- zw - ((zw Vg) Tg') Vg'.
+// Order (derived from which reflectors overlap): sweep blocks from the last to the first, inside a block k ascending.
+constexpr int QW = 32;            // sweeps per group
+constexpr int QH = SB + QW;       // window height, padded (SB + QW - 1 rows are used)
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+__device__ __forceinline__ float sbr_vg(const float* __restrict__ V2, int64_t ldv2, int64_t n, int64_t S, int k, int r, int c) {
+  // Vg[r][c] of group (S, k): entry of reflector (S + c, k) at window row r
+  const int64_t s = S + c;
+  if (s + 2 >= n) return 0.f;                       // no such sweep
+  const int64_t rk = s + 1 + (int64_t)k * SB;       // first row of the reflector = R0 + c
+  if (rk >= n) return 0.f;                          // the sweep has no task k
+  const int64_t L = (n - rk < SB) ? n - rk : SB;
+  const int rr = r - c;
+  return (rr >= 0 && rr < L) ? V2[s * ldv2 + rk + rr] : 0.f;
+}
+
+// T factors of all groups: grid (nk, nblk), one wave
+__global__ __launch_bounds__(64) void sbr_q2_build_t(const float* __restrict__ V2, int64_t ldv2, const float* __restrict__ TAU2,
+                                                     int64_t ldt, int64_t n, int nk, float* __restrict__ Tg) {
+  __shared__ float Vg[QH][QW + 1];
+  __shared__ float T[QW][QW + 1];
+  __shared__ float g[QW];
+  const int k = blockIdx.x, blk = blockIdx.y, l = threadIdx.x;
+  const int64_t S = (int64_t)blk * QW;
+  for (int idx = l; idx < QH * QW; idx += 64) {
+    const int r = idx / QW, c = idx % QW;
+    Vg[r][c] = sbr_vg(V2, ldv2, n, S, k, r, c);
+  }
+  if (l < QW)
+    for (int c = 0; c < QW; ++c) T[l][c] = 0.f;
+  __syncthreads();
+  for (int c = 0; c < QW; ++c) {
+    const int64_t s = S + c;
+    float tau = 0.f;
+    if (s + 2 < n && s + 1 + (int64_t)k * SB < n) tau = TAU2[s * ldt + k];
+    if (l < c) {  // g_l = Vg[:, l]' Vg[:, c]
+      float acc = 0.f;
+      for (int r = c; r < QH; ++r) acc += Vg[r][l] * Vg[r][c];
+      g[l] = acc;
+    }
+    __syncthreads();
+    if (l < c) {
+      float acc = 0.f;
+      for (int j = l; j < c; ++j) acc += T[l][j] * g[j];
+      T[l][c] = -tau * acc;
+    }
+    if (l == c) T[c][c] = tau;
+    __syncthreads();
+  }
+  float* out = Tg + ((int64_t)blk * nk + k) * QW * QW;
+  for (int idx = l; idx < QW * QW; idx += 64) out[idx] = T[idx / QW][idx % QW];
+}
+
+// apply: one workgroup (4 waves) per tile of QV = 32 vectors
+constexpr int QV = 32;
+__global__ __launch_bounds__(256) void sbr_q2_apply(const float* __restrict__ V2, int64_t ldv2, const float* __restrict__ Tg, int nk,
+                                                    int64_t n, float* __restrict__ Zt, int64_t m, int64_t ldz) {
+  __shared__ float Zw[QV][QH + 1];       // the window of the vector tile
+  __shared__ float Vg[QH][QW + 1];
+  __shared__ float Ts[QW][QW + 1];
+  __shared__ float Wp[4][QV][QW + 1];    // K-split partials of zw Vg, then W (in [0]) and W2 (in [1])
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, l31 = lane & 31, h = lane >> 5;
+  const int64_t v0 = (int64_t)blockIdx.x * QV;
+  const int64_t nsweep = n - 2;
+  const int nblk = (int)((nsweep + QW - 1) / QW);
+  for (int blk = nblk - 1; blk >= 0; --blk) {
+    const int64_t S = (int64_t)blk * QW;
+    const int K = sbr_tasks_of(S, n);  // the first sweep of the block has the most tasks
+    for (int k = 0; k < K; ++k) {
+      const int64_t R0 = S + 1 + (int64_t)k * SB;
+      // ---- stage 0: window of Z, the group, its T
+      for (int idx = tid; idx < QV * QH; idx += 256) {
+        const int v = idx / QH, r = idx % QH;
+        const int64_t row = R0 + r;
+        Zw[v][r] = (v0 + v < m && row < n) ? Zt[(v0 + v) * ldz + row] : 0.f;
+      }
+      for (int idx = tid; idx < QH * QW; idx += 256) {
+        const int r = idx / QW, c = idx % QW;
+        Vg[r][c] = sbr_vg(V2, ldv2, n, S, k, r, c);
+      }
+      {
+        const float* tg = Tg + ((int64_t)blk * nk + k) * QW * QW;
+        for (int idx = tid; idx < QW * QW; idx += 256) Ts[idx / QW][idx % QW] = tg[idx];
+      }
+      __syncthreads();
+      // ---- stage 1: W = Zw Vg (32 x 96 times 96 x 32), K split over the four waves (24 each)
+      {
+        f32x16 acc;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+        const int kb = wv * (QH / 4);
+#pragma unroll
+        for (int kk = 0; kk < QH / 4; kk += 2) {
+          const float a = Zw[l31][kb + kk + h];
+          const float b = Vg[kb + kk + h][l31];
+          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+        }
+#pragma unroll
+        for (int e = 0; e < 16; ++e) Wp[wv][(e & 3) + 8 * (e >> 2) + 4 * h][l31] = acc[e];
+      }
+      __syncthreads();
+      for (int idx = tid; idx < QV * QW; idx += 256) {
+        const int v = idx / QW, c = idx % QW;
+        Wp[0][v][c] = (Wp[0][v][c] + Wp[1][v][c]) + (Wp[2][v][c] + Wp[3][v][c]);
+      }
+      __syncthreads();
+      // ---- stage 2: W2 = W Tg' (wave 0)
+      if (wv == 0) {
+        f32x16 acc;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+#pragma unroll
+        for (int kk = 0; kk < QW; kk += 2) {
+          const float a = Wp[0][l31][kk + h];
+          const float b = Ts[l31][kk + h];  // (Tg')[k][col] = Tg[col][k]
+          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+        }
+#pragma unroll
+        for (int e = 0; e < 16; ++e) Wp[1][(e & 3) + 8 * (e >> 2) + 4 * h][l31] = acc[e];
+      }
+      __syncthreads();
+      // ---- stage 3: Zw -= W2 Vg' (three 32-column tiles of the window, waves 0..2), written straight back
+      if (wv < 3) {
+        f32x16 acc;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+#pragma unroll
+        for (int kk = 0; kk < QW; kk += 2) {
+          const float a = Wp[1][l31][kk + h];
+          const float b = Vg[32 * wv + l31][kk + h];  // (Vg')[k][col] = Vg[col][k]
+          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+        }
+        const int col = 32 * wv + l31;
+        const int64_t row = R0 + col;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const int v = (e & 3) + 8 * (e >> 2) + 4 * h;
+          if (v0 + v < m && row < n) Zt[(v0 + v) * ldz + row] = Zw[v][col] - acc[e];
+        }
+      }
+      __syncthreads();
+    }
+  }
+}
+
 int sbr_apply_q2(Ctx* ctx, int64_t n, float* Zt, int64_t m, int64_t ldz) {
   if (m <= 0) return SCLENS_OK;
   StageTimer tm(ctx, "sbr_q2");
@@ -771,14 +920,24 @@ int sbr_apply_q2(Ctx* ctx, int64_t n, float* Zt, int64_t m, int64_t ldz) {
   const float* V2 = static_cast<const float*>(ctx->ws.count("sbr.V2") ? ctx->ws.at("sbr.V2").first : nullptr);
   const float* TAU2 = static_cast<const float*>(ctx->ws.count("sbr.TAU2") ? ctx->ws.at("sbr.TAU2").first : nullptr);
   if (!V2 || !TAU2) return ctx->fail(SCLENS_ERR_STATE, "sbr_apply_q2: no reflectors of a preceding sb2st_f32 on this context");
-  int VT = (int)((150 * 1024) / (4 * n));
-  if (VT > 8) VT = 8;
-  if (VT < 1) return ctx->fail(SCLENS_ERR_ARG, "sbr_apply_q2 (reference version): order too large for one vector in LDS");
-  const size_t lds = sizeof(float) * (size_t)VT * (size_t)n;
-  SCL_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(sbr_q2_simple), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                   (int)lds));
-  hipLaunchKernelGGL(sbr_q2_simple, dim3((unsigned)((m + VT - 1) / VT)), dim3(256), lds, ctx->stream, V2, ldv2, TAU2, ldt, n, Zt,
-                     m, ldz, VT);
+  if (getenv("SCLENS_HIP_Q2_REFERENCE")) {  // the unblocked reference version (tests)
+    int VT = (int)((150 * 1024) / (4 * n));
+    if (VT > 8) VT = 8;
+    if (VT < 1) return ctx->fail(SCLENS_ERR_ARG, "sbr_apply_q2 (reference version): order too large for one vector in LDS");
+    const size_t lds = sizeof(float) * (size_t)VT * (size_t)n;
+    SCL_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(sbr_q2_simple), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                     (int)lds));
+    hipLaunchKernelGGL(sbr_q2_simple, dim3((unsigned)((m + VT - 1) / VT)), dim3(256), lds, ctx->stream, V2, ldv2, TAU2, ldt, n,
+                       Zt, m, ldz, VT);
+    SCL_HIP(ctx, hipGetLastError());
+    return SCLENS_OK;
+  }
+  const int64_t nsweep = n - 2;
+  if (nsweep <= 0) return SCLENS_OK;
+  const int nblk = (int)((nsweep + QW - 1) / QW), nk = (int)((n - 1 + SB - 1) / SB);
+  SCL_WS(ctx, Tg, float, "sbr.Tg", (int64_t)nblk * nk * QW * QW);
+  hipLaunchKernelGGL(sbr_q2_build_t, dim3((unsigned)nk, (unsigned)nblk), dim3(64), 0, ctx->stream, V2, ldv2, TAU2, ldt, n, nk, Tg);
+  hipLaunchKernelGGL(sbr_q2_apply, dim3((unsigned)((m + QV - 1) / QV)), dim3(256), 0, ctx->stream, V2, ldv2, Tg, nk, n, Zt, m, ldz);
   SCL_HIP(ctx, hipGetLastError());
   return SCLENS_OK;
 }
