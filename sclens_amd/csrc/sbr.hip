@@ -821,95 +821,155 @@ __global__ __launch_bounds__(64) void sbr_q2_build_t(const float* __restrict__ V
   for (int idx = l; idx < QW * QW; idx += 64) out[idx] = T[idx / QW][idx % QW];
 }
 
-// apply: one workgroup (4 waves) per tile of QV = 32 vectors
+// apply: one workgroup (4 waves) per tile of QV = 32 vectors. Per group: the 64 window rows that the previous group of the
+// block did not touch, the group's reflectors and its T are fetched into registers while the previous group is still being
+// applied (they do not depend on it); the 32 rows shared with the previous group are carried over in LDS.
 constexpr int QV = 32;
+struct SbrQ2Pref {
+  float z[8], v[12], t[4];
+};
+__device__ __forceinline__ void sbr_q2_fetch(SbrQ2Pref& p, const float* __restrict__ V2, int64_t ldv2, const float* __restrict__ Tg,
+                                             int nk, int64_t n, const float* __restrict__ Zt, int64_t m, int64_t ldz, int64_t v0,
+                                             int blk, int k, bool first, int tid) {
+  const int64_t S = (int64_t)blk * QW, R0 = S + 1 + (int64_t)k * SB;
+  // Z rows: window rows 32..95 (all 96 when `first`): thread -> (vector = tid / 8, 8 consecutive... ) use row-fastest mapping
+  // 32 vectors x 64 rows = 2048 values, 8 per thread: value q -> idx = tid + 256 q, v = idx >> 6, r = 32 + (idx & 63)
+#pragma unroll
+  for (int q = 0; q < 8; ++q) {
+    const int idx = tid + 256 * q, v = idx >> 6, r = 32 + (idx & 63);
+    const int64_t row = R0 + r;
+    p.z[q] = (v0 + v < m && row < n) ? Zt[(v0 + v) * ldz + row] : 0.f;
+  }
+  // group: element idx = tid + 256 q -> column c = idx / QH (a sweep), window row r = idx % QH: coalesced along a reflector
+#pragma unroll
+  for (int q = 0; q < 12; ++q) {
+    const int idx = tid + 256 * q, c = idx / QH, r = idx % QH;
+    const int64_t s = S + c, rk = s + 1 + (int64_t)k * SB;
+    const bool have = (s + 2 < n) && (rk < n);
+    const int64_t L = have ? ((n - rk < SB) ? n - rk : SB) : 0;
+    const int rr = r - c;
+    p.v[q] = (rr >= 0 && rr < L) ? V2[s * ldv2 + rk + rr] : 0.f;
+  }
+  const float* tg = Tg + ((int64_t)blk * nk + k) * QW * QW;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) p.t[q] = tg[tid + 256 * q];
+  (void)first;
+}
+
 __global__ __launch_bounds__(256) void sbr_q2_apply(const float* __restrict__ V2, int64_t ldv2, const float* __restrict__ Tg, int nk,
                                                     int64_t n, float* __restrict__ Zt, int64_t m, int64_t ldz) {
   __shared__ float Zw[QV][QH + 1];       // the window of the vector tile
   __shared__ float Vg[QH][QW + 1];
   __shared__ float Ts[QW][QW + 1];
-  __shared__ float Wp[4][QV][QW + 1];    // K-split partials of zw Vg, then W (in [0]) and W2 (in [1])
+  __shared__ float Wp[4][QV][QW + 1];    // K-split partials of zw Vg
+  __shared__ float Wq[3][QV][QW + 1];    // W2, one private copy per wave that needs it as an MFMA operand
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, l31 = lane & 31, h = lane >> 5;
   const int64_t v0 = (int64_t)blockIdx.x * QV;
   const int64_t nsweep = n - 2;
   const int nblk = (int)((nsweep + QW - 1) / QW);
-  for (int blk = nblk - 1; blk >= 0; --blk) {
-    const int64_t S = (int64_t)blk * QW;
-    const int K = sbr_tasks_of(S, n);  // the first sweep of the block has the most tasks
-    for (int k = 0; k < K; ++k) {
-      const int64_t R0 = S + 1 + (int64_t)k * SB;
-      // ---- stage 0: window of Z, the group, its T
-      for (int idx = tid; idx < QV * QH; idx += 256) {
-        const int v = idx / QH, r = idx % QH;
+  SbrQ2Pref pf;
+  // flat sequence of groups: blocks descending, k ascending
+  int blk = nblk - 1, k = 0;
+  int K = sbr_tasks_of((int64_t)blk * QW, n);
+  sbr_q2_fetch(pf, V2, ldv2, Tg, nk, n, Zt, m, ldz, v0, blk, k, true, tid);
+  while (blk >= 0) {
+    const int64_t S = (int64_t)blk * QW, R0 = S + 1 + (int64_t)k * SB;
+    // ---- stage 0: registers -> LDS; the first group of a block also loads the window rows 0..31
+    if (k == 0) {
+      for (int idx = tid; idx < QV * 32; idx += 256) {
+        const int v = idx >> 5, r = idx & 31;
         const int64_t row = R0 + r;
         Zw[v][r] = (v0 + v < m && row < n) ? Zt[(v0 + v) * ldz + row] : 0.f;
       }
-      for (int idx = tid; idx < QH * QW; idx += 256) {
-        const int r = idx / QW, c = idx % QW;
-        Vg[r][c] = sbr_vg(V2, ldv2, n, S, k, r, c);
-      }
-      {
-        const float* tg = Tg + ((int64_t)blk * nk + k) * QW * QW;
-        for (int idx = tid; idx < QW * QW; idx += 256) Ts[idx / QW][idx % QW] = tg[idx];
-      }
-      __syncthreads();
-      // ---- stage 1: W = Zw Vg (32 x 96 times 96 x 32), K split over the four waves (24 each)
-      {
-        f32x16 acc;
-#pragma unroll
-        for (int e = 0; e < 16; ++e) acc[e] = 0.f;
-        const int kb = wv * (QH / 4);
-#pragma unroll
-        for (int kk = 0; kk < QH / 4; kk += 2) {
-          const float a = Zw[l31][kb + kk + h];
-          const float b = Vg[kb + kk + h][l31];
-          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
-        }
-#pragma unroll
-        for (int e = 0; e < 16; ++e) Wp[wv][(e & 3) + 8 * (e >> 2) + 4 * h][l31] = acc[e];
-      }
-      __syncthreads();
-      for (int idx = tid; idx < QV * QW; idx += 256) {
-        const int v = idx / QW, c = idx % QW;
-        Wp[0][v][c] = (Wp[0][v][c] + Wp[1][v][c]) + (Wp[2][v][c] + Wp[3][v][c]);
-      }
-      __syncthreads();
-      // ---- stage 2: W2 = W Tg' (wave 0)
-      if (wv == 0) {
-        f32x16 acc;
-#pragma unroll
-        for (int e = 0; e < 16; ++e) acc[e] = 0.f;
-#pragma unroll
-        for (int kk = 0; kk < QW; kk += 2) {
-          const float a = Wp[0][l31][kk + h];
-          const float b = Ts[l31][kk + h];  // (Tg')[k][col] = Tg[col][k]
-          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
-        }
-#pragma unroll
-        for (int e = 0; e < 16; ++e) Wp[1][(e & 3) + 8 * (e >> 2) + 4 * h][l31] = acc[e];
-      }
-      __syncthreads();
-      // ---- stage 3: Zw -= W2 Vg' (three 32-column tiles of the window, waves 0..2), written straight back
-      if (wv < 3) {
-        f32x16 acc;
-#pragma unroll
-        for (int e = 0; e < 16; ++e) acc[e] = 0.f;
-#pragma unroll
-        for (int kk = 0; kk < QW; kk += 2) {
-          const float a = Wp[1][l31][kk + h];
-          const float b = Vg[32 * wv + l31][kk + h];  // (Vg')[k][col] = Vg[col][k]
-          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
-        }
-        const int col = 32 * wv + l31;
-        const int64_t row = R0 + col;
-#pragma unroll
-        for (int e = 0; e < 16; ++e) {
-          const int v = (e & 3) + 8 * (e >> 2) + 4 * h;
-          if (v0 + v < m && row < n) Zt[(v0 + v) * ldz + row] = Zw[v][col] - acc[e];
-        }
-      }
-      __syncthreads();
     }
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const int idx = tid + 256 * q;
+      Zw[idx >> 6][32 + (idx & 63)] = pf.z[q];
+    }
+#pragma unroll
+    for (int q = 0; q < 12; ++q) {
+      const int idx = tid + 256 * q;
+      Vg[idx % QH][idx / QH] = pf.v[q];
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int idx = tid + 256 * q;
+      Ts[idx >> 5][idx & 31] = pf.t[q];
+    }
+    __syncthreads();
+    // next group in the sequence; its independent data is fetched now and lands in LDS after this group is done
+    int nblk2 = blk, nk2 = k + 1, K2 = K;
+    if (nk2 >= K) {
+      nblk2 = blk - 1;
+      nk2 = 0;
+      K2 = (nblk2 >= 0) ? sbr_tasks_of((int64_t)nblk2 * QW, n) : 0;
+    }
+    // (the first group of the next block overlaps this group's rows when this group is itself a first group: fetch later)
+    const bool early = nblk2 >= 0 && !(nk2 == 0 && k == 0);
+    if (early) sbr_q2_fetch(pf, V2, ldv2, Tg, nk, n, Zt, m, ldz, v0, nblk2, nk2, nk2 == 0, tid);
+    // ---- stage 1: W = Zw Vg (32 x 96 times 96 x 32), K split over the four waves (24 each)
+    {
+      f32x16 acc;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+      const int kb = wv * (QH / 4);
+#pragma unroll
+      for (int kk = 0; kk < QH / 4; kk += 2) {
+        const float a = Zw[l31][kb + kk + h];
+        const float b = Vg[kb + kk + h][l31];
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+      }
+#pragma unroll
+      for (int e = 0; e < 16; ++e) Wp[wv][(e & 3) + 8 * (e >> 2) + 4 * h][l31] = acc[e];
+    }
+    __syncthreads();
+    // ---- stages 2 + 3 per wave (waves 0..2): W2 = (sum of the partials) Tg', then one 32-column tile of Zw -= W2 Vg'
+    if (wv < 3) {
+      f32x16 acc;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+#pragma unroll
+      for (int kk = 0; kk < QW; kk += 2) {
+        const float a = (Wp[0][l31][kk + h] + Wp[1][l31][kk + h]) + (Wp[2][l31][kk + h] + Wp[3][l31][kk + h]);
+        const float b = Ts[l31][kk + h];  // (Tg')[k][col] = Tg[col][k]
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+      }
+#pragma unroll
+      for (int e = 0; e < 16; ++e) Wq[wv][(e & 3) + 8 * (e >> 2) + 4 * h][l31] = acc[e];
+      // wave-private round trip through LDS: D layout -> A operand layout
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+#pragma unroll
+      for (int kk = 0; kk < QW; kk += 2) {
+        const float a = Wq[wv][l31][kk + h];
+        const float b = Vg[32 * wv + l31][kk + h];  // (Vg')[k][col] = Vg[col][k]
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+      }
+      const int col = 32 * wv + l31;
+      const int64_t row = R0 + col;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int v = (e & 3) + 8 * (e >> 2) + 4 * h;
+        const float out = Zw[v][col] - acc[e];
+        if (v0 + v < m && row < n) Zt[(v0 + v) * ldz + row] = out;
+        if (wv == 2) acc[e] = out;  // rows 64..95 are the rows 0..31 of the next group of this block
+      }
+      if (wv == 2) {
+        // stash for the carry-over; copied into Zw[:, 0..31] after the barrier
+#pragma unroll
+        for (int e = 0; e < 16; ++e) Wq[2][(e & 3) + 8 * (e >> 2) + 4 * h][l31] = acc[e];
+      }
+    }
+    __syncthreads();
+    if (nk2 != 0) {  // carry-over inside the block
+      for (int idx = tid; idx < QV * 32; idx += 256) Zw[idx >> 5][idx & 31] = Wq[2][idx >> 5][idx & 31];
+    }
+    if (nblk2 >= 0 && !early) sbr_q2_fetch(pf, V2, ldv2, Tg, nk, n, Zt, m, ldz, v0, nblk2, nk2, true, tid);
+    blk = nblk2;
+    k = nk2;
+    K = K2;
   }
 }
 
