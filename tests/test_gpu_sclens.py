@@ -379,3 +379,59 @@ def test_multi_rank_sclens_equals_single_rank(ctx, world, streams):
         assert np.array_equal(res["nL_set"][t], ref["nL_set"][t])
     for r in range(1, world):  # the other ranks return the shared part of the result
         assert np.array_equal(out[r]["L"], ref["L"]) and out[r]["p_"] == ref["p_"] and "pca" not in out[r]
+
+
+def _run_ranks(X, d, world, device, **kw):
+    import threading
+
+    from devutil import ThreadShard
+    from sclens_amd._lib import Context
+
+    group = ThreadShard.Group(world)
+    out, err = [None] * world, [None] * world
+
+    def work(r):
+        c = Context(device)
+        try:
+            out[r] = api.sclens(X, draws=d, ctx=c, shard=ThreadShard(group, r), **kw)
+        except BaseException as e:  # noqa: BLE001
+            err[r] = e
+            group.bar.abort()
+        finally:
+            c.close()
+
+    th = [threading.Thread(target=work, args=(r,)) for r in range(world)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    for e in err:
+        if e is not None and not isinstance(e, threading.BrokenBarrierError):
+            raise e
+    assert all(e is None for e in err)
+    return out
+
+
+def test_multi_rank_corner_cases(ctx):
+    """Eight ranks with one stream each on a cells > genes matrix (more ranks than first decompositions, more search slots
+    than iterations), and a matrix without signals on three ranks (every rank must take the early return of
+    scLENS.jl:780-784 together)."""
+    import scipy.sparse as sp
+
+    X = api._csc_f32(synth_counts(600, 250, seed=1, C=5, marker_frac=0.2, marker_sd=1.5))
+    d = api.make_draws_native(X, seed=3)
+    ref = api.sclens(X, draws=d, n_perturb=5, ctx=ctx, streams=1)
+    out = _run_ranks(X, d, 8, ctx.device, n_perturb=5, streams=1)
+    assert np.array_equal(out[0]["L"], ref["L"]) and out[0]["p_"] == ref["p_"] and out[0]["n_search"] == ref["n_search"]
+    assert np.array_equal(out[0]["sig_id"], ref["sig_id"])
+    assert np.array_equal(out[0]["robustness_scores"]["b_"], ref["robustness_scores"]["b_"])
+    assert all(o["p_"] == ref["p_"] for o in out)
+    rng = np.random.default_rng(0)
+    Xn = sp.csc_matrix(rng.poisson(0.12, size=(150, 260)).astype(np.float32))
+    Xn = Xn[np.asarray(Xn.sum(axis=1)).ravel() > 0][:, np.asarray(Xn.sum(axis=0)).ravel() > 0]
+    Xn = api._csc_f32(Xn[:, np.diff(Xn.tocsc().indptr) >= 2].tocsc())
+    dn = api.make_draws_native(Xn, seed=1)
+    refn = api.sclens(Xn, draws=dn, n_perturb=3, ctx=ctx, max_search_iters=5)
+    outn = _run_ranks(Xn, dn, 3, ctx.device, n_perturb=3, max_search_iters=5, streams=2)
+    assert len(outn[0].get("signal_ev", [])) == len(refn.get("signal_ev", []))
+    assert np.array_equal(outn[0]["L"], refn["L"]) and all(o["p_"] == refn["p_"] for o in outn)
