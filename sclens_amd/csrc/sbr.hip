@@ -24,6 +24,7 @@
 namespace scl {
 
 constexpr int SB = 64;
+constexpr int SBR_CHUNK = 256;   // long-dimension positions per workgroup of sbr_cross_part
 
 // ---- partial cross products of two 64-row blocks: part[wg][i][j] = sum_{k in chunk wg} X[i][k] * Y[j][k]  (fp64) ------
 __global__ __launch_bounds__(256) void sbr_cross_part(const float* __restrict__ X, int64_t ldx, const float* __restrict__ Y,
@@ -36,8 +37,8 @@ __global__ __launch_bounds__(256) void sbr_cross_part(const float* __restrict__ 
   for (int u = 0; u < 4; ++u)
 #pragma unroll
     for (int v = 0; v < 4; ++v) acc[u][v] = 0.0;
-  const int64_t k0 = (int64_t)blockIdx.x * 256;
-  const int64_t kend = (k0 + 256 < len) ? k0 + 256 : len;
+  const int64_t k0 = (int64_t)blockIdx.x * SBR_CHUNK;
+  const int64_t kend = (k0 + SBR_CHUNK < len) ? k0 + SBR_CHUNK : len;
   for (int64_t kc = k0; kc < kend; kc += 32) {
 #pragma unroll
     for (int q = 0; q < 8; ++q) {
@@ -372,22 +373,20 @@ __global__ void sbr_cvt64(const float* __restrict__ in, double* __restrict__ out
   if (i < n) out[i] = (double)in[i];
 }
 
-// Sh = 1/2 T' (V'Y), V'Y = sum of the cross partials in a fixed order; one wave, lane = row
-__global__ __launch_bounds__(64) void sbr_small_s(const double* __restrict__ part, int nparts, const float* __restrict__ T,
+// Sh = 1/2 T' (V'Y), V'Y = sum of the cross partials in a fixed order; 256 threads, 4 x 4 outputs each
+__global__ __launch_bounds__(256) void sbr_small_s(const double* __restrict__ part, int nparts, const float* __restrict__ T,
                                                   double* __restrict__ Sh) {
-  __shared__ double G[SB][SB];
-  const int l = threadIdx.x;
-  for (int c = 0; c < SB; ++c) {
+  __shared__ double G[SB * SB], Tt[SB * SB], R[SB * SB];
+  const int tid = threadIdx.x;
+  for (int idx = tid; idx < SB * SB; idx += 256) {
     double s = 0.0;
-    for (int p = 0; p < nparts; ++p) s += part[(int64_t)p * SB * SB + l * SB + c];
-    G[l][c] = s;
+    for (int p = 0; p < nparts; ++p) s += part[(int64_t)p * SB * SB + idx];
+    G[idx] = s;
+    Tt[(idx & 63) * SB + (idx >> 6)] = (double)T[idx];  // T' (T is upper: its strictly lower part is stored as 0)
   }
   __syncthreads();
-  for (int c = 0; c < SB; ++c) {  // (T' G)[l][c] = sum_k T[k][l] G[k][c], T upper: k <= l
-    double s = 0.0;
-    for (int k = 0; k <= l; ++k) s += (double)T[k * SB + l] * G[k][c];
-    Sh[l * SB + c] = 0.5 * s;
-  }
+  mm64(R, Tt, G);
+  for (int idx = tid; idx < SB * SB; idx += 256) Sh[idx] = 0.5 * R[idx];
 }
 
 // ---- host driver ------------------------------------------------------------------------------------------------------
@@ -401,7 +400,7 @@ int sy2sb_f32(Ctx* ctx, float* A, int64_t n, int64_t lda, float* Tall, int* brea
   StageTimer tm(ctx, "sy2sb");
   const int64_t npan = n / SB - 1;  // the last diagonal block needs no reduction
   const int64_t ldw = round_up(n, 64);
-  const int64_t maxparts = (n + 255) / 256 + 1;
+  const int64_t maxparts = (n + SBR_CHUNK - 1) / SBR_CHUNK + 1;
   const int S = 8;  // K-slices of the skinny product W = A22 V
   SCL_WS(ctx, part, double, "sbr.part", maxparts * SB * SB);
   SCL_WS(ctx, Mat, double, "sbr.M", 2 * SB * SB);   // M | Sh
@@ -420,7 +419,7 @@ int sy2sb_f32(Ctx* ctx, float* A, int64_t n, int64_t lda, float* Tall, int* brea
     const int64_t c0 = p * SB, r0 = c0 + SB, np = n - r0;
     float* Pt = A + c0 * lda + r0;  // transposed panel: Pt[j][i] = A[c0 + j][r0 + i] = P[i][j] (symmetric storage)
     float* Tp = Tall + p * SB * SB;
-    const int nparts = (int)((np + 255) / 256);
+    const int nparts = (int)((np + SBR_CHUNK - 1) / SBR_CHUNK);
     hipLaunchKernelGGL(sbr_cross_part, dim3(nparts), dim3(256), 0, st, Pt, lda, Pt, lda, np, part);
     SbrSmall sm{Mat, V1, Tp, V1 + SB * SB, flag};
     if (np == SB)  // last panel: may contain the zero rows of the padding
@@ -449,7 +448,7 @@ int sy2sb_f32(Ctx* ctx, float* A, int64_t n, int64_t lda, float* Tall, int* brea
     hipLaunchKernelGGL(sbr_cvt64, dim3(16), dim3(256), 0, st, Tp, Mat + SB * SB, SB * SB);
     hipLaunchKernelGGL(sbr_rightmul, dim3((unsigned)((np + 255) / 256)), dim3(256), 0, st, my);
     hipLaunchKernelGGL(sbr_cross_part, dim3(nparts), dim3(256), 0, st, Pt, lda, Yt, ldw, np, part);
-    hipLaunchKernelGGL(sbr_small_s, dim3(1), dim3(64), 0, st, part, nparts, Tp, Mat + SB * SB);
+    hipLaunchKernelGGL(sbr_small_s, dim3(1), dim3(256), 0, st, part, nparts, Tp, Mat + SB * SB);
     SbrMul mz{};  // Z = Y - V Sh, and the row-major operands of the rank-2SB update
     mz.in = Pt; mz.ldi = lda; mz.Mat = Mat + SB * SB; mz.len = np; mz.mode = 3;
     mz.Y = Yt; mz.ldy = ldw; mz.VW = VW; mz.WV = WV;
