@@ -4,6 +4,7 @@
 #include <algorithm>
 #include <cstdint>
 #include <cstring>
+#include <thread>
 #include <vector>
 
 #include "../../include/sclens_hip.h"
@@ -66,37 +67,68 @@ int sclens_draw_null_matrix(int64_t N, int64_t M, const int64_t* colptr, const f
                             int32_t* out_rowval, float* out_nzval) {
   if (N <= 0 || M <= 0 || !colptr || !nzval || !out_rowval || !out_nzval) return SCLENS_ERR_ARG;
   const int64_t nnz = colptr[M];
-  Xo rng(seed ^ 0xA5A5A5A5DEADBEEFull);
-  std::copy(nzval, nzval + nnz, out_nzval);
-  for (int64_t i = nnz - 1; i > 0; --i) std::swap(out_nzval[i], out_nzval[rng.below((uint64_t)i + 1)]);  // shuffle (:275)
-  std::vector<uint64_t> mark((N + 63) / 64);
-  for (int64_t j = 0; j < M; ++j) {  // per gene: the same number of entries at uniformly drawn distinct cells (:247)
-    const int64_t b = colptr[j], c = colptr[j + 1] - b;
-    if (c <= 0) continue;
-    if (c > N) return SCLENS_ERR_ARG;
-    std::fill(mark.begin(), mark.end(), 0);
-    if (2 * c <= N) {
-      int64_t got = 0;
-      while (got < c) {
-        const uint64_t r = rng.below((uint64_t)N);
-        if (mark[r >> 6] & (1ull << (r & 63))) continue;
-        mark[r >> 6] |= 1ull << (r & 63);
-        ++got;
-      }
-    } else {  // dense column: draw the complement
-      int64_t got = 0;
-      while (got < N - c) {
-        const uint64_t r = rng.below((uint64_t)N);
-        if (mark[r >> 6] & (1ull << (r & 63))) continue;
-        mark[r >> 6] |= 1ull << (r & 63);
-        ++got;
-      }
-      for (auto& w : mark) w = ~w;
+  for (int64_t j = 0; j < M; ++j)
+    if (colptr[j + 1] - colptr[j] > N || colptr[j + 1] < colptr[j]) return SCLENS_ERR_ARG;
+  const int T = (int)std::max<int64_t>(1, std::min<int64_t>(8, nnz / 1000000 + 1));  // host threads
+  // (1) the stored values in random order (scLENS.jl:275), as a two-level shuffle: every value goes to one of NBK buckets
+  //     chosen uniformly (one sequential pass), then each bucket -- small enough for the cache -- gets its own Fisher-Yates
+  //     shuffle from its own generator (in parallel). Concatenated, that is a uniform random permutation, and it depends
+  //     on the seed only, not on the thread count.
+  // (2) per gene the same number of entries at uniformly drawn distinct cells (:247): gene j has its own generator
+  //     seeded from (seed, j)
+  constexpr int NBK = 256;
+  std::vector<int64_t> bstart(NBK + 1, 0);
+  {
+    Xo rng(seed ^ 0xA5A5A5A5DEADBEEFull);
+    std::vector<uint8_t> bucket((size_t)nnz);
+    for (int64_t q = 0; q < nnz; ++q) {
+      const uint8_t b = (uint8_t)(rng.next() >> 56);
+      bucket[q] = b;
+      bstart[b + 1] += 1;
     }
-    int64_t q = b;
-    for (int64_t r = 0; r < N && q < b + c; ++r)
-      if (mark[r >> 6] & (1ull << (r & 63))) out_rowval[q++] = (int32_t)r;  // ascending rows
+    for (int b = 0; b < NBK; ++b) bstart[b + 1] += bstart[b];
+    std::vector<int64_t> cur(bstart.begin(), bstart.end() - 1);
+    for (int64_t q = 0; q < nnz; ++q) out_nzval[cur[bucket[q]]++] = nzval[q];
   }
+  auto work = [&](int t) {
+    for (int b = NBK * t / T; b < NBK * (t + 1) / T; ++b) {
+      uint64_t sb = seed ^ (0xC2B2AE3D27D4EB4Full * (uint64_t)(b + 1));
+      Xo rb(scl::splitmix64(sb));
+      float* v = out_nzval + bstart[b];
+      for (int64_t i = bstart[b + 1] - bstart[b] - 1; i > 0; --i) std::swap(v[i], v[rb.below((uint64_t)i + 1)]);
+    }
+    std::vector<uint64_t> mark((N + 63) / 64);
+    const int64_t j0 = M * t / T, j1 = M * (t + 1) / T;
+    for (int64_t j = j0; j < j1; ++j) {
+      const int64_t b = colptr[j], c = colptr[j + 1] - b;
+      if (c <= 0) continue;
+      uint64_t sj = seed + 0x9E3779B97F4A7C15ull * (uint64_t)(j + 1);
+      Xo rng(scl::splitmix64(sj));
+      std::fill(mark.begin(), mark.end(), 0);
+      const bool complement = 2 * c > N;  // dense gene: draw the cells that are NOT expressed
+      const int64_t want = complement ? N - c : c;
+      int64_t got = 0;
+      while (got < want) {
+        const uint64_t r = rng.below((uint64_t)N);
+        if (mark[r >> 6] & (1ull << (r & 63))) continue;
+        mark[r >> 6] |= 1ull << (r & 63);
+        ++got;
+      }
+      int64_t q = b;
+      for (size_t wi = 0; wi < mark.size(); ++wi) {  // ascending cells, word by word
+        uint64_t w = complement ? ~mark[wi] : mark[wi];
+        if (wi == mark.size() - 1 && (N & 63)) w &= (1ull << (N & 63)) - 1;
+        while (w) {
+          out_rowval[q++] = (int32_t)(wi * 64 + (size_t)__builtin_ctzll(w));
+          w &= w - 1;
+        }
+      }
+    }
+  };
+  std::vector<std::thread> th;
+  for (int t = 1; t < T; ++t) th.emplace_back(work, t);
+  work(0);
+  for (auto& x : th) x.join();
   return SCLENS_OK;
 }
 
