@@ -210,6 +210,9 @@ int sclens_hip_session_spectrum(sclens_hip_session* s, const int64_t* r_colptr, 
  * (sclens_hip_session_clone) while the main session decomposes the data matrix. */
 int sclens_hip_session_null_spectrum(sclens_hip_session* s, const int64_t* r_colptr, const int32_t* r_rowval,
                                      const float* r_nzval, double* Lr);
+/* null_spectrum from a pattern of X_r built beforehand with sclens_hip_pattern_create (n_cand = 0), so that the host part of
+ * the upload can run while the session is still being created; the pattern stays with the caller. */
+int sclens_hip_session_null_spectrum_pattern(sclens_hip_session* s, sclens_hip_pattern* x_r, double* Lr);
 int sclens_hip_session_data_spectrum(sclens_hip_session* s, double* L, double* rec_tgc, double* rec_mat2_mean,
                                      double* rec_mat2_std, double* rec_norm_tgc, double* rec_cent);
 /* Share read-only device results between sessions of one GPU: what = 1 Vr2 (after binary_basis on src), 2 the seed

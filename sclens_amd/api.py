@@ -549,6 +549,11 @@ class Session:
                                                                      ptr(nz, C.c_float), ptr(Lr, C.c_double)))
         return Lr
 
+    def null_spectrum_pattern(self, pat: "Pattern") -> np.ndarray:
+        Lr = np.empty(self.n)
+        self.ctx.check(self.ctx.lib.sclens_hip_session_null_spectrum_pattern(self.h, pat.h, ptr(Lr, C.c_double)))
+        return Lr
+
     def data_spectrum(self, with_rec_vals: bool = True):
         L = np.empty(self.n)
         if not with_rec_vals:  # centering="median": the reference's rec_vals Dict stays empty (scLENS.jl:697-698)
@@ -728,13 +733,17 @@ def sclens(inp_df, device_="gpu", th=60, p_step=0.001, n_perturb=20, centering="
     ses.set_int("chefsi", 1 if partial_eig else 0)
     ses.set_int("centering", 1 if median else 0)
     lap("session_create")
-    aux_ctx = Context(ctx.device)
-    aux_pool = ThreadPoolExecutor(max_workers=1)
+    aux_ctx, aux_ctx2 = Context(ctx.device), Context(ctx.device)
+    aux_pool = ThreadPoolExecutor(max_workers=2)
 
     def build_pattern():
         z1_, z2_ = _resolve(draws.z_idx1), _resolve(draws.z_idx2)
         return Pattern(aux_ctx, X_, z1_, z2_), z1_, z2_
 
+    def build_null_pattern():  # the null matrix's pattern, ready when the null decomposition starts
+        return Pattern(aux_ctx2, _csc_f32(_resolve(draws.X_r)), [], [])
+
+    null_future = aux_pool.submit(build_null_pattern)
     pat_future = aux_pool.submit(build_pattern)
     pat = None
     try:
@@ -797,7 +806,7 @@ def sclens(inp_df, device_="gpu", th=60, p_step=0.001, n_perturb=20, centering="
                 jobs.append((0, lambda: ("data", ses.data_spectrum(not median))))
             if shard.rank == r_null:
                 w_null = free[0]
-                jobs.append((workers.index(w_null), lambda: ("null", w_null.null_spectrum(_resolve(draws.X_r)))))
+                jobs.append((workers.index(w_null), lambda: ("null", w_null.null_spectrum_pattern(null_future.result()))))
             if shard.rank == r_bin:
                 w_bin = free[1] if (shard.rank == r_null and len(free) > 1) else free[0]
                 jobs.append((workers.index(w_bin), lambda: ("bin", w_bin.binary_basis())))
@@ -808,12 +817,12 @@ def sclens(inp_df, device_="gpu", th=60, p_step=0.001, n_perturb=20, centering="
             r_vr2 = int(shard.bcast_host(np.array([float(got["bin"][1]) if "bin" in got else 0.0]), r_bin)[0])
         elif W == 1:  # serial order of the reference: null and data spectra, signal vectors, then Vr2
             w_bin = ses
-            Lr = ses.null_spectrum(_resolve(draws.X_r))
+            Lr = ses.null_spectrum_pattern(null_future.result())
             L, rec_vals = ses.data_spectrum(not median)
             r_vr2 = None
         else:  # the main session keeps the data matrix's reflectors for signal_vectors; workers take the other two
             w_null, w_bin = workers[1], workers[2 if W >= 3 else 1]
-            (L, rec_vals), Lr, (_, r_vr2) = run_all([(0, lambda: ses.data_spectrum(not median)), (1, lambda: w_null.null_spectrum(_resolve(draws.X_r))),
+            (L, rec_vals), Lr, (_, r_vr2) = run_all([(0, lambda: ses.data_spectrum(not median)), (1, lambda: w_null.null_spectrum_pattern(null_future.result())),
                                                      (2 if W >= 3 else 1, w_bin.binary_basis)], lockstep=True)
         L_mp, _, b_min = _mp_calculation(L, Lr[:-1])  # Lr[1:end-1] (:537, :576)
         lambda_c = _tw(L, L_mp)[0]
@@ -974,8 +983,13 @@ def sclens(inp_df, device_="gpu", th=60, p_step=0.001, n_perturb=20, centering="
                 pat = pat_future.result()[0]
         except Exception:
             pat = None
+        try:
+            null_future.result().close()
+        except Exception:
+            pass
         aux_pool.shutdown(wait=True)
         ses.close()
         if pat is not None:
             pat.close()
         aux_ctx.close()
+        aux_ctx2.close()

@@ -20,6 +20,7 @@ int pattern_create(Ctx*, int64_t, int64_t, const int64_t*, const int32_t*, const
                    const uint32_t*, PatternOwner**);
 void pattern_destroy(PatternOwner*);
 int session_set_pattern(Session*, PatternOwner*);
+int session_null_spectrum_pattern(Session*, PatternOwner*, double*);
 int session_signal_vectors(Session*, int64_t, float*);
 int session_binary_basis(Session*, double*, int64_t*);
 int session_search_step(Session*, const uint32_t*, int64_t, int64_t, double*, int64_t*);
@@ -257,6 +258,11 @@ int sclens_hip_session_null_spectrum(sclens_hip_session* w, const int64_t* rc, c
   SES_GUARD(w);
   if (!rc || !rr || !rv) return SCLENS_ERR_ARG;
   return scl::session_null_spectrum(w->s, rc, rr, rv, Lr);
+}
+int sclens_hip_session_null_spectrum_pattern(sclens_hip_session* w, sclens_hip_pattern* p, double* Lr) {
+  SES_GUARD(w);
+  if (!p) return SCLENS_ERR_ARG;
+  return scl::session_null_spectrum_pattern(w->s, reinterpret_cast<scl::PatternOwner*>(p), Lr);
 }
 int sclens_hip_session_data_spectrum(sclens_hip_session* w, double* L, double* rec_tgc, double* rec_mean, double* rec_std,
                                      double* rec_norm, double* rec_cent) {

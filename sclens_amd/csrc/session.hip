@@ -443,6 +443,20 @@ int session_null_spectrum(Session* s, const int64_t* rc_, const int32_t* rr_, co
   return SCLENS_OK;
 }
 
+// the same from a pattern that was built (and uploaded) beforehand, e.g. on a host thread while the session was created
+int session_null_spectrum_pattern(Session* s, PatternOwner* pr, double* Lr) {
+  Ctx* ctx = s->ctx;
+  if (!pr || pr->allocs.empty() || pr->dev.N != s->N || pr->dev.M != s->M)
+    return ctx->fail(SCLENS_ERR_ARG, "null_spectrum: the pattern is empty or has different dimensions");
+  float* valr = static_cast<float*>(ctx->workspace("ses.valr", sizeof(float) * (size_t)pr->dev.nU));
+  if (!valr) return SCLENS_ERR_OOM;
+  SCL_TRY(make_values(ctx, pr->dev, pr->base_val, 0, nullptr, 0, valr));
+  SCL_TRY(decompose(s, pr->dev, valr, 1, s->Btmp, (float)s->M, nullptr));
+  SCL_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  if (Lr) std::copy(s->w_host.begin(), s->w_host.end(), Lr);
+  return SCLENS_OK;
+}
+
 // data matrix: inline Float64 path with rec_vals (scLENS.jl:676-696); divisor size(X,2) = M
 int session_data_spectrum(Session* s, double* L, ScaleVecs* keep) {
   Ctx* ctx = s->ctx;
