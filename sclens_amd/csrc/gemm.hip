@@ -8,6 +8,8 @@
 // LDS image is [k][m] for both operands (row stride 132 floats), so a fragment read is 32
 // consecutive floats per half-wave (conflict-free ds_read_b32); global->LDS goes through registers
 // (prefetch of tile t+1 is issued before the MFMAs of tile t; one barrier per K-step).
+#include <algorithm>
+
 #include "common.h"
 
 namespace scl {
@@ -174,6 +176,210 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs a, int tiles_n) {
     }
 }
 
+
+// ---- large-tile NT kernel (both operands K-contiguous) ---------------------------------------------------------------------
+// 256x256x32 block tile, 512 threads = 8 waves (2 x 4), each wave 128x64 = 4x2 MFMA tiles (128 accumulator registers, one
+// workgroup per CU, two waves per SIMD). Operands go global -> LDS directly (`global_load_lds_dwordx4`, no VGPR staging), two
+// LDS stages of 64 KB. One wave-instruction moves 8 rows x 128 B (full cache lines); the LDS image is lane-linear
+// ([row][8 chunks of 16 B]) and chunk q of row r is stored at slot q ^ ((r >> 1) & 7) by permuting the SOURCE address, so
+// that the fragment reads (`ds_read_b128`, 16-lane groups with 16 different rows) are bank-conflict free.
+// k order inside an 8-deep group: MFMA step t takes k = t from the lanes 0-31 and k = 4 + t from the lanes 32-63 (lane half h
+// reads chunk 2 j + h), so one 16-byte read per operand tile feeds four MFMA steps.
+// The block -> tile map is a host-built list: blocks that share blockIdx % 8 (one XCD, one L2) walk through compact squares of
+// tiles, so an XCD's concurrent tiles share operand panels in its L2.
+constexpr int GB = 256, GK = 32;
+constexpr int G_STAGE_FLOATS = 2 * GB * GK;  // A image + B image of one stage
+
+typedef __attribute__((address_space(3))) void lds_void;
+typedef const __attribute__((address_space(1))) void glb_void;
+
+__global__ __launch_bounds__(512, 2) void gemm_nt_big(GemmArgs a, const int2* __restrict__ tiles) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int2 tl = tiles[blockIdx.x];
+  if (tl.x < 0) return;
+  const int64_t m0 = (int64_t)tl.x * GB, n0 = (int64_t)tl.y * GB;
+  if (a.splits > 1) {
+    const int64_t koff = (int64_t)blockIdx.y * a.k_chunk;
+    const int64_t kleft = a.K - koff;
+    a.K = kleft < 0 ? 0 : (kleft < a.k_chunk ? kleft : a.k_chunk);
+    a.P += koff;
+    a.Q += koff;
+    a.C += (int64_t)blockIdx.y * a.c_split_off;
+  }
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int wm = wid >> 2, wn = wid & 3, l31 = lane & 31, h = lane >> 5;
+
+  // staging: wave w moves row groups 4 w .. 4 w + 3 (8 rows each) of both operands
+  const int srow = lane >> 3, sq = lane & 7;
+  const float* srcA[4];
+  const float* srcB[4];
+  int64_t rowA[4], rowB[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int r = (wid * 4 + i) * 8 + srow;
+    const int chunk = sq ^ ((r >> 1) & 7);
+    int64_t ra = m0 + r, rb = n0 + r;
+    if (ra > a.M - 1) ra = a.M - 1;
+    if (rb > a.N - 1) rb = a.N - 1;
+    rowA[i] = ra;
+    rowB[i] = rb;
+    srcA[i] = a.P + ra * a.ldp + 4 * chunk;
+    srcB[i] = a.Q + rb * a.ldq + 4 * chunk;
+  }
+  const int64_t nfull = a.K / GK, nkt = (a.K + GK - 1) / GK;
+  auto stage = [&](int buf, int64_t kt) {
+    float* As = lds + buf * G_STAGE_FLOATS;
+    float* Bs = As + GB * GK;
+    if (kt < nfull) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int g = wid * 4 + i;
+        __builtin_amdgcn_global_load_lds((glb_void*)(srcA[i] + kt * GK), (lds_void*)(As + g * 256), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((glb_void*)(srcB[i] + kt * GK), (lds_void*)(Bs + g * 256), 16, 0, 0);
+      }
+    } else {  // K tail: through registers, zero beyond K
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int g = wid * 4 + i, r = g * 8 + srow;
+        const int chunk = sq ^ ((r >> 1) & 7);
+        const int64_t kk = kt * GK + 4 * chunk;
+        *reinterpret_cast<f32x4*>(As + g * 256 + lane * 4) = ld4<true>(a.P, a.ldp, rowA[i], a.M, kk, a.K);
+        *reinterpret_cast<f32x4*>(Bs + g * 256 + lane * 4) = ld4<true>(a.Q, a.ldq, rowB[i], a.N, kk, a.K);
+      }
+    }
+  };
+
+  f32x16 acc[4][2];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  // fragment read offsets (floats) inside a stage: row r -> r * 32 + ((c ^ ((r >> 1) & 7)) << 2), c = 2 j8 + h
+  int offA[4], offB[2], swA[4], swB[2];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int r = wm * 128 + i * 32 + l31;
+    offA[i] = r * 32;
+    swA[i] = (r >> 1) & 7;
+  }
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int r = wn * 64 + j * 32 + l31;
+    offB[j] = GB * GK + r * 32;
+    swB[j] = (r >> 1) & 7;
+  }
+
+  if (nkt > 0) stage(0, 0);
+  __syncthreads();
+  for (int64_t kt = 0; kt < nkt; ++kt) {
+    const int buf = (int)(kt & 1);
+    if (kt + 1 < nkt) stage(buf ^ 1, kt + 1);
+    const float* S = lds + buf * G_STAGE_FLOATS;
+#pragma unroll
+    for (int j8 = 0; j8 < 4; ++j8) {
+      const int c = 2 * j8 + h;
+      f32x4 av[4], bv[2];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) av[i] = *reinterpret_cast<const f32x4*>(S + offA[i] + ((c ^ swA[i]) << 2));
+#pragma unroll
+      for (int j = 0; j < 2; ++j) bv[j] = *reinterpret_cast<const f32x4*>(S + offB[j] + ((c ^ swB[j]) << 2));
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i][t], bv[j][t], acc[i][j], 0, 0, 0);
+    }
+    __syncthreads();
+  }
+
+  // ---- epilogue. D layout of the 32x32 MFMA: col = lane&31, rows (e&3) + 8*(e>>2) + 4*(lane>>5): four consecutive rows per
+  //      register quad, so the mirrored (transposed) store of `lower` is one 16-byte store per quad.
+  if (a.colabsmax) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      float mx = 0.f;
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) mx = fmaxf(mx, fabsf(a.alpha * acc[i][j][e]));
+      // rows beyond M hold copies of row M-1 (clamped loads): harmless for a maximum
+      mx = fmaxf(mx, __shfl_xor(mx, 32));
+      const int64_t col = n0 + wn * 64 + j * 32 + l31;
+      if (h == 0 && col < a.N) atomicMax(&a.colabsmax[col], __float_as_uint(mx));
+    }
+    return;
+  }
+  const bool vec_mirror = a.lower && (a.ldc % 4 == 0) && ((reinterpret_cast<uintptr_t>(a.C) & 15u) == 0);
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int64_t col = n0 + wn * 64 + j * 32 + l31;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int64_t rowq = m0 + wm * 128 + i * 32 + 8 * q + 4 * h;
+        f32x4 v;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int64_t row = rowq + u;
+          float x = a.alpha * acc[i][j][4 * q + u];
+          if (row < a.M && col < a.N && (!a.lower || col <= row)) {
+            if (a.beta != 0.f) x += a.beta * a.C[row * a.ldc + col];
+            a.C[row * a.ldc + col] = x;
+          }
+          v[u] = x;
+        }
+        if (a.lower && col < a.N) {
+          if (vec_mirror && rowq + 3 < a.M && col < rowq) {
+            *reinterpret_cast<f32x4*>(&a.C[col * a.ldc + rowq]) = v;
+          } else {
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+              if (rowq + u < a.M && col < rowq + u) a.C[col * a.ldc + rowq + u] = v[u];
+          }
+        }
+      }
+    }
+}
+
+// block -> tile list of gemm_nt_big: tiles ordered by squares of SQ x SQ tiles; chunk c of CH = SQ*SQ consecutive tiles goes
+// to the blocks {b : b % 8 == c % 8} in order (blocks are dealt round-robin over the 8 XCDs), padded with (-1,-1)
+static int big_tile_list(Ctx* ctx, int64_t tm, int64_t tn, int lower, const int2** out, int64_t* nblocks) {
+  constexpr int SQ = 6, CH = SQ * SQ;
+  const std::string key = "gemm.tiles." + std::to_string(tm) + "x" + std::to_string(tn) + (lower ? "L" : "F");
+  std::vector<int2> seq;
+  for (int64_t si = 0; si < (tm + SQ - 1) / SQ; ++si)
+    for (int64_t sj = 0; sj < (tn + SQ - 1) / SQ; ++sj) {
+      if (lower && sj > si) break;
+      for (int64_t i = si * SQ; i < std::min<int64_t>(tm, (si + 1) * SQ); ++i)
+        for (int64_t j = sj * SQ; j < std::min<int64_t>(tn, (sj + 1) * SQ); ++j)
+          if (!lower || j <= i) seq.push_back(make_int2((int)i, (int)j));
+    }
+  const int64_t nt = (int64_t)seq.size();
+  const int64_t nb = round_up(nt, 8 * CH);
+  *nblocks = nb;
+  auto it = ctx->ws.find(key);
+  if (it != ctx->ws.end()) {
+    *out = static_cast<const int2*>(it->second.first);
+    return SCLENS_OK;
+  }
+  std::vector<int2> list((size_t)nb);
+  for (int64_t b = 0; b < nb; ++b) {
+    const int64_t loc = b >> 3, idx = ((loc / CH) * 8 + (b & 7)) * CH + loc % CH;
+    list[(size_t)b] = idx < nt ? seq[(size_t)idx] : make_int2(-1, -1);
+  }
+  int2* dev = static_cast<int2*>(ctx->workspace(key, sizeof(int2) * (size_t)nb));
+  if (!dev) return SCLENS_ERR_OOM;
+  SCL_HIP(ctx, hipMemcpyAsync(dev, list.data(), sizeof(int2) * (size_t)nb, hipMemcpyHostToDevice, ctx->stream));
+  SCL_HIP(ctx, hipStreamSynchronize(ctx->stream));  // `list` is a local
+  *out = dev;
+  return SCLENS_OK;
+}
+
 int gemm_f32(Ctx* ctx, const GemmArgs& a) {
   if (a.M <= 0 || a.N <= 0) return SCLENS_OK;
   if (a.lower && a.M != a.N) return ctx->fail(SCLENS_ERR_ARG, "gemm_f32: lower needs M == N");
@@ -184,6 +390,21 @@ int gemm_f32(Ctx* ctx, const GemmArgs& a) {
                    (a.ldp % 4 == 0) && (a.ldq % 4 == 0);
   if (a.splits > 1 && (a.k_chunk <= 0 || a.k_chunk % 16 != 0 || a.colabsmax || a.beta != 0.f))
     return ctx->fail(SCLENS_ERR_ARG, "gemm_f32: bad split-K arguments");
+  if (a.q_kcontig && vec && a.K >= GK && a.M >= 160 && a.N >= 160 && (a.splits <= 1 || a.k_chunk % GK == 0) &&
+      !getenv("SCLENS_HIP_GEMM_SMALL")) {
+    const int64_t bm = (a.M + GB - 1) / GB, bn = (a.N + GB - 1) / GB;
+    const int2* tiles = nullptr;
+    int64_t nb = 0;
+    SCL_TRY(big_tile_list(ctx, bm, bn, a.lower, &tiles, &nb));
+    static const hipError_t attr_rc = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_big),
+                                                          hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                          2 * G_STAGE_FLOATS * (int)sizeof(float));
+    SCL_HIP(ctx, attr_rc);
+    hipLaunchKernelGGL(gemm_nt_big, dim3((unsigned)nb, (unsigned)(a.splits > 1 ? a.splits : 1)), dim3(512),
+                       2 * G_STAGE_FLOATS * sizeof(float), ctx->stream, a, tiles);
+    SCL_HIP(ctx, hipGetLastError());
+    return SCLENS_OK;
+  }
   dim3 grid((unsigned)ntiles, (unsigned)(a.splits > 1 ? a.splits : 1)), block(256);
   if (a.q_kcontig) {
     if (vec)
