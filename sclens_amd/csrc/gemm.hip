@@ -278,20 +278,30 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_big(GemmArgs a, const int2* __
     const int buf = (int)(kt & 1);
     if (kt + 1 < nkt) stage(buf ^ 1, kt + 1);
     const float* S = lds + buf * G_STAGE_FLOATS;
+    // fragments of the 8-deep group j8 + 1 are fetched before the MFMAs of group j8 (two named register sets)
+    f32x4 av[2][4], bv[2][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) av[0][i] = *reinterpret_cast<const f32x4*>(S + offA[i] + ((h ^ swA[i]) << 2));
+#pragma unroll
+    for (int j = 0; j < 2; ++j) bv[0][j] = *reinterpret_cast<const f32x4*>(S + offB[j] + ((h ^ swB[j]) << 2));
 #pragma unroll
     for (int j8 = 0; j8 < 4; ++j8) {
-      const int c = 2 * j8 + h;
-      f32x4 av[4], bv[2];
+      const int cur = j8 & 1, nxt = cur ^ 1;
+      if (j8 + 1 < 4) {
+        const int c = 2 * (j8 + 1) + h;
 #pragma unroll
-      for (int i = 0; i < 4; ++i) av[i] = *reinterpret_cast<const f32x4*>(S + offA[i] + ((c ^ swA[i]) << 2));
+        for (int i = 0; i < 4; ++i) av[nxt][i] = *reinterpret_cast<const f32x4*>(S + offA[i] + ((c ^ swA[i]) << 2));
 #pragma unroll
-      for (int j = 0; j < 2; ++j) bv[j] = *reinterpret_cast<const f32x4*>(S + offB[j] + ((c ^ swB[j]) << 2));
+        for (int j = 0; j < 2; ++j) bv[nxt][j] = *reinterpret_cast<const f32x4*>(S + offB[j] + ((c ^ swB[j]) << 2));
+      }
+      __builtin_amdgcn_sched_barrier(0);  // keep the reads ahead of this group's MFMAs (hipcc would sink them behind)
 #pragma unroll
       for (int t = 0; t < 4; ++t)
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
-          for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i][t], bv[j][t], acc[i][j], 0, 0, 0);
+          for (int j = 0; j < 2; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[cur][i][t], bv[cur][j][t], acc[i][j], 0, 0, 0);
     }
     __syncthreads();
   }
@@ -390,9 +400,10 @@ int gemm_f32(Ctx* ctx, const GemmArgs& a) {
                    (a.ldp % 4 == 0) && (a.ldq % 4 == 0);
   if (a.splits > 1 && (a.k_chunk <= 0 || a.k_chunk % 16 != 0 || a.colabsmax || a.beta != 0.f))
     return ctx->fail(SCLENS_ERR_ARG, "gemm_f32: bad split-K arguments");
-  if (a.q_kcontig && vec && a.K >= GK && a.M >= 160 && a.N >= 160 && (a.splits <= 1 || a.k_chunk % GK == 0) &&
-      !getenv("SCLENS_HIP_GEMM_SMALL")) {
-    const int64_t bm = (a.M + GB - 1) / GB, bn = (a.N + GB - 1) / GB;
+  const int64_t bm = (a.M + GB - 1) / GB, bn = (a.N + GB - 1) / GB;
+  // the large-tile kernel needs enough tiles for the 256 CUs (one workgroup each)
+  if (a.q_kcontig && vec && a.K >= GK && (a.lower ? bm * (bm + 1) / 2 : bm * bn) * (a.splits > 1 ? a.splits : 1) >= 200 &&
+      (a.splits <= 1 || a.k_chunk % GK == 0) && !getenv("SCLENS_HIP_GEMM_SMALL")) {
     const int2* tiles = nullptr;
     int64_t nb = 0;
     SCL_TRY(big_tile_list(ctx, bm, bn, a.lower, &tiles, &nb));
