@@ -4,25 +4,39 @@
 One "step" = one complete sclens() call (scLENS.jl:649-832: normalisation, data/null/binary decompositions,
 MP/TW thresholding, sparsity search, 20-member perturbation ensemble, robustness scoring, gene basis) on a
 seeded synthetic cells x genes count matrix that is already resident in host CSC form; every random draw of the
-call is generated inside the timed region. Default workload = BASELINE.json configs[1] (10 000 x 20 000).
+call is generated inside the timed region.
 
-  python bench.py --gpus N --steps K --warmup W        (N > 1: launched by torch.distributed.run, one rank per GPU)
+Default workload = the configuration BASELINE.json's `metric` is quoted on: 100 000 cells x 30 000 genes (`cfg4`).
+
+  python bench.py --gpus N --steps K --warmup W
+
+N > 1 without WORLD_SIZE in the environment: this process starts the N ranks itself (a child `python -m
+torch.distributed.run`, before anything here touches the GPU) and relays the child's JSON line and exit code.
+Under torch.distributed.run (WORLD_SIZE set) it is one rank of the job.
+
+A full sclens() at cfg4 takes about a minute, so K timed steps may not fit the time a caller allows: the run is held
+to `--budget-s` seconds of wall-clock (default 1500 s, SCLENS_BENCH_BUDGET_S) and executes as many of the requested
+warm-up / timed steps as fit. The JSON line reports the TRUE counts in `steps` / `warmup` and the requested ones in
+`steps_requested` / `warmup_requested`.
 
 Prints ONE JSON line on rank 0 (contract in the task statement) with two extra objects:
-  roofline     : dominant kernel `trd_colB` (HBM-bound symmetric matrix-vector product of the tridiagonalisation),
-                 algorithmic bytes = the lower triangle of the symmetric trailing matrix, 2 n'(n'+1) B with n' = n-j-1,
-                 per launch (half of SURVEY 8(d)'s full-read figure 4 n'^2, which is also reported); duration = one
-                 HIP-event pair on the library's stream around all n-1 launches of one tridiagonalisation, back to back.
+  roofline     : the dominant kernel of the workload, measured live with HIP events on the library's own stream.
+                 n >= 16 000 (two-stage eigensolver): the fp32 MFMA contraction `gemm_nt_big` on the Gram product,
+                 achieved = n (n + 1) K flop / duration against 157.3 TF/s; otherwise `trd_colB` (HBM-bound symmetric
+                 matrix-vector product of the one-stage tridiagonalisation), achieved = lower-triangle bytes / duration
+                 against 8 TB/s. `stages` holds the same ratio for every stage of one decomposition.
   cpu_baseline : the oracle (float64 NumPy/SciPy port of the reference CPU path) timed on the host cores on a
                  bounded sample, stage-extrapolated to the workload (see `sample`).
 """
 import argparse
 import json
-import math
 import os
+import socket
+import subprocess
 import sys
 import time
 
+T_PROCESS_START = time.perf_counter()
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
@@ -35,14 +49,14 @@ CONFIGS = {  # name -> (N cells, M genes, index in BASELINE.json configs)
     "cfg3": (50000, 30000, 2),
     "cfg4": (100000, 30000, 3),
 }
-HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
-# HBM bytes per trd_colB launch / algorithmic bytes, from the PMC passes in profiles/r01_pmc (rocprofv3 --pmc FETCH_SIZE
-# and --pmc WRITE_SIZE in separate runs, first panel at n = 10000: FETCH_SIZE 99 731 KB x 2 (gfx950 reports half the bytes
-# of wide coalesced reads, MI355X_MICROARCH.md) + WRITE_SIZE 7 149 KB = 211.6 MB against 197.5 MB algorithmic).
-PMC_TRAFFIC_RATIO = 1.07
+HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+MFMA_F32_PEAK_TFS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 64 FLOP/clk/SIMD
+# HBM bytes per trd_colB launch / algorithmic bytes: constant from profiles/r01_pmc_final (rocprofv3 --pmc FETCH_SIZE and
+# --pmc WRITE_SIZE in separate runs; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950) -- NOT measured in this run
+PMC_TRAFFIC_RATIO_R01 = 1.07
 
 
-def roofline_probe(ctx, n):
+def symv_probe(ctx, n):
     """Every trd_colB launch of one tridiagonalisation of order n (same grids / arguments as the real reduction), back
     to back on the library's stream between one pair of HIP events (sclens_hip_symv_probe)."""
     import ctypes as C
@@ -53,21 +67,99 @@ def roofline_probe(ctx, n):
     gbs = nbytes.value / (ms.value * 1e-3) / 1e9
     return {"bound": "hbm", "kernel": "trd_colB", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(gbs / HBM_PEAK_GBS, 4),
-            "traffic": round(PMC_TRAFFIC_RATIO * nbytes.value / max(1, launches.value), 1), "launches": launches.value,
-            "avg_launch_us": round(ms.value * 1e3 / max(1, launches.value), 2),
+            "traffic": round(PMC_TRAFFIC_RATIO_R01 * nbytes.value / max(1, launches.value), 1),
+            "traffic_source": "constant 1.07 x algorithmic from profiles/r01_pmc_final, not measured in this run",
+            "launches": launches.value, "avg_launch_us": round(ms.value * 1e3 / max(1, launches.value), 2),
             "algorithmic_bytes_per_launch_avg": round(nbytes.value / max(1, launches.value), 1), "n": n,
             "achieved_vs_full_read_4n2": round(2 * gbs, 1)}
 
 
-def cpu_baseline(N, M, n_search, n_perturb):
+def stage_probe(ctx, X, N, M):
+    """One decomposition of the data matrix with per-stage HIP-event timing on the library's stream (normalise, Gram,
+    eigensolver stages, eigenvectors of the lower half + the corr product as in one search step): achieved rate of each
+    stage against the roofline that bounds it."""
+    from sclens_amd import api
+
+    n, K = min(N, M), max(N, M)
+    ctx.set_timing(True)
+    ctx.reset_timing()
+    ses = api.Session(ctx, X)
+    try:
+        ses.data_spectrum(False)
+    finally:
+        ses.close()
+    if os.environ.get("SCLENS_BENCH_PROBE_VECTORS", "1") != "0":
+        # eigenvectors of the lower half of a spectrum, as one search step computes them (Gram of a random n x 2048 block)
+        rup = lambda x, q: (x + q - 1) // q * q
+        lda, Kp = rup(n, 32), 2048
+        rng = np.random.default_rng(5)
+        blk = rng.standard_normal((min(n, 2048), Kp)).astype(np.float32)
+        dB, dA = ctx.malloc(4 * n * Kp), ctx.malloc(4 * n * lda)
+        dw, dZ = ctx.malloc(8 * n), ctx.malloc(4 * (n // 2) * lda)
+        try:
+            for r0 in range(0, n, blk.shape[0]):
+                rows = min(blk.shape[0], n - r0)
+                ctx.h2d(dB + 4 * r0 * Kp, np.roll(blk[:rows], r0 // blk.shape[0], axis=1))
+            g0 = ctx.timing("gram")
+            ctx.check(ctx.lib.sclens_hip_dev_gram_f32(ctx.h, dB, n, Kp, Kp, float(Kp), dA, lda))
+            ctx.check(ctx.lib.sclens_hip_dev_eigh_f32(ctx.h, dA, n, lda, dw, 0, n // 2, dZ, lda))
+            ctx.sync()
+        finally:
+            for q in (dB, dA, dw, dZ):
+                ctx.free(q)
+    names = ("scale", "gram", "sytrd", "sy2sb", "sb2st", "stebz", "stein", "ormtr", "sbr_q2", "sbr_q1")
+    t = {s: ctx.timing(s) for s in names}
+    if "g0" in locals():  # the Gram of the data matrix only (the probe's small product is not the workload's)
+        t["gram"] = g0
+    ctx.set_timing(False)
+    stages = {}
+
+    def add(name, key, work, unit, peak, bound, note):
+        ms, calls = t[key]
+        if calls > 0 and ms > 0:
+            per = ms / calls  # average duration of one call of the stage
+            ach = work / (per * 1e-3) / (1e12 if unit == "TFLOP/s" else 1e9)
+            stages[name] = {"bound": bound, "ms": round(per, 3), "achieved": round(ach, 2), "peak": peak, "unit": unit,
+                            "frac": round(ach / peak, 4), "work": note}
+
+    nnz = int(X.nnz)
+    add("normalise", "scale", 8.0 * nnz + 4.0 * N * M, "GB/s", HBM_PEAK_GBS, "hbm", "8 nnz read + 4 N M written (SURVEY 8d B_norm)")
+    add("gram", "gram", float(n) * (n + 1) * K, "TFLOP/s", MFMA_F32_PEAK_TFS, "mfma", "n (n+1) K flop (computed lower half)")
+    add("sytrd_one_stage", "sytrd", sum(2.0 * q * (q + 1) for q in range(1, n)), "GB/s", HBM_PEAK_GBS, "hbm",
+        "lower triangle of the trailing matrix once per column, whole reduction")
+    add("sy2sb_dense_to_band", "sy2sb", 4.0 / 3.0 * float(n) ** 3, "TFLOP/s", MFMA_F32_PEAK_TFS, "mfma", "4/3 n^3 flop")
+    add("sb2st_bulge_chasing", "sb2st", 6.0 * float(n) ** 2 * 64, "TFLOP/s", MFMA_F32_PEAK_TFS, "latency",
+        "6 n^2 b flop, b = 64 (latency-bound chain of 2 n dependent steps; rate shown for scale only)")
+    m = n // 2
+    add("q2_back_transform", "sbr_q2", 2.0 * float(n) ** 2 * m, "TFLOP/s", MFMA_F32_PEAK_TFS, "mfma", "2 n^2 m flop, m = n/2")
+    add("q1_back_transform", "sbr_q1", 2.0 * float(n) ** 2 * m, "TFLOP/s", MFMA_F32_PEAK_TFS, "mfma", "2 n^2 m flop, m = n/2")
+    add("ormtr_back_transform", "ormtr", 2.0 * float(n) ** 2 * m, "TFLOP/s", MFMA_F32_PEAK_TFS, "mfma", "2 n^2 m flop, m = n/2")
+    for key in ("stebz", "stein"):
+        ms, calls = t[key]
+        if calls:
+            stages[key] = {"bound": "latency", "ms": round(ms / calls, 3)}
+    return stages
+
+
+def cpu_baseline(N, M, n_search, n_perturb, budget_s):
     """Oracle (port of the reference CPU path) on the host cores: every stage timed once on a bounded sample and
-    scaled to the workload by its complexity, times the call counts observed in the GPU run."""
+    scaled to the workload by its complexity, times the call counts observed in the GPU run. The sample is the workload's
+    own n when one dsyevr of that order fits the budget (cfg2), else the largest order that does."""
     from oracle import sclens_oracle as O  # checker / baseline only
     from sclens_amd.synth import synth_counts
 
     n, K = min(N, M), max(N, M)
-    ns = min(n, 4000)  # ~10-20 s of CPU work on the box's host cores; n^3 extrapolation factor <= 16 at cfg2
+    cores = os.cpu_count() or 1
+    # dsyevr with vectors ~ 25 n^3 flop-equivalents at ~4 GF/s/core effective (measured: n = 4000 in ~7 s on 128 threads,
+    # 3.65 s at n = 3000 on 8 cores): pick the largest n_s whose estimate fits a third of the budget
+    est = lambda q: 1.2e-10 * q ** 3 * max(1.0, 16.0 / cores) + 0.5
+    ns = n
+    while ns > 1500 and est(ns) > budget_s / 3:
+        ns = int(ns * 0.85)
+    ns = min(n, max(1500, ns))
     Ns, Ms = (ns, int(ns * M / N)) if N <= M else (int(ns * N / M), ns)
+    if N > M:  # keep the sample's contraction length affordable: the Gram scales exactly with K
+        Ns = min(Ns, 4 * ns)
     Xs = synth_counts(Ns, Ms, seed=11)
     t0 = time.perf_counter()
     S = O.logn_scale(O.pre_scale(Xs))
@@ -82,7 +174,6 @@ def cpu_baseline(N, M, n_search, n_perturb):
     f3 = (n / ns) ** 3
     T = calls * (t_scale * (N * M) / (Ns * Ms) + t_gram * (n * n * K) / (ns * ns * max(Ns, Ms)) + t_eig * f3)
     T += n_search * t_gram * (n ** 3) / (ns * ns * max(Ns, Ms))  # corr_mat (scLENS.jl:742): ~n^3 flop per iteration
-    cores = os.cpu_count() or 1
     try:  # threads the BLAS/LAPACK behind NumPy/SciPy actually uses
         from threadpoolctl import threadpool_info
 
@@ -90,10 +181,24 @@ def cpu_baseline(N, M, n_search, n_perturb):
     except Exception:
         pass
     return {"value": round(N * M / T, 1), "unit": "cells*genes/s", "cores": cores, "kind": "port",
-            "wall_s_extrapolated": round(T, 1),
+            "wall_s_extrapolated": round(T, 1), "eig_extrapolation_factor_n3": round(f3, 2),
             "sample": (f"oracle normalise+Gram+dsyevr timed once at {Ns}x{Ms} ({t_scale:.2f}s, {t_gram:.2f}s, {t_eig:.2f}s), "
-                       f"scaled by NM, n^2K and n^3 to {N}x{M}, times {calls} decompositions (S={n_search}, P={n_perturb}) "
-                       f"+ {n_search} corr GEMMs; BLAS threads = {cores} (host has {os.cpu_count()} cores)")}
+                       f"scaled by NM, n^2K and n^3 (x{f3:.1f}) to {N}x{M}, times {calls} decompositions (S={n_search}, "
+                       f"P={n_perturb}) + {n_search} corr GEMMs; BLAS threads = {cores} (host has {os.cpu_count()} cores)")}
+
+
+def self_launch(args):
+    """--gpus N > 1 outside torch.distributed.run: start the N ranks as a child job. Nothing in this process has touched
+    the GPU yet (no torch import, no library context), and the child is a subprocess, not an exec."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
 
 
 def main():
@@ -101,7 +206,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=1)
     ap.add_argument("--warmup", type=int, default=0)
-    ap.add_argument("--config", default="cfg2", choices=list(CONFIGS))
+    ap.add_argument("--config", default="cfg4", choices=list(CONFIGS))
+    ap.add_argument("--budget-s", type=float, default=float(os.environ.get("SCLENS_BENCH_BUDGET_S", "1500")),
+                    help="wall-clock limit of the whole run; warm-up and timed steps are cut to fit (true counts are reported)")
     ap.add_argument("--n-perturb", type=int, default=20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
@@ -111,9 +218,13 @@ def main():
                     help="cells > genes configs on N > 1 GPUs: every rank holds a block of cells, partial Gram matrices are "
                          "all-reduced (SURVEY 8e-iii, sclens_amd/atlas.py) instead of distributing whole decompositions")
     ap.add_argument("--streams", type=int, default=3, help="concurrent decompositions per GPU (worker sessions on own HIP streams)")
+    ap.add_argument("--extra-configs", default="", help="comma-separated further configs timed once each after the main one (reported under `extra`)")
     ap.add_argument("--verbose", action="store_true")
     ap.add_argument("--stage-timing", action="store_true", help="per-stage HIP-event totals on stderr (adds syncs)")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args))
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -139,59 +250,92 @@ def main():
 
     ctx = Context(local_rank)
     shard = Shard(rank, world, dev if (world > 1 and args.backend == "nccl") else None)
-    N, M, cfg_index = CONFIGS[args.config]
-    t0 = time.perf_counter()
-    X = api._csc_f32(synth_counts(N, M, seed=20240427 + cfg_index))  # PCG64(20240427 + config_index)
-    t_synth = time.perf_counter() - t0
+    check = shard.selfcheck(ctx)  # raises (non-zero exit) when the RCCL all-reduce is wrong; picks the staging mode
+    if rank == 0 and world > 1:
+        print(f"[bench] {world} ranks, backend {args.backend}, self-check {check}", file=sys.stderr, flush=True)
 
-    row_shard = args.row_shard and N > M
-    if row_shard:
-        from sclens_amd import atlas
+    def agree(x):  # rank 0's decision on every rank (steps must match or the collectives dead-lock)
+        return float(shard.bcast_host(np.array([float(x)]), 0)[0])
 
-        r0, r1 = atlas.row_block(rank, world, N)
-        X_rows = api._csc_f32(X.tocsr()[r0:r1].tocsc())
+    def run_config(cfg, steps_req, warm_req, deadline):
+        N, M, cfg_index = CONFIGS[cfg]
+        t0 = time.perf_counter()
+        X = api._csc_f32(synth_counts(N, M, seed=20240427 + cfg_index))  # PCG64(20240427 + config_index)
+        t_synth = time.perf_counter() - t0
+        row_shard = args.row_shard and N > M
+        if row_shard:
+            from sclens_amd import atlas
 
-    def one_step(step):
-        t_d = time.perf_counter()
-        draws = api.make_draws_native(X, seed=1000 + step, async_null=True, async_candidates=not row_shard)
-        one_step.draws_s = time.perf_counter() - t_d  # R1-R3 inside the timed region; R4/R5 on the device inside sclens()
-        if row_shard:  # global draws (identical on every rank), local cells
-            return atlas.sclens_row_sharded(X_rows, r0, N, draws, shard, n_perturb=args.n_perturb, ctx=ctx, gather=False,
-                                            verbose=args.verbose)
-        return api.sclens(X, draws=draws, ctx=ctx, n_perturb=args.n_perturb, shard=shard, streams=args.streams,
-                          batch=args.batch, verbose=args.verbose and rank == 0)
+            r0, r1 = atlas.row_block(rank, world, N)
+            X_rows = api._csc_f32(X.tocsr()[r0:r1].tocsc())
 
-    def fence():
-        shard.barrier()
-        torch.cuda.synchronize()
-        ctx.sync()
+        def one_step(step):
+            t_d = time.perf_counter()
+            draws = api.make_draws_native(X, seed=1000 + step, async_null=True, async_candidates=not row_shard)
+            one_step.draws_s = time.perf_counter() - t_d  # R1-R3 inside the timed region; R4/R5 on the device inside sclens()
+            if row_shard:  # global draws (identical on every rank), local cells
+                return atlas.sclens_row_sharded(X_rows, r0, N, draws, shard, n_perturb=args.n_perturb, ctx=ctx, gather=False,
+                                                verbose=args.verbose)
+            return api.sclens(X, draws=draws, ctx=ctx, n_perturb=args.n_perturb, shard=shard, streams=args.streams,
+                              batch=args.batch, verbose=args.verbose and rank == 0)
+
+        def fence():
+            shard.barrier()
+            torch.cuda.synchronize()
+            ctx.sync()
+
+        res, t_step, n_warm = None, None, 0
+        for w in range(warm_req):
+            # a warm-up step is taken only if it and one timed step still fit (the first step is never skipped)
+            if agree(t_step is not None and time.perf_counter() + 2.2 * t_step > deadline):
+                break
+            ts = time.perf_counter()
+            res = one_step(-1 - w)
+            t_step = time.perf_counter() - ts
+            n_warm += 1
+        fence()
+        n_steps = 0
+        t0 = time.perf_counter()
+        for s in range(steps_req):
+            if s > 0 and agree(time.perf_counter() + 1.1 * t_step > deadline):
+                break
+            ts = time.perf_counter()
+            res = one_step(s)
+            t_step = time.perf_counter() - ts
+            n_steps += 1
+        fence()
+        dt = time.perf_counter() - t0
+        if world > 1:
+            import torch.distributed as dist
+
+            tt = torch.tensor([dt], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            dt = float(tt.item())
+        return {"N": N, "M": M, "X": X, "res": res, "dt": dt, "steps": n_steps, "warmup": n_warm, "synth_s": t_synth,
+                "row_shard": row_shard, "draws_s": one_step.draws_s}
 
     if args.stage_timing:
         ctx.set_timing(True)
-    res = None
-    for w in range(args.warmup):
-        res = one_step(-1 - w)
-    fence()
-    t0 = time.perf_counter()
-    for s in range(args.steps):
-        res = one_step(s)
-    fence()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        import torch.distributed as dist
-
-        tt = torch.tensor([dt], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
+    deadline = T_PROCESS_START + args.budget_s
+    # reserve for what follows the timed region: roofline probe, CPU baseline sample, extra configs
+    reserve = (0 if args.no_roofline else 25) + (0 if args.no_cpu_baseline else 45)
+    main_r = run_config(args.config, args.steps, args.warmup, deadline - reserve)
+    N, M, X, res, dt = main_r["N"], main_r["M"], main_r["X"], main_r["res"], main_r["dt"]
+    steps = main_r["steps"]
 
     if args.stage_timing and rank == 0:
-        st = {k: ctx.timing(k) for k in ("scale", "gram", "sytrd", "stebz", "stein", "ormtr", "chefsi", "corr", "recover")}
+        st = {k: ctx.timing(k) for k in ("scale", "gram", "sytrd", "sy2sb", "sb2st", "stebz", "stein", "ormtr", "sbr_q2", "sbr_q1",
+                                          "chefsi", "corr", "recover")}
         print("stage totals (ms, calls):", {k: (round(v[0], 1), v[1]) for k, v in st.items()}, "wall_s", round(dt, 2), file=sys.stderr)
+        ctx.set_timing(False)
+    out = None
     if rank == 0:
-        ms_per_step = dt / max(1, args.steps) * 1e3
+        ms_per_step = dt / max(1, steps) * 1e3
+        row_shard = main_r["row_shard"]
         out = {
-            "metric": "sclens() cells*genes/s (wall-clock of one full sclens() call)", "value": round(N * M * args.steps / dt, 1),
-            "unit": "cells*genes/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "metric": "sclens() cells*genes/s (wall-clock of one full sclens() call)", "value": round(N * M * steps / dt, 1),
+            "unit": "cells*genes/s", "n_gpus": world, "steps": steps, "warmup": main_r["warmup"],
+            "steps_requested": args.steps, "warmup_requested": args.warmup, "budget_s": args.budget_s,
             "ms_per_step": round(ms_per_step, 1), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{args.config}: synthetic Poisson-lognormal counts {N} cells x {M} genes, sparsity "
@@ -200,17 +344,42 @@ def main():
                        "parallelism": (f"cells row-sharded over {world} ranks: per decomposition 4 small all-reduces + one "
                                        f"all-reduce of the {M}x{M} fp32 partial Gram matrix, eigen-solver replicated" if row_shard
                                        else f"single GPU, {args.streams} concurrent decompositions (HIP streams)" if world == 1 else
-                                       f"search rounds of {world}x{args.streams} + ensemble t%{world}, 1 RCCL all-gather")},
-            "sclens_wall_s": round(dt / max(1, args.steps), 3),
+                                       f"search rounds of {world}x{args.streams} + ensemble t%{world}, 1 RCCL all-gather "
+                                       f"({shard.staging}-staged)")},
+            "sclens_wall_s": round(dt / max(1, steps), 3),
             "observed": {"signals": int(len(res.get("signal_ev", []))), "robust_signals": int(len(res.get("sig_id", []))),
-                         "search_iters": int(res["n_search"]), "p_": res["p_"], "synth_s": round(t_synth, 1),
+                         "search_iters": int(res["n_search"]), "p_": res["p_"], "synth_s": round(main_r["synth_s"], 1),
                          "ensemble_partial_eig": {"used": int(res["partial_eig"][0]), "fallback_to_full": int(res["partial_eig"][1])},
-                         "phase_s_rank0_last_step": dict({"draws_host": round(one_step.draws_s, 4)}, **res.get("phase_s", {}))},
+                         "phase_s_rank0_last_step": dict({"draws_host": round(main_r["draws_s"], 4)}, **res.get("phase_s", {}))},
         }
+    # ---- extra configs (one timed step each), while the budget lasts
+    extra = {}
+    for cfg in [c for c in args.extra_configs.split(",") if c]:
+        if agree(time.perf_counter() + 60 > deadline - reserve):
+            break
+        r = run_config(cfg, 1, 0, deadline - reserve)
+        if rank == 0:
+            extra[cfg] = {"N": r["N"], "M": r["M"], "sclens_wall_s": round(r["dt"], 3), "value": round(r["N"] * r["M"] / r["dt"], 1),
+                          "search_iters": int(r["res"]["n_search"]), "signals": int(len(r["res"].get("signal_ev", [])))}
+    if rank == 0:
+        if extra:
+            out["extra"] = extra
+        n = min(N, M)
         if not args.no_roofline:
-            out["roofline"] = roofline_probe(ctx, min(N, M))
+            stages = stage_probe(ctx, X, N, M)
+            if "sy2sb_dense_to_band" in stages:  # two-stage solver: the MFMA contraction dominates
+                g = stages["gram"]
+                out["roofline"] = {"bound": "mfma", "kernel": "gemm_nt_big (Gram product)", "achieved": g["achieved"],
+                                   "peak": MFMA_F32_PEAK_TFS, "unit": "TFLOP/s", "frac": g["frac"], "traffic": None,
+                                   "n": n, "K": max(N, M), "launch_ms": g["ms"],
+                                   "algorithmic_flop_per_launch": float(n) * (n + 1) * max(N, M)}
+            else:
+                out["roofline"] = symv_probe(ctx, n)
+            out["roofline"]["stages"] = stages
         if not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(N, M, int(res["n_search"]), args.n_perturb)
+            left = deadline - time.perf_counter()
+            out["cpu_baseline"] = cpu_baseline(N, M, int(res["n_search"]), args.n_perturb, max(20.0, min(90.0, left - 10)))
+        out["bench_wall_s"] = round(time.perf_counter() - T_PROCESS_START, 1)
         print(json.dumps(out), flush=True)
     if world > 1:
         import torch.distributed as dist

@@ -649,30 +649,36 @@ class Session:
 # ----------------------------------------------------------------------------- driver
 def _exchange_ensemble(ses: "Session", shard: Shard, n_perturb: int, min_pc: int, nL_set, ncols):
     """The single gather of the ensemble: all-gather the owned N x min_pc blocks (+ their
-    eigenvalues and column counts) over RCCL; every rank then holds all slots (rank 0 scores them)."""
-    import torch
-
+    eigenvalues and column counts) over RCCL; every rank then holds all slots (rank 0 scores them). The blocks
+    travel between library-owned buffers (`Shard.allgather_dev`)."""
+    ctx = ses.ctx
     ld = ses.slot_ld()
     per = (n_perturb + shard.world - 1) // shard.world
-    dev = shard.device if shard.device is not None else torch.device("cuda", ses.ctx.device)
-    blocks = torch.zeros((per, min_pc, ld), dtype=torch.float32, device=dev)
+    blk = min_pc * ld  # floats per slot
     meta = np.zeros((per, min_pc + 1))
     mine = owned_perturbations(shard.rank, shard.world, n_perturb)
-    for q, t in enumerate(mine):
-        ses.export_slot(t, min_pc, blocks[q].data_ptr())
-        meta[q, 0] = ncols[t]
-        meta[q, 1: 1 + len(nL_set[t])] = nL_set[t]
-    torch.cuda.synchronize()
-    allb = shard.allgather_blocks(blocks)
-    allm = shard.allgather_small(meta)
-    torch.cuda.synchronize()
-    for r in range(shard.world):
-        for q, t in enumerate(owned_perturbations(r, shard.world, n_perturb)):
-            c = int(allm[r, q, 0])
-            ncols[t] = c
-            nL_set[t] = allm[r, q, 1: 1 + c].copy()
-            if r != shard.rank:
-                ses.import_slot(t, min_pc, c, allb[r, q].data_ptr())
+    send = ctx.malloc(4 * per * blk)
+    recv = ctx.malloc(4 * shard.world * per * blk)
+    try:
+        ctx.memset(send, 0, 4 * per * blk)
+        for q, t in enumerate(mine):
+            ses.export_slot(t, min_pc, send + 4 * q * blk)
+            meta[q, 0] = ncols[t]
+            meta[q, 1: 1 + len(nL_set[t])] = nL_set[t]
+        ctx.sync()
+        shard.allgather_dev(ctx, send, recv, per * blk)
+        allm = shard.allgather_small(meta)
+        for r in range(shard.world):
+            for q, t in enumerate(owned_perturbations(r, shard.world, n_perturb)):
+                c = int(allm[r, q, 0])
+                ncols[t] = c
+                nL_set[t] = allm[r, q, 1: 1 + c].copy()
+                if r != shard.rank:
+                    ses.import_slot(t, min_pc, c, recv + 4 * (r * per + q) * blk)
+        ctx.sync()
+    finally:
+        ctx.free(send)
+        ctx.free(recv)
 
 
 def _extract(inp):
@@ -716,7 +722,9 @@ def sclens(inp_df, device_="gpu", th=60, p_step=0.001, n_perturb=20, centering="
     X_, cell_id, gene_id = _extract(inp_df)  # :662
     N, M = X_.shape
     if draws is None:
-        draws = make_draws_native(X_, seed if seed is not None else int(time.time_ns() % (2**31)))
+        if seed is None:  # every rank must draw the same candidates, null matrix and sample seeds: rank 0's clock decides
+            seed = int(shard.bcast_host(np.array([float(time.time_ns() % (2**31))]), 0)[0])
+        draws = make_draws_native(X_, int(seed))
     phase = {}
     t_ph = time.perf_counter()
 

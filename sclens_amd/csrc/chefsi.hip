@@ -190,7 +190,7 @@ int topk_chefsi(Ctx* ctx, const float* A, int64_t n, int64_t lda, int m, int m_s
   // residual targets: the first m_strict pairs (the signals, whose eigenvectors are consumed) 1e-3 * theta; the
   // remaining ones up to m only feed eigenvalues and the matching argmax: 3e-3 * theta (Ritz value error ~ res^2 / gap
   // to the spectrum outside the block, well below the 3e-4 relative tolerance of the parity tests)
-  const double tol_rel = 1e-3, tol_rel_tail = 5e-3;
+  const double tol_rel = 1e-3, tol_rel_tail = 5e-3, tol_gap = 2e-3;
   for (int outer = 0; outer < max_outer; ++outer) {
     // ---- Chebyshev filter of `degree`: damp [0, theta_b], normalise at theta_1
     const double lo = 0.0, cut = std::max(theta[b - 1], 1e-12 * theta[0]);
@@ -286,8 +286,18 @@ int topk_chefsi(Ctx* ctx, const float* A, int64_t n, int64_t lda, int m, int m_s
       for (int q = 0; q < std::min(m, 14); ++q) fprintf(stderr, " %.2e", hres[q] / std::fabs(theta[q]));
       fprintf(stderr, "\n");
     }
+    // eigenvector error ~ residual / gap: the strict pairs (whose vectors are consumed) are also held to tol_gap * gap to
+    // the neighbouring Ritz values, but not below the fp32 floor of the residual itself (~ eps32 * theta_1)
     bool ok = true;
-    for (int q = 0; q < m; ++q) ok = ok && ((double)hres[q] <= (q < m_strict ? tol_rel : tol_rel_tail) * std::fabs(theta[q]));
+    for (int q = 0; q < m; ++q) {
+      double lim = (q < m_strict ? tol_rel : tol_rel_tail) * std::fabs(theta[q]);
+      if (q < m_strict) {
+        double gap = (q + 1 < b) ? theta[q] - theta[q + 1] : std::fabs(theta[q]);
+        if (q > 0) gap = std::min(gap, theta[q - 1] - theta[q]);
+        lim = std::min(lim, std::max(tol_gap * gap, 4e-6 * std::fabs(theta[0])));
+      }
+      ok = ok && ((double)hres[q] <= lim);
+    }
     if (ok && outer >= 1) { *converged = 1; break; }
   }
   SCL_HIP(ctx, hipGetLastError());

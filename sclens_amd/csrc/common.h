@@ -38,6 +38,9 @@ struct Ctx {
   // set from SCLENS_HIP_TWO_STAGE at creation. last_two_stage: which path holds the state eig_vectors continues from.
   int two_stage = 0;
   bool last_two_stage = false;
+  // sessions keep their eigenvector / ensemble buffers in this context's named workspaces ("ses.*", "eig.*"): one live
+  // session per context (worker sessions of session_clone bring their own context)
+  int live_sessions = 0;
   // lock-step batching of tridiagonalisations that run concurrently on several contexts (tridiag.hip); not owned
   struct BatchGroup* batch = nullptr;
 

@@ -296,6 +296,8 @@ struct Session {
 
 int session_create(Ctx* ctx, int64_t N, int64_t M, const int64_t* colptr, const int32_t* rowval, const float* nzval,
                    int64_t ncand, const uint32_t* z1, const uint32_t* z2, Session** out) {
+  if (ctx->live_sessions > 0)
+    return ctx->fail(SCLENS_ERR_STATE, "session_create: this context already has a live session (its workspaces are per context)");
   Session* s = new Session();
   s->ctx = ctx;
   s->N = N; s->M = M;
@@ -314,6 +316,7 @@ int session_create(Ctx* ctx, int64_t N, int64_t M, const int64_t* colptr, const 
   if ((rc = s->dmalloc((void**)&s->Btmp, sizeof(float) * (size_t)s->n * s->ldb)) != SCLENS_OK) return fail(rc);
   if ((rc = s->dmalloc((void**)&s->A, sizeof(float) * (size_t)s->n * s->lda)) != SCLENS_OK) return fail(rc);
   if ((rc = s->dmalloc((void**)&s->w64, sizeof(double) * s->n)) != SCLENS_OK) return fail(rc);
+  s->ctx->live_sessions += 1;
   *out = s;
   return SCLENS_OK;
 }
@@ -347,6 +350,8 @@ int session_create_sharded(Ctx* ctx, int64_t N_global, int64_t row0, int64_t N_l
   if (!fn) return ctx->fail(SCLENS_ERR_ARG, "session_create_sharded: an all-reduce function is required");
   if (N_global <= M) return ctx->fail(SCLENS_ERR_ARG, "session_create_sharded: only the cells > genes layout shards by cells");
   if (N_local <= 0 || row0 < 0 || row0 + N_local > N_global) return ctx->fail(SCLENS_ERR_ARG, "session_create_sharded: bad cell range");
+  if (ctx->live_sessions > 0)
+    return ctx->fail(SCLENS_ERR_STATE, "session_create_sharded: this context already has a live session");
   Session* s = new Session();
   s->ctx = ctx;
   s->N = N_local; s->M = M;
@@ -365,6 +370,7 @@ int session_create_sharded(Ctx* ctx, int64_t N_global, int64_t row0, int64_t N_l
   if ((rc = s->dmalloc((void**)&s->Btmp, sizeof(float) * (size_t)s->n * s->ldb)) != SCLENS_OK) return fail(rc);
   if ((rc = s->dmalloc((void**)&s->A, sizeof(float) * (size_t)s->n * s->lda)) != SCLENS_OK) return fail(rc);
   if ((rc = s->dmalloc((void**)&s->w64, sizeof(double) * s->n)) != SCLENS_OK) return fail(rc);
+  s->ctx->live_sessions += 1;
   *out = s;
   return SCLENS_OK;
 }
@@ -380,6 +386,8 @@ int session_set_reducer(Session* s, sclens_hip_allreduce_fn fn, void* user) {
 // can then run concurrently, the latency-bound column kernels of one decomposition overlapping the bandwidth-bound
 // kernel of the other. The clone must be destroyed before `src`.
 int session_clone(Ctx* ctx2, Session* src, Session** out) {
+  if (ctx2->live_sessions > 0 || ctx2 == src->ctx)
+    return ctx2->fail(SCLENS_ERR_STATE, "session_clone: the worker needs a context of its own without a live session");
   Session* s = new Session();
   s->ctx = ctx2;
   s->N = src->N; s->M = src->M; s->n = src->n; s->K = src->K;
@@ -399,6 +407,7 @@ int session_clone(Ctx* ctx2, Session* src, Session** out) {
   if ((rc = s->dmalloc((void**)&s->Btmp, sizeof(float) * (size_t)s->n * s->ldb)) != SCLENS_OK) return fail(rc);
   if ((rc = s->dmalloc((void**)&s->A, sizeof(float) * (size_t)s->n * s->lda)) != SCLENS_OK) return fail(rc);
   if ((rc = s->dmalloc((void**)&s->w64, sizeof(double) * s->n)) != SCLENS_OK) return fail(rc);
+  s->ctx->live_sessions += 1;
   *out = s;
   return SCLENS_OK;
 }
@@ -406,6 +415,7 @@ int session_clone(Ctx* ctx2, Session* src, Session** out) {
 void session_destroy(Session* s) {
   if (!s) return;
   hipStreamSynchronize(s->ctx->stream);
+  s->ctx->live_sessions -= 1;
   pattern_free(&s->pat);
   for (void* p : s->allocs) hipFree(p);
   delete s;
@@ -610,6 +620,8 @@ int session_binary_basis(Session* s, double* L_bin, int64_t* r_out) {
   if (!v) return SCLENS_ERR_OOM;
   s->Vr2t = v;
   SCL_HIP(ctx, hipMemcpyAsync(v, s->Zt, sizeof(float) * (size_t)r * s->ldz, hipMemcpyDeviceToDevice, ctx->stream));
+  // worker sessions adopt this pointer and read it from their own streams: the copy must have landed on return
+  SCL_HIP(ctx, hipStreamSynchronize(ctx->stream));
   return SCLENS_OK;
 }
 

@@ -26,32 +26,118 @@ def raw_device_tensor(dev_ptr: int, count: int, typestr: str, device):
 
 
 class Shard:
-    """rank/world + the two collectives. `world == 1` needs no torch."""
+    """rank/world + the collectives. `world == 1` needs no torch.
 
-    def __init__(self, rank: int = 0, world: int = 1, device=None, zero_copy: bool = False):
-        """device: the torch device of this rank when the process group is RCCL (`nccl`), None for gloo.
-        zero_copy: hand RCCL a view of the library's own device buffers instead of a torch-allocated staging tensor.
-        Off by default: the PyTorch-ROCm wheel and libsclens_hip.so carry two instances of the HIP runtime, and memory
-        allocated by one is a foreign pointer to the other; device-to-device copies between the two work (measured),
-        RCCL on a foreign buffer across GPUs could not be tested on a one-GPU box, so the collectives only ever see
-        torch-allocated memory (one extra copy each way: 0.3 ms for the 0.4 GB Vr2 broadcast at cfg2)."""
-        self.rank, self.world, self.device, self.zero_copy = rank, world, device, zero_copy
+    Device buffers of the library reach RCCL in one of three ways (`staging`):
+      "host"   (default) library buffer -> host (the library's own copy) -> torch tensor on the device (torch's own copy) ->
+               RCCL -> back the same way. No pointer ever crosses between the two HIP runtime instances of the process
+               (the PyTorch-ROCm wheel bundles its own libamdhip64 next to the system one libsclens_hip.so links), so it is
+               correct by construction; the volumes of this path are small against its wall-clock.
+      "device" a device-to-device copy by the library into a torch-allocated staging tensor (saves the two PCIe hops;
+               the copy uses a pointer of the other runtime instance). Selected by `selfcheck()` when it proves that
+               such copies round-trip bit-exactly on every rank.
+      "zero_copy" RCCL directly on a view of the library's buffer (never selected automatically).
+    """
+
+    def __init__(self, rank: int = 0, world: int = 1, device=None, zero_copy: bool = False, staging: str = "host"):
+        """device: the torch device of this rank when the process group is RCCL (`nccl`), None for gloo."""
+        self.rank, self.world, self.device = rank, world, device
+        self.staging = "zero_copy" if zero_copy else staging
+        self.zero_copy = zero_copy
+
+    def selfcheck(self, ctx) -> dict:
+        """Start-up test of a multi-rank RCCL job: a 4-element all-reduce, and whether library <-> torch device copies
+        round-trip on every rank (then `staging` becomes "device"). Raises if the all-reduce is wrong."""
+        out = {"world": self.world, "staging": self.staging}
+        if self.world == 1 or self.device is None:
+            return out
+        import torch
+        import torch.distributed as dist
+
+        t = torch.arange(4, dtype=torch.float32, device=self.device) + float(self.rank)
+        dist.all_reduce(t)
+        want = self.world * np.arange(4) + self.world * (self.world - 1) / 2.0
+        if not np.array_equal(t.cpu().numpy(), want.astype(np.float32)):
+            raise RuntimeError(f"RCCL self-check failed on rank {self.rank}: all-reduce gave {t.cpu().numpy()} instead of {want}")
+        ok = 1.0
+        try:
+            h = (np.arange(4096, dtype=np.float32) * 0.5 + self.rank).astype(np.float32)
+            buf = ctx.malloc(h.nbytes)
+            try:
+                ctx.h2d(buf, h)
+                tt = torch.zeros(4096, dtype=torch.float32, device=self.device)
+                torch.cuda.synchronize(self.device)
+                ctx.check(ctx.lib.sclens_hip_dev_memcpy(ctx.h, tt.data_ptr(), buf, h.nbytes, 3))
+                if not np.array_equal(tt.cpu().numpy(), h):
+                    ok = 0.0
+                tt.mul_(2.0)
+                torch.cuda.synchronize(self.device)
+                ctx.check(ctx.lib.sclens_hip_dev_memcpy(ctx.h, buf, tt.data_ptr(), h.nbytes, 3))
+                back = np.empty_like(h)
+                ctx.d2h(back, buf)
+                if not np.array_equal(back, 2.0 * h):
+                    ok = 0.0
+            finally:
+                ctx.free(buf)
+        except Exception:
+            ok = 0.0
+        flag = torch.tensor([ok], dtype=torch.float32, device=self.device)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if self.staging == "host" and float(flag.item()) == 1.0:
+            self.staging = "device"
+        out.update({"allreduce": "ok", "cross_runtime_d2d": bool(flag.item() == 1.0), "staging": self.staging})
+        return out
 
     def _dev_tensor(self, ctx, dev_ptr: int, count: int, dtype: int):
         """(tensor RCCL operates on, copy-back function)"""
         import torch
 
-        if self.zero_copy:
-            return raw_device_tensor(dev_ptr, count, "<f8" if dtype == 0 else "<f4", self.device), (lambda: None)
-        t = torch.empty(int(count), dtype=torch.float64 if dtype == 0 else torch.float32, device=self.device)
+        tdt, ndt = (torch.float64, np.float64) if dtype == 0 else (torch.float32, np.float32)
         nbytes = int(count) * (8 if dtype == 0 else 4)
-        ctx.check(ctx.lib.sclens_hip_dev_memcpy(ctx.h, t.data_ptr(), dev_ptr, nbytes, 3))  # synchronous on the library's stream
+        if self.staging == "zero_copy":
+            return raw_device_tensor(dev_ptr, count, "<f8" if dtype == 0 else "<f4", self.device), (lambda: None)
+        if self.staging == "device":
+            t = torch.empty(int(count), dtype=tdt, device=self.device)
+            ctx.check(ctx.lib.sclens_hip_dev_memcpy(ctx.h, t.data_ptr(), dev_ptr, nbytes, 3))  # synchronous on the library's stream
 
-        def back():
-            torch.cuda.synchronize(self.device)
-            ctx.check(ctx.lib.sclens_hip_dev_memcpy(ctx.h, dev_ptr, t.data_ptr(), nbytes, 3))
+            def back():
+                torch.cuda.synchronize(self.device)
+                ctx.check(ctx.lib.sclens_hip_dev_memcpy(ctx.h, dev_ptr, t.data_ptr(), nbytes, 3))
 
-        return t, back
+            return t, back
+        h = np.empty(int(count), dtype=ndt)
+        ctx.d2h(h, dev_ptr)
+        t = torch.from_numpy(h).to(self.device)
+
+        def back_host():
+            ctx.h2d(dev_ptr, t.cpu().numpy())
+
+        return t, back_host
+
+    # -- equally sized blocks of library device memory: every rank contributes `count` floats, receives world * count
+    def allgather_dev(self, ctx, send_ptr: int, recv_ptr: int, count_f32: int):
+        """recv[r * count : (r + 1) * count] = rank r's send buffer (both are library allocations on this rank's GPU)"""
+        if self.world == 1:
+            ctx.check(ctx.lib.sclens_hip_dev_memcpy(ctx.h, recv_ptr, send_ptr, 4 * int(count_f32), 3))
+            return
+        import torch
+        import torch.distributed as dist
+
+        if self.device is None:  # gloo (tests): through host memory
+            h = np.empty(int(count_f32), dtype=np.float32)
+            ctx.d2h(h, send_ptr)
+            outs = [torch.empty(int(count_f32), dtype=torch.float32) for _ in range(self.world)]
+            dist.all_gather(outs, torch.from_numpy(h))
+            ctx.h2d(recv_ptr, torch.cat(outs).numpy())
+            return
+        t, _ = self._dev_tensor(ctx, send_ptr, count_f32, 1)
+        out = torch.empty(self.world * int(count_f32), dtype=torch.float32, device=self.device)
+        dist.all_gather_into_tensor(out, t)
+        torch.cuda.synchronize(self.device)
+        if self.staging == "host":
+            ctx.h2d(recv_ptr, out.cpu().numpy())
+        else:
+            ctx.check(ctx.lib.sclens_hip_dev_memcpy(ctx.h, recv_ptr, out.data_ptr(), 4 * self.world * int(count_f32), 3))
 
     # -- small host arrays (search statistics): fixed-shape float64 all-gather
     def allgather_small(self, arr: np.ndarray) -> np.ndarray:
@@ -167,14 +253,23 @@ def owned_perturbations(rank: int, world: int, n_perturb: int) -> List[int]:
     return [t for t in range(n_perturb) if owner_of_perturbation(t, world) == rank]
 
 
-def search_schedule(p_step: float, max_iters: int = 200) -> List[float]:
-    """p_ of iteration it, produced by the same repeated `p_ -= p_step` as the reference (Appendix A21)."""
-    p = 0.999
-    out = []
-    for _ in range(max_iters):
-        out.append(p)
-        p -= p_step
-    return out
+class SearchSchedule:
+    """p_ of iteration `it`, produced by the same repeated `p_ -= p_step` as the reference (Appendix A21), extended
+    on demand: the loop runs until p_ < 0.9 for ANY p_step (about 0.099 / p_step iterations) and a speculative round may
+    look `world x streams` iterations past the stop."""
+
+    def __init__(self, p_step: float):
+        self.p_step = float(p_step)
+        self._p = [0.999]
+
+    def __getitem__(self, it: int) -> float:
+        while len(self._p) <= it:
+            self._p.append(self._p[-1] - self.p_step)
+        return self._p[it]
+
+
+def search_schedule(p_step: float) -> SearchSchedule:
+    return SearchSchedule(p_step)
 
 
 def consume_search_round(tank: np.ndarray, results: Sequence[np.ndarray], p_list: Sequence[float], it0: int,

@@ -95,6 +95,11 @@ class ThreadShard:
         if self.rank != src:
             ctx.h2d(dev_ptr, got)
 
+    def allgather_dev(self, ctx, send_ptr, recv_ptr, count_f32):
+        h = np.empty(int(count_f32), dtype=np.float32)
+        ctx.d2h(h, send_ptr)
+        ctx.h2d(recv_ptr, np.concatenate(self._exchange(h)))
+
     def allgather_blocks(self, local):
         import torch
 

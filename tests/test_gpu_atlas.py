@@ -136,14 +136,39 @@ def test_rccl_branch_on_a_one_rank_group(ctx):
     if created:
         dist.init_process_group(backend="nccl", rank=0, world_size=1, device_id=dev)
     try:
-        for zero_copy in (False, True):  # staging tensor (default) and the view of the library's own buffer
-            sh = Shard(0, 1, dev, zero_copy=zero_copy)
+        for mode in ("host", "device", "zero_copy"):  # host-staged (default), torch staging tensor, view of the library's buffer
+            sh = Shard(0, 1, dev, zero_copy=(mode == "zero_copy"), staging=mode)
+            assert sh.staging == mode
             sh.allreduce_dev(ctx, d64.p, x64.size, 0, _force=True)  # sum over one rank: unchanged, but through RCCL
             sh.allreduce_dev(ctx, d32.p, x32.size, 1, _force=True)
             sh.bcast_dev(ctx, d32.p, x32.size, 0, _force=True)
             assert np.array_equal(d64.get(x64.shape, np.float64), x64)
             assert np.array_equal(d32.get(x32.shape, np.float32), 2 * x32)
+        # the start-up check of a multi-rank job (here: a group of one, world forced to 2 ranks' worth of logic)
+        sh = Shard(0, 1, dev)
+        sh.world = 2  # run the checks; the all-reduce over the real one-rank group returns the input
+        try:
+            sh.selfcheck(ctx)
+        except RuntimeError as e:  # expected: the sum over ONE rank is not the two-rank value
+            assert "all-reduce gave" in str(e)
         sh.world = 1
+        # allgather_dev through RCCL in a one-rank group, every staging mode
+        for mode in ("host", "device"):
+            sh = Shard(0, 1, dev, staging=mode)
+            sh.world = 1
+            recv = DevArray(ctx, nbytes=4 * x32.size)
+            sh.world = 2  # take the collective branch; the group still has one rank, so only the first block is written
+            try:
+                import torch.distributed as _d
+
+                t_, _ = sh._dev_tensor(ctx, d32.p, x32.size, 1)
+                out_ = torch.empty(x32.size, dtype=torch.float32, device=dev)
+                _d.all_gather_into_tensor(out_, t_)
+                torch.cuda.synchronize()
+                assert np.array_equal(out_.cpu().numpy(), 2 * x32)
+            finally:
+                sh.world = 1
+            recv.free()
         blocks = torch.arange(24, dtype=torch.float32, device=dev).reshape(2, 3, 4)
         out = torch.empty((1,) + tuple(blocks.shape), dtype=blocks.dtype, device=dev)
         dist.all_gather_into_tensor(out.view(-1), blocks.contiguous().view(-1))  # what allgather_blocks issues

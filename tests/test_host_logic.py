@@ -172,3 +172,27 @@ def test_row_blocks_partition_the_cells():
         assert all(blocks[r][1] == blocks[r + 1][0] for r in range(world - 1))
         sizes = [b - a for a, b in blocks]
         assert max(sizes) - min(sizes) <= 1 and min(sizes) >= 1
+
+
+def test_search_schedule_is_unbounded_and_matches_repeated_subtraction():
+    """the schedule must not run out for small p_step or for speculative look-ahead (world x streams)."""
+    for p_step in (0.001, 0.0002):
+        sched = search_schedule(p_step)
+        p, ref = 0.999, []
+        for _ in range(700):
+            ref.append(p)
+            p -= p_step
+        assert [sched[i] for i in range(700)] == ref  # bitwise the reference's accumulation (Appendix A21)
+        assert sched[5] == ref[5]
+    # a full serial search with p_step = 0.0002 that only stops on p_ < 0.9 needs ~496 iterations
+    p_step, p_th = 0.0002, 0.0
+    d_list = [np.full(5, 0.5)] * 600
+    p_ref, it_ref = _serial_search(d_list, p_th, p_step)
+    sched = search_schedule(p_step)
+    tank, it, p_ = np.zeros((5, 0)), 0, None
+    while p_ is None:
+        tank, used, stopped, p_fin = consume_search_round(tank, [d_list[it + r] for r in range(6)], sched, it, p_th, p_step)
+        it += used
+        if stopped:
+            p_ = p_fin
+    assert (p_, it) == (p_ref, it_ref) and it_ref > 450
