@@ -402,8 +402,12 @@ int gemm_f32(Ctx* ctx, const GemmArgs& a) {
     return ctx->fail(SCLENS_ERR_ARG, "gemm_f32: bad split-K arguments");
   const int64_t bm = (a.M + GB - 1) / GB, bn = (a.N + GB - 1) / GB;
   // the large-tile kernel needs enough tiles for the 256 CUs (one workgroup each)
-  if (a.q_kcontig && vec && a.K >= GK && (a.lower ? bm * (bm + 1) / 2 : bm * bn) * (a.splits > 1 ? a.splits : 1) >= 200 &&
-      (a.splits <= 1 || a.k_chunk % GK == 0) && !getenv("SCLENS_HIP_GEMM_SMALL")) {
+  // (measured at n = 10^4, 820 tiles, three concurrent decompositions: the 128x128 kernel, which shares a CU with the kernels
+  // of the other streams, is as fast alone and 4 % faster in the mix; at n = 3 * 10^4 the large tiles are 11 % faster)
+  const bool force_big = getenv("SCLENS_HIP_GEMM_BIG") != nullptr;  // tests: the large-tile kernel on small shapes
+  const bool want_big = a.K >= 256 && (a.lower ? bm * (bm + 1) / 2 : bm * bn) * (a.splits > 1 ? a.splits : 1) >= 1500;
+  if (a.q_kcontig && vec && a.K >= GK && (want_big || force_big) && (a.splits <= 1 || a.k_chunk % GK == 0) &&
+      !getenv("SCLENS_HIP_GEMM_SMALL")) {
     const int2* tiles = nullptr;
     int64_t nb = 0;
     SCL_TRY(big_tile_list(ctx, bm, bn, a.lower, &tiles, &nb));

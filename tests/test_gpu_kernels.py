@@ -27,7 +27,8 @@ def _gemm(ctx, P, Q, C0, alpha, beta, q_kcontig, lower=0, absmax=False):
 
 @pytest.mark.parametrize("M,N,K", [(128, 128, 16), (130, 257, 33), (64, 300, 1000), (1000, 77, 515), (5, 5, 3),
                                    (300, 520, 1000), (512, 256, 64), (700, 161, 37), (161, 769, 4100)])
-def test_gemm_nt_nn(ctx, M, N, K):
+def test_gemm_nt_nn(ctx, M, N, K, monkeypatch):
+    monkeypatch.setenv("SCLENS_HIP_GEMM_BIG", "1")  # NT shapes that fit go through the 256x256 kernel as well
     rng = np.random.default_rng(M * 7 + N)
     P = rng.standard_normal((M, K)).astype(np.float32)
     Qn = rng.standard_normal((N, K)).astype(np.float32)
@@ -48,8 +49,11 @@ def test_gemm_asymmetric_identity(ctx):
     assert np.array_equal(out, B)
 
 
+@pytest.mark.parametrize("big", [0, 1])
 @pytest.mark.parametrize("n,K", [(200, 64), (333, 257), (1300, 100), (520, 16)])
-def test_gemm_lower_mirror_and_absmax(ctx, n, K):
+def test_gemm_lower_mirror_and_absmax(ctx, n, K, big, monkeypatch):
+    if big:
+        monkeypatch.setenv("SCLENS_HIP_GEMM_BIG", "1")
     rng = np.random.default_rng(n)
     P = rng.standard_normal((n, K)).astype(np.float32)
     Q = rng.standard_normal((n, K)).astype(np.float32)
