@@ -820,156 +820,221 @@ __global__ __launch_bounds__(64) void sbr_q2_build_t(const float* __restrict__ V
   for (int idx = l; idx < QW * QW; idx += 64) out[idx] = T[idx / QW][idx % QW];
 }
 
-// apply: one workgroup (4 waves) per tile of QV = 32 vectors. Per group: the 64 window rows that the previous group of the
-// block did not touch, the group's reflectors and its T are fetched into registers while the previous group is still being
-// applied (they do not depend on it); the 32 rows shared with the previous group are carried over in LDS.
-constexpr int QV = 32;
-struct SbrQ2Pref {
-  float z[8], v[12], t[4];
+// apply: one wave per tile of 16 vectors, 4 waves per workgroup, `v_mfma_f32_16x16x4_f32`. The window of the vector tile lives in
+// REGISTERS in the MFMA result layout (lane = vector + 16 * row quad, register = row inside the quad), which is also the
+// B-operand layout of the next product, so a group costs three chained MFMA products and no LDS traffic for Z at all:
+//   W' = Vg' Zw'   (32 x 16)      A = Vg' from LDS ([reflector][row], 16-byte reads), B = the window registers
+//   U' = Tg W'     (32 x 16)      A = Tg from LDS, B = W' registers
+//   Zw' -= Vg U'   (96 x 16)      A = Vg from the same LDS image (4-byte reads), B = -U' registers, C = the window
+// Only the 16 x 16 tile pairs that meet the parallelogram are multiplied (40 + 12 + 40 MFMAs per group instead of 48 + 16 + 48).
+// QJ consecutive sweep blocks are applied in one pass over Z (wavefront order: k ascending, inside a k the blocks descending;
+// groups of different blocks at the same k overlap by 32 rows, groups at different k of that order are disjoint), so Z is
+// streamed n / (32 QJ) times instead of n / 32 times: the union window of a step is 96 + 32 (QJ - 1) rows = QNT register
+// tiles, 64 rows leave and 64 enter per step. The group data (reflectors + T) is staged through a double-buffered LDS image
+// shared by the four waves, fetched one group ahead.
+// Z is addressed as Zq[v * ldq + 3 + row]: every window starts at a row = 1 (mod 4), so the 4-row register quads are
+// 16-byte aligned in this shifted layout.
+constexpr int QJ = 4;
+constexpr int QNT = 6 + 2 * (QJ - 1);
+constexpr int Q_RS = 100;  // floats per reflector in the LDS image: b128 reads 2-way, b32 reads conflict-free
+constexpr int Q_RT = 40;   // floats per row of Tg: conflict-free b128 reads
+constexpr int Q_BUF = QW * Q_RS + QW * Q_RT;
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+struct SbrQ2Args {
+  const float* V2;
+  int64_t ldv2;
+  const float* Tg;
+  int nk, nblk;
+  int64_t n;
+  float* Zq;
+  int64_t m, ldq;
 };
-__device__ __forceinline__ void sbr_q2_fetch(SbrQ2Pref& p, const float* __restrict__ V2, int64_t ldv2, const float* __restrict__ Tg,
-                                             int nk, int64_t n, const float* __restrict__ Zt, int64_t m, int64_t ldz, int64_t v0,
-                                             int blk, int k, bool first, int tid) {
-  const int64_t S = (int64_t)blk * QW, R0 = S + 1 + (int64_t)k * SB;
-  // Z rows: window rows 32..95 (all 96 when `first`): thread -> (vector = tid / 8, 8 consecutive... ) use row-fastest mapping
-  // 32 vectors x 64 rows = 2048 values, 8 per thread: value q -> idx = tid + 256 q, v = idx >> 6, r = 32 + (idx & 63)
+
+struct SbrQ2Fetch {
+  float v[8], t[4];
+};
+
+__device__ __forceinline__ void sbr_q2_fetch16(SbrQ2Fetch& f, const SbrQ2Args& a, int b, int t, int tid) {
+  const int64_t S = (int64_t)b * QW;
 #pragma unroll
   for (int q = 0; q < 8; ++q) {
-    const int idx = tid + 256 * q, v = idx >> 6, r = 32 + (idx & 63);
-    const int64_t row = R0 + r;
-    p.z[q] = (v0 + v < m && row < n) ? Zt[(v0 + v) * ldz + row] : 0.f;
+    const int idx = tid + 256 * q, c = idx >> 6, rr = idx & 63;
+    const int64_t s = S + c, rk = s + 1 + (int64_t)t * SB;
+    const bool have = (b >= 0) && (s + 2 < a.n) && (rk + rr < a.n);
+    f.v[q] = have ? a.V2[s * a.ldv2 + rk + rr] : 0.f;
   }
-  // group: element idx = tid + 256 q -> column c = idx / QH (a sweep), window row r = idx % QH: coalesced along a reflector
+  const bool tv = (b >= 0) && (t < a.nk);
+  const float* tg = a.Tg + ((int64_t)(tv ? b : 0) * a.nk + (tv ? t : 0)) * QW * QW;
 #pragma unroll
-  for (int q = 0; q < 12; ++q) {
-    const int idx = tid + 256 * q, c = idx / QH, r = idx % QH;
-    const int64_t s = S + c, rk = s + 1 + (int64_t)k * SB;
-    const bool have = (s + 2 < n) && (rk < n);
-    const int64_t L = have ? ((n - rk < SB) ? n - rk : SB) : 0;
-    const int rr = r - c;
-    p.v[q] = (rr >= 0 && rr < L) ? V2[s * ldv2 + rk + rr] : 0.f;
-  }
-  const float* tg = Tg + ((int64_t)blk * nk + k) * QW * QW;
-#pragma unroll
-  for (int q = 0; q < 4; ++q) p.t[q] = tg[tid + 256 * q];
-  (void)first;
+  for (int q = 0; q < 4; ++q) f.t[q] = tv ? tg[tid + 256 * q] : 0.f;
 }
 
-__global__ __launch_bounds__(256) void sbr_q2_apply(const float* __restrict__ V2, int64_t ldv2, const float* __restrict__ Tg, int nk,
-                                                    int64_t n, float* __restrict__ Zt, int64_t m, int64_t ldz) {
-  __shared__ float Zw[QV][QH + 1];       // the window of the vector tile
-  __shared__ float Vg[QH][QW + 1];
-  __shared__ float Ts[QW][QW + 1];
-  __shared__ float Wp[4][QV][QW + 1];    // K-split partials of zw Vg
-  __shared__ float Wq[3][QV][QW + 1];    // W2, one private copy per wave that needs it as an MFMA operand
-  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, l31 = lane & 31, h = lane >> 5;
-  const int64_t v0 = (int64_t)blockIdx.x * QV;
-  const int64_t nsweep = n - 2;
-  const int nblk = (int)((nsweep + QW - 1) / QW);
-  SbrQ2Pref pf;
-  // flat sequence of groups: blocks descending, k ascending
-  int blk = nblk - 1, k = 0;
-  int K = sbr_tasks_of((int64_t)blk * QW, n);
-  sbr_q2_fetch(pf, V2, ldv2, Tg, nk, n, Zt, m, ldz, v0, blk, k, true, tid);
-  while (blk >= 0) {
-    const int64_t S = (int64_t)blk * QW, R0 = S + 1 + (int64_t)k * SB;
-    // ---- stage 0: registers -> LDS; the first group of a block also loads the window rows 0..31
-    if (k == 0) {
-      for (int idx = tid; idx < QV * 32; idx += 256) {
-        const int v = idx >> 5, r = idx & 31;
-        const int64_t row = R0 + r;
-        Zw[v][r] = (v0 + v < m && row < n) ? Zt[(v0 + v) * ldz + row] : 0.f;
-      }
-    }
+__device__ __forceinline__ void sbr_q2_stash16(const SbrQ2Fetch& f, float* buf, int tid) {
 #pragma unroll
-    for (int q = 0; q < 8; ++q) {
-      const int idx = tid + 256 * q;
-      Zw[idx >> 6][32 + (idx & 63)] = pf.z[q];
-    }
-#pragma unroll
-    for (int q = 0; q < 12; ++q) {
-      const int idx = tid + 256 * q;
-      Vg[idx % QH][idx / QH] = pf.v[q];
-    }
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const int idx = tid + 256 * q;
-      Ts[idx >> 5][idx & 31] = pf.t[q];
-    }
-    __syncthreads();
-    // next group in the sequence; its independent data is fetched now and lands in LDS after this group is done
-    int nblk2 = blk, nk2 = k + 1, K2 = K;
-    if (nk2 >= K) {
-      nblk2 = blk - 1;
-      nk2 = 0;
-      K2 = (nblk2 >= 0) ? sbr_tasks_of((int64_t)nblk2 * QW, n) : 0;
-    }
-    // (the first group of the next block overlaps this group's rows when this group is itself a first group: fetch later)
-    const bool early = nblk2 >= 0 && !(nk2 == 0 && k == 0);
-    if (early) sbr_q2_fetch(pf, V2, ldv2, Tg, nk, n, Zt, m, ldz, v0, nblk2, nk2, nk2 == 0, tid);
-    // ---- stage 1: W = Zw Vg (32 x 96 times 96 x 32), K split over the four waves (24 each)
-    {
-      f32x16 acc;
-#pragma unroll
-      for (int e = 0; e < 16; ++e) acc[e] = 0.f;
-      const int kb = wv * (QH / 4);
-#pragma unroll
-      for (int kk = 0; kk < QH / 4; kk += 2) {
-        const float a = Zw[l31][kb + kk + h];
-        const float b = Vg[kb + kk + h][l31];
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
-      }
-#pragma unroll
-      for (int e = 0; e < 16; ++e) Wp[wv][(e & 3) + 8 * (e >> 2) + 4 * h][l31] = acc[e];
-    }
-    __syncthreads();
-    // ---- stages 2 + 3 per wave (waves 0..2): W2 = (sum of the partials) Tg', then one 32-column tile of Zw -= W2 Vg'
-    if (wv < 3) {
-      f32x16 acc;
-#pragma unroll
-      for (int e = 0; e < 16; ++e) acc[e] = 0.f;
-#pragma unroll
-      for (int kk = 0; kk < QW; kk += 2) {
-        const float a = (Wp[0][l31][kk + h] + Wp[1][l31][kk + h]) + (Wp[2][l31][kk + h] + Wp[3][l31][kk + h]);
-        const float b = Ts[l31][kk + h];  // (Tg')[k][col] = Tg[col][k]
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
-      }
-#pragma unroll
-      for (int e = 0; e < 16; ++e) Wq[wv][(e & 3) + 8 * (e >> 2) + 4 * h][l31] = acc[e];
-      // wave-private round trip through LDS: D layout -> A operand layout
-      __builtin_amdgcn_wave_barrier();
-#pragma unroll
-      for (int e = 0; e < 16; ++e) acc[e] = 0.f;
-#pragma unroll
-      for (int kk = 0; kk < QW; kk += 2) {
-        const float a = Wq[wv][l31][kk + h];
-        const float b = Vg[32 * wv + l31][kk + h];  // (Vg')[k][col] = Vg[col][k]
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
-      }
-      const int col = 32 * wv + l31;
-      const int64_t row = R0 + col;
-#pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        const int v = (e & 3) + 8 * (e >> 2) + 4 * h;
-        const float out = Zw[v][col] - acc[e];
-        if (v0 + v < m && row < n) Zt[(v0 + v) * ldz + row] = out;
-        if (wv == 2) acc[e] = out;  // rows 64..95 are the rows 0..31 of the next group of this block
-      }
-      if (wv == 2) {
-        // stash for the carry-over; copied into Zw[:, 0..31] after the barrier
-#pragma unroll
-        for (int e = 0; e < 16; ++e) Wq[2][(e & 3) + 8 * (e >> 2) + 4 * h][l31] = acc[e];
-      }
-    }
-    __syncthreads();
-    if (nk2 != 0) {  // carry-over inside the block
-      for (int idx = tid; idx < QV * 32; idx += 256) Zw[idx >> 5][idx & 31] = Wq[2][idx >> 5][idx & 31];
-    }
-    if (nblk2 >= 0 && !early) sbr_q2_fetch(pf, V2, ldv2, Tg, nk, n, Zt, m, ldz, v0, nblk2, nk2, true, tid);
-    blk = nblk2;
-    k = nk2;
-    K = K2;
+  for (int q = 0; q < 8; ++q) {
+    const int idx = tid + 256 * q, c = idx >> 6, rr = idx & 63;
+    buf[c * Q_RS + c + rr] = f.v[q];
   }
+  float* T = buf + QW * Q_RS;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int idx = tid + 256 * q;
+    T[(idx >> 5) * Q_RT + (idx & 31)] = f.t[q];
+  }
+}
+
+// one group applied to the six window tiles z[0..5] (rows 0..95 of the group's window)
+__device__ __forceinline__ void sbr_q2_group16(f32x4* z, const float* buf, int vi, int g) {
+  const float* VgT = buf;
+  const float* T = buf + QW * Q_RS;
+  f32x4 w0 = {0.f, 0.f, 0.f, 0.f}, w1 = {0.f, 0.f, 0.f, 0.f};
+  // W' = Vg' Zw': reflector tile 0 meets row tiles 0..4, reflector tile 1 row tiles 1..5
+#pragma unroll
+  for (int rt = 0; rt < 5; ++rt) {
+    const f32x4 a0 = *reinterpret_cast<const f32x4*>(VgT + vi * Q_RS + 16 * rt + 4 * g);
+    const f32x4 a1 = *reinterpret_cast<const f32x4*>(VgT + (16 + vi) * Q_RS + 16 * (rt + 1) + 4 * g);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      w0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[e], z[rt][e], w0, 0, 0, 0);
+      w1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[e], z[rt + 1][e], w1, 0, 0, 0);
+    }
+  }
+  __builtin_amdgcn_sched_barrier(0);  // keep the operand reads of the three products apart (register pressure)
+  // U' = Tg W' (Tg upper triangular: tile (1,0) is zero)
+  f32x4 u0 = {0.f, 0.f, 0.f, 0.f}, u1 = {0.f, 0.f, 0.f, 0.f};
+  {
+    const f32x4 t00 = *reinterpret_cast<const f32x4*>(T + vi * Q_RT + 4 * g);
+    const f32x4 t01 = *reinterpret_cast<const f32x4*>(T + vi * Q_RT + 16 + 4 * g);
+    const f32x4 t11 = *reinterpret_cast<const f32x4*>(T + (16 + vi) * Q_RT + 16 + 4 * g);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      u0 = __builtin_amdgcn_mfma_f32_16x16x4f32(t00[e], w0[e], u0, 0, 0, 0);
+      u1 = __builtin_amdgcn_mfma_f32_16x16x4f32(t11[e], w1[e], u1, 0, 0, 0);
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) u0 = __builtin_amdgcn_mfma_f32_16x16x4f32(t01[e], w1[e], u0, 0, 0, 0);
+  }
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    u0[e] = -u0[e];
+    u1[e] = -u1[e];
+  }
+  __builtin_amdgcn_sched_barrier(0);
+  // Zw' -= Vg U': A[row][reflector 4 g + e] from the [reflector][row] image
+#pragma unroll
+  for (int rt = 0; rt < 6; ++rt) {
+    if (rt < 5) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        z[rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(VgT[(4 * g + e) * Q_RS + 16 * rt + vi], u0[e], z[rt], 0, 0, 0);
+    }
+    if (rt > 0) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        z[rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(VgT[(16 + 4 * g + e) * Q_RS + 16 * rt + vi], u1[e], z[rt], 0, 0, 0);
+    }
+    if (rt & 1) __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
+__device__ __forceinline__ f32x4 sbr_q2_ldz(const float* zrow, int64_t row, int64_t n, bool live) {
+  f32x4 v = {0.f, 0.f, 0.f, 0.f};
+  if (live && row >= -3 && row < n) {
+    if (row + 3 < n) {
+      v = *reinterpret_cast<const f32x4*>(zrow + row);
+    } else {
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        if (row + e < n) v[e] = zrow[row + e];
+    }
+  }
+  return v;
+}
+__device__ __forceinline__ void sbr_q2_stz(float* zrow, int64_t row, int64_t n, bool live, f32x4 v) {
+  if (live && row >= -3 && row < n) {
+    if (row + 3 < n) {
+      *reinterpret_cast<f32x4*>(zrow + row) = v;
+    } else {
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        if (row + e < n) zrow[row + e] = v[e];
+    }
+  }
+}
+
+__global__ __launch_bounds__(256, 1) void sbr_q2_apply16(SbrQ2Args a) {
+  __shared__ __attribute__((aligned(16))) float lds[2 * Q_BUF];
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, vi = lane & 15, g = lane >> 4;
+  const int64_t v = (int64_t)blockIdx.x * 64 + wv * 16 + vi;
+  const bool live = v < a.m;
+  float* zrow = a.Zq + (live ? v : 0) * a.ldq + 3;
+  for (int i = tid; i < 2 * Q_BUF; i += 256) lds[i] = 0.f;  // outside the parallelogram the images stay zero
+  __syncthreads();
+  const int nsb = (a.nblk + QJ - 1) / QJ;
+  SbrQ2Fetch pf;
+  sbr_q2_fetch16(pf, a, a.nblk - 1, 0, tid);
+  sbr_q2_stash16(pf, lds, tid);
+  __syncthreads();
+  int cur = 0;
+  f32x4 z[QNT];
+  for (int sb = 0; sb < nsb; ++sb) {
+    const int bh = a.nblk - 1 - sb * QJ, blow = bh - QJ + 1;
+    const int Kmax = sbr_tasks_of((int64_t)(blow > 0 ? blow : 0) * QW, a.n);
+    const int64_t base0 = (int64_t)blow * QW + 1;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the stores of the previous pass have left before rows are re-read
+#pragma unroll
+    for (int i = 0; i < QNT; ++i) z[i] = sbr_q2_ldz(zrow, base0 + 16 * i + 4 * g, a.n, live);
+    for (int t = 0; t < Kmax; ++t) {
+      const int64_t base = base0 + (int64_t)t * SB;
+      f32x4 pz[4];
+      const bool more = t + 1 < Kmax;
+      if (more) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) pz[i] = sbr_q2_ldz(zrow, base + 16 * (QNT + i) + 4 * g, a.n, live);
+      }
+#pragma unroll
+      for (int j = 0; j < QJ; ++j) {
+        // the group after this one in the sequence
+        int nb, nt;
+        if (j + 1 < QJ) {
+          nb = bh - (j + 1);
+          nt = t;
+        } else if (more) {
+          nb = bh;
+          nt = t + 1;
+        } else {
+          nb = bh - QJ;
+          nt = 0;
+        }
+        sbr_q2_fetch16(pf, a, nb, nt, tid);
+        const int b = bh - j;
+        if (b >= 0 && t < sbr_tasks_of((int64_t)b * QW, a.n)) sbr_q2_group16(z + 2 * (QJ - 1 - j), lds + cur * Q_BUF, vi, g);
+        sbr_q2_stash16(pf, lds + (cur ^ 1) * Q_BUF, tid);
+        __syncthreads();
+        cur ^= 1;
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) sbr_q2_stz(zrow, base + 16 * i + 4 * g, a.n, live, z[i]);
+      if (more) {
+#pragma unroll
+        for (int i = 0; i + 4 < QNT; ++i) z[i] = z[i + 4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) z[QNT - 4 + i] = pz[i];
+      } else {
+#pragma unroll
+        for (int i = 4; i < QNT; ++i) sbr_q2_stz(zrow, base + 16 * i + 4 * g, a.n, live, z[i]);
+      }
+    }
+  }
+}
+
+// Zq[v][3 + r] <-> Zt[v][r]
+__global__ void sbr_q2_shift(const float* __restrict__ in, int64_t ldi, int64_t offi, float* __restrict__ out, int64_t ldo,
+                             int64_t offo, int64_t n) {
+  const int64_t r = blockIdx.y;
+  const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (c < n) out[r * ldo + offo + c] = in[r * ldi + offi + c];
 }
 
 int sbr_apply_q2(Ctx* ctx, int64_t n, float* Zt, int64_t m, int64_t ldz) {
@@ -996,7 +1061,21 @@ int sbr_apply_q2(Ctx* ctx, int64_t n, float* Zt, int64_t m, int64_t ldz) {
   const int nblk = (int)((nsweep + QW - 1) / QW), nk = (int)((n - 1 + SB - 1) / SB);
   SCL_WS(ctx, Tg, float, "sbr.Tg", (int64_t)nblk * nk * QW * QW);
   hipLaunchKernelGGL(sbr_q2_build_t, dim3((unsigned)nk, (unsigned)nblk), dim3(64), 0, ctx->stream, V2, ldv2, TAU2, ldt, n, nk, Tg);
-  hipLaunchKernelGGL(sbr_q2_apply, dim3((unsigned)((m + QV - 1) / QV)), dim3(256), 0, ctx->stream, V2, ldv2, Tg, nk, n, Zt, m, ldz);
+  // the apply kernel works on the shifted layout Zq[v][3 + row] (16-byte aligned register quads, see above)
+  const int64_t ldq = round_up(n + 3, 4);
+  SCL_WS(ctx, Zq, float, "sbr.Zq", m * ldq);
+  for (int64_t r0 = 0; r0 < m; r0 += 65535) {
+    const int64_t rows = (m - r0 < 65535) ? m - r0 : 65535;
+    hipLaunchKernelGGL(sbr_q2_shift, dim3((unsigned)((n + 255) / 256), (unsigned)rows), dim3(256), 0, ctx->stream, Zt + r0 * ldz, ldz,
+                       (int64_t)0, Zq + r0 * ldq, ldq, (int64_t)3, n);
+  }
+  SbrQ2Args qa{V2, ldv2, Tg, nk, nblk, n, Zq, m, ldq};
+  hipLaunchKernelGGL(sbr_q2_apply16, dim3((unsigned)((m + 63) / 64)), dim3(256), 0, ctx->stream, qa);
+  for (int64_t r0 = 0; r0 < m; r0 += 65535) {
+    const int64_t rows = (m - r0 < 65535) ? m - r0 : 65535;
+    hipLaunchKernelGGL(sbr_q2_shift, dim3((unsigned)((n + 255) / 256), (unsigned)rows), dim3(256), 0, ctx->stream, Zq + r0 * ldq, ldq,
+                       (int64_t)3, Zt + r0 * ldz, ldz, (int64_t)0, n);
+  }
   SCL_HIP(ctx, hipGetLastError());
   return SCLENS_OK;
 }

@@ -9,6 +9,9 @@ from devutil import DevArray, rup
 n = int(sys.argv[1]); K = int(sys.argv[2]) if len(sys.argv) > 2 else 2 * n
 mvec = int(sys.argv[3]) if len(sys.argv) > 3 else n
 ctx = Context(0)
+if os.environ.get("TWO_STAGE"):
+    ctx.set_option("two_stage", 1)
+lo_first = bool(os.environ.get("LOW_HALF"))
 rng = np.random.default_rng(0)
 B = rng.standard_normal((n, K)).astype(np.float32)
 B -= B.mean(axis=0, keepdims=True)
@@ -21,7 +24,7 @@ for rep in range(2):
     ctx.reset_timing()
     t0 = time.perf_counter()
     ctx.check(ctx.lib.sclens_hip_dev_gram_f32(ctx.h, dB.p, n, K, ldb, float(K), dA.p, lda))
-    ctx.check(ctx.lib.sclens_hip_dev_eigh_f32(ctx.h, dA.p, n, lda, dw.p, n - mvec, n, dZ.p, lda))
+    ctx.check(ctx.lib.sclens_hip_dev_eigh_f32(ctx.h, dA.p, n, lda, dw.p, 0 if lo_first else n - mvec, mvec if lo_first else n, dZ.p, lda))
     ctx.sync()
     wall = time.perf_counter() - t0
     out = {s: ctx.timing(s) for s in ("gram", "sytrd", "sy2sb", "sb2st", "stebz", "stein", "ormtr", "sbr_q2", "sbr_q1")}

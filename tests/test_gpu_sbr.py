@@ -165,7 +165,8 @@ def test_two_stage_eigenvectors(ctx, n, m):
     assert np.abs(Z @ Z.T - np.eye(m)).max() < 2e-4
 
 
-@pytest.mark.parametrize("n,lo,hi", [(300, 0, 300), (515, 100, 360), (1000, 990, 1000), (2048, 0, 1025), (100, 0, 100)])
+@pytest.mark.parametrize("n,lo,hi", [(300, 0, 300), (515, 100, 360), (1000, 990, 1000), (2048, 0, 1025), (100, 0, 100),
+                                     (8192, 4000, 4100)])
 def test_two_stage_solver_behind_eigh(ctx, n, lo, hi):
     """sclens_hip_dev_eigh_f32 with the context option "two_stage": orders that are not multiples of 64 go through the
     padded copy (decoupled sentinel block), n = 100 is below the threshold and silently takes the one-stage path."""
@@ -195,6 +196,39 @@ def test_two_stage_solver_behind_eigh(ctx, n, lo, hi):
         assert np.abs(Z @ Z.T - np.eye(m)).max() < 3e-4
     finally:
         c2.close()
+
+
+@pytest.mark.parametrize("n,m", [(192, 192), (1088, 100), (2560, 70), (640, 641 - 1)])
+def test_second_back_transformation_matches_the_unblocked_reference(ctx, n, m, monkeypatch):
+    """The register-resident MFMA version of Q2 (16-vector wave tiles, QJ sweep blocks per pass) against the one-reflector-at-
+    a-time reference kernel on the same reflectors: vector counts that are not multiples of 16 / 64, several super-blocks."""
+    A = _sym_psd(n, 13 * n + 5)
+    lda = rup(n, 32)
+    dA = DevArray(ctx, pad_rows(A, lda))
+    dT = DevArray(ctx, nbytes=4 * max(1, n // SB - 1) * SB * SB)
+    dd, de = DevArray(ctx, nbytes=8 * n), DevArray(ctx, nbytes=8 * n)
+    bd = C.c_int(-1)
+    ctx.check(ctx.lib.sclens_hip_dev_sy2sb_f32(ctx.h, dA.p, n, lda, dT.p, C.byref(bd)))
+    ctx.check(ctx.lib.sclens_hip_dev_sb2st_f32(ctx.h, dA.p, n, lda, dd.p, de.p))
+    rng = np.random.default_rng(n + m)
+    Z0 = np.zeros((m, lda), dtype=np.float32)
+    Z0[:, :n] = rng.standard_normal((m, n)) / np.sqrt(n)
+    outs = []
+    for ref in (True, False):
+        if ref:
+            monkeypatch.setenv("SCLENS_HIP_Q2_REFERENCE", "1")
+        else:
+            monkeypatch.delenv("SCLENS_HIP_Q2_REFERENCE", raising=False)
+        dZ = DevArray(ctx, Z0)
+        ctx.check(ctx.lib.sclens_hip_dev_sbr_apply_q2_f32(ctx.h, n, dZ.p, m, lda))
+        ctx.sync()
+        outs.append(dZ.get((m, lda), np.float32)[:, :n].astype(np.float64))
+        dZ.free()
+    for x in (dA, dT, dd, de):
+        x.free()
+    assert np.abs(outs[0] - outs[1]).max() < 2e-5 * np.abs(outs[0]).max() * np.sqrt(n / 64)
+    # orthogonal transformation: norms are preserved
+    assert np.abs(np.linalg.norm(outs[1], axis=1) - np.linalg.norm(Z0[:, :n].astype(np.float64), axis=1)).max() < 1e-4
 
 
 def test_sclens_with_the_two_stage_solver(ctx, monkeypatch):
