@@ -555,138 +555,178 @@ __global__ void sbr_pack_band(const float* __restrict__ A, int64_t n, int64_t ld
 
 __device__ __forceinline__ int sbr_tasks_of(int64_t s, int64_t n) { return (int)((n - s - 1 + SB - 1) / SB); }
 
-__global__ __launch_bounds__(256) void sbr_chase(float* __restrict__ Bd, int64_t n, float* __restrict__ V2, int64_t ldv2,
-                                                 float* __restrict__ TAU2, int64_t ldt, int* __restrict__ done) {
-  __shared__ float D[SB][SB + 1], B[SB][SB + 1];
-  __shared__ float v[SB], vp[SB], y[SB], w[SB];
-  __shared__ float sc[4];  // tau, beta, alpha2, tau_prev
-  const int tid = threadIdx.x, lane4 = tid & 3, row4 = tid >> 2;  // 4 threads per row for the matrix-vector products
+// One task = one workgroup step: 256 threads in two register mappings of a 64 x 64 block,
+//   T1: lane = row i, wave = 16-column group jq   (global loads / stores are 256-byte runs per wave-instruction),
+//   T2: lane = column j, wave = 16-row group       (the product v'B, reading the column-major LDS image with stride 65).
+// Vectors (v, v_prev, w, z) live one entry per lane in EVERY wave (all four waves compute the reflector redundantly from the
+// same numbers), so a product needs its vector as wave-uniform values: v_readlane, no LDS, no barrier. The block B is only
+// read from LDS (never updated there): with z = v'B - tau_p (v'w) v_p' the two one-sided updates collapse into
+// B <- B - tau_p w v_p' - tau v z', applied to the registers that hold the loaded block and stored straight to memory.
+// Three workgroup barriers per task. Hand-off between sweeps (workgroups): every store of band data is write-through
+// (`buffer_store ... sc1`), every storing wave drains `vmcnt(0)` before the barrier, one lane then stores the progress
+// counter (sc1); the consumer polls that counter from one lane and reads band data only with `buffer_load ... sc1`
+// (MI355X_MICROARCH.md, valid forms of an inter-workgroup hand-off, first table row). Out-of-range buffer offsets make
+// masked lanes load 0 / store nothing without a branch. A bounded spin + a shared abort word keep a logic error from
+// hanging the GPU.
+struct SbrChaseArgs {
+  float* Bd;
+  int64_t n;
+  float* V2;
+  int64_t ldv2;
+  float* TAU2;
+  int64_t ldt;
+  unsigned* done;   // [n] progress counters + [n] : abort word
+};
+
+__device__ __forceinline__ float sbr_rl(float x, int l) {
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), l));
+}
+__device__ __forceinline__ float sbr_wave_sum(float x) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) x += __shfl_xor(x, o);
+  return x;
+}
+__device__ __forceinline__ double sbr_wave_sum(double x) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) x += __shfl_xor(x, o);
+  return x;
+}
+
+__global__ __launch_bounds__(256) void sbr_chase(SbrChaseArgs a) {
+  __shared__ float Bt[SB * 65], Dt[SB * 65];
+  __shared__ float part[4 * SB], part2[4 * SB], partD[4 * SB];
+  __shared__ int pd_s;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wq = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int64_t n = a.n;
+  const unsigned nbytes = (unsigned)(n * LDB2 * sizeof(float));
+  __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(a.Bd, 0, nbytes, 0x00020000);
+  const unsigned OOR = 0xfffffff0u;  // beyond num_records: loads return 0, stores are dropped
+  unsigned* abort_w = a.done + n;
   for (int64_t s = blockIdx.x; s + 2 < n; s += gridDim.x) {
     const int K = sbr_tasks_of(s, n);
     const int Kprev = (s > 0) ? sbr_tasks_of(s - 1, n) : 0;
+    int pd = (s > 0) ? 0 : 0x7fffffff;
+    float vp = 0.f, tp = 0.f;
     for (int k = 0; k < K; ++k) {
-      if (s > 0) {  // wait for sweep s-1 to be two tasks ahead (or finished)
-        const int need = (k + 2 < Kprev) ? k + 2 : Kprev;
-        while (__hip_atomic_load(&done[s - 1], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < need) __builtin_amdgcn_s_sleep(2);
-      }
-      __syncthreads();
       const int64_t rk = s + 1 + (int64_t)k * SB;
       const int L = (int)((n - rk < SB) ? n - rk : SB);
-      // ---- load D (full symmetric image) and B
-      for (int idx = tid; idx < SB * SB; idx += 256) {
-        const int j = idx >> 6, i = idx & 63;  // coalesced over i (the row offset inside a packed column)
-        float dv = 0.f;
-        if (i < L && j < L) dv = (i >= j) ? Bd[(rk + j) * LDB2 + (i - j)] : Bd[(rk + i) * LDB2 + (j - i)];
-        D[i][j] = dv;
-        float bv = 0.f;
-        if (k > 0 && i < L) bv = Bd[(rk - SB + j) * LDB2 + (SB + i - j)];
-        B[i][j] = bv;
-      }
-      if (tid < SB) {
-        if (k == 0) y[tid] = (tid < L) ? Bd[s * LDB2 + 1 + tid] : 0.f;  // column s below the diagonal
-      }
-      __syncthreads();
-      if (k > 0) {
-        // ---- B <- B H_prev :  yv = B vp ; B -= tau_prev yv vp'
-        float part = 0.f;
-#pragma unroll
-        for (int q = 0; q < 16; ++q) part += B[row4][lane4 * 16 + q] * vp[lane4 * 16 + q];
-        part += __shfl_xor(part, 1);
-        part += __shfl_xor(part, 2);
-        if (lane4 == 0) w[row4] = part;
-        __syncthreads();
-        const float tp = sc[3];
-#pragma unroll
-        for (int q = 0; q < 16; ++q) B[row4][lane4 * 16 + q] -= tp * w[row4] * vp[lane4 * 16 + q];
-        __syncthreads();
-        if (tid < SB) y[tid] = B[tid][0];
-        __syncthreads();
-      }
-      // ---- reflector from x = y[0..L)
-      if (tid < 64) {
-        const float xi = (tid >= 1 && tid < L) ? y[tid] : 0.f;
-        double sg = (double)xi * (double)xi;
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) sg += __shfl_xor(sg, o);
-        const float alpha = y[0];
-        float tau = 0.f, beta = alpha, scale = 0.f;
-        if (sg > 0.0) {
-          const double nrm = sqrt((double)alpha * (double)alpha + sg);
-          beta = (float)((alpha >= 0.f) ? -nrm : nrm);
-          tau = (beta - alpha) / beta;
-          scale = 1.f / (alpha - beta);
-        }
-        v[tid] = (tid == 0) ? 1.f : xi * scale;
+      const int need = (k + 2 < Kprev) ? k + 2 : Kprev;
+      if (pd < need) {  // workgroup-uniform
         if (tid == 0) {
-          sc[0] = tau;
-          sc[1] = beta;
+          int x = 0;
+          for (unsigned spins = 0;; ++spins) {
+            x = (int)__hip_atomic_load(a.done + (s - 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (x >= need) break;
+            if ((spins & 1023u) == 1023u) {
+              if (__hip_atomic_load(abort_w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u || spins > (1u << 24)) {
+                __hip_atomic_store(abort_w, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                x = -1;
+                break;
+              }
+            }
+            __builtin_amdgcn_s_sleep(1);
+          }
+          pd_s = x;
+        }
+        __syncthreads();
+        pd = pd_s;
+        if (pd < 0) return;  // aborted
+      }
+      // ---- loads (T1), write-through reads of another workgroup's stores
+      float rb[16], rd[16];
+      const unsigned colB0 = (unsigned)(rk - SB), colD0 = (unsigned)rk;
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        const int j = 16 * wq + q;
+        const unsigned ob = (k > 0 && lane < L) ? ((colB0 + j) * LDB2 + SB + lane - j) * 4u : OOR;
+        rb[q] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, ob, 0, 16));
+        const unsigned od = (lane >= j && lane < L) ? ((colD0 + j) * LDB2 + lane - j) * 4u : OOR;
+        rd[q] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, od, 0, 16));
+      }
+      float ycol = 0.f;
+      if (k == 0) {
+        const unsigned oy = (lane < L) ? ((unsigned)s * LDB2 + 1 + lane) * 4u : OOR;
+        ycol = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, oy, 0, 16));
+      }
+      // ---- LDS images (column-major: X[i][j] at j * 65 + i); D gets both triangles
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        const int j = 16 * wq + q;
+        Bt[j * 65 + lane] = rb[q];
+        if (lane >= j) {
+          Dt[j * 65 + lane] = rd[q];
+          Dt[lane * 65 + j] = rd[q];
         }
       }
+      // ---- w = B v_prev (partial sums over this wave's columns)
+      float pw = 0.f;
+#pragma unroll
+      for (int q = 0; q < 16; ++q) pw += rb[q] * sbr_rl(vp, 16 * wq + q);
+      part[wq * SB + lane] = pw;
       __syncthreads();
-      const float tau = sc[0], beta = sc[1];
+      const float w = (part[lane] + part[SB + lane]) + (part[2 * SB + lane] + part[3 * SB + lane]);
+      const float y = (k > 0) ? Bt[lane] - tp * w * sbr_rl(vp, 0) : ycol;
+      // ---- reflector from y (every wave, identical arithmetic)
+      const float xi = (lane >= 1 && lane < L) ? y : 0.f;
+      const double sg = sbr_wave_sum((double)xi * (double)xi);
+      const float alpha = sbr_rl(y, 0);
+      float tau = 0.f, beta = alpha, scale = 0.f;
+      if (sg > 0.0) {
+        const double nrm = sqrt((double)alpha * (double)alpha + sg);
+        beta = (float)((alpha >= 0.f) ? -nrm : nrm);
+        tau = (beta - alpha) / beta;
+        scale = 1.f / (alpha - beta);
+      }
+      const float v = (lane == 0) ? 1.f : xi * scale;
+      // ---- z0 = v'B (T2: lane = column), D v (T1)
+      float pz = 0.f;
       if (k > 0) {
-        // ---- B <- H B (columns 1..): z = v' B ; B -= tau v z'   (thread: column row4, quarter of the rows)
-        float part = 0.f;
 #pragma unroll
-        for (int q = 0; q < 16; ++q) part += v[lane4 * 16 + q] * B[lane4 * 16 + q][row4];
-        part += __shfl_xor(part, 1);
-        part += __shfl_xor(part, 2);
-        if (lane4 == 0) w[row4] = part;
-        __syncthreads();
-#pragma unroll
-        for (int q = 0; q < 16; ++q) {
-          const int i = lane4 * 16 + q;
-          B[i][row4] = (row4 == 0) ? (i == 0 ? beta : 0.f) : B[i][row4] - tau * v[i] * w[row4];
-        }
-        __syncthreads();
-        for (int idx = tid; idx < SB * SB; idx += 256) {
-          const int j = idx >> 6, i = idx & 63;
-          if (i < L) Bd[(rk - SB + j) * LDB2 + (SB + i - j)] = B[i][j];
-        }
-      } else if (tid < L) {
-        Bd[s * LDB2 + 1 + tid] = (tid == 0) ? beta : 0.f;
+        for (int q = 0; q < 16; ++q) pz += Bt[lane * 65 + 16 * wq + q] * sbr_rl(v, 16 * wq + q);
       }
-      // ---- D <- H D H :  w = tau D v ; a2 = -1/2 tau v'w ; w += a2 v ; D -= v w' + w v'
-      {
-        float part = 0.f;
+      part2[wq * SB + lane] = pz;
+      const float vw = sbr_wave_sum(v * w);
+      float dd[16];
+      float pdv = 0.f;
 #pragma unroll
-        for (int q = 0; q < 16; ++q) part += D[row4][lane4 * 16 + q] * v[lane4 * 16 + q];
-        part += __shfl_xor(part, 1);
-        part += __shfl_xor(part, 2);
-        __syncthreads();  // w is free again (the B update above has consumed it)
-        if (lane4 == 0) w[row4] = tau * part;
-        __syncthreads();
-        if (tid < 64) {
-          float t = v[tid] * w[tid];
-#pragma unroll
-          for (int o = 32; o > 0; o >>= 1) t += __shfl_xor(t, o);
-          if (tid == 0) sc[2] = -0.5f * tau * t;
-        }
-        __syncthreads();
-        if (tid < SB) w[tid] += sc[2] * v[tid];
-        __syncthreads();
-#pragma unroll
-        for (int q = 0; q < 16; ++q) {
-          const int j = lane4 * 16 + q;
-          D[row4][j] -= v[row4] * w[j] + w[row4] * v[j];
-        }
-        __syncthreads();
-        for (int idx = tid; idx < SB * SB; idx += 256) {
-          const int j = idx >> 6, i = idx & 63;
-          if (i >= j && i < L) Bd[(rk + j) * LDB2 + (i - j)] = D[i][j];
-        }
+      for (int q = 0; q < 16; ++q) {
+        dd[q] = Dt[(16 * wq + q) * 65 + lane];
+        pdv += dd[q] * sbr_rl(v, 16 * wq + q);
       }
-      if (tid < SB) {
-        if (tid < L) V2[s * ldv2 + rk + tid] = v[tid];
-        vp[tid] = v[tid];
-        if (tid == 0) {
-          TAU2[s * ldt + k] = tau;
-          sc[3] = tau;
-        }
-      }
-      __threadfence();
+      partD[wq * SB + lane] = pdv;
       __syncthreads();
-      if (tid == 0) __hip_atomic_store(&done[s], k + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+      const float z = ((part2[lane] + part2[SB + lane]) + (part2[2 * SB + lane] + part2[3 * SB + lane])) - tp * vw * vp;
+      float w2 = tau * ((partD[lane] + partD[SB + lane]) + (partD[2 * SB + lane] + partD[3 * SB + lane]));
+      const float a2 = -0.5f * tau * sbr_wave_sum(v * w2);
+      w2 += a2 * v;
+      // ---- B <- H (B H_prev), D <- H D H on the registers, stored write-through
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        const int j = 16 * wq + q;
+        if (k > 0) {
+          float bn = rb[q] - tp * w * sbr_rl(vp, j) - tau * v * sbr_rl(z, j);
+          if (j == 0) bn = (lane == 0) ? beta : 0.f;
+          const unsigned ob = (lane < L) ? ((colB0 + j) * LDB2 + SB + lane - j) * 4u : OOR;
+          __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, bn), rs, ob, 0, 16);
+        }
+        const float dn = dd[q] - v * sbr_rl(w2, j) - w2 * sbr_rl(v, j);
+        const unsigned od = (lane >= j && lane < L) ? ((colD0 + j) * LDB2 + lane - j) * 4u : OOR;
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, dn), rs, od, 0, 16);
+      }
+      if (wq == 0) {
+        if (k == 0) {
+          const unsigned oy = (lane < L) ? ((unsigned)s * LDB2 + 1 + lane) * 4u : OOR;
+          __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, (lane == 0) ? beta : 0.f), rs, oy, 0, 16);
+        }
+        if (lane < L) a.V2[s * a.ldv2 + rk + lane] = v;
+        if (lane == 0) a.TAU2[s * a.ldt + k] = tau;
+      }
+      vp = v;
+      tp = tau;
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every storing wave: its write-through stores have left
+      __syncthreads();
+      if (tid == 0) __hip_atomic_store(a.done + s, (unsigned)(k + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
   }
 }
@@ -707,9 +747,9 @@ int sb2st_f32(Ctx* ctx, const float* A, int64_t n, int64_t lda, double* d_dev, d
   SCL_WS(ctx, Bd, float, "sbr.Bd", n * LDB2);
   SCL_WS(ctx, V2, float, "sbr.V2", n * ldv2);
   SCL_WS(ctx, TAU2, float, "sbr.TAU2", n * ldt);
-  SCL_WS(ctx, done, int, "sbr.done", n);
+  SCL_WS(ctx, done, unsigned, "sbr.done", n + 4);  // progress counters + abort word
   hipStream_t st = ctx->stream;
-  SCL_HIP(ctx, hipMemsetAsync(done, 0, sizeof(int) * n, st));
+  SCL_HIP(ctx, hipMemsetAsync(done, 0, sizeof(unsigned) * (n + 4), st));
   SCL_HIP(ctx, hipMemsetAsync(TAU2, 0, sizeof(float) * n * ldt, st));
   hipLaunchKernelGGL(sbr_pack_band, dim3((unsigned)n), dim3(128), 0, st, A, n, lda, Bd);
   // every workgroup must be resident (a sweep spins on its predecessor): one per CU is always safe
@@ -718,9 +758,15 @@ int sb2st_f32(Ctx* ctx, const float* A, int64_t n, int64_t lda, double* d_dev, d
   SCL_HIP(ctx, hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
   int G = (int)std::min<int64_t>(cus > 0 ? cus : 64, n / (2 * SB) + 1);
   if (G < 1) G = 1;
-  hipLaunchKernelGGL(sbr_chase, dim3(G), dim3(256), 0, st, Bd, n, V2, ldv2, TAU2, ldt, done);
+  if (const char* eg = getenv("SCLENS_HIP_CHASE_WGS")) G = std::max(1, std::min(G, atoi(eg)));
+  SbrChaseArgs ca{Bd, n, V2, ldv2, TAU2, ldt, done};
+  hipLaunchKernelGGL(sbr_chase, dim3(G), dim3(256), 0, st, ca);
   hipLaunchKernelGGL(sbr_band_diag, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, Bd, n, d_dev, e_dev);
   SCL_HIP(ctx, hipGetLastError());
+  unsigned aborted = 0;
+  SCL_HIP(ctx, hipMemcpyAsync(&aborted, done + n, sizeof(unsigned), hipMemcpyDeviceToHost, st));
+  SCL_HIP(ctx, hipStreamSynchronize(st));
+  if (aborted) return ctx->fail(SCLENS_ERR_HIP, "sb2st_f32: a sweep waited too long for its predecessor (bulge chasing aborted)");
   return SCLENS_OK;
 }
 
