@@ -119,6 +119,9 @@ struct GemmArgs {
   int splits = 1;
   int64_t k_chunk = 0;
   int64_t c_split_off = 0;
+  // ask for the large-tile NT kernels (256 x 256, or 256 x 64 when N <= 64) even for a short K / fewer tiles: callers whose
+  // product is bound by the C traffic or runs alone on the GPU (band reduction, back-transformations)
+  int prefer_big = 0;
 };
 int gemm_f32(Ctx* ctx, const GemmArgs& a);
 

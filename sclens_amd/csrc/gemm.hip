@@ -188,16 +188,42 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs a, int tiles_n) {
 // The block -> tile map is a host-built list: blocks that share blockIdx % 8 (one XCD, one L2) walk through compact squares of
 // tiles, so an XCD's concurrent tiles share operand panels in its L2.
 constexpr int GB = 256, GK = 32;
-constexpr int G_STAGE_FLOATS = 2 * GB * GK;  // A image + B image of one stage
+// wave grid WM x WN, each wave TM x TN MFMA tiles: block tile BM = 32 WM TM = 256 rows by BN = 32 WN TN columns.
+//   <2,4,4,2>: 256 x 256 (wave 128 x 64)  -- square products (Gram, rank-k updates, corr_mat)
+//   <8,1,1,2>: 256 x 64  (wave 32 x 64)   -- skinny products with 64 columns (band reduction, back-transformations)
+template <int WM, int WN, int TM, int TN>
+struct BigCfg {
+  static constexpr int BM = 32 * WM * TM, BN = 32 * WN * TN;
+  static constexpr int STAGE = (BM + BN) * GK;  // floats of one LDS stage (A image + B image)
+  static constexpr int GA = BM / 8 / (WM * WN), GBq = BN / 8 / (WM * WN);  // 8-row staging groups per wave
+};
 
 typedef __attribute__((address_space(3))) void lds_void;
 typedef const __attribute__((address_space(1))) void glb_void;
 
-__global__ __launch_bounds__(512, 2) void gemm_nt_big(GemmArgs a, const int2* __restrict__ tiles) {
+template <int WM, int WN, int TM, int TN>
+__global__ __launch_bounds__(512, 2) void gemm_nt_big(GemmArgs a, const int2* __restrict__ tiles, int tiles_n) {
+  using Cfg = BigCfg<WM, WN, TM, TN>;
+  static_assert(WM * WN == 8 && Cfg::BM == GB && Cfg::GA >= 1 && Cfg::GBq >= 1, "8 waves, 256 rows");
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  const int2 tl = tiles[blockIdx.x];
+  int2 tl;
+  if (tiles) {
+    tl = tiles[blockIdx.x];
+  } else {  // no list (shapes that change from call to call): the XCD-contiguous run of tile ids of the 128x128 kernel
+    const unsigned nwg = gridDim.x, bid = blockIdx.x;
+    const unsigned q = nwg >> 3, r = nwg & 7u, xcd = bid & 7u;
+    const unsigned t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    if (a.lower) {
+      int ti = (int)((sqrtf(8.f * (float)t + 1.f) - 1.f) * 0.5f);
+      while ((unsigned)(ti + 1) * (unsigned)(ti + 2) / 2 <= t) ++ti;
+      while ((unsigned)ti * (unsigned)(ti + 1) / 2 > t) --ti;
+      tl = make_int2(ti, (int)(t - (unsigned)ti * (unsigned)(ti + 1) / 2));
+    } else {
+      tl = make_int2((int)(t / (unsigned)tiles_n), (int)(t % (unsigned)tiles_n));
+    }
+  }
   if (tl.x < 0) return;
-  const int64_t m0 = (int64_t)tl.x * GB, n0 = (int64_t)tl.y * GB;
+  const int64_t m0 = (int64_t)tl.x * Cfg::BM, n0 = (int64_t)tl.y * Cfg::BN;
   if (a.splits > 1) {
     const int64_t koff = (int64_t)blockIdx.y * a.k_chunk;
     const int64_t kleft = a.K - koff;
@@ -207,68 +233,78 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_big(GemmArgs a, const int2* __
     a.C += (int64_t)blockIdx.y * a.c_split_off;
   }
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-  const int wm = wid >> 2, wn = wid & 3, l31 = lane & 31, h = lane >> 5;
+  const int wm = wid / WN, wn = wid % WN, l31 = lane & 31, h = lane >> 5;
 
-  // staging: wave w moves row groups 4 w .. 4 w + 3 (8 rows each) of both operands
+  // staging: wave w moves the 8-row groups GA w .. GA w + GA - 1 of A and GBq w .. of B
   const int srow = lane >> 3, sq = lane & 7;
-  const float* srcA[4];
-  const float* srcB[4];
-  int64_t rowA[4], rowB[4];
+  const float* srcA[Cfg::GA];
+  const float* srcB[Cfg::GBq];
+  int64_t rowA[Cfg::GA], rowB[Cfg::GBq];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int r = (wid * 4 + i) * 8 + srow;
+  for (int i = 0; i < Cfg::GA; ++i) {
+    const int r = (wid * Cfg::GA + i) * 8 + srow;
     const int chunk = sq ^ ((r >> 1) & 7);
-    int64_t ra = m0 + r, rb = n0 + r;
+    int64_t ra = m0 + r;
     if (ra > a.M - 1) ra = a.M - 1;
-    if (rb > a.N - 1) rb = a.N - 1;
     rowA[i] = ra;
-    rowB[i] = rb;
     srcA[i] = a.P + ra * a.ldp + 4 * chunk;
+  }
+#pragma unroll
+  for (int i = 0; i < Cfg::GBq; ++i) {
+    const int r = (wid * Cfg::GBq + i) * 8 + srow;
+    const int chunk = sq ^ ((r >> 1) & 7);
+    int64_t rb = n0 + r;
+    if (rb > a.N - 1) rb = a.N - 1;
+    rowB[i] = rb;
     srcB[i] = a.Q + rb * a.ldq + 4 * chunk;
   }
   const int64_t nfull = a.K / GK, nkt = (a.K + GK - 1) / GK;
   auto stage = [&](int buf, int64_t kt) {
-    float* As = lds + buf * G_STAGE_FLOATS;
-    float* Bs = As + GB * GK;
+    float* As = lds + buf * Cfg::STAGE;
+    float* Bs = As + Cfg::BM * GK;
     if (kt < nfull) {
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int g = wid * 4 + i;
-        __builtin_amdgcn_global_load_lds((glb_void*)(srcA[i] + kt * GK), (lds_void*)(As + g * 256), 16, 0, 0);
-        __builtin_amdgcn_global_load_lds((glb_void*)(srcB[i] + kt * GK), (lds_void*)(Bs + g * 256), 16, 0, 0);
-      }
+      for (int i = 0; i < Cfg::GA; ++i)
+        __builtin_amdgcn_global_load_lds((glb_void*)(srcA[i] + kt * GK), (lds_void*)(As + (wid * Cfg::GA + i) * 256), 16, 0, 0);
+#pragma unroll
+      for (int i = 0; i < Cfg::GBq; ++i)
+        __builtin_amdgcn_global_load_lds((glb_void*)(srcB[i] + kt * GK), (lds_void*)(Bs + (wid * Cfg::GBq + i) * 256), 16, 0, 0);
     } else {  // K tail: through registers, zero beyond K
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int g = wid * 4 + i, r = g * 8 + srow;
+      for (int i = 0; i < Cfg::GA; ++i) {
+        const int g = wid * Cfg::GA + i, r = g * 8 + srow;
         const int chunk = sq ^ ((r >> 1) & 7);
-        const int64_t kk = kt * GK + 4 * chunk;
-        *reinterpret_cast<f32x4*>(As + g * 256 + lane * 4) = ld4<true>(a.P, a.ldp, rowA[i], a.M, kk, a.K);
-        *reinterpret_cast<f32x4*>(Bs + g * 256 + lane * 4) = ld4<true>(a.Q, a.ldq, rowB[i], a.N, kk, a.K);
+        *reinterpret_cast<f32x4*>(As + g * 256 + lane * 4) = ld4<true>(a.P, a.ldp, rowA[i], a.M, kt * GK + 4 * chunk, a.K);
+      }
+#pragma unroll
+      for (int i = 0; i < Cfg::GBq; ++i) {
+        const int g = wid * Cfg::GBq + i, r = g * 8 + srow;
+        const int chunk = sq ^ ((r >> 1) & 7);
+        *reinterpret_cast<f32x4*>(Bs + g * 256 + lane * 4) = ld4<true>(a.Q, a.ldq, rowB[i], a.N, kt * GK + 4 * chunk, a.K);
       }
     }
   };
 
-  f32x16 acc[4][2];
+  f32x16 acc[TM][TN];
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+  for (int i = 0; i < TM; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+    for (int j = 0; j < TN; ++j)
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
   // fragment read offsets (floats) inside a stage: row r -> r * 32 + ((c ^ ((r >> 1) & 7)) << 2), c = 2 j8 + h
-  int offA[4], offB[2], swA[4], swB[2];
+  int offA[TM], offB[TN], swA[TM], swB[TN];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int r = wm * 128 + i * 32 + l31;
+  for (int i = 0; i < TM; ++i) {
+    const int r = wm * (32 * TM) + i * 32 + l31;
     offA[i] = r * 32;
     swA[i] = (r >> 1) & 7;
   }
 #pragma unroll
-  for (int j = 0; j < 2; ++j) {
-    const int r = wn * 64 + j * 32 + l31;
-    offB[j] = GB * GK + r * 32;
+  for (int j = 0; j < TN; ++j) {
+    const int r = wn * (32 * TN) + j * 32 + l31;
+    offB[j] = Cfg::BM * GK + r * 32;
     swB[j] = (r >> 1) & 7;
   }
 
@@ -277,30 +313,30 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_big(GemmArgs a, const int2* __
   for (int64_t kt = 0; kt < nkt; ++kt) {
     const int buf = (int)(kt & 1);
     if (kt + 1 < nkt) stage(buf ^ 1, kt + 1);
-    const float* S = lds + buf * G_STAGE_FLOATS;
+    const float* S = lds + buf * Cfg::STAGE;
     // fragments of the 8-deep group j8 + 1 are fetched before the MFMAs of group j8 (two named register sets)
-    f32x4 av[2][4], bv[2][2];
+    f32x4 av[2][TM], bv[2][TN];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) av[0][i] = *reinterpret_cast<const f32x4*>(S + offA[i] + ((h ^ swA[i]) << 2));
+    for (int i = 0; i < TM; ++i) av[0][i] = *reinterpret_cast<const f32x4*>(S + offA[i] + ((h ^ swA[i]) << 2));
 #pragma unroll
-    for (int j = 0; j < 2; ++j) bv[0][j] = *reinterpret_cast<const f32x4*>(S + offB[j] + ((h ^ swB[j]) << 2));
+    for (int j = 0; j < TN; ++j) bv[0][j] = *reinterpret_cast<const f32x4*>(S + offB[j] + ((h ^ swB[j]) << 2));
 #pragma unroll
     for (int j8 = 0; j8 < 4; ++j8) {
       const int cur = j8 & 1, nxt = cur ^ 1;
       if (j8 + 1 < 4) {
         const int c = 2 * (j8 + 1) + h;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) av[nxt][i] = *reinterpret_cast<const f32x4*>(S + offA[i] + ((c ^ swA[i]) << 2));
+        for (int i = 0; i < TM; ++i) av[nxt][i] = *reinterpret_cast<const f32x4*>(S + offA[i] + ((c ^ swA[i]) << 2));
 #pragma unroll
-        for (int j = 0; j < 2; ++j) bv[nxt][j] = *reinterpret_cast<const f32x4*>(S + offB[j] + ((c ^ swB[j]) << 2));
+        for (int j = 0; j < TN; ++j) bv[nxt][j] = *reinterpret_cast<const f32x4*>(S + offB[j] + ((c ^ swB[j]) << 2));
       }
       __builtin_amdgcn_sched_barrier(0);  // keep the reads ahead of this group's MFMAs (hipcc would sink them behind)
 #pragma unroll
       for (int t = 0; t < 4; ++t)
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < TM; ++i)
 #pragma unroll
-          for (int j = 0; j < 2; ++j)
+          for (int j = 0; j < TN; ++j)
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[cur][i][t], bv[cur][j][t], acc[i][j], 0, 0, 0);
     }
     __syncthreads();
@@ -310,28 +346,28 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_big(GemmArgs a, const int2* __
   //      register quad, so the mirrored (transposed) store of `lower` is one 16-byte store per quad.
   if (a.colabsmax) {
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
+    for (int j = 0; j < TN; ++j) {
       float mx = 0.f;
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
+      for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int e = 0; e < 16; ++e) mx = fmaxf(mx, fabsf(a.alpha * acc[i][j][e]));
       // rows beyond M hold copies of row M-1 (clamped loads): harmless for a maximum
       mx = fmaxf(mx, __shfl_xor(mx, 32));
-      const int64_t col = n0 + wn * 64 + j * 32 + l31;
+      const int64_t col = n0 + wn * (32 * TN) + j * 32 + l31;
       if (h == 0 && col < a.N) atomicMax(&a.colabsmax[col], __float_as_uint(mx));
     }
     return;
   }
   const bool vec_mirror = a.lower && (a.ldc % 4 == 0) && ((reinterpret_cast<uintptr_t>(a.C) & 15u) == 0);
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+  for (int i = 0; i < TM; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const int64_t col = n0 + wn * 64 + j * 32 + l31;
+    for (int j = 0; j < TN; ++j) {
+      const int64_t col = n0 + wn * (32 * TN) + j * 32 + l31;
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
-        const int64_t rowq = m0 + wm * 128 + i * 32 + 8 * q + 4 * h;
+        const int64_t rowq = m0 + wm * (32 * TM) + i * 32 + 8 * q + 4 * h;
         f32x4 v;
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
@@ -359,7 +395,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_big(GemmArgs a, const int2* __
 // block -> tile list of gemm_nt_big: tiles ordered by squares of SQ x SQ tiles; chunk c of CH = SQ*SQ consecutive tiles goes
 // to the blocks {b : b % 8 == c % 8} in order (blocks are dealt round-robin over the 8 XCDs), padded with (-1,-1)
 static int big_tile_list(Ctx* ctx, int64_t tm, int64_t tn, int lower, const int2** out, int64_t* nblocks) {
-  constexpr int SQ = 6, CH = SQ * SQ;
+  constexpr int SQ = 6, CH = SQ * SQ;  // (a single tile column degenerates to runs of 36 row tiles per XCD)
   const std::string key = "gemm.tiles." + std::to_string(tm) + "x" + std::to_string(tn) + (lower ? "L" : "F");
   std::vector<int2> seq;
   for (int64_t si = 0; si < (tm + SQ - 1) / SQ; ++si)
@@ -400,23 +436,38 @@ int gemm_f32(Ctx* ctx, const GemmArgs& a) {
                    (a.ldp % 4 == 0) && (a.ldq % 4 == 0);
   if (a.splits > 1 && (a.k_chunk <= 0 || a.k_chunk % 16 != 0 || a.colabsmax || a.beta != 0.f))
     return ctx->fail(SCLENS_ERR_ARG, "gemm_f32: bad split-K arguments");
+  // ---- large-tile NT kernels
+  const bool force_big = getenv("SCLENS_HIP_GEMM_BIG") != nullptr;  // tests: the large-tile kernels on small shapes
+  const bool big_ok = a.q_kcontig && vec && a.K >= GK && (a.splits <= 1 || a.k_chunk % GK == 0) && !getenv("SCLENS_HIP_GEMM_SMALL");
+  const int nsl = a.splits > 1 ? a.splits : 1;
+  if (big_ok && a.N <= 64 && !a.lower && !a.colabsmax && (a.prefer_big || force_big)) {  // skinny: 256 x 64 tiles
+    using Cfg = BigCfg<8, 1, 1, 2>;
+    const int64_t bm = (a.M + GB - 1) / GB;
+    static const hipError_t attr_rc = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_big<8, 1, 1, 2>),
+                                                          hipFuncAttributeMaxDynamicSharedMemorySize, 2 * Cfg::STAGE * (int)sizeof(float));
+    SCL_HIP(ctx, attr_rc);
+    hipLaunchKernelGGL((gemm_nt_big<8, 1, 1, 2>), dim3((unsigned)bm, (unsigned)nsl), dim3(512), 2 * Cfg::STAGE * sizeof(float),
+                       ctx->stream, a, (const int2*)nullptr, 1);
+    SCL_HIP(ctx, hipGetLastError());
+    return SCLENS_OK;
+  }
   const int64_t bm = (a.M + GB - 1) / GB, bn = (a.N + GB - 1) / GB;
-  // the large-tile kernel needs enough tiles for the 256 CUs (one workgroup each)
+  // the 256 x 256 kernel needs enough tiles for the 256 CUs (one workgroup each)
   // (measured at n = 10^4, 820 tiles, three concurrent decompositions: the 128x128 kernel, which shares a CU with the kernels
   // of the other streams, is as fast alone and 4 % faster in the mix; at n = 3 * 10^4 the large tiles are 11 % faster)
-  const bool force_big = getenv("SCLENS_HIP_GEMM_BIG") != nullptr;  // tests: the large-tile kernel on small shapes
-  const bool want_big = a.K >= 256 && (a.lower ? bm * (bm + 1) / 2 : bm * bn) * (a.splits > 1 ? a.splits : 1) >= 1500;
-  if (a.q_kcontig && vec && a.K >= GK && (want_big || force_big) && (a.splits <= 1 || a.k_chunk % GK == 0) &&
-      !getenv("SCLENS_HIP_GEMM_SMALL")) {
+  const int64_t ntb = a.lower ? bm * (bm + 1) / 2 : bm * bn;
+  const bool want_list = a.K >= 256 && ntb * nsl >= 1500;       // long contractions: tile list with compact squares per XCD
+  const bool want_nolist = a.prefer_big && ntb * nsl >= 400;    // short K, shape changes per call: no list
+  if (big_ok && (want_list || want_nolist || force_big) && a.N > 64) {
+    using Cfg = BigCfg<2, 4, 4, 2>;
     const int2* tiles = nullptr;
-    int64_t nb = 0;
-    SCL_TRY(big_tile_list(ctx, bm, bn, a.lower, &tiles, &nb));
-    static const hipError_t attr_rc = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_big),
-                                                          hipFuncAttributeMaxDynamicSharedMemorySize,
-                                                          2 * G_STAGE_FLOATS * (int)sizeof(float));
+    int64_t nb = ntb;
+    if (want_list || (force_big && !a.prefer_big)) SCL_TRY(big_tile_list(ctx, bm, bn, a.lower, &tiles, &nb));
+    static const hipError_t attr_rc = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_big<2, 4, 4, 2>),
+                                                          hipFuncAttributeMaxDynamicSharedMemorySize, 2 * Cfg::STAGE * (int)sizeof(float));
     SCL_HIP(ctx, attr_rc);
-    hipLaunchKernelGGL(gemm_nt_big, dim3((unsigned)nb, (unsigned)(a.splits > 1 ? a.splits : 1)), dim3(512),
-                       2 * G_STAGE_FLOATS * sizeof(float), ctx->stream, a, tiles);
+    hipLaunchKernelGGL((gemm_nt_big<2, 4, 4, 2>), dim3((unsigned)nb, (unsigned)nsl), dim3(512), 2 * Cfg::STAGE * sizeof(float),
+                       ctx->stream, a, tiles, (int)bn);
     SCL_HIP(ctx, hipGetLastError());
     return SCLENS_OK;
   }

@@ -24,6 +24,7 @@
 namespace scl {
 
 constexpr int SB = 64;
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 constexpr int SBR_CHUNK = 256;   // long-dimension positions per workgroup of sbr_cross_part
 
 // ---- partial cross products of two 64-row blocks: part[wg][i][j] = sum_{k in chunk wg} X[i][k] * Y[j][k]  (fp64) ------
@@ -331,12 +332,12 @@ __global__ __launch_bounds__(256) void sbr_rightmul(SbrMul a) {
     return;
   }
   float x[SB];  // every loop over x is fully unrolled: the array lives in registers
-  if (a.mode == 2) {
+  if (a.mode == 2) {  // in = split-K slabs of W, each [len][SB] row-major: 16-byte loads, slabs summed in a fixed order
 #pragma unroll
-    for (int i = 0; i < SB; ++i) {
-      float s = 0.f;
-      for (int q = 0; q < a.nslab; ++q) s += a.in[(int64_t)q * a.slab + (int64_t)i * a.ldi + r];  // fixed order
-      x[i] = s;
+    for (int i = 0; i < SB; i += 4) {
+      f32x4 s4 = {0.f, 0.f, 0.f, 0.f};
+      for (int q = 0; q < a.nslab; ++q) s4 += *reinterpret_cast<const f32x4*>(a.in + (int64_t)q * a.slab + r * SB + i);
+      x[i] = s4[0]; x[i + 1] = s4[1]; x[i + 2] = s4[2]; x[i + 3] = s4[3];
     }
   } else {
 #pragma unroll
@@ -401,7 +402,7 @@ int sy2sb_f32(Ctx* ctx, float* A, int64_t n, int64_t lda, float* Tall, int* brea
   const int64_t npan = n / SB - 1;  // the last diagonal block needs no reduction
   const int64_t ldw = round_up(n, 64);
   const int64_t maxparts = (n + SBR_CHUNK - 1) / SBR_CHUNK + 1;
-  const int S = 8;  // K-slices of the skinny product W = A22 V
+  const int S = 16;  // at most this many K-slices of the skinny product W = A22 V
   SCL_WS(ctx, part, double, "sbr.part", maxparts * SB * SB);
   SCL_WS(ctx, Mat, double, "sbr.M", 2 * SB * SB);   // M | Sh
   SCL_WS(ctx, V1, float, "sbr.V1", 2 * SB * SB);    // V1 | Rh
@@ -430,20 +431,26 @@ int sy2sb_f32(Ctx* ctx, float* A, int64_t n, int64_t lda, float* Tall, int* brea
     mv.in = Pt; mv.ldi = lda; mv.Mat = Mat; mv.out = Pt; mv.ldo = lda; mv.len = np; mv.mode = 1;
     mv.V1 = V1; mv.Rh = V1 + SB * SB; mv.band = A + r0 * lda + c0; mv.lda = lda;
     hipLaunchKernelGGL(sbr_rightmul, dim3((unsigned)((np + 255) / 256)), dim3(256), 0, st, mv);
-    // W' (SB x n') = V' A22, K = n' split into S slices inside one launch
+    // W (n' x SB) = A22 V as an NT product (A22 is stored in full and symmetric: its rows are K-contiguous), 256 x 64 tiles,
+    // K = n' split into S slices inside one launch (slab s = its own [n'][SB] partial, summed by the next kernel)
     float* A22 = A + r0 * lda + r0;
+    const int64_t tiles_w = (np + 255) / 256;
+    int Sw = (int)std::min<int64_t>(S, std::max<int64_t>(1, (640 + tiles_w - 1) / tiles_w));
+    const int64_t kch = round_up((np + Sw - 1) / Sw, 32);
+    Sw = (int)((np + kch - 1) / kch);
     {
       GemmArgs g{};
-      g.P = Pt; g.Q = A22; g.C = Wp;
-      g.M = SB; g.N = np; g.K = np;
-      g.ldp = lda; g.ldq = lda; g.ldc = ldw;
-      g.alpha = 1.f; g.beta = 0.f; g.q_kcontig = 0; g.lower = 0; g.colabsmax = nullptr;
-      g.splits = S; g.k_chunk = round_up((np + S - 1) / S, 16); g.c_split_off = (int64_t)SB * ldw;
+      g.P = A22; g.Q = Pt; g.C = Wp;
+      g.M = np; g.N = SB; g.K = np;
+      g.ldp = lda; g.ldq = lda; g.ldc = SB;
+      g.alpha = 1.f; g.beta = 0.f; g.q_kcontig = 1; g.lower = 0; g.colabsmax = nullptr;
+      g.splits = Sw; g.k_chunk = kch; g.c_split_off = (int64_t)SB * ldw;
+      g.prefer_big = 1;
       SCL_TRY(gemm_f32(ctx, g));
     }
     SbrMul my{};  // Y' = T' W'
     my.in = Wp; my.ldi = ldw; my.Mat = Mat + SB * SB; my.out = Yt; my.ldo = ldw; my.len = np; my.mode = 2;
-    my.nslab = S; my.slab = (int64_t)SB * ldw;
+    my.nslab = Sw; my.slab = (int64_t)SB * ldw;
     // sbr_rightmul takes its matrix in fp64: Mat + SB*SB holds T for this launch, then Sh
     hipLaunchKernelGGL(sbr_cvt64, dim3(16), dim3(256), 0, st, Tp, Mat + SB * SB, SB * SB);
     hipLaunchKernelGGL(sbr_rightmul, dim3((unsigned)((np + 255) / 256)), dim3(256), 0, st, my);
@@ -459,6 +466,7 @@ int sy2sb_f32(Ctx* ctx, float* A, int64_t n, int64_t lda, float* Tall, int* brea
       g.M = np; g.N = np; g.K = 2 * SB;
       g.ldp = 2 * SB; g.ldq = 2 * SB; g.ldc = lda;
       g.alpha = -1.f; g.beta = 1.f; g.q_kcontig = 1; g.lower = 1; g.colabsmax = nullptr;
+      g.prefer_big = 1;  // K = 128: bound by the traffic of C, whose mirrored half the large-tile kernel stores 16 bytes at a time
       SCL_TRY(gemm_f32(ctx, g));
     }
   }
@@ -885,7 +893,6 @@ constexpr int QNT = 6 + 2 * (QJ - 1);
 constexpr int Q_RS = 100;  // floats per reflector in the LDS image: b128 reads 2-way, b32 reads conflict-free
 constexpr int Q_RT = 40;   // floats per row of Tg: conflict-free b128 reads
 constexpr int Q_BUF = QW * Q_RS + QW * Q_RT;
-typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 struct SbrQ2Args {
   const float* V2;

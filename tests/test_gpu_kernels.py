@@ -26,7 +26,7 @@ def _gemm(ctx, P, Q, C0, alpha, beta, q_kcontig, lower=0, absmax=False):
 
 
 @pytest.mark.parametrize("M,N,K", [(128, 128, 16), (130, 257, 33), (64, 300, 1000), (1000, 77, 515), (5, 5, 3),
-                                   (300, 520, 1000), (512, 256, 64), (700, 161, 37), (161, 769, 4100)])
+                                   (300, 520, 1000), (512, 256, 64), (700, 161, 37), (161, 769, 4100), (700, 64, 515), (300, 40, 96)])
 def test_gemm_nt_nn(ctx, M, N, K, monkeypatch):
     monkeypatch.setenv("SCLENS_HIP_GEMM_BIG", "1")  # NT shapes that fit go through the 256x256 kernel as well
     rng = np.random.default_rng(M * 7 + N)
