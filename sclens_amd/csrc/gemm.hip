@@ -365,27 +365,38 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_big(GemmArgs a, const int2* __
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
       const int64_t col = n0 + wn * (32 * TN) + j * 32 + l31;
+      const int64_t row0 = m0 + wm * (32 * TM) + i * 32 + 4 * h;
+      // beta: all 16 loads of this 32 x 32 tile are issued before its first store (a store to C would otherwise fence every
+      // later load of C: one memory round trip per element)
+      f32x16 cin;
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const int64_t rowq = m0 + wm * (32 * TM) + i * 32 + 8 * q + 4 * h;
-        f32x4 v;
+      for (int e = 0; e < 16; ++e) cin[e] = 0.f;
+      if (a.beta != 0.f) {
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          const int64_t row = rowq + u;
-          float x = a.alpha * acc[i][j][4 * q + u];
-          if (row < a.M && col < a.N && (!a.lower || col <= row)) {
-            if (a.beta != 0.f) x += a.beta * a.C[row * a.ldc + col];
-            a.C[row * a.ldc + col] = x;
-          }
-          v[u] = x;
+        for (int e = 0; e < 16; ++e) {
+          const int64_t row = row0 + (e & 3) + 8 * (e >> 2);
+          if (row < a.M && col < a.N && (!a.lower || col <= row)) cin[e] = a.C[row * a.ldc + col];
         }
-        if (a.lower && col < a.N) {
+      }
+      f32x16 outv;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) outv[e] = a.alpha * acc[i][j][e] + a.beta * cin[e];
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int64_t row = row0 + (e & 3) + 8 * (e >> 2);
+        if (row < a.M && col < a.N && (!a.lower || col <= row)) a.C[row * a.ldc + col] = outv[e];
+      }
+      if (a.lower && col < a.N) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int64_t rowq = row0 + 8 * q;
           if (vec_mirror && rowq + 3 < a.M && col < rowq) {
+            f32x4 v = {outv[4 * q], outv[4 * q + 1], outv[4 * q + 2], outv[4 * q + 3]};
             *reinterpret_cast<f32x4*>(&a.C[col * a.ldc + rowq]) = v;
           } else {
 #pragma unroll
             for (int u = 0; u < 4; ++u)
-              if (rowq + u < a.M && col < rowq + u) a.C[col * a.ldc + rowq + u] = v[u];
+              if (rowq + u < a.M && col < rowq + u) a.C[col * a.ldc + rowq + u] = outv[4 * q + u];
           }
         }
       }

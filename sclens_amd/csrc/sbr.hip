@@ -70,6 +70,15 @@ __global__ __launch_bounds__(256) void sbr_cross_part(const float* __restrict__ 
     for (int v = 0; v < 4; ++v) out[(4 * ti + u) * SB + 4 * tj + v] = acc[u][v];
 }
 
+// sum of the partials in a fixed order: out[idx] = sum_p part[p][idx], idx < SB * SB (16 workgroups instead of a serial loop
+// inside the single-workgroup panel kernels)
+__global__ __launch_bounds__(256) void sbr_sum_parts(const double* __restrict__ part, int nparts, double* __restrict__ out) {
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  double s = 0.0;
+  for (int p = 0; p < nparts; ++p) s += part[(int64_t)p * SB * SB + idx];
+  out[idx] = s;
+}
+
 // ---- the SB x SB algebra of one panel, one wave, fp64 in LDS -----------------------------------------------------------
 // in : part[nparts][SB][SB] (Gram partials of the panel), Ptop = transposed top block of the panel
 //      (Ptop[j * ldp + i] = P[i][j], i, j < SB)
@@ -404,6 +413,7 @@ int sy2sb_f32(Ctx* ctx, float* A, int64_t n, int64_t lda, float* Tall, int* brea
   const int64_t maxparts = (n + SBR_CHUNK - 1) / SBR_CHUNK + 1;
   const int S = 16;  // at most this many K-slices of the skinny product W = A22 V
   SCL_WS(ctx, part, double, "sbr.part", maxparts * SB * SB);
+  SCL_WS(ctx, psum, double, "sbr.psum", SB * SB);
   SCL_WS(ctx, Mat, double, "sbr.M", 2 * SB * SB);   // M | Sh
   SCL_WS(ctx, V1, float, "sbr.V1", 2 * SB * SB);    // V1 | Rh
   SCL_WS(ctx, Wp, float, "sbr.Wp", (int64_t)S * SB * ldw);
@@ -422,11 +432,12 @@ int sy2sb_f32(Ctx* ctx, float* A, int64_t n, int64_t lda, float* Tall, int* brea
     float* Tp = Tall + p * SB * SB;
     const int nparts = (int)((np + SBR_CHUNK - 1) / SBR_CHUNK);
     hipLaunchKernelGGL(sbr_cross_part, dim3(nparts), dim3(256), 0, st, Pt, lda, Pt, lda, np, part);
+    hipLaunchKernelGGL(sbr_sum_parts, dim3(SB * SB / 256), dim3(256), 0, st, part, nparts, psum);
     SbrSmall sm{Mat, V1, Tp, V1 + SB * SB, flag};
     if (np == SB)  // last panel: may contain the zero rows of the padding
       hipLaunchKernelGGL(sbr_panel_house, dim3(1), dim3(64), 0, st, Pt, lda, sm);
     else
-      hipLaunchKernelGGL(sbr_panel_small, dim3(1), dim3(256), 4 * SB * SB * sizeof(double), st, part, nparts, Pt, lda, sm);
+      hipLaunchKernelGGL(sbr_panel_small, dim3(1), dim3(256), 4 * SB * SB * sizeof(double), st, psum, 1, Pt, lda, sm);
     SbrMul mv{};
     mv.in = Pt; mv.ldi = lda; mv.Mat = Mat; mv.out = Pt; mv.ldo = lda; mv.len = np; mv.mode = 1;
     mv.V1 = V1; mv.Rh = V1 + SB * SB; mv.band = A + r0 * lda + c0; mv.lda = lda;
@@ -455,7 +466,8 @@ int sy2sb_f32(Ctx* ctx, float* A, int64_t n, int64_t lda, float* Tall, int* brea
     hipLaunchKernelGGL(sbr_cvt64, dim3(16), dim3(256), 0, st, Tp, Mat + SB * SB, SB * SB);
     hipLaunchKernelGGL(sbr_rightmul, dim3((unsigned)((np + 255) / 256)), dim3(256), 0, st, my);
     hipLaunchKernelGGL(sbr_cross_part, dim3(nparts), dim3(256), 0, st, Pt, lda, Yt, ldw, np, part);
-    hipLaunchKernelGGL(sbr_small_s, dim3(1), dim3(256), 0, st, part, nparts, Tp, Mat + SB * SB);
+    hipLaunchKernelGGL(sbr_sum_parts, dim3(SB * SB / 256), dim3(256), 0, st, part, nparts, psum);
+    hipLaunchKernelGGL(sbr_small_s, dim3(1), dim3(256), 0, st, psum, 1, Tp, Mat + SB * SB);
     SbrMul mz{};  // Z = Y - V Sh, and the row-major operands of the rank-2SB update
     mz.in = Pt; mz.ldi = lda; mz.Mat = Mat + SB * SB; mz.len = np; mz.mode = 3;
     mz.Y = Yt; mz.ldy = ldw; mz.VW = VW; mz.WV = WV;
