@@ -56,9 +56,11 @@ int sclens_hip_symv_profile_read(sclens_hip_ctx* ctx, int64_t* launches, double*
 /* Roofline probe: all n-1 trd_colB launches of one tridiagonalisation of order n, back to back between one pair of HIP
  * events on the context's stream (synthetic finite data; same grids and arguments as the real reduction). */
 int sclens_hip_symv_probe(sclens_hip_ctx* ctx, int64_t n, int64_t* launches, double* total_ms, double* total_bytes);
-/* Context options. "two_stage" (0 / 1; default from the environment variable SCLENS_HIP_TWO_STAGE, else 0): eigen-solver by
- * the two-stage reduction (dense -> band -> tridiagonal, sbr.hip; falls back to the one-stage reduction for orders
- * below 128 or above 38 000 and when a panel is numerically rank deficient). Experimental: correct, not yet faster. */
+/* Context options. "two_stage" (-1 / 0 / 1; default -1, or the environment variable SCLENS_HIP_TWO_STAGE): which reduction the
+ * eigen-solver that replaces cuSOLVER syevd! (scLENS.jl:377) uses. 1 = two-stage (dense -> band of half-width 64 on the
+ * matrix cores -> tridiagonal by bulge chasing, sbr.hip; falls back to the one-stage reduction for orders below 128 and when
+ * a panel is numerically rank deficient), 0 = one-stage (tridiag.hip), -1 = by order: two-stage from n = 16 000
+ * (SCLENS_HIP_TWO_STAGE_MIN_N) upwards. */
 int sclens_hip_set_option(sclens_hip_ctx* ctx, const char* name, int64_t value);
 /* raw stream handle (hipStream_t) so a host framework can order its own work after ours */
 void* sclens_hip_stream(sclens_hip_ctx* ctx);

@@ -66,14 +66,14 @@ int sclens_hip_create(sclens_hip_ctx** out, int device_id) {
     delete h;
     return SCLENS_ERR_NO_DEVICE;
   }
-  if (const char* ts = getenv("SCLENS_HIP_TWO_STAGE")) h->c.two_stage = atoi(ts) != 0;
+  if (const char* ts = getenv("SCLENS_HIP_TWO_STAGE")) h->c.two_stage = atoi(ts) < 0 ? -1 : (atoi(ts) != 0);
   *out = h;
   return SCLENS_OK;
 }
 int sclens_hip_set_option(sclens_hip_ctx* h, const char* name, int64_t value) {
   if (!h || !name) return SCLENS_ERR_ARG;
   if (std::string(name) == "two_stage") {
-    h->c.two_stage = value != 0;
+    h->c.two_stage = value < 0 ? -1 : (value != 0);
     return SCLENS_OK;
   }
   return h->c.fail(SCLENS_ERR_ARG, std::string("set_option: unknown option ") + name);

@@ -34,9 +34,9 @@ struct Ctx {
     bool valid = false;
     int64_t N = 0, M = 0, n_cells = 0, n_genes = 0, nnz_out = 0;
   } pp;
-  // eigen-solver selection: 0 = one-stage reduction (tridiag.hip), 1 = two-stage (sbr.hip) with fall-back to one-stage;
+  // eigen-solver selection: 0 = one-stage reduction (tridiag.hip), 1 = two-stage (sbr.hip) with fall-back to one-stage, -1 = by order;
   // set from SCLENS_HIP_TWO_STAGE at creation. last_two_stage: which path holds the state eig_vectors continues from.
-  int two_stage = 0;
+  int two_stage = -1;
   bool last_two_stage = false;
   // sessions keep their eigenvector / ensemble buffers in this context's named workspaces ("ses.*", "eig.*"): one live
   // session per context (worker sessions of session_clone bring their own context)

@@ -776,7 +776,9 @@ int sb2st_f32(Ctx* ctx, const float* A, int64_t n, int64_t lda, double* d_dev, d
   int dev = 0, cus = 0;
   SCL_HIP(ctx, hipGetDevice(&dev));
   SCL_HIP(ctx, hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
-  int G = (int)std::min<int64_t>(cus > 0 ? cus : 64, n / (2 * SB) + 1);
+  // (at most half the CUs: three workgroups fit a CU, so the chases of up to six concurrent streams stay co-resident; the
+  // pipeline is bound by the lag between consecutive sweeps, not by the number of workgroups -- DESIGN.md)
+  int G = (int)std::min<int64_t>(cus > 0 ? cus / 2 : 64, n / (2 * SB) + 1);
   if (G < 1) G = 1;
   if (const char* eg = getenv("SCLENS_HIP_CHASE_WGS")) G = std::max(1, std::min(G, atoi(eg)));
   SbrChaseArgs ca{Bd, n, V2, ldv2, TAU2, ldt, done};
@@ -1182,7 +1184,7 @@ __global__ void sbr_copy_f64(const double* __restrict__ in, double* __restrict__
 int eig_values_two_stage(Ctx* ctx, const float* A, int64_t n, int64_t lda, double* w64_dev, int* used) {
   *used = 0;
   const int64_t np = round_up(n, SB);
-  if (np < 2 * SB || np > 38000) return SCLENS_OK;  // 38000: the reference second back-transformation keeps a vector in LDS
+  if (np < 2 * SB || np > 120000) return SCLENS_OK;  // 120000: 32-bit byte offsets of the packed band in sbr_chase
   const int64_t ldp = np;
   SCL_WS(ctx, Ap, float, "sbr.Ap", np * ldp);
   SCL_WS(ctx, Tall, float, "sbr.Tall", (np / SB) * SB * SB);

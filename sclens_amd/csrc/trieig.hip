@@ -332,8 +332,10 @@ int stein_f64(Ctx* ctx, const double* d_dev, const double* e_dev, int64_t n, con
   StageTimer tm(ctx, "stein");
   double* info = static_cast<double*>(ctx->workspace("tri.info", 8 * sizeof(double)));  // filled by stebz_f64
   if (!info) return SCLENS_ERR_OOM;
-  // batch so that the six [n][B] workspaces stay below ~6 GiB
-  int64_t B = (int64_t)(6.0e9 / (41.0 * (double)n));
+  // batch so that the six [n][B] workspaces stay below ~24 GB (one thread per eigenvector and a sequential recurrence of
+  // length n: the kernel is latency-bound, so the batch should cover all requested vectors -- 15 008 vectors of order
+  // 30 016 in four batches of 76 waves took 280 ms, in one batch of 235 waves 70 ms)
+  int64_t B = (int64_t)(24.0e9 / (41.0 * (double)n));
   B = B / 64 * 64;
   if (B < 64) B = 64;
   if (B > round_up(m, 64)) B = round_up(m, 64);
@@ -493,7 +495,11 @@ __global__ __launch_bounds__(256) void k_mgs_rows(float* __restrict__ Zt, int64_
 int eig_values(Ctx* ctx, float* A, int64_t n, int64_t lda, double* w64_dev) {
   if (n <= 0) return SCLENS_OK;
   ctx->last_two_stage = false;
-  if (ctx->two_stage) {
+  // two_stage: 1 = always (orders >= 128), 0 = never, -1 (default) = from the order: the one-stage reduction streams the
+  // trailing matrix once per column (2/3 n^3 bytes) and wins while that fits the caches / overlaps across streams; measured
+  // cross-over between n = 10^4 (one-stage 0.42 s vs two-stage 0.41 s with n/2 vectors) and n = 3 * 10^4 (5.3 s vs 2.7 s)
+  static const int64_t min_n = getenv("SCLENS_HIP_TWO_STAGE_MIN_N") ? atoll(getenv("SCLENS_HIP_TWO_STAGE_MIN_N")) : 16000;
+  if (ctx->two_stage == 1 || (ctx->two_stage < 0 && n >= min_n)) {
     int used = 0;
     SCL_TRY(eig_values_two_stage(ctx, A, n, lda, w64_dev, &used));
     if (used) {
