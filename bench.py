@@ -217,7 +217,8 @@ def main():
     ap.add_argument("--row-shard", action="store_true",
                     help="cells > genes configs on N > 1 GPUs: every rank holds a block of cells, partial Gram matrices are "
                          "all-reduced (SURVEY 8e-iii, sclens_amd/atlas.py) instead of distributing whole decompositions")
-    ap.add_argument("--streams", type=int, default=3, help="concurrent decompositions per GPU (worker sessions on own HIP streams)")
+    ap.add_argument("--streams", type=int, default=None,
+                    help="concurrent decompositions per GPU (worker sessions on own HIP streams); default: 3 below n = 16 000, else 1")
     ap.add_argument("--extra-configs", default="", help="comma-separated further configs timed once each after the main one (reported under `extra`)")
     ap.add_argument("--verbose", action="store_true")
     ap.add_argument("--stage-timing", action="store_true", help="per-stage HIP-event totals on stderr (adds syncs)")
@@ -332,6 +333,7 @@ def main():
     if rank == 0:
         ms_per_step = dt / max(1, steps) * 1e3
         row_shard = main_r["row_shard"]
+        n_streams = args.streams if args.streams is not None else (3 if min(N, M) < 16000 else 1)
         out = {
             "metric": "sclens() cells*genes/s (wall-clock of one full sclens() call)", "value": round(N * M * steps / dt, 1),
             "unit": "cells*genes/s", "n_gpus": world, "steps": steps, "warmup": main_r["warmup"],
@@ -343,8 +345,8 @@ def main():
                                    f"perturbation ensemble", "N": N, "M": M, "nnz": int(X.nnz), "n_perturb": args.n_perturb,
                        "parallelism": (f"cells row-sharded over {world} ranks: per decomposition 4 small all-reduces + one "
                                        f"all-reduce of the {M}x{M} fp32 partial Gram matrix, eigen-solver replicated" if row_shard
-                                       else f"single GPU, {args.streams} concurrent decompositions (HIP streams)" if world == 1 else
-                                       f"search rounds of {world}x{args.streams} + ensemble t%{world}, 1 RCCL all-gather "
+                                       else f"single GPU, {n_streams} concurrent decompositions (HIP streams)" if world == 1 else
+                                       f"search rounds of {world}x{n_streams} + ensemble t%{world}, 1 RCCL all-gather "
                                        f"({shard.staging}-staged)")},
             "sclens_wall_s": round(dt / max(1, steps), 3),
             "observed": {"signals": int(len(res.get("signal_ev", []))), "robust_signals": int(len(res.get("sig_id", []))),
