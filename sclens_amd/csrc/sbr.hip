@@ -495,60 +495,159 @@ int sy2sb_f32(Ctx* ctx, float* A, int64_t n, int64_t lda, float* Tall, int* brea
 // z_A = H_0 (H_1 (... H_{P-1} z_B)), H_p = I - V_p T_p V_p' on the coordinates >= r0_p. In row form, per panel from the
 // last to the first:  Zt[:, r0:] -= ((Zt[:, r0:] V) T') V'  -- three GEMMs, the first one split over K in one launch and
 // summed by the second through an S-fold replicated T (the scheme of ormtr_f32).
-__global__ void sbr_rep_t(const float* __restrict__ Tall, int64_t npan, int S, float* __restrict__ Trep) {
-  // Trep[p][j][s * SB + i] = T_p[j][i]
-  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const int64_t per = (int64_t)SB * S * SB;
-  if (idx >= npan * per) return;
-  const int64_t p = idx / per, rem = idx % per;
-  const int j = (int)(rem / (S * SB)), c = (int)(rem % (S * SB)), i = c % SB;
-  Trep[idx] = Tall[p * SB * SB + j * SB + i];
+// Panels are applied in groups of Q1G = 4: H_a H_{a+1} H_{a+2} H_{a+3} = I - Vm Tm Vm' with Vm = [V_a .. V_{a+3}] (each later
+// block starting 64 rows further down: a zero staircase) and the block upper triangular Tm whose diagonal blocks are the
+// panels' own T factors and whose off-diagonal blocks follow the larft recurrence Tm[0:j, j] = -Tm[0:j, 0:j] (Vm[0:j]' V_j) T_j.
+// A group therefore costs three products with a 256-deep inner dimension instead of twelve with 64: the traffic of Z (read once
+// by the first product, read + written by the last) per unit of work drops fourfold, which is what bounds the unmerged form.
+constexpr int Q1G = 4, Q1W = Q1G * SB;
+
+// clean copies of the group's reflectors: Vm[c][i] (c = 64 q + j: reflector j of panel q, i = position relative to the FIRST
+// panel's r0) and its transpose VmT[i][c]; entries above a panel's own start (i < 64 q) and rows of missing panels are zero
+__global__ __launch_bounds__(256) void sbr_q1_build_vm(const float* __restrict__ A, int64_t lda, int64_t c0, int cnt, int64_t np,
+                                                       float* __restrict__ Vm, int64_t ldv, float* __restrict__ VmT) {
+  __shared__ float tile[32][33];
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+  const int64_t i0 = (int64_t)blockIdx.x * 32;
+  const int cb = blockIdx.y * 32;
+  for (int r = ty; r < 32; r += 8) {
+    const int c = cb + r, q = c >> 6;
+    const int64_t i = i0 + tx;
+    float v = 0.f;
+    if (q < cnt && i < np && i >= (int64_t)q * SB) v = A[(c0 + c) * lda + (c0 + SB) + i];
+    tile[r][tx] = v;
+    if (i < ldv) Vm[(int64_t)c * ldv + i] = (i < np) ? v : 0.f;
+  }
+  __syncthreads();
+  for (int r = ty; r < 32; r += 8) {
+    const int64_t i = i0 + r;
+    if (i < np) VmT[i * Q1W + cb + tx] = tile[tx][r];
+  }
+}
+
+// Tm from the Gram matrix of the group's reflectors (split-K slabs, summed in a fixed order) and the panels' T factors; also
+// written S-fold replicated along the contraction (Trep[c2][s * Q1W + c] = Tm[c2][c]) for the product that sums the split-K
+// slabs of W1. One workgroup; fp32 in, fp64 accumulation.
+__global__ __launch_bounds__(256) void sbr_q1_merge_t(const float* __restrict__ Gp, int nslab, const float* __restrict__ Tp, int cnt,
+                                                      float* __restrict__ Tm, float* __restrict__ Trep, int S) {
+  extern __shared__ float sh[];
+  float* X = sh;                     // [<= 192][64]  Vm[0:j]' V_j, then the result block
+  float* R = sh + 3 * SB * SB;       // [<= 192][64]  X T_j
+  const int tid = threadIdx.x;
+  for (int idx = tid; idx < Q1W * Q1W; idx += 256) {
+    const int r = idx / Q1W, c = idx % Q1W;
+    float v = 0.f;
+    if ((r >> 6) == (c >> 6) && (r >> 6) < cnt) v = Tp[(int64_t)(r >> 6) * SB * SB + (r & 63) * SB + (c & 63)];
+    Tm[idx] = v;
+  }
+  __threadfence_block();
+  __syncthreads();
+  for (int j = 1; j < cnt; ++j) {
+    const int rows = j * SB;
+    // X = G[0:rows, block j]
+    for (int idx = tid; idx < rows * SB; idx += 256) {
+      const int r = idx >> 6, c = idx & 63;
+      double g = 0.0;
+      for (int q = 0; q < nslab; ++q) g += (double)Gp[(int64_t)q * Q1W * Q1W + r * Q1W + j * SB + c];
+      X[idx] = (float)g;
+    }
+    __syncthreads();
+    // R = X T_j
+    const float* Tj = Tp + (int64_t)j * SB * SB;
+    for (int idx = tid; idx < rows * SB; idx += 256) {
+      const int r = idx >> 6, c = idx & 63;
+      double acc = 0.0;
+      for (int k = 0; k <= c; ++k) acc += (double)X[r * SB + k] * (double)Tj[k * SB + c];  // T_j upper triangular
+      R[idx] = (float)acc;
+    }
+    __syncthreads();
+    // Tm[0:rows, block j] = -Tm[0:rows, 0:rows] R   (Tm[0:rows, 0:rows] upper triangular: k >= r)
+    for (int idx = tid; idx < rows * SB; idx += 256) {
+      const int r = idx >> 6, c = idx & 63;
+      double acc = 0.0;
+      for (int k = r; k < rows; ++k) acc += (double)Tm[r * Q1W + k] * (double)R[k * SB + c];
+      X[idx] = (float)(-acc);
+    }
+    __syncthreads();
+    for (int idx = tid; idx < rows * SB; idx += 256) Tm[(idx >> 6) * Q1W + j * SB + (idx & 63)] = X[idx];
+    __threadfence_block();
+    __syncthreads();
+  }
+  for (int idx = tid; idx < Q1W * Q1W; idx += 256) {
+    const float v = Tm[idx];
+    const int r = idx / Q1W, c = idx % Q1W;
+    for (int q = 0; q < S; ++q) Trep[(int64_t)r * S * Q1W + q * Q1W + c] = v;
+  }
 }
 
 int sbr_apply_q1(Ctx* ctx, const float* A, int64_t n, int64_t lda, const float* Tall, float* Zt, int64_t m, int64_t ldz) {
   if (m <= 0) return SCLENS_OK;
   if (n % SB != 0) return ctx->fail(SCLENS_ERR_ARG, "sbr_apply_q1: the order must be a multiple of 64");
+  if (ldz % 4 != 0 || (reinterpret_cast<uintptr_t>(Zt) & 15u))
+    return ctx->fail(SCLENS_ERR_ARG, "sbr_apply_q1: Zt must be 16-byte aligned with ldz a multiple of 4");
   StageTimer tm(ctx, "sbr_q1");
   const int64_t npan = n / SB - 1;
   if (npan <= 0) return SCLENS_OK;
-  const int64_t tiles_m = (m + 127) / 128;
-  int S = (int)((512 + tiles_m - 1) / tiles_m);
-  if (S < 1) S = 1;
-  if (S > 16) S = 16;
-  SCL_WS(ctx, Trep, float, "sbr.Trep", npan * SB * (int64_t)S * SB);
-  SCL_WS(ctx, W1, float, "sbr.W1", m * (int64_t)S * SB);
-  SCL_WS(ctx, W2, float, "sbr.W2", m * SB);
-  {
-    const int64_t tot = npan * SB * (int64_t)S * SB;
-    hipLaunchKernelGGL(sbr_rep_t, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, ctx->stream, Tall, npan, S, Trep);
-  }
-  for (int64_t p = npan - 1; p >= 0; --p) {
-    const int64_t c0 = p * SB, r0 = c0 + SB, np = n - r0;
-    const float* Vt = A + c0 * lda + r0;  // [SB][np], row stride lda
-    {
-      GemmArgs g{};
-      g.P = Zt + r0; g.Q = Vt; g.C = W1;
-      g.M = m; g.N = SB; g.K = np;
-      g.ldp = ldz; g.ldq = lda; g.ldc = (int64_t)S * SB;
-      g.alpha = 1.f; g.beta = 0.f; g.q_kcontig = 1; g.lower = 0; g.colabsmax = nullptr;
-      g.splits = S; g.k_chunk = round_up((np + S - 1) / S, 16); g.c_split_off = SB;
-      SCL_TRY(gemm_f32(ctx, g));
+  const int64_t ngrp = (npan + Q1G - 1) / Q1G;
+  const int64_t ldv = round_up(n, 32);
+  const int64_t tiles_m = (m + 255) / 256;
+  int S = (int)std::min<int64_t>(16, std::max<int64_t>(1, (512 + tiles_m - 1) / tiles_m));
+  const int SG = 16;  // K-slices of the 256 x 256 Gram product
+  SCL_WS(ctx, Vm, float, "sbr.Vm", Q1W * ldv);
+  SCL_WS(ctx, VmT, float, "sbr.VmT", ldv * Q1W);
+  SCL_WS(ctx, Gp, float, "sbr.q1G", (int64_t)SG * Q1W * Q1W);
+  SCL_WS(ctx, Tm, float, "sbr.q1T", Q1W * Q1W);
+  SCL_WS(ctx, Trep, float, "sbr.Trep", (int64_t)Q1W * S * Q1W);
+  SCL_WS(ctx, W1, float, "sbr.W1", m * (int64_t)S * Q1W);
+  SCL_WS(ctx, W2, float, "sbr.W2", m * Q1W);
+  hipStream_t st = ctx->stream;
+  static const hipError_t attr_rc = hipFuncSetAttribute(reinterpret_cast<const void*>(sbr_q1_merge_t),
+                                                        hipFuncAttributeMaxDynamicSharedMemorySize, 6 * SB * SB * (int)sizeof(float));
+  SCL_HIP(ctx, attr_rc);
+  for (int64_t g = ngrp - 1; g >= 0; --g) {
+    const int64_t p0 = g * Q1G;
+    const int cnt = (int)std::min<int64_t>(Q1G, npan - p0);
+    const int64_t c0 = p0 * SB, r0 = c0 + SB, np = n - r0;
+    hipLaunchKernelGGL(sbr_q1_build_vm, dim3((unsigned)((ldv + 31) / 32), Q1W / 32), dim3(256), 0, st, A, lda, c0, cnt, np, Vm, ldv, VmT);
+    {  // Gram matrix of the group's reflectors, split over K
+      GemmArgs gm{};
+      gm.P = Vm; gm.Q = Vm; gm.C = Gp;
+      gm.M = Q1W; gm.N = Q1W; gm.K = np;
+      gm.ldp = ldv; gm.ldq = ldv; gm.ldc = Q1W;
+      gm.alpha = 1.f; gm.beta = 0.f; gm.q_kcontig = 1; gm.lower = 0; gm.colabsmax = nullptr;
+      gm.splits = SG; gm.k_chunk = round_up((np + SG - 1) / SG, 32); gm.c_split_off = (int64_t)Q1W * Q1W;
+      SCL_TRY(gemm_f32(ctx, gm));
     }
-    {
-      GemmArgs g{};
-      g.P = W1; g.Q = Trep + p * SB * ((int64_t)S * SB); g.C = W2;
-      g.M = m; g.N = SB; g.K = (int64_t)S * SB;
-      g.ldp = (int64_t)S * SB; g.ldq = (int64_t)S * SB; g.ldc = SB;
-      g.alpha = 1.f; g.beta = 0.f; g.q_kcontig = 1; g.lower = 0; g.colabsmax = nullptr;
-      SCL_TRY(gemm_f32(ctx, g));
+    const int nsl = (int)((np + round_up((np + SG - 1) / SG, 32) - 1) / round_up((np + SG - 1) / SG, 32));
+    hipLaunchKernelGGL(sbr_q1_merge_t, dim3(1), dim3(256), 6 * SB * SB * sizeof(float), st, Gp, nsl, Tall + p0 * SB * SB, cnt, Tm,
+                       Trep, S);
+    const int64_t kch = round_up((np + S - 1) / S, 32);
+    {  // W1[m][s][256] = split-K partials of Zt[:, r0:] Vm'
+      GemmArgs g1{};
+      g1.P = Zt + r0; g1.Q = Vm; g1.C = W1;
+      g1.M = m; g1.N = Q1W; g1.K = np;
+      g1.ldp = ldz; g1.ldq = ldv; g1.ldc = (int64_t)S * Q1W;
+      g1.alpha = 1.f; g1.beta = 0.f; g1.q_kcontig = 1; g1.lower = 0; g1.colabsmax = nullptr;
+      g1.splits = S; g1.k_chunk = kch; g1.c_split_off = Q1W;
+      g1.prefer_big = 1;
+      SCL_TRY(gemm_f32(ctx, g1));
     }
-    {
-      GemmArgs g{};
-      g.P = W2; g.Q = Vt; g.C = Zt + r0;
-      g.M = m; g.N = np; g.K = SB;
-      g.ldp = SB; g.ldq = lda; g.ldc = ldz;
-      g.alpha = -1.f; g.beta = 1.f; g.q_kcontig = 0; g.lower = 0; g.colabsmax = nullptr;
-      SCL_TRY(gemm_f32(ctx, g));
+    {  // W2 = (sum_s W1_s) Tm'  (NT with the S-fold replicated Tm; slices beyond np contributed zeros)
+      GemmArgs g2{};
+      g2.P = W1; g2.Q = Trep; g2.C = W2;
+      g2.M = m; g2.N = Q1W; g2.K = (int64_t)S * Q1W;
+      g2.ldp = (int64_t)S * Q1W; g2.ldq = (int64_t)S * Q1W; g2.ldc = Q1W;
+      g2.alpha = 1.f; g2.beta = 0.f; g2.q_kcontig = 1; g2.lower = 0; g2.colabsmax = nullptr;
+      SCL_TRY(gemm_f32(ctx, g2));
+    }
+    {  // Zt[:, r0:] -= W2 Vm   (NT against the transposed copy)
+      GemmArgs g3{};
+      g3.P = W2; g3.Q = VmT; g3.C = Zt + r0;
+      g3.M = m; g3.N = np; g3.K = Q1W;
+      g3.ldp = Q1W; g3.ldq = Q1W; g3.ldc = ldz;
+      g3.alpha = -1.f; g3.beta = 1.f; g3.q_kcontig = 1; g3.lower = 0; g3.colabsmax = nullptr;
+      g3.prefer_big = 1;
+      SCL_TRY(gemm_f32(ctx, g3));
     }
   }
   SCL_HIP(ctx, hipGetLastError());
