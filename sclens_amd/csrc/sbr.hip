@@ -525,59 +525,89 @@ __global__ __launch_bounds__(256) void sbr_q1_build_vm(const float* __restrict__
   }
 }
 
-// Tm from the Gram matrix of the group's reflectors (split-K slabs, summed in a fixed order) and the panels' T factors; also
-// written S-fold replicated along the contraction (Trep[c2][s * Q1W + c] = Tm[c2][c]) for the product that sums the split-K
-// slabs of W1. One workgroup; fp32 in, fp64 accumulation.
-__global__ __launch_bounds__(256) void sbr_q1_merge_t(const float* __restrict__ Gp, int nslab, const float* __restrict__ Tp, int cnt,
-                                                      float* __restrict__ Tm, float* __restrict__ Trep, int S) {
-  extern __shared__ float sh[];
-  float* X = sh;                     // [<= 192][64]  Vm[0:j]' V_j, then the result block
-  float* R = sh + 3 * SB * SB;       // [<= 192][64]  X T_j
-  const int tid = threadIdx.x;
-  for (int idx = tid; idx < Q1W * Q1W; idx += 256) {
-    const int r = idx / Q1W, c = idx % Q1W;
-    float v = 0.f;
-    if ((r >> 6) == (c >> 6) && (r >> 6) < cnt) v = Tp[(int64_t)(r >> 6) * SB * SB + (r & 63) * SB + (c & 63)];
-    Tm[idx] = v;
+// G = sum of the split-K slabs of the group's Gram matrix, in a fixed order
+__global__ __launch_bounds__(256) void sbr_q1_sum_g(const float* __restrict__ Gp, int nslab, float* __restrict__ G) {
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  float s = 0.f;
+  for (int q = 0; q < nslab; ++q) s += Gp[(int64_t)q * Q1W * Q1W + idx];
+  G[idx] = s;
+}
+
+// Tm, one block diagonal at a time (level 0 = the panels' own T factors, level d = the blocks (a, a + d)):
+//   Tm[a][b] = -( sum_{q = a}^{b-1} Tm[a][q] G[q][b] ) T_b,
+// one workgroup per 64 x 64 block, operands staged in LDS, fp64 accumulation. Launched once per level (the blocks of a level
+// only need lower levels).
+__global__ __launch_bounds__(256) void sbr_q1_merge_level(const float* __restrict__ G, const float* __restrict__ Tp, int cnt, int level,
+                                                          float* __restrict__ Tm) {
+  __shared__ float Ls[SB][SB + 1], Rs[SB][SB + 1];
+  const int a = blockIdx.x, b = a + level, tid = threadIdx.x, ti = tid >> 4, tj = tid & 15;
+  if (level == 0) {  // diagonal blocks, and zero everything else of block row a (upper part is filled by the later levels)
+    for (int idx = tid; idx < SB * Q1W; idx += 256) {
+      const int r = idx / Q1W, c = idx % Q1W;
+      Tm[(a * SB + r) * Q1W + c] = ((c >> 6) == a && a < cnt) ? Tp[(int64_t)a * SB * SB + r * SB + (c & 63)] : 0.f;
+    }
+    return;
   }
-  __threadfence_block();
+  if (b >= cnt) return;
+  double acc[4][4];
+#pragma unroll
+  for (int u = 0; u < 4; ++u)
+#pragma unroll
+    for (int v = 0; v < 4; ++v) acc[u][v] = 0.0;
+  for (int q = a; q < b; ++q) {  // acc += Tm[a][q] G[q][b]
+    for (int idx = tid; idx < SB * SB; idx += 256) {
+      const int r = idx >> 6, c = idx & 63;
+      Ls[r][c] = Tm[(a * SB + r) * Q1W + q * SB + c];
+      Rs[r][c] = G[(q * SB + r) * Q1W + b * SB + c];
+    }
+    __syncthreads();
+    for (int k = 0; k < SB; ++k) {
+      float l[4], r4[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) l[u] = Ls[4 * ti + u][k];
+#pragma unroll
+      for (int v = 0; v < 4; ++v) r4[v] = Rs[k][4 * tj + v];
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int v = 0; v < 4; ++v) acc[u][v] += (double)l[u] * (double)r4[v];
+    }
+    __syncthreads();
+  }
+  // X = acc (to LDS), then Tm[a][b] = -X T_b
+  for (int idx = tid; idx < SB * SB; idx += 256) Rs[idx >> 6][idx & 63] = Tp[(int64_t)b * SB * SB + idx];
+#pragma unroll
+  for (int u = 0; u < 4; ++u)
+#pragma unroll
+    for (int v = 0; v < 4; ++v) Ls[4 * ti + u][4 * tj + v] = (float)acc[u][v];
   __syncthreads();
-  for (int j = 1; j < cnt; ++j) {
-    const int rows = j * SB;
-    // X = G[0:rows, block j]
-    for (int idx = tid; idx < rows * SB; idx += 256) {
-      const int r = idx >> 6, c = idx & 63;
-      double g = 0.0;
-      for (int q = 0; q < nslab; ++q) g += (double)Gp[(int64_t)q * Q1W * Q1W + r * Q1W + j * SB + c];
-      X[idx] = (float)g;
-    }
-    __syncthreads();
-    // R = X T_j
-    const float* Tj = Tp + (int64_t)j * SB * SB;
-    for (int idx = tid; idx < rows * SB; idx += 256) {
-      const int r = idx >> 6, c = idx & 63;
-      double acc = 0.0;
-      for (int k = 0; k <= c; ++k) acc += (double)X[r * SB + k] * (double)Tj[k * SB + c];  // T_j upper triangular
-      R[idx] = (float)acc;
-    }
-    __syncthreads();
-    // Tm[0:rows, block j] = -Tm[0:rows, 0:rows] R   (Tm[0:rows, 0:rows] upper triangular: k >= r)
-    for (int idx = tid; idx < rows * SB; idx += 256) {
-      const int r = idx >> 6, c = idx & 63;
-      double acc = 0.0;
-      for (int k = r; k < rows; ++k) acc += (double)Tm[r * Q1W + k] * (double)R[k * SB + c];
-      X[idx] = (float)(-acc);
-    }
-    __syncthreads();
-    for (int idx = tid; idx < rows * SB; idx += 256) Tm[(idx >> 6) * Q1W + j * SB + (idx & 63)] = X[idx];
-    __threadfence_block();
-    __syncthreads();
+#pragma unroll
+  for (int u = 0; u < 4; ++u)
+#pragma unroll
+    for (int v = 0; v < 4; ++v) acc[u][v] = 0.0;
+  for (int k = 0; k < SB; ++k) {
+    float l[4], r4[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) l[u] = Ls[4 * ti + u][k];
+#pragma unroll
+    for (int v = 0; v < 4; ++v) r4[v] = Rs[k][4 * tj + v];
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+      for (int v = 0; v < 4; ++v) acc[u][v] += (double)l[u] * (double)r4[v];
   }
-  for (int idx = tid; idx < Q1W * Q1W; idx += 256) {
-    const float v = Tm[idx];
-    const int r = idx / Q1W, c = idx % Q1W;
-    for (int q = 0; q < S; ++q) Trep[(int64_t)r * S * Q1W + q * Q1W + c] = v;
-  }
+#pragma unroll
+  for (int u = 0; u < 4; ++u)
+#pragma unroll
+    for (int v = 0; v < 4; ++v) Tm[(a * SB + 4 * ti + u) * Q1W + b * SB + 4 * tj + v] = (float)(-acc[u][v]);
+}
+
+// Trep[c2][s * Q1W + c] = Tm[c2][c]: the S-fold copy along the contraction that sums the split-K slabs of W1
+__global__ __launch_bounds__(256) void sbr_q1_rep_t(const float* __restrict__ Tm, int S, float* __restrict__ Trep) {
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  const float v = Tm[idx];
+  const int r = idx / Q1W, c = idx % Q1W;
+  for (int q = 0; q < S; ++q) Trep[(int64_t)r * S * Q1W + q * Q1W + c] = v;
 }
 
 int sbr_apply_q1(Ctx* ctx, const float* A, int64_t n, int64_t lda, const float* Tall, float* Zt, int64_t m, int64_t ldz) {
@@ -592,18 +622,16 @@ int sbr_apply_q1(Ctx* ctx, const float* A, int64_t n, int64_t lda, const float* 
   const int64_t ldv = round_up(n, 32);
   const int64_t tiles_m = (m + 255) / 256;
   int S = (int)std::min<int64_t>(16, std::max<int64_t>(1, (512 + tiles_m - 1) / tiles_m));
-  const int SG = 16;  // K-slices of the 256 x 256 Gram product
+  const int SG = 64;  // K-slices of the 256 x 256 Gram product (one output tile: the slices are the only parallelism)
   SCL_WS(ctx, Vm, float, "sbr.Vm", Q1W * ldv);
   SCL_WS(ctx, VmT, float, "sbr.VmT", ldv * Q1W);
   SCL_WS(ctx, Gp, float, "sbr.q1G", (int64_t)SG * Q1W * Q1W);
   SCL_WS(ctx, Tm, float, "sbr.q1T", Q1W * Q1W);
+  SCL_WS(ctx, Gs, float, "sbr.q1Gs", Q1W * Q1W);
   SCL_WS(ctx, Trep, float, "sbr.Trep", (int64_t)Q1W * S * Q1W);
   SCL_WS(ctx, W1, float, "sbr.W1", m * (int64_t)S * Q1W);
   SCL_WS(ctx, W2, float, "sbr.W2", m * Q1W);
   hipStream_t st = ctx->stream;
-  static const hipError_t attr_rc = hipFuncSetAttribute(reinterpret_cast<const void*>(sbr_q1_merge_t),
-                                                        hipFuncAttributeMaxDynamicSharedMemorySize, 6 * SB * SB * (int)sizeof(float));
-  SCL_HIP(ctx, attr_rc);
   for (int64_t g = ngrp - 1; g >= 0; --g) {
     const int64_t p0 = g * Q1G;
     const int cnt = (int)std::min<int64_t>(Q1G, npan - p0);
@@ -618,9 +646,10 @@ int sbr_apply_q1(Ctx* ctx, const float* A, int64_t n, int64_t lda, const float* 
       gm.splits = SG; gm.k_chunk = round_up((np + SG - 1) / SG, 32); gm.c_split_off = (int64_t)Q1W * Q1W;
       SCL_TRY(gemm_f32(ctx, gm));
     }
-    const int nsl = (int)((np + round_up((np + SG - 1) / SG, 32) - 1) / round_up((np + SG - 1) / SG, 32));
-    hipLaunchKernelGGL(sbr_q1_merge_t, dim3(1), dim3(256), 6 * SB * SB * sizeof(float), st, Gp, nsl, Tall + p0 * SB * SB, cnt, Tm,
-                       Trep, S);
+    hipLaunchKernelGGL(sbr_q1_sum_g, dim3(Q1W * Q1W / 256), dim3(256), 0, st, Gp, SG, Gs);
+    for (int level = 0; level < cnt; ++level)
+      hipLaunchKernelGGL(sbr_q1_merge_level, dim3(level == 0 ? Q1G : Q1G - level), dim3(256), 0, st, Gs, Tall + p0 * SB * SB, cnt, level, Tm);
+    hipLaunchKernelGGL(sbr_q1_rep_t, dim3(Q1W * Q1W / 256), dim3(256), 0, st, Tm, S, Trep);
     const int64_t kch = round_up((np + S - 1) / S, 32);
     {  // W1[m][s][256] = split-K partials of Zt[:, r0:] Vm'
       GemmArgs g1{};
