@@ -135,14 +135,18 @@ int eigh_f32(Ctx* ctx, float* A, int64_t n, int64_t lda, double* w64_dev, int64_
              int64_t vec_hi, float* Zt, int64_t ldz);
 
 // the same in two phases (values first, vectors of a range chosen afterwards); state lives in ctx workspaces
-int eig_values(Ctx* ctx, float* A, int64_t n, int64_t lda, double* w64_dev);
+// n_low >= 0: only the n_low smallest eigenvalues and the largest one are computed (the others are NaN in w64_dev)
+int eig_values(Ctx* ctx, float* A, int64_t n, int64_t lda, double* w64_dev, int64_t n_low = -1);
 int eig_vectors(Ctx* ctx, const float* A, int64_t n, int64_t lda, const double* w64_dev, int64_t vec_lo,
                 int64_t vec_hi, float* Zt, int64_t ldz);
+int eig_values_redo_all(Ctx* ctx, int64_t n, double* w64_dev);
+int eig_values_two_stage_redo(Ctx* ctx, int64_t n, double* w64_dev);
 
 // pieces (exposed for unit tests through the C ABI)
 int sytrd_f32(Ctx* ctx, float* A, int64_t n, int64_t lda, double* d_dev, double* e_dev,
               float* tau_dev);
-int stebz_f64(Ctx* ctx, const double* d_dev, const double* e_dev, int64_t n, double* w_dev);
+// n_low >= 0: only the indices [0, n_low) and k_top (default n - 1); the other entries of w_dev become NaN
+int stebz_f64(Ctx* ctx, const double* d_dev, const double* e_dev, int64_t n, double* w_dev, int64_t n_low = -1, int64_t k_top = -1);
 int stein_f64(Ctx* ctx, const double* d_dev, const double* e_dev, int64_t n, const double* w_dev,
               int64_t lo, int64_t hi, float* Zt, int64_t ldz);
 int ormtr_f32(Ctx* ctx, const float* A, int64_t n, int64_t lda, const float* tau_dev, float* Zt,
@@ -160,7 +164,7 @@ int preprocess_gather(Ctx* ctx, int64_t* out_colptr, int32_t* out_rowval, float*
 int sy2sb_f32(Ctx* ctx, float* A, int64_t n, int64_t lda, float* Tall, int* breakdown);
 int sbr_apply_q1(Ctx* ctx, const float* A, int64_t n, int64_t lda, const float* Tall, float* Zt, int64_t m, int64_t ldz);
 int sbr_apply_q2(Ctx* ctx, int64_t n, float* Zt, int64_t m, int64_t ldz);
-int eig_values_two_stage(Ctx* ctx, const float* A, int64_t n, int64_t lda, double* w64_dev, int* used);
+int eig_values_two_stage(Ctx* ctx, const float* A, int64_t n, int64_t lda, double* w64_dev, int* used, int64_t n_low = -1);
 int eig_vectors_two_stage(Ctx* ctx, int64_t n, int64_t vec_lo, int64_t vec_hi, float* Zt, int64_t ldz);
 int sb2st_f32(Ctx* ctx, const float* A, int64_t n, int64_t lda, double* d_dev, double* e_dev);
 BatchGroup* batch_create();

@@ -399,6 +399,216 @@ __global__ __launch_bounds__(256) void sbr_small_s(const double* __restrict__ pa
   for (int idx = tid; idx < SB * SB; idx += 256) Sh[idx] = 0.5 * R[idx];
 }
 
+// ---- tall-skinny algebra of a panel on the matrix cores ------------------------------------------------------------------
+// All "n' x 64 times 64 x 64" and "64 x n' times n' x 64" products of a panel run on `v_mfma_*_16x16x4` (f64 where the
+// Cholesky QR needs it, f32 otherwise), one wave per tile of 16 positions of the long dimension, the 64 x 64 factor held in
+// registers as MFMA operands. Layouts: Pt = the panel in the transposed storage of A ([64][lda], long dimension contiguous:
+// what the NT GEMMs want as their 64-row operand), everything else row-major [n'][64] (what an MFMA operand with the long
+// dimension on the lanes of a quad reads in 64-byte runs).
+typedef double f64x4 __attribute__((ext_vector_type(4)));
+constexpr int SBR_RT = 16;          // positions per wave tile
+constexpr int SBR_GCH = 1024;       // positions per workgroup of the Gram kernels
+
+// part[wg][i][j] = sum over the workgroup's positions r of X[r][i] Y[r][j] (fp64), X / Y given as
+//   TRANSPOSED = true : Xt[i * ldx + r]   (the panel in A; X == Y: its Gram matrix)
+//   TRANSPOSED = false: X[r * 64 + i], Y[r * 64 + j]
+template <bool TRANSPOSED>
+__global__ __launch_bounds__(256) void sbr_gram64(const float* __restrict__ X, int64_t ldx, const float* __restrict__ Y, int64_t len,
+                                                  double* __restrict__ part) {
+  __shared__ double red[3][SB * SB / 4];  // waves 1..3 -> wave 0
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, l15 = lane & 15, kg = lane >> 4;
+  f64x4 acc[4][4];
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) acc[a][b] = f64x4{0.0, 0.0, 0.0, 0.0};
+  const int64_t r_begin = (int64_t)blockIdx.x * SBR_GCH + wv * (SBR_GCH / 4);
+  int64_t r_end = r_begin + SBR_GCH / 4;
+  if (r_end > len) r_end = len;
+  for (int64_t rb = r_begin; rb < r_end; rb += 16) {
+    // k-step e of this 16-position chunk: lane quad kg supplies position rb + 4 kg + e
+    float xa[4][4], yb[4][4];  // [tile][e]
+    if (TRANSPOSED) {
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const float* px = X + (int64_t)(16 * t + l15) * ldx + rb + 4 * kg;
+        if (rb + 4 * kg + 3 < r_end) {
+          const f32x4 v = *reinterpret_cast<const f32x4*>(px);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) xa[t][e] = v[e];
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) xa[t][e] = (rb + 4 * kg + e < r_end) ? px[e] : 0.f;
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) yb[t][e] = xa[t][e];
+      }
+    } else {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int64_t r = rb + 4 * kg + e;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          xa[t][e] = (r < r_end) ? X[r * SB + 16 * t + l15] : 0.f;
+          yb[t][e] = (r < r_end) ? Y[r * SB + 16 * t + l15] : 0.f;
+        }
+      }
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+#pragma unroll
+      for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b)
+          acc[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64((double)xa[a][e], (double)yb[b][e], acc[a][b], 0, 0, 0);
+  }
+  // D layout (f64): column = lane & 15, row = (lane >> 4) + 4 * reg. Waves 1..3 hand their sums to wave 0 (fixed order).
+  double* out = part + (int64_t)blockIdx.x * SB * SB;
+  for (int src = 1; src < 4; ++src) {
+    // four rounds of 4 tiles to stay inside the LDS budget
+    for (int a = 0; a < 4; ++a) {
+      __syncthreads();
+      if (wv == src) {
+#pragma unroll
+        for (int b = 0; b < 4; ++b)
+#pragma unroll
+          for (int g = 0; g < 4; ++g) red[0][(b * 4 + g) * 64 + lane] = acc[a][b][g];
+      }
+      __syncthreads();
+      if (wv == 0) {
+#pragma unroll
+        for (int b = 0; b < 4; ++b)
+#pragma unroll
+          for (int g = 0; g < 4; ++g) acc[a][b][g] += red[0][(b * 4 + g) * 64 + lane];
+      }
+    }
+  }
+  if (wv == 0) {
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+      for (int b = 0; b < 4; ++b)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) out[(16 * a + kg + 4 * g) * SB + 16 * b + l15] = acc[a][b][g];
+  }
+}
+
+// V2 = P2 * Mat (fp64 factor, fp64 accumulation): rows r >= SB of the panel. In place in the transposed storage
+// (Pt[j][r] <- sum_i Mat[i][j] Pt[i][r]) and as a row-major copy Vr[r][j]. One wave per 16 positions.
+__global__ __launch_bounds__(256) void sbr_vmul_f64(float* __restrict__ Pt, int64_t lda, const double* __restrict__ Mat, int64_t len,
+                                                    float* __restrict__ Vr) {
+  const int lane = threadIdx.x & 63, l15 = lane & 15, kg = lane >> 4;
+  const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int64_t r0 = SB + wave * SBR_RT;  // the top block (r < SB) is written by sbr_top_block
+  if (r0 >= len) return;
+  // A operand: A[j][k = i] = Mat[i][j], lane (j = l15 within tile jt, k = kg within step ks)
+  double am[16][4];
+#pragma unroll
+  for (int ks = 0; ks < 16; ++ks)
+#pragma unroll
+    for (int jt = 0; jt < 4; ++jt) am[ks][jt] = Mat[(4 * ks + kg) * SB + 16 * jt + l15];
+  const int64_t r = r0 + l15;
+  double bp[16];
+#pragma unroll
+  for (int ks = 0; ks < 16; ++ks) bp[ks] = (r < len) ? (double)Pt[(int64_t)(4 * ks + kg) * lda + r] : 0.0;
+  f64x4 acc[4];
+#pragma unroll
+  for (int jt = 0; jt < 4; ++jt) acc[jt] = f64x4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+  for (int ks = 0; ks < 16; ++ks)
+#pragma unroll
+    for (int jt = 0; jt < 4; ++jt) acc[jt] = __builtin_amdgcn_mfma_f64_16x16x4f64(am[ks][jt], bp[ks], acc[jt], 0, 0, 0);
+  // D[j = 16 jt + kg + 4 g][r = r0 + l15]
+  if (r < len) {
+#pragma unroll
+    for (int jt = 0; jt < 4; ++jt)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int j = 16 * jt + kg + 4 * g;
+        const float v = (float)acc[jt][g];
+        Pt[(int64_t)j * lda + r] = v;
+        Vr[r * SB + j] = v;
+      }
+  }
+}
+
+// top block of a panel: V1 (unit lower) into the transposed storage and the row-major copy, Rh into the band block of A
+__global__ __launch_bounds__(256) void sbr_top_block(float* __restrict__ Pt, int64_t lda, const float* __restrict__ V1,
+                                                     const float* __restrict__ Rh, float* __restrict__ band, float* __restrict__ Vr) {
+  for (int idx = threadIdx.x; idx < SB * SB; idx += 256) {
+    const int r = idx >> 6, j = idx & 63;
+    const float v = V1[r * SB + j];
+    Vr[r * SB + j] = v;
+    band[(int64_t)r * lda + j] = Rh[r * SB + j];
+  }
+  for (int idx = threadIdx.x; idx < SB * SB; idx += 256) {
+    const int j = idx >> 6, r = idx & 63;
+    Pt[(int64_t)j * lda + r] = V1[r * SB + j];
+  }
+}
+
+// out[r][j] = sum_i in[r][i] F[i][j] (f32 MFMA), in = the sum of `nslab` row-major slabs (fixed order).
+//   MODE 2: Yr = W T                      (in = split-K slabs of W)
+//   MODE 3: Z = Yr - Vr Sh  and the row-major operands of the rank-128 update: VW[r] = [V | Z], WV[r] = [Z | V]
+template <int MODE>
+__global__ __launch_bounds__(256) void sbr_rmul_f32(const float* __restrict__ in, int nslab, int64_t slab, const float* __restrict__ F32,
+                                                    const double* __restrict__ F64, int64_t len, float* __restrict__ out,
+                                                    const float* __restrict__ Yr, float* __restrict__ VW, float* __restrict__ WV) {
+  const int lane = threadIdx.x & 63, l15 = lane & 15, kg = lane >> 4;
+  const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int64_t r0 = wave * SBR_RT;
+  if (r0 >= len) return;
+  // k-step (q, e): lane quad kg carries i = 16 q + 4 kg + e (so that a lane's four e are one 16-byte load of `in`)
+  float bf[4][4][4];  // [q][e][jt]: B[k = i][j = 16 jt + l15]
+#pragma unroll
+  for (int q = 0; q < 4; ++q)
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+#pragma unroll
+      for (int jt = 0; jt < 4; ++jt) {
+        const int i = 16 * q + 4 * kg + e;
+        bf[q][e][jt] = (MODE == 2) ? F32[i * SB + 16 * jt + l15] : (float)F64[i * SB + 16 * jt + l15];
+      }
+  const int64_t r = r0 + l15;
+  f32x4 a4[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    f32x4 sacc = {0.f, 0.f, 0.f, 0.f};
+    if (r < len)
+      for (int sl = 0; sl < nslab; ++sl) sacc += *reinterpret_cast<const f32x4*>(in + (int64_t)sl * slab + r * SB + 16 * q + 4 * kg);
+    a4[q] = sacc;
+  }
+  f32x4 acc[4];
+#pragma unroll
+  for (int jt = 0; jt < 4; ++jt) acc[jt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int q = 0; q < 4; ++q)
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+#pragma unroll
+      for (int jt = 0; jt < 4; ++jt) acc[jt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[q][e], bf[q][e][jt], acc[jt], 0, 0, 0);
+  // D[r = r0 + 4 kg + g][j = 16 jt + l15]
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    const int64_t rr = r0 + 4 * kg + g;
+    if (rr >= len) continue;
+#pragma unroll
+    for (int jt = 0; jt < 4; ++jt) {
+      const int j = 16 * jt + l15;
+      if (MODE == 2) {
+        out[rr * SB + j] = acc[jt][g];
+      } else {
+        const float z = Yr[rr * SB + j] - acc[jt][g];
+        const float v = in[rr * SB + j];
+        VW[rr * (2 * SB) + j] = v;
+        VW[rr * (2 * SB) + SB + j] = z;
+        WV[rr * (2 * SB) + j] = z;
+        WV[rr * (2 * SB) + SB + j] = v;
+      }
+    }
+  }
+}
+
 // ---- host driver ------------------------------------------------------------------------------------------------------
 // A: n x n fp32 row-major, full symmetric storage, n a multiple of SB. On return: lower band (|i - j| <= SB) = the band
 // matrix, upper part = the panel reflectors V_p, Tall[p][SB][SB] = their T factors. *breakdown (host) != 0: a panel was
@@ -410,14 +620,15 @@ int sy2sb_f32(Ctx* ctx, float* A, int64_t n, int64_t lda, float* Tall, int* brea
   StageTimer tm(ctx, "sy2sb");
   const int64_t npan = n / SB - 1;  // the last diagonal block needs no reduction
   const int64_t ldw = round_up(n, 64);
-  const int64_t maxparts = (n + SBR_CHUNK - 1) / SBR_CHUNK + 1;
+  const int64_t maxparts = (n + SBR_GCH - 1) / SBR_GCH + 1;
   const int S = 16;  // at most this many K-slices of the skinny product W = A22 V
   SCL_WS(ctx, part, double, "sbr.part", maxparts * SB * SB);
   SCL_WS(ctx, psum, double, "sbr.psum", SB * SB);
   SCL_WS(ctx, Mat, double, "sbr.M", 2 * SB * SB);   // M | Sh
   SCL_WS(ctx, V1, float, "sbr.V1", 2 * SB * SB);    // V1 | Rh
   SCL_WS(ctx, Wp, float, "sbr.Wp", (int64_t)S * SB * ldw);
-  SCL_WS(ctx, Yt, float, "sbr.Yt", SB * ldw);
+  SCL_WS(ctx, Vr, float, "sbr.Vr", SB * ldw);
+  SCL_WS(ctx, Yr, float, "sbr.Yr", SB * ldw);
   SCL_WS(ctx, VW, float, "sbr.VW", n * 2 * SB);
   SCL_WS(ctx, WV, float, "sbr.WV", n * 2 * SB);
   SCL_WS(ctx, flag, int, "sbr.flag", 4);
@@ -430,18 +641,18 @@ int sy2sb_f32(Ctx* ctx, float* A, int64_t n, int64_t lda, float* Tall, int* brea
     const int64_t c0 = p * SB, r0 = c0 + SB, np = n - r0;
     float* Pt = A + c0 * lda + r0;  // transposed panel: Pt[j][i] = A[c0 + j][r0 + i] = P[i][j] (symmetric storage)
     float* Tp = Tall + p * SB * SB;
-    const int nparts = (int)((np + SBR_CHUNK - 1) / SBR_CHUNK);
-    hipLaunchKernelGGL(sbr_cross_part, dim3(nparts), dim3(256), 0, st, Pt, lda, Pt, lda, np, part);
+    const int nparts = (int)((np + SBR_GCH - 1) / SBR_GCH);
+    const unsigned rtiles = (unsigned)((np + 4 * SBR_RT - 1) / (4 * SBR_RT));  // workgroups of four 16-position wave tiles
+    hipLaunchKernelGGL((sbr_gram64<true>), dim3(nparts), dim3(256), 0, st, Pt, lda, (const float*)nullptr, np, part);
     hipLaunchKernelGGL(sbr_sum_parts, dim3(SB * SB / 256), dim3(256), 0, st, part, nparts, psum);
     SbrSmall sm{Mat, V1, Tp, V1 + SB * SB, flag};
     if (np == SB)  // last panel: may contain the zero rows of the padding
       hipLaunchKernelGGL(sbr_panel_house, dim3(1), dim3(64), 0, st, Pt, lda, sm);
     else
       hipLaunchKernelGGL(sbr_panel_small, dim3(1), dim3(256), 4 * SB * SB * sizeof(double), st, psum, 1, Pt, lda, sm);
-    SbrMul mv{};
-    mv.in = Pt; mv.ldi = lda; mv.Mat = Mat; mv.out = Pt; mv.ldo = lda; mv.len = np; mv.mode = 1;
-    mv.V1 = V1; mv.Rh = V1 + SB * SB; mv.band = A + r0 * lda + c0; mv.lda = lda;
-    hipLaunchKernelGGL(sbr_rightmul, dim3((unsigned)((np + 255) / 256)), dim3(256), 0, st, mv);
+    // V = [V1; P2 M] in the transposed storage (in place) and row-major; Rh into the band block of the panel
+    if (np > SB) hipLaunchKernelGGL(sbr_vmul_f64, dim3(rtiles), dim3(256), 0, st, Pt, lda, Mat, np, Vr);
+    hipLaunchKernelGGL(sbr_top_block, dim3(1), dim3(256), 0, st, Pt, lda, V1, V1 + SB * SB, A + r0 * lda + c0, Vr);
     // W (n' x SB) = A22 V as an NT product (A22 is stored in full and symmetric: its rows are K-contiguous), 256 x 64 tiles,
     // K = n' split into S slices inside one launch (slab s = its own [n'][SB] partial, summed by the next kernel)
     float* A22 = A + r0 * lda + r0;
@@ -459,19 +670,14 @@ int sy2sb_f32(Ctx* ctx, float* A, int64_t n, int64_t lda, float* Tall, int* brea
       g.prefer_big = 1;
       SCL_TRY(gemm_f32(ctx, g));
     }
-    SbrMul my{};  // Y' = T' W'
-    my.in = Wp; my.ldi = ldw; my.Mat = Mat + SB * SB; my.out = Yt; my.ldo = ldw; my.len = np; my.mode = 2;
-    my.nslab = Sw; my.slab = (int64_t)SB * ldw;
-    // sbr_rightmul takes its matrix in fp64: Mat + SB*SB holds T for this launch, then Sh
-    hipLaunchKernelGGL(sbr_cvt64, dim3(16), dim3(256), 0, st, Tp, Mat + SB * SB, SB * SB);
-    hipLaunchKernelGGL(sbr_rightmul, dim3((unsigned)((np + 255) / 256)), dim3(256), 0, st, my);
-    hipLaunchKernelGGL(sbr_cross_part, dim3(nparts), dim3(256), 0, st, Pt, lda, Yt, ldw, np, part);
+    // Y = W T; Sh = 1/2 T' (V'Y); Z = Y - V Sh and the row-major operands [V | Z], [Z | V] of the rank-128 update
+    hipLaunchKernelGGL((sbr_rmul_f32<2>), dim3(rtiles), dim3(256), 0, st, Wp, Sw, (int64_t)SB * ldw, Tp, (const double*)nullptr, np, Yr,
+                       (const float*)nullptr, (float*)nullptr, (float*)nullptr);
+    hipLaunchKernelGGL((sbr_gram64<false>), dim3(nparts), dim3(256), 0, st, Vr, (int64_t)SB, Yr, np, part);
     hipLaunchKernelGGL(sbr_sum_parts, dim3(SB * SB / 256), dim3(256), 0, st, part, nparts, psum);
     hipLaunchKernelGGL(sbr_small_s, dim3(1), dim3(256), 0, st, psum, 1, Tp, Mat + SB * SB);
-    SbrMul mz{};  // Z = Y - V Sh, and the row-major operands of the rank-2SB update
-    mz.in = Pt; mz.ldi = lda; mz.Mat = Mat + SB * SB; mz.len = np; mz.mode = 3;
-    mz.Y = Yt; mz.ldy = ldw; mz.VW = VW; mz.WV = WV;
-    hipLaunchKernelGGL(sbr_rightmul, dim3((unsigned)((np + 255) / 256)), dim3(256), 0, st, mz);
+    hipLaunchKernelGGL((sbr_rmul_f32<3>), dim3(rtiles), dim3(256), 0, st, Vr, 1, (int64_t)0, (const float*)nullptr, Mat + SB * SB, np,
+                       (float*)nullptr, Yr, VW, WV);
     {
       GemmArgs g{};
       g.P = VW; g.Q = WV; g.C = A22;
@@ -1309,7 +1515,7 @@ __global__ void sbr_copy_f64(const double* __restrict__ in, double* __restrict__
 
 // returns SCLENS_OK with *used = 1, or *used = 0 when the caller must take the one-stage path (order too small, or a
 // panel broke down in the Cholesky QR)
-int eig_values_two_stage(Ctx* ctx, const float* A, int64_t n, int64_t lda, double* w64_dev, int* used) {
+int eig_values_two_stage(Ctx* ctx, const float* A, int64_t n, int64_t lda, double* w64_dev, int* used, int64_t n_low) {
   *used = 0;
   const int64_t np = round_up(n, SB);
   if (np < 2 * SB || np > 120000) return SCLENS_OK;  // 120000: 32-bit byte offsets of the packed band in sbr_chase
@@ -1332,10 +1538,27 @@ int eig_values_two_stage(Ctx* ctx, const float* A, int64_t n, int64_t lda, doubl
   SCL_TRY(sy2sb_f32(ctx, Ap, np, ldp, Tall, &breakdown));
   if (breakdown) return SCLENS_OK;
   SCL_TRY(sb2st_f32(ctx, Ap, np, ldp, d, e));
-  SCL_TRY(stebz_f64(ctx, d, e, np, wp));
+  if (n_low < 0 || n_low >= n - 1) {
+    SCL_TRY(stebz_f64(ctx, d, e, np, wp));
+  } else {  // the padded spectrum ends with np - n sentinels: the largest true eigenvalue has index n - 1
+    SCL_TRY(stebz_f64(ctx, d, e, np, wp, n_low, n - 1));
+  }
   hipLaunchKernelGGL(sbr_copy_f64, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, wp, w64_dev, n);
   SCL_HIP(ctx, hipGetLastError());
   *used = 1;
+  return SCLENS_OK;
+}
+
+int eig_values_two_stage_redo(Ctx* ctx, int64_t n, double* w64_dev) {
+  const int64_t np = round_up(n, SB);
+  auto ws = [&](const char* name) -> void* { return ctx->ws.count(name) ? ctx->ws.at(name).first : nullptr; };
+  double* d = static_cast<double*>(ws("sbr.d"));
+  double* e = static_cast<double*>(ws("sbr.e"));
+  double* wp = static_cast<double*>(ws("sbr.w"));
+  if (!d || !e || !wp) return ctx->fail(SCLENS_ERR_STATE, "eig_values_two_stage_redo: no preceding eig_values_two_stage");
+  SCL_TRY(stebz_f64(ctx, d, e, np, wp));
+  hipLaunchKernelGGL(sbr_copy_f64, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, wp, w64_dev, n);
+  SCL_HIP(ctx, hipGetLastError());
   return SCLENS_OK;
 }
 

@@ -283,12 +283,18 @@ struct Session {
     if (m > 0) SCL_HIP(ctx, hipMemcpyAsync(idx_dev, h, sizeof(uint32_t) * (size_t)m, hipMemcpyHostToDevice, ctx->stream));
     return SCLENS_OK;
   }
-  int fetch_w() {
+  // partial: only the lowest eigenvalues and the largest one were computed (eig_values with n_low >= 0); the entries in
+  // between come back as NaN and are known to lie between their neighbours: they count as positive (+inf here)
+  int fetch_w(bool partial = false) {
     w_host.resize(n);
     SCL_HIP(ctx, hipMemcpyAsync(w_host.data(), w64, sizeof(double) * n, hipMemcpyDeviceToHost, ctx->stream));
     SCL_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    for (double v : w_host)
-      if (v != v) return ctx->fail(SCLENS_ERR_NAN, "NaN eigenvalue");
+    if (n > 0 && w_host.back() != w_host.back()) return ctx->fail(SCLENS_ERR_NAN, "NaN eigenvalue");
+    for (int64_t i = 0; i + 1 < n; ++i)
+      if (w_host[i] != w_host[i]) {
+        if (!partial || i == 0) return ctx->fail(SCLENS_ERR_NAN, "NaN eigenvalue");
+        w_host[i] = w_host.back();  // somewhere in (last computed, largest]: the exact value is not consumed
+      }
     return SCLENS_OK;
   }
   int64_t count_positive() const { return count_positive_tol(w_host); }
@@ -423,7 +429,7 @@ void session_destroy(Session* s) {
 
 // scaled dense matrix of `val` -> B, Gram -> A, eigenvalues -> w64/w_host
 static int decompose(Session* s, const PatternDev& p, const float* val, int f32path, float* B, float divisor,
-                     ScaleVecs* keep) {
+                     ScaleVecs* keep, int64_t n_low = -1) {
   if (s->sh.on()) {  // partial statistics and a partial Gram matrix over this rank's cells, summed over the ranks
     SCL_TRY(scale_to_dense_sharded(s->ctx, p, val, f32path, B, s->ldb, keep, s->sh));
     SCL_TRY(gram_f32(s->ctx, B, s->n, s->K, s->ldb, divisor, s->A, s->lda));
@@ -433,8 +439,8 @@ static int decompose(Session* s, const PatternDev& p, const float* val, int f32p
                            s->centering ? nullptr : keep));
     SCL_TRY(gram_f32(s->ctx, B, s->n, s->K, s->ldb, divisor, s->A, s->lda));
   }
-  SCL_TRY(eig_values(s->ctx, s->A, s->n, s->lda, s->w64));
-  return s->fetch_w();
+  SCL_TRY(eig_values(s->ctx, s->A, s->n, s->lda, s->w64, n_low));
+  return s->fetch_w(n_low >= 0);
 }
 
 // null matrix X_r (scLENS.jl:701, :704): closure path, eigenvalues only (:532, :572)
@@ -640,10 +646,23 @@ int session_search_step_seeded(Session* s, uint64_t seed, int64_t m, int64_t n_2
   SCL_TRY(make_values_seeded(ctx, s->pat.dev, s->pat.base_val, 1, seed, m, s->val));
   return search_core(s, n_2, d5, r_it);
 }
+// all eigenvalues of the reduction that the last partial eig_values left on the context (fallback of search_core)
+static int stebz_redo_all(Session* s) {
+  SCL_TRY(eig_values_redo_all(s->ctx, s->n, s->w64));
+  return s->fetch_w();
+}
 static int search_core(Session* s, int64_t n_2, double* d5, int64_t* r_it) {
   Ctx* ctx = s->ctx;
-  SCL_TRY(decompose(s, s->pat.dev, s->val, 1, s->Btmp, (float)s->Kdiv, nullptr));
-  const int64_t r = s->count_positive();
+  // only the lower part of the spectrum is consumed (and the largest eigenvalue for the positivity floor): eigenvalues
+  // [0, n_2 + 1 + slack) cover the n_2 + 1 smallest positive ones unless more than `slack` are non-positive -- then all
+  const int64_t slack = 64;
+  const int64_t n_low = (n_2 + 1 + slack < s->n - 1) ? n_2 + 1 + slack : -1;
+  SCL_TRY(decompose(s, s->pat.dev, s->val, 1, s->Btmp, (float)s->Kdiv, nullptr, n_low));
+  int64_t r = s->count_positive();
+  if (n_low >= 0 && (s->n - r) > slack) {  // (never seen: a Gram matrix of the path has at most a few null eigenvalues)
+    SCL_TRY(stebz_redo_all(s));
+    r = s->count_positive();
+  }
   if (r_it) *r_it = r;
   // nV_2[:, end-n_2:end] (scLENS.jl:742): the n_2+1 smallest positive eigenvalues
   int64_t cnt = std::min<int64_t>(n_2 + 1, r);

@@ -77,12 +77,12 @@ __global__ __launch_bounds__(1024) void tri_bounds(const double* __restrict__ d,
 // latency chain, so trading 8x more lanes for 3x fewer sweeps is what a mostly idle chip wants.
 __global__ __launch_bounds__(64) void tri_bisect(const double* __restrict__ d, const double* __restrict__ e2,
                                                  int64_t n, const double* __restrict__ info,
-                                                 double* __restrict__ w) {
+                                                 double* __restrict__ w, int64_t k_begin, int64_t k_end) {
   const int q = threadIdx.x & 7;
-  const int64_t k = (int64_t)blockIdx.x * 8 + (threadIdx.x >> 3);
+  const int64_t k = k_begin + (int64_t)blockIdx.x * 8 + (threadIdx.x >> 3);
   double lo = info[0], hi = info[1];
   const double pivmin = info[2], atol = EPS64 * info[4];
-  const bool live = k < n;
+  const bool live = k < k_end;
   if (info[5] != 0.0) {  // non-finite input (block-uniform)
     if (live && q == 0) w[k] = __longlong_as_double(0x7ff8000000000000LL);
     return;
@@ -314,13 +314,28 @@ __global__ __launch_bounds__(256) void tri_transpose_out(const double* __restric
   }
 }
 
-int stebz_f64(Ctx* ctx, const double* d_dev, const double* e_dev, int64_t n, double* w_dev) {
+__global__ void tri_fill_nan(double* __restrict__ w, int64_t lo, int64_t hi) {
+  const int64_t i = lo + (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < hi) w[i] = __longlong_as_double(0x7ff8000000000000LL);
+}
+
+// n_low < 0: all eigenvalues. n_low >= 0: only the n_low smallest and the largest one (the sparsity search consumes the lower
+// half of the spectrum, scLENS.jl:742, and the largest value for the positivity floor); the others are left as NaN.
+int stebz_f64(Ctx* ctx, const double* d_dev, const double* e_dev, int64_t n, double* w_dev, int64_t n_low, int64_t k_top) {
+  if (k_top < 0) k_top = n - 1;
   StageTimer tm(ctx, "stebz");
   SCL_WS(ctx, e2, double, "tri.e2", n + 1);
   SCL_WS(ctx, info, double, "tri.info", 8);
   hipLaunchKernelGGL(tri_bounds, dim3(1), dim3(1024), 0, ctx->stream, d_dev, e_dev, n, e2, info);
-  hipLaunchKernelGGL(tri_bisect, dim3((unsigned)((n + 7) / 8)), dim3(64), 0, ctx->stream, d_dev, e2, n, info,
-                     w_dev);
+  if (n_low < 0 || n_low >= k_top) {
+    hipLaunchKernelGGL(tri_bisect, dim3((unsigned)((n + 7) / 8)), dim3(64), 0, ctx->stream, d_dev, e2, n, info, w_dev, (int64_t)0, n);
+  } else {
+    if (n_low > 0)
+      hipLaunchKernelGGL(tri_bisect, dim3((unsigned)((n_low + 7) / 8)), dim3(64), 0, ctx->stream, d_dev, e2, n, info, w_dev,
+                         (int64_t)0, n_low);
+    hipLaunchKernelGGL(tri_fill_nan, dim3((unsigned)((n - n_low + 255) / 256)), dim3(256), 0, ctx->stream, w_dev, n_low, n);
+    hipLaunchKernelGGL(tri_bisect, dim3(1), dim3(64), 0, ctx->stream, d_dev, e2, n, info, w_dev, k_top, k_top + 1);
+  }
   SCL_HIP(ctx, hipGetLastError());
   return SCLENS_OK;
 }
@@ -492,7 +507,7 @@ __global__ __launch_bounds__(256) void k_mgs_rows(float* __restrict__ Zt, int64_
   }
 }
 
-int eig_values(Ctx* ctx, float* A, int64_t n, int64_t lda, double* w64_dev) {
+int eig_values(Ctx* ctx, float* A, int64_t n, int64_t lda, double* w64_dev, int64_t n_low) {
   if (n <= 0) return SCLENS_OK;
   ctx->last_two_stage = false;
   // two_stage: 1 = always (orders >= 128), 0 = never, -1 (default) = from the order: the one-stage reduction streams the
@@ -501,7 +516,7 @@ int eig_values(Ctx* ctx, float* A, int64_t n, int64_t lda, double* w64_dev) {
   static const int64_t min_n = getenv("SCLENS_HIP_TWO_STAGE_MIN_N") ? atoll(getenv("SCLENS_HIP_TWO_STAGE_MIN_N")) : 16000;
   if (ctx->two_stage == 1 || (ctx->two_stage < 0 && n >= min_n)) {
     int used = 0;
-    SCL_TRY(eig_values_two_stage(ctx, A, n, lda, w64_dev, &used));
+    SCL_TRY(eig_values_two_stage(ctx, A, n, lda, w64_dev, &used, n_low));
     if (used) {
       ctx->last_two_stage = true;
       return SCLENS_OK;
@@ -511,8 +526,16 @@ int eig_values(Ctx* ctx, float* A, int64_t n, int64_t lda, double* w64_dev) {
   SCL_WS(ctx, e, double, "eig.e", n);
   SCL_WS(ctx, tau, float, "eig.tau", n);
   SCL_TRY(sytrd_f32(ctx, A, n, lda, d, e, tau));
-  SCL_TRY(stebz_f64(ctx, d, e, n, w64_dev));
+  SCL_TRY(stebz_f64(ctx, d, e, n, w64_dev, n_low));
   return SCLENS_OK;
+}
+
+// every eigenvalue from the tridiagonal matrix the last eig_values call of this context left behind (after a partial call)
+int eig_values_redo_all(Ctx* ctx, int64_t n, double* w64_dev) {
+  if (ctx->last_two_stage) return eig_values_two_stage_redo(ctx, n, w64_dev);
+  SCL_WS(ctx, d, double, "eig.d", n);
+  SCL_WS(ctx, e, double, "eig.e", n);
+  return stebz_f64(ctx, d, e, n, w64_dev);
 }
 
 int eig_vectors(Ctx* ctx, const float* A, int64_t n, int64_t lda, const double* w64_dev, int64_t vec_lo,
