@@ -16,6 +16,9 @@ namespace scl {
 struct Ctx {
   int device = 0;
   hipStream_t stream = nullptr;
+  // second stream + events for work that overlaps inside one call (look-ahead of the band reduction); created on first use
+  hipStream_t aux_stream = nullptr;
+  hipEvent_t aux_ev[2] = {nullptr, nullptr};
   std::string err;
   // grow-only named device workspaces (freed at destroy); avoids hipMalloc inside hot loops
   std::map<std::string, std::pair<void*, size_t>> ws;

@@ -407,7 +407,7 @@ __global__ __launch_bounds__(256) void sbr_small_s(const double* __restrict__ pa
 // dimension on the lanes of a quad reads in 64-byte runs).
 typedef double f64x4 __attribute__((ext_vector_type(4)));
 constexpr int SBR_RT = 16;          // positions per wave tile
-constexpr int SBR_GCH = 1024;       // positions per workgroup of the Gram kernels
+constexpr int SBR_GCH = 256;        // positions per workgroup of the Gram kernels (four waves of 64)
 
 // part[wg][i][j] = sum over the workgroup's positions r of X[r][i] Y[r][j] (fp64), X / Y given as
 //   TRANSPOSED = true : Xt[i * ldx + r]   (the panel in A; X == Y: its Gram matrix)
@@ -637,22 +637,42 @@ int sy2sb_f32(Ctx* ctx, float* A, int64_t n, int64_t lda, float* Tall, int* brea
   // 128 KB of dynamic LDS for the panel algebra (above the 64 KB default; idempotent, cheap)
   SCL_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(sbr_panel_small),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, 4 * SB * SB * (int)sizeof(double)));
-  for (int64_t p = 0; p < npan; ++p) {
+  // Look-ahead: panel p + 1 only needs the first SB columns of the trailing matrix of step p. Those are updated first
+  // (a strip product, its transposed copy, and the diagonal block), then the panel is factored on a second stream while
+  // the main stream applies the rest of the rank-128 update: the latency-bound panel algebra (Gram, SB x SB factorisations,
+  // V = P M) leaves the critical path.
+  if (!ctx->aux_stream) {
+    SCL_HIP(ctx, hipStreamCreateWithFlags(&ctx->aux_stream, hipStreamNonBlocking));
+    SCL_HIP(ctx, hipEventCreateWithFlags(&ctx->aux_ev[0], hipEventDisableTiming));
+    SCL_HIP(ctx, hipEventCreateWithFlags(&ctx->aux_ev[1], hipEventDisableTiming));
+  }
+  hipStream_t st2 = ctx->aux_stream;
+  const bool lookahead = getenv("SCLENS_HIP_NO_LOOKAHEAD") == nullptr;
+  auto factor_panel = [&](int64_t p, hipStream_t s_) -> int {
     const int64_t c0 = p * SB, r0 = c0 + SB, np = n - r0;
     float* Pt = A + c0 * lda + r0;  // transposed panel: Pt[j][i] = A[c0 + j][r0 + i] = P[i][j] (symmetric storage)
     float* Tp = Tall + p * SB * SB;
     const int nparts = (int)((np + SBR_GCH - 1) / SBR_GCH);
     const unsigned rtiles = (unsigned)((np + 4 * SBR_RT - 1) / (4 * SBR_RT));  // workgroups of four 16-position wave tiles
-    hipLaunchKernelGGL((sbr_gram64<true>), dim3(nparts), dim3(256), 0, st, Pt, lda, (const float*)nullptr, np, part);
-    hipLaunchKernelGGL(sbr_sum_parts, dim3(SB * SB / 256), dim3(256), 0, st, part, nparts, psum);
+    hipLaunchKernelGGL((sbr_gram64<true>), dim3(nparts), dim3(256), 0, s_, Pt, lda, (const float*)nullptr, np, part);
+    hipLaunchKernelGGL(sbr_sum_parts, dim3(SB * SB / 256), dim3(256), 0, s_, part, nparts, psum);
     SbrSmall sm{Mat, V1, Tp, V1 + SB * SB, flag};
     if (np == SB)  // last panel: may contain the zero rows of the padding
-      hipLaunchKernelGGL(sbr_panel_house, dim3(1), dim3(64), 0, st, Pt, lda, sm);
+      hipLaunchKernelGGL(sbr_panel_house, dim3(1), dim3(64), 0, s_, Pt, lda, sm);
     else
-      hipLaunchKernelGGL(sbr_panel_small, dim3(1), dim3(256), 4 * SB * SB * sizeof(double), st, psum, 1, Pt, lda, sm);
+      hipLaunchKernelGGL(sbr_panel_small, dim3(1), dim3(256), 4 * SB * SB * sizeof(double), s_, psum, 1, Pt, lda, sm);
     // V = [V1; P2 M] in the transposed storage (in place) and row-major; Rh into the band block of the panel
-    if (np > SB) hipLaunchKernelGGL(sbr_vmul_f64, dim3(rtiles), dim3(256), 0, st, Pt, lda, Mat, np, Vr);
-    hipLaunchKernelGGL(sbr_top_block, dim3(1), dim3(256), 0, st, Pt, lda, V1, V1 + SB * SB, A + r0 * lda + c0, Vr);
+    if (np > SB) hipLaunchKernelGGL(sbr_vmul_f64, dim3(rtiles), dim3(256), 0, s_, Pt, lda, Mat, np, Vr);
+    hipLaunchKernelGGL(sbr_top_block, dim3(1), dim3(256), 0, s_, Pt, lda, V1, V1 + SB * SB, A + r0 * lda + c0, Vr);
+    return SCLENS_OK;
+  };
+  SCL_TRY(factor_panel(0, st));
+  for (int64_t p = 0; p < npan; ++p) {
+    const int64_t c0 = p * SB, r0 = c0 + SB, np = n - r0;
+    float* Pt = A + c0 * lda + r0;
+    float* Tp = Tall + p * SB * SB;
+    const int nparts = (int)((np + SBR_GCH - 1) / SBR_GCH);
+    const unsigned rtiles = (unsigned)((np + 4 * SBR_RT - 1) / (4 * SBR_RT));
     // W (n' x SB) = A22 V as an NT product (A22 is stored in full and symmetric: its rows are K-contiguous), 256 x 64 tiles,
     // K = n' split into S slices inside one launch (slab s = its own [n'][SB] partial, summed by the next kernel)
     float* A22 = A + r0 * lda + r0;
@@ -678,14 +698,30 @@ int sy2sb_f32(Ctx* ctx, float* A, int64_t n, int64_t lda, float* Tall, int* brea
     hipLaunchKernelGGL(sbr_small_s, dim3(1), dim3(256), 0, st, psum, 1, Tp, Mat + SB * SB);
     hipLaunchKernelGGL((sbr_rmul_f32<3>), dim3(rtiles), dim3(256), 0, st, Vr, 1, (int64_t)0, (const float*)nullptr, Mat + SB * SB, np,
                        (float*)nullptr, Yr, VW, WV);
-    {
+    auto update = [&](int64_t off, int64_t rows, int64_t cols, int lower) -> int {  // A22[off:off+rows, (lower ? off : 0) : +cols]
       GemmArgs g{};
-      g.P = VW; g.Q = WV; g.C = A22;
-      g.M = np; g.N = np; g.K = 2 * SB;
+      g.P = VW + off * 2 * SB; g.Q = WV + (lower ? off : 0) * 2 * SB; g.C = A22 + off * lda + (lower ? off : 0);
+      g.M = rows; g.N = cols; g.K = 2 * SB;
       g.ldp = 2 * SB; g.ldq = 2 * SB; g.ldc = lda;
-      g.alpha = -1.f; g.beta = 1.f; g.q_kcontig = 1; g.lower = 1; g.colabsmax = nullptr;
+      g.alpha = -1.f; g.beta = 1.f; g.q_kcontig = 1; g.lower = lower; g.colabsmax = nullptr;
       g.prefer_big = 1;  // K = 128: bound by the traffic of C, whose mirrored half the large-tile kernel stores 16 bytes at a time
-      SCL_TRY(gemm_f32(ctx, g));
+      return gemm_f32(ctx, g);
+    };
+    if (p + 1 < npan && lookahead && np > 2 * SB) {
+      // (i) what panel p + 1 reads: the diagonal block (lower + mirror), the strip below it, and the strip's exact transpose
+      SCL_TRY(update(0, SB, SB, 1));
+      SCL_TRY(update(SB, np - SB, SB, 0));
+      SCL_TRY(transpose_f32(ctx, A22 + SB * lda, np - SB, SB, lda, A22 + SB, lda));
+      SCL_HIP(ctx, hipEventRecord(ctx->aux_ev[0], st));
+      SCL_HIP(ctx, hipStreamWaitEvent(st2, ctx->aux_ev[0], 0));
+      SCL_TRY(factor_panel(p + 1, st2));
+      SCL_HIP(ctx, hipEventRecord(ctx->aux_ev[1], st2));
+      // (ii) the rest of the trailing matrix, concurrently with the factorisation of panel p + 1
+      SCL_TRY(update(SB, np - SB, np - SB, 1));
+      SCL_HIP(ctx, hipStreamWaitEvent(st, ctx->aux_ev[1], 0));
+    } else {
+      SCL_TRY(update(0, np, np, 1));
+      if (p + 1 < npan) SCL_TRY(factor_panel(p + 1, st));
     }
   }
   SCL_HIP(ctx, hipGetLastError());
