@@ -1135,12 +1135,13 @@ int sb2st_f32(Ctx* ctx, const float* A, int64_t n, int64_t lda, double* d_dev, d
   StageTimer tm(ctx, "sb2st");
   const int64_t ldv2 = round_up(n, 64), ldt = n / SB + 2;
   SCL_WS(ctx, Bd, float, "sbr.Bd", n * LDB2);
-  SCL_WS(ctx, V2, float, "sbr.V2", n * ldv2);
+  SCL_WS(ctx, V2, float, "sbr.V2", (n + 64) * ldv2);  // spare rows: the back-transformation reads whole 64-float runs
   SCL_WS(ctx, TAU2, float, "sbr.TAU2", n * ldt);
   SCL_WS(ctx, done, unsigned, "sbr.done", n + 4);  // progress counters + abort word
   hipStream_t st = ctx->stream;
   SCL_HIP(ctx, hipMemsetAsync(done, 0, sizeof(unsigned) * (n + 4), st));
   SCL_HIP(ctx, hipMemsetAsync(TAU2, 0, sizeof(float) * n * ldt, st));
+  SCL_HIP(ctx, hipMemsetAsync(V2, 0, sizeof(float) * (n + 64) * ldv2, st));  // entries no reflector owns must read as zero
   hipLaunchKernelGGL(sbr_pack_band, dim3((unsigned)n), dim3(128), 0, st, A, n, lda, Bd);
   // every workgroup must be resident (a sweep spins on its predecessor): one per CU is always safe
   int dev = 0, cus = 0;
@@ -1322,6 +1323,7 @@ __device__ __forceinline__ void sbr_q2_stash16(const SbrQ2Fetch& f, float* buf, 
 }
 
 // one group applied to the six window tiles z[0..5] (rows 0..95 of the group's window)
+template <int RT>
 __device__ __forceinline__ void sbr_q2_group16(f32x4* z, const float* buf, int vi, int g) {
   const float* VgT = buf;
   const float* T = buf + QW * Q_RS;
@@ -1337,13 +1339,12 @@ __device__ __forceinline__ void sbr_q2_group16(f32x4* z, const float* buf, int v
       w1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[e], z[rt + 1][e], w1, 0, 0, 0);
     }
   }
-  __builtin_amdgcn_sched_barrier(0);  // keep the operand reads of the three products apart (register pressure)
   // U' = Tg W' (Tg upper triangular: tile (1,0) is zero)
   f32x4 u0 = {0.f, 0.f, 0.f, 0.f}, u1 = {0.f, 0.f, 0.f, 0.f};
   {
-    const f32x4 t00 = *reinterpret_cast<const f32x4*>(T + vi * Q_RT + 4 * g);
-    const f32x4 t01 = *reinterpret_cast<const f32x4*>(T + vi * Q_RT + 16 + 4 * g);
-    const f32x4 t11 = *reinterpret_cast<const f32x4*>(T + (16 + vi) * Q_RT + 16 + 4 * g);
+    const f32x4 t00 = *reinterpret_cast<const f32x4*>(T + vi * RT + 4 * g);
+    const f32x4 t01 = *reinterpret_cast<const f32x4*>(T + vi * RT + 16 + 4 * g);
+    const f32x4 t11 = *reinterpret_cast<const f32x4*>(T + (16 + vi) * RT + 16 + 4 * g);
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       u0 = __builtin_amdgcn_mfma_f32_16x16x4f32(t00[e], w0[e], u0, 0, 0, 0);
@@ -1357,7 +1358,6 @@ __device__ __forceinline__ void sbr_q2_group16(f32x4* z, const float* buf, int v
     u0[e] = -u0[e];
     u1[e] = -u1[e];
   }
-  __builtin_amdgcn_sched_barrier(0);
   // Zw' -= Vg U': A[row][reflector 4 g + e] from the [reflector][row] image
 #pragma unroll
   for (int rt = 0; rt < 6; ++rt) {
@@ -1371,7 +1371,6 @@ __device__ __forceinline__ void sbr_q2_group16(f32x4* z, const float* buf, int v
       for (int e = 0; e < 4; ++e)
         z[rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(VgT[(16 + 4 * g + e) * Q_RS + 16 * rt + vi], u1[e], z[rt], 0, 0, 0);
     }
-    if (rt & 1) __builtin_amdgcn_sched_barrier(0);
   }
 }
 
@@ -1446,10 +1445,107 @@ __global__ __launch_bounds__(256, 1) void sbr_q2_apply16(SbrQ2Args a) {
         }
         sbr_q2_fetch16(pf, a, nb, nt, tid);
         const int b = bh - j;
-        if (b >= 0 && t < sbr_tasks_of((int64_t)b * QW, a.n)) sbr_q2_group16(z + 2 * (QJ - 1 - j), lds + cur * Q_BUF, vi, g);
+        if (b >= 0 && t < sbr_tasks_of((int64_t)b * QW, a.n)) sbr_q2_group16<Q_RT>(z + 2 * (QJ - 1 - j), lds + cur * Q_BUF, vi, g);
         sbr_q2_stash16(pf, lds + (cur ^ 1) * Q_BUF, tid);
         __syncthreads();
         cur ^= 1;
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) sbr_q2_stz(zrow, base + 16 * i + 4 * g, a.n, live, z[i]);
+      if (more) {
+#pragma unroll
+        for (int i = 0; i + 4 < QNT; ++i) z[i] = z[i + 4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) z[QNT - 4 + i] = pz[i];
+      } else {
+#pragma unroll
+        for (int i = 4; i < QNT; ++i) sbr_q2_stz(zrow, base + 16 * i + 4 * g, a.n, live, z[i]);
+      }
+    }
+  }
+}
+
+// The same application without workgroup barriers: every wave stages the group data into LDS images OF ITS OWN with the
+// LDS-DMA path (`global_load_lds_dword`: no registers, no ds_write; one instruction per reflector = 64 consecutive floats
+// of V2 into the parallelogram row, 16 instructions for the 32 x 32 T factor), one group ahead, and orders them against its
+// own reads with `s_waitcnt vmcnt(0)`. Nothing is shared between waves, so a wave never waits for another one and hipcc can
+// pipeline the operand reads of a group behind the MFMAs of the previous one. The images hold zeros outside the
+// parallelogram (written once); reflectors that do not exist read zeros from V2 (zero-filled, one spare row) and have a zero
+// row / column in T. LDS: 4 waves x 2 buffers x 16.9 KB.
+constexpr int Q_RT2 = 32;
+constexpr int Q_BUF2 = QW * Q_RS + QW * Q_RT2;
+typedef __attribute__((address_space(3))) void sbr_lds_void;
+typedef const __attribute__((address_space(1))) void sbr_glb_void;
+
+__device__ __forceinline__ void sbr_q2_dma(const SbrQ2Args& a, int b, int t, float* buf, int lane) {
+  // the caller guarantees b >= 0 and t < nk (addresses stay inside V2 / Tg); contents may be those of a partial group
+  const int64_t S = (int64_t)b * QW;
+#pragma unroll
+  for (int c = 0; c < QW; ++c) {
+    const int64_t s = S + c;
+    const float* src = a.V2 + s * a.ldv2 + (s + 1 + (int64_t)t * SB) + lane;
+    __builtin_amdgcn_global_load_lds((sbr_glb_void*)src, (sbr_lds_void*)(buf + c * Q_RS + c), 4, 0, 0);
+  }
+  const float* tg = a.Tg + ((int64_t)b * a.nk + t) * QW * QW + lane;
+  float* T = buf + QW * Q_RS;
+#pragma unroll
+  for (int i = 0; i < QW * QW / 64; ++i)
+    __builtin_amdgcn_global_load_lds((sbr_glb_void*)(tg + 64 * i), (sbr_lds_void*)(T + 64 * i), 4, 0, 0);
+}
+
+__global__ __launch_bounds__(256, 1) void sbr_q2_apply16w(SbrQ2Args a) {
+  extern __shared__ __attribute__((aligned(16))) float lds_dyn[];
+  const int tid = threadIdx.x, lane = tid & 63, vi = lane & 15, g = lane >> 4;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  float* mybuf = lds_dyn + wv * 2 * Q_BUF2;
+  const int64_t v = (int64_t)blockIdx.x * 64 + wv * 16 + vi;
+  const bool live = v < a.m;
+  float* zrow = a.Zq + (live ? v : 0) * a.ldq + 3;
+  for (int i = lane; i < 2 * Q_BUF2; i += 64) mybuf[i] = 0.f;  // outside the parallelogram the images stay zero
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  const int nsb = (a.nblk + QJ - 1) / QJ;
+  sbr_q2_dma(a, a.nblk - 1, 0, mybuf, lane);
+  int cur = 0;
+  f32x4 z[QNT];
+  for (int sb = 0; sb < nsb; ++sb) {
+    const int bh = a.nblk - 1 - sb * QJ, blow = bh - QJ + 1;
+    const int Kmax = sbr_tasks_of((int64_t)(blow > 0 ? blow : 0) * QW, a.n);
+    const int64_t base0 = (int64_t)blow * QW + 1;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the stores of the previous pass have left before rows are re-read
+#pragma unroll
+    for (int i = 0; i < QNT; ++i) z[i] = sbr_q2_ldz(zrow, base0 + 16 * i + 4 * g, a.n, live);
+    for (int t = 0; t < Kmax; ++t) {
+      const int64_t base = base0 + (int64_t)t * SB;
+      f32x4 pz[4];
+      const bool more = t + 1 < Kmax;
+      if (more) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) pz[i] = sbr_q2_ldz(zrow, base + 16 * (QNT + i) + 4 * g, a.n, live);
+      }
+#pragma unroll
+      for (int j = 0; j < QJ; ++j) {
+        int nb, nt;
+        if (j + 1 < QJ) {
+          nb = bh - (j + 1);
+          nt = t;
+        } else if (more) {
+          nb = bh;
+          nt = t + 1;
+        } else {
+          nb = bh - QJ;
+          nt = 0;
+        }
+        // this group's image (requested one group ago) has landed; then request the next one into the other buffer
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const bool nvalid = nb >= 0 && nt < sbr_tasks_of((int64_t)nb * QW, a.n);
+        if (nvalid) sbr_q2_dma(a, nb, nt, mybuf + (cur ^ 1) * Q_BUF2, lane);
+        const int b = bh - j;
+        const bool valid = b >= 0 && t < sbr_tasks_of((int64_t)b * QW, a.n);
+        if (valid) sbr_q2_group16<Q_RT2>(z + 2 * (QJ - 1 - j), mybuf + cur * Q_BUF2, vi, g);
+        // the reads of this buffer must have returned before a later DMA may overwrite it (two groups from now): the MFMAs
+        // that consume them are issued before the next wait, and the buffer after next is this one again
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        cur ^= 1;  // every slot of the sequence alternates, valid or not: slot q + 1's image always goes to the other buffer
       }
 #pragma unroll
       for (int i = 0; i < 4; ++i) sbr_q2_stz(zrow, base + 16 * i + 4 * g, a.n, live, z[i]);
@@ -1507,7 +1603,15 @@ int sbr_apply_q2(Ctx* ctx, int64_t n, float* Zt, int64_t m, int64_t ldz) {
                        (int64_t)0, Zq + r0 * ldq, ldq, (int64_t)3, n);
   }
   SbrQ2Args qa{V2, ldv2, Tg, nk, nblk, n, Zq, m, ldq};
-  hipLaunchKernelGGL(sbr_q2_apply16, dim3((unsigned)((m + 63) / 64)), dim3(256), 0, ctx->stream, qa);
+  if (getenv("SCLENS_HIP_Q2_BARRIER")) {  // the workgroup-shared staging with one barrier per group (kept for comparison)
+    hipLaunchKernelGGL(sbr_q2_apply16, dim3((unsigned)((m + 63) / 64)), dim3(256), 0, ctx->stream, qa);
+  } else {
+    const size_t lds_w = sizeof(float) * 4 * 2 * Q_BUF2;
+    static const hipError_t attr_rc = hipFuncSetAttribute(reinterpret_cast<const void*>(sbr_q2_apply16w),
+                                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_w);
+    SCL_HIP(ctx, attr_rc);
+    hipLaunchKernelGGL(sbr_q2_apply16w, dim3((unsigned)((m + 63) / 64)), dim3(256), lds_w, ctx->stream, qa);
+  }
   for (int64_t r0 = 0; r0 < m; r0 += 65535) {
     const int64_t rows = (m - r0 < 65535) ? m - r0 : 65535;
     hipLaunchKernelGGL(sbr_q2_shift, dim3((unsigned)((n + 255) / 256), (unsigned)rows), dim3(256), 0, ctx->stream, Zq + r0 * ldq, ldq,
