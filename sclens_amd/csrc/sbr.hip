@@ -1603,7 +1603,10 @@ int sbr_apply_q2(Ctx* ctx, int64_t n, float* Zt, int64_t m, int64_t ldz) {
                        (int64_t)0, Zq + r0 * ldq, ldq, (int64_t)3, n);
   }
   SbrQ2Args qa{V2, ldv2, Tg, nk, nblk, n, Zq, m, ldq};
-  if (getenv("SCLENS_HIP_Q2_BARRIER")) {  // the workgroup-shared staging with one barrier per group (kept for comparison)
+  if (!getenv("SCLENS_HIP_Q2_DMA")) {
+    // default: workgroup-shared staging with one barrier per group. The barrier-free variant below (per-wave images filled by
+    // LDS-DMA) measured SLOWER (617 vs 512 ms at n = 30 016, m = 15 008): 48 DMA instructions per group and wave cost about
+    // as many issue cycles as the group's 92 MFMAs.
     hipLaunchKernelGGL(sbr_q2_apply16, dim3((unsigned)((m + 63) / 64)), dim3(256), 0, ctx->stream, qa);
   } else {
     const size_t lds_w = sizeof(float) * 4 * 2 * Q_BUF2;
