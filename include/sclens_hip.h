@@ -228,6 +228,12 @@ int sclens_hip_session_adopt(sclens_hip_session* dst, sclens_hip_session* src, i
  * before the broadcast lands. For the seed block *dev_ptr may come back NULL (*rows_out = 0): no seed, full solver. */
 int sclens_hip_session_shared_buffer(sclens_hip_session* s, int what, int64_t rows, int64_t k, double* theta0,
                                      void** dev_ptr, int64_t* rows_out, int64_t* k_out, int64_t* ld);
+/* Guard band of the signal threshold: `sum(L .> lambda_c)` (scLENS.jl:539, :541, :580) is a hard cut on eigenvalues that the
+ * fp32 solver (the reference: cuSOLVER syevd!, scLENS.jl:377) delivers with an error of ~ sqrt(n) eps32 lambda_max. For the
+ * ascending eigen-indices idx_lo .. idx_hi-1 of the data matrix, rho[q] receives the float64 Rayleigh quotient of the fp32
+ * eigenvector against the resident scaled matrix, which the host substitutes for L before the comparison. Valid between
+ * session_data_spectrum (session_spectrum) and session_signal_vectors. */
+int sclens_hip_session_refine_eigenvalues(sclens_hip_session* s, int64_t idx_lo, int64_t idx_hi, double* rho);
 /* Second half (scLENS.jl:541-558, :580-590): cell-side eigenvectors of the k largest eigenvalues,
  * descending; nV is N x k (may be NULL: they also stay on the device for the later steps). */
 int sclens_hip_session_signal_vectors(sclens_hip_session* s, int64_t k, float* nV);

@@ -126,6 +126,15 @@ function sclens_hip(inp_df; th=60, p_step=0.001, n_perturb=20, centering="mean",
                 s, rcp, rrv, rnz, L, Lr, recp("TGC"), recp("mat2_mean"), recp("mat2_std"), recp("norm_tgc"), recp("cent_")))
             L_mp, _, b_min = scLENS._mp_calculation(L, Lr[1:end-1])           # host statistics stay in Julia (:537-538)
             lambda_c, _ = scLENS._tw(L, L_mp)
+            # guard band of the hard cut `L .> lambda_c` (:539, :541): eigenvalues within 4 sqrt(n) eps32 lambda_max of it are
+            # replaced by float64 Rayleigh quotients of their eigenvectors (0-based, half-open index range for the ABI)
+            near = findall(abs.(L .- lambda_c) .<= 4 * sqrt(nm) * 5.96e-8 * L[end])
+            if !isempty(near) && length(near) <= 64
+                rho = Vector{Float64}(undef, last(near) - first(near) + 1)
+                GC.@preserve rho check(ctx, ccall((:sclens_hip_session_refine_eigenvalues, LIB), Cint,
+                    (Ptr{Cvoid}, Int64, Int64, Ptr{Float64}), s, first(near) - 1, last(near), rho))
+                L[first(near):last(near)] .= rho
+            end
             k = sum(L .> lambda_c); nL = reverse(L[L .> lambda_c])
             nV = Matrix{Float32}(undef, N, k)
             GC.@preserve nV check(ctx, ccall((:sclens_hip_session_signal_vectors, LIB), Cint, (Ptr{Cvoid}, Int64, Ptr{Float32}), s, k, nV))

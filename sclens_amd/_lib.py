@@ -87,6 +87,7 @@ SIGNATURES = {
     "sclens_hip_session_data_spectrum": (C.c_int, [vp, c_f64p, c_f64p, c_f64p, c_f64p, c_f64p, c_f64p]),
     "sclens_hip_session_adopt": (C.c_int, [vp, vp, C.c_int]),
     "sclens_hip_session_signal_vectors": (C.c_int, [vp, i64, c_f32p]),
+    "sclens_hip_session_refine_eigenvalues": (C.c_int, [vp, i64, i64, c_f64p]),
     "sclens_hip_session_binary_basis": (C.c_int, [vp, c_f64p, c_i64p]),
     "sclens_hip_session_search_step": (C.c_int, [vp, c_u32p, i64, i64, c_f64p, c_i64p]),
     "sclens_hip_session_perturb": (C.c_int, [vp, i64, c_u32p, i64, i64, c_f64p, c_i64p]),

@@ -569,6 +569,12 @@ class Session:
     def adopt(self, src: "Session", what: int):
         self.ctx.check(self.ctx.lib.sclens_hip_session_adopt(self.h, src.h, int(what)))
 
+    def refine_eigenvalues(self, idx_lo: int, idx_hi: int) -> np.ndarray:
+        rho = np.empty(max(0, idx_hi - idx_lo))
+        if rho.size:
+            self.ctx.check(self.ctx.lib.sclens_hip_session_refine_eigenvalues(self.h, int(idx_lo), int(idx_hi), ptr(rho, C.c_double)))
+        return rho
+
     def signal_vectors(self, k: int) -> np.ndarray:
         nV = np.empty((self.N, k), dtype=np.float32, order="F")
         self.ctx.check(self.ctx.lib.sclens_hip_session_signal_vectors(self.h, int(k), ptr(nV, C.c_float)))
@@ -704,11 +710,14 @@ def _extract(inp):
 def sclens(inp_df, device_="gpu", th=60, p_step=0.001, n_perturb=20, centering="mean", draws: Optional[Draws] = None,
            seed: Optional[int] = None, ctx: Optional[Context] = None, max_search_iters: Optional[int] = None,
            keep_intermediates: bool = False, verbose: bool = False, shard: Optional[Shard] = None,
-           partial_eig: bool = True, streams: Optional[int] = 1, batch: bool = False, spread_initial: bool = True) -> Dict[str, object]:
+           partial_eig: bool = True, streams: Optional[int] = 1, batch: bool = False, spread_initial: bool = True,
+           guard_band: float = 4.0) -> Dict[str, object]:
     """scLENS.sclens (scLENS.jl:649-832) on one MI355X.
 
     Same keyword arguments as the reference. `draws`/`seed` expose the randomness the reference takes from
-    Julia's global RNG; `max_search_iters` is a test-only cap of the sparsity search.
+    Julia's global RNG; `max_search_iters` is a test-only cap of the sparsity search; `guard_band` is the half-width of the
+    band around the signal threshold, in units of sqrt(n) eps32 lambda_max, inside which eigenvalues are re-evaluated in
+    float64 before the cut (0 switches the refinement off).
     """
     if device_ != "gpu":
         raise NotImplementedError("sclens_amd implements the device path only; use the reference for device_='cpu'")
@@ -840,6 +849,19 @@ def sclens(inp_df, device_="gpu", th=60, p_step=0.001, n_perturb=20, centering="
                                                      (2 if W >= 3 else 1, w_bin.binary_basis)], lockstep=True)
         L_mp, _, b_min = _mp_calculation(L, Lr[:-1])  # Lr[1:end-1] (:537, :576)
         lambda_c = _tw(L, L_mp)[0]
+        # guard band: eigenvalues within +-4 sqrt(n) eps32 lambda_max of the cut are replaced by float64 Rayleigh quotients
+        # before `L .> lambda_c` (:541, :580) is taken (the rank that holds the data matrix refines, all ranks use its values)
+        band = float(guard_band) * math.sqrt(len(L)) * 5.96e-8 * float(L[-1])
+        near = np.flatnonzero(np.abs(L - lambda_c) <= band)
+        guard = {"band": band, "refined": []}
+        if guard_band > 0 and near.size and near.size <= 64:
+            lo_i, hi_i = int(near[0]), int(near[-1]) + 1
+            rho = ses.refine_eigenvalues(lo_i, hi_i) if (not spread or shard.rank == 0) else np.zeros(hi_i - lo_i)
+            if spread:
+                rho = shard.bcast_host(rho, 0)
+            guard["refined"] = [(int(i), float(L[i]), float(rho[i - lo_i])) for i in range(lo_i, hi_i)]
+            L = L.copy()
+            L[lo_i:hi_i] = rho
         sel = L > lambda_c
         k = int(sel.sum())
         if verbose:
@@ -963,7 +985,7 @@ def sclens(inp_df, device_="gpu", th=60, p_step=0.001, n_perturb=20, centering="
 
         res: Dict[str, object] = {"L": L, "L_mp": L_mp, "λ": lambda_c, "lambda_c": lambda_c, "cell_id": cell_id,
                                   "p_": p_, "p_th": p_th, "n_search": it, "search_trace": trace,
-                                  "partial_eig": pe_counts}
+                                  "partial_eig": pe_counts, "guard_band": guard}
         if min_s == 0:  # :780-784
             res["wall_s"] = time.perf_counter() - t_all
             return res

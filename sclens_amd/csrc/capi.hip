@@ -22,6 +22,7 @@ void pattern_destroy(PatternOwner*);
 int session_set_pattern(Session*, PatternOwner*);
 int session_null_spectrum_pattern(Session*, PatternOwner*, double*);
 int session_signal_vectors(Session*, int64_t, float*);
+int session_refine_eigenvalues(Session*, int64_t, int64_t, double*);
 int session_binary_basis(Session*, double*, int64_t*);
 int session_search_step(Session*, const uint32_t*, int64_t, int64_t, double*, int64_t*);
 int session_perturb(Session*, int64_t, const uint32_t*, int64_t, int64_t, double*, int64_t*);
@@ -301,6 +302,10 @@ int sclens_hip_session_adopt(sclens_hip_session* dst, sclens_hip_session* src, i
   SES_GUARD(dst);
   if (!src || !src->s) return SCLENS_ERR_ARG;
   return scl::session_adopt(dst->s, src->s, what);
+}
+int sclens_hip_session_refine_eigenvalues(sclens_hip_session* w, int64_t idx_lo, int64_t idx_hi, double* rho) {
+  if (!w) return SCLENS_ERR_ARG;
+  return scl::session_refine_eigenvalues(w->s, idx_lo, idx_hi, rho);
 }
 int sclens_hip_session_signal_vectors(sclens_hip_session* w, int64_t k, float* nV) {
   SES_GUARD(w);

@@ -572,6 +572,83 @@ static int to_cell_side(Session* s, const float* B, int64_t cnt, float* dst, boo
                     : reverse_rows_f32(ctx, tmp, cnt, s->N, s->ldn, dst, s->ldn);
 }
 
+// Guard band of the signal threshold (hard part 2): `sum(L .> lambda_c)` (scLENS.jl:539, :580) is a hard
+// cut, and an fp32 eigenvalue carries an error of about sqrt(n) eps32 lambda_max. For the eigenvalues idx_lo .. idx_hi-1
+// (ascending index) of the data matrix this returns the fp64 Rayleigh quotients rho = ||B' z||^2 / divisor of their fp32
+// eigenvectors z against the resident scaled matrix B (products and sums in fp64): second-order accurate in the error of z,
+// i.e. the eigenvalue of the fp32 data to ~1e-9 relative. Valid between data_spectrum and signal_vectors.
+constexpr int RQ_V = 8;  // vectors per pass over B
+__global__ __launch_bounds__(256) void k_rayleigh_part(const float* __restrict__ B, int64_t n, int64_t K, int64_t ldb,
+                                                       const float* __restrict__ Zt, int64_t ldz, int cnt, double* __restrict__ part) {
+  __shared__ float zs[RQ_V][256];
+  __shared__ double red[4][RQ_V];
+  const int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  double y[RQ_V];
+#pragma unroll
+  for (int q = 0; q < RQ_V; ++q) y[q] = 0.0;
+  for (int64_t i0 = 0; i0 < n; i0 += 256) {
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < RQ_V; ++q) zs[q][threadIdx.x] = (q < cnt && i0 + threadIdx.x < n) ? Zt[(int64_t)q * ldz + i0 + threadIdx.x] : 0.f;
+    __syncthreads();
+    const int lim = (int)((n - i0 < 256) ? n - i0 : 256);
+    if (k < K) {
+      for (int i = 0; i < lim; ++i) {
+        const double b = (double)B[(i0 + i) * ldb + k];
+#pragma unroll
+        for (int q = 0; q < RQ_V; ++q) y[q] += b * (double)zs[q][i];
+      }
+    }
+  }
+  // sum of y^2 over the block's columns, fixed order
+#pragma unroll
+  for (int q = 0; q < RQ_V; ++q) {
+    double v = y[q] * y[q];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6][q] = v;
+  }
+  __syncthreads();
+  if (threadIdx.x < RQ_V) part[(int64_t)blockIdx.x * RQ_V + threadIdx.x] =
+      (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+}
+
+int session_refine_eigenvalues(Session* s, int64_t idx_lo, int64_t idx_hi, double* rho) {
+  Ctx* ctx = s->ctx;
+  if (!s->have_spectrum || !s->Bmain) return ctx->fail(SCLENS_ERR_STATE, "refine_eigenvalues: call data_spectrum first");
+  if (idx_lo < 0 || idx_hi > s->n || idx_lo > idx_hi || !rho) return ctx->fail(SCLENS_ERR_ARG, "refine_eigenvalues: bad index range");
+  const int64_t cnt = idx_hi - idx_lo;
+  if (cnt == 0) return SCLENS_OK;
+  StageTimer tm(ctx, "refine");
+  SCL_TRY(s->ensure_zt(cnt));
+  SCL_TRY(eig_vectors(ctx, s->A, s->n, s->lda, s->w64, idx_lo, idx_hi, s->Zt, s->ldz));
+  const int64_t nb = (s->K + 255) / 256;
+  SCL_WS(ctx, part, double, "ses.rq", nb * RQ_V);
+  std::vector<double> hp((size_t)nb * RQ_V);
+  for (int64_t q0 = 0; q0 < cnt; q0 += RQ_V) {
+    const int c = (int)std::min<int64_t>(RQ_V, cnt - q0);
+    hipLaunchKernelGGL(k_rayleigh_part, dim3((unsigned)nb), dim3(256), 0, ctx->stream, s->Bmain, s->n, s->K, s->ldb,
+                       s->Zt + q0 * s->ldz, s->ldz, c, part);
+    SCL_HIP(ctx, hipGetLastError());
+    SCL_HIP(ctx, hipMemcpyAsync(hp.data(), part, sizeof(double) * nb * RQ_V, hipMemcpyDeviceToHost, ctx->stream));
+    SCL_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    for (int q = 0; q < c; ++q) {
+      double acc = 0.0;
+      for (int64_t b = 0; b < nb; ++b) acc += hp[(size_t)b * RQ_V + q];
+      rho[q0 + q] = acc;
+    }
+  }
+  if (s->sh.on()) {  // row-sharded: this rank holds a block of the contraction (cells); sum the partial quotients
+    SCL_WS(ctx, dr, double, "ses.rqd", cnt);
+    SCL_HIP(ctx, hipMemcpyAsync(dr, rho, sizeof(double) * cnt, hipMemcpyHostToDevice, ctx->stream));
+    SCL_TRY(s->sh.sum(ctx, dr, cnt, 0));
+    SCL_HIP(ctx, hipMemcpyAsync(rho, dr, sizeof(double) * cnt, hipMemcpyDeviceToHost, ctx->stream));
+    SCL_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  }
+  for (int64_t q = 0; q < cnt; ++q) rho[q] /= (double)s->M;  // the divisor of data_spectrum: size(X, 2) = M (Appendix A8)
+  return SCLENS_OK;
+}
+
 int session_signal_vectors(Session* s, int64_t k, float* nV) {
   Ctx* ctx = s->ctx;
   if (!s->have_spectrum) return ctx->fail(SCLENS_ERR_STATE, "signal_vectors: call spectrum first");

@@ -1,0 +1,141 @@
+"""-m gpu: parity and properties at the sizes BASELINE.json names.
+
+  * the guard band of the signal threshold: float64 Rayleigh quotients against a float64 eigensolver;
+  * a cells > genes case of order n = 6 000 through the two-stage eigensolver against the oracle, decisions exact;
+  * configs[2] (50 000 x 30 000) and configs[3] (100 000 x 30 000) at full size through size-independent properties
+    (the float64 oracle would need days there): spectrum identities, eigen-equation residuals of every signal pair by
+    float64 host matrix-vector products, orthonormality, determinism of a repeated decomposition.
+The two full-size cases take minutes each (synthesis included); SCLENS_TEST_SKIP_FULL=1 skips them.
+"""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import sclens_oracle as O
+from sclens_amd import api
+from sclens_amd.synth import synth_counts
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("N,M", [(300, 500), (600, 250)])
+def test_guard_band_rayleigh_quotients(ctx, N, M):
+    X = synth_counts(N, M, seed=5, C=5, marker_frac=0.2, marker_sd=1.5)
+    S = O.scale_main(X)[0]  # float64 scaled matrix of the reference's inline path
+    G = (S @ S.T if N <= M else S.T @ S) / M
+    ref = np.linalg.eigvalsh(G)
+    ses = api.Session(ctx, api._csc_f32(X))
+    try:
+        L, _ = ses.data_spectrum(True)
+        n = len(L)
+        for lo, hi in ((n - 9, n), (n // 2, n // 2 + 12), (3, 4)):
+            rho = ses.refine_eigenvalues(lo, hi)
+            # the scaled matrix is held in fp32 on the device: its eigenvalues differ from the float64 matrix's by ~1e-7 relative
+            assert np.abs(rho - ref[lo:hi]).max() < 4e-7 * ref[-1], (lo, hi, np.abs(rho - ref[lo:hi]).max() / ref[-1])
+        assert np.abs(L - ref).max() < 2e-5 * ref[-1]
+    finally:
+        ses.close()
+
+
+def test_guard_band_is_applied_before_the_cut(ctx):
+    """A wide band (every eigenvalue within 2 % of the threshold) goes through the refinement: same decisions, refined values
+    reported, and they agree with the float64 oracle two orders of magnitude better than the fp32 eigenvalues need to."""
+    X = synth_counts(300, 500, seed=1, C=5, marker_frac=0.2, marker_sd=1.5)
+    d = api.make_draws(X, seed=7, p_th_trials=300)
+    od = O.Draws(d.z_idx1, d.z_idx2, d.X_r, d.p_th, d.sampler)
+    ref = O.sclens(X, od, n_perturb=3, max_search_iters=5, null_tol=O.NULL_DROP)
+    wide = 0.02 * ref["lambda_c"] / (np.sqrt(300) * 5.96e-8 * ref["L"].max())
+    res = api.sclens(X, draws=d, n_perturb=3, max_search_iters=5, ctx=ctx, guard_band=wide)
+    off = api.sclens(X, draws=d, n_perturb=3, max_search_iters=5, ctx=ctx, guard_band=0.0)
+    assert len(res["guard_band"]["refined"]) >= 1 and off["guard_band"]["refined"] == []
+    for i, l32, rho in res["guard_band"]["refined"]:
+        assert abs(rho - ref["L"][i]) < 4e-7 * ref["L"].max()
+        assert abs(l32 - off["L"][i]) == 0.0
+    assert len(res["signal_ev"]) == len(ref["signal_ev"]) == len(off["signal_ev"])
+    assert np.array_equal(res["sig_id"], ref["sig_id"])
+
+
+def test_parity_order_6000_cells_gt_genes_two_stage(ctx, monkeypatch):
+    """cfg3-shaped (cells > genes: the gene-side Gram matrix X'X, recovered cell-side vectors) at order n = 6 000 through the
+    two-stage eigensolver (dense -> band -> tridiagonal), against the float64 oracle on the same draws."""
+    from sclens_amd._lib import Context
+
+    N, M = 9000, 6000
+    X = synth_counts(N, M, seed=606, C=7, marker_frac=0.1, marker_sd=1.3)
+    d = api.make_draws_native(X, seed=11, host_sampler=True)
+    od = O.Draws(d.z_idx1, d.z_idx2, d.X_r, d.p_th, d.sampler)
+    ref = O.sclens(X, od, n_perturb=2, max_search_iters=4, null_tol=O.NULL_DROP)
+    monkeypatch.setenv("SCLENS_HIP_TWO_STAGE", "1")
+    c2 = Context(ctx.device)
+    try:
+        res = api.sclens(X, draws=api.make_draws_native(X, seed=11), n_perturb=2, max_search_iters=4, ctx=c2, streams=1)
+    finally:
+        c2.close()
+    k = len(ref["signal_ev"])
+    assert len(res["signal_ev"]) == k >= 4  # retained-signal count identical
+    assert np.allclose(res["signal_ev"], ref["signal_ev"], rtol=2e-4)
+    assert np.abs(res["L"] - ref["L"]).max() < 2e-4 * ref["L"].max()
+    assert abs(res["lambda_c"] - ref["lambda_c"]) < 2e-4 * ref["lambda_c"]
+    assert res["n_search"] == ref["n_search"] and res["p_"] == ref["p_"]
+    tr, trr = np.array([a for _, a in res["search_trace"]]), np.array([a for _, a in ref["search_trace"]])
+    assert np.abs(tr - trr).max() < 3e-3
+    assert np.array_equal(res["sig_id"], ref["sig_id"])
+    assert np.array_equal(res["robustness_scores"]["a_b"], ref["robustness_scores"]["a_b"])
+    assert np.abs(res["robustness_scores"]["rob_score"] - ref["robustness_scores"]["rob_score"]).max() < 5e-3
+    cos = np.abs(np.sum(res["signal_evec"].astype(np.float64) * ref["signal_evec"], axis=0))
+    gaps = np.minimum(np.abs(np.diff(ref["signal_ev"], prepend=np.inf)), np.abs(np.diff(ref["signal_ev"], append=ref["lambda_c"])))
+    assert np.all(cos[gaps > 0.02 * ref["signal_ev"]] > 1 - 2e-3)
+
+
+FULL = {"cfg3": (50000, 30000, 2), "cfg4": (100000, 30000, 3)}
+
+
+@pytest.mark.skipif(os.environ.get("SCLENS_TEST_SKIP_FULL") == "1", reason="full-size cases skipped on request")
+@pytest.mark.parametrize("cfg", list(FULL))
+def test_full_size_properties(ctx, cfg):
+    N, M, idx = FULL[cfg]
+    X = synth_counts(N, M, seed=20240427 + idx, C=8)  # the matrix bench.py times
+    d = api.make_draws_native(X, seed=1000)
+    a = api.sclens(X, draws=d, ctx=ctx, n_perturb=3, max_search_iters=2, streams=1)
+    L = a["L"]
+    assert L.shape == (M,) and np.all(np.diff(L[np.isfinite(L)]) >= -1e-6 * L[-1]) and L[0] > -1e-5 * L[-1]
+    # the scaled matrix the path decomposes (scaling drop-in, fp32), used in row blocks so that no float64 copy is needed
+    S, rec = api.logn_scale(X, "mean", inline_f64=True, ctx=ctx)
+    for key in ("TGC", "mat2_mean", "mat2_std", "norm_tgc", "cent_"):
+        assert np.allclose(np.ravel(a["rec_vals"][key]), np.ravel(rec[key]), rtol=1e-12, atol=0)
+    V, lam = a["signal_evec"].astype(np.float64), a["signal_ev"]
+    k = V.shape[1]
+    assert k == len(lam) >= 6 and np.all(np.diff(lam) < 0) and np.all(lam > a["lambda_c"])
+    assert np.abs(V.T @ V - np.eye(k)).max() < 1e-4
+    # S is column-major (Julia layout): work in blocks of genes
+    fro, colmean_max = 0.0, 0.0
+    StV = np.zeros((M, k))
+    step = 2048
+    for c0 in range(0, M, step):
+        blk = S[:, c0:c0 + step].astype(np.float64)
+        fro += float((blk * blk).sum())
+        colmean_max = max(colmean_max, float(np.abs(blk.mean(axis=0)).max()))
+        StV[c0:c0 + step] = blk.T @ V
+    assert abs(L.sum() - fro / M) < 1e-4 * L.sum()  # trace identity: sum of the eigenvalues of X'X / M
+    assert colmean_max < 1e-5                      # column-centred (scLENS.jl:695-696)
+    # eigen-equation of the cell-side Gram matrix XX'/M for every signal pair, float64 host products
+    GV = np.zeros((N, k))
+    for c0 in range(0, M, step):
+        GV += S[:, c0:c0 + step].astype(np.float64) @ StV[c0:c0 + step]
+    GV /= M
+    res_max = float(np.abs(GV - V * lam[None, :]).max())
+    assert res_max < 2e-4 * L[-1] / np.sqrt(N) * 50, res_max
+    assert 0.9 <= a["p_"] < 1.0 and a["n_search"] == 2
+    rs = a["robustness_scores"]["rob_score"]
+    assert rs.shape == (k,) and np.all((rs >= 0) & (rs <= 1 + 1e-6))
+    assert np.allclose(a["pca"], a["signal_evec"] * np.sqrt(lam)[None, :].astype(np.float32), rtol=1e-5, atol=1e-6)
+    # determinism: the spectrum of a second decomposition of the same matrix has the same bits
+    ses = api.Session(ctx, X)
+    try:
+        L2, _ = ses.data_spectrum(False)
+    finally:
+        ses.close()
+    near = {i for i, _, _ in a["guard_band"]["refined"]}
+    same = np.array([i not in near for i in range(M)])
+    assert np.array_equal(L2[same], L[same])
