@@ -39,16 +39,17 @@ def test_guard_band_rayleigh_quotients(ctx, N, M):
 
 
 def test_guard_band_is_applied_before_the_cut(ctx):
-    """A wide band (every eigenvalue within 2 % of the threshold) goes through the refinement: same decisions, refined values
-    reported, and they agree with the float64 oracle two orders of magnitude better than the fp32 eigenvalues need to."""
+    """A band wide enough to hold the five eigenvalues nearest to the threshold: they go through the refinement, the decisions
+    stay those of the oracle, and the refined values agree with the float64 oracle to 4e-7 lambda_max."""
     X = synth_counts(300, 500, seed=1, C=5, marker_frac=0.2, marker_sd=1.5)
     d = api.make_draws(X, seed=7, p_th_trials=300)
     od = O.Draws(d.z_idx1, d.z_idx2, d.X_r, d.p_th, d.sampler)
     ref = O.sclens(X, od, n_perturb=3, max_search_iters=5, null_tol=O.NULL_DROP)
-    wide = 0.02 * ref["lambda_c"] / (np.sqrt(300) * 5.96e-8 * ref["L"].max())
+    dist = np.sort(np.abs(ref["L"] - ref["lambda_c"]))[4]
+    wide = 1.01 * dist / (np.sqrt(300) * 5.96e-8 * ref["L"].max())
     res = api.sclens(X, draws=d, n_perturb=3, max_search_iters=5, ctx=ctx, guard_band=wide)
     off = api.sclens(X, draws=d, n_perturb=3, max_search_iters=5, ctx=ctx, guard_band=0.0)
-    assert len(res["guard_band"]["refined"]) >= 1 and off["guard_band"]["refined"] == []
+    assert len(res["guard_band"]["refined"]) >= 5 and off["guard_band"]["refined"] == []
     for i, l32, rho in res["guard_band"]["refined"]:
         assert abs(rho - ref["L"][i]) < 4e-7 * ref["L"].max()
         assert abs(l32 - off["L"][i]) == 0.0
