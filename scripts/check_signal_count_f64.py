@@ -30,7 +30,7 @@ log = {"config": cfg, "N": N, "M": M, "nnz": int(X.nnz), "synth_s": round(time.p
 t0 = time.perf_counter()
 res = api.sclens(X, draws=draws, n_perturb=2, max_search_iters=5, streams=1)
 log["device_s"] = round(time.perf_counter() - t0, 1)
-L32, lc32, k32 = res["L"], float(res["lambda_c"]), int(len(res["signal_ev"]))
+L32, lc32, k32 = res["L"], float(res["lambda_c"]), int(len(res.get("signal_ev", [])))
 
 
 def spectrum64(Xs):
@@ -61,7 +61,7 @@ log.update({
     "gap_below_cut_over_lambda_max": float((lc64 - L64[L64 <= lc64].max()) / lmax),
     "gap_above_cut_over_lambda_max": float((L64[L64 > lc64].min() - lc64) / lmax),
     "guard_band": {"band_over_lambda_max": res["guard_band"]["band"] / lmax, "refined": res["guard_band"]["refined"]},
-    "signal_ev_device": [float(v) for v in res["signal_ev"]], "signal_ev_f64": [float(v) for v in L64[L64 > lc64][::-1]],
+    "signal_ev_device": [float(v) for v in res.get("signal_ev", [])], "signal_ev_f64": [float(v) for v in L64[L64 > lc64][::-1]],
     "host_cores": os.cpu_count(),
 })
 out = json.dumps(log, indent=1)
