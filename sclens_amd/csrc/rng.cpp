@@ -3,6 +3,7 @@
 // permutation the device uses). Plain C++ (no HIP). xoshiro256** seeded by splitmix64.
 #include <algorithm>
 #include <cstdint>
+#include <cstdlib>
 #include <cstring>
 #include <thread>
 #include <vector>
@@ -35,31 +36,101 @@ struct Xo {
 
 extern "C" {
 
+// R1 (scLENS.jl:668-673): nnz uniform (i, j) draws with replacement, minus the stored entries, duplicates removed, in
+// first-occurrence order. Draw t is a pure function of (seed, t) (counter-based: two splitmix64 outputs mapped to [0, N) and
+// [0, M) by a 128-bit multiply), so any number of host threads produces the same list: thread b owns a range of genes, walks
+// ALL draws, keeps those of its genes that its private bitmap (stored entries + earlier draws) has not seen, and the per-thread
+// survivor lists (each ascending in t) are merged back into draw order.
+static inline void r1_draw(uint64_t seed, uint64_t t, uint64_t N, uint64_t M, uint64_t* i, uint64_t* j) {
+  uint64_t s = seed + 0x632BE59BD9B4E019ull * (t + 1);
+  const uint64_t a = scl::splitmix64(s), b = scl::splitmix64(s);
+  *i = (uint64_t)(((__uint128_t)a * N) >> 64);
+  *j = (uint64_t)(((__uint128_t)b * M) >> 64);
+}
+
+static int host_threads(int64_t work_items) {
+  int T = (int)std::thread::hardware_concurrency();
+  if (const char* e = getenv("SCLENS_HIP_HOST_THREADS")) T = atoi(e);
+  T = std::max(1, std::min(T, 64));
+  return (int)std::max<int64_t>(1, std::min<int64_t>(T, work_items / 500000 + 1));
+}
+
 int sclens_draw_zero_candidates(int64_t N, int64_t M, const int64_t* colptr, const int32_t* rowval, uint64_t seed,
                                 uint32_t* z1, uint32_t* z2, int64_t* count) {
   if (N <= 0 || M <= 0 || !colptr || !z1 || !z2 || !count) return SCLENS_ERR_ARG;
   const int64_t nnz = colptr[M];
-  const uint64_t cells = (uint64_t)N * (uint64_t)M;
-  std::vector<uint64_t> taken((cells + 63) / 64, 0);  // stored entries + already drawn pairs
-  for (int64_t j = 0; j < M; ++j)
-    for (int64_t q = colptr[j]; q < colptr[j + 1]; ++q) {
-      const uint64_t key = (uint64_t)rowval[q] + (uint64_t)j * (uint64_t)N;
-      taken[key >> 6] |= 1ull << (key & 63);
+  const int T = (int)std::min<int64_t>(host_threads(nnz), M);
+  struct Hit { uint32_t t, i, j; };
+  std::vector<std::vector<Hit>> hits(T);
+  auto owner = [&](int b) {
+    const int64_t j0 = M * b / T, j1 = M * (b + 1) / T;
+    std::vector<uint64_t> taken(((uint64_t)(j1 - j0) * (uint64_t)N + 63) / 64, 0);  // stored entries + already drawn pairs
+    for (int64_t j = j0; j < j1; ++j)
+      for (int64_t q = colptr[j]; q < colptr[j + 1]; ++q) {
+        const uint64_t key = (uint64_t)rowval[q] + (uint64_t)(j - j0) * (uint64_t)N;
+        taken[key >> 6] |= 1ull << (key & 63);
+      }
+    std::vector<Hit>& out = hits[b];
+    out.reserve((size_t)(nnz / T + nnz / (8 * T) + 16));
+    for (int64_t t = 0; t < nnz; ++t) {
+      uint64_t i, j;
+      r1_draw(seed, (uint64_t)t, (uint64_t)N, (uint64_t)M, &i, &j);
+      if ((int64_t)j < j0 || (int64_t)j >= j1) continue;
+      const uint64_t key = i + (j - (uint64_t)j0) * (uint64_t)N;
+      uint64_t& w = taken[key >> 6];
+      const uint64_t bit = 1ull << (key & 63);
+      if (w & bit) continue;  // stored entry (setdiff, :671) or duplicate draw (first occurrence kept)
+      w |= bit;
+      out.push_back(Hit{(uint32_t)t, (uint32_t)i, (uint32_t)j});
     }
-  Xo rng(seed);
-  int64_t c = 0;
-  for (int64_t t = 0; t < nnz; ++t) {  // nnz uniform (i, j) draws with replacement (scLENS.jl:669)
-    const uint64_t i = rng.below((uint64_t)N), j = rng.below((uint64_t)M);
-    const uint64_t key = i + j * (uint64_t)N;
-    uint64_t& w = taken[key >> 6];
-    const uint64_t bit = 1ull << (key & 63);
-    if (w & bit) continue;  // stored entry (setdiff, :671) or duplicate draw (first occurrence kept)
-    w |= bit;
-    z1[c] = (uint32_t)i;
-    z2[c] = (uint32_t)j;
-    ++c;
+  };
+  {
+    std::vector<std::thread> th;
+    for (int b = 1; b < T; ++b) th.emplace_back(owner, b);
+    owner(0);
+    for (auto& x : th) x.join();
   }
-  *count = c;
+  // merge by draw index: thread c writes the survivors with t in [nnz c / T, nnz (c + 1) / T)
+  std::vector<int64_t> offs(T + 1, 0);
+  std::vector<std::vector<size_t>> lo(T, std::vector<size_t>(T + 1));
+  for (int b = 0; b < T; ++b) {
+    for (int c = 0; c <= T; ++c) {
+      const uint32_t tb = (uint32_t)std::min<int64_t>(nnz * c / T, 0xFFFFFFFFll);
+      lo[b][c] = (c == T) ? hits[b].size()
+                          : (size_t)(std::lower_bound(hits[b].begin(), hits[b].end(), tb, [](const Hit& h, uint32_t v) { return h.t < v; }) -
+                                     hits[b].begin());
+    }
+  }
+  for (int c = 0; c < T; ++c) {
+    int64_t n_c = 0;
+    for (int b = 0; b < T; ++b) n_c += (int64_t)(lo[b][c + 1] - lo[b][c]);
+    offs[c + 1] = offs[c] + n_c;
+  }
+  auto merger = [&](int c) {
+    std::vector<size_t> cur(T);
+    for (int b = 0; b < T; ++b) cur[b] = lo[b][c];
+    int64_t o = offs[c];
+    while (o < offs[c + 1]) {  // T-way merge by t (T <= 64: linear scan of the heads)
+      int best = -1;
+      uint32_t bt = 0xFFFFFFFFu;
+      for (int b = 0; b < T; ++b)
+        if (cur[b] < lo[b][c + 1] && (best < 0 || hits[b][cur[b]].t < bt)) {
+          best = b;
+          bt = hits[b][cur[b]].t;
+        }
+      const Hit& h = hits[best][cur[best]++];
+      z1[o] = h.i;
+      z2[o] = h.j;
+      ++o;
+    }
+  };
+  {
+    std::vector<std::thread> th;
+    for (int c = 1; c < T; ++c) th.emplace_back(merger, c);
+    merger(0);
+    for (auto& x : th) x.join();
+  }
+  *count = offs[T];
   return SCLENS_OK;
 }
 
@@ -69,7 +140,7 @@ int sclens_draw_null_matrix(int64_t N, int64_t M, const int64_t* colptr, const f
   const int64_t nnz = colptr[M];
   for (int64_t j = 0; j < M; ++j)
     if (colptr[j + 1] - colptr[j] > N || colptr[j + 1] < colptr[j]) return SCLENS_ERR_ARG;
-  const int T = (int)std::max<int64_t>(1, std::min<int64_t>(8, nnz / 1000000 + 1));  // host threads
+  const int T = host_threads(nnz);
   // (1) the stored values in random order (scLENS.jl:275), as a two-level shuffle: every value goes to one of NBK buckets
   //     chosen uniformly (one sequential pass), then each bucket -- small enough for the cache -- gets its own Fisher-Yates
   //     shuffle from its own generator (in parallel). Concatenated, that is a uniform random permutation, and it depends

@@ -1,22 +1,24 @@
-// Two-stage tridiagonalisation, stage 1: dense symmetric -> symmetric band of half-width SB, on the matrix cores.
-// (An experimental alternative to the one-stage reduction of tridiag.hip, whose symmetric matrix-vector product streams the
-// trailing matrix once per column -- 2/3 n^3 bytes; selected per context by the option "two_stage")
+// Two-stage symmetric eigensolver for gfx950: dense -> band of half-width SB = 64 on the matrix cores (sy2sb_f32), band ->
+// tridiagonal by bulge chasing in one persistent kernel (sb2st_f32), and the two back-transformations (sbr_apply_q2,
+// sbr_apply_q1). Selected by order (n >= 16 000) or by the context option "two_stage"; the one-stage reduction of tridiag.hip
+// streams the trailing matrix once per column (2/3 n^3 bytes) and is the faster one below that.
 //
-// Replaces, together with the later stages, the first phase of `_get_eigen` (scLENS.jl:375-387 -> cuSOLVER ssyevd / LAPACK
+// Replaces, together with the tridiagonal solver of trieig.hip, `_get_eigen` (scLENS.jl:375-387 -> cuSOLVER ssyevd / LAPACK
 // dsyevr in the reference).
 //
-// Panel p reduces the columns [p SB, (p+1) SB) below the band: P = A[r0:, c0:c0+SB] (n' x SB, r0 = c0 + SB) is factored
-// P = Q R by a Cholesky QR whose Gram matrix and triangular algebra are fp64 (fp32 data: orthogonality ~ eps64 cond(P)^2 +
-// eps32, so one pass is enough up to cond ~ 1e4; a non-positive pivot raises the breakdown flag and the caller falls back
-// to the one-stage solver), the Householder representation Q D = (I - V T V')[:, :SB] is reconstructed from the thin Q
-// by the sign-modified LU of its top block (Ballard, Demmel, Grigori, Jacquelin, Knight, Nguyen: "Reconstructing
-// Householder vectors from tall-skinny QR", 2015): only SB x SB work is sequential, the rest is one n' x SB triangular
-// product. The trailing matrix then gets the two-sided update A22 <- A22 - V Z' - Z V' with W = A22 V, Y = W T,
-// Z = Y - 1/2 V (T' V' Y): one skinny MFMA product (split over K inside one launch) and one rank-2SB symmetric MFMA
-// update per panel, the same gemm_kernel as everywhere else.
+// Stage 1. Panel p reduces the columns [p SB, (p+1) SB) below the band: P = A[r0:, c0:c0+SB] (n' x SB, r0 = c0 + SB) is
+// factored P = Q R by a Cholesky QR whose Gram matrix and triangular algebra are fp64 (fp32 data: orthogonality ~ eps64
+// cond(P)^2 + eps32, so one pass is enough up to cond ~ 1e4; a non-positive pivot raises the breakdown flag and the caller
+// falls back to the one-stage solver), the Householder representation Q D = (I - V T V')[:, :SB] is reconstructed from the
+// thin Q by the sign-modified LU of its top block (Ballard, Demmel, Grigori, Jacquelin, Knight, Nguyen: "Reconstructing
+// Householder vectors from tall-skinny QR", 2015): only SB x SB work is sequential. The trailing matrix then gets the
+// two-sided update A22 <- A22 - V Z' - Z V' with W = A22 V, Y = W T, Z = Y - 1/2 V (T' V' Y): one skinny MFMA product
+// (256 x 64 tiles, split over K inside one launch) and one rank-128 symmetric MFMA update (256 x 256 tiles) per panel; the
+// tall-skinny algebra in between runs on 16x16x4 MFMAs (f64 where the Cholesky QR needs it). The next panel is factored on
+// a second stream while the bulk of the update runs (look-ahead).
 // Storage: V_p is kept in the UPPER part of A (rows c0..c0+SB-1, columns r0..n-1: contiguous over the long dimension, the
-// layout every GEMM here wants), the band in the LOWER part, T_p in a side array. The matrix order must be a multiple of
-// SB (the caller pads with a decoupled diagonal block). All reductions run in a fixed order: bitwise reproducible.
+// layout every NT product here wants), the band in the LOWER part, T_p in a side array. The matrix order must be a multiple
+// of SB (the caller pads with a decoupled diagonal block). All reductions run in a fixed order: bitwise reproducible.
 #include <algorithm>
 
 #include "common.h"
@@ -25,50 +27,6 @@ namespace scl {
 
 constexpr int SB = 64;
 typedef float f32x4 __attribute__((ext_vector_type(4)));
-constexpr int SBR_CHUNK = 256;   // long-dimension positions per workgroup of sbr_cross_part
-
-// ---- partial cross products of two 64-row blocks: part[wg][i][j] = sum_{k in chunk wg} X[i][k] * Y[j][k]  (fp64) ------
-__global__ __launch_bounds__(256) void sbr_cross_part(const float* __restrict__ X, int64_t ldx, const float* __restrict__ Y,
-                                                      int64_t ldy, int64_t len, double* __restrict__ part) {
-  __shared__ float xs[SB][33], ys[SB][33];
-  const int tid = threadIdx.x, ti = tid >> 4, tj = tid & 15;
-  const bool same = (X == Y);
-  double acc[4][4];
-#pragma unroll
-  for (int u = 0; u < 4; ++u)
-#pragma unroll
-    for (int v = 0; v < 4; ++v) acc[u][v] = 0.0;
-  const int64_t k0 = (int64_t)blockIdx.x * SBR_CHUNK;
-  const int64_t kend = (k0 + SBR_CHUNK < len) ? k0 + SBR_CHUNK : len;
-  for (int64_t kc = k0; kc < kend; kc += 32) {
-#pragma unroll
-    for (int q = 0; q < 8; ++q) {
-      const int idx = tid + 256 * q, r = idx >> 5, c = idx & 31;
-      const int64_t k = kc + c;
-      xs[r][c] = (k < kend) ? X[(int64_t)r * ldx + k] : 0.f;
-      if (!same) ys[r][c] = (k < kend) ? Y[(int64_t)r * ldy + k] : 0.f;
-    }
-    __syncthreads();
-#pragma unroll 4
-    for (int c = 0; c < 32; ++c) {
-      double a[4], b[4];
-#pragma unroll
-      for (int u = 0; u < 4; ++u) a[u] = (double)xs[4 * ti + u][c];
-#pragma unroll
-      for (int v = 0; v < 4; ++v) b[v] = (double)(same ? xs[4 * tj + v][c] : ys[4 * tj + v][c]);
-#pragma unroll
-      for (int u = 0; u < 4; ++u)
-#pragma unroll
-        for (int v = 0; v < 4; ++v) acc[u][v] += a[u] * b[v];
-    }
-    __syncthreads();
-  }
-  double* out = part + (int64_t)blockIdx.x * SB * SB;
-#pragma unroll
-  for (int u = 0; u < 4; ++u)
-#pragma unroll
-    for (int v = 0; v < 4; ++v) out[(4 * ti + u) * SB + 4 * tj + v] = acc[u][v];
-}
 
 // sum of the partials in a fixed order: out[idx] = sum_p part[p][idx], idx < SB * SB (16 workgroups instead of a serial loop
 // inside the single-workgroup panel kernels)
@@ -295,92 +253,6 @@ __global__ __launch_bounds__(64) void sbr_panel_house(const float* __restrict__ 
     o.T[l * SB + c] = (c >= l) ? (float)T[l][c] : 0.f;
     o.M[l * SB + c] = 0.0;
   }
-}
-
-// ---- "right multiplication" of a 64-row block by a 64 x 64 matrix, one thread per long-dimension position -------------
-//   out[j][r] = sum_i in[i][r] * Mat[i][j]                      (mode 0)
-//   mode 1: V of a panel. in = out = the panel in its transposed storage; positions r < SB take V1 (and the lower-part
-//           band block of the panel receives Rh), positions r >= SB get P2 * Mat
-//   mode 2: in = the sum of `nslab` split-K slabs (slab stride `slab`), Mat = T  ->  Y = W T, also stores W's sum? no: only Y
-//   mode 3: Z = Y - V * Sh (in = V, Mat = Sh = 1/2 T'V'Y, acc = Y); also writes the row-major [V|Z] / [Z|V] operands
-struct SbrMul {
-  const float* in;
-  int64_t ldi;
-  const double* Mat;   // [SB][SB] fp64, row-major
-  float* out;
-  int64_t ldo;
-  int64_t len;
-  int mode;
-  // mode 1
-  const float* V1;
-  const float* Rh;
-  float* band;         // &A[r0][c0]: lower-part block of the panel (stride lda)
-  int64_t lda;
-  // mode 2
-  int nslab;
-  int64_t slab;
-  // mode 3
-  const float* Y;
-  int64_t ldy;
-  float* VW;           // [len][2 SB]
-  float* WV;
-};
-
-__global__ __launch_bounds__(256) void sbr_rightmul(SbrMul a) {
-  __shared__ double Ms[SB][SB];
-  for (int idx = threadIdx.x; idx < SB * SB; idx += 256) Ms[idx >> 6][idx & 63] = a.Mat[idx];
-  __syncthreads();
-  const int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (r >= a.len) return;
-  if (a.mode == 1 && r < SB) {
-    // top block: V1 row r, and the band block of the panel: row r of Rh (upper triangular)
-    for (int j = 0; j < SB; ++j) {
-      a.out[(int64_t)j * a.ldo + r] = a.V1[r * SB + j];
-      a.band[r * a.lda + j] = a.Rh[r * SB + j];
-    }
-    return;
-  }
-  float x[SB];  // every loop over x is fully unrolled: the array lives in registers
-  if (a.mode == 2) {  // in = split-K slabs of W, each [len][SB] row-major: 16-byte loads, slabs summed in a fixed order
-#pragma unroll
-    for (int i = 0; i < SB; i += 4) {
-      f32x4 s4 = {0.f, 0.f, 0.f, 0.f};
-      for (int q = 0; q < a.nslab; ++q) s4 += *reinterpret_cast<const f32x4*>(a.in + (int64_t)q * a.slab + r * SB + i);
-      x[i] = s4[0]; x[i + 1] = s4[1]; x[i + 2] = s4[2]; x[i + 3] = s4[3];
-    }
-  } else {
-#pragma unroll
-    for (int i = 0; i < SB; ++i) x[i] = a.in[(int64_t)i * a.ldi + r];
-  }
-  float* vw = nullptr;
-  float* wv = nullptr;
-  if (a.mode == 3) {
-    vw = a.VW + r * (2 * SB);
-    wv = a.WV + r * (2 * SB);
-#pragma unroll
-    for (int i = 0; i < SB; ++i) {
-      vw[i] = x[i];
-      wv[SB + i] = x[i];
-    }
-  }
-#pragma unroll 1
-  for (int j = 0; j < SB; ++j) {
-    double s = 0.0;
-#pragma unroll
-    for (int i = 0; i < SB; ++i) s += (double)x[i] * Ms[i][j];
-    if (a.mode == 3) {
-      const float zz = a.Y[(int64_t)j * a.ldy + r] - (float)s;
-      vw[SB + j] = zz;
-      wv[j] = zz;
-    } else {
-      a.out[(int64_t)j * a.ldo + r] = (float)s;
-    }
-  }
-}
-
-__global__ void sbr_cvt64(const float* __restrict__ in, double* __restrict__ out, int n) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) out[i] = (double)in[i];
 }
 
 // Sh = 1/2 T' (V'Y), V'Y = sum of the cross partials in a fixed order; 256 threads, 4 x 4 outputs each

@@ -138,13 +138,11 @@ int pattern_build(Ctx* ctx, int64_t N, int64_t M, const int64_t* colptr, const i
   std::vector<int32_t> urow(nU);
   std::vector<float> uval(nU, 0.f);
   std::vector<int64_t> cpos(ncand);
-  // candidate cursors per column (sequential: candidate order inside a column is the order of the list)
-  {
-    std::vector<int64_t> cur(M);
-    for (int64_t j = 0; j < M; ++j) cur[j] = ucol[j] + (colptr[j + 1] - colptr[j]);
-    for (int64_t t = 0; t < ncand; ++t) cpos[t] = local(t) ? cur[z2[t]]++ : -1;
-  }
-  const int T = (int)std::max<int64_t>(1, std::min<int64_t>(8, nU / 2000000 + 1));  // host threads
+  // host threads: every pass below is split by a range of genes or of cells whose owner scans the whole input and handles
+  // its own part, so the result does not depend on the thread count
+  int T = (int)std::thread::hardware_concurrency();
+  if (const char* e = getenv("SCLENS_HIP_HOST_THREADS")) T = atoi(e);
+  T = (int)std::max<int64_t>(1, std::min<int64_t>(std::min(T, 64), nU / 1000000 + 1));
   std::vector<int> bad(T, 0);
   auto run = [&](auto&& fn) {
     std::vector<std::thread> th;
@@ -152,7 +150,7 @@ int pattern_build(Ctx* ctx, int64_t N, int64_t M, const int64_t* colptr, const i
     fn(0);
     for (auto& x : th) x.join();
   };
-  // CSC fill: stored counts (by column range) and candidates (by list range)
+  // CSC fill: stored counts and the candidate cursors of the owner's genes (candidate order inside a gene = list order)
   run([&](int t) {
     const int64_t j0 = M * t / T, j1 = M * (t + 1) / T;
     for (int64_t j = j0; j < j1; ++j) {
@@ -163,16 +161,32 @@ int pattern_build(Ctx* ctx, int64_t N, int64_t M, const int64_t* colptr, const i
         uval[q] = nzval[s];
       }
     }
-    const int64_t t0 = ncand * t / T, t1 = ncand * (t + 1) / T;
-    for (int64_t c = t0; c < t1; ++c)
-      if (cpos[c] >= 0) urow[cpos[c]] = (int32_t)((int64_t)z1[c] - row0);
+    std::vector<int64_t> cur(j1 - j0);
+    for (int64_t j = j0; j < j1; ++j) cur[j - j0] = ucol[j] + (colptr[j + 1] - colptr[j]);
+    for (int64_t c = 0; c < ncand; ++c) {
+      const int64_t j = (int64_t)z2[c];
+      if (j < j0 || j >= j1) continue;
+      if (local(c)) {
+        const int64_t pos = cur[j - j0]++;
+        cpos[c] = pos;
+        urow[pos] = (int32_t)((int64_t)z1[c] - row0);
+      } else {
+        cpos[c] = -1;
+      }
+    }
   });
   for (int b : bad)
     if (b) return ctx->fail(SCLENS_ERR_ARG, "row index out of range");
-  // CSR view: thread t owns the row range [r0, r1): it scans every slot but only places its own rows, so the
+  // CSR view: thread t owns the row range [r0, r1): it scans every slot but only counts / places its own rows, so the
   // order inside a row (ascending column, slot order inside a column) does not depend on the thread count
   std::vector<int64_t> rptr(N + 1, 0);
-  for (int64_t q = 0; q < nU; ++q) rptr[urow[q] + 1] += 1;
+  run([&](int t) {
+    const int32_t r0 = (int32_t)(N * t / T), r1 = (int32_t)(N * (t + 1) / T);
+    for (int64_t q = 0; q < nU; ++q) {
+      const int32_t r = urow[q];
+      if (r >= r0 && r < r1) rptr[r + 1] += 1;
+    }
+  });
   for (int64_t i = 0; i < N; ++i) rptr[i + 1] += rptr[i];
   std::vector<int64_t> c2c(nU);
   std::vector<int32_t> ccol(nU);

@@ -136,3 +136,26 @@ def test_preprocess_counts_hand_case():
     # ribosomal filter (:204-208): c0 has 25 % ribosomal counts, c3 62.5 %
     out = O.preprocess_counts(X, names, min_genes_per_cell=3, min_cells_per_gene=2, mito_percent=30.0, ribo_percent=30.0)
     assert list(out[2]) == [0]
+
+
+def test_literal_null_eigenvalue_rule_versus_the_dropped_one():
+    """VERDICT r1 (weak 3): the device path always drops the structurally zero eigenvalue of a centred cells <= genes matrix
+    (`positive <=> lambda > 8 eps32 sqrt(n) lambda_max`), the reference keeps or drops it by the sign of its rounding error
+    (`L .> 0`, scLENS.jl:495, :515). This pins what the rule can move: with null_tol = 0 (literal) against NULL_DROP the
+    oracle's signal count, signal eigenvalues, lambda_c and robust signals are identical (they never see the null pair); the
+    number of positive eigenvectors r of the binarised / perturbed matrices differs by at most one, hence n_2 = round(r / 2)
+    (scLENS.jl:722) by at most one, and an extra ~0 entry can enter d_arr (scLENS.jl:742) -- the search statistic may differ,
+    so p_ is compared with a tolerance of a few steps rather than exactly."""
+    from sclens_amd.synth import synth_counts
+
+    X = synth_counts(120, 200, seed=3, C=4, marker_frac=0.3, marker_sd=1.5)  # cells <= genes: one structural null vector
+    d = O.make_draws(X, seed=5, p_th_trials=200)
+    lit = O.sclens(X, d, n_perturb=4, max_search_iters=8, null_tol=0.0)
+    drp = O.sclens(X, d, n_perturb=4, max_search_iters=8, null_tol=O.NULL_DROP)
+    assert len(lit["signal_ev"]) == len(drp["signal_ev"])
+    assert np.array_equal(lit["signal_ev"], drp["signal_ev"]) and lit["lambda_c"] == drp["lambda_c"]
+    assert np.array_equal(lit["sig_id"], drp["sig_id"])
+    assert abs(lit["p_"] - drp["p_"]) <= 4 * 0.001 + 1e-12
+    # the data-matrix spectrum has exactly one eigenvalue that the two rules treat differently
+    L = lit["L"]
+    assert np.sum(np.abs(L) <= O.NULL_DROP * L.max()) == 1
