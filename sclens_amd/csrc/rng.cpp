@@ -49,10 +49,7 @@ static inline void r1_draw(uint64_t seed, uint64_t t, uint64_t N, uint64_t M, ui
 }
 
 static int host_threads(int64_t work_items) {
-  int T = (int)std::thread::hardware_concurrency();
-  if (const char* e = getenv("SCLENS_HIP_HOST_THREADS")) T = atoi(e);
-  T = std::max(1, std::min(T, 64));
-  return (int)std::max<int64_t>(1, std::min<int64_t>(T, work_items / 500000 + 1));
+  return (int)std::max<int64_t>(1, std::min<int64_t>(scl::host_parallelism(), work_items / 500000 + 1));
 }
 
 int sclens_draw_zero_candidates(int64_t N, int64_t M, const int64_t* colptr, const int32_t* rowval, uint64_t seed,

@@ -4,6 +4,12 @@
 // memory, no host round trip, and is identical on host and device.
 #pragma once
 #include <cstdint>
+#if !defined(__HIP_DEVICE_COMPILE__)
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <thread>
+#endif
 
 #if defined(__HIPCC__)
 #define SCL_HD __host__ __device__
@@ -58,5 +64,30 @@ SCL_HD inline uint64_t feistel_apply(const FeistelPerm& p, uint64_t t) {
   } while (x >= p.len);
   return x;
 }
+
+#if !defined(__HIP_DEVICE_COMPILE__)
+// Host threads a parallel host pass may use: the CPUs this process can actually run on -- the cgroup quota (containers:
+// 256 visible CPUs with a quota of 16 is what the GPU box hands out), capped at 64; SCLENS_HIP_HOST_THREADS overrides.
+inline int host_parallelism() {
+  if (const char* e = getenv("SCLENS_HIP_HOST_THREADS")) return std::max(1, std::min(64, atoi(e)));
+  int T = (int)std::thread::hardware_concurrency();
+  if (T <= 0) T = 1;
+  if (FILE* f = fopen("/sys/fs/cgroup/cpu.max", "r")) {  // cgroup v2: "<quota> <period>" or "max <period>"
+    long long q = 0, per = 0;
+    if (fscanf(f, "%lld %lld", &q, &per) == 2 && q > 0 && per > 0) T = std::min<int>(T, (int)((q + per - 1) / per));
+    fclose(f);
+  } else if (FILE* f1 = fopen("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "r")) {  // cgroup v1
+    long long q = -1, per = 100000;
+    if (fscanf(f1, "%lld", &q) != 1) q = -1;
+    fclose(f1);
+    if (FILE* f2 = fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r")) {
+      if (fscanf(f2, "%lld", &per) != 1) per = 100000;
+      fclose(f2);
+    }
+    if (q > 0 && per > 0) T = std::min<int>(T, (int)((q + per - 1) / per));
+  }
+  return std::max(1, std::min(T, 64));
+}
+#endif
 
 }  // namespace scl

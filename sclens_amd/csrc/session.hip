@@ -8,6 +8,7 @@
 
 #include "common.h"
 #include "pattern.h"
+#include "rng.h"
 
 namespace scl {
 
@@ -140,9 +141,7 @@ int pattern_build(Ctx* ctx, int64_t N, int64_t M, const int64_t* colptr, const i
   std::vector<int64_t> cpos(ncand);
   // host threads: every pass below is split by a range of genes or of cells whose owner scans the whole input and handles
   // its own part, so the result does not depend on the thread count
-  int T = (int)std::thread::hardware_concurrency();
-  if (const char* e = getenv("SCLENS_HIP_HOST_THREADS")) T = atoi(e);
-  T = (int)std::max<int64_t>(1, std::min<int64_t>(std::min(T, 64), nU / 1000000 + 1));
+  const int T = (int)std::max<int64_t>(1, std::min<int64_t>(host_parallelism(), nU / 1000000 + 1));
   std::vector<int> bad(T, 0);
   auto run = [&](auto&& fn) {
     std::vector<std::thread> th;
