@@ -4,12 +4,10 @@
 // memory, no host round trip, and is identical on host and device.
 #pragma once
 #include <cstdint>
-#if !defined(__HIP_DEVICE_COMPILE__)
 #include <algorithm>
 #include <cstdio>
 #include <cstdlib>
 #include <thread>
-#endif
 
 #if defined(__HIPCC__)
 #define SCL_HD __host__ __device__
@@ -65,7 +63,6 @@ SCL_HD inline uint64_t feistel_apply(const FeistelPerm& p, uint64_t t) {
   return x;
 }
 
-#if !defined(__HIP_DEVICE_COMPILE__)
 // Host threads a parallel host pass may use: the CPUs this process can actually run on -- the cgroup quota (containers:
 // 256 visible CPUs with a quota of 16 is what the GPU box hands out), capped at 64; SCLENS_HIP_HOST_THREADS overrides.
 inline int host_parallelism() {
@@ -88,6 +85,5 @@ inline int host_parallelism() {
   }
   return std::max(1, std::min(T, 64));
 }
-#endif
 
 }  // namespace scl
