@@ -149,10 +149,16 @@ def cpu_baseline(N, M, n_search, n_perturb, budget_s):
     from sclens_amd.synth import synth_counts
 
     n, K = min(N, M), max(N, M)
-    cores = os.cpu_count() or 1
-    # dsyevr with vectors ~ 25 n^3 flop-equivalents at ~4 GF/s/core effective (measured: n = 4000 in ~7 s on 128 threads,
-    # 3.65 s at n = 3000 on 8 cores): pick the largest n_s whose estimate fits a third of the budget
-    est = lambda q: 1.2e-10 * q ** 3 * max(1.0, 16.0 / cores) + 0.5
+    cores = usable_cpus()
+    try:  # BLAS / LAPACK threads = the CPUs the process may use (a 256-thread pool on a 16-CPU quota only thrashes)
+        from threadpoolctl import threadpool_limits
+
+        threadpool_limits(limits=cores)
+    except Exception:
+        pass
+    # dsyevr with vectors: measured 7 s at n = 4000 on this box's 16-CPU quota; pick the largest n_s whose n^3 estimate fits a
+    # third of the budget
+    est = lambda q: 1.1e-10 * q ** 3 * max(1.0, 16.0 / cores) + 0.5
     ns = n
     while ns > 1500 and est(ns) > budget_s / 3:
         ns = int(ns * 0.85)
@@ -174,17 +180,23 @@ def cpu_baseline(N, M, n_search, n_perturb, budget_s):
     f3 = (n / ns) ** 3
     T = calls * (t_scale * (N * M) / (Ns * Ms) + t_gram * (n * n * K) / (ns * ns * max(Ns, Ms)) + t_eig * f3)
     T += n_search * t_gram * (n ** 3) / (ns * ns * max(Ns, Ms))  # corr_mat (scLENS.jl:742): ~n^3 flop per iteration
-    try:  # threads the BLAS/LAPACK behind NumPy/SciPy actually uses
-        from threadpoolctl import threadpool_info
-
-        cores = max([int(i.get("num_threads", 1)) for i in threadpool_info()] or [cores])
-    except Exception:
-        pass
     return {"value": round(N * M / T, 1), "unit": "cells*genes/s", "cores": cores, "kind": "port",
             "wall_s_extrapolated": round(T, 1), "eig_extrapolation_factor_n3": round(f3, 2),
             "sample": (f"oracle normalise+Gram+dsyevr timed once at {Ns}x{Ms} ({t_scale:.2f}s, {t_gram:.2f}s, {t_eig:.2f}s), "
                        f"scaled by NM, n^2K and n^3 (x{f3:.1f}) to {N}x{M}, times {calls} decompositions (S={n_search}, "
-                       f"P={n_perturb}) + {n_search} corr GEMMs; BLAS threads = {cores} (host has {os.cpu_count()} cores)")}
+                       f"P={n_perturb}) + {n_search} corr GEMMs; BLAS threads = {cores} = the CPUs this process may use (cgroup quota; {os.cpu_count()} visible)")}
+
+
+def usable_cpus():
+    """CPUs this process may really use: affinity and cgroup quota (the GPU box shows 256 CPUs with a quota of 16)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            n = min(n, max(1, -(-int(q) // int(per))))
+    except Exception:
+        pass
+    return max(1, n)
 
 
 def self_launch(args):

@@ -8,8 +8,26 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 
+def _usable_cpus():
+    """CPUs this process may really use: affinity and cgroup quota (the GPU box shows 256 CPUs with a quota of 16)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            n = min(n, max(1, -(-int(q) // int(per))))
+    except Exception:
+        pass
+    return max(1, n)
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    try:  # the oracle's BLAS / LAPACK calls: one thread per usable CPU, not per visible one
+        from threadpoolctl import threadpool_limits
+
+        config._sclens_blas_limit = threadpool_limits(limits=_usable_cpus())
+    except Exception:
+        pass
 
 
 @pytest.fixture(scope="session")
