@@ -130,17 +130,25 @@ void jacobi_eig(std::vector<double> C, int b, std::vector<double>& ev, std::vect
 }  // namespace
 
 int topk_chefsi(Ctx* ctx, const float* A, int64_t n, int64_t lda, int m, int m_strict, int b, const float* X0t, int64_t ldx,
-                const double* theta0, double* w_desc, float* Zt, int64_t ldz, int* converged, int* iters) {
+                const double* theta0, double* w_desc, float* Zt, int64_t ldz, int* converged, int* iters, const float* Bop,
+                int64_t Kop, int64_t ldb, float div) {
   *converged = 0;
   if (iters) *iters = 0;
   if (m <= 0 || b < m || b > 128 || b > n) return ctx->fail(SCLENS_ERR_ARG, "topk_chefsi: bad block sizes");
   StageTimer tm(ctx, "chefsi");
   hipStream_t st = ctx->stream;
   const int64_t ld = round_up(n, 32);
-  // split-K so that one block product launches >= ~320 blocks
+  // split-K so that one block product launches >= ~320 blocks (implicit operator: the contraction over Kop is much longer
+  // than a tile row is wide, so at least four slices)
   const int64_t tiles_n = (n + 127) / 128;
   int S = (int)((320 + tiles_n - 1) / tiles_n);
-  S = std::max(1, std::min(S, 8));
+  S = std::max(Bop ? 4 : 1, std::min(S, 8));
+  const int64_t ldt = Bop ? round_up(Kop, 32) : 0;
+  float* Tb = nullptr;
+  if (Bop) {
+    Tb = static_cast<float*>(ctx->workspace("che.T", sizeof(float) * (size_t)b * ldt));
+    if (!Tb) return SCLENS_ERR_OOM;
+  }
   const int64_t slab = (int64_t)b * ld;
   SCL_WS(ctx, X, float, "che.X", slab);
   SCL_WS(ctx, Y1, float, "che.Y1", slab);
@@ -160,6 +168,23 @@ int topk_chefsi(Ctx* ctx, const float* A, int64_t n, int64_t lda, int m, int m_s
   SCL_HIP(ctx, hipMemsetAsync(Y2, 0, sizeof(float) * slab, st));
 
   auto block_product = [&](const float* V) -> int {  // part[s] = V * A (slice s of the contraction)
+    if (Bop) {
+      // A = Bop Bop' / div is never formed: V A = (V Bop) Bop' / div, two products that stream Bop once each
+      // (2 * 2 b n Kop flop against n^2 Kop for the Gram matrix: cheaper below ~n / (4 b) applications)
+      GemmArgs g1{};
+      g1.P = V; g1.Q = Bop; g1.C = Tb;
+      g1.M = b; g1.N = Kop; g1.K = n;
+      g1.ldp = ld; g1.ldq = ldb; g1.ldc = ldt;
+      g1.alpha = 1.f; g1.beta = 0.f; g1.q_kcontig = 0; g1.lower = 0; g1.colabsmax = nullptr;
+      SCL_TRY(gemm_f32(ctx, g1));
+      GemmArgs g2{};
+      g2.P = Tb; g2.Q = Bop; g2.C = part;
+      g2.M = b; g2.N = n; g2.K = Kop;
+      g2.ldp = ldt; g2.ldq = ldb; g2.ldc = ld;
+      g2.alpha = 1.f / div; g2.beta = 0.f; g2.q_kcontig = 1; g2.lower = 0; g2.colabsmax = nullptr;
+      g2.splits = S; g2.k_chunk = round_up((Kop + S - 1) / S, 32); g2.c_split_off = slab;
+      return gemm_f32(ctx, g2);
+    }
     GemmArgs g{};
     g.P = V; g.Q = A; g.C = part;
     g.M = b; g.N = n; g.K = n;

@@ -181,8 +181,11 @@ int symv_probe(Ctx* ctx, int64_t n, int64_t* launches, double* total_ms, double*
 // subspace iteration with Rayleigh-Ritz, started from X0t (b rows of n: approximate leading eigenvectors) and
 // theta0[b] (their eigenvalue estimates, descending); the first m_strict pairs get the tight residual target. On success (*converged = 1) w_desc[m] (host) holds the m largest
 // eigenvalues (descending) and Zt rows 0..m-1 (device, ldz) the unit eigenvectors in the same order.
+// Bop != nullptr: A is given implicitly as Bop Bop' / div with Bop [n x Kop] row-major (ldb) -- the Gram matrix is not needed
+// (A may be nullptr); every block product then costs two passes over Bop.
 int topk_chefsi(Ctx* ctx, const float* A, int64_t n, int64_t lda, int m, int m_strict, int b, const float* X0t, int64_t ldx,
-                const double* theta0, double* w_desc, float* Zt, int64_t ldz, int* converged, int* iters);
+                const double* theta0, double* w_desc, float* Zt, int64_t ldz, int* converged, int* iters,
+                const float* Bop = nullptr, int64_t Kop = 0, int64_t ldb = 0, float div = 1.f);
 
 // ------------------------------------------------------------------ small device helpers (util.hip)
 int fill_f32(Ctx* ctx, float* p, int64_t n, float v);

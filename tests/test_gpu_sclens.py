@@ -148,10 +148,13 @@ def test_native_draws_agree_with_oracle(ctx):
     assert np.abs(res["robustness_scores"]["rob_score"] - ref["robustness_scores"]["rob_score"]).max() < 3e-3
 
 
+@pytest.mark.parametrize("implicit", [0, 1])
 @pytest.mark.parametrize("N,M", [(300, 500), (600, 250)])
-def test_partial_eigensolver_matches_full_solver(ctx, N, M):
+def test_partial_eigensolver_matches_full_solver(ctx, N, M, implicit, monkeypatch):
     """Ensemble members via the leading-eigenpair subspace iteration vs the full eigensolver: same decisions,
-    eigenvalues to 3e-4, signal eigenvectors to |cos| >= 1 - 3e-3."""
+    eigenvalues to 3e-4, signal eigenvectors to |cos| >= 1 - 3e-3. implicit = 1: the iteration applies the Gram matrix as
+    two passes over the scaled matrix and never forms it (the default from n = 16 000)."""
+    monkeypatch.setenv("SCLENS_HIP_IMPLICIT_MIN_N", "1" if implicit else "1000000000")
     X = synth_counts(N, M, seed=1, C=5, marker_frac=0.2, marker_sd=1.5)
     d = api.make_draws_native(X, seed=9)
     a = api.sclens(X, draws=d, n_perturb=5, ctx=ctx, keep_intermediates=True, max_search_iters=6, partial_eig=True)
