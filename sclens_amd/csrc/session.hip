@@ -672,9 +672,8 @@ int session_signal_vectors(Session* s, int64_t k, float* nV) {
   // iteration of the ensemble members (min_pc = ceil(1.5 k) wanted + a guard band)
   const int64_t min_pc = (3 * k + 1) / 2;
   int64_t b0 = round_up(min_pc + 40, 32);  // guard band: the block product streams the matrix once whatever b <= 128 is
-  // large orders: a block product costs the same for any b <= 128 (one 128-row MFMA tile), and a wider guard band pushes the
-  // block's lowest Ritz value deeper into the bulk, which is what sets the convergence rate of the bulk-edge vectors k..min_pc
-  if (s->n >= 16000 && min_pc + 8 <= 128) b0 = 128;
+  // (a 128-row block was measured at 50 000 x 30 000: 5 instead of 6.25 sweeps per member, but 248 instead of 194 ms -- the
+  // b x b Rayleigh-Ritz problem on the host grows with b^3; SCLENS_HIP_CHEFSI_B0 overrides for experiments)
   if (const char* e = getenv("SCLENS_HIP_CHEFSI_B0")) b0 = round_up(std::max<int64_t>(min_pc + 8, atoll(e)), 32);
   if (b0 > 128 || b0 > s->n / 2) b0 = 0;  // too wide for the small-block solver: ensemble uses the full solver
   const int64_t nv = std::max(k, b0);
