@@ -17,7 +17,7 @@ namespace scl {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-constexpr int BM = 128, BN = 128, BK = 16, LDT = 132;
+constexpr int BM = 128, BN = 128, BK = 16;
 
 template <bool VEC>
 __device__ __forceinline__ f32x4 ld4(const float* __restrict__ base, int64_t ld, int64_t r,
@@ -38,10 +38,14 @@ __device__ __forceinline__ f32x4 ld4(const float* __restrict__ base, int64_t ld,
   return v;
 }
 
-template <bool QKC, bool VEC>
+// WM = 2: block tile 128 x 128 (waves 2 x 2); WM = 1: 64 x 256 (waves 1 x 4) for products with at most 64 rows (the block
+// products of the subspace iteration: a 128-row tile would spend half of its MFMAs on zero rows)
+template <bool QKC, bool VEC, int WM>
 __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs a, int tiles_n) {
-  __shared__ __attribute__((aligned(16))) float As[2][BK][LDT];
-  __shared__ __attribute__((aligned(16))) float Bs[2][BK][LDT];
+  constexpr int BMt = 64 * WM, BNt = 256 / WM, LDA = BMt + 4, LDB = BNt + 4;
+  constexpr int RA = BMt / 64, RB = BNt / 64;  // 64-row groups of the staged tiles
+  __shared__ __attribute__((aligned(16))) float As[2][BK][LDA];
+  __shared__ __attribute__((aligned(16))) float Bs[2][BK][LDB];
 
   // ---- block -> tile, XCD-aware: blocks that share blockIdx%8 (one XCD's L2) get a contiguous
   //      run of tile ids, so neighbouring tiles (same P row panel) hit the same L2.
@@ -58,7 +62,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs a, int tiles_n) {
     ti = (int)(t / (unsigned)tiles_n);
     tj = (int)(t % (unsigned)tiles_n);
   }
-  const int64_t m0 = (int64_t)ti * BM, n0 = (int64_t)tj * BN;
+  const int64_t m0 = (int64_t)ti * BMt, n0 = (int64_t)tj * BNt;
   if (a.splits > 1) {  // this block's K slice and private output (grid.y = slice)
     const int64_t koff = (int64_t)blockIdx.y * a.k_chunk;
     const int64_t kleft = a.K - koff;
@@ -69,11 +73,11 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs a, int tiles_n) {
   }
 
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-  const int wm = wid >> 1, wn = wid & 1, l31 = lane & 31, h = lane >> 5;
+  const int wm = (WM == 2) ? (wid >> 1) : 0, wn = (WM == 2) ? (wid & 1) : wid, l31 = lane & 31, h = lane >> 5;
 
   // staging coordinates
-  const int pr = tid >> 2, pkq = tid & 3;   // K-contiguous operand: rows pr, pr+64; k = 4*pkq..
-  const int qk = tid >> 5, qnq = tid & 31;  // N-contiguous operand: k rows qk, qk+8; n = 4*qnq..
+  const int pr = tid >> 2, pkq = tid & 3;   // K-contiguous operand: rows pr + 64 g; k = 4*pkq..
+  const int qk = tid >> 5, qnq = tid & 31;  // N-contiguous operand: k rows qk, qk+8; n = 4*qnq + 128 c..
 
   f32x16 acc[2][2];
 #pragma unroll
@@ -83,33 +87,37 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs a, int tiles_n) {
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
-  f32x4 ra0, ra1, rb0, rb1;
+  f32x4 ra[RA], rb[RB];
   auto gload = [&](int64_t k0) {
-    ra0 = ld4<VEC>(a.P, a.ldp, m0 + pr, a.M, k0 + 4 * pkq, a.K);
-    ra1 = ld4<VEC>(a.P, a.ldp, m0 + pr + 64, a.M, k0 + 4 * pkq, a.K);
+#pragma unroll
+    for (int g = 0; g < RA; ++g) ra[g] = ld4<VEC>(a.P, a.ldp, m0 + pr + 64 * g, a.M, k0 + 4 * pkq, a.K);
     if (QKC) {
-      rb0 = ld4<VEC>(a.Q, a.ldq, n0 + pr, a.N, k0 + 4 * pkq, a.K);
-      rb1 = ld4<VEC>(a.Q, a.ldq, n0 + pr + 64, a.N, k0 + 4 * pkq, a.K);
+#pragma unroll
+      for (int g = 0; g < RB; ++g) rb[g] = ld4<VEC>(a.Q, a.ldq, n0 + pr + 64 * g, a.N, k0 + 4 * pkq, a.K);
     } else {
-      rb0 = ld4<VEC>(a.Q, a.ldq, k0 + qk, a.K, n0 + 4 * qnq, a.N);
-      rb1 = ld4<VEC>(a.Q, a.ldq, k0 + qk + 8, a.K, n0 + 4 * qnq, a.N);
+#pragma unroll
+      for (int c = 0; c < RB / 2; ++c) {
+        rb[2 * c] = ld4<VEC>(a.Q, a.ldq, k0 + qk, a.K, n0 + 4 * qnq + 128 * c, a.N);
+        rb[2 * c + 1] = ld4<VEC>(a.Q, a.ldq, k0 + qk + 8, a.K, n0 + 4 * qnq + 128 * c, a.N);
+      }
     }
   };
   auto sstore = [&](int buf) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      As[buf][4 * pkq + i][pr] = ra0[i];
-      As[buf][4 * pkq + i][pr + 64] = ra1[i];
-    }
+    for (int g = 0; g < RA; ++g)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) As[buf][4 * pkq + i][pr + 64 * g] = ra[g][i];
     if (QKC) {
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        Bs[buf][4 * pkq + i][pr] = rb0[i];
-        Bs[buf][4 * pkq + i][pr + 64] = rb1[i];
-      }
+      for (int g = 0; g < RB; ++g)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) Bs[buf][4 * pkq + i][pr + 64 * g] = rb[g][i];
     } else {
-      *reinterpret_cast<f32x4*>(&Bs[buf][qk][4 * qnq]) = rb0;
-      *reinterpret_cast<f32x4*>(&Bs[buf][qk + 8][4 * qnq]) = rb1;
+#pragma unroll
+      for (int c = 0; c < RB / 2; ++c) {
+        *reinterpret_cast<f32x4*>(&Bs[buf][qk][4 * qnq + 128 * c]) = rb[2 * c];
+        *reinterpret_cast<f32x4*>(&Bs[buf][qk + 8][4 * qnq + 128 * c]) = rb[2 * c + 1];
+      }
     }
   };
 
@@ -175,7 +183,6 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs a, int tiles_n) {
       }
     }
 }
-
 
 // ---- large-tile NT kernel (both operands K-contiguous) ---------------------------------------------------------------------
 // 256x256x32 block tile, 512 threads = 8 waves (2 x 4), each wave 128x64 = 4x2 MFMA tiles (128 accumulator registers, one
@@ -482,17 +489,35 @@ int gemm_f32(Ctx* ctx, const GemmArgs& a) {
     SCL_HIP(ctx, hipGetLastError());
     return SCLENS_OK;
   }
-  dim3 grid((unsigned)ntiles, (unsigned)(a.splits > 1 ? a.splits : 1)), block(256);
+  const unsigned gy = (unsigned)(a.splits > 1 ? a.splits : 1);
+  if (a.M <= 64 && !a.lower) {  // 64 x 256 tiles
+    const int64_t tn2 = (a.N + 255) / 256;
+    dim3 grid((unsigned)tn2, gy), block(256);
+    if (a.q_kcontig) {
+      if (vec)
+        hipLaunchKernelGGL((gemm_kernel<true, true, 1>), grid, block, 0, ctx->stream, a, (int)tn2);
+      else
+        hipLaunchKernelGGL((gemm_kernel<true, false, 1>), grid, block, 0, ctx->stream, a, (int)tn2);
+    } else {
+      if (vec)
+        hipLaunchKernelGGL((gemm_kernel<false, true, 1>), grid, block, 0, ctx->stream, a, (int)tn2);
+      else
+        hipLaunchKernelGGL((gemm_kernel<false, false, 1>), grid, block, 0, ctx->stream, a, (int)tn2);
+    }
+    SCL_HIP(ctx, hipGetLastError());
+    return SCLENS_OK;
+  }
+  dim3 grid((unsigned)ntiles, gy), block(256);
   if (a.q_kcontig) {
     if (vec)
-      hipLaunchKernelGGL((gemm_kernel<true, true>), grid, block, 0, ctx->stream, a, (int)tn);
+      hipLaunchKernelGGL((gemm_kernel<true, true, 2>), grid, block, 0, ctx->stream, a, (int)tn);
     else
-      hipLaunchKernelGGL((gemm_kernel<true, false>), grid, block, 0, ctx->stream, a, (int)tn);
+      hipLaunchKernelGGL((gemm_kernel<true, false, 2>), grid, block, 0, ctx->stream, a, (int)tn);
   } else {
     if (vec)
-      hipLaunchKernelGGL((gemm_kernel<false, true>), grid, block, 0, ctx->stream, a, (int)tn);
+      hipLaunchKernelGGL((gemm_kernel<false, true, 2>), grid, block, 0, ctx->stream, a, (int)tn);
     else
-      hipLaunchKernelGGL((gemm_kernel<false, false>), grid, block, 0, ctx->stream, a, (int)tn);
+      hipLaunchKernelGGL((gemm_kernel<false, false, 2>), grid, block, 0, ctx->stream, a, (int)tn);
   }
   SCL_HIP(ctx, hipGetLastError());
   return SCLENS_OK;
