@@ -74,3 +74,49 @@ def synth_counts(N: int, M: int, seed: int, C: int = 8, sparsity: float = 0.90,
         X = X.tocsc()
     X.sort_indices()
     return X.astype(np.float32)
+
+
+def synth_counts_rows(N_total: int, M: int, seed: int, row0: int, row1: int, C: int = 8, sparsity: float = 0.90,
+                      chunk_rows: int = 4096, marker_frac: float = 0.05, marker_sd: float = 1.0,
+                      min_genes_per_cell: int = 200) -> sp.csc_matrix:
+    """Rows [row0, row1) of an N_total x M matrix of the same model as `synth_counts`, for matrices that are never held
+    in one piece (the 1M x 30k atlas configuration is generated chunk-wise). The gene parameters, cluster
+    labels and library sizes come from the generator seeded with `seed`; the Poisson draws of chunk c (rows
+    [c * chunk_rows, (c + 1) * chunk_rows)) from a generator seeded with (seed, c), so any range of rows is reproducible on
+    its own and only one chunk is ever dense on the host. Cells with fewer than `min_genes_per_cell` expressed genes get
+    single counts planted (scLENS.jl:160-162); the per-gene minimum is a property of the whole matrix and is not enforced
+    on a slab."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    beta0, delta = _rates(M, C, rng, marker_frac, marker_sd)
+    lo, hi = -8.0, 8.0
+    for _ in range(60):
+        mid = 0.5 * (lo + hi)
+        if _sparsity_for_offset(beta0, mid) > sparsity:
+            lo = mid
+        else:
+            hi = mid
+    beta0 = beta0 + 0.5 * (lo + hi)
+    labels = np.arange(N_total) % C
+    rng.shuffle(labels)
+    lib = rng.lognormal(0.0, 0.3, size=N_total)
+    mg = min(min_genes_per_cell, max(2, M // 20))
+    rows, cols, vals = [], [], []
+    c0 = row0 // chunk_rows
+    for c in range(c0, (row1 + chunk_rows - 1) // chunk_rows):
+        a, b = c * chunk_rows, min(N_total, (c + 1) * chunk_rows)
+        crng = np.random.Generator(np.random.PCG64([seed, c]))
+        lam = lib[a:b, None] * np.exp(beta0[None, :] + delta[labels[a:b]])
+        x = crng.poisson(lam).astype(np.float32)
+        short = np.flatnonzero((x > 0).sum(axis=1) < mg)
+        for i in short:  # plant single counts (deterministic given seed and chunk)
+            zero_cols = np.flatnonzero(x[i] == 0)
+            x[i, crng.choice(zero_cols, size=mg - int((x[i] > 0).sum()), replace=False)] = 1.0
+        s0, s1 = max(a, row0) - a, min(b, row1) - a
+        i, j = np.nonzero(x[s0:s1])
+        rows.append((i + a + s0 - row0).astype(np.int64))
+        cols.append(j.astype(np.int64))
+        vals.append(x[s0:s1][i, j])
+    X = sp.csc_matrix((np.concatenate(vals), (np.concatenate(rows), np.concatenate(cols))), shape=(row1 - row0, M),
+                      dtype=np.float32)
+    X.sort_indices()
+    return X

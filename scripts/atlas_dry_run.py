@@ -1,0 +1,92 @@
+"""Atlas configuration (BASELINE.json configs[4]: 1M cells x 30k genes on 8 GPUs) -- dry run of ONE rank on one
+GPU: rank 0's slab of 125 000 cells is generated chunk-wise (`synth_counts_rows`, never dense on the host) and goes through
+the row-sharded session (`sclens_hip_session_create_sharded`) with the inter-rank all-reduce STUBBED (the callback counts
+calls and bytes and returns at once), so the numbers are this rank's compute time and HBM footprint; the spectra are those of
+the slab alone and are not checked. Candidates are drawn for the slab's own cells only (what each rank of a real run would
+hold). Usage: atlas_dry_run.py [N_total world out.json]"""
+import json
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+
+from sclens_amd import _lib, api
+from sclens_amd.atlas import row_block
+from sclens_amd.synth import synth_counts_rows
+
+N_total = int(sys.argv[1]) if len(sys.argv) > 1 else 1_000_000
+world = int(sys.argv[2]) if len(sys.argv) > 2 else 8
+M = int(os.environ.get("ATLAS_M", "30000"))
+out_path = sys.argv[3] if len(sys.argv) > 3 else None
+import torch  # device-level free memory (mem_get_info) and runtime order
+
+torch.cuda.init()
+ctx = api.Context(0)
+free0, total = torch.cuda.mem_get_info(0)
+log = {"N_total": N_total, "M": M, "world": world, "hbm_total_GB": round(total / 1e9, 1)}
+r0, r1 = row_block(0, world, N_total)
+t0 = time.perf_counter()
+X = api._csc_f32(synth_counts_rows(N_total, M, 20240427 + 4, r0, r1))
+log["slab"] = {"rows": [r0, r1], "nnz": int(X.nnz), "synth_s": round(time.perf_counter() - t0, 1)}
+t0 = time.perf_counter()
+d = api.make_draws_native(X, seed=1000)
+z1, z2, Xr = api._resolve(d.z_idx1), api._resolve(d.z_idx2), api._resolve(d.X_r)
+log["draws_s"] = round(time.perf_counter() - t0, 1)
+stat = {"calls": 0, "bytes": 0, "largest": 0}
+
+
+def stub(_user, dev_ptr, count, dtype):
+    nb = int(count) * (8 if dtype == 0 else 4)
+    stat["calls"] += 1
+    stat["bytes"] += nb
+    stat["largest"] = max(stat["largest"], nb)
+    return 0
+
+
+reducer = _lib.ALLREDUCE_FN(stub)
+times = {}
+
+
+def timed(name, f):
+    ctx.sync()
+    t = time.perf_counter()
+    r = f()
+    ctx.sync()
+    times[name] = round(time.perf_counter() - t, 3)
+    return r
+
+
+ses = timed("session_create_sharded", lambda: api.Session.create_sharded(ctx, X, r0, N_total, z1, z2, reducer))
+try:
+    Lr = timed("null_spectrum", lambda: ses.null_spectrum(Xr))
+    L, _ = timed("data_spectrum", lambda: ses.data_spectrum())
+    k = 8  # a fixed number of signal vectors: the slab's own spectrum is not the atlas's
+    timed("signal_vectors", lambda: ses.signal_vectors(k))
+    _, r_vr2 = timed("binary_basis", lambda: ses.binary_basis())
+    n_2 = int(round(r_vr2 / 2))
+    for it in range(2):
+        m = int(round((1 - (0.999 - 0.001 * it)) * M * (r1 - r0)))  # the slab's share of the flipped zeros
+        timed(f"search_step_{it}", lambda: ses.search_step_seeded(api.sample_seed_for(d.sample_seed, "search", it), min(m, len(z1)), n_2))
+    min_pc = 12
+    m_pert = int(round(0.015 * M * (r1 - r0)))
+    for t in range(2):
+        timed(f"perturb_{t}", lambda: ses.perturb_seeded(t, api.sample_seed_for(d.sample_seed, "perturb", t), min(m_pert, len(z1)), min_pc))
+    timed("robustness", lambda: ses.robustness(k, 2))
+    timed("gene_basis", lambda: ses.gene_basis(np.sort(L)[::-1][:k].copy()))
+    free1, _ = torch.cuda.mem_get_info(0)
+    log["hbm_used_GB"] = round((free0 - free1) / 1e9, 1)
+finally:
+    ses.close()
+log["times_s"] = times
+log["stubbed_allreduce"] = {"calls": stat["calls"], "total_GB": round(stat["bytes"] / 1e9, 2), "largest_GB": round(stat["largest"] / 1e9, 2),
+                            "ring_estimate_s_at_153GBps_per_link": round(2 * (world - 1) / world * stat["bytes"] / 153e9, 2)}
+S_est, P = 19, 20
+log["projected_rank_wall_s"] = round(times["session_create_sharded"] + times["null_spectrum"] + times["data_spectrum"] + times["signal_vectors"] +
+                                     times["binary_basis"] + S_est * times["search_step_1"] + P * times["perturb_1"] + times["robustness"] +
+                                     times["gene_basis"], 1)
+txt = json.dumps(log, indent=1)
+print(txt)
+if out_path:
+    open(out_path, "w").write(txt + "\n")
