@@ -298,9 +298,12 @@ def main():
             ctx.sync()
 
         res, t_step, n_warm = None, None, 0
+        t_warm0 = time.perf_counter()
         for w in range(warm_req):
-            # a warm-up step is taken only if it and one timed step still fit (the first step is never skipped)
-            if agree(t_step is not None and time.perf_counter() + 2.2 * t_step > deadline):
+            # a further warm-up step is taken only while warm-up stays below 15 % of the budget and it plus one timed step
+            # still fit (the first one is never skipped): at ~80 s per step the budget goes to timed steps
+            if agree(t_step is not None and (time.perf_counter() + 2.2 * t_step > deadline or
+                                             time.perf_counter() - t_warm0 + t_step > 0.15 * args.budget_s)):
                 break
             ts = time.perf_counter()
             res = one_step(-1 - w)
