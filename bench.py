@@ -284,7 +284,7 @@ def main():
 
         def one_step(step):
             t_d = time.perf_counter()
-            draws = api.make_draws_native(X, seed=1000 + step, async_null=True, async_candidates=not row_shard)
+            draws = api.make_draws_native(X, seed=1000 + step, async_null=True, device_candidates=not row_shard)
             one_step.draws_s = time.perf_counter() - t_d  # R1-R3 inside the timed region; R4/R5 on the device inside sclens()
             if row_shard:  # global draws (identical on every rank), local cells
                 return atlas.sclens_row_sharded(X_rows, r0, N, draws, shard, n_perturb=args.n_perturb, ctx=ctx, gather=False,

@@ -199,6 +199,16 @@ typedef struct sclens_hip_pattern sclens_hip_pattern;
 int sclens_hip_pattern_create(sclens_hip_ctx* ctx, int64_t N, int64_t M, const int64_t* colptr, const int32_t* rowval,
                               const float* nzval, int64_t n_cand, const uint32_t* z_idx1, const uint32_t* z_idx2,
                               sclens_hip_pattern** out);
+/* The same with the zero candidates drawn ON THE DEVICE (R1, scLENS.jl:668-673: nnz uniform (i, j) pairs minus the stored
+ * entries, first occurrences in draw order; the list sclens_draw_zero_candidates returns for the same seed) and merged into
+ * the union pattern there: the host passes only the counts' CSC. *n_cand = length of the candidate list.
+ * sclens_hip_pattern_candidates copies that list to the host (z1 = cells, z2 = genes, 0-based, n_cand entries each);
+ * sclens_hip_pattern_download copies one device array of the pattern (tests: which = 0 colptr[M+1] i64, 1 row[nU] i32,
+ * 2 rowptr[N+1] i64, 3 csr2csc[nU] i64, 4 csrcol[nU] i32, 5 cand_pos[n_cand] i64, 6 base_val[nU] f32). */
+int sclens_hip_pattern_create_drawn(sclens_hip_ctx* ctx, int64_t N, int64_t M, const int64_t* colptr, const int32_t* rowval,
+                                    const float* nzval, uint64_t seed, sclens_hip_pattern** out, int64_t* n_cand);
+int sclens_hip_pattern_candidates(sclens_hip_ctx* ctx, sclens_hip_pattern* p, uint32_t* z1, uint32_t* z2);
+int sclens_hip_pattern_download(sclens_hip_ctx* ctx, sclens_hip_pattern* p, int which, void* dst);
 void sclens_hip_pattern_destroy(sclens_hip_pattern* p);
 int sclens_hip_session_set_pattern(sclens_hip_session* s, sclens_hip_pattern* p);
 

@@ -62,6 +62,9 @@ SIGNATURES = {
     "sclens_hip_session_set_reducer": (C.c_int, [vp, ALLREDUCE_FN, vp]),
     "sclens_hip_session_shared_buffer": (C.c_int, [vp, C.c_int, i64, i64, c_f64p, C.POINTER(vp), c_i64p, c_i64p, c_i64p]),
     "sclens_hip_pattern_create": (C.c_int, [vp, i64, i64, c_i64p, c_i32p, c_f32p, i64, c_u32p, c_u32p, C.POINTER(vp)]),
+    "sclens_hip_pattern_create_drawn": (C.c_int, [vp, i64, i64, c_i64p, c_i32p, c_f32p, C.c_uint64, C.POINTER(vp), c_i64p]),
+    "sclens_hip_pattern_candidates": (C.c_int, [vp, vp, c_u32p, c_u32p]),
+    "sclens_hip_pattern_download": (C.c_int, [vp, vp, C.c_int, vp]),
     "sclens_hip_pattern_destroy": (None, [vp]),
     "sclens_hip_session_set_pattern": (C.c_int, [vp, vp]),
     "sclens_hip_session_null_spectrum_pattern": (C.c_int, [vp, vp, c_f64p]),

@@ -255,6 +255,9 @@ class Draws:
     # R4/R5: (kind, iteration, population, m) -> index vector; None = draw on the device from `sample_seed`
     sampler: Optional[Callable[[str, int, int, int], np.ndarray]] = None
     sample_seed: int = 0
+    # R1 on the device: z_idx1 / z_idx2 are None and the candidate list is drawn from this seed inside the library
+    # (sclens_hip_pattern_create_drawn; sclens_draw_zero_candidates(seed) gives the identical list on the host)
+    cand_seed: Optional[int] = None
 
 
 _M64 = (1 << 64) - 1
@@ -346,7 +349,7 @@ class _FutureItem:
 
 
 def make_draws_native(X, seed: int, host_sampler: bool = False, async_null: bool = False,
-                      async_candidates: bool = False) -> Draws:
+                      async_candidates: bool = False, device_candidates: bool = False) -> Draws:
     """All draws from the library's own generators (C++ on the host for R1/R2, the exact expectation for R3 --
     the quantity scLENS.jl:709-712 estimates with 5000 Monte-Carlo trials -- and the device-side keyed permutation
     for R4/R5). `host_sampler=True` materialises the identical R4/R5 index vectors on the host instead."""
@@ -369,7 +372,9 @@ def make_draws_native(X, seed: int, host_sampler: bool = False, async_null: bool
 
     # async_candidates: the candidate list is only needed once the sparsity search starts (sclens() attaches it to the
     # session after the first three decompositions), so it can be drawn on a host thread meanwhile
-    if async_candidates:
+    if device_candidates:  # R1 is drawn on the device when sclens() builds the union pattern (nothing to do on the host)
+        z1 = z2 = None
+    elif async_candidates:
         zf = _draw_pool.submit(candidates)
         z1, z2 = _FutureItem(zf, 0), _FutureItem(zf, 1)
     else:
@@ -391,6 +396,8 @@ def make_draws_native(X, seed: int, host_sampler: bool = False, async_null: bool
     Xr = _draw_pool.submit(null_matrix) if async_null else null_matrix()
     p_th = float(lib.sclens_noise_baseline_exact(min(N, M)))
     d = Draws(z1, z2, Xr, p_th, None, int(seed))
+    if device_candidates:
+        d.cand_seed = int(seed) & _M64
     if host_sampler:
         d.sampler = lambda kind, it, population, m: sample_indices(population, m, sample_seed_for(int(seed), kind, it))
     return d
@@ -427,6 +434,30 @@ class Pattern:
                                                     ptr(rowval, C.c_int32), ptr(nzval, C.c_float), self.ncand,
                                                     ptr(z1, C.c_uint32), ptr(z2, C.c_uint32), C.byref(h)))
         self.h = h
+
+    @classmethod
+    def drawn(cls, ctx: Context, X: sp.csc_matrix, seed: int) -> "Pattern":
+        """counts' CSC in; the zero candidates (R1) are drawn and merged into the union pattern on the device"""
+        p = cls.__new__(cls)
+        p.ctx = ctx
+        colptr = np.ascontiguousarray(X.indptr, dtype=np.int64)
+        rowval = np.ascontiguousarray(X.indices, dtype=np.int32)
+        nzval = np.ascontiguousarray(X.data, dtype=np.float32)
+        h, nc = C.c_void_p(), C.c_int64(0)
+        ctx.check(ctx.lib.sclens_hip_pattern_create_drawn(ctx.h, X.shape[0], X.shape[1], ptr(colptr, C.c_int64), ptr(rowval, C.c_int32),
+                                                          ptr(nzval, C.c_float), int(seed) & _M64, C.byref(h), C.byref(nc)))
+        p.h, p.ncand = h, int(nc.value)
+        return p
+
+    def candidates(self):
+        z1, z2 = np.empty(self.ncand, dtype=np.uint32), np.empty(self.ncand, dtype=np.uint32)
+        self.ctx.check(self.ctx.lib.sclens_hip_pattern_candidates(self.ctx.h, self.h, ptr(z1, C.c_uint32), ptr(z2, C.c_uint32)))
+        return z1, z2
+
+    def download(self, which: int, count: int) -> np.ndarray:
+        out = np.empty(count, dtype=[np.int64, np.int32, np.int64, np.int64, np.int32, np.int64, np.float32][which])
+        self.ctx.check(self.ctx.lib.sclens_hip_pattern_download(self.ctx.h, self.h, int(which), out.ctypes.data_as(C.c_void_p)))
+        return out
 
     def close(self):
         if getattr(self, "h", None):
@@ -760,6 +791,8 @@ def sclens(inp_df, device_="gpu", th=60, p_step=0.001, n_perturb=20, centering="
     aux_pool = ThreadPoolExecutor(max_workers=2)
 
     def build_pattern():
+        if draws.z_idx1 is None and draws.cand_seed is not None:  # R1 drawn on the device
+            return Pattern.drawn(aux_ctx, X_, draws.cand_seed), None, None
         z1_, z2_ = _resolve(draws.z_idx1), _resolve(draws.z_idx2)
         return Pattern(aux_ctx, X_, z1_, z2_), z1_, z2_
 
@@ -891,6 +924,7 @@ def sclens(inp_df, device_="gpu", th=60, p_step=0.001, n_perturb=20, centering="
                 w_bin = holder
         lap("spectra_signal_vectors_vr2")
         pat, z1, z2 = pat_future.result()
+        n_cand = pat.ncand
         ses.set_pattern(pat)
         for w in workers:  # share Vr2 (from w_bin), the seed block of the partial eigensolver and the pattern (from ses)
             if w is not w_bin:
@@ -909,9 +943,9 @@ def sclens(inp_df, device_="gpu", th=60, p_step=0.001, n_perturb=20, centering="
             def f():
                 nnzidx = int(round((1 - p_list[my_it]) * M * N))  # :726
                 out = np.full(6, np.nan)
-                if len(z1) >= nnzidx:
+                if n_cand >= nnzidx:
                     if draws.sampler is not None:
-                        idx = draws.sampler("search", my_it, len(z1), nnzidx)  # :731
+                        idx = draws.sampler("search", my_it, n_cand, nnzidx)  # :731
                         d5, _r = workers[wk].search_step(idx, n_2)  # :733-747
                     else:
                         d5, _r = workers[wk].search_step_seeded(sample_seed_for(draws.sample_seed, "search", my_it), nnzidx, n_2)
@@ -951,7 +985,7 @@ def sclens(inp_df, device_="gpu", th=60, p_step=0.001, n_perturb=20, centering="
                 def pert_job(wk, t):
                     def f():
                         if draws.sampler is not None:
-                            idx = draws.sampler("perturb", t, len(z1), m_pert)
+                            idx = draws.sampler("perturb", t, n_cand, m_pert)
                             return workers[wk].perturb(t, idx, min_pc)
                         return workers[wk].perturb_seeded(t, sample_seed_for(draws.sample_seed, "perturb", t), m_pert, min_pc)
                     return f

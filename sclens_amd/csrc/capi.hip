@@ -16,6 +16,9 @@ int session_spectrum(Session*, const int64_t*, const int32_t*, const float*, dou
 int session_null_spectrum(Session*, const int64_t*, const int32_t*, const float*, double*);
 int session_data_spectrum(Session*, double*, ScaleVecs*);
 int session_adopt(Session*, Session*, int);
+int pattern_create_drawn(Ctx*, int64_t, int64_t, const int64_t*, const int32_t*, const float*, uint64_t, PatternOwner**, int64_t*);
+int pattern_candidates(Ctx*, PatternOwner*, uint32_t*, uint32_t*);
+int pattern_download(Ctx*, PatternOwner*, int, void*);
 int pattern_create(Ctx*, int64_t, int64_t, const int64_t*, const int32_t*, const float*, int64_t, const uint32_t*,
                    const uint32_t*, PatternOwner**);
 void pattern_destroy(PatternOwner*);
@@ -286,6 +289,25 @@ int sclens_hip_pattern_create(sclens_hip_ctx* h, int64_t N, int64_t M, const int
   const int rc = scl::pattern_create(&h->c, N, M, colptr, rowval, nzval, n_cand, z1, z2, &p);
   if (rc == SCLENS_OK) *out = reinterpret_cast<sclens_hip_pattern*>(p);
   return rc;
+}
+int sclens_hip_pattern_create_drawn(sclens_hip_ctx* h, int64_t N, int64_t M, const int64_t* colptr, const int32_t* rowval,
+                                    const float* nzval, uint64_t seed, sclens_hip_pattern** out, int64_t* n_cand) {
+  CTX_GUARD(h);
+  if (!out) return SCLENS_ERR_ARG;
+  scl::PatternOwner* p = nullptr;
+  const int rc = scl::pattern_create_drawn(&h->c, N, M, colptr, rowval, nzval, seed, &p, n_cand);
+  if (rc == SCLENS_OK) *out = reinterpret_cast<sclens_hip_pattern*>(p);
+  return rc;
+}
+int sclens_hip_pattern_candidates(sclens_hip_ctx* h, sclens_hip_pattern* p, uint32_t* z1, uint32_t* z2) {
+  CTX_GUARD(h);
+  if (!p) return SCLENS_ERR_ARG;
+  return scl::pattern_candidates(&h->c, reinterpret_cast<scl::PatternOwner*>(p), z1, z2);
+}
+int sclens_hip_pattern_download(sclens_hip_ctx* h, sclens_hip_pattern* p, int which, void* dst) {
+  CTX_GUARD(h);
+  if (!p) return SCLENS_ERR_ARG;
+  return scl::pattern_download(&h->c, reinterpret_cast<scl::PatternOwner*>(p), which, dst);
 }
 void sclens_hip_pattern_destroy(sclens_hip_pattern* p) { scl::pattern_destroy(reinterpret_cast<scl::PatternOwner*>(p)); }
 int sclens_hip_session_set_pattern(sclens_hip_session* w, sclens_hip_pattern* p) {

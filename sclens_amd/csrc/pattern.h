@@ -18,6 +18,8 @@ struct PatternDev {
 struct PatternOwner {  // owns the device arrays of a PatternDev
   PatternDev dev;
   float* base_val = nullptr;  // [nU] stored counts, 0 in candidate slots
+  const uint32_t* z1_dev = nullptr;  // [ncand] candidate list on the device (device-built patterns; nullptr otherwise)
+  const uint32_t* z2_dev = nullptr;
   std::vector<void*> allocs;
 };
 
@@ -27,6 +29,10 @@ int pattern_build(Ctx* ctx, int64_t N, int64_t M, const int64_t* colptr, const i
                   int64_t ncand, const uint32_t* z1, const uint32_t* z2, PatternOwner* out, int64_t row0 = 0,
                   int64_t N_global = 0);
 void pattern_free(PatternOwner* p);
+// The same arrays built on the device from the counts' CSC (pattern_dev.hip); draw != 0 also draws the candidate list there
+// (R1, scLENS.jl:668-673; the list of sclens_draw_zero_candidates for the same seed). Sessions that hold all cells only.
+int pattern_build_device(Ctx* ctx, int64_t N, int64_t M, const int64_t* colptr, const int32_t* rowval, const float* nzval, int64_t ncand,
+                         const uint32_t* z1_h, const uint32_t* z2_h, int draw, uint64_t seed, PatternOwner* out);
 
 // Row-sharded session: the all-reduce the host supplies. dtype 0 = fp64, 1 = fp32; sum over all ranks, in
 // place, on a device buffer; called from the thread that made the session call, after the session's stream has been

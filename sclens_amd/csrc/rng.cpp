@@ -41,12 +41,7 @@ extern "C" {
 // [0, M) by a 128-bit multiply), so any number of host threads produces the same list: thread b owns a range of genes, walks
 // ALL draws, keeps those of its genes that its private bitmap (stored entries + earlier draws) has not seen, and the per-thread
 // survivor lists (each ascending in t) are merged back into draw order.
-static inline void r1_draw(uint64_t seed, uint64_t t, uint64_t N, uint64_t M, uint64_t* i, uint64_t* j) {
-  uint64_t s = seed + 0x632BE59BD9B4E019ull * (t + 1);
-  const uint64_t a = scl::splitmix64(s), b = scl::splitmix64(s);
-  *i = (uint64_t)(((__uint128_t)a * N) >> 64);
-  *j = (uint64_t)(((__uint128_t)b * M) >> 64);
-}
+using scl::r1_draw;
 
 static int host_threads(int64_t work_items) {
   return (int)std::max<int64_t>(1, std::min<int64_t>(scl::host_parallelism(), work_items / 500000 + 1));

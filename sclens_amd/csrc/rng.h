@@ -28,6 +28,23 @@ SCL_HD inline uint64_t splitmix64(uint64_t& s) {
   return z ^ (z >> 31);
 }
 
+// R1 (scLENS.jl:669): draw t of the zero-candidate list as a pure function of (seed, t): two splitmix64 outputs mapped to
+// [0, N) x [0, M) by the high half of a 64 x 64 bit product. Shared by the host generator (rng.cpp) and the device one
+// (pattern_dev.hip): both produce the same list.
+SCL_HD inline uint64_t mulhi64(uint64_t a, uint64_t b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return __umul64hi(a, b);
+#else
+  return (uint64_t)(((__uint128_t)a * b) >> 64);
+#endif
+}
+SCL_HD inline void r1_draw(uint64_t seed, uint64_t t, uint64_t N, uint64_t M, uint64_t* i, uint64_t* j) {
+  uint64_t s = seed + 0x632BE59BD9B4E019ull * (t + 1);
+  const uint64_t a = splitmix64(s), b = splitmix64(s);
+  *i = mulhi64(a, N);
+  *j = mulhi64(b, M);
+}
+
 struct FeistelPerm {
   uint64_t len;
   uint32_t half_bits, half_mask;

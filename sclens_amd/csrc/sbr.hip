@@ -1019,9 +1019,9 @@ int sb2st_f32(Ctx* ctx, const float* A, int64_t n, int64_t lda, double* d_dev, d
   int dev = 0, cus = 0;
   SCL_HIP(ctx, hipGetDevice(&dev));
   SCL_HIP(ctx, hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
-  // (at most half the CUs: three workgroups fit a CU, so the chases of up to six concurrent streams stay co-resident; the
-  // pipeline is bound by the lag between consecutive sweeps, not by the number of workgroups -- DESIGN.md)
-  int G = (int)std::min<int64_t>(cus > 0 ? cus / 2 : 64, n / (2 * SB) + 1);
+  // (three workgroups fit a CU -- 145 VGPRs, 36 KB of LDS -- so the chases of up to three concurrent streams stay co-resident
+  // even at one workgroup per sweep in flight; SCLENS_HIP_CHASE_WGS lowers it. 128 workgroups: 330 ms, 235: 297 ms at n = 30 016)
+  int G = (int)std::min<int64_t>(cus > 0 ? cus : 64, n / (2 * SB) + 1);
   if (G < 1) G = 1;
   if (const char* eg = getenv("SCLENS_HIP_CHASE_WGS")) G = std::max(1, std::min(G, atoi(eg)));
   SbrChaseArgs ca{Bd, n, V2, ldv2, TAU2, ldt, done};
@@ -1145,7 +1145,7 @@ __global__ __launch_bounds__(64) void sbr_q2_build_t(const float* __restrict__ V
 // shared by the four waves, fetched one group ahead.
 // Z is addressed as Zq[v * ldq + 3 + row]: every window starts at a row = 1 (mod 4), so the 4-row register quads are
 // 16-byte aligned in this shifted layout.
-constexpr int QJ = 4;
+constexpr int QJ = 4;                  // sweep blocks per pass (the DMA variant; the default kernel is templated on it)
 constexpr int QNT = 6 + 2 * (QJ - 1);
 constexpr int Q_RS = 100;  // floats per reflector in the LDS image: b128 reads 2-way, b32 reads conflict-free
 constexpr int Q_RT = 40;   // floats per row of Tg: conflict-free b128 reads
@@ -1271,6 +1271,7 @@ __device__ __forceinline__ void sbr_q2_stz(float* zrow, int64_t row, int64_t n, 
   }
 }
 
+template <int QJ, int QNT>
 __global__ __launch_bounds__(256, 1) void sbr_q2_apply16(SbrQ2Args a) {
   __shared__ __attribute__((aligned(16))) float lds[2 * Q_BUF];
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, vi = lane & 15, g = lane >> 4;
@@ -1479,7 +1480,13 @@ int sbr_apply_q2(Ctx* ctx, int64_t n, float* Zt, int64_t m, int64_t ldz) {
     // default: workgroup-shared staging with one barrier per group. The barrier-free variant below (per-wave images filled by
     // LDS-DMA) measured SLOWER (617 vs 512 ms at n = 30 016, m = 15 008): 48 DMA instructions per group and wave cost about
     // as many issue cycles as the group's 92 MFMAs.
-    hipLaunchKernelGGL(sbr_q2_apply16, dim3((unsigned)((m + 63) / 64)), dim3(256), 0, ctx->stream, qa);
+    const int qj = getenv("SCLENS_HIP_Q2_QJ") ? atoi(getenv("SCLENS_HIP_Q2_QJ")) : 4;
+    if (qj == 8)
+      hipLaunchKernelGGL((sbr_q2_apply16<8, 20>), dim3((unsigned)((m + 63) / 64)), dim3(256), 0, ctx->stream, qa);
+    else if (qj == 2)
+      hipLaunchKernelGGL((sbr_q2_apply16<2, 8>), dim3((unsigned)((m + 63) / 64)), dim3(256), 0, ctx->stream, qa);
+    else
+      hipLaunchKernelGGL((sbr_q2_apply16<4, 12>), dim3((unsigned)((m + 63) / 64)), dim3(256), 0, ctx->stream, qa);
   } else {
     const size_t lds_w = sizeof(float) * 4 * 2 * Q_BUF2;
     static const hipError_t attr_rc = hipFuncSetAttribute(reinterpret_cast<const void*>(sbr_q2_apply16w),

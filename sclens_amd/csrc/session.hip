@@ -121,6 +121,10 @@ int pattern_build(Ctx* ctx, int64_t N, int64_t M, const int64_t* colptr, const i
     return ctx->fail(SCLENS_ERR_ARG, "pattern_build: bad arguments");
   if (N_global <= 0) N_global = N;
   if (row0 < 0 || row0 + N > N_global) return ctx->fail(SCLENS_ERR_ARG, "pattern_build: bad row range");
+  // all cells in this session: the pattern is built on the device (pattern_dev.hip: identical arrays, no host passes);
+  // SCLENS_HIP_HOST_PATTERN=1 keeps the host builder (tests compare the two)
+  if (row0 == 0 && N_global == N && !getenv("SCLENS_HIP_HOST_PATTERN"))
+    return pattern_build_device(ctx, N, M, colptr, rowval, nzval, ncand, z1, z2, 0, 0, out);
   const int64_t nnz = colptr[M];
   // candidates whose cell lies in [row0, row0 + N) are local; the others keep their list index with slot -1
   auto local = [&](int64_t t) { return (int64_t)z1[t] >= row0 && (int64_t)z1[t] < row0 + N; };
@@ -221,6 +225,7 @@ void pattern_free(PatternOwner* p) {
   p->allocs.clear();
   p->dev = PatternDev();
   p->base_val = nullptr;
+  p->z1_dev = p->z2_dev = nullptr;
 }
 
 // `L .> 0` (scLENS.jl:495, :515) with a rounding floor. For N <= M the centred matrix has one structurally
@@ -350,6 +355,52 @@ int pattern_create(Ctx* ctx, int64_t N, int64_t M, const int64_t* colptr, const 
     return rc;
   }
   *out = p;
+  return SCLENS_OK;
+}
+// counts' CSC in, candidates drawn on the device (R1) and merged into the union pattern there
+int pattern_create_drawn(Ctx* ctx, int64_t N, int64_t M, const int64_t* colptr, const int32_t* rowval, const float* nzval, uint64_t seed,
+                         PatternOwner** out, int64_t* ncand) {
+  PatternOwner* p = new PatternOwner();
+  const int rc = pattern_build_device(ctx, N, M, colptr, rowval, nzval, 0, nullptr, nullptr, 1, seed, p);
+  if (rc != SCLENS_OK) {
+    pattern_free(p);
+    delete p;
+    return rc;
+  }
+  if (ncand) *ncand = p->dev.ncand;
+  *out = p;
+  return SCLENS_OK;
+}
+int pattern_candidates(Ctx* ctx, PatternOwner* p, uint32_t* z1, uint32_t* z2) {
+  if (!p || (p->dev.ncand > 0 && (!p->z1_dev || !p->z2_dev)))
+    return ctx->fail(SCLENS_ERR_STATE, "pattern_candidates: this pattern does not hold its candidate list on the device");
+  if (p->dev.ncand > 0) {
+    SCL_HIP(ctx, hipMemcpyAsync(z1, p->z1_dev, sizeof(uint32_t) * p->dev.ncand, hipMemcpyDeviceToHost, ctx->stream));
+    SCL_HIP(ctx, hipMemcpyAsync(z2, p->z2_dev, sizeof(uint32_t) * p->dev.ncand, hipMemcpyDeviceToHost, ctx->stream));
+    SCL_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  }
+  return SCLENS_OK;
+}
+// the device arrays of a pattern, for tests (host copies): which = 0 colptr[M+1] i64, 1 row[nU] i32, 2 rowptr[N+1] i64,
+// 3 csr2csc[nU] i64, 4 csrcol[nU] i32, 5 cand_pos[ncand] i64, 6 base_val[nU] f32
+int pattern_download(Ctx* ctx, PatternOwner* p, int which, void* dst) {
+  const PatternDev& d = p->dev;
+  const void* src = nullptr;
+  size_t bytes = 0;
+  switch (which) {
+    case 0: src = d.colptr; bytes = sizeof(int64_t) * (d.M + 1); break;
+    case 1: src = d.row; bytes = sizeof(int32_t) * d.nU; break;
+    case 2: src = d.rowptr; bytes = sizeof(int64_t) * (d.N + 1); break;
+    case 3: src = d.csr2csc; bytes = sizeof(int64_t) * d.nU; break;
+    case 4: src = d.csrcol; bytes = sizeof(int32_t) * d.nU; break;
+    case 5: src = d.cand_pos; bytes = sizeof(int64_t) * d.ncand; break;
+    case 6: src = p->base_val; bytes = sizeof(float) * d.nU; break;
+    default: return ctx->fail(SCLENS_ERR_ARG, "pattern_download: which must be 0..6");
+  }
+  if (bytes) {
+    SCL_HIP(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    SCL_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  }
   return SCLENS_OK;
 }
 void pattern_destroy(PatternOwner* p) {
