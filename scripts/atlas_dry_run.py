@@ -30,10 +30,12 @@ r0, r1 = row_block(0, world, N_total)
 t0 = time.perf_counter()
 X = api._csc_f32(synth_counts_rows(N_total, M, 20240427 + 4, r0, r1))
 log["slab"] = {"rows": [r0, r1], "nnz": int(X.nnz), "synth_s": round(time.perf_counter() - t0, 1)}
+print("[atlas] slab generated", log["slab"], file=sys.stderr, flush=True)
 t0 = time.perf_counter()
 d = api.make_draws_native(X, seed=1000)
 z1, z2, Xr = api._resolve(d.z_idx1), api._resolve(d.z_idx2), api._resolve(d.X_r)
 log["draws_s"] = round(time.perf_counter() - t0, 1)
+print("[atlas] draws", log["draws_s"], "s, candidates", len(z1), file=sys.stderr, flush=True)
 stat = {"calls": 0, "bytes": 0, "largest": 0}
 
 
@@ -55,6 +57,7 @@ def timed(name, f):
     r = f()
     ctx.sync()
     times[name] = round(time.perf_counter() - t, 3)
+    print(f"[atlas] {name}: {times[name]} s", file=sys.stderr, flush=True)
     return r
 
 
