@@ -565,8 +565,15 @@ int eig_vectors(Ctx* ctx, const float* A, int64_t n, int64_t lda, const double* 
       int64_t jn = i;
       while (jn + 1 < m && w[jn + 1] - w[jn] <= tol) ++jn;
       if (jn > i) {
-        hipLaunchKernelGGL(k_mgs_rows, dim3(1), dim3(256), 0, ctx->stream, Zt, ldz, n, i, (int)(jn - i + 1));
-        ctx->t_calls["degenerate_clusters"] += 1;
+        // one workgroup, O(cnt^2 n): meant for the handful of numerically coincident pairs of this path. A cluster of more
+        // than 128 (a rank-deficient input, e.g. thousands of exact null eigenvalues) is left as inverse iteration returned
+        // it -- unit vectors spanning the eigenspace, not orthogonalised -- and counted.
+        if (jn - i + 1 <= 128) {
+          hipLaunchKernelGGL(k_mgs_rows, dim3(1), dim3(256), 0, ctx->stream, Zt, ldz, n, i, (int)(jn - i + 1));
+          ctx->t_calls["degenerate_clusters"] += 1;
+        } else {
+          ctx->t_calls["degenerate_clusters_skipped"] += 1;
+        }
       }
       i = jn + 1;
     }

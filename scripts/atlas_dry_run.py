@@ -1,8 +1,8 @@
 """Atlas configuration (BASELINE.json configs[4]: 1M cells x 30k genes on 8 GPUs) -- dry run of ONE rank on one
 GPU: rank 0's slab of 125 000 cells is generated chunk-wise (`synth_counts_rows`, never dense on the host) and goes through
 the row-sharded session (`sclens_hip_session_create_sharded`) with the inter-rank all-reduce STUBBED (the callback counts
-calls and bytes and returns at once), so the numbers are this rank's compute time and HBM footprint; the spectra are those of
-the slab alone and are not checked. Candidates are drawn for the slab's own cells only (what each rank of a real run would
+calls and bytes and multiplies the buffer by the number of ranks, as if all ranks held this slab: no data moves), so the numbers
+are this rank's compute time and HBM footprint; the spectra are those of 8 copies of the slab and are not checked. Candidates are drawn for the slab's own cells only (what each rank of a real run would
 hold). Usage: atlas_dry_run.py [N_total world out.json]"""
 import json
 import os
@@ -14,6 +14,7 @@ import numpy as np
 
 from sclens_amd import _lib, api
 from sclens_amd.atlas import row_block
+from sclens_amd.shard import raw_device_tensor
 from sclens_amd.synth import synth_counts_rows
 
 N_total = int(sys.argv[1]) if len(sys.argv) > 1 else 1_000_000
@@ -40,10 +41,15 @@ stat = {"calls": 0, "bytes": 0, "largest": 0}
 
 
 def stub(_user, dev_ptr, count, dtype):
+    """stands in for the sum over `world` ranks: as if every rank held this same slab (buffer *= world), so that the
+    statistics stay consistent with N_total; no data moves"""
     nb = int(count) * (8 if dtype == 0 else 4)
     stat["calls"] += 1
     stat["bytes"] += nb
     stat["largest"] = max(stat["largest"], nb)
+    t = raw_device_tensor(dev_ptr, int(count), "<f8" if dtype == 0 else "<f4", torch.device("cuda", 0))
+    t.mul_(float(world))
+    torch.cuda.synchronize()
     return 0
 
 
