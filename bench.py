@@ -386,8 +386,13 @@ def main():
             stages = stage_probe(ctx, X, N, M)
             if "sy2sb_dense_to_band" in stages:  # two-stage solver: the MFMA contraction dominates
                 g = stages["gram"]
+                # HBM bytes per launch: not measured in this run -- rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes on the same
+                # kernel, shape and tile order (profiles/r02_pmc_gemm: 268.1e6 KB fetched, doubled as MI355X_MICROARCH.md
+                # prescribes for gfx950, + 3.52e6 KB written), quoted only for the workload they were taken on
+                traffic = 2 * 268.089e9 + 3.516e9 if (n == 30000 and max(N, M) == 100000) else None
                 out["roofline"] = {"bound": "mfma", "kernel": "gemm_nt_big (Gram product)", "achieved": g["achieved"],
-                                   "peak": MFMA_F32_PEAK_TFS, "unit": "TFLOP/s", "frac": g["frac"], "traffic": None,
+                                   "peak": MFMA_F32_PEAK_TFS, "unit": "TFLOP/s", "frac": g["frac"], "traffic": traffic,
+                                   "traffic_source": "constant from profiles/r02_pmc_gemm (separate --pmc passes), not measured in this run",
                                    "n": n, "K": max(N, M), "launch_ms": g["ms"],
                                    "algorithmic_flop_per_launch": float(n) * (n + 1) * max(N, M)}
             else:
