@@ -1338,6 +1338,73 @@ __global__ __launch_bounds__(256, 1) void sbr_q2_apply16(SbrQ2Args a) {
   }
 }
 
+// Variant with ONE barrier per step of the sequence instead of one per group: the QJ groups of a step (the sweep blocks
+// bh, bh-1, .. at the same k) are staged together (2 x QJ images of 17.9 KB in dynamic LDS), so the waves run QJ groups = 368
+// MFMAs between two rendezvous and hipcc can move the operand reads of a group behind the MFMAs of the previous one.
+template <int QJ, int QNT>
+__global__ __launch_bounds__(256, 1) void sbr_q2_apply16s(SbrQ2Args a) {
+  extern __shared__ __attribute__((aligned(16))) float lds_s[];  // [2][QJ][Q_BUF]
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, vi = lane & 15, g = lane >> 4;
+  const int64_t v = (int64_t)blockIdx.x * 64 + wv * 16 + vi;
+  const bool live = v < a.m;
+  float* zrow = a.Zq + (live ? v : 0) * a.ldq + 3;
+  for (int i = tid; i < 2 * QJ * Q_BUF; i += 256) lds_s[i] = 0.f;  // outside the parallelogram the images stay zero
+  __syncthreads();
+  const int nsb = (a.nblk + QJ - 1) / QJ;
+  SbrQ2Fetch pf[QJ];
+#pragma unroll
+  for (int j = 0; j < QJ; ++j) {
+    sbr_q2_fetch16(pf[j], a, a.nblk - 1 - j, 0, tid);
+    sbr_q2_stash16(pf[j], lds_s + j * Q_BUF, tid);
+  }
+  __syncthreads();
+  int cur = 0;
+  f32x4 z[QNT];
+  for (int sb = 0; sb < nsb; ++sb) {
+    const int bh = a.nblk - 1 - sb * QJ, blow = bh - QJ + 1;
+    const int Kmax = sbr_tasks_of((int64_t)(blow > 0 ? blow : 0) * QW, a.n);
+    const int64_t base0 = (int64_t)blow * QW + 1;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the stores of the previous pass have left before rows are re-read
+#pragma unroll
+    for (int i = 0; i < QNT; ++i) z[i] = sbr_q2_ldz(zrow, base0 + 16 * i + 4 * g, a.n, live);
+    for (int t = 0; t < Kmax; ++t) {
+      const int64_t base = base0 + (int64_t)t * SB;
+      f32x4 pz[4];
+      const bool more = t + 1 < Kmax;
+      if (more) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) pz[i] = sbr_q2_ldz(zrow, base + 16 * (QNT + i) + 4 * g, a.n, live);
+      }
+      // the next step of the sequence: same sweep blocks at k + 1, or the next QJ blocks at k = 0
+      const int nbh = more ? bh : bh - QJ, nt = more ? t + 1 : 0;
+#pragma unroll
+      for (int j = 0; j < QJ; ++j) sbr_q2_fetch16(pf[j], a, nbh - j, nt, tid);
+      const float* cb = lds_s + cur * QJ * Q_BUF;
+#pragma unroll
+      for (int j = 0; j < QJ; ++j) {
+        const int b = bh - j;
+        if (b >= 0 && t < sbr_tasks_of((int64_t)b * QW, a.n)) sbr_q2_group16<Q_RT>(z + 2 * (QJ - 1 - j), cb + j * Q_BUF, vi, g);
+      }
+      float* nbuf = lds_s + (cur ^ 1) * QJ * Q_BUF;
+#pragma unroll
+      for (int j = 0; j < QJ; ++j) sbr_q2_stash16(pf[j], nbuf + j * Q_BUF, tid);
+      __syncthreads();
+      cur ^= 1;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) sbr_q2_stz(zrow, base + 16 * i + 4 * g, a.n, live, z[i]);
+      if (more) {
+#pragma unroll
+        for (int i = 0; i + 4 < QNT; ++i) z[i] = z[i + 4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) z[QNT - 4 + i] = pz[i];
+      } else {
+#pragma unroll
+        for (int i = 4; i < QNT; ++i) sbr_q2_stz(zrow, base + 16 * i + 4 * g, a.n, live, z[i]);
+      }
+    }
+  }
+}
+
 // The same application without workgroup barriers: every wave stages the group data into LDS images OF ITS OWN with the
 // LDS-DMA path (`global_load_lds_dword`: no registers, no ds_write; one instruction per reflector = 64 consecutive floats
 // of V2 into the parallelogram row, 16 instructions for the 32 x 32 T factor), one group ahead, and orders them against its
@@ -1480,6 +1547,13 @@ int sbr_apply_q2(Ctx* ctx, int64_t n, float* Zt, int64_t m, int64_t ldz) {
     // default: workgroup-shared staging with one barrier per group. The barrier-free variant below (per-wave images filled by
     // LDS-DMA) measured SLOWER (617 vs 512 ms at n = 30 016, m = 15 008): 48 DMA instructions per group and wave cost about
     // as many issue cycles as the group's 92 MFMAs.
+    if (getenv("SCLENS_HIP_Q2_STEP")) {  // one barrier per step of four groups (experiment)
+      const size_t lds_b = sizeof(float) * 2 * 4 * Q_BUF;
+      static const hipError_t arc = hipFuncSetAttribute(reinterpret_cast<const void*>(sbr_q2_apply16s<4, 12>),
+                                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_b);
+      SCL_HIP(ctx, arc);
+      hipLaunchKernelGGL((sbr_q2_apply16s<4, 12>), dim3((unsigned)((m + 63) / 64)), dim3(256), lds_b, ctx->stream, qa);
+    } else {
     const int qj = getenv("SCLENS_HIP_Q2_QJ") ? atoi(getenv("SCLENS_HIP_Q2_QJ")) : 4;
     if (qj == 8)
       hipLaunchKernelGGL((sbr_q2_apply16<8, 20>), dim3((unsigned)((m + 63) / 64)), dim3(256), 0, ctx->stream, qa);
@@ -1487,6 +1561,7 @@ int sbr_apply_q2(Ctx* ctx, int64_t n, float* Zt, int64_t m, int64_t ldz) {
       hipLaunchKernelGGL((sbr_q2_apply16<2, 8>), dim3((unsigned)((m + 63) / 64)), dim3(256), 0, ctx->stream, qa);
     else
       hipLaunchKernelGGL((sbr_q2_apply16<4, 12>), dim3((unsigned)((m + 63) / 64)), dim3(256), 0, ctx->stream, qa);
+    }
   } else {
     const size_t lds_w = sizeof(float) * 4 * 2 * Q_BUF2;
     static const hipError_t attr_rc = hipFuncSetAttribute(reinterpret_cast<const void*>(sbr_q2_apply16w),
