@@ -1165,18 +1165,14 @@ struct SbrQ2Fetch {
   float v[8], t[4];
 };
 
-// thread (wave w, lane l) moves the entries l of the reflectors c = w + 4 q (q < 8) and the T entries tid + 256 q: the
-// reflector index and every base address are wave-uniform (scalar registers), only the lane is a vector quantity
 __device__ __forceinline__ void sbr_q2_fetch16(SbrQ2Fetch& f, const SbrQ2Args& a, int b, int t, int tid) {
-  const int lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int64_t S = (int64_t)b * QW;
 #pragma unroll
   for (int q = 0; q < 8; ++q) {
-    const int c = w + 4 * q;
+    const int idx = tid + 256 * q, c = idx >> 6, rr = idx & 63;
     const int64_t s = S + c, rk = s + 1 + (int64_t)t * SB;
-    const bool have = (b >= 0) && (s + 2 < a.n) && (rk + lane < a.n);
-    const float* src = a.V2 + (s * a.ldv2 + rk);
-    f.v[q] = have ? src[lane] : 0.f;
+    const bool have = (b >= 0) && (s + 2 < a.n) && (rk + rr < a.n);
+    f.v[q] = have ? a.V2[s * a.ldv2 + rk + rr] : 0.f;
   }
   const bool tv = (b >= 0) && (t < a.nk);
   const float* tg = a.Tg + ((int64_t)(tv ? b : 0) * a.nk + (tv ? t : 0)) * QW * QW;
@@ -1185,11 +1181,10 @@ __device__ __forceinline__ void sbr_q2_fetch16(SbrQ2Fetch& f, const SbrQ2Args& a
 }
 
 __device__ __forceinline__ void sbr_q2_stash16(const SbrQ2Fetch& f, float* buf, int tid) {
-  const int lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
 #pragma unroll
   for (int q = 0; q < 8; ++q) {
-    const int c = w + 4 * q;
-    buf[c * Q_RS + c + lane] = f.v[q];
+    const int idx = tid + 256 * q, c = idx >> 6, rr = idx & 63;
+    buf[c * Q_RS + c + rr] = f.v[q];
   }
   float* T = buf + QW * Q_RS;
 #pragma unroll
