@@ -1145,8 +1145,6 @@ __global__ __launch_bounds__(64) void sbr_q2_build_t(const float* __restrict__ V
 // shared by the four waves, fetched one group ahead.
 // Z is addressed as Zq[v * ldq + 3 + row]: every window starts at a row = 1 (mod 4), so the 4-row register quads are
 // 16-byte aligned in this shifted layout.
-constexpr int QJ = 4;                  // sweep blocks per pass (the DMA variant; the default kernel is templated on it)
-constexpr int QNT = 6 + 2 * (QJ - 1);
 constexpr int Q_RS = 100;  // floats per reflector in the LDS image: b128 reads 2-way, b32 reads conflict-free
 constexpr int Q_RT = 40;   // floats per row of Tg: conflict-free b128 reads
 constexpr int Q_BUF = QW * Q_RS + QW * Q_RT;
@@ -1338,170 +1336,6 @@ __global__ __launch_bounds__(256, 1) void sbr_q2_apply16(SbrQ2Args a) {
   }
 }
 
-// Variant with ONE barrier per step of the sequence instead of one per group: the QJ groups of a step (the sweep blocks
-// bh, bh-1, .. at the same k) are staged together (2 x QJ images of 17.9 KB in dynamic LDS), so the waves run QJ groups = 368
-// MFMAs between two rendezvous and hipcc can move the operand reads of a group behind the MFMAs of the previous one.
-template <int QJ, int QNT>
-__global__ __launch_bounds__(256, 1) void sbr_q2_apply16s(SbrQ2Args a) {
-  extern __shared__ __attribute__((aligned(16))) float lds_s[];  // [2][QJ][Q_BUF]
-  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, vi = lane & 15, g = lane >> 4;
-  const int64_t v = (int64_t)blockIdx.x * 64 + wv * 16 + vi;
-  const bool live = v < a.m;
-  float* zrow = a.Zq + (live ? v : 0) * a.ldq + 3;
-  for (int i = tid; i < 2 * QJ * Q_BUF; i += 256) lds_s[i] = 0.f;  // outside the parallelogram the images stay zero
-  __syncthreads();
-  const int nsb = (a.nblk + QJ - 1) / QJ;
-  SbrQ2Fetch pf[QJ];
-#pragma unroll
-  for (int j = 0; j < QJ; ++j) {
-    sbr_q2_fetch16(pf[j], a, a.nblk - 1 - j, 0, tid);
-    sbr_q2_stash16(pf[j], lds_s + j * Q_BUF, tid);
-  }
-  __syncthreads();
-  int cur = 0;
-  f32x4 z[QNT];
-  for (int sb = 0; sb < nsb; ++sb) {
-    const int bh = a.nblk - 1 - sb * QJ, blow = bh - QJ + 1;
-    const int Kmax = sbr_tasks_of((int64_t)(blow > 0 ? blow : 0) * QW, a.n);
-    const int64_t base0 = (int64_t)blow * QW + 1;
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the stores of the previous pass have left before rows are re-read
-#pragma unroll
-    for (int i = 0; i < QNT; ++i) z[i] = sbr_q2_ldz(zrow, base0 + 16 * i + 4 * g, a.n, live);
-    for (int t = 0; t < Kmax; ++t) {
-      const int64_t base = base0 + (int64_t)t * SB;
-      f32x4 pz[4];
-      const bool more = t + 1 < Kmax;
-      if (more) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) pz[i] = sbr_q2_ldz(zrow, base + 16 * (QNT + i) + 4 * g, a.n, live);
-      }
-      // the next step of the sequence: same sweep blocks at k + 1, or the next QJ blocks at k = 0
-      const int nbh = more ? bh : bh - QJ, nt = more ? t + 1 : 0;
-#pragma unroll
-      for (int j = 0; j < QJ; ++j) sbr_q2_fetch16(pf[j], a, nbh - j, nt, tid);
-      const float* cb = lds_s + cur * QJ * Q_BUF;
-#pragma unroll
-      for (int j = 0; j < QJ; ++j) {
-        const int b = bh - j;
-        if (b >= 0 && t < sbr_tasks_of((int64_t)b * QW, a.n)) sbr_q2_group16<Q_RT>(z + 2 * (QJ - 1 - j), cb + j * Q_BUF, vi, g);
-      }
-      float* nbuf = lds_s + (cur ^ 1) * QJ * Q_BUF;
-#pragma unroll
-      for (int j = 0; j < QJ; ++j) sbr_q2_stash16(pf[j], nbuf + j * Q_BUF, tid);
-      __syncthreads();
-      cur ^= 1;
-#pragma unroll
-      for (int i = 0; i < 4; ++i) sbr_q2_stz(zrow, base + 16 * i + 4 * g, a.n, live, z[i]);
-      if (more) {
-#pragma unroll
-        for (int i = 0; i + 4 < QNT; ++i) z[i] = z[i + 4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) z[QNT - 4 + i] = pz[i];
-      } else {
-#pragma unroll
-        for (int i = 4; i < QNT; ++i) sbr_q2_stz(zrow, base + 16 * i + 4 * g, a.n, live, z[i]);
-      }
-    }
-  }
-}
-
-// The same application without workgroup barriers: every wave stages the group data into LDS images OF ITS OWN with the
-// LDS-DMA path (`global_load_lds_dword`: no registers, no ds_write; one instruction per reflector = 64 consecutive floats
-// of V2 into the parallelogram row, 16 instructions for the 32 x 32 T factor), one group ahead, and orders them against its
-// own reads with `s_waitcnt vmcnt(0)`. Nothing is shared between waves, so a wave never waits for another one and hipcc can
-// pipeline the operand reads of a group behind the MFMAs of the previous one. The images hold zeros outside the
-// parallelogram (written once); reflectors that do not exist read zeros from V2 (zero-filled, one spare row) and have a zero
-// row / column in T. LDS: 4 waves x 2 buffers x 16.9 KB.
-constexpr int Q_RT2 = 32;
-constexpr int Q_BUF2 = QW * Q_RS + QW * Q_RT2;
-typedef __attribute__((address_space(3))) void sbr_lds_void;
-typedef const __attribute__((address_space(1))) void sbr_glb_void;
-
-__device__ __forceinline__ void sbr_q2_dma(const SbrQ2Args& a, int b, int t, float* buf, int lane) {
-  // the caller guarantees b >= 0 and t < nk (addresses stay inside V2 / Tg); contents may be those of a partial group
-  const int64_t S = (int64_t)b * QW;
-#pragma unroll
-  for (int c = 0; c < QW; ++c) {
-    const int64_t s = S + c;
-    const float* src = a.V2 + s * a.ldv2 + (s + 1 + (int64_t)t * SB) + lane;
-    __builtin_amdgcn_global_load_lds((sbr_glb_void*)src, (sbr_lds_void*)(buf + c * Q_RS + c), 4, 0, 0);
-  }
-  const float* tg = a.Tg + ((int64_t)b * a.nk + t) * QW * QW + lane;
-  float* T = buf + QW * Q_RS;
-#pragma unroll
-  for (int i = 0; i < QW * QW / 64; ++i)
-    __builtin_amdgcn_global_load_lds((sbr_glb_void*)(tg + 64 * i), (sbr_lds_void*)(T + 64 * i), 4, 0, 0);
-}
-
-__global__ __launch_bounds__(256, 1) void sbr_q2_apply16w(SbrQ2Args a) {
-  extern __shared__ __attribute__((aligned(16))) float lds_dyn[];
-  const int tid = threadIdx.x, lane = tid & 63, vi = lane & 15, g = lane >> 4;
-  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-  float* mybuf = lds_dyn + wv * 2 * Q_BUF2;
-  const int64_t v = (int64_t)blockIdx.x * 64 + wv * 16 + vi;
-  const bool live = v < a.m;
-  float* zrow = a.Zq + (live ? v : 0) * a.ldq + 3;
-  for (int i = lane; i < 2 * Q_BUF2; i += 64) mybuf[i] = 0.f;  // outside the parallelogram the images stay zero
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  const int nsb = (a.nblk + QJ - 1) / QJ;
-  sbr_q2_dma(a, a.nblk - 1, 0, mybuf, lane);
-  int cur = 0;
-  f32x4 z[QNT];
-  for (int sb = 0; sb < nsb; ++sb) {
-    const int bh = a.nblk - 1 - sb * QJ, blow = bh - QJ + 1;
-    const int Kmax = sbr_tasks_of((int64_t)(blow > 0 ? blow : 0) * QW, a.n);
-    const int64_t base0 = (int64_t)blow * QW + 1;
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the stores of the previous pass have left before rows are re-read
-#pragma unroll
-    for (int i = 0; i < QNT; ++i) z[i] = sbr_q2_ldz(zrow, base0 + 16 * i + 4 * g, a.n, live);
-    for (int t = 0; t < Kmax; ++t) {
-      const int64_t base = base0 + (int64_t)t * SB;
-      f32x4 pz[4];
-      const bool more = t + 1 < Kmax;
-      if (more) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) pz[i] = sbr_q2_ldz(zrow, base + 16 * (QNT + i) + 4 * g, a.n, live);
-      }
-#pragma unroll
-      for (int j = 0; j < QJ; ++j) {
-        int nb, nt;
-        if (j + 1 < QJ) {
-          nb = bh - (j + 1);
-          nt = t;
-        } else if (more) {
-          nb = bh;
-          nt = t + 1;
-        } else {
-          nb = bh - QJ;
-          nt = 0;
-        }
-        // this group's image (requested one group ago) has landed; then request the next one into the other buffer
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        const bool nvalid = nb >= 0 && nt < sbr_tasks_of((int64_t)nb * QW, a.n);
-        if (nvalid) sbr_q2_dma(a, nb, nt, mybuf + (cur ^ 1) * Q_BUF2, lane);
-        const int b = bh - j;
-        const bool valid = b >= 0 && t < sbr_tasks_of((int64_t)b * QW, a.n);
-        if (valid) sbr_q2_group16<Q_RT2>(z + 2 * (QJ - 1 - j), mybuf + cur * Q_BUF2, vi, g);
-        // the reads of this buffer must have returned before a later DMA may overwrite it (two groups from now): the MFMAs
-        // that consume them are issued before the next wait, and the buffer after next is this one again
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        cur ^= 1;  // every slot of the sequence alternates, valid or not: slot q + 1's image always goes to the other buffer
-      }
-#pragma unroll
-      for (int i = 0; i < 4; ++i) sbr_q2_stz(zrow, base + 16 * i + 4 * g, a.n, live, z[i]);
-      if (more) {
-#pragma unroll
-        for (int i = 0; i + 4 < QNT; ++i) z[i] = z[i + 4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) z[QNT - 4 + i] = pz[i];
-      } else {
-#pragma unroll
-        for (int i = 4; i < QNT; ++i) sbr_q2_stz(zrow, base + 16 * i + 4 * g, a.n, live, z[i]);
-      }
-    }
-  }
-}
-
 // Zq[v][3 + r] <-> Zt[v][r]
 __global__ void sbr_q2_shift(const float* __restrict__ in, int64_t ldi, int64_t offi, float* __restrict__ out, int64_t ldo,
                              int64_t offo, int64_t n) {
@@ -1543,32 +1377,12 @@ int sbr_apply_q2(Ctx* ctx, int64_t n, float* Zt, int64_t m, int64_t ldz) {
                        (int64_t)0, Zq + r0 * ldq, ldq, (int64_t)3, n);
   }
   SbrQ2Args qa{V2, ldv2, Tg, nk, nblk, n, Zq, m, ldq};
-  if (!getenv("SCLENS_HIP_Q2_DMA")) {
-    // default: workgroup-shared staging with one barrier per group. The barrier-free variant below (per-wave images filled by
-    // LDS-DMA) measured SLOWER (617 vs 512 ms at n = 30 016, m = 15 008): 48 DMA instructions per group and wave cost about
-    // as many issue cycles as the group's 92 MFMAs.
-    if (getenv("SCLENS_HIP_Q2_STEP")) {  // one barrier per step of four groups (experiment)
-      const size_t lds_b = sizeof(float) * 2 * 4 * Q_BUF;
-      static const hipError_t arc = hipFuncSetAttribute(reinterpret_cast<const void*>(sbr_q2_apply16s<4, 12>),
-                                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_b);
-      SCL_HIP(ctx, arc);
-      hipLaunchKernelGGL((sbr_q2_apply16s<4, 12>), dim3((unsigned)((m + 63) / 64)), dim3(256), lds_b, ctx->stream, qa);
-    } else {
-    const int qj = getenv("SCLENS_HIP_Q2_QJ") ? atoi(getenv("SCLENS_HIP_Q2_QJ")) : 4;
-    if (qj == 8)
-      hipLaunchKernelGGL((sbr_q2_apply16<8, 20>), dim3((unsigned)((m + 63) / 64)), dim3(256), 0, ctx->stream, qa);
-    else if (qj == 2)
-      hipLaunchKernelGGL((sbr_q2_apply16<2, 8>), dim3((unsigned)((m + 63) / 64)), dim3(256), 0, ctx->stream, qa);
-    else
-      hipLaunchKernelGGL((sbr_q2_apply16<4, 12>), dim3((unsigned)((m + 63) / 64)), dim3(256), 0, ctx->stream, qa);
-    }
-  } else {
-    const size_t lds_w = sizeof(float) * 4 * 2 * Q_BUF2;
-    static const hipError_t attr_rc = hipFuncSetAttribute(reinterpret_cast<const void*>(sbr_q2_apply16w),
-                                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_w);
-    SCL_HIP(ctx, attr_rc);
-    hipLaunchKernelGGL(sbr_q2_apply16w, dim3((unsigned)((m + 63) / 64)), dim3(256), lds_w, ctx->stream, qa);
-  }
+  // Measured and dropped (n = 30 016, m = 15 008; this kernel: 510 ms): a barrier-free variant with per-wave LDS images filled by
+  // LDS-DMA (617 ms: 48 DMA instructions per group and wave cost as many issue cycles as the group's 92 MFMAs), one barrier per
+  // step of four groups instead of one per group (533 ms), 2 / 8 sweep blocks per pass (599 / 1020 ms), wave-uniform scalar
+  // addressing of the group fetch (554 ms). PMC (profiles/r02_pmc_eig.txt): the MFMA pipe is busy 55 % of the wave cycles, 33 %
+  // of them issue other instructions, 23 % wait at barriers / waitcnt.
+  hipLaunchKernelGGL((sbr_q2_apply16<4, 12>), dim3((unsigned)((m + 63) / 64)), dim3(256), 0, ctx->stream, qa);
   for (int64_t r0 = 0; r0 < m; r0 += 65535) {
     const int64_t rows = (m - r0 < 65535) ? m - r0 : 65535;
     hipLaunchKernelGGL(sbr_q2_shift, dim3((unsigned)((n + 255) / 256), (unsigned)rows), dim3(256), 0, ctx->stream, Zq + r0 * ldq, ldq,
