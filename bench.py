@@ -270,10 +270,34 @@ def main():
     def agree(x):  # rank 0's decision on every rank (steps must match or the collectives dead-lock)
         return float(shard.bcast_host(np.array([float(x)]), 0)[0])
 
+    def cached_counts(cfg, N, M, seed):
+        """The seeded synthetic matrix, kept as an .npz in SCLENS_BENCH_CACHE (default: the temp dir; "0" disables) so that
+        back-to-back runs on one box (N = 1, 2, 4, 8) and the ranks of one run do not each spend a minute regenerating it."""
+        import scipy.sparse as sp
+        import tempfile
+
+        d = os.environ.get("SCLENS_BENCH_CACHE", tempfile.gettempdir())
+        path = os.path.join(d, f"sclens_bench_v2_{cfg}_{N}x{M}_{seed}.npz") if d not in ("", "0") else None
+        if path and os.path.exists(path):
+            try:
+                z = np.load(path)
+                return sp.csc_matrix((z["data"], z["indices"], z["indptr"]), shape=(N, M))
+            except Exception as e:  # truncated / foreign file: regenerate
+                print(f"[bench] ignoring cache {path}: {e}", file=sys.stderr)
+        X = synth_counts(N, M, seed=seed)
+        if path:
+            try:
+                tmp = f"{path}.{os.getpid()}.tmp.npz"
+                np.savez(tmp, data=X.data, indices=X.indices, indptr=X.indptr)
+                os.replace(tmp, path)
+            except OSError as e:
+                print(f"[bench] synthetic matrix not cached ({e})", file=sys.stderr)
+        return X
+
     def run_config(cfg, steps_req, warm_req, deadline):
         N, M, cfg_index = CONFIGS[cfg]
         t0 = time.perf_counter()
-        X = api._csc_f32(synth_counts(N, M, seed=20240427 + cfg_index))  # PCG64(20240427 + config_index)
+        X = api._csc_f32(cached_counts(cfg, N, M, 20240427 + cfg_index))  # SURVEY 8(d): PCG64(20240427 + config_index)
         t_synth = time.perf_counter() - t0
         row_shard = args.row_shard and N > M
         if row_shard:

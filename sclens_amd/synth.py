@@ -56,22 +56,32 @@ def synth_counts(N: int, M: int, seed: int, C: int = 8, sparsity: float = 0.90,
     # enforce the QC invariants by planting single counts where needed (deterministic given seed)
     mg = min(200, max(2, M // 20)) if min_genes_per_cell is None else min_genes_per_cell
     mc = min(15, max(2, N // 20)) if min_cells_per_gene is None else min_cells_per_gene
-    X = X.tolil()
-    csr_nnz = np.diff(X.tocsr().indptr)
-    for i in np.flatnonzero(csr_nnz < mg):
-        need = mg - csr_nnz[i]
-        zero_cols = np.setdiff1d(np.arange(M), np.asarray(X.rows[i]))
-        X[i, rng.choice(zero_cols, size=need, replace=False)] = 1.0
-    X = X.tocsc()
+    # (planted entries are collected as coordinates and added in one sparse sum: a LIL round trip of a 3e8-entry matrix
+    # cost a third of the generation time; the draws and the result are the same)
+    row_nnz = np.bincount(X.indices, minlength=N)
+    short_rows = np.flatnonzero(row_nnz < mg)
+    if len(short_rows):
+        Xr = X.tocsr()
+        pi, pj = [], []
+        for i in short_rows:
+            need = mg - row_nnz[i]
+            zero_cols = np.setdiff1d(np.arange(M), Xr.indices[Xr.indptr[i]:Xr.indptr[i + 1]])
+            pj.append(rng.choice(zero_cols, size=need, replace=False))
+            pi.append(np.full(need, i, dtype=np.int64))
+        pi, pj = np.concatenate(pi), np.concatenate(pj)
+        X = (X + sp.csc_matrix((np.ones(len(pi), np.float32), (pi, pj)), shape=(N, M))).tocsc()
+        X.sort_indices()
     col_nnz = np.diff(X.indptr)
-    if np.any(col_nnz < mc):
-        X = X.tolil()
-        Xc = X.tocsc()
-        for j in np.flatnonzero(col_nnz < mc):
-            present = Xc.indices[Xc.indptr[j]:Xc.indptr[j + 1]]
+    short_cols = np.flatnonzero(col_nnz < mc)
+    if len(short_cols):
+        pi, pj = [], []
+        for j in short_cols:
+            present = X.indices[X.indptr[j]:X.indptr[j + 1]]
             zero_rows = np.setdiff1d(np.arange(N), present)
-            X[rng.choice(zero_rows, size=mc - len(present), replace=False), j] = 1.0
-        X = X.tocsc()
+            pi.append(rng.choice(zero_rows, size=mc - len(present), replace=False))
+            pj.append(np.full(mc - len(present), j, dtype=np.int64))
+        pi, pj = np.concatenate(pi), np.concatenate(pj)
+        X = (X + sp.csc_matrix((np.ones(len(pi), np.float32), (pi, pj)), shape=(N, M))).tocsc()
     X.sort_indices()
     return X.astype(np.float32)
 
