@@ -115,6 +115,12 @@ int sclens_hip_preprocess_gather(sclens_hip_ctx* ctx, int64_t* out_colptr, int32
 int sclens_hip_scale_csc_f32(sclens_hip_ctx* ctx, int64_t N, int64_t M, const int64_t* colptr, const int32_t* rowval,
                              const float* nzval, int centering, int f32path, float* out, double* rec_tgc,
                              double* rec_mat2_mean, double* rec_mat2_std, double* rec_norm_tgc, double* rec_cent);
+/* Piece exposed for unit tests: the M x M Gram matrix (row-major, fp32) of logn_scale(pre_scale(P)) / divisor for the BINARISED
+ * counts P (every stored value counts as 1; scLENS.jl:664), N > M. use_bits = 0: scaled matrix + fp32 product (the general
+ * path); 1: weighted co-occurrence product on the fp16 MFMA without forming the scaled matrix (gram_bits.hip), which the
+ * sparsity search uses for large problems (context option "gram_bits"). */
+int sclens_hip_gram_binary_f32(sclens_hip_ctx* ctx, int64_t N, int64_t M, const int64_t* colptr, const int32_t* rowval,
+                               const float* nzval, int use_bits, float divisor, float* out);
 /* get_eigvec(X; device)  (scLENS.jl:489-524): X is N x M scaled data. nL[r] positive eigenvalues
  * descending, nV is N x r (cell-side eigenvectors, unit columns). On input *r = capacity in columns
  * (min(N,M) always suffices); on output the number of positive eigenvalues. keep_top > 0 limits the

@@ -167,6 +167,22 @@ def logn_scale(X, centering: str = "mean", inline_f64: bool = False, device="gpu
     return (out, rec) if inline_f64 else out
 
 
+def _gram_binary(X, use_bits: bool, divisor: Optional[float] = None, ctx: Optional[Context] = None) -> np.ndarray:
+    """Unit-test piece (sclens_hip_gram_binary_f32): M x M Gram matrix of logn_scale(pre_scale(P)) / divisor for the
+    binarised counts P of an N > M matrix; `use_bits` picks the fp16-MFMA co-occurrence product of the sparsity search
+    (csrc/gram_bits.hip) instead of the scaled matrix + fp32 product."""
+    ctx = ctx or default_context()
+    Xc = _csc_f32(X)
+    N, M = Xc.shape
+    colptr = np.ascontiguousarray(Xc.indptr, dtype=np.int64)
+    rowval = np.ascontiguousarray(Xc.indices, dtype=np.int32)
+    nzval = np.ascontiguousarray(Xc.data, dtype=np.float32)
+    out = np.empty((M, M), dtype=np.float32)
+    ctx.check(ctx.lib.sclens_hip_gram_binary_f32(ctx.h, N, M, ptr(colptr, C.c_int64), ptr(rowval, C.c_int32), ptr(nzval, C.c_float),
+                                                 1 if use_bits else 0, float(N if divisor is None else divisor), ptr(out, C.c_float)))
+    return out
+
+
 def get_denoised_df(inp_obj: Dict[str, object], device_="gpu", ctx: Optional[Context] = None) -> np.ndarray:
     """scLENS.jl:889-931: denoised count means from the robust signals of an sclens() result (N x M array; the
     reference wraps it in a DataFrame with `gene_id` columns and a `cell` column)."""
@@ -806,6 +822,7 @@ def sclens(inp_df, device_="gpu", th=60, p_step=0.001, n_perturb=20, centering="
         # local workers: `streams` sessions on this GPU (own stream + scratch each, shared read-only data), one host
         # thread per session (ctypes releases the GIL), so independent decompositions overlap on the device
         workers = [ses]
+        gb0 = ses.get_int("gram_bits_used")  # a context-lifetime counter: this call's share is the difference
         wctx = []
         for _ in range(max(1, int(streams)) - 1):
             c2 = Context(ctx.device)
@@ -1005,6 +1022,7 @@ def sclens(inp_df, device_="gpu", th=60, p_step=0.001, n_perturb=20, centering="
                 if shard.world > 1:
                     _exchange_ensemble(ses, shard, n_perturb, min_pc, nL_set, ncols)
             pe_counts = (sum(w.get_int("chefsi_used") for w in workers), sum(w.get_int("chefsi_fallback") for w in workers))
+            gram_bits_used = sum(w.get_int("gram_bits_used") for w in workers) - gb0
             lap("perturbation_ensemble")
         finally:
             if pool is not None:
@@ -1019,7 +1037,8 @@ def sclens(inp_df, device_="gpu", th=60, p_step=0.001, n_perturb=20, centering="
 
         res: Dict[str, object] = {"L": L, "L_mp": L_mp, "λ": lambda_c, "lambda_c": lambda_c, "cell_id": cell_id,
                                   "p_": p_, "p_th": p_th, "n_search": it, "search_trace": trace,
-                                  "partial_eig": pe_counts, "guard_band": guard}
+                                  "partial_eig": pe_counts, "guard_band": guard,
+                                  "gram_bits_used": gram_bits_used}
         if min_s == 0:  # :780-784
             res["wall_s"] = time.perf_counter() - t_all
             return res

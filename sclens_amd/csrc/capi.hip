@@ -44,6 +44,7 @@ int get_eigen_host(Ctx*, const float*, int64_t, float*, float*);
 int corr_mat_host(Ctx*, const float*, int64_t, int64_t, const float*, int64_t, float*);
 int get_eigvec_host(Ctx*, const float*, int64_t, int64_t, int64_t, float*, float*, int64_t*);
 int scale_csc_host(Ctx*, int64_t, int64_t, const int64_t*, const int32_t*, const float*, int, int, float*, ScaleVecs*);
+int gram_binary_host(Ctx*, int64_t, int64_t, const int64_t*, const int32_t*, const float*, int, float, float*);
 int denoise_host(Ctx*, const float*, int64_t, int64_t, const float*, int64_t, const double*, const double*, const double*,
                  const double*, const double*, float*);
 }  // namespace scl
@@ -71,6 +72,7 @@ int sclens_hip_create(sclens_hip_ctx** out, int device_id) {
     return SCLENS_ERR_NO_DEVICE;
   }
   if (const char* ts = getenv("SCLENS_HIP_TWO_STAGE")) h->c.two_stage = atoi(ts) < 0 ? -1 : (atoi(ts) != 0);
+  if (const char* gb = getenv("SCLENS_HIP_GRAM_BITS")) h->c.gram_bits = atoi(gb) < 0 ? -1 : (atoi(gb) != 0);
   *out = h;
   return SCLENS_OK;
 }
@@ -78,6 +80,10 @@ int sclens_hip_set_option(sclens_hip_ctx* h, const char* name, int64_t value) {
   if (!h || !name) return SCLENS_ERR_ARG;
   if (std::string(name) == "two_stage") {
     h->c.two_stage = value < 0 ? -1 : (value != 0);
+    return SCLENS_OK;
+  }
+  if (std::string(name) == "gram_bits") {
+    h->c.gram_bits = value < 0 ? -1 : (value != 0);
     return SCLENS_OK;
   }
   return h->c.fail(SCLENS_ERR_ARG, std::string("set_option: unknown option ") + name);
@@ -178,6 +184,11 @@ int sclens_hip_scale_csc_f32(sclens_hip_ctx* h, int64_t N, int64_t M, const int6
   if (any && !(rec_tgc && rec_mean && rec_std && rec_norm && rec_cent))
     return h->c.fail(SCLENS_ERR_ARG, "scale_csc: pass all rec_* buffers or none");
   return scl::scale_csc_host(&h->c, N, M, colptr, rowval, nzval, centering, f32path, out, any ? &k : nullptr);
+}
+int sclens_hip_gram_binary_f32(sclens_hip_ctx* h, int64_t N, int64_t M, const int64_t* colptr, const int32_t* rowval,
+                               const float* nzval, int use_bits, float divisor, float* out) {
+  CTX_GUARD(h);
+  return scl::gram_binary_host(&h->c, N, M, colptr, rowval, nzval, use_bits, divisor, out);
 }
 int sclens_hip_get_eigvec_f32(sclens_hip_ctx* h, const float* X, int64_t N, int64_t M, int64_t keep_top, float* nL,
                               float* nV, int64_t* r) {

@@ -41,6 +41,10 @@ struct Ctx {
   // set from SCLENS_HIP_TWO_STAGE at creation. last_two_stage: which path holds the state eig_vectors continues from.
   int two_stage = -1;
   bool last_two_stage = false;
+  // Gram matrix of a binary pattern on the fp16 MFMA (gram_bits.hip): 1 = whenever the layout allows, 0 = never, -1 = from the
+  // order (SCLENS_HIP_GRAM_BITS_MIN_N, default 16000); set from SCLENS_HIP_GRAM_BITS at creation. gram_bits_used counts calls.
+  int gram_bits = -1;
+  long gram_bits_used = 0;
   // sessions keep their eigenvector / ensemble buffers in this context's named workspaces ("ses.*", "eig.*"): one live
   // session per context (worker sessions of session_clone bring their own context)
   int live_sessions = 0;

@@ -412,7 +412,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_big(GemmArgs a, const int2* __
 
 // block -> tile list of gemm_nt_big: tiles ordered by squares of SQ x SQ tiles; chunk c of CH = SQ*SQ consecutive tiles goes
 // to the blocks {b : b % 8 == c % 8} in order (blocks are dealt round-robin over the 8 XCDs), padded with (-1,-1)
-static int big_tile_list(Ctx* ctx, int64_t tm, int64_t tn, int lower, const int2** out, int64_t* nblocks) {
+int big_tile_list(Ctx* ctx, int64_t tm, int64_t tn, int lower, const int2** out, int64_t* nblocks) {
   constexpr int SQ = 6, CH = SQ * SQ;  // (a single tile column degenerates to runs of 36 row tiles per XCD)
   const std::string key = "gemm.tiles." + std::to_string(tm) + "x" + std::to_string(tn) + (lower ? "L" : "F");
   std::vector<int2> seq;

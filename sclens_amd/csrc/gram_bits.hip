@@ -1,0 +1,341 @@
+// Gram matrix of the scaled matrix of a BINARY count pattern without forming the scaled matrix.
+//
+// The sparsity search (scLENS.jl:725-751) decomposes ~20 matrices `logn_scale(pre_scale(P))` whose counts are all 0 or 1
+// (scLENS.jl:664 binarises, :735 adds ones). For such a matrix every stored entry of cell i has the same value
+// l_i = log1p(1 / TGC_i) (proj_l + log1p, scLENS.jl:607, :650), so with the statistics of scale.hip
+//     B_ij = s_i (P_ij l_i / std_j - mu_j) - cent_j          (scale.hip header; mean centring, cent_j = column mean)
+// and the Gram matrix over genes is a weighted co-occurrence count plus rank-one terms:
+//     (B'B)_jk = d_j d_k C_jk - u_j mu_k - mu_j u_k + S2 mu_j mu_k - N cent_j cent_k ,
+//     C = P' diag(w) P ,  w_i = (s_i l_i)^2 ,  d_j = 1/std_j ,  u_j = d_j sum_i P_ij s_i^2 l_i ,  S2 = sum(s_i^2) .
+// C is the only O(M^2 N) term and both of its factors are exact in 16 bits: P as fp16 0/1, and w split into NW fp16 pieces
+// w = w^(1) + w^(2) (+ w^(3)) (22 or 33 significant bits, scaled by a power of two into the fp16 range), so
+//     C = sum_t P' (diag(w^(t)) P)
+// runs on the fp16 MFMA (v_mfma_f32_32x32x16_f16, fp32 accumulate) with every product exact: the rounding is that of the fp32
+// accumulation, as in the fp32 product it replaces, at 1/16 of the MFMA cycles per piece. The rank-one terms and the final
+// combination are evaluated in fp64 in the epilogue.
+//
+// Kernel = the 256 x 256 NT kernel of gemm.hip re-typed: the same direct global -> LDS staging (rows of 128 B = 64 cells of
+// fp16), the same swizzle and XCD-aware tile list; per 16 cells a wave reads its 4 + 2 operand fragments and the NW weight
+// fragments (LDS broadcast), forms the weighted B fragments with packed fp16 multiplies (1.0 * w and 0 * w are exact) and
+// issues 8 NW MFMAs.
+#include "common.h"
+#include "pattern.h"
+
+namespace scl {
+
+int big_tile_list(Ctx* ctx, int64_t tm, int64_t tn, int lower, const int2** out, int64_t* nblocks);  // gemm.hip
+
+namespace {
+
+typedef _Float16 h16x8 __attribute__((ext_vector_type(8)));
+typedef float v16f __attribute__((ext_vector_type(16)));
+typedef float v4f __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) void lds_void_t;
+typedef const __attribute__((address_space(1))) void glb_void_t;
+
+__device__ __forceinline__ double wsum_d(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+
+// w_i = (s_i l_i)^2 and sa_i = s_i^2 l_i, l_i as the closure path rounds it (scale.hip k_col_stats); block maxima -> wmax_part
+__global__ __launch_bounds__(256) void k_cell_weights(int64_t N, const double* __restrict__ tgc, const double* __restrict__ srow,
+                                                      int f32path, double* __restrict__ w, double* __restrict__ sa,
+                                                      double* __restrict__ wmax_part) {
+  __shared__ double sm[4];
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  double x = 0.0;
+  if (i < N) {
+    const double t = tgc[i];
+    double l = 0.0;
+    if (t > 0.0) l = f32path ? (double)log1pf((1.0f / (float)t) * 1.0f) : log1p(1.0 / t);
+    const double a = srow[i] * l;
+    x = a * a;
+    w[i] = x;
+    sa[i] = srow[i] * a;
+  }
+  double m = x;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) m = fmax(m, __shfl_xor(m, o));
+  if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) wmax_part[blockIdx.x] = fmax(fmax(sm[0], sm[1]), fmax(sm[2], sm[3]));
+}
+
+// sc[0] = 1 / scale with scale = the power of two that puts max w into [2^14, 2^15); sc[1] = scale; sc[2] = sum s_i^2
+__global__ __launch_bounds__(1024) void k_weight_scale(const double* __restrict__ wmax_part, int64_t nparts,
+                                                       const double* __restrict__ srow, int64_t N, double* __restrict__ sc) {
+  __shared__ double sm[16], ss[16];
+  double m = 0.0, s2 = 0.0;
+  for (int64_t i = threadIdx.x; i < nparts; i += 1024) m = fmax(m, wmax_part[i]);
+  for (int64_t i = threadIdx.x; i < N; i += 1024) s2 += srow[i] * srow[i];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) m = fmax(m, __shfl_xor(m, o));
+  s2 = wsum_d(s2);
+  if ((threadIdx.x & 63) == 0) {
+    sm[threadIdx.x >> 6] = m;
+    ss[threadIdx.x >> 6] = s2;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double mm = 0.0, t = 0.0;
+    for (int w = 0; w < 16; ++w) {
+      mm = fmax(mm, sm[w]);
+      t += ss[w];
+    }
+    const double scale = (mm > 0.0 && isfinite(mm)) ? ldexp(1.0, 14 - ilogb(mm)) : 1.0;
+    sc[0] = 1.0 / scale;
+    sc[1] = scale;
+    sc[2] = t;
+  }
+}
+
+// wq[(i / 8) * NW + t][i % 8] = t-th fp16 piece of scale * w_i (0 for the padding cells i >= N)
+__global__ __launch_bounds__(256) void k_split_weights(const double* __restrict__ w, int64_t N, int64_t ldm, int nw,
+                                                       const double* __restrict__ sc, _Float16* __restrict__ wq) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= ldm) return;
+  double x = i < N ? w[i] * sc[1] : 0.0;
+  for (int t = 0; t < nw; ++t) {
+    const _Float16 hv = (_Float16)(float)x;  // any rounding will do: the residual below is exact in fp64
+    wq[((i >> 3) * nw + t) * 8 + (i & 7)] = hv;
+    x -= (double)hv;
+  }
+}
+
+// gv[j] = (d_j, u_j, mu_j, cent_j), u_j = d_j sum over the cells of gene j of sa_i (CSC view, one wave per gene, fixed order)
+__global__ __launch_bounds__(256) void k_gene_vecs(PatternDev p, const float* __restrict__ val, const double* __restrict__ sa,
+                                                   const double* __restrict__ stdv, const double* __restrict__ mu,
+                                                   const double* __restrict__ cent, double4* __restrict__ gv) {
+  const int64_t col = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (col >= p.M) return;
+  double s = 0.0;
+  for (int64_t q = p.colptr[col] + lane; q < p.colptr[col + 1]; q += 64)
+    if (val[q] != 0.f) s += sa[p.row[q]];
+  s = wsum_d(s);
+  const double d = 1.0 / stdv[col];
+  if (lane == 0) gv[col] = make_double4(d, d * s, mu[col], cent[col]);
+}
+
+// fp16 image of P, genes-major: Pm[j * ldm + i] = 1.0 where val != 0 (the buffer was zero-filled)
+__global__ __launch_bounds__(256) void k_mask_scatter(PatternDev p, const float* __restrict__ val, unsigned short* __restrict__ Pm,
+                                                      int64_t ldm) {
+  const int64_t col = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (col >= p.M) return;
+  unsigned short* dst = Pm + col * ldm;
+  for (int64_t q = p.colptr[col] + lane; q < p.colptr[col + 1]; q += 64)
+    if (val[q] != 0.f) dst[p.row[q]] = 0x3C00u;
+}
+
+struct GramBitsArgs {
+  const unsigned short* Pm;  // [n][ldm] fp16 0/1, zero beyond the N cells
+  const _Float16* wq;        // [ldm / 8][NW][8]
+  const double4* gv;         // [n]
+  const double* sc;          // [0] = 1/scale of the weights, [2] = sum s^2
+  float* C;
+  int64_t n, ldm, ldc;
+  double Ncells, inv_div;
+};
+
+template <int NW>
+__global__ __launch_bounds__(512, 2) void gram_bits_kernel(GramBitsArgs a, const int2* __restrict__ tiles) {
+  constexpr int TM = 4, TN = 2;
+  constexpr int OPB = 256 * 128;             // bytes of one operand image: 256 rows of 64 fp16
+  constexpr int STAGE = 2 * OPB + 128 * NW;  // + the weight pieces of the stage's 64 cells
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+  const int2 tl = tiles[blockIdx.x];
+  if (tl.x < 0) return;
+  const int64_t m0 = (int64_t)tl.x * 256, n0 = (int64_t)tl.y * 256;
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int wm = wid >> 2, wn = wid & 3, l31 = lane & 31, h = lane >> 5;
+
+  // staging: wave w moves the 8-row groups 4 w .. 4 w + 3 of both operands; chunk q of row r lands in slot q ^ ((r >> 1) & 7)
+  const int srow = lane >> 3, sq = lane & 7;
+  const unsigned short* srcA[4];
+  const unsigned short* srcB[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int r = (wid * 4 + i) * 8 + srow;
+    const int chunk = sq ^ ((r >> 1) & 7);
+    int64_t ra = m0 + r, rb = n0 + r;
+    if (ra > a.n - 1) ra = a.n - 1;
+    if (rb > a.n - 1) rb = a.n - 1;
+    srcA[i] = a.Pm + ra * a.ldm + 8 * chunk;
+    srcB[i] = a.Pm + rb * a.ldm + 8 * chunk;
+  }
+  const int64_t nkt = a.ldm / 64;
+  auto stage = [&](int buf, int64_t kt) {
+    unsigned char* As = lds + buf * STAGE;
+    unsigned char* Bs = As + OPB;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      __builtin_amdgcn_global_load_lds((glb_void_t*)(srcA[i] + kt * 64), (lds_void_t*)(As + (wid * 4 + i) * 1024), 16, 0, 0);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      __builtin_amdgcn_global_load_lds((glb_void_t*)(srcB[i] + kt * 64), (lds_void_t*)(Bs + (wid * 4 + i) * 1024), 16, 0, 0);
+    if (wid == 7 && lane < 8 * NW)  // 8 chunks x NW pieces x 16 B, lane-linear
+      __builtin_amdgcn_global_load_lds((glb_void_t*)(a.wq + (kt * 8 * NW + lane) * 8), (lds_void_t*)(Bs + OPB), 16, 0, 0);
+  };
+
+  v16f acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  int offA[TM], offB[TN], swA[TM], swB[TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+    const int r = wm * 128 + i * 32 + l31;
+    offA[i] = r * 128;
+    swA[i] = (r >> 1) & 7;
+  }
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int r = wn * 64 + j * 32 + l31;
+    offB[j] = OPB + r * 128;
+    swB[j] = (r >> 1) & 7;
+  }
+
+  stage(0, 0);
+  __syncthreads();
+  for (int64_t kt = 0; kt < nkt; ++kt) {
+    const int buf = (int)(kt & 1);
+    if (kt + 1 < nkt) stage(buf ^ 1, kt + 1);
+    const unsigned char* S = lds + buf * STAGE;
+    const unsigned char* W = S + 2 * OPB;
+    // MFMA step kk takes the cells 8 (2 kk + h) .. + 7 of the stage: lane half h reads chunk c = 2 kk + h of A, B and w
+    h16x8 av[2][TM], bv[2][TN], wv[2][NW];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) av[0][i] = *reinterpret_cast<const h16x8*>(S + offA[i] + ((h ^ swA[i]) << 4));
+#pragma unroll
+    for (int j = 0; j < TN; ++j) bv[0][j] = *reinterpret_cast<const h16x8*>(S + offB[j] + ((h ^ swB[j]) << 4));
+#pragma unroll
+    for (int t = 0; t < NW; ++t) wv[0][t] = *reinterpret_cast<const h16x8*>(W + ((h * NW + t) << 4));
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+      const int cur = kk & 1, nxt = cur ^ 1;
+      if (kk + 1 < 4) {
+        const int c = 2 * (kk + 1) + h;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) av[nxt][i] = *reinterpret_cast<const h16x8*>(S + offA[i] + ((c ^ swA[i]) << 4));
+#pragma unroll
+        for (int j = 0; j < TN; ++j) bv[nxt][j] = *reinterpret_cast<const h16x8*>(S + offB[j] + ((c ^ swB[j]) << 4));
+#pragma unroll
+        for (int t = 0; t < NW; ++t) wv[nxt][t] = *reinterpret_cast<const h16x8*>(W + ((c * NW + t) << 4));
+      }
+      __builtin_amdgcn_sched_barrier(0);  // keep the reads of the next step ahead of this step's MFMAs
+#pragma unroll
+      for (int t = 0; t < NW; ++t) {
+        h16x8 bw[TN];
+#pragma unroll
+        for (int j = 0; j < TN; ++j) bw[j] = bv[cur][j] * wv[cur][t];
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(av[cur][i], bw[j], acc[i][j], 0, 0, 0);
+      }
+    }
+    __syncthreads();
+  }
+
+  // ---- epilogue (D layout: col = lane & 31, rows (e & 3) + 8 (e >> 2) + 4 (lane >> 5)): fp64 combination with the rank-one
+  //      terms, lower triangle + mirrored 16-byte stores
+  const double unscale = a.sc[0], S2 = a.sc[2];
+  const bool vec_mirror = (a.ldc % 4 == 0) && ((reinterpret_cast<uintptr_t>(a.C) & 15u) == 0);
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int64_t col = n0 + wn * 64 + j * 32 + l31;
+      const int64_t row0 = m0 + wm * 128 + i * 32 + 4 * h;
+      if (col >= a.n) continue;
+      const double4 gc = a.gv[col];
+      const double cd = gc.x * unscale;
+      v16f outv;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int64_t row = row0 + (e & 3) + 8 * (e >> 2);
+        double v = 0.0;
+        if (row < a.n) {
+          const double4 gr = a.gv[row];
+          v = (double)acc[i][j][e] * (cd * gr.x) - gr.y * gc.z - gr.z * gc.y + S2 * (gr.z * gc.z) - a.Ncells * (gr.w * gc.w);
+        }
+        outv[e] = (float)(v * a.inv_div);
+      }
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int64_t row = row0 + (e & 3) + 8 * (e >> 2);
+        if (row < a.n && col <= row) a.C[row * a.ldc + col] = outv[e];
+      }
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int64_t rowq = row0 + 8 * q;
+        if (vec_mirror && rowq + 3 < a.n && col < rowq) {
+          v4f v = {outv[4 * q], outv[4 * q + 1], outv[4 * q + 2], outv[4 * q + 3]};
+          *reinterpret_cast<v4f*>(&a.C[col * a.ldc + rowq]) = v;
+        } else {
+#pragma unroll
+          for (int u = 0; u < 4; ++u)
+            if (rowq + u < a.n && col < rowq + u) a.C[col * a.ldc + rowq + u] = outv[4 * q + u];
+        }
+      }
+    }
+}
+
+template <int NW>
+int launch_gram_bits(Ctx* ctx, const GramBitsArgs& a, const int2* tiles, int64_t nb) {
+  constexpr int LDS_BYTES = 2 * (2 * 256 * 128 + 128 * NW);
+  static const hipError_t attr_rc = hipFuncSetAttribute(reinterpret_cast<const void*>(gram_bits_kernel<NW>),
+                                                        hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+  SCL_HIP(ctx, attr_rc);
+  hipLaunchKernelGGL((gram_bits_kernel<NW>), dim3((unsigned)nb), dim3(512), LDS_BYTES, ctx->stream, a, tiles);
+  SCL_HIP(ctx, hipGetLastError());
+  return SCLENS_OK;
+}
+
+}  // namespace
+
+size_t gram_binary_scratch_bytes(int64_t N, int64_t M) { return sizeof(unsigned short) * (size_t)M * (size_t)round_up(N, 64); }
+
+int gram_binary(Ctx* ctx, const PatternDev& p, const float* val, int f32path, void* scratch, float divisor, float* A, int64_t lda) {
+  const int64_t N = p.N, M = p.M, ldm = round_up(N, 64);
+  const char* nw_env = getenv("SCLENS_HIP_GRAM_BITS_TERMS");  // 2 (22 bits of the weights, default) or 3 (33 bits)
+  const int nw = (nw_env && atoi(nw_env) == 3) ? 3 : 2;
+  hipStream_t st = ctx->stream;
+  unsigned short* Pm = static_cast<unsigned short*>(scratch);
+  const int64_t nparts = (N + 255) / 256;
+  SCL_WS(ctx, w, double, "gb.w", N);
+  SCL_WS(ctx, sa, double, "gb.sa", N);
+  SCL_WS(ctx, wpart, double, "gb.wpart", nparts);
+  SCL_WS(ctx, sc, double, "gb.sc", 4);
+  SCL_WS(ctx, wq, _Float16, "gb.wq", ldm * 3);
+  SCL_WS(ctx, gv, double4, "gb.gv", M);
+  {
+    StageTimer tm(ctx, "scale");
+    ScaleStats ss;
+    SCL_TRY(scale_stats(ctx, p, val, f32path, 0, &ss));
+    hipLaunchKernelGGL(k_cell_weights, dim3((unsigned)nparts), dim3(256), 0, st, N, ss.tgc, ss.srow, f32path, w, sa, wpart);
+    hipLaunchKernelGGL(k_weight_scale, dim3(1), dim3(1024), 0, st, wpart, nparts, ss.srow, N, sc);
+    hipLaunchKernelGGL(k_split_weights, dim3((unsigned)((ldm + 255) / 256)), dim3(256), 0, st, w, N, ldm, nw, sc, wq);
+    hipLaunchKernelGGL(k_gene_vecs, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, st, p, val, sa, ss.stdv, ss.mu, ss.cent, gv);
+    SCL_HIP(ctx, hipMemsetAsync(Pm, 0, gram_binary_scratch_bytes(N, M), st));
+    hipLaunchKernelGGL(k_mask_scatter, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, st, p, val, Pm, ldm);
+    SCL_HIP(ctx, hipGetLastError());
+  }
+  StageTimer tm(ctx, "gram");
+  SCL_HIP(ctx, hipMemsetAsync(A, 0, sizeof(float) * (size_t)M * lda, st));
+  const int64_t bm = (M + 255) / 256;
+  const int2* tiles = nullptr;
+  int64_t nb = 0;
+  SCL_TRY(big_tile_list(ctx, bm, bm, 1, &tiles, &nb));
+  GramBitsArgs a{Pm, wq, gv, sc, A, M, ldm, lda, (double)N, 1.0 / (double)divisor};
+  return nw == 3 ? launch_gram_bits<3>(ctx, a, tiles, nb) : launch_gram_bits<2>(ctx, a, tiles, nb);
+}
+
+}  // namespace scl

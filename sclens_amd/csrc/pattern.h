@@ -67,6 +67,19 @@ struct ScaleVecs {  // host destinations for rec_vals (scLENS.jl:676-696); all f
 int scale_to_dense(Ctx* ctx, const PatternDev& p, const float* val, int f32path, int centering, int cells_major,
                    float* B, int64_t ldb, ScaleVecs* keep);
 
+// the statistics alone (device pointers into the context's workspaces, valid until the next normalisation on this context)
+struct ScaleStats {
+  double *tgc, *lg, *mean, *stdv, *mu, *l2, *srow, *cent;
+  double* red;  // [0] = ||mu||^2, [1] = sum_i l_i, [2] = sum_i s_i
+};
+int scale_stats(Ctx* ctx, const PatternDev& p, const float* val, int f32path, int centering, ScaleStats* out);
+
+// Gram matrix of the scaled matrix of a BINARY value array (val in {0, 1}; mean centring, all cells on this device, N > M
+// layout) without forming the scaled matrix (gram_bits.hip): A (M x M, lda, zero padded, exactly symmetric) =
+// scaled(P)' scaled(P) / divisor. `scratch` holds the M x round_up(N, 64) fp16 image of P.
+size_t gram_binary_scratch_bytes(int64_t N, int64_t M);
+int gram_binary(Ctx* ctx, const PatternDev& p, const float* val, int f32path, void* scratch, float divisor, float* A, int64_t lda);
+
 // the same for a session that holds p.N of sh.N_global cells (N > M layout: B[j][i_local]); mean centring only
 int scale_to_dense_sharded(Ctx* ctx, const PatternDev& p, const float* val, int f32path, float* B, int64_t ldb,
                            ScaleVecs* keep, const ShardReduce& sh);

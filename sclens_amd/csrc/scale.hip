@@ -255,9 +255,7 @@ __global__ __launch_bounds__(256) void k_dense_scatter(PatternDev p, int cells_m
   }
 }
 
-int scale_to_dense(Ctx* ctx, const PatternDev& p, const float* val, int f32path, int centering, int cells_major,
-                   float* B, int64_t ldb, ScaleVecs* keep) {
-  StageTimer tm(ctx, "scale");
+int scale_stats(Ctx* ctx, const PatternDev& p, const float* val, int f32path, int centering, ScaleStats* out) {
   const int64_t N = p.N, M = p.M;
   SCL_WS(ctx, tgc, double, "sc.tgc", N);
   SCL_WS(ctx, lg, double, "sc.lg", p.nU);
@@ -285,6 +283,20 @@ int scale_to_dense(Ctx* ctx, const PatternDev& p, const float* val, int f32path,
     hipLaunchKernelGGL(k_col_cent, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, st, p, lg, stdv, mu, srow, red + 2,
                        cent);
   }
+  SCL_HIP(ctx, hipGetLastError());
+  *out = ScaleStats{tgc, lg, mean, stdv, mu, l2, srow, cent, red};
+  return SCLENS_OK;
+}
+
+int scale_to_dense(Ctx* ctx, const PatternDev& p, const float* val, int f32path, int centering, int cells_major,
+                   float* B, int64_t ldb, ScaleVecs* keep) {
+  StageTimer tm(ctx, "scale");
+  const int64_t N = p.N, M = p.M;
+  ScaleStats ss;
+  SCL_TRY(scale_stats(ctx, p, val, f32path, centering, &ss));
+  const double *tgc = ss.tgc, *lg = ss.lg, *mean = ss.mean, *stdv = ss.stdv, *mu = ss.mu, *l2 = ss.l2, *srow = ss.srow,
+               *cent = ss.cent;
+  hipStream_t st = ctx->stream;
   const int64_t nr = cells_major ? N : M, nc = cells_major ? M : N;
   if (nr > 65535LL * 65535LL) return ctx->fail(SCLENS_ERR_ARG, "scale_to_dense: too many rows");
   // grid.y is limited to 65535: loop over row slabs

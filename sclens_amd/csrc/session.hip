@@ -460,6 +460,8 @@ int session_clone(Ctx* ctx2, Session* src, Session** out) {
     return ctx2->fail(SCLENS_ERR_STATE, "session_clone: the worker needs a context of its own without a live session");
   Session* s = new Session();
   s->ctx = ctx2;
+  ctx2->two_stage = src->ctx->two_stage;  // the worker decomposes the way its parent does
+  ctx2->gram_bits = src->ctx->gram_bits;
   s->N = src->N; s->M = src->M; s->n = src->n; s->K = src->K;
   s->Kdiv = src->Kdiv;
   s->sh = src->sh;  // same cells; the worker gets its own reducer channel through session_set_reducer
@@ -492,9 +494,20 @@ void session_destroy(Session* s) {
 }
 
 // scaled dense matrix of `val` -> B, Gram -> A, eigenvalues -> w64/w_host
+// binary: every value of `val` is 0 or 1 (sparsity search): large problems in the genes-major layout then skip the scaled
+// matrix and form the Gram matrix on the fp16 MFMA (gram_bits.hip); B is only scratch in that case
+static bool use_gram_bits(const Session* s) {
+  if (s->sh.on() || s->centering || s->cells_major || s->ctx->gram_bits == 0) return false;
+  if (s->ctx->gram_bits == 1) return true;
+  static const int64_t min_n = getenv("SCLENS_HIP_GRAM_BITS_MIN_N") ? atoll(getenv("SCLENS_HIP_GRAM_BITS_MIN_N")) : 16000;
+  return s->n >= min_n;
+}
 static int decompose(Session* s, const PatternDev& p, const float* val, int f32path, float* B, float divisor,
-                     ScaleVecs* keep, int64_t n_low = -1) {
-  if (s->sh.on()) {  // partial statistics and a partial Gram matrix over this rank's cells, summed over the ranks
+                     ScaleVecs* keep, int64_t n_low = -1, bool binary = false) {
+  if (binary && !keep && use_gram_bits(s)) {
+    SCL_TRY(gram_binary(s->ctx, p, val, f32path, B, divisor, s->A, s->lda));
+    s->ctx->gram_bits_used += 1;
+  } else if (s->sh.on()) {  // partial statistics and a partial Gram matrix over this rank's cells, summed over the ranks
     SCL_TRY(scale_to_dense_sharded(s->ctx, p, val, f32path, B, s->ldb, keep, s->sh));
     SCL_TRY(gram_f32(s->ctx, B, s->n, s->K, s->ldb, divisor, s->A, s->lda));
     SCL_TRY(s->sh.sum(s->ctx, s->A, s->n * s->lda, 1));
@@ -758,7 +771,7 @@ int session_binary_basis(Session* s, double* L_bin, int64_t* r_out) {
   Ctx* ctx = s->ctx;
   SCL_TRY(make_values(ctx, s->pat.dev, s->pat.base_val, 1, nullptr, 0, s->val));
   // get_eigvec(scaled', ...) for N > M / get_eigvec(scaled) otherwise: n x n Gram, divisor = K (Appendix A8)
-  SCL_TRY(decompose(s, s->pat.dev, s->val, 1, s->Btmp, (float)s->Kdiv, nullptr));
+  SCL_TRY(decompose(s, s->pat.dev, s->val, 1, s->Btmp, (float)s->Kdiv, nullptr, -1, /*binary=*/true));
   if (L_bin) std::copy(s->w_host.begin(), s->w_host.end(), L_bin);
   const int64_t r = s->count_positive();
   s->r_vr2 = r;
@@ -801,7 +814,7 @@ static int search_core(Session* s, int64_t n_2, double* d5, int64_t* r_it) {
   // [0, n_2 + 1 + slack) cover the n_2 + 1 smallest positive ones unless more than `slack` are non-positive -- then all
   const int64_t slack = 64;
   const int64_t n_low = (n_2 + 1 + slack < s->n - 1) ? n_2 + 1 + slack : -1;
-  SCL_TRY(decompose(s, s->pat.dev, s->val, 1, s->Btmp, (float)s->Kdiv, nullptr, n_low));
+  SCL_TRY(decompose(s, s->pat.dev, s->val, 1, s->Btmp, (float)s->Kdiv, nullptr, n_low, /*binary=*/true));
   int64_t r = s->count_positive();
   if (n_low >= 0 && (s->n - r) > slack) {  // (never seen: a Gram matrix of the path has at most a few null eigenvalues)
     SCL_TRY(stebz_redo_all(s));
@@ -962,6 +975,7 @@ int session_get_int(Session* s, const char* name, int64_t* value) {
   if (k == "chefsi_fallback") { *value = s->chefsi_fallback; return SCLENS_OK; }
   if (k == "chefsi") { *value = s->use_chefsi; return SCLENS_OK; }
   if (k == "centering") { *value = s->centering; return SCLENS_OK; }
+  if (k == "gram_bits_used") { *value = s->ctx->gram_bits_used; return SCLENS_OK; }
   return s->ctx->fail(SCLENS_ERR_ARG, "session_get_int: unknown option " + k);
 }
 
@@ -1209,6 +1223,32 @@ int scale_csc_host(Ctx* ctx, int64_t N, int64_t M, const int64_t* colptr, const 
   if (rc == SCLENS_OK) rc = make_values(ctx, pr.dev, pr.base_val, 0, nullptr, 0, val);
   if (rc == SCLENS_OK) rc = scale_to_dense(ctx, pr.dev, val, centering ? 1 : f32path, centering, /*cells_major=*/0, B, ldb, keep);
   if (rc == SCLENS_OK) rc = download_packed(ctx, B, M, N, ldb, out);
+  hipStreamSynchronize(ctx->stream);
+  pattern_free(&pr);
+  return rc;
+}
+
+// Gram matrix of the scaled binarised counts, both ways (unit-test piece, see sclens_hip.h)
+int gram_binary_host(Ctx* ctx, int64_t N, int64_t M, const int64_t* colptr, const int32_t* rowval, const float* nzval, int use_bits,
+                     float divisor, float* out) {
+  if (!colptr || !rowval || !nzval || !out || N <= 0 || M <= 0 || N < M) return ctx->fail(SCLENS_ERR_ARG, "gram_binary: bad arguments");
+  PatternOwner pr;
+  SCL_TRY(pattern_build(ctx, N, M, colptr, rowval, nzval, 0, nullptr, nullptr, &pr));
+  const int64_t ldb = round_up(N, 64), lda = round_up(M, 32);
+  float* val = static_cast<float*>(ctx->workspace("w.scval", sizeof(float) * (size_t)pr.dev.nU));
+  float* B = static_cast<float*>(ctx->workspace("w.scB", sizeof(float) * (size_t)M * ldb));
+  float* A = static_cast<float*>(ctx->workspace("w.A", sizeof(float) * (size_t)M * lda));
+  int rc = (val && B && A) ? SCLENS_OK : SCLENS_ERR_OOM;
+  if (rc == SCLENS_OK) rc = make_values(ctx, pr.dev, pr.base_val, /*binary=*/1, nullptr, 0, val);
+  if (rc == SCLENS_OK) {
+    if (use_bits) {
+      rc = gram_binary(ctx, pr.dev, val, 1, B, divisor, A, lda);
+    } else {
+      rc = scale_to_dense(ctx, pr.dev, val, 1, 0, /*cells_major=*/0, B, ldb, nullptr);
+      if (rc == SCLENS_OK) rc = gram_f32(ctx, B, M, N, ldb, divisor, A, lda);
+    }
+  }
+  if (rc == SCLENS_OK) rc = download_packed(ctx, A, M, M, lda, out);
   hipStreamSynchronize(ctx->stream);
   pattern_free(&pr);
   return rc;

@@ -1,0 +1,84 @@
+"""-m gpu: the Gram matrix of a binarised, scaled count matrix formed on the fp16 MFMA as a weighted co-occurrence product
+(csrc/gram_bits.hip, the sparsity search's path for large N > M problems) against the float64 oracle and against the general
+path (scaled matrix + fp32 product), kernel level and end to end.
+
+Tolerance: both device paths accumulate in fp32; entries are compared relative to the largest entry of the Gram matrix
+(its diagonal), 2e-5, and the fp16 path may not be worse than twice the general path's own error (+ 1e-6)."""
+import os
+
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+from oracle import sclens_oracle as O
+from sclens_amd import api
+from sclens_amd.synth import synth_counts
+
+pytestmark = pytest.mark.gpu
+
+
+def _binarised(N, M, seed):
+    X = synth_counts(N, M, seed=seed, C=5, marker_frac=0.2, marker_sd=1.5).tocsc()
+    X.data[:] = 1.0
+    return X
+
+
+@pytest.mark.parametrize("N,M,terms", [(700, 300, 2), (1500, 520, 2), (2113, 1030, 2), (1500, 520, 3)])
+def test_gram_bits_matches_oracle_and_fp32_path(ctx, N, M, terms):
+    """sizes: M not a multiple of the 256-gene tile, N not a multiple of the 64-cell stage (zero-padded cells), more than one
+    tile row; 2 and 3 fp16 pieces of the cell weights."""
+    Xb = _binarised(N, M, seed=N + M)
+    S = np.asarray(O.logn_scale(O.pre_scale(Xb)), dtype=np.float64)  # N x M, the closure path of scLENS.jl:650-652
+    want = S.T @ S / N
+    os.environ["SCLENS_HIP_GRAM_BITS_TERMS"] = str(terms)
+    try:
+        got = api._gram_binary(Xb, use_bits=True, ctx=ctx)
+    finally:
+        del os.environ["SCLENS_HIP_GRAM_BITS_TERMS"]
+    dense = api._gram_binary(Xb, use_bits=False, ctx=ctx)
+    scale = np.abs(want).max()
+    e_bits, e_dense = np.abs(got - want).max() / scale, np.abs(dense - want).max() / scale
+    assert np.array_equal(got, got.T)  # exactly symmetric (mirrored stores)
+    assert e_bits < 2e-5, (e_bits, e_dense)
+    assert e_bits < 2 * e_dense + 1e-6, (e_bits, e_dense)
+    # spectrum: what the search consumes
+    wl, gl = np.linalg.eigvalsh(want), np.linalg.eigvalsh(got.astype(np.float64))
+    assert np.abs(wl - gl).max() < 2e-5 * wl.max()
+
+
+def test_gram_bits_other_divisor_and_dense_cells(ctx):
+    """a divisor other than N and cells that express most genes (large weights spread: TGC from ~20 to ~M)."""
+    N, M = 900, 400
+    rng = np.random.default_rng(3)
+    dens = np.concatenate([np.full(N // 3, 0.05), np.full(N // 3, 0.4), np.full(N - 2 * (N // 3), 0.95)])
+    P = (rng.random((N, M)) < dens[:, None]).astype(np.float32)
+    P[np.arange(N), rng.integers(0, M, size=N)] = 1.0  # every cell expresses something
+    P[rng.integers(0, N, size=M), np.arange(M)] = 1.0  # every gene is seen
+    Xb = sp.csc_matrix(P)
+    S = np.asarray(O.logn_scale(O.pre_scale(Xb)), dtype=np.float64)
+    want = S.T @ S / 123.0
+    got = api._gram_binary(Xb, use_bits=True, divisor=123.0, ctx=ctx)
+    assert np.abs(got - want).max() < 2e-5 * np.abs(want).max()
+
+
+def test_sclens_with_gram_bits_matches_oracle(ctx):
+    """End to end, N > M, the fp16 Gram path forced on (context option "gram_bits"): same decisions as the float64 oracle
+    on the same draws -- search length, p_, signal count -- and the search statistics within the fp32 tolerance."""
+    N, M = 600, 250
+    X = synth_counts(N, M, seed=1, C=5, marker_frac=0.2, marker_sd=1.5)
+    d = api.make_draws(X, seed=7, p_th_trials=300)
+    od = O.Draws(d.z_idx1, d.z_idx2, d.X_r, d.p_th, d.sampler)
+    ref = O.sclens(X, od, n_perturb=6, keep_intermediates=True, null_tol=O.NULL_DROP)
+    ctx.set_option("gram_bits", 1)
+    try:
+        res = api.sclens(X, draws=d, n_perturb=6, ctx=ctx, keep_intermediates=True, streams=1)
+    finally:
+        ctx.set_option("gram_bits", -1)
+    assert res["gram_bits_used"] >= res["n_search"] + 1  # binary basis + every search step took the fp16 path
+    assert res["n_search"] == ref["n_search"]
+    assert res["p_"] == ref["p_"]
+    for (p1, d1), (p2, d2) in zip(res["search_trace"], ref["search_trace"]):
+        assert p1 == p2
+        assert np.abs(d1 - d2).max() < 3e-3, (d1, d2)
+    assert len(res["signal_ev"]) == len(ref["signal_ev"]) > 0
+    assert list(res["sig_id"]) == list(ref["sig_id"])
