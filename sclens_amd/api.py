@@ -167,6 +167,19 @@ def logn_scale(X, centering: str = "mean", inline_f64: bool = False, device="gpu
     return (out, rec) if inline_f64 else out
 
 
+def _corr_colmax(X, Y, use_split: bool, ctx: Optional[Context] = None) -> np.ndarray:
+    """Unit-test piece (sclens_hip_corr_colmax_f32): max over the columns of X of |X' Y| per column of Y."""
+    ctx = ctx or default_context()
+    Xf = np.asfortranarray(X, dtype=np.float32)
+    Yf = np.asfortranarray(Y, dtype=np.float32)
+    n, p = Xf.shape
+    q = Yf.shape[1]
+    out = np.empty(q, dtype=np.float32)
+    ctx.check(ctx.lib.sclens_hip_corr_colmax_f32(ctx.h, ptr(Xf, C.c_float), n, p, ptr(Yf, C.c_float), q, 1 if use_split else 0,
+                                                 ptr(out, C.c_float)))
+    return out
+
+
 def _gram_binary(X, use_bits: bool, divisor: Optional[float] = None, ctx: Optional[Context] = None) -> np.ndarray:
     """Unit-test piece (sclens_hip_gram_binary_f32): M x M Gram matrix of logn_scale(pre_scale(P)) / divisor for the
     binarised counts P of an N > M matrix; `use_bits` picks the fp16-MFMA co-occurrence product of the sparsity search

@@ -44,6 +44,7 @@ int get_eigen_host(Ctx*, const float*, int64_t, float*, float*);
 int corr_mat_host(Ctx*, const float*, int64_t, int64_t, const float*, int64_t, float*);
 int get_eigvec_host(Ctx*, const float*, int64_t, int64_t, int64_t, float*, float*, int64_t*);
 int scale_csc_host(Ctx*, int64_t, int64_t, const int64_t*, const int32_t*, const float*, int, int, float*, ScaleVecs*);
+int corr_colmax_host(Ctx*, const float*, int64_t, int64_t, const float*, int64_t, int, float*);
 int gram_binary_host(Ctx*, int64_t, int64_t, const int64_t*, const int32_t*, const float*, int, float, float*);
 int denoise_host(Ctx*, const float*, int64_t, int64_t, const float*, int64_t, const double*, const double*, const double*,
                  const double*, const double*, float*);
@@ -184,6 +185,11 @@ int sclens_hip_scale_csc_f32(sclens_hip_ctx* h, int64_t N, int64_t M, const int6
   if (any && !(rec_tgc && rec_mean && rec_std && rec_norm && rec_cent))
     return h->c.fail(SCLENS_ERR_ARG, "scale_csc: pass all rec_* buffers or none");
   return scl::scale_csc_host(&h->c, N, M, colptr, rowval, nzval, centering, f32path, out, any ? &k : nullptr);
+}
+int sclens_hip_corr_colmax_f32(sclens_hip_ctx* h, const float* X, int64_t n, int64_t p, const float* Y, int64_t q, int use_split,
+                               float* out) {
+  CTX_GUARD(h);
+  return scl::corr_colmax_host(&h->c, X, n, p, Y, q, use_split, out);
 }
 int sclens_hip_gram_binary_f32(sclens_hip_ctx* h, int64_t N, int64_t M, const int64_t* colptr, const int32_t* rowval,
                                const float* nzval, int use_bits, float divisor, float* out) {

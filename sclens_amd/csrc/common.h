@@ -132,6 +132,12 @@ struct GemmArgs {
 };
 int gemm_f32(Ctx* ctx, const GemmArgs& a);
 
+// fp32-accurate NT products on the fp16 MFMA from operands split into two fp16 pieces (gram_bits.hip): the split image of
+// a row-major [rows][K] matrix, and colabsmax[j] = max(colabsmax[j], max_i |A_i . B_j|) from two images
+size_t split_image_bytes(int64_t rows, int64_t K);
+int split_image_f16(Ctx* ctx, const float* src, int64_t rows, int64_t K, int64_t ld, void* dst);
+int corr_colabsmax_split(Ctx* ctx, const void* Aimg, int64_t M, const void* Bimg, int64_t N, int64_t K, unsigned* colabsmax);
+
 // ------------------------------------------------------------------ eigensolver (tridiag.hip, trieig.hip)
 // Symmetric eigensolver on a device-resident n x n fp32 matrix A (row-major, lda, FULL storage,
 // exactly symmetric). A is destroyed (holds the Householder reflectors afterwards).

@@ -18,6 +18,8 @@
 // fp16), the same swizzle and XCD-aware tile list; per 16 cells a wave reads its 4 + 2 operand fragments and the NW weight
 // fragments (LDS broadcast), forms the weighted B fragments with packed fp16 multiplies (1.0 * w and 0 * w are exact) and
 // issues 8 NW MFMAs.
+#include <algorithm>
+
 #include "common.h"
 #include "pattern.h"
 
@@ -299,6 +301,134 @@ int launch_gram_bits(Ctx* ctx, const GramBitsArgs& a, const int2* tiles, int64_t
   return SCLENS_OK;
 }
 
+
+// ---- fp32-accurate NT product on the fp16 MFMA from operands split into two fp16 pieces ------------------------------------
+// The search statistic max_i |Vr2_i' nV2_j| (scLENS.jl:742) is a 3 10^4 x 1.5 10^4 x 3 10^4 product of unit vectors per step.
+// Each operand is scaled by 2^12 and split x = hi + lo (hi = fp16(x), lo = fp16(x - hi): 22 significant bits, the residual
+// is exact in fp32); a b = ah bh + ah bl + al bh up to the dropped al bl <= 2^-22 |a b| -- three fp16 MFMAs with fp32
+// accumulation in place of sixteen fp32 MFMA cycles. "Split image" of a row-major [rows][K] matrix: per row and per 32 k,
+// 32 hi then 32 lo halves (128 B), zero beyond K: the staging, swizzle and fragment reads of gram_bits_kernel apply unchanged
+// (chunks 0-3 of a stage row are the hi pieces, 4-7 the lo pieces).
+__global__ __launch_bounds__(256) void k_split_image(const float* __restrict__ src, int64_t rows, int64_t K, int64_t ld, int64_t Kp,
+                                                     _Float16* __restrict__ dst) {
+  const int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (k >= Kp) return;
+  for (int64_t r = blockIdx.y; r < rows; r += gridDim.y) {
+    const float x = k < K ? src[r * ld + k] * 4096.f : 0.f;
+    const _Float16 hi = (_Float16)x;
+    const _Float16 lo = (_Float16)(x - (float)hi);
+    _Float16* d = dst + r * 2 * Kp + (k >> 5) * 64 + (k & 31);
+    d[0] = hi;
+    d[32] = lo;
+  }
+}
+
+struct SplitCorrArgs {
+  const _Float16* A;  // split image, M rows
+  const _Float16* B;  // split image, N rows
+  int64_t M, N, Kp;
+  unsigned* colabsmax;  // [N] float bit patterns, zero-filled by the caller
+  float alpha;          // 2^-24: undoes the two operand scalings
+};
+
+__global__ __launch_bounds__(512, 2) void corr_split_kernel(SplitCorrArgs a, const int2* __restrict__ tiles) {
+  constexpr int TM = 4, TN = 2;
+  constexpr int OPB = 256 * 128, STAGE = 2 * OPB;
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+  const int2 tl = tiles[blockIdx.x];
+  if (tl.x < 0) return;
+  const int64_t m0 = (int64_t)tl.x * 256, n0 = (int64_t)tl.y * 256;
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int wm = wid >> 2, wn = wid & 3, l31 = lane & 31, h = lane >> 5;
+  const int srow = lane >> 3, sq = lane & 7;
+  const _Float16* srcA[4];
+  const _Float16* srcB[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int r = (wid * 4 + i) * 8 + srow;
+    const int chunk = sq ^ ((r >> 1) & 7);
+    int64_t ra = m0 + r, rb = n0 + r;
+    if (ra > a.M - 1) ra = a.M - 1;
+    if (rb > a.N - 1) rb = a.N - 1;
+    srcA[i] = a.A + ra * 2 * a.Kp + 8 * chunk;
+    srcB[i] = a.B + rb * 2 * a.Kp + 8 * chunk;
+  }
+  const int64_t nkt = a.Kp / 32;
+  auto stage = [&](int buf, int64_t kt) {
+    unsigned char* As = lds + buf * STAGE;
+    unsigned char* Bs = As + OPB;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      __builtin_amdgcn_global_load_lds((glb_void_t*)(srcA[i] + kt * 64), (lds_void_t*)(As + (wid * 4 + i) * 1024), 16, 0, 0);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      __builtin_amdgcn_global_load_lds((glb_void_t*)(srcB[i] + kt * 64), (lds_void_t*)(Bs + (wid * 4 + i) * 1024), 16, 0, 0);
+  };
+  v16f acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+  int offA[TM], offB[TN], swA[TM], swB[TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+    const int r = wm * 128 + i * 32 + l31;
+    offA[i] = r * 128;
+    swA[i] = (r >> 1) & 7;
+  }
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int r = wn * 64 + j * 32 + l31;
+    offB[j] = OPB + r * 128;
+    swB[j] = (r >> 1) & 7;
+  }
+  stage(0, 0);
+  __syncthreads();
+  for (int64_t kt = 0; kt < nkt; ++kt) {
+    const int buf = (int)(kt & 1);
+    if (kt + 1 < nkt) stage(buf ^ 1, kt + 1);
+    const unsigned char* S = lds + buf * STAGE;
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {  // 16 k per step: lane half h takes the 8 k of chunk 2 kk + h (hi) and 4 + 2 kk + h (lo)
+      const int ch = 2 * kk + h, cl = 4 + 2 * kk + h;
+      h16x8 ah[TM], al[TM], bh[TN], bl[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        ah[i] = *reinterpret_cast<const h16x8*>(S + offA[i] + ((ch ^ swA[i]) << 4));
+        al[i] = *reinterpret_cast<const h16x8*>(S + offA[i] + ((cl ^ swA[i]) << 4));
+      }
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        bh[j] = *reinterpret_cast<const h16x8*>(S + offB[j] + ((ch ^ swB[j]) << 4));
+        bl[j] = *reinterpret_cast<const h16x8*>(S + offB[j] + ((cl ^ swB[j]) << 4));
+      }
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh[j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+        }
+    }
+    __syncthreads();
+  }
+  // column maxima of |alpha acc| (rows beyond M hold copies of row M - 1: harmless for a maximum)
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    float mx = 0.f;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) mx = fmaxf(mx, fabsf(a.alpha * acc[i][j][e]));
+    mx = fmaxf(mx, __shfl_xor(mx, 32));
+    const int64_t col = n0 + wn * 64 + j * 32 + l31;
+    if (h == 0 && col < a.N) atomicMax(&a.colabsmax[col], __float_as_uint(mx));
+  }
+}
+
 }  // namespace
 
 size_t gram_binary_scratch_bytes(int64_t N, int64_t M) { return sizeof(unsigned short) * (size_t)M * (size_t)round_up(N, 64); }
@@ -336,6 +466,35 @@ int gram_binary(Ctx* ctx, const PatternDev& p, const float* val, int f32path, vo
   SCL_TRY(big_tile_list(ctx, bm, bm, 1, &tiles, &nb));
   GramBitsArgs a{Pm, wq, gv, sc, A, M, ldm, lda, (double)N, 1.0 / (double)divisor};
   return nw == 3 ? launch_gram_bits<3>(ctx, a, tiles, nb) : launch_gram_bits<2>(ctx, a, tiles, nb);
+}
+
+size_t split_image_bytes(int64_t rows, int64_t K) { return sizeof(_Float16) * (size_t)rows * 2 * (size_t)round_up(K, 32); }
+
+int split_image_f16(Ctx* ctx, const float* src, int64_t rows, int64_t K, int64_t ld, void* dst) {
+  if (rows <= 0) return SCLENS_OK;
+  const int64_t Kp = round_up(K, 32);
+  hipLaunchKernelGGL(k_split_image, dim3((unsigned)((Kp + 255) / 256), (unsigned)std::min<int64_t>(rows, 65535)), dim3(256), 0,
+                     ctx->stream, src, rows, K, ld, Kp, static_cast<_Float16*>(dst));
+  SCL_HIP(ctx, hipGetLastError());
+  return SCLENS_OK;
+}
+
+// colabsmax[j] = max(colabsmax[j], max_i |A_i . B_j|) for the split images of A [M][K] and B [N][K]
+int corr_colabsmax_split(Ctx* ctx, const void* Aimg, int64_t M, const void* Bimg, int64_t N, int64_t K, unsigned* colabsmax) {
+  if (M <= 0 || N <= 0) return SCLENS_OK;
+  const int64_t bm = (M + 255) / 256, bn = (N + 255) / 256;
+  const int2* tiles = nullptr;
+  int64_t nb = 0;
+  SCL_TRY(big_tile_list(ctx, bm, bn, 0, &tiles, &nb));
+  constexpr int LDS_BYTES = 2 * 2 * 256 * 128;
+  static const hipError_t attr_rc = hipFuncSetAttribute(reinterpret_cast<const void*>(corr_split_kernel),
+                                                        hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+  SCL_HIP(ctx, attr_rc);
+  SplitCorrArgs a{static_cast<const _Float16*>(Aimg), static_cast<const _Float16*>(Bimg), M, N, round_up(K, 32), colabsmax,
+                  1.0f / 16777216.0f};
+  hipLaunchKernelGGL(corr_split_kernel, dim3((unsigned)nb), dim3(512), LDS_BYTES, ctx->stream, a, tiles);
+  SCL_HIP(ctx, hipGetLastError());
+  return SCLENS_OK;
 }
 
 }  // namespace scl

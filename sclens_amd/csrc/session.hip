@@ -249,6 +249,9 @@ struct Session {
   float* val = nullptr;       // [nU] working value array
   float* Bmain = nullptr;     // scaled data matrix, [n][ldb]
   float* Btmp = nullptr;      // scaled null / binary / perturbed matrix
+  // split fp16 image of Vr2t for the search statistic on the fp16 MFMA (gram_bits.hip); valid while Vr2h_of == Vr2t
+  void* Vr2h = nullptr;
+  const float* Vr2h_of = nullptr;
   int64_t ldb = 0;
   float* A = nullptr;         // [n][lda] Gram / reflectors
   int64_t lda = 0;
@@ -502,6 +505,13 @@ static bool use_gram_bits(const Session* s) {
   static const int64_t min_n = getenv("SCLENS_HIP_GRAM_BITS_MIN_N") ? atoll(getenv("SCLENS_HIP_GRAM_BITS_MIN_N")) : 16000;
   return s->n >= min_n;
 }
+// the search statistic from split fp16 images (22-bit operands, fp32 accumulation) under the same switch
+static bool use_f16_corr(const Session* s) {
+  if (s->ctx->gram_bits == 0) return false;
+  if (s->ctx->gram_bits == 1) return true;
+  static const int64_t min_n = getenv("SCLENS_HIP_GRAM_BITS_MIN_N") ? atoll(getenv("SCLENS_HIP_GRAM_BITS_MIN_N")) : 16000;
+  return s->n >= min_n;
+}
 static int decompose(Session* s, const PatternDev& p, const float* val, int f32path, float* B, float divisor,
                      ScaleVecs* keep, int64_t n_low = -1, bool binary = false) {
   if (binary && !keep && use_gram_bits(s)) {
@@ -607,7 +617,7 @@ int session_adopt(Session* dst, Session* src, int what) {
     dst->pat.base_val = src->pat.base_val;
     SCL_TRY(session_realloc_val(dst));
   }
-  if (what & 1) { dst->Vr2t = src->Vr2t; dst->r_vr2 = src->r_vr2; }
+  if (what & 1) { dst->Vr2t = src->Vr2t; dst->r_vr2 = src->r_vr2; dst->Vr2h_of = nullptr; }
   if (what & 2) { dst->Z0t = src->Z0t; dst->theta0 = src->theta0; dst->b0 = src->b0; dst->k = src->k; }
   return SCLENS_OK;
 }
@@ -782,6 +792,7 @@ int session_binary_basis(Session* s, double* L_bin, int64_t* r_out) {
   float* v = static_cast<float*>(ctx->workspace("ses.Vr2t", sizeof(float) * (size_t)r * s->ldz));
   if (!v) return SCLENS_ERR_OOM;
   s->Vr2t = v;
+  s->Vr2h_of = nullptr;
   SCL_HIP(ctx, hipMemcpyAsync(v, s->Zt, sizeof(float) * (size_t)r * s->ldz, hipMemcpyDeviceToDevice, ctx->stream));
   // worker sessions adopt this pointer and read it from their own streams: the copy must have landed on return
   SCL_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -832,12 +843,25 @@ static int search_core(Session* s, int64_t n_2, double* d5, int64_t* r_it) {
   {
     StageTimer tm(ctx, "corr");
     SCL_HIP(ctx, hipMemsetAsync(cmax, 0, sizeof(unsigned) * (size_t)cnt, ctx->stream));
-    GemmArgs g{};  // |Vr2' * nV_2| column maxima (scLENS.jl:742), never materialised
-    g.P = s->Vr2t; g.Q = s->Zt; g.C = nullptr;
-    g.M = s->r_vr2; g.N = cnt; g.K = s->n;
-    g.ldp = s->ldz; g.ldq = s->ldz; g.ldc = 0;
-    g.alpha = 1.f; g.beta = 0.f; g.q_kcontig = 1; g.lower = 0; g.colabsmax = cmax;
-    SCL_TRY(gemm_f32(ctx, g));
+    if (use_f16_corr(s)) {  // |Vr2' * nV_2| column maxima (scLENS.jl:742) on the fp16 MFMA from split operands
+      if (s->Vr2h_of != s->Vr2t) {  // once per binary basis
+        s->Vr2h = ctx->workspace("ses.Vr2h", split_image_bytes(s->r_vr2, s->n));
+        if (!s->Vr2h) return SCLENS_ERR_OOM;
+        SCL_TRY(split_image_f16(ctx, s->Vr2t, s->r_vr2, s->n, s->ldz, s->Vr2h));
+        s->Vr2h_of = s->Vr2t;
+      }
+      void* zimg = ctx->workspace("ses.Zh", split_image_bytes(cnt, s->n));
+      if (!zimg) return SCLENS_ERR_OOM;
+      SCL_TRY(split_image_f16(ctx, s->Zt, cnt, s->n, s->ldz, zimg));
+      SCL_TRY(corr_colabsmax_split(ctx, s->Vr2h, s->r_vr2, zimg, cnt, s->n, cmax));
+    } else {
+      GemmArgs g{};  // the same, never materialised, on the fp32 MFMA
+      g.P = s->Vr2t; g.Q = s->Zt; g.C = nullptr;
+      g.M = s->r_vr2; g.N = cnt; g.K = s->n;
+      g.ldp = s->ldz; g.ldq = s->ldz; g.ldc = 0;
+      g.alpha = 1.f; g.beta = 0.f; g.q_kcontig = 1; g.lower = 0; g.colabsmax = cmax;
+      SCL_TRY(gemm_f32(ctx, g));
+    }
   }
   std::vector<float> d(cnt);
   SCL_HIP(ctx, hipMemcpyAsync(d.data(), cmax, sizeof(float) * (size_t)cnt, hipMemcpyDeviceToHost, ctx->stream));
@@ -1205,6 +1229,36 @@ int corr_mat_host(Ctx* ctx, const float* X, int64_t n, int64_t p, const float* Y
   g.alpha = 1.f; g.beta = 0.f; g.q_kcontig = 1; g.lower = 0; g.colabsmax = nullptr;
   SCL_TRY(gemm_f32(ctx, g));
   return download_packed(ctx, dC, q, p, ldc, out);
+}
+
+// out[j] = max_i |X_i' Y_j| (the search statistic, scLENS.jl:742), fp32 product or split fp16 images (unit-test piece)
+int corr_colmax_host(Ctx* ctx, const float* X, int64_t n, int64_t p, const float* Yv, int64_t q, int use_split, float* out) {
+  if (!X || !Yv || !out || n <= 0 || p <= 0 || q <= 0) return ctx->fail(SCLENS_ERR_ARG, "corr_colmax: bad arguments");
+  const int64_t ld = round_up(n, 32);
+  SCL_WS(ctx, dX, float, "c.X", p * ld);
+  SCL_WS(ctx, dY, float, "c.Y", q * ld);
+  SCL_WS(ctx, cmax, unsigned, "c.max", q);
+  SCL_TRY(upload_padded(ctx, X, p, n, dX, ld));
+  SCL_TRY(upload_padded(ctx, Yv, q, n, dY, ld));
+  SCL_HIP(ctx, hipMemsetAsync(cmax, 0, sizeof(unsigned) * (size_t)q, ctx->stream));
+  if (use_split) {
+    void* xi = ctx->workspace("c.Xh", split_image_bytes(p, n));
+    void* yi = ctx->workspace("c.Yh", split_image_bytes(q, n));
+    if (!xi || !yi) return SCLENS_ERR_OOM;
+    SCL_TRY(split_image_f16(ctx, dX, p, n, ld, xi));
+    SCL_TRY(split_image_f16(ctx, dY, q, n, ld, yi));
+    SCL_TRY(corr_colabsmax_split(ctx, xi, p, yi, q, n, cmax));
+  } else {
+    GemmArgs g{};
+    g.P = dX; g.Q = dY; g.C = nullptr;
+    g.M = p; g.N = q; g.K = n;
+    g.ldp = ld; g.ldq = ld; g.ldc = 0;
+    g.alpha = 1.f; g.beta = 0.f; g.q_kcontig = 1; g.lower = 0; g.colabsmax = cmax;
+    SCL_TRY(gemm_f32(ctx, g));
+  }
+  SCL_HIP(ctx, hipMemcpyAsync(out, cmax, sizeof(float) * (size_t)q, hipMemcpyDeviceToHost, ctx->stream));
+  SCL_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return SCLENS_OK;
 }
 
 // logn_scale(pre_scale(x)) (scLENS.jl:650-654) / the inline twin of the data matrix (:676-696) as a per-call drop-in:

@@ -82,3 +82,21 @@ def test_sclens_with_gram_bits_matches_oracle(ctx):
         assert np.abs(d1 - d2).max() < 3e-3, (d1, d2)
     assert len(res["signal_ev"]) == len(ref["signal_ev"]) > 0
     assert list(res["sig_id"]) == list(ref["sig_id"])
+
+
+@pytest.mark.parametrize("n,p,q", [(500, 300, 130), (1000, 777, 260), (2050, 520, 515)])
+def test_corr_colmax_split_fp16(ctx, n, p, q):
+    """max_i |X_i' Y_j| from split fp16 images against float64 and against the fp32 product: unit columns with entries over
+    several orders of magnitude (localised + delocalised vectors), n not a multiple of the 32-deep stage."""
+    rng = np.random.default_rng(n)
+    X = rng.standard_normal((n, p)) * np.exp(rng.normal(0, 2.0, size=(n, 1)))
+    Y = rng.standard_normal((n, q)) * np.exp(rng.normal(0, 2.0, size=(n, 1)))
+    Y[:, 0] = X[:, 3]  # one perfectly correlated pair
+    X /= np.linalg.norm(X, axis=0)
+    Y /= np.linalg.norm(Y, axis=0)
+    want = np.abs(X.astype(np.float32).astype(np.float64).T @ Y.astype(np.float32).astype(np.float64)).max(axis=0)
+    got = api._corr_colmax(X, Y, use_split=True, ctx=ctx)
+    ref32 = api._corr_colmax(X, Y, use_split=False, ctx=ctx)
+    assert abs(got[0] - 1.0) < 2e-6
+    assert np.abs(got - want).max() < 2e-6, np.abs(got - want).max()
+    assert np.abs(got - want).max() < 2 * np.abs(ref32 - want).max() + 1e-6
