@@ -77,12 +77,15 @@ __global__ __launch_bounds__(1024) void tri_bounds(const double* __restrict__ d,
 // latency chain, so trading 8x more lanes for 3x fewer sweeps is what a mostly idle chip wants.
 __global__ __launch_bounds__(64) void tri_bisect(const double* __restrict__ d, const double* __restrict__ e2,
                                                  int64_t n, const double* __restrict__ info,
-                                                 double* __restrict__ w, int64_t k_begin, int64_t k_end) {
+                                                 double* __restrict__ w, int64_t k_begin, int64_t k_end, int64_t k_extra) {
+  // k_extra >= 0: one more block at the end of the grid finds that single index (the largest eigenvalue of a partial
+  // spectrum) concurrently with the range -- as a launch of its own it costs a full latency chain of 18 x n steps
   const int q = threadIdx.x & 7;
-  const int64_t k = k_begin + (int64_t)blockIdx.x * 8 + (threadIdx.x >> 3);
+  const bool extra = k_extra >= 0 && blockIdx.x == gridDim.x - 1;
+  const int64_t k = extra ? k_extra + (threadIdx.x >> 3) : k_begin + (int64_t)blockIdx.x * 8 + (threadIdx.x >> 3);
   double lo = info[0], hi = info[1];
   const double pivmin = info[2], atol = EPS64 * info[4];
-  const bool live = k < k_end;
+  const bool live = extra ? (threadIdx.x >> 3) == 0 : k < k_end;
   if (info[5] != 0.0) {  // non-finite input (block-uniform)
     if (live && q == 0) w[k] = __longlong_as_double(0x7ff8000000000000LL);
     return;
@@ -94,12 +97,30 @@ __global__ __launch_bounds__(64) void tri_bisect(const double* __restrict__ d, c
     const double xq = lo + (double)(q + 1) * step;
     double p = d[0] - xq;
     if (fabs(p) < pivmin) p = -pivmin;
-    int64_t cnt = (p < 0.0) ? 1 : 0;
-    for (int64_t i = 1; i < n; ++i) {
-      p = d[i] - xq - e2[i - 1] / p;
+    int cnt = (p < 0.0) ? 1 : 0;
+    // e2 / p as e2 * (1/p): v_rcp_f64 refined by two Newton steps (|p| >= pivmin, so 1/p is finite) -- the full IEEE
+    // division sequence is twice as long and this chain is the whole kernel; eight steps per trip so that the (uniform,
+    // scalar) loads of d and e2 are issued as two wide loads ahead of the eight dependent steps
+    auto step1 = [&](double di, double ei) {
+      double r = __builtin_amdgcn_rcp(p);
+      r = fma(fma(-p, r, 1.0), r, r);
+      r = fma(fma(-p, r, 1.0), r, r);
+      p = (di - xq) - ei * r;
       if (fabs(p) < pivmin) p = -pivmin;
       cnt += (p < 0.0) ? 1 : 0;
+    };
+    int64_t i = 1;
+    for (; i + 8 <= n; i += 8) {
+      double dd[8], ee[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        dd[u] = d[i + u];
+        ee[u] = e2[i - 1 + u];
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) step1(dd[u], ee[u]);
     }
+    for (; i < n; ++i) step1(d[i], e2[i - 1]);
     // m = number of probe points of this group with count <= k (eigenvalue k is not below them)
     int below = (cnt <= k) ? 1 : 0;
     int m = below;
@@ -328,13 +349,12 @@ int stebz_f64(Ctx* ctx, const double* d_dev, const double* e_dev, int64_t n, dou
   SCL_WS(ctx, info, double, "tri.info", 8);
   hipLaunchKernelGGL(tri_bounds, dim3(1), dim3(1024), 0, ctx->stream, d_dev, e_dev, n, e2, info);
   if (n_low < 0 || n_low >= k_top) {
-    hipLaunchKernelGGL(tri_bisect, dim3((unsigned)((n + 7) / 8)), dim3(64), 0, ctx->stream, d_dev, e2, n, info, w_dev, (int64_t)0, n);
+    hipLaunchKernelGGL(tri_bisect, dim3((unsigned)((n + 7) / 8)), dim3(64), 0, ctx->stream, d_dev, e2, n, info, w_dev, (int64_t)0, n,
+                       (int64_t)-1);
   } else {
-    if (n_low > 0)
-      hipLaunchKernelGGL(tri_bisect, dim3((unsigned)((n_low + 7) / 8)), dim3(64), 0, ctx->stream, d_dev, e2, n, info, w_dev,
-                         (int64_t)0, n_low);
     hipLaunchKernelGGL(tri_fill_nan, dim3((unsigned)((n - n_low + 255) / 256)), dim3(256), 0, ctx->stream, w_dev, n_low, n);
-    hipLaunchKernelGGL(tri_bisect, dim3(1), dim3(64), 0, ctx->stream, d_dev, e2, n, info, w_dev, k_top, k_top + 1);
+    hipLaunchKernelGGL(tri_bisect, dim3((unsigned)((n_low + 7) / 8 + 1)), dim3(64), 0, ctx->stream, d_dev, e2, n, info, w_dev,
+                       (int64_t)0, n_low, k_top);
   }
   SCL_HIP(ctx, hipGetLastError());
   return SCLENS_OK;
