@@ -50,6 +50,7 @@ CONFIGS = {  # name -> (N cells, M genes, index in BASELINE.json configs)
     "cfg4": (100000, 30000, 3),
 }
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+MFMA_F16_PEAK_TFS = 2500.0  # dense fp16/bf16 MFMA peak (MI355X_MICROARCH.md)
 MFMA_F32_PEAK_TFS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 64 FLOP/clk/SIMD
 # HBM bytes per trd_colB launch / algorithmic bytes: constant from profiles/r01_pmc_final (rocprofv3 --pmc FETCH_SIZE and
 # --pmc WRITE_SIZE in separate runs; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950) -- NOT measured in this run
@@ -84,8 +85,17 @@ def stage_probe(ctx, X, N, M):
     ctx.set_timing(True)
     ctx.reset_timing()
     ses = api.Session(ctx, X)
+    bits_ms, extra = None, {}
     try:
         ses.data_spectrum(False)
+        if N > M:  # the Gram product of the binarised matrix as the sparsity search forms it (fp16 MFMA for large problems)
+            snap = lambda: {s: ctx.timing(s) for s in ("scale", "gram", "sytrd", "sy2sb", "sb2st", "stebz", "stein", "ormtr", "sbr_q2", "sbr_q1")}
+            before, gb0 = snap(), ses.get_int("gram_bits_used")
+            ses.binary_basis()
+            after = snap()
+            extra = {s: (after[s][0] - before[s][0], after[s][1] - before[s][1]) for s in after}  # kept out of the averages below
+            if ses.get_int("gram_bits_used") > gb0:
+                bits_ms = extra["gram"][0]
     finally:
         ses.close()
     if os.environ.get("SCLENS_BENCH_PROBE_VECTORS", "1") != "0":
@@ -109,6 +119,7 @@ def stage_probe(ctx, X, N, M):
                 ctx.free(q)
     names = ("scale", "gram", "sytrd", "sy2sb", "sb2st", "stebz", "stein", "ormtr", "sbr_q2", "sbr_q1")
     t = {s: ctx.timing(s) for s in names}
+    t = {s: (t[s][0] - extra.get(s, (0.0, 0))[0], t[s][1] - extra.get(s, (0.0, 0))[1]) for s in names}
     if "g0" in locals():  # the Gram of the data matrix only (the probe's small product is not the workload's)
         t["gram"] = g0
     ctx.set_timing(False)
@@ -125,6 +136,14 @@ def stage_probe(ctx, X, N, M):
     nnz = int(X.nnz)
     add("normalise", "scale", 8.0 * nnz + 4.0 * N * M, "GB/s", HBM_PEAK_GBS, "hbm", "8 nnz read + 4 N M written (SURVEY 8d B_norm)")
     add("gram", "gram", float(n) * (n + 1) * K, "TFLOP/s", MFMA_F32_PEAK_TFS, "mfma", "n (n+1) K flop (computed lower half)")
+    if bits_ms:
+        work = 2.0 * float(n) * (n + 1) * K  # two fp16 pieces of the cell weights: two MFMA products per gene pair and cell
+        ach = work / (bits_ms * 1e-3) / 1e12
+        stages["gram_binary_f16"] = {"bound": "mfma", "ms": round(bits_ms, 3), "achieved": round(ach, 1), "peak": MFMA_F16_PEAK_TFS,
+                                     "unit": "TFLOP/s", "frac": round(ach / MFMA_F16_PEAK_TFS, 4),
+                                     "work": "2 n (n+1) K flop issued on the fp16 MFMA (exact products, fp32 accumulation) for the "
+                                             "n (n+1) K flop of the fp32 product it replaces in the sparsity search",
+                                     "fp32_equivalent_TFLOPs": round(ach / 2.0, 1)}
     add("sytrd_one_stage", "sytrd", sum(2.0 * q * (q + 1) for q in range(1, n)), "GB/s", HBM_PEAK_GBS, "hbm",
         "lower triangle of the trailing matrix once per column, whole reduction")
     add("sy2sb_dense_to_band", "sy2sb", 4.0 / 3.0 * float(n) ** 3, "TFLOP/s", MFMA_F32_PEAK_TFS, "mfma", "4/3 n^3 flop")

@@ -143,11 +143,23 @@ int topk_chefsi(Ctx* ctx, const float* A, int64_t n, int64_t lda, int m, int m_s
   const int64_t tiles_n = (n + 127) / 128;
   int S = (int)((320 + tiles_n - 1) / tiles_n);
   S = std::max(Bop ? 4 : 1, std::min(S, 8));
+  // implicit operator: both products stream Bop once and are HBM-bound; S (second product) and S1 (first) cut the contractions
+  int S1 = 1;
+  if (Bop) {
+    // (measured at cfg4, 20 perturbations: S/S1 = 4/1 7.7 s, 9/3 7.5 s, 8/2 8.1 s, 16/6 25.8 s -- the products already run at
+    // about half of the HBM roofline and more slices do not help; the knobs stay for other shapes)
+    if (const char* e = getenv("SCLENS_HIP_CHEFSI_SPLITS")) S = std::max(1, std::min(16, atoi(e)));
+    if (const char* e = getenv("SCLENS_HIP_CHEFSI_SPLITS1")) S1 = std::max(1, std::min(16, atoi(e)));
+  }
   const int64_t ldt = Bop ? round_up(Kop, 32) : 0;
-  float* Tb = nullptr;
+  float *Tb = nullptr, *Tpart = nullptr;
   if (Bop) {
     Tb = static_cast<float*>(ctx->workspace("che.T", sizeof(float) * (size_t)b * ldt));
     if (!Tb) return SCLENS_ERR_OOM;
+    if (S1 > 1) {
+      Tpart = static_cast<float*>(ctx->workspace("che.Tp", sizeof(float) * (size_t)S1 * b * ldt));
+      if (!Tpart) return SCLENS_ERR_OOM;
+    }
   }
   const int64_t slab = (int64_t)b * ld;
   SCL_WS(ctx, X, float, "che.X", slab);
@@ -172,11 +184,17 @@ int topk_chefsi(Ctx* ctx, const float* A, int64_t n, int64_t lda, int m, int m_s
       // A = Bop Bop' / div is never formed: V A = (V Bop) Bop' / div, two products that stream Bop once each
       // (2 * 2 b n Kop flop against n^2 Kop for the Gram matrix: cheaper below ~n / (4 b) applications)
       GemmArgs g1{};
-      g1.P = V; g1.Q = Bop; g1.C = Tb;
+      g1.P = V; g1.Q = Bop; g1.C = S1 > 1 ? Tpart : Tb;
       g1.M = b; g1.N = Kop; g1.K = n;
       g1.ldp = ld; g1.ldq = ldb; g1.ldc = ldt;
       g1.alpha = 1.f; g1.beta = 0.f; g1.q_kcontig = 0; g1.lower = 0; g1.colabsmax = nullptr;
+      if (S1 > 1) {
+        g1.splits = S1; g1.k_chunk = round_up((n + S1 - 1) / S1, 16); g1.c_split_off = (int64_t)b * ldt;
+      }
       SCL_TRY(gemm_f32(ctx, g1));
+      if (S1 > 1)
+        hipLaunchKernelGGL(k_sum_slabs, dim3((unsigned)(((int64_t)b * ldt + 255) / 256)), dim3(256), 0, st, Tpart, S1, (int64_t)b * ldt, Tb,
+                           (int64_t)b * ldt);
       GemmArgs g2{};
       g2.P = Tb; g2.Q = Bop; g2.C = part;
       g2.M = b; g2.N = n; g2.K = Kop;
