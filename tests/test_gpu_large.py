@@ -59,7 +59,8 @@ def test_guard_band_is_applied_before_the_cut(ctx):
 
 def test_parity_order_6000_cells_gt_genes_two_stage(ctx, monkeypatch):
     """cfg3-shaped (cells > genes: the gene-side Gram matrix X'X, recovered cell-side vectors) at order n = 6 000 through the
-    two-stage eigensolver (dense -> band -> tridiagonal), against the float64 oracle on the same draws."""
+    large-problem path -- two-stage eigensolver (dense -> band -> tridiagonal), Gram matrices of the binarised search matrices
+    and the search statistic on the fp16 MFMA (gram_bits.hip) -- against the float64 oracle on the same draws."""
     from sclens_amd._lib import Context
 
     N, M = 9000, 6000
@@ -69,10 +70,12 @@ def test_parity_order_6000_cells_gt_genes_two_stage(ctx, monkeypatch):
     ref = O.sclens(X, od, n_perturb=2, max_search_iters=4, null_tol=O.NULL_DROP)
     monkeypatch.setenv("SCLENS_HIP_TWO_STAGE", "1")
     c2 = Context(ctx.device)
+    c2.set_option("gram_bits", 1)
     try:
         res = api.sclens(X, draws=api.make_draws_native(X, seed=11), n_perturb=2, max_search_iters=4, ctx=c2, streams=1)
     finally:
         c2.close()
+    assert res["gram_bits_used"] == res["n_search"] + 1
     k = len(ref["signal_ev"])
     assert len(res["signal_ev"]) == k >= 4  # retained-signal count identical
     assert np.allclose(res["signal_ev"], ref["signal_ev"], rtol=2e-4)
