@@ -121,7 +121,7 @@ def stage_probe(ctx, X, N, M):
     t = {s: ctx.timing(s) for s in names}
     t = {s: (t[s][0] - extra.get(s, (0.0, 0))[0], t[s][1] - extra.get(s, (0.0, 0))[1]) for s in names}
     if "g0" in locals():  # the Gram of the data matrix only (the probe's small product is not the workload's)
-        t["gram"] = g0
+        t["gram"] = (g0[0] - extra.get("gram", (0.0, 0))[0], g0[1] - extra.get("gram", (0.0, 0))[1])
     ctx.set_timing(False)
     stages = {}
 

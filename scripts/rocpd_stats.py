@@ -11,7 +11,7 @@ rows = list(cur.execute(f"select {name_col}, count(*), sum(end - start), min(end
 tot = sum(r[2] for r in rows)
 lines = ["Name,Calls,TotalDurationNs,AverageNs,Percentage,MinNs,MaxNs"]
 for nm, c, t, mn, mx in rows:
-    short = nm.split("(")[0][-70:]
+    short = nm.replace("(anonymous namespace)::", "").split("(")[0][-70:]
     lines.append(f'"{short}",{c},{t},{t / c:.1f},{100.0 * t / tot:.2f},{mn},{mx}')
 out = "\n".join(lines)
 if len(sys.argv) > 2:
