@@ -304,7 +304,7 @@ def main():
             except Exception as e:  # truncated / foreign file: regenerate
                 print(f"[bench] ignoring cache {path}: {e}", file=sys.stderr)
         X = synth_counts(N, M, seed=seed)
-        if path:
+        if path and local_rank == 0:  # one writer per box; the other ranks of a first run generate their own copy
             try:
                 tmp = f"{path}.{os.getpid()}.tmp.npz"
                 np.savez(tmp, data=X.data, indices=X.indices, indptr=X.indptr)
@@ -433,7 +433,9 @@ def main():
                 # kernel, shape and tile order (profiles/r02_pmc_gemm: 268.1e6 KB fetched, doubled as MI355X_MICROARCH.md
                 # prescribes for gfx950, + 3.52e6 KB written), quoted only for the workload they were taken on
                 traffic = 2 * 268.089e9 + 3.516e9 if (n == 30000 and max(N, M) == 100000) else None
-                out["roofline"] = {"bound": "mfma", "kernel": "gemm_nt_big (Gram product)", "achieved": g["achieved"],
+                bm = (n + 255) // 256
+                gram_kernel = "gemm_nt_big<2,4,4,2>" if bm * (bm + 1) // 2 >= 1500 else "gemm_kernel<NT> 128x128"
+                out["roofline"] = {"bound": "mfma", "kernel": gram_kernel + " (Gram product)", "achieved": g["achieved"],
                                    "peak": MFMA_F32_PEAK_TFS, "unit": "TFLOP/s", "frac": g["frac"], "traffic": traffic,
                                    "traffic_source": "constant from profiles/r02_pmc_gemm (separate --pmc passes), not measured in this run",
                                    "n": n, "K": max(N, M), "launch_ms": g["ms"],

@@ -531,9 +531,11 @@ int eig_values(Ctx* ctx, float* A, int64_t n, int64_t lda, double* w64_dev, int6
   if (n <= 0) return SCLENS_OK;
   ctx->last_two_stage = false;
   // two_stage: 1 = always (orders >= 128), 0 = never, -1 (default) = from the order: the one-stage reduction streams the
-  // trailing matrix once per column (2/3 n^3 bytes) and wins while that fits the caches / overlaps across streams; measured
-  // cross-over between n = 10^4 (one-stage 0.42 s vs two-stage 0.41 s with n/2 vectors) and n = 3 * 10^4 (5.3 s vs 2.7 s)
-  static const int64_t min_n = getenv("SCLENS_HIP_TWO_STAGE_MIN_N") ? atoll(getenv("SCLENS_HIP_TWO_STAGE_MIN_N")) : 16000;
+  // trailing matrix once per column (2/3 n^3 bytes). A single decomposition of order 10^4 takes the same time either way
+  // (0.42 s vs 0.41 s with n/2 vectors; 5.3 s vs 2.0 s at 3 * 10^4), but three concurrent ones (the host's default below
+  // n = 16 000) overlap better in the two-stage form: a whole sclens() call at 10 000 x 20 000 takes 4.76 s instead of 6.09 s
+  // (scripts/sweep_cfg2_paths.sh), so the two-stage solver is the default from n = 8 192
+  static const int64_t min_n = getenv("SCLENS_HIP_TWO_STAGE_MIN_N") ? atoll(getenv("SCLENS_HIP_TWO_STAGE_MIN_N")) : 8192;
   if (ctx->two_stage == 1 || (ctx->two_stage < 0 && n >= min_n)) {
     int used = 0;
     SCL_TRY(eig_values_two_stage(ctx, A, n, lda, w64_dev, &used, n_low));
