@@ -166,9 +166,14 @@ int topk_chefsi(Ctx* ctx, const float* A, int64_t n, int64_t lda, int m, int m_s
   SCL_WS(ctx, Y1, float, "che.Y1", slab);
   SCL_WS(ctx, Y2, float, "che.Y2", slab);
   SCL_WS(ctx, AX, float, "che.AX", slab);
-  SCL_WS(ctx, part, float, "che.part", (int64_t)S * slab);
+  SCL_WS(ctx, part, float, "che.part", (int64_t)(S + 1) * slab);  // + one slab for the deflation term of locked pairs
   const int SG = 32;  // split-K of the two b x b products
-  SCL_WS(ctx, gpart, float, "che.gpart", (int64_t)SG * b * b);
+  constexpr int NLMAX = 32;  // at most this many leading pairs are locked
+  SCL_WS(ctx, gpart, float, "che.gpart", (int64_t)SG * b * std::max(b, NLMAX));
+  SCL_WS(ctx, Lk, float, "che.Lk", (int64_t)NLMAX * ld);    // locked vectors (rows)
+  SCL_WS(ctx, LkT, float, "che.LkT", (int64_t)NLMAX * ld);  // - theta_i * locked vector i
+  SCL_WS(ctx, C1, float, "che.C1", (int64_t)b * NLMAX);
+  SCL_WS(ctx, nthd, float, "che.nth", NLMAX);
   SCL_WS(ctx, GH, float, "che.GH", 2 * b * b);
   SCL_WS(ctx, Wd, float, "che.W", b * b);
   SCL_WS(ctx, thd, float, "che.theta", b);
@@ -179,13 +184,17 @@ int topk_chefsi(Ctx* ctx, const float* A, int64_t n, int64_t lda, int m, int m_s
   SCL_HIP(ctx, hipMemsetAsync(Y1, 0, sizeof(float) * slab, st));
   SCL_HIP(ctx, hipMemsetAsync(Y2, 0, sizeof(float) * slab, st));
 
-  auto block_product = [&](const float* V) -> int {  // part[s] = V * A (slice s of the contraction)
+  // part[s] rows r0.. = V[r0..] * A (slice s of the contraction); rows below r0 (locked pairs) are left alone
+  auto block_product = [&](const float* V0, int r0 = 0) -> int {
+    const float* V = V0 + (int64_t)r0 * ld;
+    float* Pr = part + (int64_t)r0 * ld;
+    const int rows = b - r0;
     if (Bop) {
       // A = Bop Bop' / div is never formed: V A = (V Bop) Bop' / div, two products that stream Bop once each
       // (2 * 2 b n Kop flop against n^2 Kop for the Gram matrix: cheaper below ~n / (4 b) applications)
       GemmArgs g1{};
       g1.P = V; g1.Q = Bop; g1.C = S1 > 1 ? Tpart : Tb;
-      g1.M = b; g1.N = Kop; g1.K = n;
+      g1.M = rows; g1.N = Kop; g1.K = n;
       g1.ldp = ld; g1.ldq = ldb; g1.ldc = ldt;
       g1.alpha = 1.f; g1.beta = 0.f; g1.q_kcontig = 0; g1.lower = 0; g1.colabsmax = nullptr;
       if (S1 > 1) {
@@ -196,16 +205,16 @@ int topk_chefsi(Ctx* ctx, const float* A, int64_t n, int64_t lda, int m, int m_s
         hipLaunchKernelGGL(k_sum_slabs, dim3((unsigned)(((int64_t)b * ldt + 255) / 256)), dim3(256), 0, st, Tpart, S1, (int64_t)b * ldt, Tb,
                            (int64_t)b * ldt);
       GemmArgs g2{};
-      g2.P = Tb; g2.Q = Bop; g2.C = part;
-      g2.M = b; g2.N = n; g2.K = Kop;
+      g2.P = Tb; g2.Q = Bop; g2.C = Pr;
+      g2.M = rows; g2.N = n; g2.K = Kop;
       g2.ldp = ldt; g2.ldq = ldb; g2.ldc = ld;
       g2.alpha = 1.f / div; g2.beta = 0.f; g2.q_kcontig = 1; g2.lower = 0; g2.colabsmax = nullptr;
       g2.splits = S; g2.k_chunk = round_up((Kop + S - 1) / S, 32); g2.c_split_off = slab;
       return gemm_f32(ctx, g2);
     }
     GemmArgs g{};
-    g.P = V; g.Q = A; g.C = part;
-    g.M = b; g.N = n; g.K = n;
+    g.P = V; g.Q = A; g.C = Pr;
+    g.M = rows; g.N = n; g.K = n;
     g.ldp = ld; g.ldq = lda; g.ldc = ld;
     g.alpha = 1.f; g.beta = 0.f; g.q_kcontig = 1; g.lower = 0; g.colabsmax = nullptr;  // A symmetric: rows are K-contiguous
     g.splits = S; g.k_chunk = round_up((n + S - 1) / S, 16); g.c_split_off = slab;
@@ -223,7 +232,31 @@ int topk_chefsi(Ctx* ctx, const float* A, int64_t n, int64_t lda, int m, int m_s
                        out, (int64_t)b * b);
     return SCLENS_OK;
   };
-  const dim3 egrid((unsigned)((n + 255) / 256), (unsigned)b);
+  // Locking. Once the leading `nlock` pairs have reached their targets they stay in the basis but are no longer filtered, and
+  // the filter runs on the deflated operator A - sum_i theta_i v_i v_i' (their eigenvalues move to 0, inside the damped
+  // interval): the degree is then set by the largest UNLOCKED Ritz value. Without it the spread limit below pins the degree at
+  // 2 as long as a signal 20x above the bulk edge is in the block, and the pairs at the edge need a dozen sweeps
+  // (cfg4: 13 sweeps of 3 products per member -> 2 sweeps + one of degree 16).
+  // slab S of `part` rows r0.. = -(V[r0..] Lk') diag(theta) Lk
+  int nlock = 0;
+  auto deflate = [&](const float* V0, int r0) -> int {
+    const int rows = b - r0;
+    GemmArgs g{};
+    g.P = V0 + (int64_t)r0 * ld; g.Q = Lk; g.C = gpart;
+    g.M = rows; g.N = nlock; g.K = n;
+    g.ldp = ld; g.ldq = ld; g.ldc = nlock;
+    g.alpha = 1.f; g.beta = 0.f; g.q_kcontig = 1; g.lower = 0; g.colabsmax = nullptr;
+    g.splits = SG; g.k_chunk = round_up((n + SG - 1) / SG, 16); g.c_split_off = (int64_t)b * NLMAX;
+    SCL_TRY(gemm_f32(ctx, g));
+    hipLaunchKernelGGL(k_sum_slabs, dim3((unsigned)((rows * nlock + 255) / 256)), dim3(256), 0, st, gpart, SG, (int64_t)b * NLMAX, C1,
+                       (int64_t)rows * nlock);
+    GemmArgs h{};
+    h.P = C1; h.Q = LkT; h.C = part + (int64_t)S * slab + (int64_t)r0 * ld;
+    h.M = rows; h.N = n; h.K = nlock;
+    h.ldp = nlock; h.ldq = ld; h.ldc = ld;
+    h.alpha = 1.f; h.beta = 0.f; h.q_kcontig = 0; h.lower = 0; h.colabsmax = nullptr;
+    return gemm_f32(ctx, h);
+  };
 
   float *B0 = X, *B1 = Y1, *B2 = Y2;  // B0 = current basis, B1/B2 = scratch
   std::vector<double> theta(theta0, theta0 + b);
@@ -238,27 +271,58 @@ int topk_chefsi(Ctx* ctx, const float* A, int64_t n, int64_t lda, int m, int m_s
     // ---- Chebyshev filter of `degree`: damp [0, theta_b], normalise at theta_1
     const double lo = 0.0, cut = std::max(theta[b - 1], 1e-12 * theta[0]);
     const double e = 0.5 * (cut - lo), c = 0.5 * (cut + lo);
-    const double sigma1 = e / (theta[0] - c);
+    const int r0 = nlock;  // rows r0 .. b-1 are filtered
+    const double sigma1 = e / (theta[r0] - c);
     double sigma = sigma1;
     // The filter scales Ritz direction q by T_d(x_q), x_q = (theta_q - c)/e. Between two re-orthogonalisations the
     // spread T_d(x_1) / T_d(1) must stay far below 1/eps32, or the rows collapse onto the leading eigenvectors.
     int degree = 2;
     {
-      const double ach = std::acosh(std::max(1.0 + 1e-9, (theta[0] - c) / e));
+      const double ach = std::acosh(std::max(1.0 + 1e-9, (theta[r0] - c) / e));
       while (degree < max_degree && std::cosh((degree + 1) * ach) <= 1e5) ++degree;
     }
+    if (r0 > 0 && outer >= 1) {
+      // no more than the sweep needs: the wanted pair q is amplified by cosh(d acosh(x_q)) against the edge of the block;
+      // ask for 4x the largest remaining residual / target ratio, at the pair that the filter separates least
+      double need = 1.0, ach_min = 1e300;
+      for (int q = r0; q < m; ++q) {
+        const double lim = (q < m_strict ? tol_rel : tol_rel_tail) * std::fabs(theta[q]);
+        need = std::max(need, (double)hres[q] / std::max(lim, 1e-300));
+        ach_min = std::min(ach_min, std::acosh(std::max(1.0 + 1e-9, (theta[q] - c) / e)));
+      }
+      if (ach_min < 1e299 && ach_min > 0.0) {
+        const int want = (int)std::ceil(std::acosh(std::max(1.0, 4.0 * need)) / ach_min);
+        degree = std::max(2, std::min(degree, want));
+      }
+    }
+    const dim3 fgrid((unsigned)((n + 255) / 256), (unsigned)(b - r0));
+    const int64_t roff = (int64_t)r0 * ld;
+    const int Sx = S + (r0 > 0 ? 1 : 0);
+    if (r0 > 0) {  // this sweep's copies of the locked vectors: Lk = rows 0 .. r0-1 of the basis, LkT = -theta_i Lk_i
+      SCL_HIP(ctx, hipMemcpyAsync(Lk, B0, sizeof(float) * (size_t)r0 * ld, hipMemcpyDeviceToDevice, st));
+      SCL_HIP(ctx, hipMemcpyAsync(LkT, B0, sizeof(float) * (size_t)r0 * ld, hipMemcpyDeviceToDevice, st));
+      std::vector<float> nth(r0);
+      for (int q = 0; q < r0; ++q) nth[q] = (float)(-theta[q]);
+      SCL_HIP(ctx, hipMemcpyAsync(nthd, nth.data(), sizeof(float) * r0, hipMemcpyHostToDevice, st));
+      SCL_HIP(ctx, hipStreamSynchronize(st));  // `nth` is a local
+      SCL_TRY(scale_rows_f32(ctx, LkT, r0, n, ld, nthd));
+    }
     float *xprev = B0, *xcur = B1, *xnext = B2;
-    SCL_TRY(block_product(B0));
-    hipLaunchKernelGGL(k_cheb_step, egrid, dim3(256), 0, st, part, S, slab, B0, (const float*)nullptr, xcur, (int64_t)b, n, ld,
-                       (float)(sigma1 / e), (float)c, 0.f);
+    SCL_TRY(block_product(B0, r0));
+    if (r0 > 0) SCL_TRY(deflate(B0, r0));
+    hipLaunchKernelGGL(k_cheb_step, fgrid, dim3(256), 0, st, part + roff, Sx, slab, B0 + roff, (const float*)nullptr, xcur + roff,
+                       (int64_t)(b - r0), n, ld, (float)(sigma1 / e), (float)c, 0.f);
     for (int i = 2; i <= degree; ++i) {
       const double sn = 1.0 / (2.0 / sigma1 - sigma);
-      SCL_TRY(block_product(xcur));
-      hipLaunchKernelGGL(k_cheb_step, egrid, dim3(256), 0, st, part, S, slab, xcur, xprev, xnext, (int64_t)b, n, ld,
-                         (float)(2.0 * sn / e), (float)c, (float)(sigma * sn));
+      SCL_TRY(block_product(xcur, r0));
+      if (r0 > 0) SCL_TRY(deflate(xcur, r0));
+      hipLaunchKernelGGL(k_cheb_step, fgrid, dim3(256), 0, st, part + roff, Sx, slab, xcur + roff, xprev + roff, xnext + roff,
+                         (int64_t)(b - r0), n, ld, (float)(2.0 * sn / e), (float)c, (float)(sigma * sn));
       float* t = xprev; xprev = xcur; xcur = xnext; xnext = t;
       sigma = sn;
     }
+    if (r0 > 0 && xcur != B0)  // the locked rows re-join the block unfiltered (B0's copies were never written)
+      SCL_HIP(ctx, hipMemcpyAsync(xcur, B0, sizeof(float) * (size_t)r0 * ld, hipMemcpyDeviceToDevice, st));
     // ---- Rayleigh-Ritz on span(xcur): rows rescaled to unit length first, G = V V^T, H = V (A V)^T
     SCL_TRY(normalize_rows_f32(ctx, xcur, b, n, ld));
     SCL_TRY(block_product(xcur));
@@ -342,6 +406,28 @@ int topk_chefsi(Ctx* ctx, const float* A, int64_t n, int64_t lda, int m, int m_s
       ok = ok && ((double)hres[q] <= lim);
     }
     if (ok && outer >= 1) { *converged = 1; break; }
+    // lock the leading run of pairs that have reached their targets (from the second sweep on); a locked pair that drifts
+    // above ten times its target unlocks everything
+    if (outer >= 1 && !getenv("SCLENS_HIP_CHEFSI_NOLOCK")) {
+      auto target = [&](int q) {
+        double lim = (q < m_strict ? tol_rel : tol_rel_tail) * std::fabs(theta[q]);
+        if (q < m_strict) {
+          double gap = (q + 1 < b) ? theta[q] - theta[q + 1] : std::fabs(theta[q]);
+          if (q > 0) gap = std::min(gap, theta[q - 1] - theta[q]);
+          lim = std::min(lim, std::max(tol_gap * gap, 4e-6 * std::fabs(theta[0])));
+        }
+        return lim;
+      };
+      bool drift = false;
+      for (int q = 0; q < nlock; ++q) drift = drift || (double)hres[q] > 10.0 * target(q);
+      if (drift) {
+        nlock = 0;
+      } else {
+        int nl = 0;
+        while (nl < m && nl < NLMAX && nl < b - 8 && (double)hres[nl] <= target(nl)) ++nl;
+        nlock = std::max(nlock, nl);
+      }
+    }
   }
   SCL_HIP(ctx, hipGetLastError());
   if (!*converged) return SCLENS_OK;
