@@ -117,7 +117,8 @@ int sclens_hip_scale_csc_f32(sclens_hip_ctx* ctx, int64_t N, int64_t M, const in
                              double* rec_mat2_mean, double* rec_mat2_std, double* rec_norm_tgc, double* rec_cent);
 /* Piece exposed for unit tests: out[j] = max_i |X_i' Y_j| for X n x p and Y n x q (column-major), the statistic of the
  * sparsity search (scLENS.jl:742 `maximum(abs.(corr_mat(...)), dims=1)`). use_split = 0: fp32 product; 1: operands split into
- * two fp16 pieces (22 significant bits), three fp16 MFMA products with fp32 accumulation (gram_bits.hip). */
+ * two fp16 pieces (22 significant bits), three fp16 MFMA products with fp32 accumulation (gram_bits.hip); the split scales by
+ * 2^12, so entries must stay below 15 in magnitude (the search passes unit vectors). */
 int sclens_hip_corr_colmax_f32(sclens_hip_ctx* ctx, const float* X, int64_t n, int64_t p, const float* Y, int64_t q, int use_split,
                                float* out);
 /* Piece exposed for unit tests: the M x M Gram matrix (row-major, fp32) of logn_scale(pre_scale(P)) / divisor for the BINARISED
