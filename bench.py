@@ -391,7 +391,7 @@ def main():
     if rank == 0:
         ms_per_step = dt / max(1, steps) * 1e3
         row_shard = main_r["row_shard"]
-        n_streams = args.streams if args.streams is not None else (3 if min(N, M) < 16000 else 1)
+        n_streams = args.streams if args.streams is not None else (3 if min(N, M) < 16000 else 2)
         out = {
             "metric": "sclens() cells*genes/s (wall-clock of one full sclens() call)", "value": round(N * M * steps / dt, 1),
             "unit": "cells*genes/s", "n_gpus": world, "steps": steps, "warmup": main_r["warmup"],

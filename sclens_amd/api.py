@@ -791,11 +791,13 @@ def sclens(inp_df, device_="gpu", th=60, p_step=0.001, n_perturb=20, centering="
     X_, cell_id, gene_id = _extract(inp_df)  # :662
     N, M = X_.shape
     if streams is None:
-        # concurrent decompositions pay while one decomposition cannot fill the GPU (one-stage reduction: latency-bound column
-        # steps, 6.6 s instead of 12.7 s at 10 000 x 20 000). From n = 16 000 the two-stage solver runs MFMA- / HBM-bound kernels
-        # and one persistent kernel: three streams then finish a round of three in the time of three serial evaluations, and
-        # the speculative rounds only add wasted evaluations (measured at 100 000 x 30 000: 21 evaluations in 67.8 s).
-        streams = 3 if min(N, M) < 16000 else 1
+        # concurrent decompositions pay while one decomposition cannot fill the GPU (latency-bound column steps / panels /
+        # bulge chasing: 4.8 s instead of 7.9 s at 10 000 x 20 000 with three streams). At n >= 16 000 a search step used to be
+        # dominated by MFMA-saturating fp32 products (three streams finished 21 evaluations in the time of 21); with the Gram
+        # matrix and the search statistic on the fp16 MFMA what remains is the two-stage eigensolver, and TWO streams overlap
+        # again: 100 000 x 30 000 in 52.7 s instead of 55.3 s (search 38.3 vs 40.8 s, ensemble 4.0 vs 5.0 s, 2.2 s of worker
+        # teardown included; profiles/r02_bench_cfg4_streams2_step1.json)
+        streams = 3 if min(N, M) < 16000 else 2
     if draws is None:
         if seed is None:  # every rank must draw the same candidates, null matrix and sample seeds: rank 0's clock decides
             seed = int(shard.bcast_host(np.array([float(time.time_ns() % (2**31))]), 0)[0])
