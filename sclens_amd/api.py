@@ -837,12 +837,12 @@ def sclens(inp_df, device_="gpu", th=60, p_step=0.001, n_perturb=20, centering="
         # local workers: `streams` sessions on this GPU (own stream + scratch each, shared read-only data), one host
         # thread per session (ctypes releases the GIL), so independent decompositions overlap on the device
         workers = [ses]
-        gb0 = ses.get_int("gram_bits_used")  # a context-lifetime counter: this call's share is the difference
         wctx = []
         for _ in range(max(1, int(streams)) - 1):
             c2 = Context(ctx.device)
             wctx.append(c2)
             workers.append(ses.clone(c2))
+        gb0 = sum(w.get_int("gram_bits_used") for w in workers)  # context-lifetime counters: this call's share is the difference
         W = len(workers)
         pool = ThreadPoolExecutor(max_workers=W) if W > 1 else None
         # batch=True: concurrent decompositions of one round advance their tridiagonalisations in shared launches (bitwise
