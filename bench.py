@@ -398,6 +398,9 @@ def main():
             "steps_requested": args.steps, "warmup_requested": args.warmup, "budget_s": args.budget_s,
             "ms_per_step": round(ms_per_step, 1), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
+            "dtype_note": "fp32 MFMA products and fp32 eigensolver with fp64 statistics / eigenvalues; from n = 16 000 the sparsity "
+                          "search's Gram product (binary x fp16 weight pieces, exact products) and search statistic (operands split "
+                          "into 2 x fp16 = 22 bits) run on the fp16 MFMA with fp32 accumulation",
             "config": {"workload": f"{args.config}: synthetic Poisson-lognormal counts {N} cells x {M} genes, sparsity "
                                    f"{1 - X.nnz / (N * M):.3f}, full sclens() incl. sparsity search and {args.n_perturb}-member "
                                    f"perturbation ensemble", "N": N, "M": M, "nnz": int(X.nnz), "n_perturb": args.n_perturb,
