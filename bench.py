@@ -244,12 +244,11 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--backend", default="nccl")
-    ap.add_argument("--batch", action="store_true", help="merge the column steps of concurrent tridiagonalisations into shared launches (opt-in)")
     ap.add_argument("--row-shard", action="store_true",
                     help="cells > genes configs on N > 1 GPUs: every rank holds a block of cells, partial Gram matrices are "
                          "all-reduced (SURVEY 8e-iii, sclens_amd/atlas.py) instead of distributing whole decompositions")
     ap.add_argument("--streams", type=int, default=None,
-                    help="concurrent decompositions per GPU (worker sessions on own HIP streams); default: 3 below n = 16 000, else 1")
+                    help="concurrent decompositions per GPU (worker sessions on own HIP streams); default: 3 below n = 16 000, else 2")
     ap.add_argument("--extra-configs", default="", help="comma-separated further configs timed once each after the main one (reported under `extra`)")
     ap.add_argument("--verbose", action="store_true")
     ap.add_argument("--stage-timing", action="store_true", help="per-stage HIP-event totals on stderr (adds syncs)")
@@ -281,8 +280,9 @@ def main():
     from sclens_amd.synth import synth_counts
 
     ctx = Context(local_rank)
-    shard = Shard(rank, world, dev if (world > 1 and args.backend == "nccl") else None)
-    check = shard.selfcheck(ctx)  # raises (non-zero exit) when the RCCL all-reduce is wrong; picks the staging mode
+    # the library's own RCCL communicator (csrc/comm.hip); torch.distributed only launched the ranks and ships the unique id
+    shard = Shard.create(ctx, rank, world, backend=args.backend)
+    check = shard.selfcheck(ctx)  # raises (non-zero exit) when the all-reduce / broadcast on library buffers is wrong
     if rank == 0 and world > 1:
         print(f"[bench] {world} ranks, backend {args.backend}, self-check {check}", file=sys.stderr, flush=True)
 
@@ -333,7 +333,7 @@ def main():
                 return atlas.sclens_row_sharded(X_rows, r0, N, draws, shard, n_perturb=args.n_perturb, ctx=ctx, gather=False,
                                                 verbose=args.verbose)
             return api.sclens(X, draws=draws, ctx=ctx, n_perturb=args.n_perturb, shard=shard, streams=args.streams,
-                              batch=args.batch, verbose=args.verbose and rank == 0)
+                              verbose=args.verbose and rank == 0)
 
         def fence():
             shard.barrier()
@@ -408,7 +408,8 @@ def main():
                                        f"all-reduce of the {M}x{M} fp32 partial Gram matrix, eigen-solver replicated" if row_shard
                                        else f"single GPU, {n_streams} concurrent decompositions (HIP streams)" if world == 1 else
                                        f"search rounds of {world}x{n_streams} + ensemble t%{world}, 1 RCCL all-gather "
-                                       f"({shard.staging}-staged)")},
+                                       f"issued by the library on its own buffers"),
+                       "comm": shard.describe()},
             "sclens_wall_s": round(dt / max(1, steps), 3),
             "observed": {"signals": int(len(res.get("signal_ev", []))), "robust_signals": int(len(res.get("sig_id", []))),
                          "search_iters": int(res["n_search"]), "p_": res["p_"], "synth_s": round(main_r["synth_s"], 1),

@@ -59,25 +59,12 @@ int sclens_hip_symv_probe(sclens_hip_ctx* ctx, int64_t n, int64_t* launches, dou
 /* Context options. "two_stage" (-1 / 0 / 1; default -1, or the environment variable SCLENS_HIP_TWO_STAGE): which reduction the
  * eigen-solver that replaces cuSOLVER syevd! (scLENS.jl:377) uses. 1 = two-stage (dense -> band of half-width 64 on the
  * matrix cores -> tridiagonal by bulge chasing, sbr.hip; falls back to the one-stage reduction for orders below 128 and when
- * a panel is numerically rank deficient), 0 = one-stage (tridiag.hip), -1 = by order: two-stage from n = 16 000
- * (SCLENS_HIP_TWO_STAGE_MIN_N) upwards. */
+ * a panel is numerically rank deficient), 0 = one-stage (tridiag.hip), -1 = by order: two-stage from n = 8 192
+ * (SCLENS_HIP_TWO_STAGE_MIN_N) upwards. "gram_bits" (-1 / 0 / 1): the Gram matrices of the binarised search matrices and the
+ * search statistic on the fp16 MFMA with exact / split operands (gram_bits.hip); -1 = from n = 16 000 (SCLENS_HIP_GRAM_BITS_MIN_N). */
 int sclens_hip_set_option(sclens_hip_ctx* ctx, const char* name, int64_t value);
 /* raw stream handle (hipStream_t) so a host framework can order its own work after ours */
 void* sclens_hip_stream(sclens_hip_ctx* ctx);
-
-/* Lock-step batching of concurrent eigendecompositions. The reference runs its 3 + S + P decompositions one after the
- * other (scLENS.jl:704, :717-721, :735-745); here independent ones run on several contexts (one host thread + one HIP
- * stream each), and the contexts attached to one batch group merge the column steps of their tridiagonalisations into
- * shared launches (each matrix keeps exactly the arithmetic of a solo run: bitwise identical results).
- * Protocol per round: sclens_hip_batch_expect(group, m), then m threads each run ONE decomposition on m different
- * attached contexts; a thread whose job fails before its decomposition calls sclens_hip_batch_leave. count <= 1 (or no
- * call) = unbatched. A participant that never arrives fails the round with SCLENS_ERR_STATE after 600 s. */
-typedef struct sclens_hip_batch sclens_hip_batch;
-sclens_hip_batch* sclens_hip_batch_create(void);
-void sclens_hip_batch_destroy(sclens_hip_batch* group);
-int sclens_hip_batch_expect(sclens_hip_batch* group, int count);
-int sclens_hip_batch_leave(sclens_hip_batch* group);
-int sclens_hip_set_batch(sclens_hip_ctx* ctx, sclens_hip_batch* group); /* group = NULL detaches */
 
 /* ---------------------------------------------------------------- (A) per-call drop-ins -------- */
 /* _wishart_matrix(X; device, dims)  (scLENS.jl:332-361): X is N x M; dims=2 -> X'X / M (M x M),
@@ -295,6 +282,31 @@ int sclens_hip_session_robustness(sclens_hip_session* s, int64_t P, int32_t* a_b
 /* gene_basis (scLENS.jl:813-818): (nL^-1/2 .* nV') * scaled_X / sqrt(M), written as out[q*M + j]
  * (k rows of M genes). */
 int sclens_hip_session_gene_basis(sclens_hip_session* s, const double* nL, float* out);
+
+/* ---------------------------------------------------------------- multi-GPU: RCCL inside the library */
+/* One process per GPU. The perturbation ensemble (scLENS.jl:771-778) runs member t on rank t mod G and needs ONE gather of the
+ * min_pc x N blocks at the end; the data / null / binarised decompositions (:704, :717-721) may run on different ranks and
+ * broadcast Vr2 and the seed block; row-sharded cells (sclens_hip_session_create_sharded) all-reduce their statistics and partial
+ * Gram matrices. These collectives are RCCL calls made BY THE LIBRARY on its own device buffers and on the owning context's
+ * stream; the host only launches the ranks and ships the 128-byte unique id from rank 0 to the others (any channel).
+ * All calls block until the result is in place. `*_host` variants take host buffers (the few doubles of the control flow). */
+#define SCLENS_HIP_COMM_ID_BYTES 128
+typedef struct sclens_hip_comm sclens_hip_comm;
+int sclens_hip_comm_unique_id(sclens_hip_ctx* ctx, uint8_t* id /*[128]*/);                 /* rank 0: ncclGetUniqueId */
+int sclens_hip_comm_create(sclens_hip_ctx* ctx, const uint8_t* id, int rank, int world, sclens_hip_comm** out);
+void sclens_hip_comm_destroy(sclens_hip_comm* comm);
+/* what RCCL reports for the communicator (ncclCommCount / ncclCommUserRank / ncclGetVersion) */
+int sclens_hip_comm_info(sclens_hip_comm* comm, int* world, int* rank, int* rccl_version);
+int sclens_hip_comm_stats(sclens_hip_comm* comm, int64_t* calls, double* bytes);
+const char* sclens_hip_comm_last_error(sclens_hip_comm* comm);
+int sclens_hip_comm_allreduce(sclens_hip_comm* comm, void* dev_ptr, int64_t count, int dtype /*0 fp64, 1 fp32*/); /* in-place sum */
+int sclens_hip_comm_broadcast(sclens_hip_comm* comm, void* dev_ptr, int64_t nbytes, int root);
+int sclens_hip_comm_allgather(sclens_hip_comm* comm, const void* send_dev, void* recv_dev, int64_t nbytes_per_rank);
+int sclens_hip_comm_allgather_host(sclens_hip_comm* comm, const void* send, void* recv, int64_t nbytes_per_rank);
+int sclens_hip_comm_broadcast_host(sclens_hip_comm* comm, void* buf, int64_t nbytes, int root);
+/* an sclens_hip_allreduce_fn whose `user` is the communicator: pass (sclens_hip_comm_allreduce_cb, comm) to
+ * sclens_hip_session_create_sharded / _set_reducer and the row-sharded session reduces over RCCL with no host callback */
+int sclens_hip_comm_allreduce_cb(void* user, void* dev_ptr, int64_t count, int dtype);
 
 /* ---------------------------------------------------------------- device-level entry points ---- */
 /* Used by the repository's own tests and bench.py (device pointers, row-major; see csrc/common.h). */

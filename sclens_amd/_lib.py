@@ -37,11 +37,6 @@ SIGNATURES = {
     "sclens_hip_reset_timing": (C.c_int, [vp]),
     "sclens_hip_set_option": (C.c_int, [vp, C.c_char_p, i64]),
     "sclens_hip_stream": (vp, [vp]),
-    "sclens_hip_batch_create": (vp, []),
-    "sclens_hip_batch_destroy": (None, [vp]),
-    "sclens_hip_batch_expect": (C.c_int, [vp, C.c_int]),
-    "sclens_hip_batch_leave": (C.c_int, [vp]),
-    "sclens_hip_set_batch": (C.c_int, [vp, vp]),
     "sclens_hip_symv_probe": (C.c_int, [vp, i64, c_i64p, c_f64p, c_f64p]),
     "sclens_hip_symv_profile": (C.c_int, [vp, C.c_int]),
     "sclens_hip_symv_profile_read": (C.c_int, [vp, c_i64p, c_f64p, c_f64p]),
@@ -99,6 +94,18 @@ SIGNATURES = {
     "sclens_hip_session_get_perturbed": (C.c_int, [vp, i64, c_f32p]),
     "sclens_hip_session_robustness": (C.c_int, [vp, i64, c_i32p, c_f64p]),
     "sclens_hip_session_gene_basis": (C.c_int, [vp, c_f64p, c_f32p]),
+    "sclens_hip_comm_unique_id": (C.c_int, [vp, c_u8p]),
+    "sclens_hip_comm_create": (C.c_int, [vp, c_u8p, C.c_int, C.c_int, C.POINTER(vp)]),
+    "sclens_hip_comm_destroy": (None, [vp]),
+    "sclens_hip_comm_info": (C.c_int, [vp, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "sclens_hip_comm_stats": (C.c_int, [vp, c_i64p, c_f64p]),
+    "sclens_hip_comm_last_error": (C.c_char_p, [vp]),
+    "sclens_hip_comm_allreduce": (C.c_int, [vp, vp, i64, C.c_int]),
+    "sclens_hip_comm_broadcast": (C.c_int, [vp, vp, i64, C.c_int]),
+    "sclens_hip_comm_allgather": (C.c_int, [vp, vp, vp, i64]),
+    "sclens_hip_comm_allgather_host": (C.c_int, [vp, vp, vp, i64]),
+    "sclens_hip_comm_broadcast_host": (C.c_int, [vp, vp, i64, C.c_int]),
+    "sclens_hip_comm_allreduce_cb": (C.c_int, [vp, vp, i64, C.c_int]),
     "sclens_hip_dev_gemm_f32": (C.c_int, [vp, vp, vp, vp, i64, i64, i64, i64, i64, i64, C.c_float, C.c_float, C.c_int, C.c_int, vp]),
     "sclens_hip_dev_gram_f32": (C.c_int, [vp, vp, i64, i64, i64, C.c_float, vp, i64]),
     "sclens_hip_dev_sy2sb_f32": (C.c_int, [vp, vp, i64, i64, vp, C.POINTER(C.c_int)]),
@@ -147,25 +154,6 @@ def ptr(a: np.ndarray, ctype):
     return a.ctypes.data_as(C.POINTER(ctype))
 
 
-class BatchGroup:
-    """sclens_hip_batch: contexts attached to one group merge the column steps of concurrent tridiagonalisations."""
-
-    def __init__(self):
-        self.lib = load()
-        self.h = vp(self.lib.sclens_hip_batch_create())
-
-    def expect(self, count: int):
-        self.lib.sclens_hip_batch_expect(self.h, int(count))
-
-    def leave(self):
-        self.lib.sclens_hip_batch_leave(self.h)
-
-    def close(self):
-        if getattr(self, "h", None):
-            self.lib.sclens_hip_batch_destroy(self.h)
-            self.h = None
-
-
 class Context:
     """Owns one sclens_hip_ctx (one GPU, one stream)."""
 
@@ -204,9 +192,6 @@ class Context:
     def set_option(self, name: str, value: int):
         self.check(self.lib.sclens_hip_set_option(self.h, name.encode(), int(value)))
 
-    def set_batch(self, group: "Optional[BatchGroup]"):
-        self.check(self.lib.sclens_hip_set_batch(self.h, group.h if group is not None else None))
-
     # ---- timing
     def set_timing(self, on: bool):
         self.check(self.lib.sclens_hip_set_timing(self.h, int(on)))
@@ -242,3 +227,72 @@ class Context:
 
     def sync(self):
         self.check(self.lib.sclens_hip_dev_sync(self.h))
+
+
+class Comm:
+    """sclens_hip_comm: this rank's RCCL communicator, created and used inside the library (csrc/comm.hip). The host only
+    ships the 128-byte unique id from rank 0 to the other ranks (`ship`: bytes-or-None -> bytes, any channel)."""
+
+    ID_BYTES = 128
+
+    def __init__(self, ctx: Context, rank: int, world: int, ship):
+        self.ctx, self.lib = ctx, ctx.lib
+        uid = np.zeros(self.ID_BYTES, dtype=np.uint8)
+        if rank == 0:
+            ctx.check(self.lib.sclens_hip_comm_unique_id(ctx.h, ptr(uid, C.c_uint8)))
+        got = ship(uid.tobytes() if rank == 0 else None)
+        uid = np.frombuffer(got, dtype=np.uint8).copy()
+        h = vp()
+        ctx.check(self.lib.sclens_hip_comm_create(ctx.h, ptr(uid, C.c_uint8), int(rank), int(world), C.byref(h)))
+        self.h = h
+        w, r, v = C.c_int(0), C.c_int(0), C.c_int(0)
+        self.check(self.lib.sclens_hip_comm_info(self.h, C.byref(w), C.byref(r), C.byref(v)))
+        self.world, self.rank, self.rccl_version = w.value, r.value, v.value  # as RCCL reports them
+        if (self.world, self.rank) != (int(world), int(rank)):
+            raise SclensHipError(4, f"RCCL reports rank {self.rank} of {self.world}, expected {rank} of {world}")
+
+    def check(self, rc):
+        if rc != 0:
+            raise SclensHipError(rc, self.lib.sclens_hip_comm_last_error(self.h).decode())
+
+    def reducer(self):
+        """(function pointer, user pointer) for Session.create_sharded: the all-reduce of a row-sharded session is then an
+        RCCL call made by the library itself"""
+        fn = C.cast(self.lib.sclens_hip_comm_allreduce_cb, ALLREDUCE_FN)
+        return fn, self.h
+
+    def allreduce(self, dev_ptr: int, count: int, dtype: int):
+        self.check(self.lib.sclens_hip_comm_allreduce(self.h, vp(dev_ptr), int(count), int(dtype)))
+
+    def broadcast(self, dev_ptr: int, nbytes: int, root: int):
+        self.check(self.lib.sclens_hip_comm_broadcast(self.h, vp(dev_ptr), int(nbytes), int(root)))
+
+    def allgather(self, send_ptr: int, recv_ptr: int, nbytes: int):
+        self.check(self.lib.sclens_hip_comm_allgather(self.h, vp(send_ptr), vp(recv_ptr), int(nbytes)))
+
+    def allgather_host(self, arr: np.ndarray) -> np.ndarray:
+        arr = np.ascontiguousarray(arr)
+        out = np.empty((self.world,) + arr.shape, dtype=arr.dtype)
+        self.check(self.lib.sclens_hip_comm_allgather_host(self.h, arr.ctypes.data, out.ctypes.data, arr.nbytes))
+        return out
+
+    def broadcast_host(self, arr: np.ndarray, root: int) -> np.ndarray:
+        buf = np.ascontiguousarray(arr).copy()
+        self.check(self.lib.sclens_hip_comm_broadcast_host(self.h, buf.ctypes.data, buf.nbytes, int(root)))
+        return buf
+
+    def stats(self):
+        calls, nbytes = C.c_int64(0), C.c_double(0)
+        self.check(self.lib.sclens_hip_comm_stats(self.h, C.byref(calls), C.byref(nbytes)))
+        return {"calls": calls.value, "bytes": nbytes.value}
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.sclens_hip_comm_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -22,7 +22,7 @@ import numpy as np
 import scipy.sparse as sp
 
 from . import _lib
-from ._lib import BatchGroup, Context, SclensHipError, ptr
+from ._lib import Context, SclensHipError, ptr
 from .shard import Shard, consume_search_round, owned_perturbations, search_schedule
 
 _default_ctx: Optional[Context] = None
@@ -524,13 +524,14 @@ class Session:
     def create_sharded(cls, ctx: Context, X_local: sp.csc_matrix, row0: int, N_global: int, z1: np.ndarray, z2: np.ndarray,
                        reducer) -> "Session":
         """Row-sharded session (sclens_hip_session_create_sharded): `X_local` = the cells [row0, row0 + N_local) of an
-        N_global x M matrix, z1 = GLOBAL cell indices of the whole candidate list, `reducer` = an `_lib.ALLREDUCE_FN`
-        object (kept alive by the session)."""
+        N_global x M matrix, z1 = GLOBAL cell indices of the whole candidate list, `reducer` = (function, user pointer) from
+        `Shard.reducer` (kept alive by the session)."""
         s = cls.__new__(cls)
         s.ctx = ctx
         s.N, s.M = X_local.shape
         s.n = s.M
-        s._reducer = reducer
+        fn, user = reducer if isinstance(reducer, tuple) else (reducer, None)
+        s._reducer = (fn, user)
         colptr = np.ascontiguousarray(X_local.indptr, dtype=np.int64)
         rowval = np.ascontiguousarray(X_local.indices, dtype=np.int32)
         nzval = np.ascontiguousarray(X_local.data, dtype=np.float32)
@@ -540,7 +541,7 @@ class Session:
         h = C.c_void_p()
         ctx.check(ctx.lib.sclens_hip_session_create_sharded(ctx.h, int(N_global), int(row0), s.N, s.M, ptr(colptr, C.c_int64),
                                                             ptr(rowval, C.c_int32), ptr(nzval, C.c_float), s.ncand,
-                                                            ptr(z1, C.c_uint32), ptr(z2, C.c_uint32), reducer, None,
+                                                            ptr(z1, C.c_uint32), ptr(z2, C.c_uint32), fn, user,
                                                             C.byref(h)))
         s.h = h
         return s
@@ -713,6 +714,34 @@ class Session:
 
 
 # ----------------------------------------------------------------------------- driver
+def cut_with_guard_band(L: np.ndarray, lambda_c: float, guard_band: float, refine: Callable[[int, int], np.ndarray]):
+    """`sum(L .> lambda_c)` (scLENS.jl:539, :541, :580) with the fp32 eigenvalues near the cut re-evaluated in float64.
+
+    L ascending (fp32 solver). Every eigenvalue within `guard_band` sqrt(n) eps32 lambda_max of lambda_c is replaced by the
+    float64 Rayleigh quotient of ITS eigenvector (`refine(lo, hi)` -> rho for the ascending indices lo..hi-1). The refined
+    values of a near-degenerate pair may come out in the other order, so the cut is taken from the top and stays contiguous:
+    k = the number of leading indices n-1, n-2, ... whose value exceeds lambda_c, which is what `signal_vectors(k)` returns
+    vectors for; eigenvalue q of `nL` is the quotient of vector q (descending index order). Returns (L with the refined
+    values, sorted ascending; k; nL; report)."""
+    L = np.asarray(L, dtype=np.float64)
+    n = len(L)
+    band = float(guard_band) * math.sqrt(n) * 5.96e-8 * float(L[-1]) if n else 0.0
+    near = np.flatnonzero(np.abs(L - lambda_c) <= band)
+    guard = {"band": band, "refined": [], "monotone": True}
+    Lw = L
+    if guard_band > 0 and near.size and near.size <= 64:
+        lo_i, hi_i = int(near[0]), int(near[-1]) + 1
+        rho = np.asarray(refine(lo_i, hi_i), dtype=np.float64)
+        guard["refined"] = [(int(i), float(L[i]), float(rho[i - lo_i])) for i in range(lo_i, hi_i)]
+        Lw = L.copy()
+        Lw[lo_i:hi_i] = rho
+        guard["monotone"] = bool(np.all(np.diff(Lw[max(lo_i - 1, 0): min(hi_i + 1, n)]) >= 0))
+    below = np.flatnonzero(~(Lw > lambda_c))  # strict, as in the reference (Appendix A11)
+    k = n - (int(below[-1]) + 1) if below.size else n
+    nL = Lw[n - k:][::-1].copy()  # descending index order: value q belongs to eigenvector q of signal_vectors(k)
+    return (Lw if guard["monotone"] else np.sort(Lw)), k, nL, guard
+
+
 def _exchange_ensemble(ses: "Session", shard: Shard, n_perturb: int, min_pc: int, nL_set, ncols):
     """The single gather of the ensemble: all-gather the owned N x min_pc blocks (+ their
     eigenvalues and column counts) over RCCL; every rank then holds all slots (rank 0 scores them). The blocks
@@ -770,7 +799,7 @@ def _extract(inp):
 def sclens(inp_df, device_="gpu", th=60, p_step=0.001, n_perturb=20, centering="mean", draws: Optional[Draws] = None,
            seed: Optional[int] = None, ctx: Optional[Context] = None, max_search_iters: Optional[int] = None,
            keep_intermediates: bool = False, verbose: bool = False, shard: Optional[Shard] = None,
-           partial_eig: bool = True, streams: Optional[int] = 1, batch: bool = False, spread_initial: bool = True,
+           partial_eig: bool = True, streams: Optional[int] = None, spread_initial: bool = True,
            guard_band: float = 4.0) -> Dict[str, object]:
     """scLENS.sclens (scLENS.jl:649-832) on one MI355X.
 
@@ -845,36 +874,19 @@ def sclens(inp_df, device_="gpu", th=60, p_step=0.001, n_perturb=20, centering="
         gb0 = sum(w.get_int("gram_bits_used") for w in workers)  # context-lifetime counters: this call's share is the difference
         W = len(workers)
         pool = ThreadPoolExecutor(max_workers=W) if W > 1 else None
-        # batch=True: concurrent decompositions of one round advance their tridiagonalisations in shared launches (bitwise
-        # the same results as solo runs). Opt-in: measured on MI355X it only pays with >= 6 streams at n <= ~3000
-        # (17.8 vs 22.8 ms per matrix); at 3 streams independent streams overlap better at every n.
-        group = BatchGroup() if (W > 1 and batch) else None
-        if group is not None:
-            for c_ in [ctx] + wctx:
-                c_.set_batch(group)
-
-        def run_all(jobs, lockstep=False):
+        def run_all(jobs):
             """jobs: list of (worker_index, callable) -> results in job order. Jobs of one worker run sequentially in
-            one thread (a session is single-threaded); different workers run concurrently. `lockstep`: every job runs
-            exactly one full decomposition (or calls group.leave()), so the round can be batched."""
+            one thread (a session is single-threaded); different workers run concurrently."""
             if pool is None:
                 return [f() for _, f in jobs]
             out = [None] * len(jobs)
             by_worker = {}
             for pos, (wk, f) in enumerate(jobs):
                 by_worker.setdefault(wk, []).append((pos, f))
-            batched = group is not None and lockstep and len(by_worker) == len(jobs) and len(jobs) > 1
-            if group is not None:
-                group.expect(len(jobs) if batched else 0)
 
             def run_group(grp):
                 for pos, f in grp:
-                    try:
-                        out[pos] = f()
-                    except BaseException:
-                        if batched:
-                            group.leave()  # no-op once this job's decomposition has been through the round
-                        raise
+                    out[pos] = f()
 
             futs = [pool.submit(run_group, g) for g in by_worker.values()]
             for f in futs:
@@ -911,27 +923,18 @@ def sclens(inp_df, device_="gpu", th=60, p_step=0.001, n_perturb=20, centering="
         else:  # the main session keeps the data matrix's reflectors for signal_vectors; workers take the other two
             w_null, w_bin = workers[1], workers[2 if W >= 3 else 1]
             (L, rec_vals), Lr, (_, r_vr2) = run_all([(0, lambda: ses.data_spectrum(not median)), (1, lambda: w_null.null_spectrum_pattern(null_future.result())),
-                                                     (2 if W >= 3 else 1, w_bin.binary_basis)], lockstep=True)
+                                                     (2 if W >= 3 else 1, w_bin.binary_basis)])
         L_mp, _, b_min = _mp_calculation(L, Lr[:-1])  # Lr[1:end-1] (:537, :576)
         lambda_c = _tw(L, L_mp)[0]
         # guard band: eigenvalues within +-4 sqrt(n) eps32 lambda_max of the cut are replaced by float64 Rayleigh quotients
         # before `L .> lambda_c` (:541, :580) is taken (the rank that holds the data matrix refines, all ranks use its values)
-        band = float(guard_band) * math.sqrt(len(L)) * 5.96e-8 * float(L[-1])
-        near = np.flatnonzero(np.abs(L - lambda_c) <= band)
-        guard = {"band": band, "refined": []}
-        if guard_band > 0 and near.size and near.size <= 64:
-            lo_i, hi_i = int(near[0]), int(near[-1]) + 1
+        def refine(lo_i, hi_i):
             rho = ses.refine_eigenvalues(lo_i, hi_i) if (not spread or shard.rank == 0) else np.zeros(hi_i - lo_i)
-            if spread:
-                rho = shard.bcast_host(rho, 0)
-            guard["refined"] = [(int(i), float(L[i]), float(rho[i - lo_i])) for i in range(lo_i, hi_i)]
-            L = L.copy()
-            L[lo_i:hi_i] = rho
-        sel = L > lambda_c
-        k = int(sel.sum())
+            return shard.bcast_host(rho, 0) if spread else rho
+
+        L, k, nL, guard = cut_with_guard_band(L, lambda_c, guard_band, refine)
         if verbose:
             print(f"(Using hip) number of signal ev: {k}")
-        nL = L[sel][::-1].copy()  # descending
         nV = ses.signal_vectors(k) if (not spread or shard.rank == 0) else None
         if r_vr2 is None:
             _, r_vr2 = ses.binary_basis()
@@ -982,8 +985,6 @@ def sclens(inp_df, device_="gpu", th=60, p_step=0.001, n_perturb=20, centering="
                     else:
                         d5, _r = workers[wk].search_step_seeded(sample_seed_for(draws.sample_seed, "search", my_it), nnzidx, n_2)
                     out[:5], out[5] = d5, 1.0
-                elif group is not None:
-                    group.leave()  # no decomposition in this job
                 return out
             return f
 
@@ -993,7 +994,7 @@ def sclens(inp_df, device_="gpu", th=60, p_step=0.001, n_perturb=20, centering="
         try:
             while p_ is None:
                 base = it + shard.rank * W
-                mine = np.stack(run_all([(w, search_job(w, base + w)) for w in range(W)], lockstep=True))  # W x 6
+                mine = np.stack(run_all([(w, search_job(w, base + w)) for w in range(W)]))  # W x 6
                 allr = shard.allgather_small(mine).reshape(shard.world * W, 6)
                 results = [allr[q, :5] if allr[q, 5] == 1.0 else None for q in range(shard.world * W)]
                 tank, used, stopped, p_fin = consume_search_round(tank, results, p_list, it, p_th, p_step, max_search_iters)
@@ -1046,9 +1047,6 @@ def sclens(inp_df, device_="gpu", th=60, p_step=0.001, n_perturb=20, centering="
                 w.close()
             for c2 in wctx:
                 c2.close()
-            if group is not None:
-                ctx.set_batch(None)
-                group.close()
 
         res: Dict[str, object] = {"L": L, "L_mp": L_mp, "λ": lambda_c, "lambda_c": lambda_c, "cell_id": cell_id,
                                   "p_": p_, "p_th": p_th, "n_search": it, "search_trace": trace,

@@ -12,15 +12,14 @@ from __future__ import annotations
 
 import math
 import time
-import traceback
 from typing import Dict, Optional
 
 import numpy as np
 import scipy.sparse as sp
 
 from . import _lib
-from .api import (Context, Draws, Session, _csc_f32, _mp_calculation, _resolve, _robust_scores, _tw, default_context,
-                  mp_check, sample_seed_for)
+from .api import (Context, Draws, Session, _csc_f32, _mp_calculation, _resolve, _robust_scores, _tw, cut_with_guard_band,
+                  default_context, mp_check, sample_seed_for)
 from .shard import Shard, consume_search_round, search_schedule
 
 
@@ -29,20 +28,6 @@ def row_block(rank: int, world: int, N: int):
     base, rem = divmod(N, world)
     row0 = rank * base + min(rank, rem)
     return row0, row0 + base + (1 if rank < rem else 0)
-
-
-def make_reducer(shard: Shard, ctx: Context):
-    """the `sclens_hip_allreduce_fn` the library calls: sum a device buffer over all ranks in place"""
-
-    def cb(_user, dev_ptr, count, dtype):
-        try:
-            shard.allreduce_dev(ctx, dev_ptr, count, dtype)
-            return 0
-        except Exception:  # never let an exception cross the C ABI
-            traceback.print_exc()
-            return 1
-
-    return _lib.ALLREDUCE_FN(cb)
 
 
 def _gather_rows(shard: Shard, local: np.ndarray, N_global: int) -> np.ndarray:
@@ -62,7 +47,7 @@ def _gather_rows(shard: Shard, local: np.ndarray, N_global: int) -> np.ndarray:
 
 def sclens_row_sharded(X_local, row0: int, N_global: int, draws: Draws, shard: Shard, th=60, p_step=0.001, n_perturb=20,
                        ctx: Optional[Context] = None, max_search_iters: Optional[int] = None, gather: bool = True,
-                       verbose: bool = False) -> Dict[str, object]:
+                       verbose: bool = False, guard_band: float = 4.0) -> Dict[str, object]:
     """scLENS.sclens (scLENS.jl:649-832) with the cells divided over the ranks of `shard`.
 
     X_local: this rank's cells (N_local x M, N_global > M). draws: the GLOBAL draws, identical on every rank (z_idx1 =
@@ -77,19 +62,17 @@ def sclens_row_sharded(X_local, row0: int, N_global: int, draws: Draws, shard: S
     z1, z2 = _resolve(draws.z_idx1), _resolve(draws.z_idx2)
     Xr = _resolve(draws.X_r)
     Xr_local = _csc_f32(sp.csc_matrix(Xr.tocsr()[row0: row0 + N_local])) if Xr.shape[0] == N_global else _csc_f32(Xr)
-    reducer = make_reducer(shard, ctx)
-    ses = Session.create_sharded(ctx, X_local, row0, N_global, z1, z2, reducer)
+    ses = Session.create_sharded(ctx, X_local, row0, N_global, z1, z2, shard.reducer(ctx))
     try:
         Lr = shard.agree(ses.null_spectrum(Xr_local))  # :704
         L, rec_vals = ses.data_spectrum()
         L = shard.agree(L)
         L_mp, _, _ = _mp_calculation(L, Lr[:-1])
         lambda_c = _tw(L, L_mp)[0]
-        sel = L > lambda_c
-        k = int(sel.sum())
+        # the same guard band as api.sclens: every rank refines (the quotient is summed over the row blocks inside the library)
+        L, k, nL, guard = cut_with_guard_band(L, lambda_c, guard_band, lambda lo, hi: shard.agree(ses.refine_eigenvalues(lo, hi)))
         if verbose and shard.rank == 0:
             print(f"(Using hip, {shard.world} row blocks) number of signal ev: {k}")
-        nL = L[sel][::-1].copy()
         nV_local = ses.signal_vectors(k)
         _, r_vr2 = ses.binary_basis()  # :717-721
         mpC = mp_check(L_mp)
@@ -116,7 +99,8 @@ def sclens_row_sharded(X_local, row0: int, N_global: int, draws: Draws, shard: S
         m_pert = int(round((1 - p_) * M * N_global))
         nL_set, ncols = [None] * n_perturb, [0] * n_perturb
         res: Dict[str, object] = {"L": L, "L_mp": L_mp, "λ": lambda_c, "lambda_c": lambda_c, "p_": p_, "p_th": p_th,
-                                  "n_search": it, "search_trace": trace, "row_block": (row0, row0 + N_local)}
+                                  "n_search": it, "search_trace": trace, "row_block": (row0, row0 + N_local),
+                                  "guard_band": guard}
         if k == 0:  # :780-784
             res["partial_eig"] = (0, 0)
             res["wall_s"] = time.perf_counter() - t_all

@@ -52,7 +52,6 @@ int denoise_host(Ctx*, const float*, int64_t, int64_t, const float*, int64_t, co
 
 using scl::Ctx;
 
-struct sclens_hip_ctx { Ctx c; };
 struct sclens_hip_session { scl::Session* s; sclens_hip_ctx* ctx; std::vector<double> scratch; };
 
 extern "C" {
@@ -107,23 +106,6 @@ void sclens_hip_destroy(sclens_hip_ctx* h) {
 const char* sclens_hip_last_error(const sclens_hip_ctx* h) { return h ? h->c.err.c_str() : "null context"; }
 void* sclens_hip_stream(sclens_hip_ctx* h) { return h ? (void*)h->c.stream : nullptr; }
 
-sclens_hip_batch* sclens_hip_batch_create(void) { return reinterpret_cast<sclens_hip_batch*>(scl::batch_create()); }
-void sclens_hip_batch_destroy(sclens_hip_batch* g) { scl::batch_destroy(reinterpret_cast<scl::BatchGroup*>(g)); }
-int sclens_hip_batch_expect(sclens_hip_batch* g, int count) {
-  if (!g) return SCLENS_ERR_ARG;
-  scl::batch_expect(reinterpret_cast<scl::BatchGroup*>(g), count);
-  return SCLENS_OK;
-}
-int sclens_hip_batch_leave(sclens_hip_batch* g) {
-  if (!g) return SCLENS_ERR_ARG;
-  scl::batch_leave(reinterpret_cast<scl::BatchGroup*>(g));
-  return SCLENS_OK;
-}
-int sclens_hip_set_batch(sclens_hip_ctx* h, sclens_hip_batch* g) {
-  if (!h) return SCLENS_ERR_ARG;
-  h->c.batch = reinterpret_cast<scl::BatchGroup*>(g);
-  return SCLENS_OK;
-}
 
 int sclens_hip_set_timing(sclens_hip_ctx* h, int enabled) {
   if (!h) return SCLENS_ERR_ARG;
@@ -343,7 +325,7 @@ int sclens_hip_session_adopt(sclens_hip_session* dst, sclens_hip_session* src, i
   return scl::session_adopt(dst->s, src->s, what);
 }
 int sclens_hip_session_refine_eigenvalues(sclens_hip_session* w, int64_t idx_lo, int64_t idx_hi, double* rho) {
-  if (!w) return SCLENS_ERR_ARG;
+  SES_GUARD(w);
   return scl::session_refine_eigenvalues(w->s, idx_lo, idx_hi, rho);
 }
 int sclens_hip_session_signal_vectors(sclens_hip_session* w, int64_t k, float* nV) {

@@ -48,8 +48,8 @@ struct Ctx {
   // sessions keep their eigenvector / ensemble buffers in this context's named workspaces ("ses.*", "eig.*"): one live
   // session per context (worker sessions of session_clone bring their own context)
   int live_sessions = 0;
-  // lock-step batching of tridiagonalisations that run concurrently on several contexts (tridiag.hip); not owned
-  struct BatchGroup* batch = nullptr;
+  // kernels whose dynamic LDS limit has been raised above 64 KB on this context's device (the attribute is per device)
+  std::map<const void*, int> lds_attr;
 
   int fail(int code, const std::string& msg) {
     err = msg;
@@ -100,6 +100,15 @@ struct StageTimer {  // HIP-event timing of one stage on ctx->stream (only when 
 };
 
 static inline int64_t round_up(int64_t x, int64_t m) { return (x + m - 1) / m * m; }
+
+// raise a kernel's dynamic-LDS limit once per context (= per device; a process-wide `static` would cover only the first device)
+static inline int ensure_dyn_lds(Ctx* ctx, const void* fn, int bytes) {
+  auto it = ctx->lds_attr.find(fn);
+  if (it != ctx->lds_attr.end() && it->second >= bytes) return SCLENS_OK;
+  SCL_HIP(ctx, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+  ctx->lds_attr[fn] = bytes;
+  return SCLENS_OK;
+}
 
 // ------------------------------------------------------------------ GEMM (gemm.hip)
 // C[M x N] (ldc) = alpha * P[M x K] * op(Q) + beta * C, everything row-major fp32.
@@ -180,10 +189,6 @@ int sbr_apply_q2(Ctx* ctx, int64_t n, float* Zt, int64_t m, int64_t ldz);
 int eig_values_two_stage(Ctx* ctx, const float* A, int64_t n, int64_t lda, double* w64_dev, int* used, int64_t n_low = -1);
 int eig_vectors_two_stage(Ctx* ctx, int64_t n, int64_t vec_lo, int64_t vec_hi, float* Zt, int64_t ldz);
 int sb2st_f32(Ctx* ctx, const float* A, int64_t n, int64_t lda, double* d_dev, double* e_dev);
-BatchGroup* batch_create();
-void batch_destroy(BatchGroup* g);
-void batch_expect(BatchGroup* g, int count);
-void batch_leave(BatchGroup* g);
 int symv_probe(Ctx* ctx, int64_t n, int64_t* launches, double* total_ms, double* total_bytes);
 
 // ------------------------------------------------------------------ partial eigensolver (chefsi.hip)
@@ -211,3 +216,8 @@ int reverse_rows_f32(Ctx* ctx, const float* in, int64_t rows, int64_t cols, int6
 int gram_f32(Ctx* ctx, const float* B, int64_t n, int64_t K, int64_t ldb, float divisor, float* A, int64_t lda);
 
 }  // namespace scl
+
+// the opaque context handle of the C ABI (capi.hip, comm.hip)
+struct sclens_hip_ctx {
+  scl::Ctx c;
+};

@@ -461,9 +461,7 @@ int gemm_f32(Ctx* ctx, const GemmArgs& a) {
   if (big_ok && a.N <= 64 && !a.lower && !a.colabsmax && (a.prefer_big || force_big)) {  // skinny: 256 x 64 tiles
     using Cfg = BigCfg<8, 1, 1, 2>;
     const int64_t bm = (a.M + GB - 1) / GB;
-    static const hipError_t attr_rc = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_big<8, 1, 1, 2>),
-                                                          hipFuncAttributeMaxDynamicSharedMemorySize, 2 * Cfg::STAGE * (int)sizeof(float));
-    SCL_HIP(ctx, attr_rc);
+    SCL_TRY(ensure_dyn_lds(ctx, reinterpret_cast<const void*>(gemm_nt_big<8, 1, 1, 2>), 2 * Cfg::STAGE * (int)sizeof(float)));
     hipLaunchKernelGGL((gemm_nt_big<8, 1, 1, 2>), dim3((unsigned)bm, (unsigned)nsl), dim3(512), 2 * Cfg::STAGE * sizeof(float),
                        ctx->stream, a, (const int2*)nullptr, 1);
     SCL_HIP(ctx, hipGetLastError());
@@ -481,9 +479,7 @@ int gemm_f32(Ctx* ctx, const GemmArgs& a) {
     const int2* tiles = nullptr;
     int64_t nb = ntb;
     if (want_list || (force_big && !a.prefer_big)) SCL_TRY(big_tile_list(ctx, bm, bn, a.lower, &tiles, &nb));
-    static const hipError_t attr_rc = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_big<2, 4, 4, 2>),
-                                                          hipFuncAttributeMaxDynamicSharedMemorySize, 2 * Cfg::STAGE * (int)sizeof(float));
-    SCL_HIP(ctx, attr_rc);
+    SCL_TRY(ensure_dyn_lds(ctx, reinterpret_cast<const void*>(gemm_nt_big<2, 4, 4, 2>), 2 * Cfg::STAGE * (int)sizeof(float)));
     hipLaunchKernelGGL((gemm_nt_big<2, 4, 4, 2>), dim3((unsigned)nb, (unsigned)nsl), dim3(512), 2 * Cfg::STAGE * sizeof(float),
                        ctx->stream, a, tiles, (int)bn);
     SCL_HIP(ctx, hipGetLastError());

@@ -293,9 +293,7 @@ __global__ __launch_bounds__(512, 2) void gram_bits_kernel(GramBitsArgs a, const
 template <int NW>
 int launch_gram_bits(Ctx* ctx, const GramBitsArgs& a, const int2* tiles, int64_t nb) {
   constexpr int LDS_BYTES = 2 * (2 * 256 * 128 + 128 * NW);
-  static const hipError_t attr_rc = hipFuncSetAttribute(reinterpret_cast<const void*>(gram_bits_kernel<NW>),
-                                                        hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
-  SCL_HIP(ctx, attr_rc);
+  SCL_TRY(ensure_dyn_lds(ctx, reinterpret_cast<const void*>(gram_bits_kernel<NW>), LDS_BYTES));
   hipLaunchKernelGGL((gram_bits_kernel<NW>), dim3((unsigned)nb), dim3(512), LDS_BYTES, ctx->stream, a, tiles);
   SCL_HIP(ctx, hipGetLastError());
   return SCLENS_OK;
@@ -487,9 +485,7 @@ int corr_colabsmax_split(Ctx* ctx, const void* Aimg, int64_t M, const void* Bimg
   int64_t nb = 0;
   SCL_TRY(big_tile_list(ctx, bm, bn, 0, &tiles, &nb));
   constexpr int LDS_BYTES = 2 * 2 * 256 * 128;
-  static const hipError_t attr_rc = hipFuncSetAttribute(reinterpret_cast<const void*>(corr_split_kernel),
-                                                        hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
-  SCL_HIP(ctx, attr_rc);
+  SCL_TRY(ensure_dyn_lds(ctx, reinterpret_cast<const void*>(corr_split_kernel), LDS_BYTES));
   SplitCorrArgs a{static_cast<const _Float16*>(Aimg), static_cast<const _Float16*>(Bimg), M, N, round_up(K, 32), colabsmax,
                   1.0f / 16777216.0f};
   hipLaunchKernelGGL(corr_split_kernel, dim3((unsigned)nb), dim3(512), LDS_BYTES, ctx->stream, a, tiles);

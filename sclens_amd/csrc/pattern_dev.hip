@@ -317,6 +317,10 @@ int pattern_build_device(Ctx* ctx, int64_t N, int64_t M, const int64_t* colptr, 
                        urow, uval);
     SCL_HIP(ctx, hipStreamSynchronize(st));
   }
+  // a stored row index outside [0, N) must not reach k_copy_rows_u32 (it counts rows through the unchecked index)
+  SCL_HIP(ctx, hipMemcpyAsync(hbad, bad, sizeof(int) * 4, hipMemcpyDeviceToHost, st));
+  SCL_HIP(ctx, hipStreamSynchronize(st));
+  if (hbad[0]) return ctx->fail(SCLENS_ERR_ARG, "row index out of range");
   // ---- CSR view
   int64_t* rptr = keep<int64_t>(ctx, out, N + 1);
   int64_t* c2c = keep<int64_t>(ctx, out, nU);

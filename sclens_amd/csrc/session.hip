@@ -8,6 +8,7 @@
 
 #include "common.h"
 #include "pattern.h"
+#include "pattern_host.h"
 #include "rng.h"
 
 namespace scl {
@@ -125,88 +126,14 @@ int pattern_build(Ctx* ctx, int64_t N, int64_t M, const int64_t* colptr, const i
   // SCLENS_HIP_HOST_PATTERN=1 keeps the host builder (tests compare the two)
   if (row0 == 0 && N_global == N && !getenv("SCLENS_HIP_HOST_PATTERN"))
     return pattern_build_device(ctx, N, M, colptr, rowval, nzval, ncand, z1, z2, 0, 0, out);
-  const int64_t nnz = colptr[M];
-  // candidates whose cell lies in [row0, row0 + N) are local; the others keep their list index with slot -1
-  auto local = [&](int64_t t) { return (int64_t)z1[t] >= row0 && (int64_t)z1[t] < row0 + N; };
-  std::vector<int64_t> ucol(M + 1, 0);
-  for (int64_t j = 0; j < M; ++j) ucol[j + 1] = colptr[j + 1] - colptr[j];
-  int64_t ncl = 0;
-  for (int64_t t = 0; t < ncand; ++t) {
-    if (z2[t] >= (uint64_t)M || z1[t] >= (uint64_t)N_global) return ctx->fail(SCLENS_ERR_ARG, "candidate index out of range");
-    if (local(t)) {
-      ucol[z2[t] + 1] += 1;
-      ncl += 1;
-    }
-  }
-  const int64_t nU = nnz + ncl;
-  for (int64_t j = 0; j < M; ++j) ucol[j + 1] += ucol[j];
-  std::vector<int32_t> urow(nU);
-  std::vector<float> uval(nU, 0.f);
-  std::vector<int64_t> cpos(ncand);
-  // host threads: every pass below is split by a range of genes or of cells whose owner scans the whole input and handles
-  // its own part, so the result does not depend on the thread count
-  const int T = (int)std::max<int64_t>(1, std::min<int64_t>(host_parallelism(), nU / 1000000 + 1));
-  std::vector<int> bad(T, 0);
-  auto run = [&](auto&& fn) {
-    std::vector<std::thread> th;
-    for (int t = 1; t < T; ++t) th.emplace_back(fn, t);
-    fn(0);
-    for (auto& x : th) x.join();
-  };
-  // CSC fill: stored counts and the candidate cursors of the owner's genes (candidate order inside a gene = list order)
-  run([&](int t) {
-    const int64_t j0 = M * t / T, j1 = M * (t + 1) / T;
-    for (int64_t j = j0; j < j1; ++j) {
-      int64_t q = ucol[j];
-      for (int64_t s = colptr[j]; s < colptr[j + 1]; ++s, ++q) {
-        if (rowval[s] < 0 || rowval[s] >= N) { bad[t] = 1; return; }
-        urow[q] = rowval[s];
-        uval[q] = nzval[s];
-      }
-    }
-    std::vector<int64_t> cur(j1 - j0);
-    for (int64_t j = j0; j < j1; ++j) cur[j - j0] = ucol[j] + (colptr[j + 1] - colptr[j]);
-    for (int64_t c = 0; c < ncand; ++c) {
-      const int64_t j = (int64_t)z2[c];
-      if (j < j0 || j >= j1) continue;
-      if (local(c)) {
-        const int64_t pos = cur[j - j0]++;
-        cpos[c] = pos;
-        urow[pos] = (int32_t)((int64_t)z1[c] - row0);
-      } else {
-        cpos[c] = -1;
-      }
-    }
-  });
-  for (int b : bad)
-    if (b) return ctx->fail(SCLENS_ERR_ARG, "row index out of range");
-  // CSR view: thread t owns the row range [r0, r1): it scans every slot but only counts / places its own rows, so the
-  // order inside a row (ascending column, slot order inside a column) does not depend on the thread count
-  std::vector<int64_t> rptr(N + 1, 0);
-  run([&](int t) {
-    const int32_t r0 = (int32_t)(N * t / T), r1 = (int32_t)(N * (t + 1) / T);
-    for (int64_t q = 0; q < nU; ++q) {
-      const int32_t r = urow[q];
-      if (r >= r0 && r < r1) rptr[r + 1] += 1;
-    }
-  });
-  for (int64_t i = 0; i < N; ++i) rptr[i + 1] += rptr[i];
-  std::vector<int64_t> c2c(nU);
-  std::vector<int32_t> ccol(nU);
-  {
-    std::vector<int64_t> rc(rptr.begin(), rptr.end() - 1);
-    run([&](int t) {
-      const int32_t r0 = (int32_t)(N * t / T), r1 = (int32_t)(N * (t + 1) / T);
-      for (int64_t j = 0; j < M; ++j)
-        for (int64_t q = ucol[j]; q < ucol[j + 1]; ++q) {
-          const int32_t r = urow[q];
-          if (r < r0 || r >= r1) continue;
-          const int64_t s = rc[r]++;
-          c2c[s] = q;
-          ccol[s] = (int32_t)j;
-        }
-    });
-  }
+  HostPattern hp;
+  std::string herr;
+  if (pattern_build_host(N, M, colptr, rowval, nzval, ncand, z1, z2, row0, N_global, 0, &hp, &herr) != SCLENS_OK)
+    return ctx->fail(SCLENS_ERR_ARG, herr);
+  const int64_t nU = hp.nU;
+  const std::vector<int64_t>&ucol = hp.ucol, &cpos = hp.cpos, &rptr = hp.rptr, &c2c = hp.c2c;
+  const std::vector<int32_t>&urow = hp.urow, &ccol = hp.ccol;
+  const std::vector<float>& uval = hp.uval;
   out->dev.N = N; out->dev.M = M; out->dev.nU = nU; out->dev.ncand = ncand;
   SCL_TRY(upload(ctx, out, ucol, &out->dev.colptr));
   SCL_TRY(upload(ctx, out, urow, &out->dev.row));
@@ -661,7 +588,7 @@ static int to_cell_side(Session* s, const float* B, int64_t cnt, float* dst, boo
 
 // Guard band of the signal threshold (hard part 2): `sum(L .> lambda_c)` (scLENS.jl:539, :580) is a hard
 // cut, and an fp32 eigenvalue carries an error of about sqrt(n) eps32 lambda_max. For the eigenvalues idx_lo .. idx_hi-1
-// (ascending index) of the data matrix this returns the fp64 Rayleigh quotients rho = ||B' z||^2 / divisor of their fp32
+// (ascending index) of the data matrix this returns the fp64 Rayleigh quotients rho = ||B' z||^2 / (divisor z'z) of their fp32
 // eigenvectors z against the resident scaled matrix B (products and sums in fp64): second-order accurate in the error of z,
 // i.e. the eigenvalue of the fp32 data to ~1e-9 relative. Valid between data_spectrum and signal_vectors.
 constexpr int RQ_V = 8;  // vectors per pass over B
@@ -732,7 +659,18 @@ int session_refine_eigenvalues(Session* s, int64_t idx_lo, int64_t idx_hi, doubl
     SCL_HIP(ctx, hipMemcpyAsync(rho, dr, sizeof(double) * cnt, hipMemcpyDeviceToHost, ctx->stream));
     SCL_HIP(ctx, hipStreamSynchronize(ctx->stream));
   }
-  for (int64_t q = 0; q < cnt; ++q) rho[q] /= (double)s->M;  // the divisor of data_spectrum: size(X, 2) = M (Appendix A8)
+  // z comes out of fp32 back-transformations: its norm is 1 only to ~1e-6 at n ~ 3 * 10^4, which is the size of the error the
+  // band is there to resolve, so the quotient is taken against z'z (fp64 sum of squares of the eigen-side vector, replicated
+  // on every rank of a row-sharded session)
+  SCL_WS(ctx, zsq, double, "ses.rqz", cnt);
+  SCL_TRY(row_sqnorms_f32(ctx, s->Zt, cnt, s->n, s->ldz, zsq));
+  std::vector<double> hz((size_t)cnt);
+  SCL_HIP(ctx, hipMemcpyAsync(hz.data(), zsq, sizeof(double) * cnt, hipMemcpyDeviceToHost, ctx->stream));
+  SCL_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  for (int64_t q = 0; q < cnt; ++q) {
+    if (!(hz[(size_t)q] > 0.0)) return ctx->fail(SCLENS_ERR_NAN, "refine_eigenvalues: zero or NaN eigenvector");
+    rho[q] /= (double)s->M * hz[(size_t)q];  // the divisor of data_spectrum: size(X, 2) = M (Appendix A8)
+  }
   return SCLENS_OK;
 }
 

@@ -62,10 +62,9 @@ struct TrdArgs {
   float* WV;        // [n][2NB] row-major [W|V]
 };
 
-// Several independent matrices of the same order advance in lock-step: blockIdx.z selects the member. A column step of
-// ONE matrix cannot fill the chip (trd_colA is a latency chain over ~n/128 blocks), so concurrent decompositions
-// (sparsity-search evaluations, data | null | binarised matrix) share their launches. Each member's arithmetic is
-// exactly that of a solo run (same blocks, same reduction orders): results are bitwise identical.
+// The kernels take an array of argument sets and blockIdx.z selects the member; the host launches ONE member. (Round 2 had a
+// host-side rendezvous that merged the column steps of concurrent decompositions into shared launches; measured no faster than
+// independent streams at the three members the path runs -- 212 vs 190 ms per matrix at n = 10^4 -- and removed in round 3.)
 constexpr int TRD_MAXB = 8;
 struct TrdBatch {
   TrdArgs a[TRD_MAXB];
@@ -599,109 +598,6 @@ static int sytrd_run(Ctx* ctx, const TrdJob* jobs, int nb) {
   return SCLENS_OK;
 }
 
-// ---- rendezvous of concurrent decompositions (one host thread + one stream each) into batched launches -------------
-struct BatchGroup {
-  std::mutex mu;
-  std::condition_variable cv;
-  int expected = 0;             // participants of the current round (set by batch_expect; <= 1: no batching)
-  bool promote = false;         // a participant left: a waiter must take the lead
-  uint64_t generation = 0;
-  std::vector<TrdJob> jobs;     // arrived so far
-  std::vector<hipEvent_t> ready;
-  hipEvent_t done = nullptr;
-  int last_rc = SCLENS_OK;
-  std::string last_err;
-};
-
-BatchGroup* batch_create() { return new BatchGroup(); }
-void batch_destroy(BatchGroup* g) {
-  if (!g) return;
-  for (hipEvent_t e : g->ready) hipEventDestroy(e);
-  if (g->done) hipEventDestroy(g->done);
-  delete g;
-}
-void batch_expect(BatchGroup* g, int count) {
-  std::lock_guard<std::mutex> lk(g->mu);
-  g->expected = count > TRD_MAXB ? 0 : count;  // more members than one launch holds: run unbatched
-  g->promote = false;
-}
-void batch_leave(BatchGroup* g) {  // a participant of this round will not arrive (it failed before its tridiagonalisation)
-  std::lock_guard<std::mutex> lk(g->mu);
-  if (g->expected <= 0) return;
-  g->expected -= 1;
-  if (!g->jobs.empty() && (int)g->jobs.size() >= g->expected) {
-    g->promote = true;
-    g->cv.notify_all();
-  }
-}
-
-// called with g->mu held by the thread that completes the round
-static int batch_lead(BatchGroup* g, Ctx* ctx) {
-  std::vector<TrdJob> jobs;
-  jobs.swap(g->jobs);
-  g->expected = 0;
-  g->promote = false;
-  int rc = SCLENS_OK;
-  auto hip_ok = [&](hipError_t e, const char* what) {
-    if (e != hipSuccess && rc == SCLENS_OK) rc = ctx->fail(SCLENS_ERR_HIP, std::string(what) + ": " + hipGetErrorString(e));
-  };
-  for (size_t i = 0; i < jobs.size(); ++i)
-    if (jobs[i].ctx != ctx) hip_ok(hipStreamWaitEvent(ctx->stream, g->ready[i], 0), "hipStreamWaitEvent");
-  bool same = true;
-  for (const TrdJob& jb : jobs) same = same && jb.a.n == jobs[0].a.n && jb.a.ldv == jobs[0].a.ldv;
-  if (rc == SCLENS_OK) {
-    if (same) {
-      rc = sytrd_run(ctx, jobs.data(), (int)jobs.size());
-    } else {
-      for (size_t i = 0; i < jobs.size() && rc == SCLENS_OK; ++i) rc = sytrd_run(ctx, &jobs[i], 1);
-    }
-  }
-  if (!g->done) hip_ok(hipEventCreateWithFlags(&g->done, hipEventDisableTiming), "hipEventCreate");
-  if (g->done) {
-    hip_ok(hipEventRecord(g->done, ctx->stream), "hipEventRecord");
-    for (const TrdJob& jb : jobs)
-      if (jb.ctx != ctx) hip_ok(hipStreamWaitEvent(jb.ctx->stream, g->done, 0), "hipStreamWaitEvent");
-  }
-  g->last_rc = rc;
-  g->last_err = ctx->err;
-  g->generation += 1;
-  g->cv.notify_all();
-  return rc;
-}
-
-static int batch_join(BatchGroup* g, Ctx* ctx, const TrdJob& job) {
-  std::unique_lock<std::mutex> lk(g->mu);
-  if (g->expected <= 1) {
-    lk.unlock();
-    return sytrd_run(ctx, &job, 1);
-  }
-  const size_t idx = g->jobs.size();
-  while (g->ready.size() <= idx) {
-    hipEvent_t ev;
-    SCL_HIP(ctx, hipEventCreateWithFlags(&ev, hipEventDisableTiming));
-    g->ready.push_back(ev);
-  }
-  SCL_HIP(ctx, hipEventRecord(g->ready[idx], ctx->stream));
-  g->jobs.push_back(job);
-  if ((int)g->jobs.size() >= g->expected) return batch_lead(g, ctx);
-  const uint64_t gen = g->generation;
-  while (g->generation == gen) {
-    if (g->promote) return batch_lead(g, ctx);
-    if (g->cv.wait_for(lk, std::chrono::seconds(600)) == std::cv_status::timeout && g->generation == gen && !g->promote) {
-      // fail the whole round loudly: every waiter returns this error
-      g->jobs.clear();
-      g->expected = 0;
-      g->last_rc = ctx->fail(SCLENS_ERR_STATE, "sytrd_f32: batched tridiagonalisation: a participant of the round never arrived");
-      g->last_err = ctx->err;
-      g->generation += 1;
-      g->cv.notify_all();
-      return g->last_rc;
-    }
-  }
-  if (g->last_rc != SCLENS_OK) ctx->err = g->last_err;
-  return g->last_rc;
-}
-
 int sytrd_f32(Ctx* ctx, float* A, int64_t n, int64_t lda, double* d_dev, double* e_dev, float* tau_dev) {
   if (n <= 0) return SCLENS_OK;
   if (lda % 4 != 0 || lda < n || (reinterpret_cast<uintptr_t>(A) & 15u))
@@ -709,7 +605,6 @@ int sytrd_f32(Ctx* ctx, float* A, int64_t n, int64_t lda, double* d_dev, double*
   StageTimer tm(ctx, "sytrd");
   TrdJob job;
   SCL_TRY(sytrd_setup(ctx, A, n, lda, d_dev, e_dev, tau_dev, &job));
-  if (ctx->batch) return batch_join(ctx->batch, ctx, job);
   return sytrd_run(ctx, &job, 1);
 }
 

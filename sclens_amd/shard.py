@@ -1,5 +1,5 @@
-"""Multi-GPU sharding of one sclens() call: one process per GPU, torch.distributed (RCCL on ROCm) for the few
-exchanges the path needs.
+"""Multi-GPU sharding of one sclens() call: one process per GPU; the few exchanges the path needs are RCCL
+calls made inside libsclens_hip.so (csrc/comm.hip), torch.distributed only launches the ranks and ships the unique id.
 
   * sparsity search (scLENS.jl:725-761): sequential early-exit loop, but each p_ evaluation is independent given
     its sample -> evaluate `world` consecutive p_ values per round, all-gather the five numbers each produces,
@@ -15,231 +15,199 @@ from typing import Callable, List, Sequence
 import numpy as np
 
 
-def raw_device_tensor(dev_ptr: int, count: int, typestr: str, device):
-    """zero-copy torch view of `count` elements of library-owned device memory (`__cuda_array_interface__`)"""
-    import torch
-
-    class _Raw:
-        __cuda_array_interface__ = {"shape": (int(count),), "typestr": typestr, "data": (int(dev_ptr), False), "version": 3}
-
-    return torch.as_tensor(_Raw(), device=device)
-
-
 class Shard:
-    """rank/world + the collectives. `world == 1` needs no torch.
+    """rank / world + the exchanges of a multi-GPU sclens() call. `world == 1` needs nothing.
 
-    Device buffers of the library reach RCCL in one of three ways (`staging`):
-      "host"   (default) library buffer -> host (the library's own copy) -> torch tensor on the device (torch's own copy) ->
-               RCCL -> back the same way. No pointer ever crosses between the two HIP runtime instances of the process
-               (the PyTorch-ROCm wheel bundles its own libamdhip64 next to the system one libsclens_hip.so links), so it is
-               correct by construction; the volumes of this path are small against its wall-clock.
-      "device" a device-to-device copy by the library into a torch-allocated staging tensor (saves the two PCIe hops;
-               the copy uses a pointer of the other runtime instance). Selected by `selfcheck()` when it proves that
-               such copies round-trip bit-exactly on every rank.
-      "zero_copy" RCCL directly on a view of the library's buffer (never selected automatically).
+    Two transports, the same control flow on both:
+      * `comm` (an `_lib.Comm`): the library's own RCCL communicator (csrc/comm.hip). Every exchange -- the ensemble gather,
+        the Vr2 / seed-block broadcasts, the all-reduces of a row-sharded session, and the few doubles of the control flow --
+        is a library call on library-owned buffers and the library's stream: no host-framework tensor, no staging copy.
+        This is what one process per GPU uses (`Shard.create(..., backend="nccl")`).
+      * no `comm`: `torch.distributed` with the gloo backend, device buffers staged through host memory. The transport of
+        the CPU tests (world 2) and of several ranks sharing one GPU; never used when a communicator exists.
+    torch.distributed itself is only the launcher and the channel that ships the 128-byte RCCL unique id.
     """
 
-    def __init__(self, rank: int = 0, world: int = 1, device=None, zero_copy: bool = False, staging: str = "host"):
-        """device: the torch device of this rank when the process group is RCCL (`nccl`), None for gloo."""
-        self.rank, self.world, self.device = rank, world, device
-        self.staging = "zero_copy" if zero_copy else staging
-        self.zero_copy = zero_copy
+    def __init__(self, rank: int = 0, world: int = 1, comm=None):
+        self.rank, self.world, self.comm = int(rank), int(world), comm
+
+    @classmethod
+    def create(cls, ctx, rank: int, world: int, backend: str = "nccl", force_comm: bool = False) -> "Shard":
+        """backend "nccl": build the library communicator on `ctx` (the unique id travels through the already initialised
+        torch.distributed group); "gloo": host-staged test transport. `force_comm`: a communicator even for one rank
+        (tests of the RCCL calls on a one-GPU box)."""
+        if backend != "nccl" or (world == 1 and not force_comm):
+            return cls(rank, world, None)
+        from ._lib import Comm
+
+        def ship(uid):
+            if world == 1:
+                return uid
+            import torch.distributed as dist
+
+            box = [uid]
+            dist.broadcast_object_list(box, src=0)
+            return box[0]
+
+        return cls(rank, world, Comm(ctx, rank, world, ship))
+
+    def close(self):
+        if self.comm is not None:
+            self.comm.close()
+            self.comm = None
+
+    def describe(self) -> dict:
+        """what bench.py prints: the rank count RCCL itself reports for the library's communicator"""
+        if self.comm is None:
+            return {"transport": "torch.distributed/gloo (host-staged)" if self.world > 1 else "none", "world": self.world}
+        return {"transport": "rccl (library communicator)", "rccl_ranks": self.comm.world, "rccl_version": self.comm.rccl_version,
+                **self.comm.stats()}
 
     def selfcheck(self, ctx) -> dict:
-        """Start-up test of a multi-rank RCCL job: a 4-element all-reduce, and whether library <-> torch device copies
-        round-trip on every rank (then `staging` becomes "device"). Raises if the all-reduce is wrong."""
-        out = {"world": self.world, "staging": self.staging}
-        if self.world == 1 or self.device is None:
+        """Start-up test of a multi-rank job: a 4-element all-reduce with a known answer on a library buffer (raises if
+        wrong) and a broadcast from the last rank."""
+        out = self.describe()
+        if self.world == 1 and self.comm is None:
             return out
-        import torch
-        import torch.distributed as dist
-
-        t = torch.arange(4, dtype=torch.float32, device=self.device) + float(self.rank)
-        dist.all_reduce(t)
-        want = self.world * np.arange(4) + self.world * (self.world - 1) / 2.0
-        if not np.array_equal(t.cpu().numpy(), want.astype(np.float32)):
-            raise RuntimeError(f"RCCL self-check failed on rank {self.rank}: all-reduce gave {t.cpu().numpy()} instead of {want}")
-        ok = 1.0
+        x = (np.arange(4, dtype=np.float64) + float(self.rank))
+        buf = ctx.malloc(x.nbytes)
         try:
-            h = (np.arange(4096, dtype=np.float32) * 0.5 + self.rank).astype(np.float32)
-            buf = ctx.malloc(h.nbytes)
-            try:
-                ctx.h2d(buf, h)
-                tt = torch.zeros(4096, dtype=torch.float32, device=self.device)
-                torch.cuda.synchronize(self.device)
-                ctx.check(ctx.lib.sclens_hip_dev_memcpy(ctx.h, tt.data_ptr(), buf, h.nbytes, 3))
-                if not np.array_equal(tt.cpu().numpy(), h):
-                    ok = 0.0
-                tt.mul_(2.0)
-                torch.cuda.synchronize(self.device)
-                ctx.check(ctx.lib.sclens_hip_dev_memcpy(ctx.h, buf, tt.data_ptr(), h.nbytes, 3))
-                back = np.empty_like(h)
-                ctx.d2h(back, buf)
-                if not np.array_equal(back, 2.0 * h):
-                    ok = 0.0
-            finally:
-                ctx.free(buf)
-        except Exception:
-            ok = 0.0
-        flag = torch.tensor([ok], dtype=torch.float32, device=self.device)
-        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-        if self.staging == "host" and float(flag.item()) == 1.0:
-            self.staging = "device"
-        out.update({"allreduce": "ok", "cross_runtime_d2d": bool(flag.item() == 1.0), "staging": self.staging})
+            ctx.h2d(buf, x)
+            self.allreduce_dev(ctx, buf, 4, 0)
+            got = np.empty(4)
+            ctx.d2h(got, buf)
+            want = self.world * np.arange(4) + self.world * (self.world - 1) / 2.0
+            if not np.array_equal(got, want):
+                raise RuntimeError(f"all-reduce self-check failed on rank {self.rank}: got {got} instead of {want}")
+            y = np.full(4, float(self.rank), dtype=np.float32)
+            ctx.h2d(buf, y)
+            self.bcast_dev(ctx, buf, 4, self.world - 1)
+            ctx.d2h(y, buf)
+            if not np.all(y == float(self.world - 1)):
+                raise RuntimeError(f"broadcast self-check failed on rank {self.rank}: got {y}")
+        finally:
+            ctx.free(buf)
+        out["selfcheck"] = "ok"
         return out
-
-    def _dev_tensor(self, ctx, dev_ptr: int, count: int, dtype: int):
-        """(tensor RCCL operates on, copy-back function)"""
-        import torch
-
-        tdt, ndt = (torch.float64, np.float64) if dtype == 0 else (torch.float32, np.float32)
-        nbytes = int(count) * (8 if dtype == 0 else 4)
-        if self.staging == "zero_copy":
-            return raw_device_tensor(dev_ptr, count, "<f8" if dtype == 0 else "<f4", self.device), (lambda: None)
-        if self.staging == "device":
-            t = torch.empty(int(count), dtype=tdt, device=self.device)
-            ctx.check(ctx.lib.sclens_hip_dev_memcpy(ctx.h, t.data_ptr(), dev_ptr, nbytes, 3))  # synchronous on the library's stream
-
-            def back():
-                torch.cuda.synchronize(self.device)
-                ctx.check(ctx.lib.sclens_hip_dev_memcpy(ctx.h, dev_ptr, t.data_ptr(), nbytes, 3))
-
-            return t, back
-        h = np.empty(int(count), dtype=ndt)
-        ctx.d2h(h, dev_ptr)
-        t = torch.from_numpy(h).to(self.device)
-
-        def back_host():
-            ctx.h2d(dev_ptr, t.cpu().numpy())
-
-        return t, back_host
 
     # -- equally sized blocks of library device memory: every rank contributes `count` floats, receives world * count
     def allgather_dev(self, ctx, send_ptr: int, recv_ptr: int, count_f32: int):
-        """recv[r * count : (r + 1) * count] = rank r's send buffer (both are library allocations on this rank's GPU)"""
+        """recv[r * count : (r + 1) * count] = rank r's send buffer (both are library allocations on this rank's GPU):
+        THE gather of the perturbation ensemble"""
+        if self.comm is not None:
+            ctx.sync()  # the blocks were written on ctx's stream; the collective runs on the communicator's
+            self.comm.allgather(send_ptr, recv_ptr, 4 * int(count_f32))
+            return
         if self.world == 1:
             ctx.check(ctx.lib.sclens_hip_dev_memcpy(ctx.h, recv_ptr, send_ptr, 4 * int(count_f32), 3))
             return
         import torch
         import torch.distributed as dist
 
-        if self.device is None:  # gloo (tests): through host memory
-            h = np.empty(int(count_f32), dtype=np.float32)
-            ctx.d2h(h, send_ptr)
-            outs = [torch.empty(int(count_f32), dtype=torch.float32) for _ in range(self.world)]
-            dist.all_gather(outs, torch.from_numpy(h))
-            ctx.h2d(recv_ptr, torch.cat(outs).numpy())
-            return
-        t, _ = self._dev_tensor(ctx, send_ptr, count_f32, 1)
-        out = torch.empty(self.world * int(count_f32), dtype=torch.float32, device=self.device)
-        dist.all_gather_into_tensor(out, t)
-        torch.cuda.synchronize(self.device)
-        if self.staging == "host":
-            ctx.h2d(recv_ptr, out.cpu().numpy())
-        else:
-            ctx.check(ctx.lib.sclens_hip_dev_memcpy(ctx.h, recv_ptr, out.data_ptr(), 4 * self.world * int(count_f32), 3))
+        h = np.empty(int(count_f32), dtype=np.float32)
+        ctx.d2h(h, send_ptr)
+        outs = [torch.empty(int(count_f32), dtype=torch.float32) for _ in range(self.world)]
+        dist.all_gather(outs, torch.from_numpy(h))
+        ctx.h2d(recv_ptr, torch.cat(outs).numpy())
 
     # -- small host arrays (search statistics): fixed-shape float64 all-gather
     def allgather_small(self, arr: np.ndarray) -> np.ndarray:
         arr = np.ascontiguousarray(arr, dtype=np.float64)
+        if self.comm is not None:
+            return self.comm.allgather_host(arr)
         if self.world == 1:
             return arr[None]
         import torch
         import torch.distributed as dist
 
         t = torch.from_numpy(arr.copy())
-        if self.device is not None:
-            t = t.to(self.device)
         out = [torch.empty_like(t) for _ in range(self.world)]
         dist.all_gather(out, t)
-        return np.stack([o.cpu().numpy() for o in out])
-
-    # -- ensemble blocks: every rank contributes `per_rank` equally sized tensors (padded), all ranks receive all
-    def allgather_blocks(self, local):
-        """local: tensor [per_rank, ...] (same shape on every rank) -> tensor [world, per_rank, ...]."""
-        import torch
-
-        if self.world == 1:
-            return local[None]
-        import torch.distributed as dist
-
-        if self.device is None:  # gloo (tests): stage through host memory
-            h = local.detach().cpu().contiguous()
-            outs = [torch.empty_like(h) for _ in range(self.world)]
-            dist.all_gather(outs, h)
-            return torch.stack(outs).to(local.device)
-        out = torch.empty((self.world,) + tuple(local.shape), dtype=local.dtype, device=local.device)
-        dist.all_gather_into_tensor(out.view(-1), local.contiguous().view(-1))
-        return out
+        return np.stack([o.numpy() for o in out])
 
     # -- in-place sum of a raw device buffer over the ranks (row-sharded sessions, SURVEY 8e-iii)
-    def allreduce_dev(self, ctx, dev_ptr: int, count: int, dtype: int, _force: bool = False):
-        """dtype 0 = float64, 1 = float32. RCCL when the process group has a device (backend nccl): the buffer is wrapped as
-        a torch tensor without a copy; otherwise (gloo, tests) it is staged through host memory. `_force`: run the
-        collective even in a one-rank group (tests of the RCCL branch on a single GPU)."""
-        if (self.world == 1 and not _force) or count == 0:
+    def allreduce_dev(self, ctx, dev_ptr: int, count: int, dtype: int):
+        """dtype 0 = float64, 1 = float32"""
+        if count == 0:
+            return
+        if self.comm is not None:
+            ctx.sync()
+            self.comm.allreduce(dev_ptr, count, dtype)
+            return
+        if self.world == 1:
             return
         import torch
         import torch.distributed as dist
 
-        np_t = np.float64 if dtype == 0 else np.float32
-        if self.device is None:
-            h = np.empty(int(count), dtype=np_t)
-            ctx.d2h(h, dev_ptr)
-            t = torch.from_numpy(h)
-            dist.all_reduce(t)
-            ctx.h2d(dev_ptr, h)
-            return
-
-        t, back = self._dev_tensor(ctx, dev_ptr, count, dtype)
+        h = np.empty(int(count), dtype=np.float64 if dtype == 0 else np.float32)
+        ctx.d2h(h, dev_ptr)
+        t = torch.from_numpy(h)
         dist.all_reduce(t)
-        torch.cuda.synchronize(self.device)
-        back()
+        ctx.h2d(dev_ptr, h)
+
+    def reducer(self, ctx):
+        """the `sclens_hip_allreduce_fn` (+ user pointer) of a row-sharded session: with a communicator the library's own
+        entry point (no host callback in the data path), otherwise a ctypes callback into `allreduce_dev`"""
+        if self.comm is not None:
+            return self.comm.reducer()
+        import traceback
+
+        from . import _lib
+
+        def cb(_user, dev_ptr, count, dtype):
+            try:
+                self.allreduce_dev(ctx, dev_ptr, count, dtype)
+                return 0
+            except Exception:  # never let an exception cross the C ABI
+                traceback.print_exc()
+                return 1
+
+        return _lib.ALLREDUCE_FN(cb), None
 
     # -- one-to-all copies for the spread initial phase (api.sclens, world > 1)
     def bcast_host(self, arr: np.ndarray, src: int) -> np.ndarray:
         """float64 host array of the same shape on every rank; returns rank `src`'s content"""
         arr = np.ascontiguousarray(arr, dtype=np.float64)
+        if self.comm is not None:
+            return self.comm.broadcast_host(arr, src)
         if self.world == 1:
             return arr
         import torch
         import torch.distributed as dist
 
         t = torch.from_numpy(arr.copy())
-        if self.device is not None:
-            t = t.to(self.device)
         dist.broadcast(t, src=src)
-        return t.cpu().numpy()
+        return t.numpy()
 
-    def bcast_dev(self, ctx, dev_ptr: int, count_f32: int, src: int, _force: bool = False):
+    def bcast_dev(self, ctx, dev_ptr: int, count_f32: int, src: int):
         """`count_f32` floats at a raw device pointer (allocated on every rank), from rank `src` to all, in place"""
-        if (self.world == 1 and not _force) or count_f32 == 0:
+        if count_f32 == 0:
+            return
+        if self.comm is not None:
+            ctx.sync()
+            self.comm.broadcast(dev_ptr, 4 * int(count_f32), src)
+            return
+        if self.world == 1:
             return
         import torch
         import torch.distributed as dist
 
-        if self.device is None:  # gloo (tests): through host memory
-            h = np.empty(int(count_f32), dtype=np.float32)
-            if self.rank == src:
-                ctx.d2h(h, dev_ptr)
-            t = torch.from_numpy(h)
-            dist.broadcast(t, src=src)
-            if self.rank != src:
-                ctx.h2d(dev_ptr, h)
-            return
-
-        t, back = self._dev_tensor(ctx, dev_ptr, count_f32, 1)
+        h = np.empty(int(count_f32), dtype=np.float32)
+        if self.rank == src:
+            ctx.d2h(h, dev_ptr)
+        t = torch.from_numpy(h)
         dist.broadcast(t, src=src)
-        torch.cuda.synchronize(self.device)
-        if self.rank != src or _force:
-            back()
+        if self.rank != src:
+            ctx.h2d(dev_ptr, h)
 
     def agree(self, arr: np.ndarray) -> np.ndarray:
         """rank 0's copy of a small host array on every rank (decisions must not diverge by a rounding bit)"""
         return self.allgather_small(arr)[0]
 
     def barrier(self):
-        if self.world > 1:
+        if self.comm is not None:
+            self.comm.allgather_host(np.zeros(1))
+        elif self.world > 1:
             import torch.distributed as dist
 
             dist.barrier()

@@ -14,7 +14,16 @@ import numpy as np
 
 from sclens_amd import _lib, api
 from sclens_amd.atlas import row_block
-from sclens_amd.shard import raw_device_tensor
+
+
+def raw_device_tensor(dev_ptr, count, typestr, device):
+    """zero-copy torch view of library-owned device memory (`__cuda_array_interface__`); this script only"""
+
+    class _Raw:
+        __cuda_array_interface__ = {"shape": (int(count),), "typestr": typestr, "data": (int(dev_ptr), False), "version": 3}
+
+    return torch.as_tensor(_Raw(), device=device)
+
 from sclens_amd.synth import synth_counts_rows
 
 N_total = int(sys.argv[1]) if len(sys.argv) > 1 else 1_000_000

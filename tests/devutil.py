@@ -54,7 +54,7 @@ class ThreadShard:
             self.bytes = 0
 
     def __init__(self, group, rank):
-        self.g, self.rank, self.world, self.device = group, rank, group.world, None
+        self.g, self.rank, self.world, self.comm = group, rank, group.world, None
 
     def _exchange(self, value):
         self.g.slots[self.rank] = value
@@ -100,8 +100,18 @@ class ThreadShard:
         ctx.d2h(h, send_ptr)
         ctx.h2d(recv_ptr, np.concatenate(self._exchange(h)))
 
-    def allgather_blocks(self, local):
-        import torch
+    def reducer(self, ctx):
+        """(sclens_hip_allreduce_fn, user) of a row-sharded session, as Shard.reducer on the host-staged transport"""
+        from sclens_amd import _lib
 
-        return torch.stack([t.to(local.device) for t in self._exchange(local.detach().clone())])
+        def cb(_user, dev_ptr, count, dtype):
+            try:
+                self.allreduce_dev(ctx, dev_ptr, count, dtype)
+                return 0
+            except Exception:
+                import traceback
 
+                traceback.print_exc()
+                return 1
+
+        return _lib.ALLREDUCE_FN(cb), None

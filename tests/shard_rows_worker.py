@@ -3,8 +3,8 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29541 \
         tests/shard_rows_worker.py [--backend gloo|nccl] [--out result.json]
 
-gloo: the ranks may share one GPU (the all-reduce is staged through host memory); nccl: one GPU per rank, RCCL on the
-device buffers. Every rank builds the same synthetic matrix and draws, takes its block of cells, runs
+gloo: the ranks may share one GPU (the all-reduce is staged through host memory); nccl: one GPU per rank, the library's own
+RCCL communicator on its device buffers. Every rank builds the same synthetic matrix and draws, takes its block of cells, runs
 atlas.sclens_row_sharded; rank 0 also runs the unsharded api.sclens and compares (same checks as tests/test_gpu_atlas.py)."""
 import argparse
 import json
@@ -37,8 +37,8 @@ def main():
     dev_id = local_rank if args.backend == "nccl" else min(local_rank, torch.cuda.device_count() - 1)
     torch.cuda.set_device(dev_id)
     dist.init_process_group(backend=args.backend, rank=rank, world_size=world)
-    shard = Shard(rank, world, torch.device("cuda", dev_id) if args.backend == "nccl" else None)
     ctx = Context(dev_id)
+    shard = Shard.create(ctx, rank, world, backend=args.backend)
     N, M = args.cells, args.genes
     X = api._csc_f32(synth_counts(N, M, seed=2, C=5, marker_frac=0.2, marker_sd=1.5))
     d = api.make_draws_native(X, seed=41)
@@ -63,6 +63,7 @@ def main():
             with open(args.out, "w") as fh:
                 json.dump(info, fh)
     dist.barrier()
+    shard.close()
     dist.destroy_process_group()
     ctx.close()
     sys.exit(0 if ok else 1)

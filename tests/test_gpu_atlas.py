@@ -107,74 +107,50 @@ def test_row_sharded_device_sampler_and_errors(ctx):
     assert rc == 1
 
 
-def test_rccl_branch_on_a_one_rank_group(ctx):
-    """The `nccl` (= RCCL) branches of Shard.allreduce_dev / bcast_dev / allgather_blocks cannot meet a second rank on a
-    one-GPU box, but everything else about them can be checked in a one-rank group: the zero-copy torch view of
-    library-owned device memory (`__cuda_array_interface__` on PyTorch-ROCm), an RCCL collective running on that view,
-    and the result landing in the library's buffer."""
-    import os
-
-    import torch
-    import torch.distributed as dist
-
+def test_library_rccl_communicator_one_rank(ctx):
+    """The RCCL calls the library makes itself (csrc/comm.hip) cannot meet a second rank on a one-GPU box, but everything else
+    about them can be checked with a one-rank communicator: librccl opens, ncclCommInitRank from a shipped unique id,
+    RCCL reports one rank, every collective runs on library-owned buffers and leaves the expected content, and a row-sharded
+    session whose reducer is the library's own entry point (no host callback) reproduces the unsharded result."""
     from devutil import DevArray
-    from sclens_amd.shard import Shard, raw_device_tensor
+    from sclens_amd.shard import Shard
 
-    dev = torch.device("cuda", ctx.device)
-    x64 = np.arange(1000, dtype=np.float64) * 0.5 - 3.0
-    x32 = np.linspace(-1, 1, 777).astype(np.float32)
-    d64, d32 = DevArray(ctx, x64), DevArray(ctx, x32)
-    # the view aliases the library's memory: a torch write is visible through the C ABI
-    t = raw_device_tensor(d32.p, x32.size, "<f4", dev)
-    assert t.dtype == torch.float32 and t.is_cuda and np.array_equal(t.cpu().numpy(), x32)
-    t.mul_(2.0)
-    torch.cuda.synchronize()
-    assert np.array_equal(d32.get(x32.shape, np.float32), 2 * x32)
-    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-    os.environ.setdefault("MASTER_PORT", "29591")
-    created = not dist.is_initialized()
-    if created:
-        dist.init_process_group(backend="nccl", rank=0, world_size=1, device_id=dev)
+    sh = Shard.create(ctx, 0, 1, backend="nccl", force_comm=True)
     try:
-        for mode in ("host", "device", "zero_copy"):  # host-staged (default), torch staging tensor, view of the library's buffer
-            sh = Shard(0, 1, dev, zero_copy=(mode == "zero_copy"), staging=mode)
-            assert sh.staging == mode
-            sh.allreduce_dev(ctx, d64.p, x64.size, 0, _force=True)  # sum over one rank: unchanged, but through RCCL
-            sh.allreduce_dev(ctx, d32.p, x32.size, 1, _force=True)
-            sh.bcast_dev(ctx, d32.p, x32.size, 0, _force=True)
-            assert np.array_equal(d64.get(x64.shape, np.float64), x64)
-            assert np.array_equal(d32.get(x32.shape, np.float32), 2 * x32)
-        # the start-up check of a multi-rank job (here: a group of one, world forced to 2 ranks' worth of logic)
-        sh = Shard(0, 1, dev)
-        sh.world = 2  # run the checks; the all-reduce over the real one-rank group returns the input
+        assert sh.comm is not None
+        info = sh.describe()
+        assert info["rccl_ranks"] == 1 and info["rccl_version"] > 0 and info["transport"].startswith("rccl")
+        assert sh.selfcheck(ctx)["selfcheck"] == "ok"
+        x64 = np.arange(1000, dtype=np.float64) * 0.5 - 3.0
+        x32 = np.linspace(-1, 1, 777).astype(np.float32)
+        d64, d32 = DevArray(ctx, x64), DevArray(ctx, x32)
+        recv = DevArray(ctx, nbytes=x32.nbytes)
         try:
-            sh.selfcheck(ctx)
-        except RuntimeError as e:  # expected: the sum over ONE rank is not the two-rank value
-            assert "all-reduce gave" in str(e)
-        sh.world = 1
-        # allgather_dev through RCCL in a one-rank group, every staging mode
-        for mode in ("host", "device"):
-            sh = Shard(0, 1, dev, staging=mode)
-            sh.world = 1
-            recv = DevArray(ctx, nbytes=4 * x32.size)
-            sh.world = 2  # take the collective branch; the group still has one rank, so only the first block is written
-            try:
-                import torch.distributed as _d
-
-                t_, _ = sh._dev_tensor(ctx, d32.p, x32.size, 1)
-                out_ = torch.empty(x32.size, dtype=torch.float32, device=dev)
-                _d.all_gather_into_tensor(out_, t_)
-                torch.cuda.synchronize()
-                assert np.array_equal(out_.cpu().numpy(), 2 * x32)
-            finally:
-                sh.world = 1
-            recv.free()
-        blocks = torch.arange(24, dtype=torch.float32, device=dev).reshape(2, 3, 4)
-        out = torch.empty((1,) + tuple(blocks.shape), dtype=blocks.dtype, device=dev)
-        dist.all_gather_into_tensor(out.view(-1), blocks.contiguous().view(-1))  # what allgather_blocks issues
-        assert torch.equal(out[0], blocks)
+            sh.allreduce_dev(ctx, d64.p, x64.size, 0)  # sum over one rank: unchanged, but through ncclAllReduce
+            sh.allreduce_dev(ctx, d32.p, x32.size, 1)
+            sh.bcast_dev(ctx, d32.p, x32.size, 0)
+            sh.allgather_dev(ctx, d32.p, recv.p, x32.size)
+            assert np.array_equal(d64.get(x64.shape, np.float64), x64)
+            assert np.array_equal(d32.get(x32.shape, np.float32), x32)
+            assert np.array_equal(recv.get(x32.shape, np.float32), x32)
+        finally:
+            d64.free(), d32.free(), recv.free()
+        got = sh.allgather_small(np.array([1.5, np.nan, -2.0]))
+        assert got.shape == (1, 3) and got[0, 0] == 1.5 and np.isnan(got[0, 1])
+        assert np.array_equal(sh.bcast_host(np.array([4.0, 5.0]), 0), [4.0, 5.0])
+        sh.barrier()
+        st = sh.comm.stats()
+        assert st["calls"] >= 8 and st["bytes"] > x64.nbytes
+        # row-sharded session reducing through the communicator: one block = the whole matrix
+        N, M = 600, 250
+        X = synth_counts(N, M, seed=2, C=5, marker_frac=0.2, marker_sd=1.5)
+        d = api.make_draws_native(X, seed=41, host_sampler=True)
+        fn, user = sh.reducer(ctx)
+        assert user is not None  # the communicator handle, not a Python callback
+        calls0 = sh.comm.stats()["calls"]
+        res = atlas.sclens_row_sharded(api._csc_f32(X), 0, N, d, sh, n_perturb=4, max_search_iters=5, ctx=ctx)
+        assert sh.comm.stats()["calls"] > calls0 + 20
+        ref = api.sclens(X, draws=d, n_perturb=4, max_search_iters=5, ctx=ctx, streams=1)
+        _compare(res, ref)
     finally:
-        if created:
-            dist.destroy_process_group()
-        d64.free()
-        d32.free()
+        sh.close()

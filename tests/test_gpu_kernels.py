@@ -153,42 +153,3 @@ def _sytrd_on(c, A, n, lda):
     for x in (dA, dd, de, dt):
         x.free()
     return out
-
-
-@pytest.mark.parametrize("n,members,leavers", [(515, 3, 0), (300, 2, 0), (700, 5, 0), (400, 3, 1)])
-def test_batched_sytrd_is_bitwise_the_solo_result(ctx, n, members, leavers):
-    """Contexts attached to one batch group run their tridiagonalisations in shared launches (blockIdx.z = member);
-    every member must reproduce its solo run bit for bit, also when an expected participant leaves the round."""
-    from concurrent.futures import ThreadPoolExecutor
-
-    from sclens_amd._lib import BatchGroup, Context
-
-    lda = rup(n, 32)
-    mats = [_sym(n, 77 + 13 * b) for b in range(members)]
-    solo = [_sytrd_on(ctx, A, n, lda) for A in mats]
-    ctxs = [Context(ctx.device) for _ in range(members)]
-    group = BatchGroup()
-    try:
-        for c in ctxs:
-            c.set_batch(group)
-        group.expect(members + leavers)
-
-        def job(b):
-            if b >= members:
-                group.leave()
-                return None
-            return _sytrd_on(ctxs[b], mats[b], n, lda)
-
-        with ThreadPoolExecutor(max_workers=members + leavers) as pool:
-            outs = list(pool.map(job, range(members + leavers)))
-        for b in range(members):
-            for got, want in zip(outs[b], solo[b]):
-                assert np.array_equal(got, want)
-        # the group is idle again: an unannounced call runs solo
-        again = _sytrd_on(ctxs[0], mats[0], n, lda)
-        assert all(np.array_equal(g, w) for g, w in zip(again, solo[0]))
-    finally:
-        for c in ctxs:
-            c.set_batch(None)
-            c.close()
-        group.close()

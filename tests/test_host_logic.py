@@ -196,3 +196,46 @@ def test_search_schedule_is_unbounded_and_matches_repeated_subtraction():
         if stopped:
             p_ = p_fin
     assert (p_, it) == (p_ref, it_ref) and it_ref > 450
+
+
+def test_host_side_under_address_and_ub_sanitizers():
+    """SURVEY section 5 (race / memory checking of the native side): stats.cpp, rng.cpp and the host pattern builder are
+    compiled with -fsanitize=address,undefined (`make asan`) and driven over their C entry points, error paths included."""
+    import subprocess
+
+    csrc = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "sclens_amd", "csrc")
+    subprocess.check_call(["make", "-C", csrc, "asan"], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    env = dict(os.environ, ASAN_OPTIONS="detect_leaks=1:abort_on_error=0", UBSAN_OPTIONS="halt_on_error=1")
+    r = subprocess.run([os.path.join(csrc, "host_selftest_asan")], capture_output=True, text=True, env=env, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "host selftest ok" in r.stdout
+
+
+def test_guard_band_cut_stays_contiguous():
+    """refined eigenvalues of a near-degenerate pair may swap; the cut must be taken from the top so that the
+    k values returned belong to the k eigenvectors signal_vectors(k) returns."""
+    from sclens_amd.api import cut_with_guard_band
+
+    L = np.array([0.1, 0.5, 1.0, 1.00001, 1.00002, 3.0, 9.0])
+    lam = 1.000012
+    # no refinement requested
+    Lo, k, nL, g = cut_with_guard_band(L, lam, 0.0, lambda lo, hi: 1 / 0)
+    assert k == 3 and np.array_equal(nL, [9.0, 3.0, 1.00002]) and g["refined"] == []
+    # band covers indices 2..4; the refined values of 3 and 4 swap sides of the threshold
+    band_units = 2e-5 / (np.sqrt(len(L)) * 5.96e-8 * L[-1])
+    calls = []
+
+    def refine(lo, hi):
+        calls.append((lo, hi))
+        return np.array([1.0, 1.000015, 1.000011])[: hi - lo]
+
+    Lo, k, nL, g = cut_with_guard_band(L, lam, band_units, refine)
+    assert calls == [(2, 5)]
+    assert k == 2 and np.array_equal(nL, [9.0, 3.0])  # index 4 fell below: the cut stops there although index 3 is above
+    assert not g["monotone"] and np.all(np.diff(Lo) >= 0) and len(g["refined"]) == 3
+    # monotone refinement: values are substituted in place
+    Lo, k, nL, g = cut_with_guard_band(L, lam, band_units, lambda lo, hi: np.array([1.0, 1.000011, 1.000013]))
+    assert k == 3 and g["monotone"] and nL[2] == 1.000013 and Lo[3] == 1.000011
+    # everything above / below
+    assert cut_with_guard_band(L, 0.0, 0.0, None)[1] == len(L)
+    assert cut_with_guard_band(L, 100.0, 0.0, None)[1] == 0
