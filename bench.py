@@ -20,13 +20,17 @@ warm-up / timed steps as fit. The JSON line reports the TRUE counts in `steps` /
 `steps_requested` / `warmup_requested`.
 
 Prints ONE JSON line on rank 0 (contract in the task statement) with two extra objects:
-  roofline     : the dominant kernel of the workload, measured live with HIP events on the library's own stream.
-                 n >= 16 000 (two-stage eigensolver): the fp32 MFMA contraction `gemm_nt_big` on the Gram product,
-                 achieved = n (n + 1) K flop / duration against 157.3 TF/s; otherwise `trd_colB` (HBM-bound symmetric
-                 matrix-vector product of the one-stage tridiagonalisation), achieved = lower-triangle bytes / duration
-                 against 8 TB/s. `stages` holds the same ratio for every stage of one decomposition.
-  cpu_baseline : the oracle (float64 NumPy/SciPy port of the reference CPU path) timed on the host cores on a
-                 bounded sample, stage-extrapolated to the workload (see `sample`).
+  roofline     : the STAGE that owns the wall clock, measured live with HIP events on the library's own stream.
+                 n >= 8 192: the two-stage symmetric eigensolver of one sparsity-search step (dense -> band -> tridiagonal,
+                 eigenvalues, inverse iteration, both back-transformations of n/2 vectors): achieved = the algorithmic
+                 4/3 n^3 + 2 n^2 (n/2) flop of SURVEY 8(d) / the sum of its stage times, against 157.3 TF/s (fp32 MFMA) --
+                 the time-weighted rate of everything that replaces `syevd!`, not of its best kernel. Otherwise `trd_colB`
+                 (HBM-bound symmetric matrix-vector product of the one-stage tridiagonalisation) against 8 TB/s.
+                 `stages` holds the same ratio for every stage of one decomposition, the Gram launch included.
+  cpu_baseline : the oracle (float64 NumPy/SciPy port of the reference CPU path) timed on the host cores on two bounded
+                 samples (the exponent of the eigensolver's cost is fitted, not assumed), stage-extrapolated to the workload.
+  extra.strict_fp32 : one further step with the fp16-MFMA products of the sparsity search switched off (SCLENS_HIP_GRAM_BITS=0),
+                 so that the fp16-assisted and the strict fp32 wall-clock are both timed by the same run.
 """
 import argparse
 import json
@@ -160,10 +164,17 @@ def stage_probe(ctx, X, N, M):
     return stages
 
 
+# A full-size CPU data point kept in the repository (profiles/r02_signal_count_cfg4.json, GPU box, 16 usable CPUs): LAPACK dsyevd,
+# VALUES ONLY, of ONE float64 30 000 x 30 000 Gram matrix took 903.1 s, the float64 Gram product (dsyrk) 110.0 s. The reference
+# computes all eigenVECTORS of 3 + S + P such matrices (scLENS.jl:384), which costs more than values only.
+CPU_FULL_SIZE_POINT = {"n": 30000, "dsyevd_values_only_s": 903.1, "dsyrk_100000x30000_s": 110.0, "cores": 16,
+                       "source": "profiles/r02_signal_count_cfg4.json"}
+
+
 def cpu_baseline(N, M, n_search, n_perturb, budget_s):
-    """Oracle (port of the reference CPU path) on the host cores: every stage timed once on a bounded sample and
-    scaled to the workload by its complexity, times the call counts observed in the GPU run. The sample is the workload's
-    own n when one dsyevr of that order fits the budget (cfg2), else the largest order that does."""
+    """Oracle (port of the reference CPU path) on the host cores: normalise, Gram and dsyevr (all vectors) timed at TWO sample
+    orders; the eigensolver's cost exponent is fitted from the two (clamped to [2.5, 3.2]) instead of assuming n^3, the other
+    stages scale exactly (N M, n^2 K). Everything is multiplied by the call counts the GPU run observed."""
     from oracle import sclens_oracle as O  # checker / baseline only
     from sclens_amd.synth import synth_counts
 
@@ -175,35 +186,55 @@ def cpu_baseline(N, M, n_search, n_perturb, budget_s):
         threadpool_limits(limits=cores)
     except Exception:
         pass
-    # dsyevr with vectors: measured 7 s at n = 4000 on this box's 16-CPU quota; pick the largest n_s whose n^3 estimate fits a
-    # third of the budget
+    # dsyevr with vectors: ~7 s at n = 4000 on a 16-CPU quota. Larger sample: its n^3 estimate fits ~45 % of the budget;
+    # smaller sample: 0.6 x that order (0.22 of the time)
     est = lambda q: 1.1e-10 * q ** 3 * max(1.0, 16.0 / cores) + 0.5
-    ns = n
-    while ns > 1500 and est(ns) > budget_s / 3:
-        ns = int(ns * 0.85)
-    ns = min(n, max(1500, ns))
-    Ns, Ms = (ns, int(ns * M / N)) if N <= M else (int(ns * N / M), ns)
-    if N > M:  # keep the sample's contraction length affordable: the Gram scales exactly with K
-        Ns = min(Ns, 4 * ns)
-    Xs = synth_counts(Ns, Ms, seed=11)
-    t0 = time.perf_counter()
-    S = O.logn_scale(O.pre_scale(Xs))
-    t_scale = time.perf_counter() - t0
-    t0 = time.perf_counter()
-    Y = O.wishart_matrix(S, 2 if Ns > Ms else 1)
-    t_gram = time.perf_counter() - t0
-    t0 = time.perf_counter()
-    O.get_eigen(Y)
-    t_eig = time.perf_counter() - t0
+    n_hi = n
+    while n_hi > 1500 and est(n_hi) > 0.45 * budget_s:
+        n_hi = int(n_hi * 0.9)
+    n_hi = min(n, max(1500, n_hi))
+    orders = [n_hi] if n_hi == n else [max(1000, int(0.6 * n_hi)), n_hi]
+    samples = []
+    for ns in orders:
+        Ns, Ms = (ns, int(ns * M / N)) if N <= M else (int(ns * N / M), ns)
+        if N > M:  # keep the sample's contraction length affordable: the Gram scales exactly with K
+            Ns = min(Ns, 4 * ns)
+        Xs = synth_counts(Ns, Ms, seed=11)
+        t0 = time.perf_counter()
+        S = O.logn_scale(O.pre_scale(Xs))
+        t_scale = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        Y = O.wishart_matrix(S, 2 if Ns > Ms else 1)
+        t_gram = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        O.get_eigen(Y)
+        t_eig = time.perf_counter() - t0
+        samples.append({"Ns": Ns, "Ms": Ms, "n": min(Ns, Ms), "scale_s": round(t_scale, 3), "gram_s": round(t_gram, 3),
+                        "dsyevr_s": round(t_eig, 3)})
+    hi = samples[-1]
+    if len(samples) == 2 and samples[0]["dsyevr_s"] > 0.05:
+        p_fit = float(np.log(hi["dsyevr_s"] / samples[0]["dsyevr_s"]) / np.log(hi["n"] / samples[0]["n"]))
+    else:
+        p_fit = 3.0
+    p_use = min(3.2, max(2.5, p_fit))
     calls = 3 + n_search + n_perturb
-    f3 = (n / ns) ** 3
-    T = calls * (t_scale * (N * M) / (Ns * Ms) + t_gram * (n * n * K) / (ns * ns * max(Ns, Ms)) + t_eig * f3)
-    T += n_search * t_gram * (n ** 3) / (ns * ns * max(Ns, Ms))  # corr_mat (scLENS.jl:742): ~n^3 flop per iteration
-    return {"value": round(N * M / T, 1), "unit": "cells*genes/s", "cores": cores, "kind": "port",
-            "wall_s_extrapolated": round(T, 1), "eig_extrapolation_factor_n3": round(f3, 2),
-            "sample": (f"oracle normalise+Gram+dsyevr timed once at {Ns}x{Ms} ({t_scale:.2f}s, {t_gram:.2f}s, {t_eig:.2f}s), "
-                       f"scaled by NM, n^2K and n^3 (x{f3:.1f}) to {N}x{M}, times {calls} decompositions (S={n_search}, "
-                       f"P={n_perturb}) + {n_search} corr GEMMs; BLAS threads = {cores} = the CPUs this process may use (cgroup quota; {os.cpu_count()} visible)")}
+    f_eig = (n / hi["n"]) ** p_use
+    t_eig_full = hi["dsyevr_s"] * f_eig
+    T = calls * (hi["scale_s"] * (N * M) / (hi["Ns"] * hi["Ms"]) + hi["gram_s"] * (n * n * K) / (hi["n"] ** 2 * max(hi["Ns"], hi["Ms"])) + t_eig_full)
+    T += n_search * hi["gram_s"] * (n ** 3) / (hi["n"] ** 2 * max(hi["Ns"], hi["Ms"]))  # corr_mat (scLENS.jl:742): ~n^3 flop per iteration
+    out = {"value": round(N * M / T, 1), "unit": "cells*genes/s", "cores": cores, "kind": "port",
+           "wall_s_extrapolated": round(T, 1), "eig_exponent_fitted": round(p_fit, 3), "eig_exponent_used": round(p_use, 3),
+           "eig_all_vectors_s_extrapolated": round(t_eig_full, 1), "samples": samples,
+           "sample": (f"oracle normalise+Gram+dsyevr (all vectors) timed at {' and '.join(str(q['Ns']) + 'x' + str(q['Ms']) for q in samples)} "
+                      f"(dsyevr {', '.join(str(q['dsyevr_s']) + ' s' for q in samples)}: exponent {p_fit:.2f} fitted, {p_use:.2f} used); "
+                      f"scaled by NM, n^2K and n^{p_use:.2f} (x{f_eig:.1f}) to {N}x{M}, times {calls} decompositions (S={n_search}, "
+                      f"P={n_perturb}) + {n_search} corr GEMMs; BLAS threads = {cores} = the CPUs this process may use "
+                      f"(cgroup quota; {os.cpu_count()} visible)")}
+    if n == CPU_FULL_SIZE_POINT["n"]:
+        out["full_size_point"] = dict(CPU_FULL_SIZE_POINT, note=(
+            f"measured once at full size: dsyevd VALUES ONLY {CPU_FULL_SIZE_POINT['dsyevd_values_only_s']} s per matrix against "
+            f"{t_eig_full:.0f} s extrapolated here for dsyevr with ALL vectors; {calls} such decompositions per call"))
+    return out
 
 
 def usable_cpus():
@@ -249,6 +280,8 @@ def main():
                          "all-reduced (SURVEY 8e-iii, sclens_amd/atlas.py) instead of distributing whole decompositions")
     ap.add_argument("--streams", type=int, default=None,
                     help="concurrent decompositions per GPU (worker sessions on own HIP streams); default: 3 below n = 16 000, else 2")
+    ap.add_argument("--strict-fp32", default="auto", choices=["auto", "on", "off"],
+                    help="one further timed step with SCLENS_HIP_GRAM_BITS=0 reported as extra.strict_fp32 (auto: for n >= 16 000)")
     ap.add_argument("--extra-configs", default="", help="comma-separated further configs timed once each after the main one (reported under `extra`)")
     ap.add_argument("--verbose", action="store_true")
     ap.add_argument("--stage-timing", action="store_true", help="per-stage HIP-event totals on stderr (adds syncs)")
@@ -313,7 +346,8 @@ def main():
                 print(f"[bench] synthetic matrix not cached ({e})", file=sys.stderr)
         return X
 
-    def run_config(cfg, steps_req, warm_req, deadline):
+    def run_config(cfg, steps_req, warm_req, deadline, tail_steps=0.0):
+        """tail_steps: keep this many step durations of the budget free for what follows (the strict-fp32 step)"""
         N, M, cfg_index = CONFIGS[cfg]
         t0 = time.perf_counter()
         X = api._csc_f32(cached_counts(cfg, N, M, 20240427 + cfg_index))  # SURVEY 8(d): PCG64(20240427 + config_index)
@@ -356,7 +390,7 @@ def main():
         n_steps = 0
         t0 = time.perf_counter()
         for s in range(steps_req):
-            if s > 0 and agree(time.perf_counter() + 1.1 * t_step > deadline):
+            if s > 0 and agree(time.perf_counter() + (1.1 + tail_steps) * t_step > deadline):
                 break
             ts = time.perf_counter()
             res = one_step(s)
@@ -364,12 +398,8 @@ def main():
             n_steps += 1
         fence()
         dt = time.perf_counter() - t0
-        if world > 1:
-            import torch.distributed as dist
-
-            tt = torch.tensor([dt], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
-            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-            dt = float(tt.item())
+        if world > 1:  # MAX over the ranks (through the library's communicator when there is one)
+            dt = float(shard.allgather_small(np.array([dt])).max())
         return {"N": N, "M": M, "X": X, "res": res, "dt": dt, "steps": n_steps, "warmup": n_warm, "synth_s": t_synth,
                 "row_shard": row_shard, "draws_s": one_step.draws_s}
 
@@ -378,7 +408,8 @@ def main():
     deadline = T_PROCESS_START + args.budget_s
     # reserve for what follows the timed region: roofline probe, CPU baseline sample, extra configs
     reserve = (0 if args.no_roofline else 25) + (0 if args.no_cpu_baseline else 45)
-    main_r = run_config(args.config, args.steps, args.warmup, deadline - reserve)
+    strict_planned = args.strict_fp32 == "on" or (args.strict_fp32 == "auto" and min(CONFIGS[args.config][:2]) >= 16000 and not args.row_shard)
+    main_r = run_config(args.config, args.steps, args.warmup, deadline - reserve, tail_steps=1.6 if strict_planned else 0.0)
     N, M, X, res, dt = main_r["N"], main_r["M"], main_r["X"], main_r["res"], main_r["dt"]
     steps = main_r["steps"]
 
@@ -416,8 +447,28 @@ def main():
                          "ensemble_partial_eig": {"used": int(res["partial_eig"][0]), "fallback_to_full": int(res["partial_eig"][1])},
                          "phase_s_rank0_last_step": dict({"draws_host": round(main_r["draws_s"], 4)}, **res.get("phase_s", {}))},
         }
-    # ---- extra configs (one timed step each), while the budget lasts
+    # ---- strict fp32: one more step with the fp16-MFMA products of the sparsity search switched off, while the budget lasts
     extra = {}
+    n_min = min(N, M)
+    want_strict = args.strict_fp32 == "on" or (args.strict_fp32 == "auto" and n_min >= 16000 and not main_r["row_shard"])
+    if want_strict and steps > 0 and not agree(time.perf_counter() + 1.4 * dt / max(1, steps) > deadline - reserve):
+        old_env = os.environ.get("SCLENS_HIP_GRAM_BITS")
+        os.environ["SCLENS_HIP_GRAM_BITS"] = "0"  # worker contexts created inside sclens() read it
+        ctx.set_option("gram_bits", 0)
+        try:
+            r = run_config(args.config, 1, 0, deadline - reserve)
+        finally:
+            ctx.set_option("gram_bits", -1)
+            if old_env is None:
+                os.environ.pop("SCLENS_HIP_GRAM_BITS", None)
+            else:
+                os.environ["SCLENS_HIP_GRAM_BITS"] = old_env
+        if rank == 0:
+            extra["strict_fp32"] = {"sclens_wall_s": round(r["dt"], 3), "value": round(r["N"] * r["M"] / r["dt"], 1),
+                                    "search_iters": int(r["res"]["n_search"]), "signals": int(len(r["res"].get("signal_ev", []))),
+                                    "p_": r["res"]["p_"], "gram_bits_used": int(r["res"].get("gram_bits_used", -1)),
+                                    "note": "SCLENS_HIP_GRAM_BITS=0: every Gram product and the search statistic on the fp32 MFMA"}
+    # ---- extra configs (one timed step each), while the budget lasts
     for cfg in [c for c in args.extra_configs.split(",") if c]:
         if agree(time.perf_counter() + 60 > deadline - reserve):
             break
@@ -431,19 +482,23 @@ def main():
         n = min(N, M)
         if not args.no_roofline:
             stages = stage_probe(ctx, X, N, M)
-            if "sy2sb_dense_to_band" in stages:  # two-stage solver: the MFMA contraction dominates
-                g = stages["gram"]
-                # HBM bytes per launch: not measured in this run -- rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes on the same
-                # kernel, shape and tile order (profiles/r02_pmc_gemm: 268.1e6 KB fetched, doubled as MI355X_MICROARCH.md
-                # prescribes for gfx950, + 3.52e6 KB written), quoted only for the workload they were taken on
-                traffic = 2 * 268.089e9 + 3.516e9 if (n == 30000 and max(N, M) == 100000) else None
-                bm = (n + 255) // 256
-                gram_kernel = "gemm_nt_big<2,4,4,2>" if bm * (bm + 1) // 2 >= 1500 else "gemm_kernel<NT> 128x128"
-                out["roofline"] = {"bound": "mfma", "kernel": gram_kernel + " (Gram product)", "achieved": g["achieved"],
-                                   "peak": MFMA_F32_PEAK_TFS, "unit": "TFLOP/s", "frac": g["frac"], "traffic": traffic,
-                                   "traffic_source": "constant from profiles/r02_pmc_gemm (separate --pmc passes), not measured in this run",
-                                   "n": n, "K": max(N, M), "launch_ms": g["ms"],
-                                   "algorithmic_flop_per_launch": float(n) * (n + 1) * max(N, M)}
+            if "sy2sb_dense_to_band" in stages:
+                # two-stage solver: ONE search step's eigensolve (n/2 vectors) is the stage with the most wall time (S of them per
+                # call, each ~85 % of its step). Algorithmic work: SURVEY 8(d) `F_eig(bottom n/2) = 4/3 n^3 + 2 n^2 (n/2)`; the
+                # denominator is the sum of the HIP-event times of every stage that replaces `syevd!` (scLENS.jl:377).
+                parts = ["sy2sb_dense_to_band", "sb2st_bulge_chasing", "stebz", "stein", "q2_back_transform", "q1_back_transform"]
+                solve_ms = sum(stages[k]["ms"] for k in parts if k in stages)
+                flop = 4.0 / 3.0 * float(n) ** 3 + 2.0 * float(n) ** 2 * (n // 2)
+                ach = flop / (solve_ms * 1e-3) / 1e12
+                out["roofline"] = {"bound": "mfma", "kernel": "two-stage symmetric eigensolver of one search step (sy2sb + sb2st + stebz + "
+                                                             "stein + Q2 + Q1, n/2 eigenvectors): the stage with the most wall time",
+                                   "achieved": round(ach, 2), "peak": MFMA_F32_PEAK_TFS, "unit": "TFLOP/s",
+                                   "frac": round(ach / MFMA_F32_PEAK_TFS, 4), "traffic": None,
+                                   "traffic_source": "not measured in this run (PMC passes are separate rocprofv3 runs: profiles/)",
+                                   "n": n, "vectors": n // 2, "launch_ms": round(solve_ms, 2), "algorithmic_flop_per_launch": flop,
+                                   "stage_ms": {k: stages[k]["ms"] for k in parts if k in stages},
+                                   "note": "time-weighted rate of the whole stage; the single best kernel (the Gram launch) is "
+                                           "`stages.gram`"}
             else:
                 out["roofline"] = symv_probe(ctx, n)
             out["roofline"]["stages"] = stages

@@ -138,6 +138,12 @@ struct GemmArgs {
   // ask for the large-tile NT kernels (256 x 256, or 256 x 64 when N <= 64) even for a short K / fewer tiles: callers whose
   // product is bound by the C traffic or runs alone on the GPU (band reduction, back-transformations)
   int prefer_big = 0;
+  // C += P Q' with C loaded into the accumulators before the contraction (alpha == beta == 1 required): the large-tile kernels
+  // then read C while the first operand stage is in flight and their epilogue only stores. Ignored by the 128 x 128 kernel's
+  // arithmetic (it applies alpha / beta as usual: same result up to the order of the fp32 additions).
+  int acc_init = 0;
+  int dbg = 0;         // timing experiments only (SCLENS_HIP_GEMM_DBG): 1 no mirrored stores, 2 no direct stores, 4 no loads of C
+  int stagger_ns = 0;  // set by gemm_f32: period over which the first workgroups of the CUs are staggered (see gemm_nt_big)
 };
 int gemm_f32(Ctx* ctx, const GemmArgs& a);
 

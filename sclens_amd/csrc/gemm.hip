@@ -230,6 +230,22 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_big(GemmArgs a, const int2* __
     }
   }
   if (tl.x < 0) return;
+  // Phase stagger (a.stagger_ns > 0): a product with a short contraction and a read-modify-write of C has three phases per tile
+  // -- load C, multiply, store C -- and every workgroup has its CU to itself (128 KB of LDS), so all CUs start in step and STAY in
+  // step (equal tiles): the whole chip loads, then the whole chip multiplies with HBM idle, then the whole chip stores; the
+  // time per tile is the SUM of the HBM time and the MFMA time (rank-128 update at n' = 30 000: 77 us per tile against 27 us of
+  // MFMA and 44 us of HBM at the fair share). Delaying the first workgroup of each CU by a different fraction of the tile period
+  // spreads the phases, so that some CUs always use the memory system while the others multiply. Only the first wave of
+  // workgroups waits (those that find an idle CU: blockIdx < 256); their successors inherit the offsets.
+  if (a.stagger_ns > 0 && blockIdx.x < 256u && blockIdx.y == 0) {
+    const unsigned slot = (blockIdx.x >> 3) & 31u;  // blocks b, b + 8, ... share an XCD: spread each XCD's 32 CUs
+    const uint64_t wait_ticks = (uint64_t)a.stagger_ns * slot / 320u;  // s_memrealtime ticks at 100 MHz (10 ns); slot / 32 of the period
+    if (threadIdx.x == 0) {
+      const uint64_t t0 = __builtin_amdgcn_s_memrealtime();
+      while (__builtin_amdgcn_s_memrealtime() - t0 < wait_ticks) __builtin_amdgcn_s_sleep(8);
+    }
+    __syncthreads();
+  }
   const int64_t m0 = (int64_t)tl.x * Cfg::BM, n0 = (int64_t)tl.y * Cfg::BN;
   if (a.splits > 1) {
     const int64_t koff = (int64_t)blockIdx.y * a.k_chunk;
@@ -299,6 +315,24 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_big(GemmArgs a, const int2* __
     for (int j = 0; j < TN; ++j)
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+  // acc_init (alpha == beta == 1): C is loaded straight into the accumulators, all loads in flight together with the first
+  // operand stage, so the epilogue is stores only. Without it every 32 x 32 tile of the epilogue pays a memory round trip of
+  // its own (load 16, wait, store 16) with the matrix cores idle -- the workgroup is alone on its CU (128 KB of LDS).
+  const bool acc_init = a.acc_init != 0;
+  if (acc_init) {
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const int64_t col = n0 + wn * (32 * TN) + j * 32 + l31;
+        const int64_t row0 = m0 + wm * (32 * TM) + i * 32 + 4 * h;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const int64_t row = row0 + (e & 3) + 8 * (e >> 2);
+          if (row < a.M && col < a.N && (!a.lower || col <= row) && !(a.dbg & 4)) acc[i][j][e] = a.C[row * a.ldc + col];
+        }
+      }
+  }
 
   // fragment read offsets (floats) inside a stage: row r -> r * 32 + ((c ^ ((r >> 1) & 7)) << 2), c = 2 j8 + h
   int offA[TM], offB[TN], swA[TM], swB[TN];
@@ -378,7 +412,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_big(GemmArgs a, const int2* __
       f32x16 cin;
 #pragma unroll
       for (int e = 0; e < 16; ++e) cin[e] = 0.f;
-      if (a.beta != 0.f) {
+      if (a.beta != 0.f && !acc_init) {
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
           const int64_t row = row0 + (e & 3) + 8 * (e >> 2);
@@ -386,14 +420,18 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_big(GemmArgs a, const int2* __
         }
       }
       f32x16 outv;
+      if (acc_init) {
+        outv = acc[i][j];
+      } else {
 #pragma unroll
-      for (int e = 0; e < 16; ++e) outv[e] = a.alpha * acc[i][j][e] + a.beta * cin[e];
+        for (int e = 0; e < 16; ++e) outv[e] = a.alpha * acc[i][j][e] + a.beta * cin[e];
+      }
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
         const int64_t row = row0 + (e & 3) + 8 * (e >> 2);
-        if (row < a.M && col < a.N && (!a.lower || col <= row)) a.C[row * a.ldc + col] = outv[e];
+        if (row < a.M && col < a.N && (!a.lower || col <= row) && !(a.dbg & 2)) a.C[row * a.ldc + col] = outv[e];
       }
-      if (a.lower && col < a.N) {
+      if (a.lower && col < a.N && !(a.dbg & 1)) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
           const int64_t rowq = row0 + 8 * q;
@@ -444,8 +482,15 @@ int big_tile_list(Ctx* ctx, int64_t tm, int64_t tn, int lower, const int2** out,
   return SCLENS_OK;
 }
 
-int gemm_f32(Ctx* ctx, const GemmArgs& a) {
+int gemm_f32(Ctx* ctx, const GemmArgs& a_in) {
+  GemmArgs a = a_in;
   if (a.M <= 0 || a.N <= 0) return SCLENS_OK;
+  // C += P Q': the large-tile kernels start their accumulators from C (see acc_init in gemm_nt_big)
+  if (a.alpha == 1.f && a.beta == 1.f && !a.colabsmax && a.splits <= 1) a.acc_init = 1;
+  static const bool no_acc_init = getenv("SCLENS_HIP_NO_ACC_INIT") != nullptr;  // A/B measurements only
+  static const int dbg = getenv("SCLENS_HIP_GEMM_DBG") ? atoi(getenv("SCLENS_HIP_GEMM_DBG")) : 0;  // timing experiments: WRONG results
+  a.dbg = dbg;
+  if (no_acc_init) a.acc_init = 0;
   if (a.lower && a.M != a.N) return ctx->fail(SCLENS_ERR_ARG, "gemm_f32: lower needs M == N");
   const int64_t tm = (a.M + BM - 1) / BM, tn = (a.N + BN - 1) / BN;
   const int64_t ntiles = a.lower ? tm * (tm + 1) / 2 : tm * tn;
@@ -454,6 +499,8 @@ int gemm_f32(Ctx* ctx, const GemmArgs& a) {
                    (a.ldp % 4 == 0) && (a.ldq % 4 == 0);
   if (a.splits > 1 && (a.k_chunk <= 0 || a.k_chunk % 16 != 0 || a.colabsmax || a.beta != 0.f))
     return ctx->fail(SCLENS_ERR_ARG, "gemm_f32: bad split-K arguments");
+  if (a.acc_init && (a.alpha != 1.f || a.beta != 1.f || a.colabsmax || a.splits > 1))
+    return ctx->fail(SCLENS_ERR_ARG, "gemm_f32: acc_init needs alpha == beta == 1, no split, no colabsmax");
   // ---- large-tile NT kernels
   const bool force_big = getenv("SCLENS_HIP_GEMM_BIG") != nullptr;  // tests: the large-tile kernels on small shapes
   const bool big_ok = a.q_kcontig && vec && a.K >= GK && (a.splits <= 1 || a.k_chunk % GK == 0) && !getenv("SCLENS_HIP_GEMM_SMALL");
@@ -480,6 +527,14 @@ int gemm_f32(Ctx* ctx, const GemmArgs& a) {
     int64_t nb = ntb;
     if (want_list || (force_big && !a.prefer_big)) SCL_TRY(big_tile_list(ctx, bm, bn, a.lower, &tiles, &nb));
     SCL_TRY(ensure_dyn_lds(ctx, reinterpret_cast<const void*>(gemm_nt_big<2, 4, 4, 2>), 2 * Cfg::STAGE * (int)sizeof(float)));
+    // stagger the CUs' phases for read-modify-write products with a short contraction and at least four rounds of tiles
+    // (period ~ MFMA time of a tile, 0.21 us per unit of K at 2.4 GHz, + its HBM time); SCLENS_HIP_GEMM_STAGGER_PCT scales it
+    a.stagger_ns = 0;
+    if (a.beta != 0.f && a.K <= 1024 && nsl == 1 && nb >= 4 * 256) {
+      static const int pct = getenv("SCLENS_HIP_GEMM_STAGGER_PCT") ? atoi(getenv("SCLENS_HIP_GEMM_STAGGER_PCT")) : 100;
+      const double period_ns = 210.0 * (double)a.K + (a.lower ? 30000.0 : 20000.0);
+      a.stagger_ns = (int)(period_ns * pct / 100.0);
+    }
     hipLaunchKernelGGL((gemm_nt_big<2, 4, 4, 2>), dim3((unsigned)nb, (unsigned)nsl), dim3(512), 2 * Cfg::STAGE * sizeof(float),
                        ctx->stream, a, tiles, (int)bn);
     SCL_HIP(ctx, hipGetLastError());

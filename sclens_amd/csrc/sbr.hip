@@ -28,13 +28,56 @@ namespace scl {
 constexpr int SB = 64;
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-// sum of the partials in a fixed order: out[idx] = sum_p part[p][idx], idx < SB * SB (16 workgroups instead of a serial loop
-// inside the single-workgroup panel kernels)
+// Split-K factor of a product whose `tiles` output tiles (one workgroup each, one workgroup per CU) do not fill the 256 CUs:
+// the grid runs in ceil(tiles S / 256) rounds of K / S each, so the time goes like rounds(S) / S. (59 row tiles with S = 9 are
+// 531 workgroups = 3 rounds of K / 9; S = 13 gives 767 = 3 rounds of K / 13: the same product in 0.69 of the time.)
+static inline int sbr_pick_splits(int64_t tiles, int max_s, int64_t K, int cus = 256) {
+  int best = 1;
+  double best_cost = 1e300;
+  for (int S = 1; S <= max_s; ++S) {
+    if (S > 1 && K / S < 256) break;  // keep the slices long enough for the staging pipeline
+    const double rounds = (double)((tiles * S + cus - 1) / cus);
+    const double cost = rounds / S + 0.004 * S;  // the slabs are summed by the consumer: a slight preference for fewer
+    if (cost < best_cost) {
+      best_cost = cost;
+      best = S;
+    }
+  }
+  return best;
+}
+
+// sum of the partials in a fixed order: out[idx] = sum_p part[p][idx], idx < SB * SB (16 workgroups). Sixteen loads in flight per
+// thread, four interleaved partial sums (p mod 4) combined as (s0 + s1) + (s2 + s3): the ~100 partials of a long panel cost a few
+// memory round trips instead of one each (a serial loop took 44 us per call in round 2, two calls per panel).
 __global__ __launch_bounds__(256) void sbr_sum_parts(const double* __restrict__ part, int nparts, double* __restrict__ out) {
   const int idx = blockIdx.x * 256 + threadIdx.x;
-  double s = 0.0;
-  for (int p = 0; p < nparts; ++p) s += part[(int64_t)p * SB * SB + idx];
-  out[idx] = s;
+  double s[4] = {0.0, 0.0, 0.0, 0.0};
+  int p = 0;
+  for (; p + 15 < nparts; p += 16) {
+    double v[16];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) v[u] = part[(int64_t)(p + u) * SB * SB + idx];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) s[u & 3] += v[u];
+  }
+  for (; p < nparts; ++p) s[p & 3] += part[(int64_t)p * SB * SB + idx];
+  out[idx] = (s[0] + s[1]) + (s[2] + s[3]);
+}
+
+// fp64 reciprocal / reciprocal square root from the fp32 hardware estimate + Newton steps: the pivots of the 64-step
+// eliminations below sit on the critical path of every step, and the IEEE division / sqrt sequences are ~10x longer.
+// Three steps from a 23-bit estimate reach full fp64 accuracy (the error squares, resp. cubes, per step) for normal arguments.
+__device__ __forceinline__ double sbr_rcp64(double d) {
+  double x = (double)__frcp_rn((float)d);
+#pragma unroll
+  for (int it = 0; it < 3; ++it) x = x + x * (1.0 - d * x);
+  return x;
+}
+__device__ __forceinline__ double sbr_rsqrt64(double d) {
+  double x = (double)rsqrtf((float)d);
+#pragma unroll
+  for (int it = 0; it < 3; ++it) x = x * (1.5 - 0.5 * d * x * x);
+  return x;
 }
 
 // ---- the SB x SB algebra of one panel, one wave, fp64 in LDS -----------------------------------------------------------
@@ -50,13 +93,13 @@ struct SbrSmall {
   int* flag;
 };
 
-__device__ __forceinline__ double& at(double* m, int r, int c) { return m[r * SB + c]; }
-
-// 64 x 64 fp64 helpers in LDS for one workgroup of 256 threads (thread = 4 x 4 output block of a product)
-// C = A * B
-__device__ __forceinline__ void mm64(double* C, const double* A, const double* B) {
+// 64 x 64 fp64 matrices in LDS, one workgroup of 256 threads. Thread (ti, tj) = (tid >> 4, tid & 15) owns the entries
+// (ti + 16 u, tj + 16 v), u, v < 4: sixteen consecutive columns per 16-lane group (two-way bank conflicts at most).
+// C = A * B, optionally with A given in fp32 (AF), B treated as upper triangular (entries below the diagonal are not read as
+// zero but skipped: the storage there may hold something else), the result negated, and written to LDS (C) or global (G32 / G64)
+template <typename TA, bool B_UPPER>
+__device__ __forceinline__ void mm64_acc(double (&acc)[4][4], const TA* A, const double* B) {
   const int ti = threadIdx.x >> 4, tj = threadIdx.x & 15;
-  double acc[4][4];
 #pragma unroll
   for (int u = 0; u < 4; ++u)
 #pragma unroll
@@ -64,127 +107,189 @@ __device__ __forceinline__ void mm64(double* C, const double* A, const double* B
   for (int k = 0; k < SB; ++k) {
     double a[4], b[4];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) a[u] = A[(4 * ti + u) * SB + k];
+    for (int u = 0; u < 4; ++u) a[u] = (double)A[(ti + 16 * u) * SB + k];
 #pragma unroll
-    for (int v = 0; v < 4; ++v) b[v] = B[k * SB + 4 * tj + v];
+    for (int v = 0; v < 4; ++v) b[v] = (!B_UPPER || k <= tj + 16 * v) ? B[k * SB + tj + 16 * v] : 0.0;
 #pragma unroll
     for (int u = 0; u < 4; ++u)
 #pragma unroll
       for (int v = 0; v < 4; ++v) acc[u][v] += a[u] * b[v];
   }
-#pragma unroll
-  for (int u = 0; u < 4; ++u)
-#pragma unroll
-    for (int v = 0; v < 4; ++v) C[(4 * ti + u) * SB + 4 * tj + v] = acc[u][v];
-  __syncthreads();
-}
-// X = R^-1 for an upper triangular R (X upper): rows from the bottom, row j = (e_j - R[j][j+1:] X[j+1:][:]) / R[j][j];
-// thread (c = tid & 63, q = tid >> 6) sums its quarter of the k range, the four quarters are combined in a fixed order
-__device__ __forceinline__ void trinv_upper(double* X, const double* R, double* red /*[4][SB]*/) {
-  const int c = threadIdx.x & 63, q = threadIdx.x >> 6;
-  for (int j = SB - 1; j >= 0; --j) {
-    double s = 0.0;
-    for (int k = j + 1 + q; k <= c; k += 4) s += R[j * SB + k] * X[k * SB + c];  // X[k][c] = 0 for k > c
-    red[q * SB + c] = s;
-    __syncthreads();
-    if (q == 0) {
-      const double tot = (red[c] + red[SB + c]) + (red[2 * SB + c] + red[3 * SB + c]);
-      X[j * SB + c] = (c < j) ? 0.0 : (((c == j) ? 1.0 : 0.0) - tot) / R[j * SB + j];
-    }
-    __syncthreads();
-  }
 }
 
-__global__ __launch_bounds__(256) void sbr_panel_small(const double* __restrict__ part, int nparts,
-                                                       const float* __restrict__ Ptop, int64_t ldp, SbrSmall o) {
+// X = U^-1 for an upper triangular U (element (j, k), k >= j, through `uel`; `inv_diag[j]` = 1 / U[j][j]), computed by ONE wave:
+// lane c owns column c of X in registers (back substitution from the diagonal upwards, x_j = (delta_jc - sum_{k > j} U_jk x_k) /
+// U_jj; entries below the diagonal are zero, so every lane runs the same fully unrolled recurrence) and no barrier is needed.
+// The other waves of the workgroup skip this and meet the caller's barrier.
+template <class UEL>
+__device__ __forceinline__ void trinv_cols(double* X, UEL uel, const double* inv_diag) {
+  const int c = threadIdx.x & 63;
+  double x[SB];
+#pragma unroll
+  for (int j = SB - 1; j >= 0; --j) {
+    double s0 = 0.0, s1 = 0.0;
+#pragma unroll
+    for (int k = j + 1; k < SB; k += 2) {
+      s0 += uel(j, k) * x[k];
+      if (k + 1 < SB) s1 += uel(j, k + 1) * x[k + 1];
+    }
+    const double v = (((j == c) ? 1.0 : 0.0) - (s0 + s1)) * inv_diag[j];
+    x[j] = (j <= c) ? v : 0.0;
+  }
+#pragma unroll
+  for (int j = 0; j < SB; ++j) X[j * SB + c] = x[j];
+}
+
+constexpr int SBR_PANEL_LDS = 4 * SB * SB * (int)sizeof(double) + SB * SB * (int)sizeof(float) + 4 * SB * (int)sizeof(double);
+
+// The SB x SB algebra of one panel. Every 64-step elimination below runs with ONE barrier per step: the pivot row / column of
+// a step is only read during the step and the entries it updates are disjoint from it (scaled rows / columns go to a second
+// matrix instead of in place); the triangular inverses are barrier-free (one wave, a column per lane).
+// First build (round 2): 3 + 2 barriers per step, inverses row by row with a reduction per row: 357 us per panel, which was the
+// critical path of every panel below n' ~ 15 000 (the look-ahead hides it only while the trailing update takes longer).
+__global__ __launch_bounds__(256) void sbr_panel_small(const double* __restrict__ G, const float* __restrict__ Ptop, int64_t ldp,
+                                                       SbrSmall o) {
   extern __shared__ double lds[];
-  double* A = lds;                 // G -> R (upper)            -> U'^-1
-  double* B = lds + SB * SB;       // R^-1                      -> T
-  double* Cm = lds + 2 * SB * SB;  // P_top -> (later) M
-  double* Dm = lds + 3 * SB * SB;  // Q_top -> LU (V1 strictly below, U' on/above the diagonal)
-  __shared__ double red[4 * SB];
-  __shared__ double dsign[SB];
-  __shared__ double piv_s;
+  double* M0 = lds;                // G (Cholesky work) -> L of the LU      -> (V1')^-1 ... see below
+  double* M1 = lds + SB * SB;      // R                                      -> U'
+  double* M2 = lds + 2 * SB * SB;  // R^-1                                   -> R^-1 D
+  double* M3 = lds + 3 * SB * SB;  // Q_top (LU work; U' raw in the upper part) -> inverse factors
+  float* F0 = reinterpret_cast<float*>(lds + 4 * SB * SB);  // P_top [i][j]
+  double* invd = reinterpret_cast<double*>(F0 + SB * SB);   // [SB] reciprocal diagonals
+  double* dsign = invd + SB;                                 // [SB]
+  double* pivs = dsign + SB;                                 // [SB]
+  double* unit_diag = pivs + SB;                             // [SB] ones
   __shared__ int bad;
-  const int tid = threadIdx.x;
+  const int tid = threadIdx.x, ti = tid >> 4, tj = tid & 15;
   if (tid == 0) bad = 0;
-  // G = sum of the partials in a fixed order; P_top (P_top[i][j] = Ptop[j * ldp + i])
   for (int idx = tid; idx < SB * SB; idx += 256) {
-    double s = 0.0;
-    for (int p = 0; p < nparts; ++p) s += part[(int64_t)p * SB * SB + idx];
-    A[idx] = s;
+    M0[idx] = G[idx];
     const int j = idx >> 6, i = idx & 63;  // coalesced over i
-    Cm[i * SB + j] = (double)Ptop[(int64_t)j * ldp + i];
+    F0[i * SB + j] = Ptop[(int64_t)j * ldp + i];
   }
   __syncthreads();
-  // Cholesky G = R' R (right-looking): row j of R, then the rank-one update of the trailing block
+  // ---- Cholesky G = R'R, right-looking on the full symmetric matrix: step j reads row j, updates the rows below it
   for (int j = 0; j < SB; ++j) {
-    if (tid == 0) {
-      double d = A[j * SB + j];
-      if (!(d > 0.0)) {
-        bad = 1;
-        d = 1.0;
+    double d = M0[j * SB + j];
+    if (!(d > 0.0)) {
+      if (tid == 0) bad = 1;
+      d = 1.0;
+    }
+    const double rs = sbr_rsqrt64(d), rd = rs * rs;
+    if (tid < SB) {
+      M1[j * SB + tid] = (tid >= j) ? ((tid == j) ? d * rs : M0[j * SB + tid] * rs) : 0.0;
+      if (tid == j) invd[j] = rs;  // 1 / R[j][j]
+    }
+    double rr[4], rc[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) rr[u] = M0[j * SB + ti + 16 * u] * rd;
+#pragma unroll
+    for (int v = 0; v < 4; ++v) rc[v] = M0[j * SB + tj + 16 * v];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int i = ti + 16 * u;
+      if (i > j) {
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+          const int c = tj + 16 * v;
+          if (c > j) M0[i * SB + c] -= rr[u] * rc[v];
+        }
       }
-      piv_s = sqrt(d);
-    }
-    __syncthreads();
-    const double rjj = piv_s;
-    if (tid >= j && tid < SB) A[j * SB + tid] = (tid == j) ? rjj : A[j * SB + tid] / rjj;
-    __syncthreads();
-    for (int idx = tid; idx < SB * SB; idx += 256) {
-      const int i = idx >> 6, c = idx & 63;
-      if (i > j && c >= i) A[idx] -= A[j * SB + i] * A[j * SB + c];
     }
     __syncthreads();
   }
-  for (int idx = tid; idx < SB * SB; idx += 256)
-    if ((idx >> 6) > (idx & 63)) A[idx] = 0.0;  // strictly lower part of R
+  // ---- R^-1 (wave 0)
+  if (tid < SB) trinv_cols(M2, [&](int j, int k) { return M1[j * SB + k]; }, invd);
   __syncthreads();
-  trinv_upper(B, A, red);
-  mm64(Dm, Cm, B);  // Q_top = P_top R^-1
-  // sign-modified LU of (Q D - E), right-looking
+  // ---- Q_top = P_top R^-1
+  {
+    double acc[4][4];
+    mm64_acc<float, true>(acc, F0, M2);
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+      for (int v = 0; v < 4; ++v) M3[(ti + 16 * u) * SB + tj + 16 * v] = acc[u][v];
+  }
+  __syncthreads();
+  // ---- sign-modified LU of (Q D - E), right-looking: D_j = -sgn(q_jj), pivot = D_j q_jj - 1 = -|q_jj| - 1,
+  //      L[i][j] = D_j q_ij / pivot (to M0), rows of U' stay in the upper part of M3
   for (int j = 0; j < SB; ++j) {
+    const double qjj = M3[j * SB + j];
+    const double dj = (qjj >= 0.0) ? -1.0 : 1.0;
+    const double piv = dj * qjj - 1.0;
+    const double rp = dj * sbr_rcp64(piv);
     if (tid == 0) {
-      const double qjj = Dm[j * SB + j];
-      const double dj = (qjj >= 0.0) ? -1.0 : 1.0;  // D_j = -sgn(q_jj)
       dsign[j] = dj;
-      piv_s = dj * qjj - 1.0;  // = -|q_jj| - 1
+      pivs[j] = piv;
+    }
+    double lc[4], ur[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) lc[u] = M3[(ti + 16 * u) * SB + j] * rp;
+#pragma unroll
+    for (int v = 0; v < 4; ++v) ur[v] = M3[j * SB + tj + 16 * v];
+    if (tj == (j & 15)) {  // the threads whose column set contains j keep L's column j
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int i = ti + 16 * u;
+        M0[i * SB + j] = (i > j) ? lc[u] : 0.0;
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int i = ti + 16 * u;
+      if (i > j) {
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+          const int c = tj + 16 * v;
+          if (c > j) M3[i * SB + c] -= lc[u] * ur[v];
+        }
+      }
     }
     __syncthreads();
-    const double piv = piv_s, dj = dsign[j];
-    if (tid > j && tid < SB) Dm[tid * SB + j] = dj * Dm[tid * SB + j] / piv;  // L[i][j]
-    __syncthreads();
-    for (int idx = tid; idx < SB * SB; idx += 256) {
-      const int i = idx >> 6, c = idx & 63;
-      if (i > j && c > j) Dm[idx] -= Dm[i * SB + j] * Dm[j * SB + c];
-    }
-    if (tid == 0) Dm[j * SB + j] = piv;
-    __syncthreads();
   }
-  // outputs that need R and the raw LU: Rh = D R, V1 (unit lower); U'[j][c] = D_c q~[j][c] above the diagonal
+  // ---- outputs that need R and the raw LU: Rh = D R, V1 (unit lower); then U' (with the column signs) replaces R in M1
   for (int idx = tid; idx < SB * SB; idx += 256) {
     const int r = idx >> 6, c = idx & 63;
-    o.Rh[idx] = (c >= r) ? (float)(dsign[r] * A[idx]) : 0.f;
-    o.V1[idx] = (c < r) ? (float)Dm[idx] : (c == r ? 1.f : 0.f);
+    o.Rh[idx] = (c >= r) ? (float)(dsign[r] * M1[idx]) : 0.f;
+    o.V1[idx] = (c < r) ? (float)M0[idx] : (c == r ? 1.f : 0.f);
   }
   __syncthreads();
-  // A = U' (upper, with the column signs), Cm = V1^T (unit upper)
   for (int idx = tid; idx < SB * SB; idx += 256) {
     const int r = idx >> 6, c = idx & 63;
-    A[idx] = (c > r) ? dsign[c] * Dm[idx] : (c == r ? Dm[idx] : 0.0);
-    Cm[idx] = (c > r) ? Dm[c * SB + r] : (c == r ? 1.0 : 0.0);
+    M1[idx] = (c > r) ? dsign[c] * M3[idx] : (c == r ? pivs[r] : 0.0);
+  }
+  if (tid < SB) {
+    invd[tid] = 1.0 / pivs[tid];
+    unit_diag[tid] = 1.0;
   }
   __syncthreads();
-  // T = -U' V1^-T = -U' (V1^T)^-1
-  trinv_upper(Dm, Cm, red);  // Dm = (V1^T)^-1
-  mm64(Cm, A, Dm);           // Cm = U' (V1^T)^-1
-  for (int idx = tid; idx < SB * SB; idx += 256) o.T[idx] = ((idx & 63) >= (idx >> 6)) ? (float)(-Cm[idx]) : 0.f;
-  // M = R^-1 D U'^-1
-  trinv_upper(Dm, A, red);  // Dm = U'^-1
-  for (int idx = tid; idx < SB * SB; idx += 256) B[idx] *= dsign[idx & 63];  // R^-1 D (scale the columns)
+  // ---- T = -U' (V1')^-1: V1' is unit upper triangular with element (j, k) = L[k][j]
+  if (tid < SB) trinv_cols(M3, [&](int j, int k) { return M0[k * SB + j]; }, unit_diag);
   __syncthreads();
-  mm64(Cm, B, Dm);
-  for (int idx = tid; idx < SB * SB; idx += 256) o.M[idx] = Cm[idx];
+  {
+    double acc[4][4];
+    mm64_acc<double, true>(acc, M1, M3);
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+      for (int v = 0; v < 4; ++v) {
+        const int r = ti + 16 * u, c = tj + 16 * v;
+        o.T[r * SB + c] = (c >= r) ? (float)(-acc[u][v]) : 0.f;
+      }
+  }
+  __syncthreads();
+  // ---- M = (R^-1 D) U'^-1
+  if (tid < SB) trinv_cols(M3, [&](int j, int k) { return M1[j * SB + k]; }, invd);
+  for (int idx = tid; idx < SB * SB; idx += 256) M2[idx] *= dsign[idx & 63];  // scale the columns of R^-1 (M2 is not read by wave 0 here)
+  __syncthreads();
+  {
+    double acc[4][4];
+    mm64_acc<double, true>(acc, M2, M3);
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+      for (int v = 0; v < 4; ++v) o.M[(ti + 16 * u) * SB + tj + 16 * v] = acc[u][v];
+  }
   if (tid == 0 && bad) atomicExch(o.flag, 1);
 }
 
@@ -255,20 +360,21 @@ __global__ __launch_bounds__(64) void sbr_panel_house(const float* __restrict__ 
   }
 }
 
-// Sh = 1/2 T' (V'Y), V'Y = sum of the cross partials in a fixed order; 256 threads, 4 x 4 outputs each
-__global__ __launch_bounds__(256) void sbr_small_s(const double* __restrict__ part, int nparts, const float* __restrict__ T,
-                                                  double* __restrict__ Sh) {
-  __shared__ double G[SB * SB], Tt[SB * SB], R[SB * SB];
-  const int tid = threadIdx.x;
+// Sh = 1/2 T' (V'Y), V'Y = the summed cross partials (sbr_sum_parts); 256 threads, 4 x 4 outputs each
+__global__ __launch_bounds__(256) void sbr_small_s(const double* __restrict__ VtY, const float* __restrict__ T, double* __restrict__ Sh) {
+  __shared__ double G[SB * SB], Tt[SB * SB];
+  const int tid = threadIdx.x, ti = tid >> 4, tj = tid & 15;
   for (int idx = tid; idx < SB * SB; idx += 256) {
-    double s = 0.0;
-    for (int p = 0; p < nparts; ++p) s += part[(int64_t)p * SB * SB + idx];
-    G[idx] = s;
+    G[idx] = VtY[idx];
     Tt[(idx & 63) * SB + (idx >> 6)] = (double)T[idx];  // T' (T is upper: its strictly lower part is stored as 0)
   }
   __syncthreads();
-  mm64(R, Tt, G);
-  for (int idx = tid; idx < SB * SB; idx += 256) Sh[idx] = 0.5 * R[idx];
+  double acc[4][4];
+  mm64_acc<double, false>(acc, Tt, G);
+#pragma unroll
+  for (int u = 0; u < 4; ++u)
+#pragma unroll
+    for (int v = 0; v < 4; ++v) Sh[(ti + 16 * u) * SB + tj + 16 * v] = 0.5 * acc[u][v];
 }
 
 // ---- tall-skinny algebra of a panel on the matrix cores ------------------------------------------------------------------
@@ -280,6 +386,7 @@ __global__ __launch_bounds__(256) void sbr_small_s(const double* __restrict__ pa
 typedef double f64x4 __attribute__((ext_vector_type(4)));
 constexpr int SBR_RT = 16;          // positions per wave tile
 constexpr int SBR_GCH = 256;        // positions per workgroup of the Gram kernels (four waves of 64)
+constexpr int SBR_GRAM_LDS = 2 * SB * SB * (int)sizeof(double);  // dynamic LDS of sbr_gram64 (64 KB: at the default limit)
 
 // part[wg][i][j] = sum over the workgroup's positions r of X[r][i] Y[r][j] (fp64), X / Y given as
 //   TRANSPOSED = true : Xt[i * ldx + r]   (the panel in A; X == Y: its Gram matrix)
@@ -287,7 +394,7 @@ constexpr int SBR_GCH = 256;        // positions per workgroup of the Gram kerne
 template <bool TRANSPOSED>
 __global__ __launch_bounds__(256) void sbr_gram64(const float* __restrict__ X, int64_t ldx, const float* __restrict__ Y, int64_t len,
                                                   double* __restrict__ part) {
-  __shared__ double red[3][SB * SB / 4];  // waves 1..3 -> wave 0
+  extern __shared__ double red[];  // 2 x [SB * SB]: waves 2, 3 -> waves 0, 1, then wave 1 -> wave 0 (two barriers, fixed order)
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, l15 = lane & 15, kg = lane >> 4;
   f64x4 acc[4][4];
 #pragma unroll
@@ -334,26 +441,44 @@ __global__ __launch_bounds__(256) void sbr_gram64(const float* __restrict__ X, i
         for (int b = 0; b < 4; ++b)
           acc[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64((double)xa[a][e], (double)yb[b][e], acc[a][b], 0, 0, 0);
   }
-  // D layout (f64): column = lane & 15, row = (lane >> 4) + 4 * reg. Waves 1..3 hand their sums to wave 0 (fixed order).
+  // D layout (f64): column = lane & 15, row = (lane >> 4) + 4 * reg. Sum of the four waves as (w0 + w2) + (w1 + w3):
   double* out = part + (int64_t)blockIdx.x * SB * SB;
-  for (int src = 1; src < 4; ++src) {
-    // four rounds of 4 tiles to stay inside the LDS budget
-    for (int a = 0; a < 4; ++a) {
-      __syncthreads();
-      if (wv == src) {
+  if (wv >= 2) {
+    double* dst = red + (wv - 2) * SB * SB;
 #pragma unroll
-        for (int b = 0; b < 4; ++b)
+    for (int a = 0; a < 4; ++a)
 #pragma unroll
-          for (int g = 0; g < 4; ++g) red[0][(b * 4 + g) * 64 + lane] = acc[a][b][g];
-      }
-      __syncthreads();
-      if (wv == 0) {
+      for (int b = 0; b < 4; ++b)
 #pragma unroll
-        for (int b = 0; b < 4; ++b)
+        for (int g = 0; g < 4; ++g) dst[((a * 4 + b) * 4 + g) * 64 + lane] = acc[a][b][g];
+  }
+  __syncthreads();
+  if (wv < 2) {
+    const double* src = red + wv * SB * SB;
 #pragma unroll
-          for (int g = 0; g < 4; ++g) acc[a][b][g] += red[0][(b * 4 + g) * 64 + lane];
-      }
-    }
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+      for (int b = 0; b < 4; ++b)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) acc[a][b][g] += src[((a * 4 + b) * 4 + g) * 64 + lane];
+  }
+  __syncthreads();
+  if (wv == 1) {
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+      for (int b = 0; b < 4; ++b)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) red[((a * 4 + b) * 4 + g) * 64 + lane] = acc[a][b][g];
+  }
+  __syncthreads();
+  if (wv == 0) {
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+      for (int b = 0; b < 4; ++b)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) acc[a][b][g] += red[((a * 4 + b) * 4 + g) * 64 + lane];
   }
   if (wv == 0) {
 #pragma unroll
@@ -421,7 +546,7 @@ __global__ __launch_bounds__(256) void sbr_top_block(float* __restrict__ Pt, int
 
 // out[r][j] = sum_i in[r][i] F[i][j] (f32 MFMA), in = the sum of `nslab` row-major slabs (fixed order).
 //   MODE 2: Yr = W T                      (in = split-K slabs of W)
-//   MODE 3: Z = Yr - Vr Sh  and the row-major operands of the rank-128 update: VW[r] = [V | Z], WV[r] = [Z | V]
+//   MODE 3: Z = Yr - Vr Sh  and the row-major operands of the rank-128 update: VW[r] = [V | Z], WV[r] = -[Z | V]
 template <int MODE>
 __global__ __launch_bounds__(256) void sbr_rmul_f32(const float* __restrict__ in, int nslab, int64_t slab, const float* __restrict__ F32,
                                                     const double* __restrict__ F64, int64_t len, float* __restrict__ out,
@@ -474,8 +599,8 @@ __global__ __launch_bounds__(256) void sbr_rmul_f32(const float* __restrict__ in
         const float v = in[rr * SB + j];
         VW[rr * (2 * SB) + j] = v;
         VW[rr * (2 * SB) + SB + j] = z;
-        WV[rr * (2 * SB) + j] = z;
-        WV[rr * (2 * SB) + SB + j] = v;
+        WV[rr * (2 * SB) + j] = -z;  // negated: the update is then C += [V | Z] [-Z | -V]' with the accumulators started from C
+        WV[rr * (2 * SB) + SB + j] = -v;
       }
     }
   }
@@ -506,9 +631,7 @@ int sy2sb_f32(Ctx* ctx, float* A, int64_t n, int64_t lda, float* Tall, int* brea
   SCL_WS(ctx, flag, int, "sbr.flag", 4);
   hipStream_t st = ctx->stream;
   SCL_HIP(ctx, hipMemsetAsync(flag, 0, sizeof(int) * 4, st));
-  // 128 KB of dynamic LDS for the panel algebra (above the 64 KB default; idempotent, cheap)
-  SCL_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(sbr_panel_small),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, 4 * SB * SB * (int)sizeof(double)));
+  SCL_TRY(ensure_dyn_lds(ctx, reinterpret_cast<const void*>(sbr_panel_small), SBR_PANEL_LDS));
   // Look-ahead: panel p + 1 only needs the first SB columns of the trailing matrix of step p. Those are updated first
   // (a strip product, its transposed copy, and the diagonal block), then the panel is factored on a second stream while
   // the main stream applies the rest of the rank-128 update: the latency-bound panel algebra (Gram, SB x SB factorisations,
@@ -526,13 +649,13 @@ int sy2sb_f32(Ctx* ctx, float* A, int64_t n, int64_t lda, float* Tall, int* brea
     float* Tp = Tall + p * SB * SB;
     const int nparts = (int)((np + SBR_GCH - 1) / SBR_GCH);
     const unsigned rtiles = (unsigned)((np + 4 * SBR_RT - 1) / (4 * SBR_RT));  // workgroups of four 16-position wave tiles
-    hipLaunchKernelGGL((sbr_gram64<true>), dim3(nparts), dim3(256), 0, s_, Pt, lda, (const float*)nullptr, np, part);
+    hipLaunchKernelGGL((sbr_gram64<true>), dim3(nparts), dim3(256), SBR_GRAM_LDS, s_, Pt, lda, (const float*)nullptr, np, part);
     hipLaunchKernelGGL(sbr_sum_parts, dim3(SB * SB / 256), dim3(256), 0, s_, part, nparts, psum);
     SbrSmall sm{Mat, V1, Tp, V1 + SB * SB, flag};
     if (np == SB)  // last panel: may contain the zero rows of the padding
       hipLaunchKernelGGL(sbr_panel_house, dim3(1), dim3(64), 0, s_, Pt, lda, sm);
     else
-      hipLaunchKernelGGL(sbr_panel_small, dim3(1), dim3(256), 4 * SB * SB * sizeof(double), s_, psum, 1, Pt, lda, sm);
+      hipLaunchKernelGGL(sbr_panel_small, dim3(1), dim3(256), SBR_PANEL_LDS, s_, psum, Pt, lda, sm);
     // V = [V1; P2 M] in the transposed storage (in place) and row-major; Rh into the band block of the panel
     if (np > SB) hipLaunchKernelGGL(sbr_vmul_f64, dim3(rtiles), dim3(256), 0, s_, Pt, lda, Mat, np, Vr);
     hipLaunchKernelGGL(sbr_top_block, dim3(1), dim3(256), 0, s_, Pt, lda, V1, V1 + SB * SB, A + r0 * lda + c0, Vr);
@@ -549,7 +672,7 @@ int sy2sb_f32(Ctx* ctx, float* A, int64_t n, int64_t lda, float* Tall, int* brea
     // K = n' split into S slices inside one launch (slab s = its own [n'][SB] partial, summed by the next kernel)
     float* A22 = A + r0 * lda + r0;
     const int64_t tiles_w = (np + 255) / 256;
-    int Sw = (int)std::min<int64_t>(S, std::max<int64_t>(1, (640 + tiles_w - 1) / tiles_w));
+    int Sw = sbr_pick_splits(tiles_w, S, np);
     const int64_t kch = round_up((np + Sw - 1) / Sw, 32);
     Sw = (int)((np + kch - 1) / kch);
     {
@@ -565,9 +688,9 @@ int sy2sb_f32(Ctx* ctx, float* A, int64_t n, int64_t lda, float* Tall, int* brea
     // Y = W T; Sh = 1/2 T' (V'Y); Z = Y - V Sh and the row-major operands [V | Z], [Z | V] of the rank-128 update
     hipLaunchKernelGGL((sbr_rmul_f32<2>), dim3(rtiles), dim3(256), 0, st, Wp, Sw, (int64_t)SB * ldw, Tp, (const double*)nullptr, np, Yr,
                        (const float*)nullptr, (float*)nullptr, (float*)nullptr);
-    hipLaunchKernelGGL((sbr_gram64<false>), dim3(nparts), dim3(256), 0, st, Vr, (int64_t)SB, Yr, np, part);
+    hipLaunchKernelGGL((sbr_gram64<false>), dim3(nparts), dim3(256), SBR_GRAM_LDS, st, Vr, (int64_t)SB, Yr, np, part);
     hipLaunchKernelGGL(sbr_sum_parts, dim3(SB * SB / 256), dim3(256), 0, st, part, nparts, psum);
-    hipLaunchKernelGGL(sbr_small_s, dim3(1), dim3(256), 0, st, psum, 1, Tp, Mat + SB * SB);
+    hipLaunchKernelGGL(sbr_small_s, dim3(1), dim3(256), 0, st, psum, Tp, Mat + SB * SB);
     hipLaunchKernelGGL((sbr_rmul_f32<3>), dim3(rtiles), dim3(256), 0, st, Vr, 1, (int64_t)0, (const float*)nullptr, Mat + SB * SB, np,
                        (float*)nullptr, Yr, VW, WV);
     auto update = [&](int64_t off, int64_t rows, int64_t cols, int lower) -> int {  // A22[off:off+rows, (lower ? off : 0) : +cols]
@@ -575,7 +698,8 @@ int sy2sb_f32(Ctx* ctx, float* A, int64_t n, int64_t lda, float* Tall, int* brea
       g.P = VW + off * 2 * SB; g.Q = WV + (lower ? off : 0) * 2 * SB; g.C = A22 + off * lda + (lower ? off : 0);
       g.M = rows; g.N = cols; g.K = 2 * SB;
       g.ldp = 2 * SB; g.ldq = 2 * SB; g.ldc = lda;
-      g.alpha = -1.f; g.beta = 1.f; g.q_kcontig = 1; g.lower = lower; g.colabsmax = nullptr;
+      g.alpha = 1.f; g.beta = 1.f; g.q_kcontig = 1; g.lower = lower; g.colabsmax = nullptr;  // WV is stored negated
+      g.acc_init = 1;
       g.prefer_big = 1;  // K = 128: bound by the traffic of C, whose mirrored half the large-tile kernel stores 16 bytes at a time
       return gemm_f32(ctx, g);
     };
@@ -609,17 +733,17 @@ int sy2sb_f32(Ctx* ctx, float* A, int64_t n, int64_t lda, float* Tall, int* brea
 // z_A = H_0 (H_1 (... H_{P-1} z_B)), H_p = I - V_p T_p V_p' on the coordinates >= r0_p. In row form, per panel from the
 // last to the first:  Zt[:, r0:] -= ((Zt[:, r0:] V) T') V'  -- three GEMMs, the first one split over K in one launch and
 // summed by the second through an S-fold replicated T (the scheme of ormtr_f32).
-// Panels are applied in groups of Q1G = 4: H_a H_{a+1} H_{a+2} H_{a+3} = I - Vm Tm Vm' with Vm = [V_a .. V_{a+3}] (each later
+// Panels are applied in groups of Q1G = 4 or 8: H_a H_{a+1} .. H_{a+Q1G-1} = I - Vm Tm Vm' with Vm = [V_a .. ] (each later
 // block starting 64 rows further down: a zero staircase) and the block upper triangular Tm whose diagonal blocks are the
 // panels' own T factors and whose off-diagonal blocks follow the larft recurrence Tm[0:j, j] = -Tm[0:j, 0:j] (Vm[0:j]' V_j) T_j.
-// A group therefore costs three products with a 256-deep inner dimension instead of twelve with 64: the traffic of Z (read once
+// A group therefore costs three products with a 64 Q1G-deep inner dimension instead of 3 Q1G with 64: the traffic of Z (read once
 // by the first product, read + written by the last) per unit of work drops fourfold, which is what bounds the unmerged form.
-constexpr int Q1G = 4, Q1W = Q1G * SB;
+constexpr int Q1G_MAX = 8;  // panels per group: Q1G = 4 or 8 at run time (SCLENS_HIP_Q1G), Q1W = 64 Q1G columns
 
 // clean copies of the group's reflectors: Vm[c][i] (c = 64 q + j: reflector j of panel q, i = position relative to the FIRST
 // panel's r0) and its transpose VmT[i][c]; entries above a panel's own start (i < 64 q) and rows of missing panels are zero
 __global__ __launch_bounds__(256) void sbr_q1_build_vm(const float* __restrict__ A, int64_t lda, int64_t c0, int cnt, int64_t np,
-                                                       float* __restrict__ Vm, int64_t ldv, float* __restrict__ VmT) {
+                                                       float* __restrict__ Vm, int64_t ldv, float* __restrict__ VmT, int Q1W) {
   __shared__ float tile[32][33];
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
   const int64_t i0 = (int64_t)blockIdx.x * 32;
@@ -640,7 +764,7 @@ __global__ __launch_bounds__(256) void sbr_q1_build_vm(const float* __restrict__
 }
 
 // G = sum of the split-K slabs of the group's Gram matrix, in a fixed order
-__global__ __launch_bounds__(256) void sbr_q1_sum_g(const float* __restrict__ Gp, int nslab, float* __restrict__ G) {
+__global__ __launch_bounds__(256) void sbr_q1_sum_g(const float* __restrict__ Gp, int nslab, float* __restrict__ G, int Q1W) {
   const int idx = blockIdx.x * 256 + threadIdx.x;
   float s = 0.f;
   for (int q = 0; q < nslab; ++q) s += Gp[(int64_t)q * Q1W * Q1W + idx];
@@ -652,7 +776,7 @@ __global__ __launch_bounds__(256) void sbr_q1_sum_g(const float* __restrict__ Gp
 // one workgroup per 64 x 64 block, operands staged in LDS, fp64 accumulation. Launched once per level (the blocks of a level
 // only need lower levels).
 __global__ __launch_bounds__(256) void sbr_q1_merge_level(const float* __restrict__ G, const float* __restrict__ Tp, int cnt, int level,
-                                                          float* __restrict__ Tm) {
+                                                          float* __restrict__ Tm, int Q1W) {
   __shared__ float Ls[SB][SB + 1], Rs[SB][SB + 1];
   const int a = blockIdx.x, b = a + level, tid = threadIdx.x, ti = tid >> 4, tj = tid & 15;
   if (level == 0) {  // diagonal blocks, and zero everything else of block row a (upper part is filled by the later levels)
@@ -716,12 +840,18 @@ __global__ __launch_bounds__(256) void sbr_q1_merge_level(const float* __restric
     for (int v = 0; v < 4; ++v) Tm[(a * SB + 4 * ti + u) * Q1W + b * SB + 4 * tj + v] = (float)(-acc[u][v]);
 }
 
-// Trep[c2][s * Q1W + c] = Tm[c2][c]: the S-fold copy along the contraction that sums the split-K slabs of W1
-__global__ __launch_bounds__(256) void sbr_q1_rep_t(const float* __restrict__ Tm, int S, float* __restrict__ Trep) {
-  const int idx = blockIdx.x * 256 + threadIdx.x;
-  const float v = Tm[idx];
-  const int r = idx / Q1W, c = idx % Q1W;
-  for (int q = 0; q < S; ++q) Trep[(int64_t)r * S * Q1W + q * Q1W + c] = v;
+// Ws[r][c] = sum_s W1[r][s][c] (the split-K slabs of the first product, fixed order), four columns per thread.
+// (Round 2 summed the slabs inside the second product by contracting against an S-fold replicated Tm: 2 m Q1W^2 S flop per
+// group on the 128 x 128 kernel, ~50 ms per back-transformation at n = 30 016; this pass reads m S Q1W floats once.)
+__global__ __launch_bounds__(256) void sbr_q1_sum_w(const float* __restrict__ W1, int S, int64_t m, int Q1W, float* __restrict__ Ws) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;  // index of a float4 of Ws
+  const int64_t q4 = Q1W / 4;
+  if (i >= m * q4) return;
+  const int64_t r = i / q4, c4 = i % q4;
+  const f32x4* src = reinterpret_cast<const f32x4*>(W1 + r * (int64_t)S * Q1W) + c4;
+  f32x4 acc = src[0];
+  for (int q = 1; q < S; ++q) acc += src[(int64_t)q * q4];
+  reinterpret_cast<f32x4*>(Ws)[i] = acc;
 }
 
 int sbr_apply_q1(Ctx* ctx, const float* A, int64_t n, int64_t lda, const float* Tall, float* Zt, int64_t m, int64_t ldz) {
@@ -732,25 +862,31 @@ int sbr_apply_q1(Ctx* ctx, const float* A, int64_t n, int64_t lda, const float* 
   StageTimer tm(ctx, "sbr_q1");
   const int64_t npan = n / SB - 1;
   if (npan <= 0) return SCLENS_OK;
+  // panels per block reflector: the three products of a group contract over 64 Q1G columns; the large-tile kernel reaches
+  // 82 / 100 TF/s at K = 256 / 512 with a read-modify-write of C (scripts/perf_update.py), so wide groups pay for many vectors
+  static const int q1g_env = getenv("SCLENS_HIP_Q1G") ? atoi(getenv("SCLENS_HIP_Q1G")) : 0;
+  const int Q1G = (q1g_env == 4 || q1g_env == 8) ? q1g_env : (m >= 2048 && npan >= 64 ? 8 : 4);
+  const int Q1W = Q1G * SB;
   const int64_t ngrp = (npan + Q1G - 1) / Q1G;
   const int64_t ldv = round_up(n, 32);
-  const int64_t tiles_m = (m + 255) / 256;
-  int S = (int)std::min<int64_t>(16, std::max<int64_t>(1, (512 + tiles_m - 1) / tiles_m));
-  const int SG = 64;  // K-slices of the 256 x 256 Gram product (one output tile: the slices are the only parallelism)
+  const int64_t tiles_w1 = ((m + 255) / 256) * (Q1W / 256);
+  const int SMAX = 16;  // upper bound of the K-slices of W1 (the workspaces are sized for it); the count is chosen per group
+  const int SG = 64;    // K-slices of the Gram product of the group's reflectors (few output tiles: the slices are the parallelism)
   SCL_WS(ctx, Vm, float, "sbr.Vm", Q1W * ldv);
   SCL_WS(ctx, VmT, float, "sbr.VmT", ldv * Q1W);
   SCL_WS(ctx, Gp, float, "sbr.q1G", (int64_t)SG * Q1W * Q1W);
-  SCL_WS(ctx, Tm, float, "sbr.q1T", Q1W * Q1W);
-  SCL_WS(ctx, Gs, float, "sbr.q1Gs", Q1W * Q1W);
-  SCL_WS(ctx, Trep, float, "sbr.Trep", (int64_t)Q1W * S * Q1W);
-  SCL_WS(ctx, W1, float, "sbr.W1", m * (int64_t)S * Q1W);
-  SCL_WS(ctx, W2, float, "sbr.W2", m * Q1W);
+  SCL_WS(ctx, Tm, float, "sbr.q1T", (int64_t)Q1W * Q1W);
+  SCL_WS(ctx, Gs, float, "sbr.q1Gs", (int64_t)Q1W * Q1W);
+  SCL_WS(ctx, W1, float, "sbr.W1", m * (int64_t)SMAX * Q1W);
+  SCL_WS(ctx, Ws, float, "sbr.Ws", m * (int64_t)Q1W);
+  SCL_WS(ctx, W2, float, "sbr.W2", m * (int64_t)Q1W);
   hipStream_t st = ctx->stream;
   for (int64_t g = ngrp - 1; g >= 0; --g) {
     const int64_t p0 = g * Q1G;
     const int cnt = (int)std::min<int64_t>(Q1G, npan - p0);
     const int64_t c0 = p0 * SB, r0 = c0 + SB, np = n - r0;
-    hipLaunchKernelGGL(sbr_q1_build_vm, dim3((unsigned)((ldv + 31) / 32), Q1W / 32), dim3(256), 0, st, A, lda, c0, cnt, np, Vm, ldv, VmT);
+    const int S = sbr_pick_splits(tiles_w1, SMAX, np);
+    hipLaunchKernelGGL(sbr_q1_build_vm, dim3((unsigned)((ldv + 31) / 32), Q1W / 32), dim3(256), 0, st, A, lda, c0, cnt, np, Vm, ldv, VmT, Q1W);
     {  // Gram matrix of the group's reflectors, split over K
       GemmArgs gm{};
       gm.P = Vm; gm.Q = Vm; gm.C = Gp;
@@ -760,12 +896,11 @@ int sbr_apply_q1(Ctx* ctx, const float* A, int64_t n, int64_t lda, const float* 
       gm.splits = SG; gm.k_chunk = round_up((np + SG - 1) / SG, 32); gm.c_split_off = (int64_t)Q1W * Q1W;
       SCL_TRY(gemm_f32(ctx, gm));
     }
-    hipLaunchKernelGGL(sbr_q1_sum_g, dim3(Q1W * Q1W / 256), dim3(256), 0, st, Gp, SG, Gs);
+    hipLaunchKernelGGL(sbr_q1_sum_g, dim3(Q1W * Q1W / 256), dim3(256), 0, st, Gp, SG, Gs, Q1W);
     for (int level = 0; level < cnt; ++level)
-      hipLaunchKernelGGL(sbr_q1_merge_level, dim3(level == 0 ? Q1G : Q1G - level), dim3(256), 0, st, Gs, Tall + p0 * SB * SB, cnt, level, Tm);
-    hipLaunchKernelGGL(sbr_q1_rep_t, dim3(Q1W * Q1W / 256), dim3(256), 0, st, Tm, S, Trep);
+      hipLaunchKernelGGL(sbr_q1_merge_level, dim3(level == 0 ? Q1G : Q1G - level), dim3(256), 0, st, Gs, Tall + p0 * SB * SB, cnt, level, Tm, Q1W);
     const int64_t kch = round_up((np + S - 1) / S, 32);
-    {  // W1[m][s][256] = split-K partials of Zt[:, r0:] Vm'
+    {  // W1[m][s][Q1W] = split-K partials of Zt[:, r0:] Vm'
       GemmArgs g1{};
       g1.P = Zt + r0; g1.Q = Vm; g1.C = W1;
       g1.M = m; g1.N = Q1W; g1.K = np;
@@ -775,20 +910,26 @@ int sbr_apply_q1(Ctx* ctx, const float* A, int64_t n, int64_t lda, const float* 
       g1.prefer_big = 1;
       SCL_TRY(gemm_f32(ctx, g1));
     }
-    {  // W2 = (sum_s W1_s) Tm'  (NT with the S-fold replicated Tm; slices beyond np contributed zeros)
+    const float* Wsum = W1;
+    if (S > 1) {
+      hipLaunchKernelGGL(sbr_q1_sum_w, dim3((unsigned)((m * (Q1W / 4) + 255) / 256)), dim3(256), 0, st, W1, S, m, Q1W, Ws);
+      Wsum = Ws;
+    }
+    {  // W2 = -(sum_s W1_s) Tm'
       GemmArgs g2{};
-      g2.P = W1; g2.Q = Trep; g2.C = W2;
-      g2.M = m; g2.N = Q1W; g2.K = (int64_t)S * Q1W;
-      g2.ldp = (int64_t)S * Q1W; g2.ldq = (int64_t)S * Q1W; g2.ldc = Q1W;
-      g2.alpha = 1.f; g2.beta = 0.f; g2.q_kcontig = 1; g2.lower = 0; g2.colabsmax = nullptr;
+      g2.P = Wsum; g2.Q = Tm; g2.C = W2;
+      g2.M = m; g2.N = Q1W; g2.K = Q1W;
+      g2.ldp = Q1W; g2.ldq = Q1W; g2.ldc = Q1W;
+      g2.alpha = -1.f; g2.beta = 0.f; g2.q_kcontig = 1; g2.lower = 0; g2.colabsmax = nullptr;  // W2 = -(...): g3 then adds
       SCL_TRY(gemm_f32(ctx, g2));
     }
-    {  // Zt[:, r0:] -= W2 Vm   (NT against the transposed copy)
+    {  // Zt[:, r0:] += W2 Vm   (NT against the transposed copy; accumulators started from Zt)
       GemmArgs g3{};
       g3.P = W2; g3.Q = VmT; g3.C = Zt + r0;
       g3.M = m; g3.N = np; g3.K = Q1W;
       g3.ldp = Q1W; g3.ldq = Q1W; g3.ldc = ldz;
-      g3.alpha = -1.f; g3.beta = 1.f; g3.q_kcontig = 1; g3.lower = 0; g3.colabsmax = nullptr;
+      g3.alpha = 1.f; g3.beta = 1.f; g3.q_kcontig = 1; g3.lower = 0; g3.colabsmax = nullptr;
+      g3.acc_init = 1;
       g3.prefer_big = 1;
       SCL_TRY(gemm_f32(ctx, g3));
     }
@@ -808,6 +949,9 @@ int sbr_apply_q1(Ctx* ctx, const float* A, int64_t n, int64_t lda, const float* 
 // with agent-scope release / acquire. Blocks live in LDS (2 x 64 x 64 floats); the band is packed as Bd[column][row - column]
 // with room for the bulge (row - column <= 2 SB).
 constexpr int LDB2 = 2 * SB + 4;  // floats per column of the packed band
+// leading dimension of the reflector store V2[sweep][row]: 128 spare columns, so that the 64-float run of a reflector that starts
+// up to 32 rows past the end (a sweep of a 32-sweep group that has no task k any more) stays inside its own, zero-filled, row
+static inline int64_t sbr_ldv2(int64_t n) { return round_up(n, 64) + 128; }
 
 __global__ void sbr_pack_band(const float* __restrict__ A, int64_t n, int64_t lda, float* __restrict__ Bd) {
   const int64_t j = blockIdx.x;
@@ -1005,7 +1149,7 @@ __global__ void sbr_band_diag(const float* __restrict__ Bd, int64_t n, double* _
 int sb2st_f32(Ctx* ctx, const float* A, int64_t n, int64_t lda, double* d_dev, double* e_dev) {
   if (n % SB != 0 || n < SB) return ctx->fail(SCLENS_ERR_ARG, "sb2st_f32: the order must be a positive multiple of 64");
   StageTimer tm(ctx, "sb2st");
-  const int64_t ldv2 = round_up(n, 64), ldt = n / SB + 2;
+  const int64_t ldv2 = sbr_ldv2(n), ldt = n / SB + 2;
   SCL_WS(ctx, Bd, float, "sbr.Bd", n * LDB2);
   SCL_WS(ctx, V2, float, "sbr.V2", (n + 64) * ldv2);  // spare rows: the back-transformation reads whole 64-float runs
   SCL_WS(ctx, TAU2, float, "sbr.TAU2", n * ldt);
@@ -1192,8 +1336,10 @@ __device__ __forceinline__ void sbr_q2_stash16(const SbrQ2Fetch& f, float* buf, 
   }
 }
 
-// one group applied to the six window tiles z[0..5] (rows 0..95 of the group's window)
-template <int RT>
+// one group applied to the six window tiles z[0..5] (rows 0..95 of the group's window); operand fragments read from LDS right
+// before their use. ILV: consecutive MFMAs of the third product go to different row tiles (a dependent accumulator costs 40 cycles
+// instead of the 32 of an independent one) and the T product runs on three accumulator chains.
+template <int RT, bool ILV>
 __device__ __forceinline__ void sbr_q2_group16(f32x4* z, const float* buf, int vi, int g) {
   const float* VgT = buf;
   const float* T = buf + QW * Q_RS;
@@ -1210,7 +1356,7 @@ __device__ __forceinline__ void sbr_q2_group16(f32x4* z, const float* buf, int v
     }
   }
   // U' = Tg W' (Tg upper triangular: tile (1,0) is zero)
-  f32x4 u0 = {0.f, 0.f, 0.f, 0.f}, u1 = {0.f, 0.f, 0.f, 0.f};
+  f32x4 u0 = {0.f, 0.f, 0.f, 0.f}, u1 = {0.f, 0.f, 0.f, 0.f}, u2 = {0.f, 0.f, 0.f, 0.f};
   {
     const f32x4 t00 = *reinterpret_cast<const f32x4*>(T + vi * RT + 4 * g);
     const f32x4 t01 = *reinterpret_cast<const f32x4*>(T + vi * RT + 16 + 4 * g);
@@ -1219,28 +1365,151 @@ __device__ __forceinline__ void sbr_q2_group16(f32x4* z, const float* buf, int v
     for (int e = 0; e < 4; ++e) {
       u0 = __builtin_amdgcn_mfma_f32_16x16x4f32(t00[e], w0[e], u0, 0, 0, 0);
       u1 = __builtin_amdgcn_mfma_f32_16x16x4f32(t11[e], w1[e], u1, 0, 0, 0);
+      if (ILV) u2 = __builtin_amdgcn_mfma_f32_16x16x4f32(t01[e], w1[e], u2, 0, 0, 0);
     }
+    if (!ILV) {
 #pragma unroll
-    for (int e = 0; e < 4; ++e) u0 = __builtin_amdgcn_mfma_f32_16x16x4f32(t01[e], w1[e], u0, 0, 0, 0);
+      for (int e = 0; e < 4; ++e) u0 = __builtin_amdgcn_mfma_f32_16x16x4f32(t01[e], w1[e], u0, 0, 0, 0);
+    }
   }
 #pragma unroll
   for (int e = 0; e < 4; ++e) {
-    u0[e] = -u0[e];
+    u0[e] = -(u0[e] + u2[e]);
     u1[e] = -u1[e];
   }
   // Zw' -= Vg U': A[row][reflector 4 g + e] from the [reflector][row] image
+  if (ILV) {
 #pragma unroll
-  for (int rt = 0; rt < 6; ++rt) {
-    if (rt < 5) {
+    for (int e = 0; e < 4; ++e) {
 #pragma unroll
-      for (int e = 0; e < 4; ++e)
+      for (int rt = 0; rt < 5; ++rt)
         z[rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(VgT[(4 * g + e) * Q_RS + 16 * rt + vi], u0[e], z[rt], 0, 0, 0);
-    }
-    if (rt > 0) {
 #pragma unroll
-      for (int e = 0; e < 4; ++e)
+      for (int rt = 1; rt < 6; ++rt)
         z[rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(VgT[(16 + 4 * g + e) * Q_RS + 16 * rt + vi], u1[e], z[rt], 0, 0, 0);
     }
+  } else {
+#pragma unroll
+    for (int rt = 0; rt < 6; ++rt) {
+      if (rt < 5) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          z[rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(VgT[(4 * g + e) * Q_RS + 16 * rt + vi], u0[e], z[rt], 0, 0, 0);
+      }
+      if (rt > 0) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          z[rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(VgT[(16 + 4 * g + e) * Q_RS + 16 * rt + vi], u1[e], z[rt], 0, 0, 0);
+      }
+    }
+  }
+}
+
+// ---- variant 3 (round 3): a second, row-major LDS image of the group's reflectors feeds the third product with 16-byte reads
+// (four consecutive reflectors of one row = the four k-steps of one MFMA group: 10 reads instead of 40), its reads are issued
+// when the first product's MFMAs have been issued (they land during the T product), and the fetch of the NEXT group's data
+// (8 + 4 global loads per thread, unconditional: see sbr_ldv2) sits between the MFMAs of the first product instead of in front
+// of the group, where the matrix pipe idles.
+constexpr int Q_NS = 36;                                  // floats per window row of the row-major image
+constexpr int Q_BUF3 = QW * Q_RS + QW * Q_RT + 96 * Q_NS;  // 7 936 floats per buffer
+
+struct SbrQ2Ptr {           // per-thread fetch state of variant 3
+  const float* v;           // V2 + wv (ldv2 + 1) + 1 + lane: reflector c = wv + 4 q of group (b, t) sits at
+                            // v + 32 b (ldv2 + 1) + 64 t + 4 q (ldv2 + 1)
+  const float* tg;          // Tg + tid
+  int64_t vstride;          // ldv2 + 1
+};
+
+__device__ __forceinline__ void sbr_q2_fetch16v3(SbrQ2Fetch& f, const SbrQ2Args& a, const SbrQ2Ptr& p, int b, int t) {
+  const int bb = b < 0 ? 0 : b;                // b < 0: past the last group; the data is never used
+  const int tt = t < a.nk ? t : a.nk - 1;
+  const float* src = p.v + ((int64_t)bb * QW) * p.vstride + (int64_t)tt * SB;
+#pragma unroll
+  for (int q = 0; q < 8; ++q) f.v[q] = src[(int64_t)(4 * q) * p.vstride];
+  const float* tg = p.tg + ((int64_t)bb * a.nk + tt) * QW * QW;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) f.t[q] = tg[256 * q];
+}
+
+__device__ __forceinline__ void sbr_q2_stash16v3(const SbrQ2Fetch& f, float* buf, int tid) {
+  float* N = buf + QW * Q_RS + QW * Q_RT;
+#pragma unroll
+  for (int q = 0; q < 8; ++q) {
+    const int idx = tid + 256 * q, c = idx >> 6, rr = idx & 63;
+    buf[c * Q_RS + c + rr] = f.v[q];
+    N[(c + rr) * Q_NS + c] = f.v[q];
+  }
+  float* T = buf + QW * Q_RS;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int idx = tid + 256 * q;
+    T[(idx >> 5) * Q_RT + (idx & 31)] = f.t[q];
+  }
+}
+
+template <bool DO>
+__device__ __forceinline__ void sbr_q2_group16v3(f32x4* z, const float* buf, int vi, int g, SbrQ2Fetch& pf, const SbrQ2Args& a,
+                                                  const SbrQ2Ptr& p, int nb, int nt) {
+  const float* VgT = buf;
+  const float* T = buf + QW * Q_RS;
+  const float* N = T + QW * Q_RT;
+  if (!DO) {  // group outside the matrix: only the fetch of the next one
+    sbr_q2_fetch16v3(pf, a, p, nb, nt);
+    return;
+  }
+  f32x4 a0[5], a1[5];
+#pragma unroll
+  for (int rt = 0; rt < 5; ++rt) {
+    a0[rt] = *reinterpret_cast<const f32x4*>(VgT + vi * Q_RS + 16 * rt + 4 * g);
+    a1[rt] = *reinterpret_cast<const f32x4*>(VgT + (16 + vi) * Q_RS + 16 * (rt + 1) + 4 * g);
+  }
+  const f32x4 t00 = *reinterpret_cast<const f32x4*>(T + vi * Q_RT + 4 * g);
+  const f32x4 t01 = *reinterpret_cast<const f32x4*>(T + vi * Q_RT + 16 + 4 * g);
+  const f32x4 t11 = *reinterpret_cast<const f32x4*>(T + (16 + vi) * Q_RT + 16 + 4 * g);
+  __builtin_amdgcn_sched_barrier(0);
+  f32x4 w0 = {0.f, 0.f, 0.f, 0.f}, w1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    w0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[0][e], z[0][e], w0, 0, 0, 0);
+    w1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[0][e], z[1][e], w1, 0, 0, 0);
+  }
+  // the next group's global loads + their address arithmetic, spread over the MFMAs of this product by the scheduler
+  sbr_q2_fetch16v3(pf, a, p, nb, nt);
+#pragma unroll
+  for (int rt = 1; rt < 5; ++rt) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      w0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[rt][e], z[rt][e], w0, 0, 0, 0);
+      w1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[rt][e], z[rt + 1][e], w1, 0, 0, 0);
+    }
+  }
+  __builtin_amdgcn_sched_barrier(0);
+  // operands of the third product (row-major image): issued now, they land while the T product runs
+  f32x4 n0[5], n1[5];
+#pragma unroll
+  for (int rt = 0; rt < 5; ++rt) {
+    n0[rt] = *reinterpret_cast<const f32x4*>(N + (16 * rt + vi) * Q_NS + 4 * g);
+    n1[rt] = *reinterpret_cast<const f32x4*>(N + (16 * (rt + 1) + vi) * Q_NS + 16 + 4 * g);
+  }
+  __builtin_amdgcn_sched_barrier(0);
+  f32x4 u0 = {0.f, 0.f, 0.f, 0.f}, u1 = {0.f, 0.f, 0.f, 0.f}, u2 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    u0 = __builtin_amdgcn_mfma_f32_16x16x4f32(t00[e], w0[e], u0, 0, 0, 0);
+    u1 = __builtin_amdgcn_mfma_f32_16x16x4f32(t11[e], w1[e], u1, 0, 0, 0);
+    u2 = __builtin_amdgcn_mfma_f32_16x16x4f32(t01[e], w1[e], u2, 0, 0, 0);
+  }
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    u0[e] = -(u0[e] + u2[e]);
+    u1[e] = -u1[e];
+  }
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+#pragma unroll
+    for (int rt = 0; rt < 5; ++rt) z[rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(n0[rt][e], u0[e], z[rt], 0, 0, 0);
+#pragma unroll
+    for (int rt = 0; rt < 5; ++rt) z[rt + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(n1[rt][e], u1[e], z[rt + 1], 0, 0, 0);
   }
 }
 
@@ -1269,7 +1538,7 @@ __device__ __forceinline__ void sbr_q2_stz(float* zrow, int64_t row, int64_t n, 
   }
 }
 
-template <int QJ, int QNT>
+template <int QJ, int QNT, bool ILV>
 __global__ __launch_bounds__(256, 1) void sbr_q2_apply16(SbrQ2Args a) {
   __shared__ __attribute__((aligned(16))) float lds[2 * Q_BUF];
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, vi = lane & 15, g = lane >> 4;
@@ -1316,8 +1585,80 @@ __global__ __launch_bounds__(256, 1) void sbr_q2_apply16(SbrQ2Args a) {
         }
         sbr_q2_fetch16(pf, a, nb, nt, tid);
         const int b = bh - j;
-        if (b >= 0 && t < sbr_tasks_of((int64_t)b * QW, a.n)) sbr_q2_group16<Q_RT>(z + 2 * (QJ - 1 - j), lds + cur * Q_BUF, vi, g);
+        if (b >= 0 && t < sbr_tasks_of((int64_t)b * QW, a.n)) sbr_q2_group16<Q_RT, ILV>(z + 2 * (QJ - 1 - j), lds + cur * Q_BUF, vi, g);
         sbr_q2_stash16(pf, lds + (cur ^ 1) * Q_BUF, tid);
+        __syncthreads();
+        cur ^= 1;
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) sbr_q2_stz(zrow, base + 16 * i + 4 * g, a.n, live, z[i]);
+      if (more) {
+#pragma unroll
+        for (int i = 0; i + 4 < QNT; ++i) z[i] = z[i + 4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) z[QNT - 4 + i] = pz[i];
+      } else {
+#pragma unroll
+        for (int i = 4; i < QNT; ++i) sbr_q2_stz(zrow, base + 16 * i + 4 * g, a.n, live, z[i]);
+      }
+    }
+  }
+}
+
+template <int QJ, int QNT>
+__global__ __launch_bounds__(256, 1) void sbr_q2_apply16v3(SbrQ2Args a) {
+  __shared__ __attribute__((aligned(16))) float lds[2 * Q_BUF3];
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, vi = lane & 15, g = lane >> 4;
+  const int64_t v = (int64_t)blockIdx.x * 64 + wv * 16 + vi;
+  const bool live = v < a.m;
+  float* zrow = a.Zq + (live ? v : 0) * a.ldq + 3;
+  for (int i = tid; i < 2 * Q_BUF3; i += 256) lds[i] = 0.f;  // outside the parallelogram the images stay zero
+  __syncthreads();
+  const int nsb = (a.nblk + QJ - 1) / QJ;
+  SbrQ2Ptr p;
+  p.vstride = a.ldv2 + 1;
+  p.v = a.V2 + (int64_t)wv * p.vstride + 1 + lane;
+  p.tg = a.Tg + tid;
+  SbrQ2Fetch pf;
+  sbr_q2_fetch16v3(pf, a, p, a.nblk - 1, 0);
+  sbr_q2_stash16v3(pf, lds, tid);
+  __syncthreads();
+  int cur = 0;
+  f32x4 z[QNT];
+  for (int sb = 0; sb < nsb; ++sb) {
+    const int bh = a.nblk - 1 - sb * QJ, blow = bh - QJ + 1;
+    const int Kmax = sbr_tasks_of((int64_t)(blow > 0 ? blow : 0) * QW, a.n);
+    const int64_t base0 = (int64_t)blow * QW + 1;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the stores of the previous pass have left before rows are re-read
+#pragma unroll
+    for (int i = 0; i < QNT; ++i) z[i] = sbr_q2_ldz(zrow, base0 + 16 * i + 4 * g, a.n, live);
+    for (int t = 0; t < Kmax; ++t) {
+      const int64_t base = base0 + (int64_t)t * SB;
+      f32x4 pz[4];
+      const bool more = t + 1 < Kmax;
+      if (more) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) pz[i] = sbr_q2_ldz(zrow, base + 16 * (QNT + i) + 4 * g, a.n, live);
+      }
+#pragma unroll
+      for (int j = 0; j < QJ; ++j) {
+        int nb, nt;  // the group after this one in the sequence
+        if (j + 1 < QJ) {
+          nb = bh - (j + 1);
+          nt = t;
+        } else if (more) {
+          nb = bh;
+          nt = t + 1;
+        } else {
+          nb = bh - QJ;
+          nt = 0;
+        }
+        const int b = bh - j;
+        if (b >= 0 && t < sbr_tasks_of((int64_t)b * QW, a.n))
+          sbr_q2_group16v3<true>(z + 2 * (QJ - 1 - j), lds + cur * Q_BUF3, vi, g, pf, a, p, nb, nt);
+        else
+          sbr_q2_group16v3<false>(z + 2 * (QJ - 1 - j), lds + cur * Q_BUF3, vi, g, pf, a, p, nb, nt);
+        sbr_q2_stash16v3(pf, lds + (cur ^ 1) * Q_BUF3, tid);
         __syncthreads();
         cur ^= 1;
       }
@@ -1347,7 +1688,7 @@ __global__ void sbr_q2_shift(const float* __restrict__ in, int64_t ldi, int64_t 
 int sbr_apply_q2(Ctx* ctx, int64_t n, float* Zt, int64_t m, int64_t ldz) {
   if (m <= 0) return SCLENS_OK;
   StageTimer tm(ctx, "sbr_q2");
-  const int64_t ldv2 = round_up(n, 64), ldt = n / SB + 2;
+  const int64_t ldv2 = sbr_ldv2(n), ldt = n / SB + 2;
   const float* V2 = static_cast<const float*>(ctx->ws.count("sbr.V2") ? ctx->ws.at("sbr.V2").first : nullptr);
   const float* TAU2 = static_cast<const float*>(ctx->ws.count("sbr.TAU2") ? ctx->ws.at("sbr.TAU2").first : nullptr);
   if (!V2 || !TAU2) return ctx->fail(SCLENS_ERR_STATE, "sbr_apply_q2: no reflectors of a preceding sb2st_f32 on this context");
@@ -1382,7 +1723,14 @@ int sbr_apply_q2(Ctx* ctx, int64_t n, float* Zt, int64_t m, int64_t ldz) {
   // step of four groups instead of one per group (533 ms), 2 / 8 sweep blocks per pass (599 / 1020 ms), wave-uniform scalar
   // addressing of the group fetch (554 ms). PMC (profiles/r02_pmc_eig.txt): the MFMA pipe is busy 55 % of the wave cycles, 33 %
   // of them issue other instructions, 23 % wait at barriers / waitcnt.
-  hipLaunchKernelGGL((sbr_q2_apply16<4, 12>), dim3((unsigned)((m + 63) / 64)), dim3(256), 0, ctx->stream, qa);
+  static const int q2_variant = getenv("SCLENS_HIP_Q2_VARIANT") ? atoi(getenv("SCLENS_HIP_Q2_VARIANT")) : 3;  // A/B measurements
+  const dim3 q2grid((unsigned)((m + 63) / 64));
+  if (q2_variant == 0)
+    hipLaunchKernelGGL((sbr_q2_apply16<4, 12, false>), q2grid, dim3(256), 0, ctx->stream, qa);
+  else if (q2_variant == 1)
+    hipLaunchKernelGGL((sbr_q2_apply16<4, 12, true>), q2grid, dim3(256), 0, ctx->stream, qa);
+  else
+    hipLaunchKernelGGL((sbr_q2_apply16v3<4, 12>), q2grid, dim3(256), 0, ctx->stream, qa);
   for (int64_t r0 = 0; r0 < m; r0 += 65535) {
     const int64_t rows = (m - r0 < 65535) ? m - r0 : 65535;
     hipLaunchKernelGGL(sbr_q2_shift, dim3((unsigned)((n + 255) / 256), (unsigned)rows), dim3(256), 0, ctx->stream, Zq + r0 * ldq, ldq,

@@ -31,7 +31,8 @@ for rep in range(2):
     print(f"n={n} K={K} mvec={mvec} rep={rep} wall={wall:.3f}s", {k: round(v[0], 2) for k, v in out.items()})
 w = dw.get((n,), np.float64)
 print("gram TF/s (full 2n^2K):", 2 * n * n * K / (out["gram"][0] * 1e-3) / 1e12)
-print("sytrd algorithmic GB/s (4/3 n^3 * 4B / 2... full-matrix symv reads 4/3 n^3 B):", (4 / 3 * n**3) / (out["sytrd"][0] * 1e-3) / 1e9)
+if out["sytrd"][0] > 0:
+    print("sytrd algorithmic GB/s (4/3 n^3 * 4B / 2... full-matrix symv reads 4/3 n^3 B):", (4 / 3 * n**3) / (out["sytrd"][0] * 1e-3) / 1e9)
 print("null eig / max eig:", w[0] / w[-1], " second:", w[1] / w[-1])
 if n <= 4000:
     ref = np.linalg.eigvalsh((B.astype(np.float64) @ B.T.astype(np.float64)) / K)

@@ -39,6 +39,10 @@ def test_gemm_nt_nn(ctx, M, N, K, monkeypatch):
     assert np.abs(out - ref).max() < tol
     out2 = _gemm(ctx, P, np.ascontiguousarray(Qn.T), C0, 0.5, 2.0, 0)
     assert np.abs(out2 - ref).max() < tol
+    # C += P Q' (alpha = beta = 1): the large-tile kernels start their accumulators from C
+    ref1 = P.astype(np.float64) @ Qn.T.astype(np.float64) + C0
+    out3 = _gemm(ctx, P, Qn, C0, 1.0, 1.0, 1)
+    assert np.abs(out3 - ref1).max() < 2e-6 * np.sqrt(K) * np.abs(ref1).max() + 1e-5
 
 
 def test_gemm_asymmetric_identity(ctx):
@@ -65,6 +69,9 @@ def test_gemm_lower_mirror_and_absmax(ctx, n, K, big, monkeypatch):
     out = _gemm(ctx, PQ, QP, C0, -1.0, 1.0, 1, lower=1)
     assert np.array_equal(out, out.T), "lower+mirror must give an exactly symmetric matrix"
     assert np.abs(out - ref).max() < 1e-4 * np.abs(ref).max()
+    out1 = _gemm(ctx, PQ, -QP, C0, 1.0, 1.0, 1, lower=1)  # the form the band reduction uses (negated operand, alpha = beta = 1)
+    assert np.array_equal(out1, out1.T)
+    assert np.abs(out1 - ref).max() < 1e-4 * np.abs(ref).max()
     am = _gemm(ctx, P, Q, np.zeros((n, n), np.float32), 1.0, 0.0, 1, absmax=True)
     refm = np.abs(P.astype(np.float64) @ Q.T.astype(np.float64)).max(axis=0)
     assert np.abs(am - refm).max() < 1e-4 * refm.max()
