@@ -63,6 +63,12 @@ int sclens_hip_symv_probe(sclens_hip_ctx* ctx, int64_t n, int64_t* launches, dou
  * (SCLENS_HIP_TWO_STAGE_MIN_N) upwards. "gram_bits" (-1 / 0 / 1): the Gram matrices of the binarised search matrices and the
  * search statistic on the fp16 MFMA with exact / split operands (gram_bits.hip); -1 = from n = 16 000 (SCLENS_HIP_GRAM_BITS_MIN_N). */
 int sclens_hip_set_option(sclens_hip_ctx* ctx, const char* name, int64_t value);
+/* Device memory of the library is pooled per device: the sessions, worker sessions and contexts of successive sclens() calls ask for
+ * the same block sizes, so freed blocks are kept and handed out again instead of going through hipFree / hipMalloc (about 2 s per
+ * call at 100 000 x 30 000). sclens_hip_trim gives the idle blocks back to the driver (device_id < 0: every device);
+ * SCLENS_HIP_POOL=0 disables pooling, SCLENS_HIP_POOL_MAX_GB caps the idle bytes kept per device (default 160). */
+int sclens_hip_trim(int device_id);
+int sclens_hip_pool_stats(int device_id, int64_t* cached_bytes, int64_t* live_bytes, int64_t* hits, int64_t* misses);
 /* raw stream handle (hipStream_t) so a host framework can order its own work after ours */
 void* sclens_hip_stream(sclens_hip_ctx* ctx);
 

@@ -37,6 +37,8 @@ SIGNATURES = {
     "sclens_hip_reset_timing": (C.c_int, [vp]),
     "sclens_hip_set_option": (C.c_int, [vp, C.c_char_p, i64]),
     "sclens_hip_stream": (vp, [vp]),
+    "sclens_hip_trim": (C.c_int, [C.c_int]),
+    "sclens_hip_pool_stats": (C.c_int, [C.c_int, c_i64p, c_i64p, c_i64p, c_i64p]),
     "sclens_hip_symv_probe": (C.c_int, [vp, i64, c_i64p, c_f64p, c_f64p]),
     "sclens_hip_symv_profile": (C.c_int, [vp, C.c_int]),
     "sclens_hip_symv_profile_read": (C.c_int, [vp, c_i64p, c_f64p, c_f64p]),

@@ -467,11 +467,24 @@ int sclens_hip_dev_eigh_f32(sclens_hip_ctx* h, float* A, int64_t n, int64_t lda,
   CTX_GUARD(h);
   return scl::eigh_f32(&h->c, A, n, lda, w, vec_lo, vec_hi, Zt, ldz);
 }
+int sclens_hip_trim(int device_id) {
+  scl::pool_trim(device_id);
+  return SCLENS_OK;
+}
+int sclens_hip_pool_stats(int device_id, int64_t* cached_bytes, int64_t* live_bytes, int64_t* hits, int64_t* misses) {
+  size_t c = 0, l = 0, h = 0, m = 0;
+  scl::pool_stats(device_id, &c, &l, &h, &m);
+  if (cached_bytes) *cached_bytes = (int64_t)c;
+  if (live_bytes) *live_bytes = (int64_t)l;
+  if (hits) *hits = (int64_t)h;
+  if (misses) *misses = (int64_t)m;
+  return SCLENS_OK;
+}
 void* sclens_hip_dev_malloc(sclens_hip_ctx* h, int64_t bytes) {
   if (!h || bytes < 0) return nullptr;
   hipSetDevice(h->c.device);
   void* p = nullptr;
-  if (hipMalloc(&p, bytes > 0 ? (size_t)bytes : 16) != hipSuccess) {
+  if (scl::pool_malloc(&p, bytes > 0 ? (size_t)bytes : 16) != hipSuccess) {
     h->c.fail(SCLENS_ERR_OOM, "dev_malloc failed");
     return nullptr;
   }
@@ -480,8 +493,7 @@ void* sclens_hip_dev_malloc(sclens_hip_ctx* h, int64_t bytes) {
 void sclens_hip_dev_free(sclens_hip_ctx* h, void* p) {
   if (!h || !p) return;
   hipSetDevice(h->c.device);
-  hipStreamSynchronize(h->c.stream);
-  hipFree(p);
+  scl::pool_free(p, h->c.stream);
 }
 int sclens_hip_dev_memcpy(sclens_hip_ctx* h, void* dst, const void* src, int64_t bytes, int kind) {
   CTX_GUARD(h);

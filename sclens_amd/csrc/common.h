@@ -101,6 +101,14 @@ struct StageTimer {  // HIP-event timing of one stage on ctx->stream (only when 
 
 static inline int64_t round_up(int64_t x, int64_t m) { return (x + m - 1) / m * m; }
 
+// ------------------------------------------------------------------ device memory pool (pool.hip)
+// every device allocation of the library; `stream` = the stream whose pending work may still touch the block (synchronised
+// before the block can be handed to another owner; nullptr: the caller has synchronised already)
+hipError_t pool_malloc(void** p, size_t bytes);
+void pool_free(void* p, hipStream_t stream);
+void pool_trim(int device);  // give cached blocks back to the driver (device < 0: all devices)
+void pool_stats(int device, size_t* cached, size_t* live, size_t* hits, size_t* misses);
+
 // raise a kernel's dynamic-LDS limit once per context (= per device; a process-wide `static` would cover only the first device)
 static inline int ensure_dyn_lds(Ctx* ctx, const void* fn, int bytes) {
   auto it = ctx->lds_attr.find(fn);

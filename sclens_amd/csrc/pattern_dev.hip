@@ -20,13 +20,15 @@ namespace {
 
 struct DevTmp {  // temporaries of one build, freed on every exit path
   std::vector<void*> p;
+  hipStream_t stream = nullptr;  // the building context's stream (set by the first get)
   ~DevTmp() {
-    for (void* q : p) hipFree(q);
+    for (void* q : p) pool_free(q, stream);
   }
   template <typename T>
   T* get(Ctx* ctx, size_t count) {
     void* q = nullptr;
-    if (hipMalloc(&q, std::max<size_t>(sizeof(T) * count, 16)) != hipSuccess) {
+    stream = ctx->stream;
+    if (pool_malloc(&q, std::max<size_t>(sizeof(T) * count, 16)) != hipSuccess) {
       ctx->fail(SCLENS_ERR_OOM, "pattern_build_device: out of device memory");
       return nullptr;
     }
@@ -38,7 +40,7 @@ struct DevTmp {  // temporaries of one build, freed on every exit path
 template <typename T>
 T* keep(Ctx* ctx, PatternOwner* o, size_t count) {
   void* q = nullptr;
-  if (hipMalloc(&q, std::max<size_t>(sizeof(T) * count, 16)) != hipSuccess) {
+  if (pool_malloc(&q, std::max<size_t>(sizeof(T) * count, 16)) != hipSuccess) {
     ctx->fail(SCLENS_ERR_OOM, "pattern_build_device: out of device memory");
     return nullptr;
   }

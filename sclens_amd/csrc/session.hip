@@ -18,13 +18,12 @@ void* Ctx::workspace(const std::string& name, size_t bytes) {
   auto it = ws.find(name);
   if (it != ws.end() && it->second.second >= bytes) return it->second.first;
   if (it != ws.end()) {
-    hipStreamSynchronize(stream);
-    hipFree(it->second.first);
+    pool_free(it->second.first, stream);
     ws.erase(it);
   }
   if (bytes == 0) bytes = 16;
   void* p = nullptr;
-  hipError_t e = hipMalloc(&p, bytes);
+  hipError_t e = pool_malloc(&p, bytes);
   if (e != hipSuccess) {
     fail(SCLENS_ERR_OOM, "hipMalloc(" + name + ", " + std::to_string(bytes) + " B): " + hipGetErrorString(e));
     return nullptr;
@@ -35,14 +34,13 @@ void* Ctx::workspace(const std::string& name, size_t bytes) {
 void Ctx::release(const std::string& name) {
   auto it = ws.find(name);
   if (it != ws.end()) {
-    hipStreamSynchronize(stream);
-    hipFree(it->second.first);
+    pool_free(it->second.first, stream);
     ws.erase(it);
   }
 }
 void Ctx::release_all() {
   if (stream) hipStreamSynchronize(stream);
-  for (auto& kv : ws) hipFree(kv.second.first);
+  for (auto& kv : ws) pool_free(kv.second.first, nullptr);
   ws.clear();
 }
 
@@ -106,7 +104,7 @@ template <typename T>
 static int upload(Ctx* ctx, PatternOwner* o, const std::vector<T>& h, const T** dev) {
   void* p = nullptr;
   const size_t bytes = std::max<size_t>(16, h.size() * sizeof(T));
-  hipError_t e = hipMalloc(&p, bytes);
+  hipError_t e = pool_malloc(&p, bytes);
   if (e != hipSuccess) return ctx->fail(SCLENS_ERR_OOM, std::string("pattern upload: ") + hipGetErrorString(e));
   o->allocs.push_back(p);
   // on the context's own stream (pattern_build synchronises it before the host vectors die): a pattern may be built
@@ -148,7 +146,7 @@ int pattern_build(Ctx* ctx, int64_t N, int64_t M, const int64_t* colptr, const i
   return SCLENS_OK;
 }
 void pattern_free(PatternOwner* p) {
-  for (void* q : p->allocs) hipFree(q);
+  for (void* q : p->allocs) pool_free(q, nullptr);  // contract: no session uses the pattern any more (blocking API: its streams are idle)
   p->allocs.clear();
   p->dev = PatternDev();
   p->base_val = nullptr;
@@ -208,7 +206,7 @@ struct Session {
   std::vector<void*> allocs;
 
   int dmalloc(void** p, size_t bytes) {
-    hipError_t e = hipMalloc(p, std::max<size_t>(bytes, 16));
+    hipError_t e = pool_malloc(p, std::max<size_t>(bytes, 16));
     if (e != hipSuccess) return ctx->fail(SCLENS_ERR_OOM, std::string("session hipMalloc: ") + hipGetErrorString(e));
     allocs.push_back(*p);
     return SCLENS_OK;
@@ -264,7 +262,7 @@ int session_create(Ctx* ctx, int64_t N, int64_t M, const int64_t* colptr, const 
   s->lda = round_up(s->n, 32);
   s->ldz = round_up(s->n, 32);
   s->ldn = round_up(N, 32);
-  auto fail = [&](int code) { pattern_free(&s->pat); for (void* p : s->allocs) hipFree(p); delete s; return code; };
+  auto fail = [&](int code) { pattern_free(&s->pat); for (void* p : s->allocs) pool_free(p, s->ctx->stream); delete s; return code; };
   if ((rc = s->dmalloc((void**)&s->val, sizeof(float) * s->pat.dev.nU)) != SCLENS_OK) return fail(rc);
   if ((rc = s->dmalloc((void**)&s->Bmain, sizeof(float) * (size_t)s->n * s->ldb)) != SCLENS_OK) return fail(rc);
   if ((rc = s->dmalloc((void**)&s->Btmp, sizeof(float) * (size_t)s->n * s->ldb)) != SCLENS_OK) return fail(rc);
@@ -364,7 +362,7 @@ int session_create_sharded(Ctx* ctx, int64_t N_global, int64_t row0, int64_t N_l
   s->lda = round_up(s->n, 32);
   s->ldz = round_up(s->n, 32);
   s->ldn = round_up(N_local, 32);
-  auto fail = [&](int code) { pattern_free(&s->pat); for (void* p : s->allocs) hipFree(p); delete s; return code; };
+  auto fail = [&](int code) { pattern_free(&s->pat); for (void* p : s->allocs) pool_free(p, s->ctx->stream); delete s; return code; };
   if ((rc = s->dmalloc((void**)&s->val, sizeof(float) * s->pat.dev.nU)) != SCLENS_OK) return fail(rc);
   if ((rc = s->dmalloc((void**)&s->Bmain, sizeof(float) * (size_t)s->n * s->ldb)) != SCLENS_OK) return fail(rc);
   if ((rc = s->dmalloc((void**)&s->Btmp, sizeof(float) * (size_t)s->n * s->ldb)) != SCLENS_OK) return fail(rc);
@@ -404,7 +402,7 @@ int session_clone(Ctx* ctx2, Session* src, Session** out) {
   s->Z0t = src->Z0t; s->theta0 = src->theta0; s->b0 = src->b0; s->use_chefsi = src->use_chefsi;
   s->k = src->k;
   int rc;
-  auto fail = [&](int code) { for (void* p : s->allocs) hipFree(p); delete s; return code; };
+  auto fail = [&](int code) { for (void* p : s->allocs) pool_free(p, s->ctx->stream); delete s; return code; };
   if ((rc = s->dmalloc((void**)&s->val, sizeof(float) * s->pat.dev.nU)) != SCLENS_OK) return fail(rc);
   if ((rc = s->dmalloc((void**)&s->Btmp, sizeof(float) * (size_t)s->n * s->ldb)) != SCLENS_OK) return fail(rc);
   if ((rc = s->dmalloc((void**)&s->A, sizeof(float) * (size_t)s->n * s->lda)) != SCLENS_OK) return fail(rc);
@@ -419,7 +417,7 @@ void session_destroy(Session* s) {
   hipStreamSynchronize(s->ctx->stream);
   s->ctx->live_sessions -= 1;
   pattern_free(&s->pat);
-  for (void* p : s->allocs) hipFree(p);
+  for (void* p : s->allocs) pool_free(p, nullptr);  // the stream has just been synchronised
   delete s;
 }
 
@@ -512,7 +510,7 @@ static int session_realloc_val(Session* s) {
   if (s->val) {
     auto it = std::find(s->allocs.begin(), s->allocs.end(), (void*)s->val);
     if (it != s->allocs.end()) s->allocs.erase(it);
-    hipFree(s->val);
+    pool_free(s->val, s->ctx->stream);
     s->val = nullptr;
   }
   return s->dmalloc((void**)&s->val, sizeof(float) * (size_t)s->pat.dev.nU);
