@@ -98,6 +98,19 @@ int sclens_hip_preprocess_csc(sclens_hip_ctx* ctx, int64_t N, int64_t M, const i
                               double ribo_percent, uint8_t* keep_cell, int64_t* gene_order, int64_t* n_cells,
                               int64_t* n_genes, int64_t* nnz_out);
 int sclens_hip_preprocess_gather(sclens_hip_ctx* ctx, int64_t* out_colptr, int32_t* out_rowval, float* out_nzval);
+/* Call 2': the filtered matrix STAYS IN HBM as a count-matrix handle (what df2sparr(pre_df) is to the reference, scLENS.jl:90-120,
+ * :662) instead of travelling to the host and back: sessions and patterns are built from it in place
+ * (sclens_hip_session_create_from_counts, sclens_hip_pattern_create_drawn_from_counts). sclens_hip_counts_upload makes the same
+ * handle from host arrays; sclens_hip_counts_download copies any of the three arrays back (NULL = skip), e.g. colptr + nzval for
+ * a host that draws the null matrix itself (sclens_draw_null_matrix needs no row indices). A handle may be used by every
+ * context of its device; destroy it after the sessions / pattern builds that read it. */
+typedef struct sclens_hip_counts sclens_hip_counts;
+int sclens_hip_preprocess_keep(sclens_hip_ctx* ctx, sclens_hip_counts** out);
+int sclens_hip_counts_upload(sclens_hip_ctx* ctx, int64_t N, int64_t M, const int64_t* colptr, const int32_t* rowval,
+                             const float* nzval, sclens_hip_counts** out);
+int sclens_hip_counts_info(const sclens_hip_counts* counts, int64_t* N, int64_t* M, int64_t* nnz);
+int sclens_hip_counts_download(sclens_hip_ctx* ctx, const sclens_hip_counts* counts, int64_t* colptr, int32_t* rowval, float* nzval);
+void sclens_hip_counts_destroy(sclens_hip_counts* counts);
 
 /* logn_scale(pre_scale(x))  (scLENS.jl:650-654: proj_l :607 -> log1p -> zscore_with_l2 :596-605 -> scaled_gdata "cent"
  * :300-305 for centering="mean"; scaled_gdata "median" :291-298 -> norm_l :608 for centering="median") and, with
@@ -164,6 +177,9 @@ int sclens_sample_without_replacement(uint64_t len, int64_t m, uint64_t seed, ui
 /* ---------------------------------------------------------------- (B) device-resident session -- */
 /* all-reduce supplied by the host for row-sharded sessions (see sclens_hip_session_create_sharded) */
 typedef int (*sclens_hip_allreduce_fn)(void* user, void* dev_ptr, int64_t count, int dtype /*0 fp64, 1 fp32*/);
+/* optional companion: the sum lands on rank `root` only (the other ranks' buffers are then undefined); see
+ * sclens_hip_session_set_reduce_to and the *_round calls of a row-sharded session */
+typedef int (*sclens_hip_reduce_fn)(void* user, void* dev_ptr, int64_t count, int dtype, int root);
 
 /* Count matrix (what df2sparr(inp_df) returns, scLENS.jl:662) + the zero-candidate list
  * (z_idx1, z_idx2 of scLENS.jl:668-673, 0-based, disjoint from the stored entries, unique). */
@@ -193,6 +209,38 @@ int sclens_hip_session_create_sharded(sclens_hip_ctx* ctx, int64_t N_global, int
                                       const uint32_t* z_idx1, const uint32_t* z_idx2, sclens_hip_allreduce_fn allreduce,
                                       void* user, sclens_hip_session** out);
 int sclens_hip_session_set_reducer(sclens_hip_session* s, sclens_hip_allreduce_fn allreduce, void* user);
+int sclens_hip_session_set_reduce_to(sclens_hip_session* s, sclens_hip_reduce_fn reduce, void* user);
+
+/* Row-sharded session whose zero candidates are LOCAL: this rank draws, on the device, its own part of the global draw sequence
+ * R1 (scLENS.jl:668-673; draw t is a pure function of (seed, t), so the pairs that land in the cells [row0, row0 + N_local) are
+ * found without the other ranks) from nnz_global = the stored entries of the WHOLE matrix. *n_cand_local = the length of this
+ * rank's list. The global candidate list that the samples of the search / the ensemble index is the concatenation of the ranks'
+ * lists in rank order: the host all-gathers the counts (a handful of integers) and tells every session its window with
+ * sclens_hip_session_set_candidate_range(cand_off = sum of the counts of the lower ranks, n_cand_global = their total).
+ * No rank ever holds another rank's candidates (1M x 30k on 8 GPUs: 2.6 GB of list + slots per rank instead of 21 GB). */
+int sclens_hip_session_create_sharded_drawn(sclens_hip_ctx* ctx, int64_t N_global, int64_t row0, int64_t N_local, int64_t M,
+                                            const int64_t* colptr, const int32_t* rowval, const float* nzval,
+                                            int64_t nnz_global, uint64_t seed, sclens_hip_allreduce_fn allreduce, void* user,
+                                            sclens_hip_session** out, int64_t* n_cand_local);
+int sclens_hip_session_set_candidate_range(sclens_hip_session* s, int64_t cand_off, int64_t n_cand_global);
+/* Local candidate list of such a session (z1 = GLOBAL cell indices, z2 = genes; n_cand_local entries each): tests / hosts
+ * that want to replay the run unsharded. */
+int sclens_hip_session_local_candidates(sclens_hip_session* s, uint32_t* z1, uint32_t* z2);
+
+/* One ROUND of the sparsity search of a row-sharded session (scLENS.jl:725-761 evaluated `count` sparsities at a time, SURVEY
+ * 8e-ii + 8e-iii): for evaluation e (sample seeds[e] of m[e] candidates) every rank forms its partial Gram matrix, which is summed
+ * onto rank roots[e] ONLY (sclens_hip_session_set_reduce_to; all-reduce otherwise); after the last one every rank decomposes the
+ * evaluation it is the root of (my_slot = its index in the round, -1: none) -- the eigensolves of a round run in parallel on
+ * different GPUs instead of replicated on all. d5 / r_it receive the statistics of evaluation my_slot. All ranks make the call
+ * with the same seeds / m / roots. */
+int sclens_hip_session_search_round_seeded(sclens_hip_session* s, const uint64_t* seeds, const int64_t* m, const int32_t* roots,
+                                           int count, int my_slot, int64_t n_2, double* d5, int64_t* r_it);
+/* The same for the perturbation ensemble (scLENS.jl:771-778): members t[e] (slots), eigen-solve of member e on rank roots[e],
+ * whose leading gene-side vectors are then shared (summed from one rank) so that every rank recovers ITS cells of the member's
+ * cell-side vectors. nL_top: count x min_pc, ncols: count (identical on every rank). */
+int sclens_hip_session_perturb_round_seeded(sclens_hip_session* s, const int64_t* t, const uint64_t* seeds, const int64_t* m,
+                                            const int32_t* roots, int count, int my_slot, int64_t min_pc, double* nL_top,
+                                            int64_t* ncols);
 
 /* Late candidate attachment. The data / null / binarised decompositions (scLENS.jl:676-721) do not involve the zero
  * candidates, so a session may be created with n_cand = 0 and start them at once, while the host still draws the
@@ -216,6 +264,11 @@ int sclens_hip_pattern_candidates(sclens_hip_ctx* ctx, sclens_hip_pattern* p, ui
 int sclens_hip_pattern_download(sclens_hip_ctx* ctx, sclens_hip_pattern* p, int which, void* dst);
 void sclens_hip_pattern_destroy(sclens_hip_pattern* p);
 int sclens_hip_session_set_pattern(sclens_hip_session* s, sclens_hip_pattern* p);
+/* The same two constructors from a device-resident count matrix (no upload): a counts-only session, and the union pattern with the
+ * zero candidates drawn on the device. */
+int sclens_hip_session_create_from_counts(sclens_hip_ctx* ctx, const sclens_hip_counts* counts, sclens_hip_session** out);
+int sclens_hip_pattern_create_drawn_from_counts(sclens_hip_ctx* ctx, const sclens_hip_counts* counts, uint64_t seed,
+                                                sclens_hip_pattern** out, int64_t* n_cand);
 
 /* First half of get_sigev (scLENS.jl:526-537, :569-576): eigenvalues (ascending, length min(N,M)) of the
  * Gram matrix of the scaled data (L) and of the scaled null matrix X_r (Lr; CSC, same shape).
@@ -313,6 +366,8 @@ int sclens_hip_comm_broadcast_host(sclens_hip_comm* comm, void* buf, int64_t nby
 /* an sclens_hip_allreduce_fn whose `user` is the communicator: pass (sclens_hip_comm_allreduce_cb, comm) to
  * sclens_hip_session_create_sharded / _set_reducer and the row-sharded session reduces over RCCL with no host callback */
 int sclens_hip_comm_allreduce_cb(void* user, void* dev_ptr, int64_t count, int dtype);
+/* an sclens_hip_reduce_fn (ncclReduce onto rank `root`) with user = the communicator */
+int sclens_hip_comm_reduce_cb(void* user, void* dev_ptr, int64_t count, int dtype, int root);
 
 /* ---------------------------------------------------------------- device-level entry points ---- */
 /* Used by the repository's own tests and bench.py (device pointers, row-major; see csrc/common.h). */

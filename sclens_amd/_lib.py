@@ -24,6 +24,8 @@ c_u32p = C.POINTER(C.c_uint32)
 vp = C.c_void_p
 # int allreduce(void* user, void* dev_ptr, int64_t count, int dtype): see sclens_hip_session_create_sharded
 ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_int)
+# int reduce(void* user, void* dev_ptr, int64_t count, int dtype, int root): the sum lands on `root` only
+REDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int)
 i64 = C.c_int64
 
 # name -> (restype, argtypes); every symbol declared in include/sclens_hip.h
@@ -54,9 +56,24 @@ SIGNATURES = {
                                             C.c_double, i64, i64, i64, C.c_double, C.c_double, c_u8p, c_i64p, c_i64p, c_i64p,
                                             c_i64p]),
     "sclens_hip_preprocess_gather": (C.c_int, [vp, c_i64p, c_i32p, c_f32p]),
+    "sclens_hip_preprocess_keep": (C.c_int, [vp, C.POINTER(vp)]),
+    "sclens_hip_counts_upload": (C.c_int, [vp, i64, i64, c_i64p, c_i32p, c_f32p, C.POINTER(vp)]),
+    "sclens_hip_counts_info": (C.c_int, [vp, c_i64p, c_i64p, c_i64p]),
+    "sclens_hip_counts_download": (C.c_int, [vp, vp, c_i64p, c_i32p, c_f32p]),
+    "sclens_hip_counts_destroy": (None, [vp]),
+    "sclens_hip_session_create_from_counts": (C.c_int, [vp, vp, C.POINTER(vp)]),
+    "sclens_hip_pattern_create_drawn_from_counts": (C.c_int, [vp, vp, C.c_uint64, C.POINTER(vp), c_i64p]),
     "sclens_hip_session_create_sharded": (C.c_int, [vp, i64, i64, i64, i64, c_i64p, c_i32p, c_f32p, i64, c_u32p, c_u32p, ALLREDUCE_FN,
                                                     vp, C.POINTER(vp)]),
     "sclens_hip_session_set_reducer": (C.c_int, [vp, ALLREDUCE_FN, vp]),
+    "sclens_hip_session_set_reduce_to": (C.c_int, [vp, REDUCE_FN, vp]),
+    "sclens_hip_session_create_sharded_drawn": (C.c_int, [vp, i64, i64, i64, i64, c_i64p, c_i32p, c_f32p, i64, C.c_uint64, ALLREDUCE_FN, vp,
+                                                          C.POINTER(vp), c_i64p]),
+    "sclens_hip_session_set_candidate_range": (C.c_int, [vp, i64, i64]),
+    "sclens_hip_session_local_candidates": (C.c_int, [vp, c_u32p, c_u32p]),
+    "sclens_hip_session_search_round_seeded": (C.c_int, [vp, C.POINTER(C.c_uint64), c_i64p, c_i32p, C.c_int, C.c_int, i64, c_f64p, c_i64p]),
+    "sclens_hip_session_perturb_round_seeded": (C.c_int, [vp, c_i64p, C.POINTER(C.c_uint64), c_i64p, c_i32p, C.c_int, C.c_int, i64, c_f64p,
+                                                          c_i64p]),
     "sclens_hip_session_shared_buffer": (C.c_int, [vp, C.c_int, i64, i64, c_f64p, C.POINTER(vp), c_i64p, c_i64p, c_i64p]),
     "sclens_hip_pattern_create": (C.c_int, [vp, i64, i64, c_i64p, c_i32p, c_f32p, i64, c_u32p, c_u32p, C.POINTER(vp)]),
     "sclens_hip_pattern_create_drawn": (C.c_int, [vp, i64, i64, c_i64p, c_i32p, c_f32p, C.c_uint64, C.POINTER(vp), c_i64p]),
@@ -108,6 +125,7 @@ SIGNATURES = {
     "sclens_hip_comm_allgather_host": (C.c_int, [vp, vp, vp, i64]),
     "sclens_hip_comm_broadcast_host": (C.c_int, [vp, vp, i64, C.c_int]),
     "sclens_hip_comm_allreduce_cb": (C.c_int, [vp, vp, i64, C.c_int]),
+    "sclens_hip_comm_reduce_cb": (C.c_int, [vp, vp, i64, C.c_int, C.c_int]),
     "sclens_hip_dev_gemm_f32": (C.c_int, [vp, vp, vp, vp, i64, i64, i64, i64, i64, i64, C.c_float, C.c_float, C.c_int, C.c_int, vp]),
     "sclens_hip_dev_gram_f32": (C.c_int, [vp, vp, i64, i64, i64, C.c_float, vp, i64]),
     "sclens_hip_dev_sy2sb_f32": (C.c_int, [vp, vp, i64, i64, vp, C.POINTER(C.c_int)]),
@@ -262,6 +280,10 @@ class Comm:
         RCCL call made by the library itself"""
         fn = C.cast(self.lib.sclens_hip_comm_allreduce_cb, ALLREDUCE_FN)
         return fn, self.h
+
+    def reducer_to(self):
+        """(function pointer, user pointer) of the sum onto ONE rank (ncclReduce): Session.set_reduce_to"""
+        return C.cast(self.lib.sclens_hip_comm_reduce_cb, REDUCE_FN), self.h
 
     def allreduce(self, dev_ptr: int, count: int, dtype: int):
         self.check(self.lib.sclens_hip_comm_allreduce(self.h, vp(dev_ptr), int(count), int(dtype)))

@@ -99,10 +99,11 @@ def get_eigvec(X, device="gpu", keep_top: int = 0, ctx: Optional[Context] = None
 
 def preprocess(X, gene_names, cell_names=None, min_tp_c=0, min_tp_g=0, max_tp_c=np.inf, max_tp_g=np.inf,
                min_genes_per_cell=200, max_genes_per_cell=0, min_cells_per_gene=15, mito_percent=5.0, ribo_percent=0.0,
-               ctx: Optional[Context] = None):
+               ctx: Optional[Context] = None, keep_on_device: bool = False):
     """scLENS.preprocess (scLENS.jl:160-236) on the device: QC-filter a raw cells x genes count matrix. Same keyword
     arguments and defaults as the reference. Returns (filtered CSC float32 with genes sorted by mean count, gene names,
-    cell names or indices) or None when no cell or gene passes (the reference prints a message and returns nothing)."""
+    cell names or indices) or None when no cell or gene passes (the reference prints a message and returns nothing).
+    `keep_on_device=True`: the first item is a `DeviceCounts` handle (the matrix stays in HBM) that `sclens()` accepts directly."""
     import re
 
     ctx = ctx or default_context()
@@ -127,6 +128,11 @@ def preprocess(X, gene_names, cell_names=None, min_tp_c=0, min_tp_g=0, max_tp_c=
         ptr(keep_cell, C.c_uint8), ptr(order, C.c_int64), C.byref(nc), C.byref(ng), C.byref(nnz)))
     if nc.value == 0 or ng.value == 0:
         return None
+    cells = np.flatnonzero(keep_cell)
+    if keep_on_device:  # the filtered matrix stays in HBM; sclens() takes the handle as it takes a matrix
+        h = C.c_void_p()
+        ctx.check(ctx.lib.sclens_hip_preprocess_keep(ctx.h, C.byref(h)))
+        return DeviceCounts(ctx, h), names[order[: ng.value]], (np.asarray(cell_names)[cells] if cell_names is not None else cells)
     out_colptr = np.empty(ng.value + 1, dtype=np.int64)
     out_row = np.empty(nnz.value, dtype=np.int32)
     out_val = np.empty(nnz.value, dtype=np.float32)
@@ -134,7 +140,6 @@ def preprocess(X, gene_names, cell_names=None, min_tp_c=0, min_tp_g=0, max_tp_c=
                                                    ptr(out_val, C.c_float)))
     Xo = sp.csc_matrix((out_val, out_row, out_colptr), shape=(nc.value, ng.value))
     Xo._sclens_canonical = True  # sorted rows, no explicit zeros, float32
-    cells = np.flatnonzero(keep_cell)
     return Xo, names[order[: ng.value]], (np.asarray(cell_names)[cells] if cell_names is not None else cells)
 
 
@@ -383,15 +388,24 @@ def make_draws_native(X, seed: int, host_sampler: bool = False, async_null: bool
     the quantity scLENS.jl:709-712 estimates with 5000 Monte-Carlo trials -- and the device-side keyed permutation
     for R4/R5). `host_sampler=True` materialises the identical R4/R5 index vectors on the host instead."""
     lib = _lib.load()
-    X = _csc_f32(X)
-    N, M = X.shape
-    cp = np.ascontiguousarray(X.indptr, dtype=np.int64)
-    rv = np.ascontiguousarray(X.indices, dtype=np.int32)
-    nz = np.ascontiguousarray(X.data, dtype=np.float32)
+    if isinstance(X, DeviceCounts):
+        # the matrix is in HBM: R1 is drawn there; the host null-matrix generator (R2) needs the gene counts and the values only
+        if not device_candidates and not async_candidates:
+            device_candidates = True
+        N, M = X.shape
+        cp, rv, nz = X.download(rowval=not device_candidates)
+        nnz_total = X.nnz
+    else:
+        X = _csc_f32(X)
+        N, M = X.shape
+        cp = np.ascontiguousarray(X.indptr, dtype=np.int64)
+        rv = np.ascontiguousarray(X.indices, dtype=np.int32)
+        nz = np.ascontiguousarray(X.data, dtype=np.float32)
+        nnz_total = X.nnz
 
     def candidates():
-        z1 = np.empty(X.nnz, dtype=np.uint32)
-        z2 = np.empty(X.nnz, dtype=np.uint32)
+        z1 = np.empty(nnz_total, dtype=np.uint32)
+        z2 = np.empty(nnz_total, dtype=np.uint32)
         cnt = C.c_int64(0)
         rc = lib.sclens_draw_zero_candidates(N, M, ptr(cp, C.c_int64), ptr(rv, C.c_int32), int(seed) & _M64,
                                              ptr(z1, C.c_uint32), ptr(z2, C.c_uint32), C.byref(cnt))
@@ -410,8 +424,8 @@ def make_draws_native(X, seed: int, host_sampler: bool = False, async_null: bool
         z1, z2 = candidates()
 
     def null_matrix():
-        rrow = np.empty(X.nnz, dtype=np.int32)
-        rval = np.empty(X.nnz, dtype=np.float32)
+        rrow = np.empty(nnz_total, dtype=np.int32)
+        rval = np.empty(nnz_total, dtype=np.float32)
         rc2 = lib.sclens_draw_null_matrix(N, M, ptr(cp, C.c_int64), ptr(nz, C.c_float), (int(seed) + 1) & _M64,
                                           ptr(rrow, C.c_int32), ptr(rval, C.c_float))
         if rc2:
@@ -447,6 +461,62 @@ def make_draws(X, seed: int, p_th_trials: int = 5000) -> Draws:
 
 
 # ----------------------------------------------------------------------------- session wrapper
+class DeviceCounts:
+    """sclens_hip_counts: a cells x genes count matrix (CSC) that lives in HBM -- what `preprocess(..., keep_on_device=True)`
+    returns instead of a scipy matrix, or `DeviceCounts.upload(ctx, X)`. `sclens()` builds its session and its union pattern
+    from it in place (no host round trip between the QC filter and the session)."""
+
+    def __init__(self, ctx: Context, handle):
+        self.ctx, self.h = ctx, handle
+        n, m, z = C.c_int64(0), C.c_int64(0), C.c_int64(0)
+        ctx.check(ctx.lib.sclens_hip_counts_info(handle, C.byref(n), C.byref(m), C.byref(z)))
+        self.shape, self.nnz = (n.value, m.value), z.value
+        self._host = {}
+
+    @classmethod
+    def upload(cls, ctx: Context, X) -> "DeviceCounts":
+        X = _csc_f32(X)
+        cp = np.ascontiguousarray(X.indptr, dtype=np.int64)
+        rv = np.ascontiguousarray(X.indices, dtype=np.int32)
+        nz = np.ascontiguousarray(X.data, dtype=np.float32)
+        h = C.c_void_p()
+        ctx.check(ctx.lib.sclens_hip_counts_upload(ctx.h, X.shape[0], X.shape[1], ptr(cp, C.c_int64), ptr(rv, C.c_int32),
+                                                   ptr(nz, C.c_float), C.byref(h)))
+        return cls(ctx, h)
+
+    def download(self, colptr=True, rowval=True, nzval=True):
+        """host copies of the requested arrays (cached): (colptr, rowval, nzval), None where not requested"""
+        want = {"colptr": colptr, "rowval": rowval, "nzval": nzval}
+        need = [k for k, w in want.items() if w and k not in self._host]
+        if need:
+            bufs = {"colptr": np.empty(self.shape[1] + 1, dtype=np.int64) if "colptr" in need else None,
+                    "rowval": np.empty(self.nnz, dtype=np.int32) if "rowval" in need else None,
+                    "nzval": np.empty(self.nnz, dtype=np.float32) if "nzval" in need else None}
+            self.ctx.check(self.ctx.lib.sclens_hip_counts_download(
+                self.ctx.h, self.h, ptr(bufs["colptr"], C.c_int64) if bufs["colptr"] is not None else None,
+                ptr(bufs["rowval"], C.c_int32) if bufs["rowval"] is not None else None,
+                ptr(bufs["nzval"], C.c_float) if bufs["nzval"] is not None else None))
+            self._host.update({k: v for k, v in bufs.items() if v is not None})
+        return tuple(self._host.get(k) if want[k] else None for k in ("colptr", "rowval", "nzval"))
+
+    def to_scipy(self) -> sp.csc_matrix:
+        cp, rv, nz = self.download()
+        X = sp.csc_matrix((nz, rv, cp), shape=self.shape)
+        X._sclens_canonical = True
+        return X
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.ctx.lib.sclens_hip_counts_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 class Pattern:
     """sclens_hip_pattern: the sparse pattern counts + zero candidates, built (host) and uploaded on `ctx`'s stream."""
 
@@ -469,6 +539,11 @@ class Pattern:
         """counts' CSC in; the zero candidates (R1) are drawn and merged into the union pattern on the device"""
         p = cls.__new__(cls)
         p.ctx = ctx
+        if isinstance(X, DeviceCounts):  # in place from the device-resident matrix
+            h, nc = C.c_void_p(), C.c_int64(0)
+            ctx.check(ctx.lib.sclens_hip_pattern_create_drawn_from_counts(ctx.h, X.h, int(seed) & _M64, C.byref(h), C.byref(nc)))
+            p.h, p.ncand = h, int(nc.value)
+            return p
         colptr = np.ascontiguousarray(X.indptr, dtype=np.int64)
         rowval = np.ascontiguousarray(X.indices, dtype=np.int32)
         nzval = np.ascontiguousarray(X.data, dtype=np.float32)
@@ -508,6 +583,14 @@ class Session:
         self.ctx = ctx
         self.N, self.M = X.shape
         self.n = min(X.shape)
+        if isinstance(X, DeviceCounts):  # counts-only session built in place from the device-resident matrix
+            if z1 is not None and len(z1):
+                raise ValueError("a session from DeviceCounts starts without candidates: attach them with set_pattern")
+            self.ncand = 0
+            h = C.c_void_p()
+            ctx.check(ctx.lib.sclens_hip_session_create_from_counts(ctx.h, X.h, C.byref(h)))
+            self.h = h
+            return
         colptr = np.ascontiguousarray(X.indptr, dtype=np.int64)
         rowval = np.ascontiguousarray(X.indices, dtype=np.int32)
         nzval = np.ascontiguousarray(X.data, dtype=np.float32)
@@ -545,6 +628,66 @@ class Session:
                                                             C.byref(h)))
         s.h = h
         return s
+
+    @classmethod
+    def create_sharded_drawn(cls, ctx: Context, X_local: sp.csc_matrix, row0: int, N_global: int, nnz_global: int, seed: int,
+                             reducer) -> "Session":
+        """Row-sharded session whose zero candidates are drawn on the device for the local cells only
+        (sclens_hip_session_create_sharded_drawn); `s.ncand` = the local count until `set_candidate_range` is called."""
+        s = cls.__new__(cls)
+        s.ctx = ctx
+        s.N, s.M = X_local.shape
+        s.n = s.M
+        fn, user = reducer if isinstance(reducer, tuple) else (reducer, None)
+        s._reducer = (fn, user)
+        colptr = np.ascontiguousarray(X_local.indptr, dtype=np.int64)
+        rowval = np.ascontiguousarray(X_local.indices, dtype=np.int32)
+        nzval = np.ascontiguousarray(X_local.data, dtype=np.float32)
+        h, nc = C.c_void_p(), C.c_int64(0)
+        ctx.check(ctx.lib.sclens_hip_session_create_sharded_drawn(ctx.h, int(N_global), int(row0), s.N, s.M, ptr(colptr, C.c_int64),
+                                                                  ptr(rowval, C.c_int32), ptr(nzval, C.c_float), int(nnz_global),
+                                                                  int(seed) & _M64, fn, user, C.byref(h), C.byref(nc)))
+        s.h = h
+        s.ncand_local = s.ncand = int(nc.value)
+        return s
+
+    def set_candidate_range(self, cand_off: int, ncand_global: int):
+        self.ctx.check(self.ctx.lib.sclens_hip_session_set_candidate_range(self.h, int(cand_off), int(ncand_global)))
+        self.ncand = int(ncand_global)
+
+    def set_reduce_to(self, reducer_to):
+        fn, user = reducer_to
+        self._reducer_to = (fn, user)
+        self.ctx.check(self.ctx.lib.sclens_hip_session_set_reduce_to(self.h, fn, user))
+
+    def local_candidates(self):
+        n = int(getattr(self, "ncand_local", 0))
+        z1, z2 = np.empty(n, dtype=np.uint32), np.empty(n, dtype=np.uint32)
+        self.ctx.check(self.ctx.lib.sclens_hip_session_local_candidates(self.h, ptr(z1, C.c_uint32), ptr(z2, C.c_uint32)))
+        return z1, z2
+
+    def search_round_seeded(self, seeds, ms, roots, my_slot: int, n_2: int):
+        """one round of a row-sharded search: returns (d5, r) of evaluation `my_slot` (None when my_slot < 0)"""
+        sd = np.ascontiguousarray(np.asarray(seeds, dtype=np.uint64))
+        mm = np.ascontiguousarray(ms, dtype=np.int64)
+        rr = np.ascontiguousarray(roots, dtype=np.int32)
+        d5, r = np.empty(5), C.c_int64(0)
+        self.ctx.check(self.ctx.lib.sclens_hip_session_search_round_seeded(self.h, sd.ctypes.data_as(C.POINTER(C.c_uint64)), ptr(mm, C.c_int64),
+                                                                         ptr(rr, C.c_int32), len(sd), int(my_slot), int(n_2),
+                                                                         ptr(d5, C.c_double), C.byref(r)))
+        return (d5, r.value) if my_slot >= 0 else (None, 0)
+
+    def perturb_round_seeded(self, ts, seeds, ms, roots, my_slot: int, min_pc: int):
+        tt = np.ascontiguousarray(ts, dtype=np.int64)
+        sd = np.ascontiguousarray(np.asarray(seeds, dtype=np.uint64))
+        mm = np.ascontiguousarray(ms, dtype=np.int64)
+        rr = np.ascontiguousarray(roots, dtype=np.int32)
+        nL = np.zeros((len(tt), int(min_pc)))
+        nc = np.zeros(len(tt), dtype=np.int64)
+        self.ctx.check(self.ctx.lib.sclens_hip_session_perturb_round_seeded(self.h, ptr(tt, C.c_int64), sd.ctypes.data_as(C.POINTER(C.c_uint64)),
+                                                                          ptr(mm, C.c_int64), ptr(rr, C.c_int32), len(tt), int(my_slot),
+                                                                          int(min_pc), ptr(nL, C.c_double), ptr(nc, C.c_int64)))
+        return [nL[e, : nc[e]].copy() for e in range(len(tt))], [int(c) for c in nc]
 
     def close(self):
         if getattr(self, "h", None):
@@ -780,6 +923,8 @@ def _extract(inp):
     """df2sparr(inp_df) (scLENS.jl:662, :90-120) for a DataFrame with a leading `cell` column, a scipy sparse
     matrix or a dense array (cells x genes)."""
     cell_id = gene_id = None
+    if isinstance(inp, DeviceCounts):
+        return inp, np.arange(inp.shape[0]).astype(str), np.arange(inp.shape[1]).astype(str)
     try:
         import pandas as pd
 
@@ -854,7 +999,7 @@ def sclens(inp_df, device_="gpu", th=60, p_step=0.001, n_perturb=20, centering="
         if draws.z_idx1 is None and draws.cand_seed is not None:  # R1 drawn on the device
             return Pattern.drawn(aux_ctx, X_, draws.cand_seed), None, None
         z1_, z2_ = _resolve(draws.z_idx1), _resolve(draws.z_idx2)
-        return Pattern(aux_ctx, X_, z1_, z2_), z1_, z2_
+        return Pattern(aux_ctx, X_.to_scipy() if isinstance(X_, DeviceCounts) else X_, z1_, z2_), z1_, z2_
 
     def build_null_pattern():  # the null matrix's pattern, ready when the null decomposition starts
         return Pattern(aux_ctx2, _csc_f32(_resolve(draws.X_r)), [], [])

@@ -47,22 +47,47 @@ def _gather_rows(shard: Shard, local: np.ndarray, N_global: int) -> np.ndarray:
 
 def sclens_row_sharded(X_local, row0: int, N_global: int, draws: Draws, shard: Shard, th=60, p_step=0.001, n_perturb=20,
                        ctx: Optional[Context] = None, max_search_iters: Optional[int] = None, gather: bool = True,
-                       verbose: bool = False, guard_band: float = 4.0) -> Dict[str, object]:
+                       verbose: bool = False, guard_band: float = 4.0, distribute: Optional[bool] = None,
+                       nnz_global: Optional[int] = None, return_candidates: bool = False) -> Dict[str, object]:
     """scLENS.sclens (scLENS.jl:649-832) with the cells divided over the ranks of `shard`.
 
-    X_local: this rank's cells (N_local x M, N_global > M). draws: the GLOBAL draws, identical on every rank (z_idx1 =
-    global cell indices; X_r = the whole null matrix, of which this rank takes its rows; sampler / sample_seed index the
-    global candidate list). Returns the reference's result keys; with `gather` the cell-side arrays cover all cells."""
+    X_local: this rank's cells (N_local x M, N_global > M). draws: the GLOBAL draws, identical on every rank (X_r = the whole
+    null matrix, of which this rank takes its rows, or already its rows; sampler / sample_seed index the global candidate list).
+    Candidates, two modes:
+      * `draws.z_idx1 / z_idx2` given (global cell indices of the whole list): every rank holds the list, slot -1 for foreign cells
+        (the mode the parity tests replay against the unsharded path);
+      * `draws.z_idx1 is None` and `draws.cand_seed` set: every rank draws ITS part of the global draw sequence on the device
+        (`nnz_global` = stored entries of the whole matrix; default: the sum over the ranks), the global list is the concatenation
+        of the ranks' lists -- no rank holds foreign candidates (what the atlas configuration needs: 21 GB -> 2.6 GB per rank).
+    `distribute` (default: world > 1 and device-side samples): the evaluations of a search round (`world` sparsities at a time)
+    and the ensemble members are decomposed by DIFFERENT ranks -- each partial Gram matrix is summed onto the rank that solves it --
+    instead of replicated on all. Returns the reference's result keys; with `gather` the cell-side arrays cover all cells."""
     ctx = ctx or default_context()
     t_all = time.perf_counter()
     X_local = _csc_f32(X_local)
     N_local, M = X_local.shape
     if N_global <= M:
         raise ValueError("row sharding needs cells > genes; use api.sclens(shard=...) otherwise")
-    z1, z2 = _resolve(draws.z_idx1), _resolve(draws.z_idx2)
     Xr = _resolve(draws.X_r)
     Xr_local = _csc_f32(sp.csc_matrix(Xr.tocsr()[row0: row0 + N_local])) if Xr.shape[0] == N_global else _csc_f32(Xr)
-    ses = Session.create_sharded(ctx, X_local, row0, N_global, z1, z2, shard.reducer(ctx))
+    local_cands = draws.z_idx1 is None and draws.cand_seed is not None
+    if distribute is None:
+        distribute = shard.world > 1 and draws.sampler is None
+    if distribute and draws.sampler is not None:
+        raise ValueError("distribute=True needs device-side samples (draws.sampler is None)")
+    if local_cands:
+        if nnz_global is None:
+            nnz_global = int(shard.allgather_small(np.array([float(X_local.nnz)])).sum())
+        ses = Session.create_sharded_drawn(ctx, X_local, row0, N_global, nnz_global, draws.cand_seed, shard.reducer(ctx))
+        counts = shard.allgather_small(np.array([float(ses.ncand_local)]))[:, 0].astype(np.int64)
+        ses.set_candidate_range(int(counts[: shard.rank].sum()), int(counts.sum()))
+        n_cand = int(counts.sum())
+    else:
+        z1, z2 = _resolve(draws.z_idx1), _resolve(draws.z_idx2)
+        ses = Session.create_sharded(ctx, X_local, row0, N_global, z1, z2, shard.reducer(ctx))
+        n_cand = len(z1)
+    if distribute:
+        ses.set_reduce_to(shard.reducer_to(ctx))
     try:
         Lr = shard.agree(ses.null_spectrum(Xr_local))  # :704
         L, rec_vals = ses.data_spectrum()
@@ -81,16 +106,34 @@ def sclens_row_sharded(X_local, row0: int, N_global: int, draws: Draws, shard: S
         p_list = search_schedule(p_step)
         tank = np.zeros((5, 0))
         it, p_ = 0, None
-        while p_ is None:  # :725-761, one evaluation at a time, all ranks together
-            nnzidx = int(round((1 - p_list[it]) * M * N_global))
-            d5 = None
-            if len(z1) >= nnzidx:
-                if draws.sampler is not None:
-                    d5, _ = ses.search_step(draws.sampler("search", it, len(z1), nnzidx), n_2)
-                else:
-                    d5, _ = ses.search_step_seeded(sample_seed_for(draws.sample_seed, "search", it), nnzidx, n_2)
-                d5 = shard.agree(d5)
-            tank, used, stopped, p_fin = consume_search_round(tank, [d5], p_list, it, p_th, p_step, max_search_iters)
+        while p_ is None:  # :725-761
+            if distribute:
+                # a round of `world` consecutive sparsities: rank r decomposes evaluation it + r (its Gram matrix is summed onto
+                # rank r only); the statistics are gathered and consumed in order with the reference's stop rule
+                W = shard.world
+                ms = [int(round((1 - p_list[it + e]) * M * N_global)) for e in range(W)]
+                ok = [n_cand >= mm for mm in ms]
+                live = [e for e in range(W) if ok[e]]
+                mine = np.full(6, np.nan)
+                if live:
+                    seeds = [sample_seed_for(draws.sample_seed, "search", it + e) for e in live]
+                    my_slot = live.index(shard.rank) if shard.rank in live else -1
+                    d5, _ = ses.search_round_seeded(seeds, [ms[e] for e in live], live, my_slot, n_2)
+                    if my_slot >= 0:
+                        mine[:5], mine[5] = d5, 1.0
+                allr = shard.allgather_small(mine)
+                results = [allr[e, :5] if allr[e, 5] == 1.0 else None for e in range(W)]
+            else:  # one evaluation at a time, all ranks together
+                nnzidx = int(round((1 - p_list[it]) * M * N_global))
+                d5 = None
+                if n_cand >= nnzidx:
+                    if draws.sampler is not None:
+                        d5, _ = ses.search_step(draws.sampler("search", it, n_cand, nnzidx), n_2)
+                    else:
+                        d5, _ = ses.search_step_seeded(sample_seed_for(draws.sample_seed, "search", it), nnzidx, n_2)
+                    d5 = shard.agree(d5)
+                results = [d5]
+            tank, used, stopped, p_fin = consume_search_round(tank, results, p_list, it, p_th, p_step, max_search_iters)
             it += used
             if stopped:
                 p_ = p_fin
@@ -100,16 +143,30 @@ def sclens_row_sharded(X_local, row0: int, N_global: int, draws: Draws, shard: S
         nL_set, ncols = [None] * n_perturb, [0] * n_perturb
         res: Dict[str, object] = {"L": L, "L_mp": L_mp, "λ": lambda_c, "lambda_c": lambda_c, "p_": p_, "p_th": p_th,
                                   "n_search": it, "search_trace": trace, "row_block": (row0, row0 + N_local),
-                                  "guard_band": guard}
+                                  "guard_band": guard, "n_cand": n_cand, "distributed": bool(distribute),
+                                  "local_candidates": bool(local_cands)}
+        if return_candidates and local_cands:  # this rank's part of the global list (global cell indices): tests replay with it
+            res["candidates_local"] = ses.local_candidates()
         if k == 0:  # :780-784
             res["partial_eig"] = (0, 0)
             res["wall_s"] = time.perf_counter() - t_all
             return res
-        for t in range(n_perturb):  # :767-778
-            if draws.sampler is not None:
-                nL_set[t], ncols[t] = ses.perturb(t, draws.sampler("perturb", t, len(z1), m_pert), min_pc)
-            else:
-                nL_set[t], ncols[t] = ses.perturb_seeded(t, sample_seed_for(draws.sample_seed, "perturb", t), m_pert, min_pc)
+        if distribute:  # :767-778, `world` members per round, member t decomposed by rank t mod world
+            W = shard.world
+            for t0 in range(0, n_perturb, W):
+                ts = list(range(t0, min(n_perturb, t0 + W)))
+                roots = [t % W for t in ts]
+                my_slot = roots.index(shard.rank) if shard.rank in roots else -1
+                nl, nc = ses.perturb_round_seeded(ts, [sample_seed_for(draws.sample_seed, "perturb", t) for t in ts],
+                                                  [m_pert] * len(ts), roots, my_slot, min_pc)
+                for e, t in enumerate(ts):
+                    nL_set[t], ncols[t] = nl[e], nc[e]
+        else:
+            for t in range(n_perturb):  # :767-778
+                if draws.sampler is not None:
+                    nL_set[t], ncols[t] = ses.perturb(t, draws.sampler("perturb", t, n_cand, m_pert), min_pc)
+                else:
+                    nL_set[t], ncols[t] = ses.perturb_seeded(t, sample_seed_for(draws.sample_seed, "perturb", t), m_pert, min_pc)
         a_b, b_ = ses.robustness(k, n_perturb)  # :786-807; the small products are summed over the ranks inside
         b_ = shard.agree(b_)
         m_score, sd_score = _robust_scores(b_)

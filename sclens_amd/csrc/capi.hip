@@ -9,6 +9,13 @@ int session_create(Ctx*, int64_t, int64_t, const int64_t*, const int32_t*, const
 int session_create_sharded(Ctx*, int64_t, int64_t, int64_t, int64_t, const int64_t*, const int32_t*, const float*, int64_t,
                            const uint32_t*, const uint32_t*, sclens_hip_allreduce_fn, void*, Session**);
 int session_set_reducer(Session*, sclens_hip_allreduce_fn, void*);
+int session_set_reduce_to(Session*, sclens_hip_reduce_fn, void*);
+int session_create_sharded_drawn(Ctx*, int64_t, int64_t, int64_t, int64_t, const int64_t*, const int32_t*, const float*, int64_t, uint64_t,
+                                 sclens_hip_allreduce_fn, void*, Session**, int64_t*);
+int session_set_candidate_range(Session*, int64_t, int64_t);
+int session_local_candidates(Session*, uint32_t*, uint32_t*);
+int session_search_round_seeded(Session*, const uint64_t*, const int64_t*, const int32_t*, int, int, int64_t, double*, int64_t*);
+int session_perturb_round_seeded(Session*, const int64_t*, const uint64_t*, const int64_t*, const int32_t*, int, int, int64_t, double*, int64_t*);
 int session_shared_buffer(Session*, int, int64_t, int64_t, double*, void**, int64_t*, int64_t*, int64_t*);
 void session_destroy(Session*);
 int session_clone(Ctx*, Session*, Session**);
@@ -23,6 +30,11 @@ int pattern_create(Ctx*, int64_t, int64_t, const int64_t*, const int32_t*, const
                    const uint32_t*, PatternOwner**);
 void pattern_destroy(PatternOwner*);
 int session_set_pattern(Session*, PatternOwner*);
+int session_create_from_counts(Ctx*, const Counts*, Session**);
+int pattern_create_drawn_from_counts(Ctx*, const Counts*, uint64_t, PatternOwner**, int64_t*);
+int counts_upload(Ctx*, int64_t, int64_t, const int64_t*, const int32_t*, const float*, Counts**);
+int counts_download(Ctx*, const Counts*, int64_t*, int32_t*, float*);
+int preprocess_keep(Ctx*, Counts**);
 int session_null_spectrum_pattern(Session*, PatternOwner*, double*);
 int session_signal_vectors(Session*, int64_t, float*);
 int session_refine_eigenvalues(Session*, int64_t, int64_t, double*);
@@ -158,6 +170,63 @@ int sclens_hip_preprocess_gather(sclens_hip_ctx* h, int64_t* out_colptr, int32_t
   CTX_GUARD(h);
   return scl::preprocess_gather(&h->c, out_colptr, out_rowval, out_nzval);
 }
+/* ---- device-resident count matrices (preprocess -> sclens without the host round trip) */
+int sclens_hip_preprocess_keep(sclens_hip_ctx* h, sclens_hip_counts** out) {
+  CTX_GUARD(h);
+  if (!out) return SCLENS_ERR_ARG;
+  scl::Counts* c = nullptr;
+  const int rc = scl::preprocess_keep(&h->c, &c);
+  if (rc == SCLENS_OK) *out = reinterpret_cast<sclens_hip_counts*>(c);
+  return rc;
+}
+int sclens_hip_counts_upload(sclens_hip_ctx* h, int64_t N, int64_t M, const int64_t* colptr, const int32_t* rowval, const float* nzval,
+                             sclens_hip_counts** out) {
+  CTX_GUARD(h);
+  if (!out) return SCLENS_ERR_ARG;
+  scl::Counts* c = nullptr;
+  const int rc = scl::counts_upload(&h->c, N, M, colptr, rowval, nzval, &c);
+  if (rc == SCLENS_OK) *out = reinterpret_cast<sclens_hip_counts*>(c);
+  return rc;
+}
+int sclens_hip_counts_info(const sclens_hip_counts* counts, int64_t* N, int64_t* M, int64_t* nnz) {
+  if (!counts) return SCLENS_ERR_ARG;
+  const scl::Counts* c = reinterpret_cast<const scl::Counts*>(counts);
+  if (N) *N = c->N;
+  if (M) *M = c->M;
+  if (nnz) *nnz = c->nnz;
+  return SCLENS_OK;
+}
+int sclens_hip_counts_download(sclens_hip_ctx* h, const sclens_hip_counts* counts, int64_t* colptr, int32_t* rowval, float* nzval) {
+  CTX_GUARD(h);
+  if (!counts) return SCLENS_ERR_ARG;
+  return scl::counts_download(&h->c, reinterpret_cast<const scl::Counts*>(counts), colptr, rowval, nzval);
+}
+void sclens_hip_counts_destroy(sclens_hip_counts* counts) {
+  if (!counts) return;
+  hipSetDevice(reinterpret_cast<scl::Counts*>(counts)->device);
+  scl::counts_free(reinterpret_cast<scl::Counts*>(counts));
+}
+int sclens_hip_session_create_from_counts(sclens_hip_ctx* h, const sclens_hip_counts* counts, sclens_hip_session** out) {
+  CTX_GUARD(h);
+  if (!out || !counts) return SCLENS_ERR_ARG;
+  scl::Session* s = nullptr;
+  const int rc = scl::session_create_from_counts(&h->c, reinterpret_cast<const scl::Counts*>(counts), &s);
+  if (rc != SCLENS_OK) return rc;
+  sclens_hip_session* w = new sclens_hip_session();
+  w->s = s;
+  w->ctx = h;
+  *out = w;
+  return SCLENS_OK;
+}
+int sclens_hip_pattern_create_drawn_from_counts(sclens_hip_ctx* h, const sclens_hip_counts* counts, uint64_t seed, sclens_hip_pattern** out,
+                                                int64_t* n_cand) {
+  CTX_GUARD(h);
+  if (!out || !counts) return SCLENS_ERR_ARG;
+  scl::PatternOwner* p = nullptr;
+  const int rc = scl::pattern_create_drawn_from_counts(&h->c, reinterpret_cast<const scl::Counts*>(counts), seed, &p, n_cand);
+  if (rc == SCLENS_OK) *out = reinterpret_cast<sclens_hip_pattern*>(p);
+  return rc;
+}
 int sclens_hip_scale_csc_f32(sclens_hip_ctx* h, int64_t N, int64_t M, const int64_t* colptr, const int32_t* rowval,
                              const float* nzval, int centering, int f32path, float* out, double* rec_tgc, double* rec_mean,
                              double* rec_std, double* rec_norm, double* rec_cent) {
@@ -244,6 +313,44 @@ void sclens_hip_session_destroy(sclens_hip_session* w) {
   if (!(w) || !(w)->s) return SCLENS_ERR_ARG; \
   hipSetDevice((w)->ctx->c.device)
 
+int sclens_hip_session_create_sharded_drawn(sclens_hip_ctx* h, int64_t N_global, int64_t row0, int64_t N_local, int64_t M,
+                                            const int64_t* colptr, const int32_t* rowval, const float* nzval, int64_t nnz_global,
+                                            uint64_t seed, sclens_hip_allreduce_fn allreduce, void* user, sclens_hip_session** out,
+                                            int64_t* n_cand_local) {
+  CTX_GUARD(h);
+  if (!out) return SCLENS_ERR_ARG;
+  scl::Session* s = nullptr;
+  const int rc = scl::session_create_sharded_drawn(&h->c, N_global, row0, N_local, M, colptr, rowval, nzval, nnz_global, seed, allreduce,
+                                                   user, &s, n_cand_local);
+  if (rc != SCLENS_OK) return rc;
+  sclens_hip_session* w = new sclens_hip_session();
+  w->s = s;
+  w->ctx = h;
+  *out = w;
+  return SCLENS_OK;
+}
+int sclens_hip_session_set_reduce_to(sclens_hip_session* w, sclens_hip_reduce_fn reduce, void* user) {
+  SES_GUARD(w);
+  return scl::session_set_reduce_to(w->s, reduce, user);
+}
+int sclens_hip_session_set_candidate_range(sclens_hip_session* w, int64_t cand_off, int64_t n_cand_global) {
+  SES_GUARD(w);
+  return scl::session_set_candidate_range(w->s, cand_off, n_cand_global);
+}
+int sclens_hip_session_local_candidates(sclens_hip_session* w, uint32_t* z1, uint32_t* z2) {
+  SES_GUARD(w);
+  return scl::session_local_candidates(w->s, z1, z2);
+}
+int sclens_hip_session_search_round_seeded(sclens_hip_session* w, const uint64_t* seeds, const int64_t* m, const int32_t* roots, int count,
+                                           int my_slot, int64_t n_2, double* d5, int64_t* r_it) {
+  SES_GUARD(w);
+  return scl::session_search_round_seeded(w->s, seeds, m, roots, count, my_slot, n_2, d5, r_it);
+}
+int sclens_hip_session_perturb_round_seeded(sclens_hip_session* w, const int64_t* t, const uint64_t* seeds, const int64_t* m,
+                                            const int32_t* roots, int count, int my_slot, int64_t min_pc, double* nL_top, int64_t* ncols) {
+  SES_GUARD(w);
+  return scl::session_perturb_round_seeded(w->s, t, seeds, m, roots, count, my_slot, min_pc, nL_top, ncols);
+}
 int sclens_hip_session_set_reducer(sclens_hip_session* w, sclens_hip_allreduce_fn allreduce, void* user) {
   SES_GUARD(w);
   return scl::session_set_reducer(w->s, allreduce, user);

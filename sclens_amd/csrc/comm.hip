@@ -30,6 +30,7 @@ struct RcclApi {
   ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
   ncclResult_t (*Broadcast)(const void*, void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
   ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*Reduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, int, ncclComm_t, hipStream_t) = nullptr;
   const char* (*GetErrorString)(ncclResult_t) = nullptr;
   ncclResult_t (*GetVersion)(int*) = nullptr;
   std::string err;
@@ -61,6 +62,7 @@ static RcclApi* rccl_api() {
     api.AllReduce = reinterpret_cast<decltype(api.AllReduce)>(sym("ncclAllReduce"));
     api.Broadcast = reinterpret_cast<decltype(api.Broadcast)>(sym("ncclBroadcast"));
     api.AllGather = reinterpret_cast<decltype(api.AllGather)>(sym("ncclAllGather"));
+    api.Reduce = reinterpret_cast<decltype(api.Reduce)>(sym("ncclReduce"));
     api.GetErrorString = reinterpret_cast<decltype(api.GetErrorString)>(sym("ncclGetErrorString"));
     api.GetVersion = reinterpret_cast<decltype(api.GetVersion)>(sym("ncclGetVersion"));
   });
@@ -149,6 +151,18 @@ int comm_allreduce(Comm* c, void* dev, int64_t count, int dtype) {
   if (count <= 0) return SCLENS_OK;
   if (dtype != 0 && dtype != 1) return c->ctx->fail(SCLENS_ERR_ARG, "comm_allreduce: dtype must be 0 (fp64) or 1 (fp32)");
   SCL_NCCL(c->ctx, rccl_api()->AllReduce(dev, dev, (size_t)count, dtype == 0 ? ncclDouble : ncclFloat, ncclSum, c->comm, c->ctx->stream));
+  SCL_HIP(c->ctx, hipStreamSynchronize(c->ctx->stream));
+  c->calls += 1;
+  c->bytes += (double)count * (dtype == 0 ? 8 : 4);
+  return SCLENS_OK;
+}
+
+// in-place sum onto rank `root` (the other ranks' buffers are unchanged)
+int comm_reduce(Comm* c, void* dev, int64_t count, int dtype, int root) {
+  if (count <= 0) return SCLENS_OK;
+  if (dtype != 0 && dtype != 1) return c->ctx->fail(SCLENS_ERR_ARG, "comm_reduce: dtype must be 0 (fp64) or 1 (fp32)");
+  if (root < 0 || root >= c->world) return c->ctx->fail(SCLENS_ERR_ARG, "comm_reduce: bad root");
+  SCL_NCCL(c->ctx, rccl_api()->Reduce(dev, dev, (size_t)count, dtype == 0 ? ncclDouble : ncclFloat, ncclSum, root, c->comm, c->ctx->stream));
   SCL_HIP(c->ctx, hipStreamSynchronize(c->ctx->stream));
   c->calls += 1;
   c->bytes += (double)count * (dtype == 0 ? 8 : 4);
@@ -270,6 +284,11 @@ int sclens_hip_comm_broadcast_host(sclens_hip_comm* comm, void* buf, int64_t nby
 /* signature of sclens_hip_allreduce_fn with user = the sclens_hip_comm handle */
 int sclens_hip_comm_allreduce_cb(void* user, void* dev_ptr, int64_t count, int dtype) {
   return sclens_hip_comm_allreduce(static_cast<sclens_hip_comm*>(user), dev_ptr, count, dtype);
+}
+int sclens_hip_comm_reduce_cb(void* user, void* dev_ptr, int64_t count, int dtype, int root) {
+  sclens_hip_comm* comm = static_cast<sclens_hip_comm*>(user);
+  COMM_GUARD(comm);
+  return scl::comm_reduce(comm->c, dev_ptr, count, dtype, root);
 }
 const char* sclens_hip_comm_last_error(sclens_hip_comm* comm) { return (comm && comm->c) ? comm->c->ctx->err.c_str() : "null communicator"; }
 

@@ -431,7 +431,12 @@ __global__ __launch_bounds__(512, 2) void corr_split_kernel(SplitCorrArgs a, con
 
 size_t gram_binary_scratch_bytes(int64_t N, int64_t M) { return sizeof(unsigned short) * (size_t)M * (size_t)round_up(N, 64); }
 
-int gram_binary(Ctx* ctx, const PatternDev& p, const float* val, int f32path, void* scratch, float divisor, float* A, int64_t lda) {
+// sh != nullptr (row-sharded session): p holds this rank's cells; the per-gene statistics are global (all-reduced inside
+// scale_stats_sharded), the cell weights, the co-occurrence product, u_j = d_j sum_i P_ij s_i^2 l_i and S2 = sum s_i^2 run over
+// the local cells and `N` in the -N cent_j cent_k term is the local count, so that A receives this rank's additive part of
+// B'B / divisor (the caller sums the parts over the ranks).
+int gram_binary(Ctx* ctx, const PatternDev& p, const float* val, int f32path, void* scratch, float divisor, float* A, int64_t lda,
+                const ShardReduce* sh) {
   const int64_t N = p.N, M = p.M, ldm = round_up(N, 64);
   const char* nw_env = getenv("SCLENS_HIP_GRAM_BITS_TERMS");  // 2 (22 bits of the weights, default) or 3 (33 bits)
   const int nw = (nw_env && atoi(nw_env) == 3) ? 3 : 2;
@@ -447,7 +452,8 @@ int gram_binary(Ctx* ctx, const PatternDev& p, const float* val, int f32path, vo
   {
     StageTimer tm(ctx, "scale");
     ScaleStats ss;
-    SCL_TRY(scale_stats(ctx, p, val, f32path, 0, &ss));
+    if (sh && sh->on()) SCL_TRY(scale_stats_sharded(ctx, p, val, f32path, *sh, &ss));
+    else SCL_TRY(scale_stats(ctx, p, val, f32path, 0, &ss));
     hipLaunchKernelGGL(k_cell_weights, dim3((unsigned)nparts), dim3(256), 0, st, N, ss.tgc, ss.srow, f32path, w, sa, wpart);
     hipLaunchKernelGGL(k_weight_scale, dim3(1), dim3(1024), 0, st, wpart, nparts, ss.srow, N, sc);
     hipLaunchKernelGGL(k_split_weights, dim3((unsigned)((ldm + 255) / 256)), dim3(256), 0, st, w, N, ldm, nw, sc, wq);

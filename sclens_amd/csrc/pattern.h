@@ -13,6 +13,11 @@ struct PatternDev {
   const int64_t* csr2csc = nullptr;  // [nU]   CSC slot of each CSR slot
   const int32_t* csrcol = nullptr;   // [nU]
   const int64_t* cand_pos = nullptr; // [ncand] CSC slot of candidate t (-1: not in this session's cells, row-sharded mode)
+  // Samples index a GLOBAL candidate list of ncand_global entries of which this pattern holds [cand_off, cand_off + ncand)
+  // (row-sharded sessions with local candidates: the global list is the concatenation of the ranks' lists in rank order).
+  // ncand_global == 0: the pattern holds the whole list (cand_off = 0, ncand_global = ncand).
+  int64_t cand_off = 0, ncand_global = 0;
+  int64_t population() const { return ncand_global > 0 ? ncand_global : ncand; }
 };
 
 struct PatternOwner {  // owns the device arrays of a PatternDev
@@ -31,8 +36,25 @@ int pattern_build(Ctx* ctx, int64_t N, int64_t M, const int64_t* colptr, const i
 void pattern_free(PatternOwner* p);
 // The same arrays built on the device from the counts' CSC (pattern_dev.hip); draw != 0 also draws the candidate list there
 // (R1, scLENS.jl:668-673; the list of sclens_draw_zero_candidates for the same seed). Sessions that hold all cells only.
+// blk != nullptr (with draw): the matrix is the block [row0, row0 + N) of the cells of an N_global x M matrix with nnz_global stored
+// entries in all; the candidates are this block's part of the GLOBAL draw sequence (local cell indices in z1_dev)
+struct BlockDraw {
+  int64_t N_global, row0, nnz_global;
+};
 int pattern_build_device(Ctx* ctx, int64_t N, int64_t M, const int64_t* colptr, const int32_t* rowval, const float* nzval, int64_t ncand,
-                         const uint32_t* z1_h, const uint32_t* z2_h, int draw, uint64_t seed, PatternOwner* out);
+                         const uint32_t* z1_h, const uint32_t* z2_h, int draw, uint64_t seed, PatternOwner* out, int64_t nnz_dev = -1,
+                         const BlockDraw* blk = nullptr);
+
+// A count matrix that lives in HBM (CSC, 0-based): the filtered output of preprocess (sclens_hip_preprocess_keep) or an upload.
+// Sessions and patterns built from it read it in place; it may be shared by the contexts of its device.
+struct Counts {
+  int device = 0;
+  int64_t N = 0, M = 0, nnz = 0;
+  int64_t* colptr = nullptr;  // [M + 1]
+  int32_t* row = nullptr;     // [nnz]
+  float* val = nullptr;       // [nnz]
+};
+void counts_free(Counts* c);
 
 // Row-sharded session: the all-reduce the host supplies. dtype 0 = fp64, 1 = fp32; sum over all ranks, in
 // place, on a device buffer; called from the thread that made the session call, after the session's stream has been
@@ -41,6 +63,10 @@ struct ShardReduce {
   int64_t N_global = 0, row0 = 0;
   sclens_hip_allreduce_fn fn = nullptr;
   void* user = nullptr;
+  // optional: sum onto ONE rank (`root`; the other ranks' buffers are left undefined). Used where only one rank consumes the sum
+  // (the Gram matrix of a search evaluation / ensemble member that `root` decomposes); absent: all-reduce.
+  sclens_hip_reduce_fn rfn = nullptr;
+  void* ruser = nullptr;
   bool on() const { return fn != nullptr; }
   int sum(Ctx* ctx, void* dev, int64_t count, int dtype) const {
     if (!fn) return SCLENS_OK;
@@ -48,6 +74,13 @@ struct ShardReduce {
     if (e != hipSuccess) return ctx->fail(SCLENS_ERR_HIP, std::string("allreduce: ") + hipGetErrorString(e));
     const int rc = fn(user, dev, count, dtype);
     return rc == 0 ? SCLENS_OK : ctx->fail(SCLENS_ERR_HIP, "allreduce callback failed with code " + std::to_string(rc));
+  }
+  int sum_to(Ctx* ctx, void* dev, int64_t count, int dtype, int root) const {
+    if (!rfn) return sum(ctx, dev, count, dtype);
+    hipError_t e = hipStreamSynchronize(ctx->stream);
+    if (e != hipSuccess) return ctx->fail(SCLENS_ERR_HIP, std::string("reduce: ") + hipGetErrorString(e));
+    const int rc = rfn(ruser, dev, count, dtype, root);
+    return rc == 0 ? SCLENS_OK : ctx->fail(SCLENS_ERR_HIP, "reduce callback failed with code " + std::to_string(rc));
   }
 };
 
@@ -78,7 +111,10 @@ int scale_stats(Ctx* ctx, const PatternDev& p, const float* val, int f32path, in
 // layout) without forming the scaled matrix (gram_bits.hip): A (M x M, lda, zero padded, exactly symmetric) =
 // scaled(P)' scaled(P) / divisor. `scratch` holds the M x round_up(N, 64) fp16 image of P.
 size_t gram_binary_scratch_bytes(int64_t N, int64_t M);
-int gram_binary(Ctx* ctx, const PatternDev& p, const float* val, int f32path, void* scratch, float divisor, float* A, int64_t lda);
+struct ShardReduce;
+int gram_binary(Ctx* ctx, const PatternDev& p, const float* val, int f32path, void* scratch, float divisor, float* A, int64_t lda,
+                const ShardReduce* sh = nullptr);
+int scale_stats_sharded(Ctx* ctx, const PatternDev& p, const float* val, int f32path, const ShardReduce& sh, ScaleStats* out);
 
 // the same for a session that holds p.N of sh.N_global cells (N > M layout: B[j][i_local]); mean centring only
 int scale_to_dense_sharded(Ctx* ctx, const PatternDev& p, const float* val, int f32path, float* B, int64_t ldb,

@@ -137,6 +137,121 @@ int r1_draw_device(Ctx* ctx, DevTmp& tmp, uint64_t seed, int64_t nnz, int64_t N,
   return SCLENS_OK;
 }
 
+// ---- R1 for a BLOCK of cells (row-sharded sessions) -----------------------------------------------------------
+// Draw t of the global list is a pure function of (seed, t) (r1_draw), so the rank that holds the cells [row0, row0 + Nl) can
+// take its own candidates out of the global draw sequence without seeing anybody else's: every rank evaluates all nnz_global
+// draws (two splitmix64 outputs each: ~10 ms per 10^9 on this device) in chunks, keeps those that land in its cells, and removes
+// stored entries and repeats among them exactly as the global procedure would (a repeat has the same cell, hence the same
+// rank). The local list is the global first-occurrence list restricted to the block, in the same order.
+template <typename K>
+__global__ void k_r1_block_hits(uint64_t seed, uint64_t t0, int64_t cnt, uint64_t Ng, uint64_t M, uint64_t row0, uint64_t Nl,
+                                unsigned* __restrict__ flag) {
+  const int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (q >= cnt) return;
+  uint64_t i, j;
+  r1_draw(seed, t0 + (uint64_t)q, Ng, M, &i, &j);
+  flag[q] = (i >= row0 && i < row0 + Nl) ? 1u : 0u;
+}
+template <typename K>
+__global__ void k_r1_block_emit(uint64_t seed, uint64_t t0, int64_t cnt, uint64_t Ng, uint64_t M, uint64_t row0, uint64_t Nl,
+                                const unsigned* __restrict__ flag, const unsigned* __restrict__ pos, int64_t base,
+                                const unsigned* __restrict__ bits, K invalid, K* __restrict__ keys, unsigned* __restrict__ seq) {
+  const int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (q >= cnt || !flag[q]) return;
+  uint64_t i, j;
+  r1_draw(seed, t0 + (uint64_t)q, Ng, M, &i, &j);
+  const uint64_t key = (i - row0) + j * Nl;  // local key
+  const int64_t o = base + pos[q];
+  keys[o] = ((bits[key >> 5] >> (key & 31)) & 1u) ? invalid : (K)key;
+  seq[o] = (unsigned)o;  // position in the (draw-ordered) local hit list
+}
+template <typename K>
+__global__ void k_r1_block_out(const K* __restrict__ keys_in_draw_order, const unsigned* __restrict__ flag, const unsigned* __restrict__ pos,
+                               int64_t nh, uint64_t Nl, uint32_t* __restrict__ z1, uint32_t* __restrict__ z2) {
+  const int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (q >= nh || !flag[q]) return;
+  const uint64_t key = (uint64_t)keys_in_draw_order[q];
+  z1[pos[q]] = (uint32_t)(key % Nl);  // LOCAL cell index
+  z2[pos[q]] = (uint32_t)(key / Nl);
+}
+
+// z1 (local cell indices) / z2 of the block's candidates; *z1o / *z2o are allocated here (kept in `out`); *ncand = their number
+template <typename K>
+int r1_draw_device_block(Ctx* ctx, PatternOwner* out, uint64_t seed, int64_t nnz_global, int64_t Ng, int64_t M, int64_t row0, int64_t Nl,
+                         const unsigned* bits, uint32_t** z1o, uint32_t** z2o, int64_t* ncand) {
+  hipStream_t st = ctx->stream;
+  const uint64_t cells = (uint64_t)Nl * (uint64_t)M;
+  const int nb = bits_for(cells);
+  const K invalid = (K)((nb >= (int)(8 * sizeof(K))) ? ~(K)0 : ((K)1 << nb));
+  // expected hits: nnz_global * Nl / Ng; capacity with 6 sigma + slack, grown on overflow (never observed)
+  const double expect = (double)nnz_global * (double)Nl / (double)Ng;
+  int64_t cap = (int64_t)(expect + 6.0 * std::sqrt(expect + 1.0) + 4096.0);
+  const int64_t CH = (int64_t)1 << 26;  // draws per chunk
+  DevTmp tmp;
+  unsigned* cflag = tmp.get<unsigned>(ctx, CH + 1);
+  unsigned* cpos = tmp.get<unsigned>(ctx, CH + 1);
+  K* keys = tmp.get<K>(ctx, cap);
+  unsigned* seq = tmp.get<unsigned>(ctx, cap);
+  if (!cflag || !cpos || !keys || !seq) return SCLENS_ERR_OOM;
+  size_t sb = 0;
+  SCL_HIP(ctx, rocprim::exclusive_scan(nullptr, sb, cflag, cpos, 0u, (size_t)CH + 1, rocprim::plus<unsigned>(), st));
+  void* sws = tmp.get<char>(ctx, sb);
+  if (!sws) return SCLENS_ERR_OOM;
+  int64_t nh = 0;
+  for (int64_t t0 = 0; t0 < nnz_global; t0 += CH) {
+    const int64_t cnt = std::min<int64_t>(CH, nnz_global - t0);
+    const unsigned gb = (unsigned)((cnt + 255) / 256);
+    SCL_HIP(ctx, hipMemsetAsync(cflag + cnt, 0, sizeof(unsigned), st));
+    hipLaunchKernelGGL((k_r1_block_hits<K>), dim3(gb), dim3(256), 0, st, seed, (uint64_t)t0, cnt, (uint64_t)Ng, (uint64_t)M, (uint64_t)row0,
+                       (uint64_t)Nl, cflag);
+    SCL_HIP(ctx, rocprim::exclusive_scan(sws, sb, cflag, cpos, 0u, (size_t)cnt + 1, rocprim::plus<unsigned>(), st));
+    unsigned got = 0;
+    SCL_HIP(ctx, hipMemcpyAsync(&got, cpos + cnt, sizeof(unsigned), hipMemcpyDeviceToHost, st));
+    SCL_HIP(ctx, hipStreamSynchronize(st));
+    if (nh + (int64_t)got > cap) return ctx->fail(SCLENS_ERR_HIP, "r1_draw_device_block: more local draws than 6 sigma above expectation");
+    hipLaunchKernelGGL((k_r1_block_emit<K>), dim3(gb), dim3(256), 0, st, seed, (uint64_t)t0, cnt, (uint64_t)Ng, (uint64_t)M, (uint64_t)row0,
+                       (uint64_t)Nl, cflag, cpos, nh, bits, invalid, keys, seq);
+    nh += (int64_t)got;
+  }
+  *ncand = 0;
+  *z1o = *z2o = nullptr;
+  if (nh == 0) return SCLENS_OK;
+  if (nh >= 0xFFFFFFF0ll) return ctx->fail(SCLENS_ERR_ARG, "r1_draw_device_block: more than 2^32 local draws");
+  // first occurrences among the valid keys: stable sort by key (ties keep draw order), run heads, back to draw order by `seq`
+  K* k1 = tmp.get<K>(ctx, nh);
+  unsigned* v1 = tmp.get<unsigned>(ctx, nh);
+  unsigned* flag = tmp.get<unsigned>(ctx, nh + 1);
+  unsigned* pos = tmp.get<unsigned>(ctx, nh + 1);
+  if (!k1 || !v1 || !flag || !pos) return SCLENS_ERR_OOM;
+  size_t bytes = 0;
+  const unsigned end_bit = (unsigned)std::min<int>(nb + 1, 8 * (int)sizeof(K));
+  SCL_HIP(ctx, rocprim::radix_sort_pairs(nullptr, bytes, keys, k1, seq, v1, (size_t)nh, 0u, end_bit, st));
+  void* ws = tmp.get<char>(ctx, bytes);
+  if (!ws) return SCLENS_ERR_OOM;
+  SCL_HIP(ctx, rocprim::radix_sort_pairs(ws, bytes, keys, k1, seq, v1, (size_t)nh, 0u, end_bit, st));
+  SCL_HIP(ctx, hipMemsetAsync(flag, 0, sizeof(unsigned) * (nh + 1), st));
+  const unsigned gh = (unsigned)((nh + 255) / 256);
+  hipLaunchKernelGGL((k_r1_flag<K>), dim3(gh), dim3(256), 0, st, k1, v1, nh, invalid, flag);  // flag[seq] = 1 for run heads
+  size_t b2 = 0;
+  SCL_HIP(ctx, rocprim::exclusive_scan(nullptr, b2, flag, pos, 0u, (size_t)nh + 1, rocprim::plus<unsigned>(), st));
+  void* ws2 = tmp.get<char>(ctx, b2);
+  if (!ws2) return SCLENS_ERR_OOM;
+  SCL_HIP(ctx, rocprim::exclusive_scan(ws2, b2, flag, pos, 0u, (size_t)nh + 1, rocprim::plus<unsigned>(), st));
+  unsigned total = 0;
+  SCL_HIP(ctx, hipMemcpyAsync(&total, pos + nh, sizeof(unsigned), hipMemcpyDeviceToHost, st));
+  SCL_HIP(ctx, hipStreamSynchronize(st));
+  *ncand = (int64_t)total;
+  if (total == 0) return SCLENS_OK;
+  uint32_t* z1 = keep<uint32_t>(ctx, out, total);
+  uint32_t* z2 = keep<uint32_t>(ctx, out, total);
+  if (!z1 || !z2) return SCLENS_ERR_OOM;
+  hipLaunchKernelGGL((k_r1_block_out<K>), dim3(gh), dim3(256), 0, st, keys, flag, pos, nh, (uint64_t)Nl, z1, z2);
+  SCL_HIP(ctx, hipStreamSynchronize(st));  // `tmp` dies with this frame
+  *z1o = z1;
+  *z2o = z2;
+  return SCLENS_OK;
+}
+
 // ---- union pattern ----------------------------------------------------------------------------------------------------------
 __global__ void k_count_u32(const uint32_t* __restrict__ key, int64_t n, uint32_t limit, unsigned* __restrict__ cnt, int* __restrict__ bad) {
   const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -227,30 +342,56 @@ int scan_i64(Ctx* ctx, DevTmp& tmp, const int64_t* in, int64_t* out, size_t n) {
 
 // draw != 0: the candidate list is drawn on the device from `seed` (z1_h / z2_h ignored); else it is uploaded from the host
 // (ncand entries). The candidate list stays on the device in out->z1_dev / z2_dev (sclens_hip_pattern_candidates downloads it).
+// nnz_dev >= 0: colptr / rowval / nzval are DEVICE arrays of a count matrix with nnz_dev stored entries (a sclens_hip_counts
+// handle: the output of the QC filter that stayed in HBM) and are read in place; otherwise host arrays, uploaded.
 int pattern_build_device(Ctx* ctx, int64_t N, int64_t M, const int64_t* colptr, const int32_t* rowval, const float* nzval, int64_t ncand,
-                         const uint32_t* z1_h, const uint32_t* z2_h, int draw, uint64_t seed, PatternOwner* out) {
-  if (N <= 0 || M <= 0 || !colptr || (colptr[M] > 0 && (!rowval || !nzval)) || (!draw && ncand > 0 && (!z1_h || !z2_h)))
+                         const uint32_t* z1_h, const uint32_t* z2_h, int draw, uint64_t seed, PatternOwner* out, int64_t nnz_dev,
+                         const BlockDraw* blk) {
+  const bool src_dev = nnz_dev >= 0;
+  if (blk && (!draw || blk->N_global < N || blk->row0 < 0 || blk->row0 + N > blk->N_global || blk->nnz_global < 0 ||
+              blk->nnz_global >= 0xFFFFFFF0ll))
+    return ctx->fail(SCLENS_ERR_ARG, "pattern_build_device: bad block-draw arguments");
+  if (N <= 0 || M <= 0 || !colptr || (!src_dev && colptr[M] > 0 && (!rowval || !nzval)) || (src_dev && nnz_dev > 0 && (!rowval || !nzval)) ||
+      (!draw && ncand > 0 && (!z1_h || !z2_h)))
     return ctx->fail(SCLENS_ERR_ARG, "pattern_build_device: bad arguments");
-  const int64_t nnz = colptr[M];
+  const int64_t nnz = src_dev ? nnz_dev : colptr[M];
   if (nnz >= 0xFFFFFFF0ll || N >= 0x7FFFFFFFll || M >= 0x7FFFFFFFll)
     return ctx->fail(SCLENS_ERR_ARG, "pattern_build_device: more than 2^32 stored entries");
   hipStream_t st = ctx->stream;
   DevTmp tmp;
-  int64_t* cp = tmp.get<int64_t>(ctx, M + 1);
-  int32_t* rv = tmp.get<int32_t>(ctx, nnz);
-  float* nz = tmp.get<float>(ctx, nnz);
+  const int64_t* cp = colptr;
+  const int32_t* rv = rowval;
+  const float* nz = nzval;
   int* bad = tmp.get<int>(ctx, 4);
-  if (!cp || !rv || !nz || !bad) return SCLENS_ERR_OOM;
-  SCL_HIP(ctx, hipMemcpyAsync(cp, colptr, sizeof(int64_t) * (M + 1), hipMemcpyHostToDevice, st));
-  if (nnz > 0) {
-    SCL_HIP(ctx, hipMemcpyAsync(rv, rowval, sizeof(int32_t) * nnz, hipMemcpyHostToDevice, st));
-    SCL_HIP(ctx, hipMemcpyAsync(nz, nzval, sizeof(float) * nnz, hipMemcpyHostToDevice, st));
+  if (!bad) return SCLENS_ERR_OOM;
+  if (!src_dev) {
+    int64_t* cpu = tmp.get<int64_t>(ctx, M + 1);
+    int32_t* rvu = tmp.get<int32_t>(ctx, nnz);
+    float* nzu = tmp.get<float>(ctx, nnz);
+    if (!cpu || !rvu || !nzu) return SCLENS_ERR_OOM;
+    SCL_HIP(ctx, hipMemcpyAsync(cpu, colptr, sizeof(int64_t) * (M + 1), hipMemcpyHostToDevice, st));
+    if (nnz > 0) {
+      SCL_HIP(ctx, hipMemcpyAsync(rvu, rowval, sizeof(int32_t) * nnz, hipMemcpyHostToDevice, st));
+      SCL_HIP(ctx, hipMemcpyAsync(nzu, nzval, sizeof(float) * nnz, hipMemcpyHostToDevice, st));
+    }
+    cp = cpu; rv = rvu; nz = nzu;
   }
   SCL_HIP(ctx, hipMemsetAsync(bad, 0, sizeof(int) * 4, st));
   const unsigned gcol = (unsigned)((M + 3) / 4);
   // ---- candidates
   uint32_t *z1 = nullptr, *z2 = nullptr;
-  if (draw) {
+  if (draw && blk) {  // this rank's part of the global draw (row-sharded session): z1 = LOCAL cell indices
+    ncand = 0;
+    const uint64_t cells = (uint64_t)N * (uint64_t)M;
+    unsigned* bits = tmp.get<unsigned>(ctx, (cells + 31) / 32 + 1);
+    if (!bits) return SCLENS_ERR_OOM;
+    SCL_HIP(ctx, hipMemsetAsync(bits, 0, sizeof(unsigned) * ((cells + 31) / 32 + 1), st));
+    if (nnz > 0) hipLaunchKernelGGL(k_nz_bitmap, dim3(gcol), dim3(256), 0, st, cp, rv, N, M, bits, bad);
+    if (cells < 0xFFFFFFF0ull)
+      SCL_TRY((r1_draw_device_block<uint32_t>(ctx, out, seed, blk->nnz_global, blk->N_global, M, blk->row0, N, bits, &z1, &z2, &ncand)));
+    else
+      SCL_TRY((r1_draw_device_block<uint64_t>(ctx, out, seed, blk->nnz_global, blk->N_global, M, blk->row0, N, bits, &z1, &z2, &ncand)));
+  } else if (draw) {
     ncand = 0;
     if (nnz > 0) {
       z1 = keep<uint32_t>(ctx, out, nnz);

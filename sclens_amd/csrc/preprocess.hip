@@ -15,6 +15,7 @@
 #include <numeric>
 
 #include "common.h"
+#include "pattern.h"
 
 namespace scl {
 
@@ -269,6 +270,42 @@ int preprocess_gather(Ctx* ctx, int64_t* out_colptr, int32_t* out_rowval, float*
   SCL_HIP(ctx, hipStreamSynchronize(st));
   ctx->pp.valid = false;
   for (const char* name : {"pp.colptr", "pp.row", "pp.val", "pp.orow", "pp.oval"}) ctx->release(name);  // the large ones
+  return SCLENS_OK;
+}
+
+// pass 4': the filtered matrix stays in HBM as a Counts object (the hand-over preprocess -> sclens of SURVEY 8f-3: what
+// preprocess_gather would send to the host, 8 bytes per stored entry, and session_create would send straight back)
+int preprocess_keep(Ctx* ctx, Counts** out) {
+  if (!ctx->pp.valid) return ctx->fail(SCLENS_ERR_STATE, "preprocess_keep: no preceding preprocess call with a non-empty result");
+  const int64_t ng = ctx->pp.n_genes, nnz = ctx->pp.nnz_out;
+  hipStream_t st = ctx->stream;
+  auto ws = [&](const char* name) { return ctx->ws.at(name).first; };
+  const int64_t* d_colptr = static_cast<const int64_t*>(ws("pp.colptr"));
+  const int32_t* d_row = static_cast<const int32_t*>(ws("pp.row"));
+  const float* d_val = static_cast<const float*>(ws("pp.val"));
+  const int32_t* d_rowmap = static_cast<const int32_t*>(ws("pp.rowmap"));
+  const int64_t* d_genes = static_cast<const int64_t*>(ws("pp.genes"));
+  const int64_t* d_ocol = static_cast<const int64_t*>(ws("pp.ocolptr"));
+  Counts* c = new Counts();
+  c->device = ctx->device; c->N = ctx->pp.n_cells; c->M = ng; c->nnz = nnz;
+  if (pool_malloc((void**)&c->colptr, sizeof(int64_t) * (ng + 1)) != hipSuccess ||
+      pool_malloc((void**)&c->row, sizeof(int32_t) * (nnz > 4 ? nnz : 4)) != hipSuccess ||
+      pool_malloc((void**)&c->val, sizeof(float) * (nnz > 4 ? nnz : 4)) != hipSuccess) {
+    counts_free(c);
+    return ctx->fail(SCLENS_ERR_OOM, "preprocess_keep: out of device memory");
+  }
+  hipLaunchKernelGGL(k_pp_gather, dim3((unsigned)((ng + 3) / 4)), dim3(256), 0, st, ng, d_genes, d_colptr, d_row, d_val,
+                     d_rowmap, d_ocol, c->row, c->val);
+  hipError_t e = hipGetLastError();
+  if (e == hipSuccess) e = hipMemcpyAsync(c->colptr, d_ocol, sizeof(int64_t) * (ng + 1), hipMemcpyDeviceToDevice, st);
+  if (e == hipSuccess) e = hipStreamSynchronize(st);
+  if (e != hipSuccess) {
+    counts_free(c);
+    return ctx->fail(SCLENS_ERR_HIP, std::string("preprocess_keep: ") + hipGetErrorString(e));
+  }
+  ctx->pp.valid = false;
+  for (const char* name : {"pp.colptr", "pp.row", "pp.val"}) ctx->release(name);  // the raw matrix
+  *out = c;
   return SCLENS_OK;
 }
 

@@ -402,9 +402,9 @@ __global__ void k_sh_col_cent_fin(const double* __restrict__ part, const double*
   if (col < M) cent[col] = (part[col] / stdv[col] - mu[col] * part[M]) / n_global;  // part[M] = sum of s over all cells
 }
 
-int scale_to_dense_sharded(Ctx* ctx, const PatternDev& p, const float* val, int f32path, float* B, int64_t ldb,
-                           ScaleVecs* keep, const ShardReduce& sh) {
-  StageTimer tm(ctx, "scale");
+// statistics of the row-sharded normalisation: per-cell vectors cover the local cells, per-gene vectors are global (identical on
+// every rank after the all-reduces)
+int scale_stats_sharded(Ctx* ctx, const PatternDev& p, const float* val, int f32path, const ShardReduce& sh, ScaleStats* out) {
   const int64_t N = p.N, M = p.M;  // N = local cells
   const double ng = (double)sh.N_global;
   SCL_WS(ctx, tgc, double, "sc.tgc", N);
@@ -435,6 +435,20 @@ int scale_to_dense_sharded(Ctx* ctx, const PatternDev& p, const float* val, int 
   hipLaunchKernelGGL(k_reduce, dim3(1), dim3(1024), 0, st, srow, N, 1, part + M);  // local sum of s, appended
   SCL_TRY(sh.sum(ctx, part, M + 1, 0));
   hipLaunchKernelGGL(k_sh_col_cent_fin, dim3(gcm), dim3(256), 0, st, part, stdv, mu, ng, M, cent);
+  SCL_HIP(ctx, hipGetLastError());
+  *out = ScaleStats{tgc, lg, mean, stdv, mu, l2, srow, cent, red};
+  return SCLENS_OK;
+}
+
+int scale_to_dense_sharded(Ctx* ctx, const PatternDev& p, const float* val, int f32path, float* B, int64_t ldb,
+                           ScaleVecs* keep, const ShardReduce& sh) {
+  StageTimer tm(ctx, "scale");
+  const int64_t N = p.N, M = p.M;
+  ScaleStats ss;
+  SCL_TRY(scale_stats_sharded(ctx, p, val, f32path, sh, &ss));
+  const double *tgc = ss.tgc, *lg = ss.lg, *mean = ss.mean, *stdv = ss.stdv, *mu = ss.mu, *l2 = ss.l2, *srow = ss.srow, *cent = ss.cent;
+  hipStream_t st = ctx->stream;
+  const unsigned gc4 = (unsigned)((M + 3) / 4);
   if (M > 65535LL * 65535LL) return ctx->fail(SCLENS_ERR_ARG, "scale_to_dense: too many rows");
   for (int64_t r0 = 0; r0 < M; r0 += 65535) {  // genes-major: B[j][i_local]
     const int64_t rows = (M - r0 < 65535) ? M - r0 : 65535;
@@ -463,13 +477,17 @@ __global__ void k_val_init(const float* __restrict__ base, int64_t nU, int binar
     out[q] = binary ? (b != 0.f ? 1.f : 0.f) : b;
   }
 }
-// out[cand_pos[idx[t]]] = 1 (indices >= ncand are ignored rather than dereferenced)
+// out[cand_pos[idx[t] - cand_off]] = 1 for the sampled candidates this pattern holds: indices outside [cand_off, cand_off + ncand)
+// belong to other ranks of a row-sharded session (or are out of range) and are ignored rather than dereferenced
 __global__ void k_val_set_ones(const uint32_t* __restrict__ idx, int64_t m, const int64_t* __restrict__ cand_pos,
-                               int64_t ncand, float* __restrict__ out) {
+                               int64_t cand_off, int64_t ncand, float* __restrict__ out) {
   const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (t < m && (int64_t)idx[t] < ncand) {
-    const int64_t pos = cand_pos[idx[t]];
-    if (pos >= 0) out[pos] = 1.f;  // -1: the candidate's cell belongs to another rank (row-sharded session)
+  if (t < m) {
+    const int64_t g = (int64_t)idx[t] - cand_off;
+    if (g >= 0 && g < ncand) {
+      const int64_t pos = cand_pos[g];
+      if (pos >= 0) out[pos] = 1.f;  // -1: the candidate's cell belongs to another rank (row-sharded session, global list)
+    }
   }
 }
 
@@ -477,31 +495,36 @@ int make_values(Ctx* ctx, const PatternDev& p, const float* base_val, int binary
                 float* out) {
   hipLaunchKernelGGL(k_val_init, dim3((unsigned)((p.nU + 255) / 256)), dim3(256), 0, ctx->stream, base_val, p.nU,
                      binary, out);
-  if (m > 0)
+  if (m > 0 && p.ncand > 0)
     hipLaunchKernelGGL(k_val_set_ones, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, ctx->stream, idx_dev, m,
-                       p.cand_pos, p.ncand, out);
+                       p.cand_pos, p.cand_off, p.ncand, out);
   SCL_HIP(ctx, hipGetLastError());
   return SCLENS_OK;
 }
 
-__global__ void k_val_set_ones_feistel(FeistelPerm perm, int64_t m, const int64_t* __restrict__ cand_pos,
-                                       float* __restrict__ out) {
+__global__ void k_val_set_ones_feistel(FeistelPerm perm, int64_t m, const int64_t* __restrict__ cand_pos, int64_t cand_off,
+                                       int64_t ncand, float* __restrict__ out) {
   const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (t < m) {
-    const int64_t pos = cand_pos[feistel_apply(perm, (uint64_t)t)];
-    if (pos >= 0) out[pos] = 1.f;
+    const int64_t g = (int64_t)feistel_apply(perm, (uint64_t)t) - cand_off;
+    if (g >= 0 && g < ncand) {
+      const int64_t pos = cand_pos[g];
+      if (pos >= 0) out[pos] = 1.f;
+    }
   }
 }
 
 int make_values_seeded(Ctx* ctx, const PatternDev& p, const float* base_val, int binary, uint64_t seed, int64_t m,
                        float* out) {
-  if (m < 0 || m > p.ncand) return ctx->fail(SCLENS_ERR_ARG, "make_values_seeded: bad sample size");
+  if (m < 0 || m > p.population()) return ctx->fail(SCLENS_ERR_ARG, "make_values_seeded: bad sample size");
   hipLaunchKernelGGL(k_val_init, dim3((unsigned)((p.nU + 255) / 256)), dim3(256), 0, ctx->stream, base_val, p.nU,
                      binary, out);
   if (m > 0) {
-    const FeistelPerm perm = feistel_make((uint64_t)p.ncand, seed);
+    // the permutation is over the GLOBAL candidate list: every rank of a row-sharded session evaluates the same sample and
+    // keeps the part that falls into its own window
+    const FeistelPerm perm = feistel_make((uint64_t)p.population(), seed);
     hipLaunchKernelGGL(k_val_set_ones_feistel, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, ctx->stream, perm, m,
-                       p.cand_pos, out);
+                       p.cand_pos, p.cand_off, p.ncand, out);
   }
   SCL_HIP(ctx, hipGetLastError());
   return SCLENS_OK;

@@ -116,7 +116,8 @@ static int upload(Ctx* ctx, PatternOwner* o, const std::vector<T>& h, const T** 
 
 int pattern_build(Ctx* ctx, int64_t N, int64_t M, const int64_t* colptr, const int32_t* rowval, const float* nzval,
                   int64_t ncand, const uint32_t* z1, const uint32_t* z2, PatternOwner* out, int64_t row0, int64_t N_global) {
-  if (N <= 0 || M <= 0 || !colptr || (colptr[M] > 0 && (!rowval || !nzval)) || (ncand > 0 && (!z1 || !z2)))
+  if (N <= 0 || M <= 0 || !colptr) return ctx->fail(SCLENS_ERR_ARG, "pattern_build: bad arguments");
+  if ((colptr[M] > 0 && (!rowval || !nzval)) || (ncand > 0 && (!z1 || !z2)))
     return ctx->fail(SCLENS_ERR_ARG, "pattern_build: bad arguments");
   if (N_global <= 0) N_global = N;
   if (row0 < 0 || row0 + N > N_global) return ctx->fail(SCLENS_ERR_ARG, "pattern_build: bad row range");
@@ -246,8 +247,9 @@ struct Session {
   int64_t count_positive() const { return count_positive_tol(w_host); }
 };
 
-int session_create(Ctx* ctx, int64_t N, int64_t M, const int64_t* colptr, const int32_t* rowval, const float* nzval,
-                   int64_t ncand, const uint32_t* z1, const uint32_t* z2, Session** out) {
+// counts != nullptr: the count matrix is a device-resident sclens_hip_counts (colptr / rowval / nzval unused)
+static int session_create_impl(Ctx* ctx, int64_t N, int64_t M, const int64_t* colptr, const int32_t* rowval, const float* nzval,
+                               int64_t ncand, const uint32_t* z1, const uint32_t* z2, const Counts* counts, Session** out) {
   if (ctx->live_sessions > 0)
     return ctx->fail(SCLENS_ERR_STATE, "session_create: this context already has a live session (its workspaces are per context)");
   Session* s = new Session();
@@ -256,8 +258,9 @@ int session_create(Ctx* ctx, int64_t N, int64_t M, const int64_t* colptr, const 
   s->n = std::min(N, M); s->K = std::max(N, M);
   s->Kdiv = s->K;
   s->cells_major = (N <= M) ? 1 : 0;
-  int rc = pattern_build(ctx, N, M, colptr, rowval, nzval, ncand, z1, z2, &s->pat);
-  if (rc != SCLENS_OK) { delete s; return rc; }
+  int rc = counts ? pattern_build_device(ctx, N, M, counts->colptr, counts->row, counts->val, ncand, z1, z2, 0, 0, &s->pat, counts->nnz)
+                  : pattern_build(ctx, N, M, colptr, rowval, nzval, ncand, z1, z2, &s->pat);
+  if (rc != SCLENS_OK) { pattern_free(&s->pat); delete s; return rc; }
   s->ldb = round_up(s->K, 32);
   s->lda = round_up(s->n, 32);
   s->ldz = round_up(s->n, 32);
@@ -271,6 +274,62 @@ int session_create(Ctx* ctx, int64_t N, int64_t M, const int64_t* colptr, const 
   s->ctx->live_sessions += 1;
   *out = s;
   return SCLENS_OK;
+}
+int session_create(Ctx* ctx, int64_t N, int64_t M, const int64_t* colptr, const int32_t* rowval, const float* nzval,
+                   int64_t ncand, const uint32_t* z1, const uint32_t* z2, Session** out) {
+  return session_create_impl(ctx, N, M, colptr, rowval, nzval, ncand, z1, z2, nullptr, out);
+}
+// the session of a count matrix that is already in HBM (preprocess -> sclens without the host round trip);
+// counts only -- the zero candidates are attached later (session_set_pattern), as api.sclens does
+int session_create_from_counts(Ctx* ctx, const Counts* c, Session** out) {
+  if (!c || c->device != ctx->device) return ctx->fail(SCLENS_ERR_ARG, "session_create_from_counts: counts of another device");
+  return session_create_impl(ctx, c->N, c->M, nullptr, nullptr, nullptr, 0, nullptr, nullptr, c, out);
+}
+int pattern_create_drawn_from_counts(Ctx* ctx, const Counts* c, uint64_t seed, PatternOwner** out, int64_t* ncand) {
+  if (!c || c->device != ctx->device) return ctx->fail(SCLENS_ERR_ARG, "pattern_create_drawn_from_counts: counts of another device");
+  PatternOwner* p = new PatternOwner();
+  const int rc = pattern_build_device(ctx, c->N, c->M, c->colptr, c->row, c->val, 0, nullptr, nullptr, 1, seed, p, c->nnz);
+  if (rc != SCLENS_OK) {
+    pattern_free(p);
+    delete p;
+    return rc;
+  }
+  if (ncand) *ncand = p->dev.ncand;
+  *out = p;
+  return SCLENS_OK;
+}
+int counts_upload(Ctx* ctx, int64_t N, int64_t M, const int64_t* colptr, const int32_t* rowval, const float* nzval, Counts** out) {
+  if (N <= 0 || M <= 0 || !colptr || colptr[M] < 0 || (colptr[M] > 0 && (!rowval || !nzval)))
+    return ctx->fail(SCLENS_ERR_ARG, "counts_upload: bad arguments");
+  Counts* c = new Counts();
+  c->device = ctx->device; c->N = N; c->M = M; c->nnz = colptr[M];
+  auto bail = [&](int code) { counts_free(c); return code; };
+  if (pool_malloc((void**)&c->colptr, sizeof(int64_t) * (M + 1)) != hipSuccess || pool_malloc((void**)&c->row, sizeof(int32_t) * std::max<int64_t>(c->nnz, 4)) != hipSuccess ||
+      pool_malloc((void**)&c->val, sizeof(float) * std::max<int64_t>(c->nnz, 4)) != hipSuccess)
+    return bail(ctx->fail(SCLENS_ERR_OOM, "counts_upload: out of device memory"));
+  hipStream_t st = ctx->stream;
+  hipError_t e = hipMemcpyAsync(c->colptr, colptr, sizeof(int64_t) * (M + 1), hipMemcpyHostToDevice, st);
+  if (e == hipSuccess && c->nnz > 0) e = hipMemcpyAsync(c->row, rowval, sizeof(int32_t) * c->nnz, hipMemcpyHostToDevice, st);
+  if (e == hipSuccess && c->nnz > 0) e = hipMemcpyAsync(c->val, nzval, sizeof(float) * c->nnz, hipMemcpyHostToDevice, st);
+  if (e == hipSuccess) e = hipStreamSynchronize(st);
+  if (e != hipSuccess) return bail(ctx->fail(SCLENS_ERR_HIP, std::string("counts_upload: ") + hipGetErrorString(e)));
+  *out = c;
+  return SCLENS_OK;
+}
+int counts_download(Ctx* ctx, const Counts* c, int64_t* colptr, int32_t* rowval, float* nzval) {
+  hipStream_t st = ctx->stream;
+  if (colptr) SCL_HIP(ctx, hipMemcpyAsync(colptr, c->colptr, sizeof(int64_t) * (c->M + 1), hipMemcpyDeviceToHost, st));
+  if (rowval && c->nnz > 0) SCL_HIP(ctx, hipMemcpyAsync(rowval, c->row, sizeof(int32_t) * c->nnz, hipMemcpyDeviceToHost, st));
+  if (nzval && c->nnz > 0) SCL_HIP(ctx, hipMemcpyAsync(nzval, c->val, sizeof(float) * c->nnz, hipMemcpyDeviceToHost, st));
+  SCL_HIP(ctx, hipStreamSynchronize(st));
+  return SCLENS_OK;
+}
+void counts_free(Counts* c) {
+  if (!c) return;
+  pool_free(c->colptr, nullptr);  // contract: no session / pattern build reads it any more (blocking API)
+  pool_free(c->row, nullptr);
+  pool_free(c->val, nullptr);
+  delete c;
 }
 
 int pattern_create(Ctx* ctx, int64_t N, int64_t M, const int64_t* colptr, const int32_t* rowval, const float* nzval,
@@ -378,6 +437,74 @@ int session_set_reducer(Session* s, sclens_hip_allreduce_fn fn, void* user) {
   s->sh.user = user;
   return SCLENS_OK;
 }
+int session_set_reduce_to(Session* s, sclens_hip_reduce_fn fn, void* user) {
+  if (!s->sh.on()) return s->ctx->fail(SCLENS_ERR_STATE, "set_reduce_to: not a row-sharded session");
+  s->sh.rfn = fn;
+  s->sh.ruser = user;
+  return SCLENS_OK;
+}
+// row-sharded session with LOCAL candidates drawn on the device (this rank's part of the global draw sequence)
+int session_create_sharded_drawn(Ctx* ctx, int64_t N_global, int64_t row0, int64_t N_local, int64_t M, const int64_t* colptr,
+                                 const int32_t* rowval, const float* nzval, int64_t nnz_global, uint64_t seed,
+                                 sclens_hip_allreduce_fn fn, void* user, Session** out, int64_t* ncand_local) {
+  if (!fn) return ctx->fail(SCLENS_ERR_ARG, "session_create_sharded_drawn: an all-reduce function is required");
+  if (N_global <= M) return ctx->fail(SCLENS_ERR_ARG, "session_create_sharded_drawn: only the cells > genes layout shards by cells");
+  if (N_local <= 0 || row0 < 0 || row0 + N_local > N_global || !colptr || nnz_global < colptr[M])
+    return ctx->fail(SCLENS_ERR_ARG, "session_create_sharded_drawn: bad cell range / entry count");
+  if (ctx->live_sessions > 0)
+    return ctx->fail(SCLENS_ERR_STATE, "session_create_sharded_drawn: this context already has a live session");
+  Session* s = new Session();
+  s->ctx = ctx;
+  s->N = N_local; s->M = M;
+  s->n = M; s->K = N_local; s->Kdiv = N_global;
+  s->cells_major = 0;
+  s->sh.N_global = N_global; s->sh.row0 = row0; s->sh.fn = fn; s->sh.user = user;
+  const BlockDraw blk{N_global, row0, nnz_global};
+  int rc = pattern_build_device(ctx, N_local, M, colptr, rowval, nzval, 0, nullptr, nullptr, 1, seed, &s->pat, -1, &blk);
+  if (rc != SCLENS_OK) { pattern_free(&s->pat); delete s; return rc; }
+  // until the host has gathered the ranks' counts the window is unknown: samples are refused (population 0 < m)
+  s->pat.dev.cand_off = 0;
+  s->pat.dev.ncand_global = s->pat.dev.ncand;
+  s->ldb = round_up(s->K, 32);
+  s->lda = round_up(s->n, 32);
+  s->ldz = round_up(s->n, 32);
+  s->ldn = round_up(N_local, 32);
+  auto fail = [&](int code) { pattern_free(&s->pat); for (void* p : s->allocs) pool_free(p, s->ctx->stream); delete s; return code; };
+  if ((rc = s->dmalloc((void**)&s->val, sizeof(float) * s->pat.dev.nU)) != SCLENS_OK) return fail(rc);
+  if ((rc = s->dmalloc((void**)&s->Bmain, sizeof(float) * (size_t)s->n * s->ldb)) != SCLENS_OK) return fail(rc);
+  if ((rc = s->dmalloc((void**)&s->Btmp, sizeof(float) * (size_t)s->n * s->ldb)) != SCLENS_OK) return fail(rc);
+  if ((rc = s->dmalloc((void**)&s->A, sizeof(float) * (size_t)s->n * s->lda)) != SCLENS_OK) return fail(rc);
+  if ((rc = s->dmalloc((void**)&s->w64, sizeof(double) * s->n)) != SCLENS_OK) return fail(rc);
+  s->ctx->live_sessions += 1;
+  if (ncand_local) *ncand_local = s->pat.dev.ncand;
+  *out = s;
+  return SCLENS_OK;
+}
+int session_set_candidate_range(Session* s, int64_t cand_off, int64_t ncand_global) {
+  if (!s->sh.on()) return s->ctx->fail(SCLENS_ERR_STATE, "set_candidate_range: not a row-sharded session");
+  if (cand_off < 0 || cand_off + s->pat.dev.ncand > ncand_global || ncand_global >= 0xFFFFFFF0ll)
+    return s->ctx->fail(SCLENS_ERR_ARG, "set_candidate_range: the window does not fit the global list");
+  s->pat.dev.cand_off = cand_off;
+  s->pat.dev.ncand_global = ncand_global;
+  return SCLENS_OK;
+}
+__global__ void k_add_u32(const uint32_t* __restrict__ in, int64_t n, uint32_t add, uint32_t* __restrict__ out) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = in[i] + add;
+}
+int session_local_candidates(Session* s, uint32_t* z1, uint32_t* z2) {
+  Ctx* ctx = s->ctx;
+  const int64_t nc = s->pat.dev.ncand;
+  if (nc > 0 && (!s->pat.z1_dev || !s->pat.z2_dev))
+    return ctx->fail(SCLENS_ERR_STATE, "local_candidates: this session does not hold its candidate list on the device");
+  if (nc == 0) return SCLENS_OK;
+  SCL_WS(ctx, tmp, uint32_t, "ses.z1g", nc);
+  hipLaunchKernelGGL(k_add_u32, dim3((unsigned)((nc + 255) / 256)), dim3(256), 0, ctx->stream, s->pat.z1_dev, nc, (uint32_t)s->sh.row0, tmp);
+  SCL_HIP(ctx, hipMemcpyAsync(z1, tmp, sizeof(uint32_t) * nc, hipMemcpyDeviceToHost, ctx->stream));
+  SCL_HIP(ctx, hipMemcpyAsync(z2, s->pat.z2_dev, sizeof(uint32_t) * nc, hipMemcpyDeviceToHost, ctx->stream));
+  SCL_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return SCLENS_OK;
+}
 
 // A second session on another context (= another stream of the same GPU) that shares the read-only device data of
 // `src` (sparse pattern, Vr2, CheFSI seed block) and owns its scratch: independent search iterations / ensemble members
@@ -425,7 +552,7 @@ void session_destroy(Session* s) {
 // binary: every value of `val` is 0 or 1 (sparsity search): large problems in the genes-major layout then skip the scaled
 // matrix and form the Gram matrix on the fp16 MFMA (gram_bits.hip); B is only scratch in that case
 static bool use_gram_bits(const Session* s) {
-  if (s->sh.on() || s->centering || s->cells_major || s->ctx->gram_bits == 0) return false;
+  if (s->centering || s->cells_major || s->ctx->gram_bits == 0) return false;  // row-sharded sessions: each rank's additive part
   if (s->ctx->gram_bits == 1) return true;
   static const int64_t min_n = getenv("SCLENS_HIP_GRAM_BITS_MIN_N") ? atoll(getenv("SCLENS_HIP_GRAM_BITS_MIN_N")) : 16000;
   return s->n >= min_n;
@@ -437,20 +564,30 @@ static bool use_f16_corr(const Session* s) {
   static const int64_t min_n = getenv("SCLENS_HIP_GRAM_BITS_MIN_N") ? atoll(getenv("SCLENS_HIP_GRAM_BITS_MIN_N")) : 16000;
   return s->n >= min_n;
 }
+// sum_root >= 0 (row-sharded session): the Gram matrix is summed onto that rank only and formed in `Aout` (default s->A);
+// solve = false: stop after the Gram matrix
 static int decompose(Session* s, const PatternDev& p, const float* val, int f32path, float* B, float divisor,
-                     ScaleVecs* keep, int64_t n_low = -1, bool binary = false) {
+                     ScaleVecs* keep, int64_t n_low = -1, bool binary = false, bool solve = true, int sum_root = -1,
+                     float* Aout = nullptr) {
+  float* Ag = Aout ? Aout : s->A;
   if (binary && !keep && use_gram_bits(s)) {
-    SCL_TRY(gram_binary(s->ctx, p, val, f32path, B, divisor, s->A, s->lda));
+    SCL_TRY(gram_binary(s->ctx, p, val, f32path, B, divisor, Ag, s->lda, s->sh.on() ? &s->sh : nullptr));
     s->ctx->gram_bits_used += 1;
+    if (s->sh.on()) {
+      if (sum_root >= 0) SCL_TRY(s->sh.sum_to(s->ctx, Ag, s->n * s->lda, 1, sum_root));
+      else SCL_TRY(s->sh.sum(s->ctx, Ag, s->n * s->lda, 1));
+    }
   } else if (s->sh.on()) {  // partial statistics and a partial Gram matrix over this rank's cells, summed over the ranks
     SCL_TRY(scale_to_dense_sharded(s->ctx, p, val, f32path, B, s->ldb, keep, s->sh));
-    SCL_TRY(gram_f32(s->ctx, B, s->n, s->K, s->ldb, divisor, s->A, s->lda));
-    SCL_TRY(s->sh.sum(s->ctx, s->A, s->n * s->lda, 1));
+    SCL_TRY(gram_f32(s->ctx, B, s->n, s->K, s->ldb, divisor, Ag, s->lda));
+    if (sum_root >= 0) SCL_TRY(s->sh.sum_to(s->ctx, Ag, s->n * s->lda, 1, sum_root));
+    else SCL_TRY(s->sh.sum(s->ctx, Ag, s->n * s->lda, 1));
   } else {
     SCL_TRY(scale_to_dense(s->ctx, p, val, s->centering ? 1 : f32path, s->centering, s->cells_major, B, s->ldb,
                            s->centering ? nullptr : keep));
-    SCL_TRY(gram_f32(s->ctx, B, s->n, s->K, s->ldb, divisor, s->A, s->lda));
+    SCL_TRY(gram_f32(s->ctx, B, s->n, s->K, s->ldb, divisor, Ag, s->lda));
   }
+  if (!solve) return SCLENS_OK;
   SCL_TRY(eig_values(s->ctx, s->A, s->n, s->lda, s->w64, n_low));
   return s->fetch_w(n_low >= 0);
 }
@@ -735,11 +872,11 @@ int session_binary_basis(Session* s, double* L_bin, int64_t* r_out) {
   return SCLENS_OK;
 }
 
-static int search_core(Session* s, int64_t n_2, double* d5, int64_t* r_it);
+static int search_core(Session* s, int64_t n_2, double* d5, int64_t* r_it, bool gram_done = false);
 int session_search_step(Session* s, const uint32_t* sample, int64_t m, int64_t n_2, double* d5, int64_t* r_it) {
   Ctx* ctx = s->ctx;
   if (!s->Vr2t) return ctx->fail(SCLENS_ERR_STATE, "search_step: call binary_basis first");
-  if (m < 0 || m > s->pat.dev.ncand) return ctx->fail(SCLENS_ERR_ARG, "search_step: bad sample size");
+  if (m < 0 || m > s->pat.dev.population()) return ctx->fail(SCLENS_ERR_ARG, "search_step: bad sample size");
   SCL_TRY(s->upload_idx(sample, m));
   SCL_TRY(make_values(ctx, s->pat.dev, s->pat.base_val, 1, s->idx_dev, m, s->val));
   return search_core(s, n_2, d5, r_it);
@@ -755,13 +892,19 @@ static int stebz_redo_all(Session* s) {
   SCL_TRY(eig_values_redo_all(s->ctx, s->n, s->w64));
   return s->fetch_w();
 }
-static int search_core(Session* s, int64_t n_2, double* d5, int64_t* r_it) {
+// gram_done: s->A already holds the (summed) Gram matrix of the evaluation (search rounds of a row-sharded session)
+static int search_core(Session* s, int64_t n_2, double* d5, int64_t* r_it, bool gram_done) {
   Ctx* ctx = s->ctx;
   // only the lower part of the spectrum is consumed (and the largest eigenvalue for the positivity floor): eigenvalues
   // [0, n_2 + 1 + slack) cover the n_2 + 1 smallest positive ones unless more than `slack` are non-positive -- then all
   const int64_t slack = 64;
   const int64_t n_low = (n_2 + 1 + slack < s->n - 1) ? n_2 + 1 + slack : -1;
-  SCL_TRY(decompose(s, s->pat.dev, s->val, 1, s->Btmp, (float)s->Kdiv, nullptr, n_low, /*binary=*/true));
+  if (gram_done) {
+    SCL_TRY(eig_values(ctx, s->A, s->n, s->lda, s->w64, n_low));
+    SCL_TRY(s->fetch_w(n_low >= 0));
+  } else {
+    SCL_TRY(decompose(s, s->pat.dev, s->val, 1, s->Btmp, (float)s->Kdiv, nullptr, n_low, /*binary=*/true));
+  }
   int64_t r = s->count_positive();
   if (n_low >= 0 && (s->n - r) > slack) {  // (never seen: a Gram matrix of the path has at most a few null eigenvalues)
     SCL_TRY(stebz_redo_all(s));
@@ -807,12 +950,38 @@ static int search_core(Session* s, int64_t n_2, double* d5, int64_t* r_it) {
   return SCLENS_OK;
 }
 
+// One round of the sparsity search of a row-sharded session: every rank contributes its partial Gram matrix to each of the
+// `count` evaluations, the sum of evaluation e lands on rank roots[e] (reduce; all-reduce if the host gave no reduce function),
+// then every rank decomposes the one evaluation it is the root of. The partial Gram products of a round cost count / world of
+// a full product per rank; the eigensolves -- 85 % of an evaluation -- run once each, in parallel, instead of on every rank.
+int session_search_round_seeded(Session* s, const uint64_t* seeds, const int64_t* m, const int32_t* roots, int count, int my_slot,
+                                int64_t n_2, double* d5, int64_t* r_it) {
+  Ctx* ctx = s->ctx;
+  if (!s->sh.on()) return ctx->fail(SCLENS_ERR_STATE, "search_round: row-sharded sessions only (use search_step)");
+  if (!s->Vr2t) return ctx->fail(SCLENS_ERR_STATE, "search_round: call binary_basis first");
+  if (count <= 0 || !seeds || !m || !roots || my_slot >= count) return ctx->fail(SCLENS_ERR_ARG, "search_round: bad arguments");
+  float* scratch = nullptr;
+  for (int e = 0; e < count; ++e) {
+    if (m[e] < 0 || m[e] > s->pat.dev.population()) return ctx->fail(SCLENS_ERR_ARG, "search_round: bad sample size");
+    SCL_TRY(make_values_seeded(ctx, s->pat.dev, s->pat.base_val, 1, seeds[e], m[e], s->val));
+    float* target = s->A;
+    if (e != my_slot) {
+      if (!scratch) scratch = static_cast<float*>(ctx->workspace("ses.Ascr", sizeof(float) * (size_t)s->n * s->lda));
+      if (!scratch) return SCLENS_ERR_OOM;
+      target = scratch;
+    }
+    SCL_TRY(decompose(s, s->pat.dev, s->val, 1, s->Btmp, (float)s->Kdiv, nullptr, -1, /*binary=*/true, /*solve=*/false, roots[e], target));
+  }
+  if (my_slot < 0) return SCLENS_OK;
+  return search_core(s, n_2, d5, r_it, /*gram_done=*/true);
+}
+
 static int perturb_core(Session* s, int64_t t, int64_t min_pc, double* nL_top, int64_t* ncols);
 int session_perturb(Session* s, int64_t t, const uint32_t* sample, int64_t m, int64_t min_pc, double* nL_top,
                     int64_t* ncols) {
   Ctx* ctx = s->ctx;
   if (t < 0 || min_pc <= 0) return ctx->fail(SCLENS_ERR_ARG, "perturb: bad slot / min_pc");
-  if (m < 0 || m > s->pat.dev.ncand) return ctx->fail(SCLENS_ERR_ARG, "perturb: bad sample size");
+  if (m < 0 || m > s->pat.dev.population()) return ctx->fail(SCLENS_ERR_ARG, "perturb: bad sample size");
   SCL_TRY(s->upload_idx(sample, m));
   SCL_TRY(make_values(ctx, s->pat.dev, s->pat.base_val, 0, s->idx_dev, m, s->val));
   return perturb_core(s, t, min_pc, nL_top, ncols);
@@ -875,6 +1044,102 @@ static int perturb_core(Session* s, int64_t t, int64_t min_pc, double* nL_top, i
   SCL_TRY(s->ensure_zt(c));
   SCL_TRY(eig_vectors(ctx, s->A, s->n, s->lda, s->w64, s->n - c, s->n, s->Zt, s->ldz));
   return to_cell_side(s, s->Btmp, c, slot);
+}
+
+// One round of the perturbation ensemble of a row-sharded session (scLENS.jl:771-778, members t[e]): partial Gram matrices summed
+// onto the members' roots, the roots decompose in parallel, then -- member by member -- the root's leading gene-side vectors are
+// shared (a sum in which the other ranks contribute zeros: min_pc x n floats) and every rank recovers its own cells of the
+// member's cell-side vectors from its block of the member's scaled matrix, which it forms a second time (the normalisation is
+// cheap next to keeping `count` scaled matrices).
+int session_perturb_round_seeded(Session* s, const int64_t* t, const uint64_t* seeds, const int64_t* m, const int32_t* roots, int count,
+                                 int my_slot, int64_t min_pc, double* nL_top, int64_t* ncols) {
+  Ctx* ctx = s->ctx;
+  if (!s->sh.on()) return ctx->fail(SCLENS_ERR_STATE, "perturb_round: row-sharded sessions only (use perturb)");
+  if (count <= 0 || !t || !seeds || !m || !roots || my_slot >= count || min_pc <= 0 || !nL_top || !ncols)
+    return ctx->fail(SCLENS_ERR_ARG, "perturb_round: bad arguments");
+  float* scratch = nullptr;
+  for (int e = 0; e < count; ++e) {
+    if (t[e] < 0 || m[e] < 0 || m[e] > s->pat.dev.population()) return ctx->fail(SCLENS_ERR_ARG, "perturb_round: bad slot / sample size");
+    SCL_TRY(make_values_seeded(ctx, s->pat.dev, s->pat.base_val, 0, seeds[e], m[e], s->val));
+    float* target = s->A;
+    if (e != my_slot) {
+      if (!scratch) scratch = static_cast<float*>(ctx->workspace("ses.Ascr", sizeof(float) * (size_t)s->n * s->lda));
+      if (!scratch) return SCLENS_ERR_OOM;
+      target = scratch;
+    }
+    SCL_TRY(decompose(s, s->pat.dev, s->val, 1, s->Btmp, (float)s->M, nullptr, -1, false, /*solve=*/false, roots[e], target));
+  }
+  // ---- the root's eigen-solve: leading min_pc pairs, rows of `mine` descending
+  float* zs = static_cast<float*>(ctx->workspace("ses.zshare", sizeof(float) * (size_t)min_pc * s->ldz));
+  double* ls = static_cast<double*>(ctx->workspace("ses.lshare", sizeof(double) * (size_t)(min_pc + 1)));
+  float* mine = static_cast<float*>(ctx->workspace("ses.zmine", sizeof(float) * (size_t)min_pc * s->ldz));
+  if (!zs || !ls || !mine) return SCLENS_ERR_OOM;
+  std::vector<double> my_l((size_t)min_pc + 1, 0.0);
+  if (my_slot >= 0) {
+    int64_t c = 0;
+    bool done = false;
+    const bool can_chefsi = s->use_chefsi && s->b0 >= min_pc + 8 && s->Z0t;
+    if (can_chefsi) {
+      SCL_TRY(s->ensure_zt(min_pc));
+      std::vector<double> wd(min_pc);
+      int conv = 0, its = 0;
+      SCL_TRY(topk_chefsi(ctx, s->A, s->n, s->lda, (int)min_pc, (int)std::min<int64_t>(s->k, min_pc), (int)s->b0, s->Z0t, s->ldz,
+                          s->theta0.data(), wd.data(), s->Zt, s->ldz, &conv, &its));
+      const double tol = 8.0 * 5.96e-8 * std::sqrt((double)s->n) * std::max(0.0, wd[0]);
+      if (conv && wd[min_pc - 1] > tol) {
+        s->chefsi_used += 1;
+        c = min_pc;
+        for (int64_t q = 0; q < min_pc; ++q) my_l[1 + q] = wd[q];
+        SCL_TRY(copy_rows_f32(ctx, s->Zt, c, s->n, s->ldz, mine, s->ldz));
+        done = true;
+      } else {
+        s->chefsi_fallback += 1;
+      }
+    }
+    if (!done) {
+      SCL_TRY(eig_values(ctx, s->A, s->n, s->lda, s->w64));
+      SCL_TRY(s->fetch_w());
+      c = std::min<int64_t>(min_pc, s->count_positive());
+      for (int64_t q = 0; q < c; ++q) my_l[1 + q] = s->w_host[s->n - 1 - q];
+      if (c > 0) {
+        SCL_TRY(s->ensure_zt(c));
+        SCL_TRY(eig_vectors(ctx, s->A, s->n, s->lda, s->w64, s->n - c, s->n, s->Zt, s->ldz));
+        SCL_TRY(reverse_rows_f32(ctx, s->Zt, c, s->n, s->ldz, mine, s->ldz));
+      }
+    }
+    my_l[0] = (double)c;
+  }
+  // ---- share member by member, recover the local cells
+  for (int e = 0; e < count; ++e) {
+    if ((int64_t)s->ens.size() <= t[e]) { s->ens.resize(t[e] + 1, nullptr); s->ens_cols.resize(t[e] + 1, 0); }
+    float* slot = static_cast<float*>(ctx->workspace("ses.ens" + std::to_string(t[e]), sizeof(float) * (size_t)min_pc * s->ldn));
+    if (!slot) return SCLENS_ERR_OOM;
+    s->ens[t[e]] = slot;
+    if (e == my_slot) {
+      SCL_HIP(ctx, hipMemcpyAsync(ls, my_l.data(), sizeof(double) * (size_t)(min_pc + 1), hipMemcpyHostToDevice, ctx->stream));
+      SCL_HIP(ctx, hipMemcpyAsync(zs, mine, sizeof(float) * (size_t)min_pc * s->ldz, hipMemcpyDeviceToDevice, ctx->stream));
+      const int64_t c = (int64_t)my_l[0];
+      if (c < min_pc)
+        SCL_HIP(ctx, hipMemsetAsync(zs + c * s->ldz, 0, sizeof(float) * (size_t)(min_pc - c) * s->ldz, ctx->stream));
+    } else {
+      SCL_HIP(ctx, hipMemsetAsync(ls, 0, sizeof(double) * (size_t)(min_pc + 1), ctx->stream));
+      SCL_HIP(ctx, hipMemsetAsync(zs, 0, sizeof(float) * (size_t)min_pc * s->ldz, ctx->stream));
+    }
+    SCL_TRY(s->sh.sum(ctx, ls, min_pc + 1, 0));
+    SCL_TRY(s->sh.sum(ctx, zs, min_pc * s->ldz, 1));
+    std::vector<double> hl((size_t)min_pc + 1);
+    SCL_HIP(ctx, hipMemcpyAsync(hl.data(), ls, sizeof(double) * (size_t)(min_pc + 1), hipMemcpyDeviceToHost, ctx->stream));
+    SCL_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    const int64_t c = (int64_t)(hl[0] + 0.5);
+    ncols[e] = c;
+    for (int64_t q = 0; q < min_pc; ++q) nL_top[(int64_t)e * min_pc + q] = (q < c) ? hl[1 + q] : 0.0;
+    s->ens_cols[t[e]] = c;
+    if (c == 0) continue;
+    SCL_TRY(make_values_seeded(ctx, s->pat.dev, s->pat.base_val, 0, seeds[e], m[e], s->val));
+    SCL_TRY(scale_to_dense_sharded(ctx, s->pat.dev, s->val, 1, s->Btmp, s->ldb, nullptr, s->sh));
+    SCL_TRY(to_cell_side(s, s->Btmp, c, slot, /*desc_input=*/true, zs));
+  }
+  return SCLENS_OK;
 }
 
 // Device buffers of the two read-only results that other ranks need when the first three decompositions are spread

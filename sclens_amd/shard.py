@@ -164,6 +164,26 @@ class Shard:
 
         return _lib.ALLREDUCE_FN(cb), None
 
+    def reducer_to(self, ctx):
+        """the `sclens_hip_reduce_fn` (+ user pointer) of a row-sharded session: the sum of a buffer onto ONE rank. With a
+        communicator ncclReduce inside the library; otherwise a host callback that all-reduces (every rank then holds the sum,
+        which is a valid implementation: non-root buffers are simply unspecified)"""
+        if self.comm is not None:
+            return self.comm.reducer_to()
+        import traceback
+
+        from . import _lib
+
+        def cb(_user, dev_ptr, count, dtype, _root):
+            try:
+                self.allreduce_dev(ctx, dev_ptr, count, dtype)
+                return 0
+            except Exception:
+                traceback.print_exc()
+                return 1
+
+        return _lib.REDUCE_FN(cb), None
+
     # -- one-to-all copies for the spread initial phase (api.sclens, world > 1)
     def bcast_host(self, arr: np.ndarray, src: int) -> np.ndarray:
         """float64 host array of the same shape on every rank; returns rank `src`'s content"""

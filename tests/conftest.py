@@ -22,6 +22,8 @@ def _usable_cpus():
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "slow: a -m gpu case dominated by the float64 oracle (tens of minutes of host LAPACK); runs "
+                                       "only with SCLENS_TEST_SLOW=1, its log is kept under profiles/")
     try:  # the oracle's BLAS / LAPACK calls: one thread per usable CPU, not per visible one
         from threadpoolctl import threadpool_limits
 

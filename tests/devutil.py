@@ -115,3 +115,32 @@ class ThreadShard:
                 return 1
 
         return _lib.ALLREDUCE_FN(cb), None
+
+    def reducer_to(self, ctx):
+        """(sclens_hip_reduce_fn, user): the sum lands on `root` only; the other ranks' buffers are POISONED (NaN), so a rank that
+        wrongly consumes a sum it is not the root of fails loudly"""
+        from sclens_amd import _lib
+
+        def cb(_user, dev_ptr, count, dtype, root):
+            try:
+                h = np.empty(int(count), dtype=np.float64 if dtype == 0 else np.float32)
+                ctx.d2h(h, dev_ptr)
+                parts = self._exchange(h)
+                if self.rank == root:
+                    tot = parts[0].copy()
+                    for p in parts[1:]:
+                        tot += p
+                else:
+                    tot = np.full_like(h, np.nan)
+                ctx.h2d(dev_ptr, tot)
+                if self.rank == 0:
+                    self.g.nreduce += 1
+                    self.g.bytes += tot.nbytes
+                return 0
+            except Exception:
+                import traceback
+
+                traceback.print_exc()
+                return 1
+
+        return _lib.REDUCE_FN(cb), None

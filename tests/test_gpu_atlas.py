@@ -107,6 +107,71 @@ def test_row_sharded_device_sampler_and_errors(ctx):
     assert rc == 1
 
 
+@pytest.mark.parametrize("world", [2, 3])
+def test_atlas_mode_local_candidates_and_distributed_eigensolves(ctx, world):
+    """SURVEY 8e-iii as the atlas configuration needs it, at 20 000 x 6 000 with 2 / 3 ranks (threads, one context each):
+      * every rank draws ITS part of the global candidate draw on the device and holds nobody else's candidates;
+      * the evaluations of a search round and the ensemble members are decomposed by DIFFERENT ranks (each partial Gram matrix
+        is summed onto the rank that solves it; the test transport poisons the buffer on every other rank).
+    Reference: the unsharded path replayed on the concatenation of the ranks' candidate lists (the global list of this mode)
+    with the same sample seeds -- decisions exact, statistics to fp32 summation-order accuracy."""
+    N, M = 20000, 6000
+    X = api._csc_f32(synth_counts(N, M, seed=31, C=6, marker_frac=0.1, marker_sd=1.3))
+    d = api.make_draws_native(X, seed=77, device_candidates=True)  # z_idx1 = None, cand_seed set, samples on the device
+    kw = dict(n_perturb=4, max_search_iters=5)
+    group = ThreadShard.Group(world)
+    Xr = X.tocsr()
+    out, err = [None] * world, [None] * world
+
+    def work(r):
+        c = Context(ctx.device)
+        try:
+            a, b = atlas.row_block(r, world, N)
+            out[r] = atlas.sclens_row_sharded(Xr[a:b].tocsc(), a, N, d, ThreadShard(group, r), ctx=c, nnz_global=X.nnz,
+                                              return_candidates=True, **kw)
+        except BaseException as e:  # noqa: BLE001
+            err[r] = e
+            group.bar.abort()
+        finally:
+            c.close()
+
+    th = [threading.Thread(target=work, args=(r,)) for r in range(world)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    for e in err:
+        if e is not None and not isinstance(e, threading.BrokenBarrierError):
+            raise e
+    for e in err:
+        if e is not None:
+            raise e
+    assert all(o["distributed"] and o["local_candidates"] for o in out)
+    # the ranks' lists: disjoint cell ranges, together the global draw with stored entries and repeats removed
+    z1 = np.concatenate([o["candidates_local"][0] for o in out])
+    z2 = np.concatenate([o["candidates_local"][1] for o in out])
+    assert len(z1) == out[0]["n_cand"]
+    for r, o in enumerate(out):
+        a, b = atlas.row_block(r, world, N)
+        zz = o["candidates_local"][0]
+        assert zz.size > 0 and zz.min() >= a and zz.max() < b
+    full1, full2 = api.Pattern.drawn(ctx, X, d.cand_seed).candidates()  # the unsharded draw of the same seed
+    key = lambda u, v: u.astype(np.int64) * M + v
+    assert np.array_equal(np.sort(key(z1, z2)), np.sort(key(full1, full2)))
+    for r in range(world):  # each rank's list is the global first-occurrence list restricted to its cells, in the same order
+        a, b = atlas.row_block(r, world, N)
+        sel = (full1 >= a) & (full1 < b)
+        assert np.array_equal(out[r]["candidates_local"][0], full1[sel]) and np.array_equal(out[r]["candidates_local"][1], full2[sel])
+    # replay unsharded on the concatenated list
+    d2 = api.Draws(z1, z2, d.X_r, d.p_th, None, d.sample_seed)
+    ref = api.sclens(X, draws=d2, ctx=ctx, streams=1, **kw)
+    for o in out:
+        _compare(o, ref)
+    for o in out[1:]:
+        assert np.array_equal(o["robustness_scores"]["b_"], out[0]["robustness_scores"]["b_"])
+        assert np.array_equal(o["gene_basis"], out[0]["gene_basis"])
+
+
 def test_library_rccl_communicator_one_rank(ctx):
     """The RCCL calls the library makes itself (csrc/comm.hip) cannot meet a second rank on a one-GPU box, but everything else
     about them can be checked with a one-rank communicator: librccl opens, ncclCommInitRank from a shipped unique id,

@@ -1,0 +1,53 @@
+"""-m gpu: parity AT THE ORDER THE BENCH RUNS (n = 30 000). The float64 oracle needs about an hour per
+decomposition there, so the reference point is the library's own plain path -- full two-stage eigensolver for every ensemble
+member, every Gram product and the search statistic on the fp32 MFMA -- against which the accelerated path that bench.py times
+(Chebyshev-filtered subspace iteration with implicit operator + locking for the ensemble, fp16-MFMA products in the sparsity
+search) must give the same decisions. Both runs go through the C ABI on the same matrix and the same draws.
+40 000 x 30 000 instead of 100 000 x 30 000 keeps the synthesis short; the order of every decomposition is the bench's."""
+import numpy as np
+import pytest
+
+from sclens_amd import api
+from sclens_amd._lib import Context
+from sclens_amd.synth import synth_counts
+
+pytestmark = pytest.mark.gpu
+
+
+def test_accelerated_path_equals_plain_path_at_order_30000(ctx):
+    N, M = 40000, 30000
+    X = api._csc_f32(synth_counts(N, M, seed=20240427 + 7, C=8))
+    kw = dict(n_perturb=2, max_search_iters=5, streams=1)  # five iterations: the smallest cap that leaves p_ < 1 (:756-760)
+    fast = api.sclens(X, draws=api.make_draws_native(X, seed=77, device_candidates=True), ctx=ctx, **kw)
+    c2 = Context(ctx.device)
+    c2.set_option("gram_bits", 0)
+    try:
+        plain = api.sclens(X, draws=api.make_draws_native(X, seed=77, device_candidates=True), ctx=c2, partial_eig=False, **kw)
+    finally:
+        c2.close()
+    # what ran: fp16-MFMA Gram for the binarised matrix and the five search steps / none; subspace iteration for both members / none
+    assert fast["gram_bits_used"] == fast["n_search"] + 1 and plain["gram_bits_used"] == 0
+    assert fast["partial_eig"] == (2, 0) and plain["partial_eig"][0] == 0
+    # identical data decomposition (the same kernels on the same matrix): the signal set is the same to the last bit
+    k = len(plain["signal_ev"])
+    assert k >= 5 and len(fast["signal_ev"]) == k and np.array_equal(fast["signal_ev"], plain["signal_ev"])
+    # (b) sparsity search: fp16-MFMA products (exact binary x 22-bit weights; 22-bit split operands) against fp32 products
+    assert fast["n_search"] == plain["n_search"] == 5 and fast["p_"] == plain["p_"]
+    for (p1, d1), (p2, d2) in zip(fast["search_trace"], plain["search_trace"]):
+        assert p1 == p2
+        # d5 = the five smallest of ~15 000 column maxima of |Vr2' nV_2| (scLENS.jl:742-747): bulk eigenvectors are determined
+        # only up to rotations inside near-degenerate clusters, so a 1e-6 relative change of the Gram matrix (another
+        # summation order is enough) moves single entries by a few 1e-4 (measured here: 1.0e-4 .. 4.1e-4 on values of 0.045,
+        # profiles/r03_bench_size_parity.log). The decision compares them with p_th = 0.027: 40x further away.
+        assert np.abs(d1 - d2).max() < 1e-3, np.abs(d1 - d2).max()
+    # (a) ensemble: subspace iteration (implicit operator + locking) against the full eigensolver
+    ra, rb = fast["robustness_scores"], plain["robustness_scores"]
+    print("[bench-size parity] max |d5 diff|", max(np.abs(d1 - d2).max() for (_, d1), (_, d2) in zip(fast["search_trace"], plain["search_trace"])),
+          "max |b_ diff|", np.abs(ra["b_"] - rb["b_"]).max(), "a_b equal", np.array_equal(ra["a_b"], rb["a_b"]))
+    assert np.array_equal(ra["a_b"], rb["a_b"])
+    assert np.abs(ra["b_"] - rb["b_"]).max() <= 3e-3, np.abs(ra["b_"] - rb["b_"]).max()
+    assert np.array_equal(fast["sig_id"], plain["sig_id"])
+    for t in range(2):
+        la, lb = np.asarray(fast["nL_set"][t]), np.asarray(plain["nL_set"][t])
+        assert la.shape == lb.shape == (fast["min_pc"],)
+        assert np.abs(la - lb).max() <= 3e-4 * lb.max(), (t, np.abs(la - lb).max() / lb.max())

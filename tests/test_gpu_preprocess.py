@@ -87,3 +87,45 @@ def test_preprocess_edge_cases(ctx):
                                        5.0, 0.0, api.ptr(np.zeros(4, np.uint8), C.c_uint8), api.ptr(np.zeros(2, np.int64), C.c_int64),
                                        C.byref(C.c_int64()), C.byref(C.c_int64()), C.byref(C.c_int64()))
     assert rc == 1
+
+
+def test_device_handover_preprocess_to_sclens(ctx):
+    """SURVEY 8f-3 remainder: the filtered matrix stays in HBM (sclens_hip_preprocess_keep) and the session + the union pattern
+    are built from it in place. Same filtered matrix bit for bit as the host round trip, and sclens() on the handle gives the
+    same result as sclens() on the downloaded matrix (same seed: identical draws, identical kernels)."""
+    from sclens_amd.synth import synth_counts
+
+    X = synth_counts(700, 900, seed=3, C=5, marker_frac=0.2, marker_sd=1.5).toarray()  # clustered: a few signals survive
+    names = np.array([("mt-x%d" % j) if j % 97 == 0 else ("g%d" % j) for j in range(X.shape[1])], dtype=object)
+    kw = dict(min_genes_per_cell=50, min_cells_per_gene=20)
+    Xh, gh, ch = api.preprocess(X, names, ctx=ctx, **kw)
+    out = api.preprocess(X, names, ctx=ctx, keep_on_device=True, **kw)
+    Xd, gd, cd = out
+    try:
+        assert isinstance(Xd, api.DeviceCounts) and Xd.shape == Xh.shape and Xd.nnz == Xh.nnz
+        assert list(gd) == list(gh) and np.array_equal(cd, ch)
+        cp, rv, nz = Xd.download()
+        assert np.array_equal(cp, Xh.indptr) and np.array_equal(rv, Xh.indices) and np.array_equal(nz, Xh.data)
+        a = api.sclens(Xd, seed=5, n_perturb=3, max_search_iters=6, ctx=ctx, streams=2)
+        d = api.make_draws_native(Xh, 5, device_candidates=True)
+        b = api.sclens(Xh, draws=d, n_perturb=3, max_search_iters=6, ctx=ctx, streams=2)
+        assert np.array_equal(a["L"], b["L"]) and a["p_"] == b["p_"] and a["n_search"] == b["n_search"]
+        for (p1, t1), (p2, t2) in zip(a["search_trace"], b["search_trace"]):
+            assert p1 == p2 and np.array_equal(t1, t2)
+        assert len(a["signal_ev"]) == len(b["signal_ev"]) >= 2
+        assert np.array_equal(a["sig_id"], b["sig_id"])
+        assert np.array_equal(a["robustness_scores"]["b_"], b["robustness_scores"]["b_"])
+        assert np.array_equal(a["gene_basis"], b["gene_basis"])
+    finally:
+        Xd.close()
+    # the same handle from host arrays, and the error paths of the hand-over
+    up = api.DeviceCounts.upload(ctx, Xh)
+    try:
+        assert up.shape == Xh.shape and np.array_equal(up.to_scipy().toarray(), Xh.toarray())
+        cp_only = up.download(rowval=False, nzval=False)
+        assert cp_only[1] is None and np.array_equal(cp_only[0], Xh.indptr)
+    finally:
+        up.close()
+    h = C.c_void_p()
+    assert ctx.lib.sclens_hip_preprocess_keep(ctx.h, C.byref(h)) == 7  # no preceding preprocess call: state error
+    assert ctx.lib.sclens_hip_session_create_from_counts(ctx.h, None, C.byref(h)) == 1
