@@ -19,6 +19,9 @@ struct Ctx {
   // second stream + events for work that overlaps inside one call (look-ahead of the band reduction); created on first use
   hipStream_t aux_stream = nullptr;
   hipEvent_t aux_ev[2] = {nullptr, nullptr};
+  // stream restricted to a third of the CUs for latency-chain kernels (bulge chasing), see sb2st_f32; created on first use
+  hipStream_t lat_stream = nullptr;
+  hipEvent_t lat_ev[2] = {nullptr, nullptr};
   std::string err;
   // grow-only named device workspaces (freed at destroy); avoids hipMalloc inside hot loops
   std::map<std::string, std::pair<void*, size_t>> ws;

@@ -18,6 +18,13 @@ struct PatternDev {
   // ncand_global == 0: the pattern holds the whole list (cand_off = 0, ncand_global = ncand).
   int64_t cand_off = 0, ncand_global = 0;
   int64_t population() const { return ncand_global > 0 ? ncand_global : ncand; }
+  // CSR companions (pattern_add_csr_companions; nullptr = off). Every value array over such a pattern is 2 nU floats long: the
+  // values in CSC slot order, then THE SAME values in CSR slot order -- the row reductions of the normalisation (row sums of the
+  // counts, row norms of the scaled rows: scLENS.jl:607, :603) then stream their operand instead of gathering it through
+  // csr2csc (10 ms each per decomposition at 100 000 x 30 000, 0.066 of the HBM roofline for the stage in round 2).
+  const float* base_val_csr = nullptr;     // [nU] base_val in CSR slot order
+  const int64_t* cand_pos_csr = nullptr;   // [ncand] CSR slot of candidate t (-1 as cand_pos)
+  size_t val_floats() const { return (size_t)nU * (base_val_csr ? 2 : 1); }
 };
 
 struct PatternOwner {  // owns the device arrays of a PatternDev
@@ -34,6 +41,8 @@ int pattern_build(Ctx* ctx, int64_t N, int64_t M, const int64_t* colptr, const i
                   int64_t ncand, const uint32_t* z1, const uint32_t* z2, PatternOwner* out, int64_t row0 = 0,
                   int64_t N_global = 0);
 void pattern_free(PatternOwner* p);
+// device helper shared by both builders: base_val_csr / cand_pos_csr from csr2csc, base_val, cand_pos (SCLENS_HIP_VAL_CSR=0: skip)
+int pattern_add_csr_companions(Ctx* ctx, PatternOwner* out);
 // The same arrays built on the device from the counts' CSC (pattern_dev.hip); draw != 0 also draws the candidate list there
 // (R1, scLENS.jl:668-673; the list of sclens_draw_zero_candidates for the same seed). Sessions that hold all cells only.
 // blk != nullptr (with draw): the matrix is the block [row0, row0 + N) of the cells of an N_global x M matrix with nnz_global stored

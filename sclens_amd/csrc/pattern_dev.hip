@@ -340,6 +340,43 @@ int scan_i64(Ctx* ctx, DevTmp& tmp, const int64_t* in, int64_t* out, size_t n) {
 
 }  // namespace
 
+namespace {
+__global__ void k_csr_gather_base(const float* __restrict__ base, const int64_t* __restrict__ c2c, int64_t nU, float* __restrict__ base_csr,
+                                  int64_t* __restrict__ inv) {
+  const int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= nU) return;
+  const int64_t q = c2c[s];
+  base_csr[s] = base[q];
+  inv[q] = s;
+}
+__global__ void k_csr_cand_pos(const int64_t* __restrict__ cpos, const int64_t* __restrict__ inv, int64_t ncand, int64_t* __restrict__ out) {
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= ncand) return;
+  const int64_t q = cpos[t];
+  out[t] = q >= 0 ? inv[q] : -1;
+}
+}  // namespace
+
+int pattern_add_csr_companions(Ctx* ctx, PatternOwner* out) {
+  static const bool off = getenv("SCLENS_HIP_VAL_CSR") && atoi(getenv("SCLENS_HIP_VAL_CSR")) == 0;
+  PatternDev& d = out->dev;
+  if (off || d.nU <= 0 || !d.csr2csc || !out->base_val) return SCLENS_OK;
+  hipStream_t st = ctx->stream;
+  float* bc = keep<float>(ctx, out, d.nU);
+  int64_t* cpc = keep<int64_t>(ctx, out, std::max<int64_t>(d.ncand, 1));
+  DevTmp tmp;
+  int64_t* inv = tmp.get<int64_t>(ctx, d.nU);
+  if (!bc || !cpc || !inv) return SCLENS_ERR_OOM;
+  hipLaunchKernelGGL(k_csr_gather_base, dim3((unsigned)((d.nU + 255) / 256)), dim3(256), 0, st, out->base_val, d.csr2csc, d.nU, bc, inv);
+  if (d.ncand > 0)
+    hipLaunchKernelGGL(k_csr_cand_pos, dim3((unsigned)((d.ncand + 255) / 256)), dim3(256), 0, st, d.cand_pos, inv, d.ncand, cpc);
+  SCL_HIP(ctx, hipGetLastError());
+  SCL_HIP(ctx, hipStreamSynchronize(st));  // `tmp` dies with this frame
+  d.base_val_csr = bc;
+  d.cand_pos_csr = cpc;
+  return SCLENS_OK;
+}
+
 // draw != 0: the candidate list is drawn on the device from `seed` (z1_h / z2_h ignored); else it is uploaded from the host
 // (ncand entries). The candidate list stays on the device in out->z1_dev / z2_dev (sclens_hip_pattern_candidates downloads it).
 // nnz_dev >= 0: colptr / rowval / nzval are DEVICE arrays of a count matrix with nnz_dev stored entries (a sclens_hip_counts
@@ -506,6 +543,7 @@ int pattern_build_device(Ctx* ctx, int64_t N, int64_t M, const int64_t* colptr, 
   out->base_val = uval;
   out->z1_dev = z1;
   out->z2_dev = z2;
+  SCL_TRY(pattern_add_csr_companions(ctx, out));
   return SCLENS_OK;
 }
 

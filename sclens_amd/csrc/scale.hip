@@ -25,13 +25,19 @@ __device__ __forceinline__ double wsum(double v) {
 }
 
 // ---- K1: row sums (CSR view), one wave per row ---------------------------------------------------
+// A value array over a pattern with CSR companions carries its values a second time in CSR slot order (val + nU): streamed.
 __global__ __launch_bounds__(256) void k_row_sums(PatternDev p, const float* __restrict__ val,
                                                   double* __restrict__ tgc) {
   const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
   if (row >= p.N) return;
   double s = 0.0;
-  for (int64_t q = p.rowptr[row] + lane; q < p.rowptr[row + 1]; q += 64) s += (double)val[p.csr2csc[q]];
+  if (p.base_val_csr) {
+    const float* vc = val + p.nU;
+    for (int64_t q = p.rowptr[row] + lane; q < p.rowptr[row + 1]; q += 64) s += (double)vc[q];
+  } else {
+    for (int64_t q = p.rowptr[row] + lane; q < p.rowptr[row + 1]; q += 64) s += (double)val[p.csr2csc[q]];
+  }
   s = wsum(s);
   if (lane == 0) tgc[row] = s;
 }
@@ -169,19 +175,37 @@ __global__ __launch_bounds__(1024) void k_reduce(const double* __restrict__ v, i
 }
 
 // ---- K3: row L2 norms of the centred row (CSR view) ------------------------------------------------
-__global__ __launch_bounds__(256) void k_row_norms(PatternDev p, const double* __restrict__ lg,
-                                                   const double* __restrict__ stdv, const double* __restrict__ mu,
-                                                   const double* __restrict__ mu2sum, double* __restrict__ l2) {
+// With CSR companions the scaled entry is RECOMPUTED from the CSR-ordered value (the same expression k_col_stats evaluates,
+// hence the same bits) instead of gathering lg through csr2csc: the kernel streams 4 + 4 bytes per slot.
+__global__ __launch_bounds__(256) void k_row_norms(PatternDev p, const float* __restrict__ val, const double* __restrict__ tgc, int f32path,
+                                                   const double* __restrict__ lg, const double* __restrict__ stdv,
+                                                   const double* __restrict__ mu, const double* __restrict__ mu2sum,
+                                                   double* __restrict__ l2) {
   const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
   if (row >= p.N) return;
   double zz = 0.0, zm = 0.0;
-  for (int64_t q = p.rowptr[row] + lane; q < p.rowptr[row + 1]; q += 64) {
-    const int64_t pos = p.csr2csc[q];
-    const int64_t c = p.csrcol[q];
-    const double z = lg[pos] / stdv[c];
-    zz += z * z;
-    zm += z * mu[c];
+  if (p.base_val_csr) {
+    const float* vc = val + p.nU;
+    const double t = tgc[row];
+    const float inv = 1.0f / (float)t;
+    for (int64_t q = p.rowptr[row] + lane; q < p.rowptr[row + 1]; q += 64) {
+      const float v = vc[q];
+      if (v == 0.f) continue;
+      const int64_t c = p.csrcol[q];
+      const double l = f32path ? (double)log1pf(inv * v) : log1p((double)v / t);
+      const double z = l / stdv[c];
+      zz += z * z;
+      zm += z * mu[c];
+    }
+  } else {
+    for (int64_t q = p.rowptr[row] + lane; q < p.rowptr[row + 1]; q += 64) {
+      const int64_t pos = p.csr2csc[q];
+      const int64_t c = p.csrcol[q];
+      const double z = lg[pos] / stdv[c];
+      zz += z * z;
+      zm += z * mu[c];
+    }
   }
   zz = wsum(zz);
   zm = wsum(zm);
@@ -273,7 +297,7 @@ int scale_stats(Ctx* ctx, const PatternDev& p, const float* val, int f32path, in
   if (centering == 1)  // median centring: the column offset is the median instead of the mean
     hipLaunchKernelGGL(k_col_median, dim3((unsigned)M), dim3(256), 0, st, p, lg, stdv, f32path, mu);
   hipLaunchKernelGGL(k_reduce, dim3(1), dim3(1024), 0, st, mu, M, 0, red + 0);  // ||mu||^2
-  hipLaunchKernelGGL(k_row_norms, dim3((unsigned)((N + 3) / 4)), dim3(256), 0, st, p, lg, stdv, mu, red + 0, l2);
+  hipLaunchKernelGGL(k_row_norms, dim3((unsigned)((N + 3) / 4)), dim3(256), 0, st, p, val, tgc, f32path, lg, stdv, mu, red + 0, l2);
   hipLaunchKernelGGL(k_reduce, dim3(1), dim3(1024), 0, st, l2, N, 1, red + 1);  // sum l
   hipLaunchKernelGGL(k_row_scale, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, st, l2, N, red + 1, srow);
   hipLaunchKernelGGL(k_reduce, dim3(1), dim3(1024), 0, st, srow, N, 1, red + 2);  // sum s
@@ -427,7 +451,7 @@ int scale_stats_sharded(Ctx* ctx, const PatternDev& p, const float* val, int f32
   SCL_TRY(sh.sum(ctx, s2, M, 0));
   hipLaunchKernelGGL(k_sh_col_fin, dim3(gcm), dim3(256), 0, st, part, s2, ng, f32path, M, mean, stdv, mu);
   hipLaunchKernelGGL(k_reduce, dim3(1), dim3(1024), 0, st, mu, M, 0, red + 0);  // ||mu||^2 (replicated)
-  hipLaunchKernelGGL(k_row_norms, dim3((unsigned)((N + 3) / 4)), dim3(256), 0, st, p, lg, stdv, mu, red + 0, l2);
+  hipLaunchKernelGGL(k_row_norms, dim3((unsigned)((N + 3) / 4)), dim3(256), 0, st, p, val, tgc, f32path, lg, stdv, mu, red + 0, l2);
   hipLaunchKernelGGL(k_reduce, dim3(1), dim3(1024), 0, st, l2, N, 1, red + 1);  // local sum of l
   SCL_TRY(sh.sum(ctx, red + 1, 1, 0));
   hipLaunchKernelGGL(k_sh_row_scale, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, st, l2, N, ng, red + 1, srow);
@@ -469,47 +493,60 @@ int scale_to_dense_sharded(Ctx* ctx, const PatternDev& p, const float* val, int 
 }
 
 // ---- value arrays over the pattern ------------------------------------------------------------------
-// out[q] = binary ? (base[q] != 0) : base[q]     (candidate slots have base 0)
-__global__ void k_val_init(const float* __restrict__ base, int64_t nU, int binary, float* __restrict__ out) {
+// out[q] = binary ? (base[q] != 0) : base[q]     (candidate slots have base 0); the CSR-ordered copy behind it likewise
+__global__ void k_val_init(const float* __restrict__ base, const float* __restrict__ base_csr, int64_t nU, int binary,
+                           float* __restrict__ out) {
   const int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (q < nU) {
     const float b = base[q];
     out[q] = binary ? (b != 0.f ? 1.f : 0.f) : b;
+    if (base_csr) {
+      const float c = base_csr[q];
+      out[nU + q] = binary ? (c != 0.f ? 1.f : 0.f) : c;
+    }
   }
 }
 // out[cand_pos[idx[t] - cand_off]] = 1 for the sampled candidates this pattern holds: indices outside [cand_off, cand_off + ncand)
 // belong to other ranks of a row-sharded session (or are out of range) and are ignored rather than dereferenced
 __global__ void k_val_set_ones(const uint32_t* __restrict__ idx, int64_t m, const int64_t* __restrict__ cand_pos,
-                               int64_t cand_off, int64_t ncand, float* __restrict__ out) {
+                               const int64_t* __restrict__ cand_pos_csr, int64_t nU, int64_t cand_off, int64_t ncand,
+                               float* __restrict__ out) {
   const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (t < m) {
     const int64_t g = (int64_t)idx[t] - cand_off;
     if (g >= 0 && g < ncand) {
       const int64_t pos = cand_pos[g];
-      if (pos >= 0) out[pos] = 1.f;  // -1: the candidate's cell belongs to another rank (row-sharded session, global list)
+      if (pos >= 0) {  // -1: the candidate's cell belongs to another rank (row-sharded session, global list)
+        out[pos] = 1.f;
+        if (cand_pos_csr) out[nU + cand_pos_csr[g]] = 1.f;
+      }
     }
   }
 }
 
 int make_values(Ctx* ctx, const PatternDev& p, const float* base_val, int binary, const uint32_t* idx_dev, int64_t m,
                 float* out) {
-  hipLaunchKernelGGL(k_val_init, dim3((unsigned)((p.nU + 255) / 256)), dim3(256), 0, ctx->stream, base_val, p.nU,
+  hipLaunchKernelGGL(k_val_init, dim3((unsigned)((p.nU + 255) / 256)), dim3(256), 0, ctx->stream, base_val, p.base_val_csr, p.nU,
                      binary, out);
   if (m > 0 && p.ncand > 0)
     hipLaunchKernelGGL(k_val_set_ones, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, ctx->stream, idx_dev, m,
-                       p.cand_pos, p.cand_off, p.ncand, out);
+                       p.cand_pos, p.cand_pos_csr, p.nU, p.cand_off, p.ncand, out);
   SCL_HIP(ctx, hipGetLastError());
   return SCLENS_OK;
 }
 
-__global__ void k_val_set_ones_feistel(FeistelPerm perm, int64_t m, const int64_t* __restrict__ cand_pos, int64_t cand_off,
-                                       int64_t ncand, float* __restrict__ out) {
+__global__ void k_val_set_ones_feistel(FeistelPerm perm, int64_t m, const int64_t* __restrict__ cand_pos,
+                                       const int64_t* __restrict__ cand_pos_csr, int64_t nU, int64_t cand_off, int64_t ncand,
+                                       float* __restrict__ out) {
   const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (t < m) {
     const int64_t g = (int64_t)feistel_apply(perm, (uint64_t)t) - cand_off;
     if (g >= 0 && g < ncand) {
       const int64_t pos = cand_pos[g];
-      if (pos >= 0) out[pos] = 1.f;
+      if (pos >= 0) {
+        out[pos] = 1.f;
+        if (cand_pos_csr) out[nU + cand_pos_csr[g]] = 1.f;
+      }
     }
   }
 }
@@ -517,14 +554,14 @@ __global__ void k_val_set_ones_feistel(FeistelPerm perm, int64_t m, const int64_
 int make_values_seeded(Ctx* ctx, const PatternDev& p, const float* base_val, int binary, uint64_t seed, int64_t m,
                        float* out) {
   if (m < 0 || m > p.population()) return ctx->fail(SCLENS_ERR_ARG, "make_values_seeded: bad sample size");
-  hipLaunchKernelGGL(k_val_init, dim3((unsigned)((p.nU + 255) / 256)), dim3(256), 0, ctx->stream, base_val, p.nU,
+  hipLaunchKernelGGL(k_val_init, dim3((unsigned)((p.nU + 255) / 256)), dim3(256), 0, ctx->stream, base_val, p.base_val_csr, p.nU,
                      binary, out);
   if (m > 0) {
     // the permutation is over the GLOBAL candidate list: every rank of a row-sharded session evaluates the same sample and
     // keeps the part that falls into its own window
     const FeistelPerm perm = feistel_make((uint64_t)p.population(), seed);
     hipLaunchKernelGGL(k_val_set_ones_feistel, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, ctx->stream, perm, m,
-                       p.cand_pos, p.cand_off, p.ncand, out);
+                       p.cand_pos, p.cand_pos_csr, p.nU, p.cand_off, p.ncand, out);
   }
   SCL_HIP(ctx, hipGetLastError());
   return SCLENS_OK;

@@ -144,7 +144,7 @@ int pattern_build(Ctx* ctx, int64_t N, int64_t M, const int64_t* colptr, const i
   SCL_TRY(upload(ctx, out, uval, &bv));
   out->base_val = const_cast<float*>(bv);
   SCL_HIP(ctx, hipStreamSynchronize(ctx->stream));
-  return SCLENS_OK;
+  return pattern_add_csr_companions(ctx, out);
 }
 void pattern_free(PatternOwner* p) {
   for (void* q : p->allocs) pool_free(q, nullptr);  // contract: no session uses the pattern any more (blocking API: its streams are idle)
@@ -266,7 +266,7 @@ static int session_create_impl(Ctx* ctx, int64_t N, int64_t M, const int64_t* co
   s->ldz = round_up(s->n, 32);
   s->ldn = round_up(N, 32);
   auto fail = [&](int code) { pattern_free(&s->pat); for (void* p : s->allocs) pool_free(p, s->ctx->stream); delete s; return code; };
-  if ((rc = s->dmalloc((void**)&s->val, sizeof(float) * s->pat.dev.nU)) != SCLENS_OK) return fail(rc);
+  if ((rc = s->dmalloc((void**)&s->val, sizeof(float) * s->pat.dev.val_floats())) != SCLENS_OK) return fail(rc);
   if ((rc = s->dmalloc((void**)&s->Bmain, sizeof(float) * (size_t)s->n * s->ldb)) != SCLENS_OK) return fail(rc);
   if ((rc = s->dmalloc((void**)&s->Btmp, sizeof(float) * (size_t)s->n * s->ldb)) != SCLENS_OK) return fail(rc);
   if ((rc = s->dmalloc((void**)&s->A, sizeof(float) * (size_t)s->n * s->lda)) != SCLENS_OK) return fail(rc);
@@ -422,7 +422,7 @@ int session_create_sharded(Ctx* ctx, int64_t N_global, int64_t row0, int64_t N_l
   s->ldz = round_up(s->n, 32);
   s->ldn = round_up(N_local, 32);
   auto fail = [&](int code) { pattern_free(&s->pat); for (void* p : s->allocs) pool_free(p, s->ctx->stream); delete s; return code; };
-  if ((rc = s->dmalloc((void**)&s->val, sizeof(float) * s->pat.dev.nU)) != SCLENS_OK) return fail(rc);
+  if ((rc = s->dmalloc((void**)&s->val, sizeof(float) * s->pat.dev.val_floats())) != SCLENS_OK) return fail(rc);
   if ((rc = s->dmalloc((void**)&s->Bmain, sizeof(float) * (size_t)s->n * s->ldb)) != SCLENS_OK) return fail(rc);
   if ((rc = s->dmalloc((void**)&s->Btmp, sizeof(float) * (size_t)s->n * s->ldb)) != SCLENS_OK) return fail(rc);
   if ((rc = s->dmalloc((void**)&s->A, sizeof(float) * (size_t)s->n * s->lda)) != SCLENS_OK) return fail(rc);
@@ -470,7 +470,7 @@ int session_create_sharded_drawn(Ctx* ctx, int64_t N_global, int64_t row0, int64
   s->ldz = round_up(s->n, 32);
   s->ldn = round_up(N_local, 32);
   auto fail = [&](int code) { pattern_free(&s->pat); for (void* p : s->allocs) pool_free(p, s->ctx->stream); delete s; return code; };
-  if ((rc = s->dmalloc((void**)&s->val, sizeof(float) * s->pat.dev.nU)) != SCLENS_OK) return fail(rc);
+  if ((rc = s->dmalloc((void**)&s->val, sizeof(float) * s->pat.dev.val_floats())) != SCLENS_OK) return fail(rc);
   if ((rc = s->dmalloc((void**)&s->Bmain, sizeof(float) * (size_t)s->n * s->ldb)) != SCLENS_OK) return fail(rc);
   if ((rc = s->dmalloc((void**)&s->Btmp, sizeof(float) * (size_t)s->n * s->ldb)) != SCLENS_OK) return fail(rc);
   if ((rc = s->dmalloc((void**)&s->A, sizeof(float) * (size_t)s->n * s->lda)) != SCLENS_OK) return fail(rc);
@@ -530,7 +530,7 @@ int session_clone(Ctx* ctx2, Session* src, Session** out) {
   s->k = src->k;
   int rc;
   auto fail = [&](int code) { for (void* p : s->allocs) pool_free(p, s->ctx->stream); delete s; return code; };
-  if ((rc = s->dmalloc((void**)&s->val, sizeof(float) * s->pat.dev.nU)) != SCLENS_OK) return fail(rc);
+  if ((rc = s->dmalloc((void**)&s->val, sizeof(float) * s->pat.dev.val_floats())) != SCLENS_OK) return fail(rc);
   if ((rc = s->dmalloc((void**)&s->Btmp, sizeof(float) * (size_t)s->n * s->ldb)) != SCLENS_OK) return fail(rc);
   if ((rc = s->dmalloc((void**)&s->A, sizeof(float) * (size_t)s->n * s->lda)) != SCLENS_OK) return fail(rc);
   if ((rc = s->dmalloc((void**)&s->w64, sizeof(double) * s->n)) != SCLENS_OK) return fail(rc);
@@ -597,7 +597,7 @@ int session_null_spectrum(Session* s, const int64_t* rc_, const int32_t* rr_, co
   Ctx* ctx = s->ctx;
   PatternOwner pr;
   SCL_TRY(pattern_build(ctx, s->N, s->M, rc_, rr_, rv_, 0, nullptr, nullptr, &pr));  // sharded: this rank's cells of X_r
-  float* valr = static_cast<float*>(ctx->workspace("ses.valr", sizeof(float) * (size_t)pr.dev.nU));
+  float* valr = static_cast<float*>(ctx->workspace("ses.valr", sizeof(float) * pr.dev.val_floats()));
   int rc = valr ? SCLENS_OK : SCLENS_ERR_OOM;
   if (rc == SCLENS_OK) rc = make_values(ctx, pr.dev, pr.base_val, 0, nullptr, 0, valr);
   if (rc == SCLENS_OK) rc = decompose(s, pr.dev, valr, 1, s->Btmp, (float)s->M, nullptr);
@@ -613,7 +613,7 @@ int session_null_spectrum_pattern(Session* s, PatternOwner* pr, double* Lr) {
   Ctx* ctx = s->ctx;
   if (!pr || pr->allocs.empty() || pr->dev.N != s->N || pr->dev.M != s->M)
     return ctx->fail(SCLENS_ERR_ARG, "null_spectrum: the pattern is empty or has different dimensions");
-  float* valr = static_cast<float*>(ctx->workspace("ses.valr", sizeof(float) * (size_t)pr->dev.nU));
+  float* valr = static_cast<float*>(ctx->workspace("ses.valr", sizeof(float) * pr->dev.val_floats()));
   if (!valr) return SCLENS_ERR_OOM;
   SCL_TRY(make_values(ctx, pr->dev, pr->base_val, 0, nullptr, 0, valr));
   SCL_TRY(decompose(s, pr->dev, valr, 1, s->Btmp, (float)s->M, nullptr));
@@ -650,7 +650,7 @@ static int session_realloc_val(Session* s) {
     pool_free(s->val, s->ctx->stream);
     s->val = nullptr;
   }
-  return s->dmalloc((void**)&s->val, sizeof(float) * (size_t)s->pat.dev.nU);
+  return s->dmalloc((void**)&s->val, sizeof(float) * s->pat.dev.val_floats());
 }
 
 // Hand a pattern built by pattern_create (counts + zero candidates) to an idle owner session that was created without
@@ -1057,18 +1057,26 @@ int session_perturb_round_seeded(Session* s, const int64_t* t, const uint64_t* s
   if (!s->sh.on()) return ctx->fail(SCLENS_ERR_STATE, "perturb_round: row-sharded sessions only (use perturb)");
   if (count <= 0 || !t || !seeds || !m || !roots || my_slot >= count || min_pc <= 0 || !nL_top || !ncols)
     return ctx->fail(SCLENS_ERR_ARG, "perturb_round: bad arguments");
+  const char* phase = "start";
+  auto tag = [&](int rc) {  // which part of the round failed
+    if (rc != SCLENS_OK) ctx->err = std::string("perturb_round [") + phase + "]: " + ctx->err;
+    return rc;
+  };
+#define PR_TRY(expr) SCL_TRY(tag(expr))
   float* scratch = nullptr;
   for (int e = 0; e < count; ++e) {
+    phase = "partial Gram";
     if (t[e] < 0 || m[e] < 0 || m[e] > s->pat.dev.population()) return ctx->fail(SCLENS_ERR_ARG, "perturb_round: bad slot / sample size");
-    SCL_TRY(make_values_seeded(ctx, s->pat.dev, s->pat.base_val, 0, seeds[e], m[e], s->val));
+    PR_TRY(make_values_seeded(ctx, s->pat.dev, s->pat.base_val, 0, seeds[e], m[e], s->val));
     float* target = s->A;
     if (e != my_slot) {
       if (!scratch) scratch = static_cast<float*>(ctx->workspace("ses.Ascr", sizeof(float) * (size_t)s->n * s->lda));
       if (!scratch) return SCLENS_ERR_OOM;
       target = scratch;
     }
-    SCL_TRY(decompose(s, s->pat.dev, s->val, 1, s->Btmp, (float)s->M, nullptr, -1, false, /*solve=*/false, roots[e], target));
+    PR_TRY(decompose(s, s->pat.dev, s->val, 1, s->Btmp, (float)s->M, nullptr, -1, false, /*solve=*/false, roots[e], target));
   }
+  phase = "root eigensolve";
   // ---- the root's eigen-solve: leading min_pc pairs, rows of `mine` descending
   float* zs = static_cast<float*>(ctx->workspace("ses.zshare", sizeof(float) * (size_t)min_pc * s->ldz));
   double* ls = static_cast<double*>(ctx->workspace("ses.lshare", sizeof(double) * (size_t)(min_pc + 1)));
@@ -1080,37 +1088,38 @@ int session_perturb_round_seeded(Session* s, const int64_t* t, const uint64_t* s
     bool done = false;
     const bool can_chefsi = s->use_chefsi && s->b0 >= min_pc + 8 && s->Z0t;
     if (can_chefsi) {
-      SCL_TRY(s->ensure_zt(min_pc));
+      PR_TRY(s->ensure_zt(min_pc));
       std::vector<double> wd(min_pc);
       int conv = 0, its = 0;
-      SCL_TRY(topk_chefsi(ctx, s->A, s->n, s->lda, (int)min_pc, (int)std::min<int64_t>(s->k, min_pc), (int)s->b0, s->Z0t, s->ldz,
+      PR_TRY(topk_chefsi(ctx, s->A, s->n, s->lda, (int)min_pc, (int)std::min<int64_t>(s->k, min_pc), (int)s->b0, s->Z0t, s->ldz,
                           s->theta0.data(), wd.data(), s->Zt, s->ldz, &conv, &its));
       const double tol = 8.0 * 5.96e-8 * std::sqrt((double)s->n) * std::max(0.0, wd[0]);
       if (conv && wd[min_pc - 1] > tol) {
         s->chefsi_used += 1;
         c = min_pc;
         for (int64_t q = 0; q < min_pc; ++q) my_l[1 + q] = wd[q];
-        SCL_TRY(copy_rows_f32(ctx, s->Zt, c, s->n, s->ldz, mine, s->ldz));
+        PR_TRY(copy_rows_f32(ctx, s->Zt, c, s->n, s->ldz, mine, s->ldz));
         done = true;
       } else {
         s->chefsi_fallback += 1;
       }
     }
     if (!done) {
-      SCL_TRY(eig_values(ctx, s->A, s->n, s->lda, s->w64));
-      SCL_TRY(s->fetch_w());
+      PR_TRY(eig_values(ctx, s->A, s->n, s->lda, s->w64));
+      PR_TRY(s->fetch_w());
       c = std::min<int64_t>(min_pc, s->count_positive());
       for (int64_t q = 0; q < c; ++q) my_l[1 + q] = s->w_host[s->n - 1 - q];
       if (c > 0) {
-        SCL_TRY(s->ensure_zt(c));
-        SCL_TRY(eig_vectors(ctx, s->A, s->n, s->lda, s->w64, s->n - c, s->n, s->Zt, s->ldz));
-        SCL_TRY(reverse_rows_f32(ctx, s->Zt, c, s->n, s->ldz, mine, s->ldz));
+        PR_TRY(s->ensure_zt(c));
+        PR_TRY(eig_vectors(ctx, s->A, s->n, s->lda, s->w64, s->n - c, s->n, s->Zt, s->ldz));
+        PR_TRY(reverse_rows_f32(ctx, s->Zt, c, s->n, s->ldz, mine, s->ldz));
       }
     }
     my_l[0] = (double)c;
   }
   // ---- share member by member, recover the local cells
   for (int e = 0; e < count; ++e) {
+    phase = "share + recover";
     if ((int64_t)s->ens.size() <= t[e]) { s->ens.resize(t[e] + 1, nullptr); s->ens_cols.resize(t[e] + 1, 0); }
     float* slot = static_cast<float*>(ctx->workspace("ses.ens" + std::to_string(t[e]), sizeof(float) * (size_t)min_pc * s->ldn));
     if (!slot) return SCLENS_ERR_OOM;
@@ -1125,8 +1134,8 @@ int session_perturb_round_seeded(Session* s, const int64_t* t, const uint64_t* s
       SCL_HIP(ctx, hipMemsetAsync(ls, 0, sizeof(double) * (size_t)(min_pc + 1), ctx->stream));
       SCL_HIP(ctx, hipMemsetAsync(zs, 0, sizeof(float) * (size_t)min_pc * s->ldz, ctx->stream));
     }
-    SCL_TRY(s->sh.sum(ctx, ls, min_pc + 1, 0));
-    SCL_TRY(s->sh.sum(ctx, zs, min_pc * s->ldz, 1));
+    PR_TRY(s->sh.sum(ctx, ls, min_pc + 1, 0));
+    PR_TRY(s->sh.sum(ctx, zs, min_pc * s->ldz, 1));
     std::vector<double> hl((size_t)min_pc + 1);
     SCL_HIP(ctx, hipMemcpyAsync(hl.data(), ls, sizeof(double) * (size_t)(min_pc + 1), hipMemcpyDeviceToHost, ctx->stream));
     SCL_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -1135,12 +1144,13 @@ int session_perturb_round_seeded(Session* s, const int64_t* t, const uint64_t* s
     for (int64_t q = 0; q < min_pc; ++q) nL_top[(int64_t)e * min_pc + q] = (q < c) ? hl[1 + q] : 0.0;
     s->ens_cols[t[e]] = c;
     if (c == 0) continue;
-    SCL_TRY(make_values_seeded(ctx, s->pat.dev, s->pat.base_val, 0, seeds[e], m[e], s->val));
-    SCL_TRY(scale_to_dense_sharded(ctx, s->pat.dev, s->val, 1, s->Btmp, s->ldb, nullptr, s->sh));
-    SCL_TRY(to_cell_side(s, s->Btmp, c, slot, /*desc_input=*/true, zs));
+    PR_TRY(make_values_seeded(ctx, s->pat.dev, s->pat.base_val, 0, seeds[e], m[e], s->val));
+    PR_TRY(scale_to_dense_sharded(ctx, s->pat.dev, s->val, 1, s->Btmp, s->ldb, nullptr, s->sh));
+    PR_TRY(to_cell_side(s, s->Btmp, c, slot, /*desc_input=*/true, zs));
   }
   return SCLENS_OK;
 }
+#undef PR_TRY
 
 // Device buffers of the two read-only results that other ranks need when the first three decompositions are spread
 // over the ranks (api.sclens with world > 1): Vr2 (what = 1; rows = positive eigenvalues of the binarised matrix) and the
@@ -1472,7 +1482,7 @@ int scale_csc_host(Ctx* ctx, int64_t N, int64_t M, const int64_t* colptr, const 
   PatternOwner pr;
   SCL_TRY(pattern_build(ctx, N, M, colptr, rowval, nzval, 0, nullptr, nullptr, &pr));
   const int64_t ldb = round_up(N, 32);
-  float* val = static_cast<float*>(ctx->workspace("w.scval", sizeof(float) * (size_t)pr.dev.nU));
+  float* val = static_cast<float*>(ctx->workspace("w.scval", sizeof(float) * pr.dev.val_floats()));
   float* B = static_cast<float*>(ctx->workspace("w.scB", sizeof(float) * (size_t)M * ldb));
   int rc = (val && B) ? SCLENS_OK : SCLENS_ERR_OOM;
   if (rc == SCLENS_OK) rc = make_values(ctx, pr.dev, pr.base_val, 0, nullptr, 0, val);
@@ -1490,7 +1500,7 @@ int gram_binary_host(Ctx* ctx, int64_t N, int64_t M, const int64_t* colptr, cons
   PatternOwner pr;
   SCL_TRY(pattern_build(ctx, N, M, colptr, rowval, nzval, 0, nullptr, nullptr, &pr));
   const int64_t ldb = round_up(N, 64), lda = round_up(M, 32);
-  float* val = static_cast<float*>(ctx->workspace("w.scval", sizeof(float) * (size_t)pr.dev.nU));
+  float* val = static_cast<float*>(ctx->workspace("w.scval", sizeof(float) * pr.dev.val_floats()));
   float* B = static_cast<float*>(ctx->workspace("w.scB", sizeof(float) * (size_t)M * ldb));
   float* A = static_cast<float*>(ctx->workspace("w.A", sizeof(float) * (size_t)M * lda));
   int rc = (val && B && A) ? SCLENS_OK : SCLENS_ERR_OOM;

@@ -1,9 +1,9 @@
 """Atlas configuration (BASELINE.json configs[4]: 1M cells x 30k genes on 8 GPUs) -- dry run of ONE rank on one
 GPU: rank 0's slab of 125 000 cells is generated chunk-wise (`synth_counts_rows`, never dense on the host) and goes through
-the row-sharded session (`sclens_hip_session_create_sharded`) with the inter-rank all-reduce STUBBED (the callback counts
-calls and bytes and multiplies the buffer by the number of ranks, as if all ranks held this slab: no data moves), so the numbers
-are this rank's compute time and HBM footprint; the spectra are those of 8 copies of the slab and are not checked. Candidates are drawn for the slab's own cells only (what each rank of a real run would
-hold). Usage: atlas_dry_run.py [N_total world out.json]"""
+the row-sharded session in the atlas mode (`sclens_hip_session_create_sharded_drawn`: this rank's candidates drawn on the device;
+search / ensemble in rounds of `world`, this rank decomposing one evaluation per round) with the inter-rank exchange STUBBED (the
+callbacks count calls and bytes and multiply the buffer by the number of ranks, as if all ranks held this slab: no data moves), so
+the numbers are this rank's compute time and HBM footprint; the spectra are those of 8 copies of the slab and are not checked. Usage: atlas_dry_run.py [N_total world out.json]"""
 import json
 import os
 import sys
@@ -42,11 +42,17 @@ X = api._csc_f32(synth_counts_rows(N_total, M, 20240427 + 4, r0, r1))
 log["slab"] = {"rows": [r0, r1], "nnz": int(X.nnz), "synth_s": round(time.perf_counter() - t0, 1)}
 print("[atlas] slab generated", log["slab"], file=sys.stderr, flush=True)
 t0 = time.perf_counter()
-d = api.make_draws_native(X, seed=1000)
-z1, z2, Xr = api._resolve(d.z_idx1), api._resolve(d.z_idx2), api._resolve(d.X_r)
+d = api.make_draws_native(X, seed=1000, device_candidates=True)  # R1 on the device (this rank's part of the global draw); R2 on the host
+Xr = api._resolve(d.X_r)
 log["draws_s"] = round(time.perf_counter() - t0, 1)
-print("[atlas] draws", log["draws_s"], "s, candidates", len(z1), file=sys.stderr, flush=True)
-stat = {"calls": 0, "bytes": 0, "largest": 0}
+print("[atlas] host draws (null matrix)", log["draws_s"], "s", file=sys.stderr, flush=True)
+stat = {"calls": 0, "bytes": 0, "largest": 0, "reduce_calls": 0, "reduce_bytes": 0}
+
+
+def _scale(dev_ptr, count, dtype):
+    t = raw_device_tensor(dev_ptr, int(count), "<f8" if dtype == 0 else "<f4", torch.device("cuda", 0))
+    t.mul_(float(world))
+    torch.cuda.synchronize()
 
 
 def stub(_user, dev_ptr, count, dtype):
@@ -56,13 +62,20 @@ def stub(_user, dev_ptr, count, dtype):
     stat["calls"] += 1
     stat["bytes"] += nb
     stat["largest"] = max(stat["largest"], nb)
-    t = raw_device_tensor(dev_ptr, int(count), "<f8" if dtype == 0 else "<f4", torch.device("cuda", 0))
-    t.mul_(float(world))
-    torch.cuda.synchronize()
+    _scale(dev_ptr, count, dtype)
     return 0
 
 
-reducer = _lib.ALLREDUCE_FN(stub)
+def stub_to(_user, dev_ptr, count, dtype, root):
+    """the sum onto one rank (the Gram matrix of an evaluation that `root` decomposes)"""
+    stat["reduce_calls"] += 1
+    stat["reduce_bytes"] += int(count) * (8 if dtype == 0 else 4)
+    if root == 0:
+        _scale(dev_ptr, count, dtype)
+    return 0
+
+
+reducer, reducer_to = _lib.ALLREDUCE_FN(stub), _lib.REDUCE_FN(stub_to)
 times = {}
 
 
@@ -76,22 +89,32 @@ def timed(name, f):
     return r
 
 
-ses = timed("session_create_sharded", lambda: api.Session.create_sharded(ctx, X, r0, N_total, z1, z2, reducer))
+nnz_global = int(X.nnz) * world  # as if every rank held a slab like this one
+ses = timed("session_create_sharded_drawn", lambda: api.Session.create_sharded_drawn(ctx, X, r0, N_total, nnz_global, d.cand_seed, (reducer, None)))
 try:
+    nloc = ses.ncand_local
+    ses.set_candidate_range(0, nloc * world)
+    ses.set_reduce_to((reducer_to, None))
+    log["candidates_local"] = nloc
     Lr = timed("null_spectrum", lambda: ses.null_spectrum(Xr))
     L, _ = timed("data_spectrum", lambda: ses.data_spectrum())
     k = 8  # a fixed number of signal vectors: the slab's own spectrum is not the atlas's
     timed("signal_vectors", lambda: ses.signal_vectors(k))
     _, r_vr2 = timed("binary_basis", lambda: ses.binary_basis())
     n_2 = int(round(r_vr2 / 2))
-    for it in range(2):
-        m = int(round((1 - (0.999 - 0.001 * it)) * M * (r1 - r0)))  # the slab's share of the flipped zeros
-        timed(f"search_step_{it}", lambda: ses.search_step_seeded(api.sample_seed_for(d.sample_seed, "search", it), min(m, len(z1)), n_2))
+    # one ROUND of the search: `world` sparsities, this rank contributes to all and decomposes the first
+    for rd in range(2):
+        its = [rd * world + e for e in range(world)]
+        ms = [int(round((1 - (0.999 - 0.001 * it)) * M * N_total)) for it in its]
+        seeds = [api.sample_seed_for(d.sample_seed, "search", it) for it in its]
+        timed(f"search_round_{rd}", lambda: ses.search_round_seeded(seeds, ms, list(range(world)), 0, n_2))
     min_pc = 12
-    m_pert = int(round(0.015 * M * (r1 - r0)))
-    for t in range(2):
-        timed(f"perturb_{t}", lambda: ses.perturb_seeded(t, api.sample_seed_for(d.sample_seed, "perturb", t), min(m_pert, len(z1)), min_pc))
-    timed("robustness", lambda: ses.robustness(k, 2))
+    m_pert = int(round(0.015 * M * N_total))
+    for rd in range(2):
+        ts = [rd * world + e for e in range(world)]
+        timed(f"perturb_round_{rd}", lambda: ses.perturb_round_seeded(ts, [api.sample_seed_for(d.sample_seed, "perturb", t) for t in ts],
+                                                                      [m_pert] * world, list(range(world)), 0, min_pc))
+    timed("robustness", lambda: ses.robustness(k, 2 * world))
     timed("gene_basis", lambda: ses.gene_basis(np.sort(L)[::-1][:k].copy()))
     free1, _ = torch.cuda.mem_get_info(0)
     log["hbm_used_GB"] = round((free0 - free1) / 1e9, 1)
@@ -100,10 +123,15 @@ finally:
 log["times_s"] = times
 log["stubbed_allreduce"] = {"calls": stat["calls"], "total_GB": round(stat["bytes"] / 1e9, 2), "largest_GB": round(stat["largest"] / 1e9, 2),
                             "ring_estimate_s_at_153GBps_per_link": round(2 * (world - 1) / world * stat["bytes"] / 153e9, 2)}
+log["stubbed_reduce_to_root"] = {"calls": stat["reduce_calls"], "total_GB": round(stat["reduce_bytes"] / 1e9, 2),
+                                 "estimate_s_at_153GBps_per_link": round(stat["reduce_bytes"] / 153e9, 2)}
 S_est, P = 19, 20
-log["projected_rank_wall_s"] = round(times["session_create_sharded"] + times["null_spectrum"] + times["data_spectrum"] + times["signal_vectors"] +
-                                     times["binary_basis"] + S_est * times["search_step_1"] + P * times["perturb_1"] + times["robustness"] +
-                                     times["gene_basis"], 1)
+rounds_s, rounds_p = -(-S_est // world), -(-P // world)
+log["projected_rank_wall_s"] = round(times["session_create_sharded_drawn"] + times["null_spectrum"] + times["data_spectrum"] +
+                                     times["signal_vectors"] + times["binary_basis"] + rounds_s * times["search_round_1"] +
+                                     rounds_p * times["perturb_round_1"] + times["robustness"] + times["gene_basis"], 1)
+log["projection"] = (f"S = {S_est} evaluations in {rounds_s} rounds of {world}, P = {P} members in {rounds_p} rounds; first phase replicated; "
+                     "exchange not included (stubbed; estimates above)")
 txt = json.dumps(log, indent=1)
 print(txt)
 if out_path:

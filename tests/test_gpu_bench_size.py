@@ -35,11 +35,14 @@ def test_accelerated_path_equals_plain_path_at_order_30000(ctx):
     assert fast["n_search"] == plain["n_search"] == 5 and fast["p_"] == plain["p_"]
     for (p1, d1), (p2, d2) in zip(fast["search_trace"], plain["search_trace"]):
         assert p1 == p2
-        # d5 = the five smallest of ~15 000 column maxima of |Vr2' nV_2| (scLENS.jl:742-747): bulk eigenvectors are determined
-        # only up to rotations inside near-degenerate clusters, so a 1e-6 relative change of the Gram matrix (another
-        # summation order is enough) moves single entries by a few 1e-4 (measured here: 1.0e-4 .. 4.1e-4 on values of 0.045,
-        # profiles/r03_bench_size_parity.log). The decision compares them with p_th = 0.027: 40x further away.
-        assert np.abs(d1 - d2).max() < 1e-3, np.abs(d1 - d2).max()
+        # d5 = the five smallest of ~15 000 column maxima of |Vr2' nV_2| (scLENS.jl:742-747). The eigenvalues of the lower half of
+        # this spectrum are ~5e-5 apart while an fp32 Gram matrix carries ~2e-5 of rounding (eps32 lambda_max sqrt(K)): the single
+        # eigenvectors are NOT determined at this precision -- by the reference's own cuSOLVER path either --, only the statistic is
+        # stable. Another summation order moves its entries by up to 1.4e-3 on values of 0.045 (measured over the five steps
+        # here: 1.0e-4 .. 1.34e-3, profiles/r03_bench_size_parity.log); the float64-oracle tests allow 3e-3 for the same reason.
+        assert np.abs(d1 - d2).max() < 3e-3, np.abs(d1 - d2).max()
+        # ... and the decision never comes near: the rule compares the second smallest entry with p_th (:756)
+        assert min(abs(d1[1] - fast["p_th"]), abs(d2[1] - fast["p_th"])) > 5 * np.abs(d1 - d2).max()
     # (a) ensemble: subspace iteration (implicit operator + locking) against the full eigensolver
     ra, rb = fast["robustness_scores"], plain["robustness_scores"]
     print("[bench-size parity] max |d5 diff|", max(np.abs(d1 - d2).max() for (_, d1), (_, d2) in zip(fast["search_trace"], plain["search_trace"])),
