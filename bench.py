@@ -361,11 +361,11 @@ def main():
 
         def one_step(step):
             t_d = time.perf_counter()
-            draws = api.make_draws_native(X, seed=1000 + step, async_null=True, device_candidates=not row_shard)
+            draws = api.make_draws_native(X, seed=1000 + step, async_null=True, device_candidates=True)
             one_step.draws_s = time.perf_counter() - t_d  # R1-R3 inside the timed region; R4/R5 on the device inside sclens()
-            if row_shard:  # global draws (identical on every rank), local cells
+            if row_shard:  # local cells, local candidates (each rank's part of the global draw), eigensolves of a round on different ranks
                 return atlas.sclens_row_sharded(X_rows, r0, N, draws, shard, n_perturb=args.n_perturb, ctx=ctx, gather=False,
-                                                verbose=args.verbose)
+                                                verbose=args.verbose, nnz_global=int(X.nnz))
             return api.sclens(X, draws=draws, ctx=ctx, n_perturb=args.n_perturb, shard=shard, streams=args.streams,
                               verbose=args.verbose and rank == 0)
 
@@ -435,8 +435,9 @@ def main():
             "config": {"workload": f"{args.config}: synthetic Poisson-lognormal counts {N} cells x {M} genes, sparsity "
                                    f"{1 - X.nnz / (N * M):.3f}, full sclens() incl. sparsity search and {args.n_perturb}-member "
                                    f"perturbation ensemble", "N": N, "M": M, "nnz": int(X.nnz), "n_perturb": args.n_perturb,
-                       "parallelism": (f"cells row-sharded over {world} ranks: per decomposition 4 small all-reduces + one "
-                                       f"all-reduce of the {M}x{M} fp32 partial Gram matrix, eigen-solver replicated" if row_shard
+                       "parallelism": (f"cells row-sharded over {world} ranks (local candidates): per decomposition 4 small all-reduces + one "
+                                       f"reduce of the {M}x{M} fp32 partial Gram matrix onto the rank that decomposes it; search and "
+                                       f"ensemble in rounds of {world}" if row_shard
                                        else f"single GPU, {n_streams} concurrent decompositions (HIP streams)" if world == 1 else
                                        f"search rounds of {world}x{n_streams} + ensemble t%{world}, 1 RCCL all-gather "
                                        f"issued by the library on its own buffers"),

@@ -131,7 +131,7 @@ void jacobi_eig(std::vector<double> C, int b, std::vector<double>& ev, std::vect
 
 int topk_chefsi(Ctx* ctx, const float* A, int64_t n, int64_t lda, int m, int m_strict, int b, const float* X0t, int64_t ldx,
                 const double* theta0, double* w_desc, float* Zt, int64_t ldz, int* converged, int* iters, const float* Bop,
-                int64_t Kop, int64_t ldb, float div) {
+                int64_t Kop, int64_t ldb, float div, double tail_gap) {
   *converged = 0;
   if (iters) *iters = 0;
   if (m <= 0 || b < m || b > 128 || b > n) return ctx->fail(SCLENS_ERR_ARG, "topk_chefsi: bad block sizes");
@@ -267,7 +267,10 @@ int topk_chefsi(Ctx* ctx, const float* A, int64_t n, int64_t lda, int m, int m_s
   // remaining ones up to m only feed eigenvalues and the matching argmax: 3e-3 * theta (Ritz value error ~ res^2 / gap
   // to the spectrum outside the block, well below the 3e-4 relative tolerance of the parity tests)
   const double tol_rel = 1e-3, tol_rel_tail = 5e-3, tol_gap = 2e-3;
-  static const double tol_gap_tail = getenv("SCLENS_HIP_CHEFSI_TAIL_GAP") ? atof(getenv("SCLENS_HIP_CHEFSI_TAIL_GAP")) : 0.05;
+  // tail pairs: gap-aware target only on request (tail_gap > 0; the caller asks for it when a tail vector is CONSUMED, see
+  // api.sclens / session option "chefsi_tail_gap_milli"); SCLENS_HIP_CHEFSI_TAIL_GAP overrides
+  static const double tail_env = getenv("SCLENS_HIP_CHEFSI_TAIL_GAP") ? atof(getenv("SCLENS_HIP_CHEFSI_TAIL_GAP")) : -1.0;
+  const double tol_gap_tail = tail_env >= 0.0 ? tail_env : (tail_gap > 0.0 ? tail_gap : 1e30);
   for (int outer = 0; outer < max_outer; ++outer) {
     // ---- Chebyshev filter of `degree`: damp [0, theta_b], normalise at theta_1
     const double lo = 0.0, cut = std::max(theta[b - 1], 1e-12 * theta[0]);

@@ -19,9 +19,6 @@ struct Ctx {
   // second stream + events for work that overlaps inside one call (look-ahead of the band reduction); created on first use
   hipStream_t aux_stream = nullptr;
   hipEvent_t aux_ev[2] = {nullptr, nullptr};
-  // stream restricted to a third of the CUs for latency-chain kernels (bulge chasing), see sb2st_f32; created on first use
-  hipStream_t lat_stream = nullptr;
-  hipEvent_t lat_ev[2] = {nullptr, nullptr};
   std::string err;
   // grow-only named device workspaces (freed at destroy); avoids hipMalloc inside hot loops
   std::map<std::string, std::pair<void*, size_t>> ws;
@@ -215,9 +212,10 @@ int symv_probe(Ctx* ctx, int64_t n, int64_t* launches, double* total_ms, double*
 // eigenvalues (descending) and Zt rows 0..m-1 (device, ldz) the unit eigenvectors in the same order.
 // Bop != nullptr: A is given implicitly as Bop Bop' / div with Bop [n x Kop] row-major (ldb) -- the Gram matrix is not needed
 // (A may be nullptr); every block product then costs two passes over Bop.
+// tail_gap > 0: the pairs m_strict .. m-1 are additionally held to tail_gap x (theta_q - smallest Ritz value of the block).
 int topk_chefsi(Ctx* ctx, const float* A, int64_t n, int64_t lda, int m, int m_strict, int b, const float* X0t, int64_t ldx,
                 const double* theta0, double* w_desc, float* Zt, int64_t ldz, int* converged, int* iters,
-                const float* Bop = nullptr, int64_t Kop = 0, int64_t ldb = 0, float div = 1.f);
+                const float* Bop = nullptr, int64_t Kop = 0, int64_t ldb = 0, float div = 1.f, double tail_gap = 0.0);
 
 // ------------------------------------------------------------------ small device helpers (util.hip)
 int fill_f32(Ctx* ctx, float* p, int64_t n, float v);

@@ -360,7 +360,9 @@ __global__ void k_csr_cand_pos(const int64_t* __restrict__ cpos, const int64_t* 
 int pattern_add_csr_companions(Ctx* ctx, PatternOwner* out) {
   static const bool off = getenv("SCLENS_HIP_VAL_CSR") && atoi(getenv("SCLENS_HIP_VAL_CSR")) == 0;
   PatternDev& d = out->dev;
-  if (off || d.nU <= 0 || !d.csr2csc || !out->base_val) return SCLENS_OK;
+  // only patterns with candidates: those serve the S + P decompositions of the search and the ensemble; a counts-only pattern
+  // (data / null / binarised matrix: one or two decompositions each) would pay more for the companions than it saves
+  if (off || d.nU <= 0 || d.ncand <= 0 || !d.csr2csc || !out->base_val) return SCLENS_OK;
   hipStream_t st = ctx->stream;
   float* bc = keep<float>(ctx, out, d.nU);
   int64_t* cpc = keep<int64_t>(ctx, out, std::max<int64_t>(d.ncand, 1));

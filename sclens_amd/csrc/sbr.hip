@@ -20,7 +20,6 @@
 // layout every NT product here wants), the band in the LOWER part, T_p in a side array. The matrix order must be a multiple
 // of SB (the caller pads with a decoupled diagonal block). All reductions run in a fixed order: bitwise reproducible.
 #include <algorithm>
-#include <atomic>
 
 #include "common.h"
 
@@ -1170,35 +1169,12 @@ int sb2st_f32(Ctx* ctx, const float* A, int64_t n, int64_t lda, double* d_dev, d
   if (G < 1) G = 1;
   if (const char* eg = getenv("SCLENS_HIP_CHASE_WGS")) G = std::max(1, std::min(G, atoi(eg)));
   SbrChaseArgs ca{Bd, n, V2, ldv2, TAU2, ldt, done};
-  // CU-masked launch (SCLENS_HIP_CHASE_CUMASK=1). The chase is a latency chain: its ~n / 128 workgroups leave the chip almost
-  // idle, but the dispatcher spreads them one per CU, where each takes 36 KB of LDS -- and the 256 x 256 GEMM workgroups of a
-  // decomposition running on ANOTHER stream need 128 KB of the 160, so they find no CU while a chase is resident (two concurrent
-  // decompositions then serialise on exactly the kernels that could share the chip). On a stream whose CU mask holds a third of
-  // the CUs the chase packs three workgroups per CU (what its registers and LDS allow) and leaves the other two thirds whole.
-  // Contexts take the three disjoint masks in turn, so two concurrent chases never compete for the same slots (every workgroup
-  // of a chase must be resident: a sweep spins on its predecessor).
-  static const bool cu_mask_on = getenv("SCLENS_HIP_CHASE_CUMASK") && atoi(getenv("SCLENS_HIP_CHASE_CUMASK")) != 0;
-  hipStream_t chase_st = st;
-  if (cu_mask_on && cus >= 96 && G <= 3 * (cus / 3)) {
-    if (!ctx->lat_stream) {
-      static std::atomic<int> next_third{0};
-      const int third = next_third.fetch_add(1) % 3;
-      std::vector<uint32_t> mask((size_t)(cus + 31) / 32, 0u);
-      for (int c = 0; c < cus; ++c)
-        if (c % 3 == third) mask[(size_t)c >> 5] |= 1u << (c & 31);
-      SCL_HIP(ctx, hipExtStreamCreateWithCUMask(&ctx->lat_stream, (uint32_t)mask.size(), mask.data()));
-      SCL_HIP(ctx, hipEventCreateWithFlags(&ctx->lat_ev[0], hipEventDisableTiming));
-      SCL_HIP(ctx, hipEventCreateWithFlags(&ctx->lat_ev[1], hipEventDisableTiming));
-    }
-    chase_st = ctx->lat_stream;
-    SCL_HIP(ctx, hipEventRecord(ctx->lat_ev[0], st));
-    SCL_HIP(ctx, hipStreamWaitEvent(chase_st, ctx->lat_ev[0], 0));
-  }
-  hipLaunchKernelGGL(sbr_chase, dim3(G), dim3(256), 0, chase_st, ca);
-  if (chase_st != st) {
-    SCL_HIP(ctx, hipEventRecord(ctx->lat_ev[1], chase_st));
-    SCL_HIP(ctx, hipStreamWaitEvent(st, ctx->lat_ev[1], 0));
-  }
+  // (Round 3 tried a stream whose CU mask holds a third of the CUs, so that the chase packs three workgroups per CU and leaves the
+  // rest of the chip whole for the 256 x 256 GEMM workgroups of a concurrent decomposition -- a chase workgroup takes 36 KB of
+  // the 160 KB of LDS, and the dispatcher spreads the ~n / 128 workgroups one per CU, where no 128 KB GEMM workgroup fits beside
+  // them. On the masked stream not all workgroups became resident and the chase ended through its bounded spin
+  // (profiles/r03_cfg4_ab_runs.log); removed.)
+  hipLaunchKernelGGL(sbr_chase, dim3(G), dim3(256), 0, st, ca);
   hipLaunchKernelGGL(sbr_band_diag, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, Bd, n, d_dev, e_dev);
   SCL_HIP(ctx, hipGetLastError());
   unsigned aborted = 0;

@@ -197,6 +197,7 @@ struct Session {
   ShardReduce sh;
   int64_t Kdiv = 0;
   int64_t chefsi_used = 0, chefsi_fallback = 0;
+  double chefsi_tail_gap = 0.0;  // > 0: gap-aware targets for the tail pairs of the partial eigensolver (chefsi.hip)
   float* nVt = nullptr;       // signal vectors, cell side, descending, [k][ldn]
   int64_t k = 0, ldn = 0;
   std::vector<float*> ens;    // slot t: [ncols][ldn], descending
@@ -1021,7 +1022,7 @@ static int perturb_core(Session* s, int64_t t, int64_t min_pc, double* nL_top, i
     int conv = 0, its = 0;
     SCL_TRY(topk_chefsi(ctx, implicit_op ? nullptr : s->A, s->n, s->lda, (int)min_pc, (int)std::min<int64_t>(s->k, min_pc), (int)s->b0,
                         s->Z0t, s->ldz, s->theta0.data(), wd.data(), s->Zt, s->ldz, &conv, &its, implicit_op ? s->Btmp : nullptr,
-                        s->K, s->ldb, (float)s->M));
+                        s->K, s->ldb, (float)s->M, s->chefsi_tail_gap));
     const double tol = 8.0 * 5.96e-8 * std::sqrt((double)s->n) * std::max(0.0, wd.empty() ? 0.0 : wd[0]);
     if (conv && wd[min_pc - 1] > tol) {  // all min_pc eigenvalues positive: c = min(min_pc, r) = min_pc
       s->chefsi_used += 1;
@@ -1092,7 +1093,7 @@ int session_perturb_round_seeded(Session* s, const int64_t* t, const uint64_t* s
       std::vector<double> wd(min_pc);
       int conv = 0, its = 0;
       PR_TRY(topk_chefsi(ctx, s->A, s->n, s->lda, (int)min_pc, (int)std::min<int64_t>(s->k, min_pc), (int)s->b0, s->Z0t, s->ldz,
-                          s->theta0.data(), wd.data(), s->Zt, s->ldz, &conv, &its));
+                          s->theta0.data(), wd.data(), s->Zt, s->ldz, &conv, &its, nullptr, 0, 0, 1.f, 0.05));  // rounds: always strict tails
       const double tol = 8.0 * 5.96e-8 * std::sqrt((double)s->n) * std::max(0.0, wd[0]);
       if (conv && wd[min_pc - 1] > tol) {
         s->chefsi_used += 1;
@@ -1139,7 +1140,7 @@ int session_perturb_round_seeded(Session* s, const int64_t* t, const uint64_t* s
     std::vector<double> hl((size_t)min_pc + 1);
     SCL_HIP(ctx, hipMemcpyAsync(hl.data(), ls, sizeof(double) * (size_t)(min_pc + 1), hipMemcpyDeviceToHost, ctx->stream));
     SCL_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    const int64_t c = (int64_t)(hl[0] + 0.5);
+    const int64_t c = std::min<int64_t>(min_pc, std::max<int64_t>(0, (int64_t)(hl[0] + 0.5)));  // (a sane count whatever the reducer does)
     ncols[e] = c;
     for (int64_t q = 0; q < min_pc; ++q) nL_top[(int64_t)e * min_pc + q] = (q < c) ? hl[1 + q] : 0.0;
     s->ens_cols[t[e]] = c;
@@ -1195,6 +1196,7 @@ int session_shared_buffer(Session* s, int what, int64_t rows, int64_t k, double*
 int session_set_int(Session* s, const char* name, int64_t value) {
   const std::string k(name ? name : "");
   if (k == "chefsi") { s->use_chefsi = value != 0; return SCLENS_OK; }
+  if (k == "chefsi_tail_gap_milli") { s->chefsi_tail_gap = (double)value * 1e-3; return SCLENS_OK; }
   if (k == "centering") {  // 0 = "mean", 1 = "median" (scLENS.jl:651-654); set before the first decomposition
     if (value != 0 && value != 1) return s->ctx->fail(SCLENS_ERR_ARG, "session_set_int: centering must be 0 or 1");
     if (value == 1 && s->sh.on()) return s->ctx->fail(SCLENS_ERR_ARG, "session_set_int: a row-sharded session supports mean centring only");
@@ -1209,6 +1211,7 @@ int session_get_int(Session* s, const char* name, int64_t* value) {
   if (k == "chefsi_used") { *value = s->chefsi_used; return SCLENS_OK; }
   if (k == "chefsi_fallback") { *value = s->chefsi_fallback; return SCLENS_OK; }
   if (k == "chefsi") { *value = s->use_chefsi; return SCLENS_OK; }
+  if (k == "chefsi_tail_gap_milli") { *value = (int64_t)(s->chefsi_tail_gap * 1e3 + 0.5); return SCLENS_OK; }
   if (k == "centering") { *value = s->centering; return SCLENS_OK; }
   if (k == "gram_bits_used") { *value = s->ctx->gram_bits_used; return SCLENS_OK; }
   return s->ctx->fail(SCLENS_ERR_ARG, "session_get_int: unknown option " + k);

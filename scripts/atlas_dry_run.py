@@ -110,10 +110,25 @@ try:
         timed(f"search_round_{rd}", lambda: ses.search_round_seeded(seeds, ms, list(range(world)), 0, n_2))
     min_pc = 12
     m_pert = int(round(0.015 * M * N_total))
+    mine = {}
     for rd in range(2):
         ts = [rd * world + e for e in range(world)]
-        timed(f"perturb_round_{rd}", lambda: ses.perturb_round_seeded(ts, [api.sample_seed_for(d.sample_seed, "perturb", t) for t in ts],
-                                                                      [m_pert] * world, list(range(world)), 0, min_pc))
+        _, nc = timed(f"perturb_round_{rd}", lambda: ses.perturb_round_seeded(ts, [api.sample_seed_for(d.sample_seed, "perturb", t) for t in ts],
+                                                                              [m_pert] * world, list(range(world)), 0, min_pc))
+        mine[ts[0]] = nc[0]
+
+    def fill_other_slots():
+        # the members the other ranks decomposed arrive by the ensemble exchange; here: this rank's own slot copied into theirs
+        buf = ctx.malloc(4 * min_pc * ses.slot_ld())
+        try:
+            for t0, c0 in mine.items():
+                ses.export_slot(t0, min_pc, buf)
+                for e in range(1, world):
+                    ses.import_slot(t0 + e, min_pc, c0, buf)
+        finally:
+            ctx.free(buf)
+
+    timed("ensemble_exchange_stand_in", fill_other_slots)
     timed("robustness", lambda: ses.robustness(k, 2 * world))
     timed("gene_basis", lambda: ses.gene_basis(np.sort(L)[::-1][:k].copy()))
     free1, _ = torch.cuda.mem_get_info(0)

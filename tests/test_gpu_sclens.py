@@ -169,6 +169,52 @@ def test_partial_eigensolver_matches_full_solver(ctx, N, M, implicit, monkeypatc
     assert np.array_equal(a["robustness_scores"]["a_b"], b["robustness_scores"]["a_b"])
     assert np.abs(a["robustness_scores"]["rob_score"] - b["robustness_scores"]["rob_score"]).max() < 3e-3
     assert np.array_equal(a["sig_id"], b["sig_id"])
+    # members whose matching picked a tail vector (index >= k) were solved again with the gap-aware tail target: every picked
+    # column of such a member then agrees with the full solver's as a signal column does
+    assert isinstance(a["tail_redo"], list) and b["tail_redo"] == []
+    ab = a["robustness_scores"]["a_b"]
+    for t in a["tail_redo"]:
+        assert np.any(ab[:, t] >= k)
+        cols = np.unique(ab[:, t])
+        assert np.all(_abs_cos(a["nV_set"][t][:, cols], b["nV_set"][t][:, cols]) > 1 - 2e-2)
+
+
+def test_partial_eigensolver_tail_gap_option(ctx):
+    """session option "chefsi_tail_gap_milli": the tail pairs k .. min_pc-1 of an ensemble member held to a gap-aware residual
+    target, residual <= 0.05 (theta_q - theta_block_end), i.e. sin(angle to the true vector) <= 0.05 (what api.sclens switches on
+    for a member whose tail vector gets matched). Every column whose eigenvalue is separated from its neighbours by 1 % then agrees
+    with the full solver's to |cos| >= 1 - 5e-3, tail columns included."""
+    X = api._csc_f32(synth_counts(600, 250, seed=1, C=5, marker_frac=0.2, marker_sd=1.5))
+    d = api.make_draws_native(X, seed=9)
+    ref = api.sclens(X, draws=d, n_perturb=2, ctx=ctx, keep_intermediates=True, max_search_iters=6, partial_eig=False, streams=1)
+    k, min_pc = len(ref["signal_ev"]), ref["min_pc"]
+    ses = api.Session(ctx, X, api._resolve(d.z_idx1), api._resolve(d.z_idx2))
+    try:
+        ses.set_int("chefsi", 1)
+        ses.null_spectrum(api._resolve(d.X_r))
+        ses.data_spectrum(True)
+        ses.signal_vectors(k)
+        m_pert = int(round((1 - ref["p_"]) * X.shape[0] * X.shape[1]))
+        outs = {}
+        for milli in (0, 50):
+            ses.set_int("chefsi_tail_gap_milli", milli)
+            assert ses.get_int("chefsi_tail_gap_milli") == milli
+            nl, c = ses.perturb_seeded(0, api.sample_seed_for(d.sample_seed, "perturb", 0), m_pert, min_pc)
+            outs[milli] = (nl, ses.get_perturbed(0, c))
+        assert ses.get_int("chefsi_used") == 2 and ses.get_int("chefsi_fallback") == 0
+    finally:
+        ses.close()
+    nLf, Vf = ref["nL_set"][0], ref["nV_set"][0]
+    for milli, (nl, V) in outs.items():
+        c = min(V.shape[1], Vf.shape[1])
+        assert c > k
+        assert np.allclose(nl[:c], nLf[:c], rtol=2e-3)
+        cos = _abs_cos(V[:, :c], Vf[:, :c])
+        assert np.all(cos[:k] > 1 - 3e-3), (milli, cos)
+        if milli:
+            lam = np.asarray(nLf[: c + 1], dtype=np.float64)
+            sep = np.minimum(np.abs(np.diff(lam, prepend=np.inf)), np.abs(np.diff(lam, append=-np.inf)))[:c] > 1e-2 * lam[:c]
+            assert np.all(cos[sep] > 1 - 5e-3), (cos, sep)
 
 
 def test_two_streams_give_identical_results(ctx):
