@@ -7,6 +7,7 @@ from __future__ import annotations
 import ctypes as C
 import os
 import sys
+import threading
 
 import numpy as np
 
@@ -193,13 +194,34 @@ class Context:
             raise SclensHipError(rc, "sclens_hip_create failed (no usable HIP device?)")
         self.h = h
         self.device = int(device)
+        # objects created on this context (sessions, patterns, device matrices, communicators) hold it open: close() with
+        # live children only marks it, the last child's close() destroys it. (The garbage collector finalises the members
+        # of a dead cycle in any order: a session must never be destroyed after its context.)
+        self._children = 0
+        self._deferred = False
+        self._lock = threading.Lock()
 
     def check(self, rc):
         if rc != 0:
             raise SclensHipError(rc, self.lib.sclens_hip_last_error(self.h).decode())
 
+    def _adopt(self):
+        with self._lock:
+            self._children += 1
+
+    def _release(self):
+        with self._lock:
+            self._children -= 1
+            last = self._children <= 0 and self._deferred
+        if last:
+            self.close()
+
     def close(self):
         if getattr(self, "h", None):
+            with self._lock:
+                if self._children > 0:
+                    self._deferred = True
+                    return
             self.lib.sclens_hip_destroy(self.h)
             self.h = None
 
@@ -265,6 +287,7 @@ class Comm:
         h = vp()
         ctx.check(self.lib.sclens_hip_comm_create(ctx.h, ptr(uid, C.c_uint8), int(rank), int(world), C.byref(h)))
         self.h = h
+        self.ctx._adopt()
         w, r, v = C.c_int(0), C.c_int(0), C.c_int(0)
         self.check(self.lib.sclens_hip_comm_info(self.h, C.byref(w), C.byref(r), C.byref(v)))
         self.world, self.rank, self.rccl_version = w.value, r.value, v.value  # as RCCL reports them
@@ -314,6 +337,7 @@ class Comm:
         if getattr(self, "h", None):
             self.lib.sclens_hip_comm_destroy(self.h)
             self.h = None
+            self.ctx._release()
 
     def __del__(self):
         try:

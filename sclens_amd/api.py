@@ -468,6 +468,7 @@ class DeviceCounts:
 
     def __init__(self, ctx: Context, handle):
         self.ctx, self.h = ctx, handle
+        ctx._adopt()
         n, m, z = C.c_int64(0), C.c_int64(0), C.c_int64(0)
         ctx.check(ctx.lib.sclens_hip_counts_info(handle, C.byref(n), C.byref(m), C.byref(z)))
         self.shape, self.nnz = (n.value, m.value), z.value
@@ -509,6 +510,7 @@ class DeviceCounts:
         if getattr(self, "h", None):
             self.ctx.lib.sclens_hip_counts_destroy(self.h)
             self.h = None
+            self.ctx._release()
 
     def __del__(self):
         try:
@@ -533,6 +535,7 @@ class Pattern:
                                                     ptr(rowval, C.c_int32), ptr(nzval, C.c_float), self.ncand,
                                                     ptr(z1, C.c_uint32), ptr(z2, C.c_uint32), C.byref(h)))
         self.h = h
+        self.ctx._adopt()
 
     @classmethod
     def drawn(cls, ctx: Context, X: sp.csc_matrix, seed: int) -> "Pattern":
@@ -543,6 +546,7 @@ class Pattern:
             h, nc = C.c_void_p(), C.c_int64(0)
             ctx.check(ctx.lib.sclens_hip_pattern_create_drawn_from_counts(ctx.h, X.h, int(seed) & _M64, C.byref(h), C.byref(nc)))
             p.h, p.ncand = h, int(nc.value)
+            ctx._adopt()
             return p
         colptr = np.ascontiguousarray(X.indptr, dtype=np.int64)
         rowval = np.ascontiguousarray(X.indices, dtype=np.int32)
@@ -551,6 +555,7 @@ class Pattern:
         ctx.check(ctx.lib.sclens_hip_pattern_create_drawn(ctx.h, X.shape[0], X.shape[1], ptr(colptr, C.c_int64), ptr(rowval, C.c_int32),
                                                           ptr(nzval, C.c_float), int(seed) & _M64, C.byref(h), C.byref(nc)))
         p.h, p.ncand = h, int(nc.value)
+        ctx._adopt()
         return p
 
     def candidates(self):
@@ -567,6 +572,7 @@ class Pattern:
         if getattr(self, "h", None):
             self.ctx.lib.sclens_hip_pattern_destroy(self.h)
             self.h = None
+            self.ctx._release()
 
     def __del__(self):
         try:
@@ -590,6 +596,7 @@ class Session:
             h = C.c_void_p()
             ctx.check(ctx.lib.sclens_hip_session_create_from_counts(ctx.h, X.h, C.byref(h)))
             self.h = h
+            self.ctx._adopt()
             return
         colptr = np.ascontiguousarray(X.indptr, dtype=np.int64)
         rowval = np.ascontiguousarray(X.indices, dtype=np.int32)
@@ -602,6 +609,7 @@ class Session:
                                                     ptr(nzval, C.c_float), self.ncand, ptr(z1, C.c_uint32),
                                                     ptr(z2, C.c_uint32), C.byref(h)))
         self.h = h
+        self.ctx._adopt()
 
     @classmethod
     def create_sharded(cls, ctx: Context, X_local: sp.csc_matrix, row0: int, N_global: int, z1: np.ndarray, z2: np.ndarray,
@@ -627,6 +635,7 @@ class Session:
                                                             ptr(z1, C.c_uint32), ptr(z2, C.c_uint32), fn, user,
                                                             C.byref(h)))
         s.h = h
+        s.ctx._adopt()
         return s
 
     @classmethod
@@ -648,6 +657,7 @@ class Session:
                                                                   ptr(rowval, C.c_int32), ptr(nzval, C.c_float), int(nnz_global),
                                                                   int(seed) & _M64, fn, user, C.byref(h), C.byref(nc)))
         s.h = h
+        s.ctx._adopt()
         s.ncand_local = s.ncand = int(nc.value)
         return s
 
@@ -693,6 +703,7 @@ class Session:
         if getattr(self, "h", None):
             self.ctx.lib.sclens_hip_session_destroy(self.h)
             self.h = None
+            self.ctx._release()
 
     def __del__(self):
         try:
@@ -726,6 +737,7 @@ class Session:
         h = C.c_void_p()
         ctx2.check(ctx2.lib.sclens_hip_session_clone(ctx2.h, self.h, C.byref(h)))
         w.h = h
+        w.ctx._adopt()
         return w
 
     def spectrum(self, X_r: sp.csc_matrix):
@@ -1007,11 +1019,10 @@ def sclens(inp_df, device_="gpu", th=60, p_step=0.001, n_perturb=20, centering="
     null_future = aux_pool.submit(build_null_pattern)
     pat_future = aux_pool.submit(build_pattern)
     pat = None
+    workers, wctx, pool = [ses], [], None
     try:
         # local workers: `streams` sessions on this GPU (own stream + scratch each, shared read-only data), one host
         # thread per session (ctypes releases the GIL), so independent decompositions overlap on the device
-        workers = [ses]
-        wctx = []
         for _ in range(max(1, int(streams)) - 1):
             c2 = Context(ctx.device)
             wctx.append(c2)
@@ -1254,6 +1265,12 @@ def sclens(inp_df, device_="gpu", th=60, p_step=0.001, n_perturb=20, centering="
         except Exception:
             pass
         aux_pool.shutdown(wait=True)
+        if pool is not None:
+            pool.shutdown(wait=True)
+        for w in workers[1:]:  # an error in the first phase leaves the worker sessions open (closing twice is harmless)
+            w.close()
+        for c2 in wctx:
+            c2.close()
         ses.close()
         if pat is not None:
             pat.close()

@@ -1137,6 +1137,258 @@ __global__ __launch_bounds__(256) void sbr_chase(SbrChaseArgs a) {
   }
 }
 
+// ---- round 3: the same task arithmetic (bitwise the same results) with a shorter hand-off chain between sweeps.
+// In sbr_chase a task is poll -> 32 loads -> compute -> 32 stores -> drain -> counter, and the successor sweep repeats that chain
+// two tasks later: per sweep 2 x (two memory round trips + compute + drain) + one more round trip = 9.9 us at n = 30 016. Here
+//  * the blocks of task k+1 are PREFETCHED at the end of task k: rows 0..62 of them were written by the predecessor's task k+1, which
+//    the counter check that admitted OUR task k's prefetch one step earlier ... (see `need2`) already covers; only the last row
+//    (global row r_k + 63 = first row of the predecessor's task k+2) is younger;
+//  * that row travels in a MESSAGE: 65 {value, tag} pairs (8-byte single-copy-atomic stores / loads, tag = sweep + 1) that the
+//    producer sends from registers the moment its update is computed, before its bulk stores; the consumer's waves poll the pairs
+//    they need (one round trip, data included) and patch lane 63 of their registers. The producer does not store that row to the
+//    band at all (the consumer's own store of its row 63 is the only writer: no write-write race);
+//  * the counter (bulk visibility: stores drained) is still written after `vmcnt(0)` + barrier, but the same wait now also covers
+//    the prefetch loads, and the consumer reads the counter with a load issued in the middle of its compute phase.
+// Chain per task: message poll -> compute -> message send; in parallel: stores + prefetch -> drain -> counter.
+constexpr int MBW = 72;  // 8-byte slots per message (65 used)
+typedef unsigned u32x2 __attribute__((vector_size(8)));
+
+struct SbrChaseMbArgs {
+  float* Bd;
+  int64_t n;
+  float* V2;
+  int64_t ldv2;
+  float* TAU2;
+  int64_t ldt;
+  unsigned* done;            // [n] progress counters + [n] : abort word
+  unsigned long long* MB;    // [R][kmax][MBW] messages of sweep s in ring slot s mod R
+  int R, kmax;
+};
+
+// every lane of the wave polls the same counter; < 0: aborted
+__device__ __forceinline__ int sbr_spin_flag(const unsigned* p, int need, unsigned* abort_w) {
+  for (unsigned spins = 0;; ++spins) {
+    const int x = __builtin_amdgcn_readfirstlane((int)__hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+    if (x >= need) return x;
+    if ((spins & 1023u) == 1023u) {
+      if (__hip_atomic_load(abort_w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u || spins > (1u << 24)) {
+        __hip_atomic_store(abort_w, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return -1;
+      }
+    }
+    __builtin_amdgcn_s_sleep(1);
+  }
+}
+
+__global__ __launch_bounds__(256) void sbr_chase_mb(SbrChaseMbArgs a) {
+  __shared__ float Bt[SB * 65], Dt[SB * 65];
+  __shared__ float part[4 * SB], part2[4 * SB], partD[4 * SB];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wq = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int64_t n = a.n;
+  const unsigned nbytes = (unsigned)(n * LDB2 * sizeof(float));
+  __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(a.Bd, 0, nbytes, 0x00020000);
+  const unsigned mbytes = (unsigned)((int64_t)a.R * a.kmax * MBW * 8);
+  __amdgpu_buffer_rsrc_t rm = __builtin_amdgcn_make_buffer_rsrc(a.MB, 0, mbytes, 0x00020000);
+  const unsigned OOR = 0xfffffff0u;  // beyond num_records: loads return 0, stores are dropped
+  unsigned* abort_w = a.done + n;
+  // the pairs this lane polls: lanes 0..15 the D row (pair 1 + 16 wq + lane), lane 16 the predecessor's beta (pair 0)
+  const bool act = lane <= 16;
+  const unsigned midx = (lane < 16) ? (1u + 16u * (unsigned)wq + (unsigned)lane) : 0u;
+  for (int64_t s = blockIdx.x; s + 2 < n; s += gridDim.x) {
+    const int K = sbr_tasks_of(s, n);
+    const int Kprev = (s > 0) ? sbr_tasks_of(s - 1, n) : 0;
+    const bool has_prev = s > 0, has_next = s + 3 < n;
+    int pd = has_prev ? 0 : 0x7fffffff;
+    const unsigned tag_in = (unsigned)s, tag_out = (unsigned)(s + 1);
+    const unsigned mb_in = (unsigned)(((s + a.R - 1) % a.R) * a.kmax), mb_out = (unsigned)((s % a.R) * a.kmax);
+    float vp = 0.f, tp = 0.f;
+    float rb[16], rd[16], ycol = 0.f;
+    u32x2 prn = {0u, 0u};  // first look at the next message, issued with the prefetch
+    const unsigned* flagp = a.done + (has_prev ? s - 1 : 0);  // the predecessor's counter
+    {  // blocks of task 0 (no off-diagonal block): the predecessor's task 0 must have drained
+      if (has_prev) {
+        pd = sbr_spin_flag(flagp, 1, abort_w);
+        if (pd < 0) return;
+      }
+      const int64_t rk = s + 1;
+      const int L = (int)((n - rk < SB) ? n - rk : SB);
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        const int j = 16 * wq + q;
+        rb[q] = 0.f;
+        const unsigned od = (lane >= j && lane < L) ? (((unsigned)rk + j) * LDB2 + lane - j) * 4u : OOR;
+        rd[q] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, od, 0, 16));
+      }
+      const unsigned oy = (lane < L) ? ((unsigned)s * LDB2 + 1 + lane) * 4u : OOR;
+      ycol = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, oy, 0, 16));
+    }
+    for (int k = 0; k < K; ++k) {
+      const int64_t rk = s + 1 + (int64_t)k * SB;
+      const int L = (int)((n - rk < SB) ? n - rk : SB);
+      const unsigned colB0 = (unsigned)(rk - SB), colD0 = (unsigned)rk;
+      // ---- the last row of the blocks: the message of the predecessor's task k+1 (exists exactly when L = SB there)
+      if (has_prev && k + 1 < Kprev) {
+        const unsigned mo = act ? ((mb_in + (unsigned)(k + 1)) * MBW + midx) * 8u : OOR;
+        u32x2 pr = prn;
+        for (unsigned spins = 0; !__all(!act || pr[1] == tag_in); ++spins) {
+          if ((spins & 1023u) == 1023u) {
+            if (__hip_atomic_load(abort_w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u || spins > (1u << 24)) {
+              __hip_atomic_store(abort_w, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+              return;
+            }
+          }
+          pr = __builtin_amdgcn_raw_buffer_load_b64(rm, mo, 0, 16);
+        }
+        const float mv = __builtin_bit_cast(float, pr[0]);
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {  // D[63][16 wq + q]: pair 1 + 16 wq + q (the last one is the predecessor's D[0][0])
+          const float val = sbr_rl(mv, q);
+          if (lane == 63) rd[q] = val;
+        }
+        const float b0 = sbr_rl(mv, 16);  // the predecessor's beta: B[63][63], or entry 63 of the sweep's first column
+        if (k > 0) {
+          if (wq == 3 && lane == 63) rb[15] = b0;
+        } else if (lane == 63) {
+          ycol = b0;
+        }
+      }
+      // ---- LDS images (column-major: X[i][j] at j * 65 + i); D gets both triangles
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        const int j = 16 * wq + q;
+        Bt[j * 65 + lane] = rb[q];
+        if (lane >= j) {
+          Dt[j * 65 + lane] = rd[q];
+          Dt[lane * 65 + j] = rd[q];
+        }
+      }
+      // ---- w = B v_prev (partial sums over this wave's columns)
+      float pw = 0.f;
+#pragma unroll
+      for (int q = 0; q < 16; ++q) pw += rb[q] * sbr_rl(vp, 16 * wq + q);
+      part[wq * SB + lane] = pw;
+      __syncthreads();
+      // the predecessor's counter for the prefetch at the end of this task: a first look now (back before it is needed), a second
+      // one after the next barrier (younger, but the wave may have to wait for it)
+      const bool more = k + 1 < K;
+      const int need2 = (k + 2 < Kprev) ? k + 2 : Kprev;
+      const unsigned fl_a = __hip_atomic_load(flagp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const float w = (part[lane] + part[SB + lane]) + (part[2 * SB + lane] + part[3 * SB + lane]);
+      const float y = (k > 0) ? Bt[lane] - tp * w * sbr_rl(vp, 0) : ycol;
+      // ---- reflector from y (every wave, identical arithmetic)
+      const float xi = (lane >= 1 && lane < L) ? y : 0.f;
+      const double sg = sbr_wave_sum((double)xi * (double)xi);
+      const float alpha = sbr_rl(y, 0);
+      float tau = 0.f, beta = alpha, scale = 0.f;
+      if (sg > 0.0) {
+        const double nrm = sqrt((double)alpha * (double)alpha + sg);
+        beta = (float)((alpha >= 0.f) ? -nrm : nrm);
+        tau = (beta - alpha) / beta;
+        scale = 1.f / (alpha - beta);
+      }
+      const float v = (lane == 0) ? 1.f : xi * scale;
+      const unsigned fl_b = __hip_atomic_load(flagp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      // ---- z0 = v'B (T2: lane = column), D v (T1)
+      float pz = 0.f;
+      if (k > 0) {
+#pragma unroll
+        for (int q = 0; q < 16; ++q) pz += Bt[lane * 65 + 16 * wq + q] * sbr_rl(v, 16 * wq + q);
+      }
+      part2[wq * SB + lane] = pz;
+      const float vw = sbr_wave_sum(v * w);
+      float dd[16];
+      float pdv = 0.f;
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        dd[q] = Dt[(16 * wq + q) * 65 + lane];
+        pdv += dd[q] * sbr_rl(v, 16 * wq + q);
+      }
+      partD[wq * SB + lane] = pdv;
+      __syncthreads();
+      const float z = ((part2[lane] + part2[SB + lane]) + (part2[2 * SB + lane] + part2[3 * SB + lane])) - tp * vw * vp;
+      float w2 = tau * ((partD[lane] + partD[SB + lane]) + (partD[2 * SB + lane] + partD[3 * SB + lane]));
+      const float a2 = -0.5f * tau * sbr_wave_sum(v * w2);
+      w2 += a2 * v;
+      // ---- B <- H (B H_prev), D <- H D H in registers
+      float bnv[16], dnv[16];
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        const int j = 16 * wq + q;
+        float bn = rb[q] - tp * w * sbr_rl(vp, j) - tau * v * sbr_rl(z, j);
+        if (j == 0) bn = (lane == 0) ? beta : 0.f;
+        bnv[q] = bn;
+        dnv[q] = dd[q] - v * sbr_rl(w2, j) - w2 * sbr_rl(v, j);
+      }
+      // ---- (1) row 0 to the successor, from lane 0 of every wave
+      const bool send = k > 0 && has_next;
+      const int lo = send ? 1 : 0;
+      const unsigned mrow = (mb_out + (unsigned)k) * MBW;
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        const u32x2 pm = {__builtin_bit_cast(unsigned, bnv[q]), tag_out};
+        __builtin_amdgcn_raw_buffer_store_b64(pm, rm, (send && lane == 0) ? (mrow + (unsigned)(16 * wq + q)) * 8u : OOR, 0, 16);
+      }
+      {
+        const u32x2 pm = {__builtin_bit_cast(unsigned, dnv[0]), tag_out};
+        __builtin_amdgcn_raw_buffer_store_b64(pm, rm, (send && wq == 0 && lane == 0) ? (mrow + 64u) * 8u : OOR, 0, 16);
+      }
+      // ---- (2) prefetch of the next task's blocks (rows 0..62 valid once the predecessor's task k+1 has drained; row 63: message)
+      __builtin_amdgcn_sched_barrier(0);  // keep the wait for the counter loads behind the message
+      {  // both looks are old enough to be back: no wait in the common case
+        int xa, xb;  // volatile asm: the compiler's own readfirstlane floats up to the loads and waits for them there
+        asm volatile("v_readfirstlane_b32 %0, %1" : "=s"(xa) : "v"(fl_a));
+        asm volatile("v_readfirstlane_b32 %0, %1" : "=s"(xb) : "v"(fl_b));
+        if (has_prev) pd = (xa > pd) ? xa : pd;
+        if (has_prev) pd = (xb > pd) ? xb : pd;
+      }
+      if (more) {
+        if (pd < need2) {
+          pd = sbr_spin_flag(flagp, need2, abort_w);
+          if (pd < 0) return;
+        }
+        const int64_t rk1 = rk + SB;
+        const int L1 = (int)((n - rk1 < SB) ? n - rk1 : SB);
+        const unsigned cB1 = (unsigned)rk, cD1 = (unsigned)rk1;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+          const int j = 16 * wq + q;
+          const unsigned ob = (lane < L1) ? ((cB1 + j) * LDB2 + SB + lane - j) * 4u : OOR;
+          rb[q] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, ob, 0, 16));
+          const unsigned od = (lane >= j && lane < L1) ? ((cD1 + j) * LDB2 + lane - j) * 4u : OOR;
+          rd[q] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, od, 0, 16));
+        }
+        // a first look at the next task's message
+        const bool msg_next = has_prev && k + 2 < Kprev;
+        prn = __builtin_amdgcn_raw_buffer_load_b64(rm, (msg_next && act) ? ((mb_in + (unsigned)(k + 2)) * MBW + midx) * 8u : OOR, 0, 16);
+      }
+      // ---- (3) the rest of the blocks, write-through
+      const bool kb = k > 0;
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        const int j = 16 * wq + q;
+        const unsigned ob = (kb && lane >= lo && lane < L) ? ((colB0 + j) * LDB2 + SB + lane - j) * 4u : OOR;
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, bnv[q]), rs, ob, 0, 16);
+        const unsigned od = (lane >= j && lane >= lo && lane < L) ? ((colD0 + j) * LDB2 + lane - j) * 4u : OOR;
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, dnv[q]), rs, od, 0, 16);
+      }
+      if (wq == 0) {
+        if (k == 0) {
+          const unsigned oy = (lane < L) ? ((unsigned)s * LDB2 + 1 + lane) * 4u : OOR;
+          __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, (lane == 0) ? beta : 0.f), rs, oy, 0, 16);
+        }
+        if (lane < L) a.V2[s * a.ldv2 + rk + lane] = v;
+        if (lane == 0) a.TAU2[s * a.ldt + k] = tau;
+      }
+      vp = v;
+      tp = tau;
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // write-through stores have left (and the prefetch has landed)
+      __syncthreads();
+      if (tid == 0) __hip_atomic_store(a.done + s, (unsigned)(k + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+}
+
 __global__ void sbr_band_diag(const float* __restrict__ Bd, int64_t n, double* __restrict__ d, double* __restrict__ e) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) {
@@ -1169,12 +1421,22 @@ int sb2st_f32(Ctx* ctx, const float* A, int64_t n, int64_t lda, double* d_dev, d
   if (G < 1) G = 1;
   if (const char* eg = getenv("SCLENS_HIP_CHASE_WGS")) G = std::max(1, std::min(G, atoi(eg)));
   SbrChaseArgs ca{Bd, n, V2, ldv2, TAU2, ldt, done};
+  int use_mb = 1;
+  if (const char* ev = getenv("SCLENS_HIP_CHASE_MB")) use_mb = atoi(ev);
   // (Round 3 tried a stream whose CU mask holds a third of the CUs, so that the chase packs three workgroups per CU and leaves the
   // rest of the chip whole for the 256 x 256 GEMM workgroups of a concurrent decomposition -- a chase workgroup takes 36 KB of
   // the 160 KB of LDS, and the dispatcher spreads the ~n / 128 workgroups one per CU, where no 128 KB GEMM workgroup fits beside
   // them. On the masked stream not all workgroups became resident and the chase ended through its bounded spin
   // (profiles/r03_cfg4_ab_runs.log); removed.)
-  hipLaunchKernelGGL(sbr_chase, dim3(G), dim3(256), 0, st, ca);
+  if (use_mb) {
+    const int R = G + 1, kmax = (int)(n / SB) + 2;  // slot of sweep s is free again once sweep s+1 has ended: before sweep s+G+1 starts
+    SCL_WS(ctx, MB, unsigned long long, "sbr.MB", (int64_t)R * kmax * MBW);
+    SCL_HIP(ctx, hipMemsetAsync(MB, 0, sizeof(unsigned long long) * (size_t)R * kmax * MBW, st));  // tag 0 = no sweep
+    SbrChaseMbArgs cm{Bd, n, V2, ldv2, TAU2, ldt, done, MB, R, kmax};
+    hipLaunchKernelGGL(sbr_chase_mb, dim3(G), dim3(256), 0, st, cm);
+  } else {
+    hipLaunchKernelGGL(sbr_chase, dim3(G), dim3(256), 0, st, ca);
+  }
   hipLaunchKernelGGL(sbr_band_diag, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, Bd, n, d_dev, e_dev);
   SCL_HIP(ctx, hipGetLastError());
   unsigned aborted = 0;
