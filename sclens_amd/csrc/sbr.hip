@@ -987,18 +987,44 @@ struct SbrChaseArgs {
 __device__ __forceinline__ float sbr_rl(float x, int l) {
   return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), l));
 }
+// Wave-wide sums on the DPP network (no LDS round trips: a ds_bpermute butterfly costs ~100 clocks per step, and a task has three
+// sums on its critical path): xor-1 and xor-2 inside quads, half-row and row mirrors -> every lane holds its row's sum; the four row
+// sums are combined as (r0 + r1) + (r2 + r3) from scalar registers. Every lane gets the same bits.
+template <int CTRL>
+__device__ __forceinline__ float sbr_dpp(float x) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), CTRL, 0xf, 0xf, true));
+}
+template <int CTRL>
+__device__ __forceinline__ double sbr_dpp(double x) {
+  const long long b = __builtin_bit_cast(long long, x);
+  const int lo = __builtin_amdgcn_update_dpp(0, (int)b, CTRL, 0xf, 0xf, true);
+  const int hi = __builtin_amdgcn_update_dpp(0, (int)(b >> 32), CTRL, 0xf, 0xf, true);
+  return __builtin_bit_cast(double, ((long long)hi << 32) | (long long)(unsigned)lo);
+}
 __device__ __forceinline__ float sbr_wave_sum(float x) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) x += __shfl_xor(x, o);
-  return x;
+  x += sbr_dpp<0xB1>(x);   // quad_perm [1,0,3,2]
+  x += sbr_dpp<0x4E>(x);   // quad_perm [2,3,0,1]
+  x += sbr_dpp<0x141>(x);  // row_half_mirror
+  x += sbr_dpp<0x140>(x);  // row_mirror
+  return (sbr_rl(x, 0) + sbr_rl(x, 16)) + (sbr_rl(x, 32) + sbr_rl(x, 48));
 }
 __device__ __forceinline__ double sbr_wave_sum(double x) {
+  x += sbr_dpp<0xB1>(x);
+  x += sbr_dpp<0x4E>(x);
+  x += sbr_dpp<0x141>(x);
+  x += sbr_dpp<0x140>(x);
+  const long long b = __builtin_bit_cast(long long, x);
+  double r[4];
 #pragma unroll
-  for (int o = 32; o > 0; o >>= 1) x += __shfl_xor(x, o);
-  return x;
+  for (int i = 0; i < 4; ++i) {
+    const int lo = __builtin_amdgcn_readlane((int)b, 16 * i), hi = __builtin_amdgcn_readlane((int)(b >> 32), 16 * i);
+    r[i] = __builtin_bit_cast(double, ((long long)hi << 32) | (long long)(unsigned)lo);
+  }
+  return (r[0] + r[1]) + (r[2] + r[3]);
 }
 
 __global__ __launch_bounds__(256) void sbr_chase(SbrChaseArgs a) {
+#pragma clang fp contract(off)  // every fused multiply-add below is written out: sbr_chase and sbr_chase_mb give the same bits
   __shared__ float Bt[SB * 65], Dt[SB * 65];
   __shared__ float part[4 * SB], part2[4 * SB], partD[4 * SB];
   __shared__ int pd_s;
@@ -1068,18 +1094,18 @@ __global__ __launch_bounds__(256) void sbr_chase(SbrChaseArgs a) {
       // ---- w = B v_prev (partial sums over this wave's columns)
       float pw = 0.f;
 #pragma unroll
-      for (int q = 0; q < 16; ++q) pw += rb[q] * sbr_rl(vp, 16 * wq + q);
+      for (int q = 0; q < 16; ++q) pw = fmaf(rb[q], sbr_rl(vp, 16 * wq + q), pw);
       part[wq * SB + lane] = pw;
       __syncthreads();
       const float w = (part[lane] + part[SB + lane]) + (part[2 * SB + lane] + part[3 * SB + lane]);
-      const float y = (k > 0) ? Bt[lane] - tp * w * sbr_rl(vp, 0) : ycol;
+      const float y = (k > 0) ? fmaf(-(tp * w), sbr_rl(vp, 0), Bt[lane]) : ycol;
       // ---- reflector from y (every wave, identical arithmetic)
       const float xi = (lane >= 1 && lane < L) ? y : 0.f;
       const double sg = sbr_wave_sum((double)xi * (double)xi);
       const float alpha = sbr_rl(y, 0);
       float tau = 0.f, beta = alpha, scale = 0.f;
       if (sg > 0.0) {
-        const double nrm = sqrt((double)alpha * (double)alpha + sg);
+        const double nrm = sqrt(fma((double)alpha, (double)alpha, sg));
         beta = (float)((alpha >= 0.f) ? -nrm : nrm);
         tau = (beta - alpha) / beta;
         scale = 1.f / (alpha - beta);
@@ -1089,7 +1115,7 @@ __global__ __launch_bounds__(256) void sbr_chase(SbrChaseArgs a) {
       float pz = 0.f;
       if (k > 0) {
 #pragma unroll
-        for (int q = 0; q < 16; ++q) pz += Bt[lane * 65 + 16 * wq + q] * sbr_rl(v, 16 * wq + q);
+        for (int q = 0; q < 16; ++q) pz = fmaf(Bt[lane * 65 + 16 * wq + q], sbr_rl(v, 16 * wq + q), pz);
       }
       part2[wq * SB + lane] = pz;
       const float vw = sbr_wave_sum(v * w);
@@ -1098,25 +1124,25 @@ __global__ __launch_bounds__(256) void sbr_chase(SbrChaseArgs a) {
 #pragma unroll
       for (int q = 0; q < 16; ++q) {
         dd[q] = Dt[(16 * wq + q) * 65 + lane];
-        pdv += dd[q] * sbr_rl(v, 16 * wq + q);
+        pdv = fmaf(dd[q], sbr_rl(v, 16 * wq + q), pdv);
       }
       partD[wq * SB + lane] = pdv;
       __syncthreads();
-      const float z = ((part2[lane] + part2[SB + lane]) + (part2[2 * SB + lane] + part2[3 * SB + lane])) - tp * vw * vp;
+      const float z = fmaf(-(tp * vw), vp, (part2[lane] + part2[SB + lane]) + (part2[2 * SB + lane] + part2[3 * SB + lane]));
       float w2 = tau * ((partD[lane] + partD[SB + lane]) + (partD[2 * SB + lane] + partD[3 * SB + lane]));
       const float a2 = -0.5f * tau * sbr_wave_sum(v * w2);
-      w2 += a2 * v;
+      w2 = fmaf(a2, v, w2);
       // ---- B <- H (B H_prev), D <- H D H on the registers, stored write-through
 #pragma unroll
       for (int q = 0; q < 16; ++q) {
         const int j = 16 * wq + q;
         if (k > 0) {
-          float bn = rb[q] - tp * w * sbr_rl(vp, j) - tau * v * sbr_rl(z, j);
+          float bn = fmaf(-(tau * v), sbr_rl(z, j), fmaf(-(tp * w), sbr_rl(vp, j), rb[q]));
           if (j == 0) bn = (lane == 0) ? beta : 0.f;
           const unsigned ob = (lane < L) ? ((colB0 + j) * LDB2 + SB + lane - j) * 4u : OOR;
           __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, bn), rs, ob, 0, 16);
         }
-        const float dn = dd[q] - v * sbr_rl(w2, j) - w2 * sbr_rl(v, j);
+        const float dn = fmaf(-w2, sbr_rl(v, j), fmaf(-v, sbr_rl(w2, j), dd[q]));
         const unsigned od = (lane >= j && lane < L) ? ((colD0 + j) * LDB2 + lane - j) * 4u : OOR;
         __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, dn), rs, od, 0, 16);
       }
@@ -1163,6 +1189,7 @@ struct SbrChaseMbArgs {
   unsigned* done;            // [n] progress counters + [n] : abort word
   unsigned long long* MB;    // [R][kmax][MBW] messages of sweep s in ring slot s mod R
   int R, kmax;
+  unsigned long long* prof;  // PROF only: [9]
 };
 
 // every lane of the wave polls the same counter; < 0: aborted
@@ -1180,7 +1207,11 @@ __device__ __forceinline__ int sbr_spin_flag(const unsigned* p, int need, unsign
   }
 }
 
+// PROF: wave 0 samples the shader clock at eight points of every task and adds the differences into a.prof[0..7], the task count
+// into a.prof[8] (SCLENS_HIP_CHASE_PROF=1 prints the averages).
+template <bool PROF>
 __global__ __launch_bounds__(256) void sbr_chase_mb(SbrChaseMbArgs a) {
+#pragma clang fp contract(off)  // every fused multiply-add below is written out: sbr_chase and sbr_chase_mb give the same bits
   __shared__ float Bt[SB * 65], Dt[SB * 65];
   __shared__ float part[4 * SB], part2[4 * SB], partD[4 * SB];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -1191,9 +1222,23 @@ __global__ __launch_bounds__(256) void sbr_chase_mb(SbrChaseMbArgs a) {
   const unsigned mbytes = (unsigned)((int64_t)a.R * a.kmax * MBW * 8);
   __amdgpu_buffer_rsrc_t rm = __builtin_amdgcn_make_buffer_rsrc(a.MB, 0, mbytes, 0x00020000);
   const unsigned OOR = 0xfffffff0u;  // beyond num_records: loads return 0, stores are dropped
+  // Block accesses: entry (row i = lane, column j = 16 wq + q) of a block whose first column is c sits at byte
+  // ((c + 16 wq) LDB2 + r0 + lane - 16 wq) 4 + q QS: a per-lane base computed once per task + a per-instruction constant (the buffer
+  // instruction's scalar offset), instead of five address / predicate instructions per access (measured: the 4 x 85 memory
+  // instructions of a task took 45 % of its time). Masked lanes get OORB, far enough out that adding q QS cannot wrap.
+  constexpr unsigned QS = (LDB2 - 1) * 4, OORB = 0x80000000u;
+  const unsigned w16 = 16u * (unsigned)wq;
+  const int dl = lane - 16 * wq;  // D is stored on and below the diagonal: entry (lane, 16 wq + q) exists for dl >= q
   unsigned* abort_w = a.done + n;
   // the pairs this lane polls: lanes 0..15 the D row (pair 1 + 16 wq + lane), lane 16 the predecessor's beta (pair 0)
   const bool act = lane <= 16;
+  unsigned long long pacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, ptasks = 0, pt = 0;
+#define SBR_PROF_MARK(i)                                          \
+  if (PROF) {                                                     \
+    const unsigned long long now_ = __builtin_amdgcn_s_memtime(); \
+    pacc[i] += now_ - pt;                                         \
+    pt = now_;                                                    \
+  }
   const unsigned midx = (lane < 16) ? (1u + 16u * (unsigned)wq + (unsigned)lane) : 0u;
   for (int64_t s = blockIdx.x; s + 2 < n; s += gridDim.x) {
     const int K = sbr_tasks_of(s, n);
@@ -1227,6 +1272,10 @@ __global__ __launch_bounds__(256) void sbr_chase_mb(SbrChaseMbArgs a) {
       const int64_t rk = s + 1 + (int64_t)k * SB;
       const int L = (int)((n - rk < SB) ? n - rk : SB);
       const unsigned colB0 = (unsigned)(rk - SB), colD0 = (unsigned)rk;
+      if (PROF) {
+        pt = __builtin_amdgcn_s_memtime();
+        ++ptasks;
+      }
       // ---- the last row of the blocks: the message of the predecessor's task k+1 (exists exactly when L = SB there)
       if (has_prev && k + 1 < Kprev) {
         const unsigned mo = act ? ((mb_in + (unsigned)(k + 1)) * MBW + midx) * 8u : OOR;
@@ -1253,6 +1302,7 @@ __global__ __launch_bounds__(256) void sbr_chase_mb(SbrChaseMbArgs a) {
           ycol = b0;
         }
       }
+      SBR_PROF_MARK(0)  // message poll + patch
       // ---- LDS images (column-major: X[i][j] at j * 65 + i); D gets both triangles
 #pragma unroll
       for (int q = 0; q < 16; ++q) {
@@ -1266,23 +1316,24 @@ __global__ __launch_bounds__(256) void sbr_chase_mb(SbrChaseMbArgs a) {
       // ---- w = B v_prev (partial sums over this wave's columns)
       float pw = 0.f;
 #pragma unroll
-      for (int q = 0; q < 16; ++q) pw += rb[q] * sbr_rl(vp, 16 * wq + q);
+      for (int q = 0; q < 16; ++q) pw = fmaf(rb[q], sbr_rl(vp, 16 * wq + q), pw);
       part[wq * SB + lane] = pw;
       __syncthreads();
+      SBR_PROF_MARK(1)  // LDS images, w partials, barrier 1
       // the predecessor's counter for the prefetch at the end of this task: a first look now (back before it is needed), a second
       // one after the next barrier (younger, but the wave may have to wait for it)
       const bool more = k + 1 < K;
       const int need2 = (k + 2 < Kprev) ? k + 2 : Kprev;
       const unsigned fl_a = __hip_atomic_load(flagp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       const float w = (part[lane] + part[SB + lane]) + (part[2 * SB + lane] + part[3 * SB + lane]);
-      const float y = (k > 0) ? Bt[lane] - tp * w * sbr_rl(vp, 0) : ycol;
+      const float y = (k > 0) ? fmaf(-(tp * w), sbr_rl(vp, 0), Bt[lane]) : ycol;
       // ---- reflector from y (every wave, identical arithmetic)
       const float xi = (lane >= 1 && lane < L) ? y : 0.f;
       const double sg = sbr_wave_sum((double)xi * (double)xi);
       const float alpha = sbr_rl(y, 0);
       float tau = 0.f, beta = alpha, scale = 0.f;
       if (sg > 0.0) {
-        const double nrm = sqrt((double)alpha * (double)alpha + sg);
+        const double nrm = sqrt(fma((double)alpha, (double)alpha, sg));
         beta = (float)((alpha >= 0.f) ? -nrm : nrm);
         tau = (beta - alpha) / beta;
         scale = 1.f / (alpha - beta);
@@ -1293,7 +1344,7 @@ __global__ __launch_bounds__(256) void sbr_chase_mb(SbrChaseMbArgs a) {
       float pz = 0.f;
       if (k > 0) {
 #pragma unroll
-        for (int q = 0; q < 16; ++q) pz += Bt[lane * 65 + 16 * wq + q] * sbr_rl(v, 16 * wq + q);
+        for (int q = 0; q < 16; ++q) pz = fmaf(Bt[lane * 65 + 16 * wq + q], sbr_rl(v, 16 * wq + q), pz);
       }
       part2[wq * SB + lane] = pz;
       const float vw = sbr_wave_sum(v * w);
@@ -1302,38 +1353,41 @@ __global__ __launch_bounds__(256) void sbr_chase_mb(SbrChaseMbArgs a) {
 #pragma unroll
       for (int q = 0; q < 16; ++q) {
         dd[q] = Dt[(16 * wq + q) * 65 + lane];
-        pdv += dd[q] * sbr_rl(v, 16 * wq + q);
+        pdv = fmaf(dd[q], sbr_rl(v, 16 * wq + q), pdv);
       }
       partD[wq * SB + lane] = pdv;
       __syncthreads();
-      const float z = ((part2[lane] + part2[SB + lane]) + (part2[2 * SB + lane] + part2[3 * SB + lane])) - tp * vw * vp;
+      SBR_PROF_MARK(2)  // reflector, z / D v partials, barrier 2
+      const float z = fmaf(-(tp * vw), vp, (part2[lane] + part2[SB + lane]) + (part2[2 * SB + lane] + part2[3 * SB + lane]));
       float w2 = tau * ((partD[lane] + partD[SB + lane]) + (partD[2 * SB + lane] + partD[3 * SB + lane]));
       const float a2 = -0.5f * tau * sbr_wave_sum(v * w2);
-      w2 += a2 * v;
+      w2 = fmaf(a2, v, w2);
       // ---- B <- H (B H_prev), D <- H D H in registers
       float bnv[16], dnv[16];
 #pragma unroll
       for (int q = 0; q < 16; ++q) {
         const int j = 16 * wq + q;
-        float bn = rb[q] - tp * w * sbr_rl(vp, j) - tau * v * sbr_rl(z, j);
+        float bn = fmaf(-(tau * v), sbr_rl(z, j), fmaf(-(tp * w), sbr_rl(vp, j), rb[q]));
         if (j == 0) bn = (lane == 0) ? beta : 0.f;
         bnv[q] = bn;
-        dnv[q] = dd[q] - v * sbr_rl(w2, j) - w2 * sbr_rl(v, j);
+        dnv[q] = fmaf(-w2, sbr_rl(v, j), fmaf(-v, sbr_rl(w2, j), dd[q]));
       }
       // ---- (1) row 0 to the successor, from lane 0 of every wave
       const bool send = k > 0 && has_next;
       const int lo = send ? 1 : 0;
+      // Wave 0 alone: its lane j forms B'[0][j] from the LDS image, w_0 and its own entries of v_prev and z -- the same two fused
+      // multiply-adds on the same operands as lane 0 of the wave that owns column j (v_0 = 1) -- so one store carries the row.
       const unsigned mrow = (mb_out + (unsigned)k) * MBW;
-#pragma unroll
-      for (int q = 0; q < 16; ++q) {
-        const u32x2 pm = {__builtin_bit_cast(unsigned, bnv[q]), tag_out};
-        __builtin_amdgcn_raw_buffer_store_b64(pm, rm, (send && lane == 0) ? (mrow + (unsigned)(16 * wq + q)) * 8u : OOR, 0, 16);
-      }
-      {
-        const u32x2 pm = {__builtin_bit_cast(unsigned, dnv[0]), tag_out};
-        __builtin_amdgcn_raw_buffer_store_b64(pm, rm, (send && wq == 0 && lane == 0) ? (mrow + 64u) * 8u : OOR, 0, 16);
+      if (wq == 0) {
+        float b0j = fmaf(-(tau * 1.f), z, fmaf(-(tp * sbr_rl(w, 0)), vp, Bt[lane * 65]));
+        if (lane == 0) b0j = beta;
+        const u32x2 pm = {__builtin_bit_cast(unsigned, b0j), tag_out};
+        __builtin_amdgcn_raw_buffer_store_b64(pm, rm, send ? (mrow + (unsigned)lane) * 8u : OOR, 0, 16);
+        const u32x2 pm2 = {__builtin_bit_cast(unsigned, dnv[0]), tag_out};
+        __builtin_amdgcn_raw_buffer_store_b64(pm2, rm, (send && lane == 0) ? (mrow + 64u) * 8u : OOR, 0, 16);
       }
       // ---- (2) prefetch of the next task's blocks (rows 0..62 valid once the predecessor's task k+1 has drained; row 63: message)
+      SBR_PROF_MARK(3)  // update arithmetic + message stores
       __builtin_amdgcn_sched_barrier(0);  // keep the wait for the counter loads behind the message
       {  // both looks are old enough to be back: no wait in the common case
         int xa, xb;  // volatile asm: the compiler's own readfirstlane floats up to the loads and waits for them there
@@ -1350,27 +1404,26 @@ __global__ __launch_bounds__(256) void sbr_chase_mb(SbrChaseMbArgs a) {
         const int64_t rk1 = rk + SB;
         const int L1 = (int)((n - rk1 < SB) ? n - rk1 : SB);
         const unsigned cB1 = (unsigned)rk, cD1 = (unsigned)rk1;
+        const unsigned lb = (lane < L1) ? ((cB1 + w16) * LDB2 + SB + lane - w16) * 4u : OORB;
+        const unsigned ld = (lane < L1) ? ((cD1 + w16) * LDB2 + lane - w16) * 4u : OORB;  // above the diagonal: not used
 #pragma unroll
         for (int q = 0; q < 16; ++q) {
-          const int j = 16 * wq + q;
-          const unsigned ob = (lane < L1) ? ((cB1 + j) * LDB2 + SB + lane - j) * 4u : OOR;
-          rb[q] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, ob, 0, 16));
-          const unsigned od = (lane >= j && lane < L1) ? ((cD1 + j) * LDB2 + lane - j) * 4u : OOR;
-          rd[q] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, od, 0, 16));
+          rb[q] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, lb, q * QS, 16));
+          rd[q] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, ld, q * QS, 16));
         }
         // a first look at the next task's message
         const bool msg_next = has_prev && k + 2 < Kprev;
         prn = __builtin_amdgcn_raw_buffer_load_b64(rm, (msg_next && act) ? ((mb_in + (unsigned)(k + 2)) * MBW + midx) * 8u : OOR, 0, 16);
       }
+      SBR_PROF_MARK(4)  // counter check + prefetch issue
       // ---- (3) the rest of the blocks, write-through
       const bool kb = k > 0;
+      const unsigned sb_ = (kb && lane >= lo && lane < L) ? ((colB0 + w16) * LDB2 + SB + lane - w16) * 4u : OORB;
+      const unsigned sd_ = (lane >= lo && lane < L) ? ((colD0 + w16) * LDB2 + lane - w16) * 4u : OORB;
 #pragma unroll
       for (int q = 0; q < 16; ++q) {
-        const int j = 16 * wq + q;
-        const unsigned ob = (kb && lane >= lo && lane < L) ? ((colB0 + j) * LDB2 + SB + lane - j) * 4u : OOR;
-        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, bnv[q]), rs, ob, 0, 16);
-        const unsigned od = (lane >= j && lane >= lo && lane < L) ? ((colD0 + j) * LDB2 + lane - j) * 4u : OOR;
-        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, dnv[q]), rs, od, 0, 16);
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, bnv[q]), rs, sb_, q * QS, 16);
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, dnv[q]), rs, (dl >= q) ? sd_ : OORB, q * QS, 16);
       }
       if (wq == 0) {
         if (k == 0) {
@@ -1382,11 +1435,20 @@ __global__ __launch_bounds__(256) void sbr_chase_mb(SbrChaseMbArgs a) {
       }
       vp = v;
       tp = tau;
+      SBR_PROF_MARK(5)  // bulk stores issued
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // write-through stores have left (and the prefetch has landed)
+      SBR_PROF_MARK(6)  // drain + prefetch landed
       __syncthreads();
       if (tid == 0) __hip_atomic_store(a.done + s, (unsigned)(k + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      SBR_PROF_MARK(7)  // barrier 3 + counter store
     }
   }
+  if (PROF && tid == 0) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) atomicAdd(a.prof + i, pacc[i]);
+    atomicAdd(a.prof + 8, ptasks);
+  }
+#undef SBR_PROF_MARK
 }
 
 __global__ void sbr_band_diag(const float* __restrict__ Bd, int64_t n, double* __restrict__ d, double* __restrict__ e) {
@@ -1432,8 +1494,36 @@ int sb2st_f32(Ctx* ctx, const float* A, int64_t n, int64_t lda, double* d_dev, d
     const int R = G + 1, kmax = (int)(n / SB) + 2;  // slot of sweep s is free again once sweep s+1 has ended: before sweep s+G+1 starts
     SCL_WS(ctx, MB, unsigned long long, "sbr.MB", (int64_t)R * kmax * MBW);
     SCL_HIP(ctx, hipMemsetAsync(MB, 0, sizeof(unsigned long long) * (size_t)R * kmax * MBW, st));  // tag 0 = no sweep
-    SbrChaseMbArgs cm{Bd, n, V2, ldv2, TAU2, ldt, done, MB, R, kmax};
-    hipLaunchKernelGGL(sbr_chase_mb, dim3(G), dim3(256), 0, st, cm);
+    SbrChaseMbArgs cm{Bd, n, V2, ldv2, TAU2, ldt, done, MB, R, kmax, nullptr};
+    const char* ep = getenv("SCLENS_HIP_CHASE_PROF");
+    if (ep && atoi(ep) > 0) {
+      SCL_WS(ctx, prof, unsigned long long, "sbr.prof", 16);
+      SCL_HIP(ctx, hipMemsetAsync(prof, 0, sizeof(unsigned long long) * 16, st));
+      cm.prof = prof;
+      hipEvent_t e0, e1;
+      SCL_HIP(ctx, hipEventCreate(&e0));
+      SCL_HIP(ctx, hipEventCreate(&e1));
+      SCL_HIP(ctx, hipEventRecord(e0, st));
+      hipLaunchKernelGGL(sbr_chase_mb<true>, dim3(G), dim3(256), 0, st, cm);
+      SCL_HIP(ctx, hipEventRecord(e1, st));
+      unsigned long long h[9];
+      SCL_HIP(ctx, hipMemcpyAsync(h, prof, sizeof(h), hipMemcpyDeviceToHost, st));
+      SCL_HIP(ctx, hipStreamSynchronize(st));
+      float ms = 0.f;
+      hipEventElapsedTime(&ms, e0, e1);
+      hipEventDestroy(e0);
+      hipEventDestroy(e1);
+      static const char* nm[8] = {"message poll + patch", "LDS images + w + barrier 1", "reflector + z, Dv + barrier 2", "update + message send",
+                                  "counter check + prefetch issue", "bulk stores issue", "drain + prefetch wait", "barrier 3 + counter"};
+      unsigned long long tot = 0;
+      for (int i = 0; i < 8; ++i) tot += h[i];
+      fprintf(stderr, "[sbr_chase_mb] n = %lld, G = %d, %.2f ms, %llu tasks, %.0f clocks per task inside a workgroup\n", (long long)n, G, ms,
+              h[8], (double)tot / (double)h[8]);
+      for (int i = 0; i < 8; ++i)
+        fprintf(stderr, "   %-34s %8.1f clocks per task (%4.1f %%)\n", nm[i], (double)h[i] / (double)h[8], 100.0 * h[i] / tot);
+    } else {
+      hipLaunchKernelGGL(sbr_chase_mb<false>, dim3(G), dim3(256), 0, st, cm);
+    }
   } else {
     hipLaunchKernelGGL(sbr_chase, dim3(G), dim3(256), 0, st, ca);
   }

@@ -1,0 +1,16 @@
+#!/bin/bash
+cd /root/repo
+export TMPDIR=/tmp
+O=gpurun_out/r3r
+mkdir -p $O
+ulimit -c 0
+timeout 900 python -m pytest tests/test_gpu_sbr.py -m gpu -x -q > $O/pytest_sbr.log 2>&1; echo "sbr rc=$?" >> $O/summary.txt
+tail -n 5 $O/pytest_sbr.log
+for g in 0 64; do
+  SCLENS_HIP_CHASE_WGS=$([ $g = 0 ] && echo 100000 || echo $g) SCLENS_HIP_CHASE_PROF=1 LOW_HALF=1 TWO_STAGE=1 timeout 600 python scripts/perf_eig.py 30016 2048 15008 > $O/prof_g$g.log 2>&1
+  grep -A9 "sbr_chase_mb" $O/prof_g$g.log | tail -n 10; grep "rep=1" $O/prof_g$g.log
+done
+for mb in 0 1; do
+  SCLENS_HIP_CHASE_MB=$mb LOW_HALF=1 TWO_STAGE=1 timeout 600 python scripts/perf_eig.py 30016 2048 15008 2>&1 | grep "rep=1" > $O/eig_mb$mb.log; cat $O/eig_mb$mb.log
+done
+cat $O/summary.txt
