@@ -546,11 +546,12 @@ __global__ __launch_bounds__(256) void sbr_top_block(float* __restrict__ Pt, int
 
 // out[r][j] = sum_i in[r][i] F[i][j] (f32 MFMA), in = the sum of `nslab` row-major slabs (fixed order).
 //   MODE 2: Yr = W T                      (in = split-K slabs of W)
-//   MODE 3: Z = Yr - Vr Sh  and the row-major operands of the rank-128 update: VW[r] = [V | Z], WV[r] = -[Z | V]
+//   MODE 3: Z = Yr - Vr Sh  and the row-major operands of the rank-128 update: VW[r] = [V | Z], WV[r] = -[Z | V] (row pitch ldo)
 template <int MODE>
 __global__ __launch_bounds__(256) void sbr_rmul_f32(const float* __restrict__ in, int nslab, int64_t slab, const float* __restrict__ F32,
                                                     const double* __restrict__ F64, int64_t len, float* __restrict__ out,
-                                                    const float* __restrict__ Yr, float* __restrict__ VW, float* __restrict__ WV) {
+                                                    const float* __restrict__ Yr, float* __restrict__ VW, float* __restrict__ WV,
+                                                    int64_t ldo) {
   const int lane = threadIdx.x & 63, l15 = lane & 15, kg = lane >> 4;
   const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   const int64_t r0 = wave * SBR_RT;
@@ -597,13 +598,22 @@ __global__ __launch_bounds__(256) void sbr_rmul_f32(const float* __restrict__ in
       } else {
         const float z = Yr[rr * SB + j] - acc[jt][g];
         const float v = in[rr * SB + j];
-        VW[rr * (2 * SB) + j] = v;
-        VW[rr * (2 * SB) + SB + j] = z;
-        WV[rr * (2 * SB) + j] = -z;  // negated: the update is then C += [V | Z] [-Z | -V]' with the accumulators started from C
-        WV[rr * (2 * SB) + SB + j] = -v;
+        VW[rr * ldo + j] = v;
+        VW[rr * ldo + SB + j] = z;
+        WV[rr * ldo + j] = -z;  // negated: the update is then C += [V | Z] [-Z | -V]' with the accumulators started from C
+        WV[rr * ldo + SB + j] = -v;
       }
     }
   }
+}
+
+// out[idx] = sum_s in[s][idx] in a fixed order (split-K slabs of a small product), idx < count
+__global__ __launch_bounds__(256) void sbr_sum_slabs(const float* __restrict__ in, int nslab, int64_t slab, int count, float* __restrict__ out) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= count) return;
+  float acc = in[i];
+  for (int q = 1; q < nslab; ++q) acc += in[(int64_t)q * slab + i];
+  out[i] = acc;
 }
 
 // ---- host driver ------------------------------------------------------------------------------------------------------
@@ -623,11 +633,15 @@ int sy2sb_f32(Ctx* ctx, float* A, int64_t n, int64_t lda, float* Tall, int* brea
   SCL_WS(ctx, psum, double, "sbr.psum", SB * SB);
   SCL_WS(ctx, Mat, double, "sbr.M", 2 * SB * SB);   // M | Sh
   SCL_WS(ctx, V1, float, "sbr.V1", 2 * SB * SB);    // V1 | Rh
-  SCL_WS(ctx, Wp, float, "sbr.Wp", (int64_t)S * SB * ldw);
+  SCL_WS(ctx, Wp, float, "sbr.Wp", (int64_t)(S + 1) * SB * ldw);  // + one slab: the pending update's share of W
   SCL_WS(ctx, Vr, float, "sbr.Vr", SB * ldw);
   SCL_WS(ctx, Yr, float, "sbr.Yr", SB * ldw);
-  SCL_WS(ctx, VW, float, "sbr.VW", n * 2 * SB);
-  SCL_WS(ctx, WV, float, "sbr.WV", n * 2 * SB);
+  // operands of the trailing update, one row per ABSOLUTE matrix row, two slots of 2 SB columns: [V Z]_even | [V Z]_odd
+  constexpr int64_t LDU = 4 * SB;
+  constexpr int GSL = 64;  // K-slices of the small product G = WV' V
+  SCL_WS(ctx, VW, float, "sbr.VW2", n * LDU);
+  SCL_WS(ctx, WV, float, "sbr.WV2", n * LDU);
+  SCL_WS(ctx, Gp, float, "sbr.Gp", (int64_t)(GSL + 1) * SB * 2 * SB);
   SCL_WS(ctx, flag, int, "sbr.flag", 4);
   hipStream_t st = ctx->stream;
   SCL_HIP(ctx, hipMemsetAsync(flag, 0, sizeof(int) * 4, st));
@@ -643,6 +657,21 @@ int sy2sb_f32(Ctx* ctx, float* A, int64_t n, int64_t lda, float* Tall, int* brea
   }
   hipStream_t st2 = ctx->aux_stream;
   const bool lookahead = getenv("SCLENS_HIP_NO_LOOKAHEAD") == nullptr;
+  // Delayed update (round 3). Per 256 x 256 tile a rank-128 update costs 20 us of C traffic + 17 us of prologue against 27 us
+  // of MFMA work (profiles/r03_update_gemm_decomposition.log), so two panels' updates applied as ONE rank-256 update save a third
+  // of the update time. An EVEN panel p therefore updates only the columns panel p + 1 is factored from (the look-ahead strip)
+  // and leaves the rest of the trailing matrix stale; the ODD panel p + 1 takes the missing share of its W = A22 V from the
+  // pending operands, W += [V Z]_p ([-Z -V]_p' V_{p+1}) (two small products, an extra slab of the split-K sum), and applies
+  // both panels' operands at once (K = 256). The price: nothing runs beside the factorisation of panel p + 1 on the second
+  // stream (~0.4 ms per pair at full size), which is why the net gain is 14 of the 76 ms the update kernels save
+  // (profiles/r03_sy2sb_delayed_update.log; a variant that kept ~1000 tiles of the even panel's update immediate to cover the
+  // factorisation was slower than this one: its K = 128 launches and the misaligned 192-column remainder cost more).
+  const bool delay_ok = lookahead && getenv("SCLENS_HIP_SY2SB_NO_DELAY") == nullptr;
+  // pair = 2 max(U, F) before, F + max(1.32 U, F) + c now (U: rank-128 update, F ~ 0.39 ms: factorisation, c ~ 0.09 ms: the two
+  // small products): pays from U ~ 0.7 ms, i.e. from a trailing matrix of order ~19 000 (SCLENS_HIP_SY2SB_DELAY_MIN)
+  int64_t delay_min = 18432;
+  if (const char* ev = getenv("SCLENS_HIP_SY2SB_DELAY_MIN")) delay_min = std::max<int64_t>(4 * SB + 1, atoll(ev));
+  bool pending = false;  // the previous panel's bulk update is outstanding (its operands sit in slot 0)
   auto factor_panel = [&](int64_t p, hipStream_t s_) -> int {
     const int64_t c0 = p * SB, r0 = c0 + SB, np = n - r0;
     float* Pt = A + c0 * lda + r0;  // transposed panel: Pt[j][i] = A[c0 + j][r0 + i] = P[i][j] (symmetric storage)
@@ -685,22 +714,61 @@ int sy2sb_f32(Ctx* ctx, float* A, int64_t n, int64_t lda, float* Tall, int* brea
       g.prefer_big = 1;
       SCL_TRY(gemm_f32(ctx, g));
     }
-    // Y = W T; Sh = 1/2 T' (V'Y); Z = Y - V Sh and the row-major operands [V | Z], [Z | V] of the rank-128 update
-    hipLaunchKernelGGL((sbr_rmul_f32<2>), dim3(rtiles), dim3(256), 0, st, Wp, Sw, (int64_t)SB * ldw, Tp, (const double*)nullptr, np, Yr,
-                       (const float*)nullptr, (float*)nullptr, (float*)nullptr);
+    int nsl_w = Sw;
+    if (pending) {
+      // G'[b][a] = sum_r V_{p+1}[r][b] WV_p[r][a] (64 x 128, the contraction over the n' rows split into slices), then the extra
+      // slab of W: VW_p (n' x 128) G (128 x 64)
+      const float* WVp = WV + r0 * LDU;  // slot 0, rows from this panel's r0 on
+      const float* VWp = VW + r0 * LDU;
+      int Sg = (int)std::min<int64_t>(GSL, std::max<int64_t>(1, np / 256));
+      const int64_t gch = round_up((np + Sg - 1) / Sg, 16);
+      Sg = (int)((np + gch - 1) / gch);
+      float* Gs = Gp + (int64_t)GSL * SB * 2 * SB;
+      {
+        GemmArgs g{};
+        g.P = Pt; g.Q = WVp; g.C = Gp;
+        g.M = SB; g.N = 2 * SB; g.K = np;
+        g.ldp = lda; g.ldq = LDU; g.ldc = 2 * SB;
+        g.alpha = 1.f; g.beta = 0.f; g.q_kcontig = 0; g.lower = 0; g.colabsmax = nullptr;
+        g.splits = Sg; g.k_chunk = gch; g.c_split_off = (int64_t)SB * 2 * SB;
+        SCL_TRY(gemm_f32(ctx, g));
+      }
+      hipLaunchKernelGGL(sbr_sum_slabs, dim3(SB * 2 * SB / 256), dim3(256), 0, st, Gp, Sg, (int64_t)SB * 2 * SB, SB * 2 * SB, Gs);
+      {
+        GemmArgs g{};
+        g.P = VWp; g.Q = Gs; g.C = Wp + (int64_t)Sw * SB * ldw;
+        g.M = np; g.N = SB; g.K = 2 * SB;
+        g.ldp = LDU; g.ldq = 2 * SB; g.ldc = SB;
+        g.alpha = 1.f; g.beta = 0.f; g.q_kcontig = 1; g.lower = 0; g.colabsmax = nullptr;
+        g.prefer_big = 1;
+        SCL_TRY(gemm_f32(ctx, g));
+      }
+      nsl_w = Sw + 1;
+    }
+    // Y = W T; Sh = 1/2 T' (V'Y); Z = Y - V Sh and the row-major operands [V | Z], [Z | V] of the update (slot 1 when the
+    // previous panel's operands are still pending in slot 0)
+    const int slot = pending ? 1 : 0;
+    float* VWs = VW + r0 * LDU + slot * 2 * SB;
+    float* WVs = WV + r0 * LDU + slot * 2 * SB;
+    hipLaunchKernelGGL((sbr_rmul_f32<2>), dim3(rtiles), dim3(256), 0, st, Wp, nsl_w, (int64_t)SB * ldw, Tp, (const double*)nullptr, np, Yr,
+                       (const float*)nullptr, (float*)nullptr, (float*)nullptr, (int64_t)0);
     hipLaunchKernelGGL((sbr_gram64<false>), dim3(nparts), dim3(256), SBR_GRAM_LDS, st, Vr, (int64_t)SB, Yr, np, part);
     hipLaunchKernelGGL(sbr_sum_parts, dim3(SB * SB / 256), dim3(256), 0, st, part, nparts, psum);
     hipLaunchKernelGGL(sbr_small_s, dim3(1), dim3(256), 0, st, psum, Tp, Mat + SB * SB);
     hipLaunchKernelGGL((sbr_rmul_f32<3>), dim3(rtiles), dim3(256), 0, st, Vr, 1, (int64_t)0, (const float*)nullptr, Mat + SB * SB, np,
-                       (float*)nullptr, Yr, VW, WV);
+                       (float*)nullptr, Yr, VWs, WVs, LDU);
+    // the update's operands: this panel's slot alone, or both slots (K = 4 SB) when the previous panel's update is pending
+    const float* Up = VW + r0 * LDU;
+    const float* Uq = WV + r0 * LDU;
+    const int64_t Ku = pending ? 4 * SB : 2 * SB;
     auto update = [&](int64_t off, int64_t rows, int64_t cols, int lower) -> int {  // A22[off:off+rows, (lower ? off : 0) : +cols]
       GemmArgs g{};
-      g.P = VW + off * 2 * SB; g.Q = WV + (lower ? off : 0) * 2 * SB; g.C = A22 + off * lda + (lower ? off : 0);
-      g.M = rows; g.N = cols; g.K = 2 * SB;
-      g.ldp = 2 * SB; g.ldq = 2 * SB; g.ldc = lda;
+      g.P = Up + off * LDU; g.Q = Uq + (lower ? off : 0) * LDU; g.C = A22 + off * lda + (lower ? off : 0);
+      g.M = rows; g.N = cols; g.K = Ku;
+      g.ldp = LDU; g.ldq = LDU; g.ldc = lda;
       g.alpha = 1.f; g.beta = 1.f; g.q_kcontig = 1; g.lower = lower; g.colabsmax = nullptr;  // WV is stored negated
       g.acc_init = 1;
-      g.prefer_big = 1;  // K = 128: bound by the traffic of C, whose mirrored half the large-tile kernel stores 16 bytes at a time
+      g.prefer_big = 1;  // short K: bound by the traffic of C, whose mirrored half the large-tile kernel stores 16 bytes at a time
       return gemm_f32(ctx, g);
     };
     if (p + 1 < npan && lookahead && np > 2 * SB) {
@@ -712,12 +780,16 @@ int sy2sb_f32(Ctx* ctx, float* A, int64_t n, int64_t lda, float* Tall, int* brea
       SCL_HIP(ctx, hipStreamWaitEvent(st2, ctx->aux_ev[0], 0));
       SCL_TRY(factor_panel(p + 1, st2));
       SCL_HIP(ctx, hipEventRecord(ctx->aux_ev[1], st2));
-      // (ii) the rest of the trailing matrix, concurrently with the factorisation of panel p + 1
-      SCL_TRY(update(SB, np - SB, np - SB, 1));
+      // (ii) the rest of the trailing matrix, concurrently with the factorisation of panel p + 1 -- or left to the next panel,
+      //      while the trailing matrix is large enough for the saved pass over it to outweigh the exposed factorisation
+      const bool delay = delay_ok && !pending && p + 2 < npan && np >= delay_min;
+      if (!delay) SCL_TRY(update(SB, np - SB, np - SB, 1));
       SCL_HIP(ctx, hipStreamWaitEvent(st, ctx->aux_ev[1], 0));
+      pending = delay;
     } else {
       SCL_TRY(update(0, np, np, 1));
       if (p + 1 < npan) SCL_TRY(factor_panel(p + 1, st));
+      pending = false;
     }
   }
   SCL_HIP(ctx, hipGetLastError());

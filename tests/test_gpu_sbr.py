@@ -41,8 +41,17 @@ def _band_of(out):
     return low + np.tril(low, -1).T
 
 
+@pytest.fixture(params=["default", "delayed"])
+def delayed_update(request, monkeypatch):
+    """sy2sb applies the trailing updates of two panels as one rank-256 update while the trailing matrix is large (from order
+    18 432 by default); "delayed" turns that on from order 321, so that the small cases here go through it."""
+    if request.param == "delayed":
+        monkeypatch.setenv("SCLENS_HIP_SY2SB_DELAY_MIN", "321")
+    return request.param
+
+
 @pytest.mark.parametrize("n", [128, 320, 1024, 2048])
-def test_sy2sb_band_has_the_same_spectrum(ctx, n):
+def test_sy2sb_band_has_the_same_spectrum(ctx, n, delayed_update):
     A = _sym_psd(n, n)
     out, T, bd = _run_sy2sb(ctx, A)
     assert bd == 0
@@ -52,8 +61,8 @@ def test_sy2sb_band_has_the_same_spectrum(ctx, n):
     assert np.abs(got - ref).max() < 4e-7 * np.sqrt(n) * ref.max() + 1e-7
 
 
-@pytest.mark.parametrize("n", [128, 256, 448])
-def test_sy2sb_reflectors_reproduce_the_band(ctx, n):
+@pytest.mark.parametrize("n", [128, 256, 448, 832])
+def test_sy2sb_reflectors_reproduce_the_band(ctx, n, delayed_update):
     """Q1 = H_0 H_1 ... with H_p = I - V_p T_p V_p' (V_p from the upper part of the output) satisfies Q1' A Q1 = band."""
     A = _sym_psd(n, 7 * n)
     out, T, bd = _run_sy2sb(ctx, A)
@@ -166,7 +175,7 @@ def test_first_back_transformation(ctx, n, m):
 
 
 @pytest.mark.parametrize("n,m", [(128, 128), (320, 64), (1024, 50)])
-def test_two_stage_eigenvectors(ctx, n, m):
+def test_two_stage_eigenvectors(ctx, n, m, delayed_update):
     """Eigenvectors of the tridiagonal matrix (host, float64) through both back-transformations are eigenvectors of A."""
     import scipy.linalg as sla
 
