@@ -1076,10 +1076,18 @@ def sclens(inp_df, device_="gpu", th=60, p_step=0.001, n_perturb=20, centering="
             Lr = ses.null_spectrum_pattern(null_future.result())
             L, rec_vals = ses.data_spectrum(not median)
             r_vr2 = None
+        elif W == 2:
+            # Two streams: data | null first. The binarised matrix (the longest of the three: all of its eigenvectors are wanted)
+            # runs afterwards beside signal_vectors, whose second back-transformation of a few vectors is one latency-bound wave
+            # (0.5 s at n = 3 * 10^4) that costs nothing next to a decomposition and 0.5 s on its own
+            # (profiles/r03_first_phase_cfg4.log).
+            w_null = w_bin = workers[1]
+            (L, rec_vals), Lr = run_all([(0, lambda: ses.data_spectrum(not median)), (1, lambda: w_null.null_spectrum_pattern(null_future.result()))])
+            r_vr2 = -1  # decomposed below, next to the signal vectors
         else:  # the main session keeps the data matrix's reflectors for signal_vectors; workers take the other two
-            w_null, w_bin = workers[1], workers[2 if W >= 3 else 1]
+            w_null, w_bin = workers[1], workers[2]
             (L, rec_vals), Lr, (_, r_vr2) = run_all([(0, lambda: ses.data_spectrum(not median)), (1, lambda: w_null.null_spectrum_pattern(null_future.result())),
-                                                     (2 if W >= 3 else 1, w_bin.binary_basis)])
+                                                     (2, w_bin.binary_basis)])
         L_mp, _, b_min = _mp_calculation(L, Lr[:-1])  # Lr[1:end-1] (:537, :576)
         lambda_c = _tw(L, L_mp)[0]
         # guard band: eigenvalues within +-4 sqrt(n) eps32 lambda_max of the cut are replaced by float64 Rayleigh quotients
@@ -1091,7 +1099,10 @@ def sclens(inp_df, device_="gpu", th=60, p_step=0.001, n_perturb=20, centering="
         L, k, nL, guard = cut_with_guard_band(L, lambda_c, guard_band, refine)
         if verbose:
             print(f"(Using hip) number of signal ev: {k}")
-        nV = ses.signal_vectors(k) if (not spread or shard.rank == 0) else None
+        if r_vr2 == -1:
+            nV, (_, r_vr2) = run_all([(0, lambda: ses.signal_vectors(k)), (1, w_bin.binary_basis)])
+        else:
+            nV = ses.signal_vectors(k) if (not spread or shard.rank == 0) else None
         if r_vr2 is None:
             _, r_vr2 = ses.binary_basis()
         if spread:
