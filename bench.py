@@ -89,17 +89,31 @@ def stage_probe(ctx, X, N, M):
     ctx.set_timing(True)
     ctx.reset_timing()
     ses = api.Session(ctx, X)
-    bits_ms, extra = None, {}
+    bits_ms, extra, search_scale = None, {}, None
     try:
         ses.data_spectrum(False)
         if N > M:  # the Gram product of the binarised matrix as the sparsity search forms it (fp16 MFMA for large problems)
             snap = lambda: {s: ctx.timing(s) for s in ("scale", "gram", "sytrd", "sy2sb", "sb2st", "stebz", "stein", "ormtr", "sbr_q2", "sbr_q1")}
             before, gb0 = snap(), ses.get_int("gram_bits_used")
-            ses.binary_basis()
+            _, r_vr2 = ses.binary_basis()
             after = snap()
             extra = {s: (after[s][0] - before[s][0], after[s][1] - before[s][1]) for s in after}  # kept out of the averages below
             if ses.get_int("gram_bits_used") > gb0:
                 bits_ms = extra["gram"][0]
+            # one evaluation of the sparsity search on the union pattern (counts + zero candidates): its normalisation runs on the
+            # pattern's CSR companion copies, which the counts-only patterns of the three first decompositions do not carry
+            pat = api.Pattern.drawn(ctx, X, 12345)
+            try:
+                ses.set_pattern(pat)
+                b2 = snap()
+                ses.search_step_seeded(777, int(round(0.01 * N * M)), int(round(r_vr2 / 2)))
+                a2 = snap()
+                step = {s: (a2[s][0] - b2[s][0], a2[s][1] - b2[s][1]) for s in a2}
+                search_scale = step["scale"]
+                extra = {s: (extra[s][0] + step[s][0], extra[s][1] + step[s][1]) for s in extra}
+            finally:
+                ses.close()
+                pat.close()
     finally:
         ses.close()
     if os.environ.get("SCLENS_BENCH_PROBE_VECTORS", "1") != "0":
@@ -139,6 +153,13 @@ def stage_probe(ctx, X, N, M):
 
     nnz = int(X.nnz)
     add("normalise", "scale", 8.0 * nnz + 4.0 * N * M, "GB/s", HBM_PEAK_GBS, "hbm", "8 nnz read + 4 N M written (SURVEY 8d B_norm)")
+    if search_scale and search_scale[1] > 0:
+        per = search_scale[0] / search_scale[1]
+        ach = (8.0 * nnz + 4.0 * N * M) / (per * 1e-3) / 1e9
+        stages["normalise_search_step"] = {"bound": "hbm", "ms": round(per, 3), "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                           "frac": round(ach / HBM_PEAK_GBS, 4),
+                                           "work": "the same bytes for one evaluation of the sparsity search (binarised values + sampled "
+                                                   "candidates on the union pattern, row reductions streamed from the CSR companion copy)"}
     add("gram", "gram", float(n) * (n + 1) * K, "TFLOP/s", MFMA_F32_PEAK_TFS, "mfma", "n (n+1) K flop (computed lower half)")
     if bits_ms:
         work = 2.0 * float(n) * (n + 1) * K  # two fp16 pieces of the cell weights: two MFMA products per gene pair and cell
