@@ -137,6 +137,90 @@ __global__ __launch_bounds__(64) void tri_bisect(const double* __restrict__ d, c
   if (live && q == 0) w[k] = 0.5 * (lo + hi);
 }
 
+// ---- round 3: the same 9-section on the Sturm count, the count taken from the three-term recurrence of the leading principal
+// minors p_i = (d_i - x) p_{i-1} - e_{i-1}^2 p_{i-2} (sign changes of p_{-1} = 1, p_0, p_1, ...) instead of the ratios
+// q_i = p_i / p_{i-1}: no division. The ratio step is a v_rcp_f64, two Newton steps, the recurrence and two clamps -- ~150 issue
+// cycles per step, and the kernel is bound by exactly that (two waves per SIMD, no stalls to hide); the product step is three
+// fp64 operations, three integer ones for the sign change and a zero guard. Range: the matrix is scaled by a power of two to
+// norm < 1 (tri_scale: exact), so |p_i| <= 3 max(|p_{i-1}|, |p_{i-2}|), and both running values are rescaled by a power of two
+// every eight steps (exact). A minor that is exactly zero is replaced by a tiny value of the sign that makes it a sign change,
+// which is what the ratio form's `pivmin` does (a decoupled block after an exact zero would otherwise see only zeros).
+__global__ void tri_scale(const double* __restrict__ d, const double* __restrict__ e2, int64_t n, double* __restrict__ info,
+                          double* __restrict__ ds, double* __restrict__ e2s) {
+  const double bound = fmax(fabs(info[0]), fabs(info[1]));
+  double sc = 1.0;
+  if (bound > 0.0 && bound < 1.0e300) {
+    int ex = 0;
+    (void)frexp(bound, &ex);  // bound = f 2^ex, 1/2 <= f < 1
+    sc = ldexp(1.0, -ex);
+  }
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) ds[i] = d[i] * sc;
+  if (i <= n) e2s[i] = e2[i] * sc * sc;
+  if (i == 0) info[6] = sc;
+}
+
+__global__ __launch_bounds__(64) void tri_bisect_prod(const double* __restrict__ ds, const double* __restrict__ e2s, int64_t n,
+                                                      const double* __restrict__ info, double* __restrict__ w, int64_t k_begin,
+                                                      int64_t k_end, int64_t k_extra) {
+  const int q = threadIdx.x & 7;
+  const bool extra = k_extra >= 0 && blockIdx.x == gridDim.x - 1;
+  const int64_t k = extra ? k_extra + (threadIdx.x >> 3) : k_begin + (int64_t)blockIdx.x * 8 + (threadIdx.x >> 3);
+  const double sc = info[6];
+  double lo = info[0] * sc, hi = info[1] * sc;
+  const double atol = EPS64 * info[4] * sc;
+  const bool live = extra ? (threadIdx.x >> 3) == 0 : k < k_end;
+  if (info[5] != 0.0) {  // non-finite input (block-uniform)
+    if (live && q == 0) w[k] = __longlong_as_double(0x7ff8000000000000LL);
+    return;
+  }
+  const double tiny = 1.0e-290;
+  for (int it = 0; it < 40; ++it) {
+    const bool done = (hi - lo) <= 2.0 * EPS64 * fmax(fabs(lo), fabs(hi)) + atol;
+    if (__all(done || !live)) break;
+    const double step = (hi - lo) / 9.0;
+    const double xq = lo + (double)(q + 1) * step;
+    double p2 = 1.0, p1 = ds[0] - xq;
+    if (p1 == 0.0) p1 = -tiny;
+    int cnt = (p1 < 0.0) ? 1 : 0;
+    auto step1 = [&](double di, double ei) {
+      double pn = fma(di - xq, p1, -(ei * p2));
+      if (pn == 0.0) pn = copysign(tiny, -p1);
+      cnt += (int)(((unsigned)(__double_as_longlong(pn) >> 32) ^ (unsigned)(__double_as_longlong(p1) >> 32)) >> 31);
+      p2 = p1;
+      p1 = pn;
+    };
+    int64_t i = 1;
+    for (; i + 8 <= n; i += 8) {
+      double dd[8], ee[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        dd[u] = ds[i + u];
+        ee[u] = e2s[i - 1 + u];
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) step1(dd[u], ee[u]);
+      int ex = 0;
+      (void)frexp(fmax(fabs(p1), fabs(p2)), &ex);
+      p1 = ldexp(p1, -ex);
+      p2 = ldexp(p2, -ex);
+    }
+    for (; i < n; ++i) step1(ds[i], e2s[i - 1]);
+    int below = (cnt <= k) ? 1 : 0;
+    int m = below;
+    m += __shfl_xor(m, 1);
+    m += __shfl_xor(m, 2);
+    m += __shfl_xor(m, 4);
+    if (!done) {
+      const double nlo = (m == 0) ? lo : lo + (double)m * step;
+      const double nhi = (m == 8) ? hi : lo + (double)(m + 1) * step;
+      lo = nlo;
+      hi = nhi;
+    }
+  }
+  if (live && q == 0) w[k] = 0.5 * (lo + hi) / sc;
+}
+
 __device__ __forceinline__ double hash_uniform(uint64_t a, uint64_t b) {  // deterministic U(-1,1)
   uint64_t z = a * 0x9E3779B97F4A7C15ull + b * 0xBF58476D1CE4E5B9ull + 0x94D049BB133111EBull;
   z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
@@ -353,13 +437,23 @@ int stebz_f64(Ctx* ctx, const double* d_dev, const double* e_dev, int64_t n, dou
   SCL_WS(ctx, e2, double, "tri.e2", n + 1);
   SCL_WS(ctx, info, double, "tri.info", 8);
   hipLaunchKernelGGL(tri_bounds, dim3(1), dim3(1024), 0, ctx->stream, d_dev, e_dev, n, e2, info);
+  const char* ebd = getenv("SCLENS_HIP_BISECT_DIV");  // 1: the ratio form (round 2), for comparison
+  const bool ratio_form = ebd && atoi(ebd) != 0;
+  const double* dd = d_dev;
+  const double* ee = e2;
+  if (!ratio_form) {  // division-free Sturm counts on a copy scaled to norm < 1
+    SCL_WS(ctx, ds, double, "tri.ds", n + 1);
+    SCL_WS(ctx, e2s, double, "tri.e2s", n + 1);
+    hipLaunchKernelGGL(tri_scale, dim3((unsigned)((n + 256) / 256)), dim3(256), 0, ctx->stream, d_dev, e2, n, info, ds, e2s);
+    dd = ds;
+    ee = e2s;
+  }
+  auto kern = ratio_form ? tri_bisect : tri_bisect_prod;
   if (n_low < 0 || n_low >= k_top) {
-    hipLaunchKernelGGL(tri_bisect, dim3((unsigned)((n + 7) / 8)), dim3(64), 0, ctx->stream, d_dev, e2, n, info, w_dev, (int64_t)0, n,
-                       (int64_t)-1);
+    hipLaunchKernelGGL(kern, dim3((unsigned)((n + 7) / 8)), dim3(64), 0, ctx->stream, dd, ee, n, info, w_dev, (int64_t)0, n, (int64_t)-1);
   } else {
     hipLaunchKernelGGL(tri_fill_nan, dim3((unsigned)((n - n_low + 255) / 256)), dim3(256), 0, ctx->stream, w_dev, n_low, n);
-    hipLaunchKernelGGL(tri_bisect, dim3((unsigned)((n_low + 7) / 8 + 1)), dim3(64), 0, ctx->stream, d_dev, e2, n, info, w_dev,
-                       (int64_t)0, n_low, k_top);
+    hipLaunchKernelGGL(kern, dim3((unsigned)((n_low + 7) / 8 + 1)), dim3(64), 0, ctx->stream, dd, ee, n, info, w_dev, (int64_t)0, n_low, k_top);
   }
   SCL_HIP(ctx, hipGetLastError());
   return SCLENS_OK;

@@ -105,6 +105,48 @@ def test_sytrd_stebz_eigenvalues(ctx, n):
         x.free()
 
 
+def _tridiag_cases():
+    rng = np.random.default_rng(4)
+    n = 777
+    cases = {}
+    cases["random"] = (rng.standard_normal(n), rng.standard_normal(n - 1))
+    d = rng.standard_normal(n)
+    e = rng.standard_normal(n - 1)
+    e[[100, 101, 400, 776 - 64]] = 0.0  # decoupled blocks, one of them a 1 x 1 block
+    cases["decoupled"] = (d, e)
+    cases["wilkinson"] = (np.abs(np.arange(n) - n // 2).astype(np.float64), np.ones(n - 1))  # pairs agreeing to 1e-14
+    cases["toeplitz_2_-1"] = (np.full(n, 2.0), np.full(n - 1, -1.0))  # probes that hit eigenvalues of leading blocks
+    cases["graded"] = (10.0 ** np.linspace(6, -6, n), 10.0 ** np.linspace(2.5, -9, n - 1))
+    cases["tiny_offdiagonals"] = (rng.standard_normal(n) * 1e3, rng.standard_normal(n - 1) * 1e-18)
+    cases["large_scale"] = (rng.standard_normal(n) * 1e150, rng.standard_normal(n - 1) * 1e150)
+    cases["all_zero"] = (np.zeros(n), np.zeros(n - 1))
+    cases["padded_like_two_stage"] = (np.concatenate([rng.standard_normal(n - 60) + 5.0, np.zeros(60)]),
+                                      np.concatenate([rng.standard_normal(n - 61), np.zeros(60)]))
+    return cases
+
+
+@pytest.mark.parametrize("name", list(_tridiag_cases()))
+@pytest.mark.parametrize("form", ["product", "ratio"])
+def test_stebz_tridiagonal_cases(ctx, name, form, monkeypatch):
+    """sclens_hip_dev_stebz_f64 on given tridiagonal matrices: the division-free Sturm count (three-term recurrence of the leading
+    minors on a copy scaled by a power of two, rescaled every eight steps, exact zeros replaced) and the ratio form
+    (SCLENS_HIP_BISECT_DIV=1) against LAPACK, to a few ulps of the norm."""
+    d, e = _tridiag_cases()[name]
+    n = len(d)
+    if form == "ratio":
+        monkeypatch.setenv("SCLENS_HIP_BISECT_DIV", "1")
+    dd, de, dw = DevArray(ctx, np.ascontiguousarray(d)), DevArray(ctx, np.concatenate([e, [0.0]])), DevArray(ctx, nbytes=8 * n)
+    ctx.check(ctx.lib.sclens_hip_dev_stebz_f64(ctx.h, dd.p, de.p, n, dw.p))
+    ctx.sync()
+    w = dw.get((n,), np.float64)
+    for x in (dd, de, dw):
+        x.free()
+    ref = sla.eigvalsh_tridiagonal(d, e)
+    nrm = max(np.abs(d).max() + 2 * np.abs(e).max(), 1e-300)
+    assert np.all(np.isfinite(w)) and np.all(np.diff(w) >= -1e-15 * nrm)  # independent bisections: ordered up to their own width
+    assert np.abs(w - ref).max() <= 8e-15 * nrm * np.sqrt(n) + 1e-300, (name, form, np.abs(w - ref).max() / nrm)
+
+
 @pytest.mark.parametrize("n,lo,hi", [(64, 0, 64), (300, 0, 300), (300, 290, 300), (515, 100, 360), (1000, 0, 1000)])
 def test_eigh_vectors(ctx, n, lo, hi):
     A = _sym(n, 1000 + n)
