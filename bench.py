@@ -185,6 +185,17 @@ def stage_probe(ctx, X, N, M):
     return stages
 
 
+# HBM traffic of ONE two-stage eigensolve of order 30 016 with 15 008 vectors (the roofline's launch), from separate
+# `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` passes over scripts/perf_eig.py (profiles/r03_pmc_eig/summary.txt): 0.996e12 B
+# fetched as counted + 0.523e12 B for the gfx950 half-count of 16-byte-per-lane streaming reads (MI355X_MICROARCH.md, HBM) on the two
+# large-tile GEMM kernels, whose corrected fetch then equals their algorithmic read (W = A22 V: 574 vs 563 GB) + 0.935e12 B written.
+# A constant of the round-3 build, not measured in the bench run (a PMC pass serialises every dispatch).
+PMC_EIG_TRAFFIC_R03 = {"bytes": 2.45e12,
+                       "source": "constant of the build: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over one eigensolve of order 30 016 "
+                                 "(profiles/r03_pmc_eig/summary.txt): 1.52e12 B fetched (gfx950 half-count of wide streaming reads corrected "
+                                 "on the large-tile GEMM kernels) + 0.94e12 B written; not measured in this run"}
+
+
 # A full-size CPU data point kept in the repository (profiles/r02_signal_count_cfg4.json, GPU box, 16 usable CPUs): LAPACK dsyevd,
 # VALUES ONLY, of ONE float64 30 000 x 30 000 Gram matrix took 903.1 s, the float64 Gram product (dsyrk) 110.0 s. The reference
 # computes all eigenVECTORS of 3 + S + P such matrices (scLENS.jl:384), which costs more than values only.
@@ -515,8 +526,10 @@ def main():
                 out["roofline"] = {"bound": "mfma", "kernel": "two-stage symmetric eigensolver of one search step (sy2sb + sb2st + stebz + "
                                                              "stein + Q2 + Q1, n/2 eigenvectors): the stage with the most wall time",
                                    "achieved": round(ach, 2), "peak": MFMA_F32_PEAK_TFS, "unit": "TFLOP/s",
-                                   "frac": round(ach / MFMA_F32_PEAK_TFS, 4), "traffic": None,
-                                   "traffic_source": "not measured in this run (PMC passes are separate rocprofv3 runs: profiles/)",
+                                   "frac": round(ach / MFMA_F32_PEAK_TFS, 4),
+                                   "traffic": PMC_EIG_TRAFFIC_R03["bytes"] if n in (30000, 30016) else None,
+                                   "traffic_source": (PMC_EIG_TRAFFIC_R03["source"] if n in (30000, 30016) else
+                                                      "not measured at this order (PMC passes are separate rocprofv3 runs: profiles/)"),
                                    "n": n, "vectors": n // 2, "launch_ms": round(solve_ms, 2), "algorithmic_flop_per_launch": flop,
                                    "stage_ms": {k: stages[k]["ms"] for k in parts if k in stages},
                                    "note": "time-weighted rate of the whole stage; the single best kernel (the Gram launch) is "
