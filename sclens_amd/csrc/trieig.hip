@@ -234,16 +234,14 @@ __device__ __forceinline__ double hash_uniform(uint64_t a, uint64_t b) {  // det
 // The recurrences are sequential in i; the loads of the next STEIN_PF steps are issued together to hide memory latency: the
 // kernel moves ~230 B per (row, vector) in seven passes (100 GB for 15 008 vectors of order 30 016) from only m / 64 waves, so
 // the bytes in flight set its speed (4 steps: 1.4 TB/s, 73 ms).
-#ifndef STEIN_PF
-#define STEIN_PF 16
-#endif
+template <int STEIN_PF>
 __global__ __launch_bounds__(64) void tri_stein(const double* __restrict__ d, const double* __restrict__ e,
                                                 int64_t n, const double* __restrict__ w, int64_t idx0,
                                                 int64_t count, int64_t B, const double* __restrict__ info,
                                                 double* __restrict__ wa, double* __restrict__ wb,
                                                 double* __restrict__ wc, double* __restrict__ wd,
                                                 unsigned char* __restrict__ win, double* __restrict__ wx,
-                                                double* __restrict__ inv_norm, int* __restrict__ fail_count) {
+                                                double* __restrict__ inv_norm, int* __restrict__ fail_count, int good_its) {
   const int64_t t = (int64_t)blockIdx.x * 64 + threadIdx.x;
   if (t >= count) return;
   const int64_t gi = idx0 + t;
@@ -397,7 +395,7 @@ __global__ __launch_bounds__(64) void tri_stein(const double* __restrict__ d, co
     xmax = nrm;
     if (nrm < dtpcrt) continue;
     ++nrmchk;
-    if (nrmchk < 3) continue;
+    if (nrmchk < good_its) continue;
     break;
   }
   inv_norm[t] = 1.0 / sqrt(s2);
@@ -482,10 +480,25 @@ int stein_f64(Ctx* ctx, const double* d_dev, const double* e_dev, int64_t n, con
   SCL_WS(ctx, failc, int, "stein.fail", 4);
   SCL_WS(ctx, invn, double, "stein.invn", B);
   SCL_HIP(ctx, hipMemsetAsync(failc, 0, sizeof(int), ctx->stream));
+  const char* epf = getenv("SCLENS_HIP_STEIN_PF");  // steps of loads in flight: 4 (round 2), 16 (default), 32
+  const int pf = epf ? atoi(epf) : 16;
+  // Iterations with sufficient growth (dstein's criterion |x|max >= sqrt(0.1 / n)) before a vector is accepted. dstein runs 1 + EXTRA
+  // = 3; here 2: the vectors leave this solver as fp32 and go through fp32 back-transformations, and the fp64 residual after the
+  // first such iteration is already at working precision (scripts/stein_its.py: residual and orthogonality of the final vectors
+  // are the same to four digits for 1, 2 and 3 at n = 1 000 .. 8 192, planted near-degenerate pairs included). -20 % of the stage.
+  const char* eit = getenv("SCLENS_HIP_STEIN_ITS");
+  const int good_its = eit ? std::max(1, std::min(5, atoi(eit))) : 2;
   for (int64_t t0 = 0; t0 < m; t0 += B) {
     const int64_t cnt = (m - t0 < B) ? m - t0 : B;
-    hipLaunchKernelGGL(tri_stein, dim3((unsigned)((cnt + 63) / 64)), dim3(64), 0, ctx->stream, d_dev, e_dev, n,
-                       w_dev, lo + t0, cnt, B, info, wa, wb, wc, wd, win, wx, invn, failc);
+    if (pf == 32)
+      hipLaunchKernelGGL(tri_stein<32>, dim3((unsigned)((cnt + 63) / 64)), dim3(64), 0, ctx->stream, d_dev, e_dev, n, w_dev, lo + t0, cnt, B,
+                         info, wa, wb, wc, wd, win, wx, invn, failc, good_its);
+    else if (pf == 4)
+      hipLaunchKernelGGL(tri_stein<4>, dim3((unsigned)((cnt + 63) / 64)), dim3(64), 0, ctx->stream, d_dev, e_dev, n, w_dev, lo + t0, cnt, B,
+                         info, wa, wb, wc, wd, win, wx, invn, failc, good_its);
+    else
+      hipLaunchKernelGGL(tri_stein<16>, dim3((unsigned)((cnt + 63) / 64)), dim3(64), 0, ctx->stream, d_dev, e_dev, n, w_dev, lo + t0, cnt, B,
+                         info, wa, wb, wc, wd, win, wx, invn, failc, good_its);
     hipLaunchKernelGGL(tri_transpose_out, dim3((unsigned)((cnt + 31) / 32), (unsigned)((n + 31) / 32)), dim3(256),
                        0, ctx->stream, wx, invn, n, cnt, B, Zt, ldz, t0);
   }
