@@ -111,6 +111,7 @@ void sclens_hip_destroy(sclens_hip_ctx* h) {
   if (h->c.aux_stream) hipStreamDestroy(h->c.aux_stream);
   for (hipEvent_t e : h->c.aux_ev)
     if (e) hipEventDestroy(e);
+  if (h->c.q2_ev) hipEventDestroy(h->c.q2_ev);
   if (h->c.stream) hipStreamDestroy(h->c.stream);
   delete h;
 }

@@ -19,6 +19,10 @@ struct Ctx {
   // second stream + events for work that overlaps inside one call (look-ahead of the band reduction); created on first use
   hipStream_t aux_stream = nullptr;
   hipEvent_t aux_ev[2] = {nullptr, nullptr};
+  // T factors of the second back-transformation, built on the auxiliary stream right after the bulge chase (sbr.hip): the event
+  // that marks them complete and the order they were built for (-1: none / not valid for the current reflectors)
+  hipEvent_t q2_ev = nullptr;
+  int64_t q2_tg_n = -1;
   std::string err;
   // grow-only named device workspaces (freed at destroy); avoids hipMalloc inside hot loops
   std::map<std::string, std::pair<void*, size_t>> ws;

@@ -616,6 +616,16 @@ __global__ __launch_bounds__(256) void sbr_sum_slabs(const float* __restrict__ i
   out[i] = acc;
 }
 
+static int sbr_ensure_aux(Ctx* ctx) {  // the context's second stream and its events, created on first use
+  if (!ctx->aux_stream) {
+    SCL_HIP(ctx, hipStreamCreateWithFlags(&ctx->aux_stream, hipStreamNonBlocking));
+    SCL_HIP(ctx, hipEventCreateWithFlags(&ctx->aux_ev[0], hipEventDisableTiming));
+    SCL_HIP(ctx, hipEventCreateWithFlags(&ctx->aux_ev[1], hipEventDisableTiming));
+  }
+  if (!ctx->q2_ev) SCL_HIP(ctx, hipEventCreateWithFlags(&ctx->q2_ev, hipEventDisableTiming));
+  return SCLENS_OK;
+}
+
 // ---- host driver ------------------------------------------------------------------------------------------------------
 // A: n x n fp32 row-major, full symmetric storage, n a multiple of SB. On return: lower band (|i - j| <= SB) = the band
 // matrix, upper part = the panel reflectors V_p, Tall[p][SB][SB] = their T factors. *breakdown (host) != 0: a panel was
@@ -650,11 +660,7 @@ int sy2sb_f32(Ctx* ctx, float* A, int64_t n, int64_t lda, float* Tall, int* brea
   // (a strip product, its transposed copy, and the diagonal block), then the panel is factored on a second stream while
   // the main stream applies the rest of the rank-128 update: the latency-bound panel algebra (Gram, SB x SB factorisations,
   // V = P M) leaves the critical path.
-  if (!ctx->aux_stream) {
-    SCL_HIP(ctx, hipStreamCreateWithFlags(&ctx->aux_stream, hipStreamNonBlocking));
-    SCL_HIP(ctx, hipEventCreateWithFlags(&ctx->aux_ev[0], hipEventDisableTiming));
-    SCL_HIP(ctx, hipEventCreateWithFlags(&ctx->aux_ev[1], hipEventDisableTiming));
-  }
+  SCL_TRY(sbr_ensure_aux(ctx));
   hipStream_t st2 = ctx->aux_stream;
   const bool lookahead = getenv("SCLENS_HIP_NO_LOOKAHEAD") == nullptr;
   // Delayed update (round 3). Per 256 x 256 tile a rank-128 update costs 20 us of C traffic + 17 us of prologue against 27 us
@@ -1531,10 +1537,14 @@ __global__ void sbr_band_diag(const float* __restrict__ Bd, int64_t n, double* _
   }
 }
 
+static int sbr_q2_launch_build_t(Ctx* ctx, int64_t n, hipStream_t st);  // below, with the second back-transformation
+
 // A: the output of sy2sb_f32 (lower band valid). d, e (fp64, device) receive the tridiagonal matrix.
 int sb2st_f32(Ctx* ctx, const float* A, int64_t n, int64_t lda, double* d_dev, double* e_dev) {
   if (n % SB != 0 || n < SB) return ctx->fail(SCLENS_ERR_ARG, "sb2st_f32: the order must be a positive multiple of 64");
   StageTimer tm(ctx, "sb2st");
+  if (ctx->q2_ev && ctx->q2_tg_n >= 0) SCL_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->q2_ev, 0));  // T factors of the previous reflectors
+  ctx->q2_tg_n = -1;
   const int64_t ldv2 = sbr_ldv2(n), ldt = n / SB + 2;
   SCL_WS(ctx, Bd, float, "sbr.Bd", n * LDB2);
   SCL_WS(ctx, V2, float, "sbr.V2", (n + 64) * ldv2);  // spare rows: the back-transformation reads whole 64-float runs
@@ -1605,6 +1615,16 @@ int sb2st_f32(Ctx* ctx, const float* A, int64_t n, int64_t lda, double* d_dev, d
   SCL_HIP(ctx, hipMemcpyAsync(&aborted, done + n, sizeof(unsigned), hipMemcpyDeviceToHost, st));
   SCL_HIP(ctx, hipStreamSynchronize(st));
   if (aborted) return ctx->fail(SCLENS_ERR_HIP, "sb2st_f32: a sweep waited too long for its predecessor (bulge chasing aborted)");
+  // The T factors of the second back-transformation (33 ms at n = 30 016) depend only on the reflectors just stored: built now on
+  // the auxiliary stream, beside the bisection and the inverse iteration (latency-bound, a few hundred waves), instead of in front
+  // of sbr_apply_q2. (The stream was just synchronised, so the reflectors are complete.)
+  const char* et = getenv("SCLENS_HIP_Q2_TG_EARLY");
+  if ((!et || atoi(et) != 0) && n - 2 > 0) {
+    SCL_TRY(sbr_ensure_aux(ctx));
+    SCL_TRY(sbr_q2_launch_build_t(ctx, n, ctx->aux_stream));
+    SCL_HIP(ctx, hipEventRecord(ctx->q2_ev, ctx->aux_stream));
+    ctx->q2_tg_n = n;
+  }
   return SCLENS_OK;
 }
 
@@ -2114,6 +2134,18 @@ __global__ void sbr_q2_shift(const float* __restrict__ in, int64_t ldi, int64_t 
   if (c < n) out[r * ldo + offo + c] = in[r * ldi + offi + c];
 }
 
+static int sbr_q2_launch_build_t(Ctx* ctx, int64_t n, hipStream_t st) {
+  const int64_t ldv2 = sbr_ldv2(n), ldt = n / SB + 2, nsweep = n - 2;
+  const float* V2 = static_cast<const float*>(ctx->ws.count("sbr.V2") ? ctx->ws.at("sbr.V2").first : nullptr);
+  const float* TAU2 = static_cast<const float*>(ctx->ws.count("sbr.TAU2") ? ctx->ws.at("sbr.TAU2").first : nullptr);
+  if (!V2 || !TAU2 || nsweep <= 0) return ctx->fail(SCLENS_ERR_STATE, "sbr_q2_build_t: no reflectors of a preceding sb2st_f32 on this context");
+  const int nblk = (int)((nsweep + QW - 1) / QW), nk = (int)((n - 1 + SB - 1) / SB);
+  SCL_WS(ctx, Tg, float, "sbr.Tg", (int64_t)nblk * nk * QW * QW);
+  hipLaunchKernelGGL(sbr_q2_build_t, dim3((unsigned)nk, (unsigned)nblk), dim3(64), 0, st, V2, ldv2, TAU2, ldt, n, nk, Tg);
+  SCL_HIP(ctx, hipGetLastError());
+  return SCLENS_OK;
+}
+
 int sbr_apply_q2(Ctx* ctx, int64_t n, float* Zt, int64_t m, int64_t ldz) {
   if (m <= 0) return SCLENS_OK;
   StageTimer tm(ctx, "sbr_q2");
@@ -2137,7 +2169,10 @@ int sbr_apply_q2(Ctx* ctx, int64_t n, float* Zt, int64_t m, int64_t ldz) {
   if (nsweep <= 0) return SCLENS_OK;
   const int nblk = (int)((nsweep + QW - 1) / QW), nk = (int)((n - 1 + SB - 1) / SB);
   SCL_WS(ctx, Tg, float, "sbr.Tg", (int64_t)nblk * nk * QW * QW);
-  hipLaunchKernelGGL(sbr_q2_build_t, dim3((unsigned)nk, (unsigned)nblk), dim3(64), 0, ctx->stream, V2, ldv2, TAU2, ldt, n, nk, Tg);
+  if (ctx->q2_tg_n == n && ctx->q2_ev)  // built on the auxiliary stream after the chase
+    SCL_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->q2_ev, 0));
+  else
+    SCL_TRY(sbr_q2_launch_build_t(ctx, n, ctx->stream));
   // the apply kernel works on the shifted layout Zq[v][3 + row] (16-byte aligned register quads, see above)
   const int64_t ldq = round_up(n + 3, 4);
   SCL_WS(ctx, Zq, float, "sbr.Zq", m * ldq);
