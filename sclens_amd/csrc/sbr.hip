@@ -1440,32 +1440,22 @@ __global__ __launch_bounds__(256) void sbr_chase_mb(SbrChaseMbArgs a) {
       float w2 = tau * ((partD[lane] + partD[SB + lane]) + (partD[2 * SB + lane] + partD[3 * SB + lane]));
       const float a2 = -0.5f * tau * sbr_wave_sum(v * w2);
       w2 = fmaf(a2, v, w2);
-      // ---- B <- H (B H_prev), D <- H D H in registers
-      float bnv[16], dnv[16];
-#pragma unroll
-      for (int q = 0; q < 16; ++q) {
-        const int j = 16 * wq + q;
-        float bn = fmaf(-(tau * v), sbr_rl(z, j), fmaf(-(tp * w), sbr_rl(vp, j), rb[q]));
-        if (j == 0) bn = (lane == 0) ? beta : 0.f;
-        bnv[q] = bn;
-        dnv[q] = fmaf(-w2, sbr_rl(v, j), fmaf(-v, sbr_rl(w2, j), dd[q]));
-      }
-      // ---- (1) row 0 to the successor, from lane 0 of every wave
+      // ---- (1) row 0 to the successor. Wave 0 alone: its lane j forms B'[0][j] from the LDS image, w_0 and its own entries of
+      // v_prev and z -- the same two fused multiply-adds on the same operands as lane 0 of the wave that owns column j (v_0 = 1) --
+      // so one store carries the row; D'[0][0] is entry (lane 0, q 0) of the update below, formed here first.
       const bool send = k > 0 && has_next;
       const int lo = send ? 1 : 0;
-      // Wave 0 alone: its lane j forms B'[0][j] from the LDS image, w_0 and its own entries of v_prev and z -- the same two fused
-      // multiply-adds on the same operands as lane 0 of the wave that owns column j (v_0 = 1) -- so one store carries the row.
       const unsigned mrow = (mb_out + (unsigned)k) * MBW;
       if (wq == 0) {
         float b0j = fmaf(-(tau * 1.f), z, fmaf(-(tp * sbr_rl(w, 0)), vp, Bt[lane * 65]));
         if (lane == 0) b0j = beta;
         const u32x2 pm = {__builtin_bit_cast(unsigned, b0j), tag_out};
         __builtin_amdgcn_raw_buffer_store_b64(pm, rm, send ? (mrow + (unsigned)lane) * 8u : OOR, 0, 16);
-        const u32x2 pm2 = {__builtin_bit_cast(unsigned, dnv[0]), tag_out};
+        const float d00 = fmaf(-w2, sbr_rl(v, 0), fmaf(-v, sbr_rl(w2, 0), dd[0]));
+        const u32x2 pm2 = {__builtin_bit_cast(unsigned, d00), tag_out};
         __builtin_amdgcn_raw_buffer_store_b64(pm2, rm, (send && lane == 0) ? (mrow + 64u) * 8u : OOR, 0, 16);
       }
-      // ---- (2) prefetch of the next task's blocks (rows 0..62 valid once the predecessor's task k+1 has drained; row 63: message)
-      SBR_PROF_MARK(3)  // update arithmetic + message stores
+      SBR_PROF_MARK(3)  // z, w2 + message stores
       __builtin_amdgcn_sched_barrier(0);  // keep the wait for the counter loads behind the message
       {  // both looks are old enough to be back: no wait in the common case
         int xa, xb;  // volatile asm: the compiler's own readfirstlane floats up to the loads and waits for them there
@@ -1474,26 +1464,35 @@ __global__ __launch_bounds__(256) void sbr_chase_mb(SbrChaseMbArgs a) {
         if (has_prev) pd = (xa > pd) ? xa : pd;
         if (has_prev) pd = (xb > pd) ? xb : pd;
       }
-      if (more) {
-        if (pd < need2) {
-          pd = sbr_spin_flag(flagp, need2, abort_w);
-          if (pd < 0) return;
-        }
-        const int64_t rk1 = rk + SB;
-        const int L1 = (int)((n - rk1 < SB) ? n - rk1 : SB);
-        const unsigned cB1 = (unsigned)rk, cD1 = (unsigned)rk1;
-        const unsigned lb = (lane < L1) ? ((cB1 + w16) * LDB2 + SB + lane - w16) * 4u : OORB;
-        const unsigned ld = (lane < L1) ? ((cD1 + w16) * LDB2 + lane - w16) * 4u : OORB;  // above the diagonal: not used
+      if (more && pd < need2) {
+        pd = sbr_spin_flag(flagp, need2, abort_w);
+        if (pd < 0) return;
+      }
+      // ---- (2) B <- H (B H_prev), D <- H D H in registers, and between the columns the loads of the NEXT task's blocks (rows 0..62
+      // valid once the predecessor's task k+1 has drained; row 63: message): a column's register is free once its update is formed,
+      // and the ~13 clocks the CU's address unit takes per load pass under the update arithmetic instead of after it
+      const int64_t rk1 = rk + SB;
+      const int L1 = (int)((n - rk1 < SB) ? n - rk1 : SB);
+      const unsigned cB1 = (unsigned)rk, cD1 = (unsigned)rk1;
+      const unsigned lb = (more && lane < L1) ? ((cB1 + w16) * LDB2 + SB + lane - w16) * 4u : OORB;
+      const unsigned ld = (more && lane < L1) ? ((cD1 + w16) * LDB2 + lane - w16) * 4u : OORB;  // above the diagonal: not used
+      float bnv[16], dnv[16];
 #pragma unroll
-        for (int q = 0; q < 16; ++q) {
-          rb[q] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, lb, q * QS, 16));
-          rd[q] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, ld, q * QS, 16));
-        }
-        // a first look at the next task's message
-        const bool msg_next = has_prev && k + 2 < Kprev;
+      for (int q = 0; q < 16; ++q) {
+        const int j = 16 * wq + q;
+        float bn = fmaf(-(tau * v), sbr_rl(z, j), fmaf(-(tp * w), sbr_rl(vp, j), rb[q]));
+        if (j == 0) bn = (lane == 0) ? beta : 0.f;
+        bnv[q] = bn;
+        dnv[q] = fmaf(-w2, sbr_rl(v, j), fmaf(-v, sbr_rl(w2, j), dd[q]));
+        rb[q] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, lb, q * QS, 16));
+        rd[q] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, ld, q * QS, 16));
+        __builtin_amdgcn_sched_barrier(0);  // keep the two loads of column q behind its arithmetic (the scheduler would issue all 32 first)
+      }
+      {  // a first look at the next task's message
+        const bool msg_next = more && has_prev && k + 2 < Kprev;
         prn = __builtin_amdgcn_raw_buffer_load_b64(rm, (msg_next && act) ? ((mb_in + (unsigned)(k + 2)) * MBW + midx) * 8u : OOR, 0, 16);
       }
-      SBR_PROF_MARK(4)  // counter check + prefetch issue
+      SBR_PROF_MARK(4)  // counter check + update arithmetic with the prefetch loads between
       // ---- (3) the rest of the blocks, write-through
       const bool kb = k > 0;
       const unsigned sb_ = (kb && lane >= lo && lane < L) ? ((colB0 + w16) * LDB2 + SB + lane - w16) * 4u : OORB;
@@ -1595,8 +1594,8 @@ int sb2st_f32(Ctx* ctx, const float* A, int64_t n, int64_t lda, double* d_dev, d
       hipEventElapsedTime(&ms, e0, e1);
       hipEventDestroy(e0);
       hipEventDestroy(e1);
-      static const char* nm[8] = {"message poll + patch", "LDS images + w + barrier 1", "reflector + z, Dv + barrier 2", "update + message send",
-                                  "counter check + prefetch issue", "bulk stores issue", "drain + prefetch wait", "barrier 3 + counter"};
+      static const char* nm[8] = {"message poll + patch", "LDS images + w + barrier 1", "reflector + z, Dv + barrier 2", "z, w2 + message send",
+                                  "counter check + update + prefetch", "bulk stores issue", "drain + prefetch wait", "barrier 3 + counter"};
       unsigned long long tot = 0;
       for (int i = 0; i < 8; ++i) tot += h[i];
       fprintf(stderr, "[sbr_chase_mb] n = %lld, G = %d, %.2f ms, %llu tasks, %.0f clocks per task inside a workgroup\n", (long long)n, G, ms,
@@ -1615,16 +1614,22 @@ int sb2st_f32(Ctx* ctx, const float* A, int64_t n, int64_t lda, double* d_dev, d
   SCL_HIP(ctx, hipMemcpyAsync(&aborted, done + n, sizeof(unsigned), hipMemcpyDeviceToHost, st));
   SCL_HIP(ctx, hipStreamSynchronize(st));
   if (aborted) return ctx->fail(SCLENS_ERR_HIP, "sb2st_f32: a sweep waited too long for its predecessor (bulge chasing aborted)");
-  // The T factors of the second back-transformation (33 ms at n = 30 016) depend only on the reflectors just stored: built now on
-  // the auxiliary stream, beside the bisection and the inverse iteration (latency-bound, a few hundred waves), instead of in front
-  // of sbr_apply_q2. (The stream was just synchronised, so the reflectors are complete.)
+  return SCLENS_OK;
+}
+
+// The T factors of the second back-transformation (33 ms at n = 30 016) depend only on the reflectors of the chase: enqueued on the
+// auxiliary stream BEHIND what the main stream holds now (the bisection: it is bound by vector-ALU issue and lost 40 ms with this
+// kernel beside it), so that they are built beside the inverse iteration -- a few hundred waves waiting for memory -- instead of in
+// front of sbr_apply_q2. profiles/r03_eig_30016_final.log.
+static int sbr_q2_prebuild(Ctx* ctx, int64_t n) {
   const char* et = getenv("SCLENS_HIP_Q2_TG_EARLY");
-  if ((!et || atoi(et) != 0) && n - 2 > 0) {
-    SCL_TRY(sbr_ensure_aux(ctx));
-    SCL_TRY(sbr_q2_launch_build_t(ctx, n, ctx->aux_stream));
-    SCL_HIP(ctx, hipEventRecord(ctx->q2_ev, ctx->aux_stream));
-    ctx->q2_tg_n = n;
-  }
+  if ((et && atoi(et) == 0) || n - 2 <= 0 || !ctx->q2_prebuild) return SCLENS_OK;
+  SCL_TRY(sbr_ensure_aux(ctx));
+  SCL_HIP(ctx, hipEventRecord(ctx->aux_ev[0], ctx->stream));
+  SCL_HIP(ctx, hipStreamWaitEvent(ctx->aux_stream, ctx->aux_ev[0], 0));
+  SCL_TRY(sbr_q2_launch_build_t(ctx, n, ctx->aux_stream));
+  SCL_HIP(ctx, hipEventRecord(ctx->q2_ev, ctx->aux_stream));
+  ctx->q2_tg_n = n;
   return SCLENS_OK;
 }
 
@@ -2266,6 +2271,7 @@ int eig_values_two_stage(Ctx* ctx, const float* A, int64_t n, int64_t lda, doubl
   } else {  // the padded spectrum ends with np - n sentinels: the largest true eigenvalue has index n - 1
     SCL_TRY(stebz_f64(ctx, d, e, np, wp, n_low, n - 1));
   }
+  SCL_TRY(sbr_q2_prebuild(ctx, np));
   hipLaunchKernelGGL(sbr_copy_f64, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, wp, w64_dev, n);
   SCL_HIP(ctx, hipGetLastError());
   *used = 1;

@@ -601,7 +601,9 @@ int session_null_spectrum(Session* s, const int64_t* rc_, const int32_t* rr_, co
   float* valr = static_cast<float*>(ctx->workspace("ses.valr", sizeof(float) * pr.dev.val_floats()));
   int rc = valr ? SCLENS_OK : SCLENS_ERR_OOM;
   if (rc == SCLENS_OK) rc = make_values(ctx, pr.dev, pr.base_val, 0, nullptr, 0, valr);
+  s->ctx->q2_prebuild = false;  // eigenvalues only
   if (rc == SCLENS_OK) rc = decompose(s, pr.dev, valr, 1, s->Btmp, (float)s->M, nullptr);
+  s->ctx->q2_prebuild = true;
   hipStreamSynchronize(ctx->stream);
   pattern_free(&pr);
   SCL_TRY(rc);
@@ -617,7 +619,10 @@ int session_null_spectrum_pattern(Session* s, PatternOwner* pr, double* Lr) {
   float* valr = static_cast<float*>(ctx->workspace("ses.valr", sizeof(float) * pr->dev.val_floats()));
   if (!valr) return SCLENS_ERR_OOM;
   SCL_TRY(make_values(ctx, pr->dev, pr->base_val, 0, nullptr, 0, valr));
-  SCL_TRY(decompose(s, pr->dev, valr, 1, s->Btmp, (float)s->M, nullptr));
+  s->ctx->q2_prebuild = false;  // eigenvalues only
+  const int rc_null = decompose(s, pr->dev, valr, 1, s->Btmp, (float)s->M, nullptr);
+  s->ctx->q2_prebuild = true;
+  SCL_TRY(rc_null);
   SCL_HIP(ctx, hipStreamSynchronize(ctx->stream));
   if (Lr) std::copy(s->w_host.begin(), s->w_host.end(), Lr);
   return SCLENS_OK;
