@@ -239,6 +239,42 @@ def test_two_stage_solver_behind_eigh(ctx, n, lo, hi):
         c2.close()
 
 
+@pytest.mark.parametrize("n,lo,hi", [(700, 0, 350), (2112, 2000, 2112)])
+def test_switches_that_only_move_work_give_the_same_bits(ctx, n, lo, hi, monkeypatch):
+    """The T factors of the second back-transformation built on the auxiliary stream behind the bisection (default) or in front of
+    the apply kernel (SCLENS_HIP_Q2_TG_EARLY=0), and the inverse iteration with 4 / 16 / 32 steps of loads in flight: the same
+    arithmetic on the same data, so eigenvalues and eigenvectors have the same bits."""
+    from sclens_amd._lib import Context
+
+    A = _sym_psd(n, 77 + n)
+    lda = rup(n, 32)
+    m = hi - lo
+    got = []
+    for env in ({}, {"SCLENS_HIP_Q2_TG_EARLY": "0"}, {"SCLENS_HIP_STEIN_PF": "4"}, {"SCLENS_HIP_STEIN_PF": "32"}):
+        for key in ("SCLENS_HIP_Q2_TG_EARLY", "SCLENS_HIP_STEIN_PF"):
+            monkeypatch.delenv(key, raising=False)
+        for key, val in env.items():
+            monkeypatch.setenv(key, val)
+        c2 = Context(ctx.device)
+        c2.set_option("two_stage", 1)
+        try:
+            dA, dw, dZ = DevArray(c2, pad_rows(A, lda)), DevArray(c2, nbytes=8 * n), DevArray(c2, nbytes=4 * m * lda)
+            for _ in range(2):  # twice on one context: the second call finds the first call's T factors and must not use them
+                c2.h2d(dA.p, pad_rows(A, lda))
+                c2.check(c2.lib.sclens_hip_dev_eigh_f32(c2.h, dA.p, n, lda, dw.p, lo, hi, dZ.p, lda))
+            c2.sync()
+            got.append((dw.get((n,), np.float64), dZ.get((m, lda), np.float32)[:, :n]))
+            for x in (dA, dw, dZ):
+                x.free()
+        finally:
+            c2.close()
+    for w, Z in got[1:]:
+        assert np.array_equal(w, got[0][0]) and np.array_equal(Z, got[0][1])
+    A64 = A.astype(np.float64)
+    Z = got[0][1].astype(np.float64)
+    assert np.abs(Z @ A64 - got[0][0][lo:hi, None] * Z).max() < 5e-5 * np.abs(got[0][0]).max() * np.sqrt(n / 64 + 1)
+
+
 @pytest.mark.parametrize("n,m", [(192, 192), (1088, 100), (2560, 70), (640, 641 - 1)])
 def test_second_back_transformation_matches_the_unblocked_reference(ctx, n, m, monkeypatch):
     """The register-resident MFMA version of Q2 (16-vector wave tiles, QJ sweep blocks per pass) against the one-reflector-at-
