@@ -279,6 +279,66 @@ __global__ __launch_bounds__(256) void k_dense_scatter(PatternDev p, int cells_m
   }
 }
 
+// ---- K5 fused (round 3, gene-major B[j][i] only): one workgroup per gene walks the cells in chunks of DF_CH: the chunk's background
+// -s_i mu_j - cent_j is formed in LDS, the gene's stored entries that fall into the chunk overwrite their slots with the same
+// expression k_dense_scatter uses, and the chunk leaves as 16-byte stores: the 4 N M bytes are written ONCE (fill + scatter wrote
+// them, then re-wrote 64-byte sectors around each of the nnz scattered dwords: 19 ms for the two kernels at 100 000 x 30 000,
+// `profiles/r03_cfg4_kernel_stats_final.csv`). A column of the pattern holds the counts with ascending cells and THEN the zero
+// candidates in draw order, so a running position q replaces any search as long as the entries keep coming in order: q advances
+// over the PREFIX of entries that lie in the current chunk; whatever is left when the last chunk has been written (the unordered
+// tail) is scattered as before, behind a barrier (same workgroup, same addresses: the chunk stores have completed).
+constexpr int DF_CH = 4096;
+__global__ __launch_bounds__(256) void k_dense_fused(PatternDev p, const float* __restrict__ val, const double* __restrict__ lg,
+                                                     const double* __restrict__ stdv, const double* __restrict__ mu,
+                                                     const double* __restrict__ cent, const double* __restrict__ srow,
+                                                     float* __restrict__ B, int64_t ldb) {
+  __shared__ __attribute__((aligned(16))) float chunk[DF_CH];
+  __shared__ int wlead[4];
+  const int64_t col = blockIdx.x;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const double isd = 1.0 / stdv[col], m = mu[col], ce = cent[col];
+  int64_t q = p.colptr[col];
+  const int64_t qend = p.colptr[col + 1];
+  float* dst = B + col * ldb;
+  for (int64_t c0 = 0; c0 < ldb; c0 += DF_CH) {
+    const int64_t cend = (c0 + DF_CH < ldb) ? c0 + DF_CH : ldb;
+#pragma unroll 4
+    for (int c = tid; c < DF_CH; c += 256) {
+      const int64_t i = c0 + c;
+      chunk[c] = (i < p.N) ? (float)(-srow[i] * m - ce) : 0.f;
+    }
+    __syncthreads();
+    while (true) {  // block-uniform trip count
+      const int64_t idx = q + tid;
+      const int64_t r = (idx < qend) ? (int64_t)p.row[idx] : (int64_t)-1;
+      const int in = (r >= c0 && r < cend) ? 1 : 0;
+      const unsigned long long out = ~__ballot(in);
+      if (lane == 0) wlead[wv] = out ? (__ffsll((long long)out) - 1) : 64;  // this wave's leading entries inside the chunk
+      __syncthreads();
+      int cnt = wlead[0];
+      if (cnt == 64) cnt += wlead[1];
+      if (cnt == 128) cnt += wlead[2];
+      if (cnt == 192) cnt += wlead[3];
+      if (tid < cnt && val[idx] != 0.f) chunk[r - c0] = (float)(srow[r] * (lg[idx] * isd - m) - ce);
+      __syncthreads();
+      q += cnt;
+      if (cnt < 256) break;
+    }
+    for (int c = 4 * tid; c0 + c < cend; c += 1024) {
+      if (c0 + c + 3 < cend)
+        *reinterpret_cast<float4*>(dst + c0 + c) = *reinterpret_cast<const float4*>(chunk + c);
+      else
+        for (int e = 0; e < 4 && c0 + c + e < cend; ++e) dst[c0 + c + e] = chunk[c + e];
+    }
+    __syncthreads();
+  }
+  for (int64_t idx = q + tid; idx < qend; idx += 256) {  // the entries that did not come in cell order
+    if (val[idx] == 0.f) continue;
+    const int64_t r = p.row[idx];
+    dst[r] = (float)(srow[r] * (lg[idx] * isd - m) - ce);
+  }
+}
+
 int scale_stats(Ctx* ctx, const PatternDev& p, const float* val, int f32path, int centering, ScaleStats* out) {
   const int64_t N = p.N, M = p.M;
   SCL_WS(ctx, tgc, double, "sc.tgc", N);
@@ -323,6 +383,11 @@ int scale_to_dense(Ctx* ctx, const PatternDev& p, const float* val, int f32path,
   hipStream_t st = ctx->stream;
   const int64_t nr = cells_major ? N : M, nc = cells_major ? M : N;
   if (nr > 65535LL * 65535LL) return ctx->fail(SCLENS_ERR_ARG, "scale_to_dense: too many rows");
+  const char* edf = getenv("SCLENS_HIP_DENSE_FUSED");  // 0: the separate fill + scatter kernels (same values)
+  const bool fused_ok = !(edf && atoi(edf) == 0);
+  if (!cells_major && fused_ok && ldb % 4 == 0 && (reinterpret_cast<uintptr_t>(B) & 15u) == 0) {
+    hipLaunchKernelGGL(k_dense_fused, dim3((unsigned)M), dim3(256), 0, st, p, val, lg, stdv, mu, cent, srow, B, ldb);
+  } else {
   // grid.y is limited to 65535: loop over row slabs
   for (int64_t r0 = 0; r0 < nr; r0 += 65535) {
     const int64_t rows = (nr - r0 < 65535) ? nr - r0 : 65535;
@@ -332,6 +397,7 @@ int scale_to_dense(Ctx* ctx, const PatternDev& p, const float* val, int f32path,
   }
   hipLaunchKernelGGL(k_dense_scatter, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, st, p, cells_major, val, lg, stdv,
                      mu, cent, srow, B, ldb);
+  }
   SCL_HIP(ctx, hipGetLastError());
   if (keep) {  // rec_vals of the data matrix (scLENS.jl:676-696) -> host
     SCL_HIP(ctx, hipMemcpyAsync(keep->tgc, tgc, sizeof(double) * N, hipMemcpyDeviceToHost, st));

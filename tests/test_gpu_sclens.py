@@ -217,6 +217,26 @@ def test_partial_eigensolver_tail_gap_option(ctx):
             assert np.all(cos[sep] > 1 - 5e-3), (cos, sep)
 
 
+def test_fused_dense_write_gives_the_same_bits(ctx, monkeypatch):
+    """k_dense_fused (one pass per gene: background + stored entries + sampled candidates through LDS chunks) against the separate
+    fill + scatter kernels (SCLENS_HIP_DENSE_FUSED=0): the dense scaled matrices are the same, so is everything downstream --
+    counts-only patterns (data / null), and the union pattern with its unordered candidate tail (ensemble members, full solver)."""
+    X = api._csc_f32(synth_counts(900, 260, seed=3, C=5, marker_frac=0.2, marker_sd=1.5))
+    d = api.make_draws_native(X, seed=17)
+    out = []
+    for flag in ("1", "0"):
+        monkeypatch.setenv("SCLENS_HIP_DENSE_FUSED", flag)
+        out.append(api.sclens(X, draws=d, n_perturb=3, ctx=ctx, keep_intermediates=True, max_search_iters=5, partial_eig=False, streams=1))
+        S, _ = api.logn_scale(X, "mean", inline_f64=True, ctx=ctx)
+        out[-1]["S"] = S
+    a, b = out
+    assert np.array_equal(a["S"], b["S"])
+    assert np.array_equal(a["L"], b["L"]) and np.array_equal(a["signal_evec"], b["signal_evec"])
+    assert np.array_equal(a["robustness_scores"]["b_"], b["robustness_scores"]["b_"])
+    for t in range(3):
+        assert np.array_equal(a["nV_set"][t], b["nV_set"][t]) and np.array_equal(a["nL_set"][t], b["nL_set"][t])
+
+
 def test_two_streams_give_identical_results(ctx):
     """streams=2 (two worker sessions on separate HIP streams, speculative search rounds of 2) must reproduce the
     serial run bit for bit: same samples per iteration, deterministic kernels, results consumed in order."""
