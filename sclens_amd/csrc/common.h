@@ -165,6 +165,17 @@ int gemm_f32(Ctx* ctx, const GemmArgs& a);
 size_t split_image_bytes(int64_t rows, int64_t K);
 int split_image_f16(Ctx* ctx, const float* src, int64_t rows, int64_t K, int64_t ld, void* dst);
 int corr_colabsmax_split(Ctx* ctx, const void* Aimg, int64_t M, const void* Bimg, int64_t N, int64_t K, unsigned* colabsmax);
+// C (+)= P Q' for short contractions with the products on the fp16 matrix cores (round 3: trailing updates of the band reduction,
+// the read-modify-write product of the first back-transformation). split_image_scaled: the split image of src [rows][K] scaled by
+// the power of two that brings its largest |entry| to [2^13, 2^14) (scale[0] receives it, device memory; scale[1] is scratch);
+// gemm_split_update: C[M][N] += P Q' (lower != 0: M == N, tiles on / below the diagonal, mirrored) from two such images and
+// their scales, accumulators started from C -- the arithmetic of `acc_init` in gemm.hip with 22-bit operands.
+int split_image_scaled(Ctx* ctx, const float* src, int64_t rows, int64_t K, int64_t ld, void* dst, float* scale_dev);
+// two matrices of the same shape that hold the same magnitudes (the two operands of a symmetric rank-2k update): one scale, from src1
+int split_image_pair_scaled(Ctx* ctx, const float* src1, const float* src2, int64_t rows, int64_t K, int64_t ld, void* dst1, void* dst2,
+                            float* scale_dev);
+int gemm_split_update(Ctx* ctx, const void* Pimg, const float* sP, int64_t M, const void* Qimg, const float* sQ, int64_t N, int64_t K,
+                      float* C, int64_t ldc, int lower);
 
 // ------------------------------------------------------------------ eigensolver (tridiag.hip, trieig.hip)
 // Symmetric eigensolver on a device-resident n x n fp32 matrix A (row-major, lda, FULL storage,

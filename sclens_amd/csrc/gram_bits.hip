@@ -427,6 +427,209 @@ __global__ __launch_bounds__(512, 2) void corr_split_kernel(SplitCorrArgs a, con
   }
 }
 
+// ---- C += P Q' from split images, accumulators started from C (round 3) ------------------------------------------------------
+__global__ __launch_bounds__(256) void k_absmax_bits(const float* __restrict__ src, int64_t rows, int64_t K, int64_t ld,
+                                                     unsigned* __restrict__ out) {
+  float mx = 0.f;
+  for (int64_t r = blockIdx.x; r < rows; r += gridDim.x)
+    for (int64_t k = threadIdx.x; k < K; k += 256) mx = fmaxf(mx, fabsf(src[r * ld + k]));
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+  if ((threadIdx.x & 63) == 0) atomicMax(out, __float_as_uint(mx));  // non-negative floats order like their bit patterns
+}
+__global__ void k_pick_scale(const unsigned* __restrict__ mxbits, float* __restrict__ scale) {
+  const float mx = __uint_as_float(mxbits[0]);
+  int ex = 0;
+  float sc = 1.f;
+  if (mx > 0.f && mx < 1.0e30f) {
+    (void)frexpf(mx, &ex);       // mx = f 2^ex, 1/2 <= f < 1
+    sc = ldexpf(1.f, 14 - ex);   // mx sc in [2^13, 2^14)
+  }
+  scale[0] = sc;
+}
+__global__ __launch_bounds__(256) void k_split_image_scaled(const float* __restrict__ src, int64_t rows, int64_t K, int64_t ld, int64_t Kp,
+                                                            const float* __restrict__ scale, _Float16* __restrict__ dst) {
+  const int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (k >= Kp) return;
+  const float sc = scale[0];
+  for (int64_t r = blockIdx.y; r < rows; r += gridDim.y) {
+    const float x = k < K ? src[r * ld + k] * sc : 0.f;
+    const _Float16 hi = (_Float16)x;
+    const _Float16 lo = (_Float16)(x - (float)hi);
+    _Float16* d = dst + r * 2 * Kp + (k >> 5) * 64 + (k & 31);
+    d[0] = hi;
+    d[32] = lo;
+  }
+}
+
+__global__ __launch_bounds__(256) void k_split_image_pair_scaled(const float* __restrict__ src1, const float* __restrict__ src2, int64_t rows,
+                                                                 int64_t K, int64_t ld, int64_t Kp, const float* __restrict__ scale,
+                                                                 _Float16* __restrict__ dst1, _Float16* __restrict__ dst2) {
+  const int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (k >= Kp) return;
+  const float sc = scale[0];
+  for (int64_t r = blockIdx.y; r < rows; r += gridDim.y) {
+    const float x1 = k < K ? src1[r * ld + k] * sc : 0.f, x2 = k < K ? src2[r * ld + k] * sc : 0.f;
+    const _Float16 h1 = (_Float16)x1, h2 = (_Float16)x2;
+    const int64_t o = r * 2 * Kp + (k >> 5) * 64 + (k & 31);
+    dst1[o] = h1;
+    dst1[o + 32] = (_Float16)(x1 - (float)h1);
+    dst2[o] = h2;
+    dst2[o + 32] = (_Float16)(x2 - (float)h2);
+  }
+}
+
+struct SplitUpdArgs {
+  const _Float16* A;  // split image, M rows
+  const _Float16* B;  // split image, N rows
+  const float* sA;    // their scales (device)
+  const float* sB;
+  int64_t M, N, Kp;
+  float* C;
+  int64_t ldc;
+  int lower;
+  int tiles_n;
+};
+
+// The main loop of corr_split_kernel with the tile decode, the accumulator start from C and the lower + mirror epilogue of
+// gemm_nt_big<2, 4, 4, 2> (same 256 x 256 tile, same 32 x 32 accumulator layout).
+__global__ __launch_bounds__(512, 2) void gemm_split_kernel(SplitUpdArgs a) {
+  constexpr int TM = 4, TN = 2;
+  constexpr int OPB = 256 * 128, STAGE = 2 * OPB;
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+  int2 tl;
+  {
+    const unsigned nwg = gridDim.x, bid = blockIdx.x;
+    const unsigned q = nwg >> 3, r = nwg & 7u, xcd = bid & 7u;
+    const unsigned t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    if (a.lower) {
+      int ti = (int)((sqrtf(8.f * (float)t + 1.f) - 1.f) * 0.5f);
+      while ((unsigned)(ti + 1) * (unsigned)(ti + 2) / 2 <= t) ++ti;
+      while ((unsigned)ti * (unsigned)(ti + 1) / 2 > t) --ti;
+      tl = make_int2(ti, (int)(t - (unsigned)ti * (unsigned)(ti + 1) / 2));
+    } else {
+      tl = make_int2((int)(t / (unsigned)a.tiles_n), (int)(t % (unsigned)a.tiles_n));
+    }
+  }
+  const int64_t m0 = (int64_t)tl.x * 256, n0 = (int64_t)tl.y * 256;
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int wm = wid >> 2, wn = wid & 3, l31 = lane & 31, h = lane >> 5;
+  const int srow = lane >> 3, sq = lane & 7;
+  const _Float16* srcA[4];
+  const _Float16* srcB[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int r = (wid * 4 + i) * 8 + srow;
+    const int chunk = sq ^ ((r >> 1) & 7);
+    int64_t ra = m0 + r, rb = n0 + r;
+    if (ra > a.M - 1) ra = a.M - 1;
+    if (rb > a.N - 1) rb = a.N - 1;
+    srcA[i] = a.A + ra * 2 * a.Kp + 8 * chunk;
+    srcB[i] = a.B + rb * 2 * a.Kp + 8 * chunk;
+  }
+  const int64_t nkt = a.Kp / 32;
+  auto stage = [&](int buf, int64_t kt) {
+    unsigned char* As = lds + buf * STAGE;
+    unsigned char* Bs = As + OPB;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      __builtin_amdgcn_global_load_lds((glb_void_t*)(srcA[i] + kt * 64), (lds_void_t*)(As + (wid * 4 + i) * 1024), 16, 0, 0);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      __builtin_amdgcn_global_load_lds((glb_void_t*)(srcB[i] + kt * 64), (lds_void_t*)(Bs + (wid * 4 + i) * 1024), 16, 0, 0);
+  };
+  stage(0, 0);
+  const float sprod = a.sA[0] * a.sB[0];  // powers of two: the products below are exact scalings
+  const float alpha = 1.f / sprod;
+  v16f acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int64_t col = n0 + wn * (32 * TN) + j * 32 + l31;
+      const int64_t row0 = m0 + wm * (32 * TM) + i * 32 + 4 * h;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int64_t row = row0 + (e & 3) + 8 * (e >> 2);
+        acc[i][j][e] = (row < a.M && col < a.N && (!a.lower || col <= row)) ? a.C[row * a.ldc + col] * sprod : 0.f;
+      }
+    }
+  int offA[TM], offB[TN], swA[TM], swB[TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+    const int r = wm * 128 + i * 32 + l31;
+    offA[i] = r * 128;
+    swA[i] = (r >> 1) & 7;
+  }
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int r = wn * 64 + j * 32 + l31;
+    offB[j] = OPB + r * 128;
+    swB[j] = (r >> 1) & 7;
+  }
+  __syncthreads();
+  for (int64_t kt = 0; kt < nkt; ++kt) {
+    const int buf = (int)(kt & 1);
+    if (kt + 1 < nkt) stage(buf ^ 1, kt + 1);
+    const unsigned char* S = lds + buf * STAGE;
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      const int ch = 2 * kk + h, cl = 4 + 2 * kk + h;
+      h16x8 ah[TM], al[TM], bh[TN], bl[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        ah[i] = *reinterpret_cast<const h16x8*>(S + offA[i] + ((ch ^ swA[i]) << 4));
+        al[i] = *reinterpret_cast<const h16x8*>(S + offA[i] + ((cl ^ swA[i]) << 4));
+      }
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        bh[j] = *reinterpret_cast<const h16x8*>(S + offB[j] + ((ch ^ swB[j]) << 4));
+        bl[j] = *reinterpret_cast<const h16x8*>(S + offB[j] + ((cl ^ swB[j]) << 4));
+      }
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh[j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+        }
+    }
+    __syncthreads();
+  }
+  const bool vec_mirror = a.lower && (a.ldc % 4 == 0) && ((reinterpret_cast<uintptr_t>(a.C) & 15u) == 0);
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int64_t col = n0 + wn * (32 * TN) + j * 32 + l31;
+      const int64_t row0 = m0 + wm * (32 * TM) + i * 32 + 4 * h;
+      v16f outv;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) outv[e] = acc[i][j][e] * alpha;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int64_t row = row0 + (e & 3) + 8 * (e >> 2);
+        if (row < a.M && col < a.N && (!a.lower || col <= row)) a.C[row * a.ldc + col] = outv[e];
+      }
+      if (a.lower && col < a.N) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int64_t rowq = row0 + 8 * q;
+          if (vec_mirror && rowq + 3 < a.M && col < rowq) {
+            typedef float f32x4_ __attribute__((ext_vector_type(4)));
+            f32x4_ v = {outv[4 * q], outv[4 * q + 1], outv[4 * q + 2], outv[4 * q + 3]};
+            *reinterpret_cast<f32x4_*>(&a.C[col * a.ldc + rowq]) = v;
+          } else {
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+              if (rowq + u < a.M && col < rowq + u) a.C[col * a.ldc + rowq + u] = outv[4 * q + u];
+          }
+        }
+      }
+    }
+}
+
 }  // namespace
 
 size_t gram_binary_scratch_bytes(int64_t N, int64_t M) { return sizeof(unsigned short) * (size_t)M * (size_t)round_up(N, 64); }
@@ -479,6 +682,51 @@ int split_image_f16(Ctx* ctx, const float* src, int64_t rows, int64_t K, int64_t
   const int64_t Kp = round_up(K, 32);
   hipLaunchKernelGGL(k_split_image, dim3((unsigned)((Kp + 255) / 256), (unsigned)std::min<int64_t>(rows, 65535)), dim3(256), 0,
                      ctx->stream, src, rows, K, ld, Kp, static_cast<_Float16*>(dst));
+  SCL_HIP(ctx, hipGetLastError());
+  return SCLENS_OK;
+}
+
+int split_image_scaled(Ctx* ctx, const float* src, int64_t rows, int64_t K, int64_t ld, void* dst, float* scale_dev) {
+  if (rows <= 0) return SCLENS_OK;
+  const int64_t Kp = round_up(K, 32);
+  hipStream_t st = ctx->stream;
+  unsigned* mx = reinterpret_cast<unsigned*>(scale_dev + 1);
+  SCL_HIP(ctx, hipMemsetAsync(mx, 0, sizeof(unsigned), st));
+  hipLaunchKernelGGL(k_absmax_bits, dim3((unsigned)std::min<int64_t>(rows, 2048)), dim3(256), 0, st, src, rows, K, ld, mx);
+  hipLaunchKernelGGL(k_pick_scale, dim3(1), dim3(1), 0, st, mx, scale_dev);
+  hipLaunchKernelGGL(k_split_image_scaled, dim3((unsigned)((Kp + 255) / 256), (unsigned)std::min<int64_t>(rows, 65535)), dim3(256), 0, st,
+                     src, rows, K, ld, Kp, scale_dev, static_cast<_Float16*>(dst));
+  SCL_HIP(ctx, hipGetLastError());
+  return SCLENS_OK;
+}
+
+int split_image_pair_scaled(Ctx* ctx, const float* src1, const float* src2, int64_t rows, int64_t K, int64_t ld, void* dst1, void* dst2,
+                            float* scale_dev) {
+  if (rows <= 0) return SCLENS_OK;
+  const int64_t Kp = round_up(K, 32);
+  hipStream_t st = ctx->stream;
+  unsigned* mx = reinterpret_cast<unsigned*>(scale_dev + 1);
+  SCL_HIP(ctx, hipMemsetAsync(mx, 0, sizeof(unsigned), st));
+  hipLaunchKernelGGL(k_absmax_bits, dim3((unsigned)std::min<int64_t>(rows, 2048)), dim3(256), 0, st, src1, rows, K, ld, mx);
+  hipLaunchKernelGGL(k_pick_scale, dim3(1), dim3(1), 0, st, mx, scale_dev);
+  hipLaunchKernelGGL(k_split_image_pair_scaled, dim3((unsigned)((Kp + 255) / 256), (unsigned)std::min<int64_t>(rows, 65535)), dim3(256), 0,
+                     st, src1, src2, rows, K, ld, Kp, scale_dev, static_cast<_Float16*>(dst1), static_cast<_Float16*>(dst2));
+  SCL_HIP(ctx, hipGetLastError());
+  return SCLENS_OK;
+}
+
+int gemm_split_update(Ctx* ctx, const void* Pimg, const float* sP, int64_t M, const void* Qimg, const float* sQ, int64_t N, int64_t K,
+                      float* C, int64_t ldc, int lower) {
+  if (M <= 0 || N <= 0) return SCLENS_OK;
+  if (lower && M != N) return ctx->fail(SCLENS_ERR_ARG, "gemm_split_update: lower needs M == N");
+  const int64_t bm = (M + 255) / 256, bn = (N + 255) / 256;
+  const int64_t nb = lower ? bm * (bm + 1) / 2 : bm * bn;
+  if (nb > 0x7fffffffLL) return ctx->fail(SCLENS_ERR_ARG, "gemm_split_update: too many tiles");
+  constexpr int LDS_BYTES = 2 * 2 * 256 * 128;
+  SCL_TRY(ensure_dyn_lds(ctx, reinterpret_cast<const void*>(gemm_split_kernel), LDS_BYTES));
+  SplitUpdArgs a{static_cast<const _Float16*>(Pimg), static_cast<const _Float16*>(Qimg), sP, sQ, M, N, round_up(K, 32), C, ldc, lower,
+                 (int)bn};
+  hipLaunchKernelGGL(gemm_split_kernel, dim3((unsigned)nb), dim3(512), LDS_BYTES, ctx->stream, a);
   SCL_HIP(ctx, hipGetLastError());
   return SCLENS_OK;
 }

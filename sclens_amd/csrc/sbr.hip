@@ -652,6 +652,16 @@ int sy2sb_f32(Ctx* ctx, float* A, int64_t n, int64_t lda, float* Tall, int* brea
   SCL_WS(ctx, VW, float, "sbr.VW2", n * LDU);
   SCL_WS(ctx, WV, float, "sbr.WV2", n * LDU);
   SCL_WS(ctx, Gp, float, "sbr.Gp", (int64_t)(GSL + 1) * SB * 2 * SB);
+  // Trailing updates of at least `split_min` rows run on the fp16 matrix cores from operands split into two fp16 pieces
+  // (gemm_split_update in gram_bits.hip: 22-bit operands, fp32 accumulation started from C -- the rank-128 / rank-256 update is then
+  // C traffic only: 27 us of fp32 matrix-pipe time per 128 of K and 256 x 256 tile become 5). SCLENS_HIP_SY2SB_SPLIT=0: fp32 products.
+  int64_t split_min = (int64_t)1 << 60;  // off unless SCLENS_HIP_SY2SB_SPLIT=<rows> (> 0)
+  if (const char* ev = getenv("SCLENS_HIP_SY2SB_SPLIT")) split_min = atoi(ev) > 0 ? std::max<int64_t>(512, atoll(ev)) : (int64_t)1 << 60;
+  const bool any_split = n >= split_min;
+  void* imgP = any_split ? ctx->workspace("sbr.imgP", split_image_bytes(n, LDU)) : nullptr;
+  void* imgQ = any_split ? ctx->workspace("sbr.imgQ", split_image_bytes(n, LDU)) : nullptr;
+  float* imgS = any_split ? static_cast<float*>(ctx->workspace("sbr.imgS", 4 * sizeof(float))) : nullptr;
+  if (any_split && (!imgP || !imgQ || !imgS)) return SCLENS_ERR_OOM;
   SCL_WS(ctx, flag, int, "sbr.flag", 4);
   hipStream_t st = ctx->stream;
   SCL_HIP(ctx, hipMemsetAsync(flag, 0, sizeof(int) * 4, st));
@@ -768,6 +778,10 @@ int sy2sb_f32(Ctx* ctx, float* A, int64_t n, int64_t lda, float* Tall, int* brea
     const float* Uq = WV + r0 * LDU;
     const int64_t Ku = pending ? 4 * SB : 2 * SB;
     auto update = [&](int64_t off, int64_t rows, int64_t cols, int lower) -> int {  // A22[off:off+rows, (lower ? off : 0) : +cols]
+      if (lower && rows == cols && rows >= split_min) {  // the bulk of the update: split-fp16 products
+        SCL_TRY(split_image_pair_scaled(ctx, Up + off * LDU, Uq + off * LDU, rows, Ku, LDU, imgP, imgQ, imgS));
+        return gemm_split_update(ctx, imgP, imgS, rows, imgQ, imgS, rows, Ku, A22 + off * lda + off, lda, 1);
+      }
       GemmArgs g{};
       g.P = Up + off * LDU; g.Q = Uq + (lower ? off : 0) * LDU; g.C = A22 + off * lda + (lower ? off : 0);
       g.M = rows; g.N = cols; g.K = Ku;
@@ -2131,6 +2145,289 @@ __global__ __launch_bounds__(256, 1) void sbr_q2_apply16v3(SbrQ2Args a) {
   }
 }
 
+// ---- variant 5 (round 3): the three products of a group on the fp16 matrix cores from operands split into two fp16 pieces
+// (x = hi + lo, 22 significant bits; a b ~ ah bh + ah bl + al bh with fp32 accumulation, as the search statistic of gram_bits.hip).
+// The register quads of variant 3 already ARE the operands of v_mfma_f32_16x16x16_f16 (a lane supplies four consecutive k of its
+// row / column): one K = 16 instruction (8 cycles) replaces four K = 4 fp32 ones (32 cycles each), three of them per product.
+// LDS images keep their float-indexed layout; the 16 bytes of four consecutive elements hold [hi x 4 | lo x 4], split once by
+// the workgroup when a group is stashed. The vector window lives scaled by 2^8 (exact), so that the low pieces of entries of
+// size 1 / sqrt(n) stay in fp16's normal range; it is split per group (z, W', U': ~120 vector instructions per lane against
+// ~2 400 cycles of matrix-pipe time saved).
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+struct SbrHL {
+  f16x4 h, l;
+};
+__device__ __forceinline__ SbrHL sbr_ld_hl(const float* p) {
+  const f32x4 r = *reinterpret_cast<const f32x4*>(p);
+  SbrHL o;
+  __builtin_memcpy(&o, &r, 16);
+  return o;
+}
+__device__ __forceinline__ void sbr_st_hl(float* img, int off, float x) {  // element at float offset `off` of a [hi x 4 | lo x 4] image
+  const _Float16 h = (_Float16)x;
+  const _Float16 l = (_Float16)(x - (float)h);
+  _Float16* q = reinterpret_cast<_Float16*>(img + (off & ~3));
+  q[off & 3] = h;
+  q[4 + (off & 3)] = l;
+}
+__device__ __forceinline__ SbrHL sbr_split(f32x4 x) {
+  // (hi by a mask on the fp32 bits instead of a conversion and back saves 80 vector instructions per group and was SLOWER,
+  // 408 against 397 ms, and less accurate: truncation instead of rounding)
+  SbrHL o;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    o.h[e] = (_Float16)x[e];
+    o.l[e] = (_Float16)(x[e] - (float)o.h[e]);
+  }
+  return o;
+}
+__device__ __forceinline__ f32x4 sbr_mfma3(const SbrHL& a, const SbrHL& b, f32x4 c) {
+  c = __builtin_amdgcn_mfma_f32_16x16x16f16(a.h, b.h, c, 0, 0, 0);
+  c = __builtin_amdgcn_mfma_f32_16x16x16f16(a.h, b.l, c, 0, 0, 0);
+  c = __builtin_amdgcn_mfma_f32_16x16x16f16(a.l, b.h, c, 0, 0, 0);
+  return c;
+}
+constexpr float Q_ZSCALE = 256.f;
+
+__device__ __forceinline__ void sbr_q2_stash16h(const SbrQ2Fetch& f, float* buf, int tid) {
+  float* N = buf + QW * Q_RS + QW * Q_RT;
+#pragma unroll
+  for (int q = 0; q < 8; ++q) {
+    const int idx = tid + 256 * q, c = idx >> 6, rr = idx & 63;
+    const _Float16 h = (_Float16)f.v[q];
+    const _Float16 l = (_Float16)(f.v[q] - (float)h);
+    {
+      const int off = c * Q_RS + c + rr;
+      _Float16* qd = reinterpret_cast<_Float16*>(buf + (off & ~3));
+      qd[off & 3] = h;
+      qd[4 + (off & 3)] = l;
+    }
+    {
+      const int off = (c + rr) * Q_NS + c;
+      _Float16* qd = reinterpret_cast<_Float16*>(N + (off & ~3));
+      qd[off & 3] = h;
+      qd[4 + (off & 3)] = l;
+    }
+  }
+  float* T = buf + QW * Q_RS;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int idx = tid + 256 * q;
+    sbr_st_hl(T, (idx >> 5) * Q_RT + (idx & 31), f.t[q]);
+  }
+}
+
+template <bool DO>
+__device__ __forceinline__ void sbr_q2_group16h(f32x4* z, const float* buf, int vi, int g, SbrQ2Fetch& pf, const SbrQ2Args& a,
+                                                 const SbrQ2Ptr& p, int nb, int nt) {
+  const float* VgT = buf;
+  const float* T = buf + QW * Q_RS;
+  const float* N = T + QW * Q_RT;
+  if (!DO) {  // group outside the matrix: only the fetch of the next one
+    sbr_q2_fetch16v3(pf, a, p, nb, nt);
+    return;
+  }
+  SbrHL a0[5], a1[5];
+#pragma unroll
+  for (int rt = 0; rt < 5; ++rt) {
+    a0[rt] = sbr_ld_hl(VgT + vi * Q_RS + 16 * rt + 4 * g);
+    a1[rt] = sbr_ld_hl(VgT + (16 + vi) * Q_RS + 16 * (rt + 1) + 4 * g);
+  }
+  const SbrHL t00 = sbr_ld_hl(T + vi * Q_RT + 4 * g);
+  const SbrHL t01 = sbr_ld_hl(T + vi * Q_RT + 16 + 4 * g);
+  const SbrHL t11 = sbr_ld_hl(T + (16 + vi) * Q_RT + 16 + 4 * g);
+  SbrHL zs[6];
+#pragma unroll
+  for (int rt = 0; rt < 6; ++rt) zs[rt] = sbr_split(z[rt]);
+  f32x4 w0 = {0.f, 0.f, 0.f, 0.f}, w1 = {0.f, 0.f, 0.f, 0.f};
+  w0 = sbr_mfma3(a0[0], zs[0], w0);
+  w1 = sbr_mfma3(a1[0], zs[1], w1);
+  sbr_q2_fetch16v3(pf, a, p, nb, nt);  // the next group's global loads, spread over the matrix instructions by the scheduler
+#pragma unroll
+  for (int rt = 1; rt < 5; ++rt) {
+    w0 = sbr_mfma3(a0[rt], zs[rt], w0);
+    w1 = sbr_mfma3(a1[rt], zs[rt + 1], w1);
+  }
+  SbrHL n0[5], n1[5];
+#pragma unroll
+  for (int rt = 0; rt < 5; ++rt) {
+    n0[rt] = sbr_ld_hl(N + (16 * rt + vi) * Q_NS + 4 * g);
+    n1[rt] = sbr_ld_hl(N + (16 * (rt + 1) + vi) * Q_NS + 16 + 4 * g);
+  }
+  const SbrHL w0s = sbr_split(w0), w1s = sbr_split(w1);
+  f32x4 u0 = {0.f, 0.f, 0.f, 0.f}, u1 = {0.f, 0.f, 0.f, 0.f}, u2 = {0.f, 0.f, 0.f, 0.f};
+  u0 = sbr_mfma3(t00, w0s, u0);
+  u1 = sbr_mfma3(t11, w1s, u1);
+  u2 = sbr_mfma3(t01, w1s, u2);
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    u0[e] = -(u0[e] + u2[e]);
+    u1[e] = -u1[e];
+  }
+  const SbrHL u0s = sbr_split(u0), u1s = sbr_split(u1);
+#pragma unroll
+  for (int rt = 0; rt < 5; ++rt) {
+    z[rt] = sbr_mfma3(n0[rt], u0s, z[rt]);
+    z[rt + 1] = sbr_mfma3(n1[rt], u1s, z[rt + 1]);
+  }
+}
+
+template <int QJ, int QNT>
+__global__ __launch_bounds__(256, 1) void sbr_q2_apply16h(SbrQ2Args a) {
+  __shared__ __attribute__((aligned(16))) float lds[2 * Q_BUF3];
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, vi = lane & 15, g = lane >> 4;
+  const int64_t v = (int64_t)blockIdx.x * 64 + wv * 16 + vi;
+  const bool live = v < a.m;
+  float* zrow = a.Zq + (live ? v : 0) * a.ldq + 3;
+  for (int i = tid; i < 2 * Q_BUF3; i += 256) lds[i] = 0.f;  // outside the parallelogram the images stay zero (hi = lo = 0)
+  __syncthreads();
+  const int nsb = (a.nblk + QJ - 1) / QJ;
+  SbrQ2Ptr p;
+  p.vstride = a.ldv2 + 1;
+  p.v = a.V2 + (int64_t)wv * p.vstride + 1 + lane;
+  p.tg = a.Tg + tid;
+  SbrQ2Fetch pf;
+  sbr_q2_fetch16v3(pf, a, p, a.nblk - 1, 0);
+  sbr_q2_stash16h(pf, lds, tid);
+  __syncthreads();
+  int cur = 0;
+  f32x4 z[QNT];
+  for (int sb = 0; sb < nsb; ++sb) {
+    const int bh = a.nblk - 1 - sb * QJ, blow = bh - QJ + 1;
+    const int Kmax = sbr_tasks_of((int64_t)(blow > 0 ? blow : 0) * QW, a.n);
+    const int64_t base0 = (int64_t)blow * QW + 1;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the stores of the previous pass have left before rows are re-read
+#pragma unroll
+    for (int i = 0; i < QNT; ++i) z[i] = sbr_q2_ldz(zrow, base0 + 16 * i + 4 * g, a.n, live) * Q_ZSCALE;
+    for (int t = 0; t < Kmax; ++t) {
+      const int64_t base = base0 + (int64_t)t * SB;
+      f32x4 pz[4];
+      const bool more = t + 1 < Kmax;
+      if (more) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) pz[i] = sbr_q2_ldz(zrow, base + 16 * (QNT + i) + 4 * g, a.n, live) * Q_ZSCALE;
+      }
+#pragma unroll
+      for (int j = 0; j < QJ; ++j) {
+        int nb, nt;  // the group after this one in the sequence
+        if (j + 1 < QJ) {
+          nb = bh - (j + 1);
+          nt = t;
+        } else if (more) {
+          nb = bh;
+          nt = t + 1;
+        } else {
+          nb = bh - QJ;
+          nt = 0;
+        }
+        const int b = bh - j;
+        if (b >= 0 && t < sbr_tasks_of((int64_t)b * QW, a.n))
+          sbr_q2_group16h<true>(z + 2 * (QJ - 1 - j), lds + cur * Q_BUF3, vi, g, pf, a, p, nb, nt);
+        else
+          sbr_q2_group16h<false>(z + 2 * (QJ - 1 - j), lds + cur * Q_BUF3, vi, g, pf, a, p, nb, nt);
+        sbr_q2_stash16h(pf, lds + (cur ^ 1) * Q_BUF3, tid);
+        __syncthreads();
+        cur ^= 1;
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) sbr_q2_stz(zrow, base + 16 * i + 4 * g, a.n, live, z[i] * (1.f / Q_ZSCALE));
+      if (more) {
+#pragma unroll
+        for (int i = 0; i + 4 < QNT; ++i) z[i] = z[i + 4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) z[QNT - 4 + i] = pz[i];
+      } else {
+#pragma unroll
+        for (int i = 4; i < QNT; ++i) sbr_q2_stz(zrow, base + 16 * i + 4 * g, a.n, live, z[i] * (1.f / Q_ZSCALE));
+      }
+    }
+  }
+}
+
+// ---- variants 6 (fp32 products) and 7 (split-fp16 products): the reflectors of a group are fetched TWO groups ahead. Variant 5 cut
+// the matrix-pipe time of a group from ~2 900 to ~600 cycles and the kernel took as long as before (518 against 503 ms at
+// n = 30 016, m = 15 008): a group's loads were issued during the previous group and waited for at its end, and one group is about
+// one HBM round trip under load (~5 000 cycles) -- every variant of this kernel was bound by that wait, whatever it did in between.
+template <int QJ, int QNT, bool F16>
+__global__ __launch_bounds__(256, 1) void sbr_q2_apply16d(SbrQ2Args a) {
+  __shared__ __attribute__((aligned(16))) float lds[2 * Q_BUF3];
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, vi = lane & 15, g = lane >> 4;
+  const int64_t v = (int64_t)blockIdx.x * 64 + wv * 16 + vi;
+  const bool live = v < a.m;
+  float* zrow = a.Zq + (live ? v : 0) * a.ldq + 3;
+  const float zs = F16 ? Q_ZSCALE : 1.f, izs = F16 ? 1.f / Q_ZSCALE : 1.f;
+  for (int i = tid; i < 2 * Q_BUF3; i += 256) lds[i] = 0.f;  // outside the parallelogram the images stay zero
+  __syncthreads();
+  const int nsb = (a.nblk + QJ - 1) / QJ;
+  SbrQ2Ptr p;
+  p.vstride = a.ldv2 + 1;
+  p.v = a.V2 + (int64_t)wv * p.vstride + 1 + lane;
+  p.tg = a.Tg + tid;
+  SbrQ2Fetch pa, pb;  // pa: the next group's data (in flight since the previous group), pb: the one after it (issued in this group)
+  sbr_q2_fetch16v3(pa, a, p, a.nblk - 1, 0);
+  if (F16) sbr_q2_stash16h(pa, lds, tid); else sbr_q2_stash16v3(pa, lds, tid);
+  sbr_q2_fetch16v3(pa, a, p, a.nblk - 2, 0);  // QJ > 1: the second group of the sequence is block nblk - 2, task 0
+  __syncthreads();
+  int cur = 0;
+  f32x4 z[QNT];
+  for (int sb = 0; sb < nsb; ++sb) {
+    const int bh = a.nblk - 1 - sb * QJ, blow = bh - QJ + 1;
+    const int Kmax = sbr_tasks_of((int64_t)(blow > 0 ? blow : 0) * QW, a.n);
+    const int64_t base0 = (int64_t)blow * QW + 1;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the stores of the previous pass have left before rows are re-read
+#pragma unroll
+    for (int i = 0; i < QNT; ++i) z[i] = sbr_q2_ldz(zrow, base0 + 16 * i + 4 * g, a.n, live) * zs;
+    for (int t = 0; t < Kmax; ++t) {
+      const int64_t base = base0 + (int64_t)t * SB;
+      f32x4 pz[4];
+      const bool more = t + 1 < Kmax;
+      if (more) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) pz[i] = sbr_q2_ldz(zrow, base + 16 * (QNT + i) + 4 * g, a.n, live) * zs;
+      }
+#pragma unroll
+      for (int j = 0; j < QJ; ++j) {
+        int nb, nt;  // the group TWO steps after this one in the sequence (j ascending inside a task, then the next task, then the next pass)
+        if (j + 2 < QJ) {
+          nb = bh - (j + 2);
+          nt = t;
+        } else if (more) {
+          nb = bh - (j + 2 - QJ);
+          nt = t + 1;
+        } else {
+          nb = bh - QJ - (j + 2 - QJ);
+          nt = 0;
+        }
+        const int b = bh - j;
+        const bool on = b >= 0 && t < sbr_tasks_of((int64_t)b * QW, a.n);
+        if (F16) {
+          if (on) sbr_q2_group16h<true>(z + 2 * (QJ - 1 - j), lds + cur * Q_BUF3, vi, g, pb, a, p, nb, nt);
+          else sbr_q2_group16h<false>(z + 2 * (QJ - 1 - j), lds + cur * Q_BUF3, vi, g, pb, a, p, nb, nt);
+          sbr_q2_stash16h(pa, lds + (cur ^ 1) * Q_BUF3, tid);
+        } else {
+          if (on) sbr_q2_group16v3<true>(z + 2 * (QJ - 1 - j), lds + cur * Q_BUF3, vi, g, pb, a, p, nb, nt);
+          else sbr_q2_group16v3<false>(z + 2 * (QJ - 1 - j), lds + cur * Q_BUF3, vi, g, pb, a, p, nb, nt);
+          sbr_q2_stash16v3(pa, lds + (cur ^ 1) * Q_BUF3, tid);
+        }
+        pa = pb;
+        __syncthreads();
+        cur ^= 1;
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) sbr_q2_stz(zrow, base + 16 * i + 4 * g, a.n, live, z[i] * izs);
+      if (more) {
+#pragma unroll
+        for (int i = 0; i + 4 < QNT; ++i) z[i] = z[i + 4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) z[QNT - 4 + i] = pz[i];
+      } else {
+#pragma unroll
+        for (int i = 4; i < QNT; ++i) sbr_q2_stz(zrow, base + 16 * i + 4 * g, a.n, live, z[i] * izs);
+      }
+    }
+  }
+}
+
 // Zq[v][3 + r] <-> Zt[v][r]
 __global__ void sbr_q2_shift(const float* __restrict__ in, int64_t ldi, int64_t offi, float* __restrict__ out, int64_t ldo,
                              int64_t offo, int64_t n) {
@@ -2192,12 +2489,23 @@ int sbr_apply_q2(Ctx* ctx, int64_t n, float* Zt, int64_t m, int64_t ldz) {
   // step of four groups instead of one per group (533 ms), 2 / 8 sweep blocks per pass (599 / 1020 ms), wave-uniform scalar
   // addressing of the group fetch (554 ms). PMC (profiles/r02_pmc_eig.txt): the MFMA pipe is busy 55 % of the wave cycles, 33 %
   // of them issue other instructions, 23 % wait at barriers / waitcnt.
-  static const int q2_variant = getenv("SCLENS_HIP_Q2_VARIANT") ? atoi(getenv("SCLENS_HIP_Q2_VARIANT")) : 3;  // A/B measurements
+  // 7 (default): split-fp16 products, reflectors fetched two groups ahead -- 397 ms against 500 ms for 3 (fp32 products, one group
+  // ahead; the default until round 3) at n = 30 016, m = 15 008, orthogonality of the result 5.1e-7 against 4.6e-7
+  // (profiles/r03_q2_variants.log). 6 = 3 with the deeper fetch (same bits, same time), 5 = 7 with the shallow one (same bits as 7,
+  // 517 ms), 0 / 1: the round-2 kernel. SCLENS_HIP_Q2_VARIANT=3 keeps every product of the solver on the fp32 matrix cores.
+  const char* eq2 = getenv("SCLENS_HIP_Q2_VARIANT");
+  const int q2_variant = eq2 ? atoi(eq2) : 7;
   const dim3 q2grid((unsigned)((m + 63) / 64));
   if (q2_variant == 0)
     hipLaunchKernelGGL((sbr_q2_apply16<4, 12, false>), q2grid, dim3(256), 0, ctx->stream, qa);
   else if (q2_variant == 1)
     hipLaunchKernelGGL((sbr_q2_apply16<4, 12, true>), q2grid, dim3(256), 0, ctx->stream, qa);
+  else if (q2_variant == 5)
+    hipLaunchKernelGGL((sbr_q2_apply16h<4, 12>), q2grid, dim3(256), 0, ctx->stream, qa);
+  else if (q2_variant == 6)
+    hipLaunchKernelGGL((sbr_q2_apply16d<4, 12, false>), q2grid, dim3(256), 0, ctx->stream, qa);
+  else if (q2_variant == 7)
+    hipLaunchKernelGGL((sbr_q2_apply16d<4, 12, true>), q2grid, dim3(256), 0, ctx->stream, qa);
   else
     hipLaunchKernelGGL((sbr_q2_apply16v3<4, 12>), q2grid, dim3(256), 0, ctx->stream, qa);
   for (int64_t r0 = 0; r0 < m; r0 += 65535) {

@@ -41,12 +41,14 @@ def _band_of(out):
     return low + np.tril(low, -1).T
 
 
-@pytest.fixture(params=["default", "delayed"])
+@pytest.fixture(params=["default", "delayed", "split", "delayed+split"])
 def delayed_update(request, monkeypatch):
     """sy2sb applies the trailing updates of two panels as one rank-256 update while the trailing matrix is large (from order
-    18 432 by default); "delayed" turns that on from order 321, so that the small cases here go through it."""
-    if request.param == "delayed":
+    18 432 by default), and runs trailing updates of at least 4 096 rows on the fp16 matrix cores from split operands; "delayed"
+    turns the first on from order 321, "split" the second from 512 rows, so that the small cases here go through them."""
+    if "delayed" in request.param:
         monkeypatch.setenv("SCLENS_HIP_SY2SB_DELAY_MIN", "321")
+    monkeypatch.setenv("SCLENS_HIP_SY2SB_SPLIT", "512" if "split" in request.param else "0")
     return request.param
 
 
@@ -275,8 +277,9 @@ def test_switches_that_only_move_work_give_the_same_bits(ctx, n, lo, hi, monkeyp
     assert np.abs(Z @ A64 - got[0][0][lo:hi, None] * Z).max() < 5e-5 * np.abs(got[0][0]).max() * np.sqrt(n / 64 + 1)
 
 
+@pytest.mark.parametrize("variant", ["7", "3"])
 @pytest.mark.parametrize("n,m", [(192, 192), (1088, 100), (2560, 70), (640, 641 - 1)])
-def test_second_back_transformation_matches_the_unblocked_reference(ctx, n, m, monkeypatch):
+def test_second_back_transformation_matches_the_unblocked_reference(ctx, n, m, variant, monkeypatch):
     """The register-resident MFMA version of Q2 (16-vector wave tiles, QJ sweep blocks per pass) against the one-reflector-at-
     a-time reference kernel on the same reflectors: vector counts that are not multiples of 16 / 64, several super-blocks."""
     A = _sym_psd(n, 13 * n + 5)
@@ -291,6 +294,7 @@ def test_second_back_transformation_matches_the_unblocked_reference(ctx, n, m, m
     Z0 = np.zeros((m, lda), dtype=np.float32)
     Z0[:, :n] = rng.standard_normal((m, n)) / np.sqrt(n)
     outs = []
+    monkeypatch.setenv("SCLENS_HIP_Q2_VARIANT", variant)  # 7: split-fp16 products (default), 3: fp32 products
     for ref in (True, False):
         if ref:
             monkeypatch.setenv("SCLENS_HIP_Q2_REFERENCE", "1")
@@ -306,6 +310,40 @@ def test_second_back_transformation_matches_the_unblocked_reference(ctx, n, m, m
     assert np.abs(outs[0] - outs[1]).max() < 2e-5 * np.abs(outs[0]).max() * np.sqrt(n / 64)
     # orthogonal transformation: norms are preserved
     assert np.abs(np.linalg.norm(outs[1], axis=1) - np.linalg.norm(Z0[:, :n].astype(np.float64), axis=1)).max() < 1e-4
+
+
+def test_second_back_transformation_variants(ctx, monkeypatch):
+    """Variants that differ only in WHEN the reflectors are fetched give the same bits (6 = 3: fp32 products; 5 = 7: split-fp16
+    products); the split-fp16 products (three fp16 matrix instructions with fp32 accumulation per product, 22-bit operands) stay
+    within 4e-6 of the fp32 ones on unit vectors and keep orthonormal rows orthonormal to 2e-6."""
+    n, m = 1344, 130
+    A = _sym_psd(n, 5 * n + 1)
+    lda = rup(n, 32)
+    dA = DevArray(ctx, pad_rows(A, lda))
+    dT = DevArray(ctx, nbytes=4 * max(1, n // SB - 1) * SB * SB)
+    dd, de = DevArray(ctx, nbytes=8 * n), DevArray(ctx, nbytes=8 * n)
+    bd = C.c_int(-1)
+    ctx.check(ctx.lib.sclens_hip_dev_sy2sb_f32(ctx.h, dA.p, n, lda, dT.p, C.byref(bd)))
+    ctx.check(ctx.lib.sclens_hip_dev_sb2st_f32(ctx.h, dA.p, n, lda, dd.p, de.p))
+    rng = np.random.default_rng(5)
+    Q, _ = np.linalg.qr(rng.standard_normal((n, m)))
+    Z0 = np.zeros((m, lda), dtype=np.float32)
+    Z0[:, :n] = Q.T.astype(np.float32)
+    out = {}
+    for v in ("3", "6", "5", "7"):
+        monkeypatch.setenv("SCLENS_HIP_Q2_VARIANT", v)
+        dZ = DevArray(ctx, Z0)
+        ctx.check(ctx.lib.sclens_hip_dev_sbr_apply_q2_f32(ctx.h, n, dZ.p, m, lda))
+        ctx.sync()
+        out[v] = dZ.get((m, lda), np.float32)[:, :n]
+        dZ.free()
+    for x in (dA, dT, dd, de):
+        x.free()
+    assert np.array_equal(out["3"], out["6"]) and np.array_equal(out["5"], out["7"])
+    assert np.abs(out["7"].astype(np.float64) - out["3"]).max() < 4e-6
+    for v in ("3", "7"):
+        Z = out[v].astype(np.float64)
+        assert np.abs(Z @ Z.T - np.eye(m)).max() < 2e-6, v
 
 
 def test_sclens_with_the_two_stage_solver(ctx, monkeypatch):
