@@ -29,7 +29,7 @@ Prints ONE JSON line on rank 0 (contract in the task statement) with two extra o
                  `stages` holds the same ratio for every stage of one decomposition, the Gram launch included.
   cpu_baseline : the oracle (float64 NumPy/SciPy port of the reference CPU path) timed on the host cores on two bounded
                  samples (the exponent of the eigensolver's cost is fitted, not assumed), stage-extrapolated to the workload.
-  extra.strict_fp32 : one further step with every fp16-MFMA product switched off (SCLENS_HIP_GRAM_BITS=0 SCLENS_HIP_Q2_VARIANT=3),
+  extra.strict_fp32 : one further step with every fp16-MFMA product switched off (SCLENS_HIP_GRAM_BITS=0 ..._SPLIT=0 SCLENS_HIP_Q2_VARIANT=3),
                  so that the fp16-assisted and the strict fp32 wall-clock are both timed by the same run.
 """
 import argparse
@@ -485,8 +485,9 @@ def main():
     n_min = min(N, M)
     want_strict = args.strict_fp32 == "on" or (args.strict_fp32 == "auto" and n_min >= 16000 and not main_r["row_shard"])
     if want_strict and steps > 0 and not agree(time.perf_counter() + 1.4 * dt / max(1, steps) > deadline - reserve):
-        strict_env = {"SCLENS_HIP_GRAM_BITS": "0",   # worker contexts created inside sclens() read it
-                      "SCLENS_HIP_Q2_VARIANT": "3"}  # second back-transformation: fp32 products instead of split-fp16 ones
+        strict_env = {"SCLENS_HIP_GRAM_BITS": "0",   # worker contexts created inside sclens() read it (also: no split-fp16 Gram)
+                      "SCLENS_HIP_GRAM_SPLIT": "0", "SCLENS_HIP_SY2SB_SPLIT": "0", "SCLENS_HIP_Q1_SPLIT": "0",
+                      "SCLENS_HIP_Q2_VARIANT": "3"}  # eigensolver: fp32 products instead of split-fp16 ones
         old_env = {k: os.environ.get(k) for k in strict_env}
         os.environ.update(strict_env)
         ctx.set_option("gram_bits", 0)
@@ -503,8 +504,8 @@ def main():
             extra["strict_fp32"] = {"sclens_wall_s": round(r["dt"], 3), "value": round(r["N"] * r["M"] / r["dt"], 1),
                                     "search_iters": int(r["res"]["n_search"]), "signals": int(len(r["res"].get("signal_ev", []))),
                                     "p_": r["res"]["p_"], "gram_bits_used": int(r["res"].get("gram_bits_used", -1)),
-                                    "note": "SCLENS_HIP_GRAM_BITS=0 SCLENS_HIP_Q2_VARIANT=3: every Gram product, the search statistic and the second "
-                                            "back-transformation on the fp32 MFMA (no fp16 operand anywhere on the path)"}
+                                    "note": "SCLENS_HIP_GRAM_BITS=0 SCLENS_HIP_GRAM_SPLIT=0 SCLENS_HIP_SY2SB_SPLIT=0 SCLENS_HIP_Q1_SPLIT=0 "
+                                            "SCLENS_HIP_Q2_VARIANT=3: every product of the path on the fp32 MFMA (no fp16 operand anywhere)"}
     # ---- extra configs (one timed step each), while the budget lasts
     for cfg in [c for c in args.extra_configs.split(",") if c]:
         if agree(time.perf_counter() + 60 > deadline - reserve):

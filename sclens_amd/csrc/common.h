@@ -175,7 +175,7 @@ int split_image_scaled(Ctx* ctx, const float* src, int64_t rows, int64_t K, int6
 int split_image_pair_scaled(Ctx* ctx, const float* src1, const float* src2, int64_t rows, int64_t K, int64_t ld, void* dst1, void* dst2,
                             float* scale_dev);
 int gemm_split_update(Ctx* ctx, const void* Pimg, const float* sP, int64_t M, const void* Qimg, const float* sQ, int64_t N, int64_t K,
-                      float* C, int64_t ldc, int lower);
+                      float* C, int64_t ldc, int lower, float post = 1.f);  // C += post * P Q'; long contractions walk the tile list
 
 // ------------------------------------------------------------------ eigensolver (tridiag.hip, trieig.hip)
 // Symmetric eigensolver on a device-resident n x n fp32 matrix A (row-major, lda, FULL storage,

@@ -435,7 +435,11 @@ __global__ __launch_bounds__(256) void k_absmax_bits(const float* __restrict__ s
     for (int64_t k = threadIdx.x; k < K; k += 256) mx = fmaxf(mx, fabsf(src[r * ld + k]));
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
-  if ((threadIdx.x & 63) == 0) atomicMax(out, __float_as_uint(mx));  // non-negative floats order like their bit patterns
+  __shared__ float wmx[4];
+  if ((threadIdx.x & 63) == 0) wmx[threadIdx.x >> 6] = mx;
+  __syncthreads();
+  // one atomic per workgroup (8 192 atomics on one word took 0.7 ms per call); non-negative floats order like their bit patterns
+  if (threadIdx.x == 0) atomicMax(out, __float_as_uint(fmaxf(fmaxf(wmx[0], wmx[1]), fmaxf(wmx[2], wmx[3]))));
 }
 __global__ void k_pick_scale(const unsigned* __restrict__ mxbits, float* __restrict__ scale) {
   const float mx = __uint_as_float(mxbits[0]);
@@ -489,6 +493,8 @@ struct SplitUpdArgs {
   int64_t ldc;
   int lower;
   int tiles_n;
+  float post;          // C += post * P Q'
+  const int2* tiles;   // tile list (compact squares per XCD, gemm.hip) for long contractions, or nullptr: decoded from the block index
 };
 
 // The main loop of corr_split_kernel with the tile decode, the accumulator start from C and the lower + mirror epilogue of
@@ -498,7 +504,10 @@ __global__ __launch_bounds__(512, 2) void gemm_split_kernel(SplitUpdArgs a) {
   constexpr int OPB = 256 * 128, STAGE = 2 * OPB;
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
   int2 tl;
-  {
+  if (a.tiles) {
+    tl = a.tiles[blockIdx.x];
+    if (tl.x < 0) return;
+  } else {
     const unsigned nwg = gridDim.x, bid = blockIdx.x;
     const unsigned q = nwg >> 3, r = nwg & 7u, xcd = bid & 7u;
     const unsigned t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
@@ -539,21 +548,21 @@ __global__ __launch_bounds__(512, 2) void gemm_split_kernel(SplitUpdArgs a) {
       __builtin_amdgcn_global_load_lds((glb_void_t*)(srcB[i] + kt * 64), (lds_void_t*)(Bs + (wid * 4 + i) * 1024), 16, 0, 0);
   };
   stage(0, 0);
-  const float sprod = a.sA[0] * a.sB[0];  // powers of two: the products below are exact scalings
-  const float alpha = 1.f / sprod;
+  const float alpha = a.post / (a.sA[0] * a.sB[0]);  // the scales are powers of two
+  // 32-bit indices relative to the tile's corner (and to the corner of its mirror image): the 64-bit row * ldc + col of every
+  // element cost this kernel 191 spilled registers
+  float* Ct = a.C + m0 * a.ldc + n0;
+  float* Cm = a.C + n0 * a.ldc + m0;
+  const int ldc = (int)a.ldc;
+  const int mrem = (int)((a.M - m0 < 256) ? a.M - m0 : 256), nrem = (int)((a.N - n0 < 256) ? a.N - n0 : 256);
+  const int diag = a.lower ? (int)(m0 - n0) : 0x40000000;  // lower: element (r, c) of the tile is kept for c <= r + diag
   v16f acc[TM][TN];
 #pragma unroll
   for (int i = 0; i < TM; ++i)
 #pragma unroll
-    for (int j = 0; j < TN; ++j) {
-      const int64_t col = n0 + wn * (32 * TN) + j * 32 + l31;
-      const int64_t row0 = m0 + wm * (32 * TM) + i * 32 + 4 * h;
+    for (int j = 0; j < TN; ++j)
 #pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        const int64_t row = row0 + (e & 3) + 8 * (e >> 2);
-        acc[i][j][e] = (row < a.M && col < a.N && (!a.lower || col <= row)) ? a.C[row * a.ldc + col] * sprod : 0.f;
-      }
-    }
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
   int offA[TM], offB[TN], swA[TM], swB[TN];
 #pragma unroll
   for (int i = 0; i < TM; ++i) {
@@ -602,28 +611,36 @@ __global__ __launch_bounds__(512, 2) void gemm_split_kernel(SplitUpdArgs a) {
   for (int i = 0; i < TM; ++i)
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
-      const int64_t col = n0 + wn * (32 * TN) + j * 32 + l31;
-      const int64_t row0 = m0 + wm * (32 * TM) + i * 32 + 4 * h;
-      v16f outv;
-#pragma unroll
-      for (int e = 0; e < 16; ++e) outv[e] = acc[i][j][e] * alpha;
+      const int c = wn * (32 * TN) + j * 32 + l31;
+      const int r0 = wm * (32 * TM) + i * 32 + 4 * h;
+      // C is read per 32 x 32 tile here (all 16 loads before the first store): started from C, the accumulators + their 128
+      // address registers did not fit 256 registers at two waves per SIMD (191 spilled), and with 5 us of matrix work per tile
+      // there is nothing to hide the loads behind anyway
+      float cin[16];
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
-        const int64_t row = row0 + (e & 3) + 8 * (e >> 2);
-        if (row < a.M && col < a.N && (!a.lower || col <= row)) a.C[row * a.ldc + col] = outv[e];
+        const int r = r0 + (e & 3) + 8 * (e >> 2);
+        cin[e] = (r < mrem && c < nrem && c <= r + diag) ? Ct[r * ldc + c] : 0.f;
       }
-      if (a.lower && col < a.N) {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = fmaf(acc[i][j][e], alpha, cin[e]);
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int r = r0 + (e & 3) + 8 * (e >> 2);
+        if (r < mrem && c < nrem && c <= r + diag) Ct[r * ldc + c] = acc[i][j][e];
+      }
+      if (a.lower && c < nrem) {  // mirror image: element (c, r) of the matrix for the strictly lower part
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-          const int64_t rowq = row0 + 8 * q;
-          if (vec_mirror && rowq + 3 < a.M && col < rowq) {
+          const int rq = r0 + 8 * q;
+          if (vec_mirror && rq + 3 < mrem && c < rq + diag) {
             typedef float f32x4_ __attribute__((ext_vector_type(4)));
-            f32x4_ v = {outv[4 * q], outv[4 * q + 1], outv[4 * q + 2], outv[4 * q + 3]};
-            *reinterpret_cast<f32x4_*>(&a.C[col * a.ldc + rowq]) = v;
+            f32x4_ v = {acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]};
+            *reinterpret_cast<f32x4_*>(&Cm[c * ldc + rq]) = v;
           } else {
 #pragma unroll
             for (int u = 0; u < 4; ++u)
-              if (rowq + u < a.M && col < rowq + u) a.C[col * a.ldc + rowq + u] = outv[4 * q + u];
+              if (rq + u < mrem && c < rq + u + diag) Cm[c * ldc + rq + u] = acc[i][j][4 * q + u];
           }
         }
       }
@@ -692,7 +709,7 @@ int split_image_scaled(Ctx* ctx, const float* src, int64_t rows, int64_t K, int6
   hipStream_t st = ctx->stream;
   unsigned* mx = reinterpret_cast<unsigned*>(scale_dev + 1);
   SCL_HIP(ctx, hipMemsetAsync(mx, 0, sizeof(unsigned), st));
-  hipLaunchKernelGGL(k_absmax_bits, dim3((unsigned)std::min<int64_t>(rows, 2048)), dim3(256), 0, st, src, rows, K, ld, mx);
+  hipLaunchKernelGGL(k_absmax_bits, dim3((unsigned)std::min<int64_t>(rows, 256)), dim3(256), 0, st, src, rows, K, ld, mx);
   hipLaunchKernelGGL(k_pick_scale, dim3(1), dim3(1), 0, st, mx, scale_dev);
   hipLaunchKernelGGL(k_split_image_scaled, dim3((unsigned)((Kp + 255) / 256), (unsigned)std::min<int64_t>(rows, 65535)), dim3(256), 0, st,
                      src, rows, K, ld, Kp, scale_dev, static_cast<_Float16*>(dst));
@@ -707,7 +724,7 @@ int split_image_pair_scaled(Ctx* ctx, const float* src1, const float* src2, int6
   hipStream_t st = ctx->stream;
   unsigned* mx = reinterpret_cast<unsigned*>(scale_dev + 1);
   SCL_HIP(ctx, hipMemsetAsync(mx, 0, sizeof(unsigned), st));
-  hipLaunchKernelGGL(k_absmax_bits, dim3((unsigned)std::min<int64_t>(rows, 2048)), dim3(256), 0, st, src1, rows, K, ld, mx);
+  hipLaunchKernelGGL(k_absmax_bits, dim3((unsigned)std::min<int64_t>(rows, 256)), dim3(256), 0, st, src1, rows, K, ld, mx);
   hipLaunchKernelGGL(k_pick_scale, dim3(1), dim3(1), 0, st, mx, scale_dev);
   hipLaunchKernelGGL(k_split_image_pair_scaled, dim3((unsigned)((Kp + 255) / 256), (unsigned)std::min<int64_t>(rows, 65535)), dim3(256), 0,
                      st, src1, src2, rows, K, ld, Kp, scale_dev, static_cast<_Float16*>(dst1), static_cast<_Float16*>(dst2));
@@ -716,16 +733,18 @@ int split_image_pair_scaled(Ctx* ctx, const float* src1, const float* src2, int6
 }
 
 int gemm_split_update(Ctx* ctx, const void* Pimg, const float* sP, int64_t M, const void* Qimg, const float* sQ, int64_t N, int64_t K,
-                      float* C, int64_t ldc, int lower) {
+                      float* C, int64_t ldc, int lower, float post) {
   if (M <= 0 || N <= 0) return SCLENS_OK;
   if (lower && M != N) return ctx->fail(SCLENS_ERR_ARG, "gemm_split_update: lower needs M == N");
   const int64_t bm = (M + 255) / 256, bn = (N + 255) / 256;
-  const int64_t nb = lower ? bm * (bm + 1) / 2 : bm * bn;
+  int64_t nb = lower ? bm * (bm + 1) / 2 : bm * bn;
   if (nb > 0x7fffffffLL) return ctx->fail(SCLENS_ERR_ARG, "gemm_split_update: too many tiles");
+  const int2* tiles = nullptr;
+  if (K >= 2048 && nb >= 1500) SCL_TRY(big_tile_list(ctx, bm, bn, lower, &tiles, &nb));  // operand panels re-used out of the L2s
   constexpr int LDS_BYTES = 2 * 2 * 256 * 128;
   SCL_TRY(ensure_dyn_lds(ctx, reinterpret_cast<const void*>(gemm_split_kernel), LDS_BYTES));
   SplitUpdArgs a{static_cast<const _Float16*>(Pimg), static_cast<const _Float16*>(Qimg), sP, sQ, M, N, round_up(K, 32), C, ldc, lower,
-                 (int)bn};
+                 (int)bn, post, tiles};
   hipLaunchKernelGGL(gemm_split_kernel, dim3((unsigned)nb), dim3(512), LDS_BYTES, ctx->stream, a);
   SCL_HIP(ctx, hipGetLastError());
   return SCLENS_OK;

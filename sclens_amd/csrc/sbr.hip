@@ -655,7 +655,7 @@ int sy2sb_f32(Ctx* ctx, float* A, int64_t n, int64_t lda, float* Tall, int* brea
   // Trailing updates of at least `split_min` rows run on the fp16 matrix cores from operands split into two fp16 pieces
   // (gemm_split_update in gram_bits.hip: 22-bit operands, fp32 accumulation started from C -- the rank-128 / rank-256 update is then
   // C traffic only: 27 us of fp32 matrix-pipe time per 128 of K and 256 x 256 tile become 5). SCLENS_HIP_SY2SB_SPLIT=0: fp32 products.
-  int64_t split_min = (int64_t)1 << 60;  // off unless SCLENS_HIP_SY2SB_SPLIT=<rows> (> 0)
+  int64_t split_min = 4096;
   if (const char* ev = getenv("SCLENS_HIP_SY2SB_SPLIT")) split_min = atoi(ev) > 0 ? std::max<int64_t>(512, atoll(ev)) : (int64_t)1 << 60;
   const bool any_split = n >= split_min;
   void* imgP = any_split ? ctx->workspace("sbr.imgP", split_image_bytes(n, LDU)) : nullptr;
@@ -972,6 +972,16 @@ int sbr_apply_q1(Ctx* ctx, const float* A, int64_t n, int64_t lda, const float* 
   SCL_WS(ctx, W1, float, "sbr.W1", m * (int64_t)SMAX * Q1W);
   SCL_WS(ctx, Ws, float, "sbr.Ws", m * (int64_t)Q1W);
   SCL_WS(ctx, W2, float, "sbr.W2", m * (int64_t)Q1W);
+  // The read-modify-write product of a group, Zt += W2 Vm, on the fp16 matrix cores from split operands when it is large enough
+  // (gemm_split_update: 22-bit operands, fp32 accumulation, C added in the epilogue): at K = 512 the fp32 matrix-pipe time is four
+  // fifths of the product. SCLENS_HIP_Q1_SPLIT=0: fp32 products.
+  const char* eqs = getenv("SCLENS_HIP_Q1_SPLIT");  // 0: off; N > 0: from N vectors and N rows (default 1024)
+  const int64_t q1_min = eqs ? atoll(eqs) : 1024;
+  const bool q1_split = q1_min > 0 && m >= q1_min;
+  void* imgW = q1_split ? ctx->workspace("sbr.q1imgW", split_image_bytes(m, Q1W)) : nullptr;
+  void* imgV = q1_split ? ctx->workspace("sbr.q1imgV", split_image_bytes(n, Q1W)) : nullptr;
+  float* imgS = q1_split ? static_cast<float*>(ctx->workspace("sbr.q1imgS", 8 * sizeof(float))) : nullptr;
+  if (q1_split && (!imgW || !imgV || !imgS)) return SCLENS_ERR_OOM;
   hipStream_t st = ctx->stream;
   for (int64_t g = ngrp - 1; g >= 0; --g) {
     const int64_t p0 = g * Q1G;
@@ -1015,7 +1025,11 @@ int sbr_apply_q1(Ctx* ctx, const float* A, int64_t n, int64_t lda, const float* 
       g2.alpha = -1.f; g2.beta = 0.f; g2.q_kcontig = 1; g2.lower = 0; g2.colabsmax = nullptr;  // W2 = -(...): g3 then adds
       SCL_TRY(gemm_f32(ctx, g2));
     }
-    {  // Zt[:, r0:] += W2 Vm   (NT against the transposed copy; accumulators started from Zt)
+    if (q1_split && np >= q1_min) {  // Zt[:, r0:] += W2 Vm from split images
+      SCL_TRY(split_image_scaled(ctx, W2, m, Q1W, Q1W, imgW, imgS));
+      SCL_TRY(split_image_scaled(ctx, VmT, np, Q1W, Q1W, imgV, imgS + 4));
+      SCL_TRY(gemm_split_update(ctx, imgW, imgS, m, imgV, imgS + 4, np, Q1W, Zt + r0, ldz, 0));
+    } else {  // Zt[:, r0:] += W2 Vm   (NT against the transposed copy; accumulators started from Zt)
       GemmArgs g3{};
       g3.P = W2; g3.Q = VmT; g3.C = Zt + r0;
       g3.M = m; g3.N = np; g3.K = Q1W;

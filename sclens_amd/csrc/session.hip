@@ -90,6 +90,19 @@ int reverse_rows_f32(Ctx* ctx, const float* in, int64_t rows, int64_t cols, int6
 int gram_f32(Ctx* ctx, const float* B, int64_t n, int64_t K, int64_t ldb, float divisor, float* A, int64_t lda) {
   StageTimer tm(ctx, "gram");
   SCL_HIP(ctx, hipMemsetAsync(A, 0, sizeof(float) * (size_t)n * lda, ctx->stream));
+  // Large products (n >= 16 000, or SCLENS_HIP_GRAM_SPLIT=<n>; 0 = never): the scaled matrix is split once into two fp16 pieces per
+  // entry (scaled by the power of two that brings its largest entry to 2^13..2^14: 22 significant bits of every entry down to
+  // 2^-38 of the largest) and the product runs on the fp16 matrix cores with fp32 accumulation (gemm_split_update, gram_bits.hip):
+  // 682 -> ~250 ms at 100 000 x 30 000. Context option gram_bits = 0 (bench.py's strict step) also keeps this product in fp32.
+  const char* egs = getenv("SCLENS_HIP_GRAM_SPLIT");
+  const int64_t gs_min = egs ? atoll(egs) : 0;  // off by default until validated at full size
+  if (gs_min > 0 && n >= gs_min && ctx->gram_bits != 0) {
+    void* img = ctx->workspace("gram.img", split_image_bytes(n, K));
+    float* sc = static_cast<float*>(ctx->workspace("gram.sc", 4 * sizeof(float)));
+    if (!img || !sc) return SCLENS_ERR_OOM;
+    SCL_TRY(split_image_scaled(ctx, B, n, K, ldb, img, sc));
+    return gemm_split_update(ctx, img, sc, n, img, sc, n, K, A, lda, 1, 1.0f / divisor);
+  }
   GemmArgs g{};
   g.P = B; g.Q = B; g.C = A;
   g.M = n; g.N = n; g.K = K;

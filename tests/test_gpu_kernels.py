@@ -105,7 +105,38 @@ def test_sytrd_stebz_eigenvalues(ctx, n):
         x.free()
 
 
-def _tridiag_cases():
+@pytest.mark.parametrize("n,K", [(300, 1000), (1030, 4100), (515, 257)])
+def test_gram_on_split_fp16_operands_matches_float64(ctx, n, K, monkeypatch):
+    """sclens_hip_dev_gram_f32 from the split image of the operand (SCLENS_HIP_GRAM_SPLIT: every entry as two fp16 pieces after a
+    power-of-two scaling, three fp16 matrix instructions per product, fp32 accumulation) on a matrix shaped like a scaled count
+    matrix -- a small negative background, a few per cent of entries up to ~80 -- against the float64 product; the fp32 path on the
+    same input for comparison. Exactly symmetric either way."""
+    rng = np.random.default_rng(n + K)
+    B = (-0.02 * rng.random((n, K))).astype(np.float32)
+    nz = rng.random((n, K)) < 0.05
+    B[nz] = (rng.gamma(0.7, 4.0, size=int(nz.sum())) + 0.1).astype(np.float32)
+    B[rng.integers(0, n, 20), rng.integers(0, K, 20)] = 80.0
+    B -= B.mean(axis=0, keepdims=True)
+    ldb, lda = rup(K, 32), rup(n, 32)
+    ref = B.astype(np.float64) @ B.astype(np.float64).T / K
+    err = {}
+    for mode in ("64", "0"):
+        monkeypatch.setenv("SCLENS_HIP_GRAM_SPLIT", mode)
+        Bp = np.zeros((n, ldb), np.float32)
+        Bp[:, :K] = B
+        dB, dA = DevArray(ctx, Bp), DevArray(ctx, nbytes=4 * n * lda)
+        ctx.check(ctx.lib.sclens_hip_dev_gram_f32(ctx.h, dB.p, n, K, ldb, float(K), dA.p, lda))
+        ctx.sync()
+        A = dA.get((n, lda), np.float32)[:, :n]
+        dB.free()
+        dA.free()
+        assert np.array_equal(A, A.T)
+        err[mode] = np.abs(A - ref).max() / np.abs(ref).max()
+    assert err["64"] < 2e-6, err
+    assert err["64"] < 2 * err["0"] + 3e-7, err
+
+
+def _tridiag_cases():def _tridiag_cases():
     rng = np.random.default_rng(4)
     n = 777
     cases = {}

@@ -49,6 +49,7 @@ def delayed_update(request, monkeypatch):
     if "delayed" in request.param:
         monkeypatch.setenv("SCLENS_HIP_SY2SB_DELAY_MIN", "321")
     monkeypatch.setenv("SCLENS_HIP_SY2SB_SPLIT", "512" if "split" in request.param else "0")
+    monkeypatch.setenv("SCLENS_HIP_Q1_SPLIT", "32" if "split" in request.param else "0")  # first back-transformation likewise
     return request.param
 
 
@@ -150,7 +151,7 @@ def test_bulge_chase_kernels_agree_bitwise(ctx, n, monkeypatch):
 
 
 @pytest.mark.parametrize("n,m", [(256, 256), (448, 100), (1024, 37)])
-def test_first_back_transformation(ctx, n, m):
+def test_first_back_transformation(ctx, n, m, delayed_update):
     """Eigenvectors of the band matrix (host, float64) multiplied by Q1 on the device are eigenvectors of A."""
     A = _sym_psd(n, 5 * n + 2)
     lda = rup(n, 32)
