@@ -136,7 +136,7 @@ def test_gram_on_split_fp16_operands_matches_float64(ctx, n, K, monkeypatch):
     assert err["64"] < 2 * err["0"] + 3e-7, err
 
 
-def _tridiag_cases():def _tridiag_cases():
+def _tridiag_cases():
     rng = np.random.default_rng(4)
     n = 777
     cases = {}
