@@ -95,7 +95,7 @@ int gram_f32(Ctx* ctx, const float* B, int64_t n, int64_t K, int64_t ldb, float 
   // 2^-38 of the largest) and the product runs on the fp16 matrix cores with fp32 accumulation (gemm_split_update, gram_bits.hip):
   // 682 -> ~250 ms at 100 000 x 30 000. Context option gram_bits = 0 (bench.py's strict step) also keeps this product in fp32.
   const char* egs = getenv("SCLENS_HIP_GRAM_SPLIT");
-  const int64_t gs_min = egs ? atoll(egs) : 0;  // off by default until validated at full size
+  const int64_t gs_min = egs ? atoll(egs) : 16000;
   if (gs_min > 0 && n >= gs_min && ctx->gram_bits != 0) {
     void* img = ctx->workspace("gram.img", split_image_bytes(n, K));
     float* sc = static_cast<float*>(ctx->workspace("gram.sc", 4 * sizeof(float)));
