@@ -199,14 +199,12 @@ def stage_probe(ctx, X, N, M):
 
 
 # HBM traffic of ONE two-stage eigensolve of order 30 016 with 15 008 vectors (the roofline's launch), from separate
-# `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` passes over scripts/perf_eig.py (profiles/r03_pmc_eig/summary.txt): 0.996e12 B
+# `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` passes over scripts/perf_eig.py (profiles/r03_pmc_eig_mid2/summary.txt): 0.996e12 B
 # fetched as counted + 0.523e12 B for the gfx950 half-count of 16-byte-per-lane streaming reads (MI355X_MICROARCH.md, HBM) on the two
 # large-tile GEMM kernels, whose corrected fetch then equals their algorithmic read (W = A22 V: 574 vs 563 GB) + 0.935e12 B written.
-# A constant of the round-3 build, not measured in the bench run (a PMC pass serialises every dispatch).
-PMC_EIG_TRAFFIC_R03 = {"bytes": 2.45e12,
-                       "source": "constant of the build: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over one eigensolve of order 30 016 "
-                                 "(profiles/r03_pmc_eig/summary.txt): 1.52e12 B fetched (gfx950 half-count of wide streaming reads corrected "
-                                 "on the large-tile GEMM kernels) + 0.94e12 B written; not measured in this run"}
+# Measured on the mid-round build (before the split-fp16 products); the passes on the final build did not complete (the WRITE_SIZE
+# pass hung under the profiler until the GPU budget ended), so the line carries traffic = null and cites this number as context.
+PMC_EIG_TRAFFIC_R03_MID = {"bytes": 2.45e12}  # 1.52e12 B fetched (half-count corrected on the large-tile GEMM kernels) + 0.94e12 B written
 
 
 # A full-size CPU data point kept in the repository (profiles/r02_signal_count_cfg4.json, GPU box, 16 usable CPUs): LAPACK dsyevd,
@@ -548,9 +546,11 @@ def main():
                                                              "stein + Q2 + Q1, n/2 eigenvectors): the stage with the most wall time",
                                    "achieved": round(ach, 2), "peak": MFMA_F32_PEAK_TFS, "unit": "TFLOP/s",
                                    "frac": round(ach / MFMA_F32_PEAK_TFS, 4),
-                                   "traffic": PMC_EIG_TRAFFIC_R03["bytes"] if n in (30000, 30016) else None,
-                                   "traffic_source": (PMC_EIG_TRAFFIC_R03["source"] if n in (30000, 30016) else
-                                                      "not measured at this order (PMC passes are separate rocprofv3 runs: profiles/)"),
+                                   "traffic": None,
+                                   "traffic_source": ("not measured for this build. The last PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, "
+                                                      "profiles/r03_pmc_eig_mid2/summary.txt) are of the build before the split-fp16 products: "
+                                                      f"{PMC_EIG_TRAFFIC_R03_MID['bytes']:.3g} B per eigensolve of order 30 016 (1.4 TB/s: not HBM-bound); "
+                                                      "the split images add ~0.1e12 B"),
                                    "n": n, "vectors": n // 2, "launch_ms": round(solve_ms, 2), "algorithmic_flop_per_launch": flop,
                                    "stage_ms": {k: stages[k]["ms"] for k in parts if k in stages},
                                    "note": "time-weighted fp32-equivalent rate of the whole stage against the fp32 MFMA peak (its large products "

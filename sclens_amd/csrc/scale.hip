@@ -283,7 +283,7 @@ __global__ __launch_bounds__(256) void k_dense_scatter(PatternDev p, int cells_m
 // -s_i mu_j - cent_j is formed in LDS, the gene's stored entries that fall into the chunk overwrite their slots with the same
 // expression k_dense_scatter uses, and the chunk leaves as 16-byte stores: the 4 N M bytes are written ONCE (fill + scatter wrote
 // them, then re-wrote 64-byte sectors around each of the nnz scattered dwords: 19 ms for the two kernels at 100 000 x 30 000,
-// `profiles/r03_cfg4_kernel_stats_final.csv`). A column of the pattern holds the counts with ascending cells and THEN the zero
+// `profiles/r03_cfg4_kernel_stats_mid2.csv`). A column of the pattern holds the counts with ascending cells and THEN the zero
 // candidates in draw order, so a running position q replaces any search as long as the entries keep coming in order: q advances
 // over the PREFIX of entries that lie in the current chunk; whatever is left when the last chunk has been written (the unordered
 // tail) is scattered as before, behind a barrier (same workgroup, same addresses: the chunk stores have completed).
