@@ -239,3 +239,21 @@ def test_guard_band_cut_stays_contiguous():
     # everything above / below
     assert cut_with_guard_band(L, 0.0, 0.0, None)[1] == len(L)
     assert cut_with_guard_band(L, 100.0, 0.0, None)[1] == 0
+
+
+def test_every_environment_switch_is_documented():
+    """INTEGRATION.md section 5 lists the SCLENS_HIP_* switches the library reads: every name in the sources is in the table and
+    every name in the table is in the sources (SCLENS_HIP_COMM_ID_BYTES is a compile-time constant of the header, not a switch)."""
+    import glob
+    import os
+    import re
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = set()
+    for pat in ("sclens_amd/csrc/*.hip", "sclens_amd/csrc/*.h", "sclens_amd/csrc/*.cpp", "sclens_amd/*.py"):
+        for f in glob.glob(os.path.join(root, pat)):
+            src |= set(re.findall(r"SCLENS_HIP_[A-Z0-9_]+", open(f).read()))
+    src.discard("SCLENS_HIP_COMM_ID_BYTES")
+    doc = set(re.findall(r"SCLENS_HIP_[A-Z0-9_]+", open(os.path.join(root, "INTEGRATION.md")).read()))
+    assert src - doc == set(), f"undocumented switches: {sorted(src - doc)}"
+    assert doc - src == set(), f"documented but not read anywhere: {sorted(doc - src)}"
