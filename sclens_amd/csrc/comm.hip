@@ -41,12 +41,15 @@ static RcclApi* rccl_api() {
   static std::once_flag once;
   std::call_once(once, [] {
     const char* names[] = {"librccl.so.1", "/opt/rocm/lib/librccl.so.1", "librccl.so"};
+    std::string why;
     for (const char* nm : names) {
       api.handle = dlopen(nm, RTLD_NOW | RTLD_GLOBAL);
       if (api.handle) break;
+      const char* e = dlerror();  // reading it clears it: read once per attempt
+      if (e && why.empty()) why = e;
     }
     if (!api.handle) {
-      api.err = std::string("librccl not found: ") + (dlerror() ? dlerror() : "");
+      api.err = "librccl not found: " + why;
       return;
     }
     auto sym = [&](const char* n) -> void* {

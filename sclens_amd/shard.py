@@ -6,7 +6,8 @@ calls made inside libsclens_hip.so (csrc/comm.hip), torch.distributed only launc
     consume them in order with the reference's stop rule (same decision sequence as the serial loop).
   * perturbation ensemble (scLENS.jl:771-778): member t runs on rank t % world; one gather of the N x min_pc
     eigenvector blocks to rank 0 at the end, which then scores robustness.
-The data/null/binary decompositions are replicated on every rank (3 of ~3+S+P; noted in DESIGN.md).
+  * first phase (scLENS.jl:704, :717-721): with 2 or more ranks the data | null | binarised decompositions run on different
+    ranks (api.sclens); Vr2 and the spectra travel by one broadcast each.
 """
 from __future__ import annotations
 
