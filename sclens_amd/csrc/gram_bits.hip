@@ -483,6 +483,67 @@ __global__ __launch_bounds__(256) void k_split_image_pair_scaled(const float* __
   }
 }
 
+// Two scales for an operand pair whose columns alternate between two kinds in blocks of `half` (the trailing update of the band
+// reduction: src1 = [V | Z | ...], src2 = [-Z | -V | ...], half = 64): V has entries up to 1 whatever the matrix, Z scales with
+// its norm, and under ONE scale the smaller kind loses bits to the fp16 subnormal spacing once the two differ by more than
+// ~2^10. Kind 0 of src1 and kind 1 of src2 (the V columns) take scale[0], the others scale[2]; every term of P Q' then carries
+// the same factor scale[0] * scale[2], which is what gemm_split_update divides by when given the two as sP and sQ.
+// scale_dev: [0] scale of kind 0, [1] its maximum (bits), [2] scale of kind 1, [3] its maximum (bits).
+__global__ __launch_bounds__(256) void k_absmax_bits2(const float* __restrict__ src, int64_t rows, int64_t K, int64_t ld, int half,
+                                                      unsigned* __restrict__ sd) {
+  float mx0 = 0.f, mx1 = 0.f;
+  for (int64_t r = blockIdx.x; r < rows; r += gridDim.x)
+    for (int64_t k = threadIdx.x; k < K; k += 256) {
+      const float v = fabsf(src[r * ld + k]);
+      if ((k / half) & 1) mx1 = fmaxf(mx1, v);
+      else mx0 = fmaxf(mx0, v);
+    }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    mx0 = fmaxf(mx0, __shfl_xor(mx0, o));
+    mx1 = fmaxf(mx1, __shfl_xor(mx1, o));
+  }
+  __shared__ float wmx[8];
+  if ((threadIdx.x & 63) == 0) {
+    wmx[threadIdx.x >> 6] = mx0;
+    wmx[4 + (threadIdx.x >> 6)] = mx1;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    atomicMax(sd + 1, __float_as_uint(fmaxf(fmaxf(wmx[0], wmx[1]), fmaxf(wmx[2], wmx[3]))));
+    atomicMax(sd + 3, __float_as_uint(fmaxf(fmaxf(wmx[4], wmx[5]), fmaxf(wmx[6], wmx[7]))));
+  }
+}
+__global__ void k_pick_scale2(float* __restrict__ sd) {
+  for (int c = 0; c < 2; ++c) {
+    const float mx = sd[2 * c + 1];  // the bits of a non-negative float, written through the unsigned view
+    int ex = 0;
+    float sc = 1.f;
+    if (mx > 0.f && mx < 1.0e30f) {
+      (void)frexpf(mx, &ex);
+      sc = ldexpf(1.f, 14 - ex);
+    }
+    sd[2 * c] = sc;
+  }
+}
+__global__ __launch_bounds__(256) void k_split_image_pair_scaled2(const float* __restrict__ src1, const float* __restrict__ src2, int64_t rows,
+                                                                  int64_t K, int64_t ld, int64_t Kp, int half, const float* __restrict__ scale,
+                                                                  _Float16* __restrict__ dst1, _Float16* __restrict__ dst2) {
+  const int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (k >= Kp) return;
+  const int kind = (int)((k / half) & 1);
+  const float s1 = kind ? scale[2] : scale[0], s2 = kind ? scale[0] : scale[2];
+  for (int64_t r = blockIdx.y; r < rows; r += gridDim.y) {
+    const float x1 = k < K ? src1[r * ld + k] * s1 : 0.f, x2 = k < K ? src2[r * ld + k] * s2 : 0.f;
+    const _Float16 h1 = (_Float16)x1, h2 = (_Float16)x2;
+    const int64_t o = r * 2 * Kp + (k >> 5) * 64 + (k & 31);
+    dst1[o] = h1;
+    dst1[o + 32] = (_Float16)(x1 - (float)h1);
+    dst2[o] = h2;
+    dst2[o + 32] = (_Float16)(x2 - (float)h2);
+  }
+}
+
 struct SplitUpdArgs {
   const _Float16* A;  // split image, M rows
   const _Float16* B;  // split image, N rows
@@ -728,6 +789,22 @@ int split_image_pair_scaled(Ctx* ctx, const float* src1, const float* src2, int6
   hipLaunchKernelGGL(k_pick_scale, dim3(1), dim3(1), 0, st, mx, scale_dev);
   hipLaunchKernelGGL(k_split_image_pair_scaled, dim3((unsigned)((Kp + 255) / 256), (unsigned)std::min<int64_t>(rows, 65535)), dim3(256), 0,
                      st, src1, src2, rows, K, ld, Kp, scale_dev, static_cast<_Float16*>(dst1), static_cast<_Float16*>(dst2));
+  SCL_HIP(ctx, hipGetLastError());
+  return SCLENS_OK;
+}
+
+int split_image_pair_scaled2(Ctx* ctx, const float* src1, const float* src2, int64_t rows, int64_t K, int64_t ld, int half, void* dst1,
+                             void* dst2, float* scale_dev) {
+  if (rows <= 0) return SCLENS_OK;
+  if (half <= 0 || K % (2 * half) != 0) return ctx->fail(SCLENS_ERR_ARG, "split_image_pair_scaled2: K must be a multiple of 2 * half");
+  const int64_t Kp = round_up(K, 32);
+  hipStream_t st = ctx->stream;
+  SCL_HIP(ctx, hipMemsetAsync(scale_dev, 0, 4 * sizeof(float), st));
+  hipLaunchKernelGGL(k_absmax_bits2, dim3((unsigned)std::min<int64_t>(rows, 256)), dim3(256), 0, st, src1, rows, K, ld, half,
+                     reinterpret_cast<unsigned*>(scale_dev));
+  hipLaunchKernelGGL(k_pick_scale2, dim3(1), dim3(1), 0, st, scale_dev);
+  hipLaunchKernelGGL(k_split_image_pair_scaled2, dim3((unsigned)((Kp + 255) / 256), (unsigned)std::min<int64_t>(rows, 65535)), dim3(256), 0,
+                     st, src1, src2, rows, K, ld, Kp, half, scale_dev, static_cast<_Float16*>(dst1), static_cast<_Float16*>(dst2));
   SCL_HIP(ctx, hipGetLastError());
   return SCLENS_OK;
 }

@@ -657,6 +657,11 @@ int sy2sb_f32(Ctx* ctx, float* A, int64_t n, int64_t lda, float* Tall, int* brea
   // C traffic only: 27 us of fp32 matrix-pipe time per 128 of K and 256 x 256 tile become 5). SCLENS_HIP_SY2SB_SPLIT=0: fp32 products.
   int64_t split_min = 4096;
   if (const char* ev = getenv("SCLENS_HIP_SY2SB_SPLIT")) split_min = atoi(ev) > 0 ? std::max<int64_t>(512, atoll(ev)) : (int64_t)1 << 60;
+  // SCLENS_HIP_SY2SB_SPLIT_SCALES=2: separate power-of-two scales for the reflector columns (entries up to 1) and the Z columns
+  // (entries ~ the norm of the matrix) of the update's operands; 1 (default): one scale for both, accurate while the norm of the
+  // matrix stays below ~2^12
+  int split_scales = 1;
+  if (const char* ev = getenv("SCLENS_HIP_SY2SB_SPLIT_SCALES")) split_scales = atoi(ev) == 2 ? 2 : 1;
   const bool any_split = n >= split_min;
   void* imgP = any_split ? ctx->workspace("sbr.imgP", split_image_bytes(n, LDU)) : nullptr;
   void* imgQ = any_split ? ctx->workspace("sbr.imgQ", split_image_bytes(n, LDU)) : nullptr;
@@ -779,6 +784,10 @@ int sy2sb_f32(Ctx* ctx, float* A, int64_t n, int64_t lda, float* Tall, int* brea
     const int64_t Ku = pending ? 4 * SB : 2 * SB;
     auto update = [&](int64_t off, int64_t rows, int64_t cols, int lower) -> int {  // A22[off:off+rows, (lower ? off : 0) : +cols]
       if (lower && rows == cols && rows >= split_min) {  // the bulk of the update: split-fp16 products
+        if (split_scales == 2) {  // one scale for the V columns, one for the Z columns (prepared in round 3, not yet the default)
+          SCL_TRY(split_image_pair_scaled2(ctx, Up + off * LDU, Uq + off * LDU, rows, Ku, LDU, (int)SB, imgP, imgQ, imgS));
+          return gemm_split_update(ctx, imgP, imgS, rows, imgQ, imgS + 2, rows, Ku, A22 + off * lda + off, lda, 1);
+        }
         SCL_TRY(split_image_pair_scaled(ctx, Up + off * LDU, Uq + off * LDU, rows, Ku, LDU, imgP, imgQ, imgS));
         return gemm_split_update(ctx, imgP, imgS, rows, imgQ, imgS, rows, Ku, A22 + off * lda + off, lda, 1);
       }
