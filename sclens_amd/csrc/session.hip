@@ -40,6 +40,10 @@ void Ctx::release(const std::string& name) {
 }
 void Ctx::release_all() {
   if (stream) hipStreamSynchronize(stream);
+  // work enqueued on the auxiliary stream is normally joined back into `stream` by an event, except the T factors of the second
+  // back-transformation that a values-only decomposition builds ahead and nobody consumes: their kernel must not outlive its
+  // workspace (the block goes back to the pool and may be handed to another context at once)
+  if (aux_stream) hipStreamSynchronize(aux_stream);
   for (auto& kv : ws) pool_free(kv.second.first, nullptr);
   ws.clear();
 }
