@@ -1,12 +1,17 @@
 """Row-sharded sclens() for the atlas configuration: cells > genes, every rank holds a contiguous block of
 cells. The Gram matrix X'X (genes x genes) is a sum over cells, so each decomposition is: local normalisation statistics
-(three O(M) all-reduces + one scalar), local partial Gram matrix, one all-reduce of 4 M^2 bytes, then the eigen-solver
-replicated on identical inputs; the recovery GEMM X_g V is row-local. All ranks run the same control flow (the serial loop of
-scLENS.jl:715-778); the library calls back into `Shard.allreduce_dev` wherever the path has a real exchange.
+(three O(M) all-reduces + one scalar), local partial Gram matrix, one sum of 4 M^2 bytes over the ranks, the eigen-solver, and
+the recovery GEMM X_g V, which is row-local. All ranks run the same control flow (the serial loop of scLENS.jl:715-778); the
+library calls the reducers of `Shard` (RCCL inside the library when there is a communicator) wherever the path has a real
+exchange.
 
-Memory is what this mode scales (the sparse pattern, the dense scaled matrix and the cell-side vectors are divided by the
-number of ranks), not the eigen-solver time; for cells <= genes, or when the matrix fits one GPU, use api.sclens(shard=...)
-which distributes independent decompositions instead.
+Two ways to place the eigen-solver: replicated on identical inputs (all-reduce of the Gram matrix; `distribute=False`), or
+-- the default for several ranks with device-side samples -- a ROUND of `world` independent decompositions (consecutive
+sparsities of the search, consecutive ensemble members) whose partial Gram matrices are each reduced onto ONE rank, which solves
+it while the others solve theirs (`search_round_seeded`, `perturb_round_seeded`). The first three decompositions (data, null,
+binarised) are still replicated. Memory scales with the ranks either way: the sparse pattern, the candidates (drawn locally:
+no rank holds foreign ones), the dense scaled matrix and the cell-side vectors are divided by their number. For cells <= genes,
+or when the matrix fits one GPU, use api.sclens(shard=...), which distributes whole decompositions instead.
 """
 from __future__ import annotations
 
