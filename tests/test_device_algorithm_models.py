@@ -231,3 +231,26 @@ def test_shared_and_separate_scales_of_the_update_operands(log2_norm):
         assert e1 < 4 * e32 + 2e-7, (e1, e32)  # the default is as good inside its regime
     if log2_norm >= 20:
         assert e1 > 8 * e2  # ... and visibly worse far outside it, which is why the second form exists
+
+
+def test_split_gram_of_a_scaled_count_matrix_keeps_the_spectrum():
+    """the product bench.py's data / null decompositions start from (session.hip gram_f32 -> split_image_scaled +
+    gemm_split_update): a synthetic count matrix through the ORACLE's normalisation, its Gram matrix from split fp16 operands
+    and from fp32 operands, spectra against the float64 product"""
+    from oracle import sclens_oracle as O
+    from sclens_amd.synth import synth_counts
+
+    N, M = 3000, 800
+    S = np.asarray(O.logn_scale(O.pre_scale(np.asarray(synth_counts(N, M, seed=5, C=6).todense(), dtype=np.float64))))
+    ref = np.linalg.eigvalsh(S.T @ S / N)
+    B = S.astype(np.float32)
+    hi, lo, sc = split_image_scaled(B)
+    H, L = hi.astype(np.float32), lo.astype(np.float32)
+    acc = H.T @ H
+    acc = acc + H.T @ L
+    acc = acc + L.T @ H
+    Gs = (acc * np.float32(1.0 / (sc * sc)) / np.float32(N)).astype(np.float64)
+    G32 = ((B.T @ B) / np.float32(N)).astype(np.float64)
+    e_split = np.abs(np.linalg.eigvalsh(0.5 * (Gs + Gs.T)) - ref).max() / ref[-1]
+    e_fp32 = np.abs(np.linalg.eigvalsh(0.5 * (G32 + G32.T)) - ref).max() / ref[-1]
+    assert e_split < 2e-7 and e_split < 10 * e_fp32 + 1e-7, (e_split, e_fp32)
