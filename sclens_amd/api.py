@@ -13,8 +13,9 @@ from __future__ import annotations
 
 import ctypes as C
 import math
+import os
 import time
-from concurrent.futures import ThreadPoolExecutor
+from concurrent.futures import Future, ThreadPoolExecutor
 from dataclasses import dataclass
 from typing import Callable, Dict, Optional
 
@@ -1082,8 +1083,34 @@ def sclens(inp_df, device_="gpu", th=60, p_step=0.001, n_perturb=20, centering="
             # (0.5 s at n = 3 * 10^4) that costs nothing next to a decomposition and 0.5 s on its own
             # (profiles/r03_first_phase_cfg4.log).
             w_null = w_bin = workers[1]
-            (L, rec_vals), Lr = run_all([(0, lambda: ses.data_spectrum(not median)), (1, lambda: w_null.null_spectrum_pattern(null_future.result()))])
-            r_vr2 = -1  # decomposed below, next to the signal vectors
+            if os.environ.get("SCLENS_FIRST_PHASE") == "chain":
+                # (prepared at the end of round 3, not yet timed on hardware, hence opt-in) the binarised decomposition does not
+                # depend on the threshold: worker 1 runs null -> binarised back to back while this thread runs the data matrix,
+                # waits for the null spectrum only, and takes the signal vectors beside the rest of the binarised decomposition
+                null_done: Future = Future()
+
+                def null_then_binary():
+                    try:
+                        null_done.set_result(w_null.null_spectrum_pattern(null_future.result()))
+                    except BaseException as e:  # the waiting thread must see it; the binarised decomposition is not started
+                        null_done.set_exception(e)
+                        raise
+                    return w_bin.binary_basis()
+
+                bin_chain = pool.submit(null_then_binary)
+                try:
+                    L, rec_vals = ses.data_spectrum(not median)
+                    Lr = null_done.result()
+                except BaseException:
+                    try:
+                        bin_chain.result()  # worker 1's session is single-threaded: let its chain end before anything closes it
+                    except BaseException:
+                        pass
+                    raise
+                r_vr2 = -2  # running on worker 1; joined after the signal vectors
+            else:
+                (L, rec_vals), Lr = run_all([(0, lambda: ses.data_spectrum(not median)), (1, lambda: w_null.null_spectrum_pattern(null_future.result()))])
+                r_vr2 = -1  # decomposed below, next to the signal vectors
         else:  # the main session keeps the data matrix's reflectors for signal_vectors; workers take the other two
             w_null, w_bin = workers[1], workers[2]
             (L, rec_vals), Lr, (_, r_vr2) = run_all([(0, lambda: ses.data_spectrum(not median)), (1, lambda: w_null.null_spectrum_pattern(null_future.result())),
@@ -1099,7 +1126,12 @@ def sclens(inp_df, device_="gpu", th=60, p_step=0.001, n_perturb=20, centering="
         L, k, nL, guard = cut_with_guard_band(L, lambda_c, guard_band, refine)
         if verbose:
             print(f"(Using hip) number of signal ev: {k}")
-        if r_vr2 == -1:
+        if r_vr2 == -2:
+            try:
+                nV = ses.signal_vectors(k)
+            finally:
+                _, r_vr2 = bin_chain.result()
+        elif r_vr2 == -1:
             nV, (_, r_vr2) = run_all([(0, lambda: ses.signal_vectors(k)), (1, w_bin.binary_basis)])
         else:
             nV = ses.signal_vectors(k) if (not spread or shard.rank == 0) else None

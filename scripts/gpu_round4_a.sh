@@ -12,6 +12,16 @@ SCLENS_TEST_EXPERIMENTAL=1 timeout 900 python -m pytest tests/test_gpu_sbr.py -m
 tail -n 5 $O/pytest_scales.log
 SCLENS_TEST_EXPERIMENTAL=1 timeout 1500 python -m pytest tests/test_gpu_bench_size.py -m gpu -x -q -s > $O/pytest_bench_size.log 2>&1; echo "bench-size (default + strict) rc=$?" >> $O/summary.txt
 grep "bench-size parity\|passed\|failed" $O/pytest_bench_size.log
+SCLENS_TEST_EXPERIMENTAL=1 timeout 600 python -m pytest tests/test_gpu_sclens.py -m gpu -x -q -k "chained_first_phase" > $O/pytest_chain.log 2>&1; echo "chained first phase rc=$?" >> $O/summary.txt
+tail -n 3 $O/pytest_chain.log
+for fp in default chain; do
+  SCLENS_FIRST_PHASE=$fp timeout 900 python bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-roofline --strict-fp32 off > $O/bench_first_phase_$fp.json 2> $O/bench_first_phase_$fp.err
+  python3 - <<PY
+import json
+d = json.loads(open("$O/bench_first_phase_$fp.json").read().strip().splitlines()[-1])
+print("first phase = $fp:", d["sclens_wall_s"], d["observed"]["phase_s_rank0_last_step"], d["observed"]["signals"], d["observed"]["search_iters"], d["observed"]["p_"])
+PY
+done
 # (2) the whole suite as the driver runs it
 timeout 2400 python -m pytest tests -m gpu -x -q > $O/pytest_gpu.log 2>&1; echo "suite rc=$?" >> $O/summary.txt
 tail -n 4 $O/pytest_gpu.log

@@ -4,6 +4,8 @@ Tolerances: the device path is fp32 (Gram, tridiagonalisation, back-transform) w
 is the reference's Float64 CPU path. Eigenvalues: 2e-4 relative to the largest; eigenvectors: |cos| >= 1 - 2e-3
 for separated signals; integer/decision outputs (signal count, p_, search length, sig_id, a_b) exact.
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -258,6 +260,23 @@ def test_two_streams_give_identical_results(ctx):
             assert p1 == p3 and np.array_equal(t1, t3)
         assert np.array_equal(a["L"], c["L"])
         assert np.array_equal(a["robustness_scores"]["b_"], c["robustness_scores"]["b_"])
+
+
+@pytest.mark.skipif(os.environ.get("SCLENS_TEST_EXPERIMENTAL") != "1", reason="SCLENS_FIRST_PHASE=chain has not run on hardware yet")
+def test_chained_first_phase_gives_identical_results(ctx, monkeypatch):
+    """SCLENS_FIRST_PHASE=chain (two streams: worker 1 runs null -> binarised back to back, the main session data -> signal
+    vectors) only moves work between streams: every output has the same bits as the default schedule"""
+    X = synth_counts(300, 500, seed=1, C=5, marker_frac=0.2, marker_sd=1.5)
+    d = api.make_draws_native(X, seed=13)
+    a = api.sclens(X, draws=d, n_perturb=5, ctx=ctx, streams=2)
+    monkeypatch.setenv("SCLENS_FIRST_PHASE", "chain")
+    b = api.sclens(X, draws=d, n_perturb=5, ctx=ctx, streams=2)
+    assert a["p_"] == b["p_"] and a["n_search"] == b["n_search"] and np.array_equal(a["L"], b["L"])
+    for (p1, t1), (p2, t2) in zip(a["search_trace"], b["search_trace"]):
+        assert p1 == p2 and np.array_equal(t1, t2)
+    assert np.array_equal(a["signal_evec"], b["signal_evec"])
+    assert np.array_equal(a["robustness_scores"]["b_"], b["robustness_scores"]["b_"])
+    assert np.array_equal(a["sig_id"], b["sig_id"])
 
 
 def test_get_denoised_df(run_pair, ctx):
