@@ -1,0 +1,155 @@
+"""CPU: the host control flow of `api.sclens` -- worker sessions on threads, speculative search rounds consumed in order, the
+slot traffic of the ensemble, guard band, scoring and result assembly -- on a float64 NumPy stand-in for the device session
+(tests/fake_session.py: the oracle's operations cut at the session entry points). On the same draws the result must be the
+oracle's; sessions must never see overlapping calls; everything `sclens()` opens must be closed when it returns or raises.
+The kernels are not involved (they have their own `-m gpu` parity tests); the C++ host statistics are the real ones."""
+import numpy as np
+import pytest
+
+import fake_session as F
+from oracle import sclens_oracle as O
+from sclens_amd import api
+from sclens_amd.synth import synth_counts
+
+
+def _pair(monkeypatch, N, M, streams, n_perturb=4, centering="mean", **kw):
+    X = synth_counts(N, M, seed=3, C=4, marker_frac=0.25, marker_sd=1.5)
+    d = api.make_draws(X, seed=11, p_th_trials=200)
+    ref = O.sclens(X, O.Draws(d.z_idx1, d.z_idx2, d.X_r, d.p_th, d.sampler), n_perturb=n_perturb, null_tol=O.NULL_DROP,
+                   centering=centering, keep_intermediates=True, **kw)
+    main = F.install(monkeypatch)
+    res = api.sclens(X, draws=d, n_perturb=n_perturb, ctx=main, streams=streams, centering=centering, keep_intermediates=True, **kw)
+    return ref, res
+
+
+def _same(ref, res):
+    assert np.allclose(res["L"], ref["L"], rtol=1e-12, atol=1e-13)
+    assert abs(res["lambda_c"] - ref["lambda_c"]) < 1e-9 * ref["lambda_c"]  # C++ host statistics against the oracle's
+    assert len(res["signal_ev"]) == len(ref["signal_ev"]) > 0
+    assert np.allclose(res["signal_ev"], ref["signal_ev"], rtol=1e-12)
+    assert res["p_"] == ref["p_"] and res["n_search"] == ref["n_search"] and res["pass"] == ref["pass"]
+    for (p1, d1), (p2, d2) in zip(res["search_trace"], ref["search_trace"]):
+        assert p1 == p2 and np.allclose(d1, d2, rtol=1e-10, atol=1e-13)
+    ra, rb = res["robustness_scores"], ref["robustness_scores"]
+    assert np.array_equal(ra["a_b"], rb["a_b"]) and np.allclose(ra["b_"], rb["b_"], atol=1e-10)
+    assert np.allclose(ra["rob_score"], rb["rob_score"], atol=1e-10) and np.array_equal(res["sig_id"], ref["sig_id"])
+    assert res["min_pc"] == ref["min_pc"]
+    for t in range(len(ref["nL_set"])):
+        assert np.allclose(res["nL_set"][t], ref["nL_set"][t], rtol=1e-10)
+        assert np.allclose(np.abs(res["nV_set"][t]), np.abs(ref["nV_set"][t]), atol=1e-5)  # the fake hands out float32
+    assert np.allclose(res["pca"], ref["pca"], atol=1e-5 * np.abs(ref["pca"]).max())
+    assert np.allclose(res["gene_basis"], ref["gene_basis"], atol=1e-5 * np.abs(ref["gene_basis"]).max())
+
+
+def _all_closed():
+    assert F.FakeSession.live == 0 and F.FakePattern.live == 0
+    assert F.FakeContext.live == 1  # the caller's own context
+
+
+@pytest.mark.parametrize("streams", [1, 2, 3])
+@pytest.mark.parametrize("N,M", [(150, 220), (260, 110)])
+def test_sclens_host_flow_reproduces_the_oracle(monkeypatch, N, M, streams):
+    ref, res = _pair(monkeypatch, N, M, streams)
+    _same(ref, res)
+    _all_closed()
+
+
+def test_capped_search_median_centering_and_five_members(monkeypatch):
+    ref, res = _pair(monkeypatch, 150, 220, 2, n_perturb=5, centering="median", max_search_iters=5)  # the smallest cap that leaves p_ < 1
+    _same(ref, res)
+    assert res["n_search"] == 5 and res["rec_vals"] == {}
+    _all_closed()
+
+
+def test_chained_first_phase_schedule(monkeypatch):
+    """SCLENS_FIRST_PHASE=chain: worker 1 runs null -> binarised back to back on one thread, the main session data -> signal
+    vectors; same result as the oracle, nothing left open"""
+    monkeypatch.setenv("SCLENS_FIRST_PHASE", "chain")
+    ref, res = _pair(monkeypatch, 150, 220, 2)
+    _same(ref, res)
+    _all_closed()
+    calls = F.FakeSession.last_calls
+    first = {what: (tid, sid) for tid, sid, what in reversed(calls)}
+    assert first["null_spectrum"] == first["binary_basis"]            # same worker session, same thread
+    assert first["data_spectrum"][1] == first["signal_vectors"][1] != first["null_spectrum"][1]
+    order = [what for _, _, what in calls]
+    assert order.index("null_spectrum") < order.index("binary_basis")
+
+
+def test_a_failure_in_a_worker_closes_everything(monkeypatch):
+    X = synth_counts(150, 220, seed=3, C=4, marker_frac=0.25, marker_sd=1.5)
+    d = api.make_draws(X, seed=11, p_th_trials=200)
+    for mode in ("", "chain"):
+        monkeypatch.setenv("SCLENS_FIRST_PHASE", mode)
+        main = F.install(monkeypatch)
+
+        def boom(self):
+            raise RuntimeError("binary basis failed")
+
+        monkeypatch.setattr(F.FakeSession, "binary_basis", boom)
+        with pytest.raises(RuntimeError, match="binary basis failed"):
+            api.sclens(X, draws=d, n_perturb=3, ctx=main, streams=2)
+        _all_closed()
+        monkeypatch.undo()
+
+
+# ---- several ranks (threads of this process): the spread first phase, rounds of world x streams evaluations, ensemble t % world
+class _FakeThreadShard:
+    """devutil.ThreadShard with the two device-buffer exchanges acting on the fakes' address space"""
+
+    def __new__(cls, group, rank):
+        from devutil import ThreadShard
+
+        class S(ThreadShard):
+            def bcast_dev(self, ctx, dev_ptr, count_f32, src):
+                got = self._exchange(F.FakeContext.mem.get(dev_ptr) if self.rank == src else None)[src]
+                if self.rank != src:
+                    F.FakeContext.mem[dev_ptr] = got
+
+            def allgather_dev(self, ctx, send_ptr, recv_ptr, count_f32):
+                nbytes = 4 * int(count_f32)
+                mine = {a - send_ptr: o for a, o in list(F.FakeContext.mem.items()) if send_ptr <= a < send_ptr + nbytes}
+                for r, part in enumerate(self._exchange(mine)):
+                    for off, o in part.items():
+                        F.FakeContext.mem[recv_ptr + r * nbytes + off] = o
+
+        return S(group, rank)
+
+
+@pytest.mark.parametrize("world,streams", [(2, 1), (2, 2), (3, 2)])
+def test_multi_rank_host_flow_reproduces_the_oracle(monkeypatch, world, streams):
+    import threading
+
+    from devutil import ThreadShard
+
+    X = synth_counts(150, 220, seed=3, C=4, marker_frac=0.25, marker_sd=1.5)
+    d = api.make_draws(X, seed=11, p_th_trials=200)
+    ref = O.sclens(X, O.Draws(d.z_idx1, d.z_idx2, d.X_r, d.p_th, d.sampler), n_perturb=5, null_tol=O.NULL_DROP, keep_intermediates=True)
+    F.install(monkeypatch).close()
+    group = ThreadShard.Group(world)
+    out, err = [None] * world, [None] * world
+
+    def work(r):
+        c = F.FakeContext(0)
+        try:
+            out[r] = api.sclens(X, draws=d, n_perturb=5, ctx=c, streams=streams, shard=_FakeThreadShard(group, r), keep_intermediates=(r == 0))
+        except BaseException as e:  # noqa: BLE001 - reported below
+            err[r] = e
+            group.bar.abort()
+        finally:
+            c.close()
+
+    th = [threading.Thread(target=work, args=(r,)) for r in range(world)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    for e in err:
+        if e is not None and not isinstance(e, threading.BrokenBarrierError):
+            raise e
+    assert all(e is None for e in err)
+    _same(ref, out[0])  # rank 0 scores: the whole result
+    for r in range(1, world):  # the other ranks return the shared part
+        assert out[r]["p_"] == ref["p_"] and out[r]["n_search"] == ref["n_search"] and "pca" not in out[r]
+        assert np.allclose(out[r]["L"], ref["L"], rtol=1e-12, atol=1e-13)
+    assert F.FakeSession.live == 0 and F.FakePattern.live == 0 and F.FakeContext.live == 0
