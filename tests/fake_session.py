@@ -287,3 +287,90 @@ def install(monkeypatch):
     monkeypatch.setattr(api, "Pattern", FakePattern)
     FakeContext.mem.clear()
     return FakeContext(0)
+
+
+# ---- row-sharded sessions (sclens_amd/atlas.py): every rank holds a block of cells ---------------------------------------------
+class FakeShardedSession(FakeSession):
+    """Stand-in for a row-sharded session. The ranks are threads of one process: each registers its block of cells, the whole
+    matrix is assembled from the blocks, and every rank evaluates the oracle's operation on the WHOLE matrix (what the partial
+    sums + reductions of the library amount to), handing back its own cells of every cell-side result. What the tests exercise
+    is atlas.py: rounds, roots, stop rule, gathers."""
+    registry = {}
+
+    @classmethod
+    def create_sharded(cls, ctx, X_local, row0, N_global, z1, z2, reducer):
+        s = cls.__new__(cls)
+        FakeSession.__init__(s, ctx, None, _shared=_Pending())
+        s.row0, s.N_local, s.N_global = int(row0), X_local.shape[0], int(N_global)
+        s.z1, s.z2, s.ncand = np.asarray(z1), np.asarray(z2), len(z1)
+        s.reduce_to = None
+        with FakeContext._lock:
+            cls.registry.setdefault("X", {})[s.row0] = X_local.tocsr()
+        return s
+
+    def _assemble(self, key):
+        import time
+
+        t0 = time.time()
+        while True:
+            with FakeContext._lock:
+                blocks = dict(self.registry.get(key, {}))
+            if sum(b.shape[0] for b in blocks.values()) == self.N_global:
+                return sp.vstack([blocks[r] for r in sorted(blocks)]).tocsc()
+            assert time.time() - t0 < 60, "the other ranks never registered their cells"
+            time.sleep(0.002)
+
+    def _full(self):
+        if isinstance(self.sh, _Pending):
+            self.sh = _Shared(self._assemble("X"))
+            self.N, self.M, self.n = self.sh.N, self.sh.M, min(self.sh.N, self.sh.M)
+        return self.sh
+
+    def _rows(self, A):
+        return A[self.row0: self.row0 + self.N_local]
+
+    def set_reduce_to(self, reducer_to):
+        self.reduce_to = reducer_to
+
+    def null_spectrum(self, Xr_local):
+        with FakeContext._lock:
+            self.registry.setdefault("Xr", {})[self.row0] = sp.csr_matrix(Xr_local)
+        self._full()
+
+        class P:
+            X = self._assemble("Xr")
+
+        return self.null_spectrum_pattern(P)
+
+    def data_spectrum(self, with_rec_vals=True):
+        self._full()
+        L, rec = FakeSession.data_spectrum(self, with_rec_vals)
+        rec = dict(rec)
+        for key in ("TGC", "norm_tgc"):  # per-cell vectors: this rank's cells
+            rec[key] = self._rows(np.ravel(rec[key]))
+        return L, rec
+
+    def signal_vectors(self, k):
+        return self._rows(FakeSession.signal_vectors(self, k))
+
+    def binary_basis(self):
+        self._full()
+        return FakeSession.binary_basis(self)
+
+    def search_round_seeded(self, seeds, ms, roots, my_slot, n_2):
+        assert len(seeds) == len(ms) == len(roots) and my_slot < len(seeds)
+        if my_slot < 0:
+            return None, 0
+        return self.search_step(api.sample_indices(self.ncand, ms[my_slot], seeds[my_slot]), n_2)
+
+    def perturb_round_seeded(self, ts, seeds, ms, roots, my_slot, min_pc):
+        nl, nc = [], []
+        for e, t in enumerate(ts):  # every rank ends up with every member's vectors (its own cells of them in the library)
+            a, c = self.perturb(t, api.sample_indices(self.ncand, ms[e], seeds[e]), min_pc)
+            nl.append(a)
+            nc.append(c)
+        return nl, nc
+
+
+class _Pending:
+    N = M = 0

@@ -153,3 +153,65 @@ def test_multi_rank_host_flow_reproduces_the_oracle(monkeypatch, world, streams)
         assert out[r]["p_"] == ref["p_"] and out[r]["n_search"] == ref["n_search"] and "pca" not in out[r]
         assert np.allclose(out[r]["L"], ref["L"], rtol=1e-12, atol=1e-13)
     assert F.FakeSession.live == 0 and F.FakePattern.live == 0 and F.FakeContext.live == 0
+
+
+# ---- the row-sharded (atlas) mode: cells divided over thread ranks ------------------------------------------------------------
+@pytest.mark.parametrize("world,distribute", [(2, True), (3, True), (2, False)])
+def test_row_sharded_host_flow_reproduces_the_oracle(monkeypatch, world, distribute):
+    """sclens_amd/atlas.py on the stand-in: rounds of `world` evaluations / members with their roots, the stop rule on gathered
+    statistics, the gathers of the cell-side results -- every rank must return the oracle's result on the whole matrix"""
+    import threading
+
+    from devutil import ThreadShard
+    from sclens_amd import atlas
+
+    N, M = 260, 110
+    X = api._csc_f32(synth_counts(N, M, seed=3, C=4, marker_frac=0.25, marker_sd=1.5))
+    d = api.make_draws_native(X, seed=19)                       # host candidates, device-side sample seeds
+    dh = api.make_draws_native(X, seed=19, host_sampler=True)   # the same samples materialised for the oracle
+    ref = O.sclens(X, O.Draws(dh.z_idx1, dh.z_idx2, dh.X_r, dh.p_th, dh.sampler), n_perturb=5, null_tol=O.NULL_DROP)
+    F.install(monkeypatch).close()
+    F.FakeShardedSession.registry.clear()
+    monkeypatch.setattr(atlas, "Session", F.FakeShardedSession)
+    group = ThreadShard.Group(world)
+    out, err = [None] * world, [None] * world
+    Xr = X.tocsr()
+
+    def work(r):
+        c = F.FakeContext(0)
+        try:
+            a, b = atlas.row_block(r, world, N)
+            out[r] = atlas.sclens_row_sharded(Xr[a:b].tocsc(), a, N, d, ThreadShard(group, r), n_perturb=5, ctx=c, distribute=distribute)
+        except BaseException as e:  # noqa: BLE001 - reported below
+            err[r] = e
+            group.bar.abort()
+        finally:
+            c.close()
+
+    th = [threading.Thread(target=work, args=(r,)) for r in range(world)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    for e in err:
+        if e is not None and not isinstance(e, threading.BrokenBarrierError):
+            raise e
+    assert all(e is None for e in err)
+    for r in range(world):
+        res = out[r]
+        assert res["distributed"] == distribute and res["row_block"] == atlas.row_block(r, world, N)
+        assert np.allclose(res["L"], ref["L"], rtol=1e-12, atol=1e-13) and len(res["signal_ev"]) == len(ref["signal_ev"]) > 0
+        assert res["p_"] == ref["p_"] and res["n_search"] == ref["n_search"]
+        for (p1, d1), (p2, d2) in zip(res["search_trace"], ref["search_trace"]):
+            assert p1 == p2 and np.allclose(d1, d2, rtol=1e-10, atol=1e-13)
+        assert np.array_equal(res["robustness_scores"]["a_b"], ref["robustness_scores"]["a_b"])
+        assert np.allclose(res["robustness_scores"]["b_"], ref["robustness_scores"]["b_"], atol=1e-10)
+        assert np.array_equal(res["sig_id"], ref["sig_id"])
+        assert res["signal_evec"].shape == ref["signal_evec"].shape  # gathered over the ranks: all cells
+        assert np.allclose(res["signal_evec"], ref["signal_evec"], atol=1e-6)
+        assert np.allclose(res["pca"], ref["pca"], atol=1e-5 * np.abs(ref["pca"]).max())
+        for key in ("TGC", "norm_tgc", "mat2_mean", "mat2_std", "cent_"):
+            assert np.allclose(np.ravel(res["rec_vals"][key]), np.ravel(ref["rec_vals"][key]), rtol=1e-12)
+        for t in range(5):
+            assert np.allclose(res["nL_set"][t], ref["nL_set"][t], rtol=1e-10)
+    assert F.FakeSession.live == 0 and F.FakeContext.live == 0
