@@ -215,3 +215,52 @@ def test_row_sharded_host_flow_reproduces_the_oracle(monkeypatch, world, distrib
         for t in range(5):
             assert np.allclose(res["nL_set"][t], ref["nL_set"][t], rtol=1e-10)
     assert F.FakeSession.live == 0 and F.FakeContext.live == 0
+
+
+@pytest.mark.parametrize("streams", [1, 2, 3])
+@pytest.mark.parametrize("where", ["data_spectrum", "null_spectrum_pattern", "signal_vectors", "binary_basis", "search_step", "perturb",
+                                   "robustness", "gene_basis"])
+def test_an_error_anywhere_propagates_and_leaves_nothing_open(monkeypatch, where, streams):
+    """a session call that fails at any stage of sclens() -- on the main session or on a worker thread -- reaches the caller as
+    the original exception, after every worker session, pattern and auxiliary context of the call has been closed"""
+    X = synth_counts(150, 220, seed=3, C=4, marker_frac=0.25, marker_sd=1.5)
+    d = api.make_draws(X, seed=11, p_th_trials=200)
+    main = F.install(monkeypatch)
+    real = getattr(F.FakeSession, where)
+    n_calls = {"n": 0}
+
+    def failing(self, *a, **kw):
+        n_calls["n"] += 1
+        if n_calls["n"] >= (2 if where in ("search_step", "perturb") else 1):  # the second search step / member: mid-loop
+            raise RuntimeError(f"{where} failed")
+        return real(self, *a, **kw)
+
+    monkeypatch.setattr(F.FakeSession, where, failing)
+    with pytest.raises(RuntimeError, match=f"{where} failed"):
+        api.sclens(X, draws=d, n_perturb=4, ctx=main, streams=streams)
+    _all_closed()
+
+
+def test_randomised_sweep_of_the_host_flow(monkeypatch):
+    """a dozen random shapes / seeds / stream counts / centrings: decisions and traces equal to the oracle's in every one"""
+    rng = np.random.default_rng(2024)
+    for case in range(12):
+        N, M = int(rng.integers(90, 260)), int(rng.integers(90, 260))
+        streams = int(rng.integers(1, 4))
+        centering = "median" if case % 4 == 3 else "mean"
+        X = synth_counts(N, M, seed=100 + case, C=int(rng.integers(2, 6)), marker_frac=0.25, marker_sd=1.5)
+        d = api.make_draws(X, seed=int(rng.integers(1, 10**6)), p_th_trials=100)
+        ref = O.sclens(X, O.Draws(d.z_idx1, d.z_idx2, d.X_r, d.p_th, d.sampler), n_perturb=3, null_tol=O.NULL_DROP,
+                       centering=centering, max_search_iters=8)
+        main = F.install(monkeypatch)
+        res = api.sclens(X, draws=d, n_perturb=3, ctx=main, streams=streams, centering=centering, max_search_iters=8)
+        tag = (case, N, M, streams, centering)
+        assert len(res.get("signal_ev", [])) == len(ref["signal_ev"]), tag
+        assert res["p_"] == ref["p_"] and res["n_search"] == ref["n_search"], tag
+        for (p1, d1), (p2, d2) in zip(res["search_trace"], ref["search_trace"]):
+            assert p1 == p2 and np.allclose(d1, d2, rtol=1e-9, atol=1e-12), tag
+        if len(ref["signal_ev"]):
+            assert np.array_equal(res["sig_id"], ref["sig_id"]), tag
+            assert np.array_equal(res["robustness_scores"]["a_b"], ref["robustness_scores"]["a_b"]), tag
+        _all_closed()
+        main.close()
