@@ -32,6 +32,15 @@ def pytest_configure(config):
         pass
 
 
+def pytest_collection_modifyitems(config, items):
+    """the full-size cases (minutes each, order 30 000) run after everything else: a quick failure elsewhere is seen first, and
+    with -x a failure in one of them does not hide the rest of the suite"""
+    def late(item):
+        return 1 if ("test_gpu_bench_size" in item.nodeid or "test_full_size_properties" in item.nodeid) else 0
+
+    items.sort(key=late)  # stable: the order inside the two groups is unchanged
+
+
 @pytest.fixture(scope="session")
 def ctx():
     # some -m gpu tests hand torch CUDA tensors to the library (ensemble exchange): PyTorch's bundled HIP runtime has to be
