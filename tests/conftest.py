@@ -24,6 +24,13 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
     config.addinivalue_line("markers", "slow: a -m gpu case dominated by the float64 oracle (tens of minutes of host LAPACK); runs "
                                        "only with SCLENS_TEST_SLOW=1, its log is kept under profiles/")
+    # last resort against a test that never returns (every spin in the library is bounded, so this should not fire): with
+    # pytest-timeout present and no limit given on the command line, a test may take 50 minutes, then the run is aborted --
+    # an aborted run beats a GPU box that has to be reclaimed
+    if (config.pluginmanager.hasplugin("timeout") and not getattr(config.option, "timeout", None)
+            and os.environ.get("SCLENS_TEST_SLOW") != "1"):  # the slow oracle cases take longer than that by design
+        config.option.timeout = 3000
+        config.option.timeout_method = "thread"
     try:  # the oracle's BLAS / LAPACK calls: one thread per usable CPU, not per visible one
         from threadpoolctl import threadpool_limits
 
