@@ -326,6 +326,7 @@ def main():
     ap.add_argument("--strict-fp32", default="auto", choices=["auto", "on", "off"],
                     help="one further timed step with SCLENS_HIP_GRAM_BITS=0 reported as extra.strict_fp32 (auto: for n >= 16 000)")
     ap.add_argument("--extra-configs", default="", help="comma-separated further configs timed once each after the main one (reported under `extra`)")
+    ap.add_argument("--seed-base", type=int, default=1000, help="timed step s draws with seed seed_base + s (warm-up steps: seed_base - 1 - w)")
     ap.add_argument("--verbose", action="store_true")
     ap.add_argument("--stage-timing", action="store_true", help="per-stage HIP-event totals on stderr (adds syncs)")
     args = ap.parse_args()
@@ -389,8 +390,19 @@ def main():
                 print(f"[bench] synthetic matrix not cached ({e})", file=sys.stderr)
         return X
 
-    def run_config(cfg, steps_req, warm_req, deadline, tail_steps=0.0):
-        """tail_steps: keep this many step durations of the budget free for what follows (the strict-fp32 step)"""
+    def decisions_of(res, seed):
+        """what one sclens() call decided (scLENS.jl:742-760 stop rule, :541 cut): the numbers two arithmetic variants must share"""
+        tr = res.get("search_trace", [])
+        d2 = [float(d5[1]) for _, d5 in tr]  # the second smallest search statistic of every evaluation (the `ppj_` row, :753)
+        p_th = float(res["p_th"])
+        return {"seed": int(seed), "signals": int(len(res.get("signal_ev", []))), "robust_signals": int(len(res.get("sig_id", []))),
+                "search_iters": int(res["n_search"]), "p_": res["p_"],
+                "min_abs_margin": (round(min(abs(x - p_th) for x in d2), 6) if d2 else None),
+                "d5_second_smallest": [round(x, 5) for x in d2], "p_th": round(p_th, 6)}
+
+    def run_config(cfg, steps_req, warm_req, deadline, tail_steps=0.0, step0=0):
+        """tail_steps: keep this many step durations of the budget free for what follows (the strict-fp32 step);
+        step0: index of the first timed step (its draws are seeded 1000 + step0)"""
         N, M, cfg_index = CONFIGS[cfg]
         t0 = time.perf_counter()
         X = api._csc_f32(cached_counts(cfg, N, M, 20240427 + cfg_index))  # SURVEY 8(d): PCG64(20240427 + config_index)
@@ -404,7 +416,7 @@ def main():
 
         def one_step(step):
             t_d = time.perf_counter()
-            draws = api.make_draws_native(X, seed=1000 + step, async_null=True, device_candidates=True)
+            draws = api.make_draws_native(X, seed=args.seed_base + step, async_null=True, device_candidates=True)
             one_step.draws_s = time.perf_counter() - t_d  # R1-R3 inside the timed region; R4/R5 on the device inside sclens()
             if row_shard:  # local cells, local candidates (each rank's part of the global draw), eigensolves of a round on different ranks
                 return atlas.sclens_row_sharded(X_rows, r0, N, draws, shard, n_perturb=args.n_perturb, ctx=ctx, gather=False,
@@ -430,21 +442,23 @@ def main():
             t_step = time.perf_counter() - ts
             n_warm += 1
         fence()
-        n_steps = 0
+        n_steps, decisions = 0, []
         t0 = time.perf_counter()
         for s in range(steps_req):
             if s > 0 and agree(time.perf_counter() + (1.1 + tail_steps) * t_step > deadline):
                 break
             ts = time.perf_counter()
-            res = one_step(s)
+            res = one_step(step0 + s)
             t_step = time.perf_counter() - ts
             n_steps += 1
+            if "search_trace" in res:
+                decisions.append(dict(decisions_of(res, args.seed_base + step0 + s), wall_s=round(t_step, 3)))
         fence()
         dt = time.perf_counter() - t0
         if world > 1:  # MAX over the ranks (through the library's communicator when there is one)
             dt = float(shard.allgather_small(np.array([dt])).max())
         return {"N": N, "M": M, "X": X, "res": res, "dt": dt, "steps": n_steps, "warmup": n_warm, "synth_s": t_synth,
-                "row_shard": row_shard, "draws_s": one_step.draws_s}
+                "row_shard": row_shard, "draws_s": one_step.draws_s, "decisions": decisions, "last_step": step0 + n_steps - 1}
 
     if args.stage_timing:
         ctx.set_timing(True)
@@ -492,7 +506,8 @@ def main():
             "observed": {"signals": int(len(res.get("signal_ev", []))), "robust_signals": int(len(res.get("sig_id", []))),
                          "search_iters": int(res["n_search"]), "p_": res["p_"], "synth_s": round(main_r["synth_s"], 1),
                          "ensemble_partial_eig": {"used": int(res["partial_eig"][0]), "fallback_to_full": int(res["partial_eig"][1])},
-                         "phase_s_rank0_last_step": dict({"draws_host": round(main_r["draws_s"], 4)}, **res.get("phase_s", {}))},
+                         "phase_s_rank0_last_step": dict({"draws_host": round(main_r["draws_s"], 4)}, **res.get("phase_s", {})),
+                         "decisions_per_step": main_r["decisions"]},
         }
     # ---- strict fp32: one more step with the fp16-MFMA products of the sparsity search switched off, while the budget lasts
     extra = {}
@@ -506,7 +521,7 @@ def main():
         os.environ.update(strict_env)
         ctx.set_option("gram_bits", 0)
         try:
-            r = run_config(args.config, 1, 0, deadline - reserve)
+            r = run_config(args.config, 1, 0, deadline - reserve, step0=max(0, main_r["last_step"]))  # the LAST timed step's draws
         finally:
             ctx.set_option("gram_bits", -1)
             for k, v in old_env.items():
@@ -515,9 +530,17 @@ def main():
                 else:
                     os.environ[k] = v
         if rank == 0:
+            acc_d = main_r["decisions"][-1] if main_r["decisions"] else None
+            str_d = r["decisions"][-1] if r["decisions"] else None
+            same = lambda a, b: all(a[q] == b[q] for q in ("signals", "robust_signals", "search_iters", "p_"))
+            out["value_strict_fp32"] = round(r["N"] * r["M"] / r["dt"], 1)  # the same metric with every product on the fp32 MFMA
+            out["decisions_differ"] = (None if acc_d is None or str_d is None else (not same(acc_d, str_d)))
             extra["strict_fp32"] = {"sclens_wall_s": round(r["dt"], 3), "value": round(r["N"] * r["M"] / r["dt"], 1),
                                     "search_iters": int(r["res"]["n_search"]), "signals": int(len(r["res"].get("signal_ev", []))),
                                     "p_": r["res"]["p_"], "gram_bits_used": int(r["res"].get("gram_bits_used", -1)),
+                                    "same_draws_as": "the last timed step", "decisions": str_d,
+                                    "max_abs_diff_d5_second_smallest": (None if acc_d is None or str_d is None else round(max(
+                                        abs(a - b) for a, b in zip(acc_d["d5_second_smallest"], str_d["d5_second_smallest"])), 6)),
                                     "note": "SCLENS_HIP_GRAM_BITS=0 SCLENS_HIP_GRAM_SPLIT=0 SCLENS_HIP_SY2SB_SPLIT=0 SCLENS_HIP_Q1_SPLIT=0 "
                                             "SCLENS_HIP_Q2_VARIANT=3: every product of the path on the fp32 MFMA (no fp16 operand anywhere)"}
     # ---- extra configs (one timed step each), while the budget lasts

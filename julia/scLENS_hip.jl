@@ -97,8 +97,44 @@ function preprocess_hip(tmp_df; min_tp_c=0, min_tp_g=0, max_tp_c=Inf, max_tp_g=I
     end
 end
 
+# The reference's count of eigenvalues above lambda_c (:539, :541, :580) with the fp32 eigenvalues near the cut re-evaluated in float64 (L ascending; `refine(lo, hi)` returns the
+# Rayleigh quotients of the 0-based ascending indices lo .. hi-1). L receives the refined values; returns (k, nL) with the cut
+# taken from the top, so the retained set is contiguous whatever order the refined values of a close pair come out in.
+function cut_with_guard_band!(L::Vector{Float64}, lambda_c, refine; guard_band=4.0)
+    n = length(L)
+    band = guard_band * sqrt(n) * 5.96e-8 * L[end]
+    near = findall(abs.(L .- lambda_c) .<= band)
+    if guard_band > 0 && !isempty(near) && length(near) <= 64
+        L[first(near):last(near)] .= refine(first(near) - 1, last(near))
+    end
+    below = findlast(x -> !(x > lambda_c), L)                                # strict, as in the reference
+    k = below === nothing ? n : n - below
+    nL = reverse(L[n-k+1:n])                                                  # value q belongs to eigenvector q of signal_vectors(k)
+    issorted(L) || sort!(L)
+    (k, nL)
+end
+
 # ---- (B) device-resident sclens() --------------------------------------------------------------------------------
-function sclens_hip(inp_df; th=60, p_step=0.001, n_perturb=20, centering="mean", device=0)
+# The reference's behaviour under failure (example.jl:9-14, scLENS.jl:504-508, :741-745): no device / out of device memory -> the CPU
+# path. Any other code is an error of the call and is re-thrown.
+function sclens_hip(inp_df; kwargs...)
+    try
+        return sclens_hip_device(inp_df; kwargs...)
+    catch e
+        (e isa HipError && e.code in (2, 3)) || rethrow()
+        println("(hip) ", e.msg, " -- falling back to device_=\"cpu\"")
+        kw = Dict(kwargs); delete!(kw, :device)
+        return scLENS.sclens(inp_df; device_="cpu", kw...)
+    end
+end
+
+function sclens_hip_device(inp_df; th=60, p_step=0.001, n_perturb=20, centering="mean", device=0)
+    if !(centering in ("mean", "median"))
+        # the reference's third branch (:655-657) is scaled_gdata(norm_l(scaled_gdata(x, "mean")), "cent") on a dense Float32 copy:
+        # the SAME function of x as the mean branch (z-score, equal-norm rows, centred columns), evaluated in Float32
+        println("Warning: The specified centering method is not supported in the current algorithm. scLENS will automatically use mean centering.")
+        centering = "mean"
+    end
     X_ = scLENS.df2sparr(inp_df)                                              # :662
     N, M = size(X_); nm = min(N, M)
     nz_row, nz_col, nz_val = findnz(X_)
@@ -127,15 +163,16 @@ function sclens_hip(inp_df; th=60, p_step=0.001, n_perturb=20, centering="mean",
             L_mp, _, b_min = scLENS._mp_calculation(L, Lr[1:end-1])           # host statistics stay in Julia (:537-538)
             lambda_c, _ = scLENS._tw(L, L_mp)
             # guard band of the hard cut `L .> lambda_c` (:539, :541): eigenvalues within 4 sqrt(n) eps32 lambda_max of it are
-            # replaced by float64 Rayleigh quotients of their eigenvectors (0-based, half-open index range for the ABI)
-            near = findall(abs.(L .- lambda_c) .<= 4 * sqrt(nm) * 5.96e-8 * L[end])
-            if !isempty(near) && length(near) <= 64
-                rho = Vector{Float64}(undef, last(near) - first(near) + 1)
+            # replaced by float64 Rayleigh quotients of THEIR eigenvectors (0-based, half-open index range for the ABI). The refined
+            # values of a near-degenerate pair may come out in the other order, so the cut is taken from the top and stays
+            # contiguous: k = the number of leading indices nm, nm-1, ... whose value exceeds lambda_c -- the vectors
+            # `signal_vectors(k)` returns -- and nL[q] is the quotient of vector q (the twin of api.cut_with_guard_band)
+            k, nL = cut_with_guard_band!(L, lambda_c, (lo, hi) -> begin
+                rho = Vector{Float64}(undef, hi - lo)
                 GC.@preserve rho check(ctx, ccall((:sclens_hip_session_refine_eigenvalues, LIB), Cint,
-                    (Ptr{Cvoid}, Int64, Int64, Ptr{Float64}), s, first(near) - 1, last(near), rho))
-                L[first(near):last(near)] .= rho
-            end
-            k = sum(L .> lambda_c); nL = reverse(L[L .> lambda_c])
+                    (Ptr{Cvoid}, Int64, Int64, Ptr{Float64}), s, lo, hi, rho))
+                rho
+            end)
             nV = Matrix{Float32}(undef, N, k)
             GC.@preserve nV check(ctx, ccall((:sclens_hip_session_signal_vectors, LIB), Cint, (Ptr{Cvoid}, Int64, Ptr{Float32}), s, k, nV))
             mpC_ = scLENS.mp_check(L_mp)
@@ -189,5 +226,5 @@ end
 end # module
 
 # One-line hook a maintainer adds at the top of scLENS.sclens (src/scLENS.jl:649):
-#     device_ == "hip" && return ScLENSHip.sclens_hip(inp_df; th=th, p_step=p_step, n_perturb=n_perturb)
-# On HipError code 2 (no device) or 3 (OOM) fall back to device_="cpu", mirroring example.jl:9-14 and :504-508.
+#     device_ == "hip" && return ScLENSHip.sclens_hip(inp_df; th=th, p_step=p_step, n_perturb=n_perturb, centering=centering)
+# sclens_hip falls back to device_="cpu" on HipError code 2 (no device) or 3 (out of device memory), mirroring example.jl:9-14 and :504-508.

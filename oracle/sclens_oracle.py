@@ -129,6 +129,18 @@ def logn_scale_median(Y: sp.csc_matrix) -> np.ndarray:
     return norm_l(scaled_gdata_median(dense)).astype(np.float64)
 
 
+def logn_scale_other(Y: sp.csc_matrix) -> np.ndarray:
+    """`logn_scale` for any other `centering` string (scLENS.jl:655-657, after the printed warning):
+    scaled_gdata(norm_l(scaled_gdata(Matrix{Float32}(x), "mean")), "cent") -- per gene (x - mean) / std, rows scaled to the mean
+    row norm, columns centred, all on a dense Float32 copy. The same function of x as the "mean" branch (zscore_with_l2 + "cent"),
+    which evaluates it through sparse Float64 identities; promoted to float64 on return like logn_scale_median."""
+    Xd = np.asarray(Y.todense(), dtype=np.float32)
+    mean = Xd.mean(axis=0, dtype=np.float32)
+    sd = Xd.std(axis=0, ddof=1, dtype=np.float32)
+    z = norm_l((Xd - mean[None, :]) / sd[None, :])
+    return (z - z.mean(axis=0, dtype=np.float32)[None, :]).astype(np.float64)
+
+
 def scale_main(X: sp.csc_matrix) -> Tuple[np.ndarray, dict]:
     """Inline Float64 normalisation of the data matrix with rec_vals (scLENS.jl:676-696)."""
     X = _as_csc_f32(X)
@@ -482,7 +494,8 @@ def sclens(
         ls = logn_scale_median  # :653-654
         scaled_X, rec_vals = ls(pre_scale(X_)), {}  # :697-698 (rec_vals stays empty)
     else:
-        raise ValueError("centering must be 'mean' or 'median' (the reference's third scaling :655-657 is not restated)")
+        ls = logn_scale_other  # :655-657 (the reference prints a warning first)
+        scaled_X, rec_vals = ls(pre_scale(X_)), {}  # :697-698
     Xr_scaled = ls(pre_scale(draws.X_r))  # :704
     nL, nV, L, L_mp, lambda_c, _ = get_sigev(scaled_X, Xr_scaled)  # :704
     mpC = mp_check(L_mp)  # :706

@@ -968,10 +968,16 @@ def sclens(inp_df, device_="gpu", th=60, p_step=0.001, n_perturb=20, centering="
     """
     if device_ != "gpu":
         raise NotImplementedError("sclens_amd implements the device path only; use the reference for device_='cpu'")
+    fallback_centering = False
     if centering not in ("mean", "median"):
-        # the reference prints a warning and runs a third, undocumented scaling (scLENS.jl:655-657); not restated
-        raise NotImplementedError(f"centering={centering!r}: only 'mean' and 'median' are implemented")
+        # scLENS.jl:655-657: the reference warns and runs scaled_gdata(norm_l(scaled_gdata(x, "mean")), "cent") on a dense Float32 copy.
+        # That is the SAME function of x as the mean branch -- (x - mean) / std per gene, rows scaled to the mean row norm, columns
+        # centred -- evaluated in Float32 instead of through the sparse Float64 identities of zscore_with_l2 (oracle.logn_scale_other
+        # restates it; tests/test_oracle.py pins the two against each other). The device path is fp32 either way: same warning, mean path.
+        print("Warning: The specified centering method is not supported in the current algorithm. scLENS will automatically use mean centering.")
+        centering, fallback_centering = "mean", True
     median = centering == "median"
+    want_rec = not median and not fallback_centering  # rec_vals is filled by the "mean" branch only (scLENS.jl:677-698)
     ctx = ctx or default_context()
     shard = shard or Shard()
     t_all = time.perf_counter()
@@ -1060,7 +1066,7 @@ def sclens(inp_df, device_="gpu", th=60, p_step=0.001, n_perturb=20, centering="
             free = workers[1:] if shard.rank == 0 else workers  # sessions for the null / binarised matrix on this rank
             jobs, w_bin = [], ses
             if shard.rank == 0:
-                jobs.append((0, lambda: ("data", ses.data_spectrum(not median))))
+                jobs.append((0, lambda: ("data", ses.data_spectrum(want_rec))))
             if shard.rank == r_null:
                 w_null = free[0]
                 jobs.append((workers.index(w_null), lambda: ("null", w_null.null_spectrum_pattern(null_future.result()))))
@@ -1075,7 +1081,7 @@ def sclens(inp_df, device_="gpu", th=60, p_step=0.001, n_perturb=20, centering="
         elif W == 1:  # serial order of the reference: null and data spectra, signal vectors, then Vr2
             w_bin = ses
             Lr = ses.null_spectrum_pattern(null_future.result())
-            L, rec_vals = ses.data_spectrum(not median)
+            L, rec_vals = ses.data_spectrum(want_rec)
             r_vr2 = None
         elif W == 2:
             # Two streams: data | null first. The binarised matrix (the longest of the three: all of its eigenvectors are wanted)
@@ -1099,7 +1105,7 @@ def sclens(inp_df, device_="gpu", th=60, p_step=0.001, n_perturb=20, centering="
 
                 bin_chain = pool.submit(null_then_binary)
                 try:
-                    L, rec_vals = ses.data_spectrum(not median)
+                    L, rec_vals = ses.data_spectrum(want_rec)
                     Lr = null_done.result()
                 except BaseException:
                     try:
@@ -1109,11 +1115,11 @@ def sclens(inp_df, device_="gpu", th=60, p_step=0.001, n_perturb=20, centering="
                     raise
                 r_vr2 = -2  # running on worker 1; joined after the signal vectors
             else:
-                (L, rec_vals), Lr = run_all([(0, lambda: ses.data_spectrum(not median)), (1, lambda: w_null.null_spectrum_pattern(null_future.result()))])
+                (L, rec_vals), Lr = run_all([(0, lambda: ses.data_spectrum(want_rec)), (1, lambda: w_null.null_spectrum_pattern(null_future.result()))])
                 r_vr2 = -1  # decomposed below, next to the signal vectors
         else:  # the main session keeps the data matrix's reflectors for signal_vectors; workers take the other two
             w_null, w_bin = workers[1], workers[2]
-            (L, rec_vals), Lr, (_, r_vr2) = run_all([(0, lambda: ses.data_spectrum(not median)), (1, lambda: w_null.null_spectrum_pattern(null_future.result())),
+            (L, rec_vals), Lr, (_, r_vr2) = run_all([(0, lambda: ses.data_spectrum(want_rec)), (1, lambda: w_null.null_spectrum_pattern(null_future.result())),
                                                      (2, w_bin.binary_basis)])
         L_mp, _, b_min = _mp_calculation(L, Lr[:-1])  # Lr[1:end-1] (:537, :576)
         lambda_c = _tw(L, L_mp)[0]

@@ -23,6 +23,7 @@ struct Ctx {
   // that marks them complete and the order they were built for (-1: none / not valid for the current reflectors)
   hipEvent_t q2_ev = nullptr;
   int64_t q2_tg_n = -1;
+  int q2_built_variant = -1;  // SCLENS_HIP_Q2_VARIANT the group data (T factors or LDS images) was last built for
   bool q2_prebuild = true;  // cleared by a caller that will ask for eigenvalues only (the null matrix)
   std::string err;
   // grow-only named device workspaces (freed at destroy); avoids hipMalloc inside hot loops

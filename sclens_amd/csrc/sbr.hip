@@ -27,6 +27,8 @@ namespace scl {
 
 constexpr int SB = 64;
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) void lds_void;
+typedef const __attribute__((address_space(1))) void glb_void;
 
 // Split-K factor of a product whose `tiles` output tiles (one workgroup each, one workgroup per CU) do not fill the 256 CUs:
 // the grid runs in ceil(tiles S / 256) rounds of K / S each, so the time goes like rounds(S) / S. (59 row tiles with S = 9 are
@@ -2451,6 +2453,242 @@ __global__ __launch_bounds__(256, 1) void sbr_q2_apply16d(SbrQ2Args a) {
   }
 }
 
+// ---- variant 8 (round 4): the group data as a PRE-BUILT image, moved global -> LDS by DMA.
+// What bound variant 7 was not the matrix pipe (69 MFMAs = ~550 cycles of a ~4 200-cycle group) but the ~430 vector instructions
+// around them (ISA count): every workgroup fetched the group's 32 reflectors + T as floats, split them into fp16 pieces and wrote
+// them to LDS with ~50 two-byte stores per thread -- the same work in all m / 64 workgroups -- and the register pressure of that
+// staging spilled to AGPRs (~100 moves per group). Here one kernel (sbr_q2_build_img, beside the inverse iteration on the
+// auxiliary stream) writes for every group (block b, task t) the finished LDS image once:
+//   part A  Vg' [reflector c][window row r], 100 floats per reflector               (operand of W' = Vg' Zw')
+//   part B  -(Vg Tg) [window row r][reflector c], 36 floats per row                 (operand of Zw' += (-Vg Tg) W')
+// each 16-byte chunk = four consecutive elements as [hi x 4 | lo x 4] fp16 pieces, 28 672 bytes per group, 6.3 GB at n = 30 016.
+// The T product is folded into part B (Zw' <- Zw' - (Vg Tg)(Vg' Zw')): two products per group instead of three (63 matrix
+// instructions, one split fewer, one dependent stage fewer). The apply kernel issues 7 `global_load_lds_dwordx4` per thread and
+// group, NBUF - 1 groups ahead, and splits only the vector window (v_cvt_pk_f16_f32 + v_fma_mix_f32: 2 instructions per element).
+constexpr int Q_IMG_A = QW * Q_RS;   // 3 200 floats
+constexpr int Q_IMG_B = QH * Q_NS;   // 3 456 floats
+constexpr int Q_IMG = 7 * 1024;      // floats per image: 7 wave-instructions of 1 KB per wave, four waves
+static_assert(Q_IMG_A + Q_IMG_B <= Q_IMG, "image layout");
+
+// index of group (b, t) among the groups that exist (t < tasks of sweep 32 b), for n a multiple of 64: blocks 2c and 2c + 1 have
+// n / 64 - c tasks each
+__host__ __device__ __forceinline__ int64_t sbr_q2_img_index(int b, int t, int64_t n) {
+  const int64_t q = n / SB, c = b >> 1;
+  return 2 * c * q - c * (c - 1) + ((b & 1) ? (q - c) : 0) + t;
+}
+static inline int64_t sbr_q2_img_count(int64_t n) { const int64_t q = n / SB; return q * q + q; }
+
+__global__ __launch_bounds__(256) void sbr_q2_build_img(const float* __restrict__ V2, int64_t ldv2, const float* __restrict__ TAU2,
+                                                        int64_t ldt, int64_t n, float* __restrict__ img) {
+  const int t = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+  if (t >= sbr_tasks_of((int64_t)b * QW, n)) return;
+  __shared__ float Vg[QH][QW + 1];
+  __shared__ float G[QW][QW + 1];
+  __shared__ float T[QW][QW + 1];
+  __shared__ float Y[QH][QW + 1];
+  __shared__ float tau[QW];
+  const int64_t S = (int64_t)b * QW;
+  for (int idx = tid; idx < QH * QW; idx += 256) {
+    const int c = idx / QH, r = idx % QH;  // consecutive threads read consecutive entries of one reflector
+    Vg[r][c] = sbr_vg(V2, ldv2, n, S, t, r, c);
+  }
+  for (int idx = tid; idx < QW * QW; idx += 256) T[idx >> 5][idx & 31] = 0.f;
+  if (tid < QW) {
+    const int64_t s = S + tid;
+    tau[tid] = (s + 2 < n && s + 1 + (int64_t)t * SB < n) ? TAU2[s * ldt + t] : 0.f;
+  }
+  __syncthreads();
+  {  // G = Vg' Vg
+    const int i = tid >> 3, j0 = 4 * (tid & 7);
+    double acc[4] = {0.0, 0.0, 0.0, 0.0};
+    for (int r = 0; r < QH; ++r) {
+      const double x = (double)Vg[r][i];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) acc[e] += x * (double)Vg[r][j0 + e];
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) G[i][j0 + e] = (float)acc[e];
+  }
+  __syncthreads();
+  // forward columnwise T factor: T[0:c, c] = -tau_c T[0:c, 0:c] (Vg[:, 0:c]' v_c), T[c][c] = tau_c (the recurrence of sbr_q2_build_t)
+  for (int c = 0; c < QW; ++c) {
+    if (tid < c) {
+      double acc = 0.0;
+      for (int j = tid; j < c; ++j) acc += (double)T[tid][j] * (double)G[j][c];
+      T[tid][c] = (float)(-(double)tau[c] * acc);
+    }
+    if (tid == c) T[c][c] = tau[c];
+    __syncthreads();
+  }
+  for (int idx = tid; idx < QH * QW; idx += 256) {  // Y = Vg Tg (Tg upper triangular)
+    const int r = idx >> 5, c = idx & 31;
+    double acc = 0.0;
+    for (int k = 0; k <= c; ++k) acc += (double)Vg[r][k] * (double)T[k][c];
+    Y[r][c] = (float)acc;
+  }
+  __syncthreads();
+  float* out = img + sbr_q2_img_index(b, t, n) * Q_IMG;
+  for (int ch = tid; ch < Q_IMG / 4; ch += 256) {
+    float x[4] = {0.f, 0.f, 0.f, 0.f};
+    if (ch < Q_IMG_A / 4) {
+      const int c = ch / (Q_RS / 4), r4 = ch % (Q_RS / 4);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) x[e] = (4 * r4 + e < QH) ? Vg[4 * r4 + e][c] : 0.f;
+    } else if (ch < (Q_IMG_A + Q_IMG_B) / 4) {
+      const int k = ch - Q_IMG_A / 4, r = k / (Q_NS / 4), c4 = k % (Q_NS / 4);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) x[e] = (4 * c4 + e < QW) ? -Y[r][4 * c4 + e] : 0.f;
+    }
+    SbrHL o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      o.h[e] = (_Float16)x[e];
+      o.l[e] = (_Float16)(x[e] - (float)o.h[e]);
+    }
+    f32x4 raw;
+    __builtin_memcpy(&raw, &o, 16);
+    *reinterpret_cast<f32x4*>(out + 4 * ch) = raw;
+  }
+}
+
+// x = hi + lo with two packed conversions and one mixed-precision fma per element (lo = x - hi exactly, hi taken as an fp16 operand)
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ SbrHL sbr_split_pk(f32x4 x) {
+  const f16x2 h01 = __builtin_convertvector(f32x2{x[0], x[1]}, f16x2);
+  const f16x2 h23 = __builtin_convertvector(f32x2{x[2], x[3]}, f16x2);
+  const unsigned u01 = __builtin_bit_cast(unsigned, h01), u23 = __builtin_bit_cast(unsigned, h23);
+  float l0, l1, l2, l3;
+  asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(l0) : "v"(u01), "v"(x[0]));
+  asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(l1) : "v"(u01), "v"(x[1]));
+  asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(l2) : "v"(u23), "v"(x[2]));
+  asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(l3) : "v"(u23), "v"(x[3]));
+  const f16x2 l01 = __builtin_convertvector(f32x2{l0, l1}, f16x2);
+  const f16x2 l23 = __builtin_convertvector(f32x2{l2, l3}, f16x2);
+  SbrHL o;
+  o.h = f16x4{h01[0], h01[1], h23[0], h23[1]};
+  o.l = f16x4{l01[0], l01[1], l23[0], l23[1]};
+  return o;
+}
+
+// the 7 DMA instructions of one image: lane l of wave w moves bytes [(q 256 + 64 w + l) 16, +16) of the image for q < 7
+__device__ __forceinline__ void sbr_q2_dma(const float* __restrict__ img, int64_t index, float* buf, int tid) {
+  const float* src = img + index * Q_IMG + 4 * tid;
+  float* dst = buf + 256 * (tid >> 6);
+#pragma unroll
+  for (int q = 0; q < 7; ++q)
+    __builtin_amdgcn_global_load_lds((glb_void*)(src + 1024 * q), (lds_void*)(dst + 1024 * q), 16, 0, 0);
+}
+
+__device__ __forceinline__ void sbr_q2_group16e(f32x4* z, const float* buf, int vi, int g) {
+  const float* VgT = buf;
+  const float* N = buf + Q_IMG_A;
+  SbrHL a0[5], a1[5];
+#pragma unroll
+  for (int rt = 0; rt < 5; ++rt) {
+    a0[rt] = sbr_ld_hl(VgT + vi * Q_RS + 16 * rt + 4 * g);
+    a1[rt] = sbr_ld_hl(VgT + (16 + vi) * Q_RS + 16 * (rt + 1) + 4 * g);
+  }
+  SbrHL zs[6];
+#pragma unroll
+  for (int rt = 0; rt < 6; ++rt) zs[rt] = sbr_split_pk(z[rt]);
+  f32x4 w0 = {0.f, 0.f, 0.f, 0.f}, w1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int rt = 0; rt < 5; ++rt) {
+    w0 = sbr_mfma3(a0[rt], zs[rt], w0);
+    w1 = sbr_mfma3(a1[rt], zs[rt + 1], w1);
+  }
+  SbrHL y0[5], y1[6];  // -(Vg Tg): reflector tile 0 reaches the window rows 0 .. 78, tile 1 the rows 0 .. 94
+#pragma unroll
+  for (int rt = 0; rt < 5; ++rt) y0[rt] = sbr_ld_hl(N + (16 * rt + vi) * Q_NS + 4 * g);
+#pragma unroll
+  for (int rt = 0; rt < 6; ++rt) y1[rt] = sbr_ld_hl(N + (16 * rt + vi) * Q_NS + 16 + 4 * g);
+  const SbrHL w0s = sbr_split_pk(w0), w1s = sbr_split_pk(w1);
+#pragma unroll
+  for (int rt = 0; rt < 6; ++rt) {
+    if (rt < 5) z[rt] = sbr_mfma3(y0[rt], w0s, z[rt]);
+    z[rt] = sbr_mfma3(y1[rt], w1s, z[rt]);
+  }
+}
+
+template <int QJ, int QNT, int NBUF>
+__global__ __launch_bounds__(256, 2) void sbr_q2_apply16e(SbrQ2Args a, const float* __restrict__ img) {
+  static_assert(NBUF == 2 || NBUF == 3, "one or two groups ahead");
+  constexpr int AH = NBUF - 1;
+  extern __shared__ __attribute__((aligned(16))) float q2lds[];  // NBUF images
+  float* lds = q2lds;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, vi = lane & 15, g = lane >> 4;
+  const int64_t v = (int64_t)blockIdx.x * 64 + wv * 16 + vi;
+  const bool live = v < a.m;
+  float* zrow = a.Zq + (live ? v : 0) * a.ldq + 3;
+  const int nsb = (a.nblk + QJ - 1) / QJ;
+  auto index_of = [&](int b, int t) -> int64_t {  // groups that do not exist read image 0 (never used)
+    return (b >= 0 && t < sbr_tasks_of((int64_t)b * QW, a.n)) ? sbr_q2_img_index(b, t, a.n) : 0;
+  };
+  // the first AH groups of the sequence: blocks nblk - 1, nblk - 2 at task 0 (QJ > AH)
+#pragma unroll
+  for (int i = 0; i < AH; ++i) sbr_q2_dma(img, index_of(a.nblk - 1 - i, 0), lds + i * Q_IMG, tid);
+  if (AH == 2) asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  int cur = 0;
+  f32x4 z[QNT];
+  for (int sb = 0; sb < nsb; ++sb) {
+    const int bh = a.nblk - 1 - sb * QJ, blow = bh - QJ + 1;
+    const int Kmax = sbr_tasks_of((int64_t)(blow > 0 ? blow : 0) * QW, a.n);
+    const int64_t base0 = (int64_t)blow * QW + 1;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the stores of the previous pass have left before rows are re-read
+#pragma unroll
+    for (int i = 0; i < QNT; ++i) z[i] = sbr_q2_ldz(zrow, base0 + 16 * i + 4 * g, a.n, live) * Q_ZSCALE;
+    for (int t = 0; t < Kmax; ++t) {
+      const int64_t base = base0 + (int64_t)t * SB;
+      f32x4 pz[4];
+      const bool more = t + 1 < Kmax;
+      if (more) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) pz[i] = sbr_q2_ldz(zrow, base + 16 * (QNT + i) + 4 * g, a.n, live) * Q_ZSCALE;
+      }
+#pragma unroll
+      for (int j = 0; j < QJ; ++j) {
+        int nb, nt;  // the group AH steps after this one in the sequence (j ascending inside a task, then the next task, then the next pass)
+        const int jj = j + AH;
+        if (jj < QJ) {
+          nb = bh - jj;
+          nt = t;
+        } else if (more) {
+          nb = bh - (jj - QJ);
+          nt = t + 1;
+        } else {
+          nb = bh - QJ - (jj - QJ);
+          nt = 0;
+        }
+        // its image goes to the buffer the PREVIOUS group was read from (all waves have passed the barrier behind it); these are the
+        // last memory instructions of the group, so `vmcnt(7)` below leaves exactly them in flight
+        asm volatile("" ::: "memory");
+        int nxt = cur + AH;
+        if (nxt >= NBUF) nxt -= NBUF;
+        sbr_q2_dma(img, index_of(nb, nt), lds + nxt * Q_IMG, tid);
+        asm volatile("" ::: "memory");
+        const int b = bh - j;
+        if (b >= 0 && t < sbr_tasks_of((int64_t)b * QW, a.n)) sbr_q2_group16e(z + 2 * (QJ - 1 - j), lds + cur * Q_IMG, vi, g);
+        if (AH == 2) asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        cur = (cur + 1 == NBUF) ? 0 : cur + 1;
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) sbr_q2_stz(zrow, base + 16 * i + 4 * g, a.n, live, z[i] * (1.f / Q_ZSCALE));
+      if (more) {
+#pragma unroll
+        for (int i = 0; i + 4 < QNT; ++i) z[i] = z[i + 4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) z[QNT - 4 + i] = pz[i];
+      } else {
+#pragma unroll
+        for (int i = 4; i < QNT; ++i) sbr_q2_stz(zrow, base + 16 * i + 4 * g, a.n, live, z[i] * (1.f / Q_ZSCALE));
+      }
+    }
+  }
+}
+
 // Zq[v][3 + r] <-> Zt[v][r]
 __global__ void sbr_q2_shift(const float* __restrict__ in, int64_t ldi, int64_t offi, float* __restrict__ out, int64_t ldo,
                              int64_t offo, int64_t n) {
@@ -2459,14 +2697,31 @@ __global__ void sbr_q2_shift(const float* __restrict__ in, int64_t ldi, int64_t 
   if (c < n) out[r * ldo + offo + c] = in[r * ldi + offi + c];
 }
 
+// 8 (default): pre-built group images + LDS-DMA; 7: split-fp16 products, reflectors staged by every workgroup (round 3);
+// 3: fp32 products (every product of the solver on the fp32 matrix cores); 0, 1, 5, 6: earlier kernels kept for comparison
+static int sbr_q2_variant(int64_t n) {
+  const char* eq2 = getenv("SCLENS_HIP_Q2_VARIANT");
+  int v = eq2 ? atoi(eq2) : 8;
+  if ((v == 8 || v == 9) && n % SB != 0) v = 7;  // the image index assumes an order that is a multiple of 64 (the two-stage solver pads)
+  return v;
+}
+
+// what the apply kernel of the selected variant needs besides the reflectors: the groups' T factors, or their finished LDS images
 static int sbr_q2_launch_build_t(Ctx* ctx, int64_t n, hipStream_t st) {
   const int64_t ldv2 = sbr_ldv2(n), ldt = n / SB + 2, nsweep = n - 2;
   const float* V2 = static_cast<const float*>(ctx->ws.count("sbr.V2") ? ctx->ws.at("sbr.V2").first : nullptr);
   const float* TAU2 = static_cast<const float*>(ctx->ws.count("sbr.TAU2") ? ctx->ws.at("sbr.TAU2").first : nullptr);
   if (!V2 || !TAU2 || nsweep <= 0) return ctx->fail(SCLENS_ERR_STATE, "sbr_q2_build_t: no reflectors of a preceding sb2st_f32 on this context");
   const int nblk = (int)((nsweep + QW - 1) / QW), nk = (int)((n - 1 + SB - 1) / SB);
-  SCL_WS(ctx, Tg, float, "sbr.Tg", (int64_t)nblk * nk * QW * QW);
-  hipLaunchKernelGGL(sbr_q2_build_t, dim3((unsigned)nk, (unsigned)nblk), dim3(64), 0, st, V2, ldv2, TAU2, ldt, n, nk, Tg);
+  const int variant = sbr_q2_variant(n);
+  if (variant == 8 || variant == 9) {
+    SCL_WS(ctx, img, float, "sbr.Q2img", (sbr_q2_img_count(n) + 1) * Q_IMG);
+    hipLaunchKernelGGL(sbr_q2_build_img, dim3((unsigned)nk, (unsigned)nblk), dim3(256), 0, st, V2, ldv2, TAU2, ldt, n, img);
+  } else {
+    SCL_WS(ctx, Tg, float, "sbr.Tg", (int64_t)nblk * nk * QW * QW);
+    hipLaunchKernelGGL(sbr_q2_build_t, dim3((unsigned)nk, (unsigned)nblk), dim3(64), 0, st, V2, ldv2, TAU2, ldt, n, nk, Tg);
+  }
+  ctx->q2_built_variant = variant;
   SCL_HIP(ctx, hipGetLastError());
   return SCLENS_OK;
 }
@@ -2493,11 +2748,15 @@ int sbr_apply_q2(Ctx* ctx, int64_t n, float* Zt, int64_t m, int64_t ldz) {
   const int64_t nsweep = n - 2;
   if (nsweep <= 0) return SCLENS_OK;
   const int nblk = (int)((nsweep + QW - 1) / QW), nk = (int)((n - 1 + SB - 1) / SB);
-  SCL_WS(ctx, Tg, float, "sbr.Tg", (int64_t)nblk * nk * QW * QW);
-  if (ctx->q2_tg_n == n && ctx->q2_ev)  // built on the auxiliary stream after the chase
-    SCL_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->q2_ev, 0));
-  else
+  const int q2_variant = sbr_q2_variant(n);
+  if (ctx->q2_tg_n == n && ctx->q2_ev && ctx->q2_built_variant == q2_variant) {  // built on the auxiliary stream after the chase
+    SCL_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->q2_ev, 0));                 // (or by an earlier call on these reflectors)
+  } else {
     SCL_TRY(sbr_q2_launch_build_t(ctx, n, ctx->stream));
+    ctx->q2_tg_n = n;  // valid until the next chase on this context (sb2st_f32 resets it)
+  }
+  const float* Tg = static_cast<const float*>(ctx->ws.count("sbr.Tg") ? ctx->ws.at("sbr.Tg").first : nullptr);
+  const float* q2img = static_cast<const float*>(ctx->ws.count("sbr.Q2img") ? ctx->ws.at("sbr.Q2img").first : nullptr);
   // the apply kernel works on the shifted layout Zq[v][3 + row] (16-byte aligned register quads, see above)
   const int64_t ldq = round_up(n + 3, 4);
   SCL_WS(ctx, Zq, float, "sbr.Zq", m * ldq);
@@ -2516,10 +2775,19 @@ int sbr_apply_q2(Ctx* ctx, int64_t n, float* Zt, int64_t m, int64_t ldz) {
   // ahead; the default until round 3) at n = 30 016, m = 15 008, orthogonality of the result 5.1e-7 against 4.6e-7
   // (profiles/r03_q2_variants.log). 6 = 3 with the deeper fetch (same bits, same time), 5 = 7 with the shallow one (same bits as 7,
   // 517 ms), 0 / 1: the round-2 kernel. SCLENS_HIP_Q2_VARIANT=3 keeps every product of the solver on the fp32 matrix cores.
-  const char* eq2 = getenv("SCLENS_HIP_Q2_VARIANT");
-  const int q2_variant = eq2 ? atoi(eq2) : 7;
+  // 8 (default since round 4): pre-built images + LDS-DMA two groups ahead (three LDS buffers, one workgroup per CU); 9: one group
+  // ahead (two buffers, two workgroups per CU)
   const dim3 q2grid((unsigned)((m + 63) / 64));
-  if (q2_variant == 0)
+  if (q2_variant == 8 || q2_variant == 9) {
+    const int lds_bytes = (q2_variant == 8 ? 3 : 2) * Q_IMG * (int)sizeof(float);
+    if (q2_variant == 8) {
+      SCL_TRY(ensure_dyn_lds(ctx, reinterpret_cast<const void*>(sbr_q2_apply16e<4, 12, 3>), lds_bytes));
+      hipLaunchKernelGGL((sbr_q2_apply16e<4, 12, 3>), q2grid, dim3(256), lds_bytes, ctx->stream, qa, q2img);
+    } else {
+      SCL_TRY(ensure_dyn_lds(ctx, reinterpret_cast<const void*>(sbr_q2_apply16e<4, 12, 2>), lds_bytes));
+      hipLaunchKernelGGL((sbr_q2_apply16e<4, 12, 2>), q2grid, dim3(256), lds_bytes, ctx->stream, qa, q2img);
+    }
+  } else if (q2_variant == 0)
     hipLaunchKernelGGL((sbr_q2_apply16<4, 12, false>), q2grid, dim3(256), 0, ctx->stream, qa);
   else if (q2_variant == 1)
     hipLaunchKernelGGL((sbr_q2_apply16<4, 12, true>), q2grid, dim3(256), 0, ctx->stream, qa);

@@ -1,5 +1,7 @@
 """CPU: the C-ABI library loads and exports every function include/sclens_hip.h declares (no GPU compute)."""
 import os
+
+import numpy as np
 import re
 
 from sclens_amd import _lib
@@ -184,3 +186,22 @@ def test_ctypes_signatures_match_the_header():
         want_ret = {"int": C.c_int, "void": None, "const char*": C.c_char_p, "int64_t": C.c_int64, "double": C.c_double,
                     "void*": C.c_void_p}[c_ret]
         assert res is want_ret or (res == want_ret), f"{name}: returns {c_ret}"
+
+
+def test_julia_shim_takes_the_signal_cut_from_the_top_and_falls_back_like_the_reference():
+    """The shim must be the Python twin where decisions are made: after the float64 refinement the number of
+    signals is NOT `sum(L .> lambda_c)` (a close pair may come out in the other order and the retained set would stop being
+    contiguous) but the count from the top (api.cut_with_guard_band); codes 2 / 3 fall back to device_="cpu"; an unsupported
+    `centering` string prints the reference's warning and runs the mean branch (scLENS.jl:655-657)."""
+    src = open(os.path.join(ROOT, "julia", "scLENS_hip.jl")).read()
+    code = "\n".join(line.split("#", 1)[0] for line in src.splitlines())  # comments stripped
+    assert "sum(L .> lambda_c)" not in code
+    assert "cut_with_guard_band!(L, lambda_c" in code and "findlast(x -> !(x > lambda_c), L)" in code
+    assert "e.code in (2, 3)" in code and 'device_="cpu"' in code
+    assert "not supported in the current algorithm" in src
+    # the helper agrees with the Python twin on a hand case: a refined pair that swaps order around the cut
+    from sclens_amd import api
+
+    L = np.array([0.5, 1.0, 1.5, 2.0 + 1e-7, 2.0 + 2e-7, 3.0, 9.0])
+    Lw, k, nL, guard = api.cut_with_guard_band(L, 2.0 + 1.5e-7, 4.0, lambda lo, hi: np.array([2.0 + 3e-7, 2.0 + 1e-7][: hi - lo]))
+    assert k == 2 and nL.tolist() == [9.0, 3.0] and guard["refined"]

@@ -346,8 +346,24 @@ def test_sclens_median_centering(ctx, N, M):
     assert np.array_equal(rr["a_b"], ro["a_b"])
     assert np.abs(rr["rob_score"] - ro["rob_score"]).max() < 3e-3
     assert np.array_equal(res["sig_id"], ref["sig_id"])
-    with pytest.raises(NotImplementedError):
-        api.sclens(X, draws=d, ctx=ctx, centering="mode")
+
+
+def test_sclens_unsupported_centering_string_runs_the_reference_fallback(ctx, capsys):
+    """Any other `centering` string (scLENS.jl:655-657): the reference prints a warning and runs
+    scaled_gdata(norm_l(scaled_gdata(x, "mean")), "cent") -- the mean branch's function of x evaluated in Float32 -- and leaves
+    rec_vals empty (:697-698). Device: same warning, mean path, empty rec_vals; against the oracle's restatement of that branch."""
+    X = synth_counts(300, 500, seed=1, C=5, marker_frac=0.2, marker_sd=1.5)
+    d = api.make_draws(X, seed=7, p_th_trials=300)
+    od = O.Draws(d.z_idx1, d.z_idx2, d.X_r, d.p_th, d.sampler)
+    ref = O.sclens(X, od, n_perturb=4, null_tol=O.NULL_DROP, centering="mode", max_search_iters=6)
+    res = api.sclens(X, draws=d, n_perturb=4, ctx=ctx, centering="mode", streams=2, max_search_iters=6)
+    assert "not supported in the current algorithm" in capsys.readouterr().out
+    assert res["rec_vals"] == {} and ref["rec_vals"] == {}
+    assert np.abs(res["L"] - ref["L"]).max() < 2e-4 * ref["L"].max()
+    k = len(ref["signal_ev"])
+    assert len(res["signal_ev"]) == k > 0 and np.allclose(res["signal_ev"], ref["signal_ev"], rtol=2e-4)
+    assert res["n_search"] == ref["n_search"] and res["p_"] == ref["p_"]
+    assert np.array_equal(res["sig_id"], ref["sig_id"])
 
 
 def test_late_candidate_attachment_equals_upfront_session(ctx):

@@ -159,3 +159,17 @@ def test_literal_null_eigenvalue_rule_versus_the_dropped_one():
     # the data-matrix spectrum has exactly one eigenvalue that the two rules treat differently
     L = lit["L"]
     assert np.sum(np.abs(L) <= O.NULL_DROP * L.max()) == 1
+
+
+def test_third_scaling_branch_is_the_mean_branch_in_float32():
+    """scLENS.jl:655-657 (unsupported `centering` strings) against :651-652: the same function of x -- (x - mean) / std per gene,
+    rows scaled to the mean row norm, columns centred -- once on a dense Float32 copy, once through zscore_with_l2's sparse
+    Float64 identities. They must agree to Float32 rounding; this is why the device path maps the branch onto its mean path."""
+    from sclens_amd.synth import synth_counts
+
+    X = synth_counts(220, 340, seed=3, C=4, marker_frac=0.2, marker_sd=1.5)
+    Y = O.pre_scale(X)
+    a, b = O.logn_scale(Y), O.logn_scale_other(Y)
+    assert a.shape == b.shape
+    assert np.abs(a - b).max() < 2e-5 * np.abs(a).max()
+    assert np.abs(b.mean(axis=0)).max() < 1e-6
