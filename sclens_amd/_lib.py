@@ -231,6 +231,10 @@ class Context:
         except Exception:
             pass
 
+    def trim_pool(self):
+        """hand the idle blocks of the library's memory pool on this device back to the driver (sclens_hip_trim)"""
+        self.lib.sclens_hip_trim(self.device)
+
     def set_option(self, name: str, value: int):
         self.check(self.lib.sclens_hip_set_option(self.h, name.encode(), int(value)))
 

@@ -954,6 +954,9 @@ def _extract(inp):
     return X, cell_id, gene_id
 
 
+_LAST_SHAPE = None  # (device, N, M) of the previous sclens() call of this process
+
+
 def sclens(inp_df, device_="gpu", th=60, p_step=0.001, n_perturb=20, centering="mean", draws: Optional[Draws] = None,
            seed: Optional[int] = None, ctx: Optional[Context] = None, max_search_iters: Optional[int] = None,
            keep_intermediates: bool = False, verbose: bool = False, shard: Optional[Shard] = None,
@@ -983,6 +986,12 @@ def sclens(inp_df, device_="gpu", th=60, p_step=0.001, n_perturb=20, centering="
     t_all = time.perf_counter()
     X_, cell_id, gene_id = _extract(inp_df)  # :662
     N, M = X_.shape
+    global _LAST_SHAPE
+    if _LAST_SHAPE is not None and _LAST_SHAPE != (ctx.device, N, M):
+        # the library's memory pool keeps the blocks of the previous call for the next call of the SAME shape; a different shape
+        # asks for other size classes, so the idle blocks go back to the driver first instead of piling up beside the new ones
+        ctx.trim_pool()
+    _LAST_SHAPE = (ctx.device, N, M)
     if streams is None:
         # concurrent decompositions pay while one decomposition cannot fill the GPU (latency-bound column steps / panels /
         # bulge chasing: 4.8 s instead of 7.9 s at 10 000 x 20 000 with three streams). At n >= 16 000 a search step used to be

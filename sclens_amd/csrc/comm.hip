@@ -91,10 +91,12 @@ struct Comm {
 
 static int comm_scratch(Comm* c, size_t bytes) {
   if (bytes <= c->scratch_bytes) return SCLENS_OK;
-  if (c->scratch) hipFree(c->scratch);
+  // through the pool, like every other allocation of the library: a plain hipMalloc does not see the pool's idle blocks and can
+  // fail while the library is sitting on tens of GB of cached memory
+  if (c->scratch) pool_free(c->scratch, c->ctx->stream);
   c->scratch = nullptr;
   c->scratch_bytes = 0;
-  SCL_HIP(c->ctx, hipMalloc(&c->scratch, bytes));
+  SCL_HIP(c->ctx, pool_malloc(&c->scratch, bytes));
   c->scratch_bytes = bytes;
   return SCLENS_OK;
 }
@@ -119,6 +121,7 @@ int comm_create(Ctx* ctx, const uint8_t* id, int rank, int world, Comm** out) {
   c->ctx = ctx;
   c->rank = rank;
   c->world = world;
+  pool_trim(ctx->device);  // RCCL allocates its own buffers with hipMalloc: hand the idle blocks back first
   ncclResult_t r = api->CommInitRank(&c->comm, world, u, rank);
   if (r != ncclSuccess) {
     delete c;
@@ -132,7 +135,7 @@ void comm_destroy(Comm* c) {
   if (!c) return;
   hipStreamSynchronize(c->ctx->stream);
   if (c->comm) rccl_api()->CommDestroy(c->comm);
-  if (c->scratch) hipFree(c->scratch);
+  if (c->scratch) pool_free(c->scratch, nullptr);  // the stream has just been synchronised
   delete c;
 }
 

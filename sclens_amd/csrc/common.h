@@ -67,6 +67,16 @@ struct Ctx {
   void release_all();
 };
 
+// Everything a context may still have in flight on a block it is about to hand back: BOTH of its streams (the look-ahead of the band
+// reduction and the group data of the second back-transformation run on the auxiliary one). hipFree used to synchronise the whole
+// device as a side effect; the pool (pool.hip) does not, so every path that returns a block while work may be queued calls this
+// first -- in particular the error paths, which leave a function in the middle of a sequence of launches.
+static inline void ctx_quiesce(Ctx* c) {
+  if (!c) return;
+  if (c->stream) (void)hipStreamSynchronize(c->stream);
+  if (c->aux_stream) (void)hipStreamSynchronize(c->aux_stream);
+}
+
 #define SCL_HIP(ctx, expr)                                                                       \
   do {                                                                                           \
     hipError_t e__ = (expr);                                                                     \

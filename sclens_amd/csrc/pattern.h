@@ -40,7 +40,7 @@ struct PatternOwner {  // owns the device arrays of a PatternDev
 int pattern_build(Ctx* ctx, int64_t N, int64_t M, const int64_t* colptr, const int32_t* rowval, const float* nzval,
                   int64_t ncand, const uint32_t* z1, const uint32_t* z2, PatternOwner* out, int64_t row0 = 0,
                   int64_t N_global = 0);
-void pattern_free(PatternOwner* p);
+void pattern_free(PatternOwner* p, Ctx* busy = nullptr);  // busy: a context whose streams may still hold work on the blocks (error paths)
 // device helper shared by both builders: base_val_csr / cand_pos_csr from csr2csc, base_val, cand_pos (SCLENS_HIP_VAL_CSR=0: skip)
 int pattern_add_csr_companions(Ctx* ctx, PatternOwner* out);
 // The same arrays built on the device from the counts' CSC (pattern_dev.hip); draw != 0 also draws the candidate list there
@@ -63,7 +63,7 @@ struct Counts {
   int32_t* row = nullptr;     // [nnz]
   float* val = nullptr;       // [nnz]
 };
-void counts_free(Counts* c);
+void counts_free(Counts* c, Ctx* busy = nullptr);
 
 // Row-sharded session: the all-reduce the host supplies. dtype 0 = fp64, 1 = fp32; sum over all ranks, in
 // place, on a device buffer; called from the thread that made the session call, after the session's stream has been

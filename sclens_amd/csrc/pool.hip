@@ -28,8 +28,27 @@ bool pool_enabled() {
   static const bool on = !(getenv("SCLENS_HIP_POOL") && atoi(getenv("SCLENS_HIP_POOL")) == 0);
   return on;
 }
-size_t pool_cap_bytes() {  // cached (idle) bytes per device above which freed blocks go straight back to the driver
-  static const size_t cap = getenv("SCLENS_HIP_POOL_MAX_GB") ? (size_t)atoll(getenv("SCLENS_HIP_POOL_MAX_GB")) << 30 : (size_t)160 << 30;
+// Cached (idle) bytes per device above which freed blocks go straight back to the driver: SCLENS_HIP_POOL_MAX_GB, else HALF of the
+// device's memory (hipMemGetInfo; 144 GB on an MI355X, 32 GB on a 64 GB part) -- a fixed 160 GB (round 3) was more than some devices
+// own. Other allocators of the process (RCCL, rocPRIM, the host framework) do not see the cache: comm_create trims it before
+// RCCL allocates, sclens_hip_trim() is the public hook, and a failed pool_malloc trims and retries.
+size_t pool_cap_bytes(int dev) {
+  static std::map<int, size_t> caps;  // under g_mu
+  auto it = caps.find(dev);
+  if (it != caps.end()) return it->second;
+  size_t cap = (size_t)64 << 30;
+  if (const char* e = getenv("SCLENS_HIP_POOL_MAX_GB")) {
+    cap = (size_t)atoll(e) << 30;
+  } else {
+    size_t fr = 0, tot = 0;
+    int cur = 0;
+    hipGetDevice(&cur);
+    if (cur != dev) hipSetDevice(dev);
+    if (hipMemGetInfo(&fr, &tot) == hipSuccess && tot > 0) cap = tot / 2;
+    if (cur != dev) hipSetDevice(cur);
+    (void)hipGetLastError();
+  }
+  caps[dev] = cap;
   return cap;
 }
 size_t size_class(size_t bytes) {
@@ -102,7 +121,7 @@ void pool_free(void* p, hipStream_t stream) {
   g_live.erase(it);
   DevPool& dp = g_pool[dev];
   dp.live -= sz;
-  if (dp.cached + sz > pool_cap_bytes()) {
+  if (dp.cached + sz > pool_cap_bytes(dev)) {
     lk.unlock();
     hipFree(p);
     return;

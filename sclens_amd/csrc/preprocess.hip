@@ -291,7 +291,7 @@ int preprocess_keep(Ctx* ctx, Counts** out) {
   if (pool_malloc((void**)&c->colptr, sizeof(int64_t) * (ng + 1)) != hipSuccess ||
       pool_malloc((void**)&c->row, sizeof(int32_t) * (nnz > 4 ? nnz : 4)) != hipSuccess ||
       pool_malloc((void**)&c->val, sizeof(float) * (nnz > 4 ? nnz : 4)) != hipSuccess) {
-    counts_free(c);
+    counts_free(c, ctx);
     return ctx->fail(SCLENS_ERR_OOM, "preprocess_keep: out of device memory");
   }
   hipLaunchKernelGGL(k_pp_gather, dim3((unsigned)((ng + 3) / 4)), dim3(256), 0, st, ng, d_genes, d_colptr, d_row, d_val,
@@ -300,7 +300,7 @@ int preprocess_keep(Ctx* ctx, Counts** out) {
   if (e == hipSuccess) e = hipMemcpyAsync(c->colptr, d_ocol, sizeof(int64_t) * (ng + 1), hipMemcpyDeviceToDevice, st);
   if (e == hipSuccess) e = hipStreamSynchronize(st);
   if (e != hipSuccess) {
-    counts_free(c);
+    counts_free(c, ctx);
     return ctx->fail(SCLENS_ERR_HIP, std::string("preprocess_keep: ") + hipGetErrorString(e));
   }
   ctx->pp.valid = false;

@@ -18,7 +18,8 @@ void* Ctx::workspace(const std::string& name, size_t bytes) {
   auto it = ws.find(name);
   if (it != ws.end() && it->second.second >= bytes) return it->second.first;
   if (it != ws.end()) {
-    pool_free(it->second.first, stream);
+    ctx_quiesce(this);  // regrow: kernels of either stream may still use the old block
+    pool_free(it->second.first, nullptr);
     ws.erase(it);
   }
   if (bytes == 0) bytes = 16;
@@ -34,7 +35,8 @@ void* Ctx::workspace(const std::string& name, size_t bytes) {
 void Ctx::release(const std::string& name) {
   auto it = ws.find(name);
   if (it != ws.end()) {
-    pool_free(it->second.first, stream);
+    ctx_quiesce(this);
+    pool_free(it->second.first, nullptr);
     ws.erase(it);
   }
 }
@@ -163,8 +165,11 @@ int pattern_build(Ctx* ctx, int64_t N, int64_t M, const int64_t* colptr, const i
   SCL_HIP(ctx, hipStreamSynchronize(ctx->stream));
   return pattern_add_csr_companions(ctx, out);
 }
-void pattern_free(PatternOwner* p) {
-  for (void* q : p->allocs) pool_free(q, nullptr);  // contract: no session uses the pattern any more (blocking API: its streams are idle)
+void pattern_free(PatternOwner* p, Ctx* busy) {
+  // contract of the normal path: no session uses the pattern any more and the blocking API has left its streams idle (busy == nullptr).
+  // Error paths leave a builder between launches: they pass the context whose streams may still hold work on the blocks.
+  ctx_quiesce(busy);
+  for (void* q : p->allocs) pool_free(q, nullptr);
   p->allocs.clear();
   p->dev = PatternDev();
   p->base_val = nullptr;
@@ -278,12 +283,12 @@ static int session_create_impl(Ctx* ctx, int64_t N, int64_t M, const int64_t* co
   s->cells_major = (N <= M) ? 1 : 0;
   int rc = counts ? pattern_build_device(ctx, N, M, counts->colptr, counts->row, counts->val, ncand, z1, z2, 0, 0, &s->pat, counts->nnz)
                   : pattern_build(ctx, N, M, colptr, rowval, nzval, ncand, z1, z2, &s->pat);
-  if (rc != SCLENS_OK) { pattern_free(&s->pat); delete s; return rc; }
+  if (rc != SCLENS_OK) { pattern_free(&s->pat, ctx); delete s; return rc; }
   s->ldb = round_up(s->K, 32);
   s->lda = round_up(s->n, 32);
   s->ldz = round_up(s->n, 32);
   s->ldn = round_up(N, 32);
-  auto fail = [&](int code) { pattern_free(&s->pat); for (void* p : s->allocs) pool_free(p, s->ctx->stream); delete s; return code; };
+  auto fail = [&](int code) { pattern_free(&s->pat, s->ctx); for (void* p : s->allocs) pool_free(p, nullptr); delete s; return code; };
   if ((rc = s->dmalloc((void**)&s->val, sizeof(float) * s->pat.dev.val_floats())) != SCLENS_OK) return fail(rc);
   if ((rc = s->dmalloc((void**)&s->Bmain, sizeof(float) * (size_t)s->n * s->ldb)) != SCLENS_OK) return fail(rc);
   if ((rc = s->dmalloc((void**)&s->Btmp, sizeof(float) * (size_t)s->n * s->ldb)) != SCLENS_OK) return fail(rc);
@@ -308,7 +313,7 @@ int pattern_create_drawn_from_counts(Ctx* ctx, const Counts* c, uint64_t seed, P
   PatternOwner* p = new PatternOwner();
   const int rc = pattern_build_device(ctx, c->N, c->M, c->colptr, c->row, c->val, 0, nullptr, nullptr, 1, seed, p, c->nnz);
   if (rc != SCLENS_OK) {
-    pattern_free(p);
+    pattern_free(p, ctx);
     delete p;
     return rc;
   }
@@ -321,7 +326,7 @@ int counts_upload(Ctx* ctx, int64_t N, int64_t M, const int64_t* colptr, const i
     return ctx->fail(SCLENS_ERR_ARG, "counts_upload: bad arguments");
   Counts* c = new Counts();
   c->device = ctx->device; c->N = N; c->M = M; c->nnz = colptr[M];
-  auto bail = [&](int code) { counts_free(c); return code; };
+  auto bail = [&](int code) { counts_free(c, ctx); return code; };
   if (pool_malloc((void**)&c->colptr, sizeof(int64_t) * (M + 1)) != hipSuccess || pool_malloc((void**)&c->row, sizeof(int32_t) * std::max<int64_t>(c->nnz, 4)) != hipSuccess ||
       pool_malloc((void**)&c->val, sizeof(float) * std::max<int64_t>(c->nnz, 4)) != hipSuccess)
     return bail(ctx->fail(SCLENS_ERR_OOM, "counts_upload: out of device memory"));
@@ -342,9 +347,10 @@ int counts_download(Ctx* ctx, const Counts* c, int64_t* colptr, int32_t* rowval,
   SCL_HIP(ctx, hipStreamSynchronize(st));
   return SCLENS_OK;
 }
-void counts_free(Counts* c) {
+void counts_free(Counts* c, Ctx* busy) {
   if (!c) return;
-  pool_free(c->colptr, nullptr);  // contract: no session / pattern build reads it any more (blocking API)
+  ctx_quiesce(busy);              // error paths: an upload / gather may still be queued on that context
+  pool_free(c->colptr, nullptr);  // contract otherwise: no session / pattern build reads it any more (blocking API)
   pool_free(c->row, nullptr);
   pool_free(c->val, nullptr);
   delete c;
@@ -355,7 +361,7 @@ int pattern_create(Ctx* ctx, int64_t N, int64_t M, const int64_t* colptr, const 
   PatternOwner* p = new PatternOwner();
   const int rc = pattern_build(ctx, N, M, colptr, rowval, nzval, ncand, z1, z2, p);
   if (rc != SCLENS_OK) {
-    pattern_free(p);
+    pattern_free(p, ctx);
     delete p;
     return rc;
   }
@@ -368,7 +374,7 @@ int pattern_create_drawn(Ctx* ctx, int64_t N, int64_t M, const int64_t* colptr, 
   PatternOwner* p = new PatternOwner();
   const int rc = pattern_build_device(ctx, N, M, colptr, rowval, nzval, 0, nullptr, nullptr, 1, seed, p);
   if (rc != SCLENS_OK) {
-    pattern_free(p);
+    pattern_free(p, ctx);
     delete p;
     return rc;
   }
@@ -439,7 +445,7 @@ int session_create_sharded(Ctx* ctx, int64_t N_global, int64_t row0, int64_t N_l
   s->lda = round_up(s->n, 32);
   s->ldz = round_up(s->n, 32);
   s->ldn = round_up(N_local, 32);
-  auto fail = [&](int code) { pattern_free(&s->pat); for (void* p : s->allocs) pool_free(p, s->ctx->stream); delete s; return code; };
+  auto fail = [&](int code) { pattern_free(&s->pat, s->ctx); for (void* p : s->allocs) pool_free(p, nullptr); delete s; return code; };
   if ((rc = s->dmalloc((void**)&s->val, sizeof(float) * s->pat.dev.val_floats())) != SCLENS_OK) return fail(rc);
   if ((rc = s->dmalloc((void**)&s->Bmain, sizeof(float) * (size_t)s->n * s->ldb)) != SCLENS_OK) return fail(rc);
   if ((rc = s->dmalloc((void**)&s->Btmp, sizeof(float) * (size_t)s->n * s->ldb)) != SCLENS_OK) return fail(rc);
@@ -479,7 +485,7 @@ int session_create_sharded_drawn(Ctx* ctx, int64_t N_global, int64_t row0, int64
   s->sh.N_global = N_global; s->sh.row0 = row0; s->sh.fn = fn; s->sh.user = user;
   const BlockDraw blk{N_global, row0, nnz_global};
   int rc = pattern_build_device(ctx, N_local, M, colptr, rowval, nzval, 0, nullptr, nullptr, 1, seed, &s->pat, -1, &blk);
-  if (rc != SCLENS_OK) { pattern_free(&s->pat); delete s; return rc; }
+  if (rc != SCLENS_OK) { pattern_free(&s->pat, ctx); delete s; return rc; }
   // until the host has gathered the ranks' counts the window is unknown: samples are refused (population 0 < m)
   s->pat.dev.cand_off = 0;
   s->pat.dev.ncand_global = s->pat.dev.ncand;
@@ -487,7 +493,7 @@ int session_create_sharded_drawn(Ctx* ctx, int64_t N_global, int64_t row0, int64
   s->lda = round_up(s->n, 32);
   s->ldz = round_up(s->n, 32);
   s->ldn = round_up(N_local, 32);
-  auto fail = [&](int code) { pattern_free(&s->pat); for (void* p : s->allocs) pool_free(p, s->ctx->stream); delete s; return code; };
+  auto fail = [&](int code) { pattern_free(&s->pat, s->ctx); for (void* p : s->allocs) pool_free(p, nullptr); delete s; return code; };
   if ((rc = s->dmalloc((void**)&s->val, sizeof(float) * s->pat.dev.val_floats())) != SCLENS_OK) return fail(rc);
   if ((rc = s->dmalloc((void**)&s->Bmain, sizeof(float) * (size_t)s->n * s->ldb)) != SCLENS_OK) return fail(rc);
   if ((rc = s->dmalloc((void**)&s->Btmp, sizeof(float) * (size_t)s->n * s->ldb)) != SCLENS_OK) return fail(rc);
@@ -547,7 +553,7 @@ int session_clone(Ctx* ctx2, Session* src, Session** out) {
   s->Z0t = src->Z0t; s->theta0 = src->theta0; s->b0 = src->b0; s->use_chefsi = src->use_chefsi;
   s->k = src->k;
   int rc;
-  auto fail = [&](int code) { for (void* p : s->allocs) pool_free(p, s->ctx->stream); delete s; return code; };
+  auto fail = [&](int code) { ctx_quiesce(s->ctx); for (void* p : s->allocs) pool_free(p, nullptr); delete s; return code; };
   if ((rc = s->dmalloc((void**)&s->val, sizeof(float) * s->pat.dev.val_floats())) != SCLENS_OK) return fail(rc);
   if ((rc = s->dmalloc((void**)&s->Btmp, sizeof(float) * (size_t)s->n * s->ldb)) != SCLENS_OK) return fail(rc);
   if ((rc = s->dmalloc((void**)&s->A, sizeof(float) * (size_t)s->n * s->lda)) != SCLENS_OK) return fail(rc);

@@ -30,6 +30,9 @@ class FakeContext:
         with FakeContext._lock:
             FakeContext.live += 1
 
+    def trim_pool(self):
+        pass
+
     def malloc(self, nbytes):
         with FakeContext._lock:
             base = FakeContext._next * FakeContext.SPAN

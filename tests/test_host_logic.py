@@ -75,13 +75,17 @@ def test_draw_generators_contract():
     assert len(np.unique(a)) == 40 and np.array_equal(a, d.sampler("search", 3, len(d.z_idx1), 40))
 
 
-def test_sclens_refuses_cpu_and_unknown_centering():
-    """No CPU fallback inside the package; the reference's undocumented third scaling (scLENS.jl:655-657) is not restated."""
+def test_sclens_refuses_cpu_and_maps_unknown_centering_onto_the_reference_fallback(capsys):
+    """No CPU fallback inside the package. An unsupported `centering` string is NOT an error in the reference (scLENS.jl:655-657:
+    a warning, then the mean branch's scaling in Float32): sclens() prints that warning and proceeds (here: up to the missing
+    device); the per-call scaling drop-in has no such branch in the reference's API and keeps refusing."""
     X = synth_counts(60, 90, seed=2, C=3)
     with pytest.raises(NotImplementedError):
         api.sclens(X, device_="cpu")
-    with pytest.raises(NotImplementedError):
+    with pytest.raises(Exception) as ei:  # no GPU in the CPU suite: the call gets as far as creating the context
         api.sclens(X, centering="mode")
+    assert not isinstance(ei.value, NotImplementedError)
+    assert "not supported in the current algorithm" in capsys.readouterr().out
     with pytest.raises(NotImplementedError):
         api.logn_scale(X, centering="mode")
 
