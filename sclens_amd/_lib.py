@@ -284,9 +284,14 @@ class Comm:
     def __init__(self, ctx: Context, rank: int, world: int, ship):
         self.ctx, self.lib = ctx, ctx.lib
         uid = np.zeros(self.ID_BYTES, dtype=np.uint8)
+        payload = None
         if rank == 0:
-            ctx.check(self.lib.sclens_hip_comm_unique_id(ctx.h, ptr(uid, C.c_uint8)))
-        got = ship(uid.tobytes() if rank == 0 else None)
+            try:
+                ctx.check(self.lib.sclens_hip_comm_unique_id(ctx.h, ptr(uid, C.c_uint8)))
+                payload = uid.tobytes()
+            except Exception as e:  # the other ranks are waiting for the id: `ship` delivers the failure and raises everywhere
+                payload = e
+        got = ship(payload)
         uid = np.frombuffer(got, dtype=np.uint8).copy()
         h = vp()
         ctx.check(self.lib.sclens_hip_comm_create(ctx.h, ptr(uid, C.c_uint8), int(rank), int(world), C.byref(h)))

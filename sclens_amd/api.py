@@ -1065,6 +1065,19 @@ def sclens(inp_df, device_="gpu", th=60, p_step=0.001, n_perturb=20, centering="
                 f.result()
             return out
 
+        def guarded(f, where):
+            """f() on this rank; with several ranks every rank then learns whether ANY rank failed (Shard.all_ok) BEFORE the next
+            collective, and all raise together -- a rank-local error must not leave the peers waiting in a broadcast / gather"""
+            if shard.world == 1:
+                return f()
+            try:
+                out = f()
+            except BaseException as e:
+                shard.all_ok(e, where)  # raises e here and a RuntimeError on the other ranks
+                raise
+            shard.all_ok(None, where)
+            return out
+
         # ---- get_sigev (:704) and Vr2 (:717-721): the data, null and binarised matrices are independent decompositions
         spread = shard.world > 1 and spread_initial
         if spread:
@@ -1082,7 +1095,7 @@ def sclens(inp_df, device_="gpu", th=60, p_step=0.001, n_perturb=20, centering="
             if shard.rank == r_bin:
                 w_bin = free[1] if (shard.rank == r_null and len(free) > 1) else free[0]
                 jobs.append((workers.index(w_bin), lambda: ("bin", w_bin.binary_basis())))
-            got = dict(run_all(jobs)) if jobs else {}
+            got = guarded(lambda: dict(run_all(jobs)) if jobs else {}, "the first decompositions")
             L, rec_vals = got.get("data", (np.zeros(ses.n), {}))
             L = shard.bcast_host(L, 0)
             Lr = shard.bcast_host(got.get("null", np.zeros(ses.n)), r_null)
@@ -1208,7 +1221,7 @@ def sclens(inp_df, device_="gpu", th=60, p_step=0.001, n_perturb=20, centering="
         try:
             while p_ is None:
                 base = it + shard.rank * W
-                mine = np.stack(run_all([(w, search_job(w, base + w)) for w in range(W)]))  # W x 6
+                mine = guarded(lambda: np.stack(run_all([(w, search_job(w, base + w)) for w in range(W)])), "the sparsity search")  # W x 6
                 allr = shard.allgather_small(mine).reshape(shard.world * W, 6)
                 results = [allr[q, :5] if allr[q, 5] == 1.0 else None for q in range(shard.world * W)]
                 tank, used, stopped, p_fin = consume_search_round(tank, results, p_list, it, p_th, p_step, max_search_iters)
@@ -1237,18 +1250,21 @@ def sclens(inp_df, device_="gpu", th=60, p_step=0.001, n_perturb=20, centering="
                         return workers[wk].perturb_seeded(t, sample_seed_for(draws.sample_seed, "perturb", t), m_pert, min_pc)
                     return f
 
-                for q0 in range(0, len(mine_t), W):
-                    chunk = mine_t[q0: q0 + W]
-                    outs = run_all([(w, pert_job(w, t)) for w, t in enumerate(chunk)])
-                    for w, t in enumerate(chunk):
-                        nL_set[t], ncols[t] = outs[w]
-                        if w > 0:  # move the slot from the worker session into the main session (device-to-device)
-                            buf = ctx.malloc(4 * min_pc * ses.slot_ld())
-                            try:
-                                workers[w].export_slot(t, min_pc, buf)
-                                ses.import_slot(t, min_pc, ncols[t], buf)
-                            finally:
-                                ctx.free(buf)
+                def my_members():
+                    for q0 in range(0, len(mine_t), W):
+                        chunk = mine_t[q0: q0 + W]
+                        outs = run_all([(w, pert_job(w, t)) for w, t in enumerate(chunk)])
+                        for w, t in enumerate(chunk):
+                            nL_set[t], ncols[t] = outs[w]
+                            if w > 0:  # move the slot from the worker session into the main session (device-to-device)
+                                buf = ctx.malloc(4 * min_pc * ses.slot_ld())
+                                try:
+                                    workers[w].export_slot(t, min_pc, buf)
+                                    ses.import_slot(t, min_pc, ncols[t], buf)
+                                finally:
+                                    ctx.free(buf)
+
+                guarded(my_members, "the perturbation ensemble")
                 if shard.world > 1:
                     _exchange_ensemble(ses, shard, n_perturb, min_pc, nL_set, ncols)
             pe_counts = (sum(w.get_int("chefsi_used") for w in workers), sum(w.get_int("chefsi_fallback") for w in workers))

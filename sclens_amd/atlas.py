@@ -123,7 +123,14 @@ def sclens_row_sharded(X_local, row0: int, N_global: int, draws: Draws, shard: S
                 if live:
                     seeds = [sample_seed_for(draws.sample_seed, "search", it + e) for e in live]
                     my_slot = live.index(shard.rank) if shard.rank in live else -1
-                    d5, _ = ses.search_round_seeded(seeds, [ms[e] for e in live], live, my_slot, n_2)
+                    # the statistic of an evaluation is computed by its root alone, after the reduces: a failure there is local to
+                    # that rank, and the gather below is a collective -- agree on the outcome first (Shard.all_ok)
+                    try:
+                        d5, _ = ses.search_round_seeded(seeds, [ms[e] for e in live], live, my_slot, n_2)
+                    except BaseException as e:
+                        shard.all_ok(e, "a search round")
+                        raise
+                    shard.all_ok(None, "a search round")
                     if my_slot >= 0:
                         mine[:5], mine[5] = d5, 1.0
                 allr = shard.allgather_small(mine)

@@ -983,22 +983,51 @@ static int search_core(Session* s, int64_t n_2, double* d5, int64_t* r_it, bool 
 // `count` evaluations, the sum of evaluation e lands on rank roots[e] (reduce; all-reduce if the host gave no reduce function),
 // then every rank decomposes the one evaluation it is the root of. The partial Gram products of a round cost count / world of
 // a full product per rank; the eigensolves -- 85 % of an evaluation -- run once each, in parallel, instead of on every rank.
+// A round of a row-sharded session is a sequence of collectives; a rank that leaves it early (bad argument, out of memory for its
+// scratch matrix) would leave its peers waiting in the next reduce for ever. Every round therefore starts with an agreement: each
+// rank's local status (everything that can fail before the first collective has been tried by then) is summed over the ranks, and
+// either all ranks enter the round or all return -- the failing ones their own code, the others SCLENS_ERR_STATE naming the cause.
+static int round_entry_agreement(Session* s, int local_rc, const char* what) {
+  Ctx* ctx = s->ctx;
+  double* flag = static_cast<double*>(ctx->workspace("ses.roundflag", sizeof(double)));
+  if (!flag) return local_rc != SCLENS_OK ? local_rc : SCLENS_ERR_OOM;  // (8 bytes: cannot fail in practice)
+  const double mine = local_rc == SCLENS_OK ? 0.0 : 1.0;
+  const std::string my_err = ctx->err;
+  hipError_t e = hipMemcpyAsync(flag, &mine, sizeof(double), hipMemcpyHostToDevice, ctx->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+  if (e != hipSuccess) return ctx->fail(SCLENS_ERR_HIP, std::string(what) + ": " + hipGetErrorString(e));
+  SCL_TRY(s->sh.sum(ctx, flag, 1, 0));
+  double total = 0.0;
+  SCL_HIP(ctx, hipMemcpy(&total, flag, sizeof(double), hipMemcpyDeviceToHost));
+  if (local_rc != SCLENS_OK) {
+    ctx->err = my_err;
+    return local_rc;
+  }
+  if (total != 0.0)
+    return ctx->fail(SCLENS_ERR_STATE, std::string(what) + ": " + std::to_string((long long)(total + 0.5)) + " other rank(s) could not enter the round");
+  return SCLENS_OK;
+}
+
 int session_search_round_seeded(Session* s, const uint64_t* seeds, const int64_t* m, const int32_t* roots, int count, int my_slot,
                                 int64_t n_2, double* d5, int64_t* r_it) {
   Ctx* ctx = s->ctx;
   if (!s->sh.on()) return ctx->fail(SCLENS_ERR_STATE, "search_round: row-sharded sessions only (use search_step)");
   if (!s->Vr2t) return ctx->fail(SCLENS_ERR_STATE, "search_round: call binary_basis first");
-  if (count <= 0 || !seeds || !m || !roots || my_slot >= count) return ctx->fail(SCLENS_ERR_ARG, "search_round: bad arguments");
+  // everything that can fail on ONE rank before the first collective, then the agreement
+  int pre = SCLENS_OK;
+  if (count <= 0 || !seeds || !m || !roots || my_slot >= count) pre = ctx->fail(SCLENS_ERR_ARG, "search_round: bad arguments");
+  for (int e = 0; pre == SCLENS_OK && e < count; ++e)
+    if (m[e] < 0 || m[e] > s->pat.dev.population()) pre = ctx->fail(SCLENS_ERR_ARG, "search_round: bad sample size");
   float* scratch = nullptr;
+  if (pre == SCLENS_OK && (count > 1 || my_slot < 0)) {
+    scratch = static_cast<float*>(ctx->workspace("ses.Ascr", sizeof(float) * (size_t)s->n * s->lda));
+    if (!scratch) pre = SCLENS_ERR_OOM;
+  }
+  SCL_TRY(round_entry_agreement(s, pre, "search_round"));
   for (int e = 0; e < count; ++e) {
-    if (m[e] < 0 || m[e] > s->pat.dev.population()) return ctx->fail(SCLENS_ERR_ARG, "search_round: bad sample size");
     SCL_TRY(make_values_seeded(ctx, s->pat.dev, s->pat.base_val, 1, seeds[e], m[e], s->val));
     float* target = s->A;
-    if (e != my_slot) {
-      if (!scratch) scratch = static_cast<float*>(ctx->workspace("ses.Ascr", sizeof(float) * (size_t)s->n * s->lda));
-      if (!scratch) return SCLENS_ERR_OOM;
-      target = scratch;
-    }
+    if (e != my_slot) target = scratch;
     SCL_TRY(decompose(s, s->pat.dev, s->val, 1, s->Btmp, (float)s->Kdiv, nullptr, -1, /*binary=*/true, /*solve=*/false, roots[e], target));
   }
   if (my_slot < 0) return SCLENS_OK;
@@ -1084,79 +1113,99 @@ int session_perturb_round_seeded(Session* s, const int64_t* t, const uint64_t* s
                                  int my_slot, int64_t min_pc, double* nL_top, int64_t* ncols) {
   Ctx* ctx = s->ctx;
   if (!s->sh.on()) return ctx->fail(SCLENS_ERR_STATE, "perturb_round: row-sharded sessions only (use perturb)");
-  if (count <= 0 || !t || !seeds || !m || !roots || my_slot >= count || min_pc <= 0 || !nL_top || !ncols)
-    return ctx->fail(SCLENS_ERR_ARG, "perturb_round: bad arguments");
   const char* phase = "start";
   auto tag = [&](int rc) {  // which part of the round failed
     if (rc != SCLENS_OK) ctx->err = std::string("perturb_round [") + phase + "]: " + ctx->err;
     return rc;
   };
 #define PR_TRY(expr) SCL_TRY(tag(expr))
-  float* scratch = nullptr;
+  // everything that can fail on ONE rank before the first collective (arguments, the workspaces of the whole round), then the
+  // agreement of round_entry_agreement: all ranks enter the round or none does
+  int pre = SCLENS_OK;
+  if (count <= 0 || !t || !seeds || !m || !roots || my_slot >= count || min_pc <= 0 || !nL_top || !ncols)
+    pre = ctx->fail(SCLENS_ERR_ARG, "perturb_round: bad arguments");
+  for (int e = 0; pre == SCLENS_OK && e < count; ++e)
+    if (t[e] < 0 || m[e] < 0 || m[e] > s->pat.dev.population()) pre = ctx->fail(SCLENS_ERR_ARG, "perturb_round: bad slot / sample size");
+  float *scratch = nullptr, *zs = nullptr, *mine = nullptr;
+  double* ls = nullptr;
+  if (pre == SCLENS_OK) {
+    if (count > 1 || my_slot < 0) scratch = static_cast<float*>(ctx->workspace("ses.Ascr", sizeof(float) * (size_t)s->n * s->lda));
+    zs = static_cast<float*>(ctx->workspace("ses.zshare", sizeof(float) * (size_t)min_pc * s->ldz));
+    ls = static_cast<double*>(ctx->workspace("ses.lshare", sizeof(double) * (size_t)(min_pc + 1)));
+    mine = static_cast<float*>(ctx->workspace("ses.zmine", sizeof(float) * (size_t)min_pc * s->ldz));
+    if (((count > 1 || my_slot < 0) && !scratch) || !zs || !ls || !mine) pre = SCLENS_ERR_OOM;
+    for (int e = 0; pre == SCLENS_OK && e < count; ++e) {
+      if ((int64_t)s->ens.size() <= t[e]) { s->ens.resize(t[e] + 1, nullptr); s->ens_cols.resize(t[e] + 1, 0); }
+      if (!ctx->workspace("ses.ens" + std::to_string(t[e]), sizeof(float) * (size_t)min_pc * s->ldn)) pre = SCLENS_ERR_OOM;
+    }
+  }
+  SCL_TRY(round_entry_agreement(s, pre, "perturb_round"));
   for (int e = 0; e < count; ++e) {
     phase = "partial Gram";
-    if (t[e] < 0 || m[e] < 0 || m[e] > s->pat.dev.population()) return ctx->fail(SCLENS_ERR_ARG, "perturb_round: bad slot / sample size");
     PR_TRY(make_values_seeded(ctx, s->pat.dev, s->pat.base_val, 0, seeds[e], m[e], s->val));
-    float* target = s->A;
-    if (e != my_slot) {
-      if (!scratch) scratch = static_cast<float*>(ctx->workspace("ses.Ascr", sizeof(float) * (size_t)s->n * s->lda));
-      if (!scratch) return SCLENS_ERR_OOM;
-      target = scratch;
-    }
+    float* target = (e != my_slot) ? scratch : s->A;
     PR_TRY(decompose(s, s->pat.dev, s->val, 1, s->Btmp, (float)s->M, nullptr, -1, false, /*solve=*/false, roots[e], target));
   }
   phase = "root eigensolve";
-  // ---- the root's eigen-solve: leading min_pc pairs, rows of `mine` descending
-  float* zs = static_cast<float*>(ctx->workspace("ses.zshare", sizeof(float) * (size_t)min_pc * s->ldz));
-  double* ls = static_cast<double*>(ctx->workspace("ses.lshare", sizeof(double) * (size_t)(min_pc + 1)));
-  float* mine = static_cast<float*>(ctx->workspace("ses.zmine", sizeof(float) * (size_t)min_pc * s->ldz));
-  if (!zs || !ls || !mine) return SCLENS_ERR_OOM;
+  // ---- the root's eigen-solve: leading min_pc pairs, rows of `mine` descending. A failure here is local to this rank while the
+  // share phase below is a collective of all: the root then shares the marker -1 in place of its column count (and zeros), every
+  // rank sees it in the summed buffer and all leave the round with an error after the exchange -- nobody waits for a peer.
   std::vector<double> my_l((size_t)min_pc + 1, 0.0);
+  int root_rc = SCLENS_OK;
+  std::string root_err;
   if (my_slot >= 0) {
-    int64_t c = 0;
-    bool done = false;
-    const bool can_chefsi = s->use_chefsi && s->b0 >= min_pc + 8 && s->Z0t;
-    if (can_chefsi) {
-      PR_TRY(s->ensure_zt(min_pc));
-      std::vector<double> wd(min_pc);
-      int conv = 0, its = 0;
-      PR_TRY(topk_chefsi(ctx, s->A, s->n, s->lda, (int)min_pc, (int)std::min<int64_t>(s->k, min_pc), (int)s->b0, s->Z0t, s->ldz,
-                          s->theta0.data(), wd.data(), s->Zt, s->ldz, &conv, &its, nullptr, 0, 0, 1.f, 0.05));  // rounds: always strict tails
-      const double tol = 8.0 * 5.96e-8 * std::sqrt((double)s->n) * std::max(0.0, wd[0]);
-      if (conv && wd[min_pc - 1] > tol) {
-        s->chefsi_used += 1;
-        c = min_pc;
-        for (int64_t q = 0; q < min_pc; ++q) my_l[1 + q] = wd[q];
-        PR_TRY(copy_rows_f32(ctx, s->Zt, c, s->n, s->ldz, mine, s->ldz));
-        done = true;
-      } else {
-        s->chefsi_fallback += 1;
+    auto solve = [&]() -> int {
+      int64_t c = 0;
+      bool done = false;
+      const bool can_chefsi = s->use_chefsi && s->b0 >= min_pc + 8 && s->Z0t;
+      if (can_chefsi) {
+        PR_TRY(s->ensure_zt(min_pc));
+        std::vector<double> wd(min_pc);
+        int conv = 0, its = 0;
+        PR_TRY(topk_chefsi(ctx, s->A, s->n, s->lda, (int)min_pc, (int)std::min<int64_t>(s->k, min_pc), (int)s->b0, s->Z0t, s->ldz,
+                            s->theta0.data(), wd.data(), s->Zt, s->ldz, &conv, &its, nullptr, 0, 0, 1.f, 0.05));  // rounds: always strict tails
+        const double tol = 8.0 * 5.96e-8 * std::sqrt((double)s->n) * std::max(0.0, wd[0]);
+        if (conv && wd[min_pc - 1] > tol) {
+          s->chefsi_used += 1;
+          c = min_pc;
+          for (int64_t q = 0; q < min_pc; ++q) my_l[1 + q] = wd[q];
+          PR_TRY(copy_rows_f32(ctx, s->Zt, c, s->n, s->ldz, mine, s->ldz));
+          done = true;
+        } else {
+          s->chefsi_fallback += 1;
+        }
       }
-    }
-    if (!done) {
-      PR_TRY(eig_values(ctx, s->A, s->n, s->lda, s->w64));
-      PR_TRY(s->fetch_w());
-      c = std::min<int64_t>(min_pc, s->count_positive());
-      for (int64_t q = 0; q < c; ++q) my_l[1 + q] = s->w_host[s->n - 1 - q];
-      if (c > 0) {
-        PR_TRY(s->ensure_zt(c));
-        PR_TRY(eig_vectors(ctx, s->A, s->n, s->lda, s->w64, s->n - c, s->n, s->Zt, s->ldz));
-        PR_TRY(reverse_rows_f32(ctx, s->Zt, c, s->n, s->ldz, mine, s->ldz));
+      if (!done) {
+        PR_TRY(eig_values(ctx, s->A, s->n, s->lda, s->w64));
+        PR_TRY(s->fetch_w());
+        c = std::min<int64_t>(min_pc, s->count_positive());
+        for (int64_t q = 0; q < c; ++q) my_l[1 + q] = s->w_host[s->n - 1 - q];
+        if (c > 0) {
+          PR_TRY(s->ensure_zt(c));
+          PR_TRY(eig_vectors(ctx, s->A, s->n, s->lda, s->w64, s->n - c, s->n, s->Zt, s->ldz));
+          PR_TRY(reverse_rows_f32(ctx, s->Zt, c, s->n, s->ldz, mine, s->ldz));
+        }
       }
+      my_l[0] = (double)c;
+      return SCLENS_OK;
+    };
+    root_rc = solve();
+    if (root_rc != SCLENS_OK) {
+      root_err = ctx->err;
+      std::fill(my_l.begin(), my_l.end(), 0.0);
+      my_l[0] = -1.0;  // the marker every rank will see
     }
-    my_l[0] = (double)c;
   }
   // ---- share member by member, recover the local cells
   for (int e = 0; e < count; ++e) {
     phase = "share + recover";
-    if ((int64_t)s->ens.size() <= t[e]) { s->ens.resize(t[e] + 1, nullptr); s->ens_cols.resize(t[e] + 1, 0); }
-    float* slot = static_cast<float*>(ctx->workspace("ses.ens" + std::to_string(t[e]), sizeof(float) * (size_t)min_pc * s->ldn));
+    float* slot = static_cast<float*>(ctx->workspace("ses.ens" + std::to_string(t[e]), sizeof(float) * (size_t)min_pc * s->ldn));  // exists (entry)
     if (!slot) return SCLENS_ERR_OOM;
     s->ens[t[e]] = slot;
     if (e == my_slot) {
       SCL_HIP(ctx, hipMemcpyAsync(ls, my_l.data(), sizeof(double) * (size_t)(min_pc + 1), hipMemcpyHostToDevice, ctx->stream));
-      SCL_HIP(ctx, hipMemcpyAsync(zs, mine, sizeof(float) * (size_t)min_pc * s->ldz, hipMemcpyDeviceToDevice, ctx->stream));
-      const int64_t c = (int64_t)my_l[0];
+      const int64_t c = std::max<int64_t>(0, (int64_t)my_l[0]);
+      if (c > 0) SCL_HIP(ctx, hipMemcpyAsync(zs, mine, sizeof(float) * (size_t)c * s->ldz, hipMemcpyDeviceToDevice, ctx->stream));
       if (c < min_pc)
         SCL_HIP(ctx, hipMemsetAsync(zs + c * s->ldz, 0, sizeof(float) * (size_t)(min_pc - c) * s->ldz, ctx->stream));
     } else {
@@ -1168,6 +1217,14 @@ int session_perturb_round_seeded(Session* s, const int64_t* t, const uint64_t* s
     std::vector<double> hl((size_t)min_pc + 1);
     SCL_HIP(ctx, hipMemcpyAsync(hl.data(), ls, sizeof(double) * (size_t)(min_pc + 1), hipMemcpyDeviceToHost, ctx->stream));
     SCL_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (hl[0] < -0.5) {  // the root of this member could not decompose it: every rank has seen the marker, all stop here
+      if (e == my_slot && root_rc != SCLENS_OK) {
+        ctx->err = root_err;
+        return root_rc;
+      }
+      return ctx->fail(SCLENS_ERR_NOCONV, "perturb_round: the root of member " + std::to_string((long long)t[e]) + " (rank " +
+                                              std::to_string(roots[e]) + ") failed to decompose it");
+    }
     const int64_t c = std::min<int64_t>(min_pc, std::max<int64_t>(0, (int64_t)(hl[0] + 0.5)));  // (a sane count whatever the reducer does)
     ncols[e] = c;
     for (int64_t q = 0; q < min_pc; ++q) nL_top[(int64_t)e * min_pc + q] = (q < c) ? hl[1 + q] : 0.0;

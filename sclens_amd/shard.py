@@ -42,12 +42,20 @@ class Shard:
         from ._lib import Comm
 
         def ship(uid):
+            """rank 0's unique id to every rank; rank 0 ships an Exception instead when it could not make one (the other ranks would
+            wait in this broadcast for ever otherwise) and every rank raises"""
             if world == 1:
+                if isinstance(uid, BaseException):
+                    raise uid
                 return uid
             import torch.distributed as dist
 
-            box = [uid]
+            box = [uid if not isinstance(uid, BaseException) else ("__error__", repr(uid))]
             dist.broadcast_object_list(box, src=0)
+            if isinstance(uid, BaseException):
+                raise uid
+            if isinstance(box[0], tuple) and box[0] and box[0][0] == "__error__":
+                raise RuntimeError(f"rank 0 could not create the RCCL unique id: {box[0][1]}")
             return box[0]
 
         return cls(rank, world, Comm(ctx, rank, world, ship))
@@ -224,6 +232,22 @@ class Shard:
     def agree(self, arr: np.ndarray) -> np.ndarray:
         """rank 0's copy of a small host array on every rank (decisions must not diverge by a rounding bit)"""
         return self.allgather_small(arr)[0]
+
+    def all_ok(self, exc=None, where: str = ""):
+        """Every rank calls this at the end of a phase whose next step is a collective, with the exception the phase raised on THIS
+        rank (or None). One small all-gather of a status word; if any rank failed, EVERY rank raises -- the failing ones their own
+        exception, the others a RuntimeError naming the ranks -- so that no rank walks into a collective its peers will never join
+        (a rank-local error used to leave the others blocked in the next all-gather / reduce for ever)."""
+        if self.world == 1:
+            if exc is not None:
+                raise exc
+            return
+        flags = self.allgather_small(np.array([0.0 if exc is None else 1.0]))[:, 0]
+        if exc is not None:
+            raise exc
+        bad = [int(r) for r in np.flatnonzero(flags != 0.0)]
+        if bad:
+            raise RuntimeError(f"sclens: rank(s) {bad} failed{(' in ' + where) if where else ''}; rank {self.rank} stops with them")
 
     def barrier(self):
         if self.comm is not None:

@@ -69,6 +69,11 @@ class ThreadShard:
     def agree(self, arr):
         return self.allgather_small(arr)[0]
 
+    def all_ok(self, exc=None, where=""):  # the product's own status agreement on this transport
+        from sclens_amd.shard import Shard
+
+        return Shard.all_ok(self, exc, where)
+
     def allreduce_dev(self, ctx, dev_ptr, count, dtype):
         h = np.empty(int(count), dtype=np.float64 if dtype == 0 else np.float32)
         ctx.d2h(h, dev_ptr)

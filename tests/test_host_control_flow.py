@@ -155,6 +155,52 @@ def test_multi_rank_host_flow_reproduces_the_oracle(monkeypatch, world, streams)
     assert F.FakeSession.live == 0 and F.FakePattern.live == 0 and F.FakeContext.live == 0
 
 
+@pytest.mark.parametrize("where", ["binary_basis", "search_step", "perturb"])
+def test_a_rank_local_failure_stops_every_rank_instead_of_hanging_the_others(monkeypatch, where):
+    """a rank-local error used to leave the other ranks waiting in the next broadcast / gather for ever. Now every phase
+    that is followed by a collective ends with Shard.all_ok: the failing rank raises its own exception, the others a RuntimeError
+    that names it -- nobody is released by the test (no barrier abort here), everything opened is closed."""
+    import threading
+
+    from devutil import ThreadShard
+
+    X = synth_counts(150, 220, seed=3, C=4, marker_frac=0.25, marker_sd=1.5)
+    d = api.make_draws(X, seed=11, p_th_trials=200)
+    F.install(monkeypatch).close()
+    world, bad_rank = 2, 1
+    group = ThreadShard.Group(world)
+    tid_of_rank = {}
+    orig = getattr(F.FakeSession, where)
+
+    def boom(self, *a, **k):
+        if threading.get_ident() in tid_of_rank.get(bad_rank, ()):  # only the sessions driven by rank 1's threads
+            raise RuntimeError(f"{where} failed on rank {bad_rank}")
+        return orig(self, *a, **k)
+
+    monkeypatch.setattr(F.FakeSession, where, boom)
+    err = [None] * world
+
+    def work(r):
+        tid_of_rank.setdefault(r, set()).add(threading.get_ident())
+        c = F.FakeContext(0)
+        try:
+            api.sclens(X, draws=d, n_perturb=4, ctx=c, streams=1, shard=_FakeThreadShard(group, r))
+        except BaseException as e:  # noqa: BLE001
+            err[r] = e
+        finally:
+            c.close()
+
+    th = [threading.Thread(target=work, args=(r,), daemon=True) for r in range(world)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join(timeout=120)
+    assert not any(t.is_alive() for t in th), "a rank is still waiting for a peer that has failed"
+    assert isinstance(err[bad_rank], RuntimeError) and f"{where} failed on rank {bad_rank}" in str(err[bad_rank])
+    assert isinstance(err[0], RuntimeError) and "rank(s) [1] failed" in str(err[0])
+    assert F.FakeSession.live == 0 and F.FakePattern.live == 0 and F.FakeContext.live == 0
+
+
 # ---- the row-sharded (atlas) mode: cells divided over thread ranks ------------------------------------------------------------
 @pytest.mark.parametrize("world,distribute", [(2, True), (3, True), (2, False)])
 def test_row_sharded_host_flow_reproduces_the_oracle(monkeypatch, world, distribute):
