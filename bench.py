@@ -49,6 +49,7 @@ import numpy as np  # noqa: E402
 CONFIGS = {  # name -> (N cells, M genes, index in BASELINE.json configs)
     "tiny": (600, 900, 0),
     "tiny_gt": (900, 400, 0),  # cells > genes, for --row-shard smoke runs
+    "rs20k": (20000, 6000, 0),  # cells > genes at the order of the row-sharded GPU tests (tests/test_gpu_multirank.py)
     "cfg2": (10000, 20000, 1),
     "cfg3": (50000, 30000, 2),
     "cfg4": (100000, 30000, 3),
@@ -361,8 +362,11 @@ def main():
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend=args.backend, rank=rank, world_size=world,
-                                device_id=dev if args.backend == "nccl" else None)
+        # torch.distributed is the launcher's rendezvous and the channel that ships ONE 128-byte id: always gloo (host side). With
+        # --backend nccl the collectives of the path are RCCL calls made by the library on its own communicator (csrc/comm.hip);
+        # torch never creates a second RCCL communicator beside it (round 3 held two per rank, a combination that had only ever
+        # run with one rank).
+        dist.init_process_group(backend="gloo", rank=rank, world_size=world)
     from sclens_amd import api
     from sclens_amd._lib import Context
     from sclens_amd.shard import Shard
