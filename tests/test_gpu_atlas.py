@@ -219,3 +219,37 @@ def test_library_rccl_communicator_one_rank(ctx):
         _compare(res, ref)
     finally:
         sh.close()
+
+
+@pytest.mark.slow
+def test_atlas_slab_of_one_rank_fits_and_runs(tmp_path):
+    """BASELINE.json configs[4] (1 000 000 cells x 30 000 genes on 8 GPUs) as far as one GPU can execute it: rank 0's slab of
+    125 000 cells through the row-sharded session in the round mode (local candidates, one search round of 8 evaluations, one
+    ensemble round of 8 members) with the exchange stubbed (scripts/atlas_dry_run.py, run as a fresh process). Asserted: the HBM
+    footprint fits the 288 GB of an MI355X with room to spare, every call returns within the bounds of the last logged run (x2),
+    the projected per-rank wall clock. ~5 minutes (77 s of synthesis): SCLENS_TEST_SLOW=1; log: profiles/r04_atlas_slab_dry_run.json"""
+    import json
+    import os
+    import subprocess
+    import sys
+
+    if os.environ.get("SCLENS_TEST_SLOW") != "1":
+        pytest.skip("one slab of the atlas configuration takes ~5 minutes: SCLENS_TEST_SLOW=1")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = tmp_path / "slab.json"
+    r = subprocess.run([sys.executable, os.path.join(root, "scripts", "atlas_dry_run.py"), "1000000", "8", str(out)],
+                       capture_output=True, text=True, timeout=1500, cwd=root)
+    assert r.returncode == 0, r.stderr[-3000:]
+    log = json.loads(out.read_text())
+    keep = os.environ.get("SCLENS_ATLAS_LOG")
+    if keep:
+        open(keep, "w").write(json.dumps(log, indent=1) + "\n")
+    assert log["slab"]["rows"] == [0, 125000] and log["M"] == 30000
+    assert log["hbm_used_GB"] < 0.75 * 288, log["hbm_used_GB"]
+    t = log["times_s"]
+    bounds = {"session_create_sharded_drawn": 1.0, "null_spectrum": 4.0, "data_spectrum": 4.0, "signal_vectors": 1.5, "binary_basis": 6.0,
+              "search_round_1": 7.0, "perturb_round_1": 19.0, "robustness": 0.5, "gene_basis": 0.1}
+    for key, b in bounds.items():
+        assert t[key] <= b, (key, t[key], b)
+    assert log["projected_rank_wall_s"] <= 91.0  # the r03 projection (45.5 s) x 2
+    assert log["stubbed_reduce_to_root"]["calls"] == 32 and log["candidates_local"] > 3e8
