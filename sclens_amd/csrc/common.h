@@ -259,7 +259,7 @@ int transpose_f32(Ctx* ctx, const float* in, int64_t rows, int64_t cols, int64_t
 // out row q = in row (rows-1-q)
 int reverse_rows_f32(Ctx* ctx, const float* in, int64_t rows, int64_t cols, int64_t ldi, float* out, int64_t ldo);
 // A (n x n, lda, zero padded) = B B^T / divisor for B [n x K] row-major (ldb), exactly symmetric
-int gram_f32(Ctx* ctx, const float* B, int64_t n, int64_t K, int64_t ldb, float divisor, float* A, int64_t lda);
+int gram_f32(Ctx* ctx, const float* B, int64_t n, int64_t K, int64_t ldb, float divisor, float* A, int64_t lda, bool allow_split = true);
 
 }  // namespace scl
 

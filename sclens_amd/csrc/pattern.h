@@ -76,15 +76,21 @@ struct ShardReduce {
   // (the Gram matrix of a search evaluation / ensemble member that `root` decomposes); absent: all-reduce.
   sclens_hip_reduce_fn rfn = nullptr;
   void* ruser = nullptr;
+  // a worker clone starts with its parent's description of the sharding but must not use the parent's channel (another host thread
+  // would issue collectives on the parent's communicator and stream): every collective is refused until session_set_reducer has
+  // given the clone a channel of its own
+  bool inherited = false;
   bool on() const { return fn != nullptr; }
   int sum(Ctx* ctx, void* dev, int64_t count, int dtype) const {
     if (!fn) return SCLENS_OK;
+    if (inherited) return ctx->fail(SCLENS_ERR_STATE, "row-sharded worker session: call set_reducer before any collective");
     hipError_t e = hipStreamSynchronize(ctx->stream);
     if (e != hipSuccess) return ctx->fail(SCLENS_ERR_HIP, std::string("allreduce: ") + hipGetErrorString(e));
     const int rc = fn(user, dev, count, dtype);
     return rc == 0 ? SCLENS_OK : ctx->fail(SCLENS_ERR_HIP, "allreduce callback failed with code " + std::to_string(rc));
   }
   int sum_to(Ctx* ctx, void* dev, int64_t count, int dtype, int root) const {
+    if (inherited) return ctx->fail(SCLENS_ERR_STATE, "row-sharded worker session: call set_reducer before any collective");
     if (!rfn) return sum(ctx, dev, count, dtype);
     hipError_t e = hipStreamSynchronize(ctx->stream);
     if (e != hipSuccess) return ctx->fail(SCLENS_ERR_HIP, std::string("reduce: ") + hipGetErrorString(e));

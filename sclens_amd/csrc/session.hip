@@ -93,7 +93,9 @@ int reverse_rows_f32(Ctx* ctx, const float* in, int64_t rows, int64_t cols, int6
   return SCLENS_OK;
 }
 
-int gram_f32(Ctx* ctx, const float* B, int64_t n, int64_t K, int64_t ldb, float divisor, float* A, int64_t lda) {
+// allow_split = false: the per-call drop-ins of the reference's functions (`_wishart_matrix`, `get_eigvec`) -- a caller that asks
+// for THE fp32 product gets it at every size unless the context option gram_bits = 1 asks for the accelerated form explicitly
+int gram_f32(Ctx* ctx, const float* B, int64_t n, int64_t K, int64_t ldb, float divisor, float* A, int64_t lda, bool allow_split) {
   StageTimer tm(ctx, "gram");
   SCL_HIP(ctx, hipMemsetAsync(A, 0, sizeof(float) * (size_t)n * lda, ctx->stream));
   // Large products (n >= 16 000, or SCLENS_HIP_GRAM_SPLIT=<n>; 0 = never): the scaled matrix is split once into two fp16 pieces per
@@ -102,7 +104,7 @@ int gram_f32(Ctx* ctx, const float* B, int64_t n, int64_t K, int64_t ldb, float 
   // 682 -> ~250 ms at 100 000 x 30 000. Context option gram_bits = 0 (bench.py's strict step) also keeps this product in fp32.
   const char* egs = getenv("SCLENS_HIP_GRAM_SPLIT");
   const int64_t gs_min = egs ? atoll(egs) : 16000;
-  if (gs_min > 0 && n >= gs_min && ctx->gram_bits != 0) {
+  if (gs_min > 0 && n >= gs_min && ctx->gram_bits != 0 && (allow_split || ctx->gram_bits == 1)) {
     void* img = ctx->workspace("gram.img", split_image_bytes(n, K));
     float* sc = static_cast<float*>(ctx->workspace("gram.sc", 4 * sizeof(float)));
     if (!img || !sc) return SCLENS_ERR_OOM;
@@ -459,6 +461,7 @@ int session_set_reducer(Session* s, sclens_hip_allreduce_fn fn, void* user) {
   if (!s->sh.on() || !fn) return s->ctx->fail(SCLENS_ERR_STATE, "set_reducer: not a row-sharded session");
   s->sh.fn = fn;
   s->sh.user = user;
+  s->sh.inherited = false;  // a worker clone now has a channel of its own
   return SCLENS_OK;
 }
 int session_set_reduce_to(Session* s, sclens_hip_reduce_fn fn, void* user) {
@@ -543,7 +546,12 @@ int session_clone(Ctx* ctx2, Session* src, Session** out) {
   ctx2->gram_bits = src->ctx->gram_bits;
   s->N = src->N; s->M = src->M; s->n = src->n; s->K = src->K;
   s->Kdiv = src->Kdiv;
-  s->sh = src->sh;  // same cells; the worker gets its own reducer channel through session_set_reducer
+  s->sh = src->sh;  // same cells; the worker gets its own reducer channel through session_set_reducer, and until then has none
+  if (s->sh.on()) {
+    s->sh.inherited = true;
+    s->sh.rfn = nullptr;
+    s->sh.ruser = nullptr;
+  }
   s->cells_major = src->cells_major;
   s->centering = src->centering;
   s->pat.dev = src->pat.dev;            // shared, not owned (allocs stays empty)
@@ -1478,7 +1486,7 @@ int wishart_host(Ctx* ctx, const float* X, int64_t N, int64_t M, int dims, float
   if (dims == 2) {  // X'X / M : rows = genes, K = N
     const int64_t lda = round_up(M, 32);
     SCL_WS(ctx, dA, float, "w.A", M * lda);
-    SCL_TRY(gram_f32(ctx, dX, M, N, ldx, (float)M, dA, lda));
+    SCL_TRY(gram_f32(ctx, dX, M, N, ldx, (float)M, dA, lda, /*allow_split=*/false));
     return download_packed(ctx, dA, M, M, lda, Y);
   }
   const int64_t ldt = round_up(M, 32), lda = round_up(N, 32);
@@ -1486,7 +1494,7 @@ int wishart_host(Ctx* ctx, const float* X, int64_t N, int64_t M, int dims, float
   SCL_WS(ctx, dA, float, "w.A", N * lda);
   SCL_HIP(ctx, hipMemsetAsync(dT, 0, sizeof(float) * (size_t)N * ldt, ctx->stream));
   SCL_TRY(transpose_f32(ctx, dX, M, N, ldx, dT, ldt));
-  SCL_TRY(gram_f32(ctx, dT, N, M, ldt, (float)M, dA, lda));  // XX' / size(X,2)
+  SCL_TRY(gram_f32(ctx, dT, N, M, ldt, (float)M, dA, lda, /*allow_split=*/false));  // XX' / size(X,2)
   return download_packed(ctx, dA, N, N, lda, Y);
 }
 
@@ -1627,7 +1635,7 @@ int get_eigvec_host(Ctx* ctx, const float* X, int64_t N, int64_t M, int64_t keep
   const int64_t lda = round_up(n, 32);
   SCL_WS(ctx, dA, float, "w.A", n * lda);
   SCL_WS(ctx, dw, double, "e.w", n);
-  SCL_TRY(gram_f32(ctx, B, n, K, ldb, (float)M, dA, lda));
+  SCL_TRY(gram_f32(ctx, B, n, K, ldb, (float)M, dA, lda, /*allow_split=*/false));
   SCL_TRY(eig_values(ctx, dA, n, lda, dw));
   std::vector<double> w(n);
   SCL_HIP(ctx, hipMemcpyAsync(w.data(), dw, sizeof(double) * n, hipMemcpyDeviceToHost, ctx->stream));
