@@ -78,10 +78,10 @@ void* sclens_hip_stream(sclens_hip_ctx* ctx);
 int sclens_hip_wishart_matrix_f32(sclens_hip_ctx* ctx, const float* X, int64_t N, int64_t M, int dims, float* Y);
 /* _get_eigen(Y; device)  (scLENS.jl:375-387): all eigenvalues ascending in L[n], eigenvectors as the
  * columns of V (n x n). Returns SCLENS_ERR_NAN if an eigenvalue is NaN.
- * Accuracy: that of an fp32 solver, ~sqrt(n) eps32 |lambda|max on the eigenvalues. From n = 8 192 the two-stage reduction forms
- * its trailing updates from fp16 pieces that share one power-of-two scale per panel: fp32-level while the 2-norm of Y is below
- * ~2^12 (the Gram matrices of this path are 10^1..10^3); a matrix of larger norm should be passed scaled (eigenvectors are
- * unchanged), or with SCLENS_HIP_SY2SB_SPLIT=0 (fp32 products) in the environment. */
+ * Accuracy: that of an fp32 solver, ~sqrt(n) eps32 |lambda|max on the eigenvalues, at any norm of Y: from n = 8 192 the two-stage
+ * reduction forms its trailing updates from operands split into two fp16 pieces, the reflector columns and the columns that
+ * scale with Y under separate power-of-two scales (round 4; tests/test_gpu_sbr.py at norms 1, 2^14, 2^20).
+ * SCLENS_HIP_SY2SB_SPLIT=0 keeps those products on the fp32 matrix cores. */
 int sclens_hip_get_eigen_f32(sclens_hip_ctx* ctx, const float* Y, int64_t n, float* L, float* V);
 /* corr_mat(X, Y; device)  (scLENS.jl:363-373): out = X' * Y, X is n x p, Y is n x q, out is p x q. */
 int sclens_hip_corr_mat_f32(sclens_hip_ctx* ctx, const float* X, int64_t n, int64_t p, const float* Y, int64_t q,

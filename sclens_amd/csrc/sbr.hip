@@ -659,11 +659,12 @@ int sy2sb_f32(Ctx* ctx, float* A, int64_t n, int64_t lda, float* Tall, int* brea
   // C traffic only: 27 us of fp32 matrix-pipe time per 128 of K and 256 x 256 tile become 5). SCLENS_HIP_SY2SB_SPLIT=0: fp32 products.
   int64_t split_min = 4096;
   if (const char* ev = getenv("SCLENS_HIP_SY2SB_SPLIT")) split_min = atoi(ev) > 0 ? std::max<int64_t>(512, atoll(ev)) : (int64_t)1 << 60;
-  // SCLENS_HIP_SY2SB_SPLIT_SCALES=2: separate power-of-two scales for the reflector columns (entries up to 1) and the Z columns
-  // (entries ~ the norm of the matrix) of the update's operands; 1 (default): one scale for both, accurate while the norm of the
-  // matrix stays below ~2^12
-  int split_scales = 1;
-  if (const char* ev = getenv("SCLENS_HIP_SY2SB_SPLIT_SCALES")) split_scales = atoi(ev) == 2 ? 2 : 1;
+  // Separate power-of-two scales for the reflector columns (entries up to 1) and the Z columns (entries ~ the norm of the matrix) of
+  // the update's operands (default since round 4: first run on hardware there, test_sy2sb_split_update_with_separate_scales at norms
+  // 1, 2^14, 2^20). SCLENS_HIP_SY2SB_SPLIT_SCALES=1: one scale for both, as in round 3 -- accurate only while the norm of the matrix
+  // stays below ~2^12, which a drop-in for `_get_eigen` cannot assume.
+  int split_scales = 2;
+  if (const char* ev = getenv("SCLENS_HIP_SY2SB_SPLIT_SCALES")) split_scales = atoi(ev) == 1 ? 1 : 2;
   const bool any_split = n >= split_min;
   void* imgP = any_split ? ctx->workspace("sbr.imgP", split_image_bytes(n, LDU)) : nullptr;
   void* imgQ = any_split ? ctx->workspace("sbr.imgQ", split_image_bytes(n, LDU)) : nullptr;

@@ -65,9 +65,6 @@ def test_sy2sb_band_has_the_same_spectrum(ctx, n, delayed_update):
     assert np.abs(got - ref).max() < 4e-7 * np.sqrt(n) * ref.max() + 1e-7
 
 
-@pytest.mark.skipif(os.environ.get("SCLENS_TEST_EXPERIMENTAL") != "1",
-                    reason="SCLENS_HIP_SY2SB_SPLIT_SCALES=2 was written after round 3's GPU budget was spent: run with "
-                           "SCLENS_TEST_EXPERIMENTAL=1 first, then drop this mark and make it the default")
 @pytest.mark.parametrize("log2_norm", [0, 14, 20])
 def test_sy2sb_split_update_with_separate_scales(ctx, log2_norm, monkeypatch):
     """a matrix of large norm: the reflector columns of the split update's operands get their own scale, so the band keeps the

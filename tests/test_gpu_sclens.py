@@ -262,7 +262,6 @@ def test_two_streams_give_identical_results(ctx):
         assert np.array_equal(a["robustness_scores"]["b_"], c["robustness_scores"]["b_"])
 
 
-@pytest.mark.skipif(os.environ.get("SCLENS_TEST_EXPERIMENTAL") != "1", reason="SCLENS_FIRST_PHASE=chain has not run on hardware yet")
 def test_chained_first_phase_gives_identical_results(ctx, monkeypatch):
     """SCLENS_FIRST_PHASE=chain (two streams: worker 1 runs null -> binarised back to back, the main session data -> signal
     vectors) only moves work between streams: every output has the same bits as the default schedule"""
