@@ -20,7 +20,7 @@ Bp = np.zeros((n, ldb), np.float32); Bp[:, :K] = B
 dB = DevArray(ctx, Bp); dA = DevArray(ctx, nbytes=4 * n * lda); dw = DevArray(ctx, nbytes=8 * n)
 dZ = DevArray(ctx, nbytes=4 * max(mvec, 1) * lda)
 ctx.set_timing(True)
-for rep in range(2):
+for rep in range(int(os.environ.get("REPS", "2"))):  # REPS=1: counter passes (every profiled dispatch is serialised)
     ctx.reset_timing()
     t0 = time.perf_counter()
     ctx.check(ctx.lib.sclens_hip_dev_gram_f32(ctx.h, dB.p, n, K, ldb, float(K), dA.p, lda))
