@@ -37,4 +37,11 @@ for c in ("FETCH_SIZE", "WRITE_SIZE"):
     print("  SUM over the profiled kernels: %.6g KB" % sum(v for _, v in agg.values()))
 PY
 cat $O/pmc_eig_summary.txt
+# kernel trace of one band reduction + chase on this build, by octile of the panel index (what is left of the dense -> band stage)
+cd /tmp
+timeout 600 rocprofv3 --kernel-trace --output-format csv -d /tmp/trace_sbr -- python3 /root/repo/scripts/perf_sbr.py 30016 > /root/repo/$O/perf_sbr.log 2>&1
+cd /root/repo
+TR=$(find /tmp/trace_sbr -name "*kernel_trace.csv" | head -1)
+[ -n "$TR" ] && python3 scripts/trace_sy2sb.py $TR $O/sy2sb_trace_summary_30016.json > $O/trace_sy2sb.log 2>&1
+tail -n 3 $O/perf_sbr.log
 cat $O/summary.txt
