@@ -2613,7 +2613,7 @@ __device__ __forceinline__ void sbr_q2_group16e(f32x4* z, const float* buf, int 
 }
 
 template <int QJ, int QNT, int NBUF>
-__global__ __launch_bounds__(256, 2) void sbr_q2_apply16e(SbrQ2Args a, const float* __restrict__ img) {
+__global__ __launch_bounds__(256, 2) void sbr_q2_apply16e(SbrQ2Args a, const float* __restrict__ img, int dbg) {
   static_assert(NBUF == 2 || NBUF == 3, "one or two groups ahead");
   constexpr int AH = NBUF - 1;
   extern __shared__ __attribute__((aligned(16))) float q2lds[];  // NBUF images
@@ -2667,10 +2667,10 @@ __global__ __launch_bounds__(256, 2) void sbr_q2_apply16e(SbrQ2Args a, const flo
         asm volatile("" ::: "memory");
         int nxt = cur + AH;
         if (nxt >= NBUF) nxt -= NBUF;
-        sbr_q2_dma(img, index_of(nb, nt), lds + nxt * Q_IMG, tid);
+        if (!(dbg & 2)) sbr_q2_dma(img, index_of(nb, nt), lds + nxt * Q_IMG, tid);  // dbg: timing experiments only (WRONG results)
         asm volatile("" ::: "memory");
         const int b = bh - j;
-        if (b >= 0 && t < sbr_tasks_of((int64_t)b * QW, a.n)) sbr_q2_group16e(z + 2 * (QJ - 1 - j), lds + cur * Q_IMG, vi, g);
+        if (b >= 0 && t < sbr_tasks_of((int64_t)b * QW, a.n) && !(dbg & 1)) sbr_q2_group16e(z + 2 * (QJ - 1 - j), lds + cur * Q_IMG, vi, g);
         if (AH == 2) asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         cur = (cur + 1 == NBUF) ? 0 : cur + 1;
@@ -2781,12 +2781,13 @@ int sbr_apply_q2(Ctx* ctx, int64_t n, float* Zt, int64_t m, int64_t ldz) {
   const dim3 q2grid((unsigned)((m + 63) / 64));
   if (q2_variant == 8 || q2_variant == 9) {
     const int lds_bytes = (q2_variant == 8 ? 3 : 2) * Q_IMG * (int)sizeof(float);
+    const int q2dbg = getenv("SCLENS_HIP_Q2_DBG") ? atoi(getenv("SCLENS_HIP_Q2_DBG")) : 0;  // 1: no products, 2: no DMA (timing experiments)
     if (q2_variant == 8) {
       SCL_TRY(ensure_dyn_lds(ctx, reinterpret_cast<const void*>(sbr_q2_apply16e<4, 12, 3>), lds_bytes));
-      hipLaunchKernelGGL((sbr_q2_apply16e<4, 12, 3>), q2grid, dim3(256), lds_bytes, ctx->stream, qa, q2img);
+      hipLaunchKernelGGL((sbr_q2_apply16e<4, 12, 3>), q2grid, dim3(256), lds_bytes, ctx->stream, qa, q2img, q2dbg);
     } else {
       SCL_TRY(ensure_dyn_lds(ctx, reinterpret_cast<const void*>(sbr_q2_apply16e<4, 12, 2>), lds_bytes));
-      hipLaunchKernelGGL((sbr_q2_apply16e<4, 12, 2>), q2grid, dim3(256), lds_bytes, ctx->stream, qa, q2img);
+      hipLaunchKernelGGL((sbr_q2_apply16e<4, 12, 2>), q2grid, dim3(256), lds_bytes, ctx->stream, qa, q2img, q2dbg);
     }
   } else if (q2_variant == 0)
     hipLaunchKernelGGL((sbr_q2_apply16<4, 12, false>), q2grid, dim3(256), 0, ctx->stream, qa);
