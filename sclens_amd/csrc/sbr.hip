@@ -2479,8 +2479,18 @@ __host__ __device__ __forceinline__ int64_t sbr_q2_img_index(int b, int t, int64
 }
 static inline int64_t sbr_q2_img_count(int64_t n) { const int64_t q = n / SB; return q * q + q; }
 
+// k32 != 0: the layout for `v_mfma_f32_16x16x32_f16` (a lane supplies EIGHT k per instruction; slot e of lane group g = window row
+// 32 p + 4 g + e for e < 4 and 32 p + 16 + 4 g + e - 4 otherwise, i.e. the register quads of the row tiles 2 p and 2 p + 1 side by
+// side; in part B the slots are the reflectors 4 g + e and 16 + 4 g + e - 4): units of 32 bytes = [hi x 8 | lo x 8],
+//   part A  [reflector c][13 units: (p, g) for p < 3, g < 4, one pad]          104 floats per reflector
+//   part B  [window row r][5 units: g < 4, one pad]                            40 floats per row
+// 18 + 18 matrix instructions of 16 cycles per group instead of 30 + 33 of 16 cycles (the K = 16 form runs at half the rate of the
+// K = 32 form on gfx950).
+constexpr int Q_RS32 = 104, Q_NS32 = 40, Q_IMG_A32 = QW * Q_RS32;
+static_assert(Q_IMG_A32 + QH * Q_NS32 <= Q_IMG, "image layout (K = 32)");
+
 __global__ __launch_bounds__(256) void sbr_q2_build_img(const float* __restrict__ V2, int64_t ldv2, const float* __restrict__ TAU2,
-                                                        int64_t ldt, int64_t n, float* __restrict__ img) {
+                                                        int64_t ldt, int64_t n, float* __restrict__ img, int k32) {
   const int t = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
   if (t >= sbr_tasks_of((int64_t)b * QW, n)) return;
   __shared__ float Vg[QH][QW + 1];
@@ -2529,6 +2539,36 @@ __global__ __launch_bounds__(256) void sbr_q2_build_img(const float* __restrict_
   }
   __syncthreads();
   float* out = img + sbr_q2_img_index(b, t, n) * Q_IMG;
+  if (k32) {
+    for (int u = tid; u < Q_IMG / 8; u += 256) {
+      float x[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+      if (u < Q_IMG_A32 / 8) {
+        const int c = u / (Q_RS32 / 8), rem = u % (Q_RS32 / 8);
+        if (rem < 12) {
+          const int p = rem >> 2, gq = rem & 3;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) x[e] = Vg[32 * p + 16 * (e >> 2) + 4 * gq + (e & 3)][c];
+        }
+      } else if (u < (Q_IMG_A32 + QH * Q_NS32) / 8) {
+        const int k = u - Q_IMG_A32 / 8, r = k / (Q_NS32 / 8), gq = k % (Q_NS32 / 8);
+        if (gq < 4) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) x[e] = -Y[r][16 * (e >> 2) + 4 * gq + (e & 3)];
+        }
+      }
+      _Float16 hl[16];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        hl[e] = (_Float16)x[e];
+        hl[8 + e] = (_Float16)(x[e] - (float)hl[e]);
+      }
+      f32x4 raw[2];
+      __builtin_memcpy(raw, hl, 32);
+      *reinterpret_cast<f32x4*>(out + 8 * u) = raw[0];
+      *reinterpret_cast<f32x4*>(out + 8 * u + 4) = raw[1];
+    }
+    return;
+  }
   for (int ch = tid; ch < Q_IMG / 4; ch += 256) {
     float x[4] = {0.f, 0.f, 0.f, 0.f};
     if (ch < Q_IMG_A / 4) {
@@ -2612,7 +2652,56 @@ __device__ __forceinline__ void sbr_q2_group16e(f32x4* z, const float* buf, int 
   }
 }
 
-template <int QJ, int QNT, int NBUF>
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+struct SbrHL8 {
+  f16x8 h, l;
+};
+__device__ __forceinline__ SbrHL8 sbr_ld_hl8(const float* p) {  // one 32-byte unit [hi x 8 | lo x 8]
+  const f32x4 r0 = *reinterpret_cast<const f32x4*>(p), r1 = *reinterpret_cast<const f32x4*>(p + 4);
+  SbrHL8 o;
+  __builtin_memcpy(&o.h, &r0, 16);
+  __builtin_memcpy(&o.l, &r1, 16);
+  return o;
+}
+__device__ __forceinline__ SbrHL8 sbr_cat(const SbrHL& a, const SbrHL& b) {
+  SbrHL8 o;
+  o.h = __builtin_shufflevector(a.h, b.h, 0, 1, 2, 3, 4, 5, 6, 7);
+  o.l = __builtin_shufflevector(a.l, b.l, 0, 1, 2, 3, 4, 5, 6, 7);
+  return o;
+}
+__device__ __forceinline__ f32x4 sbr_mfma3_k32(const SbrHL8& a, const SbrHL8& b, f32x4 c) {
+  c = __builtin_amdgcn_mfma_f32_16x16x32_f16(a.h, b.h, c, 0, 0, 0);
+  c = __builtin_amdgcn_mfma_f32_16x16x32_f16(a.h, b.l, c, 0, 0, 0);
+  c = __builtin_amdgcn_mfma_f32_16x16x32_f16(a.l, b.h, c, 0, 0, 0);
+  return c;
+}
+__device__ __forceinline__ void sbr_q2_group16f(f32x4* z, const float* buf, int vi, int g) {
+  const float* VgT = buf;
+  const float* N = buf + Q_IMG_A32;
+  SbrHL8 a0[3], a1[3];
+#pragma unroll
+  for (int p = 0; p < 3; ++p) {
+    a0[p] = sbr_ld_hl8(VgT + vi * Q_RS32 + 32 * p + 8 * g);
+    a1[p] = sbr_ld_hl8(VgT + (16 + vi) * Q_RS32 + 32 * p + 8 * g);
+  }
+  SbrHL8 zz[3];
+#pragma unroll
+  for (int p = 0; p < 3; ++p) zz[p] = sbr_cat(sbr_split_pk(z[2 * p]), sbr_split_pk(z[2 * p + 1]));
+  f32x4 w0 = {0.f, 0.f, 0.f, 0.f}, w1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int p = 0; p < 3; ++p) {
+    w0 = sbr_mfma3_k32(a0[p], zz[p], w0);
+    w1 = sbr_mfma3_k32(a1[p], zz[p], w1);
+  }
+  SbrHL8 y[6];
+#pragma unroll
+  for (int rt = 0; rt < 6; ++rt) y[rt] = sbr_ld_hl8(N + (16 * rt + vi) * Q_NS32 + 8 * g);
+  const SbrHL8 ws = sbr_cat(sbr_split_pk(w0), sbr_split_pk(w1));
+#pragma unroll
+  for (int rt = 0; rt < 6; ++rt) z[rt] = sbr_mfma3_k32(y[rt], ws, z[rt]);
+}
+
+template <int QJ, int QNT, int NBUF, bool K32>
 __global__ __launch_bounds__(256, 2) void sbr_q2_apply16e(SbrQ2Args a, const float* __restrict__ img, int dbg) {
   static_assert(NBUF == 2 || NBUF == 3, "one or two groups ahead");
   constexpr int AH = NBUF - 1;
@@ -2670,7 +2759,10 @@ __global__ __launch_bounds__(256, 2) void sbr_q2_apply16e(SbrQ2Args a, const flo
         if (!(dbg & 2)) sbr_q2_dma(img, index_of(nb, nt), lds + nxt * Q_IMG, tid);  // dbg: timing experiments only (WRONG results)
         asm volatile("" ::: "memory");
         const int b = bh - j;
-        if (b >= 0 && t < sbr_tasks_of((int64_t)b * QW, a.n) && !(dbg & 1)) sbr_q2_group16e(z + 2 * (QJ - 1 - j), lds + cur * Q_IMG, vi, g);
+        if (b >= 0 && t < sbr_tasks_of((int64_t)b * QW, a.n) && !(dbg & 1)) {
+          if (K32) sbr_q2_group16f(z + 2 * (QJ - 1 - j), lds + cur * Q_IMG, vi, g);
+          else sbr_q2_group16e(z + 2 * (QJ - 1 - j), lds + cur * Q_IMG, vi, g);
+        }
         if (AH == 2) asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         cur = (cur + 1 == NBUF) ? 0 : cur + 1;
@@ -2703,7 +2795,7 @@ __global__ void sbr_q2_shift(const float* __restrict__ in, int64_t ldi, int64_t 
 static int sbr_q2_variant(int64_t n) {
   const char* eq2 = getenv("SCLENS_HIP_Q2_VARIANT");
   int v = eq2 ? atoi(eq2) : 8;
-  if ((v == 8 || v == 9) && n % SB != 0) v = 7;  // the image index assumes an order that is a multiple of 64 (the two-stage solver pads)
+  if (v >= 8 && v <= 11 && n % SB != 0) v = 7;  // the image index assumes an order that is a multiple of 64 (the two-stage solver pads)
   return v;
 }
 
@@ -2715,9 +2807,9 @@ static int sbr_q2_launch_build_t(Ctx* ctx, int64_t n, hipStream_t st) {
   if (!V2 || !TAU2 || nsweep <= 0) return ctx->fail(SCLENS_ERR_STATE, "sbr_q2_build_t: no reflectors of a preceding sb2st_f32 on this context");
   const int nblk = (int)((nsweep + QW - 1) / QW), nk = (int)((n - 1 + SB - 1) / SB);
   const int variant = sbr_q2_variant(n);
-  if (variant == 8 || variant == 9) {
+  if (variant >= 8 && variant <= 11) {
     SCL_WS(ctx, img, float, "sbr.Q2img", (sbr_q2_img_count(n) + 1) * Q_IMG);
-    hipLaunchKernelGGL(sbr_q2_build_img, dim3((unsigned)nk, (unsigned)nblk), dim3(256), 0, st, V2, ldv2, TAU2, ldt, n, img);
+    hipLaunchKernelGGL(sbr_q2_build_img, dim3((unsigned)nk, (unsigned)nblk), dim3(256), 0, st, V2, ldv2, TAU2, ldt, n, img, variant >= 10 ? 1 : 0);
   } else {
     SCL_WS(ctx, Tg, float, "sbr.Tg", (int64_t)nblk * nk * QW * QW);
     hipLaunchKernelGGL(sbr_q2_build_t, dim3((unsigned)nk, (unsigned)nblk), dim3(64), 0, st, V2, ldv2, TAU2, ldt, n, nk, Tg);
@@ -2779,16 +2871,21 @@ int sbr_apply_q2(Ctx* ctx, int64_t n, float* Zt, int64_t m, int64_t ldz) {
   // 8 (default since round 4): pre-built images + LDS-DMA two groups ahead (three LDS buffers, one workgroup per CU); 9: one group
   // ahead (two buffers, two workgroups per CU)
   const dim3 q2grid((unsigned)((m + 63) / 64));
-  if (q2_variant == 8 || q2_variant == 9) {
-    const int lds_bytes = (q2_variant == 8 ? 3 : 2) * Q_IMG * (int)sizeof(float);
+  if (q2_variant >= 8 && q2_variant <= 11) {
+    // 8 / 9: K = 16 matrix instructions, DMA two / one group(s) ahead (three / two LDS buffers); 10 / 11: the K = 32 form, one / two ahead
+    const bool three = (q2_variant == 8 || q2_variant == 11);
+    const int lds_bytes = (three ? 3 : 2) * Q_IMG * (int)sizeof(float);
     const int q2dbg = getenv("SCLENS_HIP_Q2_DBG") ? atoi(getenv("SCLENS_HIP_Q2_DBG")) : 0;  // 1: no products, 2: no DMA (timing experiments)
-    if (q2_variant == 8) {
-      SCL_TRY(ensure_dyn_lds(ctx, reinterpret_cast<const void*>(sbr_q2_apply16e<4, 12, 3>), lds_bytes));
-      hipLaunchKernelGGL((sbr_q2_apply16e<4, 12, 3>), q2grid, dim3(256), lds_bytes, ctx->stream, qa, q2img, q2dbg);
-    } else {
-      SCL_TRY(ensure_dyn_lds(ctx, reinterpret_cast<const void*>(sbr_q2_apply16e<4, 12, 2>), lds_bytes));
-      hipLaunchKernelGGL((sbr_q2_apply16e<4, 12, 2>), q2grid, dim3(256), lds_bytes, ctx->stream, qa, q2img, q2dbg);
-    }
+#define SBR_Q2E_LAUNCH(NBUF, K32)                                                                                              \
+  do {                                                                                                                         \
+    SCL_TRY(ensure_dyn_lds(ctx, reinterpret_cast<const void*>(sbr_q2_apply16e<4, 12, NBUF, K32>), lds_bytes));                \
+    hipLaunchKernelGGL((sbr_q2_apply16e<4, 12, NBUF, K32>), q2grid, dim3(256), lds_bytes, ctx->stream, qa, q2img, q2dbg);     \
+  } while (0)
+    if (q2_variant == 8) SBR_Q2E_LAUNCH(3, false);
+    else if (q2_variant == 9) SBR_Q2E_LAUNCH(2, false);
+    else if (q2_variant == 10) SBR_Q2E_LAUNCH(2, true);
+    else SBR_Q2E_LAUNCH(3, true);
+#undef SBR_Q2E_LAUNCH
   } else if (q2_variant == 0)
     hipLaunchKernelGGL((sbr_q2_apply16<4, 12, false>), q2grid, dim3(256), 0, ctx->stream, qa);
   else if (q2_variant == 1)

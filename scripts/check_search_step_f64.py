@@ -50,7 +50,10 @@ def scaled_gram_f64(P: sp.csc_matrix, chunk: int = 4000, log=None) -> np.ndarray
         D -= mu[None, :]
         D *= inv_s[a:b, None]
         D -= cent[None, :]
-        G += D.T @ D
+        # column blocks through dgemm: NumPy maps `D.T @ D` onto dsyrk, which segfaults inside the bundled OpenBLAS at order 30 000
+        # (reproduced in isolation on the build box, round 4)
+        for j0 in range(0, M, 6000):
+            G[:, j0:j0 + 6000] += D.T @ D[:, j0:j0 + 6000]
         if log and (a // chunk) % 5 == 0:
             log(f"  gram rows {b}/{N} ({time.perf_counter() - t0:.0f} s)")
     G /= N

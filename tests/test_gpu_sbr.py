@@ -299,7 +299,7 @@ def test_switches_that_only_move_work_give_the_same_bits(ctx, n, lo, hi, monkeyp
     assert np.abs(Z @ A64 - got[0][0][lo:hi, None] * Z).max() < 5e-5 * np.abs(got[0][0]).max() * np.sqrt(n / 64 + 1)
 
 
-@pytest.mark.parametrize("variant", ["8", "9", "7", "3"])
+@pytest.mark.parametrize("variant", ["10", "11", "8", "9", "7", "3"])
 @pytest.mark.parametrize("n,m", [(192, 192), (1088, 100), (2560, 70), (640, 641 - 1)])
 def test_second_back_transformation_matches_the_unblocked_reference(ctx, n, m, variant, monkeypatch):
     """The register-resident MFMA version of Q2 (16-vector wave tiles, QJ sweep blocks per pass) against the one-reflector-at-
@@ -354,7 +354,7 @@ def test_second_back_transformation_variants(ctx, monkeypatch):
     Z0 = np.zeros((m, lda), dtype=np.float32)
     Z0[:, :n] = Q.T.astype(np.float32)
     out = {}
-    for v in ("3", "6", "5", "7", "8", "9"):
+    for v in ("3", "6", "5", "7", "8", "9", "10", "11"):
         monkeypatch.setenv("SCLENS_HIP_Q2_VARIANT", v)
         dZ = DevArray(ctx, Z0)
         ctx.check(ctx.lib.sclens_hip_dev_sbr_apply_q2_f32(ctx.h, n, dZ.p, m, lda))
@@ -366,7 +366,8 @@ def test_second_back_transformation_variants(ctx, monkeypatch):
     assert np.array_equal(out["3"], out["6"]) and np.array_equal(out["5"], out["7"]) and np.array_equal(out["8"], out["9"])
     assert np.abs(out["7"].astype(np.float64) - out["3"]).max() < 4e-6
     assert np.abs(out["8"].astype(np.float64) - out["3"]).max() < 4e-6
-    for v in ("3", "7", "8"):
+    assert np.array_equal(out["10"], out["11"]) and np.abs(out["10"].astype(np.float64) - out["3"]).max() < 4e-6
+    for v in ("3", "7", "8", "10"):
         Z = out[v].astype(np.float64)
         assert np.abs(Z @ Z.T - np.eye(m)).max() < 2e-6, v
 
