@@ -112,6 +112,7 @@ void sclens_hip_destroy(sclens_hip_ctx* h) {
   for (hipEvent_t e : h->c.aux_ev)
     if (e) hipEventDestroy(e);
   if (h->c.q2_ev) hipEventDestroy(h->c.q2_ev);
+  if (h->c.q1_ev) hipEventDestroy(h->c.q1_ev);
   if (h->c.stream) hipStreamDestroy(h->c.stream);
   delete h;
 }

@@ -24,6 +24,11 @@ struct Ctx {
   hipEvent_t q2_ev = nullptr;
   int64_t q2_tg_n = -1;
   int q2_built_variant = -1;  // SCLENS_HIP_Q2_VARIANT the group data (T factors or LDS images) was last built for
+  // block reflectors of the first back-transformation prepared on the auxiliary stream right after the band reduction (sbr.hip,
+  // sbr_q1_prepare): the order / panels per group they were built for (-1: none) and the event that marks them complete
+  int64_t q1p_n = -1;
+  int q1p_g = 0;
+  hipEvent_t q1_ev = nullptr;
   bool q2_prebuild = true;  // cleared by a caller that will ask for eigenvalues only (the null matrix)
   std::string err;
   // grow-only named device workspaces (freed at destroy); avoids hipMalloc inside hot loops

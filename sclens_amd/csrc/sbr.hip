@@ -637,6 +637,7 @@ int sy2sb_f32(Ctx* ctx, float* A, int64_t n, int64_t lda, float* Tall, int* brea
   if (lda % 4 != 0 || lda < n || (reinterpret_cast<uintptr_t>(A) & 15u))
     return ctx->fail(SCLENS_ERR_ARG, "sy2sb_f32: A must be 16-byte aligned with lda a multiple of 4");
   StageTimer tm(ctx, "sy2sb");
+  ctx->q1p_n = -1;  // new reflectors: group data prepared for the previous ones is void
   const int64_t npan = n / SB - 1;  // the last diagonal block needs no reduction
   const int64_t ldw = round_up(n, 64);
   const int64_t maxparts = (n + SBR_GCH - 1) / SBR_GCH + 1;
@@ -958,6 +959,105 @@ __global__ __launch_bounds__(256) void sbr_q1_sum_w(const float* __restrict__ W1
   reinterpret_cast<f32x4*>(Ws)[i] = acc;
 }
 
+// ---- the group data of the first back-transformation, prepared ahead --------------------------------------------------------------
+// Per group of Q1G panels the apply loop below needs the clean reflector block Vm, its transpose as a split-fp16 image, and the
+// merged T factor: a Gram product of the group's reflectors, a slab sum and Q1G level kernels of ~40 us each that only depend on the
+// band reduction's output -- 0.7 ms per group, 41 of the stage's 210 ms at order 30 016, all of it a chain of small launches in
+// front of the group's three large products. sbr_q1_prepare builds the data of ALL groups on the auxiliary stream right after the
+// band reduction, beside the bulge chase (a latency chain that leaves most of the chip idle); sbr_apply_q1 then only waits for one
+// event. 3.7 GB of workspace at order 30 016 (SCLENS_HIP_Q1_PREP=0: off, the groups are prepared inline as before).
+struct Q1Layout {
+  int Q1G = 0, Q1W = 0;
+  int64_t ngrp = 0, vm_total = 0, img_total = 0;
+  std::vector<int64_t> np, ldv, vm_off, img_off;  // per group: rows below the group's first panel, stride of Vm, offsets (floats / bytes)
+};
+static Q1Layout sbr_q1_layout(int64_t n, int Q1G) {
+  Q1Layout L;
+  L.Q1G = Q1G;
+  L.Q1W = Q1G * SB;
+  const int64_t npan = n / SB - 1;
+  L.ngrp = (npan + Q1G - 1) / Q1G;
+  for (int64_t g = 0; g < L.ngrp; ++g) {
+    const int64_t np = n - (g * Q1G * SB + SB);
+    L.np.push_back(np);
+    L.ldv.push_back(round_up(np, 32));
+    L.vm_off.push_back(L.vm_total);
+    L.img_off.push_back(L.img_total);
+    L.vm_total += (int64_t)L.Q1W * round_up(np, 32);
+    L.img_total += (int64_t)round_up((int64_t)split_image_bytes(np, L.Q1W), 256);
+  }
+  return L;
+}
+static int64_t sbr_q1_split_min() {  // the read-modify-write product of a group runs from split images from this many vectors / rows
+  const char* eqs = getenv("SCLENS_HIP_Q1_SPLIT");  // 0: off; N > 0: from N vectors and N rows (default 1024)
+  return eqs ? atoll(eqs) : 1024;
+}
+
+// Vm, VmT, Tm of the group that starts at panel p0 (cnt panels), on ctx->stream; Gp / Gs: scratch
+static int sbr_q1_group_data(Ctx* ctx, const float* A, int64_t n, int64_t lda, const float* Tall, int64_t p0, int cnt, int Q1G, float* Vm,
+                             int64_t ldv, float* VmT, float* Gp, float* Gs, float* Tm) {
+  const int Q1W = Q1G * SB, SG = 64;  // K-slices of the Gram product of the group's reflectors (few output tiles: the slices are the parallelism)
+  const int64_t c0 = p0 * SB, np = n - (c0 + SB);
+  hipStream_t st = ctx->stream;
+  hipLaunchKernelGGL(sbr_q1_build_vm, dim3((unsigned)((ldv + 31) / 32), Q1W / 32), dim3(256), 0, st, A, lda, c0, cnt, np, Vm, ldv, VmT, Q1W);
+  {  // Gram matrix of the group's reflectors, split over K
+    GemmArgs gm{};
+    gm.P = Vm; gm.Q = Vm; gm.C = Gp;
+    gm.M = Q1W; gm.N = Q1W; gm.K = np;
+    gm.ldp = ldv; gm.ldq = ldv; gm.ldc = Q1W;
+    gm.alpha = 1.f; gm.beta = 0.f; gm.q_kcontig = 1; gm.lower = 0; gm.colabsmax = nullptr;
+    gm.splits = SG; gm.k_chunk = round_up((np + SG - 1) / SG, 32); gm.c_split_off = (int64_t)Q1W * Q1W;
+    SCL_TRY(gemm_f32(ctx, gm));
+  }
+  hipLaunchKernelGGL(sbr_q1_sum_g, dim3(Q1W * Q1W / 256), dim3(256), 0, st, Gp, SG, Gs, Q1W);
+  for (int level = 0; level < cnt; ++level)
+    hipLaunchKernelGGL(sbr_q1_merge_level, dim3(level == 0 ? Q1G : Q1G - level), dim3(256), 0, st, Gs, Tall + p0 * SB * SB, cnt, level, Tm, Q1W);
+  return SCLENS_OK;
+}
+
+int sbr_q1_prepare(Ctx* ctx, const float* A, int64_t n, int64_t lda, const float* Tall) {
+  ctx->q1p_n = -1;
+  const char* ep = getenv("SCLENS_HIP_Q1_PREP");
+  const int64_t npan = n / SB - 1, q1_min = sbr_q1_split_min();
+  static const int q1g_env = getenv("SCLENS_HIP_Q1G") ? atoi(getenv("SCLENS_HIP_Q1G")) : 0;
+  // for the block size of MANY vectors (8 panels); a later call with few vectors (4 panels per group) prepares its groups inline
+  if ((ep && atoi(ep) == 0) || !ctx->q2_prebuild || npan < 64 || q1_min <= 0 || (q1g_env != 0 && q1g_env != 8) || n % SB != 0) return SCLENS_OK;
+  const int Q1G = 8;
+  const Q1Layout L = sbr_q1_layout(n, Q1G);
+  const int Q1W = L.Q1W, SG = 64;
+  SCL_WS(ctx, VmAll, float, "sbr.q1pVm", L.vm_total);
+  void* imgAll = ctx->workspace("sbr.q1pImg", (size_t)L.img_total);
+  SCL_WS(ctx, TmAll, float, "sbr.q1pTm", L.ngrp * (int64_t)Q1W * Q1W);
+  SCL_WS(ctx, SAll, float, "sbr.q1pS", L.ngrp * 4);
+  SCL_WS(ctx, VmT, float, "sbr.q1pVmT", round_up(n, 32) * (int64_t)Q1W);
+  SCL_WS(ctx, Gp, float, "sbr.q1pG", (int64_t)SG * Q1W * Q1W);
+  SCL_WS(ctx, Gs, float, "sbr.q1pGs", (int64_t)Q1W * Q1W);
+  if (!imgAll) return SCLENS_ERR_OOM;
+  SCL_TRY(sbr_ensure_aux(ctx));
+  if (!ctx->q1_ev) SCL_HIP(ctx, hipEventCreateWithFlags(&ctx->q1_ev, hipEventDisableTiming));
+  SCL_HIP(ctx, hipEventRecord(ctx->aux_ev[0], ctx->stream));
+  SCL_HIP(ctx, hipStreamWaitEvent(ctx->aux_stream, ctx->aux_ev[0], 0));
+  // every helper launches on ctx->stream: the auxiliary stream stands in for it while the groups are enqueued
+  struct Swap {
+    Ctx* c;
+    hipStream_t main;
+    explicit Swap(Ctx* c_) : c(c_), main(c_->stream) { c->stream = c->aux_stream; }
+    ~Swap() { c->stream = main; }
+  } swap(ctx);
+  for (int64_t g = L.ngrp - 1; g >= 0; --g) {  // the order the apply loop consumes them in
+    if (L.np[g] < q1_min) continue;            // short groups keep the fp32 product and are prepared inline
+    const int cnt = (int)std::min<int64_t>(Q1G, npan - g * Q1G);
+    float* Vm = VmAll + L.vm_off[g];
+    SCL_TRY(sbr_q1_group_data(ctx, A, n, lda, Tall, g * Q1G, cnt, Q1G, Vm, L.ldv[g], VmT, Gp, Gs, TmAll + g * (int64_t)Q1W * Q1W));
+    SCL_TRY(split_image_scaled(ctx, VmT, L.np[g], Q1W, Q1W, static_cast<char*>(imgAll) + L.img_off[g], SAll + 4 * g));
+  }
+  SCL_HIP(ctx, hipEventRecord(ctx->q1_ev, ctx->stream));
+  SCL_HIP(ctx, hipGetLastError());
+  ctx->q1p_n = n;
+  ctx->q1p_g = Q1G;
+  return SCLENS_OK;
+}
+
 int sbr_apply_q1(Ctx* ctx, const float* A, int64_t n, int64_t lda, const float* Tall, float* Zt, int64_t m, int64_t ldz) {
   if (m <= 0) return SCLENS_OK;
   if (n % SB != 0) return ctx->fail(SCLENS_ERR_ARG, "sbr_apply_q1: the order must be a multiple of 64");
@@ -975,7 +1075,27 @@ int sbr_apply_q1(Ctx* ctx, const float* A, int64_t n, int64_t lda, const float* 
   const int64_t ldv = round_up(n, 32);
   const int64_t tiles_w1 = ((m + 255) / 256) * (Q1W / 256);
   const int SMAX = 16;  // upper bound of the K-slices of W1 (the workspaces are sized for it); the count is chosen per group
-  const int SG = 64;    // K-slices of the Gram product of the group's reflectors (few output tiles: the slices are the parallelism)
+  const int SG = 64;
+  // The read-modify-write product of a group, Zt += W2 Vm, on the fp16 matrix cores from split operands when it is large enough
+  // (gemm_split_update: 22-bit operands, fp32 accumulation, C added in the epilogue): at K = 512 the fp32 matrix-pipe time is four
+  // fifths of the product. SCLENS_HIP_Q1_SPLIT=0: fp32 products.
+  const int64_t q1_min = sbr_q1_split_min();
+  const bool q1_split = q1_min > 0 && m >= q1_min;
+  // groups prepared ahead on the auxiliary stream (sbr_q1_prepare): valid for this order, this group size and the split product
+  const bool prepared = q1_split && ctx->q1p_n == n && ctx->q1p_g == Q1G && ctx->q1_ev;
+  Q1Layout L;
+  float *VmAll = nullptr, *TmAll = nullptr, *SAll = nullptr;
+  char* imgAll = nullptr;
+  if (prepared) {
+    L = sbr_q1_layout(n, Q1G);
+    auto ws = [&](const char* name) -> void* { return ctx->ws.count(name) ? ctx->ws.at(name).first : nullptr; };
+    VmAll = static_cast<float*>(ws("sbr.q1pVm"));
+    imgAll = static_cast<char*>(ws("sbr.q1pImg"));
+    TmAll = static_cast<float*>(ws("sbr.q1pTm"));
+    SAll = static_cast<float*>(ws("sbr.q1pS"));
+    if (!VmAll || !imgAll || !TmAll || !SAll) return ctx->fail(SCLENS_ERR_STATE, "sbr_apply_q1: prepared group data missing");
+    SCL_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->q1_ev, 0));
+  }
   SCL_WS(ctx, Vm, float, "sbr.Vm", Q1W * ldv);
   SCL_WS(ctx, VmT, float, "sbr.VmT", ldv * Q1W);
   SCL_WS(ctx, Gp, float, "sbr.q1G", (int64_t)SG * Q1W * Q1W);
@@ -984,12 +1104,6 @@ int sbr_apply_q1(Ctx* ctx, const float* A, int64_t n, int64_t lda, const float* 
   SCL_WS(ctx, W1, float, "sbr.W1", m * (int64_t)SMAX * Q1W);
   SCL_WS(ctx, Ws, float, "sbr.Ws", m * (int64_t)Q1W);
   SCL_WS(ctx, W2, float, "sbr.W2", m * (int64_t)Q1W);
-  // The read-modify-write product of a group, Zt += W2 Vm, on the fp16 matrix cores from split operands when it is large enough
-  // (gemm_split_update: 22-bit operands, fp32 accumulation, C added in the epilogue): at K = 512 the fp32 matrix-pipe time is four
-  // fifths of the product. SCLENS_HIP_Q1_SPLIT=0: fp32 products.
-  const char* eqs = getenv("SCLENS_HIP_Q1_SPLIT");  // 0: off; N > 0: from N vectors and N rows (default 1024)
-  const int64_t q1_min = eqs ? atoll(eqs) : 1024;
-  const bool q1_split = q1_min > 0 && m >= q1_min;
   void* imgW = q1_split ? ctx->workspace("sbr.q1imgW", split_image_bytes(m, Q1W)) : nullptr;
   void* imgV = q1_split ? ctx->workspace("sbr.q1imgV", split_image_bytes(n, Q1W)) : nullptr;
   float* imgS = q1_split ? static_cast<float*>(ctx->workspace("sbr.q1imgS", 8 * sizeof(float))) : nullptr;
@@ -1000,25 +1114,18 @@ int sbr_apply_q1(Ctx* ctx, const float* A, int64_t n, int64_t lda, const float* 
     const int cnt = (int)std::min<int64_t>(Q1G, npan - p0);
     const int64_t c0 = p0 * SB, r0 = c0 + SB, np = n - r0;
     const int S = sbr_pick_splits(tiles_w1, SMAX, np);
-    hipLaunchKernelGGL(sbr_q1_build_vm, dim3((unsigned)((ldv + 31) / 32), Q1W / 32), dim3(256), 0, st, A, lda, c0, cnt, np, Vm, ldv, VmT, Q1W);
-    {  // Gram matrix of the group's reflectors, split over K
-      GemmArgs gm{};
-      gm.P = Vm; gm.Q = Vm; gm.C = Gp;
-      gm.M = Q1W; gm.N = Q1W; gm.K = np;
-      gm.ldp = ldv; gm.ldq = ldv; gm.ldc = Q1W;
-      gm.alpha = 1.f; gm.beta = 0.f; gm.q_kcontig = 1; gm.lower = 0; gm.colabsmax = nullptr;
-      gm.splits = SG; gm.k_chunk = round_up((np + SG - 1) / SG, 32); gm.c_split_off = (int64_t)Q1W * Q1W;
-      SCL_TRY(gemm_f32(ctx, gm));
-    }
-    hipLaunchKernelGGL(sbr_q1_sum_g, dim3(Q1W * Q1W / 256), dim3(256), 0, st, Gp, SG, Gs, Q1W);
-    for (int level = 0; level < cnt; ++level)
-      hipLaunchKernelGGL(sbr_q1_merge_level, dim3(level == 0 ? Q1G : Q1G - level), dim3(256), 0, st, Gs, Tall + p0 * SB * SB, cnt, level, Tm, Q1W);
+    const bool split_g = q1_split && np >= q1_min;
+    const bool ready = prepared && split_g;  // this group's Vm, Tm and the split image of VmT exist already
+    const float* Vm_g = ready ? VmAll + L.vm_off[g] : Vm;
+    const int64_t ldv_g = ready ? L.ldv[g] : ldv;
+    const float* Tm_g = ready ? TmAll + g * (int64_t)Q1W * Q1W : Tm;
+    if (!ready) SCL_TRY(sbr_q1_group_data(ctx, A, n, lda, Tall, p0, cnt, Q1G, Vm, ldv, VmT, Gp, Gs, Tm));
     const int64_t kch = round_up((np + S - 1) / S, 32);
     {  // W1[m][s][Q1W] = split-K partials of Zt[:, r0:] Vm'
       GemmArgs g1{};
-      g1.P = Zt + r0; g1.Q = Vm; g1.C = W1;
+      g1.P = Zt + r0; g1.Q = Vm_g; g1.C = W1;
       g1.M = m; g1.N = Q1W; g1.K = np;
-      g1.ldp = ldz; g1.ldq = ldv; g1.ldc = (int64_t)S * Q1W;
+      g1.ldp = ldz; g1.ldq = ldv_g; g1.ldc = (int64_t)S * Q1W;
       g1.alpha = 1.f; g1.beta = 0.f; g1.q_kcontig = 1; g1.lower = 0; g1.colabsmax = nullptr;
       g1.splits = S; g1.k_chunk = kch; g1.c_split_off = Q1W;
       g1.prefer_big = 1;
@@ -1031,16 +1138,23 @@ int sbr_apply_q1(Ctx* ctx, const float* A, int64_t n, int64_t lda, const float* 
     }
     {  // W2 = -(sum_s W1_s) Tm'
       GemmArgs g2{};
-      g2.P = Wsum; g2.Q = Tm; g2.C = W2;
+      g2.P = Wsum; g2.Q = Tm_g; g2.C = W2;
       g2.M = m; g2.N = Q1W; g2.K = Q1W;
       g2.ldp = Q1W; g2.ldq = Q1W; g2.ldc = Q1W;
       g2.alpha = -1.f; g2.beta = 0.f; g2.q_kcontig = 1; g2.lower = 0; g2.colabsmax = nullptr;  // W2 = -(...): g3 then adds
       SCL_TRY(gemm_f32(ctx, g2));
     }
-    if (q1_split && np >= q1_min) {  // Zt[:, r0:] += W2 Vm from split images
+    if (split_g) {  // Zt[:, r0:] += W2 Vm from split images
       SCL_TRY(split_image_scaled(ctx, W2, m, Q1W, Q1W, imgW, imgS));
-      SCL_TRY(split_image_scaled(ctx, VmT, np, Q1W, Q1W, imgV, imgS + 4));
-      SCL_TRY(gemm_split_update(ctx, imgW, imgS, m, imgV, imgS + 4, np, Q1W, Zt + r0, ldz, 0));
+      const void* iv = imgV;
+      const float* sv = imgS + 4;
+      if (ready) {
+        iv = imgAll + L.img_off[g];
+        sv = SAll + 4 * g;
+      } else {
+        SCL_TRY(split_image_scaled(ctx, VmT, np, Q1W, Q1W, imgV, imgS + 4));
+      }
+      SCL_TRY(gemm_split_update(ctx, imgW, imgS, m, iv, sv, np, Q1W, Zt + r0, ldz, 0));
     } else {  // Zt[:, r0:] += W2 Vm   (NT against the transposed copy; accumulators started from Zt)
       GemmArgs g3{};
       g3.P = W2; g3.Q = VmT; g3.C = Zt + r0;
@@ -2963,6 +3077,7 @@ int eig_values_two_stage(Ctx* ctx, const float* A, int64_t n, int64_t lda, doubl
   int breakdown = 0;
   SCL_TRY(sy2sb_f32(ctx, Ap, np, ldp, Tall, &breakdown));
   if (breakdown) return SCLENS_OK;
+  SCL_TRY(sbr_q1_prepare(ctx, Ap, np, ldp, Tall));  // on the auxiliary stream, beside the chase
   SCL_TRY(sb2st_f32(ctx, Ap, np, ldp, d, e));
   if (n_low < 0 || n_low >= n - 1) {
     SCL_TRY(stebz_f64(ctx, d, e, np, wp));

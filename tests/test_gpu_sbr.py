@@ -299,6 +299,40 @@ def test_switches_that_only_move_work_give_the_same_bits(ctx, n, lo, hi, monkeyp
     assert np.abs(Z @ A64 - got[0][0][lo:hi, None] * Z).max() < 5e-5 * np.abs(got[0][0]).max() * np.sqrt(n / 64 + 1)
 
 
+def test_first_back_transformation_group_data_prepared_ahead_gives_the_same_bits(ctx, monkeypatch):
+    """Round 4: the block reflectors of the first back-transformation (clean reflector blocks, merged T factors, split images) are
+    built for all groups on the auxiliary stream right after the band reduction (sbr_q1_prepare) instead of group by group inside
+    the apply loop (SCLENS_HIP_Q1_PREP=0): the same kernels on the same data -- the same bits. Order 4 288 = 66 panels (groups of
+    8 from 64 panels), 2 112 vectors (from 2 048), the split products forced on as at the bench's order."""
+    from sclens_amd._lib import Context
+
+    n, lo, hi = 4288, 1000, 3112
+    A = _sym_psd(n, 31 + n)
+    lda = rup(n, 32)
+    m = hi - lo
+    got = []
+    for prep in ("1", "0"):
+        monkeypatch.setenv("SCLENS_HIP_Q1_PREP", prep)
+        c2 = Context(ctx.device)
+        c2.set_option("two_stage", 1)
+        try:
+            dA, dw, dZ = DevArray(c2, pad_rows(A, lda)), DevArray(c2, nbytes=8 * n), DevArray(c2, nbytes=4 * m * lda)
+            for _ in range(2):  # twice: the second decomposition must not pick up the first one's group data
+                c2.h2d(dA.p, pad_rows(A, lda))
+                c2.check(c2.lib.sclens_hip_dev_eigh_f32(c2.h, dA.p, n, lda, dw.p, lo, hi, dZ.p, lda))
+            c2.sync()
+            got.append((dw.get((n,), np.float64), dZ.get((m, lda), np.float32)[:, :n]))
+            for x in (dA, dw, dZ):
+                x.free()
+        finally:
+            c2.close()
+    assert np.array_equal(got[0][0], got[1][0]) and np.array_equal(got[0][1], got[1][1])
+    A64 = A.astype(np.float64)
+    Z = got[0][1].astype(np.float64)
+    assert np.abs(Z @ A64 - got[0][0][lo:hi, None] * Z).max() < 5e-5 * np.abs(got[0][0]).max() * np.sqrt(n / 64 + 1)
+    assert np.abs(Z @ Z.T - np.eye(m)).max() < 3e-4
+
+
 @pytest.mark.parametrize("variant", ["10", "11", "8", "9", "7", "3"])
 @pytest.mark.parametrize("n,m", [(192, 192), (1088, 100), (2560, 70), (640, 641 - 1)])
 def test_second_back_transformation_matches_the_unblocked_reference(ctx, n, m, variant, monkeypatch):
