@@ -2904,11 +2904,14 @@ __global__ void sbr_q2_shift(const float* __restrict__ in, int64_t ldi, int64_t 
   if (c < n) out[r * ldo + offo + c] = in[r * ldi + offi + c];
 }
 
-// 8 (default): pre-built group images + LDS-DMA; 7: split-fp16 products, reflectors staged by every workgroup (round 3);
-// 3: fp32 products (every product of the solver on the fp32 matrix cores); 0, 1, 5, 6: earlier kernels kept for comparison
+// 10 (default): pre-built group images moved by LDS-DMA one group ahead, K = 32 matrix instructions; 11: two groups ahead; 8 / 9: the
+// K = 16 form; 7: split-fp16 products, reflectors staged by every workgroup (round 3); 3: fp32 products (every product of the
+// solver on the fp32 matrix cores); 0, 1, 5, 6: earlier kernels kept for comparison. Measured at n = 30 016 (profiles/r04_q2_*):
+// m = 15 008: 385 (7), 307 (8), 296 (9), 295 (10), 303 (11) ms; all 30 016 vectors: 553 (7), 613 (8: three LDS buffers = one
+// workgroup per CU), 497 (9), 462 (10).
 static int sbr_q2_variant(int64_t n) {
   const char* eq2 = getenv("SCLENS_HIP_Q2_VARIANT");
-  int v = eq2 ? atoi(eq2) : 8;
+  int v = eq2 ? atoi(eq2) : 10;
   if (v >= 8 && v <= 11 && n % SB != 0) v = 7;  // the image index assumes an order that is a multiple of 64 (the two-stage solver pads)
   return v;
 }
