@@ -187,6 +187,11 @@ int corr_colabsmax_split(Ctx* ctx, const void* Aimg, int64_t M, const void* Bimg
 // gemm_split_update: C[M][N] += P Q' (lower != 0: M == N, tiles on / below the diagonal, mirrored) from two such images and
 // their scales, accumulators started from C -- the arithmetic of `acc_init` in gemm.hip with 22-bit operands.
 int split_image_scaled(Ctx* ctx, const float* src, int64_t rows, int64_t K, int64_t ld, void* dst, float* scale_dev);
+// the same under a FIXED power-of-two scale (no pass over the data): operands whose entries are at most 1 in magnitude
+int split_image_fixed(Ctx* ctx, const float* src, int64_t rows, int64_t K, int64_t ld, void* dst, float* scale_dev, float scale);
+// C_s = P Q' over the K-slice s of `splits` (slab s at C + s * c_split_off, row pitch ldc; C is not read): split-K partials
+int gemm_split_nt(Ctx* ctx, const void* Pimg, const float* sP, int64_t M, const void* Qimg, const float* sQ, int64_t N, int64_t K, float* C,
+                  int64_t ldc, int splits, int64_t k_chunk, int64_t c_split_off);
 // two matrices of the same shape that hold the same magnitudes (the two operands of a symmetric rank-2k update): one scale, from src1
 int split_image_pair_scaled(Ctx* ctx, const float* src1, const float* src2, int64_t rows, int64_t K, int64_t ld, void* dst1, void* dst2,
                             float* scale_dev);

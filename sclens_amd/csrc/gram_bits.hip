@@ -451,6 +451,7 @@ __global__ void k_pick_scale(const unsigned* __restrict__ mxbits, float* __restr
   }
   scale[0] = sc;
 }
+__global__ void k_set_scale(float* __restrict__ scale, float v) { scale[0] = v; }
 __global__ __launch_bounds__(256) void k_split_image_scaled(const float* __restrict__ src, int64_t rows, int64_t K, int64_t ld, int64_t Kp,
                                                             const float* __restrict__ scale, _Float16* __restrict__ dst) {
   const int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -556,6 +557,11 @@ struct SplitUpdArgs {
   int tiles_n;
   float post;          // C += post * P Q'
   const int2* tiles;   // tile list (compact squares per XCD, gemm.hip) for long contractions, or nullptr: decoded from the block index
+  // split over K inside one launch (gridDim.y slices of kt_chunk 32-deep steps; slice s writes C + s * c_split_off), and
+  // overwrite != 0: C = post * P Q' (C is not read) -- the split-K partials of a product with few output tiles
+  int64_t kt_chunk;
+  int64_t c_split_off;
+  int overwrite;
 };
 
 // The main loop of corr_split_kernel with the tile decode, the accumulator start from C and the lower + mirror epilogue of
@@ -597,7 +603,14 @@ __global__ __launch_bounds__(512, 2) void gemm_split_kernel(SplitUpdArgs a) {
     srcA[i] = a.A + ra * 2 * a.Kp + 8 * chunk;
     srcB[i] = a.B + rb * 2 * a.Kp + 8 * chunk;
   }
-  const int64_t nkt = a.Kp / 32;
+  int64_t kt_lo = 0, nkt = a.Kp / 32;
+  if (gridDim.y > 1) {  // this slice of the contraction
+    kt_lo = (int64_t)blockIdx.y * a.kt_chunk;
+    const int64_t kt_hi = kt_lo + a.kt_chunk;
+    nkt = kt_hi < nkt ? kt_hi : nkt;
+    if (kt_lo > nkt) kt_lo = nkt;
+    a.C += (int64_t)blockIdx.y * a.c_split_off;
+  }
   auto stage = [&](int buf, int64_t kt) {
     unsigned char* As = lds + buf * STAGE;
     unsigned char* Bs = As + OPB;
@@ -608,7 +621,7 @@ __global__ __launch_bounds__(512, 2) void gemm_split_kernel(SplitUpdArgs a) {
     for (int i = 0; i < 4; ++i)
       __builtin_amdgcn_global_load_lds((glb_void_t*)(srcB[i] + kt * 64), (lds_void_t*)(Bs + (wid * 4 + i) * 1024), 16, 0, 0);
   };
-  stage(0, 0);
+  if (kt_lo < nkt) stage((int)(kt_lo & 1), kt_lo);
   const float alpha = a.post / (a.sA[0] * a.sB[0]);  // the scales are powers of two
   // 32-bit indices relative to the tile's corner (and to the corner of its mirror image): the 64-bit row * ldc + col of every
   // element cost this kernel 191 spilled registers
@@ -638,7 +651,7 @@ __global__ __launch_bounds__(512, 2) void gemm_split_kernel(SplitUpdArgs a) {
     swB[j] = (r >> 1) & 7;
   }
   __syncthreads();
-  for (int64_t kt = 0; kt < nkt; ++kt) {
+  for (int64_t kt = kt_lo; kt < nkt; ++kt) {
     const int buf = (int)(kt & 1);
     if (kt + 1 < nkt) stage(buf ^ 1, kt + 1);
     const unsigned char* S = lds + buf * STAGE;
@@ -681,7 +694,7 @@ __global__ __launch_bounds__(512, 2) void gemm_split_kernel(SplitUpdArgs a) {
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
         const int r = r0 + (e & 3) + 8 * (e >> 2);
-        cin[e] = (r < mrem && c < nrem && c <= r + diag) ? Ct[r * ldc + c] : 0.f;
+        cin[e] = (!a.overwrite && r < mrem && c < nrem && c <= r + diag) ? Ct[r * ldc + c] : 0.f;
       }
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[i][j][e] = fmaf(acc[i][j][e], alpha, cin[e]);
@@ -821,8 +834,38 @@ int gemm_split_update(Ctx* ctx, const void* Pimg, const float* sP, int64_t M, co
   constexpr int LDS_BYTES = 2 * 2 * 256 * 128;
   SCL_TRY(ensure_dyn_lds(ctx, reinterpret_cast<const void*>(gemm_split_kernel), LDS_BYTES));
   SplitUpdArgs a{static_cast<const _Float16*>(Pimg), static_cast<const _Float16*>(Qimg), sP, sQ, M, N, round_up(K, 32), C, ldc, lower,
-                 (int)bn, post, tiles};
+                 (int)bn, post, tiles, 0, 0, 0};
   hipLaunchKernelGGL(gemm_split_kernel, dim3((unsigned)nb), dim3(512), LDS_BYTES, ctx->stream, a);
+  SCL_HIP(ctx, hipGetLastError());
+  return SCLENS_OK;
+}
+
+// C_s[M][N] = P Q' over the K-slice s (s < splits, k_chunk a multiple of 32), C_s at C + s * c_split_off with row pitch ldc: the
+// split-K partials of a product with few output tiles on the fp16 matrix cores (the consumer sums the slabs in a fixed order)
+int gemm_split_nt(Ctx* ctx, const void* Pimg, const float* sP, int64_t M, const void* Qimg, const float* sQ, int64_t N, int64_t K, float* C,
+                  int64_t ldc, int splits, int64_t k_chunk, int64_t c_split_off) {
+  if (M <= 0 || N <= 0) return SCLENS_OK;
+  if (splits < 1 || (splits > 1 && k_chunk % 32 != 0)) return ctx->fail(SCLENS_ERR_ARG, "gemm_split_nt: k_chunk must be a multiple of 32");
+  const int64_t bm = (M + 255) / 256, bn = (N + 255) / 256, nb = bm * bn;
+  if (nb > 0x7fffffffLL) return ctx->fail(SCLENS_ERR_ARG, "gemm_split_nt: too many tiles");
+  constexpr int LDS_BYTES = 2 * 2 * 256 * 128;
+  SCL_TRY(ensure_dyn_lds(ctx, reinterpret_cast<const void*>(gemm_split_kernel), LDS_BYTES));
+  SplitUpdArgs a{static_cast<const _Float16*>(Pimg), static_cast<const _Float16*>(Qimg), sP, sQ, M, N, round_up(K, 32), C, ldc, 0,
+                 (int)bn, 1.0f, nullptr, splits > 1 ? k_chunk / 32 : round_up(K, 32) / 32, c_split_off, 1};
+  hipLaunchKernelGGL(gemm_split_kernel, dim3((unsigned)nb, (unsigned)splits), dim3(512), LDS_BYTES, ctx->stream, a);
+  SCL_HIP(ctx, hipGetLastError());
+  return SCLENS_OK;
+}
+
+// the split image of src [rows][K] under a FIXED power-of-two scale (operands whose entries are known to be at most 1 in magnitude:
+// rows of orthogonal matrices, reflector blocks): no pass over the data for its largest entry. scale_dev[0] receives the scale.
+int split_image_fixed(Ctx* ctx, const float* src, int64_t rows, int64_t K, int64_t ld, void* dst, float* scale_dev, float scale) {
+  if (rows <= 0) return SCLENS_OK;
+  const int64_t Kp = round_up(K, 32);
+  hipStream_t st = ctx->stream;
+  hipLaunchKernelGGL(k_set_scale, dim3(1), dim3(1), 0, st, scale_dev, scale);
+  hipLaunchKernelGGL(k_split_image_scaled, dim3((unsigned)((Kp + 255) / 256), (unsigned)std::min<int64_t>(rows, 65535)), dim3(256), 0, st,
+                     src, rows, K, ld, Kp, scale_dev, static_cast<_Float16*>(dst));
   SCL_HIP(ctx, hipGetLastError());
   return SCLENS_OK;
 }

@@ -968,8 +968,9 @@ __global__ __launch_bounds__(256) void sbr_q1_sum_w(const float* __restrict__ W1
 // event. 3.7 GB of workspace at order 30 016 (SCLENS_HIP_Q1_PREP=0: off, the groups are prepared inline as before).
 struct Q1Layout {
   int Q1G = 0, Q1W = 0;
-  int64_t ngrp = 0, vm_total = 0, img_total = 0;
-  std::vector<int64_t> np, ldv, vm_off, img_off;  // per group: rows below the group's first panel, stride of Vm, offsets (floats / bytes)
+  int64_t ngrp = 0, vm_total = 0, img_total = 0, vimg_total = 0;
+  // per group: rows below the group's first panel, stride of Vm, offsets of Vm (floats), of the split image of VmT and of Vm (bytes)
+  std::vector<int64_t> np, ldv, vm_off, img_off, vimg_off;
 };
 static Q1Layout sbr_q1_layout(int64_t n, int Q1G) {
   Q1Layout L;
@@ -983,8 +984,10 @@ static Q1Layout sbr_q1_layout(int64_t n, int Q1G) {
     L.ldv.push_back(round_up(np, 32));
     L.vm_off.push_back(L.vm_total);
     L.img_off.push_back(L.img_total);
+    L.vimg_off.push_back(L.vimg_total);
     L.vm_total += (int64_t)L.Q1W * round_up(np, 32);
     L.img_total += (int64_t)round_up((int64_t)split_image_bytes(np, L.Q1W), 256);
+    L.vimg_total += (int64_t)round_up((int64_t)split_image_bytes(L.Q1W, np), 256);
   }
   return L;
 }
@@ -1028,7 +1031,9 @@ int sbr_q1_prepare(Ctx* ctx, const float* A, int64_t n, int64_t lda, const float
   SCL_WS(ctx, VmAll, float, "sbr.q1pVm", L.vm_total);
   void* imgAll = ctx->workspace("sbr.q1pImg", (size_t)L.img_total);
   SCL_WS(ctx, TmAll, float, "sbr.q1pTm", L.ngrp * (int64_t)Q1W * Q1W);
-  SCL_WS(ctx, SAll, float, "sbr.q1pS", L.ngrp * 4);
+  SCL_WS(ctx, SAll, float, "sbr.q1pS", L.ngrp * 8);
+  void* vimgAll = ctx->workspace("sbr.q1pVimg", (size_t)L.vimg_total);  // split images of the Vm blocks (operand of W1 = Z Vm')
+  if (!vimgAll) return SCLENS_ERR_OOM;
   SCL_WS(ctx, VmT, float, "sbr.q1pVmT", round_up(n, 32) * (int64_t)Q1W);
   SCL_WS(ctx, Gp, float, "sbr.q1pG", (int64_t)SG * Q1W * Q1W);
   SCL_WS(ctx, Gs, float, "sbr.q1pGs", (int64_t)Q1W * Q1W);
@@ -1049,7 +1054,8 @@ int sbr_q1_prepare(Ctx* ctx, const float* A, int64_t n, int64_t lda, const float
     const int cnt = (int)std::min<int64_t>(Q1G, npan - g * Q1G);
     float* Vm = VmAll + L.vm_off[g];
     SCL_TRY(sbr_q1_group_data(ctx, A, n, lda, Tall, g * Q1G, cnt, Q1G, Vm, L.ldv[g], VmT, Gp, Gs, TmAll + g * (int64_t)Q1W * Q1W));
-    SCL_TRY(split_image_scaled(ctx, VmT, L.np[g], Q1W, Q1W, static_cast<char*>(imgAll) + L.img_off[g], SAll + 4 * g));
+    SCL_TRY(split_image_scaled(ctx, VmT, L.np[g], Q1W, Q1W, static_cast<char*>(imgAll) + L.img_off[g], SAll + 8 * g));
+    SCL_TRY(split_image_fixed(ctx, Vm, Q1W, L.np[g], L.ldv[g], static_cast<char*>(vimgAll) + L.vimg_off[g], SAll + 8 * g + 4, 8192.f));
   }
   SCL_HIP(ctx, hipEventRecord(ctx->q1_ev, ctx->stream));
   SCL_HIP(ctx, hipGetLastError());
@@ -1085,7 +1091,7 @@ int sbr_apply_q1(Ctx* ctx, const float* A, int64_t n, int64_t lda, const float* 
   const bool prepared = q1_split && ctx->q1p_n == n && ctx->q1p_g == Q1G && ctx->q1_ev;
   Q1Layout L;
   float *VmAll = nullptr, *TmAll = nullptr, *SAll = nullptr;
-  char* imgAll = nullptr;
+  char *imgAll = nullptr, *vimgAll = nullptr;
   if (prepared) {
     L = sbr_q1_layout(n, Q1G);
     auto ws = [&](const char* name) -> void* { return ctx->ws.count(name) ? ctx->ws.at(name).first : nullptr; };
@@ -1093,7 +1099,8 @@ int sbr_apply_q1(Ctx* ctx, const float* A, int64_t n, int64_t lda, const float* 
     imgAll = static_cast<char*>(ws("sbr.q1pImg"));
     TmAll = static_cast<float*>(ws("sbr.q1pTm"));
     SAll = static_cast<float*>(ws("sbr.q1pS"));
-    if (!VmAll || !imgAll || !TmAll || !SAll) return ctx->fail(SCLENS_ERR_STATE, "sbr_apply_q1: prepared group data missing");
+    vimgAll = static_cast<char*>(ws("sbr.q1pVimg"));
+    if (!VmAll || !imgAll || !TmAll || !SAll || !vimgAll) return ctx->fail(SCLENS_ERR_STATE, "sbr_apply_q1: prepared group data missing");
     SCL_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->q1_ev, 0));
   }
   SCL_WS(ctx, Vm, float, "sbr.Vm", Q1W * ldv);
@@ -1106,8 +1113,18 @@ int sbr_apply_q1(Ctx* ctx, const float* A, int64_t n, int64_t lda, const float* 
   SCL_WS(ctx, W2, float, "sbr.W2", m * (int64_t)Q1W);
   void* imgW = q1_split ? ctx->workspace("sbr.q1imgW", split_image_bytes(m, Q1W)) : nullptr;
   void* imgV = q1_split ? ctx->workspace("sbr.q1imgV", split_image_bytes(n, Q1W)) : nullptr;
-  float* imgS = q1_split ? static_cast<float*>(ctx->workspace("sbr.q1imgS", 8 * sizeof(float))) : nullptr;
+  float* imgS = q1_split ? static_cast<float*>(ctx->workspace("sbr.q1imgS", 16 * sizeof(float))) : nullptr;
   if (q1_split && (!imgW || !imgV || !imgS)) return SCLENS_ERR_OOM;
+  // Round 4: the FIRST product of a group, W1 = Zt[:, r0:] Vm', from split images too (the largest product of the stage that was
+  // still on the fp32 matrix cores: 0.11 of its 0.21 s). Rows of Zt are unit vectors and reflector entries are at most 1, so both
+  // images take the fixed scale 2^13 -- no pass for the largest entry; the image of Zt's columns is formed per group (they change
+  // with every group's update: one streaming pass, 8 bytes per entry), the image of Vm with the prepared group data or inline.
+  // SCLENS_HIP_Q1_W1_SPLIT=0: this product stays fp32.
+  const char* ew1 = getenv("SCLENS_HIP_Q1_W1_SPLIT");
+  const bool w1_split = q1_split && !(ew1 && atoi(ew1) == 0);
+  void* imgZ = w1_split ? ctx->workspace("sbr.q1imgZ", split_image_bytes(m, n)) : nullptr;
+  void* imgVm = w1_split ? ctx->workspace("sbr.q1imgVm", split_image_bytes(Q1W, n)) : nullptr;
+  if (w1_split && (!imgZ || !imgVm)) return SCLENS_ERR_OOM;
   hipStream_t st = ctx->stream;
   for (int64_t g = ngrp - 1; g >= 0; --g) {
     const int64_t p0 = g * Q1G;
@@ -1121,7 +1138,18 @@ int sbr_apply_q1(Ctx* ctx, const float* A, int64_t n, int64_t lda, const float* 
     const float* Tm_g = ready ? TmAll + g * (int64_t)Q1W * Q1W : Tm;
     if (!ready) SCL_TRY(sbr_q1_group_data(ctx, A, n, lda, Tall, p0, cnt, Q1G, Vm, ldv, VmT, Gp, Gs, Tm));
     const int64_t kch = round_up((np + S - 1) / S, 32);
-    {  // W1[m][s][Q1W] = split-K partials of Zt[:, r0:] Vm'
+    if (w1_split && split_g) {  // W1[m][s][Q1W] = split-K partials of Zt[:, r0:] Vm' on the fp16 matrix cores
+      SCL_TRY(split_image_fixed(ctx, Zt + r0, m, np, ldz, imgZ, imgS + 8, 8192.f));
+      const void* ivm = imgVm;
+      const float* svm = imgS + 12;
+      if (ready) {
+        ivm = vimgAll + L.vimg_off[g];
+        svm = SAll + 8 * g + 4;
+      } else {
+        SCL_TRY(split_image_fixed(ctx, Vm_g, Q1W, np, ldv_g, imgVm, imgS + 12, 8192.f));
+      }
+      SCL_TRY(gemm_split_nt(ctx, imgZ, imgS + 8, m, ivm, svm, Q1W, np, W1, (int64_t)S * Q1W, S, kch, Q1W));
+    } else {  // W1[m][s][Q1W] = split-K partials of Zt[:, r0:] Vm'
       GemmArgs g1{};
       g1.P = Zt + r0; g1.Q = Vm_g; g1.C = W1;
       g1.M = m; g1.N = Q1W; g1.K = np;
@@ -1150,7 +1178,7 @@ int sbr_apply_q1(Ctx* ctx, const float* A, int64_t n, int64_t lda, const float* 
       const float* sv = imgS + 4;
       if (ready) {
         iv = imgAll + L.img_off[g];
-        sv = SAll + 4 * g;
+        sv = SAll + 8 * g;
       } else {
         SCL_TRY(split_image_scaled(ctx, VmT, np, Q1W, Q1W, imgV, imgS + 4));
       }
