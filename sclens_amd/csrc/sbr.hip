@@ -2843,16 +2843,50 @@ __device__ __forceinline__ void sbr_q2_group16f(f32x4* z, const float* buf, int 
   for (int rt = 0; rt < 6; ++rt) z[rt] = sbr_mfma3_k32(y[rt], ws, z[rt]);
 }
 
+// Window loads / stores of the image-fed kernel: buffer instructions on a resource that covers the workgroup's 64 vectors, one
+// instruction per lane and call WHATEVER the row (quads outside [-3, n - 3] and vectors past m get an offset beyond the resource:
+// the load returns 0, the store is dropped) -- the number of memory instructions between two waits is then a constant, which the
+// counted `s_waitcnt vmcnt(N)` below rely on. A quad that starts at row n - 3 ends in the row's padding (ldq >= n + 4 floats, zeroed
+// by sbr_q2_shift).
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+struct SbrZWin {
+  __amdgpu_buffer_rsrc_t rs;
+  int64_t lane_base;  // float index of row 0 of this lane's vector inside the resource
+  int64_t n;
+};
+__device__ __forceinline__ unsigned sbr_zoff(const SbrZWin& w, int64_t row) {
+  return (row >= -3 && row <= w.n - 3) ? (unsigned)((w.lane_base + row) * 4) : 0xfffffff0u;
+}
+__device__ __forceinline__ f32x4 sbr_zld(const SbrZWin& w, int64_t row) {
+  return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(w.rs, sbr_zoff(w, row), 0, 0));
+}
+__device__ __forceinline__ void sbr_zst(const SbrZWin& w, int64_t row, f32x4 v) {
+  __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), w.rs, sbr_zoff(w, row), 0, 0);
+}
+template <int N>
+__device__ __forceinline__ void sbr_vmcnt() {  // at most N vector-memory instructions of this wave may still be in flight
+  static_assert(N == 0 || N == 4 || N == 7 || N == 8 || N == 11 || N == 15, "counts of the image-fed kernel");
+  if (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if (N == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+  if (N == 7) asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
+  if (N == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+  if (N == 11) asm volatile("s_waitcnt vmcnt(11)" ::: "memory");
+  if (N == 15) asm volatile("s_waitcnt vmcnt(15)" ::: "memory");
+}
+
 template <int QJ, int QNT, int NBUF, bool K32>
 __global__ __launch_bounds__(256, 2) void sbr_q2_apply16e(SbrQ2Args a, const float* __restrict__ img, int dbg) {
   static_assert(NBUF == 2 || NBUF == 3, "one or two groups ahead");
-  constexpr int AH = NBUF - 1;
+  constexpr int AH = NBUF - 1, DM = (AH == 2) ? 7 : 0;  // DMA instructions that may stay in flight past the end of a group
   extern __shared__ __attribute__((aligned(16))) float q2lds[];  // NBUF images
   float* lds = q2lds;
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, vi = lane & 15, g = lane >> 4;
-  const int64_t v = (int64_t)blockIdx.x * 64 + wv * 16 + vi;
-  const bool live = v < a.m;
-  float* zrow = a.Zq + (live ? v : 0) * a.ldq + 3;
+  const int64_t v0 = (int64_t)blockIdx.x * 64;
+  const int64_t nvec = (a.m - v0 < 64) ? a.m - v0 : 64;
+  SbrZWin zw;
+  zw.rs = __builtin_amdgcn_make_buffer_rsrc(a.Zq + v0 * a.ldq, 0, (unsigned)(nvec * a.ldq * 4), 0x00020000);
+  zw.lane_base = (int64_t)(wv * 16 + vi) * a.ldq + 3;
+  zw.n = a.n;
   const int nsb = (a.nblk + QJ - 1) / QJ;
   auto index_of = [&](int b, int t) -> int64_t {  // groups that do not exist read image 0 (never used)
     return (b >= 0 && t < sbr_tasks_of((int64_t)b * QW, a.n)) ? sbr_q2_img_index(b, t, a.n) : 0;
@@ -2860,7 +2894,7 @@ __global__ __launch_bounds__(256, 2) void sbr_q2_apply16e(SbrQ2Args a, const flo
   // the first AH groups of the sequence: blocks nblk - 1, nblk - 2 at task 0 (QJ > AH)
 #pragma unroll
   for (int i = 0; i < AH; ++i) sbr_q2_dma(img, index_of(a.nblk - 1 - i, 0), lds + i * Q_IMG, tid);
-  if (AH == 2) asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  sbr_vmcnt<DM>();
   __syncthreads();
   int cur = 0;
   f32x4 z[QNT];
@@ -2868,17 +2902,17 @@ __global__ __launch_bounds__(256, 2) void sbr_q2_apply16e(SbrQ2Args a, const flo
     const int bh = a.nblk - 1 - sb * QJ, blow = bh - QJ + 1;
     const int Kmax = sbr_tasks_of((int64_t)(blow > 0 ? blow : 0) * QW, a.n);
     const int64_t base0 = (int64_t)blow * QW + 1;
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the stores of the previous pass have left before rows are re-read
+    sbr_vmcnt<0>();  // the stores of the previous pass have left before rows are re-read
 #pragma unroll
-    for (int i = 0; i < QNT; ++i) z[i] = sbr_q2_ldz(zrow, base0 + 16 * i + 4 * g, a.n, live) * Q_ZSCALE;
+    for (int i = 0; i < QNT; ++i) z[i] = sbr_zld(zw, base0 + 16 * i + 4 * g) * Q_ZSCALE;
+    f32x4 zout[4];       // the 64 rows that left the window at the end of the previous task: stored inside the next task's first
+    bool pend = false;   // group, BEHIND its DMA instructions (memory instructions complete in issue order: a wait for the image
+                         // would otherwise also wait one HBM round trip for stores and loads nobody needs yet -- 0.5 us per group,
+                         // 111 of the kernel's 295 ms, profiles/r04_q2_variants.log)
     for (int t = 0; t < Kmax; ++t) {
       const int64_t base = base0 + (int64_t)t * SB;
       f32x4 pz[4];
       const bool more = t + 1 < Kmax;
-      if (more) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) pz[i] = sbr_q2_ldz(zrow, base + 16 * (QNT + i) + 4 * g, a.n, live) * Q_ZSCALE;
-      }
 #pragma unroll
       for (int j = 0; j < QJ; ++j) {
         int nb, nt;  // the group AH steps after this one in the sequence (j ascending inside a task, then the next task, then the next pass)
@@ -2893,32 +2927,53 @@ __global__ __launch_bounds__(256, 2) void sbr_q2_apply16e(SbrQ2Args a, const flo
           nb = bh - QJ - (jj - QJ);
           nt = 0;
         }
-        // its image goes to the buffer the PREVIOUS group was read from (all waves have passed the barrier behind it); these are the
-        // last memory instructions of the group, so `vmcnt(7)` below leaves exactly them in flight
+        // its image goes to the buffer the PREVIOUS group was read from (all waves have passed the barrier behind it)
         asm volatile("" ::: "memory");
         int nxt = cur + AH;
         if (nxt >= NBUF) nxt -= NBUF;
         if (!(dbg & 2)) sbr_q2_dma(img, index_of(nb, nt), lds + nxt * Q_IMG, tid);  // dbg: timing experiments only (WRONG results)
         asm volatile("" ::: "memory");
+        if (j == 0) {  // the window traffic of this task, behind the DMA: 4 stores (rows that left), 4 loads (rows that will enter)
+          if (pend) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) sbr_zst(zw, base - SB + 16 * i + 4 * g, zout[i]);
+          }
+          if (more) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) pz[i] = sbr_zld(zw, base + 16 * (QNT + i) + 4 * g);
+          }
+          asm volatile("" ::: "memory");
+        }
         const int b = bh - j;
         if (b >= 0 && t < sbr_tasks_of((int64_t)b * QW, a.n) && !(dbg & 1)) {
           if (K32) sbr_q2_group16f(z + 2 * (QJ - 1 - j), lds + cur * Q_IMG, vi, g);
           else sbr_q2_group16e(z + 2 * (QJ - 1 - j), lds + cur * Q_IMG, vi, g);
         }
-        if (AH == 2) asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        // the image of the next group must have landed (AH == 1), or the one after it may still be in flight (AH == 2); the window
+        // traffic issued in this group (j == 0) may stay in flight as well: it is waited for one group later (j == 1: everything)
+        if (j == 0) {
+          const int nz = (pend ? 4 : 0) + (more ? 4 : 0);
+          if (nz == 8) sbr_vmcnt<DM + 8>();
+          else if (nz == 4) sbr_vmcnt<DM + 4>();
+          else sbr_vmcnt<DM>();
+        } else {
+          sbr_vmcnt<DM>();
+        }
         __syncthreads();
         cur = (cur + 1 == NBUF) ? 0 : cur + 1;
       }
-#pragma unroll
-      for (int i = 0; i < 4; ++i) sbr_q2_stz(zrow, base + 16 * i + 4 * g, a.n, live, z[i] * (1.f / Q_ZSCALE));
       if (more) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) zout[i] = z[i] * (1.f / Q_ZSCALE);
+        pend = true;
 #pragma unroll
         for (int i = 0; i + 4 < QNT; ++i) z[i] = z[i + 4];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) z[QNT - 4 + i] = pz[i];
+        for (int i = 0; i < 4; ++i) z[QNT - 4 + i] = pz[i] * Q_ZSCALE;
       } else {
 #pragma unroll
-        for (int i = 4; i < QNT; ++i) sbr_q2_stz(zrow, base + 16 * i + 4 * g, a.n, live, z[i] * (1.f / Q_ZSCALE));
+        for (int i = 0; i < QNT; ++i) sbr_zst(zw, base + 16 * i + 4 * g, z[i] * (1.f / Q_ZSCALE));
+        pend = false;
       }
     }
   }
@@ -2930,6 +2985,9 @@ __global__ void sbr_q2_shift(const float* __restrict__ in, int64_t ldi, int64_t 
   const int64_t r = blockIdx.y;
   const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (c < n) out[r * ldo + offo + c] = in[r * ldi + offi + c];
+  // into the shifted layout (offo = 3): the three floats in front of row 0 and the padding behind row n - 1 are read as window rows
+  if (offo > 0 && c < offo) out[r * ldo + c] = 0.f;
+  if (offo > 0 && c < ldo - offo - n) out[r * ldo + offo + n + c] = 0.f;
 }
 
 // 10 (default): pre-built group images moved by LDS-DMA one group ahead, K = 32 matrix instructions; 11: two groups ahead; 8 / 9: the
