@@ -1111,13 +1111,26 @@ def sclens(inp_df, device_="gpu", th=60, p_step=0.001, n_perturb=20, centering="
             # (0.5 s at n = 3 * 10^4) that costs nothing next to a decomposition and 0.5 s on its own
             # (profiles/r03_first_phase_cfg4.log).
             w_null = w_bin = workers[1]
-            if os.environ.get("SCLENS_FIRST_PHASE") == "chain":
+            fp_mode = os.environ.get("SCLENS_FIRST_PHASE", "")
+            if fp_mode in ("chain", "chain2"):
                 # (prepared at the end of round 3, not yet timed on hardware, hence opt-in) the binarised decomposition does not
                 # depend on the threshold: worker 1 runs null -> binarised back to back while this thread runs the data matrix,
                 # waits for the null spectrum only, and takes the signal vectors beside the rest of the binarised decomposition
                 null_done: Future = Future()
 
                 def null_then_binary():
+                    if fp_mode == "chain2":
+                        # the binarised decomposition FIRST: it needs nothing from the host, while the null matrix is still being
+                        # drawn there (R2, ~0.6 s at 100 000 x 30 000) when the call starts; the null spectrum follows on the same
+                        # worker and releases the main thread (threshold -> signal vectors)
+                        try:
+                            out = w_bin.binary_basis()
+                            null_done.set_result(w_null.null_spectrum_pattern(null_future.result()))
+                        except BaseException as e:
+                            if not null_done.done():
+                                null_done.set_exception(e)
+                            raise
+                        return out
                     try:
                         null_done.set_result(w_null.null_spectrum_pattern(null_future.result()))
                     except BaseException as e:  # the waiting thread must see it; the binarised decomposition is not started

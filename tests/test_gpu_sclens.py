@@ -262,13 +262,14 @@ def test_two_streams_give_identical_results(ctx):
         assert np.array_equal(a["robustness_scores"]["b_"], c["robustness_scores"]["b_"])
 
 
-def test_chained_first_phase_gives_identical_results(ctx, monkeypatch):
-    """SCLENS_FIRST_PHASE=chain (two streams: worker 1 runs null -> binarised back to back, the main session data -> signal
-    vectors) only moves work between streams: every output has the same bits as the default schedule"""
+@pytest.mark.parametrize("mode", ["chain", "chain2"])
+def test_chained_first_phase_gives_identical_results(ctx, monkeypatch, mode):
+    """SCLENS_FIRST_PHASE=chain / chain2 (two streams: worker 1 runs null -> binarised, or binarised -> null, back to back; the main
+    session data -> signal vectors) only moves work between streams: every output has the same bits as the default schedule"""
     X = synth_counts(300, 500, seed=1, C=5, marker_frac=0.2, marker_sd=1.5)
     d = api.make_draws_native(X, seed=13)
     a = api.sclens(X, draws=d, n_perturb=5, ctx=ctx, streams=2)
-    monkeypatch.setenv("SCLENS_FIRST_PHASE", "chain")
+    monkeypatch.setenv("SCLENS_FIRST_PHASE", mode)
     b = api.sclens(X, draws=d, n_perturb=5, ctx=ctx, streams=2)
     assert a["p_"] == b["p_"] and a["n_search"] == b["n_search"] and np.array_equal(a["L"], b["L"])
     for (p1, t1), (p2, t2) in zip(a["search_trace"], b["search_trace"]):

@@ -61,10 +61,11 @@ def test_capped_search_median_centering_and_five_members(monkeypatch):
     _all_closed()
 
 
-def test_chained_first_phase_schedule(monkeypatch):
-    """SCLENS_FIRST_PHASE=chain: worker 1 runs null -> binarised back to back on one thread, the main session data -> signal
-    vectors; same result as the oracle, nothing left open"""
-    monkeypatch.setenv("SCLENS_FIRST_PHASE", "chain")
+@pytest.mark.parametrize("mode", ["chain", "chain2"])
+def test_chained_first_phase_schedule(monkeypatch, mode):
+    """SCLENS_FIRST_PHASE=chain / chain2: worker 1 runs null -> binarised (chain) or binarised -> null (chain2) back to back on one
+    thread, the main session data -> signal vectors; same result as the oracle, nothing left open"""
+    monkeypatch.setenv("SCLENS_FIRST_PHASE", mode)
     ref, res = _pair(monkeypatch, 150, 220, 2)
     _same(ref, res)
     _all_closed()
@@ -73,13 +74,13 @@ def test_chained_first_phase_schedule(monkeypatch):
     assert first["null_spectrum"] == first["binary_basis"]            # same worker session, same thread
     assert first["data_spectrum"][1] == first["signal_vectors"][1] != first["null_spectrum"][1]
     order = [what for _, _, what in calls]
-    assert order.index("null_spectrum") < order.index("binary_basis")
+    assert (order.index("null_spectrum") < order.index("binary_basis")) == (mode == "chain")
 
 
 def test_a_failure_in_a_worker_closes_everything(monkeypatch):
     X = synth_counts(150, 220, seed=3, C=4, marker_frac=0.25, marker_sd=1.5)
     d = api.make_draws(X, seed=11, p_th_trials=200)
-    for mode in ("", "chain"):
+    for mode in ("", "chain", "chain2"):
         monkeypatch.setenv("SCLENS_FIRST_PHASE", mode)
         main = F.install(monkeypatch)
 
