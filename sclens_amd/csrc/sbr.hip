@@ -2874,13 +2874,23 @@ __device__ __forceinline__ void sbr_vmcnt() {  // at most N vector-memory instru
   if (N == 15) asm volatile("s_waitcnt vmcnt(15)" ::: "memory");
 }
 
-template <int QJ, int QNT, int NBUF, bool K32>
-__global__ __launch_bounds__(256, 2) void sbr_q2_apply16e(SbrQ2Args a, const float* __restrict__ img, int dbg) {
+// LW (variant 12): four LOADER waves beside the four compute waves (512 threads, one workgroup per CU). A wave executes its
+// instructions in order, so in the one-role kernel a group costs DMA issue (7 pieces of 60-180 cycles each) + products + barrier --
+// measured 274 ms with the products off, 203 ms with the DMA off, 280 ms together (profiles/r04_q2_variants.log): the two do not
+// overlap. With a loader wave on every SIMD the DMA instructions issue beside the other wave's matrix instructions (different issue
+// ports), the compute waves carry no DMA and no counted waits, and the group barrier doubles as the "image has landed" signal (a
+// loader arrives at it only behind its own `vmcnt`).
+template <int QJ, int QNT, int NBUF, bool K32, bool LW>
+__global__ __launch_bounds__(LW ? 512 : 256, LW ? 1 : 2) void sbr_q2_apply16e(SbrQ2Args a, const float* __restrict__ img, int dbg) {
   static_assert(NBUF == 2 || NBUF == 3, "one or two groups ahead");
   constexpr int AH = NBUF - 1, DM = (AH == 2) ? 7 : 0;  // DMA instructions that may stay in flight past the end of a group
   extern __shared__ __attribute__((aligned(16))) float q2lds[];  // NBUF images
   float* lds = q2lds;
-  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, vi = lane & 15, g = lane >> 4;
+  const int tid = threadIdx.x, lane = tid & 63, vi = lane & 15, g = lane >> 4;
+  const bool loader = LW && (tid >> 8) != 0;       // waves 4 .. 7
+  const int wv = (tid >> 6) & 3;                   // index among the waves of its role
+  const int dtid = tid & 255;                      // the lane's share of an image's DMA
+  const bool does_dma = LW ? loader : true, does_math = !loader;
   const int64_t v0 = (int64_t)blockIdx.x * 64;
   const int64_t nvec = (a.m - v0 < 64) ? a.m - v0 : 64;
   SbrZWin zw;
@@ -2893,7 +2903,8 @@ __global__ __launch_bounds__(256, 2) void sbr_q2_apply16e(SbrQ2Args a, const flo
   };
   // the first AH groups of the sequence: blocks nblk - 1, nblk - 2 at task 0 (QJ > AH)
 #pragma unroll
-  for (int i = 0; i < AH; ++i) sbr_q2_dma(img, index_of(a.nblk - 1 - i, 0), lds + i * Q_IMG, tid);
+  for (int i = 0; i < AH; ++i)
+    if (does_dma) sbr_q2_dma(img, index_of(a.nblk - 1 - i, 0), lds + i * Q_IMG, dtid);
   sbr_vmcnt<DM>();
   __syncthreads();
   int cur = 0;
@@ -2902,9 +2913,11 @@ __global__ __launch_bounds__(256, 2) void sbr_q2_apply16e(SbrQ2Args a, const flo
     const int bh = a.nblk - 1 - sb * QJ, blow = bh - QJ + 1;
     const int Kmax = sbr_tasks_of((int64_t)(blow > 0 ? blow : 0) * QW, a.n);
     const int64_t base0 = (int64_t)blow * QW + 1;
-    sbr_vmcnt<0>();  // the stores of the previous pass have left before rows are re-read
+    if (does_math) {
+      sbr_vmcnt<0>();  // the stores of the previous pass have left before rows are re-read
 #pragma unroll
-    for (int i = 0; i < QNT; ++i) z[i] = sbr_zld(zw, base0 + 16 * i + 4 * g) * Q_ZSCALE;
+      for (int i = 0; i < QNT; ++i) z[i] = sbr_zld(zw, base0 + 16 * i + 4 * g) * Q_ZSCALE;
+    }
     f32x4 zout[4];       // the 64 rows that left the window at the end of the previous task: stored inside the next task's first
     bool pend = false;   // group, BEHIND its DMA instructions (memory instructions complete in issue order: a wait for the image
                          // would otherwise also wait one HBM round trip for stores and loads nobody needs yet -- 0.5 us per group,
@@ -2931,9 +2944,9 @@ __global__ __launch_bounds__(256, 2) void sbr_q2_apply16e(SbrQ2Args a, const flo
         asm volatile("" ::: "memory");
         int nxt = cur + AH;
         if (nxt >= NBUF) nxt -= NBUF;
-        if (!(dbg & 2)) sbr_q2_dma(img, index_of(nb, nt), lds + nxt * Q_IMG, tid);  // dbg: timing experiments only (WRONG results)
+        if (does_dma && !(dbg & 2)) sbr_q2_dma(img, index_of(nb, nt), lds + nxt * Q_IMG, dtid);  // dbg: timing experiments only (WRONG results)
         asm volatile("" ::: "memory");
-        if (j == 0) {  // the window traffic of this task, behind the DMA: 4 stores (rows that left), 4 loads (rows that will enter)
+        if (j == 0 && does_math) {  // the window traffic of this task, behind the DMA: 4 stores (rows that left), 4 loads (rows that will enter)
           if (pend) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) sbr_zst(zw, base - SB + 16 * i + 4 * g, zout[i]);
@@ -2945,13 +2958,15 @@ __global__ __launch_bounds__(256, 2) void sbr_q2_apply16e(SbrQ2Args a, const flo
           asm volatile("" ::: "memory");
         }
         const int b = bh - j;
-        if (b >= 0 && t < sbr_tasks_of((int64_t)b * QW, a.n) && !(dbg & 1)) {
+        if (does_math && b >= 0 && t < sbr_tasks_of((int64_t)b * QW, a.n) && !(dbg & 1)) {
           if (K32) sbr_q2_group16f(z + 2 * (QJ - 1 - j), lds + cur * Q_IMG, vi, g);
           else sbr_q2_group16e(z + 2 * (QJ - 1 - j), lds + cur * Q_IMG, vi, g);
         }
         // the image of the next group must have landed (AH == 1), or the one after it may still be in flight (AH == 2); the window
         // traffic issued in this group (j == 0) may stay in flight as well: it is waited for one group later (j == 1: everything)
-        if (j == 0) {
+        if (LW) {  // loaders: their DMA only; compute waves: nothing to wait for (the compiler waits where a loaded row is used)
+          if (loader) sbr_vmcnt<DM>();
+        } else if (j == 0) {
           const int nz = (pend ? 4 : 0) + (more ? 4 : 0);
           if (nz == 8) sbr_vmcnt<DM + 8>();
           else if (nz == 4) sbr_vmcnt<DM + 4>();
@@ -2962,6 +2977,7 @@ __global__ __launch_bounds__(256, 2) void sbr_q2_apply16e(SbrQ2Args a, const flo
         __syncthreads();
         cur = (cur + 1 == NBUF) ? 0 : cur + 1;
       }
+      if (!does_math) continue;
       if (more) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) zout[i] = z[i] * (1.f / Q_ZSCALE);
@@ -2998,7 +3014,7 @@ __global__ void sbr_q2_shift(const float* __restrict__ in, int64_t ldi, int64_t 
 static int sbr_q2_variant(int64_t n) {
   const char* eq2 = getenv("SCLENS_HIP_Q2_VARIANT");
   int v = eq2 ? atoi(eq2) : 10;
-  if (v >= 8 && v <= 11 && n % SB != 0) v = 7;  // the image index assumes an order that is a multiple of 64 (the two-stage solver pads)
+  if (v >= 8 && v <= 13 && n % SB != 0) v = 7;  // the image index assumes an order that is a multiple of 64 (the two-stage solver pads)
   return v;
 }
 
@@ -3010,7 +3026,7 @@ static int sbr_q2_launch_build_t(Ctx* ctx, int64_t n, hipStream_t st) {
   if (!V2 || !TAU2 || nsweep <= 0) return ctx->fail(SCLENS_ERR_STATE, "sbr_q2_build_t: no reflectors of a preceding sb2st_f32 on this context");
   const int nblk = (int)((nsweep + QW - 1) / QW), nk = (int)((n - 1 + SB - 1) / SB);
   const int variant = sbr_q2_variant(n);
-  if (variant >= 8 && variant <= 11) {
+  if (variant >= 8 && variant <= 13) {
     SCL_WS(ctx, img, float, "sbr.Q2img", (sbr_q2_img_count(n) + 1) * Q_IMG);
     hipLaunchKernelGGL(sbr_q2_build_img, dim3((unsigned)nk, (unsigned)nblk), dim3(256), 0, st, V2, ldv2, TAU2, ldt, n, img, variant >= 10 ? 1 : 0);
   } else {
@@ -3074,20 +3090,22 @@ int sbr_apply_q2(Ctx* ctx, int64_t n, float* Zt, int64_t m, int64_t ldz) {
   // 8 (default since round 4): pre-built images + LDS-DMA two groups ahead (three LDS buffers, one workgroup per CU); 9: one group
   // ahead (two buffers, two workgroups per CU)
   const dim3 q2grid((unsigned)((m + 63) / 64));
-  if (q2_variant >= 8 && q2_variant <= 11) {
+  if (q2_variant >= 8 && q2_variant <= 13) {
     // 8 / 9: K = 16 matrix instructions, DMA two / one group(s) ahead (three / two LDS buffers); 10 / 11: the K = 32 form, one / two ahead
-    const bool three = (q2_variant == 8 || q2_variant == 11);
+    const bool three = (q2_variant == 8 || q2_variant == 11 || q2_variant == 12);  // 12 / 13: loader waves, two / one group(s) ahead
     const int lds_bytes = (three ? 3 : 2) * Q_IMG * (int)sizeof(float);
     const int q2dbg = getenv("SCLENS_HIP_Q2_DBG") ? atoi(getenv("SCLENS_HIP_Q2_DBG")) : 0;  // 1: no products, 2: no DMA (timing experiments)
-#define SBR_Q2E_LAUNCH(NBUF, K32)                                                                                              \
+#define SBR_Q2E_LAUNCH(NBUF, K32, LW)                                                                                          \
   do {                                                                                                                         \
-    SCL_TRY(ensure_dyn_lds(ctx, reinterpret_cast<const void*>(sbr_q2_apply16e<4, 12, NBUF, K32>), lds_bytes));                \
-    hipLaunchKernelGGL((sbr_q2_apply16e<4, 12, NBUF, K32>), q2grid, dim3(256), lds_bytes, ctx->stream, qa, q2img, q2dbg);     \
+    SCL_TRY(ensure_dyn_lds(ctx, reinterpret_cast<const void*>(sbr_q2_apply16e<4, 12, NBUF, K32, LW>), lds_bytes));            \
+    hipLaunchKernelGGL((sbr_q2_apply16e<4, 12, NBUF, K32, LW>), q2grid, dim3(LW ? 512 : 256), lds_bytes, ctx->stream, qa, q2img, q2dbg); \
   } while (0)
-    if (q2_variant == 8) SBR_Q2E_LAUNCH(3, false);
-    else if (q2_variant == 9) SBR_Q2E_LAUNCH(2, false);
-    else if (q2_variant == 10) SBR_Q2E_LAUNCH(2, true);
-    else SBR_Q2E_LAUNCH(3, true);
+    if (q2_variant == 8) SBR_Q2E_LAUNCH(3, false, false);
+    else if (q2_variant == 9) SBR_Q2E_LAUNCH(2, false, false);
+    else if (q2_variant == 10) SBR_Q2E_LAUNCH(2, true, false);
+    else if (q2_variant == 11) SBR_Q2E_LAUNCH(3, true, false);
+    else if (q2_variant == 12) SBR_Q2E_LAUNCH(3, true, true);
+    else SBR_Q2E_LAUNCH(2, true, true);
 #undef SBR_Q2E_LAUNCH
   } else if (q2_variant == 0)
     hipLaunchKernelGGL((sbr_q2_apply16<4, 12, false>), q2grid, dim3(256), 0, ctx->stream, qa);
