@@ -253,3 +253,51 @@ def test_atlas_slab_of_one_rank_fits_and_runs(tmp_path):
         assert t[key] <= b, (key, t[key], b)
     assert log["projected_rank_wall_s"] <= 91.0  # the r03 projection (45.5 s) x 2
     assert log["stubbed_reduce_to_root"]["calls"] == 32 and log["candidates_local"] > 3e8
+
+
+@pytest.mark.parametrize("where", ["search", "ensemble"])
+def test_a_failing_rank_inside_a_round_stops_all_ranks(ctx, monkeypatch, where):
+    """ADVICE r3 on hardware: a round of a row-sharded session is a sequence of reduces; a rank that cannot enter it (here: a sample
+    size beyond the candidate list, on rank 1 only) used to return while its peers waited in the next reduce for ever. The round
+    now starts with an agreement inside the library (round_entry_agreement): the failing rank gets its own error, the others
+    SCLENS_ERR_STATE naming the cause, and the host's status agreement (Shard.all_ok) ends the call on every rank. Nobody is
+    released by the test (no barrier abort); every thread must come back on its own."""
+    N, M, world, bad_rank = 2600, 700, 2, 1
+    X = api._csc_f32(synth_counts(N, M, seed=9, C=4, marker_frac=0.2, marker_sd=1.4))
+    d = api.make_draws_native(X, seed=41, device_candidates=True)
+    group = ThreadShard.Group(world)
+    Xr = X.tocsr()
+    tid_rank = {}
+    name = "search_round_seeded" if where == "search" else "perturb_round_seeded"
+    orig = getattr(api.Session, name)
+
+    def sabotage(self, *args):
+        args = list(args)
+        if tid_rank.get(threading.get_ident()) == bad_rank:
+            k = 1 if where == "search" else 2  # the list of sample sizes
+            args[k] = [int(v) + (1 << 40) for v in args[k]]
+        return orig(self, *args)
+
+    monkeypatch.setattr(api.Session, name, sabotage)
+    err = [None] * world
+
+    def work(r):
+        tid_rank[threading.get_ident()] = r
+        c = Context(ctx.device)
+        try:
+            a, b = atlas.row_block(r, world, N)
+            atlas.sclens_row_sharded(Xr[a:b].tocsc(), a, N, d, ThreadShard(group, r), ctx=c, n_perturb=4, max_search_iters=6)
+        except BaseException as e:  # noqa: BLE001
+            err[r] = e
+        finally:
+            c.close()
+
+    th = [threading.Thread(target=work, args=(r,), daemon=True) for r in range(world)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join(timeout=300)
+    assert not any(t.is_alive() for t in th), "a rank is still waiting in a collective for a peer that has left the round"
+    assert all(e is not None for e in err), err
+    assert "bad" in str(err[bad_rank]).lower() or "sample size" in str(err[bad_rank])
+    assert "could not enter the round" in str(err[0]) or "failed" in str(err[0])
