@@ -7,7 +7,8 @@ device-side candidate draw and sampler give the same candidates and the same sam
 chunks, so that 100 000 x 30 000 fits the host (the dense float64 matrix would be 24 GB; here: two 7.2 GB Gram / vector
 matrices at a time); `--selftest` pins the chunked form against the oracle's own functions at a small size.
 
-Usage: check_search_step_f64.py cfg seed it [it ...] [--out file.json] [--threads n] [--device-json bench_line.json]
+Usage: check_search_step_f64.py cfg seed it [it ...] [--out file.json] [--threads n] [--device-null-rule]
+  (--threads: the bundled OpenBLAS crashes in dsyrk / dsyr2k at order 30 000 with 2 .. 7 threads on the build box; 1 or all 8 work)
   cfg: cfg4 | cfg3 | tiny_gt ; seed: the draw seed of the sclens() call (bench.py: seed_base + step); it: 0-based search iterations
 """
 import json
@@ -81,6 +82,10 @@ def main():
     ap.add_argument("--out")
     ap.add_argument("--threads", type=int)
     ap.add_argument("--selftest", action="store_true")
+    ap.add_argument("--device-null-rule", action="store_true",
+                    help="count an eigenvalue as positive iff it exceeds 8 eps32 sqrt(n) lambda_max (the device's rounding floor, DESIGN.md "
+                         "section 2 position 6) instead of the oracle's NULL_DROP = 1e-9 lambda_max: at 100 000 x 30 000 the binarised "
+                         "matrix has ONE eigenvalue of 1.7e-9 lambda_max, which the two rules treat differently")
     a = ap.parse_args()
     if a.selftest:
         return selftest()
@@ -91,7 +96,9 @@ def main():
         threadpool_limits(limits=a.threads)
     N, M, idx = CFG[cfg]
     assert N > M, "cells > genes configurations only"
-    out = {"config": cfg, "seed": seed, "iterations": its, "host_cores": os.cpu_count(), "results": []}
+    out = {"config": cfg, "seed": seed, "iterations": its, "host_cores": os.cpu_count(), "results": [],
+           "null_rule": "device: 8 eps32 sqrt(n) lambda_max" if a.device_null_rule else "oracle: NULL_DROP = 1e-9 lambda_max"}
+    floor = (lambda w: 8.0 * 5.96e-8 * np.sqrt(len(w)) * w.max()) if a.device_null_rule else (lambda w: O.NULL_DROP * w.max())
     T0 = time.perf_counter()
     log = lambda m: print(f"[{time.perf_counter() - T0:7.0f} s] {m}", flush=True)
     selftest()
@@ -108,7 +115,7 @@ def main():
     log("Gram of the binarised matrix done; dsyevr (all vectors) ...")
     L, V = sla.eigh(G, driver="evr", overwrite_a=True, check_finite=False)
     del G
-    pos_ = L > O.NULL_DROP * L.max()
+    pos_ = L > floor(L)
     Vr2 = V[:, pos_]
     del V
     r = int(pos_.sum())
@@ -129,7 +136,7 @@ def main():
         G = scaled_gram_f64(P, log=log)
         log("  dsyevr (all values, lower-half vectors) ...")
         w = sla.eigh(G, driver="evr", eigvals_only=True, check_finite=False)
-        npos = int((w > O.NULL_DROP * w.max()).sum())
+        npos = int((w > floor(w)).sum())
         lo = M - npos  # ascending index of the smallest positive eigenvalue
         # nV_2[:, end-n_2:end] of the DESCENDING order = the n_2 + 1 smallest positive eigenvalues (Appendix A17)
         w2, V2 = sla.eigh(G, driver="evr", subset_by_index=[lo, lo + n_2], overwrite_a=True, check_finite=False)
