@@ -93,6 +93,7 @@ struct SbrSmall {
   float* T;      // [SB][SB]
   float* Rh;     // [SB][SB]
   int* flag;
+  unsigned long long* prof;  // SCLENS_HIP_PANEL_PROF=1: [10] shader clocks per phase of sbr_panel_small + the call count (else nullptr)
 };
 
 // 64 x 64 fp64 matrices in LDS, one workgroup of 256 threads. Thread (ti, tj) = (tid >> 4, tid & 15) owns the entries
@@ -163,6 +164,13 @@ __global__ __launch_bounds__(256) void sbr_panel_small(const double* __restrict_
   double* unit_diag = pivs + SB;                             // [SB] ones
   __shared__ int bad;
   const int tid = threadIdx.x, ti = tid >> 4, tj = tid & 15;
+  unsigned long long pt = o.prof ? __builtin_amdgcn_s_memtime() : 0ull;
+#define SBR_PP(i)                                                             \
+  if (o.prof && tid == 0) {                                                   \
+    const unsigned long long now_ = __builtin_amdgcn_s_memtime();             \
+    atomicAdd(o.prof + (i), now_ - pt);                                       \
+    pt = now_;                                                                \
+  }
   if (tid == 0) bad = 0;
   for (int idx = tid; idx < SB * SB; idx += 256) {
     M0[idx] = G[idx];
@@ -170,6 +178,7 @@ __global__ __launch_bounds__(256) void sbr_panel_small(const double* __restrict_
     F0[i * SB + j] = Ptop[(int64_t)j * ldp + i];
   }
   __syncthreads();
+  SBR_PP(0)  // loads
   // ---- Cholesky G = R'R, right-looking on the full symmetric matrix: step j reads row j, updates the rows below it
   for (int j = 0; j < SB; ++j) {
     double d = M0[j * SB + j];
@@ -200,9 +209,11 @@ __global__ __launch_bounds__(256) void sbr_panel_small(const double* __restrict_
     }
     __syncthreads();
   }
+  SBR_PP(1)  // Cholesky
   // ---- R^-1 (wave 0)
   if (tid < SB) trinv_cols(M2, [&](int j, int k) { return M1[j * SB + k]; }, invd);
   __syncthreads();
+  SBR_PP(2)  // R^-1
   // ---- Q_top = P_top R^-1
   {
     double acc[4][4];
@@ -213,6 +224,7 @@ __global__ __launch_bounds__(256) void sbr_panel_small(const double* __restrict_
       for (int v = 0; v < 4; ++v) M3[(ti + 16 * u) * SB + tj + 16 * v] = acc[u][v];
   }
   __syncthreads();
+  SBR_PP(3)  // Q_top = P_top R^-1
   // ---- sign-modified LU of (Q D - E), right-looking: D_j = -sgn(q_jj), pivot = D_j q_jj - 1 = -|q_jj| - 1,
   //      L[i][j] = D_j q_ij / pivot (to M0), rows of U' stay in the upper part of M3
   for (int j = 0; j < SB; ++j) {
@@ -249,6 +261,7 @@ __global__ __launch_bounds__(256) void sbr_panel_small(const double* __restrict_
     }
     __syncthreads();
   }
+  SBR_PP(4)  // LU
   // ---- outputs that need R and the raw LU: Rh = D R, V1 (unit lower); then U' (with the column signs) replaces R in M1
   for (int idx = tid; idx < SB * SB; idx += 256) {
     const int r = idx >> 6, c = idx & 63;
@@ -265,9 +278,11 @@ __global__ __launch_bounds__(256) void sbr_panel_small(const double* __restrict_
     unit_diag[tid] = 1.0;
   }
   __syncthreads();
+  SBR_PP(5)  // Rh, V1, U'
   // ---- T = -U' (V1')^-1: V1' is unit upper triangular with element (j, k) = L[k][j]
   if (tid < SB) trinv_cols(M3, [&](int j, int k) { return M0[k * SB + j]; }, unit_diag);
   __syncthreads();
+  SBR_PP(6)  // (V1')^-1
   {
     double acc[4][4];
     mm64_acc<double, true>(acc, M1, M3);
@@ -280,10 +295,12 @@ __global__ __launch_bounds__(256) void sbr_panel_small(const double* __restrict_
       }
   }
   __syncthreads();
+  SBR_PP(7)  // T
   // ---- M = (R^-1 D) U'^-1
   if (tid < SB) trinv_cols(M3, [&](int j, int k) { return M1[j * SB + k]; }, invd);
   for (int idx = tid; idx < SB * SB; idx += 256) M2[idx] *= dsign[idx & 63];  // scale the columns of R^-1 (M2 is not read by wave 0 here)
   __syncthreads();
+  SBR_PP(8)  // U'^-1
   {
     double acc[4][4];
     mm64_acc<double, true>(acc, M2, M3);
@@ -292,6 +309,9 @@ __global__ __launch_bounds__(256) void sbr_panel_small(const double* __restrict_
 #pragma unroll
       for (int v = 0; v < 4; ++v) o.M[(ti + 16 * u) * SB + tj + 16 * v] = acc[u][v];
   }
+  SBR_PP(9)  // M
+  if (o.prof && tid == 0) atomicAdd(o.prof + 10, 1ull);
+#undef SBR_PP
   if (tid == 0 && bad) atomicExch(o.flag, 1);
 }
 
@@ -696,6 +716,15 @@ int sy2sb_f32(Ctx* ctx, float* A, int64_t n, int64_t lda, float* Tall, int* brea
   // small products): pays from U ~ 0.7 ms, i.e. from a trailing matrix of order ~19 000 (SCLENS_HIP_SY2SB_DELAY_MIN)
   int64_t delay_min = 18432;
   if (const char* ev = getenv("SCLENS_HIP_SY2SB_DELAY_MIN")) delay_min = std::max<int64_t>(4 * SB + 1, atoll(ev));
+  unsigned long long* pprof = nullptr;  // SCLENS_HIP_PANEL_PROF=1: per-phase shader clocks of sbr_panel_small on stderr
+  if (const char* epp = getenv("SCLENS_HIP_PANEL_PROF")) {
+    if (atoi(epp) > 0) {
+      pprof = static_cast<unsigned long long*>(ctx->workspace("sbr.pprof", 16 * sizeof(unsigned long long)));
+      if (!pprof) return SCLENS_ERR_OOM;
+      SCL_HIP(ctx, hipMemsetAsync(pprof, 0, 16 * sizeof(unsigned long long), st));
+      SCL_HIP(ctx, hipStreamSynchronize(st));
+    }
+  }
   bool pending = false;  // the previous panel's bulk update is outstanding (its operands sit in slot 0)
   auto factor_panel = [&](int64_t p, hipStream_t s_) -> int {
     const int64_t c0 = p * SB, r0 = c0 + SB, np = n - r0;
@@ -705,7 +734,7 @@ int sy2sb_f32(Ctx* ctx, float* A, int64_t n, int64_t lda, float* Tall, int* brea
     const unsigned rtiles = (unsigned)((np + 4 * SBR_RT - 1) / (4 * SBR_RT));  // workgroups of four 16-position wave tiles
     hipLaunchKernelGGL((sbr_gram64<true>), dim3(nparts), dim3(256), SBR_GRAM_LDS, s_, Pt, lda, (const float*)nullptr, np, part);
     hipLaunchKernelGGL(sbr_sum_parts, dim3(SB * SB / 256), dim3(256), 0, s_, part, nparts, psum);
-    SbrSmall sm{Mat, V1, Tp, V1 + SB * SB, flag};
+    SbrSmall sm{Mat, V1, Tp, V1 + SB * SB, flag, pprof};
     if (np == SB)  // last panel: may contain the zero rows of the padding
       hipLaunchKernelGGL(sbr_panel_house, dim3(1), dim3(64), 0, s_, Pt, lda, sm);
     else
@@ -829,6 +858,18 @@ int sy2sb_f32(Ctx* ctx, float* A, int64_t n, int64_t lda, float* Tall, int* brea
   if (breakdown) {
     SCL_HIP(ctx, hipMemcpyAsync(breakdown, flag, sizeof(int), hipMemcpyDeviceToHost, st));
     SCL_HIP(ctx, hipStreamSynchronize(st));
+  }
+  if (pprof) {
+    unsigned long long h[11];
+    SCL_HIP(ctx, hipStreamSynchronize(st2));
+    SCL_HIP(ctx, hipMemcpy(h, pprof, sizeof(h), hipMemcpyDeviceToHost));
+    static const char* nm[10] = {"loads", "Cholesky (64 steps)", "R^-1 (one wave)", "Q_top = P_top R^-1", "LU (64 steps)", "Rh, V1, U'",
+                                 "(V1')^-1 (one wave)", "T = -U' (V1')^-1", "U'^-1 (one wave)", "M = R^-1 D U'^-1 + stores"};
+    unsigned long long tot = 0;
+    for (int i = 0; i < 10; ++i) tot += h[i];
+    fprintf(stderr, "[sbr_panel_small] n = %lld, %llu calls, %.0f clocks per call\n", (long long)n, h[10], (double)tot / (double)std::max<unsigned long long>(1, h[10]));
+    for (int i = 0; i < 10; ++i)
+      fprintf(stderr, "   %-28s %8.0f clocks (%4.1f %%)\n", nm[i], (double)h[i] / (double)std::max<unsigned long long>(1, h[10]), 100.0 * h[i] / (double)std::max<unsigned long long>(1, tot));
   }
   return SCLENS_OK;
 }
