@@ -3051,7 +3051,11 @@ __global__ void sbr_q2_shift(const float* __restrict__ in, int64_t ldi, int64_t 
 // K = 16 form; 7: split-fp16 products, reflectors staged by every workgroup (round 3); 3: fp32 products (every product of the
 // solver on the fp32 matrix cores); 0, 1, 5, 6: earlier kernels kept for comparison. Measured at n = 30 016 (profiles/r04_q2_*):
 // m = 15 008: 385 (7), 307 (8), 296 (9), 295 (10), 303 (11) ms; all 30 016 vectors: 553 (7), 613 (8: three LDS buffers = one
-// workgroup per CU), 497 (9), 462 (10).
+// workgroup per CU), 497 (9), 462 (10). With the window traffic behind the DMA (counted waits): 280 (10), 284 (11); loader waves
+// (12 / 13): 288 / 285 -- the same bits, no gain: with the products off the kernel still takes 265-274 ms whoever issues the DMA and
+// however many groups are in flight, i.e. the delivery of 28 KB per group and CU (10 B per clock and CU with all CUs pulling the same
+// image) is what bounds it, not its issue slots. Fewer image bytes per vector (128 vectors per fetch, or images without their zero
+// padding) is the lever that is left.
 static int sbr_q2_variant(int64_t n) {
   const char* eq2 = getenv("SCLENS_HIP_Q2_VARIANT");
   int v = eq2 ? atoi(eq2) : 10;
