@@ -143,7 +143,65 @@ __device__ __forceinline__ void trinv_cols(double* X, UEL uel, const double* inv
   for (int j = 0; j < SB; ++j) X[j * SB + c] = x[j];
 }
 
-constexpr int SBR_PANEL_LDS = 4 * SB * SB * (int)sizeof(double) + SB * SB * (int)sizeof(float) + 4 * SB * (int)sizeof(double);
+// The same inverse by ALL 256 threads, blocked 16 x 16 (round 4). The column recurrence above is 2 016 dependent {broadcast LDS read,
+// fp64 fma} pairs on ONE wave: 76 000 clocks per inverse, three inverses per panel = 41 % of sbr_panel_small
+// (profiles/r04_panel_small_phase_clocks.log) while three waves wait at the barrier. Here: (1) the four diagonal blocks by the same
+// recurrence on 16 columns each, one block per wave, in parallel (120 pairs per lane); (2) the blocks at distance d = 1, 2, 3 above
+// the diagonal from X_ij = -X_ii (sum_{i < k <= j} U_ik X_kj): every thread one entry of every block of that distance, the inner
+// sums through a 6 KB scratch, two barriers per distance. Entries below the diagonal are written as zeros (the products that consume
+// X read its first operand in full). Contains barriers: every thread of the workgroup must call it.
+template <class UEL>
+__device__ __forceinline__ void trinv_blocked(double* X, UEL uel, const double* inv_diag, double* S) {
+  constexpr int NB = 16;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  for (int idx = tid; idx < SB * SB; idx += 256) X[idx] = 0.0;
+  __syncthreads();
+  if (lane < NB) {  // diagonal block `wave`, column `lane`
+    const int o = NB * wave, c = lane;
+    double x[NB];
+#pragma unroll
+    for (int j = NB - 1; j >= 0; --j) {
+      double s0 = 0.0, s1 = 0.0;
+#pragma unroll
+      for (int k = j + 1; k < NB; k += 2) {
+        s0 += uel(o + j, o + k) * x[k];
+        if (k + 1 < NB) s1 += uel(o + j, o + k + 1) * x[k + 1];
+      }
+      const double v = (((j == c) ? 1.0 : 0.0) - (s0 + s1)) * inv_diag[o + j];
+      x[j] = (j <= c) ? v : 0.0;
+    }
+#pragma unroll
+    for (int j = 0; j < NB; ++j) X[(o + j) * SB + o + c] = x[j];
+  }
+  __syncthreads();
+  const int r = tid >> 4, c = tid & 15;
+#pragma unroll
+  for (int d = 1; d < SB / NB; ++d) {
+    // inner sums S_b = sum_{kb = br + 1 .. bc} U[br][kb] X[kb][bc] of the blocks (br, bc = br + d), br = 0 .. 3 - d
+#pragma unroll
+    for (int br = 0; br + d < SB / NB; ++br) {
+      const int bc = br + d;
+      double acc = 0.0;
+      for (int kb = br + 1; kb <= bc; ++kb)
+#pragma unroll
+        for (int t = 0; t < NB; ++t) acc += uel(NB * br + r, NB * kb + t) * X[(NB * kb + t) * SB + NB * bc + c];
+      S[br * NB * NB + r * NB + c] = acc;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int br = 0; br + d < SB / NB; ++br) {
+      const int bc = br + d;
+      double acc = 0.0;
+#pragma unroll
+      for (int t = 0; t < NB; ++t) acc += X[(NB * br + r) * SB + NB * br + t] * S[br * NB * NB + t * NB + c];
+      X[(NB * br + r) * SB + NB * bc + c] = -acc;
+    }
+    __syncthreads();
+  }
+}
+
+constexpr int SBR_PANEL_LDS = 4 * SB * SB * (int)sizeof(double) + SB * SB * (int)sizeof(float) + 4 * SB * (int)sizeof(double) +
+                              3 * 16 * 16 * (int)sizeof(double);
 
 // The SB x SB algebra of one panel. Every 64-step elimination below runs with ONE barrier per step: the pivot row / column of
 // a step is only read during the step and the entries it updates are disjoint from it (scaled rows / columns go to a second
@@ -162,6 +220,7 @@ __global__ __launch_bounds__(256) void sbr_panel_small(const double* __restrict_
   double* dsign = invd + SB;                                 // [SB]
   double* pivs = dsign + SB;                                 // [SB]
   double* unit_diag = pivs + SB;                             // [SB] ones
+  double* trS = unit_diag + SB;                              // [3][16][16] scratch of the blocked inverses
   __shared__ int bad;
   const int tid = threadIdx.x, ti = tid >> 4, tj = tid & 15;
   unsigned long long pt = o.prof ? __builtin_amdgcn_s_memtime() : 0ull;
@@ -210,9 +269,8 @@ __global__ __launch_bounds__(256) void sbr_panel_small(const double* __restrict_
     __syncthreads();
   }
   SBR_PP(1)  // Cholesky
-  // ---- R^-1 (wave 0)
-  if (tid < SB) trinv_cols(M2, [&](int j, int k) { return M1[j * SB + k]; }, invd);
-  __syncthreads();
+  // ---- R^-1
+  trinv_blocked(M2, [&](int j, int k) { return M1[j * SB + k]; }, invd, trS);
   SBR_PP(2)  // R^-1
   // ---- Q_top = P_top R^-1
   {
@@ -280,8 +338,7 @@ __global__ __launch_bounds__(256) void sbr_panel_small(const double* __restrict_
   __syncthreads();
   SBR_PP(5)  // Rh, V1, U'
   // ---- T = -U' (V1')^-1: V1' is unit upper triangular with element (j, k) = L[k][j]
-  if (tid < SB) trinv_cols(M3, [&](int j, int k) { return M0[k * SB + j]; }, unit_diag);
-  __syncthreads();
+  trinv_blocked(M3, [&](int j, int k) { return M0[k * SB + j]; }, unit_diag, trS);
   SBR_PP(6)  // (V1')^-1
   {
     double acc[4][4];
@@ -297,8 +354,8 @@ __global__ __launch_bounds__(256) void sbr_panel_small(const double* __restrict_
   __syncthreads();
   SBR_PP(7)  // T
   // ---- M = (R^-1 D) U'^-1
-  if (tid < SB) trinv_cols(M3, [&](int j, int k) { return M1[j * SB + k]; }, invd);
-  for (int idx = tid; idx < SB * SB; idx += 256) M2[idx] *= dsign[idx & 63];  // scale the columns of R^-1 (M2 is not read by wave 0 here)
+  trinv_blocked(M3, [&](int j, int k) { return M1[j * SB + k]; }, invd, trS);
+  for (int idx = tid; idx < SB * SB; idx += 256) M2[idx] *= dsign[idx & 63];  // scale the columns of R^-1
   __syncthreads();
   SBR_PP(8)  // U'^-1
   {
