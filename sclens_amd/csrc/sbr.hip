@@ -201,7 +201,7 @@ __device__ __forceinline__ void trinv_blocked(double* X, UEL uel, const double* 
 }
 
 constexpr int SBR_PANEL_LDS = 4 * SB * SB * (int)sizeof(double) + SB * SB * (int)sizeof(float) + 4 * SB * (int)sizeof(double) +
-                              3 * 16 * 16 * (int)sizeof(double);
+                              3 * 16 * 16 * (int)sizeof(double) + 4 * SB * (int)sizeof(double);
 
 // The SB x SB algebra of one panel. Every 64-step elimination below runs with ONE barrier per step: the pivot row / column of
 // a step is only read during the step and the entries it updates are disjoint from it (scaled rows / columns go to a second
@@ -221,6 +221,8 @@ __global__ __launch_bounds__(256) void sbr_panel_small(const double* __restrict_
   double* pivs = dsign + SB;                                 // [SB]
   double* unit_diag = pivs + SB;                             // [SB] ones
   double* trS = unit_diag + SB;                              // [3][16][16] scratch of the blocked inverses
+  double* rowb = trS + 3 * 16 * 16;                          // [2][SB] pivot row of an elimination step (double-buffered)
+  double* colb = rowb + 2 * SB;                              // [2][SB] pivot column (LU)
   __shared__ int bad;
   const int tid = threadIdx.x, ti = tid >> 4, tj = tid & 15;
   unsigned long long pt = o.prof ? __builtin_amdgcn_s_memtime() : 0ull;
@@ -238,55 +240,86 @@ __global__ __launch_bounds__(256) void sbr_panel_small(const double* __restrict_
   }
   __syncthreads();
   SBR_PP(0)  // loads
-  // ---- Cholesky G = R'R, right-looking on the full symmetric matrix: step j reads row j, updates the rows below it
-  for (int j = 0; j < SB; ++j) {
-    double d = M0[j * SB + j];
-    if (!(d > 0.0)) {
-      if (tid == 0) bad = 1;
-      d = 1.0;
-    }
-    const double rs = sbr_rsqrt64(d), rd = rs * rs;
-    if (tid < SB) {
-      M1[j * SB + tid] = (tid >= j) ? ((tid == j) ? d * rs : M0[j * SB + tid] * rs) : 0.0;
-      if (tid == j) invd[j] = rs;  // 1 / R[j][j]
-    }
-    double rr[4], rc[4];
+  // ---- Cholesky G = R'R, right-looking on the full symmetric matrix. Round 4: the matrix lives in REGISTERS (thread (ti, tj) owns
+  // the entries (ti + 16 u, tj + 16 v)); a step publishes its pivot row through a double-buffered 64-entry LDS line (one barrier per
+  // step) instead of reading and rewriting the 32 KB matrix in LDS -- 64 KB of LDS traffic per step at 128 B / clock were the 1 760
+  // clocks of a step (profiles/r04_panel_small_phase_clocks.log). Same operations on the same operands: the same bits.
+  {
+    double a[4][4];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) rr[u] = M0[j * SB + ti + 16 * u] * rd;
+    for (int u = 0; u < 4; ++u)
 #pragma unroll
-    for (int v = 0; v < 4; ++v) rc[v] = M0[j * SB + tj + 16 * v];
+      for (int v = 0; v < 4; ++v) a[u][v] = M0[(ti + 16 * u) * SB + tj + 16 * v];
+    if (ti == 0) {  // row 0
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const int i = ti + 16 * u;
-      if (i > j) {
-#pragma unroll
-        for (int v = 0; v < 4; ++v) {
-          const int c = tj + 16 * v;
-          if (c > j) M0[i * SB + c] -= rr[u] * rc[v];
-        }
-      }
+      for (int v = 0; v < 4; ++v) rowb[tj + 16 * v] = a[0][v];
     }
     __syncthreads();
+    for (int j = 0; j < SB; ++j) {
+      const double* row = rowb + (j & 1) * SB;
+      double d = row[j];
+      if (!(d > 0.0)) {
+        if (tid == 0) bad = 1;
+        d = 1.0;
+      }
+      const double rs = sbr_rsqrt64(d), rd = rs * rs;
+      if (tid < SB) {
+        M1[j * SB + tid] = (tid >= j) ? ((tid == j) ? d * rs : row[tid] * rs) : 0.0;
+        if (tid == j) invd[j] = rs;  // 1 / R[j][j]
+      }
+      double rr[4], rc[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) rr[u] = row[ti + 16 * u] * rd;
+#pragma unroll
+      for (int v = 0; v < 4; ++v) rc[v] = row[tj + 16 * v];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int i = ti + 16 * u;
+        if (i > j) {
+#pragma unroll
+          for (int v = 0; v < 4; ++v) {
+            const int c = tj + 16 * v;
+            if (c > j) a[u][v] -= rr[u] * rc[v];
+          }
+        }
+      }
+      // the owners of row j + 1 publish it for the next step (the other line: this step's readers may still be at work)
+      if (j + 1 < SB && ti == ((j + 1) & 15)) {
+        double* nxt = rowb + ((j + 1) & 1) * SB;
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+          if (u == ((j + 1) >> 4)) {
+#pragma unroll
+            for (int v = 0; v < 4; ++v) nxt[tj + 16 * v] = a[u][v];
+          }
+      }
+      __syncthreads();
+    }
   }
   SBR_PP(1)  // Cholesky
   // ---- R^-1
   trinv_blocked(M2, [&](int j, int k) { return M1[j * SB + k]; }, invd, trS);
   SBR_PP(2)  // R^-1
-  // ---- Q_top = P_top R^-1
-  {
-    double acc[4][4];
-    mm64_acc<float, true>(acc, F0, M2);
+  // ---- Q_top = P_top R^-1, kept in registers for the elimination below (thread (ti, tj): entries (ti + 16 u, tj + 16 v))
+  double q[4][4];
+  mm64_acc<float, true>(q, F0, M2);
+  if (ti == 0) {
 #pragma unroll
-    for (int u = 0; u < 4; ++u)
+    for (int v = 0; v < 4; ++v) rowb[tj + 16 * v] = q[0][v];
+  }
+  if (tj == 0) {
 #pragma unroll
-      for (int v = 0; v < 4; ++v) M3[(ti + 16 * u) * SB + tj + 16 * v] = acc[u][v];
+    for (int u = 0; u < 4; ++u) colb[ti + 16 * u] = q[u][0];
   }
   __syncthreads();
   SBR_PP(3)  // Q_top = P_top R^-1
   // ---- sign-modified LU of (Q D - E), right-looking: D_j = -sgn(q_jj), pivot = D_j q_jj - 1 = -|q_jj| - 1,
-  //      L[i][j] = D_j q_ij / pivot (to M0), rows of U' stay in the upper part of M3
+  //      L[i][j] = D_j q_ij / pivot (to M0); the rows of U' are written back to the upper part of M3 after the loop. As in the
+  //      Cholesky loop the matrix stays in registers and a step publishes its pivot row and column through LDS lines.
   for (int j = 0; j < SB; ++j) {
-    const double qjj = M3[j * SB + j];
+    const double* row = rowb + (j & 1) * SB;
+    const double* col = colb + (j & 1) * SB;
+    const double qjj = row[j];
     const double dj = (qjj >= 0.0) ? -1.0 : 1.0;
     const double piv = dj * qjj - 1.0;
     const double rp = dj * sbr_rcp64(piv);
@@ -296,9 +329,9 @@ __global__ __launch_bounds__(256) void sbr_panel_small(const double* __restrict_
     }
     double lc[4], ur[4];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) lc[u] = M3[(ti + 16 * u) * SB + j] * rp;
+    for (int u = 0; u < 4; ++u) lc[u] = col[ti + 16 * u] * rp;
 #pragma unroll
-    for (int v = 0; v < 4; ++v) ur[v] = M3[j * SB + tj + 16 * v];
+    for (int v = 0; v < 4; ++v) ur[v] = row[tj + 16 * v];
     if (tj == (j & 15)) {  // the threads whose column set contains j keep L's column j
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
@@ -313,12 +346,38 @@ __global__ __launch_bounds__(256) void sbr_panel_small(const double* __restrict_
 #pragma unroll
         for (int v = 0; v < 4; ++v) {
           const int c = tj + 16 * v;
-          if (c > j) M3[i * SB + c] -= lc[u] * ur[v];
+          if (c > j) q[u][v] -= lc[u] * ur[v];
         }
+      }
+    }
+    if (j + 1 < SB) {  // pivot row / column of the next step, into the other pair of lines
+      const int jn = j + 1;
+      if (ti == (jn & 15)) {
+        double* nxt = rowb + (jn & 1) * SB;
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+          if (u == (jn >> 4)) {
+#pragma unroll
+            for (int v = 0; v < 4; ++v) nxt[tj + 16 * v] = q[u][v];
+          }
+      }
+      if (tj == (jn & 15)) {
+        double* nxt = colb + (jn & 1) * SB;
+#pragma unroll
+        for (int v = 0; v < 4; ++v)
+          if (v == (jn >> 4)) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) nxt[ti + 16 * u] = q[u][v];
+          }
       }
     }
     __syncthreads();
   }
+#pragma unroll
+  for (int u = 0; u < 4; ++u)
+#pragma unroll
+    for (int v = 0; v < 4; ++v) M3[(ti + 16 * u) * SB + tj + 16 * v] = q[u][v];
+  __syncthreads();
   SBR_PP(4)  // LU
   // ---- outputs that need R and the raw LU: Rh = D R, V1 (unit lower); then U' (with the column signs) replaces R in M1
   for (int idx = tid; idx < SB * SB; idx += 256) {
