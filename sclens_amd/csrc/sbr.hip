@@ -830,7 +830,7 @@ int sy2sb_f32(Ctx* ctx, float* A, int64_t n, int64_t lda, float* Tall, int* brea
   const bool delay_ok = lookahead && getenv("SCLENS_HIP_SY2SB_NO_DELAY") == nullptr;
   // pair = 2 max(U, F) before, F + max(1.32 U, F) + c now (U: rank-128 update, F ~ 0.39 ms: factorisation, c ~ 0.09 ms: the two
   // small products): pays from U ~ 0.7 ms, i.e. from a trailing matrix of order ~19 000 (SCLENS_HIP_SY2SB_DELAY_MIN)
-  int64_t delay_min = 18432;
+  int64_t delay_min = 12288;  // round 4: the factorisation an even panel exposes got cheaper (0.39 -> 0.25 ms): 457.6 ms at 18 432, 452.5 at 12 288 (r4m)
   if (const char* ev = getenv("SCLENS_HIP_SY2SB_DELAY_MIN")) delay_min = std::max<int64_t>(4 * SB + 1, atoll(ev));
   unsigned long long* pprof = nullptr;  // SCLENS_HIP_PANEL_PROF=1: per-phase shader clocks of sbr_panel_small on stderr
   if (const char* epp = getenv("SCLENS_HIP_PANEL_PROF")) {
