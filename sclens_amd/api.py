@@ -1149,6 +1149,31 @@ def sclens(inp_df, device_="gpu", th=60, p_step=0.001, n_perturb=20, centering="
                         pass
                     raise
                 r_vr2 = -2  # running on worker 1; joined after the signal vectors
+            elif fp_mode == "three":
+                # All three decompositions at once, the null one on a THIRD session that lives for this phase only: what serialises
+                # two concurrent decompositions are their full-chip products (a round of two costs 2 F + P), so the
+                # data | null pair followed by the binarised matrix costs 3 F + 2 P, while three at once cost 3 F + ~P; and the null
+                # matrix, which the host is still drawing when the call starts (R2, ~0.6 s), no longer delays the pair it belongs to.
+                c3 = Context(ctx.device)
+                w3 = None
+                try:
+                    w3 = ses.clone(c3)
+                    with ThreadPoolExecutor(max_workers=3) as tp:
+                        futs = [tp.submit(lambda: ses.data_spectrum(want_rec)), tp.submit(w_bin.binary_basis),
+                                tp.submit(lambda: w3.null_spectrum_pattern(null_future.result()))]
+                        errs = []
+                        for f in futs:  # every session is single-threaded: all three must have ended before anything is closed
+                            try:
+                                f.result()
+                            except BaseException as e:  # noqa: BLE001 - re-raised below
+                                errs.append(e)
+                        if errs:
+                            raise errs[0]
+                    (L, rec_vals), (_, r_vr2), Lr = futs[0].result(), futs[1].result(), futs[2].result()
+                finally:
+                    if w3 is not None:
+                        w3.close()
+                    c3.close()
             else:
                 (L, rec_vals), Lr = run_all([(0, lambda: ses.data_spectrum(want_rec)), (1, lambda: w_null.null_spectrum_pattern(null_future.result()))])
                 r_vr2 = -1  # decomposed below, next to the signal vectors

@@ -262,7 +262,7 @@ def test_two_streams_give_identical_results(ctx):
         assert np.array_equal(a["robustness_scores"]["b_"], c["robustness_scores"]["b_"])
 
 
-@pytest.mark.parametrize("mode", ["chain", "chain2"])
+@pytest.mark.parametrize("mode", ["chain", "chain2", "three"])
 def test_chained_first_phase_gives_identical_results(ctx, monkeypatch, mode):
     """SCLENS_FIRST_PHASE=chain / chain2 (two streams: worker 1 runs null -> binarised, or binarised -> null, back to back; the main
     session data -> signal vectors) only moves work between streams: every output has the same bits as the default schedule"""

@@ -77,10 +77,23 @@ def test_chained_first_phase_schedule(monkeypatch, mode):
     assert (order.index("null_spectrum") < order.index("binary_basis")) == (mode == "chain")
 
 
+def test_three_at_once_first_phase_schedule(monkeypatch):
+    """SCLENS_FIRST_PHASE=three: data, binarised and null decompositions at once, the null one on a third session that is closed when
+    the phase ends; same result as the oracle, nothing left open"""
+    monkeypatch.setenv("SCLENS_FIRST_PHASE", "three")
+    ref, res = _pair(monkeypatch, 150, 220, 2)
+    _same(ref, res)
+    _all_closed()
+    calls = F.FakeSession.last_calls
+    first = {what: (tid, sid) for tid, sid, what in reversed(calls)}
+    assert len({first["null_spectrum"][1], first["binary_basis"][1], first["data_spectrum"][1]}) == 3  # three sessions
+    assert first["data_spectrum"][1] == first["signal_vectors"][1]
+
+
 def test_a_failure_in_a_worker_closes_everything(monkeypatch):
     X = synth_counts(150, 220, seed=3, C=4, marker_frac=0.25, marker_sd=1.5)
     d = api.make_draws(X, seed=11, p_th_trials=200)
-    for mode in ("", "chain", "chain2"):
+    for mode in ("", "chain", "chain2", "three"):
         monkeypatch.setenv("SCLENS_FIRST_PHASE", mode)
         main = F.install(monkeypatch)
 
