@@ -472,6 +472,11 @@ def main():
                 decisions.append(dict(decisions_of(res, args.seed_base + step0 + s), wall_s=round(t_step, 3)))
         fence()
         dt = time.perf_counter() - t0
+        try:  # device memory in use on this rank's GPU after the timed steps (the library's pool keeps the call's blocks cached)
+            free_b, total_b = torch.cuda.mem_get_info(local_rank)
+            run_config.hbm_in_use_gb = round((total_b - free_b) / 1e9, 1)
+        except Exception:
+            run_config.hbm_in_use_gb = None
         if world > 1:  # MAX over the ranks (through the library's communicator when there is one)
             dt = float(shard.allgather_small(np.array([dt])).max())
         return {"N": N, "M": M, "X": X, "res": res, "dt": dt, "steps": n_steps, "warmup": n_warm, "synth_s": t_synth,
@@ -524,7 +529,8 @@ def main():
                          "search_iters": int(res["n_search"]), "p_": res["p_"], "synth_s": round(main_r["synth_s"], 1),
                          "ensemble_partial_eig": {"used": int(res["partial_eig"][0]), "fallback_to_full": int(res["partial_eig"][1])},
                          "phase_s_rank0_last_step": dict({"draws_host": round(main_r["draws_s"], 4)}, **res.get("phase_s", {})),
-                         "decisions_per_step": main_r["decisions"]},
+                         "decisions_per_step": main_r["decisions"],
+                         "hbm_in_use_GB_after_timed_steps": getattr(run_config, "hbm_in_use_gb", None)},
         }
     # ---- strict fp32: one more step with the fp16-MFMA products of the sparsity search switched off, while the budget lasts
     extra = {}
