@@ -530,7 +530,8 @@ def main():
                          "ensemble_partial_eig": {"used": int(res["partial_eig"][0]), "fallback_to_full": int(res["partial_eig"][1])},
                          "phase_s_rank0_last_step": dict({"draws_host": round(main_r["draws_s"], 4)}, **res.get("phase_s", {})),
                          "decisions_per_step": main_r["decisions"],
-                         "hbm_in_use_GB_after_timed_steps": getattr(run_config, "hbm_in_use_gb", None)},
+                         "hbm_in_use_GB_after_timed_steps": getattr(run_config, "hbm_in_use_gb", None),
+                         "search_job_s_last_step": [list(q) for q in res.get("search_job_s", [])]},
         }
     # ---- strict fp32: one more step with the fp16-MFMA products of the sparsity search switched off, while the budget lasts
     extra = {}

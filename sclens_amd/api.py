@@ -1239,8 +1239,17 @@ def sclens(inp_df, device_="gpu", th=60, p_step=0.001, n_perturb=20, centering="
         n_2 = int(round(r_vr2 / 2))  # :722
         p_list = search_schedule(p_step)
 
+        job_log = []  # (worker, iteration, seconds) of every search evaluation: res["search_job_s"]
+
         def search_job(wk, my_it):
             def f():
+                t_job = time.perf_counter()
+                try:
+                    return f_inner()
+                finally:
+                    job_log.append((wk, my_it, round(time.perf_counter() - t_job, 4)))
+
+            def f_inner():
                 nnzidx = int(round((1 - p_list[my_it]) * M * N))  # :726
                 out = np.full(6, np.nan)
                 if n_cand >= nnzidx:
@@ -1319,7 +1328,7 @@ def sclens(inp_df, device_="gpu", th=60, p_step=0.001, n_perturb=20, centering="
         res: Dict[str, object] = {"L": L, "L_mp": L_mp, "λ": lambda_c, "lambda_c": lambda_c, "cell_id": cell_id,
                                   "p_": p_, "p_th": p_th, "n_search": it, "search_trace": trace,
                                   "partial_eig": pe_counts, "guard_band": guard,
-                                  "gram_bits_used": gram_bits_used}
+                                  "gram_bits_used": gram_bits_used, "search_job_s": sorted(job_log, key=lambda q: (q[1], q[0]))}
         if min_s == 0:  # :780-784
             res["wall_s"] = time.perf_counter() - t_all
             return res
