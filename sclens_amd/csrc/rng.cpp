@@ -134,24 +134,59 @@ int sclens_draw_null_matrix(int64_t N, int64_t M, const int64_t* colptr, const f
     if (colptr[j + 1] - colptr[j] > N || colptr[j + 1] < colptr[j]) return SCLENS_ERR_ARG;
   const int T = host_threads(nnz);
   // (1) the stored values in random order (scLENS.jl:275), as a two-level shuffle: every value goes to one of NBK buckets
-  //     chosen uniformly (one sequential pass), then each bucket -- small enough for the cache -- gets its own Fisher-Yates
-  //     shuffle from its own generator (in parallel). Concatenated, that is a uniform random permutation, and it depends
-  //     on the seed only, not on the thread count.
+  //     chosen uniformly -- round 4: by a COUNTER-based draw, bucket(q) = top byte of splitmix64(key + q), so that the pass runs on
+  //     all threads (chunks of q with per-chunk histograms, a prefix sum, a stable scatter: the result is the one the sequential
+  //     loop over q gives and does not depend on the thread count; the sequential generator of rounds 1-3 made this pass 0.4 of the
+  //     0.6 s the null matrix takes at 100 000 x 30 000, which the null decomposition of sclens() waits for) --, then each bucket --
+  //     small enough for the cache -- gets its own Fisher-Yates shuffle from its own generator (in parallel). Concatenated, that is
+  //     a uniform random permutation that depends on the seed only.
   // (2) per gene the same number of entries at uniformly drawn distinct cells (:247): gene j has its own generator
   //     seeded from (seed, j)
   constexpr int NBK = 256;
   std::vector<int64_t> bstart(NBK + 1, 0);
   {
-    Xo rng(seed ^ 0xA5A5A5A5DEADBEEFull);
+    auto mix = [](uint64_t x) { return scl::splitmix64(x); };  // (by value: the generator form advances its argument)
+    const uint64_t key = mix(seed ^ 0xA5A5A5A5DEADBEEFull);
     std::vector<uint8_t> bucket((size_t)nnz);
-    for (int64_t q = 0; q < nnz; ++q) {
-      const uint8_t b = (uint8_t)(rng.next() >> 56);
-      bucket[q] = b;
-      bstart[b + 1] += 1;
+    std::vector<std::vector<int64_t>> hist(T, std::vector<int64_t>(NBK, 0));
+    auto count = [&](int t) {
+      std::vector<int64_t>& h = hist[t];
+      for (int64_t q = nnz * t / T; q < nnz * (t + 1) / T; ++q) {
+        const uint8_t b = (uint8_t)(mix(key + 0x9E3779B97F4A7C15ull * (uint64_t)q) >> 56);
+        bucket[q] = b;
+        h[b] += 1;
+      }
+    };
+    {
+      std::vector<std::thread> th;
+      for (int t = 1; t < T; ++t) th.emplace_back(count, t);
+      count(0);
+      for (auto& x : th) x.join();
     }
-    for (int b = 0; b < NBK; ++b) bstart[b + 1] += bstart[b];
-    std::vector<int64_t> cur(bstart.begin(), bstart.end() - 1);
-    for (int64_t q = 0; q < nnz; ++q) out_nzval[cur[bucket[q]]++] = nzval[q];
+    for (int b = 0; b < NBK; ++b) {
+      int64_t c = 0;
+      for (int t = 0; t < T; ++t) c += hist[t][b];
+      bstart[b + 1] = bstart[b] + c;
+    }
+    // start of chunk t inside bucket b: the bucket's start + the counts of the earlier chunks (order of q preserved)
+    for (int b = 0; b < NBK; ++b) {
+      int64_t o = bstart[b];
+      for (int t = 0; t < T; ++t) {
+        const int64_t c = hist[t][b];
+        hist[t][b] = o;
+        o += c;
+      }
+    }
+    auto scatter = [&](int t) {
+      std::vector<int64_t>& cur = hist[t];
+      for (int64_t q = nnz * t / T; q < nnz * (t + 1) / T; ++q) out_nzval[cur[bucket[q]]++] = nzval[q];
+    };
+    {
+      std::vector<std::thread> th;
+      for (int t = 1; t < T; ++t) th.emplace_back(scatter, t);
+      scatter(0);
+      for (auto& x : th) x.join();
+    }
   }
   auto work = [&](int t) {
     for (int b = NBK * t / T; b < NBK * (t + 1) / T; ++b) {

@@ -261,3 +261,17 @@ def test_every_environment_switch_is_documented():
     doc = set(re.findall(r"SCLENS_HIP_[A-Z0-9_]+", open(os.path.join(root, "INTEGRATION.md")).read()))
     assert src - doc == set(), f"undocumented switches: {sorted(src - doc)}"
     assert doc - src == set(), f"documented but not read anywhere: {sorted(doc - src)}"
+
+
+def test_null_matrix_draw_does_not_depend_on_the_thread_count(monkeypatch):
+    """R2 (scLENS.jl:701 -> :261-289): the two-level shuffle of the stored values draws its buckets from a counter-based hash since round 4
+    (the pass runs on all host threads); chunking by thread must not show in the result."""
+    X = api._csc_f32(synth_counts(400, 700, seed=6, C=4))
+    out = []
+    for threads in ("1", "3", "8"):
+        monkeypatch.setenv("SCLENS_HIP_HOST_THREADS", threads)
+        Xr = api._resolve(api.make_draws_native(X, seed=21, host_sampler=True).X_r)
+        out.append((Xr.indptr.copy(), Xr.indices.copy(), Xr.data.copy()))
+    for o in out[1:]:
+        assert all(np.array_equal(a, b) for a, b in zip(o, out[0]))
+    assert np.array_equal(np.sort(out[0][2]), np.sort(X.data)) and np.array_equal(np.diff(out[0][0]), np.diff(X.indptr))
