@@ -14,6 +14,7 @@ from __future__ import annotations
 import ctypes as C
 import math
 import os
+import threading
 import time
 from concurrent.futures import Future, ThreadPoolExecutor
 from dataclasses import dataclass
@@ -1000,6 +1001,10 @@ def sclens(inp_df, device_="gpu", th=60, p_step=0.001, n_perturb=20, centering="
         # again: 100 000 x 30 000 in 52.7 s instead of 55.3 s (search 38.3 vs 40.8 s, ensemble 4.0 vs 5.0 s, 2.2 s of worker
         # teardown included; profiles/r02_bench_cfg4_streams2_step1.json)
         streams = 3 if min(N, M) < 16000 else 2
+    # sparsity search on ONE GPU with several local workers: continuous hand-out of iterations with staggered workers
+    # (search_pipelined below) or rounds of W evaluations (SCLENS_SEARCH_PIPELINE=0; always with several ranks)
+    search_pipeline = os.environ.get("SCLENS_SEARCH_PIPELINE", "0") != "0"
+    search_stagger_s = float(os.environ.get("SCLENS_SEARCH_STAGGER_S", "0.65"))
     if draws is None:
         if seed is None:  # every rank must draw the same candidates, null matrix and sample seeds: rank 0's clock decides
             seed = int(shard.bcast_host(np.array([float(time.time_ns() % (2**31))]), 0)[0])
@@ -1265,7 +1270,69 @@ def sclens(inp_df, device_="gpu", th=60, p_step=0.001, n_perturb=20, centering="
         tank = np.zeros((5, 0))
         it = 0
         p_ = None
+
+        def search_pipelined(stagger_s):
+            """One GPU, W > 1 local workers: no round barrier. Each worker takes the next unstarted iteration the moment it is free;
+            results are consumed in iteration order by the stop rule (:747-760), exactly as the rounds do -- the evaluations, their
+            seeds and the rule are the same, only WHEN an evaluation starts differs. Worker w starts `w stagger_s` late, so that the
+            workers stay out of phase: the full-chip kernels of one evaluation (Gram product, band reduction, first
+            back-transformation, statistic) then run beside the latency-bound ones of the other (bulge chase, bisection, inverse
+            iteration, second back-transformation) instead of beside the same full-chip kernels of its twin."""
+            nonlocal tank, it, p_
+            lock = threading.Condition()
+            st = {"next": 0, "done": {}, "stop": False, "err": None}
+
+            def advance():  # under the lock
+                nonlocal tank, it, p_
+                while not st["stop"] and it in st["done"]:
+                    r = st["done"].pop(it)
+                    tank, used, stopped, p_fin = consume_search_round(tank, [r[:5] if r[5] == 1.0 else None], p_list, it, p_th,
+                                                                      p_step, max_search_iters)
+                    it += used
+                    if stopped:
+                        p_ = p_fin
+                        st["stop"] = True
+                lock.notify_all()
+
+            def loop(wk):
+                if wk and stagger_s > 0:
+                    time.sleep(stagger_s * wk)
+                while True:
+                    with lock:
+                        # at most W iterations beyond the last consumed one are in flight (what a round speculates)
+                        while st["next"] >= it + W and not st["stop"] and st["err"] is None:
+                            lock.wait()
+                        if st["stop"] or st["err"] is not None:
+                            return
+                        my = st["next"]
+                        st["next"] = my + 1
+                    try:
+                        out = search_job(wk, my)()
+                    except BaseException as e:
+                        with lock:
+                            if st["err"] is None:
+                                st["err"] = e
+                            lock.notify_all()
+                        return
+                    with lock:
+                        st["done"][my] = out
+                        try:
+                            advance()
+                        except BaseException as e:
+                            if st["err"] is None:
+                                st["err"] = e
+                            lock.notify_all()
+                            return
+
+            futs = [pool.submit(loop, w) for w in range(W)]
+            for f in futs:
+                f.result()
+            if st["err"] is not None:
+                raise st["err"]
+
         try:
+            if search_pipeline and shard.world == 1 and W > 1:
+                search_pipelined(search_stagger_s)
             while p_ is None:
                 base = it + shard.rank * W
                 mine = guarded(lambda: np.stack(run_all([(w, search_job(w, base + w)) for w in range(W)])), "the sparsity search")  # W x 6

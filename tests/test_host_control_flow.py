@@ -90,6 +90,43 @@ def test_three_at_once_first_phase_schedule(monkeypatch):
     assert first["data_spectrum"][1] == first["signal_vectors"][1]
 
 
+@pytest.mark.parametrize("streams", [2, 3])
+@pytest.mark.parametrize("stagger", ["0", "0.02"])
+def test_pipelined_search_reproduces_the_oracle(monkeypatch, streams, stagger):
+    """SCLENS_SEARCH_PIPELINE=1: iterations handed out one by one to staggered workers, results consumed in iteration order: same
+    search trace, p_ and everything after it as the oracle; every iteration evaluated at most once and none skipped"""
+    monkeypatch.setenv("SCLENS_SEARCH_PIPELINE", "1")
+    monkeypatch.setenv("SCLENS_SEARCH_STAGGER_S", stagger)
+    ref, res = _pair(monkeypatch, 150, 220, streams)
+    _same(ref, res)
+    _all_closed()
+    its = sorted(i for _, i, _ in res["search_job_s"])
+    assert its == list(range(len(its))) and ref["n_search"] <= len(its) <= ref["n_search"] + streams - 1
+    assert len({w for w, _, _ in res["search_job_s"]}) >= (2 if ref["n_search"] > 2 else 1)
+
+
+def test_pipelined_search_failure_stops_the_other_workers_and_closes_everything(monkeypatch):
+    monkeypatch.setenv("SCLENS_SEARCH_PIPELINE", "1")
+    monkeypatch.setenv("SCLENS_SEARCH_STAGGER_S", "0.01")
+    X = synth_counts(150, 220, seed=3, C=4, marker_frac=0.25, marker_sd=1.5)
+    d = api.make_draws(X, seed=11, p_th_trials=200)
+    main = F.install(monkeypatch)
+    seen = []
+    orig = F.FakeSession.search_step
+
+    def third_call_fails(self, sample, n_2):
+        seen.append(1)
+        if len(seen) == 3:
+            raise RuntimeError("search evaluation failed")
+        return orig(self, sample, n_2)
+
+    monkeypatch.setattr(F.FakeSession, "search_step", third_call_fails)
+    with pytest.raises(RuntimeError, match="search evaluation failed"):
+        api.sclens(X, draws=d, n_perturb=3, ctx=main, streams=2)
+    assert len(seen) <= 5  # the other worker finishes what it had started and takes nothing new
+    _all_closed()
+
+
 def test_a_failure_in_a_worker_closes_everything(monkeypatch):
     X = synth_counts(150, 220, seed=3, C=4, marker_frac=0.25, marker_sd=1.5)
     d = api.make_draws(X, seed=11, p_th_trials=200)
