@@ -30,6 +30,21 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) void lds_void;
 typedef const __attribute__((address_space(1))) void glb_void;
 
+// fp16 pieces of fp32 values, x = hi + lo (22 significant bits): four (K = 16 matrix instruction) or eight (K = 32) per lane
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+struct SbrHL {
+  f16x4 h, l;
+};
+struct SbrHL8 {
+  f16x8 h, l;
+};
+__device__ __forceinline__ SbrHL sbr_split_pk(f32x4 x);
+__device__ __forceinline__ SbrHL8 sbr_cat(const SbrHL& a, const SbrHL& b);
+__global__ void sbr_row_abs_max(const float* __restrict__ A, int64_t n, int64_t lda, unsigned* __restrict__ out);
+
 // Split-K factor of a product whose `tiles` output tiles (one workgroup each, one workgroup per CU) do not fill the 256 CUs:
 // the grid runs in ceil(tiles S / 256) rounds of K / S each, so the time goes like rounds(S) / S. (59 row tiles with S = 9 are
 // 531 workgroups = 3 rounds of K / 9; S = 13 gives 767 = 3 rounds of K / 13: the same product in 0.69 of the time.)
@@ -764,6 +779,141 @@ static int sbr_ensure_aux(Ctx* ctx) {  // the context's second stream and its ev
   return SCLENS_OK;
 }
 
+// ---- W = A22 V on the fp16 matrix cores (round 4) ---------------------------------------------------------------------
+// The skinny product streams the whole trailing matrix once per panel (4 n'^2 bytes) for 2 * 64 n'^2 flop: on the fp32 matrix pipe
+// (256 x 64 tiles of gemm_nt_big) it is bound by that pipe from the second octile on (the trailing matrix then comes out of the
+// 256 MB MALL faster than the pipe consumes it). Here the fp32 tile of A22 arrives in LDS by DMA exactly as before, each lane
+// splits the eight k-consecutive values of its fragment into fp16 pieces in registers (x = hi + lo of the value scaled by a power
+// of two: 2 conversions + 1 mixed fma per element), V comes as a finished image of [hi | lo] fp16 units built once per panel
+// (sbr_v_image), and the product is hi hi + hi lo + lo hi on v_mfma_f32_16x16x32_f16 with fp32 accumulation: 24 matrix
+// instructions of 16 clocks per wave and 32 of K instead of 32 of 64 clocks -- the kernel is bound by the delivery of A22 alone.
+// Scales: every entry of every trailing matrix is bounded by the 2-norm of A, hence by its largest absolute row sum (computed
+// once per reduction); A22 is scaled so that this bound sits below 2^15, V (entries at most 1 in magnitude) by 2^13.
+struct SbrWArgs {
+  const float* A22;
+  int64_t lda;
+  const float* Vimg;  // per 32 rows of V: 2048 floats = hi units [g 4][col 64][8 halves], then the lo units
+  float* Wp;          // slab s = W partial of K-slice s, [n'][64]
+  int64_t np, kch, slab;
+  const float* sc;    // {scale of A22, 1 / (scale of A22 * 2^13)}
+};
+constexpr int SBR_W_STAGE = 256 * 32 + 2048;  // floats of one LDS stage: the A22 tile (32 KB) + the V image of the step (8 KB)
+constexpr float SBR_W_VSCALE = 8192.f;
+
+__global__ void sbr_w_scale(const unsigned* __restrict__ bound, float mul, float add, float* __restrict__ sc) {
+  const float limit = mul * __uint_as_float(*bound) + add;
+  float s = 1.f;
+  if (limit > 0.f && limit < 3.0e38f) s = ldexpf(1.f, 15 - (ilogbf(limit) + 1));  // limit * s < 2^15
+  sc[0] = s;
+  sc[1] = 1.f / (s * SBR_W_VSCALE);
+}
+
+// V image of one panel: block kt covers the rows 32 kt .. 32 kt + 31 of V (row-major [n'][64])
+__global__ __launch_bounds__(256) void sbr_v_image(const float* __restrict__ Vr, float* __restrict__ img) {
+  const int u = threadIdx.x, g = u >> 6, col = u & 63;
+  const float* src = Vr + ((int64_t)blockIdx.x * 32 + 8 * g) * SB + col;
+  f32x4 x0, x1;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    x0[e] = src[e * SB] * SBR_W_VSCALE;
+    x1[e] = src[(4 + e) * SB] * SBR_W_VSCALE;
+  }
+  const SbrHL8 o = sbr_cat(sbr_split_pk(x0), sbr_split_pk(x1));
+  f32x4 rh, rl;
+  __builtin_memcpy(&rh, &o.h, 16);
+  __builtin_memcpy(&rl, &o.l, 16);
+  float* dst = img + (int64_t)blockIdx.x * 2048;
+  *reinterpret_cast<f32x4*>(dst + 4 * u) = rh;
+  *reinterpret_cast<f32x4*>(dst + 1024 + 4 * u) = rl;
+}
+
+__global__ __launch_bounds__(512, 2) void sbr_w_split(SbrWArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float wl[];
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int l15 = lane & 15, g = lane >> 4;
+  const int64_t m0 = (int64_t)blockIdx.x * 256;
+  const int64_t k0 = (int64_t)blockIdx.y * a.kch;
+  const int64_t kleft = a.np - k0;
+  const int nkt = (int)((kleft < a.kch ? kleft : a.kch) / 32);
+  const float sA = a.sc[0], inv = a.sc[1];
+  // staging: wave w moves the 8-row groups 4 w .. 4 w + 3 of the A22 tile (chunk q of row r lands in slot q ^ ((r >> 1) & 7): the
+  // layout of gemm_nt_big) and its 1 KB of the V image
+  const int srow = lane >> 3, sq = lane & 7;
+  const float* srcA[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int r = (wid * 4 + i) * 8 + srow;
+    int64_t ra = m0 + r;
+    if (ra > a.np - 1) ra = a.np - 1;
+    srcA[i] = a.A22 + ra * a.lda + k0 + 4 * (sq ^ ((r >> 1) & 7));
+  }
+  const float* srcV = a.Vimg + (k0 / 32) * 2048 + 4 * tid;
+  auto stage = [&](int buf, int kt) {
+    float* As = wl + buf * SBR_W_STAGE;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      __builtin_amdgcn_global_load_lds((glb_void*)(srcA[i] + (int64_t)kt * 32), (lds_void*)(As + (wid * 4 + i) * 256), 16, 0, 0);
+    __builtin_amdgcn_global_load_lds((glb_void*)(srcV + (int64_t)kt * 2048), (lds_void*)(As + 8192 + wid * 256), 16, 0, 0);
+  };
+  // wave w owns the rows 32 w .. 32 w + 31 of the tile (two 16-row fragments) and all 64 columns of W (four fragments).
+  // The matrix instruction takes V as its first operand: D[m = column of W][n = row of A22], so a lane's four results are four
+  // consecutive columns of one row of W (one 16-byte store).
+  int offA[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int r = wid * 32 + 16 * i + l15, sw = (r >> 1) & 7;
+    offA[i][0] = r * 32 + (((2 * g) ^ sw) << 2);
+    offA[i][1] = r * 32 + (((2 * g + 1) ^ sw) << 2);
+  }
+  const int offV = 8192 + 4 * (g * 64 + l15);
+  f32x4 acc[2][4];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  if (nkt > 0) stage(0, 0);
+  __syncthreads();
+  for (int kt = 0; kt < nkt; ++kt) {
+    const int buf = kt & 1;
+    if (kt + 1 < nkt) stage(buf ^ 1, kt + 1);
+    const float* S = wl + buf * SBR_W_STAGE;
+    f32x4 x[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      x[i][0] = *reinterpret_cast<const f32x4*>(S + offA[i][0]);
+      x[i][1] = *reinterpret_cast<const f32x4*>(S + offA[i][1]);
+    }
+    SbrHL8 v[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const f32x4 rh = *reinterpret_cast<const f32x4*>(S + offV + 64 * j);
+      const f32x4 rl = *reinterpret_cast<const f32x4*>(S + offV + 1024 + 64 * j);
+      __builtin_memcpy(&v[j].h, &rh, 16);
+      __builtin_memcpy(&v[j].l, &rl, 16);
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const SbrHL8 b = sbr_cat(sbr_split_pk(x[i][0] * sA), sbr_split_pk(x[i][1] * sA));
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(v[j].h, b.h, acc[i][j], 0, 0, 0);
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(v[j].l, b.h, acc[i][j], 0, 0, 0);
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(v[j].h, b.l, acc[i][j], 0, 0, 0);
+      }
+    }
+    __syncthreads();
+  }
+  float* Ws = a.Wp + (int64_t)blockIdx.y * a.slab;
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int64_t row = m0 + wid * 32 + 16 * i + l15;
+    if (row < a.np) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) *reinterpret_cast<f32x4*>(Ws + row * SB + 16 * j + 4 * g) = acc[i][j] * inv;
+    }
+  }
+}
+
 // ---- host driver ------------------------------------------------------------------------------------------------------
 // A: n x n fp32 row-major, full symmetric storage, n a multiple of SB. On return: lower band (|i - j| <= SB) = the band
 // matrix, upper part = the panel reflectors V_p, Tall[p][SB][SB] = their T factors. *breakdown (host) != 0: a panel was
@@ -810,6 +960,23 @@ int sy2sb_f32(Ctx* ctx, float* A, int64_t n, int64_t lda, float* Tall, int* brea
   SCL_WS(ctx, flag, int, "sbr.flag", 4);
   hipStream_t st = ctx->stream;
   SCL_HIP(ctx, hipMemsetAsync(flag, 0, sizeof(int) * 4, st));
+  // W = A22 V from fp16 pieces (sbr_w_split) while the trailing matrix has at least `wsplit_min` rows: follows the switch of the
+  // trailing updates; SCLENS_HIP_SY2SB_WSPLIT=0: fp32 product, = r: from r rows
+  int64_t wsplit_min = split_min;
+  if (const char* ev = getenv("SCLENS_HIP_SY2SB_WSPLIT")) wsplit_min = atoi(ev) > 0 ? std::max<int64_t>(2 * SB, atoll(ev)) : (int64_t)1 << 60;
+  const bool any_wsplit = n - SB >= wsplit_min;
+  float* Vimg = nullptr;
+  float* wsc = nullptr;
+  if (any_wsplit) {
+    Vimg = static_cast<float*>(ctx->workspace("sbr.Vimg", sizeof(float) * (size_t)(n * SB)));
+    wsc = static_cast<float*>(ctx->workspace("sbr.wsc", 4 * sizeof(float)));
+    unsigned* wbound = static_cast<unsigned*>(ctx->workspace("sbr.wbound", 4 * sizeof(unsigned)));
+    if (!Vimg || !wsc || !wbound) return SCLENS_ERR_OOM;
+    SCL_HIP(ctx, hipMemsetAsync(wbound, 0, 4 * sizeof(unsigned), st));
+    hipLaunchKernelGGL(sbr_row_abs_max, dim3((unsigned)n), dim3(256), 0, st, A, n, lda, wbound);
+    hipLaunchKernelGGL(sbr_w_scale, dim3(1), dim3(1), 0, st, wbound, 1.f, 0.f, wsc);
+    SCL_TRY(ensure_dyn_lds(ctx, reinterpret_cast<const void*>(sbr_w_split), 2 * SBR_W_STAGE * (int)sizeof(float)));
+  }
   SCL_TRY(ensure_dyn_lds(ctx, reinterpret_cast<const void*>(sbr_panel_small), SBR_PANEL_LDS));
   // Look-ahead: panel p + 1 only needs the first SB columns of the trailing matrix of step p. Those are updated first
   // (a strip product, its transposed copy, and the diagonal block), then the panel is factored on a second stream while
@@ -858,6 +1025,7 @@ int sy2sb_f32(Ctx* ctx, float* A, int64_t n, int64_t lda, float* Tall, int* brea
     // V = [V1; P2 M] in the transposed storage (in place) and row-major; Rh into the band block of the panel
     if (np > SB) hipLaunchKernelGGL(sbr_vmul_f64, dim3(rtiles), dim3(256), 0, s_, Pt, lda, Mat, np, Vr);
     hipLaunchKernelGGL(sbr_top_block, dim3(1), dim3(256), 0, s_, Pt, lda, V1, V1 + SB * SB, A + r0 * lda + c0, Vr);
+    if (any_wsplit && np >= wsplit_min) hipLaunchKernelGGL(sbr_v_image, dim3((unsigned)(np / 32)), dim3(256), 0, s_, Vr, Vimg);
     return SCLENS_OK;
   };
   SCL_TRY(factor_panel(0, st));
@@ -874,7 +1042,10 @@ int sy2sb_f32(Ctx* ctx, float* A, int64_t n, int64_t lda, float* Tall, int* brea
     int Sw = sbr_pick_splits(tiles_w, S, np);
     const int64_t kch = round_up((np + Sw - 1) / Sw, 32);
     Sw = (int)((np + kch - 1) / kch);
-    {
+    if (any_wsplit && np >= wsplit_min) {
+      SbrWArgs wa{A22, lda, Vimg, Wp, np, kch, (int64_t)SB * ldw, wsc};
+      hipLaunchKernelGGL(sbr_w_split, dim3((unsigned)tiles_w, (unsigned)Sw), dim3(512), 2 * SBR_W_STAGE * sizeof(float), st, wa);
+    } else {
       GemmArgs g{};
       g.P = A22; g.Q = Pt; g.C = Wp;
       g.M = np; g.N = SB; g.K = np;
@@ -2478,10 +2649,6 @@ __global__ __launch_bounds__(256, 1) void sbr_q2_apply16v3(SbrQ2Args a) {
 // the workgroup when a group is stashed. The vector window lives scaled by 2^8 (exact), so that the low pieces of entries of
 // size 1 / sqrt(n) stay in fp16's normal range; it is split per group (z, W', U': ~120 vector instructions per lane against
 // ~2 400 cycles of matrix-pipe time saved).
-typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
-struct SbrHL {
-  f16x4 h, l;
-};
 __device__ __forceinline__ SbrHL sbr_ld_hl(const float* p) {
   const f32x4 r = *reinterpret_cast<const f32x4*>(p);
   SbrHL o;
@@ -2892,8 +3059,6 @@ __global__ __launch_bounds__(256) void sbr_q2_build_img(const float* __restrict_
 }
 
 // x = hi + lo with two packed conversions and one mixed-precision fma per element (lo = x - hi exactly, hi taken as an fp16 operand)
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ SbrHL sbr_split_pk(f32x4 x) {
   const f16x2 h01 = __builtin_convertvector(f32x2{x[0], x[1]}, f16x2);
   const f16x2 h23 = __builtin_convertvector(f32x2{x[2], x[3]}, f16x2);
@@ -2951,10 +3116,6 @@ __device__ __forceinline__ void sbr_q2_group16e(f32x4* z, const float* buf, int 
   }
 }
 
-typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
-struct SbrHL8 {
-  f16x8 h, l;
-};
 __device__ __forceinline__ SbrHL8 sbr_ld_hl8(const float* p) {  // one 32-byte unit [hi x 8 | lo x 8]
   const f32x4 r0 = *reinterpret_cast<const f32x4*>(p), r1 = *reinterpret_cast<const f32x4*>(p + 4);
   SbrHL8 o;

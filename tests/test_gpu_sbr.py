@@ -50,6 +50,7 @@ def delayed_update(request, monkeypatch):
     if "delayed" in request.param:
         monkeypatch.setenv("SCLENS_HIP_SY2SB_DELAY_MIN", "321")
     monkeypatch.setenv("SCLENS_HIP_SY2SB_SPLIT", "512" if "split" in request.param else "0")
+    monkeypatch.setenv("SCLENS_HIP_SY2SB_WSPLIT", "128" if "split" in request.param else "0")  # W = A22 V from fp16 pieces
     monkeypatch.setenv("SCLENS_HIP_Q1_SPLIT", "32" if "split" in request.param else "0")  # first back-transformation likewise
     return request.param
 
@@ -83,6 +84,33 @@ def test_sy2sb_split_update_with_separate_scales(ctx, log2_norm, monkeypatch):
     assert err["2"] < 4e-7 * np.sqrt(n) + 1e-7, err
     if log2_norm <= 14:
         assert err["1"] < 4e-7 * np.sqrt(n) + 1e-7, err
+
+
+@pytest.mark.parametrize("shape", ["gram", "dominant", "graded"])
+@pytest.mark.parametrize("log2_norm", [-20, 0, 14, 20])
+def test_sy2sb_w_product_from_fp16_pieces(ctx, log2_norm, shape, monkeypatch):
+    """W = A22 V with the trailing matrix split into fp16 pieces in registers (sbr_w_split; scale from the largest absolute row sum,
+    which bounds every entry of every trailing matrix): the band keeps the spectrum to the tolerance of the fp32 product, whatever
+    the norm, with one dominant eigenvalue (entries of the trailing matrices far above those of A) and with graded rows"""
+    n = 1536
+    A = _sym_psd(n, 5).astype(np.float64)
+    if shape == "dominant":
+        u = np.ones(n) / np.sqrt(n)
+        A = A + 3000.0 * np.outer(u, u)  # lambda_max 3000 x the bulk, entries of A ~ 2: the band holds an entry ~ 3000
+    elif shape == "graded":
+        d = np.logspace(0, -3, n)
+        A = A * d[:, None] * d[None, :]
+    A = (A * 2.0 ** log2_norm).astype(np.float32)
+    ref = np.linalg.eigvalsh(A.astype(np.float64))
+    monkeypatch.setenv("SCLENS_HIP_SY2SB_SPLIT", "0")  # trailing updates on the fp32 matrix cores: the W product is what differs
+    err = {}
+    for w in ("128", "0"):
+        monkeypatch.setenv("SCLENS_HIP_SY2SB_WSPLIT", w)
+        out, T, bd = _run_sy2sb(ctx, A)
+        assert bd == 0
+        err[w] = np.abs(np.linalg.eigvalsh(_band_of(out)) - ref).max() / np.abs(ref).max()
+    assert err["128"] < 4e-7 * np.sqrt(n) + 1e-7, err
+    assert err["128"] < 3 * err["0"] + 2e-7, err
 
 
 @pytest.mark.parametrize("n", [128, 256, 448, 832])
