@@ -562,6 +562,11 @@ struct SplitUpdArgs {
   int64_t kt_chunk;
   int64_t c_split_off;
   int overwrite;
+  // acc_init != 0 (|post| == 1, no overwrite): the accumulators start from C / alpha (alpha a power of two: exact), every element of
+  // the C tile requested before the first operand stage -- one memory round trip per tile with 256 KB in flight per CU instead of
+  // eight of 32 KB in the epilogue, which is what bounded the rank-256 updates of the band reduction (65 us per tile, 39 at the fair
+  // share of HBM)
+  int acc_init;
 };
 
 // The main loop of corr_split_kernel with the tile decode, the accumulator start from C and the lower + mirror epilogue of
@@ -587,6 +592,8 @@ __global__ __launch_bounds__(512, 2) void gemm_split_kernel(SplitUpdArgs a) {
       tl = make_int2((int)(t / (unsigned)a.tiles_n), (int)(t % (unsigned)a.tiles_n));
     }
   }
+  tl.x = __builtin_amdgcn_readfirstlane(tl.x);  // uniform by construction: tile corner, C pointers and the buffer resource in scalars
+  tl.y = __builtin_amdgcn_readfirstlane(tl.y);
   const int64_t m0 = (int64_t)tl.x * 256, n0 = (int64_t)tl.y * 256;
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int wm = wid >> 2, wn = wid & 3, l31 = lane & 31, h = lane >> 5;
@@ -637,6 +644,24 @@ __global__ __launch_bounds__(512, 2) void gemm_split_kernel(SplitUpdArgs a) {
     for (int j = 0; j < TN; ++j)
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+  const bool cinit = a.acc_init != 0 && !a.overwrite;
+  if (cinit) {
+    // buffer loads: the lane's part of the address in one register, the row of the element in a scalar, no predicate -- rows beyond
+    // the matrix are beyond the resource (zero), columns beyond it and the upper part of a diagonal tile are loaded and never stored
+    const unsigned nrec = (unsigned)(((int64_t)(mrem - 1) * a.ldc + nrem) * 4);
+    const __amdgpu_buffer_rsrc_t rc = __builtin_amdgcn_make_buffer_rsrc(Ct, 0, nrec, 0x00020000);
+    const unsigned vo = (unsigned)((4 * h * ldc + wn * 64 + l31) * 4);
+    const int wms = __builtin_amdgcn_readfirstlane(wm);
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const unsigned so = (unsigned)((wms * 128 + i * 32 + (e & 3) + 8 * (e >> 2)) * ldc) * 4u;
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+          acc[i][j][e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rc, vo + (unsigned)(j * 128), so, 0));
+      }
+  }
   int offA[TM], offB[TN], swA[TM], swB[TN];
 #pragma unroll
   for (int i = 0; i < TM; ++i) {
@@ -649,6 +674,15 @@ __global__ __launch_bounds__(512, 2) void gemm_split_kernel(SplitUpdArgs a) {
     const int r = wn * 64 + j * 32 + l31;
     offB[j] = OPB + r * 128;
     swB[j] = (r >> 1) & 7;
+  }
+  if (cinit) {
+    const float inv_alpha = 1.f / alpha;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[i][j][e] *= inv_alpha;
   }
   __syncthreads();
   for (int64_t kt = kt_lo; kt < nkt; ++kt) {
@@ -694,7 +728,7 @@ __global__ __launch_bounds__(512, 2) void gemm_split_kernel(SplitUpdArgs a) {
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
         const int r = r0 + (e & 3) + 8 * (e >> 2);
-        cin[e] = (!a.overwrite && r < mrem && c < nrem && c <= r + diag) ? Ct[r * ldc + c] : 0.f;
+        cin[e] = (!cinit && !a.overwrite && r < mrem && c < nrem && c <= r + diag) ? Ct[r * ldc + c] : 0.f;
       }
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[i][j][e] = fmaf(acc[i][j][e], alpha, cin[e]);
@@ -833,8 +867,9 @@ int gemm_split_update(Ctx* ctx, const void* Pimg, const float* sP, int64_t M, co
   if (K >= 2048 && nb >= 1500) SCL_TRY(big_tile_list(ctx, bm, bn, lower, &tiles, &nb));  // operand panels re-used out of the L2s
   constexpr int LDS_BYTES = 2 * 2 * 256 * 128;
   SCL_TRY(ensure_dyn_lds(ctx, reinterpret_cast<const void*>(gemm_split_kernel), LDS_BYTES));
+  const bool no_acc_init = getenv("SCLENS_HIP_SPLIT_ACC_INIT") && atoi(getenv("SCLENS_HIP_SPLIT_ACC_INIT")) == 0;  // A/B: C in the epilogue
   SplitUpdArgs a{static_cast<const _Float16*>(Pimg), static_cast<const _Float16*>(Qimg), sP, sQ, M, N, round_up(K, 32), C, ldc, lower,
-                 (int)bn, post, tiles, 0, 0, 0};
+                 (int)bn, post, tiles, 0, 0, 0, (!no_acc_init && fabsf(post) == 1.f) ? 1 : 0};
   hipLaunchKernelGGL(gemm_split_kernel, dim3((unsigned)nb), dim3(512), LDS_BYTES, ctx->stream, a);
   SCL_HIP(ctx, hipGetLastError());
   return SCLENS_OK;
@@ -851,7 +886,7 @@ int gemm_split_nt(Ctx* ctx, const void* Pimg, const float* sP, int64_t M, const 
   constexpr int LDS_BYTES = 2 * 2 * 256 * 128;
   SCL_TRY(ensure_dyn_lds(ctx, reinterpret_cast<const void*>(gemm_split_kernel), LDS_BYTES));
   SplitUpdArgs a{static_cast<const _Float16*>(Pimg), static_cast<const _Float16*>(Qimg), sP, sQ, M, N, round_up(K, 32), C, ldc, 0,
-                 (int)bn, 1.0f, nullptr, splits > 1 ? k_chunk / 32 : round_up(K, 32) / 32, c_split_off, 1};
+                 (int)bn, 1.0f, nullptr, splits > 1 ? k_chunk / 32 : round_up(K, 32) / 32, c_split_off, 1, 0};
   hipLaunchKernelGGL(gemm_split_kernel, dim3((unsigned)nb, (unsigned)splits), dim3(512), LDS_BYTES, ctx->stream, a);
   SCL_HIP(ctx, hipGetLastError());
   return SCLENS_OK;

@@ -779,6 +779,14 @@ static int sbr_ensure_aux(Ctx* ctx) {  // the context's second stream and its ev
   return SCLENS_OK;
 }
 
+// upper half of the leading 64 x 64 block = its lower half (exact symmetry after a full, unsymmetrically rounded update of the block)
+__global__ __launch_bounds__(256) void sbr_mirror_diag(float* __restrict__ A, int64_t lda) {
+  for (int idx = threadIdx.x; idx < SB * SB; idx += 256) {
+    const int i = idx / SB, j = idx % SB;
+    if (j > i) A[i * lda + j] = A[j * lda + i];
+  }
+}
+
 // ---- W = A22 V on the fp16 matrix cores (round 4) ---------------------------------------------------------------------
 // The skinny product streams the whole trailing matrix once per panel (4 n'^2 bytes) for 2 * 64 n'^2 flop: on the fp32 matrix pipe
 // (256 x 64 tiles of gemm_nt_big) it is bound by that pipe from the second octile on (the trailing matrix then comes out of the
@@ -803,7 +811,11 @@ constexpr float SBR_W_VSCALE = 8192.f;
 __global__ void sbr_w_scale(const unsigned* __restrict__ bound, float mul, float add, float* __restrict__ sc) {
   const float limit = mul * __uint_as_float(*bound) + add;
   float s = 1.f;
-  if (limit > 0.f && limit < 3.0e38f) s = ldexpf(1.f, 15 - (ilogbf(limit) + 1));  // limit * s < 2^15
+  if (limit > 0.f && limit < 3.0e38f) {  // limit * s < 2^15; the exponent clamped so that s, 1 / s and 1 / (2^13 s) stay normal
+    int e = 15 - (ilogbf(limit) + 1);
+    e = e > 100 ? 100 : (e < -100 ? -100 : e);
+    s = ldexpf(1.f, e);
+  }
   sc[0] = s;
   sc[1] = 1.f / (s * SBR_W_VSCALE);
 }
@@ -965,6 +977,8 @@ int sy2sb_f32(Ctx* ctx, float* A, int64_t n, int64_t lda, float* Tall, int* brea
   int64_t wsplit_min = split_min;
   if (const char* ev = getenv("SCLENS_HIP_SY2SB_WSPLIT")) wsplit_min = atoi(ev) > 0 ? std::max<int64_t>(2 * SB, atoll(ev)) : (int64_t)1 << 60;
   const bool any_wsplit = n - SB >= wsplit_min;
+  int ws_slots = 512;
+  if (const char* ev = getenv("SCLENS_HIP_SY2SB_WS_SLOTS")) ws_slots = std::max(64, atoi(ev));
   float* Vimg = nullptr;
   float* wsc = nullptr;
   if (any_wsplit) {
@@ -1008,6 +1022,9 @@ int sy2sb_f32(Ctx* ctx, float* A, int64_t n, int64_t lda, float* Tall, int* brea
       SCL_HIP(ctx, hipStreamSynchronize(st));
     }
   }
+  // The look-ahead strip's diagonal block used to be a launch of its own (lower + mirror, one workgroup: 41 us of latency per panel
+  // on the main stream, 17 ms per reduction); SCLENS_HIP_SY2SB_FOLD_DIAG=0 restores it
+  const bool fold_diag = !(getenv("SCLENS_HIP_SY2SB_FOLD_DIAG") && atoi(getenv("SCLENS_HIP_SY2SB_FOLD_DIAG")) == 0);
   bool pending = false;  // the previous panel's bulk update is outstanding (its operands sit in slot 0)
   auto factor_panel = [&](int64_t p, hipStream_t s_) -> int {
     const int64_t c0 = p * SB, r0 = c0 + SB, np = n - r0;
@@ -1039,7 +1056,7 @@ int sy2sb_f32(Ctx* ctx, float* A, int64_t n, int64_t lda, float* Tall, int* brea
     // K = n' split into S slices inside one launch (slab s = its own [n'][SB] partial, summed by the next kernel)
     float* A22 = A + r0 * lda + r0;
     const int64_t tiles_w = (np + 255) / 256;
-    int Sw = sbr_pick_splits(tiles_w, S, np);
+    int Sw = sbr_pick_splits(tiles_w, S, np, (any_wsplit && np >= wsplit_min) ? ws_slots : 256);  // sbr_w_split: two workgroups per CU
     const int64_t kch = round_up((np + Sw - 1) / Sw, 32);
     Sw = (int)((np + kch - 1) / kch);
     if (any_wsplit && np >= wsplit_min) {
@@ -1122,8 +1139,13 @@ int sy2sb_f32(Ctx* ctx, float* A, int64_t n, int64_t lda, float* Tall, int* brea
     };
     if (p + 1 < npan && lookahead && np > 2 * SB) {
       // (i) what panel p + 1 reads: the diagonal block (lower + mirror), the strip below it, and the strip's exact transpose
-      SCL_TRY(update(0, SB, SB, 1));
-      SCL_TRY(update(SB, np - SB, SB, 0));
+      if (fold_diag) {  // one launch for the diagonal block and the strip; the block's upper half then copied from its lower half
+        SCL_TRY(update(0, np, SB, 0));
+        hipLaunchKernelGGL(sbr_mirror_diag, dim3(1), dim3(256), 0, st, A22, lda);
+      } else {
+        SCL_TRY(update(0, SB, SB, 1));
+        SCL_TRY(update(SB, np - SB, SB, 0));
+      }
       SCL_TRY(transpose_f32(ctx, A22 + SB * lda, np - SB, SB, lda, A22 + SB, lda));
       SCL_HIP(ctx, hipEventRecord(ctx->aux_ev[0], st));
       SCL_HIP(ctx, hipStreamWaitEvent(st2, ctx->aux_ev[0], 0));

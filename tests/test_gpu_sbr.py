@@ -86,6 +86,26 @@ def test_sy2sb_split_update_with_separate_scales(ctx, log2_norm, monkeypatch):
         assert err["1"] < 4e-7 * np.sqrt(n) + 1e-7, err
 
 
+@pytest.mark.parametrize("n", [1024, 2368])
+def test_sy2sb_split_update_started_from_c(ctx, n, monkeypatch):
+    """the split-fp16 trailing update with its accumulators started from C / alpha (all of the C tile requested up front through
+    unpredicated buffer loads; default) against C added in the epilogue (SCLENS_HIP_SPLIT_ACC_INIT=0): partial edge tiles, diagonal
+    tiles, rank-128 and rank-256 (delayed) updates; both keep the spectrum to the fp32 path's tolerance"""
+    A = _sym_psd(n, 11)
+    ref = np.linalg.eigvalsh(A.astype(np.float64))
+    monkeypatch.setenv("SCLENS_HIP_SY2SB_DELAY_MIN", "321")
+    monkeypatch.setenv("SCLENS_HIP_SY2SB_SPLIT", "512")
+    err, band = {}, {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("SCLENS_HIP_SPLIT_ACC_INIT", mode)
+        out, T, bd = _run_sy2sb(ctx, A)
+        assert bd == 0
+        band[mode] = _band_of(out)
+        err[mode] = np.abs(np.linalg.eigvalsh(band[mode]) - ref).max() / ref.max()
+    assert err["1"] < 4e-7 * np.sqrt(n) + 1e-7 and err["0"] < 4e-7 * np.sqrt(n) + 1e-7, err
+    assert err["1"] < 3 * err["0"] + 2e-7, err
+
+
 @pytest.mark.parametrize("shape", ["gram", "dominant", "graded"])
 @pytest.mark.parametrize("log2_norm", [-20, 0, 14, 20])
 def test_sy2sb_w_product_from_fp16_pieces(ctx, log2_norm, shape, monkeypatch):
