@@ -415,7 +415,8 @@ def main():
         return {"seed": int(seed), "signals": int(len(res.get("signal_ev", []))), "robust_signals": int(len(res.get("sig_id", []))),
                 "search_iters": int(res["n_search"]), "p_": res["p_"],
                 "min_abs_margin": (round(min(abs(x - p_th) for x in d2), 6) if d2 else None),
-                "d5_second_smallest": [round(x, 5) for x in d2], "p_th": round(p_th, 6)}
+                "d5_second_smallest": [round(x, 5) for x in d2], "p_th": round(p_th, 6),
+                "phase_s": {k: round(float(v), 3) for k, v in (res.get("phase_s") or {}).items()}}
 
     def run_config(cfg, steps_req, warm_req, deadline, tail_steps=0.0, step0=0):
         """tail_steps: keep this many step durations of the budget free for what follows (the strict-fp32 step);
@@ -531,7 +532,8 @@ def main():
                          "phase_s_rank0_last_step": dict({"draws_host": round(main_r["draws_s"], 4)}, **res.get("phase_s", {})),
                          "decisions_per_step": main_r["decisions"],
                          "hbm_in_use_GB_after_timed_steps": getattr(run_config, "hbm_in_use_gb", None),
-                         "search_job_s_last_step": [list(q) for q in res.get("search_job_s", [])]},
+                         "search_job_s_last_step": [list(q) for q in res.get("search_job_s", [])],
+                         "first_phase_jobs_s_last_step": [list(q) for q in res.get("first_phase_s", [])]},
         }
     # ---- strict fp32: one more step with the fp16-MFMA products of the sparsity search switched off, while the budget lasts
     extra = {}

@@ -1083,6 +1083,21 @@ def sclens(inp_df, device_="gpu", th=60, p_step=0.001, n_perturb=20, centering="
             shard.all_ok(None, where)
             return out
 
+        fp_log = []  # (what, start, end) in seconds since the call began: the jobs of the first phase (res["first_phase_s"])
+
+        def timed(what, f):
+            def g(*a_, **k_):
+                t0_ = time.perf_counter() - t_all
+                try:
+                    return f(*a_, **k_)
+                finally:
+                    fp_log.append((what, round(t0_, 3), round(time.perf_counter() - t_all, 3)))
+            return g
+
+        def null_spectrum_job(w_):
+            pat_null = timed("null_matrix_wait", null_future.result)()
+            return timed("null_spectrum", w_.null_spectrum_pattern)(pat_null)
+
         # ---- get_sigev (:704) and Vr2 (:717-721): the data, null and binarised matrices are independent decompositions
         spread = shard.world > 1 and spread_initial
         if spread:
@@ -1180,7 +1195,7 @@ def sclens(inp_df, device_="gpu", th=60, p_step=0.001, n_perturb=20, centering="
                         w3.close()
                     c3.close()
             else:
-                (L, rec_vals), Lr = run_all([(0, lambda: ses.data_spectrum(want_rec)), (1, lambda: w_null.null_spectrum_pattern(null_future.result()))])
+                (L, rec_vals), Lr = run_all([(0, lambda: timed("data_spectrum", ses.data_spectrum)(want_rec)), (1, lambda: null_spectrum_job(w_null))])
                 r_vr2 = -1  # decomposed below, next to the signal vectors
         else:  # the main session keeps the data matrix's reflectors for signal_vectors; workers take the other two
             w_null, w_bin = workers[1], workers[2]
@@ -1203,7 +1218,7 @@ def sclens(inp_df, device_="gpu", th=60, p_step=0.001, n_perturb=20, centering="
             finally:
                 _, r_vr2 = bin_chain.result()
         elif r_vr2 == -1:
-            nV, (_, r_vr2) = run_all([(0, lambda: ses.signal_vectors(k)), (1, w_bin.binary_basis)])
+            nV, (_, r_vr2) = run_all([(0, lambda: timed("signal_vectors", ses.signal_vectors)(k)), (1, timed("binary_basis", w_bin.binary_basis))])
         else:
             nV = ses.signal_vectors(k) if (not spread or shard.rank == 0) else None
         if r_vr2 is None:
@@ -1395,7 +1410,8 @@ def sclens(inp_df, device_="gpu", th=60, p_step=0.001, n_perturb=20, centering="
         res: Dict[str, object] = {"L": L, "L_mp": L_mp, "λ": lambda_c, "lambda_c": lambda_c, "cell_id": cell_id,
                                   "p_": p_, "p_th": p_th, "n_search": it, "search_trace": trace,
                                   "partial_eig": pe_counts, "guard_band": guard,
-                                  "gram_bits_used": gram_bits_used, "search_job_s": sorted(job_log, key=lambda q: (q[1], q[0]))}
+                                  "gram_bits_used": gram_bits_used, "search_job_s": sorted(job_log, key=lambda q: (q[1], q[0])),
+                                  "first_phase_s": sorted(fp_log, key=lambda q: q[1])}
         if min_s == 0:  # :780-784
             res["wall_s"] = time.perf_counter() - t_all
             return res

@@ -2977,6 +2977,22 @@ static inline int64_t sbr_q2_img_count(int64_t n) { const int64_t q = n / SB; re
 constexpr int Q_RS32 = 104, Q_NS32 = 40, Q_IMG_A32 = QW * Q_RS32;
 static_assert(Q_IMG_A32 + QH * Q_NS32 <= Q_IMG, "image layout (K = 32)");
 
+// k32 == 2 (variants 14 / 15): ONE copy of the reflectors + the T factor, 16 384 bytes per group instead of 28 672 -- the kernel is
+// bound by the delivery of the images (below), and gfx950's transposing LDS read (`ds_read_b64_tr_b16`) hands the SAME Vg' image to
+// the third product as its row operand: Zw' <- Zw' + Vg (-Tg (Vg' Zw')), three products, the middle one 32 x 32 x 16 per wave.
+//   part A: four planes (s, hl) of 3 072 bytes, s = which 16-row half of a 32-row K step, hl = hi / lo piece; inside a plane
+//           [reflector tile ct 2][K step p 3][512 bytes]; the 8-byte cell of (m = reflector in the tile, p' = 0..3) holds the four
+//           window rows 32 p + 16 s + 4 p' + e at cell index ((m ^ 8 (p' & 1)) & 15) + 16 ((p' >> 1) ^ (m >> 3)) + 32 (m >> 3):
+//           conflict-free for the row reads of the first product, whether they are issued as ds_read_b64 (64 banks, lanes m = 0..15
+//           x p' in {0, 1} or {2, 3} per 32-lane half) or paired by the compiler into ds_read2st64_b64 (32 banks, 16 lanes m = 0..15 of
+//           one p'), and for the transposed reads of the third (64 banks, lanes m = 0..7 or 8..15 x p' = 0..3 per half)
+//   T part: -Tg as the row operand of the middle product, [hl 2][tile ct' 2][g 4][m 16] units of 16 bytes = the eight k slots
+//           {c = 4 g + e} and {c = 16 + 4 g + e} of row c' = 16 ct' + m
+constexpr int Q_IMG2 = 4096, Q2_PLANE = 768, Q2_TOFF = 4 * Q2_PLANE;
+__host__ __device__ __forceinline__ int sbr_q2_cell(int m, int pq) {  // float offset of the cell inside its 512-byte block
+  return 2 * (((m ^ ((pq & 1) << 3)) & 15) + 16 * (((pq >> 1) ^ (m >> 3)) & 1) + 32 * (m >> 3));
+}
+
 __global__ __launch_bounds__(256) void sbr_q2_build_img(const float* __restrict__ V2, int64_t ldv2, const float* __restrict__ TAU2,
                                                         int64_t ldt, int64_t n, float* __restrict__ img, int k32) {
   const int t = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
@@ -3026,6 +3042,38 @@ __global__ __launch_bounds__(256) void sbr_q2_build_img(const float* __restrict_
     Y[r][c] = (float)acc;
   }
   __syncthreads();
+  if (k32 == 2) {
+    float* out2 = img + sbr_q2_img_index(b, t, n) * Q_IMG2;
+    for (int it = tid; it < 2 * 2 * 3 * 16 * 4; it += 256) {
+      const int pq = it & 3, m = (it >> 2) & 15, blk = it >> 6, p = blk % 3, ct = (blk / 3) & 1, sh = blk / 6;
+      f32x4 x;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) x[e] = Vg[32 * p + 16 * sh + 4 * pq + e][16 * ct + m];
+      const SbrHL o = sbr_split_pk(x);
+      const int off = (ct * 3 + p) * 128 + sbr_q2_cell(m, pq);
+      f32x2 rh, rl;
+      __builtin_memcpy(&rh, &o.h, 8);
+      __builtin_memcpy(&rl, &o.l, 8);
+      *reinterpret_cast<f32x2*>(out2 + (2 * sh) * Q2_PLANE + off) = rh;
+      *reinterpret_cast<f32x2*>(out2 + (2 * sh + 1) * Q2_PLANE + off) = rl;
+    }
+    if (tid < 128) {
+      const int m = tid & 15, gq = (tid >> 4) & 3, ct = tid >> 6;
+      f32x4 x0, x1;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        x0[e] = -T[16 * ct + m][4 * gq + e];
+        x1[e] = -T[16 * ct + m][16 + 4 * gq + e];
+      }
+      const SbrHL8 o = sbr_cat(sbr_split_pk(x0), sbr_split_pk(x1));
+      f32x4 rh, rl;
+      __builtin_memcpy(&rh, &o.h, 16);
+      __builtin_memcpy(&rl, &o.l, 16);
+      *reinterpret_cast<f32x4*>(out2 + Q2_TOFF + ((0 * 2 + ct) * 4 + gq) * 64 + 4 * m) = rh;
+      *reinterpret_cast<f32x4*>(out2 + Q2_TOFF + ((1 * 2 + ct) * 4 + gq) * 64 + 4 * m) = rl;
+    }
+    return;
+  }
   float* out = img + sbr_q2_img_index(b, t, n) * Q_IMG;
   if (k32) {
     for (int u = tid; u < Q_IMG / 8; u += 256) {
@@ -3099,11 +3147,12 @@ __device__ __forceinline__ SbrHL sbr_split_pk(f32x4 x) {
 }
 
 // the 7 DMA instructions of one image: lane l of wave w moves bytes [(q 256 + 64 w + l) 16, +16) of the image for q < 7
+template <int NP = 7>
 __device__ __forceinline__ void sbr_q2_dma(const float* __restrict__ img, int64_t index, float* buf, int tid) {
-  const float* src = img + index * Q_IMG + 4 * tid;
+  const float* src = img + index * (NP * 1024) + 4 * tid;
   float* dst = buf + 256 * (tid >> 6);
 #pragma unroll
-  for (int q = 0; q < 7; ++q)
+  for (int q = 0; q < NP; ++q)
     __builtin_amdgcn_global_load_lds((glb_void*)(src + 1024 * q), (lds_void*)(dst + 1024 * q), 16, 0, 0);
 }
 
@@ -3183,6 +3232,63 @@ __device__ __forceinline__ void sbr_q2_group16f(f32x4* z, const float* buf, int 
   for (int rt = 0; rt < 6; ++rt) z[rt] = sbr_mfma3_k32(y[rt], ws, z[rt]);
 }
 
+// the group of variants 14 / 15: three products from the 16 KB image (layout at Q_IMG2)
+typedef __fp16 fp16x4_t __attribute__((__vector_size__(4 * sizeof(__fp16))));
+typedef __attribute__((address_space(3))) fp16x4_t lds_fp16x4;
+__device__ __forceinline__ f16x4 sbr_ld_tr(const float* p) {  // transposing read: EXEC must be all ones (it is: whole-wave code)
+  return __builtin_bit_cast(f16x4, __builtin_amdgcn_ds_read_tr16_b64_v4f16((lds_fp16x4*)p));
+}
+__device__ __forceinline__ f16x4 sbr_ld_h4(const float* p) {
+  const f32x2 r = *reinterpret_cast<const f32x2*>(p);
+  return __builtin_bit_cast(f16x4, r);
+}
+__device__ __forceinline__ f16x8 sbr_cat4(f16x4 a, f16x4 b) { return __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7); }
+__device__ __forceinline__ void sbr_q2_group16t(f32x4* z, const float* buf, int vi, int g) {
+  // W' = Vg' Zw': rows = reflectors (two tiles), K = the 96 window rows in three steps
+  const float* ar = buf + sbr_q2_cell(vi, g);
+  SbrHL8 zz[3];
+#pragma unroll
+  for (int p = 0; p < 3; ++p) zz[p] = sbr_cat(sbr_split_pk(z[2 * p]), sbr_split_pk(z[2 * p + 1]));
+  f32x4 w0 = {0.f, 0.f, 0.f, 0.f}, w1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int p = 0; p < 3; ++p) {
+    SbrHL8 a0, a1;
+    a0.h = sbr_cat4(sbr_ld_h4(ar + p * 128), sbr_ld_h4(ar + 2 * Q2_PLANE + p * 128));
+    a0.l = sbr_cat4(sbr_ld_h4(ar + Q2_PLANE + p * 128), sbr_ld_h4(ar + 3 * Q2_PLANE + p * 128));
+    a1.h = sbr_cat4(sbr_ld_h4(ar + (3 + p) * 128), sbr_ld_h4(ar + 2 * Q2_PLANE + (3 + p) * 128));
+    a1.l = sbr_cat4(sbr_ld_h4(ar + Q2_PLANE + (3 + p) * 128), sbr_ld_h4(ar + 3 * Q2_PLANE + (3 + p) * 128));
+    w0 = sbr_mfma3_k32(a0, zz[p], w0);
+    w1 = sbr_mfma3_k32(a1, zz[p], w1);
+  }
+  // U = -Tg W'
+  const SbrHL8 ws = sbr_cat(sbr_split_pk(w0), sbr_split_pk(w1));
+  const float* tp = buf + Q2_TOFF + g * 64 + 4 * vi;
+  SbrHL8 t0, t1;
+  {
+    const f32x4 h0 = *reinterpret_cast<const f32x4*>(tp), h1 = *reinterpret_cast<const f32x4*>(tp + 256);
+    const f32x4 l0 = *reinterpret_cast<const f32x4*>(tp + 512), l1 = *reinterpret_cast<const f32x4*>(tp + 768);
+    __builtin_memcpy(&t0.h, &h0, 16);
+    __builtin_memcpy(&t1.h, &h1, 16);
+    __builtin_memcpy(&t0.l, &l0, 16);
+    __builtin_memcpy(&t1.l, &l1, 16);
+  }
+  const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+  const f32x4 u0 = sbr_mfma3_k32(t0, ws, zero), u1 = sbr_mfma3_k32(t1, ws, zero);
+  const SbrHL8 us = sbr_cat(sbr_split_pk(u0), sbr_split_pk(u1));
+  // Zw' += Vg U: rows = window rows (six tiles), K = the 32 reflectors; Vg read out of the Vg' image by transposing reads: lane
+  // 4 q + p'' of a 16-lane group addresses the cell of reflector 4 g + q (then 16 + 4 g + q), rows 4 p'' .. 4 p'' + 3 of the tile
+  const int mc = 4 * g + (vi >> 2);
+  const float* at = buf + sbr_q2_cell(mc, vi & 3);
+#pragma unroll
+  for (int rt = 0; rt < 6; ++rt) {
+    const int p = rt >> 1, sh = rt & 1;
+    SbrHL8 y;
+    y.h = sbr_cat4(sbr_ld_tr(at + (2 * sh) * Q2_PLANE + p * 128), sbr_ld_tr(at + (2 * sh) * Q2_PLANE + (3 + p) * 128));
+    y.l = sbr_cat4(sbr_ld_tr(at + (2 * sh + 1) * Q2_PLANE + p * 128), sbr_ld_tr(at + (2 * sh + 1) * Q2_PLANE + (3 + p) * 128));
+    z[rt] = sbr_mfma3_k32(y, us, z[rt]);
+  }
+}
+
 // Window loads / stores of the image-fed kernel: buffer instructions on a resource that covers the workgroup's 64 vectors, one
 // instruction per lane and call WHATEVER the row (quads outside [-3, n - 3] and vectors past m get an offset beyond the resource:
 // the load returns 0, the store is dropped) -- the number of memory instructions between two waits is then a constant, which the
@@ -3205,12 +3311,13 @@ __device__ __forceinline__ void sbr_zst(const SbrZWin& w, int64_t row, f32x4 v) 
 }
 template <int N>
 __device__ __forceinline__ void sbr_vmcnt() {  // at most N vector-memory instructions of this wave may still be in flight
-  static_assert(N == 0 || N == 4 || N == 7 || N == 8 || N == 11 || N == 15, "counts of the image-fed kernel");
+  static_assert(N == 0 || N == 4 || N == 7 || N == 8 || N == 11 || N == 12 || N == 15, "counts of the image-fed kernel");
   if (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   if (N == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
   if (N == 7) asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
   if (N == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
   if (N == 11) asm volatile("s_waitcnt vmcnt(11)" ::: "memory");
+  if (N == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
   if (N == 15) asm volatile("s_waitcnt vmcnt(15)" ::: "memory");
 }
 
@@ -3220,10 +3327,12 @@ __device__ __forceinline__ void sbr_vmcnt() {  // at most N vector-memory instru
 // overlap. With a loader wave on every SIMD the DMA instructions issue beside the other wave's matrix instructions (different issue
 // ports), the compute waves carry no DMA and no counted waits, and the group barrier doubles as the "image has landed" signal (a
 // loader arrives at it only behind its own `vmcnt`).
-template <int QJ, int QNT, int NBUF, bool K32, bool LW>
+template <int QJ, int QNT, int NBUF, bool K32, bool LW, bool TV = false>
 __global__ __launch_bounds__(LW ? 512 : 256, LW ? 1 : 2) void sbr_q2_apply16e(SbrQ2Args a, const float* __restrict__ img, int dbg) {
   static_assert(NBUF == 2 || NBUF == 3, "one or two groups ahead");
-  constexpr int AH = NBUF - 1, DM = (AH == 2) ? 7 : 0;  // DMA instructions that may stay in flight past the end of a group
+  static_assert(!TV || (K32 && !LW), "the 16 KB image is a K = 32 form without loader waves");
+  constexpr int NP = TV ? 4 : 7, QI = NP * 1024;          // DMA pieces (4 KB) and floats per image
+  constexpr int AH = NBUF - 1, DM = (AH == 2) ? NP : 0;  // DMA instructions that may stay in flight past the end of a group
   extern __shared__ __attribute__((aligned(16))) float q2lds[];  // NBUF images
   float* lds = q2lds;
   const int tid = threadIdx.x, lane = tid & 63, vi = lane & 15, g = lane >> 4;
@@ -3244,7 +3353,7 @@ __global__ __launch_bounds__(LW ? 512 : 256, LW ? 1 : 2) void sbr_q2_apply16e(Sb
   // the first AH groups of the sequence: blocks nblk - 1, nblk - 2 at task 0 (QJ > AH)
 #pragma unroll
   for (int i = 0; i < AH; ++i)
-    if (does_dma) sbr_q2_dma(img, index_of(a.nblk - 1 - i, 0), lds + i * Q_IMG, dtid);
+    if (does_dma) sbr_q2_dma<NP>(img, index_of(a.nblk - 1 - i, 0), lds + i * QI, dtid);
   sbr_vmcnt<DM>();
   __syncthreads();
   int cur = 0;
@@ -3284,7 +3393,7 @@ __global__ __launch_bounds__(LW ? 512 : 256, LW ? 1 : 2) void sbr_q2_apply16e(Sb
         asm volatile("" ::: "memory");
         int nxt = cur + AH;
         if (nxt >= NBUF) nxt -= NBUF;
-        if (does_dma && !(dbg & 2)) sbr_q2_dma(img, index_of(nb, nt), lds + nxt * Q_IMG, dtid);  // dbg: timing experiments only (WRONG results)
+        if (does_dma && !(dbg & 2)) sbr_q2_dma<NP>(img, index_of(nb, nt), lds + nxt * QI, dtid);  // dbg: timing experiments only (WRONG results)
         asm volatile("" ::: "memory");
         if (j == 0 && does_math) {  // the window traffic of this task, behind the DMA: 4 stores (rows that left), 4 loads (rows that will enter)
           if (pend) {
@@ -3299,8 +3408,9 @@ __global__ __launch_bounds__(LW ? 512 : 256, LW ? 1 : 2) void sbr_q2_apply16e(Sb
         }
         const int b = bh - j;
         if (does_math && b >= 0 && t < sbr_tasks_of((int64_t)b * QW, a.n) && !(dbg & 1)) {
-          if (K32) sbr_q2_group16f(z + 2 * (QJ - 1 - j), lds + cur * Q_IMG, vi, g);
-          else sbr_q2_group16e(z + 2 * (QJ - 1 - j), lds + cur * Q_IMG, vi, g);
+          if (TV) sbr_q2_group16t(z + 2 * (QJ - 1 - j), lds + cur * QI, vi, g);
+          else if (K32) sbr_q2_group16f(z + 2 * (QJ - 1 - j), lds + cur * QI, vi, g);
+          else sbr_q2_group16e(z + 2 * (QJ - 1 - j), lds + cur * QI, vi, g);
         }
         // the image of the next group must have landed (AH == 1), or the one after it may still be in flight (AH == 2); the window
         // traffic issued in this group (j == 0) may stay in flight as well: it is waited for one group later (j == 1: everything)
@@ -3358,7 +3468,7 @@ __global__ void sbr_q2_shift(const float* __restrict__ in, int64_t ldi, int64_t 
 static int sbr_q2_variant(int64_t n) {
   const char* eq2 = getenv("SCLENS_HIP_Q2_VARIANT");
   int v = eq2 ? atoi(eq2) : 10;
-  if (v >= 8 && v <= 13 && n % SB != 0) v = 7;  // the image index assumes an order that is a multiple of 64 (the two-stage solver pads)
+  if (v >= 8 && v <= 15 && n % SB != 0) v = 7;  // the image index assumes an order that is a multiple of 64 (the two-stage solver pads)
   return v;
 }
 
@@ -3370,9 +3480,10 @@ static int sbr_q2_launch_build_t(Ctx* ctx, int64_t n, hipStream_t st) {
   if (!V2 || !TAU2 || nsweep <= 0) return ctx->fail(SCLENS_ERR_STATE, "sbr_q2_build_t: no reflectors of a preceding sb2st_f32 on this context");
   const int nblk = (int)((nsweep + QW - 1) / QW), nk = (int)((n - 1 + SB - 1) / SB);
   const int variant = sbr_q2_variant(n);
-  if (variant >= 8 && variant <= 13) {
-    SCL_WS(ctx, img, float, "sbr.Q2img", (sbr_q2_img_count(n) + 1) * Q_IMG);
-    hipLaunchKernelGGL(sbr_q2_build_img, dim3((unsigned)nk, (unsigned)nblk), dim3(256), 0, st, V2, ldv2, TAU2, ldt, n, img, variant >= 10 ? 1 : 0);
+  if (variant >= 8 && variant <= 15) {
+    SCL_WS(ctx, img, float, "sbr.Q2img", (sbr_q2_img_count(n) + 1) * (variant >= 14 ? Q_IMG2 : Q_IMG));
+    hipLaunchKernelGGL(sbr_q2_build_img, dim3((unsigned)nk, (unsigned)nblk), dim3(256), 0, st, V2, ldv2, TAU2, ldt, n, img,
+                       variant >= 14 ? 2 : (variant >= 10 ? 1 : 0));
   } else {
     SCL_WS(ctx, Tg, float, "sbr.Tg", (int64_t)nblk * nk * QW * QW);
     hipLaunchKernelGGL(sbr_q2_build_t, dim3((unsigned)nk, (unsigned)nblk), dim3(64), 0, st, V2, ldv2, TAU2, ldt, n, nk, Tg);
@@ -3434,22 +3545,25 @@ int sbr_apply_q2(Ctx* ctx, int64_t n, float* Zt, int64_t m, int64_t ldz) {
   // 8 (default since round 4): pre-built images + LDS-DMA two groups ahead (three LDS buffers, one workgroup per CU); 9: one group
   // ahead (two buffers, two workgroups per CU)
   const dim3 q2grid((unsigned)((m + 63) / 64));
-  if (q2_variant >= 8 && q2_variant <= 13) {
+  if (q2_variant >= 8 && q2_variant <= 15) {
     // 8 / 9: K = 16 matrix instructions, DMA two / one group(s) ahead (three / two LDS buffers); 10 / 11: the K = 32 form, one / two ahead
-    const bool three = (q2_variant == 8 || q2_variant == 11 || q2_variant == 12);  // 12 / 13: loader waves, two / one group(s) ahead
-    const int lds_bytes = (three ? 3 : 2) * Q_IMG * (int)sizeof(float);
+    // 14 / 15: the 16 KB image (one copy of the reflectors + T, transposing LDS reads for the third product), one / two ahead
+    const bool three = (q2_variant == 8 || q2_variant == 11 || q2_variant == 12 || q2_variant == 15);  // 12 / 13: loader waves, two / one group(s) ahead
+    const int lds_bytes = (three ? 3 : 2) * (q2_variant >= 14 ? Q_IMG2 : Q_IMG) * (int)sizeof(float);
     const int q2dbg = getenv("SCLENS_HIP_Q2_DBG") ? atoi(getenv("SCLENS_HIP_Q2_DBG")) : 0;  // 1: no products, 2: no DMA (timing experiments)
-#define SBR_Q2E_LAUNCH(NBUF, K32, LW)                                                                                          \
+#define SBR_Q2E_LAUNCH(NBUF, K32, LW, TV)                                                                                      \
   do {                                                                                                                         \
-    SCL_TRY(ensure_dyn_lds(ctx, reinterpret_cast<const void*>(sbr_q2_apply16e<4, 12, NBUF, K32, LW>), lds_bytes));            \
-    hipLaunchKernelGGL((sbr_q2_apply16e<4, 12, NBUF, K32, LW>), q2grid, dim3(LW ? 512 : 256), lds_bytes, ctx->stream, qa, q2img, q2dbg); \
+    SCL_TRY(ensure_dyn_lds(ctx, reinterpret_cast<const void*>(sbr_q2_apply16e<4, 12, NBUF, K32, LW, TV>), lds_bytes));        \
+    hipLaunchKernelGGL((sbr_q2_apply16e<4, 12, NBUF, K32, LW, TV>), q2grid, dim3(LW ? 512 : 256), lds_bytes, ctx->stream, qa, q2img, q2dbg); \
   } while (0)
-    if (q2_variant == 8) SBR_Q2E_LAUNCH(3, false, false);
-    else if (q2_variant == 9) SBR_Q2E_LAUNCH(2, false, false);
-    else if (q2_variant == 10) SBR_Q2E_LAUNCH(2, true, false);
-    else if (q2_variant == 11) SBR_Q2E_LAUNCH(3, true, false);
-    else if (q2_variant == 12) SBR_Q2E_LAUNCH(3, true, true);
-    else SBR_Q2E_LAUNCH(2, true, true);
+    if (q2_variant == 8) SBR_Q2E_LAUNCH(3, false, false, false);
+    else if (q2_variant == 9) SBR_Q2E_LAUNCH(2, false, false, false);
+    else if (q2_variant == 10) SBR_Q2E_LAUNCH(2, true, false, false);
+    else if (q2_variant == 11) SBR_Q2E_LAUNCH(3, true, false, false);
+    else if (q2_variant == 12) SBR_Q2E_LAUNCH(3, true, true, false);
+    else if (q2_variant == 13) SBR_Q2E_LAUNCH(2, true, true, false);
+    else if (q2_variant == 14) SBR_Q2E_LAUNCH(2, true, false, true);
+    else SBR_Q2E_LAUNCH(3, true, false, true);
 #undef SBR_Q2E_LAUNCH
   } else if (q2_variant == 0)
     hipLaunchKernelGGL((sbr_q2_apply16<4, 12, false>), q2grid, dim3(256), 0, ctx->stream, qa);

@@ -388,7 +388,7 @@ def test_first_back_transformation_group_data_prepared_ahead_gives_the_same_bits
     assert d < 5e-6
 
 
-@pytest.mark.parametrize("variant", ["10", "11", "12", "13", "8", "9", "7", "3"])
+@pytest.mark.parametrize("variant", ["14", "15", "10", "11", "12", "13", "8", "9", "7", "3"])
 @pytest.mark.parametrize("n,m", [(192, 192), (1088, 100), (2560, 70), (640, 641 - 1)])
 def test_second_back_transformation_matches_the_unblocked_reference(ctx, n, m, variant, monkeypatch):
     """The register-resident MFMA version of Q2 (16-vector wave tiles, QJ sweep blocks per pass) against the one-reflector-at-
@@ -443,7 +443,7 @@ def test_second_back_transformation_variants(ctx, monkeypatch):
     Z0 = np.zeros((m, lda), dtype=np.float32)
     Z0[:, :n] = Q.T.astype(np.float32)
     out = {}
-    for v in ("3", "6", "5", "7", "8", "9", "10", "11", "12", "13"):
+    for v in ("3", "6", "5", "7", "8", "9", "10", "11", "12", "13", "14", "15"):
         monkeypatch.setenv("SCLENS_HIP_Q2_VARIANT", v)
         dZ = DevArray(ctx, Z0)
         ctx.check(ctx.lib.sclens_hip_dev_sbr_apply_q2_f32(ctx.h, n, dZ.p, m, lda))
@@ -457,7 +457,9 @@ def test_second_back_transformation_variants(ctx, monkeypatch):
     assert np.abs(out["8"].astype(np.float64) - out["3"]).max() < 4e-6
     assert np.array_equal(out["10"], out["11"]) and np.abs(out["10"].astype(np.float64) - out["3"]).max() < 4e-6
     assert np.array_equal(out["10"], out["12"]) and np.array_equal(out["10"], out["13"])  # loader waves: the same arithmetic
-    for v in ("3", "7", "8", "10"):
+    # 14 / 15: one copy of the reflectors + T in a 16 KB image, the third product's operand by transposing LDS reads: three products
+    assert np.array_equal(out["14"], out["15"]) and np.abs(out["14"].astype(np.float64) - out["3"]).max() < 4e-6
+    for v in ("3", "7", "8", "10", "14"):
         Z = out[v].astype(np.float64)
         assert np.abs(Z @ Z.T - np.eye(m)).max() < 2e-6, v
 
