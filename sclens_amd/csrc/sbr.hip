@@ -2287,6 +2287,7 @@ struct SbrQ2Args {
   int64_t n;
   float* Zq;
   int64_t m, ldq;
+  unsigned long long* prof;  // SCLENS_HIP_Q2_PROF=1 (image-fed kernels): per-phase shader clocks of wave 0 of one workgroup, else null
 };
 
 struct SbrQ2Fetch {
@@ -3358,6 +3359,15 @@ __global__ __launch_bounds__(LW ? 512 : 256, LW ? 1 : 2) void sbr_q2_apply16e(Sb
   __syncthreads();
   int cur = 0;
   f32x4 z[QNT];
+  // phase clocks (a.prof): 0 DMA issue, 1 window loads / stores issue, 2 products, 3 counted wait, 4 barrier, 5 between groups
+  const bool prof = a.prof != nullptr && blockIdx.x == gridDim.x / 2 && tid < 64;
+  unsigned long long pacc[6] = {0, 0, 0, 0, 0, 0}, pn = 0, pt = prof ? __builtin_amdgcn_s_memtime() : 0ull;
+#define SBR_Q2_STAMP(i)                                               \
+  if (prof) {                                                         \
+    const unsigned long long now_ = __builtin_amdgcn_s_memtime();     \
+    pacc[i] += now_ - pt;                                             \
+    pt = now_;                                                        \
+  }
   for (int sb = 0; sb < nsb; ++sb) {
     const int bh = a.nblk - 1 - sb * QJ, blow = bh - QJ + 1;
     const int Kmax = sbr_tasks_of((int64_t)(blow > 0 ? blow : 0) * QW, a.n);
@@ -3391,10 +3401,12 @@ __global__ __launch_bounds__(LW ? 512 : 256, LW ? 1 : 2) void sbr_q2_apply16e(Sb
         }
         // its image goes to the buffer the PREVIOUS group was read from (all waves have passed the barrier behind it)
         asm volatile("" ::: "memory");
+        SBR_Q2_STAMP(5)
         int nxt = cur + AH;
         if (nxt >= NBUF) nxt -= NBUF;
         if (does_dma && !(dbg & 2)) sbr_q2_dma<NP>(img, index_of(nb, nt), lds + nxt * QI, dtid);  // dbg: timing experiments only (WRONG results)
         asm volatile("" ::: "memory");
+        SBR_Q2_STAMP(0)
         if (j == 0 && does_math) {  // the window traffic of this task, behind the DMA: 4 stores (rows that left), 4 loads (rows that will enter)
           if (pend) {
 #pragma unroll
@@ -3406,12 +3418,19 @@ __global__ __launch_bounds__(LW ? 512 : 256, LW ? 1 : 2) void sbr_q2_apply16e(Sb
           }
           asm volatile("" ::: "memory");
         }
+        SBR_Q2_STAMP(1)
         const int b = bh - j;
         if (does_math && b >= 0 && t < sbr_tasks_of((int64_t)b * QW, a.n) && !(dbg & 1)) {
           if (TV) sbr_q2_group16t(z + 2 * (QJ - 1 - j), lds + cur * QI, vi, g);
           else if (K32) sbr_q2_group16f(z + 2 * (QJ - 1 - j), lds + cur * QI, vi, g);
           else sbr_q2_group16e(z + 2 * (QJ - 1 - j), lds + cur * QI, vi, g);
         }
+        if (prof) {  // the products' results are in registers when the stamp is taken
+#pragma unroll
+          for (int i = 0; i < QNT; ++i) asm volatile("" ::"v"(z[i]));
+          asm volatile("s_nop 7\n\ts_nop 7" ::: "memory");
+        }
+        SBR_Q2_STAMP(2)
         // the image of the next group must have landed (AH == 1), or the one after it may still be in flight (AH == 2); the window
         // traffic issued in this group (j == 0) may stay in flight as well: it is waited for one group later (j == 1: everything)
         if (LW) {  // loaders: their DMA only; compute waves: nothing to wait for (the compiler waits where a loaded row is used)
@@ -3424,7 +3443,10 @@ __global__ __launch_bounds__(LW ? 512 : 256, LW ? 1 : 2) void sbr_q2_apply16e(Sb
         } else {
           sbr_vmcnt<DM>();
         }
+        SBR_Q2_STAMP(3)
         __syncthreads();
+        SBR_Q2_STAMP(4)
+        ++pn;
         cur = (cur + 1 == NBUF) ? 0 : cur + 1;
       }
       if (!does_math) continue;
@@ -3442,6 +3464,12 @@ __global__ __launch_bounds__(LW ? 512 : 256, LW ? 1 : 2) void sbr_q2_apply16e(Sb
         pend = false;
       }
     }
+  }
+#undef SBR_Q2_STAMP
+  if (prof && tid == 0) {
+#pragma unroll
+    for (int i = 0; i < 6; ++i) a.prof[i] = pacc[i];
+    a.prof[6] = pn;
   }
 }
 
@@ -3532,7 +3560,14 @@ int sbr_apply_q2(Ctx* ctx, int64_t n, float* Zt, int64_t m, int64_t ldz) {
     hipLaunchKernelGGL(sbr_q2_shift, dim3((unsigned)((n + 255) / 256), (unsigned)rows), dim3(256), 0, ctx->stream, Zt + r0 * ldz, ldz,
                        (int64_t)0, Zq + r0 * ldq, ldq, (int64_t)3, n);
   }
-  SbrQ2Args qa{V2, ldv2, Tg, nk, nblk, n, Zq, m, ldq};
+  SbrQ2Args qa{V2, ldv2, Tg, nk, nblk, n, Zq, m, ldq, nullptr};
+  if (const char* ep = getenv("SCLENS_HIP_Q2_PROF")) {
+    if (atoi(ep) > 0) {
+      qa.prof = static_cast<unsigned long long*>(ctx->workspace("sbr.q2prof", 8 * sizeof(unsigned long long)));
+      if (!qa.prof) return SCLENS_ERR_OOM;
+      SCL_HIP(ctx, hipMemsetAsync(qa.prof, 0, 8 * sizeof(unsigned long long), ctx->stream));
+    }
+  }
   // Measured and dropped (n = 30 016, m = 15 008; this kernel: 510 ms): a barrier-free variant with per-wave LDS images filled by
   // LDS-DMA (617 ms: 48 DMA instructions per group and wave cost as many issue cycles as the group's 92 MFMAs), one barrier per
   // step of four groups instead of one per group (533 ms), 2 / 8 sweep blocks per pass (599 / 1020 ms), wave-uniform scalar
@@ -3583,6 +3618,18 @@ int sbr_apply_q2(Ctx* ctx, int64_t n, float* Zt, int64_t m, int64_t ldz) {
                        (int64_t)3, Zt + r0 * ldz, ldz, (int64_t)0, n);
   }
   SCL_HIP(ctx, hipGetLastError());
+  if (qa.prof) {
+    unsigned long long h[8];
+    SCL_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    SCL_HIP(ctx, hipMemcpy(h, qa.prof, sizeof(h), hipMemcpyDeviceToHost));
+    static const char* nm[6] = {"DMA issue", "window loads / stores issue", "products", "counted wait", "barrier", "between groups"};
+    unsigned long long tot = 0;
+    for (int i = 0; i < 6; ++i) tot += h[i];
+    fprintf(stderr, "[sbr_q2 variant %d] n = %lld, m = %lld: %llu groups, %.0f shader clocks per group (wave 0 of one workgroup)\n", q2_variant, (long long)n,
+            (long long)m, h[6], (double)tot / (double)std::max<unsigned long long>(1, h[6]));
+    for (int i = 0; i < 6; ++i)
+      fprintf(stderr, "   %-30s %8.0f clocks (%4.1f %%)\n", nm[i], (double)h[i] / (double)std::max<unsigned long long>(1, h[6]), 100.0 * h[i] / (double)std::max<unsigned long long>(1, tot));
+  }
   return SCLENS_OK;
 }
 
