@@ -3245,47 +3245,125 @@ __device__ __forceinline__ f16x4 sbr_ld_h4(const float* p) {
 }
 __device__ __forceinline__ f16x8 sbr_cat4(f16x4 a, f16x4 b) { return __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7); }
 __device__ __forceinline__ void sbr_q2_group16t(f32x4* z, const float* buf, int vi, int g) {
-  // W' = Vg' Zw': rows = reflectors (two tiles), K = the 96 window rows in three steps
-  const float* ar = buf + sbr_q2_cell(vi, g);
+  // With one wave per SIMD (m = n / 2: 938 wave tiles for 1 024 SIMDs) nothing hides a wave's own latencies, and left to itself the
+  // compiler puts every LDS read next to its use (~20 exposed round trips per group, profiles/r04_q2_phase_clocks.log); a scheduling
+  // barrier does not stop it, a memory-clobbering statement makes it wait for the reads at once, and it guards the transposing read
+  // (a builtin) with `s_waitcnt vmcnt(0)`, i.e. with the DMA of the images still in flight. So the LDS reads of this function are
+  // volatile statements (kept in program order), each stage's reads are all in flight before the arithmetic that hides them, and the
+  // waits are written out: one `lgkmcnt(0)` per stage, tied to the registers it releases.
+  const unsigned lb = (unsigned)(__UINTPTR_TYPE__)(lds_void*)buf;
+  // (1) operands of W' = Vg' Zw' (rows = reflectors, two tiles; K = the 96 window rows in three steps) and of U = -Tg W'
+  const unsigned aa = lb + 4u * (unsigned)sbr_q2_cell(vi, g);
+  f32x2 ah[2][3][2], al[2][3][2];  // [reflector tile][K step][16-row half]
+  asm volatile("ds_read_b64 %0, %1 offset:0" : "=v"(ah[0][0][0]) : "v"(aa));
+  asm volatile("ds_read_b64 %0, %1 offset:3072" : "=v"(al[0][0][0]) : "v"(aa));
+  asm volatile("ds_read_b64 %0, %1 offset:6144" : "=v"(ah[0][0][1]) : "v"(aa));
+  asm volatile("ds_read_b64 %0, %1 offset:9216" : "=v"(al[0][0][1]) : "v"(aa));
+  asm volatile("ds_read_b64 %0, %1 offset:512" : "=v"(ah[0][1][0]) : "v"(aa));
+  asm volatile("ds_read_b64 %0, %1 offset:3584" : "=v"(al[0][1][0]) : "v"(aa));
+  asm volatile("ds_read_b64 %0, %1 offset:6656" : "=v"(ah[0][1][1]) : "v"(aa));
+  asm volatile("ds_read_b64 %0, %1 offset:9728" : "=v"(al[0][1][1]) : "v"(aa));
+  asm volatile("ds_read_b64 %0, %1 offset:1024" : "=v"(ah[0][2][0]) : "v"(aa));
+  asm volatile("ds_read_b64 %0, %1 offset:4096" : "=v"(al[0][2][0]) : "v"(aa));
+  asm volatile("ds_read_b64 %0, %1 offset:7168" : "=v"(ah[0][2][1]) : "v"(aa));
+  asm volatile("ds_read_b64 %0, %1 offset:10240" : "=v"(al[0][2][1]) : "v"(aa));
+  asm volatile("ds_read_b64 %0, %1 offset:1536" : "=v"(ah[1][0][0]) : "v"(aa));
+  asm volatile("ds_read_b64 %0, %1 offset:4608" : "=v"(al[1][0][0]) : "v"(aa));
+  asm volatile("ds_read_b64 %0, %1 offset:7680" : "=v"(ah[1][0][1]) : "v"(aa));
+  asm volatile("ds_read_b64 %0, %1 offset:10752" : "=v"(al[1][0][1]) : "v"(aa));
+  asm volatile("ds_read_b64 %0, %1 offset:2048" : "=v"(ah[1][1][0]) : "v"(aa));
+  asm volatile("ds_read_b64 %0, %1 offset:5120" : "=v"(al[1][1][0]) : "v"(aa));
+  asm volatile("ds_read_b64 %0, %1 offset:8192" : "=v"(ah[1][1][1]) : "v"(aa));
+  asm volatile("ds_read_b64 %0, %1 offset:11264" : "=v"(al[1][1][1]) : "v"(aa));
+  asm volatile("ds_read_b64 %0, %1 offset:2560" : "=v"(ah[1][2][0]) : "v"(aa));
+  asm volatile("ds_read_b64 %0, %1 offset:5632" : "=v"(al[1][2][0]) : "v"(aa));
+  asm volatile("ds_read_b64 %0, %1 offset:8704" : "=v"(ah[1][2][1]) : "v"(aa));
+  asm volatile("ds_read_b64 %0, %1 offset:11776" : "=v"(al[1][2][1]) : "v"(aa));
+  const unsigned ta = lb + 4u * (unsigned)(Q2_TOFF + g * 64 + 4 * vi);
+  f32x4 th[2], tl[2];
+  asm volatile("ds_read_b128 %0, %1 offset:0" : "=v"(th[0]) : "v"(ta));
+  asm volatile("ds_read_b128 %0, %1 offset:2048" : "=v"(tl[0]) : "v"(ta));
+  asm volatile("ds_read_b128 %0, %1 offset:1024" : "=v"(th[1]) : "v"(ta));
+  asm volatile("ds_read_b128 %0, %1 offset:3072" : "=v"(tl[1]) : "v"(ta));
+  // (2) the window in fp16 pieces: vector instructions under the reads' latency (the window passes through a volatile statement
+  //     behind the reads, so that its splits cannot be scheduled in front of them)
+  asm volatile("" : "+v"(z[0]), "+v"(z[1]), "+v"(z[2]), "+v"(z[3]), "+v"(z[4]), "+v"(z[5]));
   SbrHL8 zz[3];
 #pragma unroll
   for (int p = 0; p < 3; ++p) zz[p] = sbr_cat(sbr_split_pk(z[2 * p]), sbr_split_pk(z[2 * p + 1]));
+  asm volatile("s_waitcnt lgkmcnt(0)"
+               : "+v"(ah[0][0][0]), "+v"(ah[0][0][1]), "+v"(ah[0][1][0]), "+v"(ah[0][1][1]), "+v"(ah[0][2][0]), "+v"(ah[0][2][1]),
+                 "+v"(ah[1][0][0]), "+v"(ah[1][0][1]), "+v"(ah[1][1][0]), "+v"(ah[1][1][1]), "+v"(ah[1][2][0]), "+v"(ah[1][2][1]),
+                 "+v"(al[0][0][0]), "+v"(al[0][0][1]), "+v"(al[0][1][0]), "+v"(al[0][1][1]), "+v"(al[0][2][0]), "+v"(al[0][2][1]),
+                 "+v"(al[1][0][0]), "+v"(al[1][0][1]), "+v"(al[1][1][0]), "+v"(al[1][1][1]), "+v"(al[1][2][0]), "+v"(al[1][2][1]),
+                 "+v"(th[0]), "+v"(th[1]), "+v"(tl[0]), "+v"(tl[1]));
+  // (3) W'
   f32x4 w0 = {0.f, 0.f, 0.f, 0.f}, w1 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
   for (int p = 0; p < 3; ++p) {
     SbrHL8 a0, a1;
-    a0.h = sbr_cat4(sbr_ld_h4(ar + p * 128), sbr_ld_h4(ar + 2 * Q2_PLANE + p * 128));
-    a0.l = sbr_cat4(sbr_ld_h4(ar + Q2_PLANE + p * 128), sbr_ld_h4(ar + 3 * Q2_PLANE + p * 128));
-    a1.h = sbr_cat4(sbr_ld_h4(ar + (3 + p) * 128), sbr_ld_h4(ar + 2 * Q2_PLANE + (3 + p) * 128));
-    a1.l = sbr_cat4(sbr_ld_h4(ar + Q2_PLANE + (3 + p) * 128), sbr_ld_h4(ar + 3 * Q2_PLANE + (3 + p) * 128));
+    a0.h = sbr_cat4(__builtin_bit_cast(f16x4, ah[0][p][0]), __builtin_bit_cast(f16x4, ah[0][p][1]));
+    a0.l = sbr_cat4(__builtin_bit_cast(f16x4, al[0][p][0]), __builtin_bit_cast(f16x4, al[0][p][1]));
+    a1.h = sbr_cat4(__builtin_bit_cast(f16x4, ah[1][p][0]), __builtin_bit_cast(f16x4, ah[1][p][1]));
+    a1.l = sbr_cat4(__builtin_bit_cast(f16x4, al[1][p][0]), __builtin_bit_cast(f16x4, al[1][p][1]));
     w0 = sbr_mfma3_k32(a0, zz[p], w0);
     w1 = sbr_mfma3_k32(a1, zz[p], w1);
   }
-  // U = -Tg W'
+  // (4) Vg for the third product out of the same image by transposing reads, all 24 in flight behind the matrix instructions of (3)
+  //     (the address passes through a statement that reads W'): lane 4 q + p'' of a 16-lane group addresses the cell of reflector
+  //     4 g + q (then 16 + 4 g + q), rows 4 p'' .. 4 p'' + 3 of the tile
+  unsigned ya = lb + 4u * (unsigned)sbr_q2_cell(4 * g + (vi >> 2), vi & 3);
+  asm volatile("" : "+v"(ya), "+v"(w0), "+v"(w1));
+  f32x2 yh[6][2], yl[6][2];  // [window-row tile][reflector tile]
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:0" : "=v"(yh[0][0]) : "v"(ya));
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:3072" : "=v"(yl[0][0]) : "v"(ya));
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:1536" : "=v"(yh[0][1]) : "v"(ya));
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:4608" : "=v"(yl[0][1]) : "v"(ya));
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:6144" : "=v"(yh[1][0]) : "v"(ya));
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:9216" : "=v"(yl[1][0]) : "v"(ya));
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:7680" : "=v"(yh[1][1]) : "v"(ya));
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:10752" : "=v"(yl[1][1]) : "v"(ya));
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:512" : "=v"(yh[2][0]) : "v"(ya));
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:3584" : "=v"(yl[2][0]) : "v"(ya));
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:2048" : "=v"(yh[2][1]) : "v"(ya));
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:5120" : "=v"(yl[2][1]) : "v"(ya));
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:6656" : "=v"(yh[3][0]) : "v"(ya));
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:9728" : "=v"(yl[3][0]) : "v"(ya));
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:8192" : "=v"(yh[3][1]) : "v"(ya));
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:11264" : "=v"(yl[3][1]) : "v"(ya));
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:1024" : "=v"(yh[4][0]) : "v"(ya));
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:4096" : "=v"(yl[4][0]) : "v"(ya));
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:2560" : "=v"(yh[4][1]) : "v"(ya));
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:5632" : "=v"(yl[4][1]) : "v"(ya));
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:7168" : "=v"(yh[5][0]) : "v"(ya));
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:10240" : "=v"(yl[5][0]) : "v"(ya));
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:8704" : "=v"(yh[5][1]) : "v"(ya));
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:11776" : "=v"(yl[5][1]) : "v"(ya));
+  // (5) U = -Tg W'
   const SbrHL8 ws = sbr_cat(sbr_split_pk(w0), sbr_split_pk(w1));
-  const float* tp = buf + Q2_TOFF + g * 64 + 4 * vi;
-  SbrHL8 t0, t1;
-  {
-    const f32x4 h0 = *reinterpret_cast<const f32x4*>(tp), h1 = *reinterpret_cast<const f32x4*>(tp + 256);
-    const f32x4 l0 = *reinterpret_cast<const f32x4*>(tp + 512), l1 = *reinterpret_cast<const f32x4*>(tp + 768);
-    __builtin_memcpy(&t0.h, &h0, 16);
-    __builtin_memcpy(&t1.h, &h1, 16);
-    __builtin_memcpy(&t0.l, &l0, 16);
-    __builtin_memcpy(&t1.l, &l1, 16);
-  }
+  f16x8 t0h, t1h, t0l, t1l;
+  __builtin_memcpy(&t0h, &th[0], 16);
+  __builtin_memcpy(&t1h, &th[1], 16);
+  __builtin_memcpy(&t0l, &tl[0], 16);
+  __builtin_memcpy(&t1l, &tl[1], 16);
   const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
-  const f32x4 u0 = sbr_mfma3_k32(t0, ws, zero), u1 = sbr_mfma3_k32(t1, ws, zero);
+  f32x4 u0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(t0h, ws.h, zero, 0, 0, 0);
+  f32x4 u1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(t1h, ws.h, zero, 0, 0, 0);
+  u0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(t0h, ws.l, u0, 0, 0, 0);
+  u1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(t1h, ws.l, u1, 0, 0, 0);
+  u0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(t0l, ws.h, u0, 0, 0, 0);
+  u1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(t1l, ws.h, u1, 0, 0, 0);
   const SbrHL8 us = sbr_cat(sbr_split_pk(u0), sbr_split_pk(u1));
-  // Zw' += Vg U: rows = window rows (six tiles), K = the 32 reflectors; Vg read out of the Vg' image by transposing reads: lane
-  // 4 q + p'' of a 16-lane group addresses the cell of reflector 4 g + q (then 16 + 4 g + q), rows 4 p'' .. 4 p'' + 3 of the tile
-  const int mc = 4 * g + (vi >> 2);
-  const float* at = buf + sbr_q2_cell(mc, vi & 3);
+  asm volatile("s_waitcnt lgkmcnt(0)"
+               : "+v"(yh[0][0]), "+v"(yh[0][1]), "+v"(yh[1][0]), "+v"(yh[1][1]), "+v"(yh[2][0]), "+v"(yh[2][1]), "+v"(yh[3][0]), "+v"(yh[3][1]),
+                 "+v"(yh[4][0]), "+v"(yh[4][1]), "+v"(yh[5][0]), "+v"(yh[5][1]), "+v"(yl[0][0]), "+v"(yl[0][1]), "+v"(yl[1][0]), "+v"(yl[1][1]),
+                 "+v"(yl[2][0]), "+v"(yl[2][1]), "+v"(yl[3][0]), "+v"(yl[3][1]), "+v"(yl[4][0]), "+v"(yl[4][1]), "+v"(yl[5][0]), "+v"(yl[5][1]));
+  // (6) Zw' += Vg U: rows = window rows (six tiles), K = the 32 reflectors
 #pragma unroll
   for (int rt = 0; rt < 6; ++rt) {
-    const int p = rt >> 1, sh = rt & 1;
     SbrHL8 y;
-    y.h = sbr_cat4(sbr_ld_tr(at + (2 * sh) * Q2_PLANE + p * 128), sbr_ld_tr(at + (2 * sh) * Q2_PLANE + (3 + p) * 128));
-    y.l = sbr_cat4(sbr_ld_tr(at + (2 * sh + 1) * Q2_PLANE + p * 128), sbr_ld_tr(at + (2 * sh + 1) * Q2_PLANE + (3 + p) * 128));
+    y.h = sbr_cat4(__builtin_bit_cast(f16x4, yh[rt][0]), __builtin_bit_cast(f16x4, yh[rt][1]));
+    y.l = sbr_cat4(__builtin_bit_cast(f16x4, yl[rt][0]), __builtin_bit_cast(f16x4, yl[rt][1]));
     z[rt] = sbr_mfma3_k32(y, us, z[rt]);
   }
 }
@@ -3359,6 +3437,7 @@ __global__ __launch_bounds__(LW ? 512 : 256, LW ? 1 : 2) void sbr_q2_apply16e(Sb
   __syncthreads();
   int cur = 0;
   f32x4 z[QNT];
+  const bool raw_barrier = !(dbg & 4);  // SCLENS_HIP_Q2_DBG=4: __syncthreads() per group, as until the end of round 4 (A/B)
   // phase clocks (a.prof): 0 DMA issue, 1 window loads / stores issue, 2 products, 3 counted wait, 4 barrier, 5 between groups
   const bool prof = a.prof != nullptr && blockIdx.x == gridDim.x / 2 && tid < 64;
   unsigned long long pacc[6] = {0, 0, 0, 0, 0, 0}, pn = 0, pt = prof ? __builtin_amdgcn_s_memtime() : 0ull;
@@ -3444,7 +3523,12 @@ __global__ __launch_bounds__(LW ? 512 : 256, LW ? 1 : 2) void sbr_q2_apply16e(Sb
           sbr_vmcnt<DM>();
         }
         SBR_Q2_STAMP(3)
-        __syncthreads();
+        // a bare barrier: __syncthreads() carries a workgroup-scope release fence, which the compiler implements as `s_waitcnt vmcnt(0)`
+        // -- every group then waited for ALL of the wave's memory instructions (the image two groups ahead, the window loads and
+        // stores), and the counted waits above were void (found in the ISA at the end of round 4: why two groups ahead never paid).
+        // What the barrier has to guarantee here is covered by the counted wait of every wave for its own pieces of the image.
+        if (raw_barrier) __builtin_amdgcn_s_barrier();
+        else __syncthreads();
         SBR_Q2_STAMP(4)
         ++pn;
         cur = (cur + 1 == NBUF) ? 0 : cur + 1;
