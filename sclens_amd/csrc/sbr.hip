@@ -3438,6 +3438,7 @@ __global__ __launch_bounds__(LW ? 512 : 256, LW ? 1 : 2) void sbr_q2_apply16e(Sb
   int cur = 0;
   f32x4 z[QNT];
   const bool raw_barrier = !(dbg & 4);  // SCLENS_HIP_Q2_DBG=4: __syncthreads() per group, as until the end of round 4 (A/B)
+  const bool late_win = !LW && !(dbg & 8);  // SCLENS_HIP_Q2_DBG=8: the window traffic right behind the DMA pieces (A/B)
   // phase clocks (a.prof): 0 DMA issue, 1 window loads / stores issue, 2 products, 3 counted wait, 4 barrier, 5 between groups
   const bool prof = a.prof != nullptr && blockIdx.x == gridDim.x / 2 && tid < 64;
   unsigned long long pacc[6] = {0, 0, 0, 0, 0, 0}, pn = 0, pt = prof ? __builtin_amdgcn_s_memtime() : 0ull;
@@ -3486,7 +3487,10 @@ __global__ __launch_bounds__(LW ? 512 : 256, LW ? 1 : 2) void sbr_q2_apply16e(Sb
         if (does_dma && !(dbg & 2)) sbr_q2_dma<NP>(img, index_of(nb, nt), lds + nxt * QI, dtid);  // dbg: timing experiments only (WRONG results)
         asm volatile("" ::: "memory");
         SBR_Q2_STAMP(0)
-        if (j == 0 && does_math) {  // the window traffic of this task, behind the DMA: 4 stores (rows that left), 4 loads (rows that will enter)
+        // the window traffic of this task, behind the DMA: 4 stores (rows that left), 4 loads (rows that will enter). Issued right behind
+        // the DMA pieces it cost 550 clocks per group (the instructions queue up behind the workgroup's 16-28 pieces); behind the
+        // products the queue is empty (`late_win`, the default without loader waves).
+        auto window_traffic = [&]() {
           if (pend) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) sbr_zst(zw, base - SB + 16 * i + 4 * g, zout[i]);
@@ -3496,7 +3500,8 @@ __global__ __launch_bounds__(LW ? 512 : 256, LW ? 1 : 2) void sbr_q2_apply16e(Sb
             for (int i = 0; i < 4; ++i) pz[i] = sbr_zld(zw, base + 16 * (QNT + i) + 4 * g);
           }
           asm volatile("" ::: "memory");
-        }
+        };
+        if (j == 0 && does_math && !late_win) window_traffic();
         SBR_Q2_STAMP(1)
         const int b = bh - j;
         if (does_math && b >= 0 && t < sbr_tasks_of((int64_t)b * QW, a.n) && !(dbg & 1)) {
@@ -3510,11 +3515,18 @@ __global__ __launch_bounds__(LW ? 512 : 256, LW ? 1 : 2) void sbr_q2_apply16e(Sb
           asm volatile("s_nop 7\n\ts_nop 7" ::: "memory");
         }
         SBR_Q2_STAMP(2)
+        if (j == 0 && does_math && late_win) {
+          asm volatile("" ::: "memory");
+          window_traffic();
+          SBR_Q2_STAMP(1)
+        }
         // the image of the next group must have landed (AH == 1), or the one after it may still be in flight (AH == 2); the window
         // traffic issued in this group (j == 0) may stay in flight as well: it is waited for one group later (j == 1: everything)
         if (LW) {  // loaders: their DMA only; compute waves: nothing to wait for (the compiler waits where a loaded row is used)
           if (loader) sbr_vmcnt<DM>();
-        } else if (j == 0) {
+        } else if (j == 0 || (j == 1 && AH == 2 && late_win)) {
+          // (two groups ahead: the image needed next was requested BEFORE this task's window traffic, so that may stay in flight for
+          // one more group)
           const int nz = (pend ? 4 : 0) + (more ? 4 : 0);
           if (nz == 8) sbr_vmcnt<DM + 8>();
           else if (nz == 4) sbr_vmcnt<DM + 4>();
