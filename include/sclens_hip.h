@@ -115,6 +115,11 @@ int sclens_hip_counts_upload(sclens_hip_ctx* ctx, int64_t N, int64_t M, const in
 int sclens_hip_counts_info(const sclens_hip_counts* counts, int64_t* N, int64_t* M, int64_t* nnz);
 int sclens_hip_counts_download(sclens_hip_ctx* ctx, const sclens_hip_counts* counts, int64_t* colptr, int32_t* rowval, float* nzval);
 void sclens_hip_counts_destroy(sclens_hip_counts* counts);
+/* Page-locked host memory for arrays the host fills and the library uploads (the null matrix drawn by sclens_draw_null_matrix: 1.1 GB of
+ * row indices and values at 100 000 x 30 000, which cross PCIe at a third of the link's rate out of pageable memory). No reference
+ * counterpart (the reference uploads dense Float32 matrices with CuArray(), scLENS.jl:346-352). SCLENS_ERR_NO_DEVICE without a HIP device. */
+int sclens_hip_host_alloc(int64_t bytes, void** out);
+void sclens_hip_host_free(void* p);
 
 /* logn_scale(pre_scale(x))  (scLENS.jl:650-654: proj_l :607 -> log1p -> zscore_with_l2 :596-605 -> scaled_gdata "cent"
  * :300-305 for centering="mean"; scaled_gdata "median" :291-298 -> norm_l :608 for centering="median") and, with

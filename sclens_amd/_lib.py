@@ -62,6 +62,8 @@ SIGNATURES = {
     "sclens_hip_counts_info": (C.c_int, [vp, c_i64p, c_i64p, c_i64p]),
     "sclens_hip_counts_download": (C.c_int, [vp, vp, c_i64p, c_i32p, c_f32p]),
     "sclens_hip_counts_destroy": (None, [vp]),
+    "sclens_hip_host_alloc": (C.c_int, [i64, C.POINTER(vp)]),
+    "sclens_hip_host_free": (None, [vp]),
     "sclens_hip_session_create_from_counts": (C.c_int, [vp, vp, C.POINTER(vp)]),
     "sclens_hip_pattern_create_drawn_from_counts": (C.c_int, [vp, vp, C.c_uint64, C.POINTER(vp), c_i64p]),
     "sclens_hip_session_create_sharded": (C.c_int, [vp, i64, i64, i64, i64, c_i64p, c_i32p, c_f32p, i64, c_u32p, c_u32p, ALLREDUCE_FN,

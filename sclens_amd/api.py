@@ -374,6 +374,71 @@ def _resolve(x):
 _draw_pool = ThreadPoolExecutor(max_workers=2)
 
 
+class _PinnedBlock:
+    """one page-locked host block (sclens_hip_host_alloc); goes back to the pool's free list when the last array built on it dies"""
+
+    def __init__(self, pool, addr, nbytes):
+        self.pool, self.addr, self.nbytes = pool, addr, nbytes
+
+    def __del__(self):
+        try:
+            self.pool._give_back(self.addr, self.nbytes)
+        except Exception:  # interpreter shutdown
+            pass
+
+
+class _PinnedPool:
+    """Arrays in page-locked host memory for what the host draws and the library uploads (the null matrix: row indices + values,
+    1.1 GB at 100 000 x 30 000 -- from pageable memory the upload took 0.3 s of the 0.6 s the null decomposition waited for its
+    pattern). A block is reused by the next call once every array on it has been garbage collected; without a HIP device
+    `array()` returns None and the caller takes ordinary memory."""
+    CAP_BYTES = 8 << 30  # idle blocks beyond this are freed
+
+    def __init__(self):
+        self.lock = threading.Lock()
+        self.free = {}  # nbytes -> [address]
+        self.idle = 0
+
+    def array(self, count: int, dtype):
+        dtype = np.dtype(dtype)
+        nbytes = max(1, -(-int(count) * dtype.itemsize // (2 << 20))) * (2 << 20)
+        with self.lock:
+            lst = self.free.get(nbytes)
+            addr = lst.pop() if lst else None
+            if addr is not None:
+                self.idle -= nbytes
+        if addr is None:
+            try:
+                lib = _lib.load()
+                out = C.c_void_p()
+                if lib.sclens_hip_host_alloc(nbytes, C.byref(out)) != 0 or not out.value:
+                    return None
+                addr = out.value
+            except Exception:
+                return None
+        buf = (C.c_char * nbytes).from_address(addr)
+        buf._sclens_block = _PinnedBlock(self, addr, nbytes)  # lives as long as `buf`, i.e. as long as any array built on it
+        return np.frombuffer(buf, dtype=dtype, count=int(count))
+
+    def _give_back(self, addr, nbytes):
+        with self.lock:
+            if self.idle + nbytes <= self.CAP_BYTES:
+                self.free.setdefault(nbytes, []).append(addr)
+                self.idle += nbytes
+                return
+        _lib.load().sclens_hip_host_free(C.c_void_p(addr))
+
+    def trim(self):
+        with self.lock:
+            blocks, self.free, self.idle = self.free, {}, 0
+        for lst in blocks.values():
+            for addr in lst:
+                _lib.load().sclens_hip_host_free(C.c_void_p(addr))
+
+
+_pinned = _PinnedPool()
+
+
 class _FutureItem:
     """item `i` of a future's tuple result, resolved by `_resolve`"""
 
@@ -426,8 +491,12 @@ def make_draws_native(X, seed: int, host_sampler: bool = False, async_null: bool
         z1, z2 = candidates()
 
     def null_matrix():
-        rrow = np.empty(nnz_total, dtype=np.int32)
-        rval = np.empty(nnz_total, dtype=np.float32)
+        rrow = rval = None
+        if nnz_total >= (1 << 22) and os.environ.get("SCLENS_PINNED_DRAWS", "1") != "0":  # page-locked: the arrays go to the device next
+            rrow, rval = _pinned.array(nnz_total, np.int32), _pinned.array(nnz_total, np.float32)
+        if rrow is None or rval is None:
+            rrow = np.empty(nnz_total, dtype=np.int32)
+            rval = np.empty(nnz_total, dtype=np.float32)
         rc2 = lib.sclens_draw_null_matrix(N, M, ptr(cp, C.c_int64), ptr(nz, C.c_float), (int(seed) + 1) & _M64,
                                           ptr(rrow, C.c_int32), ptr(rval, C.c_float))
         if rc2:

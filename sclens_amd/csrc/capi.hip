@@ -208,6 +208,25 @@ void sclens_hip_counts_destroy(sclens_hip_counts* counts) {
   hipSetDevice(reinterpret_cast<scl::Counts*>(counts)->device);
   scl::counts_free(reinterpret_cast<scl::Counts*>(counts));
 }
+int sclens_hip_host_alloc(int64_t bytes, void** out) {
+  if (!out || bytes <= 0) return SCLENS_ERR_ARG;
+  *out = nullptr;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
+    (void)hipGetLastError();
+    return SCLENS_ERR_NO_DEVICE;
+  }
+  void* p = nullptr;
+  if (hipHostMalloc(&p, (size_t)bytes, hipHostMallocPortable) != hipSuccess || !p) {
+    (void)hipGetLastError();
+    return SCLENS_ERR_OOM;
+  }
+  *out = p;
+  return SCLENS_OK;
+}
+void sclens_hip_host_free(void* p) {
+  if (p) (void)hipHostFree(p);
+}
 int sclens_hip_session_create_from_counts(sclens_hip_ctx* h, const sclens_hip_counts* counts, sclens_hip_session** out) {
   CTX_GUARD(h);
   if (!out || !counts) return SCLENS_ERR_ARG;

@@ -77,3 +77,42 @@ def test_sclens_with_device_drawn_candidates(ctx):
         assert p1 == p2 and np.array_equal(t1, t2)
     assert np.array_equal(a["L"], b["L"]) and np.array_equal(a["sig_id"], b["sig_id"])
     assert np.array_equal(a["robustness_scores"]["b_"], b["robustness_scores"]["b_"])
+
+
+def test_null_matrix_in_page_locked_memory(ctx, monkeypatch):
+    """the null matrix drawn into page-locked host blocks (sclens_hip_host_alloc, above 4M stored entries) is the matrix drawn into
+    ordinary memory, its pattern on the device is the same, and a block is handed out again once the matrix built on it is gone"""
+    import gc
+
+    def block(arr):  # the page-locked block under an array (views of views of the ctypes buffer the pool wrapped)
+        while isinstance(arr, np.ndarray):
+            arr = arr.base
+        return arr._sclens_block
+
+    X = api._csc_f32(synth_counts(30000, 1500, seed=9, C=3))
+    assert X.nnz >= (1 << 22), X.nnz
+    monkeypatch.setenv("SCLENS_PINNED_DRAWS", "0")
+    plain = api.make_draws_native(X, seed=77).X_r
+    monkeypatch.setenv("SCLENS_PINNED_DRAWS", "1")
+    api._pinned.trim()
+    pinned = api.make_draws_native(X, seed=77).X_r
+    assert api._pinned.idle == 0 and block(pinned.indices).nbytes >= 4 * X.nnz  # really on page-locked blocks, both in use
+    assert np.array_equal(pinned.indptr, plain.indptr) and np.array_equal(pinned.indices, plain.indices)
+    assert np.array_equal(pinned.data, plain.data)
+    pa, pb = api.Pattern(ctx, plain, [], []), api.Pattern(ctx, pinned, [], [])
+    try:
+        for w, c in enumerate(COUNTS(pa, plain)):
+            assert np.array_equal(pa.download(w, c), pb.download(w, c)), w
+    finally:
+        pa.close()
+        pb.close()
+    addrs = {block(pinned.indices).addr, block(pinned.data).addr}
+    del pinned, pb
+    gc.collect()
+    assert api._pinned.idle > 0  # both blocks are back on the free list ...
+    again = api.make_draws_native(X, seed=78).X_r
+    assert {block(again.indices).addr, block(again.data).addr} == addrs  # ... and are handed out again
+    del again
+    gc.collect()
+    api._pinned.trim()
+    assert api._pinned.idle == 0
