@@ -3438,7 +3438,7 @@ __global__ __launch_bounds__(LW ? 512 : 256, LW ? 1 : 2) void sbr_q2_apply16e(Sb
   int cur = 0;
   f32x4 z[QNT];
   const bool raw_barrier = !(dbg & 4);  // SCLENS_HIP_Q2_DBG=4: __syncthreads() per group, as until the end of round 4 (A/B)
-  const bool late_win = !LW && !(dbg & 8);  // SCLENS_HIP_Q2_DBG=8: the window traffic right behind the DMA pieces (A/B)
+  const bool late_win = !LW && (dbg & 8);  // SCLENS_HIP_Q2_DBG=8: the window traffic behind the products instead of behind the DMA pieces
   // phase clocks (a.prof): 0 DMA issue, 1 window loads / stores issue, 2 products, 3 counted wait, 4 barrier, 5 between groups
   const bool prof = a.prof != nullptr && blockIdx.x == gridDim.x / 2 && tid < 64;
   unsigned long long pacc[6] = {0, 0, 0, 0, 0, 0}, pn = 0, pt = prof ? __builtin_amdgcn_s_memtime() : 0ull;
@@ -3487,9 +3487,10 @@ __global__ __launch_bounds__(LW ? 512 : 256, LW ? 1 : 2) void sbr_q2_apply16e(Sb
         if (does_dma && !(dbg & 2)) sbr_q2_dma<NP>(img, index_of(nb, nt), lds + nxt * QI, dtid);  // dbg: timing experiments only (WRONG results)
         asm volatile("" ::: "memory");
         SBR_Q2_STAMP(0)
-        // the window traffic of this task, behind the DMA: 4 stores (rows that left), 4 loads (rows that will enter). Issued right behind
-        // the DMA pieces it cost 550 clocks per group (the instructions queue up behind the workgroup's 16-28 pieces); behind the
-        // products the queue is empty (`late_win`, the default without loader waves).
+        // the window traffic of this task, behind the DMA: 4 stores (rows that left), 4 loads (rows that will enter). Right behind the
+        // DMA pieces their issue costs ~550 clocks per group (they queue up behind the workgroup's 16-28 pieces); issued behind the
+        // products instead (`late_win`, SCLENS_HIP_Q2_DBG=8) they issue at once but land later: 265 against 250 ms (variant 15,
+        // profiles/r04_q2_final_variants.log) -- the early position stays.
         auto window_traffic = [&]() {
           if (pend) {
 #pragma unroll
@@ -3524,7 +3525,7 @@ __global__ __launch_bounds__(LW ? 512 : 256, LW ? 1 : 2) void sbr_q2_apply16e(Sb
         // traffic issued in this group (j == 0) may stay in flight as well: it is waited for one group later (j == 1: everything)
         if (LW) {  // loaders: their DMA only; compute waves: nothing to wait for (the compiler waits where a loaded row is used)
           if (loader) sbr_vmcnt<DM>();
-        } else if (j == 0 || (j == 1 && AH == 2 && late_win)) {
+        } else if (j == 0 || (j == 1 && AH == 2)) {
           // (two groups ahead: the image needed next was requested BEFORE this task's window traffic, so that may stay in flight for
           // one more group)
           const int nz = (pend ? 4 : 0) + (more ? 4 : 0);
@@ -3580,18 +3581,21 @@ __global__ void sbr_q2_shift(const float* __restrict__ in, int64_t ldi, int64_t 
   if (offo > 0 && c < ldo - offo - n) out[r * ldo + offo + n + c] = 0.f;
 }
 
-// 10 (default): pre-built group images moved by LDS-DMA one group ahead, K = 32 matrix instructions; 11: two groups ahead; 8 / 9: the
-// K = 16 form; 7: split-fp16 products, reflectors staged by every workgroup (round 3); 3: fp32 products (every product of the
-// solver on the fp32 matrix cores); 0, 1, 5, 6: earlier kernels kept for comparison. Measured at n = 30 016 (profiles/r04_q2_*):
-// m = 15 008: 385 (7), 307 (8), 296 (9), 295 (10), 303 (11) ms; all 30 016 vectors: 553 (7), 613 (8: three LDS buffers = one
-// workgroup per CU), 497 (9), 462 (10). With the window traffic behind the DMA (counted waits): 280 (10), 284 (11); loader waves
-// (12 / 13): 288 / 285 -- the same bits, no gain: with the products off the kernel still takes 265-274 ms whoever issues the DMA and
-// however many groups are in flight, i.e. the delivery of 28 KB per group and CU (10 B per clock and CU with all CUs pulling the same
-// image) is what bounds it, not its issue slots. Fewer image bytes per vector (128 vectors per fetch, or images without their zero
-// padding) is the lever that is left.
+// 15 (default since the end of round 4): 16 KB group images (one copy of the reflectors + T, the third product's operand by
+// transposing LDS reads, hand-scheduled LDS reads), two groups ahead; 14: one ahead; 10 / 11: 28 KB images with T folded into a second
+// operand copy (two products), one / two ahead, K = 32 matrix instructions; 8 / 9: their K = 16 form; 12 / 13: loader waves; 7:
+// split-fp16 products, reflectors staged by every workgroup (round 3); 3: fp32 products (every product of the solver on the fp32 matrix
+// cores); 0, 1, 5, 6: earlier kernels kept for comparison. Measured at n = 30 016 (profiles/r04_q2_*): m = 15 008: 385 (7), 307 (8),
+// 296 (9), 295 (10), 303 (11) ms, with the window traffic behind the DMA (counted waits) 280 (10), 284 (11), loader waves 288 / 285.
+// What the phase clocks of a group showed at the end of round 4 (SCLENS_HIP_Q2_PROF, profiles/r04_q2_phase_clocks.log; one wave per
+// SIMD at m = n / 2, so nothing hides a wave's own latencies): (i) __syncthreads() carries a release fence = `s_waitcnt vmcnt(0)`, so
+// every group waited for ALL memory instructions and "two groups ahead" never was; (ii) the 28 KB of an image take ~3 000 clocks to
+// arrive whatever is in flight (9.5 B per clock and CU), as long as a group of variant 10 -- the products hid behind the barrier; (iii)
+// the compiler put every LDS read next to its use: ~20 exposed round trips per group. With a bare barrier, 16 KB images and the reads
+// of a stage issued together: 250 ms where variant 10 takes 293 on the same box (profiles/r04_q2_final_variants.log), all vectors 444 -> 414.
 static int sbr_q2_variant(int64_t n) {
   const char* eq2 = getenv("SCLENS_HIP_Q2_VARIANT");
-  int v = eq2 ? atoi(eq2) : 10;
+  int v = eq2 ? atoi(eq2) : 15;
   if (v >= 8 && v <= 15 && n % SB != 0) v = 7;  // the image index assumes an order that is a multiple of 64 (the two-stage solver pads)
   return v;
 }
