@@ -416,7 +416,8 @@ def main():
                 "search_iters": int(res["n_search"]), "p_": res["p_"],
                 "min_abs_margin": (round(min(abs(x - p_th) for x in d2), 6) if d2 else None),
                 "d5_second_smallest": [round(x, 5) for x in d2], "p_th": round(p_th, 6),
-                "phase_s": {k: round(float(v), 3) for k, v in (res.get("phase_s") or {}).items()}}
+                "phase_s": {k: round(float(v), 3) for k, v in (res.get("phase_s") or {}).items()},
+                "first_phase_jobs_s": [list(q) for q in res.get("first_phase_s", [])]}
 
     def run_config(cfg, steps_req, warm_req, deadline, tail_steps=0.0, step0=0):
         """tail_steps: keep this many step durations of the budget free for what follows (the strict-fp32 step);

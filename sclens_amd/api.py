@@ -492,7 +492,11 @@ def make_draws_native(X, seed: int, host_sampler: bool = False, async_null: bool
 
     def null_matrix():
         rrow = rval = None
-        if nnz_total >= (1 << 22) and os.environ.get("SCLENS_PINNED_DRAWS", "1") != "0":  # page-locked: the arrays go to the device next
+        # page-locked blocks for arrays that go to the device next: opt-in (SCLENS_PINNED_DRAWS=1). Measured at 100 000 x 30 000
+        # (profiles/r04_pinned_null_matrix.log): the null pattern is on the device 0.8 s earlier (0.40 instead of 1.23 s into the call),
+        # but the data | null pair then runs fully concurrently and ends no earlier, and the call was 1.2 s SLOWER on the box it was
+        # timed on (the pair started 1.2 s late; not understood, one box) -- off by default.
+        if nnz_total >= (1 << 22) and os.environ.get("SCLENS_PINNED_DRAWS", "0") == "1":
             rrow, rval = _pinned.array(nnz_total, np.int32), _pinned.array(nnz_total, np.float32)
         if rrow is None or rval is None:
             rrow = np.empty(nnz_total, dtype=np.int32)

@@ -192,11 +192,15 @@ int split_image_fixed(Ctx* ctx, const float* src, int64_t rows, int64_t K, int64
 // C_s = P Q' over the K-slice s of `splits` (slab s at C + s * c_split_off, row pitch ldc; C is not read): split-K partials
 int gemm_split_nt(Ctx* ctx, const void* Pimg, const float* sP, int64_t M, const void* Qimg, const float* sQ, int64_t N, int64_t K, float* C,
                   int64_t ldc, int splits, int64_t k_chunk, int64_t c_split_off);
+int gemm_split_nt_f32a(Ctx* ctx, const float* P, int64_t ldp, float p_scale, int64_t M, const void* Qimg, const float* sQ, int64_t N, int64_t K,
+                       float* C, int64_t ldc, int splits, int64_t k_chunk, int64_t c_split_off);
 // two matrices of the same shape that hold the same magnitudes (the two operands of a symmetric rank-2k update): one scale, from src1
 int split_image_pair_scaled(Ctx* ctx, const float* src1, const float* src2, int64_t rows, int64_t K, int64_t ld, void* dst1, void* dst2,
                             float* scale_dev);
 // two kinds of columns alternating in blocks of `half`, one scale each (scale_dev: 4 floats; pass scale_dev and scale_dev + 2 to
 // gemm_split_update as sP and sQ)
+int split_image_pair_zmax(Ctx* ctx, const float* src1, const float* src2, int64_t rows, int64_t K, int64_t ld, int half, void* dst1,
+                          void* dst2, float* scale_dev, const unsigned* zmax_dev, int nz);
 int split_image_pair_scaled2(Ctx* ctx, const float* src1, const float* src2, int64_t rows, int64_t K, int64_t ld, int half, void* dst1,
                              void* dst2, float* scale_dev);
 int gemm_split_update(Ctx* ctx, const void* Pimg, const float* sP, int64_t M, const void* Qimg, const float* sQ, int64_t N, int64_t K,

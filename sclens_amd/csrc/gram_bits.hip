@@ -545,6 +545,42 @@ __global__ __launch_bounds__(256) void k_split_image_pair_scaled2(const float* _
   }
 }
 
+// The same pair of images when the largest entries are known beforehand: kind 0 (the reflector columns of the band reduction, entries
+// at most 1) under the FIXED scale 2^13, kind 1 under the scale that brings max(zmax[0], zmax[1]) -- the bits of non-negative floats,
+// written by the kernels that produced the columns -- into [2^13, 2^14). No pass over the operands for their maxima, no memset, no
+// scale kernel: every thread derives the two scales itself, thread 0 of block 0 leaves them in scale[0], scale[2] for the product.
+__global__ __launch_bounds__(256) void k_split_image_pair_zmax(const float* __restrict__ src1, const float* __restrict__ src2, int64_t rows,
+                                                               int64_t K, int64_t ld, int64_t Kp, int half, const unsigned* __restrict__ zmax,
+                                                               int nz, float* __restrict__ scale, _Float16* __restrict__ dst1,
+                                                               _Float16* __restrict__ dst2) {
+  float mx = __uint_as_float(zmax[0]);
+  if (nz > 1) mx = fmaxf(mx, __uint_as_float(zmax[1]));
+  int ex = 0;
+  float sz = 1.f;
+  if (mx > 0.f && mx < 1.0e30f) {
+    (void)frexpf(mx, &ex);
+    sz = ldexpf(1.f, 14 - ex);
+  }
+  const float sv = 8192.f;
+  if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) {
+    scale[0] = sv;
+    scale[2] = sz;
+  }
+  const int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (k >= Kp) return;
+  const int kind = (int)((k / half) & 1);
+  const float s1 = kind ? sz : sv, s2 = kind ? sv : sz;
+  for (int64_t r = blockIdx.y; r < rows; r += gridDim.y) {
+    const float x1 = k < K ? src1[r * ld + k] * s1 : 0.f, x2 = k < K ? src2[r * ld + k] * s2 : 0.f;
+    const _Float16 h1 = (_Float16)x1, h2 = (_Float16)x2;
+    const int64_t o = r * 2 * Kp + (k >> 5) * 64 + (k & 31);
+    dst1[o] = h1;
+    dst1[o + 32] = (_Float16)(x1 - (float)h1);
+    dst2[o] = h2;
+    dst2[o + 32] = (_Float16)(x2 - (float)h2);
+  }
+}
+
 struct SplitUpdArgs {
   const _Float16* A;  // split image, M rows
   const _Float16* B;  // split image, N rows
@@ -567,10 +603,36 @@ struct SplitUpdArgs {
   // eight of 32 KB in the epilogue, which is what bounded the rank-256 updates of the band reduction (65 us per tile, 39 at the fair
   // share of HBM)
   int acc_init;
+  // AF32 instantiation: the first operand is an fp32 matrix (row pitch ldaf, rows K-contiguous) instead of a split image; its tile
+  // is staged as it is and every lane splits the eight k of its fragment in registers, scaled by af_scale (a power of two)
+  const float* Af;
+  int64_t ldaf;
+  float af_scale;
 };
+
+// x = hi + lo (fp16 pieces) of eight scaled fp32 values: two packed conversions and one mixed-precision fma per element
+typedef float gb_f32x2 __attribute__((ext_vector_type(2)));
+typedef float gb_f32x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 gb_f16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void split_pk8(gb_f32x4 x0, gb_f32x4 x1, h16x8& hi, h16x8& lo) {
+  gb_f16x2 h[4], l[4];
+  const float x[8] = {x0[0], x0[1], x0[2], x0[3], x1[0], x1[1], x1[2], x1[3]};
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    h[q] = __builtin_convertvector(gb_f32x2{x[2 * q], x[2 * q + 1]}, gb_f16x2);
+    const unsigned u = __builtin_bit_cast(unsigned, h[q]);
+    float r0, r1;
+    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(r0) : "v"(u), "v"(x[2 * q]));
+    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r1) : "v"(u), "v"(x[2 * q + 1]));
+    l[q] = __builtin_convertvector(gb_f32x2{r0, r1}, gb_f16x2);
+  }
+  hi = h16x8{h[0][0], h[0][1], h[1][0], h[1][1], h[2][0], h[2][1], h[3][0], h[3][1]};
+  lo = h16x8{l[0][0], l[0][1], l[1][0], l[1][1], l[2][0], l[2][1], l[3][0], l[3][1]};
+}
 
 // The main loop of corr_split_kernel with the tile decode, the accumulator start from C and the lower + mirror epilogue of
 // gemm_nt_big<2, 4, 4, 2> (same 256 x 256 tile, same 32 x 32 accumulator layout).
+template <bool AF32>
 __global__ __launch_bounds__(512, 2) void gemm_split_kernel(SplitUpdArgs a) {
   constexpr int TM = 4, TN = 2;
   constexpr int OPB = 256 * 128, STAGE = 2 * OPB;
@@ -599,6 +661,7 @@ __global__ __launch_bounds__(512, 2) void gemm_split_kernel(SplitUpdArgs a) {
   const int wm = wid >> 2, wn = wid & 3, l31 = lane & 31, h = lane >> 5;
   const int srow = lane >> 3, sq = lane & 7;
   const _Float16* srcA[4];
+  const float* srcAf[4];
   const _Float16* srcB[4];
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
@@ -608,6 +671,7 @@ __global__ __launch_bounds__(512, 2) void gemm_split_kernel(SplitUpdArgs a) {
     if (ra > a.M - 1) ra = a.M - 1;
     if (rb > a.N - 1) rb = a.N - 1;
     srcA[i] = a.A + ra * 2 * a.Kp + 8 * chunk;
+    srcAf[i] = AF32 ? a.Af + ra * a.ldaf + 4 * chunk : nullptr;  // 128 bytes per row and 32 of K either way
     srcB[i] = a.B + rb * 2 * a.Kp + 8 * chunk;
   }
   int64_t kt_lo = 0, nkt = a.Kp / 32;
@@ -622,14 +686,16 @@ __global__ __launch_bounds__(512, 2) void gemm_split_kernel(SplitUpdArgs a) {
     unsigned char* As = lds + buf * STAGE;
     unsigned char* Bs = As + OPB;
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
-      __builtin_amdgcn_global_load_lds((glb_void_t*)(srcA[i] + kt * 64), (lds_void_t*)(As + (wid * 4 + i) * 1024), 16, 0, 0);
+    for (int i = 0; i < 4; ++i) {
+      if (AF32) __builtin_amdgcn_global_load_lds((glb_void_t*)(srcAf[i] + kt * 32), (lds_void_t*)(As + (wid * 4 + i) * 1024), 16, 0, 0);
+      else __builtin_amdgcn_global_load_lds((glb_void_t*)(srcA[i] + kt * 64), (lds_void_t*)(As + (wid * 4 + i) * 1024), 16, 0, 0);
+    }
 #pragma unroll
     for (int i = 0; i < 4; ++i)
       __builtin_amdgcn_global_load_lds((glb_void_t*)(srcB[i] + kt * 64), (lds_void_t*)(Bs + (wid * 4 + i) * 1024), 16, 0, 0);
   };
   if (kt_lo < nkt) stage((int)(kt_lo & 1), kt_lo);
-  const float alpha = a.post / (a.sA[0] * a.sB[0]);  // the scales are powers of two
+  const float alpha = a.post / ((AF32 ? a.af_scale : a.sA[0]) * a.sB[0]);  // the scales are powers of two
   // 32-bit indices relative to the tile's corner (and to the corner of its mirror image): the 64-bit row * ldc + col of every
   // element cost this kernel 191 spilled registers
   float* Ct = a.C + m0 * a.ldc + n0;
@@ -695,8 +761,15 @@ __global__ __launch_bounds__(512, 2) void gemm_split_kernel(SplitUpdArgs a) {
       h16x8 ah[TM], al[TM], bh[TN], bl[TN];
 #pragma unroll
       for (int i = 0; i < TM; ++i) {
-        ah[i] = *reinterpret_cast<const h16x8*>(S + offA[i] + ((ch ^ swA[i]) << 4));
-        al[i] = *reinterpret_cast<const h16x8*>(S + offA[i] + ((cl ^ swA[i]) << 4));
+        if (AF32) {  // the fp32 tile: k = 16 kk + 8 h .. + 7 of this row are the 16-byte chunks 4 kk + 2 h and the next one
+          const int c0 = 4 * kk + 2 * h;
+          const gb_f32x4 x0 = *reinterpret_cast<const gb_f32x4*>(S + offA[i] + ((c0 ^ swA[i]) << 4));
+          const gb_f32x4 x1 = *reinterpret_cast<const gb_f32x4*>(S + offA[i] + (((c0 + 1) ^ swA[i]) << 4));
+          split_pk8(x0 * a.af_scale, x1 * a.af_scale, ah[i], al[i]);
+        } else {
+          ah[i] = *reinterpret_cast<const h16x8*>(S + offA[i] + ((ch ^ swA[i]) << 4));
+          al[i] = *reinterpret_cast<const h16x8*>(S + offA[i] + ((cl ^ swA[i]) << 4));
+        }
       }
 #pragma unroll
       for (int j = 0; j < TN; ++j) {
@@ -856,6 +929,18 @@ int split_image_pair_scaled2(Ctx* ctx, const float* src1, const float* src2, int
   return SCLENS_OK;
 }
 
+int split_image_pair_zmax(Ctx* ctx, const float* src1, const float* src2, int64_t rows, int64_t K, int64_t ld, int half, void* dst1,
+                          void* dst2, float* scale_dev, const unsigned* zmax_dev, int nz) {
+  if (rows <= 0) return SCLENS_OK;
+  if (half <= 0 || K % (2 * half) != 0 || nz < 1 || nz > 2) return ctx->fail(SCLENS_ERR_ARG, "split_image_pair_zmax: bad arguments");
+  const int64_t Kp = round_up(K, 32);
+  hipLaunchKernelGGL(k_split_image_pair_zmax, dim3((unsigned)((Kp + 255) / 256), (unsigned)std::min<int64_t>(rows, 65535)), dim3(256), 0,
+                     ctx->stream, src1, src2, rows, K, ld, Kp, half, zmax_dev, nz, scale_dev, static_cast<_Float16*>(dst1),
+                     static_cast<_Float16*>(dst2));
+  SCL_HIP(ctx, hipGetLastError());
+  return SCLENS_OK;
+}
+
 int gemm_split_update(Ctx* ctx, const void* Pimg, const float* sP, int64_t M, const void* Qimg, const float* sQ, int64_t N, int64_t K,
                       float* C, int64_t ldc, int lower, float post) {
   if (M <= 0 || N <= 0) return SCLENS_OK;
@@ -866,11 +951,11 @@ int gemm_split_update(Ctx* ctx, const void* Pimg, const float* sP, int64_t M, co
   const int2* tiles = nullptr;
   if (K >= 2048 && nb >= 1500) SCL_TRY(big_tile_list(ctx, bm, bn, lower, &tiles, &nb));  // operand panels re-used out of the L2s
   constexpr int LDS_BYTES = 2 * 2 * 256 * 128;
-  SCL_TRY(ensure_dyn_lds(ctx, reinterpret_cast<const void*>(gemm_split_kernel), LDS_BYTES));
+  SCL_TRY(ensure_dyn_lds(ctx, reinterpret_cast<const void*>(gemm_split_kernel<false>), LDS_BYTES));
   const bool no_acc_init = getenv("SCLENS_HIP_SPLIT_ACC_INIT") && atoi(getenv("SCLENS_HIP_SPLIT_ACC_INIT")) == 0;  // A/B: C in the epilogue
   SplitUpdArgs a{static_cast<const _Float16*>(Pimg), static_cast<const _Float16*>(Qimg), sP, sQ, M, N, round_up(K, 32), C, ldc, lower,
-                 (int)bn, post, tiles, 0, 0, 0, (!no_acc_init && fabsf(post) == 1.f) ? 1 : 0};
-  hipLaunchKernelGGL(gemm_split_kernel, dim3((unsigned)nb), dim3(512), LDS_BYTES, ctx->stream, a);
+                 (int)bn, post, tiles, 0, 0, 0, (!no_acc_init && fabsf(post) == 1.f) ? 1 : 0, nullptr, 0, 1.f};
+  hipLaunchKernelGGL(gemm_split_kernel<false>, dim3((unsigned)nb), dim3(512), LDS_BYTES, ctx->stream, a);
   SCL_HIP(ctx, hipGetLastError());
   return SCLENS_OK;
 }
@@ -884,10 +969,30 @@ int gemm_split_nt(Ctx* ctx, const void* Pimg, const float* sP, int64_t M, const 
   const int64_t bm = (M + 255) / 256, bn = (N + 255) / 256, nb = bm * bn;
   if (nb > 0x7fffffffLL) return ctx->fail(SCLENS_ERR_ARG, "gemm_split_nt: too many tiles");
   constexpr int LDS_BYTES = 2 * 2 * 256 * 128;
-  SCL_TRY(ensure_dyn_lds(ctx, reinterpret_cast<const void*>(gemm_split_kernel), LDS_BYTES));
+  SCL_TRY(ensure_dyn_lds(ctx, reinterpret_cast<const void*>(gemm_split_kernel<false>), LDS_BYTES));
   SplitUpdArgs a{static_cast<const _Float16*>(Pimg), static_cast<const _Float16*>(Qimg), sP, sQ, M, N, round_up(K, 32), C, ldc, 0,
-                 (int)bn, 1.0f, nullptr, splits > 1 ? k_chunk / 32 : round_up(K, 32) / 32, c_split_off, 1, 0};
-  hipLaunchKernelGGL(gemm_split_kernel, dim3((unsigned)nb, (unsigned)splits), dim3(512), LDS_BYTES, ctx->stream, a);
+                 (int)bn, 1.0f, nullptr, splits > 1 ? k_chunk / 32 : round_up(K, 32) / 32, c_split_off, 1, 0, nullptr, 0, 1.f};
+  hipLaunchKernelGGL(gemm_split_kernel<false>, dim3((unsigned)nb, (unsigned)splits), dim3(512), LDS_BYTES, ctx->stream, a);
+  SCL_HIP(ctx, hipGetLastError());
+  return SCLENS_OK;
+}
+
+// the same with the first operand taken as it is: P [M][K] fp32 (row pitch ldp, K a multiple of 32), scaled by `p_scale` (a power of
+// two that brings its entries into fp16 range) and split in registers by the kernel -- no image pass over P (the first
+// back-transformation's W1 = Z Vm': the image of Z cost a read and a write of the vector block per group, profiles/r04_cfg4_kernel_stats.csv)
+int gemm_split_nt_f32a(Ctx* ctx, const float* P, int64_t ldp, float p_scale, int64_t M, const void* Qimg, const float* sQ, int64_t N, int64_t K,
+                       float* C, int64_t ldc, int splits, int64_t k_chunk, int64_t c_split_off) {
+  if (M <= 0 || N <= 0) return SCLENS_OK;
+  if (K % 32 != 0 || ldp % 4 != 0 || (reinterpret_cast<uintptr_t>(P) & 15u))
+    return ctx->fail(SCLENS_ERR_ARG, "gemm_split_nt_f32a: K must be a multiple of 32 and P 16-byte aligned with a pitch that is a multiple of 4");
+  if (splits < 1 || (splits > 1 && k_chunk % 32 != 0)) return ctx->fail(SCLENS_ERR_ARG, "gemm_split_nt_f32a: k_chunk must be a multiple of 32");
+  const int64_t bm = (M + 255) / 256, bn = (N + 255) / 256, nb = bm * bn;
+  if (nb > 0x7fffffffLL) return ctx->fail(SCLENS_ERR_ARG, "gemm_split_nt_f32a: too many tiles");
+  constexpr int LDS_BYTES = 2 * 2 * 256 * 128;
+  SCL_TRY(ensure_dyn_lds(ctx, reinterpret_cast<const void*>(gemm_split_kernel<true>), LDS_BYTES));
+  SplitUpdArgs a{nullptr, static_cast<const _Float16*>(Qimg), nullptr, sQ, M, N, K, C, ldc, 0,
+                 (int)bn, 1.0f, nullptr, splits > 1 ? k_chunk / 32 : K / 32, c_split_off, 1, 0, P, ldp, p_scale};
+  hipLaunchKernelGGL(gemm_split_kernel<true>, dim3((unsigned)nb, (unsigned)splits), dim3(512), LDS_BYTES, ctx->stream, a);
   SCL_HIP(ctx, hipGetLastError());
   return SCLENS_OK;
 }

@@ -514,9 +514,11 @@ __global__ __launch_bounds__(64) void sbr_panel_house(const float* __restrict__ 
 }
 
 // Sh = 1/2 T' (V'Y), V'Y = the summed cross partials (sbr_sum_parts); 256 threads, 4 x 4 outputs each
-__global__ __launch_bounds__(256) void sbr_small_s(const double* __restrict__ VtY, const float* __restrict__ T, double* __restrict__ Sh) {
+__global__ __launch_bounds__(256) void sbr_small_s(const double* __restrict__ VtY, const float* __restrict__ T, double* __restrict__ Sh,
+                                                   unsigned* __restrict__ zmax) {
   __shared__ double G[SB * SB], Tt[SB * SB];
   const int tid = threadIdx.x, ti = tid >> 4, tj = tid & 15;
+  if (zmax && tid == 0) *zmax = 0u;  // the next kernel (sbr_rmul_f32<3>) leaves the largest |Z| of this panel here
   for (int idx = tid; idx < SB * SB; idx += 256) {
     G[idx] = VtY[idx];
     Tt[(idx & 63) * SB + (idx >> 6)] = (double)T[idx];  // T' (T is upper: its strictly lower part is stored as 0)
@@ -704,7 +706,7 @@ template <int MODE>
 __global__ __launch_bounds__(256) void sbr_rmul_f32(const float* __restrict__ in, int nslab, int64_t slab, const float* __restrict__ F32,
                                                     const double* __restrict__ F64, int64_t len, float* __restrict__ out,
                                                     const float* __restrict__ Yr, float* __restrict__ VW, float* __restrict__ WV,
-                                                    int64_t ldo) {
+                                                    int64_t ldo, unsigned* __restrict__ zmax = nullptr) {
   const int lane = threadIdx.x & 63, l15 = lane & 15, kg = lane >> 4;
   const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   const int64_t r0 = wave * SBR_RT;
@@ -739,6 +741,7 @@ __global__ __launch_bounds__(256) void sbr_rmul_f32(const float* __restrict__ in
 #pragma unroll
       for (int jt = 0; jt < 4; ++jt) acc[jt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[q][e], bf[q][e][jt], acc[jt], 0, 0, 0);
   // D[r = r0 + 4 kg + g][j = 16 jt + l15]
+  float zm = 0.f;
 #pragma unroll
   for (int g = 0; g < 4; ++g) {
     const int64_t rr = r0 + 4 * kg + g;
@@ -751,12 +754,19 @@ __global__ __launch_bounds__(256) void sbr_rmul_f32(const float* __restrict__ in
       } else {
         const float z = Yr[rr * SB + j] - acc[jt][g];
         const float v = in[rr * SB + j];
+        zm = fmaxf(zm, fabsf(z));
         VW[rr * ldo + j] = v;
         VW[rr * ldo + SB + j] = z;
         WV[rr * ldo + j] = -z;  // negated: the update is then C += [V | Z] [-Z | -V]' with the accumulators started from C
         WV[rr * ldo + SB + j] = -v;
       }
     }
+  }
+  if (MODE == 3 && zmax) {  // largest |Z| of the panel for the scale of the split update's operands (one atomic per wave; a maximum
+                            // does not depend on the order of its arguments)
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) zm = fmaxf(zm, __shfl_xor(zm, o));
+    if (lane == 0) atomicMax(zmax, __float_as_uint(zm));
   }
 }
 
@@ -970,6 +980,14 @@ int sy2sb_f32(Ctx* ctx, float* A, int64_t n, int64_t lda, float* Tall, int* brea
   float* imgS = any_split ? static_cast<float*>(ctx->workspace("sbr.imgS", 4 * sizeof(float))) : nullptr;
   if (any_split && (!imgP || !imgQ || !imgS)) return SCLENS_ERR_OOM;
   SCL_WS(ctx, flag, int, "sbr.flag", 4);
+  // Largest |Z| of a panel (slot 0 / 1 of a delayed pair), left by the kernel that writes Z: the scales of the split update's operands
+  // then need no pass over the operands, no memset and no scale kernel (three launches of ~40 us per update on the main stream). The V
+  // columns take the fixed scale 2^13. SCLENS_HIP_SY2SB_ZMAX=0: the largest entries by a pass over the operands (until round 4).
+  unsigned* zmax = nullptr;
+  if (any_split && split_scales == 2 && !(getenv("SCLENS_HIP_SY2SB_ZMAX") && atoi(getenv("SCLENS_HIP_SY2SB_ZMAX")) == 0)) {
+    zmax = static_cast<unsigned*>(ctx->workspace("sbr.zmax", 4 * sizeof(unsigned)));
+    if (!zmax) return SCLENS_ERR_OOM;
+  }
   hipStream_t st = ctx->stream;
   SCL_HIP(ctx, hipMemsetAsync(flag, 0, sizeof(int) * 4, st));
   // W = A22 V from fp16 pieces (sbr_w_split) while the trailing matrix has at least `wsplit_min` rows: follows the switch of the
@@ -1112,9 +1130,9 @@ int sy2sb_f32(Ctx* ctx, float* A, int64_t n, int64_t lda, float* Tall, int* brea
                        (const float*)nullptr, (float*)nullptr, (float*)nullptr, (int64_t)0);
     hipLaunchKernelGGL((sbr_gram64<false>), dim3(nparts), dim3(256), SBR_GRAM_LDS, st, Vr, (int64_t)SB, Yr, np, part);
     hipLaunchKernelGGL(sbr_sum_parts, dim3(SB * SB / 256), dim3(256), 0, st, part, nparts, psum);
-    hipLaunchKernelGGL(sbr_small_s, dim3(1), dim3(256), 0, st, psum, Tp, Mat + SB * SB);
+    hipLaunchKernelGGL(sbr_small_s, dim3(1), dim3(256), 0, st, psum, Tp, Mat + SB * SB, zmax ? zmax + slot : (unsigned*)nullptr);
     hipLaunchKernelGGL((sbr_rmul_f32<3>), dim3(rtiles), dim3(256), 0, st, Vr, 1, (int64_t)0, (const float*)nullptr, Mat + SB * SB, np,
-                       (float*)nullptr, Yr, VWs, WVs, LDU);
+                       (float*)nullptr, Yr, VWs, WVs, LDU, zmax ? zmax + slot : (unsigned*)nullptr);
     // the update's operands: this panel's slot alone, or both slots (K = 4 SB) when the previous panel's update is pending
     const float* Up = VW + r0 * LDU;
     const float* Uq = WV + r0 * LDU;
@@ -1122,7 +1140,8 @@ int sy2sb_f32(Ctx* ctx, float* A, int64_t n, int64_t lda, float* Tall, int* brea
     auto update = [&](int64_t off, int64_t rows, int64_t cols, int lower) -> int {  // A22[off:off+rows, (lower ? off : 0) : +cols]
       if (lower && rows == cols && rows >= split_min) {  // the bulk of the update: split-fp16 products
         if (split_scales == 2) {  // one scale for the V columns, one for the Z columns (prepared in round 3, not yet the default)
-          SCL_TRY(split_image_pair_scaled2(ctx, Up + off * LDU, Uq + off * LDU, rows, Ku, LDU, (int)SB, imgP, imgQ, imgS));
+          if (zmax) SCL_TRY(split_image_pair_zmax(ctx, Up + off * LDU, Uq + off * LDU, rows, Ku, LDU, (int)SB, imgP, imgQ, imgS, zmax, pending ? 2 : 1));
+          else SCL_TRY(split_image_pair_scaled2(ctx, Up + off * LDU, Uq + off * LDU, rows, Ku, LDU, (int)SB, imgP, imgQ, imgS));
           return gemm_split_update(ctx, imgP, imgS, rows, imgQ, imgS + 2, rows, Ku, A22 + off * lda + off, lda, 1);
         }
         SCL_TRY(split_image_pair_scaled(ctx, Up + off * LDU, Uq + off * LDU, rows, Ku, LDU, imgP, imgQ, imgS));
@@ -1472,9 +1491,12 @@ int sbr_apply_q1(Ctx* ctx, const float* A, int64_t n, int64_t lda, const float* 
   // SCLENS_HIP_Q1_W1_SPLIT=0: this product stays fp32.
   const char* ew1 = getenv("SCLENS_HIP_Q1_W1_SPLIT");
   const bool w1_split = q1_split && !(ew1 && atoi(ew1) == 0);
-  void* imgZ = w1_split ? ctx->workspace("sbr.q1imgZ", split_image_bytes(m, n)) : nullptr;
+  // (end of round 4) Z enters that product as it is and is split in registers by the kernel (gemm_split_nt_f32a): the image of Z was
+  // a read and a write of the vector block per group, 62 ms of the 125 ms of this stage at n = 30 016. SCLENS_HIP_Q1_W1_SPLIT=2: the image.
+  const bool w1_regs = w1_split && !(ew1 && atoi(ew1) == 2);
+  void* imgZ = (w1_split && !w1_regs) ? ctx->workspace("sbr.q1imgZ", split_image_bytes(m, n)) : nullptr;
   void* imgVm = w1_split ? ctx->workspace("sbr.q1imgVm", split_image_bytes(Q1W, n)) : nullptr;
-  if (w1_split && (!imgZ || !imgVm)) return SCLENS_ERR_OOM;
+  if (w1_split && ((!w1_regs && !imgZ) || !imgVm)) return SCLENS_ERR_OOM;
   hipStream_t st = ctx->stream;
   for (int64_t g = ngrp - 1; g >= 0; --g) {
     const int64_t p0 = g * Q1G;
@@ -1489,7 +1511,7 @@ int sbr_apply_q1(Ctx* ctx, const float* A, int64_t n, int64_t lda, const float* 
     if (!ready) SCL_TRY(sbr_q1_group_data(ctx, A, n, lda, Tall, p0, cnt, Q1G, Vm, ldv, VmT, Gp, Gs, Tm));
     const int64_t kch = round_up((np + S - 1) / S, 32);
     if (w1_split && split_g) {  // W1[m][s][Q1W] = split-K partials of Zt[:, r0:] Vm' on the fp16 matrix cores
-      SCL_TRY(split_image_fixed(ctx, Zt + r0, m, np, ldz, imgZ, imgS + 8, 8192.f));
+      if (!w1_regs) SCL_TRY(split_image_fixed(ctx, Zt + r0, m, np, ldz, imgZ, imgS + 8, 8192.f));
       const void* ivm = imgVm;
       const float* svm = imgS + 12;
       if (ready) {
@@ -1498,7 +1520,8 @@ int sbr_apply_q1(Ctx* ctx, const float* A, int64_t n, int64_t lda, const float* 
       } else {
         SCL_TRY(split_image_fixed(ctx, Vm_g, Q1W, np, ldv_g, imgVm, imgS + 12, 8192.f));
       }
-      SCL_TRY(gemm_split_nt(ctx, imgZ, imgS + 8, m, ivm, svm, Q1W, np, W1, (int64_t)S * Q1W, S, kch, Q1W));
+      if (w1_regs) SCL_TRY(gemm_split_nt_f32a(ctx, Zt + r0, ldz, 8192.f, m, ivm, svm, Q1W, np, W1, (int64_t)S * Q1W, S, kch, Q1W));
+      else SCL_TRY(gemm_split_nt(ctx, imgZ, imgS + 8, m, ivm, svm, Q1W, np, W1, (int64_t)S * Q1W, S, kch, Q1W));
     } else {  // W1[m][s][Q1W] = split-K partials of Zt[:, r0:] Vm'
       GemmArgs g1{};
       g1.P = Zt + r0; g1.Q = Vm_g; g1.C = W1;

@@ -80,7 +80,7 @@ def test_sclens_with_device_drawn_candidates(ctx):
 
 
 def test_null_matrix_in_page_locked_memory(ctx, monkeypatch):
-    """the null matrix drawn into page-locked host blocks (sclens_hip_host_alloc, above 4M stored entries) is the matrix drawn into
+    """(opt-in, SCLENS_PINNED_DRAWS=1) the null matrix drawn into page-locked host blocks (sclens_hip_host_alloc, above 4M stored entries) is the matrix drawn into
     ordinary memory, its pattern on the device is the same, and a block is handed out again once the matrix built on it is gone"""
     import gc
 

@@ -76,12 +76,15 @@ def test_sy2sb_split_update_with_separate_scales(ctx, log2_norm, monkeypatch):
     monkeypatch.setenv("SCLENS_HIP_SY2SB_DELAY_MIN", "321")
     monkeypatch.setenv("SCLENS_HIP_SY2SB_SPLIT", "512")
     err = {}
-    for scales in ("2", "1"):
-        monkeypatch.setenv("SCLENS_HIP_SY2SB_SPLIT_SCALES", scales)
+    for scales in ("2", "1", "2-pass"):
+        monkeypatch.setenv("SCLENS_HIP_SY2SB_SPLIT_SCALES", scales[0])
+        # "2": the Z columns' largest entry comes from the kernel that writes Z and the V columns take the fixed scale 2^13 (default);
+        # "2-pass": both maxima by a pass over the operands (until the end of round 4)
+        monkeypatch.setenv("SCLENS_HIP_SY2SB_ZMAX", "0" if scales == "2-pass" else "1")
         out, T, bd = _run_sy2sb(ctx, A)
         assert bd == 0
         err[scales] = np.abs(np.linalg.eigvalsh(_band_of(out)) - ref).max() / ref.max()
-    assert err["2"] < 4e-7 * np.sqrt(n) + 1e-7, err
+    assert err["2"] < 4e-7 * np.sqrt(n) + 1e-7 and err["2-pass"] < 4e-7 * np.sqrt(n) + 1e-7, err
     if log2_norm <= 14:
         assert err["1"] < 4e-7 * np.sqrt(n) + 1e-7, err
 
@@ -359,7 +362,7 @@ def test_first_back_transformation_group_data_prepared_ahead_gives_the_same_bits
     lda = rup(n, 32)
     m = hi - lo
     got = []
-    for prep, w1 in (("1", "1"), ("0", "1"), ("1", "0")):
+    for prep, w1 in (("1", "1"), ("0", "1"), ("1", "0"), ("1", "2")):
         monkeypatch.setenv("SCLENS_HIP_Q1_PREP", prep)
         monkeypatch.setenv("SCLENS_HIP_Q1_W1_SPLIT", w1)  # "0": the first product of every group on the fp32 matrix cores (round 3)
         c2 = Context(ctx.device)
@@ -376,6 +379,8 @@ def test_first_back_transformation_group_data_prepared_ahead_gives_the_same_bits
         finally:
             c2.close()
     assert np.array_equal(got[0][0], got[1][0]) and np.array_equal(got[0][1], got[1][1])
+    # "2": Z through a split image instead of split in registers by the product's kernel (the default): the same pieces, the same bits
+    assert np.array_equal(got[0][0], got[3][0]) and np.array_equal(got[0][1], got[3][1])
     A64 = A.astype(np.float64)
     for w, Zf in (got[0], got[2]):  # W1 = Z Vm' from split images (22-bit operands, fixed scale 2^13) / in fp32
         Z = Zf.astype(np.float64)
