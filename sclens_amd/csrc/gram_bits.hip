@@ -632,7 +632,11 @@ __device__ __forceinline__ void split_pk8(gb_f32x4 x0, gb_f32x4 x1, h16x8& hi, h
 
 // The main loop of corr_split_kernel with the tile decode, the accumulator start from C and the lower + mirror epilogue of
 // gemm_nt_big<2, 4, 4, 2> (same 256 x 256 tile, same 32 x 32 accumulator layout).
-template <bool AF32>
+// DEEP (default since the end of round 4): the operands arrive in HALF stages of 16 of K -- four LDS buffers of 32 KB, three half
+// stages in flight, counted `s_waitcnt vmcnt` and a bare `s_barrier` per half stage. The two-buffer loop (DEEP = false) ends every
+// 32 of K with __syncthreads(), whose release fence is `s_waitcnt vmcnt(0)`: one 64 KB stage in flight, which the L2 -> LDS path
+// delivers in 2.7 us against 1.3 us of matrix work -- 22 of the 55 us of a rank-256 update tile (profiles/r04_split_deep.log).
+template <bool AF32, bool DEEP>
 __global__ __launch_bounds__(512, 2) void gemm_split_kernel(SplitUpdArgs a) {
   constexpr int TM = 4, TN = 2;
   constexpr int OPB = 256 * 128, STAGE = 2 * OPB;
@@ -694,7 +698,42 @@ __global__ __launch_bounds__(512, 2) void gemm_split_kernel(SplitUpdArgs a) {
     for (int i = 0; i < 4; ++i)
       __builtin_amdgcn_global_load_lds((glb_void_t*)(srcB[i] + kt * 64), (lds_void_t*)(Bs + (wid * 4 + i) * 1024), 16, 0, 0);
   };
-  if (kt_lo < nkt) stage((int)(kt_lo & 1), kt_lo);
+  // half stages (DEEP): lane = 16 rows x 4 slots of 16 bytes; chunk q of row r sits in slot q ^ ((r >> 2) & 3) (source permuted), q = 0, 1:
+  // the hi pieces of k = 0..7, 8..15 of the half stage, q = 2, 3 the lo pieces (fp32 operand: the four quads of its 16 k)
+  constexpr int HSB = 2 * 256 * 64;  // bytes of one half-stage buffer: A rows, then B rows, 64 bytes each
+  const int hrow = lane >> 2, hslot = lane & 3;
+  const _Float16* hsA[2];
+  const float* hsAf[2];
+  const _Float16* hsB[2];
+  if (DEEP) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int r = (wid * 2 + i) * 16 + hrow;
+      const int q = hslot ^ ((r >> 2) & 3);
+      const int cq0 = q < 2 ? q : q + 2;  // 16-byte chunk of the 128-byte image row at kk = 0 (kk = 1: two further)
+      int64_t ra = m0 + r, rb = n0 + r;
+      if (ra > a.M - 1) ra = a.M - 1;
+      if (rb > a.N - 1) rb = a.N - 1;
+      hsA[i] = a.A + ra * 2 * a.Kp + 8 * cq0;
+      hsAf[i] = AF32 ? a.Af + ra * a.ldaf + 4 * q : nullptr;
+      hsB[i] = a.B + rb * 2 * a.Kp + 8 * cq0;
+    }
+  }
+  auto hstage = [&](int64_t hs) {  // hs = half-stage index counted from kt_lo
+    unsigned char* As = lds + (int)(hs & 3) * HSB;
+    unsigned char* Bs = As + 256 * 64;
+    const int64_t kt = kt_lo + (hs >> 1), kk = hs & 1;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      if (AF32) __builtin_amdgcn_global_load_lds((glb_void_t*)(hsAf[i] + kt * 32 + kk * 16), (lds_void_t*)(As + (wid * 2 + i) * 1024), 16, 0, 0);
+      else __builtin_amdgcn_global_load_lds((glb_void_t*)(hsA[i] + kt * 64 + kk * 16), (lds_void_t*)(As + (wid * 2 + i) * 1024), 16, 0, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+      __builtin_amdgcn_global_load_lds((glb_void_t*)(hsB[i] + kt * 64 + kk * 16), (lds_void_t*)(Bs + (wid * 2 + i) * 1024), 16, 0, 0);
+  };
+  const int64_t NH = 2 * (nkt - kt_lo);
+  if (!DEEP && kt_lo < nkt) stage((int)(kt_lo & 1), kt_lo);
   const float alpha = a.post / ((AF32 ? a.af_scale : a.sA[0]) * a.sB[0]);  // the scales are powers of two
   // 32-bit indices relative to the tile's corner (and to the corner of its mirror image): the 64-bit row * ldc + col of every
   // element cost this kernel 191 spilled registers
@@ -728,19 +767,30 @@ __global__ __launch_bounds__(512, 2) void gemm_split_kernel(SplitUpdArgs a) {
           acc[i][j][e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rc, vo + (unsigned)(j * 128), so, 0));
       }
   }
+  if (DEEP) {  // behind the loads of C: memory instructions complete in order, so "half stage 0 has landed" covers them
+#pragma unroll
+    for (int p = 0; p < 3; ++p)
+      if (p < NH) hstage(p);
+  }
   int offA[TM], offB[TN], swA[TM], swB[TN];
 #pragma unroll
   for (int i = 0; i < TM; ++i) {
     const int r = wm * 128 + i * 32 + l31;
-    offA[i] = r * 128;
-    swA[i] = (r >> 1) & 7;
+    offA[i] = DEEP ? r * 64 : r * 128;
+    swA[i] = DEEP ? (r >> 2) & 3 : (r >> 1) & 7;
   }
 #pragma unroll
   for (int j = 0; j < TN; ++j) {
     const int r = wn * 64 + j * 32 + l31;
-    offB[j] = OPB + r * 128;
-    swB[j] = (r >> 1) & 7;
+    offB[j] = DEEP ? 256 * 64 + r * 64 : OPB + r * 128;
+    swB[j] = DEEP ? (r >> 2) & 3 : (r >> 1) & 7;
   }
+  auto hwait = [&](int64_t left) {  // at most `left` (0..2) half stages of this wave's DMA may still be in flight
+    if (left >= 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else if (left == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  };
+  if (DEEP) hwait((NH < 3 ? NH : 3) - 1);
   if (cinit) {
     const float inv_alpha = 1.f / alpha;
 #pragma unroll
@@ -750,6 +800,43 @@ __global__ __launch_bounds__(512, 2) void gemm_split_kernel(SplitUpdArgs a) {
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[i][j][e] *= inv_alpha;
   }
+  if (DEEP) {
+    __builtin_amdgcn_s_barrier();
+    for (int64_t hs = 0; hs < NH; ++hs) {
+      if (hs + 3 < NH) hstage(hs + 3);  // into the buffer of half stage hs - 1: every wave has passed the barrier behind it
+      const unsigned char* S = lds + (int)(hs & 3) * HSB;
+      h16x8 ah[TM], al[TM], bh[TN], bl[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        if (AF32) {
+          const gb_f32x4 x0 = *reinterpret_cast<const gb_f32x4*>(S + offA[i] + (((2 * h) ^ swA[i]) << 4));
+          const gb_f32x4 x1 = *reinterpret_cast<const gb_f32x4*>(S + offA[i] + (((2 * h + 1) ^ swA[i]) << 4));
+          split_pk8(x0 * a.af_scale, x1 * a.af_scale, ah[i], al[i]);
+        } else {
+          ah[i] = *reinterpret_cast<const h16x8*>(S + offA[i] + ((h ^ swA[i]) << 4));
+          al[i] = *reinterpret_cast<const h16x8*>(S + offA[i] + (((2 + h) ^ swA[i]) << 4));
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        bh[j] = *reinterpret_cast<const h16x8*>(S + offB[j] + ((h ^ swB[j]) << 4));
+        bl[j] = *reinterpret_cast<const h16x8*>(S + offB[j] + (((2 + h) ^ swB[j]) << 4));
+      }
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh[j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+        }
+      if (hs + 1 < NH) {  // half stage hs + 1 must have landed; those behind it may stay in flight
+        const int64_t last = hs + 3 < NH ? hs + 3 : NH - 1;
+        hwait(last - (hs + 1));
+        __builtin_amdgcn_s_barrier();
+      }
+    }
+  } else {
   __syncthreads();
   for (int64_t kt = kt_lo; kt < nkt; ++kt) {
     const int buf = (int)(kt & 1);
@@ -786,6 +873,7 @@ __global__ __launch_bounds__(512, 2) void gemm_split_kernel(SplitUpdArgs a) {
         }
     }
     __syncthreads();
+  }
   }
   const bool vec_mirror = a.lower && (a.ldc % 4 == 0) && ((reinterpret_cast<uintptr_t>(a.C) & 15u) == 0);
 #pragma unroll
@@ -941,6 +1029,25 @@ int split_image_pair_zmax(Ctx* ctx, const float* src1, const float* src2, int64_
   return SCLENS_OK;
 }
 
+// SCLENS_HIP_SPLIT_DEEP=0: the two-buffer main loop of gemm_split_kernel (until the end of round 4)
+static bool split_deep() {
+  const char* e = getenv("SCLENS_HIP_SPLIT_DEEP");
+  return !(e && atoi(e) == 0);
+}
+template <bool AF32>
+static int launch_split_kernel(Ctx* ctx, const SplitUpdArgs& a, dim3 grid) {
+  constexpr int LDS_BYTES = 2 * 2 * 256 * 128;
+  if (split_deep()) {
+    SCL_TRY(ensure_dyn_lds(ctx, reinterpret_cast<const void*>(gemm_split_kernel<AF32, true>), LDS_BYTES));
+    hipLaunchKernelGGL((gemm_split_kernel<AF32, true>), grid, dim3(512), LDS_BYTES, ctx->stream, a);
+  } else {
+    SCL_TRY(ensure_dyn_lds(ctx, reinterpret_cast<const void*>(gemm_split_kernel<AF32, false>), LDS_BYTES));
+    hipLaunchKernelGGL((gemm_split_kernel<AF32, false>), grid, dim3(512), LDS_BYTES, ctx->stream, a);
+  }
+  SCL_HIP(ctx, hipGetLastError());
+  return SCLENS_OK;
+}
+
 int gemm_split_update(Ctx* ctx, const void* Pimg, const float* sP, int64_t M, const void* Qimg, const float* sQ, int64_t N, int64_t K,
                       float* C, int64_t ldc, int lower, float post) {
   if (M <= 0 || N <= 0) return SCLENS_OK;
@@ -950,14 +1057,10 @@ int gemm_split_update(Ctx* ctx, const void* Pimg, const float* sP, int64_t M, co
   if (nb > 0x7fffffffLL) return ctx->fail(SCLENS_ERR_ARG, "gemm_split_update: too many tiles");
   const int2* tiles = nullptr;
   if (K >= 2048 && nb >= 1500) SCL_TRY(big_tile_list(ctx, bm, bn, lower, &tiles, &nb));  // operand panels re-used out of the L2s
-  constexpr int LDS_BYTES = 2 * 2 * 256 * 128;
-  SCL_TRY(ensure_dyn_lds(ctx, reinterpret_cast<const void*>(gemm_split_kernel<false>), LDS_BYTES));
   const bool no_acc_init = getenv("SCLENS_HIP_SPLIT_ACC_INIT") && atoi(getenv("SCLENS_HIP_SPLIT_ACC_INIT")) == 0;  // A/B: C in the epilogue
   SplitUpdArgs a{static_cast<const _Float16*>(Pimg), static_cast<const _Float16*>(Qimg), sP, sQ, M, N, round_up(K, 32), C, ldc, lower,
                  (int)bn, post, tiles, 0, 0, 0, (!no_acc_init && fabsf(post) == 1.f) ? 1 : 0, nullptr, 0, 1.f};
-  hipLaunchKernelGGL(gemm_split_kernel<false>, dim3((unsigned)nb), dim3(512), LDS_BYTES, ctx->stream, a);
-  SCL_HIP(ctx, hipGetLastError());
-  return SCLENS_OK;
+  return launch_split_kernel<false>(ctx, a, dim3((unsigned)nb));
 }
 
 // C_s[M][N] = P Q' over the K-slice s (s < splits, k_chunk a multiple of 32), C_s at C + s * c_split_off with row pitch ldc: the
@@ -968,13 +1071,9 @@ int gemm_split_nt(Ctx* ctx, const void* Pimg, const float* sP, int64_t M, const 
   if (splits < 1 || (splits > 1 && k_chunk % 32 != 0)) return ctx->fail(SCLENS_ERR_ARG, "gemm_split_nt: k_chunk must be a multiple of 32");
   const int64_t bm = (M + 255) / 256, bn = (N + 255) / 256, nb = bm * bn;
   if (nb > 0x7fffffffLL) return ctx->fail(SCLENS_ERR_ARG, "gemm_split_nt: too many tiles");
-  constexpr int LDS_BYTES = 2 * 2 * 256 * 128;
-  SCL_TRY(ensure_dyn_lds(ctx, reinterpret_cast<const void*>(gemm_split_kernel<false>), LDS_BYTES));
   SplitUpdArgs a{static_cast<const _Float16*>(Pimg), static_cast<const _Float16*>(Qimg), sP, sQ, M, N, round_up(K, 32), C, ldc, 0,
                  (int)bn, 1.0f, nullptr, splits > 1 ? k_chunk / 32 : round_up(K, 32) / 32, c_split_off, 1, 0, nullptr, 0, 1.f};
-  hipLaunchKernelGGL(gemm_split_kernel<false>, dim3((unsigned)nb, (unsigned)splits), dim3(512), LDS_BYTES, ctx->stream, a);
-  SCL_HIP(ctx, hipGetLastError());
-  return SCLENS_OK;
+  return launch_split_kernel<false>(ctx, a, dim3((unsigned)nb, (unsigned)splits));
 }
 
 // the same with the first operand taken as it is: P [M][K] fp32 (row pitch ldp, K a multiple of 32), scaled by `p_scale` (a power of
@@ -988,13 +1087,9 @@ int gemm_split_nt_f32a(Ctx* ctx, const float* P, int64_t ldp, float p_scale, int
   if (splits < 1 || (splits > 1 && k_chunk % 32 != 0)) return ctx->fail(SCLENS_ERR_ARG, "gemm_split_nt_f32a: k_chunk must be a multiple of 32");
   const int64_t bm = (M + 255) / 256, bn = (N + 255) / 256, nb = bm * bn;
   if (nb > 0x7fffffffLL) return ctx->fail(SCLENS_ERR_ARG, "gemm_split_nt_f32a: too many tiles");
-  constexpr int LDS_BYTES = 2 * 2 * 256 * 128;
-  SCL_TRY(ensure_dyn_lds(ctx, reinterpret_cast<const void*>(gemm_split_kernel<true>), LDS_BYTES));
   SplitUpdArgs a{nullptr, static_cast<const _Float16*>(Qimg), nullptr, sQ, M, N, K, C, ldc, 0,
                  (int)bn, 1.0f, nullptr, splits > 1 ? k_chunk / 32 : K / 32, c_split_off, 1, 0, P, ldp, p_scale};
-  hipLaunchKernelGGL(gemm_split_kernel<true>, dim3((unsigned)nb, (unsigned)splits), dim3(512), LDS_BYTES, ctx->stream, a);
-  SCL_HIP(ctx, hipGetLastError());
-  return SCLENS_OK;
+  return launch_split_kernel<true>(ctx, a, dim3((unsigned)nb, (unsigned)splits));
 }
 
 // the split image of src [rows][K] under a FIXED power-of-two scale (operands whose entries are known to be at most 1 in magnitude:
