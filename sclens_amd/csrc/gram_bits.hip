@@ -31,6 +31,9 @@ namespace {
 
 typedef _Float16 h16x8 __attribute__((ext_vector_type(8)));
 typedef float v16f __attribute__((ext_vector_type(16)));
+typedef float gb_f32x2 __attribute__((ext_vector_type(2)));
+typedef float gb_f32x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 gb_f16x2 __attribute__((ext_vector_type(2)));
 typedef float v4f __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) void lds_void_t;
 typedef const __attribute__((address_space(1))) void glb_void_t;
@@ -329,6 +332,11 @@ struct SplitCorrArgs {
   float alpha;          // 2^-24: undoes the two operand scalings
 };
 
+// RS: the operand stages go through REGISTERS (global_load_dwordx4 -> ds_write_b128, the next stage's loads in flight during this
+// stage's matrix instructions) instead of LDS-DMA. A DMA piece of 1 KB occupies the CU's texture addresser for ~100 clocks, i.e. the
+// DMA path delivers ~10 B per clock and CU -- 64 KB per 32 of K in 6 500 clocks against 3 100 clocks of matrix work: this kernel ran
+// at 0.46 of the fp16 peak, bound by its own staging instructions (profiles/r04_corr_register_staging.log).
+template <bool RS>
 __global__ __launch_bounds__(512, 2) void corr_split_kernel(SplitCorrArgs a, const int2* __restrict__ tiles) {
   constexpr int TM = 4, TN = 2;
   constexpr int OPB = 256 * 128, STAGE = 2 * OPB;
@@ -382,11 +390,36 @@ __global__ __launch_bounds__(512, 2) void corr_split_kernel(SplitCorrArgs a, con
     offB[j] = OPB + r * 128;
     swB[j] = (r >> 1) & 7;
   }
-  stage(0, 0);
+  gb_f32x4 ra[4], rb[4];
+  auto gload = [&](int64_t kt) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      ra[i] = *reinterpret_cast<const gb_f32x4*>(srcA[i] + kt * 64);
+      rb[i] = *reinterpret_cast<const gb_f32x4*>(srcB[i] + kt * 64);
+    }
+  };
+  auto lstore = [&](int buf) {  // the lane-linear image the DMA writes: 16 bytes per lane, 1 KB per wave and 8-row group
+    unsigned char* As = lds + buf * STAGE;
+    unsigned char* Bs = As + OPB;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      *reinterpret_cast<gb_f32x4*>(As + (wid * 4 + i) * 1024 + lane * 16) = ra[i];
+      *reinterpret_cast<gb_f32x4*>(Bs + (wid * 4 + i) * 1024 + lane * 16) = rb[i];
+    }
+  };
+  if (RS) {
+    gload(0);
+    lstore(0);
+  } else {
+    stage(0, 0);
+  }
   __syncthreads();
   for (int64_t kt = 0; kt < nkt; ++kt) {
     const int buf = (int)(kt & 1);
-    if (kt + 1 < nkt) stage(buf ^ 1, kt + 1);
+    if (kt + 1 < nkt) {
+      if (RS) gload(kt + 1);
+      else stage(buf ^ 1, kt + 1);
+    }
     const unsigned char* S = lds + buf * STAGE;
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk) {  // 16 k per step: lane half h takes the 8 k of chunk 2 kk + h (hi) and 4 + 2 kk + h (lo)
@@ -411,6 +444,7 @@ __global__ __launch_bounds__(512, 2) void corr_split_kernel(SplitCorrArgs a, con
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[j], acc[i][j], 0, 0, 0);
         }
     }
+    if (RS && kt + 1 < nkt) lstore(buf ^ 1);  // the buffer of stage kt - 1: every wave has passed the barrier behind it
     __syncthreads();
   }
   // column maxima of |alpha acc| (rows beyond M hold copies of row M - 1: harmless for a maximum)
@@ -611,9 +645,6 @@ struct SplitUpdArgs {
 };
 
 // x = hi + lo (fp16 pieces) of eight scaled fp32 values: two packed conversions and one mixed-precision fma per element
-typedef float gb_f32x2 __attribute__((ext_vector_type(2)));
-typedef float gb_f32x4 __attribute__((ext_vector_type(4)));
-typedef _Float16 gb_f16x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ void split_pk8(gb_f32x4 x0, gb_f32x4 x1, h16x8& hi, h16x8& lo) {
   gb_f16x2 h[4], l[4];
   const float x[8] = {x0[0], x0[1], x0[2], x0[3], x1[0], x1[1], x1[2], x1[3]};
@@ -632,7 +663,7 @@ __device__ __forceinline__ void split_pk8(gb_f32x4 x0, gb_f32x4 x1, h16x8& hi, h
 
 // The main loop of corr_split_kernel with the tile decode, the accumulator start from C and the lower + mirror epilogue of
 // gemm_nt_big<2, 4, 4, 2> (same 256 x 256 tile, same 32 x 32 accumulator layout).
-// DEEP (default since the end of round 4): the operands arrive in HALF stages of 16 of K -- four LDS buffers of 32 KB, three half
+// DEEP (opt-in, SCLENS_HIP_SPLIT_DEEP=1; measured slower, see split_deep()): the operands arrive in HALF stages of 16 of K -- four LDS buffers of 32 KB, three half
 // stages in flight, counted `s_waitcnt vmcnt` and a bare `s_barrier` per half stage. The two-buffer loop (DEEP = false) ends every
 // 32 of K with __syncthreads(), whose release fence is `s_waitcnt vmcnt(0)`: one 64 KB stage in flight, which the L2 -> LDS path
 // delivers in 2.7 us against 1.3 us of matrix work -- 22 of the 55 us of a rank-256 update tile (profiles/r04_split_deep.log).
@@ -1029,10 +1060,11 @@ int split_image_pair_zmax(Ctx* ctx, const float* src1, const float* src2, int64_
   return SCLENS_OK;
 }
 
-// SCLENS_HIP_SPLIT_DEEP=0: the two-buffer main loop of gemm_split_kernel (until the end of round 4)
+// SCLENS_HIP_SPLIT_DEEP=1: half stages of 16 of K, three in flight (measured SLOWER than the two-buffer loop: dense Gram 166 against
+// 155 ms, Q1 108 against 100 ms, band reduction unchanged -- profiles/r04_split_deep.log; opt-in)
 static bool split_deep() {
   const char* e = getenv("SCLENS_HIP_SPLIT_DEEP");
-  return !(e && atoi(e) == 0);
+  return e && atoi(e) != 0;
 }
 template <bool AF32>
 static int launch_split_kernel(Ctx* ctx, const SplitUpdArgs& a, dim3 grid) {
@@ -1113,10 +1145,16 @@ int corr_colabsmax_split(Ctx* ctx, const void* Aimg, int64_t M, const void* Bimg
   int64_t nb = 0;
   SCL_TRY(big_tile_list(ctx, bm, bn, 0, &tiles, &nb));
   constexpr int LDS_BYTES = 2 * 2 * 256 * 128;
-  SCL_TRY(ensure_dyn_lds(ctx, reinterpret_cast<const void*>(corr_split_kernel), LDS_BYTES));
   SplitCorrArgs a{static_cast<const _Float16*>(Aimg), static_cast<const _Float16*>(Bimg), M, N, round_up(K, 32), colabsmax,
                   1.0f / 16777216.0f};
-  hipLaunchKernelGGL(corr_split_kernel, dim3((unsigned)nb), dim3(512), LDS_BYTES, ctx->stream, a, tiles);
+  const bool rs = getenv("SCLENS_HIP_CORR_RS") && atoi(getenv("SCLENS_HIP_CORR_RS")) != 0;  // operand stages through registers (A/B)
+  if (rs) {
+    SCL_TRY(ensure_dyn_lds(ctx, reinterpret_cast<const void*>(corr_split_kernel<true>), LDS_BYTES));
+    hipLaunchKernelGGL(corr_split_kernel<true>, dim3((unsigned)nb), dim3(512), LDS_BYTES, ctx->stream, a, tiles);
+  } else {
+    SCL_TRY(ensure_dyn_lds(ctx, reinterpret_cast<const void*>(corr_split_kernel<false>), LDS_BYTES));
+    hipLaunchKernelGGL(corr_split_kernel<false>, dim3((unsigned)nb), dim3(512), LDS_BYTES, ctx->stream, a, tiles);
+  }
   SCL_HIP(ctx, hipGetLastError());
   return SCLENS_OK;
 }
