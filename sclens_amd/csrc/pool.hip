@@ -28,10 +28,12 @@ bool pool_enabled() {
   static const bool on = !(getenv("SCLENS_HIP_POOL") && atoi(getenv("SCLENS_HIP_POOL")) == 0);
   return on;
 }
-// Cached (idle) bytes per device above which freed blocks go straight back to the driver: SCLENS_HIP_POOL_MAX_GB, else HALF of the
-// device's memory (hipMemGetInfo; 144 GB on an MI355X, 32 GB on a 64 GB part) -- a fixed 160 GB (round 3) was more than some devices
-// own. Other allocators of the process (RCCL, rocPRIM, the host framework) do not see the cache: comm_create trims it before
-// RCCL allocates, sclens_hip_trim() is the public hook, and a failed pool_malloc trims and retries.
+// Cached (idle) bytes per device above which freed blocks go straight back to the driver: SCLENS_HIP_POOL_MAX_GB, else the device's
+// memory less an eighth of it (at least 24 GB) for everybody else (hipMemGetInfo; 252 GB on an MI355X, 40 GB on a 64 GB part). Round 4
+// started with HALF of the device: a 100 000 x 30 000 call holds ~218 GB, so every call ended ~50 GB over that cap, those blocks went
+// back to the driver and the NEXT call began with 1.2 s of hipMalloc in front of its first decompositions (29.15 against 28.6 s per
+// call, profiles/r04_pool_cap.log). Other allocators of the process (RCCL, rocPRIM, the host framework) do not see the cache:
+// comm_create trims it before RCCL allocates, sclens_hip_trim() is the public hook, and a failed pool_malloc trims and retries.
 size_t pool_cap_bytes(int dev) {
   static std::map<int, size_t> caps;  // under g_mu
   auto it = caps.find(dev);
@@ -44,7 +46,7 @@ size_t pool_cap_bytes(int dev) {
     int cur = 0;
     hipGetDevice(&cur);
     if (cur != dev) hipSetDevice(dev);
-    if (hipMemGetInfo(&fr, &tot) == hipSuccess && tot > 0) cap = tot / 2;
+    if (hipMemGetInfo(&fr, &tot) == hipSuccess && tot > 0) cap = tot - std::max<size_t>(tot / 8, std::min<size_t>((size_t)24 << 30, tot / 2));
     if (cur != dev) hipSetDevice(cur);
     (void)hipGetLastError();
   }
