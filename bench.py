@@ -19,7 +19,8 @@ to `--budget-s` seconds of wall-clock (default 1500 s, SCLENS_BENCH_BUDGET_S) an
 warm-up / timed steps as fit. The JSON line reports the TRUE counts in `steps` / `warmup` and the requested ones in
 `steps_requested` / `warmup_requested`.
 
-Prints ONE JSON line on rank 0 (contract in the task statement) with two extra objects:
+Prints ONE JSON line on rank 0 (contract in the task statement), at most 4 KB (`compact_line`; everything else -- per-step decisions,
+job timelines, every stage's rate, the CPU samples -- goes to `bench_detail.json` beside this file and to stderr), with two objects:
   roofline     : the STAGE that owns the wall clock, measured live with HIP events on the library's own stream.
                  n >= 8 192: the two-stage symmetric eigensolver of one sparsity-search step (dense -> band -> tridiagonal,
                  eigenvalues, inverse iteration, both back-transformations of n/2 vectors): achieved = the algorithmic
@@ -29,8 +30,10 @@ Prints ONE JSON line on rank 0 (contract in the task statement) with two extra o
                  `stages` holds the same ratio for every stage of one decomposition, the Gram launch included.
   cpu_baseline : the oracle (float64 NumPy/SciPy port of the reference CPU path) timed on the host cores on two bounded
                  samples (the exponent of the eigensolver's cost is fitted, not assumed), stage-extrapolated to the workload.
-  extra.strict_fp32 : one further step with every fp16-MFMA product switched off (SCLENS_HIP_GRAM_BITS=0 ..._SPLIT=0 SCLENS_HIP_Q2_VARIANT=3),
-                 so that the fp16-assisted and the strict fp32 wall-clock are both timed by the same run.
+  value_strict_fp32 : the same metric over `strict_steps` further steps with the context option precision = 0 (every product on the fp32
+                 matrix cores: the arithmetic of the reference's own GPU path), on the draws of the LAST timed steps, so that both
+                 arithmetic variants are timed by the same run; `decisions_differ`: whether any of those steps ended with another
+                 (signals, robust signals, search length, p_) than its accelerated twin.
 """
 import argparse
 import json
@@ -81,6 +84,7 @@ def symv_probe(ctx, n):
 
 
 def stage_probe(ctx, X, N, M):
+    split_products = ctx.get_option("precision") != 0
     """One decomposition of the data matrix with per-stage HIP-event timing on the library's stream (normalise, Gram,
     eigensolver stages, eigenvectors of the lower half + the corr product as in one search step): achieved rate of each
     stage against the roofline that bounds it."""
@@ -161,8 +165,8 @@ def stage_probe(ctx, X, N, M):
                                            "frac": round(ach / HBM_PEAK_GBS, 4),
                                            "work": "the same bytes for one evaluation of the sparsity search (binarised values + sampled "
                                                    "candidates on the union pattern, row reductions streamed from the CSR companion copy)"}
-    gs_min = int(os.environ.get("SCLENS_HIP_GRAM_SPLIT", "16000") or 0)
-    if gs_min > 0 and n >= gs_min and os.environ.get("SCLENS_HIP_GRAM_BITS", "") != "0":
+    gs_min = ctx.get_option("gram_split_min_n")
+    if split_products and gs_min > 0 and n >= gs_min and ctx.get_option("gram_bits") != 0:
         # the data matrix's Gram product runs on the fp16 MFMA from split operands: three matrix instructions per product
         ms, calls = t["gram"]
         if calls > 0 and ms > 0:
@@ -185,12 +189,22 @@ def stage_probe(ctx, X, N, M):
                                      "fp32_equivalent_TFLOPs": round(ach / 2.0, 1)}
     add("sytrd_one_stage", "sytrd", sum(2.0 * q * (q + 1) for q in range(1, n)), "GB/s", HBM_PEAK_GBS, "hbm",
         "lower triangle of the trailing matrix once per column, whole reduction")
-    add("sy2sb_dense_to_band", "sy2sb", 4.0 / 3.0 * float(n) ** 3, "TFLOP/s", MFMA_F32_PEAK_TFS, "mfma", "4/3 n^3 flop")
+    add("sy2sb_dense_to_band", "sy2sb", 4.0 / 3.0 * float(n) ** 3, "TFLOP/s", MFMA_F32_PEAK_TFS, "mfma",
+        "4/3 n^3 flop, fp32-equivalent (its updates and W = A22 V issue 3x that on the fp16 MFMA when precision = 1; the panel algebra is fp64)")
     add("sb2st_bulge_chasing", "sb2st", 6.0 * float(n) ** 2 * 64, "TFLOP/s", MFMA_F32_PEAK_TFS, "latency",
         "6 n^2 b flop, b = 64 (latency-bound chain of 2 n dependent steps; rate shown for scale only)")
     m = n // 2
-    add("q2_back_transform", "sbr_q2", 2.0 * float(n) ** 2 * m, "TFLOP/s", MFMA_F32_PEAK_TFS, "mfma", "2 n^2 m flop, m = n/2")
-    add("q1_back_transform", "sbr_q1", 2.0 * float(n) ** 2 * m, "TFLOP/s", MFMA_F32_PEAK_TFS, "mfma", "2 n^2 m flop, m = n/2")
+    if split_products:
+        # both back-transformations issue THREE fp16 matrix instructions per fp32-equivalent product (hi hi + hi lo + lo hi): the rate
+        # that compares with a peak is the issued one against the fp16 peak (a fp32-equivalent rate over the fp32 peak can exceed 1)
+        for name, key in (("q2_back_transform", "sbr_q2"), ("q1_back_transform", "sbr_q1")):
+            add(name, key, 3.0 * 2.0 * float(n) ** 2 * m, "TFLOP/s", MFMA_F16_PEAK_TFS, "mfma",
+                "3 x 2 n^2 m flop issued on the fp16 MFMA (split operands), m = n/2")
+            if name in stages:
+                stages[name]["fp32_equivalent_TFLOPs"] = round(stages[name]["achieved"] / 3.0, 1)
+    else:
+        add("q2_back_transform", "sbr_q2", 2.0 * float(n) ** 2 * m, "TFLOP/s", MFMA_F32_PEAK_TFS, "mfma", "2 n^2 m flop, m = n/2")
+        add("q1_back_transform", "sbr_q1", 2.0 * float(n) ** 2 * m, "TFLOP/s", MFMA_F32_PEAK_TFS, "mfma", "2 n^2 m flop, m = n/2")
     add("ormtr_back_transform", "ormtr", 2.0 * float(n) ** 2 * m, "TFLOP/s", MFMA_F32_PEAK_TFS, "mfma", "2 n^2 m flop, m = n/2")
     for key in ("stebz", "stein"):
         ms, calls = t[key]
@@ -205,7 +219,7 @@ def stage_probe(ctx, X, N, M):
 # half-count of 16-byte-per-lane streaming reads (MI355X_MICROARCH.md, HBM) on the large-tile GEMM operand streams and the Q2 images
 # + 941 GB written = 2.30e12 B, 1.07 x the algorithmic bytes of the stages. A constant measured on this build at this size, not in
 # this run (a PMC pass serialises every profiled dispatch); the line carries it only for the workload it was measured on.
-PMC_EIG_TRAFFIC_R04 = {"bytes": 2.296e12, "n": 30016, "vectors": 15008, "algorithmic_bytes": 2.15e12,
+PMC_EIG_TRAFFIC = {"bytes": 2.296e12, "n": 30016, "vectors": 15008, "algorithmic_bytes": 2.15e12,
                        "source": "profiles/r04_pmc_eig/summary.txt"}
 
 
@@ -294,6 +308,60 @@ def cpu_baseline(N, M, n_search, n_perturb, budget_s):
     return out
 
 
+DTYPE_SPLIT = "f32 (large products: operands as 2 x f16 pieces = 22 bit, f32 accumulate)"
+DTYPE_NOTE = ("fp32 data and accumulation, fp64 statistics / eigenvalues / panel algebra. Context option precision = 1 (default): the large "
+              "products run on the fp16 MFMA from operands split into two fp16 pieces (22 significant bits, three matrix instructions per "
+              "product; the Gram matrix of a binarised matrix as an exact 0/1 x 22-bit-weight product) -- Gram products from n = 16 000, the "
+              "search statistic, trailing updates and W = A22 V of the band reduction, both back-transformations. value_strict_fp32 = the "
+              "same call with precision = 0: every product on the fp32 MFMA")
+
+LINE_LIMIT = 4096  # bytes of the ONE JSON line on stdout (the driver keeps the tail of stdout; round 4's 25 KB line was cut and never parsed)
+
+
+def compact_line(full, detail_path=None):
+    """The stdout line: the contract's keys + value_strict_fp32 / strict_steps / decisions_differ + a trimmed roofline and cpu_baseline;
+    every list, timeline and note stays in the detail file. Never longer than LINE_LIMIT bytes (tests/test_host_logic.py)."""
+    keep = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "steps_requested", "warmup_requested", "ms_per_step", "higher_is_better",
+            "scaling", "vs_baseline", "dtype", "data", "value_strict_fp32", "strict_steps", "strict_ms_per_step", "decisions_differ",
+            "bench_wall_s")
+    line = {k: full[k] for k in keep if k in full}
+    cfg = full.get("config", {})
+    line["config"] = {k: cfg[k] for k in ("workload", "N", "M", "n_perturb", "parallelism", "comm", "precision", "keep_warm") if k in cfg}
+    for k in ("workload", "parallelism", "comm"):
+        if isinstance(line["config"].get(k), str) and len(line["config"][k]) > 220:
+            line["config"][k] = line["config"][k][:217] + "..."
+    obs = full.get("observed", {})
+    line["observed"] = {k: obs[k] for k in ("signals", "robust_signals", "search_iters", "p_", "hbm_in_use_GB_after_timed_steps") if k in obs}
+    dec = obs.get("decisions_per_step") or []
+    if dec:
+        line["observed"]["wall_s_per_step"] = [d.get("wall_s") for d in dec][:40]
+        margins = [d["min_abs_margin"] for d in dec if d.get("min_abs_margin") is not None]
+        if margins:
+            line["observed"]["min_abs_margin_over_steps"] = min(margins)
+    rf = full.get("roofline")
+    if rf:
+        line["roofline"] = {k: rf[k] for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "n", "vectors", "launch_ms",
+                                               "launches", "avg_launch_us", "stage_ms") if k in rf}
+        if isinstance(line["roofline"].get("kernel"), str) and len(line["roofline"]["kernel"]) > 160:
+            line["roofline"]["kernel"] = line["roofline"]["kernel"][:157] + "..."
+        st = rf.get("stages") or {}
+        line["roofline"]["stage_frac"] = {k: v["frac"] for k, v in st.items() if isinstance(v, dict) and "frac" in v}
+    cb = full.get("cpu_baseline")
+    if cb:
+        line["cpu_baseline"] = {k: cb[k] for k in ("value", "unit", "cores", "kind", "wall_s_lower_bound", "wall_s_extrapolated") if k in cb}
+        line["cpu_baseline"]["sample"] = (cb.get("sample") or "")[:300]
+    if detail_path:
+        line["detail"] = os.path.basename(detail_path)
+    # last resort: drop the optional parts, longest first, until the line fits
+    for victim in (("observed", "wall_s_per_step"), ("roofline", "stage_frac"), ("roofline", "stage_ms"), ("cpu_baseline", "sample"),
+                   ("config", "comm"), ("config", "parallelism")):
+        if len(json.dumps(line)) <= LINE_LIMIT:
+            break
+        line.get(victim[0], {}).pop(victim[1], None)
+    assert len(json.dumps(line)) <= LINE_LIMIT, len(json.dumps(line))
+    return line
+
+
 def usable_cpus():
     """CPUs this process may really use: affinity and cgroup quota (the GPU box shows 256 CPUs with a quota of 16)."""
     n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
@@ -338,7 +406,9 @@ def main():
     ap.add_argument("--streams", type=int, default=None,
                     help="concurrent decompositions per GPU (worker sessions on own HIP streams); default: 3 below n = 16 000, else 2")
     ap.add_argument("--strict-fp32", default="auto", choices=["auto", "on", "off"],
-                    help="one further timed step with SCLENS_HIP_GRAM_BITS=0 reported as extra.strict_fp32 (auto: for n >= 16 000)")
+                    help="further timed steps with the context option precision = 0 reported as value_strict_fp32 (auto: for n >= 16 000)")
+    ap.add_argument("--strict-steps", type=int, default=3, help="how many of them (on the draws of the last timed steps)")
+    ap.add_argument("--precision", type=int, default=1, choices=[0, 1], help="context option precision of the timed steps (1: split-fp16 products)")
     ap.add_argument("--extra-configs", default="", help="comma-separated further configs timed once each after the main one (reported under `extra`)")
     ap.add_argument("--seed-base", type=int, default=1000, help="timed step s draws with seed seed_base + s (warm-up steps: seed_base - 1 - w)")
     ap.add_argument("--verbose", action="store_true")
@@ -374,6 +444,7 @@ def main():
     from sclens_amd.synth import synth_counts
 
     ctx = Context(local_rank)
+    ctx.set_option("precision", args.precision)
     # the library's own RCCL communicator (csrc/comm.hip); torch.distributed only launched the ranks and ships the unique id
     shard = Shard.create(ctx, rank, world, backend=args.backend)
     check = shard.selfcheck(ctx)  # raises (non-zero exit) when the all-reduce / broadcast on library buffers is wrong
@@ -441,7 +512,7 @@ def main():
                 return atlas.sclens_row_sharded(X_rows, r0, N, draws, shard, n_perturb=args.n_perturb, ctx=ctx, gather=False,
                                                 verbose=args.verbose, nnz_global=int(X.nnz))
             return api.sclens(X, draws=draws, ctx=ctx, n_perturb=args.n_perturb, shard=shard, streams=args.streams,
-                              verbose=args.verbose and rank == 0)
+                              verbose=args.verbose and rank == 0, keep_warm=True)  # a loop of calls: the pool keeps the blocks between them
 
         def fence():
             shard.barrier()
@@ -489,8 +560,11 @@ def main():
     deadline = T_PROCESS_START + args.budget_s
     # reserve for what follows the timed region: roofline probe, CPU baseline sample, extra configs
     reserve = (0 if args.no_roofline else 25) + (0 if args.no_cpu_baseline else 45)
-    strict_planned = args.strict_fp32 == "on" or (args.strict_fp32 == "auto" and min(CONFIGS[args.config][:2]) >= 16000 and not args.row_shard)
-    main_r = run_config(args.config, args.steps, args.warmup, deadline - reserve, tail_steps=1.6 if strict_planned else 0.0)
+    n_min0 = min(CONFIGS[args.config][:2])
+    strict_planned = args.strict_fp32 == "on" or (args.strict_fp32 == "auto" and n_min0 >= 16000 and not args.row_shard)
+    strict_req = max(1, args.strict_steps) if strict_planned else 0
+    # a strict step takes ~1.9 x an accelerated one at cfg4: keep that many step durations of the budget free
+    main_r = run_config(args.config, args.steps, args.warmup, deadline - reserve, tail_steps=2.0 * strict_req)
     N, M, X, res, dt = main_r["N"], main_r["M"], main_r["X"], main_r["res"], main_r["dt"]
     steps = main_r["steps"]
 
@@ -500,6 +574,7 @@ def main():
         print("stage totals (ms, calls):", {k: (round(v[0], 1), v[1]) for k, v in st.items()}, "wall_s", round(dt, 2), file=sys.stderr)
         ctx.set_timing(False)
     out = None
+    precision = ctx.get_option("precision")
     if rank == 0:
         ms_per_step = dt / max(1, steps) * 1e3
         row_shard = main_r["row_shard"]
@@ -509,13 +584,8 @@ def main():
             "unit": "cells*genes/s", "n_gpus": world, "steps": steps, "warmup": main_r["warmup"],
             "steps_requested": args.steps, "warmup_requested": args.warmup, "budget_s": args.budget_s,
             "ms_per_step": round(ms_per_step, 1), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
-            "dtype_note": "fp32 data, fp32 accumulation, fp64 statistics / eigenvalues. The large products run on the fp16 MFMA from "
-                          "operands split into two fp16 pieces (22 significant bits, three matrix instructions per product, fp32 "
-                          "accumulation; measured as accurate as the fp32 MFMA products they replace): Gram products from n = 16 000 "
-                          "(the binarised matrices': exact binary x 22-bit weights), the search statistic, the trailing updates of "
-                          "the band reduction and both back-transformations. extra.strict_fp32 = the same call with every product on "
-                          "the fp32 MFMA",
+            "dtype": DTYPE_SPLIT if precision != 0 else "f32", "data": "synthetic",
+            "dtype_note": DTYPE_NOTE if precision != 0 else "context option precision = 0: every product on the fp32 matrix cores",
             "config": {"workload": f"{args.config}: synthetic Poisson-lognormal counts {N} cells x {M} genes, sparsity "
                                    f"{1 - X.nnz / (N * M):.3f}, full sclens() incl. sparsity search and {args.n_perturb}-member "
                                    f"perturbation ensemble", "N": N, "M": M, "nnz": int(X.nnz), "n_perturb": args.n_perturb,
@@ -525,7 +595,7 @@ def main():
                                        else f"single GPU, {n_streams} concurrent decompositions (HIP streams)" if world == 1 else
                                        f"search rounds of {world}x{n_streams} + ensemble t%{world}, 1 RCCL all-gather "
                                        f"issued by the library on its own buffers"),
-                       "comm": shard.describe()},
+                       "comm": shard.describe(), "precision": precision, "keep_warm": True},
             "sclens_wall_s": round(dt / max(1, steps), 3),
             "observed": {"signals": int(len(res.get("signal_ev", []))), "robust_signals": int(len(res.get("sig_id", []))),
                          "search_iters": int(res["n_search"]), "p_": res["p_"], "synth_s": round(main_r["synth_s"], 1),
@@ -536,40 +606,32 @@ def main():
                          "search_job_s_last_step": [list(q) for q in res.get("search_job_s", [])],
                          "first_phase_jobs_s_last_step": [list(q) for q in res.get("first_phase_s", [])]},
         }
-    # ---- strict fp32: one more step with the fp16-MFMA products of the sparsity search switched off, while the budget lasts
+    # ---- strict fp32: further steps with every product on the fp32 matrix cores (context option precision = 0; the worker contexts of a
+    #      call inherit it), on the draws of the LAST timed steps, while the budget lasts
     extra = {}
     n_min = min(N, M)
-    want_strict = args.strict_fp32 == "on" or (args.strict_fp32 == "auto" and n_min >= 16000 and not main_r["row_shard"])
-    if want_strict and steps > 0 and not agree(time.perf_counter() + 1.4 * dt / max(1, steps) > deadline - reserve):
-        strict_env = {"SCLENS_HIP_GRAM_BITS": "0",   # worker contexts created inside sclens() read it (also: no split-fp16 Gram)
-                      "SCLENS_HIP_GRAM_SPLIT": "0", "SCLENS_HIP_SY2SB_SPLIT": "0", "SCLENS_HIP_Q1_SPLIT": "0",
-                      "SCLENS_HIP_Q2_VARIANT": "3"}  # eigensolver: fp32 products instead of split-fp16 ones
-        old_env = {k: os.environ.get(k) for k in strict_env}
-        os.environ.update(strict_env)
-        ctx.set_option("gram_bits", 0)
-        try:
-            r = run_config(args.config, 1, 0, deadline - reserve, step0=max(0, main_r["last_step"]))  # the LAST timed step's draws
-        finally:
-            ctx.set_option("gram_bits", -1)
-            for k, v in old_env.items():
-                if v is None:
-                    os.environ.pop(k, None)
-                else:
-                    os.environ[k] = v
-        if rank == 0:
-            acc_d = main_r["decisions"][-1] if main_r["decisions"] else None
-            str_d = r["decisions"][-1] if r["decisions"] else None
+    want_strict = strict_req > 0 and precision != 0 and not main_r["row_shard"]
+    if want_strict and steps > 0 and not agree(time.perf_counter() + 2.0 * dt / max(1, steps) > deadline - reserve):
+        k_strict = min(strict_req, steps)
+        first = max(0, main_r["last_step"] - k_strict + 1)
+        with ctx.options(precision=0):
+            r = run_config(args.config, k_strict, 0, deadline - reserve, step0=first)
+        if rank == 0 and r["steps"] > 0:
+            by_seed = {d["seed"]: d for d in main_r["decisions"]}
+            pairs = [(by_seed.get(d["seed"]), d) for d in r["decisions"]]
             same = lambda a, b: all(a[q] == b[q] for q in ("signals", "robust_signals", "search_iters", "p_"))
-            out["value_strict_fp32"] = round(r["N"] * r["M"] / r["dt"], 1)  # the same metric with every product on the fp32 MFMA
-            out["decisions_differ"] = (None if acc_d is None or str_d is None else (not same(acc_d, str_d)))
-            extra["strict_fp32"] = {"sclens_wall_s": round(r["dt"], 3), "value": round(r["N"] * r["M"] / r["dt"], 1),
-                                    "search_iters": int(r["res"]["n_search"]), "signals": int(len(r["res"].get("signal_ev", []))),
-                                    "p_": r["res"]["p_"], "gram_bits_used": int(r["res"].get("gram_bits_used", -1)),
-                                    "same_draws_as": "the last timed step", "decisions": str_d,
-                                    "max_abs_diff_d5_second_smallest": (None if acc_d is None or str_d is None else round(max(
-                                        abs(a - b) for a, b in zip(acc_d["d5_second_smallest"], str_d["d5_second_smallest"])), 6)),
-                                    "note": "SCLENS_HIP_GRAM_BITS=0 SCLENS_HIP_GRAM_SPLIT=0 SCLENS_HIP_SY2SB_SPLIT=0 SCLENS_HIP_Q1_SPLIT=0 "
-                                            "SCLENS_HIP_Q2_VARIANT=3: every product of the path on the fp32 MFMA (no fp16 operand anywhere)"}
+            differ = [b["seed"] for a, b in pairs if a is not None and not same(a, b)]
+            out["value_strict_fp32"] = round(r["N"] * r["M"] * r["steps"] / r["dt"], 1)  # the same metric at the reference GPU path's arithmetic
+            out["strict_steps"] = r["steps"]
+            out["strict_ms_per_step"] = round(r["dt"] / r["steps"] * 1e3, 1)
+            out["decisions_differ"] = (None if not pairs or any(a is None for a, _ in pairs) else bool(differ))
+            extra["strict_fp32"] = {"sclens_wall_s": round(r["dt"] / r["steps"], 3), "steps": r["steps"], "value": out["value_strict_fp32"],
+                                    "same_draws_as": f"the last {r['steps']} timed steps", "decisions": r["decisions"],
+                                    "seeds_whose_decisions_differ": differ,
+                                    "max_abs_diff_d5_second_smallest": [
+                                        (None if a is None else round(max(abs(x - y) for x, y in zip(a["d5_second_smallest"], b["d5_second_smallest"])), 6))
+                                        for a, b in pairs],
+                                    "note": "context option precision = 0: every product of the path on the fp32 MFMA (no fp16 operand anywhere)"}
     # ---- extra configs (one timed step each), while the budget lasts
     for cfg in [c for c in args.extra_configs.split(",") if c]:
         if agree(time.perf_counter() + 60 > deadline - reserve):
@@ -592,22 +654,22 @@ def main():
                 solve_ms = sum(stages[k]["ms"] for k in parts if k in stages)
                 flop = 4.0 / 3.0 * float(n) ** 3 + 2.0 * float(n) ** 2 * (n // 2)
                 ach = flop / (solve_ms * 1e-3) / 1e12
+                pmc = PMC_EIG_TRAFFIC if abs(n - PMC_EIG_TRAFFIC["n"]) <= 64 else None
                 out["roofline"] = {"bound": "mfma", "kernel": "two-stage symmetric eigensolver of one search step (sy2sb + sb2st + stebz + "
                                                              "stein + Q2 + Q1, n/2 eigenvectors): the stage with the most wall time",
                                    "achieved": round(ach, 2), "peak": MFMA_F32_PEAK_TFS, "unit": "TFLOP/s",
                                    "frac": round(ach / MFMA_F32_PEAK_TFS, 4),
-                                   "traffic": (PMC_EIG_TRAFFIC_R04["bytes"] if abs(n - PMC_EIG_TRAFFIC_R04["n"]) <= 64 else None),
-                                   "traffic_source": ("rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, FETCH_SIZE doubled on the 16-byte-"
-                                                      "per-lane streams as MI355X_MICROARCH.md prescribes for gfx950) over one eigensolve of order "
-                                                      f"{PMC_EIG_TRAFFIC_R04['n']} with {PMC_EIG_TRAFFIC_R04['vectors']} vectors on this build: "
-                                                      f"{PMC_EIG_TRAFFIC_R04['bytes']:.3g} B = 1.07 x the algorithmic {PMC_EIG_TRAFFIC_R04['algorithmic_bytes']:.3g} B "
-                                                      f"of its stages ({PMC_EIG_TRAFFIC_R04['source']}); a constant of the build, not measured in this run; "
-                                                      "over the launch's duration ~1.8 TB/s: the solver is not HBM-bound"),
+                                   "traffic": (pmc["bytes"] if pmc else None),
+                                   "traffic_source": (f"rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, FETCH_SIZE doubled on the 16-byte-per-lane "
+                                                      f"streams as MI355X_MICROARCH.md prescribes) over one eigensolve of order {pmc['n']} with {pmc['vectors']} "
+                                                      f"vectors: {pmc['bytes']:.3g} B = {pmc['bytes'] / pmc['algorithmic_bytes']:.2f} x the algorithmic "
+                                                      f"{pmc['algorithmic_bytes']:.3g} B ({pmc['source']}); a constant of the build, not measured in this run"
+                                                      if pmc else None),
                                    "n": n, "vectors": n // 2, "launch_ms": round(solve_ms, 2), "algorithmic_flop_per_launch": flop,
                                    "stage_ms": {k: stages[k]["ms"] for k in parts if k in stages},
-                                   "note": "time-weighted fp32-equivalent rate of the whole stage against the fp32 MFMA peak (its large products "
-                                           "run on the fp16 MFMA from split operands: see dtype_note); the single best kernel (the Gram launch) is "
-                                           "`stages.gram`"}
+                                   "note": "time-weighted fp32-EQUIVALENT rate of the whole stage against the fp32 MFMA peak (with precision = 1 "
+                                           "its large products issue 3x their fp32-equivalent flop on the fp16 MFMA: see dtype_note and the "
+                                           "per-stage fractions against the fp16 peak in the detail file)"}
             else:
                 out["roofline"] = symv_probe(ctx, n)
             out["roofline"]["stages"] = stages
@@ -615,7 +677,16 @@ def main():
             left = deadline - time.perf_counter()
             out["cpu_baseline"] = cpu_baseline(N, M, int(res["n_search"]), args.n_perturb, max(20.0, min(90.0, left - 10)))
         out["bench_wall_s"] = round(time.perf_counter() - T_PROCESS_START, 1)
-        print(json.dumps(out), flush=True)
+        detail_path = os.environ.get("SCLENS_BENCH_DETAIL", os.path.join(ROOT, "bench_detail.json"))
+        try:
+            with open(detail_path, "w") as f:
+                json.dump(out, f, indent=1)
+                f.write("\n")
+        except OSError as e:
+            print(f"[bench] detail file not written ({e})", file=sys.stderr)
+            detail_path = None
+        print("[bench] full record:", json.dumps(out), file=sys.stderr, flush=True)
+        print(json.dumps(compact_line(out, detail_path)), flush=True)
     if world > 1:
         import torch.distributed as dist
 

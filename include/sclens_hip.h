@@ -56,18 +56,37 @@ int sclens_hip_symv_profile_read(sclens_hip_ctx* ctx, int64_t* launches, double*
 /* Roofline probe: all n-1 trd_colB launches of one tridiagonalisation of order n, back to back between one pair of HIP
  * events on the context's stream (synthetic finite data; same grids and arguments as the real reduction). */
 int sclens_hip_symv_probe(sclens_hip_ctx* ctx, int64_t n, int64_t* launches, double* total_ms, double* total_bytes);
-/* Context options. "two_stage" (-1 / 0 / 1; default -1, or the environment variable SCLENS_HIP_TWO_STAGE): which reduction the
- * eigen-solver that replaces cuSOLVER syevd! (scLENS.jl:377) uses. 1 = two-stage (dense -> band of half-width 64 on the
- * matrix cores -> tridiagonal by bulge chasing, sbr.hip; falls back to the one-stage reduction for orders below 128 and when
- * a panel is numerically rank deficient), 0 = one-stage (tridiag.hip), -1 = by order: two-stage from n = 8 192
- * (SCLENS_HIP_TWO_STAGE_MIN_N) upwards. "gram_bits" (-1 / 0 / 1): the Gram matrices of the binarised search matrices and the
- * search statistic on the fp16 MFMA with exact / split operands (gram_bits.hip); -1 = from n = 16 000 (SCLENS_HIP_GRAM_BITS_MIN_N). */
+/* Context options: every tunable of the library is a named integer of the context (table with defaults: csrc/common.h,
+ * SCL_OPTION_TABLE; INTEGRATION.md section 3 lists them). A new context starts from the defaults; the environment variable
+ * SCLENS_HIP_OPTIONS ("name=value,name=value") is applied once, inside sclens_hip_create -- nothing is read from the environment per
+ * call. Unknown names return SCLENS_ERR_ARG. The ones a host touches:
+ *   "precision"  (1 / 0) what the reference selects with `device_` (scLENS.jl:649: "gpu" = Float32 cuBLAS / cuSOLVER, :335-343, :377):
+ *                0 = every product on the fp32 matrix cores (v_mfma_f32_32x32x2_f32 / 16x16x4_f32), the reference GPU path's arithmetic;
+ *                1 (default) = the large products (Gram, search statistic, trailing updates and W of the band reduction, both
+ *                back-transformations) from operands split into two fp16 pieces on the fp16 matrix cores: 22-bit operands, fp32
+ *                accumulation, measured as accurate as the fp32 products they replace;
+ *   "two_stage"  (-1 / 0 / 1) which reduction the eigensolver that replaces cuSOLVER syevd! (scLENS.jl:377) uses: 1 = two-stage (dense ->
+ *                band of half-width 64 -> tridiagonal by bulge chasing, sbr.hip; falls back to the one-stage reduction for orders below
+ *                128 and when a panel is numerically rank deficient), 0 = one-stage (tridiag.hip), -1 = two-stage from "two_stage_min_n"
+ *                (8 192) upwards;
+ *   "gram_bits"  (-1 / 0 / 1) the Gram matrices of the binarised search matrices as exact co-occurrence products and the search statistic
+ *                from split operands (gram_bits.hip); -1 = from "gram_bits_min_n" (16 000); "gram_bits_terms" 2 / 3 = 22 / 33 bits of the
+ *                cell weights.
+ * sclens_hip_copy_options hands one context's settings to another (the worker contexts a host creates for concurrent decompositions;
+ * sclens_hip_session_clone does it for the worker it is given). */
 int sclens_hip_set_option(sclens_hip_ctx* ctx, const char* name, int64_t value);
+int sclens_hip_get_option(sclens_hip_ctx* ctx, const char* name, int64_t* value);
+int sclens_hip_copy_options(sclens_hip_ctx* dst, const sclens_hip_ctx* src);
 /* Device memory of the library is pooled per device: the sessions, worker sessions and contexts of successive sclens() calls ask for
  * the same block sizes, so freed blocks are kept and handed out again instead of going through hipFree / hipMalloc (about 2 s per
- * call at 100 000 x 30 000). sclens_hip_trim gives the idle blocks back to the driver (device_id < 0: every device);
- * SCLENS_HIP_POOL=0 disables pooling, SCLENS_HIP_POOL_MAX_GB caps the idle bytes kept per device (default 160). */
+ * call at 100 000 x 30 000). The cache is for back-to-back calls only: sclens_hip_trim gives the idle blocks back to the driver
+ * (device_id < 0: every device) and a host calls it when sclens() returns unless it is about to call again (api.sclens(keep_warm=...),
+ * the Julia shim's `keep_warm` keyword). Idle bytes kept per device: what was free on the device when the pool first looked, less an
+ * eighth of the device for everybody else; sclens_hip_pool_set_cap overrides it (bytes < 0: back to that rule) -- a host that puts
+ * several ranks on one device gives each its share. Environment (process level, read once): SCLENS_HIP_POOL=0 disables pooling,
+ * SCLENS_HIP_POOL_MAX_GB = the cap. */
 int sclens_hip_trim(int device_id);
+int sclens_hip_pool_set_cap(int device_id, int64_t bytes);
 int sclens_hip_pool_stats(int device_id, int64_t* cached_bytes, int64_t* live_bytes, int64_t* hits, int64_t* misses);
 /* raw stream handle (hipStream_t) so a host framework can order its own work after ours */
 void* sclens_hip_stream(sclens_hip_ctx* ctx);

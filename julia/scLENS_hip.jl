@@ -123,12 +123,16 @@ function sclens_hip(inp_df; kwargs...)
     catch e
         (e isa HipError && e.code in (2, 3)) || rethrow()
         println("(hip) ", e.msg, " -- falling back to device_=\"cpu\"")
-        kw = Dict(kwargs); delete!(kw, :device)
+        kw = Dict(kwargs); delete!(kw, :device); delete!(kw, :precision); delete!(kw, :keep_warm)
         return scLENS.sclens(inp_df; device_="cpu", kw...)
     end
 end
 
-function sclens_hip_device(inp_df; th=60, p_step=0.001, n_perturb=20, centering="mean", device=0)
+# `precision`: the arithmetic, as `device_` picks it in the reference (scLENS.jl:649): 1 (device_="hip") = large products from two fp16
+# pieces per operand on the fp16 matrix cores with fp32 accumulation, 0 (device_="hip-fp32") = every product on the fp32 matrix cores.
+# `keep_warm=true` leaves the call's device blocks in the library's pool for a next call of the same shape; the default hands them back
+# to the driver when the call returns (sclens_hip_trim), so that whatever runs next on the GPU (apply_umap!, :863-873) finds them free.
+function sclens_hip_device(inp_df; th=60, p_step=0.001, n_perturb=20, centering="mean", device=0, precision=1, keep_warm=false)
     if !(centering in ("mean", "median"))
         # the reference's third branch (:655-657) is scaled_gdata(norm_l(scaled_gdata(x, "mean")), "cent") on a dense Float32 copy:
         # the SAME function of x as the mean branch (z-score, equal-norm rows, centred columns), evaluated in Float32
@@ -145,6 +149,7 @@ function sclens_hip_device(inp_df; th=60, p_step=0.001, n_perturb=20, centering=
     X_r = scLENS.df2sparr(scLENS.random_nz(inp_df, rmix=true))                # R2 (:701)
     cp, rv, nz = csc0(X_); rcp, rrv, rnz = csc0(X_r)
     with_ctx(device) do ctx
+        check(ctx, ccall((:sclens_hip_set_option, LIB), Cint, (Ptr{Cvoid}, Cstring, Int64), ctx, "precision", precision))
         ses = Ref{Ptr{Cvoid}}(C_NULL)
         GC.@preserve cp rv nz z1 z2 check(ctx, ccall((:sclens_hip_session_create, LIB), Cint,
             (Ptr{Cvoid}, Int64, Int64, Ptr{Int64}, Ptr{Int32}, Ptr{Float32}, Int64, Ptr{UInt32}, Ptr{UInt32}, Ref{Ptr{Cvoid}}),
@@ -219,6 +224,7 @@ function sclens_hip_device(inp_df; th=60, p_step=0.001, n_perturb=20, centering=
                 :gene_basis => permutedims(gt), :pass => mpC_[:pass], :rec_vals => rec)   # keys of :826-829
         finally
             ccall((:sclens_hip_session_destroy, LIB), Cvoid, (Ptr{Cvoid},), s)
+            keep_warm || ccall((:sclens_hip_trim, LIB), Cint, (Cint,), device)
         end
     end
 end
@@ -226,5 +232,6 @@ end
 end # module
 
 # One-line hook a maintainer adds at the top of scLENS.sclens (src/scLENS.jl:649):
-#     device_ == "hip" && return ScLENSHip.sclens_hip(inp_df; th=th, p_step=p_step, n_perturb=n_perturb, centering=centering)
+#     device_ in ("hip", "hip-fp32") && return ScLENSHip.sclens_hip(inp_df; th=th, p_step=p_step, n_perturb=n_perturb, centering=centering,
+#                                                                     precision=(device_ == "hip" ? 1 : 0))
 # sclens_hip falls back to device_="cpu" on HipError code 2 (no device) or 3 (out of device memory), mirroring example.jl:9-14 and :504-508.

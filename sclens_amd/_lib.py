@@ -39,8 +39,11 @@ SIGNATURES = {
     "sclens_hip_get_timing": (C.c_int, [vp, C.c_char_p, c_f64p, c_i64p]),
     "sclens_hip_reset_timing": (C.c_int, [vp]),
     "sclens_hip_set_option": (C.c_int, [vp, C.c_char_p, i64]),
+    "sclens_hip_get_option": (C.c_int, [vp, C.c_char_p, c_i64p]),
+    "sclens_hip_copy_options": (C.c_int, [vp, vp]),
     "sclens_hip_stream": (vp, [vp]),
     "sclens_hip_trim": (C.c_int, [C.c_int]),
+    "sclens_hip_pool_set_cap": (C.c_int, [C.c_int, i64]),
     "sclens_hip_pool_stats": (C.c_int, [C.c_int, c_i64p, c_i64p, c_i64p, c_i64p]),
     "sclens_hip_symv_probe": (C.c_int, [vp, i64, c_i64p, c_f64p, c_f64p]),
     "sclens_hip_symv_profile": (C.c_int, [vp, C.c_int]),
@@ -238,7 +241,35 @@ class Context:
         self.lib.sclens_hip_trim(self.device)
 
     def set_option(self, name: str, value: int):
+        """a named tunable of this context (include/sclens_hip.h: "precision", "two_stage", "gram_bits", ...; csrc/common.h has the table)"""
         self.check(self.lib.sclens_hip_set_option(self.h, name.encode(), int(value)))
+
+    def get_option(self, name: str) -> int:
+        v = C.c_int64(0)
+        self.check(self.lib.sclens_hip_get_option(self.h, name.encode(), C.byref(v)))
+        return int(v.value)
+
+    def copy_options_from(self, other: "Context"):
+        """worker contexts decompose the way the caller's context does"""
+        self.check(self.lib.sclens_hip_copy_options(self.h, other.h))
+        return self
+
+    def options(self, **kw):
+        """`with ctx.options(precision=0, q2_variant=14): ...` -- set, run, restore"""
+        import contextlib
+
+        @contextlib.contextmanager
+        def scope():
+            old = {k: self.get_option(k) for k in kw}
+            try:
+                for k, v in kw.items():
+                    self.set_option(k, v)
+                yield self
+            finally:
+                for k, v in old.items():
+                    self.set_option(k, v)
+
+        return scope()
 
     # ---- timing
     def set_timing(self, on: bool):

@@ -1035,13 +1035,17 @@ def sclens(inp_df, device_="gpu", th=60, p_step=0.001, n_perturb=20, centering="
            seed: Optional[int] = None, ctx: Optional[Context] = None, max_search_iters: Optional[int] = None,
            keep_intermediates: bool = False, verbose: bool = False, shard: Optional[Shard] = None,
            partial_eig: bool = True, streams: Optional[int] = None, spread_initial: bool = True,
-           guard_band: float = 4.0) -> Dict[str, object]:
+           guard_band: float = 4.0, keep_warm: bool = False) -> Dict[str, object]:
     """scLENS.sclens (scLENS.jl:649-832) on one MI355X.
 
     Same keyword arguments as the reference. `draws`/`seed` expose the randomness the reference takes from
     Julia's global RNG; `max_search_iters` is a test-only cap of the sparsity search; `guard_band` is the half-width of the
     band around the signal threshold, in units of sqrt(n) eps32 lambda_max, inside which eigenvalues are re-evaluated in
-    float64 before the cut (0 switches the refinement off).
+    float64 before the cut (0 switches the refinement off). The arithmetic (the reference's `device_` picks Float32 GPU or Float64
+    CPU, scLENS.jl:649) is the context's "precision" option: `ctx.set_option("precision", 0)` = every product on the fp32 matrix cores,
+    1 (default) = large products from two fp16 pieces; worker contexts inherit the caller's options. `keep_warm=True` leaves the call's
+    device blocks in the library's pool for a next call of the same shape (a loop of calls, bench.py); the default gives them back to
+    the driver when the call returns (sclens_hip_trim), so that whatever runs next on the GPU finds the memory free.
     """
     if device_ != "gpu":
         raise NotImplementedError("sclens_amd implements the device path only; use the reference for device_='cpu'")
@@ -1098,7 +1102,7 @@ def sclens(inp_df, device_="gpu", th=60, p_step=0.001, n_perturb=20, centering="
     ses.set_int("chefsi", 1 if partial_eig else 0)
     ses.set_int("centering", 1 if median else 0)
     lap("session_create")
-    aux_ctx, aux_ctx2 = Context(ctx.device), Context(ctx.device)
+    aux_ctx, aux_ctx2 = Context(ctx.device).copy_options_from(ctx), Context(ctx.device).copy_options_from(ctx)
     aux_pool = ThreadPoolExecutor(max_workers=2)
 
     def build_pattern():
@@ -1125,7 +1129,7 @@ def sclens(inp_df, device_="gpu", th=60, p_step=0.001, n_perturb=20, centering="
         # local workers: `streams` sessions on this GPU (own stream + scratch each, shared read-only data), one host
         # thread per session (ctypes releases the GIL), so independent decompositions overlap on the device
         for _ in range(max(1, int(streams)) - 1):
-            c2 = Context(ctx.device)
+            c2 = Context(ctx.device).copy_options_from(ctx)
             wctx.append(c2)
             workers.append(ses.clone(c2))
         gb0 = sum(w.get_int("gram_bits_used") for w in workers)  # context-lifetime counters: this call's share is the difference
@@ -1254,7 +1258,7 @@ def sclens(inp_df, device_="gpu", th=60, p_step=0.001, n_perturb=20, centering="
                 # two concurrent decompositions are their full-chip products (a round of two costs 2 F + P), so the
                 # data | null pair followed by the binarised matrix costs 3 F + 2 P, while three at once cost 3 F + ~P; and the null
                 # matrix, which the host is still drawing when the call starts (R2, ~0.6 s), no longer delays the pair it belongs to.
-                c3 = Context(ctx.device)
+                c3 = Context(ctx.device).copy_options_from(ctx)
                 w3 = None
                 try:
                     w3 = ses.clone(c3)
@@ -1487,7 +1491,7 @@ def sclens(inp_df, device_="gpu", th=60, p_step=0.001, n_perturb=20, centering="
             for c2 in wctx:
                 c2.close()
 
-        res: Dict[str, object] = {"L": L, "L_mp": L_mp, "λ": lambda_c, "lambda_c": lambda_c, "cell_id": cell_id,
+        res: Dict[str, object] = {"L": L, "Lr": Lr, "L_mp": L_mp, "λ": lambda_c, "lambda_c": lambda_c, "cell_id": cell_id,
                                   "p_": p_, "p_th": p_th, "n_search": it, "search_trace": trace,
                                   "partial_eig": pe_counts, "guard_band": guard,
                                   "gram_bits_used": gram_bits_used, "search_job_s": sorted(job_log, key=lambda q: (q[1], q[0])),
@@ -1560,3 +1564,5 @@ def sclens(inp_df, device_="gpu", th=60, p_step=0.001, n_perturb=20, centering="
             pat.close()
         aux_ctx.close()
         aux_ctx2.close()
+        if not keep_warm:
+            ctx.trim_pool()

@@ -83,22 +83,35 @@ int sclens_hip_create(sclens_hip_ctx** out, int device_id) {
     delete h;
     return SCLENS_ERR_NO_DEVICE;
   }
-  if (const char* ts = getenv("SCLENS_HIP_TWO_STAGE")) h->c.two_stage = atoi(ts) < 0 ? -1 : (atoi(ts) != 0);
-  if (const char* gb = getenv("SCLENS_HIP_GRAM_BITS")) h->c.gram_bits = atoi(gb) < 0 ? -1 : (atoi(gb) != 0);
+  // the one place the library's tunables meet the environment: once per context, never per call (common.h, SCL_OPTION_TABLE)
+  if (const char* eo = getenv("SCLENS_HIP_OPTIONS")) {
+    std::string bad;
+    h->c.opt.parse(eo, &bad);
+    if (!bad.empty()) {
+      h->c.err = "SCLENS_HIP_OPTIONS: not understood: " + bad;
+      std::string msg = h->c.err;
+      sclens_hip_destroy(h);
+      fprintf(stderr, "[sclens_hip] %s\n", msg.c_str());
+      return SCLENS_ERR_ARG;
+    }
+  }
   *out = h;
   return SCLENS_OK;
 }
 int sclens_hip_set_option(sclens_hip_ctx* h, const char* name, int64_t value) {
   if (!h || !name) return SCLENS_ERR_ARG;
-  if (std::string(name) == "two_stage") {
-    h->c.two_stage = value < 0 ? -1 : (value != 0);
-    return SCLENS_OK;
-  }
-  if (std::string(name) == "gram_bits") {
-    h->c.gram_bits = value < 0 ? -1 : (value != 0);
-    return SCLENS_OK;
-  }
+  if (h->c.opt.set(name, value)) return SCLENS_OK;
   return h->c.fail(SCLENS_ERR_ARG, std::string("set_option: unknown option ") + name);
+}
+int sclens_hip_get_option(sclens_hip_ctx* h, const char* name, int64_t* value) {
+  if (!h || !name || !value) return SCLENS_ERR_ARG;
+  if (h->c.opt.get(name, value)) return SCLENS_OK;
+  return h->c.fail(SCLENS_ERR_ARG, std::string("get_option: unknown option ") + name);
+}
+int sclens_hip_copy_options(sclens_hip_ctx* dst, const sclens_hip_ctx* src) {
+  if (!dst || !src) return SCLENS_ERR_ARG;
+  dst->c.opt = src->c.opt;
+  return SCLENS_OK;
 }
 
 void sclens_hip_destroy(sclens_hip_ctx* h) {
@@ -597,6 +610,10 @@ int sclens_hip_dev_eigh_f32(sclens_hip_ctx* h, float* A, int64_t n, int64_t lda,
 }
 int sclens_hip_trim(int device_id) {
   scl::pool_trim(device_id);
+  return SCLENS_OK;
+}
+int sclens_hip_pool_set_cap(int device_id, int64_t bytes) {
+  scl::pool_set_cap(device_id, (long long)bytes);
   return SCLENS_OK;
 }
 int sclens_hip_pool_stats(int device_id, int64_t* cached_bytes, int64_t* live_bytes, int64_t* hits, int64_t* misses) {

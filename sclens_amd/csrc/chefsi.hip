@@ -144,13 +144,9 @@ int topk_chefsi(Ctx* ctx, const float* A, int64_t n, int64_t lda, int m, int m_s
   int S = (int)((320 + tiles_n - 1) / tiles_n);
   S = std::max(Bop ? 4 : 1, std::min(S, 8));
   // implicit operator: both products stream Bop once and are HBM-bound; S (second product) and S1 (first) cut the contractions
-  int S1 = 1;
-  if (Bop) {
-    // (measured at cfg4, 20 perturbations: S/S1 = 4/1 7.7 s, 9/3 7.5 s, 8/2 8.1 s, 16/6 25.8 s -- the products already run at
-    // about half of the HBM roofline and more slices do not help; the knobs stay for other shapes)
-    if (const char* e = getenv("SCLENS_HIP_CHEFSI_SPLITS")) S = std::max(1, std::min(16, atoi(e)));
-    if (const char* e = getenv("SCLENS_HIP_CHEFSI_SPLITS1")) S1 = std::max(1, std::min(16, atoi(e)));
-  }
+  // (measured at cfg4, 20 perturbations: S/S1 = 4/1 7.7 s, 9/3 7.5 s, 8/2 8.1 s, 16/6 25.8 s -- the products already run at
+  // about half of the HBM roofline and more slices do not help)
+  const int S1 = 1;
   const int64_t ldt = Bop ? round_up(Kop, 32) : 0;
   float *Tb = nullptr, *Tpart = nullptr;
   if (Bop) {
@@ -268,8 +264,8 @@ int topk_chefsi(Ctx* ctx, const float* A, int64_t n, int64_t lda, int m, int m_s
   // to the spectrum outside the block, well below the 3e-4 relative tolerance of the parity tests)
   const double tol_rel = 1e-3, tol_rel_tail = 5e-3, tol_gap = 2e-3;
   // tail pairs: gap-aware target only on request (tail_gap > 0; the caller asks for it when a tail vector is CONSUMED, see
-  // api.sclens / session option "chefsi_tail_gap_milli"); SCLENS_HIP_CHEFSI_TAIL_GAP overrides
-  static const double tail_env = getenv("SCLENS_HIP_CHEFSI_TAIL_GAP") ? atof(getenv("SCLENS_HIP_CHEFSI_TAIL_GAP")) : -1.0;
+  // api.sclens / session option "chefsi_tail_gap_milli"); the context option chefsi_tail_gap_micro overrides
+  const double tail_env = ctx->opt.chefsi_tail_gap_micro >= 0 ? 1e-6 * (double)ctx->opt.chefsi_tail_gap_micro : -1.0;
   const double tol_gap_tail = tail_env >= 0.0 ? tail_env : (tail_gap > 0.0 ? tail_gap : 1e30);
   for (int outer = 0; outer < max_outer; ++outer) {
     // ---- Chebyshev filter of `degree`: damp [0, theta_b], normalise at theta_1
@@ -342,7 +338,7 @@ int topk_chefsi(Ctx* ctx, const float* A, int64_t n, int64_t lda, int m, int m_s
         H[i * b + j] = 0.5 * ((double)hGH[b * b + i * b + j] + (double)hGH[b * b + j * b + i]);
       }
     if (!cholesky_lower(G, b)) {  // numerically rank deficient block -> let the caller fall back
-      if (getenv("SCLENS_HIP_DEBUG")) fprintf(stderr, "[chefsi] outer %d: Gram of the block not SPD\n", outer);
+      if (ctx->opt.debug) fprintf(stderr, "[chefsi] outer %d: Gram of the block not SPD\n", outer);
       break;
     }
     invert_lower(G, Li, b);
@@ -391,7 +387,7 @@ int topk_chefsi(Ctx* ctx, const float* A, int64_t n, int64_t lda, int m, int m_s
     SCL_HIP(ctx, hipMemcpyAsync(hres.data(), resd, sizeof(float) * b, hipMemcpyDeviceToHost, st));
     SCL_HIP(ctx, hipStreamSynchronize(st));
     if (iters) *iters = outer + 1;
-    if (getenv("SCLENS_HIP_DEBUG")) {
+    if (ctx->opt.debug) {
       fprintf(stderr, "[chefsi] outer %d deg %d cut %.4g theta:", outer, degree, cut);
       for (int q = 0; q < std::min(b, 14); ++q) fprintf(stderr, " %.5g", theta[q]);
       fprintf(stderr, " ... %.5g | res/theta:", theta[b - 1]);
@@ -421,7 +417,7 @@ int topk_chefsi(Ctx* ctx, const float* A, int64_t n, int64_t lda, int m, int m_s
     if (ok && outer >= 1) { *converged = 1; break; }
     // lock the leading run of pairs that have reached their targets (from the second sweep on); a locked pair that drifts
     // above ten times its target unlocks everything
-    if (outer >= 1 && !getenv("SCLENS_HIP_CHEFSI_NOLOCK")) {
+    if (outer >= 1 && ctx->opt.chefsi_lock) {
       bool drift = false;
       for (int q = 0; q < nlock; ++q) drift = drift || (double)hres[q] > 10.0 * target(q);
       if (drift) {

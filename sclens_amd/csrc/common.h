@@ -13,17 +13,116 @@
 
 namespace scl {
 
+// ------------------------------------------------------------------ options of a context
+// Every tunable of the library is a named integer of the context: sclens_hip_set_option(ctx, "name", value) / sclens_hip_get_option,
+// sclens_hip_copy_options for the worker contexts of a call. A new context starts from the defaults below; SCLENS_HIP_OPTIONS
+// ("name=value,name=value") is applied ONCE, at sclens_hip_create -- nothing in the library reads the environment per call.
+// `precision` is the one a host normally touches (the reference's `device_` kwarg picks the arithmetic, scLENS.jl:649): 0 = every
+// product on the fp32 matrix cores (v_mfma_f32_32x32x2_f32 / 16x16x4: the reference GPU path's arithmetic), 1 = the large products
+// from operands split into two fp16 pieces on the fp16 matrix cores (22-bit operands, fp32 accumulation; default). With precision = 0
+// the *_split* / gram_bits thresholds below are ignored and q2_variant reads as 3.
+#define SCL_OPTION_TABLE(X)                                                                                                        \
+  X(precision, 1)                                                                                                                  \
+  X(two_stage, -1)          /* eigensolver: 1 two-stage (sbr.hip), 0 one-stage (tridiag.hip), -1 by order */                       \
+  X(two_stage_min_n, 8192)                                                                                                         \
+  X(gram_bits, -1)          /* Gram of binarised matrices + search statistic on the fp16 MFMA: 1 always, 0 never, -1 by order */   \
+  X(gram_bits_min_n, 16000)                                                                                                        \
+  X(gram_bits_terms, 2)     /* fp16 pieces of the cell weights: 2 (22 bits) or 3 (33 bits) */                                      \
+  X(gram_split_min_n, 16000) /* dense Gram products from split operands from this order (0: never) */                              \
+  X(implicit_min_n, 16000)  /* ensemble: the Gram matrix applied as two passes over the scaled matrix from this order */           \
+  X(chefsi_b0, 0)           /* block size of the partial eigensolver (0: min_pc + 40 rounded up to 32) */                          \
+  X(chefsi_tail_gap_micro, -1) /* gap-aware target of the tail pairs x 1e6 (-1: what the caller asks for) */                       \
+  X(chefsi_lock, 1)                                                                                                                \
+  X(sy2sb_split_min, 4096)  /* trailing updates of the band reduction from split operands from this many rows (0: never) */        \
+  X(sy2sb_split_scales, 2)  /* 2: separate scales for reflector and Z columns, 1: one scale (round 3) */                           \
+  X(sy2sb_zmax, 1)          /* largest |Z| from the kernel that writes Z (0: by a pass over the operands) */                       \
+  X(sy2sb_wsplit_min, -1)   /* W = A22 V from pieces split in registers from this many rows (-1: sy2sb_split_min, 0: never) */     \
+  X(sy2sb_lookahead, 1)                                                                                                            \
+  X(sy2sb_delay, 1)         /* rank-256 updates for pairs of panels ... */                                                         \
+  X(sy2sb_delay_min, 12288) /* ... while the trailing matrix has at least this many rows */                                        \
+  X(sy2sb_fold_diag, 1)                                                                                                            \
+  X(q1_split_min, 1024)     /* first back-transformation from split operands from this many vectors / rows (0: never) */           \
+  X(q1_w1_split, 1)         /* its first product: 0 fp32, 1 Z split in registers, 2 Z through a split image */                     \
+  X(q1_prep, 1)             /* block reflectors of all groups prepared beside the chase */                                         \
+  X(q1_group, 0)            /* panels per block reflector: 4, 8 or 0 = by size */                                                  \
+  X(chase_mb, 1)            /* bulge chase by messages + prefetch (0: the round-2 kernel, the bitwise reference) */                \
+  X(chase_wgs, 0)           /* cap on its workgroups (0: one per CU) */                                                            \
+  X(q2_variant, 15)         /* second back-transformation: 15 / 14 image-fed (two / one group ahead), 3 fp32 products */           \
+  X(q2_reference, 0)        /* 1: the unblocked reference kernel (tests) */                                                        \
+  X(q2_tg_early, 1)         /* its group data built on the auxiliary stream beside the inverse iteration */                        \
+  X(stein_pf, 16)           /* inverse iteration: steps of loads in flight (4, 16, 32) */                                          \
+  X(stein_its, 2)           /* growth-checked iterations before a vector is accepted (dstein: 3) */                                \
+  X(bisect_div, 0)          /* 1: Sturm counts in the ratio form (round 2) */                                                      \
+  X(split_acc_init, 1)      /* split updates start their accumulators from C (0: C added in the epilogue) */                       \
+  X(dense_fused, 1)         /* scaled matrix written in one pass per gene (0: fill + scatter kernels) */                           \
+  X(host_pattern, 0)        /* 1: sparse pattern built on the host (tests compare the two builders) */                             \
+  X(val_csr, 1)             /* CSR-ordered companion copies of the value arrays */                                                 \
+  X(gemm_force, 0)          /* tests: 1 the large-tile kernels on small shapes, 2 the 128 x 128 kernel on every shape */           \
+  X(panel_prof, 0) X(chase_prof, 0) X(q2_prof, 0) /* per-phase shader clocks on stderr (diagnostic builds of the same kernels) */  \
+  X(debug, 0)
+
+struct Options {
+#define X(name, def) int64_t name = def;
+  SCL_OPTION_TABLE(X)
+#undef X
+  bool set(const std::string& key, int64_t v) {
+#define X(name, def) \
+  if (key == #name) { name = v; return true; }
+    SCL_OPTION_TABLE(X)
+#undef X
+    return false;
+  }
+  bool get(const std::string& key, int64_t* v) const {
+#define X(name, def) \
+  if (key == #name) { *v = name; return true; }
+    SCL_OPTION_TABLE(X)
+#undef X
+    return false;
+  }
+  // "a=1,b=2": unknown names and malformed items are reported in *bad (comma separated), the rest is applied
+  void parse(const char* text, std::string* bad) {
+    std::string s(text ? text : "");
+    size_t i = 0;
+    while (i < s.size()) {
+      size_t j = s.find(',', i);
+      if (j == std::string::npos) j = s.size();
+      const std::string item = s.substr(i, j - i);
+      const size_t eq = item.find('=');
+      bool ok = false;
+      if (eq != std::string::npos && eq > 0 && eq + 1 < item.size()) {
+        char* end = nullptr;
+        const long long v = strtoll(item.c_str() + eq + 1, &end, 10);
+        ok = end && *end == 0 && set(item.substr(0, eq), (int64_t)v);
+      }
+      if (!ok && !item.empty() && bad) *bad += (bad->empty() ? "" : ",") + item;
+      i = j + 1;
+    }
+  }
+  // ---- effective switches: `precision == 0` keeps every product on the fp32 matrix cores
+  bool split() const { return precision != 0; }
+  static int64_t from(int64_t min_n) { return min_n > 0 ? min_n : ((int64_t)1 << 60); }  // "0 = never" thresholds
+  int64_t eff_gram_split_min() const { return split() ? from(gram_split_min_n) : from(0); }
+  int64_t eff_sy2sb_split_min() const { return split() ? from(sy2sb_split_min) : from(0); }
+  int64_t eff_sy2sb_wsplit_min() const { return split() ? (sy2sb_wsplit_min < 0 ? from(sy2sb_split_min) : from(sy2sb_wsplit_min)) : from(0); }
+  int64_t eff_q1_split_min() const { return split() ? q1_split_min : 0; }
+  int eff_gram_bits() const { return split() ? (gram_bits < 0 ? -1 : (gram_bits != 0)) : 0; }
+  int eff_q2_variant() const { return split() ? (int)q2_variant : 3; }
+  int eff_two_stage() const { return two_stage < 0 ? -1 : (two_stage != 0); }
+};
+
 struct Ctx {
   int device = 0;
+  Options opt;
   hipStream_t stream = nullptr;
   // second stream + events for work that overlaps inside one call (look-ahead of the band reduction); created on first use
   hipStream_t aux_stream = nullptr;
+  hipStream_t swapped_main = nullptr;  // the main stream while `stream` temporarily names the auxiliary one (sbr_q1_prepare)
   hipEvent_t aux_ev[2] = {nullptr, nullptr};
   // T factors of the second back-transformation, built on the auxiliary stream right after the bulge chase (sbr.hip): the event
   // that marks them complete and the order they were built for (-1: none / not valid for the current reflectors)
   hipEvent_t q2_ev = nullptr;
   int64_t q2_tg_n = -1;
-  int q2_built_variant = -1;  // SCLENS_HIP_Q2_VARIANT the group data (T factors or LDS images) was last built for
+  int q2_built_variant = -1;  // opt.q2_variant the group data (T factors or LDS images) was last built for
   // block reflectors of the first back-transformation prepared on the auxiliary stream right after the band reduction (sbr.hip,
   // sbr_q1_prepare): the order / panels per group they were built for (-1: none) and the event that marks them complete
   int64_t q1p_n = -1;
@@ -48,13 +147,8 @@ struct Ctx {
     bool valid = false;
     int64_t N = 0, M = 0, n_cells = 0, n_genes = 0, nnz_out = 0;
   } pp;
-  // eigen-solver selection: 0 = one-stage reduction (tridiag.hip), 1 = two-stage (sbr.hip) with fall-back to one-stage, -1 = by order;
-  // set from SCLENS_HIP_TWO_STAGE at creation. last_two_stage: which path holds the state eig_vectors continues from.
-  int two_stage = -1;
+  // which eigensolver holds the state eig_vectors continues from (opt.two_stage selects it); calls of gram_binary
   bool last_two_stage = false;
-  // Gram matrix of a binary pattern on the fp16 MFMA (gram_bits.hip): 1 = whenever the layout allows, 0 = never, -1 = from the
-  // order (SCLENS_HIP_GRAM_BITS_MIN_N, default 16000); set from SCLENS_HIP_GRAM_BITS at creation. gram_bits_used counts calls.
-  int gram_bits = -1;
   long gram_bits_used = 0;
   // sessions keep their eigenvector / ensemble buffers in this context's named workspaces ("ses.*", "eig.*"): one live
   // session per context (worker sessions of session_clone bring their own context)
@@ -80,6 +174,7 @@ static inline void ctx_quiesce(Ctx* c) {
   if (!c) return;
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   if (c->aux_stream) (void)hipStreamSynchronize(c->aux_stream);
+  if (c->swapped_main) (void)hipStreamSynchronize(c->swapped_main);
 }
 
 #define SCL_HIP(ctx, expr)                                                                       \
@@ -128,6 +223,7 @@ static inline int64_t round_up(int64_t x, int64_t m) { return (x + m - 1) / m * 
 hipError_t pool_malloc(void** p, size_t bytes);
 void pool_free(void* p, hipStream_t stream);
 void pool_trim(int device);  // give cached blocks back to the driver (device < 0: all devices)
+void pool_set_cap(int device, long long bytes);  // idle bytes kept per device (bytes < 0: the default rule)
 void pool_stats(int device, size_t* cached, size_t* live, size_t* hits, size_t* misses);
 
 // raise a kernel's dynamic-LDS limit once per context (= per device; a process-wide `static` would cover only the first device)
@@ -171,7 +267,6 @@ struct GemmArgs {
   // then read C while the first operand stage is in flight and their epilogue only stores. Ignored by the 128 x 128 kernel's
   // arithmetic (it applies alpha / beta as usual: same result up to the order of the fp32 additions).
   int acc_init = 0;
-  int dbg = 0;         // timing experiments only (SCLENS_HIP_GEMM_DBG): 1 no mirrored stores, 2 no direct stores, 4 no loads of C
   int stagger_ns = 0;  // set by gemm_f32: period over which the first workgroups of the CUs are staggered (see gemm_nt_big)
 };
 int gemm_f32(Ctx* ctx, const GemmArgs& a);

@@ -329,7 +329,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_big(GemmArgs a, const int2* __
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
           const int64_t row = row0 + (e & 3) + 8 * (e >> 2);
-          if (row < a.M && col < a.N && (!a.lower || col <= row) && !(a.dbg & 4)) acc[i][j][e] = a.C[row * a.ldc + col];
+          if (row < a.M && col < a.N && (!a.lower || col <= row)) acc[i][j][e] = a.C[row * a.ldc + col];
         }
       }
   }
@@ -429,9 +429,9 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_big(GemmArgs a, const int2* __
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
         const int64_t row = row0 + (e & 3) + 8 * (e >> 2);
-        if (row < a.M && col < a.N && (!a.lower || col <= row) && !(a.dbg & 2)) a.C[row * a.ldc + col] = outv[e];
+        if (row < a.M && col < a.N && (!a.lower || col <= row)) a.C[row * a.ldc + col] = outv[e];
       }
-      if (a.lower && col < a.N && !(a.dbg & 1)) {
+      if (a.lower && col < a.N) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
           const int64_t rowq = row0 + 8 * q;
@@ -487,10 +487,6 @@ int gemm_f32(Ctx* ctx, const GemmArgs& a_in) {
   if (a.M <= 0 || a.N <= 0) return SCLENS_OK;
   // C += P Q': the large-tile kernels start their accumulators from C (see acc_init in gemm_nt_big)
   if (a.alpha == 1.f && a.beta == 1.f && !a.colabsmax && a.splits <= 1) a.acc_init = 1;
-  static const bool no_acc_init = getenv("SCLENS_HIP_NO_ACC_INIT") != nullptr;  // A/B measurements only
-  static const int dbg = getenv("SCLENS_HIP_GEMM_DBG") ? atoi(getenv("SCLENS_HIP_GEMM_DBG")) : 0;  // timing experiments: WRONG results
-  a.dbg = dbg;
-  if (no_acc_init) a.acc_init = 0;
   if (a.lower && a.M != a.N) return ctx->fail(SCLENS_ERR_ARG, "gemm_f32: lower needs M == N");
   const int64_t tm = (a.M + BM - 1) / BM, tn = (a.N + BN - 1) / BN;
   const int64_t ntiles = a.lower ? tm * (tm + 1) / 2 : tm * tn;
@@ -502,8 +498,8 @@ int gemm_f32(Ctx* ctx, const GemmArgs& a_in) {
   if (a.acc_init && (a.alpha != 1.f || a.beta != 1.f || a.colabsmax || a.splits > 1))
     return ctx->fail(SCLENS_ERR_ARG, "gemm_f32: acc_init needs alpha == beta == 1, no split, no colabsmax");
   // ---- large-tile NT kernels
-  const bool force_big = getenv("SCLENS_HIP_GEMM_BIG") != nullptr;  // tests: the large-tile kernels on small shapes
-  const bool big_ok = a.q_kcontig && vec && a.K >= GK && (a.splits <= 1 || a.k_chunk % GK == 0) && !getenv("SCLENS_HIP_GEMM_SMALL");
+  const bool force_big = ctx->opt.gemm_force == 1;  // tests: the large-tile kernels on small shapes
+  const bool big_ok = a.q_kcontig && vec && a.K >= GK && (a.splits <= 1 || a.k_chunk % GK == 0) && ctx->opt.gemm_force != 2;
   const int nsl = a.splits > 1 ? a.splits : 1;
   if (big_ok && a.N <= 64 && !a.lower && !a.colabsmax && (a.prefer_big || force_big)) {  // skinny: 256 x 64 tiles
     using Cfg = BigCfg<8, 1, 1, 2>;
@@ -528,13 +524,9 @@ int gemm_f32(Ctx* ctx, const GemmArgs& a_in) {
     if (want_list || (force_big && !a.prefer_big)) SCL_TRY(big_tile_list(ctx, bm, bn, a.lower, &tiles, &nb));
     SCL_TRY(ensure_dyn_lds(ctx, reinterpret_cast<const void*>(gemm_nt_big<2, 4, 4, 2>), 2 * Cfg::STAGE * (int)sizeof(float)));
     // stagger the CUs' phases for read-modify-write products with a short contraction and at least four rounds of tiles
-    // (period ~ MFMA time of a tile, 0.21 us per unit of K at 2.4 GHz, + its HBM time); SCLENS_HIP_GEMM_STAGGER_PCT scales it
+    // (period ~ MFMA time of a tile, 0.21 us per unit of K at 2.4 GHz, + its HBM time)
     a.stagger_ns = 0;
-    if (a.beta != 0.f && a.K <= 1024 && nsl == 1 && nb >= 4 * 256) {
-      static const int pct = getenv("SCLENS_HIP_GEMM_STAGGER_PCT") ? atoi(getenv("SCLENS_HIP_GEMM_STAGGER_PCT")) : 100;
-      const double period_ns = 210.0 * (double)a.K + (a.lower ? 30000.0 : 20000.0);
-      a.stagger_ns = (int)(period_ns * pct / 100.0);
-    }
+    if (a.beta != 0.f && a.K <= 1024 && nsl == 1 && nb >= 4 * 256) a.stagger_ns = (int)(210.0 * (double)a.K + (a.lower ? 30000.0 : 20000.0));
     hipLaunchKernelGGL((gemm_nt_big<2, 4, 4, 2>), dim3((unsigned)nb, (unsigned)nsl), dim3(512), 2 * Cfg::STAGE * sizeof(float),
                        ctx->stream, a, tiles, (int)bn);
     SCL_HIP(ctx, hipGetLastError());

@@ -332,11 +332,8 @@ struct SplitCorrArgs {
   float alpha;          // 2^-24: undoes the two operand scalings
 };
 
-// RS: the operand stages go through REGISTERS (global_load_dwordx4 -> ds_write_b128, the next stage's loads in flight during this
-// stage's matrix instructions) instead of LDS-DMA. A DMA piece of 1 KB occupies the CU's texture addresser for ~100 clocks, i.e. the
-// DMA path delivers ~10 B per clock and CU -- 64 KB per 32 of K in 6 500 clocks against 3 100 clocks of matrix work: this kernel ran
-// at 0.46 of the fp16 peak, bound by its own staging instructions (profiles/r04_corr_register_staging.log).
-template <bool RS>
+// (Measured and removed in round 5: the operand stages through REGISTERS -- global_load_dwordx4 -> ds_write_b128 -- instead of
+// LDS-DMA: the same time, profiles/r04_corr_register_staging.log.)
 __global__ __launch_bounds__(512, 2) void corr_split_kernel(SplitCorrArgs a, const int2* __restrict__ tiles) {
   constexpr int TM = 4, TN = 2;
   constexpr int OPB = 256 * 128, STAGE = 2 * OPB;
@@ -390,36 +387,11 @@ __global__ __launch_bounds__(512, 2) void corr_split_kernel(SplitCorrArgs a, con
     offB[j] = OPB + r * 128;
     swB[j] = (r >> 1) & 7;
   }
-  gb_f32x4 ra[4], rb[4];
-  auto gload = [&](int64_t kt) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      ra[i] = *reinterpret_cast<const gb_f32x4*>(srcA[i] + kt * 64);
-      rb[i] = *reinterpret_cast<const gb_f32x4*>(srcB[i] + kt * 64);
-    }
-  };
-  auto lstore = [&](int buf) {  // the lane-linear image the DMA writes: 16 bytes per lane, 1 KB per wave and 8-row group
-    unsigned char* As = lds + buf * STAGE;
-    unsigned char* Bs = As + OPB;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      *reinterpret_cast<gb_f32x4*>(As + (wid * 4 + i) * 1024 + lane * 16) = ra[i];
-      *reinterpret_cast<gb_f32x4*>(Bs + (wid * 4 + i) * 1024 + lane * 16) = rb[i];
-    }
-  };
-  if (RS) {
-    gload(0);
-    lstore(0);
-  } else {
-    stage(0, 0);
-  }
+  stage(0, 0);
   __syncthreads();
   for (int64_t kt = 0; kt < nkt; ++kt) {
     const int buf = (int)(kt & 1);
-    if (kt + 1 < nkt) {
-      if (RS) gload(kt + 1);
-      else stage(buf ^ 1, kt + 1);
-    }
+    if (kt + 1 < nkt) stage(buf ^ 1, kt + 1);
     const unsigned char* S = lds + buf * STAGE;
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk) {  // 16 k per step: lane half h takes the 8 k of chunk 2 kk + h (hi) and 4 + 2 kk + h (lo)
@@ -444,7 +416,6 @@ __global__ __launch_bounds__(512, 2) void corr_split_kernel(SplitCorrArgs a, con
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[j], acc[i][j], 0, 0, 0);
         }
     }
-    if (RS && kt + 1 < nkt) lstore(buf ^ 1);  // the buffer of stage kt - 1: every wave has passed the barrier behind it
     __syncthreads();
   }
   // column maxima of |alpha acc| (rows beyond M hold copies of row M - 1: harmless for a maximum)
@@ -593,7 +564,12 @@ __global__ __launch_bounds__(256) void k_split_image_pair_zmax(const float* __re
   float sz = 1.f;
   if (mx > 0.f && mx < 1.0e30f) {
     (void)frexpf(mx, &ex);
-    sz = ldexpf(1.f, 14 - ex);
+    // the exponent clamped as in sbr_w_scale: sz, 1 / (sv sz) and C / alpha of the update that follows stay normal numbers even when
+    // the Z columns of a nearly deflated trailing matrix are tiny (entries that small then lose their low piece, an absolute error far
+    // below the rounding of C)
+    int e = 14 - ex;
+    e = e > 60 ? 60 : (e < -60 ? -60 : e);
+    sz = ldexpf(1.f, e);
   }
   const float sv = 8192.f;
   if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) {
@@ -663,11 +639,9 @@ __device__ __forceinline__ void split_pk8(gb_f32x4 x0, gb_f32x4 x1, h16x8& hi, h
 
 // The main loop of corr_split_kernel with the tile decode, the accumulator start from C and the lower + mirror epilogue of
 // gemm_nt_big<2, 4, 4, 2> (same 256 x 256 tile, same 32 x 32 accumulator layout).
-// DEEP (opt-in, SCLENS_HIP_SPLIT_DEEP=1; measured slower, see split_deep()): the operands arrive in HALF stages of 16 of K -- four LDS buffers of 32 KB, three half
-// stages in flight, counted `s_waitcnt vmcnt` and a bare `s_barrier` per half stage. The two-buffer loop (DEEP = false) ends every
-// 32 of K with __syncthreads(), whose release fence is `s_waitcnt vmcnt(0)`: one 64 KB stage in flight, which the L2 -> LDS path
-// delivers in 2.7 us against 1.3 us of matrix work -- 22 of the 55 us of a rank-256 update tile (profiles/r04_split_deep.log).
-template <bool AF32, bool DEEP>
+// (Measured and removed in round 5: operands in HALF stages of 16 of K, four LDS buffers, three half stages in flight behind counted
+// waits -- dense Gram 166 against 155 ms, first back-transformation 108 against 100 ms, profiles/r04_split_deep.log.)
+template <bool AF32>
 __global__ __launch_bounds__(512, 2) void gemm_split_kernel(SplitUpdArgs a) {
   constexpr int TM = 4, TN = 2;
   constexpr int OPB = 256 * 128, STAGE = 2 * OPB;
@@ -729,42 +703,7 @@ __global__ __launch_bounds__(512, 2) void gemm_split_kernel(SplitUpdArgs a) {
     for (int i = 0; i < 4; ++i)
       __builtin_amdgcn_global_load_lds((glb_void_t*)(srcB[i] + kt * 64), (lds_void_t*)(Bs + (wid * 4 + i) * 1024), 16, 0, 0);
   };
-  // half stages (DEEP): lane = 16 rows x 4 slots of 16 bytes; chunk q of row r sits in slot q ^ ((r >> 2) & 3) (source permuted), q = 0, 1:
-  // the hi pieces of k = 0..7, 8..15 of the half stage, q = 2, 3 the lo pieces (fp32 operand: the four quads of its 16 k)
-  constexpr int HSB = 2 * 256 * 64;  // bytes of one half-stage buffer: A rows, then B rows, 64 bytes each
-  const int hrow = lane >> 2, hslot = lane & 3;
-  const _Float16* hsA[2];
-  const float* hsAf[2];
-  const _Float16* hsB[2];
-  if (DEEP) {
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int r = (wid * 2 + i) * 16 + hrow;
-      const int q = hslot ^ ((r >> 2) & 3);
-      const int cq0 = q < 2 ? q : q + 2;  // 16-byte chunk of the 128-byte image row at kk = 0 (kk = 1: two further)
-      int64_t ra = m0 + r, rb = n0 + r;
-      if (ra > a.M - 1) ra = a.M - 1;
-      if (rb > a.N - 1) rb = a.N - 1;
-      hsA[i] = a.A + ra * 2 * a.Kp + 8 * cq0;
-      hsAf[i] = AF32 ? a.Af + ra * a.ldaf + 4 * q : nullptr;
-      hsB[i] = a.B + rb * 2 * a.Kp + 8 * cq0;
-    }
-  }
-  auto hstage = [&](int64_t hs) {  // hs = half-stage index counted from kt_lo
-    unsigned char* As = lds + (int)(hs & 3) * HSB;
-    unsigned char* Bs = As + 256 * 64;
-    const int64_t kt = kt_lo + (hs >> 1), kk = hs & 1;
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      if (AF32) __builtin_amdgcn_global_load_lds((glb_void_t*)(hsAf[i] + kt * 32 + kk * 16), (lds_void_t*)(As + (wid * 2 + i) * 1024), 16, 0, 0);
-      else __builtin_amdgcn_global_load_lds((glb_void_t*)(hsA[i] + kt * 64 + kk * 16), (lds_void_t*)(As + (wid * 2 + i) * 1024), 16, 0, 0);
-    }
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-      __builtin_amdgcn_global_load_lds((glb_void_t*)(hsB[i] + kt * 64 + kk * 16), (lds_void_t*)(Bs + (wid * 2 + i) * 1024), 16, 0, 0);
-  };
-  const int64_t NH = 2 * (nkt - kt_lo);
-  if (!DEEP && kt_lo < nkt) stage((int)(kt_lo & 1), kt_lo);
+  if (kt_lo < nkt) stage((int)(kt_lo & 1), kt_lo);
   const float alpha = a.post / ((AF32 ? a.af_scale : a.sA[0]) * a.sB[0]);  // the scales are powers of two
   // 32-bit indices relative to the tile's corner (and to the corner of its mirror image): the 64-bit row * ldc + col of every
   // element cost this kernel 191 spilled registers
@@ -798,30 +737,19 @@ __global__ __launch_bounds__(512, 2) void gemm_split_kernel(SplitUpdArgs a) {
           acc[i][j][e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rc, vo + (unsigned)(j * 128), so, 0));
       }
   }
-  if (DEEP) {  // behind the loads of C: memory instructions complete in order, so "half stage 0 has landed" covers them
-#pragma unroll
-    for (int p = 0; p < 3; ++p)
-      if (p < NH) hstage(p);
-  }
   int offA[TM], offB[TN], swA[TM], swB[TN];
 #pragma unroll
   for (int i = 0; i < TM; ++i) {
     const int r = wm * 128 + i * 32 + l31;
-    offA[i] = DEEP ? r * 64 : r * 128;
-    swA[i] = DEEP ? (r >> 2) & 3 : (r >> 1) & 7;
+    offA[i] = r * 128;
+    swA[i] = (r >> 1) & 7;
   }
 #pragma unroll
   for (int j = 0; j < TN; ++j) {
     const int r = wn * 64 + j * 32 + l31;
-    offB[j] = DEEP ? 256 * 64 + r * 64 : OPB + r * 128;
-    swB[j] = DEEP ? (r >> 2) & 3 : (r >> 1) & 7;
+    offB[j] = OPB + r * 128;
+    swB[j] = (r >> 1) & 7;
   }
-  auto hwait = [&](int64_t left) {  // at most `left` (0..2) half stages of this wave's DMA may still be in flight
-    if (left >= 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-    else if (left == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  };
-  if (DEEP) hwait((NH < 3 ? NH : 3) - 1);
   if (cinit) {
     const float inv_alpha = 1.f / alpha;
 #pragma unroll
@@ -831,43 +759,6 @@ __global__ __launch_bounds__(512, 2) void gemm_split_kernel(SplitUpdArgs a) {
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[i][j][e] *= inv_alpha;
   }
-  if (DEEP) {
-    __builtin_amdgcn_s_barrier();
-    for (int64_t hs = 0; hs < NH; ++hs) {
-      if (hs + 3 < NH) hstage(hs + 3);  // into the buffer of half stage hs - 1: every wave has passed the barrier behind it
-      const unsigned char* S = lds + (int)(hs & 3) * HSB;
-      h16x8 ah[TM], al[TM], bh[TN], bl[TN];
-#pragma unroll
-      for (int i = 0; i < TM; ++i) {
-        if (AF32) {
-          const gb_f32x4 x0 = *reinterpret_cast<const gb_f32x4*>(S + offA[i] + (((2 * h) ^ swA[i]) << 4));
-          const gb_f32x4 x1 = *reinterpret_cast<const gb_f32x4*>(S + offA[i] + (((2 * h + 1) ^ swA[i]) << 4));
-          split_pk8(x0 * a.af_scale, x1 * a.af_scale, ah[i], al[i]);
-        } else {
-          ah[i] = *reinterpret_cast<const h16x8*>(S + offA[i] + ((h ^ swA[i]) << 4));
-          al[i] = *reinterpret_cast<const h16x8*>(S + offA[i] + (((2 + h) ^ swA[i]) << 4));
-        }
-      }
-#pragma unroll
-      for (int j = 0; j < TN; ++j) {
-        bh[j] = *reinterpret_cast<const h16x8*>(S + offB[j] + ((h ^ swB[j]) << 4));
-        bl[j] = *reinterpret_cast<const h16x8*>(S + offB[j] + (((2 + h) ^ swB[j]) << 4));
-      }
-#pragma unroll
-      for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j) {
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh[j], acc[i][j], 0, 0, 0);
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl[j], acc[i][j], 0, 0, 0);
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[j], acc[i][j], 0, 0, 0);
-        }
-      if (hs + 1 < NH) {  // half stage hs + 1 must have landed; those behind it may stay in flight
-        const int64_t last = hs + 3 < NH ? hs + 3 : NH - 1;
-        hwait(last - (hs + 1));
-        __builtin_amdgcn_s_barrier();
-      }
-    }
-  } else {
   __syncthreads();
   for (int64_t kt = kt_lo; kt < nkt; ++kt) {
     const int buf = (int)(kt & 1);
@@ -904,7 +795,6 @@ __global__ __launch_bounds__(512, 2) void gemm_split_kernel(SplitUpdArgs a) {
         }
     }
     __syncthreads();
-  }
   }
   const bool vec_mirror = a.lower && (a.ldc % 4 == 0) && ((reinterpret_cast<uintptr_t>(a.C) & 15u) == 0);
 #pragma unroll
@@ -958,8 +848,7 @@ size_t gram_binary_scratch_bytes(int64_t N, int64_t M) { return sizeof(unsigned 
 int gram_binary(Ctx* ctx, const PatternDev& p, const float* val, int f32path, void* scratch, float divisor, float* A, int64_t lda,
                 const ShardReduce* sh) {
   const int64_t N = p.N, M = p.M, ldm = round_up(N, 64);
-  const char* nw_env = getenv("SCLENS_HIP_GRAM_BITS_TERMS");  // 2 (22 bits of the weights, default) or 3 (33 bits)
-  const int nw = (nw_env && atoi(nw_env) == 3) ? 3 : 2;
+  const int nw = ctx->opt.gram_bits_terms == 3 ? 3 : 2;  // fp16 pieces of the cell weights: 22 bits (default) or 33
   hipStream_t st = ctx->stream;
   unsigned short* Pm = static_cast<unsigned short*>(scratch);
   const int64_t nparts = (N + 255) / 256;
@@ -1060,22 +949,11 @@ int split_image_pair_zmax(Ctx* ctx, const float* src1, const float* src2, int64_
   return SCLENS_OK;
 }
 
-// SCLENS_HIP_SPLIT_DEEP=1: half stages of 16 of K, three in flight (measured SLOWER than the two-buffer loop: dense Gram 166 against
-// 155 ms, Q1 108 against 100 ms, band reduction unchanged -- profiles/r04_split_deep.log; opt-in)
-static bool split_deep() {
-  const char* e = getenv("SCLENS_HIP_SPLIT_DEEP");
-  return e && atoi(e) != 0;
-}
 template <bool AF32>
 static int launch_split_kernel(Ctx* ctx, const SplitUpdArgs& a, dim3 grid) {
   constexpr int LDS_BYTES = 2 * 2 * 256 * 128;
-  if (split_deep()) {
-    SCL_TRY(ensure_dyn_lds(ctx, reinterpret_cast<const void*>(gemm_split_kernel<AF32, true>), LDS_BYTES));
-    hipLaunchKernelGGL((gemm_split_kernel<AF32, true>), grid, dim3(512), LDS_BYTES, ctx->stream, a);
-  } else {
-    SCL_TRY(ensure_dyn_lds(ctx, reinterpret_cast<const void*>(gemm_split_kernel<AF32, false>), LDS_BYTES));
-    hipLaunchKernelGGL((gemm_split_kernel<AF32, false>), grid, dim3(512), LDS_BYTES, ctx->stream, a);
-  }
+  SCL_TRY(ensure_dyn_lds(ctx, reinterpret_cast<const void*>(gemm_split_kernel<AF32>), LDS_BYTES));
+  hipLaunchKernelGGL((gemm_split_kernel<AF32>), grid, dim3(512), LDS_BYTES, ctx->stream, a);
   SCL_HIP(ctx, hipGetLastError());
   return SCLENS_OK;
 }
@@ -1089,7 +967,7 @@ int gemm_split_update(Ctx* ctx, const void* Pimg, const float* sP, int64_t M, co
   if (nb > 0x7fffffffLL) return ctx->fail(SCLENS_ERR_ARG, "gemm_split_update: too many tiles");
   const int2* tiles = nullptr;
   if (K >= 2048 && nb >= 1500) SCL_TRY(big_tile_list(ctx, bm, bn, lower, &tiles, &nb));  // operand panels re-used out of the L2s
-  const bool no_acc_init = getenv("SCLENS_HIP_SPLIT_ACC_INIT") && atoi(getenv("SCLENS_HIP_SPLIT_ACC_INIT")) == 0;  // A/B: C in the epilogue
+  const bool no_acc_init = ctx->opt.split_acc_init == 0;  // C added in the epilogue (tests compare the two forms)
   SplitUpdArgs a{static_cast<const _Float16*>(Pimg), static_cast<const _Float16*>(Qimg), sP, sQ, M, N, round_up(K, 32), C, ldc, lower,
                  (int)bn, post, tiles, 0, 0, 0, (!no_acc_init && fabsf(post) == 1.f) ? 1 : 0, nullptr, 0, 1.f};
   return launch_split_kernel<false>(ctx, a, dim3((unsigned)nb));
@@ -1147,14 +1025,8 @@ int corr_colabsmax_split(Ctx* ctx, const void* Aimg, int64_t M, const void* Bimg
   constexpr int LDS_BYTES = 2 * 2 * 256 * 128;
   SplitCorrArgs a{static_cast<const _Float16*>(Aimg), static_cast<const _Float16*>(Bimg), M, N, round_up(K, 32), colabsmax,
                   1.0f / 16777216.0f};
-  const bool rs = getenv("SCLENS_HIP_CORR_RS") && atoi(getenv("SCLENS_HIP_CORR_RS")) != 0;  // operand stages through registers (A/B)
-  if (rs) {
-    SCL_TRY(ensure_dyn_lds(ctx, reinterpret_cast<const void*>(corr_split_kernel<true>), LDS_BYTES));
-    hipLaunchKernelGGL(corr_split_kernel<true>, dim3((unsigned)nb), dim3(512), LDS_BYTES, ctx->stream, a, tiles);
-  } else {
-    SCL_TRY(ensure_dyn_lds(ctx, reinterpret_cast<const void*>(corr_split_kernel<false>), LDS_BYTES));
-    hipLaunchKernelGGL(corr_split_kernel<false>, dim3((unsigned)nb), dim3(512), LDS_BYTES, ctx->stream, a, tiles);
-  }
+  SCL_TRY(ensure_dyn_lds(ctx, reinterpret_cast<const void*>(corr_split_kernel), LDS_BYTES));
+  hipLaunchKernelGGL(corr_split_kernel, dim3((unsigned)nb), dim3(512), LDS_BYTES, ctx->stream, a, tiles);
   SCL_HIP(ctx, hipGetLastError());
   return SCLENS_OK;
 }

@@ -41,7 +41,7 @@ int pattern_build(Ctx* ctx, int64_t N, int64_t M, const int64_t* colptr, const i
                   int64_t ncand, const uint32_t* z1, const uint32_t* z2, PatternOwner* out, int64_t row0 = 0,
                   int64_t N_global = 0);
 void pattern_free(PatternOwner* p, Ctx* busy = nullptr);  // busy: a context whose streams may still hold work on the blocks (error paths)
-// device helper shared by both builders: base_val_csr / cand_pos_csr from csr2csc, base_val, cand_pos (SCLENS_HIP_VAL_CSR=0: skip)
+// device helper shared by both builders: base_val_csr / cand_pos_csr from csr2csc, base_val, cand_pos (context option val_csr = 0: skip)
 int pattern_add_csr_companions(Ctx* ctx, PatternOwner* out);
 // The same arrays built on the device from the counts' CSC (pattern_dev.hip); draw != 0 also draws the candidate list there
 // (R1, scLENS.jl:668-673; the list of sclens_draw_zero_candidates for the same seed). Sessions that hold all cells only.

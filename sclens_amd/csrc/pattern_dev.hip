@@ -358,7 +358,7 @@ __global__ void k_csr_cand_pos(const int64_t* __restrict__ cpos, const int64_t* 
 }  // namespace
 
 int pattern_add_csr_companions(Ctx* ctx, PatternOwner* out) {
-  static const bool off = getenv("SCLENS_HIP_VAL_CSR") && atoi(getenv("SCLENS_HIP_VAL_CSR")) == 0;
+  const bool off = ctx->opt.val_csr == 0;
   PatternDev& d = out->dev;
   // only patterns with candidates: those serve the S + P decompositions of the search and the ensemble; a counts-only pattern
   // (data / null / binarised matrix: one or two decompositions each) would pay more for the companions than it saves

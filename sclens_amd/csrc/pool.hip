@@ -28,29 +28,36 @@ bool pool_enabled() {
   static const bool on = !(getenv("SCLENS_HIP_POOL") && atoi(getenv("SCLENS_HIP_POOL")) == 0);
   return on;
 }
-// Cached (idle) bytes per device above which freed blocks go straight back to the driver: SCLENS_HIP_POOL_MAX_GB, else the device's
-// memory less an eighth of it (at least 24 GB) for everybody else (hipMemGetInfo; 252 GB on an MI355X, 40 GB on a 64 GB part). Round 4
-// started with HALF of the device: a 100 000 x 30 000 call holds ~218 GB, so every call ended ~50 GB over that cap, those blocks went
-// back to the driver and the NEXT call began with 1.2 s of hipMalloc in front of its first decompositions (29.15 against 28.6 s per
-// call, profiles/r04_pool_cap.log). Other allocators of the process (RCCL, rocPRIM, the host framework) do not see the cache:
-// comm_create trims it before RCCL allocates, sclens_hip_trim() is the public hook, and a failed pool_malloc trims and retries.
+// Cached (idle) bytes per device above which freed blocks go straight back to the driver. Default: what was FREE on the device when the
+// pool first looked (other processes and other allocators of this process keep what they hold), less an eighth of the device (at least
+// 24 GB) for everybody else -- 252 GB on an otherwise empty MI355X. sclens_hip_pool_set_cap() overrides it (hosts that put several
+// ranks on one device give each its share; SCLENS_HIP_POOL_MAX_GB is the same knob for unmodified hosts, read once). Round 4 started
+// with HALF of the device: a 100 000 x 30 000 call held ~218 GB then, so every call ended over that cap and the NEXT call began with
+// 1.2 s of hipMalloc (profiles/r04_pool_cap.log). The cache is only an optimisation for back-to-back calls: api.sclens() and the
+// Julia shim trim it when a call returns unless the host asks to keep it warm, comm_create trims it before RCCL allocates,
+// sclens_hip_trim() is the public hook, and a failed pool_malloc trims and retries.
+std::map<int, size_t> g_caps;  // under g_mu
 size_t pool_cap_bytes(int dev) {
-  static std::map<int, size_t> caps;  // under g_mu
-  auto it = caps.find(dev);
-  if (it != caps.end()) return it->second;
+  auto it = g_caps.find(dev);
+  if (it != g_caps.end()) return it->second;
   size_t cap = (size_t)64 << 30;
-  if (const char* e = getenv("SCLENS_HIP_POOL_MAX_GB")) {
+  static const char* e = getenv("SCLENS_HIP_POOL_MAX_GB");
+  if (e) {
     cap = (size_t)atoll(e) << 30;
   } else {
     size_t fr = 0, tot = 0;
     int cur = 0;
     hipGetDevice(&cur);
     if (cur != dev) hipSetDevice(dev);
-    if (hipMemGetInfo(&fr, &tot) == hipSuccess && tot > 0) cap = tot - std::max<size_t>(tot / 8, std::min<size_t>((size_t)24 << 30, tot / 2));
+    if (hipMemGetInfo(&fr, &tot) == hipSuccess && tot > 0) {
+      const size_t reserve = std::max<size_t>(tot / 8, std::min<size_t>((size_t)24 << 30, tot / 2));
+      const size_t avail = std::min(fr + g_pool[dev].cached, tot);  // what this process could use: free now + what the pool already holds idle
+      cap = avail > reserve ? avail - reserve : 0;
+    }
     if (cur != dev) hipSetDevice(cur);
     (void)hipGetLastError();
   }
-  caps[dev] = cap;
+  g_caps[dev] = cap;
   return cap;
 }
 size_t size_class(size_t bytes) {
@@ -142,6 +149,12 @@ void pool_trim(int device) {
       trim_locked(kv.second);
       hipSetDevice(cur);
     }
+}
+
+void pool_set_cap(int device, long long bytes) {  // bytes < 0: back to the default rule (evaluated again at the next free)
+  std::lock_guard<std::mutex> lk(g_mu);
+  if (bytes < 0) g_caps.erase(device);
+  else g_caps[device] = (size_t)bytes;
 }
 
 void pool_stats(int device, size_t* cached, size_t* live, size_t* hits, size_t* misses) {

@@ -21,28 +21,10 @@
 // of SB (the caller pads with a decoupled diagonal block). All reductions run in a fixed order: bitwise reproducible.
 #include <algorithm>
 
-#include "common.h"
+#include "sbr_common.h"
 
 namespace scl {
 
-constexpr int SB = 64;
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-typedef __attribute__((address_space(3))) void lds_void;
-typedef const __attribute__((address_space(1))) void glb_void;
-
-// fp16 pieces of fp32 values, x = hi + lo (22 significant bits): four (K = 16 matrix instruction) or eight (K = 32) per lane
-typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
-typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
-typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-struct SbrHL {
-  f16x4 h, l;
-};
-struct SbrHL8 {
-  f16x8 h, l;
-};
-__device__ __forceinline__ SbrHL sbr_split_pk(f32x4 x);
-__device__ __forceinline__ SbrHL8 sbr_cat(const SbrHL& a, const SbrHL& b);
 __global__ void sbr_row_abs_max(const float* __restrict__ A, int64_t n, int64_t lda, unsigned* __restrict__ out);
 
 // Split-K factor of a product whose `tiles` output tiles (one workgroup each, one workgroup per CU) do not fill the 256 CUs:
@@ -108,7 +90,7 @@ struct SbrSmall {
   float* T;      // [SB][SB]
   float* Rh;     // [SB][SB]
   int* flag;
-  unsigned long long* prof;  // SCLENS_HIP_PANEL_PROF=1: [10] shader clocks per phase of sbr_panel_small + the call count (else nullptr)
+  unsigned long long* prof;  // context option panel_prof = 1: [10] shader clocks per phase of sbr_panel_small + the call count (else nullptr)
 };
 
 // 64 x 64 fp64 matrices in LDS, one workgroup of 256 threads. Thread (ti, tj) = (tid >> 4, tid & 15) owns the entries
@@ -779,7 +761,7 @@ __global__ __launch_bounds__(256) void sbr_sum_slabs(const float* __restrict__ i
   out[i] = acc;
 }
 
-static int sbr_ensure_aux(Ctx* ctx) {  // the context's second stream and its events, created on first use
+int sbr_ensure_aux(Ctx* ctx) {  // the context's second stream and its events, created on first use
   if (!ctx->aux_stream) {
     SCL_HIP(ctx, hipStreamCreateWithFlags(&ctx->aux_stream, hipStreamNonBlocking));
     SCL_HIP(ctx, hipEventCreateWithFlags(&ctx->aux_ev[0], hipEventDisableTiming));
@@ -965,15 +947,13 @@ int sy2sb_f32(Ctx* ctx, float* A, int64_t n, int64_t lda, float* Tall, int* brea
   SCL_WS(ctx, Gp, float, "sbr.Gp", (int64_t)(GSL + 1) * SB * 2 * SB);
   // Trailing updates of at least `split_min` rows run on the fp16 matrix cores from operands split into two fp16 pieces
   // (gemm_split_update in gram_bits.hip: 22-bit operands, fp32 accumulation started from C -- the rank-128 / rank-256 update is then
-  // C traffic only: 27 us of fp32 matrix-pipe time per 128 of K and 256 x 256 tile become 5). SCLENS_HIP_SY2SB_SPLIT=0: fp32 products.
-  int64_t split_min = 4096;
-  if (const char* ev = getenv("SCLENS_HIP_SY2SB_SPLIT")) split_min = atoi(ev) > 0 ? std::max<int64_t>(512, atoll(ev)) : (int64_t)1 << 60;
+  // C traffic only: 27 us of fp32 matrix-pipe time per 128 of K and 256 x 256 tile become 5). Context option sy2sb_split_min = 0 (or precision = 0): fp32 products.
+  const int64_t split_min = std::max<int64_t>(512, ctx->opt.eff_sy2sb_split_min());
   // Separate power-of-two scales for the reflector columns (entries up to 1) and the Z columns (entries ~ the norm of the matrix) of
   // the update's operands (default since round 4: first run on hardware there, test_sy2sb_split_update_with_separate_scales at norms
-  // 1, 2^14, 2^20). SCLENS_HIP_SY2SB_SPLIT_SCALES=1: one scale for both, as in round 3 -- accurate only while the norm of the matrix
+  // 1, 2^14, 2^20). Context option sy2sb_split_scales = 1: one scale for both, as in round 3 -- accurate only while the norm of the matrix
   // stays below ~2^12, which a drop-in for `_get_eigen` cannot assume.
-  int split_scales = 2;
-  if (const char* ev = getenv("SCLENS_HIP_SY2SB_SPLIT_SCALES")) split_scales = atoi(ev) == 1 ? 1 : 2;
+  const int split_scales = ctx->opt.sy2sb_split_scales == 1 ? 1 : 2;
   const bool any_split = n >= split_min;
   void* imgP = any_split ? ctx->workspace("sbr.imgP", split_image_bytes(n, LDU)) : nullptr;
   void* imgQ = any_split ? ctx->workspace("sbr.imgQ", split_image_bytes(n, LDU)) : nullptr;
@@ -982,21 +962,19 @@ int sy2sb_f32(Ctx* ctx, float* A, int64_t n, int64_t lda, float* Tall, int* brea
   SCL_WS(ctx, flag, int, "sbr.flag", 4);
   // Largest |Z| of a panel (slot 0 / 1 of a delayed pair), left by the kernel that writes Z: the scales of the split update's operands
   // then need no pass over the operands, no memset and no scale kernel (three launches of ~40 us per update on the main stream). The V
-  // columns take the fixed scale 2^13. SCLENS_HIP_SY2SB_ZMAX=0: the largest entries by a pass over the operands (until round 4).
+  // columns take the fixed scale 2^13. Context option sy2sb_zmax = 0: the largest entries by a pass over the operands (until round 4).
   unsigned* zmax = nullptr;
-  if (any_split && split_scales == 2 && !(getenv("SCLENS_HIP_SY2SB_ZMAX") && atoi(getenv("SCLENS_HIP_SY2SB_ZMAX")) == 0)) {
+  if (any_split && split_scales == 2 && ctx->opt.sy2sb_zmax != 0) {
     zmax = static_cast<unsigned*>(ctx->workspace("sbr.zmax", 4 * sizeof(unsigned)));
     if (!zmax) return SCLENS_ERR_OOM;
   }
   hipStream_t st = ctx->stream;
   SCL_HIP(ctx, hipMemsetAsync(flag, 0, sizeof(int) * 4, st));
   // W = A22 V from fp16 pieces (sbr_w_split) while the trailing matrix has at least `wsplit_min` rows: follows the switch of the
-  // trailing updates; SCLENS_HIP_SY2SB_WSPLIT=0: fp32 product, = r: from r rows
-  int64_t wsplit_min = split_min;
-  if (const char* ev = getenv("SCLENS_HIP_SY2SB_WSPLIT")) wsplit_min = atoi(ev) > 0 ? std::max<int64_t>(2 * SB, atoll(ev)) : (int64_t)1 << 60;
+  // trailing updates; context option sy2sb_wsplit_min = 0: fp32 product, = r: from r rows
+  const int64_t wsplit_min = std::max<int64_t>(2 * SB, ctx->opt.eff_sy2sb_wsplit_min());
   const bool any_wsplit = n - SB >= wsplit_min;
-  int ws_slots = 512;
-  if (const char* ev = getenv("SCLENS_HIP_SY2SB_WS_SLOTS")) ws_slots = std::max(64, atoi(ev));
+  const int ws_slots = 512;  // resident workgroups the split-K slices are chosen for (256 and 1 024 were 7 and 11 ms slower)
   float* Vimg = nullptr;
   float* wsc = nullptr;
   if (any_wsplit) {
@@ -1016,7 +994,7 @@ int sy2sb_f32(Ctx* ctx, float* A, int64_t n, int64_t lda, float* Tall, int* brea
   // V = P M) leaves the critical path.
   SCL_TRY(sbr_ensure_aux(ctx));
   hipStream_t st2 = ctx->aux_stream;
-  const bool lookahead = getenv("SCLENS_HIP_NO_LOOKAHEAD") == nullptr;
+  const bool lookahead = ctx->opt.sy2sb_lookahead != 0;
   // Delayed update (round 3). Per 256 x 256 tile a rank-128 update costs 20 us of C traffic + 17 us of prologue against 27 us
   // of MFMA work (profiles/r03_update_gemm_decomposition.log), so two panels' updates applied as ONE rank-256 update save a third
   // of the update time. An EVEN panel p therefore updates only the columns panel p + 1 is factored from (the look-ahead strip)
@@ -1026,14 +1004,13 @@ int sy2sb_f32(Ctx* ctx, float* A, int64_t n, int64_t lda, float* Tall, int* brea
   // stream (~0.4 ms per pair at full size), which is why the net gain is 14 of the 76 ms the update kernels save
   // (profiles/r03_sy2sb_delayed_update.log; a variant that kept ~1000 tiles of the even panel's update immediate to cover the
   // factorisation was slower than this one: its K = 128 launches and the misaligned 192-column remainder cost more).
-  const bool delay_ok = lookahead && getenv("SCLENS_HIP_SY2SB_NO_DELAY") == nullptr;
+  const bool delay_ok = lookahead && ctx->opt.sy2sb_delay != 0;
   // pair = 2 max(U, F) before, F + max(1.32 U, F) + c now (U: rank-128 update, F ~ 0.39 ms: factorisation, c ~ 0.09 ms: the two
-  // small products): pays from U ~ 0.7 ms, i.e. from a trailing matrix of order ~19 000 (SCLENS_HIP_SY2SB_DELAY_MIN)
-  int64_t delay_min = 12288;  // round 4: the factorisation an even panel exposes got cheaper (0.39 -> 0.25 ms): 457.6 ms at 18 432, 452.5 at 12 288 (r4m)
-  if (const char* ev = getenv("SCLENS_HIP_SY2SB_DELAY_MIN")) delay_min = std::max<int64_t>(4 * SB + 1, atoll(ev));
-  unsigned long long* pprof = nullptr;  // SCLENS_HIP_PANEL_PROF=1: per-phase shader clocks of sbr_panel_small on stderr
-  if (const char* epp = getenv("SCLENS_HIP_PANEL_PROF")) {
-    if (atoi(epp) > 0) {
+  // small products): pays from U ~ 0.7 ms, i.e. from a trailing matrix of order ~19 000 (context option sy2sb_delay_min)
+  const int64_t delay_min = std::max<int64_t>(4 * SB + 1, ctx->opt.sy2sb_delay_min);  // round 4: the factorisation an even panel exposes got cheaper (0.39 -> 0.25 ms): 457.6 ms at 18 432, 452.5 at 12 288 (r4m)
+  unsigned long long* pprof = nullptr;  // context option panel_prof = 1: per-phase shader clocks of sbr_panel_small on stderr
+  {
+    if (ctx->opt.panel_prof > 0) {
       pprof = static_cast<unsigned long long*>(ctx->workspace("sbr.pprof", 16 * sizeof(unsigned long long)));
       if (!pprof) return SCLENS_ERR_OOM;
       SCL_HIP(ctx, hipMemsetAsync(pprof, 0, 16 * sizeof(unsigned long long), st));
@@ -1041,8 +1018,8 @@ int sy2sb_f32(Ctx* ctx, float* A, int64_t n, int64_t lda, float* Tall, int* brea
     }
   }
   // The look-ahead strip's diagonal block used to be a launch of its own (lower + mirror, one workgroup: 41 us of latency per panel
-  // on the main stream, 17 ms per reduction); SCLENS_HIP_SY2SB_FOLD_DIAG=0 restores it
-  const bool fold_diag = !(getenv("SCLENS_HIP_SY2SB_FOLD_DIAG") && atoi(getenv("SCLENS_HIP_SY2SB_FOLD_DIAG")) == 0);
+  // on the main stream, 17 ms per reduction); context option sy2sb_fold_diag = 0 restores it
+  const bool fold_diag = ctx->opt.sy2sb_fold_diag != 0;
   bool pending = false;  // the previous panel's bulk update is outstanding (its operands sit in slot 0)
   auto factor_panel = [&](int64_t p, hipStream_t s_) -> int {
     const int64_t c0 = p * SB, r0 = c0 + SB, np = n - r0;
@@ -1212,7 +1189,7 @@ int sy2sb_f32(Ctx* ctx, float* A, int64_t n, int64_t lda, float* Tall, int* brea
 // panels' own T factors and whose off-diagonal blocks follow the larft recurrence Tm[0:j, j] = -Tm[0:j, 0:j] (Vm[0:j]' V_j) T_j.
 // A group therefore costs three products with a 64 Q1G-deep inner dimension instead of 3 Q1G with 64: the traffic of Z (read once
 // by the first product, read + written by the last) per unit of work drops fourfold, which is what bounds the unmerged form.
-constexpr int Q1G_MAX = 8;  // panels per group: Q1G = 4 or 8 at run time (SCLENS_HIP_Q1G), Q1W = 64 Q1G columns
+constexpr int Q1G_MAX = 8;  // panels per group: Q1G = 4 or 8 at run time (context option q1_group), Q1W = 64 Q1G columns
 
 // clean copies of the group's reflectors: Vm[c][i] (c = 64 q + j: reflector j of panel q, i = position relative to the FIRST
 // panel's r0) and its transpose VmT[i][c]; entries above a panel's own start (i < 64 q) and rows of missing panels are zero
@@ -1334,7 +1311,7 @@ __global__ __launch_bounds__(256) void sbr_q1_sum_w(const float* __restrict__ W1
 // band reduction's output -- 0.7 ms per group, 41 of the stage's 210 ms at order 30 016, all of it a chain of small launches in
 // front of the group's three large products. sbr_q1_prepare builds the data of ALL groups on the auxiliary stream right after the
 // band reduction, beside the bulge chase (a latency chain that leaves most of the chip idle); sbr_apply_q1 then only waits for one
-// event. 3.7 GB of workspace at order 30 016 (SCLENS_HIP_Q1_PREP=0: off, the groups are prepared inline as before).
+// event. 3.7 GB of workspace at order 30 016 (context option q1_prep = 0: off, the groups are prepared inline as before).
 struct Q1Layout {
   int Q1G = 0, Q1W = 0;
   int64_t ngrp = 0, vm_total = 0, img_total = 0, vimg_total = 0;
@@ -1360,9 +1337,8 @@ static Q1Layout sbr_q1_layout(int64_t n, int Q1G) {
   }
   return L;
 }
-static int64_t sbr_q1_split_min() {  // the read-modify-write product of a group runs from split images from this many vectors / rows
-  const char* eqs = getenv("SCLENS_HIP_Q1_SPLIT");  // 0: off; N > 0: from N vectors and N rows (default 1024)
-  return eqs ? atoll(eqs) : 1024;
+static int64_t sbr_q1_split_min(const Ctx* ctx) {  // the read-modify-write product of a group runs from split images from this many vectors / rows
+  return ctx->opt.eff_q1_split_min();  // 0: off; N > 0: from N vectors and N rows (default 1024)
 }
 
 // Vm, VmT, Tm of the group that starts at panel p0 (cnt panels), on ctx->stream; Gp / Gs: scratch
@@ -1387,13 +1363,12 @@ static int sbr_q1_group_data(Ctx* ctx, const float* A, int64_t n, int64_t lda, c
   return SCLENS_OK;
 }
 
-int sbr_q1_prepare(Ctx* ctx, const float* A, int64_t n, int64_t lda, const float* Tall) {
+static int sbr_q1_prepare_impl(Ctx* ctx, const float* A, int64_t n, int64_t lda, const float* Tall) {
   ctx->q1p_n = -1;
-  const char* ep = getenv("SCLENS_HIP_Q1_PREP");
-  const int64_t npan = n / SB - 1, q1_min = sbr_q1_split_min();
-  static const int q1g_env = getenv("SCLENS_HIP_Q1G") ? atoi(getenv("SCLENS_HIP_Q1G")) : 0;
+  const int64_t npan = n / SB - 1, q1_min = sbr_q1_split_min(ctx);
+  const int q1g_env = (int)ctx->opt.q1_group;
   // for the block size of MANY vectors (8 panels); a later call with few vectors (4 panels per group) prepares its groups inline
-  if ((ep && atoi(ep) == 0) || !ctx->q2_prebuild || npan < 64 || q1_min <= 0 || (q1g_env != 0 && q1g_env != 8) || n % SB != 0) return SCLENS_OK;
+  if (ctx->opt.q1_prep == 0 || !ctx->q2_prebuild || npan < 64 || q1_min <= 0 || (q1g_env != 0 && q1g_env != 8) || n % SB != 0) return SCLENS_OK;
   const int Q1G = 8;
   const Q1Layout L = sbr_q1_layout(n, Q1G);
   const int Q1W = L.Q1W, SG = 64;
@@ -1415,8 +1390,8 @@ int sbr_q1_prepare(Ctx* ctx, const float* A, int64_t n, int64_t lda, const float
   struct Swap {
     Ctx* c;
     hipStream_t main;
-    explicit Swap(Ctx* c_) : c(c_), main(c_->stream) { c->stream = c->aux_stream; }
-    ~Swap() { c->stream = main; }
+    explicit Swap(Ctx* c_) : c(c_), main(c_->stream) { c->stream = c->aux_stream; c->swapped_main = main; }  // ctx_quiesce still covers it
+    ~Swap() { c->stream = main; c->swapped_main = nullptr; }
   } swap(ctx);
   for (int64_t g = L.ngrp - 1; g >= 0; --g) {  // the order the apply loop consumes them in
     if (L.np[g] < q1_min) continue;            // short groups keep the fp32 product and are prepared inline
@@ -1432,6 +1407,18 @@ int sbr_q1_prepare(Ctx* ctx, const float* A, int64_t n, int64_t lda, const float
   ctx->q1p_g = Q1G;
   return SCLENS_OK;
 }
+// The preparation is an overlap optimisation with 3.7 GB of workspace of its own at order 30 016: when it fails (out of memory on a
+// smaller part, or with three worker contexts) the call goes on and sbr_apply_q1 prepares every group inline, as without it.
+int sbr_q1_prepare(Ctx* ctx, const float* A, int64_t n, int64_t lda, const float* Tall) {
+  const int rc = sbr_q1_prepare_impl(ctx, A, n, lda, Tall);
+  if (rc == SCLENS_OK) return rc;
+  ctx_quiesce(ctx);
+  (void)hipGetLastError();
+  ctx->err.clear();
+  ctx->q1p_n = -1;
+  for (const char* w : {"sbr.q1pVm", "sbr.q1pImg", "sbr.q1pTm", "sbr.q1pS", "sbr.q1pVimg", "sbr.q1pVmT", "sbr.q1pG", "sbr.q1pGs"}) ctx->release(w);
+  return SCLENS_OK;
+}
 
 int sbr_apply_q1(Ctx* ctx, const float* A, int64_t n, int64_t lda, const float* Tall, float* Zt, int64_t m, int64_t ldz) {
   if (m <= 0) return SCLENS_OK;
@@ -1443,7 +1430,7 @@ int sbr_apply_q1(Ctx* ctx, const float* A, int64_t n, int64_t lda, const float* 
   if (npan <= 0) return SCLENS_OK;
   // panels per block reflector: the three products of a group contract over 64 Q1G columns; the large-tile kernel reaches
   // 82 / 100 TF/s at K = 256 / 512 with a read-modify-write of C (scripts/perf_update.py), so wide groups pay for many vectors
-  static const int q1g_env = getenv("SCLENS_HIP_Q1G") ? atoi(getenv("SCLENS_HIP_Q1G")) : 0;
+  const int q1g_env = (int)ctx->opt.q1_group;
   const int Q1G = (q1g_env == 4 || q1g_env == 8) ? q1g_env : (m >= 2048 && npan >= 64 ? 8 : 4);
   const int Q1W = Q1G * SB;
   const int64_t ngrp = (npan + Q1G - 1) / Q1G;
@@ -1453,8 +1440,8 @@ int sbr_apply_q1(Ctx* ctx, const float* A, int64_t n, int64_t lda, const float* 
   const int SG = 64;
   // The read-modify-write product of a group, Zt += W2 Vm, on the fp16 matrix cores from split operands when it is large enough
   // (gemm_split_update: 22-bit operands, fp32 accumulation, C added in the epilogue): at K = 512 the fp32 matrix-pipe time is four
-  // fifths of the product. SCLENS_HIP_Q1_SPLIT=0: fp32 products.
-  const int64_t q1_min = sbr_q1_split_min();
+  // fifths of the product. Context option q1_split_min = 0: fp32 products.
+  const int64_t q1_min = sbr_q1_split_min(ctx);
   const bool q1_split = q1_min > 0 && m >= q1_min;
   // groups prepared ahead on the auxiliary stream (sbr_q1_prepare): valid for this order, this group size and the split product
   const bool prepared = q1_split && ctx->q1p_n == n && ctx->q1p_g == Q1G && ctx->q1_ev;
@@ -1488,12 +1475,12 @@ int sbr_apply_q1(Ctx* ctx, const float* A, int64_t n, int64_t lda, const float* 
   // still on the fp32 matrix cores: 0.11 of its 0.21 s). Rows of Zt are unit vectors and reflector entries are at most 1, so both
   // images take the fixed scale 2^13 -- no pass for the largest entry; the image of Zt's columns is formed per group (they change
   // with every group's update: one streaming pass, 8 bytes per entry), the image of Vm with the prepared group data or inline.
-  // SCLENS_HIP_Q1_W1_SPLIT=0: this product stays fp32.
-  const char* ew1 = getenv("SCLENS_HIP_Q1_W1_SPLIT");
-  const bool w1_split = q1_split && !(ew1 && atoi(ew1) == 0);
+  // Context option q1_w1_split = 0: this product stays fp32.
+  const int64_t ew1 = ctx->opt.q1_w1_split;
+  const bool w1_split = q1_split && ew1 != 0;
   // (end of round 4) Z enters that product as it is and is split in registers by the kernel (gemm_split_nt_f32a): the image of Z was
-  // a read and a write of the vector block per group, 62 ms of the 125 ms of this stage at n = 30 016. SCLENS_HIP_Q1_W1_SPLIT=2: the image.
-  const bool w1_regs = w1_split && !(ew1 && atoi(ew1) == 2);
+  // a read and a write of the vector block per group, 62 ms of the 125 ms of this stage at n = 30 016. q1_w1_split = 2: the image.
+  const bool w1_regs = w1_split && ew1 != 2;
   void* imgZ = (w1_split && !w1_regs) ? ctx->workspace("sbr.q1imgZ", split_image_bytes(m, n)) : nullptr;
   void* imgVm = w1_split ? ctx->workspace("sbr.q1imgVm", split_image_bytes(Q1W, n)) : nullptr;
   if (w1_split && ((!w1_regs && !imgZ) || !imgVm)) return SCLENS_ERR_OOM;
@@ -1582,9 +1569,6 @@ int sbr_apply_q1(Ctx* ctx, const float* A, int64_t n, int64_t lda, const float* 
 // with agent-scope release / acquire. Blocks live in LDS (2 x 64 x 64 floats); the band is packed as Bd[column][row - column]
 // with room for the bulge (row - column <= 2 SB).
 constexpr int LDB2 = 2 * SB + 4;  // floats per column of the packed band
-// leading dimension of the reflector store V2[sweep][row]: 128 spare columns, so that the 64-float run of a reflector that starts
-// up to 32 rows past the end (a sweep of a 32-sweep group that has no task k any more) stays inside its own, zero-filled, row
-static inline int64_t sbr_ldv2(int64_t n) { return round_up(n, 64) + 128; }
 
 __global__ void sbr_pack_band(const float* __restrict__ A, int64_t n, int64_t lda, float* __restrict__ Bd) {
   const int64_t j = blockIdx.x;
@@ -1592,7 +1576,6 @@ __global__ void sbr_pack_band(const float* __restrict__ A, int64_t n, int64_t ld
     Bd[j * LDB2 + r] = (r <= SB && j + r < n) ? A[(j + r) * lda + j] : 0.f;
 }
 
-__device__ __forceinline__ int sbr_tasks_of(int64_t s, int64_t n) { return (int)((n - s - 1 + SB - 1) / SB); }
 
 // One task = one workgroup step: 256 threads in two register mappings of a 64 x 64 block,
 //   T1: lane = row i, wave = 16-column group jq   (global loads / stores are 256-byte runs per wave-instruction),
@@ -1841,7 +1824,7 @@ __device__ __forceinline__ int sbr_spin_flag(const unsigned* p, int need, unsign
 }
 
 // PROF: wave 0 samples the shader clock at eight points of every task and adds the differences into a.prof[0..7], the task count
-// into a.prof[8] (SCLENS_HIP_CHASE_PROF=1 prints the averages).
+// into a.prof[8] (context option chase_prof = 1 prints the averages).
 template <bool PROF>
 __global__ __launch_bounds__(256) void sbr_chase_mb(SbrChaseMbArgs a) {
 #pragma clang fp contract(off)  // every fused multiply-add below is written out: sbr_chase and sbr_chase_mb give the same bits
@@ -2091,7 +2074,6 @@ __global__ void sbr_band_diag(const float* __restrict__ Bd, int64_t n, double* _
   }
 }
 
-static int sbr_q2_launch_build_t(Ctx* ctx, int64_t n, hipStream_t st);  // below, with the second back-transformation
 
 // A: the output of sy2sb_f32 (lower band valid). d, e (fp64, device) receive the tridiagonal matrix.
 int sb2st_f32(Ctx* ctx, const float* A, int64_t n, int64_t lda, double* d_dev, double* e_dev) {
@@ -2114,13 +2096,12 @@ int sb2st_f32(Ctx* ctx, const float* A, int64_t n, int64_t lda, double* d_dev, d
   SCL_HIP(ctx, hipGetDevice(&dev));
   SCL_HIP(ctx, hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
   // (three workgroups fit a CU -- 145 VGPRs, 36 KB of LDS -- so the chases of up to three concurrent streams stay co-resident
-  // even at one workgroup per sweep in flight; SCLENS_HIP_CHASE_WGS lowers it. 128 workgroups: 330 ms, 235: 297 ms at n = 30 016)
+  // even at one workgroup per sweep in flight; context option chase_wgs lowers it. 128 workgroups: 330 ms, 235: 297 ms at n = 30 016)
   int G = (int)std::min<int64_t>(cus > 0 ? cus : 64, n / (2 * SB) + 1);
   if (G < 1) G = 1;
-  if (const char* eg = getenv("SCLENS_HIP_CHASE_WGS")) G = std::max(1, std::min(G, atoi(eg)));
+  if (ctx->opt.chase_wgs > 0) G = std::max(1, std::min(G, (int)ctx->opt.chase_wgs));
   SbrChaseArgs ca{Bd, n, V2, ldv2, TAU2, ldt, done};
-  int use_mb = 1;
-  if (const char* ev = getenv("SCLENS_HIP_CHASE_MB")) use_mb = atoi(ev);
+  const int use_mb = (int)ctx->opt.chase_mb;
   // (Round 3 tried a stream whose CU mask holds a third of the CUs, so that the chase packs three workgroups per CU and leaves the
   // rest of the chip whole for the 256 x 256 GEMM workgroups of a concurrent decomposition -- a chase workgroup takes 36 KB of
   // the 160 KB of LDS, and the dispatcher spreads the ~n / 128 workgroups one per CU, where no 128 KB GEMM workgroup fits beside
@@ -2131,8 +2112,7 @@ int sb2st_f32(Ctx* ctx, const float* A, int64_t n, int64_t lda, double* d_dev, d
     SCL_WS(ctx, MB, unsigned long long, "sbr.MB", (int64_t)R * kmax * MBW);
     SCL_HIP(ctx, hipMemsetAsync(MB, 0, sizeof(unsigned long long) * (size_t)R * kmax * MBW, st));  // tag 0 = no sweep
     SbrChaseMbArgs cm{Bd, n, V2, ldv2, TAU2, ldt, done, MB, R, kmax, nullptr};
-    const char* ep = getenv("SCLENS_HIP_CHASE_PROF");
-    if (ep && atoi(ep) > 0) {
+    if (ctx->opt.chase_prof > 0) {
       SCL_WS(ctx, prof, unsigned long long, "sbr.prof", 16);
       SCL_HIP(ctx, hipMemsetAsync(prof, 0, sizeof(unsigned long long) * 16, st));
       cm.prof = prof;
@@ -2171,1591 +2151,6 @@ int sb2st_f32(Ctx* ctx, const float* A, int64_t n, int64_t lda, double* d_dev, d
   if (aborted) return ctx->fail(SCLENS_ERR_HIP, "sb2st_f32: a sweep waited too long for its predecessor (bulge chasing aborted)");
   return SCLENS_OK;
 }
-
-// The T factors of the second back-transformation (33 ms at n = 30 016) depend only on the reflectors of the chase: enqueued on the
-// auxiliary stream BEHIND what the main stream holds now (the bisection: it is bound by vector-ALU issue and lost 40 ms with this
-// kernel beside it), so that they are built beside the inverse iteration -- a few hundred waves waiting for memory -- instead of in
-// front of sbr_apply_q2. profiles/r03_eig_30016_final.log.
-static int sbr_q2_prebuild(Ctx* ctx, int64_t n) {
-  const char* et = getenv("SCLENS_HIP_Q2_TG_EARLY");
-  if ((et && atoi(et) == 0) || n - 2 <= 0 || !ctx->q2_prebuild) return SCLENS_OK;
-  SCL_TRY(sbr_ensure_aux(ctx));
-  SCL_HIP(ctx, hipEventRecord(ctx->aux_ev[0], ctx->stream));
-  SCL_HIP(ctx, hipStreamWaitEvent(ctx->aux_stream, ctx->aux_ev[0], 0));
-  SCL_TRY(sbr_q2_launch_build_t(ctx, n, ctx->aux_stream));
-  SCL_HIP(ctx, hipEventRecord(ctx->q2_ev, ctx->aux_stream));
-  ctx->q2_tg_n = n;
-  return SCLENS_OK;
-}
-
-
-// ---- second back-transformation, reference version: rows of Zt (eigenvectors of the tridiagonal matrix) -> eigenvectors
-// of the band matrix. z_B = Q2 z_T with Q2 = prod_{s ascending} prod_k H_{s,k}: the reflectors are applied in the reverse
-// order of their creation, sweep by sweep (the tasks of one sweep act on disjoint coordinates). One workgroup keeps
-// `VT` whole vectors in LDS and streams all reflectors: every workgroup reads all of V2, so this version is only meant
-// for tests and small orders; the blocked version (groups of consecutive sweeps as WY blocks) replaces it.
-__global__ __launch_bounds__(256) void sbr_q2_simple(const float* __restrict__ V2, int64_t ldv2, const float* __restrict__ TAU2,
-                                                     int64_t ldt, int64_t n, float* __restrict__ Zt, int64_t m, int64_t ldz,
-                                                     int VT) {
-  extern __shared__ float zs[];  // [VT][n]
-  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-  const int64_t v0 = (int64_t)blockIdx.x * VT;
-  const int nv = (int)((m - v0 < VT) ? m - v0 : VT);
-  for (int q = 0; q < nv; ++q)
-    for (int64_t c = tid; c < n; c += 256) zs[(int64_t)q * n + c] = Zt[(v0 + q) * ldz + c];
-  __syncthreads();
-  for (int64_t s = n - 3; s >= 0; --s) {
-    const int K = sbr_tasks_of(s, n);
-    for (int k = wv; k < K; k += 4) {
-      const int64_t rk = s + 1 + (int64_t)k * SB;
-      const int L = (int)((n - rk < SB) ? n - rk : SB);
-      const float tau = TAU2[s * ldt + k];
-      if (tau == 0.f) continue;  // wave-uniform
-      const float vi = (lane < L) ? V2[s * ldv2 + rk + lane] : 0.f;
-      for (int q = 0; q < nv; ++q) {
-        float* z = zs + (int64_t)q * n + rk;
-        const float zi = (lane < L) ? z[lane] : 0.f;
-        float dot = vi * zi;
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) dot += __shfl_xor(dot, o);
-        if (lane < L) z[lane] = zi - tau * dot * vi;
-      }
-    }
-    __syncthreads();
-  }
-  for (int q = 0; q < nv; ++q)
-    for (int64_t c = tid; c < n; c += 256) Zt[(v0 + q) * ldz + c] = zs[(int64_t)q * n + c];
-}
-
-// ---- second back-transformation, blocked: WY groups on the matrix cores -----------------------------------------------------
-// Group (blk, k) = the reflectors (s, k) of the QW consecutive sweeps s = QW blk + c, c < QW: in the window of rows
-// R0 = QW blk + 1 + SB k .. R0 + SB + QW - 2 they form a parallelogram Vg (column c occupies the rows c .. c + L_c - 1);
-// H_S H_{S+1} ... = I - Vg Tg Vg' with the forward columnwise T factor. Row form: zw <- zw - ((zw Vg) Tg') Vg'.
-// Order (derived from which reflectors overlap): sweep blocks from the last to the first, inside a block k ascending.
-constexpr int QW = 32;            // sweeps per group
-constexpr int QH = SB + QW;       // window height, padded (SB + QW - 1 rows are used)
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-
-__device__ __forceinline__ float sbr_vg(const float* __restrict__ V2, int64_t ldv2, int64_t n, int64_t S, int k, int r, int c) {
-  // Vg[r][c] of group (S, k): entry of reflector (S + c, k) at window row r
-  const int64_t s = S + c;
-  if (s + 2 >= n) return 0.f;                       // no such sweep
-  const int64_t rk = s + 1 + (int64_t)k * SB;       // first row of the reflector = R0 + c
-  if (rk >= n) return 0.f;                          // the sweep has no task k
-  const int64_t L = (n - rk < SB) ? n - rk : SB;
-  const int rr = r - c;
-  return (rr >= 0 && rr < L) ? V2[s * ldv2 + rk + rr] : 0.f;
-}
-
-// T factors of all groups: grid (nk, nblk), one wave
-__global__ __launch_bounds__(64) void sbr_q2_build_t(const float* __restrict__ V2, int64_t ldv2, const float* __restrict__ TAU2,
-                                                     int64_t ldt, int64_t n, int nk, float* __restrict__ Tg) {
-  __shared__ float Vg[QH][QW + 1];
-  __shared__ float T[QW][QW + 1];
-  __shared__ float g[QW];
-  const int k = blockIdx.x, blk = blockIdx.y, l = threadIdx.x;
-  const int64_t S = (int64_t)blk * QW;
-  for (int idx = l; idx < QH * QW; idx += 64) {
-    const int r = idx / QW, c = idx % QW;
-    Vg[r][c] = sbr_vg(V2, ldv2, n, S, k, r, c);
-  }
-  if (l < QW)
-    for (int c = 0; c < QW; ++c) T[l][c] = 0.f;
-  __syncthreads();
-  for (int c = 0; c < QW; ++c) {
-    const int64_t s = S + c;
-    float tau = 0.f;
-    if (s + 2 < n && s + 1 + (int64_t)k * SB < n) tau = TAU2[s * ldt + k];
-    if (l < c) {  // g_l = Vg[:, l]' Vg[:, c]
-      float acc = 0.f;
-      for (int r = c; r < QH; ++r) acc += Vg[r][l] * Vg[r][c];
-      g[l] = acc;
-    }
-    __syncthreads();
-    if (l < c) {
-      float acc = 0.f;
-      for (int j = l; j < c; ++j) acc += T[l][j] * g[j];
-      T[l][c] = -tau * acc;
-    }
-    if (l == c) T[c][c] = tau;
-    __syncthreads();
-  }
-  float* out = Tg + ((int64_t)blk * nk + k) * QW * QW;
-  for (int idx = l; idx < QW * QW; idx += 64) out[idx] = T[idx / QW][idx % QW];
-}
-
-// apply: one wave per tile of 16 vectors, 4 waves per workgroup, `v_mfma_f32_16x16x4_f32`. The window of the vector tile lives in
-// REGISTERS in the MFMA result layout (lane = vector + 16 * row quad, register = row inside the quad), which is also the
-// B-operand layout of the next product, so a group costs three chained MFMA products and no LDS traffic for Z at all:
-//   W' = Vg' Zw'   (32 x 16)      A = Vg' from LDS ([reflector][row], 16-byte reads), B = the window registers
-//   U' = Tg W'     (32 x 16)      A = Tg from LDS, B = W' registers
-//   Zw' -= Vg U'   (96 x 16)      A = Vg from the same LDS image (4-byte reads), B = -U' registers, C = the window
-// Only the 16 x 16 tile pairs that meet the parallelogram are multiplied (40 + 12 + 40 MFMAs per group instead of 48 + 16 + 48).
-// QJ consecutive sweep blocks are applied in one pass over Z (wavefront order: k ascending, inside a k the blocks descending;
-// groups of different blocks at the same k overlap by 32 rows, groups at different k of that order are disjoint), so Z is
-// streamed n / (32 QJ) times instead of n / 32 times: the union window of a step is 96 + 32 (QJ - 1) rows = QNT register
-// tiles, 64 rows leave and 64 enter per step. The group data (reflectors + T) is staged through a double-buffered LDS image
-// shared by the four waves, fetched one group ahead.
-// Z is addressed as Zq[v * ldq + 3 + row]: every window starts at a row = 1 (mod 4), so the 4-row register quads are
-// 16-byte aligned in this shifted layout.
-constexpr int Q_RS = 100;  // floats per reflector in the LDS image: b128 reads 2-way, b32 reads conflict-free
-constexpr int Q_RT = 40;   // floats per row of Tg: conflict-free b128 reads
-constexpr int Q_BUF = QW * Q_RS + QW * Q_RT;
-
-struct SbrQ2Args {
-  const float* V2;
-  int64_t ldv2;
-  const float* Tg;
-  int nk, nblk;
-  int64_t n;
-  float* Zq;
-  int64_t m, ldq;
-  unsigned long long* prof;  // SCLENS_HIP_Q2_PROF=1 (image-fed kernels): per-phase shader clocks of wave 0 of one workgroup, else null
-};
-
-struct SbrQ2Fetch {
-  float v[8], t[4];
-};
-
-__device__ __forceinline__ void sbr_q2_fetch16(SbrQ2Fetch& f, const SbrQ2Args& a, int b, int t, int tid) {
-  const int64_t S = (int64_t)b * QW;
-#pragma unroll
-  for (int q = 0; q < 8; ++q) {
-    const int idx = tid + 256 * q, c = idx >> 6, rr = idx & 63;
-    const int64_t s = S + c, rk = s + 1 + (int64_t)t * SB;
-    const bool have = (b >= 0) && (s + 2 < a.n) && (rk + rr < a.n);
-    f.v[q] = have ? a.V2[s * a.ldv2 + rk + rr] : 0.f;
-  }
-  const bool tv = (b >= 0) && (t < a.nk);
-  const float* tg = a.Tg + ((int64_t)(tv ? b : 0) * a.nk + (tv ? t : 0)) * QW * QW;
-#pragma unroll
-  for (int q = 0; q < 4; ++q) f.t[q] = tv ? tg[tid + 256 * q] : 0.f;
-}
-
-__device__ __forceinline__ void sbr_q2_stash16(const SbrQ2Fetch& f, float* buf, int tid) {
-#pragma unroll
-  for (int q = 0; q < 8; ++q) {
-    const int idx = tid + 256 * q, c = idx >> 6, rr = idx & 63;
-    buf[c * Q_RS + c + rr] = f.v[q];
-  }
-  float* T = buf + QW * Q_RS;
-#pragma unroll
-  for (int q = 0; q < 4; ++q) {
-    const int idx = tid + 256 * q;
-    T[(idx >> 5) * Q_RT + (idx & 31)] = f.t[q];
-  }
-}
-
-// one group applied to the six window tiles z[0..5] (rows 0..95 of the group's window); operand fragments read from LDS right
-// before their use. ILV: consecutive MFMAs of the third product go to different row tiles (a dependent accumulator costs 40 cycles
-// instead of the 32 of an independent one) and the T product runs on three accumulator chains.
-template <int RT, bool ILV>
-__device__ __forceinline__ void sbr_q2_group16(f32x4* z, const float* buf, int vi, int g) {
-  const float* VgT = buf;
-  const float* T = buf + QW * Q_RS;
-  f32x4 w0 = {0.f, 0.f, 0.f, 0.f}, w1 = {0.f, 0.f, 0.f, 0.f};
-  // W' = Vg' Zw': reflector tile 0 meets row tiles 0..4, reflector tile 1 row tiles 1..5
-#pragma unroll
-  for (int rt = 0; rt < 5; ++rt) {
-    const f32x4 a0 = *reinterpret_cast<const f32x4*>(VgT + vi * Q_RS + 16 * rt + 4 * g);
-    const f32x4 a1 = *reinterpret_cast<const f32x4*>(VgT + (16 + vi) * Q_RS + 16 * (rt + 1) + 4 * g);
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      w0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[e], z[rt][e], w0, 0, 0, 0);
-      w1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[e], z[rt + 1][e], w1, 0, 0, 0);
-    }
-  }
-  // U' = Tg W' (Tg upper triangular: tile (1,0) is zero)
-  f32x4 u0 = {0.f, 0.f, 0.f, 0.f}, u1 = {0.f, 0.f, 0.f, 0.f}, u2 = {0.f, 0.f, 0.f, 0.f};
-  {
-    const f32x4 t00 = *reinterpret_cast<const f32x4*>(T + vi * RT + 4 * g);
-    const f32x4 t01 = *reinterpret_cast<const f32x4*>(T + vi * RT + 16 + 4 * g);
-    const f32x4 t11 = *reinterpret_cast<const f32x4*>(T + (16 + vi) * RT + 16 + 4 * g);
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      u0 = __builtin_amdgcn_mfma_f32_16x16x4f32(t00[e], w0[e], u0, 0, 0, 0);
-      u1 = __builtin_amdgcn_mfma_f32_16x16x4f32(t11[e], w1[e], u1, 0, 0, 0);
-      if (ILV) u2 = __builtin_amdgcn_mfma_f32_16x16x4f32(t01[e], w1[e], u2, 0, 0, 0);
-    }
-    if (!ILV) {
-#pragma unroll
-      for (int e = 0; e < 4; ++e) u0 = __builtin_amdgcn_mfma_f32_16x16x4f32(t01[e], w1[e], u0, 0, 0, 0);
-    }
-  }
-#pragma unroll
-  for (int e = 0; e < 4; ++e) {
-    u0[e] = -(u0[e] + u2[e]);
-    u1[e] = -u1[e];
-  }
-  // Zw' -= Vg U': A[row][reflector 4 g + e] from the [reflector][row] image
-  if (ILV) {
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-#pragma unroll
-      for (int rt = 0; rt < 5; ++rt)
-        z[rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(VgT[(4 * g + e) * Q_RS + 16 * rt + vi], u0[e], z[rt], 0, 0, 0);
-#pragma unroll
-      for (int rt = 1; rt < 6; ++rt)
-        z[rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(VgT[(16 + 4 * g + e) * Q_RS + 16 * rt + vi], u1[e], z[rt], 0, 0, 0);
-    }
-  } else {
-#pragma unroll
-    for (int rt = 0; rt < 6; ++rt) {
-      if (rt < 5) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e)
-          z[rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(VgT[(4 * g + e) * Q_RS + 16 * rt + vi], u0[e], z[rt], 0, 0, 0);
-      }
-      if (rt > 0) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e)
-          z[rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(VgT[(16 + 4 * g + e) * Q_RS + 16 * rt + vi], u1[e], z[rt], 0, 0, 0);
-      }
-    }
-  }
-}
-
-// ---- variant 3 (round 3): a second, row-major LDS image of the group's reflectors feeds the third product with 16-byte reads
-// (four consecutive reflectors of one row = the four k-steps of one MFMA group: 10 reads instead of 40), its reads are issued
-// when the first product's MFMAs have been issued (they land during the T product), and the fetch of the NEXT group's data
-// (8 + 4 global loads per thread, unconditional: see sbr_ldv2) sits between the MFMAs of the first product instead of in front
-// of the group, where the matrix pipe idles.
-constexpr int Q_NS = 36;                                  // floats per window row of the row-major image
-constexpr int Q_BUF3 = QW * Q_RS + QW * Q_RT + 96 * Q_NS;  // 7 936 floats per buffer
-
-struct SbrQ2Ptr {           // per-thread fetch state of variant 3
-  const float* v;           // V2 + wv (ldv2 + 1) + 1 + lane: reflector c = wv + 4 q of group (b, t) sits at
-                            // v + 32 b (ldv2 + 1) + 64 t + 4 q (ldv2 + 1)
-  const float* tg;          // Tg + tid
-  int64_t vstride;          // ldv2 + 1
-};
-
-__device__ __forceinline__ void sbr_q2_fetch16v3(SbrQ2Fetch& f, const SbrQ2Args& a, const SbrQ2Ptr& p, int b, int t) {
-  const int bb = b < 0 ? 0 : b;                // b < 0: past the last group; the data is never used
-  const int tt = t < a.nk ? t : a.nk - 1;
-  const float* src = p.v + ((int64_t)bb * QW) * p.vstride + (int64_t)tt * SB;
-#pragma unroll
-  for (int q = 0; q < 8; ++q) f.v[q] = src[(int64_t)(4 * q) * p.vstride];
-  const float* tg = p.tg + ((int64_t)bb * a.nk + tt) * QW * QW;
-#pragma unroll
-  for (int q = 0; q < 4; ++q) f.t[q] = tg[256 * q];
-}
-
-__device__ __forceinline__ void sbr_q2_stash16v3(const SbrQ2Fetch& f, float* buf, int tid) {
-  float* N = buf + QW * Q_RS + QW * Q_RT;
-#pragma unroll
-  for (int q = 0; q < 8; ++q) {
-    const int idx = tid + 256 * q, c = idx >> 6, rr = idx & 63;
-    buf[c * Q_RS + c + rr] = f.v[q];
-    N[(c + rr) * Q_NS + c] = f.v[q];
-  }
-  float* T = buf + QW * Q_RS;
-#pragma unroll
-  for (int q = 0; q < 4; ++q) {
-    const int idx = tid + 256 * q;
-    T[(idx >> 5) * Q_RT + (idx & 31)] = f.t[q];
-  }
-}
-
-template <bool DO>
-__device__ __forceinline__ void sbr_q2_group16v3(f32x4* z, const float* buf, int vi, int g, SbrQ2Fetch& pf, const SbrQ2Args& a,
-                                                  const SbrQ2Ptr& p, int nb, int nt) {
-  const float* VgT = buf;
-  const float* T = buf + QW * Q_RS;
-  const float* N = T + QW * Q_RT;
-  if (!DO) {  // group outside the matrix: only the fetch of the next one
-    sbr_q2_fetch16v3(pf, a, p, nb, nt);
-    return;
-  }
-  f32x4 a0[5], a1[5];
-#pragma unroll
-  for (int rt = 0; rt < 5; ++rt) {
-    a0[rt] = *reinterpret_cast<const f32x4*>(VgT + vi * Q_RS + 16 * rt + 4 * g);
-    a1[rt] = *reinterpret_cast<const f32x4*>(VgT + (16 + vi) * Q_RS + 16 * (rt + 1) + 4 * g);
-  }
-  const f32x4 t00 = *reinterpret_cast<const f32x4*>(T + vi * Q_RT + 4 * g);
-  const f32x4 t01 = *reinterpret_cast<const f32x4*>(T + vi * Q_RT + 16 + 4 * g);
-  const f32x4 t11 = *reinterpret_cast<const f32x4*>(T + (16 + vi) * Q_RT + 16 + 4 * g);
-  __builtin_amdgcn_sched_barrier(0);
-  f32x4 w0 = {0.f, 0.f, 0.f, 0.f}, w1 = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-  for (int e = 0; e < 4; ++e) {
-    w0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[0][e], z[0][e], w0, 0, 0, 0);
-    w1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[0][e], z[1][e], w1, 0, 0, 0);
-  }
-  // the next group's global loads + their address arithmetic, spread over the MFMAs of this product by the scheduler
-  sbr_q2_fetch16v3(pf, a, p, nb, nt);
-#pragma unroll
-  for (int rt = 1; rt < 5; ++rt) {
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      w0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[rt][e], z[rt][e], w0, 0, 0, 0);
-      w1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[rt][e], z[rt + 1][e], w1, 0, 0, 0);
-    }
-  }
-  __builtin_amdgcn_sched_barrier(0);
-  // operands of the third product (row-major image): issued now, they land while the T product runs
-  f32x4 n0[5], n1[5];
-#pragma unroll
-  for (int rt = 0; rt < 5; ++rt) {
-    n0[rt] = *reinterpret_cast<const f32x4*>(N + (16 * rt + vi) * Q_NS + 4 * g);
-    n1[rt] = *reinterpret_cast<const f32x4*>(N + (16 * (rt + 1) + vi) * Q_NS + 16 + 4 * g);
-  }
-  __builtin_amdgcn_sched_barrier(0);
-  f32x4 u0 = {0.f, 0.f, 0.f, 0.f}, u1 = {0.f, 0.f, 0.f, 0.f}, u2 = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-  for (int e = 0; e < 4; ++e) {
-    u0 = __builtin_amdgcn_mfma_f32_16x16x4f32(t00[e], w0[e], u0, 0, 0, 0);
-    u1 = __builtin_amdgcn_mfma_f32_16x16x4f32(t11[e], w1[e], u1, 0, 0, 0);
-    u2 = __builtin_amdgcn_mfma_f32_16x16x4f32(t01[e], w1[e], u2, 0, 0, 0);
-  }
-#pragma unroll
-  for (int e = 0; e < 4; ++e) {
-    u0[e] = -(u0[e] + u2[e]);
-    u1[e] = -u1[e];
-  }
-#pragma unroll
-  for (int e = 0; e < 4; ++e) {
-#pragma unroll
-    for (int rt = 0; rt < 5; ++rt) z[rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(n0[rt][e], u0[e], z[rt], 0, 0, 0);
-#pragma unroll
-    for (int rt = 0; rt < 5; ++rt) z[rt + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(n1[rt][e], u1[e], z[rt + 1], 0, 0, 0);
-  }
-}
-
-__device__ __forceinline__ f32x4 sbr_q2_ldz(const float* zrow, int64_t row, int64_t n, bool live) {
-  f32x4 v = {0.f, 0.f, 0.f, 0.f};
-  if (live && row >= -3 && row < n) {
-    if (row + 3 < n) {
-      v = *reinterpret_cast<const f32x4*>(zrow + row);
-    } else {
-#pragma unroll
-      for (int e = 0; e < 4; ++e)
-        if (row + e < n) v[e] = zrow[row + e];
-    }
-  }
-  return v;
-}
-__device__ __forceinline__ void sbr_q2_stz(float* zrow, int64_t row, int64_t n, bool live, f32x4 v) {
-  if (live && row >= -3 && row < n) {
-    if (row + 3 < n) {
-      *reinterpret_cast<f32x4*>(zrow + row) = v;
-    } else {
-#pragma unroll
-      for (int e = 0; e < 4; ++e)
-        if (row + e < n) zrow[row + e] = v[e];
-    }
-  }
-}
-
-template <int QJ, int QNT, bool ILV>
-__global__ __launch_bounds__(256, 1) void sbr_q2_apply16(SbrQ2Args a) {
-  __shared__ __attribute__((aligned(16))) float lds[2 * Q_BUF];
-  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, vi = lane & 15, g = lane >> 4;
-  const int64_t v = (int64_t)blockIdx.x * 64 + wv * 16 + vi;
-  const bool live = v < a.m;
-  float* zrow = a.Zq + (live ? v : 0) * a.ldq + 3;
-  for (int i = tid; i < 2 * Q_BUF; i += 256) lds[i] = 0.f;  // outside the parallelogram the images stay zero
-  __syncthreads();
-  const int nsb = (a.nblk + QJ - 1) / QJ;
-  SbrQ2Fetch pf;
-  sbr_q2_fetch16(pf, a, a.nblk - 1, 0, tid);
-  sbr_q2_stash16(pf, lds, tid);
-  __syncthreads();
-  int cur = 0;
-  f32x4 z[QNT];
-  for (int sb = 0; sb < nsb; ++sb) {
-    const int bh = a.nblk - 1 - sb * QJ, blow = bh - QJ + 1;
-    const int Kmax = sbr_tasks_of((int64_t)(blow > 0 ? blow : 0) * QW, a.n);
-    const int64_t base0 = (int64_t)blow * QW + 1;
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the stores of the previous pass have left before rows are re-read
-#pragma unroll
-    for (int i = 0; i < QNT; ++i) z[i] = sbr_q2_ldz(zrow, base0 + 16 * i + 4 * g, a.n, live);
-    for (int t = 0; t < Kmax; ++t) {
-      const int64_t base = base0 + (int64_t)t * SB;
-      f32x4 pz[4];
-      const bool more = t + 1 < Kmax;
-      if (more) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) pz[i] = sbr_q2_ldz(zrow, base + 16 * (QNT + i) + 4 * g, a.n, live);
-      }
-#pragma unroll
-      for (int j = 0; j < QJ; ++j) {
-        // the group after this one in the sequence
-        int nb, nt;
-        if (j + 1 < QJ) {
-          nb = bh - (j + 1);
-          nt = t;
-        } else if (more) {
-          nb = bh;
-          nt = t + 1;
-        } else {
-          nb = bh - QJ;
-          nt = 0;
-        }
-        sbr_q2_fetch16(pf, a, nb, nt, tid);
-        const int b = bh - j;
-        if (b >= 0 && t < sbr_tasks_of((int64_t)b * QW, a.n)) sbr_q2_group16<Q_RT, ILV>(z + 2 * (QJ - 1 - j), lds + cur * Q_BUF, vi, g);
-        sbr_q2_stash16(pf, lds + (cur ^ 1) * Q_BUF, tid);
-        __syncthreads();
-        cur ^= 1;
-      }
-#pragma unroll
-      for (int i = 0; i < 4; ++i) sbr_q2_stz(zrow, base + 16 * i + 4 * g, a.n, live, z[i]);
-      if (more) {
-#pragma unroll
-        for (int i = 0; i + 4 < QNT; ++i) z[i] = z[i + 4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) z[QNT - 4 + i] = pz[i];
-      } else {
-#pragma unroll
-        for (int i = 4; i < QNT; ++i) sbr_q2_stz(zrow, base + 16 * i + 4 * g, a.n, live, z[i]);
-      }
-    }
-  }
-}
-
-template <int QJ, int QNT>
-__global__ __launch_bounds__(256, 1) void sbr_q2_apply16v3(SbrQ2Args a) {
-  __shared__ __attribute__((aligned(16))) float lds[2 * Q_BUF3];
-  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, vi = lane & 15, g = lane >> 4;
-  const int64_t v = (int64_t)blockIdx.x * 64 + wv * 16 + vi;
-  const bool live = v < a.m;
-  float* zrow = a.Zq + (live ? v : 0) * a.ldq + 3;
-  for (int i = tid; i < 2 * Q_BUF3; i += 256) lds[i] = 0.f;  // outside the parallelogram the images stay zero
-  __syncthreads();
-  const int nsb = (a.nblk + QJ - 1) / QJ;
-  SbrQ2Ptr p;
-  p.vstride = a.ldv2 + 1;
-  p.v = a.V2 + (int64_t)wv * p.vstride + 1 + lane;
-  p.tg = a.Tg + tid;
-  SbrQ2Fetch pf;
-  sbr_q2_fetch16v3(pf, a, p, a.nblk - 1, 0);
-  sbr_q2_stash16v3(pf, lds, tid);
-  __syncthreads();
-  int cur = 0;
-  f32x4 z[QNT];
-  for (int sb = 0; sb < nsb; ++sb) {
-    const int bh = a.nblk - 1 - sb * QJ, blow = bh - QJ + 1;
-    const int Kmax = sbr_tasks_of((int64_t)(blow > 0 ? blow : 0) * QW, a.n);
-    const int64_t base0 = (int64_t)blow * QW + 1;
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the stores of the previous pass have left before rows are re-read
-#pragma unroll
-    for (int i = 0; i < QNT; ++i) z[i] = sbr_q2_ldz(zrow, base0 + 16 * i + 4 * g, a.n, live);
-    for (int t = 0; t < Kmax; ++t) {
-      const int64_t base = base0 + (int64_t)t * SB;
-      f32x4 pz[4];
-      const bool more = t + 1 < Kmax;
-      if (more) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) pz[i] = sbr_q2_ldz(zrow, base + 16 * (QNT + i) + 4 * g, a.n, live);
-      }
-#pragma unroll
-      for (int j = 0; j < QJ; ++j) {
-        int nb, nt;  // the group after this one in the sequence
-        if (j + 1 < QJ) {
-          nb = bh - (j + 1);
-          nt = t;
-        } else if (more) {
-          nb = bh;
-          nt = t + 1;
-        } else {
-          nb = bh - QJ;
-          nt = 0;
-        }
-        const int b = bh - j;
-        if (b >= 0 && t < sbr_tasks_of((int64_t)b * QW, a.n))
-          sbr_q2_group16v3<true>(z + 2 * (QJ - 1 - j), lds + cur * Q_BUF3, vi, g, pf, a, p, nb, nt);
-        else
-          sbr_q2_group16v3<false>(z + 2 * (QJ - 1 - j), lds + cur * Q_BUF3, vi, g, pf, a, p, nb, nt);
-        sbr_q2_stash16v3(pf, lds + (cur ^ 1) * Q_BUF3, tid);
-        __syncthreads();
-        cur ^= 1;
-      }
-#pragma unroll
-      for (int i = 0; i < 4; ++i) sbr_q2_stz(zrow, base + 16 * i + 4 * g, a.n, live, z[i]);
-      if (more) {
-#pragma unroll
-        for (int i = 0; i + 4 < QNT; ++i) z[i] = z[i + 4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) z[QNT - 4 + i] = pz[i];
-      } else {
-#pragma unroll
-        for (int i = 4; i < QNT; ++i) sbr_q2_stz(zrow, base + 16 * i + 4 * g, a.n, live, z[i]);
-      }
-    }
-  }
-}
-
-// ---- variant 5 (round 3): the three products of a group on the fp16 matrix cores from operands split into two fp16 pieces
-// (x = hi + lo, 22 significant bits; a b ~ ah bh + ah bl + al bh with fp32 accumulation, as the search statistic of gram_bits.hip).
-// The register quads of variant 3 already ARE the operands of v_mfma_f32_16x16x16_f16 (a lane supplies four consecutive k of its
-// row / column): one K = 16 instruction (8 cycles) replaces four K = 4 fp32 ones (32 cycles each), three of them per product.
-// LDS images keep their float-indexed layout; the 16 bytes of four consecutive elements hold [hi x 4 | lo x 4], split once by
-// the workgroup when a group is stashed. The vector window lives scaled by 2^8 (exact), so that the low pieces of entries of
-// size 1 / sqrt(n) stay in fp16's normal range; it is split per group (z, W', U': ~120 vector instructions per lane against
-// ~2 400 cycles of matrix-pipe time saved).
-__device__ __forceinline__ SbrHL sbr_ld_hl(const float* p) {
-  const f32x4 r = *reinterpret_cast<const f32x4*>(p);
-  SbrHL o;
-  __builtin_memcpy(&o, &r, 16);
-  return o;
-}
-__device__ __forceinline__ void sbr_st_hl(float* img, int off, float x) {  // element at float offset `off` of a [hi x 4 | lo x 4] image
-  const _Float16 h = (_Float16)x;
-  const _Float16 l = (_Float16)(x - (float)h);
-  _Float16* q = reinterpret_cast<_Float16*>(img + (off & ~3));
-  q[off & 3] = h;
-  q[4 + (off & 3)] = l;
-}
-__device__ __forceinline__ SbrHL sbr_split(f32x4 x) {
-  // (hi by a mask on the fp32 bits instead of a conversion and back saves 80 vector instructions per group and was SLOWER,
-  // 408 against 397 ms, and less accurate: truncation instead of rounding)
-  SbrHL o;
-#pragma unroll
-  for (int e = 0; e < 4; ++e) {
-    o.h[e] = (_Float16)x[e];
-    o.l[e] = (_Float16)(x[e] - (float)o.h[e]);
-  }
-  return o;
-}
-__device__ __forceinline__ f32x4 sbr_mfma3(const SbrHL& a, const SbrHL& b, f32x4 c) {
-  c = __builtin_amdgcn_mfma_f32_16x16x16f16(a.h, b.h, c, 0, 0, 0);
-  c = __builtin_amdgcn_mfma_f32_16x16x16f16(a.h, b.l, c, 0, 0, 0);
-  c = __builtin_amdgcn_mfma_f32_16x16x16f16(a.l, b.h, c, 0, 0, 0);
-  return c;
-}
-constexpr float Q_ZSCALE = 256.f;
-
-__device__ __forceinline__ void sbr_q2_stash16h(const SbrQ2Fetch& f, float* buf, int tid) {
-  float* N = buf + QW * Q_RS + QW * Q_RT;
-#pragma unroll
-  for (int q = 0; q < 8; ++q) {
-    const int idx = tid + 256 * q, c = idx >> 6, rr = idx & 63;
-    const _Float16 h = (_Float16)f.v[q];
-    const _Float16 l = (_Float16)(f.v[q] - (float)h);
-    {
-      const int off = c * Q_RS + c + rr;
-      _Float16* qd = reinterpret_cast<_Float16*>(buf + (off & ~3));
-      qd[off & 3] = h;
-      qd[4 + (off & 3)] = l;
-    }
-    {
-      const int off = (c + rr) * Q_NS + c;
-      _Float16* qd = reinterpret_cast<_Float16*>(N + (off & ~3));
-      qd[off & 3] = h;
-      qd[4 + (off & 3)] = l;
-    }
-  }
-  float* T = buf + QW * Q_RS;
-#pragma unroll
-  for (int q = 0; q < 4; ++q) {
-    const int idx = tid + 256 * q;
-    sbr_st_hl(T, (idx >> 5) * Q_RT + (idx & 31), f.t[q]);
-  }
-}
-
-template <bool DO>
-__device__ __forceinline__ void sbr_q2_group16h(f32x4* z, const float* buf, int vi, int g, SbrQ2Fetch& pf, const SbrQ2Args& a,
-                                                 const SbrQ2Ptr& p, int nb, int nt) {
-  const float* VgT = buf;
-  const float* T = buf + QW * Q_RS;
-  const float* N = T + QW * Q_RT;
-  if (!DO) {  // group outside the matrix: only the fetch of the next one
-    sbr_q2_fetch16v3(pf, a, p, nb, nt);
-    return;
-  }
-  SbrHL a0[5], a1[5];
-#pragma unroll
-  for (int rt = 0; rt < 5; ++rt) {
-    a0[rt] = sbr_ld_hl(VgT + vi * Q_RS + 16 * rt + 4 * g);
-    a1[rt] = sbr_ld_hl(VgT + (16 + vi) * Q_RS + 16 * (rt + 1) + 4 * g);
-  }
-  const SbrHL t00 = sbr_ld_hl(T + vi * Q_RT + 4 * g);
-  const SbrHL t01 = sbr_ld_hl(T + vi * Q_RT + 16 + 4 * g);
-  const SbrHL t11 = sbr_ld_hl(T + (16 + vi) * Q_RT + 16 + 4 * g);
-  SbrHL zs[6];
-#pragma unroll
-  for (int rt = 0; rt < 6; ++rt) zs[rt] = sbr_split(z[rt]);
-  f32x4 w0 = {0.f, 0.f, 0.f, 0.f}, w1 = {0.f, 0.f, 0.f, 0.f};
-  w0 = sbr_mfma3(a0[0], zs[0], w0);
-  w1 = sbr_mfma3(a1[0], zs[1], w1);
-  sbr_q2_fetch16v3(pf, a, p, nb, nt);  // the next group's global loads, spread over the matrix instructions by the scheduler
-#pragma unroll
-  for (int rt = 1; rt < 5; ++rt) {
-    w0 = sbr_mfma3(a0[rt], zs[rt], w0);
-    w1 = sbr_mfma3(a1[rt], zs[rt + 1], w1);
-  }
-  SbrHL n0[5], n1[5];
-#pragma unroll
-  for (int rt = 0; rt < 5; ++rt) {
-    n0[rt] = sbr_ld_hl(N + (16 * rt + vi) * Q_NS + 4 * g);
-    n1[rt] = sbr_ld_hl(N + (16 * (rt + 1) + vi) * Q_NS + 16 + 4 * g);
-  }
-  const SbrHL w0s = sbr_split(w0), w1s = sbr_split(w1);
-  f32x4 u0 = {0.f, 0.f, 0.f, 0.f}, u1 = {0.f, 0.f, 0.f, 0.f}, u2 = {0.f, 0.f, 0.f, 0.f};
-  u0 = sbr_mfma3(t00, w0s, u0);
-  u1 = sbr_mfma3(t11, w1s, u1);
-  u2 = sbr_mfma3(t01, w1s, u2);
-#pragma unroll
-  for (int e = 0; e < 4; ++e) {
-    u0[e] = -(u0[e] + u2[e]);
-    u1[e] = -u1[e];
-  }
-  const SbrHL u0s = sbr_split(u0), u1s = sbr_split(u1);
-#pragma unroll
-  for (int rt = 0; rt < 5; ++rt) {
-    z[rt] = sbr_mfma3(n0[rt], u0s, z[rt]);
-    z[rt + 1] = sbr_mfma3(n1[rt], u1s, z[rt + 1]);
-  }
-}
-
-template <int QJ, int QNT>
-__global__ __launch_bounds__(256, 1) void sbr_q2_apply16h(SbrQ2Args a) {
-  __shared__ __attribute__((aligned(16))) float lds[2 * Q_BUF3];
-  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, vi = lane & 15, g = lane >> 4;
-  const int64_t v = (int64_t)blockIdx.x * 64 + wv * 16 + vi;
-  const bool live = v < a.m;
-  float* zrow = a.Zq + (live ? v : 0) * a.ldq + 3;
-  for (int i = tid; i < 2 * Q_BUF3; i += 256) lds[i] = 0.f;  // outside the parallelogram the images stay zero (hi = lo = 0)
-  __syncthreads();
-  const int nsb = (a.nblk + QJ - 1) / QJ;
-  SbrQ2Ptr p;
-  p.vstride = a.ldv2 + 1;
-  p.v = a.V2 + (int64_t)wv * p.vstride + 1 + lane;
-  p.tg = a.Tg + tid;
-  SbrQ2Fetch pf;
-  sbr_q2_fetch16v3(pf, a, p, a.nblk - 1, 0);
-  sbr_q2_stash16h(pf, lds, tid);
-  __syncthreads();
-  int cur = 0;
-  f32x4 z[QNT];
-  for (int sb = 0; sb < nsb; ++sb) {
-    const int bh = a.nblk - 1 - sb * QJ, blow = bh - QJ + 1;
-    const int Kmax = sbr_tasks_of((int64_t)(blow > 0 ? blow : 0) * QW, a.n);
-    const int64_t base0 = (int64_t)blow * QW + 1;
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the stores of the previous pass have left before rows are re-read
-#pragma unroll
-    for (int i = 0; i < QNT; ++i) z[i] = sbr_q2_ldz(zrow, base0 + 16 * i + 4 * g, a.n, live) * Q_ZSCALE;
-    for (int t = 0; t < Kmax; ++t) {
-      const int64_t base = base0 + (int64_t)t * SB;
-      f32x4 pz[4];
-      const bool more = t + 1 < Kmax;
-      if (more) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) pz[i] = sbr_q2_ldz(zrow, base + 16 * (QNT + i) + 4 * g, a.n, live) * Q_ZSCALE;
-      }
-#pragma unroll
-      for (int j = 0; j < QJ; ++j) {
-        int nb, nt;  // the group after this one in the sequence
-        if (j + 1 < QJ) {
-          nb = bh - (j + 1);
-          nt = t;
-        } else if (more) {
-          nb = bh;
-          nt = t + 1;
-        } else {
-          nb = bh - QJ;
-          nt = 0;
-        }
-        const int b = bh - j;
-        if (b >= 0 && t < sbr_tasks_of((int64_t)b * QW, a.n))
-          sbr_q2_group16h<true>(z + 2 * (QJ - 1 - j), lds + cur * Q_BUF3, vi, g, pf, a, p, nb, nt);
-        else
-          sbr_q2_group16h<false>(z + 2 * (QJ - 1 - j), lds + cur * Q_BUF3, vi, g, pf, a, p, nb, nt);
-        sbr_q2_stash16h(pf, lds + (cur ^ 1) * Q_BUF3, tid);
-        __syncthreads();
-        cur ^= 1;
-      }
-#pragma unroll
-      for (int i = 0; i < 4; ++i) sbr_q2_stz(zrow, base + 16 * i + 4 * g, a.n, live, z[i] * (1.f / Q_ZSCALE));
-      if (more) {
-#pragma unroll
-        for (int i = 0; i + 4 < QNT; ++i) z[i] = z[i + 4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) z[QNT - 4 + i] = pz[i];
-      } else {
-#pragma unroll
-        for (int i = 4; i < QNT; ++i) sbr_q2_stz(zrow, base + 16 * i + 4 * g, a.n, live, z[i] * (1.f / Q_ZSCALE));
-      }
-    }
-  }
-}
-
-// ---- variants 6 (fp32 products) and 7 (split-fp16 products): the reflectors of a group are fetched TWO groups ahead. Variant 5 cut
-// the matrix-pipe time of a group from ~2 900 to ~600 cycles and the kernel took as long as before (518 against 503 ms at
-// n = 30 016, m = 15 008): a group's loads were issued during the previous group and waited for at its end, and one group is about
-// one HBM round trip under load (~5 000 cycles) -- every variant of this kernel was bound by that wait, whatever it did in between.
-template <int QJ, int QNT, bool F16>
-__global__ __launch_bounds__(256, 1) void sbr_q2_apply16d(SbrQ2Args a) {
-  __shared__ __attribute__((aligned(16))) float lds[2 * Q_BUF3];
-  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, vi = lane & 15, g = lane >> 4;
-  const int64_t v = (int64_t)blockIdx.x * 64 + wv * 16 + vi;
-  const bool live = v < a.m;
-  float* zrow = a.Zq + (live ? v : 0) * a.ldq + 3;
-  const float zs = F16 ? Q_ZSCALE : 1.f, izs = F16 ? 1.f / Q_ZSCALE : 1.f;
-  for (int i = tid; i < 2 * Q_BUF3; i += 256) lds[i] = 0.f;  // outside the parallelogram the images stay zero
-  __syncthreads();
-  const int nsb = (a.nblk + QJ - 1) / QJ;
-  SbrQ2Ptr p;
-  p.vstride = a.ldv2 + 1;
-  p.v = a.V2 + (int64_t)wv * p.vstride + 1 + lane;
-  p.tg = a.Tg + tid;
-  SbrQ2Fetch pa, pb;  // pa: the next group's data (in flight since the previous group), pb: the one after it (issued in this group)
-  sbr_q2_fetch16v3(pa, a, p, a.nblk - 1, 0);
-  if (F16) sbr_q2_stash16h(pa, lds, tid); else sbr_q2_stash16v3(pa, lds, tid);
-  sbr_q2_fetch16v3(pa, a, p, a.nblk - 2, 0);  // QJ > 1: the second group of the sequence is block nblk - 2, task 0
-  __syncthreads();
-  int cur = 0;
-  f32x4 z[QNT];
-  for (int sb = 0; sb < nsb; ++sb) {
-    const int bh = a.nblk - 1 - sb * QJ, blow = bh - QJ + 1;
-    const int Kmax = sbr_tasks_of((int64_t)(blow > 0 ? blow : 0) * QW, a.n);
-    const int64_t base0 = (int64_t)blow * QW + 1;
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the stores of the previous pass have left before rows are re-read
-#pragma unroll
-    for (int i = 0; i < QNT; ++i) z[i] = sbr_q2_ldz(zrow, base0 + 16 * i + 4 * g, a.n, live) * zs;
-    for (int t = 0; t < Kmax; ++t) {
-      const int64_t base = base0 + (int64_t)t * SB;
-      f32x4 pz[4];
-      const bool more = t + 1 < Kmax;
-      if (more) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) pz[i] = sbr_q2_ldz(zrow, base + 16 * (QNT + i) + 4 * g, a.n, live) * zs;
-      }
-#pragma unroll
-      for (int j = 0; j < QJ; ++j) {
-        int nb, nt;  // the group TWO steps after this one in the sequence (j ascending inside a task, then the next task, then the next pass)
-        if (j + 2 < QJ) {
-          nb = bh - (j + 2);
-          nt = t;
-        } else if (more) {
-          nb = bh - (j + 2 - QJ);
-          nt = t + 1;
-        } else {
-          nb = bh - QJ - (j + 2 - QJ);
-          nt = 0;
-        }
-        const int b = bh - j;
-        const bool on = b >= 0 && t < sbr_tasks_of((int64_t)b * QW, a.n);
-        if (F16) {
-          if (on) sbr_q2_group16h<true>(z + 2 * (QJ - 1 - j), lds + cur * Q_BUF3, vi, g, pb, a, p, nb, nt);
-          else sbr_q2_group16h<false>(z + 2 * (QJ - 1 - j), lds + cur * Q_BUF3, vi, g, pb, a, p, nb, nt);
-          sbr_q2_stash16h(pa, lds + (cur ^ 1) * Q_BUF3, tid);
-        } else {
-          if (on) sbr_q2_group16v3<true>(z + 2 * (QJ - 1 - j), lds + cur * Q_BUF3, vi, g, pb, a, p, nb, nt);
-          else sbr_q2_group16v3<false>(z + 2 * (QJ - 1 - j), lds + cur * Q_BUF3, vi, g, pb, a, p, nb, nt);
-          sbr_q2_stash16v3(pa, lds + (cur ^ 1) * Q_BUF3, tid);
-        }
-        pa = pb;
-        __syncthreads();
-        cur ^= 1;
-      }
-#pragma unroll
-      for (int i = 0; i < 4; ++i) sbr_q2_stz(zrow, base + 16 * i + 4 * g, a.n, live, z[i] * izs);
-      if (more) {
-#pragma unroll
-        for (int i = 0; i + 4 < QNT; ++i) z[i] = z[i + 4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) z[QNT - 4 + i] = pz[i];
-      } else {
-#pragma unroll
-        for (int i = 4; i < QNT; ++i) sbr_q2_stz(zrow, base + 16 * i + 4 * g, a.n, live, z[i] * izs);
-      }
-    }
-  }
-}
-
-// ---- variant 8 (round 4): the group data as a PRE-BUILT image, moved global -> LDS by DMA.
-// What bound variant 7 was not the matrix pipe (69 MFMAs = ~550 cycles of a ~4 200-cycle group) but the ~430 vector instructions
-// around them (ISA count): every workgroup fetched the group's 32 reflectors + T as floats, split them into fp16 pieces and wrote
-// them to LDS with ~50 two-byte stores per thread -- the same work in all m / 64 workgroups -- and the register pressure of that
-// staging spilled to AGPRs (~100 moves per group). Here one kernel (sbr_q2_build_img, beside the inverse iteration on the
-// auxiliary stream) writes for every group (block b, task t) the finished LDS image once:
-//   part A  Vg' [reflector c][window row r], 100 floats per reflector               (operand of W' = Vg' Zw')
-//   part B  -(Vg Tg) [window row r][reflector c], 36 floats per row                 (operand of Zw' += (-Vg Tg) W')
-// each 16-byte chunk = four consecutive elements as [hi x 4 | lo x 4] fp16 pieces, 28 672 bytes per group, 6.3 GB at n = 30 016.
-// The T product is folded into part B (Zw' <- Zw' - (Vg Tg)(Vg' Zw')): two products per group instead of three (63 matrix
-// instructions, one split fewer, one dependent stage fewer). The apply kernel issues 7 `global_load_lds_dwordx4` per thread and
-// group, NBUF - 1 groups ahead, and splits only the vector window (v_cvt_pk_f16_f32 + v_fma_mix_f32: 2 instructions per element).
-constexpr int Q_IMG_A = QW * Q_RS;   // 3 200 floats
-constexpr int Q_IMG_B = QH * Q_NS;   // 3 456 floats
-constexpr int Q_IMG = 7 * 1024;      // floats per image: 7 wave-instructions of 1 KB per wave, four waves
-static_assert(Q_IMG_A + Q_IMG_B <= Q_IMG, "image layout");
-
-// index of group (b, t) among the groups that exist (t < tasks of sweep 32 b), for n a multiple of 64: blocks 2c and 2c + 1 have
-// n / 64 - c tasks each
-__host__ __device__ __forceinline__ int64_t sbr_q2_img_index(int b, int t, int64_t n) {
-  const int64_t q = n / SB, c = b >> 1;
-  return 2 * c * q - c * (c - 1) + ((b & 1) ? (q - c) : 0) + t;
-}
-static inline int64_t sbr_q2_img_count(int64_t n) { const int64_t q = n / SB; return q * q + q; }
-
-// k32 != 0: the layout for `v_mfma_f32_16x16x32_f16` (a lane supplies EIGHT k per instruction; slot e of lane group g = window row
-// 32 p + 4 g + e for e < 4 and 32 p + 16 + 4 g + e - 4 otherwise, i.e. the register quads of the row tiles 2 p and 2 p + 1 side by
-// side; in part B the slots are the reflectors 4 g + e and 16 + 4 g + e - 4): units of 32 bytes = [hi x 8 | lo x 8],
-//   part A  [reflector c][13 units: (p, g) for p < 3, g < 4, one pad]          104 floats per reflector
-//   part B  [window row r][5 units: g < 4, one pad]                            40 floats per row
-// 18 + 18 matrix instructions of 16 cycles per group instead of 30 + 33 of 16 cycles (the K = 16 form runs at half the rate of the
-// K = 32 form on gfx950).
-constexpr int Q_RS32 = 104, Q_NS32 = 40, Q_IMG_A32 = QW * Q_RS32;
-static_assert(Q_IMG_A32 + QH * Q_NS32 <= Q_IMG, "image layout (K = 32)");
-
-// k32 == 2 (variants 14 / 15): ONE copy of the reflectors + the T factor, 16 384 bytes per group instead of 28 672 -- the kernel is
-// bound by the delivery of the images (below), and gfx950's transposing LDS read (`ds_read_b64_tr_b16`) hands the SAME Vg' image to
-// the third product as its row operand: Zw' <- Zw' + Vg (-Tg (Vg' Zw')), three products, the middle one 32 x 32 x 16 per wave.
-//   part A: four planes (s, hl) of 3 072 bytes, s = which 16-row half of a 32-row K step, hl = hi / lo piece; inside a plane
-//           [reflector tile ct 2][K step p 3][512 bytes]; the 8-byte cell of (m = reflector in the tile, p' = 0..3) holds the four
-//           window rows 32 p + 16 s + 4 p' + e at cell index ((m ^ 8 (p' & 1)) & 15) + 16 ((p' >> 1) ^ (m >> 3)) + 32 (m >> 3):
-//           conflict-free for the row reads of the first product, whether they are issued as ds_read_b64 (64 banks, lanes m = 0..15
-//           x p' in {0, 1} or {2, 3} per 32-lane half) or paired by the compiler into ds_read2st64_b64 (32 banks, 16 lanes m = 0..15 of
-//           one p'), and for the transposed reads of the third (64 banks, lanes m = 0..7 or 8..15 x p' = 0..3 per half)
-//   T part: -Tg as the row operand of the middle product, [hl 2][tile ct' 2][g 4][m 16] units of 16 bytes = the eight k slots
-//           {c = 4 g + e} and {c = 16 + 4 g + e} of row c' = 16 ct' + m
-constexpr int Q_IMG2 = 4096, Q2_PLANE = 768, Q2_TOFF = 4 * Q2_PLANE;
-__host__ __device__ __forceinline__ int sbr_q2_cell(int m, int pq) {  // float offset of the cell inside its 512-byte block
-  return 2 * (((m ^ ((pq & 1) << 3)) & 15) + 16 * (((pq >> 1) ^ (m >> 3)) & 1) + 32 * (m >> 3));
-}
-
-__global__ __launch_bounds__(256) void sbr_q2_build_img(const float* __restrict__ V2, int64_t ldv2, const float* __restrict__ TAU2,
-                                                        int64_t ldt, int64_t n, float* __restrict__ img, int k32) {
-  const int t = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
-  if (t >= sbr_tasks_of((int64_t)b * QW, n)) return;
-  __shared__ float Vg[QH][QW + 1];
-  __shared__ float G[QW][QW + 1];
-  __shared__ float T[QW][QW + 1];
-  __shared__ float Y[QH][QW + 1];
-  __shared__ float tau[QW];
-  const int64_t S = (int64_t)b * QW;
-  for (int idx = tid; idx < QH * QW; idx += 256) {
-    const int c = idx / QH, r = idx % QH;  // consecutive threads read consecutive entries of one reflector
-    Vg[r][c] = sbr_vg(V2, ldv2, n, S, t, r, c);
-  }
-  for (int idx = tid; idx < QW * QW; idx += 256) T[idx >> 5][idx & 31] = 0.f;
-  if (tid < QW) {
-    const int64_t s = S + tid;
-    tau[tid] = (s + 2 < n && s + 1 + (int64_t)t * SB < n) ? TAU2[s * ldt + t] : 0.f;
-  }
-  __syncthreads();
-  {  // G = Vg' Vg
-    const int i = tid >> 3, j0 = 4 * (tid & 7);
-    double acc[4] = {0.0, 0.0, 0.0, 0.0};
-    for (int r = 0; r < QH; ++r) {
-      const double x = (double)Vg[r][i];
-#pragma unroll
-      for (int e = 0; e < 4; ++e) acc[e] += x * (double)Vg[r][j0 + e];
-    }
-#pragma unroll
-    for (int e = 0; e < 4; ++e) G[i][j0 + e] = (float)acc[e];
-  }
-  __syncthreads();
-  // forward columnwise T factor: T[0:c, c] = -tau_c T[0:c, 0:c] (Vg[:, 0:c]' v_c), T[c][c] = tau_c (the recurrence of sbr_q2_build_t)
-  for (int c = 0; c < QW; ++c) {
-    if (tid < c) {
-      double acc = 0.0;
-      for (int j = tid; j < c; ++j) acc += (double)T[tid][j] * (double)G[j][c];
-      T[tid][c] = (float)(-(double)tau[c] * acc);
-    }
-    if (tid == c) T[c][c] = tau[c];
-    __syncthreads();
-  }
-  for (int idx = tid; idx < QH * QW; idx += 256) {  // Y = Vg Tg (Tg upper triangular)
-    const int r = idx >> 5, c = idx & 31;
-    double acc = 0.0;
-    for (int k = 0; k <= c; ++k) acc += (double)Vg[r][k] * (double)T[k][c];
-    Y[r][c] = (float)acc;
-  }
-  __syncthreads();
-  if (k32 == 2) {
-    float* out2 = img + sbr_q2_img_index(b, t, n) * Q_IMG2;
-    for (int it = tid; it < 2 * 2 * 3 * 16 * 4; it += 256) {
-      const int pq = it & 3, m = (it >> 2) & 15, blk = it >> 6, p = blk % 3, ct = (blk / 3) & 1, sh = blk / 6;
-      f32x4 x;
-#pragma unroll
-      for (int e = 0; e < 4; ++e) x[e] = Vg[32 * p + 16 * sh + 4 * pq + e][16 * ct + m];
-      const SbrHL o = sbr_split_pk(x);
-      const int off = (ct * 3 + p) * 128 + sbr_q2_cell(m, pq);
-      f32x2 rh, rl;
-      __builtin_memcpy(&rh, &o.h, 8);
-      __builtin_memcpy(&rl, &o.l, 8);
-      *reinterpret_cast<f32x2*>(out2 + (2 * sh) * Q2_PLANE + off) = rh;
-      *reinterpret_cast<f32x2*>(out2 + (2 * sh + 1) * Q2_PLANE + off) = rl;
-    }
-    if (tid < 128) {
-      const int m = tid & 15, gq = (tid >> 4) & 3, ct = tid >> 6;
-      f32x4 x0, x1;
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        x0[e] = -T[16 * ct + m][4 * gq + e];
-        x1[e] = -T[16 * ct + m][16 + 4 * gq + e];
-      }
-      const SbrHL8 o = sbr_cat(sbr_split_pk(x0), sbr_split_pk(x1));
-      f32x4 rh, rl;
-      __builtin_memcpy(&rh, &o.h, 16);
-      __builtin_memcpy(&rl, &o.l, 16);
-      *reinterpret_cast<f32x4*>(out2 + Q2_TOFF + ((0 * 2 + ct) * 4 + gq) * 64 + 4 * m) = rh;
-      *reinterpret_cast<f32x4*>(out2 + Q2_TOFF + ((1 * 2 + ct) * 4 + gq) * 64 + 4 * m) = rl;
-    }
-    return;
-  }
-  float* out = img + sbr_q2_img_index(b, t, n) * Q_IMG;
-  if (k32) {
-    for (int u = tid; u < Q_IMG / 8; u += 256) {
-      float x[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-      if (u < Q_IMG_A32 / 8) {
-        const int c = u / (Q_RS32 / 8), rem = u % (Q_RS32 / 8);
-        if (rem < 12) {
-          const int p = rem >> 2, gq = rem & 3;
-#pragma unroll
-          for (int e = 0; e < 8; ++e) x[e] = Vg[32 * p + 16 * (e >> 2) + 4 * gq + (e & 3)][c];
-        }
-      } else if (u < (Q_IMG_A32 + QH * Q_NS32) / 8) {
-        const int k = u - Q_IMG_A32 / 8, r = k / (Q_NS32 / 8), gq = k % (Q_NS32 / 8);
-        if (gq < 4) {
-#pragma unroll
-          for (int e = 0; e < 8; ++e) x[e] = -Y[r][16 * (e >> 2) + 4 * gq + (e & 3)];
-        }
-      }
-      _Float16 hl[16];
-#pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        hl[e] = (_Float16)x[e];
-        hl[8 + e] = (_Float16)(x[e] - (float)hl[e]);
-      }
-      f32x4 raw[2];
-      __builtin_memcpy(raw, hl, 32);
-      *reinterpret_cast<f32x4*>(out + 8 * u) = raw[0];
-      *reinterpret_cast<f32x4*>(out + 8 * u + 4) = raw[1];
-    }
-    return;
-  }
-  for (int ch = tid; ch < Q_IMG / 4; ch += 256) {
-    float x[4] = {0.f, 0.f, 0.f, 0.f};
-    if (ch < Q_IMG_A / 4) {
-      const int c = ch / (Q_RS / 4), r4 = ch % (Q_RS / 4);
-#pragma unroll
-      for (int e = 0; e < 4; ++e) x[e] = (4 * r4 + e < QH) ? Vg[4 * r4 + e][c] : 0.f;
-    } else if (ch < (Q_IMG_A + Q_IMG_B) / 4) {
-      const int k = ch - Q_IMG_A / 4, r = k / (Q_NS / 4), c4 = k % (Q_NS / 4);
-#pragma unroll
-      for (int e = 0; e < 4; ++e) x[e] = (4 * c4 + e < QW) ? -Y[r][4 * c4 + e] : 0.f;
-    }
-    SbrHL o;
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      o.h[e] = (_Float16)x[e];
-      o.l[e] = (_Float16)(x[e] - (float)o.h[e]);
-    }
-    f32x4 raw;
-    __builtin_memcpy(&raw, &o, 16);
-    *reinterpret_cast<f32x4*>(out + 4 * ch) = raw;
-  }
-}
-
-// x = hi + lo with two packed conversions and one mixed-precision fma per element (lo = x - hi exactly, hi taken as an fp16 operand)
-__device__ __forceinline__ SbrHL sbr_split_pk(f32x4 x) {
-  const f16x2 h01 = __builtin_convertvector(f32x2{x[0], x[1]}, f16x2);
-  const f16x2 h23 = __builtin_convertvector(f32x2{x[2], x[3]}, f16x2);
-  const unsigned u01 = __builtin_bit_cast(unsigned, h01), u23 = __builtin_bit_cast(unsigned, h23);
-  float l0, l1, l2, l3;
-  asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(l0) : "v"(u01), "v"(x[0]));
-  asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(l1) : "v"(u01), "v"(x[1]));
-  asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(l2) : "v"(u23), "v"(x[2]));
-  asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(l3) : "v"(u23), "v"(x[3]));
-  const f16x2 l01 = __builtin_convertvector(f32x2{l0, l1}, f16x2);
-  const f16x2 l23 = __builtin_convertvector(f32x2{l2, l3}, f16x2);
-  SbrHL o;
-  o.h = f16x4{h01[0], h01[1], h23[0], h23[1]};
-  o.l = f16x4{l01[0], l01[1], l23[0], l23[1]};
-  return o;
-}
-
-// the 7 DMA instructions of one image: lane l of wave w moves bytes [(q 256 + 64 w + l) 16, +16) of the image for q < 7
-template <int NP = 7>
-__device__ __forceinline__ void sbr_q2_dma(const float* __restrict__ img, int64_t index, float* buf, int tid) {
-  const float* src = img + index * (NP * 1024) + 4 * tid;
-  float* dst = buf + 256 * (tid >> 6);
-#pragma unroll
-  for (int q = 0; q < NP; ++q)
-    __builtin_amdgcn_global_load_lds((glb_void*)(src + 1024 * q), (lds_void*)(dst + 1024 * q), 16, 0, 0);
-}
-
-__device__ __forceinline__ void sbr_q2_group16e(f32x4* z, const float* buf, int vi, int g) {
-  const float* VgT = buf;
-  const float* N = buf + Q_IMG_A;
-  SbrHL a0[5], a1[5];
-#pragma unroll
-  for (int rt = 0; rt < 5; ++rt) {
-    a0[rt] = sbr_ld_hl(VgT + vi * Q_RS + 16 * rt + 4 * g);
-    a1[rt] = sbr_ld_hl(VgT + (16 + vi) * Q_RS + 16 * (rt + 1) + 4 * g);
-  }
-  SbrHL zs[6];
-#pragma unroll
-  for (int rt = 0; rt < 6; ++rt) zs[rt] = sbr_split_pk(z[rt]);
-  f32x4 w0 = {0.f, 0.f, 0.f, 0.f}, w1 = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-  for (int rt = 0; rt < 5; ++rt) {
-    w0 = sbr_mfma3(a0[rt], zs[rt], w0);
-    w1 = sbr_mfma3(a1[rt], zs[rt + 1], w1);
-  }
-  SbrHL y0[5], y1[6];  // -(Vg Tg): reflector tile 0 reaches the window rows 0 .. 78, tile 1 the rows 0 .. 94
-#pragma unroll
-  for (int rt = 0; rt < 5; ++rt) y0[rt] = sbr_ld_hl(N + (16 * rt + vi) * Q_NS + 4 * g);
-#pragma unroll
-  for (int rt = 0; rt < 6; ++rt) y1[rt] = sbr_ld_hl(N + (16 * rt + vi) * Q_NS + 16 + 4 * g);
-  const SbrHL w0s = sbr_split_pk(w0), w1s = sbr_split_pk(w1);
-#pragma unroll
-  for (int rt = 0; rt < 6; ++rt) {
-    if (rt < 5) z[rt] = sbr_mfma3(y0[rt], w0s, z[rt]);
-    z[rt] = sbr_mfma3(y1[rt], w1s, z[rt]);
-  }
-}
-
-__device__ __forceinline__ SbrHL8 sbr_ld_hl8(const float* p) {  // one 32-byte unit [hi x 8 | lo x 8]
-  const f32x4 r0 = *reinterpret_cast<const f32x4*>(p), r1 = *reinterpret_cast<const f32x4*>(p + 4);
-  SbrHL8 o;
-  __builtin_memcpy(&o.h, &r0, 16);
-  __builtin_memcpy(&o.l, &r1, 16);
-  return o;
-}
-__device__ __forceinline__ SbrHL8 sbr_cat(const SbrHL& a, const SbrHL& b) {
-  SbrHL8 o;
-  o.h = __builtin_shufflevector(a.h, b.h, 0, 1, 2, 3, 4, 5, 6, 7);
-  o.l = __builtin_shufflevector(a.l, b.l, 0, 1, 2, 3, 4, 5, 6, 7);
-  return o;
-}
-__device__ __forceinline__ f32x4 sbr_mfma3_k32(const SbrHL8& a, const SbrHL8& b, f32x4 c) {
-  c = __builtin_amdgcn_mfma_f32_16x16x32_f16(a.h, b.h, c, 0, 0, 0);
-  c = __builtin_amdgcn_mfma_f32_16x16x32_f16(a.h, b.l, c, 0, 0, 0);
-  c = __builtin_amdgcn_mfma_f32_16x16x32_f16(a.l, b.h, c, 0, 0, 0);
-  return c;
-}
-__device__ __forceinline__ void sbr_q2_group16f(f32x4* z, const float* buf, int vi, int g) {
-  const float* VgT = buf;
-  const float* N = buf + Q_IMG_A32;
-  SbrHL8 a0[3], a1[3];
-#pragma unroll
-  for (int p = 0; p < 3; ++p) {
-    a0[p] = sbr_ld_hl8(VgT + vi * Q_RS32 + 32 * p + 8 * g);
-    a1[p] = sbr_ld_hl8(VgT + (16 + vi) * Q_RS32 + 32 * p + 8 * g);
-  }
-  SbrHL8 zz[3];
-#pragma unroll
-  for (int p = 0; p < 3; ++p) zz[p] = sbr_cat(sbr_split_pk(z[2 * p]), sbr_split_pk(z[2 * p + 1]));
-  f32x4 w0 = {0.f, 0.f, 0.f, 0.f}, w1 = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-  for (int p = 0; p < 3; ++p) {
-    w0 = sbr_mfma3_k32(a0[p], zz[p], w0);
-    w1 = sbr_mfma3_k32(a1[p], zz[p], w1);
-  }
-  SbrHL8 y[6];
-#pragma unroll
-  for (int rt = 0; rt < 6; ++rt) y[rt] = sbr_ld_hl8(N + (16 * rt + vi) * Q_NS32 + 8 * g);
-  const SbrHL8 ws = sbr_cat(sbr_split_pk(w0), sbr_split_pk(w1));
-#pragma unroll
-  for (int rt = 0; rt < 6; ++rt) z[rt] = sbr_mfma3_k32(y[rt], ws, z[rt]);
-}
-
-// the group of variants 14 / 15: three products from the 16 KB image (layout at Q_IMG2)
-typedef __fp16 fp16x4_t __attribute__((__vector_size__(4 * sizeof(__fp16))));
-typedef __attribute__((address_space(3))) fp16x4_t lds_fp16x4;
-__device__ __forceinline__ f16x4 sbr_ld_tr(const float* p) {  // transposing read: EXEC must be all ones (it is: whole-wave code)
-  return __builtin_bit_cast(f16x4, __builtin_amdgcn_ds_read_tr16_b64_v4f16((lds_fp16x4*)p));
-}
-__device__ __forceinline__ f16x4 sbr_ld_h4(const float* p) {
-  const f32x2 r = *reinterpret_cast<const f32x2*>(p);
-  return __builtin_bit_cast(f16x4, r);
-}
-__device__ __forceinline__ f16x8 sbr_cat4(f16x4 a, f16x4 b) { return __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7); }
-__device__ __forceinline__ void sbr_q2_group16t(f32x4* z, const float* buf, int vi, int g) {
-  // With one wave per SIMD (m = n / 2: 938 wave tiles for 1 024 SIMDs) nothing hides a wave's own latencies, and left to itself the
-  // compiler puts every LDS read next to its use (~20 exposed round trips per group, profiles/r04_q2_phase_clocks.log); a scheduling
-  // barrier does not stop it, a memory-clobbering statement makes it wait for the reads at once, and it guards the transposing read
-  // (a builtin) with `s_waitcnt vmcnt(0)`, i.e. with the DMA of the images still in flight. So the LDS reads of this function are
-  // volatile statements (kept in program order), each stage's reads are all in flight before the arithmetic that hides them, and the
-  // waits are written out: one `lgkmcnt(0)` per stage, tied to the registers it releases.
-  const unsigned lb = (unsigned)(__UINTPTR_TYPE__)(lds_void*)buf;
-  // (1) operands of W' = Vg' Zw' (rows = reflectors, two tiles; K = the 96 window rows in three steps) and of U = -Tg W'
-  const unsigned aa = lb + 4u * (unsigned)sbr_q2_cell(vi, g);
-  f32x2 ah[2][3][2], al[2][3][2];  // [reflector tile][K step][16-row half]
-  asm volatile("ds_read_b64 %0, %1 offset:0" : "=v"(ah[0][0][0]) : "v"(aa));
-  asm volatile("ds_read_b64 %0, %1 offset:3072" : "=v"(al[0][0][0]) : "v"(aa));
-  asm volatile("ds_read_b64 %0, %1 offset:6144" : "=v"(ah[0][0][1]) : "v"(aa));
-  asm volatile("ds_read_b64 %0, %1 offset:9216" : "=v"(al[0][0][1]) : "v"(aa));
-  asm volatile("ds_read_b64 %0, %1 offset:512" : "=v"(ah[0][1][0]) : "v"(aa));
-  asm volatile("ds_read_b64 %0, %1 offset:3584" : "=v"(al[0][1][0]) : "v"(aa));
-  asm volatile("ds_read_b64 %0, %1 offset:6656" : "=v"(ah[0][1][1]) : "v"(aa));
-  asm volatile("ds_read_b64 %0, %1 offset:9728" : "=v"(al[0][1][1]) : "v"(aa));
-  asm volatile("ds_read_b64 %0, %1 offset:1024" : "=v"(ah[0][2][0]) : "v"(aa));
-  asm volatile("ds_read_b64 %0, %1 offset:4096" : "=v"(al[0][2][0]) : "v"(aa));
-  asm volatile("ds_read_b64 %0, %1 offset:7168" : "=v"(ah[0][2][1]) : "v"(aa));
-  asm volatile("ds_read_b64 %0, %1 offset:10240" : "=v"(al[0][2][1]) : "v"(aa));
-  asm volatile("ds_read_b64 %0, %1 offset:1536" : "=v"(ah[1][0][0]) : "v"(aa));
-  asm volatile("ds_read_b64 %0, %1 offset:4608" : "=v"(al[1][0][0]) : "v"(aa));
-  asm volatile("ds_read_b64 %0, %1 offset:7680" : "=v"(ah[1][0][1]) : "v"(aa));
-  asm volatile("ds_read_b64 %0, %1 offset:10752" : "=v"(al[1][0][1]) : "v"(aa));
-  asm volatile("ds_read_b64 %0, %1 offset:2048" : "=v"(ah[1][1][0]) : "v"(aa));
-  asm volatile("ds_read_b64 %0, %1 offset:5120" : "=v"(al[1][1][0]) : "v"(aa));
-  asm volatile("ds_read_b64 %0, %1 offset:8192" : "=v"(ah[1][1][1]) : "v"(aa));
-  asm volatile("ds_read_b64 %0, %1 offset:11264" : "=v"(al[1][1][1]) : "v"(aa));
-  asm volatile("ds_read_b64 %0, %1 offset:2560" : "=v"(ah[1][2][0]) : "v"(aa));
-  asm volatile("ds_read_b64 %0, %1 offset:5632" : "=v"(al[1][2][0]) : "v"(aa));
-  asm volatile("ds_read_b64 %0, %1 offset:8704" : "=v"(ah[1][2][1]) : "v"(aa));
-  asm volatile("ds_read_b64 %0, %1 offset:11776" : "=v"(al[1][2][1]) : "v"(aa));
-  const unsigned ta = lb + 4u * (unsigned)(Q2_TOFF + g * 64 + 4 * vi);
-  f32x4 th[2], tl[2];
-  asm volatile("ds_read_b128 %0, %1 offset:0" : "=v"(th[0]) : "v"(ta));
-  asm volatile("ds_read_b128 %0, %1 offset:2048" : "=v"(tl[0]) : "v"(ta));
-  asm volatile("ds_read_b128 %0, %1 offset:1024" : "=v"(th[1]) : "v"(ta));
-  asm volatile("ds_read_b128 %0, %1 offset:3072" : "=v"(tl[1]) : "v"(ta));
-  // (2) the window in fp16 pieces: vector instructions under the reads' latency (the window passes through a volatile statement
-  //     behind the reads, so that its splits cannot be scheduled in front of them)
-  asm volatile("" : "+v"(z[0]), "+v"(z[1]), "+v"(z[2]), "+v"(z[3]), "+v"(z[4]), "+v"(z[5]));
-  SbrHL8 zz[3];
-#pragma unroll
-  for (int p = 0; p < 3; ++p) zz[p] = sbr_cat(sbr_split_pk(z[2 * p]), sbr_split_pk(z[2 * p + 1]));
-  asm volatile("s_waitcnt lgkmcnt(0)"
-               : "+v"(ah[0][0][0]), "+v"(ah[0][0][1]), "+v"(ah[0][1][0]), "+v"(ah[0][1][1]), "+v"(ah[0][2][0]), "+v"(ah[0][2][1]),
-                 "+v"(ah[1][0][0]), "+v"(ah[1][0][1]), "+v"(ah[1][1][0]), "+v"(ah[1][1][1]), "+v"(ah[1][2][0]), "+v"(ah[1][2][1]),
-                 "+v"(al[0][0][0]), "+v"(al[0][0][1]), "+v"(al[0][1][0]), "+v"(al[0][1][1]), "+v"(al[0][2][0]), "+v"(al[0][2][1]),
-                 "+v"(al[1][0][0]), "+v"(al[1][0][1]), "+v"(al[1][1][0]), "+v"(al[1][1][1]), "+v"(al[1][2][0]), "+v"(al[1][2][1]),
-                 "+v"(th[0]), "+v"(th[1]), "+v"(tl[0]), "+v"(tl[1]));
-  // (3) W'
-  f32x4 w0 = {0.f, 0.f, 0.f, 0.f}, w1 = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-  for (int p = 0; p < 3; ++p) {
-    SbrHL8 a0, a1;
-    a0.h = sbr_cat4(__builtin_bit_cast(f16x4, ah[0][p][0]), __builtin_bit_cast(f16x4, ah[0][p][1]));
-    a0.l = sbr_cat4(__builtin_bit_cast(f16x4, al[0][p][0]), __builtin_bit_cast(f16x4, al[0][p][1]));
-    a1.h = sbr_cat4(__builtin_bit_cast(f16x4, ah[1][p][0]), __builtin_bit_cast(f16x4, ah[1][p][1]));
-    a1.l = sbr_cat4(__builtin_bit_cast(f16x4, al[1][p][0]), __builtin_bit_cast(f16x4, al[1][p][1]));
-    w0 = sbr_mfma3_k32(a0, zz[p], w0);
-    w1 = sbr_mfma3_k32(a1, zz[p], w1);
-  }
-  // (4) Vg for the third product out of the same image by transposing reads, all 24 in flight behind the matrix instructions of (3)
-  //     (the address passes through a statement that reads W'): lane 4 q + p'' of a 16-lane group addresses the cell of reflector
-  //     4 g + q (then 16 + 4 g + q), rows 4 p'' .. 4 p'' + 3 of the tile
-  unsigned ya = lb + 4u * (unsigned)sbr_q2_cell(4 * g + (vi >> 2), vi & 3);
-  asm volatile("" : "+v"(ya), "+v"(w0), "+v"(w1));
-  f32x2 yh[6][2], yl[6][2];  // [window-row tile][reflector tile]
-  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:0" : "=v"(yh[0][0]) : "v"(ya));
-  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:3072" : "=v"(yl[0][0]) : "v"(ya));
-  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:1536" : "=v"(yh[0][1]) : "v"(ya));
-  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:4608" : "=v"(yl[0][1]) : "v"(ya));
-  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:6144" : "=v"(yh[1][0]) : "v"(ya));
-  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:9216" : "=v"(yl[1][0]) : "v"(ya));
-  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:7680" : "=v"(yh[1][1]) : "v"(ya));
-  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:10752" : "=v"(yl[1][1]) : "v"(ya));
-  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:512" : "=v"(yh[2][0]) : "v"(ya));
-  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:3584" : "=v"(yl[2][0]) : "v"(ya));
-  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:2048" : "=v"(yh[2][1]) : "v"(ya));
-  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:5120" : "=v"(yl[2][1]) : "v"(ya));
-  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:6656" : "=v"(yh[3][0]) : "v"(ya));
-  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:9728" : "=v"(yl[3][0]) : "v"(ya));
-  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:8192" : "=v"(yh[3][1]) : "v"(ya));
-  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:11264" : "=v"(yl[3][1]) : "v"(ya));
-  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:1024" : "=v"(yh[4][0]) : "v"(ya));
-  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:4096" : "=v"(yl[4][0]) : "v"(ya));
-  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:2560" : "=v"(yh[4][1]) : "v"(ya));
-  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:5632" : "=v"(yl[4][1]) : "v"(ya));
-  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:7168" : "=v"(yh[5][0]) : "v"(ya));
-  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:10240" : "=v"(yl[5][0]) : "v"(ya));
-  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:8704" : "=v"(yh[5][1]) : "v"(ya));
-  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:11776" : "=v"(yl[5][1]) : "v"(ya));
-  // (5) U = -Tg W'
-  const SbrHL8 ws = sbr_cat(sbr_split_pk(w0), sbr_split_pk(w1));
-  f16x8 t0h, t1h, t0l, t1l;
-  __builtin_memcpy(&t0h, &th[0], 16);
-  __builtin_memcpy(&t1h, &th[1], 16);
-  __builtin_memcpy(&t0l, &tl[0], 16);
-  __builtin_memcpy(&t1l, &tl[1], 16);
-  const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
-  f32x4 u0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(t0h, ws.h, zero, 0, 0, 0);
-  f32x4 u1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(t1h, ws.h, zero, 0, 0, 0);
-  u0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(t0h, ws.l, u0, 0, 0, 0);
-  u1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(t1h, ws.l, u1, 0, 0, 0);
-  u0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(t0l, ws.h, u0, 0, 0, 0);
-  u1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(t1l, ws.h, u1, 0, 0, 0);
-  const SbrHL8 us = sbr_cat(sbr_split_pk(u0), sbr_split_pk(u1));
-  asm volatile("s_waitcnt lgkmcnt(0)"
-               : "+v"(yh[0][0]), "+v"(yh[0][1]), "+v"(yh[1][0]), "+v"(yh[1][1]), "+v"(yh[2][0]), "+v"(yh[2][1]), "+v"(yh[3][0]), "+v"(yh[3][1]),
-                 "+v"(yh[4][0]), "+v"(yh[4][1]), "+v"(yh[5][0]), "+v"(yh[5][1]), "+v"(yl[0][0]), "+v"(yl[0][1]), "+v"(yl[1][0]), "+v"(yl[1][1]),
-                 "+v"(yl[2][0]), "+v"(yl[2][1]), "+v"(yl[3][0]), "+v"(yl[3][1]), "+v"(yl[4][0]), "+v"(yl[4][1]), "+v"(yl[5][0]), "+v"(yl[5][1]));
-  // (6) Zw' += Vg U: rows = window rows (six tiles), K = the 32 reflectors
-#pragma unroll
-  for (int rt = 0; rt < 6; ++rt) {
-    SbrHL8 y;
-    y.h = sbr_cat4(__builtin_bit_cast(f16x4, yh[rt][0]), __builtin_bit_cast(f16x4, yh[rt][1]));
-    y.l = sbr_cat4(__builtin_bit_cast(f16x4, yl[rt][0]), __builtin_bit_cast(f16x4, yl[rt][1]));
-    z[rt] = sbr_mfma3_k32(y, us, z[rt]);
-  }
-}
-
-// Window loads / stores of the image-fed kernel: buffer instructions on a resource that covers the workgroup's 64 vectors, one
-// instruction per lane and call WHATEVER the row (quads outside [-3, n - 3] and vectors past m get an offset beyond the resource:
-// the load returns 0, the store is dropped) -- the number of memory instructions between two waits is then a constant, which the
-// counted `s_waitcnt vmcnt(N)` below rely on. A quad that starts at row n - 3 ends in the row's padding (ldq >= n + 4 floats, zeroed
-// by sbr_q2_shift).
-typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-struct SbrZWin {
-  __amdgpu_buffer_rsrc_t rs;
-  int64_t lane_base;  // float index of row 0 of this lane's vector inside the resource
-  int64_t n;
-};
-__device__ __forceinline__ unsigned sbr_zoff(const SbrZWin& w, int64_t row) {
-  return (row >= -3 && row <= w.n - 3) ? (unsigned)((w.lane_base + row) * 4) : 0xfffffff0u;
-}
-__device__ __forceinline__ f32x4 sbr_zld(const SbrZWin& w, int64_t row) {
-  return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(w.rs, sbr_zoff(w, row), 0, 0));
-}
-__device__ __forceinline__ void sbr_zst(const SbrZWin& w, int64_t row, f32x4 v) {
-  __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), w.rs, sbr_zoff(w, row), 0, 0);
-}
-template <int N>
-__device__ __forceinline__ void sbr_vmcnt() {  // at most N vector-memory instructions of this wave may still be in flight
-  static_assert(N == 0 || N == 4 || N == 7 || N == 8 || N == 11 || N == 12 || N == 15, "counts of the image-fed kernel");
-  if (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  if (N == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-  if (N == 7) asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
-  if (N == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-  if (N == 11) asm volatile("s_waitcnt vmcnt(11)" ::: "memory");
-  if (N == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
-  if (N == 15) asm volatile("s_waitcnt vmcnt(15)" ::: "memory");
-}
-
-// LW (variant 12): four LOADER waves beside the four compute waves (512 threads, one workgroup per CU). A wave executes its
-// instructions in order, so in the one-role kernel a group costs DMA issue (7 pieces of 60-180 cycles each) + products + barrier --
-// measured 274 ms with the products off, 203 ms with the DMA off, 280 ms together (profiles/r04_q2_variants.log): the two do not
-// overlap. With a loader wave on every SIMD the DMA instructions issue beside the other wave's matrix instructions (different issue
-// ports), the compute waves carry no DMA and no counted waits, and the group barrier doubles as the "image has landed" signal (a
-// loader arrives at it only behind its own `vmcnt`).
-template <int QJ, int QNT, int NBUF, bool K32, bool LW, bool TV = false>
-__global__ __launch_bounds__(LW ? 512 : 256, LW ? 1 : 2) void sbr_q2_apply16e(SbrQ2Args a, const float* __restrict__ img, int dbg) {
-  static_assert(NBUF == 2 || NBUF == 3, "one or two groups ahead");
-  static_assert(!TV || (K32 && !LW), "the 16 KB image is a K = 32 form without loader waves");
-  constexpr int NP = TV ? 4 : 7, QI = NP * 1024;          // DMA pieces (4 KB) and floats per image
-  constexpr int AH = NBUF - 1, DM = (AH == 2) ? NP : 0;  // DMA instructions that may stay in flight past the end of a group
-  extern __shared__ __attribute__((aligned(16))) float q2lds[];  // NBUF images
-  float* lds = q2lds;
-  const int tid = threadIdx.x, lane = tid & 63, vi = lane & 15, g = lane >> 4;
-  const bool loader = LW && (tid >> 8) != 0;       // waves 4 .. 7
-  const int wv = (tid >> 6) & 3;                   // index among the waves of its role
-  const int dtid = tid & 255;                      // the lane's share of an image's DMA
-  const bool does_dma = LW ? loader : true, does_math = !loader;
-  const int64_t v0 = (int64_t)blockIdx.x * 64;
-  const int64_t nvec = (a.m - v0 < 64) ? a.m - v0 : 64;
-  SbrZWin zw;
-  zw.rs = __builtin_amdgcn_make_buffer_rsrc(a.Zq + v0 * a.ldq, 0, (unsigned)(nvec * a.ldq * 4), 0x00020000);
-  zw.lane_base = (int64_t)(wv * 16 + vi) * a.ldq + 3;
-  zw.n = a.n;
-  const int nsb = (a.nblk + QJ - 1) / QJ;
-  auto index_of = [&](int b, int t) -> int64_t {  // groups that do not exist read image 0 (never used)
-    return (b >= 0 && t < sbr_tasks_of((int64_t)b * QW, a.n)) ? sbr_q2_img_index(b, t, a.n) : 0;
-  };
-  // the first AH groups of the sequence: blocks nblk - 1, nblk - 2 at task 0 (QJ > AH)
-#pragma unroll
-  for (int i = 0; i < AH; ++i)
-    if (does_dma) sbr_q2_dma<NP>(img, index_of(a.nblk - 1 - i, 0), lds + i * QI, dtid);
-  sbr_vmcnt<DM>();
-  __syncthreads();
-  int cur = 0;
-  f32x4 z[QNT];
-  const bool raw_barrier = !(dbg & 4);  // SCLENS_HIP_Q2_DBG=4: __syncthreads() per group, as until the end of round 4 (A/B)
-  const bool late_win = !LW && (dbg & 8);  // SCLENS_HIP_Q2_DBG=8: the window traffic behind the products instead of behind the DMA pieces
-  // phase clocks (a.prof): 0 DMA issue, 1 window loads / stores issue, 2 products, 3 counted wait, 4 barrier, 5 between groups
-  const bool prof = a.prof != nullptr && blockIdx.x == gridDim.x / 2 && tid < 64;
-  unsigned long long pacc[6] = {0, 0, 0, 0, 0, 0}, pn = 0, pt = prof ? __builtin_amdgcn_s_memtime() : 0ull;
-#define SBR_Q2_STAMP(i)                                               \
-  if (prof) {                                                         \
-    const unsigned long long now_ = __builtin_amdgcn_s_memtime();     \
-    pacc[i] += now_ - pt;                                             \
-    pt = now_;                                                        \
-  }
-  for (int sb = 0; sb < nsb; ++sb) {
-    const int bh = a.nblk - 1 - sb * QJ, blow = bh - QJ + 1;
-    const int Kmax = sbr_tasks_of((int64_t)(blow > 0 ? blow : 0) * QW, a.n);
-    const int64_t base0 = (int64_t)blow * QW + 1;
-    if (does_math) {
-      sbr_vmcnt<0>();  // the stores of the previous pass have left before rows are re-read
-#pragma unroll
-      for (int i = 0; i < QNT; ++i) z[i] = sbr_zld(zw, base0 + 16 * i + 4 * g) * Q_ZSCALE;
-    }
-    f32x4 zout[4];       // the 64 rows that left the window at the end of the previous task: stored inside the next task's first
-    bool pend = false;   // group, BEHIND its DMA instructions (memory instructions complete in issue order: a wait for the image
-                         // would otherwise also wait one HBM round trip for stores and loads nobody needs yet -- 0.5 us per group,
-                         // 111 of the kernel's 295 ms, profiles/r04_q2_variants.log)
-    for (int t = 0; t < Kmax; ++t) {
-      const int64_t base = base0 + (int64_t)t * SB;
-      f32x4 pz[4];
-      const bool more = t + 1 < Kmax;
-#pragma unroll
-      for (int j = 0; j < QJ; ++j) {
-        int nb, nt;  // the group AH steps after this one in the sequence (j ascending inside a task, then the next task, then the next pass)
-        const int jj = j + AH;
-        if (jj < QJ) {
-          nb = bh - jj;
-          nt = t;
-        } else if (more) {
-          nb = bh - (jj - QJ);
-          nt = t + 1;
-        } else {
-          nb = bh - QJ - (jj - QJ);
-          nt = 0;
-        }
-        // its image goes to the buffer the PREVIOUS group was read from (all waves have passed the barrier behind it)
-        asm volatile("" ::: "memory");
-        SBR_Q2_STAMP(5)
-        int nxt = cur + AH;
-        if (nxt >= NBUF) nxt -= NBUF;
-        if (does_dma && !(dbg & 2)) sbr_q2_dma<NP>(img, index_of(nb, nt), lds + nxt * QI, dtid);  // dbg: timing experiments only (WRONG results)
-        asm volatile("" ::: "memory");
-        SBR_Q2_STAMP(0)
-        // the window traffic of this task, behind the DMA: 4 stores (rows that left), 4 loads (rows that will enter). Right behind the
-        // DMA pieces their issue costs ~550 clocks per group (they queue up behind the workgroup's 16-28 pieces); issued behind the
-        // products instead (`late_win`, SCLENS_HIP_Q2_DBG=8) they issue at once but land later: 265 against 250 ms (variant 15,
-        // profiles/r04_q2_final_variants.log) -- the early position stays.
-        auto window_traffic = [&]() {
-          if (pend) {
-#pragma unroll
-            for (int i = 0; i < 4; ++i) sbr_zst(zw, base - SB + 16 * i + 4 * g, zout[i]);
-          }
-          if (more) {
-#pragma unroll
-            for (int i = 0; i < 4; ++i) pz[i] = sbr_zld(zw, base + 16 * (QNT + i) + 4 * g);
-          }
-          asm volatile("" ::: "memory");
-        };
-        if (j == 0 && does_math && !late_win) window_traffic();
-        SBR_Q2_STAMP(1)
-        const int b = bh - j;
-        if (does_math && b >= 0 && t < sbr_tasks_of((int64_t)b * QW, a.n) && !(dbg & 1)) {
-          if (TV) sbr_q2_group16t(z + 2 * (QJ - 1 - j), lds + cur * QI, vi, g);
-          else if (K32) sbr_q2_group16f(z + 2 * (QJ - 1 - j), lds + cur * QI, vi, g);
-          else sbr_q2_group16e(z + 2 * (QJ - 1 - j), lds + cur * QI, vi, g);
-        }
-        if (prof) {  // the products' results are in registers when the stamp is taken
-#pragma unroll
-          for (int i = 0; i < QNT; ++i) asm volatile("" ::"v"(z[i]));
-          asm volatile("s_nop 7\n\ts_nop 7" ::: "memory");
-        }
-        SBR_Q2_STAMP(2)
-        if (j == 0 && does_math && late_win) {
-          asm volatile("" ::: "memory");
-          window_traffic();
-          SBR_Q2_STAMP(1)
-        }
-        // the image of the next group must have landed (AH == 1), or the one after it may still be in flight (AH == 2); the window
-        // traffic issued in this group (j == 0) may stay in flight as well: it is waited for one group later (j == 1: everything)
-        if (LW) {  // loaders: their DMA only; compute waves: nothing to wait for (the compiler waits where a loaded row is used)
-          if (loader) sbr_vmcnt<DM>();
-        } else if (j == 0 || (j == 1 && AH == 2)) {
-          // (two groups ahead: the image needed next was requested BEFORE this task's window traffic, so that may stay in flight for
-          // one more group)
-          const int nz = (pend ? 4 : 0) + (more ? 4 : 0);
-          if (nz == 8) sbr_vmcnt<DM + 8>();
-          else if (nz == 4) sbr_vmcnt<DM + 4>();
-          else sbr_vmcnt<DM>();
-        } else {
-          sbr_vmcnt<DM>();
-        }
-        SBR_Q2_STAMP(3)
-        // a bare barrier: __syncthreads() carries a workgroup-scope release fence, which the compiler implements as `s_waitcnt vmcnt(0)`
-        // -- every group then waited for ALL of the wave's memory instructions (the image two groups ahead, the window loads and
-        // stores), and the counted waits above were void (found in the ISA at the end of round 4: why two groups ahead never paid).
-        // What the barrier has to guarantee here is covered by the counted wait of every wave for its own pieces of the image.
-        if (raw_barrier) __builtin_amdgcn_s_barrier();
-        else __syncthreads();
-        SBR_Q2_STAMP(4)
-        ++pn;
-        cur = (cur + 1 == NBUF) ? 0 : cur + 1;
-      }
-      if (!does_math) continue;
-      if (more) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) zout[i] = z[i] * (1.f / Q_ZSCALE);
-        pend = true;
-#pragma unroll
-        for (int i = 0; i + 4 < QNT; ++i) z[i] = z[i + 4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) z[QNT - 4 + i] = pz[i] * Q_ZSCALE;
-      } else {
-#pragma unroll
-        for (int i = 0; i < QNT; ++i) sbr_zst(zw, base + 16 * i + 4 * g, z[i] * (1.f / Q_ZSCALE));
-        pend = false;
-      }
-    }
-  }
-#undef SBR_Q2_STAMP
-  if (prof && tid == 0) {
-#pragma unroll
-    for (int i = 0; i < 6; ++i) a.prof[i] = pacc[i];
-    a.prof[6] = pn;
-  }
-}
-
-// Zq[v][3 + r] <-> Zt[v][r]
-__global__ void sbr_q2_shift(const float* __restrict__ in, int64_t ldi, int64_t offi, float* __restrict__ out, int64_t ldo,
-                             int64_t offo, int64_t n) {
-  const int64_t r = blockIdx.y;
-  const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (c < n) out[r * ldo + offo + c] = in[r * ldi + offi + c];
-  // into the shifted layout (offo = 3): the three floats in front of row 0 and the padding behind row n - 1 are read as window rows
-  if (offo > 0 && c < offo) out[r * ldo + c] = 0.f;
-  if (offo > 0 && c < ldo - offo - n) out[r * ldo + offo + n + c] = 0.f;
-}
-
-// 15 (default since the end of round 4): 16 KB group images (one copy of the reflectors + T, the third product's operand by
-// transposing LDS reads, hand-scheduled LDS reads), two groups ahead; 14: one ahead; 10 / 11: 28 KB images with T folded into a second
-// operand copy (two products), one / two ahead, K = 32 matrix instructions; 8 / 9: their K = 16 form; 12 / 13: loader waves; 7:
-// split-fp16 products, reflectors staged by every workgroup (round 3); 3: fp32 products (every product of the solver on the fp32 matrix
-// cores); 0, 1, 5, 6: earlier kernels kept for comparison. Measured at n = 30 016 (profiles/r04_q2_*): m = 15 008: 385 (7), 307 (8),
-// 296 (9), 295 (10), 303 (11) ms, with the window traffic behind the DMA (counted waits) 280 (10), 284 (11), loader waves 288 / 285.
-// What the phase clocks of a group showed at the end of round 4 (SCLENS_HIP_Q2_PROF, profiles/r04_q2_phase_clocks.log; one wave per
-// SIMD at m = n / 2, so nothing hides a wave's own latencies): (i) __syncthreads() carries a release fence = `s_waitcnt vmcnt(0)`, so
-// every group waited for ALL memory instructions and "two groups ahead" never was; (ii) the 28 KB of an image take ~3 000 clocks to
-// arrive whatever is in flight (9.5 B per clock and CU), as long as a group of variant 10 -- the products hid behind the barrier; (iii)
-// the compiler put every LDS read next to its use: ~20 exposed round trips per group. With a bare barrier, 16 KB images and the reads
-// of a stage issued together: 250 ms where variant 10 takes 293 on the same box (profiles/r04_q2_final_variants.log), all vectors 444 -> 414.
-static int sbr_q2_variant(int64_t n) {
-  const char* eq2 = getenv("SCLENS_HIP_Q2_VARIANT");
-  int v = eq2 ? atoi(eq2) : 15;
-  if (v >= 8 && v <= 15 && n % SB != 0) v = 7;  // the image index assumes an order that is a multiple of 64 (the two-stage solver pads)
-  return v;
-}
-
-// what the apply kernel of the selected variant needs besides the reflectors: the groups' T factors, or their finished LDS images
-static int sbr_q2_launch_build_t(Ctx* ctx, int64_t n, hipStream_t st) {
-  const int64_t ldv2 = sbr_ldv2(n), ldt = n / SB + 2, nsweep = n - 2;
-  const float* V2 = static_cast<const float*>(ctx->ws.count("sbr.V2") ? ctx->ws.at("sbr.V2").first : nullptr);
-  const float* TAU2 = static_cast<const float*>(ctx->ws.count("sbr.TAU2") ? ctx->ws.at("sbr.TAU2").first : nullptr);
-  if (!V2 || !TAU2 || nsweep <= 0) return ctx->fail(SCLENS_ERR_STATE, "sbr_q2_build_t: no reflectors of a preceding sb2st_f32 on this context");
-  const int nblk = (int)((nsweep + QW - 1) / QW), nk = (int)((n - 1 + SB - 1) / SB);
-  const int variant = sbr_q2_variant(n);
-  if (variant >= 8 && variant <= 15) {
-    SCL_WS(ctx, img, float, "sbr.Q2img", (sbr_q2_img_count(n) + 1) * (variant >= 14 ? Q_IMG2 : Q_IMG));
-    hipLaunchKernelGGL(sbr_q2_build_img, dim3((unsigned)nk, (unsigned)nblk), dim3(256), 0, st, V2, ldv2, TAU2, ldt, n, img,
-                       variant >= 14 ? 2 : (variant >= 10 ? 1 : 0));
-  } else {
-    SCL_WS(ctx, Tg, float, "sbr.Tg", (int64_t)nblk * nk * QW * QW);
-    hipLaunchKernelGGL(sbr_q2_build_t, dim3((unsigned)nk, (unsigned)nblk), dim3(64), 0, st, V2, ldv2, TAU2, ldt, n, nk, Tg);
-  }
-  ctx->q2_built_variant = variant;
-  SCL_HIP(ctx, hipGetLastError());
-  return SCLENS_OK;
-}
-
-int sbr_apply_q2(Ctx* ctx, int64_t n, float* Zt, int64_t m, int64_t ldz) {
-  if (m <= 0) return SCLENS_OK;
-  StageTimer tm(ctx, "sbr_q2");
-  const int64_t ldv2 = sbr_ldv2(n), ldt = n / SB + 2;
-  const float* V2 = static_cast<const float*>(ctx->ws.count("sbr.V2") ? ctx->ws.at("sbr.V2").first : nullptr);
-  const float* TAU2 = static_cast<const float*>(ctx->ws.count("sbr.TAU2") ? ctx->ws.at("sbr.TAU2").first : nullptr);
-  if (!V2 || !TAU2) return ctx->fail(SCLENS_ERR_STATE, "sbr_apply_q2: no reflectors of a preceding sb2st_f32 on this context");
-  if (getenv("SCLENS_HIP_Q2_REFERENCE")) {  // the unblocked reference version (tests)
-    int VT = (int)((150 * 1024) / (4 * n));
-    if (VT > 8) VT = 8;
-    if (VT < 1) return ctx->fail(SCLENS_ERR_ARG, "sbr_apply_q2 (reference version): order too large for one vector in LDS");
-    const size_t lds = sizeof(float) * (size_t)VT * (size_t)n;
-    SCL_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(sbr_q2_simple), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                     (int)lds));
-    hipLaunchKernelGGL(sbr_q2_simple, dim3((unsigned)((m + VT - 1) / VT)), dim3(256), lds, ctx->stream, V2, ldv2, TAU2, ldt, n,
-                       Zt, m, ldz, VT);
-    SCL_HIP(ctx, hipGetLastError());
-    return SCLENS_OK;
-  }
-  const int64_t nsweep = n - 2;
-  if (nsweep <= 0) return SCLENS_OK;
-  const int nblk = (int)((nsweep + QW - 1) / QW), nk = (int)((n - 1 + SB - 1) / SB);
-  const int q2_variant = sbr_q2_variant(n);
-  if (ctx->q2_tg_n == n && ctx->q2_ev && ctx->q2_built_variant == q2_variant) {  // built on the auxiliary stream after the chase
-    SCL_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->q2_ev, 0));                 // (or by an earlier call on these reflectors)
-  } else {
-    SCL_TRY(sbr_q2_launch_build_t(ctx, n, ctx->stream));
-    ctx->q2_tg_n = n;  // valid until the next chase on this context (sb2st_f32 resets it)
-  }
-  const float* Tg = static_cast<const float*>(ctx->ws.count("sbr.Tg") ? ctx->ws.at("sbr.Tg").first : nullptr);
-  const float* q2img = static_cast<const float*>(ctx->ws.count("sbr.Q2img") ? ctx->ws.at("sbr.Q2img").first : nullptr);
-  // the apply kernel works on the shifted layout Zq[v][3 + row] (16-byte aligned register quads, see above)
-  const int64_t ldq = round_up(n + 3, 4);
-  SCL_WS(ctx, Zq, float, "sbr.Zq", m * ldq);
-  for (int64_t r0 = 0; r0 < m; r0 += 65535) {
-    const int64_t rows = (m - r0 < 65535) ? m - r0 : 65535;
-    hipLaunchKernelGGL(sbr_q2_shift, dim3((unsigned)((n + 255) / 256), (unsigned)rows), dim3(256), 0, ctx->stream, Zt + r0 * ldz, ldz,
-                       (int64_t)0, Zq + r0 * ldq, ldq, (int64_t)3, n);
-  }
-  SbrQ2Args qa{V2, ldv2, Tg, nk, nblk, n, Zq, m, ldq, nullptr};
-  if (const char* ep = getenv("SCLENS_HIP_Q2_PROF")) {
-    if (atoi(ep) > 0) {
-      qa.prof = static_cast<unsigned long long*>(ctx->workspace("sbr.q2prof", 8 * sizeof(unsigned long long)));
-      if (!qa.prof) return SCLENS_ERR_OOM;
-      SCL_HIP(ctx, hipMemsetAsync(qa.prof, 0, 8 * sizeof(unsigned long long), ctx->stream));
-    }
-  }
-  // Measured and dropped (n = 30 016, m = 15 008; this kernel: 510 ms): a barrier-free variant with per-wave LDS images filled by
-  // LDS-DMA (617 ms: 48 DMA instructions per group and wave cost as many issue cycles as the group's 92 MFMAs), one barrier per
-  // step of four groups instead of one per group (533 ms), 2 / 8 sweep blocks per pass (599 / 1020 ms), wave-uniform scalar
-  // addressing of the group fetch (554 ms). PMC (profiles/r02_pmc_eig.txt): the MFMA pipe is busy 55 % of the wave cycles, 33 %
-  // of them issue other instructions, 23 % wait at barriers / waitcnt.
-  // 7 (default): split-fp16 products, reflectors fetched two groups ahead -- 397 ms against 500 ms for 3 (fp32 products, one group
-  // ahead; the default until round 3) at n = 30 016, m = 15 008, orthogonality of the result 5.1e-7 against 4.6e-7
-  // (profiles/r03_q2_variants.log). 6 = 3 with the deeper fetch (same bits, same time), 5 = 7 with the shallow one (same bits as 7,
-  // 517 ms), 0 / 1: the round-2 kernel. SCLENS_HIP_Q2_VARIANT=3 keeps every product of the solver on the fp32 matrix cores.
-  // 8 (default since round 4): pre-built images + LDS-DMA two groups ahead (three LDS buffers, one workgroup per CU); 9: one group
-  // ahead (two buffers, two workgroups per CU)
-  const dim3 q2grid((unsigned)((m + 63) / 64));
-  if (q2_variant >= 8 && q2_variant <= 15) {
-    // 8 / 9: K = 16 matrix instructions, DMA two / one group(s) ahead (three / two LDS buffers); 10 / 11: the K = 32 form, one / two ahead
-    // 14 / 15: the 16 KB image (one copy of the reflectors + T, transposing LDS reads for the third product), one / two ahead
-    const bool three = (q2_variant == 8 || q2_variant == 11 || q2_variant == 12 || q2_variant == 15);  // 12 / 13: loader waves, two / one group(s) ahead
-    const int lds_bytes = (three ? 3 : 2) * (q2_variant >= 14 ? Q_IMG2 : Q_IMG) * (int)sizeof(float);
-    const int q2dbg = getenv("SCLENS_HIP_Q2_DBG") ? atoi(getenv("SCLENS_HIP_Q2_DBG")) : 0;  // 1: no products, 2: no DMA (timing experiments)
-#define SBR_Q2E_LAUNCH(NBUF, K32, LW, TV)                                                                                      \
-  do {                                                                                                                         \
-    SCL_TRY(ensure_dyn_lds(ctx, reinterpret_cast<const void*>(sbr_q2_apply16e<4, 12, NBUF, K32, LW, TV>), lds_bytes));        \
-    hipLaunchKernelGGL((sbr_q2_apply16e<4, 12, NBUF, K32, LW, TV>), q2grid, dim3(LW ? 512 : 256), lds_bytes, ctx->stream, qa, q2img, q2dbg); \
-  } while (0)
-    if (q2_variant == 8) SBR_Q2E_LAUNCH(3, false, false, false);
-    else if (q2_variant == 9) SBR_Q2E_LAUNCH(2, false, false, false);
-    else if (q2_variant == 10) SBR_Q2E_LAUNCH(2, true, false, false);
-    else if (q2_variant == 11) SBR_Q2E_LAUNCH(3, true, false, false);
-    else if (q2_variant == 12) SBR_Q2E_LAUNCH(3, true, true, false);
-    else if (q2_variant == 13) SBR_Q2E_LAUNCH(2, true, true, false);
-    else if (q2_variant == 14) SBR_Q2E_LAUNCH(2, true, false, true);
-    else SBR_Q2E_LAUNCH(3, true, false, true);
-#undef SBR_Q2E_LAUNCH
-  } else if (q2_variant == 0)
-    hipLaunchKernelGGL((sbr_q2_apply16<4, 12, false>), q2grid, dim3(256), 0, ctx->stream, qa);
-  else if (q2_variant == 1)
-    hipLaunchKernelGGL((sbr_q2_apply16<4, 12, true>), q2grid, dim3(256), 0, ctx->stream, qa);
-  else if (q2_variant == 5)
-    hipLaunchKernelGGL((sbr_q2_apply16h<4, 12>), q2grid, dim3(256), 0, ctx->stream, qa);
-  else if (q2_variant == 6)
-    hipLaunchKernelGGL((sbr_q2_apply16d<4, 12, false>), q2grid, dim3(256), 0, ctx->stream, qa);
-  else if (q2_variant == 7)
-    hipLaunchKernelGGL((sbr_q2_apply16d<4, 12, true>), q2grid, dim3(256), 0, ctx->stream, qa);
-  else
-    hipLaunchKernelGGL((sbr_q2_apply16v3<4, 12>), q2grid, dim3(256), 0, ctx->stream, qa);
-  for (int64_t r0 = 0; r0 < m; r0 += 65535) {
-    const int64_t rows = (m - r0 < 65535) ? m - r0 : 65535;
-    hipLaunchKernelGGL(sbr_q2_shift, dim3((unsigned)((n + 255) / 256), (unsigned)rows), dim3(256), 0, ctx->stream, Zq + r0 * ldq, ldq,
-                       (int64_t)3, Zt + r0 * ldz, ldz, (int64_t)0, n);
-  }
-  SCL_HIP(ctx, hipGetLastError());
-  if (qa.prof) {
-    unsigned long long h[8];
-    SCL_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    SCL_HIP(ctx, hipMemcpy(h, qa.prof, sizeof(h), hipMemcpyDeviceToHost));
-    static const char* nm[6] = {"DMA issue", "window loads / stores issue", "products", "counted wait", "barrier", "between groups"};
-    unsigned long long tot = 0;
-    for (int i = 0; i < 6; ++i) tot += h[i];
-    fprintf(stderr, "[sbr_q2 variant %d] n = %lld, m = %lld: %llu groups, %.0f shader clocks per group (wave 0 of one workgroup)\n", q2_variant, (long long)n,
-            (long long)m, h[6], (double)tot / (double)std::max<unsigned long long>(1, h[6]));
-    for (int i = 0; i < 6; ++i)
-      fprintf(stderr, "   %-30s %8.0f clocks (%4.1f %%)\n", nm[i], (double)h[i] / (double)std::max<unsigned long long>(1, h[6]), 100.0 * h[i] / (double)std::max<unsigned long long>(1, tot));
-  }
-  return SCLENS_OK;
-}
-
 
 // ---- the two-stage eigen-solver behind eig_values / eig_vectors (selected by Ctx::two_stage) ----------------------------
 // Orders that are not multiples of SB are embedded in a padded copy: [A 0; 0 diag(sentinel)] with the sentinel above
@@ -3802,6 +2197,9 @@ int eig_values_two_stage(Ctx* ctx, const float* A, int64_t n, int64_t lda, doubl
   SCL_WS(ctx, wp, double, "sbr.w", np);
   SCL_WS(ctx, bound, unsigned, "sbr.bound", 4);
   hipStream_t st = ctx->stream;
+  // group data of the PREVIOUS decomposition may still be in preparation on the auxiliary stream when its vectors were never asked
+  // for: it reads Ap, which the pad copy below overwrites
+  if (ctx->q1p_n >= 0 && ctx->q1_ev) SCL_HIP(ctx, hipStreamWaitEvent(st, ctx->q1_ev, 0));
   SCL_HIP(ctx, hipMemsetAsync(bound, 0, sizeof(unsigned) * 4, st));
   hipLaunchKernelGGL(sbr_row_abs_max, dim3((unsigned)n), dim3(256), 0, st, A, n, lda, bound);
   for (int64_t r0 = 0; r0 < np; r0 += 65535) {

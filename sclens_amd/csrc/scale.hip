@@ -383,8 +383,7 @@ int scale_to_dense(Ctx* ctx, const PatternDev& p, const float* val, int f32path,
   hipStream_t st = ctx->stream;
   const int64_t nr = cells_major ? N : M, nc = cells_major ? M : N;
   if (nr > 65535LL * 65535LL) return ctx->fail(SCLENS_ERR_ARG, "scale_to_dense: too many rows");
-  const char* edf = getenv("SCLENS_HIP_DENSE_FUSED");  // 0: the separate fill + scatter kernels (same values)
-  const bool fused_ok = !(edf && atoi(edf) == 0);
+  const bool fused_ok = ctx->opt.dense_fused != 0;  // 0: the separate fill + scatter kernels (same values)
   if (!cells_major && fused_ok && ldb % 4 == 0 && (reinterpret_cast<uintptr_t>(B) & 15u) == 0) {
     hipLaunchKernelGGL(k_dense_fused, dim3((unsigned)M), dim3(256), 0, st, p, val, lg, stdv, mu, cent, srow, B, ldb);
   } else {

@@ -98,13 +98,12 @@ int reverse_rows_f32(Ctx* ctx, const float* in, int64_t rows, int64_t cols, int6
 int gram_f32(Ctx* ctx, const float* B, int64_t n, int64_t K, int64_t ldb, float divisor, float* A, int64_t lda, bool allow_split) {
   StageTimer tm(ctx, "gram");
   SCL_HIP(ctx, hipMemsetAsync(A, 0, sizeof(float) * (size_t)n * lda, ctx->stream));
-  // Large products (n >= 16 000, or SCLENS_HIP_GRAM_SPLIT=<n>; 0 = never): the scaled matrix is split once into two fp16 pieces per
+  // Large products (n >= 16 000, or context option gram_split_min_n = <n>; 0 = never): the scaled matrix is split once into two fp16 pieces per
   // entry (scaled by the power of two that brings its largest entry to 2^13..2^14: 22 significant bits of every entry down to
   // 2^-38 of the largest) and the product runs on the fp16 matrix cores with fp32 accumulation (gemm_split_update, gram_bits.hip):
   // 682 -> ~250 ms at 100 000 x 30 000. Context option gram_bits = 0 (bench.py's strict step) also keeps this product in fp32.
-  const char* egs = getenv("SCLENS_HIP_GRAM_SPLIT");
-  const int64_t gs_min = egs ? atoll(egs) : 16000;
-  if (gs_min > 0 && n >= gs_min && ctx->gram_bits != 0 && (allow_split || ctx->gram_bits == 1)) {
+  const int gb = ctx->opt.eff_gram_bits();
+  if (n >= ctx->opt.eff_gram_split_min() && gb != 0 && (allow_split || gb == 1)) {
     void* img = ctx->workspace("gram.img", split_image_bytes(n, K));
     float* sc = static_cast<float*>(ctx->workspace("gram.sc", 4 * sizeof(float)));
     if (!img || !sc) return SCLENS_ERR_OOM;
@@ -143,8 +142,8 @@ int pattern_build(Ctx* ctx, int64_t N, int64_t M, const int64_t* colptr, const i
   if (N_global <= 0) N_global = N;
   if (row0 < 0 || row0 + N > N_global) return ctx->fail(SCLENS_ERR_ARG, "pattern_build: bad row range");
   // all cells in this session: the pattern is built on the device (pattern_dev.hip: identical arrays, no host passes);
-  // SCLENS_HIP_HOST_PATTERN=1 keeps the host builder (tests compare the two)
-  if (row0 == 0 && N_global == N && !getenv("SCLENS_HIP_HOST_PATTERN"))
+  // context option host_pattern = 1 keeps the host builder (tests compare the two)
+  if (row0 == 0 && N_global == N && !ctx->opt.host_pattern)
     return pattern_build_device(ctx, N, M, colptr, rowval, nzval, ncand, z1, z2, 0, 0, out);
   HostPattern hp;
   std::string herr;
@@ -542,8 +541,7 @@ int session_clone(Ctx* ctx2, Session* src, Session** out) {
     return ctx2->fail(SCLENS_ERR_STATE, "session_clone: the worker needs a context of its own without a live session");
   Session* s = new Session();
   s->ctx = ctx2;
-  ctx2->two_stage = src->ctx->two_stage;  // the worker decomposes the way its parent does
-  ctx2->gram_bits = src->ctx->gram_bits;
+  ctx2->opt = src->ctx->opt;  // the worker decomposes the way its parent does
   s->N = src->N; s->M = src->M; s->n = src->n; s->K = src->K;
   s->Kdiv = src->Kdiv;
   s->sh = src->sh;  // same cells; the worker gets its own reducer channel through session_set_reducer, and until then has none
@@ -584,17 +582,14 @@ void session_destroy(Session* s) {
 // binary: every value of `val` is 0 or 1 (sparsity search): large problems in the genes-major layout then skip the scaled
 // matrix and form the Gram matrix on the fp16 MFMA (gram_bits.hip); B is only scratch in that case
 static bool use_gram_bits(const Session* s) {
-  if (s->centering || s->cells_major || s->ctx->gram_bits == 0) return false;  // row-sharded sessions: each rank's additive part
-  if (s->ctx->gram_bits == 1) return true;
-  static const int64_t min_n = getenv("SCLENS_HIP_GRAM_BITS_MIN_N") ? atoll(getenv("SCLENS_HIP_GRAM_BITS_MIN_N")) : 16000;
-  return s->n >= min_n;
+  const int gb = s->ctx->opt.eff_gram_bits();
+  if (s->centering || s->cells_major || gb == 0) return false;  // row-sharded sessions: each rank's additive part
+  return gb == 1 || s->n >= s->ctx->opt.gram_bits_min_n;
 }
 // the search statistic from split fp16 images (22-bit operands, fp32 accumulation) under the same switch
 static bool use_f16_corr(const Session* s) {
-  if (s->ctx->gram_bits == 0) return false;
-  if (s->ctx->gram_bits == 1) return true;
-  static const int64_t min_n = getenv("SCLENS_HIP_GRAM_BITS_MIN_N") ? atoll(getenv("SCLENS_HIP_GRAM_BITS_MIN_N")) : 16000;
-  return s->n >= min_n;
+  const int gb = s->ctx->opt.eff_gram_bits();
+  return gb == 1 || (gb < 0 && s->n >= s->ctx->opt.gram_bits_min_n);
 }
 // sum_root >= 0 (row-sharded session): the Gram matrix is summed onto that rank only and formed in `Aout` (default s->A);
 // solve = false: stop after the Gram matrix
@@ -857,8 +852,8 @@ int session_signal_vectors(Session* s, int64_t k, float* nV) {
   const int64_t min_pc = (3 * k + 1) / 2;
   int64_t b0 = round_up(min_pc + 40, 32);  // guard band: the block product streams the matrix once whatever b <= 128 is
   // (a 128-row block was measured at 50 000 x 30 000: 5 instead of 6.25 sweeps per member, but 248 instead of 194 ms -- the
-  // b x b Rayleigh-Ritz problem on the host grows with b^3; SCLENS_HIP_CHEFSI_B0 overrides for experiments)
-  if (const char* e = getenv("SCLENS_HIP_CHEFSI_B0")) b0 = round_up(std::max<int64_t>(min_pc + 8, atoll(e)), 32);
+  // b x b Rayleigh-Ritz problem on the host grows with b^3; context option chefsi_b0 overrides for experiments)
+  if (ctx->opt.chefsi_b0 > 0) b0 = round_up(std::max<int64_t>(min_pc + 8, ctx->opt.chefsi_b0), 32);
   if (b0 > 128 || b0 > s->n / 2) b0 = 0;  // too wide for the small-block solver: ensemble uses the full solver
   const int64_t nv = std::max(k, b0);
   SCL_TRY(s->ensure_zt(nv));
@@ -1071,7 +1066,7 @@ static int perturb_core(Session* s, int64_t t, int64_t min_pc, double* nL_top, i
   // n x n x K Gram product is skipped altogether (0.69 s per member at 100 000 x 30 000); it is formed only if the iteration
   // does not converge and the full solver has to run.
   const bool can_chefsi = s->use_chefsi && s->b0 >= min_pc + 8 && s->Z0t;
-  const int64_t implicit_min_n = getenv("SCLENS_HIP_IMPLICIT_MIN_N") ? atoll(getenv("SCLENS_HIP_IMPLICIT_MIN_N")) : 16000;
+  const int64_t implicit_min_n = ctx->opt.implicit_min_n;
   const bool implicit_op = can_chefsi && !s->sh.on() && s->n >= implicit_min_n;
   if (s->sh.on()) {
     SCL_TRY(scale_to_dense_sharded(ctx, s->pat.dev, s->val, 1, s->Btmp, s->ldb, nullptr, s->sh));

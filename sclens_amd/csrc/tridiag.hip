@@ -545,10 +545,7 @@ static int sytrd_run(Ctx* ctx, const TrdJob* jobs, int nb) {
   const int64_t n = bt.a[0].n, ldv = bt.a[0].ldv;
   const bool prof = ctx->prof_symv && nb == 1;
   int nbB_prev = 0, na_prev = 0;
-  // profiling hook only (PMC passes serialise every dispatch): stop after this many columns; results are then meaningless
-  const char* maxc_env = getenv("SCLENS_HIP_SYTRD_MAXCOLS");
-  const int64_t maxcols = maxc_env ? atoll(maxc_env) : n;
-  for (int64_t p = 0; p < n && p < maxcols; p += NB) {
+  for (int64_t p = 0; p < n; p += NB) {
     const int64_t pe = (p + NB < n) ? p + NB : n;
     for (int b = 0; b < nb; ++b) SCL_HIP(ctx, hipMemsetAsync(bt.a[b].VWt, 0, sizeof(float) * 2 * NB * ldv, ctx->stream));
     for (int64_t j = p; j < pe; ++j) {

@@ -435,8 +435,7 @@ int stebz_f64(Ctx* ctx, const double* d_dev, const double* e_dev, int64_t n, dou
   SCL_WS(ctx, e2, double, "tri.e2", n + 1);
   SCL_WS(ctx, info, double, "tri.info", 8);
   hipLaunchKernelGGL(tri_bounds, dim3(1), dim3(1024), 0, ctx->stream, d_dev, e_dev, n, e2, info);
-  const char* ebd = getenv("SCLENS_HIP_BISECT_DIV");  // 1: the ratio form (round 2), for comparison
-  const bool ratio_form = ebd && atoi(ebd) != 0;
+  const bool ratio_form = ctx->opt.bisect_div != 0;  // 1: the ratio form (round 2), for comparison
   const double* dd = d_dev;
   const double* ee = e2;
   if (!ratio_form) {  // division-free Sturm counts on a copy scaled to norm < 1
@@ -480,14 +479,12 @@ int stein_f64(Ctx* ctx, const double* d_dev, const double* e_dev, int64_t n, con
   SCL_WS(ctx, failc, int, "stein.fail", 4);
   SCL_WS(ctx, invn, double, "stein.invn", B);
   SCL_HIP(ctx, hipMemsetAsync(failc, 0, sizeof(int), ctx->stream));
-  const char* epf = getenv("SCLENS_HIP_STEIN_PF");  // steps of loads in flight: 4 (round 2), 16 (default), 32
-  const int pf = epf ? atoi(epf) : 16;
+  const int pf = (int)ctx->opt.stein_pf;  // steps of loads in flight: 4 (round 2), 16 (default), 32
   // Iterations with sufficient growth (dstein's criterion |x|max >= sqrt(0.1 / n)) before a vector is accepted. dstein runs 1 + EXTRA
   // = 3; here 2: the vectors leave this solver as fp32 and go through fp32 back-transformations, and the fp64 residual after the
   // first such iteration is already at working precision (scripts/stein_its.py: residual and orthogonality of the final vectors
   // are the same to four digits for 1, 2 and 3 at n = 1 000 .. 8 192, planted near-degenerate pairs included). -20 % of the stage.
-  const char* eit = getenv("SCLENS_HIP_STEIN_ITS");
-  const int good_its = eit ? std::max(1, std::min(5, atoi(eit))) : 2;
+  const int good_its = (int)std::max<int64_t>(1, std::min<int64_t>(5, ctx->opt.stein_its));
   for (int64_t t0 = 0; t0 < m; t0 += B) {
     const int64_t cnt = (m - t0 < B) ? m - t0 : B;
     if (pf == 32)
@@ -647,8 +644,8 @@ int eig_values(Ctx* ctx, float* A, int64_t n, int64_t lda, double* w64_dev, int6
   // (0.42 s vs 0.41 s with n/2 vectors; 5.3 s vs 2.0 s at 3 * 10^4), but three concurrent ones (the host's default below
   // n = 16 000) overlap better in the two-stage form: a whole sclens() call at 10 000 x 20 000 takes 4.76 s instead of 6.09 s
   // (scripts/sweep_cfg2_paths.sh), so the two-stage solver is the default from n = 8 192
-  static const int64_t min_n = getenv("SCLENS_HIP_TWO_STAGE_MIN_N") ? atoll(getenv("SCLENS_HIP_TWO_STAGE_MIN_N")) : 8192;
-  if (ctx->two_stage == 1 || (ctx->two_stage < 0 && n >= min_n)) {
+  const int ts = ctx->opt.eff_two_stage();
+  if (ts == 1 || (ts < 0 && n >= ctx->opt.two_stage_min_n)) {
     int used = 0;
     SCL_TRY(eig_values_two_stage(ctx, A, n, lda, w64_dev, &used, n_low));
     if (used) {

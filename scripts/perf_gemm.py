@@ -25,10 +25,7 @@ for n, K in zip(args[0::2], args[1::2]):
     res = {}
     for rnd in range(3):
         for small in ("1", ""):
-            if small:
-                os.environ["SCLENS_HIP_GEMM_SMALL"] = "1"
-            else:
-                os.environ.pop("SCLENS_HIP_GEMM_SMALL", None)
+            ctx.set_option("gemm_force", 2 if small else 0)
             ctx.sync()
             t0 = time.perf_counter()
             ctx.check(ctx.lib.sclens_hip_dev_gram_f32(ctx.h, dB.p, n, K, ldb, float(K), dA.p, lda))

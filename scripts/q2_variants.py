@@ -37,11 +37,9 @@ else:
 outs = {}
 ctx.set_timing(True)
 for v in variants:
-    if v == "ref":
-        os.environ["SCLENS_HIP_Q2_REFERENCE"] = "1"
-    else:
-        os.environ.pop("SCLENS_HIP_Q2_REFERENCE", None)
-        os.environ["SCLENS_HIP_Q2_VARIANT"] = v
+    ctx.set_option("q2_reference", 1 if v == "ref" else 0)
+    if v != "ref":
+        ctx.set_option("q2_variant", int(v))
     for rep in range(2):
         dZ = DevArray(ctx, Z0)
         ctx.reset_timing()

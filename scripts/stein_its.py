@@ -1,4 +1,4 @@
-"""fp64 quality of the inverse-iteration vectors for SCLENS_HIP_STEIN_ITS = 3 (dstein's 1 + EXTRA) against 2: residual
+"""fp64 quality of the inverse-iteration vectors for the context option stein_its = 3 (dstein's 1 + EXTRA) against 2: residual
 |T z - lambda z| and orthogonality of the tridiagonal eigenvectors BEFORE any fp32 back-transformation is not observable through
 the C ABI (vectors leave the solver as fp32), so: eigenvectors of a symmetric matrix through the whole solver, residual and
 orthogonality in float64 on the host. Usage: stein_its.py n"""
@@ -22,7 +22,7 @@ A = ((A + A.T) / 2).astype(np.float32)
 lda = rup(n, 32)
 Ap = np.zeros((n, lda), np.float32); Ap[:, :n] = A
 for its in ("3", "2", "1"):
-    os.environ["SCLENS_HIP_STEIN_ITS"] = its
+    ctx.set_option("stein_its", int(its))
     dA = DevArray(ctx, Ap); dw = DevArray(ctx, nbytes=8 * n); dZ = DevArray(ctx, nbytes=4 * n * lda)
     ctx.set_timing(True); ctx.reset_timing()
     ctx.check(ctx.lib.sclens_hip_dev_eigh_f32(ctx.h, dA.p, n, lda, dw.p, 0, n, dZ.p, lda))

@@ -61,3 +61,32 @@ def ctx():
     c = Context(0)
     yield c
     c.close()
+
+
+class _Options:
+    """context options for the duration of one test: `opt(sy2sb_split_min=512)`; everything is restored at teardown"""
+
+    def __init__(self, ctx):
+        self.ctx, self.saved = ctx, {}
+
+    def __call__(self, **kw):
+        for k, v in kw.items():
+            self.saved.setdefault(k, self.ctx.get_option(k))
+            self.ctx.set_option(k, int(v))
+
+    def reset(self, *names):
+        for k in names:
+            if k in self.saved:
+                self.ctx.set_option(k, self.saved[k])
+
+    def restore(self):
+        for k, v in self.saved.items():
+            self.ctx.set_option(k, v)
+        self.saved.clear()
+
+
+@pytest.fixture
+def opt(ctx):
+    o = _Options(ctx)
+    yield o
+    o.restore()

@@ -31,7 +31,11 @@ class FakeContext:
             FakeContext.live += 1
 
     def trim_pool(self):
-        pass
+        FakeContext.trims = getattr(FakeContext, "trims", 0) + 1
+
+    def copy_options_from(self, other):  # worker contexts inherit the caller's options (sclens_hip_copy_options)
+        self.options_from = other
+        return self
 
     def malloc(self, nbytes):
         with FakeContext._lock:

@@ -8,8 +8,8 @@ product of the data matrix) must give the same decisions. Both runs go through t
 Two reference points: `default` -- the plain path with the eigensolver as built (its large products run from split fp16
 operands on both sides; their accuracy is pinned against float64 in test_gpu_sbr.py / test_gpu_kernels.py); the last full GPU
 run of round 3 passed this combination with the data matrix's Gram product in fp32 on both sides -- since then the accelerated
-side forms it from split fp16 operands, which is why its eigenvalues are compared to 2e-5 instead of bitwise. `strict` -- additionally no fp16 operand anywhere in the plain run (what
-bench.py's extra.strict_fp32 step runs; first run on hardware in round 4: profiles/r04_bench_size_parity.log, max |d5 diff| 9.4e-4,
+side forms it from split fp16 operands, which is why its eigenvalues are compared to 2e-5 instead of bitwise. `strict` -- the context option precision = 0: no fp16 operand anywhere in the plain run (what
+bench.py's strict steps run; first run on hardware in round 4: profiles/r04_bench_size_parity.log, max |d5 diff| 9.4e-4,
 `b_` 4.7e-5, `a_b` equal). What the test does NOT claim: at 100 000 x 30 000 the statistic can sit within 5e-5 of p_th (seed 1019,
 evaluation 13: profiles/r04_seed1019_decisions.log), closer than any two fp32 evaluation orders agree, and the search then ends one
 evaluation earlier or later -- DESIGN.md section 2 and scripts/check_search_step_f64.py (the float64 arbiter)."""
@@ -25,28 +25,22 @@ from sclens_amd.synth import synth_counts
 pytestmark = pytest.mark.gpu
 
 
-STRICT_ENV = {"SCLENS_HIP_GRAM_SPLIT": "0", "SCLENS_HIP_SY2SB_SPLIT": "0", "SCLENS_HIP_Q1_SPLIT": "0", "SCLENS_HIP_Q2_VARIANT": "3"}
-
-
 @pytest.mark.parametrize("plain_solver", ["default", "strict"])
-def test_accelerated_path_equals_plain_path_at_order_30000(ctx, monkeypatch, plain_solver):
+def test_accelerated_path_equals_plain_path_at_order_30000(ctx, plain_solver):
     N, M = 40000, 30000
     X = api._csc_f32(synth_counts(N, M, seed=20240427 + 7, C=8))
     kw = dict(n_perturb=2, max_search_iters=5, streams=1)  # five iterations: the smallest cap that leaves p_ < 1 (:756-760)
     fast = api.sclens(X, draws=api.make_draws_native(X, seed=77, device_candidates=True), ctx=ctx, **kw)
     # the plain path: fp32 Gram products and fp32 search statistic (context option gram_bits = 0), full solver for the members;
     # "strict": fp32 products in the band reduction and both back-transformations as well -- no fp16 operand anywhere
-    if plain_solver == "strict":
-        for key, val in STRICT_ENV.items():
-            monkeypatch.setenv(key, val)
     c2 = Context(ctx.device)
     c2.set_option("gram_bits", 0)
+    if plain_solver == "strict":
+        c2.set_option("precision", 0)  # worker contexts of the call inherit it
     try:
         plain = api.sclens(X, draws=api.make_draws_native(X, seed=77, device_candidates=True), ctx=c2, partial_eig=False, **kw)
     finally:
         c2.close()
-        for key in STRICT_ENV:
-            monkeypatch.delenv(key, raising=False)
     # what ran: fp16-MFMA Gram for the binarised matrix and the five search steps / none; subspace iteration for both members / none
     assert fast["gram_bits_used"] == fast["n_search"] + 1 and plain["gram_bits_used"] == 0
     assert fast["partial_eig"] == (2, 0) and plain["partial_eig"][0] == 0
@@ -79,3 +73,42 @@ def test_accelerated_path_equals_plain_path_at_order_30000(ctx, monkeypatch, pla
         la, lb = np.asarray(fast["nL_set"][t]), np.asarray(plain["nL_set"][t])
         assert la.shape == lb.shape == (fast["min_pc"],)
         assert np.abs(la - lb).max() <= 3e-4 * lb.max(), (t, np.abs(la - lb).max() / lb.max())
+
+
+GOLDEN_SPECTRA = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "cfg4_f64_spectra.npz")
+
+
+@pytest.mark.parametrize("precision", [1, 0])
+def test_spectrum_of_the_shipped_arithmetic_against_float64(ctx, precision):
+    """cfg4 (100 000 x 30 000, the bench's matrix and the draws of its first timed step): eigenvalues of the data and null Wishart
+    matrices, lambda_c and the retained-signal count of the device path -- with the split-fp16 products (precision = 1, what bench.py
+    times) and with every product on the fp32 matrix cores (precision = 0) -- against LAPACK dsyevd on the float64 Gram matrices of the
+    float64-scaled matrices (the oracle's arithmetic; fixture + generator: tests/golden/cfg4_f64_spectra.npz, scripts/f64_spectra.py).
+    north_star: "retained-signal count and eigenvalue ordering identical"; eigenvalues to a few sqrt(n) eps32 lambda_max."""
+    if not os.path.exists(GOLDEN_SPECTRA):
+        pytest.skip("tests/golden/cfg4_f64_spectra.npz not generated yet (scripts/f64_spectra.py cfg4: ~1.5 h of host LAPACK)")
+    z = np.load(GOLDEN_SPECTRA)
+    N, M = int(z["N"]), int(z["M"])
+    X = api._csc_f32(synth_counts(N, M, seed=int(z["synth_seed"])))
+    assert int(X.nnz) == int(z["nnz"])  # the same matrix the fixture was computed from
+    c2 = Context(ctx.device)
+    c2.set_option("precision", precision)
+    try:
+        res = api.sclens(X, draws=api.make_draws_native(X, seed=int(z["draw_seed"]), device_candidates=True), ctx=c2, n_perturb=2,
+                         max_search_iters=2, streams=1, keep_intermediates=True)
+    finally:
+        c2.close()
+    L64, lmax = z["L"], float(z["L"][-1])
+    tol = 4.0 * np.sqrt(M) * 5.96e-8 * lmax  # 4 sqrt(n) eps32 lambda_max = 4e-5 lambda_max; measured ~6e-7 (profiles/r02_signal_count_cfg4.json)
+    err = float(np.abs(res["L"] - L64).max())
+    print(f"[cfg4 spectrum, precision {precision}] max |L - L64| / lambda_max = {err / lmax:.2e}; lambda_c {res['lambda_c']:.9f} vs {float(z['lambda_c']):.9f}; "
+          f"k {len(res['signal_ev'])} vs {int(z['k'])}")
+    assert err < tol, err / lmax
+    assert np.all(np.diff(res["L"]) >= 0)  # ascending, as the reference's _get_eigen returns them
+    assert abs(res["lambda_c"] - float(z["lambda_c"])) < 2e-5 * float(z["lambda_c"])
+    assert len(res["signal_ev"]) == int(z["k"])
+    # the signals themselves (descending): same ordering, same values to the tolerance
+    sig64 = L64[L64 > float(z["lambda_c"])][::-1]
+    assert np.abs(np.asarray(res["signal_ev"]) - sig64).max() < tol
+    if "Lr" in res:
+        assert np.abs(np.asarray(res["Lr"]) - z["Lr"]).max() < tol

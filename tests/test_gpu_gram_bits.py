@@ -30,11 +30,8 @@ def test_gram_bits_matches_oracle_and_fp32_path(ctx, N, M, terms):
     Xb = _binarised(N, M, seed=N + M)
     S = np.asarray(O.logn_scale(O.pre_scale(Xb)), dtype=np.float64)  # N x M, the closure path of scLENS.jl:650-652
     want = S.T @ S / N
-    os.environ["SCLENS_HIP_GRAM_BITS_TERMS"] = str(terms)
-    try:
+    with ctx.options(gram_bits_terms=terms):
         got = api._gram_binary(Xb, use_bits=True, ctx=ctx)
-    finally:
-        del os.environ["SCLENS_HIP_GRAM_BITS_TERMS"]
     dense = api._gram_binary(Xb, use_bits=False, ctx=ctx)
     scale = np.abs(want).max()
     e_bits, e_dense = np.abs(got - want).max() / scale, np.abs(dense - want).max() / scale

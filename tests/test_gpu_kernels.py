@@ -27,8 +27,8 @@ def _gemm(ctx, P, Q, C0, alpha, beta, q_kcontig, lower=0, absmax=False):
 
 @pytest.mark.parametrize("M,N,K", [(128, 128, 16), (130, 257, 33), (64, 300, 1000), (1000, 77, 515), (5, 5, 3),
                                    (300, 520, 1000), (512, 256, 64), (700, 161, 37), (161, 769, 4100), (700, 64, 515), (300, 40, 96)])
-def test_gemm_nt_nn(ctx, M, N, K, monkeypatch):
-    monkeypatch.setenv("SCLENS_HIP_GEMM_BIG", "1")  # NT shapes that fit go through the 256x256 kernel as well
+def test_gemm_nt_nn(ctx, M, N, K, opt):
+    opt(gemm_force=1)  # NT shapes that fit go through the 256x256 kernel as well
     rng = np.random.default_rng(M * 7 + N)
     P = rng.standard_normal((M, K)).astype(np.float32)
     Qn = rng.standard_normal((N, K)).astype(np.float32)
@@ -55,9 +55,9 @@ def test_gemm_asymmetric_identity(ctx):
 
 @pytest.mark.parametrize("big", [0, 1])
 @pytest.mark.parametrize("n,K", [(200, 64), (333, 257), (1300, 100), (520, 16)])
-def test_gemm_lower_mirror_and_absmax(ctx, n, K, big, monkeypatch):
+def test_gemm_lower_mirror_and_absmax(ctx, n, K, big, opt):
     if big:
-        monkeypatch.setenv("SCLENS_HIP_GEMM_BIG", "1")
+        opt(gemm_force=1)
     rng = np.random.default_rng(n)
     P = rng.standard_normal((n, K)).astype(np.float32)
     Q = rng.standard_normal((n, K)).astype(np.float32)
@@ -106,8 +106,8 @@ def test_sytrd_stebz_eigenvalues(ctx, n):
 
 
 @pytest.mark.parametrize("n,K", [(300, 1000), (1030, 4100), (515, 257)])
-def test_gram_on_split_fp16_operands_matches_float64(ctx, n, K, monkeypatch):
-    """sclens_hip_dev_gram_f32 from the split image of the operand (SCLENS_HIP_GRAM_SPLIT: every entry as two fp16 pieces after a
+def test_gram_on_split_fp16_operands_matches_float64(ctx, n, K, opt):
+    """sclens_hip_dev_gram_f32 from the split image of the operand (context option gram_split_min_n: every entry as two fp16 pieces after a
     power-of-two scaling, three fp16 matrix instructions per product, fp32 accumulation) on a matrix shaped like a scaled count
     matrix -- a small negative background, a few per cent of entries up to ~80 -- against the float64 product; the fp32 path on the
     same input for comparison. Exactly symmetric either way."""
@@ -121,7 +121,7 @@ def test_gram_on_split_fp16_operands_matches_float64(ctx, n, K, monkeypatch):
     ref = B.astype(np.float64) @ B.astype(np.float64).T / K
     err = {}
     for mode in ("64", "0"):
-        monkeypatch.setenv("SCLENS_HIP_GRAM_SPLIT", mode)
+        opt(gram_split_min_n=int(mode))
         Bp = np.zeros((n, ldb), np.float32)
         Bp[:, :K] = B
         dB, dA = DevArray(ctx, Bp), DevArray(ctx, nbytes=4 * n * lda)
@@ -158,14 +158,14 @@ def _tridiag_cases():
 
 @pytest.mark.parametrize("name", list(_tridiag_cases()))
 @pytest.mark.parametrize("form", ["product", "ratio"])
-def test_stebz_tridiagonal_cases(ctx, name, form, monkeypatch):
+def test_stebz_tridiagonal_cases(ctx, name, form, opt):
     """sclens_hip_dev_stebz_f64 on given tridiagonal matrices: the division-free Sturm count (three-term recurrence of the leading
     minors on a copy scaled by a power of two, rescaled every eight steps, exact zeros replaced) and the ratio form
-    (SCLENS_HIP_BISECT_DIV=1) against LAPACK, to a few ulps of the norm."""
+    (context option bisect_div = 1) against LAPACK, to a few ulps of the norm."""
     d, e = _tridiag_cases()[name]
     n = len(d)
     if form == "ratio":
-        monkeypatch.setenv("SCLENS_HIP_BISECT_DIV", "1")
+        opt(bisect_div=1)
     dd, de, dw = DevArray(ctx, np.ascontiguousarray(d)), DevArray(ctx, np.concatenate([e, [0.0]])), DevArray(ctx, nbytes=8 * n)
     ctx.check(ctx.lib.sclens_hip_dev_stebz_f64(ctx.h, dd.p, de.p, n, dw.p))
     ctx.sync()

@@ -58,7 +58,7 @@ def test_guard_band_is_applied_before_the_cut(ctx):
 
 
 @pytest.mark.parametrize("n_perturb,cap", [(2, 4), pytest.param(6, None, marks=pytest.mark.slow)])
-def test_parity_order_6000_cells_gt_genes_two_stage(ctx, monkeypatch, n_perturb, cap):
+def test_parity_order_6000_cells_gt_genes_two_stage(ctx, n_perturb, cap):
     """cfg3-shaped (cells > genes: the gene-side Gram matrix X'X, recovered cell-side vectors) at order n = 6 000 through the
     large-problem path -- two-stage eigensolver (dense -> band -> tridiagonal), Gram matrices of the binarised search matrices
     and the search statistic on the fp16 MFMA (gram_bits.hip) -- against the float64 oracle on the same draws.
@@ -74,8 +74,8 @@ def test_parity_order_6000_cells_gt_genes_two_stage(ctx, monkeypatch, n_perturb,
     d = api.make_draws_native(X, seed=11, host_sampler=True)
     od = O.Draws(d.z_idx1, d.z_idx2, d.X_r, d.p_th, d.sampler)
     ref = O.sclens(X, od, n_perturb=n_perturb, max_search_iters=cap, null_tol=O.NULL_DROP)
-    monkeypatch.setenv("SCLENS_HIP_TWO_STAGE", "1")
     c2 = Context(ctx.device)
+    c2.set_option("two_stage", 1)
     c2.set_option("gram_bits", 1)
     try:
         res = api.sclens(X, draws=api.make_draws_native(X, seed=11), n_perturb=n_perturb, max_search_iters=cap, ctx=c2, streams=1)

@@ -34,15 +34,15 @@ def _host_candidates(X, seed):
 
 
 @pytest.mark.parametrize("N,M", [(300, 500), (900, 260), (64, 70)])
-def test_device_pattern_equals_host_pattern(ctx, N, M, monkeypatch):
+def test_device_pattern_equals_host_pattern(ctx, N, M, opt):
     X = api._csc_f32(synth_counts(N, M, seed=N + M, C=4, marker_frac=0.2))
     z1, z2 = _host_candidates(X, 77)
     assert len(z1) > 0 and len(set(zip(z1.tolist(), z2.tolist()))) == len(z1)  # distinct pairs, none a stored entry
     dense = X.toarray()
     assert not np.any(dense[z1, z2] != 0)
-    monkeypatch.setenv("SCLENS_HIP_HOST_PATTERN", "1")
+    opt(host_pattern=1)
     ph = api.Pattern(ctx, X, z1, z2)
-    monkeypatch.delenv("SCLENS_HIP_HOST_PATTERN")
+    opt(host_pattern=0)
     pd_ = api.Pattern(ctx, X, z1, z2)       # device build from the same host list
     pr = api.Pattern.drawn(ctx, X, 77)       # device build with the list drawn on the device
     try:
@@ -54,9 +54,9 @@ def test_device_pattern_equals_host_pattern(ctx, N, M, monkeypatch):
             assert np.array_equal(a, b), f"array {w}: device build differs from the host build"
             assert np.array_equal(a, c), f"array {w}: device-drawn build differs from the host build"
         # counts-only pattern (what session_create and the null matrix use)
-        monkeypatch.setenv("SCLENS_HIP_HOST_PATTERN", "1")
+        opt(host_pattern=1)
         p0h = api.Pattern(ctx, X, np.zeros(0, np.uint32), np.zeros(0, np.uint32))
-        monkeypatch.delenv("SCLENS_HIP_HOST_PATTERN")
+        opt(host_pattern=0)
         p0d = api.Pattern(ctx, X, np.zeros(0, np.uint32), np.zeros(0, np.uint32))
         for a, b in zip(_arrays(p0h, X), _arrays(p0d, X)):
             assert np.array_equal(a, b)

@@ -43,15 +43,15 @@ def _band_of(out):
 
 
 @pytest.fixture(params=["default", "delayed", "split", "delayed+split"])
-def delayed_update(request, monkeypatch):
+def delayed_update(request, opt):
     """sy2sb applies the trailing updates of two panels as one rank-256 update while the trailing matrix is large (from order
     18 432 by default), and runs trailing updates of at least 4 096 rows on the fp16 matrix cores from split operands; "delayed"
     turns the first on from order 321, "split" the second from 512 rows, so that the small cases here go through them."""
     if "delayed" in request.param:
-        monkeypatch.setenv("SCLENS_HIP_SY2SB_DELAY_MIN", "321")
-    monkeypatch.setenv("SCLENS_HIP_SY2SB_SPLIT", "512" if "split" in request.param else "0")
-    monkeypatch.setenv("SCLENS_HIP_SY2SB_WSPLIT", "128" if "split" in request.param else "0")  # W = A22 V from fp16 pieces
-    monkeypatch.setenv("SCLENS_HIP_Q1_SPLIT", "32" if "split" in request.param else "0")  # first back-transformation likewise
+        opt(sy2sb_delay_min=321)
+    on = "split" in request.param
+    # trailing updates, W = A22 V and the first back-transformation from fp16 pieces, or all of them on the fp32 matrix cores
+    opt(sy2sb_split_min=512 if on else 0, sy2sb_wsplit_min=128 if on else 0, q1_split_min=32 if on else 0)
     return request.param
 
 
@@ -67,20 +67,19 @@ def test_sy2sb_band_has_the_same_spectrum(ctx, n, delayed_update):
 
 
 @pytest.mark.parametrize("log2_norm", [0, 14, 20])
-def test_sy2sb_split_update_with_separate_scales(ctx, log2_norm, monkeypatch):
+def test_sy2sb_split_update_with_separate_scales(ctx, log2_norm, opt):
     """a matrix of large norm: the reflector columns of the split update's operands get their own scale, so the band keeps the
     spectrum to the fp32 path's tolerance at every norm (the shared scale does inside its range: DESIGN.md section 4)"""
     n = 2048
     A = (_sym_psd(n, 3) * np.float32(2.0 ** log2_norm)).astype(np.float32)
     ref = np.linalg.eigvalsh(A.astype(np.float64))
-    monkeypatch.setenv("SCLENS_HIP_SY2SB_DELAY_MIN", "321")
-    monkeypatch.setenv("SCLENS_HIP_SY2SB_SPLIT", "512")
+    opt(sy2sb_delay_min=321, sy2sb_split_min=512)
     err = {}
     for scales in ("2", "1", "2-pass"):
-        monkeypatch.setenv("SCLENS_HIP_SY2SB_SPLIT_SCALES", scales[0])
+        opt(sy2sb_split_scales=int(scales[0]))
         # "2": the Z columns' largest entry comes from the kernel that writes Z and the V columns take the fixed scale 2^13 (default);
         # "2-pass": both maxima by a pass over the operands (until the end of round 4)
-        monkeypatch.setenv("SCLENS_HIP_SY2SB_ZMAX", "0" if scales == "2-pass" else "1")
+        opt(sy2sb_zmax=0 if scales == "2-pass" else 1)
         out, T, bd = _run_sy2sb(ctx, A)
         assert bd == 0
         err[scales] = np.abs(np.linalg.eigvalsh(_band_of(out)) - ref).max() / ref.max()
@@ -90,17 +89,16 @@ def test_sy2sb_split_update_with_separate_scales(ctx, log2_norm, monkeypatch):
 
 
 @pytest.mark.parametrize("n", [1024, 2368])
-def test_sy2sb_split_update_started_from_c(ctx, n, monkeypatch):
+def test_sy2sb_split_update_started_from_c(ctx, n, opt):
     """the split-fp16 trailing update with its accumulators started from C / alpha (all of the C tile requested up front through
-    unpredicated buffer loads; default) against C added in the epilogue (SCLENS_HIP_SPLIT_ACC_INIT=0): partial edge tiles, diagonal
+    unpredicated buffer loads; default) against C added in the epilogue (context option split_acc_init = 0): partial edge tiles, diagonal
     tiles, rank-128 and rank-256 (delayed) updates; both keep the spectrum to the fp32 path's tolerance"""
     A = _sym_psd(n, 11)
     ref = np.linalg.eigvalsh(A.astype(np.float64))
-    monkeypatch.setenv("SCLENS_HIP_SY2SB_DELAY_MIN", "321")
-    monkeypatch.setenv("SCLENS_HIP_SY2SB_SPLIT", "512")
+    opt(sy2sb_delay_min=321, sy2sb_split_min=512)
     err, band = {}, {}
     for mode in ("1", "0"):
-        monkeypatch.setenv("SCLENS_HIP_SPLIT_ACC_INIT", mode)
+        opt(split_acc_init=int(mode))
         out, T, bd = _run_sy2sb(ctx, A)
         assert bd == 0
         band[mode] = _band_of(out)
@@ -111,7 +109,7 @@ def test_sy2sb_split_update_started_from_c(ctx, n, monkeypatch):
 
 @pytest.mark.parametrize("shape", ["gram", "dominant", "graded"])
 @pytest.mark.parametrize("log2_norm", [-20, 0, 14, 20])
-def test_sy2sb_w_product_from_fp16_pieces(ctx, log2_norm, shape, monkeypatch):
+def test_sy2sb_w_product_from_fp16_pieces(ctx, log2_norm, shape, opt):
     """W = A22 V with the trailing matrix split into fp16 pieces in registers (sbr_w_split; scale from the largest absolute row sum,
     which bounds every entry of every trailing matrix): the band keeps the spectrum to the tolerance of the fp32 product, whatever
     the norm, with one dominant eigenvalue (entries of the trailing matrices far above those of A) and with graded rows"""
@@ -125,10 +123,10 @@ def test_sy2sb_w_product_from_fp16_pieces(ctx, log2_norm, shape, monkeypatch):
         A = A * d[:, None] * d[None, :]
     A = (A * 2.0 ** log2_norm).astype(np.float32)
     ref = np.linalg.eigvalsh(A.astype(np.float64))
-    monkeypatch.setenv("SCLENS_HIP_SY2SB_SPLIT", "0")  # trailing updates on the fp32 matrix cores: the W product is what differs
+    opt(sy2sb_split_min=0)  # trailing updates on the fp32 matrix cores: the W product is what differs
     err = {}
     for w in ("128", "0"):
-        monkeypatch.setenv("SCLENS_HIP_SY2SB_WSPLIT", w)
+        opt(sy2sb_wsplit_min=int(w))
         out, T, bd = _run_sy2sb(ctx, A)
         assert bd == 0
         err[w] = np.abs(np.linalg.eigvalsh(_band_of(out)) - ref).max() / np.abs(ref).max()
@@ -191,7 +189,7 @@ def test_two_stage_tridiagonal_has_the_same_spectrum(ctx, n):
 
 
 @pytest.mark.parametrize("n", [128, 192, 576, 2048, 4160])
-def test_bulge_chase_kernels_agree_bitwise(ctx, n, monkeypatch):
+def test_bulge_chase_kernels_agree_bitwise(ctx, n, opt):
     """sbr_chase_mb (row hand-off between sweeps by tagged messages, blocks prefetched one task ahead) does the arithmetic of
     sbr_chase (counter + loads per task) in the same order: the tridiagonal matrix and the stored reflectors (seen through the
     second back-transformation of a random block) have the same bits."""
@@ -203,7 +201,7 @@ def test_bulge_chase_kernels_agree_bitwise(ctx, n, monkeypatch):
     Z0[:, :n] = rng.standard_normal((m, n)).astype(np.float32)
     got = {}
     for mb in ("0", "1"):
-        monkeypatch.setenv("SCLENS_HIP_CHASE_MB", mb)
+        opt(chase_mb=int(mb))
         dA = DevArray(ctx, pad_rows(A, lda))
         dT = DevArray(ctx, nbytes=4 * max(1, n // SB - 1) * SB * SB)
         dd, de = DevArray(ctx, nbytes=8 * n), DevArray(ctx, nbytes=8 * n)
@@ -315,9 +313,9 @@ def test_two_stage_solver_behind_eigh(ctx, n, lo, hi):
 
 
 @pytest.mark.parametrize("n,lo,hi", [(700, 0, 350), (2112, 2000, 2112)])
-def test_switches_that_only_move_work_give_the_same_bits(ctx, n, lo, hi, monkeypatch):
+def test_switches_that_only_move_work_give_the_same_bits(ctx, n, lo, hi):
     """The T factors of the second back-transformation built on the auxiliary stream behind the bisection (default) or in front of
-    the apply kernel (SCLENS_HIP_Q2_TG_EARLY=0), and the inverse iteration with 4 / 16 / 32 steps of loads in flight: the same
+    the apply kernel (context option q2_tg_early = 0), and the inverse iteration with 4 / 16 / 32 steps of loads in flight: the same
     arithmetic on the same data, so eigenvalues and eigenvectors have the same bits."""
     from sclens_amd._lib import Context
 
@@ -325,13 +323,11 @@ def test_switches_that_only_move_work_give_the_same_bits(ctx, n, lo, hi, monkeyp
     lda = rup(n, 32)
     m = hi - lo
     got = []
-    for env in ({}, {"SCLENS_HIP_Q2_TG_EARLY": "0"}, {"SCLENS_HIP_STEIN_PF": "4"}, {"SCLENS_HIP_STEIN_PF": "32"}):
-        for key in ("SCLENS_HIP_Q2_TG_EARLY", "SCLENS_HIP_STEIN_PF"):
-            monkeypatch.delenv(key, raising=False)
-        for key, val in env.items():
-            monkeypatch.setenv(key, val)
+    for options in ({}, {"q2_tg_early": 0}, {"stein_pf": 4}, {"stein_pf": 32}):
         c2 = Context(ctx.device)
         c2.set_option("two_stage", 1)
+        for key, val in options.items():
+            c2.set_option(key, val)
         try:
             dA, dw, dZ = DevArray(c2, pad_rows(A, lda)), DevArray(c2, nbytes=8 * n), DevArray(c2, nbytes=4 * m * lda)
             for _ in range(2):  # twice on one context: the second call finds the first call's T factors and must not use them
@@ -350,10 +346,10 @@ def test_switches_that_only_move_work_give_the_same_bits(ctx, n, lo, hi, monkeyp
     assert np.abs(Z @ A64 - got[0][0][lo:hi, None] * Z).max() < 5e-5 * np.abs(got[0][0]).max() * np.sqrt(n / 64 + 1)
 
 
-def test_first_back_transformation_group_data_prepared_ahead_gives_the_same_bits(ctx, monkeypatch):
+def test_first_back_transformation_group_data_prepared_ahead_gives_the_same_bits(ctx):
     """Round 4: the block reflectors of the first back-transformation (clean reflector blocks, merged T factors, split images) are
     built for all groups on the auxiliary stream right after the band reduction (sbr_q1_prepare) instead of group by group inside
-    the apply loop (SCLENS_HIP_Q1_PREP=0): the same kernels on the same data -- the same bits. Order 4 288 = 66 panels (groups of
+    the apply loop (context option q1_prep = 0): the same kernels on the same data -- the same bits. Order 4 288 = 66 panels (groups of
     8 from 64 panels), 2 112 vectors (from 2 048), the split products forced on as at the bench's order."""
     from sclens_amd._lib import Context
 
@@ -363,10 +359,10 @@ def test_first_back_transformation_group_data_prepared_ahead_gives_the_same_bits
     m = hi - lo
     got = []
     for prep, w1 in (("1", "1"), ("0", "1"), ("1", "0"), ("1", "2")):
-        monkeypatch.setenv("SCLENS_HIP_Q1_PREP", prep)
-        monkeypatch.setenv("SCLENS_HIP_Q1_W1_SPLIT", w1)  # "0": the first product of every group on the fp32 matrix cores (round 3)
         c2 = Context(ctx.device)
         c2.set_option("two_stage", 1)
+        c2.set_option("q1_prep", int(prep))
+        c2.set_option("q1_w1_split", int(w1))  # 0: the first product of every group on the fp32 matrix cores (round 3)
         try:
             dA, dw, dZ = DevArray(c2, pad_rows(A, lda)), DevArray(c2, nbytes=8 * n), DevArray(c2, nbytes=4 * m * lda)
             for _ in range(2):  # twice: the second decomposition must not pick up the first one's group data
@@ -393,9 +389,9 @@ def test_first_back_transformation_group_data_prepared_ahead_gives_the_same_bits
     assert d < 5e-6
 
 
-@pytest.mark.parametrize("variant", ["14", "15", "10", "11", "12", "13", "8", "9", "7", "3"])
+@pytest.mark.parametrize("variant", [14, 15, 3])
 @pytest.mark.parametrize("n,m", [(192, 192), (1088, 100), (2560, 70), (640, 641 - 1)])
-def test_second_back_transformation_matches_the_unblocked_reference(ctx, n, m, variant, monkeypatch):
+def test_second_back_transformation_matches_the_unblocked_reference(ctx, n, m, variant, opt):
     """The register-resident MFMA version of Q2 (16-vector wave tiles, QJ sweep blocks per pass) against the one-reflector-at-
     a-time reference kernel on the same reflectors: vector counts that are not multiples of 16 / 64, several super-blocks."""
     A = _sym_psd(n, 13 * n + 5)
@@ -410,14 +406,11 @@ def test_second_back_transformation_matches_the_unblocked_reference(ctx, n, m, v
     Z0 = np.zeros((m, lda), dtype=np.float32)
     Z0[:, :n] = rng.standard_normal((m, n)) / np.sqrt(n)
     outs = []
-    # 8 (default): pre-built group images moved by LDS-DMA, T folded into the second operand; 9: the same one group ahead;
-    # 7: split-fp16 products staged by every workgroup (round 3); 3: fp32 products
-    monkeypatch.setenv("SCLENS_HIP_Q2_VARIANT", variant)
+    # 15 (default) / 14: pre-built 16 KB group images moved by LDS-DMA, two / one group(s) ahead, split-fp16 products;
+    # 3: fp32 products, reflectors staged by every workgroup (what `precision = 0` selects)
+    opt(q2_variant=variant)
     for ref in (True, False):
-        if ref:
-            monkeypatch.setenv("SCLENS_HIP_Q2_REFERENCE", "1")
-        else:
-            monkeypatch.delenv("SCLENS_HIP_Q2_REFERENCE", raising=False)
+        opt(q2_reference=1 if ref else 0)
         dZ = DevArray(ctx, Z0)
         ctx.check(ctx.lib.sclens_hip_dev_sbr_apply_q2_f32(ctx.h, n, dZ.p, m, lda))
         ctx.sync()
@@ -430,10 +423,10 @@ def test_second_back_transformation_matches_the_unblocked_reference(ctx, n, m, v
     assert np.abs(np.linalg.norm(outs[1], axis=1) - np.linalg.norm(Z0[:, :n].astype(np.float64), axis=1)).max() < 1e-4
 
 
-def test_second_back_transformation_variants(ctx, monkeypatch):
-    """Variants that differ only in WHEN the reflectors are fetched give the same bits (6 = 3: fp32 products; 5 = 7: split-fp16
-    products); the split-fp16 products (three fp16 matrix instructions with fp32 accumulation per product, 22-bit operands) stay
-    within 4e-6 of the fp32 ones on unit vectors and keep orthonormal rows orthonormal to 2e-6."""
+def test_second_back_transformation_variants(ctx, opt):
+    """Variants that differ only in WHEN the group images are fetched give the same bits (14: one group ahead, 15: two); the split-fp16
+    products (three fp16 matrix instructions with fp32 accumulation per product, 22-bit operands) stay within 4e-6 of the fp32 ones
+    (variant 3, also what `precision = 0` selects) on unit vectors and keep orthonormal rows orthonormal to 2e-6."""
     n, m = 1344, 130
     A = _sym_psd(n, 5 * n + 1)
     lda = rup(n, 32)
@@ -448,8 +441,11 @@ def test_second_back_transformation_variants(ctx, monkeypatch):
     Z0 = np.zeros((m, lda), dtype=np.float32)
     Z0[:, :n] = Q.T.astype(np.float32)
     out = {}
-    for v in ("3", "6", "5", "7", "8", "9", "10", "11", "12", "13", "14", "15"):
-        monkeypatch.setenv("SCLENS_HIP_Q2_VARIANT", v)
+    for v in ("3", "14", "15", "strict"):
+        if v == "strict":
+            opt(q2_variant=15, precision=0)
+        else:
+            opt(q2_variant=int(v))
         dZ = DevArray(ctx, Z0)
         ctx.check(ctx.lib.sclens_hip_dev_sbr_apply_q2_f32(ctx.h, n, dZ.p, m, lda))
         ctx.sync()
@@ -457,20 +453,16 @@ def test_second_back_transformation_variants(ctx, monkeypatch):
         dZ.free()
     for x in (dA, dT, dd, de):
         x.free()
-    assert np.array_equal(out["3"], out["6"]) and np.array_equal(out["5"], out["7"]) and np.array_equal(out["8"], out["9"])
-    assert np.abs(out["7"].astype(np.float64) - out["3"]).max() < 4e-6
-    assert np.abs(out["8"].astype(np.float64) - out["3"]).max() < 4e-6
-    assert np.array_equal(out["10"], out["11"]) and np.abs(out["10"].astype(np.float64) - out["3"]).max() < 4e-6
-    assert np.array_equal(out["10"], out["12"]) and np.array_equal(out["10"], out["13"])  # loader waves: the same arithmetic
+    assert np.array_equal(out["3"], out["strict"])  # precision = 0 IS the fp32 kernel, whatever q2_variant says
     # 14 / 15: one copy of the reflectors + T in a 16 KB image, the third product's operand by transposing LDS reads: three products
     assert np.array_equal(out["14"], out["15"]) and np.abs(out["14"].astype(np.float64) - out["3"]).max() < 4e-6
-    for v in ("3", "7", "8", "10", "14"):
+    for v in ("3", "14"):
         Z = out[v].astype(np.float64)
         assert np.abs(Z @ Z.T - np.eye(m)).max() < 2e-6, v
 
 
-def test_sclens_with_the_two_stage_solver(ctx, monkeypatch):
-    """The whole path with SCLENS_HIP_TWO_STAGE=1 (every context created inside sclens() picks it up): same decisions as
+def test_sclens_with_the_two_stage_solver(ctx):
+    """The whole path with the context option two_stage = 1 (every worker context created inside sclens() inherits it): same decisions as
     the default solver, spectra and scores within the fp32 tolerances."""
     from sclens_amd import api
     from sclens_amd._lib import Context
@@ -479,8 +471,8 @@ def test_sclens_with_the_two_stage_solver(ctx, monkeypatch):
     X = synth_counts(300, 500, seed=1, C=5, marker_frac=0.2, marker_sd=1.5)
     d = api.make_draws_native(X, seed=19)
     ref = api.sclens(X, draws=d, n_perturb=5, ctx=ctx, streams=2)
-    monkeypatch.setenv("SCLENS_HIP_TWO_STAGE", "1")
     c2 = Context(ctx.device)
+    c2.set_option("two_stage", 1)
     try:
         res = api.sclens(X, draws=d, n_perturb=5, ctx=c2, streams=2)
     finally:

@@ -152,11 +152,11 @@ def test_native_draws_agree_with_oracle(ctx):
 
 @pytest.mark.parametrize("implicit", [0, 1])
 @pytest.mark.parametrize("N,M", [(300, 500), (600, 250)])
-def test_partial_eigensolver_matches_full_solver(ctx, N, M, implicit, monkeypatch):
+def test_partial_eigensolver_matches_full_solver(ctx, N, M, implicit, opt):
     """Ensemble members via the leading-eigenpair subspace iteration vs the full eigensolver: same decisions,
     eigenvalues to 3e-4, signal eigenvectors to |cos| >= 1 - 3e-3. implicit = 1: the iteration applies the Gram matrix as
     two passes over the scaled matrix and never forms it (the default from n = 16 000)."""
-    monkeypatch.setenv("SCLENS_HIP_IMPLICIT_MIN_N", "1" if implicit else "1000000000")
+    opt(implicit_min_n=1 if implicit else 1000000000)
     X = synth_counts(N, M, seed=1, C=5, marker_frac=0.2, marker_sd=1.5)
     d = api.make_draws_native(X, seed=9)
     a = api.sclens(X, draws=d, n_perturb=5, ctx=ctx, keep_intermediates=True, max_search_iters=6, partial_eig=True)
@@ -219,15 +219,15 @@ def test_partial_eigensolver_tail_gap_option(ctx):
             assert np.all(cos[sep] > 1 - 5e-3), (cos, sep)
 
 
-def test_fused_dense_write_gives_the_same_bits(ctx, monkeypatch):
+def test_fused_dense_write_gives_the_same_bits(ctx, opt):
     """k_dense_fused (one pass per gene: background + stored entries + sampled candidates through LDS chunks) against the separate
-    fill + scatter kernels (SCLENS_HIP_DENSE_FUSED=0): the dense scaled matrices are the same, so is everything downstream --
+    fill + scatter kernels (context option dense_fused = 0): the dense scaled matrices are the same, so is everything downstream --
     counts-only patterns (data / null), and the union pattern with its unordered candidate tail (ensemble members, full solver)."""
     X = api._csc_f32(synth_counts(900, 260, seed=3, C=5, marker_frac=0.2, marker_sd=1.5))
     d = api.make_draws_native(X, seed=17)
     out = []
     for flag in ("1", "0"):
-        monkeypatch.setenv("SCLENS_HIP_DENSE_FUSED", flag)
+        opt(dense_fused=int(flag))
         out.append(api.sclens(X, draws=d, n_perturb=3, ctx=ctx, keep_intermediates=True, max_search_iters=5, partial_eig=False, streams=1))
         S, _ = api.logn_scale(X, "mean", inline_f64=True, ctx=ctx)
         out[-1]["S"] = S

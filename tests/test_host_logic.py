@@ -245,22 +245,34 @@ def test_guard_band_cut_stays_contiguous():
     assert cut_with_guard_band(L, 100.0, 0.0, None)[1] == 0
 
 
-def test_every_environment_switch_is_documented():
-    """INTEGRATION.md section 5 lists the SCLENS_HIP_* switches the library reads: every name in the sources is in the table and
-    every name in the table is in the sources (SCLENS_HIP_COMM_ID_BYTES is a compile-time constant of the header, not a switch)."""
+def test_options_are_abi_not_environment():
+    """Round 5: the library's tunables are named options of a context (csrc/common.h, SCL_OPTION_TABLE) reached
+    through sclens_hip_set_option; the environment is read in a handful of places, once each. INTEGRATION.md section 5 documents every
+    option and every SCLENS_HIP_* variable the sources mention, and nothing else."""
     import glob
     import os
     import re
 
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    src = set()
+    src, n_getenv = set(), 0
     for pat in ("sclens_amd/csrc/*.hip", "sclens_amd/csrc/*.h", "sclens_amd/csrc/*.cpp", "sclens_amd/*.py"):
         for f in glob.glob(os.path.join(root, pat)):
-            src |= set(re.findall(r"SCLENS_HIP_[A-Z0-9_]+", open(f).read()))
-    src.discard("SCLENS_HIP_COMM_ID_BYTES")
-    doc = set(re.findall(r"SCLENS_HIP_[A-Z0-9_]+", open(os.path.join(root, "INTEGRATION.md")).read()))
-    assert src - doc == set(), f"undocumented switches: {sorted(src - doc)}"
+            text = open(f).read()
+            src |= set(re.findall(r"SCLENS_HIP_[A-Z0-9_]+", text))
+            if "/csrc/" in f:
+                n_getenv += len(re.findall(r"\bgetenv\(", text))
+    src.discard("SCLENS_HIP_COMM_ID_BYTES")  # a compile-time constant of the header
+    assert n_getenv < 10, n_getenv
+    doc_text = open(os.path.join(root, "INTEGRATION.md")).read()
+    doc = set(re.findall(r"SCLENS_HIP_[A-Z0-9_]+", doc_text))
+    assert src - doc == set(), f"undocumented variables: {sorted(src - doc)}"
     assert doc - src == set(), f"documented but not read anywhere: {sorted(doc - src)}"
+    table = open(os.path.join(root, "sclens_amd/csrc/common.h")).read()
+    table = table[table.index("#define SCL_OPTION_TABLE(X)"):table.index("struct Options {")]
+    names = re.findall(r"X\((\w+),", table)
+    assert len(names) > 30 and "precision" in names
+    missing = [q for q in names if f"`{q}`" not in doc_text]
+    assert not missing, f"options missing from INTEGRATION.md section 5: {missing}"
 
 
 def test_null_matrix_draw_does_not_depend_on_the_thread_count(monkeypatch):
@@ -275,3 +287,55 @@ def test_null_matrix_draw_does_not_depend_on_the_thread_count(monkeypatch):
     for o in out[1:]:
         assert all(np.array_equal(a, b) for a, b in zip(o, out[0]))
     assert np.array_equal(np.sort(out[0][2]), np.sort(X.data)) and np.array_equal(np.diff(out[0][0]), np.diff(X.indptr))
+
+
+def test_bench_line_fits_what_the_driver_reads():
+    """round 4's stdout line grew to 25 KB (per-step decisions of 20 steps, job timelines, every stage) and the driver,
+    which keeps the tail of stdout, could not parse it. `bench.compact_line` must stay under 4 KB for the driver's own `--steps 20
+    --warmup 5`, parse as JSON, and still carry the contract's keys + roofline + cpu_baseline; the full record goes to a side file."""
+    import json
+
+    import bench
+
+    steps = 20
+    dec = [{"seed": 1000 + s, "signals": 7, "robust_signals": 7, "search_iters": 19, "p_": 0.985, "min_abs_margin": 2.3e-5 + 1e-6 * s,
+            "d5_second_smallest": [0.0301 - 0.0003 * q for q in range(19)], "p_th": 0.024661, "wall_s": 28.4 + 0.01 * s,
+            "phase_s": {"session_create": 0.06, "first_decompositions": 3.8, "sparsity_search": 20.7, "ensemble": 3.7, "scoring": 0.18},
+            "first_phase_jobs_s": [["data_spectrum", 0.07, 1.35], ["null_spectrum", 0.93, 2.0], ["binary_basis", 2.0, 3.9]]} for s in range(steps)]
+    stage = lambda ms, frac: {"bound": "mfma", "ms": ms, "achieved": 100.0, "peak": 157.3, "unit": "TFLOP/s", "frac": frac, "work": "w" * 150}
+    full = {
+        "metric": "sclens() cells*genes/s (wall-clock of one full sclens() call)", "value": 1.056e8, "unit": "cells*genes/s", "n_gpus": 1,
+        "steps": steps, "warmup": 5, "steps_requested": steps, "warmup_requested": 5, "budget_s": 1500.0, "ms_per_step": 28410.0,
+        "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": bench.DTYPE_SPLIT, "data": "synthetic",
+        "dtype_note": bench.DTYPE_NOTE,
+        "config": {"workload": "cfg4: " + "x" * 200, "N": 100000, "M": 30000, "nnz": 310629691, "n_perturb": 20, "parallelism": "p" * 150,
+                   "comm": "c" * 300, "precision": 1, "keep_warm": True},
+        "sclens_wall_s": 28.41,
+        "observed": {"signals": 7, "robust_signals": 7, "search_iters": 19, "p_": 0.985, "synth_s": 2.0, "decisions_per_step": dec,
+                     "hbm_in_use_GB_after_timed_steps": 264.0, "search_job_s_last_step": [[q, 0, 1.0 * q, 1.0 * q + 1] for q in range(20)],
+                     "first_phase_jobs_s_last_step": [["a", 0.0, 1.0]] * 8},
+        "value_strict_fp32": 5.41e7, "strict_steps": 3, "strict_ms_per_step": 55400.0, "decisions_differ": False,
+        "extra": {"strict_fp32": {"decisions": dec[-3:]}},
+        "roofline": {"bound": "mfma", "kernel": "two-stage symmetric eigensolver " + "k" * 200, "achieved": 57.6, "peak": 157.3, "unit": "TFLOP/s",
+                     "frac": 0.366, "traffic": 2.296e12, "traffic_source": "t" * 500, "n": 30016, "vectors": 15008, "launch_ms": 1093.0,
+                     "stage_ms": {k: 100.0 for k in ("sy2sb_dense_to_band", "sb2st_bulge_chasing", "stebz", "stein", "q2_back_transform", "q1_back_transform")},
+                     "stages": {k: stage(100.0, 0.4) for k in ("normalise", "normalise_search_step", "gram", "gram_binary_f16", "sy2sb_dense_to_band",
+                                                               "sb2st_bulge_chasing", "q2_back_transform", "q1_back_transform")}, "note": "n" * 400},
+        "cpu_baseline": {"value": 72224.6, "unit": "cells*genes/s", "cores": 16, "kind": "port", "wall_s_extrapolated": 15913.2,
+                         "wall_s_lower_bound": 41537.1, "samples": [{"Ns": 1, "Ms": 2}] * 2, "sample": "s" * 700, "lower_bound_note": "l" * 600},
+        "bench_wall_s": 856.8}
+    line = bench.compact_line(full, "/somewhere/bench_detail.json")
+    text = json.dumps(line)
+    assert len(text) <= 4096 and len(json.dumps(full)) > 15000
+    back = json.loads(text)
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
+                "data", "config", "roofline", "cpu_baseline", "value_strict_fp32", "strict_steps", "decisions_differ"):
+        assert key in back, key
+    assert set(("bound", "achieved", "peak", "unit", "frac", "traffic")) <= set(back["roofline"])
+    assert set(("value", "unit", "cores", "kind", "sample")) <= set(back["cpu_baseline"])
+    assert back["config"]["workload"].startswith("cfg4") and back["detail"] == "bench_detail.json"
+    assert all(v <= 1.0 for v in back["roofline"]["stage_frac"].values())
+    # twice the steps and absurdly long strings: the optional parts are dropped until it fits
+    full["observed"]["decisions_per_step"] = dec * 4
+    full["config"]["comm"] = "c" * 5000
+    assert len(json.dumps(bench.compact_line(full, None))) <= 4096
