@@ -395,7 +395,9 @@ class _PinnedPool:
     CAP_BYTES = 8 << 30  # idle blocks beyond this are freed
 
     def __init__(self):
-        self.lock = threading.Lock()
+        # re-entrant: a garbage collection triggered inside array() / _give_back() may finalise another _PinnedBlock on the same thread,
+        # whose __del__ comes back here
+        self.lock = threading.RLock()
         self.free = {}  # nbytes -> [address]
         self.idle = 0
 
@@ -1125,11 +1127,14 @@ def sclens(inp_df, device_="gpu", th=60, p_step=0.001, n_perturb=20, centering="
     pat_future = aux_pool.submit(build_pattern)
     pat = None
     workers, wctx, pool = [ses], [], None
+    pstage_cus = ctx.get_option("pstage_cus") if hasattr(ctx, "get_option") else 0
     try:
         # local workers: `streams` sessions on this GPU (own stream + scratch each, shared read-only data), one host
         # thread per session (ctypes releases the GIL), so independent decompositions overlap on the device
         for _ in range(max(1, int(streams)) - 1):
             c2 = Context(ctx.device).copy_options_from(ctx)
+            if pstage_cus > 0:  # every worker packs its partial-chip stages onto its own CUs (disjoint ranges of the driver's numbering)
+                c2.set_option("pstage_cu_first", ctx.get_option("pstage_cu_first") + (len(wctx) + 1) * pstage_cus)
             wctx.append(c2)
             workers.append(ses.clone(c2))
         gb0 = sum(w.get_int("gram_bits_used") for w in workers)  # context-lifetime counters: this call's share is the difference

@@ -145,7 +145,10 @@ struct GramBitsArgs {
   double Ncells, inv_div;
 };
 
-template <int NW>
+// PIPE (round 5, context option split_pipe): the stage loop as a software pipeline -- see split_mainloop_pipe; here a stage is four
+// units of 8 NW matrix instructions (one per 16 cells), the barrier sits between units 2 and 3, the DMA pieces go out one per two
+// matrix instructions behind it (four during unit 3, the other four and the weights during unit 0 of the next stage).
+template <int NW, bool PIPE>
 __global__ __launch_bounds__(512, 2) void gram_bits_kernel(GramBitsArgs a, const int2* __restrict__ tiles) {
   constexpr int TM = 4, TN = 2;
   constexpr int OPB = 256 * 128;             // bytes of one operand image: 256 rows of 64 fp16
@@ -207,6 +210,66 @@ __global__ __launch_bounds__(512, 2) void gram_bits_kernel(GramBitsArgs a, const
     swB[j] = (r >> 1) & 7;
   }
 
+  if (PIPE) {
+    // one DMA piece of the stage kt (clamped to the last one: a reload nobody reads) into buffer buf: 0..3 A, 4..7 B, 8 the weights
+    auto piece = [&](int buf, int64_t kt, int pc) {
+      if (kt > nkt - 1) kt = nkt - 1;
+      unsigned char* As = lds + buf * STAGE;
+      if (pc < 4) __builtin_amdgcn_global_load_lds((glb_void_t*)(srcA[pc] + kt * 64), (lds_void_t*)(As + (wid * 4 + pc) * 1024), 16, 0, 0);
+      else if (pc < 8) __builtin_amdgcn_global_load_lds((glb_void_t*)(srcB[pc - 4] + kt * 64), (lds_void_t*)(As + OPB + (wid * 4 + pc - 4) * 1024), 16, 0, 0);
+      else if (wid == 7 && lane < 8 * NW)
+        __builtin_amdgcn_global_load_lds((glb_void_t*)(a.wq + (kt * 8 * NW + lane) * 8), (lds_void_t*)(As + 2 * OPB), 16, 0, 0);
+    };
+    h16x8 av[2][TM], bv[2][TN], wv[2][NW];
+    auto reads = [&](int set, const unsigned char* S, int kk) {
+      const int c = 2 * kk + h;
+#pragma unroll
+      for (int i = 0; i < TM; ++i) av[set][i] = *reinterpret_cast<const h16x8*>(S + offA[i] + ((c ^ swA[i]) << 4));
+#pragma unroll
+      for (int j = 0; j < TN; ++j) bv[set][j] = *reinterpret_cast<const h16x8*>(S + offB[j] + ((c ^ swB[j]) << 4));
+#pragma unroll
+      for (int t = 0; t < NW; ++t) wv[set][t] = *reinterpret_cast<const h16x8*>(S + 2 * OPB + ((c * NW + t) << 4));
+    };
+    // a unit = the cells of one kk: NW x TM groups of TN matrix instructions; `pre(g)` in front of group g, `next()` behind group 0
+    auto unit = [&](int set, auto pre, auto next) {
+#pragma unroll
+      for (int t = 0; t < NW; ++t) {
+        h16x8 bw[TN];
+#pragma unroll
+        for (int j = 0; j < TN; ++j) bw[j] = bv[set][j] * wv[set][t];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+          pre(t * TM + i);
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(av[set][i], bw[j], acc[i][j], 0, 0, 0);
+          __builtin_amdgcn_sched_barrier(0);
+          if (t == 0 && i == 0) {
+            next();
+            __builtin_amdgcn_sched_barrier(0);
+          }
+        }
+      }
+    };
+    auto none = [](int) {};
+#pragma unroll
+    for (int pc = 0; pc < 9; ++pc) piece(0, 0, pc);
+    __syncthreads();
+#pragma unroll
+    for (int pc = 0; pc < 4; ++pc) piece(1, 1, pc);
+    reads(0, lds, 0);
+    for (int64_t kt = 0; kt < nkt; ++kt) {
+      const int cur = (int)(kt & 1);
+      const unsigned char* S = lds + cur * STAGE;
+      const unsigned char* Sn = lds + (cur ^ 1) * STAGE;
+      unit(0, [&](int g) { if (g < 5) piece(cur ^ 1, kt + 1, 4 + g); }, [&]() { reads(1, S, 1); });
+      unit(1, none, [&]() { reads(0, S, 2); });
+      unit(0, none, [&]() { reads(1, S, 3); });
+      __syncthreads();  // every wave has issued its reads of `cur`; stage kt + 1 has landed in the other buffer
+      unit(1, [&](int g) { if (g < 4) piece(cur, kt + 2, g); }, [&]() { reads(0, Sn, 0); });
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // no DMA piece may outlive the workgroup's LDS
+  } else {
   stage(0, 0);
   __syncthreads();
   for (int64_t kt = 0; kt < nkt; ++kt) {
@@ -247,6 +310,7 @@ __global__ __launch_bounds__(512, 2) void gram_bits_kernel(GramBitsArgs a, const
       }
     }
     __syncthreads();
+  }
   }
 
   // ---- epilogue (D layout: col = lane & 31, rows (e & 3) + 8 (e >> 2) + 4 (lane >> 5)): fp64 combination with the rank-one
@@ -296,8 +360,13 @@ __global__ __launch_bounds__(512, 2) void gram_bits_kernel(GramBitsArgs a, const
 template <int NW>
 int launch_gram_bits(Ctx* ctx, const GramBitsArgs& a, const int2* tiles, int64_t nb) {
   constexpr int LDS_BYTES = 2 * (2 * 256 * 128 + 128 * NW);
-  SCL_TRY(ensure_dyn_lds(ctx, reinterpret_cast<const void*>(gram_bits_kernel<NW>), LDS_BYTES));
-  hipLaunchKernelGGL((gram_bits_kernel<NW>), dim3((unsigned)nb), dim3(512), LDS_BYTES, ctx->stream, a, tiles);
+  if (ctx->opt.split_pipe != 0) {
+    SCL_TRY(ensure_dyn_lds(ctx, reinterpret_cast<const void*>(gram_bits_kernel<NW, true>), LDS_BYTES));
+    hipLaunchKernelGGL((gram_bits_kernel<NW, true>), dim3((unsigned)nb), dim3(512), LDS_BYTES, ctx->stream, a, tiles);
+  } else {
+    SCL_TRY(ensure_dyn_lds(ctx, reinterpret_cast<const void*>(gram_bits_kernel<NW, false>), LDS_BYTES));
+    hipLaunchKernelGGL((gram_bits_kernel<NW, false>), dim3((unsigned)nb), dim3(512), LDS_BYTES, ctx->stream, a, tiles);
+  }
   SCL_HIP(ctx, hipGetLastError());
   return SCLENS_OK;
 }
@@ -432,6 +501,166 @@ __global__ __launch_bounds__(512, 2) void corr_split_kernel(SplitCorrArgs a, con
   }
 }
 
+// The same product with the stage loop written as a software pipeline (round 5; context option split_pipe). What the two-buffer loop
+// above loses per 32 of K (ISA + stage clocks: 6 500 clocks against 3 100 of matrix instructions at two waves per SIMD): its 8 DMA
+// instructions are issued back to back at the top of a stage by BOTH waves of a SIMD at once (60-185 clocks of issue each, nothing on
+// the matrix pipe meanwhile), the compiler places every group of LDS reads right in front of its matrix instructions with a full
+// `lgkmcnt(0)` wait (~10 exposed LDS round trips per stage, again in both waves at once), and the stage ends in a barrier behind which
+// the first reads of the next stage are exposed once more. Here a stage is four units of 12 matrix instructions (u = 2 kk + half of
+// the row tiles); the fragments of unit u + 1 are read before the matrix instructions of unit u (two register sets), the barrier sits
+// between units 2 and 3 -- the point at which every wave has issued its last read of the current buffer and the next stage has
+// landed -- and the DMA pieces of the stage after next go out one per three matrix instructions behind that barrier (four during
+// unit 3, four during unit 0 of the next stage), so that the matrix pipe stays fed while they issue. Same products in the same
+// order per accumulator: the same bits as the loop above.
+// acc += A B' over `nst` stages of 32 of K starting at byte offset koff0 of the image rows (A: 256 rows from baseA, B: 256 rows from
+// baseB, rows beyond mlast / nlast re-read the last one); all 512 threads of the workgroup, 128 KB of dynamic LDS. scale_acc: the
+// accumulators hold values whose loads may still be in flight (C of a read-modify-write product): they are multiplied by acc_scale
+// behind the wait for the first stage, which covers those loads (memory instructions complete in issue order)
+__device__ __forceinline__ void split_mainloop_pipe(v16f (&acc)[4][2], unsigned char* lds, const unsigned char* baseA, const unsigned char* baseB,
+                                                    unsigned rowb, int mlast, int nlast, unsigned koff0, int64_t nst, bool scale_acc = false,
+                                                    float acc_scale = 1.f) {
+  constexpr int TN = 2;
+  constexpr int OPB = 256 * 128, STAGE = 2 * OPB;
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int wm = wid >> 2, wn = wid & 3, l31 = lane & 31, h = lane >> 5;
+  const int srow = lane >> 3, sq = lane & 7;
+  // DMA sources: a uniform base per operand + one 32-bit byte offset per piece (a stage row is 128 bytes, an image row 4 Kp bytes: a
+  // tile's 256 rows span < 2^31 bytes); pieces 0..3 are the wave's four 8-row groups of A, 4..7 those of B
+  unsigned offp[8];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int r = (wid * 4 + i) * 8 + srow;
+    const unsigned chunk = (unsigned)(sq ^ ((r >> 1) & 7));
+    offp[i] = (unsigned)(r < mlast ? r : mlast) * rowb + 16u * chunk;
+    offp[4 + i] = (unsigned)(r < nlast ? r : nlast) * rowb + 16u * chunk;
+  }
+  const unsigned ldsw = (unsigned)(wid * 4096);  // the wave's four 1 KB pieces of an operand image
+  auto dma = [&](int buf, unsigned koff, int piece) {  // piece 0..7 of the stage at byte offset koff of the image rows into buffer buf
+    unsigned char* dst = lds + buf * STAGE + (piece >> 2) * OPB + ldsw + (piece & 3) * 1024;
+    const unsigned char* g = (piece < 4 ? baseA : baseB) + (offp[piece] + koff);
+    __builtin_amdgcn_global_load_lds((glb_void_t*)g, (lds_void_t*)dst, 16, 0, 0);
+  };
+  // fragment addresses: row r = wm 128 + i 32 + l31 of A (wn 64 + j 32 + l31 of B) at r * 128 bytes, chunk c in slot c ^ ((r >> 1) & 7)
+  // = c ^ ((l31 >> 1) & 7) for every tile of the lane: one base per operand, the tile as an immediate, four slot offsets per lane
+  const int sw = (l31 >> 1) & 7;
+  const int fa = (wm * 128 + l31) * 128, fb = OPB + (wn * 64 + l31) * 128;
+  int slot[2][2];  // [kk][hi / lo]: byte offset of the lane's chunk inside its row
+#pragma unroll
+  for (int kk = 0; kk < 2; ++kk) {
+    slot[kk][0] = ((2 * kk + h) ^ sw) << 4;
+    slot[kk][1] = ((4 + 2 * kk + h) ^ sw) << 4;
+  }
+  h16x8 ah[2][2], al[2][2], bh[2][TN], bl[2][TN];  // [register set][row tile of the unit / column tile]
+  auto readA = [&](int set, const unsigned char* S, int kk, int half) {
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const int i = 2 * half + q;
+      ah[set][q] = *reinterpret_cast<const h16x8*>(S + fa + i * 4096 + slot[kk][0]);
+      al[set][q] = *reinterpret_cast<const h16x8*>(S + fa + i * 4096 + slot[kk][1]);
+    }
+  };
+  auto readB = [&](int set, const unsigned char* S, int kk) {
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      bh[set][j] = *reinterpret_cast<const h16x8*>(S + fb + j * 4096 + slot[kk][0]);
+      bl[set][j] = *reinterpret_cast<const h16x8*>(S + fb + j * 4096 + slot[kk][1]);
+    }
+  };
+  // the 12 matrix instructions of a unit in four groups of three; mode 1 / 2: DMA piece g / 4 + g of the stage at `koff` into `buf` goes
+  // out in front of group g. No branches in the loop body: beyond the last stage the offsets are clamped to it (a reload nobody reads).
+  // `next()` issues the LDS reads of the following unit BEHIND the first group: the wait the compiler puts in front of a unit's first
+  // matrix instruction is `lgkmcnt(0)`, which must not cover reads issued a moment ago
+  const unsigned klast = koff0 + (unsigned)(nst - 1) * 128u;
+  auto unit = [&](int aset, int bset, int half, int mode, int buf, unsigned koff, auto next) {
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        if (mode) dma(buf, koff < klast ? koff : klast, (mode == 2 ? 4 : 0) + q * TN + j);
+        __builtin_amdgcn_sched_barrier(0);
+        const int i = 2 * half + q;
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[aset][q], bh[bset][j], acc[i][j], 0, 0, 0);
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[aset][q], bl[bset][j], acc[i][j], 0, 0, 0);
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[aset][q], bh[bset][j], acc[i][j], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        if (q == 0 && j == 0) {
+          next();
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+  };
+  // prologue: stage 0 landed, the first half of stage 1 in flight, the fragments of unit 0 in register set 0
+#pragma unroll
+  for (int pc = 0; pc < 8; ++pc) dma(0, koff0, pc);
+  __syncthreads();
+#pragma unroll
+  for (int pc = 0; pc < 4; ++pc) dma(1, koff0 + 128u < klast ? koff0 + 128u : klast, pc);
+  if (scale_acc) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[i][j][e] *= acc_scale;
+  }
+  readA(0, lds, 0, 0);
+  readB(0, lds, 0);
+  for (int64_t t = 0; t < nst; ++t) {
+    const int cur = (int)(t & 1);
+    const unsigned char* S = lds + cur * STAGE;
+    const unsigned char* Sn = lds + (cur ^ 1) * STAGE;
+    const unsigned koff = koff0 + (unsigned)t * 128u;
+    // unit 0 (kk 0, row tiles 0-1): sets A0, B0; reads of unit 1 -> A1; the second half of the DMA of stage t + 1 goes out here
+    unit(0, 0, 0, 2, cur ^ 1, koff + 128u, [&]() { readA(1, S, 0, 1); });
+    // unit 1 (kk 0, row tiles 2-3): sets A1, B0; reads of unit 2: A (kk 1, tiles 0-1) -> A0, B (kk 1) -> B1. (Set A0 is free: unit 0
+    // is done; B1 was last used by unit 3 of the previous stage.)
+    unit(1, 0, 1, 0, 0, 0u, [&]() { readA(0, S, 1, 0); readB(1, S, 1); });
+    // unit 2 (kk 1, row tiles 0-1): sets A0, B1; reads of unit 3 -> A1: the last reads of this buffer
+    unit(0, 1, 0, 0, 0, 0u, [&]() { readA(1, S, 1, 1); });
+    // every wave has issued its reads of `cur`, stage t + 1 has landed in the other buffer (vmcnt(0) + barrier)
+    __syncthreads();
+    // unit 3 (kk 1, row tiles 2-3): sets A1, B1; the fragments of unit 0 of stage t + 1 -> A0, B0; first half of the DMA of stage t + 2
+    unit(1, 1, 1, 1, cur, koff + 256u, [&]() { readA(0, Sn, 0, 0); readB(0, Sn, 0); });
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // no DMA piece may outlive the workgroup's LDS
+}
+
+__global__ __launch_bounds__(512, 2) void corr_split_kernel_p(SplitCorrArgs a, const int2* __restrict__ tiles) {
+  constexpr int TM = 4, TN = 2;
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+  int2 tl = tiles[blockIdx.x];
+  if (tl.x < 0) return;
+  tl.x = __builtin_amdgcn_readfirstlane(tl.x);
+  tl.y = __builtin_amdgcn_readfirstlane(tl.y);
+  const int64_t m0 = (int64_t)tl.x * 256, n0 = (int64_t)tl.y * 256;
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const int wn = wid & 3, l31 = lane & 31, h = lane >> 5;
+  const unsigned rowb = (unsigned)(4 * a.Kp);
+  const unsigned char* baseA = reinterpret_cast<const unsigned char*>(a.A) + m0 * rowb;
+  const unsigned char* baseB = reinterpret_cast<const unsigned char*>(a.B) + n0 * rowb;
+  const int mlast = (int)((a.M - 1 - m0 < 255) ? a.M - 1 - m0 : 255), nlast = (int)((a.N - 1 - n0 < 255) ? a.N - 1 - n0 : 255);
+  v16f acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+  split_mainloop_pipe(acc, lds, baseA, baseB, rowb, mlast, nlast, 0u, a.Kp / 32);
+  // column maxima of |alpha acc| (rows beyond M hold copies of row M - 1: harmless for a maximum)
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    float mx = 0.f;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) mx = fmaxf(mx, fabsf(a.alpha * acc[i][j][e]));
+    mx = fmaxf(mx, __shfl_xor(mx, 32));
+    const int64_t col = n0 + wn * 64 + j * 32 + l31;
+    if (h == 0 && col < a.N) atomicMax(&a.colabsmax[col], __float_as_uint(mx));
+  }
+}
+
 // ---- C += P Q' from split images, accumulators started from C (round 3) ------------------------------------------------------
 __global__ __launch_bounds__(256) void k_absmax_bits(const float* __restrict__ src, int64_t rows, int64_t K, int64_t ld,
                                                      unsigned* __restrict__ out) {
@@ -470,6 +699,73 @@ __global__ __launch_bounds__(256) void k_split_image_scaled(const float* __restr
     d[0] = hi;
     d[32] = lo;
   }
+}
+
+// The split image of a short, fat block (the b rows of a subspace-iteration block: magnitudes differ by up to 1e5 from row to row) with
+// ONE POWER-OF-TWO SCALE PER ROW: row r is scaled so that its largest |entry| lands in [2^13, 2^14) and inv_scale[r] receives the
+// reciprocal (exact), which the consumer multiplies back into row r of the product. One workgroup per row.
+__global__ __launch_bounds__(256) void k_split_image_rows(const float* __restrict__ src, int64_t K, int64_t ld, int64_t Kp,
+                                                          _Float16* __restrict__ dst, float* __restrict__ inv_scale) {
+  __shared__ float sw[4];
+  const int64_t r = blockIdx.x;
+  const float* a = src + r * ld;
+  float mx = 0.f;
+  for (int64_t k = threadIdx.x; k < K; k += 256) mx = fmaxf(mx, fabsf(a[k]));
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+  if ((threadIdx.x & 63) == 0) sw[threadIdx.x >> 6] = mx;
+  __syncthreads();
+  mx = fmaxf(fmaxf(sw[0], sw[1]), fmaxf(sw[2], sw[3]));
+  float sc = 1.f;
+  if (mx > 0.f && mx < 3.0e38f) {
+    int ex = 0;
+    (void)frexpf(mx, &ex);
+    int e = 14 - ex;
+    e = e > 100 ? 100 : (e < -100 ? -100 : e);  // sc and 1 / sc stay normal numbers
+    sc = ldexpf(1.f, e);
+  }
+  if (threadIdx.x == 0) inv_scale[r] = 1.f / sc;
+  _Float16* d0 = dst + r * 2 * Kp;
+  for (int64_t k = threadIdx.x; k < Kp; k += 256) {
+    const float x = k < K ? a[k] * sc : 0.f;
+    const _Float16 hi = (_Float16)x;
+    _Float16* d = d0 + (k >> 5) * 64 + (k & 31);
+    d[0] = hi;
+    d[32] = (_Float16)(x - (float)hi);
+  }
+}
+
+// The split image of the TRANSPOSE of src [rows][K] (image rows = the K columns of src, contraction index = its rows) under the scale
+// scale[0] that the image of src itself carries: tiles of 32 rows x 64 columns through LDS, 16-byte stores of eight hi / eight lo pieces.
+__global__ __launch_bounds__(256) void k_split_image_transposed(const float* __restrict__ src, int64_t rows, int64_t K, int64_t ld, int64_t Rp,
+                                                                const float* __restrict__ scale, _Float16* __restrict__ dst) {
+  __shared__ float tile[32][65];
+  const int64_t r0 = (int64_t)blockIdx.y * 32, c0 = (int64_t)blockIdx.x * 64;
+  const int t = threadIdx.x;
+  const float sc = scale[0];
+  {
+    const int rr = t >> 3, cc = (t & 7) * 8;
+    const int64_t r = r0 + rr;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int64_t c = c0 + cc + e;
+      tile[rr][cc + e] = (r < rows && c < K) ? src[r * ld + c] * sc : 0.f;
+    }
+  }
+  __syncthreads();
+  const int cell = t >> 2, part = t & 3;
+  const int64_t c = c0 + cell;
+  if (c >= K) return;
+  h16x8 hi, lo;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const float x = tile[part * 8 + e][cell];
+    hi[e] = (_Float16)x;
+    lo[e] = (_Float16)(x - (float)hi[e]);
+  }
+  _Float16* d = dst + c * 2 * Rp + (r0 >> 5) * 64 + part * 8;
+  *reinterpret_cast<h16x8*>(d) = hi;
+  *reinterpret_cast<h16x8*>(d + 32) = lo;
 }
 
 __global__ __launch_bounds__(256) void k_split_image_pair_scaled(const float* __restrict__ src1, const float* __restrict__ src2, int64_t rows,
@@ -641,8 +937,10 @@ __device__ __forceinline__ void split_pk8(gb_f32x4 x0, gb_f32x4 x1, h16x8& hi, h
 // gemm_nt_big<2, 4, 4, 2> (same 256 x 256 tile, same 32 x 32 accumulator layout).
 // (Measured and removed in round 5: operands in HALF stages of 16 of K, four LDS buffers, three half stages in flight behind counted
 // waits -- dense Gram 166 against 155 ms, first back-transformation 108 against 100 ms, profiles/r04_split_deep.log.)
-template <bool AF32>
+// PIPE (image x image products only): the stage loop as the software pipeline of split_mainloop_pipe
+template <bool AF32, bool PIPE = false>
 __global__ __launch_bounds__(512, 2) void gemm_split_kernel(SplitUpdArgs a) {
+  static_assert(!(AF32 && PIPE), "the pipelined loop reads split images on both sides");
   constexpr int TM = 4, TN = 2;
   constexpr int OPB = 256 * 128, STAGE = 2 * OPB;
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
@@ -703,7 +1001,7 @@ __global__ __launch_bounds__(512, 2) void gemm_split_kernel(SplitUpdArgs a) {
     for (int i = 0; i < 4; ++i)
       __builtin_amdgcn_global_load_lds((glb_void_t*)(srcB[i] + kt * 64), (lds_void_t*)(Bs + (wid * 4 + i) * 1024), 16, 0, 0);
   };
-  if (kt_lo < nkt) stage((int)(kt_lo & 1), kt_lo);
+  if (!PIPE && kt_lo < nkt) stage((int)(kt_lo & 1), kt_lo);
   const float alpha = a.post / ((AF32 ? a.af_scale : a.sA[0]) * a.sB[0]);  // the scales are powers of two
   // 32-bit indices relative to the tile's corner (and to the corner of its mirror image): the 64-bit row * ldc + col of every
   // element cost this kernel 191 spilled registers
@@ -750,7 +1048,7 @@ __global__ __launch_bounds__(512, 2) void gemm_split_kernel(SplitUpdArgs a) {
     offB[j] = OPB + r * 128;
     swB[j] = (r >> 1) & 7;
   }
-  if (cinit) {
+  if (cinit && !(PIPE && kt_lo < nkt)) {
     const float inv_alpha = 1.f / alpha;
 #pragma unroll
     for (int i = 0; i < TM; ++i)
@@ -759,6 +1057,14 @@ __global__ __launch_bounds__(512, 2) void gemm_split_kernel(SplitUpdArgs a) {
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[i][j][e] *= inv_alpha;
   }
+  if (PIPE) {
+    if (kt_lo < nkt) {
+      const unsigned rowb = (unsigned)(4 * a.Kp);
+      split_mainloop_pipe(acc, lds, reinterpret_cast<const unsigned char*>(a.A) + m0 * rowb, reinterpret_cast<const unsigned char*>(a.B) + n0 * rowb,
+                          rowb, (int)((a.M - 1 - m0 < 255) ? a.M - 1 - m0 : 255), (int)((a.N - 1 - n0 < 255) ? a.N - 1 - n0 : 255),
+                          (unsigned)kt_lo * 128u, nkt - kt_lo, cinit, 1.f / alpha);
+    }
+  } else {
   __syncthreads();
   for (int64_t kt = kt_lo; kt < nkt; ++kt) {
     const int buf = (int)(kt & 1);
@@ -795,6 +1101,7 @@ __global__ __launch_bounds__(512, 2) void gemm_split_kernel(SplitUpdArgs a) {
         }
     }
     __syncthreads();
+  }
   }
   const bool vec_mirror = a.lower && (a.ldc % 4 == 0) && ((reinterpret_cast<uintptr_t>(a.C) & 15u) == 0);
 #pragma unroll
@@ -952,8 +1259,13 @@ int split_image_pair_zmax(Ctx* ctx, const float* src1, const float* src2, int64_
 template <bool AF32>
 static int launch_split_kernel(Ctx* ctx, const SplitUpdArgs& a, dim3 grid) {
   constexpr int LDS_BYTES = 2 * 2 * 256 * 128;
-  SCL_TRY(ensure_dyn_lds(ctx, reinterpret_cast<const void*>(gemm_split_kernel<AF32>), LDS_BYTES));
-  hipLaunchKernelGGL((gemm_split_kernel<AF32>), grid, dim3(512), LDS_BYTES, ctx->stream, a);
+  if (!AF32 && ctx->opt.split_pipe != 0) {
+    SCL_TRY(ensure_dyn_lds(ctx, reinterpret_cast<const void*>(gemm_split_kernel<false, true>), LDS_BYTES));
+    hipLaunchKernelGGL((gemm_split_kernel<false, true>), grid, dim3(512), LDS_BYTES, ctx->stream, a);
+  } else {
+    SCL_TRY(ensure_dyn_lds(ctx, reinterpret_cast<const void*>(gemm_split_kernel<AF32, false>), LDS_BYTES));
+    hipLaunchKernelGGL((gemm_split_kernel<AF32, false>), grid, dim3(512), LDS_BYTES, ctx->stream, a);
+  }
   SCL_HIP(ctx, hipGetLastError());
   return SCLENS_OK;
 }
@@ -1015,6 +1327,24 @@ int split_image_fixed(Ctx* ctx, const float* src, int64_t rows, int64_t K, int64
   return SCLENS_OK;
 }
 
+int split_image_rows(Ctx* ctx, const float* src, int64_t rows, int64_t K, int64_t ld, void* dst, float* inv_scale_dev) {
+  if (rows <= 0) return SCLENS_OK;
+  hipLaunchKernelGGL(k_split_image_rows, dim3((unsigned)rows), dim3(256), 0, ctx->stream, src, K, ld, round_up(K, 32), static_cast<_Float16*>(dst),
+                     inv_scale_dev);
+  SCL_HIP(ctx, hipGetLastError());
+  return SCLENS_OK;
+}
+
+int split_image_transposed(Ctx* ctx, const float* src, int64_t rows, int64_t K, int64_t ld, void* dst, const float* scale_dev) {
+  if (rows <= 0 || K <= 0) return SCLENS_OK;
+  const int64_t gy = (round_up(rows, 32)) / 32;
+  if (gy > 65535) return ctx->fail(SCLENS_ERR_ARG, "split_image_transposed: too many rows");
+  hipLaunchKernelGGL(k_split_image_transposed, dim3((unsigned)((K + 63) / 64), (unsigned)gy), dim3(256), 0, ctx->stream, src, rows, K, ld,
+                     round_up(rows, 32), scale_dev, static_cast<_Float16*>(dst));
+  SCL_HIP(ctx, hipGetLastError());
+  return SCLENS_OK;
+}
+
 // colabsmax[j] = max(colabsmax[j], max_i |A_i . B_j|) for the split images of A [M][K] and B [N][K]
 int corr_colabsmax_split(Ctx* ctx, const void* Aimg, int64_t M, const void* Bimg, int64_t N, int64_t K, unsigned* colabsmax) {
   if (M <= 0 || N <= 0) return SCLENS_OK;
@@ -1025,8 +1355,13 @@ int corr_colabsmax_split(Ctx* ctx, const void* Aimg, int64_t M, const void* Bimg
   constexpr int LDS_BYTES = 2 * 2 * 256 * 128;
   SplitCorrArgs a{static_cast<const _Float16*>(Aimg), static_cast<const _Float16*>(Bimg), M, N, round_up(K, 32), colabsmax,
                   1.0f / 16777216.0f};
-  SCL_TRY(ensure_dyn_lds(ctx, reinterpret_cast<const void*>(corr_split_kernel), LDS_BYTES));
-  hipLaunchKernelGGL(corr_split_kernel, dim3((unsigned)nb), dim3(512), LDS_BYTES, ctx->stream, a, tiles);
+  if (ctx->opt.split_pipe != 0) {
+    SCL_TRY(ensure_dyn_lds(ctx, reinterpret_cast<const void*>(corr_split_kernel_p), LDS_BYTES));
+    hipLaunchKernelGGL(corr_split_kernel_p, dim3((unsigned)nb), dim3(512), LDS_BYTES, ctx->stream, a, tiles);
+  } else {
+    SCL_TRY(ensure_dyn_lds(ctx, reinterpret_cast<const void*>(corr_split_kernel), LDS_BYTES));
+    hipLaunchKernelGGL(corr_split_kernel, dim3((unsigned)nb), dim3(512), LDS_BYTES, ctx->stream, a, tiles);
+  }
   SCL_HIP(ctx, hipGetLastError());
   return SCLENS_OK;
 }

@@ -38,7 +38,35 @@ free0, total = torch.cuda.mem_get_info(0)
 log = {"N_total": N_total, "M": M, "world": world, "hbm_total_GB": round(total / 1e9, 1)}
 r0, r1 = row_block(0, world, N_total)
 t0 = time.perf_counter()
-X = api._csc_f32(synth_counts_rows(N_total, M, 20240427 + 4, r0, r1))
+
+
+def cached_slab():
+    """the seeded slab, kept as an .npz in SCLENS_BENCH_CACHE (default: the temp dir; "0" disables) like bench.py's matrices, so that
+    a second run on one box does not spend 77 s regenerating it"""
+    import tempfile
+
+    import scipy.sparse as sp
+
+    d = os.environ.get("SCLENS_BENCH_CACHE", tempfile.gettempdir())
+    path = os.path.join(d, f"sclens_atlas_slab_v1_{N_total}x{M}_{r0}_{r1}.npz") if d not in ("", "0") else None
+    if path and os.path.exists(path):
+        try:
+            z = np.load(path)
+            return sp.csc_matrix((z["data"], z["indices"], z["indptr"]), shape=(r1 - r0, M))
+        except Exception as e:
+            print(f"[atlas] ignoring cache {path}: {e}", file=sys.stderr)
+    Xs = synth_counts_rows(N_total, M, 20240427 + 4, r0, r1)
+    if path:
+        try:
+            tmp = f"{path}.{os.getpid()}.tmp.npz"
+            np.savez(tmp, data=Xs.data, indices=Xs.indices, indptr=Xs.indptr)
+            os.replace(tmp, path)
+        except OSError as e:
+            print(f"[atlas] slab not cached ({e})", file=sys.stderr)
+    return Xs
+
+
+X = api._csc_f32(cached_slab())
 log["slab"] = {"rows": [r0, r1], "nnz": int(X.nnz), "synth_s": round(time.perf_counter() - t0, 1)}
 print("[atlas] slab generated", log["slab"], file=sys.stderr, flush=True)
 t0 = time.perf_counter()

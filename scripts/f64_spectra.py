@@ -32,8 +32,8 @@ DRAW_SEED = 1000  # bench.py: seed_base + step 0
 
 
 def gram_of_scaled_f64(Y: sp.csc_matrix, f32_std: bool, chunk: int = 4000, log=None) -> np.ndarray:
-    """(1 / N) S' S for S = zscore_with_l2(Y) centred per gene (scLENS.jl:596-605 + :300-305; the inline twin :682-696 when
-    f32_std is False), cells > genes (`_wishart_matrix(X'; dims=1)` divides by the column count of its argument = cells, :352-359).
+    """(1 / M) S' S for S = zscore_with_l2(Y) centred per gene (scLENS.jl:596-605 + :300-305; the inline twin :682-696 when
+    f32_std is False), cells > genes: get_sigev (:526-541) takes `_wishart_matrix(X; dims=2)` = X'X / size(X, 2) = / GENES (:352-359).
     The same operations as oracle.zscore_with_l2 on the sparse side; the dense N x M matrix exists only `chunk` rows at a time."""
     N, M = Y.shape
     _, std = O._sparse_col_mean_std(Y, np.float32 if f32_std else np.float64)
@@ -58,7 +58,7 @@ def gram_of_scaled_f64(Y: sp.csc_matrix, f32_std: bool, chunk: int = 4000, log=N
             G[:, j0:j0 + 6000] += D.T @ D[:, j0:j0 + 6000]
         if log and (a // chunk) % 5 == 0:
             log(f"  gram rows {b}/{N} ({time.perf_counter() - t0:.0f} s)")
-    G /= N
+    G /= M
     return G
 
 
@@ -79,10 +79,10 @@ def null_gram_f64(Xr, **kw):
 def selftest():
     X = api._csc_f32(synth_counts(700, 300, seed=5, C=4))
     Xr = O.random_nz(X, np.random.default_rng(3))
-    ref = O.wishart_matrix(O.scale_main(X)[0].T, 1)
+    ref = O.wishart_matrix(O.scale_main(X)[0], 2)
     got = data_gram_f64(X, chunk=128)
     e1 = np.abs(got - ref).max() / np.abs(ref).max()
-    ref = O.wishart_matrix(O.logn_scale(O.pre_scale(Xr)).T, 1)
+    ref = O.wishart_matrix(O.logn_scale(O.pre_scale(Xr)), 2)
     got = null_gram_f64(Xr, chunk=128)
     e2 = np.abs(got - ref).max() / np.abs(ref).max()
     assert e1 < 1e-12 and e2 < 1e-12, (e1, e2)

@@ -32,6 +32,8 @@ def test_gram_bits_matches_oracle_and_fp32_path(ctx, N, M, terms):
     want = S.T @ S / N
     with ctx.options(gram_bits_terms=terms):
         got = api._gram_binary(Xb, use_bits=True, ctx=ctx)
+        with ctx.options(split_pipe=0):  # the two-buffer stage loop of round 4: the same products in the same order
+            assert np.array_equal(got, api._gram_binary(Xb, use_bits=True, ctx=ctx))
     dense = api._gram_binary(Xb, use_bits=False, ctx=ctx)
     scale = np.abs(want).max()
     e_bits, e_dense = np.abs(got - want).max() / scale, np.abs(dense - want).max() / scale
@@ -81,8 +83,9 @@ def test_sclens_with_gram_bits_matches_oracle(ctx):
     assert list(res["sig_id"]) == list(ref["sig_id"])
 
 
-@pytest.mark.parametrize("n,p,q", [(500, 300, 130), (1000, 777, 260), (2050, 520, 515)])
-def test_corr_colmax_split_fp16(ctx, n, p, q):
+@pytest.mark.parametrize("pipe", [1, 0])
+@pytest.mark.parametrize("n,p,q", [(500, 300, 130), (1000, 777, 260), (2050, 520, 515), (96, 40, 33)])
+def test_corr_colmax_split_fp16(ctx, n, p, q, pipe, opt):
     """max_i |X_i' Y_j| from split fp16 images against float64 and against the fp32 product: unit columns with entries over
     several orders of magnitude (localised + delocalised vectors), n not a multiple of the 32-deep stage."""
     rng = np.random.default_rng(n)
@@ -92,7 +95,11 @@ def test_corr_colmax_split_fp16(ctx, n, p, q):
     X /= np.linalg.norm(X, axis=0)
     Y /= np.linalg.norm(Y, axis=0)
     want = np.abs(X.astype(np.float32).astype(np.float64).T @ Y.astype(np.float32).astype(np.float64)).max(axis=0)
+    opt(split_pipe=pipe)  # 1: the stage loop as a software pipeline (round 5), 0: the two-buffer loop; the same products in the same order
     got = api._corr_colmax(X, Y, use_split=True, ctx=ctx)
+    if pipe:
+        opt(split_pipe=0)
+        assert np.array_equal(got, api._corr_colmax(X, Y, use_split=True, ctx=ctx))  # the same bits
     ref32 = api._corr_colmax(X, Y, use_split=False, ctx=ctx)
     assert abs(got[0] - 1.0) < 2e-6
     assert np.abs(got - want).max() < 2e-6, np.abs(got - want).max()

@@ -119,9 +119,9 @@ def test_gram_on_split_fp16_operands_matches_float64(ctx, n, K, opt):
     B -= B.mean(axis=0, keepdims=True)
     ldb, lda = rup(K, 32), rup(n, 32)
     ref = B.astype(np.float64) @ B.astype(np.float64).T / K
-    err = {}
-    for mode in ("64", "0"):
-        opt(gram_split_min_n=int(mode))
+    err, got = {}, {}
+    for mode in ("64", "64/two-buffer", "0"):
+        opt(gram_split_min_n=int(mode.split("/")[0]), split_pipe=0 if "two-buffer" in mode else 1)
         Bp = np.zeros((n, ldb), np.float32)
         Bp[:, :K] = B
         dB, dA = DevArray(ctx, Bp), DevArray(ctx, nbytes=4 * n * lda)
@@ -131,7 +131,8 @@ def test_gram_on_split_fp16_operands_matches_float64(ctx, n, K, opt):
         dB.free()
         dA.free()
         assert np.array_equal(A, A.T)
-        err[mode] = np.abs(A - ref).max() / np.abs(ref).max()
+        err[mode], got[mode] = np.abs(A - ref).max() / np.abs(ref).max(), A.copy()
+    assert np.array_equal(got["64"], got["64/two-buffer"])  # the pipelined stage loop (round 5): the same products in the same order
     assert err["64"] < 2e-6, err
     assert err["64"] < 2 * err["0"] + 3e-7, err
 

@@ -17,15 +17,24 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def _bench(*args, timeout=900):
+    """the ONE stdout line must parse and stay under 4 KB (what the driver reads); the per-step decisions are in the detail file"""
+    import tempfile
+
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     env.pop("WORLD_SIZE", None)
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *args], capture_output=True, text=True, env=env,
-                       timeout=timeout, cwd=ROOT)
-    assert r.returncode == 0, (r.returncode, r.stdout[-2000:], r.stderr[-4000:])
-    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
-    assert len(lines) == 1, r.stdout[-2000:]
-    return json.loads(lines[0])
+    with tempfile.TemporaryDirectory() as d:
+        env["SCLENS_BENCH_DETAIL"] = os.path.join(d, "detail.json")
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *args], capture_output=True, text=True, env=env,
+                           timeout=timeout, cwd=ROOT)
+        assert r.returncode == 0, (r.returncode, r.stdout[-2000:], r.stderr[-4000:])
+        lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+        assert len(lines) == 1 and len(lines[0]) <= 4096, r.stdout[-2000:]
+        line = json.loads(lines[0])
+        full = json.load(open(env["SCLENS_BENCH_DETAIL"]))
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "ms_per_step", "dtype", "config"):
+        assert line[key] == full[key], key
+    return full
 
 
 def _decisions(out):
