@@ -44,6 +44,7 @@ SIGNATURES = {
     "sclens_hip_stream": (vp, [vp]),
     "sclens_hip_trim": (C.c_int, [C.c_int]),
     "sclens_hip_pool_set_cap": (C.c_int, [C.c_int, i64]),
+    "sclens_hip_release_scratch": (C.c_int, [vp, C.c_char_p]),
     "sclens_hip_pool_stats": (C.c_int, [C.c_int, c_i64p, c_i64p, c_i64p, c_i64p]),
     "sclens_hip_symv_probe": (C.c_int, [vp, i64, c_i64p, c_f64p, c_f64p]),
     "sclens_hip_symv_profile": (C.c_int, [vp, C.c_int]),
@@ -239,6 +240,10 @@ class Context:
     def trim_pool(self):
         """hand the idle blocks of the library's memory pool on this device back to the driver (sclens_hip_trim)"""
         self.lib.sclens_hip_trim(self.device)
+
+    def release_scratch(self, family: str):
+        """hand one family of this context's idle scratch back to the pool: "eigensolver", "gram", "chefsi", "corr" or "all" """
+        self.check(self.lib.sclens_hip_release_scratch(self.h, family.encode()))
 
     def set_option(self, name: str, value: int):
         """a named tunable of this context (include/sclens_hip.h: "precision", "two_stage", "gram_bits", ...; csrc/common.h has the table)"""

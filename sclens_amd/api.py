@@ -1331,6 +1331,10 @@ def sclens(inp_df, device_="gpu", th=60, p_step=0.001, n_perturb=20, centering="
                 ptr1, _, _ = holder.shared_buffer(1, rows=0 if shard.rank == r_bin else r_vr2)
                 shard.bcast_dev(ctx, ptr1, r_vr2 * ses.ldz(), r_bin)
                 w_bin = holder
+        # the split images of the dense Gram products (12 GB per context at 100 000 x 30 000) are idle from here on: back to the pool,
+        # where the union pattern and the search's workspaces find them
+        for c_ in [ctx] + wctx:
+            c_.release_scratch("gram")
         lap("spectra_signal_vectors_vr2")
         pat, z1, z2 = pat_future.result()
         n_cand = pat.ncand
@@ -1449,6 +1453,12 @@ def sclens(inp_df, device_="gpu", th=60, p_step=0.001, n_perturb=20, centering="
             trace = [(p_list[q], tank[:, q].copy()) for q in range(tank.shape[1])]
             if verbose:
                 print(f"Selected perturb sparisty: {p_}")
+            # the eigensolver's scratch (band reduction, chase, inverse iteration, both back-transformations: 30-40 GB per context at
+            # 100 000 x 30 000) and the search statistic's images are idle during the ensemble, whose partial eigensolver wants 24 GB of
+            # split images per context instead
+            for c_ in [ctx] + wctx:
+                c_.release_scratch("eigensolver")
+                c_.release_scratch("corr")
             lap("sparsity_search")
 
             # ---- perturbation ensemble (:767-778): member t runs on rank t % world, local worker round-robin

@@ -615,6 +615,32 @@ int sclens_hip_trim(int device_id) {
   scl::pool_trim(device_id);
   return SCLENS_OK;
 }
+int sclens_hip_release_scratch(sclens_hip_ctx* h, const char* family) {
+  CTX_GUARD(h);
+  if (!family) return SCLENS_ERR_ARG;
+  const std::string f(family);
+  std::vector<std::string> pre;
+  if (f == "eigensolver" || f == "all") for (const char* q : {"sbr.", "stein.", "tri.", "trd.", "orm.", "eig."}) pre.push_back(q);
+  if (f == "gram" || f == "all") for (const char* q : {"gram.", "gb."}) pre.push_back(q);
+  if (f == "chefsi" || f == "all") pre.push_back("che.");
+  if (f == "corr" || f == "all") pre.push_back("c.");
+  if (pre.empty()) return h->c.fail(SCLENS_ERR_ARG, "release_scratch: family must be eigensolver, gram, chefsi, corr or all");
+  scl::Ctx& c = h->c;
+  std::vector<std::string> names;
+  for (const auto& kv : c.ws)
+    for (const std::string& q : pre)
+      if (kv.first.compare(0, q.size(), q) == 0) names.push_back(kv.first);
+  if (names.empty()) return SCLENS_OK;
+  scl::ctx_quiesce(&c);
+  for (const std::string& nm : names) c.release(nm);
+  if (f == "eigensolver" || f == "all") {  // nothing a later call could continue from: the next decomposition starts from scratch
+    c.q2_tg_n = -1;
+    c.q2_built_variant = -1;
+    c.q1p_n = -1;
+    c.last_two_stage = false;
+  }
+  return SCLENS_OK;
+}
 int sclens_hip_pool_set_cap(int device_id, int64_t bytes) {
   scl::pool_set_cap(device_id, (long long)bytes);
   return SCLENS_OK;

@@ -33,6 +33,9 @@ class FakeContext:
     def trim_pool(self):
         FakeContext.trims = getattr(FakeContext, "trims", 0) + 1
 
+    def release_scratch(self, family):
+        pass
+
     def copy_options_from(self, other):  # worker contexts inherit the caller's options (sclens_hip_copy_options)
         self.options_from = other
         return self
