@@ -1127,14 +1127,11 @@ def sclens(inp_df, device_="gpu", th=60, p_step=0.001, n_perturb=20, centering="
     pat_future = aux_pool.submit(build_pattern)
     pat = None
     workers, wctx, pool = [ses], [], None
-    pstage_cus = ctx.get_option("pstage_cus") if hasattr(ctx, "get_option") else 0
     try:
         # local workers: `streams` sessions on this GPU (own stream + scratch each, shared read-only data), one host
         # thread per session (ctypes releases the GIL), so independent decompositions overlap on the device
         for _ in range(max(1, int(streams)) - 1):
             c2 = Context(ctx.device).copy_options_from(ctx)
-            if pstage_cus > 0:  # every worker packs its partial-chip stages onto its own CUs (disjoint ranges of the driver's numbering)
-                c2.set_option("pstage_cu_first", ctx.get_option("pstage_cu_first") + (len(wctx) + 1) * pstage_cus)
             wctx.append(c2)
             workers.append(ses.clone(c2))
         gb0 = sum(w.get_int("gram_bits_used") for w in workers)  # context-lifetime counters: this call's share is the difference
@@ -1333,7 +1330,7 @@ def sclens(inp_df, device_="gpu", th=60, p_step=0.001, n_perturb=20, centering="
                 w_bin = holder
         # the split images of the dense Gram products (12 GB per context at 100 000 x 30 000) are idle from here on: back to the pool,
         # where the union pattern and the search's workspaces find them
-        for c_ in [ctx] + wctx:
+        for c_ in ([] if os.environ.get("SCLENS_NO_RELEASE") else [ctx] + wctx):
             c_.release_scratch("gram")
         lap("spectra_signal_vectors_vr2")
         pat, z1, z2 = pat_future.result()
@@ -1456,7 +1453,7 @@ def sclens(inp_df, device_="gpu", th=60, p_step=0.001, n_perturb=20, centering="
             # the eigensolver's scratch (band reduction, chase, inverse iteration, both back-transformations: 30-40 GB per context at
             # 100 000 x 30 000) and the search statistic's images are idle during the ensemble, whose partial eigensolver wants 24 GB of
             # split images per context instead
-            for c_ in [ctx] + wctx:
+            for c_ in ([] if os.environ.get("SCLENS_NO_RELEASE") else [ctx] + wctx):
                 c_.release_scratch("eigensolver")
                 c_.release_scratch("corr")
             lap("sparsity_search")

@@ -122,9 +122,6 @@ void sclens_hip_destroy(sclens_hip_ctx* h) {
   if (h->c.ev1) hipEventDestroy(h->c.ev1);
   for (hipEvent_t e : h->c.prof_ev) hipEventDestroy(e);
   if (h->c.aux_stream) hipStreamDestroy(h->c.aux_stream);
-  if (h->c.lat_stream) hipStreamDestroy(h->c.lat_stream);
-  for (hipEvent_t e : h->c.lat_ev)
-    if (e) hipEventDestroy(e);
   for (hipEvent_t e : h->c.aux_ev)
     if (e) hipEventDestroy(e);
   if (h->c.q2_ev) hipEventDestroy(h->c.q2_ev);

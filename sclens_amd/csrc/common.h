@@ -33,8 +33,6 @@ namespace scl {
   X(chefsi_b0, 0)           /* block size of the partial eigensolver (0: min_pc + 40 rounded up to 32) */                          \
   X(chefsi_tail_gap_micro, -1) /* gap-aware target of the tail pairs x 1e6 (-1: what the caller asks for) */                       \
   X(chefsi_lock, 1)                                                                                                                \
-  X(chefsi_split, 1)        /* implicit block products of the partial eigensolver from split images (0: fp32 products) */          \
-  X(chefsi_split_s1, 0) X(chefsi_split_s2, 0) /* split-K slices of its two products (0: chosen to fill whole rounds of CUs) */        \
   X(sy2sb_split_min, 4096)  /* trailing updates of the band reduction from split operands from this many rows (0: never) */        \
   X(sy2sb_split_scales, 2)  /* 2: separate scales for reflector and Z columns, 1: one scale (round 3) */                           \
   X(sy2sb_zmax, 1)          /* largest |Z| from the kernel that writes Z (0: by a pass over the operands) */                       \
@@ -61,8 +59,6 @@ namespace scl {
   X(host_pattern, 0)        /* 1: sparse pattern built on the host (tests compare the two builders) */                             \
   X(val_csr, 1)             /* CSR-ordered companion copies of the value arrays */                                                 \
   X(gemm_force, 0)          /* tests: 1 the large-tile kernels on small shapes, 2 the 128 x 128 kernel on every shape */           \
-  X(pstage_cus, 0)          /* > 0: the partial-chip stages of the eigensolver (bulge chase, inverse iteration, second back-transformation) */ \
-  X(pstage_cu_first, 0)     /* run on a stream whose CU mask holds the CUs [first, first + cus) of the driver's numbering: see LatStream */    \
   X(panel_prof, 0) X(chase_prof, 0) X(q2_prof, 0) /* per-phase shader clocks on stderr (diagnostic builds of the same kernels) */  \
   X(debug, 0)
 
@@ -121,11 +117,7 @@ struct Ctx {
   hipStream_t stream = nullptr;
   // second stream + events for work that overlaps inside one call (look-ahead of the band reduction); created on first use
   hipStream_t aux_stream = nullptr;
-  hipStream_t swapped_main = nullptr;  // the main stream while `stream` temporarily names another one (sbr_q1_prepare, LatStream)
-  // CU-masked stream for the partial-chip stages (options pstage_cus / pstage_cu_first; created on first use, re-created when they change)
-  hipStream_t lat_stream = nullptr;
-  hipEvent_t lat_ev[2] = {nullptr, nullptr};
-  int64_t lat_cus = 0, lat_first = 0;
+  hipStream_t swapped_main = nullptr;  // the main stream while `stream` temporarily names the auxiliary one (sbr_q1_prepare)
   hipEvent_t aux_ev[2] = {nullptr, nullptr};
   // T factors of the second back-transformation, built on the auxiliary stream right after the bulge chase (sbr.hip): the event
   // that marks them complete and the order they were built for (-1: none / not valid for the current reflectors)
@@ -184,7 +176,6 @@ static inline void ctx_quiesce(Ctx* c) {
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   if (c->aux_stream) (void)hipStreamSynchronize(c->aux_stream);
   if (c->swapped_main) (void)hipStreamSynchronize(c->swapped_main);
-  if (c->lat_stream && c->lat_stream != c->stream) (void)hipStreamSynchronize(c->lat_stream);
 }
 
 #define SCL_HIP(ctx, expr)                                                                       \
@@ -235,25 +226,6 @@ void pool_free(void* p, hipStream_t stream);
 void pool_trim(int device);  // give cached blocks back to the driver (device < 0: all devices)
 void pool_set_cap(int device, long long bytes);  // idle bytes kept per device (bytes < 0: the default rule)
 void pool_stats(int device, size_t* cached, size_t* live, size_t* hits, size_t* misses);
-
-// The partial-chip stages of a decomposition on a CU-masked stream (round 5). A 256 x 256 GEMM workgroup needs a WHOLE CU (128 KB of LDS,
-// the whole register file), and the dispatcher spreads the ~235 workgroups of a bulge chase, of an inverse iteration or of a second
-// back-transformation one per CU -- so while one decomposition is in such a stage, the full-chip kernels of a decomposition on ANOTHER
-// stream find no CU, although the stage uses a few per cent of the machine: concurrent decompositions serialise exactly where they
-// could overlap. With `pstage_cus` = c > 0 those stages run on a stream created with
-// hipExtStreamCreateWithCUMask over the CUs [pstage_cu_first, pstage_cu_first + c) of the driver's numbering (which deals consecutive
-// numbers round-robin over the 8 XCDs, so a contiguous range is balanced) and pack 2-3 workgroups per CU there; the rest of the chip
-// stays whole. Worker contexts take disjoint ranges (api.sclens). While the object lives, ctx->stream IS the masked stream (fenced by
-// events against the main stream on both sides). on() is false when the option is off or the stream cannot be created.
-struct LatStream {
-  Ctx* c;
-  hipStream_t main = nullptr;
-  bool active = false;
-  explicit LatStream(Ctx* ctx, bool enable = true);
-  ~LatStream();
-  bool on() const { return active; }
-  int64_t cus() const { return active ? c->lat_cus : 0; }
-};
 
 // raise a kernel's dynamic-LDS limit once per context (= per device; a process-wide `static` would cover only the first device)
 static inline int ensure_dyn_lds(Ctx* ctx, const void* fn, int bytes) {
@@ -313,10 +285,6 @@ int corr_colabsmax_split(Ctx* ctx, const void* Aimg, int64_t M, const void* Bimg
 int split_image_scaled(Ctx* ctx, const float* src, int64_t rows, int64_t K, int64_t ld, void* dst, float* scale_dev);
 // the same under a FIXED power-of-two scale (no pass over the data): operands whose entries are at most 1 in magnitude
 int split_image_fixed(Ctx* ctx, const float* src, int64_t rows, int64_t K, int64_t ld, void* dst, float* scale_dev, float scale);
-// one power-of-two scale PER ROW (largest |entry| of the row -> [2^13, 2^14)); inv_scale_dev[r] = 1 / scale of row r (exact)
-int split_image_rows(Ctx* ctx, const float* src, int64_t rows, int64_t K, int64_t ld, void* dst, float* inv_scale_dev);
-// the split image of the TRANSPOSE of src [rows][K] (K image rows of round_up(rows, 32) entries) under the scale scale_dev[0]
-int split_image_transposed(Ctx* ctx, const float* src, int64_t rows, int64_t K, int64_t ld, void* dst, const float* scale_dev);
 // C_s = P Q' over the K-slice s of `splits` (slab s at C + s * c_split_off, row pitch ldc; C is not read): split-K partials
 int gemm_split_nt(Ctx* ctx, const void* Pimg, const float* sP, int64_t M, const void* Qimg, const float* sQ, int64_t N, int64_t K, float* C,
                   int64_t ldc, int splits, int64_t k_chunk, int64_t c_split_off);

@@ -701,73 +701,6 @@ __global__ __launch_bounds__(256) void k_split_image_scaled(const float* __restr
   }
 }
 
-// The split image of a short, fat block (the b rows of a subspace-iteration block: magnitudes differ by up to 1e5 from row to row) with
-// ONE POWER-OF-TWO SCALE PER ROW: row r is scaled so that its largest |entry| lands in [2^13, 2^14) and inv_scale[r] receives the
-// reciprocal (exact), which the consumer multiplies back into row r of the product. One workgroup per row.
-__global__ __launch_bounds__(256) void k_split_image_rows(const float* __restrict__ src, int64_t K, int64_t ld, int64_t Kp,
-                                                          _Float16* __restrict__ dst, float* __restrict__ inv_scale) {
-  __shared__ float sw[4];
-  const int64_t r = blockIdx.x;
-  const float* a = src + r * ld;
-  float mx = 0.f;
-  for (int64_t k = threadIdx.x; k < K; k += 256) mx = fmaxf(mx, fabsf(a[k]));
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
-  if ((threadIdx.x & 63) == 0) sw[threadIdx.x >> 6] = mx;
-  __syncthreads();
-  mx = fmaxf(fmaxf(sw[0], sw[1]), fmaxf(sw[2], sw[3]));
-  float sc = 1.f;
-  if (mx > 0.f && mx < 3.0e38f) {
-    int ex = 0;
-    (void)frexpf(mx, &ex);
-    int e = 14 - ex;
-    e = e > 100 ? 100 : (e < -100 ? -100 : e);  // sc and 1 / sc stay normal numbers
-    sc = ldexpf(1.f, e);
-  }
-  if (threadIdx.x == 0) inv_scale[r] = 1.f / sc;
-  _Float16* d0 = dst + r * 2 * Kp;
-  for (int64_t k = threadIdx.x; k < Kp; k += 256) {
-    const float x = k < K ? a[k] * sc : 0.f;
-    const _Float16 hi = (_Float16)x;
-    _Float16* d = d0 + (k >> 5) * 64 + (k & 31);
-    d[0] = hi;
-    d[32] = (_Float16)(x - (float)hi);
-  }
-}
-
-// The split image of the TRANSPOSE of src [rows][K] (image rows = the K columns of src, contraction index = its rows) under the scale
-// scale[0] that the image of src itself carries: tiles of 32 rows x 64 columns through LDS, 16-byte stores of eight hi / eight lo pieces.
-__global__ __launch_bounds__(256) void k_split_image_transposed(const float* __restrict__ src, int64_t rows, int64_t K, int64_t ld, int64_t Rp,
-                                                                const float* __restrict__ scale, _Float16* __restrict__ dst) {
-  __shared__ float tile[32][65];
-  const int64_t r0 = (int64_t)blockIdx.y * 32, c0 = (int64_t)blockIdx.x * 64;
-  const int t = threadIdx.x;
-  const float sc = scale[0];
-  {
-    const int rr = t >> 3, cc = (t & 7) * 8;
-    const int64_t r = r0 + rr;
-#pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      const int64_t c = c0 + cc + e;
-      tile[rr][cc + e] = (r < rows && c < K) ? src[r * ld + c] * sc : 0.f;
-    }
-  }
-  __syncthreads();
-  const int cell = t >> 2, part = t & 3;
-  const int64_t c = c0 + cell;
-  if (c >= K) return;
-  h16x8 hi, lo;
-#pragma unroll
-  for (int e = 0; e < 8; ++e) {
-    const float x = tile[part * 8 + e][cell];
-    hi[e] = (_Float16)x;
-    lo[e] = (_Float16)(x - (float)hi[e]);
-  }
-  _Float16* d = dst + c * 2 * Rp + (r0 >> 5) * 64 + part * 8;
-  *reinterpret_cast<h16x8*>(d) = hi;
-  *reinterpret_cast<h16x8*>(d + 32) = lo;
-}
-
 __global__ __launch_bounds__(256) void k_split_image_pair_scaled(const float* __restrict__ src1, const float* __restrict__ src2, int64_t rows,
                                                                  int64_t K, int64_t ld, int64_t Kp, const float* __restrict__ scale,
                                                                  _Float16* __restrict__ dst1, _Float16* __restrict__ dst2) {
@@ -1323,24 +1256,6 @@ int split_image_fixed(Ctx* ctx, const float* src, int64_t rows, int64_t K, int64
   hipLaunchKernelGGL(k_set_scale, dim3(1), dim3(1), 0, st, scale_dev, scale);
   hipLaunchKernelGGL(k_split_image_scaled, dim3((unsigned)((Kp + 255) / 256), (unsigned)std::min<int64_t>(rows, 65535)), dim3(256), 0, st,
                      src, rows, K, ld, Kp, scale_dev, static_cast<_Float16*>(dst));
-  SCL_HIP(ctx, hipGetLastError());
-  return SCLENS_OK;
-}
-
-int split_image_rows(Ctx* ctx, const float* src, int64_t rows, int64_t K, int64_t ld, void* dst, float* inv_scale_dev) {
-  if (rows <= 0) return SCLENS_OK;
-  hipLaunchKernelGGL(k_split_image_rows, dim3((unsigned)rows), dim3(256), 0, ctx->stream, src, K, ld, round_up(K, 32), static_cast<_Float16*>(dst),
-                     inv_scale_dev);
-  SCL_HIP(ctx, hipGetLastError());
-  return SCLENS_OK;
-}
-
-int split_image_transposed(Ctx* ctx, const float* src, int64_t rows, int64_t K, int64_t ld, void* dst, const float* scale_dev) {
-  if (rows <= 0 || K <= 0) return SCLENS_OK;
-  const int64_t gy = (round_up(rows, 32)) / 32;
-  if (gy > 65535) return ctx->fail(SCLENS_ERR_ARG, "split_image_transposed: too many rows");
-  hipLaunchKernelGGL(k_split_image_transposed, dim3((unsigned)((K + 63) / 64), (unsigned)gy), dim3(256), 0, ctx->stream, src, rows, K, ld,
-                     round_up(rows, 32), scale_dev, static_cast<_Float16*>(dst));
   SCL_HIP(ctx, hipGetLastError());
   return SCLENS_OK;
 }

@@ -2086,7 +2086,6 @@ int sb2st_f32(Ctx* ctx, const float* A, int64_t n, int64_t lda, double* d_dev, d
   SCL_WS(ctx, V2, float, "sbr.V2", (n + 64) * ldv2);  // spare rows: the back-transformation reads whole 64-float runs
   SCL_WS(ctx, TAU2, float, "sbr.TAU2", n * ldt);
   SCL_WS(ctx, done, unsigned, "sbr.done", n + 4);  // progress counters + abort word
-  LatStream lat(ctx);  // options pstage_cus / pstage_cu_first: the chase on a few CUs, the rest of the chip free for another stream
   hipStream_t st = ctx->stream;
   SCL_HIP(ctx, hipMemsetAsync(done, 0, sizeof(unsigned) * (n + 4), st));
   SCL_HIP(ctx, hipMemsetAsync(TAU2, 0, sizeof(float) * n * ldt, st));
@@ -2101,13 +2100,14 @@ int sb2st_f32(Ctx* ctx, const float* A, int64_t n, int64_t lda, double* d_dev, d
   int G = (int)std::min<int64_t>(cus > 0 ? cus : 64, n / (2 * SB) + 1);
   if (G < 1) G = 1;
   if (ctx->opt.chase_wgs > 0) G = std::max(1, std::min(G, (int)ctx->opt.chase_wgs));
-  // on the masked stream every workgroup must still be resident: three fit a CU; a quarter of the slots stays free, because the
-  // dispatcher deals workgroups to the XCDs without looking at the mask
-  if (lat.on()) G = std::max(1, std::min<int>(G, (int)(lat.cus() * 9 / 4)));
   SbrChaseArgs ca{Bd, n, V2, ldv2, TAU2, ldt, done};
   const int use_mb = (int)ctx->opt.chase_mb;
-  // (Round 3 tried a masked stream of every third CU with all ~235 workgroups: not all became resident and the chase ended through its
-  // bounded spin, profiles/r03_cfg4_ab_runs.log. LatStream takes a contiguous range of the driver's numbering and caps G.)
+  // (CU-masked streams for this and the other partial-chip stages were measured twice and removed. Round 3: every third CU, all ~235
+  // workgroups: not all became resident, the chase ended through its bounded spin. Round 5: a contiguous range of 64 / 96 / 128 CUs of
+  // the driver's numbering with the workgroups capped at 9/4 per CU: the chase takes 381 / 308 / 278 ms instead of 254, the second
+  // back-transformation 661 / 550 / 352 instead of 267 -- packed 2-3 per CU these stages are NOT idle waiters, they are bound by their
+  // CU's LDS / L2 delivery -- and a Gram product on another stream still gained nothing (eigensolve + Gram concurrently = their sum):
+  // a whole call 41.8 s instead of 29.0. profiles/r05_pipe_masks_chefsi_split.log.)
   if (use_mb) {
     const int R = G + 1, kmax = (int)(n / SB) + 2;  // slot of sweep s is free again once sweep s+1 has ended: before sweep s+G+1 starts
     SCL_WS(ctx, MB, unsigned long long, "sbr.MB", (int64_t)R * kmax * MBW);

@@ -835,7 +835,6 @@ static int sbr_q2_launch_build_t(Ctx* ctx, int64_t n, hipStream_t st) {
 int sbr_apply_q2(Ctx* ctx, int64_t n, float* Zt, int64_t m, int64_t ldz) {
   if (m <= 0) return SCLENS_OK;
   StageTimer tm(ctx, "sbr_q2");
-  LatStream lat(ctx, (m + 63) / 64 <= 256);  // up to n / 2 vectors at n = 30 016: 235 workgroups, one per CU unless the stream is masked
   const int64_t ldv2 = sbr_ldv2(n), ldt = n / SB + 2;
   const float* V2 = static_cast<const float*>(ctx->ws.count("sbr.V2") ? ctx->ws.at("sbr.V2").first : nullptr);
   const float* TAU2 = static_cast<const float*>(ctx->ws.count("sbr.TAU2") ? ctx->ws.at("sbr.TAU2").first : nullptr);

@@ -46,52 +46,8 @@ void Ctx::release_all() {
   // back-transformation that a values-only decomposition builds ahead and nobody consumes: their kernel must not outlive its
   // workspace (the block goes back to the pool and may be handed to another context at once)
   if (aux_stream) hipStreamSynchronize(aux_stream);
-  if (lat_stream) hipStreamSynchronize(lat_stream);
   for (auto& kv : ws) pool_free(kv.second.first, nullptr);
   ws.clear();
-}
-
-LatStream::LatStream(Ctx* ctx, bool enable) : c(ctx) {
-  const int64_t want = c->opt.pstage_cus, first = c->opt.pstage_cu_first;
-  if (!enable || want <= 0 || c->swapped_main) return;
-  if (c->lat_stream && (c->lat_cus != want || c->lat_first != first)) {
-    (void)hipStreamSynchronize(c->lat_stream);
-    (void)hipStreamDestroy(c->lat_stream);
-    c->lat_stream = nullptr;
-  }
-  if (!c->lat_stream) {
-    int cus = 0;
-    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, c->device) != hipSuccess || cus <= 0 || first < 0 || first + want > cus) {
-      (void)hipGetLastError();
-      return;
-    }
-    std::vector<uint32_t> mask((size_t)(cus + 31) / 32, 0u);
-    for (int64_t q = first; q < first + want; ++q) mask[(size_t)q >> 5] |= 1u << (q & 31);
-    if (hipExtStreamCreateWithCUMask(&c->lat_stream, (uint32_t)mask.size(), mask.data()) != hipSuccess) {
-      (void)hipGetLastError();
-      c->lat_stream = nullptr;
-      return;
-    }
-    for (int e = 0; e < 2; ++e)
-      if (!c->lat_ev[e] && hipEventCreateWithFlags(&c->lat_ev[e], hipEventDisableTiming) != hipSuccess) return;
-    c->lat_cus = want;
-    c->lat_first = first;
-  }
-  main = c->stream;
-  if (hipEventRecord(c->lat_ev[0], main) != hipSuccess || hipStreamWaitEvent(c->lat_stream, c->lat_ev[0], 0) != hipSuccess) {
-    (void)hipGetLastError();
-    return;
-  }
-  c->stream = c->lat_stream;
-  c->swapped_main = main;
-  active = true;
-}
-LatStream::~LatStream() {
-  if (!active) return;
-  (void)hipEventRecord(c->lat_ev[1], c->lat_stream);
-  c->stream = main;
-  c->swapped_main = nullptr;
-  (void)hipStreamWaitEvent(main, c->lat_ev[1], 0);
 }
 
 // ------------------------------------------------------------------------------------------------ utils

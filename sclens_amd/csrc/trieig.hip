@@ -461,7 +461,6 @@ int stein_f64(Ctx* ctx, const double* d_dev, const double* e_dev, int64_t n, con
   const int64_t m = hi - lo;
   if (m <= 0) return SCLENS_OK;
   StageTimer tm(ctx, "stein");
-  LatStream lat(ctx, (m + 63) / 64 <= 256);  // one thread per vector: a few hundred waves that would otherwise sit one per CU
   double* info = static_cast<double*>(ctx->workspace("tri.info", 8 * sizeof(double)));  // filled by stebz_f64
   if (!info) return SCLENS_ERR_OOM;
   // batch so that the six [n][B] workspaces stay below ~24 GB (one thread per eigenvector and a sequential recurrence of

@@ -234,3 +234,39 @@ def _sytrd_on(c, A, n, lda):
     for x in (dA, dd, de, dt):
         x.free()
     return out
+
+
+def test_release_scratch_hands_the_eigensolver_workspaces_back_and_the_next_call_rebuilds_them(ctx):
+    """sclens_hip_release_scratch (round 5): api.sclens() returns the idle scratch families of its contexts to the pool at the phase
+    boundaries. After a release the pool holds the bytes, the context's next decomposition allocates again and gives the same bits."""
+    import ctypes as C
+
+    from sclens_amd._lib import Context
+
+    n, lda = 1100, rup(1100, 32)
+    rng = np.random.default_rng(3)
+    B = rng.standard_normal((n, 300)).astype(np.float32)
+    A = np.zeros((n, lda), np.float32)
+    A[:, :n] = B @ B.T / 300
+    c2 = Context(ctx.device)
+    c2.set_option("two_stage", 1)
+    try:
+        out = []
+        for rep in range(2):
+            dA, dw, dZ = DevArray(c2, A), DevArray(c2, nbytes=8 * n), DevArray(c2, nbytes=4 * 200 * lda)
+            c2.check(c2.lib.sclens_hip_dev_eigh_f32(c2.h, dA.p, n, lda, dw.p, n - 200, n, dZ.p, lda))
+            c2.sync()
+            out.append((dw.get((n,), np.float64), dZ.get((200, lda), np.float32)))
+            for x in (dA, dw, dZ):
+                x.free()
+            cached0 = C.c_int64(0)
+            c2.lib.sclens_hip_pool_stats(c2.device, C.byref(cached0), None, None, None)
+            c2.release_scratch("eigensolver")
+            cached1 = C.c_int64(0)
+            c2.lib.sclens_hip_pool_stats(c2.device, C.byref(cached1), None, None, None)
+            assert cached1.value > cached0.value  # the workspaces went to the pool's idle list
+        assert np.array_equal(out[0][0], out[1][0]) and np.array_equal(out[0][1], out[1][1])
+        with pytest.raises(Exception):
+            c2.release_scratch("no such family")
+    finally:
+        c2.close()
