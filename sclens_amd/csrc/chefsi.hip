@@ -40,6 +40,12 @@ __global__ void k_sum_slabs(const float* __restrict__ part, int S, int64_t slab,
   out[i] = s;
 }
 
+// part[z][r][c] = 0 for the slabs of a split-K sum that a product with fewer slices does not write
+__global__ __launch_bounds__(256) void k_zero_slabs(float* __restrict__ part, int64_t slab, int64_t cols, int64_t ld) {
+  const int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (c < cols) part[(int64_t)blockIdx.z * slab + (int64_t)blockIdx.y * ld + c] = 0.f;
+}
+
 // res[r] = || Y[r,:] - theta[r] X[r,:] ||_2
 __global__ __launch_bounds__(256) void k_resid_rows(const float* __restrict__ Y, const float* __restrict__ X,
                                                     const float* __restrict__ theta, int64_t cols, int64_t ld,
@@ -145,18 +151,57 @@ int topk_chefsi(Ctx* ctx, const float* A, int64_t n, int64_t lda, int m, int m_s
   S = std::max(Bop ? 4 : 1, std::min(S, 8));
   // implicit operator: both products stream Bop once and are HBM-bound; S (second product) and S1 (first) cut the contractions
   // (measured at cfg4, 20 perturbations: S/S1 = 4/1 7.7 s, 9/3 7.5 s, 8/2 8.1 s, 16/6 25.8 s -- the products already run at
-  // about half of the HBM roofline and more slices do not help. Round 5 measured both products from split-fp16 images of Bop and of
-  // its transpose on the 256 x 256 split kernel, one power-of-two scale per block row: NOT faster -- a product with b = 64 rows pays
-  // the 256-row tile's operand delivery whatever the matrix instruction, 4.0 ms per pass either way, plus 15 ms per member for the two
-  // images: ensemble 4.5 against 4.0 s, 24 GB more per context; removed, profiles/r05_pipe_masks_chefsi_split.log. What would pay is
-  // a 64 x 256 tile that streams only Bop: DESIGN.md section 7.)
+  // about half of the HBM roofline and more slices do not help.)
   const int S1 = 1;
   const int64_t ldt = Bop ? round_up(Kop, 32) : 0;
   float *Tb = nullptr, *Tpart = nullptr;
+  // Round 5: the implicit operator on the fp16 matrix cores. Both products contract b = 64 rows against the whole 12 GB scaled matrix:
+  // 2 b n Kop flop per pass -- on the fp32 matrix cores that takes as long as the HBM pass itself and the two did not overlap (4.0-4.4 ms
+  // per pass where the bytes take 2.4). From split images (the same 4 bytes per entry, three matrix instructions at 16x the rate) on a
+  // 64 x 256 tile (gemm_split_skinny: the 256 x 256 split kernel was measured first and is NOT faster for 64 rows, it pays its tile's
+  // operand delivery: profiles/r05_pipe_masks_chefsi_split.log) the products stream Bop at HBM rate. Needs the image of Bop AND of its
+  // transpose (the first product contracts over the rows of Bop), built once per call; the block rows (V, then T = V Bop) get ONE
+  // POWER-OF-TWO SCALE PER ROW -- a Chebyshev sweep spreads the row norms by up to 1e5 -- multiplied back into the rows of the result
+  // (exact). `precision = 0` / option chefsi_split = 0: fp32 products.
+  const bool split_op = Bop && ctx->opt.split() && ctx->opt.chefsi_split != 0;
+  int SS1 = 1, SS2 = 1;  // split-K slices of the two split products
+  void *imgB = nullptr, *imgBt = nullptr, *imgV = nullptr, *imgT = nullptr;
+  float *scB = nullptr, *one = nullptr, *rsV = nullptr, *rsT = nullptr;
   if (Bop) {
     Tb = static_cast<float*>(ctx->workspace("che.T", sizeof(float) * (size_t)b * ldt));
     if (!Tb) return SCLENS_ERR_OOM;
-    const int nslab1 = S1;
+    if (split_op) {
+      // output tiles of 256 columns, two workgroups per CU: slices so that the grid fills whole rounds of the 512 slots
+      auto pick = [](int64_t tiles, int64_t K, int max_s) {
+        int best = 1;
+        double best_cost = 1e300;
+        for (int q = 1; q <= max_s; ++q) {
+          if (q > 1 && K / q < 2048) break;
+          const double rounds = (double)((tiles * q + 511) / 512);
+          const double cost = rounds / q + 0.01 * q;
+          if (cost < best_cost) { best_cost = cost; best = q; }
+        }
+        return best;
+      };
+      SS1 = ctx->opt.chefsi_split_s1 > 0 ? (int)ctx->opt.chefsi_split_s1 : pick((Kop + 255) / 256, n, 8);
+      SS2 = ctx->opt.chefsi_split_s2 > 0 ? (int)ctx->opt.chefsi_split_s2 : pick((n + 255) / 256, Kop, 16);
+      if (SS2 > S) SS2 = S;  // `part` holds S slabs
+      imgB = ctx->workspace("che.imgB", split_image_bytes(n, Kop));
+      imgBt = ctx->workspace("che.imgBt", split_image_bytes(Kop, n));
+      imgV = ctx->workspace("che.imgV", split_image_bytes(b, n));
+      imgT = ctx->workspace("che.imgT", split_image_bytes(b, Kop));
+      scB = static_cast<float*>(ctx->workspace("che.scB", 8 * sizeof(float)));
+      rsV = static_cast<float*>(ctx->workspace("che.rsV", 2 * b * sizeof(float)));
+      if (!imgB || !imgBt || !imgV || !imgT || !scB || !rsV) return SCLENS_ERR_OOM;
+      one = scB + 4;
+      rsT = rsV + b;
+      SCL_TRY(split_image_scaled(ctx, Bop, n, Kop, ldb, imgB, scB));
+      SCL_TRY(split_image_transposed(ctx, Bop, n, Kop, ldb, imgBt, scB));
+      const float h1 = 1.f;
+      SCL_HIP(ctx, hipMemcpyAsync(one, &h1, sizeof(float), hipMemcpyHostToDevice, st));
+      SCL_HIP(ctx, hipStreamSynchronize(st));  // `h1` is a local
+    }
+    const int nslab1 = split_op ? SS1 : S1;
     if (nslab1 > 1) {
       Tpart = static_cast<float*>(ctx->workspace("che.Tp", sizeof(float) * (size_t)nslab1 * b * ldt));
       if (!Tpart) return SCLENS_ERR_OOM;
@@ -190,6 +235,31 @@ int topk_chefsi(Ctx* ctx, const float* A, int64_t n, int64_t lda, int m, int m_s
     const float* V = V0 + (int64_t)r0 * ld;
     float* Pr = part + (int64_t)r0 * ld;
     const int rows = b - r0;
+    if (split_op) {
+      // T' = (D V) Bop from the images of V (row scales D) and of Bop'; then (E T') Bop' from the images of T' (row scales E) and of Bop,
+      // 64 block rows at a time; the row scales and 1 / div are multiplied back by the second product's epilogue
+      SCL_TRY(split_image_rows(ctx, V, rows, n, ld, imgV, rsV));
+      const size_t rbV = split_image_bytes(1, n), rbT = split_image_bytes(1, Kop);
+      for (int q0 = 0; q0 < rows; q0 += 64) {
+        const int qr = std::min(64, rows - q0);
+        SCL_TRY(gemm_split_skinny(ctx, static_cast<const char*>(imgV) + (size_t)q0 * rbV, one, rsV + q0, qr, imgBt, scB, Kop, n,
+                                  (SS1 > 1 ? Tpart : Tb) + (int64_t)q0 * ldt, ldt, SS1, round_up((n + SS1 - 1) / SS1, 32), (int64_t)b * ldt, 1.f));
+      }
+      if (SS1 > 1)
+        hipLaunchKernelGGL(k_sum_slabs, dim3((unsigned)(((int64_t)rows * ldt + 255) / 256)), dim3(256), 0, st, Tpart, SS1, (int64_t)b * ldt, Tb,
+                           (int64_t)rows * ldt);
+      SCL_TRY(split_image_rows(ctx, Tb, rows, Kop, ldt, imgT, rsT));
+      for (int q0 = 0; q0 < rows; q0 += 64) {
+        const int qr = std::min(64, rows - q0);
+        SCL_TRY(gemm_split_skinny(ctx, static_cast<const char*>(imgT) + (size_t)q0 * rbT, one, rsT + q0, qr, imgB, scB, n, Kop,
+                                  Pr + (int64_t)q0 * ld, ld, SS2, round_up((Kop + SS2 - 1) / SS2, 32), slab, 1.f / div));
+      }
+      if (SS2 < S)  // the slabs SS2 .. S - 1 of `part` are not written by this product: zero for the consumers, which sum S of them
+        hipLaunchKernelGGL(k_zero_slabs, dim3((unsigned)((n + 255) / 256), (unsigned)rows, (unsigned)(S - SS2)), dim3(256), 0, st,
+                           Pr + (int64_t)SS2 * slab, slab, n, ld);
+      SCL_HIP(ctx, hipGetLastError());
+      return SCLENS_OK;
+    }
     if (Bop) {
       // A = Bop Bop' / div is never formed: V A = (V Bop) Bop' / div, two products that stream Bop once each
       // (2 * 2 b n Kop flop against n^2 Kop for the Gram matrix: cheaper below ~n / (4 b) applications)

@@ -33,6 +33,8 @@ namespace scl {
   X(chefsi_b0, 0)           /* block size of the partial eigensolver (0: min_pc + 40 rounded up to 32) */                          \
   X(chefsi_tail_gap_micro, -1) /* gap-aware target of the tail pairs x 1e6 (-1: what the caller asks for) */                       \
   X(chefsi_lock, 1)                                                                                                                \
+  X(chefsi_split, 1)        /* implicit block products (blocks of <= 64 rows) from split images on the 64 x 256 kernel (0: fp32) */  \
+  X(chefsi_split_s1, 0) X(chefsi_split_s2, 0) /* split-K slices of its two products (0: chosen to fill whole rounds of CU slots) */   \
   X(sy2sb_split_min, 4096)  /* trailing updates of the band reduction from split operands from this many rows (0: never) */        \
   X(sy2sb_split_scales, 2)  /* 2: separate scales for reflector and Z columns, 1: one scale (round 3) */                           \
   X(sy2sb_zmax, 1)          /* largest |Z| from the kernel that writes Z (0: by a pass over the operands) */                       \
@@ -285,6 +287,14 @@ int corr_colabsmax_split(Ctx* ctx, const void* Aimg, int64_t M, const void* Bimg
 int split_image_scaled(Ctx* ctx, const float* src, int64_t rows, int64_t K, int64_t ld, void* dst, float* scale_dev);
 // the same under a FIXED power-of-two scale (no pass over the data): operands whose entries are at most 1 in magnitude
 int split_image_fixed(Ctx* ctx, const float* src, int64_t rows, int64_t K, int64_t ld, void* dst, float* scale_dev, float scale);
+// one power-of-two scale PER ROW (largest |entry| of the row -> [2^13, 2^14)); inv_scale_dev[r] = 1 / scale of row r (exact)
+int split_image_rows(Ctx* ctx, const float* src, int64_t rows, int64_t K, int64_t ld, void* dst, float* inv_scale_dev);
+// the split image of the TRANSPOSE of src [rows][K] (K image rows of round_up(rows, 32) entries) under the scale scale_dev[0]
+int split_image_transposed(Ctx* ctx, const float* src, int64_t rows, int64_t K, int64_t ld, void* dst, const float* scale_dev);
+// C_s[M <= 64][N] = post * rowscale[m] * A B' over K-slice s from split images: 64 x 256 tiles, two workgroups per CU, for products that
+// stream a large B against a block of at most 64 rows (slab s at C + s * c_split_off; C is not read)
+int gemm_split_skinny(Ctx* ctx, const void* Aimg, const float* sA, const float* rowscale, int64_t M, const void* Bimg, const float* sB, int64_t N,
+                      int64_t K, float* C, int64_t ldc, int splits, int64_t k_chunk, int64_t c_split_off, float post);
 // C_s = P Q' over the K-slice s of `splits` (slab s at C + s * c_split_off, row pitch ldc; C is not read): split-K partials
 int gemm_split_nt(Ctx* ctx, const void* Pimg, const float* sP, int64_t M, const void* Qimg, const float* sQ, int64_t N, int64_t K, float* C,
                   int64_t ldc, int splits, int64_t k_chunk, int64_t c_split_off);

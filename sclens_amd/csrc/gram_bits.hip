@@ -701,6 +701,172 @@ __global__ __launch_bounds__(256) void k_split_image_scaled(const float* __restr
   }
 }
 
+// The split image of a short, fat block (the b rows of a subspace-iteration block: magnitudes differ by up to 1e5 from row to row) with
+// ONE POWER-OF-TWO SCALE PER ROW: row r is scaled so that its largest |entry| lands in [2^13, 2^14) and inv_scale[r] receives the
+// reciprocal (exact), which the consumer multiplies back into row r of the product. One workgroup per row.
+__global__ __launch_bounds__(256) void k_split_image_rows(const float* __restrict__ src, int64_t K, int64_t ld, int64_t Kp,
+                                                          _Float16* __restrict__ dst, float* __restrict__ inv_scale) {
+  __shared__ float sw[4];
+  const int64_t r = blockIdx.x;
+  const float* a = src + r * ld;
+  float mx = 0.f;
+  for (int64_t k = threadIdx.x; k < K; k += 256) mx = fmaxf(mx, fabsf(a[k]));
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+  if ((threadIdx.x & 63) == 0) sw[threadIdx.x >> 6] = mx;
+  __syncthreads();
+  mx = fmaxf(fmaxf(sw[0], sw[1]), fmaxf(sw[2], sw[3]));
+  float sc = 1.f;
+  if (mx > 0.f && mx < 3.0e38f) {
+    int ex = 0;
+    (void)frexpf(mx, &ex);
+    int e = 14 - ex;
+    e = e > 100 ? 100 : (e < -100 ? -100 : e);  // sc and 1 / sc stay normal numbers
+    sc = ldexpf(1.f, e);
+  }
+  if (threadIdx.x == 0) inv_scale[r] = 1.f / sc;
+  _Float16* d0 = dst + r * 2 * Kp;
+  for (int64_t k = threadIdx.x; k < Kp; k += 256) {
+    const float x = k < K ? a[k] * sc : 0.f;
+    const _Float16 hi = (_Float16)x;
+    _Float16* d = d0 + (k >> 5) * 64 + (k & 31);
+    d[0] = hi;
+    d[32] = (_Float16)(x - (float)hi);
+  }
+}
+
+// The split image of the TRANSPOSE of src [rows][K] (image rows = the K columns of src, contraction index = its rows) under the scale
+// scale[0] that the image of src itself carries: tiles of 32 rows x 64 columns through LDS, 16-byte stores of eight hi / eight lo pieces.
+__global__ __launch_bounds__(256) void k_split_image_transposed(const float* __restrict__ src, int64_t rows, int64_t K, int64_t ld, int64_t Rp,
+                                                                const float* __restrict__ scale, _Float16* __restrict__ dst) {
+  __shared__ float tile[32][65];
+  const int64_t r0 = (int64_t)blockIdx.y * 32, c0 = (int64_t)blockIdx.x * 64;
+  const int t = threadIdx.x;
+  const float sc = scale[0];
+  {
+    const int rr = t >> 3, cc = (t & 7) * 8;
+    const int64_t r = r0 + rr;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int64_t c = c0 + cc + e;
+      tile[rr][cc + e] = (r < rows && c < K) ? src[r * ld + c] * sc : 0.f;
+    }
+  }
+  __syncthreads();
+  const int cell = t >> 2, part = t & 3;
+  const int64_t c = c0 + cell;
+  if (c >= K) return;
+  h16x8 hi, lo;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const float x = tile[part * 8 + e][cell];
+    hi[e] = (_Float16)x;
+    lo[e] = (_Float16)(x - (float)hi[e]);
+  }
+  _Float16* d = dst + c * 2 * Rp + (r0 >> 5) * 64 + part * 8;
+  *reinterpret_cast<h16x8*>(d) = hi;
+  *reinterpret_cast<h16x8*>(d + 32) = lo;
+}
+
+// ---- C_s[M <= 64][N] = A B' from split images, for a short, fat A (the block of the partial eigensolver against the scaled matrix) ----
+// The 256 x 256 kernel spends a stage (64 KB of operands in flight per CU) waiting for the slowest of its DMA pieces, ~6 000 clocks,
+// whatever the matrix instruction: a product with 64 rows on it pays for 256 -- 4 ms per pass over a 12 GB operand, as long as the fp32
+// product it would replace (profiles/r05_pipe_masks_chefsi_split.log). Here the tile is 64 x 256: a stage is 8 KB of A + 32 KB of B, two
+// stage buffers are 80 KB, so TWO workgroups share a CU and 64 KB of the streamed operand are in flight per CU: the kernel moves B at
+// the rate HBM delivers it. 8 waves; wave w owns the 32 columns 32 w .. of the tile for both 32-row tiles of A (2 x 16 accumulators).
+// rowscale (nullable): row m of the result is multiplied by rowscale[m] (the per-row power-of-two scales of split_image_rows).
+struct SplitSkinnyArgs {
+  const _Float16* A;  // split image, M <= 64 rows
+  const _Float16* B;  // split image, N rows
+  const float* sA;    // scales (device); sA may be a constant 1 when A carries per-row scales
+  const float* sB;
+  const float* rowscale;
+  int64_t M, N, Kp;
+  float* C;
+  int64_t ldc;
+  int64_t kt_chunk;     // 32-deep steps per K-slice (gridDim.y slices)
+  int64_t c_split_off;  // slab pitch
+  float post;
+};
+__global__ __launch_bounds__(512, 4) void gemm_split_skinny_kernel(SplitSkinnyArgs a) {
+  constexpr int OPA = 64 * 128, OPB = 256 * 128, STAGE = OPA + OPB;
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+  const int64_t n0 = (int64_t)blockIdx.x * 256;
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int l31 = lane & 31, h = lane >> 5, srow = lane >> 3, sq = lane & 7;
+  int64_t kt_lo = (int64_t)blockIdx.y * a.kt_chunk, nkt = a.Kp / 32;
+  {
+    const int64_t kt_hi = kt_lo + a.kt_chunk;
+    nkt = kt_hi < nkt ? kt_hi : nkt;
+    if (kt_lo > nkt) kt_lo = nkt;
+  }
+  float* C = a.C + (int64_t)blockIdx.y * a.c_split_off;
+  // DMA pieces of a stage: 8 of A (wave w moves rows 8 w .. 8 w + 7) and 32 of B (wave w moves rows 32 w .. 32 w + 31 in four pieces);
+  // chunk q of row r lands in slot q ^ ((r >> 1) & 7) by permuting the source
+  const unsigned rowb = (unsigned)(4 * a.Kp);
+  const unsigned char* baseA = reinterpret_cast<const unsigned char*>(a.A);
+  const unsigned char* baseB = reinterpret_cast<const unsigned char*>(a.B) + n0 * rowb;
+  const int mlast = (int)(a.M - 1), nlast = (int)((a.N - 1 - n0 < 255) ? a.N - 1 - n0 : 255);
+  unsigned offA, offB[4];
+  {
+    const int r = wid * 8 + srow;
+    offA = (unsigned)(r < mlast ? r : mlast) * rowb + 16u * (unsigned)(sq ^ ((r >> 1) & 7));
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int r = (wid * 4 + i) * 8 + srow;
+    offB[i] = (unsigned)(r < nlast ? r : nlast) * rowb + 16u * (unsigned)(sq ^ ((r >> 1) & 7));
+  }
+  auto stage = [&](int buf, int64_t kt) {
+    unsigned char* As = lds + buf * STAGE;
+    unsigned char* Bs = As + OPA;
+    const unsigned koff = (unsigned)kt * 128u;
+    __builtin_amdgcn_global_load_lds((glb_void_t*)(baseA + (offA + koff)), (lds_void_t*)(As + wid * 1024), 16, 0, 0);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      __builtin_amdgcn_global_load_lds((glb_void_t*)(baseB + (offB[i] + koff)), (lds_void_t*)(Bs + (wid * 4 + i) * 1024), 16, 0, 0);
+  };
+  v16f acc[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
+  const int sw = (l31 >> 1) & 7;
+  const int fa = l31 * 128, fb = OPA + (wid * 32 + l31) * 128;
+  if (kt_lo < nkt) stage(0, kt_lo);
+  __syncthreads();
+  for (int64_t kt = kt_lo; kt < nkt; ++kt) {
+    const int buf = (int)((kt - kt_lo) & 1);
+    if (kt + 1 < nkt) stage(buf ^ 1, kt + 1);
+    const unsigned char* S = lds + buf * STAGE;
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {  // 16 k per step: lane half h takes chunk 2 kk + h (hi) and 4 + 2 kk + h (lo)
+      const int sh = ((2 * kk + h) ^ sw) << 4, sl = ((4 + 2 * kk + h) ^ sw) << 4;
+      const h16x8 bh = *reinterpret_cast<const h16x8*>(S + fb + sh), bl = *reinterpret_cast<const h16x8*>(S + fb + sl);
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const h16x8 ah = *reinterpret_cast<const h16x8*>(S + fa + i * 4096 + sh), al = *reinterpret_cast<const h16x8*>(S + fa + i * 4096 + sl);
+        acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc[i], 0, 0, 0);
+        acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, acc[i], 0, 0, 0);
+        acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc[i], 0, 0, 0);
+      }
+    }
+    __syncthreads();
+  }
+  // D layout of a 32 x 32 tile: column = lane & 31 (row of B = output column), rows (e & 3) + 8 (e >> 2) + 4 h
+  const float alpha = a.post / (a.sA[0] * a.sB[0]);
+  const int64_t col = n0 + wid * 32 + l31;
+  if (col < a.N) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int64_t row = i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+        if (row < a.M) C[row * a.ldc + col] = acc[i][e] * (a.rowscale ? alpha * a.rowscale[row] : alpha);
+      }
+  }
+}
+
 __global__ __launch_bounds__(256) void k_split_image_pair_scaled(const float* __restrict__ src1, const float* __restrict__ src2, int64_t rows,
                                                                  int64_t K, int64_t ld, int64_t Kp, const float* __restrict__ scale,
                                                                  _Float16* __restrict__ dst1, _Float16* __restrict__ dst2) {
@@ -1256,6 +1422,39 @@ int split_image_fixed(Ctx* ctx, const float* src, int64_t rows, int64_t K, int64
   hipLaunchKernelGGL(k_set_scale, dim3(1), dim3(1), 0, st, scale_dev, scale);
   hipLaunchKernelGGL(k_split_image_scaled, dim3((unsigned)((Kp + 255) / 256), (unsigned)std::min<int64_t>(rows, 65535)), dim3(256), 0, st,
                      src, rows, K, ld, Kp, scale_dev, static_cast<_Float16*>(dst));
+  SCL_HIP(ctx, hipGetLastError());
+  return SCLENS_OK;
+}
+
+int split_image_rows(Ctx* ctx, const float* src, int64_t rows, int64_t K, int64_t ld, void* dst, float* inv_scale_dev) {
+  if (rows <= 0) return SCLENS_OK;
+  hipLaunchKernelGGL(k_split_image_rows, dim3((unsigned)rows), dim3(256), 0, ctx->stream, src, K, ld, round_up(K, 32), static_cast<_Float16*>(dst),
+                     inv_scale_dev);
+  SCL_HIP(ctx, hipGetLastError());
+  return SCLENS_OK;
+}
+
+int split_image_transposed(Ctx* ctx, const float* src, int64_t rows, int64_t K, int64_t ld, void* dst, const float* scale_dev) {
+  if (rows <= 0 || K <= 0) return SCLENS_OK;
+  const int64_t gy = (round_up(rows, 32)) / 32;
+  if (gy > 65535) return ctx->fail(SCLENS_ERR_ARG, "split_image_transposed: too many rows");
+  hipLaunchKernelGGL(k_split_image_transposed, dim3((unsigned)((K + 63) / 64), (unsigned)gy), dim3(256), 0, ctx->stream, src, rows, K, ld,
+                     round_up(rows, 32), scale_dev, static_cast<_Float16*>(dst));
+  SCL_HIP(ctx, hipGetLastError());
+  return SCLENS_OK;
+}
+
+int gemm_split_skinny(Ctx* ctx, const void* Aimg, const float* sA, const float* rowscale, int64_t M, const void* Bimg, const float* sB, int64_t N,
+                      int64_t K, float* C, int64_t ldc, int splits, int64_t k_chunk, int64_t c_split_off, float post) {
+  if (M <= 0 || N <= 0) return SCLENS_OK;
+  if (M > 64) return ctx->fail(SCLENS_ERR_ARG, "gemm_split_skinny: at most 64 rows");
+  if (splits < 1 || (splits > 1 && k_chunk % 32 != 0)) return ctx->fail(SCLENS_ERR_ARG, "gemm_split_skinny: k_chunk must be a multiple of 32");
+  const int64_t Kp = round_up(K, 32), bn = (N + 255) / 256;
+  constexpr int LDS_BYTES = 2 * (64 * 128 + 256 * 128);
+  SplitSkinnyArgs a{static_cast<const _Float16*>(Aimg), static_cast<const _Float16*>(Bimg), sA, sB, rowscale, M, N, Kp, C, ldc,
+                    splits > 1 ? k_chunk / 32 : Kp / 32, c_split_off, post};
+  SCL_TRY(ensure_dyn_lds(ctx, reinterpret_cast<const void*>(gemm_split_skinny_kernel), LDS_BYTES));
+  hipLaunchKernelGGL(gemm_split_skinny_kernel, dim3((unsigned)bn, (unsigned)splits), dim3(512), LDS_BYTES, ctx->stream, a);
   SCL_HIP(ctx, hipGetLastError());
   return SCLENS_OK;
 }
