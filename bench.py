@@ -331,7 +331,7 @@ def compact_line(full, detail_path=None):
         if isinstance(line["config"].get(k), str) and len(line["config"][k]) > 220:
             line["config"][k] = line["config"][k][:217] + "..."
     obs = full.get("observed", {})
-    line["observed"] = {k: obs[k] for k in ("signals", "robust_signals", "search_iters", "p_", "hbm_in_use_GB_after_timed_steps") if k in obs}
+    line["observed"] = {k: obs[k] for k in ("signals", "robust_signals", "search_iters", "p_", "hbm_in_use_GB_after_timed_steps", "hbm_peak_live_GB") if k in obs}
     dec = obs.get("decisions_per_step") or []
     if dec:
         line["observed"]["wall_s_per_step"] = [d.get("wall_s") for d in dec][:40]
@@ -532,6 +532,7 @@ def main():
             t_step = time.perf_counter() - ts
             n_warm += 1
         fence()
+        ctx.lib.sclens_hip_pool_peak(ctx.device, 1)  # peak of the library's live device bytes over the timed steps
         n_steps, decisions = 0, []
         t0 = time.perf_counter()
         for s in range(steps_req):
@@ -548,6 +549,7 @@ def main():
         try:  # device memory in use on this rank's GPU after the timed steps (the library's pool keeps the call's blocks cached)
             free_b, total_b = torch.cuda.mem_get_info(local_rank)
             run_config.hbm_in_use_gb = round((total_b - free_b) / 1e9, 1)
+            run_config.hbm_peak_live_gb = round(ctx.lib.sclens_hip_pool_peak(ctx.device, 0) / 1e9, 1)
         except Exception:
             run_config.hbm_in_use_gb = None
         if world > 1:  # MAX over the ranks (through the library's communicator when there is one)
@@ -603,6 +605,7 @@ def main():
                          "phase_s_rank0_last_step": dict({"draws_host": round(main_r["draws_s"], 4)}, **res.get("phase_s", {})),
                          "decisions_per_step": main_r["decisions"],
                          "hbm_in_use_GB_after_timed_steps": getattr(run_config, "hbm_in_use_gb", None),
+                         "hbm_peak_live_GB": getattr(run_config, "hbm_peak_live_gb", None),
                          "search_job_s_last_step": [list(q) for q in res.get("search_job_s", [])],
                          "first_phase_jobs_s_last_step": [list(q) for q in res.get("first_phase_s", [])]},
         }

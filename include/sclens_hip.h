@@ -87,6 +87,8 @@ int sclens_hip_copy_options(sclens_hip_ctx* dst, const sclens_hip_ctx* src);
  * SCLENS_HIP_POOL_MAX_GB = the cap. */
 int sclens_hip_trim(int device_id);
 int sclens_hip_pool_set_cap(int device_id, int64_t bytes);
+/* the largest number of bytes the library held at once on the device (live blocks, the idle cache not counted) since the last reset */
+int64_t sclens_hip_pool_peak(int device_id, int reset);
 /* A context keeps its scratch (grow-only named workspaces) until it is destroyed; between the phases of one sclens() call most of it is
  * idle -- the eigensolver's 30-40 GB per context during the ensemble, the Gram images after the first decompositions. This hands one
  * family of a context's scratch back to the pool ("eigensolver", "gram", "chefsi", "corr" or "all"), where the next phase's requests of

@@ -44,6 +44,7 @@ SIGNATURES = {
     "sclens_hip_stream": (vp, [vp]),
     "sclens_hip_trim": (C.c_int, [C.c_int]),
     "sclens_hip_pool_set_cap": (C.c_int, [C.c_int, i64]),
+    "sclens_hip_pool_peak": (i64, [C.c_int, C.c_int]),
     "sclens_hip_release_scratch": (C.c_int, [vp, C.c_char_p]),
     "sclens_hip_pool_stats": (C.c_int, [C.c_int, c_i64p, c_i64p, c_i64p, c_i64p]),
     "sclens_hip_symv_probe": (C.c_int, [vp, i64, c_i64p, c_f64p, c_f64p]),

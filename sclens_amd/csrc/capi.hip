@@ -638,6 +638,7 @@ int sclens_hip_release_scratch(sclens_hip_ctx* h, const char* family) {
   }
   return SCLENS_OK;
 }
+int64_t sclens_hip_pool_peak(int device_id, int reset) { return (int64_t)scl::pool_peak(device_id, reset != 0); }
 int sclens_hip_pool_set_cap(int device_id, int64_t bytes) {
   scl::pool_set_cap(device_id, (long long)bytes);
   return SCLENS_OK;

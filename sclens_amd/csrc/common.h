@@ -226,7 +226,8 @@ static inline int64_t round_up(int64_t x, int64_t m) { return (x + m - 1) / m * 
 hipError_t pool_malloc(void** p, size_t bytes);
 void pool_free(void* p, hipStream_t stream);
 void pool_trim(int device);  // give cached blocks back to the driver (device < 0: all devices)
-void pool_set_cap(int device, long long bytes);  // idle bytes kept per device (bytes < 0: the default rule)
+void pool_set_cap(int device, long long bytes);
+size_t pool_peak(int device, bool reset);  // peak of the live bytes since the last reset  // idle bytes kept per device (bytes < 0: the default rule)
 void pool_stats(int device, size_t* cached, size_t* live, size_t* hits, size_t* misses);
 
 // raise a kernel's dynamic-LDS limit once per context (= per device; a process-wide `static` would cover only the first device)

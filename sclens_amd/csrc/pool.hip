@@ -7,7 +7,6 @@
 //
 // Ordering: a block is only put on the free list by pool_free(p, stream) AFTER `stream` (the stream of the context that used it)
 // has been synchronised, so a later owner on another stream never races with pending work on the block.
-#include <atomic>
 #include <map>
 #include <mutex>
 #include <unordered_map>
@@ -19,21 +18,11 @@ namespace scl {
 namespace {
 struct DevPool {
   std::multimap<size_t, void*> free_blocks;  // size -> block
-  size_t cached = 0, live = 0, hits = 0, misses = 0;
+  size_t cached = 0, live = 0, hits = 0, misses = 0, peak = 0;  // peak: largest `live` since the last reset
 };
 std::mutex g_mu;
 std::map<int, DevPool> g_pool;                              // by device
 std::unordered_map<void*, std::pair<int, size_t>> g_live;   // block -> (device, size)
-// EXPERIMENT (round 5, SCLENS_HIP_POOL_STAGGER=1): large blocks start at a pseudo-random multiple of 4 KB inside a 2 MB pad instead of on
-// a 2 MB boundary, so that which buffers of a decomposition alias modulo the memory system's interleave no longer depends on the order
-// in which a context first touched its workspaces (the search phase runs 5-10 % slower after some first-phase schedules, same kernels,
-// same bits: DESIGN.md section 5)
-std::unordered_map<void*, void*> g_base;  // user pointer -> allocation base (staggered blocks only)
-bool pool_stagger() {
-  static const bool on = getenv("SCLENS_HIP_POOL_STAGGER") && atoi(getenv("SCLENS_HIP_POOL_STAGGER")) != 0;
-  return on;
-}
-
 bool pool_enabled() {
   static const bool on = !(getenv("SCLENS_HIP_POOL") && atoi(getenv("SCLENS_HIP_POOL")) == 0);
   return on;
@@ -75,30 +64,8 @@ size_t size_class(size_t bytes) {
   if (bytes < (1u << 20)) return (bytes + 511) & ~(size_t)511;
   return (bytes + ((size_t)2 << 20) - 1) & ~(((size_t)2 << 20) - 1);  // 2 MB granules
 }
-void raw_free(void* user) {  // under g_mu or for a block no longer in any table
-  auto it = g_base.find(user);
-  if (it != g_base.end()) {
-    hipFree(it->second);
-    g_base.erase(it);
-  } else {
-    hipFree(user);
-  }
-}
-hipError_t raw_malloc(void** p, size_t sz) {  // g_mu NOT held
-  if (!pool_stagger() || sz < ((size_t)64 << 20)) return hipMalloc(p, sz);
-  static std::atomic<unsigned> counter{0};
-  void* base = nullptr;
-  hipError_t e = hipMalloc(&base, sz + ((size_t)2 << 20));
-  if (e != hipSuccess) return e;
-  const unsigned c = counter.fetch_add(1) + 1;
-  const size_t off = (size_t)((c * 2654435761u) >> 23) % 512 * 4096;
-  *p = static_cast<char*>(base) + off;
-  std::lock_guard<std::mutex> lk(g_mu);
-  g_base[*p] = base;
-  return hipSuccess;
-}
 void trim_locked(DevPool& dp) {
-  for (auto& kv : dp.free_blocks) raw_free(kv.second);
+  for (auto& kv : dp.free_blocks) hipFree(kv.second);
   dp.free_blocks.clear();
   dp.cached = 0;
 }
@@ -120,6 +87,7 @@ hipError_t pool_malloc(void** p, size_t bytes) {
       *p = it->second;
       dp.cached -= it->first;
       dp.live += it->first;
+      if (dp.live > dp.peak) dp.peak = dp.live;
       g_live[*p] = {dev, it->first};
       dp.free_blocks.erase(it);
       dp.hits += 1;
@@ -127,18 +95,19 @@ hipError_t pool_malloc(void** p, size_t bytes) {
     }
     dp.misses += 1;
   }
-  e = raw_malloc(p, sz);
+  e = hipMalloc(p, sz);
   if (e != hipSuccess) {  // give the cache back and try once more
     {
       std::lock_guard<std::mutex> lk(g_mu);
       trim_locked(g_pool[dev]);
     }
     (void)hipGetLastError();
-    e = raw_malloc(p, sz);
+    e = hipMalloc(p, sz);
     if (e != hipSuccess) return e;
   }
   std::lock_guard<std::mutex> lk(g_mu);
   g_pool[dev].live += sz;
+  if (g_pool[dev].live > g_pool[dev].peak) g_pool[dev].peak = g_pool[dev].live;
   g_live[*p] = {dev, sz};
   return hipSuccess;
 }
@@ -163,7 +132,8 @@ void pool_free(void* p, hipStream_t stream) {
   DevPool& dp = g_pool[dev];
   dp.live -= sz;
   if (dp.cached + sz > pool_cap_bytes(dev)) {
-    raw_free(p);  // under the lock: the staggered block's base is looked up in g_base
+    lk.unlock();
+    hipFree(p);
     return;
   }
   dp.free_blocks.emplace(sz, p);
@@ -186,6 +156,14 @@ void pool_set_cap(int device, long long bytes) {  // bytes < 0: back to the defa
   std::lock_guard<std::mutex> lk(g_mu);
   if (bytes < 0) g_caps.erase(device);
   else g_caps[device] = (size_t)bytes;
+}
+
+size_t pool_peak(int device, bool reset) {  // largest number of bytes the library held at once on the device since the last reset
+  std::lock_guard<std::mutex> lk(g_mu);
+  DevPool& dp = g_pool[device];
+  const size_t p = dp.peak;
+  if (reset) dp.peak = dp.live;
+  return p;
 }
 
 void pool_stats(int device, size_t* cached, size_t* live, size_t* hits, size_t* misses) {

@@ -95,7 +95,7 @@ def test_spectrum_of_the_shipped_arithmetic_against_float64(ctx, precision):
     c2.set_option("precision", precision)
     try:
         res = api.sclens(X, draws=api.make_draws_native(X, seed=int(z["draw_seed"]), device_candidates=True), ctx=c2, n_perturb=2,
-                         max_search_iters=2, streams=1, keep_intermediates=True)
+                         max_search_iters=5, streams=1, keep_intermediates=True)  # five: the smallest cap that leaves p_ < 1 (:756-760)
     finally:
         c2.close()
     L64, lmax = z["L"], float(z["L"][-1])

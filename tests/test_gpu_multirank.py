@@ -32,8 +32,9 @@ def _bench(*args, timeout=900):
         assert len(lines) == 1 and len(lines[0]) <= 4096, r.stdout[-2000:]
         line = json.loads(lines[0])
         full = json.load(open(env["SCLENS_BENCH_DETAIL"]))
-    for key in ("metric", "value", "unit", "n_gpus", "steps", "ms_per_step", "dtype", "config"):
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "ms_per_step", "dtype"):
         assert line[key] == full[key], key
+    assert all(full["config"][k] == v for k, v in line["config"].items())  # the line's config is a subset of the full record's
     return full
 
 
