@@ -411,6 +411,9 @@ def main():
     ap.add_argument("--precision", type=int, default=1, choices=[0, 1], help="context option precision of the timed steps (1: split-fp16 products)")
     ap.add_argument("--extra-configs", default="", help="comma-separated further configs timed once each after the main one (reported under `extra`)")
     ap.add_argument("--seed-base", type=int, default=1000, help="timed step s draws with seed seed_base + s (warm-up steps: seed_base - 1 - w)")
+    ap.add_argument("--ballast-gb", type=float, default=0.0,
+                    help="diagnostic: hold this much extra device memory for the whole run (how close to a full HBM may the footprint come "
+                         "before kernels slow down? DESIGN.md section 5)")
     ap.add_argument("--verbose", action="store_true")
     ap.add_argument("--stage-timing", action="store_true", help="per-stage HIP-event totals on stderr (adds syncs)")
     args = ap.parse_args()
@@ -443,6 +446,7 @@ def main():
     from sclens_amd.shard import Shard
     from sclens_amd.synth import synth_counts
 
+    ballast = torch.empty(int(args.ballast_gb * 1e9), dtype=torch.uint8, device=dev) if args.ballast_gb > 0 else None  # noqa: F841
     ctx = Context(local_rank)
     ctx.set_option("precision", args.precision)
     # the library's own RCCL communicator (csrc/comm.hip); torch.distributed only launched the ranks and ships the unique id

@@ -1330,7 +1330,7 @@ def sclens(inp_df, device_="gpu", th=60, p_step=0.001, n_perturb=20, centering="
                 w_bin = holder
         # the split images of the dense Gram products (12 GB per context at 100 000 x 30 000) are idle from here on: back to the pool,
         # where the union pattern and the search's workspaces find them
-        for c_ in ([] if os.environ.get("SCLENS_NO_RELEASE") else [ctx] + wctx):
+        for c_ in [ctx] + wctx:
             c_.release_scratch("gram")
         lap("spectra_signal_vectors_vr2")
         pat, z1, z2 = pat_future.result()
@@ -1453,7 +1453,7 @@ def sclens(inp_df, device_="gpu", th=60, p_step=0.001, n_perturb=20, centering="
             # the eigensolver's scratch (band reduction, chase, inverse iteration, both back-transformations: 30-40 GB per context at
             # 100 000 x 30 000) and the search statistic's images are idle during the ensemble, whose partial eigensolver wants 24 GB of
             # split images per context instead
-            for c_ in ([] if os.environ.get("SCLENS_NO_RELEASE") else [ctx] + wctx):
+            for c_ in [ctx] + wctx:
                 c_.release_scratch("eigensolver")
                 c_.release_scratch("corr")
             lap("sparsity_search")
