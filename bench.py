@@ -213,14 +213,15 @@ def stage_probe(ctx, X, N, M):
     return stages
 
 
-# HBM traffic of ONE two-stage eigensolve of order 30 016 with 15 008 vectors (the roofline's launch) on the round-4 build, from
+# HBM traffic of ONE two-stage eigensolve of order 30 016 with 15 008 vectors (the roofline's launch) on the round-5 build, from
 # separate `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` passes over scripts/perf_eig.py (counters collected for the kernels that
-# move the bytes, --kernel-include-regex; profiles/r04_pmc_eig/summary.txt): 939 GB fetched as counted + 416 GB for the gfx950
-# half-count of 16-byte-per-lane streaming reads (MI355X_MICROARCH.md, HBM) on the large-tile GEMM operand streams and the Q2 images
-# + 941 GB written = 2.30e12 B, 1.07 x the algorithmic bytes of the stages. A constant measured on this build at this size, not in
-# this run (a PMC pass serialises every profiled dispatch); the line carries it only for the workload it was measured on.
-PMC_EIG_TRAFFIC = {"bytes": 2.296e12, "n": 30016, "vectors": 15008, "algorithmic_bytes": 2.15e12,
-                       "source": "profiles/r04_pmc_eig/summary.txt"}
+# move the bytes, --kernel-include-regex; profiles/r05_pmc_eig/summary.txt): 890 GB fetched as counted + 673 GB for the gfx950
+# half-count of 16-byte-per-lane streaming reads (MI355X_MICROARCH.md, HBM) on the operand streams of the 256 x 256 kernels, the A22
+# tiles of `sbr_w_split` and the Q2 images + 842 GB written = 2.40e12 B, 1.12 x the algorithmic bytes of the stages. A constant
+# measured on this build at this size, not in this run (a PMC pass serialises every profiled dispatch); the line carries it only for
+# the workload it was measured on.
+PMC_EIG_TRAFFIC = {"bytes": 2.404e12, "n": 30016, "vectors": 15008, "algorithmic_bytes": 2.15e12,
+                       "source": "profiles/r05_pmc_eig/summary.txt"}
 
 
 # A full-size CPU data point kept in the repository (profiles/r02_signal_count_cfg4.json, GPU box, 16 usable CPUs): LAPACK dsyevd,
@@ -536,8 +537,7 @@ def main():
             t_step = time.perf_counter() - ts
             n_warm += 1
         fence()
-        ctx.lib.sclens_hip_pool_peak(ctx.device, 1)  # peak of the library's live device bytes over the timed steps
-        n_steps, decisions = 0, []
+        n_steps, decisions, phase_peaks = 0, [], {}  # phase_peaks: largest live device bytes of the library's pool per phase, timed steps
         t0 = time.perf_counter()
         for s in range(steps_req):
             if s > 0 and agree(time.perf_counter() + (1.1 + tail_steps) * t_step > deadline):
@@ -546,6 +546,8 @@ def main():
             res = one_step(step0 + s)
             t_step = time.perf_counter() - ts
             n_steps += 1
+            for k_, v_ in (res.get("phase_peak_GB") or {}).items():
+                phase_peaks[k_] = max(phase_peaks.get(k_, 0.0), float(v_))
             if "search_trace" in res:
                 decisions.append(dict(decisions_of(res, args.seed_base + step0 + s), wall_s=round(t_step, 3)))
         fence()
@@ -553,7 +555,8 @@ def main():
         try:  # device memory in use on this rank's GPU after the timed steps (the library's pool keeps the call's blocks cached)
             free_b, total_b = torch.cuda.mem_get_info(local_rank)
             run_config.hbm_in_use_gb = round((total_b - free_b) / 1e9, 1)
-            run_config.hbm_peak_live_gb = round(ctx.lib.sclens_hip_pool_peak(ctx.device, 0) / 1e9, 1)
+            run_config.hbm_peak_live_gb = max(phase_peaks.values()) if phase_peaks else None
+            run_config.hbm_phase_peaks_gb = phase_peaks
         except Exception:
             run_config.hbm_in_use_gb = None
         if world > 1:  # MAX over the ranks (through the library's communicator when there is one)
@@ -610,6 +613,7 @@ def main():
                          "decisions_per_step": main_r["decisions"],
                          "hbm_in_use_GB_after_timed_steps": getattr(run_config, "hbm_in_use_gb", None),
                          "hbm_peak_live_GB": getattr(run_config, "hbm_peak_live_gb", None),
+                         "hbm_peak_live_GB_by_phase": getattr(run_config, "hbm_phase_peaks_gb", None),
                          "search_job_s_last_step": [list(q) for q in res.get("search_job_s", [])],
                          "first_phase_jobs_s_last_step": [list(q) for q in res.get("first_phase_s", [])]},
         }

@@ -246,6 +246,10 @@ class Context:
         """hand one family of this context's idle scratch back to the pool: "eigensolver", "gram", "chefsi", "corr" or "all" """
         self.check(self.lib.sclens_hip_release_scratch(self.h, family.encode()))
 
+    def pool_peak(self, reset: bool = False) -> int:
+        """largest number of live (handed-out) device bytes of the library's pool on this device since the last reset"""
+        return int(self.lib.sclens_hip_pool_peak(self.device, 1 if reset else 0))
+
     def set_option(self, name: str, value: int):
         """a named tunable of this context (include/sclens_hip.h: "precision", "two_stage", "gram_bits", ...; csrc/common.h has the table)"""
         self.check(self.lib.sclens_hip_set_option(self.h, name.encode(), int(value)))

@@ -1080,21 +1080,19 @@ def sclens(inp_df, device_="gpu", th=60, p_step=0.001, n_perturb=20, centering="
         # again: 100 000 x 30 000 in 52.7 s instead of 55.3 s (search 38.3 vs 40.8 s, ensemble 4.0 vs 5.0 s, 2.2 s of worker
         # teardown included; profiles/r02_bench_cfg4_streams2_step1.json)
         streams = 3 if min(N, M) < 16000 else 2
-    # sparsity search on ONE GPU with several local workers: continuous hand-out of iterations with staggered workers
-    # (search_pipelined below) or rounds of W evaluations (SCLENS_SEARCH_PIPELINE=0; always with several ranks)
-    search_pipeline = os.environ.get("SCLENS_SEARCH_PIPELINE", "0") != "0"
-    search_stagger_s = float(os.environ.get("SCLENS_SEARCH_STAGGER_S", "0.65"))
     if draws is None:
         if seed is None:  # every rank must draw the same candidates, null matrix and sample seeds: rank 0's clock decides
             seed = int(shard.bcast_host(np.array([float(time.time_ns() % (2**31))]), 0)[0])
         draws = make_draws_native(X_, int(seed))
-    phase = {}
+    phase, phase_peak = {}, {}
     t_ph = time.perf_counter()
+    ctx.pool_peak(reset=True)
 
-    def lap(name):
+    def lap(name):  # wall time of the phase that ends here and the pool's largest live footprint on this device during it
         nonlocal t_ph
         now = time.perf_counter()
         phase[name] = phase.get(name, 0.0) + (now - t_ph)
+        phase_peak[name] = max(phase_peak.get(name, 0), ctx.pool_peak(reset=True))
         t_ph = now
 
     # The session starts with the counts only: the data / null / binarised decompositions (:676-721) do not involve the
@@ -1215,74 +1213,12 @@ def sclens(inp_df, device_="gpu", th=60, p_step=0.001, n_perturb=20, centering="
             # Two streams: data | null first. The binarised matrix (the longest of the three: all of its eigenvectors are wanted)
             # runs afterwards beside signal_vectors, whose second back-transformation of a few vectors is one latency-bound wave
             # (0.5 s at n = 3 * 10^4) that costs nothing next to a decomposition and 0.5 s on its own
-            # (profiles/r03_first_phase_cfg4.log).
+            # (profiles/r03_first_phase_cfg4.log). Three other schedules (null -> binarised chained on worker 1, binarised -> null, all three
+            # at once on a third session) were measured in rounds 4 and 5 and removed: none shortens this phase by more than 0.1 s and
+            # each makes the search that follows 0.8-2 s slower (profiles/r05_schedules_release_stagger_chefsi_skinny.log).
             w_null = w_bin = workers[1]
-            fp_mode = os.environ.get("SCLENS_FIRST_PHASE", "")
-            if fp_mode in ("chain", "chain2"):
-                # (prepared at the end of round 3, not yet timed on hardware, hence opt-in) the binarised decomposition does not
-                # depend on the threshold: worker 1 runs null -> binarised back to back while this thread runs the data matrix,
-                # waits for the null spectrum only, and takes the signal vectors beside the rest of the binarised decomposition
-                null_done: Future = Future()
-
-                def null_then_binary():
-                    if fp_mode == "chain2":
-                        # the binarised decomposition FIRST: it needs nothing from the host, while the null matrix is still being
-                        # drawn there (R2, ~0.6 s at 100 000 x 30 000) when the call starts; the null spectrum follows on the same
-                        # worker and releases the main thread (threshold -> signal vectors)
-                        try:
-                            out = w_bin.binary_basis()
-                            null_done.set_result(w_null.null_spectrum_pattern(null_future.result()))
-                        except BaseException as e:
-                            if not null_done.done():
-                                null_done.set_exception(e)
-                            raise
-                        return out
-                    try:
-                        null_done.set_result(w_null.null_spectrum_pattern(null_future.result()))
-                    except BaseException as e:  # the waiting thread must see it; the binarised decomposition is not started
-                        null_done.set_exception(e)
-                        raise
-                    return w_bin.binary_basis()
-
-                bin_chain = pool.submit(null_then_binary)
-                try:
-                    L, rec_vals = ses.data_spectrum(want_rec)
-                    Lr = null_done.result()
-                except BaseException:
-                    try:
-                        bin_chain.result()  # worker 1's session is single-threaded: let its chain end before anything closes it
-                    except BaseException:
-                        pass
-                    raise
-                r_vr2 = -2  # running on worker 1; joined after the signal vectors
-            elif fp_mode == "three":
-                # All three decompositions at once, the null one on a THIRD session that lives for this phase only: what serialises
-                # two concurrent decompositions are their full-chip products (a round of two costs 2 F + P), so the
-                # data | null pair followed by the binarised matrix costs 3 F + 2 P, while three at once cost 3 F + ~P; and the null
-                # matrix, which the host is still drawing when the call starts (R2, ~0.6 s), no longer delays the pair it belongs to.
-                c3 = Context(ctx.device).copy_options_from(ctx)
-                w3 = None
-                try:
-                    w3 = ses.clone(c3)
-                    with ThreadPoolExecutor(max_workers=3) as tp:
-                        futs = [tp.submit(lambda: ses.data_spectrum(want_rec)), tp.submit(w_bin.binary_basis),
-                                tp.submit(lambda: w3.null_spectrum_pattern(null_future.result()))]
-                        errs = []
-                        for f in futs:  # every session is single-threaded: all three must have ended before anything is closed
-                            try:
-                                f.result()
-                            except BaseException as e:  # noqa: BLE001 - re-raised below
-                                errs.append(e)
-                        if errs:
-                            raise errs[0]
-                    (L, rec_vals), (_, r_vr2), Lr = futs[0].result(), futs[1].result(), futs[2].result()
-                finally:
-                    if w3 is not None:
-                        w3.close()
-                    c3.close()
-            else:
-                (L, rec_vals), Lr = run_all([(0, lambda: timed("data_spectrum", ses.data_spectrum)(want_rec)), (1, lambda: null_spectrum_job(w_null))])
-                r_vr2 = -1  # decomposed below, next to the signal vectors
+            (L, rec_vals), Lr = run_all([(0, lambda: timed("data_spectrum", ses.data_spectrum)(want_rec)), (1, lambda: null_spectrum_job(w_null))])
+            r_vr2 = -1  # decomposed below, next to the signal vectors
         else:  # the main session keeps the data matrix's reflectors for signal_vectors; workers take the other two
             w_null, w_bin = workers[1], workers[2]
             (L, rec_vals), Lr, (_, r_vr2) = run_all([(0, lambda: ses.data_spectrum(want_rec)), (1, lambda: w_null.null_spectrum_pattern(null_future.result())),
@@ -1298,12 +1234,7 @@ def sclens(inp_df, device_="gpu", th=60, p_step=0.001, n_perturb=20, centering="
         L, k, nL, guard = cut_with_guard_band(L, lambda_c, guard_band, refine)
         if verbose:
             print(f"(Using hip) number of signal ev: {k}")
-        if r_vr2 == -2:
-            try:
-                nV = ses.signal_vectors(k)
-            finally:
-                _, r_vr2 = bin_chain.result()
-        elif r_vr2 == -1:
+        if r_vr2 == -1:
             nV, (_, r_vr2) = run_all([(0, lambda: timed("signal_vectors", ses.signal_vectors)(k)), (1, timed("binary_basis", w_bin.binary_basis))])
         else:
             nV = ses.signal_vectors(k) if (not spread or shard.rank == 0) else None
@@ -1376,68 +1307,7 @@ def sclens(inp_df, device_="gpu", th=60, p_step=0.001, n_perturb=20, centering="
         it = 0
         p_ = None
 
-        def search_pipelined(stagger_s):
-            """One GPU, W > 1 local workers: no round barrier. Each worker takes the next unstarted iteration the moment it is free;
-            results are consumed in iteration order by the stop rule (:747-760), exactly as the rounds do -- the evaluations, their
-            seeds and the rule are the same, only WHEN an evaluation starts differs. Worker w starts `w stagger_s` late, so that the
-            workers stay out of phase: the full-chip kernels of one evaluation (Gram product, band reduction, first
-            back-transformation, statistic) then run beside the latency-bound ones of the other (bulge chase, bisection, inverse
-            iteration, second back-transformation) instead of beside the same full-chip kernels of its twin."""
-            nonlocal tank, it, p_
-            lock = threading.Condition()
-            st = {"next": 0, "done": {}, "stop": False, "err": None}
-
-            def advance():  # under the lock
-                nonlocal tank, it, p_
-                while not st["stop"] and it in st["done"]:
-                    r = st["done"].pop(it)
-                    tank, used, stopped, p_fin = consume_search_round(tank, [r[:5] if r[5] == 1.0 else None], p_list, it, p_th,
-                                                                      p_step, max_search_iters)
-                    it += used
-                    if stopped:
-                        p_ = p_fin
-                        st["stop"] = True
-                lock.notify_all()
-
-            def loop(wk):
-                if wk and stagger_s > 0:
-                    time.sleep(stagger_s * wk)
-                while True:
-                    with lock:
-                        # at most W iterations beyond the last consumed one are in flight (what a round speculates)
-                        while st["next"] >= it + W and not st["stop"] and st["err"] is None:
-                            lock.wait()
-                        if st["stop"] or st["err"] is not None:
-                            return
-                        my = st["next"]
-                        st["next"] = my + 1
-                    try:
-                        out = search_job(wk, my)()
-                    except BaseException as e:
-                        with lock:
-                            if st["err"] is None:
-                                st["err"] = e
-                            lock.notify_all()
-                        return
-                    with lock:
-                        st["done"][my] = out
-                        try:
-                            advance()
-                        except BaseException as e:
-                            if st["err"] is None:
-                                st["err"] = e
-                            lock.notify_all()
-                            return
-
-            futs = [pool.submit(loop, w) for w in range(W)]
-            for f in futs:
-                f.result()
-            if st["err"] is not None:
-                raise st["err"]
-
         try:
-            if search_pipeline and shard.world == 1 and W > 1:
-                search_pipelined(search_stagger_s)
             while p_ is None:
                 base = it + shard.rank * W
                 mine = guarded(lambda: np.stack(run_all([(w, search_job(w, base + w)) for w in range(W)])), "the sparsity search")  # W x 6
@@ -1552,6 +1422,7 @@ def sclens(inp_df, device_="gpu", th=60, p_step=0.001, n_perturb=20, centering="
             res["nV_set"] = [ses.get_perturbed(t, ncols[t]) for t in range(n_perturb)]
         lap("robustness_gene_basis")
         res["phase_s"] = {k_: round(v_, 4) for k_, v_ in phase.items()}
+        res["phase_peak_GB"] = {k_: round(v_ / 1e9, 1) for k_, v_ in phase_peak.items()}
         res["wall_s"] = time.perf_counter() - t_all
         return res
     finally:

@@ -703,19 +703,27 @@ __global__ __launch_bounds__(256) void k_split_image_scaled(const float* __restr
 
 // The split image of a short, fat block (the b rows of a subspace-iteration block: magnitudes differ by up to 1e5 from row to row) with
 // ONE POWER-OF-TWO SCALE PER ROW: row r is scaled so that its largest |entry| lands in [2^13, 2^14) and inv_scale[r] receives the
-// reciprocal (exact), which the consumer multiplies back into row r of the product. One workgroup per row.
-__global__ __launch_bounds__(256) void k_split_image_rows(const float* __restrict__ src, int64_t K, int64_t ld, int64_t Kp,
-                                                          _Float16* __restrict__ dst, float* __restrict__ inv_scale) {
-  __shared__ float sw[4];
-  const int64_t r = blockIdx.x;
+// reciprocal (exact), which the consumer multiplies back into row r of the product. Two launches over (chunks of the row, rows): the
+// largest |entry| of every row by atomicMax on the bit patterns of non-negative floats (order-independent), then the image. (One
+// workgroup per row took 0.55 ms per call at 64 x 100 000: 22 ms of every ensemble member, profiles/r05_cfg4_kernel_stats_*.csv.)
+__global__ __launch_bounds__(256) void k_row_absmax_bits(const float* __restrict__ src, int64_t K, int64_t ld, unsigned* __restrict__ out) {
+  const int64_t r = blockIdx.y, k0 = (int64_t)blockIdx.x * 4096;
   const float* a = src + r * ld;
   float mx = 0.f;
-  for (int64_t k = threadIdx.x; k < K; k += 256) mx = fmaxf(mx, fabsf(a[k]));
+#pragma unroll 4
+  for (int q = 0; q < 16; ++q) {
+    const int64_t k = k0 + threadIdx.x + 256 * q;
+    if (k < K) mx = fmaxf(mx, fabsf(a[k]));
+  }
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
-  if ((threadIdx.x & 63) == 0) sw[threadIdx.x >> 6] = mx;
-  __syncthreads();
-  mx = fmaxf(fmaxf(sw[0], sw[1]), fmaxf(sw[2], sw[3]));
+  if ((threadIdx.x & 63) == 0 && mx > 0.f) atomicMax(out + r, __float_as_uint(mx));
+}
+__global__ __launch_bounds__(256) void k_split_image_rows(const float* __restrict__ src, int64_t K, int64_t ld, int64_t Kp,
+                                                          const unsigned* __restrict__ mxbits, _Float16* __restrict__ dst,
+                                                          float* __restrict__ inv_scale) {
+  const int64_t r = blockIdx.y, k = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const float mx = __uint_as_float(mxbits[r]);
   float sc = 1.f;
   if (mx > 0.f && mx < 3.0e38f) {
     int ex = 0;
@@ -724,15 +732,13 @@ __global__ __launch_bounds__(256) void k_split_image_rows(const float* __restric
     e = e > 100 ? 100 : (e < -100 ? -100 : e);  // sc and 1 / sc stay normal numbers
     sc = ldexpf(1.f, e);
   }
-  if (threadIdx.x == 0) inv_scale[r] = 1.f / sc;
-  _Float16* d0 = dst + r * 2 * Kp;
-  for (int64_t k = threadIdx.x; k < Kp; k += 256) {
-    const float x = k < K ? a[k] * sc : 0.f;
-    const _Float16 hi = (_Float16)x;
-    _Float16* d = d0 + (k >> 5) * 64 + (k & 31);
-    d[0] = hi;
-    d[32] = (_Float16)(x - (float)hi);
-  }
+  if (blockIdx.x == 0 && threadIdx.x == 0) inv_scale[r] = 1.f / sc;
+  if (k >= Kp) return;
+  const float x = k < K ? src[r * ld + k] * sc : 0.f;
+  const _Float16 hi = (_Float16)x;
+  _Float16* d = dst + r * 2 * Kp + (k >> 5) * 64 + (k & 31);
+  d[0] = hi;
+  d[32] = (_Float16)(x - (float)hi);
 }
 
 // The split image of the TRANSPOSE of src [rows][K] (image rows = the K columns of src, contraction index = its rows) under the scale
@@ -1428,8 +1434,14 @@ int split_image_fixed(Ctx* ctx, const float* src, int64_t rows, int64_t K, int64
 
 int split_image_rows(Ctx* ctx, const float* src, int64_t rows, int64_t K, int64_t ld, void* dst, float* inv_scale_dev) {
   if (rows <= 0) return SCLENS_OK;
-  hipLaunchKernelGGL(k_split_image_rows, dim3((unsigned)rows), dim3(256), 0, ctx->stream, src, K, ld, round_up(K, 32), static_cast<_Float16*>(dst),
-                     inv_scale_dev);
+  if (rows > 65535) return ctx->fail(SCLENS_ERR_ARG, "split_image_rows: too many rows");
+  const int64_t Kp = round_up(K, 32);
+  hipStream_t st = ctx->stream;
+  SCL_WS(ctx, mx, unsigned, "gram.rowmax", rows);
+  SCL_HIP(ctx, hipMemsetAsync(mx, 0, sizeof(unsigned) * (size_t)rows, st));
+  hipLaunchKernelGGL(k_row_absmax_bits, dim3((unsigned)((K + 4095) / 4096), (unsigned)rows), dim3(256), 0, st, src, K, ld, mx);
+  hipLaunchKernelGGL(k_split_image_rows, dim3((unsigned)((Kp + 255) / 256), (unsigned)rows), dim3(256), 0, st, src, K, ld, Kp, mx,
+                     static_cast<_Float16*>(dst), inv_scale_dev);
   SCL_HIP(ctx, hipGetLastError());
   return SCLENS_OK;
 }

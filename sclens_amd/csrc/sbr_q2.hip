@@ -807,7 +807,7 @@ __global__ void sbr_q2_shift(const float* __restrict__ in, int64_t ldi, int64_t 
 // stage issued together.
 static int sbr_q2_variant(const Ctx* ctx, int64_t n) {
   int v = ctx->opt.eff_q2_variant();
-  if (v != 14 && v != 15) v = 3;
+  if (v != 14 && v != 15 && v != 16 && v != 17) v = 3;
   if (v != 3 && n % SB != 0) v = 3;  // the image index assumes an order that is a multiple of 64 (the two-stage solver pads)
   return v;
 }
@@ -882,6 +882,14 @@ int sbr_apply_q2(Ctx* ctx, int64_t n, float* Zt, int64_t m, int64_t ldz) {
     const int lds_bytes = 3 * Q_IMG2 * (int)sizeof(float);
     SCL_TRY(ensure_dyn_lds(ctx, reinterpret_cast<const void*>(sbr_q2_apply16e<4, 12, 3>), lds_bytes));
     hipLaunchKernelGGL((sbr_q2_apply16e<4, 12, 3>), q2grid, dim3(256), lds_bytes, ctx->stream, qa, q2img);
+  } else if (q2_variant == 16) {  // 15 with passes of eight blocks: half the window traffic, a window of 320 rows in registers
+    const int lds_bytes = 3 * Q_IMG2 * (int)sizeof(float);
+    SCL_TRY(ensure_dyn_lds(ctx, reinterpret_cast<const void*>(sbr_q2_apply16e<8, 20, 3>), lds_bytes));
+    hipLaunchKernelGGL((sbr_q2_apply16e<8, 20, 3>), q2grid, dim3(256), lds_bytes, ctx->stream, qa, q2img);
+  } else if (q2_variant == 17) {  // passes of six blocks
+    const int lds_bytes = 3 * Q_IMG2 * (int)sizeof(float);
+    SCL_TRY(ensure_dyn_lds(ctx, reinterpret_cast<const void*>(sbr_q2_apply16e<6, 16, 3>), lds_bytes));
+    hipLaunchKernelGGL((sbr_q2_apply16e<6, 16, 3>), q2grid, dim3(256), lds_bytes, ctx->stream, qa, q2img);
   } else if (q2_variant == 14) {
     const int lds_bytes = 2 * Q_IMG2 * (int)sizeof(float);
     SCL_TRY(ensure_dyn_lds(ctx, reinterpret_cast<const void*>(sbr_q2_apply16e<4, 12, 2>), lds_bytes));

@@ -36,6 +36,9 @@ class FakeContext:
     def release_scratch(self, family):
         pass
 
+    def pool_peak(self, reset=False):
+        return 0
+
     def copy_options_from(self, other):  # worker contexts inherit the caller's options (sclens_hip_copy_options)
         self.options_from = other
         return self

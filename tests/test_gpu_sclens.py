@@ -262,23 +262,6 @@ def test_two_streams_give_identical_results(ctx):
         assert np.array_equal(a["robustness_scores"]["b_"], c["robustness_scores"]["b_"])
 
 
-@pytest.mark.parametrize("mode", ["chain", "chain2", "three"])
-def test_chained_first_phase_gives_identical_results(ctx, monkeypatch, mode):
-    """SCLENS_FIRST_PHASE=chain / chain2 (two streams: worker 1 runs null -> binarised, or binarised -> null, back to back; the main
-    session data -> signal vectors) only moves work between streams: every output has the same bits as the default schedule"""
-    X = synth_counts(300, 500, seed=1, C=5, marker_frac=0.2, marker_sd=1.5)
-    d = api.make_draws_native(X, seed=13)
-    a = api.sclens(X, draws=d, n_perturb=5, ctx=ctx, streams=2)
-    monkeypatch.setenv("SCLENS_FIRST_PHASE", mode)
-    b = api.sclens(X, draws=d, n_perturb=5, ctx=ctx, streams=2)
-    assert a["p_"] == b["p_"] and a["n_search"] == b["n_search"] and np.array_equal(a["L"], b["L"])
-    for (p1, t1), (p2, t2) in zip(a["search_trace"], b["search_trace"]):
-        assert p1 == p2 and np.array_equal(t1, t2)
-    assert np.array_equal(a["signal_evec"], b["signal_evec"])
-    assert np.array_equal(a["robustness_scores"]["b_"], b["robustness_scores"]["b_"])
-    assert np.array_equal(a["sig_id"], b["sig_id"])
-
-
 def test_get_denoised_df(run_pair, ctx):
     """the denoised reconstruction (scLENS.jl:889-931) on the device vs the oracle, both from the oracle's
     sclens() result (so the comparison isolates this function)."""

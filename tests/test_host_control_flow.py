@@ -61,53 +61,21 @@ def test_capped_search_median_centering_and_five_members(monkeypatch):
     _all_closed()
 
 
-@pytest.mark.parametrize("mode", ["chain", "chain2"])
-def test_chained_first_phase_schedule(monkeypatch, mode):
-    """SCLENS_FIRST_PHASE=chain / chain2: worker 1 runs null -> binarised (chain) or binarised -> null (chain2) back to back on one
-    thread, the main session data -> signal vectors; same result as the oracle, nothing left open"""
-    monkeypatch.setenv("SCLENS_FIRST_PHASE", mode)
-    ref, res = _pair(monkeypatch, 150, 220, 2)
-    _same(ref, res)
+def test_a_failure_in_a_worker_closes_everything(monkeypatch):
+    X = synth_counts(150, 220, seed=3, C=4, marker_frac=0.25, marker_sd=1.5)
+    d = api.make_draws(X, seed=11, p_th_trials=200)
+    main = F.install(monkeypatch)
+
+    def boom(self):
+        raise RuntimeError("binary basis failed")
+
+    monkeypatch.setattr(F.FakeSession, "binary_basis", boom)
+    with pytest.raises(RuntimeError, match="binary basis failed"):
+        api.sclens(X, draws=d, n_perturb=3, ctx=main, streams=2)
     _all_closed()
-    calls = F.FakeSession.last_calls
-    first = {what: (tid, sid) for tid, sid, what in reversed(calls)}
-    assert first["null_spectrum"] == first["binary_basis"]            # same worker session, same thread
-    assert first["data_spectrum"][1] == first["signal_vectors"][1] != first["null_spectrum"][1]
-    order = [what for _, _, what in calls]
-    assert (order.index("null_spectrum") < order.index("binary_basis")) == (mode == "chain")
 
 
-def test_three_at_once_first_phase_schedule(monkeypatch):
-    """SCLENS_FIRST_PHASE=three: data, binarised and null decompositions at once, the null one on a third session that is closed when
-    the phase ends; same result as the oracle, nothing left open"""
-    monkeypatch.setenv("SCLENS_FIRST_PHASE", "three")
-    ref, res = _pair(monkeypatch, 150, 220, 2)
-    _same(ref, res)
-    _all_closed()
-    calls = F.FakeSession.last_calls
-    first = {what: (tid, sid) for tid, sid, what in reversed(calls)}
-    assert len({first["null_spectrum"][1], first["binary_basis"][1], first["data_spectrum"][1]}) == 3  # three sessions
-    assert first["data_spectrum"][1] == first["signal_vectors"][1]
-
-
-@pytest.mark.parametrize("streams", [2, 3])
-@pytest.mark.parametrize("stagger", ["0", "0.02"])
-def test_pipelined_search_reproduces_the_oracle(monkeypatch, streams, stagger):
-    """SCLENS_SEARCH_PIPELINE=1: iterations handed out one by one to staggered workers, results consumed in iteration order: same
-    search trace, p_ and everything after it as the oracle; every iteration evaluated at most once and none skipped"""
-    monkeypatch.setenv("SCLENS_SEARCH_PIPELINE", "1")
-    monkeypatch.setenv("SCLENS_SEARCH_STAGGER_S", stagger)
-    ref, res = _pair(monkeypatch, 150, 220, streams)
-    _same(ref, res)
-    _all_closed()
-    its = sorted(i for _, i, _ in res["search_job_s"])
-    assert its == list(range(len(its))) and ref["n_search"] <= len(its) <= ref["n_search"] + streams - 1
-    assert len({w for w, _, _ in res["search_job_s"]}) >= (2 if ref["n_search"] > 2 else 1)
-
-
-def test_pipelined_search_failure_stops_the_other_workers_and_closes_everything(monkeypatch):
-    monkeypatch.setenv("SCLENS_SEARCH_PIPELINE", "1")
-    monkeypatch.setenv("SCLENS_SEARCH_STAGGER_S", "0.01")
+def test_a_failed_search_evaluation_closes_everything(monkeypatch):
     X = synth_counts(150, 220, seed=3, C=4, marker_frac=0.25, marker_sd=1.5)
     d = api.make_draws(X, seed=11, p_th_trials=200)
     main = F.install(monkeypatch)
@@ -123,25 +91,8 @@ def test_pipelined_search_failure_stops_the_other_workers_and_closes_everything(
     monkeypatch.setattr(F.FakeSession, "search_step", third_call_fails)
     with pytest.raises(RuntimeError, match="search evaluation failed"):
         api.sclens(X, draws=d, n_perturb=3, ctx=main, streams=2)
-    assert len(seen) <= 5  # the other worker finishes what it had started and takes nothing new
+    assert len(seen) <= 4  # the round that failed ends; no further round starts
     _all_closed()
-
-
-def test_a_failure_in_a_worker_closes_everything(monkeypatch):
-    X = synth_counts(150, 220, seed=3, C=4, marker_frac=0.25, marker_sd=1.5)
-    d = api.make_draws(X, seed=11, p_th_trials=200)
-    for mode in ("", "chain", "chain2", "three"):
-        monkeypatch.setenv("SCLENS_FIRST_PHASE", mode)
-        main = F.install(monkeypatch)
-
-        def boom(self):
-            raise RuntimeError("binary basis failed")
-
-        monkeypatch.setattr(F.FakeSession, "binary_basis", boom)
-        with pytest.raises(RuntimeError, match="binary basis failed"):
-            api.sclens(X, draws=d, n_perturb=3, ctx=main, streams=2)
-        _all_closed()
-        monkeypatch.undo()
 
 
 # ---- several ranks (threads of this process): the spread first phase, rounds of world x streams evaluations, ensemble t % world
