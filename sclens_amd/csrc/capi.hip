@@ -1,4 +1,6 @@
 // extern "C" surface of libsclens_hip.so (see include/sclens_hip.h). Thin: argument checks + forwarding.
+#include <algorithm>
+
 #include "common.h"
 #include "pattern.h"
 
@@ -623,6 +625,18 @@ int sclens_hip_release_scratch(sclens_hip_ctx* h, const char* family) {
   if (f == "corr" || f == "all") pre.push_back("c.");
   if (pre.empty()) return h->c.fail(SCLENS_ERR_ARG, "release_scratch: family must be eigensolver, gram, chefsi, corr or all");
   scl::Ctx& c = h->c;
+  if (c.opt.debug >= 2) {  // what this context's named workspaces hold at the moment a family goes back (footprint table of INTEGRATION.md 6)
+    std::vector<std::pair<size_t, std::string>> tab;
+    size_t tot = 0;
+    for (const auto& kv : c.ws) {
+      tab.emplace_back(kv.second.second, kv.first);
+      tot += kv.second.second;
+    }
+    std::sort(tab.rbegin(), tab.rend());
+    fprintf(stderr, "[workspaces] context %p before release_scratch(%s): %.2f GB in %zu blocks\n", (void*)h, family, tot / 1e9, tab.size());
+    for (const auto& t : tab)
+      if (t.first >= ((size_t)64 << 20)) fprintf(stderr, "[workspaces]   %-16s %8.2f GB\n", t.second.c_str(), t.first / 1e9);
+  }
   std::vector<std::string> names;
   for (const auto& kv : c.ws)
     for (const std::string& q : pre)

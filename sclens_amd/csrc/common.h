@@ -49,7 +49,7 @@ namespace scl {
   X(q1_group, 0)            /* panels per block reflector: 4, 8 or 0 = by size */                                                  \
   X(chase_mb, 1)            /* bulge chase by messages + prefetch (0: the round-2 kernel, the bitwise reference) */                \
   X(chase_wgs, 0)           /* cap on its workgroups (0: one per CU) */                                                            \
-  X(q2_variant, 15)         /* second back-transformation: 15 / 14 image-fed (two / one group ahead), 3 fp32 products */           \
+  X(q2_variant, 16)         /* second back-transformation: 16 / 15 / 14 image-fed (passes of 8 / 4 blocks; one group ahead), 3 fp32 */ \
   X(q2_reference, 0)        /* 1: the unblocked reference kernel (tests) */                                                        \
   X(q2_tg_early, 1)         /* its group data built on the auxiliary stream beside the inverse iteration */                        \
   X(stein_pf, 16)           /* inverse iteration: steps of loads in flight (4, 16, 32) */                                          \

@@ -798,7 +798,7 @@ __global__ void sbr_q2_shift(const float* __restrict__ in, int64_t ldi, int64_t 
   if (offo > 0 && c < ldo - offo - n) out[r * ldo + offo + n + c] = 0.f;
 }
 
-// 15 (default): 16 KB group images, two groups ahead; 14: one ahead; 3: fp32 products from reflectors staged by every workgroup
+// 16 (default): 16 KB group images, two groups ahead, passes of eight blocks; 15: passes of four; 14: one group ahead; 3: fp32 products from reflectors staged by every workgroup
 // (every product of the solver on the fp32 matrix cores: precision = 0). Measured at n = 30 016, m = 15 008 (profiles/r04_q2_*):
 // 500 ms (3), 250 (15). What the phase clocks of a group showed (context option q2_prof, profiles/r04_q2_phase_clocks.log; one wave per
 // SIMD at m = n / 2, so nothing hides a wave's own latencies): (i) __syncthreads() carries a release fence = `s_waitcnt vmcnt(0)`, so
@@ -807,7 +807,7 @@ __global__ void sbr_q2_shift(const float* __restrict__ in, int64_t ldi, int64_t 
 // stage issued together.
 static int sbr_q2_variant(const Ctx* ctx, int64_t n) {
   int v = ctx->opt.eff_q2_variant();
-  if (v != 14 && v != 15 && v != 16 && v != 17) v = 3;
+  if (v != 14 && v != 15 && v != 16) v = 3;
   if (v != 3 && n % SB != 0) v = 3;  // the image index assumes an order that is a multiple of 64 (the two-stage solver pads)
   return v;
 }
@@ -882,14 +882,14 @@ int sbr_apply_q2(Ctx* ctx, int64_t n, float* Zt, int64_t m, int64_t ldz) {
     const int lds_bytes = 3 * Q_IMG2 * (int)sizeof(float);
     SCL_TRY(ensure_dyn_lds(ctx, reinterpret_cast<const void*>(sbr_q2_apply16e<4, 12, 3>), lds_bytes));
     hipLaunchKernelGGL((sbr_q2_apply16e<4, 12, 3>), q2grid, dim3(256), lds_bytes, ctx->stream, qa, q2img);
-  } else if (q2_variant == 16) {  // 15 with passes of eight blocks: half the window traffic, a window of 320 rows in registers
+  } else if (q2_variant == 16) {
+    // 15 with passes of EIGHT blocks of sweeps instead of four: the window (now 320 rows, 224 VGPRs) is loaded and stored half as often
+    // (the window traffic of a pass, 8 memory instructions per task and the drain at its end, was a fifth of the kernel): 264 -> 229 ms
+    // at n = 30 016 with 15 008 vectors, 425 -> 340 ms with all vectors, same bits (profiles/r05_q2_pass_length.log). Passes of 6: 234 ms;
+    // of 12 (460 VGPRs, one workgroup per CU): 252 ms; of 16: spills.
     const int lds_bytes = 3 * Q_IMG2 * (int)sizeof(float);
     SCL_TRY(ensure_dyn_lds(ctx, reinterpret_cast<const void*>(sbr_q2_apply16e<8, 20, 3>), lds_bytes));
     hipLaunchKernelGGL((sbr_q2_apply16e<8, 20, 3>), q2grid, dim3(256), lds_bytes, ctx->stream, qa, q2img);
-  } else if (q2_variant == 17) {  // passes of six blocks
-    const int lds_bytes = 3 * Q_IMG2 * (int)sizeof(float);
-    SCL_TRY(ensure_dyn_lds(ctx, reinterpret_cast<const void*>(sbr_q2_apply16e<6, 16, 3>), lds_bytes));
-    hipLaunchKernelGGL((sbr_q2_apply16e<6, 16, 3>), q2grid, dim3(256), lds_bytes, ctx->stream, qa, q2img);
   } else if (q2_variant == 14) {
     const int lds_bytes = 2 * Q_IMG2 * (int)sizeof(float);
     SCL_TRY(ensure_dyn_lds(ctx, reinterpret_cast<const void*>(sbr_q2_apply16e<4, 12, 2>), lds_bytes));

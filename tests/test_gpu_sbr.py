@@ -389,7 +389,7 @@ def test_first_back_transformation_group_data_prepared_ahead_gives_the_same_bits
     assert d < 5e-6
 
 
-@pytest.mark.parametrize("variant", [14, 15, 3])
+@pytest.mark.parametrize("variant", [14, 15, 16, 3])
 @pytest.mark.parametrize("n,m", [(192, 192), (1088, 100), (2560, 70), (640, 641 - 1)])
 def test_second_back_transformation_matches_the_unblocked_reference(ctx, n, m, variant, opt):
     """The register-resident MFMA version of Q2 (16-vector wave tiles, QJ sweep blocks per pass) against the one-reflector-at-
@@ -406,7 +406,7 @@ def test_second_back_transformation_matches_the_unblocked_reference(ctx, n, m, v
     Z0 = np.zeros((m, lda), dtype=np.float32)
     Z0[:, :n] = rng.standard_normal((m, n)) / np.sqrt(n)
     outs = []
-    # 15 (default) / 14: pre-built 16 KB group images moved by LDS-DMA, two / one group(s) ahead, split-fp16 products;
+    # 16 (default) / 15 / 14: pre-built 16 KB group images moved by LDS-DMA (passes of 8 / 4 blocks; one group ahead), split-fp16 products;
     # 3: fp32 products, reflectors staged by every workgroup (what `precision = 0` selects)
     opt(q2_variant=variant)
     for ref in (True, False):
@@ -424,7 +424,8 @@ def test_second_back_transformation_matches_the_unblocked_reference(ctx, n, m, v
 
 
 def test_second_back_transformation_variants(ctx, opt):
-    """Variants that differ only in WHEN the group images are fetched give the same bits (14: one group ahead, 15: two); the split-fp16
+    """Variants that differ only in WHEN the group images and the window are fetched give the same bits (14: one group ahead, 15: two,
+    16: two and passes of eight blocks); the split-fp16
     products (three fp16 matrix instructions with fp32 accumulation per product, 22-bit operands) stay within 4e-6 of the fp32 ones
     (variant 3, also what `precision = 0` selects) on unit vectors and keep orthonormal rows orthonormal to 2e-6."""
     n, m = 1344, 130
@@ -441,7 +442,7 @@ def test_second_back_transformation_variants(ctx, opt):
     Z0 = np.zeros((m, lda), dtype=np.float32)
     Z0[:, :n] = Q.T.astype(np.float32)
     out = {}
-    for v in ("3", "14", "15", "strict"):
+    for v in ("3", "14", "15", "16", "strict"):
         if v == "strict":
             opt(q2_variant=15, precision=0)
         else:
@@ -455,7 +456,7 @@ def test_second_back_transformation_variants(ctx, opt):
         x.free()
     assert np.array_equal(out["3"], out["strict"])  # precision = 0 IS the fp32 kernel, whatever q2_variant says
     # 14 / 15: one copy of the reflectors + T in a 16 KB image, the third product's operand by transposing LDS reads: three products
-    assert np.array_equal(out["14"], out["15"]) and np.abs(out["14"].astype(np.float64) - out["3"]).max() < 4e-6
+    assert np.array_equal(out["14"], out["15"]) and np.array_equal(out["16"], out["15"]) and np.abs(out["14"].astype(np.float64) - out["3"]).max() < 4e-6
     for v in ("3", "14"):
         Z = out[v].astype(np.float64)
         assert np.abs(Z @ Z.T - np.eye(m)).max() < 2e-6, v
