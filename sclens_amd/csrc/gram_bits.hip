@@ -117,8 +117,23 @@ __global__ __launch_bounds__(256) void k_gene_vecs(PatternDev p, const float* __
   const int lane = threadIdx.x & 63;
   if (col >= p.M) return;
   double s = 0.0;
-  for (int64_t q = p.colptr[col] + lane; q < p.colptr[col + 1]; q += 64)
-    if (val[q] != 0.f) s += sa[p.row[q]];
+  const int64_t e = p.colptr[col + 1];
+  for (int64_t q0 = p.colptr[col] + lane; q0 < e; q0 += 256) {  // four entries of a lane per trip, taken in ascending order
+    float v[4];
+    int32_t r[4];
+    double a4[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const bool in = q0 + 64 * u < e;
+      v[u] = in ? val[q0 + 64 * u] : 0.f;
+      r[u] = in ? p.row[q0 + 64 * u] : 0;
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) a4[u] = sa[r[u]];
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+      if (v[u] != 0.f) s += a4[u];
+  }
   s = wsum_d(s);
   const double d = 1.0 / stdv[col];
   if (lane == 0) gv[col] = make_double4(d, d * s, mu[col], cent[col]);
@@ -133,6 +148,50 @@ __global__ __launch_bounds__(256) void k_mask_scatter(PatternDev p, const float*
   unsigned short* dst = Pm + col * ldm;
   for (int64_t q = p.colptr[col] + lane; q < p.colptr[col + 1]; q += 64)
     if (val[q] != 0.f) dst[p.row[q]] = 0x3C00u;
+}
+
+// The same image written ONCE (round 5): one workgroup per gene walks the cells in chunks of MF_CH, zeroes the chunk in LDS, marks the
+// gene's stored entries that fall into it and stores the chunk with 16-byte stores -- no 6 GB memset in front, no 2-byte scattered
+// stores that re-write a sector each (memset 1.5 ms + scatter 5.1 ms at 100 000 x 30 000, profiles/r05_cfg4_kernel_stats_one_stream.csv).
+// The walk is k_dense_fused's (scale.hip): a column holds its counts with ascending cells, then the zero candidates in draw order; a
+// running position covers the ordered prefix, what is left after the last chunk is scattered behind a barrier.
+constexpr int MF_CH = 8192;
+__global__ __launch_bounds__(256) void k_mask_fused(PatternDev p, const float* __restrict__ val, unsigned short* __restrict__ Pm,
+                                                    int64_t ldm) {
+  __shared__ __attribute__((aligned(16))) unsigned short chunk[MF_CH];
+  __shared__ int wlead[4];
+  const int64_t col = blockIdx.x;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  int64_t q = p.colptr[col];
+  const int64_t qend = p.colptr[col + 1];
+  unsigned short* dst = Pm + col * ldm;
+  for (int64_t c0 = 0; c0 < ldm; c0 += MF_CH) {
+    const int64_t cend = (c0 + MF_CH < ldm) ? c0 + MF_CH : ldm;
+#pragma unroll
+    for (int c = tid; c < MF_CH / 8; c += 256) reinterpret_cast<uint4*>(chunk)[c] = make_uint4(0u, 0u, 0u, 0u);
+    __syncthreads();
+    while (true) {  // block-uniform trip count
+      const int64_t idx = q + tid;
+      const int64_t r = (idx < qend) ? (int64_t)p.row[idx] : (int64_t)-1;
+      const int in = (r >= c0 && r < cend) ? 1 : 0;
+      const unsigned long long out = ~__ballot(in);
+      if (lane == 0) wlead[wv] = out ? (__ffsll((long long)out) - 1) : 64;  // this wave's leading entries inside the chunk
+      __syncthreads();
+      int cnt = wlead[0];
+      if (cnt == 64) cnt += wlead[1];
+      if (cnt == 128) cnt += wlead[2];
+      if (cnt == 192) cnt += wlead[3];
+      if (tid < cnt && val[idx] != 0.f) chunk[r - c0] = 0x3C00u;
+      __syncthreads();
+      q += cnt;
+      if (cnt < 256) break;
+    }
+    for (int c = 8 * tid; c0 + c < cend; c += 2048)  // ldm is a multiple of 64: whole 16-byte pieces
+      *reinterpret_cast<uint4*>(dst + c0 + c) = *reinterpret_cast<const uint4*>(chunk + c);
+    __syncthreads();
+  }
+  for (int64_t idx = q + tid; idx < qend; idx += 256)  // the entries that did not come in cell order
+    if (val[idx] != 0.f) dst[p.row[idx]] = 0x3C00u;
 }
 
 struct GramBitsArgs {
@@ -1279,8 +1338,12 @@ int gram_binary(Ctx* ctx, const PatternDev& p, const float* val, int f32path, vo
     hipLaunchKernelGGL(k_weight_scale, dim3(1), dim3(1024), 0, st, wpart, nparts, ss.srow, N, sc);
     hipLaunchKernelGGL(k_split_weights, dim3((unsigned)((ldm + 255) / 256)), dim3(256), 0, st, w, N, ldm, nw, sc, wq);
     hipLaunchKernelGGL(k_gene_vecs, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, st, p, val, sa, ss.stdv, ss.mu, ss.cent, gv);
-    SCL_HIP(ctx, hipMemsetAsync(Pm, 0, gram_binary_scratch_bytes(N, M), st));
-    hipLaunchKernelGGL(k_mask_scatter, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, st, p, val, Pm, ldm);
+    if (ctx->opt.dense_fused != 0 && (reinterpret_cast<uintptr_t>(Pm) & 15u) == 0) {
+      hipLaunchKernelGGL(k_mask_fused, dim3((unsigned)M), dim3(256), 0, st, p, val, Pm, ldm);
+    } else {  // (same image)
+      SCL_HIP(ctx, hipMemsetAsync(Pm, 0, gram_binary_scratch_bytes(N, M), st));
+      hipLaunchKernelGGL(k_mask_scatter, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, st, p, val, Pm, ldm);
+    }
     SCL_HIP(ctx, hipGetLastError());
   }
   StageTimer tm(ctx, "gram");

@@ -32,11 +32,27 @@ __global__ __launch_bounds__(256) void k_row_sums(PatternDev p, const float* __r
   const int lane = threadIdx.x & 63;
   if (row >= p.N) return;
   double s = 0.0;
+  const int64_t b = p.rowptr[row], e = p.rowptr[row + 1];
+  // four loads of a lane in flight per trip (the lane still adds its entries in ascending order: same sums as the plain loop)
   if (p.base_val_csr) {
     const float* vc = val + p.nU;
-    for (int64_t q = p.rowptr[row] + lane; q < p.rowptr[row + 1]; q += 64) s += (double)vc[q];
+    for (int64_t q0 = b + lane; q0 < e; q0 += 256) {
+      float v[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) v[u] = (q0 + 64 * u < e) ? vc[q0 + 64 * u] : 0.f;
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        if (q0 + 64 * u < e) s += (double)v[u];
+    }
   } else {
-    for (int64_t q = p.rowptr[row] + lane; q < p.rowptr[row + 1]; q += 64) s += (double)val[p.csr2csc[q]];
+    for (int64_t q0 = b + lane; q0 < e; q0 += 256) {
+      float v[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) v[u] = (q0 + 64 * u < e) ? val[p.csr2csc[q0 + 64 * u]] : 0.f;
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        if (q0 + 64 * u < e) s += (double)v[u];
+    }
   }
   s = wsum(s);
   if (lane == 0) tgc[row] = s;
@@ -53,27 +69,53 @@ __global__ __launch_bounds__(256) void k_col_stats(PatternDev p, const float* __
   if (col >= p.M) return;
   const int64_t b = p.colptr[col], e = p.colptr[col + 1];
   double s = 0.0;
-  for (int64_t q = b + lane; q < e; q += 64) {
-    const float v = val[q];
-    double l = 0.0;
-    if (v != 0.f) {
-      const int64_t r = p.row[q];
-      if (f32path) {
-        const float inv = 1.0f / (float)tgc[r];
-        l = (double)log1pf(inv * v);
-      } else {
-        l = log1p((double)v / tgc[r]);
+  // four entries of a lane per trip: their loads, then their gathers of the cell totals, are in flight together (a trip of the plain
+  // loop was one dependent chain load -> gather -> log1p -> store: 6.7 ms for 8 GB at 100 000 x 30 000); the lane still takes its
+  // entries in ascending order, so the sums are the ones of the plain loop
+  for (int64_t q0 = b + lane; q0 < e; q0 += 256) {
+    float v[4];
+    int32_t r[4];
+    double t[4], l[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const bool in = q0 + 64 * u < e;
+      v[u] = in ? val[q0 + 64 * u] : 0.f;
+      r[u] = in ? p.row[q0 + 64 * u] : 0;
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) t[u] = tgc[r[u]];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      l[u] = 0.0;
+      if (v[u] != 0.f) {
+        if (f32path) {
+          const float inv = 1.0f / (float)t[u];
+          l[u] = (double)log1pf(inv * v[u]);
+        } else {
+          l[u] = log1p((double)v[u] / t[u]);
+        }
       }
     }
-    lg[q] = l;
-    s += l;
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+      if (q0 + 64 * u < e) {
+        lg[q0 + 64 * u] = l[u];
+        s += l[u];
+      }
   }
   s = wsum(s);
   const double m = s / (double)p.N;
   double s2 = 0.0;
-  for (int64_t q = b + lane; q < e; q += 64) {
-    const double dlt = lg[q] - m;  // written by this lane above
-    s2 += dlt * dlt;
+  for (int64_t q0 = b + lane; q0 < e; q0 += 256) {
+    double l[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) l[u] = (q0 + 64 * u < e) ? lg[q0 + 64 * u] : m;  // written by this lane above
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+      if (q0 + 64 * u < e) {
+        const double dlt = l[u] - m;
+        s2 += dlt * dlt;
+      }
   }
   s2 = wsum(s2);
   s2 += (double)(p.N - (e - b)) * m * m;  // implicit zeros
@@ -189,14 +231,30 @@ __global__ __launch_bounds__(256) void k_row_norms(PatternDev p, const float* __
     const float* vc = val + p.nU;
     const double t = tgc[row];
     const float inv = 1.0f / (float)t;
-    for (int64_t q = p.rowptr[row] + lane; q < p.rowptr[row + 1]; q += 64) {
-      const float v = vc[q];
-      if (v == 0.f) continue;
-      const int64_t c = p.csrcol[q];
-      const double l = f32path ? (double)log1pf(inv * v) : log1p((double)v / t);
-      const double z = l / stdv[c];
-      zz += z * z;
-      zm += z * mu[c];
+    const int64_t e = p.rowptr[row + 1];
+    for (int64_t q0 = p.rowptr[row] + lane; q0 < e; q0 += 256) {  // four entries of a lane per trip, taken in ascending order
+      float v[4];
+      int32_t c[4];
+      double sd[4], m4[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const bool in = q0 + 64 * u < e;
+        v[u] = in ? vc[q0 + 64 * u] : 0.f;
+        c[u] = in ? p.csrcol[q0 + 64 * u] : 0;
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        sd[u] = stdv[c[u]];
+        m4[u] = mu[c[u]];
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        if (v[u] == 0.f) continue;
+        const double l = f32path ? (double)log1pf(inv * v[u]) : log1p((double)v[u] / t);
+        const double z = l / sd[u];
+        zz += z * z;
+        zm += z * m4[u];
+      }
     }
   } else {
     for (int64_t q = p.rowptr[row] + lane; q < p.rowptr[row + 1]; q += 64) {
@@ -228,7 +286,22 @@ __global__ __launch_bounds__(256) void k_col_cent(PatternDev p, const double* __
   const int lane = threadIdx.x & 63;
   if (col >= p.M) return;
   double s = 0.0;
-  for (int64_t q = p.colptr[col] + lane; q < p.colptr[col + 1]; q += 64) s += srow[p.row[q]] * lg[q];
+  const int64_t e = p.colptr[col + 1];
+  for (int64_t q0 = p.colptr[col] + lane; q0 < e; q0 += 256) {  // four entries of a lane per trip, taken in ascending order
+    int32_t r[4];
+    double l[4], sr[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const bool in = q0 + 64 * u < e;
+      r[u] = in ? p.row[q0 + 64 * u] : 0;
+      l[u] = in ? lg[q0 + 64 * u] : 0.0;
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) sr[u] = srow[r[u]];
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+      if (q0 + 64 * u < e) s += sr[u] * l[u];
+  }
   s = wsum(s);
   if (lane == 0) cent[col] = (s / stdv[col] - mu[col] * ssum[0]) / (double)p.N;
 }
