@@ -117,23 +117,8 @@ __global__ __launch_bounds__(256) void k_gene_vecs(PatternDev p, const float* __
   const int lane = threadIdx.x & 63;
   if (col >= p.M) return;
   double s = 0.0;
-  const int64_t e = p.colptr[col + 1];
-  for (int64_t q0 = p.colptr[col] + lane; q0 < e; q0 += 256) {  // four entries of a lane per trip, taken in ascending order
-    float v[4];
-    int32_t r[4];
-    double a4[4];
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const bool in = q0 + 64 * u < e;
-      v[u] = in ? val[q0 + 64 * u] : 0.f;
-      r[u] = in ? p.row[q0 + 64 * u] : 0;
-    }
-#pragma unroll
-    for (int u = 0; u < 4; ++u) a4[u] = sa[r[u]];
-#pragma unroll
-    for (int u = 0; u < 4; ++u)
-      if (v[u] != 0.f) s += a4[u];
-  }
+  for (int64_t q = p.colptr[col] + lane; q < p.colptr[col + 1]; q += 64)
+    if (val[q] != 0.f) s += sa[p.row[q]];
   s = wsum_d(s);
   const double d = 1.0 / stdv[col];
   if (lane == 0) gv[col] = make_double4(d, d * s, mu[col], cent[col]);

@@ -231,30 +231,14 @@ __global__ __launch_bounds__(256) void k_row_norms(PatternDev p, const float* __
     const float* vc = val + p.nU;
     const double t = tgc[row];
     const float inv = 1.0f / (float)t;
-    const int64_t e = p.rowptr[row + 1];
-    for (int64_t q0 = p.rowptr[row] + lane; q0 < e; q0 += 256) {  // four entries of a lane per trip, taken in ascending order
-      float v[4];
-      int32_t c[4];
-      double sd[4], m4[4];
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const bool in = q0 + 64 * u < e;
-        v[u] = in ? vc[q0 + 64 * u] : 0.f;
-        c[u] = in ? p.csrcol[q0 + 64 * u] : 0;
-      }
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        sd[u] = stdv[c[u]];
-        m4[u] = mu[c[u]];
-      }
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        if (v[u] == 0.f) continue;
-        const double l = f32path ? (double)log1pf(inv * v[u]) : log1p((double)v[u] / t);
-        const double z = l / sd[u];
-        zz += z * z;
-        zm += z * m4[u];
-      }
+    for (int64_t q = p.rowptr[row] + lane; q < p.rowptr[row + 1]; q += 64) {
+      const float v = vc[q];
+      if (v == 0.f) continue;
+      const int64_t c = p.csrcol[q];
+      const double l = f32path ? (double)log1pf(inv * v) : log1p((double)v / t);
+      const double z = l / stdv[c];
+      zz += z * z;
+      zm += z * mu[c];
     }
   } else {
     for (int64_t q = p.rowptr[row] + lane; q < p.rowptr[row + 1]; q += 64) {
@@ -286,22 +270,7 @@ __global__ __launch_bounds__(256) void k_col_cent(PatternDev p, const double* __
   const int lane = threadIdx.x & 63;
   if (col >= p.M) return;
   double s = 0.0;
-  const int64_t e = p.colptr[col + 1];
-  for (int64_t q0 = p.colptr[col] + lane; q0 < e; q0 += 256) {  // four entries of a lane per trip, taken in ascending order
-    int32_t r[4];
-    double l[4], sr[4];
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const bool in = q0 + 64 * u < e;
-      r[u] = in ? p.row[q0 + 64 * u] : 0;
-      l[u] = in ? lg[q0 + 64 * u] : 0.0;
-    }
-#pragma unroll
-    for (int u = 0; u < 4; ++u) sr[u] = srow[r[u]];
-#pragma unroll
-    for (int u = 0; u < 4; ++u)
-      if (q0 + 64 * u < e) s += sr[u] * l[u];
-  }
+  for (int64_t q = p.colptr[col] + lane; q < p.colptr[col + 1]; q += 64) s += srow[p.row[q]] * lg[q];
   s = wsum(s);
   if (lane == 0) cent[col] = (s / stdv[col] - mu[col] * ssum[0]) / (double)p.N;
 }
