@@ -185,6 +185,8 @@ function sclens_hip_device(inp_df; th=60, p_step=0.001, n_perturb=20, centering=
             r = Ref{Int64}(0)
             check(ctx, ccall((:sclens_hip_session_binary_basis, LIB), Cint, (Ptr{Cvoid}, Ptr{Float64}, Ref{Int64}), s, C_NULL, r))
             n_2 = round(Int, r[] / 2)                                         # :722
+            # the split images of the dense Gram products are idle from here on (12 GB at 100 000 x 30 000): back to the library's pool
+            check(ctx, ccall((:sclens_hip_release_scratch, LIB), Cint, (Ptr{Cvoid}, Cstring), ctx, "gram"))
             p_ = 0.999; tank_ = zeros(5, 0); d5 = zeros(5); rit = Ref{Int64}(0)
             while true                                                       # :725-761
                 nnzidx = Int(round((1 - p_) * M * N))
@@ -199,6 +201,10 @@ function sclens_hip_device(inp_df; th=60, p_step=0.001, n_perturb=20, centering=
             end
             min_s = k; min_pc = Int(ceil(min_s * 1.5))
             iszero(min_s) && return Dict(:L => L, :L_mp => L_mp, :λ => lambda_c, :cell_id => string.(inp_df.cell))   # :780-784
+            # the full eigensolver's and the search statistic's scratch (30-40 GB) are idle during the ensemble, whose partial
+            # eigensolver wants 24 GB of images instead
+            check(ctx, ccall((:sclens_hip_release_scratch, LIB), Cint, (Ptr{Cvoid}, Cstring), ctx, "eigensolver"))
+            check(ctx, ccall((:sclens_hip_release_scratch, LIB), Cint, (Ptr{Cvoid}, Cstring), ctx, "corr"))
             nLt = zeros(min_pc); nc = Ref{Int64}(0)
             for t in 1:n_perturb                                             # :771-778
                 sple = UInt32.(sample(UInt32(1):UInt32(length(z1)), Int(round((1 - p_) * M * N)), replace=false) .- 1)   # R5

@@ -83,6 +83,24 @@ def test_sclens_with_gram_bits_matches_oracle(ctx):
     assert list(res["sig_id"]) == list(ref["sig_id"])
 
 
+def test_pattern_image_written_once_gives_the_same_bits(ctx, opt):
+    """k_mask_fused (round 5: the 0/1 image of a binarised matrix written once from LDS chunks of 8 192 cells) against memset +
+    scatter (context option dense_fused = 0): N spans three chunks with a partial last one, the union pattern has the unordered
+    candidate tail; the search statistics of every evaluation and the binarised basis' eigenvalue count are bitwise the same."""
+    N, M = 20000, 300
+    X = synth_counts(N, M, seed=4, C=5, marker_frac=0.2, marker_sd=1.5)
+    d = api.make_draws_native(X, seed=23)
+    out = []
+    for flag in (1, 0):
+        opt(gram_bits=1, dense_fused=flag)
+        out.append(api.sclens(X, draws=d, n_perturb=2, ctx=ctx, max_search_iters=4, streams=1))
+    a, b = out
+    assert a["gram_bits_used"] >= a["n_search"] + 1 and a["gram_bits_used"] == b["gram_bits_used"]
+    assert a["n_search"] == b["n_search"] and a["p_"] == b["p_"]
+    for (p1, t1), (p2, t2) in zip(a["search_trace"], b["search_trace"]):
+        assert p1 == p2 and np.array_equal(t1, t2)
+
+
 @pytest.mark.parametrize("pipe", [1, 0])
 @pytest.mark.parametrize("n,p,q", [(500, 300, 130), (1000, 777, 260), (2050, 520, 515), (96, 40, 33)])
 def test_corr_colmax_split_fp16(ctx, n, p, q, pipe, opt):
