@@ -327,7 +327,7 @@ def compact_line(full, detail_path=None):
             "bench_wall_s")
     line = {k: full[k] for k in keep if k in full}
     cfg = full.get("config", {})
-    line["config"] = {k: cfg[k] for k in ("workload", "N", "M", "n_perturb", "parallelism", "comm", "precision", "keep_warm") if k in cfg}
+    line["config"] = {k: cfg[k] for k in ("workload", "N", "M", "n_perturb", "parallelism", "comm", "precision", "keep_warm", "ensemble_tail") if k in cfg}
     for k in ("workload", "parallelism", "comm"):
         if isinstance(line["config"].get(k), str) and len(line["config"][k]) > 220:
             line["config"][k] = line["config"][k][:217] + "..."
@@ -493,6 +493,7 @@ def main():
                 "min_abs_margin": (round(min(abs(x - p_th) for x in d2), 6) if d2 else None),
                 "d5_second_smallest": [round(x, 5) for x in d2], "p_th": round(p_th, 6),
                 "phase_s": {k: round(float(v), 3) for k, v in (res.get("phase_s") or {}).items()},
+                "ensemble_tail": res.get("ensemble_tail"), "members_solved_again": [int(t) for t in res.get("tail_redo", [])],
                 "first_phase_jobs_s": [list(q) for q in res.get("first_phase_s", [])]}
 
     def run_config(cfg, steps_req, warm_req, deadline, tail_steps=0.0, step0=0):
@@ -604,7 +605,8 @@ def main():
                                        else f"single GPU, {n_streams} concurrent decompositions (HIP streams)" if world == 1 else
                                        f"search rounds of {world}x{n_streams} + ensemble t%{world}, 1 RCCL all-gather "
                                        f"issued by the library on its own buffers"),
-                       "comm": shard.describe(), "precision": precision, "keep_warm": True},
+                       "comm": shard.describe(), "precision": precision, "keep_warm": True,
+                       "ensemble_tail": res.get("ensemble_tail")},
             "sclens_wall_s": round(dt / max(1, steps), 3),
             "observed": {"signals": int(len(res.get("signal_ev", []))), "robust_signals": int(len(res.get("sig_id", []))),
                          "search_iters": int(res["n_search"]), "p_": res["p_"], "synth_s": round(main_r["synth_s"], 1),

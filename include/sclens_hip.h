@@ -362,7 +362,15 @@ int sclens_hip_session_perturb(sclens_hip_session* s, int64_t t, const uint32_t*
 int sclens_hip_session_get_perturbed(sclens_hip_session* s, int64_t t, float* nV_t);
 /* Options / counters. set: "chefsi" (1 = ensemble members use the leading-eigenpair subspace iteration seeded with the
  * data matrix's eigenvectors, falling back to the full solver if it does not converge; 0 = always the full solver).
- * get: "chefsi", "chefsi_used", "chefsi_fallback". */
+ * get: "chefsi", "chefsi_used", "chefsi_fallback".
+ * "chefsi_tail_gap_milli" (set / get): the eigenpairs k .. min_pc-1 of a member additionally held to value/1000 x their gap to the
+ * block's smallest Ritz value (a host switches it on to solve a member again whose tail vector the matching :788 picked).
+ * "chefsi_tail_free" (set / get, round 5): 1 = those tail pairs are not converged at all (a member then costs a third of the passes
+ * over its scaled matrix); sclens_hip_session_robustness then records per member whether the matching provably does not depend on
+ * them -- signal i correlates with any unit vector orthogonal to the member's first k eigenvectors by at most
+ * sqrt(1 - sum_{j<k} c_ij^2), so the argmax of :788 lies among the first k whenever the best of them beats that bound --:
+ * get "match_uncertain:<t>" = 1 for a member t without that proof (or whose matching picked a column >= k), "match_uncertain_count"
+ * their number. The host solves such members again with "chefsi_tail_free" = 0 and repeats sclens_hip_session_robustness. */
 int sclens_hip_session_set_int(sclens_hip_session* s, const char* name, int64_t value);
 int sclens_hip_session_get_int(sclens_hip_session* s, const char* name, int64_t* value);
 /* Multi-GPU ensemble sharding: copy slot t to / from a contiguous device buffer of min_pc x ldn floats

@@ -206,14 +206,41 @@ function sclens_hip_device(inp_df; th=60, p_step=0.001, n_perturb=20, centering=
             check(ctx, ccall((:sclens_hip_release_scratch, LIB), Cint, (Ptr{Cvoid}, Cstring), ctx, "eigensolver"))
             check(ctx, ccall((:sclens_hip_release_scratch, LIB), Cint, (Ptr{Cvoid}, Cstring), ctx, "corr"))
             nLt = zeros(min_pc); nc = Ref{Int64}(0)
-            for t in 1:n_perturb                                             # :771-778
-                sple = UInt32.(sample(UInt32(1):UInt32(length(z1)), Int(round((1 - p_) * M * N)), replace=false) .- 1)   # R5
+            # R5: member t draws from its own generator, so that a member can be solved a second time on the same sample (below)
+            pseeds = rand(UInt64, n_perturb)
+            member(t) = begin                                                # :771-778
+                sple = UInt32.(sample(MersenneTwister(pseeds[t]), UInt32(1):UInt32(length(z1)), Int(round((1 - p_) * M * N)), replace=false) .- 1)
                 GC.@preserve sple nLt check(ctx, ccall((:sclens_hip_session_perturb, LIB), Cint,
                     (Ptr{Cvoid}, Int64, Ptr{UInt32}, Int64, Int64, Ptr{Float64}, Ref{Int64}), s, t - 1, sple, length(sple), min_pc, nLt, nc))
             end
+            # the eigenpairs k .. min_pc-1 of a member (:776) are consumed only if the matching (:788) picks one. From order 16 000 they are
+            # not converged at all ("chefsi_tail_free"); the library then reports per member whether the matching provably does not
+            # depend on them ("match_uncertain:<t>", include/sclens_hip.h), and the members without that proof -- or whose matching
+            # picked a tail column -- are solved again with the tail converged
+            tail_free = nm >= 16000
+            setint(name, v) = check(ctx, ccall((:sclens_hip_session_set_int, LIB), Cint, (Ptr{Cvoid}, Cstring, Int64), s, name, v))
+            getint(name) = begin
+                v = Ref{Int64}(0)
+                check(ctx, ccall((:sclens_hip_session_get_int, LIB), Cint, (Ptr{Cvoid}, Cstring, Ref{Int64}), s, name, v))
+                v[]
+            end
+            setint("chefsi_tail_free", tail_free ? 1 : 0)
+            for t in 1:n_perturb
+                member(t)
+            end
             npairs = div(n_perturb * (n_perturb - 1), 2)
             a_b = Matrix{Int32}(undef, k, n_perturb); bt = Matrix{Float64}(undef, npairs, k)   # row-major k x npairs
-            GC.@preserve a_b bt check(ctx, ccall((:sclens_hip_session_robustness, LIB), Cint, (Ptr{Cvoid}, Int64, Ptr{Int32}, Ptr{Float64}), s, n_perturb, a_b, bt))
+            score() = GC.@preserve a_b bt check(ctx, ccall((:sclens_hip_session_robustness, LIB), Cint, (Ptr{Cvoid}, Int64, Ptr{Int32}, Ptr{Float64}), s, n_perturb, a_b, bt))
+            score()
+            again = [t for t in 1:n_perturb if any(a_b[:, t] .>= k) || (tail_free && getint("match_uncertain:$(t - 1)") != 0)]
+            if !isempty(again)
+                setint("chefsi_tail_free", 0); setint("chefsi_tail_gap_milli", 50)
+                for t in again
+                    member(t)
+                end
+                setint("chefsi_tail_gap_milli", 0)
+                score()
+            end
             b_ = permutedims(bt)
             q1 = mapslices(x -> quantile(x, 0.25), b_, dims=2)[:]; q3 = mapslices(x -> quantile(x, 0.75), b_, dims=2)[:]
             iq = mapslices(iqr, b_, dims=2)[:]

@@ -1037,7 +1037,7 @@ def sclens(inp_df, device_="gpu", th=60, p_step=0.001, n_perturb=20, centering="
            seed: Optional[int] = None, ctx: Optional[Context] = None, max_search_iters: Optional[int] = None,
            keep_intermediates: bool = False, verbose: bool = False, shard: Optional[Shard] = None,
            partial_eig: bool = True, streams: Optional[int] = None, spread_initial: bool = True,
-           guard_band: float = 4.0, keep_warm: bool = False) -> Dict[str, object]:
+           guard_band: float = 4.0, keep_warm: bool = False, ensemble_tail: str = "auto") -> Dict[str, object]:
     """scLENS.sclens (scLENS.jl:649-832) on one MI355X.
 
     Same keyword arguments as the reference. `draws`/`seed` expose the randomness the reference takes from
@@ -1048,6 +1048,11 @@ def sclens(inp_df, device_="gpu", th=60, p_step=0.001, n_perturb=20, centering="
     1 (default) = large products from two fp16 pieces; worker contexts inherit the caller's options. `keep_warm=True` leaves the call's
     device blocks in the library's pool for a next call of the same shape (a loop of calls, bench.py); the default gives them back to
     the driver when the call returns (sclens_hip_trim), so that whatever runs next on the GPU finds the memory free.
+    `ensemble_tail`: how the partial eigensolver treats the eigenpairs k .. ceil(1.5 k)-1 of an ensemble member, which the reference
+    computes (:776) and consumes only if the matching (:788) picks one: "converged" = to 5e-3 of their eigenvalue; "certified" = not
+    at all, and the matching is accepted per member only with a proof that no vector outside the first k could have been picked
+    (else that member is solved again, tail included); "auto" = certified from order 16 000. The outputs are the same either way;
+    `nL_set[t][k:]` (not a reference output) are estimates in the certified mode.
     """
     if device_ != "gpu":
         raise NotImplementedError("sclens_amd implements the device path only; use the reference for device_='cpu'")
@@ -1084,6 +1089,9 @@ def sclens(inp_df, device_="gpu", th=60, p_step=0.001, n_perturb=20, centering="
         if seed is None:  # every rank must draw the same candidates, null matrix and sample seeds: rank 0's clock decides
             seed = int(shard.bcast_host(np.array([float(time.time_ns() % (2**31))]), 0)[0])
         draws = make_draws_native(X_, int(seed))
+    if ensemble_tail not in ("auto", "certified", "converged"):
+        raise ValueError("ensemble_tail must be 'auto', 'certified' or 'converged'")
+    tail_free = bool(partial_eig) and (ensemble_tail == "certified" or (ensemble_tail == "auto" and min(N, M) >= 16000))
     phase, phase_peak = {}, {}
     t_ph = time.perf_counter()
     ctx.pool_peak(reset=True)
@@ -1332,6 +1340,9 @@ def sclens(inp_df, device_="gpu", th=60, p_step=0.001, n_perturb=20, centering="
             min_s = k
             min_pc = int(math.ceil(min_s * 1.5))
             m_pert = int(round((1 - p_) * M * N))
+            if tail_free:
+                for w in workers:
+                    w.set_int("chefsi_tail_free", 1)
             nL_set = [None] * n_perturb
             ncols = [0] * n_perturb
             if min_s > 0:
@@ -1391,9 +1402,18 @@ def sclens(inp_df, device_="gpu", th=60, p_step=0.001, n_perturb=20, centering="
         # k .. min_pc-1 sit at the edge of the bulk and are accepted at 5e-3 theta. They only matter if the matching (:788) PICKS one:
         # then that member is solved again with the gap-aware target on the tail as well (chefsi.hip; +0.1 s per member instead of
         # +2.5 s per call for applying it to every member) and the matching is redone -- every vector that enters b_ has met it.
+        # `ensemble_tail = "certified"` (the default from order 16 000, where a member's eigensolver applies its operator implicitly and
+        # two thirds of its passes over the scaled matrix went into those four or five tail pairs): the tail is not converged at all, and
+        # the matching is accepted only where it provably does not depend on it -- signal i correlates with ANY unit vector orthogonal to
+        # a member's first k eigenvectors by at most sqrt(1 - sum_{j<k} c_ij^2); where the best of the first k beats that bound the
+        # argmax lies among them whatever the tail columns hold (session_robustness, `match_uncertain`). Members without that proof
+        # are solved again like the ones above. nL_set[t][k:] are then Ritz estimates (a few per cent), not eigenvalues.
         tail_redo = []
         if partial_eig and pe_counts[0] > 0 and ncols and max(ncols) > k:
             tail_redo = [t for t in range(n_perturb) if ncols[t] > k and np.any(a_b[:, t] >= k)]
+            if tail_free:
+                tail_redo = sorted(set(tail_redo) | {t for t in range(n_perturb) if ses.get_int(f"match_uncertain:{t}")})
+                ses.set_int("chefsi_tail_free", 0)
             if tail_redo:
                 ses.set_int("chefsi_tail_gap_milli", 50)
                 try:
@@ -1406,6 +1426,7 @@ def sclens(inp_df, device_="gpu", th=60, p_step=0.001, n_perturb=20, centering="
                     ses.set_int("chefsi_tail_gap_milli", 0)
                 a_b, b_ = ses.robustness(k, n_perturb)
         res["tail_redo"] = tail_redo
+        res["ensemble_tail"] = "certified" if tail_free else "converged"
         m_score, sd_score = _robust_scores(b_)
         rob_score = m_score
         sig_id = np.flatnonzero(rob_score > th_)

@@ -137,7 +137,7 @@ void jacobi_eig(std::vector<double> C, int b, std::vector<double>& ev, std::vect
 
 int topk_chefsi(Ctx* ctx, const float* A, int64_t n, int64_t lda, int m, int m_strict, int b, const float* X0t, int64_t ldx,
                 const double* theta0, double* w_desc, float* Zt, int64_t ldz, int* converged, int* iters, const float* Bop,
-                int64_t Kop, int64_t ldb, float div, double tail_gap) {
+                int64_t Kop, int64_t ldb, float div, double tail_gap, int tail_free) {
   *converged = 0;
   if (iters) *iters = 0;
   if (m <= 0 || b < m || b > 128 || b > n) return ctx->fail(SCLENS_ERR_ARG, "topk_chefsi: bad block sizes");
@@ -342,6 +342,10 @@ int topk_chefsi(Ctx* ctx, const float* A, int64_t n, int64_t lda, int m, int m_s
   // api.sclens / session option "chefsi_tail_gap_milli"); the context option chefsi_tail_gap_micro overrides
   const double tail_env = ctx->opt.chefsi_tail_gap_micro >= 0 ? 1e-6 * (double)ctx->opt.chefsi_tail_gap_micro : -1.0;
   const double tol_gap_tail = tail_env >= 0.0 ? tail_env : (tail_gap > 0.0 ? tail_gap : 1e30);
+  // tail_free: only the strict pairs decide convergence, locking and the filter's degree; the pairs m_strict .. m-1 come back as
+  // whatever Ritz pairs the block holds when the strict ones are done (orthonormal to them by the Rayleigh-Ritz step, eigenvalues
+  // to a few per cent). For callers that can PROVE they do not consume them (session_robustness' matching certificate).
+  const int m_conv = tail_free ? std::min(m, std::max(1, m_strict)) : m;
   for (int outer = 0; outer < max_outer; ++outer) {
     // ---- Chebyshev filter of `degree`: damp [0, theta_b], normalise at theta_1
     const double lo = 0.0, cut = std::max(theta[b - 1], 1e-12 * theta[0]);
@@ -360,7 +364,7 @@ int topk_chefsi(Ctx* ctx, const float* A, int64_t n, int64_t lda, int m, int m_s
       // no more than the sweep needs: the wanted pair q is amplified by cosh(d acosh(x_q)) against the edge of the block;
       // ask for 4x the largest remaining residual / target ratio, at the pair that the filter separates least
       double need = 1.0, ach_min = 1e300;
-      for (int q = r0; q < m; ++q) {
+      for (int q = r0; q < m_conv; ++q) {
         double lim = (q < m_strict ? tol_rel : tol_rel_tail) * std::fabs(theta[q]);
         if (q >= m_strict && b > m) lim = std::min(lim, std::max(tol_gap_tail * (theta[q] - theta[b - 1]), 4e-6 * std::fabs(theta[0])));
         need = std::max(need, (double)hres[q] / std::max(lim, 1e-300));
@@ -488,7 +492,7 @@ int topk_chefsi(Ctx* ctx, const float* A, int64_t n, int64_t lda, int m, int m_s
       return lim;
     };
     bool ok = true;
-    for (int q = 0; q < m; ++q) ok = ok && ((double)hres[q] <= target(q));
+    for (int q = 0; q < m_conv; ++q) ok = ok && ((double)hres[q] <= target(q));
     if (ok && outer >= 1) { *converged = 1; break; }
     // lock the leading run of pairs that have reached their targets (from the second sweep on); a locked pair that drifts
     // above ten times its target unlocks everything
@@ -499,7 +503,7 @@ int topk_chefsi(Ctx* ctx, const float* A, int64_t n, int64_t lda, int m, int m_s
         nlock = 0;
       } else {
         int nl = 0;
-        while (nl < m && nl < NLMAX && nl < b - 8 && (double)hres[nl] <= target(nl)) ++nl;
+        while (nl < m_conv && nl < NLMAX && nl < b - 8 && (double)hres[nl] <= target(nl)) ++nl;
         nlock = std::max(nlock, nl);
       }
     }

@@ -365,9 +365,10 @@ int symv_probe(Ctx* ctx, int64_t n, int64_t* launches, double* total_ms, double*
 // Bop != nullptr: A is given implicitly as Bop Bop' / div with Bop [n x Kop] row-major (ldb) -- the Gram matrix is not needed
 // (A may be nullptr); every block product then costs two passes over Bop.
 // tail_gap > 0: the pairs m_strict .. m-1 are additionally held to tail_gap x (theta_q - smallest Ritz value of the block).
+// tail_free != 0: the pairs m_strict .. m-1 are not part of the convergence test at all (Ritz pairs of the block as they are).
 int topk_chefsi(Ctx* ctx, const float* A, int64_t n, int64_t lda, int m, int m_strict, int b, const float* X0t, int64_t ldx,
                 const double* theta0, double* w_desc, float* Zt, int64_t ldz, int* converged, int* iters,
-                const float* Bop = nullptr, int64_t Kop = 0, int64_t ldb = 0, float div = 1.f, double tail_gap = 0.0);
+                const float* Bop = nullptr, int64_t Kop = 0, int64_t ldb = 0, float div = 1.f, double tail_gap = 0.0, int tail_free = 0);
 
 // ------------------------------------------------------------------ small device helpers (util.hip)
 int fill_f32(Ctx* ctx, float* p, int64_t n, float v);

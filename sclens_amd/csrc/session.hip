@@ -221,6 +221,9 @@ struct Session {
   int64_t Kdiv = 0;
   int64_t chefsi_used = 0, chefsi_fallback = 0;
   double chefsi_tail_gap = 0.0;  // > 0: gap-aware targets for the tail pairs of the partial eigensolver (chefsi.hip)
+  int chefsi_tail_free = 0;      // != 0: the tail pairs k .. min_pc-1 of an ensemble member are not converged at all (chefsi.hip); the caller
+                                 // consults match_uncertain after session_robustness and solves the members it names again
+  std::vector<int> match_uncertain;  // per member: the matching certificate of session_robustness did NOT hold
   float* nVt = nullptr;       // signal vectors, cell side, descending, [k][ldn]
   int64_t k = 0, ldn = 0;
   std::vector<float*> ens;    // slot t: [ncols][ldn], descending
@@ -1082,7 +1085,7 @@ static int perturb_core(Session* s, int64_t t, int64_t min_pc, double* nL_top, i
     int conv = 0, its = 0;
     SCL_TRY(topk_chefsi(ctx, implicit_op ? nullptr : s->A, s->n, s->lda, (int)min_pc, (int)std::min<int64_t>(s->k, min_pc), (int)s->b0,
                         s->Z0t, s->ldz, s->theta0.data(), wd.data(), s->Zt, s->ldz, &conv, &its, implicit_op ? s->Btmp : nullptr,
-                        s->K, s->ldb, (float)s->M, s->chefsi_tail_gap));
+                        s->K, s->ldb, (float)s->M, s->chefsi_tail_gap, s->chefsi_tail_free));
     const double tol = 8.0 * 5.96e-8 * std::sqrt((double)s->n) * std::max(0.0, wd.empty() ? 0.0 : wd[0]);
     if (conv && wd[min_pc - 1] > tol) {  // all min_pc eigenvalues positive: c = min(min_pc, r) = min_pc
       s->chefsi_used += 1;
@@ -1285,6 +1288,7 @@ int session_set_int(Session* s, const char* name, int64_t value) {
   const std::string k(name ? name : "");
   if (k == "chefsi") { s->use_chefsi = value != 0; return SCLENS_OK; }
   if (k == "chefsi_tail_gap_milli") { s->chefsi_tail_gap = (double)value * 1e-3; return SCLENS_OK; }
+  if (k == "chefsi_tail_free") { s->chefsi_tail_free = value != 0; return SCLENS_OK; }
   if (k == "centering") {  // 0 = "mean", 1 = "median" (scLENS.jl:651-654); set before the first decomposition
     if (value != 0 && value != 1) return s->ctx->fail(SCLENS_ERR_ARG, "session_set_int: centering must be 0 or 1");
     if (value == 1 && s->sh.on()) return s->ctx->fail(SCLENS_ERR_ARG, "session_set_int: a row-sharded session supports mean centring only");
@@ -1300,6 +1304,17 @@ int session_get_int(Session* s, const char* name, int64_t* value) {
   if (k == "chefsi_fallback") { *value = s->chefsi_fallback; return SCLENS_OK; }
   if (k == "chefsi") { *value = s->use_chefsi; return SCLENS_OK; }
   if (k == "chefsi_tail_gap_milli") { *value = (int64_t)(s->chefsi_tail_gap * 1e3 + 0.5); return SCLENS_OK; }
+  if (k == "chefsi_tail_free") { *value = s->chefsi_tail_free; return SCLENS_OK; }
+  if (k == "match_uncertain_count") {
+    *value = 0;
+    for (int u : s->match_uncertain) *value += u != 0;
+    return SCLENS_OK;
+  }
+  if (k.compare(0, 16, "match_uncertain:") == 0) {  // member t of the last session_robustness
+    const int64_t t = atoll(k.c_str() + 16);
+    *value = (t >= 0 && t < (int64_t)s->match_uncertain.size()) ? s->match_uncertain[t] : 0;
+    return SCLENS_OK;
+  }
   if (k == "centering") { *value = s->centering; return SCLENS_OK; }
   if (k == "gram_bits_used") { *value = s->ctx->gram_bits_used; return SCLENS_OK; }
   return s->ctx->fail(SCLENS_ERR_ARG, "session_get_int: unknown option " + k);
@@ -1359,6 +1374,12 @@ int session_robustness(Session* s, int64_t P, int32_t* a_b, double* b) {
   if (!C1 || !sub || !pick) return SCLENS_ERR_OOM;
   std::vector<float> hC((size_t)k * cmax);
   std::vector<int32_t> hp(k);
+  // Matching certificate. Signal vector i has unit length and the eigenvectors of a member are orthonormal, so every unit vector
+  // orthogonal to the member's first k eigenvectors correlates with it by at most sqrt(1 - S_i), S_i = sum_{j<k} c_ij^2. If the best
+  // of the first k beats that bound, the argmax of :788 lies among them WHATEVER the columns k .. min_pc-1 hold: those columns are
+  // then provably not consumed (the partial eigensolver may leave them unconverged, `chefsi_tail_free`). match_uncertain[t] = 1
+  // where that cannot be shown for some signal (or a column >= k was picked); the caller solves such a member again.
+  s->match_uncertain.assign((size_t)P, 0);
   for (int64_t t = 0; t < P; ++t) {
     const int64_t c = s->ens_cols[t];
     GemmArgs g{};
@@ -1379,6 +1400,13 @@ int session_robustness(Session* s, int64_t P, int32_t* a_b, double* b) {
       }
       hp[i] = best;
       a_b[i + t * k] = best;
+      double S = 0.0, bk = 0.0;
+      for (int64_t j = 0; j < std::min<int64_t>(k, c); ++j) {
+        const double v = (double)hC[i * cmax + j];
+        S += v * v;
+        bk = std::max(bk, std::fabs(v));
+      }
+      if (best >= k || bk * bk <= (1.0 - S) + 1e-3) s->match_uncertain[t] = 1;  // 1e-3: fp32 products, vectors orthonormal to ~1e-6
     }
     SCL_HIP(ctx, hipMemcpyAsync(pick, hp.data(), sizeof(int32_t) * k, hipMemcpyHostToDevice, ctx->stream));
     hipLaunchKernelGGL(k_gather_rows, dim3((unsigned)((s->N + 255) / 256), (unsigned)k), dim3(256), 0, ctx->stream,

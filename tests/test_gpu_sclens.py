@@ -181,6 +181,45 @@ def test_partial_eigensolver_matches_full_solver(ctx, N, M, implicit, opt):
         assert np.all(_abs_cos(a["nV_set"][t][:, cols], b["nV_set"][t][:, cols]) > 1 - 2e-2)
 
 
+@pytest.mark.parametrize("implicit", [0, 1])
+@pytest.mark.parametrize("N,M,sd", [(300, 500, 1.5), (600, 250, 1.5), (600, 250, 0.8)])
+def test_certified_ensemble_tail_gives_the_outputs_of_the_full_solver(ctx, N, M, sd, implicit, opt):
+    """ensemble_tail = "certified" (the default from order 16 000): the eigenpairs k .. min_pc-1 of a member are left unconverged and
+    the matching (scLENS.jl:788) is accepted per member only with the proof that no vector outside the first k could have been picked
+    (session_robustness: best_k^2 > 1 - sum_{j<k} c_ij^2); members without it are solved again with the tail converged. Every OUTPUT
+    equals the full solver's: a_b, sig_id exactly, scores and signal pairs to the usual tolerances; the certificate the library
+    reports equals the one recomputed here from the vectors (weak markers, sd = 0.8: members without proof do occur)."""
+    opt(implicit_min_n=1 if implicit else 1000000000)
+    X = synth_counts(N, M, seed=1, C=5, marker_frac=0.2, marker_sd=sd)
+    d = api.make_draws_native(X, seed=9)
+    kw = dict(draws=d, n_perturb=5, ctx=ctx, keep_intermediates=True, max_search_iters=6)
+    a = api.sclens(X, partial_eig=True, ensemble_tail="certified", **kw)
+    b = api.sclens(X, partial_eig=False, **kw)
+    if "robustness_scores" not in b:
+        pytest.skip("no signal in this matrix")
+    assert a["ensemble_tail"] == "certified" and b["ensemble_tail"] == "converged"
+    assert a["partial_eig"][0] >= 5 and a["partial_eig"][1] == 0, a["partial_eig"]
+    k = len(b["signal_ev"])
+    assert k >= 1
+    ab = a["robustness_scores"]["a_b"]
+    assert np.array_equal(ab, b["robustness_scores"]["a_b"])
+    assert np.abs(a["robustness_scores"]["rob_score"] - b["robustness_scores"]["rob_score"]).max() < 3e-3
+    assert np.array_equal(a["sig_id"], b["sig_id"])
+    nV = b["signal_evec"].astype(np.float64)
+    for t in range(5):
+        assert np.allclose(a["nL_set"][t][:k], b["nL_set"][t][:k], rtol=3e-4)
+        assert np.all(_abs_cos(a["nV_set"][t][:, :k], b["nV_set"][t][:, :k]) > 1 - 3e-3)
+        # the certificate, from the full solver's vectors: where it holds the member was not solved again, and vice versa up to the margin
+        c = np.abs(nV.T @ b["nV_set"][t][:, :k].astype(np.float64))
+        proof = np.all(c.max(axis=1) ** 2 > 1.0 - (c ** 2).sum(axis=1) + 5e-3)
+        if proof:
+            assert t not in a["tail_redo"], (t, a["tail_redo"])
+        if t in a["tail_redo"]:  # solved again: every picked column agrees with the full solver's
+            cols = np.unique(ab[:, t])
+            assert np.all(_abs_cos(a["nV_set"][t][:, cols], b["nV_set"][t][:, cols]) > 1 - 2e-2)
+    print(f"[certified tail {N}x{M} sd {sd} implicit {implicit}] k {k}, members solved again: {a['tail_redo']}")
+
+
 def test_partial_eigensolver_tail_gap_option(ctx):
     """session option "chefsi_tail_gap_milli": the tail pairs k .. min_pc-1 of an ensemble member held to a gap-aware residual
     target, residual <= 0.05 (theta_q - theta_block_end), i.e. sin(angle to the true vector) <= 0.05 (what api.sclens switches on

@@ -12,11 +12,12 @@ from sclens_amd import api
 from sclens_amd.synth import synth_counts
 
 
-def _pair(monkeypatch, N, M, streams, n_perturb=4, centering="mean", **kw):
+def _pair(monkeypatch, N, M, streams, n_perturb=4, centering="mean", ensemble_tail="auto", **kw):
     X = synth_counts(N, M, seed=3, C=4, marker_frac=0.25, marker_sd=1.5)
     d = api.make_draws(X, seed=11, p_th_trials=200)
     ref = O.sclens(X, O.Draws(d.z_idx1, d.z_idx2, d.X_r, d.p_th, d.sampler), n_perturb=n_perturb, null_tol=O.NULL_DROP,
                    centering=centering, keep_intermediates=True, **kw)
+    kw = dict(kw, ensemble_tail=ensemble_tail)
     main = F.install(monkeypatch)
     res = api.sclens(X, draws=d, n_perturb=n_perturb, ctx=main, streams=streams, centering=centering, keep_intermediates=True, **kw)
     return ref, res
@@ -59,6 +60,24 @@ def test_capped_search_median_centering_and_five_members(monkeypatch):
     _same(ref, res)
     assert res["n_search"] == 5 and res["rec_vals"] == {}
     _all_closed()
+
+
+def test_certified_ensemble_tail_redoes_the_members_the_session_names(monkeypatch):
+    """ensemble_tail = "certified": every worker gets chefsi_tail_free = 1 before the ensemble; after the matching the members the
+    session reports as uncertain (match_uncertain:t) are solved again on the main session with the tail converged (tail_free back to
+    0, gap-aware target on), and the matching is redone; same result as the oracle, nothing left open"""
+    log = []
+    orig_set, orig_get = F.FakeSession.set_int, F.FakeSession.get_int
+    monkeypatch.setattr(F.FakeSession, "set_int", lambda self, name, value: (log.append((id(self), name, value)), orig_set(self, name, value))[1])
+    monkeypatch.setattr(F.FakeSession, "get_int", lambda self, name: 1 if name in ("match_uncertain:1", "chefsi_used") else orig_get(self, name))
+    ref, res = _pair(monkeypatch, 150, 220, 2, ensemble_tail="certified")
+    _same(ref, res)
+    _all_closed()
+    assert res["ensemble_tail"] == "certified" and res["tail_redo"] == [1]
+    frees = [(sid, v) for sid, name, v in log if name == "chefsi_tail_free"]
+    assert len({sid for sid, v in frees if v == 1}) == 2 and frees[-1][1] == 0  # both workers switched on; the main session off for the redo
+    gaps = [v for _, name, v in log if name == "chefsi_tail_gap_milli"]
+    assert gaps == [50, 0]
 
 
 def test_a_failure_in_a_worker_closes_everything(monkeypatch):
