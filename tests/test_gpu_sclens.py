@@ -220,6 +220,71 @@ def test_certified_ensemble_tail_gives_the_outputs_of_the_full_solver(ctx, N, M,
     print(f"[certified tail {N}x{M} sd {sd} implicit {implicit}] k {k}, members solved again: {a['tail_redo']}")
 
 
+def test_matching_certificate_of_the_session_equals_its_definition(ctx):
+    """session_robustness with "chefsi_tail_free": match_uncertain:t against the definition evaluated here from the downloaded vectors
+    -- member t is certain iff every signal i has best_k^2 > 1 - sum_{j<k} c_ij^2 (+ 1e-3) with c = nV' V_t[:, :k] and its argmax over
+    all min_pc columns lies among the first k. Session A: members of its own matrix (the signals survive the perturbation: certain).
+    Session B, another matrix of the same shape: A's members imported into its slots -- B's signals have nothing to do with them, so
+    no proof can exist: both answers occur and both equal the definition."""
+    XA = api._csc_f32(synth_counts(600, 250, seed=1, C=5, marker_frac=0.2, marker_sd=1.5))
+    XB = api._csc_f32(synth_counts(600, 250, seed=2, C=4, marker_frac=0.25, marker_sd=1.5))
+    d = api.make_draws_native(XA, seed=9)
+    ref = api.sclens(XA, draws=d, n_perturb=2, ctx=ctx, max_search_iters=6, partial_eig=False, streams=1)
+    k, min_pc = len(ref["signal_ev"]), ref["min_pc"]
+    m_pert = int(round((1 - ref["p_"]) * XA.shape[0] * XA.shape[1]))
+
+    def definition(nV, V, kk):
+        c = np.abs(nV.T @ V)
+        slack = c[:, :kk].max(axis=1) ** 2 - (1.0 - (c[:, :kk] ** 2).sum(axis=1) + 1e-3)
+        return int(np.any(c.argmax(axis=1) >= kk) or np.any(slack <= 0)), bool(np.any(np.abs(slack) < 1e-4))
+
+    sesA = api.Session(ctx, XA, api._resolve(d.z_idx1), api._resolve(d.z_idx2))
+    sesB = None
+    buf = 0
+    try:
+        sesA.set_int("chefsi", 1)
+        sesA.null_spectrum(api._resolve(d.X_r))
+        sesA.data_spectrum(True)
+        nVA = sesA.signal_vectors(k).astype(np.float64)
+        sesA.set_int("chefsi_tail_free", 1)
+        assert sesA.get_int("chefsi_tail_free") == 1
+        V = []
+        for t in range(2):
+            _, c = sesA.perturb_seeded(t, api.sample_seed_for(d.sample_seed, "perturb", t), m_pert, min_pc)
+            assert c == min_pc
+            V.append(sesA.get_perturbed(t, c).astype(np.float64))
+        sesA.robustness(k, 2)
+        gotA = [sesA.get_int(f"match_uncertain:{t}") for t in range(2)]
+        assert sesA.get_int("match_uncertain_count") == sum(gotA)
+        # session B: its own signals, A's members
+        dB = api.make_draws_native(XB, seed=10)
+        sesB = api.Session(ctx, XB, api._resolve(dB.z_idx1), api._resolve(dB.z_idx2))
+        sesB.null_spectrum(api._resolve(dB.X_r))
+        LB, _ = sesB.data_spectrum(True)
+        kB = min(k, 3)
+        nVB = sesB.signal_vectors(kB).astype(np.float64)
+        buf = ctx.malloc(4 * min_pc * sesA.slot_ld())
+        for t in range(2):
+            sesA.export_slot(t, min_pc, buf)
+            sesB.import_slot(t, min_pc, min_pc, buf)
+        sesB.robustness(kB, 2)
+        gotB = [sesB.get_int(f"match_uncertain:{t}") for t in range(2)]
+        assert sesB.get_int("match_uncertain_count") == sum(gotB)
+    finally:
+        if buf:
+            ctx.free(buf)
+        sesA.close()
+        if sesB is not None:
+            sesB.close()
+    wantA = [definition(nVA, V[t], k) for t in range(2)]
+    wantB = [definition(nVB, V[t], kB) for t in range(2)]
+    print(f"[matching certificate] k {k}: own members {gotA} (definition {[w for w, _ in wantA]}); foreign members {gotB} (definition {[w for w, _ in wantB]})")
+    for got, want in ((gotA, wantA), (gotB, wantB)):
+        for t in range(2):
+            assert want[t][1] or got[t] == want[t][0], (t, got, want)
+    assert gotA == [0, 0] and gotB == [1, 1]
+
+
 def test_partial_eigensolver_tail_gap_option(ctx):
     """session option "chefsi_tail_gap_milli": the tail pairs k .. min_pc-1 of an ensemble member held to a gap-aware residual
     target, residual <= 0.05 (theta_q - theta_block_end), i.e. sin(angle to the true vector) <= 0.05 (what api.sclens switches on
