@@ -11,6 +11,7 @@ import pytest
 
 from oracle import sclens_oracle as O
 from sclens_amd import api
+from sclens_amd._lib import Context
 from sclens_amd.synth import synth_counts
 
 pytestmark = pytest.mark.gpu
@@ -239,7 +240,7 @@ def test_matching_certificate_of_the_session_equals_its_definition(ctx):
         return int(np.any(c.argmax(axis=1) >= kk) or np.any(slack <= 0)), bool(np.any(np.abs(slack) < 1e-4))
 
     sesA = api.Session(ctx, XA, api._resolve(d.z_idx1), api._resolve(d.z_idx2))
-    sesB = None
+    sesB = ctxB = None
     buf = 0
     try:
         sesA.set_int("chefsi", 1)
@@ -258,7 +259,8 @@ def test_matching_certificate_of_the_session_equals_its_definition(ctx):
         assert sesA.get_int("match_uncertain_count") == sum(gotA)
         # session B: its own signals, A's members
         dB = api.make_draws_native(XB, seed=10)
-        sesB = api.Session(ctx, XB, api._resolve(dB.z_idx1), api._resolve(dB.z_idx2))
+        ctxB = Context(ctx.device)  # one live session per context
+        sesB = api.Session(ctxB, XB, api._resolve(dB.z_idx1), api._resolve(dB.z_idx2))
         sesB.null_spectrum(api._resolve(dB.X_r))
         LB, _ = sesB.data_spectrum(True)
         kB = min(k, 3)
@@ -276,6 +278,8 @@ def test_matching_certificate_of_the_session_equals_its_definition(ctx):
         sesA.close()
         if sesB is not None:
             sesB.close()
+        if ctxB is not None:
+            ctxB.close()
     wantA = [definition(nVA, V[t], k) for t in range(2)]
     wantB = [definition(nVB, V[t], kB) for t in range(2)]
     print(f"[matching certificate] k {k}: own members {gotA} (definition {[w for w, _ in wantA]}); foreign members {gotB} (definition {[w for w, _ in wantB]})")
