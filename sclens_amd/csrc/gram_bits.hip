@@ -152,7 +152,6 @@ __global__ __launch_bounds__(256) void k_mask_fused(PatternDev p, const float* _
   unsigned short* dst = Pm + col * ldm;
   for (int64_t c0 = 0; c0 < ldm; c0 += MF_CH) {
     const int64_t cend = (c0 + MF_CH < ldm) ? c0 + MF_CH : ldm;
-#pragma unroll
     for (int c = tid; c < MF_CH / 8; c += 256) reinterpret_cast<uint4*>(chunk)[c] = make_uint4(0u, 0u, 0u, 0u);
     __syncthreads();
     while (true) {  // block-uniform trip count
