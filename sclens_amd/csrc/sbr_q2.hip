@@ -367,7 +367,7 @@ __host__ __device__ __forceinline__ int64_t sbr_q2_img_index(int b, int t, int64
 }
 static inline int64_t sbr_q2_img_count(int64_t n) { const int64_t q = n / SB; return q * q + q; }
 
-// ---- image-fed apply kernel (variants 14 / 15, round 4): the group data as a PRE-BUILT LDS image, moved global -> LDS by DMA.
+// ---- image-fed apply kernel (variants 14 / 15 / 16, rounds 4-5): the group data as a PRE-BUILT LDS image, moved global -> LDS by DMA.
 // What bound the kernels that staged the reflectors themselves (round 3) was not the matrix pipe but ~430 vector instructions around
 // the 69 matrix instructions of a group: every workgroup fetched the group's 32 reflectors + T as floats, split them into fp16 pieces
 // and wrote LDS with two-byte stores -- the same work in all m / 64 workgroups. Here one kernel (sbr_q2_build_img, beside the inverse
@@ -481,7 +481,7 @@ __device__ __forceinline__ f32x4 sbr_mfma3_k32(const SbrHL8& a, const SbrHL8& b,
 }
 constexpr float Q_ZSCALE = 256.f;  // the vector window lives scaled by 2^8 (exact) inside the image-fed kernel
 
-// the group of variants 14 / 15: three products from the 16 KB image (layout at Q_IMG2)
+// the group of variants 14 / 15 / 16: three products from the 16 KB image (layout at Q_IMG2)
 typedef __fp16 fp16x4_t __attribute__((__vector_size__(4 * sizeof(__fp16))));
 typedef __attribute__((address_space(3))) fp16x4_t lds_fp16x4;
 __device__ __forceinline__ f16x4 sbr_ld_tr(const float* p) {  // transposing read: EXEC must be all ones (it is: whole-wave code)
