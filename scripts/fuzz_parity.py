@@ -1,4 +1,5 @@
-"""Randomised end-to-end parity sweep against the oracle (GPU box; not part of the test-suite). Usage: fuzz_parity.py [cases] [seed]"""
+"""Randomised end-to-end parity sweep against the oracle (GPU box; not part of the test-suite).
+Usage: fuzz_parity.py [cases] [seed] [ensemble_tail = auto | certified | converged]"""
 import os
 import sys
 import time
@@ -11,7 +12,8 @@ from sclens_amd.synth import synth_counts
 
 cases = int(sys.argv[1]) if len(sys.argv) > 1 else 30
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
-bad = 0
+tail = sys.argv[3] if len(sys.argv) > 3 else "auto"
+bad = again = 0
 t0 = time.time()
 for c in range(cases):
     N, M = int(rng.integers(90, 420)), int(rng.integers(90, 420))
@@ -28,7 +30,8 @@ for c in range(cases):
     d = api.make_draws_native(X, seed=seed, host_sampler=True)
     od = O.Draws(d.z_idx1, d.z_idx2, d.X_r, d.p_th, d.sampler)
     ref = O.sclens(X, od, n_perturb=4, null_tol=O.NULL_DROP, centering=cent, max_search_iters=25)
-    res = api.sclens(X, draws=d, n_perturb=4, centering=cent, streams=streams, max_search_iters=25)
+    res = api.sclens(X, draws=d, n_perturb=4, centering=cent, streams=streams, max_search_iters=25, ensemble_tail=tail)
+    again += len(res.get("tail_redo", []))
     msgs = []
     if np.abs(res["L"] - ref["L"]).max() > 2e-4 * ref["L"].max():
         msgs.append("L")
@@ -38,6 +41,8 @@ for c in range(cases):
         msgs.append(f"search {res['n_search']}/{res['p_']} vs {ref['n_search']}/{ref['p_']}")
     if "sig_id" in ref and not np.array_equal(res.get("sig_id"), ref["sig_id"]):
         msgs.append(f"sig_id {res.get('sig_id')} vs {ref['sig_id']}")
+    if "robustness_scores" in ref and "robustness_scores" in res and not np.array_equal(res["robustness_scores"]["a_b"], ref["robustness_scores"]["a_b"]):
+        msgs.append("a_b")
     if msgs:
         bad += 1
         # how close was the decision that differs? (margins of the thresholds involved)
@@ -48,4 +53,4 @@ for c in range(cases):
         print(c, f"N={N} M={M} C={C} seed={seed} {cent} streams={streams}: MISMATCH", msgs, f"min |L - lambda_c|/lambda_c = {gap:.2e}", extra, flush=True)
     else:
         print(c, f"N={N} M={M} C={C} {cent} streams={streams}: ok k={len(ref.get('signal_ev', []))} S={ref['n_search']}", flush=True)
-print(f"{cases} cases, {bad} mismatches, {time.time() - t0:.0f} s")
+print(f"{cases} cases, {bad} mismatches, ensemble_tail = {tail}: {again} members solved again, {time.time() - t0:.0f} s")
