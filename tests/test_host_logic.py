@@ -339,3 +339,25 @@ def test_bench_line_fits_what_the_driver_reads():
     full["observed"]["decisions_per_step"] = dec * 4
     full["config"]["comm"] = "c" * 5000
     assert len(json.dumps(bench.compact_line(full, None))) <= 4096
+
+
+def test_matching_certificate_bound():
+    """The bound behind `ensemble_tail = "certified"` (session_robustness, api.sclens): for a unit vector v and an orthonormal basis
+    Q, every unit vector u orthogonal to the first k columns satisfies |v'u| <= sqrt(1 - sum_{j<k} (v'q_j)^2) -- so if the best of the
+    first k beats that bound, the argmax over ANY set of further orthonormal columns (exact tail eigenvectors or unconverged Ritz
+    vectors alike) lies among the first k. Checked on random bases, for the remaining columns and for random unit combinations of them."""
+    rng = np.random.default_rng(12)
+    for n, k in ((40, 3), (120, 7), (300, 11)):
+        Q, _ = np.linalg.qr(rng.standard_normal((n, n)))
+        for _ in range(20):
+            v = Q[:, :k] @ rng.standard_normal(k) * rng.uniform(0.2, 3.0) + Q[:, k:] @ rng.standard_normal(n - k) * rng.uniform(0.0, 1.0)
+            v /= np.linalg.norm(v)
+            c = Q.T @ v
+            bound = np.sqrt(max(0.0, 1.0 - float(np.sum(c[:k] ** 2))))
+            assert np.all(np.abs(c[k:]) <= bound + 1e-12)
+            for _ in range(5):
+                u = Q[:, k:] @ rng.standard_normal(n - k)
+                u /= np.linalg.norm(u)
+                assert abs(float(v @ u)) <= bound + 1e-12
+            if np.max(np.abs(c[:k])) ** 2 > 1.0 - float(np.sum(c[:k] ** 2)):
+                assert int(np.argmax(np.abs(c))) < k
