@@ -21,8 +21,12 @@ for c in range(cases):
     seed = int(rng.integers(1, 10 ** 6))
     cent = "median" if rng.random() < 0.25 else "mean"
     streams = int(rng.integers(1, 4))
+    only = os.environ.get("FUZZ_ONLY")  # replay single cases of a sweep (the parameters of every case are still drawn)
+    mf, ms = float(rng.uniform(0.1, 0.4)), float(rng.uniform(0.8, 1.8))
+    if only and str(c) not in only.split(","):
+        continue
     try:
-        X = synth_counts(N, M, seed=seed, C=C, marker_frac=float(rng.uniform(0.1, 0.4)), marker_sd=float(rng.uniform(0.8, 1.8)),
+        X = synth_counts(N, M, seed=seed, C=C, marker_frac=mf, marker_sd=ms,
                          min_genes_per_cell=5, min_cells_per_gene=4)
     except Exception as e:  # the generator can fail its QC invariants for tiny shapes
         print(c, "skip (synth):", e)
@@ -50,6 +54,10 @@ for c in range(cases):
         if "robustness_scores" in ref and "robustness_scores" in res:
             extra = f" rob {np.round(res['robustness_scores']['rob_score'], 4)} vs {np.round(ref['robustness_scores']['rob_score'], 4)}"
         gap = np.min(np.abs(ref["L"] - ref["lambda_c"])) / ref["lambda_c"]
+        if "search_trace" in res and "search_trace" in ref:
+            da = [float(t[1]) for _, t in res["search_trace"]]
+            db = [float(t[1]) for _, t in ref["search_trace"]]
+            print("   p_th", ref["p_th"], "device d5[1]:", np.round(da, 5), "oracle:", np.round(db, 5))
         print(c, f"N={N} M={M} C={C} seed={seed} {cent} streams={streams}: MISMATCH", msgs, f"min |L - lambda_c|/lambda_c = {gap:.2e}", extra, flush=True)
     else:
         print(c, f"N={N} M={M} C={C} {cent} streams={streams}: ok k={len(ref.get('signal_ev', []))} S={ref['n_search']}", flush=True)
