@@ -199,3 +199,167 @@ def sclens_row_sharded(X_local, row0: int, N_global: int, draws: Draws, shard: S
         return res
     finally:
         ses.close()
+
+
+# ------------------------------------------------------------------------------------------------------------------------------
+# The atlas matrices themselves (BASELINE.json configs[4], 1 000 000 x 30 000): a matrix of that size is never held in one piece --
+# 3.1e9 stored entries are 37 GB as a scipy CSC (64-bit indices) -- so the data matrix and the null matrix exist as row slabs.
+# ------------------------------------------------------------------------------------------------------------------------------
+def _slab_cache_path(tag: str, N_total: int, M: int, seed: int, a: int, b: int, cache_dir: Optional[str]):
+    import os
+    import tempfile
+
+    d = os.environ.get("SCLENS_BENCH_CACHE", tempfile.gettempdir()) if cache_dir is None else cache_dir
+    return os.path.join(d, f"sclens_atlas_{tag}_v2_{N_total}x{M}_s{seed}_{a}_{b}.npz") if d not in ("", "0") else None
+
+
+def _load_slab(path, shape):
+    z = np.load(path)
+    return sp.csc_matrix((z["data"], z["indices"], z["indptr"]), shape=shape)
+
+
+def _save_slab(path, X):
+    import os
+
+    tmp = f"{path}.{os.getpid()}.tmp.npz"
+    np.savez(tmp, data=X.data, indices=X.indices.astype(np.int32), indptr=X.indptr.astype(np.int64))
+    os.replace(tmp, path)
+
+
+def _synth_one(args):
+    from .synth import synth_counts_rows
+
+    N_total, M, seed, a, b, path = args
+    X = synth_counts_rows(N_total, M, seed, a, b)
+    _save_slab(path, X)
+    return int(X.nnz)
+
+
+class SlabSet:
+    """`world` row slabs of one N_total x M matrix, kept as .npz files (`cache_dir`, default SCLENS_BENCH_CACHE or the temp dir) and
+    loaded one at a time: `slab(g)` -> scipy CSC with LOCAL row indices (int32), `rows(g)` -> its cell range."""
+
+    def __init__(self, N_total: int, M: int, world: int, paths, nnz):
+        self.N_total, self.M, self.world, self.paths, self.nnz = N_total, M, world, list(paths), [int(v) for v in nnz]
+
+    def rows(self, g: int):
+        return row_block(g, self.world, self.N_total)
+
+    def slab(self, g: int) -> sp.csc_matrix:
+        a, b = self.rows(g)
+        return _load_slab(self.paths[g], (b - a, self.M))
+
+    @property
+    def nnz_total(self) -> int:
+        return int(sum(self.nnz))
+
+
+def synth_slabs(N_total: int, M: int, seed: int, world: int, cache_dir: Optional[str] = None, workers: Optional[int] = None,
+                log=None) -> SlabSet:
+    """The seeded synthetic count matrix of `sclens_amd.synth.synth_counts_rows` (a function of (N_total, M, seed) only: the slab
+    boundaries do not enter) as `world` slab files, generated by `workers` processes (default: one per 12 GB of available memory, at
+    most the CPUs this process may use; ~80 s per 125 000 x 30 000 slab and process)."""
+    import multiprocessing as mp
+    import os
+
+    todo, paths = [], []
+    for g in range(world):
+        a, b = row_block(g, world, N_total)
+        p = _slab_cache_path("data", N_total, M, seed, a, b, cache_dir)
+        if p is None:
+            raise ValueError("the atlas slabs need a cache directory (SCLENS_BENCH_CACHE must not be 0)")
+        paths.append(p)
+        if not os.path.exists(p):
+            todo.append((N_total, M, seed, a, b, p))
+    if todo:
+        if workers is None:
+            try:
+                import psutil
+
+                mem = psutil.virtual_memory().available / 1e9
+            except Exception:
+                mem = 32.0
+            workers = max(1, min(len(os.sched_getaffinity(0)), len(todo), int(mem // 12)))
+        if log:
+            log(f"generating {len(todo)} slab(s) with {workers} process(es)")
+        if workers > 1:
+            with mp.get_context("fork").Pool(workers) as pool:
+                pool.map(_synth_one, todo, chunksize=1)
+        else:
+            for t in todo:
+                _synth_one(t)
+    nnz = []
+    for g, p in enumerate(paths):
+        with np.load(p) as z:
+            nnz.append(int(z["indptr"][-1]))
+    return SlabSet(N_total, M, world, paths, nnz)
+
+
+def null_slabs(data: SlabSet, seed: int, cache_dir: Optional[str] = None, log=None) -> SlabSet:
+    """R2 (scLENS.jl:701 `random_nz(pre_df, rmix=true)` -> :261-289, :239-248) of the WHOLE matrix: the stored values of all cells
+    shuffled globally, every gene keeps its number of entries at distinct cells drawn uniformly from ALL N_total cells -- the library's
+    own generator (`sclens_draw_null_matrix`, seed + 1 as in `api.make_draws_native`) on the concatenation of the slabs in global CSC
+    order (gene by gene, cells ascending), then cut into the same row slabs. A function of the matrix and the seed only: the slab
+    boundaries do not enter. Peak host memory ~ 13 bytes per stored entry (41 GB at 1M x 30k); the data slabs are read from their files
+    one at a time."""
+    import ctypes as C
+    import os
+
+    N_total, M, world = data.N_total, data.M, data.world
+    paths = []
+    for g in range(world):
+        a, b = data.rows(g)
+        paths.append(_slab_cache_path("null", N_total, M, seed, a, b, cache_dir))
+    if all(os.path.exists(p) for p in paths):
+        nnz = []
+        for p in paths:
+            with np.load(p) as z:
+                nnz.append(int(z["indptr"][-1]))
+        return SlabSet(N_total, M, world, paths, nnz)
+    lib = _lib.load()
+    cnt = np.zeros((world, M), dtype=np.int64)
+    for g in range(world):
+        with np.load(data.paths[g]) as z:
+            cnt[g] = np.diff(z["indptr"])
+    gcol = np.zeros(M + 1, dtype=np.int64)
+    gcol[1:] = np.cumsum(cnt.sum(axis=0))
+    nnz = int(gcol[-1])
+    nz = np.empty(nnz, dtype=np.float32)
+    pref = np.zeros(M, dtype=np.int64)
+    for g in range(world):
+        s = data.slab(g)
+        ip = s.indptr.astype(np.int64)
+        dest = np.arange(s.nnz, dtype=np.int64)
+        dest += np.repeat(gcol[:-1] + pref - ip[:-1], cnt[g])
+        nz[dest] = s.data
+        pref += cnt[g]
+        del s, dest
+    if log:
+        log(f"null draw over {nnz} stored entries")
+    rrow = np.empty(nnz, dtype=np.int32)
+    rval = np.empty(nnz, dtype=np.float32)
+    from ._lib import ptr
+
+    rc = lib.sclens_draw_null_matrix(N_total, M, ptr(gcol, C.c_int64), ptr(nz, C.c_float), (int(seed) + 1) & 0xFFFFFFFFFFFFFFFF,
+                                     ptr(rrow, C.c_int32), ptr(rval, C.c_float))
+    if rc:
+        raise RuntimeError(f"sclens_draw_null_matrix: {rc}")
+    del nz
+    bounds = np.array([data.rows(g)[0] for g in range(world)] + [N_total], dtype=np.int32)
+    cuts = np.empty((M, world + 1), dtype=np.int64)  # per gene: first entry of each slab (rows ascend inside a gene)
+    for j in range(M):
+        cuts[j] = np.searchsorted(rrow[gcol[j]: gcol[j + 1]], bounds)
+    out_nnz = []
+    for g in range(world):
+        a, b = data.rows(g)
+        c = cuts[:, g + 1] - cuts[:, g]
+        ip = np.zeros(M + 1, dtype=np.int64)
+        ip[1:] = np.cumsum(c)
+        src = np.arange(int(ip[-1]), dtype=np.int64)
+        src += np.repeat(gcol[:-1] + cuts[:, g] - ip[:-1], c)
+        rows = rrow[src] - np.int32(a)
+        Xg = sp.csc_matrix((rval[src], rows, ip), shape=(b - a, M))
+        _save_slab(paths[g], Xg)
+        out_nnz.append(int(ip[-1]))
+        del src, rows, Xg
+    return SlabSet(N_total, M, world, paths, out_nnz)

@@ -13,10 +13,12 @@ if os.environ.get("TWO_STAGE"):
     ctx.set_option("two_stage", 1)
 lo_first = bool(os.environ.get("LOW_HALF"))
 rng = np.random.default_rng(0)
-B = rng.standard_normal((n, K)).astype(np.float32)
-B -= B.mean(axis=0, keepdims=True)
 ldb = rup(K, 32); lda = rup(n, 32)
-Bp = np.zeros((n, ldb), np.float32); Bp[:, :K] = B
+Bp = np.zeros((n, ldb), np.float32)
+for r0 in range(0, n, 2048):  # float32 draws in row chunks: 30 016 x 100 000 must not pass through a float64 temporary
+    Bp[r0:r0 + 2048, :K] = rng.standard_normal((min(2048, n - r0), K), dtype=np.float32)
+Bp[:, :K] -= Bp[:, :K].mean(axis=0, keepdims=True)
+B = Bp[:, :K]
 dB = DevArray(ctx, Bp); dA = DevArray(ctx, nbytes=4 * n * lda); dw = DevArray(ctx, nbytes=8 * n)
 dZ = DevArray(ctx, nbytes=4 * max(mvec, 1) * lda)
 ctx.set_timing(True)
