@@ -30,10 +30,13 @@ job timelines, every stage's rate, the CPU samples -- goes to `bench_detail.json
                  `stages` holds the same ratio for every stage of one decomposition, the Gram launch included.
   cpu_baseline : the oracle (float64 NumPy/SciPy port of the reference CPU path) timed on the host cores on two bounded
                  samples (the exponent of the eigensolver's cost is fitted, not assumed), stage-extrapolated to the workload.
-  value_strict_fp32 : the same metric over `strict_steps` further steps with the context option precision = 0 (every product on the fp32
-                 matrix cores: the arithmetic of the reference's own GPU path), on the draws of the LAST timed steps, so that both
-                 arithmetic variants are timed by the same run; `decisions_differ`: whether any of those steps ended with another
-                 (signals, robust signals, search length, p_) than its accelerated twin.
+The timed steps run with the context option precision = 0 (default since round 6): every dense product on the fp32 matrix cores, the
+arithmetic of the reference's own GPU path (scLENS.jl:335-343, :377) -- `dtype` "f32".
+  value_split_f16 : the same metric over `split_steps` further steps with precision = 1 (the large products from operands split into two
+                 fp16 pieces, 22 bits), on the draws of those TIMED steps whose search statistic came closest to its threshold, so that
+                 both arithmetic variants are timed by the same run; `decisions_differ`: "k of m" = how many of those m steps ended
+                 with another (signals, robust signals, search length, p_) than their fp32 twin.
+(`--precision 1` swaps the roles: the split variant is timed, `value_strict_fp32` reports the fp32 one.)
 """
 import argparse
 import json
@@ -310,6 +313,13 @@ def cpu_baseline(N, M, n_search, n_perturb, budget_s):
 
 
 DTYPE_SPLIT = "f32 (large products: operands as 2 x f16 pieces = 22 bit, f32 accumulate)"
+DTYPE_NOTE_F32 = ("context option precision = 0: fp32 data, every dense product (Gram, search statistic, band reduction, both back-transformations) on "
+                  "the fp32 matrix cores (v_mfma_f32_32x32x2_f32 / 16x16x4_f32: 24-bit operands, fp32 accumulate -- the arithmetic of the "
+                  "reference's cuBLAS SGEMM / cuSOLVER ssyevd path, scLENS.jl:335-343, :377), fp64 statistics / eigenvalues / panel algebra. The "
+                  "Gram matrix of a BINARISED matrix (sparsity search, scLENS.jl:735-738) is formed as the exact co-occurrence product of its 0/1 "
+                  "pattern (exact in fp16) with the cell weights as three fp16 pieces = 33 bits, fp32 accumulate, rank-one terms in fp64: no "
+                  "operand narrower than fp32 (context option gram_bits_strict = 0 sends it through the fp32 product as well). value_split_f16 = "
+                  "the same call with precision = 1 (large products from operands split into two fp16 pieces, 22 bits)")
 DTYPE_NOTE = ("fp32 data and accumulation, fp64 statistics / eigenvalues / panel algebra. Context option precision = 1 (default): the large "
               "products run on the fp16 MFMA from operands split into two fp16 pieces (22 significant bits, three matrix instructions per "
               "product; the Gram matrix of a binarised matrix as an exact 0/1 x 22-bit-weight product) -- Gram products from n = 16 000, the "
@@ -323,8 +333,8 @@ def compact_line(full, detail_path=None):
     """The stdout line: the contract's keys + value_strict_fp32 / strict_steps / decisions_differ + a trimmed roofline and cpu_baseline;
     every list, timeline and note stays in the detail file. Never longer than LINE_LIMIT bytes (tests/test_host_logic.py)."""
     keep = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "steps_requested", "warmup_requested", "ms_per_step", "higher_is_better",
-            "scaling", "vs_baseline", "dtype", "data", "value_strict_fp32", "strict_steps", "strict_ms_per_step", "decisions_differ",
-            "bench_wall_s")
+            "scaling", "vs_baseline", "dtype", "data", "value_strict_fp32", "strict_steps", "strict_ms_per_step", "value_split_f16", "split_steps",
+            "split_ms_per_step", "decisions_differ", "bench_wall_s")
     line = {k: full[k] for k in keep if k in full}
     cfg = full.get("config", {})
     line["config"] = {k: cfg[k] for k in ("workload", "N", "M", "n_perturb", "parallelism", "comm", "precision", "keep_warm", "ensemble_tail") if k in cfg}
@@ -406,10 +416,14 @@ def main():
                          "all-reduced (SURVEY 8e-iii, sclens_amd/atlas.py) instead of distributing whole decompositions")
     ap.add_argument("--streams", type=int, default=None,
                     help="concurrent decompositions per GPU (worker sessions on own HIP streams); default: 3 below n = 16 000, else 2")
-    ap.add_argument("--strict-fp32", default="auto", choices=["auto", "on", "off"],
-                    help="further timed steps with the context option precision = 0 reported as value_strict_fp32 (auto: for n >= 16 000)")
-    ap.add_argument("--strict-steps", type=int, default=3, help="how many of them (on the draws of the last timed steps)")
-    ap.add_argument("--precision", type=int, default=1, choices=[0, 1], help="context option precision of the timed steps (1: split-fp16 products)")
+    ap.add_argument("--strict-fp32", "--other-variant", dest="strict_fp32", default="auto", choices=["auto", "on", "off"],
+                    help="further timed steps with the OTHER arithmetic variant (precision = 1 - the timed one), reported as value_split_f16 / "
+                         "value_strict_fp32 (auto: for n >= 16 000)")
+    ap.add_argument("--strict-steps", "--other-steps", dest="strict_steps", type=int, default=5,
+                    help="how many of them (on the draws of the timed steps with the smallest margin of the search statistic)")
+    ap.add_argument("--precision", type=int, default=0, choices=[0, 1],
+                    help="context option precision of the timed steps (0: every dense product on the fp32 MFMA, the reference GPU path's "
+                         "arithmetic; 1: split-fp16 products)")
     ap.add_argument("--extra-configs", default="", help="comma-separated further configs timed once each after the main one (reported under `extra`)")
     ap.add_argument("--seed-base", type=int, default=1000, help="timed step s draws with seed seed_base + s (warm-up steps: seed_base - 1 - w)")
     ap.add_argument("--ballast-gb", type=float, default=0.0,
@@ -496,9 +510,10 @@ def main():
                 "ensemble_tail": res.get("ensemble_tail"), "members_solved_again": [int(t) for t in res.get("tail_redo", [])],
                 "first_phase_jobs_s": [list(q) for q in res.get("first_phase_s", [])]}
 
-    def run_config(cfg, steps_req, warm_req, deadline, tail_steps=0.0, step0=0):
-        """tail_steps: keep this many step durations of the budget free for what follows (the strict-fp32 step);
-        step0: index of the first timed step (its draws are seeded 1000 + step0)"""
+    def run_config(cfg, steps_req, warm_req, deadline, tail_steps=0.0, step0=0, step_list=None):
+        """tail_steps: keep this many step durations of the budget free for what follows (the steps of the other arithmetic variant);
+        step0: index of the first timed step (its draws are seeded 1000 + step0); step_list: the step indices to run instead of
+        step0, step0 + 1, ..."""
         N, M, cfg_index = CONFIGS[cfg]
         t0 = time.perf_counter()
         X = api._csc_f32(cached_counts(cfg, N, M, 20240427 + cfg_index))  # SURVEY 8(d): PCG64(20240427 + config_index)
@@ -544,13 +559,14 @@ def main():
             if s > 0 and agree(time.perf_counter() + (1.1 + tail_steps) * t_step > deadline):
                 break
             ts = time.perf_counter()
-            res = one_step(step0 + s)
+            this = step_list[s] if step_list is not None else step0 + s
+            res = one_step(this)
             t_step = time.perf_counter() - ts
             n_steps += 1
             for k_, v_ in (res.get("phase_peak_GB") or {}).items():
                 phase_peaks[k_] = max(phase_peaks.get(k_, 0.0), float(v_))
             if "search_trace" in res:
-                decisions.append(dict(decisions_of(res, args.seed_base + step0 + s), wall_s=round(t_step, 3)))
+                decisions.append(dict(decisions_of(res, args.seed_base + this), wall_s=round(t_step, 3)))
         fence()
         dt = time.perf_counter() - t0
         try:  # device memory in use on this rank's GPU after the timed steps (the library's pool keeps the call's blocks cached)
@@ -573,8 +589,9 @@ def main():
     n_min0 = min(CONFIGS[args.config][:2])
     strict_planned = args.strict_fp32 == "on" or (args.strict_fp32 == "auto" and n_min0 >= 16000 and not args.row_shard)
     strict_req = max(1, args.strict_steps) if strict_planned else 0
-    # a strict step takes ~1.9 x an accelerated one at cfg4: keep that many step durations of the budget free
-    main_r = run_config(args.config, args.steps, args.warmup, deadline - reserve, tail_steps=2.0 * strict_req)
+    # a fp32 step takes ~1.7 x a split one at cfg4: keep that many step durations of the budget free for the other variant's steps
+    main_r = run_config(args.config, args.steps, args.warmup, deadline - reserve,
+                        tail_steps=(0.65 if args.precision == 0 else 1.8) * strict_req)
     N, M, X, res, dt = main_r["N"], main_r["M"], main_r["X"], main_r["res"], main_r["dt"]
     steps = main_r["steps"]
 
@@ -595,7 +612,7 @@ def main():
             "steps_requested": args.steps, "warmup_requested": args.warmup, "budget_s": args.budget_s,
             "ms_per_step": round(ms_per_step, 1), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": DTYPE_SPLIT if precision != 0 else "f32", "data": "synthetic",
-            "dtype_note": DTYPE_NOTE if precision != 0 else "context option precision = 0: every product on the fp32 matrix cores",
+            "dtype_note": DTYPE_NOTE if precision != 0 else DTYPE_NOTE_F32,
             "config": {"workload": f"{args.config}: synthetic Poisson-lognormal counts {N} cells x {M} genes, sparsity "
                                    f"{1 - X.nnz / (N * M):.3f}, full sclens() incl. sparsity search and {args.n_perturb}-member "
                                    f"perturbation ensemble", "N": N, "M": M, "nnz": int(X.nnz), "n_perturb": args.n_perturb,
@@ -619,32 +636,41 @@ def main():
                          "search_job_s_last_step": [list(q) for q in res.get("search_job_s", [])],
                          "first_phase_jobs_s_last_step": [list(q) for q in res.get("first_phase_s", [])]},
         }
-    # ---- strict fp32: further steps with every product on the fp32 matrix cores (context option precision = 0; the worker contexts of a
-    #      call inherit it), on the draws of the LAST timed steps, while the budget lasts
+    # ---- the OTHER arithmetic variant (precision = 1 - the timed one; the worker contexts of a call inherit it): further steps on the draws of
+    #      the timed steps whose search statistic came closest to its threshold (those are the ones that can decide differently)
     extra = {}
     n_min = min(N, M)
-    want_strict = strict_req > 0 and precision != 0 and not main_r["row_shard"]
-    if want_strict and steps > 0 and not agree(time.perf_counter() + 2.0 * dt / max(1, steps) > deadline - reserve):
-        k_strict = min(strict_req, steps)
-        first = max(0, main_r["last_step"] - k_strict + 1)
-        with ctx.options(precision=0):
-            r = run_config(args.config, k_strict, 0, deadline - reserve, step0=first)
+    other = 0 if precision != 0 else 1
+    want_other = strict_req > 0 and not main_r["row_shard"]
+    t_other_est = (1.9 if other == 0 else 0.6) * dt / max(1, steps)
+    if want_other and steps > 0 and not agree(time.perf_counter() + t_other_est > deadline - reserve):
+        k_other = min(strict_req, steps)
+        ranked = sorted(main_r["decisions"], key=lambda d_: (d_["min_abs_margin"] if d_.get("min_abs_margin") is not None else 1e9))
+        chosen = sorted(int(d_["seed"]) - args.seed_base for d_ in ranked[:k_other]) or list(range(max(0, main_r["last_step"] - k_other + 1), main_r["last_step"] + 1))
+        chosen = [int(v) for v in shard.bcast_host(np.array(chosen, dtype=np.float64), 0)] if world > 1 else chosen
+        with ctx.options(precision=other):
+            r = run_config(args.config, len(chosen), 0, deadline - reserve, step_list=chosen)
         if rank == 0 and r["steps"] > 0:
-            by_seed = {d["seed"]: d for d in main_r["decisions"]}
-            pairs = [(by_seed.get(d["seed"]), d) for d in r["decisions"]]
+            by_seed = {d_["seed"]: d_ for d_ in main_r["decisions"]}
+            pairs = [(by_seed.get(d_["seed"]), d_) for d_ in r["decisions"]]
             same = lambda a, b: all(a[q] == b[q] for q in ("signals", "robust_signals", "search_iters", "p_"))
             differ = [b["seed"] for a, b in pairs if a is not None and not same(a, b)]
-            out["value_strict_fp32"] = round(r["N"] * r["M"] * r["steps"] / r["dt"], 1)  # the same metric at the reference GPU path's arithmetic
-            out["strict_steps"] = r["steps"]
-            out["strict_ms_per_step"] = round(r["dt"] / r["steps"] * 1e3, 1)
-            out["decisions_differ"] = (None if not pairs or any(a is None for a, _ in pairs) else bool(differ))
-            extra["strict_fp32"] = {"sclens_wall_s": round(r["dt"] / r["steps"], 3), "steps": r["steps"], "value": out["value_strict_fp32"],
-                                    "same_draws_as": f"the last {r['steps']} timed steps", "decisions": r["decisions"],
-                                    "seeds_whose_decisions_differ": differ,
-                                    "max_abs_diff_d5_second_smallest": [
-                                        (None if a is None else round(max(abs(x - y) for x, y in zip(a["d5_second_smallest"], b["d5_second_smallest"])), 6))
-                                        for a, b in pairs],
-                                    "note": "context option precision = 0: every product of the path on the fp32 MFMA (no fp16 operand anywhere)"}
+            key = "value_strict_fp32" if other == 0 else "value_split_f16"
+            pre = "strict" if other == 0 else "split"
+            out[key] = round(r["N"] * r["M"] * r["steps"] / r["dt"], 1)
+            out[pre + "_steps"] = r["steps"]
+            out[pre + "_ms_per_step"] = round(r["dt"] / r["steps"] * 1e3, 1)
+            compared = [p_ for p_ in pairs if p_[0] is not None]
+            out["decisions_differ"] = f"{len(differ)} of {len(compared)}" if compared else None
+            extra["other_variant"] = {"precision": other, "sclens_wall_s": round(r["dt"] / r["steps"], 3), "steps": r["steps"], "value": out[key],
+                                      "same_draws_as": "the timed steps with the smallest |search statistic - p_th| (seeds below)",
+                                      "seeds": [d_["seed"] for d_ in r["decisions"]], "decisions": r["decisions"],
+                                      "seeds_whose_decisions_differ": differ,
+                                      "max_abs_diff_d5_second_smallest": [
+                                          (None if a is None else round(max(abs(x - y) for x, y in zip(a["d5_second_smallest"], b["d5_second_smallest"])), 6))
+                                          for a, b in pairs],
+                                      "note": ("context option precision = 0: every dense product on the fp32 MFMA" if other == 0 else
+                                               "context option precision = 1: large products from operands split into two fp16 pieces (22 bits)")}
     # ---- extra configs (one timed step each), while the budget lasts
     for cfg in [c for c in args.extra_configs.split(",") if c]:
         if agree(time.perf_counter() + 60 > deadline - reserve):

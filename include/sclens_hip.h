@@ -61,7 +61,10 @@ int sclens_hip_symv_probe(sclens_hip_ctx* ctx, int64_t n, int64_t* launches, dou
  * SCLENS_HIP_OPTIONS ("name=value,name=value") is applied once, inside sclens_hip_create -- nothing is read from the environment per
  * call. Unknown names return SCLENS_ERR_ARG. The ones a host touches:
  *   "precision"  (1 / 0) what the reference selects with `device_` (scLENS.jl:649: "gpu" = Float32 cuBLAS / cuSOLVER, :335-343, :377):
- *                0 = every product on the fp32 matrix cores (v_mfma_f32_32x32x2_f32 / 16x16x4_f32), the reference GPU path's arithmetic;
+ *                0 = every dense product on the fp32 matrix cores (v_mfma_f32_32x32x2_f32 / 16x16x4_f32), the reference GPU path's
+ *                arithmetic; the Gram matrix of a BINARISED matrix (scLENS.jl:735-738) is still formed as the exact co-occurrence product
+ *                of its 0/1 pattern (exact in fp16) with the cell weights as three fp16 pieces = 33 bits -- no operand narrower than fp32
+ *                ("gram_bits_strict" = 0 sends it through the fp32 product as well);
  *                1 (default) = the large products (Gram, search statistic, trailing updates and W of the band reduction, both
  *                back-transformations) from operands split into two fp16 pieces on the fp16 matrix cores: 22-bit operands, fp32
  *                accumulation, measured as accurate as the fp32 products they replace;
@@ -108,7 +111,7 @@ int sclens_hip_wishart_matrix_f32(sclens_hip_ctx* ctx, const float* X, int64_t N
  * Accuracy: that of an fp32 solver, ~sqrt(n) eps32 |lambda|max on the eigenvalues, at any norm of Y: from n = 8 192 the two-stage
  * reduction forms its trailing updates from operands split into two fp16 pieces, the reflector columns and the columns that
  * scale with Y under separate power-of-two scales (round 4; tests/test_gpu_sbr.py at norms 1, 2^14, 2^20).
- * SCLENS_HIP_SY2SB_SPLIT=0 keeps those products on the fp32 matrix cores. */
+ * The context option precision = 0 keeps those products on the fp32 matrix cores. */
 int sclens_hip_get_eigen_f32(sclens_hip_ctx* ctx, const float* Y, int64_t n, float* L, float* V);
 /* corr_mat(X, Y; device)  (scLENS.jl:363-373): out = X' * Y, X is n x p, Y is n x q, out is p x q. */
 int sclens_hip_corr_mat_f32(sclens_hip_ctx* ctx, const float* X, int64_t n, int64_t p, const float* Y, int64_t q,
@@ -262,6 +265,28 @@ int sclens_hip_session_set_candidate_range(sclens_hip_session* s, int64_t cand_o
 /* Local candidate list of such a session (z1 = GLOBAL cell indices, z2 = genes; n_cand_local entries each): tests / hosts
  * that want to replay the run unsharded. */
 int sclens_hip_session_local_candidates(sclens_hip_session* s, uint32_t* z1, uint32_t* z2);
+
+/* Chunked session (BASELINE configs[4], "chunked Gram accumulation"; cells > genes): ALL cells on this device, held as CSC chunks of
+ * consecutive cells (8 bytes per stored entry in HBM) because the forms the plain session keeps resident do not fit -- at 1 000 000 x
+ * 30 000 the union pattern is 175 GB and one scaled matrix 120 GB. Every decomposition then visits the chunks: the chunk's sparse
+ * pattern is built on the device (with ITS part of the global candidate draw R1, scLENS.jl:668-673, when the matrix carries candidate
+ * ones: the convention of sclens_hip_session_create_sharded_drawn; kept between visits as far as the context option chunk_cache_gb
+ * allows), the statistics that span all cells (scLENS.jl:597-603, :682-690) are summed over the chunks in three passes, and the Gram
+ * matrix is the sum of the chunks' contributions (scLENS.jl:332-361, X'X as a sum over cell blocks). The gene side -- eigensolver,
+ * search statistic, partial eigensolver, scoring -- is that of the plain session; cell-side outputs cover all N_global cells.
+ *   create_chunked: the shell; nnz_global = stored entries of the whole matrix, seed = the candidate seed.
+ *   chunk_add(which = 0): chunk g = cells [row0, row0 + N_local) of the count matrix (LOCAL row indices), uploaded at once -- the host
+ *     needs one chunk at a time; chunk_commit when all are in. which = 1 (after commit): the same cells of the null matrix X_r
+ *     (scLENS.jl:701), consumed and released by null_spectrum_chunked (the chunked form of sclens_hip_session_null_spectrum).
+ *   Then the calls of the plain session: data_spectrum, refine_eigenvalues, signal_vectors, binary_basis, search_step[_seeded],
+ *   perturb[_seeded], robustness, gene_basis (mean centring; no worker clones; samples index the global candidate list, whose length
+ *   session_get_int "n_cand" returns -- counted on first use). get_int "chunk_builds" / "chunk_visits": pattern builds / chunk visits. */
+int sclens_hip_session_create_chunked(sclens_hip_ctx* ctx, int64_t N_global, int64_t M, int n_chunks, int64_t nnz_global, uint64_t seed,
+                                      sclens_hip_session** out);
+int sclens_hip_session_chunk_add(sclens_hip_session* s, int which, int g, int64_t row0, int64_t N_local, const int64_t* colptr,
+                                 const int32_t* rowval, const float* nzval);
+int sclens_hip_session_chunk_commit(sclens_hip_session* s);
+int sclens_hip_session_null_spectrum_chunked(sclens_hip_session* s, double* Lr);
 
 /* One ROUND of the sparsity search of a row-sharded session (scLENS.jl:725-761 evaluated `count` sparsities at a time, SURVEY
  * 8e-ii + 8e-iii): for evaluation e (sample seeds[e] of m[e] candidates) every rank forms its partial Gram matrix, which is summed

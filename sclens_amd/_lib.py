@@ -78,6 +78,10 @@ SIGNATURES = {
     "sclens_hip_session_create_sharded_drawn": (C.c_int, [vp, i64, i64, i64, i64, c_i64p, c_i32p, c_f32p, i64, C.c_uint64, ALLREDUCE_FN, vp,
                                                           C.POINTER(vp), c_i64p]),
     "sclens_hip_session_set_candidate_range": (C.c_int, [vp, i64, i64]),
+    "sclens_hip_session_create_chunked": (C.c_int, [vp, i64, i64, C.c_int, i64, C.c_uint64, C.POINTER(vp)]),
+    "sclens_hip_session_chunk_add": (C.c_int, [vp, C.c_int, C.c_int, i64, i64, c_i64p, c_i32p, c_f32p]),
+    "sclens_hip_session_chunk_commit": (C.c_int, [vp]),
+    "sclens_hip_session_null_spectrum_chunked": (C.c_int, [vp, c_f64p]),
     "sclens_hip_session_local_candidates": (C.c_int, [vp, c_u32p, c_u32p]),
     "sclens_hip_session_search_round_seeded": (C.c_int, [vp, C.POINTER(C.c_uint64), c_i64p, c_i32p, C.c_int, C.c_int, i64, c_f64p, c_i64p]),
     "sclens_hip_session_perturb_round_seeded": (C.c_int, [vp, c_i64p, C.POINTER(C.c_uint64), c_i64p, c_i32p, C.c_int, C.c_int, i64, c_f64p,

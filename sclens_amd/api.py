@@ -738,6 +738,37 @@ class Session:
         s.ncand_local = s.ncand = int(nc.value)
         return s
 
+    @classmethod
+    def create_chunked(cls, ctx: Context, N_global: int, M: int, n_chunks: int, nnz_global: int, seed: int) -> "Session":
+        """Chunked session (sclens_hip_session_create_chunked): all cells of an N_global x M matrix on this device as `n_chunks` CSC chunks of
+        consecutive cells, added one at a time with `chunk_add` and sealed with `chunk_commit`; `seed` = the candidate seed (R1)."""
+        s = cls.__new__(cls)
+        s.ctx = ctx
+        s.N, s.M = int(N_global), int(M)
+        s.n = s.M
+        s.ncand = 0
+        h = C.c_void_p()
+        ctx.check(ctx.lib.sclens_hip_session_create_chunked(ctx.h, s.N, s.M, int(n_chunks), int(nnz_global), int(seed) & _M64, C.byref(h)))
+        s.h = h
+        s.ctx._adopt()
+        return s
+
+    def chunk_add(self, which: int, g: int, row0: int, X_chunk: sp.csc_matrix):
+        """cells [row0, row0 + rows) of the count matrix (which = 0) or of the null matrix X_r (which = 1), LOCAL row indices"""
+        colptr = np.ascontiguousarray(X_chunk.indptr, dtype=np.int64)
+        rowval = np.ascontiguousarray(X_chunk.indices, dtype=np.int32)
+        nzval = np.ascontiguousarray(X_chunk.data, dtype=np.float32)
+        self.ctx.check(self.ctx.lib.sclens_hip_session_chunk_add(self.h, int(which), int(g), int(row0), int(X_chunk.shape[0]),
+                                                                 ptr(colptr, C.c_int64), ptr(rowval, C.c_int32), ptr(nzval, C.c_float)))
+
+    def chunk_commit(self):
+        self.ctx.check(self.ctx.lib.sclens_hip_session_chunk_commit(self.h))
+
+    def null_spectrum_chunked(self) -> np.ndarray:
+        Lr = np.empty(self.n, dtype=np.float64)
+        self.ctx.check(self.ctx.lib.sclens_hip_session_null_spectrum_chunked(self.h, ptr(Lr, C.c_double)))
+        return Lr
+
     def set_candidate_range(self, cand_off: int, ncand_global: int):
         self.ctx.check(self.ctx.lib.sclens_hip_session_set_candidate_range(self.h, int(cand_off), int(ncand_global)))
         self.ncand = int(ncand_global)

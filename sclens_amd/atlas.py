@@ -257,7 +257,8 @@ class SlabSet:
 def synth_slabs(N_total: int, M: int, seed: int, world: int, cache_dir: Optional[str] = None, workers: Optional[int] = None,
                 log=None) -> SlabSet:
     """The seeded synthetic count matrix of `sclens_amd.synth.synth_counts_rows` (a function of (N_total, M, seed) only: the slab
-    boundaries do not enter) as `world` slab files, generated by `workers` processes (default: one per 12 GB of available memory, at
+    boundaries do not enter) as `world` slab files, generated by `workers` processes (default: one per 24 GB of available memory -- a
+    125 000 x 30 000 slab peaks at ~20 GB while its COO triplets are sorted into CSC --, at
     most the CPUs this process may use; ~80 s per 125 000 x 30 000 slab and process)."""
     import multiprocessing as mp
     import os
@@ -279,7 +280,7 @@ def synth_slabs(N_total: int, M: int, seed: int, world: int, cache_dir: Optional
                 mem = psutil.virtual_memory().available / 1e9
             except Exception:
                 mem = 32.0
-            workers = max(1, min(len(os.sched_getaffinity(0)), len(todo), int(mem // 12)))
+            workers = max(1, min(len(os.sched_getaffinity(0)), len(todo), int(mem // 24)))
         if log:
             log(f"generating {len(todo)} slab(s) with {workers} process(es)")
         if workers > 1:
@@ -363,3 +364,146 @@ def null_slabs(data: SlabSet, seed: int, cache_dir: Optional[str] = None, log=No
         out_nnz.append(int(ip[-1]))
         del src, rows, Xg
     return SlabSet(N_total, M, world, paths, out_nnz)
+
+
+# ------------------------------------------------------------------------------------------------------------------------------
+# scLENS.sclens on ONE GPU for a matrix that only fits in chunks (BASELINE configs[4] on one MI355X): the chunked session
+# (include/sclens_hip.h, sclens_hip_session_create_chunked). The serial loop of scLENS.jl:649-832; every decomposition sums the Gram
+# contributions of the chunks of cells (:332-361 as a sum over cell blocks).
+# ------------------------------------------------------------------------------------------------------------------------------
+def chunked_session(ctx: Context, data, cand_seed: int, log=None) -> Session:
+    """`data`: a SlabSet, or a list of (row0, csc) chunks of consecutive cells. The host holds one chunk at a time."""
+    if isinstance(data, SlabSet):
+        N, M, n = data.N_total, data.M, data.world
+        nnz = data.nnz_total
+        chunks = ((data.rows(g)[0], data.slab(g)) for g in range(n))
+    else:
+        data = list(data)
+        N = sum(int(X.shape[0]) for _, X in data)
+        M, n = int(data[0][1].shape[1]), len(data)
+        nnz = sum(int(X.nnz) for _, X in data)
+        chunks = iter(data)
+    ses = Session.create_chunked(ctx, N, M, n, nnz, cand_seed)
+    try:
+        for g, (row0, X) in enumerate(chunks):
+            ses.chunk_add(0, g, row0, _csc_f32(X))
+            if log:
+                log(f"chunk {g}: cells [{row0}, {row0 + X.shape[0]}), {X.nnz} stored entries")
+            del X
+        ses.chunk_commit()
+    except BaseException:
+        ses.close()
+        raise
+    return ses
+
+
+def sclens_chunked(data, null, draws: Draws, th=60, p_step=0.001, n_perturb=20, ctx: Optional[Context] = None,
+                   max_search_iters: Optional[int] = None, verbose: bool = False, guard_band: float = 4.0, log=None,
+                   stop_after: Optional[str] = None) -> Dict[str, object]:
+    """scLENS.sclens (scLENS.jl:649-832) on a chunked session. `data` / `null`: SlabSets (or lists of (row0, csc)) of the count matrix
+    and of the null matrix X_r cut into the same blocks of cells; `draws`: cand_seed (R1 drawn on the device, chunk by chunk),
+    sample_seed (R4 / R5: keyed permutations of the global candidate list), p_th. Returns the reference's result keys plus per-phase
+    wall times. stop_after = "spectra": stop after the data / null spectra, lambda_c and the signal count (what the float64 fixture pins)."""
+    ctx = ctx or default_context()
+    t_all = time.perf_counter()
+    phases: Dict[str, float] = {}
+
+    def lap(name, t0):
+        ctx.sync()
+        phases[name] = round(time.perf_counter() - t0, 3)
+        if log:
+            log(f"{name}: {phases[name]} s")
+
+    if draws.cand_seed is None:
+        raise ValueError("sclens_chunked draws the zero candidates on the device: draws.cand_seed must be set")
+    t0 = time.perf_counter()
+    ses = chunked_session(ctx, data, draws.cand_seed, log=log if verbose else None)
+    lap("session_create", t0)
+    N, M = ses.N, ses.M
+    try:
+        t0 = time.perf_counter()
+        nullc = ((null.rows(g)[0], null.slab(g)) for g in range(null.world)) if isinstance(null, SlabSet) else iter(null)
+        for g, (row0, X) in enumerate(nullc):
+            ses.chunk_add(1, g, row0, _csc_f32(X))
+            del X
+        Lr = ses.null_spectrum_chunked()  # :704
+        lap("null_spectrum", t0)
+        t0 = time.perf_counter()
+        L, rec_vals = ses.data_spectrum()
+        lap("data_spectrum", t0)
+        L_mp, _, _ = _mp_calculation(L, Lr[:-1])
+        lambda_c = _tw(L, L_mp)[0]
+        t0 = time.perf_counter()
+        L, k, nL, guard = cut_with_guard_band(L, lambda_c, guard_band, ses.refine_eigenvalues)
+        lap("guard_band", t0)
+        if verbose:
+            print(f"(Using hip, {ses.get_int('chunks')} chunks of cells) number of signal ev: {k}")
+        res: Dict[str, object] = {"L": L, "Lr": Lr, "L_mp": L_mp, "λ": lambda_c, "lambda_c": lambda_c, "k": k, "guard_band": guard,
+                                  "rec_vals": rec_vals, "phase_s": phases, "chunks": ses.get_int("chunks")}
+        if stop_after == "spectra":
+            res["chunk_builds"], res["chunk_visits"] = ses.get_int("chunk_builds"), ses.get_int("chunk_visits")
+            res["wall_s"] = time.perf_counter() - t_all
+            return res
+        t0 = time.perf_counter()
+        nV = ses.signal_vectors(k)
+        lap("signal_vectors", t0)
+        t0 = time.perf_counter()
+        _, r_vr2 = ses.binary_basis()  # :717-721
+        lap("binary_basis", t0)
+        mpC = mp_check(L_mp)
+        p_th = draws.p_th
+        n_2 = int(round(r_vr2 / 2))
+        p_list = search_schedule(p_step)
+        t0 = time.perf_counter()
+        n_cand = ses.get_int("n_cand")
+        lap("candidate_count", t0)
+        tank = np.zeros((5, 0))
+        it, p_ = 0, None
+        t0 = time.perf_counter()
+        while p_ is None:  # :725-761
+            nnzidx = int(round((1 - p_list[it]) * M * N))
+            d5 = None
+            if n_cand >= nnzidx:
+                if draws.sampler is not None:
+                    d5, _ = ses.search_step(draws.sampler("search", it, n_cand, nnzidx), n_2)
+                else:
+                    d5, _ = ses.search_step_seeded(sample_seed_for(draws.sample_seed, "search", it), nnzidx, n_2)
+            tank, used, stopped, p_fin = consume_search_round(tank, [d5], p_list, it, p_th, p_step, max_search_iters)
+            it += used
+            if log:
+                log(f"search evaluation {it}: d5[1] = {None if d5 is None else round(float(d5[1]), 6)} (p_th {p_th:.6f})")
+            if stopped:
+                p_ = p_fin
+        lap("sparsity_search", t0)
+        trace = [(p_list[q], tank[:, q].copy()) for q in range(tank.shape[1])]
+        min_pc = int(math.ceil(k * 1.5))
+        m_pert = int(round((1 - p_) * M * N))
+        res.update({"p_": p_, "p_th": p_th, "n_search": it, "search_trace": trace, "n_cand": n_cand})
+        if k == 0:  # :780-784
+            res["wall_s"] = time.perf_counter() - t_all
+            return res
+        nL_set, ncols = [None] * n_perturb, [0] * n_perturb
+        t0 = time.perf_counter()
+        for t in range(n_perturb):  # :767-778
+            if draws.sampler is not None:
+                nL_set[t], ncols[t] = ses.perturb(t, draws.sampler("perturb", t, n_cand, m_pert), min_pc)
+            else:
+                nL_set[t], ncols[t] = ses.perturb_seeded(t, sample_seed_for(draws.sample_seed, "perturb", t), m_pert, min_pc)
+        lap("perturbation_ensemble", t0)
+        t0 = time.perf_counter()
+        a_b, b_ = ses.robustness(k, n_perturb)  # :786-807
+        m_score, sd_score = _robust_scores(b_)
+        sig_id = np.flatnonzero(m_score > math.cos(math.radians(th)))
+        gmat = ses.gene_basis(nL)
+        lap("robustness_gene_basis", t0)
+        res.update({"pca": nV * np.sqrt(nL)[None, :].astype(np.float32),
+                    "pca_n1": nV[:, sig_id] * np.sqrt(nL[sig_id])[None, :].astype(np.float32), "sig_id": sig_id,
+                    "robustness_scores": {"b_": b_, "rob_score": m_score, "m_scores": m_score, "sd_scores": sd_score, "a_b": a_b},
+                    "signal_evec": nV, "signal_ev": nL, "gene_basis": gmat, "pass": mpC["pass"], "ks_static": mpC["ks_static"],
+                    "nL_set": nL_set, "min_pc": min_pc,
+                    "partial_eig": (ses.get_int("chefsi_used"), ses.get_int("chefsi_fallback")),
+                    "chunk_builds": ses.get_int("chunk_builds"), "chunk_visits": ses.get_int("chunk_visits")})
+        res["wall_s"] = time.perf_counter() - t_all
+        return res
+    finally:
+        ses.close()

@@ -15,6 +15,10 @@ int session_set_reduce_to(Session*, sclens_hip_reduce_fn, void*);
 int session_create_sharded_drawn(Ctx*, int64_t, int64_t, int64_t, int64_t, const int64_t*, const int32_t*, const float*, int64_t, uint64_t,
                                  sclens_hip_allreduce_fn, void*, Session**, int64_t*);
 int session_set_candidate_range(Session*, int64_t, int64_t);
+int session_create_chunked(Ctx*, int64_t, int64_t, int, int64_t, uint64_t, Session**);
+int session_chunk_add(Session*, int, int, int64_t, int64_t, const int64_t*, const int32_t*, const float*);
+int session_chunk_commit(Session*);
+int session_null_spectrum_chunked(Session*, double*);
 int session_local_candidates(Session*, uint32_t*, uint32_t*);
 int session_search_round_seeded(Session*, const uint64_t*, const int64_t*, const int32_t*, int, int, int64_t, double*, int64_t*);
 int session_perturb_round_seeded(Session*, const int64_t*, const uint64_t*, const int64_t*, const int32_t*, int, int, int64_t, double*, int64_t*);
@@ -364,6 +368,32 @@ int sclens_hip_session_create_sharded_drawn(sclens_hip_ctx* h, int64_t N_global,
   w->ctx = h;
   *out = w;
   return SCLENS_OK;
+}
+int sclens_hip_session_create_chunked(sclens_hip_ctx* h, int64_t N_global, int64_t M, int n_chunks, int64_t nnz_global, uint64_t seed,
+                                      sclens_hip_session** out) {
+  CTX_GUARD(h);
+  if (!out) return SCLENS_ERR_ARG;
+  scl::Session* s = nullptr;
+  const int rc = scl::session_create_chunked(&h->c, N_global, M, n_chunks, nnz_global, seed, &s);
+  if (rc != SCLENS_OK) return rc;
+  sclens_hip_session* w = new sclens_hip_session();
+  w->s = s;
+  w->ctx = h;
+  *out = w;
+  return SCLENS_OK;
+}
+int sclens_hip_session_chunk_add(sclens_hip_session* w, int which, int g, int64_t row0, int64_t N_local, const int64_t* colptr,
+                                 const int32_t* rowval, const float* nzval) {
+  SES_GUARD(w);
+  return scl::session_chunk_add(w->s, which, g, row0, N_local, colptr, rowval, nzval);
+}
+int sclens_hip_session_chunk_commit(sclens_hip_session* w) {
+  SES_GUARD(w);
+  return scl::session_chunk_commit(w->s);
+}
+int sclens_hip_session_null_spectrum_chunked(sclens_hip_session* w, double* Lr) {
+  SES_GUARD(w);
+  return scl::session_null_spectrum_chunked(w->s, Lr);
 }
 int sclens_hip_session_set_reduce_to(sclens_hip_session* w, sclens_hip_reduce_fn reduce, void* user) {
   SES_GUARD(w);

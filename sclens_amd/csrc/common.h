@@ -20,7 +20,8 @@ namespace scl {
 // `precision` is the one a host normally touches (the reference's `device_` kwarg picks the arithmetic, scLENS.jl:649): 0 = every
 // product on the fp32 matrix cores (v_mfma_f32_32x32x2_f32 / 16x16x4: the reference GPU path's arithmetic), 1 = the large products
 // from operands split into two fp16 pieces on the fp16 matrix cores (22-bit operands, fp32 accumulation; default). With precision = 0
-// the *_split* / gram_bits thresholds below are ignored and q2_variant reads as 3.
+// the *_split* thresholds below are ignored, q2_variant reads as 3, and gram_bits only keeps the exact co-occurrence product of
+// binarised matrices (with 33-bit cell weights: gram_bits_strict).
 #define SCL_OPTION_TABLE(X)                                                                                                        \
   X(precision, 1)                                                                                                                  \
   X(two_stage, -1)          /* eigensolver: 1 two-stage (sbr.hip), 0 one-stage (tridiag.hip), -1 by order */                       \
@@ -28,6 +29,8 @@ namespace scl {
   X(gram_bits, -1)          /* Gram of binarised matrices + search statistic on the fp16 MFMA: 1 always, 0 never, -1 by order */   \
   X(gram_bits_min_n, 16000)                                                                                                        \
   X(gram_bits_terms, 2)     /* fp16 pieces of the cell weights: 2 (22 bits) or 3 (33 bits) */                                      \
+  X(gram_bits_strict, 1)    /* precision = 0: the Gram matrix of a BINARISED matrix still as the exact co-occurrence product, with   \
+                               33-bit cell weights (no operand narrower than fp32: the 0/1 pattern is exact in fp16); 0: fp32 product */ \
   X(gram_split_min_n, 16000) /* dense Gram products from split operands from this order (0: never) */                              \
   X(implicit_min_n, 16000)  /* ensemble: the Gram matrix applied as two passes over the scaled matrix from this order */           \
   X(chefsi_b0, 0)           /* block size of the partial eigensolver (0: min_pc + 40 rounded up to 32) */                          \
@@ -60,6 +63,7 @@ namespace scl {
   X(dense_fused, 1)         /* scaled matrix written in one pass per gene (0: fill + scatter kernels) */                           \
   X(host_pattern, 0)        /* 1: sparse pattern built on the host (tests compare the two builders) */                             \
   X(val_csr, 1)             /* CSR-ordered companion copies of the value arrays */                                                 \
+  X(chunk_cache_gb, 64)     /* chunked session: device memory for chunk patterns kept between visits (the rest are rebuilt) */     \
   X(gemm_force, 0)          /* tests: 1 the large-tile kernels on small shapes, 2 the 128 x 128 kernel on every shape */           \
   X(panel_prof, 0) X(chase_prof, 0) X(q2_prof, 0) /* per-phase shader clocks on stderr (diagnostic builds of the same kernels) */  \
   X(debug, 0)
@@ -109,6 +113,10 @@ struct Options {
   int64_t eff_sy2sb_wsplit_min() const { return split() ? (sy2sb_wsplit_min < 0 ? from(sy2sb_split_min) : from(sy2sb_wsplit_min)) : from(0); }
   int64_t eff_q1_split_min() const { return split() ? q1_split_min : 0; }
   int eff_gram_bits() const { return split() ? (gram_bits < 0 ? -1 : (gram_bits != 0)) : 0; }
+  // the co-occurrence form of a binarised matrix's Gram product alone (session.hip, use_gram_bits): also with precision = 0, where
+  // its operands are no narrower than fp32 -- the pattern is 0/1, the cell weights carry three fp16 pieces = 33 bits
+  int eff_gram_binary() const { return split() ? eff_gram_bits() : ((gram_bits_strict != 0 && gram_bits != 0) ? (gram_bits < 0 ? -1 : 1) : 0); }
+  int eff_gram_bits_terms() const { return split() ? (gram_bits_terms == 3 ? 3 : 2) : 3; }
   int eff_q2_variant() const { return split() ? (int)q2_variant : 3; }
   int eff_two_stage() const { return two_stage < 0 ? -1 : (two_stage != 0); }
 };
@@ -381,7 +389,9 @@ int transpose_f32(Ctx* ctx, const float* in, int64_t rows, int64_t cols, int64_t
 // out row q = in row (rows-1-q)
 int reverse_rows_f32(Ctx* ctx, const float* in, int64_t rows, int64_t cols, int64_t ldi, float* out, int64_t ldo);
 // A (n x n, lda, zero padded) = B B^T / divisor for B [n x K] row-major (ldb), exactly symmetric
-int gram_f32(Ctx* ctx, const float* B, int64_t n, int64_t K, int64_t ldb, float divisor, float* A, int64_t lda, bool allow_split = true);
+// accumulate: A += B B^T / divisor (A must hold an exactly symmetric matrix; chunked sessions sum the contributions of their cell chunks)
+int gram_f32(Ctx* ctx, const float* B, int64_t n, int64_t K, int64_t ldb, float divisor, float* A, int64_t lda, bool allow_split = true,
+             bool accumulate = false);
 
 }  // namespace scl
 

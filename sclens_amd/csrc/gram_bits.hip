@@ -1303,7 +1303,7 @@ size_t gram_binary_scratch_bytes(int64_t N, int64_t M) { return sizeof(unsigned 
 int gram_binary(Ctx* ctx, const PatternDev& p, const float* val, int f32path, void* scratch, float divisor, float* A, int64_t lda,
                 const ShardReduce* sh) {
   const int64_t N = p.N, M = p.M, ldm = round_up(N, 64);
-  const int nw = ctx->opt.gram_bits_terms == 3 ? 3 : 2;  // fp16 pieces of the cell weights: 22 bits (default) or 33
+  const int nw = ctx->opt.eff_gram_bits_terms();  // fp16 pieces of the cell weights: 22 bits (default) or 33 (always with precision = 0)
   hipStream_t st = ctx->stream;
   unsigned short* Pm = static_cast<unsigned short*>(scratch);
   const int64_t nparts = (N + 255) / 256;

@@ -135,6 +135,16 @@ int scale_stats_sharded(Ctx* ctx, const PatternDev& p, const float* val, int f32
 int scale_to_dense_sharded(Ctx* ctx, const PatternDev& p, const float* val, int f32path, float* B, int64_t ldb,
                            ScaleVecs* keep, const ShardReduce& sh);
 
+// chunked session (session.hip): the normalisation of a matrix whose cells are visited in chunks (scale.hip, "chunked variant")
+int chunk_pass_sum(Ctx* ctx, const PatternDev& p, const float* val, int f32path, double* acc);
+int chunk_pass_var(Ctx* ctx, const PatternDev& p, const float* val, int f32path, const double* acc, double n_global, double* acc_s2);
+int chunk_stats_finish(Ctx* ctx, int64_t M, const double* acc, const double* acc_s2, double n_global, int f32path, double* mean, double* stdv,
+                       double* mu, double* red);
+int chunk_dense(Ctx* ctx, const PatternDev& p, const float* val, int f32path, const double* stdv, const double* mu, const double* red, double num,
+                const double* cent, double* accT, float* B, int64_t ldb, double** tgc_out, double** l2_out);
+int chunk_gram_finish(Ctx* ctx, float* A, int64_t n, int64_t lda, const double* T, const double* stdv, const double* mu, double n_global,
+                      double divisor, double* cent);
+
 // val = (binary ? pattern-of-counts : counts), then 1 at the candidate slots idx_dev[0..m)
 int make_values(Ctx* ctx, const PatternDev& p, const float* base_val, int binary, const uint32_t* idx_dev, int64_t m,
                 float* out);

@@ -599,6 +599,120 @@ int scale_to_dense_sharded(Ctx* ctx, const PatternDev& p, const float* val, int 
   return SCLENS_OK;
 }
 
+// ---- chunked variant (cells > genes, ALL cells on this device but visited in chunks of rows; session.hip, "chunked session") -----
+// The same statistics as the row-sharded path, with the sums over ranks replaced by sums over the chunks of ONE session: a matrix
+// whose scaled form (4 N M bytes: 120 GB at 1 000 000 x 30 000) does not fit is normalised and contracted chunk by chunk,
+//     B'B = sum over chunks of B_g' B_g                       (the identity behind scLENS.jl:332-361 for dims = 2)
+// Three passes over the chunks instead of the row-sharded path's five exchange points: (1) per-gene sums, (2) per-gene squared
+// deviations (two-pass variance, as everywhere else), (3) the cells' norms l_i together with the Gram contribution, for which the
+// global mean of the norms c = mean(l) is not needed yet: with U_ij = (Z_ij - mu_j) / l_i (unit rows) the scaled matrix is
+// B = c U - 1 cent', cent_j = (c / N) sum_i U_ij, hence B'B = c^2 U'U - N cent cent' -- the chunk contributes U_g'U_g and
+// sum_i U_ij, and c, cent and the rank-one term are applied once at the end in fp64.
+__global__ void k_axpy_f64(const double* __restrict__ x, int64_t n, double* __restrict__ y) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) y[i] += x[i];
+}
+__global__ void k_inv_f64(const double* __restrict__ x, int64_t n, double num, double* __restrict__ y) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) y[i] = num / x[i];
+}
+static int chunk_lg(Ctx* ctx, const PatternDev& p, const float* val, int f32path, double** tgc_out, double** lg_out, double* part) {
+  SCL_WS(ctx, tgc, double, "sc.tgc", p.N);
+  SCL_WS(ctx, lg, double, "sc.lg", p.nU);
+  hipLaunchKernelGGL(k_row_sums, dim3((unsigned)((p.N + 3) / 4)), dim3(256), 0, ctx->stream, p, val, tgc);
+  hipLaunchKernelGGL(k_sh_col_sum, dim3((unsigned)((p.M + 3) / 4)), dim3(256), 0, ctx->stream, p, val, tgc, f32path, lg, part, p.M);
+  SCL_HIP(ctx, hipGetLastError());
+  *tgc_out = tgc;
+  *lg_out = lg;
+  return SCLENS_OK;
+}
+// pass 1: acc[0..M) += per-gene sums of lg over this chunk, acc[M..2M) += its slots per gene
+int chunk_pass_sum(Ctx* ctx, const PatternDev& p, const float* val, int f32path, double* acc) {
+  SCL_WS(ctx, part, double, "sc.part", 2 * p.M + 8);
+  double *tgc, *lg;
+  SCL_TRY(chunk_lg(ctx, p, val, f32path, &tgc, &lg, part));
+  hipLaunchKernelGGL(k_axpy_f64, dim3((unsigned)((2 * p.M + 255) / 256)), dim3(256), 0, ctx->stream, part, 2 * p.M, acc);
+  SCL_HIP(ctx, hipGetLastError());
+  return SCLENS_OK;
+}
+// pass 2: acc_s2[j] += sum over this chunk's slots of (lg - mean_j)^2, mean_j = acc[j] / n_global
+int chunk_pass_var(Ctx* ctx, const PatternDev& p, const float* val, int f32path, const double* acc, double n_global, double* acc_s2) {
+  SCL_WS(ctx, part, double, "sc.part", 2 * p.M + 8);
+  SCL_WS(ctx, s2, double, "sc.s2", p.M);
+  double *tgc, *lg;
+  SCL_TRY(chunk_lg(ctx, p, val, f32path, &tgc, &lg, part));
+  hipLaunchKernelGGL(k_sh_col_var, dim3((unsigned)((p.M + 3) / 4)), dim3(256), 0, ctx->stream, p, lg, acc, n_global, s2, p.M);
+  hipLaunchKernelGGL(k_axpy_f64, dim3((unsigned)((p.M + 255) / 256)), dim3(256), 0, ctx->stream, s2, p.M, acc_s2);
+  SCL_HIP(ctx, hipGetLastError());
+  return SCLENS_OK;
+}
+// mean / std / mu of all cells from the accumulated sums; red[0] = ||mu||^2
+int chunk_stats_finish(Ctx* ctx, int64_t M, const double* acc, const double* acc_s2, double n_global, int f32path, double* mean,
+                       double* stdv, double* mu, double* red) {
+  hipLaunchKernelGGL(k_sh_col_fin, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, ctx->stream, acc, acc_s2, n_global, f32path, M, mean, stdv, mu);
+  hipLaunchKernelGGL(k_reduce, dim3(1), dim3(1024), 0, ctx->stream, mu, M, 0, red + 0);
+  SCL_HIP(ctx, hipGetLastError());
+  return SCLENS_OK;
+}
+// pass 3 / dense pass. The chunk's cells' norms l (-> l2_out, device, p.N doubles, optional), then the dense block
+//   B[j][i] = srow_i (Z_ij - mu_j) - cent_j      with srow_i = num / l_i
+// num = 1, cent = zeros: the unit-row form U of pass 3, together with accT[0..M) += sum_i lg_ij / l_i, accT[M] += sum_i 1 / l_i,
+// accT[M + 1] += sum_i l_i (accT != nullptr); num = c = mean(l), cent = the finished centring vector: the scaled matrix itself.
+int chunk_dense(Ctx* ctx, const PatternDev& p, const float* val, int f32path, const double* stdv, const double* mu, const double* red,
+                double num, const double* cent, double* accT, float* B, int64_t ldb, double** tgc_out, double** l2_out) {
+  const int64_t N = p.N, M = p.M;
+  SCL_WS(ctx, part, double, "sc.part", 2 * M + 8);
+  SCL_WS(ctx, l2, double, "sc.l2", N);
+  SCL_WS(ctx, srow, double, "sc.srow", N);
+  double *tgc, *lg;
+  SCL_TRY(chunk_lg(ctx, p, val, f32path, &tgc, &lg, part));
+  hipStream_t st = ctx->stream;
+  hipLaunchKernelGGL(k_row_norms, dim3((unsigned)((N + 3) / 4)), dim3(256), 0, st, p, val, tgc, f32path, lg, stdv, mu, red + 0, l2);
+  hipLaunchKernelGGL(k_inv_f64, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, st, l2, N, num, srow);
+  if (accT) {
+    hipLaunchKernelGGL(k_sh_col_cent_part, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, st, p, lg, srow, part, M);
+    hipLaunchKernelGGL(k_reduce, dim3(1), dim3(1024), 0, st, srow, N, 1, part + M);
+    hipLaunchKernelGGL(k_reduce, dim3(1), dim3(1024), 0, st, l2, N, 1, part + M + 1);
+    hipLaunchKernelGGL(k_axpy_f64, dim3((unsigned)((M + 2 + 255) / 256)), dim3(256), 0, st, part, M + 2, accT);
+  }
+  if (B) {
+    if (ldb % 4 != 0 || (reinterpret_cast<uintptr_t>(B) & 15u) != 0) return ctx->fail(SCLENS_ERR_ARG, "chunk_dense: unaligned block");
+    hipLaunchKernelGGL(k_dense_fused, dim3((unsigned)M), dim3(256), 0, st, p, val, lg, stdv, mu, cent, srow, B, ldb);
+  }
+  SCL_HIP(ctx, hipGetLastError());
+  if (tgc_out) *tgc_out = tgc;
+  if (l2_out) *l2_out = l2;
+  return SCLENS_OK;
+}
+// cent_j = (c T_j / std_j - mu_j c T_M) / N with c = T_{M+1} / N (all on the device: no host round trip), then
+// A = c^2 A - (N / divisor) cent cent' (A holds sum_g U_g'U_g / divisor; fp64 per element, symmetric in (j, k))
+__global__ void k_chunk_cent_fin(const double* __restrict__ T, const double* __restrict__ stdv, const double* __restrict__ mu,
+                                 double n_global, int64_t M, double* __restrict__ cent) {
+  const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= M) return;
+  const double c = T[M + 1] / n_global;
+  cent[j] = (c * T[j] / stdv[j] - mu[j] * c * T[M]) / n_global;
+}
+__global__ void k_chunk_gram_fin(float* __restrict__ A, int64_t n, int64_t lda, const double* __restrict__ T, const double* __restrict__ cent_rows,
+                                 const double* __restrict__ cent, double n_global, double nd) {
+  const int64_t j = blockIdx.y;
+  const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= n) return;
+  const double c = T[n + 1] / n_global;
+  A[j * lda + k] = (float)(c * c * (double)A[j * lda + k] - nd * (cent_rows[j] * cent[k]));
+}
+int chunk_gram_finish(Ctx* ctx, float* A, int64_t n, int64_t lda, const double* T, const double* stdv, const double* mu, double n_global,
+                      double divisor, double* cent) {
+  hipLaunchKernelGGL(k_chunk_cent_fin, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, T, stdv, mu, n_global, n, cent);
+  for (int64_t r0 = 0; r0 < n; r0 += 65535) {
+    const int64_t rows = std::min<int64_t>(65535, n - r0);
+    hipLaunchKernelGGL(k_chunk_gram_fin, dim3((unsigned)((n + 255) / 256), (unsigned)rows), dim3(256), 0, ctx->stream, A + r0 * lda, n, lda, T,
+                       cent + r0, cent, n_global, n_global / divisor);
+  }
+  SCL_HIP(ctx, hipGetLastError());
+  return SCLENS_OK;
+}
+
 // ---- value arrays over the pattern ------------------------------------------------------------------
 // out[q] = binary ? (base[q] != 0) : base[q]     (candidate slots have base 0); the CSR-ordered copy behind it likewise
 __global__ void k_val_init(const float* __restrict__ base, const float* __restrict__ base_csr, int64_t nU, int binary,

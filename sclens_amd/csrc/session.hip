@@ -95,9 +95,10 @@ int reverse_rows_f32(Ctx* ctx, const float* in, int64_t rows, int64_t cols, int6
 
 // allow_split = false: the per-call drop-ins of the reference's functions (`_wishart_matrix`, `get_eigvec`) -- a caller that asks
 // for THE fp32 product gets it at every size unless the context option gram_bits = 1 asks for the accelerated form explicitly
-int gram_f32(Ctx* ctx, const float* B, int64_t n, int64_t K, int64_t ldb, float divisor, float* A, int64_t lda, bool allow_split) {
+int gram_f32(Ctx* ctx, const float* B, int64_t n, int64_t K, int64_t ldb, float divisor, float* A, int64_t lda, bool allow_split,
+             bool accumulate) {
   StageTimer tm(ctx, "gram");
-  SCL_HIP(ctx, hipMemsetAsync(A, 0, sizeof(float) * (size_t)n * lda, ctx->stream));
+  if (!accumulate) SCL_HIP(ctx, hipMemsetAsync(A, 0, sizeof(float) * (size_t)n * lda, ctx->stream));
   // Large products (n >= 16 000, or context option gram_split_min_n = <n>; 0 = never): the scaled matrix is split once into two fp16 pieces per
   // entry (scaled by the power of two that brings its largest entry to 2^13..2^14: 22 significant bits of every entry down to
   // 2^-38 of the largest) and the product runs on the fp16 matrix cores with fp32 accumulation (gemm_split_update, gram_bits.hip):
@@ -114,7 +115,7 @@ int gram_f32(Ctx* ctx, const float* B, int64_t n, int64_t K, int64_t ldb, float 
   g.P = B; g.Q = B; g.C = A;
   g.M = n; g.N = n; g.K = K;
   g.ldp = ldb; g.ldq = ldb; g.ldc = lda;
-  g.alpha = 1.0f / divisor; g.beta = 0.f;
+  g.alpha = 1.0f / divisor; g.beta = accumulate ? 1.f : 0.f;
   g.q_kcontig = 1; g.lower = 1; g.colabsmax = nullptr;
   return gemm_f32(ctx, g);
 }
@@ -190,6 +191,33 @@ static int64_t count_positive_tol(const std::vector<double>& w) {
 }
 
 // ------------------------------------------------------------------------------------------------ session
+// Chunked session (cells > genes; all cells on this device, visited in chunks of rows): what a matrix of a chunked decomposition is
+struct MatSpec {
+  int set = 0;     // 0: the count matrix, 1: the null matrix X_r
+  int cands = 0;   // the chunk patterns carry the zero candidates
+  int binary = 0;  // stored counts as ones (scLENS.jl:664)
+  int sample = 0;  // 0: no candidate ones, 1: the uploaded index list (idx_dev, m), 2: the keyed permutation (seed, m)
+  uint64_t seed = 0;
+  int64_t m = 0;
+  int f32path = 1;
+};
+struct ChunkSrc {
+  int64_t row0 = 0, N = 0;
+  Counts* counts = nullptr;         // the chunk's cells as device CSC (owned)
+  int64_t ncand = 0, cand_off = 0;  // its window of the global candidate list
+};
+struct ChunkPat {
+  int set = 0, cands = 0, g = 0;
+  PatternOwner pat;
+  size_t bytes = 0;
+};
+struct ChunkStatsDev {  // statistics of one normalisation that span all cells (device, session-owned): what rebuilds a chunk's scaled block
+  double *stdv = nullptr, *mu = nullptr, *cent = nullptr, *red = nullptr;  // red[0] = ||mu||^2
+  double c = 0.0;                                                         // mean cell norm
+  MatSpec spec;
+  bool valid = false;
+};
+
 struct Session {
   Ctx* ctx = nullptr;
   int64_t N = 0, M = 0, n = 0, K = 0;
@@ -232,6 +260,18 @@ struct Session {
   int64_t idx_cap = 0;
   bool have_spectrum = false;
   std::vector<void*> allocs;
+  // chunked session: N = all cells, the count matrix (and, during null_spectrum, X_r) as device-resident CSC chunks of rows; Btmp is ONE
+  // chunk's scaled block [M][ldb], ldb = largest chunk rounded up; Bmain does not exist (blocks are rebuilt from st_data when needed)
+  std::vector<ChunkSrc> chunks, null_chunks;
+  std::vector<ChunkPat*> pcache;  // chunk patterns kept between visits (context option chunk_cache_gb); all of one (set, cands) kind
+  size_t pcache_bytes = 0;
+  bool chunk_committed = false, cands_counted = false;
+  uint64_t cand_seed = 0;
+  int64_t nnz_global = 0, ncand_total = 0;
+  MatSpec cspec;  // the matrix the next decomposition is about
+  ChunkStatsDev st_data, st_last;
+  int64_t chunk_builds = 0, chunk_visits = 0;
+  bool chunked() const { return !chunks.empty(); }
 
   int dmalloc(void** p, size_t bytes) {
     hipError_t e = pool_malloc(p, std::max<size_t>(bytes, 16));
@@ -542,6 +582,7 @@ int session_local_candidates(Session* s, uint32_t* z1, uint32_t* z2) {
 int session_clone(Ctx* ctx2, Session* src, Session** out) {
   if (ctx2->live_sessions > 0 || ctx2 == src->ctx)
     return ctx2->fail(SCLENS_ERR_STATE, "session_clone: the worker needs a context of its own without a live session");
+  if (src->chunked()) return ctx2->fail(SCLENS_ERR_STATE, "session_clone: a chunked session has no worker sessions");
   Session* s = new Session();
   s->ctx = ctx2;
   ctx2->opt = src->ctx->opt;  // the worker decomposes the way its parent does
@@ -572,21 +613,275 @@ int session_clone(Ctx* ctx2, Session* src, Session** out) {
   return SCLENS_OK;
 }
 
+static void chunk_cache_flush(Session* s);
+static std::vector<ChunkSrc>& chunk_set(Session* s, int set);
+// Chunked session: the shell (gene-side buffers), then the chunks one at a time (the host never holds more than one), then commit.
+int session_create_chunked(Ctx* ctx, int64_t N_global, int64_t M, int n_chunks, int64_t nnz_global, uint64_t seed, Session** out) {
+  if (N_global <= M || M <= 0 || n_chunks <= 0 || n_chunks > 4096 || nnz_global < 0 || nnz_global >= 0xFFFFFFF0ll)
+    return ctx->fail(SCLENS_ERR_ARG, "session_create_chunked: needs cells > genes, 1..4096 chunks, fewer than 2^32 stored entries");
+  if (ctx->live_sessions > 0) return ctx->fail(SCLENS_ERR_STATE, "session_create_chunked: this context already has a live session");
+  Session* s = new Session();
+  s->ctx = ctx;
+  s->N = N_global; s->M = M;
+  s->n = M; s->K = N_global; s->Kdiv = N_global;
+  s->cells_major = 0;
+  s->chunks.resize((size_t)n_chunks);
+  s->nnz_global = nnz_global;
+  s->cand_seed = seed;
+  s->lda = round_up(M, 32);
+  s->ldz = round_up(M, 32);
+  s->ldn = round_up(N_global, 32);
+  int rc;
+  auto fail = [&](int code) { for (void* p : s->allocs) pool_free(p, nullptr); delete s; return code; };
+  if ((rc = s->dmalloc((void**)&s->A, sizeof(float) * (size_t)s->n * s->lda)) != SCLENS_OK) return fail(rc);
+  if ((rc = s->dmalloc((void**)&s->w64, sizeof(double) * s->n)) != SCLENS_OK) return fail(rc);
+  for (ChunkStatsDev* st : {&s->st_data, &s->st_last}) {
+    double* blk = nullptr;
+    if ((rc = s->dmalloc((void**)&blk, sizeof(double) * (size_t)(3 * M + 8))) != SCLENS_OK) return fail(rc);
+    st->stdv = blk; st->mu = blk + M; st->cent = blk + 2 * M; st->red = blk + 3 * M;
+  }
+  s->ctx->live_sessions += 1;
+  *out = s;
+  return SCLENS_OK;
+}
+int session_chunk_add(Session* s, int which, int g, int64_t row0, int64_t N_local, const int64_t* colptr, const int32_t* rowval,
+                      const float* nzval) {
+  Ctx* ctx = s->ctx;
+  if (!s->chunked()) return ctx->fail(SCLENS_ERR_STATE, "chunk_add: not a chunked session");
+  if ((which != 0 && which != 1) || g < 0 || g >= (int)s->chunks.size() || N_local <= 0 || row0 < 0 || row0 + N_local > s->N || !colptr)
+    return ctx->fail(SCLENS_ERR_ARG, "chunk_add: bad chunk index / cell range");
+  if (which == 0 && s->chunk_committed) return ctx->fail(SCLENS_ERR_STATE, "chunk_add: the count matrix is already committed");
+  if (which == 1) {
+    if (!s->chunk_committed) return ctx->fail(SCLENS_ERR_STATE, "chunk_add: commit the count matrix before adding X_r");
+    if (s->null_chunks.empty()) s->null_chunks.resize(s->chunks.size());
+    if (row0 != s->chunks[g].row0 || N_local != s->chunks[g].N) return ctx->fail(SCLENS_ERR_ARG, "chunk_add: X_r must be cut like the count matrix");
+  }
+  ChunkSrc& c = chunk_set(s, which)[g];
+  if (c.counts) return ctx->fail(SCLENS_ERR_STATE, "chunk_add: this chunk has been added already");
+  c.row0 = row0; c.N = N_local;
+  return counts_upload(ctx, N_local, s->M, colptr, rowval, nzval, &c.counts);
+}
+int session_chunk_commit(Session* s) {
+  Ctx* ctx = s->ctx;
+  if (!s->chunked() || s->chunk_committed) return ctx->fail(SCLENS_ERR_STATE, "chunk_commit: not a chunked session, or committed already");
+  int64_t next = 0, nmax = 0, nnz = 0;
+  for (const ChunkSrc& c : s->chunks) {  // consecutive blocks of cells covering [0, N)
+    if (!c.counts || c.row0 != next) return ctx->fail(SCLENS_ERR_ARG, "chunk_commit: the chunks must be consecutive blocks of cells, all added");
+    next += c.N;
+    nmax = std::max(nmax, c.N);
+    nnz += c.counts->nnz;
+  }
+  if (next != s->N) return ctx->fail(SCLENS_ERR_ARG, "chunk_commit: the chunks do not cover all cells");
+  if (nnz != s->nnz_global) return ctx->fail(SCLENS_ERR_ARG, "chunk_commit: stored entries of the chunks != nnz_global");
+  s->ldb = round_up(nmax, 32);
+  SCL_TRY(s->dmalloc((void**)&s->Btmp, sizeof(float) * (size_t)s->n * s->ldb));
+  s->chunk_committed = true;
+  return SCLENS_OK;
+}
 void session_destroy(Session* s) {
   if (!s) return;
   hipStreamSynchronize(s->ctx->stream);
   s->ctx->live_sessions -= 1;
+  chunk_cache_flush(s);
+  for (ChunkSrc& c : s->chunks) counts_free(c.counts);
+  for (ChunkSrc& c : s->null_chunks) counts_free(c.counts);
   pattern_free(&s->pat);
   for (void* p : s->allocs) pool_free(p, nullptr);  // the stream has just been synchronised
   delete s;
+}
+
+// ------------------------------------------------------------------------------------------------ chunked session
+// BASELINE configs[4] ("chunked Gram accumulation"): a cells > genes matrix whose scaled form does not fit the device -- 1 000 000 x
+// 30 000 is 120 GB dense, 175 GB as a union pattern -- is held as device-resident CSC chunks of rows (8 bytes per stored entry) and
+// every decomposition visits the chunks: pattern of the chunk (built on the device, with the chunk's part of the global candidate
+// draw when the matrix carries candidate ones; kept between visits as far as chunk_cache_gb allows), value array, the chunk's terms
+// of the statistics (scale.hip, chunked variant: three passes), its scaled block, and the block's contribution to the M x M Gram
+// matrix (scLENS.jl:332-361 as a sum over cell blocks). Everything on the gene side -- eigensolver, search statistic, partial
+// eigensolver, robustness -- is the code of the plain session; the cell-side vectors of ALL cells stay resident (k x N floats).
+// One GPU does then what SURVEY 8e-iii spreads over ranks; the row-sharded session remains the multi-GPU form.
+static void chunk_cache_flush(Session* s) {
+  if (!s->pcache.empty()) ctx_quiesce(s->ctx);
+  for (ChunkPat* e : s->pcache) {
+    pattern_free(&e->pat);
+    delete e;
+  }
+  s->pcache.clear();
+  s->pcache_bytes = 0;
+}
+static std::vector<ChunkSrc>& chunk_set(Session* s, int set) { return set == 0 ? s->chunks : s->null_chunks; }
+struct ChunkPatRef {
+  ChunkPat* e = nullptr;
+  bool transient = false;
+};
+static int chunk_count_candidates(Session* s);
+static int chunk_pattern(Session* s, int set, int cands, int g, ChunkPatRef* ref) {
+  Ctx* ctx = s->ctx;
+  if (cands && !s->cands_counted) SCL_TRY(chunk_count_candidates(s));
+  if (!s->pcache.empty() && (s->pcache[0]->set != set || s->pcache[0]->cands != cands)) chunk_cache_flush(s);  // a phase is over
+  s->chunk_visits += 1;
+  for (ChunkPat* e : s->pcache)
+    if (e->g == g) {
+      ref->e = e;
+      ref->transient = false;
+      return SCLENS_OK;
+    }
+  const ChunkSrc& c = chunk_set(s, set)[g];
+  if (!c.counts) return ctx->fail(SCLENS_ERR_STATE, "chunked session: chunk " + std::to_string(g) + " has not been added");
+  size_t live0 = 0, live1 = 0;
+  pool_stats(ctx->device, nullptr, &live0, nullptr, nullptr);
+  ChunkPat* e = new ChunkPat();
+  e->set = set; e->cands = cands; e->g = g;
+  const BlockDraw blk{s->N, c.row0, s->nnz_global};
+  const int rc = pattern_build_device(ctx, c.N, s->M, c.counts->colptr, c.counts->row, c.counts->val, 0, nullptr, nullptr, cands ? 1 : 0,
+                                      s->cand_seed, &e->pat, c.counts->nnz, cands ? &blk : nullptr);
+  if (rc != SCLENS_OK) {
+    pattern_free(&e->pat, ctx);
+    delete e;
+    return rc;
+  }
+  s->chunk_builds += 1;
+  if (cands) {
+    e->pat.dev.cand_off = c.cand_off;
+    e->pat.dev.ncand_global = s->ncand_total;
+  }
+  pool_stats(ctx->device, nullptr, &live1, nullptr, nullptr);
+  e->bytes = live1 > live0 ? live1 - live0 : 0;
+  const size_t budget = (size_t)std::max<int64_t>(0, ctx->opt.chunk_cache_gb) << 30;
+  if (s->pcache_bytes + e->bytes <= budget) {
+    s->pcache.push_back(e);
+    s->pcache_bytes += e->bytes;
+    ref->transient = false;
+  } else {
+    ref->transient = true;
+  }
+  ref->e = e;
+  return SCLENS_OK;
+}
+static void chunk_pattern_done(Session* s, ChunkPatRef* ref) {
+  if (ref->e && ref->transient) {
+    ctx_quiesce(s->ctx);
+    pattern_free(&ref->e->pat);
+    delete ref->e;
+  }
+  ref->e = nullptr;
+}
+// the windows of the chunks in the global candidate list (R1, scLENS.jl:668-673): the list is the concatenation of the chunks' parts of
+// the one global draw sequence, in chunk order -- the convention of the row-sharded session with local candidates
+static int chunk_count_candidates(Session* s) {
+  Ctx* ctx = s->ctx;
+  if (!s->chunk_committed) return ctx->fail(SCLENS_ERR_STATE, "chunked session: call chunk_commit first");
+  s->cands_counted = true;  // (chunk_pattern below must not recurse)
+  s->ncand_total = 0;
+  chunk_cache_flush(s);
+  int64_t off = 0;
+  for (size_t g = 0; g < s->chunks.size(); ++g) {
+    ChunkPatRef ref;
+    const int rc = chunk_pattern(s, 0, 1, (int)g, &ref);
+    if (rc != SCLENS_OK) { s->cands_counted = false; return rc; }
+    s->chunks[g].ncand = ref.e->pat.dev.ncand;
+    s->chunks[g].cand_off = off;
+    off += s->chunks[g].ncand;
+    chunk_pattern_done(s, &ref);
+  }
+  if (off >= 0xFFFFFFF0ll) { s->cands_counted = false; return ctx->fail(SCLENS_ERR_ARG, "chunked session: more than 2^32 zero candidates"); }
+  s->ncand_total = off;
+  for (ChunkPat* e : s->pcache) {  // the patterns that stayed in the cache were built before the windows were known
+    e->pat.dev.cand_off = s->chunks[e->g].cand_off;
+    e->pat.dev.ncand_global = off;
+  }
+  return SCLENS_OK;
+}
+static int chunk_values(Session* s, const MatSpec& ms, const PatternOwner& p, float** out) {
+  Ctx* ctx = s->ctx;
+  float* val = static_cast<float*>(ctx->workspace("ses.cval", sizeof(float) * p.dev.val_floats()));
+  if (!val) return SCLENS_ERR_OOM;
+  if (ms.sample != 0 && !ms.cands) return ctx->fail(SCLENS_ERR_STATE, "chunked session: a sample needs patterns with candidates");
+  if (ms.sample == 2) SCL_TRY(make_values_seeded(ctx, p.dev, p.base_val, ms.binary, ms.seed, ms.m, val));
+  else SCL_TRY(make_values(ctx, p.dev, p.base_val, ms.binary, ms.sample == 1 ? s->idx_dev : nullptr, ms.sample == 1 ? ms.m : 0, val));
+  *out = val;
+  return SCLENS_OK;
+}
+// Gram matrix of the scaled matrix `ms` (all cells) / divisor -> A, its statistics -> st (and rec_vals -> keep)
+static int chunked_gram(Session* s, const MatSpec& ms, float divisor, ScaleVecs* keep, float* A, ChunkStatsDev* st) {
+  Ctx* ctx = s->ctx;
+  const int64_t M = s->M;
+  const double ng = (double)s->N;
+  std::vector<ChunkSrc>& set = chunk_set(s, ms.set);
+  if (!s->chunk_committed || set.empty()) return ctx->fail(SCLENS_ERR_STATE, "chunked session: no chunks (chunk_add / chunk_commit first)");
+  SCL_WS(ctx, acc, double, "ck.acc", 2 * M);
+  SCL_WS(ctx, acc2, double, "ck.acc2", M);
+  SCL_WS(ctx, accT, double, "ck.accT", M + 2);
+  SCL_WS(ctx, mean, double, "ck.mean", M);
+  SCL_WS(ctx, zero, double, "ck.zero", M);
+  hipStream_t stq = ctx->stream;
+  SCL_HIP(ctx, hipMemsetAsync(acc, 0, sizeof(double) * 2 * M, stq));
+  SCL_HIP(ctx, hipMemsetAsync(acc2, 0, sizeof(double) * M, stq));
+  SCL_HIP(ctx, hipMemsetAsync(accT, 0, sizeof(double) * (M + 2), stq));
+  SCL_HIP(ctx, hipMemsetAsync(zero, 0, sizeof(double) * M, stq));
+  st->valid = false;
+  for (int pass = 0; pass < 3; ++pass) {
+    for (size_t g = 0; g < set.size(); ++g) {
+      ChunkPatRef ref;
+      SCL_TRY(chunk_pattern(s, ms.set, ms.cands, (int)g, &ref));
+      float* val = nullptr;
+      int rc = chunk_values(s, ms, ref.e->pat, &val);
+      const PatternDev& p = ref.e->pat.dev;
+      if (rc == SCLENS_OK && pass == 0) rc = chunk_pass_sum(ctx, p, val, ms.f32path, acc);
+      if (rc == SCLENS_OK && pass == 1) rc = chunk_pass_var(ctx, p, val, ms.f32path, acc, ng, acc2);
+      if (rc == SCLENS_OK && pass == 2) {
+        double *tgc = nullptr, *l2 = nullptr;
+        {
+          StageTimer tm(ctx, "scale");
+          rc = chunk_dense(ctx, p, val, ms.f32path, st->stdv, st->mu, st->red, 1.0, zero, accT, s->Btmp, s->ldb, &tgc, &l2);
+        }
+        if (rc == SCLENS_OK && keep) {
+          hipError_t e1 = hipMemcpyAsync(keep->tgc + set[g].row0, tgc, sizeof(double) * set[g].N, hipMemcpyDeviceToHost, stq);
+          hipError_t e2 = hipMemcpyAsync(keep->norm_tgc + set[g].row0, l2, sizeof(double) * set[g].N, hipMemcpyDeviceToHost, stq);
+          if (e1 != hipSuccess || e2 != hipSuccess) rc = ctx->fail(SCLENS_ERR_HIP, "chunked session: rec_vals copy failed");
+        }
+        if (rc == SCLENS_OK) rc = gram_f32(ctx, s->Btmp, M, set[g].N, s->ldb, divisor, A, s->lda, true, g > 0);
+      }
+      chunk_pattern_done(s, &ref);
+      SCL_TRY(rc);
+    }
+    if (pass == 1) SCL_TRY(chunk_stats_finish(ctx, M, acc, acc2, ng, ms.f32path, mean, st->stdv, st->mu, st->red));
+  }
+  SCL_TRY(chunk_gram_finish(ctx, A, M, s->lda, accT, st->stdv, st->mu, ng, (double)divisor, st->cent));
+  double lsum = 0.0;
+  SCL_HIP(ctx, hipMemcpyAsync(&lsum, accT + M + 1, sizeof(double), hipMemcpyDeviceToHost, stq));
+  if (keep) {
+    SCL_HIP(ctx, hipMemcpyAsync(keep->mat2_mean, mean, sizeof(double) * M, hipMemcpyDeviceToHost, stq));
+    SCL_HIP(ctx, hipMemcpyAsync(keep->mat2_std, st->stdv, sizeof(double) * M, hipMemcpyDeviceToHost, stq));
+    SCL_HIP(ctx, hipMemcpyAsync(keep->cent, st->cent, sizeof(double) * M, hipMemcpyDeviceToHost, stq));
+  }
+  SCL_HIP(ctx, hipStreamSynchronize(stq));
+  st->c = lsum / ng;
+  st->spec = ms;
+  st->valid = true;
+  return SCLENS_OK;
+}
+// the scaled block of chunk g of the matrix st describes -> s->Btmp ([M][ldb], columns = the chunk's cells)
+static int chunk_block(Session* s, const ChunkStatsDev& st, int g) {
+  Ctx* ctx = s->ctx;
+  if (!st.valid) return ctx->fail(SCLENS_ERR_STATE, "chunked session: no statistics to rebuild the scaled block from");
+  ChunkPatRef ref;
+  SCL_TRY(chunk_pattern(s, st.spec.set, st.spec.cands, g, &ref));
+  float* val = nullptr;
+  int rc = chunk_values(s, st.spec, ref.e->pat, &val);
+  if (rc == SCLENS_OK) {
+    StageTimer tm(ctx, "scale");
+    rc = chunk_dense(ctx, ref.e->pat.dev, val, st.spec.f32path, st.stdv, st.mu, st.red, st.c, st.cent, nullptr, s->Btmp, s->ldb, nullptr, nullptr);
+  }
+  chunk_pattern_done(s, &ref);
+  return rc;
 }
 
 // scaled dense matrix of `val` -> B, Gram -> A, eigenvalues -> w64/w_host
 // binary: every value of `val` is 0 or 1 (sparsity search): large problems in the genes-major layout then skip the scaled
 // matrix and form the Gram matrix on the fp16 MFMA (gram_bits.hip); B is only scratch in that case
 static bool use_gram_bits(const Session* s) {
-  const int gb = s->ctx->opt.eff_gram_bits();
-  if (s->centering || s->cells_major || gb == 0) return false;  // row-sharded sessions: each rank's additive part
+  const int gb = s->ctx->opt.eff_gram_binary();
+  if (s->centering || s->cells_major || gb == 0 || s->chunked()) return false;  // row-sharded sessions: each rank's additive part
   return gb == 1 || s->n >= s->ctx->opt.gram_bits_min_n;
 }
 // the search statistic from split fp16 images (22-bit operands, fp32 accumulation) under the same switch
@@ -600,7 +895,9 @@ static int decompose(Session* s, const PatternDev& p, const float* val, int f32p
                      ScaleVecs* keep, int64_t n_low = -1, bool binary = false, bool solve = true, int sum_root = -1,
                      float* Aout = nullptr) {
   float* Ag = Aout ? Aout : s->A;
-  if (binary && !keep && use_gram_bits(s)) {
+  if (s->chunked()) {  // the matrix is s->cspec (p / val / B unused): statistics and Gram matrix summed over the chunks of cells
+    SCL_TRY(chunked_gram(s, s->cspec, divisor, keep, Ag, keep ? &s->st_data : &s->st_last));
+  } else if (binary && !keep && use_gram_bits(s)) {
     SCL_TRY(gram_binary(s->ctx, p, val, f32path, B, divisor, Ag, s->lda, s->sh.on() ? &s->sh : nullptr));
     s->ctx->gram_bits_used += 1;
     if (s->sh.on()) {
@@ -622,9 +919,30 @@ static int decompose(Session* s, const PatternDev& p, const float* val, int f32p
   return s->fetch_w(n_low >= 0);
 }
 
+// null matrix X_r (scLENS.jl:701, :704) of a chunked session: its chunks have been added with which = 1 and are released afterwards
+int session_null_spectrum_chunked(Session* s, double* Lr) {
+  Ctx* ctx = s->ctx;
+  if (!s->chunked() || s->null_chunks.empty()) return ctx->fail(SCLENS_ERR_STATE, "null_spectrum_chunked: add the chunks of X_r first");
+  for (const ChunkSrc& c : s->null_chunks)
+    if (!c.counts) return ctx->fail(SCLENS_ERR_STATE, "null_spectrum_chunked: a chunk of X_r is missing");
+  s->cspec = MatSpec{};
+  s->cspec.set = 1;
+  s->ctx->q2_prebuild = false;  // eigenvalues only
+  PatternDev none;
+  const int rc = decompose(s, none, nullptr, 1, s->Btmp, (float)s->M, nullptr);
+  s->ctx->q2_prebuild = true;
+  chunk_cache_flush(s);
+  for (ChunkSrc& c : s->null_chunks) counts_free(c.counts, ctx);
+  s->null_chunks.clear();
+  SCL_TRY(rc);
+  if (Lr) std::copy(s->w_host.begin(), s->w_host.end(), Lr);
+  return SCLENS_OK;
+}
+
 // null matrix X_r (scLENS.jl:701, :704): closure path, eigenvalues only (:532, :572)
 int session_null_spectrum(Session* s, const int64_t* rc_, const int32_t* rr_, const float* rv_, double* Lr) {
   Ctx* ctx = s->ctx;
+  if (s->chunked()) return ctx->fail(SCLENS_ERR_STATE, "null_spectrum: a chunked session takes X_r as chunks (chunk_add which = 1, null_spectrum_chunked)");
   PatternOwner pr;
   SCL_TRY(pattern_build(ctx, s->N, s->M, rc_, rr_, rv_, 0, nullptr, nullptr, &pr));  // sharded: this rank's cells of X_r
   float* valr = static_cast<float*>(ctx->workspace("ses.valr", sizeof(float) * pr.dev.val_floats()));
@@ -643,6 +961,7 @@ int session_null_spectrum(Session* s, const int64_t* rc_, const int32_t* rr_, co
 // the same from a pattern that was built (and uploaded) beforehand, e.g. on a host thread while the session was created
 int session_null_spectrum_pattern(Session* s, PatternOwner* pr, double* Lr) {
   Ctx* ctx = s->ctx;
+  if (s->chunked()) return ctx->fail(SCLENS_ERR_STATE, "null_spectrum: a chunked session takes X_r as chunks (chunk_add which = 1, null_spectrum_chunked)");
   if (!pr || pr->allocs.empty() || pr->dev.N != s->N || pr->dev.M != s->M)
     return ctx->fail(SCLENS_ERR_ARG, "null_spectrum: the pattern is empty or has different dimensions");
   float* valr = static_cast<float*>(ctx->workspace("ses.valr", sizeof(float) * pr->dev.val_floats()));
@@ -660,10 +979,24 @@ int session_null_spectrum_pattern(Session* s, PatternOwner* pr, double* Lr) {
 // data matrix: inline Float64 path with rec_vals (scLENS.jl:676-696); divisor size(X,2) = M
 int session_data_spectrum(Session* s, double* L, ScaleVecs* keep) {
   Ctx* ctx = s->ctx;
-  if (!s->Bmain) return ctx->fail(SCLENS_ERR_STATE, "data_spectrum: not available on a worker session");
+  if (!s->Bmain && !s->chunked()) return ctx->fail(SCLENS_ERR_STATE, "data_spectrum: not available on a worker session");
   if (s->centering && keep)
     return ctx->fail(SCLENS_ERR_ARG, "data_spectrum: centering=median has no rec_vals (scLENS.jl:697-698), pass NULL");
-  SCL_TRY(make_values(ctx, s->pat.dev, s->pat.base_val, 0, nullptr, 0, s->val));
+  if (s->chunked()) {
+    // the statistics must land in st_data whether or not the caller wants rec_vals: a host-side sink when it does not
+    static thread_local std::vector<double> sink_n, sink_m;
+    ScaleVecs local{};
+    if (!keep) {
+      sink_n.resize((size_t)2 * s->N);
+      sink_m.resize((size_t)3 * s->M);
+      local = ScaleVecs{sink_n.data(), sink_m.data(), sink_m.data() + s->M, sink_n.data() + s->N, sink_m.data() + 2 * s->M};
+      keep = &local;
+    }
+    s->cspec = MatSpec{};
+    s->cspec.f32path = 0;
+  } else {
+    SCL_TRY(make_values(ctx, s->pat.dev, s->pat.base_val, 0, nullptr, 0, s->val));
+  }
   SCL_TRY(decompose(s, s->pat.dev, s->val, 0, s->Bmain, (float)s->M, keep));
   if (L) std::copy(s->w_host.begin(), s->w_host.end(), L);
   s->have_spectrum = true;
@@ -727,10 +1060,33 @@ static int copy_rows_f32(Ctx* ctx, const float* src, int64_t rows, int64_t cols,
                                 hipMemcpyDeviceToDevice, ctx->stream));
   return SCLENS_OK;
 }
+// chunked session: B is not resident -- the blocks of the matrix `st` describes are rebuilt one at a time, each yields its cells' part
+static int to_cell_side_chunked(Session* s, const ChunkStatsDev& st, int64_t cnt, float* dst, bool desc_input, const float* src) {
+  Ctx* ctx = s->ctx;
+  StageTimer tm(ctx, "recover");
+  float* tmp = static_cast<float*>(ctx->workspace("ses.rec", sizeof(float) * (size_t)cnt * s->ldn));
+  float* tc = static_cast<float*>(ctx->workspace("ses.recc", sizeof(float) * (size_t)cnt * s->ldb));
+  if (!tmp || !tc) return SCLENS_ERR_OOM;
+  for (size_t g = 0; g < s->chunks.size(); ++g) {
+    const ChunkSrc& c = s->chunks[g];
+    SCL_TRY(chunk_block(s, st, (int)g));
+    GemmArgs a{};
+    a.P = src; a.Q = s->Btmp; a.C = tc;
+    a.M = cnt; a.N = c.N; a.K = s->M;
+    a.ldp = s->ldz; a.ldq = s->ldb; a.ldc = s->ldb;
+    a.alpha = 1.f; a.beta = 0.f; a.q_kcontig = 0; a.lower = 0; a.colabsmax = nullptr;
+    SCL_TRY(gemm_f32(ctx, a));
+    SCL_HIP(ctx, hipMemcpy2DAsync(tmp + c.row0, sizeof(float) * s->ldn, tc, sizeof(float) * s->ldb, sizeof(float) * c.N, cnt,
+                                  hipMemcpyDeviceToDevice, ctx->stream));
+  }
+  SCL_TRY(normalize_rows_f32(ctx, tmp, cnt, s->N, s->ldn));
+  return desc_input ? copy_rows_f32(ctx, tmp, cnt, s->N, s->ldn, dst, s->ldn) : reverse_rows_f32(ctx, tmp, cnt, s->N, s->ldn, dst, s->ldn);
+}
 static int to_cell_side(Session* s, const float* B, int64_t cnt, float* dst, bool desc_input = false,
                         const float* src = nullptr) {
   Ctx* ctx = s->ctx;
   if (!src) src = s->Zt;
+  if (s->chunked()) return to_cell_side_chunked(s, B == nullptr ? s->st_data : s->st_last, cnt, dst, desc_input, src);
   if (s->cells_major)
     return desc_input ? copy_rows_f32(ctx, src, cnt, s->N, s->ldz, dst, s->ldn)
                       : reverse_rows_f32(ctx, src, cnt, s->N, s->ldz, dst, s->ldn);
@@ -799,17 +1155,37 @@ __global__ __launch_bounds__(256) void k_rayleigh_part(const float* __restrict__
 
 int session_refine_eigenvalues(Session* s, int64_t idx_lo, int64_t idx_hi, double* rho) {
   Ctx* ctx = s->ctx;
-  if (!s->have_spectrum || !s->Bmain) return ctx->fail(SCLENS_ERR_STATE, "refine_eigenvalues: call data_spectrum first");
+  if (!s->have_spectrum || (!s->Bmain && !s->chunked())) return ctx->fail(SCLENS_ERR_STATE, "refine_eigenvalues: call data_spectrum first");
   if (idx_lo < 0 || idx_hi > s->n || idx_lo > idx_hi || !rho) return ctx->fail(SCLENS_ERR_ARG, "refine_eigenvalues: bad index range");
   const int64_t cnt = idx_hi - idx_lo;
   if (cnt == 0) return SCLENS_OK;
   StageTimer tm(ctx, "refine");
   SCL_TRY(s->ensure_zt(cnt));
   SCL_TRY(eig_vectors(ctx, s->A, s->n, s->lda, s->w64, idx_lo, idx_hi, s->Zt, s->ldz));
-  const int64_t nb = (s->K + 255) / 256;
-  SCL_WS(ctx, part, double, "ses.rq", nb * RQ_V);
+  if (s->chunked()) {  // ||B' z||^2 is a sum over the cells: block by block (each rebuilt once, all vector groups against it)
+    const int64_t nbc = (s->ldb + 255) / 256;
+    SCL_WS(ctx, partc, double, "ses.rq", nbc * RQ_V);
+    std::vector<double> hpc((size_t)nbc * RQ_V);
+    std::fill(rho, rho + cnt, 0.0);
+    for (size_t g = 0; g < s->chunks.size(); ++g) {
+      SCL_TRY(chunk_block(s, s->st_data, (int)g));
+      const int64_t Kc = s->chunks[g].N, nbg = (Kc + 255) / 256;
+      for (int64_t q0 = 0; q0 < cnt; q0 += RQ_V) {
+        const int c = (int)std::min<int64_t>(RQ_V, cnt - q0);
+        hipLaunchKernelGGL(k_rayleigh_part, dim3((unsigned)nbg), dim3(256), 0, ctx->stream, s->Btmp, s->n, Kc, s->ldb, s->Zt + q0 * s->ldz, s->ldz,
+                           c, partc);
+        SCL_HIP(ctx, hipGetLastError());
+        SCL_HIP(ctx, hipMemcpyAsync(hpc.data(), partc, sizeof(double) * nbg * RQ_V, hipMemcpyDeviceToHost, ctx->stream));
+        SCL_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        for (int q = 0; q < c; ++q)
+          for (int64_t b = 0; b < nbg; ++b) rho[q0 + q] += hpc[(size_t)b * RQ_V + q];
+      }
+    }
+  }
+  const int64_t nb = s->chunked() ? 0 : (s->K + 255) / 256;
+  SCL_WS(ctx, part, double, "ses.rq2", nb * RQ_V + 1);
   std::vector<double> hp((size_t)nb * RQ_V);
-  for (int64_t q0 = 0; q0 < cnt; q0 += RQ_V) {
+  for (int64_t q0 = 0; !s->chunked() && q0 < cnt; q0 += RQ_V) {
     const int c = (int)std::min<int64_t>(RQ_V, cnt - q0);
     hipLaunchKernelGGL(k_rayleigh_part, dim3((unsigned)nb), dim3(256), 0, ctx->stream, s->Bmain, s->n, s->K, s->ldb,
                        s->Zt + q0 * s->ldz, s->ldz, c, part);
@@ -887,7 +1263,12 @@ int session_signal_vectors(Session* s, int64_t k, float* nV) {
 
 int session_binary_basis(Session* s, double* L_bin, int64_t* r_out) {
   Ctx* ctx = s->ctx;
-  SCL_TRY(make_values(ctx, s->pat.dev, s->pat.base_val, 1, nullptr, 0, s->val));
+  if (s->chunked()) {
+    s->cspec = MatSpec{};
+    s->cspec.binary = 1;
+  } else {
+    SCL_TRY(make_values(ctx, s->pat.dev, s->pat.base_val, 1, nullptr, 0, s->val));
+  }
   // get_eigvec(scaled', ...) for N > M / get_eigvec(scaled) otherwise: n x n Gram, divisor = K (Appendix A8)
   SCL_TRY(decompose(s, s->pat.dev, s->val, 1, s->Btmp, (float)s->Kdiv, nullptr, -1, /*binary=*/true));
   if (L_bin) std::copy(s->w_host.begin(), s->w_host.end(), L_bin);
@@ -911,6 +1292,14 @@ static int search_core(Session* s, int64_t n_2, double* d5, int64_t* r_it, bool 
 int session_search_step(Session* s, const uint32_t* sample, int64_t m, int64_t n_2, double* d5, int64_t* r_it) {
   Ctx* ctx = s->ctx;
   if (!s->Vr2t) return ctx->fail(SCLENS_ERR_STATE, "search_step: call binary_basis first");
+  if (s->chunked()) {
+    if (!s->cands_counted) SCL_TRY(chunk_count_candidates(s));
+    if (m < 0 || m > s->ncand_total) return ctx->fail(SCLENS_ERR_ARG, "search_step: bad sample size");
+    SCL_TRY(s->upload_idx(sample, m));
+    s->cspec = MatSpec{};
+    s->cspec.cands = 1; s->cspec.binary = 1; s->cspec.sample = 1; s->cspec.m = m;
+    return search_core(s, n_2, d5, r_it);
+  }
   if (m < 0 || m > s->pat.dev.population()) return ctx->fail(SCLENS_ERR_ARG, "search_step: bad sample size");
   SCL_TRY(s->upload_idx(sample, m));
   SCL_TRY(make_values(ctx, s->pat.dev, s->pat.base_val, 1, s->idx_dev, m, s->val));
@@ -919,6 +1308,13 @@ int session_search_step(Session* s, const uint32_t* sample, int64_t m, int64_t n
 int session_search_step_seeded(Session* s, uint64_t seed, int64_t m, int64_t n_2, double* d5, int64_t* r_it) {
   Ctx* ctx = s->ctx;
   if (!s->Vr2t) return ctx->fail(SCLENS_ERR_STATE, "search_step: call binary_basis first");
+  if (s->chunked()) {
+    if (!s->cands_counted) SCL_TRY(chunk_count_candidates(s));
+    if (m < 0 || m > s->ncand_total) return ctx->fail(SCLENS_ERR_ARG, "search_step: bad sample size");
+    s->cspec = MatSpec{};
+    s->cspec.cands = 1; s->cspec.binary = 1; s->cspec.sample = 2; s->cspec.seed = seed; s->cspec.m = m;
+    return search_core(s, n_2, d5, r_it);
+  }
   SCL_TRY(make_values_seeded(ctx, s->pat.dev, s->pat.base_val, 1, seed, m, s->val));
   return search_core(s, n_2, d5, r_it);
 }
@@ -1045,6 +1441,14 @@ int session_perturb(Session* s, int64_t t, const uint32_t* sample, int64_t m, in
                     int64_t* ncols) {
   Ctx* ctx = s->ctx;
   if (t < 0 || min_pc <= 0) return ctx->fail(SCLENS_ERR_ARG, "perturb: bad slot / min_pc");
+  if (s->chunked()) {
+    if (!s->cands_counted) SCL_TRY(chunk_count_candidates(s));
+    if (m < 0 || m > s->ncand_total) return ctx->fail(SCLENS_ERR_ARG, "perturb: bad sample size");
+    SCL_TRY(s->upload_idx(sample, m));
+    s->cspec = MatSpec{};
+    s->cspec.cands = 1; s->cspec.sample = 1; s->cspec.m = m;
+    return perturb_core(s, t, min_pc, nL_top, ncols);
+  }
   if (m < 0 || m > s->pat.dev.population()) return ctx->fail(SCLENS_ERR_ARG, "perturb: bad sample size");
   SCL_TRY(s->upload_idx(sample, m));
   SCL_TRY(make_values(ctx, s->pat.dev, s->pat.base_val, 0, s->idx_dev, m, s->val));
@@ -1054,6 +1458,13 @@ int session_perturb_seeded(Session* s, int64_t t, uint64_t seed, int64_t m, int6
                            int64_t* ncols) {
   Ctx* ctx = s->ctx;
   if (t < 0 || min_pc <= 0) return ctx->fail(SCLENS_ERR_ARG, "perturb: bad slot / min_pc");
+  if (s->chunked()) {
+    if (!s->cands_counted) SCL_TRY(chunk_count_candidates(s));
+    if (m < 0 || m > s->ncand_total) return ctx->fail(SCLENS_ERR_ARG, "perturb: bad sample size");
+    s->cspec = MatSpec{};
+    s->cspec.cands = 1; s->cspec.sample = 2; s->cspec.seed = seed; s->cspec.m = m;
+    return perturb_core(s, t, min_pc, nL_top, ncols);
+  }
   SCL_TRY(make_values_seeded(ctx, s->pat.dev, s->pat.base_val, 0, seed, m, s->val));
   return perturb_core(s, t, min_pc, nL_top, ncols);
 }
@@ -1070,8 +1481,10 @@ static int perturb_core(Session* s, int64_t t, int64_t min_pc, double* nL_top, i
   // does not converge and the full solver has to run.
   const bool can_chefsi = s->use_chefsi && s->b0 >= min_pc + 8 && s->Z0t;
   const int64_t implicit_min_n = ctx->opt.implicit_min_n;
-  const bool implicit_op = can_chefsi && !s->sh.on() && s->n >= implicit_min_n;
-  if (s->sh.on()) {
+  const bool implicit_op = can_chefsi && !s->sh.on() && !s->chunked() && s->n >= implicit_min_n;
+  if (s->chunked()) {  // the member's Gram matrix summed over the chunks (the scaled matrix is never whole: no implicit operator)
+    SCL_TRY(chunked_gram(s, s->cspec, (float)s->M, nullptr, s->A, &s->st_last));
+  } else if (s->sh.on()) {
     SCL_TRY(scale_to_dense_sharded(ctx, s->pat.dev, s->val, 1, s->Btmp, s->ldb, nullptr, s->sh));
     SCL_TRY(gram_f32(ctx, s->Btmp, s->n, s->K, s->ldb, (float)s->M, s->A, s->lda));
     SCL_TRY(s->sh.sum(ctx, s->A, s->n * s->lda, 1));
@@ -1316,6 +1729,15 @@ int session_get_int(Session* s, const char* name, int64_t* value) {
     return SCLENS_OK;
   }
   if (k == "centering") { *value = s->centering; return SCLENS_OK; }
+  if (k == "n_cand") {  // length of the candidate list the samples index (chunked session: counted on first use, one pattern build per chunk)
+    if (s->chunked() && !s->cands_counted) SCL_TRY(chunk_count_candidates(s));
+    *value = s->chunked() ? s->ncand_total : s->pat.dev.population();
+    return SCLENS_OK;
+  }
+  if (k == "chunks") { *value = (int64_t)s->chunks.size(); return SCLENS_OK; }
+  if (k == "chunk_builds") { *value = s->chunk_builds; return SCLENS_OK; }
+  if (k == "chunk_visits") { *value = s->chunk_visits; return SCLENS_OK; }
+  if (k == "chunk_cached") { *value = (int64_t)s->pcache.size(); return SCLENS_OK; }
   if (k == "gram_bits_used") { *value = s->ctx->gram_bits_used; return SCLENS_OK; }
   return s->ctx->fail(SCLENS_ERR_ARG, "session_get_int: unknown option " + k);
 }
@@ -1457,6 +1879,29 @@ int session_gene_basis(Session* s, const double* nL, float* out) {
   float* sc = static_cast<float*>(ctx->workspace("ses.gbs", sizeof(float) * (size_t)k));
   if (!G || !sc) return SCLENS_ERR_OOM;
   const int64_t ldg = round_up(s->M, 32);
+  if (s->chunked()) {  // G = sum over the chunks of nV[cells of the chunk]' * block (the contraction runs over the cells)
+    float* nc = static_cast<float*>(ctx->workspace("ses.gbc", sizeof(float) * (size_t)k * s->ldb));
+    if (!nc) return SCLENS_ERR_OOM;
+    for (size_t g = 0; g < s->chunks.size(); ++g) {
+      const ChunkSrc& c = s->chunks[g];
+      SCL_TRY(chunk_block(s, s->st_data, (int)g));
+      SCL_HIP(ctx, hipMemcpy2DAsync(nc, sizeof(float) * s->ldb, s->nVt + c.row0, sizeof(float) * s->ldn, sizeof(float) * c.N, k,
+                                    hipMemcpyDeviceToDevice, ctx->stream));
+      GemmArgs a{};
+      a.P = nc; a.Q = s->Btmp; a.C = G;
+      a.M = k; a.N = s->M; a.K = c.N;
+      a.ldp = s->ldb; a.ldq = s->ldb; a.ldc = ldg;
+      a.alpha = 1.f; a.beta = g > 0 ? 1.f : 0.f; a.q_kcontig = 1; a.lower = 0; a.colabsmax = nullptr;
+      SCL_TRY(gemm_f32(ctx, a));
+    }
+    std::vector<float> hsc(k);
+    for (int64_t q = 0; q < k; ++q) hsc[q] = (float)(1.0 / std::sqrt(nL[q]) / std::sqrt((double)s->M));
+    SCL_HIP(ctx, hipMemcpyAsync(sc, hsc.data(), sizeof(float) * k, hipMemcpyHostToDevice, ctx->stream));
+    SCL_TRY(scale_rows_f32(ctx, G, k, s->M, ldg, sc));
+    SCL_HIP(ctx, hipMemcpy2DAsync(out, sizeof(float) * s->M, G, sizeof(float) * ldg, sizeof(float) * s->M, k, hipMemcpyDeviceToHost, ctx->stream));
+    SCL_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return SCLENS_OK;
+  }
   // k rows only: the product streams the whole scaled matrix once, so the contraction over the cells is split over the
   // grid (one tile row of M / 128 blocks would read 4 N bytes per gene each from a single CU: 3.7 s at 100 000 x 30 000)
   const int64_t tiles = (s->M + 127) / 128;

@@ -123,10 +123,11 @@ def synth_counts_rows(N_total: int, M: int, seed: int, row0: int, row1: int, C: 
             x[i, crng.choice(zero_cols, size=mg - int((x[i] > 0).sum()), replace=False)] = 1.0
         s0, s1 = max(a, row0) - a, min(b, row1) - a
         i, j = np.nonzero(x[s0:s1])
-        rows.append((i + a + s0 - row0).astype(np.int64))
-        cols.append(j.astype(np.int64))
+        rows.append((i + (a + s0 - row0)).astype(np.int32))  # (32-bit triplets: a 125 000 x 30 000 slab peaked at 23 GB with 64-bit ones)
+        cols.append(j.astype(np.int32))
         vals.append(x[s0:s1][i, j])
-    X = sp.csc_matrix((np.concatenate(vals), (np.concatenate(rows), np.concatenate(cols))), shape=(row1 - row0, M),
-                      dtype=np.float32)
+    rows, cols, vals = np.concatenate(rows), np.concatenate(cols), np.concatenate(vals)
+    X = sp.csc_matrix((vals, (rows, cols)), shape=(row1 - row0, M), dtype=np.float32)
+    del rows, cols, vals
     X.sort_indices()
     return X

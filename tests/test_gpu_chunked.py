@@ -1,0 +1,164 @@
+"""-m gpu: the chunked session (sclens_hip_session_create_chunked + sclens_amd.atlas.sclens_chunked; BASELINE configs[4] on ONE GPU):
+all cells on the device as CSC chunks of rows, every decomposition a sum of the chunks' Gram contributions (scLENS.jl:332-361 over
+cell blocks). Against (1) the plain session on the same matrix and draws at small sizes -- the global candidate list of a chunked
+session is the concatenation of the chunks' parts of the one global draw, so the plain path is replayed on exactly that list --, and
+(2) at the atlas size itself, the float64 fixture tests/golden/cfg5_f64_spectra.npz (scripts/f64_spectra_atlas.py: data and null
+spectra, lambda_c and the signal count of the 1 000 000 x 30 000 matrix by LAPACK on float64 Gram matrices accumulated over the slabs)."""
+import os
+import time
+
+import numpy as np
+import pytest
+
+from sclens_amd import api, atlas
+from sclens_amd.synth import synth_counts
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "cfg5_f64_spectra.npz")
+
+
+def _cos(U, V):
+    return np.abs(np.sum(U.astype(np.float64) * V.astype(np.float64), axis=0))
+
+
+def _chunks(X, n):
+    Xr = X.tocsr()
+    N = X.shape[0]
+    return [(a, Xr[a:b].tocsc()) for a, b in (atlas.row_block(g, n, N) for g in range(n))]
+
+
+def _replay_draws(ctx, X, d, n):
+    """the candidate list of a chunked session with n chunks: the unsharded first-occurrence list (same seed), chunk by chunk"""
+    full1, full2 = api.Pattern.drawn(ctx, X, d.cand_seed).candidates()
+    z1, z2 = [], []
+    for g in range(n):
+        a, b = atlas.row_block(g, n, X.shape[0])
+        sel = (full1 >= a) & (full1 < b)
+        z1.append(full1[sel])
+        z2.append(full2[sel])
+    return api.Draws(np.concatenate(z1), np.concatenate(z2), d.X_r, d.p_th, None, d.sample_seed)
+
+
+def _compare(res, ref):
+    assert np.abs(res["L"] - ref["L"]).max() < 2e-5 * ref["L"].max()
+    assert abs(res["lambda_c"] - ref["lambda_c"]) < 2e-5 * ref["lambda_c"]
+    k = len(ref["signal_ev"])
+    assert len(res["signal_ev"]) == k > 0
+    assert np.allclose(res["signal_ev"], ref["signal_ev"], rtol=5e-5)
+    assert res["n_search"] == ref["n_search"] and res["p_"] == ref["p_"]
+    for (p1, d1), (p2, d2) in zip(res["search_trace"], ref["search_trace"]):
+        assert p1 == p2 and np.abs(d1 - d2).max() < 2e-3
+    assert np.all(_cos(res["signal_evec"], ref["signal_evec"]) > 1 - 1e-3)
+    assert np.array_equal(res["robustness_scores"]["a_b"], ref["robustness_scores"]["a_b"])
+    assert np.abs(res["robustness_scores"]["rob_score"] - ref["robustness_scores"]["rob_score"]).max() < 3e-3
+    assert np.array_equal(res["sig_id"], ref["sig_id"])
+    s = np.sign(np.sum(res["signal_evec"] * ref["signal_evec"], axis=0))
+    assert np.abs(res["gene_basis"] * s[:, None] - ref["gene_basis"]).max() < 5e-3 * np.abs(ref["gene_basis"]).max()
+    for key in ("TGC", "mat2_mean", "mat2_std", "norm_tgc", "cent_"):
+        assert np.allclose(np.ravel(res["rec_vals"][key]), np.ravel(ref["rec_vals"][key]), rtol=1e-9, atol=1e-12), key
+
+
+@pytest.mark.parametrize("n_chunks", [1, 2, 3])
+def test_chunked_session_matches_plain_session(ctx, n_chunks):
+    N, M = 600, 250
+    X = api._csc_f32(synth_counts(N, M, seed=1, C=5, marker_frac=0.2, marker_sd=1.5))
+    d = api.make_draws_native(X, seed=23, device_candidates=True)
+    Xn = api._csc_f32(api._resolve(d.X_r))
+    res = atlas.sclens_chunked(_chunks(X, n_chunks), _chunks(Xn, n_chunks), d, n_perturb=5, ctx=ctx)
+    ref = api.sclens(X, draws=_replay_draws(ctx, X, d, n_chunks), n_perturb=5, ctx=ctx, streams=1)
+    _compare(res, ref)
+    assert res["n_cand"] == len(_replay_draws(ctx, X, d, n_chunks).z_idx1)
+    assert res["chunks"] == n_chunks and res["chunk_visits"] >= 3 * n_chunks * (3 + res["n_search"] + 5)
+
+
+@pytest.mark.parametrize("cache_gb", [64, 0])
+def test_chunked_session_two_stage_size_with_and_without_pattern_cache(ctx, opt, cache_gb):
+    """9 000 x 6 000 (the order at which the two-stage solver and the split products are on), 4 unequal chunks; chunk_cache_gb = 0:
+    every visit rebuilds its pattern (the state of a device too full to keep any), same results"""
+    N, M = 9000, 6000
+    X = api._csc_f32(synth_counts(N, M, seed=31, C=6, marker_frac=0.1, marker_sd=1.3))
+    d = api.make_draws_native(X, seed=77, device_candidates=True)
+    Xn = api._csc_f32(api._resolve(d.X_r))
+    cuts = [0, 1000, 4200, 4300, N]
+    Xr, Xnr = X.tocsr(), Xn.tocsr()
+    data = [(a, Xr[a:b].tocsc()) for a, b in zip(cuts[:-1], cuts[1:])]
+    null = [(a, Xnr[a:b].tocsc()) for a, b in zip(cuts[:-1], cuts[1:])]
+    opt(chunk_cache_gb=cache_gb, two_stage_min_n=4096, gram_split_min_n=4096, gram_bits_min_n=4096)
+    res = atlas.sclens_chunked(data, null, d, n_perturb=3, max_search_iters=4, ctx=ctx)
+    # the plain path on the list in chunk order
+    full1, full2 = api.Pattern.drawn(ctx, X, d.cand_seed).candidates()
+    sel = [np.flatnonzero((full1 >= a) & (full1 < b)) for a, b in zip(cuts[:-1], cuts[1:])]
+    order = np.concatenate(sel)
+    d2 = api.Draws(full1[order], full2[order], d.X_r, d.p_th, None, d.sample_seed)
+    ref = api.sclens(X, draws=d2, n_perturb=3, max_search_iters=4, ctx=ctx, streams=1)
+    _compare(res, ref)
+    if cache_gb == 0:
+        assert res["chunk_builds"] == res["chunk_visits"]
+    else:
+        assert res["chunk_builds"] < res["chunk_visits"] / 2
+
+
+def test_chunked_session_argument_errors(ctx):
+    N, M = 600, 250
+    X = api._csc_f32(synth_counts(N, M, seed=1, C=5, marker_frac=0.2, marker_sd=1.5))
+    with pytest.raises(api.SclensHipError):  # cells <= genes does not chunk by cells
+        api.Session.create_chunked(ctx, 200, 250, 2, 10, 1)
+    ses = api.Session.create_chunked(ctx, N, M, 2, X.nnz, 5)
+    try:
+        ch = _chunks(X, 2)
+        ses.chunk_add(0, 0, ch[0][0], ch[0][1])
+        with pytest.raises(api.SclensHipError):  # added twice
+            ses.chunk_add(0, 0, ch[0][0], ch[0][1])
+        with pytest.raises(api.SclensHipError):  # a chunk is missing
+            ses.chunk_commit()
+        with pytest.raises(api.SclensHipError):  # no decomposition before the commit
+            ses.data_spectrum()
+        ses.chunk_add(0, 1, ch[1][0], ch[1][1])
+        ses.chunk_commit()
+        with pytest.raises(api.SclensHipError):  # X_r has to be cut like the count matrix
+            ses.chunk_add(1, 0, 7, ch[1][1])
+        with pytest.raises(api.SclensHipError):  # no X_r yet
+            ses.null_spectrum_chunked()
+        L, _ = ses.data_spectrum()
+        assert np.all(np.diff(L) >= 0) and L[-1] > 0
+    finally:
+        ses.close()
+
+
+@pytest.mark.skipif(not os.path.exists(GOLD), reason="tests/golden/cfg5_f64_spectra.npz not generated (scripts/f64_spectra_atlas.py)")
+@pytest.mark.parametrize("precision", [1, 0])
+def test_atlas_spectra_of_one_million_cells_against_float64(ctx, opt, precision):
+    """BASELINE configs[4], 1 000 000 x 30 000, on one MI355X: the data and null spectra (all 30 000 eigenvalues each), lambda_c and the
+    retained-signal count of the chunked session against float64 (the fixture), for both arithmetic variants. The Gram matrix is a
+    contraction over K = 10^6 cells accumulated in fp32 chunk by chunk -- where fp32 / split-fp16 accumulation is most exposed:
+    the tolerance is the one of the cfg4 test, 4 sqrt(n) eps32 lambda_max (measured values in the assertion messages and in
+    profiles/r06_cfg5_*). ~6 minutes of host time to generate the 2 x 3.1e9-entry matrices (cached per box), ~1 minute of GPU."""
+    g = np.load(GOLD)
+    N, M = int(g["N"]), int(g["M"])
+    t0 = time.perf_counter()
+    S = atlas.synth_slabs(N, M, int(g["synth_seed"]), 8)
+    assert S.nnz_total == int(g["nnz"])
+    R = atlas.null_slabs(S, int(g["draw_seed"]))
+    t_gen = time.perf_counter() - t0
+    opt(precision=precision)
+    ctx.trim_pool()
+    d = api.Draws(None, None, None, 0.0, None, int(g["draw_seed"]))
+    d.cand_seed = int(g["draw_seed"])
+    res = atlas.sclens_chunked(S, R, d, ctx=ctx, stop_after="spectra")
+    L, Lr = res["L"], res["Lr"]
+    tol = 4.0 * np.sqrt(M) * 5.96e-8 * g["L"][-1]
+    eL, eLr = np.abs(L - g["L"]).max(), np.abs(Lr - g["Lr"]).max()
+    print(f"[cfg5 precision={precision}] max |L - L64| = {eL:.3e}, max |Lr - Lr64| = {eLr:.3e} (tolerance {tol:.3e}, lambda_max {g['L'][-1]:.6f}); "
+          f"lambda_c {res['lambda_c']:.9f} vs {float(g['lambda_c']):.9f}; k {res['k']} vs {int(g['k'])}; generation {t_gen:.0f} s; phases {res['phase_s']}")
+    assert eL < tol and eLr < tol, (eL, eLr, tol)
+    assert abs(res["lambda_c"] - float(g["lambda_c"])) < 2e-5 * float(g["lambda_c"])
+    assert res["k"] == int(g["k"])
+    keep = os.environ.get("SCLENS_ATLAS_LOG")
+    if keep:
+        import json
+
+        with open(f"{keep}.spectra_p{precision}.json", "w") as f:
+            json.dump({"precision": precision, "max_abs_err_L": float(eL), "max_abs_err_Lr": float(eLr), "tolerance": float(tol),
+                       "lambda_c": float(res["lambda_c"]), "lambda_c_f64": float(g["lambda_c"]), "k": int(res["k"]), "k_f64": int(g["k"]),
+                       "phase_s": res["phase_s"], "chunk_builds": res["chunk_builds"], "chunk_visits": res["chunk_visits"],
+                       "generation_s": round(t_gen, 1), "guard_band": {k: (v if not hasattr(v, "tolist") else v.tolist()) for k, v in res["guard_band"].items()} if isinstance(res["guard_band"], dict) else str(res["guard_band"])}, f, indent=1)
