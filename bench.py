@@ -183,13 +183,14 @@ def stage_probe(ctx, X, N, M):
     else:
         add("gram", "gram", float(n) * (n + 1) * K, "TFLOP/s", MFMA_F32_PEAK_TFS, "mfma", "n (n+1) K flop (computed lower half)")
     if bits_ms:
-        work = 2.0 * float(n) * (n + 1) * K  # two fp16 pieces of the cell weights: two MFMA products per gene pair and cell
+        nw = 3 if (not split_products or ctx.get_option("gram_bits_terms") == 3) else 2  # fp16 pieces of the cell weights (22 / 33 bits)
+        work = float(nw) * float(n) * (n + 1) * K  # one MFMA product per piece, gene pair and cell
         ach = work / (bits_ms * 1e-3) / 1e12
         stages["gram_binary_f16"] = {"bound": "mfma", "ms": round(bits_ms, 3), "achieved": round(ach, 1), "peak": MFMA_F16_PEAK_TFS,
                                      "unit": "TFLOP/s", "frac": round(ach / MFMA_F16_PEAK_TFS, 4),
-                                     "work": "2 n (n+1) K flop issued on the fp16 MFMA (exact products, fp32 accumulation) for the "
-                                             "n (n+1) K flop of the fp32 product it replaces in the sparsity search",
-                                     "fp32_equivalent_TFLOPs": round(ach / 2.0, 1)}
+                                     "work": f"{nw} n (n+1) K flop issued on the fp16 MFMA (exact 0/1 pattern x {11 * nw}-bit cell weights, fp32 "
+                                             "accumulation) for the n (n+1) K flop of the fp32 product it replaces in the sparsity search",
+                                     "fp32_equivalent_TFLOPs": round(ach / nw, 1)}
     add("sytrd_one_stage", "sytrd", sum(2.0 * q * (q + 1) for q in range(1, n)), "GB/s", HBM_PEAK_GBS, "hbm",
         "lower triangle of the trailing matrix once per column, whole reduction")
     add("sy2sb_dense_to_band", "sy2sb", 4.0 / 3.0 * float(n) ** 3, "TFLOP/s", MFMA_F32_PEAK_TFS, "mfma",
@@ -216,15 +217,16 @@ def stage_probe(ctx, X, N, M):
     return stages
 
 
-# HBM traffic of ONE two-stage eigensolve of order 30 016 with 15 008 vectors (the roofline's launch) on the round-5 build, from
-# separate `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` passes over scripts/perf_eig.py (counters collected for the kernels that
-# move the bytes, --kernel-include-regex; profiles/r05_pmc_eig/summary.txt): 838 GB fetched as counted + 620 GB for the gfx950
-# half-count of 16-byte-per-lane streaming reads (MI355X_MICROARCH.md, HBM) on the operand streams of the 256 x 256 kernels, the A22
-# tiles of `sbr_w_split` and the Q2 images + 738 GB written = 2.20e12 B, 1.02 x the algorithmic bytes of the stages. A constant
-# measured on this build at this size, not in this run (a PMC pass serialises every profiled dispatch); the line carries it only for
-# the workload it was measured on.
-PMC_EIG_TRAFFIC = {"bytes": 2.196e12, "n": 30016, "vectors": 15008, "algorithmic_bytes": 2.15e12,
-                       "source": "profiles/r05_pmc_eig/summary.txt"}
+# HBM traffic of ONE two-stage eigensolve of order 30 016 with 15 008 vectors (the roofline's launch), from separate `rocprofv3 --pmc
+# FETCH_SIZE` / `--pmc WRITE_SIZE` passes over scripts/perf_eig.py (counters collected for the kernels that move the bytes,
+# --kernel-include-regex), FETCH_SIZE doubled on the 16-byte-per-lane operand streams of the 256 x 256 kernels as MI355X_MICROARCH.md (HBM)
+# prescribes for gfx950. precision = 0 (round-6 build, profiles/r06_pmc_eig_fp32/summary.txt): 1006 GB fetched as counted + 504 GB for the
+# half-count + 868 GB written = 2.38e12 B = 1.17 x the algorithmic bytes (the fp32 Q2 kernel takes the vectors down the matrix in passes
+# of four blocks). precision = 1 (round-5 build, profiles/r05_pmc_eig/summary.txt): 2.20e12 B = 1.02 x. Constants measured on the build at
+# this size, not in this run (a PMC pass serialises every profiled dispatch); the line carries them only for the workload they were
+# measured on.
+PMC_EIG_TRAFFIC = {1: {"bytes": 2.196e12, "n": 30016, "vectors": 15008, "algorithmic_bytes": 2.15e12, "source": "profiles/r05_pmc_eig/summary.txt"},
+                   0: {"bytes": 2.378e12, "n": 30016, "vectors": 15008, "algorithmic_bytes": 2.04e12, "source": "profiles/r06_pmc_eig_fp32/summary.txt"}}
 
 
 # A full-size CPU data point kept in the repository (profiles/r02_signal_count_cfg4.json, GPU box, 16 usable CPUs): LAPACK dsyevd,
@@ -693,7 +695,8 @@ def main():
                 solve_ms = sum(stages[k]["ms"] for k in parts if k in stages)
                 flop = 4.0 / 3.0 * float(n) ** 3 + 2.0 * float(n) ** 2 * (n // 2)
                 ach = flop / (solve_ms * 1e-3) / 1e12
-                pmc = PMC_EIG_TRAFFIC if abs(n - PMC_EIG_TRAFFIC["n"]) <= 64 else None
+                pmc = PMC_EIG_TRAFFIC[1 if precision != 0 else 0]
+                pmc = pmc if abs(n - pmc["n"]) <= 64 else None
                 out["roofline"] = {"bound": "mfma", "kernel": "two-stage symmetric eigensolver of one search step (sy2sb + sb2st + stebz + "
                                                              "stein + Q2 + Q1, n/2 eigenvectors): the stage with the most wall time",
                                    "achieved": round(ach, 2), "peak": MFMA_F32_PEAK_TFS, "unit": "TFLOP/s",
@@ -706,9 +709,11 @@ def main():
                                                       if pmc else None),
                                    "n": n, "vectors": n // 2, "launch_ms": round(solve_ms, 2), "algorithmic_flop_per_launch": flop,
                                    "stage_ms": {k: stages[k]["ms"] for k in parts if k in stages},
-                                   "note": "time-weighted fp32-EQUIVALENT rate of the whole stage against the fp32 MFMA peak (with precision = 1 "
-                                           "its large products issue 3x their fp32-equivalent flop on the fp16 MFMA: see dtype_note and the "
-                                           "per-stage fractions against the fp16 peak in the detail file)"}
+                                   "note": ("time-weighted rate of the whole stage -- six kernel families, two of them latency chains -- against the fp32 "
+                                            "MFMA peak its products run on" if precision == 0 else
+                                            "time-weighted fp32-EQUIVALENT rate of the whole stage against the fp32 MFMA peak (with precision = 1 "
+                                            "its large products issue 3x their fp32-equivalent flop on the fp16 MFMA: see dtype_note and the "
+                                            "per-stage fractions against the fp16 peak in the detail file)")}
             else:
                 out["roofline"] = symv_probe(ctx, n)
             out["roofline"]["stages"] = stages

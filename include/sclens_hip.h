@@ -94,9 +94,11 @@ int sclens_hip_pool_set_cap(int device_id, int64_t bytes);
 int64_t sclens_hip_pool_peak(int device_id, int reset);
 /* A context keeps its scratch (grow-only named workspaces) until it is destroyed; between the phases of one sclens() call most of it is
  * idle -- the eigensolver's 30-40 GB per context during the ensemble, the Gram images after the first decompositions. This hands one
- * family of a context's scratch back to the pool ("eigensolver", "gram", "chefsi", "corr" or "all"), where the next phase's requests of
- * the same sizes find it; the next call that needs it allocates it again. Not while a session of the context is between
- * session_spectrum / eig values and the vectors that continue from them. */
+ * family of a context's scratch back to the pool ("eigensolver", "gram", "chefsi", "corr" -- the search statistic's images -- or "all" of
+ * these), where the next phase's requests of the same sizes find it; the next call that needs it allocates it again. Not while a
+ * session of the context is between session_spectrum / eig values and the vectors that continue from them. "everything": every named
+ * workspace of the context (vector blocks and ensemble slots included) -- only when no session of the context is alive (SCLENS_ERR_STATE
+ * otherwise): what a host does before sclens_hip_trim when its context outlives the call. */
 int sclens_hip_release_scratch(sclens_hip_ctx* ctx, const char* family);
 int sclens_hip_pool_stats(int device_id, int64_t* cached_bytes, int64_t* live_bytes, int64_t* hits, int64_t* misses);
 /* raw stream handle (hipStream_t) so a host framework can order its own work after ours */

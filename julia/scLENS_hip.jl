@@ -17,6 +17,12 @@ struct HipError <: Exception
 end
 check(ctx, rc) = rc == 0 ? nothing : throw(HipError(rc, unsafe_string(ccall((:sclens_hip_last_error, LIB), Cstring, (Ptr{Cvoid},), ctx))))
 
+getint_s(s, name) = begin
+    v = Ref{Int64}(0)
+    ccall((:sclens_hip_session_get_int, LIB), Cint, (Ptr{Cvoid}, Cstring, Ref{Int64}), s, name, v)
+    v[]
+end
+
 function with_ctx(f, device::Integer=0)
     h = Ref{Ptr{Cvoid}}(C_NULL)
     rc = ccall((:sclens_hip_create, LIB), Cint, (Ref{Ptr{Cvoid}}, Cint), h, device)
@@ -148,7 +154,7 @@ function sclens_hip_device(inp_df; th=60, p_step=0.001, n_perturb=20, centering=
     z1 = UInt32[s[1] - 1 for s in nzz_]; z2 = UInt32[s[2] - 1 for s in nzz_]
     X_r = scLENS.df2sparr(scLENS.random_nz(inp_df, rmix=true))                # R2 (:701)
     cp, rv, nz = csc0(X_); rcp, rrv, rnz = csc0(X_r)
-    with_ctx(device) do ctx
+    result = with_ctx(device) do ctx
         check(ctx, ccall((:sclens_hip_set_option, LIB), Cint, (Ptr{Cvoid}, Cstring, Int64), ctx, "precision", precision))
         ses = Ref{Ptr{Cvoid}}(C_NULL)
         GC.@preserve cp rv nz z1 z2 check(ctx, ccall((:sclens_hip_session_create, LIB), Cint,
@@ -217,7 +223,7 @@ function sclens_hip_device(inp_df; th=60, p_step=0.001, n_perturb=20, centering=
             # not converged at all ("chefsi_tail_free"); the library then reports per member whether the matching provably does not
             # depend on them ("match_uncertain:<t>", include/sclens_hip.h), and the members without that proof -- or whose matching
             # picked a tail column -- are solved again with the tail converged
-            tail_free = nm >= 16000
+            tail_free = nm >= 16000 && getint_s(s, "chefsi") != 0      # (only where the partial eigensolver is on at all)
             setint(name, v) = check(ctx, ccall((:sclens_hip_session_set_int, LIB), Cint, (Ptr{Cvoid}, Cstring, Int64), s, name, v))
             getint(name) = begin
                 v = Ref{Int64}(0)
@@ -232,7 +238,9 @@ function sclens_hip_device(inp_df; th=60, p_step=0.001, n_perturb=20, centering=
             a_b = Matrix{Int32}(undef, k, n_perturb); bt = Matrix{Float64}(undef, npairs, k)   # row-major k x npairs
             score() = GC.@preserve a_b bt check(ctx, ccall((:sclens_hip_session_robustness, LIB), Cint, (Ptr{Cvoid}, Int64, Ptr{Int32}, Ptr{Float64}), s, n_perturb, a_b, bt))
             score()
-            again = [t for t in 1:n_perturb if any(a_b[:, t] .>= k) || (tail_free && getint("match_uncertain:$(t - 1)") != 0)]
+            # only members the PARTIAL eigensolver produced can gain from a second solve (the full solver would return the same vectors)
+            again = getint("chefsi_used") > 0 ?
+                    [t for t in 1:n_perturb if any(a_b[:, t] .>= k) || (tail_free && getint("match_uncertain:$(t - 1)") != 0)] : Int[]
             if !isempty(again)
                 setint("chefsi_tail_free", 0); setint("chefsi_tail_gap_milli", 50)
                 for t in again
@@ -257,9 +265,12 @@ function sclens_hip_device(inp_df; th=60, p_step=0.001, n_perturb=20, centering=
                 :gene_basis => permutedims(gt), :pass => mpC_[:pass], :rec_vals => rec)   # keys of :826-829
         finally
             ccall((:sclens_hip_session_destroy, LIB), Cvoid, (Ptr{Cvoid},), s)
-            keep_warm || ccall((:sclens_hip_trim, LIB), Cint, (Cint,), device)
         end
     end
+    # AFTER with_ctx has destroyed the context: only then are its named workspaces (24 GB of partial-eigensolver images, the vector
+    # blocks, the re-grown eigensolver scratch) back in the pool's idle cache, and the trim hands everything to the driver
+    keep_warm || ccall((:sclens_hip_trim, LIB), Cint, (Cint,), device)
+    return result
 end
 
 end # module

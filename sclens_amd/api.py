@@ -1500,4 +1500,10 @@ def sclens(inp_df, device_="gpu", th=60, p_step=0.001, n_perturb=20, centering="
         aux_ctx.close()
         aux_ctx2.close()
         if not keep_warm:
+            # the caller's context outlives the call: its grow-only workspaces (vector blocks, partial-eigensolver images, re-grown
+            # eigensolver scratch) go back to the pool first, THEN the pool's idle blocks go back to the driver
+            try:
+                ctx.release_scratch("everything")
+            except Exception:
+                pass
             ctx.trim_pool()

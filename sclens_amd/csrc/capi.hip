@@ -652,9 +652,16 @@ int sclens_hip_release_scratch(sclens_hip_ctx* h, const char* family) {
   if (f == "eigensolver" || f == "all") for (const char* q : {"sbr.", "stein.", "tri.", "trd.", "orm.", "eig."}) pre.push_back(q);
   if (f == "gram" || f == "all") for (const char* q : {"gram.", "gb."}) pre.push_back(q);
   if (f == "chefsi" || f == "all") pre.push_back("che.");
-  if (f == "corr" || f == "all") pre.push_back("c.");
-  if (pre.empty()) return h->c.fail(SCLENS_ERR_ARG, "release_scratch: family must be eigensolver, gram, chefsi, corr or all");
+  if (f == "corr" || f == "all") for (const char* q : {"c.", "ses.Vr2h", "ses.Zh", "ses.cmax"}) pre.push_back(q);  // the search statistic's images
   scl::Ctx& c = h->c;
+  if (f == "everything") {  // every named workspace of the context: only between calls (no live session holds pointers into them)
+    if (c.live_sessions > 0) return c.fail(SCLENS_ERR_STATE, "release_scratch(everything): a session of this context is still alive");
+    c.release_all();
+    c.ws_epoch += 1;
+    c.q2_tg_n = -1; c.q2_built_variant = -1; c.q1p_n = -1; c.last_two_stage = false;
+    return SCLENS_OK;
+  }
+  if (pre.empty()) return c.fail(SCLENS_ERR_ARG, "release_scratch: family must be eigensolver, gram, chefsi, corr, all or everything");
   if (c.opt.debug >= 2) {  // what this context's named workspaces hold at the moment a family goes back (footprint table of INTEGRATION.md 6)
     std::vector<std::pair<size_t, std::string>> tab;
     size_t tot = 0;

@@ -143,6 +143,7 @@ struct Ctx {
   std::string err;
   // grow-only named device workspaces (freed at destroy); avoids hipMalloc inside hot loops
   std::map<std::string, std::pair<void*, size_t>> ws;
+  long ws_epoch = 0;  // bumped whenever a workspace is released: holders of derived data (a session's split image of Vr2) re-derive
   // per-stage timing (ms) accumulated when timing is enabled
   bool timing = false;
   std::map<std::string, double> t_ms;

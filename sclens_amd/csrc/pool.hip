@@ -29,14 +29,15 @@ bool pool_enabled() {
 }
 // Cached (idle) bytes per device above which freed blocks go straight back to the driver. Default: what was FREE on the device when the
 // pool first looked (other processes and other allocators of this process keep what they hold), less an eighth of the device (at least
-// 24 GB) for everybody else -- 252 GB on an otherwise empty MI355X. sclens_hip_pool_set_cap() overrides it (hosts that put several
+// 24 GB) for everybody else -- 252 GB on an otherwise empty MI355X (what the library itself holds at that moment counts as available). sclens_hip_pool_set_cap() overrides it (hosts that put several
 // ranks on one device give each its share; SCLENS_HIP_POOL_MAX_GB is the same knob for unmodified hosts, read once). Round 4 started
 // with HALF of the device: a 100 000 x 30 000 call held ~218 GB then, so every call ended over that cap and the NEXT call began with
 // 1.2 s of hipMalloc (profiles/r04_pool_cap.log). The cache is only an optimisation for back-to-back calls: api.sclens() and the
 // Julia shim trim it when a call returns unless the host asks to keep it warm, comm_create trims it before RCCL allocates,
 // sclens_hip_trim() is the public hook, and a failed pool_malloc trims and retries.
 std::map<int, size_t> g_caps;  // under g_mu
-size_t pool_cap_bytes(int dev) {
+// pending: bytes of a block that is being freed right now (already off `live`, still allocated as far as hipMemGetInfo can see)
+size_t pool_cap_bytes(int dev, size_t pending = 0) {
   auto it = g_caps.find(dev);
   if (it != g_caps.end()) return it->second;
   size_t cap = (size_t)64 << 30;
@@ -50,7 +51,9 @@ size_t pool_cap_bytes(int dev) {
     if (cur != dev) hipSetDevice(dev);
     if (hipMemGetInfo(&fr, &tot) == hipSuccess && tot > 0) {
       const size_t reserve = std::max<size_t>(tot / 8, std::min<size_t>((size_t)24 << 30, tot / 2));
-      const size_t avail = std::min(fr + g_pool[dev].cached, tot);  // what this process could use: free now + what the pool already holds idle
+      // what this process could use: free now + what the library itself holds -- idle in the cache, handed out (live), and the block in
+      // hand. (Without the last two a first free under tens of GB of live blocks fixed the cap too low for the rest of the process.)
+      const size_t avail = std::min(fr + g_pool[dev].cached + g_pool[dev].live + pending, tot);
       cap = avail > reserve ? avail - reserve : 0;
     }
     if (cur != dev) hipSetDevice(cur);
@@ -131,7 +134,7 @@ void pool_free(void* p, hipStream_t stream) {
   g_live.erase(it);
   DevPool& dp = g_pool[dev];
   dp.live -= sz;
-  if (dp.cached + sz > pool_cap_bytes(dev)) {
+  if (dp.cached + sz > pool_cap_bytes(dev, sz)) {
     lk.unlock();
     hipFree(p);
     return;
@@ -154,8 +157,24 @@ void pool_trim(int device) {
 
 void pool_set_cap(int device, long long bytes) {  // bytes < 0: back to the default rule (evaluated again at the next free)
   std::lock_guard<std::mutex> lk(g_mu);
-  if (bytes < 0) g_caps.erase(device);
-  else g_caps[device] = (size_t)bytes;
+  if (bytes < 0) {
+    g_caps.erase(device);
+    return;
+  }
+  g_caps[device] = (size_t)bytes;
+  DevPool& dp = g_pool[device];
+  if (dp.cached > (size_t)bytes) {  // a lower cap takes effect at once: idle blocks above it go back to the driver, largest first
+    int cur = 0;
+    hipGetDevice(&cur);
+    if (cur != device) hipSetDevice(device);
+    while (dp.cached > (size_t)bytes && !dp.free_blocks.empty()) {
+      auto last = std::prev(dp.free_blocks.end());
+      hipFree(last->second);
+      dp.cached -= last->first;
+      dp.free_blocks.erase(last);
+    }
+    if (cur != device) hipSetDevice(cur);
+  }
 }
 
 size_t pool_peak(int device, bool reset) {  // largest number of bytes the library held at once on the device since the last reset

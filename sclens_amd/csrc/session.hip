@@ -38,6 +38,7 @@ void Ctx::release(const std::string& name) {
     ctx_quiesce(this);
     pool_free(it->second.first, nullptr);
     ws.erase(it);
+    ws_epoch += 1;
   }
 }
 void Ctx::release_all() {
@@ -229,6 +230,7 @@ struct Session {
   // split fp16 image of Vr2t for the search statistic on the fp16 MFMA (gram_bits.hip); valid while Vr2h_of == Vr2t
   void* Vr2h = nullptr;
   const float* Vr2h_of = nullptr;
+  long Vr2h_epoch = -1;  // ctx->ws_epoch when the image was built (a release_scratch in between may have taken the block)
   int64_t ldb = 0;
   float* A = nullptr;         // [n][lda] Gram / reflectors
   int64_t lda = 0;
@@ -1354,11 +1356,12 @@ static int search_core(Session* s, int64_t n_2, double* d5, int64_t* r_it, bool 
     StageTimer tm(ctx, "corr");
     SCL_HIP(ctx, hipMemsetAsync(cmax, 0, sizeof(unsigned) * (size_t)cnt, ctx->stream));
     if (use_f16_corr(s)) {  // |Vr2' * nV_2| column maxima (scLENS.jl:742) on the fp16 MFMA from split operands
-      if (s->Vr2h_of != s->Vr2t) {  // once per binary basis
+      if (s->Vr2h_of != s->Vr2t || s->Vr2h_epoch != ctx->ws_epoch) {  // once per binary basis (and again after a scratch release)
         s->Vr2h = ctx->workspace("ses.Vr2h", split_image_bytes(s->r_vr2, s->n));
         if (!s->Vr2h) return SCLENS_ERR_OOM;
         SCL_TRY(split_image_f16(ctx, s->Vr2t, s->r_vr2, s->n, s->ldz, s->Vr2h));
         s->Vr2h_of = s->Vr2t;
+        s->Vr2h_epoch = ctx->ws_epoch;
       }
       void* zimg = ctx->workspace("ses.Zh", split_image_bytes(cnt, s->n));
       if (!zimg) return SCLENS_ERR_OOM;
@@ -1799,7 +1802,8 @@ int session_robustness(Session* s, int64_t P, int32_t* a_b, double* b) {
   // Matching certificate. Signal vector i has unit length and the eigenvectors of a member are orthonormal, so every unit vector
   // orthogonal to the member's first k eigenvectors correlates with it by at most sqrt(1 - S_i), S_i = sum_{j<k} c_ij^2. If the best
   // of the first k beats that bound, the argmax of :788 lies among them WHATEVER the columns k .. min_pc-1 hold: those columns are
-  // then provably not consumed (the partial eigensolver may leave them unconverged, `chefsi_tail_free`). match_uncertain[t] = 1
+  // then not consumed, up to the angle error of the strict pairs (margin below; the partial eigensolver may leave the tail unconverged,
+  // `chefsi_tail_free`). match_uncertain[t] = 1
   // where that cannot be shown for some signal (or a column >= k was picked); the caller solves such a member again.
   s->match_uncertain.assign((size_t)P, 0);
   for (int64_t t = 0; t < P; ++t) {
@@ -1828,7 +1832,11 @@ int session_robustness(Session* s, int64_t P, int32_t* a_b, double* b) {
         S += v * v;
         bk = std::max(bk, std::fabs(v));
       }
-      if (best >= k || bk * bk <= (1.0 - S) + 1e-3) s->match_uncertain[t] = 1;  // 1e-3: fp32 products, vectors orthonormal to ~1e-6
+      // margin 2e-2: the bound holds for vectors orthogonal to the COMPUTED first k Ritz vectors, the reference's converged tail
+      // vectors are orthogonal to the true ones -- the strict pairs are accepted at a residual of 2e-3 (theta_q - block edge), which
+      // allows a tilt of up to res / (lambda_k - lambda_{k+1}) ~ 1e-2 when a weak signal sits next to the bulk edge; the margin covers
+      // that tilt (and the ~1e-6 of the fp32 products). A member inside it is simply solved again with the tail converged.
+      if (best >= k || bk * bk <= (1.0 - S) + 2e-2) s->match_uncertain[t] = 1;
     }
     SCL_HIP(ctx, hipMemcpyAsync(pick, hp.data(), sizeof(int32_t) * k, hipMemcpyHostToDevice, ctx->stream));
     hipLaunchKernelGGL(k_gather_rows, dim3((unsigned)((s->N + 255) / 256), (unsigned)k), dim3(256), 0, ctx->stream,

@@ -68,3 +68,16 @@ def test_bench_row_sharded_two_ranks_on_one_gpu():
     (k1, r1, s1, p1), (k2, r2, s2, p2) = _decisions(one)[0], _decisions(two)[0]
     assert k1 == k2 > 0 and r1 == r2
     assert abs(p1 - p2) <= 0.002 + 1e-12 and abs(s1 - s2) <= 2
+
+
+def test_bench_eight_ranks_on_one_gpu_equal_the_one_rank_run():
+    """the driver's N = 8 launch (`python bench.py --gpus 8`, one rank per GPU of the target node) rehearsed on the one-GPU box: eight gloo
+    ranks share the device at 900 x 400 -- search rounds of 8 x streams evaluations, ensemble members t mod 8, first decompositions on
+    ranks 0 / 1 / 2, the status agreements and the final gather all run at the target world size; decisions equal the one-rank run"""
+    common = ["--config", "tiny_gt", "--steps", "1", "--warmup", "0", "--no-cpu-baseline", "--no-roofline", "--strict-fp32", "off",
+              "--budget-s", "800"]
+    one = _bench("--gpus", "1", *common)
+    eight = _bench("--gpus", "8", "--backend", "gloo", *common, timeout=1500)
+    assert eight["n_gpus"] == 8 and eight["config"]["comm"]["world"] == 8
+    assert _decisions(one) == _decisions(eight), (_decisions(one), _decisions(eight))
+    assert one["observed"]["signals"] > 0

@@ -212,7 +212,7 @@ def test_certified_ensemble_tail_gives_the_outputs_of_the_full_solver(ctx, N, M,
         assert np.all(_abs_cos(a["nV_set"][t][:, :k], b["nV_set"][t][:, :k]) > 1 - 3e-3)
         # the certificate, from the full solver's vectors: where it holds the member was not solved again, and vice versa up to the margin
         c = np.abs(nV.T @ b["nV_set"][t][:, :k].astype(np.float64))
-        proof = np.all(c.max(axis=1) ** 2 > 1.0 - (c ** 2).sum(axis=1) + 5e-3)
+        proof = np.all(c.max(axis=1) ** 2 > 1.0 - (c ** 2).sum(axis=1) + 2.5e-2)  # the library's margin is 2e-2
         if proof:
             assert t not in a["tail_redo"], (t, a["tail_redo"])
         if t in a["tail_redo"]:  # solved again: every picked column agrees with the full solver's
@@ -223,7 +223,7 @@ def test_certified_ensemble_tail_gives_the_outputs_of_the_full_solver(ctx, N, M,
 
 def test_matching_certificate_of_the_session_equals_its_definition(ctx):
     """session_robustness with "chefsi_tail_free": match_uncertain:t against the definition evaluated here from the downloaded vectors
-    -- member t is certain iff every signal i has best_k^2 > 1 - sum_{j<k} c_ij^2 (+ 1e-3) with c = nV' V_t[:, :k] and its argmax over
+    -- member t is certain iff every signal i has best_k^2 > 1 - sum_{j<k} c_ij^2 (+ 2e-2) with c = nV' V_t[:, :k] and its argmax over
     all min_pc columns lies among the first k. Session A: members of its own matrix (the signals survive the perturbation: certain).
     Session B, another matrix of the same shape: A's members imported into its slots -- B's signals have nothing to do with them, so
     no proof can exist: both answers occur and both equal the definition."""
@@ -236,7 +236,7 @@ def test_matching_certificate_of_the_session_equals_its_definition(ctx):
 
     def definition(nV, V, kk):
         c = np.abs(nV.T @ V)
-        slack = c[:, :kk].max(axis=1) ** 2 - (1.0 - (c[:, :kk] ** 2).sum(axis=1) + 1e-3)
+        slack = c[:, :kk].max(axis=1) ** 2 - (1.0 - (c[:, :kk] ** 2).sum(axis=1) + 2e-2)
         return int(np.any(c.argmax(axis=1) >= kk) or np.any(slack <= 0)), bool(np.any(np.abs(slack) < 1e-4))
 
     sesA = api.Session(ctx, XA, api._resolve(d.z_idx1), api._resolve(d.z_idx2))
@@ -573,6 +573,58 @@ def test_multi_rank_sclens_equals_single_rank(ctx, world, streams):
         assert np.array_equal(res["nL_set"][t], ref["nL_set"][t])
     for r in range(1, world):  # the other ranks return the shared part of the result
         assert np.array_equal(out[r]["L"], ref["L"]) and out[r]["p_"] == ref["p_"] and "pca" not in out[r]
+
+
+def test_eight_rank_rehearsal_of_the_whole_call(ctx):
+    """SURVEY 8e-i/ii/iv at the world size of the target node (8 x MI355X), rehearsed on one GPU with thread ranks: 20 ensemble members
+    spread 3 + 3 + 3 + 3 + 2 + 2 + 2 + 2 over the ranks (t mod 8), one gather at the end; search rounds of 8 evaluations, more than
+    the search takes, so that the evaluations past the stopping one are computed and DISCARDED (the overshoot path of
+    consume_search_round); the data / null / binarised decompositions on ranks 0 / 1 / 2 with their results broadcast. Rank 0's result
+    equals the single-rank run bit for bit; every rank returns the shared decisions (scLENS.jl:725-761, :771-778)."""
+    import threading
+
+    from devutil import ThreadShard
+    from sclens_amd._lib import Context
+
+    world, P = 8, 20
+    X = api._csc_f32(synth_counts(300, 500, seed=1, C=5, marker_frac=0.2, marker_sd=1.5))
+    d = api.make_draws_native(X, seed=13)
+    ref = api.sclens(X, draws=d, n_perturb=P, ctx=ctx, streams=1)
+    assert ref["n_search"] % world != 0  # the last round is cut short by the stop rule: results beyond it are discarded
+    group = ThreadShard.Group(world)
+    out, err = [None] * world, [None] * world
+
+    def work(r):
+        c = Context(ctx.device)
+        try:
+            out[r] = api.sclens(X, draws=d, n_perturb=P, ctx=c, streams=1, shard=ThreadShard(group, r))
+        except BaseException as e:  # noqa: BLE001
+            err[r] = e
+            group.bar.abort()
+        finally:
+            c.close()
+
+    th = [threading.Thread(target=work, args=(r,)) for r in range(world)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    for e in err:
+        if e is not None and not isinstance(e, threading.BrokenBarrierError):
+            raise e
+    assert all(e is None for e in err)
+    res = out[0]
+    assert np.array_equal(res["L"], ref["L"]) and res["p_"] == ref["p_"] and res["n_search"] == ref["n_search"]
+    for (p1, t1), (p2, t2) in zip(res["search_trace"], ref["search_trace"]):
+        assert p1 == p2 and np.array_equal(t1, t2)
+    assert np.array_equal(res["signal_evec"], ref["signal_evec"])
+    assert np.array_equal(res["robustness_scores"]["a_b"], ref["robustness_scores"]["a_b"])
+    assert np.array_equal(res["robustness_scores"]["b_"], ref["robustness_scores"]["b_"])
+    assert np.array_equal(res["sig_id"], ref["sig_id"]) and np.array_equal(res["gene_basis"], ref["gene_basis"])
+    for t in range(P):
+        assert np.array_equal(res["nL_set"][t], ref["nL_set"][t])
+    for r in range(1, world):
+        assert np.array_equal(out[r]["L"], ref["L"]) and out[r]["p_"] == ref["p_"] and out[r]["n_search"] == ref["n_search"]
 
 
 def _run_ranks(X, d, world, device, **kw):
