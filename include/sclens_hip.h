@@ -174,6 +174,14 @@ int sclens_hip_corr_colmax_f32(sclens_hip_ctx* ctx, const float* X, int64_t n, i
  * sparsity search uses for large problems (context option "gram_bits"). */
 int sclens_hip_gram_binary_f32(sclens_hip_ctx* ctx, int64_t N, int64_t M, const int64_t* colptr, const int32_t* rowval,
                                const float* nzval, int use_bits, float divisor, float* out);
+/* Piece exposed for unit tests and for the A/B of SURVEY 8f-1: the M x M Gram matrix (row-major, fp32) of logn_scale(pre_scale(X)) /
+ * divisor (f32path = 1; scLENS.jl:650-652) or of the inline Float64 twin (f32path = 0; :676-696) for a COUNT-VALUED N x M matrix, N >= M
+ * (binary != 0: stored counts as ones). mode 0: scaled dense matrix + the dense product the context's precision selects (the general
+ * path); mode 1: from the sparse structure of the scaled matrix, sparse + rank two -- the identity of scLENS.jl:601-603 applied to the
+ * Gram product: fp32 products of the stored entries accumulated in 64-bit fixed point per 128 x 128 tile of gene pairs, rank-two terms
+ * in fp64 (gram_sparse.hip; context option "gram_sparse" selects it inside sessions). */
+int sclens_hip_gram_counts_f32(sclens_hip_ctx* ctx, int64_t N, int64_t M, const int64_t* colptr, const int32_t* rowval,
+                               const float* nzval, int mode, int f32path, int binary, float divisor, float* out);
 /* get_eigvec(X; device)  (scLENS.jl:489-524): X is N x M scaled data. nL[r] positive eigenvalues
  * descending, nV is N x r (cell-side eigenvectors, unit columns). On input *r = capacity in columns
  * (min(N,M) always suffices); on output the number of positive eigenvalues. keep_top > 0 limits the

@@ -98,6 +98,7 @@ SIGNATURES = {
                                            c_f64p, c_f64p]),
     "sclens_hip_corr_colmax_f32": (C.c_int, [vp, c_f32p, i64, i64, c_f32p, i64, C.c_int, c_f32p]),
     "sclens_hip_gram_binary_f32": (C.c_int, [vp, i64, i64, c_i64p, c_i32p, c_f32p, C.c_int, C.c_float, c_f32p]),
+    "sclens_hip_gram_counts_f32": (C.c_int, [vp, i64, i64, c_i64p, c_i32p, c_f32p, C.c_int, C.c_int, C.c_int, C.c_float, c_f32p]),
     "sclens_hip_get_eigvec_f32": (C.c_int, [vp, c_f32p, i64, i64, i64, c_f32p, c_f32p, c_i64p]),
     "sclens_hip_get_denoised_f32": (C.c_int, [vp, c_f32p, i64, i64, c_f32p, i64, c_f64p, c_f64p, c_f64p, c_f64p, c_f64p, c_f32p]),
     "sclens_mp_calculation": (C.c_int, [c_f64p, i64, c_f64p, i64, c_f64p, c_f64p, c_u8p]),

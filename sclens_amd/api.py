@@ -203,6 +203,22 @@ def _gram_binary(X, use_bits: bool, divisor: Optional[float] = None, ctx: Option
     return out
 
 
+def _gram_counts(X, mode: int, f32path: bool = True, binary: bool = False, divisor: Optional[float] = None, ctx: Optional[Context] = None) -> np.ndarray:
+    """Unit-test / A-B piece (sclens_hip_gram_counts_f32): M x M Gram matrix of the scaled count matrix, mode 0 = dense product, 1 = from
+    the sparse structure."""
+    ctx = ctx or default_context()
+    Xc = _csc_f32(X)
+    N, M = Xc.shape
+    colptr = np.ascontiguousarray(Xc.indptr, dtype=np.int64)
+    rowval = np.ascontiguousarray(Xc.indices, dtype=np.int32)
+    nzval = np.ascontiguousarray(Xc.data, dtype=np.float32)
+    out = np.empty((M, M), dtype=np.float32)
+    ctx.check(ctx.lib.sclens_hip_gram_counts_f32(ctx.h, N, M, ptr(colptr, C.c_int64), ptr(rowval, C.c_int32), ptr(nzval, C.c_float), int(mode),
+                                                 1 if f32path else 0, 1 if binary else 0, float(divisor if divisor is not None else M),
+                                                 ptr(out, C.c_float)))
+    return out
+
+
 def get_denoised_df(inp_obj: Dict[str, object], device_="gpu", ctx: Optional[Context] = None) -> np.ndarray:
     """scLENS.jl:889-931: denoised count means from the robust signals of an sclens() result (N x M array; the
     reference wraps it in a DataFrame with `gene_id` columns and a `cell` column)."""
@@ -1172,6 +1188,7 @@ def sclens(inp_df, device_="gpu", th=60, p_step=0.001, n_perturb=20, centering="
             wctx.append(c2)
             workers.append(ses.clone(c2))
         gb0 = sum(w.get_int("gram_bits_used") for w in workers)  # context-lifetime counters: this call's share is the difference
+        gs0 = sum(w.get_int("gram_sparse_used") for w in workers)
         W = len(workers)
         pool = ThreadPoolExecutor(max_workers=W) if W > 1 else None
         def run_all(jobs):
@@ -1406,6 +1423,7 @@ def sclens(inp_df, device_="gpu", th=60, p_step=0.001, n_perturb=20, centering="
                     _exchange_ensemble(ses, shard, n_perturb, min_pc, nL_set, ncols)
             pe_counts = (sum(w.get_int("chefsi_used") for w in workers), sum(w.get_int("chefsi_fallback") for w in workers))
             gram_bits_used = sum(w.get_int("gram_bits_used") for w in workers) - gb0
+            gram_sparse_used = sum(w.get_int("gram_sparse_used") for w in workers) - gs0
             lap("perturbation_ensemble")
         finally:
             if pool is not None:
@@ -1418,7 +1436,7 @@ def sclens(inp_df, device_="gpu", th=60, p_step=0.001, n_perturb=20, centering="
         res: Dict[str, object] = {"L": L, "Lr": Lr, "L_mp": L_mp, "λ": lambda_c, "lambda_c": lambda_c, "cell_id": cell_id,
                                   "p_": p_, "p_th": p_th, "n_search": it, "search_trace": trace,
                                   "partial_eig": pe_counts, "guard_band": guard,
-                                  "gram_bits_used": gram_bits_used, "search_job_s": sorted(job_log, key=lambda q: (q[1], q[0])),
+                                  "gram_bits_used": gram_bits_used, "gram_sparse_used": gram_sparse_used, "search_job_s": sorted(job_log, key=lambda q: (q[1], q[0])),
                                   "first_phase_s": sorted(fp_log + aux_log, key=lambda q: q[1])}
         if min_s == 0:  # :780-784
             res["wall_s"] = time.perf_counter() - t_all

@@ -64,6 +64,7 @@ int get_eigvec_host(Ctx*, const float*, int64_t, int64_t, int64_t, float*, float
 int scale_csc_host(Ctx*, int64_t, int64_t, const int64_t*, const int32_t*, const float*, int, int, float*, ScaleVecs*);
 int corr_colmax_host(Ctx*, const float*, int64_t, int64_t, const float*, int64_t, int, float*);
 int gram_binary_host(Ctx*, int64_t, int64_t, const int64_t*, const int32_t*, const float*, int, float, float*);
+int gram_counts_host(Ctx*, int64_t, int64_t, const int64_t*, const int32_t*, const float*, int, int, int, float, float*);
 int denoise_host(Ctx*, const float*, int64_t, int64_t, const float*, int64_t, const double*, const double*, const double*,
                  const double*, const double*, float*);
 }  // namespace scl
@@ -286,6 +287,11 @@ int sclens_hip_gram_binary_f32(sclens_hip_ctx* h, int64_t N, int64_t M, const in
                                const float* nzval, int use_bits, float divisor, float* out) {
   CTX_GUARD(h);
   return scl::gram_binary_host(&h->c, N, M, colptr, rowval, nzval, use_bits, divisor, out);
+}
+int sclens_hip_gram_counts_f32(sclens_hip_ctx* h, int64_t N, int64_t M, const int64_t* colptr, const int32_t* rowval, const float* nzval,
+                               int mode, int f32path, int binary, float divisor, float* out) {
+  CTX_GUARD(h);
+  return scl::gram_counts_host(&h->c, N, M, colptr, rowval, nzval, mode, f32path, binary, divisor, out);
 }
 int sclens_hip_get_eigvec_f32(sclens_hip_ctx* h, const float* X, int64_t N, int64_t M, int64_t keep_top, float* nL,
                               float* nV, int64_t* r) {

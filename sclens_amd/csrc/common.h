@@ -32,6 +32,9 @@ namespace scl {
   X(gram_bits_strict, 1)    /* precision = 0: the Gram matrix of a BINARISED matrix still as the exact co-occurrence product, with   \
                                33-bit cell weights (no operand narrower than fp32: the 0/1 pattern is exact in fp16); 0: fp32 product */ \
   X(gram_split_min_n, 16000) /* dense Gram products from split operands from this order (0: never) */                              \
+  X(gram_sparse, 0)         /* Gram matrices of cells > genes matrices from their sparse structure (gram_sparse.hip): 1 always,     \
+                               0 never, -1 from gram_sparse_min_n */                                                               \
+  X(gram_sparse_min_n, 16000)                                                                                                      \
   X(implicit_min_n, 16000)  /* ensemble: the Gram matrix applied as two passes over the scaled matrix from this order */           \
   X(chefsi_b0, 0)           /* block size of the partial eigensolver (0: min_pc + 40 rounded up to 32) */                          \
   X(chefsi_tail_gap_micro, -1) /* gap-aware target of the tail pairs x 1e6 (-1: what the caller asks for) */                       \
@@ -162,6 +165,7 @@ struct Ctx {
   // which eigensolver holds the state eig_vectors continues from (opt.two_stage selects it); calls of gram_binary
   bool last_two_stage = false;
   long gram_bits_used = 0;
+  long gram_sparse_used = 0;
   // sessions keep their eigenvector / ensemble buffers in this context's named workspaces ("ses.*", "eig.*"): one live
   // session per context (worker sessions of session_clone bring their own context)
   int live_sessions = 0;

@@ -121,6 +121,13 @@ struct ScaleStats {
   double* red;  // [0] = ||mu||^2, [1] = sum_i l_i, [2] = sum_i s_i
 };
 int scale_stats(Ctx* ctx, const PatternDev& p, const float* val, int f32path, int centering, ScaleStats* out);
+// scale_to_dense that also hands out the statistics it computed; B == nullptr: the statistics (and rec_vals) only
+int scale_to_dense_stats(Ctx* ctx, const PatternDev& p, const float* val, int f32path, int centering, int cells_major, float* B, int64_t ldb,
+                         ScaleVecs* keep, ScaleStats* out);
+// Gram matrix of the scaled matrix from its SPARSE structure (gram_sparse.hip; cells > genes layout, mean centring)
+int gram_sparse(Ctx* ctx, const PatternDev& p, const float* val, int f32path, const double* tgc, const double* lg, const double* stdv,
+                const double* mu, const double* l2, const double* cent, const double* lsum, double n_all, double alpha, double beta,
+                float* A, int64_t lda, bool accumulate);
 
 // Gram matrix of the scaled matrix of a BINARY value array (val in {0, 1}; mean centring, all cells on this device, N > M
 // layout) without forming the scaled matrix (gram_bits.hip): A (M x M, lda, zero padded, exactly symmetric) =

@@ -416,17 +416,24 @@ int scale_stats(Ctx* ctx, const PatternDev& p, const float* val, int f32path, in
 
 int scale_to_dense(Ctx* ctx, const PatternDev& p, const float* val, int f32path, int centering, int cells_major,
                    float* B, int64_t ldb, ScaleVecs* keep) {
+  return scale_to_dense_stats(ctx, p, val, f32path, centering, cells_major, B, ldb, keep, nullptr);
+}
+int scale_to_dense_stats(Ctx* ctx, const PatternDev& p, const float* val, int f32path, int centering, int cells_major, float* B, int64_t ldb,
+                         ScaleVecs* keep, ScaleStats* out) {
   StageTimer tm(ctx, "scale");
   const int64_t N = p.N, M = p.M;
   ScaleStats ss;
   SCL_TRY(scale_stats(ctx, p, val, f32path, centering, &ss));
+  if (out) *out = ss;
   const double *tgc = ss.tgc, *lg = ss.lg, *mean = ss.mean, *stdv = ss.stdv, *mu = ss.mu, *l2 = ss.l2, *srow = ss.srow,
                *cent = ss.cent;
   hipStream_t st = ctx->stream;
   const int64_t nr = cells_major ? N : M, nc = cells_major ? M : N;
   if (nr > 65535LL * 65535LL) return ctx->fail(SCLENS_ERR_ARG, "scale_to_dense: too many rows");
   const bool fused_ok = ctx->opt.dense_fused != 0;  // 0: the separate fill + scatter kernels (same values)
-  if (!cells_major && fused_ok && ldb % 4 == 0 && (reinterpret_cast<uintptr_t>(B) & 15u) == 0) {
+  if (!B) {
+    // statistics only (the caller forms the Gram matrix from the sparse structure and does not need the dense matrix)
+  } else if (!cells_major && fused_ok && ldb % 4 == 0 && (reinterpret_cast<uintptr_t>(B) & 15u) == 0) {
     hipLaunchKernelGGL(k_dense_fused, dim3((unsigned)M), dim3(256), 0, st, p, val, lg, stdv, mu, cent, srow, B, ldb);
   } else {
   // grid.y is limited to 65535: loop over row slabs

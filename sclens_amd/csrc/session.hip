@@ -891,6 +891,11 @@ static bool use_f16_corr(const Session* s) {
   const int gb = s->ctx->opt.eff_gram_bits();
   return gb == 1 || (gb < 0 && s->n >= s->ctx->opt.gram_bits_min_n);
 }
+static bool use_gram_sparse(const Session* s) {
+  const int64_t g = s->ctx->opt.gram_sparse;
+  if (g == 0 || s->centering || s->cells_major || s->sh.on() || s->chunked() || s->pat.dev.nU >= 0x7FFFFFFFll) return false;
+  return g == 1 || s->n >= s->ctx->opt.gram_sparse_min_n;
+}
 // sum_root >= 0 (row-sharded session): the Gram matrix is summed onto that rank only and formed in `Aout` (default s->A);
 // solve = false: stop after the Gram matrix
 static int decompose(Session* s, const PatternDev& p, const float* val, int f32path, float* B, float divisor,
@@ -911,6 +916,14 @@ static int decompose(Session* s, const PatternDev& p, const float* val, int f32p
     SCL_TRY(gram_f32(s->ctx, B, s->n, s->K, s->ldb, divisor, Ag, s->lda));
     if (sum_root >= 0) SCL_TRY(s->sh.sum_to(s->ctx, Ag, s->n * s->lda, 1, sum_root));
     else SCL_TRY(s->sh.sum(s->ctx, Ag, s->n * s->lda, 1));
+  } else if (use_gram_sparse(s)) {
+    // the Gram matrix from the sparse structure of the scaled matrix (sparse + rank two); the dense matrix is written only
+    // where a later step reads it (the data matrix: recovery, guard band, gene basis)
+    ScaleStats ss;
+    SCL_TRY(scale_to_dense_stats(s->ctx, p, val, f32path, 0, 0, B == s->Bmain ? B : nullptr, s->ldb, keep, &ss));
+    SCL_TRY(gram_sparse(s->ctx, p, val, f32path, ss.tgc, ss.lg, ss.stdv, ss.mu, ss.l2, ss.cent, ss.red + 1, (double)p.N, 1.0 / (double)divisor,
+                        (double)p.N / (double)divisor, Ag, s->lda, false));
+    s->ctx->gram_sparse_used += 1;
   } else {
     SCL_TRY(scale_to_dense(s->ctx, p, val, s->centering ? 1 : f32path, s->centering, s->cells_major, B, s->ldb,
                            s->centering ? nullptr : keep));
@@ -947,9 +960,14 @@ int session_null_spectrum(Session* s, const int64_t* rc_, const int32_t* rr_, co
   if (s->chunked()) return ctx->fail(SCLENS_ERR_STATE, "null_spectrum: a chunked session takes X_r as chunks (chunk_add which = 1, null_spectrum_chunked)");
   PatternOwner pr;
   SCL_TRY(pattern_build(ctx, s->N, s->M, rc_, rr_, rv_, 0, nullptr, nullptr, &pr));  // sharded: this rank's cells of X_r
-  float* valr = static_cast<float*>(ctx->workspace("ses.valr", sizeof(float) * pr.dev.val_floats()));
-  int rc = valr ? SCLENS_OK : SCLENS_ERR_OOM;
-  if (rc == SCLENS_OK) rc = make_values(ctx, pr.dev, pr.base_val, 0, nullptr, 0, valr);
+  const float* valr = pr.base_val;  // (no copy: see session_data_spectrum)
+  int rc = SCLENS_OK;
+  if (pr.dev.base_val_csr) {
+    float* vr = static_cast<float*>(ctx->workspace("ses.valr", sizeof(float) * pr.dev.val_floats()));
+    rc = vr ? SCLENS_OK : SCLENS_ERR_OOM;
+    if (rc == SCLENS_OK) rc = make_values(ctx, pr.dev, pr.base_val, 0, nullptr, 0, vr);
+    valr = vr;
+  }
   s->ctx->q2_prebuild = false;  // eigenvalues only
   if (rc == SCLENS_OK) rc = decompose(s, pr.dev, valr, 1, s->Btmp, (float)s->M, nullptr);
   s->ctx->q2_prebuild = true;
@@ -966,9 +984,13 @@ int session_null_spectrum_pattern(Session* s, PatternOwner* pr, double* Lr) {
   if (s->chunked()) return ctx->fail(SCLENS_ERR_STATE, "null_spectrum: a chunked session takes X_r as chunks (chunk_add which = 1, null_spectrum_chunked)");
   if (!pr || pr->allocs.empty() || pr->dev.N != s->N || pr->dev.M != s->M)
     return ctx->fail(SCLENS_ERR_ARG, "null_spectrum: the pattern is empty or has different dimensions");
-  float* valr = static_cast<float*>(ctx->workspace("ses.valr", sizeof(float) * pr->dev.val_floats()));
-  if (!valr) return SCLENS_ERR_OOM;
-  SCL_TRY(make_values(ctx, pr->dev, pr->base_val, 0, nullptr, 0, valr));
+  const float* valr = pr->base_val;  // (no copy: see session_data_spectrum)
+  if (pr->dev.base_val_csr) {
+    float* vr = static_cast<float*>(ctx->workspace("ses.valr", sizeof(float) * pr->dev.val_floats()));
+    if (!vr) return SCLENS_ERR_OOM;
+    SCL_TRY(make_values(ctx, pr->dev, pr->base_val, 0, nullptr, 0, vr));
+    valr = vr;
+  }
   s->ctx->q2_prebuild = false;  // eigenvalues only
   const int rc_null = decompose(s, pr->dev, valr, 1, s->Btmp, (float)s->M, nullptr);
   s->ctx->q2_prebuild = true;
@@ -996,10 +1018,15 @@ int session_data_spectrum(Session* s, double* L, ScaleVecs* keep) {
     }
     s->cspec = MatSpec{};
     s->cspec.f32path = 0;
-  } else {
-    SCL_TRY(make_values(ctx, s->pat.dev, s->pat.base_val, 0, nullptr, 0, s->val));
   }
-  SCL_TRY(decompose(s, s->pat.dev, s->val, 0, s->Bmain, (float)s->M, keep));
+  // the stored counts themselves are the value array of the data matrix: a pattern without CSR companion copies (counts-only patterns)
+  // needs no copy of them (k_val_init moved 2.5 GB for nothing at 100 000 x 30 000)
+  const float* vdata = s->val;
+  if (!s->chunked()) {
+    if (s->pat.dev.base_val_csr) SCL_TRY(make_values(ctx, s->pat.dev, s->pat.base_val, 0, nullptr, 0, s->val));
+    else vdata = s->pat.base_val;
+  }
+  SCL_TRY(decompose(s, s->pat.dev, vdata, 0, s->Bmain, (float)s->M, keep));
   if (L) std::copy(s->w_host.begin(), s->w_host.end(), L);
   s->have_spectrum = true;
   return SCLENS_OK;
@@ -1742,6 +1769,7 @@ int session_get_int(Session* s, const char* name, int64_t* value) {
   if (k == "chunk_visits") { *value = s->chunk_visits; return SCLENS_OK; }
   if (k == "chunk_cached") { *value = (int64_t)s->pcache.size(); return SCLENS_OK; }
   if (k == "gram_bits_used") { *value = s->ctx->gram_bits_used; return SCLENS_OK; }
+  if (k == "gram_sparse_used") { *value = s->ctx->gram_sparse_used; return SCLENS_OK; }
   return s->ctx->fail(SCLENS_ERR_ARG, "session_get_int: unknown option " + k);
 }
 
@@ -2083,6 +2111,40 @@ int gram_binary_host(Ctx* ctx, int64_t N, int64_t M, const int64_t* colptr, cons
       rc = gram_binary(ctx, pr.dev, val, 1, B, divisor, A, lda);
     } else {
       rc = scale_to_dense(ctx, pr.dev, val, 1, 0, /*cells_major=*/0, B, ldb, nullptr);
+      if (rc == SCLENS_OK) rc = gram_f32(ctx, B, M, N, ldb, divisor, A, lda);
+    }
+  }
+  if (rc == SCLENS_OK) rc = download_packed(ctx, A, M, M, lda, out);
+  hipStreamSynchronize(ctx->stream);
+  pattern_free(&pr);
+  return rc;
+}
+
+// Gram matrix of logn_scale(pre_scale(X)) / divisor (f32path = 1) or of the inline Float64 twin (f32path = 0) for a COUNT-VALUED matrix,
+// both ways (unit-test piece and the A/B of SURVEY 8f-1): mode 0 = scaled dense matrix + the dense product the context's precision
+// selects, mode 1 = from the sparse structure (gram_sparse.hip). binary: every stored count as 1.
+int gram_counts_host(Ctx* ctx, int64_t N, int64_t M, const int64_t* colptr, const int32_t* rowval, const float* nzval, int mode, int f32path,
+                     int binary, float divisor, float* out) {
+  if (!colptr || !rowval || !nzval || !out || N <= 0 || M <= 0 || N < M || (mode != 0 && mode != 1))
+    return ctx->fail(SCLENS_ERR_ARG, "gram_counts: bad arguments");
+  PatternOwner pr;
+  SCL_TRY(pattern_build(ctx, N, M, colptr, rowval, nzval, 0, nullptr, nullptr, &pr));
+  const int64_t ldb = round_up(N, 32), lda = round_up(M, 32);
+  float* val = static_cast<float*>(ctx->workspace("w.scval", sizeof(float) * pr.dev.val_floats()));
+  float* A = static_cast<float*>(ctx->workspace("w.A", sizeof(float) * (size_t)M * lda));
+  int rc = (val && A) ? SCLENS_OK : SCLENS_ERR_OOM;
+  if (rc == SCLENS_OK) rc = make_values(ctx, pr.dev, pr.base_val, binary, nullptr, 0, val);
+  if (rc == SCLENS_OK) {
+    if (mode == 1) {
+      ScaleStats ss;
+      rc = scale_to_dense_stats(ctx, pr.dev, val, f32path, 0, 0, nullptr, ldb, nullptr, &ss);
+      if (rc == SCLENS_OK)
+        rc = gram_sparse(ctx, pr.dev, val, f32path, ss.tgc, ss.lg, ss.stdv, ss.mu, ss.l2, ss.cent, ss.red + 1, (double)N, 1.0 / (double)divisor,
+                         (double)N / (double)divisor, A, lda, false);
+    } else {
+      float* B = static_cast<float*>(ctx->workspace("w.scB", sizeof(float) * (size_t)M * ldb));
+      rc = B ? SCLENS_OK : SCLENS_ERR_OOM;
+      if (rc == SCLENS_OK) rc = scale_to_dense(ctx, pr.dev, val, f32path, 0, /*cells_major=*/0, B, ldb, nullptr);
       if (rc == SCLENS_OK) rc = gram_f32(ctx, B, M, N, ldb, divisor, A, lda);
     }
   }
