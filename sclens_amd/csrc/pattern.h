@@ -148,7 +148,7 @@ int chunk_pass_var(Ctx* ctx, const PatternDev& p, const float* val, int f32path,
 int chunk_stats_finish(Ctx* ctx, int64_t M, const double* acc, const double* acc_s2, double n_global, int f32path, double* mean, double* stdv,
                        double* mu, double* red);
 int chunk_dense(Ctx* ctx, const PatternDev& p, const float* val, int f32path, const double* stdv, const double* mu, const double* red, double num,
-                const double* cent, double* accT, float* B, int64_t ldb, double** tgc_out, double** l2_out);
+                const double* cent, double* accT, float* B, int64_t ldb, double** tgc_out, double** l2_out, double** lg_out = nullptr);
 int chunk_gram_finish(Ctx* ctx, float* A, int64_t n, int64_t lda, const double* T, const double* stdv, const double* mu, double n_global,
                       double divisor, double* cent);
 

@@ -748,7 +748,11 @@ static int chunk_pattern(Session* s, int set, int cands, int g, ChunkPatRef* ref
   }
   pool_stats(ctx->device, nullptr, &live1, nullptr, nullptr);
   e->bytes = live1 > live0 ? live1 - live0 : 0;
-  const size_t budget = (size_t)std::max<int64_t>(0, ctx->opt.chunk_cache_gb) << 30;
+  size_t budget = (size_t)std::max<int64_t>(0, ctx->opt.chunk_cache_gb) << 30;
+  if (ctx->opt.chunk_cache_gb < 0) {  // auto: what the device has beyond the working set of a visit + the gene side (measured 132 GB at 1M x 30k)
+    size_t fr = 0, tot = 0;
+    budget = (hipMemGetInfo(&fr, &tot) == hipSuccess && tot > ((size_t)160 << 30)) ? tot - ((size_t)160 << 30) : 0;
+  }
   if (s->pcache_bytes + e->bytes <= budget) {
     s->pcache.push_back(e);
     s->pcache_bytes += e->bytes;
@@ -831,17 +835,24 @@ static int chunked_gram(Session* s, const MatSpec& ms, float divisor, ScaleVecs*
       if (rc == SCLENS_OK && pass == 0) rc = chunk_pass_sum(ctx, p, val, ms.f32path, acc);
       if (rc == SCLENS_OK && pass == 1) rc = chunk_pass_var(ctx, p, val, ms.f32path, acc, ng, acc2);
       if (rc == SCLENS_OK && pass == 2) {
-        double *tgc = nullptr, *l2 = nullptr;
+        double *tgc = nullptr, *l2 = nullptr, *lg = nullptr;
+        const bool sparse = ctx->opt.gram_sparse != 0 && p.nU < 0x7FFFFFFFll &&
+                            (ctx->opt.gram_sparse == 1 || s->n >= ctx->opt.gram_sparse_min_n);  // no dense block at all
         {
           StageTimer tm(ctx, "scale");
-          rc = chunk_dense(ctx, p, val, ms.f32path, st->stdv, st->mu, st->red, 1.0, zero, accT, s->Btmp, s->ldb, &tgc, &l2);
+          rc = chunk_dense(ctx, p, val, ms.f32path, st->stdv, st->mu, st->red, 1.0, zero, accT, sparse ? nullptr : s->Btmp, s->ldb, &tgc, &l2, &lg);
         }
         if (rc == SCLENS_OK && keep) {
           hipError_t e1 = hipMemcpyAsync(keep->tgc + set[g].row0, tgc, sizeof(double) * set[g].N, hipMemcpyDeviceToHost, stq);
           hipError_t e2 = hipMemcpyAsync(keep->norm_tgc + set[g].row0, l2, sizeof(double) * set[g].N, hipMemcpyDeviceToHost, stq);
           if (e1 != hipSuccess || e2 != hipSuccess) rc = ctx->fail(SCLENS_ERR_HIP, "chunked session: rec_vals copy failed");
         }
-        if (rc == SCLENS_OK) rc = gram_f32(ctx, s->Btmp, M, set[g].N, s->ldb, divisor, A, s->lda, true, g > 0);
+        if (rc == SCLENS_OK && sparse) {  // the chunk's U'U / divisor from its sparse structure (c = 1, no cent term: applied at the end)
+          rc = gram_sparse(ctx, p, val, ms.f32path, tgc, lg, st->stdv, st->mu, l2, nullptr, nullptr, 1.0, 1.0 / (double)divisor, 0.0, A, s->lda, g > 0);
+          if (rc == SCLENS_OK) ctx->gram_sparse_used += 1;
+        } else if (rc == SCLENS_OK) {
+          rc = gram_f32(ctx, s->Btmp, M, set[g].N, s->ldb, divisor, A, s->lda, true, g > 0);
+        }
       }
       chunk_pattern_done(s, &ref);
       SCL_TRY(rc);

@@ -72,10 +72,11 @@ def test_bench_row_sharded_two_ranks_on_one_gpu():
 
 def test_bench_eight_ranks_on_one_gpu_equal_the_one_rank_run():
     """the driver's N = 8 launch (`python bench.py --gpus 8`, one rank per GPU of the target node) rehearsed on the one-GPU box: eight gloo
-    ranks share the device at 900 x 400 -- search rounds of 8 x streams evaluations, ensemble members t mod 8, first decompositions on
-    ranks 0 / 1 / 2, the status agreements and the final gather all run at the target world size; decisions equal the one-rank run"""
-    common = ["--config", "tiny_gt", "--steps", "1", "--warmup", "0", "--no-cpu-baseline", "--no-roofline", "--strict-fp32", "off",
-              "--budget-s", "800"]
+    ranks share the device at 20 000 x 6 000 (a matrix with signals: the search, the ensemble and the scoring all run) -- search rounds of
+    8 x streams evaluations, 16 ensemble members t mod 8, first decompositions on ranks 0 / 1 / 2, the status agreements and the final
+    gather all at the target world size; decisions equal the one-rank run"""
+    common = ["--config", "rs20k", "--steps", "1", "--warmup", "0", "--no-cpu-baseline", "--no-roofline", "--strict-fp32", "off",
+              "--budget-s", "1200", "--n-perturb", "16"]
     one = _bench("--gpus", "1", *common)
     eight = _bench("--gpus", "8", "--backend", "gloo", *common, timeout=1500)
     assert eight["n_gpus"] == 8 and eight["config"]["comm"]["world"] == 8
