@@ -71,6 +71,19 @@ def test_chunked_session_matches_plain_session(ctx, n_chunks):
     assert res["chunks"] == n_chunks and res["chunk_visits"] >= 3 * n_chunks * (3 + res["n_search"] + 5)
 
 
+def test_chunked_session_with_the_sparse_structured_gram(ctx, opt):
+    """the chunks' Gram contributions from the sparse structure of their scaled blocks (context option gram_sparse): no
+    dense block is formed for a decomposition at all; same decisions and results as the plain session"""
+    N, M, n_chunks = 1500, 400, 3
+    X = api._csc_f32(synth_counts(N, M, seed=4, C=5, marker_frac=0.2, marker_sd=1.5))
+    d = api.make_draws_native(X, seed=29, device_candidates=True)
+    Xn = api._csc_f32(api._resolve(d.X_r))
+    ref = api.sclens(X, draws=_replay_draws(ctx, X, d, n_chunks), n_perturb=4, ctx=ctx, streams=1)
+    opt(gram_sparse=1)
+    res = atlas.sclens_chunked(_chunks(X, n_chunks), _chunks(Xn, n_chunks), d, n_perturb=4, ctx=ctx)
+    _compare(res, ref)
+
+
 @pytest.mark.parametrize("cache_gb", [64, 0])
 def test_chunked_session_two_stage_size_with_and_without_pattern_cache(ctx, opt, cache_gb):
     """9 000 x 6 000 (the order at which the two-stage solver and the split products are on), 4 unequal chunks; chunk_cache_gb = 0:
