@@ -191,6 +191,33 @@ __global__ __launch_bounds__(SG_THREADS) void k_sg_tile(SgArgs a) {
 
 }  // namespace
 
+// sum_i r_i^2 / 2 over the rows of a CSR view: the multiply-adds of the sparse form (what decides between it and the dense product)
+__global__ __launch_bounds__(1024) void k_sg_macs(const int64_t* __restrict__ rowptr, int64_t n, double* __restrict__ out) {
+  __shared__ double sw[16];
+  double s = 0.0;
+  for (int64_t i = threadIdx.x; i < n; i += 1024) {
+    const double r = (double)(rowptr[i + 1] - rowptr[i]);
+    s += 0.5 * r * r;
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+  if ((threadIdx.x & 63) == 0) sw[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double q = 0.0;
+    for (int w = 0; w < 16; ++w) q += sw[w];
+    out[0] = q;
+  }
+}
+int gram_sparse_macs(Ctx* ctx, const PatternDev& p, double* macs) {
+  SCL_WS(ctx, d, double, "gs.macs", 2);
+  hipLaunchKernelGGL(k_sg_macs, dim3(1), dim3(1024), 0, ctx->stream, p.rowptr, p.N, d);
+  SCL_HIP(ctx, hipGetLastError());
+  SCL_HIP(ctx, hipMemcpyAsync(macs, d, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+  SCL_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return SCLENS_OK;
+}
+
 // A (n = M genes, lda, zero padded outside) (+)= alpha c^2 (U'U - mu t' - t mu' + D2 mu mu') - beta cent cent'
 //   p / val: the matrix (CSR view of the pattern + its values); tgc, lg, stdv, mu, l2: its statistics (scale_stats / chunk_dense);
 //   lsum != nullptr: c = lsum[0] / n_all (device scalar: the sum of the cells' norms), else c = 1; cent == nullptr: no cent term.

@@ -124,7 +124,9 @@ int scale_stats(Ctx* ctx, const PatternDev& p, const float* val, int f32path, in
 // scale_to_dense that also hands out the statistics it computed; B == nullptr: the statistics (and rec_vals) only
 int scale_to_dense_stats(Ctx* ctx, const PatternDev& p, const float* val, int f32path, int centering, int cells_major, float* B, int64_t ldb,
                          ScaleVecs* keep, ScaleStats* out);
-// Gram matrix of the scaled matrix from its SPARSE structure (gram_sparse.hip; cells > genes layout, mean centring)
+// Gram matrix of the scaled matrix from its SPARSE structure (gram_sparse.hip; cells > genes layout, mean centring); gram_sparse_macs:
+// its multiply-adds, sum_i r_i^2 / 2 over the slots of the rows
+int gram_sparse_macs(Ctx* ctx, const PatternDev& p, double* macs);
 int gram_sparse(Ctx* ctx, const PatternDev& p, const float* val, int f32path, const double* tgc, const double* lg, const double* stdv,
                 const double* mu, const double* l2, const double* cent, const double* lsum, double n_all, double alpha, double beta,
                 float* A, int64_t lda, bool accumulate);

@@ -617,6 +617,7 @@ int session_clone(Ctx* ctx2, Session* src, Session** out) {
 
 static void chunk_cache_flush(Session* s);
 static std::vector<ChunkSrc>& chunk_set(Session* s, int set);
+static bool gram_sparse_pays(Ctx* ctx, const PatternDev& p, int64_t n, int64_t K);
 // Chunked session: the shell (gene-side buffers), then the chunks one at a time (the host never holds more than one), then commit.
 int session_create_chunked(Ctx* ctx, int64_t N_global, int64_t M, int n_chunks, int64_t nnz_global, uint64_t seed, Session** out) {
   if (N_global <= M || M <= 0 || n_chunks <= 0 || n_chunks > 4096 || nnz_global < 0 || nnz_global >= 0xFFFFFFF0ll)
@@ -836,8 +837,8 @@ static int chunked_gram(Session* s, const MatSpec& ms, float divisor, ScaleVecs*
       if (rc == SCLENS_OK && pass == 1) rc = chunk_pass_var(ctx, p, val, ms.f32path, acc, ng, acc2);
       if (rc == SCLENS_OK && pass == 2) {
         double *tgc = nullptr, *l2 = nullptr, *lg = nullptr;
-        const bool sparse = ctx->opt.gram_sparse != 0 && p.nU < 0x7FFFFFFFll &&
-                            (ctx->opt.gram_sparse == 1 || s->n >= ctx->opt.gram_sparse_min_n);  // no dense block at all
+        const bool sparse = ctx->opt.gram_sparse != 0 && p.nU < 0x7FFFFFFFll &&  // no dense block at all
+                            (ctx->opt.gram_sparse == 1 || (s->n >= ctx->opt.gram_sparse_min_n && gram_sparse_pays(ctx, p, s->n, p.N)));
         {
           StageTimer tm(ctx, "scale");
           rc = chunk_dense(ctx, p, val, ms.f32path, st->stdv, st->mu, st->red, 1.0, zero, accT, sparse ? nullptr : s->Btmp, s->ldb, &tgc, &l2, &lg);
@@ -902,10 +903,20 @@ static bool use_f16_corr(const Session* s) {
   const int gb = s->ctx->opt.eff_gram_bits();
   return gb == 1 || (gb < 0 && s->n >= s->ctx->opt.gram_bits_min_n);
 }
-static bool use_gram_sparse(const Session* s) {
+// measured at 100 000 x 30 000 (profiles/r06_gram_sparse_ab_cfg4.log): 5.1e11 multiply-adds in 1.19 s against 0.68 s (fp32 MFMA) / 0.24 s
+// (split fp16) for the 9.0e13 flop of the dense lower half
+static bool gram_sparse_pays(Ctx* ctx, const PatternDev& p, int64_t n, int64_t K) {
+  double macs = 0.0;
+  if (gram_sparse_macs(ctx, p, &macs) != SCLENS_OK) return false;
+  const double t_sparse = macs / 4.3e11;
+  const double t_dense = (double)n * (double)(n + 1) * (double)K / (ctx->opt.split() && n >= ctx->opt.eff_gram_split_min() ? 3.66e14 : 1.31e14);
+  return t_sparse < 0.9 * t_dense;
+}
+static bool use_gram_sparse(const Session* s, const PatternDev& p) {
   const int64_t g = s->ctx->opt.gram_sparse;
-  if (g == 0 || s->centering || s->cells_major || s->sh.on() || s->chunked() || s->pat.dev.nU >= 0x7FFFFFFFll) return false;
-  return g == 1 || s->n >= s->ctx->opt.gram_sparse_min_n;
+  if (g == 0 || s->centering || s->cells_major || s->sh.on() || s->chunked() || p.nU >= 0x7FFFFFFFll || !p.rowptr) return false;
+  if (g == 1) return true;
+  return s->n >= s->ctx->opt.gram_sparse_min_n && gram_sparse_pays(s->ctx, p, s->n, p.N);
 }
 // sum_root >= 0 (row-sharded session): the Gram matrix is summed onto that rank only and formed in `Aout` (default s->A);
 // solve = false: stop after the Gram matrix
@@ -927,7 +938,7 @@ static int decompose(Session* s, const PatternDev& p, const float* val, int f32p
     SCL_TRY(gram_f32(s->ctx, B, s->n, s->K, s->ldb, divisor, Ag, s->lda));
     if (sum_root >= 0) SCL_TRY(s->sh.sum_to(s->ctx, Ag, s->n * s->lda, 1, sum_root));
     else SCL_TRY(s->sh.sum(s->ctx, Ag, s->n * s->lda, 1));
-  } else if (use_gram_sparse(s)) {
+  } else if (use_gram_sparse(s, p)) {
     // the Gram matrix from the sparse structure of the scaled matrix (sparse + rank two); the dense matrix is written only
     // where a later step reads it (the data matrix: recovery, guard band, gene basis)
     ScaleStats ss;

@@ -54,7 +54,23 @@ d1 = run("dense, split fp16 (precision 1)", 0, 1)
 s0 = run("sparse structure (gram_sparse)", 1, 0)
 sc = np.abs(d0).max()
 print(f"  max |sparse - dense fp32| / largest entry {np.abs(s0 - d0).max() / sc:.2e}; |split - dense fp32| {np.abs(d1 - d0).max() / sc:.2e}; "
-      f"symmetric {np.array_equal(s0, s0.T)}")
+      f"|sparse - split| {np.abs(s0 - d1).max() / sc:.2e}; symmetric {np.array_equal(s0, s0.T)}")
+
+
+def where(name, a, b):
+    e = np.abs(a - b)
+    j, k = np.unravel_index(int(np.argmax(e)), e.shape)
+    print(f"  {name}: largest difference at ({j}, {k}): {a[j, k]:.9g} vs {b[j, k]:.9g}; entries off by more than 1e-5 of the largest entry: "
+          f"{int((e > 1e-5 * sc).sum())} of {e.size}; diagonal only: {float(np.abs(np.diag(a) - np.diag(b)).max() / sc):.2e}; "
+          f"largest entry {sc:.6g} at {np.unravel_index(int(np.argmax(np.abs(b))), b.shape)}")
+
+
+where("dense fp32 vs sparse", d0, s0)
+where("split vs sparse", d1, s0)
+ctx.set_option("gemm_force", 2)
+d2 = run("dense, fp32 MFMA, 128 x 128 kernel (gemm_force = 2)", 0, 0)
+ctx.set_option("gemm_force", 0)
+where("dense fp32 (128 x 128 kernel) vs sparse", d2, s0)
 print("binarised matrix:")
 b0 = run("dense, fp32 MFMA (precision 0)", 0, 0, binary=True)
 b2 = run("co-occurrence product, 33-bit weights (gram_bits, precision 0)", 0, 0, bits=1)

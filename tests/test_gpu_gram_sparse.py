@@ -57,3 +57,16 @@ def test_sclens_with_the_sparse_structured_gram(ctx, opt):
     assert np.array_equal(res["robustness_scores"]["a_b"], ref["robustness_scores"]["a_b"])
     assert np.array_equal(res["sig_id"], ref["sig_id"])
     assert np.abs(res["robustness_scores"]["rob_score"] - ref["robustness_scores"]["rob_score"]).max() < 3e-3
+
+
+def test_sparse_form_is_chosen_by_its_multiply_adds(ctx, opt):
+    """context option gram_sparse = -1 (the default): from order gram_sparse_min_n the sparse form is taken where its multiply-adds,
+    sum_i r_i^2 / 2 at the measured rate, undercut the dense product -- a 3 % dense matrix takes it, a 30 % dense one does not"""
+    opt(gram_sparse=-1, gram_sparse_min_n=256, gram_bits=0)
+    kw = dict(n_perturb=2, max_search_iters=3, streams=1, ctx=ctx)
+    Xs = api._csc_f32(synth_counts(6000, 500, seed=2, C=4, sparsity=0.97, min_genes_per_cell=5, marker_frac=0.2, marker_sd=1.5))
+    Xd = api._csc_f32(synth_counts(6000, 500, seed=2, C=4, sparsity=0.70, marker_frac=0.2, marker_sd=1.5))
+    assert Xs.nnz < 0.05 * 6000 * 500 and Xd.nnz > 0.25 * 6000 * 500
+    rs = api.sclens(Xs, draws=api.make_draws_native(Xs, seed=5), **kw)
+    rd = api.sclens(Xd, draws=api.make_draws_native(Xd, seed=5), **kw)
+    assert rs["gram_sparse_used"] >= 1 + rs["n_search"] and rd["gram_sparse_used"] == 0
