@@ -69,4 +69,5 @@ def test_sparse_form_is_chosen_by_its_multiply_adds(ctx, opt):
     assert Xs.nnz < 0.05 * 6000 * 500 and Xd.nnz > 0.25 * 6000 * 500
     rs = api.sclens(Xs, draws=api.make_draws_native(Xs, seed=5), **kw)
     rd = api.sclens(Xd, draws=api.make_draws_native(Xd, seed=5), **kw)
-    assert rs["gram_sparse_used"] >= 1 + rs["n_search"] and rd["gram_sparse_used"] == 0
+    assert rs["gram_sparse_used"] >= 1 and rd["gram_sparse_used"] == 0  # (counted from the binarised basis on; the union pattern of the
+    # search carries twice the slots, four times the multiply-adds: there the estimate may go either way)
