@@ -403,9 +403,16 @@ int sclens_hip_session_get_perturbed(sclens_hip_session* s, int64_t t, float* nV
  * "chefsi_tail_free" (set / get, round 5): 1 = those tail pairs are not converged at all (a member then costs a third of the passes
  * over its scaled matrix); sclens_hip_session_robustness then records per member whether the matching provably does not depend on
  * them -- signal i correlates with any unit vector orthogonal to the member's first k eigenvectors by at most
- * sqrt(1 - sum_{j<k} c_ij^2), so the argmax of :788 lies among the first k whenever the best of them beats that bound --:
+ * sqrt(1 - sum_{j<k} c_ij^2), so the argmax of :788 lies among the first k whenever the best of them beats that bound (with a margin of
+ * 2e-2 for the angle error of the strict pairs) --:
  * get "match_uncertain:<t>" = 1 for a member t without that proof (or whose matching picked a column >= k), "match_uncertain_count"
  * their number. The host solves such members again with "chefsi_tail_free" = 0 and repeats sclens_hip_session_robustness. */
+/* Row-sharded sessions, set: "shard_rank" (this rank's index, once) and "solve_root" (-1 = every rank, the default): the rank that runs
+ * the eigensolver of the NEXT null_spectrum / data_spectrum (+ the refine_eigenvalues / signal_vectors that continue from it) /
+ * binary_basis -- the partial Gram matrix is summed onto that rank only (sclens_hip_session_set_reduce_to) and its eigenvalues, the
+ * vectors the other ranks recover their cells from, and Vr2 reach them as sums in which they contribute zeros: the three first
+ * decompositions (scLENS.jl:704, :717-721) run on three ranks side by side instead of replicated on all (sclens_amd/atlas.py).
+ * get: "n_cand", "chunks", "chunk_builds", "chunk_visits", "chunk_cached" (chunked sessions), "gram_sparse_used". */
 int sclens_hip_session_set_int(sclens_hip_session* s, const char* name, int64_t value);
 int sclens_hip_session_get_int(sclens_hip_session* s, const char* name, int64_t* value);
 /* Multi-GPU ensemble sharding: copy slot t to / from a contiguous device buffer of min_pc x ldn floats

@@ -9,7 +9,7 @@ Two ways to place the eigen-solver: replicated on identical inputs (all-reduce o
 -- the default for several ranks with device-side samples -- a ROUND of `world` independent decompositions (consecutive
 sparsities of the search, consecutive ensemble members) whose partial Gram matrices are each reduced onto ONE rank, which solves
 it while the others solve theirs (`search_round_seeded`, `perturb_round_seeded`). The first three decompositions (data, null,
-binarised) are still replicated. Memory scales with the ranks either way: the sparse pattern, the candidates (drawn locally:
+binarised) run on one rank each as well (session option `solve_root`; their results are shared inside the library). Memory scales with the ranks either way: the sparse pattern, the candidates (drawn locally:
 no rank holds foreign ones), the dense scaled matrix and the cell-side vectors are divided by their number. For cells <= genes,
 or when the matrix fits one GPU, use api.sclens(shard=...), which distributes whole decompositions instead.
 """
@@ -93,8 +93,15 @@ def sclens_row_sharded(X_local, row0: int, N_global: int, draws: Draws, shard: S
         n_cand = len(z1)
     if distribute:
         ses.set_reduce_to(shard.reducer_to(ctx))
+        ses.set_int("shard_rank", shard.rank)
+    # the three first decompositions on ONE rank each (data 0, null 1, binarised 2, modulo the ranks) instead of replicated on all:
+    # the partial Gram matrix is summed onto that rank only, it alone runs the eigensolver, and the eigenvalues + the few vectors the
+    # others recover their cells from (+ Vr2) are shared inside the library (session option solve_root; round 6)
+    first_root = (lambda q: q % shard.world) if distribute else (lambda q: -1)
     try:
+        ses.set_int("solve_root", first_root(1)) if distribute else None
         Lr = shard.agree(ses.null_spectrum(Xr_local))  # :704
+        ses.set_int("solve_root", first_root(0)) if distribute else None
         L, rec_vals = ses.data_spectrum()
         L = shard.agree(L)
         L_mp, _, _ = _mp_calculation(L, Lr[:-1])
@@ -104,7 +111,9 @@ def sclens_row_sharded(X_local, row0: int, N_global: int, draws: Draws, shard: S
         if verbose and shard.rank == 0:
             print(f"(Using hip, {shard.world} row blocks) number of signal ev: {k}")
         nV_local = ses.signal_vectors(k)
+        ses.set_int("solve_root", first_root(2)) if distribute else None
         _, r_vr2 = ses.binary_basis()  # :717-721
+        ses.set_int("solve_root", -1) if distribute else None
         mpC = mp_check(L_mp)
         p_th = draws.p_th
         n_2 = int(round(r_vr2 / 2))

@@ -249,6 +249,12 @@ struct Session {
   // size(X', 2) = number of ALL cells; sh.fn sums partial results over the ranks
   ShardReduce sh;
   int64_t Kdiv = 0;
+  // first decompositions of a row-sharded session on ONE rank each instead of replicated (session_set_int "shard_rank", "solve_root"):
+  // the partial Gram matrix is summed onto solve_root only, that rank runs the eigensolver, and what the others need of its result --
+  // the eigenvalues, the few eigenvectors they recover their cells from, Vr2 -- reaches them as a sum in which they contribute zeros
+  int shard_rank = -1, solve_root = -1;
+  int data_root = -1;  // the rank that holds the data matrix's reduction (refine_eigenvalues / signal_vectors continue from it)
+  bool solves(int root) const { return root < 0 || shard_rank == root; }
   int64_t chefsi_used = 0, chefsi_fallback = 0;
   double chefsi_tail_gap = 0.0;  // > 0: gap-aware targets for the tail pairs of the partial eigensolver (chefsi.hip)
   int chefsi_tail_free = 0;      // != 0: the tail pairs k .. min_pc-1 of an ensemble member are not converged at all (chefsi.hip); the caller
@@ -893,6 +899,34 @@ static int chunk_block(Session* s, const ChunkStatsDev& st, int g) {
 // scaled dense matrix of `val` -> B, Gram -> A, eigenvalues -> w64/w_host
 // binary: every value of `val` is 0 or 1 (sparsity search): large problems in the genes-major layout then skip the scaled
 // matrix and form the Gram matrix on the fp16 MFMA (gram_bits.hip); B is only scratch in that case
+// root's buffer to every rank of a row-sharded session: the others contribute zeros to a sum (no broadcast primitive in the reducer
+// interface; the same device as perturb_round's share phase). A root whose eigensolver failed still enters the sum, with NaNs, so that
+// every rank sees the failure instead of waiting for ever.
+static int share_from_root(Session* s, int root, void* dev, int64_t count, int dtype, int root_rc) {
+  Ctx* ctx = s->ctx;
+  if (root < 0 || !s->sh.on()) return root_rc;
+  const size_t bytes = (size_t)count * (dtype == 0 ? 8 : 4);
+  if (!s->solves(root)) SCL_HIP(ctx, hipMemsetAsync(dev, 0, bytes, ctx->stream));
+  else if (root_rc != SCLENS_OK) (void)hipMemsetAsync(dev, 0xFF, bytes, ctx->stream);  // all-ones words are NaNs in both widths
+  const std::string keep = ctx->err;
+  SCL_TRY(s->sh.sum(ctx, dev, count, dtype));
+  if (root_rc != SCLENS_OK) ctx->err = keep;
+  return root_rc;
+}
+static int eig_values_on_root(Session* s, int root, int64_t n_low) {
+  Ctx* ctx = s->ctx;
+  int rc = SCLENS_OK;
+  if (s->solves(root)) rc = eig_values(ctx, s->A, s->n, s->lda, s->w64, n_low);
+  SCL_TRY(share_from_root(s, root, s->w64, s->n, 0, rc));
+  return s->fetch_w(n_low >= 0);  // a NaN from a failed root ends the call on every rank
+}
+static int eig_vectors_on_root(Session* s, int root, int64_t lo, int64_t hi) {  // -> s->Zt rows 0 .. hi - lo - 1 on every rank
+  Ctx* ctx = s->ctx;
+  int rc = SCLENS_OK;
+  if (s->solves(root)) rc = eig_vectors(ctx, s->A, s->n, s->lda, s->w64, lo, hi, s->Zt, s->ldz);
+  return share_from_root(s, root, s->Zt, (hi - lo) * s->ldz, 1, rc);
+}
+
 static bool use_gram_bits(const Session* s) {
   const int gb = s->ctx->opt.eff_gram_binary();
   if (s->centering || s->cells_major || gb == 0 || s->chunked()) return false;  // row-sharded sessions: each rank's additive part
@@ -952,8 +986,7 @@ static int decompose(Session* s, const PatternDev& p, const float* val, int f32p
     SCL_TRY(gram_f32(s->ctx, B, s->n, s->K, s->ldb, divisor, Ag, s->lda));
   }
   if (!solve) return SCLENS_OK;
-  SCL_TRY(eig_values(s->ctx, s->A, s->n, s->lda, s->w64, n_low));
-  return s->fetch_w(n_low >= 0);
+  return eig_values_on_root(s, s->sh.on() ? sum_root : -1, n_low);
 }
 
 // null matrix X_r (scLENS.jl:701, :704) of a chunked session: its chunks have been added with which = 1 and are released afterwards
@@ -991,7 +1024,7 @@ int session_null_spectrum(Session* s, const int64_t* rc_, const int32_t* rr_, co
     valr = vr;
   }
   s->ctx->q2_prebuild = false;  // eigenvalues only
-  if (rc == SCLENS_OK) rc = decompose(s, pr.dev, valr, 1, s->Btmp, (float)s->M, nullptr);
+  if (rc == SCLENS_OK) rc = decompose(s, pr.dev, valr, 1, s->Btmp, (float)s->M, nullptr, -1, false, true, s->sh.on() ? s->solve_root : -1);
   s->ctx->q2_prebuild = true;
   hipStreamSynchronize(ctx->stream);
   pattern_free(&pr);
@@ -1014,7 +1047,7 @@ int session_null_spectrum_pattern(Session* s, PatternOwner* pr, double* Lr) {
     valr = vr;
   }
   s->ctx->q2_prebuild = false;  // eigenvalues only
-  const int rc_null = decompose(s, pr->dev, valr, 1, s->Btmp, (float)s->M, nullptr);
+  const int rc_null = decompose(s, pr->dev, valr, 1, s->Btmp, (float)s->M, nullptr, -1, false, true, s->sh.on() ? s->solve_root : -1);
   s->ctx->q2_prebuild = true;
   SCL_TRY(rc_null);
   SCL_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -1048,7 +1081,8 @@ int session_data_spectrum(Session* s, double* L, ScaleVecs* keep) {
     if (s->pat.dev.base_val_csr) SCL_TRY(make_values(ctx, s->pat.dev, s->pat.base_val, 0, nullptr, 0, s->val));
     else vdata = s->pat.base_val;
   }
-  SCL_TRY(decompose(s, s->pat.dev, vdata, 0, s->Bmain, (float)s->M, keep));
+  s->data_root = s->sh.on() ? s->solve_root : -1;
+  SCL_TRY(decompose(s, s->pat.dev, vdata, 0, s->Bmain, (float)s->M, keep, -1, false, true, s->data_root));
   if (L) std::copy(s->w_host.begin(), s->w_host.end(), L);
   s->have_spectrum = true;
   return SCLENS_OK;
@@ -1212,7 +1246,7 @@ int session_refine_eigenvalues(Session* s, int64_t idx_lo, int64_t idx_hi, doubl
   if (cnt == 0) return SCLENS_OK;
   StageTimer tm(ctx, "refine");
   SCL_TRY(s->ensure_zt(cnt));
-  SCL_TRY(eig_vectors(ctx, s->A, s->n, s->lda, s->w64, idx_lo, idx_hi, s->Zt, s->ldz));
+  SCL_TRY(eig_vectors_on_root(s, s->data_root, idx_lo, idx_hi));
   if (s->chunked()) {  // ||B' z||^2 is a sum over the cells: block by block (each rebuilt once, all vector groups against it)
     const int64_t nbc = (s->ldb + 255) / 256;
     SCL_WS(ctx, partc, double, "ses.rq", nbc * RQ_V);
@@ -1287,7 +1321,7 @@ int session_signal_vectors(Session* s, int64_t k, float* nV) {
   if (b0 > 128 || b0 > s->n / 2) b0 = 0;  // too wide for the small-block solver: ensemble uses the full solver
   const int64_t nv = std::max(k, b0);
   SCL_TRY(s->ensure_zt(nv));
-  SCL_TRY(eig_vectors(ctx, s->A, s->n, s->lda, s->w64, s->n - nv, s->n, s->Zt, s->ldz));
+  SCL_TRY(eig_vectors_on_root(s, s->data_root, s->n - nv, s->n));
   s->b0 = b0;
   if (b0 > 0) {
     float* z0 = static_cast<float*>(ctx->workspace("ses.Z0t", sizeof(float) * (size_t)b0 * s->ldz));
@@ -1321,14 +1355,15 @@ int session_binary_basis(Session* s, double* L_bin, int64_t* r_out) {
     SCL_TRY(make_values(ctx, s->pat.dev, s->pat.base_val, 1, nullptr, 0, s->val));
   }
   // get_eigvec(scaled', ...) for N > M / get_eigvec(scaled) otherwise: n x n Gram, divisor = K (Appendix A8)
-  SCL_TRY(decompose(s, s->pat.dev, s->val, 1, s->Btmp, (float)s->Kdiv, nullptr, -1, /*binary=*/true));
+  const int broot = s->sh.on() ? s->solve_root : -1;
+  SCL_TRY(decompose(s, s->pat.dev, s->val, 1, s->Btmp, (float)s->Kdiv, nullptr, -1, /*binary=*/true, true, broot));
   if (L_bin) std::copy(s->w_host.begin(), s->w_host.end(), L_bin);
   const int64_t r = s->count_positive();
   s->r_vr2 = r;
   if (r_out) *r_out = r;
   if (r == 0) return SCLENS_OK;
   SCL_TRY(s->ensure_zt(r));
-  SCL_TRY(eig_vectors(ctx, s->A, s->n, s->lda, s->w64, s->n - r, s->n, s->Zt, s->ldz));
+  SCL_TRY(eig_vectors_on_root(s, broot, s->n - r, s->n));
   float* v = static_cast<float*>(ctx->workspace("ses.Vr2t", sizeof(float) * (size_t)r * s->ldz));
   if (!v) return SCLENS_ERR_OOM;
   s->Vr2t = v;
@@ -1754,6 +1789,13 @@ int session_set_int(Session* s, const char* name, int64_t value) {
   if (k == "chefsi") { s->use_chefsi = value != 0; return SCLENS_OK; }
   if (k == "chefsi_tail_gap_milli") { s->chefsi_tail_gap = (double)value * 1e-3; return SCLENS_OK; }
   if (k == "chefsi_tail_free") { s->chefsi_tail_free = value != 0; return SCLENS_OK; }
+  if (k == "shard_rank" || k == "solve_root") {
+    if (!s->sh.on()) return s->ctx->fail(SCLENS_ERR_STATE, "session_set_int: " + k + " is an option of row-sharded sessions");
+    if (value < -1) return s->ctx->fail(SCLENS_ERR_ARG, "session_set_int: bad rank");
+    if (k == "solve_root" && value >= 0 && s->shard_rank < 0) return s->ctx->fail(SCLENS_ERR_STATE, "session_set_int: set shard_rank before solve_root");
+    (k == "shard_rank" ? s->shard_rank : s->solve_root) = (int)value;
+    return SCLENS_OK;
+  }
   if (k == "centering") {  // 0 = "mean", 1 = "median" (scLENS.jl:651-654); set before the first decomposition
     if (value != 0 && value != 1) return s->ctx->fail(SCLENS_ERR_ARG, "session_set_int: centering must be 0 or 1");
     if (value == 1 && s->sh.on()) return s->ctx->fail(SCLENS_ERR_ARG, "session_set_int: a row-sharded session supports mean centring only");
