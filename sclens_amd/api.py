@@ -1099,7 +1099,8 @@ def sclens(inp_df, device_="gpu", th=60, p_step=0.001, n_perturb=20, centering="
     computes (:776) and consumes only if the matching (:788) picks one: "converged" = to 5e-3 of their eigenvalue; "certified" = not
     at all, and the matching is accepted per member only with a proof that no vector outside the first k could have been picked
     (else that member is solved again, tail included); "auto" = certified from order 16 000. The outputs are the same either way;
-    `nL_set[t][k:]` (not a reference output) are estimates in the certified mode.
+    `nL_set[t][k:]` (not a reference output) is NaN in the certified mode for members that were not solved again; the unconverged
+    block's Ritz values are returned as `nL_tail_ritz_estimates[t]`.
     """
     if device_ != "gpu":
         raise NotImplementedError("sclens_amd implements the device path only; use the reference for device_='cpu'")
@@ -1476,6 +1477,14 @@ def sclens(inp_df, device_="gpu", th=60, p_step=0.001, n_perturb=20, centering="
                 a_b, b_ = ses.robustness(k, n_perturb)
         res["tail_redo"] = tail_redo
         res["ensemble_tail"] = "certified" if tail_free else "converged"
+        if tail_free and pe_counts[0] > 0:
+            # certified mode: the entries k .. min_pc-1 of a member that was not solved again are Ritz values of an unconverged block
+            # (a few per cent low), not eigenvalues -- they leave `nL_set` (NaN there) and are kept under a name that says what they are
+            res["nL_tail_ritz_estimates"] = [np.asarray(v, dtype=np.float64)[k:].copy() for v in nL_set]
+            for t in range(n_perturb):
+                if t not in tail_redo and nL_set[t] is not None and len(nL_set[t]) > k:
+                    nL_set[t] = np.asarray(nL_set[t], dtype=np.float64).copy()
+                    nL_set[t][k:] = np.nan
         m_score, sd_score = _robust_scores(b_)
         rob_score = m_score
         sig_id = np.flatnonzero(rob_score > th_)

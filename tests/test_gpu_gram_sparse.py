@@ -63,7 +63,7 @@ def test_sparse_form_is_chosen_by_its_multiply_adds(ctx, opt):
     """context option gram_sparse = -1 (the default): from order gram_sparse_min_n the sparse form is taken where its multiply-adds,
     sum_i r_i^2 / 2 at the measured rate, undercut the dense product -- a 3 % dense matrix takes it, a 30 % dense one does not"""
     opt(gram_sparse=-1, gram_sparse_min_n=256, gram_bits=0)
-    kw = dict(n_perturb=2, max_search_iters=3, streams=1, ctx=ctx)
+    kw = dict(n_perturb=2, max_search_iters=5, streams=1, ctx=ctx)  # five: the smallest cap that leaves p_ < 1 (:756-760)
     Xs = api._csc_f32(synth_counts(6000, 500, seed=2, C=4, sparsity=0.97, min_genes_per_cell=5, marker_frac=0.2, marker_sd=1.5))
     Xd = api._csc_f32(synth_counts(6000, 500, seed=2, C=4, sparsity=0.70, marker_frac=0.2, marker_sd=1.5))
     assert Xs.nnz < 0.05 * 6000 * 500 and Xd.nnz > 0.25 * 6000 * 500
