@@ -32,6 +32,11 @@ for rep in range(int(os.environ.get("REPS", "2"))):  # REPS=1: counter passes (e
     out = {s: ctx.timing(s) for s in ("gram", "sytrd", "sy2sb", "sb2st", "stebz", "stein", "ormtr", "sbr_q2", "sbr_q1")}
     print(f"n={n} K={K} mvec={mvec} rep={rep} wall={wall:.3f}s", {k: round(v[0], 2) for k, v in out.items()})
 w = dw.get((n,), np.float64)
+if os.environ.get("PRINT_HASH"):  # compare variants of a back-transformation bit by bit
+    import zlib
+    Zh = dZ.get((mvec, lda), np.float32)
+    print("eigenvector block: crc32", zlib.crc32(Zh.tobytes()), "sum |z|", float(np.abs(Zh[:, :n]).sum(dtype=np.float64)),
+          "max |row norm - 1|", float(np.abs(np.sqrt((Zh[:, :n].astype(np.float64) ** 2).sum(axis=1)) - 1).max()))
 print("gram TF/s (full 2n^2K):", 2 * n * n * K / (out["gram"][0] * 1e-3) / 1e12)
 if out["sytrd"][0] > 0:
     print("sytrd algorithmic GB/s (4/3 n^3 * 4B / 2... full-matrix symv reads 4/3 n^3 B):", (4 / 3 * n**3) / (out["sytrd"][0] * 1e-3) / 1e9)
