@@ -894,6 +894,10 @@ int sbr_apply_q2(Ctx* ctx, int64_t n, float* Zt, int64_t m, int64_t ldz) {
     const int lds_bytes = 2 * Q_IMG2 * (int)sizeof(float);
     SCL_TRY(ensure_dyn_lds(ctx, reinterpret_cast<const void*>(sbr_q2_apply16e<4, 12, 2>), lds_bytes));
     hipLaunchKernelGGL((sbr_q2_apply16e<4, 12, 2>), q2grid, dim3(256), lds_bytes, ctx->stream, qa, q2img);
+  } else if (ctx->opt.q2_fp32_blocks == 16) {
+    hipLaunchKernelGGL((sbr_q2_apply16v3<16, 36>), q2grid, dim3(256), 0, ctx->stream, qa);
+  } else if (ctx->opt.q2_fp32_blocks == 12) {
+    hipLaunchKernelGGL((sbr_q2_apply16v3<12, 28>), q2grid, dim3(256), 0, ctx->stream, qa);
   } else if (ctx->opt.q2_fp32_blocks == 8) {
     // the fp32 kernel with passes of EIGHT blocks of 32 sweeps (a window of 320 rows in registers): half the window loads, stores and
     // drains of the four-block passes, as in the split kernel (round 6)
