@@ -58,7 +58,7 @@ namespace scl {
   X(chase_wgs, 0)           /* cap on its workgroups (0: one per CU) */                                                            \
   X(q2_variant, 16)         /* second back-transformation: 16 / 15 / 14 image-fed (passes of 8 / 4 blocks; one group ahead), 3 fp32 */ \
   X(q2_reference, 0)        /* 1: the unblocked reference kernel (tests) */                                                        \
-  X(q2_fp32_blocks, 16)     /* fp32 kernel of the second back-transformation: blocks of 32 sweeps per pass (4, 8, 12, 16) */       \
+  X(q2_fp32_blocks, 4)      /* fp32 Q2 kernel: blocks of 32 sweeps per pass (4, 8, 12, 16): longer is faster ALONE, 4 inside a call */  \
   X(q2_tg_early, 1)         /* its group data built on the auxiliary stream beside the inverse iteration */                        \
   X(stein_pf, 16)           /* inverse iteration: steps of loads in flight (4, 16, 32) */                                          \
   X(stein_its, 2)           /* growth-checked iterations before a vector is accepted (dstein: 3) */                                \

@@ -899,8 +899,10 @@ int sbr_apply_q2(Ctx* ctx, int64_t n, float* Zt, int64_t m, int64_t ldz) {
   } else if (ctx->opt.q2_fp32_blocks == 12) {
     hipLaunchKernelGGL((sbr_q2_apply16v3<12, 28>), q2grid, dim3(256), 0, ctx->stream, qa);
   } else if (ctx->opt.q2_fp32_blocks == 8) {
-    // the fp32 kernel with passes of EIGHT blocks of 32 sweeps (a window of 320 rows in registers): half the window loads, stores and
-    // drains of the four-block passes, as in the split kernel (round 6)
+    // the fp32 kernel with longer passes (8 / 12 / 16 blocks of 32 sweeps: a window of up to 576 rows in registers): fewer window loads,
+    // stores and drains -- 486 -> 451 / 442 / 439 ms ALONE at order 30 016 with 15 008 vectors, same bits -- but 221 .. 256 VGPRs, and
+    // inside a call, beside the twin kernel of the other stream, the call gets SLOWER (40.9 -> 41.7 / 42.1 s at cfg4,
+    // profiles/r06_q2_fp32_pass_length.log): the default stays at four blocks
     hipLaunchKernelGGL((sbr_q2_apply16v3<8, 20>), q2grid, dim3(256), 0, ctx->stream, qa);
   } else {
     hipLaunchKernelGGL((sbr_q2_apply16v3<4, 12>), q2grid, dim3(256), 0, ctx->stream, qa);
