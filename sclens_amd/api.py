@@ -993,6 +993,24 @@ class Session:
 
 
 # ----------------------------------------------------------------------------- driver
+def _needs_chunks(ctx: Context, X_, streams) -> bool:
+    """does the plain session's resident state exceed the device? (cells > genes only: chunks are chunks of cells)"""
+    if isinstance(X_, DeviceCounts):
+        return False
+    N, M = X_.shape
+    if N <= M:
+        return False
+    try:  # (the ABI has no memory-info entry point: the device's size through torch when it is there, else an MI355X's)
+        import torch
+
+        total = torch.cuda.get_device_properties(ctx.device).total_memory
+    except Exception:
+        total = 288 << 30
+    n_streams = streams if streams is not None else (3 if min(N, M) < 16000 else 2)
+    need = 56 * 2 * int(X_.nnz) + (1 + n_streams) * 4 * N * M + 8 * 2 * int(X_.nnz) + n_streams * (45 << 30)
+    return need > 0.85 * total
+
+
 def cut_with_guard_band(L: np.ndarray, lambda_c: float, guard_band: float, refine: Callable[[int, int], np.ndarray]):
     """`sum(L .> lambda_c)` (scLENS.jl:539, :541, :580) with the fp32 eigenvalues near the cut re-evaluated in float64.
 
@@ -1084,7 +1102,8 @@ def sclens(inp_df, device_="gpu", th=60, p_step=0.001, n_perturb=20, centering="
            seed: Optional[int] = None, ctx: Optional[Context] = None, max_search_iters: Optional[int] = None,
            keep_intermediates: bool = False, verbose: bool = False, shard: Optional[Shard] = None,
            partial_eig: bool = True, streams: Optional[int] = None, spread_initial: bool = True,
-           guard_band: float = 4.0, keep_warm: bool = False, ensemble_tail: str = "auto") -> Dict[str, object]:
+           guard_band: float = 4.0, keep_warm: bool = False, ensemble_tail: str = "auto",
+           chunk_rows: Optional[int] = None) -> Dict[str, object]:
     """scLENS.sclens (scLENS.jl:649-832) on one MI355X.
 
     Same keyword arguments as the reference. `draws`/`seed` expose the randomness the reference takes from
@@ -1136,7 +1155,30 @@ def sclens(inp_df, device_="gpu", th=60, p_step=0.001, n_perturb=20, centering="
     if draws is None:
         if seed is None:  # every rank must draw the same candidates, null matrix and sample seeds: rank 0's clock decides
             seed = int(shard.bcast_host(np.array([float(time.time_ns() % (2**31))]), 0)[0])
-        draws = make_draws_native(X_, int(seed))
+        draws = make_draws_native(X_, int(seed), device_candidates=chunk_rows is not None or _needs_chunks(ctx, X_, streams))
+    # A matrix whose resident forms do not fit the device (union pattern 56 B per stored entry, three scaled matrices of 4 N M bytes, the
+    # eigensolver's scratch) goes through the CHUNKED session when it has more cells than genes: the same call sequence over chunks of cells
+    # (atlas.sclens_chunked; BASELINE configs[4], 1 000 000 x 30 000, on one MI355X). `chunk_rows` forces it (tests).
+    if shard.world == 1 and N > M and not median and not isinstance(X_, DeviceCounts) and (chunk_rows is not None or _needs_chunks(ctx, X_, streams)):
+        if draws.cand_seed is None or draws.sampler is not None:
+            raise ValueError("this matrix only fits the device in chunks of cells (atlas.sclens_chunked), which draws the zero candidates and "
+                             "the samples on the device: pass draws made with make_draws_native(..., device_candidates=True) or none")
+        from . import atlas
+
+        rows = int(chunk_rows) if chunk_rows is not None else max(1, int((12 << 30) // (4 * M)))  # ~12 GB per scaled block
+        cuts = list(range(0, N, rows)) + [N]
+        Xr_, Xn_ = X_.tocsr(), _csc_f32(_resolve(draws.X_r)).tocsr()
+        res = atlas.sclens_chunked([(a, Xr_[a:b].tocsc()) for a, b in zip(cuts[:-1], cuts[1:])],
+                                   [(a, Xn_[a:b].tocsc()) for a, b in zip(cuts[:-1], cuts[1:])], draws, th=th, p_step=p_step,
+                                   n_perturb=n_perturb, ctx=ctx, max_search_iters=max_search_iters, verbose=verbose, guard_band=guard_band)
+        res.update({"cell_id": cell_id, "gene_id": gene_id})
+        if not keep_warm:
+            try:
+                ctx.release_scratch("everything")
+            except Exception:
+                pass
+            ctx.trim_pool()
+        return res
     if ensemble_tail not in ("auto", "certified", "converged"):
         raise ValueError("ensemble_tail must be 'auto', 'certified' or 'converged'")
     tail_free = bool(partial_eig) and (ensemble_tail == "certified" or (ensemble_tail == "auto" and min(N, M) >= 16000))

@@ -111,6 +111,24 @@ def test_chunked_session_two_stage_size_with_and_without_pattern_cache(ctx, opt,
         assert res["chunk_builds"] < res["chunk_visits"] / 2
 
 
+def test_sclens_dispatches_to_chunks_of_cells(ctx):
+    """api.sclens(chunk_rows=...) -- the path a matrix takes by itself when its resident forms exceed the device (1M x 30k on one MI355X):
+    the same result keys, the decisions of the plain session on the candidate list in chunk order"""
+    N, M, rows = 1500, 400, 550
+    X = api._csc_f32(synth_counts(N, M, seed=4, C=5, marker_frac=0.2, marker_sd=1.5))
+    d = api.make_draws_native(X, seed=29, device_candidates=True)
+    res = api.sclens(X, draws=d, n_perturb=4, ctx=ctx, chunk_rows=rows)
+    assert res["chunks"] == 3
+    full1, full2 = api.Pattern.drawn(ctx, X, d.cand_seed).candidates()
+    order = np.concatenate([np.flatnonzero((full1 >= a) & (full1 < min(N, a + rows))) for a in range(0, N, rows)])
+    d2 = api.Draws(full1[order], full2[order], d.X_r, d.p_th, None, d.sample_seed)
+    ref = api.sclens(X, draws=d2, n_perturb=4, ctx=ctx, streams=1)
+    _compare(res, ref)
+    assert not api._needs_chunks(ctx, X, None)  # (this one fits: only chunk_rows sent it there)
+    with pytest.raises(ValueError):  # host-side candidates cannot be replayed chunk by chunk
+        api.sclens(X, draws=d2, n_perturb=4, ctx=ctx, chunk_rows=rows)
+
+
 def test_chunked_session_argument_errors(ctx):
     N, M = 600, 250
     X = api._csc_f32(synth_counts(N, M, seed=1, C=5, marker_frac=0.2, marker_sd=1.5))

@@ -35,8 +35,13 @@ def _same(ref, res):
     assert np.array_equal(ra["a_b"], rb["a_b"]) and np.allclose(ra["b_"], rb["b_"], atol=1e-10)
     assert np.allclose(ra["rob_score"], rb["rob_score"], atol=1e-10) and np.array_equal(res["sig_id"], ref["sig_id"])
     assert res["min_pc"] == ref["min_pc"]
+    k = len(ref["signal_ev"])
     for t in range(len(ref["nL_set"])):
-        assert np.allclose(res["nL_set"][t], ref["nL_set"][t], rtol=1e-10)
+        got, want = np.asarray(res["nL_set"][t], dtype=np.float64), np.asarray(ref["nL_set"][t], dtype=np.float64)
+        have = ~np.isnan(got)  # certified mode: the tail of a member that was not solved again is NaN, its values are kept as estimates
+        assert have[:k].all() and np.allclose(got[have], want[have], rtol=1e-10)
+        if not have.all():
+            assert np.allclose(res["nL_tail_ritz_estimates"][t], want[k:], rtol=1e-10)
         assert np.allclose(np.abs(res["nV_set"][t]), np.abs(ref["nV_set"][t]), atol=1e-5)  # the fake hands out float32
     assert np.allclose(res["pca"], ref["pca"], atol=1e-5 * np.abs(ref["pca"]).max())
     assert np.allclose(res["gene_basis"], ref["gene_basis"], atol=1e-5 * np.abs(ref["gene_basis"]).max())
