@@ -186,6 +186,7 @@ struct GramBitsArgs {
   float* C;
   int64_t n, ldm, ldc;
   double Ncells, inv_div;
+  int accumulate;  // C += (chunked sessions: the Gram matrix is a sum over chunks of cells)
 };
 
 // PIPE (round 5, context option split_pipe): the stage loop as a software pipeline -- see split_mainloop_pipe; here a stage is four
@@ -379,6 +380,7 @@ __global__ __launch_bounds__(512, 2) void gram_bits_kernel(GramBitsArgs a, const
           v = (double)acc[i][j][e] * (cd * gr.x) - gr.y * gc.z - gr.z * gc.y + S2 * (gr.z * gc.z) - a.Ncells * (gr.w * gc.w);
         }
         outv[e] = (float)(v * a.inv_div);
+        if (a.accumulate && row < a.n && col <= row) outv[e] += a.C[row * a.ldc + col];  // (the mirrored entry is written from here too)
       }
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
@@ -1302,6 +1304,12 @@ size_t gram_binary_scratch_bytes(int64_t N, int64_t M) { return sizeof(unsigned 
 // B'B / divisor (the caller sums the parts over the ranks).
 int gram_binary(Ctx* ctx, const PatternDev& p, const float* val, int f32path, void* scratch, float divisor, float* A, int64_t lda,
                 const ShardReduce* sh) {
+  return gram_binary_stats(ctx, p, val, f32path, nullptr, scratch, divisor, A, lda, sh, false);
+}
+// given != nullptr: the statistics are the caller's (a chunk of cells of a chunked session: per-gene vectors of ALL cells, per-cell
+// vectors of the chunk, srow = 1 / l and cent = 0 -- the chunk's U'U, see scale.hip "chunked variant"); accumulate: A += the product
+int gram_binary_stats(Ctx* ctx, const PatternDev& p, const float* val, int f32path, const ScaleStats* given, void* scratch, float divisor,
+                      float* A, int64_t lda, const ShardReduce* sh, bool accumulate) {
   const int64_t N = p.N, M = p.M, ldm = round_up(N, 64);
   const int nw = ctx->opt.eff_gram_bits_terms();  // fp16 pieces of the cell weights: 22 bits (default) or 33 (always with precision = 0)
   hipStream_t st = ctx->stream;
@@ -1316,7 +1324,8 @@ int gram_binary(Ctx* ctx, const PatternDev& p, const float* val, int f32path, vo
   {
     StageTimer tm(ctx, "scale");
     ScaleStats ss;
-    if (sh && sh->on()) SCL_TRY(scale_stats_sharded(ctx, p, val, f32path, *sh, &ss));
+    if (given) ss = *given;
+    else if (sh && sh->on()) SCL_TRY(scale_stats_sharded(ctx, p, val, f32path, *sh, &ss));
     else SCL_TRY(scale_stats(ctx, p, val, f32path, 0, &ss));
     hipLaunchKernelGGL(k_cell_weights, dim3((unsigned)nparts), dim3(256), 0, st, N, ss.tgc, ss.srow, f32path, w, sa, wpart);
     hipLaunchKernelGGL(k_weight_scale, dim3(1), dim3(1024), 0, st, wpart, nparts, ss.srow, N, sc);
@@ -1331,12 +1340,12 @@ int gram_binary(Ctx* ctx, const PatternDev& p, const float* val, int f32path, vo
     SCL_HIP(ctx, hipGetLastError());
   }
   StageTimer tm(ctx, "gram");
-  SCL_HIP(ctx, hipMemsetAsync(A, 0, sizeof(float) * (size_t)M * lda, st));
+  if (!accumulate) SCL_HIP(ctx, hipMemsetAsync(A, 0, sizeof(float) * (size_t)M * lda, st));
   const int64_t bm = (M + 255) / 256;
   const int2* tiles = nullptr;
   int64_t nb = 0;
   SCL_TRY(big_tile_list(ctx, bm, bm, 1, &tiles, &nb));
-  GramBitsArgs a{Pm, wq, gv, sc, A, M, ldm, lda, (double)N, 1.0 / (double)divisor};
+  GramBitsArgs a{Pm, wq, gv, sc, A, M, ldm, lda, (double)N, 1.0 / (double)divisor, accumulate ? 1 : 0};
   return nw == 3 ? launch_gram_bits<3>(ctx, a, tiles, nb) : launch_gram_bits<2>(ctx, a, tiles, nb);
 }
 

@@ -138,6 +138,8 @@ size_t gram_binary_scratch_bytes(int64_t N, int64_t M);
 struct ShardReduce;
 int gram_binary(Ctx* ctx, const PatternDev& p, const float* val, int f32path, void* scratch, float divisor, float* A, int64_t lda,
                 const ShardReduce* sh = nullptr);
+int gram_binary_stats(Ctx* ctx, const PatternDev& p, const float* val, int f32path, const ScaleStats* given, void* scratch, float divisor,
+                      float* A, int64_t lda, const ShardReduce* sh, bool accumulate);
 int scale_stats_sharded(Ctx* ctx, const PatternDev& p, const float* val, int f32path, const ShardReduce& sh, ScaleStats* out);
 
 // the same for a session that holds p.N of sh.N_global cells (N > M layout: B[j][i_local]); mean centring only
@@ -150,7 +152,8 @@ int chunk_pass_var(Ctx* ctx, const PatternDev& p, const float* val, int f32path,
 int chunk_stats_finish(Ctx* ctx, int64_t M, const double* acc, const double* acc_s2, double n_global, int f32path, double* mean, double* stdv,
                        double* mu, double* red);
 int chunk_dense(Ctx* ctx, const PatternDev& p, const float* val, int f32path, const double* stdv, const double* mu, const double* red, double num,
-                const double* cent, double* accT, float* B, int64_t ldb, double** tgc_out, double** l2_out, double** lg_out = nullptr);
+                const double* cent, double* accT, float* B, int64_t ldb, double** tgc_out, double** l2_out, double** lg_out = nullptr,
+                double** srow_out = nullptr);
 int chunk_gram_finish(Ctx* ctx, float* A, int64_t n, int64_t lda, const double* T, const double* stdv, const double* mu, double n_global,
                       double divisor, double* cent);
 

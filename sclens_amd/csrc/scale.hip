@@ -666,7 +666,8 @@ int chunk_stats_finish(Ctx* ctx, int64_t M, const double* acc, const double* acc
 // num = 1, cent = zeros: the unit-row form U of pass 3, together with accT[0..M) += sum_i lg_ij / l_i, accT[M] += sum_i 1 / l_i,
 // accT[M + 1] += sum_i l_i (accT != nullptr); num = c = mean(l), cent = the finished centring vector: the scaled matrix itself.
 int chunk_dense(Ctx* ctx, const PatternDev& p, const float* val, int f32path, const double* stdv, const double* mu, const double* red,
-                double num, const double* cent, double* accT, float* B, int64_t ldb, double** tgc_out, double** l2_out, double** lg_out) {
+                double num, const double* cent, double* accT, float* B, int64_t ldb, double** tgc_out, double** l2_out, double** lg_out,
+                double** srow_out) {
   const int64_t N = p.N, M = p.M;
   SCL_WS(ctx, part, double, "sc.part", 2 * M + 8);
   SCL_WS(ctx, l2, double, "sc.l2", N);
@@ -690,6 +691,7 @@ int chunk_dense(Ctx* ctx, const PatternDev& p, const float* val, int f32path, co
   if (tgc_out) *tgc_out = tgc;
   if (l2_out) *l2_out = l2;
   if (lg_out) *lg_out = lg;
+  if (srow_out) *srow_out = srow;
   return SCLENS_OK;
 }
 // cent_j = (c T_j / std_j - mu_j c T_M) / N with c = T_{M+1} / N (all on the device: no host round trip), then

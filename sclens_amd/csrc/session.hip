@@ -842,19 +842,28 @@ static int chunked_gram(Session* s, const MatSpec& ms, float divisor, ScaleVecs*
       if (rc == SCLENS_OK && pass == 0) rc = chunk_pass_sum(ctx, p, val, ms.f32path, acc);
       if (rc == SCLENS_OK && pass == 1) rc = chunk_pass_var(ctx, p, val, ms.f32path, acc, ng, acc2);
       if (rc == SCLENS_OK && pass == 2) {
-        double *tgc = nullptr, *l2 = nullptr, *lg = nullptr;
-        const bool sparse = ctx->opt.gram_sparse != 0 && p.nU < 0x7FFFFFFFll &&  // no dense block at all
+        double *tgc = nullptr, *l2 = nullptr, *lg = nullptr, *srow = nullptr;
+        // a binarised matrix: the chunk's U'U as the exact co-occurrence product (gram_bits.hip), under the switch of the plain session
+        const int gbc = ctx->opt.eff_gram_binary();
+        const bool bits = ms.binary && (gbc == 1 || (gbc < 0 && s->n >= ctx->opt.gram_bits_min_n)) &&
+                          gram_binary_scratch_bytes(p.N, M) <= sizeof(float) * (size_t)s->n * (size_t)s->ldb;
+        const bool sparse = !bits && ctx->opt.gram_sparse != 0 && p.nU < 0x7FFFFFFFll &&  // no dense block at all
                             (ctx->opt.gram_sparse == 1 || (s->n >= ctx->opt.gram_sparse_min_n && gram_sparse_pays(ctx, p, s->n, p.N)));
         {
           StageTimer tm(ctx, "scale");
-          rc = chunk_dense(ctx, p, val, ms.f32path, st->stdv, st->mu, st->red, 1.0, zero, accT, sparse ? nullptr : s->Btmp, s->ldb, &tgc, &l2, &lg);
+          rc = chunk_dense(ctx, p, val, ms.f32path, st->stdv, st->mu, st->red, 1.0, zero, accT, (sparse || bits) ? nullptr : s->Btmp, s->ldb, &tgc, &l2,
+                           &lg, &srow);
         }
         if (rc == SCLENS_OK && keep) {
           hipError_t e1 = hipMemcpyAsync(keep->tgc + set[g].row0, tgc, sizeof(double) * set[g].N, hipMemcpyDeviceToHost, stq);
           hipError_t e2 = hipMemcpyAsync(keep->norm_tgc + set[g].row0, l2, sizeof(double) * set[g].N, hipMemcpyDeviceToHost, stq);
           if (e1 != hipSuccess || e2 != hipSuccess) rc = ctx->fail(SCLENS_ERR_HIP, "chunked session: rec_vals copy failed");
         }
-        if (rc == SCLENS_OK && sparse) {  // the chunk's U'U / divisor from its sparse structure (c = 1, no cent term: applied at the end)
+        if (rc == SCLENS_OK && bits) {
+          const ScaleStats cs{tgc, lg, mean, st->stdv, st->mu, l2, srow, zero, st->red};  // srow = 1 / l, cent = 0: the chunk's U'U
+          rc = gram_binary_stats(ctx, p, val, ms.f32path, &cs, s->Btmp, divisor, A, s->lda, nullptr, g > 0);
+          if (rc == SCLENS_OK) ctx->gram_bits_used += 1;
+        } else if (rc == SCLENS_OK && sparse) {  // the chunk's U'U / divisor from its sparse structure (c = 1, no cent term: applied at the end)
           rc = gram_sparse(ctx, p, val, ms.f32path, tgc, lg, st->stdv, st->mu, l2, nullptr, nullptr, 1.0, 1.0 / (double)divisor, 0.0, A, s->lda, g > 0);
           if (rc == SCLENS_OK) ctx->gram_sparse_used += 1;
         } else if (rc == SCLENS_OK) {
