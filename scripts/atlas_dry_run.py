@@ -1,9 +1,10 @@
 """Atlas configuration (BASELINE.json configs[4]: 1M cells x 30k genes on 8 GPUs) -- dry run of ONE rank on one
-GPU: rank 0's slab of 125 000 cells is generated chunk-wise (`synth_counts_rows`, never dense on the host) and goes through
+GPU: rank 0's slab of 125 000 cells (`sclens_amd.atlas.synth_slabs`: generated chunk-wise, never dense on the host) goes through
 the row-sharded session in the atlas mode (`sclens_hip_session_create_sharded_drawn`: this rank's candidates drawn on the device;
 search / ensemble in rounds of `world`, this rank decomposing one evaluation per round) with the inter-rank exchange STUBBED (the
 callbacks count calls and bytes and multiply the buffer by the number of ranks, as if all ranks held this slab: no data moves), so
-the numbers are this rank's compute time and HBM footprint; the spectra are those of 8 copies of the slab and are not checked. Usage: atlas_dry_run.py [N_total world out.json]"""
+the numbers are this rank's compute time and HBM footprint of the 8-GPU form. (The matrix itself is checked against float64 on ONE GPU through the
+chunked session: tests/test_gpu_chunked.py, scripts/atlas_chunked_run.py.) Usage: atlas_dry_run.py [N_total world out.json]"""
 import json
 import os
 import sys
@@ -24,7 +25,6 @@ def raw_device_tensor(dev_ptr, count, typestr, device):
 
     return torch.as_tensor(_Raw(), device=device)
 
-from sclens_amd.synth import synth_counts_rows
 
 N_total = int(sys.argv[1]) if len(sys.argv) > 1 else 1_000_000
 world = int(sys.argv[2]) if len(sys.argv) > 2 else 8
@@ -41,29 +41,11 @@ t0 = time.perf_counter()
 
 
 def cached_slab():
-    """the seeded slab, kept as an .npz in SCLENS_BENCH_CACHE (default: the temp dir; "0" disables) like bench.py's matrices, so that
-    a second run on one box does not spend 77 s regenerating it"""
-    import tempfile
+    """rank 0's slab of the seeded atlas matrix, from the slab files of sclens_amd.atlas.synth_slabs (SCLENS_BENCH_CACHE, default the temp
+    dir): generated once per box by as many processes as memory allows and shared with tests/test_gpu_chunked.py's cfg5 case"""
+    from sclens_amd import atlas
 
-    import scipy.sparse as sp
-
-    d = os.environ.get("SCLENS_BENCH_CACHE", tempfile.gettempdir())
-    path = os.path.join(d, f"sclens_atlas_slab_v1_{N_total}x{M}_{r0}_{r1}.npz") if d not in ("", "0") else None
-    if path and os.path.exists(path):
-        try:
-            z = np.load(path)
-            return sp.csc_matrix((z["data"], z["indices"], z["indptr"]), shape=(r1 - r0, M))
-        except Exception as e:
-            print(f"[atlas] ignoring cache {path}: {e}", file=sys.stderr)
-    Xs = synth_counts_rows(N_total, M, 20240427 + 4, r0, r1)
-    if path:
-        try:
-            tmp = f"{path}.{os.getpid()}.tmp.npz"
-            np.savez(tmp, data=Xs.data, indices=Xs.indices, indptr=Xs.indptr)
-            os.replace(tmp, path)
-        except OSError as e:
-            print(f"[atlas] slab not cached ({e})", file=sys.stderr)
-    return Xs
+    return atlas.synth_slabs(N_total, M, 20240427 + 4, world).slab(0)
 
 
 X = api._csc_f32(cached_slab())
