@@ -681,3 +681,32 @@ def test_multi_rank_corner_cases(ctx):
     outn = _run_ranks(Xn, dn, 3, ctx.device, n_perturb=3, max_search_iters=5, streams=2)
     assert len(outn[0].get("signal_ev", [])) == len(refn.get("signal_ev", []))
     assert np.array_equal(outn[0]["L"], refn["L"]) and all(o["p_"] == refn["p_"] for o in outn)
+
+
+def test_default_call_hands_its_device_memory_back(ctx):
+    """`keep_warm=False` (the default) must leave nothing of the call on the device -- the caller's context outlives the call, so
+    its grow-only workspaces go back to the pool first (release_scratch "everything") and the pool's idle blocks to the driver after
+    that (sclens_hip_trim): the library's live bytes are what they were before the call, its idle cache is empty. With keep_warm=True the
+    blocks stay cached for the next call of the same shape."""
+    import ctypes as C
+
+    from sclens_amd._lib import Context
+
+    def stats():
+        c, l, h, m = C.c_int64(0), C.c_int64(0), C.c_int64(0), C.c_int64(0)
+        assert ctx.lib.sclens_hip_pool_stats(ctx.device, C.byref(c), C.byref(l), C.byref(h), C.byref(m)) == 0
+        return c.value, l.value
+
+    X = api._csc_f32(synth_counts(900, 400, seed=1, C=5, marker_frac=0.2, marker_sd=1.5))
+    c2 = Context(ctx.device)
+    try:
+        ctx.trim_pool()
+        _, live0 = stats()
+        api.sclens(X, draws=api.make_draws_native(X, seed=3), n_perturb=3, ctx=c2, streams=2, keep_warm=True)
+        cached_w, live_w = stats()
+        assert cached_w > 0 and live_w > live0  # warm: the call's blocks wait in the pool, the context keeps its workspaces
+        api.sclens(X, draws=api.make_draws_native(X, seed=3), n_perturb=3, ctx=c2, streams=2)
+        cached, live = stats()
+        assert cached == 0 and live == live0, (cached, live, live0)
+    finally:
+        c2.close()
