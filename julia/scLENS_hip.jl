@@ -154,7 +154,8 @@ function sclens_hip_device(inp_df; th=60, p_step=0.001, n_perturb=20, centering=
     z1 = UInt32[s[1] - 1 for s in nzz_]; z2 = UInt32[s[2] - 1 for s in nzz_]
     X_r = scLENS.df2sparr(scLENS.random_nz(inp_df, rmix=true))                # R2 (:701)
     cp, rv, nz = csc0(X_); rcp, rrv, rnz = csc0(X_r)
-    result = with_ctx(device) do ctx
+    try
+    return with_ctx(device) do ctx
         check(ctx, ccall((:sclens_hip_set_option, LIB), Cint, (Ptr{Cvoid}, Cstring, Int64), ctx, "precision", precision))
         ses = Ref{Ptr{Cvoid}}(C_NULL)
         GC.@preserve cp rv nz z1 z2 check(ctx, ccall((:sclens_hip_session_create, LIB), Cint,
@@ -267,10 +268,12 @@ function sclens_hip_device(inp_df; th=60, p_step=0.001, n_perturb=20, centering=
             ccall((:sclens_hip_session_destroy, LIB), Cvoid, (Ptr{Cvoid},), s)
         end
     end
-    # AFTER with_ctx has destroyed the context: only then are its named workspaces (24 GB of partial-eigensolver images, the vector
-    # blocks, the re-grown eigensolver scratch) back in the pool's idle cache, and the trim hands everything to the driver
-    keep_warm || ccall((:sclens_hip_trim, LIB), Cint, (Cint,), device)
-    return result
+    finally
+        # AFTER with_ctx has destroyed the context (also when the call throws): only then are its named workspaces (24 GB of
+        # partial-eigensolver images, the vector blocks, the re-grown eigensolver scratch) back in the pool's idle cache, and the trim
+        # hands everything to the driver
+        keep_warm || ccall((:sclens_hip_trim, LIB), Cint, (Cint,), device)
+    end
 end
 
 end # module
