@@ -69,7 +69,7 @@ namespace scl {
   X(host_pattern, 0)        /* 1: sparse pattern built on the host (tests compare the two builders) */                             \
   X(val_csr, 1)             /* CSR-ordered companion copies of the value arrays */                                                 \
   X(chunk_cache_gb, -1)     /* chunked session: device memory for chunk patterns kept between visits (the rest are rebuilt);       \
-                               -1: the device's memory less 180 GB for everything else (108 GB on an MI355X) */                     \
+                               -1: the device's memory less 200 GiB for everything else (88 GiB on an MI355X) */                     \
   X(gemm_force, 0)          /* tests: 1 the large-tile kernels on small shapes, 2 the 128 x 128 kernel on every shape */           \
   X(panel_prof, 0) X(chase_prof, 0) X(q2_prof, 0) /* per-phase shader clocks on stderr (diagnostic builds of the same kernels) */  \
   X(debug, 0)

@@ -756,9 +756,10 @@ static int chunk_pattern(Session* s, int set, int cands, int g, ChunkPatRef* ref
   pool_stats(ctx->device, nullptr, &live1, nullptr, nullptr);
   e->bytes = live1 > live0 ? live1 - live0 : 0;
   size_t budget = (size_t)std::max<int64_t>(0, ctx->opt.chunk_cache_gb) << 30;
-  if (ctx->opt.chunk_cache_gb < 0) {  // auto: what the device has beyond the working set of a visit + the gene side (measured 133 - 147 GB
-    size_t fr = 0, tot = 0;           // at 1M x 30k: 273 GB live at the peak with 126 GB of patterns, 196 GB with 63 GB)
-    budget = (hipMemGetInfo(&fr, &tot) == hipSuccess && tot > ((size_t)180 << 30)) ? tot - ((size_t)180 << 30) : 0;
+  if (ctx->opt.chunk_cache_gb < 0) {  // auto: what the device has beyond the working set of a visit + the gene side (measured at 1M x 30k:
+    size_t fr = 0, tot = 0;           // 273 GB live at the peak with 126 GB of patterns, 275 / 247 GB with 105 GB at precision 1 / 0,
+                                      // 196 GB with 63 GB): the device (288 GiB) less 200 GiB = four union patterns of 21 GB
+    budget = (hipMemGetInfo(&fr, &tot) == hipSuccess && tot > ((size_t)200 << 30)) ? tot - ((size_t)200 << 30) : 0;
   }
   if (s->pcache_bytes + e->bytes <= budget) {
     s->pcache.push_back(e);
