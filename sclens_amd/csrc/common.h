@@ -32,6 +32,7 @@ namespace scl {
   X(gram_bits_strict, 1)    /* precision = 0: the Gram matrix of a BINARISED matrix still as the exact co-occurrence product, with   \
                                33-bit cell weights (no operand narrower than fp32: the 0/1 pattern is exact in fp16); 0: fp32 product */ \
   X(gram_split_min_n, 16000) /* dense Gram products from split operands from this order (0: never) */                              \
+  X(gram_ksplit, 32768)     /* dense fp32 Gram products longer than 1.5 x this in slices of this many cells, added once (0: one chain) */ \
   X(gram_sparse, -1)        /* Gram matrices of cells > genes matrices from their sparse structure (gram_sparse.hip): 1 always,     \
                                0 never, -1 from gram_sparse_min_n AND where its multiply-adds (sum r_i^2 / 2) at the measured 4.3e11 \
                                per second undercut the dense product (131 / 366 TF/s): below ~7 % / ~4.5 % density at 100k x 30k */   \

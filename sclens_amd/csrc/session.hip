@@ -13,6 +13,8 @@
 
 namespace scl {
 
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+
 // ------------------------------------------------------------------------------------------------ ctx
 void* Ctx::workspace(const std::string& name, size_t bytes) {
   auto it = ws.find(name);
@@ -94,6 +96,16 @@ int reverse_rows_f32(Ctx* ctx, const float* in, int64_t rows, int64_t cols, int6
   return SCLENS_OK;
 }
 
+// y += x, both n x lda fp32 with lda a multiple of 4 (the padding is zero on both sides): one rounding per entry
+__global__ void k_add_f32(const float* __restrict__ x, int64_t n, float* __restrict__ y) {
+  const int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+  if (i + 3 < n) {
+    f32x4_t a = *reinterpret_cast<const f32x4_t*>(x + i), b = *reinterpret_cast<const f32x4_t*>(y + i);
+    *reinterpret_cast<f32x4_t*>(y + i) = a + b;
+  } else {
+    for (int64_t q = i; q < n; ++q) y[q] += x[q];
+  }
+}
 // allow_split = false: the per-call drop-ins of the reference's functions (`_wishart_matrix`, `get_eigvec`) -- a caller that asks
 // for THE fp32 product gets it at every size unless the context option gram_bits = 1 asks for the accelerated form explicitly
 int gram_f32(Ctx* ctx, const float* B, int64_t n, int64_t K, int64_t ldb, float divisor, float* A, int64_t lda, bool allow_split,
@@ -118,6 +130,31 @@ int gram_f32(Ctx* ctx, const float* B, int64_t n, int64_t K, int64_t ldb, float 
   g.ldp = ldb; g.ldq = ldb; g.ldc = lda;
   g.alpha = 1.0f / divisor; g.beta = accumulate ? 1.f : 0.f;
   g.q_kcontig = 1; g.lower = 1; g.colabsmax = nullptr;
+  // A long contraction in slices (context option gram_ksplit, default 32 768): every accumulator of the fp32 product is ONE chain of K
+  // additions, and once it has grown the small terms of a dense scaled matrix (its background -s_i mu_j - cent_j) drop out of its
+  // mantissa -- at K = 100 000 the diagonal entries of sparsely expressed genes come out up to 8e-4 low (round 6,
+  // profiles/r06_gram_sparse_ab_cfg4.log). Slices are formed on their own and added with one rounding each: the chain is K / slices long.
+  const int64_t ks = ctx->opt.gram_ksplit;
+  if (ks >= 1024 && K > ks + ks / 2 && n >= 1024) {
+    float* part = static_cast<float*>(ctx->workspace("gram.kpart", sizeof(float) * (size_t)n * lda));
+    if (!part) return SCLENS_ERR_OOM;
+    const int64_t step = round_up(ks, 32);
+    for (int64_t k0 = 0; k0 < K; k0 += step) {
+      const bool direct = k0 == 0 && !accumulate;  // the first slice of a fresh product goes straight to A
+      if (!direct) SCL_HIP(ctx, hipMemsetAsync(part, 0, sizeof(float) * (size_t)n * lda, ctx->stream));
+      g.P = B + k0; g.Q = B + k0;
+      g.K = std::min(step, K - k0);
+      g.C = direct ? A : part;
+      g.beta = 0.f;
+      SCL_TRY(gemm_f32(ctx, g));
+      if (!direct) {
+        const int64_t cnt = n * lda;
+        hipLaunchKernelGGL(k_add_f32, dim3((unsigned)((cnt / 4 + 255) / 256)), dim3(256), 0, ctx->stream, part, cnt, A);
+        SCL_HIP(ctx, hipGetLastError());
+      }
+    }
+    return SCLENS_OK;
+  }
   return gemm_f32(ctx, g);
 }
 
@@ -868,7 +905,20 @@ static int chunked_gram(Session* s, const MatSpec& ms, float divisor, ScaleVecs*
           rc = gram_sparse(ctx, p, val, ms.f32path, tgc, lg, st->stdv, st->mu, l2, nullptr, nullptr, 1.0, 1.0 / (double)divisor, 0.0, A, s->lda, g > 0);
           if (rc == SCLENS_OK) ctx->gram_sparse_used += 1;
         } else if (rc == SCLENS_OK) {
-          rc = gram_f32(ctx, s->Btmp, M, set[g].N, s->ldb, divisor, A, s->lda, true, g > 0);
+          // every chunk's product is formed on its own and added to the sum in ONE fp32 addition per entry: started from the running
+          // sum (accumulators loaded from A), the small terms of a chunk would be added to an accumulator that already holds the
+          // contributions of all earlier chunks and drop out of its fp32 mantissa (the bias of a long fp32 chain)
+          float* target = A;
+          if (g > 0) {
+            target = static_cast<float*>(ctx->workspace("ck.Atmp", sizeof(float) * (size_t)s->n * s->lda));
+            if (!target) rc = SCLENS_ERR_OOM;
+          }
+          if (rc == SCLENS_OK) rc = gram_f32(ctx, s->Btmp, M, set[g].N, s->ldb, divisor, target, s->lda, true, false);
+          if (rc == SCLENS_OK && g > 0) {
+            const int64_t cnt = s->n * s->lda;
+            hipLaunchKernelGGL(k_add_f32, dim3((unsigned)((cnt / 4 + 255) / 256)), dim3(256), 0, ctx->stream, target, cnt, A);
+            if (hipGetLastError() != hipSuccess) rc = ctx->fail(SCLENS_ERR_HIP, "chunked session: k_add_f32 launch failed");
+          }
         }
       }
       chunk_pattern_done(s, &ref);
