@@ -144,12 +144,12 @@ def _cfg4_matrix(synth_seed, N, M):
 @pytest.mark.parametrize("precision", [0, 1])
 def test_search_statistic_of_single_evaluations_against_the_float64_arbiter(ctx, precision):
     """The first oracle-grade check of the BOTTOM-HALF eigenvectors at n = 30 000 (scLENS.jl:733-747): the two evaluations of the sparsity
-    search at cfg4 for which the float64 arbiter has been run (seeds 1017 and 1019, evaluation 13: the ones where the two arithmetic
-    variants ended the search one evaluation apart in rounds 4 / 5) are replayed through the C ABI -- same matrix, same candidate draw,
+    search at cfg4 for which the float64 arbiter has been run (seeds 1017 and 1019, evaluation 13, and seed 1002, evaluation 15: the ones
+    where the two arithmetic variants ended the search apart in rounds 4 / 5 / 6) are replayed through the C ABI -- same matrix, same candidate draw,
     same sample -- and the five smallest column maxima of |Vr2' nV_2| are compared with the float64 ones. The statistic is an extreme
     value over ~15 000 columns of eigenvectors whose eigenvalues are ~5e-5 apart: fp32 determines it to ~1e-3 (measured 1e-4 .. 7e-4
     between the two variants), which is the tolerance; on which SIDE of p_th the second smallest lands is reported, not asserted -- the
-    float64 value itself sits 3e-5 (seed 1019) / 1.6e-4 (seed 1017) below it."""
+    float64 value itself sits 3e-5 (seed 1019) / 1.6e-4 (seed 1017) / 1.1e-4 (seed 1002) below it."""
     import json
 
     fx = json.load(open(SEARCH_F64))
