@@ -43,9 +43,21 @@ t0 = time.perf_counter()
 def cached_slab():
     """rank 0's slab of the seeded atlas matrix, from the slab files of sclens_amd.atlas.synth_slabs (SCLENS_BENCH_CACHE, default the temp
     dir): generated once per box by as many processes as memory allows and shared with tests/test_gpu_chunked.py's cfg5 case"""
+    import shutil
+    import tempfile
+
     from sclens_amd import atlas
 
-    return atlas.synth_slabs(N_total, M, 20240427 + 4, world).slab(0)
+    d = os.environ.get("SCLENS_BENCH_CACHE", tempfile.gettempdir())
+    try:
+        room = d not in ("", "0") and shutil.disk_usage(d).free > 8.5 * N_total * M * 0.11  # the data slabs: 8 bytes per stored entry
+    except OSError:
+        room = False
+    if room:
+        return atlas.synth_slabs(N_total, M, 20240427 + 4, world).slab(0)
+    from sclens_amd.synth import synth_counts_rows  # no room for the slab files: this rank's slab alone, not kept
+
+    return synth_counts_rows(N_total, M, 20240427 + 4, r0, r1)
 
 
 X = api._csc_f32(cached_slab())
