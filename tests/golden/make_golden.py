@@ -53,6 +53,31 @@ def run_case(name, X, seed, n_perturb, centering="mean"):
           f"{os.path.getsize(path) / 1e6:.2f} MB")
 
 
+def run_case_native(name, X, seed, n_perturb):
+    """the same for a matrix whose injected samples would not fit a fixture (3838 x 9083: 1e7 sampled indices): every draw comes from the
+    library's own seeded generators (api.make_draws_native(..., host_sampler=True): C++ host code, no GPU), which the test regenerates
+    from the seed -- the fixture holds the input matrix, the seed and the oracle's outputs"""
+    from sclens_amd import api
+
+    X = sp.csc_matrix(X)
+    d = api.make_draws_native(api._csc_f32(X), seed=seed, host_sampler=True)
+    od = O.Draws(api._resolve(d.z_idx1), api._resolve(d.z_idx2), api._resolve(d.X_r), d.p_th, d.sampler)
+    res = O.sclens(X, od, n_perturb=n_perturb, keep_intermediates=False, null_tol=O.NULL_DROP)
+    rob = res["robustness_scores"]
+    out = dict(N=X.shape[0], M=X.shape[1], indptr=X.indptr.astype(np.int64), indices=X.indices.astype(np.int32), data=X.data.astype(np.float32),
+               seed=np.int64(seed), n_perturb=np.int64(n_perturb), p_th=np.float64(d.p_th), n_cand=np.int64(len(od.z_idx1)),
+               L=res["L"], n_L_mp=np.int64(len(res["L_mp"])), lambda_c=np.float64(res["lambda_c"]), signal_ev=res["signal_ev"],
+               signal_evec=res["signal_evec"].astype(np.float32), p_=np.float64(res["p_"]), n_search=np.int64(res["n_search"]),
+               search_trace=np.array([a for _, a in res["search_trace"]]), a_b=rob["a_b"], b_=rob["b_"], rob_score=rob["rob_score"],
+               sig_id=res["sig_id"], nL_set=np.array(res["nL_set"]), mp_pass=np.bool_(res["pass"]), ks_static=np.float64(res["ks_static"]),
+               gene_basis=res["gene_basis"].astype(np.float32), rec_TGC=res["rec_vals"]["TGC"], rec_mat2_mean=res["rec_vals"]["mat2_mean"],
+               rec_mat2_std=res["rec_vals"]["mat2_std"], rec_norm_tgc=res["rec_vals"]["norm_tgc"], rec_cent=res["rec_vals"]["cent_"])
+    path = os.path.join(HERE, name + ".npz")
+    np.savez_compressed(path, **out)
+    print(name, X.shape, "k =", len(res["signal_ev"]), "sig_id =", res["sig_id"], "S =", res["n_search"], "p_ =", res["p_"],
+          f"{os.path.getsize(path) / 1e6:.2f} MB")
+
+
 def known_answer_spectra():
     """Analytic MP cases for _mp_calculation/_tw: white Wishart -> 0 signals; rank-3 spikes above the BBP threshold -> 3."""
     rng = np.random.default_rng(42)
@@ -109,6 +134,14 @@ def main():
         Xq, genes, cells = O.preprocess_counts(df.iloc[:, 1:].to_numpy(dtype=np.float32), list(df.columns[1:]))
         print("z_data_785 after QC:", Xq.shape)
         run_case("zheng_785", sp.csc_matrix(Xq), seed=11, n_perturb=5)
+    ref2 = "/root/reference/data/Real_Zheng_data/z_data_3869.csv.gz"  # BASELINE.md's closest analogue of the missing Z8eq (8 balanced types)
+    if want("zheng_3869") and os.path.exists(ref2):
+        import pandas as pd
+
+        df = pd.read_csv(ref2)
+        Xq, genes, cells = O.preprocess_counts(df.iloc[:, 1:].to_numpy(dtype=np.float32), list(df.columns[1:]))
+        print("z_data_3869 after QC:", Xq.shape)
+        run_case_native("zheng_3869", sp.csc_matrix(Xq), seed=17, n_perturb=6)
 
 
 if __name__ == "__main__":

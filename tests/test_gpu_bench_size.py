@@ -84,6 +84,33 @@ GOLDEN_SPECTRA = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golde
 
 
 @pytest.mark.parametrize("precision", [1, 0])
+def test_cfg3_spectrum_against_float64(ctx, precision):
+    """the same check as below at BASELINE configs[2] (50 000 x 30 000), when its fixture exists (scripts/f64_spectra.py cfg3)"""
+    path = os.path.join(os.path.dirname(GOLDEN_SPECTRA), "cfg3_f64_spectra.npz")
+    if not os.path.exists(path):
+        pytest.skip("tests/golden/cfg3_f64_spectra.npz not generated (scripts/f64_spectra.py cfg3)")
+    z = np.load(path)
+    N, M = int(z["N"]), int(z["M"])
+    X = _cfg4_matrix(int(z["synth_seed"]), N, M, cfg="cfg3")
+    assert int(X.nnz) == int(z["nnz"])
+    c2 = Context(ctx.device)
+    c2.set_option("precision", precision)
+    try:
+        res = api.sclens(X, draws=api.make_draws_native(X, seed=int(z["draw_seed"]), device_candidates=True), ctx=c2, n_perturb=2,
+                         max_search_iters=5, streams=1, keep_intermediates=True)
+    finally:
+        c2.close()
+    lmax = float(z["L"][-1])
+    tol = 4.0 * np.sqrt(M) * 5.96e-8 * lmax
+    err = float(np.abs(res["L"] - z["L"]).max())
+    print(f"[cfg3 spectrum, precision {precision}] max |L - L64| / lambda_max = {err / lmax:.2e}; lambda_c {res['lambda_c']:.9f} vs {float(z['lambda_c']):.9f}; "
+          f"k {len(res['signal_ev'])} vs {int(z['k'])}")
+    assert err < tol and abs(res["lambda_c"] - float(z["lambda_c"])) < 2e-5 * float(z["lambda_c"]) and len(res["signal_ev"]) == int(z["k"])
+    if "Lr" in res:
+        assert np.abs(np.asarray(res["Lr"]) - z["Lr"]).max() < tol
+
+
+@pytest.mark.parametrize("precision", [1, 0])
 def test_spectrum_of_the_shipped_arithmetic_against_float64(ctx, precision):
     """cfg4 (100 000 x 30 000, the bench's matrix and the draws of its first timed step): eigenvalues of the data and null Wishart
     matrices, lambda_c and the retained-signal count of the device path -- with the split-fp16 products (precision = 1, what bench.py
@@ -122,13 +149,13 @@ def test_spectrum_of_the_shipped_arithmetic_against_float64(ctx, precision):
 SEARCH_F64 = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "cfg4_search_step_f64.json")
 
 
-def _cfg4_matrix(synth_seed, N, M):
+def _cfg4_matrix(synth_seed, N, M, cfg="cfg4"):
     """the bench's matrix, from bench.py's per-box cache when it is there (64 s of synthesis otherwise)"""
     import tempfile
 
     import scipy.sparse as sp
 
-    path = os.path.join(os.environ.get("SCLENS_BENCH_CACHE", tempfile.gettempdir()), f"sclens_bench_v2_cfg4_{N}x{M}_{synth_seed}.npz")
+    path = os.path.join(os.environ.get("SCLENS_BENCH_CACHE", tempfile.gettempdir()), f"sclens_bench_v2_{cfg}_{N}x{M}_{synth_seed}.npz")
     if os.path.exists(path):
         z = np.load(path)
         return api._csc_f32(sp.csc_matrix((z["data"], z["indices"], z["indptr"]), shape=(N, M)))
