@@ -647,6 +647,7 @@ int sclens_hip_dev_eigh_f32(sclens_hip_ctx* h, float* A, int64_t n, int64_t lda,
   return scl::eigh_f32(&h->c, A, n, lda, w, vec_lo, vec_hi, Zt, ldz);
 }
 int sclens_hip_trim(int device_id) {
+  scl::stein_shared_release(device_id, nullptr);  // the device-wide inverse-iteration block is idle between its users' kernels
   scl::pool_trim(device_id);
   return SCLENS_OK;
 }
@@ -663,6 +664,7 @@ int sclens_hip_release_scratch(sclens_hip_ctx* h, const char* family) {
   if (f == "everything") {  // every named workspace of the context: only between calls (no live session holds pointers into them)
     if (c.live_sessions > 0) return c.fail(SCLENS_ERR_STATE, "release_scratch(everything): a session of this context is still alive");
     c.release_all();
+    scl::stein_shared_release(c.device, c.stream);
     c.ws_epoch += 1;
     c.q2_tg_n = -1; c.q2_built_variant = -1; c.q1p_n = -1; c.last_two_stage = false;
     return SCLENS_OK;
@@ -684,6 +686,7 @@ int sclens_hip_release_scratch(sclens_hip_ctx* h, const char* family) {
   for (const auto& kv : c.ws)
     for (const std::string& q : pre)
       if (kv.first.compare(0, q.size(), q) == 0) names.push_back(kv.first);
+  if (f == "eigensolver" || f == "all") scl::stein_shared_release(c.device, c.stream);
   if (names.empty()) return SCLENS_OK;
   scl::ctx_quiesce(&c);
   for (const std::string& nm : names) c.release(nm);

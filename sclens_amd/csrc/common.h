@@ -63,6 +63,7 @@ namespace scl {
   X(q2_tg_early, 1)         /* its group data built on the auxiliary stream beside the inverse iteration */                        \
   X(stein_pf, 16)           /* inverse iteration: steps of loads in flight (4, 16, 32) */                                          \
   X(stein_its, 2)           /* growth-checked iterations before a vector is accepted (dstein: 3) */                                \
+  X(stein_shared, 0)        /* its [n][batch] workspaces: 0 one set per context; 1 ONE per device, used in turn (-18 GB, +0.9 % time) */ \
   X(bisect_div, 0)          /* 1: Sturm counts in the ratio form (round 2) */                                                      \
   X(split_pipe, 1)          /* stage loop of the split-fp16 products as a software pipeline (0: the two-buffer loop of round 4) */   \
   X(split_acc_init, 1)      /* split updates start their accumulators from C (0: C added in the epilogue) */                       \
@@ -354,6 +355,7 @@ int sytrd_f32(Ctx* ctx, float* A, int64_t n, int64_t lda, double* d_dev, double*
 int stebz_f64(Ctx* ctx, const double* d_dev, const double* e_dev, int64_t n, double* w_dev, int64_t n_low = -1, int64_t k_top = -1);
 int stein_f64(Ctx* ctx, const double* d_dev, const double* e_dev, int64_t n, const double* w_dev,
               int64_t lo, int64_t hi, float* Zt, int64_t ldz);
+void stein_shared_release(int device, hipStream_t stream);
 int ormtr_f32(Ctx* ctx, const float* A, int64_t n, int64_t lda, const float* tau_dev, float* Zt,
               int64_t m, int64_t ldz);
 

@@ -14,6 +14,8 @@
 //                the tridiagonalisation already formed (no extra pass over V).
 #include <algorithm>
 #include <cmath>
+#include <map>
+#include <mutex>
 #include <vector>
 
 #include "common.h"
@@ -456,6 +458,17 @@ int stebz_f64(Ctx* ctx, const double* d_dev, const double* e_dev, int64_t n, dou
   return SCLENS_OK;
 }
 
+namespace {
+struct SteinShared {
+  void* p = nullptr;
+  size_t bytes = 0;
+  hipEvent_t last = nullptr;  // recorded after the last launch that used the block
+  bool used = false;
+};
+std::mutex g_stein_mu;
+std::map<int, SteinShared> g_stein;  // by device, under g_stein_mu
+}  // namespace
+
 int stein_f64(Ctx* ctx, const double* d_dev, const double* e_dev, int64_t n, const double* w_dev, int64_t lo,
               int64_t hi, float* Zt, int64_t ldz) {
   const int64_t m = hi - lo;
@@ -470,12 +483,50 @@ int stein_f64(Ctx* ctx, const double* d_dev, const double* e_dev, int64_t n, con
   B = B / 64 * 64;
   if (B < 64) B = 64;
   if (B > round_up(m, 64)) B = round_up(m, 64);
-  SCL_WS(ctx, wa, double, "stein.a", n * B);
-  SCL_WS(ctx, wb, double, "stein.b", n * B);
-  SCL_WS(ctx, wc, double, "stein.c", n * B);
-  SCL_WS(ctx, wd, double, "stein.d", n * B);
-  SCL_WS(ctx, wx, double, "stein.x", n * B);
-  SCL_WS(ctx, win, unsigned char, "stein.in", n * B);
+  // The six [n][B] workspaces: per context (default), or ONE set per device used in turn by every context of the process (stein_shared =
+  // 1). With two streams the two contexts of a call each hold 24 GB of them at 30 000 genes -- 48 of the 172 GB at the peak of the search
+  // -- for a 42 ms stage. Turn-taking is stream-ordered: a user waits on the event the previous user recorded after its last launch and
+  // records its own; the host lock covers the enqueue only. Measured at 100 000 x 30 000, two streams (profiles/r06_stein_shared.md):
+  // peak 172.0 -> 153.8 GB, call 41.07 -> 41.43 s (the two streams' inverse iterations no longer overlap): off by default, for hosts
+  // that share the device.
+  const size_t nb8 = (sizeof(double) * (size_t)n * (size_t)B + 255) & ~(size_t)255;
+  const size_t nb1 = ((size_t)n * (size_t)B + 255) & ~(size_t)255;
+  double *wa, *wb, *wc, *wd, *wx;
+  unsigned char* win;
+  std::unique_lock<std::mutex> turn(g_stein_mu, std::defer_lock);
+  SteinShared* shared = nullptr;
+  if (ctx->opt.stein_shared) {
+    turn.lock();
+    shared = &g_stein[ctx->device];
+    if (!shared->last) SCL_HIP(ctx, hipEventCreateWithFlags(&shared->last, hipEventDisableTiming));
+    const size_t need = 5 * nb8 + nb1;
+    if (shared->bytes < need) {
+      if (shared->p) {
+        if (shared->used) SCL_HIP(ctx, hipEventSynchronize(shared->last));
+        pool_free(shared->p, ctx->stream);
+        shared->p = nullptr;
+        shared->bytes = 0;
+      }
+      if (pool_malloc(&shared->p, need) != hipSuccess) return ctx->fail(SCLENS_ERR_OOM, "stein: shared workspaces");
+      shared->bytes = need;
+    }
+    if (shared->used) SCL_HIP(ctx, hipStreamWaitEvent(ctx->stream, shared->last, 0));
+    char* q = static_cast<char*>(shared->p);
+    wa = reinterpret_cast<double*>(q);
+    wb = reinterpret_cast<double*>(q + nb8);
+    wc = reinterpret_cast<double*>(q + 2 * nb8);
+    wd = reinterpret_cast<double*>(q + 3 * nb8);
+    wx = reinterpret_cast<double*>(q + 4 * nb8);
+    win = reinterpret_cast<unsigned char*>(q + 5 * nb8);
+  } else {
+    wa = static_cast<double*>(ctx->workspace("stein.a", nb8));
+    wb = static_cast<double*>(ctx->workspace("stein.b", nb8));
+    wc = static_cast<double*>(ctx->workspace("stein.c", nb8));
+    wd = static_cast<double*>(ctx->workspace("stein.d", nb8));
+    wx = static_cast<double*>(ctx->workspace("stein.x", nb8));
+    win = static_cast<unsigned char*>(ctx->workspace("stein.in", nb1));
+    if (!wa || !wb || !wc || !wd || !wx || !win) return SCLENS_ERR_OOM;
+  }
   SCL_WS(ctx, failc, int, "stein.fail", 4);
   SCL_WS(ctx, invn, double, "stein.invn", B);
   SCL_HIP(ctx, hipMemsetAsync(failc, 0, sizeof(int), ctx->stream));
@@ -500,7 +551,23 @@ int stein_f64(Ctx* ctx, const double* d_dev, const double* e_dev, int64_t n, con
                        0, ctx->stream, wx, invn, n, cnt, B, Zt, ldz, t0);
   }
   SCL_HIP(ctx, hipGetLastError());
+  if (shared) {
+    SCL_HIP(ctx, hipEventRecord(shared->last, ctx->stream));
+    shared->used = true;
+  }
   return SCLENS_OK;
+}
+
+// the device's shared inverse-iteration workspaces back to the pool (release_scratch: eigensolver / all / everything)
+void stein_shared_release(int device, hipStream_t stream) {  // device < 0: every device
+  std::lock_guard<std::mutex> lk(g_stein_mu);
+  for (auto& kv : g_stein) {
+    if ((device >= 0 && kv.first != device) || !kv.second.p) continue;
+    if (kv.second.used) (void)hipEventSynchronize(kv.second.last);  // the last user's kernels have left the block
+    pool_free(kv.second.p, stream);
+    kv.second.p = nullptr;
+    kv.second.bytes = 0;
+  }
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -710,3 +710,38 @@ def test_default_call_hands_its_device_memory_back(ctx):
         assert cached == 0 and live == live0, (cached, live, live0)
     finally:
         c2.close()
+
+
+def test_shared_inverse_iteration_workspaces_give_the_same_bits(ctx):
+    """stein_shared = 1: the six [n][batch] workspaces of the inverse iteration exist once per device and the contexts of a call take turns
+    (an event recorded after one user's last launch, awaited by the next): same bits as the per-context workspaces, with two and three
+    streams, and nothing of the block left on the device after a default (keep_warm=False) call."""
+    import ctypes as C
+
+    from sclens_amd._lib import Context
+
+    def live():
+        c, l, h, m = C.c_int64(0), C.c_int64(0), C.c_int64(0), C.c_int64(0)
+        assert ctx.lib.sclens_hip_pool_stats(ctx.device, C.byref(c), C.byref(l), C.byref(h), C.byref(m)) == 0
+        return c.value, l.value
+
+    X = synth_counts(600, 900, seed=2, C=5, marker_frac=0.2, marker_sd=1.5)
+    d = api.make_draws_native(X, seed=17)
+    a = api.sclens(X, draws=d, n_perturb=5, ctx=ctx, streams=2)
+    c2 = Context(ctx.device)
+    c2.set_option("stein_shared", 1)
+    try:
+        ctx.trim_pool()
+        _, live0 = live()
+        for streams in (2, 3, 1):
+            b = api.sclens(X, draws=d, n_perturb=5, ctx=c2, streams=streams)
+            assert a["p_"] == b["p_"] and a["n_search"] == b["n_search"]
+            for (p1, t1), (p2, t2) in zip(a["search_trace"], b["search_trace"]):
+                assert p1 == p2 and np.array_equal(t1, t2)
+            assert np.array_equal(a["L"], b["L"]) and np.array_equal(a["signal_evec"], b["signal_evec"])
+            assert np.array_equal(a["robustness_scores"]["b_"], b["robustness_scores"]["b_"])
+            assert np.array_equal(a["sig_id"], b["sig_id"])
+            cached, l1 = live()
+            assert cached == 0 and l1 == live0, (cached, l1, live0)
+    finally:
+        c2.close()
