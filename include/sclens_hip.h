@@ -87,7 +87,8 @@ int sclens_hip_copy_options(sclens_hip_ctx* dst, const sclens_hip_ctx* src);
  * the Julia shim's `keep_warm` keyword). Idle bytes kept per device: what was free on the device when the pool first looked, less an
  * eighth of the device for everybody else; sclens_hip_pool_set_cap overrides it (bytes < 0: back to that rule) -- a host that puts
  * several ranks on one device gives each its share. Environment (process level, read once): SCLENS_HIP_POOL=0 disables pooling,
- * SCLENS_HIP_POOL_MAX_GB = the cap. */
+ * SCLENS_HIP_POOL_MAX_GB = the cap. With the option stein_shared = 1 the inverse iteration's workspaces are one block per device outside
+ * any context; sclens_hip_trim (and release_scratch "eigensolver" / "all" / "everything") waits for its last user and frees it too. */
 int sclens_hip_trim(int device_id);
 int sclens_hip_pool_set_cap(int device_id, int64_t bytes);
 /* the largest number of bytes the library held at once on the device (live blocks, the idle cache not counted) since the last reset */
