@@ -83,7 +83,7 @@ def main():
     ap.add_argument("--threads", type=int)
     ap.add_argument("--selftest", action="store_true")
     ap.add_argument("--device-null-rule", action="store_true",
-                    help="count an eigenvalue as positive iff it exceeds 8 eps32 sqrt(n) lambda_max (the device's rounding floor, DESIGN.md "
+                    help="count an eigenvalue as positive iff it exceeds eps32 sqrt(n) lambda_max (the device's rounding floor, DESIGN.md "
                          "section 2 position 6) instead of the oracle's NULL_DROP = 1e-9 lambda_max: at 100 000 x 30 000 the binarised "
                          "matrix has ONE eigenvalue of 1.7e-9 lambda_max, which the two rules treat differently")
     a = ap.parse_args()
@@ -97,8 +97,8 @@ def main():
     N, M, idx = CFG[cfg]
     assert N > M, "cells > genes configurations only"
     out = {"config": cfg, "seed": seed, "iterations": its, "host_cores": os.cpu_count(), "results": [],
-           "null_rule": "device: 8 eps32 sqrt(n) lambda_max" if a.device_null_rule else "oracle: NULL_DROP = 1e-9 lambda_max"}
-    floor = (lambda w: 8.0 * 5.96e-8 * np.sqrt(len(w)) * w.max()) if a.device_null_rule else (lambda w: O.NULL_DROP * w.max())
+           "null_rule": "device (sessions since the end of round 6): eps32 sqrt(n) lambda_max" if a.device_null_rule else "oracle: NULL_DROP = 1e-9 lambda_max"}
+    floor = (lambda w: 1.0 * 5.96e-8 * np.sqrt(len(w)) * w.max()) if a.device_null_rule else (lambda w: O.NULL_DROP * w.max())
     T0 = time.perf_counter()
     log = lambda m: print(f"[{time.perf_counter() - T0:7.0f} s] {m}", flush=True)
     selftest()
