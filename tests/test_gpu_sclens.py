@@ -745,3 +745,37 @@ def test_shared_inverse_iteration_workspaces_give_the_same_bits(ctx):
             assert cached == 0 and l1 == live0, (cached, l1, live0)
     finally:
         c2.close()
+
+
+def _sweep_case(sweep_seed, index):
+    """parameters of case `index` of `scripts/fuzz_parity.py <cases> <sweep_seed>` (the same draws in the same order)"""
+    rng = np.random.default_rng(sweep_seed)
+    for c in range(index + 1):
+        N, M = int(rng.integers(90, 420)), int(rng.integers(90, 420))
+        C = int(rng.integers(2, 7))
+        seed = int(rng.integers(1, 10 ** 6))
+        cent = "median" if rng.random() < 0.25 else "mean"
+        streams = int(rng.integers(1, 4))
+        mf, ms = float(rng.uniform(0.1, 0.4)), float(rng.uniform(0.8, 1.8))
+    return N, M, C, seed, cent, streams, mf, ms
+
+
+@pytest.mark.parametrize("sweep_seed,index,shape", [(41, 100, (292, 260)), (41, 121, (259, 233)), (51, 117, (371, 329))])
+def test_small_genuine_eigenvalue_of_a_nearly_square_matrix_stays_in_the_binarised_basis(ctx, sweep_seed, index, shape):
+    """cells > genes and nearly square: the binarised matrix has a GENUINE eigenvalue of ~7e-6 lambda_max (no structural zero on this
+    side). The reference's `L .> 0` (scLENS.jl:495) keeps it; a positivity floor of 8 sqrt(n) eps32 lambda_max (7.7e-6 at n = 260) dropped
+    it from Vr2 but not from the perturbed matrices' bases, one ~0 entry entered d_arr (:742) and the search ended an evaluation early --
+    the cases the random sweeps of rounds 5 / 6 turned up (profiles/r06_fuzz_null_floor.md). Every evaluation's statistic and the search
+    length against the oracle."""
+    N, M, C, seed, cent, streams, mf, ms = _sweep_case(sweep_seed, index)
+    assert (N, M) == shape and cent == "mean"
+    X = synth_counts(N, M, seed=seed, C=C, marker_frac=mf, marker_sd=ms, min_genes_per_cell=5, min_cells_per_gene=4)
+    d = api.make_draws_native(X, seed=seed, host_sampler=True)
+    od = O.Draws(d.z_idx1, d.z_idx2, d.X_r, d.p_th, d.sampler)
+    ref = O.sclens(X, od, n_perturb=4, null_tol=O.NULL_DROP, max_search_iters=25)
+    res = api.sclens(X, draws=d, n_perturb=4, ctx=ctx, streams=streams, max_search_iters=25)
+    assert res["n_search"] == ref["n_search"] and res["p_"] == ref["p_"]
+    for (p1, d1), (p2, d2) in zip(res["search_trace"], ref["search_trace"]):
+        assert p1 == p2 and np.abs(d1 - d2).max() < 1e-3, (p1, d1, d2)
+    assert np.array_equal(res["sig_id"], ref["sig_id"])
+    assert np.array_equal(res["robustness_scores"]["a_b"], ref["robustness_scores"]["a_b"])
